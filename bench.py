@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- forward+adjoint mul! pairs/sec on a tall JopBlock (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): the configuration the metric is quoted on -- a 1024x1 tall JopBlock of
+diagonal blocks, 256^3 Float32 per block (64 MiB/block; 64 GiB of coefficients + 64 GiB range
+vector), synthetic U[0,1) data from the counter-based generator (seeds a=1, m=2, d=3), resident in
+HBM before the timed region.  One step = one forward mul!(d, A, m) + one adjoint mul!(m, A', d).
+With N GPUs the SAME operator is row-partitioned (1024/N block rows per rank, "strong" scaling);
+the adjoint ends with one RCCL all-reduce of the 64 MiB domain vector.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+HIP-event timed on the library stream) and `cpu_baseline` (the CPU oracle, single thread, on a
+bounded sample; rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nblocks", type=int, default=1024, help="global block rows of the tall operator")
+    ap.add_argument("--edge", type=int, default=256, help="block is edge^3 Float32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-blocks", type=int, default=16)
+    ap.add_argument("--cpu-pairs", type=int, default=4)
+    ap.add_argument("--tune", type=str, default="", help="k=v,k=v kernel knobs (fwd_group, fwd_unroll, adj_unroll, adj_depth, nt, wg)")
+    ap.add_argument("--fused-normal", action="store_true", help="also time the fused A'A kernel (extra field, not the metric)")
+    return ap.parse_args()
+
+
+def cpu_baseline(edge: int, nblocks_full: int, sample_blocks: int, pairs: int) -> dict:
+    """The CPU oracle's JetBlock_df!/df'! (reference loop structure incl. per-call temporaries,
+    oracle/jets_oracle_body.inc) on a bounded sample, single thread."""
+    import numpy as np
+    from oracle import jets_oracle as jo
+
+    n = edge ** 3
+    a = [jo.rng_u01(np.float32, 1, 0, i * n, n) for i in range(sample_blocks)]
+    m = jo.rng_u01(np.float32, 2, 0, 0, n)
+    d = [jo.rng_u01(np.float32, 3, 0, i * n, n) for i in range(sample_blocks)]
+    mt = np.zeros(n, dtype=np.float32)
+    ops = [[jo.Block("diag", n, coeff=ai)] for ai in a]
+    jo.block_df(ops, d, [m])
+    jo.block_df_adj(ops, [mt], d)  # warm-up pair
+    times = []
+    for _ in range(pairs):
+        t0 = time.perf_counter()
+        jo.block_df(ops, d, [m])
+        jo.block_df_adj(ops, [mt], d)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    bytes_pair = (4 * sample_blocks * n + 2 * n) * 4
+    return {
+        "value": (1.0 / med) * sample_blocks / nblocks_full,
+        "unit": "pairs/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{sample_blocks} of {nblocks_full} block rows ({edge}^3 Float32 each), median of {pairs} pairs = {med:.3f} s/pair, "
+                  f"{bytes_pair / med / 1e9:.1f} GB/s algorithmic; value = sample pairs/s x {sample_blocks}/{nblocks_full} (bandwidth-bound, linear in rows)",
+        "host_cores_available": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import jets_jl_amd as J
+
+    J.init(local_rank)
+    if args.tune:
+        J.tune(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
+
+    edge, nblocks = args.edge, args.nblocks
+    n = edge ** 3
+    part = J.rowpart.partition_rows(nblocks, world, rank)
+    nloc = part.count
+
+    # ---- operator + vectors, resident in HBM ------------------------------------------------------
+    blk = J.JetSpace("float32", edge, edge, edge)
+    Rloc = J.JetBSpace([blk] * nloc)
+    coeff = J.rand(Rloc, seed=1, stream=0, index_base=part.first * n)      # all diagonals of this rank: one slab
+    A = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
+    m = J.rand(J.domain(A), seed=2, stream=0)
+    d = J.rand(J.range(A), seed=3, stream=0, index_base=part.first * n)
+    mt = J.zeros(J.domain(A))
+    shard = J.rowpart.for_device(part, A) if world > 1 else None
+    J.synchronize()
+
+    def forward():
+        J.mul_(d, A, m)
+
+    def adjoint():
+        if shard is not None:
+            shard.mul_adj_(mt, d)
+        else:
+            J.mul_(mt, A.H, d)
+
+    for _ in range(args.warmup):
+        forward()
+        adjoint()
+
+    ev = [[J.Event() for _ in range(3)] for _ in range(args.steps)]
+
+    def fence():
+        J.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        forward()
+        ev[k][1].record()
+        adjoint()
+        ev[k][2].record()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fwd_ms = sum(ev[k][0].elapsed_ms(ev[k][1]) for k in range(args.steps)) / args.steps
+    adj_ms = sum(ev[k][1].elapsed_ms(ev[k][2]) for k in range(args.steps)) / args.steps
+    s = 4
+    fwd_bytes = (2 * nloc * n + n) * s        # read a, read m, write d      
+    adj_bytes = (2 * nloc * n + n) * s        # read a, read d, write m
+    pair_bytes_global = (4 * nblocks * n + 2 * n) * s
+    kernels = {
+        "forward": {"kernel": "k_tall_diag_fwd", "ms": fwd_ms, "bytes": fwd_bytes, "GBps": fwd_bytes / fwd_ms / 1e6},
+        "adjoint": {"kernel": "k_tall_diag_adj" + ("+allreduce" if world > 1 else ""), "ms": adj_ms, "bytes": adj_bytes,
+                    "GBps": adj_bytes / adj_ms / 1e6},
+    }
+    dom = max(kernels.values(), key=lambda kv: kv["ms"])
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("nblocks") == nloc and tj.get("edge") == edge:
+                traffic = tj.get(dom["kernel"].split("+")[0])
+        except Exception:
+            traffic = None
+
+    extra = {}
+    if args.fused_normal and world == 1:
+        y = J.zeros(J.domain(A))
+        C = A.H @ A
+        J.mul_(y, C, m)
+        e0, e1 = J.Event().record(), None
+        for _ in range(args.steps):
+            J.mul_(y, C, m)
+        e1 = J.Event().record()
+        ms = e0.elapsed_ms(e1) / args.steps
+        nb = (nloc * n + 2 * n) * s
+        extra["fused_normal"] = {"ms": ms, "bytes": nb, "GBps": nb / ms / 1e6, "unfused_pair_ms": fwd_ms + adj_ms}
+
+    if rank == 0:
+        pairs_per_s = args.steps / elapsed
+        out = {
+            "metric": "fwd+adj mul! pairs/sec, 1024-block tall JopBlock (256^3 Float32 diagonal blocks)",
+            "value": pairs_per_s,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic U[0,1) Float32 from the counter-based generator (seeds a=1, m=2, d=3), generated on device",
+            "config": {
+                "workload": f"{nblocks}x1 tall JopBlock of diagonal JopLn, {edge}^3 Float32 blocks, fwd+adj mul! pair",
+                "nblocks": nblocks, "block": [edge, edge, edge], "rows_per_gpu": nloc,
+                "parallelism": f"row-partition x{world}" + (" + RCCL all-reduce(64 MiB) in adjoint" if world > 1 else ""),
+                "tune": {k: J.tune_get(k) for k in ("fwd_group", "fwd_unroll", "adj_unroll", "adj_depth", "nt", "wg")},
+            },
+            "achieved_GBps_pair": pair_bytes_global * pairs_per_s / 1e9,
+            "roofline_frac_pair": pair_bytes_global * pairs_per_s / 1e9 / (HBM_PEAK_GBS * world),
+            "roofline": {
+                "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                "bytes_per_launch": dom["bytes"], "ms_per_launch": dom["ms"],
+            },
+            "kernels": kernels,
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(edge, nblocks, min(args.cpu_sample_blocks, nblocks), args.cpu_pairs)
+            except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
+                out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

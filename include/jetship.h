@@ -1,0 +1,157 @@
+/*
+ * jetship.h -- C ABI of libjetship.so: MI355X (gfx950) native block-operator mul! path for the
+ * Jets.jl operator API.
+ *
+ * This is the drop-in boundary.  Jets.jl (/root/reference/src/Jets.jl) is pure Julia and has no
+ * FFI of its own; its only extension point is the Jet keyword constructor (src/Jets.jl:170-188)
+ * whose closures are called from mul! (src/Jets.jl:390-392).  A Julia maintainer binds the entry
+ * points below with `ccall` inside methods of JetBlock_df!/JetBlock_df'! (src/Jets.jl:1010-1057),
+ * BlockArray (src/Jets.jl:809-924) and JetBSpace (src/Jets.jl:736-807); INTEGRATION.md shows the
+ * stubs.  Each entry point names the reference lines it replaces.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only.  Every function returns a jh_status (0 = ok);
+ *    jh_last_error() returns a thread-local message for the last failure (the Julia wrapper turns
+ *    it into `error(msg)`, src/Jets.jl:131,179,1116).
+ *  - Block indices and element offsets are 0-based here; the Julia wrapper converts (1-based
+ *    inclusive ranges of src/Jets.jl:742-748  <->  offset = start-1, len = stop-start+1).
+ *  - One process drives one GPU (jh_init(device)).  All work is enqueued on one HIP stream
+ *    (jh_get_stream/jh_set_stream); functions return after enqueue, except those that return a
+ *    scalar or copy to host memory, which synchronise the stream first.
+ *  - Handles are opaque, created/destroyed explicitly; the library never frees caller memory.
+ *    Destroying a vector invalidates borrowed block pointers and views of it.
+ *  - A block vector ("bvec", the device BlockArray) is ONE contiguous slab; block i lives at
+ *    element offset sum(len[0..i-1]) -- the layout of JetBSpace.indices (src/Jets.jl:742-748), so
+ *    reshape(flat, R) (src/Jets.jl:1112) and convert(Array, x) (src/Jets.jl:862-868) are free.
+ *    A plain N-d array (the domain of a one-column block operator, src/Jets.jl:927) is a bvec
+ *    with one block.
+ */
+#ifndef JETSHIP_H
+#define JETSHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JETSHIP_ABI_VERSION 1
+
+typedef enum {
+    JH_OK = 0,
+    JH_ERR_INVALID = 1,      /* bad argument: index out of range, length/dtype mismatch, null handle */
+    JH_ERR_HIP = 2,          /* a HIP runtime call failed (message carries hipGetErrorString)       */
+    JH_ERR_NOMEM = 3,        /* device or host allocation failed                                    */
+    JH_ERR_UNSUPPORTED = 4,  /* valid request the device path does not implement                    */
+    JH_ERR_STATE = 5,        /* library not initialised / already shut down                         */
+    JH_ERR_COMM = 6          /* RCCL failure                                                        */
+} jh_status;
+
+typedef enum { JH_F32 = 0, JH_F64 = 1, JH_C32 = 2, JH_C64 = 3 } jh_dtype;
+
+/* device-native block kinds: the closed set of child operators the fused kernels understand.
+ * The Julia side recognises them by typeof(df!) exactly like iszero/isblockop do
+ * (src/Jets.jl:949, 1085, 1097). */
+typedef enum {
+    JH_OP_ZERO = 0,      /* JopZeroBlock, src/Jets.jl:941-942 (skipped by the block loops: 1022, 1047) */
+    JH_OP_IDENTITY = 1,  /* d .= m                                                                     */
+    JH_OP_SCALE = 2,     /* d .= a*m ; adjoint m .= conj(a)*d, src/Jets.jl:1159-1160                   */
+    JH_OP_DIAG = 3,      /* d .= diagonal .* m ; adjoint conj.(diagonal) .* d, test/runtests.jl:3-4    */
+    JH_OP_DENSE = 4      /* d .= A*m ; adjoint A'*d (column-major A), test/runtests.jl:27-28           */
+} jh_opkind;
+
+typedef struct {
+    int32_t kind;        /* jh_opkind                                                        */
+    int32_t adjoint;     /* 1: this block is the JopAdjoint of the described operator        */
+    const void *coeff;   /* DEVICE pointer. DIAG: nr elements. DENSE: column-major nr x nc.  */
+    double scale_re;     /* SCALE: a                                                         */
+    double scale_im;
+    int64_t nr, nc;      /* range / domain length of the described (un-adjointed) operator   */
+} jh_block_desc;
+
+typedef struct jh_bvec jh_bvec;
+typedef struct jh_blockop jh_blockop;
+typedef struct jh_event jh_event;
+
+/* ---------------------------------------------------------------- context ------------------- */
+int jh_abi_version(void);
+const char *jh_last_error(void);
+int jh_device_count(int *count);
+int jh_init(int device);                 /* hipSetDevice + stream; idempotent for the same device */
+int jh_shutdown(void);
+int jh_device_info(char *name, int name_cap, int64_t *total_mem, int64_t *free_mem, int *cu_count);
+int jh_get_stream(void **hip_stream);    /* hipStream_t the library enqueues on                   */
+int jh_set_stream(void *hip_stream);     /* NULL restores the library's own stream                */
+int jh_synchronize(void);
+/* HIP events on the library stream: roofline timing in bench.py */
+int jh_event_create(jh_event **ev);
+int jh_event_record(jh_event *ev);
+int jh_event_elapsed_ms(jh_event *start, jh_event *stop, float *ms);   /* synchronises on stop */
+int jh_event_destroy(jh_event *ev);
+
+/* ---------------------------------------------------------------- block vectors ------------- */
+/* zeros(R::JetBSpace) / Array(R) storage, src/Jets.jl:922-924; JetBSpace ctor 739-750. Zero-filled. */
+int jh_bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec **out);
+/* reshape(x::AbstractArray, R::JetBSpace), src/Jets.jl:1112: block view over caller-owned device memory */
+int jh_bvec_wrap(void *device_ptr, int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec **out);
+/* view of blocks [first, first+count) of parent sharing memory (getblock(x,i) by reference, 914) */
+int jh_bvec_view(jh_bvec *parent, int64_t first_block, int64_t count, jh_bvec **out);
+int jh_bvec_destroy(jh_bvec *v);
+int jh_bvec_info(const jh_bvec *v, int64_t *nblocks, int64_t *length, int *dtype, void **device_ptr);
+/* indices(x,i) / getblock(x,i) as a borrowed device pointer, src/Jets.jl:858, 914 */
+int jh_bvec_block(const jh_bvec *v, int64_t iblock, int64_t *offset, int64_t *len, void **device_ptr);
+
+/* getblock!(x, i, dst), src/Jets.jl:915 */
+int jh_getblock_copy(const jh_bvec *v, int64_t iblock, void *dst, int dst_on_device);
+/* setblock!(x, i, src::AbstractArray), src/Jets.jl:916 */
+int jh_setblock_copy(jh_bvec *v, int64_t iblock, const void *src, int src_on_device);
+/* setblock!(x, i, scalar), src/Jets.jl:916 with a Number (test/runtests.jl:518-519) */
+int jh_setblock_fill(jh_bvec *v, int64_t iblock, double re, double im);
+/* fill!(x, a), src/Jets.jl:880-885 */
+int jh_fill(jh_bvec *v, double re, double im);
+/* y .= x for two block vectors of equal length (src/Jets.jl:905-911 with bc = identity) */
+int jh_copy(jh_bvec *dst, const jh_bvec *src);
+/* convert(Array, x) (src/Jets.jl:862-868) and its inverse, on an element range of the slab */
+int jh_download(const jh_bvec *v, int64_t offset, int64_t count, void *host_dst);
+int jh_upload(jh_bvec *v, int64_t offset, int64_t count, const void *host_src);
+/* rand(R) (src/Jets.jl:922-924) from the counter-based generator of SURVEY.md 8d:
+ * element k = mix64(key + (k+1)*0x9E3779B97F4A7C15), key = mix64(seed*0x9E37...+stream);
+ * index_base shifts k so a row-partitioned shard reproduces its slice of the global vector. */
+int jh_fill_uniform(jh_bvec *v, uint64_t seed, uint64_t stream, int64_t index_base);
+
+/* BlockArray broadcast, src/Jets.jl:889-911.  dst = c0*x0 .+ c1*x1 .+ ... evaluated left to right in
+ * eltype T (each product and each sum rounded, no FMA); coef is k (re,im) pairs; dst may alias any x. */
+int jh_lincomb(jh_bvec *dst, int k, const double *coef_re_im, const jh_bvec *const *x);
+/* dst = x .* y (conj_x: conj.(x) .* y) -- the masks of dot_product_test, src/Jets.jl:1215-1219 */
+int jh_hadamard(jh_bvec *dst, const jh_bvec *x, const jh_bvec *y, int conj_x);
+/* dot(x,y), src/Jets.jl:850-856 (conjugates x). fp64 accumulation, deterministic order. */
+int jh_dot(const jh_bvec *x, const jh_bvec *y, double *re, double *im);
+/* norm(x,p), src/Jets.jl:834-848: p = 2, 1, 0, +Inf, -Inf or any other real */
+int jh_norm(const jh_bvec *x, double p, double *out);
+/* extrema(x), src/Jets.jl:870-878 (real dtypes) */
+int jh_extrema(const jh_bvec *x, double *mn, double *mx);
+
+/* ---------------------------------------------------------------- block operators ----------- */
+/* JetBlock(ops) for device-native blocks, src/Jets.jl:926-930. blocks is column-major nrow x ncol
+ * (a Julia Matrix{Jop}); row_len[i] = length(range(ops[i,1])), col_len[j] = length(domain(ops[1,j])). */
+int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, const int64_t *row_len,
+                      const int64_t *col_len, int dtype, jh_blockop **out);
+int jh_blockop_destroy(jh_blockop *op);
+/* mul!(d, A, m) -> JetBlock_df!, src/Jets.jl:1010-1032, one fused launch.  Reference quirks kept:
+ * zero blocks are skipped (1022); with ncol > 1 the result is accumulated into d without zeroing (1024). */
+int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m);
+/* mul!(m, A', d) -> JetBlock_df'!, src/Jets.jl:1034-1057: m zeroed when nrow > 1 (1042), rows summed
+ * in order i = 0..nrow-1 with the product rounded before the add (1049) => bit-exact on one GPU. */
+int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d);
+/* (A' o A) m -> JetComposite_df! over (A', A), src/Jets.jl:530-534, fused: A's coefficients are read
+ * once and the range-side intermediate is never materialised.  Same rounding sequence as the
+ * unfused pair, so the result is bit-identical to jh_blockop_mul followed by jh_blockop_mul_adj. */
+int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m);
+/* kernel-shape tuning knobs (bench/tests only): name in {"fwd_group","fwd_unroll","adj_unroll","nt"} */
+int jh_tune_set(const char *name, int64_t value);
+int jh_tune_get(const char *name, int64_t *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JETSHIP_H */

@@ -1,0 +1,118 @@
+"""ctypes binding of libjetship.so (the C ABI declared in include/jetship.h).
+
+This is the Python twin of the `ccall` stubs a Julia maintainer would write: every
+symbol of include/jetship.h is bound here with its exact C signature.  There is no CPU fallback:
+if the shared library is missing the import fails loudly, and `init()` fails loudly when no
+gfx950 device is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+__all__ = ["lib", "check", "JetsHipError", "LIB_PATH", "BlockDesc", "SYMBOLS", "DTYPES", "KINDS"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("JETSHIP_LIB", os.path.join(_HERE, "libjetship.so"))
+
+
+class JetsHipError(RuntimeError):
+    """Raised for every non-zero jh_status; carries jh_last_error() (reference: `error(...)`,
+    src/Jets.jl:131,179,1116)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libjetship status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+class BlockDesc(C.Structure):
+    """jh_block_desc (include/jetship.h)."""
+
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("adjoint", C.c_int32),
+        ("coeff", C.c_void_p),
+        ("scale_re", C.c_double),
+        ("scale_im", C.c_double),
+        ("nr", C.c_int64),
+        ("nc", C.c_int64),
+    ]
+
+
+DTYPES = {"f32": 0, "f64": 1, "c32": 2, "c64": 3}
+KINDS = {"zero": 0, "identity": 1, "scale": 2, "diag": 3, "dense": 4}
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_i64p = C.POINTER(C.c_int64)
+_dblp = C.POINTER(C.c_double)
+_int = C.c_int
+_intp = C.POINTER(C.c_int)
+_vpp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); must list every function declared in include/jetship.h
+SYMBOLS = {
+    "jh_abi_version": (_int, []),
+    "jh_last_error": (C.c_char_p, []),
+    "jh_device_count": (_int, [_intp]),
+    "jh_init": (_int, [_int]),
+    "jh_shutdown": (_int, []),
+    "jh_device_info": (_int, [C.c_char_p, _int, _i64p, _i64p, _intp]),
+    "jh_get_stream": (_int, [_vpp]),
+    "jh_set_stream": (_int, [_vp]),
+    "jh_synchronize": (_int, []),
+    "jh_event_create": (_int, [_vpp]),
+    "jh_event_record": (_int, [_vp]),
+    "jh_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    "jh_event_destroy": (_int, [_vp]),
+    "jh_bvec_create": (_int, [_i64, _i64p, _int, _vpp]),
+    "jh_bvec_wrap": (_int, [_vp, _i64, _i64p, _int, _vpp]),
+    "jh_bvec_view": (_int, [_vp, _i64, _i64, _vpp]),
+    "jh_bvec_destroy": (_int, [_vp]),
+    "jh_bvec_info": (_int, [_vp, _i64p, _i64p, _intp, _vpp]),
+    "jh_bvec_block": (_int, [_vp, _i64, _i64p, _i64p, _vpp]),
+    "jh_getblock_copy": (_int, [_vp, _i64, _vp, _int]),
+    "jh_setblock_copy": (_int, [_vp, _i64, _vp, _int]),
+    "jh_setblock_fill": (_int, [_vp, _i64, C.c_double, C.c_double]),
+    "jh_fill": (_int, [_vp, C.c_double, C.c_double]),
+    "jh_copy": (_int, [_vp, _vp]),
+    "jh_download": (_int, [_vp, _i64, _i64, _vp]),
+    "jh_upload": (_int, [_vp, _i64, _i64, _vp]),
+    "jh_fill_uniform": (_int, [_vp, C.c_uint64, C.c_uint64, _i64]),
+    "jh_lincomb": (_int, [_vp, _int, _dblp, _vpp]),
+    "jh_hadamard": (_int, [_vp, _vp, _vp, _int]),
+    "jh_dot": (_int, [_vp, _vp, _dblp, _dblp]),
+    "jh_norm": (_int, [_vp, C.c_double, _dblp]),
+    "jh_extrema": (_int, [_vp, _dblp, _dblp]),
+    "jh_blockop_create": (_int, [_i64, _i64, C.POINTER(BlockDesc), _i64p, _i64p, _int, _vpp]),
+    "jh_blockop_destroy": (_int, [_vp]),
+    "jh_blockop_mul": (_int, [_vp, _vp, _vp]),
+    "jh_blockop_mul_adj": (_int, [_vp, _vp, _vp]),
+    "jh_blockop_normal_mul": (_int, [_vp, _vp, _vp]),
+    "jh_tune_set": (_int, [C.c_char_p, _i64]),
+    "jh_tune_get": (_int, [C.c_char_p, _i64p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"libjetship.so not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C jets.jl_amd/csrc`. There is no CPU fallback for the block-operator path."
+        )
+    handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(handle, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return handle
+
+
+lib = _load()
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = lib.jh_last_error()
+        raise JetsHipError(status, msg.decode("utf-8", "replace") if msg else "")

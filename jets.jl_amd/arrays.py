@@ -1,0 +1,516 @@
+"""Device-backed vectors: DeviceArray (plain N-d array) and BlockArray (north_star's "JetBArray").
+
+Mirrors /root/reference/src/Jets.jl:809-924 (BlockArray, norm/dot/extrema/fill!/convert,
+broadcast, getblock/getblock!/setblock!, factories) and 1112-1118 (reshape to a block space) over
+the C ABI of include/jetship.h.  A BlockArray is ONE contiguous HBM slab; block i starts at
+element offset indices[i].start (the layout of JetBSpace.indices), so `reshape(flat, R)` and the
+per-block views alias the slab with no copy, exactly like the reference's views.
+
+All arithmetic runs in HIP kernels through libjetship.so; nothing here computes on the host.
+"""
+from __future__ import annotations
+
+import builtins
+import ctypes as C
+import itertools
+import math
+from typing import Sequence
+
+import numpy as np
+
+from ._ffi import lib, check
+from . import device as _device
+from .spaces import JetAbstractSpace, JetSpace, JetBSpace, dtype_code
+
+__all__ = [
+    "DeviceArray", "BlockArray", "LinExpr", "zeros", "ones", "rand", "randn", "Array", "from_numpy", "space", "nblocks",
+    "indices", "getblock", "getblock_", "setblock_", "norm", "dot", "extrema", "fill_", "copyto_", "lincomb_",
+    "hadamard_", "similar", "convert_array", "reshape", "vec", "length",
+]
+
+_rand_counter = itertools.count(1)
+_DEFAULT_SEED = 0x4A455453  # "JETS"
+
+
+def _i64arr(vals: Sequence[int]):
+    return (C.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+class _DevVec:
+    """Common base: owns (or borrows) one jh_bvec handle."""
+
+    _h = None
+    _owner = None  # keeps the parent alive for views / wraps
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise ValueError("device vector already closed")
+        return self._h
+
+    @property
+    def dtype(self) -> np.dtype:
+        return self._dtype
+
+    def eltype(self):
+        return self._dtype
+
+    def length(self) -> int:
+        return self._length
+
+    def __len__(self) -> int:
+        return self._length
+
+    @property
+    def ptr(self) -> int:
+        p = C.c_void_p()
+        check(lib.jh_bvec_info(self.handle, None, None, None, C.byref(p)))
+        return p.value or 0
+
+    def close(self) -> None:
+        if self._h is not None:
+            h, self._h = self._h, None
+            lib.jh_bvec_destroy(h)
+        self._owner = None
+
+    def __del__(self):  # the Julia wrapper registers the same thing as a finalizer
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- host transfer (convert(Array, x), src/Jets.jl:862-868) -----------------------------------
+    def _download(self, offset: int = 0, count: int | None = None) -> np.ndarray:
+        count = self._length - offset if count is None else count
+        out = np.empty(count, dtype=self._dtype)
+        if count:
+            check(lib.jh_download(self.handle, offset, count, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def _upload(self, host: np.ndarray, offset: int = 0) -> None:
+        host = np.ascontiguousarray(host, dtype=self._dtype).ravel()
+        if host.size:
+            check(lib.jh_upload(self.handle, offset, host.size, host.ctypes.data_as(C.c_void_p)))
+
+    # --- LinExpr sugar:  y.assign(a*u + b*v - w) is  y .= a*u .+ b*v .- w  ------------------------
+    def __mul__(self, a):
+        if isinstance(a, (int, float, complex, np.number)):
+            return LinExpr([(a, self)])
+        return NotImplemented
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return LinExpr([(-1.0, self)])
+
+    def __add__(self, other):
+        return LinExpr([(1.0, self)]) + other
+
+    def __sub__(self, other):
+        return LinExpr([(1.0, self)]) - other
+
+    def assign(self, expr) -> "_DevVec":
+        """`self .= expr` (src/Jets.jl:905-911)."""
+        if isinstance(expr, LinExpr):
+            lincomb_(self, [c for c, _ in expr.terms], [x for _, x in expr.terms])
+        elif isinstance(expr, _DevVec):
+            copyto_(self, expr)
+        elif isinstance(expr, (int, float, complex, np.number)):
+            fill_(self, expr)
+        else:
+            self._upload(np.asarray(expr).ravel(order="F"))
+        return self
+
+
+class LinExpr:
+    """Lazy `c1*x1 .+ c2*x2 .+ ...` (the Broadcasted tree of src/Jets.jl:889-911, restricted to linear
+    combinations); evaluated left to right in one fused kernel by `assign` / `materialize`."""
+
+    def __init__(self, terms):
+        self.terms = list(terms)
+
+    def __add__(self, other):
+        if isinstance(other, _DevVec):
+            other = LinExpr([(1.0, other)])
+        if not isinstance(other, LinExpr):
+            return NotImplemented
+        return LinExpr(self.terms + other.terms)
+
+    def __sub__(self, other):
+        if isinstance(other, _DevVec):
+            other = LinExpr([(1.0, other)])
+        if not isinstance(other, LinExpr):
+            return NotImplemented
+        return LinExpr(self.terms + [(-c, x) for c, x in other.terms])
+
+    def __mul__(self, a):
+        if isinstance(a, (int, float, complex, np.number)):
+            return LinExpr([(a * c, x) for c, x in self.terms])
+        return NotImplemented
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return LinExpr([(-c, x) for c, x in self.terms])
+
+    def materialize(self):
+        """similar(find_blockarray(bc)) then copyto! (src/Jets.jl:893-898)."""
+        first = next((x for _, x in self.terms if isinstance(x, BlockArray)), self.terms[0][1])
+        return similar(first).assign(self)
+
+
+class DeviceArray(_DevVec):
+    """A plain N-d array in HBM (column-major shape metadata), e.g. the domain vector of a one-column
+    block operator (src/Jets.jl:927) or one block of a BlockArray (getblock, src/Jets.jl:914)."""
+
+    def __init__(self, handle, shape, dtype, owner=None):
+        self._h = handle
+        self.shape = tuple(int(s) for s in shape)
+        self._dtype = np.dtype(dtype)
+        self._length = int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
+        self._owner = owner
+
+    @property
+    def ndim(self) -> int:
+        return len(self.shape)
+
+    @property
+    def size(self) -> int:
+        return self._length
+
+    @property
+    def __cuda_array_interface__(self):
+        item = self._dtype.itemsize
+        strides, acc = [], item
+        for s in self.shape:  # Fortran order
+            strides.append(acc)
+            acc *= s
+        return {"shape": self.shape, "typestr": self._dtype.str, "data": (self.ptr, False), "version": 3,
+                "strides": tuple(strides) if len(self.shape) > 1 else None}
+
+    def to_numpy(self) -> np.ndarray:
+        return self._download().reshape(self.shape, order="F")
+
+    def reshape(self, *shape) -> "DeviceArray":
+        """reshape(x, dims): shares memory (src/Jets.jl:38)."""
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        if int(np.prod(shape, dtype=np.int64)) != self._length:
+            raise ValueError("dimension mismatch in reshape")
+        h = C.c_void_p()
+        check(lib.jh_bvec_view(self.handle, 0, 1, C.byref(h)))
+        return DeviceArray(h, shape, self._dtype, owner=self)
+
+    def __repr__(self):
+        return f"DeviceArray({self._dtype.name}, shape={self.shape})"
+
+
+class BlockArray(_DevVec):
+    """Jets.BlockArray (src/Jets.jl:809-812) backed by one HIP slab."""
+
+    def __init__(self, handle, spaces: Sequence[JetAbstractSpace], dtype, owner=None):
+        self._h = handle
+        self.spaces = list(spaces)
+        self._dtype = np.dtype(dtype)
+        self.indices = []
+        stop = 0
+        for s in self.spaces:
+            self.indices.append(builtins.range(stop, stop + s.length()))
+            stop += s.length()
+        self._length = stop
+        self._owner = owner
+        self._views = None
+
+    @property
+    def arrays(self) -> list:
+        """x.arrays: the blocks, by reference (views of the slab)."""
+        if self._views is None:
+            views = []
+            for i, s in enumerate(self.spaces):
+                h = C.c_void_p()
+                check(lib.jh_bvec_view(self.handle, i, 1, C.byref(h)))
+                views.append(DeviceArray(h, s.size(), self._dtype, owner=self))
+            self._views = views
+        return self._views
+
+    @property
+    def shape(self):  # src/Jets.jl:818
+        return (self._length,)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self._length,), "typestr": self._dtype.str, "data": (self.ptr, False), "version": 3, "strides": None}
+
+    def close(self) -> None:
+        if self._views is not None:
+            for v in self._views:
+                v.close()
+            self._views = None
+        super().close()
+
+    def to_numpy(self) -> np.ndarray:
+        """convert(Array, x) (src/Jets.jl:862-868) brought to the host."""
+        return self._download()
+
+    # linear indexing (src/Jets.jl:820-827): slow path by design, like the reference's findfirst
+    def _locate(self, i: int):
+        if i < 0:
+            i += self._length
+        for j, r in enumerate(self.indices):
+            if i in r:
+                return j, i - r.start
+        raise IndexError(i)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            start, stop, step = i.indices(self._length)
+            if step != 1:
+                raise IndexError("only unit-stride slices")
+            return self._download(start, builtins.max(0, stop - start))
+        self._locate(i)
+        return self._download(int(i) % self._length if i < 0 else int(i), 1)[0]
+
+    def __setitem__(self, i, v):
+        if isinstance(i, slice):
+            start, stop, step = i.indices(self._length)
+            if step != 1:
+                raise IndexError("only unit-stride slices")
+            vals = np.broadcast_to(np.asarray(v, dtype=self._dtype), (builtins.max(0, stop - start),))
+            self._upload(vals, start)
+            return
+        self._locate(i)
+        self._upload(np.asarray([v], dtype=self._dtype), int(i) % self._length if i < 0 else int(i))
+
+    def __repr__(self):
+        return f"BlockArray({self._dtype.name}, {len(self.spaces)} blocks, length {self._length})"
+
+
+# ------------------------------------------------------------------------------ factories ----------
+def _new_handle(block_lens: Sequence[int], T) -> C.c_void_p:
+    _device.init()
+    h = C.c_void_p()
+    check(lib.jh_bvec_create(len(block_lens), _i64arr(block_lens), dtype_code(T), C.byref(h)))
+    return h
+
+
+def Array(R: JetAbstractSpace):
+    """Array(R) / zeros(R): device storage for the space (src/Jets.jl:105-108, 922-924).  Device
+    allocations are always zero-filled."""
+    if isinstance(R, JetBSpace):
+        return BlockArray(_new_handle(R.block_lengths(), R.eltype()), R.spaces, R.eltype())
+    return DeviceArray(_new_handle([R.length()], R.eltype()), R.size(), R.eltype())
+
+
+zeros = Array
+
+
+def ones(R: JetAbstractSpace):
+    return fill_(Array(R), 1.0)
+
+
+def rand(R: JetAbstractSpace, seed: int | None = None, stream: int | None = None, index_base: int = 0):
+    """rand(R): U[0,1) from the counter-based generator.  With seed/stream given the
+    values are a pure function of (seed, stream, element index) and reproducible on the CPU oracle."""
+    x = Array(R)
+    if seed is None:
+        seed, stream = _DEFAULT_SEED, next(_rand_counter)
+    check(lib.jh_fill_uniform(x.handle, int(seed), int(stream or 0), int(index_base)))
+    return x
+
+
+def randn(R: JetAbstractSpace, seed: int | None = None):
+    """randn(R): test-data generation only (host generator, uploaded); not on any timed path."""
+    rng = np.random.default_rng(seed)
+    x = Array(R)
+    n = x.length()
+    T = np.dtype(R.eltype())
+    if T.kind == "c":
+        vals = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) / math.sqrt(2.0)
+    else:
+        vals = rng.standard_normal(n)
+    x._upload(vals.astype(T))
+    return x
+
+
+def from_numpy(a: np.ndarray, R: JetAbstractSpace | None = None):
+    """Upload a host array; shape metadata is column-major (Julia order)."""
+    a = np.asarray(a)
+    if R is None:
+        R = JetSpace(a.dtype, *a.shape)
+    x = Array(R)
+    x._upload(a.ravel(order="F") if not isinstance(R, JetBSpace) else a.ravel())
+    return x
+
+
+# ------------------------------------------------------------------------------ generic functions --
+def space(x):
+    """space(x) (src/Jets.jl:126, 814)."""
+    if isinstance(x, BlockArray):
+        return JetBSpace([JetSpace(x.dtype, *s.size()) for s in x.spaces])
+    if isinstance(x, DeviceArray):
+        return JetSpace(x.dtype, *x.shape)
+    a = np.asarray(x)
+    return JetSpace(a.dtype, *a.shape)
+
+
+def length(x) -> int:
+    return x.length() if hasattr(x, "length") else len(x)
+
+
+def nblocks(x) -> int:
+    """nblocks (src/Jets.jl:806-807, 860)."""
+    if isinstance(x, (BlockArray, JetBSpace)):
+        return len(x.spaces)
+    return 1
+
+
+def indices(x, i: int):
+    """indices(R, i) / indices(x, i) (src/Jets.jl:780, 858): 0-based half-open range."""
+    return x.indices[i]
+
+
+def getblock(x, iblock: int):
+    """getblock(x, i): by reference (src/Jets.jl:914); a plain array is its own block (918)."""
+    if isinstance(x, BlockArray):
+        return x.arrays[iblock]
+    return x
+
+
+def getblock_(x, iblock: int, out):
+    """getblock!(x, i, out) (src/Jets.jl:915, 919): copies block i into `out` (device or numpy array)."""
+    src = getblock(x, iblock)
+    if isinstance(out, _DevVec):
+        if out.length() != src.length():
+            raise ValueError("DimensionMismatch in getblock!")
+        check(lib.jh_getblock_copy(src.handle, 0, C.c_void_p(out.ptr), 1))
+        return out
+    if out.size != src.length():
+        raise ValueError("DimensionMismatch in getblock!")
+    out[...] = src.to_numpy().reshape(out.shape, order="F")
+    return out
+
+
+def setblock_(x, iblock: int, value):
+    """setblock!(x, i, v) (src/Jets.jl:916, 920): v is a scalar, a device array or a host array."""
+    dst = getblock(x, iblock)
+    if isinstance(value, (int, float, complex, np.number)):
+        v = complex(value)
+        if isinstance(x, BlockArray):
+            check(lib.jh_setblock_fill(x.handle, iblock, v.real, v.imag))
+        else:
+            check(lib.jh_fill(x.handle, v.real, v.imag))
+    elif isinstance(value, _DevVec):
+        if value.length() != dst.length():
+            raise ValueError("DimensionMismatch in setblock!")
+        check(lib.jh_setblock_copy(dst.handle, 0, C.c_void_p(value.ptr), 1))
+    else:
+        a = np.asarray(value, dtype=dst.dtype)
+        if a.size != dst.length():
+            raise ValueError("DimensionMismatch in setblock!")
+        dst._upload(a.ravel(order="F"))
+    return dst
+
+
+def norm(x: _DevVec, p: float = 2) -> float:
+    """norm(x, p) (src/Jets.jl:834-848); returned in real(eltype) precision like the reference."""
+    out = C.c_double(0)
+    check(lib.jh_norm(x.handle, float(p), C.byref(out)))
+    real_t = np.float32 if x.dtype in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
+    return real_t(out.value)
+
+
+def dot(x: _DevVec, y: _DevVec):
+    """dot(x, y) (src/Jets.jl:850-856): conjugates x; result cast to eltype T."""
+    re, im = C.c_double(0), C.c_double(0)
+    check(lib.jh_dot(x.handle, y.handle, C.byref(re), C.byref(im)))
+    if x.dtype.kind == "c":
+        return x.dtype.type(complex(re.value, im.value))
+    return x.dtype.type(re.value)
+
+
+def extrema(x: _DevVec):
+    """extrema(x) (src/Jets.jl:870-878)."""
+    mn, mx = C.c_double(0), C.c_double(0)
+    check(lib.jh_extrema(x.handle, C.byref(mn), C.byref(mx)))
+    return x.dtype.type(mn.value), x.dtype.type(mx.value)
+
+
+def fill_(x: _DevVec, a):
+    """fill!(x, a) (src/Jets.jl:880-885)."""
+    v = complex(a)
+    check(lib.jh_fill(x.handle, v.real, v.imag))
+    return x
+
+
+def copyto_(dst: _DevVec, src: _DevVec):
+    """dst .= src for equal-length device vectors."""
+    check(lib.jh_copy(dst.handle, src.handle))
+    return dst
+
+
+def lincomb_(dst: _DevVec, coefs: Sequence, xs: Sequence[_DevVec]):
+    """dst .= c1*x1 .+ c2*x2 .+ ... in one fused pass, evaluated left to right in eltype T."""
+    k = len(xs)
+    cf = (C.c_double * (2 * k))()
+    for j, c in enumerate(coefs):
+        cc = complex(c)
+        cf[2 * j], cf[2 * j + 1] = cc.real, cc.imag
+    hs = (C.c_void_p * k)(*[x.handle for x in xs])
+    check(lib.jh_lincomb(dst.handle, k, cf, hs))
+    return dst
+
+
+def hadamard_(dst: _DevVec, x: _DevVec, y: _DevVec, conj_x: bool = False):
+    """dst .= x .* y   (conj_x: conj.(x) .* y)."""
+    check(lib.jh_hadamard(dst.handle, x.handle, y.handle, 1 if conj_x else 0))
+    return dst
+
+
+def similar(x: _DevVec, T=None, n: int | None = None):
+    """similar(x[, T[, n]]) (src/Jets.jl:829-832): a BlockArray when n == length(x), else a plain array."""
+    T = x.dtype if T is None else np.dtype(T)
+    if isinstance(n, tuple):
+        n = n[0]
+    if isinstance(x, BlockArray):
+        if n is None or n == x.length():
+            return Array(JetBSpace([JetSpace(T, *s.size()) for s in x.spaces]))
+        return Array(JetSpace(T, n))
+    if n is None:
+        return Array(JetSpace(T, *x.shape))
+    return Array(JetSpace(T, n))
+
+
+def convert_array(x: _DevVec) -> DeviceArray:
+    """convert(Array, x::BlockArray) (src/Jets.jl:862-868) as a flat device array: the slab is
+    already in that layout, so this is one device-to-device copy."""
+    out = Array(JetSpace(x.dtype, x.length()))
+    check(lib.jh_copy(out.handle, x.handle))
+    return out
+
+
+def reshape(x, R):
+    """reshape(x, R) (src/Jets.jl:38, 1112-1118): shares memory with x."""
+    if isinstance(R, JetBSpace):
+        if isinstance(x, BlockArray):  # :1115-1118
+            if x.length() != R.length():
+                raise ValueError("dimension mismatch, unable to reshape block array")
+            return x
+        if x.length() != R.length():
+            raise ValueError("dimension mismatch, unable to reshape array into block space")
+        h = C.c_void_p()
+        check(lib.jh_bvec_wrap(C.c_void_p(x.ptr), R.nblocks(), _i64arr(R.block_lengths()), dtype_code(x.dtype), C.byref(h)))
+        return BlockArray(h, R.spaces, x.dtype, owner=x)  # :1112 views of x
+    if isinstance(x, BlockArray):
+        if x.length() != R.length():
+            raise ValueError("dimension mismatch in reshape")
+        h = C.c_void_p()
+        check(lib.jh_bvec_wrap(C.c_void_p(x.ptr), 1, _i64arr([x.length()]), dtype_code(x.dtype), C.byref(h)))
+        return DeviceArray(h, R.size(), x.dtype, owner=x)
+    return x.reshape(R.size())
+
+
+def vec(x):
+    """vec(x): 1-D view sharing memory."""
+    if isinstance(x, BlockArray):
+        return x
+    return x.reshape((x.length(),))

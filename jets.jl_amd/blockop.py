@@ -1,0 +1,354 @@
+"""Block operators: JetBlock / JopBlock / @blockop / JopZeroBlock and the block loops.
+
+Mirrors /root/reference/src/Jets.jl:926-1124.  `JetBlock_df` / `JetBlock_df_adj` issue ONE call into
+libjetship.so (jh_blockop_mul / jh_blockop_mul_adj) when every block is a device-native kind
+(zero / identity / scaled identity / diagonal, recognised by the identity of its df function the
+way the reference recognises JopZeroBlock by typeof(df!), src/Jets.jl:949); any other block
+falls back to the reference's per-block loop over child mul! calls on slab views.
+"""
+from __future__ import annotations
+
+import builtins
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from ._ffi import lib, check, BlockDesc, KINDS
+from . import arrays as _arr
+from .arrays import DeviceArray, BlockArray, zeros, lincomb_, hadamard_, copyto_, fill_, getblock, _i64arr
+from .spaces import JetAbstractSpace, JetSpace, JetBSpace, dtype_code
+from . import jets as _j
+from .jets import Jet, Jop, JopLn, JopNl, JopAdjoint, mul_, domain, range_, jet, adjoint, state, point_, close
+
+__all__ = [
+    "JetBlock", "JopBlock", "blockop", "JopZeroBlock", "JopZeroBlock_df", "iszero", "JetBlock_f", "JetBlock_df",
+    "JetBlock_df_adj", "nblocks_op", "getblock_op", "isblockop", "JopDiagonal", "JopIdentity", "diagonal_df",
+    "diagonal_df_adj", "identity_df", "NativeBlockOp",
+]
+
+
+# ------------------------------------------------------------------------------ native kinds -------
+def JopZeroBlock_df(d, m, **kw):  # src/Jets.jl:942   d .= 0
+    return fill_(d, 0)
+
+
+def JopZeroBlock(dom: JetAbstractSpace, rng: JetAbstractSpace) -> JopLn:  # :941
+    return JopLn(df=JopZeroBlock_df, dom=dom, rng=rng)
+
+
+def iszero(A) -> bool:  # :949-951  a type test on df!, not a value test
+    j = A if isinstance(A, Jet) else jet(A)
+    return j.df is JopZeroBlock_df
+
+
+def diagonal_df(d, m, *, diagonal, **kw):  # test/runtests.jl:3   d .= diagonal .* m
+    return hadamard_(d, diagonal, m)
+
+
+def diagonal_df_adj(m, d, *, diagonal, **kw):  # test/runtests.jl:4   m .= conj.(diagonal) .* d
+    return hadamard_(m, diagonal, d, conj_x=True)
+
+
+def JopDiagonal(diag: DeviceArray) -> JopLn:
+    """Diagonal operator over a device array (the reference's test fixture JopFoo, test/runtests.jl:3-8;
+    JetPack's JopDiagonal in docs/src/index.md:205)."""
+    spc = JetSpace(diag.dtype, *diag.shape)
+    return JopLn(df=diagonal_df, df_adj=diagonal_df_adj, dom=spc, rng=spc, s={"diagonal": diag})
+
+
+def identity_df(d, m, **kw):  # d .= m
+    return copyto_(d, m)
+
+
+def JopIdentity(spc: JetAbstractSpace) -> JopLn:
+    return JopLn(df=identity_df, dom=spc, rng=spc)
+
+
+def _native_desc(op: Jop):
+    """(kind, adjoint_flag, coeff_array_or_None, scale) if `op` is device-native, else None."""
+    adj = 0
+    if isinstance(op, JopAdjoint):
+        adj, op = 1, op.op
+    if not isinstance(op, JopLn):
+        return None
+    j = op.jet
+    if j.df is JopZeroBlock_df:
+        return ("zero", adj, None, 0.0)
+    if j.df is identity_df:
+        return ("identity", adj, None, 0.0)
+    if j.df is diagonal_df and j.df_adj is diagonal_df_adj:
+        return ("diag", adj, j.s["diagonal"], 0.0)
+    if j.df is _j.constdiag_df and j.df_adj is _j.constdiag_df_adj:
+        return ("scale", adj, None, complex(j.s["a"]))
+    return None
+
+
+class NativeBlockOp:
+    """Owns a jh_blockop handle for a matrix of device-native blocks."""
+
+    def __init__(self, ops: np.ndarray, descs, dtype):
+        nrow, ncol = ops.shape
+        arr = (BlockDesc * (nrow * ncol))()
+        self._keep = []
+        for jcol in builtins.range(ncol):
+            for irow in builtins.range(nrow):
+                kind, adj, coeff, scale = descs[irow][jcol]
+                op = ops[irow, jcol]
+                base = op.op if isinstance(op, JopAdjoint) else op
+                b = arr[irow + jcol * nrow]  # column-major like a Julia Matrix
+                b.kind, b.adjoint = KINDS[kind], adj
+                b.coeff = coeff.ptr if coeff is not None else None
+                sc = complex(scale)
+                b.scale_re, b.scale_im = sc.real, sc.imag
+                b.nr, b.nc = range_(base).length(), domain(base).length()
+                if coeff is not None:
+                    self._keep.append(coeff)
+        row_len = [range_(ops[i, 0]).length() for i in builtins.range(nrow)]
+        col_len = [domain(ops[0, jc]).length() for jc in builtins.range(ncol)]
+        self._h = C.c_void_p()
+        check(lib.jh_blockop_create(nrow, ncol, arr, _i64arr(row_len), _i64arr(col_len), dtype_code(dtype), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise ValueError("native block operator already closed")
+        return self._h
+
+    def mul(self, d, m):
+        check(lib.jh_blockop_mul(self.handle, d.handle, m.handle))
+        return d
+
+    def mul_adj(self, m, d):
+        check(lib.jh_blockop_mul_adj(self.handle, m.handle, d.handle))
+        return m
+
+    def normal_mul(self, y, m):
+        check(lib.jh_blockop_normal_mul(self.handle, y.handle, m.handle))
+        return y
+
+    def close(self):
+        if self._h is not None:
+            h, self._h = self._h, None
+            lib.jh_blockop_destroy(h)
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _NativeCell:
+    """Mutable slot in a block jet's state holding its lazily built NativeBlockOp (closures only see
+    the state as keyword arguments, src/Jets.jl:391, so the cache travels with the state)."""
+
+    def __init__(self):
+        self.value = "unset"
+
+    def __deepcopy__(self, memo):  # copy(jet) deep-copies the state (src/Jets.jl:230): fresh cache
+        return _NativeCell()
+
+    def close(self):
+        if isinstance(self.value, NativeBlockOp):
+            self.value.close()
+        self.value = "unset"
+
+
+def _native_op(cell, ops, dtype):
+    """The cached NativeBlockOp of a block jet, or None when some block is not device-native."""
+    if cell is None:
+        cell = _NativeCell()
+    if cell.value != "unset":
+        return cell.value
+    descs = [[_native_desc(ops[i, jc]) for jc in builtins.range(ops.shape[1])] for i in builtins.range(ops.shape[0])]
+    if any(dsc is None for row in descs for dsc in row):
+        cell.value = None
+    else:
+        cell.value = NativeBlockOp(ops, descs, dtype)
+    return cell.value
+
+
+# ------------------------------------------------------------------------------ construction -------
+def _as_matrix(ops) -> np.ndarray:
+    if isinstance(ops, np.ndarray) and ops.dtype == object:
+        m = ops
+    else:
+        rows = list(ops)
+        if rows and isinstance(rows[0], Jop):  # vector -> N x 1   (src/Jets.jl:933)
+            m = np.empty((len(rows), 1), dtype=object)
+            for i, op in enumerate(rows):
+                m[i, 0] = op
+            return m
+        m = np.empty((len(rows), len(rows[0])), dtype=object)
+        for i, row in enumerate(rows):
+            if len(row) != m.shape[1]:
+                raise ValueError("ragged block matrix")
+            for jc, op in enumerate(row):
+                m[i, jc] = op
+    if m.ndim == 1:
+        m = m.reshape(-1, 1)
+    return m
+
+
+def JetBlock(ops, dadom: bool = False, **kwargs) -> Jet:  # :926-930
+    ops = _as_matrix(ops)
+    nrow, ncol = ops.shape
+    dom = domain(ops[0, 0]) if (ncol == 1 and not dadom) else JetBSpace([domain(ops[0, jc]) for jc in builtins.range(ncol)])
+    rng = JetBSpace([range_(ops[i, 0]) for i in builtins.range(nrow)])
+    return Jet(f=JetBlock_f, df=JetBlock_df, df_adj=JetBlock_df_adj, dom=dom, rng=rng,
+               s={"ops": ops, "dom": dom, "rng": rng, "_native": _NativeCell(), **kwargs})
+
+
+def JopBlock(ops, **kwargs) -> Jop:  # :931-933
+    ops = _as_matrix(ops)
+    if all(isinstance(op, (JopLn, JopAdjoint)) for op in ops.flat):
+        return JopLn(JetBlock(ops, **kwargs))
+    return JopNl(JetBlock(ops, **kwargs))
+
+
+def blockop(ops, **kwargs) -> Jop:
+    """@blockop ops [kw...]  (src/Jets.jl:953-986)."""
+    return JopBlock(ops, **kwargs)
+
+
+# ------------------------------------------------------------------------------ the block loops ----
+def JetBlock_f(d, m, *, ops, dom, rng, _native=None, **kw):  # :988-1008
+    nrow, ncol = ops.shape
+    dtmp = zeros(range_(ops[0, 0])) if ncol > 1 else None
+    for i in builtins.range(nrow):
+        _d = getblock(d, i)
+        if ncol > 1 and dtmp.shape != tuple(range_(ops[i, 0]).size()):
+            dtmp = zeros(range_(ops[i, 0]))
+        for jc in builtins.range(ncol):
+            _m = getblock(m, jc)
+            if ncol > 1:
+                lincomb_(_d, [1.0, 1.0], [_d, mul_(dtmp, ops[i, jc], _m)])  # _d .+= mul!(dtmp, op, _m)   (:1001)
+            else:
+                mul_(_d, ops[i, jc], m)  # (:1003)
+    return d
+
+
+def JetBlock_df(d, m, *, ops, dom, rng, _native=None, **kw):  # :1010-1032
+    nat = _native_op(_native, ops, rng.eltype())
+    if nat is not None:
+        return nat.mul(d, m)  # one fused launch, same loop order and rounding
+    nrow, ncol = ops.shape
+    dtmp = zeros(range_(ops[0, 0])) if ncol > 1 else None  # :1012-1014
+    for i in builtins.range(nrow):  # :1015
+        _d = getblock(d, i)
+        if ncol > 1 and dtmp.shape != tuple(range_(ops[i, 0]).size()):  # :1018
+            dtmp = zeros(range_(ops[i, 0]))
+        for jc in builtins.range(ncol):  # :1020
+            _m = getblock(m, jc)
+            if not iszero(ops[i, jc]):  # :1022
+                if ncol > 1:
+                    lincomb_(_d, [1.0, 1.0], [_d, mul_(dtmp, JopLn(ops[i, jc]), _m)])  # :1024
+                else:
+                    mul_(_d, JopLn(ops[i, jc]), _m)  # :1026
+    return d
+
+
+def JetBlock_df_adj(m, d, *, ops, dom, rng, _native=None, **kw):  # :1034-1057
+    nat = _native_op(_native, ops, rng.eltype())
+    if nat is not None:
+        return nat.mul_adj(m, d)
+    nrow, ncol = ops.shape
+    mtmp = zeros(domain(ops[0, 0])) if nrow > 1 else None  # :1036-1038
+    for jc in builtins.range(ncol):  # :1039
+        _m = getblock(m, jc)
+        if nrow > 1:
+            fill_(_m, 0)  # :1042
+            if mtmp.shape != tuple(domain(ops[0, jc]).size()):  # :1043
+                mtmp = zeros(domain(ops[0, jc]))
+        for i in builtins.range(nrow):  # :1045
+            _d = getblock(d, i)
+            if not iszero(ops[i, jc]):  # :1047
+                if nrow > 1:
+                    lincomb_(_m, [1.0, 1.0], [_m, mul_(mtmp, adjoint(JopLn(ops[i, jc])), _d)])  # :1049
+                else:
+                    mul_(_m, adjoint(JopLn(ops[i, jc])), _d)  # :1051
+    return m
+
+
+def point_block(j: Jet, mo):  # :1059-1066
+    ops = j.s["ops"]
+    j.mo = mo
+    for jc in builtins.range(ops.shape[1]):
+        for i in builtins.range(ops.shape[0]):
+            point_(jet(ops[i, jc]), getblock(mo, jc))
+    return j
+
+
+def close_block(j: Jet):  # :1120-1124
+    ops = j.s["ops"]
+    for op in ops.flat:
+        close(op)
+    cell = j.s.get("_native")
+    if cell is not None:
+        cell.close()
+    return None
+
+
+def nblocks_op(A, i=None):  # :1074-1077
+    r, dm = _arr.nblocks(range_(A)), _arr.nblocks(domain(A))
+    if i is None:
+        return (r, dm)
+    return r if i == 1 else dm
+
+
+def isblockop(A) -> bool:  # :1097-1098
+    return isinstance(A, Jop) and jet(A).f is JetBlock_f
+
+
+def getblock_op(A, i: int, jc: int, kind=None):  # :1085-1090, 1100-1110
+    if kind is JopNl:  # getblock(JopNl, A, i, j)
+        r = getblock_op(jet(A), i, jc)
+        if not isinstance(r, JopNl):
+            raise TypeError("block is not a JopNl")
+        return r
+    if kind is JopLn:
+        return JopLn(getblock_op(jet(A), i, jc))
+    if isinstance(A, Jet):
+        if A.f is JetBlock_f:
+            return A.s["ops"][i, jc]  # :1085
+        if A.f is _j.JetComposite_f:  # :1100-1110
+            ops = [getblock_op(op, i, jc) if isblockop(op) else op for op in A.s["ops"]]
+            out = ops[0]
+            for op in ops[1:]:
+                out = _j.compose(out, op)
+            return out
+        raise TypeError("not a block operator")
+    if isinstance(A, JopAdjoint):
+        return adjoint(getblock_op(A.op, jc, i))  # :1088
+    if isinstance(A, JopLn):
+        return JopLn(getblock_op(A.jet, i, jc))  # :1086
+    return getblock_op(A.jet, i, jc)  # :1087
+
+
+# ------------------------------------------------------------------------------ fused A' o A -------
+def try_fused_normal(out, x, ops: Sequence[Jop]):
+    """JetComposite_df over (A', A) with A a tall all-diagonal native block operator: one kernel that
+    reads A once (jh_blockop_normal_mul).  Returns None when the chain does not qualify."""
+    if len(ops) != 2:
+        return None
+    left, right = ops
+    if not (isinstance(left, JopAdjoint) and left.op is right and isinstance(right, JopLn) and isblockop(right)):
+        return None
+    j = right.jet
+    nat = _native_op(j.s.get("_native"), j.s["ops"], j.rng.eltype())
+    if nat is None or j.s["ops"].shape[1] != 1 or j.s["ops"].shape[0] < 2:
+        return None
+    try:
+        return nat.normal_mul(out, x)
+    except _arr_check_error() as e:  # not eligible for the fused kernel (mixed kinds, ragged blocks)
+        if e.status == 4:
+            return None
+        raise
+
+
+def _arr_check_error():
+    from ._ffi import JetsHipError
+
+    return JetsHipError

@@ -1,0 +1,573 @@
+// jh_blockop.hip -- JetBlock_df! / JetBlock_df'! (src/Jets.jl:1010-1057) and the fused A'oA
+// (src/Jets.jl:530-534 over (A', A)) as hand-written gfx950 kernels.
+//
+// Data layout in HBM: the range vector d is one slab, block i at element offset row_off[i];
+// a DIAG block's coefficients are a device array of the block's length; the domain vector m of a
+// tall (one-column) operator is a plain array (src/Jets.jl:927).
+//
+// Two kernel families:
+//  * tall fast path (ncol == 1, every block DIAG, equal block length, 16-byte aligned): the
+//    BASELINE.json workload.  Forward: a workgroup owns an element tile, keeps its m tile in
+//    registers and streams `fwd_group` blocks through it (a read once, d written once, m
+//    re-read nrow/fwd_group times, from L2/MALL).  Adjoint: a thread owns 16-byte element
+//    vectors and walks the rows IN ORDER, product rounded then added -- the reference's
+//    `_m .+= mul!(mtmp, op', _d)` (1049) without the mtmp round trip -- so the result is
+//    bit-identical to the sequential CPU loop.  HBM-bound: 16 B/lane loads, `adj_depth` rows in
+//    flight per thread, nontemporal on the streamed operands.
+//  * general path: any nrow x ncol mix of ZERO / IDENTITY / SCALE / DIAG blocks with ragged block
+//    lengths; one thread per element walks a block row (forward) or block column (adjoint) in
+//    the reference's loop order with the same rounding sequence.
+#include "jh_internal.h"
+
+namespace {
+
+template <typename S, int NS> struct vec_of { typedef S type __attribute__((ext_vector_type(NS))); };
+template <typename S> struct vec_of<S, 1> { typedef S type; };
+
+// every operand of these kernels lives in HBM: load/store through address_space(1) pointers so the
+// compiler emits global_load/global_store (never flat_*), also for pointers read from the block table
+template <bool NT, typename V> __device__ inline V ld(const V *p)
+{
+    typedef const V __attribute__((address_space(1))) *gp;
+    if (NT) return __builtin_nontemporal_load((gp)p);
+    return *(gp)p;
+}
+template <bool NT, typename V> __device__ inline void st(V *p, V v)
+{
+    typedef V __attribute__((address_space(1))) *gp;
+    if (NT) __builtin_nontemporal_store(v, (gp)p);
+    else *(gp)p = v;
+}
+
+// a (conj?) * b on a vector of NS scalars holding NS/E elements; every product/sum rounded.
+template <typename S, int E, int NS, typename V> __device__ inline V vmul(V a, V b, bool conj_a)
+{
+    if constexpr (E == 1) {
+        return a * b;
+    } else {
+        V o;
+#pragma unroll
+        for (int e = 0; e < NS; e += 2) {
+            S ar = a[e], ai = conj_a ? -a[e + 1] : a[e + 1], br = b[e], bi = b[e + 1];
+            o[e] = ar * br - ai * bi;
+            o[e + 1] = ar * bi + ai * br;
+        }
+        return o;
+    }
+}
+
+// ------------------------------------------------------------------ tall fast path ------------
+// grid.x = element tiles, grid.y = row groups.  n_scalars % NS == 0.
+template <typename S, int E, int NS, int U, bool NT, int BLK>
+__global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__restrict__ blocks, int64_t nrow, int rows_per_wg,
+                                                       const S *__restrict__ a_base, int64_t a_stride,
+                                                       const S *__restrict__ m, S *__restrict__ d, int64_t n_scalars)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t s0 = ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
+    const int64_t i0 = (int64_t)blockIdx.y * rows_per_wg;
+    const int64_t i1 = (i0 + rows_per_wg < nrow) ? i0 + rows_per_wg : nrow;
+    const bool full = ((int64_t)(blockIdx.x + 1) * U * BLK * NS) <= n_scalars;
+    V mv[U];
+    if (full) {
+#pragma unroll
+        for (int k = 0; k < U; k++) mv[k] = ld<false>(reinterpret_cast<const V *>(m + s0 + (int64_t)k * BLK * NS));
+#pragma unroll 2
+        for (int64_t i = i0; i < i1; i++) {
+            const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
+            S *di = d + i * n_scalars;
+            V av[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) av[k] = ld<NT>(reinterpret_cast<const V *>(a + s0 + (int64_t)k * BLK * NS));
+#pragma unroll
+            for (int k = 0; k < U; k++)
+                st<NT>(reinterpret_cast<V *>(di + s0 + (int64_t)k * BLK * NS), vmul<S, E, NS, V>(av[k], mv[k], false));
+        }
+    } else {
+        bool ok[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
+            if (ok[k]) mv[k] = ld<false>(reinterpret_cast<const V *>(m + s0 + (int64_t)k * BLK * NS));
+        }
+        for (int64_t i = i0; i < i1; i++) {
+            const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
+            S *di = d + i * n_scalars;
+#pragma unroll
+            for (int k = 0; k < U; k++)
+                if (ok[k]) {
+                    V av = ld<NT>(reinterpret_cast<const V *>(a + s0 + (int64_t)k * BLK * NS));
+                    st<NT>(reinterpret_cast<V *>(di + s0 + (int64_t)k * BLK * NS), vmul<S, E, NS, V>(av, mv[k], false));
+                }
+        }
+    }
+}
+
+// one thread: U vectors of the domain, all rows in order.  MODE 0: adjoint (reads a_i, d_i);
+// MODE 1: fused normal equations y = sum_i conj(a_i) .* (a_i .* m) (reads a_i only).
+template <typename S, int E, int NS, int U, int DEPTH, bool NT, int MODE, int BLK>
+__global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__restrict__ blocks, int64_t nrow,
+                                                       const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ out,
+                                                       const S *__restrict__ in, int64_t n_scalars, int direct)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t s0 = ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
+    bool ok[U];
+    V acc[U], mv[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
+        acc[k] = (V)(S)0;
+        if (MODE == 1) mv[k] = ok[k] ? ld<false>(reinterpret_cast<const V *>(in + s0 + (int64_t)k * BLK * NS)) : (V)(S)0;
+    }
+    // clamp out-of-range vectors onto a valid address so the main loop is branch-free
+    int64_t sk[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
+
+    int64_t i = 0;
+    for (; !direct && i + DEPTH <= nrow; i += DEPTH) {
+        V av[DEPTH][U], dv[DEPTH][U];
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            const S *a = a_base ? a_base + (i + j) * a_stride : (const S *)blocks[i + j].coeff;
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                av[j][k] = ld<NT>(reinterpret_cast<const V *>(a + sk[k]));
+                if (MODE == 0) dv[j][k] = ld<NT>(reinterpret_cast<const V *>(in + (i + j) * n_scalars + sk[k]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                V t = (MODE == 0) ? dv[j][k] : vmul<S, E, NS, V>(av[j][k], mv[k], false);   // d_i = a_i .* m   (1026)
+                V p = vmul<S, E, NS, V>(av[j][k], t, true);                                 // mtmp = conj(a_i) .* d_i
+                acc[k] = acc[k] + p;                                                         // _m .+= mtmp   (1049)
+            }
+    }
+    for (; i < nrow; i++) {
+        const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            V av = ld<NT>(reinterpret_cast<const V *>(a + sk[k]));
+            V t = (MODE == 0) ? ld<NT>(reinterpret_cast<const V *>(in + i * n_scalars + sk[k])) : vmul<S, E, NS, V>(av, mv[k], false);
+            V p = vmul<S, E, NS, V>(av, t, true);
+            acc[k] = direct ? p : acc[k] + p;     // nrow == 1: mul!(_m, op', _d) writes directly (1051)
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++)
+        if (ok[k]) st<false>(reinterpret_cast<V *>(out + s0 + (int64_t)k * BLK * NS), acc[k]);
+}
+
+// ------------------------------------------------------------------ general path --------------
+template <typename S, int E> struct elem {
+    S re, im;
+};
+template <typename S, int E> __device__ inline elem<S, E> eload(const S *p, int64_t idx)
+{
+    typedef const S __attribute__((address_space(1))) *gp;
+    elem<S, E> r;
+    r.re = ((gp)p)[idx * E];
+    r.im = (E == 2) ? ((gp)p)[idx * E + 1] : (S)0;
+    return r;
+}
+template <typename S, int E> __device__ inline void estore(S *p, int64_t idx, elem<S, E> v)
+{
+    p[idx * E] = v.re;
+    if (E == 2) p[idx * E + 1] = v.im;
+}
+template <typename S, int E> __device__ inline elem<S, E> emul(elem<S, E> a, elem<S, E> b)
+{
+    elem<S, E> r;
+    if (E == 1) { r.re = a.re * b.re; r.im = 0; }
+    else { r.re = a.re * b.re - a.im * b.im; r.im = a.re * b.im + a.im * b.re; }
+    return r;
+}
+template <typename S, int E> __device__ inline elem<S, E> eadd(elem<S, E> a, elem<S, E> b)
+{
+    elem<S, E> r;
+    r.re = a.re + b.re;
+    r.im = (E == 2) ? a.im + b.im : (S)0;
+    return r;
+}
+
+// child mul! of an elementwise block applied to one element x at local index e.
+// `transposed` = we are inside df'! (so the child is op').  Effective conjugation = adjoint XOR transposed.
+template <typename S, int E>
+__device__ inline elem<S, E> apply_block(const jh_dev_block &b, elem<S, E> x, int64_t e, bool transposed)
+{
+    const bool cj = (b.adjoint != 0) != transposed;
+    switch (b.kind) {
+    case JH_OP_IDENTITY: return x;
+    case JH_OP_SCALE: {
+        elem<S, E> a;
+        a.re = (S)b.sre;
+        a.im = (E == 2) ? (cj ? -(S)b.sim : (S)b.sim) : (S)0;
+        return emul<S, E>(a, x);                       // d .= a*m / m .= conj(a)*d   (1159-1160)
+    }
+    case JH_OP_DIAG: {
+        elem<S, E> a = eload<S, E>((const S *)b.coeff, e);
+        if (E == 2 && cj) a.im = -a.im;
+        return emul<S, E>(a, x);                       // diagonal .* m / conj.(diagonal) .* d
+    }
+    default: {
+        elem<S, E> z;
+        z.re = 0; z.im = 0;
+        return z;
+    }
+    }
+}
+
+// JetBlock_df! (1010-1032): grid.y = block row, threads over the row's elements.
+template <typename S, int E>
+__global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
+                                    const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
+                                    const S *__restrict__ m, S *__restrict__ d)
+{
+    const int64_t i = blockIdx.y;
+    const int64_t n = row_off[i + 1] - row_off[i];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        elem<S, E> acc;
+        bool touched = false;
+        if (ncol > 1) { acc = eload<S, E>(d, row_off[i] + e); }          // `_d .+=` accumulates into d as found (1024)
+        else { acc.re = 0; acc.im = 0; }
+        for (int64_t j = 0; j < ncol; j++) {                               // (1020)
+            const jh_dev_block b = blocks[i + j * nrow];
+            if (b.kind == JH_OP_ZERO) continue;                            // (1022)
+            elem<S, E> x = eload<S, E>(m, col_off[j] + e);
+            elem<S, E> p = apply_block<S, E>(b, x, e, false);              // mul!(dtmp, op, _m)
+            acc = (ncol > 1) ? eadd<S, E>(acc, p) : p;                     // (1024) / (1026)
+            touched = true;
+        }
+        if (touched) estore<S, E>(d, row_off[i] + e, acc);
+    }
+}
+
+// JetBlock_df'! (1034-1057): grid.y = block column, threads over the column's elements.
+template <typename S, int E>
+__global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
+                                    const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
+                                    S *__restrict__ m, const S *__restrict__ d)
+{
+    const int64_t j = blockIdx.y;
+    const int64_t n = col_off[j + 1] - col_off[j];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        elem<S, E> acc;
+        acc.re = 0; acc.im = 0;                                            // `_m .= 0` when nrow > 1 (1042)
+        bool touched = (nrow > 1);
+        for (int64_t i = 0; i < nrow; i++) {                               // (1045)
+            const jh_dev_block b = blocks[i + j * nrow];
+            if (b.kind == JH_OP_ZERO) continue;                            // (1047)
+            elem<S, E> x = eload<S, E>(d, row_off[i] + e);
+            elem<S, E> p = apply_block<S, E>(b, x, e, true);               // mul!(mtmp, op', _d)
+            acc = (nrow > 1) ? eadd<S, E>(acc, p) : p;                     // (1049) / (1051)
+            touched = true;
+        }
+        if (touched) estore<S, E>(m, col_off[j] + e, acc);
+    }
+}
+
+// ------------------------------------------------------------------ launch helpers ------------
+template <typename S, int E, int NS, bool NT, int BLK>
+int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
+{
+    jh_context &c = jh_ctx();
+    const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
+    const int64_t a_stride = op->diag_stride_elems * E;
+    int64_t G = c.fwd_group;
+    if (G > op->nrow) G = op->nrow;
+    int64_t gy = (op->nrow + G - 1) / G;
+    while (gy > 65535) { G *= 2; gy = (op->nrow + G - 1) / G; }
+#define JH_FWD_CASE(U)                                                                                               \
+    case U: {                                                                                                         \
+        int64_t gx = (n_scalars + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                               \
+        hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, NT, BLK>), dim3((unsigned)gx, (unsigned)gy), dim3(BLK), 0,   \
+                           c.stream, op->dev_blocks, op->nrow, (int)G, a_base, a_stride, (const S *)m, (S *)d, n_scalars); \
+    } break;
+    switch (c.fwd_unroll) {
+        JH_FWD_CASE(1)
+        JH_FWD_CASE(2)
+        JH_FWD_CASE(4)
+        JH_FWD_CASE(8)
+    default: return jh_fail(JH_ERR_INVALID, "fwd_unroll %lld unsupported", (long long)c.fwd_unroll);
+    }
+#undef JH_FWD_CASE
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+template <typename S, int E, int NS, bool NT, int MODE, int BLK>
+int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n_scalars)
+{
+    jh_context &c = jh_ctx();
+    const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
+    const int64_t a_stride = op->diag_stride_elems * E;
+    const int direct = (op->nrow == 1 && MODE == 0) ? 1 : 0;
+#define JH_ADJ_CASE(U, DEPTH)                                                                                          \
+    if (c.adj_unroll == U && c.adj_depth == DEPTH) {                                                                   \
+        int64_t gx = (n_scalars + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                                \
+        hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, NT, MODE, BLK>), dim3((unsigned)gx), dim3(BLK), 0,     \
+                           c.stream, op->dev_blocks, op->nrow, a_base, a_stride, (S *)out, (const S *)in, n_scalars, direct); \
+        JH_CHECK_HIP(hipGetLastError());                                                                               \
+        return JH_OK;                                                                                                  \
+    }
+    JH_ADJ_CASE(1, 1) JH_ADJ_CASE(1, 2) JH_ADJ_CASE(1, 4) JH_ADJ_CASE(1, 8)
+    JH_ADJ_CASE(2, 1) JH_ADJ_CASE(2, 2) JH_ADJ_CASE(2, 4) JH_ADJ_CASE(2, 8)
+    JH_ADJ_CASE(4, 1) JH_ADJ_CASE(4, 2) JH_ADJ_CASE(4, 4)
+#undef JH_ADJ_CASE
+    return jh_fail(JH_ERR_INVALID, "adj_unroll %lld x adj_depth %lld unsupported", (long long)c.adj_unroll, (long long)c.adj_depth);
+}
+
+template <typename S, int E, int NS>
+int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
+{
+    jh_context &c = jh_ctx();
+    if (c.wg == 256) return c.nt ? launch_tall_fwd_u<S, E, NS, true, 256>(op, d, m, n_scalars) : launch_tall_fwd_u<S, E, NS, false, 256>(op, d, m, n_scalars);
+    if (c.wg == 512) return c.nt ? launch_tall_fwd_u<S, E, NS, true, 512>(op, d, m, n_scalars) : launch_tall_fwd_u<S, E, NS, false, 512>(op, d, m, n_scalars);
+    return c.nt ? launch_tall_fwd_u<S, E, NS, true, 1024>(op, d, m, n_scalars) : launch_tall_fwd_u<S, E, NS, false, 1024>(op, d, m, n_scalars);
+}
+template <typename S, int E, int NS, int MODE>
+int launch_tall_adj(const jh_blockop *op, void *out, const void *in, int64_t n_scalars)
+{
+    jh_context &c = jh_ctx();
+    if (c.wg == 256) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 256>(op, out, in, n_scalars) : launch_tall_adj_u<S, E, NS, false, MODE, 256>(op, out, in, n_scalars);
+    if (c.wg == 512) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 512>(op, out, in, n_scalars) : launch_tall_adj_u<S, E, NS, false, MODE, 512>(op, out, in, n_scalars);
+    return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 1024>(op, out, in, n_scalars) : launch_tall_adj_u<S, E, NS, false, MODE, 1024>(op, out, in, n_scalars);
+}
+
+// fast path usable?  (tall, all DIAG, uniform rows, 16-byte aligned everything, no conj flags on complex)
+bool tall_fast_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
+{
+    if (!(op->tall && op->all_diag && op->uniform_rows)) return false;
+    const size_t es = jh_dtype_size(op->dtype);
+    const int64_t n = op->row_len[0];
+    if (n == 0 || (n * (int64_t)es) % 16 != 0) return false;
+    if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & 15u) return false;
+    for (const auto &b : op->blocks)
+        if (((uintptr_t)b.coeff) & 15u) return false;
+    return true;
+}
+
+template <typename S, int E>
+int general_fwd(const jh_blockop *op, void *d, const void *m)
+{
+    int64_t maxn = 0;
+    for (int64_t i = 0; i < op->nrow; i++) maxn = op->row_len[i] > maxn ? op->row_len[i] : maxn;
+    if (maxn == 0) return JH_OK;
+    int64_t gx = (maxn + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    JH_REQUIRE(op->nrow <= 65535, "general block forward supports at most 65535 block rows (got %lld)", (long long)op->nrow);
+    hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3((unsigned)gx, (unsigned)op->nrow), dim3(256), 0, jh_ctx().stream,
+                       op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+template <typename S, int E>
+int general_adj(const jh_blockop *op, void *m, const void *d)
+{
+    int64_t maxn = 0;
+    for (int64_t j = 0; j < op->ncol; j++) maxn = op->col_len[j] > maxn ? op->col_len[j] : maxn;
+    if (maxn == 0) return JH_OK;
+    int64_t gx = (maxn + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    JH_REQUIRE(op->ncol <= 65535, "general block adjoint supports at most 65535 block columns (got %lld)", (long long)op->ncol);
+    hipLaunchKernelGGL((k_block_adj_general<S, E>), dim3((unsigned)gx, (unsigned)op->ncol), dim3(256), 0, jh_ctx().stream,
+                       op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+int check_vectors(const jh_blockop *op, const jh_bvec *rng, const jh_bvec *dom, const char *who)
+{
+    JH_REQUIRE(op && rng && dom, "%s: null argument", who);
+    JH_REQUIRE(rng->dtype == op->dtype && dom->dtype == op->dtype, "%s: dtype mismatch (op %d, range %d, domain %d)", who,
+               op->dtype, rng->dtype, dom->dtype);
+    JH_REQUIRE(rng->length == op->row_off[(size_t)op->nrow], "%s: range vector has %lld elements, operator range has %lld", who,
+               (long long)rng->length, (long long)op->row_off[(size_t)op->nrow]);
+    JH_REQUIRE(dom->length == op->col_off[(size_t)op->ncol], "%s: domain vector has %lld elements, operator domain has %lld", who,
+               (long long)dom->length, (long long)op->col_off[(size_t)op->ncol]);
+    return JH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, const int64_t *row_len, const int64_t *col_len,
+                      int dtype, jh_blockop **out)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(out && blocks && row_len && col_len, "jh_blockop_create: null argument");
+    JH_REQUIRE(nrow >= 1 && ncol >= 1, "jh_blockop_create: need at least one block row and column (got %lld x %lld)",
+               (long long)nrow, (long long)ncol);
+    JH_REQUIRE(jh_dtype_size(dtype) != 0, "jh_blockop_create: unknown dtype %d", dtype);
+    jh_blockop *op = new jh_blockop();
+    op->dtype = dtype;
+    op->nrow = nrow;
+    op->ncol = ncol;
+    op->blocks.assign(blocks, blocks + nrow * ncol);
+    op->row_len.assign(row_len, row_len + nrow);
+    op->col_len.assign(col_len, col_len + ncol);
+    op->row_off.assign((size_t)nrow + 1, 0);
+    op->col_off.assign((size_t)ncol + 1, 0);
+    for (int64_t i = 0; i < nrow; i++) op->row_off[(size_t)i + 1] = op->row_off[(size_t)i] + row_len[i];
+    for (int64_t j = 0; j < ncol; j++) op->col_off[(size_t)j + 1] = op->col_off[(size_t)j] + col_len[j];
+    op->tall = (ncol == 1);
+    op->uniform_rows = true;
+    op->all_diag = true;
+    op->elementwise = true;
+    int status = JH_OK;
+    for (int64_t j = 0; j < ncol && status == JH_OK; j++)
+        for (int64_t i = 0; i < nrow && status == JH_OK; i++) {
+            const jh_block_desc &b = op->blocks[(size_t)(i + j * nrow)];
+            if (row_len[i] != row_len[0]) op->uniform_rows = false;
+            const int64_t rl = b.adjoint ? b.nc : b.nr, dl = b.adjoint ? b.nr : b.nc;
+            if (row_len[i] < 0 || col_len[j] < 0)
+                status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: negative block length");
+            else if (rl != row_len[i] || dl != col_len[j])
+                status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: block (%lld,%lld) maps %lld -> %lld but its row/column are %lld / %lld",
+                                 (long long)i, (long long)j, (long long)dl, (long long)rl, (long long)col_len[j], (long long)row_len[i]);
+            else if (b.kind == JH_OP_DENSE) {
+                op->elementwise = false;
+                op->all_diag = false;
+            } else if (b.kind == JH_OP_DIAG || b.kind == JH_OP_IDENTITY || b.kind == JH_OP_SCALE) {
+                if (b.nr != b.nc)
+                    status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: elementwise block (%lld,%lld) must be square (%lld x %lld)",
+                                     (long long)i, (long long)j, (long long)b.nr, (long long)b.nc);
+                if (b.kind == JH_OP_DIAG && !b.coeff && b.nr > 0)
+                    status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: DIAG block (%lld,%lld) has no coefficients", (long long)i, (long long)j);
+                if (b.kind != JH_OP_DIAG) op->all_diag = false;
+                if (b.kind == JH_OP_DIAG && b.adjoint && jh_dtype_complex(dtype)) op->all_diag = false;
+                if (b.kind == JH_OP_SCALE && b.scale_im != 0.0 && !jh_dtype_complex(dtype))
+                    status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: complex scale on a real operator");
+            } else if (b.kind == JH_OP_ZERO) {
+                op->all_diag = false;
+            } else {
+                status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: unknown block kind %d at (%lld,%lld)", b.kind, (long long)i, (long long)j);
+            }
+        }
+    if (status == JH_OK && !op->elementwise)
+        status = jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_create: DENSE blocks are not implemented on the device path yet");
+    if (status != JH_OK) { delete op; return status; }
+
+    // strided-diagonal detection: coeff[i] = coeff[0] + i*stride  (e.g. one slab holding all diagonals)
+    if (op->tall && op->all_diag && nrow >= 1) {
+        op->diag_strided = true;
+        const size_t es = jh_dtype_size(dtype);
+        if (nrow >= 2) {
+            const intptr_t st = (const char *)op->blocks[1].coeff - (const char *)op->blocks[0].coeff;
+            if (st <= 0 || (size_t)st % es != 0) op->diag_strided = false;
+            for (int64_t i = 2; i < nrow && op->diag_strided; i++)
+                if ((const char *)op->blocks[(size_t)i].coeff - (const char *)op->blocks[(size_t)i - 1].coeff != st) op->diag_strided = false;
+            if (op->diag_strided) op->diag_stride_elems = (int64_t)((size_t)st / es);
+        } else {
+            op->diag_stride_elems = 0;
+        }
+    }
+
+    std::vector<jh_dev_block> host((size_t)(nrow * ncol));
+    for (size_t k = 0; k < host.size(); k++) {
+        host[k].coeff = op->blocks[k].coeff;
+        host[k].sre = op->blocks[k].scale_re;
+        host[k].sim = op->blocks[k].scale_im;
+        host[k].kind = op->blocks[k].kind;
+        host[k].adjoint = op->blocks[k].adjoint;
+    }
+    hipStream_t st = jh_ctx().stream;
+    hipError_t e = hipMalloc((void **)&op->dev_blocks, host.size() * sizeof(jh_dev_block));
+    if (e == hipSuccess) e = hipMalloc((void **)&op->dev_row_off, sizeof(int64_t) * ((size_t)nrow + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&op->dev_col_off, sizeof(int64_t) * ((size_t)ncol + 1));
+    if (e == hipSuccess) e = hipMemcpyAsync(op->dev_blocks, host.data(), host.size() * sizeof(jh_dev_block), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(op->dev_row_off, op->row_off.data(), sizeof(int64_t) * ((size_t)nrow + 1), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(op->dev_col_off, op->col_off.data(), sizeof(int64_t) * ((size_t)ncol + 1), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);   // host staging vector dies at return
+    if (e != hipSuccess) {
+        jh_blockop_destroy(op);
+        return jh_fail(JH_ERR_HIP, "jh_blockop_create: %s", hipGetErrorString(e));
+    }
+    *out = op;
+    return JH_OK;
+}
+
+int jh_blockop_destroy(jh_blockop *op)
+{
+    if (!op) return JH_OK;
+    if (jh_ctx().ready) (void)hipStreamSynchronize(jh_ctx().stream);
+    if (op->dev_blocks) (void)hipFree(op->dev_blocks);
+    if (op->dev_row_off) (void)hipFree(op->dev_row_off);
+    if (op->dev_col_off) (void)hipFree(op->dev_col_off);
+    delete op;
+    return JH_OK;
+}
+
+int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
+{
+    JH_TRY(jh_require_ready());
+    JH_TRY(check_vectors(op, d, m, "jh_blockop_mul"));
+    if (tall_fast_ok(op, d->data, m->data)) {
+        const int64_t n = op->row_len[0];
+        switch (op->dtype) {
+        case JH_F32: return launch_tall_fwd<float, 1, 4>(op, d->data, m->data, n);
+        case JH_F64: return launch_tall_fwd<double, 1, 2>(op, d->data, m->data, n);
+        case JH_C32: return launch_tall_fwd<float, 2, 4>(op, d->data, m->data, 2 * n);
+        case JH_C64: return launch_tall_fwd<double, 2, 2>(op, d->data, m->data, 2 * n);
+        }
+    }
+    switch (op->dtype) {
+    case JH_F32: return general_fwd<float, 1>(op, d->data, m->data);
+    case JH_F64: return general_fwd<double, 1>(op, d->data, m->data);
+    case JH_C32: return general_fwd<float, 2>(op, d->data, m->data);
+    case JH_C64: return general_fwd<double, 2>(op, d->data, m->data);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blockop_mul: unknown dtype %d", op->dtype);
+}
+
+int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
+{
+    JH_TRY(jh_require_ready());
+    JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_adj"));
+    if (tall_fast_ok(op, d->data, m->data)) {
+        const int64_t n = op->row_len[0];
+        switch (op->dtype) {
+        case JH_F32: return launch_tall_adj<float, 1, 4, 0>(op, m->data, d->data, n);
+        case JH_F64: return launch_tall_adj<double, 1, 2, 0>(op, m->data, d->data, n);
+        case JH_C32: return launch_tall_adj<float, 2, 4, 0>(op, m->data, d->data, 2 * n);
+        case JH_C64: return launch_tall_adj<double, 2, 2, 0>(op, m->data, d->data, 2 * n);
+        }
+    }
+    switch (op->dtype) {
+    case JH_F32: return general_adj<float, 1>(op, m->data, d->data);
+    case JH_F64: return general_adj<double, 1>(op, m->data, d->data);
+    case JH_C32: return general_adj<float, 2>(op, m->data, d->data);
+    case JH_C64: return general_adj<double, 2>(op, m->data, d->data);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blockop_mul_adj: unknown dtype %d", op->dtype);
+}
+
+int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(op && y && m, "jh_blockop_normal_mul: null argument");
+    JH_REQUIRE(y->dtype == op->dtype && m->dtype == op->dtype, "jh_blockop_normal_mul: dtype mismatch");
+    JH_REQUIRE(y->length == op->col_off[(size_t)op->ncol] && m->length == y->length,
+               "jh_blockop_normal_mul: domain vectors have %lld / %lld elements, operator domain has %lld", (long long)y->length,
+               (long long)m->length, (long long)op->col_off[(size_t)op->ncol]);
+    JH_REQUIRE(y->data != m->data, "jh_blockop_normal_mul: y must not alias m");
+    if (!tall_fast_ok(op, y->data, m->data) || op->nrow < 2)
+        return jh_fail(JH_ERR_UNSUPPORTED,
+                       "jh_blockop_normal_mul: fused A'A needs a tall (>= 2 rows) all-DIAG operator with equal, 16-byte aligned blocks; "
+                       "chain jh_blockop_mul and jh_blockop_mul_adj instead");
+    const int64_t n = op->row_len[0];
+    switch (op->dtype) {
+    case JH_F32: return launch_tall_adj<float, 1, 4, 1>(op, y->data, m->data, n);
+    case JH_F64: return launch_tall_adj<double, 1, 2, 1>(op, y->data, m->data, n);
+    case JH_C32: return launch_tall_adj<float, 2, 4, 1>(op, y->data, m->data, 2 * n);
+    case JH_C64: return launch_tall_adj<double, 2, 2, 1>(op, y->data, m->data, 2 * n);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blockop_normal_mul: unknown dtype %d", op->dtype);
+}
+
+}  // extern "C"

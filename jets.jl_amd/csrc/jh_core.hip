@@ -1,0 +1,393 @@
+// jh_core.hip -- context, device block vectors (slabs), copies, events.  gfx950 only.
+#include "jh_internal.h"
+
+static thread_local char g_err[512] = "";
+
+int jh_fail(int status, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+jh_context &jh_ctx()
+{
+    static jh_context ctx;
+    return ctx;
+}
+
+int jh_require_ready()
+{
+    if (!jh_ctx().ready) return jh_fail(JH_ERR_STATE, "libjetship: jh_init(device) has not been called");
+    return JH_OK;
+}
+
+extern "C" {
+
+int jh_abi_version(void) { return JETSHIP_ABI_VERSION; }
+const char *jh_last_error(void) { return g_err; }
+
+int jh_device_count(int *count)
+{
+    JH_REQUIRE(count, "jh_device_count: null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return jh_fail(JH_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return JH_OK;
+}
+
+int jh_init(int device)
+{
+    jh_context &c = jh_ctx();
+    if (c.ready) {
+        if (c.device == device) return JH_OK;
+        return jh_fail(JH_ERR_STATE, "jh_init: already initialised on device %d (one process drives one GPU)", c.device);
+    }
+    int n = 0;
+    JH_CHECK_HIP(hipGetDeviceCount(&n));
+    if (n <= 0) return jh_fail(JH_ERR_HIP, "jh_init: no HIP device visible; libjetship has no CPU fallback");
+    JH_REQUIRE(device >= 0 && device < n, "jh_init: device %d out of range (0..%d)", device, n - 1);
+    JH_CHECK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    JH_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_init: device %d is %s; libjetship is built for gfx950 (MI355X) only", device,
+                       prop.gcnArchName);
+    c.cu_count = prop.multiProcessorCount;
+    JH_CHECK_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    c.stream = c.own_stream;
+    JH_CHECK_HIP(hipMalloc((void **)&c.red_dev, sizeof(double) * 4 * JH_RED_SLOTS));
+    JH_CHECK_HIP(hipHostMalloc((void **)&c.red_host, sizeof(double) * 8, hipHostMallocDefault));
+    c.device = device;
+    c.ready = true;
+    return JH_OK;
+}
+
+int jh_shutdown(void)
+{
+    jh_context &c = jh_ctx();
+    if (!c.ready) return JH_OK;
+    (void)hipSetDevice(c.device);
+    (void)hipStreamSynchronize(c.stream);
+    if (c.red_dev) (void)hipFree(c.red_dev);
+    if (c.red_host) (void)hipHostFree(c.red_host);
+    if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
+    c = jh_context();
+    return JH_OK;
+}
+
+int jh_device_info(char *name, int name_cap, int64_t *total_mem, int64_t *free_mem, int *cu_count)
+{
+    JH_TRY(jh_require_ready());
+    jh_context &c = jh_ctx();
+    hipDeviceProp_t prop;
+    JH_CHECK_HIP(hipGetDeviceProperties(&prop, c.device));
+    if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    size_t fr = 0, tot = 0;
+    JH_CHECK_HIP(hipMemGetInfo(&fr, &tot));
+    if (total_mem) *total_mem = (int64_t)tot;
+    if (free_mem) *free_mem = (int64_t)fr;
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    return JH_OK;
+}
+
+int jh_get_stream(void **hip_stream)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(hip_stream, "jh_get_stream: null output");
+    *hip_stream = (void *)jh_ctx().stream;
+    return JH_OK;
+}
+
+int jh_set_stream(void *hip_stream)
+{
+    JH_TRY(jh_require_ready());
+    jh_context &c = jh_ctx();
+    c.stream = hip_stream ? (hipStream_t)hip_stream : c.own_stream;
+    return JH_OK;
+}
+
+int jh_synchronize(void)
+{
+    JH_TRY(jh_require_ready());
+    JH_CHECK_HIP(hipStreamSynchronize(jh_ctx().stream));
+    return JH_OK;
+}
+
+int jh_event_create(jh_event **ev)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(ev, "jh_event_create: null output");
+    jh_event *e = new jh_event();
+    hipError_t r = hipEventCreate(&e->ev);
+    if (r != hipSuccess) {
+        delete e;
+        return jh_fail(JH_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(r));
+    }
+    *ev = e;
+    return JH_OK;
+}
+
+int jh_event_record(jh_event *ev)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(ev, "jh_event_record: null event");
+    JH_CHECK_HIP(hipEventRecord(ev->ev, jh_ctx().stream));
+    return JH_OK;
+}
+
+int jh_event_elapsed_ms(jh_event *start, jh_event *stop, float *ms)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(start && stop && ms, "jh_event_elapsed_ms: null argument");
+    JH_CHECK_HIP(hipEventSynchronize(stop->ev));
+    JH_CHECK_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return JH_OK;
+}
+
+int jh_event_destroy(jh_event *ev)
+{
+    if (!ev) return JH_OK;
+    if (ev->ev) (void)hipEventDestroy(ev->ev);
+    delete ev;
+    return JH_OK;
+}
+
+// ------------------------------------------------------------------ block vectors -------------
+static int build_layout(jh_bvec *v, int64_t nblocks, const int64_t *block_len, int dtype, const char *who)
+{
+    JH_REQUIRE(nblocks >= 1, "%s: nblocks must be >= 1 (got %lld)", who, (long long)nblocks);
+    JH_REQUIRE(block_len, "%s: null block_len", who);
+    JH_REQUIRE(jh_dtype_size(dtype) != 0, "%s: unknown dtype %d", who, dtype);
+    v->dtype = dtype;
+    v->nblocks = nblocks;
+    v->off.resize((size_t)nblocks + 1);
+    v->off[0] = 0;
+    v->uniform = true;
+    for (int64_t i = 0; i < nblocks; i++) {
+        JH_REQUIRE(block_len[i] >= 0, "%s: block %lld has negative length", who, (long long)i);
+        // src/Jets.jl:745-746  start = stop+1 ; stop = start+length-1  (0-based: off[i+1] = off[i] + len)
+        v->off[(size_t)i + 1] = v->off[(size_t)i] + block_len[i];
+        if (block_len[i] != block_len[0]) v->uniform = false;
+    }
+    v->length = v->off[(size_t)nblocks];
+    return JH_OK;
+}
+
+int jh_bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec **out)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(out, "jh_bvec_create: null output");
+    jh_bvec *v = new jh_bvec();
+    int s = build_layout(v, nblocks, block_len, dtype, "jh_bvec_create");
+    if (s != JH_OK) { delete v; return s; }
+    size_t bytes = (size_t)v->length * jh_dtype_size(dtype);
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&v->data, bytes);
+    if (e != hipSuccess) {
+        delete v;
+        return jh_fail(JH_ERR_NOMEM, "jh_bvec_create: hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    v->owns = true;
+    e = hipMemsetAsync(v->data, 0, bytes, jh_ctx().stream);     // zeros(R), src/Jets.jl:922-924
+    if (e != hipSuccess) {
+        (void)hipFree(v->data);
+        delete v;
+        return jh_fail(JH_ERR_HIP, "jh_bvec_create: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    *out = v;
+    return JH_OK;
+}
+
+int jh_bvec_wrap(void *device_ptr, int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec **out)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(out, "jh_bvec_wrap: null output");
+    JH_REQUIRE(device_ptr, "jh_bvec_wrap: null device pointer");
+    jh_bvec *v = new jh_bvec();
+    int s = build_layout(v, nblocks, block_len, dtype, "jh_bvec_wrap");
+    if (s != JH_OK) { delete v; return s; }
+    v->data = device_ptr;
+    v->owns = false;
+    *out = v;
+    return JH_OK;
+}
+
+int jh_bvec_view(jh_bvec *parent, int64_t first_block, int64_t count, jh_bvec **out)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(parent && out, "jh_bvec_view: null argument");
+    JH_REQUIRE(first_block >= 0 && count >= 1 && first_block + count <= parent->nblocks,
+               "jh_bvec_view: blocks [%lld, %lld) out of range (nblocks = %lld)", (long long)first_block,
+               (long long)(first_block + count), (long long)parent->nblocks);
+    jh_bvec *v = new jh_bvec();
+    v->dtype = parent->dtype;
+    v->nblocks = count;
+    v->off.resize((size_t)count + 1);
+    v->uniform = true;
+    int64_t base = parent->off[(size_t)first_block];
+    for (int64_t i = 0; i <= count; i++) v->off[(size_t)i] = parent->off[(size_t)(first_block + i)] - base;
+    for (int64_t i = 0; i < count; i++)
+        if (v->len(i) != v->len(0)) v->uniform = false;
+    v->length = v->off[(size_t)count];
+    v->data = parent->ptr(base);
+    v->owns = false;
+    *out = v;
+    return JH_OK;
+}
+
+int jh_bvec_destroy(jh_bvec *v)
+{
+    if (!v) return JH_OK;
+    if (v->owns && v->data) {
+        // stream-ordered work may still reference the slab
+        if (jh_ctx().ready) (void)hipStreamSynchronize(jh_ctx().stream);
+        (void)hipFree(v->data);
+    }
+    delete v;
+    return JH_OK;
+}
+
+int jh_bvec_info(const jh_bvec *v, int64_t *nblocks, int64_t *length, int *dtype, void **device_ptr)
+{
+    JH_REQUIRE(v, "jh_bvec_info: null vector");
+    if (nblocks) *nblocks = v->nblocks;
+    if (length) *length = v->length;
+    if (dtype) *dtype = v->dtype;
+    if (device_ptr) *device_ptr = v->data;
+    return JH_OK;
+}
+
+int jh_bvec_block(const jh_bvec *v, int64_t iblock, int64_t *offset, int64_t *len, void **device_ptr)
+{
+    JH_REQUIRE(v, "jh_bvec_block: null vector");
+    JH_REQUIRE(iblock >= 0 && iblock < v->nblocks, "jh_bvec_block: block %lld out of range (nblocks = %lld)",
+               (long long)iblock, (long long)v->nblocks);
+    if (offset) *offset = v->off[(size_t)iblock];
+    if (len) *len = v->len(iblock);
+    if (device_ptr) *device_ptr = v->ptr(v->off[(size_t)iblock]);
+    return JH_OK;
+}
+
+int jh_getblock_copy(const jh_bvec *v, int64_t iblock, void *dst, int dst_on_device)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(v && dst, "jh_getblock_copy: null argument");
+    JH_REQUIRE(iblock >= 0 && iblock < v->nblocks, "jh_getblock_copy: block %lld out of range (nblocks = %lld)",
+               (long long)iblock, (long long)v->nblocks);
+    size_t bytes = (size_t)v->len(iblock) * jh_dtype_size(v->dtype);
+    if (bytes == 0) return JH_OK;
+    hipStream_t st = jh_ctx().stream;
+    JH_CHECK_HIP(hipMemcpyAsync(dst, v->ptr(v->off[(size_t)iblock]), bytes,
+                                dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    if (!dst_on_device) JH_CHECK_HIP(hipStreamSynchronize(st));
+    return JH_OK;
+}
+
+int jh_setblock_copy(jh_bvec *v, int64_t iblock, const void *src, int src_on_device)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(v && src, "jh_setblock_copy: null argument");
+    JH_REQUIRE(iblock >= 0 && iblock < v->nblocks, "jh_setblock_copy: block %lld out of range (nblocks = %lld)",
+               (long long)iblock, (long long)v->nblocks);
+    size_t bytes = (size_t)v->len(iblock) * jh_dtype_size(v->dtype);
+    if (bytes == 0) return JH_OK;
+    hipStream_t st = jh_ctx().stream;
+    JH_CHECK_HIP(hipMemcpyAsync(v->ptr(v->off[(size_t)iblock]), src, bytes,
+                                src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    if (!src_on_device) JH_CHECK_HIP(hipStreamSynchronize(st));   // caller may reuse its host buffer
+    return JH_OK;
+}
+
+int jh_setblock_fill(jh_bvec *v, int64_t iblock, double re, double im)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(v, "jh_setblock_fill: null vector");
+    JH_REQUIRE(iblock >= 0 && iblock < v->nblocks, "jh_setblock_fill: block %lld out of range (nblocks = %lld)",
+               (long long)iblock, (long long)v->nblocks);
+    return jh_launch_fill_range(v->ptr(v->off[(size_t)iblock]), v->dtype, v->len(iblock), re, im);
+}
+
+int jh_fill(jh_bvec *v, double re, double im)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(v, "jh_fill: null vector");
+    return jh_launch_fill_range(v->data, v->dtype, v->length, re, im);
+}
+
+int jh_copy(jh_bvec *dst, const jh_bvec *src)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(dst && src, "jh_copy: null argument");
+    JH_REQUIRE(dst->dtype == src->dtype, "jh_copy: dtype mismatch (%d vs %d)", dst->dtype, src->dtype);
+    JH_REQUIRE(dst->length == src->length, "jh_copy: length mismatch (%lld vs %lld)", (long long)dst->length,
+               (long long)src->length);
+    size_t bytes = (size_t)dst->length * jh_dtype_size(dst->dtype);
+    if (bytes == 0 || dst->data == src->data) return JH_OK;
+    JH_CHECK_HIP(hipMemcpyAsync(dst->data, src->data, bytes, hipMemcpyDeviceToDevice, jh_ctx().stream));
+    return JH_OK;
+}
+
+int jh_download(const jh_bvec *v, int64_t offset, int64_t count, void *host_dst)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(v && host_dst, "jh_download: null argument");
+    JH_REQUIRE(offset >= 0 && count >= 0 && offset + count <= v->length,
+               "jh_download: range [%lld, %lld) outside vector of length %lld", (long long)offset,
+               (long long)(offset + count), (long long)v->length);
+    if (count == 0) return JH_OK;
+    hipStream_t st = jh_ctx().stream;
+    JH_CHECK_HIP(hipMemcpyAsync(host_dst, v->ptr(offset), (size_t)count * jh_dtype_size(v->dtype), hipMemcpyDeviceToHost, st));
+    JH_CHECK_HIP(hipStreamSynchronize(st));
+    return JH_OK;
+}
+
+int jh_upload(jh_bvec *v, int64_t offset, int64_t count, const void *host_src)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(v && host_src, "jh_upload: null argument");
+    JH_REQUIRE(offset >= 0 && count >= 0 && offset + count <= v->length,
+               "jh_upload: range [%lld, %lld) outside vector of length %lld", (long long)offset,
+               (long long)(offset + count), (long long)v->length);
+    if (count == 0) return JH_OK;
+    hipStream_t st = jh_ctx().stream;
+    JH_CHECK_HIP(hipMemcpyAsync(v->ptr(offset), host_src, (size_t)count * jh_dtype_size(v->dtype), hipMemcpyHostToDevice, st));
+    JH_CHECK_HIP(hipStreamSynchronize(st));
+    return JH_OK;
+}
+
+int jh_tune_set(const char *name, int64_t value)
+{
+    JH_REQUIRE(name, "jh_tune_set: null name");
+    jh_context &c = jh_ctx();
+    if (!strcmp(name, "fwd_group")) { JH_REQUIRE(value >= 1 && value <= 65536, "fwd_group out of range"); c.fwd_group = value; }
+    else if (!strcmp(name, "fwd_unroll")) { JH_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, "fwd_unroll must be 1, 2, 4 or 8"); c.fwd_unroll = value; }
+    else if (!strcmp(name, "adj_unroll")) { JH_REQUIRE(value == 1 || value == 2 || value == 4, "adj_unroll must be 1, 2 or 4"); c.adj_unroll = value; }
+    else if (!strcmp(name, "adj_depth")) { JH_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, "adj_depth must be 1, 2, 4 or 8"); c.adj_depth = value; }
+    else if (!strcmp(name, "nt")) { c.nt = value ? 1 : 0; }
+    else if (!strcmp(name, "wg")) { JH_REQUIRE(value == 256 || value == 512 || value == 1024, "wg must be 256, 512 or 1024"); c.wg = value; }
+    else return jh_fail(JH_ERR_INVALID, "jh_tune_set: unknown knob '%s'", name);
+    return JH_OK;
+}
+
+int jh_tune_get(const char *name, int64_t *value)
+{
+    JH_REQUIRE(name && value, "jh_tune_get: null argument");
+    jh_context &c = jh_ctx();
+    if (!strcmp(name, "fwd_group")) *value = c.fwd_group;
+    else if (!strcmp(name, "fwd_unroll")) *value = c.fwd_unroll;
+    else if (!strcmp(name, "adj_unroll")) *value = c.adj_unroll;
+    else if (!strcmp(name, "adj_depth")) *value = c.adj_depth;
+    else if (!strcmp(name, "nt")) *value = c.nt;
+    else if (!strcmp(name, "wg")) *value = c.wg;
+    else return jh_fail(JH_ERR_INVALID, "jh_tune_get: unknown knob '%s'", name);
+    return JH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+// jh_internal.h -- shared internals of libjetship.so (gfx950 only; no CUDA/compat paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../include/jetship.h"
+
+// ---- error plumbing: status code + thread-local message, no exceptions across the ABI --------
+int jh_fail(int status, const char *fmt, ...);
+#define JH_CHECK_HIP(expr)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return jh_fail(_e == hipErrorOutOfMemory ? JH_ERR_NOMEM : JH_ERR_HIP, "%s: %s (%s:%d)", \
+                           #expr, hipGetErrorString(_e), __FILE__, __LINE__);                   \
+    } while (0)
+#define JH_REQUIRE(cond, ...)                                  \
+    do {                                                       \
+        if (!(cond)) return jh_fail(JH_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+#define JH_TRY(expr)                  \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != JH_OK) return _s;   \
+    } while (0)
+
+struct jh_context {
+    bool ready = false;
+    int device = -1;
+    int cu_count = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream everything is enqueued on
+    // reduction workspace (per-workgroup partials + a pinned host landing zone)
+    double *red_dev = nullptr;         // JH_RED_SLOTS * 4 doubles
+    double *red_host = nullptr;        // pinned, 8 doubles
+    // tuning knobs (jh_tune_set)
+    int64_t fwd_group = 16;            // blocks per workgroup in the tall forward kernel
+    int64_t fwd_unroll = 4;            // 16-byte vectors per thread per block (tall forward)
+    int64_t adj_unroll = 2;            // 16-byte vectors per thread (tall adjoint)
+    int64_t adj_depth = 4;             // blocks in flight per thread (tall adjoint)
+    int64_t nt = 1;                    // nontemporal loads/stores on the streamed operands
+    int64_t wg = 256;                  // threads per workgroup in the tall kernels
+};
+jh_context &jh_ctx();
+int jh_require_ready();
+
+constexpr int JH_RED_SLOTS = 4096;     // max workgroups in a reduction launch
+
+static inline size_t jh_dtype_size(int dtype)
+{
+    switch (dtype) {
+    case JH_F32: return 4;
+    case JH_F64: return 8;
+    case JH_C32: return 8;
+    case JH_C64: return 16;
+    default: return 0;
+    }
+}
+static inline bool jh_dtype_complex(int dtype) { return dtype == JH_C32 || dtype == JH_C64; }
+
+struct jh_bvec {
+    int dtype = JH_F32;
+    int64_t nblocks = 0;
+    int64_t length = 0;                 // total elements
+    std::vector<int64_t> off;           // nblocks+1 cumulative element offsets (0-based)
+    void *data = nullptr;               // device pointer to element 0
+    bool owns = false;                  // hipFree on destroy
+    bool uniform = false;               // all blocks the same length
+    inline int64_t len(int64_t i) const { return off[i + 1] - off[i]; }
+    inline char *ptr(int64_t elem) const { return (char *)data + (size_t)elem * jh_dtype_size(dtype); }
+};
+
+struct jh_event {
+    hipEvent_t ev = nullptr;
+};
+
+// one entry per block, device-resident, column-major nrow x ncol
+struct jh_dev_block {
+    const void *coeff;
+    double sre, sim;
+    int32_t kind;
+    int32_t adjoint;
+};
+
+struct jh_blockop {
+    int dtype = JH_F32;
+    int64_t nrow = 0, ncol = 0;
+    std::vector<jh_block_desc> blocks;   // host copy
+    std::vector<int64_t> row_len, col_len;
+    std::vector<int64_t> row_off, col_off;   // cumulative (nrow+1 / ncol+1)
+    jh_dev_block *dev_blocks = nullptr;      // nrow*ncol
+    int64_t *dev_row_off = nullptr;          // nrow+1
+    int64_t *dev_col_off = nullptr;          // ncol+1
+    // classification for the fast paths
+    bool tall = false;                       // ncol == 1
+    bool uniform_rows = false;               // all row_len equal
+    bool all_diag = false;                   // every block is an un-adjointed... DIAG (adjoint flag irrelevant up to conj)
+    bool elementwise = false;                // no DENSE block
+    bool diag_strided = false;               // coeff[i] = coeff[0] + i*stride bytes
+    int64_t diag_stride_elems = 0;
+};
+
+// vecops entry used by blockop for generic pieces
+int jh_launch_fill_range(void *ptr, int dtype, int64_t count, double re, double im);

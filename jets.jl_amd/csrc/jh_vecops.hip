@@ -1,0 +1,528 @@
+// jh_vecops.hip -- flat slab kernels behind the BlockArray API: fill / rand / broadcast (lincomb,
+// hadamard) / dot / norm / extrema.  Because a device BlockArray is ONE contiguous slab
+// (src/Jets.jl:742-748 layout), every whole-vector op is a flat, fully coalesced stream:
+// 16 B per lane, grid-stride, <= 2048 workgroups.  Reductions: fp64 per-thread accumulators ->
+// wave64 shuffle -> LDS across the 4 waves -> one partial per workgroup -> a single-workgroup
+// second kernel that folds the partials in index order (deterministic, no float atomics).
+#include "jh_internal.h"
+#include <cmath>
+
+namespace {
+
+constexpr int WG = 256;
+
+template <typename S, int NS>
+struct alignas(sizeof(S) * NS) Pack {
+    S v[NS];
+};
+
+__host__ __device__ inline uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+constexpr uint64_t GOLDEN = 0x9E3779B97F4A7C15ULL;
+
+template <typename S> __device__ inline S u01_from(uint64_t h);
+template <> __device__ inline float u01_from<float>(uint64_t h) { return (float)(h >> 40) * 0x1.0p-24f; }
+template <> __device__ inline double u01_from<double>(uint64_t h) { return (double)(h >> 11) * 0x1.0p-53; }
+
+inline int grid_for(int64_t work_items, int per_thread)
+{
+    int64_t g = (work_items + (int64_t)WG * per_thread - 1) / ((int64_t)WG * per_thread);
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (int)g;
+}
+
+// number of leading scalars to peel so that p + head is 16-byte aligned (NS scalars per pack)
+template <typename S>
+inline int64_t head_scalars(const void *p, int64_t n)
+{
+    uintptr_t a = (uintptr_t)p;
+    uintptr_t mis = a & 15u;
+    if (mis == 0) return 0;
+    int64_t h = (int64_t)((16 - mis) / sizeof(S));
+    return h < n ? h : n;
+}
+
+// ---------------------------------------------------------------- fill ------------------------
+// scalar lane k of the range gets (k & 1) ? im : re for complex, re for real (period = PER scalars)
+template <typename S, int NS, int PER>
+__global__ void k_fill(S *__restrict__ p, int64_t n, int64_t head, S re, S im)
+{
+    const int64_t nvec = (n - head) / NS;
+    const int64_t tail0 = head + nvec * NS;
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * WG;
+    Pack<S, NS> val;
+#pragma unroll
+    for (int c = 0; c < NS; c++) val.v[c] = (PER == 2 && ((head + c) & 1)) ? im : re;
+    Pack<S, NS> *pv = reinterpret_cast<Pack<S, NS> *>(p + head);
+    for (int64_t v = tid; v < nvec; v += stride) pv[v] = val;
+    if (tid < head) p[tid] = (PER == 2 && (tid & 1)) ? im : re;
+    if (tid < n - tail0) p[tail0 + tid] = (PER == 2 && ((tail0 + tid) & 1)) ? im : re;
+}
+
+template <typename S, int PER>
+int fill_scalars(S *p, int64_t n, double re, double im)
+{
+    if (n <= 0) return JH_OK;
+    constexpr int NS = 16 / sizeof(S);
+    int64_t head = head_scalars<S>(p, n);
+    int64_t nvec = (n - head) / NS;
+    hipLaunchKernelGGL((k_fill<S, NS, PER>), dim3(grid_for(nvec > 0 ? nvec : 1, 4)), dim3(WG), 0, jh_ctx().stream, p, n,
+                       head, (S)re, (S)im);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+// ---------------------------------------------------------------- uniform random --------------
+template <typename S, int NS>
+__global__ void k_uniform(S *__restrict__ p, int64_t n, uint64_t key, int64_t lane_base)
+{
+    const int64_t nvec = n / NS;
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * WG;
+    Pack<S, NS> *pv = reinterpret_cast<Pack<S, NS> *>(p);
+    for (int64_t v = tid; v < nvec; v += stride) {
+        Pack<S, NS> o;
+#pragma unroll
+        for (int c = 0; c < NS; c++) o.v[c] = u01_from<S>(mix64(key + (uint64_t)(lane_base + v * NS + c + 1) * GOLDEN));
+        pv[v] = o;
+    }
+    const int64_t tail0 = nvec * NS;
+    if (tid < n - tail0) p[tail0 + tid] = u01_from<S>(mix64(key + (uint64_t)(lane_base + tail0 + tid + 1) * GOLDEN));
+}
+
+// ---------------------------------------------------------------- lincomb ---------------------
+constexpr int MAX_TERMS = 8;
+struct LincombArgs {
+    const void *x[MAX_TERMS];
+    double cre[MAX_TERMS], cim[MAX_TERMS];
+    int k;
+};
+
+// dst = c0*x0 + c1*x1 + ... left to right, every product and sum rounded in S (no contraction:
+// the translation unit is built with -ffp-contract=off).  E = scalars per element (1 real, 2 complex).
+template <typename S, int E>
+__device__ inline void lincomb_elem(const LincombArgs &a, int64_t scalar_index, S *out)
+{
+    S accr = 0, acci = 0;
+#pragma unroll
+    for (int j = 0; j < MAX_TERMS; j++) {
+        if (j >= a.k) break;
+        const S *xj = (const S *)a.x[j] + scalar_index;
+        S tr, ti = 0;
+        if (E == 1) {
+            tr = (S)a.cre[j] * xj[0];
+        } else {
+            S cr = (S)a.cre[j], ci = (S)a.cim[j], xr = xj[0], xi = xj[1];
+            tr = cr * xr - ci * xi;     // Julia Base complex.jl `*`
+            ti = cr * xi + ci * xr;
+        }
+        if (j == 0) { accr = tr; acci = ti; }
+        else { accr = accr + tr; acci = acci + ti; }
+    }
+    out[0] = accr;
+    if (E == 2) out[1] = acci;
+}
+
+template <typename S, int E, int NS>   // NS scalars per pack, NS % E == 0
+__global__ void k_lincomb(S *__restrict__ dst, int64_t n_scalars, LincombArgs a)
+{
+    const int64_t nvec = n_scalars / NS;
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * WG;
+    for (int64_t v = tid; v < nvec; v += stride) {
+        Pack<S, NS> xin[MAX_TERMS];
+#pragma unroll
+        for (int j = 0; j < MAX_TERMS; j++)
+            if (j < a.k) xin[j] = reinterpret_cast<const Pack<S, NS> *>(a.x[j])[v];
+        Pack<S, NS> o;
+#pragma unroll
+        for (int e = 0; e < NS; e += E) {
+            S accr = 0, acci = 0;
+#pragma unroll
+            for (int j = 0; j < MAX_TERMS; j++) {
+                if (j < a.k) {
+                    S tr, ti = 0;
+                    if (E == 1) {
+                        tr = (S)a.cre[j] * xin[j].v[e];
+                    } else {
+                        S cr = (S)a.cre[j], ci = (S)a.cim[j], xr = xin[j].v[e], xi = xin[j].v[e + 1];
+                        tr = cr * xr - ci * xi;
+                        ti = cr * xi + ci * xr;
+                    }
+                    if (j == 0) { accr = tr; acci = ti; }
+                    else { accr = accr + tr; acci = acci + ti; }
+                }
+            }
+            o.v[e] = accr;
+            if (E == 2) o.v[e + 1] = acci;
+        }
+        reinterpret_cast<Pack<S, NS> *>(dst)[v] = o;
+    }
+    const int64_t tail0 = nvec * NS;
+    const int64_t ntail_elems = (n_scalars - tail0) / E;
+    if (tid < ntail_elems) lincomb_elem<S, E>(a, tail0 + tid * E, dst + tail0 + tid * E);
+}
+
+// ---------------------------------------------------------------- hadamard --------------------
+template <typename S, int E, int NS>
+__global__ void k_hadamard(S *__restrict__ dst, const S *__restrict__ x, const S *__restrict__ y, int64_t n_scalars, int conj_x)
+{
+    const int64_t nvec = n_scalars / NS;
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * WG;
+    auto one = [&](const S *xe, const S *ye, S *oe) {
+        if (E == 1) {
+            oe[0] = xe[0] * ye[0];
+        } else {
+            S xr = xe[0], xi = conj_x ? -xe[1] : xe[1], yr = ye[0], yi = ye[1];
+            oe[0] = xr * yr - xi * yi;
+            oe[1] = xr * yi + xi * yr;
+        }
+    };
+    for (int64_t v = tid; v < nvec; v += stride) {
+        Pack<S, NS> xv = reinterpret_cast<const Pack<S, NS> *>(x)[v];
+        Pack<S, NS> yv = reinterpret_cast<const Pack<S, NS> *>(y)[v];
+        Pack<S, NS> o;
+#pragma unroll
+        for (int e = 0; e < NS; e += E) one(&xv.v[e], &yv.v[e], &o.v[e]);
+        reinterpret_cast<Pack<S, NS> *>(dst)[v] = o;
+    }
+    const int64_t tail0 = nvec * NS;
+    const int64_t ntail_elems = (n_scalars - tail0) / E;
+    if (tid < ntail_elems) one(x + tail0 + tid * E, y + tail0 + tid * E, dst + tail0 + tid * E);
+}
+
+// ---------------------------------------------------------------- reductions ------------------
+enum RedOp { RED_DOT = 0, RED_SUMSQ, RED_SUMABS, RED_COUNTNZ, RED_MAXABS, RED_MINABS, RED_SUMPOW, RED_EXTREMA };
+
+template <int OP> __device__ inline void red_init(double &a0, double &a1)
+{
+    if (OP == RED_MINABS) { a0 = INFINITY; a1 = 0; }
+    else if (OP == RED_EXTREMA) { a0 = INFINITY; a1 = -INFINITY; }
+    else { a0 = 0; a1 = 0; }
+}
+template <int OP> __device__ inline void red_combine(double &a0, double &a1, double b0, double b1)
+{
+    if (OP == RED_MAXABS) { a0 = b0 > a0 ? b0 : a0; }
+    else if (OP == RED_MINABS) { a0 = b0 < a0 ? b0 : a0; }
+    else if (OP == RED_EXTREMA) { a0 = b0 < a0 ? b0 : a0; a1 = b1 > a1 ? b1 : a1; }
+    else { a0 += b0; a1 += b1; }
+}
+template <typename S, int E, int OP>
+__device__ inline void red_elem(const S *xe, const S *ye, double p, double &a0, double &a1)
+{
+    const double xr = (double)xe[0];
+    const double xi = (E == 2) ? (double)xe[1] : 0.0;
+    if (OP == RED_DOT) {
+        const double yr = (double)ye[0];
+        const double yi = (E == 2) ? (double)ye[1] : 0.0;
+        // conj(x) * y
+        a0 += xr * yr + xi * yi;
+        if (E == 2) a1 += xr * yi - xi * yr;
+    } else if (OP == RED_SUMSQ) {
+        a0 += xr * xr + xi * xi;
+    } else if (OP == RED_EXTREMA) {
+        a0 = xr < a0 ? xr : a0;
+        a1 = xr > a1 ? xr : a1;
+    } else {
+        const double ab = (E == 2) ? hypot(xr, xi) : fabs(xr);
+        if (OP == RED_SUMABS) a0 += ab;
+        else if (OP == RED_COUNTNZ) a0 += (ab != 0.0) ? 1.0 : 0.0;
+        else if (OP == RED_MAXABS) a0 = ab > a0 ? ab : a0;
+        else if (OP == RED_MINABS) a0 = ab < a0 ? ab : a0;
+        else if (OP == RED_SUMPOW) a0 += pow(ab, p);
+    }
+}
+
+template <int OP>
+__device__ inline void block_reduce_store(double a0, double a1, double *partials)
+{
+    __shared__ double s0[WG / 64], s1[WG / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double b0 = __shfl_down(a0, off, 64);
+        double b1 = __shfl_down(a1, off, 64);
+        red_combine<OP>(a0, a1, b0, b1);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { s0[wave] = a0; s1[wave] = a1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r0 = s0[0], r1 = s1[0];
+#pragma unroll
+        for (int w = 1; w < WG / 64; w++) red_combine<OP>(r0, r1, s0[w], s1[w]);
+        partials[2 * blockIdx.x + 0] = r0;
+        partials[2 * blockIdx.x + 1] = r1;
+    }
+}
+
+template <typename S, int E, int NS, int OP>
+__global__ void k_reduce(const S *__restrict__ x, const S *__restrict__ y, int64_t n_scalars, double p, double *__restrict__ partials)
+{
+    double a0, a1;
+    red_init<OP>(a0, a1);
+    const int64_t nvec = n_scalars / NS;
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * WG;
+    constexpr int UN = 4;
+    int64_t v = tid;
+    for (; v + (UN - 1) * stride < nvec; v += UN * stride) {
+        Pack<S, NS> xv[UN], yv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            xv[u] = reinterpret_cast<const Pack<S, NS> *>(x)[v + u * stride];
+            if (OP == RED_DOT) yv[u] = reinterpret_cast<const Pack<S, NS> *>(y)[v + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+#pragma unroll
+            for (int e = 0; e < NS; e += E) red_elem<S, E, OP>(&xv[u].v[e], &yv[u].v[e], p, a0, a1);
+    }
+    for (; v < nvec; v += stride) {
+        Pack<S, NS> xv = reinterpret_cast<const Pack<S, NS> *>(x)[v], yv;
+        if (OP == RED_DOT) yv = reinterpret_cast<const Pack<S, NS> *>(y)[v];
+#pragma unroll
+        for (int e = 0; e < NS; e += E) red_elem<S, E, OP>(&xv.v[e], &yv.v[e], p, a0, a1);
+    }
+    const int64_t tail0 = nvec * NS;
+    const int64_t ntail_elems = (n_scalars - tail0) / E;
+    if (tid < ntail_elems) red_elem<S, E, OP>(x + tail0 + tid * E, OP == RED_DOT ? y + tail0 + tid * E : x, p, a0, a1);
+    block_reduce_store<OP>(a0, a1, partials);
+}
+
+template <int OP>
+__global__ void k_reduce_final(const double *__restrict__ partials, int nparts, double *__restrict__ out)
+{
+    // one workgroup; thread t folds partials t, t+WG, ... in index order, then the fixed tree
+    double a0, a1;
+    red_init<OP>(a0, a1);
+    for (int i = threadIdx.x; i < nparts; i += WG) red_combine<OP>(a0, a1, partials[2 * i], partials[2 * i + 1]);
+    __shared__ double s0[WG], s1[WG];
+    s0[threadIdx.x] = a0;
+    s1[threadIdx.x] = a1;
+    __syncthreads();
+    for (int off = WG / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            double r0 = s0[threadIdx.x], r1 = s1[threadIdx.x];
+            red_combine<OP>(r0, r1, s0[threadIdx.x + off], s1[threadIdx.x + off]);
+            s0[threadIdx.x] = r0;
+            s1[threadIdx.x] = r1;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = s0[0]; out[1] = s1[0]; }
+}
+
+template <typename S, int E, int OP>
+int reduce_launch(const void *x, const void *y, int64_t n_elems, double p, double *r0, double *r1)
+{
+    jh_context &c = jh_ctx();
+    const int64_t n_scalars = n_elems * E;
+    constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
+    const bool aligned = (((uintptr_t)x | (uintptr_t)(y ? y : x)) & 15u) == 0;
+    double *partials = c.red_dev + 8;   // [0..7] hold final results
+    int grid;
+    if (aligned) {
+        grid = grid_for(n_scalars / NSV + 1, 4);
+        hipLaunchKernelGGL((k_reduce<S, E, NSV, OP>), dim3(grid), dim3(WG), 0, c.stream, (const S *)x, (const S *)y,
+                           n_scalars, p, partials);
+    } else {
+        grid = grid_for(n_elems + 1, 4);
+        hipLaunchKernelGGL((k_reduce<S, E, E, OP>), dim3(grid), dim3(WG), 0, c.stream, (const S *)x, (const S *)y, n_scalars,
+                           p, partials);
+    }
+    JH_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL((k_reduce_final<OP>), dim3(1), dim3(WG), 0, c.stream, partials, grid, c.red_dev);
+    JH_CHECK_HIP(hipGetLastError());
+    JH_CHECK_HIP(hipMemcpyAsync(c.red_host, c.red_dev, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+    *r0 = c.red_host[0];
+    *r1 = c.red_host[1];
+    return JH_OK;
+}
+
+template <int OP>
+int reduce_dispatch(int dtype, const void *x, const void *y, int64_t n, double p, double *r0, double *r1)
+{
+    switch (dtype) {
+    case JH_F32: return reduce_launch<float, 1, OP>(x, y, n, p, r0, r1);
+    case JH_F64: return reduce_launch<double, 1, OP>(x, y, n, p, r0, r1);
+    case JH_C32: return reduce_launch<float, 2, OP>(x, y, n, p, r0, r1);
+    case JH_C64: return reduce_launch<double, 2, OP>(x, y, n, p, r0, r1);
+    }
+    return jh_fail(JH_ERR_INVALID, "unknown dtype %d", dtype);
+}
+
+template <typename S, int E>
+int lincomb_launch(void *dst, int64_t n_elems, const LincombArgs &a)
+{
+    const int64_t n_scalars = n_elems * E;
+    if (n_scalars == 0) return JH_OK;
+    constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
+    uintptr_t bits = (uintptr_t)dst;
+    for (int j = 0; j < a.k; j++) bits |= (uintptr_t)a.x[j];
+    if ((bits & 15u) == 0)
+        hipLaunchKernelGGL((k_lincomb<S, E, NSV>), dim3(grid_for(n_scalars / NSV + 1, 2)), dim3(WG), 0, jh_ctx().stream, (S *)dst,
+                           n_scalars, a);
+    else
+        hipLaunchKernelGGL((k_lincomb<S, E, E>), dim3(grid_for(n_elems + 1, 2)), dim3(WG), 0, jh_ctx().stream, (S *)dst, n_scalars, a);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+template <typename S, int E>
+int hadamard_launch(void *dst, const void *x, const void *y, int64_t n_elems, int conj_x)
+{
+    const int64_t n_scalars = n_elems * E;
+    if (n_scalars == 0) return JH_OK;
+    constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
+    uintptr_t bits = (uintptr_t)dst | (uintptr_t)x | (uintptr_t)y;
+    if ((bits & 15u) == 0)
+        hipLaunchKernelGGL((k_hadamard<S, E, NSV>), dim3(grid_for(n_scalars / NSV + 1, 2)), dim3(WG), 0, jh_ctx().stream, (S *)dst,
+                           (const S *)x, (const S *)y, n_scalars, conj_x);
+    else
+        hipLaunchKernelGGL((k_hadamard<S, E, E>), dim3(grid_for(n_elems + 1, 2)), dim3(WG), 0, jh_ctx().stream, (S *)dst,
+                           (const S *)x, (const S *)y, n_scalars, conj_x);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+}  // namespace
+
+int jh_launch_fill_range(void *ptr, int dtype, int64_t count, double re, double im)
+{
+    switch (dtype) {
+    case JH_F32: return fill_scalars<float, 1>((float *)ptr, count, re, 0);
+    case JH_F64: return fill_scalars<double, 1>((double *)ptr, count, re, 0);
+    case JH_C32: return fill_scalars<float, 2>((float *)ptr, 2 * count, re, im);
+    case JH_C64: return fill_scalars<double, 2>((double *)ptr, 2 * count, re, im);
+    }
+    return jh_fail(JH_ERR_INVALID, "fill: unknown dtype %d", dtype);
+}
+
+extern "C" {
+
+int jh_fill_uniform(jh_bvec *v, uint64_t seed, uint64_t stream, int64_t index_base)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(v, "jh_fill_uniform: null vector");
+    JH_REQUIRE(index_base >= 0, "jh_fill_uniform: negative index_base");
+    JH_REQUIRE((((uintptr_t)v->data) & 15u) == 0, "jh_fill_uniform: slab must be 16-byte aligned");
+    if (v->length == 0) return JH_OK;
+    const uint64_t key = mix64(seed * GOLDEN + stream);
+    const int lanes = jh_dtype_complex(v->dtype) ? 2 : 1;
+    const int64_t n = v->length * lanes, base = index_base * lanes;
+    hipStream_t st = jh_ctx().stream;
+    if (v->dtype == JH_F32 || v->dtype == JH_C32)
+        hipLaunchKernelGGL((k_uniform<float, 4>), dim3(grid_for(n / 4 + 1, 4)), dim3(WG), 0, st, (float *)v->data, n, key, base);
+    else
+        hipLaunchKernelGGL((k_uniform<double, 2>), dim3(grid_for(n / 2 + 1, 4)), dim3(WG), 0, st, (double *)v->data, n, key, base);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+int jh_lincomb(jh_bvec *dst, int k, const double *coef, const jh_bvec *const *x)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(dst && coef && x, "jh_lincomb: null argument");
+    JH_REQUIRE(k >= 1 && k <= MAX_TERMS, "jh_lincomb: k = %d outside 1..%d", k, MAX_TERMS);
+    LincombArgs a;
+    a.k = k;
+    for (int j = 0; j < k; j++) {
+        JH_REQUIRE(x[j], "jh_lincomb: null operand %d", j);
+        JH_REQUIRE(x[j]->dtype == dst->dtype, "jh_lincomb: dtype mismatch on operand %d", j);
+        JH_REQUIRE(x[j]->length == dst->length, "jh_lincomb: length mismatch on operand %d (%lld vs %lld)", j,
+                   (long long)x[j]->length, (long long)dst->length);
+        JH_REQUIRE(jh_dtype_complex(dst->dtype) || coef[2 * j + 1] == 0.0,
+                   "jh_lincomb: complex coefficient %d on a real vector", j);
+        a.x[j] = x[j]->data;
+        a.cre[j] = coef[2 * j];
+        a.cim[j] = coef[2 * j + 1];
+    }
+    switch (dst->dtype) {
+    case JH_F32: return lincomb_launch<float, 1>(dst->data, dst->length, a);
+    case JH_F64: return lincomb_launch<double, 1>(dst->data, dst->length, a);
+    case JH_C32: return lincomb_launch<float, 2>(dst->data, dst->length, a);
+    case JH_C64: return lincomb_launch<double, 2>(dst->data, dst->length, a);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_lincomb: unknown dtype %d", dst->dtype);
+}
+
+int jh_hadamard(jh_bvec *dst, const jh_bvec *x, const jh_bvec *y, int conj_x)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(dst && x && y, "jh_hadamard: null argument");
+    JH_REQUIRE(dst->dtype == x->dtype && dst->dtype == y->dtype, "jh_hadamard: dtype mismatch");
+    JH_REQUIRE(dst->length == x->length && dst->length == y->length, "jh_hadamard: length mismatch (%lld, %lld, %lld)",
+               (long long)dst->length, (long long)x->length, (long long)y->length);
+    switch (dst->dtype) {
+    case JH_F32: return hadamard_launch<float, 1>(dst->data, x->data, y->data, dst->length, conj_x);
+    case JH_F64: return hadamard_launch<double, 1>(dst->data, x->data, y->data, dst->length, conj_x);
+    case JH_C32: return hadamard_launch<float, 2>(dst->data, x->data, y->data, dst->length, conj_x);
+    case JH_C64: return hadamard_launch<double, 2>(dst->data, x->data, y->data, dst->length, conj_x);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_hadamard: unknown dtype %d", dst->dtype);
+}
+
+int jh_dot(const jh_bvec *x, const jh_bvec *y, double *re, double *im)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(x && y && re, "jh_dot: null argument");
+    JH_REQUIRE(x->dtype == y->dtype, "jh_dot: dtype mismatch (%d vs %d)", x->dtype, y->dtype);
+    JH_REQUIRE(x->length == y->length, "jh_dot: length mismatch (%lld vs %lld)", (long long)x->length, (long long)y->length);
+    double r0 = 0, r1 = 0;
+    if (x->length > 0) JH_TRY((reduce_dispatch<RED_DOT>(x->dtype, x->data, y->data, x->length, 0.0, &r0, &r1)));
+    *re = r0;
+    if (im) *im = r1;
+    return JH_OK;
+}
+
+int jh_norm(const jh_bvec *x, double p, double *out)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(x && out, "jh_norm: null argument");
+    JH_REQUIRE(!std::isnan(p), "jh_norm: p is NaN");
+    double r0 = 0, r1 = 0;
+    if (x->length == 0) { *out = 0.0; return JH_OK; }
+    if (p == INFINITY) {            // src/Jets.jl:835-836
+        JH_TRY((reduce_dispatch<RED_MAXABS>(x->dtype, x->data, nullptr, x->length, p, &r0, &r1)));
+        *out = r0;
+    } else if (p == -INFINITY) {    // :837-838
+        JH_TRY((reduce_dispatch<RED_MINABS>(x->dtype, x->data, nullptr, x->length, p, &r0, &r1)));
+        *out = r0;
+    } else if (p == 1.0) {          // :839-840
+        JH_TRY((reduce_dispatch<RED_SUMABS>(x->dtype, x->data, nullptr, x->length, p, &r0, &r1)));
+        *out = r0;
+    } else if (p == 0.0) {          // :841-842
+        JH_TRY((reduce_dispatch<RED_COUNTNZ>(x->dtype, x->data, nullptr, x->length, p, &r0, &r1)));
+        *out = r0;
+    } else if (p == 2.0) {          // :843-846 with p = 2: (sum_i norm(x_i)^2)^(1/2)
+        JH_TRY((reduce_dispatch<RED_SUMSQ>(x->dtype, x->data, nullptr, x->length, p, &r0, &r1)));
+        *out = sqrt(r0);
+    } else {                        // :843-846
+        JH_TRY((reduce_dispatch<RED_SUMPOW>(x->dtype, x->data, nullptr, x->length, p, &r0, &r1)));
+        *out = pow(r0, 1.0 / p);
+    }
+    return JH_OK;
+}
+
+int jh_extrema(const jh_bvec *x, double *mn, double *mx)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(x && mn && mx, "jh_extrema: null argument");
+    JH_REQUIRE(!jh_dtype_complex(x->dtype), "jh_extrema: complex values are not ordered");
+    JH_REQUIRE(x->length > 0, "jh_extrema: empty vector");
+    double r0 = 0, r1 = 0;
+    JH_TRY((reduce_dispatch<RED_EXTREMA>(x->dtype, x->data, nullptr, x->length, 0.0, &r0, &r1)));
+    *mn = r0;
+    *mx = r1;
+    return JH_OK;
+}
+
+}  // extern "C"

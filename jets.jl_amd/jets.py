@@ -1,0 +1,543 @@
+"""Jet / Jop core, composition, sums, scalar multiples, vectorised operators and test utilities.
+
+Host-side mirror of /root/reference/src/Jets.jl:131-403 (Jet, JopNl/JopLn/JopAdjoint, accessors,
+mul!), 518-623 (JetComposite), 625-731 (JetSum), 1126-1164 (JetVec, scalar * operator) and
+1187-1226 (dot_product_test), for operators whose vectors live in HBM.  Only dispatch lives here:
+every array operation is a HIP kernel behind the C ABI.
+
+Python spelling of the Julia API (INTEGRATION.md has the full table):
+    mul!(d, A, m)  -> mul_(d, A, m)        A*m     -> A * m            A'      -> A.H  /  adjoint(A)
+    A2 o A1        -> A2 @ A1 / compose    A1 + A2 -> A1 + A2          a*A     -> a * A
+    f!, df!, df'!  -> f=, df=, df_adj=     upstate! -> upstate=        m_o kw  -> mo=
+Closures have the reference's signatures: f(d, m, **state), df(d, m, mo=..., **state),
+df_adj(m, d, mo=..., **state); each mutates and RETURNS its first argument (src/Jets.jl:190-192).
+Operator kinds are recognised by the identity of the `f` function, the way the reference dispatches
+on typeof(f!) (src/Jets.jl:543, 949, 1085, 1097).
+"""
+from __future__ import annotations
+
+import builtins
+import copy as _copy
+from typing import Any, Callable, Sequence
+
+import numpy as np
+
+from . import arrays as _arr
+from .arrays import DeviceArray, BlockArray, zeros, ones, lincomb_, hadamard_, copyto_, fill_, reshape, dot
+from .spaces import JetAbstractSpace, JetSpace, JetBSpace
+
+__all__ = [
+    "Jet", "Jop", "JopNl", "JopLn", "JopAdjoint", "jet_missing", "f_", "df_", "df_adj_", "domain", "range_", "eltype",
+    "state", "state_", "perfstat", "point", "point_", "close", "jet", "shape", "size", "jacobian_", "jacobian", "adjoint",
+    "mul_", "mul", "JetComposite", "JetComposite_f", "JetComposite_df", "JetComposite_df_adj", "compose", "JetSum",
+    "JetSum_f", "JetSum_df", "JetSum_df_adj", "JetVec", "JopVec", "JetVec_f", "JetVec_df", "JetVec_df_adj", "vec_op",
+    "scale_op", "constdiag_df", "constdiag_df_adj", "dot_product_test", "copy_op", "PLUS", "MINUS",
+]
+
+
+def jet_missing(*_a, **_k):  # src/Jets.jl:131
+    raise NotImplementedError("not implemented")
+
+
+def _default_upstate(m, s):  # src/Jets.jl:176
+    return None
+
+
+class Jet:
+    """Jet(; dom, rng, f!, df!, df'!, upstate!, s)  (src/Jets.jl:133-188)."""
+
+    def __init__(self, *, dom: JetAbstractSpace, rng: JetAbstractSpace, f: Callable = jet_missing, df: Callable = jet_missing,
+                 df_adj: Callable = jet_missing, upstate: Callable = _default_upstate, s: dict | None = None, mo: Any = None):
+        if f is jet_missing and df is jet_missing:  # :178-180
+            raise ValueError("must set at-least one of f! and df!")
+        if f is jet_missing:  # :181-183
+            f = df
+        if df_adj is jet_missing:  # :184-186
+            df_adj = df
+        self.dom, self.rng = dom, rng
+        self.f, self.df, self.df_adj, self.upstate = f, df, df_adj, upstate
+        self.mo = mo  # the reference holds a zero-size array here until point! is called (:187)
+        self.s = dict(s or {})
+
+
+def f_(d, jet_: Jet, m, **kw):  # :190
+    return jet_.f(d, m, **kw)
+
+
+def df_(d, jet_: Jet, m, **kw):  # :191
+    return jet_.df(d, m, **kw)
+
+
+def df_adj_(m, jet_: Jet, d, **kw):  # :192
+    return jet_.df_adj(m, d, **kw)
+
+
+class Jop:
+    """abstract Jop (src/Jets.jl:194)."""
+
+    # A * m  (:399) ;  a * A (:1161-1164)
+    def __mul__(self, m):
+        if isinstance(m, (DeviceArray, BlockArray)):
+            return mul(self, m)
+        return NotImplemented
+
+    def __rmul__(self, a):
+        if isinstance(a, (int, float, complex, np.number)):
+            return scale_op(a, self)
+        return NotImplemented
+
+    def __matmul__(self, other):  # A2 o A1
+        if isinstance(other, Jop):
+            return compose(self, other)
+        return NotImplemented
+
+    def __add__(self, other):
+        return _sum(self, other, PLUS)
+
+    def __sub__(self, other):
+        return _sum(self, other, MINUS)
+
+    @property
+    def H(self):
+        return adjoint(self)
+
+    T = H
+
+
+class JopNl(Jop):  # :196-207
+    def __init__(self, jet_: Jet | None = None, **kw):
+        self.jet = jet_ if jet_ is not None else Jet(**kw)
+
+    def __repr__(self):  # :403
+        return f"Jet nonlinear operator, {domain(self).size()} -> {range_(self).size()}"
+
+
+class JopLn(Jop):  # :209-224
+    def __new__(cls, jet_=None, mo=None, **kw):
+        if isinstance(jet_, JopLn):  # JopLn(A::JopLn) = A  (:223)
+            return jet_
+        if isinstance(jet_, JopAdjoint):  # JopLn(A::JopAdjoint) = A  (:235)
+            return jet_
+        return super().__new__(cls)
+
+    def __init__(self, jet_=None, mo=None, **kw):
+        if isinstance(jet_, (JopLn, JopAdjoint)):
+            return
+        if isinstance(jet_, JopNl):  # JopLn(F::JopNl) = JopLn(jet(F))  (:224)
+            jet_ = jet_.jet
+        if jet_ is None:
+            jet_ = Jet(**kw)  # :221
+        if mo is not None:  # JopLn(jet, mo) = JopLn(point!(jet, mo))  (:212)
+            point_(jet_, mo)
+        self.jet = jet_
+
+    def __repr__(self):  # :401
+        return f"Jet linear operator, {domain(self).size()} -> {range_(self).size()}"
+
+
+class JopAdjoint(Jop):  # :226-228
+    def __init__(self, op: Jop):
+        self.op = op
+
+    def __repr__(self):  # :402
+        return f"Jet adjoint operator, {domain(self).size()} -> {range_(self).size()}"
+
+
+def copy_op(A, copymo: bool = True):
+    """copy(jet/op) (src/Jets.jl:230-233): same closures, deep-copied state, optionally copied mo."""
+    if isinstance(A, Jet):
+        mo = A.mo
+        if copymo and mo is not None:
+            mo = copyto_(_arr.similar(mo), mo)
+        j = Jet(dom=A.dom, rng=A.rng, f=A.f, df=A.df, df_adj=A.df_adj, upstate=A.upstate, mo=mo)
+        j.s = {k: (copy_op(v, copymo) if isinstance(v, (Jet, Jop)) else _deepcopy_state(v, copymo)) for k, v in A.s.items()}
+        return j
+    if isinstance(A, JopLn):
+        return JopLn(copy_op(A.jet, copymo))
+    if isinstance(A, JopAdjoint):
+        return JopAdjoint(copy_op(A.op, copymo))
+    if isinstance(A, JopNl):
+        return JopNl(copy_op(A.jet, copymo))
+    raise TypeError(type(A))
+
+
+def _deepcopy_state(v, copymo):
+    if isinstance(v, (DeviceArray, BlockArray)):
+        return copyto_(_arr.similar(v), v)
+    if isinstance(v, (list, tuple)):
+        return type(v)(_deepcopy_state(x, copymo) if not isinstance(x, (Jet, Jop)) else copy_op(x, copymo) for x in v)
+    if isinstance(v, np.ndarray) and v.dtype == object:
+        out = np.empty_like(v)
+        for idx in np.ndindex(v.shape):
+            x = v[idx]
+            out[idx] = copy_op(x, copymo) if isinstance(x, (Jet, Jop)) else _deepcopy_state(x, copymo)
+        return out
+    return _copy.deepcopy(v)
+
+
+# ------------------------------------------------------------------------------ accessors ----------
+def jet(A) -> Jet:  # :308-309
+    if isinstance(A, JopAdjoint):
+        return jet(A.op)
+    return A.jet
+
+
+def domain(A):  # :242, 319, 322
+    if isinstance(A, Jet):
+        return A.dom
+    if isinstance(A, JopAdjoint):
+        return range_(A.op)
+    return A.jet.dom
+
+
+def range_(A):  # :249, 320, 323
+    if isinstance(A, Jet):
+        return A.rng
+    if isinstance(A, JopAdjoint):
+        return domain(A.op)
+    return A.jet.rng
+
+
+def eltype(A):  # :256, 310
+    if isinstance(A, (JetAbstractSpace, DeviceArray, BlockArray)):
+        return A.eltype()
+    j = A if isinstance(A, Jet) else jet(A)
+    return np.promote_types(j.dom.eltype(), j.rng.eltype())
+
+
+def state(A, key=None):  # :264-265, 313-314, 607-623
+    j = A if isinstance(A, Jet) else jet(A)
+    if key is None:
+        return j.s
+    if j.f is JetComposite_f and key not in j.s:  # :607-623
+        found = [op for op in j.s["ops"] if key in state(op)]
+        if not found:
+            raise KeyError(f"key {key} does not exist in the state of the composite operator")
+        if len(found) > 1:
+            raise KeyError(f"ambiguous: key {key} exists in more than one operator in the composition")
+        return state(found[0], key)
+    return j.s[key]
+
+
+def state_(A, s: dict):  # :272, 315  merge
+    j = A if isinstance(A, Jet) else jet(A)
+    j.s = {**j.s, **s}
+    return A
+
+
+_perfstat_registry: dict = {}
+
+
+def perfstat(A):  # :281, 316, 597-605, 723-731
+    j = A if isinstance(A, Jet) else jet(A)
+    if j.f is JetComposite_f or j.f is JetSum_f:
+        s = None
+        for op in j.s["ops"]:
+            s = perfstat(op)
+            if s is not None:
+                break
+        return s
+    fn = _perfstat_registry.get(j.f)
+    return fn(j) if fn else None
+
+
+def register_perfstat(f: Callable, fn: Callable) -> None:
+    """Operator authors override perfstat for their jet kind (test/runtests.jl:9)."""
+    _perfstat_registry[f] = fn
+
+
+def point(A):  # :288, 311-312
+    j = A if isinstance(A, Jet) else jet(A)
+    return j.mo
+
+
+_close_registry: dict = {}
+
+
+def register_close(f: Callable, fn: Callable) -> None:
+    """Operator authors release resources on close (test/runtests.jl:18)."""
+    _close_registry[f] = fn
+
+
+def close(A):  # :290, 317, 591-595, 717-721, 1120-1124
+    j = A if isinstance(A, Jet) else jet(A)
+    from . import blockop as _blk  # late import: blockop imports this module
+
+    if j.f is JetComposite_f or j.f is JetSum_f:
+        for op in j.s["ops"]:
+            close(op)
+        return None
+    if j.f is _blk.JetBlock_f:
+        _blk.close_block(j)
+        return None
+    if j.f is JetVec_f:
+        return close(j.s["op"])
+    fn = _close_registry.get(j.f)
+    if fn:
+        return fn(j)
+    return False
+
+
+def point_(A, mo):  # :297-301, 578-589, 710-715, 1059-1066
+    j = A if isinstance(A, Jet) else jet(A)
+    from . import blockop as _blk
+
+    if j.f is JetComposite_f:  # :578-589
+        j.mo = mo
+        ops = j.s["ops"]
+        _m = copyto_(_arr.similar(mo), mo)
+        for i in builtins.range(len(ops) - 1, -1, -1):
+            point_(jet(ops[i]), _m)
+            if i > 0:
+                _m = mul_(zeros(range_(ops[i])), ops[i], _m)
+        return A
+    if j.f is JetSum_f:  # :710-715
+        for op in j.s["ops"]:
+            point_(jet(op), mo)
+        return A
+    if j.f is _blk.JetBlock_f:  # :1059-1066
+        _blk.point_block(j, mo)
+        return A
+    j.mo = mo
+    j.upstate(mo, j.s)
+    return A
+
+
+def shape(A, i=None):  # :328-345
+    if i is None:
+        return (range_(A).size(), domain(A).size())
+    return range_(A).size() if i == 1 else domain(A).size()
+
+
+def size(A, i=None):  # :354-355  (i = 1: range, i = 2: domain, as in the reference)
+    if i is None:
+        return (range_(A).length(), domain(A).length())
+    return range_(A).length() if i == 1 else domain(A).length()
+
+
+def jacobian_(F, mo):  # :364-366
+    if isinstance(F, Jet):
+        return JopLn(F, mo)
+    if isinstance(F, JopNl):
+        return jacobian_(F.jet, mo)
+    return F
+
+
+def jacobian(F, mo):  # :374
+    return jacobian_(copy_op(F, False), copyto_(_arr.similar(mo), mo))
+
+
+def adjoint(A):  # :382-383
+    if isinstance(A, JopAdjoint):
+        return A.op
+    if isinstance(A, JopLn):
+        return JopAdjoint(A)
+    raise TypeError("adjoint is defined for linear operators (JopLn / JopAdjoint)")
+
+
+# ------------------------------------------------------------------------------ mul! ---------------
+def mul_(d, A: Jop, m):
+    """mul!(d, A, m) (src/Jets.jl:390-392)."""
+    if isinstance(A, JopNl):
+        return f_(d, A.jet, m, **A.jet.s)
+    if isinstance(A, JopLn):
+        return df_(d, A.jet, m, mo=A.jet.mo, **A.jet.s)
+    if isinstance(A, JopAdjoint):
+        if not isinstance(A.op, JopLn):
+            raise TypeError("mul! with an adjoint needs a linear operator")
+        j = A.op.jet
+        return df_adj_(d, j, m, mo=j.mo, **j.s)
+    raise TypeError(type(A))
+
+
+def mul(A: Jop, m):
+    """A*m = mul!(zeros(range(A)), A, m) (src/Jets.jl:399)."""
+    return mul_(zeros(range_(A)), A, m)
+
+
+# ------------------------------------------------------------------------------ composition --------
+def JetComposite(ops: Sequence[Jop]) -> Jet:  # :522
+    ops = tuple(ops)
+    return Jet(f=JetComposite_f, df=JetComposite_df, df_adj=JetComposite_df_adj, dom=domain(ops[-1]), rng=range_(ops[0]),
+               s={"ops": ops})
+
+
+def JetComposite_f(d, m, *, ops, **kw):  # :524-528  right-to-left chain through zeros() temporaries
+    x = m
+    for op in reversed(ops):
+        x = mul_(zeros(range_(op)), op, x)
+    return copyto_(d, x)
+
+
+def JetComposite_df(d, m, *, ops, **kw):  # :530-534
+    from . import blockop as _blk
+
+    fused = _blk.try_fused_normal(d, m, ops)
+    if fused is not None:
+        return fused
+    x = m
+    for op in reversed(ops):
+        L = JopLn(op)
+        x = mul_(zeros(range_(L)), L, x)
+    return copyto_(d, x)
+
+
+def JetComposite_df_adj(m, d, *, ops, **kw):  # :536-540
+    from . import blockop as _blk
+
+    fused = _blk.try_fused_normal(m, d, tuple(adjoint(JopLn(op)) for op in reversed(ops)))
+    if fused is not None:
+        return fused
+    x = d
+    for op in ops:
+        L = adjoint(JopLn(op))
+        x = mul_(zeros(domain(JopLn(op))), L, x)
+    return copyto_(m, x)
+
+
+def jops_comp(op: Jop) -> tuple:  # :542-550
+    if isinstance(op, (JopLn, JopNl)) and op.jet.f is JetComposite_f:
+        return tuple(op.jet.s["ops"])
+    if isinstance(op, JopAdjoint) and isinstance(op.op, JopLn) and op.op.jet.f is JetComposite_f:
+        ops = op.op.jet.s["ops"]
+        return tuple(JopAdjoint(o) if not isinstance(o, JopAdjoint) else o.op for o in reversed(ops))
+    return (op,)
+
+
+def compose(A2: Jop, A1: Jop) -> Jop:  # :569-570
+    ops = jops_comp(A2) + jops_comp(A1)
+    if isinstance(A2, (JopLn, JopAdjoint)) and isinstance(A1, (JopLn, JopAdjoint)):
+        return JopLn(JetComposite(ops))
+    return JopNl(JetComposite(ops))
+
+
+# ------------------------------------------------------------------------------ sums ---------------
+PLUS, MINUS = "+", "-"
+
+
+def JetSum(ops: Sequence[Jop], sgns: Sequence[str]) -> Jet:  # :628
+    ops = tuple(ops)
+    return Jet(f=JetSum_f, df=JetSum_df, df_adj=JetSum_df_adj, dom=domain(ops[0]), rng=range_(ops[0]),
+               s={"ops": ops, "sgns": tuple(sgns)})
+
+
+def _accumulate(sgn: str, acc, term):
+    """broadcast!(sgn, acc, acc, term) (src/Jets.jl:634)."""
+    return lincomb_(acc, [1.0, 1.0 if sgn == PLUS else -1.0], [acc, term])
+
+
+def JetSum_f(d, m, *, ops, sgns, **kw):  # :630-637
+    fill_(d, 0)
+    _d = zeros(range_(ops[0]))
+    for op, sg in zip(ops, sgns):
+        _accumulate(sg, d, mul_(_d, op, m))
+    return d
+
+
+def JetSum_df(d, m, *, ops, sgns, **kw):  # :639-646
+    fill_(d, 0)
+    _d = zeros(range_(ops[0]))
+    for op, sg in zip(ops, sgns):
+        _accumulate(sg, d, mul_(_d, JopLn(op), m))
+    return d
+
+
+def JetSum_df_adj(m, d, *, ops, sgns, **kw):  # :648-655
+    fill_(m, 0)
+    _m = zeros(domain(ops[0]))
+    for op, sg in zip(ops, sgns):
+        _accumulate(sg, m, mul_(_m, adjoint(JopLn(op)), d))
+    return m
+
+
+def jops_sum(op: Jop) -> tuple:  # :657-665
+    if isinstance(op, (JopLn, JopNl)) and op.jet.f is JetSum_f:
+        return tuple(op.jet.s["ops"])
+    if isinstance(op, JopAdjoint) and isinstance(op.op, JopLn) and op.op.jet.f is JetSum_f:
+        return tuple(JopAdjoint(o) for o in op.op.jet.s["ops"])
+    return (op,)
+
+
+def flipsgn(sgn: str, sgnnew: str) -> str:  # :667-671
+    if sgnnew == PLUS:
+        return sgn
+    return PLUS if sgn == MINUS else MINUS
+
+
+def sgns(op: Jop, r: str) -> tuple:  # :673-676
+    inner = op.op if isinstance(op, JopAdjoint) else op
+    if isinstance(inner, (JopLn, JopNl)) and inner.jet.f is JetSum_f:
+        return tuple(flipsgn(s, r) for s in inner.jet.s["sgns"])
+    return (r,)
+
+
+def _sum(A2, A1, sign: str):  # :689-690, 705-706
+    if not isinstance(A1, Jop) or not isinstance(A2, Jop):
+        return NotImplemented
+    ops = jops_sum(A2) + jops_sum(A1)
+    sg = sgns(A2, PLUS) + sgns(A1, sign)
+    if isinstance(A2, (JopLn, JopAdjoint)) and isinstance(A1, (JopLn, JopAdjoint)):
+        return JopLn(JetSum(ops, sg))
+    return JopNl(JetSum(ops, sg))
+
+
+# ------------------------------------------------------------------------------ scalar * operator --
+def constdiag_df(d, m, *, a, **kw):  # :1159   d .= a * m
+    return lincomb_(d, [a], [m])
+
+
+def constdiag_df_adj(m, d, *, a, **kw):  # :1160   m .= conj(a) * d
+    return lincomb_(m, [np.conj(a)], [d])
+
+
+def scale_op(a, A: Jop) -> Jop:  # :1161-1164  (built on domain(A) for dom AND rng, as in the reference)
+    _a = JopLn(dom=domain(A), rng=domain(A), df=constdiag_df, df_adj=constdiag_df_adj, s={"a": a})
+    return compose(_a, A)
+
+
+# ------------------------------------------------------------------------------ vectorised op ------
+def JetVec(op: Jop):  # :1129-1130
+    if range_(op).ndims() == 1 and domain(op).ndims() == 1:
+        return op
+    return Jet(f=JetVec_f, df=JetVec_df, df_adj=JetVec_df_adj, dom=domain(op).vec(), rng=range_(op).vec(), s={"op": op})
+
+
+def JopVec(op: Jop):  # :1131-1132
+    j = JetVec(op)
+    if isinstance(j, Jop):
+        return j
+    return JopLn(j) if isinstance(op, (JopLn, JopAdjoint)) else JopNl(j)
+
+
+vec_op = JopVec  # vec(A)  (:1154)
+
+
+def JetVec_f(d, m, *, op, **kw):  # :1134
+    mul_(reshape(d, range_(op)), op, reshape(m, domain(op)))
+    return d
+
+
+def JetVec_df(d, m, *, op, **kw):  # :1135
+    mul_(reshape(d, range_(op)), JopLn(op), reshape(m, domain(op)))
+    return d
+
+
+def JetVec_df_adj(m, d, *, op, **kw):  # :1136
+    mul_(reshape(m, domain(op)), adjoint(JopLn(op)), reshape(d, range_(op)))
+    return m
+
+
+# ------------------------------------------------------------------------------ utilities ----------
+def dot_product_test(op: JopLn, m, d, mmask=None, dmask=None):
+    """lhs, rhs = dot_product_test(A, m, d; mmask, dmask)  (src/Jets.jl:1211-1226)."""
+    mmask = ones(domain(op)) if mmask is None else mmask  # :1212
+    dmask = ones(range_(op)) if dmask is None else dmask  # :1213
+    mm = hadamard_(_arr.similar(m), mmask, m)  # mmask .* m
+    dd = hadamard_(_arr.similar(d), dmask, d)  # dmask .* d
+    ds = mul(op, mm)  # :1215
+    ms = mul(adjoint(op), dd)  # :1216
+    lhs = dot(mm, ms)  # :1218
+    rhs = dot(ds, dd)  # :1219
+    if np.iscomplexobj(lhs) and np.iscomplexobj(rhs):  # :1221-1225
+        return lhs, rhs
+    return np.real(lhs), np.real(rhs)

@@ -1,0 +1,149 @@
+"""Row partition of a tall block operator across the GPUs of one node.
+
+A tall JopBlock (many block rows x one block column, src/Jets.jl:926-933) shards naturally:
+the forward needs no exchange (each range block depends only on m, src/Jets.jl:1015-1031) and the
+adjoint is a sum over rows (1045-1053).  One process per GPU; rank g owns the contiguous rows
+[first, first+count) -- the slab order of JetBSpace.indices is preserved, so a global block index
+maps to (rank, local index) by integer arithmetic.  Domain-side vectors are replicated; the only
+data-path collective is ONE all-reduce (RCCL over xGMI via torch.distributed's "nccl" backend) of
+the domain vector after the local adjoint, and scalar all-reduces for range-side dot/norm.
+
+The summation order across ranks differs from the sequential reference => tolerance parity at
+world_size > 1 (bit-exact at world_size 1).
+
+The compute engine is injected (`local_mul`, `local_mul_adj`, `as_tensor`) so the sharding and
+collective logic can be exercised with world_size-2 gloo tests on CPU against a test double; the
+product wiring (`for_device`) uses the HIP path only.
+"""
+from __future__ import annotations
+
+import builtins
+import math
+from dataclasses import dataclass
+from typing import Callable
+
+__all__ = ["RowPartition", "partition_rows", "Comm", "RowPartitionedOp", "for_device"]
+
+
+@dataclass(frozen=True)
+class RowPartition:
+    nrow: int        # global block rows
+    world: int
+    rank: int
+    first: int       # first global row owned by this rank
+    count: int       # rows owned
+
+    def owner(self, irow: int) -> int:
+        """Rank owning global row `irow`."""
+        base, rem = divmod(self.nrow, self.world)
+        cut = rem * (base + 1)
+        return irow // (base + 1) if irow < cut else rem + (irow - cut) // builtins.max(base, 1)
+
+    def local_index(self, irow: int) -> int:
+        return irow - partition_rows(self.nrow, self.world, self.owner(irow)).first
+
+
+def partition_rows(nrow: int, world: int, rank: int) -> RowPartition:
+    """Contiguous chunks; the first nrow % world ranks get one extra row."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(nrow, world)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + builtins.min(rank, rem)
+    return RowPartition(nrow, world, rank, first, count)
+
+
+class Comm:
+    """Thin wrapper over torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" in CPU tests)."""
+
+    def __init__(self, as_tensor: Callable, stream_ctx: Callable | None = None):
+        import torch.distributed as dist
+
+        self._dist = dist
+        self._as_tensor = as_tensor
+        self._stream_ctx = stream_ctx
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+
+    def all_reduce_sum_(self, x):
+        """In-place sum of a replicated domain vector over all ranks (the adjoint accumulate)."""
+        if self.world == 1:
+            return x
+        t = self._as_tensor(x)
+        if self._stream_ctx is not None:
+            with self._stream_ctx():
+                self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        else:
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return x
+
+    def all_reduce_scalars(self, values, op: str = "sum"):
+        """Batched scalar all-reduce (range-side dot / norm^2 / extrema partials), fp64 on the host path."""
+        import torch
+
+        if self.world == 1:
+            return list(values)
+        t = torch.tensor(list(values), dtype=torch.float64)
+        backend = self._dist.get_backend()
+        if backend == "nccl":
+            t = t.cuda()
+        red = {"sum": self._dist.ReduceOp.SUM, "max": self._dist.ReduceOp.MAX, "min": self._dist.ReduceOp.MIN}[op]
+        self._dist.all_reduce(t, op=red)
+        return t.cpu().tolist()
+
+    def barrier(self):
+        if self.world > 1:
+            self._dist.barrier()
+
+
+class RowPartitionedOp:
+    """This rank's shard of a tall block operator plus the exchange step."""
+
+    def __init__(self, part: RowPartition, local_op, comm: Comm, local_mul: Callable, local_mul_adj: Callable,
+                 local_dot: Callable, local_norm: Callable):
+        self.part, self.local_op, self.comm = part, local_op, comm
+        self._mul, self._mul_adj, self._dot, self._norm = local_mul, local_mul_adj, local_dot, local_norm
+
+    def mul_(self, d_local, m):
+        """d_local = A[rows of this rank] m   -- no communication."""
+        return self._mul(d_local, self.local_op, m)
+
+    def mul_adj_(self, m, d_local):
+        """m = sum over ALL rows A_i' d_i  -- local ordered sum, then one all-reduce."""
+        self._mul_adj(m, self.local_op, d_local)
+        return self.comm.all_reduce_sum_(m)
+
+    def dot_range(self, x_local, y_local) -> float:
+        return self.comm.all_reduce_scalars([float(self._dot(x_local, y_local))], "sum")[0]
+
+    def norm_range(self, x_local, p: float = 2) -> float:
+        if p == 2:
+            return math.sqrt(self.comm.all_reduce_scalars([float(self._norm(x_local, 2)) ** 2], "sum")[0])
+        if p == math.inf:
+            return self.comm.all_reduce_scalars([float(self._norm(x_local, p))], "max")[0]
+        if p == -math.inf:
+            return self.comm.all_reduce_scalars([float(self._norm(x_local, p))], "min")[0]
+        if p in (0, 1):
+            return self.comm.all_reduce_scalars([float(self._norm(x_local, p))], "sum")[0]
+        return self.comm.all_reduce_scalars([float(self._norm(x_local, p)) ** p], "sum")[0] ** (1.0 / p)
+
+
+def for_device(part: RowPartition, local_op) -> RowPartitionedOp:
+    """Product wiring: HIP kernels for the local work, RCCL (torch.distributed "nccl") for the exchange.
+    The all-reduce is ordered against the library's HIP stream through torch.cuda.ExternalStream."""
+    import torch
+
+    from . import device as _device
+    from .arrays import dot, norm
+    from .jets import mul_, adjoint
+
+    ext = torch.cuda.ExternalStream(_device.stream_handle(), device=torch.device("cuda", _device.init()))
+
+    def as_tensor(x):
+        return torch.as_tensor(x, device=torch.device("cuda", _device.init()))
+
+    def stream_ctx():
+        return torch.cuda.stream(ext)
+
+    comm = Comm(as_tensor, stream_ctx)
+    return RowPartitionedOp(part, local_op, comm, lambda d, A, m: mul_(d, A, m), lambda m, A, d: mul_(m, adjoint(A), d), dot, norm)

@@ -1,0 +1,128 @@
+"""Jet spaces: shape + eltype metadata (host side, no device work).
+
+Mirrors /root/reference/src/Jets.jl:5-129 (JetAbstractSpace, JetSpace) and 736-807 (JetBSpace).
+Python conventions: block indices and element indices are 0-based; `indices(R, i)` is a Python
+`range(start, stop)` (half-open), i.e. Julia's `a:b` (src/Jets.jl:742-748) maps to `range(a-1, b)`.
+Arrays are column-major like Julia's (a block is contiguous; shape metadata only).
+"""
+from __future__ import annotations
+
+import builtins
+from typing import Sequence
+
+import numpy as np
+
+__all__ = ["JetAbstractSpace", "JetSpace", "JetBSpace", "DTYPE_CODES", "dtype_code"]
+
+DTYPE_CODES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.complex64): 2, np.dtype(np.complex128): 3}
+
+
+def dtype_code(T) -> int:
+    dt = np.dtype(T)
+    if dt not in DTYPE_CODES:
+        raise TypeError(f"element type {dt} is not supported on the device (Float32/Float64/ComplexF32/ComplexF64)")
+    return DTYPE_CODES[dt]
+
+
+class JetAbstractSpace:
+    """src/Jets.jl:5-38."""
+
+    def eltype(self):  # :12
+        return self._T
+
+    def size(self, i: int | None = None):  # :30
+        s = self._size()
+        return s if i is None else s[i]
+
+    def ndims(self) -> int:  # :15
+        return len(self._size())
+
+    def length(self) -> int:  # :22  prod(size(R))
+        n = 1
+        for k in self._size():
+            n *= int(k)
+        return n
+
+    def __len__(self) -> int:
+        return self.length()
+
+
+class JetSpace(JetAbstractSpace):
+    """JetSpace(T, n...)  (src/Jets.jl:40-68)."""
+
+    def __init__(self, T, *n):
+        if len(n) == 1 and isinstance(n[0], (tuple, list)):  # JetSpace(T, (n1, n2))  :61
+            n = tuple(n[0])
+        self._T = np.dtype(T)
+        self.n = tuple(int(k) for k in n)
+        if any(k < 0 for k in self.n):
+            raise ValueError("negative dimension")
+
+    def _size(self):  # :63
+        return self.n
+
+    def vec(self) -> "JetSpace":  # :66
+        return JetSpace(self._T, self.length())
+
+    def similar(self, *dims) -> "JetSpace":  # :67-68
+        if len(dims) == 1 and isinstance(dims[0], (tuple, list)):
+            dims = tuple(dims[0])
+        return JetSpace(self._T, *dims)
+
+    def __eq__(self, other):
+        return isinstance(other, JetSpace) and self._T == other._T and self.n == other.n
+
+    def __hash__(self):
+        return hash((self._T.str, self.n))
+
+    def __repr__(self):
+        return f"JetSpace({self._T.name}, {', '.join(map(str, self.n))})"
+
+
+class JetBSpace(JetAbstractSpace):
+    """Block space: always 1-D, contiguous cumulative ranges (src/Jets.jl:736-760)."""
+
+    def __init__(self, spaces: Sequence[JetAbstractSpace]):
+        spaces = list(spaces)
+        if not spaces:
+            raise ValueError("JetBSpace needs at least one block")
+        T = spaces[0].eltype()
+        for s in spaces:
+            if s.eltype() != T:
+                raise TypeError("all blocks of a JetBSpace must share one element type")
+        self._T = T
+        self.spaces = spaces
+        self.indices = []
+        stop = 0  # :743  (1-based inclusive `stop`; 0-based half-open range(stop_prev, stop))
+        for s in spaces:  # :744-748
+            start = stop + 1
+            stop = start + s.length() - 1
+            self.indices.append(builtins.range(start - 1, stop))
+
+    def _size(self):  # :755
+        return (self.indices[-1].stop,)
+
+    def vec(self) -> "JetBSpace":  # :758
+        return self
+
+    def similar(self, *dims) -> JetSpace:  # :759-760
+        if len(dims) == 1 and isinstance(dims[0], (tuple, list)):
+            dims = tuple(dims[0])
+        if len(dims) != 1:
+            raise ValueError("a block space is one dimensional")
+        return JetSpace(self._T, *dims)
+
+    def nblocks(self) -> int:  # :806
+        return len(self.spaces)
+
+    def block_lengths(self) -> list[int]:
+        return [len(r) for r in self.indices]
+
+    def __eq__(self, other):  # :753
+        return isinstance(other, JetBSpace) and self.spaces == other.spaces and self.indices == other.indices
+
+    def __hash__(self):
+        return hash(tuple(self.spaces))
+
+    def __repr__(self):
+        return f"JetBSpace({self._T.name}, {self.nblocks()} blocks, length {self.length()})"

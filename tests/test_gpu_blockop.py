@@ -1,0 +1,292 @@
+"""GPU parity: JetBlock_df! / JetBlock_df'! / fused A'oA on the MI355X vs the CPU oracle.
+
+The HIP path is driven through the product package (-> ctypes -> C ABI of include/jetship.h).
+Re-encodes on seeded inputs: test/runtests.jl:720-742 (tall-and-skinny), 744-758 (short-and-fat),
+622-695 (mixed 3x4 with zero blocks, dirty-output adjoint 684), 704-718 (singleton), 901-918
+(dot product test), BASELINE.json configs[0] (4x4 identity, Float64, n = 128).
+Bar: BIT-EXACT for the forward, the one-GPU adjoint (ordered mul-then-add) and the fused normal
+operator; dot-product test |lhs-rhs|/|lhs+rhs| < 1e-5 (Float32) / 1e-12 (Float64).
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+from .helpers import DTYPES, SEED_D, SEED_M, assert_bits_equal, dev_blocks_to_numpy, make_tall_diag, u01
+
+pytestmark = pytest.mark.gpu
+
+
+def _dpt_tol(dt):
+    return 1e-5 if np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-12
+
+
+# ---------------------------------------------------------------------------------- tall fast path
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,shape", [(3, (8, 4, 4)), (5, (1024,)), (17, (32, 33, 4)), (64, (16, 16, 16)), (2, (4,))])
+def test_tall_diag_forward_adjoint_bit_exact(Jets, oracle, dt, nrow, shape):
+    A, _, ops, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    assert Jets.nblocks_op(A) == (nrow, 1)                                        # test/runtests.jl:739
+    assert isinstance(Jets.domain(A), Jets.JetSpace)                              # src/Jets.jl:927
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=0)
+    hm = u01(oracle, dt, SEED_M, 0, n)
+    d = A * m                                                                     # zeros(range) then mul!  (:399)
+    ref_d = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [hm])
+    assert_bits_equal(d.to_numpy(), np.concatenate(ref_d), "A*m")
+    for i in (0, nrow - 1):                                                       # A*m == [B1 m; B2 m; ...]  (:724)
+        assert_bits_equal(Jets.getblock(d, i).to_numpy().ravel(order="F"), ref_d[i], f"block {i}")
+
+    dd = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    hd = u01(oracle, dt, SEED_D, 0, nrow * n)
+    hd_blocks = [hd[i * n:(i + 1) * n].copy() for i in range(nrow)]
+    mt = Jets.rand(Jets.domain(A), seed=99, stream=99)                            # dirty output: must be overwritten (:684)
+    Jets.mul_(mt, A.H, dd)
+    ref_m = oracle.block_df_adj(ops, [np.full(n, 7, dtype=dt)], hd_blocks)
+    assert_bits_equal(mt.to_numpy().ravel(order="F"), ref_m[0], "A'*d")
+
+
+@pytest.mark.parametrize("knobs", [
+    dict(fwd_group=1, fwd_unroll=1, adj_unroll=1, adj_depth=1, nt=0, wg=256),
+    dict(fwd_group=4, fwd_unroll=2, adj_unroll=2, adj_depth=2, nt=1, wg=256),
+    dict(fwd_group=16, fwd_unroll=4, adj_unroll=2, adj_depth=4, nt=1, wg=256),
+    dict(fwd_group=7, fwd_unroll=8, adj_unroll=1, adj_depth=8, nt=1, wg=512),
+    dict(fwd_group=64, fwd_unroll=4, adj_unroll=4, adj_depth=4, nt=0, wg=1024),
+    dict(fwd_group=3, fwd_unroll=2, adj_unroll=4, adj_depth=2, nt=1, wg=512),
+])
+def test_every_kernel_shape_gives_identical_bits(Jets, oracle, knobs):
+    """The tuning knobs change tiling only -- never results."""
+    saved = {k: Jets.tune_get(k) for k in knobs}
+    try:
+        Jets.tune(**knobs)
+        dt, nrow, shape = np.float32, 13, (40, 40, 12)          # 19200 elements: partial tiles for every tiling
+        A, _, ops, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+        n = int(np.prod(shape))
+        m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=0)
+        hm = u01(oracle, dt, SEED_M, 0, n)
+        d = A * m
+        ref_d = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [hm])
+        assert_bits_equal(d.to_numpy(), np.concatenate(ref_d), f"forward {knobs}")
+        mt = A.H * d
+        ref_m = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], ref_d)
+        assert_bits_equal(mt.to_numpy().ravel(order="F"), ref_m[0], f"adjoint {knobs}")
+        y = Jets.mul(A.H @ A, m)
+        assert_bits_equal(y.to_numpy().ravel(order="F"), ref_m[0], f"fused normal {knobs}")
+    finally:
+        Jets.tune(**saved)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_fused_normal_equals_unfused_and_oracle(Jets, oracle, dt):
+    """JetComposite (A' o A): src/Jets.jl:530-534.  Fused kernel == chained kernels == oracle, bitwise."""
+    nrow, shape = 9, (12, 8, 4)
+    A, _, ops, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=5)
+    hm = u01(oracle, dt, SEED_M, 5, n)
+    C = A.H @ A
+    assert len(Jets.state(C)["ops"]) == 2
+    y_fused = C * m
+    y_chain = A.H * (A * m)
+    ref = oracle.normal_df(ops, [np.zeros(n, dtype=dt)], [hm])
+    assert_bits_equal(y_fused.to_numpy().ravel(order="F"), ref[0], "fused A'A vs oracle")
+    assert_bits_equal(y_chain.to_numpy().ravel(order="F"), ref[0], "chained A'A vs oracle")
+    ya = C.H * m                                                                  # composite adjoint (self-adjoint chain)
+    assert_bits_equal(ya.to_numpy().ravel(order="F"), ref[0], "(A'A)' m")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
+def test_dot_product_test_tall(Jets, oracle, dt):
+    """src/Jets.jl:1211-1226 with and without masks (test/runtests.jl:901-918)."""
+    nrow, shape = 6, (16, 8, 8)
+    A, _, ops, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=1)
+    d = Jets.rand(Jets.range(A), seed=SEED_D, stream=1)
+    lhs, rhs = Jets.dot_product_test(A, m, d)
+    assert abs(lhs - rhs) / abs(lhs + rhs) < _dpt_tol(dt)
+    mmask, dmask = Jets.ones(Jets.domain(A)), Jets.ones(Jets.range(A))
+    Jets.getblock(dmask, 0).assign(0.0)
+    Jets.setblock_(dmask, 2, 0.0)
+    lhs2, rhs2 = Jets.dot_product_test(A, m, d, mmask=mmask, dmask=dmask)
+    assert abs(lhs2 - rhs2) / abs(lhs2 + rhs2) < _dpt_tol(dt)
+    assert abs(lhs2) < abs(lhs)
+    if np.dtype(dt).kind == "c":
+        assert np.iscomplexobj(lhs) and np.iscomplexobj(rhs)                      # :1221-1222
+    # the oracle's own dot-product test agrees within tolerance
+    n = int(np.prod(shape))
+    hm, hd = u01(oracle, dt, SEED_M, 1, n), u01(oracle, dt, SEED_D, 1, nrow * n)
+    olhs, orhs = oracle.dot_product_test(ops, [hm], [hd[i * n:(i + 1) * n].copy() for i in range(nrow)])
+    assert abs(complex(lhs) - complex(olhs)) <= 50 * _dpt_tol(dt) * abs(olhs)
+
+
+# ---------------------------------------------------------------------------------- general path
+def _mixed_ops(Jets, oracle, dt, kinds, lens_r, lens_c, seed=21):
+    """Build the same nrow x ncol mixed operator on the device and in the oracle. kinds[i][j] in
+    {'zero','identity','scale','diag','diag_adj'}; elementwise blocks need lens_r[i] == lens_c[j]."""
+    dev_rows, ora_rows = [], []
+    for i, row in enumerate(kinds):
+        dr, orow = [], []
+        for j, k in enumerate(row):
+            nr, nc = lens_r[i], lens_c[j]
+            dom, rng = Jets.JetSpace(dt, nc), Jets.JetSpace(dt, nr)
+            if k == "zero":
+                dr.append(Jets.JopZeroBlock(dom, rng)); orow.append(oracle.Block("zero", nr, nc))
+            elif k == "identity":
+                dr.append(Jets.JopIdentity(dom)); orow.append(oracle.Block("identity", nr))
+            elif k == "scale":
+                a = (0.3 + i) - (0.25j * (j + 1) if np.dtype(dt).kind == "c" else 0)
+                dr.append(Jets.JopLn(dom=dom, rng=dom, df=Jets.constdiag_df, df_adj=Jets.constdiag_df_adj, s={"a": a}))
+                orow.append(oracle.Block("scale", nr, scale=a))
+            else:
+                stream = 100 * i + j
+                dg = Jets.rand(dom, seed=seed, stream=stream)
+                op = Jets.JopDiagonal(dg)
+                hb = oracle.Block("diag", nr, coeff=u01(oracle, dt, seed, stream, nr), adjoint=(k == "diag_adj"))
+                dr.append(op.H if k == "diag_adj" else op); orow.append(hb)
+        dev_rows.append(dr); ora_rows.append(orow)
+    return Jets.blockop(dev_rows), ora_rows
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_mixed_3x4_with_zero_blocks_bit_exact(Jets, oracle, dt):
+    """test/runtests.jl:622-695 shape (3x4, zero blocks at (2,2),(3,4)) with native kinds."""
+    kinds = [["diag", "identity", "diag", "scale"],
+             ["diag_adj", "zero", "diag", "diag"],
+             ["scale", "diag", "diag_adj", "zero"]]
+    n = 10
+    A, ops = _mixed_ops(Jets, oracle, dt, kinds, [n] * 3, [n] * 4)
+    assert Jets.nblocks_op(A) == (3, 4) and Jets.nblocks_op(A, 1) == 3 and Jets.nblocks_op(A, 2) == 4
+    assert isinstance(Jets.domain(A), Jets.JetBSpace) and Jets.domain(A).length() == 40 and Jets.range(A).length() == 30
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=2)
+    hm = u01(oracle, dt, SEED_M, 2, 40)
+    hm_blocks = [hm[j * n:(j + 1) * n].copy() for j in range(4)]
+    d = A * m
+    ref_d = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(3)], hm_blocks)
+    assert_bits_equal(d.to_numpy(), np.concatenate(ref_d), "F*m")
+    dd = Jets.rand(Jets.range(A), seed=SEED_D, stream=2)
+    hd = u01(oracle, dt, SEED_D, 2, 30)
+    hd_blocks = [hd[i * n:(i + 1) * n].copy() for i in range(3)]
+    mt = Jets.mul_(Jets.rand(Jets.domain(A), seed=5, stream=5), A.H, dd)          # dirty output (:684)
+    ref_m = oracle.block_df_adj(ops, [np.full(n, 3, dtype=dt) for _ in range(4)], hd_blocks)
+    assert_bits_equal(mt.to_numpy(), np.concatenate(ref_m), "L'*d into a dirty vector")
+    lhs, rhs = Jets.dot_product_test(A, m, dd)
+    assert abs(lhs - rhs) / abs(lhs + rhs) < _dpt_tol(dt)
+
+
+def test_forward_accumulates_into_dirty_output_when_ncol_gt_1(Jets, oracle):
+    """Reference quirk, src/Jets.jl:1024: `_d .+=` without zeroing -- mul!(d, A, m) on a dirty d
+    returns d_old + A m for ncol > 1; overwrite for ncol == 1 (1026)."""
+    dt, n = np.float64, 12
+    A, ops = _mixed_ops(Jets, oracle, dt, [["diag", "diag"], ["identity", "zero"]], [n, n], [n, n])
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=3)
+    hm = u01(oracle, dt, SEED_M, 3, 2 * n)
+    d = Jets.rand(Jets.range(A), seed=8, stream=8)
+    hd0 = u01(oracle, dt, 8, 8, 2 * n)
+    Jets.mul_(d, A, m)
+    ref = oracle.block_df(ops, [hd0[:n].copy(), hd0[n:].copy()], [hm[:n].copy(), hm[n:].copy()])
+    assert_bits_equal(d.to_numpy(), np.concatenate(ref), "dirty accumulate")
+    assert not np.array_equal(np.concatenate(ref), np.concatenate(oracle.block_df(ops, [np.zeros(n), np.zeros(n)], [hm[:n].copy(), hm[n:].copy()])))
+
+
+def test_zero_block_leaves_output_untouched_in_tall_forward(Jets, oracle):
+    """src/Jets.jl:1022: a zero block in a one-column operator is skipped, d_i keeps its old value."""
+    dt, n = np.float32, 20
+    A, ops = _mixed_ops(Jets, oracle, dt, [["diag"], ["zero"], ["scale"]], [n, n, n], [n])
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=4)
+    hm = u01(oracle, dt, SEED_M, 4, n)
+    d = Jets.rand(Jets.range(A), seed=8, stream=9)
+    hd0 = u01(oracle, dt, 8, 9, 3 * n)
+    Jets.mul_(d, A, m)
+    ref = oracle.block_df(ops, [hd0[i * n:(i + 1) * n].copy() for i in range(3)], [hm])
+    assert_bits_equal(d.to_numpy(), np.concatenate(ref), "zero block skipped")
+    assert_bits_equal(Jets.getblock(d, 1).to_numpy(), hd0[n:2 * n], "untouched block")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex128])
+def test_short_and_fat_and_singleton(Jets, oracle, dt):
+    """test/runtests.jl:744-758 (1x3) and 704-718 (1x1)."""
+    n = 15
+    A, ops = _mixed_ops(Jets, oracle, dt, [["diag", "diag_adj", "scale"]], [n], [n, n, n])
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=6)
+    hm = u01(oracle, dt, SEED_M, 6, 3 * n)
+    d = A * m
+    ref_d = oracle.block_df(ops, [np.zeros(n, dtype=dt)], [hm[j * n:(j + 1) * n].copy() for j in range(3)])
+    assert_bits_equal(d.to_numpy(), ref_d[0], "wide forward")
+    dd = Jets.rand(Jets.range(A), seed=SEED_D, stream=6)
+    hd = u01(oracle, dt, SEED_D, 6, n)
+    mt = A.H * dd
+    ref_m = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt) for _ in range(3)], [hd])
+    assert_bits_equal(mt.to_numpy(), np.concatenate(ref_m), "wide adjoint == [B1'd; B2'd; B3'd]")
+
+    S, sops = _mixed_ops(Jets, oracle, dt, [["diag"]], [n], [n])
+    ms = Jets.rand(Jets.domain(S), seed=SEED_M, stream=7)
+    hms = u01(oracle, dt, SEED_M, 7, n)
+    assert_bits_equal((S * ms).to_numpy(), oracle.block_df(sops, [np.zeros(n, dtype=dt)], [hms])[0], "singleton A*m")
+    assert_bits_equal((S.H * ms).to_numpy().ravel(order="F"), oracle.block_df_adj(sops, [np.zeros(n, dtype=dt)], [hms])[0], "singleton A'*d")
+
+
+def test_ragged_block_lengths(Jets, oracle):
+    """Heterogeneous block sizes (benchmark/benchmarks.jl:126-157 'Block, heterogeneous'): odd lengths
+    put block starts off 16-byte alignment; zero blocks may be rectangular."""
+    dt = np.float32
+    lens = [7, 130, 1]
+    kinds = [["diag", "zero", "zero"], ["zero", "diag", "zero"], ["zero", "zero", "scale"]]
+    A, ops = _mixed_ops(Jets, oracle, dt, kinds, lens, lens)
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=8)
+    hm = u01(oracle, dt, SEED_M, 8, sum(lens))
+    offs = np.cumsum([0] + lens)
+    hm_blocks = [hm[offs[j]:offs[j + 1]].copy() for j in range(3)]
+    d = A * m
+    ref_d = oracle.block_df(ops, [np.zeros(k, dtype=dt) for k in lens], hm_blocks)
+    assert_bits_equal(d.to_numpy(), np.concatenate(ref_d), "ragged forward")
+    mt = A.H * d
+    ref_m = oracle.block_df_adj(ops, [np.zeros(k, dtype=dt) for k in lens], ref_d)
+    assert_bits_equal(mt.to_numpy(), np.concatenate(ref_m), "ragged adjoint")
+
+
+def test_config1_4x4_identity_float64_dot_product_test(Jets, oracle):
+    """BASELINE.json configs[0]: 4x4 JopBlock of identity JopLn on JetSpace(Float64,128)."""
+    dt, n = np.float64, 128
+    A, ops = _mixed_ops(Jets, oracle, dt, [["identity"] * 4 for _ in range(4)], [n] * 4, [n] * 4)
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=9)
+    d = Jets.rand(Jets.range(A), seed=SEED_D, stream=9)
+    lhs, rhs = Jets.dot_product_test(A, m, d)
+    assert abs(lhs - rhs) / abs(lhs + rhs) < 1e-12
+    hm, hd = u01(oracle, dt, SEED_M, 9, 4 * n), u01(oracle, dt, SEED_D, 9, 4 * n)
+    split = lambda v: [v[i * n:(i + 1) * n].copy() for i in range(4)]
+    olhs, orhs = oracle.dot_product_test(ops, split(hm), split(hd))
+    assert abs(olhs - orhs) / abs(olhs + orhs) < 1e-12
+    assert lhs == pytest.approx(olhs, rel=1e-12) and rhs == pytest.approx(orhs, rel=1e-12)
+    ref = oracle.block_df(ops, [np.zeros(n) for _ in range(4)], split(hm))
+    assert_bits_equal((A * m).to_numpy(), np.concatenate(ref), "4x4 identity forward")
+
+
+def test_tiny_and_denormal_values_survive(Jets, oracle):
+    """No flush-to-zero, no FMA contraction: products of tiny values match the CPU bit for bit."""
+    dt, n, nrow = np.float32, 64, 4
+    tiny = (np.arange(1, n + 1, dtype=np.float32) * np.float32(1e-22)).astype(dt)
+    diags = [tiny * np.float32(k + 1) for k in range(nrow)]
+    A = Jets.blockop([[Jets.JopDiagonal(Jets.from_numpy(g))] for g in diags])
+    ops = [[oracle.Block("diag", n, coeff=g)] for g in diags]
+    hm = (np.arange(n, 0, -1, dtype=np.float32) * np.float32(3e-20)).astype(dt)     # products ~1e-40: denormal
+    m = Jets.from_numpy(hm)
+    d = A * m
+    ref_d = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [hm])
+    assert np.any((np.concatenate(ref_d) != 0) & (np.abs(np.concatenate(ref_d)) < np.finfo(np.float32).tiny))
+    assert_bits_equal(d.to_numpy(), np.concatenate(ref_d), "denormal forward")
+    big = [np.full(n, 3e18, dtype=dt) for _ in range(nrow)]
+    dd = Jets.from_numpy(np.concatenate(big), Jets.range(A))
+    mt = A.H * dd
+    ref_m = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], big)
+    assert_bits_equal(mt.to_numpy(), ref_m[0], "ordered accumulate")
+
+
+def test_shape_errors_are_loud(Jets, oracle):
+    A, *_ = make_tall_diag(Jets, oracle, np.float32, 3, (8,))
+    with pytest.raises(Jets.JetsHipError):
+        Jets.mul_(Jets.zeros(Jets.JetSpace(np.float32, 23)), A, Jets.zeros(Jets.domain(A)))
+    with pytest.raises(Jets.JetsHipError):
+        Jets.mul_(Jets.zeros(Jets.range(A)), A, Jets.zeros(Jets.JetSpace(np.float64, 8)))
+    with pytest.raises(Jets.JetsHipError):                                         # elementwise block must be square
+        Jets.blockop([[Jets.JopDiagonal(Jets.rand(Jets.JetSpace(np.float32, 4))), Jets.JopDiagonal(Jets.rand(Jets.JetSpace(np.float32, 5)))]]) * \
+            Jets.zeros(Jets.JetBSpace([Jets.JetSpace(np.float32, 4), Jets.JetSpace(np.float32, 5)]))

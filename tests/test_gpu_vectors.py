@@ -1,0 +1,232 @@
+"""GPU parity: device BlockArray (one HIP slab) vs the CPU oracle, through the C ABI.
+
+Re-encodes the reference's block-array test sets on seeded inputs:
+  test/runtests.jl:512-551 "block arrays", 553-600 "block arrays, broadcasting",
+  602-620 "block array, reshaped from array".
+Bar: bit-exact for layout / fill / copies / random fill / broadcast; reductions within
+1e-5 (Float32, ComplexF32) or 1e-12 (Float64, ComplexF64) relative to an fp64 host value
+(tighter than the reference's own `isapprox` default rtol = sqrt(eps)).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from .helpers import DTYPES, assert_bits_equal, dev_blocks_to_numpy, u01
+
+pytestmark = pytest.mark.gpu
+
+RAGGED = [(2,), (2, 2), (2, 3)]                    # test/runtests.jl:513
+SHAPES_MIX = [(5,), (1,), (7, 3), (4, 4, 4), (129,), (1000, 3)]   # odd sizes: unaligned block starts
+
+
+def _tol(dt):
+    return 1e-5 if np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-12
+
+
+def _bspace(J, dt, shapes):
+    return J.JetBSpace([J.JetSpace(dt, *s) for s in shapes])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_layout_matches_reference_ranges(Jets, oracle, dt):
+    R = _bspace(Jets, dt, SHAPES_MIX)
+    x = Jets.zeros(R)
+    lens = [int(np.prod(s)) for s in SHAPES_MIX]
+    start1, stop1 = oracle.bspace_indices(lens)            # 1-based inclusive (src/Jets.jl:742-748)
+    for i in range(len(lens)):
+        assert Jets.indices(x, i) == range(start1[i] - 1, stop1[i])
+        assert Jets.indices(R, i) == range(start1[i] - 1, stop1[i])
+    assert x.length() == stop1[-1] == R.length()
+    assert Jets.nblocks(x) == len(lens)
+    assert Jets.space(x) == R
+    assert np.all(x.to_numpy() == 0)
+
+
+def test_pi_fill_literals(Jets):
+    """test/runtests.jl:513-526 (literal values)."""
+    R = _bspace(Jets, np.float64, RAGGED)
+    x = Jets.ones(R)
+    assert np.array_equal(Jets.getblock(x, 0).to_numpy(), np.ones(2))
+    assert np.array_equal(Jets.getblock(x, 1).to_numpy(), np.ones((2, 2)))
+    assert np.array_equal(Jets.getblock(x, 2).to_numpy(), np.ones((2, 3)))
+    Jets.setblock_(x, 0, math.pi)
+    Jets.setblock_(x, 1, 2 * math.pi)
+    Jets.setblock_(x, 2, 3 * math.pi * np.ones((2, 3)))
+    out = Jets.getblock_(x, 1, np.empty((2, 2)))
+    assert np.array_equal(out, 2 * math.pi * np.ones((2, 2)))
+    _x = Jets.convert_array(x).to_numpy()
+    assert np.array_equal(_x, np.concatenate([np.full(2, math.pi), np.full(4, 2 * math.pi), np.full(6, 3 * math.pi)]))
+    assert np.array_equal(_x, x.to_numpy())
+    assert Jets.norm(x) == pytest.approx(np.linalg.norm(_x), rel=1e-14)
+    assert Jets.norm(x, 0) == np.count_nonzero(_x)
+    assert Jets.norm(x, math.inf) == 3 * math.pi
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_rand_is_the_oracle_stream_bit_exact(Jets, oracle, dt):
+    R = _bspace(Jets, dt, SHAPES_MIX)
+    x = Jets.rand(R, seed=7, stream=11)
+    assert_bits_equal(x.to_numpy(), u01(oracle, dt, 7, 11, R.length()), "rand slab")
+    # a shard regenerates its slice of the global vector (index_base)
+    y = Jets.rand(Jets.JetSpace(dt, 1000), seed=7, stream=11, index_base=37)
+    assert_bits_equal(y.to_numpy(), u01(oracle, dt, 7, 11, 1000, index0=37), "rand slice")
+    v = x.to_numpy()
+    assert (v.real >= 0).all() and (v.real < 1).all()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("p", [2, 1, 0, math.inf, -math.inf, 3, 2.5])
+def test_norm(Jets, oracle, dt, p):
+    R = _bspace(Jets, dt, SHAPES_MIX)
+    x = Jets.rand(R, seed=3, stream=1)
+    if p == 0:
+        Jets.setblock_(x, 1, 0.0)                           # some exact zeros to count
+    blocks = dev_blocks_to_numpy(x)
+    got = float(Jets.norm(x, p))
+    flat = np.concatenate(blocks).astype(np.complex128)
+    truth = float(np.linalg.norm(flat, p)) if p not in (0,) else float(np.count_nonzero(flat))
+    assert got == pytest.approx(truth, rel=_tol(dt))
+    assert got == pytest.approx(oracle.barr_norm(blocks, float(p)), rel=10 * _tol(dt) if np.dtype(dt).itemsize <= 8 else 1e-10)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_dot(Jets, oracle, dt):
+    R = _bspace(Jets, dt, SHAPES_MIX)
+    x, y = Jets.rand(R, seed=3, stream=1), Jets.rand(R, seed=3, stream=2)
+    bx, by = dev_blocks_to_numpy(x), dev_blocks_to_numpy(y)
+    truth = np.vdot(np.concatenate(bx).astype(np.complex128), np.concatenate(by).astype(np.complex128))
+    got = complex(Jets.dot(x, y))
+    assert abs(got - truth) <= _tol(dt) * abs(truth)
+    ora = complex(oracle.barr_dot(bx, by))
+    assert abs(got - ora) <= 20 * _tol(dt) * abs(truth)
+    # dot(x,x) ~ dot(_x,_x)  (test/runtests.jl:550), result type follows eltype
+    assert type(Jets.dot(x, x)) == np.dtype(dt).type
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_extrema(Jets, oracle, dt):
+    R = _bspace(Jets, dt, SHAPES_MIX)
+    x = Jets.rand(R, seed=9, stream=4)
+    x.assign(2.0 * x - 1.0 * Jets.ones(R))                  # signed values
+    blocks = dev_blocks_to_numpy(x)
+    mn, mx = Jets.extrema(x)
+    omn, omx = oracle.barr_extrema(blocks)
+    assert (float(mn), float(mx)) == (omn, omx)             # exact: compares only
+    flat = np.concatenate(blocks)
+    assert (mn, mx) == (flat.min(), flat.max())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_fill_and_setblock_bit_exact(Jets, oracle, dt):
+    R = _bspace(Jets, dt, SHAPES_MIX)
+    x = Jets.rand(R, seed=1, stream=1)
+    val = 3.14 if np.dtype(dt).kind != "c" else 3.14 - 2.5j
+    Jets.fill_(x, val)                                      # x .= 3.14  (test/runtests.jl:584)
+    ref = oracle.barr_fill([np.empty(int(np.prod(s)), dtype=dt) for s in SHAPES_MIX], val)
+    assert_bits_equal(x.to_numpy(), np.concatenate(ref), "fill!")
+    for i, s in enumerate(SHAPES_MIX):                      # scalar setblock! on every (unaligned) block
+        Jets.setblock_(x, i, float(i) + 0.5)
+    ref = np.concatenate([np.full(int(np.prod(s)), i + 0.5, dtype=dt) for i, s in enumerate(SHAPES_MIX)])
+    assert_bits_equal(x.to_numpy(), ref, "setblock! scalar")
+    blk = u01(oracle, dt, 5, 5, int(np.prod(SHAPES_MIX[3])))
+    Jets.setblock_(x, 3, blk.reshape(SHAPES_MIX[3], order="F"))
+    ref[Jets.indices(x, 3).start:Jets.indices(x, 3).stop] = blk
+    assert_bits_equal(x.to_numpy(), ref, "setblock! array")
+    dev_src = Jets.rand(Jets.JetSpace(dt, *SHAPES_MIX[2]), seed=6, stream=6)
+    Jets.setblock_(x, 2, dev_src)                           # device-to-device
+    ref[Jets.indices(x, 2).start:Jets.indices(x, 2).stop] = dev_src.to_numpy().ravel(order="F")
+    assert_bits_equal(x.to_numpy(), ref, "setblock! device array")
+
+
+def test_getblock_is_a_reference_not_a_copy(Jets):
+    """docs/src/index.md:223 / src/Jets.jl:914."""
+    R = _bspace(Jets, np.float64, RAGGED)
+    x = Jets.zeros(R)
+    b1 = Jets.getblock(x, 1)
+    Jets.fill_(b1, 5.0)
+    assert np.array_equal(x.to_numpy(), np.concatenate([np.zeros(2), np.full(4, 5.0), np.zeros(6)]))
+    assert b1.shape == (2, 2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_broadcast_lincomb_bit_exact(Jets, oracle, dt):
+    """x = a*u .+ b*v .+ c*w  (test/runtests.jl:555-568), evaluated left to right in eltype T."""
+    R = _bspace(Jets, dt, SHAPES_MIX)
+    u, v, w = (Jets.rand(R, seed=2, stream=k) for k in (1, 2, 3))
+    a, b, c = 0.37, 0.81, 0.59
+    if np.dtype(dt).kind == "c":
+        a, b, c = 0.37 + 0.2j, 0.81 - 0.4j, -0.59 + 1.5j
+    x = (a * u + b * v + c * w).materialize()
+    assert isinstance(x, Jets.BlockArray) and x.dtype == np.dtype(dt)      # :562
+    bu, bv, bw = (dev_blocks_to_numpy(t) for t in (u, v, w))
+    ref = oracle.barr_lincomb([np.empty_like(t) for t in bu], [a, b, c], [bu, bv, bw])
+    assert_bits_equal(x.to_numpy(), np.concatenate(ref), "a*u .+ b*v .+ c*w")
+    y = Jets.zeros(R)
+    y.assign(x)                                                             # y .= x  (:570-571)
+    assert_bits_equal(y.to_numpy(), x.to_numpy(), "y .= x")
+    # in-place with aliasing: u .= u .- v
+    u.assign(u - v)
+    ref2 = oracle.barr_lincomb([np.empty_like(t) for t in bu], [1.0, -1.0], [bu, bv])
+    assert_bits_equal(u.to_numpy(), np.concatenate(ref2), "u .= u .- v")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_hadamard_bit_exact(Jets, oracle, dt):
+    R = _bspace(Jets, dt, SHAPES_MIX)
+    x, y = Jets.rand(R, seed=2, stream=7), Jets.rand(R, seed=2, stream=8)
+    hx, hy = x.to_numpy(), y.to_numpy()
+    blk = oracle.Block("diag", hx.size, coeff=hx)            # d .= diagonal .* m / m .= conj.(diagonal) .* d
+    z = Jets.hadamard_(Jets.zeros(R), x, y)
+    assert_bits_equal(z.to_numpy(), oracle.child_mul(blk, np.empty_like(hx), hy), "x .* y")
+    zc = Jets.hadamard_(Jets.zeros(R), x, y, conj_x=True)
+    assert_bits_equal(zc.to_numpy(), oracle.child_mul_adj(blk, np.empty_like(hx), hy), "conj.(x) .* y")
+
+
+def test_similar_variants(Jets):
+    """test/runtests.jl:595-599."""
+    R = _bspace(Jets, np.float64, RAGGED)
+    y = Jets.rand(R)
+    assert isinstance(Jets.similar(y, np.float32), Jets.BlockArray)
+    assert isinstance(Jets.similar(y, np.float32, y.length()), Jets.BlockArray)
+    assert isinstance(Jets.similar(y, np.float32, (y.length(),)), Jets.BlockArray)
+    assert isinstance(Jets.similar(y, np.float32, 5), Jets.DeviceArray)
+    assert R.similar((0,)) == Jets.JetSpace(np.float64, 0)                 # :619
+
+
+def test_reshape_shares_memory(Jets):
+    """test/runtests.jl:602-610: reshape(x, R) aliases x; linear indexing reads through."""
+    x = Jets.rand(Jets.JetSpace(np.float64, 5, 10), seed=4, stream=4)
+    R = Jets.JetBSpace([Jets.JetSpace(np.float64, 5) for _ in range(10)])
+    _x = Jets.reshape(x, R)
+    host = x.to_numpy().ravel(order="F")
+    for i in range(len(_x)):
+        assert _x[i] == host[i]
+        _x[i] = float(i)
+    assert np.array_equal(x.to_numpy().ravel(order="F"), np.arange(50.0))
+    assert Jets.reshape(_x, R) is _x                                        # src/Jets.jl:1115-1118
+    with pytest.raises(ValueError):
+        Jets.reshape(_x, Jets.JetBSpace([Jets.JetSpace(np.float64, 7)]))
+
+
+def test_empty_and_degenerate_blocks(Jets):
+    R = Jets.JetBSpace([Jets.JetSpace(np.float32, 0), Jets.JetSpace(np.float32, 3), Jets.JetSpace(np.float32, 0)])
+    x = Jets.ones(R)
+    assert x.length() == 3 and Jets.indices(x, 0) == range(0, 0) and Jets.indices(x, 2) == range(3, 3)
+    assert float(Jets.norm(x)) == pytest.approx(math.sqrt(3.0))
+    assert float(Jets.dot(x, x)) == 3.0
+    Jets.setblock_(x, 0, 9.0)                                               # no-op on an empty block
+    assert np.array_equal(x.to_numpy(), np.ones(3, dtype=np.float32))
+
+
+def test_errors_are_loud(Jets):
+    R = _bspace(Jets, np.float32, RAGGED)
+    x = Jets.zeros(R)
+    with pytest.raises(Jets.JetsHipError):
+        Jets.dot(x, Jets.zeros(Jets.JetSpace(np.float32, 5)))               # length mismatch
+    with pytest.raises(Jets.JetsHipError):
+        Jets.dot(x, Jets.zeros(_bspace(Jets, np.float64, RAGGED)))          # dtype mismatch
+    with pytest.raises(IndexError):
+        x[12]
+    with pytest.raises(IndexError):
+        Jets.getblock(x, 3)
