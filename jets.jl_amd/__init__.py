@@ -8,7 +8,7 @@ through the `jets_jl_amd` shim at the repository root:
     d = A * m;  mt = A.H * d
 
 Layers: `_ffi` (ctypes binding of include/jetship.h) -> `device`, `spaces`, `arrays` (BlockArray on
-one HIP slab) -> `jets` (Jet/Jop/mul!/composition/sums) -> `blockop` (JetBlock loops, fused launch).
+one HIP slab) -> `jets` (Jet/Jop/mul!/composition/sums) -> `jetblock` (JetBlock loops, fused launch).
 There is no CPU fallback: importing needs libjetship.so, computing needs a gfx950 device.
 """
 from ._ffi import JetsHipError, LIB_PATH  # noqa: F401
@@ -19,5 +19,5 @@ from .arrays import *  # noqa: F401,F403
 from .jets import *  # noqa: F401,F403
 from .jets import range_ as range  # noqa: F401,A001  Jets.range(A)
 from .jets import register_close, register_perfstat  # noqa: F401
-from .blockop import *  # noqa: F401,F403
+from .jetblock import *  # noqa: F401,F403
 from . import rowpart  # noqa: F401

@@ -261,7 +261,7 @@ def register_close(f: Callable, fn: Callable) -> None:
 
 def close(A):  # :290, 317, 591-595, 717-721, 1120-1124
     j = A if isinstance(A, Jet) else jet(A)
-    from . import blockop as _blk  # late import: blockop imports this module
+    from . import jetblock as _blk  # late import: blockop imports this module
 
     if j.f is JetComposite_f or j.f is JetSum_f:
         for op in j.s["ops"]:
@@ -280,7 +280,7 @@ def close(A):  # :290, 317, 591-595, 717-721, 1120-1124
 
 def point_(A, mo):  # :297-301, 578-589, 710-715, 1059-1066
     j = A if isinstance(A, Jet) else jet(A)
-    from . import blockop as _blk
+    from . import jetblock as _blk
 
     if j.f is JetComposite_f:  # :578-589
         j.mo = mo
@@ -370,7 +370,7 @@ def JetComposite_f(d, m, *, ops, **kw):  # :524-528  right-to-left chain through
 
 
 def JetComposite_df(d, m, *, ops, **kw):  # :530-534
-    from . import blockop as _blk
+    from . import jetblock as _blk
 
     fused = _blk.try_fused_normal(d, m, ops)
     if fused is not None:
@@ -383,7 +383,7 @@ def JetComposite_df(d, m, *, ops, **kw):  # :530-534
 
 
 def JetComposite_df_adj(m, d, *, ops, **kw):  # :536-540
-    from . import blockop as _blk
+    from . import jetblock as _blk
 
     fused = _blk.try_fused_normal(m, d, tuple(adjoint(JopLn(op)) for op in reversed(ops)))
     if fused is not None:
