@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-blocks", type=int, default=16)
     ap.add_argument("--cpu-pairs", type=int, default=4)
-    ap.add_argument("--tune", type=str, default="", help="k=v,k=v kernel knobs (fwd_group, fwd_unroll, adj_unroll, adj_depth, nt, wg)")
+    ap.add_argument("--tune", type=str, default="", help="k=v,k=v kernel knobs (fwd_group, fwd_unroll, fwd_wg, adj_unroll, adj_depth, adj_wg, nt; 0 = automatic)")
     ap.add_argument("--fused-normal", action="store_true", help="also time the fused A'A kernel (extra field, not the metric)")
     return ap.parse_args()
 
@@ -212,7 +212,7 @@ def main():
                 "workload": f"{nblocks}x1 tall JopBlock of diagonal JopLn, {edge}^3 Float32 blocks, fwd+adj mul! pair",
                 "nblocks": nblocks, "block": [edge, edge, edge], "rows_per_gpu": nloc,
                 "parallelism": f"row-partition x{world}" + (" + RCCL all-reduce(64 MiB) in adjoint" if world > 1 else ""),
-                "tune": {k: J.tune_get(k) for k in ("fwd_group", "fwd_unroll", "adj_unroll", "adj_depth", "nt", "wg")},
+                "tune": {k: J.tune_get(k) for k in ("fwd_group", "fwd_unroll", "fwd_wg", "adj_unroll", "adj_depth", "adj_wg", "nt")},
             },
             "achieved_GBps_pair": pair_bytes_global * pairs_per_s / 1e9,
             "roofline_frac_pair": pair_bytes_global * pairs_per_s / 1e9 / (HBM_PEAK_GBS * world),

@@ -270,13 +270,59 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
 }
 
 // ------------------------------------------------------------------ launch helpers ------------
+// Kernel shapes.  Measured on MI355X at 1024 x 256^3 Float32 (profiles/sweep_r01.txt): forward best at
+// 1024-thread workgroups x 8 vectors x 16 rows (6.04 TB/s), adjoint best at 1024 x 4 vectors x 4 rows
+// in flight (6.50 TB/s).  Smaller problems shrink the tile until the grid has >= ~8 workgroups per CU
+// worth of threads, so a 128^3 block still fills the chip.
+struct TallShape { int wg, unroll, aux; };   // aux = rows per workgroup (forward) / rows in flight (adjoint)
+
+TallShape pick_fwd_shape(int64_t nvec, int64_t nrow)
+{
+    jh_context &c = jh_ctx();
+    TallShape s{1024, 8, 16};
+    const int64_t want_threads = (int64_t)c.cu_count * 2048 * 4;       // 4 full waves of residency
+    auto threads = [&](const TallShape &t) {
+        int64_t tiles = (nvec + (int64_t)t.wg * t.unroll - 1) / ((int64_t)t.wg * t.unroll);
+        int64_t groups = (nrow + t.aux - 1) / t.aux;
+        return tiles * groups * t.wg;
+    };
+    while (threads(s) < want_threads) {
+        if (s.aux > 4) s.aux /= 2;
+        else if (s.unroll > 1) s.unroll /= 2;
+        else if (s.wg > 256) s.wg /= 2;
+        else if (s.aux > 1) s.aux /= 2;
+        else break;
+    }
+    if (c.fwd_wg) s.wg = (int)c.fwd_wg;
+    if (c.fwd_unroll) s.unroll = (int)c.fwd_unroll;
+    if (c.fwd_group) s.aux = (int)c.fwd_group;
+    return s;
+}
+
+TallShape pick_adj_shape(int64_t nvec)
+{
+    jh_context &c = jh_ctx();
+    TallShape s{1024, 4, 4};
+    const int64_t want_threads = (int64_t)c.cu_count * 2048;           // one full residency
+    while ((nvec + s.unroll - 1) / s.unroll < want_threads) {
+        if (s.unroll > 1) s.unroll /= 2;
+        else break;
+    }
+    if ((nvec + s.unroll - 1) / s.unroll < want_threads) s.wg = 256;   // finer workgroups balance better on small grids
+    if (c.adj_wg) s.wg = (int)c.adj_wg;
+    if (c.adj_unroll) s.unroll = (int)c.adj_unroll;
+    if (c.adj_depth) s.aux = (int)c.adj_depth;
+    if (s.unroll == 4 && s.aux == 8) s.aux = 4;                        // 4 x 8 is not instantiated (register budget)
+    return s;
+}
+
 template <typename S, int E, int NS, bool NT, int BLK>
-int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
+int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_scalars, const TallShape &sh)
 {
     jh_context &c = jh_ctx();
     const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
     const int64_t a_stride = op->diag_stride_elems * E;
-    int64_t G = c.fwd_group;
+    int64_t G = sh.aux;
     if (G > op->nrow) G = op->nrow;
     int64_t gy = (op->nrow + G - 1) / G;
     while (gy > 65535) { G *= 2; gy = (op->nrow + G - 1) / G; }
@@ -286,12 +332,12 @@ int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_sc
         hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, NT, BLK>), dim3((unsigned)gx, (unsigned)gy), dim3(BLK), 0,   \
                            c.stream, op->dev_blocks, op->nrow, (int)G, a_base, a_stride, (const S *)m, (S *)d, n_scalars); \
     } break;
-    switch (c.fwd_unroll) {
+    switch (sh.unroll) {
         JH_FWD_CASE(1)
         JH_FWD_CASE(2)
         JH_FWD_CASE(4)
         JH_FWD_CASE(8)
-    default: return jh_fail(JH_ERR_INVALID, "fwd_unroll %lld unsupported", (long long)c.fwd_unroll);
+    default: return jh_fail(JH_ERR_INVALID, "fwd_unroll %d unsupported", sh.unroll);
     }
 #undef JH_FWD_CASE
     JH_CHECK_HIP(hipGetLastError());
@@ -299,14 +345,14 @@ int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_sc
 }
 
 template <typename S, int E, int NS, bool NT, int MODE, int BLK>
-int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n_scalars)
+int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n_scalars, const TallShape &sh)
 {
     jh_context &c = jh_ctx();
     const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
     const int64_t a_stride = op->diag_stride_elems * E;
     const int direct = (op->nrow == 1 && MODE == 0) ? 1 : 0;
 #define JH_ADJ_CASE(U, DEPTH)                                                                                          \
-    if (c.adj_unroll == U && c.adj_depth == DEPTH) {                                                                   \
+    if (sh.unroll == U && sh.aux == DEPTH) {                                                                           \
         int64_t gx = (n_scalars + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                                \
         hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, NT, MODE, BLK>), dim3((unsigned)gx), dim3(BLK), 0,     \
                            c.stream, op->dev_blocks, op->nrow, a_base, a_stride, (S *)out, (const S *)in, n_scalars, direct); \
@@ -317,24 +363,26 @@ int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n
     JH_ADJ_CASE(2, 1) JH_ADJ_CASE(2, 2) JH_ADJ_CASE(2, 4) JH_ADJ_CASE(2, 8)
     JH_ADJ_CASE(4, 1) JH_ADJ_CASE(4, 2) JH_ADJ_CASE(4, 4)
 #undef JH_ADJ_CASE
-    return jh_fail(JH_ERR_INVALID, "adj_unroll %lld x adj_depth %lld unsupported", (long long)c.adj_unroll, (long long)c.adj_depth);
+    return jh_fail(JH_ERR_INVALID, "adj_unroll %d x adj_depth %d unsupported", sh.unroll, sh.aux);
 }
 
 template <typename S, int E, int NS>
 int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
 {
     jh_context &c = jh_ctx();
-    if (c.wg == 256) return c.nt ? launch_tall_fwd_u<S, E, NS, true, 256>(op, d, m, n_scalars) : launch_tall_fwd_u<S, E, NS, false, 256>(op, d, m, n_scalars);
-    if (c.wg == 512) return c.nt ? launch_tall_fwd_u<S, E, NS, true, 512>(op, d, m, n_scalars) : launch_tall_fwd_u<S, E, NS, false, 512>(op, d, m, n_scalars);
-    return c.nt ? launch_tall_fwd_u<S, E, NS, true, 1024>(op, d, m, n_scalars) : launch_tall_fwd_u<S, E, NS, false, 1024>(op, d, m, n_scalars);
+    const TallShape sh = pick_fwd_shape(n_scalars / NS, op->nrow);
+    if (sh.wg == 256) return c.nt ? launch_tall_fwd_u<S, E, NS, true, 256>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 256>(op, d, m, n_scalars, sh);
+    if (sh.wg == 512) return c.nt ? launch_tall_fwd_u<S, E, NS, true, 512>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 512>(op, d, m, n_scalars, sh);
+    return c.nt ? launch_tall_fwd_u<S, E, NS, true, 1024>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 1024>(op, d, m, n_scalars, sh);
 }
 template <typename S, int E, int NS, int MODE>
 int launch_tall_adj(const jh_blockop *op, void *out, const void *in, int64_t n_scalars)
 {
     jh_context &c = jh_ctx();
-    if (c.wg == 256) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 256>(op, out, in, n_scalars) : launch_tall_adj_u<S, E, NS, false, MODE, 256>(op, out, in, n_scalars);
-    if (c.wg == 512) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 512>(op, out, in, n_scalars) : launch_tall_adj_u<S, E, NS, false, MODE, 512>(op, out, in, n_scalars);
-    return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 1024>(op, out, in, n_scalars) : launch_tall_adj_u<S, E, NS, false, MODE, 1024>(op, out, in, n_scalars);
+    const TallShape sh = pick_adj_shape(n_scalars / NS);
+    if (sh.wg == 256) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 256>(op, out, in, n_scalars, sh) : launch_tall_adj_u<S, E, NS, false, MODE, 256>(op, out, in, n_scalars, sh);
+    if (sh.wg == 512) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 512>(op, out, in, n_scalars, sh) : launch_tall_adj_u<S, E, NS, false, MODE, 512>(op, out, in, n_scalars, sh);
+    return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 1024>(op, out, in, n_scalars, sh) : launch_tall_adj_u<S, E, NS, false, MODE, 1024>(op, out, in, n_scalars, sh);
 }
 
 // fast path usable?  (tall, all DIAG, uniform rows, 16-byte aligned everything, no conj flags on complex)

@@ -1,5 +1,6 @@
 // jh_core.hip -- context, device block vectors (slabs), copies, events.  gfx950 only.
 #include "jh_internal.h"
+#include <initializer_list>
 
 static thread_local char g_err[512] = "";
 
@@ -366,12 +367,14 @@ int jh_tune_set(const char *name, int64_t value)
 {
     JH_REQUIRE(name, "jh_tune_set: null name");
     jh_context &c = jh_ctx();
-    if (!strcmp(name, "fwd_group")) { JH_REQUIRE(value >= 1 && value <= 65536, "fwd_group out of range"); c.fwd_group = value; }
-    else if (!strcmp(name, "fwd_unroll")) { JH_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, "fwd_unroll must be 1, 2, 4 or 8"); c.fwd_unroll = value; }
-    else if (!strcmp(name, "adj_unroll")) { JH_REQUIRE(value == 1 || value == 2 || value == 4, "adj_unroll must be 1, 2 or 4"); c.adj_unroll = value; }
-    else if (!strcmp(name, "adj_depth")) { JH_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, "adj_depth must be 1, 2, 4 or 8"); c.adj_depth = value; }
+    auto one_of = [&](std::initializer_list<int64_t> ok) { for (int64_t v : ok) if (v == value) return true; return false; };
+    if (!strcmp(name, "fwd_group")) { JH_REQUIRE(value >= 0 && value <= 65536, "fwd_group out of range"); c.fwd_group = value; }
+    else if (!strcmp(name, "fwd_unroll")) { JH_REQUIRE(one_of({0, 1, 2, 4, 8}), "fwd_unroll must be 0 (auto), 1, 2, 4 or 8"); c.fwd_unroll = value; }
+    else if (!strcmp(name, "fwd_wg")) { JH_REQUIRE(one_of({0, 256, 512, 1024}), "fwd_wg must be 0 (auto), 256, 512 or 1024"); c.fwd_wg = value; }
+    else if (!strcmp(name, "adj_unroll")) { JH_REQUIRE(one_of({0, 1, 2, 4}), "adj_unroll must be 0 (auto), 1, 2 or 4"); c.adj_unroll = value; }
+    else if (!strcmp(name, "adj_depth")) { JH_REQUIRE(one_of({0, 1, 2, 4, 8}), "adj_depth must be 0 (auto), 1, 2, 4 or 8"); c.adj_depth = value; }
+    else if (!strcmp(name, "adj_wg")) { JH_REQUIRE(one_of({0, 256, 512, 1024}), "adj_wg must be 0 (auto), 256, 512 or 1024"); c.adj_wg = value; }
     else if (!strcmp(name, "nt")) { c.nt = value ? 1 : 0; }
-    else if (!strcmp(name, "wg")) { JH_REQUIRE(value == 256 || value == 512 || value == 1024, "wg must be 256, 512 or 1024"); c.wg = value; }
     else return jh_fail(JH_ERR_INVALID, "jh_tune_set: unknown knob '%s'", name);
     return JH_OK;
 }
@@ -382,10 +385,11 @@ int jh_tune_get(const char *name, int64_t *value)
     jh_context &c = jh_ctx();
     if (!strcmp(name, "fwd_group")) *value = c.fwd_group;
     else if (!strcmp(name, "fwd_unroll")) *value = c.fwd_unroll;
+    else if (!strcmp(name, "fwd_wg")) *value = c.fwd_wg;
     else if (!strcmp(name, "adj_unroll")) *value = c.adj_unroll;
     else if (!strcmp(name, "adj_depth")) *value = c.adj_depth;
+    else if (!strcmp(name, "adj_wg")) *value = c.adj_wg;
     else if (!strcmp(name, "nt")) *value = c.nt;
-    else if (!strcmp(name, "wg")) *value = c.wg;
     else return jh_fail(JH_ERR_INVALID, "jh_tune_get: unknown knob '%s'", name);
     return JH_OK;
 }

@@ -37,12 +37,14 @@ struct jh_context {
     double *red_dev = nullptr;         // JH_RED_SLOTS * 4 doubles
     double *red_host = nullptr;        // pinned, 8 doubles
     // tuning knobs (jh_tune_set)
-    int64_t fwd_group = 16;            // blocks per workgroup in the tall forward kernel
-    int64_t fwd_unroll = 4;            // 16-byte vectors per thread per block (tall forward)
-    int64_t adj_unroll = 2;            // 16-byte vectors per thread (tall adjoint)
-    int64_t adj_depth = 4;             // blocks in flight per thread (tall adjoint)
+    // 0 = pick from the problem size (jh_blockop.hip: pick_fwd_shape / pick_adj_shape)
+    int64_t fwd_group = 0;             // block rows streamed per workgroup (tall forward)
+    int64_t fwd_unroll = 0;            // 16-byte vectors per thread per block (tall forward)
+    int64_t fwd_wg = 0;                // threads per workgroup (tall forward)
+    int64_t adj_unroll = 0;            // 16-byte vectors per thread (tall adjoint / fused normal)
+    int64_t adj_depth = 0;             // block rows in flight per thread (tall adjoint / fused normal)
+    int64_t adj_wg = 0;                // threads per workgroup (tall adjoint / fused normal)
     int64_t nt = 1;                    // nontemporal loads/stores on the streamed operands
-    int64_t wg = 256;                  // threads per workgroup in the tall kernels
 };
 jh_context &jh_ctx();
 int jh_require_ready();

@@ -99,8 +99,8 @@ class Event:
 
 
 def tune(**knobs) -> None:
-    """Kernel-shape knobs of the tall fast path (bench/tests): fwd_group, fwd_unroll, adj_unroll,
-    adj_depth, nt, wg."""
+    """Kernel-shape knobs of the tall fast path (bench/tests): fwd_group, fwd_unroll, fwd_wg, adj_unroll,
+    adj_depth, adj_wg (0 = pick from the problem size) and nt."""
     for k, v in knobs.items():
         check(lib.jh_tune_set(k.encode(), int(v)))
 
