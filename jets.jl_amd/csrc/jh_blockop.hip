@@ -57,17 +57,22 @@ template <typename S, int E, int NS, typename V> __device__ inline V vmul(V a, V
 }
 
 // ------------------------------------------------------------------ tall fast path ------------
-// grid.x = element tiles, grid.y = row groups.  n_scalars % NS == 0.
+// 1-D grid of ntiles * ngroups workgroups.  order 0: tile index fastest (the chip sweeps one block row
+// at a time, fully sequential HBM streams); order 1: row group fastest (workgroups sharing an m tile are
+// dispatched together, so the tile is re-read from L2/MALL instead of HBM).  n_scalars % NS == 0.
 template <typename S, int E, int NS, int U, bool NT, int BLK>
 __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__restrict__ blocks, int64_t nrow, int rows_per_wg,
                                                        const S *__restrict__ a_base, int64_t a_stride,
-                                                       const S *__restrict__ m, S *__restrict__ d, int64_t n_scalars)
+                                                       const S *__restrict__ m, S *__restrict__ d, int64_t n_scalars,
+                                                       unsigned ntiles, unsigned ngroups, int order)
 {
     typedef typename vec_of<S, NS>::type V;
-    const int64_t s0 = ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
-    const int64_t i0 = (int64_t)blockIdx.y * rows_per_wg;
+    const unsigned tile = order ? blockIdx.x / ngroups : blockIdx.x % ntiles;
+    const unsigned grp = order ? blockIdx.x % ngroups : blockIdx.x / ntiles;
+    const int64_t s0 = ((int64_t)tile * U * BLK + threadIdx.x) * NS;
+    const int64_t i0 = (int64_t)grp * rows_per_wg;
     const int64_t i1 = (i0 + rows_per_wg < nrow) ? i0 + rows_per_wg : nrow;
-    const bool full = ((int64_t)(blockIdx.x + 1) * U * BLK * NS) <= n_scalars;
+    const bool full = ((int64_t)(tile + 1) * U * BLK * NS) <= n_scalars;
     V mv[U];
     if (full) {
 #pragma unroll
@@ -324,13 +329,14 @@ int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     const int64_t a_stride = op->diag_stride_elems * E;
     int64_t G = sh.aux;
     if (G > op->nrow) G = op->nrow;
-    int64_t gy = (op->nrow + G - 1) / G;
-    while (gy > 65535) { G *= 2; gy = (op->nrow + G - 1) / G; }
+    const int64_t gy = (op->nrow + G - 1) / G;
 #define JH_FWD_CASE(U)                                                                                               \
     case U: {                                                                                                         \
         int64_t gx = (n_scalars + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                               \
-        hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, NT, BLK>), dim3((unsigned)gx, (unsigned)gy), dim3(BLK), 0,   \
-                           c.stream, op->dev_blocks, op->nrow, (int)G, a_base, a_stride, (const S *)m, (S *)d, n_scalars); \
+        JH_REQUIRE(gx * gy < (int64_t)1 << 31, "tall forward: grid of %lld workgroups is too large", (long long)(gx * gy)); \
+        hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, NT, BLK>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, \
+                           op->dev_blocks, op->nrow, (int)G, a_base, a_stride, (const S *)m, (S *)d, n_scalars,      \
+                           (unsigned)gx, (unsigned)gy, (int)c.fwd_order);                                            \
     } break;
     switch (sh.unroll) {
         JH_FWD_CASE(1)

@@ -1,0 +1,71 @@
+"""CPU: the C-ABI library loads, exports every symbol include/jetship.h declares, and fails loudly
+without a GPU.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "jetship.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"^\s*(?:int|const char \*)\s*(jh_\w+)\s*\(", text, flags=re.M)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = declared_symbols()
+    for must in ("jh_init", "jh_last_error", "jh_bvec_create", "jh_getblock_copy", "jh_setblock_copy", "jh_setblock_fill",
+                 "jh_fill", "jh_dot", "jh_norm", "jh_extrema", "jh_lincomb", "jh_blockop_create", "jh_blockop_mul",
+                 "jh_blockop_mul_adj", "jh_blockop_normal_mul"):
+        assert must in syms
+    assert len(syms) >= 35
+
+
+def test_library_exports_every_declared_symbol():
+    import jets_jl_amd as J
+    from jets_jl_amd._ffi import SYMBOLS
+
+    handle = C.CDLL(J.LIB_PATH)
+    declared = declared_symbols()
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/jetship.h but not exported by libjetship.so"
+    assert sorted(SYMBOLS) == declared, "jets.jl_amd/_ffi.py must bind exactly the symbols the header declares"
+    assert handle.jh_abi_version() == 1
+
+
+def test_header_cites_the_reference_for_every_entry_point_group():
+    text = open(HEADER).read()
+    assert text.count("src/Jets.jl:") >= 25
+    for anchor in ("1010-1032", "1034-1057", "834-848", "850-856", "870-878", "880-885", "914", "915", "916", "1112", "530-534"):
+        assert anchor in text, f"include/jetship.h should cite src/Jets.jl:{anchor}"
+
+
+def test_fails_loudly_without_a_gpu():
+    import jets_jl_amd as J
+    from jets_jl_amd._ffi import lib
+
+    n = C.c_int(-1)
+    rc = lib.jh_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is visible; the no-GPU failure mode is checked on CPU-only boxes")
+    with pytest.raises(J.JetsHipError):
+        J.init(0)
+    h = C.c_void_p()
+    lens = (C.c_int64 * 1)(4)
+    rc = lib.jh_bvec_create(1, lens, 0, C.byref(h))
+    assert rc == 5 and b"jh_init" in lib.jh_last_error()            # JH_ERR_STATE, nothing allocated on the host instead
+    with pytest.raises(J.JetsHipError):
+        J.zeros(J.JetSpace("float32", 4))
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "jets.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "jets_oracle" not in src and "libjets_oracle" not in src and "from oracle" not in src, f"{f} references the oracle"

@@ -1,0 +1,132 @@
+"""Golden fixtures (tests/golden/jets_block_path_v1.npz, made by tests/golden/make_golden.py).
+
+CPU: the oracle still reproduces every stored output bit for bit (regression pin on the checker).
+GPU: the HIP path, fed the stored INPUTS through the C ABI, reproduces the stored outputs bit for
+bit (reductions: within the stated tolerance).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from .helpers import assert_bits_equal
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "jets_block_path_v1.npz"))
+
+TALL = [("tall_f32", np.float32), ("tall_f64", np.float64), ("tall_c32", np.complex64), ("tall_c64", np.complex128)]
+MIXED = [("mixed_f64", np.float64), ("mixed_c32", np.complex64)]
+VEC = [("vec_f32", np.float32), ("vec_c64", np.complex128)]
+
+
+def _split(flat, lens):
+    offs = np.cumsum([0] + list(lens))
+    return [np.ascontiguousarray(flat[offs[i]:offs[i + 1]]) for i in range(len(lens))]
+
+
+# ------------------------------------------------------------------ CPU: oracle vs fixtures
+@pytest.mark.parametrize("tag,dt", TALL)
+def test_oracle_reproduces_tall_fixtures(oracle, tag, dt):
+    a, m, d = G[f"{tag}_a"], G[f"{tag}_m"], G[f"{tag}_d"]
+    assert a.dtype == np.dtype(dt)
+    nrow, n = a.shape
+    ops = [[oracle.Block("diag", n, coeff=np.ascontiguousarray(a[i]))] for i in range(nrow)]
+    fwd = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [m])
+    assert_bits_equal(np.stack(fwd), G[f"{tag}_fwd"], f"{tag} forward")
+    adj = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], [np.ascontiguousarray(d[i]) for i in range(nrow)])
+    assert_bits_equal(adj[0], G[f"{tag}_adj"], f"{tag} adjoint")
+    assert_bits_equal(oracle.normal_df(ops, [np.zeros(n, dtype=dt)], [m])[0], G[f"{tag}_normal"], f"{tag} normal")
+
+
+@pytest.mark.parametrize("tag,dt", MIXED)
+def test_oracle_reproduces_mixed_fixtures(oracle, tag, dt):
+    from .golden.make_golden import mixed_blocks
+
+    coeffs, m, d, d0 = G[f"{tag}_coeffs"], G[f"{tag}_m"], G[f"{tag}_d"], G[f"{tag}_d0"]
+    n = m.shape[1]
+    ops = mixed_blocks(dt, n, coeffs)
+    ms = [np.ascontiguousarray(m[j]) for j in range(4)]
+    fwd = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(3)], ms)
+    assert_bits_equal(np.stack(fwd), G[f"{tag}_fwd"], f"{tag} forward")
+    dirty = oracle.block_df(ops, [d0[i].copy() for i in range(3)], ms)
+    assert_bits_equal(np.stack(dirty), G[f"{tag}_fwd_dirty"], f"{tag} forward into dirty d")
+    adj = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt) for _ in range(4)], [np.ascontiguousarray(d[i]) for i in range(3)])
+    assert_bits_equal(np.stack(adj), G[f"{tag}_adj"], f"{tag} adjoint")
+
+
+@pytest.mark.parametrize("tag,dt", VEC)
+def test_oracle_reproduces_vector_fixtures(oracle, tag, dt):
+    lens = G[f"{tag}_lens"]
+    u, v, w = (_split(G[f"{tag}_{k}"], lens) for k in "uvw")
+    x = oracle.barr_lincomb([np.empty_like(t) for t in u], list(G[f"{tag}_coef"]), [u, v, w])
+    assert_bits_equal(np.concatenate(x), G[f"{tag}_x"], f"{tag} lincomb")
+    for p, want in zip(G[f"{tag}_norm_p"], G[f"{tag}_norms"]):
+        assert oracle.barr_norm(u, float(p)) == want
+    dv = oracle.barr_dot(u, v)
+    assert (np.real(dv), np.imag(dv)) == tuple(G[f"{tag}_dot"])
+
+
+# ------------------------------------------------------------------ GPU: HIP path vs fixtures
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,dt", TALL)
+def test_hip_reproduces_tall_fixtures(Jets, tag, dt):
+    a, m, d = G[f"{tag}_a"], G[f"{tag}_m"], G[f"{tag}_d"]
+    nrow, n = a.shape
+    diags = [Jets.from_numpy(a[i]) for i in range(nrow)]
+    A = Jets.blockop([[Jets.JopDiagonal(g)] for g in diags])
+    dm = Jets.from_numpy(m)
+    assert_bits_equal((A * dm).to_numpy(), G[f"{tag}_fwd"].ravel(), f"{tag} forward")
+    dd = Jets.from_numpy(d.ravel(), Jets.range(A))
+    assert_bits_equal((A.H * dd).to_numpy(), G[f"{tag}_adj"], f"{tag} adjoint")
+    assert_bits_equal(((A.H @ A) * dm).to_numpy(), G[f"{tag}_normal"], f"{tag} fused normal")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,dt", MIXED)
+def test_hip_reproduces_mixed_fixtures(Jets, tag, dt):
+    from .golden.make_golden import MIXED_KINDS
+
+    coeffs, m, d, d0 = G[f"{tag}_coeffs"], G[f"{tag}_m"], G[f"{tag}_d"], G[f"{tag}_d0"]
+    n = m.shape[1]
+    spc = Jets.JetSpace(dt, n)
+    rows = []
+    for i, row in enumerate(MIXED_KINDS):
+        r = []
+        for j, k in enumerate(row):
+            if k == "zero":
+                r.append(Jets.JopZeroBlock(spc, spc))
+            elif k == "identity":
+                r.append(Jets.JopIdentity(spc))
+            elif k == "scale":
+                a = (0.5 + i) - (0.25j * (j + 1) if np.dtype(dt).kind == "c" else 0)
+                r.append(Jets.JopLn(dom=spc, rng=spc, df=Jets.constdiag_df, df_adj=Jets.constdiag_df_adj, s={"a": a}))
+            else:
+                op = Jets.JopDiagonal(Jets.from_numpy(coeffs[i, j]))
+                r.append(op.H if k == "diag_adj" else op)
+        rows.append(r)
+    A = Jets.blockop(rows)
+    dm = Jets.from_numpy(m.ravel(), Jets.domain(A))
+    assert_bits_equal((A * dm).to_numpy(), G[f"{tag}_fwd"].ravel(), f"{tag} forward")
+    dirty = Jets.mul_(Jets.from_numpy(d0.ravel(), Jets.range(A)), A, dm)
+    assert_bits_equal(dirty.to_numpy(), G[f"{tag}_fwd_dirty"].ravel(), f"{tag} forward into dirty d")
+    dd = Jets.from_numpy(d.ravel(), Jets.range(A))
+    assert_bits_equal((A.H * dd).to_numpy(), G[f"{tag}_adj"].ravel(), f"{tag} adjoint")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,dt", VEC)
+def test_hip_reproduces_vector_fixtures(Jets, tag, dt):
+    lens = [int(k) for k in G[f"{tag}_lens"]]
+    R = Jets.JetBSpace([Jets.JetSpace(dt, k) for k in lens])
+    u, v, w = (Jets.from_numpy(G[f"{tag}_{k}"], R) for k in "uvw")
+    c = list(G[f"{tag}_coef"])
+    x = (c[0] * u + c[1] * v + c[2] * w).materialize()
+    assert_bits_equal(x.to_numpy(), G[f"{tag}_x"], f"{tag} lincomb")
+    tol = 1e-5 if np.dtype(dt) == np.dtype(np.float32) else 1e-12
+    for p, want in zip(G[f"{tag}_norm_p"], G[f"{tag}_norms"]):
+        assert float(Jets.norm(u, float(p))) == pytest.approx(float(want), rel=10 * tol)
+    dv = complex(Jets.dot(u, v))
+    want = complex(*G[f"{tag}_dot"])
+    assert abs(dv - want) <= 10 * tol * abs(want)
+    if np.dtype(dt).kind != "c":
+        assert tuple(float(t) for t in Jets.extrema(u)) == tuple(G[f"{tag}_extrema"])

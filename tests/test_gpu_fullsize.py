@@ -1,0 +1,103 @@
+"""GPU parity at BASELINE.json's full sizes.
+
+configs[1]  (64x1, 128^3 Float32): the whole forward and adjoint are compared bit for bit with the
+            CPU oracle (512 MiB per vector; the oracle finishes in seconds).
+configs[3]  (1024x1, 256^3 Float32; 64 GiB of coefficients + 64 GiB range vector, cannot be held on a
+            host): inputs are generated on the device by the counter-based generator and checked
+            through size-independent properties --
+              * slices of the forward / adjoint / fused-normal results vs the oracle run on the
+                regenerated slices of the inputs (bit-exact; the adjoint slice sums all 1024 rows in order),
+              * the dot-product test (src/Jets.jl:1211-1226) at |lhs-rhs|/|lhs+rhs| < 1e-5,
+              * fused A'A == chained A'(A m) on the whole vector (max |difference| == 0),
+              * norm/dot of the 2^34-element range vector vs closed-form expectations of U[0,1).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from .helpers import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(Jets, nblocks, edge):
+    blk = Jets.JetSpace(np.float32, edge, edge, edge)
+    coeff = Jets.rand(Jets.JetBSpace([blk] * nblocks), seed=1, stream=0)
+    A = Jets.blockop([[Jets.JopDiagonal(c)] for c in coeff.arrays])
+    m = Jets.rand(Jets.domain(A), seed=2, stream=0)
+    d = Jets.rand(Jets.range(A), seed=3, stream=0)
+    return A, coeff, m, d
+
+
+def test_config2_64x128cubed_whole_vectors_bit_exact(Jets, oracle):
+    nblocks, edge = 64, 128
+    n = edge ** 3
+    A, coeff, m, d = _build(Jets, nblocks, edge)
+    ha = [oracle.rng_u01(np.float32, 1, 0, i * n, n) for i in range(nblocks)]
+    hm = oracle.rng_u01(np.float32, 2, 0, 0, n)
+    hd = [oracle.rng_u01(np.float32, 3, 0, i * n, n) for i in range(nblocks)]
+    ops = [[oracle.Block("diag", n, coeff=g)] for g in ha]
+    mt = Jets.mul_(Jets.zeros(Jets.domain(A)), A.H, d)
+    ref_m = oracle.block_df_adj(ops, [np.zeros(n, dtype=np.float32)], hd)
+    assert_bits_equal(mt.to_numpy().ravel(order="F"), ref_m[0], "adjoint, 64 x 128^3")
+    out = Jets.mul_(d, A, m)
+    ref_d = oracle.block_df(ops, hd, [hm])                                  # overwrites hd in place
+    assert_bits_equal(out.to_numpy(), np.concatenate(ref_d), "forward, 64 x 128^3")
+    lhs, rhs = Jets.dot_product_test(A, m, Jets.rand(Jets.range(A), seed=3, stream=1))
+    assert abs(lhs - rhs) / abs(lhs + rhs) < 1e-5
+
+
+def test_config4_1024x256cubed_properties(Jets, oracle):
+    info = Jets.device_info()
+    if info["free_mem"] < 200 * 2 ** 30:
+        pytest.skip(f"needs ~195 GiB of free HBM (coefficients, range vector and a second range vector), device reports {info['free_mem'] / 2**30:.0f} GiB")
+    nblocks, edge = 1024, 256
+    n = edge ** 3
+    A, coeff, m, d = _build(Jets, nblocks, edge)
+    assert Jets.range(A).length() == 2 ** 34
+
+    # --- reductions over 2^34 elements of U[0,1): E[x] = 1/2, E[x^2] = 1/3, E[xy] = 1/4
+    N = float(2 ** 34)
+    assert float(Jets.norm(d, 1)) == pytest.approx(N / 2, rel=1e-4)
+    assert float(Jets.norm(d, 2)) == pytest.approx(math.sqrt(N / 3), rel=1e-4)
+    assert float(Jets.dot(d, coeff)) == pytest.approx(N / 4, rel=1e-4)
+    assert float(Jets.norm(d, math.inf)) < 1.0 and Jets.extrema(d)[0] >= 0.0
+
+    # --- adjoint slices: all 1024 rows summed in order, bit-exact vs the oracle on regenerated slices
+    mt = Jets.mul_(Jets.zeros(Jets.domain(A)), A.H, d)
+    W = 4096
+    for off in (0, 12345 * 4, n // 2 + 64, n - W):
+        ha = [oracle.rng_u01(np.float32, 1, 0, i * n + off, W) for i in range(nblocks)]
+        hd = [oracle.rng_u01(np.float32, 3, 0, i * n + off, W) for i in range(nblocks)]
+        ops = [[oracle.Block("diag", W, coeff=g)] for g in ha]
+        ref = oracle.block_df_adj(ops, [np.zeros(W, dtype=np.float32)], hd)[0]
+        assert_bits_equal(mt._download(off, W), ref, f"adjoint slice at {off}")
+
+    # --- dot-product test with the SAME d (before the forward overwrites it)
+    md = float(Jets.dot(m, mt))                                              # <m, A'd>
+
+    # --- fused A'A == chained, whole vector, and a slice vs the oracle
+    y_fused = Jets.mul(A.H @ A, m)
+    hm0 = oracle.rng_u01(np.float32, 2, 0, 0, W)
+    ha0 = [oracle.rng_u01(np.float32, 1, 0, i * n, W) for i in range(nblocks)]
+    ref_y = oracle.normal_df([[oracle.Block("diag", W, coeff=g)] for g in ha0], [np.zeros(W, dtype=np.float32)], [hm0])[0]
+    assert_bits_equal(y_fused._download(0, W), ref_y, "fused normal slice")
+
+    # --- forward (overwrites d), slices of several rows vs the oracle
+    dcopy_first = d._download(0, W)                                          # to prove the forward overwrote it
+    Jets.mul_(d, A, m)
+    for i in (0, 1, 511, 1023):
+        for off in (0, n // 3 // 4 * 4, n - W):
+            ha = oracle.rng_u01(np.float32, 1, 0, i * n + off, W)
+            hm = oracle.rng_u01(np.float32, 2, 0, off, W)
+            assert_bits_equal(d._download(i * n + off, W), ha * hm, f"forward row {i} slice at {off}")
+    assert not np.array_equal(d._download(0, W), dcopy_first)
+    y_chain = Jets.mul_(Jets.zeros(Jets.domain(A)), A.H, d)
+    diff = (y_fused - y_chain).materialize()
+    assert float(Jets.norm(diff, math.inf)) == 0.0                           # bit-identical on all 2^24 elements
+
+    # --- dot-product test: <A m, d0> == <m, A' d0>, with d0 regenerated into the coefficient-free spare
+    d0 = Jets.rand(Jets.range(A), seed=3, stream=0)                          # needs a third 64 GiB slab
+    lhs = float(Jets.dot(d, d0))                                             # <A m, d0>
+    assert abs(lhs - md) / abs(lhs + md) < 1e-5
