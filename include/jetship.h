@@ -147,7 +147,7 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d);
  * once and the range-side intermediate is never materialised.  Same rounding sequence as the
  * unfused pair, so the result is bit-identical to jh_blockop_mul followed by jh_blockop_mul_adj. */
 int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m);
-/* kernel-shape tuning knobs (bench/tests only): 0 = automatic; name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg","fwd_order","nt"} */
+/* kernel-shape tuning knobs (bench/tests only): 0 = automatic (fwd_order: -1); name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg","fwd_order","nt"} */
 int jh_tune_set(const char *name, int64_t value);
 int jh_tune_get(const char *name, int64_t *value);
 

@@ -41,6 +41,7 @@ class _DevVec:
 
     _h = None
     _owner = None  # keeps the parent alive for views / wraps
+    __array_ufunc__ = None  # numpy scalars defer to __rmul__ / __radd__ instead of iterating the vector
 
     @property
     def handle(self):
@@ -106,6 +107,9 @@ class _DevVec:
     def __add__(self, other):
         return LinExpr([(1.0, self)]) + other
 
+    def __radd__(self, other):
+        return other + LinExpr([(1.0, self)]) if isinstance(other, LinExpr) else NotImplemented
+
     def __sub__(self, other):
         return LinExpr([(1.0, self)]) - other
 
@@ -125,6 +129,8 @@ class _DevVec:
 class LinExpr:
     """Lazy `c1*x1 .+ c2*x2 .+ ...` (the Broadcasted tree of src/Jets.jl:889-911, restricted to linear
     combinations); evaluated left to right in one fused kernel by `assign` / `materialize`."""
+
+    __array_ufunc__ = None
 
     def __init__(self, terms):
         self.terms = list(terms)

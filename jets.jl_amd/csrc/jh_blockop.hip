@@ -275,49 +275,47 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
 }
 
 // ------------------------------------------------------------------ launch helpers ------------
-// Kernel shapes.  Measured on MI355X at 1024 x 256^3 Float32 (profiles/sweep_r01.txt): forward best at
-// 1024-thread workgroups x 8 vectors x 16 rows (6.04 TB/s), adjoint best at 1024 x 4 vectors x 4 rows
-// in flight (6.50 TB/s).  Smaller problems shrink the tile until the grid has >= ~8 workgroups per CU
-// worth of threads, so a 128^3 block still fills the chip.
-struct TallShape { int wg, unroll, aux; };   // aux = rows per workgroup (forward) / rows in flight (adjoint)
+// Kernel shapes, fitted to interleaved sweeps on MI355X (profiles/sweep_r01*.txt; Float32):
+//   forward  1024 x 256^3 (128 GiB): row-group-fastest order, 2 rows x 1 vector x 512 threads   6.37 TB/s
+//            (tile-fastest order, the first design: 6.04 TB/s -- it re-reads the m tile from HBM)
+//            64 x 128^3, 1024 x 64^3 (1-2 GiB): tile-fastest, 2 rows x 1 vector x 256 threads   6.43 TB/s
+//            16 x 256^3: tile-fastest, 4 rows x 4 vectors x 256 threads                          6.26 TB/s
+//   adjoint  wants FEW, FAT workgroups: 4 vectors per thread as long as >= 256 workgroups remain
+//            (1024 x 256^3: 6.50 TB/s at 1024 threads; 64 x 128^3: 7.1 TB/s; 1024 x 64^3: 1 vector, 7.1 TB/s)
+//   fused A'A reads one stream, so it keeps twice the rows in flight.
+struct TallShape { int wg, unroll, aux, order; };   // aux = rows per workgroup (forward) / rows in flight (adjoint)
 
-TallShape pick_fwd_shape(int64_t nvec, int64_t nrow)
+TallShape pick_fwd_shape(int64_t nvec, int64_t nrow, size_t vec_bytes)
 {
     jh_context &c = jh_ctx();
-    TallShape s{1024, 8, 16};
-    const int64_t want_threads = (int64_t)c.cu_count * 2048 * 4;       // 4 full waves of residency
-    auto threads = [&](const TallShape &t) {
-        int64_t tiles = (nvec + (int64_t)t.wg * t.unroll - 1) / ((int64_t)t.wg * t.unroll);
-        int64_t groups = (nrow + t.aux - 1) / t.aux;
-        return tiles * groups * t.wg;
-    };
-    while (threads(s) < want_threads) {
-        if (s.aux > 4) s.aux /= 2;
-        else if (s.unroll > 1) s.unroll /= 2;
-        else if (s.wg > 256) s.wg /= 2;
-        else if (s.aux > 1) s.aux /= 2;
-        else break;
-    }
+    const double stream_bytes = 2.0 * (double)nrow * (double)nvec * (double)vec_bytes;   // a read + d written
+    TallShape s;
+    if (stream_bytes >= 8.0 * (double)(1ull << 30)) s = TallShape{512, 1, 2, 1};          // far beyond the 256 MiB MALL
+    else if (nvec >= (int64_t)1 << 21) s = TallShape{256, 4, 4, 0};
+    else s = TallShape{256, 1, 2, 0};
     if (c.fwd_wg) s.wg = (int)c.fwd_wg;
     if (c.fwd_unroll) s.unroll = (int)c.fwd_unroll;
     if (c.fwd_group) s.aux = (int)c.fwd_group;
+    if (c.fwd_order >= 0) s.order = (int)c.fwd_order;
     return s;
 }
 
-TallShape pick_adj_shape(int64_t nvec)
+TallShape pick_adj_shape(int64_t nvec, int64_t nrow, int mode)
 {
     jh_context &c = jh_ctx();
-    TallShape s{1024, 4, 4};
-    const int64_t want_threads = (int64_t)c.cu_count * 2048;           // one full residency
-    while ((nvec + s.unroll - 1) / s.unroll < want_threads) {
-        if (s.unroll > 1) s.unroll /= 2;
-        else break;
+    TallShape s{256, 1, 4, 0};
+    if (nvec >= 4 * 256 * 256) s.unroll = 4;
+    else if (nvec >= 2 * 256 * 256) s.unroll = 2;
+    if (s.unroll == 4) s.aux = (nrow >= 256) ? 4 : 2;
+    if (nvec >= ((int64_t)1 << 22) && nrow >= 256) s.wg = 1024;
+    if (mode == 1) {                                   // fused normal operator: one input stream
+        s.aux = (s.unroll == 4) ? 4 : 8;
+        if (nvec >= ((int64_t)1 << 22)) s.wg = 1024;
     }
-    if ((nvec + s.unroll - 1) / s.unroll < want_threads) s.wg = 256;   // finer workgroups balance better on small grids
     if (c.adj_wg) s.wg = (int)c.adj_wg;
     if (c.adj_unroll) s.unroll = (int)c.adj_unroll;
     if (c.adj_depth) s.aux = (int)c.adj_depth;
-    if (s.unroll == 4 && s.aux == 8) s.aux = 4;                        // 4 x 8 is not instantiated (register budget)
+    if (s.unroll == 4 && s.aux == 8) s.aux = 4;        // 4 x 8 is not instantiated (register budget)
     return s;
 }
 
@@ -336,7 +334,7 @@ int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_sc
         JH_REQUIRE(gx * gy < (int64_t)1 << 31, "tall forward: grid of %lld workgroups is too large", (long long)(gx * gy)); \
         hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, NT, BLK>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, \
                            op->dev_blocks, op->nrow, (int)G, a_base, a_stride, (const S *)m, (S *)d, n_scalars,      \
-                           (unsigned)gx, (unsigned)gy, (int)c.fwd_order);                                            \
+                           (unsigned)gx, (unsigned)gy, sh.order);                                            \
     } break;
     switch (sh.unroll) {
         JH_FWD_CASE(1)
@@ -376,7 +374,7 @@ template <typename S, int E, int NS>
 int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
 {
     jh_context &c = jh_ctx();
-    const TallShape sh = pick_fwd_shape(n_scalars / NS, op->nrow);
+    const TallShape sh = pick_fwd_shape(n_scalars / NS, op->nrow, sizeof(S) * NS);
     if (sh.wg == 256) return c.nt ? launch_tall_fwd_u<S, E, NS, true, 256>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 256>(op, d, m, n_scalars, sh);
     if (sh.wg == 512) return c.nt ? launch_tall_fwd_u<S, E, NS, true, 512>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 512>(op, d, m, n_scalars, sh);
     return c.nt ? launch_tall_fwd_u<S, E, NS, true, 1024>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 1024>(op, d, m, n_scalars, sh);
@@ -385,7 +383,7 @@ template <typename S, int E, int NS, int MODE>
 int launch_tall_adj(const jh_blockop *op, void *out, const void *in, int64_t n_scalars)
 {
     jh_context &c = jh_ctx();
-    const TallShape sh = pick_adj_shape(n_scalars / NS);
+    const TallShape sh = pick_adj_shape(n_scalars / NS, op->nrow, MODE);
     if (sh.wg == 256) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 256>(op, out, in, n_scalars, sh) : launch_tall_adj_u<S, E, NS, false, MODE, 256>(op, out, in, n_scalars, sh);
     if (sh.wg == 512) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 512>(op, out, in, n_scalars, sh) : launch_tall_adj_u<S, E, NS, false, MODE, 512>(op, out, in, n_scalars, sh);
     return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 1024>(op, out, in, n_scalars, sh) : launch_tall_adj_u<S, E, NS, false, MODE, 1024>(op, out, in, n_scalars, sh);

@@ -1,0 +1,207 @@
+# JetsHIP.jl -- Julia binding of libjetship.so (include/jetship.h) for Jets.jl.
+#
+# STATUS: WRITTEN, NOT EXECUTED.  This image has no Julia toolchain, so this file has never been
+# parsed or run; it documents, in the reference's own language, the `ccall` stubs a Jets.jl
+# maintainer adds to put JopBlock mul! on an MI355X.  The same ABI is exercised end to end by the
+# Python binding (jets.jl_amd/_ffi.py) and the GPU test-suite.
+#
+# Everything is additive: new array types (`HipArray`, `HipBlockArray`) plus methods of existing
+# Jets.jl generics that dispatch on them.  No reference source is modified.
+module JetsHIP
+
+using Jets, LinearAlgebra
+import Jets: JetBSpace, JetSpace, JetAbstractSpace, Jop, JopLn, JopAdjoint, Jet, jet, state, domain,
+             getblock, getblock!, setblock!, indices, nblocks, space, JopZeroBlock_df!, JetBlock_df!, JetBlock_df′!
+
+const LIB = get(ENV, "JETSHIP_LIB", "libjetship.so")
+
+# ---------------------------------------------------------------- errors (src/Jets.jl:131,179,1116: plain error(...))
+check(status::Cint) = status == 0 ? nothing : error("libjetship: " * unsafe_string(ccall((:jh_last_error, LIB), Cstring, ())))
+
+init(device::Integer=0) = check(ccall((:jh_init, LIB), Cint, (Cint,), device))
+synchronize() = check(ccall((:jh_synchronize, LIB), Cint, ()))
+
+dtype_code(::Type{Float32}) = Cint(0)
+dtype_code(::Type{Float64}) = Cint(1)
+dtype_code(::Type{ComplexF32}) = Cint(2)
+dtype_code(::Type{ComplexF64}) = Cint(3)
+
+# ---------------------------------------------------------------- device vectors
+# One HBM slab; block i at element offset R.indices[i][1]-1 (src/Jets.jl:742-748).
+mutable struct HipBlockArray{T} <: AbstractArray{T,1}
+    handle::Ptr{Cvoid}
+    spaces::Vector{<:JetAbstractSpace}
+    indices::Vector{UnitRange{Int}}
+    parent::Any                       # keeps the owner alive for views
+    function HipBlockArray{T}(handle, spaces, indices, parent=nothing) where {T}
+        x = new{T}(handle, spaces, indices, parent)
+        finalizer(x -> ccall((:jh_bvec_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), x)
+        x
+    end
+end
+
+# a plain N-d array is a one-block slab (domain of a one-column block operator, src/Jets.jl:927)
+mutable struct HipArray{T,N} <: AbstractArray{T,N}
+    handle::Ptr{Cvoid}
+    dims::NTuple{N,Int}
+    parent::Any
+    function HipArray{T,N}(handle, dims, parent=nothing) where {T,N}
+        x = new{T,N}(handle, dims, parent)
+        finalizer(x -> ccall((:jh_bvec_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), x)
+        x
+    end
+end
+
+Base.size(x::HipBlockArray) = (x.indices[end][end],)                      # src/Jets.jl:818
+Base.size(x::HipArray) = x.dims
+Jets.nblocks(x::HipBlockArray) = length(x.indices)                       # :860
+Jets.indices(x::HipBlockArray, i) = x.indices[i]                         # :858
+Jets.space(x::HipBlockArray) = JetBSpace(x.spaces)                       # :814
+
+function _create(lens::Vector{Int}, ::Type{T}) where {T}
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:jh_bvec_create, LIB), Cint, (Int64, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}), length(lens), lens, dtype_code(T), h))
+    h[]
+end
+
+# zeros(R) / Array(R) on the device (src/Jets.jl:105-108, 922-924); device storage is always zero-filled
+hipzeros(R::JetBSpace{T}) where {T} = HipBlockArray{T}(_create([length(R.indices[i]) for i = 1:length(R.indices)], T), R.spaces, R.indices)
+hipzeros(R::JetSpace{T,N}) where {T,N} = HipArray{T,N}(_create([length(R)], T), size(R))
+hiprand(R::JetAbstractSpace; seed=1, stream=0) = (x = hipzeros(R); check(ccall((:jh_fill_uniform, LIB), Cint, (Ptr{Cvoid}, UInt64, UInt64, Int64), x.handle, seed, stream, 0)); x)
+
+# getblock(x, i): by reference (src/Jets.jl:914) -- 1-based i -> 0-based block
+function Jets.getblock(x::HipBlockArray{T}, iblock) where {T}
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:jh_bvec_view, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), x.handle, iblock - 1, 1, h))
+    HipArray{T,ndims(x.spaces[iblock])}(h[], size(x.spaces[iblock]), x)
+end
+Jets.getblock(x::HipArray, iblock) = x                                    # :918
+# getblock!(x, i, xblock) (:915) and setblock!(x, i, v) (:916) for host arrays and scalars
+Jets.getblock!(x::HipBlockArray, iblock, out::Array) = (check(ccall((:jh_getblock_copy, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Cint), x.handle, iblock - 1, out, 0)); out)
+Jets.setblock!(x::HipBlockArray, iblock, v::Array) = check(ccall((:jh_setblock_copy, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Cint), x.handle, iblock - 1, v, 0))
+Jets.setblock!(x::HipBlockArray, iblock, a::Number) = check(ccall((:jh_setblock_fill, LIB), Cint, (Ptr{Cvoid}, Int64, Cdouble, Cdouble), x.handle, iblock - 1, real(a), imag(a)))
+
+# convert(Array, x) (:862-868)
+function Base.convert(::Type{Array}, x::Union{HipBlockArray{T},HipArray{T}}) where {T}
+    out = Vector{T}(undef, length(x))
+    check(ccall((:jh_download, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}), x.handle, 0, length(x), out))
+    x isa HipArray ? reshape(out, size(x)) : out
+end
+
+# fill!, norm, dot, extrema (:834-885)
+Base.fill!(x::Union{HipBlockArray,HipArray}, a) = (check(ccall((:jh_fill, LIB), Cint, (Ptr{Cvoid}, Cdouble, Cdouble), x.handle, real(a), imag(a))); x)
+function LinearAlgebra.norm(x::Union{HipBlockArray{T},HipArray{T}}, p::Real=2) where {T}
+    out = Ref{Cdouble}()
+    check(ccall((:jh_norm, LIB), Cint, (Ptr{Cvoid}, Cdouble, Ref{Cdouble}), x.handle, p, out))
+    float(real(T))(out[])
+end
+function LinearAlgebra.dot(x::Union{HipBlockArray{T},HipArray{T}}, y::Union{HipBlockArray{T},HipArray{T}}) where {T}
+    re, im = Ref{Cdouble}(), Ref{Cdouble}()
+    check(ccall((:jh_dot, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}), x.handle, y.handle, re, im))
+    T <: Complex ? T(re[], im[]) : T(re[])
+end
+function Base.extrema(x::Union{HipBlockArray{T},HipArray{T}}) where {T<:Real}
+    mn, mx = Ref{Cdouble}(), Ref{Cdouble}()
+    check(ccall((:jh_extrema, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}), x.handle, mn, mx))
+    T(mn[]), T(mx[])
+end
+
+# y .= c1*x1 .+ c2*x2 .+ ...   (the BlockArrayStyle copyto!, :905-911, for linear combinations)
+function lincomb!(y, coefs::Vector{<:Number}, xs::Vector)
+    cf = Float64[]
+    for c in coefs
+        push!(cf, real(c), imag(c))
+    end
+    hs = Ptr{Cvoid}[x.handle for x in xs]
+    check(ccall((:jh_lincomb, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Ptr{Cvoid}}), y.handle, length(xs), cf, hs))
+    y
+end
+
+# ---------------------------------------------------------------- device-native operator kinds
+# recognised by typeof(df!) exactly as iszero/isblockop do (src/Jets.jl:949, 1097)
+JopHipDiagonal_df!(d, m; diagonal, kwargs...) = (check(ccall((:jh_hadamard, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), d.handle, diagonal.handle, m.handle, 0)); d)
+JopHipDiagonal_df′!(m, d; diagonal, kwargs...) = (check(ccall((:jh_hadamard, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), m.handle, diagonal.handle, d.handle, 1)); m)
+function JopHipDiagonal(diag::HipArray{T,N}) where {T,N}
+    spc = JetSpace(T, size(diag))
+    JopLn(;df! = JopHipDiagonal_df!, df′! = JopHipDiagonal_df′!, dom = spc, rng = spc, s = (diagonal=diag,))
+end
+
+struct jh_block_desc          # mirrors include/jetship.h
+    kind::Int32
+    adjoint::Int32
+    coeff::Ptr{Cvoid}
+    scale_re::Cdouble
+    scale_im::Cdouble
+    nr::Int64
+    nc::Int64
+end
+
+function block_desc(op::Jop)
+    adj = op isa JopAdjoint
+    base = adj ? op.op : op
+    j = jet(base)
+    nr, nc = length(range(base)), length(domain(base))
+    if j.df! === JopZeroBlock_df!
+        return jh_block_desc(0, adj, C_NULL, 0, 0, nr, nc)
+    elseif j.df! === JopHipDiagonal_df!
+        return jh_block_desc(3, adj, _device_ptr(state(base).diagonal), 0, 0, nr, nc)
+    elseif j.df! === Jets._constdiag_df!
+        a = state(base).a
+        return jh_block_desc(2, adj, C_NULL, real(a), imag(a), nr, nc)
+    end
+    nothing            # not device-native: the reference's per-block loop handles it
+end
+
+function _device_ptr(x)
+    p = Ref{Ptr{Cvoid}}()
+    check(ccall((:jh_bvec_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Cint}, Ref{Ptr{Cvoid}}), x.handle, C_NULL, C_NULL, C_NULL, p))
+    p[]
+end
+
+const _handles = IdDict{Any,Ptr{Cvoid}}()        # ops matrix -> jh_blockop*
+
+function native_handle(ops::AbstractMatrix{<:Jop}, ::Type{T}) where {T}
+    get!(_handles, ops) do
+        descs = [block_desc(ops[i,j]) for i = 1:size(ops,1), j = 1:size(ops,2)]      # column-major == the C layout
+        any(isnothing, descs) && return C_NULL
+        row_len = Int64[length(range(ops[i,1])) for i = 1:size(ops,1)]
+        col_len = Int64[length(domain(ops[1,j])) for j = 1:size(ops,2)]
+        h = Ref{Ptr{Cvoid}}()
+        check(ccall((:jh_blockop_create, LIB), Cint, (Int64, Int64, Ptr{jh_block_desc}, Ptr{Int64}, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}),
+                    size(ops,1), size(ops,2), vec(convert(Matrix{jh_block_desc}, descs)), row_len, col_len, dtype_code(T), h))
+        h[]
+    end
+end
+
+# ---------------------------------------------------------------- the hot path: ONE ccall per mul!
+# More specific methods of the reference's block loops (src/Jets.jl:1010-1057) for device vectors.
+function Jets.JetBlock_df!(d::HipBlockArray{T}, m::Union{HipArray{T},HipBlockArray{T}}; ops, dom, rng, kwargs...) where {T}
+    h = native_handle(ops, T)
+    h == C_NULL && return invoke(Jets.JetBlock_df!, Tuple{AbstractArray,AbstractArray}, d, m; ops, dom, rng, kwargs...)
+    check(ccall((:jh_blockop_mul, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, d.handle, m.handle))
+    d
+end
+
+function Jets.JetBlock_df′!(m::Union{HipArray{T},HipBlockArray{T}}, d::HipBlockArray{T}; ops, dom, rng, kwargs...) where {T}
+    h = native_handle(ops, T)
+    h == C_NULL && return invoke(Jets.JetBlock_df′!, Tuple{AbstractArray,AbstractArray}, m, d; ops, dom, rng, kwargs...)
+    check(ccall((:jh_blockop_mul_adj, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, m.handle, d.handle))
+    m
+end
+
+# (A' o A) * m fused (src/Jets.jl:530-534 over (A', A)): called from a JetComposite_df! method that
+# recognises ops == (A', A) with A a native tall block operator
+function normal_mul!(y::HipArray{T}, A::JopLn, m::HipArray{T}) where {T}
+    h = native_handle(state(A).ops, T)
+    check(ccall((:jh_blockop_normal_mul, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, y.handle, m.handle))
+    y
+end
+
+# close(A) releases the device operator (src/Jets.jl:1120-1124 cascade)
+function release!(ops)
+    h = pop!(_handles, ops, C_NULL)
+    h == C_NULL || ccall((:jh_blockop_destroy, LIB), Cint, (Ptr{Cvoid},), h)
+    nothing
+end
+
+end # module

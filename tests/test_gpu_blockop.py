@@ -47,13 +47,13 @@ def test_tall_diag_forward_adjoint_bit_exact(Jets, oracle, dt, nrow, shape):
 
 
 @pytest.mark.parametrize("knobs", [
-    dict(fwd_group=0, fwd_unroll=0, fwd_wg=0, adj_unroll=0, adj_depth=0, adj_wg=0, nt=1),      # automatic shapes
-    dict(fwd_group=1, fwd_unroll=1, fwd_wg=256, adj_unroll=1, adj_depth=1, adj_wg=256, nt=0),
+    dict(fwd_group=0, fwd_unroll=0, fwd_wg=0, fwd_order=-1, adj_unroll=0, adj_depth=0, adj_wg=0, nt=1),      # automatic shapes
+    dict(fwd_group=1, fwd_unroll=1, fwd_wg=256, fwd_order=1, adj_unroll=1, adj_depth=1, adj_wg=256, nt=0),
     dict(fwd_group=4, fwd_unroll=2, fwd_wg=256, adj_unroll=2, adj_depth=2, adj_wg=512, nt=1),
-    dict(fwd_group=16, fwd_unroll=8, fwd_wg=1024, adj_unroll=4, adj_depth=4, adj_wg=1024, nt=1),  # the 1024 x 256^3 shapes
-    dict(fwd_group=7, fwd_unroll=8, fwd_wg=512, adj_unroll=1, adj_depth=8, adj_wg=512, nt=1),
+    dict(fwd_group=2, fwd_unroll=1, fwd_wg=512, fwd_order=1, adj_unroll=4, adj_depth=4, adj_wg=1024, nt=1),  # the 1024 x 256^3 shapes
+    dict(fwd_group=7, fwd_unroll=8, fwd_wg=512, fwd_order=1, adj_unroll=1, adj_depth=8, adj_wg=512, nt=1),
     dict(fwd_group=64, fwd_unroll=4, fwd_wg=1024, adj_unroll=4, adj_depth=8, adj_wg=256, nt=0),
-    dict(fwd_group=3, fwd_unroll=2, fwd_wg=512, adj_unroll=2, adj_depth=8, adj_wg=1024, nt=1),
+    dict(fwd_group=3, fwd_unroll=2, fwd_wg=512, fwd_order=0, adj_unroll=2, adj_depth=8, adj_wg=1024, nt=1),
 ])
 def test_every_kernel_shape_gives_identical_bits(Jets, oracle, knobs):
     """The tuning knobs change tiling only -- never results."""

@@ -50,8 +50,9 @@ def main():
         fwd_cfgs = [dict(fwd_wg=w, fwd_unroll=u, fwd_group=g, nt=t) for w in (256, 512) for u in (2, 4) for g in (8, 32) for t in (0, 1)]
         adj_cfgs = [dict(adj_wg=w, adj_unroll=u, adj_depth=dp, nt=t) for w in (256, 512) for u in (1, 2) for dp in (2, 4) for t in (0, 1)]
     else:
-        fwd_cfgs = [dict(fwd_wg=w, fwd_unroll=u, fwd_group=g, nt=t) for w in (256, 512, 1024) for u in (1, 2, 4, 8) for g in (2, 4, 8, 16, 32, 64, 128) for t in (0, 1)]
-        adj_cfgs = [dict(adj_wg=w, adj_unroll=u, adj_depth=dp, nt=t) for w in (256, 512, 1024) for u in (1, 2, 4) for dp in (1, 2, 4, 8) for t in (0, 1)
+        fwd_cfgs = [dict(fwd_wg=w, fwd_unroll=u, fwd_group=g, fwd_order=o, nt=1) for w in (256, 512, 1024) for u in (1, 2, 4, 8) for g in (2, 4, 8, 16, 32, 64) for o in (0, 1)
+                    if g <= args.nblocks]
+        adj_cfgs = [dict(adj_wg=w, adj_unroll=u, adj_depth=dp, nt=1) for w in (256, 512, 1024) for u in (1, 2, 4) for dp in (1, 2, 4, 8)
                     if not (u == 4 and dp == 8)]
     for rnd in range(args.rounds):
         if "fwd" in which:
