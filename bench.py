@@ -89,7 +89,9 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
-    import torch
+    late_torch = world == 1 and os.environ.get("BENCH_LATE_TORCH", "0") == "1"
+    if not late_torch:
+        import torch
 
     dist = None
     if world > 1:
@@ -134,6 +136,9 @@ def main():
         adjoint()
 
     ev = [[J.Event() for _ in range(3)] for _ in range(args.steps)]
+
+    if late_torch:
+        import torch
 
     def fence():
         J.synchronize()
@@ -212,6 +217,8 @@ def main():
                 "workload": f"{nblocks}x1 tall JopBlock of diagonal JopLn, {edge}^3 Float32 blocks, fwd+adj mul! pair",
                 "nblocks": nblocks, "block": [edge, edge, edge], "rows_per_gpu": nloc,
                 "parallelism": f"row-partition x{world}" + (" + RCCL all-reduce(64 MiB) in adjoint" if world > 1 else ""),
+                "slab_va_alignment_log2": {"coeff": (coeff.ptr & -coeff.ptr).bit_length() - 1, "d": (d.ptr & -d.ptr).bit_length() - 1,
+                                           "m": (m.ptr & -m.ptr).bit_length() - 1},
                 "tune": {k: J.tune_get(k) for k in ("fwd_group", "fwd_unroll", "fwd_wg", "fwd_order", "adj_unroll", "adj_depth", "adj_wg", "nt")},
             },
             "achieved_GBps_pair": pair_bytes_global * pairs_per_s / 1e9,

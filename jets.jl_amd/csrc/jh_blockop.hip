@@ -57,18 +57,23 @@ template <typename S, int E, int NS, typename V> __device__ inline V vmul(V a, V
 }
 
 // ------------------------------------------------------------------ tall fast path ------------
-// 1-D grid of ntiles * ngroups workgroups.  order 0: tile index fastest (the chip sweeps one block row
-// at a time, fully sequential HBM streams); order 1: row group fastest (workgroups sharing an m tile are
-// dispatched together, so the tile is re-read from L2/MALL instead of HBM).  n_scalars % NS == 0.
+// 1-D grid of ntiles * ngroups workgroups, walked in BANDS of `band` row groups: inside a band the row
+// group is the fastest index (workgroups sharing an m tile are dispatched together, so the tile is
+// re-read from L2/MALL, not HBM), bands follow one another.  band = 1 is the fully sequential sweep
+// (one block row at a time); band = ngroups touches every row concurrently.  n_scalars % NS == 0.
 template <typename S, int E, int NS, int U, bool NT, int BLK>
 __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__restrict__ blocks, int64_t nrow, int rows_per_wg,
                                                        const S *__restrict__ a_base, int64_t a_stride,
                                                        const S *__restrict__ m, S *__restrict__ d, int64_t n_scalars,
-                                                       unsigned ntiles, unsigned ngroups, int order)
+                                                       unsigned ntiles, unsigned ngroups, unsigned band)
 {
     typedef typename vec_of<S, NS>::type V;
-    const unsigned tile = order ? blockIdx.x / ngroups : blockIdx.x % ntiles;
-    const unsigned grp = order ? blockIdx.x % ngroups : blockIdx.x / ntiles;
+    const unsigned per_band = ntiles * band;                  // workgroups in a full band
+    const unsigned b = blockIdx.x / per_band;
+    const unsigned r = blockIdx.x - b * per_band;
+    const unsigned width = (b * band + band <= ngroups) ? band : ngroups - b * band;   // last band may be narrower
+    const unsigned tile = r / width;
+    const unsigned grp = b * band + r % width;
     const int64_t s0 = ((int64_t)tile * U * BLK + threadIdx.x) * NS;
     const int64_t i0 = (int64_t)grp * rows_per_wg;
     const int64_t i1 = (i0 + rows_per_wg < nrow) ? i0 + rows_per_wg : nrow;
@@ -275,23 +280,25 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
 }
 
 // ------------------------------------------------------------------ launch helpers ------------
-// Kernel shapes, fitted to interleaved sweeps on MI355X (profiles/sweep_r01*.txt; Float32):
-//   forward  1024 x 256^3 (128 GiB): row-group-fastest order, 2 rows x 1 vector x 512 threads   6.37 TB/s
-//            (tile-fastest order, the first design: 6.04 TB/s -- it re-reads the m tile from HBM)
-//            64 x 128^3, 1024 x 64^3 (1-2 GiB): tile-fastest, 2 rows x 1 vector x 256 threads   6.43 TB/s
-//            16 x 256^3: tile-fastest, 4 rows x 4 vectors x 256 threads                          6.26 TB/s
+// Kernel shapes, fitted to interleaved sweeps on MI355X (profiles/sweep_r01*.txt, profiles/repeat_r01.txt; Float32):
+//   forward  1024 x 256^3 (128 GiB): sequential row sweep, 1024 threads x 8 vectors x 16 rows: 6.04 TB/s in
+//            every process.  Walking all rows concurrently (order 1) reaches 6.4-6.5 TB/s in some processes
+//            and 5.2-5.6 TB/s in others (same binary, same box: physical placement luck), banded walks sit
+//            in between -- so the sequential sweep is the default and the other orders stay behind the knob.
+//            256 x 256^3 ... 16 x 256^3: 256 threads x 4 vectors x 4 rows (5.8-6.3 TB/s)
+//            64 x 128^3, 1024 x 64^3 (1-2 GiB): 256 threads x 1 vector x 2 rows (6.3-6.4 TB/s)
 //   adjoint  wants FEW, FAT workgroups: 4 vectors per thread as long as >= 256 workgroups remain
-//            (1024 x 256^3: 6.50 TB/s at 1024 threads; 64 x 128^3: 7.1 TB/s; 1024 x 64^3: 1 vector, 7.1 TB/s)
+//            (1024 x 256^3: 6.6-6.7 TB/s; 64 x 128^3: 6.8-7.1 TB/s; 1024 x 64^3: 1 vector, 7.1 TB/s)
 //   fused A'A reads one stream, so it keeps twice the rows in flight.
 struct TallShape { int wg, unroll, aux, order; };   // aux = rows per workgroup (forward) / rows in flight (adjoint)
 
 TallShape pick_fwd_shape(int64_t nvec, int64_t nrow, size_t vec_bytes)
 {
     jh_context &c = jh_ctx();
-    const double stream_bytes = 2.0 * (double)nrow * (double)nvec * (double)vec_bytes;   // a read + d written
+    (void)vec_bytes;
     TallShape s;
-    if (stream_bytes >= 8.0 * (double)(1ull << 30)) s = TallShape{512, 1, 2, 1};          // far beyond the 256 MiB MALL
-    else if (nvec >= (int64_t)1 << 21) s = TallShape{256, 4, 4, 0};
+    if (nvec >= ((int64_t)1 << 21) && nrow >= 512) s = TallShape{1024, 8, 16, 0};
+    else if (nvec >= ((int64_t)1 << 21)) s = TallShape{256, 4, 4, 0};
     else s = TallShape{256, 1, 2, 0};
     if (c.fwd_wg) s.wg = (int)c.fwd_wg;
     if (c.fwd_unroll) s.unroll = (int)c.fwd_unroll;
@@ -307,7 +314,7 @@ TallShape pick_adj_shape(int64_t nvec, int64_t nrow, int mode)
     if (nvec >= 4 * 256 * 256) s.unroll = 4;
     else if (nvec >= 2 * 256 * 256) s.unroll = 2;
     if (s.unroll == 4) s.aux = (nrow >= 256) ? 4 : 2;
-    if (nvec >= ((int64_t)1 << 22) && nrow >= 256) s.wg = 1024;
+    if (nvec >= ((int64_t)1 << 22)) s.wg = 512;
     if (mode == 1) {                                   // fused normal operator: one input stream
         s.aux = (s.unroll == 4) ? 4 : 8;
         if (nvec >= ((int64_t)1 << 22)) s.wg = 1024;
@@ -328,13 +335,15 @@ int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     int64_t G = sh.aux;
     if (G > op->nrow) G = op->nrow;
     const int64_t gy = (op->nrow + G - 1) / G;
+    int64_t band = sh.order <= 0 ? 1 : (sh.order == 1 ? gy : sh.order);   // order: 0 sequential, 1 all rows, k>1 = k groups per band
+    if (band > gy) band = gy;
 #define JH_FWD_CASE(U)                                                                                               \
     case U: {                                                                                                         \
         int64_t gx = (n_scalars + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                               \
         JH_REQUIRE(gx * gy < (int64_t)1 << 31, "tall forward: grid of %lld workgroups is too large", (long long)(gx * gy)); \
         hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, NT, BLK>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, \
                            op->dev_blocks, op->nrow, (int)G, a_base, a_stride, (const S *)m, (S *)d, n_scalars,      \
-                           (unsigned)gx, (unsigned)gy, sh.order);                                            \
+                           (unsigned)gx, (unsigned)gy, (unsigned)band);                                            \
     } break;
     switch (sh.unroll) {
         JH_FWD_CASE(1)

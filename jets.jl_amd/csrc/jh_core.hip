@@ -374,7 +374,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "adj_unroll")) { JH_REQUIRE(one_of({0, 1, 2, 4}), "adj_unroll must be 0 (auto), 1, 2 or 4"); c.adj_unroll = value; }
     else if (!strcmp(name, "adj_depth")) { JH_REQUIRE(one_of({0, 1, 2, 4, 8}), "adj_depth must be 0 (auto), 1, 2, 4 or 8"); c.adj_depth = value; }
     else if (!strcmp(name, "adj_wg")) { JH_REQUIRE(one_of({0, 256, 512, 1024}), "adj_wg must be 0 (auto), 256, 512 or 1024"); c.adj_wg = value; }
-    else if (!strcmp(name, "fwd_order")) { JH_REQUIRE(one_of({-1, 0, 1}), "fwd_order must be -1 (auto), 0 or 1"); c.fwd_order = value; }
+    else if (!strcmp(name, "fwd_order")) { JH_REQUIRE(value >= -1 && value <= 65536, "fwd_order must be -1 (auto), 0 (sequential), 1 (all rows) or k > 1 (k row groups per band)"); c.fwd_order = value; }
     else if (!strcmp(name, "nt")) { c.nt = value ? 1 : 0; }
     else return jh_fail(JH_ERR_INVALID, "jh_tune_set: unknown knob '%s'", name);
     return JH_OK;

@@ -44,7 +44,7 @@ struct jh_context {
     int64_t adj_unroll = 0;            // 16-byte vectors per thread (tall adjoint / fused normal)
     int64_t adj_depth = 0;             // block rows in flight per thread (tall adjoint / fused normal)
     int64_t adj_wg = 0;                // threads per workgroup (tall adjoint / fused normal)
-    int64_t fwd_order = -1;            // -1: automatic; 0: tile-fastest grid order; 1: row-group-fastest (tall forward)
+    int64_t fwd_order = -1;            // -1: automatic; 0: sequential row sweep; 1: all row groups concurrent; k>1: bands of k row groups
     int64_t nt = 1;                    // nontemporal loads/stores on the streamed operands
 };
 jh_context &jh_ctx();
