@@ -147,6 +147,13 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d);
  * once and the range-side intermediate is never materialised.  Same rounding sequence as the
  * unfused pair, so the result is bit-identical to jh_blockop_mul followed by jh_blockop_mul_adj. */
 int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m);
+/* Fused solver updates (the two halves of an LSQR / CGLS iteration; callers: IterativeSolvers-style loops over
+ * vec(A), src/Jets.jl:1138-1154).  d = alpha*(A m) + beta*d  /  m = alpha*(A' d) + beta*m  with real alpha, beta,
+ * and ||result||^2 (fp64) returned through normsq when it is not NULL (then the call synchronises).
+ * Same rounding sequence as mul! into a temporary followed by `y .= alpha*tmp .+ beta*y`; no temporary
+ * range vector, no separate axpby or norm pass.  Tall all-DIAG operators only (else JH_ERR_UNSUPPORTED). */
+int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double alpha, double beta, double *normsq);
+int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double alpha, double beta, double *normsq);
 /* kernel-shape tuning knobs (bench/tests only): 0 = automatic (fwd_order: -1); name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg","fwd_order","nt"} */
 int jh_tune_set(const char *name, int64_t value);
 int jh_tune_get(const char *name, int64_t *value);

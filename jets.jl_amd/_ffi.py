@@ -90,6 +90,8 @@ SYMBOLS = {
     "jh_blockop_mul": (_int, [_vp, _vp, _vp]),
     "jh_blockop_mul_adj": (_int, [_vp, _vp, _vp]),
     "jh_blockop_normal_mul": (_int, [_vp, _vp, _vp]),
+    "jh_blockop_mul_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
+    "jh_blockop_mul_adj_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
     "jh_tune_set": (_int, [C.c_char_p, _i64]),
     "jh_tune_get": (_int, [C.c_char_p, _i64p]),
 }

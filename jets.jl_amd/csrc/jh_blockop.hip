@@ -171,6 +171,147 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
         if (ok[k]) st<false>(reinterpret_cast<V *>(out + s0 + (int64_t)k * BLK * NS), acc[k]);
 }
 
+// ------------------------------------------------------------------ fused solver updates ------
+// y = alpha * (A x) + beta * y with ||y||^2 in the same pass: the two halves of an LSQR/CGLS iteration
+// (u <- A v - alpha u ; v <- A'u - beta v, each followed by a norm) without a temporary range vector,
+// a separate axpby pass or a separate norm pass.  Rounding sequence == the unfused chain
+// (mul! into a temporary, then `y .= alpha*tmp .+ beta*y`): product, scale, scale, add, each rounded.
+template <int BLK> __device__ inline void wg_sum_store(double v, double *slot)
+{
+    __shared__ double sm[BLK / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sm[0];
+#pragma unroll
+        for (int w = 1; w < BLK / 64; w++) r += sm[w];
+        *slot = r;
+    }
+}
+
+template <typename S, int NS, typename V> __device__ inline double vnorm2(V r)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < NS; e++) acc += (double)r[e] * (double)r[e];
+    return acc;
+}
+
+// forward: d_i = alpha * (a_i .* m) + beta * d_i ; sequential row sweep (tile index fastest)
+template <typename S, int E, int NS, int U, int BLK>
+__global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block *__restrict__ blocks, int64_t nrow, int rows_per_wg,
+                                                              const S *__restrict__ a_base, int64_t a_stride,
+                                                              const S *__restrict__ m, S *__restrict__ d, int64_t n_scalars,
+                                                              unsigned ntiles, S alpha, S beta, double *__restrict__ partials)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const unsigned tile = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
+    const int64_t s0 = ((int64_t)tile * U * BLK + threadIdx.x) * NS;
+    const int64_t i0 = (int64_t)grp * rows_per_wg;
+    const int64_t i1 = (i0 + rows_per_wg < nrow) ? i0 + rows_per_wg : nrow;
+    bool ok[U];
+    int64_t sk[U];
+    V mv[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
+        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
+        mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
+    }
+    double nrm = 0.0;
+    for (int64_t i = i0; i < i1; i++) {
+        const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
+        S *di = d + i * n_scalars;
+        V av[U], dv[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            av[k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+            dv[k] = ld<true>(reinterpret_cast<const V *>(di + sk[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            V t = vmul<S, E, NS, V>(av[k], mv[k], false);      // mul!(tmp, A_i, m)
+            V s1 = (V)alpha * t;
+            V s2 = (V)beta * dv[k];
+            V r = s1 + s2;                                      // d_i .= alpha*tmp .+ beta*d_i
+            if (ok[k]) {
+                st<true>(reinterpret_cast<V *>(di + sk[k]), r);
+                nrm += vnorm2<S, NS, V>(r);
+            }
+        }
+    }
+    wg_sum_store<BLK>(nrm, partials + blockIdx.x);
+}
+
+// adjoint: out = alpha * (sum_i conj(a_i) .* d_i, rows in order) + beta * out
+template <typename S, int E, int NS, int U, int DEPTH, int BLK>
+__global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block *__restrict__ blocks, int64_t nrow,
+                                                              const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ out,
+                                                              const S *__restrict__ in, int64_t n_scalars, int direct, S alpha, S beta,
+                                                              double *__restrict__ partials)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t s0 = ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
+    bool ok[U];
+    int64_t sk[U];
+    V acc[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
+        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
+        acc[k] = (V)(S)0;
+    }
+    int64_t i = 0;
+    for (; !direct && i + DEPTH <= nrow; i += DEPTH) {
+        V av[DEPTH][U], dv[DEPTH][U];
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            const S *a = a_base ? a_base + (i + j) * a_stride : (const S *)blocks[i + j].coeff;
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                av[j][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+                dv[j][k] = ld<true>(reinterpret_cast<const V *>(in + (i + j) * n_scalars + sk[k]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], dv[j][k], true);
+    }
+    for (; i < nrow; i++) {
+        const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            V p = vmul<S, E, NS, V>(ld<true>(reinterpret_cast<const V *>(a + sk[k])),
+                                    ld<true>(reinterpret_cast<const V *>(in + i * n_scalars + sk[k])), true);
+            acc[k] = direct ? p : acc[k] + p;
+        }
+    }
+    double nrm = 0.0;
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        V old = ld<false>(reinterpret_cast<const V *>(out + sk[k]));
+        V s1 = (V)alpha * acc[k];
+        V s2 = (V)beta * old;
+        V r = s1 + s2;
+        if (ok[k]) {
+            st<false>(reinterpret_cast<V *>(out + sk[k]), r);
+            nrm += vnorm2<S, NS, V>(r);
+        }
+    }
+    wg_sum_store<BLK>(nrm, partials + blockIdx.x);
+}
+
+// one workgroup folds the per-workgroup partials in index order (deterministic)
+__global__ void k_sum_partials(const double *__restrict__ partials, int64_t n, double *__restrict__ out)
+{
+    double v = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) v += partials[i];
+    wg_sum_store<256>(v, out);
+}
+
 // ------------------------------------------------------------------ general path --------------
 template <typename S, int E> struct elem {
     S re, im;
@@ -441,6 +582,76 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
     return JH_OK;
 }
 
+// ---- fused solver updates: launch + partial fold ---------------------------------------------------
+int finish_normsq(int64_t nparts, double *normsq)
+{
+    jh_context &c = jh_ctx();
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, c.part_dev, nparts, c.red_dev);
+    JH_CHECK_HIP(hipGetLastError());
+    if (normsq) {
+        JH_CHECK_HIP(hipMemcpyAsync(c.red_host, c.red_dev, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+        *normsq = c.red_host[0];
+    }
+    return JH_OK;
+}
+
+template <typename S, int E, int NS>
+int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_scalars, double alpha, double beta, double *normsq)
+{
+    jh_context &c = jh_ctx();
+    const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
+    const int64_t a_stride = op->diag_stride_elems * E;
+    const int64_t nvec = n_scalars / NS;
+    // three streams per row (a, d in, d out): same tilings as the plain forward, fewer instantiations
+    int wg, U, G;
+    if (nvec >= ((int64_t)1 << 21) && op->nrow >= 512) { wg = 1024; U = 8; G = 16; }
+    else if (nvec >= ((int64_t)1 << 21)) { wg = 256; U = 4; G = 4; }
+    else { wg = 256; U = 1; G = 2; }
+    if (G > op->nrow) G = (int)op->nrow;
+    const int64_t gy = (op->nrow + G - 1) / G;
+    const int64_t gx = (nvec + (int64_t)wg * U - 1) / ((int64_t)wg * U);
+    JH_REQUIRE(gx * gy < (int64_t)1 << 31, "fused forward update: grid of %lld workgroups is too large", (long long)(gx * gy));
+    JH_TRY(jh_ensure_partials(gx * gy));
+#define JH_LAUNCH(BLK, UU)                                                                                             \
+    hipLaunchKernelGGL((k_tall_diag_fwd_update<S, E, NS, UU, BLK>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream,  \
+                       op->dev_blocks, op->nrow, G, a_base, a_stride, (const S *)m, (S *)d, n_scalars, (unsigned)gx,   \
+                       (S)alpha, (S)beta, c.part_dev)
+    if (wg == 1024) JH_LAUNCH(1024, 8);
+    else if (U == 4) JH_LAUNCH(256, 4);
+    else JH_LAUNCH(256, 1);
+#undef JH_LAUNCH
+    JH_CHECK_HIP(hipGetLastError());
+    return finish_normsq(gx * gy, normsq);
+}
+
+template <typename S, int E, int NS>
+int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n_scalars, double alpha, double beta, double *normsq)
+{
+    jh_context &c = jh_ctx();
+    const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
+    const int64_t a_stride = op->diag_stride_elems * E;
+    const int64_t nvec = n_scalars / NS;
+    const int direct = op->nrow == 1 ? 1 : 0;
+    int wg = 256, U = 1;
+    if (nvec >= 4 * 256 * 256) U = 4;
+    else if (nvec >= 2 * 256 * 256) U = 2;
+    if (nvec >= ((int64_t)1 << 22)) wg = 512;
+    const int64_t gx = (nvec + (int64_t)wg * U - 1) / ((int64_t)wg * U);
+    JH_TRY(jh_ensure_partials(gx));
+#define JH_LAUNCH(BLK, UU, DD)                                                                                         \
+    hipLaunchKernelGGL((k_tall_diag_adj_update<S, E, NS, UU, DD, BLK>), dim3((unsigned)gx), dim3(BLK), 0, c.stream,     \
+                       op->dev_blocks, op->nrow, a_base, a_stride, (S *)out, (const S *)in, n_scalars, direct, (S)alpha, \
+                       (S)beta, c.part_dev)
+    if (wg == 512) JH_LAUNCH(512, 4, 4);
+    else if (U == 4) JH_LAUNCH(256, 4, 2);
+    else if (U == 2) JH_LAUNCH(256, 2, 4);
+    else JH_LAUNCH(256, 1, 4);
+#undef JH_LAUNCH
+    JH_CHECK_HIP(hipGetLastError());
+    return finish_normsq(gx, normsq);
+}
+
 int check_vectors(const jh_blockop *op, const jh_bvec *rng, const jh_bvec *dom, const char *who)
 {
     JH_REQUIRE(op && rng && dom, "%s: null argument", who);
@@ -629,6 +840,40 @@ int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m)
     case JH_C64: return launch_tall_adj<double, 2, 2, 1>(op, y->data, m->data, 2 * n);
     }
     return jh_fail(JH_ERR_INVALID, "jh_blockop_normal_mul: unknown dtype %d", op->dtype);
+}
+
+int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double alpha, double beta, double *normsq)
+{
+    JH_TRY(jh_require_ready());
+    JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_axpby"));
+    if (!tall_fast_ok(op, d->data, m->data))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_axpby: needs a tall all-DIAG operator with equal, 16-byte aligned blocks; "
+                                           "use jh_blockop_mul into a temporary, jh_lincomb and jh_norm instead");
+    const int64_t n = op->row_len[0];
+    switch (op->dtype) {
+    case JH_F32: return launch_fwd_update<float, 1, 4>(op, d->data, m->data, n, alpha, beta, normsq);
+    case JH_F64: return launch_fwd_update<double, 1, 2>(op, d->data, m->data, n, alpha, beta, normsq);
+    case JH_C32: return launch_fwd_update<float, 2, 4>(op, d->data, m->data, 2 * n, alpha, beta, normsq);
+    case JH_C64: return launch_fwd_update<double, 2, 2>(op, d->data, m->data, 2 * n, alpha, beta, normsq);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blockop_mul_axpby: unknown dtype %d", op->dtype);
+}
+
+int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double alpha, double beta, double *normsq)
+{
+    JH_TRY(jh_require_ready());
+    JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_adj_axpby"));
+    if (!tall_fast_ok(op, d->data, m->data))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_axpby: needs a tall all-DIAG operator with equal, 16-byte aligned blocks; "
+                                           "use jh_blockop_mul_adj into a temporary, jh_lincomb and jh_norm instead");
+    const int64_t n = op->row_len[0];
+    switch (op->dtype) {
+    case JH_F32: return launch_adj_update<float, 1, 4>(op, m->data, d->data, n, alpha, beta, normsq);
+    case JH_F64: return launch_adj_update<double, 1, 2>(op, m->data, d->data, n, alpha, beta, normsq);
+    case JH_C32: return launch_adj_update<float, 2, 4>(op, m->data, d->data, 2 * n, alpha, beta, normsq);
+    case JH_C64: return launch_adj_update<double, 2, 2>(op, m->data, d->data, 2 * n, alpha, beta, normsq);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blockop_mul_adj_axpby: unknown dtype %d", op->dtype);
 }
 
 }  // extern "C"

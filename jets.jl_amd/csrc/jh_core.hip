@@ -19,6 +19,23 @@ jh_context &jh_ctx()
     return ctx;
 }
 
+int jh_ensure_partials(int64_t n)
+{
+    jh_context &c = jh_ctx();
+    if (n <= c.part_cap) return JH_OK;
+    int64_t cap = c.part_cap ? c.part_cap : 4096;
+    while (cap < n) cap *= 2;
+    if (c.part_dev) {
+        JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+        JH_CHECK_HIP(hipFree(c.part_dev));
+        c.part_dev = nullptr;
+        c.part_cap = 0;
+    }
+    JH_CHECK_HIP(hipMalloc((void **)&c.part_dev, sizeof(double) * (size_t)cap));
+    c.part_cap = cap;
+    return JH_OK;
+}
+
 int jh_require_ready()
 {
     if (!jh_ctx().ready) return jh_fail(JH_ERR_STATE, "libjetship: jh_init(device) has not been called");
@@ -77,6 +94,7 @@ int jh_shutdown(void)
     (void)hipSetDevice(c.device);
     (void)hipStreamSynchronize(c.stream);
     if (c.red_dev) (void)hipFree(c.red_dev);
+    if (c.part_dev) (void)hipFree(c.part_dev);
     if (c.red_host) (void)hipHostFree(c.red_host);
     if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
     c = jh_context();

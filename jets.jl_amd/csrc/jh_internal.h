@@ -36,6 +36,8 @@ struct jh_context {
     // reduction workspace (per-workgroup partials + a pinned host landing zone)
     double *red_dev = nullptr;         // JH_RED_SLOTS * 4 doubles
     double *red_host = nullptr;        // pinned, 8 doubles
+    double *part_dev = nullptr;        // growable per-workgroup partials of the fused solver updates
+    int64_t part_cap = 0;
     // tuning knobs (jh_tune_set)
     // 0 = pick from the problem size (jh_blockop.hip: pick_fwd_shape / pick_adj_shape)
     int64_t fwd_group = 0;             // block rows streamed per workgroup (tall forward)
@@ -106,5 +108,6 @@ struct jh_blockop {
     int64_t diag_stride_elems = 0;
 };
 
+int jh_ensure_partials(int64_t n);     // grows ctx.part_dev to >= n doubles (may synchronise + reallocate)
 // vecops entry used by blockop for generic pieces
 int jh_launch_fill_range(void *ptr, int dtype, int64_t count, double re, double im);

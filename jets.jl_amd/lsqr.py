@@ -1,0 +1,211 @@
+"""LSQR over the Jets operator API (BASELINE.json configs[4]).
+
+The reference does not ship a solver: its documented caller is IterativeSolvers.jl's `lsqr(vec(A), vec(d))`
+(src/Jets.jl:1143-1152, docs/src/index.md:235-246), an un-vendored package with no pinned version, so this
+is a from-scratch implementation of the published algorithm (Paige & Saunders, "LSQR: an algorithm for
+sparse linear equations and sparse least squares", ACM TOMS 8(1), 1982), checked against the fp64 CPU
+restatement in oracle/lsqr_ref.py (LSQR parity is otherwise unpinned).
+
+Per iteration it needs   u <- A v - alpha u, ||u||   and   v <- A'u - beta v, ||v||.
+For a device-native tall block operator each half is ONE fused kernel (jh_blockop_mul_axpby /
+jh_blockop_mul_adj_axpby): no temporary range vector, no separate axpby or norm pass.  The big range-side
+vector u is never normalised in memory -- its scale 1/beta is carried into the next two updates -- which
+removes another read+write of the range vector per iteration.  Algorithmic HBM bytes per iteration for an
+N x 1 operator of n-element blocks of s bytes:  forward half 3*N*n*s + n*s (a, u in, u out, v), adjoint half
+2*N*n*s + 2*n*s; the small domain-side updates (x, w, v: 3 vectors of n) add ~8*n*s.  Any other operator
+runs the same recurrences through mul!, one fused broadcast and one norm per half.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+from ._ffi import lib, check, JetsHipError
+from . import arrays as _arr
+from .arrays import zeros, lincomb_, norm, copyto_, reshape
+from . import jets as _j
+from . import jetblock as _blk
+
+__all__ = ["lsqr", "LsqrResult"]
+
+
+class LsqrResult:
+    """x plus the convergence record (names follow the LSQR paper / scipy's lsqr)."""
+
+    def __init__(self, x, istop, itn, r1norm, r2norm, anorm, acond, arnorm, xnorm, history):
+        self.x, self.istop, self.itn = x, istop, itn
+        self.r1norm, self.r2norm, self.anorm, self.acond, self.arnorm, self.xnorm = r1norm, r2norm, anorm, acond, arnorm, xnorm
+        self.history = history  # list of (itn, r1norm, arnorm) per iteration
+
+    def __iter__(self):  # x, info = lsqr(...)
+        yield self.x
+        yield self
+
+
+def _unwrap_vec(A):
+    """vec(A) (src/Jets.jl:1129-1136) just reshapes; run the recurrences on the inner operator's own spaces."""
+    j = _j.jet(A)
+    if j.f is _j.JetVec_f:
+        return j.s["op"]
+    return A
+
+
+class _Engine:
+    """The two half-iterations, fused when the operator is a device-native tall block operator."""
+
+    def __init__(self, A):
+        self.A = A
+        self.L = _j.JopLn(A) if not isinstance(A, _j.JopAdjoint) else A
+        self.native = None
+        if isinstance(A, _j.JopLn) and _blk.isblockop(A):
+            jt = A.jet
+            nat = _blk._native_op(jt.s.get("_native"), jt.s["ops"], jt.rng.eltype())
+            if nat is not None and jt.s["ops"].shape[1] == 1:
+                self.native = nat
+        self._tmp_r = None
+        self._tmp_d = None
+
+    def fwd(self, u, v, alpha, beta):
+        """u <- alpha*(A v) + beta*u ; returns ||u||."""
+        if self.native is not None:
+            out = C.c_double(0)
+            try:
+                check(lib.jh_blockop_mul_axpby(self.native.handle, u.handle, v.handle, float(alpha), float(beta), C.byref(out)))
+                return math.sqrt(out.value)
+            except JetsHipError as e:
+                if e.status != 4:  # JH_ERR_UNSUPPORTED: mixed kinds / ragged blocks -> generic path
+                    raise
+                self.native = None
+        if self._tmp_r is None:
+            self._tmp_r = zeros(_j.range_(self.A))
+        _j.mul_(self._tmp_r, self.L, v)
+        lincomb_(u, [alpha, beta], [self._tmp_r, u])
+        return float(norm(u))
+
+    def adj(self, v, u, alpha, beta):
+        """v <- alpha*(A' u) + beta*v ; returns ||v||."""
+        if self.native is not None:
+            out = C.c_double(0)
+            try:
+                check(lib.jh_blockop_mul_adj_axpby(self.native.handle, v.handle, u.handle, float(alpha), float(beta), C.byref(out)))
+                return math.sqrt(out.value)
+            except JetsHipError as e:
+                if e.status != 4:
+                    raise
+                self.native = None
+        if self._tmp_d is None:
+            self._tmp_d = zeros(_j.domain(self.A))
+        _j.mul_(self._tmp_d, _j.adjoint(self.L), u)
+        lincomb_(v, [alpha, beta], [self._tmp_d, v])
+        return float(norm(v))
+
+
+def lsqr(A, b, x0=None, damp: float = 0.0, atol: float = 1e-6, btol: float = 1e-6, conlim: float = 1e8, maxiter: int = 100,
+         overwrite_b: bool = False) -> LsqrResult:
+    """min ||A x - b||_2 (+ damp^2 ||x||^2).  `b` lives in range(A) (a BlockArray for a block operator), the
+    result in domain(A).  `overwrite_b=True` lets the solver use b's storage for the Lanczos vector u (at the
+    headline size b is 64 GiB)."""
+    A = _unwrap_vec(A)
+    dom, rng = _j.domain(A), _j.range_(A)
+    eng = _Engine(A)
+    b = reshape(b, rng)
+    x = zeros(dom) if x0 is None else copyto_(zeros(dom), reshape(x0, dom))
+    u = b if overwrite_b else copyto_(zeros(rng), b)
+    bnorm = float(norm(b))
+
+    # u_hat holds beta*u (un-normalised); `beta` is its norm.  u = b - A x0
+    if x0 is not None:
+        beta = eng.fwd(u, x, -1.0, 1.0)
+    else:
+        beta = bnorm
+    v = zeros(dom)
+    w = zeros(dom)
+    history = []
+    itn, istop = 0, 0
+    anorm = acond = ddnorm = res2 = xnorm = xxnorm = z = 0.0
+    cs2, sn2 = -1.0, 0.0
+    if beta > 0:
+        alpha = eng.adj(v, u, 1.0 / beta, 0.0)          # v = A'u with u = u_hat / beta
+    else:
+        copyto_(v, x)
+        alpha = 0.0
+    if alpha > 0:
+        lincomb_(v, [1.0 / alpha], [v])
+    copyto_(w, v)
+    rhobar, phibar = alpha, beta
+    rnorm = r1norm = r2norm = beta
+    arnorm = alpha * beta
+    if arnorm == 0:
+        return LsqrResult(x, 0, 0, r1norm, r2norm, anorm, acond, arnorm, xnorm, history)
+    eps = 2.220446049250313e-16
+    ctol = 1.0 / conlim if conlim > 0 else 0.0
+
+    while itn < maxiter:
+        itn += 1
+        # --- bidiagonalisation:  beta*u = A v - alpha*u ;  alpha*v = A'u - beta*v
+        beta_prev = beta
+        beta = eng.fwd(u, v, 1.0, -alpha / beta_prev)    # u_hat <- A v - alpha * (u_hat / beta_prev)
+        if beta > 0:
+            anorm = math.sqrt(anorm ** 2 + alpha ** 2 + beta ** 2 + damp ** 2)
+            alpha = eng.adj(v, u, 1.0 / beta, -beta)     # v <- A'(u_hat / beta) - beta v
+            if alpha > 0:
+                lincomb_(v, [1.0 / alpha], [v])
+        # --- eliminate the damping parameter
+        rhobar1 = math.sqrt(rhobar ** 2 + damp ** 2)
+        cs1, sn1 = rhobar / rhobar1, damp / rhobar1
+        psi = sn1 * phibar
+        phibar = cs1 * phibar
+        # --- plane rotation to eliminate the subdiagonal of the bidiagonal matrix
+        rho = math.sqrt(rhobar1 ** 2 + beta ** 2)
+        cs, sn = rhobar1 / rho, beta / rho
+        theta = sn * alpha
+        rhobar = -cs * alpha
+        phi = cs * phibar
+        phibar = sn * phibar
+        tau = sn * phi
+        # --- update x and w (domain-sized vectors)
+        t1, t2 = phi / rho, -theta / rho
+        ddnorm += (float(norm(w)) / rho) ** 2            # ||w / rho||^2 without materialising w / rho
+        lincomb_(x, [1.0, t1], [x, w])
+        lincomb_(w, [1.0, t2], [v, w])
+        # --- norms for the stopping rules
+        delta = sn2 * rho
+        gambar = -cs2 * rho
+        rhs = phi - delta * z
+        zbar = rhs / gambar
+        xnorm = math.sqrt(xxnorm + zbar ** 2)
+        gamma = math.sqrt(gambar ** 2 + theta ** 2)
+        cs2, sn2 = gambar / gamma, theta / gamma
+        z = rhs / gamma
+        xxnorm += z ** 2
+        acond = anorm * math.sqrt(ddnorm)
+        res1 = phibar ** 2
+        res2 += psi ** 2
+        rnorm = math.sqrt(res1 + res2)
+        arnorm = alpha * abs(tau)
+        r1sq = rnorm ** 2 - damp ** 2 * xxnorm
+        r1norm = math.sqrt(abs(r1sq)) * (1 if r1sq >= 0 else -1)
+        r2norm = rnorm
+        history.append((itn, r1norm, arnorm))
+        test1 = rnorm / bnorm if bnorm > 0 else 0.0
+        test2 = arnorm / (anorm * rnorm + eps) if rnorm > 0 else 0.0
+        test3 = 1.0 / (acond + eps)
+        t1_ = test1 / (1 + anorm * xnorm / bnorm) if bnorm > 0 else 0.0
+        rtol = btol + atol * anorm * xnorm / bnorm if bnorm > 0 else 0.0
+        if itn >= maxiter:
+            istop = 7
+        if 1 + test3 <= 1:
+            istop = 6
+        if 1 + test2 <= 1:
+            istop = 5
+        if 1 + t1_ <= 1:
+            istop = 4
+        if test3 <= ctol:
+            istop = 3
+        if test2 <= atol:
+            istop = 2
+        if test1 <= rtol:
+            istop = 1
+        if istop:
+            break
+    return LsqrResult(x, istop, itn, r1norm, r2norm, anorm, acond, arnorm, xnorm, history)

@@ -1,0 +1,131 @@
+"""GPU: fused solver updates (jh_blockop_mul_axpby / _mul_adj_axpby) and the LSQR driver.
+
+Bar: the fused updates are BIT-EXACT against the unfused chain restated by the oracle (block loop into a
+temporary, then `y .= alpha*tmp .+ beta*y`); their ||.||^2 within 1e-6 (Float32) / 1e-13 (Float64) of an
+fp64 host value.  LSQR (Float32 data) after a fixed number of iterations: solution within 1e-4 (rel l2),
+residual-norm history within 1e-4, of the fp64 CPU LSQR (oracle/lsqr_ref.py) on the same operator --
+IterativeSolvers.jl, the reference's solver caller, is un-vendored, so LSQR parity is pinned on the
+published algorithm only.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle.lsqr_ref import lsqr_fp64
+
+from .helpers import DTYPES, assert_bits_equal, make_tall_diag, u01
+
+pytestmark = pytest.mark.gpu
+
+
+def _native(Jets, A):
+    from jets_jl_amd import jetblock
+
+    j = A.jet
+    return jetblock._native_op(j.s["_native"], j.s["ops"], j.rng.eltype())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,shape", [(4, (8, 8, 4)), (3, (100, 100, 27)), (2, (128, 128, 33)), (1, (64,)), (5, (1 << 20,))])
+def test_fused_updates_bit_exact_vs_unfused_chain(Jets, oracle, dt, nrow, shape):
+    from jets_jl_amd._ffi import lib, check
+
+    if np.dtype(dt).itemsize * int(np.prod(shape)) * nrow > 2 ** 28:
+        pytest.skip("kept small")
+    A, _, ops, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    nat = _native(Jets, A)
+    alpha, beta = 0.75, -1.375
+    m = Jets.rand(Jets.domain(A), seed=41, stream=0)
+    d = Jets.rand(Jets.range(A), seed=42, stream=0)
+    hm = u01(oracle, dt, 41, 0, n)
+    hd = u01(oracle, dt, 42, 0, nrow * n)
+    hd_blocks = [hd[i * n:(i + 1) * n].copy() for i in range(nrow)]
+
+    # forward half:  d <- alpha*(A m) + beta*d
+    out = C.c_double(0)
+    check(lib.jh_blockop_mul_axpby(nat.handle, d.handle, m.handle, alpha, beta, C.byref(out)))
+    tmp = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [hm])
+    ref = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [alpha, beta], [tmp, hd_blocks])
+    assert_bits_equal(d.to_numpy(), np.concatenate(ref), "d <- alpha*A m + beta*d")
+    truth = float(np.sum(np.abs(np.concatenate(ref).astype(np.complex128)) ** 2))
+    tol = 1e-6 if np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-13
+    assert out.value == pytest.approx(truth, rel=tol)
+
+    # adjoint half:  m <- alpha*(A' d) + beta*m   (d is now `ref`)
+    check(lib.jh_blockop_mul_adj_axpby(nat.handle, m.handle, d.handle, alpha, beta, C.byref(out)))
+    tmpm = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], ref)
+    refm = oracle.barr_lincomb([np.empty(n, dtype=dt)], [alpha, beta], [tmpm, [hm]])
+    assert_bits_equal(m.to_numpy().ravel(order="F"), refm[0], "m <- alpha*A'd + beta*m")
+    assert out.value == pytest.approx(float(np.sum(np.abs(refm[0].astype(np.complex128)) ** 2)), rel=tol)
+    # normsq == NULL: asynchronous, same result
+    check(lib.jh_blockop_mul_adj_axpby(nat.handle, m.handle, d.handle, 0.0, 1.0, None))
+    Jets.synchronize()
+
+
+def _host_ops(a_blocks, dt64):
+    a64 = [g.astype(dt64) for g in a_blocks]
+    n = a64[0].size
+    matvec = lambda x: np.concatenate([g * x for g in a64])
+    rmatvec = lambda y: sum(np.conj(g) * y[i * n:(i + 1) * n] for i, g in enumerate(a64))
+    return matvec, rmatvec
+
+
+@pytest.mark.parametrize("dt,xtol", [(np.float32, 1e-4), (np.float64, 1e-10), (np.complex64, 1e-4)])
+def test_lsqr_matches_fp64_cpu_lsqr(Jets, oracle, dt, xtol):
+    nrow, shape, iters = 6, (16, 16, 16), 12
+    A, _, _, diags = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    matvec, rmatvec = _host_ops(diags, dt64)
+    hb = (u01(oracle, dt, 51, 0, nrow * n) - dt(0.5)).astype(dt)                    # inconsistent right-hand side
+    b = Jets.from_numpy(hb, Jets.range(A))
+    res = Jets.lsqr(A, b, atol=0.0, btol=0.0, conlim=0.0, maxiter=iters)
+    xr, info = lsqr_fp64(matvec, rmatvec, hb.astype(dt64), n, atol=0.0, btol=0.0, conlim=0.0, maxiter=iters)
+    assert res.itn == iters == info["itn"]
+    x = res.x.to_numpy().ravel(order="F").astype(dt64)
+    assert np.linalg.norm(x - xr) / np.linalg.norm(xr) < xtol
+    for (i1, r1, ar1), (i2, r2, ar2) in zip(res.history, info["history"]):
+        assert i1 == i2 and r1 == pytest.approx(r2, rel=max(xtol, 1e-9))
+    assert np.array_equal(b.to_numpy(), hb)                                          # b untouched (overwrite_b=False)
+    # closed form: the normal equations are diagonal
+    a64 = np.stack([g.astype(dt64) for g in diags])
+    x_ls = (np.conj(a64) * hb.astype(dt64).reshape(nrow, n)).sum(0) / (np.abs(a64) ** 2).sum(0)
+    assert np.linalg.norm(x - x_ls) / np.linalg.norm(x_ls) < 50 * xtol
+
+
+def test_lsqr_generic_path_and_vec_and_warm_start(Jets, oracle):
+    """Operators that are not all-diagonal take the mul! + fused-broadcast + norm path; vec(A) is unwrapped."""
+    dt, n, shape = np.float64, 24, (4, 6)
+    spc = Jets.JetSpace(dt, *shape)
+    g1, g2 = Jets.rand(spc, seed=61, stream=1), Jets.rand(spc, seed=61, stream=2)
+    scale = Jets.JopLn(dom=spc, rng=spc, df=Jets.constdiag_df, df_adj=Jets.constdiag_df_adj, s={"a": 0.5})
+    A = Jets.blockop([Jets.JopDiagonal(g1), Jets.JopIdentity(spc), scale, Jets.JopDiagonal(g2)])
+    h1, h2 = g1.to_numpy().ravel(order="F"), g2.to_numpy().ravel(order="F")
+    matvec = lambda x: np.concatenate([h1 * x, x, 0.5 * x, h2 * x])
+    rmatvec = lambda y: h1 * y[:n] + y[n:2 * n] + 0.5 * y[2 * n:3 * n] + h2 * y[3 * n:]
+    hb = u01(oracle, dt, 62, 0, 4 * n) - 0.5
+    b = Jets.from_numpy(hb, Jets.range(A))
+    xr, info = lsqr_fp64(matvec, rmatvec, hb, n, atol=1e-14, btol=1e-14, maxiter=50)
+    res = Jets.lsqr(Jets.vec_op(A), b, atol=1e-14, btol=1e-14, maxiter=50)           # lsqr(vec(A), vec(d))  (docs/src/index.md:240)
+    assert res.x.shape == shape
+    assert np.allclose(res.x.to_numpy().ravel(order="F"), xr, rtol=1e-10, atol=1e-12)
+    x0 = Jets.from_numpy((xr + 0.01).reshape(shape, order="F"))
+    res2 = Jets.lsqr(A, b, x0=x0, atol=1e-14, btol=1e-14, maxiter=50)
+    assert np.allclose(res2.x.to_numpy().ravel(order="F"), xr, rtol=1e-9, atol=1e-11)
+    xd, _ = lsqr_fp64(matvec, rmatvec, hb, n, damp=0.3, atol=1e-14, btol=1e-14, maxiter=50)
+    resd = Jets.lsqr(A, b, damp=0.3, atol=1e-14, btol=1e-14, maxiter=50)
+    assert np.allclose(resd.x.to_numpy().ravel(order="F"), xd, rtol=1e-9, atol=1e-11)
+
+
+def test_lsqr_consistent_system_recovers_x_true_and_stops(Jets, oracle):
+    dt, nrow, shape = np.float32, 8, (32, 32, 8)
+    A, _, _, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    x_true = Jets.rand(Jets.domain(A), seed=4, stream=0)
+    b = A * x_true
+    res = Jets.lsqr(A, b, atol=1e-6, btol=1e-6, maxiter=100, overwrite_b=True)
+    assert res.istop in (1, 2) and res.itn < 100
+    err = (res.x - x_true).materialize()
+    assert float(Jets.norm(err)) / float(Jets.norm(x_true)) < 1e-4
