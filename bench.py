@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--cpu-pairs", type=int, default=4)
     ap.add_argument("--tune", type=str, default="", help="k=v,k=v kernel knobs (fwd_group, fwd_unroll, fwd_wg, adj_unroll, adj_depth, adj_wg, nt; 0 = automatic)")
     ap.add_argument("--fused-normal", action="store_true", help="also time the fused A'A kernel (extra field, not the metric)")
+    ap.add_argument("--lsqr", type=int, default=0, help="also run this many LSQR iterations on b = A x_true (extra field, not the metric; 1 GPU)")
     return ap.parse_args()
 
 
@@ -197,6 +198,21 @@ def main():
         ms = e0.elapsed_ms(e1) / args.steps
         nb = (nloc * n + 2 * n) * s
         extra["fused_normal"] = {"ms": ms, "bytes": nb, "GBps": nb / ms / 1e6, "unfused_pair_ms": fwd_ms + adj_ms}
+
+    if args.lsqr and world == 1:
+        x_true = J.rand(J.domain(A), seed=4, stream=0)
+        J.mul_(d, A, x_true)                                   # b = A x_true, in the range vector's storage
+        J.synchronize()
+        t_l = time.perf_counter()
+        res = J.lsqr(A, d, atol=0.0, btol=0.0, conlim=0.0, maxiter=args.lsqr, overwrite_b=True, force_maxiter=True)
+        J.synchronize()
+        t_l = time.perf_counter() - t_l
+        err = (res.x - x_true).materialize()
+        it_bytes = (5 * nloc * n + 11 * n) * s               # fwd half 3Nn+n, adj half 2Nn+2n, x/w/v updates ~8n
+        extra["lsqr"] = {"iterations": res.itn, "ms_per_iteration": 1e3 * t_l / max(res.itn, 1), "algorithmic_bytes_per_iteration": it_bytes,
+                         "GBps": it_bytes * res.itn / t_l / 1e9, "rel_err_vs_x_true": float(J.norm(err)) / float(J.norm(x_true)),
+                         "istop": res.istop, "r1norm_first_last": [res.history[0][1], res.history[-1][1]],
+                         "schedule": "fused: u<-Av-(alpha/beta)u with ||u||^2 (jh_blockop_mul_axpby), v<-A'u/beta-beta v with ||v||^2 (jh_blockop_mul_adj_axpby); u never normalised in memory"}
 
     if rank == 0:
         pairs_per_s = args.steps / elapsed

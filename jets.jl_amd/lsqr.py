@@ -101,10 +101,11 @@ class _Engine:
 
 
 def lsqr(A, b, x0=None, damp: float = 0.0, atol: float = 1e-6, btol: float = 1e-6, conlim: float = 1e8, maxiter: int = 100,
-         overwrite_b: bool = False) -> LsqrResult:
+         overwrite_b: bool = False, force_maxiter: bool = False) -> LsqrResult:
     """min ||A x - b||_2 (+ damp^2 ||x||^2).  `b` lives in range(A) (a BlockArray for a block operator), the
     result in domain(A).  `overwrite_b=True` lets the solver use b's storage for the Lanczos vector u (at the
-    headline size b is 64 GiB)."""
+    headline size b is 64 GiB).  `force_maxiter=True` keeps iterating past every stopping rule (throughput
+    measurements only)."""
     A = _unwrap_vec(A)
     dom, rng = _j.domain(A), _j.range_(A)
     eng = _Engine(A)
@@ -206,6 +207,6 @@ def lsqr(A, b, x0=None, damp: float = 0.0, atol: float = 1e-6, btol: float = 1e-
             istop = 2
         if test1 <= rtol:
             istop = 1
-        if istop:
+        if istop and not (force_maxiter and itn < maxiter):
             break
     return LsqrResult(x, istop, itn, r1norm, r2norm, anorm, acond, arnorm, xnorm, history)

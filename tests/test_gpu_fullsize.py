@@ -101,3 +101,37 @@ def test_config4_1024x256cubed_properties(Jets, oracle):
     d0 = Jets.rand(Jets.range(A), seed=3, stream=0)                          # needs a third 64 GiB slab
     lhs = float(Jets.dot(d, d0))                                             # <A m, d0>
     assert abs(lhs - md) / abs(lhs + md) < 1e-5
+
+
+def test_config5_100_lsqr_iterations_on_1024x256cubed(Jets, oracle):
+    """BASELINE.json configs[4]: 100-iteration LSQR on the 1024 x 256^3 operator, b = A x_true.
+    fp tolerance: rel l2 error of x vs x_true <= 1e-4 (Float32 data; the fp64 CPU LSQR of
+    oracle/lsqr_ref.py reaches the same on a 4096-element slice of the problem, which is separable)."""
+    info = Jets.device_info()
+    if info["free_mem"] < 140 * 2 ** 30:
+        pytest.skip(f"needs ~130 GiB of free HBM, device reports {info['free_mem'] / 2**30:.0f} GiB")
+    from oracle.lsqr_ref import lsqr_fp64
+
+    nblocks, edge = 1024, 256
+    n = edge ** 3
+    blk = Jets.JetSpace(np.float32, edge, edge, edge)
+    coeff = Jets.rand(Jets.JetBSpace([blk] * nblocks), seed=1, stream=0)
+    A = Jets.blockop([[Jets.JopDiagonal(c)] for c in coeff.arrays])
+    x_true = Jets.rand(Jets.domain(A), seed=4, stream=0)
+    b = A * x_true
+    res = Jets.lsqr(A, b, atol=0.0, btol=0.0, conlim=0.0, maxiter=100, overwrite_b=True)
+    assert res.itn <= 100 and res.istop in (4, 5, 6, 7)       # runs to machine precision (tolerances are zero) or 100
+    err = (res.x - x_true).materialize()
+    rel = float(Jets.norm(err)) / float(Jets.norm(x_true))
+    assert rel <= 1e-4, rel
+    r = [h[1] for h in res.history]
+    assert r[5] < 1e-3 * r[0] or r[0] < 1e-3 * float(Jets.norm(x_true))       # converges within a few iterations
+    # the problem is separable per element: a W-element slice solved by the fp64 CPU LSQR must agree
+    W = 4096
+    ha = np.stack([oracle.rng_u01(np.float32, 1, 0, i * n, W) for i in range(nblocks)]).astype(np.float64)
+    hx = oracle.rng_u01(np.float32, 4, 0, 0, W).astype(np.float64)
+    hb = (ha.astype(np.float32) * hx.astype(np.float32)).astype(np.float64)   # b as the device computed it (one rounded product)
+    xr, _ = lsqr_fp64(lambda v: (ha * v).ravel(), lambda y: (ha * y.reshape(nblocks, W)).sum(0), hb.ravel(), W,
+                      atol=0.0, btol=0.0, conlim=0.0, maxiter=30)
+    got = res.x._download(0, W).astype(np.float64)
+    assert np.linalg.norm(got - xr) / np.linalg.norm(xr) <= 1e-4
