@@ -131,6 +131,11 @@ int jh_norm(const jh_bvec *x, double p, double *out);
 /* extrema(x), src/Jets.jl:870-878 (real dtypes) */
 int jh_extrema(const jh_bvec *x, double *mn, double *mx);
 
+/* child mul! of a dense operator (test/runtests.jl:27-33 JopBaz): y = A x (adjoint = 0) or y = A' x (adjoint = 1)
+ * for a column-major nr x nc matrix in device memory.  Forward: columns accumulated in order, product rounded
+ * then added (bit-identical to the sequential loop); adjoint: fp64 wave reduction (tolerance parity). */
+int jh_gemv(const void *A_device, int64_t nr, int64_t nc, int dtype, jh_bvec *y, const jh_bvec *x, int adjoint);
+
 /* ---------------------------------------------------------------- block operators ----------- */
 /* JetBlock(ops) for device-native blocks, src/Jets.jl:926-930. blocks is column-major nrow x ncol
  * (a Julia Matrix{Jop}); row_len[i] = length(range(ops[i,1])), col_len[j] = length(domain(ops[1,j])). */

@@ -652,6 +652,79 @@ int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n
     return finish_normsq(gx, normsq);
 }
 
+// ---- per-block loop (operators containing DENSE blocks): the reference's loops (src/Jets.jl:1010-1057)
+// with device temporaries -- one child launch (+ one accumulate launch) per non-zero block.
+int child_apply(int dtype, const jh_block_desc &b, void *out, const void *in, bool transposed)
+{
+    const bool adj = (b.adjoint != 0) != transposed;          // (op')' = op
+    const int64_t n_out = adj ? b.nc : b.nr;
+    switch (b.kind) {
+    case JH_OP_DENSE: return jh_launch_gemv(b.coeff, b.nr, b.nc, dtype, out, in, adj ? 1 : 0);
+    case JH_OP_DIAG: return jh_launch_hadamard_raw(out, b.coeff, in, dtype, n_out, adj ? 1 : 0);
+    case JH_OP_SCALE: {
+        const double cre = b.scale_re, cim = adj ? -b.scale_im : b.scale_im;
+        const void *xs[1] = {in};
+        return jh_launch_lincomb_raw(out, dtype, n_out, 1, &cre, &cim, xs);
+    }
+    case JH_OP_IDENTITY:
+        if (n_out > 0) JH_CHECK_HIP(hipMemcpyAsync(out, in, (size_t)n_out * jh_dtype_size(dtype), hipMemcpyDeviceToDevice, jh_ctx().stream));
+        return JH_OK;
+    default: return jh_fail(JH_ERR_INVALID, "child_apply: unexpected block kind %d", b.kind);
+    }
+}
+
+int accumulate(int dtype, void *acc, const void *term, int64_t n)     // acc .+= term
+{
+    const double one[2] = {1.0, 1.0}, zero[2] = {0.0, 0.0};
+    const void *xs[2] = {acc, term};
+    return jh_launch_lincomb_raw(acc, dtype, n, 2, one, zero, xs);
+}
+
+int loop_fwd(const jh_blockop *op, void *d, const void *m)           // JetBlock_df!
+{
+    const size_t es = jh_dtype_size(op->dtype);
+    for (int64_t i = 0; i < op->nrow; i++) {                          // (1015)
+        char *_d = (char *)d + (size_t)op->row_off[(size_t)i] * es;
+        for (int64_t j = 0; j < op->ncol; j++) {                      // (1020)
+            const jh_block_desc &b = op->blocks[(size_t)(i + j * op->nrow)];
+            if (b.kind == JH_OP_ZERO) continue;                       // (1022)
+            const char *_m = (const char *)m + (size_t)op->col_off[(size_t)j] * es;
+            if (op->ncol > 1) {
+                void *dtmp = nullptr;                                 // (1013, 1018)
+                JH_TRY(jh_ensure_scratch((size_t)op->row_len[(size_t)i] * es + 16, &dtmp));
+                JH_TRY(child_apply(op->dtype, b, dtmp, _m, false));   // mul!(dtmp, op, _m)
+                JH_TRY(accumulate(op->dtype, _d, dtmp, op->row_len[(size_t)i]));   // _d .+= dtmp   (1024)
+            } else {
+                JH_TRY(child_apply(op->dtype, b, _d, _m, false));     // (1026)
+            }
+        }
+    }
+    return JH_OK;
+}
+
+int loop_adj(const jh_blockop *op, void *m, const void *d)           // JetBlock_df'!
+{
+    const size_t es = jh_dtype_size(op->dtype);
+    for (int64_t j = 0; j < op->ncol; j++) {                          // (1039)
+        char *_m = (char *)m + (size_t)op->col_off[(size_t)j] * es;
+        if (op->nrow > 1) JH_TRY(jh_launch_fill_range(_m, op->dtype, op->col_len[(size_t)j], 0.0, 0.0));   // _m .= 0  (1042)
+        for (int64_t i = 0; i < op->nrow; i++) {                      // (1045)
+            const jh_block_desc &b = op->blocks[(size_t)(i + j * op->nrow)];
+            if (b.kind == JH_OP_ZERO) continue;                       // (1047)
+            const char *_d = (const char *)d + (size_t)op->row_off[(size_t)i] * es;
+            if (op->nrow > 1) {
+                void *mtmp = nullptr;                                 // (1037, 1043)
+                JH_TRY(jh_ensure_scratch((size_t)op->col_len[(size_t)j] * es + 16, &mtmp));
+                JH_TRY(child_apply(op->dtype, b, mtmp, _d, true));    // mul!(mtmp, op', _d)
+                JH_TRY(accumulate(op->dtype, _m, mtmp, op->col_len[(size_t)j]));   // _m .+= mtmp   (1049)
+            } else {
+                JH_TRY(child_apply(op->dtype, b, _m, _d, true));      // (1051)
+            }
+        }
+    }
+    return JH_OK;
+}
+
 int check_vectors(const jh_blockop *op, const jh_bvec *rng, const jh_bvec *dom, const char *who)
 {
     JH_REQUIRE(op && rng && dom, "%s: null argument", who);
@@ -705,6 +778,8 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
             else if (b.kind == JH_OP_DENSE) {
                 op->elementwise = false;
                 op->all_diag = false;
+                if (!b.coeff && b.nr * b.nc > 0)
+                    status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: DENSE block (%lld,%lld) has no matrix", (long long)i, (long long)j);
             } else if (b.kind == JH_OP_DIAG || b.kind == JH_OP_IDENTITY || b.kind == JH_OP_SCALE) {
                 if (b.nr != b.nc)
                     status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: elementwise block (%lld,%lld) must be square (%lld x %lld)",
@@ -721,8 +796,6 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
                 status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: unknown block kind %d at (%lld,%lld)", b.kind, (long long)i, (long long)j);
             }
         }
-    if (status == JH_OK && !op->elementwise)
-        status = jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_create: DENSE blocks are not implemented on the device path yet");
     if (status != JH_OK) { delete op; return status; }
 
     // strided-diagonal detection: coeff[i] = coeff[0] + i*stride  (e.g. one slab holding all diagonals)
@@ -788,6 +861,7 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
         case JH_C64: return launch_tall_fwd<double, 2, 2>(op, d->data, m->data, 2 * n);
         }
     }
+    if (!op->elementwise) return loop_fwd(op, d->data, m->data);
     switch (op->dtype) {
     case JH_F32: return general_fwd<float, 1>(op, d->data, m->data);
     case JH_F64: return general_fwd<double, 1>(op, d->data, m->data);
@@ -810,6 +884,7 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
         case JH_C64: return launch_tall_adj<double, 2, 2, 0>(op, m->data, d->data, 2 * n);
         }
     }
+    if (!op->elementwise) return loop_adj(op, m->data, d->data);
     switch (op->dtype) {
     case JH_F32: return general_adj<float, 1>(op, m->data, d->data);
     case JH_F64: return general_adj<double, 1>(op, m->data, d->data);

@@ -36,6 +36,25 @@ int jh_ensure_partials(int64_t n)
     return JH_OK;
 }
 
+int jh_ensure_scratch(size_t bytes, void **out)
+{
+    jh_context &c = jh_ctx();
+    if (bytes > c.scratch_cap) {
+        size_t cap = c.scratch_cap ? c.scratch_cap : (size_t)1 << 20;
+        while (cap < bytes) cap *= 2;
+        if (c.scratch_dev) {
+            JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+            JH_CHECK_HIP(hipFree(c.scratch_dev));
+            c.scratch_dev = nullptr;
+            c.scratch_cap = 0;
+        }
+        JH_CHECK_HIP(hipMalloc(&c.scratch_dev, cap));
+        c.scratch_cap = cap;
+    }
+    *out = c.scratch_dev;
+    return JH_OK;
+}
+
 int jh_require_ready()
 {
     if (!jh_ctx().ready) return jh_fail(JH_ERR_STATE, "libjetship: jh_init(device) has not been called");
@@ -95,6 +114,7 @@ int jh_shutdown(void)
     (void)hipStreamSynchronize(c.stream);
     if (c.red_dev) (void)hipFree(c.red_dev);
     if (c.part_dev) (void)hipFree(c.part_dev);
+    if (c.scratch_dev) (void)hipFree(c.scratch_dev);
     if (c.red_host) (void)hipHostFree(c.red_host);
     if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
     c = jh_context();

@@ -38,6 +38,8 @@ struct jh_context {
     double *red_host = nullptr;        // pinned, 8 doubles
     double *part_dev = nullptr;        // growable per-workgroup partials of the fused solver updates
     int64_t part_cap = 0;
+    void *scratch_dev = nullptr;       // growable scratch: dtmp / mtmp of the per-block loop (src/Jets.jl:1013, 1037)
+    size_t scratch_cap = 0;
     // tuning knobs (jh_tune_set)
     // 0 = pick from the problem size (jh_blockop.hip: pick_fwd_shape / pick_adj_shape)
     int64_t fwd_group = 0;             // block rows streamed per workgroup (tall forward)
@@ -111,3 +113,8 @@ struct jh_blockop {
 int jh_ensure_partials(int64_t n);     // grows ctx.part_dev to >= n doubles (may synchronise + reallocate)
 // vecops entry used by blockop for generic pieces
 int jh_launch_fill_range(void *ptr, int dtype, int64_t count, double re, double im);
+int jh_launch_hadamard_raw(void *dst, const void *x, const void *y, int dtype, int64_t count, int conj_x);
+int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const double *cre, const double *cim, const void *const *x);
+// dense child operator (jh_dense.hip): y = A x (rows) or y = A^H x / A^T x (cols); A column-major nr x nc
+int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, const void *x, int adjoint);
+int jh_ensure_scratch(size_t bytes, void **out);   // growable device scratch (block-loop temporaries)

@@ -395,6 +395,32 @@ int hadamard_launch(void *dst, const void *x, const void *y, int64_t n_elems, in
 
 }  // namespace
 
+int jh_launch_hadamard_raw(void *dst, const void *x, const void *y, int dtype, int64_t count, int conj_x)
+{
+    switch (dtype) {
+    case JH_F32: return hadamard_launch<float, 1>(dst, x, y, count, conj_x);
+    case JH_F64: return hadamard_launch<double, 1>(dst, x, y, count, conj_x);
+    case JH_C32: return hadamard_launch<float, 2>(dst, x, y, count, conj_x);
+    case JH_C64: return hadamard_launch<double, 2>(dst, x, y, count, conj_x);
+    }
+    return jh_fail(JH_ERR_INVALID, "hadamard: unknown dtype %d", dtype);
+}
+
+// dst = c0*x0 (+ c1*x1): k in {1, 2}
+int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const double *cre, const double *cim, const void *const *x)
+{
+    LincombArgs a;
+    a.k = k;
+    for (int j = 0; j < k; j++) { a.x[j] = x[j]; a.cre[j] = cre[j]; a.cim[j] = cim[j]; }
+    switch (dtype) {
+    case JH_F32: return lincomb_launch<float, 1>(dst, count, a);
+    case JH_F64: return lincomb_launch<double, 1>(dst, count, a);
+    case JH_C32: return lincomb_launch<float, 2>(dst, count, a);
+    case JH_C64: return lincomb_launch<double, 2>(dst, count, a);
+    }
+    return jh_fail(JH_ERR_INVALID, "lincomb: unknown dtype %d", dtype);
+}
+
 int jh_launch_fill_range(void *ptr, int dtype, int64_t count, double re, double im)
 {
     switch (dtype) {

@@ -24,7 +24,7 @@ from .jets import Jet, Jop, JopLn, JopNl, JopAdjoint, mul_, domain, range_, jet,
 __all__ = [
     "JetBlock", "JopBlock", "blockop", "JopZeroBlock", "JopZeroBlock_df", "iszero", "JetBlock_f", "JetBlock_df",
     "JetBlock_df_adj", "nblocks_op", "getblock_op", "isblockop", "JopDiagonal", "JopIdentity", "diagonal_df",
-    "diagonal_df_adj", "identity_df", "NativeBlockOp",
+    "diagonal_df_adj", "identity_df", "NativeBlockOp", "JopDense", "dense_df", "dense_df_adj",
 ]
 
 
@@ -65,6 +65,24 @@ def JopIdentity(spc: JetAbstractSpace) -> JopLn:
     return JopLn(df=identity_df, dom=spc, rng=spc)
 
 
+def dense_df(d, m, *, A, **kw):  # test/runtests.jl:27   d .= A * m
+    check(lib.jh_gemv(C.c_void_p(A.ptr), A.shape[0], A.shape[1], dtype_code(A.dtype), d.handle, m.handle, 0))
+    return d
+
+
+def dense_df_adj(m, d, *, A, **kw):  # test/runtests.jl:28   m .= A' * d
+    check(lib.jh_gemv(C.c_void_p(A.ptr), A.shape[0], A.shape[1], dtype_code(A.dtype), m.handle, d.handle, 1))
+    return m
+
+
+def JopDense(A: DeviceArray) -> JopLn:
+    """Dense matrix operator over a 2-D device array (the reference's test fixture JopBaz, test/runtests.jl:27-33)."""
+    if A.ndim != 2:
+        raise ValueError("JopDense needs a 2-D device array")
+    dom, rng = JetSpace(A.dtype, A.shape[1]), JetSpace(A.dtype, A.shape[0])
+    return JopLn(df=dense_df, df_adj=dense_df_adj, dom=dom, rng=rng, s={"A": A})
+
+
 def _native_desc(op: Jop):
     """(kind, adjoint_flag, coeff_array_or_None, scale) if `op` is device-native, else None."""
     adj = 0
@@ -81,6 +99,8 @@ def _native_desc(op: Jop):
         return ("diag", adj, j.s["diagonal"], 0.0)
     if j.df is _j.constdiag_df and j.df_adj is _j.constdiag_df_adj:
         return ("scale", adj, None, complex(j.s["a"]))
+    if j.df is dense_df and j.df_adj is dense_df_adj:
+        return ("dense", adj, j.s["A"], 0.0)
     return None
 
 

@@ -207,6 +207,6 @@ def lsqr(A, b, x0=None, damp: float = 0.0, atol: float = 1e-6, btol: float = 1e-
             istop = 2
         if test1 <= rtol:
             istop = 1
-        if istop and not (force_maxiter and itn < maxiter):
+        if istop and not (force_maxiter and itn < maxiter and alpha > 0 and beta > 0):
             break
     return LsqrResult(x, istop, itn, r1norm, r2norm, anorm, acond, arnorm, xnorm, history)

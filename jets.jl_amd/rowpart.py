@@ -64,12 +64,20 @@ class Comm:
         self._stream_ctx = stream_ctx
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self._views = {}   # id(vector) -> (vector, tensor): the solver all-reduces the same few vectors every iteration
 
-    def all_reduce_sum_(self, x):
-        """In-place sum of a replicated domain vector over all ranks (the adjoint accumulate)."""
-        if self.world == 1:
+    def all_reduce_sum_(self, x, force: bool = False):
+        """In-place sum of a replicated domain vector over all ranks (the adjoint accumulate).
+        `force` runs the collective even with one rank (exercises the RCCL path on a one-GPU box)."""
+        if self.world == 1 and not (force and self._dist.is_initialized()):
             return x
-        t = self._as_tensor(x)
+        hit = self._views.get(id(x))
+        if hit is None or hit[0] is not x:
+            if len(self._views) > 64:
+                self._views.clear()
+            hit = (x, self._as_tensor(x))
+            self._views[id(x)] = hit
+        t = hit[1]
         if self._stream_ctx is not None:
             with self._stream_ctx():
                 self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
@@ -108,10 +116,10 @@ class RowPartitionedOp:
         """d_local = A[rows of this rank] m   -- no communication."""
         return self._mul(d_local, self.local_op, m)
 
-    def mul_adj_(self, m, d_local):
+    def mul_adj_(self, m, d_local, force_collective: bool = False):
         """m = sum over ALL rows A_i' d_i  -- local ordered sum, then one all-reduce."""
         self._mul_adj(m, self.local_op, d_local)
-        return self.comm.all_reduce_sum_(m)
+        return self.comm.all_reduce_sum_(m, force=force_collective)
 
     def dot_range(self, x_local, y_local) -> float:
         return self.comm.all_reduce_scalars([float(self._dot(x_local, y_local))], "sum")[0]
@@ -140,7 +148,11 @@ def for_device(part: RowPartition, local_op) -> RowPartitionedOp:
     ext = torch.cuda.ExternalStream(_device.stream_handle(), device=torch.device("cuda", _device.init()))
 
     def as_tensor(x):
-        return torch.as_tensor(x, device=torch.device("cuda", _device.init()))
+        # RCCL needs a contiguous tensor: hand it the flat 1-D view of the slab (shares memory with x)
+        flat = x if len(x.shape) == 1 else x.reshape((x.length(),))
+        t = torch.as_tensor(flat, device=torch.device("cuda", _device.init()))
+        t._jets_owner = flat  # keep the view alive while torch holds the pointer
+        return t
 
     def stream_ctx():
         return torch.cuda.stream(ext)

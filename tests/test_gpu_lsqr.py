@@ -130,3 +130,36 @@ def test_lsqr_consistent_system_recovers_x_true_and_stops(Jets, oracle):
     assert res.istop in (1, 2) and res.itn < 100
     err = (res.x - x_true).materialize()
     assert float(Jets.norm(err)) / float(Jets.norm(x_true)) < 1e-4
+
+
+def test_rccl_path_with_one_rank(Jets, oracle):
+    """The product wiring of the exchange step (rowpart.for_device): zero-copy torch view of the library's
+    slab, collective ordered on the library's HIP stream.  One rank only here (one GPU); the two-rank logic
+    is covered by the gloo tests."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        dt, nrow, shape = np.float32, 4, (16, 8, 8)
+        A, _, ops, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+        n = int(np.prod(shape))
+        part = Jets.rowpart.partition_rows(nrow, 1, 0)
+        shard = Jets.rowpart.for_device(part, A)
+        d = Jets.rand(Jets.range(A), seed=71, stream=0)
+        hd = u01(oracle, dt, 71, 0, nrow * n)
+        mt = Jets.zeros(Jets.domain(A))
+        shard.mul_adj_(mt, d, force_collective=True)                 # local adjoint + ncclAllReduce over 1 rank
+        Jets.synchronize()
+        ref = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], [hd[i * n:(i + 1) * n].copy() for i in range(nrow)])
+        assert_bits_equal(mt.to_numpy().ravel(order="F"), ref[0], "adjoint through the RCCL path")
+        assert shard.dot_range(d, d) == pytest.approx(float(np.dot(hd.astype(np.float64), hd.astype(np.float64))), rel=1e-6)
+        assert shard.norm_range(d, 2) == pytest.approx(float(np.linalg.norm(hd.astype(np.float64))), rel=1e-6)
+    finally:
+        dist.destroy_process_group()
