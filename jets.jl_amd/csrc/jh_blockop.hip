@@ -420,6 +420,76 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
     }
 }
 
+// 16-byte-per-lane variants of the two general kernels, used when every block offset, block length and
+// coefficient pointer is a multiple of 16 bytes.  Same loop order and rounding as the scalar versions.
+template <typename S, int E, int NS, typename V>
+__device__ inline V apply_block_vec(const jh_dev_block &b, V x, int64_t s, bool transposed)
+{
+    const bool cj = (b.adjoint != 0) != transposed;
+    switch (b.kind) {
+    case JH_OP_IDENTITY: return x;
+    case JH_OP_SCALE: {
+        if constexpr (E == 1) {
+            return (V)(S)b.sre * x;
+        } else {
+            V a;
+#pragma unroll
+            for (int e = 0; e < NS; e += 2) { a[e] = (S)b.sre; a[e + 1] = (S)b.sim; }
+            return vmul<S, E, NS, V>(a, x, cj);
+        }
+    }
+    case JH_OP_DIAG: return vmul<S, E, NS, V>(ld<false>(reinterpret_cast<const V *>((const S *)b.coeff + s)), x, cj);
+    default: return (V)(S)0;
+    }
+}
+
+template <typename S, int E, int NS>
+__global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
+                                        const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
+                                        const S *__restrict__ m, S *__restrict__ d)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t i = blockIdx.y;
+    const int64_t ns = (row_off[i + 1] - row_off[i]) * E;                 // scalars in this block row
+    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * NS; s < ns; s += (int64_t)gridDim.x * blockDim.x * NS) {
+        V acc = (V)(S)0;
+        bool touched = false;
+        if (ncol > 1) acc = ld<false>(reinterpret_cast<const V *>(d + row_off[i] * E + s));
+        for (int64_t j = 0; j < ncol; j++) {
+            const jh_dev_block b = blocks[i + j * nrow];
+            if (b.kind == JH_OP_ZERO) continue;
+            V x = ld<false>(reinterpret_cast<const V *>(m + col_off[j] * E + s));
+            V p = apply_block_vec<S, E, NS, V>(b, x, s, false);
+            acc = (ncol > 1) ? acc + p : p;
+            touched = true;
+        }
+        if (touched) st<false>(reinterpret_cast<V *>(d + row_off[i] * E + s), acc);
+    }
+}
+
+template <typename S, int E, int NS>
+__global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
+                                        const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
+                                        S *__restrict__ m, const S *__restrict__ d)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t j = blockIdx.y;
+    const int64_t ns = (col_off[j + 1] - col_off[j]) * E;
+    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * NS; s < ns; s += (int64_t)gridDim.x * blockDim.x * NS) {
+        V acc = (V)(S)0;
+        bool touched = (nrow > 1);
+        for (int64_t i = 0; i < nrow; i++) {
+            const jh_dev_block b = blocks[i + j * nrow];
+            if (b.kind == JH_OP_ZERO) continue;
+            V x = ld<false>(reinterpret_cast<const V *>(d + row_off[i] * E + s));
+            V p = apply_block_vec<S, E, NS, V>(b, x, s, true);
+            acc = (nrow > 1) ? acc + p : p;
+            touched = true;
+        }
+        if (touched) st<false>(reinterpret_cast<V *>(m + col_off[j] * E + s), acc);
+    }
+}
+
 // ------------------------------------------------------------------ launch helpers ------------
 // Kernel shapes, fitted to interleaved sweeps on MI355X (profiles/sweep_r01*.txt, profiles/repeat_r01.txt; Float32):
 //   forward  1024 x 256^3 (128 GiB): sequential row sweep, 1024 threads x 8 vectors x 16 rows: 6.04 TB/s in
@@ -552,15 +622,35 @@ bool tall_fast_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr
     return true;
 }
 
+// every block boundary / coefficient pointer / vector base on a 16-byte boundary?
+bool general_vec_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
+{
+    const int64_t es = (int64_t)jh_dtype_size(op->dtype);
+    if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & 15u) return false;
+    for (int64_t v : op->row_len) if ((v * es) % 16) return false;
+    for (int64_t v : op->col_len) if ((v * es) % 16) return false;
+    for (const auto &b : op->blocks) if (b.kind == JH_OP_DIAG && (((uintptr_t)b.coeff) & 15u)) return false;
+    return true;
+}
+
 template <typename S, int E>
 int general_fwd(const jh_blockop *op, void *d, const void *m)
 {
     int64_t maxn = 0;
     for (int64_t i = 0; i < op->nrow; i++) maxn = op->row_len[i] > maxn ? op->row_len[i] : maxn;
     if (maxn == 0) return JH_OK;
+    JH_REQUIRE(op->nrow <= 65535, "general block forward supports at most 65535 block rows (got %lld)", (long long)op->nrow);
+    if (general_vec_ok(op, d, m)) {
+        constexpr int NS = 16 / sizeof(S);
+        int64_t gxv = (maxn * E / NS + 255) / 256;
+        if (gxv > 4096) gxv = 4096;
+        hipLaunchKernelGGL((k_block_fwd_general_vec<S, E, NS>), dim3((unsigned)gxv, (unsigned)op->nrow), dim3(256), 0, jh_ctx().stream,
+                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d);
+        JH_CHECK_HIP(hipGetLastError());
+        return JH_OK;
+    }
     int64_t gx = (maxn + 255) / 256;
     if (gx > 4096) gx = 4096;
-    JH_REQUIRE(op->nrow <= 65535, "general block forward supports at most 65535 block rows (got %lld)", (long long)op->nrow);
     hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3((unsigned)gx, (unsigned)op->nrow), dim3(256), 0, jh_ctx().stream,
                        op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d);
     JH_CHECK_HIP(hipGetLastError());
@@ -573,9 +663,18 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
     int64_t maxn = 0;
     for (int64_t j = 0; j < op->ncol; j++) maxn = op->col_len[j] > maxn ? op->col_len[j] : maxn;
     if (maxn == 0) return JH_OK;
+    JH_REQUIRE(op->ncol <= 65535, "general block adjoint supports at most 65535 block columns (got %lld)", (long long)op->ncol);
+    if (general_vec_ok(op, d, m)) {
+        constexpr int NS = 16 / sizeof(S);
+        int64_t gxv = (maxn * E / NS + 255) / 256;
+        if (gxv > 4096) gxv = 4096;
+        hipLaunchKernelGGL((k_block_adj_general_vec<S, E, NS>), dim3((unsigned)gxv, (unsigned)op->ncol), dim3(256), 0, jh_ctx().stream,
+                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d);
+        JH_CHECK_HIP(hipGetLastError());
+        return JH_OK;
+    }
     int64_t gx = (maxn + 255) / 256;
     if (gx > 4096) gx = 4096;
-    JH_REQUIRE(op->ncol <= 65535, "general block adjoint supports at most 65535 block columns (got %lld)", (long long)op->ncol);
     hipLaunchKernelGGL((k_block_adj_general<S, E>), dim3((unsigned)gx, (unsigned)op->ncol), dim3(256), 0, jh_ctx().stream,
                        op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d);
     JH_CHECK_HIP(hipGetLastError());

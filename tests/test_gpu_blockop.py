@@ -149,23 +149,23 @@ def _mixed_ops(Jets, oracle, dt, kinds, lens_r, lens_c, seed=21):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_mixed_3x4_with_zero_blocks_bit_exact(Jets, oracle, dt):
+@pytest.mark.parametrize("n", [10, 64, 4100])      # 10: scalar kernel (odd 16-byte alignment); 64, 4100: 16-byte vector kernel
+def test_mixed_3x4_with_zero_blocks_bit_exact(Jets, oracle, dt, n):
     """test/runtests.jl:622-695 shape (3x4, zero blocks at (2,2),(3,4)) with native kinds."""
     kinds = [["diag", "identity", "diag", "scale"],
              ["diag_adj", "zero", "diag", "diag"],
              ["scale", "diag", "diag_adj", "zero"]]
-    n = 10
     A, ops = _mixed_ops(Jets, oracle, dt, kinds, [n] * 3, [n] * 4)
     assert Jets.nblocks_op(A) == (3, 4) and Jets.nblocks_op(A, 1) == 3 and Jets.nblocks_op(A, 2) == 4
-    assert isinstance(Jets.domain(A), Jets.JetBSpace) and Jets.domain(A).length() == 40 and Jets.range(A).length() == 30
+    assert isinstance(Jets.domain(A), Jets.JetBSpace) and Jets.domain(A).length() == 4 * n and Jets.range(A).length() == 3 * n
     m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=2)
-    hm = u01(oracle, dt, SEED_M, 2, 40)
+    hm = u01(oracle, dt, SEED_M, 2, 4 * n)
     hm_blocks = [hm[j * n:(j + 1) * n].copy() for j in range(4)]
     d = A * m
     ref_d = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(3)], hm_blocks)
     assert_bits_equal(d.to_numpy(), np.concatenate(ref_d), "F*m")
     dd = Jets.rand(Jets.range(A), seed=SEED_D, stream=2)
-    hd = u01(oracle, dt, SEED_D, 2, 30)
+    hd = u01(oracle, dt, SEED_D, 2, 3 * n)
     hd_blocks = [hd[i * n:(i + 1) * n].copy() for i in range(3)]
     mt = Jets.mul_(Jets.rand(Jets.domain(A), seed=5, stream=5), A.H, dd)          # dirty output (:684)
     ref_m = oracle.block_df_adj(ops, [np.full(n, 3, dtype=dt) for _ in range(4)], hd_blocks)
