@@ -545,13 +545,17 @@ int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     const int64_t a_stride = op->diag_stride_elems * E;
     int64_t G = sh.aux;
     if (G > op->nrow) G = op->nrow;
-    const int64_t gy = (op->nrow + G - 1) / G;
+    int64_t gy = (op->nrow + G - 1) / G;
+    {   // HIP: grid x block must stay below 2^32 threads
+        const int64_t gx0 = (n_scalars / NS + (int64_t)sh.unroll * BLK - 1) / ((int64_t)sh.unroll * BLK);
+        while (gx0 * gy * BLK >= ((int64_t)1 << 32) && G < op->nrow) { G *= 2; gy = (op->nrow + G - 1) / G; }
+    }
     int64_t band = sh.order <= 0 ? 1 : (sh.order == 1 ? gy : sh.order);   // order: 0 sequential, 1 all rows, k>1 = k groups per band
     if (band > gy) band = gy;
 #define JH_FWD_CASE(U)                                                                                               \
     case U: {                                                                                                         \
         int64_t gx = (n_scalars + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                               \
-        JH_REQUIRE(gx * gy < (int64_t)1 << 31, "tall forward: grid of %lld workgroups is too large", (long long)(gx * gy)); \
+        JH_REQUIRE(gx * gy * BLK < (int64_t)1 << 32, "tall forward: grid of %lld workgroups is too large", (long long)(gx * gy)); \
         hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, NT, BLK>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, \
                            op->dev_blocks, op->nrow, (int)G, a_base, a_stride, (const S *)m, (S *)d, n_scalars,      \
                            (unsigned)gx, (unsigned)gy, (unsigned)band);                                            \
@@ -704,13 +708,18 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     const int64_t nvec = n_scalars / NS;
     // three streams per row (a, d in, d out): same tilings as the plain forward, fewer instantiations
     int wg, U, G;
-    if (nvec >= ((int64_t)1 << 21) && op->nrow >= 512) { wg = 1024; U = 8; G = 16; }
-    else if (nvec >= ((int64_t)1 << 21)) { wg = 256; U = 4; G = 4; }
-    else { wg = 256; U = 1; G = 2; }
+    // profiles/sweep_r01_update_1024x256.txt: 256 threads x 4 vectors x 4 rows, 5.50 TB/s (1024 x 8 x 16: 5.29)
+    if (nvec >= ((int64_t)1 << 21)) { wg = 256; U = 4; G = 4; }
+    else { wg = 256; U = 4; G = 8; }
+    if (c.fwd_wg == 1024 && c.fwd_unroll == 8) { wg = 1024; U = 8; }          // knob overrides (3 instantiated tilings)
+    else if (c.fwd_wg == 256 && c.fwd_unroll == 4) { wg = 256; U = 4; }
+    else if (c.fwd_wg == 256 && c.fwd_unroll == 1) { wg = 256; U = 1; }
+    if (c.fwd_group) G = (int)c.fwd_group;
     if (G > op->nrow) G = (int)op->nrow;
-    const int64_t gy = (op->nrow + G - 1) / G;
     const int64_t gx = (nvec + (int64_t)wg * U - 1) / ((int64_t)wg * U);
-    JH_REQUIRE(gx * gy < (int64_t)1 << 31, "fused forward update: grid of %lld workgroups is too large", (long long)(gx * gy));
+    int64_t gy = (op->nrow + G - 1) / G;
+    while (gx * gy * wg >= ((int64_t)1 << 32) && G < op->nrow) { G *= 2; gy = (op->nrow + G - 1) / G; }   // HIP: grid x block < 2^32 threads
+    JH_REQUIRE(gx * gy * wg < ((int64_t)1 << 32), "fused forward update: grid of %lld workgroups is too large", (long long)(gx * gy));
     JH_TRY(jh_ensure_partials(gx * gy));
 #define JH_LAUNCH(BLK, UU)                                                                                             \
     hipLaunchKernelGGL((k_tall_diag_fwd_update<S, E, NS, UU, BLK>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream,  \
