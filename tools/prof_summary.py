@@ -22,8 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name: str) -> str:
-    for key in ("k_tall_diag_fwd", "k_tall_diag_adj", "k_block_fwd_general", "k_block_adj_general", "k_uniform", "k_reduce_final",
-                "k_reduce", "k_lincomb", "k_hadamard", "k_fill", "k_gemv"):
+    for key in ("k_tall_diag_fwd_update", "k_tall_diag_adj_update", "k_tall_diag_fwd", "k_tall_diag_adj", "k_block_fwd_general", "k_block_adj_general", "k_uniform", "k_reduce_final",
+                "k_reduce", "k_lincomb", "k_hadamard", "k_fill", "k_gemv", "k_sum_partials"):
         if key in name:
             return key
     return name.split("(")[0][-48:]
@@ -57,7 +57,8 @@ def main():
     fetch, nf = counters(args.fetch, "FETCH_SIZE") if args.fetch else ({}, {})
     write, nw = counters(args.write, "WRITE_SIZE") if args.write else ({}, {})
     n = args.edge ** 3
-    algo = {"k_tall_diag_fwd": (2 * args.nblocks * n + n) * 4, "k_tall_diag_adj": (2 * args.nblocks * n + n) * 4}
+    algo = {"k_tall_diag_fwd": (2 * args.nblocks * n + n) * 4, "k_tall_diag_adj": (2 * args.nblocks * n + n) * 4,
+            "k_tall_diag_fwd_update": (3 * args.nblocks * n + n) * 4, "k_tall_diag_adj_update": (2 * args.nblocks * n + 2 * n) * 4}
     lines = [f"# rocprofv3 summary, round {args.round}", "",
              f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- {args.cmd}` on one MI355X (gfx950);",
              "PMC: separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes of the same program (3 timed steps).",
