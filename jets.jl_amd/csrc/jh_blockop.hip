@@ -304,12 +304,15 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block
     wg_sum_store<BLK>(nrm, partials + blockIdx.x);
 }
 
-// one workgroup folds the per-workgroup partials in index order (deterministic)
-__global__ void k_sum_partials(const double *__restrict__ partials, int64_t n, double *__restrict__ out)
+// fold the per-workgroup partials deterministically: workgroup b sums the contiguous chunk
+// [b*chunk, (b+1)*chunk) in a fixed order and writes out[b]; launched twice for large counts (1M -> 1024 -> 1)
+__global__ void k_sum_partials(const double *__restrict__ partials, int64_t n, int64_t chunk, double *__restrict__ out)
 {
+    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    const int64_t hi = lo + chunk < n ? lo + chunk : n;
     double v = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) v += partials[i];
-    wg_sum_store<256>(v, out);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) v += partials[i];
+    wg_sum_store<256>(v, out + blockIdx.x);
 }
 
 // ------------------------------------------------------------------ general path --------------
@@ -689,7 +692,14 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
 int finish_normsq(int64_t nparts, double *normsq)
 {
     jh_context &c = jh_ctx();
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, c.part_dev, nparts, c.red_dev);
+    if (nparts > 8192) {        // two levels: <= 1024 chunk sums (red_dev + 16 ...), then one workgroup
+        const int64_t nchunk = 1024, chunk = (nparts + nchunk - 1) / nchunk;
+        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)nchunk), dim3(256), 0, c.stream, c.part_dev, nparts, chunk, c.red_dev + 16);
+        JH_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, c.red_dev + 16, nchunk, nchunk, c.red_dev);
+    } else {
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, c.part_dev, nparts, nparts, c.red_dev);
+    }
     JH_CHECK_HIP(hipGetLastError());
     if (normsq) {
         JH_CHECK_HIP(hipMemcpyAsync(c.red_host, c.red_dev, sizeof(double), hipMemcpyDeviceToHost, c.stream));
