@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--cpu-pairs", type=int, default=4)
     ap.add_argument("--tune", type=str, default="", help="k=v,k=v kernel knobs (fwd_group, fwd_unroll, fwd_wg, adj_unroll, adj_depth, adj_wg, nt; 0 = automatic)")
     ap.add_argument("--fused-normal", action="store_true", help="also time the fused A'A kernel (extra field, not the metric)")
-    ap.add_argument("--lsqr", type=int, default=0, help="also run this many LSQR iterations on b = A x_true (extra field, not the metric; 1 GPU)")
+    ap.add_argument("--lsqr", type=int, default=0, help="also run this many LSQR iterations on b = A x_true (extra field, not the metric)")
     return ap.parse_args()
 
 
@@ -90,9 +90,7 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
-    late_torch = world == 1 and os.environ.get("BENCH_LATE_TORCH", "0") == "1"
-    if not late_torch:
-        import torch
+    import torch
 
     force_dist = os.environ.get("BENCH_FORCE_DIST", "0") == "1"      # run the RCCL path even with one rank (validation)
     dist = None
@@ -138,9 +136,6 @@ def main():
         adjoint()
 
     ev = [[J.Event() for _ in range(3)] for _ in range(args.steps)]
-
-    if late_torch:
-        import torch
 
     def fence():
         J.synchronize()
@@ -200,16 +195,21 @@ def main():
         nb = (nloc * n + 2 * n) * s
         extra["fused_normal"] = {"ms": ms, "bytes": nb, "GBps": nb / ms / 1e6, "unfused_pair_ms": fwd_ms + adj_ms}
 
-    if args.lsqr and world == 1:
+    if args.lsqr:
         x_true = J.rand(J.domain(A), seed=4, stream=0)
-        J.mul_(d, A, x_true)                                   # b = A x_true, in the range vector's storage
-        J.synchronize()
+        J.mul_(d, A, x_true)                                   # b = A x_true (this rank's rows), in the range vector's storage
+        fence()
         t_l = time.perf_counter()
-        res = J.lsqr(A, d, atol=0.0, btol=0.0, conlim=0.0, maxiter=args.lsqr, overwrite_b=True, force_maxiter=True)
-        J.synchronize()
+        res = J.lsqr(shard if shard is not None else A, d, atol=0.0, btol=0.0, conlim=0.0, maxiter=args.lsqr, overwrite_b=True,
+                     force_maxiter=True)
+        fence()
         t_l = time.perf_counter() - t_l
+        if dist is not None:
+            tt = torch.tensor([t_l], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_l = float(tt.item())
         err = (res.x - x_true).materialize()
-        it_bytes = (5 * nloc * n + 11 * n) * s               # fwd half 3Nn+n, adj half 2Nn+2n, x/w/v updates ~8n
+        it_bytes = (5 * nblocks * n + 11 * n * world) * s   # whole job: fwd half 3Nn+n, adj half 2Nn+2n, x/w/v updates ~8n per rank
         extra["lsqr"] = {"iterations": res.itn, "ms_per_iteration": 1e3 * t_l / max(res.itn, 1), "algorithmic_bytes_per_iteration": it_bytes,
                          "GBps": it_bytes * res.itn / t_l / 1e9, "rel_err_vs_x_true": float(J.norm(err)) / float(J.norm(x_true)),
                          "istop": res.istop, "r1norm_first_last": [res.history[0][1], res.history[-1][1]],
@@ -234,8 +234,6 @@ def main():
                 "workload": f"{nblocks}x1 tall JopBlock of diagonal JopLn, {edge}^3 Float32 blocks, fwd+adj mul! pair",
                 "nblocks": nblocks, "block": [edge, edge, edge], "rows_per_gpu": nloc,
                 "parallelism": f"row-partition x{world}" + (" + RCCL all-reduce(64 MiB) in adjoint" if world > 1 else ""),
-                "slab_va_alignment_log2": {"coeff": (coeff.ptr & -coeff.ptr).bit_length() - 1, "d": (d.ptr & -d.ptr).bit_length() - 1,
-                                           "m": (m.ptr & -m.ptr).bit_length() - 1},
                 "tune": {k: J.tune_get(k) for k in ("fwd_group", "fwd_unroll", "fwd_wg", "fwd_order", "adj_unroll", "adj_depth", "adj_wg", "nt")},
             },
             "achieved_GBps_pair": pair_bytes_global * pairs_per_s / 1e9,

@@ -26,7 +26,7 @@ from .arrays import zeros, lincomb_, norm, copyto_, reshape
 from . import jets as _j
 from . import jetblock as _blk
 
-__all__ = ["lsqr", "LsqrResult"]
+__all__ = ["lsqr", "lsqr_core", "LsqrResult"]
 
 
 class LsqrResult:
@@ -51,7 +51,9 @@ def _unwrap_vec(A):
 
 
 class _Engine:
-    """The two half-iterations, fused when the operator is a device-native tall block operator."""
+    """Vector algebra + the two half-iterations on one GPU; the halves are fused kernels when the operator is a
+    device-native tall block operator.  `lsqr_core` only talks to this interface, so the row-partitioned
+    engine below (and the CPU test double of tests/test_rowpart_gloo.py) can replace it."""
 
     def __init__(self, A):
         self.A = A
@@ -65,13 +67,32 @@ class _Engine:
         self._tmp_r = None
         self._tmp_d = None
 
-    def fwd(self, u, v, alpha, beta):
-        """u <- alpha*(A v) + beta*u ; returns ||u||."""
+    # --- vector algebra
+    def zeros_dom(self):
+        return zeros(_j.domain(self.A))
+
+    def zeros_rng(self):
+        return zeros(_j.range_(self.A))
+
+    def copy(self, dst, src):
+        return copyto_(dst, src)
+
+    def lincomb(self, dst, coefs, xs):
+        return lincomb_(dst, coefs, xs)
+
+    def norm_dom(self, x) -> float:
+        return float(norm(x))
+
+    def norm_rng(self, x) -> float:
+        return float(norm(x))
+
+    # --- half-iterations (return the LOCAL sum of squares; `finish` makes it a global norm)
+    def _fwd_local(self, u, v, alpha, beta) -> float:
         if self.native is not None:
             out = C.c_double(0)
             try:
                 check(lib.jh_blockop_mul_axpby(self.native.handle, u.handle, v.handle, float(alpha), float(beta), C.byref(out)))
-                return math.sqrt(out.value)
+                return out.value
             except JetsHipError as e:
                 if e.status != 4:  # JH_ERR_UNSUPPORTED: mixed kinds / ragged blocks -> generic path
                     raise
@@ -80,9 +101,13 @@ class _Engine:
             self._tmp_r = zeros(_j.range_(self.A))
         _j.mul_(self._tmp_r, self.L, v)
         lincomb_(u, [alpha, beta], [self._tmp_r, u])
-        return float(norm(u))
+        return float(norm(u)) ** 2
 
-    def adj(self, v, u, alpha, beta):
+    def fwd(self, u, v, alpha, beta) -> float:
+        """u <- alpha*(A v) + beta*u ; returns ||u||."""
+        return math.sqrt(self._fwd_local(u, v, alpha, beta))
+
+    def adj(self, v, u, alpha, beta) -> float:
         """v <- alpha*(A' u) + beta*v ; returns ||v||."""
         if self.native is not None:
             out = C.c_double(0)
@@ -100,27 +125,63 @@ class _Engine:
         return float(norm(v))
 
 
+class _ShardEngine(_Engine):
+    """Row-partitioned tall operator (rowpart.RowPartitionedOp): range-side vectors are this rank's rows,
+    domain-side vectors are replicated.  Forward half: local fused kernel + one scalar all-reduce for ||u||^2.
+    Adjoint half: local ordered sum, ONE all-reduce of the domain vector, then the small axpby + norm."""
+
+    def __init__(self, shard):
+        super().__init__(shard.local_op)
+        self.shard = shard
+
+    def norm_rng(self, x) -> float:
+        return self.shard.norm_range(x, 2)
+
+    def fwd(self, u, v, alpha, beta) -> float:
+        return math.sqrt(self.shard.comm.all_reduce_scalars([self._fwd_local(u, v, alpha, beta)], "sum")[0])
+
+    def adj(self, v, u, alpha, beta) -> float:
+        if self._tmp_d is None:
+            self._tmp_d = zeros(_j.domain(self.A))
+        self.shard.mul_adj_(self._tmp_d, u)              # local A'u + all-reduce
+        lincomb_(v, [alpha, beta], [self._tmp_d, v])
+        return float(norm(v))
+
+
 def lsqr(A, b, x0=None, damp: float = 0.0, atol: float = 1e-6, btol: float = 1e-6, conlim: float = 1e8, maxiter: int = 100,
          overwrite_b: bool = False, force_maxiter: bool = False) -> LsqrResult:
     """min ||A x - b||_2 (+ damp^2 ||x||^2).  `b` lives in range(A) (a BlockArray for a block operator), the
-    result in domain(A).  `overwrite_b=True` lets the solver use b's storage for the Lanczos vector u (at the
-    headline size b is 64 GiB).  `force_maxiter=True` keeps iterating past every stopping rule (throughput
-    measurements only)."""
-    A = _unwrap_vec(A)
-    dom, rng = _j.domain(A), _j.range_(A)
-    eng = _Engine(A)
+    result in domain(A).  `A` may also be a rowpart.RowPartitionedOp (then `b` is this rank's rows of the
+    right-hand side and every rank returns the same x).  `overwrite_b=True` lets the solver use b's storage for
+    the Lanczos vector u (at the headline size b is 64 GiB).  `force_maxiter=True` keeps iterating past every
+    stopping rule (throughput measurements only)."""
+    from .rowpart import RowPartitionedOp
+
+    if isinstance(A, RowPartitionedOp):
+        eng = _ShardEngine(A)
+        dom, rng = _j.domain(A.local_op), _j.range_(A.local_op)
+    else:
+        A = _unwrap_vec(A)
+        eng = _Engine(A)
+        dom, rng = _j.domain(A), _j.range_(A)
     b = reshape(b, rng)
-    x = zeros(dom) if x0 is None else copyto_(zeros(dom), reshape(x0, dom))
-    u = b if overwrite_b else copyto_(zeros(rng), b)
-    bnorm = float(norm(b))
+    x0 = None if x0 is None else reshape(x0, dom)
+    return lsqr_core(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b, force_maxiter)
+
+
+def lsqr_core(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b=False, force_maxiter=False) -> LsqrResult:
+    """Paige & Saunders' recurrences on an engine (see _Engine for the interface)."""
+    x = eng.zeros_dom() if x0 is None else eng.copy(eng.zeros_dom(), x0)
+    u = b if overwrite_b else eng.copy(eng.zeros_rng(), b)
+    bnorm = eng.norm_rng(b)
 
     # u_hat holds beta*u (un-normalised); `beta` is its norm.  u = b - A x0
     if x0 is not None:
         beta = eng.fwd(u, x, -1.0, 1.0)
     else:
         beta = bnorm
-    v = zeros(dom)
-    w = zeros(dom)
+    v = eng.zeros_dom()
+    w = eng.zeros_dom()
     history = []
     itn, istop = 0, 0
     anorm = acond = ddnorm = res2 = xnorm = xxnorm = z = 0.0
@@ -128,11 +189,11 @@ def lsqr(A, b, x0=None, damp: float = 0.0, atol: float = 1e-6, btol: float = 1e-
     if beta > 0:
         alpha = eng.adj(v, u, 1.0 / beta, 0.0)          # v = A'u with u = u_hat / beta
     else:
-        copyto_(v, x)
+        eng.copy(v, x)
         alpha = 0.0
     if alpha > 0:
-        lincomb_(v, [1.0 / alpha], [v])
-    copyto_(w, v)
+        eng.lincomb(v, [1.0 / alpha], [v])
+    eng.copy(w, v)
     rhobar, phibar = alpha, beta
     rnorm = r1norm = r2norm = beta
     arnorm = alpha * beta
@@ -150,7 +211,7 @@ def lsqr(A, b, x0=None, damp: float = 0.0, atol: float = 1e-6, btol: float = 1e-
             anorm = math.sqrt(anorm ** 2 + alpha ** 2 + beta ** 2 + damp ** 2)
             alpha = eng.adj(v, u, 1.0 / beta, -beta)     # v <- A'(u_hat / beta) - beta v
             if alpha > 0:
-                lincomb_(v, [1.0 / alpha], [v])
+                eng.lincomb(v, [1.0 / alpha], [v])
         # --- eliminate the damping parameter
         rhobar1 = math.sqrt(rhobar ** 2 + damp ** 2)
         cs1, sn1 = rhobar / rhobar1, damp / rhobar1
@@ -166,9 +227,9 @@ def lsqr(A, b, x0=None, damp: float = 0.0, atol: float = 1e-6, btol: float = 1e-
         tau = sn * phi
         # --- update x and w (domain-sized vectors)
         t1, t2 = phi / rho, -theta / rho
-        ddnorm += (float(norm(w)) / rho) ** 2            # ||w / rho||^2 without materialising w / rho
-        lincomb_(x, [1.0, t1], [x, w])
-        lincomb_(w, [1.0, t2], [v, w])
+        ddnorm += (eng.norm_dom(w) / rho) ** 2           # ||w / rho||^2 without materialising w / rho
+        eng.lincomb(x, [1.0, t1], [x, w])
+        eng.lincomb(w, [1.0, t2], [v, w])
         # --- norms for the stopping rules
         delta = sn2 * rho
         gambar = -cs2 * rho

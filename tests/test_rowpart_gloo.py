@@ -116,3 +116,90 @@ def test_world_size_2_forward_is_local_and_adjoint_all_reduces(tmp_path, nrow, n
     assert res[0]["nrm"][0] == pytest.approx(np.linalg.norm(flat_d), rel=1e-5)
     assert res[0]["nrm"][1] == pytest.approx(np.abs(flat_d).max(), rel=1e-7)
     assert res[0]["nrm"][2] == pytest.approx(np.abs(flat_d).sum(), rel=1e-5)
+
+
+# ---------------------------------------------------------------------------------- distributed LSQR
+def _lsqr_worker(rank, world, port, nrow, n, iters, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import math
+
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jets_jl_amd import rowpart
+    from jets_jl_amd.lsqr import lsqr_core
+    from oracle import jets_oracle as jo
+
+    dt = np.float64
+    part = rowpart.partition_rows(nrow, world, rank)
+    a_loc = [jo.rng_u01(dt, 1, 0, (part.first + i) * n, n) + 0.05 for i in range(part.count)]
+    b_loc = [jo.rng_u01(dt, 5, 0, (part.first + i) * n, n) - 0.5 for i in range(part.count)]
+    ops = [[jo.Block("diag", n, coeff=g)] for g in a_loc]
+    comm = rowpart.Comm(as_tensor=torch.from_numpy)
+
+    class NumpyShardEngine:
+        """CPU test double with the interface of lsqr._Engine / _ShardEngine: range vectors are lists of this
+        rank's blocks, domain vectors are replicated numpy arrays; compute by the oracle, exchange by gloo."""
+
+        def zeros_dom(self):
+            return np.zeros(n, dtype=dt)
+
+        def zeros_rng(self):
+            return [np.zeros(n, dtype=dt) for _ in range(part.count)]
+
+        def copy(self, dst, src):
+            if isinstance(dst, list):
+                for x, y in zip(dst, src):
+                    x[...] = y
+            else:
+                dst[...] = src
+            return dst
+
+        def lincomb(self, dst, coefs, xs):
+            dst[...] = sum(c * x for c, x in zip(coefs, xs))
+            return dst
+
+        def norm_dom(self, x):
+            return float(np.linalg.norm(x))
+
+        def norm_rng(self, x):
+            return math.sqrt(comm.all_reduce_scalars([sum(float(np.dot(t, t)) for t in x)], "sum")[0])
+
+        def fwd(self, u, v, alpha, beta):
+            tmp = jo.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(part.count)], [v])   # no communication
+            for ui, ti in zip(u, tmp):
+                ui[...] = alpha * ti + beta * ui
+            return self.norm_rng(u)                                                           # one scalar all-reduce
+
+        def adj(self, v, u, alpha, beta):
+            tmp = jo.block_df_adj(ops, [np.zeros(n, dtype=dt)], u)[0]
+            comm.all_reduce_sum_(tmp)                                                          # the one vector all-reduce
+            v[...] = alpha * tmp + beta * v
+            return float(np.linalg.norm(v))
+
+    res = lsqr_core(NumpyShardEngine(), b_loc, None, 0.0, 0.0, 0.0, 0.0, iters)
+    np.savez(os.path.join(out_dir, f"lsqr{rank}.npz"), x=res.x, r=np.array([h[1] for h in res.history]), itn=res.itn)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_lsqr_matches_single_process_fp64_lsqr(tmp_path):
+    import torch.multiprocessing as mp
+
+    from oracle import jets_oracle as jo
+    from oracle.lsqr_ref import lsqr_fp64
+
+    world, port, nrow, n, iters = 2, _free_port(), 5, 64, 25
+    mp.spawn(_lsqr_worker, args=(world, port, nrow, n, iters, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(tmp_path / f"lsqr{r}.npz") for r in range(world)]
+    a = np.stack([jo.rng_u01(np.float64, 1, 0, i * n, n) + 0.05 for i in range(nrow)])
+    b = np.concatenate([jo.rng_u01(np.float64, 5, 0, i * n, n) - 0.5 for i in range(nrow)])
+    xr, info = lsqr_fp64(lambda v: (a * v).ravel(), lambda y: (a * y.reshape(nrow, n)).sum(0), b, n,
+                         atol=0.0, btol=0.0, conlim=0.0, maxiter=iters)
+    assert res[0]["x"].tobytes() == res[1]["x"].tobytes()                       # replicas stay identical
+    assert int(res[0]["itn"]) == info["itn"]
+    assert np.linalg.norm(res[0]["x"] - xr) <= 1e-10 * np.linalg.norm(xr)
+    ref_r = np.array([h[1] for h in info["history"]])
+    assert np.allclose(res[0]["r"], ref_r, rtol=1e-9)
