@@ -119,6 +119,12 @@ int jh_upload(jh_bvec *v, int64_t offset, int64_t count, const void *host_src);
  * index_base shifts k so a row-partitioned shard reproduces its slice of the global vector. */
 int jh_fill_uniform(jh_bvec *v, uint64_t seed, uint64_t stream, int64_t index_base);
 
+/* randn(R) (src/Jets.jl:105-108, 922-924): Box-Muller over the same counter generator (two draws per scalar lane;
+ * complex lanes scaled by 1/sqrt(2)).  Reproducible on the CPU to transcendental-function accuracy, not bitwise. */
+int jh_fill_normal(jh_bvec *v, uint64_t seed, uint64_t stream, int64_t index_base);
+/* abs.(x) into a real vector of the same length (test/runtests.jl:545-547) */
+int jh_abs(jh_bvec *dst_real, const jh_bvec *x);
+
 /* BlockArray broadcast, src/Jets.jl:889-911.  dst = c0*x0 .+ c1*x1 .+ ... evaluated left to right in
  * eltype T (each product and each sum rounded, no FMA); coef is k (re,im) pairs; dst may alias any x. */
 int jh_lincomb(jh_bvec *dst, int k, const double *coef_re_im, const jh_bvec *const *x);

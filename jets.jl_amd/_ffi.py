@@ -80,6 +80,8 @@ SYMBOLS = {
     "jh_download": (_int, [_vp, _i64, _i64, _vp]),
     "jh_upload": (_int, [_vp, _i64, _i64, _vp]),
     "jh_fill_uniform": (_int, [_vp, C.c_uint64, C.c_uint64, _i64]),
+    "jh_fill_normal": (_int, [_vp, C.c_uint64, C.c_uint64, _i64]),
+    "jh_abs": (_int, [_vp, _vp]),
     "jh_lincomb": (_int, [_vp, _int, _dblp, _vpp]),
     "jh_hadamard": (_int, [_vp, _vp, _vp, _int]),
     "jh_dot": (_int, [_vp, _vp, _dblp, _dblp]),

@@ -25,7 +25,7 @@ from .spaces import JetAbstractSpace, JetSpace, JetBSpace, dtype_code
 __all__ = [
     "DeviceArray", "BlockArray", "LinExpr", "zeros", "ones", "rand", "randn", "Array", "from_numpy", "space", "nblocks",
     "indices", "getblock", "getblock_", "setblock_", "norm", "dot", "extrema", "fill_", "copyto_", "lincomb_",
-    "hadamard_", "similar", "convert_array", "reshape", "vec", "length",
+    "hadamard_", "similar", "convert_array", "reshape", "vec", "length", "abs_",
 ]
 
 _rand_counter = itertools.count(1)
@@ -324,18 +324,21 @@ def rand(R: JetAbstractSpace, seed: int | None = None, stream: int | None = None
     return x
 
 
-def randn(R: JetAbstractSpace, seed: int | None = None):
-    """randn(R): test-data generation only (host generator, uploaded); not on any timed path."""
-    rng = np.random.default_rng(seed)
+def randn(R: JetAbstractSpace, seed: int | None = None, stream: int | None = None, index_base: int = 0):
+    """randn(R): standard normal values generated on the device (Box-Muller over the counter generator)."""
     x = Array(R)
-    n = x.length()
-    T = np.dtype(R.eltype())
-    if T.kind == "c":
-        vals = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) / math.sqrt(2.0)
-    else:
-        vals = rng.standard_normal(n)
-    x._upload(vals.astype(T))
+    if seed is None:
+        seed, stream = _DEFAULT_SEED, next(_rand_counter)
+    check(lib.jh_fill_normal(x.handle, int(seed), int(stream or 0), int(index_base)))
     return x
+
+
+def abs_(x: "_DevVec"):
+    """abs.(x): a real vector with the block structure of x (test/runtests.jl:545-547)."""
+    real_t = np.float32 if x.dtype in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
+    out = similar(x, real_t)
+    check(lib.jh_abs(out.handle, x.handle))
+    return out
 
 
 def from_numpy(a: np.ndarray, R: JetAbstractSpace | None = None):

@@ -96,6 +96,34 @@ __global__ void k_uniform(S *__restrict__ p, int64_t n, uint64_t key, int64_t la
     if (tid < n - tail0) p[tail0 + tid] = u01_from<S>(mix64(key + (uint64_t)(lane_base + tail0 + tid + 1) * GOLDEN));
 }
 
+// standard normal by Box-Muller from two counter-RNG draws per scalar lane: lane k uses draws 2k and 2k+1.
+// u1 in (0,1] so log() is finite.  Complex lanes are scaled by 1/sqrt(2) (Julia: randn(ComplexF64) has unit variance).
+template <typename S>
+__global__ void k_normal(S *__restrict__ p, int64_t n, uint64_t key, int64_t lane_base, S scale)
+{
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * WG;
+    for (int64_t k = tid; k < n; k += stride) {
+        const uint64_t h1 = mix64(key + (uint64_t)(2 * (lane_base + k) + 1) * GOLDEN);
+        const uint64_t h2 = mix64(key + (uint64_t)(2 * (lane_base + k) + 2) * GOLDEN);
+        const double u1 = ((double)(h1 >> 11) + 1.0) * 0x1.0p-53;
+        const double u2 = (double)(h2 >> 11) * 0x1.0p-53;
+        p[k] = (S)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2)) * scale;
+    }
+}
+
+// |x| of a complex (or real) vector into a real vector: abs.(x) (test/runtests.jl:545-547)
+template <typename S, int E>
+__global__ void k_abs(S *__restrict__ dst, const S *__restrict__ x, int64_t n_elems)
+{
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * WG;
+    for (int64_t k = tid; k < n_elems; k += stride) {
+        if (E == 1) dst[k] = x[k] < 0 ? -x[k] : x[k];
+        else dst[k] = (S)hypot((double)x[2 * k], (double)x[2 * k + 1]);
+    }
+}
+
 // ---------------------------------------------------------------- lincomb ---------------------
 constexpr int MAX_TERMS = 8;
 struct LincombArgs {
@@ -449,6 +477,46 @@ int jh_fill_uniform(jh_bvec *v, uint64_t seed, uint64_t stream, int64_t index_ba
         hipLaunchKernelGGL((k_uniform<float, 4>), dim3(grid_for(n / 4 + 1, 4)), dim3(WG), 0, st, (float *)v->data, n, key, base);
     else
         hipLaunchKernelGGL((k_uniform<double, 2>), dim3(grid_for(n / 2 + 1, 4)), dim3(WG), 0, st, (double *)v->data, n, key, base);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+int jh_fill_normal(jh_bvec *v, uint64_t seed, uint64_t stream, int64_t index_base)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(v, "jh_fill_normal: null vector");
+    JH_REQUIRE(index_base >= 0, "jh_fill_normal: negative index_base");
+    if (v->length == 0) return JH_OK;
+    const uint64_t key = mix64(seed * GOLDEN + stream);
+    const bool cplx = jh_dtype_complex(v->dtype);
+    const int lanes = cplx ? 2 : 1;
+    const int64_t n = v->length * lanes, base = index_base * lanes;
+    const double scale = cplx ? 0.7071067811865476 : 1.0;
+    hipStream_t st = jh_ctx().stream;
+    if (v->dtype == JH_F32 || v->dtype == JH_C32)
+        hipLaunchKernelGGL((k_normal<float>), dim3(grid_for(n, 4)), dim3(WG), 0, st, (float *)v->data, n, key, base, (float)scale);
+    else
+        hipLaunchKernelGGL((k_normal<double>), dim3(grid_for(n, 4)), dim3(WG), 0, st, (double *)v->data, n, key, base, scale);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+int jh_abs(jh_bvec *dst, const jh_bvec *x)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(dst && x, "jh_abs: null argument");
+    JH_REQUIRE(dst->length == x->length, "jh_abs: length mismatch (%lld vs %lld)", (long long)dst->length, (long long)x->length);
+    const int want = (x->dtype == JH_F32 || x->dtype == JH_C32) ? JH_F32 : JH_F64;
+    JH_REQUIRE(dst->dtype == want, "jh_abs: destination must be the real type of the source (dtype %d), got %d", want, dst->dtype);
+    if (x->length == 0) return JH_OK;
+    hipStream_t st = jh_ctx().stream;
+    const int g = grid_for(x->length, 4);
+    switch (x->dtype) {
+    case JH_F32: hipLaunchKernelGGL((k_abs<float, 1>), dim3(g), dim3(WG), 0, st, (float *)dst->data, (const float *)x->data, x->length); break;
+    case JH_F64: hipLaunchKernelGGL((k_abs<double, 1>), dim3(g), dim3(WG), 0, st, (double *)dst->data, (const double *)x->data, x->length); break;
+    case JH_C32: hipLaunchKernelGGL((k_abs<float, 2>), dim3(g), dim3(WG), 0, st, (float *)dst->data, (const float *)x->data, x->length); break;
+    case JH_C64: hipLaunchKernelGGL((k_abs<double, 2>), dim3(g), dim3(WG), 0, st, (double *)dst->data, (const double *)x->data, x->length); break;
+    }
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }

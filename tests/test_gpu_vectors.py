@@ -230,3 +230,22 @@ def test_errors_are_loud(Jets):
         x[12]
     with pytest.raises(IndexError):
         Jets.getblock(x, 3)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_randn_and_abs(Jets, dt):
+    """randn(R) (test/runtests.jl:535-540) and abs.(x) (545-547)."""
+    R = Jets.JetBSpace([Jets.JetSpace(dt, 200_000), Jets.JetSpace(dt, 50, 7), Jets.JetSpace(dt, 3)])
+    x = Jets.randn(R, seed=5, stream=2)
+    v = x.to_numpy().astype(np.complex128)
+    assert abs(v.mean()) < 0.01 and abs(np.mean(np.abs(v) ** 2) - 1.0) < 0.01            # zero mean, unit variance
+    assert np.array_equal(x.to_numpy(), Jets.randn(R, seed=5, stream=2).to_numpy())       # pure function of (seed, stream, index)
+    y = Jets.randn(Jets.JetSpace(dt, 1000), seed=5, stream=2, index_base=100)
+    assert np.array_equal(y.to_numpy(), x.to_numpy()[100:1100])
+    a = Jets.abs_(x)
+    single = np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64))
+    assert isinstance(a, Jets.BlockArray) and a.dtype == np.dtype(np.float32 if single else np.float64)   # eltype(abs.(x)) is real
+    assert np.allclose(a.to_numpy(), np.abs(x.to_numpy()), rtol=1e-6 if single else 1e-14)
+    if np.dtype(dt).kind != "c":
+        mn, mx = Jets.extrema(x)
+        assert (mn, mx) == (x.to_numpy().min(), x.to_numpy().max()) and mn < 0 < mx
