@@ -165,6 +165,18 @@ int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m);
  * range vector, no separate axpby or norm pass.  Tall all-DIAG operators only (else JH_ERR_UNSUPPORTED). */
 int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double alpha, double beta, double *normsq);
 int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double alpha, double beta, double *normsq);
+/* ---------------------------------------------------------------- RCCL over xGMI ----------- */
+/* Row partition of a tall operator across the GPUs of a node (one process per GPU): the forward needs no exchange
+ * (src/Jets.jl:1015-1031), the adjoint is a sum over rows (1045-1053) -> one in-place all-reduce of the domain vector
+ * after the local jh_blockop_mul_adj; range-side dot/norm -> scalar all-reduce of the local partials.  The host
+ * language distributes the 128-byte id of rank 0.  Collectives are enqueued on the library stream. */
+int jh_comm_unique_id(void *out128);
+int jh_comm_init_rank(const void *id128, int nranks, int rank);
+int jh_comm_destroy(void);
+int jh_comm_info(int *nranks, int *rank);
+int jh_comm_allreduce_sum(jh_bvec *v);
+int jh_comm_allreduce_scalars(double *values, int n, int op);   /* op: 0 sum, 1 max, 2 min; synchronises */
+
 /* kernel-shape tuning knobs (bench/tests only): 0 = automatic (fwd_order: -1); name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg","fwd_order","nt"} */
 int jh_tune_set(const char *name, int64_t value);
 int jh_tune_get(const char *name, int64_t *value);

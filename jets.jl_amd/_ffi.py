@@ -95,6 +95,12 @@ SYMBOLS = {
     "jh_blockop_normal_mul": (_int, [_vp, _vp, _vp]),
     "jh_blockop_mul_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
     "jh_blockop_mul_adj_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
+    "jh_comm_unique_id": (_int, [_vp]),
+    "jh_comm_init_rank": (_int, [_vp, _int, _int]),
+    "jh_comm_destroy": (_int, []),
+    "jh_comm_info": (_int, [_intp, _intp]),
+    "jh_comm_allreduce_sum": (_int, [_vp]),
+    "jh_comm_allreduce_scalars": (_int, [_dblp, _int, _int]),
     "jh_tune_set": (_int, [C.c_char_p, _i64]),
     "jh_tune_get": (_int, [C.c_char_p, _i64p]),
 }

@@ -22,7 +22,7 @@ import math
 from dataclasses import dataclass
 from typing import Callable
 
-__all__ = ["RowPartition", "partition_rows", "Comm", "RowPartitionedOp", "for_device"]
+__all__ = ["RowPartition", "partition_rows", "Comm", "AbiComm", "RowPartitionedOp", "for_device"]
 
 
 @dataclass(frozen=True)
@@ -104,6 +104,48 @@ class Comm:
             self._dist.barrier()
 
 
+class AbiComm:
+    """The same exchange step through the C ABI's own RCCL entry points (jh_comm_*, include/jetship.h) -- what a
+    host without torch.distributed (the Julia binding) uses.  `exchange_id` ships rank 0's 128-byte id to the other
+    ranks (MPI broadcast, a socket, a file); with one rank it is not needed."""
+
+    def __init__(self, nranks: int = 1, rank: int = 0, exchange_id: Callable | None = None):
+        import ctypes as C
+
+        from ._ffi import lib, check
+        from . import device as _device
+
+        _device.init()
+        self._C, self._lib, self._check = C, lib, check
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            check(lib.jh_comm_unique_id(ident))
+        if nranks > 1:
+            if exchange_id is None:
+                raise ValueError("exchange_id(bytes_or_None) -> bytes is required for more than one rank")
+            ident = C.create_string_buffer(exchange_id(ident.raw if rank == 0 else None), 128)
+        check(lib.jh_comm_init_rank(ident, nranks, rank))
+        self.world, self.rank = nranks, rank
+
+    def all_reduce_sum_(self, x, force: bool = False):
+        if self.world == 1 and not force:
+            return x
+        self._check(self._lib.jh_comm_allreduce_sum(x.handle))
+        return x
+
+    def all_reduce_scalars(self, values, op: str = "sum"):
+        vals = list(values)
+        buf = (self._C.c_double * len(vals))(*vals)
+        self._check(self._lib.jh_comm_allreduce_scalars(buf, len(vals), {"sum": 0, "max": 1, "min": 2}[op]))
+        return list(buf)
+
+    def barrier(self):
+        self.all_reduce_scalars([0.0])
+
+    def close(self):
+        self._check(self._lib.jh_comm_destroy())
+
+
 class RowPartitionedOp:
     """This rank's shard of a tall block operator plus the exchange step."""
 
@@ -136,14 +178,17 @@ class RowPartitionedOp:
         return self.comm.all_reduce_scalars([float(self._norm(x_local, p)) ** p], "sum")[0] ** (1.0 / p)
 
 
-def for_device(part: RowPartition, local_op) -> RowPartitionedOp:
-    """Product wiring: HIP kernels for the local work, RCCL (torch.distributed "nccl") for the exchange.
-    The all-reduce is ordered against the library's HIP stream through torch.cuda.ExternalStream."""
-    import torch
-
+def for_device(part: RowPartition, local_op, comm=None) -> RowPartitionedOp:
+    """Product wiring: HIP kernels for the local work, RCCL for the exchange -- through torch.distributed's "nccl"
+    backend (default; the all-reduce is ordered against the library's HIP stream with torch.cuda.ExternalStream)
+    or through the C ABI's own RCCL entry points when an AbiComm is passed."""
     from . import device as _device
     from .arrays import dot, norm
     from .jets import mul_, adjoint
+
+    if comm is not None:
+        return RowPartitionedOp(part, local_op, comm, lambda d, A, m: mul_(d, A, m), lambda m, A, d: mul_(m, adjoint(A), d), dot, norm)
+    import torch
 
     ext = torch.cuda.ExternalStream(_device.stream_handle(), device=torch.device("cuda", _device.init()))
 

@@ -163,3 +163,28 @@ def test_rccl_path_with_one_rank(Jets, oracle):
         assert shard.norm_range(d, 2) == pytest.approx(float(np.linalg.norm(hd.astype(np.float64))), rel=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+def test_c_abi_rccl_entry_points_with_one_rank(Jets, oracle):
+    """jh_comm_* (the RCCL path a non-Python host uses): id, init, vector and scalar all-reduce, destroy."""
+    comm = Jets.rowpart.AbiComm(nranks=1, rank=0)
+    try:
+        dt, nrow, shape = np.float32, 3, (16, 16, 4)
+        A, _, ops, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+        n = int(np.prod(shape))
+        shard = Jets.rowpart.for_device(Jets.rowpart.partition_rows(nrow, 1, 0), A, comm=comm)
+        d = Jets.rand(Jets.range(A), seed=72, stream=0)
+        hd = u01(oracle, dt, 72, 0, nrow * n)
+        mt = Jets.zeros(Jets.domain(A))
+        shard.mul_adj_(mt, d, force_collective=True)                # ncclAllReduce on the library stream
+        ref = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], [hd[i * n:(i + 1) * n].copy() for i in range(nrow)])
+        assert_bits_equal(mt.to_numpy().ravel(order="F"), ref[0], "adjoint through jh_comm_allreduce_sum")
+        assert comm.all_reduce_scalars([1.5, -2.0], "sum") == [1.5, -2.0]
+        assert comm.all_reduce_scalars([3.0], "max") == [3.0]
+        res = Jets.lsqr(shard, A * Jets.rand(Jets.domain(A), seed=73, stream=0), atol=1e-7, btol=1e-7, maxiter=40)
+        assert res.istop in (1, 2, 4, 5)
+    finally:
+        comm.close()
+    with pytest.raises(Jets.JetsHipError):
+        from jets_jl_amd._ffi import lib, check
+        check(lib.jh_comm_allreduce_sum(mt.handle))                  # no communicator any more: loud
