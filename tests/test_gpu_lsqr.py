@@ -181,8 +181,10 @@ def test_c_abi_rccl_entry_points_with_one_rank(Jets, oracle):
         assert_bits_equal(mt.to_numpy().ravel(order="F"), ref[0], "adjoint through jh_comm_allreduce_sum")
         assert comm.all_reduce_scalars([1.5, -2.0], "sum") == [1.5, -2.0]
         assert comm.all_reduce_scalars([3.0], "max") == [3.0]
-        res = Jets.lsqr(shard, A * Jets.rand(Jets.domain(A), seed=73, stream=0), atol=1e-7, btol=1e-7, maxiter=40)
-        assert res.istop in (1, 2, 4, 5)
+        x_true = Jets.rand(Jets.domain(A), seed=73, stream=0)
+        res = Jets.lsqr(shard, A * x_true, atol=1e-5, btol=1e-5, maxiter=200)          # row-partitioned engine, one rank
+        err = (res.x - x_true).materialize()
+        assert float(Jets.norm(err)) / float(Jets.norm(x_true)) < 1e-3
     finally:
         comm.close()
     with pytest.raises(Jets.JetsHipError):
