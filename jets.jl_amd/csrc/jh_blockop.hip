@@ -598,10 +598,60 @@ int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n
 }
 
 template <typename S, int E, int NS>
+int launch_tall_fwd_shape(const jh_blockop *op, void *d, const void *m, int64_t n_scalars, const TallShape &sh);
+
+// For operators far larger than the caches the row-concurrent walk is 5-7 % faster than the sequential sweep in
+// some processes and 10-15 % slower in others (profiles/repeat_r01.txt: same binary, same box; it depends on where
+// the slabs landed physically), so the first forward of such an operator times both once (4 extra launches of an
+// idempotent kernel, ~0.1 s, synchronous) and keeps the winner.  Skipped while the stream is being captured.
+template <typename S, int E, int NS>
+int autotune_fwd_walk(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
+{
+    jh_context &c = jh_ctx();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c.stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return JH_OK;   // stay untried
+    const TallShape cand[2] = {TallShape{1024, 8, 16, 0}, TallShape{512, 1, 2, 1}};
+    float best = 0.f;
+    int pick = 0;
+    hipEvent_t e0, e1;
+    JH_CHECK_HIP(hipEventCreate(&e0));
+    JH_CHECK_HIP(hipEventCreate(&e1));
+    for (int k = 0; k < 2; k++) {
+        int st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, cand[k]);          // warm
+        if (st == JH_OK) st = (hipEventRecord(e0, c.stream) == hipSuccess) ? JH_OK : JH_ERR_HIP;
+        if (st == JH_OK) st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, cand[k]);
+        float ms = 0.f;
+        if (st == JH_OK && (hipEventRecord(e1, c.stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                            hipEventElapsedTime(&ms, e0, e1) != hipSuccess))
+            st = jh_fail(JH_ERR_HIP, "autotune: event timing failed");
+        if (st != JH_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st; }
+        if (k == 0 || ms < best) { best = ms; pick = k; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    op->fwd_walk = pick;
+    return JH_OK;
+}
+
+template <typename S, int E, int NS>
 int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
 {
     jh_context &c = jh_ctx();
-    const TallShape sh = pick_fwd_shape(n_scalars / NS, op->nrow, sizeof(S) * NS);
+    TallShape sh = pick_fwd_shape(n_scalars / NS, op->nrow, sizeof(S) * NS);
+    const bool knobs_free = !c.fwd_wg && !c.fwd_unroll && !c.fwd_group && c.fwd_order < 0;
+    const double stream_bytes = 2.0 * (double)op->nrow * (double)n_scalars * sizeof(S);
+    if (c.autotune && knobs_free && stream_bytes >= 8.0 * (double)(1ull << 30) && op->nrow >= 64) {
+        if (op->fwd_walk < 0) JH_TRY((autotune_fwd_walk<S, E, NS>(op, d, m, n_scalars)));
+        if (op->fwd_walk == 1) sh = TallShape{512, 1, 2, 1};
+        else if (op->fwd_walk == 0) sh = TallShape{1024, 8, 16, 0};
+    }
+    return launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, sh);
+}
+
+template <typename S, int E, int NS>
+int launch_tall_fwd_shape(const jh_blockop *op, void *d, const void *m, int64_t n_scalars, const TallShape &sh)
+{
+    jh_context &c = jh_ctx();
     if (sh.wg == 256) return c.nt ? launch_tall_fwd_u<S, E, NS, true, 256>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 256>(op, d, m, n_scalars, sh);
     if (sh.wg == 512) return c.nt ? launch_tall_fwd_u<S, E, NS, true, 512>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 512>(op, d, m, n_scalars, sh);
     return c.nt ? launch_tall_fwd_u<S, E, NS, true, 1024>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 1024>(op, d, m, n_scalars, sh);

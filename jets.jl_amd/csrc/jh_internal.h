@@ -50,6 +50,7 @@ struct jh_context {
     int64_t adj_wg = 0;                // threads per workgroup (tall adjoint / fused normal)
     int64_t fwd_order = -1;            // -1: automatic; 0: sequential row sweep; 1: all row groups concurrent; k>1: bands of k row groups
     int64_t nt = 1;                    // nontemporal loads/stores on the streamed operands
+    int64_t autotune = 1;              // time both grid walks of the tall forward once per large operator
 };
 jh_context &jh_ctx();
 int jh_require_ready();
@@ -107,6 +108,7 @@ struct jh_blockop {
     bool all_diag = false;                   // every block is an un-adjointed... DIAG (adjoint flag irrelevant up to conj)
     bool elementwise = false;                // no DENSE block
     bool diag_strided = false;               // coeff[i] = coeff[0] + i*stride bytes
+    mutable int fwd_walk = -1;               // autotuned grid walk of the tall forward: -1 untried, 0 sequential, 1 all rows
     int64_t diag_stride_elems = 0;
 };
 
