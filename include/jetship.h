@@ -154,6 +154,10 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m);
 /* mul!(m, A', d) -> JetBlock_df'!, src/Jets.jl:1034-1057: m zeroed when nrow > 1 (1042), rows summed
  * in order i = 0..nrow-1 with the product rounded before the add (1049) => bit-exact on one GPU. */
 int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d);
+/* The same adjoint restricted to the elements [first_elem, first_elem+count) of the domain vector (16-byte aligned
+ * bounds; tall all-DIAG operators): lets a multi-GPU host pipeline the exchange chunk by chunk -- all-reduce chunk k
+ * while the kernel computes chunk k+1.  Results are identical to jh_blockop_mul_adj on those elements. */
+int jh_blockop_mul_adj_range(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, int64_t first_elem, int64_t count);
 /* (A' o A) m -> JetComposite_df! over (A', A), src/Jets.jl:530-534, fused: A's coefficients are read
  * once and the range-side intermediate is never materialised.  Same rounding sequence as the
  * unfused pair, so the result is bit-identical to jh_blockop_mul followed by jh_blockop_mul_adj. */

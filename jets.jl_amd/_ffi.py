@@ -92,6 +92,7 @@ SYMBOLS = {
     "jh_blockop_destroy": (_int, [_vp]),
     "jh_blockop_mul": (_int, [_vp, _vp, _vp]),
     "jh_blockop_mul_adj": (_int, [_vp, _vp, _vp]),
+    "jh_blockop_mul_adj_range": (_int, [_vp, _vp, _vp, _i64, _i64]),
     "jh_blockop_normal_mul": (_int, [_vp, _vp, _vp]),
     "jh_blockop_mul_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
     "jh_blockop_mul_adj_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),

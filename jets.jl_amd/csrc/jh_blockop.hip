@@ -118,22 +118,25 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__res
 template <typename S, int E, int NS, int U, int DEPTH, bool NT, int MODE, int BLK>
 __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                        const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ out,
-                                                       const S *__restrict__ in, int64_t n_scalars, int direct)
+                                                       const S *__restrict__ in, int64_t n_scalars, int direct,
+                                                       int64_t s_begin, int64_t s_end)
 {
+    // the launch covers the scalar range [s_begin, s_end) of the domain vector (the whole vector, or one chunk
+    // when the multi-GPU exchange is pipelined chunk by chunk against this kernel)
     typedef typename vec_of<S, NS>::type V;
-    const int64_t s0 = ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
+    const int64_t s0 = s_begin + ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
     bool ok[U];
     V acc[U], mv[U];
 #pragma unroll
     for (int k = 0; k < U; k++) {
-        ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
+        ok[k] = (s0 + (int64_t)k * BLK * NS) < s_end;
         acc[k] = (V)(S)0;
         if (MODE == 1) mv[k] = ok[k] ? ld<false>(reinterpret_cast<const V *>(in + s0 + (int64_t)k * BLK * NS)) : (V)(S)0;
     }
     // clamp out-of-range vectors onto a valid address so the main loop is branch-free
     int64_t sk[U];
 #pragma unroll
-    for (int k = 0; k < U; k++) sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
+    for (int k = 0; k < U; k++) sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : s_begin;
 
     int64_t i = 0;
     for (; !direct && i + DEPTH <= nrow; i += DEPTH) {
@@ -576,7 +579,8 @@ int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_sc
 }
 
 template <typename S, int E, int NS, bool NT, int MODE, int BLK>
-int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n_scalars, const TallShape &sh)
+int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n_scalars, const TallShape &sh, int64_t s_begin,
+                      int64_t s_end)
 {
     jh_context &c = jh_ctx();
     const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
@@ -584,9 +588,10 @@ int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n
     const int direct = (op->nrow == 1 && MODE == 0) ? 1 : 0;
 #define JH_ADJ_CASE(U, DEPTH)                                                                                          \
     if (sh.unroll == U && sh.aux == DEPTH) {                                                                           \
-        int64_t gx = (n_scalars + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                                \
+        int64_t gx = (s_end - s_begin + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                          \
         hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, NT, MODE, BLK>), dim3((unsigned)gx), dim3(BLK), 0,     \
-                           c.stream, op->dev_blocks, op->nrow, a_base, a_stride, (S *)out, (const S *)in, n_scalars, direct); \
+                           c.stream, op->dev_blocks, op->nrow, a_base, a_stride, (S *)out, (const S *)in, n_scalars, direct, \
+                           s_begin, s_end);                                                                            \
         JH_CHECK_HIP(hipGetLastError());                                                                               \
         return JH_OK;                                                                                                  \
     }
@@ -657,13 +662,15 @@ int launch_tall_fwd_shape(const jh_blockop *op, void *d, const void *m, int64_t 
     return c.nt ? launch_tall_fwd_u<S, E, NS, true, 1024>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 1024>(op, d, m, n_scalars, sh);
 }
 template <typename S, int E, int NS, int MODE>
-int launch_tall_adj(const jh_blockop *op, void *out, const void *in, int64_t n_scalars)
+int launch_tall_adj(const jh_blockop *op, void *out, const void *in, int64_t n_scalars, int64_t s_begin = 0, int64_t s_end = -1)
 {
     jh_context &c = jh_ctx();
+    if (s_end < 0) s_end = n_scalars;
+    if (s_end <= s_begin) return JH_OK;
     const TallShape sh = pick_adj_shape(n_scalars / NS, op->nrow, MODE);
-    if (sh.wg == 256) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 256>(op, out, in, n_scalars, sh) : launch_tall_adj_u<S, E, NS, false, MODE, 256>(op, out, in, n_scalars, sh);
-    if (sh.wg == 512) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 512>(op, out, in, n_scalars, sh) : launch_tall_adj_u<S, E, NS, false, MODE, 512>(op, out, in, n_scalars, sh);
-    return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 1024>(op, out, in, n_scalars, sh) : launch_tall_adj_u<S, E, NS, false, MODE, 1024>(op, out, in, n_scalars, sh);
+    if (sh.wg == 256) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 256>(op, out, in, n_scalars, sh, s_begin, s_end) : launch_tall_adj_u<S, E, NS, false, MODE, 256>(op, out, in, n_scalars, sh, s_begin, s_end);
+    if (sh.wg == 512) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 512>(op, out, in, n_scalars, sh, s_begin, s_end) : launch_tall_adj_u<S, E, NS, false, MODE, 512>(op, out, in, n_scalars, sh, s_begin, s_end);
+    return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 1024>(op, out, in, n_scalars, sh, s_begin, s_end) : launch_tall_adj_u<S, E, NS, false, MODE, 1024>(op, out, in, n_scalars, sh, s_begin, s_end);
 }
 
 // fast path usable?  (tall, all DIAG, uniform rows, 16-byte aligned everything, no conj flags on complex)
@@ -1060,6 +1067,27 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
     case JH_C64: return general_adj<double, 2>(op, m->data, d->data);
     }
     return jh_fail(JH_ERR_INVALID, "jh_blockop_mul_adj: unknown dtype %d", op->dtype);
+}
+
+int jh_blockop_mul_adj_range(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, int64_t first_elem, int64_t count)
+{
+    JH_TRY(jh_require_ready());
+    JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_adj_range"));
+    JH_REQUIRE(first_elem >= 0 && count >= 0 && first_elem + count <= m->length,
+               "jh_blockop_mul_adj_range: elements [%lld, %lld) outside the domain vector (%lld elements)", (long long)first_elem,
+               (long long)(first_elem + count), (long long)m->length);
+    if (!tall_fast_ok(op, d->data, m->data))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_range: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
+    const int64_t es = (int64_t)jh_dtype_size(op->dtype);
+    JH_REQUIRE((first_elem * es) % 16 == 0 && (count * es) % 16 == 0, "jh_blockop_mul_adj_range: chunk boundaries must be 16-byte aligned");
+    const int64_t n = op->row_len[0];
+    switch (op->dtype) {
+    case JH_F32: return launch_tall_adj<float, 1, 4, 0>(op, m->data, d->data, n, first_elem, first_elem + count);
+    case JH_F64: return launch_tall_adj<double, 1, 2, 0>(op, m->data, d->data, n, first_elem, first_elem + count);
+    case JH_C32: return launch_tall_adj<float, 2, 4, 0>(op, m->data, d->data, 2 * n, 2 * first_elem, 2 * (first_elem + count));
+    case JH_C64: return launch_tall_adj<double, 2, 2, 0>(op, m->data, d->data, 2 * n, 2 * first_elem, 2 * (first_elem + count));
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blockop_mul_adj_range: unknown dtype %d", op->dtype);
 }
 
 int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m)

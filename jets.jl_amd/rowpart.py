@@ -150,16 +150,21 @@ class RowPartitionedOp:
     """This rank's shard of a tall block operator plus the exchange step."""
 
     def __init__(self, part: RowPartition, local_op, comm: Comm, local_mul: Callable, local_mul_adj: Callable,
-                 local_dot: Callable, local_norm: Callable):
+                 local_dot: Callable, local_norm: Callable, pipelined_adj: Callable | None = None):
         self.part, self.local_op, self.comm = part, local_op, comm
         self._mul, self._mul_adj, self._dot, self._norm = local_mul, local_mul_adj, local_dot, local_norm
+        self._pipelined_adj = pipelined_adj   # optional: local adjoint and all-reduce pipelined chunk by chunk
 
     def mul_(self, d_local, m):
         """d_local = A[rows of this rank] m   -- no communication."""
         return self._mul(d_local, self.local_op, m)
 
     def mul_adj_(self, m, d_local, force_collective: bool = False):
-        """m = sum over ALL rows A_i' d_i  -- local ordered sum, then one all-reduce."""
+        """m = sum over ALL rows A_i' d_i  -- local ordered sum, then one all-reduce (or, with the device wiring,
+        the two pipelined chunk by chunk: all-reduce of chunk k overlaps the kernel of chunk k+1)."""
+        if self._pipelined_adj is not None and (self.comm.world > 1 or force_collective):
+            if self._pipelined_adj(m, self.local_op, d_local):
+                return m
         self._mul_adj(m, self.local_op, d_local)
         return self.comm.all_reduce_sum_(m, force=force_collective)
 
@@ -203,4 +208,51 @@ def for_device(part: RowPartition, local_op, comm=None) -> RowPartitionedOp:
         return torch.cuda.stream(ext)
 
     comm = Comm(as_tensor, stream_ctx)
-    return RowPartitionedOp(part, local_op, comm, lambda d, A, m: mul_(d, A, m), lambda m, A, d: mul_(m, adjoint(A), d), dot, norm)
+
+    import os
+
+    import torch.distributed as dist
+
+    from ._ffi import lib, check, JetsHipError
+    from . import jetblock as _blk
+
+    nchunks = int(os.environ.get("JETS_AR_CHUNKS", "4"))
+    views = {}
+
+    def pipelined_adj(m, A, d) -> bool:
+        """Local adjoint in `nchunks` element ranges (jh_blockop_mul_adj_range); the all-reduce of a finished range
+        runs on RCCL's stream while the kernel of the next range runs on the library stream.  Same values as the
+        unpipelined path.  Returns False when the operator has no ranged kernel (then the caller does it in one piece)."""
+        if nchunks <= 1 or not dist.is_initialized() or not _blk.isblockop(A):
+            return False
+        jt = A.jet
+        nat = _blk._native_op(jt.s.get("_native"), jt.s["ops"], jt.rng.eltype())
+        if nat is None:
+            return False
+        n = m.length()
+        step = -(-n // nchunks)
+        step = -(-step // 16384) * 16384                      # chunk bounds on 64 KiB boundaries
+        key = id(m)
+        if key not in views or views[key][0] is not m:
+            views[key] = (m, as_tensor(m))
+        t = views[key][1]
+        works = []
+        lo = 0
+        try:
+            while lo < n:
+                cnt = builtins.min(step, n - lo)
+                check(lib.jh_blockop_mul_adj_range(nat.handle, m.handle, d.handle, lo, cnt))
+                with torch.cuda.stream(ext):
+                    works.append(dist.all_reduce(t[lo:lo + cnt], op=dist.ReduceOp.SUM, async_op=True))
+                lo += cnt
+        except JetsHipError as e:
+            if e.status == 4 and not works:                   # JH_ERR_UNSUPPORTED before anything was enqueued
+                return False
+            raise
+        with torch.cuda.stream(ext):
+            for w in works:
+                w.wait()                                      # the library stream waits for every chunk's all-reduce
+        return True
+
+    return RowPartitionedOp(part, local_op, comm, lambda d, A, m: mul_(d, A, m), lambda m, A, d: mul_(m, adjoint(A), d), dot, norm,
+                            pipelined_adj=pipelined_adj)

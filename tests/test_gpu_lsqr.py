@@ -190,3 +190,24 @@ def test_c_abi_rccl_entry_points_with_one_rank(Jets, oracle):
     with pytest.raises(Jets.JetsHipError):
         from jets_jl_amd._ffi import lib, check
         check(lib.jh_comm_allreduce_sum(mt.handle))                  # no communicator any more: loud
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex128])
+def test_ranged_adjoint_equals_whole_adjoint(Jets, oracle, dt):
+    """jh_blockop_mul_adj_range over consecutive element ranges == jh_blockop_mul_adj, bit for bit."""
+    from jets_jl_amd._ffi import lib, check
+
+    nrow, shape = 5, (64, 64, 20)                                   # 81920 elements
+    A, _, ops, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    nat = _native(Jets, A)
+    d = Jets.rand(Jets.range(A), seed=81, stream=0)
+    whole = Jets.mul_(Jets.zeros(Jets.domain(A)), A.H, d)
+    parts = Jets.rand(Jets.domain(A), seed=82, stream=0)            # dirty: every element must be overwritten
+    n = parts.length()
+    for lo, cnt in ((0, 16384), (16384, 32768), (49152, 4), (49156, n - 49156)):
+        check(lib.jh_blockop_mul_adj_range(nat.handle, parts.handle, d.handle, lo, cnt))
+    assert_bits_equal(parts.to_numpy(), whole.to_numpy(), "ranged adjoint")
+    with pytest.raises(Jets.JetsHipError):
+        check(lib.jh_blockop_mul_adj_range(nat.handle, parts.handle, d.handle, 1, 4))       # unaligned chunk start
+    with pytest.raises(Jets.JetsHipError):
+        check(lib.jh_blockop_mul_adj_range(nat.handle, parts.handle, d.handle, n - 4, 8))   # past the end
