@@ -207,7 +207,8 @@ def test_ranged_adjoint_equals_whole_adjoint(Jets, oracle, dt):
     for lo, cnt in ((0, 16384), (16384, 32768), (49152, 4), (49156, n - 49156)):
         check(lib.jh_blockop_mul_adj_range(nat.handle, parts.handle, d.handle, lo, cnt))
     assert_bits_equal(parts.to_numpy(), whole.to_numpy(), "ranged adjoint")
-    with pytest.raises(Jets.JetsHipError):
-        check(lib.jh_blockop_mul_adj_range(nat.handle, parts.handle, d.handle, 1, 4))       # unaligned chunk start
+    if np.dtype(dt).itemsize < 16:
+        with pytest.raises(Jets.JetsHipError):
+            check(lib.jh_blockop_mul_adj_range(nat.handle, parts.handle, d.handle, 1, 4))   # chunk start off a 16-byte boundary
     with pytest.raises(Jets.JetsHipError):
         check(lib.jh_blockop_mul_adj_range(nat.handle, parts.handle, d.handle, n - 4, 8))   # past the end
