@@ -166,9 +166,13 @@ int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m);
  * vec(A), src/Jets.jl:1138-1154).  d = alpha*(A m) + beta*d  /  m = alpha*(A' d) + beta*m  with real alpha, beta,
  * and ||result||^2 (fp64) returned through normsq when it is not NULL (then the call synchronises).
  * Same rounding sequence as mul! into a temporary followed by `y .= alpha*tmp .+ beta*y`; no temporary
- * range vector, no separate axpby or norm pass.  Tall all-DIAG operators only (else JH_ERR_UNSUPPORTED). */
+ * range vector, no separate axpby or norm pass.  beta == 0 never reads the output (BLAS convention).  The adjoint
+ * form also takes in_scale: every d_i is multiplied by it (rounded) before A_i' is applied -- with alpha = 1,
+ * beta = 0 this is (a*A)' d = A'(conj(a) d) of the scalar-times-operator chain (src/Jets.jl:1159-1164) in one
+ * launch; pass 1.0 otherwise (exact).  Tall all-DIAG operators only (else JH_ERR_UNSUPPORTED). */
 int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double alpha, double beta, double *normsq);
-int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double alpha, double beta, double *normsq);
+int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double alpha, double beta, double in_scale,
+                             double *normsq);
 /* ---------------------------------------------------------------- RCCL over xGMI ----------- */
 /* Row partition of a tall operator across the GPUs of a node (one process per GPU): the forward needs no exchange
  * (src/Jets.jl:1015-1031), the adjoint is a sum over rows (1045-1053) -> one in-place all-reduce of the domain vector

@@ -95,7 +95,7 @@ SYMBOLS = {
     "jh_blockop_mul_adj_range": (_int, [_vp, _vp, _vp, _i64, _i64]),
     "jh_blockop_normal_mul": (_int, [_vp, _vp, _vp]),
     "jh_blockop_mul_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
-    "jh_blockop_mul_adj_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
+    "jh_blockop_mul_adj_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _dblp]),
     "jh_comm_unique_id": (_int, [_vp]),
     "jh_comm_init_rank": (_int, [_vp, _int, _int]),
     "jh_comm_destroy": (_int, []),

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block
         sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
         mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
     }
+    const bool use_old = (beta != (S)0);
     double nrm = 0.0;
     for (int64_t i = i0; i < i1; i++) {
         const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
@@ -231,14 +232,14 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block
 #pragma unroll
         for (int k = 0; k < U; k++) {
             av[k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
-            dv[k] = ld<true>(reinterpret_cast<const V *>(di + sk[k]));
+            dv[k] = use_old ? ld<true>(reinterpret_cast<const V *>(di + sk[k])) : (V)(S)0;   // beta == 0: d is write-only
         }
 #pragma unroll
         for (int k = 0; k < U; k++) {
             V t = vmul<S, E, NS, V>(av[k], mv[k], false);      // mul!(tmp, A_i, m)
             V s1 = (V)alpha * t;
-            V s2 = (V)beta * dv[k];
-            V r = s1 + s2;                                      // d_i .= alpha*tmp .+ beta*d_i
+            V r = s1;
+            if (use_old) { V s2 = (V)beta * dv[k]; r = s1 + s2; }   // d_i .= alpha*tmp .+ beta*d_i
             if (ok[k]) {
                 st<true>(reinterpret_cast<V *>(di + sk[k]), r);
                 nrm += vnorm2<S, NS, V>(r);
@@ -253,7 +254,7 @@ template <typename S, int E, int NS, int U, int DEPTH, int BLK>
 __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                               const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ out,
                                                               const S *__restrict__ in, int64_t n_scalars, int direct, S alpha, S beta,
-                                                              double *__restrict__ partials)
+                                                              S gamma, double *__restrict__ partials)
 {
     typedef typename vec_of<S, NS>::type V;
     const int64_t s0 = ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
@@ -281,24 +282,23 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block
 #pragma unroll
         for (int j = 0; j < DEPTH; j++)
 #pragma unroll
-            for (int k = 0; k < U; k++) acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], dv[j][k], true);
+            for (int k = 0; k < U; k++) acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], (V)gamma * dv[j][k], true);   // gamma = 1: exact
     }
     for (; i < nrow; i++) {
         const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
 #pragma unroll
         for (int k = 0; k < U; k++) {
             V p = vmul<S, E, NS, V>(ld<true>(reinterpret_cast<const V *>(a + sk[k])),
-                                    ld<true>(reinterpret_cast<const V *>(in + i * n_scalars + sk[k])), true);
+                                    (V)gamma * ld<true>(reinterpret_cast<const V *>(in + i * n_scalars + sk[k])), true);
             acc[k] = direct ? p : acc[k] + p;
         }
     }
     double nrm = 0.0;
 #pragma unroll
     for (int k = 0; k < U; k++) {
-        V old = ld<false>(reinterpret_cast<const V *>(out + sk[k]));
         V s1 = (V)alpha * acc[k];
-        V s2 = (V)beta * old;
-        V r = s1 + s2;
+        V r = s1;
+        if (beta != (S)0) { V s2 = (V)beta * ld<false>(reinterpret_cast<const V *>(out + sk[k])); r = s1 + s2; }
         if (ok[k]) {
             st<false>(reinterpret_cast<V *>(out + sk[k]), r);
             nrm += vnorm2<S, NS, V>(r);
@@ -801,7 +801,8 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
 }
 
 template <typename S, int E, int NS>
-int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n_scalars, double alpha, double beta, double *normsq)
+int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n_scalars, double alpha, double beta, double gamma,
+                      double *normsq)
 {
     jh_context &c = jh_ctx();
     const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
@@ -817,7 +818,7 @@ int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n
 #define JH_LAUNCH(BLK, UU, DD)                                                                                         \
     hipLaunchKernelGGL((k_tall_diag_adj_update<S, E, NS, UU, DD, BLK>), dim3((unsigned)gx), dim3(BLK), 0, c.stream,     \
                        op->dev_blocks, op->nrow, a_base, a_stride, (S *)out, (const S *)in, n_scalars, direct, (S)alpha, \
-                       (S)beta, c.part_dev)
+                       (S)beta, (S)gamma, c.part_dev)
     if (wg == 512) JH_LAUNCH(512, 4, 4);
     else if (U == 4) JH_LAUNCH(256, 4, 2);
     else if (U == 2) JH_LAUNCH(256, 2, 4);
@@ -1130,7 +1131,8 @@ int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, dou
     return jh_fail(JH_ERR_INVALID, "jh_blockop_mul_axpby: unknown dtype %d", op->dtype);
 }
 
-int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double alpha, double beta, double *normsq)
+int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double alpha, double beta, double in_scale,
+                             double *normsq)
 {
     JH_TRY(jh_require_ready());
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_adj_axpby"));
@@ -1139,10 +1141,10 @@ int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d,
                                            "use jh_blockop_mul_adj into a temporary, jh_lincomb and jh_norm instead");
     const int64_t n = op->row_len[0];
     switch (op->dtype) {
-    case JH_F32: return launch_adj_update<float, 1, 4>(op, m->data, d->data, n, alpha, beta, normsq);
-    case JH_F64: return launch_adj_update<double, 1, 2>(op, m->data, d->data, n, alpha, beta, normsq);
-    case JH_C32: return launch_adj_update<float, 2, 4>(op, m->data, d->data, 2 * n, alpha, beta, normsq);
-    case JH_C64: return launch_adj_update<double, 2, 2>(op, m->data, d->data, 2 * n, alpha, beta, normsq);
+    case JH_F32: return launch_adj_update<float, 1, 4>(op, m->data, d->data, n, alpha, beta, in_scale, normsq);
+    case JH_F64: return launch_adj_update<double, 1, 2>(op, m->data, d->data, n, alpha, beta, in_scale, normsq);
+    case JH_C32: return launch_adj_update<float, 2, 4>(op, m->data, d->data, 2 * n, alpha, beta, in_scale, normsq);
+    case JH_C64: return launch_adj_update<double, 2, 2>(op, m->data, d->data, 2 * n, alpha, beta, in_scale, normsq);
     }
     return jh_fail(JH_ERR_INVALID, "jh_blockop_mul_adj_axpby: unknown dtype %d", op->dtype);
 }

@@ -347,25 +347,61 @@ def getblock_op(A, i: int, jc: int, kind=None):  # :1085-1090, 1100-1110
     return getblock_op(A.jet, i, jc)  # :1087
 
 
-# ------------------------------------------------------------------------------ fused A' o A -------
-def try_fused_normal(out, x, ops: Sequence[Jop]):
-    """JetComposite_df over (A', A) with A a tall all-diagonal native block operator: one kernel that
-    reads A once (jh_blockop_normal_mul).  Returns None when the chain does not qualify."""
+# ------------------------------------------------------------------------------ fused chains -------
+def _tall_native(op):
+    """The NativeBlockOp of a tall (one-column) device-native block operator, else None."""
+    if not (isinstance(op, JopLn) and isblockop(op)):
+        return None
+    j = op.jet
+    if j.s["ops"].shape[1] != 1:
+        return None
+    return _native_op(j.s.get("_native"), j.s["ops"], j.rng.eltype())
+
+
+def _real_scale(op):
+    """The real scalar a of an `a*` operator (src/Jets.jl:1159-1162), else None."""
+    if isinstance(op, JopAdjoint):
+        op = op.op                                    # conj(a) == a for a real a
+    if isinstance(op, JopLn) and op.jet.df is _j.constdiag_df and op.jet.df_adj is _j.constdiag_df_adj:
+        a = complex(op.jet.s["a"])
+        return a.real if a.imag == 0.0 else None
+    return None
+
+
+def try_fused_chain(out, x, ops: Sequence[Jop]):
+    """Two-stage chains of JetComposite_df / df' (src/Jets.jl:530-540) that one kernel computes with the unfused
+    chain's exact rounding sequence; returns None when the chain does not qualify:
+      (A', A)   normal operator, coefficients read once            -> jh_blockop_normal_mul
+      (a, A)    scalar * operator, forward                         -> jh_blockop_mul_axpby(alpha = a, beta = 0)
+      (A', a')  scalar * operator, adjoint: A'(conj(a) d)          -> jh_blockop_mul_adj_axpby(in_scale = a)
+    for a tall all-diagonal device-native block operator A and a real scalar a."""
     if len(ops) != 2:
         return None
     left, right = ops
-    if not (isinstance(left, JopAdjoint) and left.op is right and isinstance(right, JopLn) and isblockop(right)):
-        return None
-    j = right.jet
-    nat = _native_op(j.s.get("_native"), j.s["ops"], j.rng.eltype())
-    if nat is None or j.s["ops"].shape[1] != 1 or j.s["ops"].shape[0] < 2:
-        return None
     try:
-        return nat.normal_mul(out, x)
+        if isinstance(left, JopAdjoint) and left.op is right:
+            nat = _tall_native(right)
+            if nat is not None and right.jet.s["ops"].shape[0] >= 2:
+                return nat.normal_mul(out, x)
+            return None
+        a = _real_scale(left)
+        if a is not None and not isinstance(right, JopAdjoint):
+            nat = _tall_native(right)
+            if nat is not None:
+                check(lib.jh_blockop_mul_axpby(nat.handle, out.handle, x.handle, a, 0.0, None))
+                return out
+            return None
+        a = _real_scale(right)
+        if a is not None and isinstance(left, JopAdjoint):
+            nat = _tall_native(left.op)
+            if nat is not None:
+                check(lib.jh_blockop_mul_adj_axpby(nat.handle, out.handle, x.handle, 1.0, 0.0, a, None))
+                return out
     except _arr_check_error() as e:  # not eligible for the fused kernel (mixed kinds, ragged blocks)
         if e.status == 4:
             return None
         raise
+    return None
 
 
 def _arr_check_error():

@@ -266,6 +266,8 @@ def close(A):  # :290, 317, 591-595, 717-721, 1120-1124
     if j.f is JetComposite_f or j.f is JetSum_f:
         for op in j.s["ops"]:
             close(op)
+        if isinstance(j.s.get("_ws"), _Workspace):
+            j.s["_ws"].close()
         return None
     if j.f is _blk.JetBlock_f:
         _blk.close_block(j)
@@ -356,43 +358,69 @@ def mul(A: Jop, m):
 
 
 # ------------------------------------------------------------------------------ composition --------
+class _Workspace:
+    """Zero-filled temporaries of a combinator, kept between calls.  The reference allocates `zeros(range(op))`
+    for every stage on every call (src/Jets.jl:525, 531, 537, 632, 641, 650) -- at 64 GiB per range vector that is
+    the dominant cost of a chain; here a stage's temporary is allocated once and re-zeroed (the zero fill is kept:
+    block operators skip zero blocks and accumulate into their output, src/Jets.jl:1022-1024)."""
+
+    def __init__(self):
+        self._pool = {}
+
+    def __deepcopy__(self, memo):  # copy(jet) gets its own, empty pool
+        return _Workspace()
+
+    def zeros(self, slot, R):
+        hit = self._pool.get(slot)
+        if hit is None or hit[0] != R:
+            hit = (R, zeros(R))
+            self._pool[slot] = hit
+            return hit[1]
+        return fill_(hit[1], 0)
+
+    def close(self):
+        for _, x in self._pool.values():
+            x.close()
+        self._pool = {}
+
+
 def JetComposite(ops: Sequence[Jop]) -> Jet:  # :522
     ops = tuple(ops)
     return Jet(f=JetComposite_f, df=JetComposite_df, df_adj=JetComposite_df_adj, dom=domain(ops[-1]), rng=range_(ops[0]),
-               s={"ops": ops})
+               s={"ops": ops, "_ws": _Workspace()})
 
 
-def JetComposite_f(d, m, *, ops, **kw):  # :524-528  right-to-left chain through zeros() temporaries
-    x = m
-    for op in reversed(ops):
-        x = mul_(zeros(range_(op)), op, x)
-    return copyto_(d, x)
+def _chain(out, x, stages, ws):
+    """x -> stages[0] -> ... -> stages[-1] -> out.  Every stage but the last writes a zero-filled temporary
+    (src/Jets.jl:525/531/537); the last writes `out` itself after zeroing it, which is the reference's
+    `d .= chain(m)` (526/532/538) without the extra copy."""
+    ws = ws if ws is not None else _Workspace()
+    for k, (op, R) in enumerate(stages[:-1]):
+        x = mul_(ws.zeros(k, R), op, x)
+    op, _ = stages[-1]
+    return mul_(fill_(out, 0), op, x)
 
 
-def JetComposite_df(d, m, *, ops, **kw):  # :530-534
+def JetComposite_f(d, m, *, ops, _ws=None, **kw):  # :524-528  right-to-left chain
+    return _chain(d, m, [(op, range_(op)) for op in reversed(ops)], _ws)
+
+
+def JetComposite_df(d, m, *, ops, _ws=None, **kw):  # :530-534
     from . import jetblock as _blk
 
-    fused = _blk.try_fused_normal(d, m, ops)
+    fused = _blk.try_fused_chain(d, m, ops)
     if fused is not None:
         return fused
-    x = m
-    for op in reversed(ops):
-        L = JopLn(op)
-        x = mul_(zeros(range_(L)), L, x)
-    return copyto_(d, x)
+    return _chain(d, m, [(JopLn(op), range_(JopLn(op))) for op in reversed(ops)], _ws)
 
 
-def JetComposite_df_adj(m, d, *, ops, **kw):  # :536-540
+def JetComposite_df_adj(m, d, *, ops, _ws=None, **kw):  # :536-540
     from . import jetblock as _blk
 
-    fused = _blk.try_fused_normal(m, d, tuple(adjoint(JopLn(op)) for op in reversed(ops)))
+    fused = _blk.try_fused_chain(m, d, tuple(adjoint(JopLn(op)) for op in reversed(ops)))
     if fused is not None:
         return fused
-    x = d
-    for op in ops:
-        L = adjoint(JopLn(op))
-        x = mul_(zeros(domain(JopLn(op))), L, x)
-    return copyto_(m, x)
+    return _chain(m, d, [(adjoint(JopLn(op)), domain(JopLn(op))) for op in ops], _ws)
 
 
 def jops_comp(op: Jop) -> tuple:  # :542-550
@@ -418,7 +446,7 @@ PLUS, MINUS = "+", "-"
 def JetSum(ops: Sequence[Jop], sgns: Sequence[str]) -> Jet:  # :628
     ops = tuple(ops)
     return Jet(f=JetSum_f, df=JetSum_df, df_adj=JetSum_df_adj, dom=domain(ops[0]), rng=range_(ops[0]),
-               s={"ops": ops, "sgns": tuple(sgns)})
+               s={"ops": ops, "sgns": tuple(sgns), "_ws": _Workspace()})
 
 
 def _accumulate(sgn: str, acc, term):
@@ -426,25 +454,25 @@ def _accumulate(sgn: str, acc, term):
     return lincomb_(acc, [1.0, 1.0 if sgn == PLUS else -1.0], [acc, term])
 
 
-def JetSum_f(d, m, *, ops, sgns, **kw):  # :630-637
+def JetSum_f(d, m, *, ops, sgns, _ws=None, **kw):  # :630-637
     fill_(d, 0)
-    _d = zeros(range_(ops[0]))
+    _d = (_ws or _Workspace()).zeros("rng", range_(ops[0]))   # one temporary, zeroed once per call like the reference (:632)
     for op, sg in zip(ops, sgns):
         _accumulate(sg, d, mul_(_d, op, m))
     return d
 
 
-def JetSum_df(d, m, *, ops, sgns, **kw):  # :639-646
+def JetSum_df(d, m, *, ops, sgns, _ws=None, **kw):  # :639-646
     fill_(d, 0)
-    _d = zeros(range_(ops[0]))
+    _d = (_ws or _Workspace()).zeros("rng", range_(ops[0]))
     for op, sg in zip(ops, sgns):
         _accumulate(sg, d, mul_(_d, JopLn(op), m))
     return d
 
 
-def JetSum_df_adj(m, d, *, ops, sgns, **kw):  # :648-655
+def JetSum_df_adj(m, d, *, ops, sgns, _ws=None, **kw):  # :648-655
     fill_(m, 0)
-    _m = zeros(domain(ops[0]))
+    _m = (_ws or _Workspace()).zeros("dom", domain(ops[0]))
     for op, sg in zip(ops, sgns):
         _accumulate(sg, m, mul_(_m, adjoint(JopLn(op)), d))
     return m
@@ -490,8 +518,11 @@ def constdiag_df_adj(m, d, *, a, **kw):  # :1160   m .= conj(a) * d
     return lincomb_(m, [np.conj(a)], [d])
 
 
-def scale_op(a, A: Jop) -> Jop:  # :1161-1164  (built on domain(A) for dom AND rng, as in the reference)
-    _a = JopLn(dom=domain(A), rng=domain(A), df=constdiag_df, df_adj=constdiag_df_adj, s={"a": a})
+def scale_op(a, A: Jop) -> Jop:  # :1161-1164
+    """a*A.  Documented fix: the reference builds the scalar operator on domain(A) for BOTH spaces (:1162), which only
+    works for square A (its test uses a 10x10 matrix, test/runtests.jl:789-795); here it lives on range(A), which is
+    identical for square operators and makes a*A valid for tall block operators too."""
+    _a = JopLn(dom=range_(A), rng=range_(A), df=constdiag_df, df_adj=constdiag_df_adj, s={"a": a})
     return compose(_a, A)
 
 

@@ -112,7 +112,7 @@ class _Engine:
         if self.native is not None:
             out = C.c_double(0)
             try:
-                check(lib.jh_blockop_mul_adj_axpby(self.native.handle, v.handle, u.handle, float(alpha), float(beta), C.byref(out)))
+                check(lib.jh_blockop_mul_adj_axpby(self.native.handle, v.handle, u.handle, float(alpha), float(beta), 1.0, C.byref(out)))
                 return math.sqrt(out.value)
             except JetsHipError as e:
                 if e.status != 4:

@@ -291,3 +291,39 @@ def test_shape_errors_are_loud(Jets, oracle):
     with pytest.raises(Jets.JetsHipError):                                         # elementwise block must be square
         Jets.blockop([[Jets.JopDiagonal(Jets.rand(Jets.JetSpace(np.float32, 4))), Jets.JopDiagonal(Jets.rand(Jets.JetSpace(np.float32, 5)))]]) * \
             Jets.zeros(Jets.JetBSpace([Jets.JetSpace(np.float32, 4), Jets.JetSpace(np.float32, 5)]))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_scalar_times_tall_block_operator_fused_bit_exact(Jets, oracle, dt):
+    """a*A (src/Jets.jl:1159-1164) on a tall diagonal block operator: one fused launch each way, same bits as the
+    unfused chain  d = a .* (A m)  and  m = A'(a .* d)  restated with the oracle."""
+    nrow, shape, a = 5, (32, 16, 8), 0.7
+    A, _, ops, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    B = a * A
+    assert Jets.range(B) == Jets.range(A) and Jets.domain(B) == Jets.domain(A)      # documented fix of src/Jets.jl:1162
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=11)
+    hm = u01(oracle, dt, SEED_M, 11, n)
+    d = Jets.mul_(Jets.rand(Jets.range(A), seed=5, stream=5), B, m)                 # dirty output, overwritten
+    tmp = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [hm])
+    ref = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [a], [tmp])
+    assert_bits_equal(d.to_numpy(), np.concatenate(ref), "(a*A) m")
+    dd = Jets.rand(Jets.range(A), seed=SEED_D, stream=11)
+    hd = u01(oracle, dt, SEED_D, 11, nrow * n)
+    hd_blocks = [hd[i * n:(i + 1) * n].copy() for i in range(nrow)]
+    mt = Jets.mul_(Jets.rand(Jets.domain(A), seed=6, stream=6), B.H, dd)
+    scaled = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [a], [hd_blocks])
+    ref_m = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], scaled)
+    assert_bits_equal(mt.to_numpy().ravel(order="F"), ref_m[0], "(a*A)' d")
+    lhs, rhs = Jets.dot_product_test(B, m, dd)
+    assert abs(lhs - rhs) / abs(lhs + rhs) < _dpt_tol(dt)
+    # a linear combination of block operators through JetSum (docs/src/index.md: A = 1.0*A1 - 2.0*A2)
+    A2, _, ops2, _ = make_tall_diag(Jets, oracle, dt, nrow, shape, seed=77)
+    S = 1.5 * A - 2.0 * A2
+    got = (S * m).to_numpy()
+    t1 = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [1.5], [tmp])
+    tmp2 = oracle.block_df(ops2, [np.zeros(n, dtype=dt) for _ in range(nrow)], [hm])
+    t2 = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [2.0], [tmp2])
+    acc = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [1.0, 1.0], [[np.zeros(n, dtype=dt)] * nrow, t1])
+    acc = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [1.0, -1.0], [acc, t2])
+    assert_bits_equal(got, np.concatenate(acc), "1.5*A - 2.0*A2")

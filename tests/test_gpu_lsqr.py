@@ -55,13 +55,13 @@ def test_fused_updates_bit_exact_vs_unfused_chain(Jets, oracle, dt, nrow, shape)
     assert out.value == pytest.approx(truth, rel=tol)
 
     # adjoint half:  m <- alpha*(A' d) + beta*m   (d is now `ref`)
-    check(lib.jh_blockop_mul_adj_axpby(nat.handle, m.handle, d.handle, alpha, beta, C.byref(out)))
+    check(lib.jh_blockop_mul_adj_axpby(nat.handle, m.handle, d.handle, alpha, beta, 1.0, C.byref(out)))
     tmpm = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], ref)
     refm = oracle.barr_lincomb([np.empty(n, dtype=dt)], [alpha, beta], [tmpm, [hm]])
     assert_bits_equal(m.to_numpy().ravel(order="F"), refm[0], "m <- alpha*A'd + beta*m")
     assert out.value == pytest.approx(float(np.sum(np.abs(refm[0].astype(np.complex128)) ** 2)), rel=tol)
     # normsq == NULL: asynchronous, same result
-    check(lib.jh_blockop_mul_adj_axpby(nat.handle, m.handle, d.handle, 0.0, 1.0, None))
+    check(lib.jh_blockop_mul_adj_axpby(nat.handle, m.handle, d.handle, 0.0, 1.0, 1.0, None))
     Jets.synchronize()
 
 

@@ -28,7 +28,7 @@ for rnd in range(2):
             e0 = J.Event().record()
             check(lib.jh_blockop_mul_axpby(nat.handle, u.handle, v.handle, 1e-3, 0.5, None))
             e1 = J.Event().record()
-            check(lib.jh_blockop_mul_adj_axpby(nat.handle, v.handle, u.handle, 1e-3, 0.5, None))
+            check(lib.jh_blockop_mul_adj_axpby(nat.handle, v.handle, u.handle, 1e-3, 0.5, 1.0, None))
             e2 = J.Event().record()
             if rep:
                 tf += e0.elapsed_ms(e1); ta += e1.elapsed_ms(e2)
