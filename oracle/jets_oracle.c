@@ -177,3 +177,46 @@ void jo_normal_df(int dtype, int64_t nrow, int64_t ncol, const jo_block *ops, vo
     DISPATCH(dtype, normal_df_f32(nrow, ncol, ops, y_arrays, m_arrays), normal_df_f64(nrow, ncol, ops, y_arrays, m_arrays),
              normal_df_c32(nrow, ncol, ops, y_arrays, m_arrays), normal_df_c64(nrow, ncol, ops, y_arrays, m_arrays));
 }
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int jo_tall_diag_fwd_omp_f32(int64_t nrow, int64_t n, const float *const *a, const float *m, float *const *d)
+{
+    int nt = 1;
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+#pragma omp single
+        nt = omp_get_num_threads();
+#endif
+#pragma omp for collapse(2) schedule(static)
+        for (int64_t i = 0; i < nrow; i++)
+            for (int64_t c = 0; c < (n + 65535) / 65536; c++) {
+                const int64_t lo = c * 65536, hi = lo + 65536 < n ? lo + 65536 : n;
+                for (int64_t k = lo; k < hi; k++) d[i][k] = a[i][k] * m[k];          /* d_i .= diagonal_i .* m */
+            }
+    }
+    return nt;
+}
+
+int jo_tall_diag_adj_omp_f32(int64_t nrow, int64_t n, const float *const *a, float *m, const float *const *d)
+{
+    int nt = 1;
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+#pragma omp single
+        nt = omp_get_num_threads();
+#endif
+#pragma omp for schedule(static)
+        for (int64_t c = 0; c < (n + 16383) / 16384; c++) {
+            const int64_t lo = c * 16384, hi = lo + 16384 < n ? lo + 16384 : n;
+            for (int64_t k = lo; k < hi; k++) m[k] = 0.0f;                            /* _m .= 0 */
+            for (int64_t i = 0; i < nrow; i++)                                         /* rows in order */
+                for (int64_t k = lo; k < hi; k++) { float p = a[i][k] * d[i][k]; m[k] = m[k] + p; }
+        }
+    }
+    return nt;
+}

@@ -90,6 +90,13 @@ void jo_block_df_adj(int dtype, int64_t nrow, int64_t ncol, const jo_block *ops,
 void jo_normal_df(int dtype, int64_t nrow, int64_t ncol, const jo_block *ops, void *const *y_arrays,
                   const void *const *m_arrays);
 
+/* All-cores variant of the tall diagonal Float32 pair, for the SEPARATELY LABELLED cpu baseline only:
+ * the reference is single-threaded, this is not its structure.  Forward: rows x element chunks in parallel.  Adjoint:
+ * element chunks in parallel, rows in order inside a chunk, product rounded then added -- same bits as the sequential
+ * loop.  Returns the number of threads used. */
+int jo_tall_diag_fwd_omp_f32(int64_t nrow, int64_t n, const float *const *a, const float *m, float *const *d);
+int jo_tall_diag_adj_omp_f32(int64_t nrow, int64_t n, const float *const *a, float *m, const float *const *d);
+
 #ifdef __cplusplus
 }
 #endif

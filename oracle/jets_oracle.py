@@ -210,6 +210,18 @@ def child_mul_adj(block: Block, m, d):
     return m
 
 
+def tall_diag_pair_omp_f32(a_blocks, m, d_blocks, mt):
+    """All-cores forward + adjoint of a tall Float32 diagonal operator (separately labelled CPU baseline only)."""
+    nrow, n = len(a_blocks), m.size
+    pa = (C.c_void_p * nrow)(*[x.ctypes.data for x in a_blocks])
+    pd = (C.c_void_p * nrow)(*[x.ctypes.data for x in d_blocks])
+    _lib.jo_tall_diag_fwd_omp_f32.restype = C.c_int
+    _lib.jo_tall_diag_adj_omp_f32.restype = C.c_int
+    nt = _lib.jo_tall_diag_fwd_omp_f32(C.c_int64(nrow), C.c_int64(n), pa, C.c_void_p(m.ctypes.data), pd)
+    _lib.jo_tall_diag_adj_omp_f32(C.c_int64(nrow), C.c_int64(n), pa, C.c_void_p(mt.ctypes.data), pd)
+    return nt
+
+
 def dot_product_test(ops, m_blocks, d_blocks, mmask=None, dmask=None):
     """dot_product_test (src/Jets.jl:1211-1226) on a block operator of native kinds."""
     dt = m_blocks[0].dtype
