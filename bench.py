@@ -199,7 +199,10 @@ def main():
         try:
             tj = json.load(open(tpath))
             if tj.get("nblocks") == nloc and tj.get("edge") == edge:
-                traffic = tj.get(dom["kernel"].split("+")[0])
+                key = dom["kernel"].split("+")[0]
+                if key == "k_tall_diag_fwd":
+                    key += "@walk%d" % J.tune_get("last_fwd_walk")      # PMC traffic is recorded per grid walk
+                traffic = tj.get(key)
         except Exception:
             traffic = None
 
@@ -256,6 +259,7 @@ def main():
                 "workload": f"{nblocks}x1 tall JopBlock of diagonal JopLn, {edge}^3 Float32 blocks, fwd+adj mul! pair",
                 "nblocks": nblocks, "block": [edge, edge, edge], "rows_per_gpu": nloc,
                 "parallelism": f"row-partition x{world}" + (" + RCCL all-reduce(64 MiB) in adjoint" if world > 1 else ""),
+                "fwd_grid_walk": {0: "sequential row sweep", 1: "all rows concurrent"}.get(J.tune_get("last_fwd_walk"), "banded"),
                 "tune": {k: J.tune_get(k) for k in ("fwd_group", "fwd_unroll", "fwd_wg", "fwd_order", "adj_unroll", "adj_depth", "adj_wg", "nt", "autotune")},
             },
             "achieved_GBps_pair": pair_bytes_global * pairs_per_s / 1e9,

@@ -558,6 +558,7 @@ int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     }
     int64_t band = sh.order <= 0 ? 1 : (sh.order == 1 ? gy : sh.order);   // order: 0 sequential, 1 all rows, k>1 = k groups per band
     if (band > gy) band = gy;
+    c.last_fwd_walk = sh.order;
 #define JH_FWD_CASE(U)                                                                                               \
     case U: {                                                                                                         \
         int64_t gx = (n_scalars + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                               \

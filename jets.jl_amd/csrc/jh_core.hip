@@ -432,6 +432,7 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "fwd_order")) *value = c.fwd_order;
     else if (!strcmp(name, "nt")) *value = c.nt;
     else if (!strcmp(name, "autotune")) *value = c.autotune;
+    else if (!strcmp(name, "last_fwd_walk")) *value = c.last_fwd_walk;
     else return jh_fail(JH_ERR_INVALID, "jh_tune_get: unknown knob '%s'", name);
     return JH_OK;
 }

@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--nblocks", type=int, default=1024)
     ap.add_argument("--edge", type=int, default=256)
     ap.add_argument("--cmd", default="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline")
+    ap.add_argument("--walk", type=int, default=None, help="grid walk of the tall forward the profiled runs were pinned to (0/1)")
+    ap.add_argument("--merge", action="store_true", help="merge into an existing traffic_latest.json instead of replacing it")
     args = ap.parse_args()
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
@@ -74,7 +76,7 @@ def main():
         f, w = fetch.get(k), write.get(k)
         tr = (2 * f + w) * 1024 if (f is not None and w is not None) else None
         if tr is not None and k in algo:
-            traffic[k] = tr
+            traffic[k + (f"@walk{args.walk}" if (k == "k_tall_diag_fwd" and args.walk is not None) else "")] = tr
         lines.append("| {} | {} | {:.3f} | {} | {} | {} | {} | {} | {} | {} |".format(
             k, r["Calls"], avg_ms, r["Percentage"], f"{ab:,}" if ab else "-",
             f"{ab / avg_ms / 1e6:.1f}" if ab else "-", f"{f:,.0f}" if f is not None else "-",
@@ -82,7 +84,12 @@ def main():
             f"{tr / ab:.3f}" if (tr is not None and ab) else "-"))
     lines += ["", "Full kernel names and min/max/stddev: `rocprof_%s_kernel_stats.csv`." % args.round, ""]
     open(os.path.join(out_dir, f"rocprof_{args.round}_summary.md"), "w").write("\n".join(lines))
-    json.dump(traffic, open(os.path.join(out_dir, "traffic_latest.json"), "w"), indent=1)
+    tpath = os.path.join(out_dir, "traffic_latest.json")
+    if args.merge and os.path.exists(tpath):
+        old = json.load(open(tpath))
+        old.update(traffic)
+        traffic = old
+    json.dump(traffic, open(tpath, "w"), indent=1)
     print("\n".join(lines))
 
 
