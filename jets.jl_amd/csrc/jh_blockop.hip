@@ -207,10 +207,13 @@ template <typename S, int E, int NS, int U, int BLK>
 __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block *__restrict__ blocks, int64_t nrow, int rows_per_wg,
                                                               const S *__restrict__ a_base, int64_t a_stride,
                                                               const S *__restrict__ m, S *__restrict__ d, int64_t n_scalars,
-                                                              unsigned ntiles, S alpha, S beta, double *__restrict__ partials)
+                                                              unsigned ntiles, unsigned ngroups, int walk, S alpha, S beta,
+                                                              double *__restrict__ partials)
 {
     typedef typename vec_of<S, NS>::type V;
-    const unsigned tile = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
+    // walk 0: tile index fastest (one block row at a time); walk 1: row group fastest (all rows concurrently)
+    const unsigned tile = walk ? blockIdx.x / ngroups : blockIdx.x % ntiles;
+    const unsigned grp = walk ? blockIdx.x % ngroups : blockIdx.x / ntiles;
     const int64_t s0 = ((int64_t)tile * U * BLK + threadIdx.x) * NS;
     const int64_t i0 = (int64_t)grp * rows_per_wg;
     const int64_t i1 = (i0 + rows_per_wg < nrow) ? i0 + rows_per_wg : nrow;
@@ -783,22 +786,54 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     else if (c.fwd_wg == 256 && c.fwd_unroll == 4) { wg = 256; U = 4; }
     else if (c.fwd_wg == 256 && c.fwd_unroll == 1) { wg = 256; U = 1; }
     if (c.fwd_group) G = (int)c.fwd_group;
+    // Grid walk: like the plain forward (autotune_fwd_walk) the row-concurrent walk wins in some processes and loses in
+    // others.  This kernel updates d in place, so it cannot be re-run for timing: the first two real calls on a large
+    // operator use walk 0 and walk 1 and are timed with events (only when the caller asked for the norm, i.e. the call
+    // synchronises anyway); later calls use the faster one.
+    const double stream_bytes = 3.0 * (double)op->nrow * (double)n_scalars * sizeof(S);
+    const bool knobs_free = !c.fwd_wg && !c.fwd_unroll && !c.fwd_group && c.fwd_order < 0;
+    const bool tunable = c.autotune && knobs_free && normsq && stream_bytes >= 8.0 * (double)(1ull << 30) && op->nrow >= 64;
+    int walk = (c.fwd_order == 1) ? 1 : 0;
+    int trial = -1;
+    if (tunable) {
+        if (op->upd_walk >= 0) walk = op->upd_walk;
+        else { trial = op->upd_trials; walk = trial; }        // trial 0 -> walk 0, trial 1 -> walk 1
+    }
+    if (walk == 1 && !c.fwd_group) G = 2;
     if (G > op->nrow) G = (int)op->nrow;
     const int64_t gx = (nvec + (int64_t)wg * U - 1) / ((int64_t)wg * U);
     int64_t gy = (op->nrow + G - 1) / G;
     while (gx * gy * wg >= ((int64_t)1 << 32) && G < op->nrow) { G *= 2; gy = (op->nrow + G - 1) / G; }   // HIP: grid x block < 2^32 threads
     JH_REQUIRE(gx * gy * wg < ((int64_t)1 << 32), "fused forward update: grid of %lld workgroups is too large", (long long)(gx * gy));
     JH_TRY(jh_ensure_partials(gx * gy));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (trial >= 0) {
+        JH_CHECK_HIP(hipEventCreate(&e0));
+        JH_CHECK_HIP(hipEventCreate(&e1));
+        JH_CHECK_HIP(hipEventRecord(e0, c.stream));
+    }
 #define JH_LAUNCH(BLK, UU)                                                                                             \
     hipLaunchKernelGGL((k_tall_diag_fwd_update<S, E, NS, UU, BLK>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream,  \
                        op->dev_blocks, op->nrow, G, a_base, a_stride, (const S *)m, (S *)d, n_scalars, (unsigned)gx,   \
-                       (S)alpha, (S)beta, c.part_dev)
+                       (unsigned)gy, walk, (S)alpha, (S)beta, c.part_dev)
     if (wg == 1024) JH_LAUNCH(1024, 8);
     else if (U == 4) JH_LAUNCH(256, 4);
     else JH_LAUNCH(256, 1);
 #undef JH_LAUNCH
     JH_CHECK_HIP(hipGetLastError());
-    return finish_normsq(gx * gy, normsq);
+    if (trial >= 0) JH_CHECK_HIP(hipEventRecord(e1, c.stream));
+    const int st = finish_normsq(gx * gy, normsq);          // synchronises (normsq != NULL on a trial)
+    if (trial >= 0) {
+        float ms = 0.f;
+        if (st == JH_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+            op->upd_ms[trial] = ms;
+            op->upd_trials = trial + 1;
+            if (op->upd_trials == 2) op->upd_walk = (op->upd_ms[1] < op->upd_ms[0]) ? 1 : 0;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    return st;
 }
 
 template <typename S, int E, int NS>

@@ -110,6 +110,9 @@ struct jh_blockop {
     bool elementwise = false;                // no DENSE block
     bool diag_strided = false;               // coeff[i] = coeff[0] + i*stride bytes
     mutable int fwd_walk = -1;               // autotuned grid walk of the tall forward: -1 untried, 0 sequential, 1 all rows
+    mutable int upd_walk = -1;               // same for the fused forward update (timed on its first two real calls)
+    mutable int upd_trials = 0;
+    mutable float upd_ms[2] = {0.f, 0.f};
     int64_t diag_stride_elems = 0;
 };
 
