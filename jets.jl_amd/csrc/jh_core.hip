@@ -368,9 +368,7 @@ int jh_copy(jh_bvec *dst, const jh_bvec *src)
     JH_REQUIRE(dst->length == src->length, "jh_copy: length mismatch (%lld vs %lld)", (long long)dst->length,
                (long long)src->length);
     size_t bytes = (size_t)dst->length * jh_dtype_size(dst->dtype);
-    if (bytes == 0 || dst->data == src->data) return JH_OK;
-    JH_CHECK_HIP(hipMemcpyAsync(dst->data, src->data, bytes, hipMemcpyDeviceToDevice, jh_ctx().stream));
-    return JH_OK;
+    return jh_launch_copy_bytes(dst->data, src->data, bytes);
 }
 
 int jh_download(const jh_bvec *v, int64_t offset, int64_t count, void *host_dst)

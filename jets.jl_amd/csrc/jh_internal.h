@@ -119,6 +119,7 @@ struct jh_blockop {
 int jh_ensure_partials(int64_t n);     // grows ctx.part_dev to >= n doubles (may synchronise + reallocate)
 // vecops entry used by blockop for generic pieces
 int jh_launch_fill_range(void *ptr, int dtype, int64_t count, double re, double im);
+int jh_launch_copy_bytes(void *dst, const void *src, size_t bytes);
 int jh_launch_hadamard_raw(void *dst, const void *x, const void *y, int dtype, int64_t count, int conj_x);
 int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const double *cre, const double *cim, const void *const *x);
 // dense child operator (jh_dense.hip): y = A x (rows) or y = A^H x / A^T x (cols); A column-major nr x nc

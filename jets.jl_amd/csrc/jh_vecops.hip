@@ -16,6 +16,31 @@ struct alignas(sizeof(S) * NS) Pack {
     S v[NS];
 };
 
+// streaming (nontemporal) pack load / store: these kernels touch every byte once
+template <typename S, int NS> __device__ inline Pack<S, NS> ldnt(const Pack<S, NS> *p)
+{
+    Pack<S, NS> o;
+    if constexpr (NS == 1) {
+        o.v[0] = __builtin_nontemporal_load(reinterpret_cast<const S *>(p));
+    } else {
+        typedef S V __attribute__((ext_vector_type(NS)));
+        V v = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+        __builtin_memcpy(&o, &v, sizeof(o));
+    }
+    return o;
+}
+template <typename S, int NS> __device__ inline void stnt(Pack<S, NS> *p, const Pack<S, NS> &o)
+{
+    if constexpr (NS == 1) {
+        __builtin_nontemporal_store(o.v[0], reinterpret_cast<S *>(p));
+    } else {
+        typedef S V __attribute__((ext_vector_type(NS)));
+        V v;
+        __builtin_memcpy(&v, &o, sizeof(o));
+        __builtin_nontemporal_store(v, reinterpret_cast<V *>(p));
+    }
+}
+
 __host__ __device__ inline uint64_t mix64(uint64_t z)
 {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -33,6 +58,18 @@ inline int grid_for(int64_t work_items, int per_thread)
     int64_t g = (work_items + (int64_t)WG * per_thread - 1) / ((int64_t)WG * per_thread);
     if (g < 1) g = 1;
     if (g > 2048) g = 2048;
+    return (int)g;
+}
+
+// Elementwise kernels: ONE pack per thread and as many workgroups as that takes (capped at 2^23 workgroups =
+// 2^31 threads, HIP's grid x block limit is 2^32; beyond that the grid-stride loop runs a second pass).
+// Measured on MI355X (tools/micro/stream.hip, 16 GiB): one-shot fill 6.7 / copy 6.6 / triad 6.5 TB/s against
+// 5.2-5.4 TB/s for a 2048-workgroup persistent grid-stride loop.  Reductions keep the persistent grid (few partials).
+inline int grid_full(int64_t packs)
+{
+    int64_t g = (packs + WG - 1) / WG;
+    if (g < 1) g = 1;
+    if (g > ((int64_t)1 << 23)) g = (int64_t)1 << 23;
     return (int)g;
 }
 
@@ -60,7 +97,7 @@ __global__ void k_fill(S *__restrict__ p, int64_t n, int64_t head, S re, S im)
 #pragma unroll
     for (int c = 0; c < NS; c++) val.v[c] = (PER == 2 && ((head + c) & 1)) ? im : re;
     Pack<S, NS> *pv = reinterpret_cast<Pack<S, NS> *>(p + head);
-    for (int64_t v = tid; v < nvec; v += stride) pv[v] = val;
+    for (int64_t v = tid; v < nvec; v += stride) stnt(pv + v, val);
     if (tid < head) p[tid] = (PER == 2 && (tid & 1)) ? im : re;
     if (tid < n - tail0) p[tail0 + tid] = (PER == 2 && ((tail0 + tid) & 1)) ? im : re;
 }
@@ -72,7 +109,7 @@ int fill_scalars(S *p, int64_t n, double re, double im)
     constexpr int NS = 16 / sizeof(S);
     int64_t head = head_scalars<S>(p, n);
     int64_t nvec = (n - head) / NS;
-    hipLaunchKernelGGL((k_fill<S, NS, PER>), dim3(grid_for(nvec > 0 ? nvec : 1, 4)), dim3(WG), 0, jh_ctx().stream, p, n,
+    hipLaunchKernelGGL((k_fill<S, NS, PER>), dim3(grid_full(nvec > 0 ? nvec : 1)), dim3(WG), 0, jh_ctx().stream, p, n,
                        head, (S)re, (S)im);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
@@ -90,7 +127,7 @@ __global__ void k_uniform(S *__restrict__ p, int64_t n, uint64_t key, int64_t la
         Pack<S, NS> o;
 #pragma unroll
         for (int c = 0; c < NS; c++) o.v[c] = u01_from<S>(mix64(key + (uint64_t)(lane_base + v * NS + c + 1) * GOLDEN));
-        pv[v] = o;
+        stnt(pv + v, o);
     }
     const int64_t tail0 = nvec * NS;
     if (tid < n - tail0) p[tail0 + tid] = u01_from<S>(mix64(key + (uint64_t)(lane_base + tail0 + tid + 1) * GOLDEN));
@@ -122,6 +159,27 @@ __global__ void k_abs(S *__restrict__ dst, const S *__restrict__ x, int64_t n_el
         if (E == 1) dst[k] = x[k] < 0 ? -x[k] : x[k];
         else dst[k] = (S)hypot((double)x[2 * k], (double)x[2 * k + 1]);
     }
+}
+
+// bitwise copy of a slab (y .= x), 16 B per lane, four packs in flight, nontemporal both ways
+__global__ void k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, int64_t nvec)
+{
+    typedef unsigned V __attribute__((ext_vector_type(4)));
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * WG;
+    int64_t v = tid;
+    for (; v + 3 * stride < nvec; v += 4 * stride) {
+        V t0 = __builtin_nontemporal_load(reinterpret_cast<const V *>(src) + v);
+        V t1 = __builtin_nontemporal_load(reinterpret_cast<const V *>(src) + v + stride);
+        V t2 = __builtin_nontemporal_load(reinterpret_cast<const V *>(src) + v + 2 * stride);
+        V t3 = __builtin_nontemporal_load(reinterpret_cast<const V *>(src) + v + 3 * stride);
+        __builtin_nontemporal_store(t0, reinterpret_cast<V *>(dst) + v);
+        __builtin_nontemporal_store(t1, reinterpret_cast<V *>(dst) + v + stride);
+        __builtin_nontemporal_store(t2, reinterpret_cast<V *>(dst) + v + 2 * stride);
+        __builtin_nontemporal_store(t3, reinterpret_cast<V *>(dst) + v + 3 * stride);
+    }
+    for (; v < nvec; v += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const V *>(src) + v), reinterpret_cast<V *>(dst) + v);
 }
 
 // ---------------------------------------------------------------- lincomb ---------------------
@@ -167,7 +225,7 @@ __global__ void k_lincomb(S *__restrict__ dst, int64_t n_scalars, LincombArgs a)
         Pack<S, NS> xin[MAX_TERMS];
 #pragma unroll
         for (int j = 0; j < MAX_TERMS; j++)
-            if (j < a.k) xin[j] = reinterpret_cast<const Pack<S, NS> *>(a.x[j])[v];
+            if (j < a.k) xin[j] = ldnt(reinterpret_cast<const Pack<S, NS> *>(a.x[j]) + v);
         Pack<S, NS> o;
 #pragma unroll
         for (int e = 0; e < NS; e += E) {
@@ -190,7 +248,7 @@ __global__ void k_lincomb(S *__restrict__ dst, int64_t n_scalars, LincombArgs a)
             o.v[e] = accr;
             if (E == 2) o.v[e + 1] = acci;
         }
-        reinterpret_cast<Pack<S, NS> *>(dst)[v] = o;
+        stnt(reinterpret_cast<Pack<S, NS> *>(dst) + v, o);
     }
     const int64_t tail0 = nvec * NS;
     const int64_t ntail_elems = (n_scalars - tail0) / E;
@@ -213,13 +271,23 @@ __global__ void k_hadamard(S *__restrict__ dst, const S *__restrict__ x, const S
             oe[1] = xr * yi + xi * yr;
         }
     };
-    for (int64_t v = tid; v < nvec; v += stride) {
-        Pack<S, NS> xv = reinterpret_cast<const Pack<S, NS> *>(x)[v];
-        Pack<S, NS> yv = reinterpret_cast<const Pack<S, NS> *>(y)[v];
+    int64_t v = tid;
+    for (; v + stride < nvec; v += 2 * stride) {                  // two packs per input in flight
+        Pack<S, NS> xv0 = ldnt(reinterpret_cast<const Pack<S, NS> *>(x) + v), yv0 = ldnt(reinterpret_cast<const Pack<S, NS> *>(y) + v);
+        Pack<S, NS> xv1 = ldnt(reinterpret_cast<const Pack<S, NS> *>(x) + v + stride), yv1 = ldnt(reinterpret_cast<const Pack<S, NS> *>(y) + v + stride);
+        Pack<S, NS> o0, o1;
+#pragma unroll
+        for (int e = 0; e < NS; e += E) { one(&xv0.v[e], &yv0.v[e], &o0.v[e]); one(&xv1.v[e], &yv1.v[e], &o1.v[e]); }
+        stnt(reinterpret_cast<Pack<S, NS> *>(dst) + v, o0);
+        stnt(reinterpret_cast<Pack<S, NS> *>(dst) + v + stride, o1);
+    }
+    for (; v < nvec; v += stride) {
+        Pack<S, NS> xv = ldnt(reinterpret_cast<const Pack<S, NS> *>(x) + v);
+        Pack<S, NS> yv = ldnt(reinterpret_cast<const Pack<S, NS> *>(y) + v);
         Pack<S, NS> o;
 #pragma unroll
         for (int e = 0; e < NS; e += E) one(&xv.v[e], &yv.v[e], &o.v[e]);
-        reinterpret_cast<Pack<S, NS> *>(dst)[v] = o;
+        stnt(reinterpret_cast<Pack<S, NS> *>(dst) + v, o);
     }
     const int64_t tail0 = nvec * NS;
     const int64_t ntail_elems = (n_scalars - tail0) / E;
@@ -264,7 +332,11 @@ __device__ inline void red_elem(const S *xe, const S *ye, double p, double &a0, 
         else if (OP == RED_COUNTNZ) a0 += (ab != 0.0) ? 1.0 : 0.0;
         else if (OP == RED_MAXABS) a0 = ab > a0 ? ab : a0;
         else if (OP == RED_MINABS) a0 = ab < a0 ? ab : a0;
-        else if (OP == RED_SUMPOW) a0 += pow(ab, p);
+        else if (OP == RED_SUMPOW) {
+            const int ip = (int)p;                     // small integer p: repeated multiplication instead of pow()
+            if ((double)ip == p && ip >= 1 && ip <= 8) { double t = ab; for (int q = 1; q < ip; q++) t *= ab; a0 += t; }
+            else a0 += pow(ab, p);
+        }
     }
 }
 
@@ -304,8 +376,8 @@ __global__ void k_reduce(const S *__restrict__ x, const S *__restrict__ y, int64
         Pack<S, NS> xv[UN], yv[UN];
 #pragma unroll
         for (int u = 0; u < UN; u++) {
-            xv[u] = reinterpret_cast<const Pack<S, NS> *>(x)[v + u * stride];
-            if (OP == RED_DOT) yv[u] = reinterpret_cast<const Pack<S, NS> *>(y)[v + u * stride];
+            xv[u] = ldnt(reinterpret_cast<const Pack<S, NS> *>(x) + v + u * stride);
+            if (OP == RED_DOT) yv[u] = ldnt(reinterpret_cast<const Pack<S, NS> *>(y) + v + u * stride);
         }
 #pragma unroll
         for (int u = 0; u < UN; u++)
@@ -396,10 +468,10 @@ int lincomb_launch(void *dst, int64_t n_elems, const LincombArgs &a)
     uintptr_t bits = (uintptr_t)dst;
     for (int j = 0; j < a.k; j++) bits |= (uintptr_t)a.x[j];
     if ((bits & 15u) == 0)
-        hipLaunchKernelGGL((k_lincomb<S, E, NSV>), dim3(grid_for(n_scalars / NSV + 1, 2)), dim3(WG), 0, jh_ctx().stream, (S *)dst,
+        hipLaunchKernelGGL((k_lincomb<S, E, NSV>), dim3(grid_full(n_scalars / NSV + 1)), dim3(WG), 0, jh_ctx().stream, (S *)dst,
                            n_scalars, a);
     else
-        hipLaunchKernelGGL((k_lincomb<S, E, E>), dim3(grid_for(n_elems + 1, 2)), dim3(WG), 0, jh_ctx().stream, (S *)dst, n_scalars, a);
+        hipLaunchKernelGGL((k_lincomb<S, E, E>), dim3(grid_full(n_elems + 1)), dim3(WG), 0, jh_ctx().stream, (S *)dst, n_scalars, a);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -412,10 +484,10 @@ int hadamard_launch(void *dst, const void *x, const void *y, int64_t n_elems, in
     constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
     uintptr_t bits = (uintptr_t)dst | (uintptr_t)x | (uintptr_t)y;
     if ((bits & 15u) == 0)
-        hipLaunchKernelGGL((k_hadamard<S, E, NSV>), dim3(grid_for(n_scalars / NSV + 1, 2)), dim3(WG), 0, jh_ctx().stream, (S *)dst,
+        hipLaunchKernelGGL((k_hadamard<S, E, NSV>), dim3(grid_full(n_scalars / NSV + 1)), dim3(WG), 0, jh_ctx().stream, (S *)dst,
                            (const S *)x, (const S *)y, n_scalars, conj_x);
     else
-        hipLaunchKernelGGL((k_hadamard<S, E, E>), dim3(grid_for(n_elems + 1, 2)), dim3(WG), 0, jh_ctx().stream, (S *)dst,
+        hipLaunchKernelGGL((k_hadamard<S, E, E>), dim3(grid_full(n_elems + 1)), dim3(WG), 0, jh_ctx().stream, (S *)dst,
                            (const S *)x, (const S *)y, n_scalars, conj_x);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
@@ -449,6 +521,24 @@ int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const doub
     return jh_fail(JH_ERR_INVALID, "lincomb: unknown dtype %d", dtype);
 }
 
+// device-to-device copy of `bytes` bytes: own streaming kernel when both ends are 16-byte aligned and large,
+// the runtime's copy otherwise
+int jh_launch_copy_bytes(void *dst, const void *src, size_t bytes)
+{
+    hipStream_t st = jh_ctx().stream;
+    if (bytes == 0 || dst == src) return JH_OK;
+    if (bytes >= ((size_t)1 << 20) && ((((uintptr_t)dst) | ((uintptr_t)src)) & 15u) == 0) {
+        const int64_t nvec = (int64_t)(bytes / 16);
+        hipLaunchKernelGGL(k_copy16, dim3(grid_full(nvec)), dim3(WG), 0, st, (uint4 *)dst, (const uint4 *)src, nvec);
+        JH_CHECK_HIP(hipGetLastError());
+        const size_t done = (size_t)nvec * 16;
+        if (done < bytes) JH_CHECK_HIP(hipMemcpyAsync((char *)dst + done, (const char *)src + done, bytes - done, hipMemcpyDeviceToDevice, st));
+        return JH_OK;
+    }
+    JH_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+    return JH_OK;
+}
+
 int jh_launch_fill_range(void *ptr, int dtype, int64_t count, double re, double im)
 {
     switch (dtype) {
@@ -474,9 +564,9 @@ int jh_fill_uniform(jh_bvec *v, uint64_t seed, uint64_t stream, int64_t index_ba
     const int64_t n = v->length * lanes, base = index_base * lanes;
     hipStream_t st = jh_ctx().stream;
     if (v->dtype == JH_F32 || v->dtype == JH_C32)
-        hipLaunchKernelGGL((k_uniform<float, 4>), dim3(grid_for(n / 4 + 1, 4)), dim3(WG), 0, st, (float *)v->data, n, key, base);
+        hipLaunchKernelGGL((k_uniform<float, 4>), dim3(grid_full(n / 4 + 1)), dim3(WG), 0, st, (float *)v->data, n, key, base);
     else
-        hipLaunchKernelGGL((k_uniform<double, 2>), dim3(grid_for(n / 2 + 1, 4)), dim3(WG), 0, st, (double *)v->data, n, key, base);
+        hipLaunchKernelGGL((k_uniform<double, 2>), dim3(grid_full(n / 2 + 1)), dim3(WG), 0, st, (double *)v->data, n, key, base);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -494,9 +584,9 @@ int jh_fill_normal(jh_bvec *v, uint64_t seed, uint64_t stream, int64_t index_bas
     const double scale = cplx ? 0.7071067811865476 : 1.0;
     hipStream_t st = jh_ctx().stream;
     if (v->dtype == JH_F32 || v->dtype == JH_C32)
-        hipLaunchKernelGGL((k_normal<float>), dim3(grid_for(n, 4)), dim3(WG), 0, st, (float *)v->data, n, key, base, (float)scale);
+        hipLaunchKernelGGL((k_normal<float>), dim3(grid_full(n)), dim3(WG), 0, st, (float *)v->data, n, key, base, (float)scale);
     else
-        hipLaunchKernelGGL((k_normal<double>), dim3(grid_for(n, 4)), dim3(WG), 0, st, (double *)v->data, n, key, base, scale);
+        hipLaunchKernelGGL((k_normal<double>), dim3(grid_full(n)), dim3(WG), 0, st, (double *)v->data, n, key, base, scale);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -510,7 +600,7 @@ int jh_abs(jh_bvec *dst, const jh_bvec *x)
     JH_REQUIRE(dst->dtype == want, "jh_abs: destination must be the real type of the source (dtype %d), got %d", want, dst->dtype);
     if (x->length == 0) return JH_OK;
     hipStream_t st = jh_ctx().stream;
-    const int g = grid_for(x->length, 4);
+    const int g = grid_full(x->length);
     switch (x->dtype) {
     case JH_F32: hipLaunchKernelGGL((k_abs<float, 1>), dim3(g), dim3(WG), 0, st, (float *)dst->data, (const float *)x->data, x->length); break;
     case JH_F64: hipLaunchKernelGGL((k_abs<double, 1>), dim3(g), dim3(WG), 0, st, (double *)dst->data, (const double *)x->data, x->length); break;
