@@ -710,8 +710,9 @@ int general_fwd(const jh_blockop *op, void *d, const void *m)
     JH_REQUIRE(op->nrow <= 65535, "general block forward supports at most 65535 block rows (got %lld)", (long long)op->nrow);
     if (general_vec_ok(op, d, m)) {
         constexpr int NS = 16 / sizeof(S);
-        int64_t gxv = (maxn * E / NS + 255) / 256;
-        if (gxv > 4096) gxv = 4096;
+        int64_t gxv = (maxn * E / NS + 255) / 256;                         // one pack per thread (see jh_vecops.hip: grid_full)
+        const int64_t cap = (((int64_t)1 << 24) / op->nrow) - 1;           // grid.x * grid.y * 256 threads < 2^32
+        if (gxv > cap) gxv = cap > 0 ? cap : 1;
         hipLaunchKernelGGL((k_block_fwd_general_vec<S, E, NS>), dim3((unsigned)gxv, (unsigned)op->nrow), dim3(256), 0, jh_ctx().stream,
                            op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d);
         JH_CHECK_HIP(hipGetLastError());
@@ -735,7 +736,8 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
     if (general_vec_ok(op, d, m)) {
         constexpr int NS = 16 / sizeof(S);
         int64_t gxv = (maxn * E / NS + 255) / 256;
-        if (gxv > 4096) gxv = 4096;
+        const int64_t cap = (((int64_t)1 << 24) / op->ncol) - 1;
+        if (gxv > cap) gxv = cap > 0 ? cap : 1;
         hipLaunchKernelGGL((k_block_adj_general_vec<S, E, NS>), dim3((unsigned)gxv, (unsigned)op->ncol), dim3(256), 0, jh_ctx().stream,
                            op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d);
         JH_CHECK_HIP(hipGetLastError());
