@@ -197,6 +197,35 @@ function normal_mul!(y::HipArray{T}, A::JopLn, m::HipArray{T}) where {T}
     y
 end
 
+# ---------------------------------------------------------------- solver halves and the multi-GPU exchange
+# u <- alpha*(A v) + beta*u, returns ||u||   /   v <- alpha*(A' (in_scale*u)) + beta*v, returns ||v||   (LSQR / CGLS)
+function mul_axpby!(u::HipBlockArray{T}, A::JopLn, v::HipArray{T}, alpha::Real, beta::Real) where {T}
+    nrm2 = Ref{Cdouble}()
+    check(ccall((:jh_blockop_mul_axpby, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Ref{Cdouble}),
+                native_handle(state(A).ops, T), u.handle, v.handle, alpha, beta, nrm2))
+    sqrt(nrm2[])
+end
+function mul_adj_axpby!(v::HipArray{T}, A::JopLn, u::HipBlockArray{T}, alpha::Real, beta::Real; in_scale::Real=1.0) where {T}
+    nrm2 = Ref{Cdouble}()
+    check(ccall((:jh_blockop_mul_adj_axpby, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Ref{Cdouble}),
+                native_handle(state(A).ops, T), v.handle, u.handle, alpha, beta, in_scale, nrm2))
+    sqrt(nrm2[])
+end
+
+# one process per GPU: rank 0 makes the id, the host (MPI.jl, sockets, a file) ships it, every rank joins
+comm_unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:jh_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id)); id)
+comm_init(id::Vector{UInt8}, nranks::Integer, rank::Integer) = check(ccall((:jh_comm_init_rank, LIB), Cint, (Ptr{UInt8}, Cint, Cint), id, nranks, rank))
+allreduce_sum!(x::Union{HipArray,HipBlockArray}) = (check(ccall((:jh_comm_allreduce_sum, LIB), Cint, (Ptr{Cvoid},), x.handle)); x)
+function allreduce_scalars!(vals::Vector{Float64}, op::Symbol=:sum)
+    check(ccall((:jh_comm_allreduce_scalars, LIB), Cint, (Ptr{Cdouble}, Cint, Cint), vals, length(vals), op === :sum ? 0 : (op === :max ? 1 : 2)))
+    vals
+end
+# adjoint of a row-partitioned tall operator: local ordered sum, then the in-place all-reduce (src/Jets.jl:1045-1053 summed over ranks)
+function mul_adj_partitioned!(m::HipArray{T}, A::JopLn, d_local::HipBlockArray{T}) where {T}
+    check(ccall((:jh_blockop_mul_adj, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), native_handle(state(A).ops, T), m.handle, d_local.handle))
+    allreduce_sum!(m)
+end
+
 # close(A) releases the device operator (src/Jets.jl:1120-1124 cascade)
 function release!(ops)
     h = pop!(_handles, ops, C_NULL)
