@@ -51,6 +51,7 @@ struct jh_context {
     int64_t fwd_order = -1;            // -1: automatic; 0: sequential row sweep; 1: all row groups concurrent; k>1: bands of k row groups
     int64_t nt = 1;                    // nontemporal loads/stores on the streamed operands
     int64_t autotune = 1;              // time both grid walks of the tall forward once per large operator
+    int64_t red_wgs = 16384;           // workgroups of a reduction launch (4 packs per lane in flight); profiles/sweep_r01_reduce.txt
     int64_t last_fwd_walk = 0;         // grid walk used by the most recent tall forward launch (read-only knob)
 };
 jh_context &jh_ctx();

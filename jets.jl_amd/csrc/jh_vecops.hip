@@ -426,14 +426,20 @@ int reduce_launch(const void *x, const void *y, int64_t n_elems, double p, doubl
     const int64_t n_scalars = n_elems * E;
     constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
     const bool aligned = (((uintptr_t)x | (uintptr_t)(y ? y : x)) & 15u) == 0;
-    double *partials = c.red_dev + 8;   // [0..7] hold final results
     int grid;
+    const int64_t cap = c.red_wgs > 0 ? c.red_wgs : 16384;
+    auto clamp_grid = [&](int64_t packs) {
+        int64_t g = (packs + (int64_t)WG * 4 - 1) / ((int64_t)WG * 4);
+        return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+    };
+    JH_TRY(jh_ensure_partials(2 * cap));
+    double *partials = c.part_dev;      // one (a0, a1) pair per workgroup
     if (aligned) {
-        grid = grid_for(n_scalars / NSV + 1, 4);
+        grid = clamp_grid(n_scalars / NSV + 1);
         hipLaunchKernelGGL((k_reduce<S, E, NSV, OP>), dim3(grid), dim3(WG), 0, c.stream, (const S *)x, (const S *)y,
                            n_scalars, p, partials);
     } else {
-        grid = grid_for(n_elems + 1, 4);
+        grid = clamp_grid(n_elems + 1);
         hipLaunchKernelGGL((k_reduce<S, E, E, OP>), dim3(grid), dim3(WG), 0, c.stream, (const S *)x, (const S *)y, n_scalars,
                            p, partials);
     }
