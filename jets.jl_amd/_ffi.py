@@ -94,6 +94,8 @@ SYMBOLS = {
     "jh_blockop_mul_adj": (_int, [_vp, _vp, _vp]),
     "jh_blockop_mul_adj_range": (_int, [_vp, _vp, _vp, _i64, _i64]),
     "jh_blockop_normal_mul": (_int, [_vp, _vp, _vp]),
+    "jh_blocksum_mul": (_int, [_int, _vpp, _dblp, _dblp, _vp, _vp]),
+    "jh_blocksum_mul_adj": (_int, [_int, _vpp, _dblp, _dblp, _vp, _vp]),
     "jh_blockop_mul_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
     "jh_blockop_mul_adj_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _dblp]),
     "jh_comm_unique_id": (_int, [_vp]),

@@ -321,6 +321,121 @@ __global__ void k_sum_partials(const double *__restrict__ partials, int64_t n, i
     wg_sum_store<256>(v, out + blockIdx.x);
 }
 
+// ------------------------------------------------------------------ fused JetSum of tall operators ---------
+// d_i = sum_k sign_k * (scale_k * (a_{k,i} .* m))      (JetSum_df!, src/Jets.jl:639-646, of terms A_k or s_k*A_k)
+// m   = sum_k sign_k * (sum_i conj(a_{k,i}) .* (scale_k * d_i))                 (JetSum_df'!, 648-655)
+// for up to JH_SUM_MAX tall all-DIAG operators of identical shape, in ONE pass over the range vector: every
+// coefficient slab is read once, d is written (forward) or read (adjoint) once -- the unfused chain moves 5 range-sized
+// streams per term.  Rounding sequence == the unfused chain: product, scale (exact when 1), signed add, terms in order;
+// in the adjoint each term's rows are summed in order into its own accumulator before the terms are combined.
+constexpr int JH_SUM_MAX = 4;
+struct SumArgs {
+    const jh_dev_block *blocks[JH_SUM_MAX];
+    const void *a_base[JH_SUM_MAX];
+    int64_t a_stride[JH_SUM_MAX];
+    double scale[JH_SUM_MAX], sign[JH_SUM_MAX];
+    int k;
+};
+
+template <typename S, int E, int NS, int U, int BLK>
+__global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow, int rows_per_wg, const S *__restrict__ m,
+                                                      S *__restrict__ d, int64_t n_scalars, unsigned ntiles)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const unsigned tile = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
+    const int64_t s0 = ((int64_t)tile * U * BLK + threadIdx.x) * NS;
+    const int64_t i0 = (int64_t)grp * rows_per_wg;
+    const int64_t i1 = (i0 + rows_per_wg < nrow) ? i0 + rows_per_wg : nrow;
+    bool ok[U];
+    int64_t sk[U];
+    V mv[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
+        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
+        mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
+    }
+    for (int64_t i = i0; i < i1; i++) {
+        V av[JH_SUM_MAX][U];
+#pragma unroll
+        for (int t = 0; t < JH_SUM_MAX; t++)
+            if (t < args.k) {
+                const S *a = args.a_base[t] ? (const S *)args.a_base[t] + i * args.a_stride[t] : (const S *)args.blocks[t][i].coeff;
+#pragma unroll
+                for (int k = 0; k < U; k++) av[t][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+            }
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            V acc = (V)(S)0;                                                     // d .= 0  (639-640)
+#pragma unroll
+            for (int t = 0; t < JH_SUM_MAX; t++)
+                if (t < args.k) {
+                    V prod = vmul<S, E, NS, V>(av[t][k], mv[k], false);          // mul!(_d, A_t, m)
+                    V term = (V)(S)(args.sign[t] * args.scale[t]) * prod;        // (s_t * .) then the sign: -(s*x) == (-s)*x exactly
+                    acc = acc + term;                                            // broadcast!(sgn, d, d, _d)
+                }
+            if (ok[k]) st<true>(reinterpret_cast<V *>(d + i * n_scalars + sk[k]), acc);
+        }
+    }
+}
+
+template <typename S, int E, int NS, int U, int DEPTH, int BLK>
+__global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow, S *__restrict__ out, const S *__restrict__ in,
+                                                      int64_t n_scalars)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t s0 = ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
+    bool ok[U];
+    int64_t sk[U];
+    V acc[JH_SUM_MAX][U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
+        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
+#pragma unroll
+        for (int t = 0; t < JH_SUM_MAX; t++) acc[t][k] = (V)(S)0;
+    }
+    const bool direct = (nrow == 1);                                            // mul!(_m, op', _d) writes directly (1051)
+    for (int64_t i = 0; i < nrow; i += DEPTH) {
+        V dv[DEPTH][U], av[DEPTH][JH_SUM_MAX][U];
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+            if (i + j < nrow) {
+#pragma unroll
+                for (int k = 0; k < U; k++) dv[j][k] = ld<true>(reinterpret_cast<const V *>(in + (i + j) * n_scalars + sk[k]));
+#pragma unroll
+                for (int t = 0; t < JH_SUM_MAX; t++)
+                    if (t < args.k) {
+                        const S *a = args.a_base[t] ? (const S *)args.a_base[t] + (i + j) * args.a_stride[t]
+                                                    : (const S *)args.blocks[t][i + j].coeff;
+#pragma unroll
+                        for (int k = 0; k < U; k++) av[j][t][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+                    }
+            }
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+            if (i + j < nrow) {
+#pragma unroll
+                for (int t = 0; t < JH_SUM_MAX; t++)
+                    if (t < args.k) {
+#pragma unroll
+                        for (int k = 0; k < U; k++) {
+                            V p = vmul<S, E, NS, V>(av[j][t][k], (V)(S)args.scale[t] * dv[j][k], true);   // conj(a_i) .* (s_t * d_i)
+                            acc[t][k] = direct ? p : acc[t][k] + p;
+                        }
+                    }
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        V r = (V)(S)0;                                                           // m .= 0  (648-649)
+#pragma unroll
+        for (int t = 0; t < JH_SUM_MAX; t++)
+            if (t < args.k) r = r + (V)(S)args.sign[t] * acc[t][k];              // broadcast!(sgn, m, m, _m)
+        if (ok[k]) st<false>(reinterpret_cast<V *>(out + sk[k]), r);
+    }
+}
+
 // ------------------------------------------------------------------ general path --------------
 template <typename S, int E> struct elem {
     S re, im;
@@ -1150,6 +1265,96 @@ int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m)
     case JH_C64: return launch_tall_adj<double, 2, 2, 1>(op, y->data, m->data, 2 * n);
     }
     return jh_fail(JH_ERR_INVALID, "jh_blockop_normal_mul: unknown dtype %d", op->dtype);
+}
+
+}  // extern "C" (templated launch helpers of the fused sum follow)
+
+static int sum_prepare(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, const jh_bvec *rng,
+                       const jh_bvec *dom, SumArgs &a, const char *who)
+{
+    JH_REQUIRE(ops && scale && sign && rng && dom, "%s: null argument", who);
+    JH_REQUIRE(nterms >= 1 && nterms <= JH_SUM_MAX, "%s: %d terms (1..%d supported)", who, nterms, JH_SUM_MAX);
+    a.k = nterms;
+    for (int t = 0; t < nterms; t++) {
+        const jh_blockop *op = ops[t];
+        JH_REQUIRE(op, "%s: null operator %d", who, t);
+        JH_TRY(check_vectors(op, rng, dom, who));
+        if (!tall_fast_ok(op, rng->data, dom->data))
+            return jh_fail(JH_ERR_UNSUPPORTED, "%s: term %d is not a tall all-DIAG operator with equal, 16-byte aligned blocks", who, t);
+        JH_REQUIRE(op->nrow == ops[0]->nrow && op->row_len[0] == ops[0]->row_len[0] && op->dtype == ops[0]->dtype,
+                   "%s: term %d has a different shape or element type", who, t);
+        JH_REQUIRE(sign[t] == 1.0 || sign[t] == -1.0, "%s: sign %d must be +1 or -1", who, t);
+        a.blocks[t] = op->dev_blocks;
+        a.a_base[t] = op->diag_strided ? op->blocks[0].coeff : nullptr;
+        a.a_stride[t] = op->diag_stride_elems * (jh_dtype_complex(op->dtype) ? 2 : 1);
+        a.scale[t] = scale[t];
+        a.sign[t] = sign[t];
+    }
+    for (int t = nterms; t < JH_SUM_MAX; t++) { a.blocks[t] = nullptr; a.a_base[t] = nullptr; a.a_stride[t] = 0; a.scale[t] = 0; a.sign[t] = 0; }
+    return JH_OK;
+}
+
+template <typename S, int E, int NS>
+static int sum_fwd_launch(const SumArgs &a, const jh_blockop *op0, void *d, const void *m, int64_t n_scalars)
+{
+    jh_context &c = jh_ctx();
+    constexpr int BLK = 256, U = 2;
+    int G = 4;
+    if (G > op0->nrow) G = (int)op0->nrow;
+    const int64_t nvec = n_scalars / NS;
+    const int64_t gx = (nvec + (int64_t)BLK * U - 1) / ((int64_t)BLK * U);
+    int64_t gy = (op0->nrow + G - 1) / G;
+    while (gx * gy * BLK >= ((int64_t)1 << 32) && G < op0->nrow) { G *= 2; gy = (op0->nrow + G - 1) / G; }
+    JH_REQUIRE(gx * gy * BLK < ((int64_t)1 << 32), "fused sum forward: grid too large");
+    hipLaunchKernelGGL((k_tall_sum_fwd<S, E, NS, U, BLK>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G,
+                       (const S *)m, (S *)d, n_scalars, (unsigned)gx);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+template <typename S, int E, int NS>
+static int sum_adj_launch(const SumArgs &a, const jh_blockop *op0, void *m, const void *d, int64_t n_scalars)
+{
+    jh_context &c = jh_ctx();
+    constexpr int BLK = 256, U = 2, DEPTH = 2;
+    const int64_t nvec = n_scalars / NS;
+    const int64_t gx = (nvec + (int64_t)BLK * U - 1) / ((int64_t)BLK * U);
+    hipLaunchKernelGGL((k_tall_sum_adj<S, E, NS, U, DEPTH, BLK>), dim3((unsigned)gx), dim3(BLK), 0, c.stream, a, op0->nrow, (S *)m,
+                       (const S *)d, n_scalars);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+extern "C" {
+
+int jh_blocksum_mul(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, jh_bvec *d, const jh_bvec *m)
+{
+    JH_TRY(jh_require_ready());
+    SumArgs a;
+    JH_TRY(sum_prepare(nterms, ops, scale, sign, d, m, a, "jh_blocksum_mul"));
+    const int64_t n = ops[0]->row_len[0];
+    switch (ops[0]->dtype) {
+    case JH_F32: return sum_fwd_launch<float, 1, 4>(a, ops[0], d->data, m->data, n);
+    case JH_F64: return sum_fwd_launch<double, 1, 2>(a, ops[0], d->data, m->data, n);
+    case JH_C32: return sum_fwd_launch<float, 2, 4>(a, ops[0], d->data, m->data, 2 * n);
+    case JH_C64: return sum_fwd_launch<double, 2, 2>(a, ops[0], d->data, m->data, 2 * n);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blocksum_mul: unknown dtype");
+}
+
+int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, jh_bvec *m, const jh_bvec *d)
+{
+    JH_TRY(jh_require_ready());
+    SumArgs a;
+    JH_TRY(sum_prepare(nterms, ops, scale, sign, d, m, a, "jh_blocksum_mul_adj"));
+    const int64_t n = ops[0]->row_len[0];
+    switch (ops[0]->dtype) {
+    case JH_F32: return sum_adj_launch<float, 1, 4>(a, ops[0], m->data, d->data, n);
+    case JH_F64: return sum_adj_launch<double, 1, 2>(a, ops[0], m->data, d->data, n);
+    case JH_C32: return sum_adj_launch<float, 2, 4>(a, ops[0], m->data, d->data, 2 * n);
+    case JH_C64: return sum_adj_launch<double, 2, 2>(a, ops[0], m->data, d->data, 2 * n);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blocksum_mul_adj: unknown dtype");
 }
 
 int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double alpha, double beta, double *normsq)

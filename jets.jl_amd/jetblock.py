@@ -404,6 +404,42 @@ def try_fused_chain(out, x, ops: Sequence[Jop]):
     return None
 
 
+def try_fused_sum(out, x, ops: Sequence[Jop], sgns: Sequence[str], transposed: bool):
+    """JetSum_df / JetSum_df' (src/Jets.jl:639-655) when every term is a tall all-diagonal device-native block operator
+    A_k or a real scalar times one (the composite (a, A_k)): one fused launch (jh_blocksum_mul / jh_blocksum_mul_adj).
+    Returns None when the sum does not qualify."""
+    if not (1 <= len(ops) <= 4):
+        return None
+    nats, scales = [], []
+    for op in ops:
+        op = JopLn(op)
+        if isinstance(op, JopAdjoint):
+            return None
+        scale = 1.0
+        if op.jet.f is _j.JetComposite_f:
+            inner = op.jet.s["ops"]
+            if len(inner) != 2 or _real_scale(inner[0]) is None or isinstance(inner[0], JopAdjoint):
+                return None
+            scale, op = _real_scale(inner[0]), inner[1]
+        nat = _tall_native(op) if not isinstance(op, JopAdjoint) else None
+        if nat is None:
+            return None
+        nats.append(nat)
+        scales.append(scale)
+    k = len(nats)
+    hs = (C.c_void_p * k)(*[n.handle for n in nats])
+    sc = (C.c_double * k)(*scales)
+    sg = (C.c_double * k)(*[1.0 if s == _j.PLUS else -1.0 for s in sgns])
+    fn = lib.jh_blocksum_mul_adj if transposed else lib.jh_blocksum_mul
+    try:
+        check(fn(k, hs, sc, sg, out.handle, x.handle))
+    except _arr_check_error() as e:
+        if e.status == 4:
+            return None
+        raise
+    return out
+
+
 def _arr_check_error():
     from ._ffi import JetsHipError
 

@@ -463,6 +463,10 @@ def JetSum_f(d, m, *, ops, sgns, _ws=None, **kw):  # :630-637
 
 
 def JetSum_df(d, m, *, ops, sgns, _ws=None, **kw):  # :639-646
+    from . import jetblock as _blk
+
+    if _blk.try_fused_sum(d, m, ops, sgns, False) is not None:
+        return d
     fill_(d, 0)
     _d = (_ws or _Workspace()).zeros("rng", range_(ops[0]))
     for op, sg in zip(ops, sgns):
@@ -471,6 +475,10 @@ def JetSum_df(d, m, *, ops, sgns, _ws=None, **kw):  # :639-646
 
 
 def JetSum_df_adj(m, d, *, ops, sgns, _ws=None, **kw):  # :648-655
+    from . import jetblock as _blk
+
+    if _blk.try_fused_sum(m, d, ops, sgns, True) is not None:
+        return m
     fill_(m, 0)
     _m = (_ws or _Workspace()).zeros("dom", domain(ops[0]))
     for op, sg in zip(ops, sgns):

@@ -327,3 +327,21 @@ def test_scalar_times_tall_block_operator_fused_bit_exact(Jets, oracle, dt):
     acc = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [1.0, 1.0], [[np.zeros(n, dtype=dt)] * nrow, t1])
     acc = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [1.0, -1.0], [acc, t2])
     assert_bits_equal(got, np.concatenate(acc), "1.5*A - 2.0*A2")
+    # adjoint of the sum: S' d = A'(1.5 d) - A2'(2.0 d), each term's rows summed in order, then the terms combined
+    got_adj = (S.H * dd).to_numpy().ravel(order="F")
+    sc1 = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [1.5], [hd_blocks])
+    sc2 = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [2.0], [hd_blocks])
+    m1 = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], sc1)
+    m2 = oracle.block_df_adj(ops2, [np.zeros(n, dtype=dt)], sc2)
+    macc = oracle.barr_lincomb([np.empty(n, dtype=dt)], [1.0, 1.0], [[np.zeros(n, dtype=dt)], m1])
+    macc = oracle.barr_lincomb([np.empty(n, dtype=dt)], [1.0, -1.0], [macc, m2])
+    assert_bits_equal(got_adj, macc[0], "(1.5*A - 2.0*A2)' d")
+    # three terms, bare and scaled mixed:  A + 0.25*A2 - A
+    S3 = A + 0.25 * A2 - A
+    t3 = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [0.25], [tmp2])
+    a3 = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [1.0, 1.0], [[np.zeros(n, dtype=dt)] * nrow, tmp])
+    a3 = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [1.0, 1.0], [a3, t3])
+    a3 = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [1.0, -1.0], [a3, tmp])
+    assert_bits_equal((S3 * m).to_numpy(), np.concatenate(a3), "A + 0.25*A2 - A")
+    lhs, rhs = Jets.dot_product_test(S, m, dd)
+    assert abs(lhs - rhs) / abs(lhs + rhs) < 10 * _dpt_tol(dt)
