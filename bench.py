@@ -12,6 +12,9 @@ HBM before the timed region.  One step = one forward mul!(d, A, m) + one adjoint
 With N GPUs the SAME operator is row-partitioned (1024/N block rows per rank, "strong" scaling);
 the adjoint ends with one RCCL all-reduce of the 64 MiB domain vector.
 
+Extras (not the metric): --fused-normal (the fused A'A kernel), --lsqr K (K LSQR iterations on b = A x_true).
+BENCH_FORCE_DIST=1 under torch.distributed.run with one process exercises the RCCL path on a one-GPU box.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
 HIP-event timed on the library stream) and `cpu_baseline` (the CPU oracle, single thread, on a
 bounded sample; rank 0, N=1 only).

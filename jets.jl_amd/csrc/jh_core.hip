@@ -112,6 +112,7 @@ int jh_shutdown(void)
     if (!c.ready) return JH_OK;
     (void)hipSetDevice(c.device);
     (void)hipStreamSynchronize(c.stream);
+    (void)jh_comm_destroy();
     if (c.red_dev) (void)hipFree(c.red_dev);
     if (c.part_dev) (void)hipFree(c.part_dev);
     if (c.scratch_dev) (void)hipFree(c.scratch_dev);

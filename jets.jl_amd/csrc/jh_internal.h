@@ -125,4 +125,5 @@ int jh_launch_hadamard_raw(void *dst, const void *x, const void *y, int dtype, i
 int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const double *cre, const double *cim, const void *const *x);
 // dense child operator (jh_dense.hip): y = A x (rows) or y = A^H x / A^T x (cols); A column-major nr x nc
 int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, const void *x, int adjoint);
-int jh_ensure_scratch(size_t bytes, void **out);   // growable device scratch (block-loop temporaries)
+int jh_ensure_scratch(size_t bytes, void **out);
+extern "C" int jh_comm_destroy(void);   // jh_comm.hip; jh_shutdown tears the communicator down first   // growable device scratch (block-loop temporaries)

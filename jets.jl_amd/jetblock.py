@@ -14,7 +14,7 @@ from typing import Sequence
 
 import numpy as np
 
-from ._ffi import lib, check, BlockDesc, KINDS
+from ._ffi import lib, check, BlockDesc, KINDS, JetsHipError
 from . import arrays as _arr
 from .arrays import DeviceArray, BlockArray, zeros, lincomb_, hadamard_, copyto_, fill_, getblock, _i64arr
 from .spaces import JetAbstractSpace, JetSpace, JetBSpace, dtype_code
@@ -397,7 +397,7 @@ def try_fused_chain(out, x, ops: Sequence[Jop]):
             if nat is not None:
                 check(lib.jh_blockop_mul_adj_axpby(nat.handle, out.handle, x.handle, 1.0, 0.0, a, None))
                 return out
-    except _arr_check_error() as e:  # not eligible for the fused kernel (mixed kinds, ragged blocks)
+    except JetsHipError as e:  # JH_ERR_UNSUPPORTED: not eligible for the fused kernel (mixed kinds, ragged blocks)
         if e.status == 4:
             return None
         raise
@@ -433,14 +433,8 @@ def try_fused_sum(out, x, ops: Sequence[Jop], sgns: Sequence[str], transposed: b
     fn = lib.jh_blocksum_mul_adj if transposed else lib.jh_blocksum_mul
     try:
         check(fn(k, hs, sc, sg, out.handle, x.handle))
-    except _arr_check_error() as e:
+    except JetsHipError as e:
         if e.status == 4:
             return None
         raise
     return out
-
-
-def _arr_check_error():
-    from ._ffi import JetsHipError
-
-    return JetsHipError
