@@ -726,21 +726,21 @@ int launch_tall_fwd_shape(const jh_blockop *op, void *d, const void *m, int64_t 
 
 // For operators far larger than the caches the row-concurrent walk is 5-7 % faster than the sequential sweep in
 // some processes and 10-15 % slower in others (profiles/repeat_r01.txt: same binary, same box; it depends on where
-// the slabs landed physically), so the first forward of such an operator times both once (4 extra launches of an
-// idempotent kernel, ~0.1 s, synchronous) and keeps the winner.  Skipped while the stream is being captured.
+// the slabs landed physically), so the first forward of such an operator times both once (6 extra launches of an
+// idempotent kernel, ~0.15 s, synchronous) and keeps the winner.  Skipped while the stream is being captured.
 template <typename S, int E, int NS>
 int autotune_fwd_walk(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
 {
     jh_context &c = jh_ctx();
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(c.stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return JH_OK;   // stay untried
-    const TallShape cand[2] = {TallShape{1024, 8, 16, 0}, TallShape{512, 1, 2, 1}};
+    const TallShape cand[3] = {TallShape{1024, 8, 16, 0}, TallShape{512, 1, 2, 1}, TallShape{256, 4, 4, 0}};
     float best = 0.f;
     int pick = 0;
     hipEvent_t e0, e1;
     JH_CHECK_HIP(hipEventCreate(&e0));
     JH_CHECK_HIP(hipEventCreate(&e1));
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 3; k++) {
         int st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, cand[k]);          // warm
         if (st == JH_OK) st = (hipEventRecord(e0, c.stream) == hipSuccess) ? JH_OK : JH_ERR_HIP;
         if (st == JH_OK) st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, cand[k]);
@@ -768,6 +768,7 @@ int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scal
         if (op->fwd_walk < 0) JH_TRY((autotune_fwd_walk<S, E, NS>(op, d, m, n_scalars)));
         if (op->fwd_walk == 1) sh = TallShape{512, 1, 2, 1};
         else if (op->fwd_walk == 0) sh = TallShape{1024, 8, 16, 0};
+        else if (op->fwd_walk == 2) sh = TallShape{256, 4, 4, 0};
     }
     return launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, sh);
 }

@@ -110,7 +110,7 @@ struct jh_blockop {
     bool all_diag = false;                   // every block is an un-adjointed... DIAG (adjoint flag irrelevant up to conj)
     bool elementwise = false;                // no DENSE block
     bool diag_strided = false;               // coeff[i] = coeff[0] + i*stride bytes
-    mutable int fwd_walk = -1;               // autotuned grid walk of the tall forward: -1 untried, 0 sequential, 1 all rows
+    mutable int fwd_walk = -1;               // autotuned tall-forward shape: -1 untried, 0 sequential 1024x8x16, 1 all rows 512x1x2, 2 sequential 256x4x4
     mutable int upd_walk = -1;               // same for the fused forward update (timed on its first two real calls)
     mutable int upd_trials = 0;
     mutable float upd_ms[2] = {0.f, 0.f};
