@@ -322,3 +322,28 @@ def test_dense_forward_is_bit_exact_and_adjoint_within_tolerance(Jets, oracle):
         adj = (A.H * Jets.from_numpy(hy)).to_numpy()
         ref = hA.astype(np.complex128).conj().T @ hy.astype(np.complex128)
         assert np.linalg.norm(adj - ref) <= tol * np.linalg.norm(hA.astype(np.complex128)) * np.linalg.norm(hy.astype(np.complex128))
+
+
+@pytest.mark.parametrize("dt,tol", [(np.float32, 2e-6), (np.float64, 1e-14), (np.complex64, 2e-6)])
+@pytest.mark.parametrize("nr,nc", [(4096, 4096), (64, 70000), (300000, 24), (1000, 1003), (5, 3)])
+def test_dense_operator_shapes(Jets, dt, tol, nr, nc):
+    """jh_gemv over the shapes that exercise each code path: square, few rows (column split), few columns (row split),
+    odd sizes (unaligned columns -> scalar path), tiny."""
+    rng = np.random.default_rng(nr * 7 + nc)
+    hA = (rng.random((nr, nc)) - 0.5).astype(dt)
+    if np.dtype(dt).kind == "c":
+        hA = (hA + 1j * (rng.random((nr, nc)) - 0.5)).astype(dt)
+    hx = (rng.random(nc) - 0.5).astype(dt)
+    hy = (rng.random(nr) - 0.5).astype(dt)
+    A = Jets.JopDense(Jets.from_numpy(np.asfortranarray(hA)))
+    A64 = hA.astype(np.complex128)
+    fwd = (A * Jets.from_numpy(hx)).to_numpy().astype(np.complex128)
+    ref = A64 @ hx.astype(np.complex128)
+    scale = np.linalg.norm(np.abs(A64) @ np.abs(hx.astype(np.complex128)))
+    assert np.linalg.norm(fwd - ref) <= tol * max(nc, 64) ** 0.5 * scale
+    adj = (A.H * Jets.from_numpy(hy)).to_numpy().astype(np.complex128)
+    refa = A64.conj().T @ hy.astype(np.complex128)
+    scalea = np.linalg.norm(np.abs(A64).T @ np.abs(hy.astype(np.complex128)))
+    assert np.linalg.norm(adj - refa) <= tol * scalea
+    lhs, rhs = Jets.dot_product_test(A, Jets.from_numpy(hx), Jets.from_numpy(hy))
+    assert abs(lhs - rhs) <= 50 * tol * max(abs(lhs), scalea * np.linalg.norm(hx) / max(nc, 1) ** 0.5)

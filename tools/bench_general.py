@@ -53,3 +53,20 @@ case("wide 1x64 diag", [["d"] * 64], n)
 case("4x4 identity (config 1 big)", [["i"] * 4 for _ in range(4)], 256 ** 3)
 case("8x8 diag", [["d"] * 8 for _ in range(8)], n)
 case("3x4 mixed with zeros", [["d", "i", "d", "s"], ["d", "z", "d", "d"], ["s", "d", "d", "z"]], 256 ** 3)
+
+
+def dense_case(nr, nc, dt=np.float32):
+    Am = J.rand(J.JetSpace(dt, nr, nc), seed=11, stream=0)
+    A = J.JopDense(Am)
+    x, y = J.rand(J.JetSpace(dt, nc), seed=12, stream=0), J.rand(J.JetSpace(dt, nr), seed=13, stream=0)
+    out_r, out_c = J.zeros(J.JetSpace(dt, nr)), J.zeros(J.JetSpace(dt, nc))
+    b = nr * nc * np.dtype(dt).itemsize
+    tf = timeit(lambda: J.mul_(out_r, A, x))
+    ta = timeit(lambda: J.mul_(out_c, A.H, y))
+    print(f"dense {nr:>8d} x {nc:<8d}          fwd {tf:8.3f} ms {b / tf / 1e6:8.1f} GB/s | adj {ta:8.3f} ms {b / ta / 1e6:8.1f} GB/s")
+
+
+dense_case(32768, 32768)
+dense_case(4096, 262144)
+dense_case(4194304, 256)
+dense_case(1024, 1024)
