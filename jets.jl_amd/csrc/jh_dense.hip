@@ -132,7 +132,7 @@ int gemv(const void *A, int64_t nr, int64_t nc, void *y, const void *x, int adjo
         const int NS = vec_ok ? NSV : E;
         const int64_t row_wgs = (ns / NS + 255) / 256;
         int64_t nchunks = 1;
-        if (bytes >= (double)(1 << 24) && row_wgs < 2048) {                    // big matrix, few rows: split the columns
+        if (bytes >= (double)(1 << 20) && row_wgs < 2048) {                    // few rows: split the columns (tiny matrices stay one ordered sum)
             nchunks = (2048 + row_wgs - 1) / row_wgs;
             const int64_t maxc = (nc + 31) / 32;
             if (nchunks > maxc) nchunks = maxc;
@@ -161,7 +161,7 @@ int gemv(const void *A, int64_t nr, int64_t nc, void *y, const void *x, int adjo
     if (nc == 0) return JH_OK;
     int64_t nchunks = 1;
     const int64_t col_wgs = (nc + 3) / 4;
-    if (bytes >= (double)(1 << 24) && col_wgs < 2048) {                        // few columns: split the rows
+    if (bytes >= (double)(1 << 20) && col_wgs < 2048) {                        // few columns: split the rows
         nchunks = (2048 + col_wgs - 1) / col_wgs;
         const int64_t maxc = (nr + 4095) / 4096;
         if (nchunks > maxc) nchunks = maxc;
