@@ -57,13 +57,18 @@ typedef enum {
     JH_OP_IDENTITY = 1,  /* d .= m                                                                     */
     JH_OP_SCALE = 2,     /* d .= a*m ; adjoint m .= conj(a)*d, src/Jets.jl:1159-1160                   */
     JH_OP_DIAG = 3,      /* d .= diagonal .* m ; adjoint conj.(diagonal) .* d, test/runtests.jl:3-4    */
-    JH_OP_DENSE = 4      /* d .= A*m ; adjoint A'*d (column-major A), test/runtests.jl:27-28           */
+    JH_OP_DENSE = 4,     /* d .= A*m ; adjoint A'*d (column-major A), test/runtests.jl:27-28           */
+    JH_OP_SQUARE = 5     /* NONLINEAR child (JopNl): f! d .= m.^2 ; Jacobian at mo dd .= 2 .* mo .* dm,
+                          * test/runtests.jl:19-24 (JopBar); adjoint of the Jacobian conj.(2 .* mo) .* dd
+                          * (== df! for real eltypes, the fixture's default src/Jets.jl:184-186).
+                          * coeff is the block of mo the child is linearised about: set by jh_blockop_point. */
 } jh_opkind;
 
 typedef struct {
     int32_t kind;        /* jh_opkind                                                        */
     int32_t adjoint;     /* 1: this block is the JopAdjoint of the described operator        */
-    const void *coeff;   /* DEVICE pointer. DIAG: nr elements. DENSE: column-major nr x nc.  */
+    const void *coeff;   /* DEVICE pointer. DIAG: nr elements. DENSE: column-major nr x nc.  *
+                          * SQUARE: ignored at create (see jh_blockop_point)                 */
     double scale_re;     /* SCALE: a                                                         */
     double scale_im;
     int64_t nr, nc;      /* range / domain length of the described (un-adjointed) operator   */
@@ -128,7 +133,8 @@ int jh_abs(jh_bvec *dst_real, const jh_bvec *x);
 /* BlockArray broadcast, src/Jets.jl:889-911.  dst = c0*x0 .+ c1*x1 .+ ... evaluated left to right in
  * eltype T (each product and each sum rounded, no FMA); coef is k (re,im) pairs; dst may alias any x. */
 int jh_lincomb(jh_bvec *dst, int k, const double *coef_re_im, const jh_bvec *const *x);
-/* dst = x .* y (conj_x: conj.(x) .* y) -- the masks of dot_product_test, src/Jets.jl:1215-1219 */
+/* dst = x .* y -- the masks of dot_product_test, src/Jets.jl:1215-1219.  conj_x is a flag word: bit 0 conj.(x) .* y;
+ * bit 1 (2 .* x) .* y, the Jacobian of d .= m.^2 about x (test/runtests.jl:20); 3 = conj.(2 .* x) .* y. */
 int jh_hadamard(jh_bvec *dst, const jh_bvec *x, const jh_bvec *y, int conj_x);
 /* dot(x,y), src/Jets.jl:850-856 (conjugates x). fp64 accumulation, deterministic order. */
 int jh_dot(const jh_bvec *x, const jh_bvec *y, double *re, double *im);
@@ -154,6 +160,16 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m);
 /* mul!(m, A', d) -> JetBlock_df'!, src/Jets.jl:1034-1057: m zeroed when nrow > 1 (1042), rows summed
  * in order i = 0..nrow-1 with the product rounded before the add (1049) => bit-exact on one GPU. */
 int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d);
+/* mul!(d, F, m) for a NONLINEAR block operator -> JetBlock_f!, src/Jets.jl:988-1008, one fused launch.  SQUARE children
+ * square their input; linear children run df! (src/Jets.jl:391-392).  Unlike the linear loop NO block is skipped: with
+ * ncol > 1 every child's output (a zero block's zeros included) is added into d as found (1001); with ncol == 1 every
+ * child overwrites its row (1003). */
+int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m);
+/* point!(jet(F), mo) for a block jet, src/Jets.jl:1059-1066: child (i,j) is linearised about block j of mo (the whole of
+ * mo for a one-column operator).  mo is BORROWED, like jet.m0 in the reference (src/Jets.jl:297-301): it must stay alive
+ * and unchanged while jh_blockop_mul / jh_blockop_mul_adj are used as the Jacobian.  Those two fail with JH_ERR_STATE on an
+ * operator that has SQUARE blocks and no point (the reference hits a DimensionMismatch on its empty m0). */
+int jh_blockop_point(jh_blockop *op, const jh_bvec *mo);
 /* The same adjoint restricted to the elements [first_elem, first_elem+count) of the domain vector (16-byte aligned
  * bounds; tall all-DIAG operators): lets a multi-GPU host pipeline the exchange chunk by chunk -- all-reduce chunk k
  * while the kernel computes chunk k+1.  Results are identical to jh_blockop_mul_adj on those elements. */

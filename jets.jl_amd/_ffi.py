@@ -41,7 +41,7 @@ class BlockDesc(C.Structure):
 
 
 DTYPES = {"f32": 0, "f64": 1, "c32": 2, "c64": 3}
-KINDS = {"zero": 0, "identity": 1, "scale": 2, "diag": 3, "dense": 4}
+KINDS = {"zero": 0, "identity": 1, "scale": 2, "diag": 3, "dense": 4, "square": 5}
 
 _vp = C.c_void_p
 _i64 = C.c_int64
@@ -92,6 +92,8 @@ SYMBOLS = {
     "jh_blockop_destroy": (_int, [_vp]),
     "jh_blockop_mul": (_int, [_vp, _vp, _vp]),
     "jh_blockop_mul_adj": (_int, [_vp, _vp, _vp]),
+    "jh_blockop_f": (_int, [_vp, _vp, _vp]),
+    "jh_blockop_point": (_int, [_vp, _vp]),
     "jh_blockop_mul_adj_range": (_int, [_vp, _vp, _vp, _i64, _i64]),
     "jh_blockop_normal_mul": (_int, [_vp, _vp, _vp]),
     "jh_blocksum_mul": (_int, [_int, _vpp, _dblp, _dblp, _vp, _vp]),

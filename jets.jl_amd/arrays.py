@@ -469,9 +469,9 @@ def lincomb_(dst: _DevVec, coefs: Sequence, xs: Sequence[_DevVec]):
     return dst
 
 
-def hadamard_(dst: _DevVec, x: _DevVec, y: _DevVec, conj_x: bool = False):
-    """dst .= x .* y   (conj_x: conj.(x) .* y)."""
-    check(lib.jh_hadamard(dst.handle, x.handle, y.handle, 1 if conj_x else 0))
+def hadamard_(dst: _DevVec, x: _DevVec, y: _DevVec, conj_x: bool = False, twice_x: bool = False):
+    """dst .= x .* y   (conj_x: conj.(x) .* y; twice_x: (2 .* x) .* y)."""
+    check(lib.jh_hadamard(dst.handle, x.handle, y.handle, (1 if conj_x else 0) | (2 if twice_x else 0)))
     return dst
 
 

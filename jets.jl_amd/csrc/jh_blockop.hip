@@ -470,12 +470,21 @@ template <typename S, int E> __device__ inline elem<S, E> eadd(elem<S, E> a, ele
 
 // child mul! of an elementwise block applied to one element x at local index e.
 // `transposed` = we are inside df'! (so the child is op').  Effective conjugation = adjoint XOR transposed.
+// `fmode` = we are inside f! (JetBlock_f!, 988-1008): a SQUARE child squares its input instead of applying its Jacobian.
 template <typename S, int E>
-__device__ inline elem<S, E> apply_block(const jh_dev_block &b, elem<S, E> x, int64_t e, bool transposed)
+__device__ inline elem<S, E> apply_block(const jh_dev_block &b, elem<S, E> x, int64_t e, bool transposed, bool fmode = false)
 {
     const bool cj = (b.adjoint != 0) != transposed;
     switch (b.kind) {
     case JH_OP_IDENTITY: return x;
+    case JH_OP_SQUARE: {
+        if (fmode && !b.adjoint) return emul<S, E>(x, x);   // d .= m.^2   (test/runtests.jl:19)
+        elem<S, E> a = eload<S, E>((const S *)b.coeff, e);  // mo
+        a.re = a.re + a.re;                                  // 2 .* mo (exact)
+        a.im = (E == 2) ? a.im + a.im : (S)0;
+        if (E == 2 && cj) a.im = -a.im;
+        return emul<S, E>(a, x);                             // (2 .* mo) .* dm / conj.(2 .* mo) .* dd   (test/runtests.jl:20)
+    }
     case JH_OP_SCALE: {
         elem<S, E> a;
         a.re = (S)b.sre;
@@ -499,20 +508,20 @@ __device__ inline elem<S, E> apply_block(const jh_dev_block &b, elem<S, E> x, in
 template <typename S, int E>
 __global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                     const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
-                                    const S *__restrict__ m, S *__restrict__ d)
+                                    const S *__restrict__ m, S *__restrict__ d, int fmode)
 {
     const int64_t i = blockIdx.y;
     const int64_t n = row_off[i + 1] - row_off[i];
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         elem<S, E> acc;
         bool touched = false;
-        if (ncol > 1) { acc = eload<S, E>(d, row_off[i] + e); }          // `_d .+=` accumulates into d as found (1024)
+        if (ncol > 1) { acc = eload<S, E>(d, row_off[i] + e); }          // `_d .+=` accumulates into d as found (1024 / 1001)
         else { acc.re = 0; acc.im = 0; }
         for (int64_t j = 0; j < ncol; j++) {                               // (1020)
             const jh_dev_block b = blocks[i + j * nrow];
-            if (b.kind == JH_OP_ZERO) continue;                            // (1022)
+            if (b.kind == JH_OP_ZERO && !fmode) continue;                  // (1022); JetBlock_f! has no such test
             elem<S, E> x = eload<S, E>(m, col_off[j] + e);
-            elem<S, E> p = apply_block<S, E>(b, x, e, false);              // mul!(dtmp, op, _m)
+            elem<S, E> p = apply_block<S, E>(b, x, e, false, fmode != 0);  // mul!(dtmp, op, _m)
             acc = (ncol > 1) ? eadd<S, E>(acc, p) : p;                     // (1024) / (1026)
             touched = true;
         }
@@ -547,11 +556,16 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
 // 16-byte-per-lane variants of the two general kernels, used when every block offset, block length and
 // coefficient pointer is a multiple of 16 bytes.  Same loop order and rounding as the scalar versions.
 template <typename S, int E, int NS, typename V>
-__device__ inline V apply_block_vec(const jh_dev_block &b, V x, int64_t s, bool transposed)
+__device__ inline V apply_block_vec(const jh_dev_block &b, V x, int64_t s, bool transposed, bool fmode = false)
 {
     const bool cj = (b.adjoint != 0) != transposed;
     switch (b.kind) {
     case JH_OP_IDENTITY: return x;
+    case JH_OP_SQUARE: {
+        if (fmode && !b.adjoint) return vmul<S, E, NS, V>(x, x, false);
+        const V mo = ld<false>(reinterpret_cast<const V *>((const S *)b.coeff + s));
+        return vmul<S, E, NS, V>(mo + mo, x, cj);
+    }
     case JH_OP_SCALE: {
         if constexpr (E == 1) {
             return (V)(S)b.sre * x;
@@ -570,7 +584,7 @@ __device__ inline V apply_block_vec(const jh_dev_block &b, V x, int64_t s, bool 
 template <typename S, int E, int NS>
 __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                         const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
-                                        const S *__restrict__ m, S *__restrict__ d)
+                                        const S *__restrict__ m, S *__restrict__ d, int fmode)
 {
     typedef typename vec_of<S, NS>::type V;
     const int64_t i = blockIdx.y;
@@ -581,9 +595,9 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
         if (ncol > 1) acc = ld<false>(reinterpret_cast<const V *>(d + row_off[i] * E + s));
         for (int64_t j = 0; j < ncol; j++) {
             const jh_dev_block b = blocks[i + j * nrow];
-            if (b.kind == JH_OP_ZERO) continue;
+            if (b.kind == JH_OP_ZERO && !fmode) continue;
             V x = ld<false>(reinterpret_cast<const V *>(m + col_off[j] * E + s));
-            V p = apply_block_vec<S, E, NS, V>(b, x, s, false);
+            V p = apply_block_vec<S, E, NS, V>(b, x, s, false, fmode != 0);
             acc = (ncol > 1) ? acc + p : p;
             touched = true;
         }
@@ -813,12 +827,13 @@ bool general_vec_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_p
     if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & 15u) return false;
     for (int64_t v : op->row_len) if ((v * es) % 16) return false;
     for (int64_t v : op->col_len) if ((v * es) % 16) return false;
-    for (const auto &b : op->blocks) if (b.kind == JH_OP_DIAG && (((uintptr_t)b.coeff) & 15u)) return false;
+    for (const auto &b : op->blocks)
+        if ((b.kind == JH_OP_DIAG || b.kind == JH_OP_SQUARE) && (((uintptr_t)b.coeff) & 15u)) return false;
     return true;
 }
 
 template <typename S, int E>
-int general_fwd(const jh_blockop *op, void *d, const void *m)
+int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
 {
     int64_t maxn = 0;
     for (int64_t i = 0; i < op->nrow; i++) maxn = op->row_len[i] > maxn ? op->row_len[i] : maxn;
@@ -830,14 +845,14 @@ int general_fwd(const jh_blockop *op, void *d, const void *m)
         const int64_t cap = (((int64_t)1 << 24) / op->nrow) - 1;           // grid.x * grid.y * 256 threads < 2^32
         if (gxv > cap) gxv = cap > 0 ? cap : 1;
         hipLaunchKernelGGL((k_block_fwd_general_vec<S, E, NS>), dim3((unsigned)gxv, (unsigned)op->nrow), dim3(256), 0, jh_ctx().stream,
-                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d);
+                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode);
         JH_CHECK_HIP(hipGetLastError());
         return JH_OK;
     }
     int64_t gx = (maxn + 255) / 256;
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3((unsigned)gx, (unsigned)op->nrow), dim3(256), 0, jh_ctx().stream,
-                       op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d);
+                       op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -984,11 +999,15 @@ int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n
 
 // ---- per-block loop (operators containing DENSE blocks): the reference's loops (src/Jets.jl:1010-1057)
 // with device temporaries -- one child launch (+ one accumulate launch) per non-zero block.
-int child_apply(int dtype, const jh_block_desc &b, void *out, const void *in, bool transposed)
+int child_apply(int dtype, const jh_block_desc &b, void *out, const void *in, bool transposed, bool fmode = false)
 {
     const bool adj = (b.adjoint != 0) != transposed;          // (op')' = op
     const int64_t n_out = adj ? b.nc : b.nr;
     switch (b.kind) {
+    case JH_OP_SQUARE:
+        if (fmode && !b.adjoint) return jh_launch_hadamard_raw(out, in, in, dtype, n_out, 0);   // d .= m.^2
+        return jh_launch_square_jvp_raw(out, b.coeff, in, dtype, n_out, adj ? 1 : 0);
+    case JH_OP_ZERO: return jh_launch_fill_range(out, dtype, n_out, 0.0, 0.0);                  // d .= 0 (942), f! path only
     case JH_OP_DENSE: return jh_launch_gemv(b.coeff, b.nr, b.nc, dtype, out, in, adj ? 1 : 0);
     case JH_OP_DIAG: return jh_launch_hadamard_raw(out, b.coeff, in, dtype, n_out, adj ? 1 : 0);
     case JH_OP_SCALE: {
@@ -1010,22 +1029,22 @@ int accumulate(int dtype, void *acc, const void *term, int64_t n)     // acc .+=
     return jh_launch_lincomb_raw(acc, dtype, n, 2, one, zero, xs);
 }
 
-int loop_fwd(const jh_blockop *op, void *d, const void *m)           // JetBlock_df!
+int loop_fwd(const jh_blockop *op, void *d, const void *m, bool fmode = false)   // JetBlock_df! / JetBlock_f!
 {
     const size_t es = jh_dtype_size(op->dtype);
     for (int64_t i = 0; i < op->nrow; i++) {                          // (1015)
         char *_d = (char *)d + (size_t)op->row_off[(size_t)i] * es;
         for (int64_t j = 0; j < op->ncol; j++) {                      // (1020)
             const jh_block_desc &b = op->blocks[(size_t)(i + j * op->nrow)];
-            if (b.kind == JH_OP_ZERO) continue;                       // (1022)
+            if (b.kind == JH_OP_ZERO && !fmode) continue;             // (1022); not in JetBlock_f!
             const char *_m = (const char *)m + (size_t)op->col_off[(size_t)j] * es;
             if (op->ncol > 1) {
                 void *dtmp = nullptr;                                 // (1013, 1018)
                 JH_TRY(jh_ensure_scratch((size_t)op->row_len[(size_t)i] * es + 16, &dtmp));
-                JH_TRY(child_apply(op->dtype, b, dtmp, _m, false));   // mul!(dtmp, op, _m)
-                JH_TRY(accumulate(op->dtype, _d, dtmp, op->row_len[(size_t)i]));   // _d .+= dtmp   (1024)
+                JH_TRY(child_apply(op->dtype, b, dtmp, _m, false, fmode));   // mul!(dtmp, op, _m)
+                JH_TRY(accumulate(op->dtype, _d, dtmp, op->row_len[(size_t)i]));   // _d .+= dtmp   (1024 / 1001)
             } else {
-                JH_TRY(child_apply(op->dtype, b, _d, _m, false));     // (1026)
+                JH_TRY(child_apply(op->dtype, b, _d, _m, false, fmode));     // (1026 / 1003)
             }
         }
     }
@@ -1110,7 +1129,14 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
                 op->all_diag = false;
                 if (!b.coeff && b.nr * b.nc > 0)
                     status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: DENSE block (%lld,%lld) has no matrix", (long long)i, (long long)j);
-            } else if (b.kind == JH_OP_DIAG || b.kind == JH_OP_IDENTITY || b.kind == JH_OP_SCALE) {
+            } else if (b.kind == JH_OP_DIAG || b.kind == JH_OP_IDENTITY || b.kind == JH_OP_SCALE || b.kind == JH_OP_SQUARE) {
+                if (b.kind == JH_OP_SQUARE) {
+                    if (b.adjoint)   // adjoint() takes a JopLn (src/Jets.jl:382-383): a JopNl child has none
+                        status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: nonlinear block (%lld,%lld) cannot carry the adjoint flag",
+                                         (long long)i, (long long)j);
+                    op->nonlinear = true;
+                    op->blocks[(size_t)(i + j * nrow)].coeff = nullptr;     // the point arrives through jh_blockop_point
+                }
                 if (b.nr != b.nc)
                     status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: elementwise block (%lld,%lld) must be square (%lld x %lld)",
                                      (long long)i, (long long)j, (long long)b.nr, (long long)b.nc);
@@ -1178,10 +1204,55 @@ int jh_blockop_destroy(jh_blockop *op)
     return JH_OK;
 }
 
+int jh_blockop_point(jh_blockop *op, const jh_bvec *mo)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(op && mo, "jh_blockop_point: null argument");
+    JH_REQUIRE(mo->dtype == op->dtype, "jh_blockop_point: dtype mismatch (op %d, point %d)", op->dtype, mo->dtype);
+    JH_REQUIRE(mo->length == op->col_off[(size_t)op->ncol], "jh_blockop_point: point has %lld elements, operator domain has %lld",
+               (long long)mo->length, (long long)op->col_off[(size_t)op->ncol]);
+    op->pointed = true;
+    if (!op->nonlinear) return JH_OK;                                   // linear children ignore the point (upstate! default, 176)
+    const size_t es = jh_dtype_size(op->dtype);
+    std::vector<jh_dev_block> host(op->blocks.size());
+    for (int64_t j = 0; j < op->ncol; j++)                              // (1062)
+        for (int64_t i = 0; i < op->nrow; i++) {
+            jh_block_desc &b = op->blocks[(size_t)(i + j * op->nrow)];
+            if (b.kind == JH_OP_SQUARE) b.coeff = (const char *)mo->data + (size_t)op->col_off[(size_t)j] * es;   // getblock(mo, icol) (1063)
+        }
+    for (size_t k = 0; k < host.size(); k++) {
+        host[k].coeff = op->blocks[k].coeff;
+        host[k].sre = op->blocks[k].scale_re;
+        host[k].sim = op->blocks[k].scale_im;
+        host[k].kind = op->blocks[k].kind;
+        host[k].adjoint = op->blocks[k].adjoint;
+    }
+    hipStream_t st = jh_ctx().stream;
+    JH_CHECK_HIP(hipMemcpyAsync(op->dev_blocks, host.data(), host.size() * sizeof(jh_dev_block), hipMemcpyHostToDevice, st));
+    JH_CHECK_HIP(hipStreamSynchronize(st));                             // host staging vector dies at return
+    return JH_OK;
+}
+
+int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
+{
+    JH_TRY(jh_require_ready());
+    JH_TRY(check_vectors(op, d, m, "jh_blockop_f"));
+    if (!op->elementwise) return loop_fwd(op, d->data, m->data, true);
+    switch (op->dtype) {
+    case JH_F32: return general_fwd<float, 1>(op, d->data, m->data, 1);
+    case JH_F64: return general_fwd<double, 1>(op, d->data, m->data, 1);
+    case JH_C32: return general_fwd<float, 2>(op, d->data, m->data, 1);
+    case JH_C64: return general_fwd<double, 2>(op, d->data, m->data, 1);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blockop_f: unknown dtype %d", op->dtype);
+}
+
 int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
 {
     JH_TRY(jh_require_ready());
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul"));
+    if (op->nonlinear && !op->pointed)
+        return jh_fail(JH_ERR_STATE, "jh_blockop_mul: operator has nonlinear blocks and no linearisation point (jh_blockop_point)");
     if (tall_fast_ok(op, d->data, m->data)) {
         const int64_t n = op->row_len[0];
         switch (op->dtype) {
@@ -1205,6 +1276,8 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
 {
     JH_TRY(jh_require_ready());
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_adj"));
+    if (op->nonlinear && !op->pointed)
+        return jh_fail(JH_ERR_STATE, "jh_blockop_mul_adj: operator has nonlinear blocks and no linearisation point (jh_blockop_point)");
     if (tall_fast_ok(op, d->data, m->data)) {
         const int64_t n = op->row_len[0];
         switch (op->dtype) {

@@ -109,6 +109,8 @@ struct jh_blockop {
     bool uniform_rows = false;               // all row_len equal
     bool all_diag = false;                   // every block is an un-adjointed... DIAG (adjoint flag irrelevant up to conj)
     bool elementwise = false;                // no DENSE block
+    bool nonlinear = false;                  // has a SQUARE block (JopNl child)
+    bool pointed = false;                    // jh_blockop_point has been called (SQUARE blocks have their mo)
     bool diag_strided = false;               // coeff[i] = coeff[0] + i*stride bytes
     mutable int fwd_walk = -1;               // autotuned tall-forward shape: -1 untried, 0 sequential 1024x8x16, 1 all rows 512x1x2, 2 sequential 256x4x4
     mutable int upd_walk = -1;               // same for the fused forward update (timed on its first two real calls)
@@ -122,6 +124,8 @@ int jh_ensure_partials(int64_t n);     // grows ctx.part_dev to >= n doubles (ma
 int jh_launch_fill_range(void *ptr, int dtype, int64_t count, double re, double im);
 int jh_launch_copy_bytes(void *dst, const void *src, size_t bytes);
 int jh_launch_hadamard_raw(void *dst, const void *x, const void *y, int dtype, int64_t count, int conj_x);
+// dst = (2 .* mo) .* x  (conj: conj.(2 .* mo) .* x): the Jacobian of d .= m.^2 about mo
+int jh_launch_square_jvp_raw(void *dst, const void *mo, const void *x, int dtype, int64_t count, int conj_mo);
 int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const double *cre, const double *cim, const void *const *x);
 // dense child operator (jh_dense.hip): y = A x (rows) or y = A^H x / A^T x (cols); A column-major nr x nc
 int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, const void *x, int adjoint);

@@ -262,11 +262,14 @@ __global__ void k_hadamard(S *__restrict__ dst, const S *__restrict__ x, const S
     const int64_t nvec = n_scalars / NS;
     const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * WG;
+    const bool cj = (conj_x & 1) != 0, twice = (conj_x & 2) != 0;     // bit 1: x -> 2 .* x (x + x, exact)
     auto one = [&](const S *xe, const S *ye, S *oe) {
         if (E == 1) {
-            oe[0] = xe[0] * ye[0];
+            const S xr = twice ? xe[0] + xe[0] : xe[0];
+            oe[0] = xr * ye[0];
         } else {
-            S xr = xe[0], xi = conj_x ? -xe[1] : xe[1], yr = ye[0], yi = ye[1];
+            S xr = xe[0], xi = cj ? -xe[1] : xe[1], yr = ye[0], yi = ye[1];
+            if (twice) { xr = xr + xr; xi = xi + xi; }
             oe[0] = xr * yr - xi * yi;
             oe[1] = xr * yi + xi * yr;
         }
@@ -512,6 +515,11 @@ int jh_launch_hadamard_raw(void *dst, const void *x, const void *y, int dtype, i
     return jh_fail(JH_ERR_INVALID, "hadamard: unknown dtype %d", dtype);
 }
 
+int jh_launch_square_jvp_raw(void *dst, const void *mo, const void *x, int dtype, int64_t count, int conj_mo)
+{
+    return jh_launch_hadamard_raw(dst, mo, x, dtype, count, 2 | (conj_mo ? 1 : 0));
+}
+
 // dst = c0*x0 (+ c1*x1): k in {1, 2}
 int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const double *cre, const double *cim, const void *const *x)
 {
@@ -649,6 +657,7 @@ int jh_hadamard(jh_bvec *dst, const jh_bvec *x, const jh_bvec *y, int conj_x)
     JH_TRY(jh_require_ready());
     JH_REQUIRE(dst && x && y, "jh_hadamard: null argument");
     JH_REQUIRE(dst->dtype == x->dtype && dst->dtype == y->dtype, "jh_hadamard: dtype mismatch");
+    JH_REQUIRE(conj_x >= 0 && conj_x <= 3, "jh_hadamard: flags must be 0..3 (got %d)", conj_x);
     JH_REQUIRE(dst->length == x->length && dst->length == y->length, "jh_hadamard: length mismatch (%lld, %lld, %lld)",
                (long long)dst->length, (long long)x->length, (long long)y->length);
     switch (dst->dtype) {

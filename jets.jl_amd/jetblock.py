@@ -24,7 +24,8 @@ from .jets import Jet, Jop, JopLn, JopNl, JopAdjoint, mul_, domain, range_, jet,
 __all__ = [
     "JetBlock", "JopBlock", "blockop", "JopZeroBlock", "JopZeroBlock_df", "iszero", "JetBlock_f", "JetBlock_df",
     "JetBlock_df_adj", "nblocks_op", "getblock_op", "isblockop", "JopDiagonal", "JopIdentity", "diagonal_df",
-    "diagonal_df_adj", "identity_df", "NativeBlockOp", "JopDense", "dense_df", "dense_df_adj",
+    "diagonal_df_adj", "identity_df", "NativeBlockOp", "JopDense", "dense_df", "dense_df_adj", "JopSquare", "square_f",
+    "square_df", "square_df_adj",
 ]
 
 
@@ -83,9 +84,38 @@ def JopDense(A: DeviceArray) -> JopLn:
     return JopLn(df=dense_df, df_adj=dense_df_adj, dom=dom, rng=rng, s={"A": A})
 
 
+def square_f(d, m, **kw):  # test/runtests.jl:19   d .= m.^2
+    return hadamard_(d, m, m)
+
+
+def _need_point(mo, n):
+    # the reference's jet holds an EMPTY mo until point! (src/Jets.jl:187): the broadcast then throws DimensionMismatch
+    if mo is None or mo.length() != n:
+        raise ValueError("DimensionMismatch: the Jacobian of a nonlinear operator needs a linearization point (point! / jacobian!)")
+    return mo
+
+
+def square_df(d, m, *, mo, **kw):  # test/runtests.jl:20   dd .= 2 .* mo .* dm
+    return hadamard_(d, _need_point(mo, m.length()), m, twice_x=True)
+
+
+def square_df_adj(m, d, *, mo, **kw):  # conj.(2 .* mo) .* dd  (== df! for real eltypes, src/Jets.jl:184-186)
+    return hadamard_(m, _need_point(mo, d.length()), d, conj_x=True, twice_x=True)
+
+
+def JopSquare(spc: JetAbstractSpace) -> JopNl:
+    """The reference's nonlinear fixture JopBar (test/runtests.jl:19-24) as a device-native block kind."""
+    return JopNl(f=square_f, df=square_df, df_adj=square_df_adj, dom=spc, rng=spc)
+
+
 def _native_desc(op: Jop):
     """(kind, adjoint_flag, coeff_array_or_None, scale) if `op` is device-native, else None."""
     adj = 0
+    if isinstance(op, JopNl):  # a nonlinear child: f! in JetBlock_f!, its Jacobian about jet.mo in JetBlock_df!/df'!
+        j = op.jet
+        if j.f is square_f and j.df is square_df and j.df_adj is square_df_adj:
+            return ("square", 0, None, 0.0)
+        return None
     if isinstance(op, JopAdjoint):
         adj, op = 1, op.op
     if not isinstance(op, JopLn):
@@ -124,6 +154,8 @@ class NativeBlockOp:
                 b.nr, b.nc = range_(base).length(), domain(base).length()
                 if coeff is not None:
                     self._keep.append(coeff)
+        self.nonlinear = any(dsc[0] == "square" for row in descs for dsc in row)
+        self._point = None  # the device array the SQUARE blocks are linearised about (kept alive here)
         row_len = [range_(ops[i, 0]).length() for i in builtins.range(nrow)]
         col_len = [domain(ops[0, jc]).length() for jc in builtins.range(ncol)]
         self._h = C.c_void_p()
@@ -143,6 +175,16 @@ class NativeBlockOp:
         check(lib.jh_blockop_mul_adj(self.handle, m.handle, d.handle))
         return m
 
+    def f(self, d, m):
+        check(lib.jh_blockop_f(self.handle, d.handle, m.handle))
+        return d
+
+    def point(self, mo):
+        if self._point is None or self._point.ptr != mo.ptr:
+            check(lib.jh_blockop_point(self.handle, mo.handle))
+            self._point = mo
+        return self
+
     def normal_mul(self, y, m):
         check(lib.jh_blockop_normal_mul(self.handle, y.handle, m.handle))
         return y
@@ -152,6 +194,7 @@ class NativeBlockOp:
             h, self._h = self._h, None
             lib.jh_blockop_destroy(h)
         self._keep = []
+        self._point = None
 
     def __del__(self):
         try:
@@ -234,7 +277,26 @@ def blockop(ops, **kwargs) -> Jop:
 
 
 # ------------------------------------------------------------------------------ the block loops ----
+def _pointed_native(nat, ops, mo):
+    """`nat` linearised about `mo`, or None when some nonlinear child sits at a point of its own (someone called point!
+    on the child, not on the block jet): then the per-child loop below is the faithful path."""
+    if not nat.nonlinear:
+        return nat
+    if mo is None or mo.length() != sum(domain(ops[0, jc]).length() for jc in builtins.range(ops.shape[1])):
+        return None
+    for jc in builtins.range(ops.shape[1]):
+        want = getblock(mo, jc).ptr
+        for i in builtins.range(ops.shape[0]):
+            op = ops[i, jc]
+            if isinstance(op, JopNl) and (op.jet.mo is None or op.jet.mo.ptr != want):
+                return None
+    return nat.point(mo)
+
+
 def JetBlock_f(d, m, *, ops, dom, rng, _native=None, **kw):  # :988-1008
+    nat = _native_op(_native, ops, rng.eltype())
+    if nat is not None:
+        return nat.f(d, m)  # one fused launch, same loop order and rounding
     nrow, ncol = ops.shape
     dtmp = zeros(range_(ops[0, 0])) if ncol > 1 else None
     for i in builtins.range(nrow):
@@ -252,6 +314,8 @@ def JetBlock_f(d, m, *, ops, dom, rng, _native=None, **kw):  # :988-1008
 
 def JetBlock_df(d, m, *, ops, dom, rng, _native=None, **kw):  # :1010-1032
     nat = _native_op(_native, ops, rng.eltype())
+    if nat is not None:
+        nat = _pointed_native(nat, ops, kw.get("mo"))
     if nat is not None:
         return nat.mul(d, m)  # one fused launch, same loop order and rounding
     nrow, ncol = ops.shape
@@ -272,6 +336,8 @@ def JetBlock_df(d, m, *, ops, dom, rng, _native=None, **kw):  # :1010-1032
 
 def JetBlock_df_adj(m, d, *, ops, dom, rng, _native=None, **kw):  # :1034-1057
     nat = _native_op(_native, ops, rng.eltype())
+    if nat is not None:
+        nat = _pointed_native(nat, ops, kw.get("mo"))
     if nat is not None:
         return nat.mul_adj(m, d)
     nrow, ncol = ops.shape

@@ -126,6 +126,12 @@ function JopHipDiagonal(diag::HipArray{T,N}) where {T,N}
     JopLn(;df! = JopHipDiagonal_df!, df′! = JopHipDiagonal_df′!, dom = spc, rng = spc, s = (diagonal=diag,))
 end
 
+# the reference's nonlinear fixture JopBar (test/runtests.jl:19-24) on device vectors: kind SQUARE
+JopHipSquare_f!(d, m; kwargs...) = (check(ccall((:jh_hadamard, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), d.handle, m.handle, m.handle, 0)); d)
+JopHipSquare_df!(δd, δm; mₒ, kwargs...) = (check(ccall((:jh_hadamard, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), δd.handle, mₒ.handle, δm.handle, 2)); δd)
+JopHipSquare_df′!(δm, δd; mₒ, kwargs...) = (check(ccall((:jh_hadamard, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), δm.handle, mₒ.handle, δd.handle, 3)); δm)
+JopHipSquare(spc::JetSpace) = JopNl(f! = JopHipSquare_f!, df! = JopHipSquare_df!, df′! = JopHipSquare_df′!, dom = spc, rng = spc)
+
 struct jh_block_desc          # mirrors include/jetship.h
     kind::Int32
     adjoint::Int32
@@ -141,7 +147,9 @@ function block_desc(op::Jop)
     base = adj ? op.op : op
     j = jet(base)
     nr, nc = length(range(base)), length(domain(base))
-    if j.df! === JopZeroBlock_df!
+    if op isa JopNl
+        return j.f! === JopHipSquare_f! ? jh_block_desc(5, 0, C_NULL, 0, 0, nr, nc) : nothing
+    elseif j.df! === JopZeroBlock_df!
         return jh_block_desc(0, adj, C_NULL, 0, 0, nr, nc)
     elseif j.df! === JopHipDiagonal_df!
         return jh_block_desc(3, adj, _device_ptr(state(base).diagonal), 0, 0, nr, nc)
@@ -187,6 +195,22 @@ function Jets.JetBlock_df′!(m::Union{HipArray{T},HipBlockArray{T}}, d::HipBloc
     h == C_NULL && return invoke(Jets.JetBlock_df′!, Tuple{AbstractArray,AbstractArray}, m, d; ops, dom, rng, kwargs...)
     check(ccall((:jh_blockop_mul_adj, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, m.handle, d.handle))
     m
+end
+
+# nonlinear block operators: JetBlock_f! (src/Jets.jl:988-1008) and the block point! (1059-1066).  The Jacobian then
+# runs through the two methods above; they call `_point_native` first when the operator has nonlinear children.
+function Jets.JetBlock_f!(d::HipBlockArray{T}, m::Union{HipArray{T},HipBlockArray{T}}; ops, dom, rng, kwargs...) where {T}
+    h = native_handle(ops, T)
+    h == C_NULL && return invoke(Jets.JetBlock_f!, Tuple{AbstractArray,AbstractArray}, d, m; ops, dom, rng, kwargs...)
+    check(ccall((:jh_blockop_f, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, d.handle, m.handle))
+    d
+end
+
+function Jets.point!(j::Jet{D,R,typeof(Jets.JetBlock_f!)}, mₒ::Union{HipArray{T},HipBlockArray{T}}) where {D,R,T}
+    invoke(Jets.point!, Tuple{Jet{D,R,typeof(Jets.JetBlock_f!)},AbstractArray}, j, mₒ)   # children first (1062-1064)
+    h = native_handle(state(j).ops, T)
+    h == C_NULL || check(ccall((:jh_blockop_point, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h, mₒ.handle))
+    j
 end
 
 # (A' o A) * m fused (src/Jets.jl:530-534 over (A', A)): called from a JetComposite_df! method that

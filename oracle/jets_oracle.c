@@ -171,6 +171,13 @@ void jo_block_df_adj(int dtype, int64_t nrow, int64_t ncol, const jo_block *ops,
              block_df_adj_c64(nrow, ncol, ops, m_arrays, d_arrays));
 }
 
+void jo_block_f(int dtype, int64_t nrow, int64_t ncol, const jo_block *ops, void *const *d_arrays,
+                const void *const *m_arrays)
+{
+    DISPATCH(dtype, block_f_f32(nrow, ncol, ops, d_arrays, m_arrays), block_f_f64(nrow, ncol, ops, d_arrays, m_arrays),
+             block_f_c32(nrow, ncol, ops, d_arrays, m_arrays), block_f_c64(nrow, ncol, ops, d_arrays, m_arrays));
+}
+
 void jo_normal_df(int dtype, int64_t nrow, int64_t ncol, const jo_block *ops, void *const *y_arrays,
                   const void *const *m_arrays)
 {

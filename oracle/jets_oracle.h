@@ -31,12 +31,12 @@ extern "C" {
 enum { JO_F32 = 0, JO_F64 = 1, JO_C32 = 2, JO_C64 = 3 };
 
 /* block kinds (same numbering as include/jetship.h) */
-enum { JO_OP_ZERO = 0, JO_OP_IDENTITY = 1, JO_OP_SCALE = 2, JO_OP_DIAG = 3, JO_OP_DENSE = 4 };
+enum { JO_OP_ZERO = 0, JO_OP_IDENTITY = 1, JO_OP_SCALE = 2, JO_OP_DIAG = 3, JO_OP_DENSE = 4, JO_OP_SQUARE = 5 };
 
 typedef struct {
     int32_t kind;       /* JO_OP_*                                                    */
     int32_t adjoint;    /* 1: the block is the JopAdjoint of the described operator   */
-    const void *coeff;  /* DIAG: diagonal (len = block len); DENSE: column-major nr x nc */
+    const void *coeff;  /* DIAG: diagonal (len = block len); DENSE: column-major nr x nc; SQUARE: the point mo */
     double sre, sim;    /* SCALE: the scalar a                                        */
     int64_t nr, nc;     /* range / domain length of the described (un-adjointed) op   */
 } jo_block;
@@ -75,7 +75,9 @@ void jo_barr_lincomb(int dtype, int64_t nb, void *const *dst, const int64_t *len
  * SCALE : src/Jets.jl:1159-1160  d .= a*m ; m .= conj(a)*d
  * ZERO  : src/Jets.jl:942        d .= 0
  * DENSE : test/runtests.jl:27-28 d .= A*m ; m .= A'*d      (column-major A, sequential k loop)
- * IDENT : d .= m */
+ * IDENT : d .= m
+ * SQUARE: test/runtests.jl:19-24 (JopBar, NONLINEAR) f!: d .= m.^2 ; Jacobian at mo (coeff): dd .= 2 .* mo .* dm ;
+ *         its adjoint conj.(2 .* mo) .* dd (the fixture is Float64 and lets df'! default to df!, src/Jets.jl:184-186) */
 void jo_child_mul(int dtype, const jo_block *b, void *d, const void *m);      /* src/Jets.jl:391 */
 void jo_child_mul_adj(int dtype, const jo_block *b, void *m, const void *d);  /* src/Jets.jl:392 */
 
@@ -83,6 +85,10 @@ void jo_child_mul_adj(int dtype, const jo_block *b, void *m, const void *d);  /*
  * d_arrays: nrow range blocks.  m_arrays: ncol domain blocks (ncol==1 => the plain domain array). */
 void jo_block_df(int dtype, int64_t nrow, int64_t ncol, const jo_block *ops, void *const *d_arrays,
                  const void *const *m_arrays);
+/* src/Jets.jl:988-1008  JetBlock_f!  (nonlinear forward: SQUARE blocks square their input, linear kinds run df!;
+ * zero blocks are NOT skipped here) */
+void jo_block_f(int dtype, int64_t nrow, int64_t ncol, const jo_block *ops, void *const *d_arrays,
+                const void *const *m_arrays);
 /* src/Jets.jl:1034-1057  JetBlock_df'! */
 void jo_block_df_adj(int dtype, int64_t nrow, int64_t ncol, const jo_block *ops, void *const *m_arrays,
                      const void *const *d_arrays);

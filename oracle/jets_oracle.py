@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libjets_oracle.so")
 
 DT = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.complex64): 2, np.dtype(np.complex128): 3}
-KIND = {"zero": 0, "identity": 1, "scale": 2, "diag": 3, "dense": 4}
+KIND = {"zero": 0, "identity": 1, "scale": 2, "diag": 3, "dense": 4, "square": 5}
 
 
 class _Block(C.Structure):
@@ -142,7 +142,8 @@ def barr_lincomb(dst, coefs, srcs):
 
 # ------------------------------------------------------------------ block operators ----------------
 class Block:
-    """One child operator of a block matrix (device-native kinds only)."""
+    """One child operator of a block matrix (device-native kinds only).  kind "square" is the nonlinear
+    d .= m.^2 (test/runtests.jl:19-24); its `coeff` is the linearisation point mo of that block."""
 
     def __init__(self, kind, nr, nc=None, coeff=None, scale=0.0, adjoint=False):
         self.kind, self.nr, self.nc = kind, int(nr), int(nr if nc is None else nc)
@@ -177,6 +178,15 @@ def block_df(ops, d_blocks, m_blocks):
     d_blocks = _check_blocks(d_blocks)
     m_blocks = _check_blocks(m_blocks, d_blocks[0].dtype)
     _lib.jo_block_df(C.c_int(DT[d_blocks[0].dtype]), C.c_int64(nrow), C.c_int64(ncol), arr, _ptrs(d_blocks), _ptrs(m_blocks))
+    return d_blocks
+
+
+def block_f(ops, d_blocks, m_blocks):
+    """JetBlock_f! (src/Jets.jl:988-1008): mutates d_blocks in place."""
+    arr, nrow, ncol = _ops_array(ops)
+    d_blocks = _check_blocks(d_blocks)
+    m_blocks = _check_blocks(m_blocks, d_blocks[0].dtype)
+    _lib.jo_block_f(C.c_int(DT[d_blocks[0].dtype]), C.c_int64(nrow), C.c_int64(ncol), arr, _ptrs(d_blocks), _ptrs(m_blocks))
     return d_blocks
 
 

@@ -285,3 +285,77 @@ def test_rng_known_answers_from_an_independent_big_int_implementation():
     assert np.array_equal(c.real, f[0::2]) and np.array_equal(c.imag, f[1::2])
     u = jo.rng_u01(np.float32, 9, 9, 0, 200000)
     assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 5e-3
+
+
+# ------------------------------------------------------------------ nonlinear blocks (JopBar, test/runtests.jl:19-24)
+def _bar_f(m):
+    return m * m                                                                        # d .= m.^2
+
+
+def _bar_J(mo, dm):
+    return (2 * mo) * dm                                                                # dd .= 2 .* mo .* dm
+
+
+@pytest.mark.parametrize("dt", ALL)
+def test_nonlinear_singleton_tall_and_fat(dt):
+    """The JopBar halves of test/runtests.jl:711-716 (singleton), 727-733 (tall), 751-757 (short-and-fat)."""
+    n = 5
+    exact = np.dtype(dt).kind != "c"
+    eq = (lambda a, b: np.array_equal(a, b)) if exact else (lambda a, b: np.allclose(a, b, rtol=tol(dt)))
+    # singleton
+    m, d = rnd(dt, n), rnd(dt, n)
+    ops = [[jo.Block("square", n, coeff=m)]]
+    assert eq(jo.block_f(ops, [rnd(dt, n)], [m])[0], _bar_f(m))                          # F*m == G*m  (:713)
+    assert eq(jo.block_df(ops, [rnd(dt, n)], [m])[0], _bar_J(m, m))                      # J*m         (:715)
+    assert eq(jo.block_df_adj(ops, [rnd(dt, n)], [d])[0], np.conj(2 * m) * d)            # J'*d        (:716)
+    # tall: F*m == [G1 m; G2 m; G3 m], J*m likewise, J'd == sum_i Ji'd_i  (:728-733)
+    ops = [[jo.Block("square", n, coeff=m)] for _ in range(3)]
+    out = jo.block_f(ops, [rnd(dt, n) for _ in range(3)], [m])
+    assert all(eq(o, _bar_f(m)) for o in out)
+    out = jo.block_df(ops, [rnd(dt, n) for _ in range(3)], [m])
+    assert all(eq(o, _bar_J(m, m)) for o in out)
+    dd = [rnd(dt, n) for _ in range(3)]
+    mt = jo.block_df_adj(ops, [rnd(dt, n)], dd)[0]
+    acc = np.zeros(n, dtype=dt)
+    for x in dd:
+        acc = acc + np.conj(2 * m) * x
+    assert eq(mt, acc)
+    # short-and-fat: F*m == sum_j Gj m_j (accumulated into d as found), J*m likewise, J'd == [Jj' d]  (:752-757)
+    mb = [rnd(dt, n) for _ in range(3)]
+    ops = [[jo.Block("square", n, coeff=x) for x in mb]]
+    d0 = rnd(dt, n)
+    acc = d0.copy()
+    for x in mb:
+        acc = acc + _bar_f(x)
+    assert eq(jo.block_f(ops, [d0.copy()], mb)[0], acc)
+    acc = np.zeros(n, dtype=dt)
+    for x in mb:
+        acc = acc + _bar_J(x, x)
+    assert eq(jo.block_df(ops, [np.zeros(n, dtype=dt)], mb)[0], acc)
+    out = jo.block_df_adj(ops, [rnd(dt, n) for _ in range(3)], [d])
+    assert all(eq(o, np.conj(2 * x) * d) for o, x in zip(out, mb))
+
+
+def test_nonlinear_forward_does_not_skip_zero_blocks():
+    """src/Jets.jl:998-1004 has no `iszero` test (1022 does): a zero block's `d .= 0` (942) runs in f!."""
+    n = 6
+    m = rnd(np.float64, n)
+    ops = [[jo.Block("square", n, coeff=m)], [jo.Block("zero", n, n)]]
+    d0 = [rnd(np.float64, n), rnd(np.float64, n)]
+    out = jo.block_f(ops, [x.copy() for x in d0], [m])
+    assert np.array_equal(out[0], m * m) and np.array_equal(out[1], np.zeros(n))
+    out = jo.block_df(ops, [x.copy() for x in d0], [m])
+    assert np.array_equal(out[1], d0[1])                                                # the linear loop skips it
+    wide = [[jo.Block("zero", n, n), jo.Block("square", n, coeff=np.zeros(n))]]
+    out = jo.block_f(wide, [np.full(n, -0.0)], [np.zeros(n), np.zeros(n)])
+    assert not np.signbit(out[0]).any()                                                 # -0.0 + 0.0 == +0.0
+
+
+def test_nonlinear_jacobian_passes_the_dot_product_test():
+    n = 40
+    for dt in ALL:
+        mo = [rnd(dt, n) for _ in range(2)]
+        ops = [[jo.Block("square", n, coeff=mo[0]), jo.Block("diag", n, coeff=rnd(dt, n))],
+               [jo.Block("zero", n, n), jo.Block("square", n, coeff=mo[1])]]
+        lhs, rhs = jo.dot_product_test(ops, [rnd(dt, n) for _ in range(2)], [rnd(dt, n) for _ in range(2)])
+        assert abs(lhs - rhs) <= 10 * tol(dt) * abs(lhs + rhs)
