@@ -664,6 +664,7 @@ TallShape pick_adj_shape(int64_t nvec, int64_t nrow, int mode)
     else if (nvec >= 2 * 256 * 256) s.unroll = 2;
     if (s.unroll == 4) s.aux = (nrow >= 256) ? 4 : 2;
     if (nvec >= ((int64_t)1 << 22)) s.wg = 512;
+    if (mode == 0 && nvec >= ((int64_t)1 << 22) && nrow < 512) { s.wg = 1024; s.aux = 2; }   // 128..256 x 256^3: +2..7 % (sweep_r01_pair_*)
     if (mode == 1) {                                   // fused normal operator: one input stream
         s.aux = (s.unroll == 4) ? 4 : 8;
         if (nvec >= ((int64_t)1 << 22)) s.wg = 1024;

@@ -296,3 +296,23 @@ def test_gauss_newton_on_a_tall_nonlinear_block_operator(Jets, oracle):
         step = Jets.lsqr(J, r, maxiter=30, atol=1e-14, btol=1e-14).x
         Jets.lincomb_(m, [1.0, 1.0], [m, step])
     np.testing.assert_allclose(m.to_numpy(), x_true, rtol=1e-9)
+
+
+def test_multiple_simultaneous_linearizations_literal_values(Jets):
+    """test/runtests.jl:203-217, literal values: jacobian (copies the jet) keeps J1 and J2 apart; jacobian! (shares the
+    jet) makes both follow the last point."""
+    F = Jets.JopSquare(Jets.JetSpace(np.float64, 2))
+    p1, p2 = Jets.from_numpy(np.array([1.0, 2.0])), Jets.from_numpy(np.array([3.0, 4.0]))
+    dm = Jets.from_numpy(np.array([1.0, 2.0]))
+    J1, J2 = Jets.jacobian(F, p1), Jets.jacobian(F, p2)
+    assert (J1 * dm).to_numpy().tolist() == [2.0, 8.0]                               # 2 .* [1,2] .* dm
+    assert (J2 * dm).to_numpy().tolist() == [6.0, 16.0]                              # 2 .* [3,4] .* dm
+    J1, J2 = Jets.jacobian_(F, p1), Jets.jacobian_(F, p2)
+    assert (J1 * dm).to_numpy().tolist() == [6.0, 16.0]
+    assert (J2 * dm).to_numpy().tolist() == (J1 * dm).to_numpy().tolist()
+    # the same through a block operator: jacobian of a copy must not disturb the original's fused handle
+    G = Jets.blockop([[Jets.JopSquare(Jets.JetSpace(np.float64, 2))] for _ in range(2)])
+    K1, K2 = Jets.jacobian(G, p1), Jets.jacobian(G, p2)
+    assert (K1 * dm).to_numpy().tolist() == [2.0, 8.0, 2.0, 8.0]
+    assert (K2 * dm).to_numpy().tolist() == [6.0, 16.0, 6.0, 16.0]
+    assert (K1.H * (K1 * dm)).to_numpy().tolist() == [8.0, 64.0]                     # sum_i (2 mo)^2 dm

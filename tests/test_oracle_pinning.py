@@ -359,3 +359,12 @@ def test_nonlinear_jacobian_passes_the_dot_product_test():
                [jo.Block("zero", n, n), jo.Block("square", n, coeff=mo[1])]]
         lhs, rhs = jo.dot_product_test(ops, [rnd(dt, n) for _ in range(2)], [rnd(dt, n) for _ in range(2)])
         assert abs(lhs - rhs) <= 10 * tol(dt) * abs(lhs + rhs)
+
+
+def test_multiple_linearizations_literal_values():
+    """test/runtests.jl:203-211: J1*dm == 2 .* [1,2] .* dm == [2, 8]; J2*dm == 2 .* [3,4] .* dm == [6, 16]."""
+    dm = np.array([1.0, 2.0])
+    for mo, want in (([1.0, 2.0], [2.0, 8.0]), ([3.0, 4.0], [6.0, 16.0])):
+        out = jo.block_df([[jo.Block("square", 2, coeff=np.array(mo))]], [np.zeros(2)], [dm])[0]
+        assert out.tolist() == want
+    assert jo.block_f([[jo.Block("square", 2, coeff=np.zeros(2))]], [np.zeros(2)], [np.array([3.0, 4.0])])[0].tolist() == [9.0, 16.0]
