@@ -1,0 +1,161 @@
+/* host_pair.c -- a C host of the drop-in boundary: no Python, no torch, nothing but include/jetship.h.
+ *
+ * TEST CODE.  It drives libjetship.so exactly as the reference-side binding would (one call per mul!), on the
+ * BASELINE.json path at a small size, and checks every result bit for bit against the CPU oracle
+ * (oracle/libjets_oracle.so -- test infrastructure, linked only here).  Built and run by tests/test_c_host.py:
+ *
+ *   gcc -O2 -std=gnu11 -Iinclude -Ioracle tests/c_host/host_pair.c -o host_pair \
+ *       -Ljets.jl_amd -ljetship -Loracle -ljets_oracle -Wl,-rpath,...
+ *
+ * Exit code 0 and a last line "C HOST OK" on success.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "jetship.h"
+#include "jets_oracle.h"
+
+#define CK(call)                                                                            \
+    do {                                                                                    \
+        int st_ = (call);                                                                   \
+        if (st_ != JH_OK) {                                                                 \
+            fprintf(stderr, "%s:%d %s -> %d: %s\n", __FILE__, __LINE__, #call, st_, jh_last_error()); \
+            return 1;                                                                       \
+        }                                                                                   \
+    } while (0)
+
+#define REQUIRE(cond, what)                                                  \
+    do {                                                                     \
+        if (!(cond)) { fprintf(stderr, "FAILED: %s (%s:%d)\n", what, __FILE__, __LINE__); return 1; } \
+    } while (0)
+
+enum { NROW = 12, EDGE = 24 };
+
+int main(void)
+{
+    const int64_t n = (int64_t)EDGE * EDGE * EDGE;      /* one block: EDGE^3 Float32, contiguous, column-major */
+    int ndev = 0;
+    CK(jh_device_count(&ndev));
+    REQUIRE(ndev >= 1, "no HIP device");
+    CK(jh_init(0));
+    char name[128];
+    int64_t hbm_total = 0, hbm_free = 0;
+    int cus = 0;
+    CK(jh_device_info(name, (int)sizeof name, &hbm_total, &hbm_free, &cus));
+    printf("device: %s, %d CUs, %.0f GiB HBM, ABI v%d\n", name, cus, (double)hbm_total / (1 << 30), jh_abi_version());
+
+    /* ---- block vectors: coefficients (one slab = all diagonals), range vector d, domain vectors m, mt, y */
+    int64_t lens[NROW];
+    for (int i = 0; i < NROW; i++) lens[i] = n;
+    jh_bvec *coeff = NULL, *d = NULL, *m = NULL, *mt = NULL, *y = NULL;
+    CK(jh_bvec_create(NROW, lens, JH_F32, &coeff));
+    CK(jh_bvec_create(NROW, lens, JH_F32, &d));
+    CK(jh_bvec_create(1, lens, JH_F32, &m));
+    CK(jh_bvec_create(1, lens, JH_F32, &mt));
+    CK(jh_bvec_create(1, lens, JH_F32, &y));
+    CK(jh_fill_uniform(coeff, 1, 0, 0));               /* seeds as in SURVEY.md 8d: a = 1, m = 2, d = 3 */
+    CK(jh_fill_uniform(m, 2, 0, 0));
+    CK(jh_fill(d, 7.0, 0.0));                          /* dirty output */
+    CK(jh_fill(mt, 7.0, 0.0));
+
+    /* ---- the operator: NROW x 1 diagonal blocks, coefficient pointers borrowed from the slab */
+    jh_block_desc desc[NROW];
+    memset(desc, 0, sizeof desc);
+    for (int i = 0; i < NROW; i++) {
+        int64_t off = 0, len = 0;
+        void *ptr = NULL;
+        CK(jh_bvec_block(coeff, i, &off, &len, &ptr));
+        REQUIRE(off == (int64_t)i * n && len == n, "JetBSpace ranges (src/Jets.jl:742-748)");
+        desc[i].kind = JH_OP_DIAG;
+        desc[i].coeff = ptr;
+        desc[i].nr = desc[i].nc = n;
+    }
+    int64_t col_len[1] = {n};
+    jh_blockop *A = NULL;
+    CK(jh_blockop_create(NROW, 1, desc, lens, col_len, JH_F32, &A));
+
+    /* ---- the hot path: one call per mul! */
+    CK(jh_blockop_mul(A, d, m));                       /* d = A m      (JetBlock_df!)  */
+    CK(jh_blockop_mul_adj(A, mt, d));                  /* mt = A' d    (JetBlock_df'!) */
+    CK(jh_blockop_normal_mul(A, y, m));                /* y = A'(A m)  fused           */
+    double nrm = 0, dre = 0, dim = 0, mn = 0, mx = 0;
+    CK(jh_norm(d, 2.0, &nrm));
+    CK(jh_dot(d, d, &dre, &dim));
+    CK(jh_extrema(d, &mn, &mx));
+
+    /* ---- bring the results to the host */
+    float *hd = malloc((size_t)NROW * n * sizeof(float)), *hmt = malloc((size_t)n * sizeof(float)), *hy = malloc((size_t)n * sizeof(float));
+    REQUIRE(hd && hmt && hy, "host allocation");
+    CK(jh_download(d, 0, (int64_t)NROW * n, hd));
+    CK(jh_download(mt, 0, n, hmt));
+    CK(jh_download(y, 0, n, hy));
+
+    /* ---- the oracle on the same seeded inputs */
+    float *oa = malloc((size_t)NROW * n * sizeof(float)), *om = malloc((size_t)n * sizeof(float));
+    float *od = malloc((size_t)NROW * n * sizeof(float)), *omt = malloc((size_t)n * sizeof(float));
+    REQUIRE(oa && om && od && omt, "host allocation");
+    jo_rng_u01(JO_F32, 1, 0, 0, (int64_t)NROW * n, oa);
+    jo_rng_u01(JO_F32, 2, 0, 0, n, om);
+    jo_block ops[NROW];
+    void *d_arrays[NROW];
+    const void *m_arrays[1] = {om};
+    memset(ops, 0, sizeof ops);
+    for (int i = 0; i < NROW; i++) {
+        ops[i].kind = JO_OP_DIAG;
+        ops[i].coeff = oa + (size_t)i * n;
+        ops[i].nr = ops[i].nc = n;
+        d_arrays[i] = od + (size_t)i * n;
+    }
+    for (int64_t k = 0; k < NROW * n; k++) od[k] = 7.0f;
+    for (int64_t k = 0; k < n; k++) omt[k] = 7.0f;
+    jo_block_df(JO_F32, NROW, 1, ops, d_arrays, m_arrays);
+    void *mt_arrays[1] = {omt};
+    jo_block_df_adj(JO_F32, NROW, 1, ops, mt_arrays, (const void *const *)d_arrays);
+
+    REQUIRE(memcmp(hd, od, (size_t)NROW * n * sizeof(float)) == 0, "forward bit-exact vs oracle");
+    REQUIRE(memcmp(hmt, omt, (size_t)n * sizeof(float)) == 0, "adjoint bit-exact vs oracle");
+    REQUIRE(memcmp(hy, omt, (size_t)n * sizeof(float)) == 0, "fused A'A bit-exact vs the unfused pair");
+    int64_t olens[NROW];
+    for (int i = 0; i < NROW; i++) olens[i] = n;
+    const double onrm = jo_barr_norm(JO_F32, NROW, (const void *const *)d_arrays, olens, 2.0);
+    double ore = 0, oim = 0, omn = 0, omx = 0;
+    jo_barr_dot(JO_F32, NROW, (const void *const *)d_arrays, (const void *const *)d_arrays, olens, &ore, &oim);
+    jo_barr_extrema(JO_F32, NROW, (const void *const *)d_arrays, olens, &omn, &omx);
+    REQUIRE(fabs(nrm - onrm) <= 1e-5 * onrm, "norm within 1e-5");
+    REQUIRE(fabs(dre - ore) <= 1e-5 * fabs(ore), "dot within 1e-5");
+    REQUIRE(mn == omn && mx == omx, "extrema exact");
+
+    /* ---- dot-product test (src/Jets.jl:1211-1226): <m, A'd> == <A m, d> */
+    double lhs = 0, rhs = 0, tmp = 0;
+    CK(jh_dot(m, mt, &lhs, &tmp));
+    rhs = dre;
+    REQUIRE(fabs(lhs - rhs) <= 1e-5 * fabs(lhs + rhs), "dot-product test");
+
+    /* ---- errors come back as status codes + a message, never as a crash */
+    REQUIRE(jh_blockop_mul(A, m, m) == JH_ERR_INVALID, "length mismatch is reported");
+    REQUIRE(strlen(jh_last_error()) > 0, "error message is set");
+    REQUIRE(jh_setblock_fill(d, NROW, 0.0, 0.0) == JH_ERR_INVALID, "block index out of range is reported");
+
+    /* ---- getblock! / setblock! round trip through a host block (src/Jets.jl:915-916) */
+    CK(jh_setblock_fill(d, 3, 2.5, 0.0));
+    CK(jh_getblock_copy(d, 3, hy, 0));
+    for (int64_t k = 0; k < n; k++) REQUIRE(hy[k] == 2.5f, "setblock!(d, 4, 2.5); getblock!(d, 4, out)");
+    CK(jh_setblock_copy(d, 5, hmt, 0));
+    CK(jh_getblock_copy(d, 5, hy, 0));
+    REQUIRE(memcmp(hy, hmt, (size_t)n * sizeof(float)) == 0, "setblock!(d, 6, array) round trip");
+
+    CK(jh_blockop_destroy(A));
+    CK(jh_bvec_destroy(coeff));
+    CK(jh_bvec_destroy(d));
+    CK(jh_bvec_destroy(m));
+    CK(jh_bvec_destroy(mt));
+    CK(jh_bvec_destroy(y));
+    CK(jh_shutdown());
+    free(hd); free(hmt); free(hy); free(oa); free(om); free(od); free(omt);
+    printf("forward, adjoint, fused A'A: bit-exact vs oracle; norm/dot within 1e-5; dot-product test %.6e ~ %.6e\n", lhs, rhs);
+    printf("C HOST OK\n");
+    return 0;
+}
