@@ -1075,6 +1075,72 @@ int loop_adj(const jh_blockop *op, void *m, const void *d)           // JetBlock
     return JH_OK;
 }
 
+void drop_loop_graphs(const jh_blockop *op)
+{
+    for (auto &g : op->loop_graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    op->loop_graphs.clear();
+}
+
+// The per-block loop is launch-bound for small blocks (one child launch + one accumulate launch per non-zero block, each a
+// few microseconds of work).  The first call with a given (output, input) pair runs eagerly (it sizes the scratch and
+// partial buffers), the second is captured into a hipGraph, later calls replay it with ONE launch.  A graph holds raw
+// pointers, so it is keyed on the vectors' addresses, dropped when the context's scratch buffers move (buf_gen) or the
+// operator is re-pointed, and never built while the caller is itself capturing the stream.  Knob: jh_tune_set("graphs", 0).
+template <typename F>
+int run_loop_graphed(const jh_blockop *op, int mode, const void *out, const void *in, F &&body)
+{
+    jh_context &c = jh_ctx();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (!c.graphs || !op->launch_bound || hipStreamIsCapturing(c.stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return body();
+    jh_blockop::LoopGraph *g = nullptr;
+    for (auto &e : op->loop_graphs)
+        if (e.out == out && e.in == in && e.mode == mode) { g = &e; break; }
+    if (g && g->exec && g->gen == c.buf_gen) {
+        JH_CHECK_HIP(hipGraphLaunch(g->exec, c.stream));
+        c.graph_replays++;
+        return JH_OK;
+    }
+    if (g && g->exec) {                                    // stale: the scratch buffers moved since the capture
+        (void)hipGraphExecDestroy(g->exec);
+        g->exec = nullptr;
+        g->seen = 0;
+    }
+    if (!g) {
+        if (op->loop_graphs.size() >= 8) {                 // solvers cycle through a handful of vectors; keep the table small
+            if (op->loop_graphs.front().exec) (void)hipGraphExecDestroy(op->loop_graphs.front().exec);
+            op->loop_graphs.erase(op->loop_graphs.begin());
+        }
+        op->loop_graphs.push_back(jh_blockop::LoopGraph{out, in, mode, 0, 0, nullptr});
+        g = &op->loop_graphs.back();
+    }
+    if (g->seen < 1) {
+        g->seen++;
+        return body();
+    }
+    const uint64_t gen0 = c.buf_gen;
+    if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return body();
+    }
+    const int st = body();
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(c.stream, &graph);
+    hipGraphExec_t exec = nullptr;
+    if (st == JH_OK && e == hipSuccess && graph && c.buf_gen == gen0 && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        g->exec = exec;
+        g->gen = gen0;
+        JH_CHECK_HIP(hipGraphLaunch(exec, c.stream));
+        c.graph_replays++;
+        return JH_OK;
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    g->seen = -1000000;                                    // not capturable (a buffer had to grow, or an error): stay eager
+    return body();
+}
+
 int check_vectors(const jh_blockop *op, const jh_bvec *rng, const jh_bvec *dom, const char *who)
 {
     JH_REQUIRE(op && rng && dom, "%s: null argument", who);
@@ -1198,6 +1264,7 @@ int jh_blockop_destroy(jh_blockop *op)
 {
     if (!op) return JH_OK;
     if (jh_ctx().ready) (void)hipStreamSynchronize(jh_ctx().stream);
+    drop_loop_graphs(op);
     if (op->dev_blocks) (void)hipFree(op->dev_blocks);
     if (op->dev_row_off) (void)hipFree(op->dev_row_off);
     if (op->dev_col_off) (void)hipFree(op->dev_col_off);
@@ -1213,7 +1280,8 @@ int jh_blockop_point(jh_blockop *op, const jh_bvec *mo)
     JH_REQUIRE(mo->length == op->col_off[(size_t)op->ncol], "jh_blockop_point: point has %lld elements, operator domain has %lld",
                (long long)mo->length, (long long)op->col_off[(size_t)op->ncol]);
     op->pointed = true;
-    if (!op->nonlinear) return JH_OK;                                   // linear children ignore the point (upstate! default, 176)
+    if (!op->nonlinear) return JH_OK;
+    drop_loop_graphs(op);                                               // captured loops hold the old point                                   // linear children ignore the point (upstate! default, 176)
     const size_t es = jh_dtype_size(op->dtype);
     std::vector<jh_dev_block> host(op->blocks.size());
     for (int64_t j = 0; j < op->ncol; j++)                              // (1062)
@@ -1238,7 +1306,7 @@ int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
 {
     JH_TRY(jh_require_ready());
     JH_TRY(check_vectors(op, d, m, "jh_blockop_f"));
-    if (!op->elementwise) return loop_fwd(op, d->data, m->data, true);
+    if (!op->elementwise) return run_loop_graphed(op, 2, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data, true); });
     switch (op->dtype) {
     case JH_F32: return general_fwd<float, 1>(op, d->data, m->data, 1);
     case JH_F64: return general_fwd<double, 1>(op, d->data, m->data, 1);
@@ -1263,7 +1331,7 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
         case JH_C64: return launch_tall_fwd<double, 2, 2>(op, d->data, m->data, 2 * n);
         }
     }
-    if (!op->elementwise) return loop_fwd(op, d->data, m->data);
+    if (!op->elementwise) return run_loop_graphed(op, 0, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data); });
     switch (op->dtype) {
     case JH_F32: return general_fwd<float, 1>(op, d->data, m->data);
     case JH_F64: return general_fwd<double, 1>(op, d->data, m->data);
@@ -1288,7 +1356,7 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
         case JH_C64: return launch_tall_adj<double, 2, 2, 0>(op, m->data, d->data, 2 * n);
         }
     }
-    if (!op->elementwise) return loop_adj(op, m->data, d->data);
+    if (!op->elementwise) return run_loop_graphed(op, 1, m->data, d->data, [&] { return loop_adj(op, m->data, d->data); });
     switch (op->dtype) {
     case JH_F32: return general_adj<float, 1>(op, m->data, d->data);
     case JH_F64: return general_adj<double, 1>(op, m->data, d->data);

@@ -33,6 +33,7 @@ int jh_ensure_partials(int64_t n)
     }
     JH_CHECK_HIP(hipMalloc((void **)&c.part_dev, sizeof(double) * (size_t)cap));
     c.part_cap = cap;
+    c.buf_gen++;
     return JH_OK;
 }
 
@@ -50,6 +51,7 @@ int jh_ensure_scratch(size_t bytes, void **out)
         }
         JH_CHECK_HIP(hipMalloc(&c.scratch_dev, cap));
         c.scratch_cap = cap;
+        c.buf_gen++;
     }
     *out = c.scratch_dev;
     return JH_OK;
@@ -414,6 +416,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "fwd_order")) { JH_REQUIRE(value >= -1 && value <= 65536, "fwd_order must be -1 (auto), 0 (sequential), 1 (all rows) or k > 1 (k row groups per band)"); c.fwd_order = value; }
     else if (!strcmp(name, "nt")) { c.nt = value ? 1 : 0; }
     else if (!strcmp(name, "autotune")) { c.autotune = value ? 1 : 0; }
+    else if (!strcmp(name, "graphs")) { c.graphs = value ? 1 : 0; }
     else if (!strcmp(name, "red_wgs")) { JH_REQUIRE(value >= 1 && value <= 1 << 20, "red_wgs out of range"); c.red_wgs = value; }
     else return jh_fail(JH_ERR_INVALID, "jh_tune_set: unknown knob '%s'", name);
     return JH_OK;
@@ -432,6 +435,8 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "fwd_order")) *value = c.fwd_order;
     else if (!strcmp(name, "nt")) *value = c.nt;
     else if (!strcmp(name, "autotune")) *value = c.autotune;
+    else if (!strcmp(name, "graphs")) *value = c.graphs;
+    else if (!strcmp(name, "graph_replays")) *value = c.graph_replays;
     else if (!strcmp(name, "red_wgs")) *value = c.red_wgs;
     else if (!strcmp(name, "last_fwd_walk")) *value = c.last_fwd_walk;
     else return jh_fail(JH_ERR_INVALID, "jh_tune_get: unknown knob '%s'", name);

@@ -51,6 +51,9 @@ struct jh_context {
     int64_t fwd_order = -1;            // -1: automatic; 0: sequential row sweep; 1: all row groups concurrent; k>1: bands of k row groups
     int64_t nt = 1;                    // nontemporal loads/stores on the streamed operands
     int64_t autotune = 1;              // time both grid walks of the tall forward once per large operator
+    int64_t graphs = 1;                // replay launch-bound per-block loops as hipGraphs (jh_blockop.hip: run_loop_graphed)
+    int64_t graph_replays = 0;         // read-only counter: hipGraphLaunch calls made by run_loop_graphed
+    uint64_t buf_gen = 0;              // bumped whenever part_dev / scratch_dev is reallocated: captured graphs holding the old pointers are stale
     int64_t red_wgs = 16384;           // workgroups of a reduction launch (4 packs per lane in flight); profiles/sweep_r01_reduce.txt
     int64_t last_fwd_walk = 0;         // grid walk used by the most recent tall forward launch (read-only knob)
 };
@@ -109,9 +112,13 @@ struct jh_blockop {
     bool uniform_rows = false;               // all row_len equal
     bool all_diag = false;                   // every block is an un-adjointed... DIAG (adjoint flag irrelevant up to conj)
     bool elementwise = false;                // no DENSE block
+    bool launch_bound = true;                // every DENSE block <= 128 x 128: the per-block loop is replayed as a hipGraph
     bool nonlinear = false;                  // has a SQUARE block (JopNl child)
     bool pointed = false;                    // jh_blockop_point has been called (SQUARE blocks have their mo)
     bool diag_strided = false;               // coeff[i] = coeff[0] + i*stride bytes
+    // hipGraph replay of the per-block loop (operators with DENSE blocks: 2 launches per block), keyed on the vectors' addresses
+    struct LoopGraph { const void *out; const void *in; int mode; int seen; uint64_t gen; hipGraphExec_t exec; };
+    mutable std::vector<LoopGraph> loop_graphs;
     mutable int fwd_walk = -1;               // autotuned tall-forward shape: -1 untried, 0 sequential 1024x8x16, 1 all rows 512x1x2, 2 sequential 256x4x4
     mutable int upd_walk = -1;               // same for the fused forward update (timed on its first two real calls)
     mutable int upd_trials = 0;

@@ -347,3 +347,4 @@ def test_dense_operator_shapes(Jets, dt, tol, nr, nc):
     assert np.linalg.norm(adj - refa) <= tol * scalea
     lhs, rhs = Jets.dot_product_test(A, Jets.from_numpy(hx), Jets.from_numpy(hy))
     assert abs(lhs - rhs) <= 50 * tol * max(abs(lhs), scalea * np.linalg.norm(hx) / max(nc, 1) ** 0.5)
+
