@@ -236,11 +236,16 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t_l = float(tt.item())
         err = (res.x - x_true).materialize()
-        it_bytes = (5 * nblocks * n + 11 * n * world) * s   # whole job: fwd half 3Nn+n, adj half 2Nn+2n, x/w/v updates ~8n per rank
+        one_pass = os.environ.get("JETS_LSQR_FUSED_STEP", "1") != "0"
+        # whole job per iteration.  one pass (jh_blockop_bidiag_step): read a, read u, write u = 3Nn, + v, w and the x/w/v updates
+        # (~12n per rank); two halves: forward 3Nn+n, adjoint 2Nn+2n, updates ~8n per rank
+        it_bytes = ((3 if one_pass else 5) * nblocks * n + (12 if one_pass else 11) * n * world) * s
         extra["lsqr"] = {"iterations": res.itn, "ms_per_iteration": 1e3 * t_l / max(res.itn, 1), "algorithmic_bytes_per_iteration": it_bytes,
                          "GBps": it_bytes * res.itn / t_l / 1e9, "rel_err_vs_x_true": float(J.norm(err)) / float(J.norm(x_true)),
                          "istop": res.istop, "r1norm_first_last": [res.history[0][1], res.history[-1][1]],
-                         "schedule": "fused: u<-Av-(alpha/beta)u with ||u||^2 (jh_blockop_mul_axpby), v<-A'u/beta-beta v with ||v||^2 (jh_blockop_mul_adj_axpby); u never normalised in memory"}
+                         "schedule": ("one pass per iteration (jh_blockop_bidiag_step): u<-Av-(alpha/beta)u, ||u||^2 and A'u together; v<-A'u/beta-beta v on domain-sized vectors"
+                                      if one_pass else "two fused halves: u<-Av-(alpha/beta)u with ||u||^2 (jh_blockop_mul_axpby), v<-A'u/beta-beta v with ||v||^2 (jh_blockop_mul_adj_axpby)")
+                                     + "; u never normalised in memory"}
 
     if rank == 0:
         pairs_per_s = args.steps / elapsed

@@ -196,6 +196,13 @@ int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *
 int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double alpha, double beta, double *normsq);
 int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double alpha, double beta, double in_scale,
                              double *normsq);
+/* One Golub-Kahan / LSQR step over vec(A) (src/Jets.jl:1138-1154) in ONE pass over the operator and the range vector:
+ *   u <- alpha*(A v) + beta*u ;   w <- A' u (the new u) ;   *normsq = ||u||^2
+ * i.e. jh_blockop_mul_axpby(op, u, v, alpha, beta, normsq) followed by jh_blockop_mul_adj(op, w, u), with u and w
+ * bit-identical to that sequence, but every coefficient and every element of u is read once and u written once:
+ * (3*N*n + 2*n)*s bytes instead of (5*N*n + 3*n)*s.  The solver then forms v <- w/||u|| - ||u||*v on domain-sized vectors
+ * (A' is linear, so the normalisation of u can follow the pass).  Tall all-DIAG operators; w must not alias v. */
+int jh_blockop_bidiag_step(const jh_blockop *op, jh_bvec *u, const jh_bvec *v, jh_bvec *w, double alpha, double beta, double *normsq);
 /* ---------------------------------------------------------------- RCCL over xGMI ----------- */
 /* Row partition of a tall operator across the GPUs of a node (one process per GPU): the forward needs no exchange
  * (src/Jets.jl:1015-1031), the adjoint is a sum over rows (1045-1053) -> one in-place all-reduce of the domain vector

@@ -100,6 +100,7 @@ SYMBOLS = {
     "jh_blocksum_mul_adj": (_int, [_int, _vpp, _dblp, _dblp, _vp, _vp]),
     "jh_blockop_mul_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
     "jh_blockop_mul_adj_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _dblp]),
+    "jh_blockop_bidiag_step": (_int, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
     "jh_comm_unique_id": (_int, [_vp]),
     "jh_comm_init_rank": (_int, [_vp, _int, _int]),
     "jh_comm_destroy": (_int, []),

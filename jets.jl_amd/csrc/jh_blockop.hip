@@ -310,6 +310,81 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block
     wg_sum_store<BLK>(nrm, partials + blockIdx.x);
 }
 
+// One Golub-Kahan (LSQR) step in ONE pass over the operator and the range vector:
+//   u_i <- alpha * (a_i .* v) + beta * u_i        (the forward half: jh_blockop_mul_axpby)
+//   w   <- sum_i conj(a_i) .* u_i  (new u, rows in order, product rounded then added: jh_blockop_mul_adj)
+//   partial ||u||^2
+// A thread owns U 16-byte vectors of the DOMAIN (v and the accumulator stay in registers) and walks all rows with DEPTH rows
+// in flight; every coefficient and every element of u is read once, u is written once: (3*N*n + 2*n)*s bytes where the two
+// separate halves move (5*N*n + 3*n)*s.  u and w come out bit-identical to the two-kernel sequence.
+template <typename S, int E, int NS, int U, int DEPTH, int BLK>
+__global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__restrict__ blocks, int64_t nrow,
+                                                          const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ u,
+                                                          const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, int direct,
+                                                          S alpha, S beta, double *__restrict__ partials)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t s0 = ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
+    bool ok[U];
+    int64_t sk[U];
+    V acc[U], vv[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
+        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
+        acc[k] = (V)(S)0;
+        vv[k] = ld<false>(reinterpret_cast<const V *>(v + sk[k]));
+    }
+    const bool use_old = (beta != (S)0);
+    double nrm = 0.0;
+    int64_t i = 0;
+    for (; !direct && i + DEPTH <= nrow; i += DEPTH) {
+        V av[DEPTH][U], uv[DEPTH][U];
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            const S *a = a_base ? a_base + (i + j) * a_stride : (const S *)blocks[i + j].coeff;
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                av[j][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+                uv[j][k] = use_old ? ld<true>(reinterpret_cast<const V *>(u + (i + j) * n_scalars + sk[k])) : (V)(S)0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                V t = vmul<S, E, NS, V>(av[j][k], vv[k], false);       // mul!(tmp, A_i, v)
+                V r = (V)alpha * t;
+                if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; }  // u_i .= alpha*tmp .+ beta*u_i
+                if (ok[k]) {
+                    st<true>(reinterpret_cast<V *>(u + (i + j) * n_scalars + sk[k]), r);
+                    nrm += vnorm2<S, NS, V>(r);
+                }
+                acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, true);  // _m .+= conj(a_i) .* u_i   (1049)
+            }
+    }
+    for (; i < nrow; i++) {
+        const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            V av = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+            V t = vmul<S, E, NS, V>(av, vv[k], false);
+            V r = (V)alpha * t;
+            if (use_old) { V s2 = (V)beta * ld<true>(reinterpret_cast<const V *>(u + i * n_scalars + sk[k])); r = r + s2; }
+            if (ok[k]) {
+                st<true>(reinterpret_cast<V *>(u + i * n_scalars + sk[k]), r);
+                nrm += vnorm2<S, NS, V>(r);
+            }
+            V p = vmul<S, E, NS, V>(av, r, true);
+            acc[k] = direct ? p : acc[k] + p;                            // nrow == 1 writes directly (1051)
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++)
+        if (ok[k]) st<false>(reinterpret_cast<V *>(w + sk[k]), acc[k]);
+    wg_sum_store<BLK>(nrm, partials + blockIdx.x);
+}
+
 // fold the per-workgroup partials deterministically: workgroup b sums the contiguous chunk
 // [b*chunk, (b+1)*chunk) in a fixed order and writes out[b]; launched twice for large counts (1M -> 1024 -> 1)
 __global__ void k_sum_partials(const double *__restrict__ partials, int64_t n, int64_t chunk, double *__restrict__ out)
@@ -998,6 +1073,41 @@ int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n
     return finish_normsq(gx, normsq);
 }
 
+template <typename S, int E, int NS>
+int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t n_scalars, double alpha, double beta, double *normsq)
+{
+    jh_context &c = jh_ctx();
+    const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
+    const int64_t a_stride = op->diag_stride_elems * E;
+    const int64_t nvec = n_scalars / NS;
+    const int direct = op->nrow == 1 ? 1 : 0;
+    // profiles/bench_lsqr_step_r01.txt: 1024 x 256^3 wants thin threads with many rows in flight (512 x 1 x 4: 6.13 TB/s),
+    // 128 x 256^3 fat ones (512 x 4 x 2: 5.46), 64 x 128^3 256 x 4 x 1 (5.9)
+    int wg = 256, U = 1, D = 4;
+    if (nvec >= 4 * 256 * 256) { U = 4; D = 1; }
+    else if (nvec >= 2 * 256 * 256) { U = 2; D = 2; }
+    if (nvec >= ((int64_t)1 << 22)) { wg = 512; U = 4; D = 2; }
+    if (nvec >= ((int64_t)1 << 22) && op->nrow >= 512) { U = 1; D = 4; }
+    if (c.adj_wg) wg = (int)c.adj_wg;                       // the adjoint's knobs select among the instantiated shapes
+    if (c.adj_unroll) U = (int)c.adj_unroll;
+    if (c.adj_depth) D = (int)c.adj_depth;
+    const int64_t gx = (nvec + (int64_t)wg * U - 1) / ((int64_t)wg * U);
+    JH_TRY(jh_ensure_partials(gx));
+#define JH_LAUNCH(BLK, UU, DD)                                                                                          \
+    if (wg == BLK && U == UU && D == DD) {                                                                              \
+        hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK>), dim3((unsigned)gx), dim3(BLK), 0, c.stream,      \
+                           op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars, direct,  \
+                           (S)alpha, (S)beta, c.part_dev);                                                               \
+        JH_CHECK_HIP(hipGetLastError());                                                                                 \
+        return finish_normsq(gx, normsq);                                                                                \
+    }
+    JH_LAUNCH(256, 1, 4) JH_LAUNCH(256, 2, 2) JH_LAUNCH(256, 4, 1) JH_LAUNCH(256, 4, 2) JH_LAUNCH(256, 1, 8)
+    JH_LAUNCH(512, 1, 4) JH_LAUNCH(512, 2, 2) JH_LAUNCH(512, 4, 1) JH_LAUNCH(512, 4, 2) JH_LAUNCH(512, 1, 8)
+    JH_LAUNCH(1024, 1, 4) JH_LAUNCH(1024, 2, 2) JH_LAUNCH(1024, 4, 1)      // 1024 x 4 x 2 would need > 128 VGPRs per lane
+#undef JH_LAUNCH
+    return jh_fail(JH_ERR_INVALID, "fused bidiagonalisation step: shape %d x %d x %d is not instantiated", wg, U, D);
+}
+
 // ---- per-block loop (operators containing DENSE blocks): the reference's loops (src/Jets.jl:1010-1057)
 // with device temporaries -- one child launch (+ one accumulate launch) per non-zero block.
 int child_apply(int dtype, const jh_block_desc &b, void *out, const void *in, bool transposed, bool fmode = false)
@@ -1498,6 +1608,24 @@ int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *
     case JH_C64: return sum_adj_launch<double, 2, 2>(a, ops[0], m->data, d->data, 2 * n);
     }
     return jh_fail(JH_ERR_INVALID, "jh_blocksum_mul_adj: unknown dtype");
+}
+
+int jh_blockop_bidiag_step(const jh_blockop *op, jh_bvec *u, const jh_bvec *v, jh_bvec *w, double alpha, double beta, double *normsq)
+{
+    JH_TRY(jh_require_ready());
+    JH_TRY(check_vectors(op, u, v, "jh_blockop_bidiag_step"));
+    JH_REQUIRE(w && w->dtype == op->dtype && w->length == v->length, "jh_blockop_bidiag_step: w must be a domain vector of the operator");
+    JH_REQUIRE(w->data != v->data, "jh_blockop_bidiag_step: w must not alias v");
+    if (!tall_fast_ok(op, u->data, v->data) || (((uintptr_t)w->data) & 15u))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_bidiag_step: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
+    const int64_t n = op->row_len[0];
+    switch (op->dtype) {
+    case JH_F32: return launch_bidiag<float, 1, 4>(op, u->data, v->data, w->data, n, alpha, beta, normsq);
+    case JH_F64: return launch_bidiag<double, 1, 2>(op, u->data, v->data, w->data, n, alpha, beta, normsq);
+    case JH_C32: return launch_bidiag<float, 2, 4>(op, u->data, v->data, w->data, 2 * n, alpha, beta, normsq);
+    case JH_C64: return launch_bidiag<double, 2, 2>(op, u->data, v->data, w->data, 2 * n, alpha, beta, normsq);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blockop_bidiag_step: unknown dtype %d", op->dtype);
 }
 
 int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double alpha, double beta, double *normsq)

@@ -7,18 +7,20 @@ sparse linear equations and sparse least squares", ACM TOMS 8(1), 1982), checked
 restatement in oracle/lsqr_ref.py (LSQR parity is otherwise unpinned).
 
 Per iteration it needs   u <- A v - alpha u, ||u||   and   v <- A'u - beta v, ||v||.
-For a device-native tall block operator each half is ONE fused kernel (jh_blockop_mul_axpby /
-jh_blockop_mul_adj_axpby): no temporary range vector, no separate axpby or norm pass.  The big range-side
-vector u is never normalised in memory -- its scale 1/beta is carried into the next two updates -- which
-removes another read+write of the range vector per iteration.  Algorithmic HBM bytes per iteration for an
-N x 1 operator of n-element blocks of s bytes:  forward half 3*N*n*s + n*s (a, u in, u out, v), adjoint half
-2*N*n*s + 2*n*s; the small domain-side updates (x, w, v: 3 vectors of n) add ~8*n*s.  Any other operator
-runs the same recurrences through mul!, one fused broadcast and one norm per half.
+For a device-native tall block operator BOTH happen in ONE pass over the operator and the range vector
+(jh_blockop_bidiag_step): u <- A v - (alpha/beta) u, ||u||^2 and w = A'u (un-normalised) together, then
+v <- w/||u|| - ||u|| v on domain-sized vectors (A' is linear, so the normalisation follows the pass).  The big
+range-side vector u is never normalised in memory -- its scale 1/beta is carried into the next update.
+Algorithmic HBM bytes per iteration for an N x 1 operator of n-element blocks of s bytes: 3*N*n*s (a, u in, u out)
++ ~12*n*s for the domain-side vectors.  JETS_LSQR_FUSED_STEP=0 selects the older schedule of two fused halves
+(jh_blockop_mul_axpby 3*N*n*s + jh_blockop_mul_adj_axpby 2*N*n*s).  Any other operator runs the same recurrences
+through mul!, one fused broadcast and one norm per half.
 """
 from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 from ._ffi import lib, check, JetsHipError
 from . import arrays as _arr
@@ -66,6 +68,7 @@ class _Engine:
                 self.native = nat
         self._tmp_r = None
         self._tmp_d = None
+        self.fused_step = os.environ.get("JETS_LSQR_FUSED_STEP", "1") != "0"   # one pass per iteration (jh_blockop_bidiag_step)
 
     # --- vector algebra
     def zeros_dom(self):
@@ -107,6 +110,28 @@ class _Engine:
         """u <- alpha*(A v) + beta*u ; returns ||u||."""
         return math.sqrt(self._fwd_local(u, v, alpha, beta))
 
+    def _step_local(self, u, v, alpha, beta):
+        """One pass: u <- alpha*(A v) + beta*u and w <- A'u (new u, un-normalised).  Returns (LOCAL ||u||^2, w) or None
+        when the operator has no fused step (then lsqr_core runs the two halves separately)."""
+        if self.native is None or not self.fused_step:
+            return None
+        if self._tmp_d is None:
+            self._tmp_d = zeros(_j.domain(self.A))
+        out = C.c_double(0)
+        try:
+            check(lib.jh_blockop_bidiag_step(self.native.handle, u.handle, v.handle, self._tmp_d.handle, float(alpha), float(beta), C.byref(out)))
+        except JetsHipError as e:
+            if e.status != 4:
+                raise
+            self.fused_step = False
+            return None
+        return out.value, self._tmp_d
+
+    def step(self, u, v, alpha, beta):
+        """u <- alpha*(A v) + beta*u ; w <- A'u.  Returns (||u||, w) or None."""
+        r = self._step_local(u, v, alpha, beta)
+        return None if r is None else (math.sqrt(r[0]), r[1])
+
     def adj(self, v, u, alpha, beta) -> float:
         """v <- alpha*(A' u) + beta*v ; returns ||v||."""
         if self.native is not None:
@@ -139,6 +164,13 @@ class _ShardEngine(_Engine):
 
     def fwd(self, u, v, alpha, beta) -> float:
         return math.sqrt(self.shard.comm.all_reduce_scalars([self._fwd_local(u, v, alpha, beta)], "sum")[0])
+
+    def step(self, u, v, alpha, beta):
+        r = self._step_local(u, v, alpha, beta)          # this rank's rows: local ||u||^2 and local A'u
+        if r is None:
+            return None
+        self.shard.comm.all_reduce_sum_(r[1])            # ONE vector all-reduce per iteration, as before
+        return math.sqrt(self.shard.comm.all_reduce_scalars([r[0]], "sum")[0]), r[1]
 
     def adj(self, v, u, alpha, beta) -> float:
         if self._tmp_d is None:
@@ -202,16 +234,27 @@ def lsqr_core(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b=False, 
     eps = 2.220446049250313e-16
     ctol = 1.0 / conlim if conlim > 0 else 0.0
 
+    step = getattr(eng, "step", None)
     while itn < maxiter:
         itn += 1
         # --- bidiagonalisation:  beta*u = A v - alpha*u ;  alpha*v = A'u - beta*v
         beta_prev = beta
-        beta = eng.fwd(u, v, 1.0, -alpha / beta_prev)    # u_hat <- A v - alpha * (u_hat / beta_prev)
-        if beta > 0:
-            anorm = math.sqrt(anorm ** 2 + alpha ** 2 + beta ** 2 + damp ** 2)
-            alpha = eng.adj(v, u, 1.0 / beta, -beta)     # v <- A'(u_hat / beta) - beta v
-            if alpha > 0:
-                eng.lincomb(v, [1.0 / alpha], [v])
+        fused = step(u, v, 1.0, -alpha / beta_prev) if step is not None else None
+        if fused is not None:                            # one pass over A and u: u_hat and A'u_hat together
+            beta, atu = fused
+            if beta > 0:
+                anorm = math.sqrt(anorm ** 2 + alpha ** 2 + beta ** 2 + damp ** 2)
+                eng.lincomb(v, [1.0 / beta, -beta], [atu, v])      # v <- A'(u_hat) / beta - beta v   (A' is linear)
+                alpha = eng.norm_dom(v)
+                if alpha > 0:
+                    eng.lincomb(v, [1.0 / alpha], [v])
+        else:
+            beta = eng.fwd(u, v, 1.0, -alpha / beta_prev)    # u_hat <- A v - alpha * (u_hat / beta_prev)
+            if beta > 0:
+                anorm = math.sqrt(anorm ** 2 + alpha ** 2 + beta ** 2 + damp ** 2)
+                alpha = eng.adj(v, u, 1.0 / beta, -beta)     # v <- A'(u_hat / beta) - beta v
+                if alpha > 0:
+                    eng.lincomb(v, [1.0 / alpha], [v])
         # --- eliminate the damping parameter
         rhobar1 = math.sqrt(rhobar ** 2 + damp ** 2)
         cs1, sn1 = rhobar / rhobar1, damp / rhobar1

@@ -236,6 +236,14 @@ function mul_adj_axpby!(v::HipArray{T}, A::JopLn, u::HipBlockArray{T}, alpha::Re
     sqrt(nrm2[])
 end
 
+# one whole Golub-Kahan step in one pass: u <- alpha*(A v) + beta*u ; w <- A'u ; returns ||u||   (3/5 of the bytes of the two halves)
+function bidiag_step!(u::HipBlockArray{T}, w::HipArray{T}, A::JopLn, v::HipArray{T}, alpha::Real, beta::Real) where {T}
+    nrm2 = Ref{Cdouble}()
+    check(ccall((:jh_blockop_bidiag_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Ref{Cdouble}),
+                native_handle(state(A).ops, T), u.handle, v.handle, w.handle, alpha, beta, nrm2))
+    sqrt(nrm2[])
+end
+
 # one process per GPU: rank 0 makes the id, the host (MPI.jl, sockets, a file) ships it, every rank joins
 comm_unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:jh_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id)); id)
 comm_init(id::Vector{UInt8}, nranks::Integer, rank::Integer) = check(ccall((:jh_comm_init_rank, LIB), Cint, (Ptr{UInt8}, Cint, Cint), id, nranks, rank))

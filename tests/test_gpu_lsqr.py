@@ -212,3 +212,103 @@ def test_ranged_adjoint_equals_whole_adjoint(Jets, oracle, dt):
             check(lib.jh_blockop_mul_adj_range(nat.handle, parts.handle, d.handle, 1, 4))   # chunk start off a 16-byte boundary
     with pytest.raises(Jets.JetsHipError):
         check(lib.jh_blockop_mul_adj_range(nat.handle, parts.handle, d.handle, n - 4, 8))   # past the end
+
+
+# ---------------------------------------------------------------------------------- one-pass Golub-Kahan step
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,shape,beta", [(4, (8, 8, 4), -1.375), (3, (100, 100, 27), 0.5), (2, (128, 128, 33), -2.0), (1, (64,), 0.25),
+                                             (5, (1 << 20,), -1.375), (7, (40, 40, 12), 0.0), (9, (1 << 18,), -0.3)])
+def test_bidiag_step_bit_exact_vs_the_two_halves(Jets, oracle, dt, nrow, shape, beta):
+    """jh_blockop_bidiag_step == jh_blockop_mul_axpby then jh_blockop_mul_adj, in one pass: u and w BIT-EXACT against the
+    oracle's unfused chain (block loop into a temporary, broadcast, adjoint block loop), ||u||^2 within 1e-6 / 1e-13."""
+    from jets_jl_amd._ffi import lib, check
+
+    A, _, ops, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    nat = _native(Jets, A)
+    alpha = 0.75
+    v = Jets.rand(Jets.domain(A), seed=51, stream=0)
+    u = Jets.rand(Jets.range(A), seed=52, stream=0)
+    w = Jets.rand(Jets.domain(A), seed=53, stream=0)                                  # dirty: must be overwritten
+    hv, hu = u01(oracle, dt, 51, 0, n), u01(oracle, dt, 52, 0, nrow * n)
+    hu_blocks = [hu[i * n:(i + 1) * n].copy() for i in range(nrow)]
+    out = C.c_double(0)
+    check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, alpha, beta, C.byref(out)))
+    tmp = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [hv])
+    if beta != 0.0:
+        ref_u = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [alpha, beta], [tmp, hu_blocks])
+    else:
+        ref_u = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [alpha], [tmp])     # beta == 0: u is write-only
+    assert_bits_equal(u.to_numpy(), np.concatenate(ref_u), "u <- alpha*A v + beta*u")
+    ref_w = oracle.block_df_adj(ops, [np.full(n, 5, dtype=dt)], ref_u)
+    assert_bits_equal(w.to_numpy().ravel(order="F"), ref_w[0], "w <- A'u")
+    truth = float(np.sum(np.abs(np.concatenate(ref_u).astype(np.complex128)) ** 2))
+    tol = 1e-6 if np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-13
+    assert out.value == pytest.approx(truth, rel=tol)
+
+
+@pytest.mark.parametrize("knobs", [dict(adj_wg=256, adj_unroll=1, adj_depth=4), dict(adj_wg=256, adj_unroll=2, adj_depth=2),
+                                   dict(adj_wg=256, adj_unroll=4, adj_depth=1), dict(adj_wg=256, adj_unroll=4, adj_depth=2),
+                                   dict(adj_wg=512, adj_unroll=1, adj_depth=4), dict(adj_wg=512, adj_unroll=2, adj_depth=2),
+                                   dict(adj_wg=512, adj_unroll=4, adj_depth=1), dict(adj_wg=512, adj_unroll=4, adj_depth=2),
+                                   dict(adj_wg=1024, adj_unroll=1, adj_depth=4), dict(adj_wg=1024, adj_unroll=2, adj_depth=2),
+                                   dict(adj_wg=1024, adj_unroll=4, adj_depth=1)])
+def test_bidiag_step_every_shape_gives_identical_bits(Jets, oracle, knobs):
+    from jets_jl_amd._ffi import lib, check
+
+    dt, nrow, shape = np.float32, 11, (40, 40, 12)
+    A, _, ops, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    nat = _native(Jets, A)
+    hv, hu = u01(oracle, dt, 51, 0, n), u01(oracle, dt, 52, 0, nrow * n)
+    tmp = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [hv])
+    ref_u = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [1.0, -0.625], [tmp, [hu[i * n:(i + 1) * n].copy() for i in range(nrow)]])
+    ref_w = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], ref_u)
+    saved = {k: Jets.tune_get(k) for k in knobs}
+    try:
+        Jets.tune(**knobs)
+        v = Jets.rand(Jets.domain(A), seed=51, stream=0)
+        u = Jets.rand(Jets.range(A), seed=52, stream=0)
+        w = Jets.zeros(Jets.domain(A))
+        out = C.c_double(0)
+        check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, 1.0, -0.625, C.byref(out)))
+        assert_bits_equal(u.to_numpy(), np.concatenate(ref_u), f"u {knobs}")
+        assert_bits_equal(w.to_numpy().ravel(order="F"), ref_w[0], f"w {knobs}")
+    finally:
+        Jets.tune(**saved)
+
+
+def test_bidiag_step_argument_checks(Jets, oracle):
+    from jets_jl_amd._ffi import lib
+
+    A, _, _, _ = make_tall_diag(Jets, oracle, np.float32, 3, (64,))
+    nat = _native(Jets, A)
+    u, v = Jets.zeros(Jets.range(A)), Jets.zeros(Jets.domain(A))
+    out = C.c_double(0)
+    assert lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, v.handle, 1.0, 0.0, C.byref(out)) == 1     # w aliases v
+    short = Jets.zeros(Jets.JetSpace(np.float32, 63))
+    assert lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, short.handle, 1.0, 0.0, C.byref(out)) == 1
+    spc = Jets.JetSpace(np.float32, 64)
+    B = Jets.blockop([[Jets.JopDiagonal(Jets.rand(spc))], [Jets.JopIdentity(spc)]])                              # not all-DIAG
+    assert lib.jh_blockop_bidiag_step(_native(Jets, B).handle, Jets.zeros(Jets.range(B)).handle, v.handle,
+                                      Jets.zeros(spc).handle, 1.0, 0.0, C.byref(out)) == 4                         # JH_ERR_UNSUPPORTED
+
+
+def test_lsqr_one_pass_and_two_pass_iterations_agree(Jets, oracle, monkeypatch):
+    """The solver's default (one fused pass per iteration) against the two-half schedule: same residual history and
+    solution to fp32 rounding (the adjoint half rounds conj(a)*(u/beta) vs (conj(a)*u)/beta)."""
+    dt, nrow, shape = np.float32, 6, (32, 32, 8)
+    A, _, _, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    x_true = Jets.rand(Jets.domain(A), seed=61, stream=0)
+    b = Jets.mul(A, x_true)
+    monkeypatch.setenv("JETS_LSQR_FUSED_STEP", "1")
+    r1 = Jets.lsqr(A, b, maxiter=15, atol=0.0, btol=0.0, force_maxiter=True)
+    monkeypatch.setenv("JETS_LSQR_FUSED_STEP", "0")
+    r0 = Jets.lsqr(A, b, maxiter=15, atol=0.0, btol=0.0, force_maxiter=True)
+    assert r1.itn == r0.itn == 15
+    h1, h0 = np.array([h[1] for h in r1.history]), np.array([h[1] for h in r0.history])
+    np.testing.assert_allclose(h1[:8], h0[:8], rtol=1e-3)
+    np.testing.assert_allclose(r1.x.to_numpy(), r0.x.to_numpy(), rtol=2e-4, atol=2e-5)
+    e1 = np.linalg.norm(r1.x.to_numpy() - x_true.to_numpy()) / np.linalg.norm(x_true.to_numpy())
+    e0 = np.linalg.norm(r0.x.to_numpy() - x_true.to_numpy()) / np.linalg.norm(x_true.to_numpy())
+    assert e1 == pytest.approx(e0, rel=1e-2) and e1 < 0.1                              # same convergence after 15 iterations

@@ -119,7 +119,7 @@ def test_world_size_2_forward_is_local_and_adjoint_all_reduces(tmp_path, nrow, n
 
 
 # ---------------------------------------------------------------------------------- distributed LSQR
-def _lsqr_worker(rank, world, port, nrow, n, iters, out_dir):
+def _lsqr_worker(rank, world, port, nrow, n, iters, out_dir, one_pass=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import math
@@ -179,20 +179,33 @@ def _lsqr_worker(rank, world, port, nrow, n, iters, out_dir):
             v[...] = alpha * tmp + beta * v
             return float(np.linalg.norm(v))
 
-    res = lsqr_core(NumpyShardEngine(), b_loc, None, 0.0, 0.0, 0.0, 0.0, iters)
+    class OnePassEngine(NumpyShardEngine):
+        """adds the one-pass Golub-Kahan step of lsqr._ShardEngine.step: local u update + local A'u, ONE vector
+        all-reduce and one scalar all-reduce per iteration."""
+
+        def step(self, u, v, alpha, beta):
+            tmp = jo.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(part.count)], [v])
+            for ui, ti in zip(u, tmp):
+                ui[...] = alpha * ti + beta * ui
+            w = jo.block_df_adj(ops, [np.zeros(n, dtype=dt)], u)[0]
+            comm.all_reduce_sum_(w)
+            return math.sqrt(comm.all_reduce_scalars([sum(float(np.dot(t, t)) for t in u)], "sum")[0]), w
+
+    res = lsqr_core(OnePassEngine() if one_pass else NumpyShardEngine(), b_loc, None, 0.0, 0.0, 0.0, 0.0, iters)
     np.savez(os.path.join(out_dir, f"lsqr{rank}.npz"), x=res.x, r=np.array([h[1] for h in res.history]), itn=res.itn)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_world_size_2_lsqr_matches_single_process_fp64_lsqr(tmp_path):
+@pytest.mark.parametrize("one_pass", [False, True])
+def test_world_size_2_lsqr_matches_single_process_fp64_lsqr(tmp_path, one_pass):
     import torch.multiprocessing as mp
 
     from oracle import jets_oracle as jo
     from oracle.lsqr_ref import lsqr_fp64
 
     world, port, nrow, n, iters = 2, _free_port(), 5, 64, 25
-    mp.spawn(_lsqr_worker, args=(world, port, nrow, n, iters, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_lsqr_worker, args=(world, port, nrow, n, iters, str(tmp_path), one_pass), nprocs=world, join=True)
     res = [np.load(tmp_path / f"lsqr{r}.npz") for r in range(world)]
     a = np.stack([jo.rng_u01(np.float64, 1, 0, i * n, n) + 0.05 for i in range(nrow)])
     b = np.concatenate([jo.rng_u01(np.float64, 5, 0, i * n, n) - 0.5 for i in range(nrow)])
