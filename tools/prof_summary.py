@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name: str) -> str:
-    for key in ("k_tall_diag_fwd_update", "k_tall_diag_adj_update", "k_tall_diag_fwd", "k_tall_diag_adj", "k_block_fwd_general", "k_block_adj_general", "k_uniform", "k_reduce_final",
+    for key in ("k_tall_diag_bidiag", "k_tall_diag_fwd_update", "k_tall_diag_adj_update", "k_tall_diag_fwd", "k_tall_diag_adj", "k_block_fwd_general", "k_block_adj_general", "k_uniform", "k_reduce_final",
                 "k_reduce", "k_lincomb", "k_hadamard", "k_fill", "k_gemv", "k_sum_partials"):
         if key in name:
             return key
@@ -49,18 +49,19 @@ def main():
     ap.add_argument("--edge", type=int, default=256)
     ap.add_argument("--cmd", default="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline")
     ap.add_argument("--walk", type=int, default=None, help="grid walk of the tall forward the profiled runs were pinned to (0/1)")
+    ap.add_argument("--tag", default="", help="suffix for the output file names (rocprof_<round><tag>_summary.md)")
     ap.add_argument("--merge", action="store_true", help="merge into an existing traffic_latest.json instead of replacing it")
     args = ap.parse_args()
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
     ks = glob.glob(os.path.join(args.kt, "**", "*_kernel_stats.csv"), recursive=True)[0]
-    shutil.copy(ks, os.path.join(out_dir, f"rocprof_{args.round}_kernel_stats.csv"))
+    shutil.copy(ks, os.path.join(out_dir, f"rocprof_{args.round}{args.tag}_kernel_stats.csv"))
     stats = list(csv.DictReader(open(ks)))
     fetch, nf = counters(args.fetch, "FETCH_SIZE") if args.fetch else ({}, {})
     write, nw = counters(args.write, "WRITE_SIZE") if args.write else ({}, {})
     n = args.edge ** 3
     algo = {"k_tall_diag_fwd": (2 * args.nblocks * n + n) * 4, "k_tall_diag_adj": (2 * args.nblocks * n + n) * 4,
-            "k_tall_diag_fwd_update": (3 * args.nblocks * n + n) * 4, "k_tall_diag_adj_update": (2 * args.nblocks * n + 2 * n) * 4}
+            "k_tall_diag_bidiag": (3 * args.nblocks * n + 2 * n) * 4, "k_tall_diag_fwd_update": (3 * args.nblocks * n + n) * 4, "k_tall_diag_adj_update": (2 * args.nblocks * n + 2 * n) * 4}
     lines = [f"# rocprofv3 summary, round {args.round}", "",
              f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- {args.cmd}` on one MI355X (gfx950);",
              "PMC: separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes of the same program (3 timed steps).",
@@ -82,8 +83,8 @@ def main():
             f"{ab / avg_ms / 1e6:.1f}" if ab else "-", f"{f:,.0f}" if f is not None else "-",
             f"{w:,.0f}" if w is not None else "-", f"{tr:,.0f}" if tr is not None else "-",
             f"{tr / ab:.3f}" if (tr is not None and ab) else "-"))
-    lines += ["", "Full kernel names and min/max/stddev: `rocprof_%s_kernel_stats.csv`." % args.round, ""]
-    open(os.path.join(out_dir, f"rocprof_{args.round}_summary.md"), "w").write("\n".join(lines))
+    lines += ["", "Full kernel names and min/max/stddev: `rocprof_%s%s_kernel_stats.csv`." % (args.round, args.tag), ""]
+    open(os.path.join(out_dir, f"rocprof_{args.round}{args.tag}_summary.md"), "w").write("\n".join(lines))
     tpath = os.path.join(out_dir, "traffic_latest.json")
     if args.merge and os.path.exists(tpath):
         old = json.load(open(tpath))
