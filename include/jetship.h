@@ -29,6 +29,7 @@
 #ifndef JETSHIP_H
 #define JETSHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -119,6 +120,15 @@ int jh_copy(jh_bvec *dst, const jh_bvec *src);
 /* convert(Array, x) (src/Jets.jl:862-868) and its inverse, on an element range of the slab */
 int jh_download(const jh_bvec *v, int64_t offset, int64_t count, void *host_dst);
 int jh_upload(jh_bvec *v, int64_t offset, int64_t count, const void *host_src);
+/* Page-locked host memory for the copies above.  A pageable host buffer moves through the runtime's staging copy
+ * (~9 GB/s on this box); a page-locked one is DMA'd directly at the PCIe rate.  jh_host_alloc/free give the host language a
+ * pinned buffer to wrap as an array (Julia: unsafe_wrap); jh_host_register/unregister pin an EXISTING host array in place
+ * (worth it when the same array is transferred repeatedly: pinning costs about one pageable copy).  Neither changes any
+ * result; both are optional. */
+int jh_host_alloc(size_t bytes, void **out);
+int jh_host_free(void *ptr);
+int jh_host_register(void *ptr, size_t bytes);
+int jh_host_unregister(void *ptr);
 /* rand(R) (src/Jets.jl:922-924) from the counter-based generator of SURVEY.md 8d:
  * element k = mix64(key + (k+1)*0x9E3779B97F4A7C15), key = mix64(seed*0x9E37...+stream);
  * index_base shifts k so a row-partitioned shard reproduces its slice of the global vector. */

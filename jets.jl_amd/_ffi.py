@@ -79,6 +79,10 @@ SYMBOLS = {
     "jh_copy": (_int, [_vp, _vp]),
     "jh_download": (_int, [_vp, _i64, _i64, _vp]),
     "jh_upload": (_int, [_vp, _i64, _i64, _vp]),
+    "jh_host_alloc": (_int, [C.c_size_t, _vpp]),
+    "jh_host_free": (_int, [_vp]),
+    "jh_host_register": (_int, [_vp, C.c_size_t]),
+    "jh_host_unregister": (_int, [_vp]),
     "jh_fill_uniform": (_int, [_vp, C.c_uint64, C.c_uint64, _i64]),
     "jh_fill_normal": (_int, [_vp, C.c_uint64, C.c_uint64, _i64]),
     "jh_abs": (_int, [_vp, _vp]),

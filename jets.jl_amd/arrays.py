@@ -25,7 +25,8 @@ from .spaces import JetAbstractSpace, JetSpace, JetBSpace, dtype_code
 __all__ = [
     "DeviceArray", "BlockArray", "LinExpr", "zeros", "ones", "rand", "randn", "Array", "from_numpy", "space", "nblocks",
     "indices", "getblock", "getblock_", "setblock_", "norm", "dot", "extrema", "fill_", "copyto_", "lincomb_",
-    "hadamard_", "similar", "convert_array", "reshape", "vec", "length", "abs_",
+    "hadamard_", "similar", "convert_array", "reshape", "vec", "length", "abs_", "pinned_empty", "host_register",
+    "host_unregister", "download_into", "upload_from",
 ]
 
 _rand_counter = itertools.count(1)
@@ -194,7 +195,11 @@ class DeviceArray(_DevVec):
         return {"shape": self.shape, "typestr": self._dtype.str, "data": (self.ptr, False), "version": 3,
                 "strides": tuple(strides) if len(self.shape) > 1 else None}
 
-    def to_numpy(self) -> np.ndarray:
+    def to_numpy(self, out: np.ndarray | None = None) -> np.ndarray:
+        """Host copy (column-major).  `out`: a flat or same-shape host array to fill instead -- pass a `pinned_empty`
+        array to move at the PCIe rate."""
+        if out is not None:
+            return download_into(self, out).reshape(self.shape, order="F")
         return self._download().reshape(self.shape, order="F")
 
     def reshape(self, *shape) -> "DeviceArray":
@@ -254,8 +259,10 @@ class BlockArray(_DevVec):
             self._views = None
         super().close()
 
-    def to_numpy(self) -> np.ndarray:
-        """convert(Array, x) (src/Jets.jl:862-868) brought to the host."""
+    def to_numpy(self, out: np.ndarray | None = None) -> np.ndarray:
+        """convert(Array, x) (src/Jets.jl:862-868) brought to the host (`out`: host array to fill, e.g. a pinned one)."""
+        if out is not None:
+            return download_into(self, out)
         return self._download()
 
     # linear indexing (src/Jets.jl:820-827): slow path by design, like the reference's findfirst
@@ -348,6 +355,78 @@ def from_numpy(a: np.ndarray, R: JetAbstractSpace | None = None):
         R = JetSpace(a.dtype, *a.shape)
     x = Array(R)
     x._upload(a.ravel(order="F") if not isinstance(R, JetBSpace) else a.ravel())
+    return x
+
+
+# ------------------------------------------------------------------------------ pinned host memory --
+class _PinnedOwner:
+    """Frees a jh_host_alloc buffer when the last numpy view of it dies."""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, nbytes
+        self.buf = (C.c_char * nbytes).from_address(ptr)
+
+    def __del__(self):
+        try:
+            lib.jh_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
+    """A page-locked (DMA-able) host array, column-major: transfers to / from it run at the PCIe rate instead of through
+    the runtime's staging copy (jh_host_alloc)."""
+    _device.init()
+    dt = np.dtype(dtype)
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(v) for v in shape)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    if nbytes == 0:
+        return np.empty(shape, dtype=dt, order="F")
+    p = C.c_void_p()
+    check(lib.jh_host_alloc(nbytes, C.byref(p)))
+    owner = _PinnedOwner(p.value, nbytes)
+    flat = np.frombuffer(owner.buf, dtype=dt)          # keeps `owner.buf` (and through the closure below, owner) alive
+    flat = flat.view(_PinnedArray)
+    flat._pinned_owner = owner
+    return flat.reshape(shape, order="F")
+
+
+class _PinnedArray(np.ndarray):
+    """ndarray that carries its pinned-buffer owner through views and reshapes."""
+
+    def __array_finalize__(self, obj):
+        if obj is not None:
+            self._pinned_owner = getattr(obj, "_pinned_owner", None)
+
+
+def host_register(a: np.ndarray) -> np.ndarray:
+    """Pin an existing contiguous host array in place (jh_host_register); undo with host_unregister."""
+    _device.init()
+    if not (a.flags.c_contiguous or a.flags.f_contiguous):
+        raise ValueError("host_register needs a contiguous array")
+    check(lib.jh_host_register(C.c_void_p(a.ctypes.data), a.nbytes))
+    return a
+
+
+def host_unregister(a: np.ndarray) -> None:
+    check(lib.jh_host_unregister(C.c_void_p(a.ctypes.data)))
+
+
+def download_into(x: "_DevVec", out: np.ndarray) -> np.ndarray:
+    """Copy a device vector into an existing host array (flat, column-major order)."""
+    if out.dtype != x.dtype or out.size != x.length() or not (out.flags.c_contiguous or out.flags.f_contiguous):
+        raise ValueError("download_into: need a contiguous host array of the vector's dtype and length")
+    if out.size:
+        check(lib.jh_download(x.handle, 0, out.size, C.c_void_p(out.ctypes.data)))
+    return out
+
+
+def upload_from(x: "_DevVec", host: np.ndarray) -> "_DevVec":
+    """Copy a contiguous host array (column-major order) into an existing device vector."""
+    if host.dtype != x.dtype or host.size != x.length() or not (host.flags.c_contiguous or host.flags.f_contiguous):
+        raise ValueError("upload_from: need a contiguous host array of the vector's dtype and length")
+    if host.size:
+        check(lib.jh_upload(x.handle, 0, host.size, C.c_void_p(host.ctypes.data)))
     return x
 
 

@@ -402,6 +402,55 @@ int jh_upload(jh_bvec *v, int64_t offset, int64_t count, const void *host_src)
     return JH_OK;
 }
 
+int jh_host_alloc(size_t bytes, void **out)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(out, "jh_host_alloc: null argument");
+    *out = nullptr;
+    if (bytes == 0) return JH_OK;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        (void)hipGetLastError();
+        return jh_fail(JH_ERR_NOMEM, "jh_host_alloc: hipHostMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    return JH_OK;
+}
+
+int jh_host_free(void *ptr)
+{
+    if (!ptr) return JH_OK;
+    JH_TRY(jh_require_ready());
+    JH_CHECK_HIP(hipStreamSynchronize(jh_ctx().stream));      // a copy into / out of it may still be in flight
+    JH_CHECK_HIP(hipHostFree(ptr));
+    return JH_OK;
+}
+
+int jh_host_register(void *ptr, size_t bytes)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(ptr && bytes > 0, "jh_host_register: null or empty buffer");
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return jh_fail(JH_ERR_HIP, "jh_host_register: hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    return JH_OK;
+}
+
+int jh_host_unregister(void *ptr)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(ptr, "jh_host_unregister: null argument");
+    JH_CHECK_HIP(hipStreamSynchronize(jh_ctx().stream));
+    hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return jh_fail(JH_ERR_INVALID, "jh_host_unregister: %s", hipGetErrorString(e));
+    }
+    return JH_OK;
+}
+
 int jh_tune_set(const char *name, int64_t value)
 {
     JH_REQUIRE(name, "jh_tune_set: null name");

@@ -249,3 +249,37 @@ def test_randn_and_abs(Jets, dt):
     if np.dtype(dt).kind != "c":
         mn, mx = Jets.extrema(x)
         assert (mn, mx) == (x.to_numpy().min(), x.to_numpy().max()) and mn < 0 < mx
+
+
+# ---------------------------------------------------------------------------------- pinned host memory
+def test_pinned_host_buffers_round_trip(Jets, oracle):
+    """jh_host_alloc / jh_host_register: page-locked host arrays for getblock!/setblock!/convert at the PCIe rate.
+    Same bytes as the pageable path."""
+    dt, n = np.float32, 1 << 20
+    R = Jets.JetBSpace([Jets.JetSpace(dt, n // 4)] * 4)
+    x = Jets.rand(R, seed=5, stream=0)
+    ref = u01(oracle, dt, 5, 0, n)
+    pin = Jets.pinned_empty(n, dt)
+    assert pin.shape == (n,) and pin.dtype == np.dtype(dt)
+    got = x.to_numpy(out=pin)
+    assert got.ctypes.data == pin.ctypes.data
+    assert_bits_equal(np.asarray(pin), ref, "download into a pinned array")
+    y = Jets.zeros(R)
+    pin[...] = ref[::-1]
+    Jets.upload_from(y, pin)
+    assert_bits_equal(y.to_numpy(), ref[::-1].copy(), "upload from a pinned array")
+    blockview = pin[: n // 4]                                                         # a view keeps the buffer alive
+    del pin, got
+    Jets.getblock_(y, 2, blockview)
+    assert_bits_equal(np.asarray(blockview), ref[::-1][n // 2: 3 * n // 4].copy(), "getblock! into a pinned view")
+    host = np.empty(n, dt)                                                            # an ordinary array, pinned in place
+    Jets.host_register(host)
+    try:
+        Jets.download_into(x, host)
+        assert_bits_equal(host, ref, "download into a registered array")
+    finally:
+        Jets.host_unregister(host)
+    with pytest.raises(Jets.JetsHipError):
+        Jets.host_unregister(host)                                                    # not registered any more
+    cube = Jets.pinned_empty((8, 4, 2), np.float64)
+    assert cube.flags.f_contiguous and cube.shape == (8, 4, 2)
