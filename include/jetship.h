@@ -146,6 +146,21 @@ int jh_lincomb(jh_bvec *dst, int k, const double *coef_re_im, const jh_bvec *con
 /* dst = x .* y -- the masks of dot_product_test, src/Jets.jl:1215-1219.  conj_x is a flag word: bit 0 conj.(x) .* y;
  * bit 1 (2 .* x) .* y, the Jacobian of d .= m.^2 about x (test/runtests.jl:20); 3 = conj.(2 .* x) .* y. */
 int jh_hadamard(jh_bvec *dst, const jh_bvec *x, const jh_bvec *y, int conj_x);
+/* BlockArray broadcast for ANY elementwise expression, src/Jets.jl:889-911, fused into one pass over the slabs.
+ * `expr` is a C expression over x0..x{nvec-1} (the elements of the vector operands, type T), s0..s{nscal-1} (scalars of
+ * type T) and literals -- what the host language prints from its broadcast tree (Julia: a Broadcasted{BlockArrayStyle}),
+ * e.g. "s0*x0 + x1/x2" or "exp(-abs2(x0)) * conj(x1)".  Available: + - * /, the HIP math library (exp, log, sqrt, sin, cos,
+ * tanh, pow, fmin, fmax, ...), and conj/real/imag/abs/abs2/sign; complex T has + - * / conj abs abs2 exp.  It is compiled once
+ * per (expr, dtype, nvec, nscal) with hiprtc for gfx950 -- the device-side twin of Julia compiling the broadcast kernel -- with
+ * -ffp-contract=off, so every operation is rounded as written (no FMA): for + - * / the result has the bits of the reference's
+ * CPU broadcast.  Programs are cached for the life of the context.  jh_bcast_check only compiles (no device needed).
+ * dst may alias any operand.  Operands are whole vectors of dst's length (a BlockArray is one slab: src/Jets.jl:899-904
+ * pairs blocks of equal index, which is the same thing). */
+typedef struct jh_bcast jh_bcast;
+int jh_bcast_check(const char *expr, int dtype, int nvec, int nscal);
+int jh_bcast_compile(const char *expr, int dtype, int nvec, int nscal, jh_bcast **out);
+int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, const double *scal_re_im);
+int jh_bcast_destroy(jh_bcast *bc);
 /* dot(x,y), src/Jets.jl:850-856 (conjugates x). fp64 accumulation, deterministic order. */
 int jh_dot(const jh_bvec *x, const jh_bvec *y, double *re, double *im);
 /* norm(x,p), src/Jets.jl:834-848: p = 2, 1, 0, +Inf, -Inf or any other real */

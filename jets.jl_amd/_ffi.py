@@ -88,6 +88,10 @@ SYMBOLS = {
     "jh_abs": (_int, [_vp, _vp]),
     "jh_lincomb": (_int, [_vp, _int, _dblp, _vpp]),
     "jh_hadamard": (_int, [_vp, _vp, _vp, _int]),
+    "jh_bcast_check": (_int, [C.c_char_p, _int, _int, _int]),
+    "jh_bcast_compile": (_int, [C.c_char_p, _int, _int, _int, _vpp]),
+    "jh_bcast_apply": (_int, [_vp, _vp, _vpp, _dblp]),
+    "jh_bcast_destroy": (_int, [_vp]),
     "jh_dot": (_int, [_vp, _vp, _dblp, _dblp]),
     "jh_norm": (_int, [_vp, C.c_double, _dblp]),
     "jh_extrema": (_int, [_vp, _dblp, _dblp]),

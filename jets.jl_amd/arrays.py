@@ -474,6 +474,8 @@ def getblock_(x, iblock: int, out):
         return out
     if out.size != src.length():
         raise ValueError("DimensionMismatch in getblock!")
+    if out.dtype == src.dtype and (out.flags.f_contiguous or out.ndim == 1 and out.flags.c_contiguous):
+        return download_into(src, out)                       # straight into the caller's array: no temporary, no first-touch faults
     out[...] = src.to_numpy().reshape(out.shape, order="F")
     return out
 

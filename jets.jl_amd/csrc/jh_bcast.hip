@@ -1,0 +1,282 @@
+// jh_bcast.hip -- BlockArray broadcast (src/Jets.jl:889-911) for ANY elementwise expression, fused into one pass.
+//
+// The reference's `copyto!(dest::BlockArray, bc::Broadcasted{BlockArrayStyle})` walks the blocks and runs Julia's
+// compiled broadcast kernel per block, so `d .= exp.(a .* u) .+ v ./ w` is one loop over k+1 streams whatever the
+// expression is.  The device equivalent of "Julia compiles the expression" is hiprtc: the host language prints the
+// Broadcasted tree as a C expression over x0..x{k-1} (vector elements) and s0..s{m-1} (scalars); it is compiled ONCE for
+// gfx950 into a kernel that streams the slabs with 16-byte loads, one pack per lane (the shape that streams fastest on
+// this chip, jh_vecops.hip), with -ffp-contract=off so every operation is rounded as written (a*u + b*v gives the bits of
+// the reference's broadcast, not an FMA's).  The BlockArray is one slab, so block boundaries do not exist for a broadcast.
+#include "jh_internal.h"
+
+#include <hip/hiprtc.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+
+struct jh_bcast {
+    int dtype = JH_F32;
+    int nvec = 0, nscal = 0;
+    hipModule_t module = nullptr;
+    hipFunction_t fn_vec = nullptr;     // 16 bytes per lane (every operand 16-byte aligned)
+    hipFunction_t fn_scalar = nullptr;  // one element per lane (views at odd offsets)
+    std::string expr;
+};
+
+namespace {
+
+constexpr int JH_BCAST_MAX_VEC = 8, JH_BCAST_MAX_SCAL = 8;
+
+// complex arithmetic for the generated code: plain formulas, every product and sum rounded (like jh_vecops.hip)
+const char *k_prelude = R"SRC(
+template <typename R> struct cx {
+    typedef R real_t;
+    R re, im;
+    __device__ cx() : re(0), im(0) {}
+    __device__ cx(R r) : re(r), im(0) {}
+    __device__ cx(R r, R i) : re(r), im(i) {}
+};
+template <typename R> __device__ inline cx<R> operator+(cx<R> a, cx<R> b) { return cx<R>(a.re + b.re, a.im + b.im); }
+template <typename R> __device__ inline cx<R> operator-(cx<R> a, cx<R> b) { return cx<R>(a.re - b.re, a.im - b.im); }
+template <typename R> __device__ inline cx<R> operator-(cx<R> a) { return cx<R>(-a.re, -a.im); }
+template <typename R> __device__ inline cx<R> operator*(cx<R> a, cx<R> b) { return cx<R>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+template <typename R> __device__ inline cx<R> operator/(cx<R> a, cx<R> b)
+{
+    const R den = b.re * b.re + b.im * b.im;
+    return cx<R>((a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den);
+}
+// real (x) complex: the real operand is a non-deduced parameter, so literals and other real types convert to R
+template <typename R> __device__ inline cx<R> operator+(cx<R> a, typename cx<R>::real_t b) { return cx<R>(a.re + b, a.im); }
+template <typename R> __device__ inline cx<R> operator+(typename cx<R>::real_t a, cx<R> b) { return cx<R>(a + b.re, b.im); }
+template <typename R> __device__ inline cx<R> operator-(cx<R> a, typename cx<R>::real_t b) { return cx<R>(a.re - b, a.im); }
+template <typename R> __device__ inline cx<R> operator-(typename cx<R>::real_t a, cx<R> b) { return cx<R>(a - b.re, -b.im); }
+template <typename R> __device__ inline cx<R> operator*(cx<R> a, typename cx<R>::real_t b) { return cx<R>(a.re * b, a.im * b); }
+template <typename R> __device__ inline cx<R> operator*(typename cx<R>::real_t a, cx<R> b) { return cx<R>(a * b.re, a * b.im); }
+template <typename R> __device__ inline cx<R> operator/(cx<R> a, typename cx<R>::real_t b) { return cx<R>(a.re / b, a.im / b); }
+template <typename R> __device__ inline cx<R> operator/(typename cx<R>::real_t a, cx<R> b) { return cx<R>(a) / b; }
+template <typename R> __device__ inline cx<R> conj(cx<R> a) { return cx<R>(a.re, -a.im); }
+template <typename R> __device__ inline R real(cx<R> a) { return a.re; }
+template <typename R> __device__ inline R imag(cx<R> a) { return a.im; }
+template <typename R> __device__ inline R abs2(cx<R> a) { return a.re * a.re + a.im * a.im; }
+template <typename R> __device__ inline R abs(cx<R> a) { return hypot(a.re, a.im); }
+template <typename R> __device__ inline cx<R> exp(cx<R> a) { const R e = exp(a.re); return cx<R>(e * cos(a.im), e * sin(a.im)); }
+__device__ inline float conj(float a) { return a; }
+__device__ inline double conj(double a) { return a; }
+__device__ inline float real(float a) { return a; }
+__device__ inline double real(double a) { return a; }
+__device__ inline float imag(float) { return 0.f; }
+__device__ inline double imag(double) { return 0.0; }
+__device__ inline float abs2(float a) { return a * a; }
+__device__ inline double abs2(double a) { return a * a; }
+__device__ inline float sign(float a) { return (a > 0.f) - (a < 0.f); }
+__device__ inline double sign(double a) { return (a > 0.0) - (a < 0.0); }
+)SRC";
+
+std::string build_source(const std::string &expr, int dtype, int nvec, int nscal)
+{
+    const bool is64 = (dtype == JH_F64 || dtype == JH_C64), cplx = jh_dtype_complex(dtype);
+    const char *R = is64 ? "double" : "float";
+    const int NS = is64 ? 2 : 4;                       // scalars per 16-byte pack
+    const int E = cplx ? 2 : 1;                        // scalars per element
+    std::string s = k_prelude;
+    s += std::string("typedef ") + R + " R;\n";
+    s += cplx ? "typedef cx<R> T;\n" : "typedef R T;\n";
+    s += "typedef R V __attribute__((ext_vector_type(" + std::to_string(NS) + ")));\n";
+    s += "typedef const V __attribute__((address_space(1))) *gvp;\ntypedef V __attribute__((address_space(1))) *gvq;\n";
+    s += "typedef const R __attribute__((address_space(1))) *gsp;\ntypedef R __attribute__((address_space(1))) *gsq;\n";
+    // element accessors on a pack
+    if (!cplx) {
+        s += "#define GET(P, e) ((T)(P)[e])\n#define PUT(P, e, val) (P)[e] = (R)(val)\n";
+    } else {
+        s += "#define GET(P, e) T((P)[2 * (e)], (P)[2 * (e) + 1])\n#define PUT(P, e, val) do { T t_ = (val); (P)[2 * (e)] = t_.re; (P)[2 * (e) + 1] = t_.im; } while (0)\n";
+    }
+    std::string params = "R *__restrict__ dst_";
+    for (int k = 0; k < nvec; k++) params += ", const R *p" + std::to_string(k);
+    for (int k = 0; k < nscal; k++) params += ", R sr" + std::to_string(k) + ", R si" + std::to_string(k);
+    params += ", long n_scalars";
+    std::string scal;
+    for (int k = 0; k < nscal; k++) {
+        const std::string i = std::to_string(k);
+        scal += cplx ? "    const T s" + i + "(sr" + i + ", si" + i + ");\n" : "    const T s" + i + " = sr" + i + "; (void)si" + i + ";\n";
+    }
+    // ---- 16 bytes per lane
+    s += "extern \"C\" __global__ __launch_bounds__(256) void jh_bcast_vec(" + params + ")\n{\n" + scal;
+    s += "    const long nvec = n_scalars / " + std::to_string(NS) + ";\n";
+    s += "    const long stride = (long)gridDim.x * 256;\n";
+    s += "    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {\n";
+    for (int k = 0; k < nvec; k++) s += "        const V X" + std::to_string(k) + " = __builtin_nontemporal_load((gvp)p" + std::to_string(k) + " + v);\n";
+    s += "        V r_;\n#pragma unroll\n        for (int e = 0; e < " + std::to_string(NS / E) + "; e++) {\n";
+    for (int k = 0; k < nvec; k++) s += "            const T x" + std::to_string(k) + " = GET(X" + std::to_string(k) + ", e);\n";
+    s += "            const T val_ = (T)(" + expr + ");\n            PUT(r_, e, val_);\n        }\n";
+    s += "        __builtin_nontemporal_store(r_, (gvq)dst_ + v);\n    }\n}\n";
+    // ---- one element per lane
+    s += "extern \"C\" __global__ __launch_bounds__(256) void jh_bcast_scalar(" + params + ")\n{\n" + scal;
+    s += "    const long nel = n_scalars / " + std::to_string(E) + ";\n";
+    s += "    const long stride = (long)gridDim.x * 256;\n";
+    s += "    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nel; i += stride) {\n";
+    for (int k = 0; k < nvec; k++) {
+        const std::string i = std::to_string(k);
+        s += cplx ? "        const T x" + i + "(((gsp)p" + i + ")[2 * i], ((gsp)p" + i + ")[2 * i + 1]);\n"
+                  : "        const T x" + i + " = ((gsp)p" + i + ")[i];\n";
+    }
+    s += "        const T val_ = (T)(" + expr + ");\n";
+    s += cplx ? "        ((gsq)dst_)[2 * i] = val_.re; ((gsq)dst_)[2 * i + 1] = val_.im;\n" : "        ((gsq)dst_)[i] = val_;\n";
+    s += "    }\n}\n";
+    return s;
+}
+
+std::mutex g_cache_mutex;
+std::map<std::string, jh_bcast *> g_cache;      // (dtype, nvec, nscal, expr) -> compiled program, shared by every handle
+
+int compile_code(const std::string &expr, int dtype, int nvec, int nscal, std::vector<char> &code)
+{
+    const std::string src = build_source(expr, dtype, nvec, nscal);
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "jh_bcast.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return jh_fail(JH_ERR_HIP, "jh_bcast_compile: hiprtcCreateProgram failed");
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17"};
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        std::string log;
+        if (hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) {
+            log.resize(n);
+            (void)hiprtcGetProgramLog(prog, &log[0]);
+        }
+        (void)hiprtcDestroyProgram(&prog);
+        if (log.size() > 1500) log.resize(1500);
+        return jh_fail(JH_ERR_INVALID, "jh_bcast_compile: `%s` does not compile as an elementwise expression over x0..x%d, s0..s%d:\n%s",
+                       expr.c_str(), nvec - 1, nscal - 1, log.c_str());
+    }
+    size_t code_size = 0;
+    if (hiprtcGetCodeSize(prog, &code_size) != HIPRTC_SUCCESS || code_size == 0) {
+        (void)hiprtcDestroyProgram(&prog);
+        return jh_fail(JH_ERR_HIP, "jh_bcast_compile: no code object");
+    }
+    code.resize(code_size);
+    (void)hiprtcGetCode(prog, code.data());
+    (void)hiprtcDestroyProgram(&prog);
+    return JH_OK;
+}
+
+int compile(const std::string &expr, int dtype, int nvec, int nscal, jh_bcast **out)
+{
+    std::vector<char> code;
+    JH_TRY(compile_code(expr, dtype, nvec, nscal, code));
+    jh_bcast *bc = new jh_bcast();
+    bc->dtype = dtype;
+    bc->nvec = nvec;
+    bc->nscal = nscal;
+    bc->expr = expr;
+    hipError_t e = hipModuleLoadData(&bc->module, code.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&bc->fn_vec, bc->module, "jh_bcast_vec");
+    if (e == hipSuccess) e = hipModuleGetFunction(&bc->fn_scalar, bc->module, "jh_bcast_scalar");
+    if (e != hipSuccess) {
+        if (bc->module) (void)hipModuleUnload(bc->module);
+        delete bc;
+        return jh_fail(JH_ERR_HIP, "jh_bcast_compile: loading the code object: %s", hipGetErrorString(e));
+    }
+    *out = bc;
+    return JH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+static int check_request(const char *expr, int dtype, int nvec, int nscal)
+{
+    JH_REQUIRE(expr, "jh_bcast_compile: null expression");
+    JH_REQUIRE(jh_dtype_size(dtype) != 0, "jh_bcast_compile: unknown dtype %d", dtype);
+    JH_REQUIRE(nvec >= 0 && nvec <= JH_BCAST_MAX_VEC && nscal >= 0 && nscal <= JH_BCAST_MAX_SCAL,
+               "jh_bcast_compile: at most %d vector and %d scalar operands (got %d, %d)", JH_BCAST_MAX_VEC, JH_BCAST_MAX_SCAL, nvec, nscal);
+    JH_REQUIRE(strlen(expr) > 0 && strlen(expr) < 4096, "jh_bcast_compile: empty or oversized expression");
+    return JH_OK;
+}
+
+int jh_bcast_check(const char *expr, int dtype, int nvec, int nscal)
+{
+    JH_TRY(check_request(expr, dtype, nvec, nscal));
+    std::vector<char> code;
+    return compile_code(expr, dtype, nvec, nscal, code);      // hiprtc cross-compiles: no device needed
+}
+
+int jh_bcast_compile(const char *expr, int dtype, int nvec, int nscal, jh_bcast **out)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(out, "jh_bcast_compile: null argument");
+    JH_TRY(check_request(expr, dtype, nvec, nscal));
+    const std::string key = std::to_string(dtype) + "/" + std::to_string(nvec) + "/" + std::to_string(nscal) + "/" + expr;
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) {
+        *out = it->second;
+        return JH_OK;
+    }
+    jh_bcast *bc = nullptr;
+    JH_TRY(compile(expr, dtype, nvec, nscal, &bc));
+    g_cache[key] = bc;
+    *out = bc;
+    return JH_OK;
+}
+
+int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, const double *scal_re_im)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(bc && dst, "jh_bcast_apply: null argument");
+    JH_REQUIRE(bc->nvec == 0 || x, "jh_bcast_apply: null operand list");
+    JH_REQUIRE(bc->nscal == 0 || scal_re_im, "jh_bcast_apply: null scalar list");
+    JH_REQUIRE(dst->dtype == bc->dtype, "jh_bcast_apply: destination dtype %d, program compiled for %d", dst->dtype, bc->dtype);
+    uintptr_t bits = (uintptr_t)dst->data;
+    for (int k = 0; k < bc->nvec; k++) {
+        JH_REQUIRE(x[k], "jh_bcast_apply: operand %d is null", k);
+        JH_REQUIRE(x[k]->dtype == bc->dtype, "jh_bcast_apply: operand %d has dtype %d, program compiled for %d", k, x[k]->dtype, bc->dtype);
+        JH_REQUIRE(x[k]->length == dst->length, "jh_bcast_apply: operand %d has %lld elements, destination %lld (DimensionMismatch)", k,
+                   (long long)x[k]->length, (long long)dst->length);
+        bits |= (uintptr_t)x[k]->data;
+    }
+    if (dst->length == 0) return JH_OK;
+    const bool cplx = jh_dtype_complex(bc->dtype), is64 = (bc->dtype == JH_F64 || bc->dtype == JH_C64);
+    const int64_t n_scalars = dst->length * (cplx ? 2 : 1);
+    const int NS = is64 ? 2 : 4;
+    const bool vec_ok = ((bits & 15u) == 0) && (n_scalars % NS == 0);
+    // kernel arguments: dst, p0.., (sr, si).., n_scalars
+    void *dptr = dst->data;
+    const void *ptrs[JH_BCAST_MAX_VEC];
+    float sf[2 * JH_BCAST_MAX_SCAL];
+    double sd[2 * JH_BCAST_MAX_SCAL];
+    long n_arg = (long)n_scalars;
+    void *args[2 + JH_BCAST_MAX_VEC + 2 * JH_BCAST_MAX_SCAL];
+    int na = 0;
+    args[na++] = &dptr;
+    for (int k = 0; k < bc->nvec; k++) { ptrs[k] = x[k]->data; args[na++] = &ptrs[k]; }
+    for (int k = 0; k < 2 * bc->nscal; k++) {
+        if (is64) { sd[k] = scal_re_im[k]; args[na++] = &sd[k]; }
+        else { sf[k] = (float)scal_re_im[k]; args[na++] = &sf[k]; }
+    }
+    args[na++] = &n_arg;
+    const int64_t work = vec_ok ? n_scalars / NS : dst->length;
+    int64_t grid = (work + 255) / 256;
+    if (grid > ((int64_t)1 << 23)) grid = (int64_t)1 << 23;              // grid x 256 threads < 2^32; the kernel strides
+    JH_CHECK_HIP(hipModuleLaunchKernel(vec_ok ? bc->fn_vec : bc->fn_scalar, (unsigned)grid, 1, 1, 256, 1, 1, 0, jh_ctx().stream, args, nullptr));
+    return JH_OK;
+}
+
+int jh_bcast_destroy(jh_bcast *bc)
+{
+    (void)bc;   // programs live in the process-wide cache (one per distinct expression) until jh_shutdown
+    return JH_OK;
+}
+
+}  // extern "C"
+
+void jh_bcast_clear_cache()
+{
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    for (auto &kv : g_cache) {
+        if (kv.second->module) (void)hipModuleUnload(kv.second->module);
+        delete kv.second;
+    }
+    g_cache.clear();
+}

@@ -115,6 +115,7 @@ int jh_shutdown(void)
     (void)hipSetDevice(c.device);
     (void)hipStreamSynchronize(c.stream);
     (void)jh_comm_destroy();
+    jh_bcast_clear_cache();
     if (c.red_dev) (void)hipFree(c.red_dev);
     if (c.part_dev) (void)hipFree(c.part_dev);
     if (c.scratch_dev) (void)hipFree(c.scratch_dev);

@@ -126,6 +126,7 @@ struct jh_blockop {
     int64_t diag_stride_elems = 0;
 };
 
+void jh_bcast_clear_cache();            // jh_bcast.hip: unload every JIT-compiled broadcast program (jh_shutdown)
 int jh_ensure_partials(int64_t n);     // grows ctx.part_dev to >= n doubles (may synchronise + reallocate)
 // vecops entry used by blockop for generic pieces
 int jh_launch_fill_range(void *ptr, int dtype, int64_t count, double re, double im);

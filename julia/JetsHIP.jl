@@ -117,6 +117,38 @@ function lincomb!(y, coefs::Vector{<:Number}, xs::Vector)
     y
 end
 
+# ---------------------------------------------------------------- broadcast: any elementwise expression, one fused pass
+# copyto!(dest::BlockArray, bc::Broadcasted{BlockArrayStyle}) (src/Jets.jl:899-911) for device vectors: print the
+# Broadcasted tree as a C expression over x0.. (vector leaves) and s0.. (scalar leaves), let libjetship compile it once
+# with hiprtc (jh_bcast_compile) and stream the slabs in ONE kernel.  `a*u .+ b*v .+ c*w`, `exp.(-u.^2) .* v`, ...
+const _cfun = Dict{Any,String}(+ => "+", - => "-", * => "*", / => "/", exp => "exp", log => "log", sqrt => "sqrt", sin => "sin",
+                               cos => "cos", tanh => "tanh", abs => "abs", abs2 => "abs2", conj => "conj", real => "real",
+                               imag => "imag", sign => "sign", max => "fmax", min => "fmin")
+_emit(x::Union{HipBlockArray,HipArray}, vecs, scals) = (i = findfirst(v -> v === x, vecs); i === nothing && (push!(vecs, x); i = length(vecs)); "x$(i-1)")
+_emit(x::Number, vecs, scals) = (push!(scals, x); "s$(length(scals)-1)")
+_emit(x::Base.RefValue, vecs, scals) = _emit(x[], vecs, scals)
+function _emit(bc::Base.Broadcast.Broadcasted, vecs, scals)
+    f, args = bc.f, map(a -> _emit(a, vecs, scals), bc.args)
+    f === Base.literal_pow && return "(" * join(fill(args[2], bc.args[3] isa Base.RefValue ? 2 : 2), " * ") * ")"   # u.^2 -> u*u
+    op = get(_cfun, f, nothing)
+    op === nothing && error("broadcast of $(f) over device vectors is not supported")
+    op in ("+", "-", "*", "/") ? (length(args) == 1 ? "($op$(args[1]))" : "(" * join(args, " $op ") * ")") : "$op(" * join(args, ", ") * ")"
+end
+const _bcast_programs = Dict{Tuple{String,DataType,Int,Int},Ptr{Cvoid}}()
+function Base.copyto!(dest::Union{HipBlockArray{T},HipArray{T}}, bc::Base.Broadcast.Broadcasted) where {T}
+    vecs, scals = Any[], Number[]
+    expr = _emit(Base.Broadcast.flatten(bc), vecs, scals)
+    prog = get!(_bcast_programs, (expr, T, length(vecs), length(scals))) do
+        h = Ref{Ptr{Cvoid}}()
+        check(ccall((:jh_bcast_compile, LIB), Cint, (Cstring, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), expr, dtype_code(T), length(vecs), length(scals), h))
+        h[]
+    end
+    sc = Cdouble[]
+    foreach(a -> (push!(sc, real(a)); push!(sc, imag(a))), scals)
+    check(ccall((:jh_bcast_apply, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Cdouble}), prog, dest.handle, Ptr{Cvoid}[v.handle for v in vecs], sc))
+    dest
+end
+
 # ---------------------------------------------------------------- device-native operator kinds
 # recognised by typeof(df!) exactly as iszero/isblockop do (src/Jets.jl:949, 1097)
 JopHipDiagonal_df!(d, m; diagonal, kwargs...) = (check(ccall((:jh_hadamard, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), d.handle, diagonal.handle, m.handle, 0)); d)

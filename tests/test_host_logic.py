@@ -234,3 +234,18 @@ def test_perfstat():
     A2 = nonlin(2)
     assert J.perfstat(A1) == np.pi and J.perfstat(A2) is None        # :893-894
     assert J.perfstat(A2 @ A1) == np.pi and J.perfstat(A2 + A1) == np.pi   # :895-898
+
+
+def test_broadcast_expressions_cross_compile_without_a_device():
+    """jh_bcast_check: the JIT source generator + hiprtc for gfx950, no GPU needed (the launch path is GPU-tested)."""
+    import jets_jl_amd as J
+    from jets_jl_amd._ffi import lib
+
+    for dt in range(4):
+        assert lib.jh_bcast_check(b"s0*x0 + x1/x2 - 2", dt, 3, 1) == 0, lib.jh_last_error()
+        assert lib.jh_bcast_check(b"exp(-abs2(x0)) * conj(x1) + real(x0)", dt, 2, 0) == 0, lib.jh_last_error()
+    assert lib.jh_bcast_check(b"x0 +", 0, 1, 0) == 1 and b"x0 +" in lib.jh_last_error()
+    assert lib.jh_bcast_check(b"x0", 0, 9, 0) == 1
+    e = 2.0 * J.lazy(3.0) + J.bc.exp(J.lazy(1.0))
+    code, vecs, scal = e.program()
+    assert code == "((s0 * s1) + exp(s2))" and vecs == [] and scal == [2.0, 3.0, 1.0]

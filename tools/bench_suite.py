@@ -63,6 +63,10 @@ row("f .= d .+ e", 3 * L * s, timeit(lambda: f.assign(d + e)))
 row("f .= d .+ e  (base-case, flat)", 3 * L * s, timeit(lambda: flat_f.assign(flat_d + flat_e)))
 row("f .= a*d .+ b*e .+ c*f", 4 * L * s, timeit(lambda: f.assign(0.3 * d + 0.5 * e + 0.2 * f)))
 row("f .= d .* e", 3 * L * s, timeit(lambda: J.hadamard_(f, d, e)))
+row("f .= a*d .+ b*e .+ c*f  [JIT broadcast]", 4 * L * s, timeit(lambda: J.broadcast_(f, "s0*x0 + s1*x1 + s2*x2", [d, e, f], [0.3, 0.5, 0.2])))
+row("f .= exp.(-d .* d) .* e  [JIT broadcast]", 3 * L * s, timeit(lambda: J.broadcast_(f, "exp(-x0*x0) * x1", [d, e])))
+row("f .= sqrt.(abs.(d)) ./ (1 .+ e)  [JIT broadcast]", 3 * L * s, timeit(lambda: J.broadcast_(f, "sqrt(abs(x0)) / (1 + x1)", [d, e])))
+row("f .= f .* f  [JIT broadcast, in place]", 2 * L * s, timeit(lambda: J.broadcast_(f, "x0*x0", [f])))
 row("fill!(f, 3.14)", L * s, timeit(lambda: J.fill_(f, 3.14)))
 row("fill!  (base-case, flat)", L * s, timeit(lambda: J.fill_(flat_f, 3.14)))
 row("dot(d, e)", 2 * L * s, timeit(lambda: J.dot(d, e)))
