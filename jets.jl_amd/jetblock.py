@@ -25,7 +25,7 @@ __all__ = [
     "JetBlock", "JopBlock", "blockop", "JopZeroBlock", "JopZeroBlock_df", "iszero", "JetBlock_f", "JetBlock_df",
     "JetBlock_df_adj", "nblocks_op", "getblock_op", "isblockop", "JopDiagonal", "JopIdentity", "diagonal_df",
     "diagonal_df_adj", "identity_df", "NativeBlockOp", "JopDense", "dense_df", "dense_df_adj", "JopSquare", "square_f",
-    "square_df", "square_df_adj",
+    "square_df", "square_df_adj", "JopElementwise", "elementwise_f", "elementwise_df", "elementwise_df_adj", "elementwise_upstate",
 ]
 
 
@@ -108,6 +108,42 @@ def JopSquare(spc: JetAbstractSpace) -> JopNl:
     return JopNl(f=square_f, df=square_df, df_adj=square_df_adj, dom=spc, rng=spc)
 
 
+def elementwise_f(d, m, *, f_expr, params, **kw):  # f!(d, m): d .= f.(m), any elementwise expression (one fused JIT kernel)
+    from .broadcast import broadcast_
+
+    return broadcast_(d, f_expr, [m], params)
+
+
+def elementwise_upstate(mo, s):  # upstate!(mo, s) (src/Jets.jl:297-301): refresh the Jacobian's diagonal IN PLACE
+    from .broadcast import broadcast_
+
+    broadcast_(s["diagonal"], s["jac_expr"], [mo], s["params"])
+    s["pointed"][0] = True
+
+
+def elementwise_df(d, m, *, diagonal, pointed, **kw):  # dd .= f'.(mo) .* dm
+    if not pointed[0]:
+        raise ValueError("DimensionMismatch: the Jacobian of a nonlinear operator needs a linearization point (point! / jacobian!)")
+    return hadamard_(d, diagonal, m)
+
+
+def elementwise_df_adj(m, d, *, diagonal, pointed, **kw):  # dm .= conj.(f'.(mo)) .* dd
+    if not pointed[0]:
+        raise ValueError("DimensionMismatch: the Jacobian of a nonlinear operator needs a linearization point (point! / jacobian!)")
+    return hadamard_(m, diagonal, d, conj_x=True)
+
+
+def JopElementwise(spc: JetAbstractSpace, f: str, jac: str, params=()) -> JopNl:
+    """A nonlinear operator d .= f.(m) for ANY elementwise f, written the way the reference's users write one
+    (`JopNl(f!, df!, df'!, upstate!)`, src/Jets.jl:196-207): `f` and `jac` are C expressions over x0 (the element of m /
+    of the linearization point) and s0.. (`params`), e.g. JopElementwise(R, "exp(x0)", "exp(x0)") or
+    JopElementwise(R, "s0*x0*x0*x0", "3*s0*x0*x0", [a]).  point! evaluates `jac` once into a diagonal kept in the state
+    (one fused pass), so the Jacobian is a DIAGONAL operator: inside a block operator it is device-native and a tall
+    operator of such children linearises onto the tall fast path (fused A'A, one-pass LSQR step)."""
+    return JopNl(f=elementwise_f, df=elementwise_df, df_adj=elementwise_df_adj, upstate=elementwise_upstate, dom=spc, rng=spc,
+                 s={"f_expr": f, "jac_expr": jac, "params": tuple(params), "diagonal": zeros(spc), "pointed": [False]})
+
+
 def _native_desc(op: Jop):
     """(kind, adjoint_flag, coeff_array_or_None, scale) if `op` is device-native, else None."""
     adj = 0
@@ -115,6 +151,8 @@ def _native_desc(op: Jop):
         j = op.jet
         if j.f is square_f and j.df is square_df and j.df_adj is square_df_adj:
             return ("square", 0, None, 0.0)
+        if j.f is elementwise_f and j.df is elementwise_df and j.df_adj is elementwise_df_adj:
+            return ("diag", 0, j.s["diagonal"], 0.0)          # its Jacobian; f! itself runs through the host loop (host_f)
         return None
     if isinstance(op, JopAdjoint):
         adj, op = 1, op.op
@@ -155,6 +193,8 @@ class NativeBlockOp:
                 if coeff is not None:
                     self._keep.append(coeff)
         self.nonlinear = any(dsc[0] == "square" for row in descs for dsc in row)
+        # children whose f! is not a device-native kind (JopElementwise: a JIT broadcast per child): JetBlock_f! loops on the host
+        self.host_f = any(isinstance(op, JopNl) and op.jet.f is elementwise_f for op in ops.flat)
         self._point = None  # the device array the SQUARE blocks are linearised about (kept alive here)
         row_len = [range_(ops[i, 0]).length() for i in builtins.range(nrow)]
         col_len = [domain(ops[0, jc]).length() for jc in builtins.range(ncol)]
@@ -280,6 +320,9 @@ def blockop(ops, **kwargs) -> Jop:
 def _pointed_native(nat, ops, mo):
     """`nat` linearised about `mo`, or None when some nonlinear child sits at a point of its own (someone called point!
     on the child, not on the block jet): then the per-child loop below is the faithful path."""
+    for op in ops.flat:                                        # JopElementwise children carry their own (refreshed in place) diagonal
+        if isinstance(op, JopNl) and op.jet.f is elementwise_f and not op.jet.s["pointed"][0]:
+            return None
     if not nat.nonlinear:
         return nat
     if mo is None or mo.length() != sum(domain(ops[0, jc]).length() for jc in builtins.range(ops.shape[1])):
@@ -295,7 +338,7 @@ def _pointed_native(nat, ops, mo):
 
 def JetBlock_f(d, m, *, ops, dom, rng, _native=None, **kw):  # :988-1008
     nat = _native_op(_native, ops, rng.eltype())
-    if nat is not None:
+    if nat is not None and not nat.host_f:
         return nat.f(d, m)  # one fused launch, same loop order and rounding
     nrow, ncol = ops.shape
     dtmp = zeros(range_(ops[0, 0])) if ncol > 1 else None

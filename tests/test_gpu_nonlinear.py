@@ -316,3 +316,96 @@ def test_multiple_simultaneous_linearizations_literal_values(Jets):
     assert (K1 * dm).to_numpy().tolist() == [2.0, 8.0, 2.0, 8.0]
     assert (K2 * dm).to_numpy().tolist() == [6.0, 16.0, 6.0, 16.0]
     assert (K1.H * (K1 * dm)).to_numpy().tolist() == [8.0, 64.0]                     # sum_i (2 mo)^2 dm
+
+
+# ---------------------------------------------------------------------------------- arbitrary elementwise nonlinear children
+def test_elementwise_operator_and_its_jacobian(Jets, oracle):
+    """JopElementwise: f and f' as expressions; point! refreshes the Jacobian's diagonal in one fused pass."""
+    dt, n = np.float64, 4096
+    spc = Jets.JetSpace(dt, n)
+    F = Jets.JopElementwise(spc, "s0*x0*x0*x0 + exp(x0)", "3*s0*x0*x0 + exp(x0)", [0.5])
+    m = Jets.rand(spc, seed=91, stream=0)
+    hm = u01(oracle, dt, 91, 0, n)
+    np.testing.assert_allclose((F * m).to_numpy(), 0.5 * hm ** 3 + np.exp(hm), rtol=1e-14)
+    with pytest.raises(ValueError, match="linearization point"):
+        Jets.mul(Jets.JopLn(Jets.jet(F)), m)
+    J = Jets.jacobian_(F, m)
+    dm = Jets.rand(spc, seed=92, stream=0)
+    hdm = u01(oracle, dt, 92, 0, n)
+    np.testing.assert_allclose((J * dm).to_numpy(), (1.5 * hm ** 2 + np.exp(hm)) * hdm, rtol=1e-14)
+    np.testing.assert_allclose((J.H * dm).to_numpy(), (1.5 * hm ** 2 + np.exp(hm)) * hdm, rtol=1e-14)
+    lhs, rhs = Jets.dot_product_test(J, Jets.rand(spc), Jets.rand(spc))
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs + rhs)
+    # linearization test in the reference's sense (src/Jets.jl:1228-1269): F(m + h dm) - F(m) - h J dm = O(h^2)
+    errs = []
+    for h in (1e-2, 1e-3):
+        mp = Jets.zeros(spc)
+        Jets.lincomb_(mp, [1.0, h], [m, dm])
+        r = Jets.zeros(spc)
+        Jets.lincomb_(r, [1.0, -1.0, -h], [F * mp, F * m, J * dm])
+        errs.append(float(Jets.norm(r)))
+    assert errs[1] < errs[0] / 50                                                     # second order: ~100x smaller for 10x smaller h
+    # two simultaneous linearizations through jacobian (copies the jet AND its diagonal)
+    m2 = Jets.rand(spc, seed=93, stream=0)
+    hm2 = u01(oracle, dt, 93, 0, n)
+    J1, J2 = Jets.jacobian(F, m), Jets.jacobian(F, m2)
+    np.testing.assert_allclose((J1 * dm).to_numpy(), (1.5 * hm ** 2 + np.exp(hm)) * hdm, rtol=1e-14)
+    np.testing.assert_allclose((J2 * dm).to_numpy(), (1.5 * hm2 ** 2 + np.exp(hm2)) * hdm, rtol=1e-14)
+
+
+def test_tall_operator_of_elementwise_children_linearises_onto_the_fast_path(Jets, oracle):
+    """A tall block operator of JopElementwise children: f! loops over the children (one fused pass each), the Jacobian is
+    a native all-DIAG operator -- the tall kernels, the fused A'A and the one-pass LSQR step apply -- and follows point!
+    without rebuilding the device handle (the diagonals are refreshed in place)."""
+    import ctypes as C
+    from jets_jl_amd._ffi import lib
+    from jets_jl_amd import jetblock
+
+    dt, n, nrow = np.float32, 1 << 14, 5
+    spc = Jets.JetSpace(dt, n)
+    exprs = [("x0*x0", "2*x0"), ("sin(x0)", "cos(x0)"), ("s0*x0", "s0"), ("exp(-x0)", "-exp(-x0)"), ("x0*x0*x0", "3*x0*x0")]
+    F = Jets.blockop([[Jets.JopElementwise(spc, f, j, [1.5])] for f, j in exprs])
+    assert isinstance(F, Jets.JopNl)
+    m = Jets.rand(spc, seed=94, stream=0)
+    hm = u01(oracle, dt, 94, 0, n).astype(np.float64)
+    d = F * m
+    want = np.concatenate([hm * hm, np.sin(hm), 1.5 * hm, np.exp(-hm), hm ** 3])
+    np.testing.assert_allclose(d.to_numpy(), want, rtol=3e-6, atol=1e-6)
+    J = Jets.jacobian_(F, m)
+    coeffs = [2 * hm, np.cos(hm), np.full(n, 1.5), -np.exp(-hm), 3 * hm * hm]
+    dm = Jets.rand(spc, seed=95, stream=0)
+    hdm = u01(oracle, dt, 95, 0, n).astype(np.float64)
+    np.testing.assert_allclose((J * dm).to_numpy(), np.concatenate([c * hdm for c in coeffs]), rtol=3e-6, atol=1e-6)
+    dd = J * dm
+    np.testing.assert_allclose((J.H * dd).to_numpy(), sum(c * c for c in coeffs) * hdm, rtol=1e-5, atol=1e-5)
+    nat = jetblock._native_op(J.jet.s["_native"], J.jet.s["ops"], J.jet.rng.eltype())
+    assert nat is not None and nat.host_f and not nat.nonlinear
+    w, out = Jets.zeros(spc), C.c_double(0)
+    u = Jets.rand(Jets.range(J), seed=96, stream=0)
+    assert lib.jh_blockop_bidiag_step(nat.handle, u.handle, dm.handle, w.handle, 1.0, 0.0, C.byref(out)) == 0   # the all-DIAG fast path
+    np.testing.assert_allclose(Jets.mul(J.H @ J, dm).to_numpy(), sum(c * c for c in coeffs) * hdm, rtol=1e-5, atol=1e-5)
+    handle_before = nat.handle.value
+    m2 = Jets.rand(spc, seed=97, stream=0)
+    hm2 = u01(oracle, dt, 97, 0, n).astype(np.float64)
+    Jets.point_(F, m2)                                                               # J shares the jet: new point, same device handle
+    coeffs2 = [2 * hm2, np.cos(hm2), np.full(n, 1.5), -np.exp(-hm2), 3 * hm2 * hm2]
+    np.testing.assert_allclose((J * dm).to_numpy(), np.concatenate([c * hdm for c in coeffs2]), rtol=3e-6, atol=1e-6)
+    assert jetblock._native_op(J.jet.s["_native"], J.jet.s["ops"], J.jet.rng.eltype()).handle.value == handle_before
+
+
+def test_gauss_newton_with_elementwise_children_and_device_lsqr(Jets, oracle):
+    dt, n = np.float64, 4096
+    spc = Jets.JetSpace(dt, n)
+    F = Jets.blockop([[Jets.JopElementwise(spc, "exp(x0)", "exp(x0)")], [Jets.JopElementwise(spc, "x0*x0*x0", "3*x0*x0")],
+                      [Jets.JopSquare(spc)]])
+    x_true = 0.25 + u01(oracle, dt, 98, 0, n)
+    dobs = Jets.from_numpy(np.concatenate([np.exp(x_true), x_true ** 3, x_true ** 2]), Jets.range(F))
+    m = Jets.ones(spc)
+    for _ in range(8):
+        r = Jets.zeros(Jets.range(F))
+        Jets.mul_(r, F, m)
+        Jets.lincomb_(r, [1.0, -1.0], [dobs, r])
+        J = Jets.jacobian_(F, m)
+        step = Jets.lsqr(J, r, maxiter=30, atol=1e-14, btol=1e-14).x
+        Jets.lincomb_(m, [1.0, 1.0], [m, step])
+    np.testing.assert_allclose(m.to_numpy(), x_true, rtol=1e-9)
