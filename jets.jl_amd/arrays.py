@@ -13,7 +13,6 @@ from __future__ import annotations
 import builtins
 import ctypes as C
 import itertools
-import math
 from typing import Sequence
 
 import numpy as np

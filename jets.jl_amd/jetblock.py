@@ -16,10 +16,10 @@ import numpy as np
 
 from ._ffi import lib, check, BlockDesc, KINDS, JetsHipError
 from . import arrays as _arr
-from .arrays import DeviceArray, BlockArray, zeros, lincomb_, hadamard_, copyto_, fill_, getblock, _i64arr
+from .arrays import DeviceArray, zeros, lincomb_, hadamard_, copyto_, fill_, getblock, _i64arr
 from .spaces import JetAbstractSpace, JetSpace, JetBSpace, dtype_code
 from . import jets as _j
-from .jets import Jet, Jop, JopLn, JopNl, JopAdjoint, mul_, domain, range_, jet, adjoint, state, point_, close
+from .jets import Jet, Jop, JopLn, JopNl, JopAdjoint, mul_, domain, range_, jet, adjoint, point_, close
 
 __all__ = [
     "JetBlock", "JopBlock", "blockop", "JopZeroBlock", "JopZeroBlock_df", "iszero", "JetBlock_f", "JetBlock_df",

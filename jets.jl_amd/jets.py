@@ -24,7 +24,7 @@ import numpy as np
 
 from . import arrays as _arr
 from .arrays import DeviceArray, BlockArray, zeros, ones, lincomb_, hadamard_, copyto_, fill_, reshape, dot
-from .spaces import JetAbstractSpace, JetSpace, JetBSpace
+from .spaces import JetAbstractSpace
 
 __all__ = [
     "Jet", "Jop", "JopNl", "JopLn", "JopAdjoint", "jet_missing", "f_", "df_", "df_adj_", "domain", "range_", "eltype",

@@ -23,7 +23,6 @@ import math
 import os
 
 from ._ffi import lib, check, JetsHipError
-from . import arrays as _arr
 from .arrays import zeros, lincomb_, norm, copyto_, reshape
 from . import jets as _j
 from . import jetblock as _blk

@@ -133,3 +133,86 @@ def test_hip_reproduces_vector_fixtures(Jets, tag, dt):
     assert abs(dv - want) <= 10 * tol * scale                       # vs the oracle's eltype-precision sequential sum
     if np.dtype(dt).kind != "c":
         assert tuple(float(t) for t in Jets.extrema(u)) == tuple(G[f"{tag}_extrema"])
+
+
+# ------------------------------------------------------------------ nonlinear path + Golub-Kahan step (jets_nonlinear_v1.npz)
+GN = np.load(os.path.join(HERE, "golden", "jets_nonlinear_v1.npz"))
+NL = [("nl_f64", np.float64), ("nl_c32", np.complex64)]
+GK = [("gk_f32", np.float32), ("gk_c64", np.complex128)]
+
+
+@pytest.mark.parametrize("tag,dt", NL)
+def test_oracle_reproduces_nonlinear_fixtures(oracle, tag, dt):
+    from .golden.make_golden_nonlinear import nl_blocks
+
+    coeffs, mo, dm, d0, dd = (GN[f"{tag}_{k}"] for k in ("coeffs", "mo", "dm", "d0", "dd"))
+    n = mo.shape[1]
+    ops = nl_blocks(dt, n, coeffs, mo)
+    f = oracle.block_f(ops, [d0[i].copy() for i in range(2)], [np.ascontiguousarray(mo[j]) for j in range(3)])
+    assert_bits_equal(np.stack(f), GN[f"{tag}_f"], f"{tag} f!")
+    jv = oracle.block_df(ops, [d0[i].copy() for i in range(2)], [np.ascontiguousarray(dm[j]) for j in range(3)])
+    assert_bits_equal(np.stack(jv), GN[f"{tag}_jv"], f"{tag} J dm")
+    jt = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt) for _ in range(3)], [np.ascontiguousarray(dd[i]) for i in range(2)])
+    assert_bits_equal(np.stack(jt), GN[f"{tag}_jt"], f"{tag} J' dd")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,dt", NL)
+def test_hip_reproduces_nonlinear_fixtures(Jets, tag, dt):
+    from .golden.make_golden_nonlinear import NL_KINDS
+
+    coeffs, mo, dm, d0, dd = (GN[f"{tag}_{k}"] for k in ("coeffs", "mo", "dm", "d0", "dd"))
+    n = mo.shape[1]
+    spc = Jets.JetSpace(dt, n)
+    rows = []
+    for i, row in enumerate(NL_KINDS):
+        r = []
+        for j, k in enumerate(row):
+            r.append({"zero": lambda: Jets.JopZeroBlock(spc, spc), "identity": lambda: Jets.JopIdentity(spc), "square": lambda: Jets.JopSquare(spc),
+                      "diag": lambda: Jets.JopDiagonal(Jets.from_numpy(np.ascontiguousarray(coeffs[i, j])))}[k]())
+        rows.append(r)
+    F = Jets.blockop(rows)
+    dmo = Jets.from_numpy(mo.ravel(), Jets.domain(F))
+    d = Jets.from_numpy(d0.ravel(), Jets.range(F))
+    Jets.mul_(d, F, dmo)
+    assert_bits_equal(d.to_numpy(), GN[f"{tag}_f"].ravel(), f"{tag} f!")
+    J = Jets.jacobian_(F, dmo)
+    d = Jets.from_numpy(d0.ravel(), Jets.range(F))
+    Jets.mul_(d, J, Jets.from_numpy(dm.ravel(), Jets.domain(F)))
+    assert_bits_equal(d.to_numpy(), GN[f"{tag}_jv"].ravel(), f"{tag} J dm")
+    mt = Jets.mul(J.H, Jets.from_numpy(dd.ravel(), Jets.range(F)))
+    assert_bits_equal(mt.to_numpy(), GN[f"{tag}_jt"].ravel(), f"{tag} J' dd")
+
+
+@pytest.mark.parametrize("tag,dt", GK)
+def test_oracle_reproduces_golub_kahan_fixtures(oracle, tag, dt):
+    a, v, u = GN[f"{tag}_a"], GN[f"{tag}_v"], GN[f"{tag}_u"]
+    alpha, beta = GN[f"{tag}_alpha_beta"]
+    nrow, n = a.shape
+    ops = [[oracle.Block("diag", n, coeff=np.ascontiguousarray(a[i]))] for i in range(nrow)]
+    tmp = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [v])
+    unew = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [alpha, beta], [tmp, [np.ascontiguousarray(u[i]) for i in range(nrow)]])
+    assert_bits_equal(np.stack(unew), GN[f"{tag}_unew"], f"{tag} u")
+    assert_bits_equal(oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], unew)[0], GN[f"{tag}_w"], f"{tag} w")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,dt", GK)
+def test_hip_reproduces_golub_kahan_fixtures(Jets, tag, dt):
+    import ctypes as C
+
+    from jets_jl_amd._ffi import lib, check
+    from jets_jl_amd import jetblock
+
+    a, v, u = GN[f"{tag}_a"], GN[f"{tag}_v"], GN[f"{tag}_u"]
+    alpha, beta = (float(x) for x in GN[f"{tag}_alpha_beta"])
+    nrow, n = a.shape
+    A = Jets.blockop([[Jets.JopDiagonal(Jets.from_numpy(np.ascontiguousarray(a[i])))] for i in range(nrow)])
+    nat = jetblock._native_op(A.jet.s["_native"], A.jet.s["ops"], A.jet.rng.eltype())
+    du, dv, dw = Jets.from_numpy(u.ravel(), Jets.range(A)), Jets.from_numpy(v), Jets.zeros(Jets.domain(A))
+    out = C.c_double(0)
+    check(lib.jh_blockop_bidiag_step(nat.handle, du.handle, dv.handle, dw.handle, alpha, beta, C.byref(out)))
+    assert_bits_equal(du.to_numpy(), GN[f"{tag}_unew"].ravel(), f"{tag} u")
+    assert_bits_equal(dw.to_numpy(), GN[f"{tag}_w"], f"{tag} w")
+    truth = float(np.sum(np.abs(GN[f"{tag}_unew"].astype(np.complex128)) ** 2))
+    assert out.value == pytest.approx(truth, rel=1e-6)

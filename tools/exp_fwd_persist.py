@@ -1,4 +1,4 @@
-import ctypes as C, os, sys
+import ctypes as C, sys
 sys.path.insert(0, "/root/repo")
 import jets_jl_amd as J
 from jets_jl_amd._ffi import lib, check
