@@ -585,7 +585,8 @@ __global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int
                                     const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
                                     const S *__restrict__ m, S *__restrict__ d, int fmode)
 {
-    const int64_t i = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.y + (int64_t)blockIdx.z * gridDim.y;   // block row (grid.y x grid.z: no 65535 cap)
+    if (i >= nrow) return;
     const int64_t n = row_off[i + 1] - row_off[i];
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         elem<S, E> acc;
@@ -610,7 +611,8 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
                                     const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
                                     S *__restrict__ m, const S *__restrict__ d)
 {
-    const int64_t j = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.y + (int64_t)blockIdx.z * gridDim.y;   // block column
+    if (j >= ncol) return;
     const int64_t n = col_off[j + 1] - col_off[j];
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         elem<S, E> acc;
@@ -662,7 +664,8 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
                                         const S *__restrict__ m, S *__restrict__ d, int fmode)
 {
     typedef typename vec_of<S, NS>::type V;
-    const int64_t i = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.y + (int64_t)blockIdx.z * gridDim.y;   // block row (grid.y x grid.z: no 65535 cap)
+    if (i >= nrow) return;
     const int64_t ns = (row_off[i + 1] - row_off[i]) * E;                 // scalars in this block row
     for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * NS; s < ns; s += (int64_t)gridDim.x * blockDim.x * NS) {
         V acc = (V)(S)0;
@@ -686,7 +689,8 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
                                         S *__restrict__ m, const S *__restrict__ d)
 {
     typedef typename vec_of<S, NS>::type V;
-    const int64_t j = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.y + (int64_t)blockIdx.z * gridDim.y;   // block column
+    if (j >= ncol) return;
     const int64_t ns = (col_off[j + 1] - col_off[j]) * E;
     for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * NS; s < ns; s += (int64_t)gridDim.x * blockDim.x * NS) {
         V acc = (V)(S)0;
@@ -914,20 +918,21 @@ int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
     int64_t maxn = 0;
     for (int64_t i = 0; i < op->nrow; i++) maxn = op->row_len[i] > maxn ? op->row_len[i] : maxn;
     if (maxn == 0) return JH_OK;
-    JH_REQUIRE(op->nrow <= 65535, "general block forward supports at most 65535 block rows (got %lld)", (long long)op->nrow);
+    JH_REQUIRE(op->nrow < ((int64_t)1 << 23), "general block forward supports fewer than 2^23 block rows (got %lld)", (long long)op->nrow);
+    const unsigned gy = (unsigned)(op->nrow < 65535 ? op->nrow : 65535), gz = (unsigned)((op->nrow + gy - 1) / gy);
     if (general_vec_ok(op, d, m)) {
         constexpr int NS = 16 / sizeof(S);
         int64_t gxv = (maxn * E / NS + 255) / 256;                         // one pack per thread (see jh_vecops.hip: grid_full)
         const int64_t cap = (((int64_t)1 << 24) / op->nrow) - 1;           // grid.x * grid.y * 256 threads < 2^32
         if (gxv > cap) gxv = cap > 0 ? cap : 1;
-        hipLaunchKernelGGL((k_block_fwd_general_vec<S, E, NS>), dim3((unsigned)gxv, (unsigned)op->nrow), dim3(256), 0, jh_ctx().stream,
+        hipLaunchKernelGGL((k_block_fwd_general_vec<S, E, NS>), dim3((unsigned)gxv, gy, gz), dim3(256), 0, jh_ctx().stream,
                            op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode);
         JH_CHECK_HIP(hipGetLastError());
         return JH_OK;
     }
     int64_t gx = (maxn + 255) / 256;
     if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3((unsigned)gx, (unsigned)op->nrow), dim3(256), 0, jh_ctx().stream,
+    hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3((unsigned)gx, gy, gz), dim3(256), 0, jh_ctx().stream,
                        op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
@@ -939,20 +944,21 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
     int64_t maxn = 0;
     for (int64_t j = 0; j < op->ncol; j++) maxn = op->col_len[j] > maxn ? op->col_len[j] : maxn;
     if (maxn == 0) return JH_OK;
-    JH_REQUIRE(op->ncol <= 65535, "general block adjoint supports at most 65535 block columns (got %lld)", (long long)op->ncol);
+    JH_REQUIRE(op->ncol < ((int64_t)1 << 23), "general block adjoint supports fewer than 2^23 block columns (got %lld)", (long long)op->ncol);
+    const unsigned gy = (unsigned)(op->ncol < 65535 ? op->ncol : 65535), gz = (unsigned)((op->ncol + gy - 1) / gy);
     if (general_vec_ok(op, d, m)) {
         constexpr int NS = 16 / sizeof(S);
         int64_t gxv = (maxn * E / NS + 255) / 256;
         const int64_t cap = (((int64_t)1 << 24) / op->ncol) - 1;
         if (gxv > cap) gxv = cap > 0 ? cap : 1;
-        hipLaunchKernelGGL((k_block_adj_general_vec<S, E, NS>), dim3((unsigned)gxv, (unsigned)op->ncol), dim3(256), 0, jh_ctx().stream,
+        hipLaunchKernelGGL((k_block_adj_general_vec<S, E, NS>), dim3((unsigned)gxv, gy, gz), dim3(256), 0, jh_ctx().stream,
                            op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d);
         JH_CHECK_HIP(hipGetLastError());
         return JH_OK;
     }
     int64_t gx = (maxn + 255) / 256;
     if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL((k_block_adj_general<S, E>), dim3((unsigned)gx, (unsigned)op->ncol), dim3(256), 0, jh_ctx().stream,
+    hipLaunchKernelGGL((k_block_adj_general<S, E>), dim3((unsigned)gx, gy, gz), dim3(256), 0, jh_ctx().stream,
                        op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;

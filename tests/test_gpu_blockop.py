@@ -345,3 +345,45 @@ def test_scalar_times_tall_block_operator_fused_bit_exact(Jets, oracle, dt):
     assert_bits_equal((S3 * m).to_numpy(), np.concatenate(a3), "A + 0.25*A2 - A")
     lhs, rhs = Jets.dot_product_test(S, m, dd)
     assert abs(lhs - rhs) / abs(lhs + rhs) < 10 * _dpt_tol(dt)
+
+
+def test_more_than_65535_block_rows_through_the_general_kernels(Jets):
+    """grid.y alone caps at 65535 workgroups: the general kernels spread block rows / columns over grid.y x grid.z."""
+    import ctypes as C
+
+    from jets_jl_amd._ffi import BlockDesc, lib, KINDS, check
+
+    nrow, n = 70_001, 4
+    arr = (BlockDesc * nrow)()
+    for i in range(nrow):
+        arr[i].kind = KINDS["identity"] if i % 2 else KINDS["scale"]
+        arr[i].scale_re = 1.0 + (i % 7)
+        arr[i].nr = arr[i].nc = n
+    rl = (C.c_int64 * nrow)(*([n] * nrow))
+    cl = (C.c_int64 * 1)(n)
+    h = C.c_void_p()
+    check(lib.jh_blockop_create(nrow, 1, arr, rl, cl, 0, C.byref(h)))
+    m = Jets.from_numpy(np.array([1.0, -2.0, 3.0, 0.5], np.float32))
+    d = Jets.zeros(Jets.JetBSpace([Jets.JetSpace(np.float32, n)] * nrow))
+    check(lib.jh_blockop_mul(h, d.handle, m.handle))
+    scale = np.array([1.0 if i % 2 else 1.0 + (i % 7) for i in range(nrow)], np.float32)
+    want = scale[:, None] * np.array([1.0, -2.0, 3.0, 0.5], np.float32)[None, :]
+    assert_bits_equal(d.to_numpy(), want.ravel(), "70001 x 1 forward")
+    mt = Jets.zeros(Jets.JetSpace(np.float32, n))
+    check(lib.jh_blockop_mul_adj(h, mt.handle, d.handle))
+    acc = np.zeros(n, np.float32)
+    for i in range(nrow):                                                             # rows in order, product rounded then added
+        acc = acc + scale[i] * want[i]
+    assert_bits_equal(mt.to_numpy(), acc, "70001 x 1 adjoint")
+    # the transpose shape: 1 x 70001 (block columns over grid.y x grid.z in the adjoint)
+    h2 = C.c_void_p()
+    check(lib.jh_blockop_create(1, nrow, arr, cl, rl, 0, C.byref(h2)))
+    mm = Jets.from_numpy(want.ravel(), Jets.JetBSpace([Jets.JetSpace(np.float32, n)] * nrow))
+    out = Jets.zeros(Jets.JetSpace(np.float32, n))
+    check(lib.jh_blockop_mul(h2, out.handle, mm.handle))                             # d += sum_j A_j m_j
+    assert_bits_equal(out.to_numpy(), acc, "1 x 70001 forward")
+    back = Jets.zeros(Jets.JetBSpace([Jets.JetSpace(np.float32, n)] * nrow))
+    check(lib.jh_blockop_mul_adj(h2, back.handle, m.handle))
+    assert_bits_equal(back.to_numpy(), want.ravel(), "1 x 70001 adjoint")
+    lib.jh_blockop_destroy(h)
+    lib.jh_blockop_destroy(h2)
