@@ -320,9 +320,10 @@ def blockop(ops, **kwargs) -> Jop:
 def _pointed_native(nat, ops, mo):
     """`nat` linearised about `mo`, or None when some nonlinear child sits at a point of its own (someone called point!
     on the child, not on the block jet): then the per-child loop below is the faithful path."""
-    for op in ops.flat:                                        # JopElementwise children carry their own (refreshed in place) diagonal
-        if isinstance(op, JopNl) and op.jet.f is elementwise_f and not op.jet.s["pointed"][0]:
-            return None
+    if nat.host_f:                                             # JopElementwise children carry their own (refreshed in place) diagonal
+        for op in ops.flat:
+            if isinstance(op, JopNl) and op.jet.f is elementwise_f and not op.jet.s["pointed"][0]:
+                return None
     if not nat.nonlinear:
         return nat
     if mo is None or mo.length() != sum(domain(ops[0, jc]).length() for jc in builtins.range(ops.shape[1])):
