@@ -312,3 +312,24 @@ def test_lsqr_one_pass_and_two_pass_iterations_agree(Jets, oracle, monkeypatch):
     e1 = np.linalg.norm(r1.x.to_numpy() - x_true.to_numpy()) / np.linalg.norm(x_true.to_numpy())
     e0 = np.linalg.norm(r0.x.to_numpy() - x_true.to_numpy()) / np.linalg.norm(x_true.to_numpy())
     assert e1 == pytest.approx(e0, rel=1e-2) and e1 < 0.1                              # same convergence after 15 iterations
+
+
+def test_lsqr_one_pass_with_damping_and_warm_start(Jets, oracle):
+    """damp (Tikhonov, handled in the scalar recurrences) and x0 (u = b - A x0 through the fused forward) on the tall
+    fast path vs the fp64 CPU LSQR."""
+    dt, nrow, shape, iters = np.float64, 5, (24, 24, 6), 25
+    A, _, _, diags = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    matvec, rmatvec = _host_ops(diags, np.float64)
+    hb = u01(oracle, dt, 71, 0, nrow * n) - 0.5
+    b = Jets.from_numpy(hb, Jets.range(A))
+    xd, info = lsqr_fp64(matvec, rmatvec, hb, n, damp=0.4, atol=0.0, btol=0.0, conlim=0.0, maxiter=iters)
+    res = Jets.lsqr(A, b, damp=0.4, atol=0.0, btol=0.0, conlim=0.0, maxiter=iters)
+    assert res.itn == info["itn"]
+    np.testing.assert_allclose(res.x.to_numpy().ravel(order="F"), xd, rtol=1e-9, atol=1e-11)
+    x_un = (np.stack(diags) * hb.reshape(nrow, n)).sum(0) / (np.stack(diags) ** 2).sum(0)              # undamped least squares
+    x0 = Jets.from_numpy((x_un + 0.01).reshape(shape, order="F"))
+    res2 = Jets.lsqr(A, b, x0=x0, atol=0.0, btol=0.0, conlim=0.0, maxiter=40)
+    e0 = 0.01 * np.sqrt(n)
+    e1 = np.linalg.norm(res2.x.to_numpy().ravel(order="F") - x_un)
+    assert e1 < 0.2 * e0                                                             # the warm start is improved, not discarded
