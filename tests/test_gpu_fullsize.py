@@ -101,6 +101,27 @@ def test_config4_1024x256cubed_properties(Jets, oracle):
     d0 = Jets.rand(Jets.range(A), seed=3, stream=0)                          # needs a third 64 GiB slab
     lhs = float(Jets.dot(d, d0))                                             # <A m, d0>
     assert abs(lhs - md) / abs(lhs + md) < 1e-5
+    del d0
+
+    # --- one-pass Golub-Kahan step on the full-size vectors (d = A m at this point): u <- 0.75*(A m) - 1.375*u, w <- A'u
+    import ctypes as C
+
+    from jets_jl_amd._ffi import lib, check
+    from jets_jl_amd import jetblock
+
+    nat = jetblock._native_op(A.jet.s["_native"], A.jet.s["ops"], A.jet.rng.eltype())
+    w, out = Jets.zeros(Jets.domain(A)), C.c_double(0)
+    check(lib.jh_blockop_bidiag_step(nat.handle, d.handle, m.handle, w.handle, 0.75, -1.375, C.byref(out)))
+    f32 = np.float32
+    for off in (0, n // 2 + 64, n - W):
+        hm = oracle.rng_u01(f32, 2, 0, off, W)
+        ha = [oracle.rng_u01(f32, 1, 0, i * n + off, W) for i in range(nblocks)]
+        hu = [f32(0.75) * (g * hm) + f32(-1.375) * (g * hm) for g in ha]     # product, scale, scale, add: each rounded
+        for i in (0, 700, 1023):
+            assert_bits_equal(d._download(i * n + off, W), hu[i], f"step: u row {i} slice at {off}")
+        ref_w = oracle.block_df_adj([[oracle.Block("diag", W, coeff=g)] for g in ha], [np.zeros(W, dtype=f32)], hu)[0]
+        assert_bits_equal(w._download(off, W), ref_w, f"step: w slice at {off}")
+    assert out.value == pytest.approx(N * 0.625 ** 2 / 9, rel=1e-3)          # E[(0.625 a m)^2] = 0.625^2 / 9
 
 
 def test_config5_100_lsqr_iterations_on_1024x256cubed(Jets, oracle):
