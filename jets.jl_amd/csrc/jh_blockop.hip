@@ -596,8 +596,12 @@ __global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int
         for (int64_t j = 0; j < ncol; j++) {                               // (1020)
             const jh_dev_block b = blocks[i + j * nrow];
             if (b.kind == JH_OP_ZERO && !fmode) continue;                  // (1022); JetBlock_f! has no such test
-            elem<S, E> x = eload<S, E>(m, col_off[j] + e);
-            elem<S, E> p = apply_block<S, E>(b, x, e, false, fmode != 0);  // mul!(dtmp, op, _m)
+            elem<S, E> p;
+            p.re = 0; p.im = 0;                                            // a zero block's `d .= 0` (942): no load -- its column may be shorter than this row
+            if (b.kind != JH_OP_ZERO) {
+                elem<S, E> x = eload<S, E>(m, col_off[j] + e);
+                p = apply_block<S, E>(b, x, e, false, fmode != 0);         // mul!(dtmp, op, _m)
+            }
             acc = (ncol > 1) ? eadd<S, E>(acc, p) : p;                     // (1024) / (1026)
             touched = true;
         }
@@ -632,17 +636,23 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
 
 // 16-byte-per-lane variants of the two general kernels, used when every block offset, block length and
 // coefficient pointer is a multiple of 16 bytes.  Same loop order and rounding as the scalar versions.
+// does this block read a coefficient pack (DIAG: its diagonal; SQUARE as a Jacobian: its linearisation point)?
+__device__ inline bool block_reads_coeff(const jh_dev_block &b, bool fmode)
+{
+    return b.kind == JH_OP_DIAG || (b.kind == JH_OP_SQUARE && !(fmode && !b.adjoint));
+}
+
+// child mul! of an elementwise block on a 16-byte pack, coefficient pack already loaded (the kernels below issue the loads of
+// GENERAL_Q blocks before combining them)
 template <typename S, int E, int NS, typename V>
-__device__ inline V apply_block_vec(const jh_dev_block &b, V x, int64_t s, bool transposed, bool fmode = false)
+__device__ inline V apply_block_loaded(const jh_dev_block &b, V x, V c, bool transposed, bool fmode)
 {
     const bool cj = (b.adjoint != 0) != transposed;
     switch (b.kind) {
     case JH_OP_IDENTITY: return x;
-    case JH_OP_SQUARE: {
+    case JH_OP_SQUARE:
         if (fmode && !b.adjoint) return vmul<S, E, NS, V>(x, x, false);
-        const V mo = ld<false>(reinterpret_cast<const V *>((const S *)b.coeff + s));
-        return vmul<S, E, NS, V>(mo + mo, x, cj);
-    }
+        return vmul<S, E, NS, V>(c + c, x, cj);
     case JH_OP_SCALE: {
         if constexpr (E == 1) {
             return (V)(S)b.sre * x;
@@ -653,10 +663,15 @@ __device__ inline V apply_block_vec(const jh_dev_block &b, V x, int64_t s, bool 
             return vmul<S, E, NS, V>(a, x, cj);
         }
     }
-    case JH_OP_DIAG: return vmul<S, E, NS, V>(ld<false>(reinterpret_cast<const V *>((const S *)b.coeff + s)), x, cj);
+    case JH_OP_DIAG: return vmul<S, E, NS, V>(c, x, cj);
     default: return (V)(S)0;
     }
 }
+
+// Blocks whose loads are issued together per thread.  4 was measured no faster than 1 (0-10 % slower, within run-to-run spread) on every M x K shape but the tall
+// mixed adjoint (profiles/exp_r01_general_prefetch.txt): with one pack per lane and a full-size grid the chip already has
+// enough loads in flight, the extra registers only cost occupancy.
+constexpr int GENERAL_Q = 1;
 
 template <typename S, int E, int NS>
 __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
@@ -671,13 +686,32 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
         V acc = (V)(S)0;
         bool touched = false;
         if (ncol > 1) acc = ld<false>(reinterpret_cast<const V *>(d + row_off[i] * E + s));
-        for (int64_t j = 0; j < ncol; j++) {
-            const jh_dev_block b = blocks[i + j * nrow];
-            if (b.kind == JH_OP_ZERO && !fmode) continue;
-            V x = ld<false>(reinterpret_cast<const V *>(m + col_off[j] * E + s));
-            V p = apply_block_vec<S, E, NS, V>(b, x, s, false, fmode != 0);
-            acc = (ncol > 1) ? acc + p : p;
-            touched = true;
+        for (int64_t j0 = 0; j0 < ncol; j0 += GENERAL_Q) {                 // (1020), GENERAL_Q columns' loads in flight
+            jh_dev_block b[GENERAL_Q];
+            V x[GENERAL_Q], c[GENERAL_Q];
+            bool on[GENERAL_Q];
+#pragma unroll
+            for (int q = 0; q < GENERAL_Q; q++) {
+                const int64_t j = j0 + q;
+                on[q] = j < ncol;
+                x[q] = (V)(S)0;
+                c[q] = (V)(S)0;
+                if (on[q]) {
+                    b[q] = blocks[i + j * nrow];
+                    if (b[q].kind == JH_OP_ZERO) on[q] = (fmode != 0);     // (1022) skipped; f! keeps it as +0 -- and never loads for it
+                    else {
+                        x[q] = ld<false>(reinterpret_cast<const V *>(m + col_off[j] * E + s));
+                        if (block_reads_coeff(b[q], fmode != 0)) c[q] = ld<false>(reinterpret_cast<const V *>((const S *)b[q].coeff + s));
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < GENERAL_Q; q++)
+                if (on[q]) {
+                    const V p = apply_block_loaded<S, E, NS, V>(b[q], x[q], c[q], false, fmode != 0);   // mul!(dtmp, op, _m)
+                    acc = (ncol > 1) ? acc + p : p;                        // (1024) / (1026), columns in order
+                    touched = true;
+                }
         }
         if (touched) st<false>(reinterpret_cast<V *>(d + row_off[i] * E + s), acc);
     }
@@ -695,13 +729,32 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
     for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * NS; s < ns; s += (int64_t)gridDim.x * blockDim.x * NS) {
         V acc = (V)(S)0;
         bool touched = (nrow > 1);
-        for (int64_t i = 0; i < nrow; i++) {
-            const jh_dev_block b = blocks[i + j * nrow];
-            if (b.kind == JH_OP_ZERO) continue;
-            V x = ld<false>(reinterpret_cast<const V *>(d + row_off[i] * E + s));
-            V p = apply_block_vec<S, E, NS, V>(b, x, s, true);
-            acc = (nrow > 1) ? acc + p : p;
-            touched = true;
+        for (int64_t i0 = 0; i0 < nrow; i0 += GENERAL_Q) {                 // (1045), GENERAL_Q rows' loads in flight
+            jh_dev_block b[GENERAL_Q];
+            V x[GENERAL_Q], c[GENERAL_Q];
+            bool on[GENERAL_Q];
+#pragma unroll
+            for (int q = 0; q < GENERAL_Q; q++) {
+                const int64_t i = i0 + q;
+                on[q] = i < nrow;
+                x[q] = (V)(S)0;
+                c[q] = (V)(S)0;
+                if (on[q]) {
+                    b[q] = blocks[i + j * nrow];
+                    if (b[q].kind == JH_OP_ZERO) on[q] = false;            // (1047)
+                    else {
+                        x[q] = ld<false>(reinterpret_cast<const V *>(d + row_off[i] * E + s));
+                        if (block_reads_coeff(b[q], false)) c[q] = ld<false>(reinterpret_cast<const V *>((const S *)b[q].coeff + s));
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < GENERAL_Q; q++)
+                if (on[q]) {
+                    const V p = apply_block_loaded<S, E, NS, V>(b[q], x[q], c[q], true, false);         // mul!(mtmp, op', _d)
+                    acc = (nrow > 1) ? acc + p : p;                        // (1049) / (1051), rows in order
+                    touched = true;
+                }
         }
         if (touched) st<false>(reinterpret_cast<V *>(m + col_off[j] * E + s), acc);
     }

@@ -53,6 +53,9 @@ case("wide 1x64 diag", [["d"] * 64], n)
 case("4x4 identity (config 1 big)", [["i"] * 4 for _ in range(4)], 256 ** 3)
 case("8x8 diag", [["d"] * 8 for _ in range(8)], n)
 case("3x4 mixed with zeros", [["d", "i", "d", "s"], ["d", "z", "d", "d"], ["s", "d", "d", "z"]], 256 ** 3)
+case("wide 1x16 diag", [["d"] * 16], 256 ** 3)
+case("8x8 diag", [["d"] * 8 for _ in range(8)], 256 ** 3)
+case("tall 64x1 mixed d/s/i", [["d"] if i % 3 == 0 else (["s"] if i % 3 == 1 else ["i"]) for i in range(64)], 256 ** 3)
 
 
 def dense_case(nr, nc, dt=np.float32):
