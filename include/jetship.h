@@ -228,6 +228,12 @@ int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d,
  * (3*N*n + 2*n)*s bytes instead of (5*N*n + 3*n)*s.  The solver then forms v <- w/||u|| - ||u||*v on domain-sized vectors
  * (A' is linear, so the normalisation of u can follow the pass).  Tall all-DIAG operators; w must not alias v. */
 int jh_blockop_bidiag_step(const jh_blockop *op, jh_bvec *u, const jh_bvec *v, jh_bvec *w, double alpha, double beta, double *normsq);
+/* The same step restricted to the elements [first_elem, first_elem+count) of the domain (16-byte aligned bounds): updates
+ * those columns of every row of u, writes that range of w, and returns that range's share of ||u||^2 (the shares add up).
+ * Lets a row-partitioned multi-GPU solver all-reduce chunk k of w while chunk k+1 is being computed.  Identical values
+ * to jh_blockop_bidiag_step on those elements. */
+int jh_blockop_bidiag_step_range(const jh_blockop *op, jh_bvec *u, const jh_bvec *v, jh_bvec *w, double alpha, double beta,
+                                 int64_t first_elem, int64_t count, double *normsq);
 /* ---------------------------------------------------------------- RCCL over xGMI ----------- */
 /* Row partition of a tall operator across the GPUs of a node (one process per GPU): the forward needs no exchange
  * (src/Jets.jl:1015-1031), the adjoint is a sum over rows (1045-1053) -> one in-place all-reduce of the domain vector

@@ -109,6 +109,7 @@ SYMBOLS = {
     "jh_blockop_mul_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
     "jh_blockop_mul_adj_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _dblp]),
     "jh_blockop_bidiag_step": (_int, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
+    "jh_blockop_bidiag_step_range": (_int, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, _i64, _i64, _dblp]),
     "jh_comm_unique_id": (_int, [_vp]),
     "jh_comm_init_rank": (_int, [_vp, _int, _int]),
     "jh_comm_destroy": (_int, []),

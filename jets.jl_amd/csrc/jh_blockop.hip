@@ -321,17 +321,19 @@ template <typename S, int E, int NS, int U, int DEPTH, int BLK>
 __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                           const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ u,
                                                           const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, int direct,
-                                                          S alpha, S beta, double *__restrict__ partials)
+                                                          S alpha, S beta, double *__restrict__ partials, int64_t s_begin, int64_t s_end)
 {
+    // the launch covers the scalar range [s_begin, s_end) of the domain (the whole vector, or one chunk when a multi-GPU
+    // host pipelines the exchange of w chunk by chunk against this kernel)
     typedef typename vec_of<S, NS>::type V;
-    const int64_t s0 = ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
+    const int64_t s0 = s_begin + ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
     bool ok[U];
     int64_t sk[U];
     V acc[U], vv[U];
 #pragma unroll
     for (int k = 0; k < U; k++) {
-        ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
-        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
+        ok[k] = (s0 + (int64_t)k * BLK * NS) < s_end;
+        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : s_begin;
         acc[k] = (V)(S)0;
         vv[k] = ld<false>(reinterpret_cast<const V *>(v + sk[k]));
     }
@@ -1133,8 +1135,11 @@ int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n
 }
 
 template <typename S, int E, int NS>
-int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t n_scalars, double alpha, double beta, double *normsq)
+int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t n_scalars, double alpha, double beta, double *normsq,
+                  int64_t s_begin = 0, int64_t s_end = -1)
 {
+    if (s_end < 0) s_end = n_scalars;
+    if (s_end <= s_begin) { if (normsq) *normsq = 0.0; return JH_OK; }
     jh_context &c = jh_ctx();
     const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
     const int64_t a_stride = op->diag_stride_elems * E;
@@ -1150,13 +1155,13 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     if (c.adj_wg) wg = (int)c.adj_wg;                       // the adjoint's knobs select among the instantiated shapes
     if (c.adj_unroll) U = (int)c.adj_unroll;
     if (c.adj_depth) D = (int)c.adj_depth;
-    const int64_t gx = (nvec + (int64_t)wg * U - 1) / ((int64_t)wg * U);
+    const int64_t gx = ((s_end - s_begin) / NS + (int64_t)wg * U - 1) / ((int64_t)wg * U);
     JH_TRY(jh_ensure_partials(gx));
 #define JH_LAUNCH(BLK, UU, DD)                                                                                          \
     if (wg == BLK && U == UU && D == DD) {                                                                              \
         hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK>), dim3((unsigned)gx), dim3(BLK), 0, c.stream,      \
                            op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars, direct,  \
-                           (S)alpha, (S)beta, c.part_dev);                                                               \
+                           (S)alpha, (S)beta, c.part_dev, s_begin, s_end);                                               \
         JH_CHECK_HIP(hipGetLastError());                                                                                 \
         return finish_normsq(gx, normsq);                                                                                \
     }
@@ -1685,6 +1690,30 @@ int jh_blockop_bidiag_step(const jh_blockop *op, jh_bvec *u, const jh_bvec *v, j
     case JH_C64: return launch_bidiag<double, 2, 2>(op, u->data, v->data, w->data, 2 * n, alpha, beta, normsq);
     }
     return jh_fail(JH_ERR_INVALID, "jh_blockop_bidiag_step: unknown dtype %d", op->dtype);
+}
+
+int jh_blockop_bidiag_step_range(const jh_blockop *op, jh_bvec *u, const jh_bvec *v, jh_bvec *w, double alpha, double beta,
+                                 int64_t first_elem, int64_t count, double *normsq)
+{
+    JH_TRY(jh_require_ready());
+    JH_TRY(check_vectors(op, u, v, "jh_blockop_bidiag_step_range"));
+    JH_REQUIRE(w && w->dtype == op->dtype && w->length == v->length, "jh_blockop_bidiag_step_range: w must be a domain vector of the operator");
+    JH_REQUIRE(w->data != v->data, "jh_blockop_bidiag_step_range: w must not alias v");
+    JH_REQUIRE(first_elem >= 0 && count >= 0 && first_elem + count <= v->length,
+               "jh_blockop_bidiag_step_range: elements [%lld, %lld) outside the domain vector (%lld elements)", (long long)first_elem,
+               (long long)(first_elem + count), (long long)v->length);
+    if (!tall_fast_ok(op, u->data, v->data) || (((uintptr_t)w->data) & 15u))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_bidiag_step_range: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
+    const int64_t es = (int64_t)jh_dtype_size(op->dtype);
+    JH_REQUIRE((first_elem * es) % 16 == 0 && (count * es) % 16 == 0, "jh_blockop_bidiag_step_range: chunk boundaries must be 16-byte aligned");
+    const int64_t n = op->row_len[0], lo = first_elem, hi = first_elem + count;
+    switch (op->dtype) {
+    case JH_F32: return launch_bidiag<float, 1, 4>(op, u->data, v->data, w->data, n, alpha, beta, normsq, lo, hi);
+    case JH_F64: return launch_bidiag<double, 1, 2>(op, u->data, v->data, w->data, n, alpha, beta, normsq, lo, hi);
+    case JH_C32: return launch_bidiag<float, 2, 4>(op, u->data, v->data, w->data, 2 * n, alpha, beta, normsq, 2 * lo, 2 * hi);
+    case JH_C64: return launch_bidiag<double, 2, 2>(op, u->data, v->data, w->data, 2 * n, alpha, beta, normsq, 2 * lo, 2 * hi);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blockop_bidiag_step_range: unknown dtype %d", op->dtype);
 }
 
 int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double alpha, double beta, double *normsq)

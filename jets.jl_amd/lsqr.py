@@ -157,6 +157,7 @@ class _ShardEngine(_Engine):
     def __init__(self, shard):
         super().__init__(shard.local_op)
         self.shard = shard
+        self.force_collective = os.environ.get("BENCH_FORCE_DIST", "0") == "1"   # run the exchange even with one rank (validation)
 
     def norm_rng(self, x) -> float:
         return self.shard.norm_range(x, 2)
@@ -165,6 +166,12 @@ class _ShardEngine(_Engine):
         return math.sqrt(self.shard.comm.all_reduce_scalars([self._fwd_local(u, v, alpha, beta)], "sum")[0])
 
     def step(self, u, v, alpha, beta):
+        if self.native is not None and self.fused_step:  # pipelined: all-reduce of a finished chunk of A'u under the next chunk's kernel
+            if self._tmp_d is None:
+                self._tmp_d = zeros(_j.domain(self.A))
+            nrm2 = self.shard.bidiag_step_(u, v, self._tmp_d, alpha, beta, force_collective=self.force_collective)
+            if nrm2 is not None:
+                return math.sqrt(nrm2), self._tmp_d
         r = self._step_local(u, v, alpha, beta)          # this rank's rows: local ||u||^2 and local A'u
         if r is None:
             return None

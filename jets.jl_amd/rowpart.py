@@ -18,6 +18,7 @@ product wiring (`for_device`) uses the HIP path only.
 from __future__ import annotations
 
 import builtins
+import ctypes as C
 import math
 from dataclasses import dataclass
 from typing import Callable
@@ -150,10 +151,23 @@ class RowPartitionedOp:
     """This rank's shard of a tall block operator plus the exchange step."""
 
     def __init__(self, part: RowPartition, local_op, comm: Comm, local_mul: Callable, local_mul_adj: Callable,
-                 local_dot: Callable, local_norm: Callable, pipelined_adj: Callable | None = None):
+                 local_dot: Callable, local_norm: Callable, pipelined_adj: Callable | None = None,
+                 pipelined_step: Callable | None = None):
         self.part, self.local_op, self.comm = part, local_op, comm
         self._mul, self._mul_adj, self._dot, self._norm = local_mul, local_mul_adj, local_dot, local_norm
         self._pipelined_adj = pipelined_adj   # optional: local adjoint and all-reduce pipelined chunk by chunk
+        self._pipelined_step = pipelined_step  # optional: one-pass Golub-Kahan step, its w all-reduced chunk by chunk
+
+    def bidiag_step_(self, u_local, v, w, alpha: float, beta: float, force_collective: bool = False):
+        """u_local <- alpha*(A_local v) + beta*u_local ; w <- sum over ALL ranks of A_local' u_local, the all-reduce of a
+        finished chunk of w overlapping the kernel of the next.  Returns the GLOBAL ||u||^2, or None when the local
+        operator has no ranged one-pass kernel (the caller then runs the step in one piece)."""
+        if self._pipelined_step is None or not (self.comm.world > 1 or force_collective):
+            return None
+        local = self._pipelined_step(u_local, v, w, alpha, beta)
+        if local is None:
+            return None
+        return self.comm.all_reduce_scalars([local], "sum")[0]
 
     def mul_(self, d_local, m):
         """d_local = A[rows of this rank] m   -- no communication."""
@@ -254,5 +268,41 @@ def for_device(part: RowPartition, local_op, comm=None) -> RowPartitionedOp:
                 w.wait()                                      # the library stream waits for every chunk's all-reduce
         return True
 
+    def pipelined_step(u, v, w, alpha, beta):
+        """jh_blockop_bidiag_step in `nchunks` element ranges; returns the local ||u||^2 (sum of the chunks' shares) or
+        None when the operator has no ranged one-pass kernel."""
+        A = local_op
+        if nchunks <= 1 or not dist.is_initialized() or not _blk.isblockop(A):
+            return None
+        jt = A.jet
+        nat = _blk._native_op(jt.s.get("_native"), jt.s["ops"], jt.rng.eltype())
+        if nat is None:
+            return None
+        n = w.length()
+        step = -(-n // nchunks)
+        step = -(-step // 16384) * 16384
+        key = id(w)
+        if key not in views or views[key][0] is not w:
+            views[key] = (w, as_tensor(w))
+        t = views[key][1]
+        works, total, lo = [], 0.0, 0
+        out = C.c_double(0)
+        try:
+            while lo < n:
+                cnt = builtins.min(step, n - lo)
+                check(lib.jh_blockop_bidiag_step_range(nat.handle, u.handle, v.handle, w.handle, float(alpha), float(beta), lo, cnt, C.byref(out)))
+                total += out.value
+                with torch.cuda.stream(ext):
+                    works.append(dist.all_reduce(t[lo:lo + cnt], op=dist.ReduceOp.SUM, async_op=True))
+                lo += cnt
+        except JetsHipError as e:
+            if e.status == 4 and not works:
+                return None
+            raise
+        with torch.cuda.stream(ext):
+            for wk in works:
+                wk.wait()
+        return total
+
     return RowPartitionedOp(part, local_op, comm, lambda d, A, m: mul_(d, A, m), lambda m, A, d: mul_(m, adjoint(A), d), dot, norm,
-                            pipelined_adj=pipelined_adj)
+                            pipelined_adj=pipelined_adj, pipelined_step=pipelined_step)

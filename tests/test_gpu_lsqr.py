@@ -333,3 +333,68 @@ def test_lsqr_one_pass_with_damping_and_warm_start(Jets, oracle):
     e0 = 0.01 * np.sqrt(n)
     e1 = np.linalg.norm(res2.x.to_numpy().ravel(order="F") - x_un)
     assert e1 < 0.2 * e0                                                             # the warm start is improved, not discarded
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_ranged_bidiag_step_equals_the_whole_step(Jets, oracle, dt):
+    """jh_blockop_bidiag_step_range over a partition of the domain == jh_blockop_bidiag_step: same u, same w, shares of
+    ||u||^2 adding up (what the pipelined multi-GPU LSQR step runs per chunk)."""
+    from jets_jl_amd._ffi import lib, check
+
+    nrow, shape = 5, (48, 40, 9)
+    A, _, _, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    nat = _native(Jets, A)
+    v = Jets.rand(Jets.domain(A), seed=81, stream=0)
+    u1, u2 = Jets.rand(Jets.range(A), seed=82, stream=0), Jets.rand(Jets.range(A), seed=82, stream=0)
+    w1, w2 = Jets.zeros(Jets.domain(A)), Jets.zeros(Jets.domain(A))
+    out = C.c_double(0)
+    check(lib.jh_blockop_bidiag_step(nat.handle, u1.handle, v.handle, w1.handle, 0.75, -1.375, C.byref(out)))
+    whole = out.value
+    total, lo = 0.0, 0
+    for cnt in (4096, 16, n // 2 // 16 * 16, 0):                                      # ragged chunks, one empty
+        check(lib.jh_blockop_bidiag_step_range(nat.handle, u2.handle, v.handle, w2.handle, 0.75, -1.375, lo, cnt, C.byref(out)))
+        total += out.value
+        lo += cnt
+    check(lib.jh_blockop_bidiag_step_range(nat.handle, u2.handle, v.handle, w2.handle, 0.75, -1.375, lo, n - lo, C.byref(out)))
+    total += out.value
+    assert_bits_equal(u2.to_numpy(), u1.to_numpy(), "u: chunks == whole")
+    assert_bits_equal(w2.to_numpy(), w1.to_numpy(), "w: chunks == whole")
+    assert total == pytest.approx(whole, rel=1e-12)
+    if np.dtype(dt).itemsize < 16:
+        assert lib.jh_blockop_bidiag_step_range(nat.handle, u2.handle, v.handle, w2.handle, 1.0, 0.0, 1, 16, C.byref(out)) == 1   # unaligned bound
+    assert lib.jh_blockop_bidiag_step_range(nat.handle, u2.handle, v.handle, w2.handle, 1.0, 0.0, 0, n + 16, C.byref(out)) == 1
+
+
+def test_pipelined_distributed_step_with_one_rank(Jets, oracle, monkeypatch):
+    """The row-partitioned one-pass LSQR step with its chunked all-reduce, forced to run with ONE rank over RCCL:
+    same iterates as the single-process solver."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        dt, nrow, shape = np.float32, 6, (64, 64, 16)
+        A, _, _, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+        x_true = Jets.rand(Jets.domain(A), seed=91, stream=0)
+        b = Jets.mul(A, x_true)
+        ref = Jets.lsqr(A, b, maxiter=12, atol=0.0, btol=0.0, force_maxiter=True)
+        shard = Jets.rowpart.for_device(Jets.rowpart.partition_rows(nrow, 1, 0), A)
+        monkeypatch.setenv("BENCH_FORCE_DIST", "1")
+        res = Jets.lsqr(shard, b, maxiter=12, atol=0.0, btol=0.0, force_maxiter=True)
+        assert res.itn == ref.itn == 12
+        np.testing.assert_allclose([h[1] for h in res.history], [h[1] for h in ref.history], rtol=1e-5)
+        np.testing.assert_allclose(res.x.to_numpy(), ref.x.to_numpy(), rtol=1e-5, atol=1e-6)
+        u, v, w = Jets.rand(Jets.range(A), seed=92, stream=0), Jets.rand(Jets.domain(A), seed=93, stream=0), Jets.zeros(Jets.domain(A))
+        nrm2 = shard.bidiag_step_(u, v, w, 1.0, -0.5, force_collective=True)          # the chunked path really ran
+        assert nrm2 is not None and nrm2 > 0
+        Jets.synchronize()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
