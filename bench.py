@@ -115,16 +115,20 @@ def main():
     import torch
 
     force_dist = os.environ.get("BENCH_FORCE_DIST", "0") == "1"      # run the RCCL path even with one rank (validation)
+    ndev = torch.cuda.device_count()                                  # (does not initialise the GPU)
+    if ndev < 1:
+        raise SystemExit("bench.py: no MI355X visible -- there is no CPU path to fall back to")
+    device = local_rank % ndev                                        # a launcher that narrows HIP_VISIBLE_DEVICES per rank leaves one device
     dist = None
     if world > 1 or (force_dist and "RANK" in os.environ):
         import torch.distributed as dist  # noqa: F811
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
 
     import jets_jl_amd as J
 
-    J.init(local_rank)
+    J.init(device)
     if args.tune:
         J.tune(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
 
