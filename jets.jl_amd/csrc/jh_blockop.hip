@@ -873,23 +873,29 @@ int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n
 template <typename S, int E, int NS>
 int launch_tall_fwd_shape(const jh_blockop *op, void *d, const void *m, int64_t n_scalars, const TallShape &sh);
 
+// the shapes the first forward of a large operator is timed with: which one wins differs from process to process
+// (profiles/repeat_r01*.txt, sweep_r01_order.txt): sequential sweeps, and walks that touch every row group concurrently
+constexpr int K_FWD_CANDIDATES = 5;
+const TallShape k_fwd_candidates[K_FWD_CANDIDATES] = {TallShape{1024, 8, 16, 0}, TallShape{512, 1, 2, 1}, TallShape{256, 4, 4, 0},
+                                                      TallShape{256, 4, 16, 1}, TallShape{512, 4, 8, 1}};
+
 // For operators far larger than the caches the row-concurrent walk is 5-7 % faster than the sequential sweep in
 // some processes and 10-15 % slower in others (profiles/repeat_r01.txt: same binary, same box; it depends on where
-// the slabs landed physically), so the first forward of such an operator times both once (6 extra launches of an
-// idempotent kernel, ~0.15 s, synchronous) and keeps the winner.  Skipped while the stream is being captured.
+// the slabs landed physically), so the first forward of such an operator times both once (10 extra launches of an
+// idempotent kernel, ~0.25 s, synchronous) and keeps the winner.  Skipped while the stream is being captured.
 template <typename S, int E, int NS>
 int autotune_fwd_walk(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
 {
     jh_context &c = jh_ctx();
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(c.stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return JH_OK;   // stay untried
-    const TallShape cand[3] = {TallShape{1024, 8, 16, 0}, TallShape{512, 1, 2, 1}, TallShape{256, 4, 4, 0}};
+    const TallShape *cand = k_fwd_candidates;
     float best = 0.f;
     int pick = 0;
     hipEvent_t e0, e1;
     JH_CHECK_HIP(hipEventCreate(&e0));
     JH_CHECK_HIP(hipEventCreate(&e1));
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < K_FWD_CANDIDATES; k++) {
         int st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, cand[k]);          // warm
         if (st == JH_OK) st = (hipEventRecord(e0, c.stream) == hipSuccess) ? JH_OK : JH_ERR_HIP;
         if (st == JH_OK) st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, cand[k]);
@@ -915,9 +921,7 @@ int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scal
     const double stream_bytes = 2.0 * (double)op->nrow * (double)n_scalars * sizeof(S);
     if (c.autotune && knobs_free && stream_bytes >= 8.0 * (double)(1ull << 30) && op->nrow >= 64) {
         if (op->fwd_walk < 0) JH_TRY((autotune_fwd_walk<S, E, NS>(op, d, m, n_scalars)));
-        if (op->fwd_walk == 1) sh = TallShape{512, 1, 2, 1};
-        else if (op->fwd_walk == 0) sh = TallShape{1024, 8, 16, 0};
-        else if (op->fwd_walk == 2) sh = TallShape{256, 4, 4, 0};
+        if (op->fwd_walk >= 0 && op->fwd_walk < K_FWD_CANDIDATES) sh = k_fwd_candidates[op->fwd_walk];
     }
     return launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, sh);
 }

@@ -119,7 +119,7 @@ struct jh_blockop {
     // hipGraph replay of the per-block loop (operators with DENSE blocks: 2 launches per block), keyed on the vectors' addresses
     struct LoopGraph { const void *out; const void *in; int mode; int seen; uint64_t gen; hipGraphExec_t exec; };
     mutable std::vector<LoopGraph> loop_graphs;
-    mutable int fwd_walk = -1;               // autotuned tall-forward shape: -1 untried, 0 sequential 1024x8x16, 1 all rows 512x1x2, 2 sequential 256x4x4
+    mutable int fwd_walk = -1;               // autotuned tall-forward shape: -1 untried, else an index into k_fwd_candidates (jh_blockop.hip)
     mutable int upd_walk = -1;               // same for the fused forward update (timed on its first two real calls)
     mutable int upd_trials = 0;
     mutable float upd_ms[2] = {0.f, 0.f};
