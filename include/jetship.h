@@ -120,11 +120,11 @@ int jh_copy(jh_bvec *dst, const jh_bvec *src);
 /* convert(Array, x) (src/Jets.jl:862-868) and its inverse, on an element range of the slab */
 int jh_download(const jh_bvec *v, int64_t offset, int64_t count, void *host_dst);
 int jh_upload(jh_bvec *v, int64_t offset, int64_t count, const void *host_src);
-/* Page-locked host memory for the copies above.  A pageable host buffer moves through the runtime's staging copy
- * (~9 GB/s on this box); a page-locked one is DMA'd directly at the PCIe rate.  jh_host_alloc/free give the host language a
- * pinned buffer to wrap as an array (Julia: unsafe_wrap); jh_host_register/unregister pin an EXISTING host array in place
- * (worth it when the same array is transferred repeatedly: pinning costs about one pageable copy).  Neither changes any
- * result; both are optional. */
+/* Page-locked host memory for the copies above.  Measured on the MI355X box (profiles/bench_pcie_r01.txt): 55-57 GB/s
+ * each way for warm host arrays, pageable or page-locked alike, but 8-9 GB/s into a freshly allocated pageable array whose
+ * pages are first touched by the copy; a page-locked buffer never pays that.  jh_host_alloc/free give the host language a
+ * pinned buffer to wrap as an array (Julia: unsafe_wrap); jh_host_register/unregister pin an EXISTING host array in place.
+ * Neither changes any result; both are optional. */
 int jh_host_alloc(size_t bytes, void **out);
 int jh_host_free(void *ptr);
 int jh_host_register(void *ptr, size_t bytes);
