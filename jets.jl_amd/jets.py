@@ -31,7 +31,8 @@ __all__ = [
     "state", "state_", "perfstat", "point", "point_", "close", "jet", "shape", "size", "jacobian_", "jacobian", "adjoint",
     "mul_", "mul", "JetComposite", "JetComposite_f", "JetComposite_df", "JetComposite_df_adj", "compose", "JetSum",
     "JetSum_f", "JetSum_df", "JetSum_df_adj", "JetVec", "JopVec", "JetVec_f", "JetVec_df", "JetVec_df_adj", "vec_op",
-    "scale_op", "constdiag_df", "constdiag_df_adj", "dot_product_test", "copy_op", "PLUS", "MINUS",
+    "scale_op", "constdiag_df", "constdiag_df_adj", "dot_product_test", "linearization_test", "linearity_test", "copy_op",
+    "PLUS", "MINUS",
 ]
 
 
@@ -580,3 +581,54 @@ def dot_product_test(op: JopLn, m, d, mmask=None, dmask=None):
     if np.iscomplexobj(lhs) and np.iscomplexobj(rhs):  # :1221-1225
         return lhs, rhs
     return np.real(lhs), np.real(rhs)
+
+
+def linearization_test(F: JopNl, mo, mu=(1.0, 0.5, 0.25, 0.125, 0.0625, 0.03125), dm=None, mmask=None, dmask=None, seed=None):
+    """mu_obs, mu_exp = linearization_test(F, mo; mu, dm, mmask, dmask, seed)  (src/Jets.jl:1228-1269): the Jacobian of F
+    satisfies F(mo + mu dm) = F(mo) + mu J dm + O(mu^2), so halving mu divides the misfit by 4.  All vector work on the
+    device (F!, point!, J, fused broadcasts, norms)."""
+    from .arrays import rand, lincomb_, norm
+
+    mmask = ones(domain(F)) if mmask is None else mmask  # :1238
+    dmask = ones(range_(F)) if dmask is None else dmask  # :1239
+    if dm is None:  # :1242-1243   dm = mmask .* (-1 .+ 2 .* rand(domain(F)))
+        r = rand(domain(F)) if seed is None else rand(domain(F), seed=int(seed), stream=0)
+        lincomb_(r, [2.0], [r])
+        r2 = ones(domain(F))
+        lincomb_(r, [1.0, -1.0], [r, r2])
+        dm = hadamard_(r, mmask, r)
+    else:
+        dm = hadamard_(dm, mmask, dm)  # :1245   dm .*= mmask
+    Fo = mul(F, mo)  # :1248
+    Jo = jacobian_(F, mo)  # :1249
+    Jodm = mul(Jo, dm)  # :1250
+    mus = sorted((float(x) for x in mu), reverse=True)  # :1252
+    phi = []
+    d_lin, m_mu = _arr.similar(Fo), _arr.similar(mo)
+    for x in mus:
+        lincomb_(d_lin, [1.0, x], [Fo, Jodm])  # :1258   d_lin = Fo .+ mu .* Jo dm
+        lincomb_(m_mu, [1.0, x], [mo, dm])
+        d_non = mul(F, m_mu)  # :1259   (re-points nothing: F's jet keeps mo until the next point!)
+        lincomb_(d_non, [1.0, -1.0], [d_non, d_lin])
+        hadamard_(d_non, dmask, d_non)
+        phi.append(float(norm(d_non)))  # :1260
+    mu_obs = [phi[i - 1] / phi[i] for i in builtins.range(1, len(mus))]  # :1262
+    mu_exp = [(mus[i - 1] / mus[i]) ** 2 for i in builtins.range(1, len(mus))]  # :1263
+    return np.array(mu_obs), np.array(mu_exp)
+
+
+def linearity_test(A, m1=None, m2=None):
+    """lhs, rhs = linearity_test(A)  (src/Jets.jl:1271-1283): A(m1 + m2) against A m1 + A m2."""
+    from .arrays import rand, lincomb_
+
+    def draw():  # :1279   -1 .* 2 .* rand(domain(A))
+        r = rand(domain(A))
+        return lincomb_(r, [-2.0], [r])
+
+    m1 = draw() if m1 is None else m1
+    m2 = draw() if m2 is None else m2
+    s12 = lincomb_(_arr.similar(m1), [1.0, 1.0], [m1, m2])
+    lhs = mul(A, s12)  # :1281
+    a1, a2 = mul(A, m1), mul(A, m2)
+    rhs = lincomb_(a1, [1.0, 1.0], [a1, a2])  # :1282
+    return lhs, rhs

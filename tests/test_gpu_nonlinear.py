@@ -409,3 +409,25 @@ def test_gauss_newton_with_elementwise_children_and_device_lsqr(Jets, oracle):
         step = Jets.lsqr(J, r, maxiter=30, atol=1e-14, btol=1e-14).x
         Jets.lincomb_(m, [1.0, 1.0], [m, step])
     np.testing.assert_allclose(m.to_numpy(), x_true, rtol=1e-9)
+
+
+def test_linearization_and_linearity_tests(Jets, oracle):
+    """test/runtests.jl:920-930: linearization_test on JopBar (observed ratios == (mu_{i-1}/mu_i)^2 for a quadratic f),
+    linearity_test on JopFoo; and on block operators."""
+    spc = Jets.JetSpace(np.float64, 10)
+    F = Jets.JopSquare(spc)
+    mu_obs, mu_exp = Jets.linearization_test(F, Jets.rand(spc), seed=7)
+    assert np.max(mu_obs) == pytest.approx(np.max(mu_exp), rel=1e-8)                  # @test maximum(mu_obs) ≈ maximum(mu_exp)
+    np.testing.assert_allclose(mu_obs, 4.0, rtol=1e-8)                                # exactly second order: m.^2
+    A = Jets.JopDiagonal(Jets.rand(spc))
+    lhs, rhs = Jets.linearity_test(A)
+    np.testing.assert_allclose(lhs.to_numpy(), rhs.to_numpy(), rtol=1e-13)            # @test lhs ≈ rhs
+    R = Jets.JetSpace(np.float64, 2000)
+    G = Jets.blockop([[Jets.JopElementwise(R, "exp(x0)", "exp(x0)")], [Jets.JopSquare(R)], [Jets.JopElementwise(R, "sin(x0)", "cos(x0)")]])
+    mu_obs, mu_exp = Jets.linearization_test(G, Jets.rand(R), mu=(0.1, 0.05, 0.025, 0.0125), seed=8)
+    np.testing.assert_allclose(mu_obs, mu_exp, rtol=0.15)                             # second order up to O(mu^3) terms
+    J = Jets.jacobian_(G, Jets.rand(R))
+    lhs, rhs = Jets.linearity_test(J)
+    np.testing.assert_allclose(lhs.to_numpy(), rhs.to_numpy(), rtol=1e-12, atol=1e-13)
+    lhs, rhs = Jets.linearity_test(J.H)
+    np.testing.assert_allclose(lhs.to_numpy(), rhs.to_numpy(), rtol=1e-12, atol=1e-13)
