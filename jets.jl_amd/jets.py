@@ -31,7 +31,7 @@ __all__ = [
     "state", "state_", "perfstat", "point", "point_", "close", "jet", "shape", "size", "jacobian_", "jacobian", "adjoint",
     "mul_", "mul", "JetComposite", "JetComposite_f", "JetComposite_df", "JetComposite_df_adj", "compose", "JetSum",
     "JetSum_f", "JetSum_df", "JetSum_df_adj", "JetVec", "JopVec", "JetVec_f", "JetVec_df", "JetVec_df_adj", "vec_op",
-    "scale_op", "constdiag_df", "constdiag_df_adj", "dot_product_test", "linearization_test", "linearity_test", "copy_op",
+    "scale_op", "constdiag_df", "constdiag_df_adj", "dot_product_test", "linearization_test", "linearity_test", "convert_op", "copy_op",
     "PLUS", "MINUS",
 ]
 
@@ -632,3 +632,22 @@ def linearity_test(A, m1=None, m2=None):
     a1, a2 = mul(A, m1), mul(A, m2)
     rhs = lincomb_(a1, [1.0, 1.0], [a1, a2])  # :1282
     return lhs, rhs
+
+
+def convert_op(A) -> np.ndarray:
+    """convert(Array, A::Jop)  (src/Jets.jl:1172-1183): the operator's matrix, one column per unit vector of the domain
+    (size(A,2) products on the device: a debugging aid for small operators, like the reference's)."""
+    from .arrays import fill_
+
+    nr, nc = size(A)
+    m, d = zeros(domain(A)), zeros(range_(A))
+    B = np.zeros((nr, nc), dtype=eltype(A))
+    for icol in builtins.range(nc):
+        fill_(m, 0)  # :1177
+        fill_(d, 0)  # :1178
+        if hasattr(m, "indices"):
+            m[icol] = 1  # :1179  (BlockArray linear indexing, src/Jets.jl:825-827)
+        else:
+            m._upload(np.ones(1, dtype=m.dtype), icol)
+        B[:, icol] = mul_(d, A, m).to_numpy().ravel(order="F")  # :1180
+    return B

@@ -205,6 +205,9 @@ def test_block_operator_3x4_with_nonlinear_zero_and_composite_blocks(Jets, T):
     dirty = Jets.from_numpy(RNG.random(40), Jets.domain(L))
     assert approx(Jets.mul_(dirty, L.H, dd), expect_adj)                                            # :684
     assert Jets.eltype(L) == np.dtype(F64)
+    K = Jets.convert_op(L)                                                                          # :686  K = convert(Array, L)
+    assert K.shape == (30, 40) and approx(L * dm, K @ dm.to_numpy())                                # :688
+    assert approx(L.H * dd, K.T @ hdd)
     _J12 = Jets.getblock_op(J, 0, 1)
     hx = RNG.random(10)
     assert approx(J12 * Jets.from_numpy(hx), _J12 * Jets.from_numpy(hx))                            # :691-694
