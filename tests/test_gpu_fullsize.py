@@ -103,6 +103,14 @@ def test_config4_1024x256cubed_properties(Jets, oracle):
     assert abs(lhs - md) / abs(lhs + md) < 1e-5
     del d0
 
+    # --- JIT broadcast over 2^34 elements (2^32 packs: beyond one lane per pack, the generated kernel strides), in place
+    Jets.broadcast_(d, "s0*x0 + x0*x0", [d], [3.0])
+    for i in (0, 511, 1023):
+        for off in (0, n - W):
+            t = oracle.rng_u01(np.float32, 1, 0, i * n + off, W) * oracle.rng_u01(np.float32, 2, 0, off, W)   # d_i = a_i .* m
+            assert_bits_equal(d._download(i * n + off, W), np.float32(3.0) * t + t * t, f"broadcast row {i} slice at {off}")
+    Jets.mul_(d, A, m)                                                       # back to d = A m for the step below
+
     # --- one-pass Golub-Kahan step on the full-size vectors (d = A m at this point): u <- 0.75*(A m) - 1.375*u, w <- A'u
     import ctypes as C
 
