@@ -88,6 +88,15 @@ function Base.convert(::Type{Array}, x::Union{HipBlockArray{T},HipArray{T}}) whe
     x isa HipArray ? reshape(out, size(x)) : out
 end
 
+# a page-locked host array (jh_host_alloc) for the copies above: no first-touch page faults under the DMA
+function pinned_array(::Type{T}, dims::Integer...) where {T}
+    p = Ref{Ptr{Cvoid}}()
+    check(ccall((:jh_host_alloc, LIB), Cint, (Csize_t, Ref{Ptr{Cvoid}}), prod(dims) * sizeof(T), p))
+    a = unsafe_wrap(Array, convert(Ptr{T}, p[]), dims; own=false)
+    finalizer(_ -> ccall((:jh_host_free, LIB), Cint, (Ptr{Cvoid},), p[]), a)
+    a
+end
+
 # fill!, norm, dot, extrema (:834-885)
 Base.fill!(x::Union{HipBlockArray,HipArray}, a) = (check(ccall((:jh_fill, LIB), Cint, (Ptr{Cvoid}, Cdouble, Cdouble), x.handle, real(a), imag(a))); x)
 function LinearAlgebra.norm(x::Union{HipBlockArray{T},HipArray{T}}, p::Real=2) where {T}
