@@ -599,7 +599,11 @@ def reshape(x, R):
 
 
 def vec(x):
-    """vec(x): 1-D view sharing memory."""
+    """vec(x): 1-D view sharing memory; vec(R): the space backed by one-dimensional arrays (src/Jets.jl:1127-1128)."""
+    if isinstance(x, JetBSpace):
+        return x
+    if isinstance(x, JetSpace):
+        return JetSpace(x.eltype(), x.length())
     if isinstance(x, BlockArray):
         return x
     return x.reshape((x.length(),))

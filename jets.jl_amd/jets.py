@@ -73,8 +73,29 @@ def df_adj_(m, jet_: Jet, d, **kw):  # :192
     return jet_.df_adj(m, d, **kw)
 
 
+def _as_op(x):
+    """A Jop as it is; a MATRIX operand of a composition or a sum (src/Jets.jl:572-576, 691-692, 707-708: `A3 o A2` with a plain
+    Julia matrix A3) wrapped as the dense operator d .= A*m / m .= A'*d: a 2-D device array, a 2-D numpy array (uploaded),
+    or a scaled device matrix like `3.0*A3`.  Anything else: None."""
+    if isinstance(x, Jop):
+        return x
+    from .arrays import LinExpr, from_numpy
+
+    if isinstance(x, LinExpr) and all(isinstance(t, DeviceArray) and len(t.shape) == 2 for _, t in x.terms):
+        x = x.materialize()
+    if isinstance(x, np.ndarray) and x.ndim == 2:
+        x = from_numpy(np.asfortranarray(x))
+    if isinstance(x, DeviceArray) and len(x.shape) == 2:
+        from .jetblock import JopDense
+
+        return JopDense(x)
+    return None
+
+
 class Jop:
     """abstract Jop (src/Jets.jl:194)."""
+
+    __array_ufunc__ = None  # numpy_matrix @ A, numpy_matrix + A reach __rmatmul__ / __radd__
 
     # A * m  (:399) ;  a * A (:1161-1164)
     def __mul__(self, m):
@@ -87,16 +108,29 @@ class Jop:
             return scale_op(a, self)
         return NotImplemented
 
-    def __matmul__(self, other):  # A2 o A1
-        if isinstance(other, Jop):
-            return compose(self, other)
-        return NotImplemented
+    def __matmul__(self, other):  # A2 o A1   (A1 may be a matrix, :575)
+        other = _as_op(other)
+        return compose(self, other) if other is not None else NotImplemented
 
-    def __add__(self, other):
-        return _sum(self, other, PLUS)
+    def __rmatmul__(self, other):  # matrix o A1   (:576)
+        other = _as_op(other)
+        return compose(other, self) if other is not None else NotImplemented
 
-    def __sub__(self, other):
-        return _sum(self, other, MINUS)
+    def __add__(self, other):  # (:689-692)
+        other = _as_op(other)
+        return _sum(self, other, PLUS) if other is not None else NotImplemented
+
+    def __radd__(self, other):
+        other = _as_op(other)
+        return _sum(other, self, PLUS) if other is not None else NotImplemented
+
+    def __sub__(self, other):  # (:705-708)
+        other = _as_op(other)
+        return _sum(self, other, MINUS) if other is not None else NotImplemented
+
+    def __rsub__(self, other):
+        other = _as_op(other)
+        return _sum(other, self, MINUS) if other is not None else NotImplemented
 
     @property
     def H(self):
