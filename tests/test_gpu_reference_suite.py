@@ -351,3 +351,104 @@ def test_dense_operator_shapes(Jets, dt, tol, nr, nc):
     lhs, rhs = Jets.dot_product_test(A, Jets.from_numpy(hx), Jets.from_numpy(hy))
     assert abs(lhs - rhs) <= 50 * tol * max(abs(lhs), scalea * np.linalg.norm(hx) / max(nc, 1) ** 0.5)
 
+
+
+# ---------------------------------------------------------------------------------- the remaining value-level test sets
+def test_linear_operator_set(Jets, T):
+    """test/runtests.jl:126-168."""
+    diag, hm = RNG.random(10), RNG.random(10)
+    A = T.JopFoo(diag)
+    m = T.dev(hm)
+    d = A * m
+    assert approx(d, diag * hm)
+    a = A.H * d
+    assert approx(a, diag * d.to_numpy())
+    Jets.fill_(d, 0)
+    Jets.mul_(d, A, m)
+    assert approx(d, diag * hm)
+    Jets.fill_(a, 0)
+    Jets.mul_(a, A.H, d)
+    assert approx(a, diag * d.to_numpy())
+    assert Jets.size(A) == (10, 10) and Jets.shape(A) == ((10,), (10,)) and Jets.size(A, 1) == 10 and Jets.shape(A, 2) == (10,)
+    assert Jets.domain(A) == Jets.JetSpace(F64, 10) and Jets.range(A) == Jets.JetSpace(F64, 10) and Jets.eltype(A) == np.dtype(F64)
+    assert approx(Jets.convert_op(A), np.diag(diag))                                   # :151
+    assert approx(Jets.state(A)["diagonal"], diag) and approx(Jets.state(A, "diagonal"), diag)
+    # JopFooBar (:35-39): a linear operator with df! only (df'! defaults to df!), 2-D space
+    hA = RNG.random((5, 5))
+    spc = Jets.JetSpace(F64, 5, 5)
+    B = Jets.JopLn(df=lambda d, m, *, A, **kw: Jets.hadamard_(d, A, m), dom=spc, rng=spc, s={"A": T.dev(hA)})
+    assert approx(Jets.convert_op(B), np.diag(hA.ravel(order="F")))                   # :157
+    m, d = Jets.rand(Jets.domain(B)), Jets.rand(Jets.range(B))
+    for mk in (Jets.jacobian, Jets.jacobian_):                                        # :160-167: the jacobian of a linear operator is itself
+        assert approx(mk(B, Jets.rand(Jets.domain(B))) * m, B * m)
+        assert approx(mk(B.H, Jets.rand(Jets.domain(B.H))).H * d, B.H * d)
+
+
+def test_nonlinear_operator_and_upstate_sets(Jets, T):
+    """test/runtests.jl:170-201."""
+    F = T.JopBar(10)
+    m = Jets.rand(Jets.domain(F))
+    hm = m.to_numpy()
+    d = F * m
+    assert approx(d, hm ** 2)
+    Jets.fill_(d, 0)
+    Jets.mul_(d, F, m)
+    assert approx(d, hm ** 2)
+    J = Jets.jacobian_(F, m)
+    assert approx(Jets.point(J), hm)
+    d = J * m
+    assert approx(d, 2 * hm * hm)
+    assert approx(J.H * d, 2 * hm * d.to_numpy())
+    assert Jets.size(F) == (10, 10) and Jets.shape(F) == ((10,), (10,)) and Jets.domain(F) == Jets.JetSpace(F64, 10)
+    # JopRosenbrock (:41-50): upstate! rewrites part of the state at every point!
+    spc = Jets.JetSpace(F64, 2)
+
+    def f(d, m, **kw):
+        h = m.to_numpy()
+        return Jets.copyto_(d, Jets.from_numpy(np.array([1 - h[0], 10 * (h[1] - h[0] ** 2)])))
+
+    def upstate(m, s):
+        Jm = s["J"].to_numpy()
+        Jm[1, 0] = -20.0 * m.to_numpy()[0]
+        Jets.copyto_(s["J"], Jets.from_numpy(np.asfortranarray(Jm)))
+
+    R = Jets.JopNl(f=f, df=lambda d, m, *, J, **kw: Jets.mul_(d, Jets.JopDense(J), m),
+                   df_adj=lambda m, d, *, J, **kw: Jets.mul_(m, Jets.JopDense(J).H, d), upstate=upstate, dom=spc, rng=spc,
+                   s={"J": T.dev(np.array([[-1.0, 0.0], [0.0, 10.0]]))})
+    hm = RNG.random(2)
+    Jr = Jets.jacobian_(R, T.dev(hm))
+    assert approx(Jets.state(Jr)["J"], np.array([[-1.0, 0.0], [-20 * hm[0], 10.0]]))   # :200
+    assert approx(Jr * T.dev(np.array([1.0, 2.0])), np.array([[-1.0, 0.0], [-20 * hm[0], 10.0]]) @ np.array([1.0, 2.0]))
+
+
+def test_composition_and_sum_with_matrix_operands(Jets, T):
+    """test/runtests.jl:328-356 and 490-498: a plain matrix takes part in `o`, `+` and `-`."""
+    B1, B2, B3, B4 = (RNG.random((10, 10)) for _ in range(4))
+    A1, A2, A4 = T.JopBaz(B1), T.JopBaz(B2), T.JopBaz(B4)
+    A3 = T.dev(B3)                                                                    # A3 = rand(10,10): a matrix, not an operator
+    A21, A321 = A2 @ A1, A3 @ A2 @ A1
+    A4321 = A4 @ A3 @ A2 @ A1
+    hm = RNG.random(10)
+    m = T.dev(hm)
+    assert approx(A21 * m, B2 @ (B1 @ hm)) and approx(A321 * m, B3 @ (B2 @ (B1 @ hm)))
+    d = A4321 * m
+    hd = d.to_numpy()
+    assert approx(d, B4 @ (B3 @ (B2 @ (B1 @ hm))))
+    assert approx(A21.H * d, B1.T @ (B2.T @ hd)) and approx(A321.H * d, B1.T @ (B2.T @ (B3.T @ hd)))
+    assert approx(A4321.H * d, B1.T @ (B2.T @ (B3.T @ (B4.T @ hd))))
+    assert Jets.domain(A4321) == Jets.JetSpace(F64, 10) and Jets.eltype(A4321) == np.dtype(F64)
+    assert approx(Jets.convert_op(A4321) @ hm, A4321 * m)                             # :354-355
+    S12 = A1 + A3                                                                     # :493   A1 + A2 (matrix)
+    S123 = A1 + A3 - A4
+    assert approx(S12 * m, B1 @ hm + B3 @ hm) and approx(S123 * m, B1 @ hm + B3 @ hm - B4 @ hm)
+
+
+def test_composition_operator_times_block_operator(Jets, T):
+    """test/runtests.jl:425-436: getblock of (block operator o operator) composes per block."""
+    A1 = T.JopFoo(RNG.random(2))
+    A2 = Jets.blockop([T.JopBar(2), T.JopBar(2)])
+    A = A2 @ A1
+    A11, A21 = Jets.getblock_op(A, 0, 0), Jets.getblock_op(A, 1, 0)
+    m = Jets.rand(Jets.domain(A))
+    Am = A * m
+    assert approx(Jets.getblock(Am, 0), A11 * m) and approx(Jets.getblock(Am, 1), A21 * m)
