@@ -581,16 +581,31 @@ __device__ inline elem<S, E> apply_block(const jh_dev_block &b, elem<S, E> x, in
     }
 }
 
-// JetBlock_df! (1010-1032): grid.y = block row, threads over the row's elements.
+// Grid of the general kernels: 1-D, (line, tile) decoded XCD-aware.  A "line" is a block row (forward) or a block column
+// (adjoint); a tile is 256 lanes' worth of its elements.  The lines of one tile read the SAME input elements (block j of
+// m is used by every block row; block i of d by every block column).  Workgroups are dispatched round-robin over the 8
+// XCDs, each with its own L2, so the lines of a tile get workgroup ids 8 apart: same XCD, dispatched together -- the shared
+// input comes from HBM once and from that L2 afterwards (without this an M x K operator with big blocks re-reads every
+// input block once per line: profiles/bench_blocks_nl_r01.txt).
+__device__ inline void general_line_tile(unsigned nlines, int64_t &line, int64_t &tile)
+{
+    const unsigned per = 8u * nlines;
+    const unsigned grp = blockIdx.x / per, rem = blockIdx.x - grp * per;
+    line = rem >> 3;
+    tile = (int64_t)grp * 8 + (rem & 7u);
+}
+
+// JetBlock_df! (1010-1032): one line per block row, threads over the row's elements.
 template <typename S, int E>
 __global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                     const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
-                                    const S *__restrict__ m, S *__restrict__ d, int fmode)
+                                    const S *__restrict__ m, S *__restrict__ d, int fmode, unsigned ntiles)
 {
-    const int64_t i = (int64_t)blockIdx.y + (int64_t)blockIdx.z * gridDim.y;   // block row (grid.y x grid.z: no 65535 cap)
-    if (i >= nrow) return;
+    int64_t i, tile;                                                       // block row, tile
+    general_line_tile((unsigned)nrow, i, tile);
+    if (tile >= ntiles) return;
     const int64_t n = row_off[i + 1] - row_off[i];
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t e = tile * 256 + threadIdx.x; e < n; e += (int64_t)ntiles * 256) {
         elem<S, E> acc;
         bool touched = false;
         if (ncol > 1) { acc = eload<S, E>(d, row_off[i] + e); }          // `_d .+=` accumulates into d as found (1024 / 1001)
@@ -615,12 +630,13 @@ __global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int
 template <typename S, int E>
 __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                     const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
-                                    S *__restrict__ m, const S *__restrict__ d)
+                                    S *__restrict__ m, const S *__restrict__ d, unsigned ntiles)
 {
-    const int64_t j = (int64_t)blockIdx.y + (int64_t)blockIdx.z * gridDim.y;   // block column
-    if (j >= ncol) return;
+    int64_t j, tile;                                                       // block column, tile
+    general_line_tile((unsigned)ncol, j, tile);
+    if (tile >= ntiles) return;
     const int64_t n = col_off[j + 1] - col_off[j];
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t e = tile * 256 + threadIdx.x; e < n; e += (int64_t)ntiles * 256) {
         elem<S, E> acc;
         acc.re = 0; acc.im = 0;                                            // `_m .= 0` when nrow > 1 (1042)
         bool touched = (nrow > 1);
@@ -678,13 +694,14 @@ constexpr int GENERAL_Q = 1;
 template <typename S, int E, int NS>
 __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                         const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
-                                        const S *__restrict__ m, S *__restrict__ d, int fmode)
+                                        const S *__restrict__ m, S *__restrict__ d, int fmode, unsigned ntiles)
 {
     typedef typename vec_of<S, NS>::type V;
-    const int64_t i = (int64_t)blockIdx.y + (int64_t)blockIdx.z * gridDim.y;   // block row (grid.y x grid.z: no 65535 cap)
-    if (i >= nrow) return;
+    int64_t i, tile;                                                       // block row, tile
+    general_line_tile((unsigned)nrow, i, tile);
+    if (tile >= ntiles) return;
     const int64_t ns = (row_off[i + 1] - row_off[i]) * E;                 // scalars in this block row
-    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * NS; s < ns; s += (int64_t)gridDim.x * blockDim.x * NS) {
+    for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < ns; s += (int64_t)ntiles * 256 * NS) {
         V acc = (V)(S)0;
         bool touched = false;
         if (ncol > 1) acc = ld<false>(reinterpret_cast<const V *>(d + row_off[i] * E + s));
@@ -722,13 +739,14 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
 template <typename S, int E, int NS>
 __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                         const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
-                                        S *__restrict__ m, const S *__restrict__ d)
+                                        S *__restrict__ m, const S *__restrict__ d, unsigned ntiles)
 {
     typedef typename vec_of<S, NS>::type V;
-    const int64_t j = (int64_t)blockIdx.y + (int64_t)blockIdx.z * gridDim.y;   // block column
-    if (j >= ncol) return;
+    int64_t j, tile;                                                       // block column, tile
+    general_line_tile((unsigned)ncol, j, tile);
+    if (tile >= ntiles) return;
     const int64_t ns = (col_off[j + 1] - col_off[j]) * E;
-    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * NS; s < ns; s += (int64_t)gridDim.x * blockDim.x * NS) {
+    for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < ns; s += (int64_t)ntiles * 256 * NS) {
         V acc = (V)(S)0;
         bool touched = (nrow > 1);
         for (int64_t i0 = 0; i0 < nrow; i0 += GENERAL_Q) {                 // (1045), GENERAL_Q rows' loads in flight
@@ -971,28 +989,38 @@ bool general_vec_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_p
     return true;
 }
 
+// tiles per line and the 1-D grid of the general kernels: ceil(ntiles / 8) * 8 * nlines workgroups of 256 lanes, < 2^24
+static inline void general_grid(int64_t want_tiles, int64_t nlines, unsigned &ntiles, unsigned &grid)
+{
+    int64_t cap = (((int64_t)1 << 24) / nlines) / 8 * 8 - 8;               // grid * 256 threads < 2^32
+    if (cap < 8) cap = 8;
+    if (want_tiles > cap) want_tiles = cap;                                // the kernels stride over the rest
+    if (want_tiles < 1) want_tiles = 1;
+    ntiles = (unsigned)want_tiles;
+    grid = (unsigned)(((want_tiles + 7) / 8) * 8 * nlines);
+}
+
 template <typename S, int E>
 int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
 {
     int64_t maxn = 0;
     for (int64_t i = 0; i < op->nrow; i++) maxn = op->row_len[i] > maxn ? op->row_len[i] : maxn;
     if (maxn == 0) return JH_OK;
-    JH_REQUIRE(op->nrow < ((int64_t)1 << 23), "general block forward supports fewer than 2^23 block rows (got %lld)", (long long)op->nrow);
-    const unsigned gy = (unsigned)(op->nrow < 65535 ? op->nrow : 65535), gz = (unsigned)((op->nrow + gy - 1) / gy);
+    JH_REQUIRE(op->nrow < ((int64_t)1 << 20), "general block forward supports fewer than 2^20 block rows (got %lld)", (long long)op->nrow);
+    unsigned ntiles, grid;
     if (general_vec_ok(op, d, m)) {
         constexpr int NS = 16 / sizeof(S);
-        int64_t gxv = (maxn * E / NS + 255) / 256;                         // one pack per thread (see jh_vecops.hip: grid_full)
-        const int64_t cap = (((int64_t)1 << 24) / op->nrow) - 1;           // grid.x * grid.y * 256 threads < 2^32
-        if (gxv > cap) gxv = cap > 0 ? cap : 1;
-        hipLaunchKernelGGL((k_block_fwd_general_vec<S, E, NS>), dim3((unsigned)gxv, gy, gz), dim3(256), 0, jh_ctx().stream,
-                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode);
+        general_grid((maxn * E / NS + 255) / 256, op->nrow, ntiles, grid);                 // one pack per thread (see jh_vecops.hip: grid_full)
+        hipLaunchKernelGGL((k_block_fwd_general_vec<S, E, NS>), dim3(grid), dim3(256), 0, jh_ctx().stream,
+                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode, ntiles);
         JH_CHECK_HIP(hipGetLastError());
         return JH_OK;
     }
-    int64_t gx = (maxn + 255) / 256;
-    if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3((unsigned)gx, gy, gz), dim3(256), 0, jh_ctx().stream,
-                       op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode);
+    int64_t want = (maxn + 255) / 256;
+    if (want > 4096) want = 4096;
+    general_grid(want, op->nrow, ntiles, grid);
+    hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3(grid), dim3(256), 0, jh_ctx().stream,
+                       op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode, ntiles);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -1003,22 +1031,21 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
     int64_t maxn = 0;
     for (int64_t j = 0; j < op->ncol; j++) maxn = op->col_len[j] > maxn ? op->col_len[j] : maxn;
     if (maxn == 0) return JH_OK;
-    JH_REQUIRE(op->ncol < ((int64_t)1 << 23), "general block adjoint supports fewer than 2^23 block columns (got %lld)", (long long)op->ncol);
-    const unsigned gy = (unsigned)(op->ncol < 65535 ? op->ncol : 65535), gz = (unsigned)((op->ncol + gy - 1) / gy);
+    JH_REQUIRE(op->ncol < ((int64_t)1 << 20), "general block adjoint supports fewer than 2^20 block columns (got %lld)", (long long)op->ncol);
+    unsigned ntiles, grid;
     if (general_vec_ok(op, d, m)) {
         constexpr int NS = 16 / sizeof(S);
-        int64_t gxv = (maxn * E / NS + 255) / 256;
-        const int64_t cap = (((int64_t)1 << 24) / op->ncol) - 1;
-        if (gxv > cap) gxv = cap > 0 ? cap : 1;
-        hipLaunchKernelGGL((k_block_adj_general_vec<S, E, NS>), dim3((unsigned)gxv, gy, gz), dim3(256), 0, jh_ctx().stream,
-                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d);
+        general_grid((maxn * E / NS + 255) / 256, op->ncol, ntiles, grid);
+        hipLaunchKernelGGL((k_block_adj_general_vec<S, E, NS>), dim3(grid), dim3(256), 0, jh_ctx().stream,
+                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d, ntiles);
         JH_CHECK_HIP(hipGetLastError());
         return JH_OK;
     }
-    int64_t gx = (maxn + 255) / 256;
-    if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL((k_block_adj_general<S, E>), dim3((unsigned)gx, gy, gz), dim3(256), 0, jh_ctx().stream,
-                       op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d);
+    int64_t want = (maxn + 255) / 256;
+    if (want > 4096) want = 4096;
+    general_grid(want, op->ncol, ntiles, grid);
+    hipLaunchKernelGGL((k_block_adj_general<S, E>), dim3(grid), dim3(256), 0, jh_ctx().stream,
+                       op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d, ntiles);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
