@@ -91,7 +91,7 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
     } else {
         s += "#define GET(P, e) T((P)[2 * (e)], (P)[2 * (e) + 1])\n#define PUT(P, e, val) do { T t_ = (val); (P)[2 * (e)] = t_.re; (P)[2 * (e) + 1] = t_.im; } while (0)\n";
     }
-    std::string params = "R *__restrict__ dst_";
+    std::string params = "R *dst_";   // may alias an operand (x .= f.(x, y)): no __restrict__
     for (int k = 0; k < nvec; k++) params += ", const R *p" + std::to_string(k);
     for (int k = 0; k < nscal; k++) params += ", R sr" + std::to_string(k) + ", R si" + std::to_string(k);
     params += ", long n_scalars";

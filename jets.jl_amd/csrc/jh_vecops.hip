@@ -216,7 +216,7 @@ __device__ inline void lincomb_elem(const LincombArgs &a, int64_t scalar_index, 
 }
 
 template <typename S, int E, int NS>   // NS scalars per pack, NS % E == 0
-__global__ void k_lincomb(S *__restrict__ dst, int64_t n_scalars, LincombArgs a)
+__global__ void k_lincomb(S *dst, int64_t n_scalars, LincombArgs a)   // dst may alias an operand (x .= a*x .+ b*y): no __restrict__
 {
     const int64_t nvec = n_scalars / NS;
     const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
@@ -257,7 +257,7 @@ __global__ void k_lincomb(S *__restrict__ dst, int64_t n_scalars, LincombArgs a)
 
 // ---------------------------------------------------------------- hadamard --------------------
 template <typename S, int E, int NS>
-__global__ void k_hadamard(S *__restrict__ dst, const S *__restrict__ x, const S *__restrict__ y, int64_t n_scalars, int conj_x)
+__global__ void k_hadamard(S *dst, const S *x, const S *y, int64_t n_scalars, int conj_x)   // dst may alias x or y (d .= mask .* d)
 {
     const int64_t nvec = n_scalars / NS;
     const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
