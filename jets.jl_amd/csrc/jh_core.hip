@@ -59,7 +59,10 @@ int jh_ensure_scratch(size_t bytes, void **out)
 
 int jh_require_ready()
 {
-    if (!jh_ctx().ready) return jh_fail(JH_ERR_STATE, "libjetship: jh_init(device) has not been called");
+    jh_context &c = jh_ctx();
+    if (!c.ready) return jh_fail(JH_ERR_STATE, "libjetship: jh_init(device) has not been called");
+    int cur = -1;                                            // another library in this thread may have switched devices
+    if (hipGetDevice(&cur) == hipSuccess && cur != c.device) JH_CHECK_HIP(hipSetDevice(c.device));
     return JH_OK;
 }
 
