@@ -1,0 +1,25 @@
+"""GPU: the row-partitioned device path with TWO processes sharing the one GPU of the test box (tools/two_ranks_one_gpu.py).
+
+RCCL refuses two ranks on one device, so the exchange is staged through the host over gloo (test-only comm object);
+everything else is the product path on real kernels with world_size = 2: each rank builds ITS rows of the seeded operator
+(index_base slices of the counter generator, like bench.py), runs the HIP forward / adjoint / LSQR, and the results are
+compared with the CPU oracle and with the single-process device run.  The script runs in its own processes (the launcher
+never touches the GPU); it is given a hard time limit because processes time-slicing one GPU can crawl."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_on_one_gpu(tmp_path):
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_ranks_one_gpu.py"), str(tmp_path)], capture_output=True,
+                             text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.skip("two processes time-slicing this GPU did not finish in 240 s (seen with a third idle context on the device)")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "TWO RANKS OK" in out.stdout
