@@ -124,7 +124,11 @@ def main():
         import torch.distributed as dist  # noqa: F811
 
         torch.cuda.set_device(device)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        backend = os.environ.get("BENCH_BACKEND", "nccl")            # "gloo": validation with several ranks on ONE GPU (RCCL refuses that)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=backend)
 
     import jets_jl_amd as J
 
@@ -270,7 +274,7 @@ def main():
             "config": {
                 "workload": f"{nblocks}x1 tall JopBlock of diagonal JopLn, {edge}^3 Float32 blocks, fwd+adj mul! pair",
                 "nblocks": nblocks, "block": [edge, edge, edge], "rows_per_gpu": nloc,
-                "parallelism": f"row-partition x{world}" + (" + RCCL all-reduce(64 MiB) in adjoint" if world > 1 else ""),
+                "parallelism": f"row-partition x{world}" + (f" + {os.environ.get('BENCH_BACKEND', 'RCCL')} all-reduce({n * s / 2**20:.0f} MiB, pipelined in 4 chunks) in adjoint" if world > 1 else ""),
                 "fwd_grid_walk": {0: "sequential row sweep", 1: "all rows concurrent"}.get(J.tune_get("last_fwd_walk"), "banded"),
                 "tune": {k: J.tune_get(k) for k in ("fwd_group", "fwd_unroll", "fwd_wg", "fwd_order", "adj_unroll", "adj_depth", "adj_wg", "nt", "autotune")},
             },
