@@ -587,8 +587,14 @@ __device__ inline elem<S, E> apply_block(const jh_dev_block &b, elem<S, E> x, in
 // XCDs, each with its own L2, so the lines of a tile get workgroup ids 8 apart: same XCD, dispatched together -- the shared
 // input comes from HBM once and from that L2 afterwards (without this an M x K operator with big blocks re-reads every
 // input block once per line: profiles/bench_blocks_nl_r01.txt).
-__device__ inline void general_line_tile(unsigned nlines, int64_t &line, int64_t &tile)
+__device__ inline void general_line_tile(unsigned nlines, unsigned ntiles, int64_t &line, int64_t &tile)
 {
+    if (ntiles & 0x80000000u) {                              // knob general_xcd = 0 (A/B measurements): tile fastest, line by line
+        const unsigned padded = ((ntiles & 0x7fffffffu) + 7u) / 8u * 8u;
+        line = blockIdx.x / padded;
+        tile = blockIdx.x - (unsigned)line * padded;
+        return;
+    }
     const unsigned per = 8u * nlines;
     const unsigned grp = blockIdx.x / per, rem = blockIdx.x - grp * per;
     line = rem >> 3;
@@ -602,7 +608,8 @@ __global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int
                                     const S *__restrict__ m, S *__restrict__ d, int fmode, unsigned ntiles)
 {
     int64_t i, tile;                                                       // block row, tile
-    general_line_tile((unsigned)nrow, i, tile);
+    general_line_tile((unsigned)nrow, ntiles, i, tile);
+    ntiles &= 0x7fffffffu;
     if (tile >= ntiles) return;
     const int64_t n = row_off[i + 1] - row_off[i];
     for (int64_t e = tile * 256 + threadIdx.x; e < n; e += (int64_t)ntiles * 256) {
@@ -633,7 +640,8 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
                                     S *__restrict__ m, const S *__restrict__ d, unsigned ntiles)
 {
     int64_t j, tile;                                                       // block column, tile
-    general_line_tile((unsigned)ncol, j, tile);
+    general_line_tile((unsigned)ncol, ntiles, j, tile);
+    ntiles &= 0x7fffffffu;
     if (tile >= ntiles) return;
     const int64_t n = col_off[j + 1] - col_off[j];
     for (int64_t e = tile * 256 + threadIdx.x; e < n; e += (int64_t)ntiles * 256) {
@@ -698,7 +706,8 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
 {
     typedef typename vec_of<S, NS>::type V;
     int64_t i, tile;                                                       // block row, tile
-    general_line_tile((unsigned)nrow, i, tile);
+    general_line_tile((unsigned)nrow, ntiles, i, tile);
+    ntiles &= 0x7fffffffu;
     if (tile >= ntiles) return;
     const int64_t ns = (row_off[i + 1] - row_off[i]) * E;                 // scalars in this block row
     for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < ns; s += (int64_t)ntiles * 256 * NS) {
@@ -743,7 +752,8 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
 {
     typedef typename vec_of<S, NS>::type V;
     int64_t j, tile;                                                       // block column, tile
-    general_line_tile((unsigned)ncol, j, tile);
+    general_line_tile((unsigned)ncol, ntiles, j, tile);
+    ntiles &= 0x7fffffffu;
     if (tile >= ntiles) return;
     const int64_t ns = (col_off[j + 1] - col_off[j]) * E;
     for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < ns; s += (int64_t)ntiles * 256 * NS) {
@@ -998,6 +1008,7 @@ static inline void general_grid(int64_t want_tiles, int64_t nlines, unsigned &nt
     if (want_tiles < 1) want_tiles = 1;
     ntiles = (unsigned)want_tiles;
     grid = (unsigned)(((want_tiles + 7) / 8) * 8 * nlines);
+    if (!jh_ctx().general_xcd) ntiles |= 0x80000000u;                      // flag for the kernels' decode (A/B knob)
 }
 
 template <typename S, int E>

@@ -470,6 +470,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "nt")) { c.nt = value ? 1 : 0; }
     else if (!strcmp(name, "autotune")) { c.autotune = value ? 1 : 0; }
     else if (!strcmp(name, "graphs")) { c.graphs = value ? 1 : 0; }
+    else if (!strcmp(name, "general_xcd")) { c.general_xcd = value ? 1 : 0; }
     else if (!strcmp(name, "red_wgs")) { JH_REQUIRE(value >= 1 && value <= 1 << 20, "red_wgs out of range"); c.red_wgs = value; }
     else return jh_fail(JH_ERR_INVALID, "jh_tune_set: unknown knob '%s'", name);
     return JH_OK;
@@ -489,6 +490,7 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "nt")) *value = c.nt;
     else if (!strcmp(name, "autotune")) *value = c.autotune;
     else if (!strcmp(name, "graphs")) *value = c.graphs;
+    else if (!strcmp(name, "general_xcd")) *value = c.general_xcd;
     else if (!strcmp(name, "graph_replays")) *value = c.graph_replays;
     else if (!strcmp(name, "red_wgs")) *value = c.red_wgs;
     else if (!strcmp(name, "last_fwd_walk")) *value = c.last_fwd_walk;

@@ -51,6 +51,7 @@ struct jh_context {
     int64_t fwd_order = -1;            // -1: automatic; 0: sequential row sweep; 1: all row groups concurrent; k>1: bands of k row groups
     int64_t nt = 1;                    // nontemporal loads/stores on the streamed operands
     int64_t autotune = 1;              // time both grid walks of the tall forward once per large operator
+    int64_t general_xcd = 1;           // general M x K kernels: XCD-aware (line, tile) decode; 0 = tile-fastest order (A/B measurements)
     int64_t graphs = 1;                // replay launch-bound per-block loops as hipGraphs (jh_blockop.hip: run_loop_graphed)
     int64_t graph_replays = 0;         // read-only counter: hipGraphLaunch calls made by run_loop_graphed
     uint64_t buf_gen = 0;              // bumped whenever part_dev / scratch_dev is reallocated: captured graphs holding the old pointers are stale
