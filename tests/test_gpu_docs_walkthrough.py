@@ -126,3 +126,23 @@ def test_vectorized_operator_with_lsqr(Jets):
     x = Jets.lsqr(Jets.vec_op(A), Jets.vec(d), atol=1e-14, btol=1e-14, maxiter=50).x
     m = Jets.reshape(x, Jets.range(A))
     assert m.shape == (n1, n2) and approx(A * m, d, rtol=1e-10)                       # A*m ≈ d  # true
+
+
+def test_readme_usage_example(Jets):
+    """The snippet in README.md, at a small size."""
+    R = Jets.JetSpace(np.float32, 16, 16, 16)
+    A = Jets.blockop([[Jets.JopDiagonal(Jets.rand(R))] for _ in range(8)])
+    m = Jets.rand(Jets.domain(A))
+    d = A * m
+    mt = A.H * d
+    y = (A.H @ A) * m
+    assert np.array_equal(y.to_numpy(), mt.to_numpy())
+    x = Jets.lsqr(A, d, maxiter=20).x
+    assert approx(x, m, rtol=1e-3)
+    F = Jets.blockop([[Jets.JopElementwise(R, "exp(x0)", "exp(x0)")], [Jets.JopSquare(R)]])
+    J = Jets.jacobian_(F, m)
+    dd = J * m
+    hm = m.to_numpy().astype(np.float64)
+    assert approx(dd, np.concatenate([(np.exp(hm) * hm).ravel(order="F"), (2 * hm * hm).ravel(order="F")]), rtol=1e-5)
+    Jets.broadcast_(mt, "s0*x0 + sqrt(abs(x1))", [m, y], [0.5])
+    assert approx(mt, 0.5 * hm + np.sqrt(np.abs(y.to_numpy().astype(np.float64))), rtol=1e-5)
