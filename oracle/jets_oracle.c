@@ -189,6 +189,34 @@ void jo_normal_df(int dtype, int64_t nrow, int64_t ncol, const jo_block *ops, vo
 #include <omp.h>
 #endif
 
+/* Both all-cores loops give a thread the SAME element chunks of every row (static schedule over chunks, rows inside), and
+ * jo_fill_u01_omp_f32 first-touches the arrays with that very partition, so on a multi-socket host every thread streams
+ * memory of its own NUMA node. */
+#define JO_OMP_CHUNK 16384
+
+int jo_fill_u01_omp_f32(int64_t nrow, int64_t n, uint64_t seed, int64_t row0, float *const *rows)
+{
+    int nt = 1;
+    const uint64_t key = jo_rng_key(seed, 0);
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+#pragma omp single
+        nt = omp_get_num_threads();
+#endif
+#pragma omp for schedule(static)
+        for (int64_t c = 0; c < (n + JO_OMP_CHUNK - 1) / JO_OMP_CHUNK; c++) {
+            const int64_t lo = c * JO_OMP_CHUNK, hi = lo + JO_OMP_CHUNK < n ? lo + JO_OMP_CHUNK : n;
+            for (int64_t i = 0; i < nrow; i++)
+                for (int64_t k = lo; k < hi; k++) {
+                    const uint64_t h = jo_mix64(key + (uint64_t)((row0 + i) * n + k + 1) * JO_GOLDEN);
+                    rows[i][k] = (float)(h >> 40) * 0x1.0p-24f;
+                }
+        }
+    }
+    return nt;
+}
+
 int jo_tall_diag_fwd_omp_f32(int64_t nrow, int64_t n, const float *const *a, const float *m, float *const *d)
 {
     int nt = 1;
@@ -198,12 +226,12 @@ int jo_tall_diag_fwd_omp_f32(int64_t nrow, int64_t n, const float *const *a, con
 #pragma omp single
         nt = omp_get_num_threads();
 #endif
-#pragma omp for collapse(2) schedule(static)
-        for (int64_t i = 0; i < nrow; i++)
-            for (int64_t c = 0; c < (n + 65535) / 65536; c++) {
-                const int64_t lo = c * 65536, hi = lo + 65536 < n ? lo + 65536 : n;
-                for (int64_t k = lo; k < hi; k++) d[i][k] = a[i][k] * m[k];          /* d_i .= diagonal_i .* m */
-            }
+#pragma omp for schedule(static)
+        for (int64_t c = 0; c < (n + JO_OMP_CHUNK - 1) / JO_OMP_CHUNK; c++) {
+            const int64_t lo = c * JO_OMP_CHUNK, hi = lo + JO_OMP_CHUNK < n ? lo + JO_OMP_CHUNK : n;
+            for (int64_t i = 0; i < nrow; i++)
+                for (int64_t k = lo; k < hi; k++) d[i][k] = a[i][k] * m[k];              /* d_i .= diagonal_i .* m */
+        }
     }
     return nt;
 }
@@ -218,8 +246,8 @@ int jo_tall_diag_adj_omp_f32(int64_t nrow, int64_t n, const float *const *a, flo
         nt = omp_get_num_threads();
 #endif
 #pragma omp for schedule(static)
-        for (int64_t c = 0; c < (n + 16383) / 16384; c++) {
-            const int64_t lo = c * 16384, hi = lo + 16384 < n ? lo + 16384 : n;
+        for (int64_t c = 0; c < (n + JO_OMP_CHUNK - 1) / JO_OMP_CHUNK; c++) {
+            const int64_t lo = c * JO_OMP_CHUNK, hi = lo + JO_OMP_CHUNK < n ? lo + JO_OMP_CHUNK : n;
             for (int64_t k = lo; k < hi; k++) m[k] = 0.0f;                            /* _m .= 0 */
             for (int64_t i = 0; i < nrow; i++)                                         /* rows in order */
                 for (int64_t k = lo; k < hi; k++) { float p = a[i][k] * d[i][k]; m[k] = m[k] + p; }

@@ -100,6 +100,8 @@ void jo_normal_df(int dtype, int64_t nrow, int64_t ncol, const jo_block *ops, vo
  * the reference is single-threaded, this is not its structure.  Forward: rows x element chunks in parallel.  Adjoint:
  * element chunks in parallel, rows in order inside a chunk, product rounded then added -- same bits as the sequential
  * loop.  Returns the number of threads used. */
+/* fills rows[i][k] = u01(seed, stream 0, element (row0+i)*n + k) with the partition of the two loops below (first touch) */
+int jo_fill_u01_omp_f32(int64_t nrow, int64_t n, uint64_t seed, int64_t row0, float *const *rows);
 int jo_tall_diag_fwd_omp_f32(int64_t nrow, int64_t n, const float *const *a, const float *m, float *const *d);
 int jo_tall_diag_adj_omp_f32(int64_t nrow, int64_t n, const float *const *a, float *m, const float *const *d);
 

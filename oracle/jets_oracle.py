@@ -232,6 +232,15 @@ def tall_diag_pair_omp_f32(a_blocks, m, d_blocks, mt):
     return nt
 
 
+def fill_u01_omp_f32(rows, seed, row0=0):
+    """Fill freshly allocated (untouched) Float32 rows with the counter generator, in parallel, with the thread partition of
+    tall_diag_pair_omp_f32 -- the first touch puts every thread's chunks on its own NUMA node."""
+    nrow, n = len(rows), rows[0].size
+    pr = (C.c_void_p * nrow)(*[x.ctypes.data for x in rows])
+    _lib.jo_fill_u01_omp_f32.restype = C.c_int
+    return _lib.jo_fill_u01_omp_f32(C.c_int64(nrow), C.c_int64(n), C.c_uint64(seed), C.c_int64(row0), pr)
+
+
 def dot_product_test(ops, m_blocks, d_blocks, mmask=None, dmask=None):
     """dot_product_test (src/Jets.jl:1211-1226) on a block operator of native kinds."""
     dt = m_blocks[0].dtype
