@@ -387,3 +387,43 @@ def test_more_than_65535_block_rows_through_the_general_kernels(Jets):
     assert_bits_equal(back.to_numpy(), want.ravel(), "1 x 70001 adjoint")
     lib.jh_blockop_destroy(h)
     lib.jh_blockop_destroy(h2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_tall_operator_with_a_few_scalar_rows_stays_on_the_tall_kernels(Jets, oracle, dt):
+    """[A_1; ...; A_6; I; a*I]: identity / scalar rows get a constant diagonal so that the operator is all-DIAG for the
+    device -- bit-identical to the scalar kinds in the oracle -- and the fused A'A and the one-pass LSQR step apply."""
+    import ctypes as C
+
+    from jets_jl_amd._ffi import lib
+    from jets_jl_amd import jetblock
+
+    n, ndiag = 4096, 6
+    spc = Jets.JetSpace(dt, n)
+    a = (0.75 - 0.5j) if np.dtype(dt).kind == "c" else -0.75
+    diags = [Jets.rand(spc, seed=7, stream=i) for i in range(ndiag)]
+    rows = [[Jets.JopDiagonal(g)] for g in diags]
+    rows += [[Jets.JopIdentity(spc)], [Jets.JopLn(dom=spc, rng=spc, df=Jets.constdiag_df, df_adj=Jets.constdiag_df_adj, s={"a": a})]]
+    A = Jets.blockop(rows)
+    ora = [[oracle.Block("diag", n, coeff=u01(oracle, dt, 7, i, n))] for i in range(ndiag)]
+    ora += [[oracle.Block("identity", n)], [oracle.Block("scale", n, scale=a)]]
+    nrow = ndiag + 2
+    m = Jets.rand(spc, seed=8, stream=0)
+    hm = u01(oracle, dt, 8, 0, n)
+    d = Jets.rand(Jets.range(A), seed=9, stream=0)
+    Jets.mul_(d, A, m)
+    ref = oracle.block_df(ora, [np.zeros(n, dt) for _ in range(nrow)], [hm])
+    assert_bits_equal(d.to_numpy(), np.concatenate(ref), "forward")
+    mt = Jets.mul(A.H, d)
+    refm = oracle.block_df_adj(ora, [np.zeros(n, dt)], ref)
+    assert_bits_equal(mt.to_numpy(), refm[0], "adjoint")
+    assert_bits_equal(Jets.mul(A.H @ A, m).to_numpy(), refm[0], "fused A'A")
+    nat = jetblock._native_op(A.jet.s["_native"], A.jet.s["ops"], A.jet.rng.eltype())
+    w, out = Jets.zeros(spc), C.c_double(0)
+    assert lib.jh_blockop_bidiag_step(nat.handle, d.handle, m.handle, w.handle, 1.0, 0.0, C.byref(out)) == 0    # all-DIAG for the device
+    assert_bits_equal(w.to_numpy(), refm[0], "one-pass step")
+    # many scalar rows: not densified (memory), the general kernels keep the kinds
+    B = Jets.blockop([[Jets.JopDiagonal(diags[0])], [Jets.JopIdentity(spc)], [Jets.JopIdentity(spc)]])
+    natB = jetblock._native_op(B.jet.s["_native"], B.jet.s["ops"], B.jet.rng.eltype())
+    u3 = Jets.zeros(Jets.range(B))
+    assert lib.jh_blockop_bidiag_step(natB.handle, u3.handle, m.handle, w.handle, 1.0, 0.0, C.byref(out)) == 4   # JH_ERR_UNSUPPORTED
