@@ -53,13 +53,6 @@ template <typename S> __device__ inline S u01_from(uint64_t h);
 template <> __device__ inline float u01_from<float>(uint64_t h) { return (float)(h >> 40) * 0x1.0p-24f; }
 template <> __device__ inline double u01_from<double>(uint64_t h) { return (double)(h >> 11) * 0x1.0p-53; }
 
-inline int grid_for(int64_t work_items, int per_thread)
-{
-    int64_t g = (work_items + (int64_t)WG * per_thread - 1) / ((int64_t)WG * per_thread);
-    if (g < 1) g = 1;
-    if (g > 2048) g = 2048;
-    return (int)g;
-}
 
 // Elementwise kernels: ONE pack per thread and as many workgroups as that takes (capped at 2^23 workgroups =
 // 2^31 threads, HIP's grid x block limit is 2^32; beyond that the grid-stride loop runs a second pass).
