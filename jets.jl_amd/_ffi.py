@@ -40,6 +40,13 @@ class BlockDesc(C.Structure):
     ]
 
 
+class LsqrResultC(C.Structure):
+    """jh_lsqr_result of include/jetship.h."""
+
+    _fields_ = [("istop", C.c_int32), ("itn", C.c_int32), ("r1norm", C.c_double), ("r2norm", C.c_double), ("anorm", C.c_double),
+                ("acond", C.c_double), ("arnorm", C.c_double), ("xnorm", C.c_double)]
+
+
 DTYPES = {"f32": 0, "f64": 1, "c32": 2, "c64": 3}
 KINDS = {"zero": 0, "identity": 1, "scale": 2, "diag": 3, "dense": 4, "square": 5}
 
@@ -110,6 +117,7 @@ SYMBOLS = {
     "jh_blockop_mul_adj_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _dblp]),
     "jh_blockop_bidiag_step": (_int, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
     "jh_blockop_bidiag_step_range": (_int, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, _i64, _i64, _dblp]),
+    "jh_lsqr_solve": (_int, [_vp, _vp, _vp, _int, C.c_double, C.c_double, C.c_double, C.c_double, _int, _int, C.POINTER(LsqrResultC), _dblp]),
     "jh_comm_unique_id": (_int, [_vp]),
     "jh_comm_init_rank": (_int, [_vp, _int, _int]),
     "jh_comm_destroy": (_int, []),

@@ -1371,6 +1371,8 @@ int check_vectors(const jh_blockop *op, const jh_bvec *rng, const jh_bvec *dom, 
 
 }  // namespace
 
+bool jh_blockop_tall_fast(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr) { return tall_fast_ok(op, rng_ptr, dom_ptr); }
+
 extern "C" {
 
 int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, const int64_t *row_len, const int64_t *col_len,

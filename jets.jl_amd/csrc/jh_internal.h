@@ -127,6 +127,7 @@ struct jh_blockop {
     int64_t diag_stride_elems = 0;
 };
 
+bool jh_blockop_tall_fast(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr);   // tall, all DIAG, equal 16-byte aligned blocks
 void jh_bcast_clear_cache();            // jh_bcast.hip: unload every JIT-compiled broadcast program (jh_shutdown)
 int jh_ensure_partials(int64_t n);     // grows ctx.part_dev to >= n doubles (may synchronise + reallocate)
 // vecops entry used by blockop for generic pieces

@@ -1,0 +1,279 @@
+// jh_lsqr.hip -- LSQR (Paige & Saunders, ACM TOMS 8(1), 1982) over a tall all-DIAG block operator, entirely behind the C
+// ABI: the caller of the block mul! path that BASELINE.json configs[4] names.  The reference reaches it as
+// `lsqr(vec(A), vec(d))` of IterativeSolvers.jl (src/Jets.jl:1143-1152, docs/src/index.md:235-246), an un-vendored
+// package, so this is the published algorithm written from scratch -- the same recurrences as jets.jl_amd/lsqr.py, which
+// stays the driver for arbitrary operators; results are checked against the fp64 CPU LSQR of oracle/lsqr_ref.py.
+//
+// One iteration = ONE pass over the operator and the range vector (jh_blockop_bidiag_step: u <- A v - (alpha/beta) u,
+// ||u||^2 and A'u together), then domain-sized updates.  u is never normalised in memory: it holds beta*u and the scale is
+// carried into the next step.  With jh_comm_init_rank done (one process per GPU, this rank holding its block rows) the local
+// A'u is all-reduced with RCCL and ||u||^2 with a scalar all-reduce: row-partitioned LSQR without a line of host code.
+#include "jh_internal.h"
+
+#include <cmath>
+
+namespace {
+
+// ---- the domain-side half of an iteration in two kernels (instead of five broadcasts and two norms) ----------------
+// All coefficients are real, so a complex vector is 2n reals here.  Rounding sequence of every element == the broadcasts
+// they replace (jh_lincomb: every product rounded, then the sum); the norms are summed in another (fixed) order than
+// jh_norm's, so alpha agrees with the unfused loop to fp64 round-off, not to the bit.
+template <int BLK> __device__ inline void wg_sum_to(double v, double *slot)
+{
+    __shared__ double sm[BLK / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sm[0];
+#pragma unroll
+        for (int w = 1; w < BLK / 64; w++) r += sm[w];
+        *slot = r;
+    }
+}
+
+// v <- c0*atu + c1*v ; partial ||v||^2
+template <typename S>
+__global__ __launch_bounds__(256) void k_lsqr_vhat(S *v, const S *__restrict__ atu, int64_t n, S c0, S c1, double *__restrict__ partials)
+{
+    double nrm = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const S a = c0 * atu[i], b = c1 * v[i];
+        const S r = a + b;
+        v[i] = r;
+        nrm += (double)r * (double)r;
+    }
+    wg_sum_to<256>(nrm, partials + blockIdx.x);
+}
+
+// v <- cv*v (normalise) ; x <- x + t1*w ; w <- v + t2*w ; partial ||w_new||^2
+template <typename S>
+__global__ __launch_bounds__(256) void k_lsqr_xw(S *v, S *x, S *w, int64_t n, S cv, S t1, S t2, double *__restrict__ partials)
+{
+    double nrm = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const S vn = cv * v[i];
+        const S wo = w[i];
+        const S xa = (S)1 * x[i], xb = t1 * wo;
+        const S wa = (S)1 * vn, wb = t2 * wo;
+        const S wn = wa + wb;
+        v[i] = vn;
+        x[i] = xa + xb;
+        w[i] = wn;
+        nrm += (double)wn * (double)wn;
+    }
+    wg_sum_to<256>(nrm, partials + blockIdx.x);
+}
+
+// one workgroup folds the per-workgroup partials in index order (deterministic)
+__global__ __launch_bounds__(256) void k_lsqr_fold(const double *__restrict__ partials, int nparts, double *__restrict__ out)
+{
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) v += partials[i];
+    wg_sum_to<256>(v, out);
+}
+
+struct Tmp {                                     // domain-sized work vectors, released on every exit path
+    jh_bvec *v = nullptr, *w = nullptr, *atu = nullptr;
+    double *parts = nullptr;                     // 2 x grid per-workgroup partials + 2 result slots
+    ~Tmp()
+    {
+        if (parts) (void)hipFree(parts);
+        if (v) (void)jh_bvec_destroy(v);
+        if (w) (void)jh_bvec_destroy(w);
+        if (atu) (void)jh_bvec_destroy(atu);
+    }
+};
+
+int lincomb1(jh_bvec *dst, double c0, const jh_bvec *x0)
+{
+    const double coef[2] = {c0, 0.0};
+    const jh_bvec *xs[1] = {x0};
+    return jh_lincomb(dst, 1, coef, xs);
+}
+
+int lincomb2(jh_bvec *dst, double c0, const jh_bvec *x0, double c1, const jh_bvec *x1)
+{
+    const double coef[4] = {c0, 0.0, c1, 0.0};
+    const jh_bvec *xs[2] = {x0, x1};
+    return jh_lincomb(dst, 2, coef, xs);
+}
+
+// launch helpers: a complex vector is 2n reals for these real-coefficient updates
+int launch_vhat(int dtype, jh_bvec *v, const jh_bvec *atu, double c0, double c1, double *parts, int grid)
+{
+    const bool f64 = (dtype == JH_F64 || dtype == JH_C64);
+    const int64_t ns = v->length * (jh_dtype_complex(dtype) ? 2 : 1);
+    hipStream_t st = jh_ctx().stream;
+    if (f64) hipLaunchKernelGGL((k_lsqr_vhat<double>), dim3(grid), dim3(256), 0, st, (double *)v->data, (const double *)atu->data, ns, c0, c1, parts);
+    else hipLaunchKernelGGL((k_lsqr_vhat<float>), dim3(grid), dim3(256), 0, st, (float *)v->data, (const float *)atu->data, ns, (float)c0, (float)c1, parts);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+int launch_xw(int dtype, jh_bvec *v, jh_bvec *x, jh_bvec *w, double cv, double t1, double t2, double *parts, int grid)
+{
+    const bool f64 = (dtype == JH_F64 || dtype == JH_C64);
+    const int64_t ns = v->length * (jh_dtype_complex(dtype) ? 2 : 1);
+    hipStream_t st = jh_ctx().stream;
+    if (f64) hipLaunchKernelGGL((k_lsqr_xw<double>), dim3(grid), dim3(256), 0, st, (double *)v->data, (double *)x->data, (double *)w->data, ns, cv, t1, t2, parts);
+    else hipLaunchKernelGGL((k_lsqr_xw<float>), dim3(grid), dim3(256), 0, st, (float *)v->data, (float *)x->data, (float *)w->data, ns, (float)cv, (float)t1, (float)t2, parts);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+}  // namespace
+
+extern "C" int jh_lsqr_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, double conlim,
+                             int maxiter, int force_maxiter, jh_lsqr_result *res, double *history)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(op && u && x && res, "jh_lsqr_solve: null argument");
+    JH_REQUIRE(maxiter >= 0, "jh_lsqr_solve: maxiter must be >= 0");
+    int64_t nb = 0, n = 0;
+    int dtype = 0;
+    JH_TRY(jh_bvec_info(x, &nb, &n, &dtype, nullptr));
+    if (!jh_blockop_tall_fast(op, u->data, x->data))                    // before anything is touched: the caller can still take another path
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_lsqr_solve: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
+    int nranks = 1, rank = 0;
+    (void)jh_comm_info(&nranks, &rank);
+    const bool dist = nranks > 1;
+    Tmp t;
+    const int64_t len1[1] = {n};
+    JH_TRY(jh_bvec_create(1, len1, dtype, &t.v));
+    JH_TRY(jh_bvec_create(1, len1, dtype, &t.w));
+    JH_TRY(jh_bvec_create(1, len1, dtype, &t.atu));
+    const int64_t ns_dom = n * (jh_dtype_complex(dtype) ? 2 : 1);
+    int grid = (int)((ns_dom + 255) / 256 < 4096 ? (ns_dom + 255) / 256 : 4096);
+    if (grid < 1) grid = 1;
+    JH_CHECK_HIP(hipMalloc((void **)&t.parts, sizeof(double) * (2 * (size_t)grid + 2)));
+    double *parts_v = t.parts, *parts_w = t.parts + grid, *slot_v = t.parts + 2 * grid, *slot_w = slot_v + 1;
+    jh_context &c = jh_ctx();
+    *res = jh_lsqr_result{};
+
+    auto global_sum = [&](double local, double *out) -> int {
+        *out = local;
+        if (dist) JH_TRY(jh_comm_allreduce_scalars(out, 1, 0));
+        return JH_OK;
+    };
+
+    if (!use_x0) JH_TRY(jh_fill(x, 0.0, 0.0));
+    double nrm = 0.0, s2 = 0.0;
+    JH_TRY(jh_norm(u, 2.0, &nrm));                                       // ||b|| (this rank's rows)
+    JH_TRY(global_sum(nrm * nrm, &s2));
+    const double bnorm = std::sqrt(s2);
+    double beta = bnorm;
+    if (use_x0) {                                                        // u <- b - A x0
+        double local = 0.0;
+        JH_TRY(jh_blockop_mul_axpby(op, u, x, -1.0, 1.0, &local));
+        JH_TRY(global_sum(local, &s2));
+        beta = std::sqrt(s2);
+    }
+    double alpha = 0.0;
+    if (beta > 0) {                                                      // v = A'u / beta
+        JH_TRY(jh_blockop_mul_adj(op, t.atu, u));
+        if (dist) JH_TRY(jh_comm_allreduce_sum(t.atu));
+        JH_TRY(lincomb1(t.v, 1.0 / beta, t.atu));
+        JH_TRY(jh_norm(t.v, 2.0, &alpha));
+    } else {
+        JH_TRY(jh_copy(t.v, x));
+    }
+    if (alpha > 0) JH_TRY(lincomb1(t.v, 1.0 / alpha, t.v));
+    JH_TRY(jh_copy(t.w, t.v));
+    double wnorm = 0.0;                                                  // ||w_k||, needed one iteration after w_k is written
+    JH_TRY(jh_norm(t.w, 2.0, &wnorm));
+    bool wnorm_pending = false;                                          // the value is in flight to red_host[5]
+
+    double rhobar = alpha, phibar = beta, rnorm = beta, r1norm = beta, r2norm = beta, arnorm = alpha * beta;
+    double anorm = 0, acond = 0, ddnorm = 0, res2 = 0, xnorm = 0, xxnorm = 0, z = 0, cs2 = -1.0, sn2 = 0.0;
+    int itn = 0, istop = 0;
+    const double eps = 2.220446049250313e-16, ctol = conlim > 0 ? 1.0 / conlim : 0.0;
+    if (arnorm != 0) {
+        while (itn < maxiter) {
+            itn++;
+            // ---- bidiagonalisation in one pass:  beta*u = A v - alpha*u ;  alpha*v = A'u - beta*v
+            const double beta_prev = beta;
+            double local = 0.0;
+            JH_TRY(jh_blockop_bidiag_step(op, u, t.v, t.atu, 1.0, -alpha / beta_prev, &local));
+            if (dist) JH_TRY(jh_comm_allreduce_sum(t.atu));
+            JH_TRY(global_sum(local, &s2));
+            beta = std::sqrt(s2);
+            if (wnorm_pending) {                                         // the step's read-back synchronised the stream: it has landed
+                wnorm = std::sqrt(c.red_host[5]);
+                wnorm_pending = false;
+            }
+            double cv = 1.0;                                             // normalisation of v, applied by the x/w kernel below
+            if (beta > 0) {
+                anorm = std::sqrt(anorm * anorm + alpha * alpha + beta * beta + damp * damp);
+                JH_TRY(launch_vhat(dtype, t.v, t.atu, 1.0 / beta, -beta, parts_v, grid));   // v <- A'(u_hat)/beta - beta v, ||v||^2
+                hipLaunchKernelGGL(k_lsqr_fold, dim3(1), dim3(256), 0, c.stream, parts_v, grid, slot_v);
+                JH_CHECK_HIP(hipGetLastError());
+                JH_CHECK_HIP(hipMemcpyAsync(c.red_host + 4, slot_v, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+                JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+                alpha = std::sqrt(c.red_host[4]);
+                if (alpha > 0) cv = 1.0 / alpha;
+            }
+            // ---- eliminate the damping parameter, then the plane rotation
+            const double rhobar1 = std::sqrt(rhobar * rhobar + damp * damp);
+            const double cs1 = rhobar / rhobar1, sn1 = damp / rhobar1;
+            const double psi = sn1 * phibar;
+            phibar = cs1 * phibar;
+            const double rho = std::sqrt(rhobar1 * rhobar1 + beta * beta);
+            const double cs = rhobar1 / rho, sn = beta / rho;
+            const double theta = sn * alpha;
+            rhobar = -cs * alpha;
+            const double phi = cs * phibar;
+            phibar = sn * phibar;
+            const double tau = sn * phi;
+            // ---- update x and w
+            const double t1 = phi / rho, t2 = -theta / rho;
+            ddnorm += (wnorm / rho) * (wnorm / rho);
+            JH_TRY(launch_xw(dtype, t.v, x, t.w, cv, t1, t2, parts_w, grid));     // v normalised; x += t1 w; w = v + t2 w; ||w||^2
+            hipLaunchKernelGGL(k_lsqr_fold, dim3(1), dim3(256), 0, c.stream, parts_w, grid, slot_w);
+            JH_CHECK_HIP(hipGetLastError());
+            JH_CHECK_HIP(hipMemcpyAsync(c.red_host + 5, slot_w, sizeof(double), hipMemcpyDeviceToHost, c.stream));   // read after the next sync
+            wnorm_pending = true;
+            // ---- norms for the stopping rules
+            const double delta = sn2 * rho, gambar = -cs2 * rho, rhs = phi - delta * z, zbar = rhs / gambar;
+            xnorm = std::sqrt(xxnorm + zbar * zbar);
+            const double gamma = std::sqrt(gambar * gambar + theta * theta);
+            cs2 = gambar / gamma;
+            sn2 = theta / gamma;
+            z = rhs / gamma;
+            xxnorm += z * z;
+            acond = anorm * std::sqrt(ddnorm);
+            const double res1 = phibar * phibar;
+            res2 += psi * psi;
+            rnorm = std::sqrt(res1 + res2);
+            arnorm = alpha * std::fabs(tau);
+            const double r1sq = rnorm * rnorm - damp * damp * xxnorm;
+            r1norm = std::sqrt(std::fabs(r1sq)) * (r1sq >= 0 ? 1.0 : -1.0);
+            r2norm = rnorm;
+            if (history) { history[2 * (itn - 1)] = r1norm; history[2 * (itn - 1) + 1] = arnorm; }
+            const double test1 = bnorm > 0 ? rnorm / bnorm : 0.0;
+            const double test2 = rnorm > 0 ? arnorm / (anorm * rnorm + eps) : 0.0;
+            const double test3 = 1.0 / (acond + eps);
+            const double t1_ = bnorm > 0 ? test1 / (1 + anorm * xnorm / bnorm) : 0.0;
+            const double rtol = bnorm > 0 ? btol + atol * anorm * xnorm / bnorm : 0.0;
+            if (itn >= maxiter) istop = 7;
+            if (1 + test3 <= 1) istop = 6;
+            if (1 + test2 <= 1) istop = 5;
+            if (1 + t1_ <= 1) istop = 4;
+            if (test3 <= ctol) istop = 3;
+            if (test2 <= atol) istop = 2;
+            if (test1 <= rtol) istop = 1;
+            if (istop && !(force_maxiter && itn < maxiter && alpha > 0 && beta > 0)) break;
+        }
+    }
+    res->istop = istop;
+    res->itn = itn;
+    res->r1norm = r1norm;
+    res->r2norm = r2norm;
+    res->anorm = anorm;
+    res->acond = acond;
+    res->arnorm = arnorm;
+    res->xnorm = xnorm;
+    JH_CHECK_HIP(hipStreamSynchronize(c.stream));                        // the temporaries die here
+    return JH_OK;
+}

@@ -18,6 +18,7 @@ through mul!, one fused broadcast and one norm per half.
 """
 from __future__ import annotations
 
+import builtins
 import ctypes as C
 import math
 import os
@@ -204,7 +205,37 @@ def lsqr(A, b, x0=None, damp: float = 0.0, atol: float = 1e-6, btol: float = 1e-
         dom, rng = _j.domain(A), _j.range_(A)
     b = reshape(b, rng)
     x0 = None if x0 is None else reshape(x0, dom)
+    native = _native_solve(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b, force_maxiter)
+    if native is not None:
+        return native
     return lsqr_core(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b, force_maxiter)
+
+
+def _native_solve(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b, force_maxiter):
+    """The whole loop behind the C ABI (jh_lsqr_solve: the same recurrences in C++ over the one-pass step) for a
+    device-native tall diagonal operator on one GPU, or row-partitioned over the ABI's own RCCL communicator (AbiComm).
+    None when it does not apply (generic operators, torch.distributed exchange, JETS_LSQR_NATIVE=0): lsqr_core then runs."""
+    from ._ffi import LsqrResultC
+    from .rowpart import AbiComm
+
+    if os.environ.get("JETS_LSQR_NATIVE", "1") == "0" or eng.native is None or not eng.fused_step:
+        return None
+    shard = getattr(eng, "shard", None)
+    if shard is not None and not (isinstance(shard.comm, AbiComm) or shard.comm.world == 1):
+        return None
+    x = eng.zeros_dom() if x0 is None else eng.copy(eng.zeros_dom(), x0)
+    u = b if overwrite_b else eng.copy(eng.zeros_rng(), b)
+    res = LsqrResultC()
+    hist = (C.c_double * builtins.max(2 * int(maxiter), 1))()
+    try:
+        check(lib.jh_lsqr_solve(eng.native.handle, u.handle, x.handle, 0 if x0 is None else 1, float(damp), float(atol), float(btol),
+                                float(conlim), int(maxiter), 1 if force_maxiter else 0, C.byref(res), hist))
+    except JetsHipError as e:
+        if e.status != 4:                                       # JH_ERR_UNSUPPORTED is raised before anything is touched: generic path
+            raise
+        return None
+    history = [(k + 1, hist[2 * k], hist[2 * k + 1]) for k in builtins.range(res.itn)]
+    return LsqrResult(x, res.istop, res.itn, res.r1norm, res.r2norm, res.anorm, res.acond, res.arnorm, res.xnorm, history)
 
 
 def lsqr_core(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b=False, force_maxiter=False) -> LsqrResult:

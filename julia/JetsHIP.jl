@@ -285,6 +285,16 @@ function bidiag_step!(u::HipBlockArray{T}, w::HipArray{T}, A::JopLn, v::HipArray
     sqrt(nrm2[])
 end
 
+# the whole LSQR loop behind the ABI (the same call solves the row-partitioned problem after comm_init on every rank)
+struct jh_lsqr_result; istop::Int32; itn::Int32; r1norm::Cdouble; r2norm::Cdouble; anorm::Cdouble; acond::Cdouble; arnorm::Cdouble; xnorm::Cdouble; end
+function hip_lsqr!(x::HipArray{T}, A::JopLn, b::HipBlockArray{T}; x0::Bool=false, damp=0.0, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=100) where {T}
+    res = Ref{jh_lsqr_result}()
+    hist = Vector{Cdouble}(undef, 2 * maxiter)
+    check(ccall((:jh_lsqr_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Ref{jh_lsqr_result}, Ptr{Cdouble}),
+                native_handle(state(A).ops, T), b.handle, x.handle, x0, damp, atol, btol, conlim, maxiter, 0, res, hist))   # b is overwritten (it becomes u)
+    x, res[], reshape(hist, 2, :)[:, 1:res[].itn]
+end
+
 # one process per GPU: rank 0 makes the id, the host (MPI.jl, sockets, a file) ships it, every rank joins
 comm_unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:jh_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id)); id)
 comm_init(id::Vector{UInt8}, nranks::Integer, rank::Integer) = check(ccall((:jh_comm_init_rank, LIB), Cint, (Ptr{UInt8}, Cint, Cint), id, nranks, rank))

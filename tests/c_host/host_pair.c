@@ -147,6 +147,33 @@ int main(void)
     CK(jh_getblock_copy(d, 5, hy, 0));
     REQUIRE(memcmp(hy, hmt, (size_t)n * sizeof(float)) == 0, "setblock!(d, 6, array) round trip");
 
+    /* ---- the solver loop behind the ABI: b = A x_true, solve with LSQR (one pass over A and u per iteration) */
+    {
+        jh_bvec *xt = NULL, *bb = NULL, *xs = NULL;
+        CK(jh_bvec_create(1, lens, JH_F32, &xt));
+        CK(jh_bvec_create(NROW, lens, JH_F32, &bb));
+        CK(jh_bvec_create(1, lens, JH_F32, &xs));
+        CK(jh_fill_uniform(xt, 4, 0, 0));
+        CK(jh_blockop_mul(A, bb, xt));
+        jh_lsqr_result lr;
+        double hist[2 * 40];
+        CK(jh_lsqr_solve(A, bb, xs, 0, 0.0, 1e-7, 1e-7, 0.0, 40, 0, &lr, hist));
+        REQUIRE(lr.itn >= 1 && lr.itn <= 40 && lr.istop >= 1, "LSQR stops by a rule");
+        REQUIRE(hist[2 * (lr.itn - 1)] < 1e-4 * hist[0] + 1e-6, "residual norm falls");
+        float *hx = malloc((size_t)n * sizeof(float)), *hxt = malloc((size_t)n * sizeof(float));
+        REQUIRE(hx && hxt, "host allocation");
+        CK(jh_download(xs, 0, n, hx));
+        CK(jh_download(xt, 0, n, hxt));
+        double num = 0, den = 0;
+        for (int64_t k = 0; k < n; k++) { num += (double)(hx[k] - hxt[k]) * (hx[k] - hxt[k]); den += (double)hxt[k] * hxt[k]; }
+        REQUIRE(sqrt(num / den) < 1e-3, "LSQR recovers x_true");
+        printf("jh_lsqr_solve: %d iterations, istop %d, ||x - x_true|| / ||x_true|| = %.2e\n", lr.itn, lr.istop, sqrt(num / den));
+        free(hx); free(hxt);
+        CK(jh_bvec_destroy(xt));
+        CK(jh_bvec_destroy(bb));
+        CK(jh_bvec_destroy(xs));
+    }
+
     CK(jh_blockop_destroy(A));
     CK(jh_bvec_destroy(coeff));
     CK(jh_bvec_destroy(d));

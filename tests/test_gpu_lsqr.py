@@ -398,3 +398,42 @@ def test_pipelined_distributed_step_with_one_rank(Jets, oracle, monkeypatch):
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64])
+def test_native_lsqr_behind_the_abi_matches_the_python_driver(Jets, oracle, dt, monkeypatch):
+    """jh_lsqr_solve (the loop in C++ behind the ABI) against lsqr_core (the same recurrences in Python over the same
+    kernels): identical iterates, with damping, a warm start and early stopping; and against the fp64 CPU LSQR."""
+    nrow, shape = 6, (24, 16, 8)
+    A, _, _, diags = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    hb = (u01(oracle, dt, 95, 0, nrow * n) - dt(0.5)).astype(dt)
+    b = Jets.from_numpy(hb, Jets.range(A))
+    x0 = Jets.rand(Jets.domain(A), seed=96, stream=0)
+    for kw in (dict(maxiter=14, atol=0.0, btol=0.0, conlim=0.0), dict(maxiter=14, atol=0.0, btol=0.0, damp=0.3),
+               dict(maxiter=40, atol=1e-5, btol=1e-5), dict(maxiter=9, atol=0.0, btol=0.0, x0=x0), dict(maxiter=6, atol=0.0, btol=0.0, force_maxiter=True)):
+        monkeypatch.setenv("JETS_LSQR_NATIVE", "1")
+        r_nat = Jets.lsqr(A, b, **kw)
+        monkeypatch.setenv("JETS_LSQR_NATIVE", "0")
+        r_py = Jets.lsqr(A, b, **kw)
+        # same kernels for the big pass; the native loop fuses the domain-side updates and sums its norms in another
+        # (deterministic) order, and the Python driver rounds every norm to the element precision (norm() returns
+        # real(eltype), like the reference): equal to fp64 round-off for Float64, to single-precision round-off otherwise
+        exact = np.dtype(dt) == np.float64
+        rt = 1e-12 if exact else 2e-6
+        assert (r_nat.itn, r_nat.istop) == (r_py.itn, r_py.istop), kw
+        np.testing.assert_allclose([h[1] for h in r_nat.history], [h[1] for h in r_py.history], rtol=rt)
+        if exact:
+            np.testing.assert_allclose(r_nat.x.to_numpy(), r_py.x.to_numpy(), rtol=1e-11, atol=1e-13)
+        else:
+            np.testing.assert_allclose(r_nat.x.to_numpy(), r_py.x.to_numpy(), rtol=1e-4, atol=1e-5)
+        for f in ("r1norm", "r2norm", "anorm", "xnorm"):
+            assert getattr(r_nat, f) == pytest.approx(getattr(r_py, f), rel=max(rt, 1e-6)), f
+    assert np.array_equal(b.to_numpy(), hb)                                          # overwrite_b=False: b untouched
+    dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    matvec, rmatvec = _host_ops(diags, dt64)
+    xr, info = lsqr_fp64(matvec, rmatvec, hb.astype(dt64), n, atol=0.0, btol=0.0, conlim=0.0, maxiter=14)
+    monkeypatch.setenv("JETS_LSQR_NATIVE", "1")
+    r = Jets.lsqr(A, b, maxiter=14, atol=0.0, btol=0.0, conlim=0.0)
+    tol = 1e-10 if np.dtype(dt) == np.float64 else 1e-4
+    assert np.linalg.norm(r.x.to_numpy().ravel(order="F") - xr) / np.linalg.norm(xr) < tol

@@ -1,5 +1,8 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""LSQR iteration cost on small and mid-size operators: the loop in C++ behind the ABI (jh_lsqr_solve) vs the Python driver
+over the same kernels (JETS_LSQR_NATIVE=0).  The kernel-only figure is 3*N*n*4 bytes at 6 TB/s."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import jets_jl_amd as J
 J.init(0)
@@ -9,11 +12,14 @@ for nrow, edge in ((64, 128), (16, 128), (64, 64), (256, 128)):
     A = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
     x_true = J.rand(J.domain(A), seed=4, stream=0)
     b = J.mul(A, x_true)
-    J.lsqr(A, b, maxiter=5, atol=0, btol=0, force_maxiter=True)
-    J.synchronize()
-    t0 = time.perf_counter()
-    res = J.lsqr(A, b, maxiter=100, atol=0, btol=0, force_maxiter=True)
-    J.synchronize()
-    t = time.perf_counter() - t0
+    out = []
+    for native in ("1", "0"):
+        os.environ["JETS_LSQR_NATIVE"] = native
+        J.lsqr(A, b, maxiter=5, atol=0, btol=0, force_maxiter=True)
+        J.synchronize()
+        t0 = time.perf_counter()
+        res = J.lsqr(A, b, maxiter=100, atol=0, btol=0, force_maxiter=True)
+        J.synchronize()
+        out.append(1e3 * (time.perf_counter() - t0) / res.itn)
     n = edge ** 3
-    print(f"{nrow} x {edge}^3: {1e3 * t / res.itn:.3f} ms/iteration ({res.itn} its); 3Nn bytes at 6 TB/s = {3 * nrow * n * 4 / 6e12 * 1e3:.3f} ms")
+    print(f"{nrow:4d} x {edge}^3: native {out[0]:.3f} ms/iteration, Python driver {out[1]:.3f} ms/iteration; kernel only (3Nn at 6 TB/s) {3 * nrow * n * 4 / 6e12 * 1e3:.3f} ms", flush=True)
