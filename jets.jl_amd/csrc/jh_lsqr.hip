@@ -93,13 +93,6 @@ int lincomb1(jh_bvec *dst, double c0, const jh_bvec *x0)
     return jh_lincomb(dst, 1, coef, xs);
 }
 
-int lincomb2(jh_bvec *dst, double c0, const jh_bvec *x0, double c1, const jh_bvec *x1)
-{
-    const double coef[4] = {c0, 0.0, c1, 0.0};
-    const jh_bvec *xs[2] = {x0, x1};
-    return jh_lincomb(dst, 2, coef, xs);
-}
-
 // launch helpers: a complex vector is 2n reals for these real-coefficient updates
 int launch_vhat(int dtype, jh_bvec *v, const jh_bvec *atu, double c0, double c1, double *parts, int grid)
 {
