@@ -218,8 +218,9 @@ def main():
             tj = json.load(open(tpath))
             if tj.get("nblocks") == nloc and tj.get("edge") == edge:
                 key = dom["kernel"].split("+")[0]
-                if key == "k_tall_diag_fwd":
-                    key += "@walk%d" % J.tune_get("last_fwd_walk")      # PMC traffic is recorded per grid walk
+                if key == "k_tall_diag_fwd":                            # PMC traffic is recorded per grid walk; the column-persistent
+                    persistent = J.tune_get("last_fwd_rows_per_wg") >= nloc   # walk re-reads no m, like the row-concurrent one
+                    key += "@walk%d" % (1 if persistent else J.tune_get("last_fwd_walk"))
                 traffic = tj.get(key)
         except Exception:
             traffic = None
@@ -282,7 +283,8 @@ def main():
                 "workload": f"{nblocks}x1 tall JopBlock of diagonal JopLn, {edge}^3 Float32 blocks, fwd+adj mul! pair",
                 "nblocks": nblocks, "block": [edge, edge, edge], "rows_per_gpu": nloc,
                 "parallelism": f"row-partition x{world}" + (f" + {os.environ.get('BENCH_BACKEND', 'RCCL')} all-reduce({n * s / 2**20:.0f} MiB, pipelined in 4 chunks) in adjoint" if world > 1 else ""),
-                "fwd_grid_walk": {0: "sequential row sweep", 1: "all rows concurrent"}.get(J.tune_get("last_fwd_walk"), "banded"),
+                "fwd_grid_walk": ("column-persistent (a workgroup streams every block row)" if J.tune_get("last_fwd_rows_per_wg") >= nloc
+                                  else {0: "sequential row sweep", 1: "all rows concurrent"}.get(J.tune_get("last_fwd_walk"), "banded")),
                 "tune": {k: J.tune_get(k) for k in ("fwd_group", "fwd_unroll", "fwd_wg", "fwd_order", "adj_unroll", "adj_depth", "adj_wg", "nt", "autotune")},
             },
             "achieved_GBps_pair": pair_bytes_global * pairs_per_s / 1e9,

@@ -854,6 +854,7 @@ int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     int64_t band = sh.order <= 0 ? 1 : (sh.order == 1 ? gy : sh.order);   // order: 0 sequential, 1 all rows, k>1 = k groups per band
     if (band > gy) band = gy;
     c.last_fwd_walk = sh.order;
+    c.last_fwd_rows_per_wg = G;
 #define JH_FWD_CASE(U)                                                                                               \
     case U: {                                                                                                         \
         int64_t gx = (n_scalars + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                               \
@@ -903,14 +904,17 @@ int launch_tall_fwd_shape(const jh_blockop *op, void *d, const void *m, int64_t 
 
 // the shapes the first forward of a large operator is timed with: which one wins differs from process to process
 // (profiles/repeat_r01*.txt, sweep_r01_order.txt): sequential sweeps, and walks that touch every row group concurrently
-constexpr int K_FWD_CANDIDATES = 5;
+// -- and the column-persistent walk (rows per workgroup = all rows: a workgroup keeps its m tile and streams every block row
+// through it, no m re-reads), which is the best of the placement-independent shapes (22.0 vs 23.0 ms for the 16-row sweep,
+// profiles/sweep_r01_fwd_persistent_1024x256.txt)
+constexpr int K_FWD_CANDIDATES = 6;
 const TallShape k_fwd_candidates[K_FWD_CANDIDATES] = {TallShape{1024, 8, 16, 0}, TallShape{512, 1, 2, 1}, TallShape{256, 4, 4, 0},
-                                                      TallShape{256, 4, 16, 1}, TallShape{512, 4, 8, 1}};
+                                                      TallShape{256, 4, 16, 1}, TallShape{512, 4, 8, 1}, TallShape{1024, 8, 1 << 20, 0}};
 
 // For operators far larger than the caches the row-concurrent walk is 5-7 % faster than the sequential sweep in
 // some processes and 10-15 % slower in others (profiles/repeat_r01.txt: same binary, same box; it depends on where
-// the slabs landed physically), so the first forward of such an operator times both once (10 extra launches of an
-// idempotent kernel, ~0.25 s, synchronous) and keeps the winner.  Skipped while the stream is being captured.
+// the slabs landed physically), so the first forward of such an operator times both once (12 extra launches of an
+// idempotent kernel, ~0.3 s, synchronous) and keeps the winner.  Skipped while the stream is being captured.
 template <typename S, int E, int NS>
 int autotune_fwd_walk(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
 {

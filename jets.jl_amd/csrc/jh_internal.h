@@ -56,6 +56,7 @@ struct jh_context {
     int64_t graph_replays = 0;         // read-only counter: hipGraphLaunch calls made by run_loop_graphed
     uint64_t buf_gen = 0;              // bumped whenever part_dev / scratch_dev is reallocated: captured graphs holding the old pointers are stale
     int64_t red_wgs = 16384;           // workgroups of a reduction launch (4 packs per lane in flight); profiles/sweep_r01_reduce.txt
+    int64_t last_fwd_rows_per_wg = 0;  // block rows per workgroup of the most recent tall forward launch (read-only knob)
     int64_t last_fwd_walk = 0;         // grid walk used by the most recent tall forward launch (read-only knob)
 };
 jh_context &jh_ctx();
