@@ -137,8 +137,12 @@ _emit(x::Union{HipBlockArray,HipArray}, vecs, scals) = (i = findfirst(v -> v ===
 _emit(x::Number, vecs, scals) = (push!(scals, x); "s$(length(scals)-1)")
 _emit(x::Base.RefValue, vecs, scals) = _emit(x[], vecs, scals)
 function _emit(bc::Base.Broadcast.Broadcasted, vecs, scals)
+    if bc.f === Base.literal_pow                                  # u.^p with a literal p: args = (Ref(^), u, Ref(Val(p)))
+        p = typeof(bc.args[3][]).parameters[1]
+        base = _emit(bc.args[2], vecs, scals)
+        return (p isa Integer && 1 <= p <= 4) ? "(" * join(fill(base, p), " * ") * ")" : "pow($base, $p)"   # u.^2 -> u*u, like Julia
+    end
     f, args = bc.f, map(a -> _emit(a, vecs, scals), bc.args)
-    f === Base.literal_pow && return "(" * join(fill(args[2], bc.args[3] isa Base.RefValue ? 2 : 2), " * ") * ")"   # u.^2 -> u*u
     op = get(_cfun, f, nothing)
     op === nothing && error("broadcast of $(f) over device vectors is not supported")
     op in ("+", "-", "*", "/") ? (length(args) == 1 ? "($op$(args[1]))" : "(" * join(args, " $op ") * ")") : "$op(" * join(args, ", ") * ")"
