@@ -119,8 +119,10 @@ template <typename S, int E, int NS, int U, int DEPTH, bool NT, int MODE, int BL
 __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                        const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ out,
                                                        const S *__restrict__ in, int64_t n_scalars, int direct,
-                                                       int64_t s_begin, int64_t s_end)
+                                                       int64_t s_begin, int64_t s_end, int64_t row0, int64_t row1, int accumulate)
 {
+    // rows [row0, row1) of the operator; accumulate != 0 continues the ordered sum from what `out` holds (a long operator
+    // can be walked in several launches with the bits of one: ((0 + p_0) + p_1) + ... is the same sequence)
     // the launch covers the scalar range [s_begin, s_end) of the domain vector (the whole vector, or one chunk
     // when the multi-GPU exchange is pipelined chunk by chunk against this kernel)
     typedef typename vec_of<S, NS>::type V;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
 #pragma unroll
     for (int k = 0; k < U; k++) {
         ok[k] = (s0 + (int64_t)k * BLK * NS) < s_end;
-        acc[k] = (V)(S)0;
+        acc[k] = (accumulate && ok[k]) ? ld<false>(reinterpret_cast<const V *>(out + s0 + (int64_t)k * BLK * NS)) : (V)(S)0;
         if (MODE == 1) mv[k] = ok[k] ? ld<false>(reinterpret_cast<const V *>(in + s0 + (int64_t)k * BLK * NS)) : (V)(S)0;
     }
     // clamp out-of-range vectors onto a valid address so the main loop is branch-free
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
 #pragma unroll
     for (int k = 0; k < U; k++) sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : s_begin;
 
-    int64_t i = 0;
-    for (; !direct && i + DEPTH <= nrow; i += DEPTH) {
+    int64_t i = row0;
+    for (; !direct && i + DEPTH <= row1; i += DEPTH) {
         V av[DEPTH][U], dv[DEPTH][U];
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) {
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
                 acc[k] = acc[k] + p;                                                         // _m .+= mtmp   (1049)
             }
     }
-    for (; i < nrow; i++) {
+    for (; i < row1; i++) {
         const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
 #pragma unroll
         for (int k = 0; k < U; k++) {
@@ -883,13 +885,21 @@ int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n
     const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
     const int64_t a_stride = op->diag_stride_elems * E;
     const int direct = (op->nrow == 1 && MODE == 0) ? 1 : 0;
+    // A 128 GiB walk runs 2-3 % faster as two launches over 512 rows each than as one (profiles/exp_r01_adj_row_chunks.txt,
+    // exp_r01_adj_by_rows.txt); the second launch continues the ordered sum, so the bits do not change.
+    int64_t rows_per_launch = op->nrow;
+    if (c.adj_rows_per_launch > 0) rows_per_launch = c.adj_rows_per_launch < op->nrow ? c.adj_rows_per_launch : op->nrow;
+    else if (op->nrow >= 768 && (double)op->nrow * (double)n_scalars * sizeof(S) >= 48.0 * (double)(1ull << 30)) rows_per_launch = 512;
 #define JH_ADJ_CASE(U, DEPTH)                                                                                          \
     if (sh.unroll == U && sh.aux == DEPTH) {                                                                           \
         int64_t gx = (s_end - s_begin + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                          \
-        hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, NT, MODE, BLK>), dim3((unsigned)gx), dim3(BLK), 0,     \
-                           c.stream, op->dev_blocks, op->nrow, a_base, a_stride, (S *)out, (const S *)in, n_scalars, direct, \
-                           s_begin, s_end);                                                                            \
-        JH_CHECK_HIP(hipGetLastError());                                                                               \
+        for (int64_t r0 = 0; r0 < op->nrow; r0 += rows_per_launch) {                                                   \
+            const int64_t r1 = r0 + rows_per_launch < op->nrow ? r0 + rows_per_launch : op->nrow;                        \
+            hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, NT, MODE, BLK>), dim3((unsigned)gx), dim3(BLK), 0, \
+                               c.stream, op->dev_blocks, op->nrow, a_base, a_stride, (S *)out, (const S *)in, n_scalars,   \
+                               direct, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0);                                            \
+            JH_CHECK_HIP(hipGetLastError());                                                                           \
+        }                                                                                                              \
         return JH_OK;                                                                                                  \
     }
     JH_ADJ_CASE(1, 1) JH_ADJ_CASE(1, 2) JH_ADJ_CASE(1, 4) JH_ADJ_CASE(1, 8)

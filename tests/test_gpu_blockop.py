@@ -427,3 +427,25 @@ def test_tall_operator_with_a_few_scalar_rows_stays_on_the_tall_kernels(Jets, or
     natB = jetblock._native_op(B.jet.s["_native"], B.jet.s["ops"], B.jet.rng.eltype())
     u3 = Jets.zeros(Jets.range(B))
     assert lib.jh_blockop_bidiag_step(natB.handle, u3.handle, m.handle, w.handle, 1.0, 0.0, C.byref(out)) == 4   # JH_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("rows", [1, 3, 5, 64])
+def test_adjoint_in_several_row_launches_gives_the_bits_of_one(Jets, oracle, rows):
+    """knob adj_rows_per_launch: the ordered sum continues across launches (also the fused A'A)."""
+    dt, nrow, shape = np.float32, 13, (40, 40, 12)
+    A, _, ops, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=0)
+    d = A * m
+    hm = u01(oracle, dt, SEED_M, 0, n)
+    ref_d = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [hm])
+    ref_m = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], ref_d)
+    try:
+        Jets.tune(adj_rows_per_launch=rows)
+        mt = Jets.rand(Jets.domain(A), seed=77, stream=0)                             # dirty output
+        Jets.mul_(mt, A.H, d)
+        assert_bits_equal(mt.to_numpy().ravel(order="F"), ref_m[0], f"adjoint, {rows} rows per launch")
+        y = Jets.mul(A.H @ A, m)
+        assert_bits_equal(y.to_numpy().ravel(order="F"), ref_m[0], f"fused A'A, {rows} rows per launch")
+    finally:
+        Jets.tune(adj_rows_per_launch=0)
