@@ -323,8 +323,10 @@ template <typename S, int E, int NS, int U, int DEPTH, int BLK>
 __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                           const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ u,
                                                           const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, int direct,
-                                                          S alpha, S beta, double *__restrict__ partials, int64_t s_begin, int64_t s_end)
+                                                          S alpha, S beta, double *__restrict__ partials, int64_t s_begin, int64_t s_end,
+                                                          int64_t row0, int64_t row1, int accumulate)
 {
+    // rows [row0, row1); accumulate != 0 continues w's ordered sum from what it holds (several launches, the bits of one)
     // the launch covers the scalar range [s_begin, s_end) of the domain (the whole vector, or one chunk when a multi-GPU
     // host pipelines the exchange of w chunk by chunk against this kernel)
     typedef typename vec_of<S, NS>::type V;
@@ -336,13 +338,13 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
     for (int k = 0; k < U; k++) {
         ok[k] = (s0 + (int64_t)k * BLK * NS) < s_end;
         sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : s_begin;
-        acc[k] = (V)(S)0;
+        acc[k] = (accumulate && ok[k]) ? ld<false>(reinterpret_cast<const V *>(w + sk[k])) : (V)(S)0;
         vv[k] = ld<false>(reinterpret_cast<const V *>(v + sk[k]));
     }
     const bool use_old = (beta != (S)0);
     double nrm = 0.0;
-    int64_t i = 0;
-    for (; !direct && i + DEPTH <= nrow; i += DEPTH) {
+    int64_t i = row0;
+    for (; !direct && i + DEPTH <= row1; i += DEPTH) {
         V av[DEPTH][U], uv[DEPTH][U];
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) {
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
                 acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, true);  // _m .+= conj(a_i) .* u_i   (1049)
             }
     }
-    for (; i < nrow; i++) {
+    for (; i < row1; i++) {
         const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
 #pragma unroll
         for (int k = 0; k < U; k++) {
@@ -1213,13 +1215,26 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     if (c.adj_depth) D = (int)c.adj_depth;
     const int64_t gx = ((s_end - s_begin) / NS + (int64_t)wg * U - 1) / ((int64_t)wg * U);
     JH_TRY(jh_ensure_partials(gx));
+    // the knob adj_rows_per_launch splits this walk too (w's ordered sum continues; ||u||^2 adds up), but unlike the plain
+    // adjoint it does not pay here: 37.0 ms in two launches of 512 rows vs 34.2 ms in one at 1024 x 256^3 (each launch ends
+    // with the read-back of its share of ||u||^2), so one launch is the default
+    int64_t rows_per_launch = op->nrow;
+    if (c.adj_rows_per_launch > 0) rows_per_launch = c.adj_rows_per_launch < op->nrow ? c.adj_rows_per_launch : op->nrow;
 #define JH_LAUNCH(BLK, UU, DD)                                                                                          \
     if (wg == BLK && U == UU && D == DD) {                                                                              \
-        hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK>), dim3((unsigned)gx), dim3(BLK), 0, c.stream,      \
-                           op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars, direct,  \
-                           (S)alpha, (S)beta, c.part_dev, s_begin, s_end);                                               \
-        JH_CHECK_HIP(hipGetLastError());                                                                                 \
-        return finish_normsq(gx, normsq);                                                                                \
+        double total = 0.0;                                                                                              \
+        for (int64_t r0 = 0; r0 < op->nrow; r0 += rows_per_launch) {                                                     \
+            const int64_t r1 = r0 + rows_per_launch < op->nrow ? r0 + rows_per_launch : op->nrow;                          \
+            hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK>), dim3((unsigned)gx), dim3(BLK), 0, c.stream,  \
+                               op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars,      \
+                               direct, (S)alpha, (S)beta, c.part_dev, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0);              \
+            JH_CHECK_HIP(hipGetLastError());                                                                             \
+            double part = 0.0;                                                                                           \
+            JH_TRY(finish_normsq(gx, normsq ? &part : nullptr));                                                         \
+            total += part;                                                                                               \
+        }                                                                                                                \
+        if (normsq) *normsq = total;                                                                                     \
+        return JH_OK;                                                                                                    \
     }
     JH_LAUNCH(256, 1, 4) JH_LAUNCH(256, 2, 2) JH_LAUNCH(256, 4, 1) JH_LAUNCH(256, 4, 2) JH_LAUNCH(256, 1, 8)
     JH_LAUNCH(512, 1, 4) JH_LAUNCH(512, 2, 2) JH_LAUNCH(512, 4, 1) JH_LAUNCH(512, 4, 2) JH_LAUNCH(512, 1, 8)
