@@ -437,3 +437,27 @@ def test_native_lsqr_behind_the_abi_matches_the_python_driver(Jets, oracle, dt, 
     r = Jets.lsqr(A, b, maxiter=14, atol=0.0, btol=0.0, conlim=0.0)
     tol = 1e-10 if np.dtype(dt) == np.float64 else 1e-4
     assert np.linalg.norm(r.x.to_numpy().ravel(order="F") - xr) / np.linalg.norm(xr) < tol
+
+
+def test_bidiag_step_in_several_row_launches(Jets, oracle):
+    """knob adj_rows_per_launch on the one-pass step: w's ordered sum continues across launches, ||u||^2 adds up."""
+    from jets_jl_amd._ffi import lib, check
+
+    dt, nrow, shape = np.float32, 11, (40, 40, 12)
+    A, _, _, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    nat = _native(Jets, A)
+    v = Jets.rand(Jets.domain(A), seed=51, stream=0)
+    outs = []
+    for rows in (0, 4):
+        Jets.tune(adj_rows_per_launch=rows)
+        try:
+            u = Jets.rand(Jets.range(A), seed=52, stream=0)
+            w = Jets.rand(Jets.domain(A), seed=53, stream=0)
+            out = C.c_double(0)
+            check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, 0.75, -1.375, C.byref(out)))
+            outs.append((u.to_numpy(), w.to_numpy(), out.value))
+        finally:
+            Jets.tune(adj_rows_per_launch=0)
+    assert_bits_equal(outs[1][0], outs[0][0], "u")
+    assert_bits_equal(outs[1][1], outs[0][1], "w")
+    assert outs[1][2] == pytest.approx(outs[0][2], rel=1e-12)
