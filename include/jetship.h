@@ -266,7 +266,7 @@ int jh_comm_allreduce_scalars(double *values, int n, int op);   /* op: 0 sum, 1 
  * "graphs" (1: operators that run the per-block loop -- those with DENSE blocks -- replay it as a hipGraph from the
  * third call with the same vectors on; 0: always eager), "general_xcd" (0: the general M x K kernels walk tile-fastest instead
  * of XCD-aware; for A/B measurements), "red_wgs"}; jh_tune_get also reads the counters
- * "last_fwd_walk" (grid walk of the latest tall forward: 0 sequential, 1 all rows), "last_fwd_rows_per_wg" and "graph_replays". */
+ * "last_fwd_walk" (grid walk of the latest tall forward: 0 sequential, 1 all rows), "last_fwd_rows_per_wg", "last_adj_launches" and "graph_replays". */
 int jh_tune_set(const char *name, int64_t value);
 int jh_tune_get(const char *name, int64_t *value);
 

@@ -892,6 +892,7 @@ int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n
     int64_t rows_per_launch = op->nrow;
     if (c.adj_rows_per_launch > 0) rows_per_launch = c.adj_rows_per_launch < op->nrow ? c.adj_rows_per_launch : op->nrow;
     else if (op->nrow >= 768 && (double)op->nrow * (double)n_scalars * sizeof(S) >= 48.0 * (double)(1ull << 30)) rows_per_launch = 512;
+    c.last_adj_launches = (op->nrow + rows_per_launch - 1) / rows_per_launch;
 #define JH_ADJ_CASE(U, DEPTH)                                                                                          \
     if (sh.unroll == U && sh.aux == DEPTH) {                                                                           \
         int64_t gx = (s_end - s_begin + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                          \

@@ -495,6 +495,7 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "general_xcd")) *value = c.general_xcd;
     else if (!strcmp(name, "graph_replays")) *value = c.graph_replays;
     else if (!strcmp(name, "last_fwd_rows_per_wg")) *value = c.last_fwd_rows_per_wg;
+    else if (!strcmp(name, "last_adj_launches")) *value = c.last_adj_launches;
     else if (!strcmp(name, "red_wgs")) *value = c.red_wgs;
     else if (!strcmp(name, "last_fwd_walk")) *value = c.last_fwd_walk;
     else return jh_fail(JH_ERR_INVALID, "jh_tune_get: unknown knob '%s'", name);

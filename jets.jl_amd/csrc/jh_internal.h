@@ -58,6 +58,7 @@ struct jh_context {
     uint64_t buf_gen = 0;              // bumped whenever part_dev / scratch_dev is reallocated: captured graphs holding the old pointers are stale
     int64_t red_wgs = 16384;           // workgroups of a reduction launch (4 packs per lane in flight); profiles/sweep_r01_reduce.txt
     int64_t last_fwd_rows_per_wg = 0;  // block rows per workgroup of the most recent tall forward launch (read-only knob)
+    int64_t last_adj_launches = 1;     // kernel launches of the most recent tall adjoint / fused normal call (read-only knob)
     int64_t last_fwd_walk = 0;         // grid walk used by the most recent tall forward launch (read-only knob)
 };
 jh_context &jh_ctx();

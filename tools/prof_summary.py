@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--edge", type=int, default=256)
     ap.add_argument("--cmd", default="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline")
     ap.add_argument("--walk", type=int, default=None, help="grid walk of the tall forward the profiled runs were pinned to (0/1)")
+    ap.add_argument("--adj-launches", type=int, default=1, help="launches per tall adjoint call (a 128 GiB adjoint goes in 2 launches of 512 rows): algorithmic bytes per LAUNCH = per call / this")
     ap.add_argument("--tag", default="", help="suffix for the output file names (rocprof_<round><tag>_summary.md)")
     ap.add_argument("--merge", action="store_true", help="merge into an existing traffic_latest.json instead of replacing it")
     args = ap.parse_args()
@@ -62,6 +63,7 @@ def main():
     n = args.edge ** 3
     algo = {"k_tall_diag_fwd": (2 * args.nblocks * n + n) * 4, "k_tall_diag_adj": (2 * args.nblocks * n + n) * 4,
             "k_tall_diag_bidiag": (3 * args.nblocks * n + 2 * n) * 4, "k_tall_diag_fwd_update": (3 * args.nblocks * n + n) * 4, "k_tall_diag_adj_update": (2 * args.nblocks * n + 2 * n) * 4}
+    algo["k_tall_diag_adj"] //= args.adj_launches
     lines = [f"# rocprofv3 summary, round {args.round}", "",
              f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- {args.cmd}` on one MI355X (gfx950);",
              "PMC: separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes of the same program (3 timed steps).",
