@@ -160,6 +160,10 @@ typedef struct jh_bcast jh_bcast;
 int jh_bcast_check(const char *expr, int dtype, int nvec, int nscal);
 int jh_bcast_compile(const char *expr, int dtype, int nvec, int nscal, jh_bcast **out);
 int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, const double *scal_re_im);
+/* `count` broadcasts in one call (a tall nonlinear operator evaluates one per child: F(m) and point! are `count` launches
+ * enqueued back to back instead of `count` trips through the host language).  Operand k's vectors and scalars follow
+ * each other in the flattened lists `x` (sum of nvec entries) and `scal_re_im` (2 * sum of nscal doubles). */
+int jh_bcast_apply_many(int count, const jh_bcast *const *progs, jh_bvec *const *dsts, const jh_bvec *const *x, const double *scal_re_im);
 int jh_bcast_destroy(jh_bcast *bc);
 /* dot(x,y), src/Jets.jl:850-856 (conjugates x). fp64 accumulation, deterministic order. */
 int jh_dot(const jh_bvec *x, const jh_bvec *y, double *re, double *im);

@@ -21,10 +21,41 @@ from ._ffi import lib, check
 from .spaces import dtype_code
 from .arrays import _DevVec, similar
 
-__all__ = ["broadcast_", "lazy", "assign_", "bc", "BExpr"]
+__all__ = ["broadcast_", "broadcast_many_", "lazy", "assign_", "bc", "BExpr"]
 
 _programs = {}
 _scalar_ids = itertools.count()
+
+
+def _program(expr: str, dtype, nvec: int, nscal: int):
+    key = (expr, np.dtype(dtype).str, nvec, nscal)
+    h = _programs.get(key)
+    if h is None:
+        h = C.c_void_p()
+        check(lib.jh_bcast_compile(expr.encode(), dtype_code(dtype), nvec, nscal, C.byref(h)))
+        _programs[key] = h
+    return h
+
+
+def broadcast_many_(jobs):
+    """[(dst, expr, vecs, scalars), ...] in ONE trip through the ABI (jh_bcast_apply_many): the launches are enqueued back
+    to back -- what a tall nonlinear operator needs for F(m) and point! over hundreds of children."""
+    jobs = list(jobs)
+    if not jobs:
+        return
+    progs = (C.c_void_p * len(jobs))()
+    dsts = (C.c_void_p * len(jobs))()
+    xs, sc = [], []
+    for k, (dst, expr, vecs, scalars) in enumerate(jobs):
+        progs[k] = _program(expr, dst.dtype, len(vecs), len(scalars))
+        dsts[k] = dst.handle
+        xs += [v.handle for v in vecs]
+        for a in scalars:
+            a = complex(a)
+            sc += [a.real, a.imag]
+    xa = (C.c_void_p * max(len(xs), 1))(*xs)
+    sa = (C.c_double * max(len(sc), 1))(*sc)
+    check(lib.jh_bcast_apply_many(len(jobs), progs, dsts, xa, sa))
 
 
 def broadcast_(dst: _DevVec, expr: str, vecs=(), scalars=()):

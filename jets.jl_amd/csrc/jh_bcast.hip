@@ -263,6 +263,19 @@ int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, co
     return JH_OK;
 }
 
+int jh_bcast_apply_many(int count, const jh_bcast *const *progs, jh_bvec *const *dsts, const jh_bvec *const *xs, const double *scal_re_im)
+{
+    JH_REQUIRE(count >= 0 && (count == 0 || (progs && dsts)), "jh_bcast_apply_many: null argument");
+    int64_t ix = 0, is = 0;                                   // running offsets into the flattened operand / scalar lists
+    for (int k = 0; k < count; k++) {
+        JH_REQUIRE(progs[k], "jh_bcast_apply_many: program %d is null", k);
+        JH_TRY(jh_bcast_apply(progs[k], dsts[k], xs ? xs + ix : nullptr, scal_re_im ? scal_re_im + is : nullptr));
+        ix += progs[k]->nvec;
+        is += 2 * progs[k]->nscal;
+    }
+    return JH_OK;
+}
+
 int jh_bcast_destroy(jh_bcast *bc)
 {
     (void)bc;   // programs live in the process-wide cache (one per distinct expression) until jh_shutdown

@@ -368,6 +368,11 @@ def JetBlock_f(d, m, *, ops, dom, rng, _native=None, **kw):  # :988-1008
     if nat is not None and not nat.host_f:
         return nat.f(d, m)  # one fused launch, same loop order and rounding
     nrow, ncol = ops.shape
+    if ncol == 1 and all(isinstance(op, JopNl) and op.jet.f is elementwise_f for op in ops.flat):
+        from .broadcast import broadcast_many_   # every child's f! (1003) enqueued in one trip through the ABI
+
+        broadcast_many_((getblock(d, i), ops[i, 0].jet.s["f_expr"], [m], ops[i, 0].jet.s["params"]) for i in builtins.range(nrow))
+        return d
     dtmp = zeros(range_(ops[0, 0])) if ncol > 1 else None
     for i in builtins.range(nrow):
         _d = getblock(d, i)
@@ -431,9 +436,21 @@ def JetBlock_df_adj(m, d, *, ops, dom, rng, _native=None, **kw):  # :1034-1057
 def point_block(j: Jet, mo):  # :1059-1066
     ops = j.s["ops"]
     j.mo = mo
+    jobs = []
     for jc in builtins.range(ops.shape[1]):
+        mo_j = getblock(mo, jc)
         for i in builtins.range(ops.shape[0]):
-            point_(jet(ops[i, jc]), getblock(mo, jc))
+            cj = jet(ops[i, jc])
+            if cj.upstate is elementwise_upstate and cj.f is elementwise_f:   # point!(child) = set mo + upstate!; the upstate!s are batched
+                cj.mo = mo_j
+                jobs.append((cj.s["diagonal"], cj.s["jac_expr"], [mo_j], cj.s["params"]))
+                cj.s["pointed"][0] = True
+            else:
+                point_(cj, mo_j)
+    if jobs:
+        from .broadcast import broadcast_many_
+
+        broadcast_many_(jobs)
     return j
 
 
