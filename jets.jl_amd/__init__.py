@@ -21,5 +21,6 @@ from .jets import range_ as range  # noqa: F401,A001  Jets.range(A)
 from .jets import register_close, register_perfstat  # noqa: F401
 from .jetblock import *  # noqa: F401,F403
 from .broadcast import *  # noqa: F401,F403
+from .symmetric import SymmetricArray, symspace  # noqa: F401
 from .lsqr import lsqr, LsqrResult  # noqa: F401
 from . import rowpart  # noqa: F401

@@ -19,7 +19,7 @@ import numpy as np
 
 from ._ffi import lib, check
 from . import device as _device
-from .spaces import JetAbstractSpace, JetSpace, JetBSpace, dtype_code
+from .spaces import JetAbstractSpace, JetSpace, JetBSpace, JetSSpace, dtype_code
 
 __all__ = [
     "DeviceArray", "BlockArray", "LinExpr", "zeros", "ones", "rand", "randn", "Array", "from_numpy", "space", "nblocks",
@@ -308,6 +308,10 @@ def _new_handle(block_lens: Sequence[int], T) -> C.c_void_p:
 def Array(R: JetAbstractSpace):
     """Array(R) / zeros(R): device storage for the space (src/Jets.jl:105-108, 922-924).  Device
     allocations are always zero-filled."""
+    if isinstance(R, JetSSpace):  # src/Jets.jl:514-516
+        from .symmetric import zeros_sym
+
+        return zeros_sym(R)
     if isinstance(R, JetBSpace):
         return BlockArray(_new_handle(R.block_lengths(), R.eltype()), R.spaces, R.eltype())
     return DeviceArray(_new_handle([R.length()], R.eltype()), R.size(), R.eltype())
@@ -317,12 +321,20 @@ zeros = Array
 
 
 def ones(R: JetAbstractSpace):
+    if isinstance(R, JetSSpace):
+        from .symmetric import ones_sym
+
+        return ones_sym(R)
     return fill_(Array(R), 1.0)
 
 
 def rand(R: JetAbstractSpace, seed: int | None = None, stream: int | None = None, index_base: int = 0):
     """rand(R): U[0,1) from the counter-based generator.  With seed/stream given the
     values are a pure function of (seed, stream, element index) and reproducible on the CPU oracle."""
+    if isinstance(R, JetSSpace):
+        from .symmetric import rand_sym
+
+        return rand_sym(R, seed=seed, stream=stream, index_base=index_base)
     x = Array(R)
     if seed is None:
         seed, stream = _DEFAULT_SEED, next(_rand_counter)
@@ -332,6 +344,10 @@ def rand(R: JetAbstractSpace, seed: int | None = None, stream: int | None = None
 
 def randn(R: JetAbstractSpace, seed: int | None = None, stream: int | None = None, index_base: int = 0):
     """randn(R): standard normal values generated on the device (Box-Muller over the counter generator)."""
+    if isinstance(R, JetSSpace):
+        from .symmetric import randn_sym
+
+        return randn_sym(R, seed=seed, stream=stream, index_base=index_base)
     x = Array(R)
     if seed is None:
         seed, stream = _DEFAULT_SEED, next(_rand_counter)
@@ -341,6 +357,11 @@ def randn(R: JetAbstractSpace, seed: int | None = None, stream: int | None = Non
 
 def abs_(x: "_DevVec"):
     """abs.(x): a real vector with the block structure of x (test/runtests.jl:545-547)."""
+    if not isinstance(x, _DevVec):
+        from .symmetric import SymmetricArray, abs_sym
+
+        if isinstance(x, SymmetricArray):
+            return abs_sym(x)
     real_t = np.float32 if x.dtype in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
     out = similar(x, real_t)
     check(lib.jh_abs(out.handle, x.handle))
@@ -431,7 +452,11 @@ def upload_from(x: "_DevVec", host: np.ndarray) -> "_DevVec":
 
 # ------------------------------------------------------------------------------ generic functions --
 def space(x):
-    """space(x) (src/Jets.jl:126, 814)."""
+    """space(x) (src/Jets.jl:126, 452, 814)."""
+    if not isinstance(x, _DevVec) and hasattr(x, "map") and hasattr(x, "A"):
+        from .symmetric import space_sym
+
+        return space_sym(x)
     if isinstance(x, BlockArray):
         return JetBSpace([JetSpace(x.dtype, *s.size()) for s in x.spaces])
     if isinstance(x, DeviceArray):
@@ -502,6 +527,10 @@ def setblock_(x, iblock: int, value):
 
 def norm(x: _DevVec, p: float = 2) -> float:
     """norm(x, p) (src/Jets.jl:834-848); returned in real(eltype) precision like the reference."""
+    if not isinstance(x, _DevVec) and hasattr(x, "map") and hasattr(x, "A"):
+        from .symmetric import norm_sym
+
+        return norm_sym(x, p)
     out = C.c_double(0)
     check(lib.jh_norm(x.handle, float(p), C.byref(out)))
     real_t = np.float32 if x.dtype in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
@@ -557,6 +586,10 @@ def hadamard_(dst: _DevVec, x: _DevVec, y: _DevVec, conj_x: bool = False, twice_
 
 def similar(x: _DevVec, T=None, n: int | None = None):
     """similar(x[, T[, n]]) (src/Jets.jl:829-832): a BlockArray when n == length(x), else a plain array."""
+    if not isinstance(x, _DevVec) and hasattr(x, "map") and hasattr(x, "A"):
+        from .symmetric import similar_sym
+
+        return similar_sym(x, T)
     T = x.dtype if T is None else np.dtype(T)
     if isinstance(n, tuple):
         n = n[0]

@@ -12,7 +12,7 @@ from typing import Sequence
 
 import numpy as np
 
-__all__ = ["JetAbstractSpace", "JetSpace", "JetBSpace", "DTYPE_CODES", "dtype_code"]
+__all__ = ["JetAbstractSpace", "JetSpace", "JetBSpace", "JetSSpace", "DTYPE_CODES", "dtype_code"]
 
 DTYPE_CODES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.complex64): 2, np.dtype(np.complex128): 3}
 
@@ -77,6 +77,37 @@ class JetSpace(JetAbstractSpace):
 
     def __repr__(self):
         return f"JetSpace({self._T.name}, {', '.join(map(str, self.n))})"
+
+
+class JetSSpace(JetAbstractSpace):
+    """JetSSpace(T, n, M, map)  (src/Jets.jl:407-446): a space of size `n` whose arrays store only the block `M` (the
+    non-redundant part, e.g. the non-negative frequencies of the spectrum of a real signal); `map` takes the 0-based index
+    tuple of an element OUTSIDE the stored block to the 0-based index tuple of the stored element it is the conjugate of."""
+
+    def __init__(self, T, n, M, map):  # noqa: A002  (the reference's field name)
+        self._T = np.dtype(T)
+        self.n = tuple(int(k) for k in n)
+        self.M = tuple(int(k) for k in M)
+        self.map = map
+        if len(self.n) != len(self.M):
+            raise ValueError("n and M must have the same number of dimensions")
+
+    def _size(self):  # :438
+        return self.n
+
+    def similar(self, *dims) -> "JetSSpace":  # :442-443
+        if len(dims) == 1 and isinstance(dims[0], (tuple, list)):
+            dims = tuple(dims[0])
+        return JetSSpace(self._T, dims, self.M, self.map)
+
+    def __eq__(self, other):
+        return isinstance(other, JetSSpace) and self._T == other._T and self.n == other.n and self.M == other.M and self.map is other.map
+
+    def __hash__(self):
+        return hash((self._T.str, self.n, self.M, id(self.map)))
+
+    def __repr__(self):
+        return f"JetSSpace({self._T.name}, {self.n}, stored {self.M})"
 
 
 class JetBSpace(JetAbstractSpace):

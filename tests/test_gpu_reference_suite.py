@@ -452,3 +452,57 @@ def test_composition_operator_times_block_operator(Jets, T):
     m = Jets.rand(Jets.domain(A))
     Am = A * m
     assert approx(Jets.getblock(Am, 0), A11 * m) and approx(Jets.getblock(Am, 1), A21 * m)
+
+
+# ---------------------------------------------------------------------------------- symmetric spaces (test/runtests.jl:218-294)
+def _indexmap(I):                                           # 0-based twin of test/runtests.jl:218-224
+    return I if I[0] < 4 else (I[0] - 4, I[1])
+
+
+def test_symmetric_space(Jets):
+    """test/runtests.jl:227-257."""
+    C128 = np.complex128
+    R = Jets.JetSSpace(C128, (8, 4), (4, 4), _indexmap)
+    assert tuple(R.size()) == (8, 4) and R.eltype() == np.dtype(C128)
+    assert np.array_equal(Jets.ones(R).to_numpy(), np.ones((8, 4), C128)) and np.array_equal(Jets.zeros(R).to_numpy(), np.zeros((8, 4), C128))
+    assert Jets.rand(R).shape == (8, 4) and Jets.Array(R).shape == (8, 4) and Jets.Array(R).dtype == np.dtype(C128)
+    _ = Jets.randn(R)
+    x = Jets.rand(R)
+    z = Jets.similar(x)
+    assert isinstance(z, Jets.SymmetricArray) and z.shape == (8, 4)
+    y = x.A                                                                           # the stored block
+    hy = y.to_numpy()
+    assert Jets.norm(x) == pytest.approx(np.sqrt(2 * np.linalg.norm(hy) ** 2), rel=1e-12)         # :243
+    assert Jets.norm(x, 2) == pytest.approx(float(Jets.norm(x)), rel=1e-14)
+    assert Jets.norm(x, 1) == pytest.approx(2 * np.abs(hy).sum(), rel=1e-12)
+    assert Jets.norm(x, np.inf) == pytest.approx(np.abs(hy).max(), rel=1e-14)
+    x[0, 0] = 0
+    x[5, 0] = 0                                                                       # x[1,1] = x[6,1] = 0  (:247)
+    assert Jets.norm(x, 0) == pytest.approx(2 * np.count_nonzero(x.A.to_numpy()), rel=1e-14)
+    assert Jets.space(Jets.rand(R)) == R
+    assert Jets.JetSSpace(C128, (0, 0), R.M, R.map) == R.similar((0, 0))
+    for i in range(32):                                                               # :252-256, linear indices (column-major)
+        x[i] = (i + 1) + (i + 1) * 1j
+        assert x[i] == (i + 1) + (i + 1) * 1j
+    full = x.to_numpy()
+    assert full[6, 1] == np.conj(x.A.to_numpy()[2, 1])                                # outside the stored block: the conjugate
+
+
+def test_symmetric_spaces_broadcast(Jets):
+    """test/runtests.jl:259-294."""
+    R = Jets.JetSSpace(np.complex128, (8, 4), (4, 4), _indexmap)
+    u, v, w = Jets.rand(R), Jets.rand(R), Jets.rand(R)
+    a, b, c = RNG.random(3)
+    x = (a * u + b * v + c * w).materialize()
+    assert isinstance(x, Jets.SymmetricArray)
+    want = a * u.A.to_numpy() + b * v.A.to_numpy() + c * w.A.to_numpy()
+    assert approx(x.A, want)
+    y = Jets.zeros(R)
+    y.assign(x)
+    assert approx(y.A, want) and np.allclose(y.to_numpy(), x.to_numpy())
+    y.assign(-1.0 * y)                                                                # y .*= -1
+    assert approx(y.parent, -want)
+    z = Jets.abs_(x)
+    assert isinstance(z, np.ndarray) and z.dtype == np.float64 and z.shape == (8, 4)  # typeof(z) == Array{Float64,2}
+    full = x.to_numpy()
+    assert np.allclose(z, np.abs(full))
