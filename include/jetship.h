@@ -187,7 +187,12 @@ int jh_blockop_destroy(jh_blockop *op);
  * zero blocks are skipped (1022); with ncol > 1 the result is accumulated into d without zeroing (1024). */
 int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m);
 /* mul!(m, A', d) -> JetBlock_df'!, src/Jets.jl:1034-1057: m zeroed when nrow > 1 (1042), rows summed
- * in order i = 0..nrow-1 with the product rounded before the add (1049) => bit-exact on one GPU. */
+ * in order i = 0..nrow-1 with the product rounded before the add (1049) => bit-exact on one GPU.
+ * Exception, automatic from 256 rows on when a block is too small to fill the chip with one thread per 16 bytes of the
+ * domain (fewer workgroups than CUs): the rows are cut into contiguous parts, each summed in order, and the parts are
+ * folded in a fixed order with fp64 accumulation -- deterministic, at least as accurate as the ordered sum, but not
+ * its bits (100x faster on 1 GiB of 4096-element rows).  jh_tune_set("adj_split", 0) keeps the ordered walk always.
+ * The same applies to jh_blockop_normal_mul, jh_blockop_mul_adj_range and the w of jh_blockop_bidiag_step. */
 int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d);
 /* mul!(d, F, m) for a NONLINEAR block operator -> JetBlock_f!, src/Jets.jl:988-1008, one fused launch.  SQUARE children
  * square their input; linear children run df! (src/Jets.jl:391-392).  Unlike the linear loop NO block is skipped: with
@@ -269,8 +274,10 @@ int jh_comm_allreduce_scalars(double *values, int n, int op);   /* op: 0 sum, 1 
 /* kernel-shape tuning knobs (bench/tests only): 0 = automatic (fwd_order: -1); name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg","fwd_order","nt","autotune",
  * "graphs" (1: operators that run the per-block loop -- those with DENSE blocks -- replay it as a hipGraph from the
  * third call with the same vectors on; 0: always eager), "general_xcd" (0: the general M x K kernels walk tile-fastest instead
- * of XCD-aware; for A/B measurements), "red_wgs"}; jh_tune_get also reads the counters
- * "last_fwd_walk" (grid walk of the latest tall forward: 0 sequential, 1 all rows), "last_fwd_rows_per_wg", "last_adj_launches" and "graph_replays". */
+ * of XCD-aware; for A/B measurements), "red_wgs", "adj_split" (split-row walk of the tall adjoint / fused normal /
+ * one-pass step: -1 automatic, 0 never -- always the ordered, bit-exact walk --, k > 1 that many row parts)};
+ * jh_tune_get also reads the counters "last_fwd_walk" (grid walk of the latest tall forward: 0 sequential, 1 all rows),
+ * "last_fwd_rows_per_wg", "last_adj_launches", "last_adj_parts" and "graph_replays". */
 int jh_tune_set(const char *name, int64_t value);
 int jh_tune_get(const char *name, int64_t *value);
 

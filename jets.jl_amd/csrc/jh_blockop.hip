@@ -119,13 +119,23 @@ template <typename S, int E, int NS, int U, int DEPTH, bool NT, int MODE, int BL
 __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                        const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ out,
                                                        const S *__restrict__ in, int64_t n_scalars, int direct,
-                                                       int64_t s_begin, int64_t s_end, int64_t row0, int64_t row1, int accumulate)
+                                                       int64_t s_begin, int64_t s_end, int64_t row0, int64_t row1, int accumulate,
+                                                       int64_t rows_per_part, S *__restrict__ part_out, int64_t part_stride)
 {
     // rows [row0, row1) of the operator; accumulate != 0 continues the ordered sum from what `out` holds (a long operator
     // can be walked in several launches with the bits of one: ((0 + p_0) + p_1) + ... is the same sequence)
     // the launch covers the scalar range [s_begin, s_end) of the domain vector (the whole vector, or one chunk
     // when the multi-GPU exchange is pipelined chunk by chunk against this kernel)
+    // rows_per_part > 0: split-row walk (many rows of small blocks, where one workgroup per element tile would leave the
+    // chip idle): workgroup row blockIdx.y sums its own rows in order into slab blockIdx.y of `part_out`; k_fold_parts
+    // adds the slabs in part order afterwards (deterministic; not the bits of the single ordered sum)
     typedef typename vec_of<S, NS>::type V;
+    if (rows_per_part > 0) {
+        row0 += (int64_t)blockIdx.y * rows_per_part;
+        if (row0 + rows_per_part < row1) row1 = row0 + rows_per_part;
+        out = part_out + (int64_t)blockIdx.y * part_stride - s_begin;
+        accumulate = 0;
+    }
     const int64_t s0 = s_begin + ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
     bool ok[U];
     V acc[U], mv[U];
@@ -324,12 +334,21 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
                                                           const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ u,
                                                           const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, int direct,
                                                           S alpha, S beta, double *__restrict__ partials, int64_t s_begin, int64_t s_end,
-                                                          int64_t row0, int64_t row1, int accumulate)
+                                                          int64_t row0, int64_t row1, int accumulate, int64_t rows_per_part,
+                                                          S *__restrict__ part_out, int64_t part_stride)
 {
     // rows [row0, row1); accumulate != 0 continues w's ordered sum from what it holds (several launches, the bits of one)
     // the launch covers the scalar range [s_begin, s_end) of the domain (the whole vector, or one chunk when a multi-GPU
     // host pipelines the exchange of w chunk by chunk against this kernel)
+    // rows_per_part > 0: split-row walk, as in k_tall_diag_adj (u is updated row by row either way: same bits; w's sum is
+    // formed per part and folded by k_fold_parts)
     typedef typename vec_of<S, NS>::type V;
+    if (rows_per_part > 0) {
+        row0 += (int64_t)blockIdx.y * rows_per_part;
+        if (row0 + rows_per_part < row1) row1 = row0 + rows_per_part;
+        w = part_out + (int64_t)blockIdx.y * part_stride - s_begin;
+        accumulate = 0;
+    }
     const int64_t s0 = s_begin + ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
     bool ok[U];
     int64_t sk[U];
@@ -388,7 +407,47 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
 #pragma unroll
     for (int k = 0; k < U; k++)
         if (ok[k]) st<false>(reinterpret_cast<V *>(w + sk[k]), acc[k]);
-    wg_sum_store<BLK>(nrm, partials + blockIdx.x);
+    wg_sum_store<BLK>(nrm, partials + blockIdx.x + (size_t)blockIdx.y * gridDim.x);
+}
+
+// out[s] = sum over parts p = 0..nparts-1 (in that order within a part lane, part lanes in order) of parts[p][s - s_begin]:
+// the second stage of the split-row walk.  64 vector lanes x 16 part lanes per workgroup; fp64 accumulation (exact
+// conversions of S, so the fold adds no rounding of its own until the final cast); fixed order => deterministic.
+template <typename S, int NS>
+__global__ __launch_bounds__(1024) void k_fold_parts(const S *__restrict__ parts, int64_t part_stride, int nparts, S *__restrict__ out,
+                                                     int64_t s_begin, int64_t s_end)
+{
+    typedef typename vec_of<S, NS>::type V;
+    __shared__ double sm[16][NS][64];
+    const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t s = s_begin + ((int64_t)blockIdx.x * 64 + v) * NS;
+    const bool ok = s < s_end;
+    double acc[NS];
+#pragma unroll
+    for (int e = 0; e < NS; e++) acc[e] = 0.0;
+    if (ok) {
+        const S *src = parts + (s - s_begin);
+#pragma unroll 4
+        for (int p = q; p < nparts; p += 16) {
+            const V x = ld<false>(reinterpret_cast<const V *>(src + (int64_t)p * part_stride));
+#pragma unroll
+            for (int e = 0; e < NS; e++) acc[e] += (double)x[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NS; e++) sm[q][e][v] = acc[e];
+    __syncthreads();
+    if (q == 0 && ok) {
+        V r;
+#pragma unroll
+        for (int e = 0; e < NS; e++) {
+            double t = acc[e];
+#pragma unroll
+            for (int qq = 1; qq < 16; qq++) t += sm[qq][e][v];
+            r[e] = (S)t;
+        }
+        st<false>(reinterpret_cast<V *>(out + s), r);
+    }
 }
 
 // fold the per-workgroup partials deterministically: workgroup b sums the contiguous chunk
@@ -842,6 +901,40 @@ TallShape pick_adj_shape(int64_t nvec, int64_t nrow, int mode)
     return s;
 }
 
+// Split-row walk of the adjoint-shaped kernels.  The ordered walk gives one thread a 16-byte vector of the DOMAIN and
+// all rows: with n elements per block that is n/4 threads, so a tall operator of many SMALL blocks (seismic traces
+// rather than volumes) leaves most of the chip idle -- 1 GiB of 4096-element Float32 rows: 10.7 ms, 200 GB/s
+// (profiles/exp_r01_small_blocks.txt).  When the ordered walk would launch fewer workgroups than the chip has CUs, the
+// rows are cut into `parts` contiguous ranges, workgroup row y sums range y in order into its own slab, and k_fold_parts
+// adds the slabs in a fixed order.  Deterministic, but not the bits of the single ordered sum (tolerance parity, like the
+// multi-GPU sum).  Knob adj_split: -1 automatic, 0 never (always the ordered, bit-exact walk), k > 1 that many parts.
+int64_t pick_adj_parts(int64_t gx, int64_t nrow)
+{
+    jh_context &c = jh_ctx();
+    if (c.adj_split == 0 || nrow < 4) return 1;
+    int64_t parts;
+    if (c.adj_split > 0) parts = c.adj_split;
+    else {
+        if (gx >= c.cu_count || nrow < 256) return 1;                     // small operators keep the ordered, bit-exact walk
+        parts = (8 * (int64_t)c.cu_count + gx - 1) / gx;                 // ~8 workgroups per CU
+        if (parts > nrow / 16) parts = nrow / 16;                       // at least 16 rows per part
+    }
+    if (parts > nrow / 2) parts = nrow / 2;
+    if (parts > 65535) parts = 65535;                                    // gridDim.y
+    return parts < 2 ? 1 : parts;
+}
+
+template <typename S, int NS>
+int launch_fold_parts(const void *parts, int64_t part_stride, int64_t nparts, void *out, int64_t s_begin, int64_t s_end)
+{
+    jh_context &c = jh_ctx();
+    const int64_t gx = ((s_end - s_begin) / NS + 63) / 64;
+    hipLaunchKernelGGL((k_fold_parts<S, NS>), dim3((unsigned)gx), dim3(1024), 0, c.stream, (const S *)parts, part_stride, (int)nparts,
+                       (S *)out, s_begin, s_end);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
 template <typename S, int E, int NS, bool NT, int BLK>
 int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_scalars, const TallShape &sh)
 {
@@ -893,16 +986,32 @@ int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n
     if (c.adj_rows_per_launch > 0) rows_per_launch = c.adj_rows_per_launch < op->nrow ? c.adj_rows_per_launch : op->nrow;
     else if (op->nrow >= 768 && (double)op->nrow * (double)n_scalars * sizeof(S) >= 48.0 * (double)(1ull << 30)) rows_per_launch = 512;
     c.last_adj_launches = (op->nrow + rows_per_launch - 1) / rows_per_launch;
+    // many rows of small blocks: split-row walk (pick_adj_parts) -- one launch over (tiles, parts), then the fold
+    const int64_t gx0 = (s_end - s_begin + (int64_t)sh.unroll * BLK * NS - 1) / ((int64_t)sh.unroll * BLK * NS);
+    int64_t parts = direct ? 1 : pick_adj_parts(gx0, op->nrow);
+    int64_t rows_per_part = 0;
+    const int64_t part_stride = s_end - s_begin;
+    void *slabs = nullptr;
+    if (parts > 1) {
+        rows_per_part = (op->nrow + parts - 1) / parts;
+        parts = (op->nrow + rows_per_part - 1) / rows_per_part;                // no empty part
+        JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)part_stride * sizeof(S), &slabs));
+        rows_per_launch = op->nrow;
+        c.last_adj_launches = 1;
+    }
+    c.last_adj_parts = parts;
 #define JH_ADJ_CASE(U, DEPTH)                                                                                          \
     if (sh.unroll == U && sh.aux == DEPTH) {                                                                           \
         int64_t gx = (s_end - s_begin + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                          \
         for (int64_t r0 = 0; r0 < op->nrow; r0 += rows_per_launch) {                                                   \
             const int64_t r1 = r0 + rows_per_launch < op->nrow ? r0 + rows_per_launch : op->nrow;                        \
-            hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, NT, MODE, BLK>), dim3((unsigned)gx), dim3(BLK), 0, \
+            hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, NT, MODE, BLK>), dim3((unsigned)gx, (unsigned)parts), \
+                               dim3(BLK), 0,                                                                           \
                                c.stream, op->dev_blocks, op->nrow, a_base, a_stride, (S *)out, (const S *)in, n_scalars,   \
-                               direct, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0);                                            \
+                               direct, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0, rows_per_part, (S *)slabs, part_stride);    \
             JH_CHECK_HIP(hipGetLastError());                                                                           \
         }                                                                                                              \
+        if (parts > 1) return launch_fold_parts<S, NS>(slabs, part_stride, parts, out, s_begin, s_end);                \
         return JH_OK;                                                                                                  \
     }
     JH_ADJ_CASE(1, 1) JH_ADJ_CASE(1, 2) JH_ADJ_CASE(1, 4) JH_ADJ_CASE(1, 8)
@@ -1215,23 +1324,38 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     if (c.adj_unroll) U = (int)c.adj_unroll;
     if (c.adj_depth) D = (int)c.adj_depth;
     const int64_t gx = ((s_end - s_begin) / NS + (int64_t)wg * U - 1) / ((int64_t)wg * U);
-    JH_TRY(jh_ensure_partials(gx));
+    // many rows of small blocks: split-row walk (pick_adj_parts): u's rows are updated as before, w's sum is folded from slabs
+    int64_t parts = direct ? 1 : pick_adj_parts(gx, op->nrow);
+    int64_t rows_per_part = 0;
+    const int64_t part_stride = s_end - s_begin;
+    void *slabs = nullptr;
+    if (parts > 1) {
+        rows_per_part = (op->nrow + parts - 1) / parts;
+        parts = (op->nrow + rows_per_part - 1) / rows_per_part;
+        JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)part_stride * sizeof(S), &slabs));
+    }
+    c.last_adj_parts = parts;
+    JH_TRY(jh_ensure_partials(gx * parts));
     // the knob adj_rows_per_launch splits this walk too (w's ordered sum continues; ||u||^2 adds up), but unlike the plain
     // adjoint it does not pay here: 37.0 ms in two launches of 512 rows vs 34.2 ms in one at 1024 x 256^3 (each launch ends
     // with the read-back of its share of ||u||^2), so one launch is the default
     int64_t rows_per_launch = op->nrow;
     if (c.adj_rows_per_launch > 0) rows_per_launch = c.adj_rows_per_launch < op->nrow ? c.adj_rows_per_launch : op->nrow;
+    if (parts > 1) rows_per_launch = op->nrow;
 #define JH_LAUNCH(BLK, UU, DD)                                                                                          \
     if (wg == BLK && U == UU && D == DD) {                                                                              \
         double total = 0.0;                                                                                              \
         for (int64_t r0 = 0; r0 < op->nrow; r0 += rows_per_launch) {                                                     \
             const int64_t r1 = r0 + rows_per_launch < op->nrow ? r0 + rows_per_launch : op->nrow;                          \
-            hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK>), dim3((unsigned)gx), dim3(BLK), 0, c.stream,  \
+            hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, \
+                               c.stream,                                                                                 \
                                op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars,      \
-                               direct, (S)alpha, (S)beta, c.part_dev, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0);              \
+                               direct, (S)alpha, (S)beta, c.part_dev, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0,              \
+                               rows_per_part, (S *)slabs, part_stride);                                                  \
             JH_CHECK_HIP(hipGetLastError());                                                                             \
+            if (parts > 1) JH_TRY((launch_fold_parts<S, NS>(slabs, part_stride, parts, w, s_begin, s_end)));              \
             double part = 0.0;                                                                                           \
-            JH_TRY(finish_normsq(gx, normsq ? &part : nullptr));                                                         \
+            JH_TRY(finish_normsq(gx * parts, normsq ? &part : nullptr));                                                 \
             total += part;                                                                                               \
         }                                                                                                                \
         if (normsq) *normsq = total;                                                                                     \

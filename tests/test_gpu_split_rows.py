@@ -1,0 +1,183 @@
+"""GPU parity: the split-row walk of the adjoint-shaped kernels (tall operators with MANY rows of SMALL blocks).
+
+The ordered walk (one thread per 16-byte vector of the domain, all rows in sequence: the reference's loop,
+src/Jets.jl:1045-1053, bit for bit) leaves the chip idle when a block has few elements; from 256 rows on, when it would
+launch fewer workgroups than the chip has CUs, the library cuts the rows into contiguous parts, sums each part in order
+and folds the parts in a fixed order with fp64 accumulation (jh_blockop.hip: pick_adj_parts, k_fold_parts).
+
+Bar (stated): the split sum is DETERMINISTIC (same bits run to run) and within rel-l2 1e-6 (Float32 / ComplexF32) or
+1e-14 (Float64 / ComplexF64) of the fp64 / exact-order-free truth -- tighter than the ordered Float32 sum itself, whose
+rounding error grows with the row count; `tune(adj_split=0)` restores the ordered walk, BIT-EXACT against the oracle.
+Everything that does not involve the cross-row sum stays bit-exact: the rows of u in the one-pass Golub-Kahan step.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from .helpers import DTYPES, SEED_A, SEED_D, SEED_M, assert_bits_equal, u01
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b) -> float:                      # helpers.rel_err works in complex128; the truth here is wider
+    a, b = np.asarray(a, dtype=np.clongdouble).ravel(), np.asarray(b, dtype=np.clongdouble).ravel()
+    return float(np.linalg.norm(np.abs(a - b).astype(np.longdouble)) / np.linalg.norm(np.abs(b).astype(np.longdouble)))
+
+
+def _tol(dt):
+    return 1e-6 if np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-14
+
+
+def _slab_operator(Jets, oracle, dt, nrow, n, table=False):
+    """nrow x 1 operator of diagonal blocks of n elements; coefficients in ONE slab (addressed by stride) or, with
+    table=True, in separately allocated arrays (addressed through the device block table)."""
+    spc = Jets.JetSpace(dt, n)
+    if table:
+        diags = [Jets.rand(spc, seed=SEED_A, stream=0, index_base=i * n) for i in range(nrow)]
+    else:
+        diags = Jets.rand(Jets.JetBSpace([spc] * nrow), seed=SEED_A, stream=0).arrays
+    A = Jets.blockop([[Jets.JopDiagonal(g)] for g in diags])
+    ha = u01(oracle, dt, SEED_A, 0, nrow * n).reshape(nrow, n)
+    return A, ha, diags
+
+
+def _native(Jets, A):
+    from jets_jl_amd.jetblock import _tall_native
+
+    return _tall_native(A)
+
+
+@pytest.fixture()
+def knob(Jets):
+    saved = Jets.tune_get("adj_split")
+    yield lambda v: Jets.tune(adj_split=v)
+    Jets.tune(adj_split=saved)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,n,table", [(300, 1024, False), (1000, 520, False), (4096, 64, False), (257, 4096, True), (2049, 16, False)])
+def test_split_adjoint_is_deterministic_and_accurate(Jets, oracle, knob, dt, nrow, n, table):
+    A, ha, _keep = _slab_operator(Jets, oracle, dt, nrow, n, table)
+    d = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    hd = u01(oracle, dt, SEED_D, 0, nrow * n).reshape(nrow, n)
+    wide = np.clongdouble if np.iscomplexobj(ha) else np.longdouble   # 64-bit mantissa on x86: a truth the Float64 sums can be measured against
+    truth = np.sum(np.conj(ha.astype(wide)) * hd.astype(wide), axis=0)           # sum_i conj(a_i) .* d_i  (1045-1053), exact order-free
+    knob(-1)
+    mt = Jets.rand(Jets.domain(A), seed=99, stream=99)                            # dirty output: must be overwritten
+    Jets.mul_(mt, A.H, d)
+    assert Jets.tune_get("last_adj_parts") > 1, "the automatic policy should split this shape"
+    got = mt.to_numpy().ravel(order="F")
+    assert got.dtype == np.dtype(dt)
+    assert rel_err(got, truth) < _tol(dt)
+    again = Jets.zeros(Jets.domain(A))
+    Jets.mul_(again, A.H, d)
+    assert_bits_equal(again.to_numpy().ravel(order="F"), got, "split adjoint, second run")
+    # the ordered walk stays available and bit-exact
+    knob(0)
+    Jets.mul_(mt, A.H, d)
+    assert Jets.tune_get("last_adj_parts") == 1
+    ops = [[oracle.Block("diag", n, coeff=ha[i].copy())] for i in range(nrow)]
+    ref = oracle.block_df_adj(ops, [np.full(n, 7, dtype=dt)], [hd[i].copy() for i in range(nrow)])
+    assert_bits_equal(mt.to_numpy().ravel(order="F"), ref[0], "ordered adjoint (adj_split=0)")
+    assert rel_err(got, truth) <= 4 * rel_err(ref[0], truth) + _tol(dt) / 10       # never worse than the ordered sum
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_split_fused_normal_equals_split_chain(Jets, oracle, knob, dt):
+    """(A' o A) m, src/Jets.jl:530-534: the fused kernel and forward-then-adjoint cut the rows identically, so they agree
+    bit for bit in split mode as well; both within tolerance of the truth."""
+    nrow, n = 600, 2048
+    A, ha, _keep = _slab_operator(Jets, oracle, dt, nrow, n)
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=0)
+    hm = u01(oracle, dt, SEED_M, 0, n)
+    knob(-1)
+    y_fused = Jets.mul(A.H @ A, m)
+    assert Jets.tune_get("last_adj_parts") > 1
+    y_chain = A.H * (A * m)
+    assert_bits_equal(y_fused.to_numpy().ravel(order="F"), y_chain.to_numpy().ravel(order="F"), "fused vs chained, split rows")
+    wide = np.clongdouble if np.iscomplexobj(ha) else np.longdouble   # 64-bit mantissa on x86: a truth the Float64 sums can be measured against
+    truth = np.sum(np.abs(ha.astype(wide)) ** 2, axis=0) * hm.astype(wide)
+    assert rel_err(y_fused.to_numpy().ravel(order="F"), truth) < 4 * _tol(dt)     # d_i = a_i .* m is rounded to eltype first
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("beta", [-1.375, 0.0])
+def test_split_bidiag_step(Jets, oracle, knob, dt, beta):
+    """One-pass Golub-Kahan step on a many-row operator: u (row-wise) BIT-EXACT against the oracle's unfused chain,
+    w = A'u within tolerance of the fp64 sum over the oracle's u, ||u||^2 within 1e-6 / 1e-13."""
+    from jets_jl_amd._ffi import lib, check
+
+    nrow, n, alpha = 777, 1024, 0.75
+    A, ha, _keep = _slab_operator(Jets, oracle, dt, nrow, n)
+    v = Jets.rand(Jets.domain(A), seed=51, stream=0)
+    u = Jets.rand(Jets.range(A), seed=52, stream=0)
+    w = Jets.rand(Jets.domain(A), seed=53, stream=0)
+    hv, hu = u01(oracle, dt, 51, 0, n), u01(oracle, dt, 52, 0, nrow * n)
+    ops = [[oracle.Block("diag", n, coeff=ha[i].copy())] for i in range(nrow)]
+    tmp = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [hv])
+    hu_blocks = [hu[i * n:(i + 1) * n].copy() for i in range(nrow)]
+    if beta != 0.0:
+        ref_u = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [alpha, beta], [tmp, hu_blocks])
+    else:
+        ref_u = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [alpha], [tmp])
+    knob(-1)
+    out = C.c_double(0)
+    check(lib.jh_blockop_bidiag_step(_native(Jets, A).handle, u.handle, v.handle, w.handle, alpha, beta, C.byref(out)))
+    assert Jets.tune_get("last_adj_parts") > 1
+    assert_bits_equal(u.to_numpy(), np.concatenate(ref_u), "u <- alpha*A v + beta*u (split rows)")
+    wide = np.clongdouble if np.iscomplexobj(ha) else np.longdouble   # 64-bit mantissa on x86: a truth the Float64 sums can be measured against
+    truth_w = np.sum(np.conj(ha.astype(wide)) * np.stack(ref_u).astype(wide), axis=0)
+    assert rel_err(w.to_numpy().ravel(order="F"), truth_w) < _tol(dt)
+    truth = float(np.sum(np.abs(np.concatenate(ref_u).astype(np.complex128)) ** 2))
+    assert out.value == pytest.approx(truth, rel=1e-6 if _tol(dt) > 1e-10 else 1e-13)
+    # same rows through the plain adjoint: the two kernels cut the rows alike here (same tiling for small blocks)
+    w2 = Jets.zeros(Jets.domain(A))
+    Jets.mul_(w2, A.H, u)
+    assert rel_err(w2.to_numpy().ravel(order="F"), truth_w) < _tol(dt)
+
+
+def test_explicit_parts_and_ranges(Jets, oracle, knob):
+    """adj_split = k forces k parts on any operator (also below the automatic threshold); the ranged entry point of the
+    multi-GPU pipeline (jh_blockop_mul_adj_range) covers the vector piece by piece in split mode too."""
+    from jets_jl_amd._ffi import lib, check
+
+    dt, nrow, n = np.float32, 50, 32768
+    A, ha, _keep = _slab_operator(Jets, oracle, dt, nrow, n)
+    d = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    hd = u01(oracle, dt, SEED_D, 0, nrow * n).reshape(nrow, n)
+    truth = np.sum(ha.astype(np.float64) * hd.astype(np.float64), axis=0)   # Float32 data: fp64 is wide enough
+    knob(-1)
+    mt = Jets.zeros(Jets.domain(A))
+    Jets.mul_(mt, A.H, d)
+    assert Jets.tune_get("last_adj_parts") == 1                                   # 50 rows: ordered by default
+    for k in (2, 7, 25, 1000):
+        knob(k)
+        Jets.mul_(mt, A.H, d)
+        assert Jets.tune_get("last_adj_parts") == {2: 2, 7: 7, 25: 25, 1000: 25}[k]  # capped at two rows per part
+        assert rel_err(mt.to_numpy(), truth) < 1e-6
+    knob(7)
+    pieces = Jets.rand(Jets.domain(A), seed=82, stream=0)
+    nat = _native(Jets, A)
+    for lo, cnt in ((0, 16384), (16384, 8192), (24576, 4), (24580, n - 24580)):
+        check(lib.jh_blockop_mul_adj_range(nat.handle, pieces.handle, d.handle, lo, cnt))
+    assert rel_err(pieces.to_numpy(), truth) < 1e-6
+    with pytest.raises(Jets.JetsHipError):
+        Jets.tune(adj_split=-2)
+
+
+def test_dot_product_test_and_lsqr_on_many_small_rows(Jets, oracle, knob):
+    """src/Jets.jl:1211-1226 and the solver loop (docs/src/index.md:235-246) on 5000 rows of 256-element blocks."""
+    dt, nrow, n = np.float32, 5000, 256
+    A, ha, _keep = _slab_operator(Jets, oracle, dt, nrow, n)
+    knob(-1)
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=1)
+    d = Jets.rand(Jets.range(A), seed=SEED_D, stream=1)
+    lhs, rhs = Jets.dot_product_test(A, m, d)
+    assert Jets.tune_get("last_adj_parts") > 1
+    assert abs(lhs - rhs) / abs(lhs + rhs) < 1e-5
+    x_true = Jets.rand(Jets.domain(A), seed=4, stream=0)
+    b = A * x_true
+    res = Jets.lsqr(A, b, atol=0.0, btol=0.0, conlim=0.0, maxiter=30, force_maxiter=True)
+    err = (res.x - x_true).materialize()
+    assert float(Jets.norm(err)) / float(Jets.norm(x_true)) < 1e-5
