@@ -1,94 +1,214 @@
 # JetsHIP.jl -- Julia binding of libjetship.so (include/jetship.h) for Jets.jl.
 #
-# STATUS: WRITTEN, NOT EXECUTED.  This image has no Julia toolchain, so this file has never been
-# parsed or run; it documents, in the reference's own language, the `ccall` stubs a Jets.jl
-# maintainer adds to put JopBlock mul! on an MI355X.  The same ABI is exercised end to end by the
-# Python binding (jets.jl_amd/_ffi.py) and the GPU test-suite.
+# STATUS: WRITTEN, NOT EXECUTED.  This image has no Julia toolchain, so this file has never been parsed or run.  What is
+# checked mechanically: every `ccall` below against the prototypes of include/jetship.h (symbol, arity, argument classes,
+# struct layouts -- tests/test_julia_binding_static.py).  The same ABI is exercised end to end by the Python binding
+# (jets.jl_amd/_ffi.py) and the GPU test-suite.
 #
-# Everything is additive: new array types (`HipArray`, `HipBlockArray`) plus methods of existing
-# Jets.jl generics that dispatch on them.  No reference source is modified.
+# How it drops in.  Jets.jl allocates every vector through its SPACES (`zeros(range(A))` in `A*m`, src/Jets.jl:399; the
+# temporaries of JetComposite / JetSum / JetBlock, 524-538, 639-655, 990-1043), so device storage enters through a space:
+#
+#     R = HipSpace(Float32, 256, 256, 256)          # instead of JetSpace(Float32, 256, 256, 256)
+#     A = @blockop [JopHipDiagonal(rand(R)) for i = 1:1024, j = 1:1]
+#     m = rand(domain(A)); d = A*m; mt = A'*d; x = lsqr(vec(A), vec(d))       # unchanged user code
+#
+# `zeros/ones/rand/randn/Array(::HipSpace)` return `HipArray`s (HIP device memory); the same factories on a
+# `JetBSpace` of HipSpaces return the reference's own `BlockArray` (src/Jets.jl:809-812) whose blocks are consecutive VIEWS
+# OF ONE HBM SLAB laid out like `JetBSpace.indices` (742-748).  Everything the reference does with a BlockArray keeps
+# working (getblock by reference, space(x), broadcasting machinery), and the more specific methods below replace the
+# per-block loops by ONE `ccall` on the slab: norm/dot/extrema/fill!/convert/broadcast, and -- the hot path --
+# JetBlock_f!/df!/df′! (988-1057), the fused A'∘A (530-534) and the LSQR loop.
+#
+# Everything is additive: new types (`HipSpace`, `HipArray`) plus methods of existing generics.  No reference source is modified.
 module JetsHIP
 
 using Jets, LinearAlgebra
-import Jets: JetBSpace, JetSpace, JetAbstractSpace, Jop, JopLn, JopAdjoint, Jet, jet, state, domain,
-             getblock, getblock!, setblock!, indices, nblocks, space, JopZeroBlock_df!, JetBlock_df!, JetBlock_df′!
+import Jets: JetAbstractSpace, JetBSpace, JetSpace, BlockArray, BlockArrayStyle, Jop, JopLn, JopNl, JopAdjoint, Jet, jet, state,
+             domain, getblock, getblock!, setblock!, indices, nblocks, space, point!, JopZeroBlock_df!, JetBlock_f!,
+             JetBlock_df!, JetBlock_df′!, JetComposite_df!, _constdiag_df!
+
+export HipSpace, HipArray, JopHipDiagonal, JopHipSquare, JopHipDense, hip_lsqr!
 
 const LIB = get(ENV, "JETSHIP_LIB", "libjetship.so")
 
 # ---------------------------------------------------------------- errors (src/Jets.jl:131,179,1116: plain error(...))
 check(status::Cint) = status == 0 ? nothing : error("libjetship: " * unsafe_string(ccall((:jh_last_error, LIB), Cstring, ())))
 
-init(device::Integer=0) = check(ccall((:jh_init, LIB), Cint, (Cint,), device))
+const _inited = Ref(false)
+init(device::Integer=0) = (check(ccall((:jh_init, LIB), Cint, (Cint,), device)); _inited[] = true; nothing)
+_ensure_init() = _inited[] || init(parse(Int, get(ENV, "JETSHIP_DEVICE", "0")))      # the first allocation picks the device
 synchronize() = check(ccall((:jh_synchronize, LIB), Cint, ()))
+tune!(name::AbstractString, value::Integer) = check(ccall((:jh_tune_set, LIB), Cint, (Cstring, Int64), name, value))   # e.g. tune!("adj_split", 0)
 
+const HipEltype = Union{Float32,Float64,ComplexF32,ComplexF64}
 dtype_code(::Type{Float32}) = Cint(0)
 dtype_code(::Type{Float64}) = Cint(1)
 dtype_code(::Type{ComplexF32}) = Cint(2)
 dtype_code(::Type{ComplexF64}) = Cint(3)
 
-# ---------------------------------------------------------------- device vectors
-# One HBM slab; block i at element offset R.indices[i][1]-1 (src/Jets.jl:742-748).
-mutable struct HipBlockArray{T} <: AbstractArray{T,1}
+# ---------------------------------------------------------------- device storage
+# Slab: the owner of one `jh_bvec*` -- a whole block vector (nblocks blocks in ONE hipMalloc), a stand-alone array (one
+# block), or a view / wrap borrowing another slab's memory (`keep` holds what it borrows from: destroying a parent
+# invalidates its views, include/jetship.h).
+mutable struct Slab
     handle::Ptr{Cvoid}
-    spaces::Vector{<:JetAbstractSpace}
-    indices::Vector{UnitRange{Int}}
-    parent::Any                       # keeps the owner alive for views
-    function HipBlockArray{T}(handle, spaces, indices, parent=nothing) where {T}
-        x = new{T}(handle, spaces, indices, parent)
-        finalizer(x -> ccall((:jh_bvec_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), x)
-        x
+    nblocks::Int
+    keep::Any
+    function Slab(handle::Ptr{Cvoid}, nblocks::Integer, keep=nothing)
+        s = new(handle, nblocks, keep)
+        finalizer(s -> ccall((:jh_bvec_destroy, LIB), Cint, (Ptr{Cvoid},), s.handle), s)
+        s
     end
 end
 
-# a plain N-d array is a one-block slab (domain of a one-column block operator, src/Jets.jl:927)
-mutable struct HipArray{T,N} <: AbstractArray{T,N}
-    handle::Ptr{Cvoid}
-    dims::NTuple{N,Int}
-    parent::Any
-    function HipArray{T,N}(handle, dims, parent=nothing) where {T,N}
-        x = new{T,N}(handle, dims, parent)
-        finalizer(x -> ccall((:jh_bvec_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), x)
-        x
-    end
-end
-
-Base.size(x::HipBlockArray) = (x.indices[end][end],)                      # src/Jets.jl:818
-Base.size(x::HipArray) = x.dims
-Jets.nblocks(x::HipBlockArray) = length(x.indices)                       # :860
-Jets.indices(x::HipBlockArray, i) = x.indices[i]                         # :858
-Jets.space(x::HipBlockArray) = JetBSpace(x.spaces)                       # :814
-
-function _create(lens::Vector{Int}, ::Type{T}) where {T}
+function _create(lens::Vector{Int64}, ::Type{T}) where {T}
+    _ensure_init()
     h = Ref{Ptr{Cvoid}}()
     check(ccall((:jh_bvec_create, LIB), Cint, (Int64, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}), length(lens), lens, dtype_code(T), h))
-    h[]
+    Slab(h[], length(lens))
 end
 
-# zeros(R) / Array(R) on the device (src/Jets.jl:105-108, 922-924); device storage is always zero-filled
-hipzeros(R::JetBSpace{T}) where {T} = HipBlockArray{T}(_create([length(R.indices[i]) for i = 1:length(R.indices)], T), R.spaces, R.indices)
-hipzeros(R::JetSpace{T,N}) where {T,N} = HipArray{T,N}(_create([length(R)], T), size(R))
-hiprand(R::JetAbstractSpace; seed=1, stream=0) = (x = hipzeros(R); check(ccall((:jh_fill_uniform, LIB), Cint, (Ptr{Cvoid}, UInt64, UInt64, Int64), x.handle, seed, stream, 0)); x)
-
-# getblock(x, i): by reference (src/Jets.jl:914) -- 1-based i -> 0-based block
-function Jets.getblock(x::HipBlockArray{T}, iblock) where {T}
+function _view(parent::Slab, iblock::Integer)                      # block `iblock` (1-based) of a slab, by reference
     h = Ref{Ptr{Cvoid}}()
-    check(ccall((:jh_bvec_view, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), x.handle, iblock - 1, 1, h))
-    HipArray{T,ndims(x.spaces[iblock])}(h[], size(x.spaces[iblock]), x)
+    check(ccall((:jh_bvec_view, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), parent.handle, iblock - 1, 1, h))
+    Slab(h[], 1, parent)
 end
-Jets.getblock(x::HipArray, iblock) = x                                    # :918
-# getblock!(x, i, xblock) (:915) and setblock!(x, i, v) (:916) for host arrays and scalars
-Jets.getblock!(x::HipBlockArray, iblock, out::Array) = (check(ccall((:jh_getblock_copy, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Cint), x.handle, iblock - 1, out, 0)); out)
-Jets.setblock!(x::HipBlockArray, iblock, v::Array) = check(ccall((:jh_setblock_copy, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Cint), x.handle, iblock - 1, v, 0))
-Jets.setblock!(x::HipBlockArray, iblock, a::Number) = check(ccall((:jh_setblock_fill, LIB), Cint, (Ptr{Cvoid}, Int64, Cdouble, Cdouble), x.handle, iblock - 1, real(a), imag(a)))
 
-# convert(Array, x) (:862-868)
-function Base.convert(::Type{Array}, x::Union{HipBlockArray{T},HipArray{T}}) where {T}
+function _device_ptr(s::Slab)
+    p = Ref{Ptr{Cvoid}}()
+    check(ccall((:jh_bvec_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Cint}, Ref{Ptr{Cvoid}}), s.handle, C_NULL, C_NULL, C_NULL, p))
+    p[]
+end
+
+# A dense column-major N-d array in HBM: a one-block jh_bvec.  `owner`/`iblock` say which block of which multi-block
+# slab it is a view of (nothing / 0 for a stand-alone array): a BlockArray whose arrays are blocks 1..n of one owner is
+# addressed as a whole through the owner's handle.
+struct HipArray{T,N} <: AbstractArray{T,N}
+    slab::Slab
+    dims::NTuple{N,Int}
+    owner::Union{Nothing,Slab}
+    iblock::Int
+end
+HipArray{T,N}(slab::Slab, dims::NTuple{N,Int}) where {T,N} = HipArray{T,N}(slab, dims, nothing, 0)
+handle(x::HipArray) = x.slab.handle
+
+const DevBlockArray{T} = BlockArray{T,<:HipArray{T}}
+const DevVec{T} = Union{HipArray{T},BlockArray{T,<:HipArray{T}}}
+
+# the slab a device BlockArray lives in, or nothing when it was assembled from unrelated arrays (then the reference's
+# per-block methods run, each block being a device array of its own)
+function whole(x::BlockArray{T,<:HipArray{T}}) where {T}
+    o = x.arrays[1].owner
+    (o === nothing || o.nblocks != length(x.arrays)) && return nothing
+    for i in eachindex(x.arrays)
+        (x.arrays[i].owner === o && x.arrays[i].iblock == i) || return nothing
+    end
+    o
+end
+handle(x::BlockArray{T,<:HipArray{T}}) where {T} = (o = whole(x); o === nothing ? C_NULL : o.handle)
+
+# ---------------------------------------------------------------- device spaces
+# JetSpace (src/Jets.jl:40-68) whose factories (105-108) allocate in HBM.
+struct HipSpace{T,N} <: JetAbstractSpace{T,N}
+    n::NTuple{N,Int}
+end
+HipSpace(::Type{T}, n::Vararg{Int,N}) where {T<:HipEltype,N} = HipSpace{T,N}(n)
+HipSpace(::Type{T}, n::NTuple{N,Int}) where {T<:HipEltype,N} = HipSpace{T,N}(n)
+Base.size(R::HipSpace) = R.n
+Base.eltype(::Type{HipSpace{T,N}}) where {T,N} = T
+Base.eltype(::Type{HipSpace{T}}) where {T} = T
+Base.vec(R::HipSpace) = HipSpace(eltype(R), length(R))
+Base.similar(R::HipSpace{T,N}, dims::NTuple{N,Int}) where {T,N} = HipSpace(T, dims)
+Base.similar(R::HipSpace, dims::Int...) = similar(R, dims)
+Jets.space(x::HipArray{T,N}) where {T,N} = HipSpace{T,N}(size(x))                      # src/Jets.jl:126
+
+const _draws = Ref{UInt64}(0)                                                           # one counter-RNG stream per rand()/randn() call
+_next_stream() = (_draws[] += 1; _draws[])
+_fill_uniform!(s::Slab, seed, stream) = check(ccall((:jh_fill_uniform, LIB), Cint, (Ptr{Cvoid}, UInt64, UInt64, Int64), s.handle, seed, stream, 0))
+_fill_normal!(s::Slab, seed, stream) = check(ccall((:jh_fill_normal, LIB), Cint, (Ptr{Cvoid}, UInt64, UInt64, Int64), s.handle, seed, stream, 0))
+_fill!(s::Slab, a) = check(ccall((:jh_fill, LIB), Cint, (Ptr{Cvoid}, Cdouble, Cdouble), s.handle, real(a), imag(a)))
+
+Base.zeros(R::HipSpace{T,N}) where {T,N} = HipArray{T,N}(_create(Int64[length(R)], T), size(R))   # device storage is created zero-filled
+Base.Array(R::HipSpace) = zeros(R)
+Base.ones(R::HipSpace{T}) where {T} = (x = zeros(R); _fill!(x.slab, one(T)); x)
+Base.rand(R::HipSpace; seed=1) = (x = zeros(R); _fill_uniform!(x.slab, seed, _next_stream()); x)
+Base.randn(R::HipSpace; seed=1) = (x = zeros(R); _fill_normal!(x.slab, seed, _next_stream()); x)
+
+# Array/zeros/ones/rand/randn(R::JetBSpace) (src/Jets.jl:922-924) for block spaces of device spaces: ONE slab, block i at
+# element offset R.indices[i][1]-1, handed out as the reference's BlockArray of block views
+function _blockarray(R::JetBSpace{T,<:HipSpace}) where {T}
+    o = _create(Int64[length(R.indices[i]) for i = 1:length(R.indices)], T)
+    arrays = [HipArray{T,ndims(R.spaces[i])}(_view(o, i), size(R.spaces[i]), o, i) for i = 1:length(R.spaces)]
+    BlockArray(arrays, R.indices), o
+end
+Base.zeros(R::JetBSpace{T,S}) where {T,S<:HipSpace} = _blockarray(R)[1]
+Base.Array(R::JetBSpace{T,S}) where {T,S<:HipSpace} = _blockarray(R)[1]
+Base.ones(R::JetBSpace{T,S}) where {T,S<:HipSpace} = ((x, o) = _blockarray(R); _fill!(o, one(T)); x)
+Base.rand(R::JetBSpace{T,S}; seed=1) where {T,S<:HipSpace} = ((x, o) = _blockarray(R); _fill_uniform!(o, seed, _next_stream()); x)
+Base.randn(R::JetBSpace{T,S}; seed=1) where {T,S<:HipSpace} = ((x, o) = _blockarray(R); _fill_normal!(o, seed, _next_stream()); x)
+
+# ---------------------------------------------------------------- HipArray: array interface
+Base.size(x::HipArray) = x.dims
+Base.IndexStyle(::Type{<:HipArray}) = IndexLinear()
+# scalar indexing works (printing, generic fallbacks) but moves one element over PCIe per call: the slow path, like
+# BlockArray's own findfirst-based getindex (src/Jets.jl:820-827)
+function Base.getindex(x::HipArray{T}, i::Int) where {T}
+    out = Vector{T}(undef, 1)
+    check(ccall((:jh_download, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}), handle(x), i - 1, 1, out))
+    out[1]
+end
+function Base.setindex!(x::HipArray{T}, v, i::Int) where {T}
+    check(ccall((:jh_upload, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}), handle(x), i - 1, 1, T[convert(T, v)]))
+    v
+end
+Base.similar(x::HipArray{T,N}) where {T,N} = zeros(HipSpace{T,N}(size(x)))
+Base.similar(x::HipArray, ::Type{S}, dims::Dims{N}) where {S<:HipEltype,N} = zeros(HipSpace{S,N}(dims))
+Base.similar(x::HipArray, ::Type{S}, dims::Dims{N}) where {S,N} = Array{S,N}(undef, dims)        # Bool masks etc. stay on the host
+# similar(x::BlockArray[, T]) (src/Jets.jl:829-832) must not fall apart into n separate allocations: keep ONE slab
+Base.similar(x::BlockArray{S,<:HipArray{S}}, ::Type{T}) where {S,T<:HipEltype} = zeros(JetBSpace([HipSpace{T,ndims(a)}(size(a)) for a in x.arrays]))
+
+# reshape shares memory (src/Jets.jl:38): a second one-block view of the same elements
+function Base.reshape(x::HipArray{T}, dims::Dims{N}) where {T,N}
+    prod(dims) == length(x) || throw(DimensionMismatch("new dimensions $(dims) must be consistent with array size $(length(x))"))
+    HipArray{T,N}(_view(x.slab, 1), dims, nothing, 0)
+end
+# reshape(x, R::JetBSpace) (src/Jets.jl:1112): a flat device vector seen as a block vector, sharing memory
+function Base.reshape(x::HipArray{T,1}, R::JetBSpace{T,<:HipSpace}) where {T}
+    length(x) == length(R) || error("dimension mismatch, unable to reshape block array")
+    lens = Int64[length(R.indices[i]) for i = 1:length(R.indices)]
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:jh_bvec_wrap, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}), _device_ptr(x.slab), length(lens), lens, dtype_code(T), h))
+    o = Slab(h[], length(lens), x.slab)
+    BlockArray([HipArray{T,ndims(R.spaces[i])}(_view(o, i), size(R.spaces[i]), o, i) for i = 1:length(R.spaces)], R.indices)
+end
+
+# host <-> device copies: convert(Array, x) (src/Jets.jl:862-868), copyto! both ways
+function Base.copyto!(dst::Array{T}, src::HipArray{T}) where {T}
+    length(dst) == length(src) || throw(DimensionMismatch("copyto!: $(length(dst)) vs $(length(src)) elements"))
+    check(ccall((:jh_download, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}), handle(src), 0, length(src), dst))
+    dst
+end
+function Base.copyto!(dst::HipArray{T}, src::Array{T}) where {T}
+    length(dst) == length(src) || throw(DimensionMismatch("copyto!: $(length(dst)) vs $(length(src)) elements"))
+    check(ccall((:jh_upload, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}), handle(dst), 0, length(src), src))
+    dst
+end
+function Base.copyto!(dst::HipArray{T}, src::HipArray{T}) where {T}
+    check(ccall((:jh_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), handle(dst), handle(src)))
+    dst
+end
+Base.copy(x::HipArray) = copyto!(similar(x), x)
+Base.Array(x::HipArray{T,N}) where {T,N} = copyto!(Array{T,N}(undef, size(x)), x)
+HipArray(a::Array{T,N}) where {T<:HipEltype,N} = copyto!(zeros(HipSpace{T,N}(size(a))), a)
+function Base.convert(::Type{Array}, x::BlockArray{T,<:HipArray{T}}) where {T}
+    h = handle(x)
+    h == C_NULL && return invoke(convert, Tuple{Type{Array},BlockArray{T}}, Array, x)
     out = Vector{T}(undef, length(x))
-    check(ccall((:jh_download, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}), x.handle, 0, length(x), out))
-    x isa HipArray ? reshape(out, size(x)) : out
+    check(ccall((:jh_download, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}), h, 0, length(x), out))
+    out
 end
 
-# a page-locked host array (jh_host_alloc) for the copies above: no first-touch page faults under the DMA
+# a page-locked host array (jh_host_alloc) for those copies: no first-touch page faults under the DMA
 function pinned_array(::Type{T}, dims::Integer...) where {T}
     p = Ref{Ptr{Cvoid}}()
     check(ccall((:jh_host_alloc, LIB), Cint, (Csize_t, Ref{Ptr{Cvoid}}), prod(dims) * sizeof(T), p))
@@ -97,46 +217,93 @@ function pinned_array(::Type{T}, dims::Integer...) where {T}
     a
 end
 
-# fill!, norm, dot, extrema (:834-885)
-Base.fill!(x::Union{HipBlockArray,HipArray}, a) = (check(ccall((:jh_fill, LIB), Cint, (Ptr{Cvoid}, Cdouble, Cdouble), x.handle, real(a), imag(a))); x)
-function LinearAlgebra.norm(x::Union{HipBlockArray{T},HipArray{T}}, p::Real=2) where {T}
+# getblock!(x, i, xblock) / setblock!(x, i, xblock) (src/Jets.jl:915-916) with HOST arrays: one DMA, no elementwise fallback;
+# with device arrays: one device-to-device copy
+function Jets.getblock!(x::BlockArray{T,<:HipArray{T}}, iblock, xblock::Array{T}) where {T}
+    o = whole(x)
+    o === nothing && return copyto!(xblock, x.arrays[iblock])
+    length(xblock) == length(x.arrays[iblock]) || throw(DimensionMismatch("getblock!: block $(iblock) has $(length(x.arrays[iblock])) elements"))
+    check(ccall((:jh_getblock_copy, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Cint), o.handle, iblock - 1, xblock, 0))
+    xblock
+end
+function Jets.setblock!(x::BlockArray{T,<:HipArray{T}}, iblock, xblock::Array{T}) where {T}
+    o = whole(x)
+    o === nothing && return copyto!(x.arrays[iblock], xblock)
+    length(xblock) == length(x.arrays[iblock]) || throw(DimensionMismatch("setblock!: block $(iblock) has $(length(x.arrays[iblock])) elements"))
+    check(ccall((:jh_setblock_copy, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Cint), o.handle, iblock - 1, xblock, 0))
+    x.arrays[iblock]
+end
+Jets.getblock!(x::BlockArray{T,<:HipArray{T}}, iblock, xblock::HipArray{T}) where {T} = copyto!(xblock, x.arrays[iblock])
+Jets.setblock!(x::BlockArray{T,<:HipArray{T}}, iblock, xblock::HipArray{T}) where {T} = copyto!(x.arrays[iblock], xblock)
+Jets.setblock!(x::BlockArray{T,<:HipArray{T}}, iblock, a::Number) where {T} = fill!(x.arrays[iblock], a)          # test/runtests.jl:518-519
+
+# ---------------------------------------------------------------- fill!, norm, dot, extrema (src/Jets.jl:834-885): one pass over the slab
+Base.fill!(x::HipArray, a) = (_fill!(x.slab, a); x)
+function Base.fill!(x::BlockArray{T,<:HipArray{T}}, a) where {T}
+    o = whole(x)
+    o === nothing ? invoke(fill!, Tuple{BlockArray,Any}, x, a) : (_fill!(o, a); x)
+end
+function _norm(h::Ptr{Cvoid}, p::Real, ::Type{T}) where {T}
     out = Ref{Cdouble}()
-    check(ccall((:jh_norm, LIB), Cint, (Ptr{Cvoid}, Cdouble, Ref{Cdouble}), x.handle, p, out))
+    check(ccall((:jh_norm, LIB), Cint, (Ptr{Cvoid}, Cdouble, Ref{Cdouble}), h, p, out))
     float(real(T))(out[])
 end
-function LinearAlgebra.dot(x::Union{HipBlockArray{T},HipArray{T}}, y::Union{HipBlockArray{T},HipArray{T}}) where {T}
+LinearAlgebra.norm(x::HipArray{T}, p::Real=2) where {T} = _norm(handle(x), p, T)
+function LinearAlgebra.norm(x::BlockArray{T,<:HipArray{T}}, p::Real=2) where {T}
+    h = handle(x)
+    h == C_NULL ? invoke(norm, Tuple{BlockArray{T},Real}, x, p) : _norm(h, p, T)
+end
+function _dot(hx::Ptr{Cvoid}, hy::Ptr{Cvoid}, ::Type{T}) where {T}
     re, im = Ref{Cdouble}(), Ref{Cdouble}()
-    check(ccall((:jh_dot, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}), x.handle, y.handle, re, im))
+    check(ccall((:jh_dot, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}), hx, hy, re, im))
     T <: Complex ? T(re[], im[]) : T(re[])
 end
-function Base.extrema(x::Union{HipBlockArray{T},HipArray{T}}) where {T<:Real}
+LinearAlgebra.dot(x::HipArray{T}, y::HipArray{T}) where {T} = _dot(handle(x), handle(y), T)
+function LinearAlgebra.dot(x::BlockArray{T,<:HipArray{T}}, y::BlockArray{T,<:HipArray{T}}) where {T}
+    hx, hy = handle(x), handle(y)
+    (hx == C_NULL || hy == C_NULL) ? invoke(dot, Tuple{BlockArray{T},BlockArray{T}}, x, y) : _dot(hx, hy, T)
+end
+function _extrema(h::Ptr{Cvoid}, ::Type{T}) where {T}
     mn, mx = Ref{Cdouble}(), Ref{Cdouble}()
-    check(ccall((:jh_extrema, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}), x.handle, mn, mx))
+    check(ccall((:jh_extrema, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}), h, mn, mx))
     T(mn[]), T(mx[])
 end
-
-# y .= c1*x1 .+ c2*x2 .+ ...   (the BlockArrayStyle copyto!, :905-911, for linear combinations)
-function lincomb!(y, coefs::Vector{<:Number}, xs::Vector)
-    cf = Float64[]
-    for c in coefs
-        push!(cf, real(c), imag(c))
-    end
-    hs = Ptr{Cvoid}[x.handle for x in xs]
-    check(ccall((:jh_lincomb, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Ptr{Cvoid}}), y.handle, length(xs), cf, hs))
-    y
+Base.extrema(x::HipArray{T}) where {T<:Real} = _extrema(handle(x), T)
+function Base.extrema(x::BlockArray{T,<:HipArray{T}}) where {T<:Real}
+    h = handle(x)
+    h == C_NULL ? invoke(extrema, Tuple{BlockArray{T}}, x) : _extrema(h, T)
 end
 
 # ---------------------------------------------------------------- broadcast: any elementwise expression, one fused pass
 # copyto!(dest::BlockArray, bc::Broadcasted{BlockArrayStyle}) (src/Jets.jl:899-911) for device vectors: print the
 # Broadcasted tree as a C expression over x0.. (vector leaves) and s0.. (scalar leaves), let libjetship compile it once
 # with hiprtc (jh_bcast_compile) and stream the slabs in ONE kernel.  `a*u .+ b*v .+ c*w`, `exp.(-u.^2) .* v`, ...
+struct HipStyle{N} <: Broadcast.AbstractArrayStyle{N} end
+HipStyle(::Val{N}) where {N} = HipStyle{N}()
+HipStyle{M}(::Val{N}) where {M,N} = HipStyle{N}()
+Base.BroadcastStyle(::Type{<:HipArray{T,N}}) where {T,N} = HipStyle{N}()
+Base.BroadcastStyle(a::BlockArrayStyle, ::HipStyle) = a                              # a flat device vector among block vectors (src/Jets.jl:902)
+_find_hip(bc::Broadcast.Broadcasted) = _find_hip(bc.args)
+_find_hip(args::Tuple) = _find_hip(_find_hip(args[1]), Base.tail(args))
+_find_hip(x) = x
+_find_hip(::Tuple{}) = nothing
+_find_hip(a::HipArray, rest) = a
+_find_hip(::Any, rest) = _find_hip(rest)
+Base.similar(bc::Broadcast.Broadcasted{HipStyle{N}}, ::Type{T}) where {N,T} = similar(_find_hip(bc), T, map(length, axes(bc)))
+
 const _cfun = Dict{Any,String}(+ => "+", - => "-", * => "*", / => "/", exp => "exp", log => "log", sqrt => "sqrt", sin => "sin",
                                cos => "cos", tanh => "tanh", abs => "abs", abs2 => "abs2", conj => "conj", real => "real",
                                imag => "imag", sign => "sign", max => "fmax", min => "fmin")
-_emit(x::Union{HipBlockArray,HipArray}, vecs, scals) = (i = findfirst(v -> v === x, vecs); i === nothing && (push!(vecs, x); i = length(vecs)); "x$(i-1)")
+function _emit(x::DevVec, vecs, scals)
+    i = findfirst(v -> v === x, vecs)
+    i === nothing && (push!(vecs, x); i = length(vecs))
+    "x$(i-1)"
+end
 _emit(x::Number, vecs, scals) = (push!(scals, x); "s$(length(scals)-1)")
 _emit(x::Base.RefValue, vecs, scals) = _emit(x[], vecs, scals)
-function _emit(bc::Base.Broadcast.Broadcasted, vecs, scals)
+_emit(x, vecs, scals) = error("broadcast over device vectors: operand of type $(typeof(x)) is not supported (host arrays must be copied to the device first)")
+function _emit(bc::Broadcast.Broadcasted, vecs, scals)
+    bc.f === identity && return _emit(bc.args[1], vecs, scals)
     if bc.f === Base.literal_pow                                  # u.^p with a literal p: args = (Ref(^), u, Ref(Val(p)))
         p = typeof(bc.args[3][]).parameters[1]
         base = _emit(bc.args[2], vecs, scals)
@@ -148,9 +315,15 @@ function _emit(bc::Base.Broadcast.Broadcasted, vecs, scals)
     op in ("+", "-", "*", "/") ? (length(args) == 1 ? "($op$(args[1]))" : "(" * join(args, " $op ") * ")") : "$op(" * join(args, ", ") * ")"
 end
 const _bcast_programs = Dict{Tuple{String,DataType,Int,Int},Ptr{Cvoid}}()
-function Base.copyto!(dest::Union{HipBlockArray{T},HipArray{T}}, bc::Base.Broadcast.Broadcasted) where {T}
+function _bcast!(dest::DevVec{T}, bc::Broadcast.Broadcasted) where {T}
     vecs, scals = Any[], Number[]
-    expr = _emit(Base.Broadcast.flatten(bc), vecs, scals)
+    expr = _emit(bc, vecs, scals)
+    hs = Ptr{Cvoid}[handle(v) for v in vecs]
+    any(h -> h == C_NULL, hs) && error("broadcast over device block vectors that do not live in one slab")
+    if expr == "x0" && isempty(scals)                              # dest .= x
+        check(ccall((:jh_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), handle(dest), hs[1]))
+        return dest
+    end
     prog = get!(_bcast_programs, (expr, T, length(vecs), length(scals))) do
         h = Ref{Ptr{Cvoid}}()
         check(ccall((:jh_bcast_compile, LIB), Cint, (Cstring, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), expr, dtype_code(T), length(vecs), length(scals), h))
@@ -158,24 +331,40 @@ function Base.copyto!(dest::Union{HipBlockArray{T},HipArray{T}}, bc::Base.Broadc
     end
     sc = Cdouble[]
     foreach(a -> (push!(sc, real(a)); push!(sc, imag(a))), scals)
-    check(ccall((:jh_bcast_apply, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Cdouble}), prog, dest.handle, Ptr{Cvoid}[v.handle for v in vecs], sc))
+    check(ccall((:jh_bcast_apply, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Cdouble}), prog, handle(dest), hs, sc))
     dest
+end
+Base.copyto!(dest::HipArray{T}, bc::Broadcast.Broadcasted{<:HipStyle}) where {T} = _bcast!(dest, bc)
+function Base.copyto!(dest::BlockArray{T,<:HipArray{T,N}}, bc::Broadcast.Broadcasted{BlockArrayStyle}) where {T,N}
+    handle(dest) == C_NULL && return invoke(copyto!, Tuple{BlockArray{T,<:AbstractArray{T,N}},Broadcast.Broadcasted{BlockArrayStyle}}, dest, bc)
+    _bcast!(dest, bc)
 end
 
 # ---------------------------------------------------------------- device-native operator kinds
 # recognised by typeof(df!) exactly as iszero/isblockop do (src/Jets.jl:949, 1097)
-JopHipDiagonal_df!(d, m; diagonal, kwargs...) = (check(ccall((:jh_hadamard, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), d.handle, diagonal.handle, m.handle, 0)); d)
-JopHipDiagonal_df′!(m, d; diagonal, kwargs...) = (check(ccall((:jh_hadamard, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), m.handle, diagonal.handle, d.handle, 1)); m)
+_hadamard!(dst, x, y, flags) = (check(ccall((:jh_hadamard, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), handle(dst), handle(x), handle(y), flags)); dst)
+JopHipDiagonal_df!(d, m; diagonal, kwargs...) = _hadamard!(d, diagonal, m, 0)          # d .= diagonal .* m            (test/runtests.jl:3)
+JopHipDiagonal_df′!(m, d; diagonal, kwargs...) = _hadamard!(m, diagonal, d, 1)         # m .= conj.(diagonal) .* d     (test/runtests.jl:4)
 function JopHipDiagonal(diag::HipArray{T,N}) where {T,N}
-    spc = JetSpace(T, size(diag))
+    spc = HipSpace{T,N}(size(diag))
     JopLn(;df! = JopHipDiagonal_df!, df′! = JopHipDiagonal_df′!, dom = spc, rng = spc, s = (diagonal=diag,))
 end
 
 # the reference's nonlinear fixture JopBar (test/runtests.jl:19-24) on device vectors: kind SQUARE
-JopHipSquare_f!(d, m; kwargs...) = (check(ccall((:jh_hadamard, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), d.handle, m.handle, m.handle, 0)); d)
-JopHipSquare_df!(δd, δm; mₒ, kwargs...) = (check(ccall((:jh_hadamard, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), δd.handle, mₒ.handle, δm.handle, 2)); δd)
-JopHipSquare_df′!(δm, δd; mₒ, kwargs...) = (check(ccall((:jh_hadamard, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), δm.handle, mₒ.handle, δd.handle, 3)); δm)
-JopHipSquare(spc::JetSpace) = JopNl(f! = JopHipSquare_f!, df! = JopHipSquare_df!, df′! = JopHipSquare_df′!, dom = spc, rng = spc)
+JopHipSquare_f!(d, m; kwargs...) = _hadamard!(d, m, m, 0)                              # d .= m.^2
+JopHipSquare_df!(δd, δm; mₒ, kwargs...) = _hadamard!(δd, mₒ, δm, 2)                    # δd .= 2 .* mₒ .* δm
+JopHipSquare_df′!(δm, δd; mₒ, kwargs...) = _hadamard!(δm, mₒ, δd, 3)                   # δm .= conj.(2 .* mₒ) .* δd
+JopHipSquare(spc::HipSpace) = JopNl(;f! = JopHipSquare_f!, df! = JopHipSquare_df!, df′! = JopHipSquare_df′!, dom = spc, rng = spc)
+
+# the reference's dense fixture JopBaz (test/runtests.jl:27-33): d = A*m, m = A'*d for a column-major matrix in HBM
+function _gemv!(y, A::HipArray{T,2}, x, adjoint) where {T}
+    check(ccall((:jh_gemv, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+                _device_ptr(A.slab), size(A, 1), size(A, 2), dtype_code(T), handle(y), handle(x), adjoint))
+    y
+end
+JopHipDense_df!(d, m; A, kwargs...) = _gemv!(d, A, m, 0)
+JopHipDense_df′!(m, d; A, kwargs...) = _gemv!(m, A, d, 1)
+JopHipDense(A::HipArray{T,2}) where {T} = JopLn(;df! = JopHipDense_df!, df′! = JopHipDense_df′!, dom = HipSpace(T, size(A, 2)), rng = HipSpace(T, size(A, 1)), s = (A=A,))
 
 struct jh_block_desc          # mirrors include/jetship.h
     kind::Int32
@@ -192,26 +381,25 @@ function block_desc(op::Jop)
     base = adj ? op.op : op
     j = jet(base)
     nr, nc = length(range(base)), length(domain(base))
-    if op isa JopNl
+    if base isa JopNl
         return j.f! === JopHipSquare_f! ? jh_block_desc(5, 0, C_NULL, 0, 0, nr, nc) : nothing
     elseif j.df! === JopZeroBlock_df!
         return jh_block_desc(0, adj, C_NULL, 0, 0, nr, nc)
     elseif j.df! === JopHipDiagonal_df!
-        return jh_block_desc(3, adj, _device_ptr(state(base).diagonal), 0, 0, nr, nc)
-    elseif j.df! === Jets._constdiag_df!
+        return jh_block_desc(3, adj, _device_ptr(state(base).diagonal.slab), 0, 0, nr, nc)
+    elseif j.df! === JopHipDense_df!
+        return jh_block_desc(4, adj, _device_ptr(state(base).A.slab), 0, 0, nr, nc)
+    elseif j.df! === JopHipSquare_df!                                   # JopLn(F) of a JopHipSquare: its Jacobian
+        return jh_block_desc(5, adj, C_NULL, 0, 0, nr, nc)
+    elseif j.df! === _constdiag_df!                                     # a*I, src/Jets.jl:1159-1164
         a = state(base).a
         return jh_block_desc(2, adj, C_NULL, real(a), imag(a), nr, nc)
     end
-    nothing            # not device-native: the reference's per-block loop handles it
+    nothing            # not device-native: the reference's per-block loop handles it (on device arrays, child by child)
 end
 
-function _device_ptr(x)
-    p = Ref{Ptr{Cvoid}}()
-    check(ccall((:jh_bvec_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Cint}, Ref{Ptr{Cvoid}}), x.handle, C_NULL, C_NULL, C_NULL, p))
-    p[]
-end
-
-const _handles = IdDict{Any,Ptr{Cvoid}}()        # ops matrix -> jh_blockop*
+const _handles = IdDict{Any,Ptr{Cvoid}}()        # ops matrix -> jh_blockop* (C_NULL: has a child the device does not know)
+const _points = IdDict{Any,Any}()                # ops matrix -> the mₒ the device operator borrows (kept alive here)
 
 function native_handle(ops::AbstractMatrix{<:Jop}, ::Type{T}) where {T}
     get!(_handles, ops) do
@@ -226,97 +414,143 @@ function native_handle(ops::AbstractMatrix{<:Jop}, ::Type{T}) where {T}
     end
 end
 
+# the device handle of a tall (one block column) JopBlock, or C_NULL
+function tall_native(A::Jop, ::Type{T}) where {T}
+    (A isa JopLn && jet(A).df! === JetBlock_df! && size(state(A).ops, 2) == 1) || return C_NULL
+    native_handle(state(A).ops, T)
+end
+
 # ---------------------------------------------------------------- the hot path: ONE ccall per mul!
-# More specific methods of the reference's block loops (src/Jets.jl:1010-1057) for device vectors.
-function Jets.JetBlock_df!(d::HipBlockArray{T}, m::Union{HipArray{T},HipBlockArray{T}}; ops, dom, rng, kwargs...) where {T}
-    h = native_handle(ops, T)
-    h == C_NULL && return invoke(Jets.JetBlock_df!, Tuple{AbstractArray,AbstractArray}, d, m; ops, dom, rng, kwargs...)
-    check(ccall((:jh_blockop_mul, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, d.handle, m.handle))
+# More specific methods of the reference's block loops (src/Jets.jl:988-1057) for device vectors; anything the device does
+# not know (a user closure among the children, a BlockArray that is not one slab) falls through to the reference's loop.
+function Jets.JetBlock_df!(d::BlockArray{T,<:HipArray{T}}, m::DevVec{T}; ops, dom, rng, kwargs...) where {T}
+    h, hd, hm = native_handle(ops, T), handle(d), handle(m)
+    (h == C_NULL || hd == C_NULL || hm == C_NULL) && return invoke(JetBlock_df!, Tuple{AbstractArray,AbstractArray}, d, m; ops=ops, dom=dom, rng=rng, kwargs...)
+    check(ccall((:jh_blockop_mul, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, hd, hm))
     d
 end
 
-function Jets.JetBlock_df′!(m::Union{HipArray{T},HipBlockArray{T}}, d::HipBlockArray{T}; ops, dom, rng, kwargs...) where {T}
-    h = native_handle(ops, T)
-    h == C_NULL && return invoke(Jets.JetBlock_df′!, Tuple{AbstractArray,AbstractArray}, m, d; ops, dom, rng, kwargs...)
-    check(ccall((:jh_blockop_mul_adj, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, m.handle, d.handle))
+function Jets.JetBlock_df′!(m::DevVec{T}, d::BlockArray{T,<:HipArray{T}}; ops, dom, rng, kwargs...) where {T}
+    h, hd, hm = native_handle(ops, T), handle(d), handle(m)
+    (h == C_NULL || hd == C_NULL || hm == C_NULL) && return invoke(JetBlock_df′!, Tuple{AbstractArray,AbstractArray}, m, d; ops=ops, dom=dom, rng=rng, kwargs...)
+    check(ccall((:jh_blockop_mul_adj, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, hm, hd))
     m
 end
 
-# nonlinear block operators: JetBlock_f! (src/Jets.jl:988-1008) and the block point! (1059-1066).  The Jacobian then
-# runs through the two methods above; they call `_point_native` first when the operator has nonlinear children.
-function Jets.JetBlock_f!(d::HipBlockArray{T}, m::Union{HipArray{T},HipBlockArray{T}}; ops, dom, rng, kwargs...) where {T}
-    h = native_handle(ops, T)
-    h == C_NULL && return invoke(Jets.JetBlock_f!, Tuple{AbstractArray,AbstractArray}, d, m; ops, dom, rng, kwargs...)
-    check(ccall((:jh_blockop_f, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, d.handle, m.handle))
+# nonlinear block operators: JetBlock_f! (src/Jets.jl:988-1008) and the block point! (1059-1066); the Jacobian then runs
+# through the two methods above (the device operator borrows mₒ: it is kept alive in _points until the next point!)
+function Jets.JetBlock_f!(d::BlockArray{T,<:HipArray{T}}, m::DevVec{T}; ops, dom, rng, kwargs...) where {T}
+    h, hd, hm = native_handle(ops, T), handle(d), handle(m)
+    (h == C_NULL || hd == C_NULL || hm == C_NULL) && return invoke(JetBlock_f!, Tuple{AbstractArray,AbstractArray}, d, m; ops=ops, dom=dom, rng=rng, kwargs...)
+    check(ccall((:jh_blockop_f, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, hd, hm))
     d
 end
 
-function Jets.point!(j::Jet{D,R,typeof(Jets.JetBlock_f!)}, mₒ::Union{HipArray{T},HipBlockArray{T}}) where {D,R,T}
-    invoke(Jets.point!, Tuple{Jet{D,R,typeof(Jets.JetBlock_f!)},AbstractArray}, j, mₒ)   # children first (1062-1064)
-    h = native_handle(state(j).ops, T)
-    h == C_NULL || check(ccall((:jh_blockop_point, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h, mₒ.handle))
+function Jets.point!(j::Jet{D,R,typeof(JetBlock_f!)}, mₒ::DevVec{T}) where {D<:JetAbstractSpace,R<:JetAbstractSpace,T}
+    invoke(point!, Tuple{Jet{D,R,typeof(JetBlock_f!)},AbstractArray}, j, mₒ)      # children first (1062-1064)
+    ops = state(j).ops
+    h, hm = native_handle(ops, T), handle(mₒ)
+    if h != C_NULL && hm != C_NULL
+        check(ccall((:jh_blockop_point, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h, hm))
+        _points[ops] = mₒ
+    end
     j
 end
 
-# (A' o A) * m fused (src/Jets.jl:530-534 over (A', A)): called from a JetComposite_df! method that
-# recognises ops == (A', A) with A a native tall block operator
-function normal_mul!(y::HipArray{T}, A::JopLn, m::HipArray{T}) where {T}
-    h = native_handle(state(A).ops, T)
-    check(ccall((:jh_blockop_normal_mul, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, y.handle, m.handle))
-    y
+# (A' ∘ A) * m fused (src/Jets.jl:530-534 over (A', A)): coefficients read once, no range-side temporary, the bits of the
+# unfused chain.  Any other composite runs the reference's chain on device arrays.
+function Jets.JetComposite_df!(d::HipArray{T}, m::HipArray{T}; ops, kwargs...) where {T}
+    if length(ops) == 2 && ops[1] isa JopAdjoint && ops[1].op === ops[2]
+        h = tall_native(ops[2], T)
+        if h != C_NULL
+            check(ccall((:jh_blockop_normal_mul, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, handle(d), handle(m)))
+            return d
+        end
+    end
+    invoke(JetComposite_df!, Tuple{AbstractArray,Any}, d, m; ops=ops, kwargs...)
 end
 
-# ---------------------------------------------------------------- solver halves and the multi-GPU exchange
-# u <- alpha*(A v) + beta*u, returns ||u||   /   v <- alpha*(A' (in_scale*u)) + beta*v, returns ||v||   (LSQR / CGLS)
-function mul_axpby!(u::HipBlockArray{T}, A::JopLn, v::HipArray{T}, alpha::Real, beta::Real) where {T}
+# ---------------------------------------------------------------- solver steps and the multi-GPU exchange
+# u <- alpha*(A v) + beta*u, returns ||u||   /   v <- alpha*(A' (in_scale*u)) + beta*v, returns ||v||   (LSQR / CGLS halves)
+function mul_axpby!(u::BlockArray{T,<:HipArray{T}}, A::JopLn, v::HipArray{T}, alpha::Real, beta::Real) where {T}
     nrm2 = Ref{Cdouble}()
     check(ccall((:jh_blockop_mul_axpby, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Ref{Cdouble}),
-                native_handle(state(A).ops, T), u.handle, v.handle, alpha, beta, nrm2))
+                tall_native(A, T), handle(u), handle(v), alpha, beta, nrm2))
     sqrt(nrm2[])
 end
-function mul_adj_axpby!(v::HipArray{T}, A::JopLn, u::HipBlockArray{T}, alpha::Real, beta::Real; in_scale::Real=1.0) where {T}
+function mul_adj_axpby!(v::HipArray{T}, A::JopLn, u::BlockArray{T,<:HipArray{T}}, alpha::Real, beta::Real; in_scale::Real=1.0) where {T}
     nrm2 = Ref{Cdouble}()
     check(ccall((:jh_blockop_mul_adj_axpby, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Ref{Cdouble}),
-                native_handle(state(A).ops, T), v.handle, u.handle, alpha, beta, in_scale, nrm2))
+                tall_native(A, T), handle(v), handle(u), alpha, beta, in_scale, nrm2))
     sqrt(nrm2[])
 end
 
 # one whole Golub-Kahan step in one pass: u <- alpha*(A v) + beta*u ; w <- A'u ; returns ||u||   (3/5 of the bytes of the two halves)
-function bidiag_step!(u::HipBlockArray{T}, w::HipArray{T}, A::JopLn, v::HipArray{T}, alpha::Real, beta::Real) where {T}
+function bidiag_step!(u::BlockArray{T,<:HipArray{T}}, w::HipArray{T}, A::JopLn, v::HipArray{T}, alpha::Real, beta::Real) where {T}
     nrm2 = Ref{Cdouble}()
     check(ccall((:jh_blockop_bidiag_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Ref{Cdouble}),
-                native_handle(state(A).ops, T), u.handle, v.handle, w.handle, alpha, beta, nrm2))
+                tall_native(A, T), handle(u), handle(v), handle(w), alpha, beta, nrm2))
     sqrt(nrm2[])
 end
 
-# the whole LSQR loop behind the ABI (the same call solves the row-partitioned problem after comm_init on every rank)
+# the whole LSQR loop behind the ABI (the same call solves the row-partitioned problem after comm_init on every rank);
+# for operators the device does not know, IterativeSolvers.lsqr(vec(A), vec(b)) runs unchanged on device arrays
 struct jh_lsqr_result; istop::Int32; itn::Int32; r1norm::Cdouble; r2norm::Cdouble; anorm::Cdouble; acond::Cdouble; arnorm::Cdouble; xnorm::Cdouble; end
-function hip_lsqr!(x::HipArray{T}, A::JopLn, b::HipBlockArray{T}; x0::Bool=false, damp=0.0, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=100) where {T}
+function hip_lsqr!(x::HipArray{T}, A::JopLn, b::BlockArray{T,<:HipArray{T}}; x0::Bool=false, damp=0.0, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=100) where {T}
+    h = tall_native(A, T)
+    h == C_NULL && error("hip_lsqr!: needs a tall block operator of device-native children")
     res = Ref{jh_lsqr_result}()
     hist = Vector{Cdouble}(undef, 2 * maxiter)
     check(ccall((:jh_lsqr_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Ref{jh_lsqr_result}, Ptr{Cdouble}),
-                native_handle(state(A).ops, T), b.handle, x.handle, x0, damp, atol, btol, conlim, maxiter, 0, res, hist))   # b is overwritten (it becomes u)
+                h, handle(b), handle(x), x0, damp, atol, btol, conlim, maxiter, 0, res, hist))   # b is overwritten (it becomes u)
     x, res[], reshape(hist, 2, :)[:, 1:res[].itn]
 end
 
 # one process per GPU: rank 0 makes the id, the host (MPI.jl, sockets, a file) ships it, every rank joins
 comm_unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:jh_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id)); id)
 comm_init(id::Vector{UInt8}, nranks::Integer, rank::Integer) = check(ccall((:jh_comm_init_rank, LIB), Cint, (Ptr{UInt8}, Cint, Cint), id, nranks, rank))
-allreduce_sum!(x::Union{HipArray,HipBlockArray}) = (check(ccall((:jh_comm_allreduce_sum, LIB), Cint, (Ptr{Cvoid},), x.handle)); x)
+comm_destroy() = check(ccall((:jh_comm_destroy, LIB), Cint, ()))
+allreduce_sum!(x::DevVec) = (check(ccall((:jh_comm_allreduce_sum, LIB), Cint, (Ptr{Cvoid},), handle(x))); x)
 function allreduce_scalars!(vals::Vector{Float64}, op::Symbol=:sum)
     check(ccall((:jh_comm_allreduce_scalars, LIB), Cint, (Ptr{Cdouble}, Cint, Cint), vals, length(vals), op === :sum ? 0 : (op === :max ? 1 : 2)))
     vals
 end
-# adjoint of a row-partitioned tall operator: local ordered sum, then the in-place all-reduce (src/Jets.jl:1045-1053 summed over ranks)
-function mul_adj_partitioned!(m::HipArray{T}, A::JopLn, d_local::HipBlockArray{T}) where {T}
-    check(ccall((:jh_blockop_mul_adj, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), native_handle(state(A).ops, T), m.handle, d_local.handle))
+# row partition (SURVEY.md 8e): this rank owns block rows first+1 : first+count of an nrow-row tall operator
+function partition_rows(nrow::Integer, world::Integer, rank::Integer)
+    base, rem = divrem(nrow, world)
+    (first = rank * base + min(rank, rem), count = base + (rank < rem ? 1 : 0))
+end
+# adjoint of a row-partitioned tall operator: local ordered sum, then the in-place all-reduce (src/Jets.jl:1045-1053 summed
+# over ranks).  In `chunks` element ranges (jh_blockop_mul_adj_range) when the host wants to hand finished ranges to its own
+# communication stream while the next range is computed.
+function mul_adj_partitioned!(m::HipArray{T}, A::JopLn, d_local::BlockArray{T,<:HipArray{T}}; chunks::Integer=1) where {T}
+    h = tall_native(A, T)
+    if chunks <= 1
+        check(ccall((:jh_blockop_mul_adj, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, handle(m), handle(d_local)))
+    else
+        n = length(m)
+        step = cld(cld(n, chunks), 16384) * 16384                         # chunk bounds on 64 KiB boundaries
+        for lo = 0:step:n-1
+            check(ccall((:jh_blockop_mul_adj_range, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64), h, handle(m), handle(d_local), lo, min(step, n - lo)))
+        end
+    end
     allreduce_sum!(m)
 end
+# range-side reductions of a row-partitioned vector: local fp64 partial, scalar all-reduce
+dot_partitioned(x::BlockArray{T,<:HipArray{T}}, y::BlockArray{T,<:HipArray{T}}) where {T<:Real} = T(allreduce_scalars!(Float64[dot(x, y)])[1])
+norm_partitioned(x::BlockArray{T,<:HipArray{T}}) where {T} = float(real(T))(sqrt(allreduce_scalars!(Float64[Float64(norm(x))^2])[1]))
 
 # close(A) releases the device operator (src/Jets.jl:1120-1124 cascade)
 function release!(ops)
     h = pop!(_handles, ops, C_NULL)
+    delete!(_points, ops)
     h == C_NULL || ccall((:jh_blockop_destroy, LIB), Cint, (Ptr{Cvoid},), h)
+    nothing
+end
+function Base.close(j::Jet{D,R,typeof(JetBlock_f!)}) where {D<:JetAbstractSpace,R<:JetBSpace{<:Any,<:HipSpace}}
+    ops = state(j).ops
+    release!(ops)
+    close.(ops)
     nothing
 end
 

@@ -167,3 +167,89 @@ def test_julia_struct_layouts_match_the_header():
     for name in ("jh_block_desc", "jh_lsqr_result"):
         cf, jf = c_fields(name), jl_fields(name)
         assert cf == jf, f"{name}: C fields {cf} vs Julia fields {jf}"
+
+
+def _julia_code_tokens():
+    """The binding's source with comments and string literals blanked (enough lexing for the structural checks below)."""
+    text = open(JULIA).read()
+    out, i, n = [], 0, len(text)
+    while i < n:
+        ch = text[i]
+        if ch == "#":
+            while i < n and text[i] != "\n":
+                i += 1
+        elif ch == '"':
+            i += 1
+            depth = 0
+            while i < n and (text[i] != '"' or depth > 0):
+                if text[i] == "\\":
+                    i += 1
+                elif text[i] == "$" and i + 1 < n and text[i + 1] == "(":
+                    depth += 1
+                    i += 1
+                elif text[i] == ")" and depth > 0:
+                    depth -= 1
+                elif text[i] == "(" and depth > 0:
+                    depth += 1
+                i += 1
+            i += 1
+            out.append('""')
+        else:
+            out.append(ch)
+            i += 1
+    return "".join(out)
+
+
+def test_julia_source_is_structurally_balanced():
+    """No Julia parser exists here; at least every block opener has its `end` and every bracket closes."""
+    code = _julia_code_tokens()
+    pairs = {")": "(", "]": "[", "}": "{"}
+    stack = []
+    for k, ch in enumerate(code):
+        if ch in "([{":
+            stack.append((ch, code[:k].count("\n") + 1))
+        elif ch in ")]}":
+            assert stack and stack[-1][0] == pairs[ch], f"julia/JetsHIP.jl:{code[:k].count(chr(10)) + 1}: unbalanced `{ch}`"
+            stack.pop()
+    assert not stack, f"unclosed bracket opened at line {stack[-1][1]}"
+    # block keywords vs `end` (an `end` inside [...] is an index, not a terminator)
+    depth_sq, openers, ends = 0, 0, 0
+    for mt in re.finditer(r"[\[\]]|(?<![\w.:])(?:mutable\s+struct|struct|function|module|if|for|while|do|let|begin|try|quote|macro|end)(?![\w!])", code):
+        tok = mt.group(0)
+        if tok == "[":
+            depth_sq += 1
+        elif tok == "]":
+            depth_sq -= 1
+        elif tok == "end":
+            if depth_sq == 0:
+                ends += 1
+        elif depth_sq == 0 or tok in ("for", "if"):          # comprehensions `[f(i) for i = 1:n if p(i)]` open no block
+            if depth_sq == 0:
+                openers += 1
+    assert openers == ends, f"{openers} block openers vs {ends} `end`s"
+
+
+def test_julia_binding_covers_the_reference_api_it_claims():
+    """Methods the drop-in story depends on: device spaces and their factories, the BlockArray primitives, the three block
+    loops, the fused composite, point!, reshape -- each must be defined on the device types."""
+    code = _julia_code_tokens()
+    for needle in ("struct HipSpace{T,N} <: JetAbstractSpace{T,N}", "struct HipArray{T,N} <: AbstractArray{T,N}",
+                   "Base.zeros(R::HipSpace", "Base.ones(R::HipSpace", "Base.rand(R::HipSpace", "Base.randn(R::HipSpace", "Base.Array(R::HipSpace",
+                   "Base.zeros(R::JetBSpace{T,S}) where {T,S<:HipSpace}", "Base.rand(R::JetBSpace{T,S}", "Jets.space(x::HipArray",
+                   "LinearAlgebra.norm(x::BlockArray{T,<:HipArray{T}}", "LinearAlgebra.dot(x::BlockArray{T,<:HipArray{T}}",
+                   "Base.extrema(x::BlockArray{T,<:HipArray{T}}", "Base.fill!(x::BlockArray{T,<:HipArray{T}}",
+                   "Base.convert(::Type{Array}, x::BlockArray{T,<:HipArray{T}}", "Base.similar(x::BlockArray{S,<:HipArray{S}}",
+                   "Base.copyto!(dest::BlockArray{T,<:HipArray{T,N}}, bc::Broadcast.Broadcasted{BlockArrayStyle})",
+                   "Base.reshape(x::HipArray{T,1}, R::JetBSpace", "Jets.getblock!(x::BlockArray{T,<:HipArray{T}}", "Jets.setblock!(x::BlockArray{T,<:HipArray{T}}",
+                   "function Jets.JetBlock_df!(d::BlockArray{T,<:HipArray{T}}", "function Jets.JetBlock_df′!(m::DevVec{T}",
+                   "function Jets.JetBlock_f!(d::BlockArray{T,<:HipArray{T}}", "function Jets.point!(j::Jet{D,R,typeof(JetBlock_f!)}",
+                   "function Jets.JetComposite_df!(d::HipArray{T}, m::HipArray{T}"):
+        assert needle in code, f"julia/JetsHIP.jl lacks `{needle}`"
+    # every name imported from Jets exists in the reference source (when it is there to be read: not on the GPU box)
+    ref = "/root/reference/src/Jets.jl"
+    if os.path.exists(ref):
+        src = open(ref).read()
+        imp = re.search(r"import Jets:(.*?)\n\n", open(JULIA).read(), flags=re.S).group(1)
+        for name in [t.strip() for t in imp.replace("\n", " ").split(",") if t.strip()]:
+            assert re.search(r"(?m)^(?:abstract type |struct |mutable struct |function |macro )?" + re.escape(name) + r"\b", src) or \
+                re.search(r"\b" + re.escape(name) + r"\(", src), f"`{name}` imported from Jets but not defined in the reference"
