@@ -98,6 +98,7 @@ const DevVec{T} = Union{HipArray{T},BlockArray{T,<:HipArray{T}}}
 # the slab a device BlockArray lives in, or nothing when it was assembled from unrelated arrays (then the reference's
 # per-block methods run, each block being a device array of its own)
 function whole(x::BlockArray{T,<:HipArray{T}}) where {T}
+    isempty(x.arrays) && return nothing
     o = x.arrays[1].owner
     (o === nothing || o.nblocks != length(x.arrays)) && return nothing
     for i in eachindex(x.arrays)
