@@ -273,8 +273,8 @@ int jh_comm_allreduce_scalars(double *values, int n, int op);   /* op: 0 sum, 1 
 
 /* kernel-shape tuning knobs (bench/tests only): 0 = automatic (fwd_order: -1); name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg","fwd_order","nt","autotune",
  * "graphs" (1: operators that run the per-block loop -- those with DENSE blocks -- replay it as a hipGraph from the
- * third call with the same vectors on; 0: always eager), "general_xcd" (0: the general M x K kernels walk tile-fastest instead
- * of XCD-aware; for A/B measurements), "red_wgs", "adj_split" (split-row walk of the tall adjoint / fused normal /
+ * third call with the same vectors on; 0: always eager), "general_xcd" (the general M x K kernels' grid order: 1 automatic -- XCD-aware when the
+ * input vector is >= 32 MiB, line by line below --, 0 never XCD-aware, 2 always), "red_wgs", "adj_split" (split-row walk of the tall adjoint / fused normal /
  * one-pass step: -1 automatic, 0 never -- always the ordered, bit-exact walk --, k > 1 that many row parts)};
  * jh_tune_get also reads the counters "last_fwd_walk" (grid walk of the latest tall forward: 0 sequential, 1 all rows),
  * "last_fwd_rows_per_wg", "last_adj_launches", "last_adj_parts" and "graph_replays". */

@@ -668,19 +668,29 @@ __device__ inline void general_line_tile(unsigned nlines, unsigned ntiles, int64
 template <typename S, int E>
 __global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                     const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
-                                    const S *__restrict__ m, S *__restrict__ d, int fmode, unsigned ntiles)
+                                    const S *__restrict__ m, S *__restrict__ d, int fmode, unsigned ntiles,
+                                    int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride)
 {
     int64_t i, tile;                                                       // block row, tile
     general_line_tile((unsigned)nrow, ntiles, i, tile);
     ntiles &= 0x7fffffffu;
     if (tile >= ntiles) return;
+    // q_per_part > 0: split walk (many block columns of small blocks, general_parts): workgroup row blockIdx.y sums its own
+    // columns, in order, from zero into slab blockIdx.y; k_fold_general adds d as found and the slabs afterwards
+    const bool split = q_per_part > 0;
+    int64_t j_lo = 0, j_hi = ncol;
+    if (split) {
+        j_lo = (int64_t)blockIdx.y * q_per_part;
+        j_hi = j_lo + q_per_part < ncol ? j_lo + q_per_part : ncol;
+        d = slabs + (int64_t)blockIdx.y * slab_stride;
+    }
     const int64_t n = row_off[i + 1] - row_off[i];
     for (int64_t e = tile * 256 + threadIdx.x; e < n; e += (int64_t)ntiles * 256) {
         elem<S, E> acc;
-        bool touched = false;
-        if (ncol > 1) { acc = eload<S, E>(d, row_off[i] + e); }          // `_d .+=` accumulates into d as found (1024 / 1001)
+        bool touched = split;
+        if (ncol > 1 && !split) { acc = eload<S, E>(d, row_off[i] + e); }   // `_d .+=` accumulates into d as found (1024 / 1001)
         else { acc.re = 0; acc.im = 0; }
-        for (int64_t j = 0; j < ncol; j++) {                               // (1020)
+        for (int64_t j = j_lo; j < j_hi; j++) {                            // (1020)
             const jh_dev_block b = blocks[i + j * nrow];
             if (b.kind == JH_OP_ZERO && !fmode) continue;                  // (1022); JetBlock_f! has no such test
             elem<S, E> p;
@@ -700,18 +710,25 @@ __global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int
 template <typename S, int E>
 __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                     const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
-                                    S *__restrict__ m, const S *__restrict__ d, unsigned ntiles)
+                                    S *__restrict__ m, const S *__restrict__ d, unsigned ntiles,
+                                    int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride)
 {
     int64_t j, tile;                                                       // block column, tile
     general_line_tile((unsigned)ncol, ntiles, j, tile);
     ntiles &= 0x7fffffffu;
     if (tile >= ntiles) return;
+    int64_t i_lo = 0, i_hi = nrow;                                         // q_per_part > 0: split walk over the block rows
+    if (q_per_part > 0) {
+        i_lo = (int64_t)blockIdx.y * q_per_part;
+        i_hi = i_lo + q_per_part < nrow ? i_lo + q_per_part : nrow;
+        m = slabs + (int64_t)blockIdx.y * slab_stride;
+    }
     const int64_t n = col_off[j + 1] - col_off[j];
     for (int64_t e = tile * 256 + threadIdx.x; e < n; e += (int64_t)ntiles * 256) {
         elem<S, E> acc;
         acc.re = 0; acc.im = 0;                                            // `_m .= 0` when nrow > 1 (1042)
         bool touched = (nrow > 1);
-        for (int64_t i = 0; i < nrow; i++) {                               // (1045)
+        for (int64_t i = i_lo; i < i_hi; i++) {                            // (1045)
             const jh_dev_block b = blocks[i + j * nrow];
             if (b.kind == JH_OP_ZERO) continue;                            // (1047)
             elem<S, E> x = eload<S, E>(d, row_off[i] + e);
@@ -765,26 +782,34 @@ constexpr int GENERAL_Q = 1;
 template <typename S, int E, int NS>
 __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                         const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
-                                        const S *__restrict__ m, S *__restrict__ d, int fmode, unsigned ntiles)
+                                        const S *__restrict__ m, S *__restrict__ d, int fmode, unsigned ntiles,
+                                        int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride)
 {
     typedef typename vec_of<S, NS>::type V;
     int64_t i, tile;                                                       // block row, tile
     general_line_tile((unsigned)nrow, ntiles, i, tile);
     ntiles &= 0x7fffffffu;
     if (tile >= ntiles) return;
+    const bool split = q_per_part > 0;                                     // split walk over the block columns (see the scalar kernel)
+    int64_t j_lo = 0, j_hi = ncol;
+    if (split) {
+        j_lo = (int64_t)blockIdx.y * q_per_part;
+        j_hi = j_lo + q_per_part < ncol ? j_lo + q_per_part : ncol;
+        d = slabs + (int64_t)blockIdx.y * slab_stride;
+    }
     const int64_t ns = (row_off[i + 1] - row_off[i]) * E;                 // scalars in this block row
     for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < ns; s += (int64_t)ntiles * 256 * NS) {
         V acc = (V)(S)0;
-        bool touched = false;
-        if (ncol > 1) acc = ld<false>(reinterpret_cast<const V *>(d + row_off[i] * E + s));
-        for (int64_t j0 = 0; j0 < ncol; j0 += GENERAL_Q) {                 // (1020), GENERAL_Q columns' loads in flight
+        bool touched = split;
+        if (ncol > 1 && !split) acc = ld<false>(reinterpret_cast<const V *>(d + row_off[i] * E + s));
+        for (int64_t j0 = j_lo; j0 < j_hi; j0 += GENERAL_Q) {              // (1020), GENERAL_Q columns' loads in flight
             jh_dev_block b[GENERAL_Q];
             V x[GENERAL_Q], c[GENERAL_Q];
             bool on[GENERAL_Q];
 #pragma unroll
             for (int q = 0; q < GENERAL_Q; q++) {
                 const int64_t j = j0 + q;
-                on[q] = j < ncol;
+                on[q] = j < j_hi;
                 x[q] = (V)(S)0;
                 c[q] = (V)(S)0;
                 if (on[q]) {
@@ -811,25 +836,32 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
 template <typename S, int E, int NS>
 __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                         const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
-                                        S *__restrict__ m, const S *__restrict__ d, unsigned ntiles)
+                                        S *__restrict__ m, const S *__restrict__ d, unsigned ntiles,
+                                        int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride)
 {
     typedef typename vec_of<S, NS>::type V;
     int64_t j, tile;                                                       // block column, tile
     general_line_tile((unsigned)ncol, ntiles, j, tile);
     ntiles &= 0x7fffffffu;
     if (tile >= ntiles) return;
+    int64_t i_lo = 0, i_hi = nrow;                                         // q_per_part > 0: split walk over the block rows
+    if (q_per_part > 0) {
+        i_lo = (int64_t)blockIdx.y * q_per_part;
+        i_hi = i_lo + q_per_part < nrow ? i_lo + q_per_part : nrow;
+        m = slabs + (int64_t)blockIdx.y * slab_stride;
+    }
     const int64_t ns = (col_off[j + 1] - col_off[j]) * E;
     for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < ns; s += (int64_t)ntiles * 256 * NS) {
         V acc = (V)(S)0;
         bool touched = (nrow > 1);
-        for (int64_t i0 = 0; i0 < nrow; i0 += GENERAL_Q) {                 // (1045), GENERAL_Q rows' loads in flight
+        for (int64_t i0 = i_lo; i0 < i_hi; i0 += GENERAL_Q) {              // (1045), GENERAL_Q rows' loads in flight
             jh_dev_block b[GENERAL_Q];
             V x[GENERAL_Q], c[GENERAL_Q];
             bool on[GENERAL_Q];
 #pragma unroll
             for (int q = 0; q < GENERAL_Q; q++) {
                 const int64_t i = i0 + q;
-                on[q] = i < nrow;
+                on[q] = i < i_hi;
                 x[q] = (V)(S)0;
                 c[q] = (V)(S)0;
                 if (on[q]) {
@@ -850,6 +882,41 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
                 }
         }
         if (touched) st<false>(reinterpret_cast<V *>(m + col_off[j] * E + s), acc);
+    }
+}
+
+// second stage of the general kernels' split walk: out[line] = (add_found ? out as found : 0) + slab 0 + slab 1 + ... for every
+// line (block row of the range / block column of the domain) that the operator touches; 64 scalar lanes x 4 part lanes per
+// workgroup, fp64 accumulation, fixed order => deterministic (tolerance parity with the single ordered sum)
+template <typename S>
+__global__ __launch_bounds__(256) void k_fold_general(const S *__restrict__ slabs, int64_t slab_stride, int nparts, S *__restrict__ out,
+                                                      const int64_t *__restrict__ off, int E, const unsigned char *__restrict__ touched,
+                                                      int add_found)
+{
+    __shared__ double sm[4][64];
+    const int64_t line = blockIdx.y;
+    if (touched && !touched[line]) return;                                 // a block row of zero blocks only: d stays as found (1022)
+    const int64_t base = off[line] * E, ns = (off[line + 1] - off[line]) * E;
+    const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (int64_t s0 = (int64_t)blockIdx.x * 64; s0 < ns; s0 += (int64_t)gridDim.x * 64) {
+        const int64_t s = s0 + v;
+        const bool ok = s < ns;
+        double acc = 0.0;
+        if (ok) {
+#pragma unroll 4
+            for (int p = q; p < nparts; p += 4) acc += (double)slabs[(int64_t)p * slab_stride + base + s];
+        }
+        sm[q][v] = acc;
+        __syncthreads();
+        if (q == 0 && ok) {
+            double t = add_found ? (double)out[base + s] : 0.0;
+            t += acc;
+            t += sm[1][v];
+            t += sm[2][v];
+            t += sm[3][v];
+            out[base + s] = (S)t;
+        }
+        __syncthreads();
     }
 }
 
@@ -1126,7 +1193,19 @@ bool general_vec_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_p
 }
 
 // tiles per line and the 1-D grid of the general kernels: ceil(ntiles / 8) * 8 * nlines workgroups of 256 lanes, < 2^24
-static inline void general_grid(int64_t want_tiles, int64_t nlines, unsigned &ntiles, unsigned &grid)
+// XCD-aware decode or line by line?  The XCD-aware order exists so that a shared input block comes from HBM once; it also
+// makes the workgroups dispatched together write (forward) or read (adjoint) one tile of EVERY line at once -- hundreds of
+// concurrent streams.  When the whole input vector is small enough to stay in L2 / Infinity Cache between lines anyway, the
+// line-by-line order is faster: tall mixed 1024 x 1 of 4 MiB blocks forward 1.54 -> 1.02 ms, 512 x 2 0.40 -> 0.36 ms, while
+// 8 x 8 of 16 MiB blocks (128 MiB of input) wants the XCD-aware order, 0.35 -> 0.28 ms (profiles/exp_r01_cliffs.txt).
+// Knob general_xcd: 1 automatic (XCD-aware from 32 MiB of input on), 0 never, 2 always.
+static inline bool general_use_xcd(int64_t input_bytes)
+{
+    const int64_t k = jh_ctx().general_xcd;
+    return k == 2 || (k == 1 && input_bytes >= ((int64_t)32 << 20));
+}
+
+static inline void general_grid(int64_t want_tiles, int64_t nlines, unsigned &ntiles, unsigned &grid, bool xcd)
 {
     int64_t cap = (((int64_t)1 << 24) / nlines) / 8 * 8 - 8;               // grid * 256 threads < 2^32
     if (cap < 8) cap = 8;
@@ -1134,56 +1213,122 @@ static inline void general_grid(int64_t want_tiles, int64_t nlines, unsigned &nt
     if (want_tiles < 1) want_tiles = 1;
     ntiles = (unsigned)want_tiles;
     grid = (unsigned)(((want_tiles + 7) / 8) * 8 * nlines);
-    if (!jh_ctx().general_xcd) ntiles |= 0x80000000u;                      // flag for the kernels' decode (A/B knob)
+    if (!xcd) ntiles |= 0x80000000u;                                       // flag for the kernels' decode: tile fastest, line by line
+}
+
+// Split walk of the general kernels.  One line (block row of the forward, block column of the adjoint) is summed by the
+// threads that own its elements, over ALL blocks of the line: a wide operator of many small blocks (or a tall one, in the
+// adjoint) launches a handful of workgroups that each walk thousands of blocks -- 1 x 16384 blocks of 16384 Float32: forward
+// 12.4 ms, 173 GB/s (profiles/exp_r01_cliffs.txt).  When the summed dimension has >= 256 blocks and the launch would have
+// fewer workgroups than the chip has CUs, it is cut into `parts` ranges (grid.y), each summed in order into its own slab,
+// and k_fold_general adds the output as found (forward: `_d .+=`, 1024) and the slabs.  Deterministic; tolerance parity.
+// Same knob as the tall kernels: adj_split (-1 automatic, 0 never, k parts).
+int64_t general_parts(int64_t wgs, int64_t nsum, int64_t out_bytes)
+{
+    jh_context &c = jh_ctx();
+    if (c.adj_split == 0 || nsum < 4) return 1;
+    int64_t parts;
+    if (c.adj_split > 0) parts = c.adj_split;
+    else {
+        // these kernels keep ONE block's loads in flight per thread (GENERAL_Q), so they want more workgroups than the tall walk
+        if (wgs >= 4 * (int64_t)c.cu_count || nsum < 256) return 1;
+        parts = (16 * (int64_t)c.cu_count + wgs - 1) / wgs;
+        if (parts > nsum / 16) parts = nsum / 16;
+    }
+    if (parts > nsum / 2) parts = nsum / 2;
+    if (parts > 65535) parts = 65535;
+    while (parts > 1 && (double)parts * (double)out_bytes > 256.0 * (double)(1 << 20)) parts /= 2;   // scratch for the slabs
+    return parts < 2 ? 1 : parts;
+}
+
+template <typename S>
+int launch_fold_general(const void *slabs, int64_t slab_stride, int64_t parts, void *out, const int64_t *dev_off, int E, int64_t nlines,
+                        int64_t max_scalars, const unsigned char *touched, int add_found)
+{
+    int64_t gx = (max_scalars + 63) / 64;
+    if (gx > 4096) gx = 4096;
+    if (gx < 1) gx = 1;
+    JH_REQUIRE(nlines <= 65535, "split walk: %lld lines exceed the grid", (long long)nlines);
+    hipLaunchKernelGGL((k_fold_general<S>), dim3((unsigned)gx, (unsigned)nlines), dim3(256), 0, jh_ctx().stream, (const S *)slabs, slab_stride,
+                       (int)parts, (S *)out, dev_off, E, touched, add_found);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
 }
 
 template <typename S, int E>
 int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
 {
+    jh_context &c = jh_ctx();
     int64_t maxn = 0;
     for (int64_t i = 0; i < op->nrow; i++) maxn = op->row_len[i] > maxn ? op->row_len[i] : maxn;
     if (maxn == 0) return JH_OK;
     JH_REQUIRE(op->nrow < ((int64_t)1 << 20), "general block forward supports fewer than 2^20 block rows (got %lld)", (long long)op->nrow);
     unsigned ntiles, grid;
-    if (general_vec_ok(op, d, m)) {
-        constexpr int NS = 16 / sizeof(S);
-        general_grid((maxn * E / NS + 255) / 256, op->nrow, ntiles, grid);                 // one pack per thread (see jh_vecops.hip: grid_full)
-        hipLaunchKernelGGL((k_block_fwd_general_vec<S, E, NS>), dim3(grid), dim3(256), 0, jh_ctx().stream,
-                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode, ntiles);
-        JH_CHECK_HIP(hipGetLastError());
-        return JH_OK;
+    const bool vec = general_vec_ok(op, d, m);
+    constexpr int NS = 16 / sizeof(S);
+    int64_t want = vec ? (maxn * E / NS + 255) / 256 : (maxn + 255) / 256;     // vec: one pack per thread (see jh_vecops.hip: grid_full)
+    if (!vec && want > 4096) want = 4096;
+    general_grid(want, op->nrow, ntiles, grid, general_use_xcd(op->col_off[(size_t)op->ncol] * (int64_t)(sizeof(S) * E)));
+    // split walk over the block columns (general_parts)
+    const int64_t out_scalars = op->row_off[(size_t)op->nrow] * E;
+    int64_t parts = (op->nrow <= 65535) ? general_parts((int64_t)grid, op->ncol, out_scalars * (int64_t)sizeof(S)) : 1;
+    int64_t per = 0;
+    void *slabs = nullptr;
+    if (parts > 1) {
+        per = (op->ncol + parts - 1) / parts;
+        parts = (op->ncol + per - 1) / per;
+        JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)out_scalars * sizeof(S), &slabs));
     }
-    int64_t want = (maxn + 255) / 256;
-    if (want > 4096) want = 4096;
-    general_grid(want, op->nrow, ntiles, grid);
-    hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3(grid), dim3(256), 0, jh_ctx().stream,
-                       op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode, ntiles);
+    c.last_adj_parts = parts;
+    if (vec)
+        hipLaunchKernelGGL((k_block_fwd_general_vec<S, E, NS>), dim3(grid, (unsigned)parts), dim3(256), 0, c.stream,
+                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode, ntiles,
+                           per, (S *)slabs, out_scalars);
+    else
+        hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3(grid, (unsigned)parts), dim3(256), 0, c.stream,
+                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode, ntiles,
+                           per, (S *)slabs, out_scalars);
     JH_CHECK_HIP(hipGetLastError());
+    if (parts > 1)      // JetBlock_f! touches every row (1001); the linear loop leaves a row of zero blocks as found (1022)
+        return launch_fold_general<S>(slabs, out_scalars, parts, d, op->dev_row_off, E, op->nrow, maxn * E, fmode ? nullptr : op->dev_row_touched, 1);
     return JH_OK;
 }
 
 template <typename S, int E>
 int general_adj(const jh_blockop *op, void *m, const void *d)
 {
+    jh_context &c = jh_ctx();
     int64_t maxn = 0;
     for (int64_t j = 0; j < op->ncol; j++) maxn = op->col_len[j] > maxn ? op->col_len[j] : maxn;
     if (maxn == 0) return JH_OK;
     JH_REQUIRE(op->ncol < ((int64_t)1 << 20), "general block adjoint supports fewer than 2^20 block columns (got %lld)", (long long)op->ncol);
     unsigned ntiles, grid;
-    if (general_vec_ok(op, d, m)) {
-        constexpr int NS = 16 / sizeof(S);
-        general_grid((maxn * E / NS + 255) / 256, op->ncol, ntiles, grid);
-        hipLaunchKernelGGL((k_block_adj_general_vec<S, E, NS>), dim3(grid), dim3(256), 0, jh_ctx().stream,
-                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d, ntiles);
-        JH_CHECK_HIP(hipGetLastError());
-        return JH_OK;
+    const bool vec = general_vec_ok(op, d, m);
+    constexpr int NS = 16 / sizeof(S);
+    int64_t want = vec ? (maxn * E / NS + 255) / 256 : (maxn + 255) / 256;
+    if (!vec && want > 4096) want = 4096;
+    general_grid(want, op->ncol, ntiles, grid, general_use_xcd(op->row_off[(size_t)op->nrow] * (int64_t)(sizeof(S) * E)));
+    // split walk over the block rows (general_parts); nrow >= 4 there, so every column is zeroed first (1042): all lines touched
+    const int64_t out_scalars = op->col_off[(size_t)op->ncol] * E;
+    int64_t parts = (op->ncol <= 65535) ? general_parts((int64_t)grid, op->nrow, out_scalars * (int64_t)sizeof(S)) : 1;
+    int64_t per = 0;
+    void *slabs = nullptr;
+    if (parts > 1) {
+        per = (op->nrow + parts - 1) / parts;
+        parts = (op->nrow + per - 1) / per;
+        JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)out_scalars * sizeof(S), &slabs));
     }
-    int64_t want = (maxn + 255) / 256;
-    if (want > 4096) want = 4096;
-    general_grid(want, op->ncol, ntiles, grid);
-    hipLaunchKernelGGL((k_block_adj_general<S, E>), dim3(grid), dim3(256), 0, jh_ctx().stream,
-                       op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d, ntiles);
+    c.last_adj_parts = parts;
+    if (vec)
+        hipLaunchKernelGGL((k_block_adj_general_vec<S, E, NS>), dim3(grid, (unsigned)parts), dim3(256), 0, c.stream,
+                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d, ntiles,
+                           per, (S *)slabs, out_scalars);
+    else
+        hipLaunchKernelGGL((k_block_adj_general<S, E>), dim3(grid, (unsigned)parts), dim3(256), 0, c.stream,
+                           op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d, ntiles,
+                           per, (S *)slabs, out_scalars);
     JH_CHECK_HIP(hipGetLastError());
+    if (parts > 1) return launch_fold_general<S>(slabs, out_scalars, parts, m, op->dev_col_off, E, op->ncol, maxn * E, nullptr, 0);
     return JH_OK;
 }
 
@@ -1623,7 +1768,14 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
     if (e == hipSuccess) e = hipMemcpyAsync(op->dev_blocks, host.data(), host.size() * sizeof(jh_dev_block), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(op->dev_row_off, op->row_off.data(), sizeof(int64_t) * ((size_t)nrow + 1), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(op->dev_col_off, op->col_off.data(), sizeof(int64_t) * ((size_t)ncol + 1), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);   // host staging vector dies at return
+    // which block rows the linear forward writes at all (a row of zero blocks only stays as found, 1022): the split walk's fold needs it
+    std::vector<unsigned char> touched((size_t)nrow, 0);
+    for (int64_t i = 0; i < nrow; i++)
+        for (int64_t j = 0; j < ncol; j++)
+            if (op->blocks[(size_t)(i + j * nrow)].kind != JH_OP_ZERO) { touched[(size_t)i] = 1; break; }
+    if (e == hipSuccess) e = hipMalloc((void **)&op->dev_row_touched, (size_t)nrow);
+    if (e == hipSuccess) e = hipMemcpyAsync(op->dev_row_touched, touched.data(), (size_t)nrow, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);   // host staging vectors die at return
     if (e != hipSuccess) {
         jh_blockop_destroy(op);
         return jh_fail(JH_ERR_HIP, "jh_blockop_create: %s", hipGetErrorString(e));
@@ -1640,6 +1792,7 @@ int jh_blockop_destroy(jh_blockop *op)
     if (op->dev_blocks) (void)hipFree(op->dev_blocks);
     if (op->dev_row_off) (void)hipFree(op->dev_row_off);
     if (op->dev_col_off) (void)hipFree(op->dev_col_off);
+    if (op->dev_row_touched) (void)hipFree(op->dev_row_touched);
     delete op;
     return JH_OK;
 }

@@ -54,7 +54,7 @@ struct jh_context {
     int64_t last_adj_parts = 1;        // row parts of the most recent tall adjoint / fused normal / one-pass step (read-only knob)
     int64_t nt = 1;                    // nontemporal loads/stores on the streamed operands
     int64_t autotune = 1;              // time both grid walks of the tall forward once per large operator
-    int64_t general_xcd = 1;           // general M x K kernels: XCD-aware (line, tile) decode; 0 = tile-fastest order (A/B measurements)
+    int64_t general_xcd = 1;           // general M x K kernels: 1 = XCD-aware (line, tile) decode from 32 MiB of input on, else line by line; 0 never; 2 always
     int64_t graphs = 1;                // replay launch-bound per-block loops as hipGraphs (jh_blockop.hip: run_loop_graphed)
     int64_t graph_replays = 0;         // read-only counter: hipGraphLaunch calls made by run_loop_graphed
     uint64_t buf_gen = 0;              // bumped whenever part_dev / scratch_dev is reallocated: captured graphs holding the old pointers are stale
@@ -113,6 +113,7 @@ struct jh_blockop {
     jh_dev_block *dev_blocks = nullptr;      // nrow*ncol
     int64_t *dev_row_off = nullptr;          // nrow+1
     int64_t *dev_col_off = nullptr;          // ncol+1
+    unsigned char *dev_row_touched = nullptr; // nrow: 1 when the block row has a non-zero block (the linear forward writes it)
     // classification for the fast paths
     bool tall = false;                       // ncol == 1
     bool uniform_rows = false;               // all row_len equal

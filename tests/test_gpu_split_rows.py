@@ -181,3 +181,147 @@ def test_dot_product_test_and_lsqr_on_many_small_rows(Jets, oracle, knob):
     res = Jets.lsqr(A, b, atol=0.0, btol=0.0, conlim=0.0, maxiter=30, force_maxiter=True)
     err = (res.x - x_true).materialize()
     assert float(Jets.norm(err)) / float(Jets.norm(x_true)) < 1e-5
+
+
+# ---------------------------------------------------------------------------------- general M x K kernels
+def _general_case(Jets, oracle, dt, nrow, ncol, n, kind_of, seed=700):
+    """nrow x ncol operator of n-element blocks, kind_of(i, j) in {diag, diag_adj, identity, scale, zero}; device + oracle twins."""
+    spc = Jets.JetSpace(dt, n)
+    dev, ora = [], []
+    for i in range(nrow):
+        dr, orow = [], []
+        for j in range(ncol):
+            k = kind_of(i, j)
+            if k == "zero":
+                dr.append(Jets.JopZeroBlock(spc, spc)); orow.append(oracle.Block("zero", n, n))
+            elif k == "identity":
+                dr.append(Jets.JopIdentity(spc)); orow.append(oracle.Block("identity", n))
+            elif k == "scale":
+                a = 0.75 - 0.001 * (i + j)
+                dr.append(Jets.JopLn(dom=spc, rng=spc, df=Jets.constdiag_df, df_adj=Jets.constdiag_df_adj, s={"a": a}))
+                orow.append(oracle.Block("scale", n, scale=a))
+            else:
+                stream = 100000 * i + j
+                op = Jets.JopDiagonal(Jets.rand(spc, seed=seed, stream=stream))
+                dr.append(op.H if k == "diag_adj" else op)
+                orow.append(oracle.Block("diag", n, coeff=u01(oracle, dt, seed, stream, n), adjoint=(k == "diag_adj")))
+        dev.append(dr); ora.append(orow)
+    return Jets.blockop(dev), ora
+
+
+def _truth_fwd(ora, d_found, m_blocks, accumulate):
+    """sum over the blocks of every row in 80-bit arithmetic (zero blocks skipped; a row of zero blocks only keeps d)."""
+    wide = np.clongdouble
+    out = []
+    for i, row in enumerate(ora):
+        acc = d_found[i].astype(wide) if accumulate else np.zeros(len(d_found[i]), dtype=wide)
+        hit = False
+        for j, b in enumerate(row):
+            if b.kind == "zero":
+                continue
+            hit = True
+            x = m_blocks[j].astype(wide)
+            if b.kind == "identity":
+                acc = acc + x
+            elif b.kind == "scale":
+                acc = acc + wide(b.scale) * x
+            else:
+                c = b.coeff.astype(wide)
+                acc = acc + (np.conj(c) if b.adjoint else c) * x
+        out.append(acc if hit else d_found[i].astype(wide))
+    return out
+
+
+KINDS5 = ("diag", "identity", "scale", "zero", "diag_adj")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,ncol,n,mix", [(1, 300, 64, False), (1, 1000, 20, True), (3, 260, 128, True), (2, 512, 7, True)])
+def test_split_general_forward_many_block_columns(Jets, oracle, knob, dt, nrow, ncol, n, mix):
+    """JetBlock_df! (src/Jets.jl:1010-1032) with hundreds of block columns of small blocks: the split walk accumulates into d as
+    found (1024), skips zero blocks, leaves a block row of zero blocks only untouched (1022); adj_split=0 is bit-exact."""
+    kind_of = (lambda i, j: "zero" if (i == 1 and mix) else KINDS5[(3 * i + j) % 5]) if mix else (lambda i, j: "diag")
+    A, ora = _general_case(Jets, oracle, dt, nrow, ncol, n, kind_of)
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=0)
+    hm = u01(oracle, dt, SEED_M, 0, ncol * n)
+    mb = [hm[j * n:(j + 1) * n].copy() for j in range(ncol)]
+    hd = u01(oracle, dt, SEED_D, 0, nrow * n)
+    db = [hd[i * n:(i + 1) * n].copy() for i in range(nrow)]
+    truth = np.concatenate(_truth_fwd(ora, db, mb, accumulate=True))
+    knob(-1)
+    d = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)                           # dirty: the reference adds into it
+    Jets.mul_(d, A, m)
+    assert Jets.tune_get("last_adj_parts") > 1
+    got = d.to_numpy()
+    assert rel_err(got, truth) < 4 * _tol(dt)
+    if mix and nrow > 1:
+        assert_bits_equal(got[n:2 * n], hd[n:2 * n], "block row of zero blocks only stays as found")
+    d2 = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    Jets.mul_(d2, A, m)
+    assert_bits_equal(d2.to_numpy(), got, "split forward, second run")
+    knob(0)
+    d3 = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    Jets.mul_(d3, A, m)
+    assert Jets.tune_get("last_adj_parts") == 1
+    ref = oracle.block_df(ora, [b.copy() for b in db], mb)
+    assert_bits_equal(d3.to_numpy(), np.concatenate(ref), "ordered forward (adj_split=0)")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,ncol,n", [(700, 1, 100), (300, 3, 64), (2000, 2, 9)])
+def test_split_general_adjoint_many_block_rows(Jets, oracle, knob, dt, nrow, ncol, n):
+    """JetBlock_df'! (1034-1057) of a tall MIXED operator (diag / identity / scale / zero / diag' rows -- not the all-diagonal
+    fast path): m zeroed, zero blocks skipped, rows summed per part and folded."""
+    kind_of = lambda i, j: KINDS5[(i + 2 * j) % 5]
+    A, ora = _general_case(Jets, oracle, dt, nrow, ncol, n, kind_of)
+    d = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    hd = u01(oracle, dt, SEED_D, 0, nrow * n)
+    db = [hd[i * n:(i + 1) * n].copy() for i in range(nrow)]
+    knob(-1)
+    mt = Jets.rand(Jets.domain(A), seed=99, stream=9)                             # dirty: must be overwritten (1042)
+    Jets.mul_(mt, A.H, d)
+    assert Jets.tune_get("last_adj_parts") > 1
+    got = mt.to_numpy().ravel(order="F")
+    # truth: the adjoint is the forward of the transposed block matrix with every child adjointed
+    oraT = [[oracle.Block(b.kind, n, n, coeff=b.coeff, scale=np.conj(b.scale), adjoint=not b.adjoint) if b.kind == "diag" else
+             oracle.Block(b.kind, n, n, scale=np.conj(b.scale)) for b in (ora[i][j] for i in range(nrow))] for j in range(ncol)]
+    truth = np.concatenate(_truth_fwd(oraT, [np.zeros(n, dtype=dt)] * ncol, db, accumulate=False))
+    assert rel_err(got, truth) < 4 * _tol(dt)
+    knob(0)
+    Jets.mul_(mt, A.H, d)
+    ref = oracle.block_df_adj(ora, [np.full(n, 3, dtype=dt) for _ in range(ncol)], db)
+    assert_bits_equal(mt.to_numpy().ravel(order="F"), np.concatenate(ref), "ordered adjoint (adj_split=0)")
+
+
+def test_split_general_nonlinear_forward(Jets, oracle, knob):
+    """JetBlock_f! (988-1008) through the split walk: no zero-block skip -- every child's output, a zero block's zeros included,
+    is added into d as found (1001)."""
+    dt, nrow, ncol, n = np.float64, 2, 300, 32
+    spc = Jets.JetSpace(dt, n)
+    rows, ora = [], []
+    for i in range(nrow):
+        r, o = [], []
+        for j in range(ncol):
+            if (i + j) % 3 == 0:
+                r.append(Jets.JopSquare(spc)); o.append(oracle.Block("square", n))
+            elif (i + j) % 3 == 1:
+                g = Jets.rand(spc, seed=31, stream=1000 * i + j)
+                r.append(Jets.JopDiagonal(g)); o.append(oracle.Block("diag", n, coeff=u01(oracle, dt, 31, 1000 * i + j, n)))
+            else:
+                r.append(Jets.JopZeroBlock(spc, spc)); o.append(oracle.Block("zero", n, n))
+        rows.append(r); ora.append(o)
+    F = Jets.blockop(rows)
+    m = Jets.rand(Jets.domain(F), seed=SEED_M, stream=0)
+    hm = u01(oracle, dt, SEED_M, 0, ncol * n)
+    mb = [hm[j * n:(j + 1) * n].copy() for j in range(ncol)]
+    hd = u01(oracle, dt, SEED_D, 0, nrow * n)
+    knob(0)
+    d0 = Jets.rand(Jets.range(F), seed=SEED_D, stream=0)
+    Jets.mul_(d0, F, m)
+    ref = oracle.block_f(ora, [hd[i * n:(i + 1) * n].copy() for i in range(nrow)], mb)
+    assert_bits_equal(d0.to_numpy(), np.concatenate(ref), "ordered JetBlock_f!")
+    knob(-1)
+    d1 = Jets.rand(Jets.range(F), seed=SEED_D, stream=0)
+    Jets.mul_(d1, F, m)
+    assert Jets.tune_get("last_adj_parts") > 1
+    assert rel_err(d1.to_numpy(), np.concatenate(ref)) < 1e-13

@@ -22,7 +22,7 @@ m, d = J.rand(J.domain(F), seed=2, stream=0), J.rand(J.range(F), seed=3, stream=
 unique = (4 + 3) * n * 4                                      # read d (2 blocks), m (3), write d (2)
 per_use = (4 + 6) * n * 4                                     # every block row reads its three inputs itself
 for xcd in (1, 0):
-    J.tune(general_xcd=xcd)
+    J.tune(general_xcd=2 if xcd else 0)
     ts = []
     for _ in range(3):
         e0 = J.Event().record()

@@ -92,6 +92,22 @@ for case in range(seed0, seed0 + ncases):
         ref_y = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt) for n in len_c], tmp)
         assert_bits_equal(y.to_numpy().ravel(order="F"), np.concatenate(ref_y), "A'A, " + tag)
         fused += 1
+        # every operator again with the rows / columns cut into k parts (split walk, tall and general kernels): tolerance parity
+        if max(nrow, ncol) >= 4:
+            J.tune(adj_split=int(rng.integers(2, 9)))
+            d2 = J.rand(J.range(A), seed=2, stream=case)
+            J.mul_(d2, A, m)
+            pf = J.tune_get("last_adj_parts")
+            mt2 = J.rand(J.domain(A), seed=4, stream=case)
+            J.mul_(mt2, A.H, dd)
+            pa = J.tune_get("last_adj_parts")
+            single = np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4
+            tol = 2e-5 if single else 1e-13                      # against the ORDERED sum, whose own rounding error is in there
+            e1 = wide_err(d2.to_numpy(), np.concatenate(ref_d))
+            e2 = wide_err(mt2.to_numpy().ravel(order="F"), np.concatenate(ref_m))
+            assert e1 < tol and e2 < tol, f"split walk: forward {e1:.2e} (parts {pf}), adjoint {e2:.2e} (parts {pa}), " + tag
+            gsplit = globals().get("gsplit", 0) + (pf > 1) + (pa > 1)
+            J.tune(adj_split=0)
         if ncol == 1 and nrow >= 4 and all(k == "diag" for r in kinds for k in r) and len_r[0] > 0:
             J.tune(adj_split=int(rng.integers(2, 9)))
             J.mul_(mt, A.H, dd)
@@ -110,4 +126,4 @@ for case in range(seed0, seed0 + ncases):
     if done % 100 == 0:
         print(f"{done} cases ok ({fused} composites, {split} split-row checks), {time.time() - t0:.0f} s", flush=True)
 J.tune(adj_split=-1)
-print(f"fuzz: {done} cases, all bit-exact vs the oracle ({fused} composites, {split} split-row checks), {time.time() - t0:.0f} s")
+print(f"fuzz: {done} cases, all bit-exact vs the oracle ({fused} composites, {split} split-row checks vs a wide sum, {globals().get('gsplit', 0)} split-walk launches within tolerance of the ordered result), {time.time() - t0:.0f} s")
