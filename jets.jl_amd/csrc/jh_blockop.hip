@@ -450,6 +450,22 @@ __global__ __launch_bounds__(1024) void k_fold_parts(const S *__restrict__ parts
     }
 }
 
+// out = c0 * t + c1 * out (c1 == 0: out = c0 * t) with partial ||out||^2: the epilogue of the fused adjoint update when the
+// row sum itself went through the split walk (real coefficients: a complex vector is 2n reals here)
+template <typename S>
+__global__ __launch_bounds__(256) void k_axpby_norm(S *__restrict__ out, const S *__restrict__ t, int64_t n_scalars, S c0, S c1,
+                                                    double *__restrict__ partials)
+{
+    double nrm = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_scalars; i += (int64_t)gridDim.x * 256) {
+        S r = c0 * t[i];
+        if (c1 != (S)0) { const S s2 = c1 * out[i]; r = r + s2; }
+        out[i] = r;
+        nrm += (double)r * (double)r;
+    }
+    wg_sum_store<256>(nrm, partials + blockIdx.x);
+}
+
 // fold the per-workgroup partials deterministically: workgroup b sums the contiguous chunk
 // [b*chunk, (b+1)*chunk) in a fixed order and writes out[b]; launched twice for large counts (1M -> 1024 -> 1)
 __global__ void k_sum_partials(const double *__restrict__ partials, int64_t n, int64_t chunk, double *__restrict__ out)
@@ -1167,6 +1183,27 @@ int launch_tall_adj(const jh_blockop *op, void *out, const void *in, int64_t n_s
     return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 1024>(op, out, in, n_scalars, sh, s_begin, s_end) : launch_tall_adj_u<S, E, NS, false, MODE, 1024>(op, out, in, n_scalars, sh, s_begin, s_end);
 }
 
+// Does the plain tall adjoint (MODE 0) take the split walk for this operator?  If so, reserve scratch for its slabs PLUS one
+// domain-sized temporary behind them and return that temporary: the kernels that have no split variant of their own
+// (fused adjoint update, JetSum adjoint) then run "split adjoint into the temporary + a small epilogue" instead of crawling.
+template <typename S, int NS>
+int split_adjoint_tmp(const jh_blockop *op, int64_t n_scalars, void **tmp)
+{
+    *tmp = nullptr;
+    if (op->nrow == 1) return JH_OK;
+    const TallShape sh = pick_adj_shape(n_scalars / NS, op->nrow, 0);
+    const int64_t gx0 = (n_scalars + (int64_t)sh.unroll * sh.wg * NS - 1) / ((int64_t)sh.unroll * sh.wg * NS);
+    int64_t parts = pick_adj_parts(gx0, op->nrow);
+    if (parts <= 1) return JH_OK;
+    const int64_t rows_per_part = (op->nrow + parts - 1) / parts;
+    parts = (op->nrow + rows_per_part - 1) / rows_per_part;
+    const size_t slab_bytes = ((size_t)parts * (size_t)n_scalars * sizeof(S) + 255) / 256 * 256;
+    void *base = nullptr;
+    JH_TRY(jh_ensure_scratch(slab_bytes + (size_t)n_scalars * sizeof(S), &base));
+    *tmp = (char *)base + slab_bytes;
+    return JH_OK;
+}
+
 // fast path usable?  (tall, all DIAG, uniform rows, 16-byte aligned everything, no conj flags on complex)
 bool tall_fast_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
 {
@@ -1428,6 +1465,22 @@ int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n
     const int64_t a_stride = op->diag_stride_elems * E;
     const int64_t nvec = n_scalars / NS;
     const int direct = op->nrow == 1 ? 1 : 0;
+    {   // many rows of small blocks: the row sum through the split walk of the plain adjoint, then out = (alpha*gamma)*t + beta*out
+        // with ||out||^2 in a small epilogue (tolerance parity, like every split sum)
+        void *tmp = nullptr;
+        JH_TRY((split_adjoint_tmp<S, NS>(op, n_scalars, &tmp)));
+        if (tmp) {
+            JH_TRY((launch_tall_adj<S, E, NS, 0>(op, tmp, in, n_scalars)));
+            int64_t g = (n_scalars + 255) / 256;
+            if (g > 2048) g = 2048;
+            JH_TRY(jh_ensure_partials(g));
+            hipLaunchKernelGGL((k_axpby_norm<S>), dim3((unsigned)g), dim3(256), 0, c.stream, (S *)out, (const S *)tmp, n_scalars,
+                               (S)(alpha * gamma), (S)beta, c.part_dev);
+            JH_CHECK_HIP(hipGetLastError());
+            return finish_normsq(g, normsq);
+        }
+    }
+    c.last_adj_parts = 1;
     int wg = 256, U = 1;
     if (nvec >= 4 * 256 * 256) U = 4;
     else if (nvec >= 2 * 256 * 256) U = 2;
@@ -1980,10 +2033,28 @@ static int sum_fwd_launch(const SumArgs &a, const jh_blockop *op0, void *d, cons
     return JH_OK;
 }
 
+// many rows of small blocks: every term's row sum through the split walk of the plain adjoint, combined term by term
+// (m = sum_k sign_k * scale_k * (A_k' d); tolerance parity)
+template <typename S, int E, int NS>
+static int sum_adj_split(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, void *m, const void *d,
+                         int64_t n_scalars, void *tmp)
+{
+    const int dtype = ops[0]->dtype;
+    const int64_t n_elems = n_scalars / E;
+    for (int t = 0; t < nterms; t++) {
+        JH_TRY((launch_tall_adj<S, E, NS, 0>(ops[t], tmp, d, n_scalars)));
+        const double cre[2] = {t == 0 ? sign[t] * scale[t] : 1.0, sign[t] * scale[t]}, cim[2] = {0.0, 0.0};
+        const void *xs[2] = {t == 0 ? tmp : m, tmp};
+        JH_TRY(jh_launch_lincomb_raw(m, dtype, n_elems, t == 0 ? 1 : 2, cre, cim, xs));
+    }
+    return JH_OK;
+}
+
 template <typename S, int E, int NS>
 static int sum_adj_launch(const SumArgs &a, const jh_blockop *op0, void *m, const void *d, int64_t n_scalars)
 {
     jh_context &c = jh_ctx();
+    c.last_adj_parts = 1;
     constexpr int BLK = 256, U = 2, DEPTH = 2;
     const int64_t nvec = n_scalars / NS;
     const int64_t gx = (nvec + (int64_t)BLK * U - 1) / ((int64_t)BLK * U);
@@ -2016,11 +2087,17 @@ int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *
     SumArgs a;
     JH_TRY(sum_prepare(nterms, ops, scale, sign, d, m, a, "jh_blocksum_mul_adj"));
     const int64_t n = ops[0]->row_len[0];
+    void *tmp = nullptr;
     switch (ops[0]->dtype) {
-    case JH_F32: return sum_adj_launch<float, 1, 4>(a, ops[0], m->data, d->data, n);
-    case JH_F64: return sum_adj_launch<double, 1, 2>(a, ops[0], m->data, d->data, n);
-    case JH_C32: return sum_adj_launch<float, 2, 4>(a, ops[0], m->data, d->data, 2 * n);
-    case JH_C64: return sum_adj_launch<double, 2, 2>(a, ops[0], m->data, d->data, 2 * n);
+#define JH_SUM_ADJ(S, E, NS, NSCAL)                                                                         \
+    JH_TRY((split_adjoint_tmp<S, NS>(ops[0], NSCAL, &tmp)));                                              \
+    if (tmp) return sum_adj_split<S, E, NS>(nterms, ops, scale, sign, m->data, d->data, NSCAL, tmp);      \
+    return sum_adj_launch<S, E, NS>(a, ops[0], m->data, d->data, NSCAL);
+    case JH_F32: JH_SUM_ADJ(float, 1, 4, n)
+    case JH_F64: JH_SUM_ADJ(double, 1, 2, n)
+    case JH_C32: JH_SUM_ADJ(float, 2, 4, 2 * n)
+    case JH_C64: JH_SUM_ADJ(double, 2, 2, 2 * n)
+#undef JH_SUM_ADJ
     }
     return jh_fail(JH_ERR_INVALID, "jh_blocksum_mul_adj: unknown dtype");
 }

@@ -325,3 +325,61 @@ def test_split_general_nonlinear_forward(Jets, oracle, knob):
     Jets.mul_(d1, F, m)
     assert Jets.tune_get("last_adj_parts") > 1
     assert rel_err(d1.to_numpy(), np.concatenate(ref)) < 1e-13
+
+
+# ---------------------------------------------------------------------------------- the kernels without a split variant of their own
+@pytest.mark.parametrize("dt", DTYPES)
+def test_split_fused_adjoint_update(Jets, oracle, knob, dt):
+    """jh_blockop_mul_adj_axpby (the adjoint half of an LSQR / CGLS iteration) on many small rows: the row sum goes through
+    the split walk of the plain adjoint, the axpby + norm through a small epilogue; adj_split=0 keeps the fused ordered kernel."""
+    from jets_jl_amd._ffi import lib, check
+
+    nrow, n = 900, 512
+    A, ha, _keep = _slab_operator(Jets, oracle, dt, nrow, n)
+    d = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    hd = u01(oracle, dt, SEED_D, 0, nrow * n).reshape(nrow, n)
+    hm = u01(oracle, dt, 41, 0, n)
+    alpha, beta, gamma = 0.75, -1.375, 0.5
+    wide = np.clongdouble if np.iscomplexobj(ha) else np.longdouble
+    truth = wide(alpha) * np.sum(np.conj(ha.astype(wide)) * (wide(gamma) * hd.astype(wide)), axis=0) + wide(beta) * hm.astype(wide)
+    out = C.c_double(0)
+    res = {}
+    for split in (-1, 0):
+        knob(split)
+        m = Jets.rand(Jets.domain(A), seed=41, stream=0)
+        check(lib.jh_blockop_mul_adj_axpby(_native(Jets, A).handle, m.handle, d.handle, alpha, beta, gamma, C.byref(out)))
+        got = m.to_numpy().ravel(order="F")
+        assert rel_err(got, truth) < (4 * _tol(dt) if split else 5e-5 if _tol(dt) > 1e-10 else 1e-13)
+        assert out.value == pytest.approx(float(np.sum(np.abs(got.astype(np.complex128)) ** 2)), rel=1e-6 if _tol(dt) > 1e-10 else 1e-13)
+        res[split] = got
+    assert Jets.tune_get("last_adj_parts") == 1                                   # the last call (adj_split=0) was the ordered kernel
+    assert rel_err(res[-1], res[0]) < (5e-5 if _tol(dt) > 1e-10 else 1e-13)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_split_jetsum_adjoint(Jets, oracle, knob, dt):
+    """(1.5*A1 - 2.0*A2)' d, src/Jets.jl:648-655, on many small rows: every term's row sum through the split walk."""
+    nrow, n = 800, 256
+    spc = Jets.JetSpace(dt, n)
+    g1 = Jets.rand(Jets.JetBSpace([spc] * nrow), seed=SEED_A, stream=0).arrays
+    g2 = Jets.rand(Jets.JetBSpace([spc] * nrow), seed=77, stream=0).arrays
+    A1 = Jets.blockop([[Jets.JopDiagonal(g)] for g in g1])
+    A2 = Jets.blockop([[Jets.JopDiagonal(g)] for g in g2])
+    h1 = u01(oracle, dt, SEED_A, 0, nrow * n).reshape(nrow, n)
+    h2 = u01(oracle, dt, 77, 0, nrow * n).reshape(nrow, n)
+    S = 1.5 * A1 - 2.0 * A2
+    d = Jets.rand(Jets.range(A1), seed=SEED_D, stream=0)
+    hd = u01(oracle, dt, SEED_D, 0, nrow * n).reshape(nrow, n)
+    wide = np.clongdouble if np.iscomplexobj(h1) else np.longdouble
+    truth = 1.5 * np.sum(np.conj(h1.astype(wide)) * hd.astype(wide), axis=0) - 2.0 * np.sum(np.conj(h2.astype(wide)) * hd.astype(wide), axis=0)
+    knob(-1)
+    got = (S.H * d).to_numpy().ravel(order="F")
+    assert Jets.tune_get("last_adj_parts") > 1
+    # the two terms nearly cancel (U[0,1) coefficients): measure against the size of the terms, not of the difference
+    scale = float(np.linalg.norm(np.abs(1.5 * np.sum(np.conj(h1.astype(wide)) * hd.astype(wide), axis=0)).astype(np.longdouble)))
+    err = float(np.linalg.norm(np.abs(got.astype(wide) - truth).astype(np.longdouble))) / scale
+    assert err < 4 * _tol(dt)
+    knob(0)
+    ordered = (S.H * d).to_numpy().ravel(order="F")
+    err0 = float(np.linalg.norm(np.abs(ordered.astype(wide) - truth).astype(np.longdouble))) / scale
+    assert err <= 4 * err0 + _tol(dt)
