@@ -99,8 +99,11 @@ class Event:
 
 
 def tune(**knobs) -> None:
-    """Kernel-shape knobs of the tall fast path (bench/tests): fwd_group, fwd_unroll, fwd_wg, adj_unroll,
-    adj_depth, adj_wg (0 = pick from the problem size) and nt."""
+    """Kernel-shape knobs (bench/tests): fwd_group, fwd_unroll, fwd_wg, adj_unroll, adj_depth, adj_wg (0 = pick from the
+    problem size), fwd_order, nt, autotune, graphs, general_xcd (1 automatic / 0 never / 2 always) and -- the one with a
+    numerical meaning -- adj_split: -1 (default) lets the kernels that sum over block rows / columns cut a long sum of
+    SMALL blocks into parts (deterministic, tolerance parity), 0 keeps the reference's ordered sum
+    always (bit-exact against the sequential CPU loop, up to 100x slower on such shapes), k > 1 forces k parts."""
     for k, v in knobs.items():
         check(lib.jh_tune_set(k.encode(), int(v)))
 
