@@ -116,6 +116,239 @@ __global__ void k_sum_col_chunks(const double *__restrict__ partial, int64_t nc,
     if (E == 2) y[c * E + 1] = (S)si;
 }
 
+// ---- the same two kernels BATCHED over the children of a tall block operator of dense blocks (blockIdx.z = child) -----------
+// A tall operator of N dense children run child by child is N tiny launches in a row -- a 256 x 256 child keeps ONE workgroup
+// busy for ~100 us, so 4096 of them (1 GiB) take 413 ms forward (profiles/bench_dense_blocks_r01.txt).  Batched, the chip sees
+// all children at once.  Uniform children only (same nr x nc, none adjointed); child z's matrix is blocks[z].coeff, its range
+// block sits at y + z*nr*E (the slab layout), the domain vector x is shared.
+template <typename S, int E, int NS>
+__global__ __launch_bounds__(256) void k_gemv_rows_batched(const jh_dev_block *__restrict__ blocks, int64_t z0, int64_t nr, int64_t nc,
+                                                           const S *__restrict__ x, S *__restrict__ out, int64_t child_stride,
+                                                           int64_t chunk_stride, int64_t cols_per_chunk)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * NS;
+    const int64_t ns = nr * E;
+    if (s >= ns) return;
+    const int64_t z = z0 + blockIdx.z;
+    const S *A = (const S *)blocks[z].coeff;
+    const int64_t c0 = (int64_t)blockIdx.y * cols_per_chunk;
+    const int64_t c1 = c0 + cols_per_chunk < nc ? c0 + cols_per_chunk : nc;
+    V acc = (V)(S)0;
+    const S *col = A + c0 * ns + s;
+#pragma unroll 4
+    for (int64_t c = c0; c < c1; c++, col += ns) {                              // columns in order, product rounded then added
+        V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col));
+        if constexpr (E == 1) {
+            acc = acc + a * (V)x[c];
+        } else {
+            const S xr = x[2 * c], xi = x[2 * c + 1];
+            V p;
+#pragma unroll
+            for (int e = 0; e < NS; e += 2) {
+                p[e] = a[e] * xr - a[e + 1] * xi;
+                p[e + 1] = a[e] * xi + a[e + 1] * xr;
+            }
+            acc = acc + p;
+        }
+    }
+    *reinterpret_cast<V *>(out + z * child_stride + (int64_t)blockIdx.y * chunk_stride + s) = acc;
+}
+
+// y[z][k] = sum over column chunks (in order) of partial[z][chunk][k]
+template <typename S>
+__global__ void k_sum_chunks_batched(const S *__restrict__ partial, int64_t ns, int nchunks, S *__restrict__ y)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= ns) return;
+    const int64_t z = blockIdx.y;
+    const S *p = partial + z * nchunks * ns + k;
+    S acc = p[0];
+    for (int c = 1; c < nchunks; c++) acc = acc + p[(int64_t)c * ns];
+    y[z * ns + k] = acc;
+}
+
+// partial[z][chunk][c] = sum over the chunk's rows of conj(A_z[r,c]) * d_z[r]   (fp64, one wave per column)
+template <typename S, int E, int NS>
+__global__ __launch_bounds__(256) void k_gemv_cols_batched(const jh_dev_block *__restrict__ blocks, int64_t z0, int64_t nr, int64_t nc,
+                                                           const S *__restrict__ d, double *__restrict__ partial, int64_t rows_per_chunk)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= nc) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t z = z0 + blockIdx.z;
+    const int64_t ns = nr * E;
+    const int64_t s0 = (int64_t)blockIdx.y * rows_per_chunk * E;
+    const int64_t s1 = s0 + rows_per_chunk * E < ns ? s0 + rows_per_chunk * E : ns;
+    const S *col = (const S *)blocks[z].coeff + c * ns;
+    const S *x = d + z * ns;
+    double sr = 0.0, si = 0.0;
+    for (int64_t s = s0 + (int64_t)lane * NS; s < s1; s += 64 * NS) {
+        V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col + s));
+        V xv = *reinterpret_cast<const V *>(x + s);
+        if constexpr (E == 1) {
+#pragma unroll
+            for (int e = 0; e < NS; e++) {
+                if constexpr (NS == 1) sr += (double)a * (double)xv;
+                else sr += (double)a[e] * (double)xv[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NS; e += 2) {
+                const double ar = a[e], ai = -(double)a[e + 1], xr = xv[e], xi = xv[e + 1];
+                sr += ar * xr - ai * xi;
+                si += ar * xi + ai * xr;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sr += __shfl_down(sr, off, 64);
+        if (E == 2) si += __shfl_down(si, off, 64);
+    }
+    if (lane == 0) {
+        double *p = partial + (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * nc + c) * 2;
+        p[0] = sr;
+        p[1] = si;
+    }
+}
+
+// group sums: group g = children [g*per_group, (g+1)*per_group) of this launch: mtmp_z = A_z' d_z (its row chunks added, then
+// rounded to the element type like the per-child kernel does, 1049) summed over the group's children in fp64 -- 64 column lanes
+// x 4 child lanes per workgroup, fixed order; k_fold_groups adds the groups.  Two stages so that thousands of small children
+// do not queue behind nc/64 workgroups.
+template <typename S, int E>
+__global__ __launch_bounds__(256) void k_fold_children(const double *__restrict__ partial, int64_t nc, int nchunks, int nchild, int per_group,
+                                                       double *__restrict__ group_sums)
+{
+    __shared__ double sm[4][64][2];
+    const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + v;
+    const int zlo = (int)blockIdx.y * per_group, zhi = zlo + per_group < nchild ? zlo + per_group : nchild;
+    double tr = 0.0, ti = 0.0;
+    if (c < nc) {
+        for (int z = zlo + q; z < zhi; z += 4) {
+            double sr = 0.0, si = 0.0;
+            const double *p = partial + ((int64_t)z * nchunks * nc + c) * 2;
+            for (int k = 0; k < nchunks; k++) { sr += p[(int64_t)k * nc * 2]; si += p[(int64_t)k * nc * 2 + 1]; }
+            tr += (double)(S)sr;
+            if (E == 2) ti += (double)(S)si;
+        }
+    }
+    sm[q][v][0] = tr;
+    sm[q][v][1] = ti;
+    __syncthreads();
+    if (q == 0 && c < nc) {
+        double r = 0.0, i = 0.0;
+        for (int qq = 0; qq < 4; qq++) { r += sm[qq][v][0]; i += sm[qq][v][1]; }
+        group_sums[((int64_t)blockIdx.y * nc + c) * 2] = r;
+        group_sums[((int64_t)blockIdx.y * nc + c) * 2 + 1] = i;
+    }
+}
+
+template <typename S, int E>
+__global__ void k_fold_groups(const double *__restrict__ group_sums, int64_t nc, int ngroups, S *__restrict__ m, int accumulate)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nc) return;
+    double r = accumulate ? (double)m[c * E] : 0.0, i = (E == 2 && accumulate) ? (double)m[c * E + 1] : 0.0;
+    for (int g = 0; g < ngroups; g++) { r += group_sums[((int64_t)g * nc + c) * 2]; i += group_sums[((int64_t)g * nc + c) * 2 + 1]; }
+    m[c * E] = (S)r;
+    if (E == 2) m[c * E + 1] = (S)i;
+}
+
+template <typename S, int E>
+int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, void *y, const void *x, int adjoint, bool aligned)
+{
+    jh_context &c = jh_ctx();
+    hipStream_t st = c.stream;
+    constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
+    const int64_t ns = nr * E;
+    const bool vec_ok = aligned && ((ns * (int64_t)sizeof(S)) % 16 == 0) && ((((uintptr_t)x) | ((uintptr_t)y)) & 15u) == 0;
+    const double child_bytes = (double)nr * (double)nc * sizeof(S) * E;
+    const int64_t zmax = 32768;                                                // gridDim.z
+    if (!adjoint) {                                                            // d_z = A_z m for every child
+        const int NS = vec_ok ? NSV : E;
+        const int64_t row_wgs = (ns / NS + 255) / 256;
+        int64_t nchunks = 1;                                                   // split the columns only while the chip is not full
+        if (child_bytes >= (double)(1 << 20) && row_wgs * nchild < 2048) {
+            nchunks = (2048 + row_wgs * nchild - 1) / (row_wgs * nchild);
+            const int64_t maxc = (nc + 31) / 32;
+            if (nchunks > maxc) nchunks = maxc;
+        }
+        const int64_t cpc = (nc + nchunks - 1) / nchunks;
+        nchunks = (nc + cpc - 1) / cpc;
+        S *out = (S *)y;
+        int64_t child_stride = ns, chunk_stride = 0;
+        if (nchunks > 1) {
+            JH_TRY(jh_ensure_partials(((int64_t)nchild * nchunks * ns * (int64_t)sizeof(S) + 7) / 8 + 2));
+            out = (S *)c.part_dev;
+            child_stride = nchunks * ns;
+            chunk_stride = ns;
+        }
+        for (int64_t z0 = 0; z0 < nchild; z0 += zmax) {
+            const unsigned gz = (unsigned)(nchild - z0 < zmax ? nchild - z0 : zmax);
+            if (vec_ok)
+                hipLaunchKernelGGL((k_gemv_rows_batched<S, E, NSV>), dim3((unsigned)row_wgs, (unsigned)nchunks, gz), dim3(256), 0, st, dev_blocks, z0,
+                                   nr, nc, (const S *)x, out, child_stride, chunk_stride, cpc);
+            else
+                hipLaunchKernelGGL((k_gemv_rows_batched<S, E, E>), dim3((unsigned)row_wgs, (unsigned)nchunks, gz), dim3(256), 0, st, dev_blocks, z0,
+                                   nr, nc, (const S *)x, out, child_stride, chunk_stride, cpc);
+            JH_CHECK_HIP(hipGetLastError());
+        }
+        if (nchunks > 1) {
+            JH_REQUIRE(nchild <= 65535, "batched dense forward: too many children for the chunk fold");
+            hipLaunchKernelGGL((k_sum_chunks_batched<S>), dim3((unsigned)((ns + 255) / 256), (unsigned)nchild), dim3(256), 0, st, out, ns,
+                               (int)nchunks, (S *)y);
+            JH_CHECK_HIP(hipGetLastError());
+        }
+        return JH_OK;
+    }
+    // m = sum_z A_z' d_z  (the caller's m is overwritten: `_m .= 0` then `_m .+= mtmp`, 1042-1049)
+    const int64_t col_wgs = (nc + 3) / 4;
+    int64_t nchunks = 1;
+    if (child_bytes >= (double)(1 << 20) && col_wgs * nchild < 2048) {
+        nchunks = (2048 + col_wgs * nchild - 1) / (col_wgs * nchild);
+        const int64_t maxc = (nr + 4095) / 4096;
+        if (nchunks > maxc) nchunks = maxc;
+        if (nchunks < 1) nchunks = 1;
+    }
+    int64_t rpc = (nr + nchunks - 1) / nchunks;
+    rpc = (rpc + 3) / 4 * 4;
+    if (rpc < 4) rpc = 4;
+    nchunks = nr ? (nr + rpc - 1) / rpc : 1;
+    int64_t zstep = zmax;                                                      // bound the fp64 partials to 64 MiB per launch
+    while (zstep > 1 && (double)zstep * (double)nchunks * (double)nc * 16.0 > 64.0 * (double)(1 << 20)) zstep /= 2;
+    for (int64_t z0 = 0; z0 < nchild; z0 += zstep) {
+        const int64_t gz = nchild - z0 < zstep ? nchild - z0 : zstep;
+        const int64_t fold_wgs = (nc + 63) / 64;
+        int64_t ngroups = (2048 + fold_wgs - 1) / fold_wgs;                    // enough workgroups for the fold of many small children
+        if (ngroups > gz / 8) ngroups = gz / 8;
+        if (ngroups < 1) ngroups = 1;
+        const int64_t per_group = (gz + ngroups - 1) / ngroups;
+        ngroups = (gz + per_group - 1) / per_group;
+        const int64_t npart = 2 * gz * nchunks * nc;
+        JH_TRY(jh_ensure_partials(npart + 2 * ngroups * nc));
+        double *group_sums = c.part_dev + npart;
+        const S *d0 = (const S *)x;
+        if (vec_ok)
+            hipLaunchKernelGGL((k_gemv_cols_batched<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)gz), dim3(256), 0, st, dev_blocks,
+                               z0, nr, nc, d0, c.part_dev, rpc);
+        else
+            hipLaunchKernelGGL((k_gemv_cols_batched<S, E, E>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)gz), dim3(256), 0, st, dev_blocks,
+                               z0, nr, nc, d0, c.part_dev, rpc);
+        JH_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL((k_fold_children<S, E>), dim3((unsigned)fold_wgs, (unsigned)ngroups), dim3(256), 0, st, c.part_dev, nc, (int)nchunks,
+                           (int)gz, (int)per_group, group_sums);
+        JH_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL((k_fold_groups<S, E>), dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, group_sums, nc, (int)ngroups, (S *)y,
+                           z0 > 0 ? 1 : 0);
+        JH_CHECK_HIP(hipGetLastError());
+    }
+    return JH_OK;
+}
+
 template <typename S, int E>
 int gemv(const void *A, int64_t nr, int64_t nc, void *y, const void *x, int adjoint)
 {
@@ -196,6 +429,19 @@ int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, co
     case JH_C64: return gemv<double, 2>(A, nr, nc, y, x, adjoint);
     }
     return jh_fail(JH_ERR_INVALID, "gemv: unknown dtype %d", dtype);
+}
+
+// all children of a tall operator of uniform dense blocks in one go (jh_blockop.hip); `aligned`: every matrix pointer on 16 bytes
+int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, int dtype, void *y, const void *x,
+                           int adjoint, bool aligned)
+{
+    switch (dtype) {
+    case JH_F32: return gemv_batched<float, 1>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
+    case JH_F64: return gemv_batched<double, 1>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
+    case JH_C32: return gemv_batched<float, 2>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
+    case JH_C64: return gemv_batched<double, 2>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
+    }
+    return jh_fail(JH_ERR_INVALID, "gemv_batched: unknown dtype %d", dtype);
 }
 
 extern "C" int jh_gemv(const void *A_device, int64_t nr, int64_t nc, int dtype, jh_bvec *y, const jh_bvec *x, int adjoint)

@@ -1,0 +1,103 @@
+"""GPU parity: tall block operators of DENSE children (the reference's JopBaz, test/runtests.jl:27-33; the tall-and-skinny test
+set 720-742 is built from exactly these) through the BATCHED GEMV kernels of jh_dense.hip -- every child of the operator in
+one launch instead of one tiny launch per child.
+
+Bar: forward BIT-EXACT against the oracle's loop (each output row: columns in order, product rounded then added) while the
+columns are not split, i.e. whenever the children alone fill the chip or a child is below 1 MiB; adjoint within rel-l2 1e-6
+(Float32 / ComplexF32) or 1e-14 of an 80-bit host sum (it is a wave reduction in fp64 -- tolerance parity, like the per-child
+kernel it replaces and like any BLAS).
+"""
+import numpy as np
+import pytest
+
+from .helpers import DTYPES, SEED_D, SEED_M, assert_bits_equal, u01
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(dt):
+    return 1e-6 if np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-14
+
+
+def _err(a, b):
+    a, b = np.asarray(a, dtype=np.clongdouble).ravel(), np.asarray(b, dtype=np.clongdouble).ravel()
+    return float(np.linalg.norm(np.abs(a - b).astype(np.longdouble)) / np.linalg.norm(np.abs(b).astype(np.longdouble)))
+
+
+def _tall_dense(Jets, oracle, dt, nchild, nr, nc, seed=900):
+    mats, ora = [], []
+    for z in range(nchild):
+        hA = np.asfortranarray(u01(oracle, dt, seed, z, nr * nc).reshape((nr, nc), order="F"))
+        mats.append(hA)
+        ora.append([oracle.Block("dense", nr, nc, coeff=hA)])
+    A = Jets.blockop([[Jets.JopDense(Jets.from_numpy(hA))] for hA in mats])
+    return A, ora, mats
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nchild,nr,nc", [(2, 8, 8), (3, 10, 10), (5, 64, 48), (40, 33, 7), (300, 16, 128), (7, 256, 512), (1100, 2, 4096)])
+def test_batched_dense_children_forward_and_adjoint(Jets, oracle, dt, nchild, nr, nc):
+    if nchild * nr * nc * np.dtype(dt).itemsize > (1 << 28):
+        pytest.skip("kept small")
+    A, ora, mats = _tall_dense(Jets, oracle, dt, nchild, nr, nc)
+    assert Jets.nblocks_op(A) == (nchild, 1)
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=0)
+    hm = u01(oracle, dt, SEED_M, 0, nc)
+    d = Jets.rand(Jets.range(A), seed=5, stream=5)                                # dirty: every row is overwritten (1026)
+    Jets.mul_(d, A, m)
+    ref_d = oracle.block_df(ora, [np.full(nr, 9, dtype=dt) for _ in range(nchild)], [hm])
+    item = np.dtype(dt).itemsize
+    lanes = -(-(nr * item) // 16)                                                 # 16-byte packs per column
+    split = nr * nc * item >= (1 << 20) and -(-lanes // 256) * nchild < 2048       # big children that do not fill the chip: columns split
+    if split:
+        assert _err(d.to_numpy(), np.concatenate(ref_d)) < _tol(dt)
+    else:
+        assert_bits_equal(d.to_numpy(), np.concatenate(ref_d), "A*m == [B1 m; B2 m; ...]  (test/runtests.jl:724)")
+    dd = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    hd = u01(oracle, dt, SEED_D, 0, nchild * nr).reshape(nchild, nr)
+    mt = Jets.rand(Jets.domain(A), seed=6, stream=6)                              # dirty: zeroed first (1042)
+    Jets.mul_(mt, A.H, dd)
+    wide = np.clongdouble if np.iscomplexobj(mats[0]) else np.longdouble
+    truth = sum(np.conj(mats[z].astype(wide)).T @ hd[z].astype(wide) for z in range(nchild))   # A'd == sum_i B_i' d_i  (:733)
+    assert _err(mt.to_numpy().ravel(order="F"), truth) < _tol(dt)
+    again = Jets.zeros(Jets.domain(A))
+    Jets.mul_(again, A.H, dd)
+    assert_bits_equal(again.to_numpy(), mt.to_numpy(), "batched dense adjoint, second run")
+    lhs, rhs = Jets.dot_product_test(A, m, dd)
+    assert abs(lhs - rhs) / abs(lhs + rhs) < (1e-5 if _tol(dt) > 1e-10 else 1e-12)
+
+
+def test_batched_dense_large_children_split_columns(Jets, oracle):
+    """Few big children: the columns are split over the grid until the chip is full (partial rows added in chunk order):
+    tolerance parity for the forward, like the single-matrix kernel on a large matrix."""
+    dt, nchild, nr, nc = np.float32, 3, 512, 2048                                 # 4 MiB per child
+    A, ora, mats = _tall_dense(Jets, oracle, dt, nchild, nr, nc)
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=0)
+    hm = u01(oracle, dt, SEED_M, 0, nc)
+    d = A * m
+    truth = np.concatenate([mats[z].astype(np.float64) @ hm.astype(np.float64) for z in range(nchild)])
+    assert _err(d.to_numpy(), truth) < 1e-6
+    dd = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    hd = u01(oracle, dt, SEED_D, 0, nchild * nr).reshape(nchild, nr)
+    mt = A.H * dd
+    truth_m = sum(mats[z].astype(np.float64).T @ hd[z].astype(np.float64) for z in range(nchild))
+    assert _err(mt.to_numpy().ravel(order="F"), truth_m) < 1e-6
+
+
+def test_adjointed_or_ragged_dense_children_keep_the_loop(Jets, oracle):
+    """A child carrying the adjoint flag, or children of different shapes, are outside the batched kernels: the reference's
+    per-block loop runs (and still matches the oracle)."""
+    dt = np.float64
+    hA = [np.asfortranarray(u01(oracle, dt, 901, z, 12 * 12).reshape((12, 12), order="F")) for z in range(3)]
+    dev = [Jets.JopDense(Jets.from_numpy(a)) for a in hA]
+    A = Jets.blockop([[dev[0]], [dev[1].H], [dev[2]]])
+    ora = [[oracle.Block("dense", 12, 12, coeff=hA[0])], [oracle.Block("dense", 12, 12, coeff=hA[1], adjoint=True)], [oracle.Block("dense", 12, 12, coeff=hA[2])]]
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=0)
+    hm = u01(oracle, dt, SEED_M, 0, 12)
+    ref = oracle.block_df(ora, [np.zeros(12, dtype=dt) for _ in range(3)], [hm])
+    assert _err((A * m).to_numpy(), np.concatenate(ref)) < 1e-14
+    hB = np.asfortranarray(u01(oracle, dt, 902, 0, 5 * 12).reshape((5, 12), order="F"))
+    B = Jets.blockop([[dev[0]], [Jets.JopDense(Jets.from_numpy(hB))]])
+    refB = oracle.block_df([[oracle.Block("dense", 12, 12, coeff=hA[0])], [oracle.Block("dense", 5, 12, coeff=hB)]],
+                           [np.zeros(12, dtype=dt), np.zeros(5, dtype=dt)], [hm])
+    assert_bits_equal((B * m).to_numpy(), np.concatenate(refB), "ragged dense children")
