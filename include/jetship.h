@@ -162,7 +162,9 @@ int jh_bcast_compile(const char *expr, int dtype, int nvec, int nscal, jh_bcast 
 int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, const double *scal_re_im);
 /* `count` broadcasts in one call (a tall nonlinear operator evaluates one per child: F(m) and point! are `count` launches
  * enqueued back to back instead of `count` trips through the host language).  Operand k's vectors and scalars follow
- * each other in the flattened lists `x` (sum of nvec entries) and `scal_re_im` (2 * sum of nscal doubles). */
+ * each other in the flattened lists `x` (sum of nvec entries) and `scal_re_im` (2 * sum of nscal doubles).  Items that share
+ * the program, the length and 16-byte alignment, and whose operands do not overlap another item's destination, run as ONE
+ * launch (same bits); otherwise the items are launched in order. */
 int jh_bcast_apply_many(int count, const jh_bcast *const *progs, jh_bvec *const *dsts, const jh_bvec *const *x, const double *scal_re_im);
 int jh_bcast_destroy(jh_bcast *bc);
 /* dot(x,y), src/Jets.jl:850-856 (conjugates x). fp64 accumulation, deterministic order. */

@@ -11,9 +11,11 @@
 
 #include <hip/hiprtc.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 
 struct jh_bcast {
     int dtype = JH_F32;
@@ -21,6 +23,7 @@ struct jh_bcast {
     hipModule_t module = nullptr;
     hipFunction_t fn_vec = nullptr;     // 16 bytes per lane (every operand 16-byte aligned)
     hipFunction_t fn_scalar = nullptr;  // one element per lane (views at odd offsets)
+    hipFunction_t fn_batched = nullptr; // fn_vec over MANY equally long destinations at once (blockIdx.y = item; pointers from a table)
     std::string expr;
 };
 
@@ -110,6 +113,26 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
     for (int k = 0; k < nvec; k++) s += "            const T x" + std::to_string(k) + " = GET(X" + std::to_string(k) + ", e);\n";
     s += "            const T val_ = (T)(" + expr + ");\n            PUT(r_, e, val_);\n        }\n";
     s += "        __builtin_nontemporal_store(r_, (gvq)dst_ + v);\n    }\n}\n";
+    // ---- 16 bytes per lane, batched: item blockIdx.y takes its destination, operands and scalars from device tables
+    // (jh_bcast_apply_many: the children of a tall nonlinear operator in ONE launch instead of one launch per child)
+    s += "extern \"C\" __global__ __launch_bounds__(256) void jh_bcast_vec_batched(const void *const *tbl_, const R *sc_, long n_scalars)\n{\n";
+    s += "    const void *const *row_ = tbl_ + (long)blockIdx.y * " + std::to_string(nvec + 1) + ";\n";
+    s += "    R *dst_ = (R *)row_[0];\n";
+    for (int k = 0; k < nvec; k++) s += "    const R *p" + std::to_string(k) + " = (const R *)row_[" + std::to_string(k + 1) + "];\n";
+    if (nscal > 0) s += "    const R *srow_ = sc_ + (long)blockIdx.y * " + std::to_string(2 * nscal) + ";\n";
+    for (int k = 0; k < nscal; k++) {
+        const std::string i = std::to_string(k);
+        s += "    const R sr" + i + " = srow_[" + std::to_string(2 * k) + "], si" + i + " = srow_[" + std::to_string(2 * k + 1) + "];\n";
+    }
+    s += scal;
+    s += "    const long nvec = n_scalars / " + std::to_string(NS) + ";\n";
+    s += "    const long stride = (long)gridDim.x * 256;\n";
+    s += "    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {\n";
+    for (int k = 0; k < nvec; k++) s += "        const V X" + std::to_string(k) + " = __builtin_nontemporal_load((gvp)p" + std::to_string(k) + " + v);\n";
+    s += "        V r_;\n#pragma unroll\n        for (int e = 0; e < " + std::to_string(NS / E) + "; e++) {\n";
+    for (int k = 0; k < nvec; k++) s += "            const T x" + std::to_string(k) + " = GET(X" + std::to_string(k) + ", e);\n";
+    s += "            const T val_ = (T)(" + expr + ");\n            PUT(r_, e, val_);\n        }\n";
+    s += "        __builtin_nontemporal_store(r_, (gvq)dst_ + v);\n    }\n}\n";
     // ---- one element per lane
     s += "extern \"C\" __global__ __launch_bounds__(256) void jh_bcast_scalar(" + params + ")\n{\n" + scal;
     s += "    const long nel = n_scalars / " + std::to_string(E) + ";\n";
@@ -172,6 +195,7 @@ int compile(const std::string &expr, int dtype, int nvec, int nscal, jh_bcast **
     hipError_t e = hipModuleLoadData(&bc->module, code.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&bc->fn_vec, bc->module, "jh_bcast_vec");
     if (e == hipSuccess) e = hipModuleGetFunction(&bc->fn_scalar, bc->module, "jh_bcast_scalar");
+    if (e == hipSuccess) e = hipModuleGetFunction(&bc->fn_batched, bc->module, "jh_bcast_vec_batched");
     if (e != hipSuccess) {
         if (bc->module) (void)hipModuleUnload(bc->module);
         delete bc;
@@ -263,9 +287,88 @@ int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, co
     return JH_OK;
 }
 
+// every item the SAME program, equally long, every pointer on 16 bytes: one launch over (packs, items) with device tables.
+// Returns JH_OK with *done = false when the request is not of that shape (the caller then launches item by item).
+static int apply_many_batched(int count, const jh_bcast *const *progs, jh_bvec *const *dsts, const jh_bvec *const *xs, const double *scal_re_im,
+                              bool *done)
+{
+    *done = false;
+    const jh_bcast *bc = progs[0];
+    if (count < 4 || !bc || !bc->fn_batched || !dsts[0]) return JH_OK;
+    const bool cplx = jh_dtype_complex(bc->dtype), is64 = (bc->dtype == JH_F64 || bc->dtype == JH_C64);
+    const int NS = is64 ? 2 : 4;
+    const int64_t len = dsts[0]->length, n_scalars = len * (cplx ? 2 : 1);
+    if (len == 0 || n_scalars % NS != 0 || (bc->nvec > 0 && !xs) || (bc->nscal > 0 && !scal_re_im)) return JH_OK;
+    uintptr_t bits = 0;
+    for (int k = 0; k < count; k++) {
+        if (progs[k] != bc || !dsts[k] || dsts[k]->length != len || dsts[k]->dtype != bc->dtype) return JH_OK;
+        bits |= (uintptr_t)dsts[k]->data;
+        for (int j = 0; j < bc->nvec; j++) {
+            const jh_bvec *x = xs[(int64_t)k * bc->nvec + j];
+            if (!x || x->dtype != bc->dtype || x->length != len) return JH_OK;      // the item-by-item path reports the error
+            bits |= (uintptr_t)x->data;
+        }
+    }
+    if (bits & 15u) return JH_OK;
+    {   // one launch has no order between items: an operand must not overlap ANOTHER item's destination (its own is fine, elementwise)
+        const size_t bytes = (size_t)len * jh_dtype_size(bc->dtype);
+        std::vector<std::pair<uintptr_t, int>> dst_lo((size_t)count);
+        for (int k = 0; k < count; k++) dst_lo[(size_t)k] = {(uintptr_t)dsts[k]->data, k};
+        std::sort(dst_lo.begin(), dst_lo.end());
+        for (size_t k = 1; k < dst_lo.size(); k++)
+            if (dst_lo[k].first < dst_lo[k - 1].first + bytes) return JH_OK;      // overlapping destinations
+        for (int k = 0; k < count; k++)
+            for (int j = 0; j < bc->nvec; j++) {
+                const uintptr_t lo = (uintptr_t)xs[(int64_t)k * bc->nvec + j]->data;
+                auto it = std::lower_bound(dst_lo.begin(), dst_lo.end(), std::make_pair(lo, -1));
+                if (it != dst_lo.end() && it->first < lo + bytes && !(it->second == k && it->first == lo)) return JH_OK;
+                if (it != dst_lo.begin()) {
+                    --it;
+                    if (it->first + bytes > lo && !(it->second == k && it->first == lo)) return JH_OK;
+                }
+            }
+    }
+    JH_TRY(jh_require_ready());
+    const size_t row = (size_t)bc->nvec + 1, tbl_bytes = ((size_t)count * row * sizeof(void *) + 255) / 256 * 256;
+    const size_t sc_bytes = (size_t)count * 2 * (size_t)bc->nscal * (is64 ? 8 : 4);
+    std::vector<const void *> tbl((size_t)count * row);
+    for (int k = 0; k < count; k++) {
+        tbl[(size_t)k * row] = dsts[k]->data;
+        for (int j = 0; j < bc->nvec; j++) tbl[(size_t)k * row + 1 + j] = xs[(int64_t)k * bc->nvec + j]->data;
+    }
+    std::vector<float> scf;
+    std::vector<double> scd;
+    const size_t nsc = (size_t)count * 2 * (size_t)bc->nscal;
+    if (is64) scd.assign(scal_re_im, scal_re_im + nsc);
+    else { scf.resize(nsc); for (size_t i = 0; i < nsc; i++) scf[i] = (float)scal_re_im[i]; }
+    void *dev = nullptr;
+    JH_TRY(jh_ensure_scratch(tbl_bytes + sc_bytes + 16, &dev));
+    hipStream_t st = jh_ctx().stream;
+    JH_CHECK_HIP(hipMemcpyAsync(dev, tbl.data(), (size_t)count * row * sizeof(void *), hipMemcpyHostToDevice, st));
+    if (nsc) JH_CHECK_HIP(hipMemcpyAsync((char *)dev + tbl_bytes, is64 ? (const void *)scd.data() : (const void *)scf.data(), sc_bytes, hipMemcpyHostToDevice, st));
+    JH_CHECK_HIP(hipStreamSynchronize(st));                   // the staging vectors die at return (the copies are tiny)
+    int64_t gx = (n_scalars / NS + 255) / 256;
+    if (gx > 65535) gx = 65535;                               // the kernel strides
+    for (int k0 = 0; k0 < count; k0 += 65535) {
+        const int gy = count - k0 < 65535 ? count - k0 : 65535;
+        const void *tbl_arg = (const char *)dev + (size_t)k0 * row * sizeof(void *);
+        const void *sc_arg = (const char *)dev + tbl_bytes + (size_t)k0 * 2 * (size_t)bc->nscal * (is64 ? 8 : 4);
+        long n_arg = (long)n_scalars;
+        void *args[3] = {&tbl_arg, &sc_arg, &n_arg};
+        JH_CHECK_HIP(hipModuleLaunchKernel(bc->fn_batched, (unsigned)gx, (unsigned)gy, 1, 256, 1, 1, 0, st, args, nullptr));
+    }
+    *done = true;
+    return JH_OK;
+}
+
 int jh_bcast_apply_many(int count, const jh_bcast *const *progs, jh_bvec *const *dsts, const jh_bvec *const *xs, const double *scal_re_im)
 {
     JH_REQUIRE(count >= 0 && (count == 0 || (progs && dsts)), "jh_bcast_apply_many: null argument");
+    if (count > 0) {
+        bool done = false;
+        JH_TRY(apply_many_batched(count, progs, dsts, xs, scal_re_im, &done));
+        if (done) return JH_OK;
+    }
     int64_t ix = 0, is = 0;                                   // running offsets into the flattened operand / scalar lists
     for (int k = 0; k < count; k++) {
         JH_REQUIRE(progs[k], "jh_bcast_apply_many: program %d is null", k);

@@ -132,3 +132,38 @@ def test_errors_are_reported_not_crashes(Jets):
         Jets.broadcast_(out, "x0", [u] * 9)                                           # more than 8 vector operands
     Jets.broadcast_(out, "x0", [u])                                                   # the context is still healthy
     assert_bits_equal(out.to_numpy(), u.to_numpy(), "copy")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
+def test_many_broadcasts_in_one_launch_equal_item_by_item(Jets, dt):
+    """jh_bcast_apply_many: items that share the program, the length and 16-byte alignment run as ONE launch over
+    (packs, items) with device tables -- same bits as one launch per item; anything else (an operand that is another item's
+    destination, mixed programs, odd lengths) keeps the item-by-item order."""
+    n, count = 1000, 37
+    R = Jets.JetBSpace([Jets.JetSpace(dt, n)] * count)
+    x, y = Jets.rand(R, seed=11, stream=0), Jets.rand(R, seed=12, stream=0)
+    expr = "s0*x0*x1 + s1"
+    one, many = Jets.zeros(R), Jets.zeros(R)
+    for k in range(count):
+        Jets.broadcast_(one.arrays[k], expr, [x.arrays[k], y.arrays[k]], [0.5 + k, -0.25 * k])
+    Jets.broadcast_many_((many.arrays[k], expr, [x.arrays[k], y.arrays[k]], [0.5 + k, -0.25 * k]) for k in range(count))
+    assert many.to_numpy().tobytes() == one.to_numpy().tobytes()
+    # in place on its own destination: still one launch, still the same bits
+    z1, z2 = Jets.rand(R, seed=13, stream=0), Jets.rand(R, seed=13, stream=0)
+    for k in range(count):
+        Jets.broadcast_(z1.arrays[k], "x0 + x1*x1", [z1.arrays[k], x.arrays[k]])
+    Jets.broadcast_many_((z2.arrays[k], "x0 + x1*x1", [z2.arrays[k], x.arrays[k]], []) for k in range(count))
+    assert z2.to_numpy().tobytes() == z1.to_numpy().tobytes()
+    # a chain (item k reads item k-1's destination) must keep its order
+    c1, c2 = Jets.rand(R, seed=14, stream=0), Jets.rand(R, seed=14, stream=0)
+    for k in range(1, count):
+        Jets.broadcast_(c1.arrays[k], "x0 + x1", [c1.arrays[k - 1], x.arrays[k]])
+    Jets.broadcast_many_((c2.arrays[k], "x0 + x1", [c2.arrays[k - 1], x.arrays[k]], []) for k in range(1, count))
+    assert c2.to_numpy().tobytes() == c1.to_numpy().tobytes()
+    # mixed programs and lengths fall back as a whole
+    S = Jets.JetBSpace([Jets.JetSpace(dt, 7 + k) for k in range(6)])
+    u, v1, v2 = Jets.rand(S, seed=15, stream=0), Jets.zeros(S), Jets.zeros(S)
+    for k in range(6):
+        Jets.broadcast_(v1.arrays[k], "x0*x0" if k % 2 else "x0 + x0", [u.arrays[k]])
+    Jets.broadcast_many_((v2.arrays[k], "x0*x0" if k % 2 else "x0 + x0", [u.arrays[k]], []) for k in range(6))
+    assert v2.to_numpy().tobytes() == v1.to_numpy().tobytes()
