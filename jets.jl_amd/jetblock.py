@@ -119,6 +119,7 @@ def elementwise_upstate(mo, s):  # upstate!(mo, s) (src/Jets.jl:297-301): refres
 
     broadcast_(s["diagonal"], s["jac_expr"], [mo], s["params"])
     s["pointed"][0] = True
+    _j.POINT_GEN[0] += 1
 
 
 def elementwise_df(d, m, *, diagonal, pointed, **kw):  # dd .= f'.(mo) .* dm
@@ -346,6 +347,19 @@ def blockop(ops, **kwargs) -> Jop:
 def _pointed_native(nat, ops, mo):
     """`nat` linearised about `mo`, or None when some nonlinear child sits at a point of its own (someone called point!
     on the child, not on the block jet): then the per-child loop below is the faithful path."""
+    if not nat.host_f and not nat.nonlinear:
+        return nat
+    # the checks below walk every child: remember their outcome until some jet's point changes (jets.POINT_GEN)
+    key = (_j.POINT_GEN[0], None if mo is None else (mo.ptr, mo.length()))
+    hit = getattr(nat, "_pt_cache", None)
+    if hit is not None and hit[0] == key:
+        return nat if hit[1] else None
+    res = _pointed_native_check(nat, ops, mo)
+    nat._pt_cache = (key, res is not None)
+    return res
+
+
+def _pointed_native_check(nat, ops, mo):
     if nat.host_f:                                             # JopElementwise children carry their own (refreshed in place) diagonal
         for op in ops.flat:
             if isinstance(op, JopNl) and op.jet.f is elementwise_f and not op.jet.s["pointed"][0]:
@@ -436,6 +450,7 @@ def JetBlock_df_adj(m, d, *, ops, dom, rng, _native=None, **kw):  # :1034-1057
 def point_block(j: Jet, mo):  # :1059-1066
     ops = j.s["ops"]
     j.mo = mo
+    _j.POINT_GEN[0] += 1
     jobs = []
     for jc in builtins.range(ops.shape[1]):
         mo_j = getblock(mo, jc)
@@ -443,6 +458,7 @@ def point_block(j: Jet, mo):  # :1059-1066
             cj = jet(ops[i, jc])
             if cj.upstate is elementwise_upstate and cj.f is elementwise_f:   # point!(child) = set mo + upstate!; the upstate!s are batched
                 cj.mo = mo_j
+                _j.POINT_GEN[0] += 1
                 jobs.append((cj.s["diagonal"], cj.s["jac_expr"], [mo_j], cj.s["params"]))
                 cj.s["pointed"][0] = True
             else:

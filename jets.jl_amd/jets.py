@@ -44,6 +44,10 @@ def _default_upstate(m, s):  # src/Jets.jl:176
     return None
 
 
+# bumped whenever any jet's linearisation point changes: block jets cache "all my children are pointed where I am" against it
+POINT_GEN = [0]
+
+
 class Jet:
     """Jet(; dom, rng, f!, df!, df'!, upstate!, s)  (src/Jets.jl:133-188)."""
 
@@ -321,6 +325,7 @@ def point_(A, mo):  # :297-301, 578-589, 710-715, 1059-1066
 
     if j.f is JetComposite_f:  # :578-589
         j.mo = mo
+        POINT_GEN[0] += 1
         ops = j.s["ops"]
         _m = copyto_(_arr.similar(mo), mo)
         for i in builtins.range(len(ops) - 1, -1, -1):
@@ -336,6 +341,7 @@ def point_(A, mo):  # :297-301, 578-589, 710-715, 1059-1066
         _blk.point_block(j, mo)
         return A
     j.mo = mo
+    POINT_GEN[0] += 1
     j.upstate(mo, j.s)
     return A
 
