@@ -21,7 +21,7 @@ from ._ffi import lib, check
 from .spaces import dtype_code
 from .arrays import _DevVec, similar
 
-__all__ = ["broadcast_", "broadcast_many_", "lazy", "assign_", "bc", "BExpr"]
+__all__ = ["broadcast_", "broadcast_many_", "pack_many", "run_packed", "lazy", "assign_", "bc", "BExpr"]
 
 _programs = {}
 _scalar_ids = itertools.count()
@@ -37,25 +37,40 @@ def _program(expr: str, dtype, nvec: int, nscal: int):
     return h
 
 
-def broadcast_many_(jobs):
-    """[(dst, expr, vecs, scalars), ...] in ONE trip through the ABI (jh_bcast_apply_many): the launches are enqueued back
-    to back -- what a tall nonlinear operator needs for F(m) and point! over hundreds of children."""
+def pack_many(jobs):
+    """[(dst, expr, vecs, scalars), ...] packed into the argument arrays of jh_bcast_apply_many.  A caller that issues the
+    same batch again and again (F(m) of a tall nonlinear operator into the same vectors) keeps the pack and calls
+    run_packed: no per-item host work."""
     jobs = list(jobs)
-    if not jobs:
-        return
-    progs = (C.c_void_p * len(jobs))()
-    dsts = (C.c_void_p * len(jobs))()
-    xs, sc = [], []
+    progs = (C.c_void_p * max(len(jobs), 1))()
+    dsts = (C.c_void_p * max(len(jobs), 1))()
+    xs, sc, keep = [], [], []
     for k, (dst, expr, vecs, scalars) in enumerate(jobs):
         progs[k] = _program(expr, dst.dtype, len(vecs), len(scalars))
         dsts[k] = dst.handle
-        xs += [v.handle for v in vecs]
+        keep.append(dst)
+        for v in vecs:
+            xs.append(v.handle)
+            keep.append(v)
         for a in scalars:
             a = complex(a)
-            sc += [a.real, a.imag]
+            sc.append(a.real)
+            sc.append(a.imag)
     xa = (C.c_void_p * max(len(xs), 1))(*xs)
     sa = (C.c_double * max(len(sc), 1))(*sc)
-    check(lib.jh_bcast_apply_many(len(jobs), progs, dsts, xa, sa))
+    return (len(jobs), progs, dsts, xa, sa, keep)
+
+
+def run_packed(pack):
+    if pack[0]:
+        check(lib.jh_bcast_apply_many(pack[0], pack[1], pack[2], pack[3], pack[4]))
+
+
+def broadcast_many_(jobs):
+    """[(dst, expr, vecs, scalars), ...] in ONE trip through the ABI (jh_bcast_apply_many): items that share the program run
+    as one launch, the rest are enqueued back to back -- what a tall nonlinear operator needs for F(m) and point! over
+    hundreds of children."""
+    run_packed(pack_many(jobs))
 
 
 def broadcast_(dst: _DevVec, expr: str, vecs=(), scalars=()):

@@ -258,6 +258,8 @@ class _NativeCell:
         if isinstance(self.value, NativeBlockOp):
             self.value.close()
         self.value = "unset"
+        self.__dict__.pop("fpacks", None)
+        self.__dict__.pop("ppack", None)
 
 
 def _native_op(cell, ops, dtype):
@@ -383,9 +385,17 @@ def JetBlock_f(d, m, *, ops, dom, rng, _native=None, **kw):  # :988-1008
         return nat.f(d, m)  # one fused launch, same loop order and rounding
     nrow, ncol = ops.shape
     if ncol == 1 and all(isinstance(op, JopNl) and op.jet.f is elementwise_f for op in ops.flat):
-        from .broadcast import broadcast_many_   # every child's f! (1003) enqueued in one trip through the ABI
+        from .broadcast import pack_many, run_packed   # every child's f! (1003) in one trip through the ABI (one launch when alike)
 
-        broadcast_many_((getblock(d, i), ops[i, 0].jet.s["f_expr"], [m], ops[i, 0].jet.s["params"]) for i in builtins.range(nrow))
+        packs = _native.__dict__.setdefault("fpacks", {}) if _native is not None else {}
+        key = (d.ptr, m.ptr, d.length(), _j.STATE_GEN[0])     # state!(child, ...) may change a child's parameters
+        pack = packs.get(key)
+        if pack is None:                                     # the argument tables of this (d, m) pair: built once, replayed afterwards
+            if len(packs) >= 4:
+                packs.clear()
+            pack = packs[key] = pack_many((getblock(d, i), ops[i, 0].jet.s["f_expr"], [m], ops[i, 0].jet.s["params"])
+                                          for i in builtins.range(nrow))
+        run_packed(pack)
         return d
     dtmp = zeros(range_(ops[0, 0])) if ncol > 1 else None
     for i in builtins.range(nrow):
@@ -449,24 +459,40 @@ def JetBlock_df_adj(m, d, *, ops, dom, rng, _native=None, **kw):  # :1034-1057
 
 def point_block(j: Jet, mo):  # :1059-1066
     ops = j.s["ops"]
+    cell = j.s.get("_native")
+    # Re-pointing at the SAME vector (a Gauss-Newton loop updates its model in place): every child already holds its block of
+    # `mo`; only the children's upstate!s have to run again -- replay their packed batch instead of walking the children.
+    if cell is not None and j.mo is mo:
+        hit = cell.__dict__.get("ppack")
+        if hit is not None and hit[0] == (mo.ptr, mo.length(), _j.POINT_GEN[0], _j.STATE_GEN[0]):
+            from .broadcast import run_packed
+
+            run_packed(hit[1])
+            return j
     j.mo = mo
     _j.POINT_GEN[0] += 1
-    jobs = []
+    jobs, all_batched = [], True
     for jc in builtins.range(ops.shape[1]):
         mo_j = getblock(mo, jc)
         for i in builtins.range(ops.shape[0]):
             cj = jet(ops[i, jc])
             if cj.upstate is elementwise_upstate and cj.f is elementwise_f:   # point!(child) = set mo + upstate!; the upstate!s are batched
                 cj.mo = mo_j
-                _j.POINT_GEN[0] += 1
                 jobs.append((cj.s["diagonal"], cj.s["jac_expr"], [mo_j], cj.s["params"]))
                 cj.s["pointed"][0] = True
             else:
                 point_(cj, mo_j)
+                # a child with an upstate! of its own, or a composite / sum / block child (whose point! recomputes the points of
+                # its members), must see every point!: no replay for such operators
+                all_batched = all_batched and cj.upstate is _j._default_upstate and cj.f not in (_j.JetComposite_f, _j.JetSum_f, JetBlock_f)
+    _j.POINT_GEN[0] += 1
     if jobs:
-        from .broadcast import broadcast_many_
+        from .broadcast import pack_many, run_packed
 
-        broadcast_many_(jobs)
+        pack = pack_many(jobs)
+        run_packed(pack)
+        if cell is not None and all_batched:
+            cell.__dict__["ppack"] = ((mo.ptr, mo.length(), _j.POINT_GEN[0], _j.STATE_GEN[0]), pack)
     return j
 
 

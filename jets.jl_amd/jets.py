@@ -46,6 +46,8 @@ def _default_upstate(m, s):  # src/Jets.jl:176
 
 # bumped whenever any jet's linearisation point changes: block jets cache "all my children are pointed where I am" against it
 POINT_GEN = [0]
+# bumped by state!: argument tables a block jet built from its children's states are stale afterwards
+STATE_GEN = [0]
 
 
 class Jet:
@@ -261,6 +263,7 @@ def state(A, key=None):  # :264-265, 313-314, 607-623
 def state_(A, s: dict):  # :272, 315  merge
     j = A if isinstance(A, Jet) else jet(A)
     j.s = {**j.s, **s}
+    STATE_GEN[0] += 1                                       # cached argument tables built from a state (jetblock) are stale now
     return A
 
 

@@ -431,3 +431,40 @@ def test_linearization_and_linearity_tests(Jets, oracle):
     np.testing.assert_allclose(lhs.to_numpy(), rhs.to_numpy(), rtol=1e-12, atol=1e-13)
     lhs, rhs = Jets.linearity_test(J.H)
     np.testing.assert_allclose(lhs.to_numpy(), rhs.to_numpy(), rtol=1e-12, atol=1e-13)
+
+
+def test_repointing_at_the_same_vector_replays_and_follows_the_contents(Jets, oracle):
+    """A Gauss-Newton loop updates its model IN PLACE and calls jacobian! again with the same vector: the block point! then
+    replays the children's packed upstate! batch instead of walking them -- and must pick up the new contents; a state!
+    on a child or a point! at another vector invalidates the replay."""
+    dt, nrow, n = np.float64, 12, 256
+    spc = Jets.JetSpace(dt, n)
+    F = Jets.blockop([[Jets.JopElementwise(spc, "s0*x0*x0*x0", "3*s0*x0*x0", [0.5 + i])] for i in range(nrow)])
+    m = Jets.rand(Jets.domain(F), seed=2, stream=0)
+    dm = Jets.rand(Jets.domain(F), seed=3, stream=0)
+    hdm = dm.to_numpy().ravel(order="F")
+
+    def expect(hm, scales):
+        return np.concatenate([(3 * scales[i] * hm * hm) * hdm for i in range(nrow)])
+
+    scales = [0.5 + i for i in range(nrow)]
+    J1 = Jets.jacobian_(F, m)
+    assert np.allclose((J1 * dm).to_numpy(), expect(m.to_numpy().ravel(order="F"), scales), rtol=1e-14)
+    m.assign(2.0 * m)                                                             # in place: same vector, new contents
+    J2 = Jets.jacobian_(F, m)                                                     # replayed batch
+    assert np.allclose((J2 * dm).to_numpy(), expect(m.to_numpy().ravel(order="F"), scales), rtol=1e-14)
+    Jets.state_(Jets.getblock_op(F, 0, 0, Jets.JopNl), {"params": (7.0,)})        # a child's parameter changes
+    scales[0] = 7.0
+    J3 = Jets.jacobian_(F, m)
+    assert np.allclose((J3 * dm).to_numpy(), expect(m.to_numpy().ravel(order="F"), scales), rtol=1e-14)
+    m2 = Jets.rand(Jets.domain(F), seed=9, stream=0)                              # another vector
+    J4 = Jets.jacobian_(F, m2)
+    assert np.allclose((J4 * dm).to_numpy(), expect(m2.to_numpy().ravel(order="F"), scales), rtol=1e-14)
+    d1, d2 = Jets.zeros(Jets.range(F)), Jets.zeros(Jets.range(F))                 # F(m) replays its packed batch too
+    Jets.mul_(d1, F, m2)
+    Jets.mul_(d1, F, m2)
+    hm2 = m2.to_numpy().ravel(order="F")
+    assert np.allclose(d1.to_numpy(), np.concatenate([scales[i] * hm2 ** 3 for i in range(nrow)]), rtol=1e-14)
+    Jets.mul_(d2, F, m)
+    hm = m.to_numpy().ravel(order="F")
+    assert np.allclose(d2.to_numpy(), np.concatenate([scales[i] * hm ** 3 for i in range(nrow)]), rtol=1e-14)
