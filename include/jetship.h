@@ -162,9 +162,9 @@ int jh_bcast_compile(const char *expr, int dtype, int nvec, int nscal, jh_bcast 
 int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, const double *scal_re_im);
 /* `count` broadcasts in one call (a tall nonlinear operator evaluates one per child: F(m) and point! are `count` launches
  * enqueued back to back instead of `count` trips through the host language).  Operand k's vectors and scalars follow
- * each other in the flattened lists `x` (sum of nvec entries) and `scal_re_im` (2 * sum of nscal doubles).  Items that share
- * the program, the length and 16-byte alignment, and whose operands do not overlap another item's destination, run as ONE
- * launch (same bits); otherwise the items are launched in order. */
+ * each other in the flattened lists `x` (sum of nvec entries) and `scal_re_im` (2 * sum of nscal doubles).  When every pointer is
+ * 16-byte aligned and no operand overlaps another item's destination (the items then have no order among them), items that
+ * share a program and a length run as ONE launch (same bits); otherwise the items are launched in order. */
 int jh_bcast_apply_many(int count, const jh_bcast *const *progs, jh_bvec *const *dsts, const jh_bvec *const *x, const double *scal_re_im);
 int jh_bcast_destroy(jh_bcast *bc);
 /* dot(x,y), src/Jets.jl:850-856 (conjugates x). fp64 accumulation, deterministic order. */
@@ -276,7 +276,7 @@ int jh_comm_allreduce_scalars(double *values, int n, int op);   /* op: 0 sum, 1 
 /* kernel-shape tuning knobs (bench/tests only): 0 = automatic (fwd_order: -1); name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg","fwd_order","nt","autotune",
  * "graphs" (1: operators that run the per-block loop -- those with DENSE blocks -- replay it as a hipGraph from the
  * third call with the same vectors on; 0: always eager), "general_xcd" (the general M x K kernels' grid order: 1 automatic -- XCD-aware when the
- * input vector is >= 32 MiB, line by line below --, 0 never XCD-aware, 2 always), "red_wgs", "adj_split" (split-row walk of the tall adjoint / fused normal /
+ * input vector is >= 32 MiB, line by line below --, 0 never XCD-aware, 2 always), "red_wgs", "bcast_item_fast" (batched broadcasts with a shared operand: -1 automatic, 0 plain kernel, 1 items fastest), "adj_split" (split-row walk of the tall adjoint / fused normal /
  * one-pass step: -1 automatic, 0 never -- always the ordered, bit-exact walk --, k > 1 that many row parts)};
  * jh_tune_get also reads the counters "last_fwd_walk" (grid walk of the latest tall forward: 0 sequential, 1 all rows),
  * "last_fwd_rows_per_wg", "last_adj_launches", "last_adj_parts" and "graph_replays". */

@@ -468,6 +468,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "adj_wg")) { JH_REQUIRE(one_of({0, 256, 512, 1024}), "adj_wg must be 0 (auto), 256, 512 or 1024"); c.adj_wg = value; }
     else if (!strcmp(name, "fwd_order")) { JH_REQUIRE(value >= -1 && value <= 65536, "fwd_order must be -1 (auto), 0 (sequential), 1 (all rows) or k > 1 (k row groups per band)"); c.fwd_order = value; }
     else if (!strcmp(name, "nt")) { c.nt = value ? 1 : 0; }
+    else if (!strcmp(name, "bcast_item_fast")) { JH_REQUIRE(value >= -1 && value <= 1, "bcast_item_fast must be -1 (auto), 0 or 1"); c.bcast_item_fast = value; }
     else if (!strcmp(name, "adj_split")) { JH_REQUIRE(value >= -1 && value <= 65535, "adj_split must be -1 (auto), 0 (never: ordered walk) or the number of row parts"); c.adj_split = value; }
     else if (!strcmp(name, "adj_rows_per_launch")) { JH_REQUIRE(value >= 0, "adj_rows_per_launch must be >= 0"); c.adj_rows_per_launch = value; }
     else if (!strcmp(name, "autotune")) { c.autotune = value ? 1 : 0; }
@@ -490,6 +491,7 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "adj_wg")) *value = c.adj_wg;
     else if (!strcmp(name, "fwd_order")) *value = c.fwd_order;
     else if (!strcmp(name, "nt")) *value = c.nt;
+    else if (!strcmp(name, "bcast_item_fast")) *value = c.bcast_item_fast;
     else if (!strcmp(name, "adj_split")) *value = c.adj_split;
     else if (!strcmp(name, "last_adj_parts")) *value = c.last_adj_parts;
     else if (!strcmp(name, "adj_rows_per_launch")) *value = c.adj_rows_per_launch;

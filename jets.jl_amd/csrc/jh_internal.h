@@ -52,6 +52,7 @@ struct jh_context {
     int64_t adj_rows_per_launch = 0;   // tall adjoint / fused normal: block rows per launch (0 = all rows in one launch); same bits either way
     int64_t adj_split = -1;            // split-row walk of the adjoint-shaped kernels: -1 automatic, 0 never (ordered, bit-exact), k > 1 parts
     int64_t last_adj_parts = 1;        // row parts of the most recent tall adjoint / fused normal / one-pass step (read-only knob)
+    int64_t bcast_item_fast = -1;      // batched broadcasts with a shared operand: items as the fastest block index (-1 automatic, 0 never, 1 always)
     int64_t nt = 1;                    // nontemporal loads/stores on the streamed operands
     int64_t autotune = 1;              // time both grid walks of the tall forward once per large operator
     int64_t general_xcd = 1;           // general M x K kernels: 1 = XCD-aware (line, tile) decode from 32 MiB of input on, else line by line; 0 never; 2 always
