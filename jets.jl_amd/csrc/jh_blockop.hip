@@ -1802,6 +1802,16 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
         }
     }
 
+    if (nrow == 1 && ncol >= 2 && ncol <= 32768 && !op->elementwise) {         // ... or wide: one block row of such children
+        op->dense_batch_wide = true;
+        op->dense_aligned = true;
+        for (int64_t j = 0; j < ncol && op->dense_batch_wide; j++) {
+            const jh_block_desc &b = op->blocks[(size_t)j];
+            if (b.kind != JH_OP_DENSE || b.adjoint || b.nr != op->blocks[0].nr || b.nc != op->blocks[0].nc || b.nr == 0 || b.nc == 0) op->dense_batch_wide = false;
+            if (((uintptr_t)b.coeff) & 15u) op->dense_aligned = false;
+        }
+    }
+
     // strided-diagonal detection: coeff[i] = coeff[0] + i*stride  (e.g. one slab holding all diagonals)
     if (op->tall && op->all_diag && nrow >= 1) {
         op->diag_strided = true;
@@ -1895,7 +1905,8 @@ int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
 {
     JH_TRY(jh_require_ready());
     JH_TRY(check_vectors(op, d, m, "jh_blockop_f"));
-    if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned);
+    if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false);
+    if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
     if (!op->elementwise) return run_loop_graphed(op, 2, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data, true); });
     switch (op->dtype) {
     case JH_F32: return general_fwd<float, 1>(op, d->data, m->data, 1);
@@ -1921,7 +1932,8 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
         case JH_C64: return launch_tall_fwd<double, 2, 2>(op, d->data, m->data, 2 * n);
         }
     }
-    if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned);
+    if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false);
+    if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
     if (!op->elementwise) return run_loop_graphed(op, 0, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data); });
     switch (op->dtype) {
     case JH_F32: return general_fwd<float, 1>(op, d->data, m->data);
@@ -1947,7 +1959,8 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
         case JH_C64: return launch_tall_adj<double, 2, 2, 0>(op, m->data, d->data, 2 * n);
         }
     }
-    if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned);
+    if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, false);
+    if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, true);
     if (!op->elementwise) return run_loop_graphed(op, 1, m->data, d->data, [&] { return loop_adj(op, m->data, d->data); });
     switch (op->dtype) {
     case JH_F32: return general_adj<float, 1>(op, m->data, d->data);

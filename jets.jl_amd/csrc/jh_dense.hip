@@ -123,8 +123,8 @@ __global__ void k_sum_col_chunks(const double *__restrict__ partial, int64_t nc,
 // block sits at y + z*nr*E (the slab layout), the domain vector x is shared.
 template <typename S, int E, int NS>
 __global__ __launch_bounds__(256) void k_gemv_rows_batched(const jh_dev_block *__restrict__ blocks, int64_t z0, int64_t nr, int64_t nc,
-                                                           const S *__restrict__ x, S *__restrict__ out, int64_t child_stride,
-                                                           int64_t chunk_stride, int64_t cols_per_chunk)
+                                                           const S *__restrict__ x, int64_t x_stride, S *__restrict__ out,
+                                                           int64_t child_stride, int64_t chunk_stride, int64_t cols_per_chunk)
 {
     typedef typename vec_of<S, NS>::type V;
     const int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * NS;
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows_batched(const jh_dev_block *_
     if (s >= ns) return;
     const int64_t z = z0 + blockIdx.z;
     const S *A = (const S *)blocks[z].coeff;
+    x += z * x_stride;                                                         // tall: every child reads m (stride 0); wide: child z reads m_z
     const int64_t c0 = (int64_t)blockIdx.y * cols_per_chunk;
     const int64_t c1 = c0 + cols_per_chunk < nc ? c0 + cols_per_chunk : nc;
     V acc = (V)(S)0;
@@ -171,7 +172,8 @@ __global__ void k_sum_chunks_batched(const S *__restrict__ partial, int64_t ns, 
 // partial[z][chunk][c] = sum over the chunk's rows of conj(A_z[r,c]) * d_z[r]   (fp64, one wave per column)
 template <typename S, int E, int NS>
 __global__ __launch_bounds__(256) void k_gemv_cols_batched(const jh_dev_block *__restrict__ blocks, int64_t z0, int64_t nr, int64_t nc,
-                                                           const S *__restrict__ d, double *__restrict__ partial, int64_t rows_per_chunk)
+                                                           const S *__restrict__ d, int64_t d_stride, double *__restrict__ partial,
+                                                           int64_t rows_per_chunk)
 {
     typedef typename vec_of<S, NS>::type V;
     const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void k_gemv_cols_batched(const jh_dev_block *_
     const int64_t s0 = (int64_t)blockIdx.y * rows_per_chunk * E;
     const int64_t s1 = s0 + rows_per_chunk * E < ns ? s0 + rows_per_chunk * E : ns;
     const S *col = (const S *)blocks[z].coeff + c * ns;
-    const S *x = d + z * ns;
+    const S *x = d + z * d_stride;                                             // tall: child z reads d_z; wide: every child reads d (stride 0)
     double sr = 0.0, si = 0.0;
     for (int64_t s = s0 + (int64_t)lane * NS; s < s1; s += 64 * NS) {
         V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col + s));
@@ -258,6 +260,145 @@ __global__ void k_fold_groups(const double *__restrict__ group_sums, int64_t nc,
     if (E == 2) m[c * E + 1] = (S)i;
 }
 
+// ---- WIDE operator (one block row of K dense children): d (+)= sum_j A_j m_j and m_j = A_j' d -----------------------------
+// forward fold, few children: the reference's order and rounding -- `_d .+= mul!(dtmp, A_j, m_j)` (1024): dtmp_j is the ordered
+// sum of its column chunks in the element type, added to d as found, j in order
+template <typename S>
+__global__ void k_fold_wide_ordered(const S *__restrict__ T, int64_t ns, int nchunks, int nchild, S *__restrict__ d)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= ns) return;
+    S acc = d[k];
+    for (int j = 0; j < nchild; j++) {
+        const S *p = T + (int64_t)j * nchunks * ns + k;
+        S t = p[0];
+        for (int c = 1; c < nchunks; c++) t = t + p[(int64_t)c * ns];
+        acc = acc + t;
+    }
+    d[k] = acc;
+}
+
+// forward fold, many children: group sums in fp64 (64 scalar lanes x 4 child lanes), then d = found + groups (tolerance parity)
+template <typename S>
+__global__ __launch_bounds__(256) void k_fold_wide_groups(const S *__restrict__ T, int64_t ns, int nchunks, int nchild, int per_group,
+                                                          double *__restrict__ group_sums)
+{
+    __shared__ double sm[4][64];
+    const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t k = (int64_t)blockIdx.x * 64 + v;
+    const int jlo = (int)blockIdx.y * per_group, jhi = jlo + per_group < nchild ? jlo + per_group : nchild;
+    double acc = 0.0;
+    if (k < ns)
+        for (int j = jlo + q; j < jhi; j += 4) {
+            const S *p = T + (int64_t)j * nchunks * ns + k;
+            S t = p[0];
+            for (int c = 1; c < nchunks; c++) t = t + p[(int64_t)c * ns];
+            acc += (double)t;
+        }
+    sm[q][v] = acc;
+    __syncthreads();
+    if (q == 0 && k < ns) group_sums[(int64_t)blockIdx.y * ns + k] = sm[0][v] + sm[1][v] + sm[2][v] + sm[3][v];
+}
+
+template <typename S>
+__global__ void k_fold_wide_final(const double *__restrict__ group_sums, int64_t ns, int ngroups, S *__restrict__ d)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= ns) return;
+    double acc = (double)d[k];
+    for (int g = 0; g < ngroups; g++) acc += group_sums[(int64_t)g * ns + k];
+    d[k] = (S)acc;
+}
+
+// adjoint: m_z[c] = sum over the row chunks of partial[z][chunk][c]  (one block row: written directly, 1051)
+template <typename S, int E>
+__global__ void k_store_col_sums(const double *__restrict__ partial, int64_t nc, int nchunks, S *__restrict__ m)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nc) return;
+    const int64_t z = blockIdx.y;
+    double sr = 0.0, si = 0.0;
+    const double *p = partial + (z * nchunks * nc + c) * 2;
+    for (int k = 0; k < nchunks; k++) { sr += p[(int64_t)k * nc * 2]; si += p[(int64_t)k * nc * 2 + 1]; }
+    m[(z * nc + c) * E] = (S)sr;
+    if (E == 2) m[(z * nc + c) * E + 1] = (S)si;
+}
+
+template <typename S, int E>
+int gemv_batched_wide(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, void *y, const void *x, int adjoint, bool aligned)
+{
+    jh_context &c = jh_ctx();
+    hipStream_t st = c.stream;
+    constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
+    const int64_t ns = nr * E;
+    const bool vec_ok = aligned && ((ns * (int64_t)sizeof(S)) % 16 == 0) && ((((uintptr_t)x) | ((uintptr_t)y)) & 15u) == 0;
+    const double child_bytes = (double)nr * (double)nc * sizeof(S) * E;
+    JH_REQUIRE(nchild <= 32768, "batched wide dense operator: too many children");
+    if (!adjoint) {                                                            // d (+)= sum_j A_j m_j
+        const int NS = vec_ok ? NSV : E;
+        const int64_t row_wgs = (ns / NS + 255) / 256;
+        int64_t nchunks = 1;
+        if (child_bytes >= (double)(1 << 20) && row_wgs * nchild < 2048) {
+            nchunks = (2048 + row_wgs * nchild - 1) / (row_wgs * nchild);
+            const int64_t maxc = (nc + 31) / 32;
+            if (nchunks > maxc) nchunks = maxc;
+        }
+        const int64_t cpc = (nc + nchunks - 1) / nchunks;
+        nchunks = (nc + cpc - 1) / cpc;
+        const int64_t t_doubles = ((int64_t)nchild * nchunks * ns * (int64_t)sizeof(S) + 7) / 8 + 2;
+        const int64_t fold_wgs = (ns + 63) / 64;
+        int64_t ngroups = (2048 + fold_wgs - 1) / fold_wgs;
+        if (ngroups > nchild / 8) ngroups = nchild / 8;
+        if (ngroups < 1) ngroups = 1;
+        const int64_t per_group = (nchild + ngroups - 1) / ngroups;
+        ngroups = (nchild + per_group - 1) / per_group;
+        JH_TRY(jh_ensure_partials(t_doubles + ngroups * ns));
+        S *T = (S *)c.part_dev;
+        double *group_sums = c.part_dev + t_doubles;
+        if (vec_ok)
+            hipLaunchKernelGGL((k_gemv_rows_batched<S, E, NSV>), dim3((unsigned)row_wgs, (unsigned)nchunks, (unsigned)nchild), dim3(256), 0, st, dev_blocks,
+                               (int64_t)0, nr, nc, (const S *)x, nc * E, T, nchunks * ns, ns, cpc);
+        else
+            hipLaunchKernelGGL((k_gemv_rows_batched<S, E, E>), dim3((unsigned)row_wgs, (unsigned)nchunks, (unsigned)nchild), dim3(256), 0, st, dev_blocks,
+                               (int64_t)0, nr, nc, (const S *)x, nc * E, T, nchunks * ns, ns, cpc);
+        JH_CHECK_HIP(hipGetLastError());
+        if (nchild <= 64) {
+            hipLaunchKernelGGL((k_fold_wide_ordered<S>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, T, ns, (int)nchunks, (int)nchild, (S *)y);
+        } else {
+            hipLaunchKernelGGL((k_fold_wide_groups<S>), dim3((unsigned)fold_wgs, (unsigned)ngroups), dim3(256), 0, st, T, ns, (int)nchunks, (int)nchild,
+                               (int)per_group, group_sums);
+            JH_CHECK_HIP(hipGetLastError());
+            hipLaunchKernelGGL((k_fold_wide_final<S>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, group_sums, ns, (int)ngroups, (S *)y);
+        }
+        JH_CHECK_HIP(hipGetLastError());
+        return JH_OK;
+    }
+    // m_j = A_j' d for every child
+    const int64_t col_wgs = (nc + 3) / 4;
+    int64_t nchunks = 1;
+    if (child_bytes >= (double)(1 << 20) && col_wgs * nchild < 2048) {
+        nchunks = (2048 + col_wgs * nchild - 1) / (col_wgs * nchild);
+        const int64_t maxc = (nr + 4095) / 4096;
+        if (nchunks > maxc) nchunks = maxc;
+        if (nchunks < 1) nchunks = 1;
+    }
+    int64_t rpc = (nr + nchunks - 1) / nchunks;
+    rpc = (rpc + 3) / 4 * 4;
+    if (rpc < 4) rpc = 4;
+    nchunks = nr ? (nr + rpc - 1) / rpc : 1;
+    JH_TRY(jh_ensure_partials(2 * nchild * nchunks * nc));
+    if (vec_ok)
+        hipLaunchKernelGGL((k_gemv_cols_batched<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)nchild), dim3(256), 0, st, dev_blocks,
+                           (int64_t)0, nr, nc, (const S *)x, (int64_t)0, c.part_dev, rpc);
+    else
+        hipLaunchKernelGGL((k_gemv_cols_batched<S, E, E>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)nchild), dim3(256), 0, st, dev_blocks,
+                           (int64_t)0, nr, nc, (const S *)x, (int64_t)0, c.part_dev, rpc);
+    JH_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL((k_store_col_sums<S, E>), dim3((unsigned)((nc + 255) / 256), (unsigned)nchild), dim3(256), 0, st, c.part_dev, nc, (int)nchunks, (S *)y);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
 template <typename S, int E>
 int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, void *y, const void *x, int adjoint, bool aligned)
 {
@@ -291,10 +432,10 @@ int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int
             const unsigned gz = (unsigned)(nchild - z0 < zmax ? nchild - z0 : zmax);
             if (vec_ok)
                 hipLaunchKernelGGL((k_gemv_rows_batched<S, E, NSV>), dim3((unsigned)row_wgs, (unsigned)nchunks, gz), dim3(256), 0, st, dev_blocks, z0,
-                                   nr, nc, (const S *)x, out, child_stride, chunk_stride, cpc);
+                                   nr, nc, (const S *)x, (int64_t)0, out, child_stride, chunk_stride, cpc);
             else
                 hipLaunchKernelGGL((k_gemv_rows_batched<S, E, E>), dim3((unsigned)row_wgs, (unsigned)nchunks, gz), dim3(256), 0, st, dev_blocks, z0,
-                                   nr, nc, (const S *)x, out, child_stride, chunk_stride, cpc);
+                                   nr, nc, (const S *)x, (int64_t)0, out, child_stride, chunk_stride, cpc);
             JH_CHECK_HIP(hipGetLastError());
         }
         if (nchunks > 1) {
@@ -334,10 +475,10 @@ int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int
         const S *d0 = (const S *)x;
         if (vec_ok)
             hipLaunchKernelGGL((k_gemv_cols_batched<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)gz), dim3(256), 0, st, dev_blocks,
-                               z0, nr, nc, d0, c.part_dev, rpc);
+                               z0, nr, nc, d0, ns, c.part_dev, rpc);
         else
             hipLaunchKernelGGL((k_gemv_cols_batched<S, E, E>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)gz), dim3(256), 0, st, dev_blocks,
-                               z0, nr, nc, d0, c.part_dev, rpc);
+                               z0, nr, nc, d0, ns, c.part_dev, rpc);
         JH_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL((k_fold_children<S, E>), dim3((unsigned)fold_wgs, (unsigned)ngroups), dim3(256), 0, st, c.part_dev, nc, (int)nchunks,
                            (int)gz, (int)per_group, group_sums);
@@ -433,8 +574,15 @@ int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, co
 
 // all children of a tall operator of uniform dense blocks in one go (jh_blockop.hip); `aligned`: every matrix pointer on 16 bytes
 int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, int dtype, void *y, const void *x,
-                           int adjoint, bool aligned)
+                           int adjoint, bool aligned, bool wide)
 {
+    if (wide)
+        switch (dtype) {
+        case JH_F32: return gemv_batched_wide<float, 1>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
+        case JH_F64: return gemv_batched_wide<double, 1>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
+        case JH_C32: return gemv_batched_wide<float, 2>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
+        case JH_C64: return gemv_batched_wide<double, 2>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
+        }
     switch (dtype) {
     case JH_F32: return gemv_batched<float, 1>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
     case JH_F64: return gemv_batched<double, 1>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);

@@ -101,3 +101,46 @@ def test_adjointed_or_ragged_dense_children_keep_the_loop(Jets, oracle):
     refB = oracle.block_df([[oracle.Block("dense", 12, 12, coeff=hA[0])], [oracle.Block("dense", 5, 12, coeff=hB)]],
                            [np.zeros(12, dtype=dt), np.zeros(5, dtype=dt)], [hm])
     assert_bits_equal((B * m).to_numpy(), np.concatenate(refB), "ragged dense children")
+
+
+def _wide_dense(Jets, oracle, dt, nchild, nr, nc, seed=950):
+    mats, orow = [], []
+    for z in range(nchild):
+        hA = np.asfortranarray(u01(oracle, dt, seed, z, nr * nc).reshape((nr, nc), order="F"))
+        mats.append(hA)
+        orow.append(oracle.Block("dense", nr, nc, coeff=hA))
+    A = Jets.blockop([[Jets.JopDense(Jets.from_numpy(hA)) for hA in mats]])
+    return A, [orow], mats
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nchild,nr,nc", [(2, 8, 8), (3, 5, 5), (5, 64, 48), (40, 12, 7), (300, 16, 128), (7, 256, 512)])
+def test_batched_dense_children_of_a_wide_operator(Jets, oracle, dt, nchild, nr, nc):
+    """test/runtests.jl:744-758 (short-and-fat): A*m == B1 m1 + B2 m2 + ... accumulated into d AS FOUND (src/Jets.jl:1024),
+    A'd == [B1'd; B2'd; ...].  Up to 64 children the forward keeps the reference's order and rounding (bit-exact while the
+    columns are not split); beyond, an fp64 fold (tolerance parity).  The adjoint is a wave reduction (tolerance parity)."""
+    A, ora, mats = _wide_dense(Jets, oracle, dt, nchild, nr, nc)
+    assert Jets.nblocks_op(A) == (1, nchild)
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=0)
+    hm = u01(oracle, dt, SEED_M, 0, nchild * nc)
+    mb = [hm[j * nc:(j + 1) * nc].copy() for j in range(nchild)]
+    d = Jets.rand(Jets.range(A), seed=5, stream=5)                                # dirty: the reference adds into it
+    hd0 = u01(oracle, dt, 5, 5, nr)
+    Jets.mul_(d, A, m)
+    ref_d = oracle.block_df(ora, [hd0.copy()], mb)
+    item = np.dtype(dt).itemsize
+    lanes = -(-(nr * item) // 16)
+    split = nr * nc * item >= (1 << 20) and -(-lanes // 256) * nchild < 2048
+    if nchild <= 64 and not split:
+        assert_bits_equal(d.to_numpy(), ref_d[0], "A*m == sum_j B_j m_j into d as found")
+    else:
+        assert _err(d.to_numpy(), ref_d[0]) < _tol(dt)
+    dd = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    hd = u01(oracle, dt, SEED_D, 0, nr)
+    mt = Jets.rand(Jets.domain(A), seed=6, stream=6)                              # dirty: overwritten (1051)
+    Jets.mul_(mt, A.H, dd)
+    wide = np.clongdouble if np.iscomplexobj(mats[0]) else np.longdouble
+    truth = np.concatenate([np.conj(mats[z].astype(wide)).T @ hd.astype(wide) for z in range(nchild)])
+    assert _err(mt.to_numpy(), truth) < _tol(dt)
+    lhs, rhs = Jets.dot_product_test(A, m, dd)
+    assert abs(lhs - rhs) / abs(lhs + rhs) < (1e-5 if _tol(dt) > 1e-10 else 1e-12)

@@ -11,6 +11,7 @@ import jets_jl_amd as J
 
 J.init(0)
 total = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024) << 20
+WIDE = len(sys.argv) > 2 and sys.argv[2] == "wide"
 
 
 def timed(fn, reps=5):
@@ -22,19 +23,19 @@ def timed(fn, reps=5):
     return best
 
 
-print(f"# tall N x 1 operators of dense k x k Float32 children, {total >> 20} MiB of matrices; best of 5")
+print(f"# {'wide 1 x N' if WIDE else 'tall N x 1'} operators of dense k x k Float32 children, {total >> 20} MiB of matrices; best of 5")
 for k in (8192, 4096, 2048, 1024, 512, 256, 128):
     nrow = total // (4 * k * k)
     if nrow > 16384:
         continue
     mats = [J.rand(J.JetSpace(np.float32, k, k), seed=1, stream=i) for i in range(nrow)]
-    A = J.blockop([[J.JopDense(M)] for M in mats])
+    A = J.blockop([[J.JopDense(M) for M in mats]]) if WIDE else J.blockop([[J.JopDense(M)] for M in mats])
     m = J.rand(J.domain(A), seed=2, stream=0)
     d = J.rand(J.range(A), seed=3, stream=0)
     mt = J.zeros(J.domain(A))
     tf = timed(lambda: J.mul_(d, A, m))
     ta = timed(lambda: J.mul_(mt, A.H, d))
     nbytes = nrow * k * k * 4
-    print(f"{nrow:6d} x 1 of {k:5d}^2: fwd {tf:8.3f} ms {nbytes / tf / 1e6:6.0f} GB/s | adj {ta:8.3f} ms {nbytes / ta / 1e6:6.0f} GB/s   "
+    print(f"{nrow:6d} children of {k:5d}^2: fwd {tf:8.3f} ms {nbytes / tf / 1e6:6.0f} GB/s | adj {ta:8.3f} ms {nbytes / ta / 1e6:6.0f} GB/s   "
           f"(graph replays so far {J.tune_get('graph_replays')})", flush=True)
     del A, mats, m, d, mt
