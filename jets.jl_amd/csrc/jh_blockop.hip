@@ -1598,6 +1598,33 @@ int accumulate(int dtype, void *acc, const void *term, int64_t n)     // acc .+=
     return jh_launch_lincomb_raw(acc, dtype, n, 2, one, zero, xs);
 }
 
+// M x K operator of uniform un-adjointed dense children (M, K >= 2): block COLUMN j is a tall operator of dense children, so
+// the batched kernels run once per column instead of one child launch per block.  Forward: d_i = ((found + A_i1 m_1) + A_i2 m_2)
+// + ... -- column by column through a range-sized temporary, the reference's order (1020-1024); adjoint: m_j = sum_i A_ij' d_i.
+int dense_grid_fwd(const jh_blockop *op, void *d, const void *m)
+{
+    const size_t es = jh_dtype_size(op->dtype);
+    const int64_t nr = op->blocks[0].nr, nc = op->blocks[0].nc, nrange = op->row_off[(size_t)op->nrow];
+    void *tmp = nullptr;
+    JH_TRY(jh_ensure_scratch((size_t)nrange * es + 16, &tmp));
+    for (int64_t j = 0; j < op->ncol; j++) {
+        JH_TRY(jh_launch_gemv_batched(op->dev_blocks + j * op->nrow, op->nrow, nr, nc, op->dtype, tmp, (const char *)m + (size_t)(j * nc) * es, 0,
+                                      op->dense_aligned, false));
+        JH_TRY(accumulate(op->dtype, d, tmp, nrange));                                    // _d .+= dtmp   (1024 / 1001)
+    }
+    return JH_OK;
+}
+
+int dense_grid_adj(const jh_blockop *op, void *m, const void *d)
+{
+    const size_t es = jh_dtype_size(op->dtype);
+    const int64_t nr = op->blocks[0].nr, nc = op->blocks[0].nc;
+    for (int64_t j = 0; j < op->ncol; j++)
+        JH_TRY(jh_launch_gemv_batched(op->dev_blocks + j * op->nrow, op->nrow, nr, nc, op->dtype, (char *)m + (size_t)(j * nc) * es, d, 1,
+                                      op->dense_aligned, false));
+    return JH_OK;
+}
+
 int loop_fwd(const jh_blockop *op, void *d, const void *m, bool fmode = false)   // JetBlock_df! / JetBlock_f!
 {
     const size_t es = jh_dtype_size(op->dtype);
@@ -1802,6 +1829,15 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
         }
     }
 
+    if (nrow >= 2 && ncol >= 2 && !op->elementwise) {                          // ... or a grid of them: one tall batch per block column
+        op->dense_batch_grid = true;
+        op->dense_aligned = true;
+        for (size_t k = 0; k < op->blocks.size() && op->dense_batch_grid; k++) {
+            const jh_block_desc &b = op->blocks[k];
+            if (b.kind != JH_OP_DENSE || b.adjoint || b.nr != op->blocks[0].nr || b.nc != op->blocks[0].nc || b.nr == 0 || b.nc == 0) op->dense_batch_grid = false;
+            if (((uintptr_t)b.coeff) & 15u) op->dense_aligned = false;
+        }
+    }
     if (nrow == 1 && ncol >= 2 && ncol <= 32768 && !op->elementwise) {         // ... or wide: one block row of such children
         op->dense_batch_wide = true;
         op->dense_aligned = true;
@@ -1907,6 +1943,7 @@ int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     JH_TRY(check_vectors(op, d, m, "jh_blockop_f"));
     if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false);
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
+    if (op->dense_batch_grid) return dense_grid_fwd(op, d->data, m->data);
     if (!op->elementwise) return run_loop_graphed(op, 2, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data, true); });
     switch (op->dtype) {
     case JH_F32: return general_fwd<float, 1>(op, d->data, m->data, 1);
@@ -1934,6 +1971,7 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     }
     if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false);
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
+    if (op->dense_batch_grid) return dense_grid_fwd(op, d->data, m->data);
     if (!op->elementwise) return run_loop_graphed(op, 0, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data); });
     switch (op->dtype) {
     case JH_F32: return general_fwd<float, 1>(op, d->data, m->data);
@@ -1961,6 +1999,7 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
     }
     if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, false);
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, true);
+    if (op->dense_batch_grid) return dense_grid_adj(op, m->data, d->data);
     if (!op->elementwise) return run_loop_graphed(op, 1, m->data, d->data, [&] { return loop_adj(op, m->data, d->data); });
     switch (op->dtype) {
     case JH_F32: return general_adj<float, 1>(op, m->data, d->data);

@@ -122,6 +122,7 @@ struct jh_blockop {
     bool elementwise = false;                // no DENSE block
     bool dense_batch = false;                // tall, >= 2 rows, every block an un-adjointed DENSE matrix of one shape: batched kernels (jh_dense.hip)
     bool dense_batch_wide = false;           // the same for ONE block row of >= 2 such children
+    bool dense_batch_grid = false;           // the same for an M x K grid (M, K >= 2): one tall batch per block column
     bool dense_aligned = false;              // ... and every matrix pointer on a 16-byte boundary
     bool launch_bound = true;                // the per-block loop of an operator with DENSE blocks is replayed as a hipGraph (it pays for small children)
     bool nonlinear = false;                  // has a SQUARE block (JopNl child)

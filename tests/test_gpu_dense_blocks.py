@@ -144,3 +144,30 @@ def test_batched_dense_children_of_a_wide_operator(Jets, oracle, dt, nchild, nr,
     assert _err(mt.to_numpy(), truth) < _tol(dt)
     lhs, rhs = Jets.dot_product_test(A, m, dd)
     assert abs(lhs - rhs) / abs(lhs + rhs) < (1e-5 if _tol(dt) > 1e-10 else 1e-12)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,ncol,nr,nc", [(2, 2, 5, 5), (3, 4, 10, 6), (6, 3, 64, 32), (40, 5, 16, 48)])
+def test_batched_dense_children_of_a_grid_operator(Jets, oracle, dt, nrow, ncol, nr, nc):
+    """An M x K operator of uniform dense children runs one tall batch per block column: d_i = ((found + A_i1 m_1) + A_i2 m_2) + ...
+    in the reference's order (src/Jets.jl:1020-1024) -- bit-exact for children below 1 MiB --, m_j = sum_i A_ij' d_i."""
+    mats = [[np.asfortranarray(u01(oracle, dt, 970, 1000 * i + j, nr * nc).reshape((nr, nc), order="F")) for j in range(ncol)] for i in range(nrow)]
+    A = Jets.blockop([[Jets.JopDense(Jets.from_numpy(mats[i][j])) for j in range(ncol)] for i in range(nrow)])
+    ora = [[oracle.Block("dense", nr, nc, coeff=mats[i][j]) for j in range(ncol)] for i in range(nrow)]
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=0)
+    hm = u01(oracle, dt, SEED_M, 0, ncol * nc)
+    mb = [hm[j * nc:(j + 1) * nc].copy() for j in range(ncol)]
+    d = Jets.rand(Jets.range(A), seed=5, stream=5)
+    hd0 = u01(oracle, dt, 5, 5, nrow * nr)
+    Jets.mul_(d, A, m)
+    ref_d = oracle.block_df(ora, [hd0[i * nr:(i + 1) * nr].copy() for i in range(nrow)], mb)
+    assert_bits_equal(d.to_numpy(), np.concatenate(ref_d), "grid of dense children, forward into d as found")
+    dd = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    hd = u01(oracle, dt, SEED_D, 0, nrow * nr).reshape(nrow, nr)
+    mt = Jets.rand(Jets.domain(A), seed=6, stream=6)
+    Jets.mul_(mt, A.H, dd)
+    wide = np.clongdouble if np.iscomplexobj(mats[0][0]) else np.longdouble
+    truth = np.concatenate([sum(np.conj(mats[i][j].astype(wide)).T @ hd[i].astype(wide) for i in range(nrow)) for j in range(ncol)])
+    assert _err(mt.to_numpy(), truth) < _tol(dt)
+    lhs, rhs = Jets.dot_product_test(A, m, dd)
+    assert abs(lhs - rhs) / abs(lhs + rhs) < (1e-5 if _tol(dt) > 1e-10 else 1e-12)
