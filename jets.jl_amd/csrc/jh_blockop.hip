@@ -1829,6 +1829,22 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
         }
     }
 
+    if (op->tall && nrow >= 2 && !op->elementwise && !op->dense_batch) {       // ... or ragged: same column count, different row counts
+        op->dense_batch_ragged = true;
+        bool al = true;
+        const size_t es = jh_dtype_size(dtype);
+        int64_t maxnr = 0;
+        for (int64_t i = 0; i < nrow && op->dense_batch_ragged; i++) {
+            const jh_block_desc &b = op->blocks[(size_t)i];
+            if (b.kind != JH_OP_DENSE || b.adjoint || b.nc != op->blocks[0].nc || b.nr == 0 || b.nc == 0) op->dense_batch_ragged = false;
+            if ((((uintptr_t)b.coeff) & 15u) || ((size_t)b.nr * es) % 16 || ((size_t)op->row_off[(size_t)i] * es) % 16) al = false;
+            if (b.nr > maxnr) maxnr = b.nr;
+        }
+        // the ragged kernels write every child's rows directly: the columns must not need splitting (children small or many)
+        const double max_bytes = (double)maxnr * (double)op->blocks[0].nc * (double)es;
+        if (op->dense_batch_ragged && max_bytes >= (double)(1 << 20) && ((maxnr * (int64_t)es / 16 + 255) / 256) * nrow < 2048) op->dense_batch_ragged = false;
+        if (op->dense_batch_ragged) { op->dense_aligned = al; op->dense_max_nr = maxnr; }
+    }
     if (nrow >= 2 && ncol >= 2 && !op->elementwise) {                          // ... or a grid of them: one tall batch per block column
         op->dense_batch_grid = true;
         op->dense_aligned = true;
@@ -1944,6 +1960,7 @@ int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false);
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
     if (op->dense_batch_grid) return dense_grid_fwd(op, d->data, m->data);
+    if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false, op->dev_row_off);
     if (!op->elementwise) return run_loop_graphed(op, 2, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data, true); });
     switch (op->dtype) {
     case JH_F32: return general_fwd<float, 1>(op, d->data, m->data, 1);
@@ -1972,6 +1989,7 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false);
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
     if (op->dense_batch_grid) return dense_grid_fwd(op, d->data, m->data);
+    if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false, op->dev_row_off);
     if (!op->elementwise) return run_loop_graphed(op, 0, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data); });
     switch (op->dtype) {
     case JH_F32: return general_fwd<float, 1>(op, d->data, m->data);
@@ -2000,6 +2018,7 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
     if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, false);
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, true);
     if (op->dense_batch_grid) return dense_grid_adj(op, m->data, d->data);
+    if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, false, op->dev_row_off);
     if (!op->elementwise) return run_loop_graphed(op, 1, m->data, d->data, [&] { return loop_adj(op, m->data, d->data); });
     switch (op->dtype) {
     case JH_F32: return general_adj<float, 1>(op, m->data, d->data);

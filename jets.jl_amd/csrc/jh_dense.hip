@@ -124,13 +124,18 @@ __global__ void k_sum_col_chunks(const double *__restrict__ partial, int64_t nc,
 template <typename S, int E, int NS>
 __global__ __launch_bounds__(256) void k_gemv_rows_batched(const jh_dev_block *__restrict__ blocks, int64_t z0, int64_t nr, int64_t nc,
                                                            const S *__restrict__ x, int64_t x_stride, S *__restrict__ out,
-                                                           int64_t child_stride, int64_t chunk_stride, int64_t cols_per_chunk)
+                                                           int64_t child_stride, int64_t chunk_stride, int64_t cols_per_chunk,
+                                                           const int64_t *__restrict__ row_off)
 {
     typedef typename vec_of<S, NS>::type V;
     const int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * NS;
-    const int64_t ns = nr * E;
-    if (s >= ns) return;
     const int64_t z = z0 + blockIdx.z;
+    int64_t ns = nr * E, obase = z * child_stride;
+    if (row_off) {                                                             // ragged children (shots with different trace counts): child z
+        ns = (row_off[z + 1] - row_off[z]) * E;                                // has its own row count (= its leading dimension) and writes
+        obase = row_off[z] * E;                                                // its block of the slab directly (one column chunk only)
+    }
+    if (s >= ns) return;
     const S *A = (const S *)blocks[z].coeff;
     x += z * x_stride;                                                         // tall: every child reads m (stride 0); wide: child z reads m_z
     const int64_t c0 = (int64_t)blockIdx.y * cols_per_chunk;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows_batched(const jh_dev_block *_
             acc = acc + p;
         }
     }
-    *reinterpret_cast<V *>(out + z * child_stride + (int64_t)blockIdx.y * chunk_stride + s) = acc;
+    *reinterpret_cast<V *>(out + obase + (int64_t)blockIdx.y * chunk_stride + s) = acc;
 }
 
 // y[z][k] = sum over column chunks (in order) of partial[z][chunk][k]
@@ -173,18 +178,22 @@ __global__ void k_sum_chunks_batched(const S *__restrict__ partial, int64_t ns, 
 template <typename S, int E, int NS>
 __global__ __launch_bounds__(256) void k_gemv_cols_batched(const jh_dev_block *__restrict__ blocks, int64_t z0, int64_t nr, int64_t nc,
                                                            const S *__restrict__ d, int64_t d_stride, double *__restrict__ partial,
-                                                           int64_t rows_per_chunk)
+                                                           int64_t rows_per_chunk, const int64_t *__restrict__ row_off)
 {
     typedef typename vec_of<S, NS>::type V;
     const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= nc) return;
     const int lane = threadIdx.x & 63;
     const int64_t z = z0 + blockIdx.z;
-    const int64_t ns = nr * E;
+    int64_t ns = nr * E, dbase = z * d_stride;
+    if (row_off) {                                                             // ragged children: own row count, own block of d
+        ns = (row_off[z + 1] - row_off[z]) * E;
+        dbase = row_off[z] * E;
+    }
     const int64_t s0 = (int64_t)blockIdx.y * rows_per_chunk * E;
     const int64_t s1 = s0 + rows_per_chunk * E < ns ? s0 + rows_per_chunk * E : ns;
     const S *col = (const S *)blocks[z].coeff + c * ns;
-    const S *x = d + z * d_stride;                                             // tall: child z reads d_z; wide: every child reads d (stride 0)
+    const S *x = d + dbase;                                                    // tall: child z reads d_z; wide: every child reads d (stride 0)
     double sr = 0.0, si = 0.0;
     for (int64_t s = s0 + (int64_t)lane * NS; s < s1; s += 64 * NS) {
         V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col + s));
@@ -357,10 +366,10 @@ int gemv_batched_wide(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr
         double *group_sums = c.part_dev + t_doubles;
         if (vec_ok)
             hipLaunchKernelGGL((k_gemv_rows_batched<S, E, NSV>), dim3((unsigned)row_wgs, (unsigned)nchunks, (unsigned)nchild), dim3(256), 0, st, dev_blocks,
-                               (int64_t)0, nr, nc, (const S *)x, nc * E, T, nchunks * ns, ns, cpc);
+                               (int64_t)0, nr, nc, (const S *)x, nc * E, T, nchunks * ns, ns, cpc, (const int64_t *)nullptr);
         else
             hipLaunchKernelGGL((k_gemv_rows_batched<S, E, E>), dim3((unsigned)row_wgs, (unsigned)nchunks, (unsigned)nchild), dim3(256), 0, st, dev_blocks,
-                               (int64_t)0, nr, nc, (const S *)x, nc * E, T, nchunks * ns, ns, cpc);
+                               (int64_t)0, nr, nc, (const S *)x, nc * E, T, nchunks * ns, ns, cpc, (const int64_t *)nullptr);
         JH_CHECK_HIP(hipGetLastError());
         if (nchild <= 64) {
             hipLaunchKernelGGL((k_fold_wide_ordered<S>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, T, ns, (int)nchunks, (int)nchild, (S *)y);
@@ -389,18 +398,20 @@ int gemv_batched_wide(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr
     JH_TRY(jh_ensure_partials(2 * nchild * nchunks * nc));
     if (vec_ok)
         hipLaunchKernelGGL((k_gemv_cols_batched<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)nchild), dim3(256), 0, st, dev_blocks,
-                           (int64_t)0, nr, nc, (const S *)x, (int64_t)0, c.part_dev, rpc);
+                           (int64_t)0, nr, nc, (const S *)x, (int64_t)0, c.part_dev, rpc, (const int64_t *)nullptr);
     else
         hipLaunchKernelGGL((k_gemv_cols_batched<S, E, E>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)nchild), dim3(256), 0, st, dev_blocks,
-                           (int64_t)0, nr, nc, (const S *)x, (int64_t)0, c.part_dev, rpc);
+                           (int64_t)0, nr, nc, (const S *)x, (int64_t)0, c.part_dev, rpc, (const int64_t *)nullptr);
     JH_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL((k_store_col_sums<S, E>), dim3((unsigned)((nc + 255) / 256), (unsigned)nchild), dim3(256), 0, st, c.part_dev, nc, (int)nchunks, (S *)y);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
 
+// row_off != nullptr: ragged children -- `nr` is then the LARGEST row count (grid sizing), every child's own count comes from the table
 template <typename S, int E>
-int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, void *y, const void *x, int adjoint, bool aligned)
+int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, void *y, const void *x, int adjoint, bool aligned,
+                 const int64_t *row_off = nullptr)
 {
     jh_context &c = jh_ctx();
     hipStream_t st = c.stream;
@@ -413,7 +424,7 @@ int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int
         const int NS = vec_ok ? NSV : E;
         const int64_t row_wgs = (ns / NS + 255) / 256;
         int64_t nchunks = 1;                                                   // split the columns only while the chip is not full
-        if (child_bytes >= (double)(1 << 20) && row_wgs * nchild < 2048) {
+        if (!row_off && child_bytes >= (double)(1 << 20) && row_wgs * nchild < 2048) {
             nchunks = (2048 + row_wgs * nchild - 1) / (row_wgs * nchild);
             const int64_t maxc = (nc + 31) / 32;
             if (nchunks > maxc) nchunks = maxc;
@@ -432,10 +443,10 @@ int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int
             const unsigned gz = (unsigned)(nchild - z0 < zmax ? nchild - z0 : zmax);
             if (vec_ok)
                 hipLaunchKernelGGL((k_gemv_rows_batched<S, E, NSV>), dim3((unsigned)row_wgs, (unsigned)nchunks, gz), dim3(256), 0, st, dev_blocks, z0,
-                                   nr, nc, (const S *)x, (int64_t)0, out, child_stride, chunk_stride, cpc);
+                                   nr, nc, (const S *)x, (int64_t)0, out, child_stride, chunk_stride, cpc, row_off);
             else
                 hipLaunchKernelGGL((k_gemv_rows_batched<S, E, E>), dim3((unsigned)row_wgs, (unsigned)nchunks, gz), dim3(256), 0, st, dev_blocks, z0,
-                                   nr, nc, (const S *)x, (int64_t)0, out, child_stride, chunk_stride, cpc);
+                                   nr, nc, (const S *)x, (int64_t)0, out, child_stride, chunk_stride, cpc, row_off);
             JH_CHECK_HIP(hipGetLastError());
         }
         if (nchunks > 1) {
@@ -475,10 +486,10 @@ int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int
         const S *d0 = (const S *)x;
         if (vec_ok)
             hipLaunchKernelGGL((k_gemv_cols_batched<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)gz), dim3(256), 0, st, dev_blocks,
-                               z0, nr, nc, d0, ns, c.part_dev, rpc);
+                               z0, nr, nc, d0, ns, c.part_dev, rpc, row_off);
         else
             hipLaunchKernelGGL((k_gemv_cols_batched<S, E, E>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)gz), dim3(256), 0, st, dev_blocks,
-                               z0, nr, nc, d0, ns, c.part_dev, rpc);
+                               z0, nr, nc, d0, ns, c.part_dev, rpc, row_off);
         JH_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL((k_fold_children<S, E>), dim3((unsigned)fold_wgs, (unsigned)ngroups), dim3(256), 0, st, c.part_dev, nc, (int)nchunks,
                            (int)gz, (int)per_group, group_sums);
@@ -574,7 +585,7 @@ int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, co
 
 // all children of a tall operator of uniform dense blocks in one go (jh_blockop.hip); `aligned`: every matrix pointer on 16 bytes
 int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, int dtype, void *y, const void *x,
-                           int adjoint, bool aligned, bool wide)
+                           int adjoint, bool aligned, bool wide, const int64_t *dev_row_off)
 {
     if (wide)
         switch (dtype) {
@@ -584,10 +595,10 @@ int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64
         case JH_C64: return gemv_batched_wide<double, 2>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
         }
     switch (dtype) {
-    case JH_F32: return gemv_batched<float, 1>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
-    case JH_F64: return gemv_batched<double, 1>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
-    case JH_C32: return gemv_batched<float, 2>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
-    case JH_C64: return gemv_batched<double, 2>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned);
+    case JH_F32: return gemv_batched<float, 1>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned, dev_row_off);
+    case JH_F64: return gemv_batched<double, 1>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned, dev_row_off);
+    case JH_C32: return gemv_batched<float, 2>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned, dev_row_off);
+    case JH_C64: return gemv_batched<double, 2>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned, dev_row_off);
     }
     return jh_fail(JH_ERR_INVALID, "gemv_batched: unknown dtype %d", dtype);
 }

@@ -122,6 +122,8 @@ struct jh_blockop {
     bool elementwise = false;                // no DENSE block
     bool dense_batch = false;                // tall, >= 2 rows, every block an un-adjointed DENSE matrix of one shape: batched kernels (jh_dense.hip)
     bool dense_batch_wide = false;           // the same for ONE block row of >= 2 such children
+    bool dense_batch_ragged = false;         // tall, every block an un-adjointed DENSE matrix with the same column count, row counts differ (one column chunk suffices)
+    int64_t dense_max_nr = 0;
     bool dense_batch_grid = false;           // the same for an M x K grid (M, K >= 2): one tall batch per block column
     bool dense_aligned = false;              // ... and every matrix pointer on a 16-byte boundary
     bool launch_bound = true;                // the per-block loop of an operator with DENSE blocks is replayed as a hipGraph (it pays for small children)
@@ -151,6 +153,6 @@ int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const doub
 // dense child operator (jh_dense.hip): y = A x (rows) or y = A^H x / A^T x (cols); A column-major nr x nc
 int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, const void *x, int adjoint);
 int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, int dtype, void *y, const void *x,
-                           int adjoint, bool aligned, bool wide);   // jh_dense.hip: every child of a tall (or wide) operator of uniform dense blocks at once
+                           int adjoint, bool aligned, bool wide, const int64_t *dev_row_off = nullptr);   // jh_dense.hip: every child of a tall (or wide) operator of uniform dense blocks at once
 int jh_ensure_scratch(size_t bytes, void **out);
 extern "C" int jh_comm_destroy(void);   // jh_comm.hip; jh_shutdown tears the communicator down first   // growable device scratch (block-loop temporaries)

@@ -84,9 +84,9 @@ def test_batched_dense_large_children_split_columns(Jets, oracle):
     assert _err(mt.to_numpy().ravel(order="F"), truth_m) < 1e-6
 
 
-def test_adjointed_or_ragged_dense_children_keep_the_loop(Jets, oracle):
-    """A child carrying the adjoint flag, or children of different shapes, are outside the batched kernels: the reference's
-    per-block loop runs (and still matches the oracle)."""
+def test_adjointed_dense_children_keep_the_loop_and_ragged_ones_batch(Jets, oracle):
+    """A child carrying the adjoint flag is outside the batched kernels: the reference's per-block loop runs (and still matches
+    the oracle); children that differ only in their ROW count (shots with different trace counts) batch through the row table."""
     dt = np.float64
     hA = [np.asfortranarray(u01(oracle, dt, 901, z, 12 * 12).reshape((12, 12), order="F")) for z in range(3)]
     dev = [Jets.JopDense(Jets.from_numpy(a)) for a in hA]
@@ -171,3 +171,28 @@ def test_batched_dense_children_of_a_grid_operator(Jets, oracle, dt, nrow, ncol,
     assert _err(mt.to_numpy(), truth) < _tol(dt)
     lhs, rhs = Jets.dot_product_test(A, m, dd)
     assert abs(lhs - rhs) / abs(lhs + rhs) < (1e-5 if _tol(dt) > 1e-10 else 1e-12)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("rows,nc", [((8, 12, 4, 16), 8), ((5, 7, 3), 6), (tuple(4 * (1 + (k * 7) % 9) for k in range(300)), 64), (tuple(3 + (k * 5) % 11 for k in range(50)), 33)])
+def test_batched_ragged_tall_dense_children(Jets, oracle, dt, rows, nc):
+    """Tall operator of dense children with different row counts (the seismic case: shots with different numbers of traces) on the
+    batched kernels through the row-offset table: forward bit-exact (every child writes its rows in one ordered column sweep),
+    adjoint within tolerance; 16-byte aligned and unaligned row counts."""
+    mats = [np.asfortranarray(u01(oracle, dt, 990, z, nr * nc).reshape((nr, nc), order="F")) for z, nr in enumerate(rows)]
+    A = Jets.blockop([[Jets.JopDense(Jets.from_numpy(a))] for a in mats])
+    ora = [[oracle.Block("dense", a.shape[0], nc, coeff=a)] for a in mats]
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=0)
+    hm = u01(oracle, dt, SEED_M, 0, nc)
+    d = Jets.rand(Jets.range(A), seed=5, stream=5)
+    Jets.mul_(d, A, m)
+    ref = oracle.block_df(ora, [np.zeros(nr, dtype=dt) for nr in rows], [hm])
+    assert_bits_equal(d.to_numpy(), np.concatenate(ref), "ragged tall dense forward")
+    dd = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    hd = u01(oracle, dt, SEED_D, 0, sum(rows))
+    off = np.cumsum((0,) + tuple(rows))
+    mt = Jets.rand(Jets.domain(A), seed=6, stream=6)
+    Jets.mul_(mt, A.H, dd)
+    wide = np.clongdouble if np.iscomplexobj(mats[0]) else np.longdouble
+    truth = sum(np.conj(mats[z].astype(wide)).T @ hd[off[z]:off[z + 1]].astype(wide) for z in range(len(rows)))
+    assert _err(mt.to_numpy().ravel(order="F"), truth) < _tol(dt)
