@@ -358,6 +358,7 @@ int gemv_batched_wide(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr
         const int64_t fold_wgs = (ns + 63) / 64;
         int64_t ngroups = (2048 + fold_wgs - 1) / fold_wgs;
         if (ngroups > nchild / 8) ngroups = nchild / 8;
+        { int64_t r = 1; while ((r + 1) * (r + 1) <= nchild) r++; if (ngroups > r) ngroups = r; }
         if (ngroups < 1) ngroups = 1;
         const int64_t per_group = (nchild + ngroups - 1) / ngroups;
         ngroups = (nchild + per_group - 1) / per_group;
@@ -475,8 +476,9 @@ int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int
     for (int64_t z0 = 0; z0 < nchild; z0 += zstep) {
         const int64_t gz = nchild - z0 < zstep ? nchild - z0 : zstep;
         const int64_t fold_wgs = (nc + 63) / 64;
-        int64_t ngroups = (2048 + fold_wgs - 1) / fold_wgs;                    // enough workgroups for the fold of many small children
+        int64_t ngroups = (2048 + fold_wgs - 1) / fold_wgs;                    // enough workgroups for the fold of many small children,
         if (ngroups > gz / 8) ngroups = gz / 8;
+        { int64_t r = 1; while ((r + 1) * (r + 1) <= gz) r++; if (ngroups > r) ngroups = r; }   // but the second stage walks the groups serially: ~sqrt
         if (ngroups < 1) ngroups = 1;
         const int64_t per_group = (gz + ngroups - 1) / ngroups;
         ngroups = (gz + per_group - 1) / per_group;
