@@ -225,6 +225,77 @@ __global__ __launch_bounds__(256) void k_gemv_cols_batched(const jh_dev_block *_
     }
 }
 
+// The same for SMALL uniform children whose column fits one pass of (part of) a wave (<= 64 packs): `lpc` lanes per column (a power
+// of two), 64/lpc columns per wave, and CH children per wave with all their loads in flight before the reductions -- a quarter of
+// the waves, each with real memory-level parallelism (4096 children of 256^2: 0.29 -> see profiles/bench_dense_blocks_r01.txt).
+template <typename S, int E, int NS, int CH>
+__global__ __launch_bounds__(256) void k_gemv_cols_small(const jh_dev_block *__restrict__ blocks, int64_t z0, int nchild, int64_t nr, int64_t nc,
+                                                         const S *__restrict__ d, int64_t d_stride, double *__restrict__ partial, int lpc)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cpw = 64 / lpc, sub = lane % lpc, which = lane / lpc;
+    const int64_t c = ((int64_t)blockIdx.x * 4 + wave) * cpw + which;
+    const int64_t ns = nr * E, s = (int64_t)sub * NS;
+    const bool live = c < nc && s < ns;
+    const int zl0 = (int)blockIdx.z * CH;
+    V a[CH], xv[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+        a[ch] = (V)(S)0;
+        xv[ch] = (V)(S)0;
+        if (live && zl0 + ch < nchild) {
+            const int64_t z = z0 + zl0 + ch;
+            a[ch] = __builtin_nontemporal_load(reinterpret_cast<const V *>((const S *)blocks[z].coeff + c * ns + s));
+            xv[ch] = *reinterpret_cast<const V *>(d + z * d_stride + s);
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+        double sr = 0.0, si = 0.0;
+        if constexpr (E == 1) {
+#pragma unroll
+            for (int e = 0; e < NS; e++) {
+                if constexpr (NS == 1) sr += (double)a[ch] * (double)xv[ch];
+                else sr += (double)a[ch][e] * (double)xv[ch][e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NS; e += 2) {
+                const double ar = a[ch][e], ai = -(double)a[ch][e + 1], xr = xv[ch][e], xi = xv[ch][e + 1];
+                sr += ar * xr - ai * xi;
+                si += ar * xi + ai * xr;
+            }
+        }
+        for (int off = lpc >> 1; off > 0; off >>= 1) {
+            sr += __shfl_down(sr, off, lpc);
+            if (E == 2) si += __shfl_down(si, off, lpc);
+        }
+        if (sub == 0 && c < nc && zl0 + ch < nchild) {
+            double *p = partial + ((int64_t)(zl0 + ch) * nc + c) * 2;
+            p[0] = sr;
+            p[1] = si;
+        }
+    }
+}
+
+template <typename S, int E, int NS>
+static bool launch_cols_small(const jh_dev_block *dev_blocks, int64_t z0, int64_t gz, int64_t nr, int64_t nc, const S *d, int64_t d_stride,
+                              double *partial, hipStream_t st)
+{
+    const int64_t packs = (nr * E + NS - 1) / NS;
+    if (packs > 64 || (nr * E) % NS != 0) return false;
+    int lpc = 1;
+    while (lpc < packs) lpc *= 2;
+    const int cpw = 64 / lpc;
+    constexpr int CH = 4;
+    const int64_t gx = (nc + 4 * cpw - 1) / (4 * cpw), gzz = (gz + CH - 1) / CH;
+    if (gx > 65535 * 32768ll || gzz > 65535) return false;
+    hipLaunchKernelGGL((k_gemv_cols_small<S, E, NS, CH>), dim3((unsigned)gx, 1, (unsigned)gzz), dim3(256), 0, st, dev_blocks, z0, (int)gz, nr, nc, d,
+                       d_stride, partial, lpc);
+    return true;
+}
+
 // group sums: group g = children [g*per_group, (g+1)*per_group) of this launch: mtmp_z = A_z' d_z (its row chunks added, then
 // rounded to the element type like the per-child kernel does, 1049) summed over the group's children in fp64 -- 64 column lanes
 // x 4 child lanes per workgroup, fixed order; k_fold_groups adds the groups.  Two stages so that thousands of small children
@@ -397,7 +468,9 @@ int gemv_batched_wide(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr
     if (rpc < 4) rpc = 4;
     nchunks = nr ? (nr + rpc - 1) / rpc : 1;
     JH_TRY(jh_ensure_partials(2 * nchild * nchunks * nc));
-    if (vec_ok)
+    if (nchunks == 1 && (vec_ok ? launch_cols_small<S, E, NSV>(dev_blocks, 0, nchild, nr, nc, (const S *)x, 0, c.part_dev, st)
+                                : launch_cols_small<S, E, E>(dev_blocks, 0, nchild, nr, nc, (const S *)x, 0, c.part_dev, st))) {
+    } else if (vec_ok)
         hipLaunchKernelGGL((k_gemv_cols_batched<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)nchild), dim3(256), 0, st, dev_blocks,
                            (int64_t)0, nr, nc, (const S *)x, (int64_t)0, c.part_dev, rpc, (const int64_t *)nullptr);
     else
@@ -486,7 +559,9 @@ int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int
         JH_TRY(jh_ensure_partials(npart + 2 * ngroups * nc));
         double *group_sums = c.part_dev + npart;
         const S *d0 = (const S *)x;
-        if (vec_ok)
+        if (!row_off && nchunks == 1 && (vec_ok ? launch_cols_small<S, E, NSV>(dev_blocks, z0, gz, nr, nc, d0, ns, c.part_dev, st)
+                                                : launch_cols_small<S, E, E>(dev_blocks, z0, gz, nr, nc, d0, ns, c.part_dev, st))) {
+        } else if (vec_ok)
             hipLaunchKernelGGL((k_gemv_cols_batched<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)gz), dim3(256), 0, st, dev_blocks,
                                z0, nr, nc, d0, ns, c.part_dev, rpc, row_off);
         else
