@@ -427,12 +427,15 @@ int gemv_batched_wide(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr
         nchunks = (nc + cpc - 1) / cpc;
         const int64_t t_doubles = ((int64_t)nchild * nchunks * ns * (int64_t)sizeof(S) + 7) / 8 + 2;
         const int64_t fold_wgs = (ns + 63) / 64;
+        // once the columns are split the sum is tolerance-level anyway: fold all (child, chunk) partial rows alike, in fp64
+        const bool ordered = nchild <= 64 && nchunks == 1;
+        const int64_t nitems = nchild * nchunks;
         int64_t ngroups = (2048 + fold_wgs - 1) / fold_wgs;
-        if (ngroups > nchild / 8) ngroups = nchild / 8;
-        { int64_t r = 1; while ((r + 1) * (r + 1) <= nchild) r++; if (ngroups > r) ngroups = r; }
+        if (ngroups > nitems / 8) ngroups = nitems / 8;
+        { int64_t r = 1; while ((r + 1) * (r + 1) <= nitems) r++; if (ngroups > r) ngroups = r; }
         if (ngroups < 1) ngroups = 1;
-        const int64_t per_group = (nchild + ngroups - 1) / ngroups;
-        ngroups = (nchild + per_group - 1) / per_group;
+        const int64_t per_group = (nitems + ngroups - 1) / ngroups;
+        ngroups = (nitems + per_group - 1) / per_group;
         JH_TRY(jh_ensure_partials(t_doubles + ngroups * ns));
         S *T = (S *)c.part_dev;
         double *group_sums = c.part_dev + t_doubles;
@@ -443,10 +446,10 @@ int gemv_batched_wide(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr
             hipLaunchKernelGGL((k_gemv_rows_batched<S, E, E>), dim3((unsigned)row_wgs, (unsigned)nchunks, (unsigned)nchild), dim3(256), 0, st, dev_blocks,
                                (int64_t)0, nr, nc, (const S *)x, nc * E, T, nchunks * ns, ns, cpc, (const int64_t *)nullptr);
         JH_CHECK_HIP(hipGetLastError());
-        if (nchild <= 64) {
+        if (ordered) {
             hipLaunchKernelGGL((k_fold_wide_ordered<S>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, T, ns, (int)nchunks, (int)nchild, (S *)y);
         } else {
-            hipLaunchKernelGGL((k_fold_wide_groups<S>), dim3((unsigned)fold_wgs, (unsigned)ngroups), dim3(256), 0, st, T, ns, (int)nchunks, (int)nchild,
+            hipLaunchKernelGGL((k_fold_wide_groups<S>), dim3((unsigned)fold_wgs, (unsigned)ngroups), dim3(256), 0, st, T, ns, 1, (int)nitems,
                                (int)per_group, group_sums);
             JH_CHECK_HIP(hipGetLastError());
             hipLaunchKernelGGL((k_fold_wide_final<S>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, group_sums, ns, (int)ngroups, (S *)y);
