@@ -186,7 +186,11 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
                       const int64_t *col_len, int dtype, jh_blockop **out);
 int jh_blockop_destroy(jh_blockop *op);
 /* mul!(d, A, m) -> JetBlock_df!, src/Jets.jl:1010-1032, one fused launch.  Reference quirks kept:
- * zero blocks are skipped (1022); with ncol > 1 the result is accumulated into d without zeroing (1024). */
+ * zero blocks are skipped (1022); with ncol > 1 the result is accumulated into d without zeroing (1024).
+ * With >= 256 block columns of blocks too small to fill the chip, the sum over the columns is cut into parts and folded
+ * (deterministic, tolerance parity; jh_tune_set("adj_split", 0) keeps the ordered sum) -- see jh_blockop_mul_adj.
+ * Tall, wide and M x K operators made of un-adjointed DENSE blocks of one shape (tall ones may differ in row counts) run
+ * batched GEMV kernels: every child in one launch. */
 int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m);
 /* mul!(m, A', d) -> JetBlock_df'!, src/Jets.jl:1034-1057: m zeroed when nrow > 1 (1042), rows summed
  * in order i = 0..nrow-1 with the product rounded before the add (1049) => bit-exact on one GPU.
