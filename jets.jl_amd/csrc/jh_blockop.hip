@@ -833,7 +833,7 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
                     if (b[q].kind == JH_OP_ZERO) on[q] = (fmode != 0);     // (1022) skipped; f! keeps it as +0 -- and never loads for it
                     else {
                         x[q] = ld<false>(reinterpret_cast<const V *>(m + col_off[j] * E + s));
-                        if (block_reads_coeff(b[q], fmode != 0)) c[q] = ld<false>(reinterpret_cast<const V *>((const S *)b[q].coeff + s));
+                        if (block_reads_coeff(b[q], fmode != 0)) c[q] = ld<true>(reinterpret_cast<const V *>((const S *)b[q].coeff + s));   // streamed once
                     }
                 }
             }
@@ -845,7 +845,10 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
                     touched = true;
                 }
         }
-        if (touched) st<false>(reinterpret_cast<V *>(d + row_off[i] * E + s), acc);
+        if (touched) {
+            if (split) st<false>(reinterpret_cast<V *>(d + row_off[i] * E + s), acc);            // a slab: the fold reads it back
+            else st<true>(reinterpret_cast<V *>(d + row_off[i] * E + s), acc);                   // the result row: written once
+        }
     }
 }
 
@@ -885,7 +888,7 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
                     if (b[q].kind == JH_OP_ZERO) on[q] = false;            // (1047)
                     else {
                         x[q] = ld<false>(reinterpret_cast<const V *>(d + row_off[i] * E + s));
-                        if (block_reads_coeff(b[q], false)) c[q] = ld<false>(reinterpret_cast<const V *>((const S *)b[q].coeff + s));
+                        if (block_reads_coeff(b[q], false)) c[q] = ld<true>(reinterpret_cast<const V *>((const S *)b[q].coeff + s));   // streamed once
                     }
                 }
             }
