@@ -104,19 +104,75 @@ def cpu_baseline(edge: int, nblocks_full: int, sample_blocks: int, pairs: int) -
         "kind": "port",
         "sample": f"{sample_blocks} of {nblocks_full} block rows ({edge}^3 Float32 each), median of {pairs} pairs = {med:.3f} s/pair, "
                   f"{bytes_pair / med / 1e9:.1f} GB/s algorithmic; value = sample pairs/s x {sample_blocks}/{nblocks_full} (bandwidth-bound, linear in rows)",
+        "build": "gcc -O2 -ftree-vectorize -ffp-contract=off (oracle/Makefile; BASELINE.md section 3)",
         "host_cores_available": os.cpu_count(),
         "all_cores_variant": allcores,
     }
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- one child process per GPU, the same
+    environment torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) --
+    BEFORE this process has made any GPU call (it never does: no torch import, no HIP), and relay the outcome: rank 0's ONE
+    JSON line goes to our stdout as is, the exit code is non-zero if any rank failed.  No process that has touched the GPU
+    is ever re-executed."""
+    import signal
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GROUP_RANK="0", BENCH_SELF_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")               # dmabuf IPC: RCCL's intra-node transport needs it on this pool
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+
+    def stop_all(*_):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()                                           # exact PIDs we started, nothing by pattern
+
+    signal.signal(signal.SIGTERM, lambda *a: (stop_all(), sys.exit(143)))
+    rc = 0
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    stop_all()
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        stop_all()
+        rc = 130
+    finally:
+        deadline = time.time() + 15
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
+
+
 def main():
     args = parse_args()
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))                      # the parent never touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
     import torch
@@ -125,13 +181,19 @@ def main():
     ndev = torch.cuda.device_count()                                  # (does not initialise the GPU)
     if ndev < 1:
         raise SystemExit("bench.py: no MI355X visible -- there is no CPU path to fall back to")
+    backend = os.environ.get("BENCH_BACKEND", "nccl")                # "gloo": validation with several ranks on ONE GPU (RCCL refuses that)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if backend == "nccl" and world > 1 and ndev < local_world and ndev != 1:
+        raise SystemExit(f"bench.py: {local_world} ranks on this node but only {ndev} devices visible (RCCL wants one device per rank)")
+    if backend == "nccl" and world > 1 and ndev == 1 and os.environ.get("HIP_VISIBLE_DEVICES") is None and os.environ.get("ROCR_VISIBLE_DEVICES") is None:
+        raise SystemExit(f"bench.py: --gpus {world} but ONE device visible: RCCL refuses several ranks on one device "
+                         "(BENCH_BACKEND=gloo validates the multi-rank flow on a one-GPU box)")
     device = local_rank % ndev                                        # a launcher that narrows HIP_VISIBLE_DEVICES per rank leaves one device
     dist = None
     if world > 1 or (force_dist and "RANK" in os.environ):
         import torch.distributed as dist  # noqa: F811
 
         torch.cuda.set_device(device)
-        backend = os.environ.get("BENCH_BACKEND", "nccl")            # "gloo": validation with several ranks on ONE GPU (RCCL refuses that)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
         else:
@@ -202,6 +264,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- multi-rank diagnostics, OUTSIDE the timed region: per-rank device times, the local adjoint kernel alone and the
+    # stand-alone all-reduce, so that the exposed part of the exchange can be read off the line (adj_ms - adj_kernel_ms)
+    multi = None
+    if dist is not None:
+        reps = max(3, min(args.steps, 10))
+        f_ms = sum(ev[k][0].elapsed_ms(ev[k][1]) for k in range(args.steps)) / args.steps
+        a_ms = sum(ev[k][1].elapsed_ms(ev[k][2]) for k in range(args.steps)) / args.steps
+        J.mul_(mt, A.H, d)
+        e0 = J.Event().record()
+        for _ in range(reps):
+            J.mul_(mt, A.H, d)                                       # this rank's rows, no exchange
+        e1 = J.Event().record()
+        k_ms = e0.elapsed_ms(e1) / reps
+        fence()
+        shard.comm.all_reduce_sum_(mt, force=force_dist)
+        e0 = J.Event().record()
+        for _ in range(reps):
+            shard.comm.all_reduce_sum_(mt, force=force_dist)         # the whole 64 MiB domain vector in one piece, nothing to hide behind
+        e1 = J.Event().record()
+        ar_ms = e0.elapsed_ms(e1) / reps
+        on_gpu = dist.get_backend() == "nccl"
+        mine = torch.tensor([f_ms, a_ms, k_ms, ar_ms], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rows = [[float(x) for x in t.cpu()] for t in every]
+        ar_bytes = n * 4
+        ar_worst = max(r[3] for r in rows)
+        multi = {
+            "backend": dist.get_backend(), "rccl_nranks": world if on_gpu else None,
+            "per_rank": [{"rank": r, "rows": J.rowpart.partition_rows(nblocks, world, r).count, "fwd_ms": rows[r][0], "adj_ms": rows[r][1],
+                          "adj_kernel_ms": rows[r][2], "exposed_exchange_ms": rows[r][1] - rows[r][2]} for r in range(world)],
+            "allreduce": {"bytes": ar_bytes, "chunks_in_adjoint": int(os.environ.get("JETS_AR_CHUNKS", "4")), "ms_standalone": ar_worst,
+                          "busbw_GBps": (2.0 * (world - 1) / world) * ar_bytes / ar_worst / 1e6 if world > 1 and ar_worst > 0 else None,
+                          "exposed_ms_max": max(r[1] - r[2] for r in rows)},
+        }
+
     fwd_t = [ev[k][0].elapsed_ms(ev[k][1]) for k in range(args.steps)]
     adj_t = [ev[k][1].elapsed_ms(ev[k][2]) for k in range(args.steps)]
     pair_t = sorted(f + a for f, a in zip(fwd_t, adj_t))
@@ -220,7 +318,7 @@ def main():
     kernels["adjoint"]["launches_per_call"] = adj_launches
     kernels["forward"]["launches_per_call"] = 1
     dom = max(kernels.values(), key=lambda kv: kv["ms"])
-    traffic = None
+    traffic, traffic_round = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
@@ -231,6 +329,7 @@ def main():
                     persistent = J.tune_get("last_fwd_rows_per_wg") >= nloc   # walk re-reads no m, like the row-concurrent one
                     key += "@walk%d" % (1 if persistent else J.tune_get("last_fwd_walk"))
                 traffic = tj.get(key)
+                traffic_round = tj.get("round")
                 if traffic is not None and dom["launches_per_call"] > 1 and traffic > 0.75 * dom["bytes"]:
                     traffic /= dom["launches_per_call"]                  # recorded when the whole call was one launch
         except Exception:
@@ -303,12 +402,18 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": (None if traffic is None else
+                                   {"measured_in_this_run": False, "file": "profiles/traffic_latest.json", "round": traffic_round,
+                                    "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command (tools/prof_default_pmc.sh), "
+                                           "(2*FETCH_SIZE + WRITE_SIZE) * 1024 B per launch of the named kernel (gfx950 corrections of MI355X_MICROARCH.md)"}),
                 "bytes_per_launch": dom["bytes"] / dom["launches_per_call"], "ms_per_launch": dom["ms"] / dom["launches_per_call"],
                 "launches_per_call": dom["launches_per_call"],
             },
             "kernels": kernels,
         }
         out.update(extra)
+        if multi is not None:
+            out["multi_gpu"] = multi
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(edge, nblocks, min(args.cpu_sample_blocks, nblocks), args.cpu_pairs)

@@ -249,6 +249,12 @@ int jh_blockop_bidiag_step(const jh_blockop *op, jh_bvec *u, const jh_bvec *v, j
  * to jh_blockop_bidiag_step on those elements. */
 int jh_blockop_bidiag_step_range(const jh_blockop *op, jh_bvec *u, const jh_bvec *v, jh_bvec *w, double alpha, double beta,
                                  int64_t first_elem, int64_t count, double *normsq);
+/* Deferred ||u||^2 for a step enqueued range by range: with normsq == NULL jh_blockop_bidiag_step_range does not synchronise;
+ * it ADDS its range's share to a device-side accumulator (stream-ordered, so the additions happen in enqueue order and the
+ * sum is deterministic).  jh_normsq_reset zeroes the accumulator (enqueued on the library stream), jh_normsq_read reads it
+ * back (synchronises): reset, k ranged steps each followed by the host's all-reduce of that range of w, ONE read-back. */
+int jh_normsq_reset(void);
+int jh_normsq_read(double *out);
 
 /* LSQR (Paige & Saunders 1982) on min ||A x - b||_2 (+ damp^2 ||x||^2) for a tall all-DIAG operator: the solver loop the
  * reference's users run as `lsqr(vec(A), vec(d))` (IterativeSolvers.jl; src/Jets.jl:1143-1152, docs/src/index.md:235-246),
@@ -257,14 +263,18 @@ int jh_blockop_bidiag_step_range(const jh_blockop *op, jh_bvec *u, const jh_bvec
  * size it is 64 GiB); `x` holds x0 on entry when use_x0 != 0 and the solution on return.  Stopping rules and istop codes are
  * the paper's (1: ||r|| small, 2: ||A'r|| small, 3: cond(A) > conlim, 4-6: the same at machine precision, 7: maxiter);
  * force_maxiter != 0 keeps iterating (throughput measurements).  history (optional, 2*maxiter doubles) receives
- * (r1norm, arnorm) per iteration.  After jh_comm_init_rank with more than one rank, `op`/`u` are this rank's block rows,
- * x is replicated, and the exchange (one all-reduce of the domain vector and one of a scalar per iteration) is done here. */
+ * (r1norm, arnorm) per iteration.  jh_lsqr_solve is always LOCAL to this process, whether or not a communicator exists.
+ * jh_lsqr_solve_partitioned is the row-partitioned solve: `op`/`u` are this rank's block rows, x is replicated, and the
+ * exchange (one all-reduce of the domain vector and one of a scalar per iteration) runs over the communicator of
+ * jh_comm_init_rank; EVERY rank must call it, in lock-step (it is a collective).  With one rank it equals jh_lsqr_solve. */
 typedef struct {
     int32_t istop, itn;
     double r1norm, r2norm, anorm, acond, arnorm, xnorm;
 } jh_lsqr_result;
 int jh_lsqr_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, double conlim,
                   int maxiter, int force_maxiter, jh_lsqr_result *res, double *history);
+int jh_lsqr_solve_partitioned(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol,
+                              double conlim, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history);
 /* ---------------------------------------------------------------- RCCL over xGMI ----------- */
 /* Row partition of a tall operator across the GPUs of a node (one process per GPU): the forward needs no exchange
  * (src/Jets.jl:1015-1031), the adjoint is a sum over rows (1045-1053) -> one in-place all-reduce of the domain vector

@@ -118,7 +118,10 @@ SYMBOLS = {
     "jh_blockop_mul_adj_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _dblp]),
     "jh_blockop_bidiag_step": (_int, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
     "jh_blockop_bidiag_step_range": (_int, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, _i64, _i64, _dblp]),
+    "jh_normsq_reset": (_int, []),
+    "jh_normsq_read": (_int, [_dblp]),
     "jh_lsqr_solve": (_int, [_vp, _vp, _vp, _int, C.c_double, C.c_double, C.c_double, C.c_double, _int, _int, C.POINTER(LsqrResultC), _dblp]),
+    "jh_lsqr_solve_partitioned": (_int, [_vp, _vp, _vp, _int, C.c_double, C.c_double, C.c_double, C.c_double, _int, _int, C.POINTER(LsqrResultC), _dblp]),
     "jh_comm_unique_id": (_int, [_vp]),
     "jh_comm_init_rank": (_int, [_vp, _int, _int]),
     "jh_comm_destroy": (_int, []),

@@ -468,13 +468,18 @@ __global__ __launch_bounds__(256) void k_axpby_norm(S *__restrict__ out, const S
 
 // fold the per-workgroup partials deterministically: workgroup b sums the contiguous chunk
 // [b*chunk, (b+1)*chunk) in a fixed order and writes out[b]; launched twice for large counts (1M -> 1024 -> 1)
-__global__ void k_sum_partials(const double *__restrict__ partials, int64_t n, int64_t chunk, double *__restrict__ out)
+// accum != 0 (single-workgroup launches only): the sum is ADDED to what out[0] holds -- the deferred ||u||^2 of a step that
+// is enqueued range by range (jh_blockop_bidiag_step_range with normsq == NULL); stream order makes the additions sequential
+__global__ void k_sum_partials(const double *__restrict__ partials, int64_t n, int64_t chunk, double *__restrict__ out, int accum)
 {
     const int64_t lo = (int64_t)blockIdx.x * chunk;
     const int64_t hi = lo + chunk < n ? lo + chunk : n;
     double v = 0.0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += 256) v += partials[i];
-    wg_sum_store<256>(v, out + blockIdx.x);
+    double *slot = out + blockIdx.x;
+    const double prev = (accum && threadIdx.x == 0) ? *slot : 0.0;
+    wg_sum_store<256>(v, slot);
+    if (accum && threadIdx.x == 0) *slot += prev;
 }
 
 // ------------------------------------------------------------------ fused JetSum of tall operators ---------
@@ -1373,16 +1378,22 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
 }
 
 // ---- fused solver updates: launch + partial fold ---------------------------------------------------
-int finish_normsq(int64_t nparts, double *normsq)
+constexpr int JH_NORMSQ_SLOT = 8;     // red_dev[8]: the deferred ||u||^2 accumulator (jh_normsq_reset / jh_normsq_read)
+
+// normsq != NULL: read the folded sum back (synchronises).  normsq == NULL and defer: add it to the device-side accumulator
+// instead (no host synchronisation at all).  normsq == NULL and !defer: the caller does not want the norm.
+int finish_normsq(int64_t nparts, double *normsq, bool defer = false)
 {
     jh_context &c = jh_ctx();
+    const int accum = (!normsq && defer) ? 1 : 0;
+    double *dst = accum ? c.red_dev + JH_NORMSQ_SLOT : c.red_dev;
     if (nparts > 8192) {        // two levels: <= 1024 chunk sums (red_dev + 16 ...), then one workgroup
         const int64_t nchunk = 1024, chunk = (nparts + nchunk - 1) / nchunk;
-        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)nchunk), dim3(256), 0, c.stream, c.part_dev, nparts, chunk, c.red_dev + 16);
+        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)nchunk), dim3(256), 0, c.stream, c.part_dev, nparts, chunk, c.red_dev + 16, 0);
         JH_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, c.red_dev + 16, nchunk, nchunk, c.red_dev);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, c.red_dev + 16, nchunk, nchunk, dst, accum);
     } else {
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, c.part_dev, nparts, nparts, c.red_dev);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c.stream, c.part_dev, nparts, nparts, dst, accum);
     }
     JH_CHECK_HIP(hipGetLastError());
     if (normsq) {
@@ -1505,7 +1516,7 @@ int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n
 
 template <typename S, int E, int NS>
 int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t n_scalars, double alpha, double beta, double *normsq,
-                  int64_t s_begin = 0, int64_t s_end = -1)
+                  int64_t s_begin = 0, int64_t s_end = -1, bool defer = false)
 {
     if (s_end < 0) s_end = n_scalars;
     if (s_end <= s_begin) { if (normsq) *normsq = 0.0; return JH_OK; }
@@ -1556,7 +1567,7 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
             JH_CHECK_HIP(hipGetLastError());                                                                             \
             if (parts > 1) JH_TRY((launch_fold_parts<S, NS>(slabs, part_stride, parts, w, s_begin, s_end)));              \
             double part = 0.0;                                                                                           \
-            JH_TRY(finish_normsq(gx * parts, normsq ? &part : nullptr));                                                 \
+            JH_TRY(finish_normsq(gx * parts, normsq ? &part : nullptr, defer));                                          \
             total += part;                                                                                               \
         }                                                                                                                \
         if (normsq) *normsq = total;                                                                                     \
@@ -2224,12 +2235,31 @@ int jh_blockop_bidiag_step_range(const jh_blockop *op, jh_bvec *u, const jh_bvec
     JH_REQUIRE((first_elem * es) % 16 == 0 && (count * es) % 16 == 0, "jh_blockop_bidiag_step_range: chunk boundaries must be 16-byte aligned");
     const int64_t n = op->row_len[0], lo = first_elem, hi = first_elem + count;
     switch (op->dtype) {
-    case JH_F32: return launch_bidiag<float, 1, 4>(op, u->data, v->data, w->data, n, alpha, beta, normsq, lo, hi);
-    case JH_F64: return launch_bidiag<double, 1, 2>(op, u->data, v->data, w->data, n, alpha, beta, normsq, lo, hi);
-    case JH_C32: return launch_bidiag<float, 2, 4>(op, u->data, v->data, w->data, 2 * n, alpha, beta, normsq, 2 * lo, 2 * hi);
-    case JH_C64: return launch_bidiag<double, 2, 2>(op, u->data, v->data, w->data, 2 * n, alpha, beta, normsq, 2 * lo, 2 * hi);
+    case JH_F32: return launch_bidiag<float, 1, 4>(op, u->data, v->data, w->data, n, alpha, beta, normsq, lo, hi, true);
+    case JH_F64: return launch_bidiag<double, 1, 2>(op, u->data, v->data, w->data, n, alpha, beta, normsq, lo, hi, true);
+    case JH_C32: return launch_bidiag<float, 2, 4>(op, u->data, v->data, w->data, 2 * n, alpha, beta, normsq, 2 * lo, 2 * hi, true);
+    case JH_C64: return launch_bidiag<double, 2, 2>(op, u->data, v->data, w->data, 2 * n, alpha, beta, normsq, 2 * lo, 2 * hi, true);
     }
     return jh_fail(JH_ERR_INVALID, "jh_blockop_bidiag_step_range: unknown dtype %d", op->dtype);
+}
+
+int jh_normsq_reset(void)
+{
+    JH_TRY(jh_require_ready());
+    jh_context &c = jh_ctx();
+    JH_CHECK_HIP(hipMemsetAsync(c.red_dev + JH_NORMSQ_SLOT, 0, sizeof(double), c.stream));
+    return JH_OK;
+}
+
+int jh_normsq_read(double *out)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(out, "jh_normsq_read: null output");
+    jh_context &c = jh_ctx();
+    JH_CHECK_HIP(hipMemcpyAsync(c.red_host + 6, c.red_dev + JH_NORMSQ_SLOT, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+    *out = c.red_host[6];
+    return JH_OK;
 }
 
 int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double alpha, double beta, double *normsq)

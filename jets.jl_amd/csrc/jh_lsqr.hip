@@ -118,8 +118,11 @@ int launch_xw(int dtype, jh_bvec *v, jh_bvec *x, jh_bvec *w, double cv, double t
 
 }  // namespace
 
-extern "C" int jh_lsqr_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, double conlim,
-                             int maxiter, int force_maxiter, jh_lsqr_result *res, double *history)
+// `dist`: op/u are this rank's block rows of a row-partitioned operator and the exchange runs over the communicator of
+// jh_comm_init_rank.  The CALLER says so (jh_lsqr_solve_partitioned); a communicator merely being alive never turns a
+// rank-local solve into a collective one.
+static int lsqr_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, double conlim,
+                     int maxiter, int force_maxiter, jh_lsqr_result *res, double *history, const bool dist)
 {
     JH_TRY(jh_require_ready());
     JH_REQUIRE(op && u && x && res, "jh_lsqr_solve: null argument");
@@ -129,9 +132,6 @@ extern "C" int jh_lsqr_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int u
     JH_TRY(jh_bvec_info(x, &nb, &n, &dtype, nullptr));
     if (!jh_blockop_tall_fast(op, u->data, x->data))                    // before anything is touched: the caller can still take another path
         return jh_fail(JH_ERR_UNSUPPORTED, "jh_lsqr_solve: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
-    int nranks = 1, rank = 0;
-    (void)jh_comm_info(&nranks, &rank);
-    const bool dist = nranks > 1;
     Tmp t;
     const int64_t len1[1] = {n};
     JH_TRY(jh_bvec_create(1, len1, dtype, &t.v));
@@ -269,4 +269,19 @@ extern "C" int jh_lsqr_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int u
     res->xnorm = xnorm;
     JH_CHECK_HIP(hipStreamSynchronize(c.stream));                        // the temporaries die here
     return JH_OK;
+}
+
+extern "C" int jh_lsqr_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, double conlim,
+                             int maxiter, int force_maxiter, jh_lsqr_result *res, double *history)
+{
+    return lsqr_impl(op, u, x, use_x0, damp, atol, btol, conlim, maxiter, force_maxiter, res, history, false);
+}
+
+extern "C" int jh_lsqr_solve_partitioned(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol,
+                                         double conlim, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history)
+{
+    int nranks = 1, rank = 0;
+    (void)jh_comm_info(&nranks, &rank);
+    // one rank: nothing to exchange (jh_comm_init_rank is then optional, so a one-GPU run of partitioned host code works)
+    return lsqr_impl(op, u, x, use_x0, damp, atol, btol, conlim, maxiter, force_maxiter, res, history, nranks > 1);
 }

@@ -262,17 +262,33 @@ class _NativeCell:
         self.__dict__.pop("ppack", None)
 
 
+def _desc_signature(descs):
+    """What the device handle captured of the children's states: kinds, adjoint flags, coefficient ADDRESSES, scalars."""
+    return tuple((dsc[0], dsc[1], None if dsc[2] is None else (dsc[2].ptr, dsc[2].length()), complex(dsc[3]))
+                 for row in descs for dsc in row)
+
+
 def _native_op(cell, ops, dtype):
-    """The cached NativeBlockOp of a block jet, or None when some block is not device-native."""
+    """The cached NativeBlockOp of a block jet, or None when some block is not device-native.
+
+    The handle holds raw coefficient pointers taken from the children's states.  The reference's `state!` merges a new
+    state that takes effect on the next `mul!` (src/Jets.jl:272, 391), so after any `state_()` (jets.STATE_GEN moved)
+    the children are described again and the handle is rebuilt when a kind, a coefficient address or a scalar changed."""
     if cell is None:
         cell = _NativeCell()
-    if cell.value != "unset":
+    gen = _j.STATE_GEN[0]
+    if cell.value != "unset" and cell.__dict__.get("gen") == gen:
         return cell.value
     descs = [[_native_desc(ops[i, jc]) for jc in builtins.range(ops.shape[1])] for i in builtins.range(ops.shape[0])]
-    if any(dsc is None for row in descs for dsc in row):
-        cell.value = None
-    else:
-        cell.value = NativeBlockOp(ops, _densify_scalar_rows(ops, descs, dtype), dtype)
+    native = not any(dsc is None for row in descs for dsc in row)
+    sig = _desc_signature(descs) if native else None
+    if cell.value != "unset" and cell.__dict__.get("sig") == sig:
+        cell.gen = gen                                         # an unrelated state changed: the handle is still right
+        return cell.value
+    if cell.value != "unset":
+        cell.close()                                           # stale pointers: drop the handle and every table built on it
+    cell.value = NativeBlockOp(ops, _densify_scalar_rows(ops, descs, dtype), dtype) if native else None
+    cell.gen, cell.sig = gen, sig
     return cell.value
 
 
@@ -544,13 +560,18 @@ def getblock_op(A, i: int, jc: int, kind=None):  # :1085-1090, 1100-1110
 
 # ------------------------------------------------------------------------------ fused chains -------
 def _tall_native(op):
-    """The NativeBlockOp of a tall (one-column) device-native block operator, else None."""
+    """The NativeBlockOp of a tall (one-column) device-native block operator, else None.  A Jacobian whose nonlinear
+    children were never pointed (or sit at points of their own) is NOT native here: the unfused path then raises the
+    reference's DimensionMismatch / runs the per-child loop, and so must the fused chains, sums and LSQR."""
     if not (isinstance(op, JopLn) and isblockop(op)):
         return None
     j = op.jet
     if j.s["ops"].shape[1] != 1:
         return None
-    return _native_op(j.s.get("_native"), j.s["ops"], j.rng.eltype())
+    nat = _native_op(j.s.get("_native"), j.s["ops"], j.rng.eltype())
+    if nat is None:
+        return None
+    return _pointed_native(nat, j.s["ops"], j.mo)
 
 
 def _real_scale(op):

@@ -228,8 +228,10 @@ def _native_solve(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b, fo
     res = LsqrResultC()
     hist = (C.c_double * builtins.max(2 * int(maxiter), 1))()
     try:
-        check(lib.jh_lsqr_solve(eng.native.handle, u.handle, x.handle, 0 if x0 is None else 1, float(damp), float(atol), float(btol),
-                                float(conlim), int(maxiter), 1 if force_maxiter else 0, C.byref(res), hist))
+        # a rank-local operator is solved locally even while an AbiComm is alive; only a RowPartitionedOp is a collective solve
+        solve = lib.jh_lsqr_solve_partitioned if shard is not None else lib.jh_lsqr_solve
+        check(solve(eng.native.handle, u.handle, x.handle, 0 if x0 is None else 1, float(damp), float(atol), float(btol),
+                    float(conlim), int(maxiter), 1 if force_maxiter else 0, C.byref(res), hist))
     except JetsHipError as e:
         if e.status != 4:                                       # JH_ERR_UNSUPPORTED is raised before anything is touched: generic path
             raise

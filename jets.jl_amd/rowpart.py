@@ -231,78 +231,83 @@ def for_device(part: RowPartition, local_op, comm=None) -> RowPartitionedOp:
     from . import jetblock as _blk
 
     nchunks = int(os.environ.get("JETS_AR_CHUNKS", "4"))
-    views = {}
+    views = {}      # id(vector) -> (vector, flat torch view): a solver exchanges the same one or two vectors every iteration
+
+    def tensor_of(x):
+        hit = views.get(id(x))
+        if hit is None or hit[0] is not x:
+            if len(views) >= 8:                               # bounded: a view pins its vector (64 MiB at the headline size)
+                views.clear()
+            hit = views[id(x)] = (x, as_tensor(x))
+        return hit[1]
+
+    def native_of(A):
+        if nchunks <= 1 or not dist.is_initialized() or not _blk.isblockop(A):
+            return None
+        jt = A.jet
+        return _blk._native_op(jt.s.get("_native"), jt.s["ops"], jt.rng.eltype())
+
+    def chunk_bounds(n):
+        step = -(-n // nchunks)
+        step = -(-step // 16384) * 16384                      # chunk bounds on 64 KiB boundaries
+        lo = 0
+        while lo < n:
+            cnt = builtins.min(step, n - lo)
+            yield lo, cnt
+            lo += cnt
+
+    def exchange(t, lo, cnt, works):
+        with torch.cuda.stream(ext):                          # RCCL's stream waits for the library stream up to here
+            works.append(dist.all_reduce(t[lo:lo + cnt], op=dist.ReduceOp.SUM, async_op=True))
+
+    def join(works):
+        with torch.cuda.stream(ext):
+            for w in works:
+                w.wait()                                      # the library stream waits for every chunk's all-reduce
 
     def pipelined_adj(m, A, d) -> bool:
         """Local adjoint in `nchunks` element ranges (jh_blockop_mul_adj_range); the all-reduce of a finished range
         runs on RCCL's stream while the kernel of the next range runs on the library stream.  Same values as the
         unpipelined path.  Returns False when the operator has no ranged kernel (then the caller does it in one piece)."""
-        if nchunks <= 1 or not dist.is_initialized() or not _blk.isblockop(A):
-            return False
-        jt = A.jet
-        nat = _blk._native_op(jt.s.get("_native"), jt.s["ops"], jt.rng.eltype())
+        nat = native_of(A)
         if nat is None:
             return False
-        n = m.length()
-        step = -(-n // nchunks)
-        step = -(-step // 16384) * 16384                      # chunk bounds on 64 KiB boundaries
-        key = id(m)
-        if key not in views or views[key][0] is not m:
-            views[key] = (m, as_tensor(m))
-        t = views[key][1]
+        t = tensor_of(m)
         works = []
-        lo = 0
         try:
-            while lo < n:
-                cnt = builtins.min(step, n - lo)
+            for lo, cnt in chunk_bounds(m.length()):
                 check(lib.jh_blockop_mul_adj_range(nat.handle, m.handle, d.handle, lo, cnt))
-                with torch.cuda.stream(ext):
-                    works.append(dist.all_reduce(t[lo:lo + cnt], op=dist.ReduceOp.SUM, async_op=True))
-                lo += cnt
+                exchange(t, lo, cnt, works)
         except JetsHipError as e:
             if e.status == 4 and not works:                   # JH_ERR_UNSUPPORTED before anything was enqueued
                 return False
             raise
-        with torch.cuda.stream(ext):
-            for w in works:
-                w.wait()                                      # the library stream waits for every chunk's all-reduce
+        join(works)
         return True
 
     def pipelined_step(u, v, w, alpha, beta):
-        """jh_blockop_bidiag_step in `nchunks` element ranges; returns the local ||u||^2 (sum of the chunks' shares) or
-        None when the operator has no ranged one-pass kernel."""
-        A = local_op
-        if nchunks <= 1 or not dist.is_initialized() or not _blk.isblockop(A):
-            return None
-        jt = A.jet
-        nat = _blk._native_op(jt.s.get("_native"), jt.s["ops"], jt.rng.eltype())
+        """jh_blockop_bidiag_step in `nchunks` element ranges, enqueued back to back: every range adds its share of ||u||^2
+        to a device-side accumulator (jh_normsq_reset / normsq == NULL / jh_normsq_read), so the host synchronises ONCE per
+        step, after the last range, while the all-reduces of the finished ranges of w run under the later kernels.  Returns
+        the local ||u||^2, or None when the operator has no ranged one-pass kernel."""
+        nat = native_of(local_op)
         if nat is None:
             return None
-        n = w.length()
-        step = -(-n // nchunks)
-        step = -(-step // 16384) * 16384
-        key = id(w)
-        if key not in views or views[key][0] is not w:
-            views[key] = (w, as_tensor(w))
-        t = views[key][1]
-        works, total, lo = [], 0.0, 0
+        t = tensor_of(w)
+        works = []
         out = C.c_double(0)
         try:
-            while lo < n:
-                cnt = builtins.min(step, n - lo)
-                check(lib.jh_blockop_bidiag_step_range(nat.handle, u.handle, v.handle, w.handle, float(alpha), float(beta), lo, cnt, C.byref(out)))
-                total += out.value
-                with torch.cuda.stream(ext):
-                    works.append(dist.all_reduce(t[lo:lo + cnt], op=dist.ReduceOp.SUM, async_op=True))
-                lo += cnt
+            check(lib.jh_normsq_reset())
+            for lo, cnt in chunk_bounds(w.length()):
+                check(lib.jh_blockop_bidiag_step_range(nat.handle, u.handle, v.handle, w.handle, float(alpha), float(beta), lo, cnt, None))
+                exchange(t, lo, cnt, works)
         except JetsHipError as e:
             if e.status == 4 and not works:
                 return None
             raise
-        with torch.cuda.stream(ext):
-            for wk in works:
-                wk.wait()
-        return total
+        check(lib.jh_normsq_read(C.byref(out)))                # the one read-back (library stream: kernels only, not the exchange)
+        join(works)
+        return out.value
 
     return RowPartitionedOp(part, local_op, comm, lambda d, A, m: mul_(d, A, m), lambda m, A, d: mul_(m, adjoint(A), d), dot, norm,
                             pipelined_adj=pipelined_adj, pipelined_step=pipelined_step)

@@ -494,16 +494,22 @@ function bidiag_step!(u::BlockArray{T,<:HipArray{T}}, w::HipArray{T}, A::JopLn, 
     sqrt(nrm2[])
 end
 
-# the whole LSQR loop behind the ABI (the same call solves the row-partitioned problem after comm_init on every rank);
-# for operators the device does not know, IterativeSolvers.lsqr(vec(A), vec(b)) runs unchanged on device arrays
+# the whole LSQR loop behind the ABI; `partitioned=true` is the row-partitioned solve (A, b = this rank's block rows, a
+# collective over comm_init's communicator: every rank calls it) -- a communicator being alive never makes a local solve
+# collective.  For operators the device does not know, IterativeSolvers.lsqr(vec(A), vec(b)) runs unchanged on device arrays
 struct jh_lsqr_result; istop::Int32; itn::Int32; r1norm::Cdouble; r2norm::Cdouble; anorm::Cdouble; acond::Cdouble; arnorm::Cdouble; xnorm::Cdouble; end
-function hip_lsqr!(x::HipArray{T}, A::JopLn, b::BlockArray{T,<:HipArray{T}}; x0::Bool=false, damp=0.0, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=100) where {T}
+function hip_lsqr!(x::HipArray{T}, A::JopLn, b::BlockArray{T,<:HipArray{T}}; x0::Bool=false, damp=0.0, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=100, partitioned::Bool=false) where {T}
     h = tall_native(A, T)
     h == C_NULL && error("hip_lsqr!: needs a tall block operator of device-native children")
     res = Ref{jh_lsqr_result}()
     hist = Vector{Cdouble}(undef, 2 * maxiter)
-    check(ccall((:jh_lsqr_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Ref{jh_lsqr_result}, Ptr{Cdouble}),
-                h, handle(b), handle(x), x0, damp, atol, btol, conlim, maxiter, 0, res, hist))   # b is overwritten (it becomes u)
+    if partitioned
+        check(ccall((:jh_lsqr_solve_partitioned, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Ref{jh_lsqr_result}, Ptr{Cdouble}),
+                    h, handle(b), handle(x), x0, damp, atol, btol, conlim, maxiter, 0, res, hist))
+    else
+        check(ccall((:jh_lsqr_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Ref{jh_lsqr_result}, Ptr{Cdouble}),
+                    h, handle(b), handle(x), x0, damp, atol, btol, conlim, maxiter, 0, res, hist))   # b is overwritten (it becomes u)
+    end
     x, res[], reshape(hist, 2, :)[:, 1:res[].itn]
 end
 

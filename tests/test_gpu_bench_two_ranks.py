@@ -40,3 +40,35 @@ def test_bench_with_two_ranks_over_gloo():
     ls = j["lsqr"]
     assert ls["iterations"] == 12 and ls["rel_err_vs_x_true"] < 1e-3                         # the partitioned solver converges
     assert ls["r1norm_first_last"][1] < 1e-3 * ls["r1norm_first_last"][0]
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it: the parent spawns the two ranks before any GPU call,
+    relays rank 0's single JSON line and exits 0 (gloo here -- one GPU; tests/test_gpu_rccl_ranks.py does it over RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nblocks", "9", "--edge", "64",
+           "--no-cpu-baseline"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        pytest.skip("two ranks time-slicing this GPU did not finish in 300 s")
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["rows_per_gpu"] == 5
+    mg = j["multi_gpu"]
+    assert mg["backend"] == "gloo" and mg["rccl_nranks"] is None and [r["rows"] for r in mg["per_rank"]] == [5, 4]
+    assert all(r["fwd_ms"] > 0 and r["adj_ms"] >= r["adj_kernel_ms"] * 0.5 for r in mg["per_rank"])
+    assert mg["allreduce"]["bytes"] == 64 ** 3 * 4
+
+
+def test_bench_fails_loudly_when_a_rank_dies():
+    """A rank that cannot start (world size that does not match) takes the whole self-spawned job down with a non-zero exit."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_BACKEND"] = "no-such-backend"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--nblocks", "4", "--edge", "32",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

@@ -1,4 +1,4 @@
-"""GPU: the row-partitioned device path with TWO processes sharing the one GPU of the test box (tools/two_ranks_one_gpu.py).
+"""GPU: the row-partitioned device path with TWO processes sharing the one GPU of the test box (tools/ranks_check.py --backend gloo).
 
 RCCL refuses two ranks on one device, so the exchange is staged through the host over gloo (test-only comm object);
 everything else is the product path on real kernels with world_size = 2: each rank builds ITS rows of the seeded operator
@@ -17,9 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_two_ranks_on_one_gpu(tmp_path):
     try:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_ranks_one_gpu.py"), str(tmp_path)], capture_output=True,
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ranks_check.py"), str(tmp_path), "--ranks", "2", "--backend", "gloo"], capture_output=True,
                              text=True, timeout=240)
     except subprocess.TimeoutExpired:
         pytest.skip("two processes time-slicing this GPU did not finish in 240 s (seen with a third idle context on the device)")
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "TWO RANKS OK" in out.stdout
+    assert "RANKS OK" in out.stdout
