@@ -61,11 +61,8 @@ class _Engine:
         self.A = A
         self.L = _j.JopLn(A) if not isinstance(A, _j.JopAdjoint) else A
         self.native = None
-        if isinstance(A, _j.JopLn) and _blk.isblockop(A):
-            jt = A.jet
-            nat = _blk._native_op(jt.s.get("_native"), jt.s["ops"], jt.rng.eltype())
-            if nat is not None and jt.s["ops"].shape[1] == 1:
-                self.native = nat
+        if isinstance(A, _j.JopLn):
+            self.native = _blk._tall_native(A)       # None for an un-pointed Jacobian: the generic path then raises like mul! does
         self._tmp_r = None
         self._tmp_d = None
         self.fused_step = os.environ.get("JETS_LSQR_FUSED_STEP", "1") != "0"   # one pass per iteration (jh_blockop_bidiag_step)
