@@ -1,0 +1,573 @@
+// tall_kernels.hip -- stand-alone shape/structure experiments for the tall kernels (one-pass LSQR step, adjoint, forward)
+// outside the library, so that a variant compiles in seconds.  Winners are ported into jets.jl_amd/csrc/jh_blockop.hip.
+//
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/micro/tall_kernels tools/micro/tall_kernels.hip
+//   tools/micro/tall_kernels NROW EDGE [bidiag|adj|fwd|all]
+//
+// Every variant is checked bit for bit against the baseline structure (the library's current kernels, restated here).
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef float V4 __attribute__((ext_vector_type(4)));
+
+template <bool NT> __device__ inline V4 ldg(const V4 *p)
+{
+    typedef const V4 __attribute__((address_space(1))) *gp;
+    if (NT) return __builtin_nontemporal_load((gp)p);
+    return *(gp)p;
+}
+template <bool NT> __device__ inline void stg(V4 *p, V4 v)
+{
+    typedef V4 __attribute__((address_space(1))) *gp;
+    if (NT) __builtin_nontemporal_store(v, (gp)p);
+    else *(gp)p = v;
+}
+
+__global__ void k_fill(float *p, int64_t n, uint64_t seed)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t z = seed + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        p[i] = (float)(z >> 40) * (1.0f / 16777216.0f);
+    }
+}
+
+template <int BLK> __device__ inline void wg_sum_store(double v, double *slot)
+{
+    __shared__ double sm[BLK / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sm[0];
+#pragma unroll
+        for (int w = 1; w < BLK / 64; w++) r += sm[w];
+        *slot = r;
+    }
+}
+
+__device__ inline double vnorm2(V4 r)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) acc += (double)r[e] * (double)r[e];
+    return acc;
+}
+
+// XCD-contiguous tile map: workgroups are dealt round-robin over the 8 XCDs, so bid % 8 names the XCD; give each XCD one
+// contiguous eighth of the tiles (its L2 and its TLB then see 1/8 of every row instead of a comb through all of it)
+__device__ inline unsigned tile_of(unsigned bid, unsigned ntiles, int remap)
+{
+    // remap == 0: tile = workgroup id (consecutive tiles on consecutive XCDs).  remap == c > 0: XCD x (= bid % 8) gets runs of
+    // c consecutive tiles: tile = (slot / c) * 8c + x * c + slot % c with slot = bid / 8 (c = ntiles / 8: one contiguous eighth
+    // per XCD).  The host guarantees ntiles % (8 c) == 0.
+    if (remap <= 0) return bid;
+    const unsigned c = (unsigned)remap, x = bid & 7u, slot = bid >> 3;
+    return (slot / c) * (8u * c) + x * c + slot % c;
+}
+
+// optional per-workgroup timeline (diagnostic builds of the harness only): start / end in 100 MHz ticks
+__device__ unsigned long long *g_stamps = nullptr;
+__device__ inline void stamp(int which)
+{
+    if (g_stamps && threadIdx.x == 0) g_stamps[2 * blockIdx.x + which] = __builtin_amdgcn_s_memrealtime();
+}
+
+// ---------------------------------------------------------------- one-pass step: baseline structure ------------------
+template <int U, int DEPTH, int BLK>
+__global__ __launch_bounds__(BLK) void k_bidiag_base(const float *__restrict__ a, float *__restrict__ u, const float *__restrict__ v,
+                                                     float *__restrict__ w, int64_t n, int64_t nrow, float alpha, float beta,
+                                                     double *__restrict__ partials, int remap, int64_t ld)
+{
+    stamp(0);
+    const unsigned tile = tile_of(blockIdx.x, gridDim.x, remap);
+    n = ld;
+    const int64_t s0 = ((int64_t)tile * U * BLK + threadIdx.x) * 4;
+    int64_t sk[U];
+    V4 acc[U], vv[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        sk[k] = s0 + (int64_t)k * BLK * 4;
+        acc[k] = (V4)0.f;
+        vv[k] = ldg<false>(reinterpret_cast<const V4 *>(v + sk[k]));
+    }
+    double nrm = 0.0;
+    int64_t i = 0;
+    for (; i + DEPTH <= nrow; i += DEPTH) {
+        V4 av[DEPTH][U], uv[DEPTH][U];
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                av[j][k] = ldg<true>(reinterpret_cast<const V4 *>(a + (i + j) * n + sk[k]));
+                uv[j][k] = ldg<true>(reinterpret_cast<const V4 *>(u + (i + j) * n + sk[k]));
+            }
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                V4 t = av[j][k] * vv[k];
+                V4 r = (V4)alpha * t;
+                V4 s2 = (V4)beta * uv[j][k];
+                r = r + s2;
+                stg<true>(reinterpret_cast<V4 *>(u + (i + j) * n + sk[k]), r);
+                nrm += vnorm2(r);
+                acc[k] = acc[k] + av[j][k] * r;
+            }
+    }
+    for (; i < nrow; i++)
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            V4 av = ldg<true>(reinterpret_cast<const V4 *>(a + i * n + sk[k]));
+            V4 r = (V4)alpha * (av * vv[k]);
+            V4 s2 = (V4)beta * ldg<true>(reinterpret_cast<const V4 *>(u + i * n + sk[k]));
+            r = r + s2;
+            stg<true>(reinterpret_cast<V4 *>(u + i * n + sk[k]), r);
+            nrm += vnorm2(r);
+            acc[k] = acc[k] + av * r;
+        }
+#pragma unroll
+    for (int k = 0; k < U; k++) stg<false>(reinterpret_cast<V4 *>(w + sk[k]), acc[k]);
+    wg_sum_store<BLK>(nrm, partials + blockIdx.x);
+    stamp(1);
+}
+
+// ---------------------------------------------------------------- one-pass step: software-pipelined ------------------
+// The loads of batch b+1 are issued BEFORE batch b is combined and stored: vmcnt counts loads and stores together in issue
+// order, so in the baseline loop the wait for a batch's loads also waits for the previous batch's stores to be acknowledged;
+// here the loads a wave waits for are always older than its outstanding stores.  Uniform row bases (SGPR) + a 32-bit lane
+// offset: no 64-bit VALU address arithmetic in the loop.
+template <int U, int DEPTH, int BLK, bool LDNT, bool STNT>
+__global__ __launch_bounds__(BLK) void k_bidiag_pipe(const float *__restrict__ a, float *__restrict__ u, const float *__restrict__ v,
+                                                     float *__restrict__ w, int64_t n, int64_t nrow, float alpha, float beta,
+                                                     double *__restrict__ partials, int remap, int64_t ld)
+{
+    stamp(0);
+    const unsigned tile = tile_of(blockIdx.x, gridDim.x, remap);
+    n = ld;
+    uint32_t off[U];                                            // byte offset of this lane's vectors inside a row (< 4 GiB)
+    V4 acc[U], vv[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        off[k] = (uint32_t)((((int64_t)tile * U + k) * BLK + threadIdx.x) * 16);
+        acc[k] = (V4)0.f;
+        vv[k] = ldg<false>(reinterpret_cast<const V4 *>((const char *)v + off[k]));
+    }
+    const int64_t row_bytes = n * 4;
+    double nrm = 0.0;
+    V4 ac[DEPTH][U], uc[DEPTH][U], an[DEPTH][U], un[DEPTH][U];
+    auto load = [&](V4(&av)[DEPTH][U], V4(&uv)[DEPTH][U], int64_t i) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            const char *ar = (const char *)a + (i + j) * row_bytes;          // uniform
+            const char *ur = (const char *)u + (i + j) * row_bytes;
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                av[j][k] = ldg<LDNT>(reinterpret_cast<const V4 *>(ar + off[k]));
+                uv[j][k] = ldg<LDNT>(reinterpret_cast<const V4 *>(ur + off[k]));
+            }
+        }
+    };
+    auto combine = [&](V4(&av)[DEPTH][U], V4(&uv)[DEPTH][U], int64_t i) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            char *ur = (char *)u + (i + j) * row_bytes;
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                V4 t = av[j][k] * vv[k];
+                V4 r = (V4)alpha * t;
+                V4 s2 = (V4)beta * uv[j][k];
+                r = r + s2;
+                stg<STNT>(reinterpret_cast<V4 *>(ur + off[k]), r);
+                nrm += vnorm2(r);
+                acc[k] = acc[k] + av[j][k] * r;
+            }
+        }
+    };
+    // ping-pong between two register sets (no copies: a copy would have to wait for the prefetched data)
+    const int64_t nb = nrow / DEPTH;
+    int64_t i = 0;
+    if (nb > 0) {
+        load(ac, uc, 0);
+        int64_t b = 0;
+        while (b + 2 < nb) {
+            load(an, un, i + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ABOVE the combine + stores (the scheduler sinks it otherwise)
+            combine(ac, uc, i);
+            __builtin_amdgcn_sched_barrier(0);
+            load(ac, uc, i + 2 * DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+            combine(an, un, i + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+            b += 2;
+            i += 2 * DEPTH;
+        }
+        if (nb - b == 2) {
+            load(an, un, i + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+            combine(ac, uc, i);
+            combine(an, un, i + DEPTH);
+            i += 2 * DEPTH;
+        } else {
+            combine(ac, uc, i);
+            i += DEPTH;
+        }
+    }
+    for (; i < nrow; i++) {
+        const char *ar = (const char *)a + i * row_bytes;
+        char *ur = (char *)u + i * row_bytes;
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            V4 av = ldg<LDNT>(reinterpret_cast<const V4 *>(ar + off[k]));
+            V4 r = (V4)alpha * (av * vv[k]);
+            V4 s2 = (V4)beta * ldg<LDNT>(reinterpret_cast<const V4 *>(ur + off[k]));
+            r = r + s2;
+            stg<STNT>(reinterpret_cast<V4 *>(ur + off[k]), r);
+            nrm += vnorm2(r);
+            acc[k] = acc[k] + av * r;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) stg<false>(reinterpret_cast<V4 *>((char *)w + off[k]), acc[k]);
+    wg_sum_store<BLK>(nrm, partials + blockIdx.x);
+    stamp(1);
+}
+
+// ---------------------------------------------------------------- adjoint (MODE 0) pipelined ------------------------
+template <int U, int DEPTH, int BLK, bool PIPE>
+__global__ __launch_bounds__(BLK) void k_adj(const float *__restrict__ a, const float *__restrict__ d, float *__restrict__ m, int64_t n,
+                                             int64_t nrow, int remap)
+{
+    const unsigned tile = tile_of(blockIdx.x, gridDim.x, remap);
+    uint32_t off[U];
+    V4 acc[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        off[k] = (uint32_t)((((int64_t)tile * U + k) * BLK + threadIdx.x) * 16);
+        acc[k] = (V4)0.f;
+    }
+    const int64_t row_bytes = n * 4;
+    V4 ac[DEPTH][U], dc[DEPTH][U], an[DEPTH][U], dn[DEPTH][U];
+    auto load = [&](V4(&av)[DEPTH][U], V4(&dv)[DEPTH][U], int64_t i) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            const char *ar = (const char *)a + (i + j) * row_bytes;
+            const char *dr = (const char *)d + (i + j) * row_bytes;
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                av[j][k] = ldg<true>(reinterpret_cast<const V4 *>(ar + off[k]));
+                dv[j][k] = ldg<true>(reinterpret_cast<const V4 *>(dr + off[k]));
+            }
+        }
+    };
+    auto combine = [&](V4(&av)[DEPTH][U], V4(&dv)[DEPTH][U]) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) acc[k] = acc[k] + av[j][k] * dv[j][k];
+    };
+    const int64_t nb = nrow / DEPTH;
+    int64_t i = 0;
+    if (nb > 0) {
+        if (PIPE) {
+            load(ac, dc, 0);
+            int64_t b = 0;
+            while (b + 2 < nb) {
+                load(an, dn, i + DEPTH);
+                __builtin_amdgcn_sched_barrier(0);
+                combine(ac, dc);
+                __builtin_amdgcn_sched_barrier(0);
+                load(ac, dc, i + 2 * DEPTH);
+                __builtin_amdgcn_sched_barrier(0);
+                combine(an, dn);
+                __builtin_amdgcn_sched_barrier(0);
+                b += 2;
+                i += 2 * DEPTH;
+            }
+            if (nb - b == 2) {
+                load(an, dn, i + DEPTH);
+                __builtin_amdgcn_sched_barrier(0);
+                combine(ac, dc);
+                combine(an, dn);
+                i += 2 * DEPTH;
+            } else {
+                combine(ac, dc);
+                i += DEPTH;
+            }
+        } else {
+            for (int64_t b = 0; b < nb; b++, i += DEPTH) {
+                load(ac, dc, i);
+                combine(ac, dc);
+            }
+        }
+    }
+    for (; i < nrow; i++) {
+        const char *ar = (const char *)a + i * row_bytes;
+        const char *dr = (const char *)d + i * row_bytes;
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            acc[k] = acc[k] + ldg<true>(reinterpret_cast<const V4 *>(ar + off[k])) * ldg<true>(reinterpret_cast<const V4 *>(dr + off[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) stg<false>(reinterpret_cast<V4 *>((char *)m + off[k]), acc[k]);
+}
+
+// ---------------------------------------------------------------- forward: a workgroup keeps its m tile, streams G rows --
+template <int U, int BLK, int PF, bool STNT>
+__global__ __launch_bounds__(BLK) void k_fwd(const float *__restrict__ a, const float *__restrict__ m, float *__restrict__ d, int64_t n,
+                                             int64_t nrow, int rows_per_wg, unsigned ntiles, unsigned ngroups, int walk)
+{
+    // walk 0: tile fastest (one row group at a time); walk 1: group fastest (all rows concurrently)
+    const unsigned tile = walk ? blockIdx.x / ngroups : blockIdx.x % ntiles;
+    const unsigned grp = walk ? blockIdx.x % ngroups : blockIdx.x / ntiles;
+    uint32_t off[U];
+    V4 mv[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        off[k] = (uint32_t)((((int64_t)tile * U + k) * BLK + threadIdx.x) * 16);
+        mv[k] = ldg<false>(reinterpret_cast<const V4 *>((const char *)m + off[k]));
+    }
+    const int64_t row_bytes = n * 4;
+    const int64_t i0 = (int64_t)grp * rows_per_wg;
+    const int64_t i1 = (i0 + rows_per_wg < nrow) ? i0 + rows_per_wg : nrow;
+    // PF rows of a in flight ahead of the row being stored
+    V4 av[PF][U];
+#pragma unroll
+    for (int p = 0; p < PF; p++) {
+        const int64_t ip = (i0 + p < i1) ? i0 + p : i1 - 1;
+        const char *ar = (const char *)a + ip * row_bytes;
+#pragma unroll
+        for (int k = 0; k < U; k++) av[p][k] = ldg<true>(reinterpret_cast<const V4 *>(ar + off[k]));
+    }
+    for (int64_t i = i0; i < i1; i += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+            if (i + p < i1) {
+                V4 r[U];
+#pragma unroll
+                for (int k = 0; k < U; k++) r[k] = av[p][k] * mv[k];
+                const int64_t ip = (i + p + PF < i1) ? i + p + PF : i1 - 1;      // refill this slot (clamped: harmless re-read at the end)
+                const char *ar = (const char *)a + ip * row_bytes;
+#pragma unroll
+                for (int k = 0; k < U; k++) av[p][k] = ldg<true>(reinterpret_cast<const V4 *>(ar + off[k]));
+                char *dr = (char *)d + (i + p) * row_bytes;
+#pragma unroll
+                for (int k = 0; k < U; k++) stg<STNT>(reinterpret_cast<V4 *>(dr + off[k]), r[k]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- harness -------------------------------------------
+struct Timer {
+    hipEvent_t e0, e1;
+    Timer() { CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); }
+    template <typename F> float run(F &&f, int reps, float *med = nullptr)
+    {
+        f(); f();
+        std::vector<float> t;
+        for (int r = 0; r < reps; r++) {
+            CK(hipEventRecord(e0));
+            f();
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            t.push_back(ms);
+        }
+        std::sort(t.begin(), t.end());
+        if (med) *med = t[t.size() / 2];
+        return t[0];
+    }
+};
+
+static float *A, *Uv, *Uref, *Vv, *Wv, *Wref;
+static double *P;
+static int64_t N, NROW, LD;      // LD: row stride in elements (N + pad)
+
+static uint64_t checksum(const float *dev, int64_t count)
+{
+    // xor-fold of the raw bits on the host over a strided sample + the full small vectors
+    std::vector<uint32_t> h((size_t)count);
+    CK(hipMemcpy(h.data(), dev, (size_t)count * 4, hipMemcpyDeviceToHost));
+    uint64_t s = 1469598103934665603ull;
+    for (uint32_t x : h) { s ^= x; s *= 1099511628211ull; }
+    return s;
+}
+
+template <typename K> static void bench_bidiag(const char *name, K kern, int U, int BLK, int remap, Timer &T, uint64_t want_w, uint64_t want_u, int reps)
+{
+    const int64_t nvec = N / 4;
+    if (nvec % ((int64_t)U * BLK) != 0) { printf("%-44s skipped (tile does not divide the block)\n", name); return; }
+    const unsigned gx = (unsigned)(nvec / ((int64_t)U * BLK));
+    if (remap < 0) remap = (int)(gx / 8);                                  // -1: one contiguous eighth per XCD
+    if (remap && gx % (8 * remap)) { printf("%-44s skipped (tiles %% 8c)\n", name); return; }
+    // correctness from the reference start state
+    CK(hipMemcpy(Uv, Uref, (size_t)std::min<int64_t>(NROW, 4) * LD * 4, hipMemcpyDeviceToDevice));   // first rows restored for the bit check
+    auto go = [&] { hipLaunchKernelGGL(kern, dim3(gx), dim3(BLK), 0, 0, A, Uv, Vv, Wv, N, NROW, 1.0f, -0.5f, P, remap, LD); };
+    // check on a 4-row operator slice (same kernel, nrow = min(NROW,4)) to keep the state reproducible
+    {
+        const int64_t keep = NROW;
+        NROW = std::min<int64_t>(NROW, 4);
+        go();
+        CK(hipDeviceSynchronize());
+        const uint64_t cw = checksum(Wv, N), cu = checksum(Uv, NROW * N > (1 << 22) ? (1 << 22) : NROW * N);
+        NROW = keep;
+        if (want_w && (cw != want_w || cu != want_u)) { printf("%-44s WRONG BITS (w %016llx vs %016llx)\n", name, (unsigned long long)cw, (unsigned long long)want_w); return; }
+    }
+    float med;
+    const float ms = T.run(go, reps, &med);
+    const double bytes = (3.0 * NROW * N + 2.0 * N) * 4;
+    printf("%-44s min %8.3f ms  med %8.3f ms  %7.1f GB/s\n", name, ms, med, bytes / ms / 1e6);
+    if (getenv("TIMELINE")) {                                             // one more launch with per-workgroup stamps
+        unsigned long long *st;
+        CK(hipMalloc(&st, sizeof(unsigned long long) * 2 * gx));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &st, sizeof(st)));
+        go();
+        CK(hipDeviceSynchronize());
+        unsigned long long *none = nullptr;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &none, sizeof(none)));
+        std::vector<unsigned long long> h(2 * (size_t)gx);
+        CK(hipMemcpy(h.data(), st, sizeof(unsigned long long) * 2 * gx, hipMemcpyDeviceToHost));
+        CK(hipFree(st));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (unsigned b = 0; b < gx; b++) { t0 = std::min(t0, h[2 * b]); t1 = std::max(t1, h[2 * b + 1]); }
+        const double span = (double)(t1 - t0) / 100.0;                    // us
+        std::vector<double> dur;
+        for (unsigned b = 0; b < gx; b++) dur.push_back((double)(h[2 * b + 1] - h[2 * b]) / 100.0);
+        std::sort(dur.begin(), dur.end());
+        // active workgroups over time, in 20 slices
+        printf("    timeline: span %.0f us; workgroup duration min/med/max %.0f/%.0f/%.0f us; active workgroups per 5%% slice:", span, dur[0], dur[gx / 2], dur[gx - 1]);
+        for (int sl = 0; sl < 20; sl++) {
+            const double tm = (double)t0 + (sl + 0.5) / 20.0 * (double)(t1 - t0);
+            unsigned act = 0;
+            for (unsigned b = 0; b < gx; b++) act += ((double)h[2 * b] <= tm && tm < (double)h[2 * b + 1]);
+            printf(" %u", act);
+        }
+        // bandwidth over time, assuming a workgroup moves its bytes at a uniform rate over its own lifetime
+        printf("\n    estimated TB/s per 5%% slice:");
+        const double wg_bytes = bytes / gx;
+        for (int sl = 0; sl < 20; sl++) {
+            const double lo = (double)t0 + sl / 20.0 * (double)(t1 - t0), hi = (double)t0 + (sl + 1) / 20.0 * (double)(t1 - t0);
+            double moved = 0.0;
+            for (unsigned b = 0; b < gx; b++) {
+                const double a0 = std::max(lo, (double)h[2 * b]), a1 = std::min(hi, (double)h[2 * b + 1]);
+                if (a1 > a0) moved += wg_bytes * (a1 - a0) / (double)(h[2 * b + 1] - h[2 * b]);
+            }
+            printf(" %.2f", moved / ((hi - lo) / 100.0 * 1e-6) / 1e12);
+        }
+        printf("\n");
+    }
+    fflush(stdout);
+}
+
+int main(int argc, char **argv)
+{
+    NROW = argc > 1 ? atoll(argv[1]) : 128;
+    const int64_t edge = argc > 2 ? atoll(argv[2]) : 256;
+    const std::string which = argc > 3 ? argv[3] : "all";
+    const int reps = argc > 4 ? atoi(argv[4]) : 7;
+    N = edge * edge * edge;
+    LD = N + (getenv("STRIDE_PAD") ? atoll(getenv("STRIDE_PAD")) : 0);
+    CK(hipSetDevice(0));
+    CK(hipMalloc(&A, (size_t)NROW * LD * 4));
+    CK(hipMalloc(&Uv, (size_t)NROW * LD * 4));
+    CK(hipMalloc(&Uref, (size_t)std::min<int64_t>(NROW, 4) * LD * 4));
+    CK(hipMalloc(&Vv, (size_t)N * 4));
+    CK(hipMalloc(&Wv, (size_t)N * 4));
+    CK(hipMalloc(&Wref, (size_t)N * 4));
+    CK(hipMalloc(&P, sizeof(double) * (1 << 20)));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, A, NROW * LD, 1ull);
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, Uv, NROW * LD, 3ull);
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, Vv, N, 2ull);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(Uref, Uv, (size_t)std::min<int64_t>(NROW, 4) * LD * 4, hipMemcpyDeviceToDevice));
+    Timer T;
+    printf("== %lld x %lld^3 Float32, row stride %lld + %lld elements ==\n", (long long)NROW, (long long)edge, (long long)N, (long long)(LD - N));
+
+    if (which == "bidiag" || which == "all") {
+        // reference bits from the baseline on the 4-row slice
+        uint64_t want_w = 0, want_u = 0;
+        {
+            const int64_t keep = NROW;
+            NROW = std::min<int64_t>(NROW, 4);
+            hipLaunchKernelGGL((k_bidiag_base<1, 4, 512>), dim3((unsigned)(N / 4 / 512)), dim3(512), 0, 0, A, Uv, Vv, Wv, N, NROW, 1.0f, -0.5f, P, 0, LD);
+            CK(hipDeviceSynchronize());
+            want_w = checksum(Wv, N);
+            want_u = checksum(Uv, NROW * N > (1 << 22) ? (1 << 22) : NROW * N);
+            NROW = keep;
+        }
+#define BASE(U, D, B) bench_bidiag("base  U" #U " D" #D " wg" #B, k_bidiag_base<U, D, B>, U, B, 0, T, want_w, want_u, reps)
+#define PIPE(U, D, B, L, S, R) bench_bidiag("pipe  U" #U " D" #D " wg" #B " remap" #R, k_bidiag_pipe<U, D, B, L, S>, U, B, R, T, want_w, want_u, reps)
+        BASE(1, 4, 512);
+        PIPE(1, 4, 512, true, true, 0); PIPE(1, 4, 512, true, true, -1); PIPE(4, 2, 512, true, true, -1); PIPE(1, 4, 1024, true, true, -1);
+        PIPE(1, 8, 256, true, true, -1); PIPE(1, 1, 256, true, true, -1); PIPE(2, 2, 256, true, true, -1);
+    }
+
+    if (which == "adj" || which == "all") {
+        float *D = Uv, *M = Wv;
+        uint64_t want = 0;
+        auto run = [&](const char *name, auto kern, int U, int BLK, int remap) {
+            const int64_t nvec = N / 4;
+            if (nvec % ((int64_t)U * BLK)) return;
+            const unsigned gx = (unsigned)(nvec / ((int64_t)U * BLK));
+            if (remap) remap = (int)(gx / 8);
+            if (remap && gx % (8 * remap)) return;
+            auto go = [&] { hipLaunchKernelGGL(kern, dim3(gx), dim3(BLK), 0, 0, A, D, M, N, NROW, remap); };
+            go();
+            CK(hipDeviceSynchronize());
+            const uint64_t c = checksum(M, N);
+            if (!want) want = c;
+            float med;
+            const float ms = T.run(go, reps, &med);
+            printf("%-44s min %8.3f ms  med %8.3f ms  %7.1f GB/s %s\n", name, ms, med, (2.0 * NROW * N + N) * 4 / ms / 1e6, c == want ? "" : "WRONG BITS");
+            fflush(stdout);
+        };
+#define ADJ(U, D, B, P, R) run("adj   U" #U " D" #D " wg" #B " pipe" #P " remap" #R, k_adj<U, D, B, P>, U, B, R)
+        ADJ(4, 2, 1024, false, 0); ADJ(4, 4, 512, false, 0); ADJ(4, 2, 512, false, 0); ADJ(1, 4, 512, false, 0); ADJ(2, 4, 512, false, 0);
+        ADJ(4, 2, 1024, true, 0); ADJ(4, 2, 512, true, 0); ADJ(1, 4, 512, true, 0); ADJ(2, 4, 512, true, 0); ADJ(2, 2, 512, true, 0); ADJ(1, 8, 512, true, 0);
+        ADJ(4, 2, 1024, false, 1); ADJ(4, 2, 512, true, 1); ADJ(1, 4, 512, true, 1); ADJ(2, 4, 512, false, 1);
+    }
+
+    if (which == "fwd" || which == "all") {
+        float *Dd = Uv, *M = Vv;
+        uint64_t want = 0;
+        auto run = [&](const char *name, auto kern, int U, int BLK, int G, int walk) {
+            const int64_t nvec = N / 4;
+            if (nvec % ((int64_t)U * BLK)) return;
+            const unsigned gx = (unsigned)(nvec / ((int64_t)U * BLK));
+            if (G > NROW) G = (int)NROW;
+            const unsigned gy = (unsigned)((NROW + G - 1) / G);
+            if ((int64_t)gx * gy * BLK >= (1ll << 32)) return;
+            auto go = [&] { hipLaunchKernelGGL(kern, dim3(gx * gy), dim3(BLK), 0, 0, A, M, Dd, N, NROW, G, gx, gy, walk); };
+            go();
+            CK(hipDeviceSynchronize());
+            const uint64_t c = checksum(Dd, 1 << 22);
+            if (!want) want = c;
+            float med;
+            const float ms = T.run(go, reps, &med);
+            printf("%-36s G%-5d walk%d  min %8.3f ms  med %8.3f ms  %7.1f GB/s %s\n", name, G, walk, ms, med, (2.0 * NROW * N + N) * 4 / ms / 1e6, c == want ? "" : "WRONG BITS");
+            fflush(stdout);
+        };
+#define FWD(U, B, PF, S, G, W) run("fwd   U" #U " wg" #B " pf" #PF " stnt" #S, k_fwd<U, B, PF, S>, U, B, G, W)
+        for (int walk = 0; walk < 2; walk++) {
+            FWD(4, 256, 1, true, 4, walk); FWD(4, 256, 2, true, 4, walk); FWD(4, 256, 2, true, 16, walk); FWD(4, 256, 4, true, 16, walk);
+            FWD(1, 512, 2, true, 2, walk); FWD(1, 512, 4, true, 8, walk); FWD(2, 512, 2, true, 8, walk); FWD(2, 512, 4, true, 16, walk);
+            FWD(4, 512, 2, true, 8, walk); FWD(4, 512, 2, true, 1 << 20, walk); FWD(2, 512, 4, true, 1 << 20, walk); FWD(1, 512, 4, true, 1 << 20, walk);
+            FWD(4, 256, 2, false, 16, walk); FWD(2, 512, 4, false, 16, walk);
+            FWD(2, 1024, 4, true, 16, walk); FWD(4, 1024, 2, true, 16, walk);
+        }
+    }
+    return 0;
+}
