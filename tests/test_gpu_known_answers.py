@@ -1,0 +1,106 @@
+"""GPU: the HIP path (through the C ABI) against known answers that do NOT come from the oracle.
+
+tests/golden/known_answers.npz is derived from the reference's source lines with exact rational arithmetic + an IEEE
+round-to-nearest-even written for the purpose (tests/golden/make_known_answers.py); tests/test_known_answers.py holds the CPU
+oracle to the same arrays.  Bit-exact for every case, under every instantiated shape of the ordered tall kernels."""
+import numpy as np
+import pytest
+
+from . import known_answers as ka
+
+pytestmark = pytest.mark.gpu
+
+ADJ_SHAPES = [dict(adj_wg=0, adj_unroll=0, adj_depth=0)] + [dict(adj_wg=w, adj_unroll=u, adj_depth=d) for w in (256, 1024) for (u, d) in ((1, 1), (1, 8), (2, 4), (4, 2))]
+
+
+@pytest.fixture(scope="module")
+def z():
+    return ka.load()
+
+
+def _dom(J, A, c, blocks):
+    flat = np.concatenate(blocks)
+    return J.from_numpy(flat, J.domain(A)) if c.ncol > 1 else J.from_numpy(flat)
+
+
+def _rng(J, A, blocks):
+    return J.from_numpy(np.concatenate(blocks), J.range(A))
+
+
+def _blocks_of(x, lens):
+    flat = x.to_numpy().ravel(order="F") if not hasattr(x, "arrays") else x.to_numpy()
+    out, o = [], 0
+    for n in lens:
+        out.append(flat[o:o + n])
+        o += n
+    return out
+
+
+@pytest.mark.parametrize("name", ka.LINEAR_CASES)
+def test_hip_path_reproduces_the_independent_known_answers(Jets, z, name):
+    J = Jets
+    c = ka.Case(z, name)
+    A = ka.device_ops(J, c)
+    m = _dom(J, A, c, c.blocks("m", c.ncol))
+    tall = c.ncol == 1 and c.nrow > 1
+    shapes = ADJ_SHAPES if tall else ADJ_SHAPES[:1]
+    try:
+        for knobs in shapes:
+            J.tune(**knobs)
+            d = _rng(J, A, c.blocks("d_found", c.nrow))                       # dirty range vector: overwritten (1026) or accumulated into (1024)
+            J.mul_(d, A, m)
+            for i, got in enumerate(_blocks_of(d, c.row_len)):
+                assert ka.bits(got) == ka.bits(c.get(f"fwd_{i}")), f"{name} {knobs}: forward block {i}"
+            mt = _dom(J, A, c, c.blocks("m_found", c.ncol))                    # dirty domain vector: zeroed (1042) / written (1051) / untouched (1047)
+            J.mul_(mt, A.H, _rng(J, A, c.adjoint_input()))
+            for j, got in enumerate(_blocks_of(mt, c.col_len)):
+                assert ka.bits(got) == ka.bits(c.get(f"adj_{j}")), f"{name} {knobs}: adjoint block {j}"
+            if c.has("normal_0"):                                             # JetComposite (A', A): the fused kernel
+                y = (A.H @ A) * m
+                assert ka.bits(y.to_numpy().ravel(order="F")) == ka.bits(c.get("normal_0")), f"{name} {knobs}: fused A'A"
+    finally:
+        J.tune(adj_wg=0, adj_unroll=0, adj_depth=0)
+
+
+@pytest.mark.parametrize("name", ["rand_tall_f32", "rand_tall_c64", "order_tall_f32"])
+def test_one_pass_step_reproduces_the_known_adjoint(Jets, z, name):
+    """jh_blockop_bidiag_step with alpha = 1, beta = 0 is forward-then-adjoint in one pass: u must be the known forward, w the
+    known adjoint of it (order_tall: of the stored d_in, so only its forward half is compared there)."""
+    import ctypes as C
+    from jets_jl_amd._ffi import lib, check
+    from jets_jl_amd import jetblock as _blk
+
+    J = Jets
+    c = ka.Case(z, name)
+    A = ka.device_ops(J, c)
+    nat = _blk._tall_native(A)
+    v = _dom(J, A, c, c.blocks("m", 1))
+    u = _rng(J, A, c.blocks("d_found", c.nrow))
+    w = J.zeros(J.domain(A))
+    out = C.c_double(0)
+    check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, 1.0, 0.0, C.byref(out)))
+    for i, got in enumerate(_blocks_of(u, c.row_len)):
+        assert ka.bits(got) == ka.bits(c.get(f"fwd_{i}")), f"{name}: u block {i}"
+    if not c.has("d_in_0"):
+        assert ka.bits(w.to_numpy().ravel(order="F")) == ka.bits(c.get("adj_0")), f"{name}: w"
+        want = sum(float(np.vdot(c.get(f"fwd_{i}").astype(np.complex128), c.get(f"fwd_{i}").astype(np.complex128)).real) for i in range(c.nrow))
+        assert abs(out.value - want) <= 1e-12 * want
+
+
+@pytest.mark.parametrize("name", ka.SUM_CASES)
+def test_jetsum_sign_rules_and_rounding_sequence(Jets, z, name):
+    """A1 - (A2 - A3): the signs flatten to (+, -, +) (src/Jets.jl:667-676) and the fused sum kernels keep the unfused chain's
+    rounding sequence, incl. `0 + (-0) = +0` after `d .= 0` (640)."""
+    J = Jets
+    c = ka.Case(z, name)
+    nrow = c.nrow
+    ops = [J.blockop([[J.JopDiagonal(J.from_numpy(c.get(f"coeff_{t}_{i}")))] for i in range(nrow)]) for t in range(3)]
+    S = ops[0] - (ops[1] - ops[2])
+    m = J.from_numpy(c.get("m_0"))
+    d = S * m
+    n = c.get("m_0").size
+    for i, got in enumerate(_blocks_of(d, [n] * nrow)):
+        assert ka.bits(got) == ka.bits(c.get(f"fwd_{i}")), f"{name}: sum forward block {i}"
+    din = _rng(J, ops[0], c.blocks("d_in", nrow))
+    mt = S.H * din
+    assert ka.bits(mt.to_numpy().ravel(order="F")) == ka.bits(c.get("adj_0")), f"{name}: sum adjoint"
