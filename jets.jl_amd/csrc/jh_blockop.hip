@@ -56,12 +56,47 @@ template <typename S, int E, int NS, typename V> __device__ inline V vmul(V a, V
     }
 }
 
+// does this block read a coefficient pack (DIAG: its diagonal; SQUARE as a Jacobian: its linearisation point)?
+__device__ inline bool block_reads_coeff(const jh_dev_block &b, bool fmode)
+{
+    return b.kind == JH_OP_DIAG || (b.kind == JH_OP_SQUARE && !(fmode && !b.adjoint));
+}
+
+// child mul! of an elementwise block on a 16-byte pack, coefficient pack already loaded (the kernels below issue the loads of
+// GENERAL_Q blocks before combining them)
+template <typename S, int E, int NS, typename V>
+__device__ inline V apply_block_loaded(const jh_dev_block &b, V x, V c, bool transposed, bool fmode)
+{
+    const bool cj = (b.adjoint != 0) != transposed;
+    switch (b.kind) {
+    case JH_OP_IDENTITY: return x;
+    case JH_OP_SQUARE:
+        if (fmode && !b.adjoint) return vmul<S, E, NS, V>(x, x, false);
+        return vmul<S, E, NS, V>(c + c, x, cj);
+    case JH_OP_SCALE: {
+        if constexpr (E == 1) {
+            return (V)(S)b.sre * x;
+        } else {
+            V a;
+#pragma unroll
+            for (int e = 0; e < NS; e += 2) { a[e] = (S)b.sre; a[e + 1] = (S)b.sim; }
+            return vmul<S, E, NS, V>(a, x, cj);
+        }
+    }
+    case JH_OP_DIAG: return vmul<S, E, NS, V>(c, x, cj);
+    default: return (V)(S)0;
+    }
+}
+
 // ------------------------------------------------------------------ tall fast path ------------
 // 1-D grid of ntiles * ngroups workgroups, walked in BANDS of `band` row groups: inside a band the row
 // group is the fastest index (workgroups sharing an m tile are dispatched together, so the tile is
 // re-read from L2/MALL, not HBM), bands follow one another.  band = 1 is the fully sequential sweep
 // (one block row at a time); band = ngroups touches every row concurrently.  n_scalars % NS == 0.
-template <typename S, int E, int NS, int U, bool NT, int BLK>
+// MIXED: the rows are not all plain diagonals -- a row may be IDENTITY, SCALE, a (conjugated) DIAG, the Jacobian of a SQUARE
+// child, or a ZERO block, which the linear loop SKIPS (src/Jets.jl:1022): its d_i stays as found.  The kind is read from the
+// row table (uniform per workgroup: scalar branches), the arithmetic is the general kernels' apply_block_loaded.
+template <typename S, int E, int NS, int U, bool NT, int BLK, bool MIXED = false>
 __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__restrict__ blocks, int64_t nrow, int rows_per_wg,
                                                        const S *__restrict__ a_base, int64_t a_stride,
                                                        const S *__restrict__ m, S *__restrict__ d, int64_t n_scalars,
@@ -79,6 +114,28 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__res
     const int64_t i1 = (i0 + rows_per_wg < nrow) ? i0 + rows_per_wg : nrow;
     const bool full = ((int64_t)(tile + 1) * U * BLK * NS) <= n_scalars;
     V mv[U];
+    if constexpr (MIXED) {
+        bool ok[U];
+        int64_t sk[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
+            sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
+            mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
+        }
+        for (int64_t i = i0; i < i1; i++) {
+            const jh_dev_block blk = blocks[i];
+            if (blk.kind == JH_OP_ZERO) continue;                                          // (1022)
+            const bool rc = block_reads_coeff(blk, false);
+            S *di = d + i * n_scalars;
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const V c = rc ? ld<NT>(reinterpret_cast<const V *>((const S *)blk.coeff + sk[k])) : (V)(S)0;
+                if (ok[k]) st<NT>(reinterpret_cast<V *>(di + sk[k]), apply_block_loaded<S, E, NS, V>(blk, mv[k], c, false, false));   // (1026)
+            }
+        }
+        return;
+    }
     if (full) {
 #pragma unroll
         for (int k = 0; k < U; k++) mv[k] = ld<false>(reinterpret_cast<const V *>(m + s0 + (int64_t)k * BLK * NS));
@@ -115,7 +172,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__res
 
 // one thread: U vectors of the domain, all rows in order.  MODE 0: adjoint (reads a_i, d_i);
 // MODE 1: fused normal equations y = sum_i conj(a_i) .* (a_i .* m) (reads a_i only).
-template <typename S, int E, int NS, int U, int DEPTH, bool NT, int MODE, int BLK>
+template <typename S, int E, int NS, int U, int DEPTH, bool NT, int MODE, int BLK, bool MIXED = false>
 __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                        const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ out,
                                                        const S *__restrict__ in, int64_t n_scalars, int direct,
@@ -151,7 +208,43 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
     for (int k = 0; k < U; k++) sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : s_begin;
 
     int64_t i = row0;
-    for (; !direct && i + DEPTH <= row1; i += DEPTH) {
+    if constexpr (MIXED) {                 // rows of any elementwise kind (see k_tall_diag_fwd); zero blocks are skipped (1047)
+        for (; i + DEPTH <= row1; i += DEPTH) {
+            jh_dev_block blk[DEPTH];
+            V av[DEPTH][U], dv[DEPTH][U];
+#pragma unroll
+            for (int j = 0; j < DEPTH; j++) {
+                blk[j] = blocks[i + j];
+                const bool on = blk[j].kind != JH_OP_ZERO, rc = block_reads_coeff(blk[j], false);
+#pragma unroll
+                for (int k = 0; k < U; k++) {
+                    av[j][k] = rc ? ld<NT>(reinterpret_cast<const V *>((const S *)blk[j].coeff + sk[k])) : (V)(S)0;
+                    dv[j][k] = (MODE == 0 && on) ? ld<NT>(reinterpret_cast<const V *>(in + (i + j) * n_scalars + sk[k])) : (V)(S)0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < DEPTH; j++)
+                if (blk[j].kind != JH_OP_ZERO) {
+#pragma unroll
+                    for (int k = 0; k < U; k++) {
+                        const V t = (MODE == 0) ? dv[j][k] : apply_block_loaded<S, E, NS, V>(blk[j], mv[k], av[j][k], false, false);
+                        acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk[j], t, av[j][k], true, false);   // _m .+= mul!(mtmp, op', _d)
+                    }
+                }
+        }
+        for (; i < row1; i++) {
+            const jh_dev_block blk = blocks[i];
+            if (blk.kind == JH_OP_ZERO) continue;
+            const bool rc = block_reads_coeff(blk, false);
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const V c = rc ? ld<NT>(reinterpret_cast<const V *>((const S *)blk.coeff + sk[k])) : (V)(S)0;
+                const V t = (MODE == 0) ? ld<NT>(reinterpret_cast<const V *>(in + i * n_scalars + sk[k])) : apply_block_loaded<S, E, NS, V>(blk, mv[k], c, false, false);
+                acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk, t, c, true, false);
+            }
+        }
+    }
+    for (; !MIXED && !direct && i + DEPTH <= row1; i += DEPTH) {
         V av[DEPTH][U], dv[DEPTH][U];
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) {
@@ -215,7 +308,7 @@ template <typename S, int NS, typename V> __device__ inline double vnorm2(V r)
 }
 
 // forward: d_i = alpha * (a_i .* m) + beta * d_i ; sequential row sweep (tile index fastest)
-template <typename S, int E, int NS, int U, int BLK>
+template <typename S, int E, int NS, int U, int BLK, bool MIXED = false>
 __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block *__restrict__ blocks, int64_t nrow, int rows_per_wg,
                                                               const S *__restrict__ a_base, int64_t a_stride,
                                                               const S *__restrict__ m, S *__restrict__ d, int64_t n_scalars,
@@ -241,17 +334,22 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block
     const bool use_old = (beta != (S)0);
     double nrm = 0.0;
     for (int64_t i = i0; i < i1; i++) {
-        const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
+        const S *a = (MIXED || !a_base) ? (const S *)blocks[i].coeff : a_base + i * a_stride;
         S *di = d + i * n_scalars;
         V av[U], dv[U];
+        jh_dev_block blk;
+        bool rc = true;
+        if constexpr (MIXED) { blk = blocks[i]; rc = block_reads_coeff(blk, false); }   // any elementwise row kind (see k_tall_diag_fwd)
 #pragma unroll
         for (int k = 0; k < U; k++) {
-            av[k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+            av[k] = rc ? ld<true>(reinterpret_cast<const V *>(a + sk[k])) : (V)(S)0;
             dv[k] = use_old ? ld<true>(reinterpret_cast<const V *>(di + sk[k])) : (V)(S)0;   // beta == 0: d is write-only
         }
 #pragma unroll
         for (int k = 0; k < U; k++) {
-            V t = vmul<S, E, NS, V>(av[k], mv[k], false);      // mul!(tmp, A_i, m)
+            V t;
+            if constexpr (MIXED) t = (blk.kind != JH_OP_ZERO) ? apply_block_loaded<S, E, NS, V>(blk, mv[k], av[k], false, false) : (V)(S)0;   // a zero row of the zeros() temporary
+            else t = vmul<S, E, NS, V>(av[k], mv[k], false);      // mul!(tmp, A_i, m)
             V s1 = (V)alpha * t;
             V r = s1;
             if (use_old) { V s2 = (V)beta * dv[k]; r = s1 + s2; }   // d_i .= alpha*tmp .+ beta*d_i
@@ -329,7 +427,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block
 // A thread owns U 16-byte vectors of the DOMAIN (v and the accumulator stay in registers) and walks all rows with DEPTH rows
 // in flight; every coefficient and every element of u is read once, u is written once: (3*N*n + 2*n)*s bytes where the two
 // separate halves move (5*N*n + 3*n)*s.  u and w come out bit-identical to the two-kernel sequence.
-template <typename S, int E, int NS, int U, int DEPTH, int BLK>
+template <typename S, int E, int NS, int U, int DEPTH, int BLK, bool MIXED = false>
 __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                           const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ u,
                                                           const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, int direct,
@@ -363,7 +461,56 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
     const bool use_old = (beta != (S)0);
     double nrm = 0.0;
     int64_t i = row0;
-    for (; !direct && i + DEPTH <= row1; i += DEPTH) {
+    if constexpr (MIXED) {
+        // rows of any elementwise kind.  A ZERO row: mul!(tmp, A, v) into the zeros() temporary leaves tmp_i = 0 (1022), so
+        // u_i <- alpha*0 + beta*u_i, and the row adds nothing to w (1047)
+        for (; i + DEPTH <= row1; i += DEPTH) {
+            jh_dev_block blk[DEPTH];
+            V av[DEPTH][U], uv[DEPTH][U];
+#pragma unroll
+            for (int j = 0; j < DEPTH; j++) {
+                blk[j] = blocks[i + j];
+                const bool rc = block_reads_coeff(blk[j], false);
+#pragma unroll
+                for (int k = 0; k < U; k++) {
+                    av[j][k] = rc ? ld<true>(reinterpret_cast<const V *>((const S *)blk[j].coeff + sk[k])) : (V)(S)0;
+                    uv[j][k] = use_old ? ld<true>(reinterpret_cast<const V *>(u + (i + j) * n_scalars + sk[k])) : (V)(S)0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < DEPTH; j++) {
+                const bool on = blk[j].kind != JH_OP_ZERO;
+#pragma unroll
+                for (int k = 0; k < U; k++) {
+                    const V t = on ? apply_block_loaded<S, E, NS, V>(blk[j], vv[k], av[j][k], false, false) : (V)(S)0;
+                    V r = (V)alpha * t;
+                    if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; }
+                    if (ok[k]) {
+                        st<true>(reinterpret_cast<V *>(u + (i + j) * n_scalars + sk[k]), r);
+                        nrm += vnorm2<S, NS, V>(r);
+                    }
+                    if (on) acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk[j], r, av[j][k], true, false);
+                }
+            }
+        }
+        for (; i < row1; i++) {
+            const jh_dev_block blk = blocks[i];
+            const bool on = blk.kind != JH_OP_ZERO, rc = block_reads_coeff(blk, false);
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const V c = rc ? ld<true>(reinterpret_cast<const V *>((const S *)blk.coeff + sk[k])) : (V)(S)0;
+                const V t = on ? apply_block_loaded<S, E, NS, V>(blk, vv[k], c, false, false) : (V)(S)0;
+                V r = (V)alpha * t;
+                if (use_old) { V s2 = (V)beta * ld<true>(reinterpret_cast<const V *>(u + i * n_scalars + sk[k])); r = r + s2; }
+                if (ok[k]) {
+                    st<true>(reinterpret_cast<V *>(u + i * n_scalars + sk[k]), r);
+                    nrm += vnorm2<S, NS, V>(r);
+                }
+                if (on) acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk, r, c, true, false);
+            }
+        }
+    }
+    for (; !MIXED && !direct && i + DEPTH <= row1; i += DEPTH) {
         V av[DEPTH][U], uv[DEPTH][U];
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) {
@@ -763,38 +910,6 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
 
 // 16-byte-per-lane variants of the two general kernels, used when every block offset, block length and
 // coefficient pointer is a multiple of 16 bytes.  Same loop order and rounding as the scalar versions.
-// does this block read a coefficient pack (DIAG: its diagonal; SQUARE as a Jacobian: its linearisation point)?
-__device__ inline bool block_reads_coeff(const jh_dev_block &b, bool fmode)
-{
-    return b.kind == JH_OP_DIAG || (b.kind == JH_OP_SQUARE && !(fmode && !b.adjoint));
-}
-
-// child mul! of an elementwise block on a 16-byte pack, coefficient pack already loaded (the kernels below issue the loads of
-// GENERAL_Q blocks before combining them)
-template <typename S, int E, int NS, typename V>
-__device__ inline V apply_block_loaded(const jh_dev_block &b, V x, V c, bool transposed, bool fmode)
-{
-    const bool cj = (b.adjoint != 0) != transposed;
-    switch (b.kind) {
-    case JH_OP_IDENTITY: return x;
-    case JH_OP_SQUARE:
-        if (fmode && !b.adjoint) return vmul<S, E, NS, V>(x, x, false);
-        return vmul<S, E, NS, V>(c + c, x, cj);
-    case JH_OP_SCALE: {
-        if constexpr (E == 1) {
-            return (V)(S)b.sre * x;
-        } else {
-            V a;
-#pragma unroll
-            for (int e = 0; e < NS; e += 2) { a[e] = (S)b.sre; a[e + 1] = (S)b.sim; }
-            return vmul<S, E, NS, V>(a, x, cj);
-        }
-    }
-    case JH_OP_DIAG: return vmul<S, E, NS, V>(c, x, cj);
-    default: return (V)(S)0;
-    }
-}
-
 // Blocks whose loads are issued together per thread.  4 was measured no faster than 1 (0-10 % slower, within run-to-run spread) on every M x K shape but the tall
 // mixed adjoint (profiles/exp_r01_general_prefetch.txt): with one pack per lane and a full-size grid the chip already has
 // enough loads in flight, the extra registers only cost occupancy.
@@ -1225,6 +1340,76 @@ bool tall_fast_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr
     return true;
 }
 
+// mixed tall path usable?  Tall with >= 2 equal rows of ANY elementwise kind (ZERO / IDENTITY / SCALE / DIAG, adjointed or
+// not / the Jacobian of SQUARE), everything 16-byte aligned -- the rows a pure-diagonal operator gains when a regularisation
+// row (identity, scalar) or a muted shot (zero block) joins it.  Such operators keep the tall kernels' tiling, the fused A'A
+// and the one-pass LSQR step instead of dropping to the general M x K kernels.
+bool tall_mixed_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
+{
+    if (!(op->tall && op->uniform_rows && op->elementwise) || op->nrow < 2 || op->all_diag) return false;
+    const size_t es = jh_dtype_size(op->dtype);
+    const int64_t n = op->row_len[0];
+    if (n == 0 || (n * (int64_t)es) % 16 != 0) return false;
+    if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & 15u) return false;
+    for (const auto &b : op->blocks)
+        if ((b.kind == JH_OP_DIAG || b.kind == JH_OP_SQUARE) && (((uintptr_t)b.coeff) & 15u)) return false;
+    return true;
+}
+
+// one shape per kernel for the mixed rows (they are the exception; the all-DIAG instantiations keep their tuned shapes)
+template <typename S, int E, int NS>
+int launch_tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
+{
+    jh_context &c = jh_ctx();
+    constexpr int BLK = 256, U = 4;
+    int64_t G = 4;
+    if (G > op->nrow) G = op->nrow;
+    const int64_t gx = (n_scalars + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);
+    int64_t gy = (op->nrow + G - 1) / G;
+    while (gx * gy * BLK >= ((int64_t)1 << 32) && G < op->nrow) { G *= 2; gy = (op->nrow + G - 1) / G; }
+    JH_REQUIRE(gx * gy * BLK < (int64_t)1 << 32, "tall forward: grid of %lld workgroups is too large", (long long)(gx * gy));
+    c.last_fwd_walk = 0;
+    c.last_fwd_rows_per_wg = G;
+    hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, true, BLK, true>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, op->dev_blocks,
+                       op->nrow, (int)G, (const S *)nullptr, (int64_t)0, (const S *)m, (S *)d, n_scalars, (unsigned)gx, (unsigned)gy, 1u);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
+template <typename S, int E, int NS, int MODE, int BLK, int U, int DEPTH>
+int launch_tall_adj_mixed_u(const jh_blockop *op, void *out, const void *in, int64_t n_scalars, int64_t s_begin, int64_t s_end)
+{
+    jh_context &c = jh_ctx();
+    const int64_t gx = (s_end - s_begin + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);
+    int64_t parts = pick_adj_parts(gx, op->nrow), rows_per_part = 0;                  // many rows of small blocks: split-row walk
+    const int64_t part_stride = s_end - s_begin;
+    void *slabs = nullptr;
+    if (parts > 1) {
+        rows_per_part = (op->nrow + parts - 1) / parts;
+        parts = (op->nrow + rows_per_part - 1) / rows_per_part;
+        JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)part_stride * sizeof(S), &slabs));
+    }
+    c.last_adj_parts = parts;
+    c.last_adj_launches = 1;
+    hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, true, MODE, BLK, true>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, c.stream,
+                       op->dev_blocks, op->nrow, (const S *)nullptr, (int64_t)0, (S *)out, (const S *)in, n_scalars, 0, s_begin, s_end,
+                       (int64_t)0, op->nrow, 0, rows_per_part, (S *)slabs, part_stride);
+    JH_CHECK_HIP(hipGetLastError());
+    if (parts > 1) return launch_fold_parts<S, NS>(slabs, part_stride, parts, out, s_begin, s_end);
+    return JH_OK;
+}
+
+template <typename S, int E, int NS, int MODE>
+int launch_tall_adj_mixed(const jh_blockop *op, void *out, const void *in, int64_t n_scalars, int64_t s_begin = 0, int64_t s_end = -1)
+{
+    if (s_end < 0) s_end = n_scalars;
+    if (s_end <= s_begin) return JH_OK;
+    // the fused normal operator reads ONE stream: fat workgroups with more rows in flight once the blocks are big (like the
+    // all-DIAG shapes of pick_adj_shape); everything else 512 x 2 x 2
+    if (MODE == 1 && n_scalars / NS >= ((int64_t)1 << 22)) return launch_tall_adj_mixed_u<S, E, NS, MODE, 1024, 4, 4>(op, out, in, n_scalars, s_begin, s_end);
+    return launch_tall_adj_mixed_u<S, E, NS, MODE, 512, 2, 2>(op, out, in, n_scalars, s_begin, s_end);
+}
+
 // every block boundary / coefficient pointer / vector base on a 16-byte boundary?
 bool general_vec_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
 {
@@ -1433,6 +1618,8 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
         if (op->upd_walk >= 0) walk = op->upd_walk;
         else { trial = op->upd_trials; walk = trial; }        // trial 0 -> walk 0, trial 1 -> walk 1
     }
+    const bool mixed = !op->all_diag;                       // rows of several elementwise kinds: the 256 x 4 tiling, sequential sweep
+    if (mixed) { wg = 256; U = 4; walk = 0; trial = -1; }
     if (walk == 1 && !c.fwd_group) G = 2;
     if (G > op->nrow) G = (int)op->nrow;
     const int64_t gx = (nvec + (int64_t)wg * U - 1) / ((int64_t)wg * U);
@@ -1450,7 +1637,11 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     hipLaunchKernelGGL((k_tall_diag_fwd_update<S, E, NS, UU, BLK>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream,  \
                        op->dev_blocks, op->nrow, G, a_base, a_stride, (const S *)m, (S *)d, n_scalars, (unsigned)gx,   \
                        (unsigned)gy, walk, (S)alpha, (S)beta, c.part_dev)
-    if (wg == 1024) JH_LAUNCH(1024, 8);
+    if (mixed)
+        hipLaunchKernelGGL((k_tall_diag_fwd_update<S, E, NS, 4, 256, true>), dim3((unsigned)(gx * gy)), dim3(256), 0, c.stream, op->dev_blocks,
+                           op->nrow, G, a_base, a_stride, (const S *)m, (S *)d, n_scalars, (unsigned)gx, (unsigned)gy, walk, (S)alpha, (S)beta,
+                           c.part_dev);
+    else if (wg == 1024) JH_LAUNCH(1024, 8);
     else if (U == 4) JH_LAUNCH(256, 4);
     else JH_LAUNCH(256, 1);
 #undef JH_LAUNCH
@@ -1535,6 +1726,8 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     if (c.adj_wg) wg = (int)c.adj_wg;                       // the adjoint's knobs select among the instantiated shapes
     if (c.adj_unroll) U = (int)c.adj_unroll;
     if (c.adj_depth) D = (int)c.adj_depth;
+    const bool mixed = !op->all_diag;                       // rows of several elementwise kinds (tall_mixed_ok): one instantiated shape
+    if (mixed) { if (nvec >= ((int64_t)1 << 22)) { wg = 512; U = 1; D = 4; } else { wg = 256; U = 2; D = 2; } }
     const int64_t gx = ((s_end - s_begin) / NS + (int64_t)wg * U - 1) / ((int64_t)wg * U);
     // many rows of small blocks: split-row walk (pick_adj_parts): u's rows are updated as before, w's sum is folded from slabs
     int64_t parts = direct ? 1 : pick_adj_parts(gx, op->nrow);
@@ -1554,12 +1747,13 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     int64_t rows_per_launch = op->nrow;
     if (c.adj_rows_per_launch > 0) rows_per_launch = c.adj_rows_per_launch < op->nrow ? c.adj_rows_per_launch : op->nrow;
     if (parts > 1) rows_per_launch = op->nrow;
-#define JH_LAUNCH(BLK, UU, DD)                                                                                          \
-    if (wg == BLK && U == UU && D == DD) {                                                                              \
+#define JH_LAUNCH(BLK, UU, DD) JH_LAUNCH_M(BLK, UU, DD, false)
+#define JH_LAUNCH_M(BLK, UU, DD, MIX)                                                                                   \
+    if (wg == BLK && U == UU && D == DD && mixed == MIX) {                                                              \
         double total = 0.0;                                                                                              \
         for (int64_t r0 = 0; r0 < op->nrow; r0 += rows_per_launch) {                                                     \
             const int64_t r1 = r0 + rows_per_launch < op->nrow ? r0 + rows_per_launch : op->nrow;                          \
-            hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, \
+            hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK, MIX>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, \
                                c.stream,                                                                                 \
                                op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars,      \
                                direct, (S)alpha, (S)beta, c.part_dev, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0,              \
@@ -1576,7 +1770,9 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     JH_LAUNCH(256, 1, 4) JH_LAUNCH(256, 2, 2) JH_LAUNCH(256, 4, 1) JH_LAUNCH(256, 4, 2) JH_LAUNCH(256, 1, 8)
     JH_LAUNCH(512, 1, 4) JH_LAUNCH(512, 2, 2) JH_LAUNCH(512, 4, 1) JH_LAUNCH(512, 4, 2) JH_LAUNCH(512, 1, 8)
     JH_LAUNCH(1024, 1, 4) JH_LAUNCH(1024, 2, 2) JH_LAUNCH(1024, 4, 1)      // 1024 x 4 x 2 would need > 128 VGPRs per lane
+    JH_LAUNCH_M(512, 1, 4, true) JH_LAUNCH_M(256, 2, 2, true)
 #undef JH_LAUNCH
+#undef JH_LAUNCH_M
     return jh_fail(JH_ERR_INVALID, "fused bidiagonalisation step: shape %d x %d x %d is not instantiated", wg, U, D);
 }
 
@@ -1764,7 +1960,10 @@ int check_vectors(const jh_blockop *op, const jh_bvec *rng, const jh_bvec *dom, 
 
 }  // namespace
 
-bool jh_blockop_tall_fast(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr) { return tall_fast_ok(op, rng_ptr, dom_ptr); }
+bool jh_blockop_tall_fast(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
+{
+    return tall_fast_ok(op, rng_ptr, dom_ptr) || (tall_mixed_ok(op, rng_ptr, dom_ptr) && !(op->nonlinear && !op->pointed));
+}
 
 extern "C" {
 
@@ -2000,6 +2199,15 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
         case JH_C64: return launch_tall_fwd<double, 2, 2>(op, d->data, m->data, 2 * n);
         }
     }
+    if (tall_mixed_ok(op, d->data, m->data)) {                 // rows of several elementwise kinds: the tall tiling with a per-row kind
+        const int64_t n = op->row_len[0];
+        switch (op->dtype) {
+        case JH_F32: return launch_tall_fwd_mixed<float, 1, 4>(op, d->data, m->data, n);
+        case JH_F64: return launch_tall_fwd_mixed<double, 1, 2>(op, d->data, m->data, n);
+        case JH_C32: return launch_tall_fwd_mixed<float, 2, 4>(op, d->data, m->data, 2 * n);
+        case JH_C64: return launch_tall_fwd_mixed<double, 2, 2>(op, d->data, m->data, 2 * n);
+        }
+    }
     if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false);
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
     if (op->dense_batch_grid) return dense_grid_fwd(op, d->data, m->data);
@@ -2029,6 +2237,15 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
         case JH_C64: return launch_tall_adj<double, 2, 2, 0>(op, m->data, d->data, 2 * n);
         }
     }
+    if (tall_mixed_ok(op, d->data, m->data)) {
+        const int64_t n = op->row_len[0];
+        switch (op->dtype) {
+        case JH_F32: return launch_tall_adj_mixed<float, 1, 4, 0>(op, m->data, d->data, n);
+        case JH_F64: return launch_tall_adj_mixed<double, 1, 2, 0>(op, m->data, d->data, n);
+        case JH_C32: return launch_tall_adj_mixed<float, 2, 4, 0>(op, m->data, d->data, 2 * n);
+        case JH_C64: return launch_tall_adj_mixed<double, 2, 2, 0>(op, m->data, d->data, 2 * n);
+        }
+    }
     if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, false);
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, true);
     if (op->dense_batch_grid) return dense_grid_adj(op, m->data, d->data);
@@ -2050,11 +2267,20 @@ int jh_blockop_mul_adj_range(const jh_blockop *op, jh_bvec *m, const jh_bvec *d,
     JH_REQUIRE(first_elem >= 0 && count >= 0 && first_elem + count <= m->length,
                "jh_blockop_mul_adj_range: elements [%lld, %lld) outside the domain vector (%lld elements)", (long long)first_elem,
                (long long)(first_elem + count), (long long)m->length);
-    if (!tall_fast_ok(op, d->data, m->data))
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_range: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
+    const bool mixed = tall_mixed_ok(op, d->data, m->data);
+    if (mixed && op->nonlinear && !op->pointed)
+        return jh_fail(JH_ERR_STATE, "jh_blockop_mul_adj_range: operator has nonlinear blocks and no linearisation point (jh_blockop_point)");
+    if (!mixed && !tall_fast_ok(op, d->data, m->data))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_range: needs a tall operator of elementwise rows with equal, 16-byte aligned blocks");
     const int64_t es = (int64_t)jh_dtype_size(op->dtype);
     JH_REQUIRE((first_elem * es) % 16 == 0 && (count * es) % 16 == 0, "jh_blockop_mul_adj_range: chunk boundaries must be 16-byte aligned");
     const int64_t n = op->row_len[0];
+    if (mixed) switch (op->dtype) {
+    case JH_F32: return launch_tall_adj_mixed<float, 1, 4, 0>(op, m->data, d->data, n, first_elem, first_elem + count);
+    case JH_F64: return launch_tall_adj_mixed<double, 1, 2, 0>(op, m->data, d->data, n, first_elem, first_elem + count);
+    case JH_C32: return launch_tall_adj_mixed<float, 2, 4, 0>(op, m->data, d->data, 2 * n, 2 * first_elem, 2 * (first_elem + count));
+    case JH_C64: return launch_tall_adj_mixed<double, 2, 2, 0>(op, m->data, d->data, 2 * n, 2 * first_elem, 2 * (first_elem + count));
+    }
     switch (op->dtype) {
     case JH_F32: return launch_tall_adj<float, 1, 4, 0>(op, m->data, d->data, n, first_elem, first_elem + count);
     case JH_F64: return launch_tall_adj<double, 1, 2, 0>(op, m->data, d->data, n, first_elem, first_elem + count);
@@ -2073,11 +2299,21 @@ int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m)
                "jh_blockop_normal_mul: domain vectors have %lld / %lld elements, operator domain has %lld", (long long)y->length,
                (long long)m->length, (long long)op->col_off[(size_t)op->ncol]);
     JH_REQUIRE(y->data != m->data, "jh_blockop_normal_mul: y must not alias m");
+    const int64_t n = op->row_len[0];
+    if (tall_mixed_ok(op, y->data, m->data)) {                  // rows of several elementwise kinds (a zero row adds nothing: 1022 + 1047)
+        if (op->nonlinear && !op->pointed)
+            return jh_fail(JH_ERR_STATE, "jh_blockop_normal_mul: operator has nonlinear blocks and no linearisation point (jh_blockop_point)");
+        switch (op->dtype) {
+        case JH_F32: return launch_tall_adj_mixed<float, 1, 4, 1>(op, y->data, m->data, n);
+        case JH_F64: return launch_tall_adj_mixed<double, 1, 2, 1>(op, y->data, m->data, n);
+        case JH_C32: return launch_tall_adj_mixed<float, 2, 4, 1>(op, y->data, m->data, 2 * n);
+        case JH_C64: return launch_tall_adj_mixed<double, 2, 2, 1>(op, y->data, m->data, 2 * n);
+        }
+    }
     if (!tall_fast_ok(op, y->data, m->data) || op->nrow < 2)
         return jh_fail(JH_ERR_UNSUPPORTED,
-                       "jh_blockop_normal_mul: fused A'A needs a tall (>= 2 rows) all-DIAG operator with equal, 16-byte aligned blocks; "
+                       "jh_blockop_normal_mul: fused A'A needs a tall (>= 2 rows) operator of elementwise rows with equal, 16-byte aligned blocks; "
                        "chain jh_blockop_mul and jh_blockop_mul_adj instead");
-    const int64_t n = op->row_len[0];
     switch (op->dtype) {
     case JH_F32: return launch_tall_adj<float, 1, 4, 1>(op, y->data, m->data, n);
     case JH_F64: return launch_tall_adj<double, 1, 2, 1>(op, y->data, m->data, n);
@@ -2207,8 +2443,8 @@ int jh_blockop_bidiag_step(const jh_blockop *op, jh_bvec *u, const jh_bvec *v, j
     JH_TRY(check_vectors(op, u, v, "jh_blockop_bidiag_step"));
     JH_REQUIRE(w && w->dtype == op->dtype && w->length == v->length, "jh_blockop_bidiag_step: w must be a domain vector of the operator");
     JH_REQUIRE(w->data != v->data, "jh_blockop_bidiag_step: w must not alias v");
-    if (!tall_fast_ok(op, u->data, v->data) || (((uintptr_t)w->data) & 15u))
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_bidiag_step: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
+    if (!jh_blockop_tall_fast(op, u->data, v->data) || (((uintptr_t)w->data) & 15u))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_bidiag_step: needs a tall operator of elementwise rows with equal, 16-byte aligned blocks");
     const int64_t n = op->row_len[0];
     switch (op->dtype) {
     case JH_F32: return launch_bidiag<float, 1, 4>(op, u->data, v->data, w->data, n, alpha, beta, normsq);
@@ -2229,8 +2465,8 @@ int jh_blockop_bidiag_step_range(const jh_blockop *op, jh_bvec *u, const jh_bvec
     JH_REQUIRE(first_elem >= 0 && count >= 0 && first_elem + count <= v->length,
                "jh_blockop_bidiag_step_range: elements [%lld, %lld) outside the domain vector (%lld elements)", (long long)first_elem,
                (long long)(first_elem + count), (long long)v->length);
-    if (!tall_fast_ok(op, u->data, v->data) || (((uintptr_t)w->data) & 15u))
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_bidiag_step_range: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
+    if (!jh_blockop_tall_fast(op, u->data, v->data) || (((uintptr_t)w->data) & 15u))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_bidiag_step_range: needs a tall operator of elementwise rows with equal, 16-byte aligned blocks");
     const int64_t es = (int64_t)jh_dtype_size(op->dtype);
     JH_REQUIRE((first_elem * es) % 16 == 0 && (count * es) % 16 == 0, "jh_blockop_bidiag_step_range: chunk boundaries must be 16-byte aligned");
     const int64_t n = op->row_len[0], lo = first_elem, hi = first_elem + count;
@@ -2266,8 +2502,8 @@ int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, dou
 {
     JH_TRY(jh_require_ready());
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_axpby"));
-    if (!tall_fast_ok(op, d->data, m->data))
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_axpby: needs a tall all-DIAG operator with equal, 16-byte aligned blocks; "
+    if (!jh_blockop_tall_fast(op, d->data, m->data))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_axpby: needs a tall operator of elementwise rows with equal, 16-byte aligned blocks; "
                                            "use jh_blockop_mul into a temporary, jh_lincomb and jh_norm instead");
     const int64_t n = op->row_len[0];
     switch (op->dtype) {

@@ -287,35 +287,9 @@ def _native_op(cell, ops, dtype):
         return cell.value
     if cell.value != "unset":
         cell.close()                                           # stale pointers: drop the handle and every table built on it
-    cell.value = NativeBlockOp(ops, _densify_scalar_rows(ops, descs, dtype), dtype) if native else None
+    cell.value = NativeBlockOp(ops, descs, dtype) if native else None
     cell.gen, cell.sig = gen, sig
     return cell.value
-
-
-def _densify_scalar_rows(ops, descs, dtype):
-    """A tall operator of diagonal rows plus a FEW identity / scalar rows (data rows and a regularisation row, say) would
-    leave the tall kernels -- and with them the fused A'A and the one-pass LSQR step -- because those need every row to
-    read a coefficient array.  Give each such row a constant diagonal (a for SCALE, 1 for IDENTITY): a*m and 1*m have the
-    bits of the scalar kinds (the same single product; 1*x == x), and the operator is all-DIAG.  Only when the scalar rows
-    are at most a quarter of the rows (each costs one block of memory and of bandwidth) and no row is a zero block
-    (a zero block must leave its row untouched, src/Jets.jl:1022, which no diagonal can do)."""
-    nrow, ncol = ops.shape
-    kinds = [row[0][0] for row in descs]
-    if ncol != 1 or nrow < 2 or not set(kinds) <= {"diag", "identity", "scale"}:
-        return descs
-    scalar = [i for i, k in enumerate(kinds) if k != "diag"]
-    if not scalar or 4 * len(scalar) > nrow or len({range_(ops[i, 0]).length() for i in builtins.range(nrow)}) != 1:
-        return descs
-    cplx = np.dtype(dtype).kind == "c"
-    if cplx and any(descs[i][0][1] for i in builtins.range(nrow) if kinds[i] == "diag"):
-        return descs                                           # an adjointed complex diagonal keeps the general kernels anyway
-    out = [list(row) for row in descs]
-    for i in scalar:
-        kind, adj, _, scale = descs[i][0]
-        a = 1.0 if kind == "identity" else (np.conj(scale) if adj else scale)
-        const = fill_(zeros(range_(ops[i, 0])), a)
-        out[i][0] = ("diag", 0, const, 0.0)
-    return out
 
 
 # ------------------------------------------------------------------------------ construction -------

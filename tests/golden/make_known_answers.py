@@ -429,6 +429,26 @@ def main():
             msum = [f(x, y) for x, y in zip(msum, tmp)]
         store(case, "adj_0", ar, msum)
 
+    # ---- 7. tall 9 x 1 with rows of EVERY elementwise kind (zero, identity, scalar, diagonal, adjointed ones): the forward leaves
+    #         the zero rows as found (1022), the adjoint skips them (1047); A'A goes through the zeros() temporary (530-534) -----
+    for dtype in ("f32", "c64"):
+        ar = Arith(dtype)
+        n = 32
+        def dg(adj=False):
+            return Child("diag", n, coeff=[rng.elem(ar) for _ in range(n)], adjoint=adj)
+        col = [dg(), Child("zero", n), Child("identity", n), Child("scale", n, scale=rng.elem(ar)), dg(adj=True), Child("zero", n), dg(),
+               Child("scale", n, scale=rng.elem(ar), adjoint=True), Child("identity", n, adjoint=True)]
+        ops = [[c] for c in col]
+        nrow = len(ops)
+        m = [[rng.elem(ar) for _ in range(n)]]
+        m[0][3] = (F(1, Fraction(0)), F(1, Fraction(0))) if ar.cplx else F(1, Fraction(0))       # a negative zero through every kind
+        d_found = [[rng.elem(ar) for _ in range(n)] for _ in range(nrow)]
+        m_found = [[rng.elem(ar) for _ in range(n)]]
+        case = f"mixed_tall_{dtype}"
+        run_linear_case(case, dtype, ops, m, d_found, m_found)
+        tmp = block_df(ar, ops, [[ar.zero() for _ in range(n)] for _ in range(nrow)], m)
+        store(case, "normal_0", ar, block_df_adj(ar, ops, [[ar.zero() for _ in range(n)]], tmp)[0])
+
     np.savez_compressed(os.path.join(HERE, "known_answers.npz"), **CASES)
     print(f"wrote {len(CASES)} arrays in {len({k.split('/')[0] for k in CASES})} cases to tests/golden/known_answers.npz")
 

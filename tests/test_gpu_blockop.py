@@ -391,8 +391,8 @@ def test_more_than_65535_block_rows_through_the_general_kernels(Jets):
 
 @pytest.mark.parametrize("dt", DTYPES)
 def test_tall_operator_with_a_few_scalar_rows_stays_on_the_tall_kernels(Jets, oracle, dt):
-    """[A_1; ...; A_6; I; a*I]: identity / scalar rows get a constant diagonal so that the operator is all-DIAG for the
-    device -- bit-identical to the scalar kinds in the oracle -- and the fused A'A and the one-pass LSQR step apply."""
+    """[A_1; ...; A_6; I; a*I]: identity / scalar rows ride the tall kernels through the per-row kind (MIXED instantiations,
+    no constant diagonals are materialised) -- bit-identical to the oracle -- and the fused A'A and the one-pass LSQR step apply."""
     import ctypes as C
 
     from jets_jl_amd._ffi import lib
@@ -420,13 +420,23 @@ def test_tall_operator_with_a_few_scalar_rows_stays_on_the_tall_kernels(Jets, or
     assert_bits_equal(Jets.mul(A.H @ A, m).to_numpy(), refm[0], "fused A'A")
     nat = jetblock._native_op(A.jet.s["_native"], A.jet.s["ops"], A.jet.rng.eltype())
     w, out = Jets.zeros(spc), C.c_double(0)
-    assert lib.jh_blockop_bidiag_step(nat.handle, d.handle, m.handle, w.handle, 1.0, 0.0, C.byref(out)) == 0    # all-DIAG for the device
+    assert lib.jh_blockop_bidiag_step(nat.handle, d.handle, m.handle, w.handle, 1.0, 0.0, C.byref(out)) == 0    # a tall operator of elementwise rows
     assert_bits_equal(w.to_numpy(), refm[0], "one-pass step")
-    # many scalar rows: not densified (memory), the general kernels keep the kinds
+    # many scalar rows are served the same way
     B = Jets.blockop([[Jets.JopDiagonal(diags[0])], [Jets.JopIdentity(spc)], [Jets.JopIdentity(spc)]])
     natB = jetblock._native_op(B.jet.s["_native"], B.jet.s["ops"], B.jet.rng.eltype())
     u3 = Jets.zeros(Jets.range(B))
-    assert lib.jh_blockop_bidiag_step(natB.handle, u3.handle, m.handle, w.handle, 1.0, 0.0, C.byref(out)) == 4   # JH_ERR_UNSUPPORTED
+    assert lib.jh_blockop_bidiag_step(natB.handle, u3.handle, m.handle, w.handle, 1.0, 0.0, C.byref(out)) == 0
+    oraB = [[oracle.Block("diag", n, coeff=u01(oracle, dt, 7, 0, n))], [oracle.Block("identity", n)], [oracle.Block("identity", n)]]
+    refB = oracle.block_df(oraB, [np.zeros(n, dt) for _ in range(3)], [hm])
+    assert_bits_equal(u3.to_numpy(), np.concatenate(refB), "one-pass step on 1 diagonal + 2 identity rows: u")
+    assert_bits_equal(w.to_numpy(), oracle.block_df_adj(oraB, [np.zeros(n, dt)], refB)[0], "... w")
+    # a block length that is not a multiple of 16 bytes has no tall tiling: the step says so and the caller takes another path
+    odd = Jets.JetSpace(dt, 4097 if np.dtype(dt).itemsize == 4 else 4097)
+    if (4097 * np.dtype(dt).itemsize) % 16:
+        Cop = Jets.blockop([[Jets.JopDiagonal(Jets.rand(odd, seed=7, stream=0))], [Jets.JopIdentity(odd)]])
+        natC = jetblock._native_op(Cop.jet.s["_native"], Cop.jet.s["ops"], Cop.jet.rng.eltype())
+        assert lib.jh_blockop_bidiag_step(natC.handle, Jets.zeros(Jets.range(Cop)).handle, Jets.zeros(odd).handle, Jets.zeros(odd).handle, 1.0, 0.0, C.byref(out)) == 4
 
 
 @pytest.mark.parametrize("rows", [1, 3, 5, 64])

@@ -62,10 +62,11 @@ def test_hip_path_reproduces_the_independent_known_answers(Jets, z, name):
         J.tune(adj_wg=0, adj_unroll=0, adj_depth=0)
 
 
-@pytest.mark.parametrize("name", ["rand_tall_f32", "rand_tall_c64", "order_tall_f32"])
+@pytest.mark.parametrize("name", ["rand_tall_f32", "rand_tall_c64", "order_tall_f32", "mixed_tall_f32", "mixed_tall_c64"])
 def test_one_pass_step_reproduces_the_known_adjoint(Jets, z, name):
     """jh_blockop_bidiag_step with alpha = 1, beta = 0 is forward-then-adjoint in one pass: u must be the known forward, w the
-    known adjoint of it (order_tall: of the stored d_in, so only its forward half is compared there)."""
+    known adjoint of it (order_tall: of the stored d_in, so only its forward half is compared there).  mixed_tall: the step's
+    forward half is A v into a zeros() temporary, so a zero row of u is 0 (not "as found") and w is the known A'A v."""
     import ctypes as C
     from jets_jl_amd._ffi import lib, check
     from jets_jl_amd import jetblock as _blk
@@ -79,9 +80,15 @@ def test_one_pass_step_reproduces_the_known_adjoint(Jets, z, name):
     w = J.zeros(J.domain(A))
     out = C.c_double(0)
     check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, 1.0, 0.0, C.byref(out)))
+    mixed = name.startswith("mixed")
     for i, got in enumerate(_blocks_of(u, c.row_len)):
-        assert ka.bits(got) == ka.bits(c.get(f"fwd_{i}")), f"{name}: u block {i}"
-    if not c.has("d_in_0"):
+        if mixed and int(c.kind[i, 0]) == 0:
+            assert not np.any(got.view(np.uint8)), f"{name}: zero row {i} of u must be +0"
+        else:
+            assert ka.bits(got) == ka.bits(c.get(f"fwd_{i}")), f"{name}: u block {i}"
+    if mixed:
+        assert ka.bits(w.to_numpy().ravel(order="F")) == ka.bits(c.get("normal_0")), f"{name}: w"
+    elif not c.has("d_in_0"):
         assert ka.bits(w.to_numpy().ravel(order="F")) == ka.bits(c.get("adj_0")), f"{name}: w"
         want = sum(float(np.vdot(c.get(f"fwd_{i}").astype(np.complex128), c.get(f"fwd_{i}").astype(np.complex128)).real) for i in range(c.nrow))
         assert abs(out.value - want) <= 1e-12 * want

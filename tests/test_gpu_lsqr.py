@@ -289,9 +289,13 @@ def test_bidiag_step_argument_checks(Jets, oracle):
     short = Jets.zeros(Jets.JetSpace(np.float32, 63))
     assert lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, short.handle, 1.0, 0.0, C.byref(out)) == 1
     spc = Jets.JetSpace(np.float32, 64)
-    B = Jets.blockop([[Jets.JopDiagonal(Jets.rand(spc))], [Jets.JopIdentity(spc)]])                              # not all-DIAG
+    B = Jets.blockop([[Jets.JopDiagonal(Jets.rand(spc))], [Jets.JopIdentity(spc)]])                              # not all-DIAG: per-row kinds
     assert lib.jh_blockop_bidiag_step(_native(Jets, B).handle, Jets.zeros(Jets.range(B)).handle, v.handle,
-                                      Jets.zeros(spc).handle, 1.0, 0.0, C.byref(out)) == 4                         # JH_ERR_UNSUPPORTED
+                                      Jets.zeros(spc).handle, 1.0, 0.0, C.byref(out)) == 0
+    odd = Jets.JetSpace(np.float32, 63)                                                                          # 252-byte rows: no 16-byte tiling
+    Cop = Jets.blockop([[Jets.JopDiagonal(Jets.rand(odd))], [Jets.JopIdentity(odd)]])
+    assert lib.jh_blockop_bidiag_step(_native(Jets, Cop).handle, Jets.zeros(Jets.range(Cop)).handle, Jets.zeros(odd).handle,
+                                      Jets.zeros(odd).handle, 1.0, 0.0, C.byref(out)) == 4                         # JH_ERR_UNSUPPORTED
 
 
 def test_lsqr_one_pass_and_two_pass_iterations_agree(Jets, oracle, monkeypatch):
