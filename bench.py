@@ -230,11 +230,16 @@ def main():
         else:
             J.mul_(mt, A.H, d)
 
-    # operator setup, outside the warm-up count: the first forward of a large operator times its grid walks once
-    # (jh_blockop.hip: autotune_fwd_walk) and the first collective builds RCCL's channels -- with --warmup 0 neither may
-    # land in the timed region
+    # operator setup, outside the warm-up count: the first forwards of a large operator each try one grid walk (lazy autotune,
+    # jh_blockop.hip: fwd_autotune_next -- no extra launches, no host sync; 12 calls until the choice is made) and the first
+    # collective builds RCCL's channels -- with --warmup 0 neither may land in the timed region
     forward()
     adjoint()
+    setup_forwards = 1
+    while J.op_tune_get(A, "fwd_walk") == -1 and 0 < J.op_tune_get(A, "fwd_trials") and setup_forwards < 16:
+        forward()
+        J.synchronize()
+        setup_forwards += 1
     for _ in range(args.warmup):
         forward()
         adjoint()
@@ -395,6 +400,7 @@ def main():
                 "parallelism": f"row-partition x{world}" + (f" + {os.environ.get('BENCH_BACKEND', 'RCCL')} all-reduce({n * s / 2**20:.0f} MiB, pipelined in 4 chunks) in adjoint" if world > 1 else ""),
                 "fwd_grid_walk": ("column-persistent (a workgroup streams every block row)" if J.tune_get("last_fwd_rows_per_wg") >= nloc
                                   else {0: "sequential row sweep", 1: "all rows concurrent"}.get(J.tune_get("last_fwd_walk"), "banded")),
+                "fwd_walk_choice": {"candidate": J.op_tune_get(A, "fwd_walk"), "setup_forward_calls": setup_forwards},
                 "tune": {k: J.tune_get(k) for k in ("fwd_group", "fwd_unroll", "fwd_wg", "fwd_order", "adj_unroll", "adj_depth", "adj_wg", "nt", "autotune")},
             },
             "achieved_GBps_pair": pair_bytes_global * pairs_per_s / 1e9,

@@ -287,7 +287,7 @@ int jh_comm_info(int *nranks, int *rank);
 int jh_comm_allreduce_sum(jh_bvec *v);
 int jh_comm_allreduce_scalars(double *values, int n, int op);   /* op: 0 sum, 1 max, 2 min; synchronises */
 
-/* kernel-shape tuning knobs (bench/tests only): 0 = automatic (fwd_order: -1); name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg","fwd_order","nt","autotune",
+/* kernel-shape tuning knobs (bench/tests only): 0 = automatic (fwd_order: -1); name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg","fwd_order","nt","autotune" (0: tall forwards keep the size-based default shape; 1: per-operator lazy measurement, see jh_blockop_tune_get),
  * "graphs" (1: operators that run the per-block loop -- those with DENSE blocks -- replay it as a hipGraph from the
  * third call with the same vectors on; 0: always eager), "general_xcd" (the general M x K kernels' grid order: 1 automatic -- XCD-aware when the
  * input vector is >= 32 MiB, line by line below --, 0 never XCD-aware, 2 always), "red_wgs", "bcast_item_fast" (batched broadcasts with a shared operand: -1 automatic, 0 plain kernel, 1 items fastest), "adj_split" (split-row walk of the tall adjoint / fused normal /
@@ -296,6 +296,14 @@ int jh_comm_allreduce_scalars(double *values, int n, int op);   /* op: 0 sum, 1 
  * "last_fwd_rows_per_wg", "last_adj_launches", "last_adj_parts" and "graph_replays". */
 int jh_tune_set(const char *name, int64_t value);
 int jh_tune_get(const char *name, int64_t *value);
+/* Per-operator choices made by measurement.  "fwd_walk": the grid walk of the tall forward of an operator far larger than the
+ * caches (which one is fastest depends on where the slabs landed physically).  It is chosen LAZILY: while it is -1 each
+ * jh_blockop_mul runs the next candidate between two events -- no extra launches, no host synchronisation, jh_blockop_mul
+ * returns after enqueue -- and after 12 calls the fastest is kept ("fwd_trials" counts the timed calls so far).  A host that
+ * wants the steady state at once (or the same choice in every process) reads it from one operator and sets it on another;
+ * setting -1 measures again.  "upd_walk" is the same for jh_blockop_mul_axpby (0 / 1, chosen over its first two calls). */
+int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value);
+int jh_blockop_tune_set(jh_blockop *op, const char *name, int64_t value);
 
 #ifdef __cplusplus
 }

@@ -130,6 +130,8 @@ SYMBOLS = {
     "jh_comm_allreduce_scalars": (_int, [_dblp, _int, _int]),
     "jh_tune_set": (_int, [C.c_char_p, _i64]),
     "jh_tune_get": (_int, [C.c_char_p, _i64p]),
+    "jh_blockop_tune_get": (_int, [_vp, C.c_char_p, _i64p]),
+    "jh_blockop_tune_set": (_int, [_vp, C.c_char_p, _i64]),
 }
 
 

@@ -1239,37 +1239,55 @@ constexpr int K_FWD_CANDIDATES = 6;
 const TallShape k_fwd_candidates[K_FWD_CANDIDATES] = {TallShape{1024, 8, 16, 0}, TallShape{512, 1, 2, 1}, TallShape{256, 4, 4, 0},
                                                       TallShape{256, 4, 16, 1}, TallShape{512, 4, 8, 1}, TallShape{1024, 8, 1 << 20, 0}};
 
-// For operators far larger than the caches the row-concurrent walk is 5-7 % faster than the sequential sweep in
-// some processes and 10-15 % slower in others (profiles/repeat_r01.txt: same binary, same box; it depends on where
-// the slabs landed physically), so the first forward of such an operator times both once (12 extra launches of an
-// idempotent kernel, ~0.3 s, synchronous) and keeps the winner.  Skipped while the stream is being captured.
-template <typename S, int E, int NS>
-int autotune_fwd_walk(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
+// For operators far larger than the caches the row-concurrent walk is 5-7 % faster than the sequential sweep in some
+// processes and 10-15 % slower in others (profiles/repeat_r01.txt: same binary, same box; it depends on where the slabs landed
+// physically), so the shape is chosen by measurement -- LAZILY: while an operator is untuned, each real forward call runs the
+// next candidate shape between two events (every candidate computes the same bits), nothing is launched that the caller did
+// not ask for and the host never waits; a later call harvests the finished timings with hipEventQuery and, once every
+// candidate has been measured twice (the first pass also warms caches and TLBs), keeps the fastest.  jh_blockop_mul returns
+// after enqueue, always.  Skipped while the stream is being captured.  jh_blockop_tune_get/set export / import the choice.
+void fwd_autotune_release(const jh_blockop *op)
 {
-    jh_context &c = jh_ctx();
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(c.stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return JH_OK;   // stay untried
-    const TallShape *cand = k_fwd_candidates;
-    float best = 0.f;
-    int pick = 0;
-    hipEvent_t e0, e1;
-    JH_CHECK_HIP(hipEventCreate(&e0));
-    JH_CHECK_HIP(hipEventCreate(&e1));
-    for (int k = 0; k < K_FWD_CANDIDATES; k++) {
-        int st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, cand[k]);          // warm
-        if (st == JH_OK) st = (hipEventRecord(e0, c.stream) == hipSuccess) ? JH_OK : JH_ERR_HIP;
-        if (st == JH_OK) st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, cand[k]);
-        float ms = 0.f;
-        if (st == JH_OK && (hipEventRecord(e1, c.stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-                            hipEventElapsedTime(&ms, e0, e1) != hipSuccess))
-            st = jh_fail(JH_ERR_HIP, "autotune: event timing failed");
-        if (st != JH_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st; }
-        if (k == 0 || ms < best) { best = ms; pick = k; }
+    for (auto &pair : op->fwd_ev)
+        for (auto &e : pair)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
+}
+
+// returns the candidate index to run for THIS call and, when it is a timed trial, its slot (else -1)
+int fwd_autotune_next(const jh_blockop *op, int *slot)
+{
+    *slot = -1;
+    constexpr int NS_ = K_FWD_CANDIDATES * jh_blockop::FWD_PASSES;
+    int measured = 0;
+    for (int t = 0; t < op->fwd_trials_launched; t++) {                    // harvest what has finished (non-blocking)
+        if (op->fwd_state[t] == 1 && hipEventQuery(op->fwd_ev[t][1]) == hipSuccess) {
+            float ms = 0.f;
+            op->fwd_state[t] = (hipEventElapsedTime(&ms, op->fwd_ev[t][0], op->fwd_ev[t][1]) == hipSuccess && ms > 0.f) ? 2 : 3;
+            op->fwd_ms[t] = ms;
+        }
+        if (op->fwd_state[t] >= 2) measured++;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    op->fwd_walk = pick;
-    return JH_OK;
+    (void)hipGetLastError();                                               // hipEventQuery's hipErrorNotReady is not an error
+    if (measured == NS_) {
+        int pick = 0;
+        float best = 0.f;
+        for (int k = 0; k < K_FWD_CANDIDATES; k++) {
+            float ms = 0.f;                                                // best of the passes that produced a timing
+            for (int p = 0; p < jh_blockop::FWD_PASSES; p++) {
+                const int t = p * K_FWD_CANDIDATES + k;
+                if (op->fwd_state[t] == 2 && (ms == 0.f || op->fwd_ms[t] < ms)) ms = op->fwd_ms[t];
+            }
+            if (ms > 0.f && (best == 0.f || ms < best)) { best = ms; pick = k; }
+        }
+        op->fwd_walk = pick;
+        fwd_autotune_release(op);
+        return pick;
+    }
+    if (op->fwd_trials_launched < NS_) {
+        *slot = op->fwd_trials_launched;
+        return *slot % K_FWD_CANDIDATES;
+    }
+    return 0;                                                              // every trial is in flight: the default shape meanwhile
 }
 
 template <typename S, int E, int NS>
@@ -1280,8 +1298,23 @@ int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scal
     const bool knobs_free = !c.fwd_wg && !c.fwd_unroll && !c.fwd_group && c.fwd_order < 0;
     const double stream_bytes = 2.0 * (double)op->nrow * (double)n_scalars * sizeof(S);
     if (c.autotune && knobs_free && stream_bytes >= 8.0 * (double)(1ull << 30) && op->nrow >= 64) {
-        if (op->fwd_walk < 0) JH_TRY((autotune_fwd_walk<S, E, NS>(op, d, m, n_scalars)));
-        if (op->fwd_walk >= 0 && op->fwd_walk < K_FWD_CANDIDATES) sh = k_fwd_candidates[op->fwd_walk];
+        int slot = -1;
+        if (op->fwd_walk < 0) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(c.stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+                const int k = fwd_autotune_next(op, &slot);
+                if (k >= 0 && k < K_FWD_CANDIDATES) sh = k_fwd_candidates[k];
+            }
+        } else if (op->fwd_walk < K_FWD_CANDIDATES) sh = k_fwd_candidates[op->fwd_walk];
+        if (slot >= 0) {                                                   // a timed trial: the caller's own launch between two events
+            bool ok = hipEventCreate(&op->fwd_ev[slot][0]) == hipSuccess && hipEventCreate(&op->fwd_ev[slot][1]) == hipSuccess &&
+                      hipEventRecord(op->fwd_ev[slot][0], c.stream) == hipSuccess;
+            const int st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, sh);
+            ok = ok && st == JH_OK && hipEventRecord(op->fwd_ev[slot][1], c.stream) == hipSuccess;
+            op->fwd_state[slot] = ok ? 1 : 3;
+            op->fwd_trials_launched = slot + 1;
+            return st;
+        }
     }
     return launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, sh);
 }
@@ -2128,6 +2161,7 @@ int jh_blockop_destroy(jh_blockop *op)
     if (!op) return JH_OK;
     if (jh_ctx().ready) (void)hipStreamSynchronize(jh_ctx().stream);
     drop_loop_graphs(op);
+    fwd_autotune_release(op);
     if (op->dev_blocks) (void)hipFree(op->dev_blocks);
     if (op->dev_row_off) (void)hipFree(op->dev_row_off);
     if (op->dev_col_off) (void)hipFree(op->dev_col_off);
@@ -2477,6 +2511,33 @@ int jh_blockop_bidiag_step_range(const jh_blockop *op, jh_bvec *u, const jh_bvec
     case JH_C64: return launch_bidiag<double, 2, 2>(op, u->data, v->data, w->data, 2 * n, alpha, beta, normsq, 2 * lo, 2 * hi, true);
     }
     return jh_fail(JH_ERR_INVALID, "jh_blockop_bidiag_step_range: unknown dtype %d", op->dtype);
+}
+
+int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value)
+{
+    JH_REQUIRE(op && name && value, "jh_blockop_tune_get: null argument");
+    if (!strcmp(name, "fwd_walk")) *value = op->fwd_walk;                       // -1: not chosen yet
+    else if (!strcmp(name, "fwd_trials")) *value = op->fwd_trials_launched;
+    else if (!strcmp(name, "upd_walk")) *value = op->upd_walk;
+    else return jh_fail(JH_ERR_INVALID, "jh_blockop_tune_get: unknown per-operator knob '%s'", name);
+    return JH_OK;
+}
+
+int jh_blockop_tune_set(jh_blockop *op, const char *name, int64_t value)
+{
+    JH_REQUIRE(op && name, "jh_blockop_tune_set: null argument");
+    if (!strcmp(name, "fwd_walk")) {
+        JH_REQUIRE(value >= -1 && value < K_FWD_CANDIDATES, "jh_blockop_tune_set: fwd_walk must be -1 (measure again) or 0..%d", K_FWD_CANDIDATES - 1);
+        fwd_autotune_release(op);
+        for (auto &st : op->fwd_state) st = 0;
+        op->fwd_trials_launched = 0;
+        op->fwd_walk = (int)value;
+    } else if (!strcmp(name, "upd_walk")) {
+        JH_REQUIRE(value >= -1 && value <= 1, "jh_blockop_tune_set: upd_walk must be -1, 0 or 1");
+        op->upd_walk = (int)value;
+        op->upd_trials = value < 0 ? 0 : 2;
+    } else return jh_fail(JH_ERR_INVALID, "jh_blockop_tune_set: unknown per-operator knob '%s'", name);
+    return JH_OK;
 }
 
 int jh_normsq_reset(void)

@@ -25,7 +25,7 @@ __all__ = [
     "JetBlock", "JopBlock", "blockop", "JopZeroBlock", "JopZeroBlock_df", "iszero", "JetBlock_f", "JetBlock_df",
     "JetBlock_df_adj", "nblocks_op", "getblock_op", "isblockop", "JopDiagonal", "JopIdentity", "diagonal_df",
     "diagonal_df_adj", "identity_df", "NativeBlockOp", "JopDense", "dense_df", "dense_df_adj", "JopSquare", "square_f",
-    "square_df", "square_df_adj", "JopElementwise", "elementwise_f", "elementwise_df", "elementwise_df_adj", "elementwise_upstate",
+    "square_df", "square_df_adj", "op_tune_get", "op_tune_set", "JopElementwise", "elementwise_f", "elementwise_df", "elementwise_df_adj", "elementwise_upstate",
 ]
 
 
@@ -229,6 +229,15 @@ class NativeBlockOp:
     def normal_mul(self, y, m):
         check(lib.jh_blockop_normal_mul(self.handle, y.handle, m.handle))
         return y
+
+    def tune_get(self, name: str) -> int:
+        v = C.c_int64(0)
+        check(lib.jh_blockop_tune_get(self.handle, name.encode(), C.byref(v)))
+        return v.value
+
+    def tune_set(self, name: str, value: int):
+        check(lib.jh_blockop_tune_set(self.handle, name.encode(), int(value)))
+        return self
 
     def close(self):
         if self._h is not None:
@@ -530,6 +539,21 @@ def getblock_op(A, i: int, jc: int, kind=None):  # :1085-1090, 1100-1110
     if isinstance(A, JopLn):
         return JopLn(getblock_op(A.jet, i, jc))  # :1086
     return getblock_op(A.jet, i, jc)  # :1087
+
+
+def op_tune_get(A, name: str):
+    """Per-operator measured choice of a block operator's device handle (jh_blockop_tune_get: "fwd_walk", "fwd_trials",
+    "upd_walk"); None when the operator has no device handle."""
+    nat = _native_op(jet(A).s.get("_native"), jet(A).s["ops"], jet(A).rng.eltype()) if isblockop(A) else None
+    return None if nat is None else nat.tune_get(name)
+
+
+def op_tune_set(A, name: str, value: int):
+    nat = _native_op(jet(A).s.get("_native"), jet(A).s["ops"], jet(A).rng.eltype()) if isblockop(A) else None
+    if nat is None:
+        raise ValueError("operator has no device handle")
+    nat.tune_set(name, value)
+    return A
 
 
 # ------------------------------------------------------------------------------ fused chains -------

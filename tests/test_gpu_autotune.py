@@ -1,0 +1,45 @@
+"""GPU: the tall forward's grid walk is chosen lazily -- every candidate runs as one of the caller's own calls (same bits),
+jh_blockop_mul never synchronises, and the choice can be exported / imported per operator (include/jetship.h)."""
+import numpy as np
+import pytest
+
+from .helpers import assert_bits_equal, u01
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lazy_forward_autotune_converges_without_changing_bits(Jets, oracle):
+    J = Jets
+    dt, nrow, n = np.float32, 64, 1 << 24                       # 2 x 64 x 64 MiB = 8 GiB streamed: the autotuned regime
+    spc = J.JetSpace(dt, n)
+    coeff = J.rand(J.JetBSpace([spc] * nrow), seed=1, stream=0)
+    A = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
+    m = J.rand(spc, seed=2, stream=0)
+    d = J.zeros(J.range(A))
+    ha0, ha9 = u01(oracle, dt, 1, 0, 4096), oracle.rng_u01(dt, 1, 0, 9 * n + 12345, 4096)
+    hm0, hm9 = u01(oracle, dt, 2, 0, 4096), oracle.rng_u01(dt, 2, 0, 12345, 4096)
+    assert J.op_tune_get(A, "fwd_walk") is None or J.op_tune_get(A, "fwd_walk") == -1
+    walks = set()
+    for call in range(14):
+        J.fill_(d, 0)
+        J.mul_(d, A, m)
+        walks.add((J.tune_get("last_fwd_walk"), J.tune_get("last_fwd_rows_per_wg")))
+        flat = d.to_numpy() if call in (0, 5, 11, 13) else None          # slices of two rows, bit for bit, under whichever candidate ran
+        if flat is not None:
+            assert_bits_equal(flat[:4096], ha0 * hm0, f"call {call}: row 0")
+            assert_bits_equal(flat[9 * n + 12345:9 * n + 12345 + 4096], ha9 * hm9, f"call {call}: row 9")
+    assert len(walks) >= 3, "the first calls must have tried several candidate shapes"
+    assert J.op_tune_get(A, "fwd_trials") == 12
+    pick = J.op_tune_get(A, "fwd_walk")
+    assert 0 <= pick < 6, "after 12 timed calls (+ their completion) the choice is made"
+    # export / import: a second operator starts in the steady state, and -1 measures again
+    B = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
+    J.mul_(d, B, m)                                             # builds the handle (and runs trial 0)
+    J.op_tune_set(B, "fwd_walk", pick)
+    J.mul_(d, B, m)
+    assert J.op_tune_get(B, "fwd_walk") == pick and J.op_tune_get(B, "fwd_trials") == 0
+    J.op_tune_set(B, "fwd_walk", -1)
+    J.mul_(d, B, m)
+    assert J.op_tune_get(B, "fwd_trials") == 1
+    with pytest.raises(Exception):
+        J.op_tune_set(B, "fwd_walk", 99)
