@@ -908,6 +908,65 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
     }
 }
 
+// ------------------------------------------------------------------ general path with SMALL dense children ----
+// Operators that mix dense matrices (adjointed or not) with the elementwise kinds -- the reference's own 3 x 4 test operator
+// (test/runtests.jl:622-695: JopBaz children, one of them adjointed, Jacobians of JopBar, zero blocks) -- used to run the
+// reference's loop literally: one child launch + one accumulate launch per non-zero block.  For SMALL children that is pure
+// launch overhead.  Here ONE launch does the whole loop: a thread owns one element of an output line (block row of d, or block
+// column of m), walks the line's blocks in the reference's order and forms a dense child's dot product itself, sequentially
+// from zero, product rounded then added -- the oracle's loop, so forward AND adjoint are bit-identical to it (the per-child
+// kernels reduce the adjoint's dot in fp64 across a wave: tolerance parity).  Used while every matrix is at most 256 KiB.
+template <typename S, int E>
+__device__ inline elem<S, E> dense_child_dot(const jh_dev_block &b, int64_t nr, int64_t nc, const S *__restrict__ x, int64_t e, bool transposed)
+{
+    const S *A = (const S *)b.coeff;                                       // column-major nr x nc
+    const bool adj = (b.adjoint != 0) != transposed;                       // (op')' = op
+    elem<S, E> s;
+    s.re = 0; s.im = 0;
+    if (!adj) {                                                            // d[e] = sum_c A[e, c] x[c]        (test/runtests.jl:27)
+        for (int64_t c = 0; c < nc; c++) s = eadd<S, E>(s, emul<S, E>(eload<S, E>(A, e + c * nr), eload<S, E>(x, c)));
+    } else {                                                               // m[e] = sum_r conj(A[r, e]) x[r]  (test/runtests.jl:28)
+        for (int64_t r = 0; r < nr; r++) {
+            elem<S, E> a = eload<S, E>(A, r + e * nr);
+            if (E == 2) a.im = -a.im;
+            s = eadd<S, E>(s, emul<S, E>(a, eload<S, E>(x, r)));
+        }
+    }
+    return s;
+}
+
+// transposed == 0: JetBlock_df! / JetBlock_f! (fmode), line = block row; transposed == 1: JetBlock_df'!, line = block column.
+// dims: per block (column-major like `blocks`) the matrix shape {nr, nc} of a DENSE child (unused for the other kinds).
+template <typename S, int E>
+__global__ __launch_bounds__(256) void k_block_loop_small(const jh_dev_block *__restrict__ blocks, const int64_t *__restrict__ dims,
+                                                          int64_t nrow, int64_t ncol, const int64_t *__restrict__ row_off,
+                                                          const int64_t *__restrict__ col_off, S *__restrict__ out,
+                                                          const S *__restrict__ in, int transposed, int fmode)
+{
+    const int64_t line = blockIdx.y;
+    const int64_t *out_off = transposed ? col_off : row_off, *in_off = transposed ? row_off : col_off;
+    const int64_t n = out_off[line + 1] - out_off[line];
+    const int64_t nsum = transposed ? nrow : ncol;                         // blocks walked per line
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        elem<S, E> acc;
+        acc.re = 0; acc.im = 0;
+        bool touched = transposed ? (nrow > 1) : false;                    // `_m .= 0` (1042)
+        if (!transposed && ncol > 1) acc = eload<S, E>(out, out_off[line] + e);   // `_d .+=` into d as found (1024 / 1001)
+        for (int64_t q = 0; q < nsum; q++) {
+            const int64_t bi = transposed ? q + line * nrow : line + q * nrow;
+            const jh_dev_block b = blocks[bi];
+            if (b.kind == JH_OP_ZERO && !fmode) continue;                  // (1022 / 1047); JetBlock_f! applies the zero block (adds 0)
+            elem<S, E> p;
+            p.re = 0; p.im = 0;
+            if (b.kind == JH_OP_DENSE) p = dense_child_dot<S, E>(b, dims[2 * bi], dims[2 * bi + 1], in + in_off[q] * E, e, transposed != 0);
+            else if (b.kind != JH_OP_ZERO) p = apply_block<S, E>(b, eload<S, E>(in, in_off[q] + e), e, transposed != 0, fmode != 0);
+            acc = (nsum > 1) ? eadd<S, E>(acc, p) : p;                     // (1024 / 1049) accumulate, (1026 / 1051) direct
+            touched = true;
+        }
+        if (touched) estore<S, E>(out, out_off[line] + e, acc);
+    }
+}
+
 // 16-byte-per-lane variants of the two general kernels, used when every block offset, block length and
 // coefficient pointer is a multiple of 16 bytes.  Same loop order and rounding as the scalar versions.
 // Blocks whose loads are issued together per thread.  4 was measured no faster than 1 (0-10 % slower, within run-to-run spread) on every M x K shape but the tall
@@ -1913,6 +1972,31 @@ int loop_adj(const jh_blockop *op, void *m, const void *d)           // JetBlock
     return JH_OK;
 }
 
+int loop_small(const jh_blockop *op, void *out, const void *in, int transposed, int fmode)
+{
+    const int64_t nlines = transposed ? op->ncol : op->nrow;
+    const std::vector<int64_t> &lens = transposed ? op->col_len : op->row_len;
+    int64_t maxn = 0;
+    for (int64_t v : lens) maxn = v > maxn ? v : maxn;
+    if (maxn == 0) return JH_OK;
+    int64_t gx = (maxn + 255) / 256;
+    if (gx > 65535) gx = 65535;
+    hipStream_t st = jh_ctx().stream;
+#define JH_SMALL(S, E)                                                                                                     \
+    hipLaunchKernelGGL((k_block_loop_small<S, E>), dim3((unsigned)gx, (unsigned)nlines), dim3(256), 0, st, op->dev_blocks, op->dev_dims, \
+                       op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)out, (const S *)in, transposed, fmode)
+    switch (op->dtype) {
+    case JH_F32: JH_SMALL(float, 1); break;
+    case JH_F64: JH_SMALL(double, 1); break;
+    case JH_C32: JH_SMALL(float, 2); break;
+    case JH_C64: JH_SMALL(double, 2); break;
+    default: return jh_fail(JH_ERR_INVALID, "loop_small: unknown dtype %d", op->dtype);
+    }
+#undef JH_SMALL
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
 void drop_loop_graphs(const jh_blockop *op)
 {
     for (auto &g : op->loop_graphs)
@@ -2110,6 +2194,15 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
         }
     }
 
+    // anything else with DENSE blocks -- adjointed children, dense next to elementwise kinds (the reference's 3 x 4 test
+    // operator) -- whose matrices are all small: the whole block loop in one launch instead of two launches per block
+    if (!op->elementwise && !op->dense_batch && !op->dense_batch_ragged && !op->dense_batch_grid && !op->dense_batch_wide && nrow <= 65535 && ncol <= 65535) {
+        op->small_loop = true;
+        const double es = (double)jh_dtype_size(dtype);
+        for (const auto &b : op->blocks)
+            if (b.kind == JH_OP_DENSE && (double)b.nr * (double)b.nc * es > (double)(256 << 10)) op->small_loop = false;   // beyond 256 KiB per child the per-child kernels win (profiles/bench_graphs_r02.txt)
+    }
+
     // strided-diagonal detection: coeff[i] = coeff[0] + i*stride  (e.g. one slab holding all diagonals)
     if (op->tall && op->all_diag && nrow >= 1) {
         op->diag_strided = true;
@@ -2147,6 +2240,13 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
             if (op->blocks[(size_t)(i + j * nrow)].kind != JH_OP_ZERO) { touched[(size_t)i] = 1; break; }
     if (e == hipSuccess) e = hipMalloc((void **)&op->dev_row_touched, (size_t)nrow);
     if (e == hipSuccess) e = hipMemcpyAsync(op->dev_row_touched, touched.data(), (size_t)nrow, hipMemcpyHostToDevice, st);
+    std::vector<int64_t> dims;
+    if (op->small_loop) {
+        dims.resize(2 * host.size());
+        for (size_t k = 0; k < host.size(); k++) { dims[2 * k] = op->blocks[k].nr; dims[2 * k + 1] = op->blocks[k].nc; }
+        if (e == hipSuccess) e = hipMalloc((void **)&op->dev_dims, sizeof(int64_t) * dims.size());
+        if (e == hipSuccess) e = hipMemcpyAsync(op->dev_dims, dims.data(), sizeof(int64_t) * dims.size(), hipMemcpyHostToDevice, st);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);   // host staging vectors die at return
     if (e != hipSuccess) {
         jh_blockop_destroy(op);
@@ -2166,6 +2266,7 @@ int jh_blockop_destroy(jh_blockop *op)
     if (op->dev_row_off) (void)hipFree(op->dev_row_off);
     if (op->dev_col_off) (void)hipFree(op->dev_col_off);
     if (op->dev_row_touched) (void)hipFree(op->dev_row_touched);
+    if (op->dev_dims) (void)hipFree(op->dev_dims);
     delete op;
     return JH_OK;
 }
@@ -2208,6 +2309,7 @@ int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
     if (op->dense_batch_grid) return dense_grid_fwd(op, d->data, m->data);
     if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false, op->dev_row_off);
+    if (op->small_loop && jh_ctx().small_loop) return loop_small(op, d->data, m->data, 0, 1);
     if (!op->elementwise) return run_loop_graphed(op, 2, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data, true); });
     switch (op->dtype) {
     case JH_F32: return general_fwd<float, 1>(op, d->data, m->data, 1);
@@ -2246,6 +2348,7 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
     if (op->dense_batch_grid) return dense_grid_fwd(op, d->data, m->data);
     if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false, op->dev_row_off);
+    if (op->small_loop && jh_ctx().small_loop) return loop_small(op, d->data, m->data, 0, 0);
     if (!op->elementwise) return run_loop_graphed(op, 0, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data); });
     switch (op->dtype) {
     case JH_F32: return general_fwd<float, 1>(op, d->data, m->data);
@@ -2284,6 +2387,7 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, true);
     if (op->dense_batch_grid) return dense_grid_adj(op, m->data, d->data);
     if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, false, op->dev_row_off);
+    if (op->small_loop && jh_ctx().small_loop) return loop_small(op, m->data, d->data, 1, 0);
     if (!op->elementwise) return run_loop_graphed(op, 1, m->data, d->data, [&] { return loop_adj(op, m->data, d->data); });
     switch (op->dtype) {
     case JH_F32: return general_adj<float, 1>(op, m->data, d->data);

@@ -57,6 +57,7 @@ struct jh_context {
     int64_t autotune = 1;              // time both grid walks of the tall forward once per large operator
     int64_t general_xcd = 1;           // general M x K kernels: 1 = XCD-aware (line, tile) decode from 32 MiB of input on, else line by line; 0 never; 2 always
     int64_t graphs = 1;                // replay launch-bound per-block loops as hipGraphs (jh_blockop.hip: run_loop_graphed)
+    int64_t small_loop = 1;            // operators mixing small DENSE children with other kinds: the whole block loop in one launch (0: the per-block loop)
     int64_t graph_replays = 0;         // read-only counter: hipGraphLaunch calls made by run_loop_graphed
     uint64_t buf_gen = 0;              // bumped whenever part_dev / scratch_dev is reallocated: captured graphs holding the old pointers are stale
     int64_t red_wgs = 16384;           // workgroups of a reduction launch (4 packs per lane in flight); profiles/sweep_r01_reduce.txt
@@ -127,6 +128,8 @@ struct jh_blockop {
     bool dense_batch_grid = false;           // the same for an M x K grid (M, K >= 2): one tall batch per block column
     bool dense_aligned = false;              // ... and every matrix pointer on a 16-byte boundary
     bool launch_bound = true;                // the per-block loop of an operator with DENSE blocks is replayed as a hipGraph (it pays for small children)
+    bool small_loop = false;                 // DENSE blocks (adjointed or not) mixed with elementwise kinds, every matrix small: the whole loop in ONE launch (k_block_loop_small)
+    int64_t *dev_dims = nullptr;             // nrow*ncol x {nr, nc} of the described operators (small_loop only)
     bool nonlinear = false;                  // has a SQUARE block (JopNl child)
     bool pointed = false;                    // jh_blockop_point has been called (SQUARE blocks have their mo)
     bool diag_strided = false;               // coeff[i] = coeff[0] + i*stride bytes

@@ -1,12 +1,21 @@
 """GPU: hipGraph replay of the launch-bound per-block loop (operators with DENSE children; jh_blockop.hip: run_loop_graphed).
 Call 1 with a given (output, input) pair is eager, call 2 is captured, calls 3+ replay the graph with one launch.
-The bar is the eager path's: forward bit-exact vs the oracle, dense adjoint within tolerance (wave reduction)."""
+The bar is the eager path's: forward bit-exact vs the oracle, dense adjoint within tolerance (wave reduction).
+Since round 2 operators whose dense children are all small run the whole loop in ONE launch (tests/test_gpu_small_loop.py);
+the per-block loop and its graphs remain for bigger children, so these tests switch the one-launch loop off."""
 import numpy as np
 import pytest
 
 from .helpers import assert_bits_equal, u01
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _per_block_loop(Jets):
+    Jets.tune(small_loop=0)
+    yield
+    Jets.tune(small_loop=1)
 
 
 def _dense_mix(Jets, oracle, dt, seed):

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Launch-bound per-block loop: eager vs hipGraph replay (jh_tune "graphs"), the reference's own 3x4 mixed block operator
-shape (test/runtests.jl:622-695) with dense children.
+"""The reference's own 3x4 mixed block operator shape (test/runtests.jl:622-695) with dense children, one adjointed:
+per-block loop eager / replayed as a hipGraph (jh_tune "graphs") vs the whole loop in ONE launch (jh_tune "small_loop",
+k_block_loop_small; matrices up to 256 KiB).
 
-    python tools/bench_graphs.py > profiles/bench_graphs_r01.txt
+    python tools/bench_graphs.py > profiles/bench_graphs_r02.txt
 """
 import os
 import sys
@@ -12,7 +13,7 @@ import numpy as np
 import jets_jl_amd as J
 
 J.init(0)
-for n in (10, 64, 512, 2048):
+for n in (10, 64, 128, 256, 512, 2048):
     spc = J.JetSpace(np.float32, n)
     blk = lambda s: J.JopDense(J.rand(J.JetSpace(np.float32, n, n), seed=1, stream=s))
     Z = lambda: J.JopZeroBlock(spc, spc)
@@ -20,8 +21,8 @@ for n in (10, 64, 512, 2048):
     m, d = J.rand(J.domain(A), seed=2, stream=0), J.zeros(J.range(A))
     mt = J.zeros(J.domain(A))
     out = []
-    for graphs in (0, 1):
-        J.tune(graphs=graphs)
+    for graphs, small in ((0, 0), (1, 0), (1, 1)):
+        J.tune(graphs=graphs, small_loop=small)
         for _ in range(3):
             J.mul_(d, A, m)
             J.mul_(mt, A.H, d)
@@ -33,6 +34,6 @@ for n in (10, 64, 512, 2048):
             J.mul_(mt, A.H, d)
         e1 = J.Event().record()
         out.append(1e3 * e0.elapsed_ms(e1) / reps)
-    J.tune(graphs=1)
-    print(f"3x4 block operator, dense {n:5d} x {n:<5d} children (10 dense + 2 zero blocks, 40 launches per fwd+adj pair): "
-          f"eager {out[0]:8.1f} us/pair   graph replay {out[1]:8.1f} us/pair   {out[0] / out[1]:4.2f}x")
+    J.tune(graphs=1, small_loop=1)
+    print(f"3x4 block operator, dense {n:5d} x {n:<5d} children (10 dense + 2 zero blocks): per-block loop eager {out[0]:8.1f} us/pair   "
+          f"graph replay {out[1]:8.1f}   one launch each way {out[2]:8.1f} us/pair ({'per-block loop: a child exceeds 256 KiB' if n * n * 4 > (256 << 10) else f'{out[0] / out[2]:4.1f}x vs eager'})")

@@ -93,7 +93,14 @@ for case in range(seed0, seed0 + ncases):
         ref = oracle.block_df(ora, [hd[offr[i]:offr[i + 1]].copy() for i in range(nrow)], [hm[offc[j]:offc[j + 1]].copy() for j in range(ncol)])
         has_adj = any(a for (_, a) in mats.values())
         big = max(row_len) * max(col_len) * np.dtype(dt).itemsize >= (1 << 20)     # a child of 1 MiB or more may have its columns split
-        if (nrow == 1 and ncol > 64 and uniform) or has_adj or big:
+        # adjointed dense children / dense next to other kinds, every matrix <= 256 KiB: the one-launch block loop
+        # (k_block_loop_small), whose in-thread sequential dots are the oracle's -- forward AND adjoint bit for bit
+        one_launch = (has_adj or flavour >= 0.9) and not uniform and max(row_len) * max(col_len) * np.dtype(dt).itemsize <= (256 << 10) \
+            and any(o.kind == "dense" for r_ in ora for o in r_) and not all(o.kind == "dense" and not o.adjoint for r_ in ora for o in r_)
+        if one_launch:
+            stats["one_launch"] = stats.get("one_launch", 0) + 1
+            assert_bits_equal(d.to_numpy(), np.concatenate(ref), "forward (one-launch loop), " + tag)
+        elif (nrow == 1 and ncol > 64 and uniform) or has_adj or big:
             single = np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4
             assert werr(d.to_numpy(), np.concatenate(ref)) < (2e-6 if single else 1e-14), "forward (tolerance), " + tag
         else:
@@ -119,10 +126,15 @@ for case in range(seed0, seed0 + ncases):
         got = mt.to_numpy()
         keep = np.concatenate([np.full(col_len[j], any((i, j) in mats for i in range(nrow)) or nrow > 1) for j in range(ncol)])
         assert werr(got[keep], np.concatenate(truth)[keep]) < (2e-6 if single else 1e-14), "adjoint, " + tag
+        if one_launch:
+            hmt = u01(oracle, dt, 4, case, NC)
+            refm = oracle.block_df_adj(ora, [hmt[offc[j]:offc[j + 1]].copy() for j in range(ncol)], [hdd[offr[i]:offr[i + 1]].copy() for i in range(nrow)])
+            assert_bits_equal(got, np.concatenate(refm), "adjoint (one-launch loop), " + tag)
     except Exception as e:
         print("FAIL", tag)
         print(repr(e)[:1500])
         raise SystemExit(1)
     if (case - seed0 + 1) % 100 == 0:
         print(f"{case - seed0 + 1} cases ok ({stats}), {time.time() - t0:.0f} s", flush=True)
-print(f"fuzz_dense: {ncases} cases ok ({stats['batched']} on the batched kernels, {stats['loop']} on the per-block loop), {time.time() - t0:.0f} s")
+print(f"fuzz_dense: {ncases} cases ok ({stats['batched']} on the batched kernels, {stats['loop']} others, of which {stats.get('one_launch', 0)} on the one-launch loop "
+      f"-- forward and adjoint bit-exact), {time.time() - t0:.0f} s")
