@@ -2,6 +2,8 @@
 
 configs[1]  (64x1, 128^3 Float32): the whole forward and adjoint are compared bit for bit with the
             CPU oracle (512 MiB per vector; the oracle finishes in seconds).
+configs[2]  (A' o A on a 256x1 tall operator, 128^3 and 256^3 blocks): fused kernel vs oracle slices, vs the unfused chain on
+            the whole vector, and <m, A'A m> = ||A m||^2.
 configs[3]  (1024x1, 256^3 Float32; 64 GiB of coefficients + 64 GiB range vector, cannot be held on a
             host): inputs are generated on the device by the counter-based generator and checked
             through size-independent properties --
@@ -46,6 +48,36 @@ def test_config2_64x128cubed_whole_vectors_bit_exact(Jets, oracle):
     assert_bits_equal(out.to_numpy(), np.concatenate(ref_d), "forward, 64 x 128^3")
     lhs, rhs = Jets.dot_product_test(A, m, Jets.rand(Jets.range(A), seed=3, stream=1))
     assert abs(lhs - rhs) / abs(lhs + rhs) < 1e-5
+
+
+@pytest.mark.parametrize("edge", [128, 256])
+def test_config3_normal_equations_matvec_on_256x1(Jets, oracle, edge):
+    """BASELINE.json configs[2]: JetComposite A' o A on a 256 x 1 tall JopBlock (src/Jets.jl:530-534 over (A', A)), at its own
+    size with both block sizes SURVEY.md 8d names (128^3: 2 GiB of coefficients, 256^3: 16 GiB).  The fused kernel against
+      * the oracle's normal_df on regenerated slices of the inputs -- all 256 rows summed in order, bit for bit,
+      * the unfused chain A'(A m) on the device, on the WHOLE vector (max |difference| == 0),
+      * the reductions the solver takes of it (<m, A'A m> = ||A m||^2 to 1e-5)."""
+    import math
+
+    nblocks = 256
+    n = edge ** 3
+    A, coeff, m, d = _build(Jets, nblocks, edge)
+    C = A.H @ A
+    y = Jets.mul(C, m)
+    W = 4096
+    for off in (0, (n // 3) // 4 * 4, n // 2 + 64, n - W):
+        ha = [oracle.rng_u01(np.float32, 1, 0, i * n + off, W) for i in range(nblocks)]
+        hm = oracle.rng_u01(np.float32, 2, 0, off, W)
+        ref = oracle.normal_df([[oracle.Block("diag", W, coeff=g)] for g in ha], [np.zeros(W, dtype=np.float32)], [hm])[0]
+        assert_bits_equal(y._download(off, W), ref, f"fused A'A slice at {off}, 256 x {edge}^3")
+    Jets.mul_(d, A, m)                                                     # the chain through the range vector
+    y_chain = Jets.mul_(Jets.zeros(Jets.domain(A)), A.H, d)
+    assert float(Jets.norm((y - y_chain).materialize(), math.inf)) == 0.0  # bit-identical on every element
+    lhs, rhs = float(Jets.dot(m, y)), float(Jets.norm(d, 2)) ** 2          # <m, A'A m> == ||A m||^2
+    assert abs(lhs - rhs) <= 1e-5 * abs(rhs)
+    # composite plumbing at this size: the adjoint of the composite is the same operator
+    y2 = Jets.mul(C.H, m)
+    assert float(Jets.norm((y - y2).materialize(), math.inf)) == 0.0
 
 
 def test_config4_1024x256cubed_properties(Jets, oracle):
