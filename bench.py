@@ -356,10 +356,28 @@ def main():
     if args.lsqr:
         x_true = J.rand(J.domain(A), seed=4, stream=0)
         J.mul_(d, A, x_true)                                   # b = A x_true (this rank's rows), in the range vector's storage
+        # N > 1: the whole distributed loop behind the C ABI (jh_lsqr_solve_partitioned over the ABI's own RCCL communicator:
+        # ranged steps, ranged all-reduces on the exchange stream, one host synchronisation per step) when every rank can set it
+        # up; otherwise the Python driver over torch.distributed.  BENCH_LSQR_ABI=0 forces the latter.
+        target, lsqr_driver = (shard if shard is not None else A), ("python driver over torch.distributed" if shard is not None else "jh_lsqr_solve")
+        if dist is not None and world > 1 and dist.get_backend() == "nccl" and os.environ.get("BENCH_LSQR_ABI", "1") == "1":
+            import ctypes as _C
+
+            from jets_jl_amd._ffi import lib as _lib
+
+            ok = torch.tensor([1 if _lib.jh_comm_unique_id(_C.create_string_buffer(128)) == 0 else 0], device="cuda")   # loads librccl: no collective yet
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                def exchange_id(raw):
+                    box = [raw]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+
+                abi = J.rowpart.AbiComm(world, rank, exchange_id=exchange_id)
+                target, lsqr_driver = J.rowpart.for_device(part, A, comm=abi), "jh_lsqr_solve_partitioned (C ABI communicator, pipelined exchange)"
         fence()
         t_l = time.perf_counter()
-        res = J.lsqr(shard if shard is not None else A, d, atol=0.0, btol=0.0, conlim=0.0, maxiter=args.lsqr, overwrite_b=True,
-                     force_maxiter=True)
+        res = J.lsqr(target, d, atol=0.0, btol=0.0, conlim=0.0, maxiter=args.lsqr, overwrite_b=True, force_maxiter=True)
         fence()
         t_l = time.perf_counter() - t_l
         if dist is not None:
@@ -373,7 +391,7 @@ def main():
         it_bytes = ((3 if one_pass else 5) * nblocks * n + (12 if one_pass else 11) * n * world) * s
         extra["lsqr"] = {"iterations": res.itn, "ms_per_iteration": 1e3 * t_l / max(res.itn, 1), "algorithmic_bytes_per_iteration": it_bytes,
                          "GBps": it_bytes * res.itn / t_l / 1e9, "rel_err_vs_x_true": float(J.norm(err)) / float(J.norm(x_true)),
-                         "istop": res.istop, "r1norm_first_last": [res.history[0][1], res.history[-1][1]],
+                         "istop": res.istop, "r1norm_first_last": [res.history[0][1], res.history[-1][1]], "driver": lsqr_driver,
                          "schedule": ("one pass per iteration (jh_blockop_bidiag_step): u<-Av-(alpha/beta)u, ||u||^2 and A'u together; v<-A'u/beta-beta v on domain-sized vectors"
                                       if one_pass else "two fused halves: u<-Av-(alpha/beta)u with ||u||^2 (jh_blockop_mul_axpby), v<-A'u/beta-beta v with ||v||^2 (jh_blockop_mul_adj_axpby)")
                                      + "; u never normalised in memory"}

@@ -286,6 +286,16 @@ int jh_comm_destroy(void);
 int jh_comm_info(int *nranks, int *rank);
 int jh_comm_allreduce_sum(jh_bvec *v);
 int jh_comm_allreduce_scalars(double *values, int n, int op);   /* op: 0 sum, 1 max, 2 min; synchronises */
+/* Pipelined exchange.  jh_comm_allreduce_sum_range sums the elements [first_elem, first_elem+count) of v over all ranks on the
+ * communicator's OWN stream, ordered after everything enqueued on the library stream so far and concurrent with what is enqueued
+ * afterwards: call it after jh_blockop_mul_adj_range / jh_blockop_bidiag_step_range of a range and the all-reduce of that range
+ * runs while the kernel of the next range computes.  jh_comm_join makes the library stream wait for every ranged all-reduce
+ * enqueued so far (no host synchronisation).  jh_comm_allreduce_normsq returns the sum over all ranks of the deferred ||u||^2
+ * accumulator (jh_normsq_reset + ranged steps with normsq == NULL) behind the ranged all-reduces: the one host synchronisation
+ * of a distributed one-pass step.  Every rank enqueues the same ranges in the same order. */
+int jh_comm_allreduce_sum_range(jh_bvec *v, int64_t first_elem, int64_t count);
+int jh_comm_join(void);
+int jh_comm_allreduce_normsq(double *out);
 
 /* kernel-shape tuning knobs (bench/tests only): 0 = automatic (fwd_order: -1); name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg","fwd_order","nt","autotune" (0: tall forwards keep the size-based default shape; 1: per-operator lazy measurement, see jh_blockop_tune_get),
  * "graphs" (1: operators that run the per-block loop -- those with DENSE blocks -- replay it as a hipGraph from the

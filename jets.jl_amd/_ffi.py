@@ -128,6 +128,9 @@ SYMBOLS = {
     "jh_comm_info": (_int, [_intp, _intp]),
     "jh_comm_allreduce_sum": (_int, [_vp]),
     "jh_comm_allreduce_scalars": (_int, [_dblp, _int, _int]),
+    "jh_comm_allreduce_sum_range": (_int, [_vp, _i64, _i64]),
+    "jh_comm_join": (_int, []),
+    "jh_comm_allreduce_normsq": (_int, [_dblp]),
     "jh_tune_set": (_int, [C.c_char_p, _i64]),
     "jh_tune_get": (_int, [C.c_char_p, _i64p]),
     "jh_blockop_tune_get": (_int, [_vp, C.c_char_p, _i64p]),

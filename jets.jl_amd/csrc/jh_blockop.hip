@@ -1655,8 +1655,6 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
 }
 
 // ---- fused solver updates: launch + partial fold ---------------------------------------------------
-constexpr int JH_NORMSQ_SLOT = 8;     // red_dev[8]: the deferred ||u||^2 accumulator (jh_normsq_reset / jh_normsq_read)
-
 // normsq != NULL: read the folded sum back (synchronises).  normsq == NULL and defer: add it to the device-side accumulator
 // instead (no host synchronisation at all).  normsq == NULL and !defer: the caller does not want the norm.
 int finish_normsq(int64_t nparts, double *normsq, bool defer = false)

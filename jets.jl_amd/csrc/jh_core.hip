@@ -474,6 +474,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "autotune")) { c.autotune = value ? 1 : 0; }
     else if (!strcmp(name, "graphs")) { c.graphs = value ? 1 : 0; }
     else if (!strcmp(name, "small_loop")) { c.small_loop = value ? 1 : 0; }
+    else if (!strcmp(name, "force_dist")) { c.force_dist = value ? 1 : 0; }
     else if (!strcmp(name, "general_xcd")) { JH_REQUIRE(value >= 0 && value <= 2, "general_xcd must be 0 (never), 1 (automatic) or 2 (always)"); c.general_xcd = value; }
     else if (!strcmp(name, "red_wgs")) { JH_REQUIRE(value >= 1 && value <= 1 << 20, "red_wgs out of range"); c.red_wgs = value; }
     else return jh_fail(JH_ERR_INVALID, "jh_tune_set: unknown knob '%s'", name);
@@ -499,6 +500,7 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "autotune")) *value = c.autotune;
     else if (!strcmp(name, "graphs")) *value = c.graphs;
     else if (!strcmp(name, "small_loop")) *value = c.small_loop;
+    else if (!strcmp(name, "force_dist")) *value = c.force_dist;
     else if (!strcmp(name, "general_xcd")) *value = c.general_xcd;
     else if (!strcmp(name, "graph_replays")) *value = c.graph_replays;
     else if (!strcmp(name, "last_fwd_rows_per_wg")) *value = c.last_fwd_rows_per_wg;

@@ -57,6 +57,7 @@ struct jh_context {
     int64_t autotune = 1;              // time both grid walks of the tall forward once per large operator
     int64_t general_xcd = 1;           // general M x K kernels: 1 = XCD-aware (line, tile) decode from 32 MiB of input on, else line by line; 0 never; 2 always
     int64_t graphs = 1;                // replay launch-bound per-block loops as hipGraphs (jh_blockop.hip: run_loop_graphed)
+    int64_t force_dist = 0;            // tests: jh_lsqr_solve_partitioned runs its exchange even with ONE rank (validates the pipelined path on a one-GPU box)
     int64_t small_loop = 1;            // operators mixing small DENSE children with other kinds: the whole block loop in one launch (0: the per-block loop)
     int64_t graph_replays = 0;         // read-only counter: hipGraphLaunch calls made by run_loop_graphed
     uint64_t buf_gen = 0;              // bumped whenever part_dev / scratch_dev is reallocated: captured graphs holding the old pointers are stale
@@ -69,6 +70,7 @@ jh_context &jh_ctx();
 int jh_require_ready();
 
 constexpr int JH_RED_SLOTS = 4096;     // max workgroups in a reduction launch
+constexpr int JH_NORMSQ_SLOT = 8;      // red_dev[8]: the deferred ||u||^2 accumulator (jh_normsq_reset / jh_normsq_read / jh_comm_allreduce_normsq)
 
 static inline size_t jh_dtype_size(int dtype)
 {
@@ -165,4 +167,5 @@ int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, co
 int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, int dtype, void *y, const void *x,
                            int adjoint, bool aligned, bool wide, const int64_t *dev_row_off = nullptr);   // jh_dense.hip: every child of a tall (or wide) operator of uniform dense blocks at once
 int jh_ensure_scratch(size_t bytes, void **out);
+extern "C" int jh_comm_exists(int *yes);  // jh_comm.hip (internal): is a communicator alive?
 extern "C" int jh_comm_destroy(void);   // jh_comm.hip; jh_shutdown tears the communicator down first   // growable device scratch (block-loop temporaries)

@@ -144,6 +144,8 @@ static int lsqr_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, d
     double *parts_v = t.parts, *parts_w = t.parts + grid, *slot_v = t.parts + 2 * grid, *slot_w = slot_v + 1;
     jh_context &c = jh_ctx();
     *res = jh_lsqr_result{};
+    int64_t chunk = (n + 3) / 4;                                          // exchange ranges: 4, on 64 KiB boundaries
+    chunk = (chunk + 16383) / 16384 * 16384;
 
     auto global_sum = [&](double local, double *out) -> int {
         *out = local;
@@ -188,9 +190,21 @@ static int lsqr_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, d
             // ---- bidiagonalisation in one pass:  beta*u = A v - alpha*u ;  alpha*v = A'u - beta*v
             const double beta_prev = beta;
             double local = 0.0;
-            JH_TRY(jh_blockop_bidiag_step(op, u, t.v, t.atu, 1.0, -alpha / beta_prev, &local));
-            if (dist) JH_TRY(jh_comm_allreduce_sum(t.atu));
-            JH_TRY(global_sum(local, &s2));
+            if (dist) {
+                // this rank's rows in 4 element ranges: the all-reduce of a finished range of A'u runs on the exchange stream while
+                // the kernel of the next range computes; ||u||^2 accumulates on the device and is summed over the ranks behind the
+                // last range -- ONE host synchronisation for the whole distributed step
+                JH_TRY(jh_normsq_reset());
+                for (int64_t lo = 0; lo < n; lo += chunk) {
+                    const int64_t cnt = lo + chunk < n ? chunk : n - lo;
+                    JH_TRY(jh_blockop_bidiag_step_range(op, u, t.v, t.atu, 1.0, -alpha / beta_prev, lo, cnt, nullptr));
+                    JH_TRY(jh_comm_allreduce_sum_range(t.atu, lo, cnt));
+                }
+                JH_TRY(jh_comm_allreduce_normsq(&s2));
+            } else {
+                JH_TRY(jh_blockop_bidiag_step(op, u, t.v, t.atu, 1.0, -alpha / beta_prev, &local));
+                s2 = local;
+            }
             beta = std::sqrt(s2);
             if (wnorm_pending) {                                         // the step's read-back synchronised the stream: it has landed
                 wnorm = std::sqrt(c.red_host[5]);
@@ -280,8 +294,11 @@ extern "C" int jh_lsqr_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int u
 extern "C" int jh_lsqr_solve_partitioned(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol,
                                          double conlim, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history)
 {
-    int nranks = 1, rank = 0;
+    int nranks = 1, rank = 0, has_comm = 0;
     (void)jh_comm_info(&nranks, &rank);
-    // one rank: nothing to exchange (jh_comm_init_rank is then optional, so a one-GPU run of partitioned host code works)
-    return lsqr_impl(op, u, x, use_x0, damp, atol, btol, conlim, maxiter, force_maxiter, res, history, nranks > 1);
+    (void)jh_comm_exists(&has_comm);
+    // one rank: nothing to exchange (jh_comm_init_rank is then optional, so a one-GPU run of partitioned host code works);
+    // the knob force_dist runs the exchange all the same (validation of the pipelined path with a one-rank communicator)
+    return lsqr_impl(op, u, x, use_x0, damp, atol, btol, conlim, maxiter, force_maxiter, res, history,
+                     nranks > 1 || (has_comm && jh_ctx().force_dist));
 }

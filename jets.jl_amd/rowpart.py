@@ -167,6 +167,8 @@ class RowPartitionedOp:
         local = self._pipelined_step(u_local, v, w, alpha, beta)
         if local is None:
             return None
+        if isinstance(local, tuple):                          # (value, True): already summed over the ranks (jh_comm_allreduce_normsq)
+            return local[0]
         return self.comm.all_reduce_scalars([local], "sum")[0]
 
     def mul_(self, d_local, m):
@@ -206,6 +208,8 @@ def for_device(part: RowPartition, local_op, comm=None) -> RowPartitionedOp:
     from .jets import mul_, adjoint
 
     if comm is not None:
+        if isinstance(comm, AbiComm):
+            return _for_device_abi(part, local_op, comm)
         return RowPartitionedOp(part, local_op, comm, lambda d, A, m: mul_(d, A, m), lambda m, A, d: mul_(m, adjoint(A), d), dot, norm)
     import torch
 
@@ -248,13 +252,7 @@ def for_device(part: RowPartition, local_op, comm=None) -> RowPartitionedOp:
         return _blk._native_op(jt.s.get("_native"), jt.s["ops"], jt.rng.eltype())
 
     def chunk_bounds(n):
-        step = -(-n // nchunks)
-        step = -(-step // 16384) * 16384                      # chunk bounds on 64 KiB boundaries
-        lo = 0
-        while lo < n:
-            cnt = builtins.min(step, n - lo)
-            yield lo, cnt
-            lo += cnt
+        return _chunk_bounds(n, nchunks)
 
     def exchange(t, lo, cnt, works):
         with torch.cuda.stream(ext):                          # RCCL's stream waits for the library stream up to here
@@ -308,6 +306,75 @@ def for_device(part: RowPartition, local_op, comm=None) -> RowPartitionedOp:
         check(lib.jh_normsq_read(C.byref(out)))                # the one read-back (library stream: kernels only, not the exchange)
         join(works)
         return out.value
+
+    return RowPartitionedOp(part, local_op, comm, lambda d, A, m: mul_(d, A, m), lambda m, A, d: mul_(m, adjoint(A), d), dot, norm,
+                            pipelined_adj=pipelined_adj, pipelined_step=pipelined_step)
+
+
+def _chunk_bounds(n: int, nchunks: int):
+    step = -(-n // nchunks)
+    step = -(-step // 16384) * 16384                          # chunk bounds on 64 KiB boundaries
+    lo = 0
+    while lo < n:
+        cnt = builtins.min(step, n - lo)
+        yield lo, cnt
+        lo += cnt
+
+
+def _for_device_abi(part: RowPartition, local_op, comm: AbiComm) -> RowPartitionedOp:
+    """The same wiring over the C ABI's own communicator and exchange stream (jh_comm_allreduce_sum_range / jh_comm_join /
+    jh_comm_allreduce_normsq): what a host without torch.distributed gets -- the pipelined adjoint and the pipelined one-pass
+    step with ONE host synchronisation per step."""
+    import os
+
+    from ._ffi import lib, check, JetsHipError
+    from . import jetblock as _blk
+    from .arrays import dot, norm
+    from .jets import mul_, adjoint
+
+    nchunks = int(os.environ.get("JETS_AR_CHUNKS", "4"))
+
+    def native_of(A):
+        if nchunks <= 1 or not _blk.isblockop(A):             # (with one rank the caller only comes here when forced: validation)
+            return None
+        jt = A.jet
+        return _blk._native_op(jt.s.get("_native"), jt.s["ops"], jt.rng.eltype())
+
+    def pipelined_adj(m, A, d) -> bool:
+        nat = native_of(A)
+        if nat is None:
+            return False
+        done = 0
+        try:
+            for lo, cnt in _chunk_bounds(m.length(), nchunks):
+                check(lib.jh_blockop_mul_adj_range(nat.handle, m.handle, d.handle, lo, cnt))
+                check(lib.jh_comm_allreduce_sum_range(m.handle, lo, cnt))
+                done += 1
+        except JetsHipError as e:
+            if e.status == 4 and done == 0:
+                return False
+            raise
+        check(lib.jh_comm_join())
+        return True
+
+    def pipelined_step(u, v, w, alpha, beta):
+        nat = native_of(local_op)
+        if nat is None:
+            return None
+        out = C.c_double(0)
+        done = 0
+        try:
+            check(lib.jh_normsq_reset())
+            for lo, cnt in _chunk_bounds(w.length(), nchunks):
+                check(lib.jh_blockop_bidiag_step_range(nat.handle, u.handle, v.handle, w.handle, float(alpha), float(beta), lo, cnt, None))
+                check(lib.jh_comm_allreduce_sum_range(w.handle, lo, cnt))
+                done += 1
+        except JetsHipError as e:
+            if e.status == 4 and done == 0:
+                return None
+            raise
+        check(lib.jh_comm_allreduce_normsq(C.byref(out)))     # global ||u||^2; kernels and ranged all-reduces are complete on return
+        return (out.value, True)
 
     return RowPartitionedOp(part, local_op, comm, lambda d, A, m: mul_(d, A, m), lambda m, A, d: mul_(m, adjoint(A), d), dot, norm,
                             pipelined_adj=pipelined_adj, pipelined_step=pipelined_step)

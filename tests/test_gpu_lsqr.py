@@ -185,6 +185,39 @@ def test_c_abi_rccl_entry_points_with_one_rank(Jets, oracle):
         res = Jets.lsqr(shard, A * x_true, atol=1e-5, btol=1e-5, maxiter=200)          # row-partitioned engine, one rank
         err = (res.x - x_true).materialize()
         assert float(Jets.norm(err)) / float(Jets.norm(x_true)) < 1e-3
+        # the pipelined exchange of the ABI (its own stream + events) with the one-rank communicator: 81 920 elements = three ranges
+        shape2 = (64, 64, 20)
+        n2 = int(np.prod(shape2))
+        B, _, ops2, _ = make_tall_diag(Jets, oracle, dt, 5, shape2)
+        shard2 = Jets.rowpart.for_device(Jets.rowpart.partition_rows(5, 1, 0), B, comm=comm)
+        d2 = Jets.rand(Jets.range(B), seed=74, stream=0)
+        hd2 = u01(oracle, dt, 74, 0, 5 * n2)
+        mt2 = Jets.rand(Jets.domain(B), seed=75, stream=0)            # dirty
+        shard2.mul_adj_(mt2, d2, force_collective=True)               # jh_blockop_mul_adj_range + jh_comm_allreduce_sum_range x 3, jh_comm_join
+        ref2 = oracle.block_df_adj(ops2, [np.zeros(n2, dtype=dt)], [hd2[i * n2:(i + 1) * n2].copy() for i in range(5)])
+        assert_bits_equal(mt2.to_numpy().ravel(order="F"), ref2[0], "pipelined adjoint through the ABI's exchange stream")
+        v = Jets.rand(Jets.domain(B), seed=76, stream=0)
+        u1, u2 = Jets.rand(Jets.range(B), seed=77, stream=0), Jets.rand(Jets.range(B), seed=77, stream=0)
+        w1, w2 = Jets.zeros(Jets.domain(B)), Jets.zeros(Jets.domain(B))
+        nrm2 = shard2.bidiag_step_(u1, v, w1, 0.75, -0.5, force_collective=True)       # ranged steps + ranged all-reduces + jh_comm_allreduce_normsq
+        import ctypes as C
+        from jets_jl_amd._ffi import lib, check
+        out = C.c_double(0)
+        check(lib.jh_blockop_bidiag_step(_native(Jets, B).handle, u2.handle, v.handle, w2.handle, 0.75, -0.5, C.byref(out)))
+        assert_bits_equal(u1.to_numpy(), u2.to_numpy(), "pipelined step: u")
+        assert_bits_equal(w1.to_numpy(), w2.to_numpy(), "pipelined step: w")
+        assert nrm2 == pytest.approx(out.value, rel=1e-13)
+        # jh_lsqr_solve_partitioned with its exchange forced on (knob force_dist): the C++ loop's pipelined distributed step
+        x2 = Jets.rand(Jets.domain(B), seed=78, stream=0)
+        try:
+            Jets.tune(force_dist=1)
+            r_dist = Jets.lsqr(shard2, B * x2, atol=0.0, btol=0.0, conlim=0.0, maxiter=20)
+        finally:
+            Jets.tune(force_dist=0)
+        r_loc = Jets.lsqr(B, B * x2, atol=0.0, btol=0.0, conlim=0.0, maxiter=20)
+        assert r_dist.itn == r_loc.itn == 20
+        np.testing.assert_allclose(r_dist.x.to_numpy(), r_loc.x.to_numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose([h[1] for h in r_dist.history], [h[1] for h in r_loc.history], rtol=1e-6)
     finally:
         comm.close()
     with pytest.raises(Jets.JetsHipError):
