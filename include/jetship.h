@@ -219,7 +219,9 @@ int jh_blockop_mul_adj_range(const jh_blockop *op, jh_bvec *m, const jh_bvec *d,
  * unfused pair, so the result is bit-identical to jh_blockop_mul followed by jh_blockop_mul_adj. */
 int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m);
 /* JetSum of tall operators, src/Jets.jl:628-655, fused: d = sum_k sign_k*(scale_k*(A_k m)) and its adjoint
- * m = sum_k sign_k*(A_k'(scale_k d)) for up to 4 tall all-DIAG operators of identical shape (the terms A_k or s_k*A_k of
+ * m = sum_k sign_k*(A_k'(scale_k d)) for tall all-DIAG operators of identical shape, ANY number of them (four per launch, later
+ * launches continuing the left-to-right sum: same sequence; (K + 2*ceil(K/4) - 1) range-sized streams where the unfused chain
+ * moves 5K + 1) (the terms A_k or s_k*A_k of
  * `1.0*A1 - 2.0*A2 + ...`, docs/src/index.md), one pass over the range vector, same rounding sequence as the unfused
  * chain (one temporary + one accumulate pass per term).  sign_k is +1 or -1, scale_k = 1 for a bare operator. */
 int jh_blocksum_mul(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, jh_bvec *d, const jh_bvec *m);

@@ -647,8 +647,9 @@ struct SumArgs {
 
 template <typename S, int E, int NS, int U, int BLK>
 __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow, int rows_per_wg, const S *__restrict__ m,
-                                                      S *__restrict__ d, int64_t n_scalars, unsigned ntiles)
+                                                      S *__restrict__ d, int64_t n_scalars, unsigned ntiles, int accumulate)
 {
+    // accumulate != 0: continue the left-to-right sum from what d holds (terms 5..8, 9..12, ... of a long JetSum: same sequence)
     typedef typename vec_of<S, NS>::type V;
     const unsigned tile = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
     const int64_t s0 = ((int64_t)tile * U * BLK + threadIdx.x) * NS;
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow
             }
 #pragma unroll
         for (int k = 0; k < U; k++) {
-            V acc = (V)(S)0;                                                     // d .= 0  (639-640)
+            V acc = accumulate ? ld<true>(reinterpret_cast<const V *>(d + i * n_scalars + sk[k])) : (V)(S)0;   // d .= 0  (639-640)
 #pragma unroll
             for (int t = 0; t < JH_SUM_MAX; t++)
                 if (t < args.k) {
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow
 
 template <typename S, int E, int NS, int U, int DEPTH, int BLK>
 __global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow, S *__restrict__ out, const S *__restrict__ in,
-                                                      int64_t n_scalars)
+                                                      int64_t n_scalars, int accumulate)
 {
     typedef typename vec_of<S, NS>::type V;
     const int64_t s0 = ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow
     }
 #pragma unroll
     for (int k = 0; k < U; k++) {
-        V r = (V)(S)0;                                                           // m .= 0  (648-649)
+        V r = accumulate ? ld<false>(reinterpret_cast<const V *>(out + sk[k])) : (V)(S)0;   // m .= 0  (648-649), or the sum so far
 #pragma unroll
         for (int t = 0; t < JH_SUM_MAX; t++)
             if (t < args.k) r = r + (V)(S)args.sign[t] * acc[t][k];              // broadcast!(sgn, m, m, _m)
@@ -2465,7 +2466,7 @@ static int sum_prepare(int nterms, const jh_blockop *const *ops, const double *s
                        const jh_bvec *dom, SumArgs &a, const char *who)
 {
     JH_REQUIRE(ops && scale && sign && rng && dom, "%s: null argument", who);
-    JH_REQUIRE(nterms >= 1 && nterms <= JH_SUM_MAX, "%s: %d terms (1..%d supported)", who, nterms, JH_SUM_MAX);
+    JH_REQUIRE(nterms >= 1 && nterms <= JH_SUM_MAX, "%s: %d terms in one group (1..%d)", who, nterms, JH_SUM_MAX);
     a.k = nterms;
     for (int t = 0; t < nterms; t++) {
         const jh_blockop *op = ops[t];
@@ -2487,7 +2488,7 @@ static int sum_prepare(int nterms, const jh_blockop *const *ops, const double *s
 }
 
 template <typename S, int E, int NS>
-static int sum_fwd_launch(const SumArgs &a, const jh_blockop *op0, void *d, const void *m, int64_t n_scalars)
+static int sum_fwd_launch(const SumArgs &a, const jh_blockop *op0, void *d, const void *m, int64_t n_scalars, int accumulate)
 {
     jh_context &c = jh_ctx();
     constexpr int BLK = 256, U = 2;
@@ -2499,7 +2500,7 @@ static int sum_fwd_launch(const SumArgs &a, const jh_blockop *op0, void *d, cons
     while (gx * gy * BLK >= ((int64_t)1 << 32) && G < op0->nrow) { G *= 2; gy = (op0->nrow + G - 1) / G; }
     JH_REQUIRE(gx * gy * BLK < ((int64_t)1 << 32), "fused sum forward: grid too large");
     hipLaunchKernelGGL((k_tall_sum_fwd<S, E, NS, U, BLK>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G,
-                       (const S *)m, (S *)d, n_scalars, (unsigned)gx);
+                       (const S *)m, (S *)d, n_scalars, (unsigned)gx, accumulate);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -2522,7 +2523,7 @@ static int sum_adj_split(int nterms, const jh_blockop *const *ops, const double 
 }
 
 template <typename S, int E, int NS>
-static int sum_adj_launch(const SumArgs &a, const jh_blockop *op0, void *m, const void *d, int64_t n_scalars)
+static int sum_adj_launch(const SumArgs &a, const jh_blockop *op0, void *m, const void *d, int64_t n_scalars, int accumulate)
 {
     jh_context &c = jh_ctx();
     c.last_adj_parts = 1;
@@ -2530,40 +2531,71 @@ static int sum_adj_launch(const SumArgs &a, const jh_blockop *op0, void *m, cons
     const int64_t nvec = n_scalars / NS;
     const int64_t gx = (nvec + (int64_t)BLK * U - 1) / ((int64_t)BLK * U);
     hipLaunchKernelGGL((k_tall_sum_adj<S, E, NS, U, DEPTH, BLK>), dim3((unsigned)gx), dim3(BLK), 0, c.stream, a, op0->nrow, (S *)m,
-                       (const S *)d, n_scalars);
+                       (const S *)d, n_scalars, accumulate);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
 
 extern "C" {
 
+// Any number of terms: groups of JH_SUM_MAX, every group after the first continuing the left-to-right sum from what the output
+// holds -- the unfused chain's sequence ((0 +- t1) +- t2) +- ... whatever the grouping.
 int jh_blocksum_mul(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, jh_bvec *d, const jh_bvec *m)
 {
     JH_TRY(jh_require_ready());
-    SumArgs a;
-    JH_TRY(sum_prepare(nterms, ops, scale, sign, d, m, a, "jh_blocksum_mul"));
-    const int64_t n = ops[0]->row_len[0];
-    switch (ops[0]->dtype) {
-    case JH_F32: return sum_fwd_launch<float, 1, 4>(a, ops[0], d->data, m->data, n);
-    case JH_F64: return sum_fwd_launch<double, 1, 2>(a, ops[0], d->data, m->data, n);
-    case JH_C32: return sum_fwd_launch<float, 2, 4>(a, ops[0], d->data, m->data, 2 * n);
-    case JH_C64: return sum_fwd_launch<double, 2, 2>(a, ops[0], d->data, m->data, 2 * n);
+    JH_REQUIRE(ops && scale && sign && d && m, "jh_blocksum_mul: null argument");
+    JH_REQUIRE(nterms >= 1 && nterms <= 4096, "jh_blocksum_mul: %d terms (1..4096 supported)", nterms);
+    for (int t = 0; t < nterms; t++) {                                   // validate EVERYTHING before the first launch touches d
+        JH_REQUIRE(ops[t], "jh_blocksum_mul: null operator %d", t);
+        SumArgs probe;
+        JH_TRY(sum_prepare(1, ops + t, scale + t, sign + t, d, m, probe, "jh_blocksum_mul"));
+        JH_REQUIRE(ops[t]->nrow == ops[0]->nrow && ops[t]->row_len[0] == ops[0]->row_len[0] && ops[t]->dtype == ops[0]->dtype,
+                   "jh_blocksum_mul: term %d has a different shape or element type", t);
     }
-    return jh_fail(JH_ERR_INVALID, "jh_blocksum_mul: unknown dtype");
+    const int64_t n = ops[0]->row_len[0];
+    for (int t0 = 0; t0 < nterms; t0 += JH_SUM_MAX) {
+        const int k = nterms - t0 < JH_SUM_MAX ? nterms - t0 : JH_SUM_MAX;
+        SumArgs a;
+        JH_TRY(sum_prepare(k, ops + t0, scale + t0, sign + t0, d, m, a, "jh_blocksum_mul"));
+        const int acc = t0 > 0 ? 1 : 0;
+        int st = JH_OK;
+        switch (ops[0]->dtype) {
+        case JH_F32: st = sum_fwd_launch<float, 1, 4>(a, ops[0], d->data, m->data, n, acc); break;
+        case JH_F64: st = sum_fwd_launch<double, 1, 2>(a, ops[0], d->data, m->data, n, acc); break;
+        case JH_C32: st = sum_fwd_launch<float, 2, 4>(a, ops[0], d->data, m->data, 2 * n, acc); break;
+        case JH_C64: st = sum_fwd_launch<double, 2, 2>(a, ops[0], d->data, m->data, 2 * n, acc); break;
+        default: return jh_fail(JH_ERR_INVALID, "jh_blocksum_mul: unknown dtype");
+        }
+        JH_TRY(st);
+    }
+    return JH_OK;
 }
 
 int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, jh_bvec *m, const jh_bvec *d)
 {
     JH_TRY(jh_require_ready());
-    SumArgs a;
-    JH_TRY(sum_prepare(nterms, ops, scale, sign, d, m, a, "jh_blocksum_mul_adj"));
+    JH_REQUIRE(ops && scale && sign && d && m, "jh_blocksum_mul_adj: null argument");
+    JH_REQUIRE(nterms >= 1 && nterms <= 4096, "jh_blocksum_mul_adj: %d terms (1..4096 supported)", nterms);
+    for (int t = 0; t < nterms; t++) {
+        JH_REQUIRE(ops[t], "jh_blocksum_mul_adj: null operator %d", t);
+        SumArgs probe;
+        JH_TRY(sum_prepare(1, ops + t, scale + t, sign + t, d, m, probe, "jh_blocksum_mul_adj"));
+        JH_REQUIRE(ops[t]->nrow == ops[0]->nrow && ops[t]->row_len[0] == ops[0]->row_len[0] && ops[t]->dtype == ops[0]->dtype,
+                   "jh_blocksum_mul_adj: term %d has a different shape or element type", t);
+    }
     const int64_t n = ops[0]->row_len[0];
     void *tmp = nullptr;
     switch (ops[0]->dtype) {
 #define JH_SUM_ADJ(S, E, NS, NSCAL)                                                                         \
     JH_TRY((split_adjoint_tmp<S, NS>(ops[0], NSCAL, &tmp)));                                              \
     if (tmp) return sum_adj_split<S, E, NS>(nterms, ops, scale, sign, m->data, d->data, NSCAL, tmp);      \
-    return sum_adj_launch<S, E, NS>(a, ops[0], m->data, d->data, NSCAL);
+    for (int t0 = 0; t0 < nterms; t0 += JH_SUM_MAX) {                                                       \
+        const int k = nterms - t0 < JH_SUM_MAX ? nterms - t0 : JH_SUM_MAX;                                  \
+        SumArgs a;                                                                                          \
+        JH_TRY(sum_prepare(k, ops + t0, scale + t0, sign + t0, d, m, a, "jh_blocksum_mul_adj"));          \
+        JH_TRY((sum_adj_launch<S, E, NS>(a, ops[0], m->data, d->data, NSCAL, t0 > 0 ? 1 : 0)));             \
+    }                                                                                                       \
+    return JH_OK;
     case JH_F32: JH_SUM_ADJ(float, 1, 4, n)
     case JH_F64: JH_SUM_ADJ(double, 1, 2, n)
     case JH_C32: JH_SUM_ADJ(float, 2, 4, 2 * n)

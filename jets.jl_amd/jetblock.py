@@ -622,7 +622,7 @@ def try_fused_sum(out, x, ops: Sequence[Jop], sgns: Sequence[str], transposed: b
     """JetSum_df / JetSum_df' (src/Jets.jl:639-655) when every term is a tall all-diagonal device-native block operator
     A_k or a real scalar times one (the composite (a, A_k)): one fused launch (jh_blocksum_mul / jh_blocksum_mul_adj).
     Returns None when the sum does not qualify."""
-    if not (1 <= len(ops) <= 4):
+    if not (1 <= len(ops) <= 4096):                          # any number of terms: the library groups them by four
         return None
     nats, scales = [], []
     for op in ops:

@@ -530,19 +530,46 @@ end
 # adjoint of a row-partitioned tall operator: local ordered sum, then the in-place all-reduce (src/Jets.jl:1045-1053 summed
 # over ranks).  In `chunks` element ranges (jh_blockop_mul_adj_range) when the host wants to hand finished ranges to its own
 # communication stream while the next range is computed.
-function mul_adj_partitioned!(m::HipArray{T}, A::JopLn, d_local::BlockArray{T,<:HipArray{T}}; chunks::Integer=1) where {T}
+function mul_adj_partitioned!(m::HipArray{T}, A::JopLn, d_local::BlockArray{T,<:HipArray{T}}; chunks::Integer=4) where {T}
     h = tall_native(A, T)
     if chunks <= 1
         check(ccall((:jh_blockop_mul_adj, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, handle(m), handle(d_local)))
-    else
-        n = length(m)
-        step = cld(cld(n, chunks), 16384) * 16384                         # chunk bounds on 64 KiB boundaries
-        for lo = 0:step:n-1
-            check(ccall((:jh_blockop_mul_adj_range, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64), h, handle(m), handle(d_local), lo, min(step, n - lo)))
-        end
+        return allreduce_sum!(m)
     end
-    allreduce_sum!(m)
+    # pipelined: the all-reduce of a finished range runs on the communicator's own stream while the next range is computed
+    n = length(m)
+    step = cld(cld(n, chunks), 16384) * 16384                             # chunk bounds on 64 KiB boundaries
+    for lo = 0:step:n-1
+        cnt = min(step, n - lo)
+        check(ccall((:jh_blockop_mul_adj_range, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64), h, handle(m), handle(d_local), lo, cnt))
+        check(ccall((:jh_comm_allreduce_sum_range, LIB), Cint, (Ptr{Cvoid}, Int64, Int64), handle(m), lo, cnt))
+    end
+    check(ccall((:jh_comm_join, LIB), Cint, ()))                           # the library stream waits for the exchange; no host sync
+    m
 end
+# one Golub-Kahan step of a row-partitioned operator, pipelined the same way; returns the GLOBAL ||u|| (the one host sync)
+function bidiag_step_partitioned!(u::BlockArray{T,<:HipArray{T}}, w::HipArray{T}, A::JopLn, v::HipArray{T}, alpha::Real, beta::Real; chunks::Integer=4) where {T}
+    h = tall_native(A, T)
+    check(ccall((:jh_normsq_reset, LIB), Cint, ()))
+    n = length(w)
+    step = cld(cld(n, chunks), 16384) * 16384
+    for lo = 0:step:n-1
+        cnt = min(step, n - lo)
+        check(ccall((:jh_blockop_bidiag_step_range, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Int64, Int64, Ptr{Cdouble}),
+                    h, handle(u), handle(v), handle(w), alpha, beta, lo, cnt, C_NULL))   # NULL: its share of ||u||^2 stays on the device
+        check(ccall((:jh_comm_allreduce_sum_range, LIB), Cint, (Ptr{Cvoid}, Int64, Int64), handle(w), lo, cnt))
+    end
+    nrm2 = Ref{Cdouble}()
+    check(ccall((:jh_comm_allreduce_normsq, LIB), Cint, (Ref{Cdouble},), nrm2))
+    sqrt(nrm2[])
+end
+# measured per-operator choices (the grid walk of the tall forward): read from one operator, set on another / in another process
+function tune_get(A::JopLn, name::AbstractString)
+    v = Ref{Int64}()
+    check(ccall((:jh_blockop_tune_get, LIB), Cint, (Ptr{Cvoid}, Cstring, Ref{Int64}), tall_native(A, eltype(range(A))), name, v))
+    v[]
+end
+tune_set!(A::JopLn, name::AbstractString, value::Integer) = check(ccall((:jh_blockop_tune_set, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), tall_native(A, eltype(range(A))), name, value))
 # range-side reductions of a row-partitioned vector: local fp64 partial, scalar all-reduce
 dot_partitioned(x::BlockArray{T,<:HipArray{T}}, y::BlockArray{T,<:HipArray{T}}) where {T<:Real} = T(allreduce_scalars!(Float64[dot(x, y)])[1])
 norm_partitioned(x::BlockArray{T,<:HipArray{T}}) where {T} = float(real(T))(sqrt(allreduce_scalars!(Float64[Float64(norm(x))^2])[1]))

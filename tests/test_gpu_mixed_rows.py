@@ -113,3 +113,44 @@ def test_lsqr_on_data_rows_plus_regularisation_and_a_muted_row(Jets, oracle):
     rmv = lambda u: sum(a * u[i * n:(i + 1) * n] for i, a in enumerate(a64) if a is not None)
     xr, _ = lsqr_fp64(mv, rmv, b.to_numpy().astype(np.float64), n, atol=0.0, btol=0.0, conlim=0.0, maxiter=25)
     assert np.linalg.norm(res.x.to_numpy().ravel() - xr) <= 1e-4 * np.linalg.norm(xr)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex128])
+@pytest.mark.parametrize("nterms", [2, 4, 5, 9, 13])
+def test_long_jetsum_keeps_the_unfused_rounding_sequence(Jets, oracle, dt, nterms):
+    """JetSum of MORE than four tall diagonal operators (src/Jets.jl:628-655): the fused kernels take the terms four at a time,
+    later launches continuing the left-to-right sum from what the output holds -- bit-identical to the unfused chain
+    d .= 0; d = d +- s_t (A_t m), whatever the grouping; same for the adjoint."""
+    J = Jets
+    nrow, n = 6, 512
+    spc = J.JetSpace(dt, n)
+    ops, hcoef = [], []
+    for t in range(nterms):
+        ops.append(J.blockop([[J.JopDiagonal(J.rand(spc, seed=90 + t, stream=i))] for i in range(nrow)]))
+        hcoef.append([u01(oracle, dt, 90 + t, i, n) for i in range(nrow)])
+    scales = [1.0 if t % 3 else 0.5 + t for t in range(nterms)]
+    signs = [1.0 if t % 2 == 0 or t == 0 else -1.0 for t in range(nterms)]
+    S = scales[0] * ops[0] if scales[0] != 1.0 else ops[0]
+    for t in range(1, nterms):
+        term = scales[t] * ops[t] if scales[t] != 1.0 else ops[t]
+        S = S + term if signs[t] > 0 else S - term
+    hm = u01(oracle, dt, 2, 0, n)
+    m = J.from_numpy(hm)
+    d = S * m
+    want = [np.zeros(n, dt) for _ in range(nrow)]
+    for t in range(nterms):
+        ora = [[oracle.Block("diag", n, coeff=c)] for c in hcoef[t]]
+        tmp = oracle.block_df(ora, [np.zeros(n, dt) for _ in range(nrow)], [hm])
+        if scales[t] != 1.0:
+            tmp = oracle.barr_lincomb([np.empty(n, dt) for _ in range(nrow)], [scales[t]], [tmp])      # (s*A) m = s * (A m)
+        want = oracle.barr_lincomb([np.empty(n, dt) for _ in range(nrow)], [1.0, signs[t]], [want, tmp])
+    assert_bits_equal(d.to_numpy(), np.concatenate(want), f"{nterms}-term sum, forward")
+    hd = [u01(oracle, dt, 3, i, n) for i in range(nrow)]
+    mt = S.H * J.from_numpy(np.concatenate(hd), J.range(ops[0]))
+    want_m = [np.zeros(n, dt)]
+    for t in range(nterms):
+        ora = [[oracle.Block("diag", n, coeff=c)] for c in hcoef[t]]
+        din = hd if scales[t] == 1.0 else oracle.barr_lincomb([np.empty(n, dt) for _ in range(nrow)], [np.conj(scales[t])], [hd])   # (s*A)' d = A'(conj(s) d)
+        tmp = oracle.block_df_adj(ora, [np.zeros(n, dt)], din)
+        want_m = oracle.barr_lincomb([np.empty(n, dt)], [1.0, signs[t]], [want_m, tmp])
+    assert_bits_equal(mt.to_numpy().ravel(order="F"), want_m[0], f"{nterms}-term sum, adjoint")

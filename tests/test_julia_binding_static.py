@@ -127,7 +127,9 @@ def test_every_julia_ccall_matches_the_header():
 
 @pytest.mark.parametrize("sym", ["jh_blockop_mul", "jh_blockop_mul_adj", "jh_blockop_normal_mul", "jh_dot", "jh_norm",
                                  "jh_getblock_copy", "jh_setblock_copy", "jh_bvec_create", "jh_blockop_create",
-                                 "jh_blockop_bidiag_step", "jh_lsqr_solve", "jh_comm_allreduce_sum"])
+                                 "jh_blockop_bidiag_step", "jh_lsqr_solve", "jh_comm_allreduce_sum", "jh_lsqr_solve_partitioned",
+                                 "jh_comm_allreduce_sum_range", "jh_comm_join", "jh_comm_allreduce_normsq", "jh_normsq_reset",
+                                 "jh_blockop_bidiag_step_range", "jh_blockop_mul_adj_range", "jh_blockop_tune_get", "jh_blockop_tune_set"])
 def test_hot_path_entry_points_are_bound_in_julia(sym):
     assert sym in {c[1] for c in julia_ccalls()}
 
