@@ -313,7 +313,8 @@ int jh_tune_get(const char *name, int64_t *value);
  * jh_blockop_mul runs the next candidate between two events -- no extra launches, no host synchronisation, jh_blockop_mul
  * returns after enqueue -- and after 12 calls the fastest is kept ("fwd_trials" counts the timed calls so far).  A host that
  * wants the steady state at once (or the same choice in every process) reads it from one operator and sets it on another;
- * setting -1 measures again.  "upd_walk" is the same for jh_blockop_mul_axpby (0 / 1, chosen over its first two calls). */
+ * setting -1 measures again.  "upd_walk" is the same for jh_blockop_mul_axpby (0 / 1, chosen over its first two calls), "step_remap"
+ * for jh_blockop_bidiag_step (XCD-contiguous tiles, 0 / 1, chosen over its first five whole-vector calls that return the norm). */
 int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value);
 int jh_blockop_tune_set(jh_blockop *op, const char *name, int64_t value);
 

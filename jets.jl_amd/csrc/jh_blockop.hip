@@ -433,9 +433,13 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
                                                           const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, int direct,
                                                           S alpha, S beta, double *__restrict__ partials, int64_t s_begin, int64_t s_end,
                                                           int64_t row0, int64_t row1, int accumulate, int64_t rows_per_part,
-                                                          S *__restrict__ part_out, int64_t part_stride)
+                                                          S *__restrict__ part_out, int64_t part_stride, int remap)
 {
     // rows [row0, row1); accumulate != 0 continues w's ordered sum from what it holds (several launches, the bits of one)
+    // remap != 0 (gridDim.x % 8 == 0): workgroups are dealt round-robin over the 8 XCDs, so id % 8 names the XCD; XCD x then owns
+    // one CONTIGUOUS eighth of the tiles instead of every eighth tile.  +4 % on this kernel at 128-256 rows of 64 MiB blocks when
+    // the rows sit at power-of-two strides, neutral or worse on other layouts (profiles/exp_r02_step_structure.txt), so it is
+    // chosen per operator by timing the first real calls (launch_bidiag).  Same values either way: only WHO computes a tile changes.
     // the launch covers the scalar range [s_begin, s_end) of the domain (the whole vector, or one chunk when a multi-GPU
     // host pipelines the exchange of w chunk by chunk against this kernel)
     // rows_per_part > 0: split-row walk, as in k_tall_diag_adj (u is updated row by row either way: same bits; w's sum is
@@ -447,7 +451,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
         w = part_out + (int64_t)blockIdx.y * part_stride - s_begin;
         accumulate = 0;
     }
-    const int64_t s0 = s_begin + ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
+    const unsigned tile = remap ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t s0 = s_begin + ((int64_t)tile * U * BLK + threadIdx.x) * NS;
     bool ok[U];
     int64_t sk[U];
     V acc[U], vv[U];
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
 #pragma unroll
     for (int k = 0; k < U; k++)
         if (ok[k]) st<false>(reinterpret_cast<V *>(w + sk[k]), acc[k]);
-    wg_sum_store<BLK>(nrm, partials + blockIdx.x + (size_t)blockIdx.y * gridDim.x);
+    wg_sum_store<BLK>(nrm, partials + tile + (size_t)blockIdx.y * gridDim.x);      // by tile: the fold's order does not depend on remap
 }
 
 // out[s] = sum over parts p = 0..nparts-1 (in that order within a part lane, part lanes in order) of parts[p][s - s_begin]:
@@ -1838,6 +1843,38 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     int64_t rows_per_launch = op->nrow;
     if (c.adj_rows_per_launch > 0) rows_per_launch = c.adj_rows_per_launch < op->nrow ? c.adj_rows_per_launch : op->nrow;
     if (parts > 1) rows_per_launch = op->nrow;
+    // XCD-contiguous tiles: per operator, by measurement.  Only whole-vector calls that read the norm back are timed (they
+    // synchronise anyway): calls 1-4 alternate off / on between two events, then the faster one stays (it must win by 1 %).
+    const bool remap_ok = parts == 1 && gx % 8 == 0 && gx >= 64 && rows_per_launch == op->nrow;
+    int remap = (remap_ok && op->step_remap > 0) ? 1 : 0;
+    int trial = -1;
+    if (remap_ok && op->step_remap < 0 && c.autotune && normsq && s_begin == 0 && s_end == n_scalars &&
+        3.0 * (double)op->nrow * (double)n_scalars * sizeof(S) >= 4.0 * (double)(1ull << 30)) {
+        trial = op->step_trials;                                  // 0 warms up (untimed), 1..4 are timed: off, on, off, on
+        remap = (trial >= 1) ? ((trial - 1) & 1) : 0;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (trial >= 1) {
+        JH_CHECK_HIP(hipEventCreate(&e0));
+        JH_CHECK_HIP(hipEventCreate(&e1));
+        JH_CHECK_HIP(hipEventRecord(e0, c.stream));
+    }
+    auto trial_done = [&](int st) {
+        if (trial >= 1) {
+            float ms = 0.f;
+            if (st == JH_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f) {
+                float &best = op->step_ms[(trial - 1) & 1];
+                if (best == 0.f || ms < best) best = ms;
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        if (trial >= 0 && st == JH_OK) {
+            op->step_trials = trial + 1;
+            if (op->step_trials == 5) op->step_remap = (op->step_ms[1] > 0.f && op->step_ms[1] < 0.99f * op->step_ms[0]) ? 1 : 0;
+        }
+        return st;
+    };
 #define JH_LAUNCH(BLK, UU, DD) JH_LAUNCH_M(BLK, UU, DD, false)
 #define JH_LAUNCH_M(BLK, UU, DD, MIX)                                                                                   \
     if (wg == BLK && U == UU && D == DD && mixed == MIX) {                                                              \
@@ -1848,15 +1885,17 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
                                c.stream,                                                                                 \
                                op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars,      \
                                direct, (S)alpha, (S)beta, c.part_dev, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0,              \
-                               rows_per_part, (S *)slabs, part_stride);                                                  \
+                               rows_per_part, (S *)slabs, part_stride, remap);                                           \
             JH_CHECK_HIP(hipGetLastError());                                                                             \
+            if (trial >= 1) JH_CHECK_HIP(hipEventRecord(e1, c.stream));                                                  \
             if (parts > 1) JH_TRY((launch_fold_parts<S, NS>(slabs, part_stride, parts, w, s_begin, s_end)));              \
             double part = 0.0;                                                                                           \
-            JH_TRY(finish_normsq(gx * parts, normsq ? &part : nullptr, defer));                                          \
+            const int st_ = finish_normsq(gx * parts, normsq ? &part : nullptr, defer);                                  \
+            if (st_ != JH_OK) return trial_done(st_);                                                                    \
             total += part;                                                                                               \
         }                                                                                                                \
         if (normsq) *normsq = total;                                                                                     \
-        return JH_OK;                                                                                                    \
+        return trial_done(JH_OK);                                                                                        \
     }
     JH_LAUNCH(256, 1, 4) JH_LAUNCH(256, 2, 2) JH_LAUNCH(256, 4, 1) JH_LAUNCH(256, 4, 2) JH_LAUNCH(256, 1, 8)
     JH_LAUNCH(512, 1, 4) JH_LAUNCH(512, 2, 2) JH_LAUNCH(512, 4, 1) JH_LAUNCH(512, 4, 2) JH_LAUNCH(512, 1, 8)
@@ -2653,6 +2692,7 @@ int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value)
     if (!strcmp(name, "fwd_walk")) *value = op->fwd_walk;                       // -1: not chosen yet
     else if (!strcmp(name, "fwd_trials")) *value = op->fwd_trials_launched;
     else if (!strcmp(name, "upd_walk")) *value = op->upd_walk;
+    else if (!strcmp(name, "step_remap")) *value = op->step_remap;
     else return jh_fail(JH_ERR_INVALID, "jh_blockop_tune_get: unknown per-operator knob '%s'", name);
     return JH_OK;
 }
@@ -2670,6 +2710,11 @@ int jh_blockop_tune_set(jh_blockop *op, const char *name, int64_t value)
         JH_REQUIRE(value >= -1 && value <= 1, "jh_blockop_tune_set: upd_walk must be -1, 0 or 1");
         op->upd_walk = (int)value;
         op->upd_trials = value < 0 ? 0 : 2;
+    } else if (!strcmp(name, "step_remap")) {
+        JH_REQUIRE(value >= -1 && value <= 1, "jh_blockop_tune_set: step_remap must be -1 (measure), 0 or 1");
+        op->step_remap = (int)value;
+        op->step_trials = value < 0 ? 0 : 5;
+        op->step_ms[0] = op->step_ms[1] = 0.f;
     } else return jh_fail(JH_ERR_INVALID, "jh_blockop_tune_set: unknown per-operator knob '%s'", name);
     return JH_OK;
 }

@@ -149,6 +149,9 @@ struct jh_blockop {
     mutable int upd_walk = -1;               // same for the fused forward update (timed on its first two real calls)
     mutable int upd_trials = 0;
     mutable float upd_ms[2] = {0.f, 0.f};
+    mutable int step_remap = -1;             // one-pass step: XCD-contiguous tiles? -1 untried (timed over the first five whole-vector calls), 0, 1
+    mutable int step_trials = 0;
+    mutable float step_ms[2] = {0.f, 0.f};
     int64_t diag_stride_elems = 0;
 };
 

@@ -72,6 +72,7 @@ __device__ inline unsigned tile_of(unsigned bid, unsigned ntiles, int remap)
     // remap == 0: tile = workgroup id (consecutive tiles on consecutive XCDs).  remap == c > 0: XCD x (= bid % 8) gets runs of
     // c consecutive tiles: tile = (slot / c) * 8c + x * c + slot % c with slot = bid / 8 (c = ntiles / 8: one contiguous eighth
     // per XCD).  The host guarantees ntiles % (8 c) == 0.
+    if (remap == -2) return (bid * 2654435761u) & (ntiles - 1u);        // scatter: neighbouring tiles never run together (ntiles a power of two)
     if (remap <= 0) return bid;
     const unsigned c = (unsigned)remap, x = bid & 7u, slot = bid >> 3;
     return (slot / c) * (8u * c) + x * c + slot % c;
@@ -326,11 +327,15 @@ __global__ __launch_bounds__(BLK) void k_adj(const float *__restrict__ a, const 
 // ---------------------------------------------------------------- forward: a workgroup keeps its m tile, streams G rows --
 template <int U, int BLK, int PF, bool STNT>
 __global__ __launch_bounds__(BLK) void k_fwd(const float *__restrict__ a, const float *__restrict__ m, float *__restrict__ d, int64_t n,
-                                             int64_t nrow, int rows_per_wg, unsigned ntiles, unsigned ngroups, int walk)
+                                             int64_t nrow, int rows_per_wg, unsigned ntiles, unsigned ngroups, int walk, int remap)
 {
     // walk 0: tile fastest (one row group at a time); walk 1: group fastest (all rows concurrently)
-    const unsigned tile = walk ? blockIdx.x / ngroups : blockIdx.x % ntiles;
+    unsigned tile = walk ? blockIdx.x / ngroups : blockIdx.x % ntiles;
     const unsigned grp = walk ? blockIdx.x % ngroups : blockIdx.x / ntiles;
+    if (remap) {                                                // walk 0 only: XCD x (= id % 8) gets a contiguous eighth of the tiles of every row group
+        const unsigned per = ntiles >> 3;
+        tile = (tile & 7u) * per + (tile >> 3);
+    }
     uint32_t off[U];
     V4 mv[U];
 #pragma unroll
@@ -411,8 +416,8 @@ template <typename K> static void bench_bidiag(const char *name, K kern, int U, 
     const int64_t nvec = N / 4;
     if (nvec % ((int64_t)U * BLK) != 0) { printf("%-44s skipped (tile does not divide the block)\n", name); return; }
     const unsigned gx = (unsigned)(nvec / ((int64_t)U * BLK));
-    if (remap < 0) remap = (int)(gx / 8);                                  // -1: one contiguous eighth per XCD
-    if (remap && gx % (8 * remap)) { printf("%-44s skipped (tiles %% 8c)\n", name); return; }
+    if (remap == -1) remap = (int)(gx / 8);                                // -1: one contiguous eighth per XCD
+    if (remap > 0 && gx % (8 * remap)) { printf("%-44s skipped (tiles %% 8c)\n", name); return; }
     // correctness from the reference start state
     CK(hipMemcpy(Uv, Uref, (size_t)std::min<int64_t>(NROW, 4) * LD * 4, hipMemcpyDeviceToDevice));   // first rows restored for the bit check
     auto go = [&] { hipLaunchKernelGGL(kern, dim3(gx), dim3(BLK), 0, 0, A, Uv, Vv, Wv, N, NROW, 1.0f, -0.5f, P, remap, LD); };
@@ -511,8 +516,8 @@ int main(int argc, char **argv)
 #define BASE(U, D, B) bench_bidiag("base  U" #U " D" #D " wg" #B, k_bidiag_base<U, D, B>, U, B, 0, T, want_w, want_u, reps)
 #define PIPE(U, D, B, L, S, R) bench_bidiag("pipe  U" #U " D" #D " wg" #B " remap" #R, k_bidiag_pipe<U, D, B, L, S>, U, B, R, T, want_w, want_u, reps)
         BASE(1, 4, 512);
-        PIPE(1, 4, 512, true, true, 0); PIPE(1, 4, 512, true, true, -1); PIPE(4, 2, 512, true, true, -1); PIPE(1, 4, 1024, true, true, -1);
-        PIPE(1, 8, 256, true, true, -1); PIPE(1, 1, 256, true, true, -1); PIPE(2, 2, 256, true, true, -1);
+        PIPE(1, 4, 512, true, true, 0); PIPE(1, 4, 512, true, true, -1); PIPE(1, 4, 512, true, true, -2);
+        PIPE(4, 2, 512, true, true, 0); PIPE(4, 2, 512, true, true, -2); PIPE(1, 4, 256, true, true, 0); PIPE(1, 4, 256, true, true, -2);
     }
 
     if (which == "adj" || which == "all") {
@@ -543,31 +548,30 @@ int main(int argc, char **argv)
     if (which == "fwd" || which == "all") {
         float *Dd = Uv, *M = Vv;
         uint64_t want = 0;
-        auto run = [&](const char *name, auto kern, int U, int BLK, int G, int walk) {
+        auto run = [&](const char *name, auto kern, int U, int BLK, int G, int walk, int remap) {
             const int64_t nvec = N / 4;
             if (nvec % ((int64_t)U * BLK)) return;
             const unsigned gx = (unsigned)(nvec / ((int64_t)U * BLK));
             if (G > NROW) G = (int)NROW;
             const unsigned gy = (unsigned)((NROW + G - 1) / G);
             if ((int64_t)gx * gy * BLK >= (1ll << 32)) return;
-            auto go = [&] { hipLaunchKernelGGL(kern, dim3(gx * gy), dim3(BLK), 0, 0, A, M, Dd, N, NROW, G, gx, gy, walk); };
+            if (remap && (gx % 8 || walk)) return;
+            auto go = [&] { hipLaunchKernelGGL(kern, dim3(gx * gy), dim3(BLK), 0, 0, A, M, Dd, N, NROW, G, gx, gy, walk, remap); };
             go();
             CK(hipDeviceSynchronize());
             const uint64_t c = checksum(Dd, 1 << 22);
             if (!want) want = c;
             float med;
             const float ms = T.run(go, reps, &med);
-            printf("%-36s G%-5d walk%d  min %8.3f ms  med %8.3f ms  %7.1f GB/s %s\n", name, G, walk, ms, med, (2.0 * NROW * N + N) * 4 / ms / 1e6, c == want ? "" : "WRONG BITS");
+            printf("%-36s G%-5d walk%d remap%d  min %8.3f ms  med %8.3f ms  %7.1f GB/s %s\n", name, G, walk, remap, ms, med, (2.0 * NROW * N + N) * 4 / ms / 1e6, c == want ? "" : "WRONG BITS");
             fflush(stdout);
         };
-#define FWD(U, B, PF, S, G, W) run("fwd   U" #U " wg" #B " pf" #PF " stnt" #S, k_fwd<U, B, PF, S>, U, B, G, W)
-        for (int walk = 0; walk < 2; walk++) {
-            FWD(4, 256, 1, true, 4, walk); FWD(4, 256, 2, true, 4, walk); FWD(4, 256, 2, true, 16, walk); FWD(4, 256, 4, true, 16, walk);
-            FWD(1, 512, 2, true, 2, walk); FWD(1, 512, 4, true, 8, walk); FWD(2, 512, 2, true, 8, walk); FWD(2, 512, 4, true, 16, walk);
-            FWD(4, 512, 2, true, 8, walk); FWD(4, 512, 2, true, 1 << 20, walk); FWD(2, 512, 4, true, 1 << 20, walk); FWD(1, 512, 4, true, 1 << 20, walk);
-            FWD(4, 256, 2, false, 16, walk); FWD(2, 512, 4, false, 16, walk);
-            FWD(2, 1024, 4, true, 16, walk); FWD(4, 1024, 2, true, 16, walk);
+#define FWD(U, B, PF, S, G, W, R) run("fwd   U" #U " wg" #B " pf" #PF " stnt" #S, k_fwd<U, B, PF, S>, U, B, G, W, R)
+        for (int remap = 0; remap < 2; remap++) {
+            FWD(4, 256, 1, true, 4, 0, remap); FWD(4, 256, 2, true, 16, 0, remap); FWD(4, 1024, 2, true, 16, 0, remap); FWD(2, 512, 2, true, 8, 0, remap);
+            FWD(4, 256, 1, true, 16, 0, remap); FWD(4, 512, 2, true, 1 << 20, 0, remap); FWD(1, 512, 4, true, 1 << 20, 0, remap); FWD(4, 1024, 2, true, 1 << 20, 0, remap);
         }
+        FWD(4, 256, 2, true, 16, 1, 0); FWD(2, 512, 4, true, 16, 1, 0);
     }
     return 0;
 }
