@@ -1311,48 +1311,77 @@ const TallShape k_fwd_candidates[K_FWD_CANDIDATES] = {TallShape{1024, 8, 16, 0},
 // not ask for and the host never waits; a later call harvests the finished timings with hipEventQuery and, once every
 // candidate has been measured twice (the first pass also warms caches and TLBs), keeps the fastest.  jh_blockop_mul returns
 // after enqueue, always.  Skipped while the stream is being captured.  jh_blockop_tune_get/set export / import the choice.
-void fwd_autotune_release(const jh_blockop *op)
+void lazy_release(jh_blockop::LazyTune &t)
 {
-    for (auto &pair : op->fwd_ev)
+    for (auto &pair : t.ev)
         for (auto &e : pair)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
 }
 
-// returns the candidate index to run for THIS call and, when it is a timed trial, its slot (else -1)
-int fwd_autotune_next(const jh_blockop *op, int *slot)
+void lazy_reset(jh_blockop::LazyTune &t)
+{
+    lazy_release(t);
+    for (auto &st : t.state) st = 0;
+    for (auto &m : t.ms) m = 0.f;
+    t.launched = 0;
+}
+
+// Which candidate should THIS call run?  Trial slots are laid out pass-major after `warm` untimed-in-effect slots (their
+// timings are discarded): slot = warm + pass * ncand + candidate.  Returns the candidate and, when the call is a trial, its
+// slot (else -1).  Once every slot has a timing, *choice = the candidate with the best time over its passes -- candidate 0
+// unless another one beats it by `margin` -- and the events are released.
+int lazy_next(jh_blockop::LazyTune &t, int ncand, int npass, int warm, float margin, int *choice, int *slot)
 {
     *slot = -1;
-    constexpr int NS_ = K_FWD_CANDIDATES * jh_blockop::FWD_PASSES;
+    const int total = warm + ncand * npass;
     int measured = 0;
-    for (int t = 0; t < op->fwd_trials_launched; t++) {                    // harvest what has finished (non-blocking)
-        if (op->fwd_state[t] == 1 && hipEventQuery(op->fwd_ev[t][1]) == hipSuccess) {
+    for (int k = 0; k < t.launched; k++) {                                  // harvest what has finished (non-blocking)
+        if (t.state[k] == 1 && hipEventQuery(t.ev[k][1]) == hipSuccess) {
             float ms = 0.f;
-            op->fwd_state[t] = (hipEventElapsedTime(&ms, op->fwd_ev[t][0], op->fwd_ev[t][1]) == hipSuccess && ms > 0.f) ? 2 : 3;
-            op->fwd_ms[t] = ms;
+            t.state[k] = (hipEventElapsedTime(&ms, t.ev[k][0], t.ev[k][1]) == hipSuccess && ms > 0.f) ? 2 : 3;
+            t.ms[k] = ms;
         }
-        if (op->fwd_state[t] >= 2) measured++;
+        if (t.state[k] >= 2) measured++;
     }
-    (void)hipGetLastError();                                               // hipEventQuery's hipErrorNotReady is not an error
-    if (measured == NS_) {
-        int pick = 0;
-        float best = 0.f;
-        for (int k = 0; k < K_FWD_CANDIDATES; k++) {
-            float ms = 0.f;                                                // best of the passes that produced a timing
-            for (int p = 0; p < jh_blockop::FWD_PASSES; p++) {
-                const int t = p * K_FWD_CANDIDATES + k;
-                if (op->fwd_state[t] == 2 && (ms == 0.f || op->fwd_ms[t] < ms)) ms = op->fwd_ms[t];
+    (void)hipGetLastError();                                                // hipEventQuery's hipErrorNotReady is not an error
+    if (measured == total) {
+        float best[8] = {};
+        for (int c = 0; c < ncand; c++)
+            for (int p = 0; p < npass; p++) {
+                const int k = warm + p * ncand + c;
+                if (t.state[k] == 2 && (best[c] == 0.f || t.ms[k] < best[c])) best[c] = t.ms[k];
             }
-            if (ms > 0.f && (best == 0.f || ms < best)) { best = ms; pick = k; }
-        }
-        op->fwd_walk = pick;
-        fwd_autotune_release(op);
+        int pick = 0;
+        for (int c = 1; c < ncand; c++)
+            if (best[c] > 0.f && (best[pick] == 0.f || best[c] < (1.f - margin) * best[pick])) pick = c;
+        *choice = pick;
+        lazy_release(t);
         return pick;
     }
-    if (op->fwd_trials_launched < NS_) {
-        *slot = op->fwd_trials_launched;
-        return *slot % K_FWD_CANDIDATES;
+    if (t.launched < total) {
+        *slot = t.launched;
+        return *slot < warm ? 0 : (*slot - warm) % ncand;
     }
-    return 0;                                                              // every trial is in flight: the default shape meanwhile
+    return 0;                                                               // every trial is in flight: the default meanwhile
+}
+
+bool lazy_begin(jh_blockop::LazyTune &t, int slot, hipStream_t st)
+{
+    return hipEventCreate(&t.ev[slot][0]) == hipSuccess && hipEventCreate(&t.ev[slot][1]) == hipSuccess &&
+           hipEventRecord(t.ev[slot][0], st) == hipSuccess;
+}
+
+void lazy_end(jh_blockop::LazyTune &t, int slot, hipStream_t st, bool ok)
+{
+    ok = ok && hipEventRecord(t.ev[slot][1], st) == hipSuccess;
+    t.state[slot] = ok ? 1 : 3;
+    t.launched = slot + 1;
+}
+
+bool stream_is_capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    return !(hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone);
 }
 
 template <typename S, int E, int NS>
@@ -1365,19 +1394,15 @@ int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scal
     if (c.autotune && knobs_free && stream_bytes >= 8.0 * (double)(1ull << 30) && op->nrow >= 64) {
         int slot = -1;
         if (op->fwd_walk < 0) {
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(c.stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
-                const int k = fwd_autotune_next(op, &slot);
+            if (!stream_is_capturing(c.stream)) {
+                const int k = lazy_next(op->fwd_tune, K_FWD_CANDIDATES, 2, 0, 0.f, &op->fwd_walk, &slot);
                 if (k >= 0 && k < K_FWD_CANDIDATES) sh = k_fwd_candidates[k];
             }
         } else if (op->fwd_walk < K_FWD_CANDIDATES) sh = k_fwd_candidates[op->fwd_walk];
         if (slot >= 0) {                                                   // a timed trial: the caller's own launch between two events
-            bool ok = hipEventCreate(&op->fwd_ev[slot][0]) == hipSuccess && hipEventCreate(&op->fwd_ev[slot][1]) == hipSuccess &&
-                      hipEventRecord(op->fwd_ev[slot][0], c.stream) == hipSuccess;
+            const bool ok = lazy_begin(op->fwd_tune, slot, c.stream);
             const int st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, sh);
-            ok = ok && st == JH_OK && hipEventRecord(op->fwd_ev[slot][1], c.stream) == hipSuccess;
-            op->fwd_state[slot] = ok ? 1 : 3;
-            op->fwd_trials_launched = slot + 1;
+            lazy_end(op->fwd_tune, slot, c.stream, ok && st == JH_OK);
             return st;
         }
     }
@@ -1843,36 +1868,18 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     int64_t rows_per_launch = op->nrow;
     if (c.adj_rows_per_launch > 0) rows_per_launch = c.adj_rows_per_launch < op->nrow ? c.adj_rows_per_launch : op->nrow;
     if (parts > 1) rows_per_launch = op->nrow;
-    // XCD-contiguous tiles: per operator, by measurement.  Only whole-vector calls that read the norm back are timed (they
-    // synchronise anyway): calls 1-4 alternate off / on between two events, then the faster one stays (it must win by 1 %).
+    // XCD-contiguous tiles: per operator, by measurement, lazily (lazy_next): the first five eligible calls -- whole-vector or
+    // ranged alike, the pipelined multi-GPU step only ever makes ranged ones -- run off (warm-up), off, on, off, on between two
+    // events; the map stays on only if it wins by 1 %.  No extra launches, no host synchronisation.
     const bool remap_ok = parts == 1 && gx % 8 == 0 && gx >= 64 && rows_per_launch == op->nrow;
     int remap = (remap_ok && op->step_remap > 0) ? 1 : 0;
-    int trial = -1;
-    if (remap_ok && op->step_remap < 0 && c.autotune && normsq && s_begin == 0 && s_end == n_scalars &&
-        3.0 * (double)op->nrow * (double)n_scalars * sizeof(S) >= 4.0 * (double)(1ull << 30)) {
-        trial = op->step_trials;                                  // 0 warms up (untimed), 1..4 are timed: off, on, off, on
-        remap = (trial >= 1) ? ((trial - 1) & 1) : 0;
-    }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (trial >= 1) {
-        JH_CHECK_HIP(hipEventCreate(&e0));
-        JH_CHECK_HIP(hipEventCreate(&e1));
-        JH_CHECK_HIP(hipEventRecord(e0, c.stream));
-    }
+    int slot = -1;
+    if (remap_ok && op->step_remap < 0 && c.autotune && !stream_is_capturing(c.stream) &&
+        3.0 * (double)op->nrow * (double)(s_end - s_begin) * sizeof(S) >= 1.0 * (double)(1ull << 30))
+        remap = lazy_next(op->step_tune, 2, 2, 1, 0.01f, &op->step_remap, &slot);
+    const bool timing = slot >= 0 && lazy_begin(op->step_tune, slot, c.stream);
     auto trial_done = [&](int st) {
-        if (trial >= 1) {
-            float ms = 0.f;
-            if (st == JH_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f) {
-                float &best = op->step_ms[(trial - 1) & 1];
-                if (best == 0.f || ms < best) best = ms;
-            }
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
-        }
-        if (trial >= 0 && st == JH_OK) {
-            op->step_trials = trial + 1;
-            if (op->step_trials == 5) op->step_remap = (op->step_ms[1] > 0.f && op->step_ms[1] < 0.99f * op->step_ms[0]) ? 1 : 0;
-        }
+        if (slot >= 0) lazy_end(op->step_tune, slot, c.stream, timing && st == JH_OK);
         return st;
     };
 #define JH_LAUNCH(BLK, UU, DD) JH_LAUNCH_M(BLK, UU, DD, false)
@@ -1887,7 +1894,6 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
                                direct, (S)alpha, (S)beta, c.part_dev, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0,              \
                                rows_per_part, (S *)slabs, part_stride, remap);                                           \
             JH_CHECK_HIP(hipGetLastError());                                                                             \
-            if (trial >= 1) JH_CHECK_HIP(hipEventRecord(e1, c.stream));                                                  \
             if (parts > 1) JH_TRY((launch_fold_parts<S, NS>(slabs, part_stride, parts, w, s_begin, s_end)));              \
             double part = 0.0;                                                                                           \
             const int st_ = finish_normsq(gx * parts, normsq ? &part : nullptr, defer);                                  \
@@ -2299,7 +2305,8 @@ int jh_blockop_destroy(jh_blockop *op)
     if (!op) return JH_OK;
     if (jh_ctx().ready) (void)hipStreamSynchronize(jh_ctx().stream);
     drop_loop_graphs(op);
-    fwd_autotune_release(op);
+    lazy_release(op->fwd_tune);
+    lazy_release(op->step_tune);
     if (op->dev_blocks) (void)hipFree(op->dev_blocks);
     if (op->dev_row_off) (void)hipFree(op->dev_row_off);
     if (op->dev_col_off) (void)hipFree(op->dev_col_off);
@@ -2690,7 +2697,8 @@ int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value)
 {
     JH_REQUIRE(op && name && value, "jh_blockop_tune_get: null argument");
     if (!strcmp(name, "fwd_walk")) *value = op->fwd_walk;                       // -1: not chosen yet
-    else if (!strcmp(name, "fwd_trials")) *value = op->fwd_trials_launched;
+    else if (!strcmp(name, "fwd_trials")) *value = op->fwd_tune.launched;
+    else if (!strcmp(name, "step_trials")) *value = op->step_tune.launched;
     else if (!strcmp(name, "upd_walk")) *value = op->upd_walk;
     else if (!strcmp(name, "step_remap")) *value = op->step_remap;
     else return jh_fail(JH_ERR_INVALID, "jh_blockop_tune_get: unknown per-operator knob '%s'", name);
@@ -2702,9 +2710,7 @@ int jh_blockop_tune_set(jh_blockop *op, const char *name, int64_t value)
     JH_REQUIRE(op && name, "jh_blockop_tune_set: null argument");
     if (!strcmp(name, "fwd_walk")) {
         JH_REQUIRE(value >= -1 && value < K_FWD_CANDIDATES, "jh_blockop_tune_set: fwd_walk must be -1 (measure again) or 0..%d", K_FWD_CANDIDATES - 1);
-        fwd_autotune_release(op);
-        for (auto &st : op->fwd_state) st = 0;
-        op->fwd_trials_launched = 0;
+        lazy_reset(op->fwd_tune);
         op->fwd_walk = (int)value;
     } else if (!strcmp(name, "upd_walk")) {
         JH_REQUIRE(value >= -1 && value <= 1, "jh_blockop_tune_set: upd_walk must be -1, 0 or 1");
@@ -2712,9 +2718,8 @@ int jh_blockop_tune_set(jh_blockop *op, const char *name, int64_t value)
         op->upd_trials = value < 0 ? 0 : 2;
     } else if (!strcmp(name, "step_remap")) {
         JH_REQUIRE(value >= -1 && value <= 1, "jh_blockop_tune_set: step_remap must be -1 (measure), 0 or 1");
+        lazy_reset(op->step_tune);
         op->step_remap = (int)value;
-        op->step_trials = value < 0 ? 0 : 5;
-        op->step_ms[0] = op->step_ms[1] = 0.f;
     } else return jh_fail(JH_ERR_INVALID, "jh_blockop_tune_set: unknown per-operator knob '%s'", name);
     return JH_OK;
 }

@@ -139,19 +139,22 @@ struct jh_blockop {
     struct LoopGraph { const void *out; const void *in; int mode; int seen; uint64_t gen; hipGraphExec_t exec; };
     mutable std::vector<LoopGraph> loop_graphs;
     mutable int fwd_walk = -1;               // autotuned tall-forward shape: -1 untried, else an index into k_fwd_candidates (jh_blockop.hip)
-    // lazy autotune of the tall forward: the first real calls each run ONE candidate shape between two events (no extra
-    // launches, no host synchronisation); finished timings are harvested with hipEventQuery on later calls
-    static constexpr int FWD_CAND_MAX = 8, FWD_PASSES = 2;
-    mutable hipEvent_t fwd_ev[FWD_CAND_MAX * FWD_PASSES][2] = {};
-    mutable float fwd_ms[FWD_CAND_MAX * FWD_PASSES] = {};
-    mutable unsigned char fwd_state[FWD_CAND_MAX * FWD_PASSES] = {};   // 0 not launched, 1 in flight, 2 measured, 3 failed
-    mutable int fwd_trials_launched = 0;
+    // lazy autotune (jh_blockop.hip: lazy_*): the first real calls each run ONE candidate between two events -- no extra
+    // launches, no host synchronisation -- and finished timings are harvested with hipEventQuery on later calls
+    struct LazyTune {
+        static constexpr int SLOTS = 16;
+        hipEvent_t ev[SLOTS][2] = {};
+        float ms[SLOTS] = {};
+        unsigned char state[SLOTS] = {};     // 0 not launched, 1 in flight, 2 measured, 3 failed
+        int launched = 0;
+    };
+    mutable LazyTune fwd_tune;               // tall forward: K_FWD_CANDIDATES shapes x 2 passes -> fwd_walk
+    mutable LazyTune step_tune;              // one-pass step: tile map off / on x 2 passes (+ a warm-up) -> step_remap
     mutable int upd_walk = -1;               // same for the fused forward update (timed on its first two real calls)
     mutable int upd_trials = 0;
     mutable float upd_ms[2] = {0.f, 0.f};
     mutable int step_remap = -1;             // one-pass step: XCD-contiguous tiles? -1 untried (timed over the first five whole-vector calls), 0, 1
-    mutable int step_trials = 0;
-    mutable float step_ms[2] = {0.f, 0.f};
+
     int64_t diag_stride_elems = 0;
 };
 

@@ -27,7 +27,7 @@ for nblocks, edge in ((128, 256), (256, 256), (1024, 256), (1024, 128), (64, 128
         one_pass(); one_pass()
         res[forced] = timed()
     nat.tune_set("step_remap", -1)
-    for _ in range(6): one_pass()
+    for _ in range(8): one_pass()
     chosen = nat.tune_get("step_remap")
     t = timed()
     print(f"{nblocks} x {edge}^3 one-pass step: tiles by id {res[0]:8.3f} ms {b3/res[0]/1e6:7.1f} GB/s | XCD-contiguous {res[1]:8.3f} ms {b3/res[1]/1e6:7.1f} GB/s | measured choice {chosen}: {t:8.3f} ms {b3/t/1e6:7.1f} GB/s", flush=True)
