@@ -334,7 +334,10 @@ def main():
                     persistent = J.tune_get("last_fwd_rows_per_wg") >= nloc   # walk re-reads no m, like the row-concurrent one
                     key += "@walk%d" % (1 if persistent else J.tune_get("last_fwd_walk"))
                 traffic = tj.get(key)
-                traffic_round = tj.get("round")
+                if traffic is None:
+                    key = key.split("@")[0]                              # counters taken over the walks the lazy autotune tried
+                    traffic = tj.get(key)
+                traffic_round = tj.get(key + "#round", "r01")
                 if traffic is not None and dom["launches_per_call"] > 1 and traffic > 0.75 * dom["bytes"]:
                     traffic /= dom["launches_per_call"]                  # recorded when the whole call was one launch
         except Exception:
@@ -360,7 +363,8 @@ def main():
         # ranged steps, ranged all-reduces on the exchange stream, one host synchronisation per step) when every rank can set it
         # up; otherwise the Python driver over torch.distributed.  BENCH_LSQR_ABI=0 forces the latter.
         target, lsqr_driver = (shard if shard is not None else A), ("python driver over torch.distributed" if shard is not None else "jh_lsqr_solve")
-        if dist is not None and world > 1 and dist.get_backend() == "nccl" and os.environ.get("BENCH_LSQR_ABI", "1") == "1":
+        abi_mode = os.environ.get("BENCH_LSQR_ABI", "1")               # "force": also with ONE rank (validation / timing on a one-GPU box)
+        if dist is not None and dist.get_backend() == "nccl" and (abi_mode == "force" or (world > 1 and abi_mode == "1")):
             import ctypes as _C
 
             from jets_jl_amd._ffi import lib as _lib
@@ -374,6 +378,8 @@ def main():
                     return box[0]
 
                 abi = J.rowpart.AbiComm(world, rank, exchange_id=exchange_id)
+                if world == 1:
+                    J.tune(force_dist=1)                             # run the exchange with the one-rank communicator
                 target, lsqr_driver = J.rowpart.for_device(part, A, comm=abi), "jh_lsqr_solve_partitioned (C ABI communicator, pipelined exchange)"
         fence()
         t_l = time.perf_counter()

@@ -41,7 +41,7 @@ def counters(dirname, counter):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r01")
+    ap.add_argument("--round", default="r02")
     ap.add_argument("--kt", required=True)
     ap.add_argument("--fetch")
     ap.add_argument("--write")
@@ -79,7 +79,9 @@ def main():
         f, w = fetch.get(k), write.get(k)
         tr = (2 * f + w) * 1024 if (f is not None and w is not None) else None
         if tr is not None and k in algo:
-            traffic[k + (f"@walk{args.walk}" if (k == "k_tall_diag_fwd" and args.walk is not None) else "")] = tr
+            key = k + (f"@walk{args.walk}" if (k == "k_tall_diag_fwd" and args.walk is not None) else "")
+            traffic[key] = tr
+            traffic[key + "#round"] = args.round              # every entry says which round's counters it comes from
         lines.append("| {} | {} | {:.3f} | {} | {} | {} | {} | {} | {} | {} |".format(
             k, r["Calls"], avg_ms, r["Percentage"], f"{ab:,}" if ab else "-",
             f"{ab / avg_ms / 1e6:.1f}" if ab else "-", f"{f:,.0f}" if f is not None else "-",
