@@ -302,7 +302,7 @@ int jh_comm_allreduce_normsq(double *out);
 /* kernel-shape tuning knobs (bench/tests only): 0 = automatic (fwd_order: -1); name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg","fwd_order","nt","autotune" (0: tall forwards keep the size-based default shape; 1: per-operator lazy measurement, see jh_blockop_tune_get),
  * "graphs" (1: operators that run the per-block loop -- those with DENSE blocks -- replay it as a hipGraph from the
  * third call with the same vectors on; 0: always eager), "general_xcd" (the general M x K kernels' grid order: 1 automatic -- XCD-aware when the
- * input vector is >= 32 MiB, line by line below --, 0 never XCD-aware, 2 always), "red_wgs", "bcast_item_fast" (batched broadcasts with a shared operand: -1 automatic, 0 plain kernel, 1 items fastest), "adj_split" (split-row walk of the tall adjoint / fused normal /
+ * input vector is >= 32 MiB, line by line below --, 0 never XCD-aware, 2 always), "red_wgs", "bcast_item_fast" (batched broadcasts with a shared operand: -1 automatic, 0 plain kernel, 1 items fastest), "step_chain" (the one-pass step as chained row chunks: -1 measured per operator, 0 never, 1 whenever the shape allows), "adj_split" (split-row walk of the tall adjoint / fused normal /
  * one-pass step: -1 automatic, 0 never -- always the ordered, bit-exact walk --, k > 1 that many row parts)};
  * jh_tune_get also reads the counters "last_fwd_walk" (grid walk of the latest tall forward: 0 sequential, 1 all rows),
  * "last_fwd_rows_per_wg", "last_adj_launches", "last_adj_parts" and "graph_replays". */
@@ -313,8 +313,9 @@ int jh_tune_get(const char *name, int64_t *value);
  * jh_blockop_mul runs the next candidate between two events -- no extra launches, no host synchronisation, jh_blockop_mul
  * returns after enqueue -- and after 12 calls the fastest is kept ("fwd_trials" counts the timed calls so far).  A host that
  * wants the steady state at once (or the same choice in every process) reads it from one operator and sets it on another;
- * setting -1 measures again.  "upd_walk" is the same for jh_blockop_mul_axpby (0 / 1, chosen over its first two calls), "step_remap"
- * for jh_blockop_bidiag_step (XCD-contiguous tiles, 0 / 1, chosen over its first five whole-vector calls that return the norm). */
+ * setting -1 measures again.  "upd_walk" is the same for jh_blockop_mul_axpby (0 / 1, chosen over its first two calls), "step_mode"
+ * for jh_blockop_bidiag_step: 0 plain walk, 1 the same with XCD-contiguous tiles, 2 chained row chunks (one batch of 8 rows per
+ * workgroup, the ordered sum handed from chunk to chunk: same bits), chosen over its first seven eligible calls. */
 int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value);
 int jh_blockop_tune_set(jh_blockop *op, const char *name, int64_t value);
 

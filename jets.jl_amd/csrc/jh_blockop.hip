@@ -562,6 +562,133 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
     wg_sum_store<BLK>(nrm, partials + tile + (size_t)blockIdx.y * gridDim.x);      // by tile: the fold's order does not depend on remap
 }
 
+// ---- the one-pass step as CHAINED ROW CHUNKS: one batch of DEPTH rows per workgroup ---------------------------------------
+// A workgroup of k_tall_diag_bidiag lives for all rows of its tile.  Kernels that read AND write like that run 5-20 % below
+// what the same chip does for workgroups that are born, move one batch and die in dispatch order (profiles/
+// exp_r02_step_chain.txt: 5.2-5.3 TB/s at 64-512 rows of 64 MiB, 5.8-6.1 at 1024, against 6.1-6.2 for every row count here).
+// So the rows are cut into chunks of DEPTH rows and workgroup (chunk c, tile t) CONTINUES the ordered sum of (c-1, t):
+//   w_t = ((((0 + p_0) + p_1) + ... ) + p_{8c-1})  |  + p_{8c} + ... + p_{8c+7}   -- the same additions in the same order, so w
+// keeps the bits of the single ordered walk (u is row-wise work anyway).  The partial sum travels through memory in the form
+// MI355X_MICROARCH.md validates for inter-workgroup hand-offs: every wave stores its piece write-through (sc1), drains
+// (s_waitcnt vmcnt(0)), the workgroup barriers, ONE lane raises flag[t] with an agent-scope store; the consumer polls flag[t] with
+// agent-scope loads from ONE lane, barriers, then loads the partial with sc1 loads.  Two alternating partial buffers.
+// No deadlock, whatever order the hardware starts workgroups in: logical ids are TICKETS taken at start, and (c, t) only waits for
+// (c-1, t), whose ticket is smaller -- it has started and depends only on still smaller tickets.  The poll is bounded all the
+// same: on its (never observed) expiry the sticky word *err is set and the caller reports it where ||u||^2 is read back.
+__device__ inline void st_sc1_16(void *p, unsigned __attribute__((ext_vector_type(4))) v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+// streaming store of one 16-byte pack, spelled out: in this kernel the compiler dropped the `nt` of __builtin_nontemporal_store on
+// the batch's stores (plain write-back stores cost 20 % here)
+__device__ inline void st_nt_16(void *p, unsigned __attribute__((ext_vector_type(4))) v)
+{
+    // s_nop 1: a VMEM store of more than 8 bytes reads its data VGPRs a wait state after issue; the compiler pads that hazard
+    // for its own stores, not behind inline assembly
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ inline unsigned __attribute__((ext_vector_type(4))) ld_sc1_16(const void *p)
+{
+    unsigned __attribute__((ext_vector_type(4))) v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <typename S, int E, int NS, int U, int DEPTH, int BLK>
+__global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_block *__restrict__ blocks, int64_t nrow,
+                                                                const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ u,
+                                                                const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, S alpha,
+                                                                S beta, double *__restrict__ partials, int64_t s_begin, int64_t s_end,
+                                                                unsigned ntiles, unsigned nchunks, unsigned *__restrict__ sync,
+                                                                S *__restrict__ wpart, unsigned *__restrict__ err)
+{
+    typedef typename vec_of<S, NS>::type V;
+    typedef unsigned U4 __attribute__((ext_vector_type(4)));
+    static_assert(sizeof(V) == 16, "one 16-byte pack per lane");
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&sync[0], 1u);              // logical id = order of arrival
+    __syncthreads();
+    const unsigned ticket = s_ticket;
+    const unsigned chunk = ticket / ntiles, tile = ticket - chunk * ntiles;
+    const int64_t row0 = (int64_t)chunk * DEPTH, row1 = (row0 + DEPTH < nrow) ? row0 + DEPTH : nrow;
+    const int64_t span = s_end - s_begin;                                   // the host guarantees span % (U * BLK * NS) == 0: full tiles only
+    int64_t sk[U];
+    V acc[U], vv[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        sk[k] = s_begin + (((int64_t)tile * U + k) * BLK + threadIdx.x) * NS;
+        acc[k] = (V)(S)0;
+        vv[k] = ld<false>(reinterpret_cast<const V *>(v + sk[k]));
+    }
+    const bool use_old = (beta != (S)0);
+    const bool full = row0 + DEPTH <= nrow;
+    V av[DEPTH][U], uv[DEPTH][U];
+    if (full) {                                                             // the batch's loads go out BEFORE the wait for the predecessor
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            const S *a = a_base ? a_base + (row0 + j) * a_stride : (const S *)blocks[row0 + j].coeff;
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                av[j][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+                uv[j][k] = use_old ? ld<true>(reinterpret_cast<const V *>(u + (row0 + j) * n_scalars + sk[k])) : (V)(S)0;
+            }
+        }
+    }
+    if (chunk > 0) {
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&sync[2 + tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 22)) { atomicOr(err, 1u); break; }    // never hang: flag it and go on
+            }
+        }
+        __syncthreads();
+        const S *src = wpart + (int64_t)((chunk - 1) & 1u) * span - s_begin;
+#pragma unroll
+        for (int k = 0; k < U; k++) acc[k] = __builtin_bit_cast(V, ld_sc1_16(src + sk[k]));
+    }
+    double nrm = 0.0;
+    if (full) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                V t = vmul<S, E, NS, V>(av[j][k], vv[k], false);            // mul!(tmp, A_i, v)
+                V r = (V)alpha * t;
+                if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; }     // u_i .= alpha*tmp .+ beta*u_i
+                st_nt_16(u + (row0 + j) * n_scalars + sk[k], __builtin_bit_cast(U4, r));
+                nrm += vnorm2<S, NS, V>(r);
+                acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, true);     // _m .+= conj(a_i) .* u_i   (1049)
+            }
+    } else {
+        for (int64_t i = row0; i < row1; i++) {
+            const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                V a1 = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+                V t = vmul<S, E, NS, V>(a1, vv[k], false);
+                V r = (V)alpha * t;
+                if (use_old) { V s2 = (V)beta * ld<true>(reinterpret_cast<const V *>(u + i * n_scalars + sk[k])); r = r + s2; }
+                st_nt_16(u + i * n_scalars + sk[k], __builtin_bit_cast(U4, r));
+                nrm += vnorm2<S, NS, V>(r);
+                acc[k] = acc[k] + vmul<S, E, NS, V>(a1, r, true);
+            }
+        }
+    }
+    if (chunk + 1 < nchunks) {                                              // hand the ordered partial sum on
+        S *dst = wpart + (int64_t)(chunk & 1u) * span - s_begin;
+#pragma unroll
+        for (int k = 0; k < U; k++) st_sc1_16(dst + sk[k], __builtin_bit_cast(U4, acc[k]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&sync[2 + tile], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+        for (int k = 0; k < U; k++) st<false>(reinterpret_cast<V *>(w + sk[k]), acc[k]);
+    }
+    wg_sum_store<BLK>(nrm, partials + ticket);
+}
+
 // out[s] = sum over parts p = 0..nparts-1 (in that order within a part lane, part lanes in order) of parts[p][s - s_begin]:
 // the second stage of the split-row walk.  64 vector lanes x 16 part lanes per workgroup; fp64 accumulation (exact
 // conversions of S, so the fold adds no rounding of its own until the final cast); fixed order => deterministic.
@@ -1688,11 +1815,14 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
 // ---- fused solver updates: launch + partial fold ---------------------------------------------------
 // normsq != NULL: read the folded sum back (synchronises).  normsq == NULL and defer: add it to the device-side accumulator
 // instead (no host synchronisation at all).  normsq == NULL and !defer: the caller does not want the norm.
-int finish_normsq(int64_t nparts, double *normsq, bool defer = false)
+int finish_normsq(int64_t nparts, double *normsq, bool defer = false, int private_slot = -1)
 {
+    // private_slot >= 0: add the folded sum to red_dev[private_slot] and return without reading anything back (a walk in
+    // several row launches sums its launches on the device and reads ONE value at the end)
     jh_context &c = jh_ctx();
-    const int accum = (!normsq && defer) ? 1 : 0;
-    double *dst = accum ? c.red_dev + JH_NORMSQ_SLOT : c.red_dev;
+    const int accum = ((!normsq && defer) || private_slot >= 0) ? 1 : 0;
+    double *dst = private_slot >= 0 ? c.red_dev + private_slot : (accum ? c.red_dev + JH_NORMSQ_SLOT : c.red_dev);
+    if (private_slot >= 0) normsq = nullptr;
     if (nparts > 8192) {        // two levels: <= 1024 chunk sums (red_dev + 16 ...), then one workgroup
         const int64_t nchunk = 1024, chunk = (nparts + nchunk - 1) / nchunk;
         hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)nchunk), dim3(256), 0, c.stream, c.part_dev, nparts, chunk, c.red_dev + 16, 0);
@@ -1704,8 +1834,10 @@ int finish_normsq(int64_t nparts, double *normsq, bool defer = false)
     JH_CHECK_HIP(hipGetLastError());
     if (normsq) {
         JH_CHECK_HIP(hipMemcpyAsync(c.red_host, c.red_dev, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        JH_CHECK_HIP(hipMemcpyAsync(c.red_host + 3, c.red_dev + JH_CHAIN_ERR_SLOT, sizeof(double), hipMemcpyDeviceToHost, c.stream));
         JH_CHECK_HIP(hipStreamSynchronize(c.stream));
         *normsq = c.red_host[0];
+        JH_TRY(jh_chain_err_check());
     }
     return JH_OK;
 }
@@ -1868,24 +2000,80 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     int64_t rows_per_launch = op->nrow;
     if (c.adj_rows_per_launch > 0) rows_per_launch = c.adj_rows_per_launch < op->nrow ? c.adj_rows_per_launch : op->nrow;
     if (parts > 1) rows_per_launch = op->nrow;
-    // XCD-contiguous tiles: per operator, by measurement, lazily (lazy_next): the first five eligible calls -- whole-vector or
-    // ranged alike, the pipelined multi-GPU step only ever makes ranged ones -- run off (warm-up), off, on, off, on between two
-    // events; the map stays on only if it wins by 1 %.  No extra launches, no host synchronisation.
+    // HOW the step walks is chosen per operator by measurement (lazy_next: the first seven eligible calls -- whole-vector or
+    // ranged alike, the pipelined multi-GPU step only ever makes ranged ones -- each run one mode between two events; no extra
+    // launches, no host synchronisation), because which one is fastest depends on the row count AND on where the slabs landed:
+    //   mode 0  plain walk: a workgroup lives for all rows of its tile (k_tall_diag_bidiag)
+    //   mode 1  the same with XCD-contiguous tiles (+3 % at 128-256 rows of 64 MiB at power-of-two strides, else neutral or worse)
+    //   mode 2  chained row chunks (k_tall_diag_bidiag_chain): one batch of 8 rows per workgroup, the ordered sum handed from
+    //           chunk to chunk -- same bits; 6.1-6.2 TB/s at 64-512 rows of 64 MiB where the plain walk gives 5.2-5.5 in most
+    //           processes and the same in some, -2 ... +4 % at 1024 rows (profiles/ab_r02_step_chain.txt); rows of >= 16 MiB only
+    // All three compute the same bits.  A mode other than 0 stays only if it wins by 1 %.  Knob step_chain: -1 measure,
+    // 0 never chain, 1 chain whenever the shape allows (tests); jh_blockop_tune_get/set "step_mode" exports / imports the choice.
+    constexpr int CD = 8;                                                 // rows per chunk = rows in flight
+    const int64_t span = s_end - s_begin, nchunks = (op->nrow + CD - 1) / CD;
+    const bool knobs_free = !c.adj_wg && !c.adj_unroll && !c.adj_depth;
+    int cb = 0;                                                           // chained: workgroup size (0: the shape does not allow it)
+    if (!mixed && !direct && parts == 1 && rows_per_launch == op->nrow && nchunks >= 2)
+        for (int b : {1024, 512, 256})
+            if (span % ((int64_t)b * NS) == 0 && (c.step_chain == 1 || (b == 1024 && span / ((int64_t)b * NS) >= 1024 && op->nrow >= 16))) { cb = b; break; }
+    const int64_t ntiles = cb ? span / ((int64_t)cb * NS) : 0;
+    if (cb && !(ntiles * nchunks * cb < ((int64_t)1 << 32) && ntiles < ((int64_t)1 << 24))) cb = 0;
+    const bool chain_ok = cb != 0 && c.step_chain != 0 && (c.step_chain == 1 || knobs_free);
     const bool remap_ok = parts == 1 && gx % 8 == 0 && gx >= 64 && rows_per_launch == op->nrow;
-    int remap = (remap_ok && op->step_remap > 0) ? 1 : 0;
-    int slot = -1;
-    if (remap_ok && op->step_remap < 0 && c.autotune && !stream_is_capturing(c.stream) &&
-        3.0 * (double)op->nrow * (double)(s_end - s_begin) * sizeof(S) >= 1.0 * (double)(1ull << 30))
-        remap = lazy_next(op->step_tune, 2, 2, 1, 0.01f, &op->step_remap, &slot);
+    int mode = 0, slot = -1;
+    if (c.step_chain == 1 && chain_ok) mode = 2;
+    else if (op->step_mode >= 0) mode = op->step_mode;
+    else if ((remap_ok || chain_ok) && c.autotune && !stream_is_capturing(c.stream) && (op->step_span == 0 || op->step_span == span) &&
+             3.0 * (double)op->nrow * (double)span * sizeof(S) >= 1.0 * (double)(1ull << 30)) {
+        op->step_span = span;                                             // the trials belong to ONE call shape (whole-vector or one range size)
+        mode = lazy_next(op->step_tune, 3, 2, 1, 0.01f, &op->step_mode, &slot);
+    }
+    if (mode == 2 && !chain_ok) mode = 0;                                 // a trial of a mode this call cannot take runs (and times) the plain walk
+    if (mode == 1 && !remap_ok) mode = 0;
+    const int remap = mode == 1 ? 1 : 0;
     const bool timing = slot >= 0 && lazy_begin(op->step_tune, slot, c.stream);
     auto trial_done = [&](int st) {
         if (slot >= 0) lazy_end(op->step_tune, slot, c.stream, timing && st == JH_OK);
         return st;
     };
+    if (mode == 2) {
+        if (c.chain_sync_cap < 2 + ntiles) {
+            if (c.chain_sync) { JH_CHECK_HIP(hipStreamSynchronize(c.stream)); JH_CHECK_HIP(hipFree(c.chain_sync)); c.chain_sync = nullptr; c.chain_sync_cap = 0; }
+            int64_t cap = 4096;
+            while (cap < 2 + ntiles) cap *= 2;
+            JH_CHECK_HIP(hipMalloc((void **)&c.chain_sync, sizeof(unsigned) * (size_t)cap));
+            c.chain_sync_cap = cap;
+            c.buf_gen++;
+        }
+        void *wpart = nullptr;
+        JH_TRY(jh_ensure_scratch(2 * (size_t)span * sizeof(S), &wpart));
+        JH_TRY(jh_ensure_partials(ntiles * nchunks));
+        JH_CHECK_HIP(hipMemsetAsync(c.chain_sync, 0, sizeof(unsigned) * (size_t)(2 + ntiles), c.stream));   // ticket counter + flags
+        unsigned *err = reinterpret_cast<unsigned *>(c.red_dev + JH_CHAIN_ERR_SLOT);
+#define JH_CHAIN(BLK)                                                                                                     \
+    hipLaunchKernelGGL((k_tall_diag_bidiag_chain<S, E, NS, 1, CD, BLK>), dim3((unsigned)(ntiles * nchunks)), dim3(BLK), 0, c.stream, \
+                       op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars, (S)alpha, (S)beta,   \
+                       c.part_dev, s_begin, s_end, (unsigned)ntiles, (unsigned)nchunks, c.chain_sync, (S *)wpart, err)
+        if (cb == 1024) JH_CHAIN(1024);
+        else if (cb == 512) JH_CHAIN(512);
+        else JH_CHAIN(256);
+#undef JH_CHAIN
+        JH_CHECK_HIP(hipGetLastError());
+        c.last_step_chain = nchunks;
+        c.last_adj_parts = 1;
+        double part = 0.0;
+        const int st_ = finish_normsq(ntiles * nchunks, normsq ? &part : nullptr, defer);
+        if (st_ == JH_OK && normsq) *normsq = part;
+        return trial_done(st_);
+    }
+    c.last_step_chain = 0;
 #define JH_LAUNCH(BLK, UU, DD) JH_LAUNCH_M(BLK, UU, DD, false)
 #define JH_LAUNCH_M(BLK, UU, DD, MIX)                                                                                   \
     if (wg == BLK && U == UU && D == DD && mixed == MIX) {                                                              \
         double total = 0.0;                                                                                              \
+        const bool several = rows_per_launch < op->nrow && normsq != nullptr;   /* one read-back for all the launches */     \
+        if (several) JH_CHECK_HIP(hipMemsetAsync(c.red_dev + 9, 0, sizeof(double), c.stream));                           \
         for (int64_t r0 = 0; r0 < op->nrow; r0 += rows_per_launch) {                                                     \
             const int64_t r1 = r0 + rows_per_launch < op->nrow ? r0 + rows_per_launch : op->nrow;                          \
             hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK, MIX>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, \
@@ -1896,9 +2084,14 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
             JH_CHECK_HIP(hipGetLastError());                                                                             \
             if (parts > 1) JH_TRY((launch_fold_parts<S, NS>(slabs, part_stride, parts, w, s_begin, s_end)));              \
             double part = 0.0;                                                                                           \
-            const int st_ = finish_normsq(gx * parts, normsq ? &part : nullptr, defer);                                  \
+            const int st_ = finish_normsq(gx * parts, normsq ? &part : nullptr, defer, several ? 9 : -1);                \
             if (st_ != JH_OK) return trial_done(st_);                                                                    \
             total += part;                                                                                               \
+        }                                                                                                                \
+        if (several) {                                                                                                   \
+            JH_CHECK_HIP(hipMemcpyAsync(c.red_host + 7, c.red_dev + 9, sizeof(double), hipMemcpyDeviceToHost, c.stream)); \
+            JH_CHECK_HIP(hipStreamSynchronize(c.stream));                                                                \
+            total = c.red_host[7];                                                                                       \
         }                                                                                                                \
         if (normsq) *normsq = total;                                                                                     \
         return trial_done(JH_OK);                                                                                        \
@@ -2700,7 +2893,7 @@ int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value)
     else if (!strcmp(name, "fwd_trials")) *value = op->fwd_tune.launched;
     else if (!strcmp(name, "step_trials")) *value = op->step_tune.launched;
     else if (!strcmp(name, "upd_walk")) *value = op->upd_walk;
-    else if (!strcmp(name, "step_remap")) *value = op->step_remap;
+    else if (!strcmp(name, "step_mode")) *value = op->step_mode;
     else return jh_fail(JH_ERR_INVALID, "jh_blockop_tune_get: unknown per-operator knob '%s'", name);
     return JH_OK;
 }
@@ -2716,10 +2909,11 @@ int jh_blockop_tune_set(jh_blockop *op, const char *name, int64_t value)
         JH_REQUIRE(value >= -1 && value <= 1, "jh_blockop_tune_set: upd_walk must be -1, 0 or 1");
         op->upd_walk = (int)value;
         op->upd_trials = value < 0 ? 0 : 2;
-    } else if (!strcmp(name, "step_remap")) {
-        JH_REQUIRE(value >= -1 && value <= 1, "jh_blockop_tune_set: step_remap must be -1 (measure), 0 or 1");
+    } else if (!strcmp(name, "step_mode")) {
+        JH_REQUIRE(value >= -1 && value <= 2, "jh_blockop_tune_set: step_mode must be -1 (measure), 0 (plain walk), 1 (XCD-contiguous tiles) or 2 (chained row chunks)");
         lazy_reset(op->step_tune);
-        op->step_remap = (int)value;
+        op->step_span = 0;
+        op->step_mode = (int)value;
     } else return jh_fail(JH_ERR_INVALID, "jh_blockop_tune_set: unknown per-operator knob '%s'", name);
     return JH_OK;
 }
@@ -2738,9 +2932,10 @@ int jh_normsq_read(double *out)
     JH_REQUIRE(out, "jh_normsq_read: null output");
     jh_context &c = jh_ctx();
     JH_CHECK_HIP(hipMemcpyAsync(c.red_host + 6, c.red_dev + JH_NORMSQ_SLOT, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    JH_CHECK_HIP(hipMemcpyAsync(c.red_host + 3, c.red_dev + JH_CHAIN_ERR_SLOT, sizeof(double), hipMemcpyDeviceToHost, c.stream));
     JH_CHECK_HIP(hipStreamSynchronize(c.stream));
     *out = c.red_host[6];
-    return JH_OK;
+    return jh_chain_err_check();
 }
 
 int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double alpha, double beta, double *normsq)

@@ -19,6 +19,20 @@ jh_context &jh_ctx()
     return ctx;
 }
 
+// the sticky "hand-off poll expired" word of the chained step, as last copied to red_host[3]
+int jh_chain_err_check()
+{
+    jh_context &c = jh_ctx();
+    unsigned bits = 0;
+    memcpy(&bits, c.red_host + 3, sizeof(bits));
+    if (bits) {
+        (void)hipMemsetAsync(c.red_dev + JH_CHAIN_ERR_SLOT, 0, sizeof(double), c.stream);
+        memset(c.red_host + 3, 0, sizeof(double));
+        return jh_fail(JH_ERR_HIP, "one-pass step: a chained hand-off poll expired (results of that step are invalid); set jh_tune_set(\"step_chain\", 0)");
+    }
+    return JH_OK;
+}
+
 int jh_ensure_partials(int64_t n)
 {
     jh_context &c = jh_ctx();
@@ -105,7 +119,9 @@ int jh_init(int device)
     JH_CHECK_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
     c.stream = c.own_stream;
     JH_CHECK_HIP(hipMalloc((void **)&c.red_dev, sizeof(double) * 4 * JH_RED_SLOTS));
+    JH_CHECK_HIP(hipMemset(c.red_dev, 0, sizeof(double) * 4 * JH_RED_SLOTS));
     JH_CHECK_HIP(hipHostMalloc((void **)&c.red_host, sizeof(double) * 8, hipHostMallocDefault));
+    memset(c.red_host, 0, sizeof(double) * 8);
     c.device = device;
     c.ready = true;
     return JH_OK;
@@ -122,6 +138,7 @@ int jh_shutdown(void)
     if (c.red_dev) (void)hipFree(c.red_dev);
     if (c.part_dev) (void)hipFree(c.part_dev);
     if (c.scratch_dev) (void)hipFree(c.scratch_dev);
+    if (c.chain_sync) (void)hipFree(c.chain_sync);
     if (c.red_host) (void)hipHostFree(c.red_host);
     if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
     c = jh_context();
@@ -475,6 +492,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "graphs")) { c.graphs = value ? 1 : 0; }
     else if (!strcmp(name, "small_loop")) { c.small_loop = value ? 1 : 0; }
     else if (!strcmp(name, "force_dist")) { c.force_dist = value ? 1 : 0; }
+    else if (!strcmp(name, "step_chain")) { JH_REQUIRE(value >= -1 && value <= 1, "step_chain must be -1 (auto), 0 or 1"); c.step_chain = value; }
     else if (!strcmp(name, "general_xcd")) { JH_REQUIRE(value >= 0 && value <= 2, "general_xcd must be 0 (never), 1 (automatic) or 2 (always)"); c.general_xcd = value; }
     else if (!strcmp(name, "red_wgs")) { JH_REQUIRE(value >= 1 && value <= 1 << 20, "red_wgs out of range"); c.red_wgs = value; }
     else return jh_fail(JH_ERR_INVALID, "jh_tune_set: unknown knob '%s'", name);
@@ -501,6 +519,8 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "graphs")) *value = c.graphs;
     else if (!strcmp(name, "small_loop")) *value = c.small_loop;
     else if (!strcmp(name, "force_dist")) *value = c.force_dist;
+    else if (!strcmp(name, "step_chain")) *value = c.step_chain;
+    else if (!strcmp(name, "last_step_chain")) *value = c.last_step_chain;
     else if (!strcmp(name, "general_xcd")) *value = c.general_xcd;
     else if (!strcmp(name, "graph_replays")) *value = c.graph_replays;
     else if (!strcmp(name, "last_fwd_rows_per_wg")) *value = c.last_fwd_rows_per_wg;

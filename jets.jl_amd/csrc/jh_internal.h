@@ -40,6 +40,9 @@ struct jh_context {
     int64_t part_cap = 0;
     void *scratch_dev = nullptr;       // growable scratch: dtmp / mtmp of the per-block loop (src/Jets.jl:1013, 1037)
     size_t scratch_cap = 0;
+    unsigned *chain_sync = nullptr;    // chained one-pass step (k_tall_diag_bidiag_chain): [0] ticket counter, [1] unused, [2..] per-tile hand-off flags
+    int64_t chain_sync_cap = 0;
+    int64_t step_chain = -1;           // knob: one-pass step as chained row chunks: -1 automatic, 0 never, 1 always (when the shape allows)
     // tuning knobs (jh_tune_set)
     // 0 = pick from the problem size (jh_blockop.hip: pick_fwd_shape / pick_adj_shape)
     int64_t fwd_group = 0;             // block rows streamed per workgroup (tall forward)
@@ -65,11 +68,14 @@ struct jh_context {
     int64_t last_fwd_rows_per_wg = 0;  // block rows per workgroup of the most recent tall forward launch (read-only knob)
     int64_t last_adj_launches = 1;     // kernel launches of the most recent tall adjoint / fused normal call (read-only knob)
     int64_t last_fwd_walk = 0;         // grid walk used by the most recent tall forward launch (read-only knob)
+    int64_t last_step_chain = 0;       // row chunks of the most recent one-pass step (0: the plain walk) (read-only knob)
 };
 jh_context &jh_ctx();
 int jh_require_ready();
 
 constexpr int JH_RED_SLOTS = 4096;     // max workgroups in a reduction launch
+constexpr int JH_CHAIN_ERR_SLOT = 10;  // red_dev[10] (as an unsigned): sticky flag "a hand-off poll of the chained step ran into its bound" -- never expected;
+                                       // copied to red_host[3] and checked wherever ||u||^2 is read back
 constexpr int JH_NORMSQ_SLOT = 8;      // red_dev[8]: the deferred ||u||^2 accumulator (jh_normsq_reset / jh_normsq_read / jh_comm_allreduce_normsq)
 
 static inline size_t jh_dtype_size(int dtype)
@@ -149,17 +155,19 @@ struct jh_blockop {
         int launched = 0;
     };
     mutable LazyTune fwd_tune;               // tall forward: K_FWD_CANDIDATES shapes x 2 passes -> fwd_walk
-    mutable LazyTune step_tune;              // one-pass step: tile map off / on x 2 passes (+ a warm-up) -> step_remap
+    mutable LazyTune step_tune;              // one-pass step: plain / tile map / chained x 2 passes (+ a warm-up) -> step_mode
     mutable int upd_walk = -1;               // same for the fused forward update (timed on its first two real calls)
     mutable int upd_trials = 0;
     mutable float upd_ms[2] = {0.f, 0.f};
-    mutable int step_remap = -1;             // one-pass step: XCD-contiguous tiles? -1 untried (timed over the first five whole-vector calls), 0, 1
+    mutable int step_mode = -1;              // one-pass step: -1 untried (measured lazily over its first seven eligible calls), 0 plain walk, 1 XCD-contiguous tiles, 2 chained row chunks
+    mutable int64_t step_span = 0;           // the call shape (scalars per call) the trials are being run on
 
     int64_t diag_stride_elems = 0;
 };
 
 bool jh_blockop_tall_fast(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr);   // tall, all DIAG, equal 16-byte aligned blocks
 void jh_bcast_clear_cache();            // jh_bcast.hip: unload every JIT-compiled broadcast program (jh_shutdown)
+int jh_chain_err_check();               // jh_blockop.hip: fails loudly if the chained step's sticky error word (copied to red_host[3]) is set
 int jh_ensure_partials(int64_t n);     // grows ctx.part_dev to >= n doubles (may synchronise + reallocate)
 // vecops entry used by blockop for generic pieces
 int jh_launch_fill_range(void *ptr, int dtype, int64_t count, double re, double im);

@@ -80,6 +80,7 @@ __device__ inline unsigned tile_of(unsigned bid, unsigned ntiles, int remap)
 
 // optional per-workgroup timeline (diagnostic builds of the harness only): start / end in 100 MHz ticks
 __device__ unsigned long long *g_stamps = nullptr;
+__device__ unsigned *g_ticket = nullptr;
 __device__ inline void stamp(int which)
 {
     if (g_stamps && threadIdx.x == 0) g_stamps[2 * blockIdx.x + which] = __builtin_amdgcn_s_memrealtime();
@@ -92,7 +93,13 @@ __global__ __launch_bounds__(BLK) void k_bidiag_base(const float *__restrict__ a
                                                      double *__restrict__ partials, int remap, int64_t ld)
 {
     stamp(0);
-    const unsigned tile = tile_of(blockIdx.x, gridDim.x, remap);
+    unsigned tile;
+    if (remap == -3) {                                          // tile = order of ARRIVAL (a ticket), not the workgroup id
+        __shared__ unsigned s_t;
+        if (threadIdx.x == 0) s_t = atomicAdd(g_ticket, 1u);
+        __syncthreads();
+        tile = s_t;
+    } else tile = tile_of(blockIdx.x, gridDim.x, remap);
     n = ld;
     const int64_t s0 = ((int64_t)tile * U * BLK + threadIdx.x) * 4;
     int64_t sk[U];
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(BLK) void k_bidiag_base(const float *__restrict__ a
         }
 #pragma unroll
     for (int k = 0; k < U; k++) stg<false>(reinterpret_cast<V4 *>(w + sk[k]), acc[k]);
-    wg_sum_store<BLK>(nrm, partials + blockIdx.x);
+    wg_sum_store<BLK>(nrm, partials + tile);
     stamp(1);
 }
 
@@ -243,6 +250,188 @@ __global__ __launch_bounds__(BLK) void k_bidiag_pipe(const float *__restrict__ a
     for (int k = 0; k < U; k++) stg<false>(reinterpret_cast<V4 *>((char *)w + off[k]), acc[k]);
     wg_sum_store<BLK>(nrm, partials + blockIdx.x);
     stamp(1);
+}
+
+// ---------------------------------------------------------------- one-pass step: chained row chunks ------------------
+// The drain of the last workgroup round costs 1.5-3.5 % because a workgroup lives for ALL rows.  Here the rows are cut into C
+// chunks; workgroup (c, tile) continues the ORDERED sum of (c-1, tile) -- same bits -- handed over through memory: the partial
+// w goes out with write-through (sc1) stores, the producer drains them and raises flag[tile]; the consumer polls the flag with
+// sc1 loads and reads the partial with sc1 loads (MI355X_MICROARCH.md, valid forms of the inter-workgroup hand-off).  Logical
+// ids come from a ticket counter, so a consumer only ever waits for a workgroup that has already STARTED (no deadlock whatever
+// the dispatch order), and the poll is bounded (an error flag instead of a hang).
+__device__ inline V4 ld_sc1(const float *p)
+{
+    V4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ inline void st_sc1(float *p, V4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");   // s_nop: the store reads its data VGPRs a wait state after issue
+}
+
+template <int U, int DEPTH, int BLK>
+__global__ __launch_bounds__(BLK) void k_bidiag_chain(const float *__restrict__ a, float *__restrict__ u, const float *__restrict__ v,
+                                                      float *__restrict__ w, int64_t n, int64_t nrow, float alpha, float beta,
+                                                      double *__restrict__ partials, unsigned ntiles, int nchunks, unsigned *__restrict__ sync,
+                                                      float *__restrict__ wpart, int64_t ld, int reuse)
+{
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&sync[0], 1u);              // sync[0]: ticket counter, sync[1]: error flag, sync[2..]: per-tile flags
+    __syncthreads();
+    const unsigned ticket = s_ticket;
+    const unsigned chunk = ticket / ntiles, tile = ticket - chunk * ntiles;
+    const int64_t rows_per = (nrow + nchunks - 1) / nchunks;
+    const int64_t row0 = (int64_t)chunk * rows_per, row1 = (row0 + rows_per < nrow) ? row0 + rows_per : nrow;
+    uint32_t off[U];
+    V4 acc[U], vv[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        off[k] = (uint32_t)((((int64_t)tile * U + k) * BLK + threadIdx.x) * 16);
+        vv[k] = ldg<false>(reinterpret_cast<const V4 *>((const char *)v + off[k]));
+        acc[k] = (V4)0.f;
+    }
+    const int64_t row_bytes = ld * 4;                                       // rows are ld elements apart; vectors (v, w, partials) have n elements
+    double nrm = 0.0;
+    // issue the first batch's loads BEFORE waiting for the predecessor: the wait hides behind them
+    V4 av[DEPTH][U], uv[DEPTH][U];
+    int64_t i = row0;
+    const bool first_full = i + DEPTH <= row1;
+    if (first_full) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                av[j][k] = ldg<true>(reinterpret_cast<const V4 *>((const char *)a + (i + j) * row_bytes + off[k]));
+                uv[j][k] = ldg<true>(reinterpret_cast<const V4 *>((const char *)u + (i + j) * row_bytes + off[k]));
+            }
+    }
+    if (chunk > 0) {
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&sync[2 + tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 20)) { atomicExch(&sync[1], 1u); break; }     // never hang: flag the failure and go on
+            }
+        }
+        __syncthreads();
+        const float *src = wpart + (int64_t)(reuse ? ((chunk - 1) & 1) : (chunk - 1)) * n;   // reuse: two alternating buffers; else one per hand-off
+#pragma unroll
+        for (int k = 0; k < U; k++) acc[k] = ld_sc1((const float *)((const char *)src + off[k]));
+    }
+    auto combine = [&](int64_t ii) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                V4 t = av[j][k] * vv[k];
+                V4 r = (V4)alpha * t;
+                V4 s2 = (V4)beta * uv[j][k];
+                r = r + s2;
+                stg<true>(reinterpret_cast<V4 *>((char *)u + (ii + j) * row_bytes + off[k]), r);
+                nrm += vnorm2(r);
+                acc[k] = acc[k] + av[j][k] * r;
+            }
+    };
+    if (first_full) { combine(i); i += DEPTH; }
+    for (; i + DEPTH <= row1; i += DEPTH) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                av[j][k] = ldg<true>(reinterpret_cast<const V4 *>((const char *)a + (i + j) * row_bytes + off[k]));
+                uv[j][k] = ldg<true>(reinterpret_cast<const V4 *>((const char *)u + (i + j) * row_bytes + off[k]));
+            }
+        combine(i);
+    }
+    for (; i < row1; i++)
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            V4 a1 = ldg<true>(reinterpret_cast<const V4 *>((const char *)a + i * row_bytes + off[k]));
+            V4 r = (V4)alpha * (a1 * vv[k]);
+            V4 s2 = (V4)beta * ldg<true>(reinterpret_cast<const V4 *>((const char *)u + i * row_bytes + off[k]));
+            r = r + s2;
+            stg<true>(reinterpret_cast<V4 *>((char *)u + i * row_bytes + off[k]), r);
+            nrm += vnorm2(r);
+            acc[k] = acc[k] + a1 * r;
+        }
+    if ((int)chunk + 1 < nchunks) {                                                 // hand the ordered partial sum on
+        float *dst = wpart + (int64_t)(reuse ? (chunk & 1) : chunk) * n;
+#pragma unroll
+        for (int k = 0; k < U; k++) st_sc1((float *)((char *)dst + off[k]), acc[k]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&sync[2 + tile], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+        for (int k = 0; k < U; k++) stg<false>(reinterpret_cast<V4 *>((char *)w + off[k]), acc[k]);
+    }
+    wg_sum_store<BLK>(nrm, partials + ticket);
+}
+
+// ---------------------------------------------------------------- adjoint: chained row chunks, one batch per workgroup --
+template <int U, int DEPTH, int BLK>
+__global__ __launch_bounds__(BLK) void k_adj_chain(const float *__restrict__ a, const float *__restrict__ d, float *__restrict__ m, int64_t n,
+                                                   int64_t nrow, unsigned ntiles, int nchunks, unsigned *__restrict__ sync, float *__restrict__ wpart)
+{
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&sync[0], 1u);
+    __syncthreads();
+    const unsigned ticket = s_ticket;
+    const unsigned chunk = ticket / ntiles, tile = ticket - chunk * ntiles;
+    const int64_t row0 = (int64_t)chunk * DEPTH, row1 = (row0 + DEPTH < nrow) ? row0 + DEPTH : nrow;
+    uint32_t off[U];
+    V4 acc[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) { off[k] = (uint32_t)((((int64_t)tile * U + k) * BLK + threadIdx.x) * 16); acc[k] = (V4)0.f; }
+    const int64_t row_bytes = n * 4;
+    V4 av[DEPTH][U], dv[DEPTH][U];
+    const bool full = row0 + DEPTH <= nrow;
+    if (full) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                av[j][k] = ldg<true>(reinterpret_cast<const V4 *>((const char *)a + (row0 + j) * row_bytes + off[k]));
+                dv[j][k] = ldg<true>(reinterpret_cast<const V4 *>((const char *)d + (row0 + j) * row_bytes + off[k]));
+            }
+    }
+    if (chunk > 0) {
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&sync[2 + tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 20)) { atomicExch(&sync[1], 1u); break; }
+            }
+        }
+        __syncthreads();
+        const float *src = wpart + (int64_t)((chunk - 1) & 1) * n;
+#pragma unroll
+        for (int k = 0; k < U; k++) acc[k] = ld_sc1((const float *)((const char *)src + off[k]));
+    }
+    if (full) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) acc[k] = acc[k] + av[j][k] * dv[j][k];
+    } else {
+        for (int64_t i = row0; i < row1; i++)
+#pragma unroll
+            for (int k = 0; k < U; k++)
+                acc[k] = acc[k] + ldg<true>(reinterpret_cast<const V4 *>((const char *)a + i * row_bytes + off[k])) *
+                                      ldg<true>(reinterpret_cast<const V4 *>((const char *)d + i * row_bytes + off[k]));
+    }
+    if ((int)chunk + 1 < nchunks) {
+        float *dst = wpart + (int64_t)(chunk & 1) * n;
+#pragma unroll
+        for (int k = 0; k < U; k++) st_sc1((float *)((char *)dst + off[k]), acc[k]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&sync[2 + tile], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+        for (int k = 0; k < U; k++) stg<false>(reinterpret_cast<V4 *>((char *)m + off[k]), acc[k]);
+    }
 }
 
 // ---------------------------------------------------------------- adjoint (MODE 0) pipelined ------------------------
@@ -420,7 +609,12 @@ template <typename K> static void bench_bidiag(const char *name, K kern, int U, 
     if (remap > 0 && gx % (8 * remap)) { printf("%-44s skipped (tiles %% 8c)\n", name); return; }
     // correctness from the reference start state
     CK(hipMemcpy(Uv, Uref, (size_t)std::min<int64_t>(NROW, 4) * LD * 4, hipMemcpyDeviceToDevice));   // first rows restored for the bit check
-    auto go = [&] { hipLaunchKernelGGL(kern, dim3(gx), dim3(BLK), 0, 0, A, Uv, Vv, Wv, N, NROW, 1.0f, -0.5f, P, remap, LD); };
+    static unsigned *ticket = nullptr;
+    if (!ticket) { CK(hipMalloc(&ticket, 64)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_ticket), &ticket, sizeof(ticket))); }
+    auto go = [&] {
+        if (remap == -3) CK(hipMemsetAsync(ticket, 0, 4, 0));
+        hipLaunchKernelGGL(kern, dim3(gx), dim3(BLK), 0, 0, A, Uv, Vv, Wv, N, NROW, 1.0f, -0.5f, P, remap, LD);
+    };
     // check on a 4-row operator slice (same kernel, nrow = min(NROW,4)) to keep the state reproducible
     {
         const int64_t keep = NROW;
@@ -492,7 +686,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&Vv, (size_t)N * 4));
     CK(hipMalloc(&Wv, (size_t)N * 4));
     CK(hipMalloc(&Wref, (size_t)N * 4));
-    CK(hipMalloc(&P, sizeof(double) * (1 << 20)));
+    CK(hipMalloc(&P, sizeof(double) * (1 << 23)));      // up to 8 M workgroups (chained variants: tiles x chunks)
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, A, NROW * LD, 1ull);
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, Uv, NROW * LD, 3ull);
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, Vv, N, 2ull);
@@ -514,10 +708,81 @@ int main(int argc, char **argv)
             NROW = keep;
         }
 #define BASE(U, D, B) bench_bidiag("base  U" #U " D" #D " wg" #B, k_bidiag_base<U, D, B>, U, B, 0, T, want_w, want_u, reps)
+#define BASET(U, D, B) bench_bidiag("base  U" #U " D" #D " wg" #B " TICKET order", k_bidiag_base<U, D, B>, U, B, -3, T, want_w, want_u, reps)
 #define PIPE(U, D, B, L, S, R) bench_bidiag("pipe  U" #U " D" #D " wg" #B " remap" #R, k_bidiag_pipe<U, D, B, L, S>, U, B, R, T, want_w, want_u, reps)
-        BASE(1, 4, 512);
-        PIPE(1, 4, 512, true, true, 0); PIPE(1, 4, 512, true, true, -1); PIPE(1, 4, 512, true, true, -2);
-        PIPE(4, 2, 512, true, true, 0); PIPE(4, 2, 512, true, true, -2); PIPE(1, 4, 256, true, true, 0); PIPE(1, 4, 256, true, true, -2);
+        BASE(1, 4, 512); BASET(1, 4, 512); BASE(1, 4, 512); BASET(1, 4, 512); BASE(1, 4, 256); BASET(1, 4, 256); BASE(4, 2, 512); BASET(4, 2, 512);
+        PIPE(1, 4, 512, true, true, 0); PIPE(1, 4, 512, true, true, -1);
+        {   // chained row chunks
+            unsigned *sync;
+            float *wpart;
+            CK(hipMalloc(&sync, sizeof(unsigned) * (2 + (N / 4 / 256))));
+            CK(hipMalloc(&wpart, (size_t)256 * N * 4));
+            // full-size reference for the bit check: one base step from the initial u (NROW <= 256: 2 x 16 GiB at most)
+            float *Ufull = nullptr;
+            uint64_t ref_w = 0, ref_u = 0;
+            const bool full_check = NROW <= 256;
+            if (full_check) {
+                CK(hipMalloc(&Ufull, (size_t)NROW * LD * 4));
+                hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, Uv, NROW * LD, 3ull);
+                CK(hipMemcpy(Ufull, Uv, (size_t)NROW * LD * 4, hipMemcpyDeviceToDevice));
+                hipLaunchKernelGGL((k_bidiag_base<1, 4, 512>), dim3((unsigned)(N / 4 / 512)), dim3(512), 0, 0, A, Uv, Vv, Wv, N, NROW, 1.0f, -0.5f, P, 0, LD);
+                CK(hipDeviceSynchronize());
+                ref_w = checksum(Wv, N);
+                ref_u = checksum(Uv + (NROW - 1) * LD, 1 << 20) ^ checksum(Uv + (NROW / 2) * LD + 4096, 1 << 20);
+            }
+            auto chain = [&](const char *name, auto kern, int U, int BLK, int C, int reuse) {
+                const int64_t nvec = N / 4;
+                const unsigned ntiles = (unsigned)(nvec / ((int64_t)U * BLK));
+                if ((int64_t)ntiles * C > (1 << 23) || C > 256 || C > NROW) { printf("%-48s skipped (bounds)\n", name); return; }
+                auto go = [&] {
+                    CK(hipMemsetAsync(sync, 0, sizeof(unsigned) * (2 + ntiles), 0));
+                    hipLaunchKernelGGL(kern, dim3(ntiles * C), dim3(BLK), 0, 0, A, Uv, Vv, Wv, N, NROW, 1.0f, -0.5f, P, ntiles, C, sync, wpart, LD, reuse);
+                };
+                unsigned err = 0;
+                const char *verdict = "";
+                if (full_check) {
+                    CK(hipMemcpy(Uv, Ufull, (size_t)NROW * LD * 4, hipMemcpyDeviceToDevice));
+                    go();
+                    CK(hipDeviceSynchronize());
+                    const uint64_t cw = checksum(Wv, N);
+                    const uint64_t cu = checksum(Uv + (NROW - 1) * LD, 1 << 20) ^ checksum(Uv + (NROW / 2) * LD + 4096, 1 << 20);
+                    verdict = (cw == ref_w && cu == ref_u) ? "  bits ok (full size)" : "  WRONG BITS";
+                }
+                float med;
+                const float ms = T.run(go, reps, &med);
+                CK(hipMemcpy(&err, sync + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+                printf("%-48s min %8.3f ms  med %8.3f ms  %7.1f GB/s%s%s\n", name, ms, med, (3.0 * NROW * N + 2.0 * N) * 4 / ms / 1e6, verdict, err ? "  POLL TIMEOUT" : "");
+                fflush(stdout);
+            };
+#define CHAIN(U, D, B, C) chain("chain U" #U " D" #D " wg" #B " chunks" #C, k_bidiag_chain<U, D, B>, U, B, C, 0)
+#define CHAINR(U, D, B, C) chain("chain U" #U " D" #D " wg" #B " chunks" #C " 2 buffers", k_bidiag_chain<U, D, B>, U, B, C, 1)
+            {
+                const int r8 = (int)(NROW / 8), r16 = (int)(NROW / 16), r4 = (int)(NROW / 4), r32 = (int)(NROW / 32);   // chunks for 8 / 16 / 4 / 32 rows per workgroup
+                auto sweep = [&](int C) {
+                    if (C < 1) return;
+                    char nm[96];
+                    snprintf(nm, sizeof nm, "chain U1 D8 wg256 chunks%d", C); chain(nm, k_bidiag_chain<1, 8, 256>, 1, 256, C, 0);
+                    snprintf(nm, sizeof nm, "chain U1 D8 wg256 chunks%d 2 buffers", C); chain(nm, k_bidiag_chain<1, 8, 256>, 1, 256, C, 1);
+                    snprintf(nm, sizeof nm, "chain U1 D4 wg512 chunks%d 2 buffers", C); chain(nm, k_bidiag_chain<1, 4, 512>, 1, 512, C, 1);
+                    snprintf(nm, sizeof nm, "chain U1 D4 wg256 chunks%d 2 buffers", C); chain(nm, k_bidiag_chain<1, 4, 256>, 1, 256, C, 1);
+                    snprintf(nm, sizeof nm, "chain U4 D2 wg512 chunks%d 2 buffers", C); chain(nm, k_bidiag_chain<4, 2, 512>, 4, 512, C, 1);
+                    snprintf(nm, sizeof nm, "chain U2 D4 wg256 chunks%d 2 buffers", C); chain(nm, k_bidiag_chain<2, 4, 256>, 2, 256, C, 1);
+                    snprintf(nm, sizeof nm, "chain U1 D8 wg512 chunks%d 2 buffers", C); chain(nm, k_bidiag_chain<1, 8, 512>, 1, 512, C, 1);
+                };
+                (void)r32; (void)r4; (void)sweep;
+                chain("chain U1 D8  wg512  R8  2 buffers", k_bidiag_chain<1, 8, 512>, 1, 512, r8, 1);
+                chain("chain U1 D8  wg256  R8  2 buffers", k_bidiag_chain<1, 8, 256>, 1, 256, r8, 1);
+                chain("chain U1 D8  wg1024 R8  2 buffers", k_bidiag_chain<1, 8, 1024>, 1, 1024, r8, 1);
+                chain("chain U1 D16 wg256  R16 2 buffers", k_bidiag_chain<1, 16, 256>, 1, 256, r16, 1);
+                chain("chain U1 D16 wg512  R16 2 buffers", k_bidiag_chain<1, 16, 512>, 1, 512, r16, 1);
+                chain("chain U2 D8  wg256  R8  2 buffers", k_bidiag_chain<2, 8, 256>, 2, 256, r8, 1);
+                chain("chain U2 D8  wg512  R8  2 buffers", k_bidiag_chain<2, 8, 512>, 2, 512, r8, 1);
+                chain("chain U2 D4  wg512  R4  2 buffers", k_bidiag_chain<2, 4, 512>, 2, 512, r4, 1);
+                chain("chain U4 D4  wg256  R4  2 buffers", k_bidiag_chain<4, 4, 256>, 4, 256, r4, 1);
+                chain("chain U1 D8  wg512  R8  2 buffers", k_bidiag_chain<1, 8, 512>, 1, 512, r8, 1);
+            }
+            if (Ufull) CK(hipFree(Ufull));
+        }
     }
 
     if (which == "adj" || which == "all") {
@@ -539,10 +804,35 @@ int main(int argc, char **argv)
             printf("%-44s min %8.3f ms  med %8.3f ms  %7.1f GB/s %s\n", name, ms, med, (2.0 * NROW * N + N) * 4 / ms / 1e6, c == want ? "" : "WRONG BITS");
             fflush(stdout);
         };
+        unsigned *async_;
+        float *apart;
+        CK(hipMalloc(&async_, sizeof(unsigned) * (2 + (N / 4 / 256))));
+        CK(hipMalloc(&apart, (size_t)2 * N * 4));
+        auto runc = [&](const char *name, auto kern, int U, int DEPTH, int BLK) {
+            const int64_t nvec = N / 4;
+            if (nvec % ((int64_t)U * BLK)) return;
+            const unsigned ntiles = (unsigned)(nvec / ((int64_t)U * BLK));
+            const int C = (int)((NROW + DEPTH - 1) / DEPTH);
+            auto go = [&] {
+                CK(hipMemsetAsync(async_, 0, sizeof(unsigned) * (2 + ntiles), 0));
+                hipLaunchKernelGGL(kern, dim3(ntiles * (unsigned)C), dim3(BLK), 0, 0, A, D, M, N, NROW, ntiles, C, async_, apart);
+            };
+            go();
+            CK(hipDeviceSynchronize());
+            const uint64_t c = checksum(M, N);
+            unsigned err = 0;
+            CK(hipMemcpy(&err, async_ + 1, 4, hipMemcpyDeviceToHost));
+            float med;
+            const float ms = T.run(go, reps, &med);
+            printf("%-44s min %8.3f ms  med %8.3f ms  %7.1f GB/s %s%s\n", name, ms, med, (2.0 * NROW * N + N) * 4 / ms / 1e6, c == want ? "bits ok" : "WRONG BITS", err ? " POLL TIMEOUT" : "");
+            fflush(stdout);
+        };
 #define ADJ(U, D, B, P, R) run("adj   U" #U " D" #D " wg" #B " pipe" #P " remap" #R, k_adj<U, D, B, P>, U, B, R)
+#define ADJC(U, D, B) runc("adj chain U" #U " D" #D " wg" #B, k_adj_chain<U, D, B>, U, D, B)
         ADJ(4, 2, 1024, false, 0); ADJ(4, 4, 512, false, 0); ADJ(4, 2, 512, false, 0); ADJ(1, 4, 512, false, 0); ADJ(2, 4, 512, false, 0);
         ADJ(4, 2, 1024, true, 0); ADJ(4, 2, 512, true, 0); ADJ(1, 4, 512, true, 0); ADJ(2, 4, 512, true, 0); ADJ(2, 2, 512, true, 0); ADJ(1, 8, 512, true, 0);
-        ADJ(4, 2, 1024, false, 1); ADJ(4, 2, 512, true, 1); ADJ(1, 4, 512, true, 1); ADJ(2, 4, 512, false, 1);
+        ADJC(1, 8, 512); ADJC(1, 8, 1024); ADJC(1, 8, 256); ADJC(1, 16, 512); ADJC(1, 16, 256); ADJC(2, 8, 512); ADJC(2, 8, 256); ADJC(4, 4, 512); ADJC(4, 4, 256); ADJC(4, 8, 256);
+        ADJ(4, 2, 1024, false, 0);
     }
 
     if (which == "fwd" || which == "all") {
