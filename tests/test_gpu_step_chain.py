@@ -119,6 +119,27 @@ def test_step_mode_is_measured_per_operator_and_every_mode_has_the_same_bits(Jet
         check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, 0.75, -1.375, C.byref(out)))
         assert J.tune_get("last_step_chain") == chunks
         check_slices(u, f"mode {mode}")
+    # the chained walk again and again on the same buffers (hand-off buffers and flags are re-used from launch to launch and, in
+    # the pipelined multi-GPU form, from range to range): every repetition must have the bits of the ordered walk
+    J.op_tune_set(A, "step_mode", 2)
+    f32 = np.float32
+    for rep, (alpha, beta, vseed) in enumerate([(1.0, -0.5, 21), (0.5, 0.25, 22), (-1.25, 1.0, 23), (1.0, 0.0, 24)]):
+        v2 = J.rand(J.domain(A), seed=vseed, stream=0)
+        u = J.rand(J.range(A), seed=3, stream=rep)
+        check(lib.jh_normsq_reset())
+        q = n // 4
+        for r in range(4):                                        # four ranges, like the pipelined exchange
+            check(lib.jh_blockop_bidiag_step_range(nat.handle, u.handle, v2.handle, w.handle, alpha, beta, r * q, q, None))
+        check(lib.jh_normsq_read(C.byref(out)))
+        assert J.tune_get("last_step_chain") == 5
+        for off in (0, q - W, q, 2 * q + 8192, n - W):
+            hv = oracle.rng_u01(dt, vseed, 0, off, W)
+            ha = [oracle.rng_u01(dt, 1, 0, i * n + off, W) for i in range(nrow)]
+            hu = [oracle.rng_u01(dt, 3, rep, i * n + off, W) for i in range(nrow)]
+            want_u = [f32(alpha) * (a * hv) + f32(beta) * uu if beta else f32(alpha) * (a * hv) for a, uu in zip(ha, hu)]
+            assert_bits_equal(u._download(17 * n + off, W), want_u[17], f"repetition {rep}: u row 17 slice at {off}")
+            want_w = oracle.block_df_adj([[oracle.Block("diag", W, coeff=a)] for a in ha], [np.zeros(W, dt)], want_u)[0]
+            assert_bits_equal(w._download(off, W), want_w, f"repetition {rep}: w slice at {off}")
     J.op_tune_set(A, "step_mode", -1)                             # measure: 1 warm-up + 3 modes x 2 passes, one per real call
     seen = set()
     for _ in range(10):
