@@ -159,6 +159,11 @@ int jh_hadamard(jh_bvec *dst, const jh_bvec *x, const jh_bvec *y, int conj_x);
 typedef struct jh_bcast jh_bcast;
 int jh_bcast_check(const char *expr, int dtype, int nvec, int nscal);
 int jh_bcast_compile(const char *expr, int dtype, int nvec, int nscal, jh_bcast **out);
+/* Mixed element types (src/Jets.jl:899-904 pairs the blocks of every BlockArray operand whatever its eltype): bit k of real_mask
+ * says vector operand k of a COMPLEX program is REAL of the matching precision (Float32 in a ComplexF32 program, ...) -- a real
+ * mask or weight on a complex vector.  Real (x) complex arithmetic is Julia's: a*(x + iy) = (a*x) + i(a*y), a + z adds to the
+ * real part.  real_mask == 0 is jh_bcast_compile. */
+int jh_bcast_compile_mixed(const char *expr, int dtype, int nvec, int real_mask, int nscal, jh_bcast **out);
 int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, const double *scal_re_im);
 /* `count` broadcasts in one call (a tall nonlinear operator evaluates one per child: F(m) and point! are `count` launches
  * enqueued back to back instead of `count` trips through the host language).  Operand k's vectors and scalars follow

@@ -97,6 +97,7 @@ SYMBOLS = {
     "jh_hadamard": (_int, [_vp, _vp, _vp, _int]),
     "jh_bcast_check": (_int, [C.c_char_p, _int, _int, _int]),
     "jh_bcast_compile": (_int, [C.c_char_p, _int, _int, _int, _vpp]),
+    "jh_bcast_compile_mixed": (_int, [C.c_char_p, _int, _int, _int, _int, _vpp]),
     "jh_bcast_apply": (_int, [_vp, _vp, _vpp, _dblp]),
     "jh_bcast_apply_many": (_int, [_int, _vpp, _vpp, _vpp, _dblp]),
     "jh_bcast_destroy": (_int, [_vp]),

@@ -27,12 +27,25 @@ _programs = {}
 _scalar_ids = itertools.count()
 
 
-def _program(expr: str, dtype, nvec: int, nscal: int):
-    key = (expr, np.dtype(dtype).str, nvec, nscal)
+def _real_mask(dtype, vecs) -> int:
+    """Bit k set: operand k is REAL of the matching precision in a complex broadcast (a real mask on a complex vector,
+    src/Jets.jl:899-904).  Any other eltype mix is refused by the library."""
+    dt = np.dtype(dtype)
+    if dt.kind != "c":
+        return 0
+    real = np.dtype(np.float32 if dt == np.complex64 else np.float64)
+    return sum(1 << k for k, v in enumerate(vecs) if np.dtype(v.dtype) == real)
+
+
+def _program(expr: str, dtype, nvec: int, nscal: int, real_mask: int = 0):
+    key = (expr, np.dtype(dtype).str, nvec, nscal, real_mask)
     h = _programs.get(key)
     if h is None:
         h = C.c_void_p()
-        check(lib.jh_bcast_compile(expr.encode(), dtype_code(dtype), nvec, nscal, C.byref(h)))
+        if real_mask:
+            check(lib.jh_bcast_compile_mixed(expr.encode(), dtype_code(dtype), nvec, real_mask, nscal, C.byref(h)))
+        else:
+            check(lib.jh_bcast_compile(expr.encode(), dtype_code(dtype), nvec, nscal, C.byref(h)))
         _programs[key] = h
     return h
 
@@ -46,7 +59,7 @@ def pack_many(jobs):
     dsts = (C.c_void_p * max(len(jobs), 1))()
     xs, sc, keep = [], [], []
     for k, (dst, expr, vecs, scalars) in enumerate(jobs):
-        progs[k] = _program(expr, dst.dtype, len(vecs), len(scalars))
+        progs[k] = _program(expr, dst.dtype, len(vecs), len(scalars), _real_mask(dst.dtype, vecs))
         dsts[k] = dst.handle
         keep.append(dst)
         for v in vecs:
@@ -77,12 +90,7 @@ def broadcast_(dst: _DevVec, expr: str, vecs=(), scalars=()):
     """dst .= expr over x0..x{k-1} = elements of `vecs`, s0.. = `scalars` (converted to dst's eltype).  dst may alias
     any operand.  Every operation is rounded as written (-ffp-contract=off)."""
     vecs, scalars = list(vecs), list(scalars)
-    key = (expr, dst.dtype.str, len(vecs), len(scalars))
-    h = _programs.get(key)
-    if h is None:
-        h = C.c_void_p()
-        check(lib.jh_bcast_compile(expr.encode(), dtype_code(dst.dtype), len(vecs), len(scalars), C.byref(h)))
-        _programs[key] = h
+    h = _program(expr, dst.dtype, len(vecs), len(scalars), _real_mask(dst.dtype, vecs))
     hs = (C.c_void_p * max(len(vecs), 1))(*[v.handle for v in vecs])
     sc = (C.c_double * max(2 * len(scalars), 1))()
     for i, a in enumerate(scalars):

@@ -20,6 +20,7 @@
 struct jh_bcast {
     int dtype = JH_F32;
     int nvec = 0, nscal = 0;
+    int real_mask = 0;                  // bit k: vector operand k is REAL in a complex program (a real mask on a complex vector)
     hipModule_t module = nullptr;
     hipFunction_t fn_vec = nullptr;     // 16 bytes per lane (every operand 16-byte aligned)
     hipFunction_t fn_scalar = nullptr;  // one element per lane (views at odd offsets)
@@ -76,7 +77,7 @@ __device__ inline float sign(float a) { return (a > 0.f) - (a < 0.f); }
 __device__ inline double sign(double a) { return (a > 0.0) - (a < 0.0); }
 )SRC";
 
-std::string build_source(const std::string &expr, int dtype, int nvec, int nscal)
+std::string build_source(const std::string &expr, int dtype, int nvec, int nscal, int real_mask)
 {
     const bool is64 = (dtype == JH_F64 || dtype == JH_C64), cplx = jh_dtype_complex(dtype);
     const char *R = is64 ? "double" : "float";
@@ -88,6 +89,12 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
     s += "typedef R V __attribute__((ext_vector_type(" + std::to_string(NS) + ")));\n";
     s += "typedef const V __attribute__((address_space(1))) *gvp;\ntypedef V __attribute__((address_space(1))) *gvq;\n";
     s += "typedef const R __attribute__((address_space(1))) *gsp;\ntypedef R __attribute__((address_space(1))) *gsq;\n";
+    // a REAL operand of a complex program (src/Jets.jl:899-904 pairs blocks whatever their eltypes; Julia's real (x) complex
+    // arithmetic = the prelude's mixed operators): NS/2 reals per lane where the complex operands have NS/2 elements
+    if (cplx && NS / 2 > 1) s += "typedef R RV __attribute__((ext_vector_type(" + std::to_string(NS / 2) + ")));\n#define RGET(P, e) ((R)(P)[e])\n";
+    else s += "typedef R RV;\n#define RGET(P, e) ((R)(P))\n";
+    s += "typedef const RV __attribute__((address_space(1))) *grvp;\n";
+    auto is_real = [&](int k) { return cplx && ((real_mask >> k) & 1); };
     // element accessors on a pack
     if (!cplx) {
         s += "#define GET(P, e) ((T)(P)[e])\n#define PUT(P, e, val) (P)[e] = (R)(val)\n";
@@ -108,9 +115,13 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
     s += "    const long nvec = n_scalars / " + std::to_string(NS) + ";\n";
     s += "    const long stride = (long)gridDim.x * 256;\n";
     s += "    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {\n";
-    for (int k = 0; k < nvec; k++) s += "        const V X" + std::to_string(k) + " = __builtin_nontemporal_load((gvp)p" + std::to_string(k) + " + v);\n";
+    for (int k = 0; k < nvec; k++)
+        s += is_real(k) ? "        const RV X" + std::to_string(k) + " = __builtin_nontemporal_load((grvp)p" + std::to_string(k) + " + v);\n"
+                        : "        const V X" + std::to_string(k) + " = __builtin_nontemporal_load((gvp)p" + std::to_string(k) + " + v);\n";
     s += "        V r_;\n#pragma unroll\n        for (int e = 0; e < " + std::to_string(NS / E) + "; e++) {\n";
-    for (int k = 0; k < nvec; k++) s += "            const T x" + std::to_string(k) + " = GET(X" + std::to_string(k) + ", e);\n";
+    for (int k = 0; k < nvec; k++)
+        s += is_real(k) ? "            const R x" + std::to_string(k) + " = RGET(X" + std::to_string(k) + ", e);\n"
+                        : "            const T x" + std::to_string(k) + " = GET(X" + std::to_string(k) + ", e);\n";
     s += "            const T val_ = (T)(" + expr + ");\n            PUT(r_, e, val_);\n        }\n";
     s += "        __builtin_nontemporal_store(r_, (gvq)dst_ + v);\n    }\n}\n";
     // ---- 16 bytes per lane, batched: item blockIdx.y takes its destination, operands and scalars from device tables
@@ -134,10 +145,13 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
     s += "    for (long v = tile_ * 256 + threadIdx.x; v < nvec; v += stride) {\n";
     // an operand every item shares is loaded through the caches (bit k of shared_mask_), the streamed ones nontemporally
     for (int k = 0; k < nvec; k++)
-        s += "        const V X" + std::to_string(k) + " = ((shared_mask_ >> " + std::to_string(k) + ") & 1) ? *((gvp)p" + std::to_string(k) +
-             " + v) : __builtin_nontemporal_load((gvp)p" + std::to_string(k) + " + v);\n";
+        s += std::string("        const ") + (is_real(k) ? "RV" : "V") + " X" + std::to_string(k) + " = ((shared_mask_ >> " + std::to_string(k) + ") & 1) ? *((" +
+             (is_real(k) ? "grvp" : "gvp") + ")p" + std::to_string(k) + " + v) : __builtin_nontemporal_load((" + (is_real(k) ? "grvp" : "gvp") + ")p" +
+             std::to_string(k) + " + v);\n";
     s += "        V r_;\n#pragma unroll\n        for (int e = 0; e < " + std::to_string(NS / E) + "; e++) {\n";
-    for (int k = 0; k < nvec; k++) s += "            const T x" + std::to_string(k) + " = GET(X" + std::to_string(k) + ", e);\n";
+    for (int k = 0; k < nvec; k++)
+        s += is_real(k) ? "            const R x" + std::to_string(k) + " = RGET(X" + std::to_string(k) + ", e);\n"
+                        : "            const T x" + std::to_string(k) + " = GET(X" + std::to_string(k) + ", e);\n";
     s += "            const T val_ = (T)(" + expr + ");\n            PUT(r_, e, val_);\n        }\n";
     s += "        __builtin_nontemporal_store(r_, (gvq)dst_ + v);\n    }\n}\n";
     // ---- one element per lane
@@ -147,6 +161,8 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
     s += "    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nel; i += stride) {\n";
     for (int k = 0; k < nvec; k++) {
         const std::string i = std::to_string(k);
+        if (is_real(k)) s += "        const R x" + i + " = ((gsp)p" + i + ")[i];\n";
+        else
         s += cplx ? "        const T x" + i + "(((gsp)p" + i + ")[2 * i], ((gsp)p" + i + ")[2 * i + 1]);\n"
                   : "        const T x" + i + " = ((gsp)p" + i + ")[i];\n";
     }
@@ -159,9 +175,9 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
 std::mutex g_cache_mutex;
 std::map<std::string, jh_bcast *> g_cache;      // (dtype, nvec, nscal, expr) -> compiled program, shared by every handle
 
-int compile_code(const std::string &expr, int dtype, int nvec, int nscal, std::vector<char> &code)
+int compile_code(const std::string &expr, int dtype, int nvec, int nscal, std::vector<char> &code, int real_mask = 0)
 {
-    const std::string src = build_source(expr, dtype, nvec, nscal);
+    const std::string src = build_source(expr, dtype, nvec, nscal, real_mask);
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "jh_bcast.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return jh_fail(JH_ERR_HIP, "jh_bcast_compile: hiprtcCreateProgram failed");
@@ -190,14 +206,15 @@ int compile_code(const std::string &expr, int dtype, int nvec, int nscal, std::v
     return JH_OK;
 }
 
-int compile(const std::string &expr, int dtype, int nvec, int nscal, jh_bcast **out)
+int compile(const std::string &expr, int dtype, int nvec, int nscal, jh_bcast **out, int real_mask = 0)
 {
     std::vector<char> code;
-    JH_TRY(compile_code(expr, dtype, nvec, nscal, code));
+    JH_TRY(compile_code(expr, dtype, nvec, nscal, code, real_mask));
     jh_bcast *bc = new jh_bcast();
     bc->dtype = dtype;
     bc->nvec = nvec;
     bc->nscal = nscal;
+    bc->real_mask = real_mask;
     bc->expr = expr;
     hipError_t e = hipModuleLoadData(&bc->module, code.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&bc->fn_vec, bc->module, "jh_bcast_vec");
@@ -252,6 +269,28 @@ int jh_bcast_compile(const char *expr, int dtype, int nvec, int nscal, jh_bcast 
     return JH_OK;
 }
 
+int jh_bcast_compile_mixed(const char *expr, int dtype, int nvec, int real_mask, int nscal, jh_bcast **out)
+{
+    JH_TRY(jh_require_ready());
+    JH_REQUIRE(out, "jh_bcast_compile_mixed: null argument");
+    JH_TRY(check_request(expr, dtype, nvec, nscal));
+    JH_REQUIRE(real_mask >= 0 && real_mask < (1 << (nvec > 0 ? nvec : 1)) + (nvec == 0 ? 0 : 0), "jh_bcast_compile_mixed: real_mask has bits beyond the %d operands", nvec);
+    JH_REQUIRE(real_mask == 0 || jh_dtype_complex(dtype), "jh_bcast_compile_mixed: real operands only make a difference in a complex program");
+    if (real_mask == 0) return jh_bcast_compile(expr, dtype, nvec, nscal, out);
+    const std::string key = std::to_string(dtype) + "/" + std::to_string(nvec) + "/" + std::to_string(nscal) + "/r" + std::to_string(real_mask) + "/" + expr;
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) {
+        *out = it->second;
+        return JH_OK;
+    }
+    jh_bcast *bc = nullptr;
+    JH_TRY(compile(expr, dtype, nvec, nscal, &bc, real_mask));
+    g_cache[key] = bc;
+    *out = bc;
+    return JH_OK;
+}
+
 int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, const double *scal_re_im)
 {
     JH_TRY(jh_require_ready());
@@ -262,7 +301,8 @@ int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, co
     uintptr_t bits = (uintptr_t)dst->data;
     for (int k = 0; k < bc->nvec; k++) {
         JH_REQUIRE(x[k], "jh_bcast_apply: operand %d is null", k);
-        JH_REQUIRE(x[k]->dtype == bc->dtype, "jh_bcast_apply: operand %d has dtype %d, program compiled for %d", k, x[k]->dtype, bc->dtype);
+        const int want_dt = ((bc->real_mask >> k) & 1) ? (bc->dtype == JH_C32 ? JH_F32 : JH_F64) : bc->dtype;      // a real operand of a complex program
+        JH_REQUIRE(x[k]->dtype == want_dt, "jh_bcast_apply: operand %d has dtype %d, program compiled for %d", k, x[k]->dtype, want_dt);
         JH_REQUIRE(x[k]->length == dst->length, "jh_bcast_apply: operand %d has %lld elements, destination %lld (DimensionMismatch)", k,
                    (long long)x[k]->length, (long long)dst->length);
         bits |= (uintptr_t)x[k]->data;

@@ -615,8 +615,15 @@ def dot_product_test(op: JopLn, m, d, mmask=None, dmask=None):
     """lhs, rhs = dot_product_test(A, m, d; mmask, dmask)  (src/Jets.jl:1211-1226)."""
     mmask = ones(domain(op)) if mmask is None else mmask  # :1212
     dmask = ones(range_(op)) if dmask is None else dmask  # :1213
-    mm = hadamard_(_arr.similar(m), mmask, m)  # mmask .* m
-    dd = hadamard_(_arr.similar(d), dmask, d)  # dmask .* d
+    def masked(mask, x):  # mask .* x ; a REAL mask on a complex vector is a mixed-eltype broadcast (real (x) complex, Julia's rule)
+        if np.dtype(mask.dtype) != np.dtype(x.dtype):
+            from .broadcast import broadcast_
+
+            return broadcast_(_arr.similar(x), "x0*x1", [mask, x])
+        return hadamard_(_arr.similar(x), mask, x)
+
+    mm = masked(mmask, m)  # mmask .* m
+    dd = masked(dmask, d)  # dmask .* d
     ds = mul(op, mm)  # :1215
     ms = mul(adjoint(op), dd)  # :1216
     lhs = dot(mm, ms)  # :1218

@@ -315,7 +315,10 @@ function _emit(bc::Broadcast.Broadcasted, vecs, scals)
     op === nothing && error("broadcast of $(f) over device vectors is not supported")
     op in ("+", "-", "*", "/") ? (length(args) == 1 ? "($op$(args[1]))" : "(" * join(args, " $op ") * ")") : "$op(" * join(args, ", ") * ")"
 end
-const _bcast_programs = Dict{Tuple{String,DataType,Int,Int},Ptr{Cvoid}}()
+const _bcast_programs = Dict{Tuple{String,DataType,Int,Int,Int},Ptr{Cvoid}}()
+# bit k-1 set: vector leaf k is REAL of the matching precision in a complex broadcast (a real mask on a complex vector)
+_real_mask(::Type{T}, vecs) where {T<:Real} = 0
+_real_mask(::Type{Complex{R}}, vecs) where {R} = sum(Int[1 << (k - 1) for k = 1:length(vecs) if eltype(vecs[k]) === R])
 function _bcast!(dest::DevVec{T}, bc::Broadcast.Broadcasted) where {T}
     vecs, scals = Any[], Number[]
     expr = _emit(bc, vecs, scals)
@@ -325,9 +328,14 @@ function _bcast!(dest::DevVec{T}, bc::Broadcast.Broadcasted) where {T}
         check(ccall((:jh_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), handle(dest), hs[1]))
         return dest
     end
-    prog = get!(_bcast_programs, (expr, T, length(vecs), length(scals))) do
+    mask = _real_mask(T, vecs)
+    prog = get!(_bcast_programs, (expr, T, length(vecs), length(scals), mask)) do
         h = Ref{Ptr{Cvoid}}()
-        check(ccall((:jh_bcast_compile, LIB), Cint, (Cstring, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), expr, dtype_code(T), length(vecs), length(scals), h))
+        if mask == 0
+            check(ccall((:jh_bcast_compile, LIB), Cint, (Cstring, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), expr, dtype_code(T), length(vecs), length(scals), h))
+        else
+            check(ccall((:jh_bcast_compile_mixed, LIB), Cint, (Cstring, Cint, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), expr, dtype_code(T), length(vecs), mask, length(scals), h))
+        end
         h[]
     end
     sc = Cdouble[]

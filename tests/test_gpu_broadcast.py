@@ -167,3 +167,61 @@ def test_many_broadcasts_in_one_launch_equal_item_by_item(Jets, dt):
         Jets.broadcast_(v1.arrays[k], "x0*x0" if k % 2 else "x0 + x0", [u.arrays[k]])
     Jets.broadcast_many_((v2.arrays[k], "x0*x0" if k % 2 else "x0 + x0", [u.arrays[k]], []) for k in range(6))
     assert v2.to_numpy().tobytes() == v1.to_numpy().tobytes()
+
+
+@pytest.mark.parametrize("cdt,rdt", [(np.complex64, np.float32), (np.complex128, np.float64)])
+def test_real_operands_in_a_complex_broadcast(Jets, cdt, rdt):
+    """Mixed element types (src/Jets.jl:899-904 pairs blocks whatever their eltypes): a REAL mask / weight on a complex vector.
+    Real (x) complex is Julia's rule -- a*(x + iy) = (a*x) + i(a*y), a + z adds to the real part -- which is numpy's too, so the
+    fused kernel must give numpy's bits; 16-byte path, the one-element path (a view at an odd offset) and the batched entry."""
+    J = Jets
+    n = 4099
+    rs = np.random.RandomState(7)
+    hz = (rs.standard_normal(n) + 1j * rs.standard_normal(n)).astype(cdt)
+    hw = (rs.standard_normal(n) - 1j * rs.standard_normal(n)).astype(cdt)
+    ha = rs.standard_normal(n).astype(rdt)
+    hz[5] = cdt(complex(-0.0, -3.0))                                   # signed zeros through the mixed product
+    ha[5] = rdt(0.0)
+    z, w, a = J.from_numpy(hz), J.from_numpy(hw), J.from_numpy(ha)
+    out = J.zeros(J.JetSpace(cdt, n))
+    def rc_mul(r, c):                                                   # Julia: *(x::Real, z::Complex) = Complex(x*real(z), x*imag(z))
+        o = np.empty(c.shape, cdt)                                     # (numpy promotes the real to complex first: other signed zeros)
+        o.real, o.imag = r * c.real, r * c.imag
+        return o
+
+    J.broadcast_(out, "x0*x1", [a, z])
+    assert out.to_numpy().tobytes() == rc_mul(ha, hz).tobytes()
+    assert np.signbit(out.to_numpy()[5].real) and np.signbit(out.to_numpy()[5].imag)   # 0 * (-0 - 3i) = -0 - 0i
+    J.broadcast_(out, "x1*x0 + x2", [a, z, w])                         # operand order free: bit 0 is the real one
+    assert out.to_numpy().tobytes() == (rc_mul(ha, hz) + hw).astype(cdt).tobytes()
+    J.broadcast_(out, "(x0 + x1)*s0 - x0", [a, z], [2.0 - 0.5j])
+    want = ((ha + hz) * cdt(2.0 - 0.5j) - ha).astype(cdt)
+    np.testing.assert_allclose(out.to_numpy(), want, rtol=3e-6 if cdt == np.complex64 else 1e-14)
+    # a block vector with a real mask of the same block structure; the one-element kernel through views at odd offsets
+    R = J.JetBSpace([J.JetSpace(cdt, 33), J.JetSpace(cdt, 1000)])
+    Rm = J.JetBSpace([J.JetSpace(rdt, 33), J.JetSpace(rdt, 1000)])
+    bz, bm = J.from_numpy(hz[:1033], R), J.from_numpy(ha[:1033], Rm)
+    bo = J.zeros(R)
+    J.broadcast_(J.getblock(bo, 1), "x0*x1", [J.getblock(bm, 1), J.getblock(bz, 1)])   # block 1 starts at element 33: odd alignment
+    assert bo.to_numpy()[33:].tobytes() == rc_mul(ha[33:1033], hz[33:1033]).tobytes()
+    assert not bo.to_numpy()[:33].any()
+    # wrong mixes are refused
+    with pytest.raises(J.JetsHipError):
+        J.broadcast_(J.zeros(J.JetSpace(rdt, n)), "x0*x1", [a, z])     # a complex operand in a real program
+    other = J.from_numpy(ha.astype(np.float64 if rdt == np.float32 else np.float32))
+    with pytest.raises(J.JetsHipError):
+        J.broadcast_(out, "x0*x1", [other, z])                         # precision mismatch
+
+
+def test_dot_product_test_with_real_masks_on_a_complex_operator(Jets):
+    """dot_product_test(A, m, d; mmask, dmask) (src/Jets.jl:1211-1226) with REAL masks on complex vectors (test/runtests.jl:915-917
+    uses complex operators; a real mute mask is the common case in practice)."""
+    J = Jets
+    dt = np.complex64
+    spc = J.JetSpace(dt, 2048)
+    A = J.blockop([[J.JopDiagonal(J.rand(spc, seed=31, stream=i))] for i in range(4)])
+    m, d = J.rand(J.domain(A), seed=32), J.rand(J.range(A), seed=33)
+    mmask = J.from_numpy((np.arange(2048) % 3 != 0).astype(np.float32))
+    dmask = J.from_numpy((np.arange(4 * 2048) % 5 != 0).astype(np.float32), J.JetBSpace([J.JetSpace(np.float32, 2048)] * 4))
+    lhs, rhs = J.dot_product_test(A, m, d, mmask=mmask, dmask=dmask)
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs + rhs)
