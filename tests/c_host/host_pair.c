@@ -174,6 +174,46 @@ int main(void)
         CK(jh_bvec_destroy(xs));
     }
 
+    /* ---- round-2 entry points from plain C: the one-pass step on two element ranges with the deferred ||u||^2, the
+     *      partitioned solve (one rank, no communicator: equals the local solve), per-operator tune export / import */
+    {
+        jh_bvec *u = NULL, *v = NULL, *w = NULL, *w2 = NULL, *u2 = NULL;
+        CK(jh_bvec_create(NROW, lens, JH_F32, &u));
+        CK(jh_bvec_create(NROW, lens, JH_F32, &u2));
+        CK(jh_bvec_create(1, lens, JH_F32, &v));
+        CK(jh_bvec_create(1, lens, JH_F32, &w));
+        CK(jh_bvec_create(1, lens, JH_F32, &w2));
+        CK(jh_fill_uniform(u, 7, 0, 0));
+        CK(jh_fill_uniform(u2, 7, 0, 0));
+        CK(jh_fill_uniform(v, 8, 0, 0));
+        double whole = 0, ranged = 0;
+        CK(jh_blockop_bidiag_step(A, u, v, w, 0.75, -0.5, &whole));
+        const int64_t half = (n / 2) / 4 * 4;
+        CK(jh_normsq_reset());
+        CK(jh_blockop_bidiag_step_range(A, u2, v, w2, 0.75, -0.5, 0, half, NULL));
+        CK(jh_blockop_bidiag_step_range(A, u2, v, w2, 0.75, -0.5, half, n - half, NULL));
+        CK(jh_normsq_read(&ranged));
+        float *ha = malloc((size_t)n * sizeof(float)), *hb = malloc((size_t)n * sizeof(float));
+        REQUIRE(ha && hb, "host allocation");
+        CK(jh_download(w, 0, n, ha));
+        CK(jh_download(w2, 0, n, hb));
+        REQUIRE(memcmp(ha, hb, (size_t)n * sizeof(float)) == 0, "ranged one-pass step == whole step (w)");
+        REQUIRE(fabs(whole - ranged) <= 1e-12 * whole, "deferred ||u||^2 of the ranges adds up");
+        free(ha); free(hb);
+        int64_t walk = 99;
+        CK(jh_blockop_tune_get(A, "fwd_walk", &walk));
+        REQUIRE(walk == -1, "a small operator's forward walk is not measured");
+        CK(jh_blockop_tune_set(A, "step_mode", 0));
+        CK(jh_blockop_tune_get(A, "step_mode", &walk));
+        REQUIRE(walk == 0, "per-operator tune round trip");
+        REQUIRE(jh_blockop_tune_set(A, "no_such_knob", 1) == JH_ERR_INVALID, "unknown per-operator knob is reported");
+        jh_lsqr_result lr;
+        CK(jh_fill(v, 0.0, 0.0));
+        CK(jh_lsqr_solve_partitioned(A, u, v, 0, 0.0, 0.0, 0.0, 0.0, 5, 1, &lr, NULL));
+        REQUIRE(lr.itn == 5, "partitioned solve with one rank runs without a communicator");
+        CK(jh_bvec_destroy(u)); CK(jh_bvec_destroy(u2)); CK(jh_bvec_destroy(v)); CK(jh_bvec_destroy(w)); CK(jh_bvec_destroy(w2));
+    }
+
     CK(jh_blockop_destroy(A));
     CK(jh_bvec_destroy(coeff));
     CK(jh_bvec_destroy(d));
