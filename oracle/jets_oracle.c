@@ -1,6 +1,6 @@
 /* jets_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY; see jets_oracle.h for the rules).
  * Plain-C restatement of the block-operator mul! path of /root/reference/src/Jets.jl.
- * Build: see oracle/Makefile (gcc -O3 -ffp-contract=off: no FMA contraction, so a product is
+ * Build: see oracle/Makefile (gcc -O2 -ftree-vectorize -ffp-contract=off: no FMA contraction, so a product is
  * rounded before it is added, exactly like the reference's two-pass `.+= mul!(tmp, ...)`). */
 #include "jets_oracle.h"
 #include <complex.h>

@@ -15,9 +15,14 @@
  * identities (test/runtests.jl:512-551, 553-600, 602-620, 622-695, 704-758, 789-795,
  * 901-918) re-encoded in tests/test_oracle_*.py with an independent numpy closed form
  * (the role Julia's plain matrices play in those tests), and against the literal-valued
- * checks at test/runtests.jl:518-526.  Intra-block summation order of dot/norm is
- * Julia-stdlib/BLAS defined (not part of the reference source) => tolerance parity only
- * for reductions; everything else is bit-exact by construction.
+ * checks at test/runtests.jl:518-526.  Since round 2 the hot loops (JetBlock_df!, JetBlock_df'!,
+ * the (A', A) composite, JetSum) are ALSO pinned by known answers that do not come from this
+ * file: tests/golden/make_known_answers.py derives them from the reference's source lines with
+ * exact rational arithmetic and an IEEE round-to-nearest-even of its own (exact-integer and
+ * order-revealing cases), and tests/test_known_answers.py requires this oracle to reproduce
+ * every one bit for bit.  Intra-block summation order of dot/norm is Julia-stdlib/BLAS defined
+ * (not part of the reference source) => tolerance parity only for reductions; everything else is
+ * bit-exact by construction.  There is no run of the reference itself behind any of this.
  */
 #ifndef JETS_ORACLE_H
 #define JETS_ORACLE_H
