@@ -93,6 +93,7 @@ def _worker(rank, world, port, backend, out_dir):
             return box[0]
 
         comm = J.rowpart.AbiComm(world, rank, exchange_id=exchange_id)
+        os.environ["JETS_AR_CHUNKS"] = "4"                        # the ABI's pipelined exchange: ranged all-reduces on its own stream + jh_comm_join
         shard_b = J.rowpart.for_device(part, A, comm=comm)
         out["mt_abi"] = shard_b.mul_adj_(J.rand(J.domain(A), seed=7, stream=rank), d).to_numpy().ravel(order="F")
         out["nrm_abi"] = shard_b.norm_range(d, 2)
