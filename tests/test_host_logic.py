@@ -249,3 +249,24 @@ def test_broadcast_expressions_cross_compile_without_a_device():
     e = 2.0 * J.lazy(3.0) + J.bc.exp(J.lazy(1.0))
     code, vecs, scal = e.program()
     assert code == "((s0 * s1) + exp(s2))" and vecs == [] and scal == [2.0, 3.0, 1.0]
+
+
+def test_bench_self_spawn_propagates_a_failing_rank_without_a_gpu():
+    """`python bench.py --gpus 2` with no launcher spawns its ranks before any GPU call; on a box without a GPU every rank exits
+    with "no MI355X visible", and the parent must relay that as a non-zero exit and print no JSON line (CPU-only check of the
+    spawn / reap logic; the GPU suite runs the successful flow)."""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible: the GPU suite covers the self-spawned flow")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                         text=True, timeout=120, env=env, cwd=ROOT)
+    assert out.returncode != 0
+    assert "no MI355X visible" in out.stderr and "stopping the other ranks" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
