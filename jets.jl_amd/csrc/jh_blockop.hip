@@ -594,7 +594,7 @@ __device__ inline unsigned __attribute__((ext_vector_type(4))) ld_sc1_16(const v
     return v;
 }
 
-template <typename S, int E, int NS, int U, int DEPTH, int BLK>
+template <typename S, int E, int NS, int U, int DEPTH, int BLK, bool MIXED = false>
 __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                                 const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ u,
                                                                 const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, S alpha,
@@ -623,13 +623,21 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
     const bool use_old = (beta != (S)0);
     const bool full = row0 + DEPTH <= nrow;
     V av[DEPTH][U], uv[DEPTH][U];
+    jh_dev_block blk[MIXED ? DEPTH : 1];                                    // MIXED: rows of any elementwise kind (as in k_tall_diag_bidiag)
     if (full) {                                                             // the batch's loads go out BEFORE the wait for the predecessor
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) {
-            const S *a = a_base ? a_base + (row0 + j) * a_stride : (const S *)blocks[row0 + j].coeff;
+            const S *a;
+            bool rc = true;
+            if constexpr (MIXED) {
+                blk[j] = blocks[row0 + j];
+                a = (const S *)blk[j].coeff;
+                rc = block_reads_coeff(blk[j], false);
+            } else
+                a = a_base ? a_base + (row0 + j) * a_stride : (const S *)blocks[row0 + j].coeff;
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                av[j][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+                av[j][k] = rc ? ld<true>(reinterpret_cast<const V *>(a + sk[k])) : (V)(S)0;
                 uv[j][k] = use_old ? ld<true>(reinterpret_cast<const V *>(u + (row0 + j) * n_scalars + sk[k])) : (V)(S)0;
             }
         }
@@ -653,25 +661,40 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
         for (int j = 0; j < DEPTH; j++)
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                V t = vmul<S, E, NS, V>(av[j][k], vv[k], false);            // mul!(tmp, A_i, v)
+                V t;
+                bool on = true;
+                if constexpr (MIXED) {                                      // a ZERO row: tmp_i stays 0 (1022) and adds nothing to w (1047)
+                    on = blk[j].kind != JH_OP_ZERO;
+                    t = on ? apply_block_loaded<S, E, NS, V>(blk[j], vv[k], av[j][k], false, false) : (V)(S)0;
+                } else
+                    t = vmul<S, E, NS, V>(av[j][k], vv[k], false);          // mul!(tmp, A_i, v)
                 V r = (V)alpha * t;
                 if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; }     // u_i .= alpha*tmp .+ beta*u_i
                 st_nt_16(u + (row0 + j) * n_scalars + sk[k], __builtin_bit_cast(U4, r));
                 nrm += vnorm2<S, NS, V>(r);
-                acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, true);     // _m .+= conj(a_i) .* u_i   (1049)
+                if constexpr (MIXED) {
+                    if (on) acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk[j], r, av[j][k], true, false);
+                } else
+                    acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, true); // _m .+= conj(a_i) .* u_i   (1049)
             }
     } else {
         for (int64_t i = row0; i < row1; i++) {
-            const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
+            jh_dev_block b1;
+            if (MIXED || !a_base) b1 = blocks[i];
+            const S *a = (!MIXED && a_base) ? a_base + i * a_stride : (const S *)b1.coeff;
+            const bool on = !MIXED || b1.kind != JH_OP_ZERO, rc = !MIXED || block_reads_coeff(b1, false);
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                V a1 = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
-                V t = vmul<S, E, NS, V>(a1, vv[k], false);
+                V a1 = rc ? ld<true>(reinterpret_cast<const V *>(a + sk[k])) : (V)(S)0;
+                V t;
+                if constexpr (MIXED) t = on ? apply_block_loaded<S, E, NS, V>(b1, vv[k], a1, false, false) : (V)(S)0;
+                else t = vmul<S, E, NS, V>(a1, vv[k], false);
                 V r = (V)alpha * t;
                 if (use_old) { V s2 = (V)beta * ld<true>(reinterpret_cast<const V *>(u + i * n_scalars + sk[k])); r = r + s2; }
                 st_nt_16(u + i * n_scalars + sk[k], __builtin_bit_cast(U4, r));
                 nrm += vnorm2<S, NS, V>(r);
-                acc[k] = acc[k] + vmul<S, E, NS, V>(a1, r, true);
+                if constexpr (MIXED) { if (on) acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(b1, r, a1, true, false); }
+                else acc[k] = acc[k] + vmul<S, E, NS, V>(a1, r, true);
             }
         }
     }
@@ -2008,13 +2031,14 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     //   mode 2  chained row chunks (k_tall_diag_bidiag_chain): one batch of 8 rows per workgroup, the ordered sum handed from
     //           chunk to chunk -- same bits; 6.1-6.2 TB/s at 64-512 rows of 64 MiB where the plain walk gives 5.2-5.5 in most
     //           processes and the same in some, -2 ... +4 % at 1024 rows (profiles/ab_r02_step_chain.txt); rows of >= 16 MiB only
+    //           (rows of any elementwise kind: the MIXED instantiation, profiles/bench_mixed_rows_r02.txt)
     // All three compute the same bits.  A mode other than 0 stays only if it wins by 1 %.  Knob step_chain: -1 measure,
     // 0 never chain, 1 chain whenever the shape allows (tests); jh_blockop_tune_get/set "step_mode" exports / imports the choice.
     constexpr int CD = 8;                                                 // rows per chunk = rows in flight
     const int64_t span = s_end - s_begin, nchunks = (op->nrow + CD - 1) / CD;
     const bool knobs_free = !c.adj_wg && !c.adj_unroll && !c.adj_depth;
     int cb = 0;                                                           // chained: workgroup size (0: the shape does not allow it)
-    if (!mixed && !direct && parts == 1 && rows_per_launch == op->nrow && nchunks >= 2)
+    if (!direct && parts == 1 && rows_per_launch == op->nrow && nchunks >= 2)
         for (int b : {1024, 512, 256})
             if (span % ((int64_t)b * NS) == 0 && (c.step_chain == 1 || (b == 1024 && span / ((int64_t)b * NS) >= 1024 && op->nrow >= 16))) { cb = b; break; }
     const int64_t ntiles = cb ? span / ((int64_t)cb * NS) : 0;
@@ -2051,13 +2075,19 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
         JH_TRY(jh_ensure_partials(ntiles * nchunks));
         JH_CHECK_HIP(hipMemsetAsync(c.chain_sync, 0, sizeof(unsigned) * (size_t)(2 + ntiles), c.stream));   // ticket counter + flags
         unsigned *err = reinterpret_cast<unsigned *>(c.red_dev + JH_CHAIN_ERR_SLOT);
-#define JH_CHAIN(BLK)                                                                                                     \
-    hipLaunchKernelGGL((k_tall_diag_bidiag_chain<S, E, NS, 1, CD, BLK>), dim3((unsigned)(ntiles * nchunks)), dim3(BLK), 0, c.stream, \
+#define JH_CHAIN(BLK, MIX)                                                                                                \
+    hipLaunchKernelGGL((k_tall_diag_bidiag_chain<S, E, NS, 1, CD, BLK, MIX>), dim3((unsigned)(ntiles * nchunks)), dim3(BLK), 0, c.stream, \
                        op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars, (S)alpha, (S)beta,   \
                        c.part_dev, s_begin, s_end, (unsigned)ntiles, (unsigned)nchunks, c.chain_sync, (S *)wpart, err)
-        if (cb == 1024) JH_CHAIN(1024);
-        else if (cb == 512) JH_CHAIN(512);
-        else JH_CHAIN(256);
+        if (mixed) {
+            if (cb == 1024) JH_CHAIN(1024, true);
+            else if (cb == 512) JH_CHAIN(512, true);
+            else JH_CHAIN(256, true);
+        } else {
+            if (cb == 1024) JH_CHAIN(1024, false);
+            else if (cb == 512) JH_CHAIN(512, false);
+            else JH_CHAIN(256, false);
+        }
 #undef JH_CHAIN
         JH_CHECK_HIP(hipGetLastError());
         c.last_step_chain = nchunks;

@@ -84,6 +84,56 @@ def test_chained_step_has_the_bits_of_the_ordered_walk(Jets, oracle, dt, nrow, s
             J.tune(step_chain=-1)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow", [9, 16, 37])
+def test_chained_step_with_rows_of_several_kinds(Jets, oracle, dt, nrow):
+    """Zero, identity, scalar and adjointed rows inside the chained walk (the MIXED instantiation of k_tall_diag_bidiag_chain):
+    the bits of the oracle's unfused sequence, whole-vector and in two ranges -- e.g. LSQR on [A; lambda*I]."""
+    from jets_jl_amd._ffi import lib, check
+    from .test_gpu_mixed_rows import KINDS, _build
+
+    J = Jets
+    n = 4096
+    rs = np.random.RandomState(300 + nrow)
+    kinds = [KINDS[k] for k in rs.randint(0, len(KINDS), size=nrow)]
+    kinds[rs.randint(nrow)] = "zero"
+    kinds[-1] = "scale"                                        # the regularisation row sits in the ragged last chunk
+    A, ops = _build(J, oracle, dt, kinds, n, seed=70 + nrow)
+    nat = _native(J, A)
+    hv = u01(oracle, dt, 2, 0, n)
+    hu = [u01(oracle, dt, 3, i, n) for i in range(nrow)]
+    v = J.from_numpy(hv)
+    out = C.c_double(0)
+    for alpha, beta in ((0.75, -0.5), (1.0, 0.0)):
+        av = oracle.block_df(ops, [np.zeros(n, dt) for _ in range(nrow)], [hv])
+        want_u = oracle.barr_lincomb([np.empty(n, dt) for _ in range(nrow)], [alpha, beta], [av, hu]) if beta else \
+            oracle.barr_lincomb([np.empty(n, dt) for _ in range(nrow)], [alpha], [av])
+        want_w = oracle.block_df_adj(ops, [np.zeros(n, dt)], want_u)[0]
+        nrm = float(sum(np.vdot(b.astype(np.complex128), b.astype(np.complex128)).real for b in want_u))
+        try:
+            J.tune(step_chain=1)
+            u = J.from_numpy(np.concatenate(hu), J.range(A))
+            w = J.rand(J.domain(A), seed=9, stream=0)
+            check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, alpha, beta, C.byref(out)))
+            assert J.tune_get("last_step_chain") == (nrow + 7) // 8
+            assert_bits_equal(u.to_numpy(), np.concatenate(want_u), f"chained mixed step: u {kinds}")
+            assert_bits_equal(w.to_numpy().ravel(order="F"), want_w, f"chained mixed step: w {kinds}")
+            assert abs(out.value - nrm) <= 1e-12 * nrm
+            u2 = J.from_numpy(np.concatenate(hu), J.range(A))
+            w2 = J.rand(J.domain(A), seed=10, stream=0)
+            check(lib.jh_normsq_reset())
+            half = n // 2
+            check(lib.jh_blockop_bidiag_step_range(nat.handle, u2.handle, v.handle, w2.handle, alpha, beta, 0, half, None))
+            check(lib.jh_blockop_bidiag_step_range(nat.handle, u2.handle, v.handle, w2.handle, alpha, beta, half, n - half, None))
+            check(lib.jh_normsq_read(C.byref(out)))
+            assert J.tune_get("last_step_chain") == (nrow + 7) // 8
+            assert_bits_equal(u2.to_numpy(), np.concatenate(want_u), "chained mixed ranged step: u")
+            assert_bits_equal(w2.to_numpy().ravel(order="F"), want_w, "chained mixed ranged step: w")
+            assert abs(out.value - nrm) <= 1e-12 * nrm
+        finally:
+            J.tune(step_chain=-1)
+
+
 def test_step_mode_is_measured_per_operator_and_every_mode_has_the_same_bits(Jets, oracle):
     """40 x 256^3 Float32 (rows of 64 MiB: the chained walk is a candidate): the first seven calls each try one mode (plain,
     XCD-contiguous tiles, chained), then the choice is kept and can be exported / imported; slices of u and w vs the oracle under

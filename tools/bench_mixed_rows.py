@@ -69,7 +69,13 @@ for name, kinds, densify in cases:
     t_f = timed(lambda: J.mul_(d, A, m))
     t_a = timed(lambda: J.mul_(mt, A.H, d))
     t_n = timed(lambda: J.mul_(w, C_, m))
-    t_s = timed(lambda: check(lib.jh_blockop_bidiag_step(nat.handle, d.handle, m.handle, w.handle, 1.0, -0.5, C.byref(out))))
+    step = lambda: check(lib.jh_blockop_bidiag_step(nat.handle, d.handle, m.handle, w.handle, 1.0, -0.5, C.byref(out)))
+    J.op_tune_set(A, "step_mode", 0)
+    t_s = timed(step)
+    J.op_tune_set(A, "step_mode", 2)                                          # chained row chunks (rows of any elementwise kind)
+    t_c = timed(step)
+    chained = J.tune_get("last_step_chain") > 0
     print(f"{nrow} x {edge}^3  {name:28s} pair {t_f + t_a:8.3f} ms {b_pair / (t_f + t_a) / 1e6:7.1f} GB/s | A'A {t_n:7.3f} ms {b_normal / t_n / 1e6:7.1f} GB/s | "
-          f"one-pass step {t_s:7.3f} ms {b_step / t_s / 1e6:7.1f} GB/s", flush=True)
+          f"one-pass step {t_s:7.3f} ms {b_step / t_s / 1e6:7.1f} GB/s | chained {t_c:7.3f} ms {b_step / t_c / 1e6:7.1f} GB/s{'' if chained else ' (not taken)'}",
+          flush=True)
     J.close(A)
