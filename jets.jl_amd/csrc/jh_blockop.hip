@@ -469,12 +469,23 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
     if constexpr (MIXED) {
         // rows of any elementwise kind.  A ZERO row: mul!(tmp, A, v) into the zeros() temporary leaves tmp_i = 0 (1022), so
         // u_i <- alpha*0 + beta*u_i, and the row adds nothing to w (1047)
+        // the row table is read one batch AHEAD (scalar loads): a batch's coefficient loads need its descriptors, and waiting for
+        // them row by row cost 12 % at 1024 rows of 8 MiB (profiles/exp_r02_mixed_step_shapes.txt)
+        jh_dev_block blk[DEPTH], nxt[DEPTH];
+        if (i + DEPTH <= row1) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; j++) nxt[j] = blocks[i + j];
+        }
         for (; i + DEPTH <= row1; i += DEPTH) {
-            jh_dev_block blk[DEPTH];
             V av[DEPTH][U], uv[DEPTH][U];
+            const int64_t ahead = (i + 2 * DEPTH <= row1) ? i + DEPTH : i;
 #pragma unroll
             for (int j = 0; j < DEPTH; j++) {
-                blk[j] = blocks[i + j];
+                blk[j] = nxt[j];
+                nxt[j] = blocks[ahead + j];
+            }
+#pragma unroll
+            for (int j = 0; j < DEPTH; j++) {
                 const bool rc = block_reads_coeff(blk[j], false);
 #pragma unroll
                 for (int k = 0; k < U; k++) {
@@ -484,6 +495,21 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
             }
 #pragma unroll
             for (int j = 0; j < DEPTH; j++) {
+                if (blk[j].kind == JH_OP_DIAG) {                 // the common row: ONE branch per row, then the all-diagonal kernel's straight line
+                    const bool cj = blk[j].adjoint != 0;
+#pragma unroll
+                    for (int k = 0; k < U; k++) {
+                        const V t = vmul<S, E, NS, V>(av[j][k], vv[k], cj);
+                        V r = (V)alpha * t;
+                        if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; }
+                        if (ok[k]) {
+                            st<true>(reinterpret_cast<V *>(u + (i + j) * n_scalars + sk[k]), r);
+                            nrm += vnorm2<S, NS, V>(r);
+                        }
+                        acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, !cj);
+                    }
+                    continue;
+                }
                 const bool on = blk[j].kind != JH_OP_ZERO;
 #pragma unroll
                 for (int k = 0; k < U; k++) {
@@ -658,25 +684,35 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
     double nrm = 0.0;
     if (full) {
 #pragma unroll
-        for (int j = 0; j < DEPTH; j++)
-#pragma unroll
-            for (int k = 0; k < U; k++) {
-                V t;
-                bool on = true;
-                if constexpr (MIXED) {                                      // a ZERO row: tmp_i stays 0 (1022) and adds nothing to w (1047)
-                    on = blk[j].kind != JH_OP_ZERO;
-                    t = on ? apply_block_loaded<S, E, NS, V>(blk[j], vv[k], av[j][k], false, false) : (V)(S)0;
-                } else
-                    t = vmul<S, E, NS, V>(av[j][k], vv[k], false);          // mul!(tmp, A_i, v)
-                V r = (V)alpha * t;
-                if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; }     // u_i .= alpha*tmp .+ beta*u_i
-                st_nt_16(u + (row0 + j) * n_scalars + sk[k], __builtin_bit_cast(U4, r));
-                nrm += vnorm2<S, NS, V>(r);
-                if constexpr (MIXED) {
-                    if (on) acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk[j], r, av[j][k], true, false);
-                } else
-                    acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, true); // _m .+= conj(a_i) .* u_i   (1049)
+        for (int j = 0; j < DEPTH; j++) {
+            bool diag = true, cj = false, on = true;                        // MIXED: ONE branch per row; a DIAG row takes the straight line
+            if constexpr (MIXED) {
+                diag = blk[j].kind == JH_OP_DIAG;
+                cj = blk[j].adjoint != 0;
+                on = blk[j].kind != JH_OP_ZERO;                             // a ZERO row: tmp_i stays 0 (1022) and adds nothing to w (1047)
             }
+            if (diag) {
+#pragma unroll
+                for (int k = 0; k < U; k++) {
+                    V t = vmul<S, E, NS, V>(av[j][k], vv[k], cj);           // mul!(tmp, A_i, v)
+                    V r = (V)alpha * t;
+                    if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; } // u_i .= alpha*tmp .+ beta*u_i
+                    st_nt_16(u + (row0 + j) * n_scalars + sk[k], __builtin_bit_cast(U4, r));
+                    nrm += vnorm2<S, NS, V>(r);
+                    acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, !cj);  // _m .+= conj(a_i) .* u_i   (1049)
+                }
+            } else if constexpr (MIXED) {
+#pragma unroll
+                for (int k = 0; k < U; k++) {
+                    V t = on ? apply_block_loaded<S, E, NS, V>(blk[j], vv[k], av[j][k], false, false) : (V)(S)0;
+                    V r = (V)alpha * t;
+                    if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; }
+                    st_nt_16(u + (row0 + j) * n_scalars + sk[k], __builtin_bit_cast(U4, r));
+                    nrm += vnorm2<S, NS, V>(r);
+                    if (on) acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk[j], r, av[j][k], true, false);
+                }
+            }
+        }
     } else {
         for (int64_t i = row0; i < row1; i++) {
             jh_dev_block b1;
@@ -2002,8 +2038,16 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     if (c.adj_wg) wg = (int)c.adj_wg;                       // the adjoint's knobs select among the instantiated shapes
     if (c.adj_unroll) U = (int)c.adj_unroll;
     if (c.adj_depth) D = (int)c.adj_depth;
-    const bool mixed = !op->all_diag;                       // rows of several elementwise kinds (tall_mixed_ok): one instantiated shape
-    if (mixed) { if (nvec >= ((int64_t)1 << 22)) { wg = 512; U = 1; D = 4; } else { wg = 256; U = 2; D = 2; } }
+    const bool mixed = !op->all_diag;                       // rows of several elementwise kinds (tall_mixed_ok): four instantiated shapes
+    if (mixed) {
+        auto inst = [](int w_, int u_, int d_) { return (w_ == 512 && u_ == 1 && d_ == 4) || (w_ == 256 && ((u_ == 2 && d_ == 2) || (u_ == 4 && d_ == 1) || (u_ == 1 && d_ == 4))); };
+        if (!inst(wg, U, D)) {                              // the all-diagonal rule without the knobs, 512 threads always as 512 x 1 x 4
+            wg = 256; U = 1; D = 4;
+            if (nvec >= 4 * 256 * 256) { U = 4; D = 1; }
+            else if (nvec >= 2 * 256 * 256) { U = 2; D = 2; }
+            if (nvec >= ((int64_t)1 << 22)) { wg = 512; U = 1; D = 4; }
+        }
+    }
     const int64_t gx = ((s_end - s_begin) / NS + (int64_t)wg * U - 1) / ((int64_t)wg * U);
     // many rows of small blocks: split-row walk (pick_adj_parts): u's rows are updated as before, w's sum is folded from slabs
     int64_t parts = direct ? 1 : pick_adj_parts(gx, op->nrow);
@@ -2129,7 +2173,7 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     JH_LAUNCH(256, 1, 4) JH_LAUNCH(256, 2, 2) JH_LAUNCH(256, 4, 1) JH_LAUNCH(256, 4, 2) JH_LAUNCH(256, 1, 8)
     JH_LAUNCH(512, 1, 4) JH_LAUNCH(512, 2, 2) JH_LAUNCH(512, 4, 1) JH_LAUNCH(512, 4, 2) JH_LAUNCH(512, 1, 8)
     JH_LAUNCH(1024, 1, 4) JH_LAUNCH(1024, 2, 2) JH_LAUNCH(1024, 4, 1)      // 1024 x 4 x 2 would need > 128 VGPRs per lane
-    JH_LAUNCH_M(512, 1, 4, true) JH_LAUNCH_M(256, 2, 2, true)
+    JH_LAUNCH_M(512, 1, 4, true) JH_LAUNCH_M(256, 2, 2, true) JH_LAUNCH_M(256, 4, 1, true) JH_LAUNCH_M(256, 1, 4, true)
 #undef JH_LAUNCH
 #undef JH_LAUNCH_M
     return jh_fail(JH_ERR_INVALID, "fused bidiagonalisation step: shape %d x %d x %d is not instantiated", wg, U, D);
