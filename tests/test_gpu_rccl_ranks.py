@@ -58,3 +58,32 @@ def test_bench_self_spawns_its_ranks_over_rccl():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["multi_gpu"]["rccl_nranks"] == 2 and len(j["multi_gpu"]["per_rank"]) == 2
     assert j["lsqr"]["rel_err_vs_x_true"] < 1e-3
+
+
+def test_bench_rccl_path_with_one_rank():
+    """The bench's RCCL code path end to end on the one-GPU test box: a launcher-style environment with WORLD_SIZE=1 and
+    BENCH_FORCE_DIST=1 makes rank 0 initialise torch.distributed's "nccl" backend, run the pipelined adjoint exchange, the
+    multi-rank diagnostics and -- BENCH_LSQR_ABI=force -- jh_lsqr_solve_partitioned over the C ABI's own RCCL communicator.
+    What N > 1 adds to this is only more ranks inside the same calls."""
+    import json
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               BENCH_FORCE_DIST="1", BENCH_LSQR_ABI="force")
+    env.pop("BENCH_BACKEND", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--nblocks", "24",
+                          "--edge", "128", "--no-cpu-baseline", "--lsqr", "10"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    mg = j["multi_gpu"]
+    assert mg["backend"] == "nccl" and mg["rccl_nranks"] == 1 and mg["per_rank"][0]["rows"] == 24
+    assert mg["allreduce"]["bytes"] == 128 ** 3 * 4 and mg["allreduce"]["ms_standalone"] > 0
+    assert j["kernels"]["adjoint"]["kernel"].endswith("+allreduce")
+    ls = j["lsqr"]
+    assert ls["driver"].startswith("jh_lsqr_solve_partitioned") and ls["iterations"] == 10 and ls["rel_err_vs_x_true"] < 1e-3
