@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name: str) -> str:
-    for key in ("k_tall_diag_bidiag", "k_tall_diag_fwd_update", "k_tall_diag_adj_update", "k_tall_diag_fwd", "k_tall_diag_adj", "k_block_fwd_general", "k_block_adj_general", "k_uniform", "k_reduce_final",
+    for key in ("k_tall_diag_bidiag_chain", "k_tall_diag_bidiag", "k_tall_diag_fwd_update", "k_tall_diag_adj_update", "k_tall_diag_fwd", "k_tall_diag_adj", "k_block_fwd_general", "k_block_adj_general", "k_uniform", "k_reduce_final",
                 "k_reduce", "k_lincomb", "k_hadamard", "k_fill", "k_gemv", "k_sum_partials"):
         if key in name:
             return key
@@ -62,7 +62,8 @@ def main():
     write, nw = counters(args.write, "WRITE_SIZE") if args.write else ({}, {})
     n = args.edge ** 3
     algo = {"k_tall_diag_fwd": (2 * args.nblocks * n + n) * 4, "k_tall_diag_adj": (2 * args.nblocks * n + n) * 4,
-            "k_tall_diag_bidiag": (3 * args.nblocks * n + 2 * n) * 4, "k_tall_diag_fwd_update": (3 * args.nblocks * n + n) * 4, "k_tall_diag_adj_update": (2 * args.nblocks * n + 2 * n) * 4}
+            "k_tall_diag_bidiag": (3 * args.nblocks * n + 2 * n) * 4, "k_tall_diag_bidiag_chain": (3 * args.nblocks * n + 2 * n) * 4,
+            "k_tall_diag_fwd_update": (3 * args.nblocks * n + n) * 4, "k_tall_diag_adj_update": (2 * args.nblocks * n + 2 * n) * 4}
     algo["k_tall_diag_adj"] //= args.adj_launches
     lines = [f"# rocprofv3 summary, round {args.round}", "",
              f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- {args.cmd}` on one MI355X (gfx950);",
