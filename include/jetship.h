@@ -15,9 +15,18 @@
  *    it into `error(msg)`, src/Jets.jl:131,179,1116).
  *  - Block indices and element offsets are 0-based here; the Julia wrapper converts (1-based
  *    inclusive ranges of src/Jets.jl:742-748  <->  offset = start-1, len = stop-start+1).
- *  - One process drives one GPU (jh_init(device)).  All work is enqueued on one HIP stream
- *    (jh_get_stream/jh_set_stream); functions return after enqueue, except those that return a
- *    scalar or copy to host memory, which synchronise the stream first.
+ *  - A CONTEXT is one GPU + one HIP stream + the library's workspaces and knobs for it.  jh_init(device)
+ *    creates the device's primary context; the usual deployment is one process per GPU with exactly
+ *    that one.  One process may also drive SEVERAL GPUs (a single Julia session):
+ *    jh_init on each device (or jh_context_create for extra contexts), and every handle remembers the
+ *    context it was created in -- an entry point that takes handles switches to THEIR context
+ *    (hipSetDevice included) and refuses handles of different contexts in one call.  Calls without a
+ *    handle (jh_bvec_create, jh_tune_set, jh_synchronize, ...) act on the calling thread's CURRENT
+ *    context: the one chosen by jh_context_use / jh_set_device / jh_init, else the one the thread's
+ *    last handle call switched to, else the first context created.
+ *  - All work of a context is enqueued on its one HIP stream (jh_get_stream/jh_set_stream);
+ *    functions return after enqueue, except those that return a scalar or copy to host memory,
+ *    which synchronise the stream first.
  *  - Handles are opaque, created/destroyed explicitly; the library never frees caller memory.
  *    Destroying a vector invalidates borrowed block pointers and views of it.
  *  - A block vector ("bvec", the device BlockArray) is ONE contiguous slab; block i lives at
@@ -83,8 +92,15 @@ typedef struct jh_event jh_event;
 int jh_abi_version(void);
 const char *jh_last_error(void);
 int jh_device_count(int *count);
-int jh_init(int device);                 /* hipSetDevice + stream; idempotent for the same device */
-int jh_shutdown(void);
+int jh_init(int device);                 /* the device's primary context (created on first call) becomes current; idempotent */
+int jh_shutdown(void);                   /* destroys every context of the process                                            */
+/* several contexts in one process (see Conventions).  Context ids are small integers (< 64). */
+int jh_context_create(int device, int *ctx);      /* an ADDITIONAL context (own stream, workspaces, knobs) -- also on a device
+                                                   * that already has one; it becomes current */
+int jh_context_use(int ctx);                      /* make it the calling thread's current context (hipSetDevice included) */
+int jh_context_current(int *ctx, int *device);
+int jh_context_destroy(int ctx);                  /* its vectors / operators must have been destroyed first */
+int jh_set_device(int device);                    /* = jh_context_use(the primary context of `device`) */
 int jh_device_info(char *name, int name_cap, int64_t *total_mem, int64_t *free_mem, int *cu_count);
 int jh_get_stream(void **hip_stream);    /* hipStream_t the library enqueues on                   */
 int jh_set_stream(void *hip_stream);     /* NULL restores the library's own stream                */
@@ -104,6 +120,7 @@ int jh_bvec_wrap(void *device_ptr, int64_t nblocks, const int64_t *block_len, in
 int jh_bvec_view(jh_bvec *parent, int64_t first_block, int64_t count, jh_bvec **out);
 int jh_bvec_destroy(jh_bvec *v);
 int jh_bvec_info(const jh_bvec *v, int64_t *nblocks, int64_t *length, int *dtype, void **device_ptr);
+int jh_bvec_context(const jh_bvec *v, int *ctx, int *device);   /* the context (and its device) the vector lives in */
 /* indices(x,i) / getblock(x,i) as a borrowed device pointer, src/Jets.jl:858, 914 */
 int jh_bvec_block(const jh_bvec *v, int64_t iblock, int64_t *offset, int64_t *len, void **device_ptr);
 
@@ -286,11 +303,22 @@ int jh_lsqr_solve_partitioned(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int 
 /* Row partition of a tall operator across the GPUs of a node (one process per GPU): the forward needs no exchange
  * (src/Jets.jl:1015-1031), the adjoint is a sum over rows (1045-1053) -> one in-place all-reduce of the domain vector
  * after the local jh_blockop_mul_adj; range-side dot/norm -> scalar all-reduce of the local partials.  The host
- * language distributes the 128-byte id of rank 0.  Collectives are enqueued on the library stream. */
+ * language distributes the 128-byte id of rank 0.  Collectives are enqueued on the library stream.
+ * A communicator belongs to a CONTEXT (the current one at jh_comm_init_rank; collectives on a vector use its context's). */
 int jh_comm_unique_id(void *out128);
 int jh_comm_init_rank(const void *id128, int nranks, int rank);
-int jh_comm_destroy(void);
-int jh_comm_info(int *nranks, int *rank);
+int jh_comm_destroy(void);                                      /* the current context's communicator (a team: all members') */
+int jh_comm_info(int *nranks, int *rank);                       /* of the current context; (1, 0) without a communicator */
+/* ONE process driving several GPUs (ncclCommInitAll, one stream per device, grouped calls): the n contexts
+ * become a TEAM, member k = contexts[k] -- on pairwise distinct devices (RCCL), or all on ONE device (several streams of one
+ * GPU: the sum is then a device kernel over the members' buffers, members added in rank order; RCCL refuses two ranks on a
+ * device).  The host issues jh_comm_allreduce_sum / _sum_range once PER MEMBER between jh_comm_group_begin and
+ * jh_comm_group_end (ncclGroupStart / ncclGroupEnd; outside a group a member's call is refused -- a single thread would block
+ * in it).  Scalars need no collective in a team: the host reads every member's partial (jh_normsq_read, jh_dot, jh_norm) and
+ * combines them; jh_comm_allreduce_scalars / _normsq and jh_lsqr_solve_partitioned are for one-process-per-GPU ranks. */
+int jh_comm_init_all(int n, const int *contexts);
+int jh_comm_group_begin(void);                                  /* on a member context of the team */
+int jh_comm_group_end(void);
 int jh_comm_allreduce_sum(jh_bvec *v);
 int jh_comm_allreduce_scalars(double *values, int n, int op);   /* op: 0 sum, 1 max, 2 min; synchronises */
 /* Pipelined exchange.  jh_comm_allreduce_sum_range sums the elements [first_elem, first_elem+count) of v over all ranks on the

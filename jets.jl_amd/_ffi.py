@@ -65,6 +65,15 @@ SYMBOLS = {
     "jh_device_count": (_int, [_intp]),
     "jh_init": (_int, [_int]),
     "jh_shutdown": (_int, []),
+    "jh_context_create": (_int, [_int, _intp]),
+    "jh_context_use": (_int, [_int]),
+    "jh_context_current": (_int, [_intp, _intp]),
+    "jh_context_destroy": (_int, [_int]),
+    "jh_set_device": (_int, [_int]),
+    "jh_bvec_context": (_int, [_vp, _intp, _intp]),
+    "jh_comm_init_all": (_int, [_int, _intp]),
+    "jh_comm_group_begin": (_int, []),
+    "jh_comm_group_end": (_int, []),
     "jh_device_info": (_int, [C.c_char_p, _int, _i64p, _i64p, _intp]),
     "jh_get_stream": (_int, [_vpp]),
     "jh_set_stream": (_int, [_vp]),

@@ -21,10 +21,16 @@ struct jh_bcast {
     int dtype = JH_F32;
     int nvec = 0, nscal = 0;
     int real_mask = 0;                  // bit k: vector operand k is REAL in a complex program (a real mask on a complex vector)
-    hipModule_t module = nullptr;
-    hipFunction_t fn_vec = nullptr;     // 16 bytes per lane (every operand 16-byte aligned)
-    hipFunction_t fn_scalar = nullptr;  // one element per lane (views at odd offsets)
-    hipFunction_t fn_batched = nullptr; // fn_vec over MANY equally long destinations at once (blockIdx.y = item; pointers from a table)
+    // a program is device-agnostic (one code object for gfx950); its module is loaded per DEVICE on first use there
+    struct on_device {
+        hipModule_t module = nullptr;
+        hipFunction_t fn_vec = nullptr;     // 16 bytes per lane (every operand 16-byte aligned)
+        hipFunction_t fn_scalar = nullptr;  // one element per lane (views at odd offsets)
+        hipFunction_t fn_batched = nullptr; // fn_vec over MANY equally long destinations at once (blockIdx.y = item; pointers from a table)
+    };
+    static constexpr int MAX_DEV = 32;
+    mutable on_device dev[MAX_DEV];
+    std::vector<char> code;
     std::string expr;
 };
 
@@ -206,6 +212,36 @@ int compile_code(const std::string &expr, int dtype, int nvec, int nscal, std::v
     return JH_OK;
 }
 
+std::mutex g_load_mutex;
+// the program's functions on the CURRENT context's device
+int loaded(const jh_bcast *bc, const jh_bcast::on_device **out)
+{
+    const int d = jh_ctx().device;
+    JH_REQUIRE(d >= 0 && d < jh_bcast::MAX_DEV, "jh_bcast: device %d beyond the %d this build keeps modules for", d, jh_bcast::MAX_DEV);
+    jh_bcast::on_device &f = bc->dev[d];
+    if (!f.fn_batched) {
+        std::lock_guard<std::mutex> lock(g_load_mutex);
+        if (!f.fn_batched) {
+            hipModule_t mod = nullptr;
+            hipFunction_t fv = nullptr, fs = nullptr, fb = nullptr;
+            hipError_t e = hipModuleLoadData(&mod, bc->code.data());
+            if (e == hipSuccess) e = hipModuleGetFunction(&fv, mod, "jh_bcast_vec");
+            if (e == hipSuccess) e = hipModuleGetFunction(&fs, mod, "jh_bcast_scalar");
+            if (e == hipSuccess) e = hipModuleGetFunction(&fb, mod, "jh_bcast_vec_batched");
+            if (e != hipSuccess) {
+                if (mod) (void)hipModuleUnload(mod);
+                return jh_fail(JH_ERR_HIP, "jh_bcast: loading the code object on device %d: %s", d, hipGetErrorString(e));
+            }
+            f.module = mod;
+            f.fn_vec = fv;
+            f.fn_scalar = fs;
+            f.fn_batched = fb;
+        }
+    }
+    *out = &f;
+    return JH_OK;
+}
+
 int compile(const std::string &expr, int dtype, int nvec, int nscal, jh_bcast **out, int real_mask = 0)
 {
     std::vector<char> code;
@@ -216,15 +252,10 @@ int compile(const std::string &expr, int dtype, int nvec, int nscal, jh_bcast **
     bc->nscal = nscal;
     bc->real_mask = real_mask;
     bc->expr = expr;
-    hipError_t e = hipModuleLoadData(&bc->module, code.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&bc->fn_vec, bc->module, "jh_bcast_vec");
-    if (e == hipSuccess) e = hipModuleGetFunction(&bc->fn_scalar, bc->module, "jh_bcast_scalar");
-    if (e == hipSuccess) e = hipModuleGetFunction(&bc->fn_batched, bc->module, "jh_bcast_vec_batched");
-    if (e != hipSuccess) {
-        if (bc->module) (void)hipModuleUnload(bc->module);
-        delete bc;
-        return jh_fail(JH_ERR_HIP, "jh_bcast_compile: loading the code object: %s", hipGetErrorString(e));
-    }
+    bc->code.swap(code);
+    const jh_bcast::on_device *fns = nullptr;
+    const int st = loaded(bc, &fns);                      // load it on the current device right away: errors surface at compile time
+    if (st != JH_OK) { delete bc; return st; }
     *out = bc;
     return JH_OK;
 }
@@ -293,7 +324,7 @@ int jh_bcast_compile_mixed(const char *expr, int dtype, int nvec, int real_mask,
 
 int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, const double *scal_re_im)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(dst));
     JH_REQUIRE(bc && dst, "jh_bcast_apply: null argument");
     JH_REQUIRE(bc->nvec == 0 || x, "jh_bcast_apply: null operand list");
     JH_REQUIRE(bc->nscal == 0 || scal_re_im, "jh_bcast_apply: null scalar list");
@@ -301,6 +332,7 @@ int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, co
     uintptr_t bits = (uintptr_t)dst->data;
     for (int k = 0; k < bc->nvec; k++) {
         JH_REQUIRE(x[k], "jh_bcast_apply: operand %d is null", k);
+        JH_REQUIRE(x[k]->ctx == dst->ctx, "jh_bcast_apply: operand %d lives in context %d, the destination in %d", k, x[k]->ctx, dst->ctx);
         const int want_dt = ((bc->real_mask >> k) & 1) ? (bc->dtype == JH_C32 ? JH_F32 : JH_F64) : bc->dtype;      // a real operand of a complex program
         JH_REQUIRE(x[k]->dtype == want_dt, "jh_bcast_apply: operand %d has dtype %d, program compiled for %d", k, x[k]->dtype, want_dt);
         JH_REQUIRE(x[k]->length == dst->length, "jh_bcast_apply: operand %d has %lld elements, destination %lld (DimensionMismatch)", k,
@@ -330,7 +362,9 @@ int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, co
     const int64_t work = vec_ok ? n_scalars / NS : dst->length;
     int64_t grid = (work + 255) / 256;
     if (grid > ((int64_t)1 << 23)) grid = (int64_t)1 << 23;              // grid x 256 threads < 2^32; the kernel strides
-    JH_CHECK_HIP(hipModuleLaunchKernel(vec_ok ? bc->fn_vec : bc->fn_scalar, (unsigned)grid, 1, 1, 256, 1, 1, 0, jh_ctx().stream, args, nullptr));
+    const jh_bcast::on_device *fns = nullptr;
+    JH_TRY(loaded(bc, &fns));
+    JH_CHECK_HIP(hipModuleLaunchKernel(vec_ok ? fns->fn_vec : fns->fn_scalar, (unsigned)grid, 1, 1, 256, 1, 1, 0, jh_ctx().stream, args, nullptr));
     return JH_OK;
 }
 
@@ -349,7 +383,8 @@ static int apply_many_batched(int count, const jh_bcast *const *progs, jh_bvec *
     uintptr_t bits = 0;
     for (int k = 0; k < count; k++) {
         const jh_bcast *bc = progs[k];
-        if (!bc || !bc->fn_batched || !dsts[k] || dsts[k]->dtype != bc->dtype || dsts[k]->length == 0) return JH_OK;
+        if (!bc || !dsts[k] || dsts[k]->dtype != bc->dtype || dsts[k]->length == 0) return JH_OK;
+        if (dsts[k]->ctx != dsts[0]->ctx) return JH_OK;                      // (the item-by-item path works context by context)
         if ((bc->nvec > 0 && !xs) || (bc->nscal > 0 && !scal_re_im)) return JH_OK;
         const int NS = (bc->dtype == JH_F64 || bc->dtype == JH_C64) ? 2 : 4;
         if ((dsts[k]->length * (jh_dtype_complex(bc->dtype) ? 2 : 1)) % NS != 0) return JH_OK;
@@ -358,7 +393,7 @@ static int apply_many_batched(int count, const jh_bcast *const *progs, jh_bvec *
         bits |= (uintptr_t)dsts[k]->data;
         for (int j = 0; j < bc->nvec; j++) {
             const jh_bvec *x = xs[ix + j];
-            if (!x || x->dtype != bc->dtype || x->length != dsts[k]->length) return JH_OK;
+            if (!x || x->dtype != bc->dtype || x->length != dsts[k]->length || x->ctx != dsts[k]->ctx) return JH_OK;
             bits |= (uintptr_t)x->data;
         }
         ix += bc->nvec;
@@ -383,7 +418,7 @@ static int apply_many_batched(int count, const jh_bcast *const *progs, jh_bvec *
                 }
             }
     }
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(dsts[0]));
     // ---- group by (program, length), keeping first-appearance order
     struct Group { const jh_bcast *bc; int64_t len; std::vector<int> items; size_t tbl_at = 0, sc_at = 0; };
     std::vector<Group> groups;
@@ -437,6 +472,8 @@ static int apply_many_batched(int count, const jh_bcast *const *progs, jh_bvec *
         const int gcount = (int)g.items.size();
         int64_t gx = (n_scalars / NS + 255) / 256;
         if (gx > 65535) gx = 65535;                           // the kernel strides
+        const jh_bcast::on_device *fns = nullptr;
+        JH_TRY(loaded(bc, &fns));
         // an operand every item of the group shares (the model vector of F(m) / point!) is loaded through the caches; beyond
         // 32 MiB per vector the items also become the fastest block index, so that it is read from HBM once per XCD instead of
         // once per item (256 children of 64 MiB: F(m) 4.8 -> 2.75 ms)
@@ -456,9 +493,9 @@ static int apply_many_batched(int count, const jh_bcast *const *progs, jh_bvec *
             long n_arg = (long)n_scalars;
             void *args[5] = {&tbl_arg, &sc_arg, &n_arg, &item_fast, &shared_mask};
             if (item_fast)
-                JH_CHECK_HIP(hipModuleLaunchKernel(bc->fn_batched, (unsigned)gy, (unsigned)gx, 1, 256, 1, 1, 0, st, args, nullptr));
+                JH_CHECK_HIP(hipModuleLaunchKernel(fns->fn_batched, (unsigned)gy, (unsigned)gx, 1, 256, 1, 1, 0, st, args, nullptr));
             else
-                JH_CHECK_HIP(hipModuleLaunchKernel(bc->fn_batched, (unsigned)gx, (unsigned)gy, 1, 256, 1, 1, 0, st, args, nullptr));
+                JH_CHECK_HIP(hipModuleLaunchKernel(fns->fn_batched, (unsigned)gx, (unsigned)gy, 1, 256, 1, 1, 0, st, args, nullptr));
         }
     }
     *done = true;
@@ -495,7 +532,8 @@ void jh_bcast_clear_cache()
 {
     std::lock_guard<std::mutex> lock(g_cache_mutex);
     for (auto &kv : g_cache) {
-        if (kv.second->module) (void)hipModuleUnload(kv.second->module);
+        for (auto &f : kv.second->dev)
+            if (f.module) (void)hipModuleUnload(f.module);
         delete kv.second;
     }
     g_cache.clear();

@@ -2404,6 +2404,7 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
                (long long)nrow, (long long)ncol);
     JH_REQUIRE(jh_dtype_size(dtype) != 0, "jh_blockop_create: unknown dtype %d", dtype);
     jh_blockop *op = new jh_blockop();
+    op->ctx = jh_ctx().id;                                   // the coefficient pointers in descs must belong to the current context's device
     op->dtype = dtype;
     op->nrow = nrow;
     op->ncol = ncol;
@@ -2570,7 +2571,10 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
 int jh_blockop_destroy(jh_blockop *op)
 {
     if (!op) return JH_OK;
-    if (jh_ctx().ready) (void)hipStreamSynchronize(jh_ctx().stream);
+    if (jh_context *c = jh_ctx_by_id(op->ctx)) {
+        (void)jh_enter(op);
+        (void)hipStreamSynchronize(c->stream);
+    }
     drop_loop_graphs(op);
     lazy_release(op->fwd_tune);
     lazy_release(op->step_tune);
@@ -2585,7 +2589,7 @@ int jh_blockop_destroy(jh_blockop *op)
 
 int jh_blockop_point(jh_blockop *op, const jh_bvec *mo)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(op, mo));
     JH_REQUIRE(op && mo, "jh_blockop_point: null argument");
     JH_REQUIRE(mo->dtype == op->dtype, "jh_blockop_point: dtype mismatch (op %d, point %d)", op->dtype, mo->dtype);
     JH_REQUIRE(mo->length == op->col_off[(size_t)op->ncol], "jh_blockop_point: point has %lld elements, operator domain has %lld",
@@ -2615,7 +2619,7 @@ int jh_blockop_point(jh_blockop *op, const jh_bvec *mo)
 
 int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(op, d, m));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_f"));
     if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false);
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
@@ -2634,7 +2638,7 @@ int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
 
 int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(op, d, m));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul"));
     if (op->nonlinear && !op->pointed)
         return jh_fail(JH_ERR_STATE, "jh_blockop_mul: operator has nonlinear blocks and no linearisation point (jh_blockop_point)");
@@ -2673,7 +2677,7 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
 
 int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(op, m, d));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_adj"));
     if (op->nonlinear && !op->pointed)
         return jh_fail(JH_ERR_STATE, "jh_blockop_mul_adj: operator has nonlinear blocks and no linearisation point (jh_blockop_point)");
@@ -2712,7 +2716,7 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
 
 int jh_blockop_mul_adj_range(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, int64_t first_elem, int64_t count)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(op, m, d));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_adj_range"));
     JH_REQUIRE(first_elem >= 0 && count >= 0 && first_elem + count <= m->length,
                "jh_blockop_mul_adj_range: elements [%lld, %lld) outside the domain vector (%lld elements)", (long long)first_elem,
@@ -2742,7 +2746,7 @@ int jh_blockop_mul_adj_range(const jh_blockop *op, jh_bvec *m, const jh_bvec *d,
 
 int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(op, y, m));
     JH_REQUIRE(op && y && m, "jh_blockop_normal_mul: null argument");
     JH_REQUIRE(y->dtype == op->dtype && m->dtype == op->dtype, "jh_blockop_normal_mul: dtype mismatch");
     JH_REQUIRE(y->length == op->col_off[(size_t)op->ncol] && m->length == y->length,
@@ -2855,11 +2859,12 @@ extern "C" {
 // holds -- the unfused chain's sequence ((0 +- t1) +- t2) +- ... whatever the grouping.
 int jh_blocksum_mul(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, jh_bvec *d, const jh_bvec *m)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(d, m));
     JH_REQUIRE(ops && scale && sign && d && m, "jh_blocksum_mul: null argument");
     JH_REQUIRE(nterms >= 1 && nterms <= 4096, "jh_blocksum_mul: %d terms (1..4096 supported)", nterms);
     for (int t = 0; t < nterms; t++) {                                   // validate EVERYTHING before the first launch touches d
         JH_REQUIRE(ops[t], "jh_blocksum_mul: null operator %d", t);
+        JH_REQUIRE(ops[t]->ctx == d->ctx, "jh_blocksum_mul: operator %d lives in context %d, the vectors in %d", t, ops[t]->ctx, d->ctx);
         SumArgs probe;
         JH_TRY(sum_prepare(1, ops + t, scale + t, sign + t, d, m, probe, "jh_blocksum_mul"));
         JH_REQUIRE(ops[t]->nrow == ops[0]->nrow && ops[t]->row_len[0] == ops[0]->row_len[0] && ops[t]->dtype == ops[0]->dtype,
@@ -2886,11 +2891,12 @@ int jh_blocksum_mul(int nterms, const jh_blockop *const *ops, const double *scal
 
 int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, jh_bvec *m, const jh_bvec *d)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(m, d));
     JH_REQUIRE(ops && scale && sign && d && m, "jh_blocksum_mul_adj: null argument");
     JH_REQUIRE(nterms >= 1 && nterms <= 4096, "jh_blocksum_mul_adj: %d terms (1..4096 supported)", nterms);
     for (int t = 0; t < nterms; t++) {
         JH_REQUIRE(ops[t], "jh_blocksum_mul_adj: null operator %d", t);
+        JH_REQUIRE(ops[t]->ctx == d->ctx, "jh_blocksum_mul_adj: operator %d lives in context %d, the vectors in %d", t, ops[t]->ctx, d->ctx);
         SumArgs probe;
         JH_TRY(sum_prepare(1, ops + t, scale + t, sign + t, d, m, probe, "jh_blocksum_mul_adj"));
         JH_REQUIRE(ops[t]->nrow == ops[0]->nrow && ops[t]->row_len[0] == ops[0]->row_len[0] && ops[t]->dtype == ops[0]->dtype,
@@ -2920,7 +2926,7 @@ int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *
 
 int jh_blockop_bidiag_step(const jh_blockop *op, jh_bvec *u, const jh_bvec *v, jh_bvec *w, double alpha, double beta, double *normsq)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(op, u, v, w));
     JH_TRY(check_vectors(op, u, v, "jh_blockop_bidiag_step"));
     JH_REQUIRE(w && w->dtype == op->dtype && w->length == v->length, "jh_blockop_bidiag_step: w must be a domain vector of the operator");
     JH_REQUIRE(w->data != v->data, "jh_blockop_bidiag_step: w must not alias v");
@@ -2939,7 +2945,7 @@ int jh_blockop_bidiag_step(const jh_blockop *op, jh_bvec *u, const jh_bvec *v, j
 int jh_blockop_bidiag_step_range(const jh_blockop *op, jh_bvec *u, const jh_bvec *v, jh_bvec *w, double alpha, double beta,
                                  int64_t first_elem, int64_t count, double *normsq)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(op, u, v, w));
     JH_TRY(check_vectors(op, u, v, "jh_blockop_bidiag_step_range"));
     JH_REQUIRE(w && w->dtype == op->dtype && w->length == v->length, "jh_blockop_bidiag_step_range: w must be a domain vector of the operator");
     JH_REQUIRE(w->data != v->data, "jh_blockop_bidiag_step_range: w must not alias v");
@@ -3014,7 +3020,7 @@ int jh_normsq_read(double *out)
 
 int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double alpha, double beta, double *normsq)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(op, d, m));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_axpby"));
     if (!jh_blockop_tall_fast(op, d->data, m->data))
         return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_axpby: needs a tall operator of elementwise rows with equal, 16-byte aligned blocks; "
@@ -3032,7 +3038,7 @@ int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, dou
 int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double alpha, double beta, double in_scale,
                              double *normsq)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(op, m, d));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_adj_axpby"));
     if (!tall_fast_ok(op, d->data, m->data))
         return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_axpby: needs a tall all-DIAG operator with equal, 16-byte aligned blocks; "

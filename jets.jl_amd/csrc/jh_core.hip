@@ -13,10 +13,123 @@ int jh_fail(int status, const char *fmt, ...)
     return status;
 }
 
+// ---- the context table ----------------------------------------------------------------------------------------------------
+#include <mutex>
+static std::mutex g_ctx_mutex;                           // creation / destruction only; a handle is used by one host thread at a time
+static jh_context *g_ctxs[JH_MAX_CTX] = {};
+static int g_first_ctx = -1;                             // a thread that never chose uses the first context created
+static thread_local int t_cur_ctx = -1;
+
+jh_context *jh_ctx_by_id(int id) { return (id >= 0 && id < JH_MAX_CTX) ? g_ctxs[id] : nullptr; }
+
 jh_context &jh_ctx()
 {
-    static jh_context ctx;
-    return ctx;
+    static jh_context none;                              // never ready: jh_require_ready() reports "jh_init has not been called"
+    jh_context *c = jh_ctx_by_id(t_cur_ctx >= 0 ? t_cur_ctx : g_first_ctx);
+    return c ? *c : none;
+}
+
+static int ctx_use(int id)
+{
+    jh_context *c = jh_ctx_by_id(id);
+    if (!c || !c->ready) return jh_fail(JH_ERR_STATE, "libjetship: context %d does not exist (destroyed, or its handle outlived jh_shutdown)", id);
+    t_cur_ctx = id;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != c->device) JH_CHECK_HIP(hipSetDevice(c->device));
+    return JH_OK;
+}
+
+int jh_enter_ids(const int *ids, int n)
+{
+    int first = -1;
+    for (int k = 0; k < n; k++) {
+        if (ids[k] < 0) continue;                        // a null handle: the entry point reports it
+        if (first < 0) first = ids[k];
+        else if (ids[k] != first)
+            return jh_fail(JH_ERR_INVALID, "libjetship: the handles of this call live in different contexts (%d and %d; devices %d and %d)", first,
+                           ids[k], jh_ctx_by_id(first) ? jh_ctx_by_id(first)->device : -1, jh_ctx_by_id(ids[k]) ? jh_ctx_by_id(ids[k])->device : -1);
+    }
+    if (first < 0) return jh_require_ready();
+    if (first == t_cur_ctx) return jh_require_ready();   // the common case: nothing to switch
+    return ctx_use(first);
+}
+
+static int ctx_create(int device, bool primary, int *id_out)
+{
+    int n = 0;
+    JH_CHECK_HIP(hipGetDeviceCount(&n));
+    if (n <= 0) return jh_fail(JH_ERR_HIP, "jh_init: no HIP device visible; libjetship has no CPU fallback");
+    JH_REQUIRE(device >= 0 && device < n, "jh_init: device %d out of range (0..%d)", device, n - 1);
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    if (primary)
+        for (int k = 0; k < JH_MAX_CTX; k++)
+            if (g_ctxs[k] && g_ctxs[k]->primary && g_ctxs[k]->device == device) { *id_out = k; return JH_OK; }   // idempotent
+    int id = -1;
+    for (int k = 0; k < JH_MAX_CTX; k++)
+        if (!g_ctxs[k]) { id = k; break; }
+    if (id < 0) return jh_fail(JH_ERR_STATE, "jh_context_create: all %d context slots are in use", JH_MAX_CTX);
+    JH_CHECK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    JH_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_init: device %d is %s; libjetship is built for gfx950 (MI355X) only", device,
+                       prop.gcnArchName);
+    jh_context *c = new jh_context();
+    auto fail = [&](hipError_t e, const char *what) {
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+        if (c->red_dev) (void)hipFree(c->red_dev);
+        if (c->red_host) (void)hipHostFree(c->red_host);
+        delete c;
+        return jh_fail(e == hipErrorOutOfMemory ? JH_ERR_NOMEM : JH_ERR_HIP, "jh_init: %s: %s", what, hipGetErrorString(e));
+    };
+    c->cu_count = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return fail(e, "hipStreamCreateWithFlags");
+    c->stream = c->own_stream;
+    e = hipMalloc((void **)&c->red_dev, sizeof(double) * 4 * JH_RED_SLOTS);
+    if (e != hipSuccess) return fail(e, "hipMalloc");
+    e = hipMemset(c->red_dev, 0, sizeof(double) * 4 * JH_RED_SLOTS);
+    if (e != hipSuccess) return fail(e, "hipMemset");
+    e = hipHostMalloc((void **)&c->red_host, sizeof(double) * 8, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(e, "hipHostMalloc");
+    memset(c->red_host, 0, sizeof(double) * 8);
+    c->device = device;
+    c->primary = primary;
+    c->id = id;
+    c->ready = true;
+    g_ctxs[id] = c;
+    if (g_first_ctx < 0) g_first_ctx = id;
+    *id_out = id;
+    return JH_OK;
+}
+
+static int ctx_destroy(int id)
+{
+    jh_context *c = jh_ctx_by_id(id);
+    if (!c) return JH_OK;
+    const int before = t_cur_ctx;
+    (void)ctx_use(id);
+    (void)hipStreamSynchronize(c->stream);
+    (void)jh_comm_destroy();                             // this context's communicator, if any
+    if (c->red_dev) (void)hipFree(c->red_dev);
+    if (c->part_dev) (void)hipFree(c->part_dev);
+    if (c->scratch_dev) (void)hipFree(c->scratch_dev);
+    if (c->chain_sync) (void)hipFree(c->chain_sync);
+    if (c->red_host) (void)hipHostFree(c->red_host);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        g_ctxs[id] = nullptr;
+        delete c;
+        if (g_first_ctx == id) {
+            g_first_ctx = -1;
+            for (int k = 0; k < JH_MAX_CTX; k++)
+                if (g_ctxs[k]) { g_first_ctx = k; break; }
+        }
+    }
+    t_cur_ctx = (before == id) ? -1 : before;
+    if (t_cur_ctx >= 0) (void)ctx_use(t_cur_ctx);
+    return JH_OK;
 }
 
 // the sticky "hand-off poll expired" word of the chained step, as last copied to red_host[3]
@@ -100,48 +213,49 @@ int jh_device_count(int *count)
 
 int jh_init(int device)
 {
-    jh_context &c = jh_ctx();
-    if (c.ready) {
-        if (c.device == device) return JH_OK;
-        return jh_fail(JH_ERR_STATE, "jh_init: already initialised on device %d (one process drives one GPU)", c.device);
-    }
-    int n = 0;
-    JH_CHECK_HIP(hipGetDeviceCount(&n));
-    if (n <= 0) return jh_fail(JH_ERR_HIP, "jh_init: no HIP device visible; libjetship has no CPU fallback");
-    JH_REQUIRE(device >= 0 && device < n, "jh_init: device %d out of range (0..%d)", device, n - 1);
-    JH_CHECK_HIP(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    JH_CHECK_HIP(hipGetDeviceProperties(&prop, device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_init: device %d is %s; libjetship is built for gfx950 (MI355X) only", device,
-                       prop.gcnArchName);
-    c.cu_count = prop.multiProcessorCount;
-    JH_CHECK_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
-    c.stream = c.own_stream;
-    JH_CHECK_HIP(hipMalloc((void **)&c.red_dev, sizeof(double) * 4 * JH_RED_SLOTS));
-    JH_CHECK_HIP(hipMemset(c.red_dev, 0, sizeof(double) * 4 * JH_RED_SLOTS));
-    JH_CHECK_HIP(hipHostMalloc((void **)&c.red_host, sizeof(double) * 8, hipHostMallocDefault));
-    memset(c.red_host, 0, sizeof(double) * 8);
-    c.device = device;
-    c.ready = true;
+    int id = -1;
+    JH_TRY(ctx_create(device, true, &id));               // the device's primary context; idempotent
+    return ctx_use(id);
+}
+
+int jh_context_create(int device, int *ctx)
+{
+    JH_REQUIRE(ctx, "jh_context_create: null output");
+    int id = -1;
+    JH_TRY(ctx_create(device, false, &id));
+    *ctx = id;
+    return ctx_use(id);
+}
+
+int jh_context_use(int ctx) { return ctx_use(ctx); }
+
+int jh_context_current(int *ctx, int *device)
+{
+    JH_TRY(jh_require_ready());
+    if (ctx) *ctx = jh_ctx().id;
+    if (device) *device = jh_ctx().device;
     return JH_OK;
+}
+
+int jh_context_destroy(int ctx)
+{
+    JH_REQUIRE(jh_ctx_by_id(ctx), "jh_context_destroy: no context %d", ctx);
+    return ctx_destroy(ctx);
+}
+
+int jh_set_device(int device)
+{
+    for (int k = 0; k < JH_MAX_CTX; k++)
+        if (g_ctxs[k] && g_ctxs[k]->primary && g_ctxs[k]->device == device) return ctx_use(k);
+    return jh_fail(JH_ERR_STATE, "jh_set_device: device %d has no context; call jh_init(%d) first", device, device);
 }
 
 int jh_shutdown(void)
 {
-    jh_context &c = jh_ctx();
-    if (!c.ready) return JH_OK;
-    (void)hipSetDevice(c.device);
-    (void)hipStreamSynchronize(c.stream);
-    (void)jh_comm_destroy();
+    for (int k = 0; k < JH_MAX_CTX; k++)
+        if (g_ctxs[k]) (void)ctx_destroy(k);
     jh_bcast_clear_cache();
-    if (c.red_dev) (void)hipFree(c.red_dev);
-    if (c.part_dev) (void)hipFree(c.part_dev);
-    if (c.scratch_dev) (void)hipFree(c.scratch_dev);
-    if (c.chain_sync) (void)hipFree(c.chain_sync);
-    if (c.red_host) (void)hipHostFree(c.red_host);
-    if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
-    c = jh_context();
+    t_cur_ctx = -1;
     return JH_OK;
 }
 
@@ -188,6 +302,7 @@ int jh_event_create(jh_event **ev)
     JH_TRY(jh_require_ready());
     JH_REQUIRE(ev, "jh_event_create: null output");
     jh_event *e = new jh_event();
+    e->ctx = jh_ctx().id;
     hipError_t r = hipEventCreate(&e->ev);
     if (r != hipSuccess) {
         delete e;
@@ -199,7 +314,7 @@ int jh_event_create(jh_event **ev)
 
 int jh_event_record(jh_event *ev)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(ev));
     JH_REQUIRE(ev, "jh_event_record: null event");
     JH_CHECK_HIP(hipEventRecord(ev->ev, jh_ctx().stream));
     return JH_OK;
@@ -207,7 +322,7 @@ int jh_event_record(jh_event *ev)
 
 int jh_event_elapsed_ms(jh_event *start, jh_event *stop, float *ms)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(start, stop));
     JH_REQUIRE(start && stop && ms, "jh_event_elapsed_ms: null argument");
     JH_CHECK_HIP(hipEventSynchronize(stop->ev));
     JH_CHECK_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
@@ -248,6 +363,7 @@ int jh_bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec
     JH_TRY(jh_require_ready());
     JH_REQUIRE(out, "jh_bvec_create: null output");
     jh_bvec *v = new jh_bvec();
+    v->ctx = jh_ctx().id;
     int s = build_layout(v, nblocks, block_len, dtype, "jh_bvec_create");
     if (s != JH_OK) { delete v; return s; }
     size_t bytes = (size_t)v->length * jh_dtype_size(dtype);
@@ -274,6 +390,7 @@ int jh_bvec_wrap(void *device_ptr, int64_t nblocks, const int64_t *block_len, in
     JH_REQUIRE(out, "jh_bvec_wrap: null output");
     JH_REQUIRE(device_ptr, "jh_bvec_wrap: null device pointer");
     jh_bvec *v = new jh_bvec();
+    v->ctx = jh_ctx().id;                                    // the caller's pointer must belong to the current context's device
     int s = build_layout(v, nblocks, block_len, dtype, "jh_bvec_wrap");
     if (s != JH_OK) { delete v; return s; }
     v->data = device_ptr;
@@ -284,12 +401,13 @@ int jh_bvec_wrap(void *device_ptr, int64_t nblocks, const int64_t *block_len, in
 
 int jh_bvec_view(jh_bvec *parent, int64_t first_block, int64_t count, jh_bvec **out)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(parent));
     JH_REQUIRE(parent && out, "jh_bvec_view: null argument");
     JH_REQUIRE(first_block >= 0 && count >= 1 && first_block + count <= parent->nblocks,
                "jh_bvec_view: blocks [%lld, %lld) out of range (nblocks = %lld)", (long long)first_block,
                (long long)(first_block + count), (long long)parent->nblocks);
     jh_bvec *v = new jh_bvec();
+    v->ctx = parent->ctx;
     v->dtype = parent->dtype;
     v->nblocks = count;
     v->off.resize((size_t)count + 1);
@@ -310,7 +428,10 @@ int jh_bvec_destroy(jh_bvec *v)
     if (!v) return JH_OK;
     if (v->owns && v->data) {
         // stream-ordered work may still reference the slab
-        if (jh_ctx().ready) (void)hipStreamSynchronize(jh_ctx().stream);
+        if (jh_context *c = jh_ctx_by_id(v->ctx)) {
+            (void)jh_enter(v);
+            (void)hipStreamSynchronize(c->stream);
+        }
         (void)hipFree(v->data);
     }
     delete v;
@@ -327,6 +448,16 @@ int jh_bvec_info(const jh_bvec *v, int64_t *nblocks, int64_t *length, int *dtype
     return JH_OK;
 }
 
+int jh_bvec_context(const jh_bvec *v, int *ctx, int *device)
+{
+    JH_REQUIRE(v, "jh_bvec_context: null vector");
+    const jh_context *c = jh_ctx_by_id(v->ctx);
+    JH_REQUIRE(c, "jh_bvec_context: the vector's context %d no longer exists", v->ctx);
+    if (ctx) *ctx = v->ctx;
+    if (device) *device = c->device;
+    return JH_OK;
+}
+
 int jh_bvec_block(const jh_bvec *v, int64_t iblock, int64_t *offset, int64_t *len, void **device_ptr)
 {
     JH_REQUIRE(v, "jh_bvec_block: null vector");
@@ -340,7 +471,7 @@ int jh_bvec_block(const jh_bvec *v, int64_t iblock, int64_t *offset, int64_t *le
 
 int jh_getblock_copy(const jh_bvec *v, int64_t iblock, void *dst, int dst_on_device)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(v));
     JH_REQUIRE(v && dst, "jh_getblock_copy: null argument");
     JH_REQUIRE(iblock >= 0 && iblock < v->nblocks, "jh_getblock_copy: block %lld out of range (nblocks = %lld)",
                (long long)iblock, (long long)v->nblocks);
@@ -355,7 +486,7 @@ int jh_getblock_copy(const jh_bvec *v, int64_t iblock, void *dst, int dst_on_dev
 
 int jh_setblock_copy(jh_bvec *v, int64_t iblock, const void *src, int src_on_device)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(v));
     JH_REQUIRE(v && src, "jh_setblock_copy: null argument");
     JH_REQUIRE(iblock >= 0 && iblock < v->nblocks, "jh_setblock_copy: block %lld out of range (nblocks = %lld)",
                (long long)iblock, (long long)v->nblocks);
@@ -370,7 +501,7 @@ int jh_setblock_copy(jh_bvec *v, int64_t iblock, const void *src, int src_on_dev
 
 int jh_setblock_fill(jh_bvec *v, int64_t iblock, double re, double im)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(v));
     JH_REQUIRE(v, "jh_setblock_fill: null vector");
     JH_REQUIRE(iblock >= 0 && iblock < v->nblocks, "jh_setblock_fill: block %lld out of range (nblocks = %lld)",
                (long long)iblock, (long long)v->nblocks);
@@ -379,14 +510,14 @@ int jh_setblock_fill(jh_bvec *v, int64_t iblock, double re, double im)
 
 int jh_fill(jh_bvec *v, double re, double im)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(v));
     JH_REQUIRE(v, "jh_fill: null vector");
     return jh_launch_fill_range(v->data, v->dtype, v->length, re, im);
 }
 
 int jh_copy(jh_bvec *dst, const jh_bvec *src)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(dst, src));
     JH_REQUIRE(dst && src, "jh_copy: null argument");
     JH_REQUIRE(dst->dtype == src->dtype, "jh_copy: dtype mismatch (%d vs %d)", dst->dtype, src->dtype);
     JH_REQUIRE(dst->length == src->length, "jh_copy: length mismatch (%lld vs %lld)", (long long)dst->length,
@@ -397,7 +528,7 @@ int jh_copy(jh_bvec *dst, const jh_bvec *src)
 
 int jh_download(const jh_bvec *v, int64_t offset, int64_t count, void *host_dst)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(v));
     JH_REQUIRE(v && host_dst, "jh_download: null argument");
     JH_REQUIRE(offset >= 0 && count >= 0 && offset + count <= v->length,
                "jh_download: range [%lld, %lld) outside vector of length %lld", (long long)offset,
@@ -411,7 +542,7 @@ int jh_download(const jh_bvec *v, int64_t offset, int64_t count, void *host_dst)
 
 int jh_upload(jh_bvec *v, int64_t offset, int64_t count, const void *host_src)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(v));
     JH_REQUIRE(v && host_src, "jh_upload: null argument");
     JH_REQUIRE(offset >= 0 && count >= 0 && offset + count <= v->length,
                "jh_upload: range [%lld, %lld) outside vector of length %lld", (long long)offset,

@@ -685,7 +685,7 @@ int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64
 
 extern "C" int jh_gemv(const void *A_device, int64_t nr, int64_t nc, int dtype, jh_bvec *y, const jh_bvec *x, int adjoint)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(y, x));
     JH_REQUIRE(A_device && y && x, "jh_gemv: null argument");
     JH_REQUIRE(nr >= 0 && nc >= 0, "jh_gemv: negative dimension");
     JH_REQUIRE(y->dtype == dtype && x->dtype == dtype, "jh_gemv: dtype mismatch");

@@ -27,8 +27,16 @@ int jh_fail(int status, const char *fmt, ...);
         if (_s != JH_OK) return _s;   \
     } while (0)
 
+// A CONTEXT is one device + one HIP stream + the library's workspaces and knobs for it.  jh_init(device) creates the PRIMARY
+// context of a device; jh_context_create adds further ones (also on a device that already has one: an independent stream).
+// A host thread has a CURRENT context (jh_context_use; the first one created until then); every handle remembers the context it
+// was created in and every entry point that takes handles switches to theirs (jh_enter) -- so one process can drive several
+// GPUs through this ABI, the way SURVEY section 8e sketches it.
+constexpr int JH_MAX_CTX = 64;
 struct jh_context {
     bool ready = false;
+    int id = -1;                       // index in the context table
+    bool primary = false;              // created by jh_init(device): jh_init(device) again returns it
     int device = -1;
     int cu_count = 256;
     hipStream_t own_stream = nullptr;
@@ -70,8 +78,18 @@ struct jh_context {
     int64_t last_fwd_walk = 0;         // grid walk used by the most recent tall forward launch (read-only knob)
     int64_t last_step_chain = 0;       // row chunks of the most recent one-pass step (0: the plain walk) (read-only knob)
 };
-jh_context &jh_ctx();
-int jh_require_ready();
+jh_context &jh_ctx();                  // the calling thread's current context (a never-ready dummy before jh_init)
+jh_context *jh_ctx_by_id(int id);      // nullptr when there is no such context
+int jh_require_ready();                // the current context exists; re-selects its device if another library switched
+int jh_enter_ids(const int *ids, int n);
+// entry points: make the handles' context current.  Null handles are skipped (the entry point reports them itself); handles of
+// different contexts in one call are refused.
+template <class... H> inline int jh_enter(const H *...h)
+{
+    const int ids[] = {(h ? h->ctx : -1)...};
+    return jh_enter_ids(ids, (int)sizeof...(H));
+}
+inline int jh_enter() { return jh_require_ready(); }
 
 constexpr int JH_RED_SLOTS = 4096;     // max workgroups in a reduction launch
 constexpr int JH_CHAIN_ERR_SLOT = 10;  // red_dev[10] (as an unsigned): sticky flag "a hand-off poll of the chained step ran into its bound" -- never expected;
@@ -91,6 +109,7 @@ static inline size_t jh_dtype_size(int dtype)
 static inline bool jh_dtype_complex(int dtype) { return dtype == JH_C32 || dtype == JH_C64; }
 
 struct jh_bvec {
+    int ctx = -1;                       // the context it was created in
     int dtype = JH_F32;
     int64_t nblocks = 0;
     int64_t length = 0;                 // total elements
@@ -103,6 +122,7 @@ struct jh_bvec {
 };
 
 struct jh_event {
+    int ctx = -1;
     hipEvent_t ev = nullptr;
 };
 
@@ -115,6 +135,7 @@ struct jh_dev_block {
 };
 
 struct jh_blockop {
+    int ctx = -1;
     int dtype = JH_F32;
     int64_t nrow = 0, ncol = 0;
     std::vector<jh_block_desc> blocks;   // host copy
@@ -181,5 +202,5 @@ int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, co
 int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, int dtype, void *y, const void *x,
                            int adjoint, bool aligned, bool wide, const int64_t *dev_row_off = nullptr);   // jh_dense.hip: every child of a tall (or wide) operator of uniform dense blocks at once
 int jh_ensure_scratch(size_t bytes, void **out);
-extern "C" int jh_comm_exists(int *yes);  // jh_comm.hip (internal): is a communicator alive?
+extern "C" int jh_comm_exists(int *yes);  // jh_comm.hip (internal): the current context's communicator: 0 none, 1 of jh_comm_init_rank, 2 member of a single-process team
 extern "C" int jh_comm_destroy(void);   // jh_comm.hip; jh_shutdown tears the communicator down first   // growable device scratch (block-loop temporaries)

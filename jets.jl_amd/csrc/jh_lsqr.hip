@@ -124,7 +124,7 @@ int launch_xw(int dtype, jh_bvec *v, jh_bvec *x, jh_bvec *w, double cv, double t
 static int lsqr_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, double conlim,
                      int maxiter, int force_maxiter, jh_lsqr_result *res, double *history, const bool dist)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(op, u, x));
     JH_REQUIRE(op && u && x && res, "jh_lsqr_solve: null argument");
     JH_REQUIRE(maxiter >= 0, "jh_lsqr_solve: maxiter must be >= 0");
     int64_t nb = 0, n = 0;
@@ -294,9 +294,13 @@ extern "C" int jh_lsqr_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int u
 extern "C" int jh_lsqr_solve_partitioned(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol,
                                          double conlim, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history)
 {
+    JH_TRY(jh_enter(op, u, x));                                         // the communicator is the one of the handles' context
     int nranks = 1, rank = 0, has_comm = 0;
     (void)jh_comm_info(&nranks, &rank);
     (void)jh_comm_exists(&has_comm);
+    if (has_comm == 2 && (nranks > 1 || jh_ctx().force_dist))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_lsqr_solve_partitioned: this context is a member of a single-process team (jh_comm_init_all); the loop over "
+                       "the members belongs to the host there (jh_blockop_bidiag_step_range per member + grouped all-reduces)");
     // one rank: nothing to exchange (jh_comm_init_rank is then optional, so a one-GPU run of partitioned host code works);
     // the knob force_dist runs the exchange all the same (validation of the pipelined path with a one-rank communicator)
     return lsqr_impl(op, u, x, use_x0, damp, atol, btol, conlim, maxiter, force_maxiter, res, history,

@@ -561,7 +561,7 @@ extern "C" {
 
 int jh_fill_uniform(jh_bvec *v, uint64_t seed, uint64_t stream, int64_t index_base)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(v));
     JH_REQUIRE(v, "jh_fill_uniform: null vector");
     JH_REQUIRE(index_base >= 0, "jh_fill_uniform: negative index_base");
     JH_REQUIRE((((uintptr_t)v->data) & 15u) == 0, "jh_fill_uniform: slab must be 16-byte aligned");
@@ -580,7 +580,7 @@ int jh_fill_uniform(jh_bvec *v, uint64_t seed, uint64_t stream, int64_t index_ba
 
 int jh_fill_normal(jh_bvec *v, uint64_t seed, uint64_t stream, int64_t index_base)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(v));
     JH_REQUIRE(v, "jh_fill_normal: null vector");
     JH_REQUIRE(index_base >= 0, "jh_fill_normal: negative index_base");
     if (v->length == 0) return JH_OK;
@@ -600,7 +600,7 @@ int jh_fill_normal(jh_bvec *v, uint64_t seed, uint64_t stream, int64_t index_bas
 
 int jh_abs(jh_bvec *dst, const jh_bvec *x)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(dst, x));
     JH_REQUIRE(dst && x, "jh_abs: null argument");
     JH_REQUIRE(dst->length == x->length, "jh_abs: length mismatch (%lld vs %lld)", (long long)dst->length, (long long)x->length);
     const int want = (x->dtype == JH_F32 || x->dtype == JH_C32) ? JH_F32 : JH_F64;
@@ -620,13 +620,14 @@ int jh_abs(jh_bvec *dst, const jh_bvec *x)
 
 int jh_lincomb(jh_bvec *dst, int k, const double *coef, const jh_bvec *const *x)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(dst));
     JH_REQUIRE(dst && coef && x, "jh_lincomb: null argument");
     JH_REQUIRE(k >= 1 && k <= MAX_TERMS, "jh_lincomb: k = %d outside 1..%d", k, MAX_TERMS);
     LincombArgs a;
     a.k = k;
     for (int j = 0; j < k; j++) {
         JH_REQUIRE(x[j], "jh_lincomb: null operand %d", j);
+        JH_REQUIRE(x[j]->ctx == dst->ctx, "jh_lincomb: operand %d lives in context %d, the destination in %d", j, x[j]->ctx, dst->ctx);
         JH_REQUIRE(x[j]->dtype == dst->dtype, "jh_lincomb: dtype mismatch on operand %d", j);
         JH_REQUIRE(x[j]->length == dst->length, "jh_lincomb: length mismatch on operand %d (%lld vs %lld)", j,
                    (long long)x[j]->length, (long long)dst->length);
@@ -647,7 +648,7 @@ int jh_lincomb(jh_bvec *dst, int k, const double *coef, const jh_bvec *const *x)
 
 int jh_hadamard(jh_bvec *dst, const jh_bvec *x, const jh_bvec *y, int conj_x)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(dst, x, y));
     JH_REQUIRE(dst && x && y, "jh_hadamard: null argument");
     JH_REQUIRE(dst->dtype == x->dtype && dst->dtype == y->dtype, "jh_hadamard: dtype mismatch");
     JH_REQUIRE(conj_x >= 0 && conj_x <= 3, "jh_hadamard: flags must be 0..3 (got %d)", conj_x);
@@ -664,7 +665,7 @@ int jh_hadamard(jh_bvec *dst, const jh_bvec *x, const jh_bvec *y, int conj_x)
 
 int jh_dot(const jh_bvec *x, const jh_bvec *y, double *re, double *im)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(x, y));
     JH_REQUIRE(x && y && re, "jh_dot: null argument");
     JH_REQUIRE(x->dtype == y->dtype, "jh_dot: dtype mismatch (%d vs %d)", x->dtype, y->dtype);
     JH_REQUIRE(x->length == y->length, "jh_dot: length mismatch (%lld vs %lld)", (long long)x->length, (long long)y->length);
@@ -677,7 +678,7 @@ int jh_dot(const jh_bvec *x, const jh_bvec *y, double *re, double *im)
 
 int jh_norm(const jh_bvec *x, double p, double *out)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(x));
     JH_REQUIRE(x && out, "jh_norm: null argument");
     JH_REQUIRE(!std::isnan(p), "jh_norm: p is NaN");
     double r0 = 0, r1 = 0;
@@ -706,7 +707,7 @@ int jh_norm(const jh_bvec *x, double p, double *out)
 
 int jh_extrema(const jh_bvec *x, double *mn, double *mx)
 {
-    JH_TRY(jh_require_ready());
+    JH_TRY(jh_enter(x));
     JH_REQUIRE(x && mn && mx, "jh_extrema: null argument");
     JH_REQUIRE(!jh_dtype_complex(x->dtype), "jh_extrema: complex values are not ordered");
     JH_REQUIRE(x->length > 0, "jh_extrema: empty vector");

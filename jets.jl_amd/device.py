@@ -1,8 +1,12 @@
 """Device context helpers over the C ABI: init, stream, events, tuning knobs.
 
-One process drives one GPU (include/jetship.h conventions).  `init()` is called lazily by the
-first array factory; it raises JetsHipError when no gfx950 device is visible -- the block-operator
-path has no CPU fallback.
+The usual deployment is one process per GPU with the device's primary context (include/jetship.h conventions).
+`init()` is called lazily by the first array factory; it raises JetsHipError when no gfx950 device is visible --
+the block-operator path has no CPU fallback.
+
+One process may also hold SEVERAL contexts (other GPUs, or further streams of one GPU): `context_create`,
+`context_use`, `using_context`.  Array factories allocate in the CURRENT context; every operation on arrays /
+operators runs in THEIR context, whatever is current (the ABI switches per call and refuses mixed handles).
 """
 from __future__ import annotations
 
@@ -12,9 +16,10 @@ import os
 from ._ffi import lib, check
 
 __all__ = ["init", "is_initialized", "shutdown", "synchronize", "device_count", "device_info", "stream_handle",
-           "set_stream", "Event", "tune", "tune_get", "local_device_from_env"]
+           "set_stream", "Event", "tune", "tune_get", "local_device_from_env", "context_create", "context_use",
+           "context_current", "context_destroy", "using_context", "context_of"]
 
-_state = {"device": None}
+_state = {"device": None, "devices": set(), "multi": False}
 
 
 def device_count() -> int:
@@ -29,11 +34,17 @@ def local_device_from_env() -> int:
 
 
 def init(device: int | None = None) -> int:
-    if _state["device"] is not None and (device is None or device == _state["device"]):
+    """The primary context of `device` (created on first use) becomes current.  Without an argument: nothing to do once any
+    context exists, else the device of LOCAL_RANK."""
+    if _state["device"] is not None and (device is None or (device == _state["device"] and not _state["multi"])):
         return _state["device"]
     dev = local_device_from_env() if device is None else int(device)
     check(lib.jh_init(dev))
-    _state["device"] = dev
+    if _state["device"] is None:
+        _state["device"] = dev
+    _state["devices"].add(dev)
+    if len(_state["devices"]) > 1:
+        _state["multi"] = True
     return dev
 
 
@@ -43,7 +54,62 @@ def is_initialized() -> bool:
 
 def shutdown() -> None:
     check(lib.jh_shutdown())
-    _state["device"] = None
+    _state.update(device=None, devices=set(), multi=False)
+
+
+def context_create(device: int | None = None) -> int:
+    """An ADDITIONAL context (own stream, workspaces, knobs) on `device` (default: the first device used); becomes current."""
+    dev = (_state["device"] if _state["device"] is not None else init()) if device is None else int(device)
+    if _state["device"] is None:
+        init(dev)
+    ctx = C.c_int(-1)
+    check(lib.jh_context_create(dev, C.byref(ctx)))
+    _state["multi"] = True
+    return ctx.value
+
+
+def context_use(ctx: int) -> None:
+    check(lib.jh_context_use(int(ctx)))
+
+
+def context_current():
+    """(context id, device) of the calling thread's current context."""
+    init()
+    ctx, dev = C.c_int(-1), C.c_int(-1)
+    check(lib.jh_context_current(C.byref(ctx), C.byref(dev)))
+    return ctx.value, dev.value
+
+
+def context_destroy(ctx: int) -> None:
+    check(lib.jh_context_destroy(int(ctx)))
+
+
+def context_of(x) -> int:
+    """The context a device array lives in."""
+    ctx = C.c_int(-1)
+    check(lib.jh_bvec_context(x.handle, C.byref(ctx), None))
+    return ctx.value
+
+
+class using_context:
+    """`with using_context(ctx): ...` -- array factories and handle-less calls inside act on `ctx`; the previous context is
+    current again afterwards."""
+
+    def __init__(self, ctx: int):
+        self.ctx = int(ctx)
+
+    def __enter__(self):
+        self.prev = context_current()[0]
+        context_use(self.ctx)
+        return self.ctx
+
+    def __exit__(self, *exc):
+        context_use(self.prev)
+        return False
+
+
+def several_contexts() -> bool:
+    return _state["multi"]
 
 
 def synchronize() -> None:

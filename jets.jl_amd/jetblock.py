@@ -16,6 +16,7 @@ import numpy as np
 
 from ._ffi import lib, check, BlockDesc, KINDS, JetsHipError
 from . import arrays as _arr
+from . import device as _dev
 from .arrays import DeviceArray, zeros, lincomb_, hadamard_, copyto_, fill_, getblock, _i64arr
 from .spaces import JetAbstractSpace, JetSpace, JetBSpace, dtype_code
 from . import jets as _j
@@ -200,6 +201,8 @@ class NativeBlockOp:
         row_len = [range_(ops[i, 0]).length() for i in builtins.range(nrow)]
         col_len = [domain(ops[0, jc]).length() for jc in builtins.range(ncol)]
         self._h = C.c_void_p()
+        if self._keep and _dev.several_contexts():          # the operator lives where its coefficients live
+            _dev.context_use(_dev.context_of(self._keep[0]))
         check(lib.jh_blockop_create(nrow, ncol, arr, _i64arr(row_len), _i64arr(col_len), dtype_code(dtype), C.byref(self._h)))
 
     @property

@@ -23,6 +23,7 @@ from typing import Any, Callable, Sequence
 import numpy as np
 
 from . import arrays as _arr
+from . import device as _dev
 from .arrays import DeviceArray, BlockArray, zeros, ones, lincomb_, hadamard_, copyto_, fill_, reshape, dot
 from .spaces import JetAbstractSpace
 
@@ -382,8 +383,16 @@ def adjoint(A):  # :382-383
 
 
 # ------------------------------------------------------------------------------ mul! ---------------
+def _enter_context_of(x):
+    """Several contexts in this process: temporaries that the combinators allocate while applying an operator must land in
+    the operand's context, so it becomes the current one (the C ABI switches per call anyway; this is for the factories)."""
+    if _dev.several_contexts() and hasattr(x, "handle"):
+        _dev.context_use(_dev.context_of(x))
+
+
 def mul_(d, A: Jop, m):
     """mul!(d, A, m) (src/Jets.jl:390-392)."""
+    _enter_context_of(m)
     if isinstance(A, JopNl):
         return f_(d, A.jet, m, **A.jet.s)
     if isinstance(A, JopLn):
@@ -398,6 +407,7 @@ def mul_(d, A: Jop, m):
 
 def mul(A: Jop, m):
     """A*m = mul!(zeros(range(A)), A, m) (src/Jets.jl:399)."""
+    _enter_context_of(m)
     return mul_(zeros(range_(A)), A, m)
 
 

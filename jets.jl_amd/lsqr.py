@@ -184,6 +184,60 @@ class _ShardEngine(_Engine):
         return float(norm(v))
 
 
+class _TeamEngine:
+    """ONE process, several contexts (rowpart.Team / TeamOp): vectors are rowpart.TeamVec -- range side: every member's
+    rows; domain side: the members' replicas, kept identical by the same deterministic updates on each.  Scalars need no
+    collective: the host adds the members' partial sums."""
+
+    def __init__(self, T):
+        self.T = T
+        self.team = T.team
+        self._tmp_d = None
+        self._engines = [_Engine(A) for A in T.local_ops]     # per member: the fused local halves
+        self.fused_step = os.environ.get("JETS_LSQR_FUSED_STEP", "1") != "0"
+        self.native = None                                    # jh_lsqr_solve* are per-rank loops: lsqr_core drives a team
+
+    def zeros_dom(self):
+        return self.team.zeros(self.T.domain())
+
+    def zeros_rng(self):
+        return self.team.zeros(self.T.ranges())
+
+    def copy(self, dst, src):
+        for k, _ in self.team.each():
+            copyto_(dst[k], src[k])
+        return dst
+
+    def lincomb(self, dst, coefs, xs):
+        for k, _ in self.team.each():
+            lincomb_(dst[k], coefs, [x[k] for x in xs])
+        return dst
+
+    def norm_dom(self, x) -> float:
+        return float(norm(x[0]))                              # replicas are identical
+
+    def norm_rng(self, x) -> float:
+        return math.sqrt(builtins.sum(float(norm(x[k])) ** 2 for k, _ in self.team.each()))
+
+    def fwd(self, u, v, alpha, beta) -> float:
+        return math.sqrt(builtins.sum(self._engines[k]._fwd_local(u[k], v[k], alpha, beta) for k, _ in self.team.each()))
+
+    def step(self, u, v, alpha, beta):
+        if not self.fused_step:
+            return None
+        if self._tmp_d is None:
+            self._tmp_d = self.zeros_dom()
+        nrm2 = self.T.bidiag_step_(u, v, self._tmp_d, alpha, beta)
+        return None if nrm2 is None else (math.sqrt(nrm2), self._tmp_d)
+
+    def adj(self, v, u, alpha, beta) -> float:
+        if self._tmp_d is None:
+            self._tmp_d = self.zeros_dom()
+        self.T.mul_adj_(self._tmp_d, u)
+        self.lincomb(v, [alpha, beta], [self._tmp_d, v])
+        return self.norm_dom(v)
+
+
 def lsqr(A, b, x0=None, damp: float = 0.0, atol: float = 1e-6, btol: float = 1e-6, conlim: float = 1e8, maxiter: int = 100,
          overwrite_b: bool = False, force_maxiter: bool = False) -> LsqrResult:
     """min ||A x - b||_2 (+ damp^2 ||x||^2).  `b` lives in range(A) (a BlockArray for a block operator), the
@@ -191,8 +245,10 @@ def lsqr(A, b, x0=None, damp: float = 0.0, atol: float = 1e-6, btol: float = 1e-
     right-hand side and every rank returns the same x).  `overwrite_b=True` lets the solver use b's storage for
     the Lanczos vector u (at the headline size b is 64 GiB).  `force_maxiter=True` keeps iterating past every
     stopping rule (throughput measurements only)."""
-    from .rowpart import RowPartitionedOp
+    from .rowpart import RowPartitionedOp, TeamOp
 
+    if isinstance(A, TeamOp):                            # one process, several contexts: b and the result are TeamVecs
+        return lsqr_core(_TeamEngine(A), b, x0, damp, atol, btol, conlim, maxiter, overwrite_b, force_maxiter)
     if isinstance(A, RowPartitionedOp):
         eng = _ShardEngine(A)
         dom, rng = _j.domain(A.local_op), _j.range_(A.local_op)

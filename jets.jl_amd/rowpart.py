@@ -378,3 +378,197 @@ def _for_device_abi(part: RowPartition, local_op, comm: AbiComm) -> RowPartition
 
     return RowPartitionedOp(part, local_op, comm, lambda d, A, m: mul_(d, A, m), lambda m, A, d: mul_(m, adjoint(A), d), dot, norm,
                             pipelined_adj=pipelined_adj, pipelined_step=pipelined_step)
+
+
+# ------------------------------------------------------------------ ONE process, several contexts -------------------------
+class TeamVec:
+    """One vector per member of a single-process team: a RANGE-side TeamVec holds every member's rows, a DOMAIN-side one
+    the members' replicas (kept identical by running the same deterministic updates on each)."""
+
+    def __init__(self, members):
+        self.members = list(members)
+
+    def __len__(self):
+        return len(self.members)
+
+    def __getitem__(self, k):
+        return self.members[k]
+
+    def close(self):
+        for x in self.members:
+            x.close()
+
+
+class Team:
+    """SURVEY section 8e's single-process form: this process holds one context per GPU (`device.context_create` /
+    `init(device)`), `jh_comm_init_all` makes them a team, and the exchange step is the members' all-reduces issued between
+    jh_comm_group_begin / jh_comm_group_end.  The members may also be several contexts of ONE GPU (then the grouped sum is a
+    device kernel: RCCL refuses two ranks on a device) -- which is how the one-GPU test box exercises this flow.
+
+        team = Team([ctx0, ctx1, ...])
+        with using_context(team.contexts[k]): A_k = blockop(rows of member k)      # built by the caller, member by member
+        T = team.operator([A_0, A_1, ...])
+        T.mul_(d, m); T.mul_adj_(m, d); lsqr(T, b)                                  # d, m, b: TeamVec
+    """
+
+    def __init__(self, contexts):
+        import ctypes as C
+
+        from ._ffi import lib, check
+
+        self.contexts = [int(c) for c in contexts]
+        arr = (C.c_int * len(self.contexts))(*self.contexts)
+        check(lib.jh_comm_init_all(len(self.contexts), arr))
+        self.world = len(self.contexts)
+        self._lib, self._check = lib, check
+
+    def each(self):
+        """Iterate over (member index, context id) with that context current."""
+        from . import device as _device
+
+        for k, ctx in enumerate(self.contexts):
+            _device.context_use(ctx)
+            yield k, ctx
+
+    def zeros(self, spaces) -> TeamVec:
+        """One zero vector per member: `spaces` is one space (replicated, domain side) or one per member (range side)."""
+        from .arrays import zeros
+
+        per = spaces if isinstance(spaces, (list, tuple)) else [spaces] * self.world
+        return TeamVec([zeros(per[k]) for k, _ in self.each()])
+
+    def group(self):
+        return _TeamGroup(self)
+
+    def operator(self, local_ops) -> "TeamOp":
+        return TeamOp(self, local_ops)
+
+    def synchronize(self):
+        from . import device as _device
+
+        for _ in self.each():
+            _device.synchronize()
+
+    def close(self):
+        from . import device as _device
+
+        _device.context_use(self.contexts[0])
+        self._check(self._lib.jh_comm_destroy())
+
+
+class _TeamGroup:
+    def __init__(self, team):
+        self.team = team
+
+    def __enter__(self):
+        from . import device as _device
+
+        _device.context_use(self.team.contexts[0])
+        self.team._check(self.team._lib.jh_comm_group_begin())
+        return self
+
+    def __exit__(self, et, ev, tb):
+        from . import device as _device
+
+        _device.context_use(self.team.contexts[0])
+        self.team._check(self.team._lib.jh_comm_group_end())
+        return False
+
+
+class TeamOp:
+    """A tall block operator whose rows are spread over the members of a Team: member k holds `local_ops[k]` (built in
+    its context).  Forward: every member's rows from its replica of m, no exchange (src/Jets.jl:1015-1031).  Adjoint:
+    every member's ordered row sum range by range, the grouped all-reduce of a finished range running on the members'
+    exchange streams while the next range computes (1045-1053 summed over members: tolerance parity, like any G > 1)."""
+
+    def __init__(self, team: Team, local_ops):
+        import os
+
+        from . import jetblock as _blk
+
+        if len(local_ops) != team.world:
+            raise ValueError(f"{team.world} members, {len(local_ops)} operators")
+        self.team, self.local_ops = team, list(local_ops)
+        self.nchunks = builtins.max(1, int(os.environ.get("JETS_AR_CHUNKS", "4")))
+        self._natives = []
+        for A in self.local_ops:
+            nat = None
+            if _blk.isblockop(A):
+                jt = A.jet
+                nat = _blk._native_op(jt.s.get("_native"), jt.s["ops"], jt.rng.eltype())
+            self._natives.append(nat)
+
+    def domain(self):
+        from .jets import domain
+
+        return domain(self.local_ops[0])
+
+    def ranges(self):
+        from .jets import range_
+
+        return [range_(A) for A in self.local_ops]
+
+    def mul_(self, d: TeamVec, m: TeamVec) -> TeamVec:
+        from .jets import mul_
+
+        for k, _ in self.team.each():
+            mul_(d[k], self.local_ops[k], m[k])
+        return d
+
+    def _ranged(self, m: TeamVec, enqueue_range) -> bool:
+        """For every range of the domain: every member's kernel for it, then the members' all-reduces of it in one group."""
+        from ._ffi import lib, check
+
+        if any(n is None for n in self._natives):
+            return False
+        for lo, cnt in _chunk_bounds(m[0].length(), self.nchunks):
+            for k, _ in self.team.each():
+                enqueue_range(k, lo, cnt)
+            with self.team.group():
+                for k in builtins.range(self.team.world):
+                    check(lib.jh_comm_allreduce_sum_range(m[k].handle, lo, cnt))
+        for _ in self.team.each():
+            check(lib.jh_comm_join())
+        return True
+
+    def mul_adj_(self, m: TeamVec, d: TeamVec) -> TeamVec:
+        from ._ffi import lib, check, JetsHipError
+        from .jets import mul_, adjoint
+
+        try:
+            if self._ranged(m, lambda k, lo, cnt: check(lib.jh_blockop_mul_adj_range(self._natives[k].handle, m[k].handle, d[k].handle, lo, cnt))):
+                return m
+        except JetsHipError as e:
+            if e.status != 4:                                  # JH_ERR_UNSUPPORTED comes before anything is enqueued (every member alike)
+                raise
+        for k, _ in self.team.each():
+            mul_(m[k], adjoint(self.local_ops[k]), d[k])
+        with self.team.group():
+            for k in builtins.range(self.team.world):
+                check(lib.jh_comm_allreduce_sum(m[k].handle))
+        return m
+
+    def bidiag_step_(self, u: TeamVec, v: TeamVec, w: TeamVec, alpha: float, beta: float):
+        """One Golub-Kahan step on every member (jh_blockop_bidiag_step_range per range) with the ranged exchange of w;
+        returns the GLOBAL ||u||^2 -- the host adds the members' deferred accumulators -- or None without a ranged kernel."""
+        import ctypes as C
+
+        from ._ffi import lib, check, JetsHipError
+
+        if any(n is None for n in self._natives):
+            return None
+        for _ in self.team.each():
+            check(lib.jh_normsq_reset())
+        try:
+            self._ranged(w, lambda k, lo, cnt: check(lib.jh_blockop_bidiag_step_range(
+                self._natives[k].handle, u[k].handle, v[k].handle, w[k].handle, float(alpha), float(beta), lo, cnt, None)))
+        except JetsHipError as e:
+            if e.status != 4:
+                raise
+            return None
+        total = 0.0
+        out = C.c_double(0)
+        for _ in self.team.each():
+            check(lib.jh_normsq_read(C.byref(out)))          # synchronises this member's stream
+            total += out.value
+        return total
