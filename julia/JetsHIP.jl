@@ -410,6 +410,21 @@ end
 const _handles = IdDict{Any,Ptr{Cvoid}}()        # ops matrix -> jh_blockop* (C_NULL: has a child the device does not know)
 const _points = IdDict{Any,Any}()                # ops matrix -> the mₒ the device operator borrows (kept alive here)
 
+# several contexts in one session: make the context of the first coefficient array current before jh_blockop_create
+function _enter_context_of_coefficients(ops)
+    for op in ops
+        base = op isa JopAdjoint ? op.op : op
+        st = state(base)
+        arr = hasproperty(st, :diagonal) ? st.diagonal : (hasproperty(st, :A) ? st.A : nothing)
+        if arr isa HipArray
+            c = Ref{Cint}(-1)
+            check(ccall((:jh_bvec_context, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}, Ptr{Cint}), arr.slab.handle, c, C_NULL))
+            check(ccall((:jh_context_use, LIB), Cint, (Cint,), c[]))
+            return
+        end
+    end
+end
+
 function native_handle(ops::AbstractMatrix{<:Jop}, ::Type{T}) where {T}
     get!(_handles, ops) do
         descs = [block_desc(ops[i,j]) for i = 1:size(ops,1), j = 1:size(ops,2)]      # column-major == the C layout
@@ -417,6 +432,7 @@ function native_handle(ops::AbstractMatrix{<:Jop}, ::Type{T}) where {T}
         row_len = Int64[length(range(ops[i,1])) for i = 1:size(ops,1)]
         col_len = Int64[length(domain(ops[1,j])) for j = 1:size(ops,2)]
         h = Ref{Ptr{Cvoid}}()
+        _enter_context_of_coefficients(ops)                                          # the operator lives where its coefficients live
         check(ccall((:jh_blockop_create, LIB), Cint, (Int64, Int64, Ptr{jh_block_desc}, Ptr{Int64}, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}),
                     size(ops,1), size(ops,2), vec(convert(Matrix{jh_block_desc}, descs)), row_len, col_len, dtype_code(T), h))
         h[]
@@ -571,6 +587,103 @@ function bidiag_step_partitioned!(u::BlockArray{T,<:HipArray{T}}, w::HipArray{T}
     check(ccall((:jh_comm_allreduce_normsq, LIB), Cint, (Ref{Cdouble},), nrm2))
     sqrt(nrm2[])
 end
+# ---------------------------------------------------------------- ONE Julia session, several GPUs (SURVEY section 8e)
+# A context = one device + one stream + the library's workspaces for it (include/jetship.h, Conventions).  `init(device)` makes
+# the device's primary context current; arrays are allocated in the CURRENT context and every operation runs in the context of
+# its arrays, so a session can hold one shard of a tall operator per GPU:
+#     ctxs = [ (JetsHIP.init(dev); JetsHIP.context_current()[1]) for dev in 0:ndev-1 ]
+#     JetsHIP.comm_init_all(ctxs)
+#     As = [ JetsHIP.with_context(ctxs[k]) do; @blockop [JopHipDiagonal(...) for i in rows_of_member_k, j=1:1]; end for k in 1:ndev ]
+#     JetsHIP.mul_adj_team!(ms, As, ds)        # ms[k]: member k's replica of the domain vector, ds[k]: its rows
+context_create(device::Integer) = (c = Ref{Cint}(-1); check(ccall((:jh_context_create, LIB), Cint, (Cint, Ref{Cint}), device, c)); _inited[] = true; Int(c[]))
+use_context(ctx::Integer) = check(ccall((:jh_context_use, LIB), Cint, (Cint,), ctx))
+set_device(device::Integer) = check(ccall((:jh_set_device, LIB), Cint, (Cint,), device))
+context_destroy(ctx::Integer) = check(ccall((:jh_context_destroy, LIB), Cint, (Cint,), ctx))
+function context_current()
+    c, d = Ref{Cint}(-1), Ref{Cint}(-1)
+    check(ccall((:jh_context_current, LIB), Cint, (Ref{Cint}, Ref{Cint}), c, d))
+    (Int(c[]), Int(d[]))
+end
+function context_of(x::DevVec)
+    c = Ref{Cint}(-1)
+    check(ccall((:jh_bvec_context, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}, Ptr{Cint}), handle(x), c, C_NULL))
+    Int(c[])
+end
+function with_context(f, ctx::Integer)
+    prev = context_current()[1]
+    use_context(ctx)
+    try
+        return f()
+    finally
+        use_context(prev)
+    end
+end
+comm_init_all(ctxs::Vector{<:Integer}) = check(ccall((:jh_comm_init_all, LIB), Cint, (Cint, Ptr{Cint}), length(ctxs), Cint.(ctxs)))
+# the members' all-reduces of one collective, issued between ncclGroupStart / ncclGroupEnd
+function comm_group(f)
+    check(ccall((:jh_comm_group_begin, LIB), Cint, ()))
+    try
+        f()
+    finally
+        check(ccall((:jh_comm_group_end, LIB), Cint, ()))
+    end
+end
+# adjoint of a tall operator whose rows are spread over the members of a team: every member's ordered row sum range by range,
+# the grouped all-reduce of a finished range on the members' exchange streams while the next range computes
+function mul_adj_team!(ms::Vector{<:HipArray{T}}, As::Vector{<:JopLn}, ds::Vector{<:BlockArray{T,<:HipArray{T}}}; chunks::Integer=4) where {T}
+    hs = [tall_native(A, T) for A in As]
+    n = length(ms[1])
+    step = cld(cld(n, max(chunks, 1)), 16384) * 16384
+    for lo = 0:step:n-1
+        cnt = min(step, n - lo)
+        for k in eachindex(As)
+            check(ccall((:jh_blockop_mul_adj_range, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64), hs[k], handle(ms[k]), handle(ds[k]), lo, cnt))
+        end
+        comm_group() do
+            for k in eachindex(As)
+                check(ccall((:jh_comm_allreduce_sum_range, LIB), Cint, (Ptr{Cvoid}, Int64, Int64), handle(ms[k]), lo, cnt))
+            end
+        end
+    end
+    for k in eachindex(As)
+        use_context(context_of(ms[k]))
+        check(ccall((:jh_comm_join, LIB), Cint, ()))
+    end
+    ms
+end
+# one Golub-Kahan step over the team; returns the GLOBAL ||u|| (the host adds the members' deferred accumulators)
+function bidiag_step_team!(us::Vector{<:BlockArray{T,<:HipArray{T}}}, ws::Vector{<:HipArray{T}}, As::Vector{<:JopLn}, vs::Vector{<:HipArray{T}},
+                           alpha::Real, beta::Real; chunks::Integer=4) where {T}
+    hs = [tall_native(A, T) for A in As]
+    for k in eachindex(As)
+        use_context(context_of(ws[k]))
+        check(ccall((:jh_normsq_reset, LIB), Cint, ()))
+    end
+    n = length(ws[1])
+    step = cld(cld(n, max(chunks, 1)), 16384) * 16384
+    for lo = 0:step:n-1
+        cnt = min(step, n - lo)
+        for k in eachindex(As)
+            check(ccall((:jh_blockop_bidiag_step_range, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Int64, Int64, Ptr{Cdouble}),
+                        hs[k], handle(us[k]), handle(vs[k]), handle(ws[k]), alpha, beta, lo, cnt, C_NULL))
+        end
+        comm_group() do
+            for k in eachindex(As)
+                check(ccall((:jh_comm_allreduce_sum_range, LIB), Cint, (Ptr{Cvoid}, Int64, Int64), handle(ws[k]), lo, cnt))
+            end
+        end
+    end
+    total = 0.0
+    for k in eachindex(As)
+        use_context(context_of(ws[k]))
+        check(ccall((:jh_comm_join, LIB), Cint, ()))
+        part = Ref{Cdouble}()
+        check(ccall((:jh_normsq_read, LIB), Cint, (Ref{Cdouble},), part))          # synchronises this member's stream
+        total += part[]
+    end
+    sqrt(total)
+end
+
 # measured per-operator choices (the grid walk of the tall forward): read from one operator, set on another / in another process
 function tune_get(A::JopLn, name::AbstractString)
     v = Ref{Int64}()

@@ -214,6 +214,72 @@ int main(void)
         CK(jh_bvec_destroy(u)); CK(jh_bvec_destroy(u2)); CK(jh_bvec_destroy(v)); CK(jh_bvec_destroy(w)); CK(jh_bvec_destroy(w2));
     }
 
+    /* ---- ONE process, several contexts (include/jetship.h Conventions): a team of two contexts -- one per device
+     *      when two devices are visible (RCCL), else two streams of this device (the sum is a device kernel) -- each holding
+     *      half of A's rows; the grouped, ranged all-reduce makes both replicas of A'd the full sum */
+    {
+        int ctx[2] = {-1, -1}, dev0 = -1;
+        CK(jh_context_current(&ctx[0], &dev0));
+        if (ndev >= 2) { CK(jh_init(1)); CK(jh_context_current(&ctx[1], NULL)); }
+        else CK(jh_context_create(0, &ctx[1]));
+        REQUIRE(ctx[1] != ctx[0], "a second context");
+        CK(jh_comm_init_all(2, ctx));
+        const int half_rows = NROW / 2;
+        jh_bvec *cf[2], *dd[2], *mm[2], *mo[2];
+        jh_blockop *Ah[2];
+        for (int k = 0; k < 2; k++) {
+            CK(jh_context_use(ctx[k]));                         /* factories allocate in the CURRENT context */
+            CK(jh_bvec_create(half_rows, lens, JH_F32, &cf[k]));
+            CK(jh_bvec_create(half_rows, lens, JH_F32, &dd[k]));
+            CK(jh_bvec_create(1, lens, JH_F32, &mm[k]));
+            CK(jh_bvec_create(1, lens, JH_F32, &mo[k]));
+            CK(jh_fill_uniform(cf[k], 1, 0, (int64_t)k * half_rows * n));      /* rows k*6 .. k*6+5 of the same generator stream */
+            CK(jh_fill_uniform(mm[k], 2, 0, 0));
+            int kc = -1;
+            CK(jh_bvec_context(cf[k], &kc, NULL));
+            REQUIRE(kc == ctx[k], "a vector remembers its context");
+            jh_block_desc dk[NROW];
+            memset(dk, 0, sizeof dk);
+            for (int i = 0; i < half_rows; i++) {
+                void *ptr = NULL;
+                CK(jh_bvec_block(cf[k], i, NULL, NULL, &ptr));
+                dk[i].kind = JH_OP_DIAG; dk[i].coeff = ptr; dk[i].nr = dk[i].nc = n;
+            }
+            CK(jh_blockop_create(half_rows, 1, dk, lens, col_len, JH_F32, &Ah[k]));
+        }
+        CK(jh_context_use(ctx[0]));                             /* whatever is current: calls run in their handles' context */
+        for (int k = 0; k < 2; k++) CK(jh_blockop_mul(Ah[k], dd[k], mm[k]));
+        REQUIRE(jh_blockop_mul(Ah[0], dd[1], mm[0]) == JH_ERR_INVALID, "handles of different contexts in one call are refused");
+        REQUIRE(jh_comm_allreduce_sum(mo[0]) == JH_ERR_STATE, "a member's collective outside a group is refused");
+        const int64_t cut = (n / 2) / 16384 * 16384 > 0 ? (n / 2) / 16384 * 16384 : (n / 2) / 4 * 4;
+        const int64_t lo[2] = {0, cut}, cnt[2] = {cut, n - cut};
+        for (int r = 0; r < 2; r++) {
+            for (int k = 0; k < 2; k++) CK(jh_blockop_mul_adj_range(Ah[k], mo[k], dd[k], lo[r], cnt[r]));
+            CK(jh_comm_group_begin());
+            for (int k = 0; k < 2; k++) CK(jh_comm_allreduce_sum_range(mo[k], lo[r], cnt[r]));
+            CK(jh_comm_group_end());
+        }
+        float *h0 = malloc((size_t)n * sizeof(float)), *h1 = malloc((size_t)n * sizeof(float));
+        REQUIRE(h0 && h1, "host allocation");
+        for (int k = 0; k < 2; k++) { CK(jh_context_use(ctx[k])); CK(jh_comm_join()); }
+        CK(jh_download(mo[0], 0, n, h0));
+        CK(jh_download(mo[1], 0, n, h1));
+        REQUIRE(memcmp(h0, h1, (size_t)n * sizeof(float)) == 0, "the members' replicas of A'd are identical");
+        double num = 0, den = 0;                               /* vs the one-context ordered sum: another summation order */
+        for (int64_t k = 0; k < n; k++) { num += (double)(h0[k] - hmt[k]) * (h0[k] - hmt[k]); den += (double)hmt[k] * hmt[k]; }
+        REQUIRE(sqrt(num / den) < 1e-6, "team adjoint within 1e-6 of the ordered sum");
+        printf("team of two contexts (%s): replicas identical, rel. difference to the ordered sum %.1e\n", ndev >= 2 ? "two devices, RCCL" : "one device", sqrt(num / den));
+        free(h0); free(h1);
+        CK(jh_context_use(ctx[0]));
+        CK(jh_comm_destroy());
+        for (int k = 0; k < 2; k++) {
+            CK(jh_blockop_destroy(Ah[k]));
+            CK(jh_bvec_destroy(cf[k])); CK(jh_bvec_destroy(dd[k])); CK(jh_bvec_destroy(mm[k])); CK(jh_bvec_destroy(mo[k]));
+        }
+        if (ndev < 2) CK(jh_context_destroy(ctx[1]));
+        CK(jh_context_use(ctx[0]));
+    }
+
     CK(jh_blockop_destroy(A));
     CK(jh_bvec_destroy(coeff));
     CK(jh_bvec_destroy(d));
