@@ -193,3 +193,46 @@ def test_a_team_of_contexts_runs_the_row_partitioned_flow(Jets, oracle, nmem):
         J.context_use(home)
         for c in extra:
             J.context_destroy(c)
+
+
+def test_a_team_of_one_goes_through_rccl(Jets, oracle):
+    """jh_comm_init_all with ONE context takes the RCCL branch (ncclCommInitAll over one device, ncclGroupStart / ncclGroupEnd
+    around the ranged all-reduces) -- the code a multi-device team runs, minus the peers: the pipelined adjoint and the one-pass
+    step then equal the single-context ordered walk bit for bit."""
+    from jets_jl_amd import rowpart
+
+    J = Jets
+    J.init(0)
+    home = J.context_current()[0]
+    dt, nrow, shape = np.float32, 6, (64, 64, 16)
+    n = int(np.prod(shape))
+    spc = J.JetSpace(dt, *shape)
+    ctx = J.context_create(0)
+    team = rowpart.Team([ctx])
+    try:
+        with J.using_context(ctx):
+            cs = [J.rand(spc, seed=1, stream=0, index_base=i * n) for i in range(nrow)]
+            A = J.blockop([[J.JopDiagonal(c)] for c in cs])
+            m = rowpart.TeamVec([J.rand(spc, seed=2, stream=0)])
+        T = team.operator([A])
+        d = team.zeros(T.ranges())
+        T.mul_(d, m)
+        mt = team.zeros(T.domain())
+        T.mul_adj_(mt, d)
+        ops = [[oracle.Block("diag", n, coeff=oracle.rng_u01(dt, 1, 0, i * n, n))] for i in range(nrow)]
+        hm = u01(oracle, dt, 2, 0, n)
+        want_d = oracle.block_df(ops, [np.zeros(n, dt) for _ in range(nrow)], [hm])
+        assert_bits_equal(mt[0].to_numpy().ravel(order="F"), oracle.block_df_adj(ops, [np.zeros(n, dt)], want_d)[0], "team of one: adjoint")
+        u = rowpart.TeamVec([J.rand(T.ranges()[0], seed=3, stream=0)])
+        hu = [oracle.rng_u01(dt, 3, 0, i * n, n) for i in range(nrow)]
+        w = team.zeros(T.domain())
+        nrm2 = T.bidiag_step_(u, m, w, 1.0, -0.5)
+        want_u = oracle.barr_lincomb([np.empty(n, dt) for _ in range(nrow)], [1.0, -0.5], [want_d, hu])
+        assert_bits_equal(u[0].to_numpy(), np.concatenate(want_u), "team of one: one-pass step, u")
+        assert_bits_equal(w[0].to_numpy().ravel(order="F"), oracle.block_df_adj(ops, [np.zeros(n, dt)], want_u)[0], "team of one: one-pass step, w")
+        assert nrm2 > 0
+        J.close(A)
+    finally:
+        team.close()
+        J.context_use(home)
+        J.context_destroy(ctx)
