@@ -299,6 +299,12 @@ int jh_lsqr_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, doub
                   int maxiter, int force_maxiter, jh_lsqr_result *res, double *history);
 int jh_lsqr_solve_partitioned(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol,
                               double conlim, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history);
+/* The same solve for a single-process TEAM (jh_comm_init_all, below): member k's context holds ops[k] (its block rows), us[k] (its
+ * rows of b; overwritten) and xs[k] (its replica of x; all replicas come out bit-identical).  One call, one host thread: the
+ * members' kernels are enqueued one after the other, the ranged all-reduces of a range go out as one group, scalars are added on
+ * the host. */
+int jh_lsqr_solve_team(int n, const jh_blockop *const *ops, jh_bvec *const *us, jh_bvec *const *xs, int use_x0, double damp, double atol,
+                       double btol, double conlim, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history);
 /* ---------------------------------------------------------------- RCCL over xGMI ----------- */
 /* Row partition of a tall operator across the GPUs of a node (one process per GPU): the forward needs no exchange
  * (src/Jets.jl:1015-1031), the adjoint is a sum over rows (1045-1053) -> one in-place all-reduce of the domain vector
@@ -315,7 +321,8 @@ int jh_comm_info(int *nranks, int *rank);                       /* of the curren
  * device).  The host issues jh_comm_allreduce_sum / _sum_range once PER MEMBER between jh_comm_group_begin and
  * jh_comm_group_end (ncclGroupStart / ncclGroupEnd; outside a group a member's call is refused -- a single thread would block
  * in it).  Scalars need no collective in a team: the host reads every member's partial (jh_normsq_read, jh_dot, jh_norm) and
- * combines them; jh_comm_allreduce_scalars / _normsq and jh_lsqr_solve_partitioned are for one-process-per-GPU ranks. */
+ * combines them (jh_lsqr_solve_team does all of this behind one call); jh_comm_allreduce_scalars / _normsq and
+ * jh_lsqr_solve_partitioned are for one-process-per-GPU ranks. */
 int jh_comm_init_all(int n, const int *contexts);
 int jh_comm_group_begin(void);                                  /* on a member context of the team */
 int jh_comm_group_end(void);

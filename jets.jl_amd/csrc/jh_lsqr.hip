@@ -118,67 +118,104 @@ int launch_xw(int dtype, jh_bvec *v, jh_bvec *x, jh_bvec *w, double cv, double t
 
 }  // namespace
 
-// `dist`: op/u are this rank's block rows of a row-partitioned operator and the exchange runs over the communicator of
-// jh_comm_init_rank.  The CALLER says so (jh_lsqr_solve_partitioned); a communicator merely being alive never turns a
-// rank-local solve into a collective one.
-static int lsqr_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, double conlim,
-                     int maxiter, int force_maxiter, jh_lsqr_result *res, double *history, const bool dist)
+// WHO sums across shards of the operator:
+//   none   one context holds all rows (jh_lsqr_solve);
+//   ranks  op/u are THIS rank's block rows of a row-partitioned operator and the exchange runs over the communicator of
+//          jh_comm_init_rank -- the CALLER says so (jh_lsqr_solve_partitioned); a communicator merely being alive never turns a
+//          rank-local solve into a collective one;
+//   team   this process holds M shards, one per member context of a single-process team (jh_comm_init_all): the members'
+//          kernels are enqueued one after the other (they return after enqueue, so the GPUs run concurrently), the ranged
+//          all-reduces of a range are issued as one group, scalars are added on the host from the members' partials, and the
+//          domain-side updates run redundantly on every member with the SAME host scalars, so the replicas stay bit-identical.
+enum class Exch { none, ranks, team };
+
+static int lsqr_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *us, jh_bvec *const *xs, int use_x0, double damp, double atol,
+                     double btol, double conlim, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history, const Exch ex)
 {
-    JH_TRY(jh_enter(op, u, x));
-    JH_REQUIRE(op && u && x && res, "jh_lsqr_solve: null argument");
+    JH_REQUIRE(ops && us && xs && res && M >= 1, "jh_lsqr_solve: null argument");
     JH_REQUIRE(maxiter >= 0, "jh_lsqr_solve: maxiter must be >= 0");
+    for (int k = 0; k < M; k++) JH_REQUIRE(ops[k] && us[k] && xs[k], "jh_lsqr_solve: null argument (member %d)", k);
+    auto use = [&](int k) { return jh_enter(ops[k], us[k], xs[k]); };
+    JH_TRY(use(0));
     int64_t nb = 0, n = 0;
     int dtype = 0;
-    JH_TRY(jh_bvec_info(x, &nb, &n, &dtype, nullptr));
-    if (!jh_blockop_tall_fast(op, u->data, x->data))                    // before anything is touched: the caller can still take another path
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_lsqr_solve: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
-    Tmp t;
+    JH_TRY(jh_bvec_info(xs[0], &nb, &n, &dtype, nullptr));
+    for (int k = 0; k < M; k++) {
+        JH_REQUIRE(xs[k]->length == n && xs[k]->dtype == dtype, "jh_lsqr_solve: member %d's x differs in length or element type", k);
+        if (!jh_blockop_tall_fast(ops[k], us[k]->data, xs[k]->data))    // before anything is touched: the caller can still take another path
+            return jh_fail(JH_ERR_UNSUPPORTED, "jh_lsqr_solve: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
+    }
+    std::vector<Tmp> t((size_t)M);
     const int64_t len1[1] = {n};
-    JH_TRY(jh_bvec_create(1, len1, dtype, &t.v));
-    JH_TRY(jh_bvec_create(1, len1, dtype, &t.w));
-    JH_TRY(jh_bvec_create(1, len1, dtype, &t.atu));
     const int64_t ns_dom = n * (jh_dtype_complex(dtype) ? 2 : 1);
     int grid = (int)((ns_dom + 255) / 256 < 4096 ? (ns_dom + 255) / 256 : 4096);
     if (grid < 1) grid = 1;
-    JH_CHECK_HIP(hipMalloc((void **)&t.parts, sizeof(double) * (2 * (size_t)grid + 2)));
-    double *parts_v = t.parts, *parts_w = t.parts + grid, *slot_v = t.parts + 2 * grid, *slot_w = slot_v + 1;
-    jh_context &c = jh_ctx();
+    for (int k = 0; k < M; k++) {
+        JH_TRY(use(k));
+        JH_TRY(jh_bvec_create(1, len1, dtype, &t[k].v));
+        JH_TRY(jh_bvec_create(1, len1, dtype, &t[k].w));
+        JH_TRY(jh_bvec_create(1, len1, dtype, &t[k].atu));
+        JH_CHECK_HIP(hipMalloc((void **)&t[k].parts, sizeof(double) * (2 * (size_t)grid + 2)));
+    }
+    auto parts_v = [&](int k) { return t[k].parts; };
+    auto parts_w = [&](int k) { return t[k].parts + grid; };
+    double *slot_v = t[0].parts + 2 * grid, *slot_w = slot_v + 1;        // member 0 folds and reports the domain-side norms
+    JH_TRY(use(0));
+    jh_context &c = jh_ctx();                                            // member 0's context: its stream carries the read-backs
     *res = jh_lsqr_result{};
     int64_t chunk = (n + 3) / 4;                                          // exchange ranges: 4, on 64 KiB boundaries
     chunk = (chunk + 16383) / 16384 * 16384;
 
-    auto global_sum = [&](double local, double *out) -> int {
-        *out = local;
-        if (dist) JH_TRY(jh_comm_allreduce_scalars(out, 1, 0));
+    // sum of one scalar per member, then over the ranks
+    auto global_sum = [&](const std::vector<double> &locals, double *out) -> int {
+        double s = 0.0;
+        for (double v : locals) s += v;
+        *out = s;
+        if (ex == Exch::ranks) JH_TRY(jh_comm_allreduce_scalars(out, 1, 0));
         return JH_OK;
     };
+    // the members' all-reduces of one collective
+    auto exchange = [&](auto &&one) -> int {
+        if (ex == Exch::none) return JH_OK;
+        if (ex == Exch::team) { JH_TRY(use(0)); JH_TRY(jh_comm_group_begin()); }
+        int st = JH_OK;
+        for (int k = 0; k < M && st == JH_OK; k++) st = one(k);
+        if (ex == Exch::team) { (void)use(0); const int st2 = jh_comm_group_end(); if (st == JH_OK) st = st2; }
+        return st;
+    };
+    std::vector<double> locals((size_t)M);
 
-    if (!use_x0) JH_TRY(jh_fill(x, 0.0, 0.0));
-    double nrm = 0.0, s2 = 0.0;
-    JH_TRY(jh_norm(u, 2.0, &nrm));                                       // ||b|| (this rank's rows)
-    JH_TRY(global_sum(nrm * nrm, &s2));
+    double s2 = 0.0;
+    for (int k = 0; k < M; k++) {
+        if (!use_x0) JH_TRY(jh_fill(xs[k], 0.0, 0.0));
+        double nrm = 0.0;
+        JH_TRY(jh_norm(us[k], 2.0, &nrm));                               // ||b|| (this shard's rows)
+        locals[k] = nrm * nrm;
+    }
+    JH_TRY(global_sum(locals, &s2));
     const double bnorm = std::sqrt(s2);
     double beta = bnorm;
     if (use_x0) {                                                        // u <- b - A x0
-        double local = 0.0;
-        JH_TRY(jh_blockop_mul_axpby(op, u, x, -1.0, 1.0, &local));
-        JH_TRY(global_sum(local, &s2));
+        for (int k = 0; k < M; k++) JH_TRY(jh_blockop_mul_axpby(ops[k], us[k], xs[k], -1.0, 1.0, &locals[k]));
+        JH_TRY(global_sum(locals, &s2));
         beta = std::sqrt(s2);
     }
     double alpha = 0.0;
     if (beta > 0) {                                                      // v = A'u / beta
-        JH_TRY(jh_blockop_mul_adj(op, t.atu, u));
-        if (dist) JH_TRY(jh_comm_allreduce_sum(t.atu));
-        JH_TRY(lincomb1(t.v, 1.0 / beta, t.atu));
-        JH_TRY(jh_norm(t.v, 2.0, &alpha));
+        for (int k = 0; k < M; k++) JH_TRY(jh_blockop_mul_adj(ops[k], t[k].atu, us[k]));
+        JH_TRY(exchange([&](int k) { return jh_comm_allreduce_sum(t[k].atu); }));
+        for (int k = 0; k < M; k++) JH_TRY(lincomb1(t[k].v, 1.0 / beta, t[k].atu));
+        JH_TRY(jh_norm(t[0].v, 2.0, &alpha));                            // replicas are identical: member 0 speaks for all
     } else {
-        JH_TRY(jh_copy(t.v, x));
+        for (int k = 0; k < M; k++) JH_TRY(jh_copy(t[k].v, xs[k]));
     }
-    if (alpha > 0) JH_TRY(lincomb1(t.v, 1.0 / alpha, t.v));
-    JH_TRY(jh_copy(t.w, t.v));
+    for (int k = 0; k < M; k++) {
+        if (alpha > 0) JH_TRY(lincomb1(t[k].v, 1.0 / alpha, t[k].v));
+        JH_TRY(jh_copy(t[k].w, t[k].v));
+    }
     double wnorm = 0.0;                                                  // ||w_k||, needed one iteration after w_k is written
-    JH_TRY(jh_norm(t.w, 2.0, &wnorm));
-    bool wnorm_pending = false;                                          // the value is in flight to red_host[5]
+    JH_TRY(jh_norm(t[0].w, 2.0, &wnorm));
+    bool wnorm_pending = false;                                          // the value is in flight to member 0's red_host[5]
 
     double rhobar = alpha, phibar = beta, rnorm = beta, r1norm = beta, r2norm = beta, arnorm = alpha * beta;
     double anorm = 0, acond = 0, ddnorm = 0, res2 = 0, xnorm = 0, xxnorm = 0, z = 0, cs2 = -1.0, sn2 = 0.0;
@@ -189,32 +226,45 @@ static int lsqr_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, d
             itn++;
             // ---- bidiagonalisation in one pass:  beta*u = A v - alpha*u ;  alpha*v = A'u - beta*v
             const double beta_prev = beta;
-            double local = 0.0;
-            if (dist) {
-                // this rank's rows in 4 element ranges: the all-reduce of a finished range of A'u runs on the exchange stream while
-                // the kernel of the next range computes; ||u||^2 accumulates on the device and is summed over the ranks behind the
-                // last range -- ONE host synchronisation for the whole distributed step
-                JH_TRY(jh_normsq_reset());
+            if (ex != Exch::none) {
+                // every shard's rows in 4 element ranges: the all-reduce of a finished range of A'u runs on the exchange stream while
+                // the kernel of the next range computes; ||u||^2 accumulates on the device and is summed behind the last range --
+                // ONE host synchronisation per shard for the whole distributed step
+                for (int k = 0; k < M; k++) { JH_TRY(use(k)); JH_TRY(jh_normsq_reset()); }
                 for (int64_t lo = 0; lo < n; lo += chunk) {
                     const int64_t cnt = lo + chunk < n ? chunk : n - lo;
-                    JH_TRY(jh_blockop_bidiag_step_range(op, u, t.v, t.atu, 1.0, -alpha / beta_prev, lo, cnt, nullptr));
-                    JH_TRY(jh_comm_allreduce_sum_range(t.atu, lo, cnt));
+                    for (int k = 0; k < M; k++)
+                        JH_TRY(jh_blockop_bidiag_step_range(ops[k], us[k], t[k].v, t[k].atu, 1.0, -alpha / beta_prev, lo, cnt, nullptr));
+                    JH_TRY(exchange([&](int k) { return jh_comm_allreduce_sum_range(t[k].atu, lo, cnt); }));
                 }
-                JH_TRY(jh_comm_allreduce_normsq(&s2));
+                if (ex == Exch::ranks) {
+                    JH_TRY(jh_comm_allreduce_normsq(&s2));
+                } else {                                                 // team: the host adds the members' accumulators
+                    s2 = 0.0;
+                    for (int k = M - 1; k >= 0; k--) {                   // member 0 last: its synchronisation also lands wnorm (below)
+                        JH_TRY(use(k));
+                        JH_TRY(jh_comm_join());
+                        double part = 0.0;
+                        JH_TRY(jh_normsq_read(&part));
+                        s2 += part;
+                    }
+                }
             } else {
-                JH_TRY(jh_blockop_bidiag_step(op, u, t.v, t.atu, 1.0, -alpha / beta_prev, &local));
-                s2 = local;
+                JH_TRY(jh_blockop_bidiag_step(ops[0], us[0], t[0].v, t[0].atu, 1.0, -alpha / beta_prev, &s2));
             }
             beta = std::sqrt(s2);
-            if (wnorm_pending) {                                         // the step's read-back synchronised the stream: it has landed
+            if (wnorm_pending) {                                         // the step's read-back synchronised member 0's stream: it has landed
                 wnorm = std::sqrt(c.red_host[5]);
                 wnorm_pending = false;
             }
             double cv = 1.0;                                             // normalisation of v, applied by the x/w kernel below
             if (beta > 0) {
                 anorm = std::sqrt(anorm * anorm + alpha * alpha + beta * beta + damp * damp);
-                JH_TRY(launch_vhat(dtype, t.v, t.atu, 1.0 / beta, -beta, parts_v, grid));   // v <- A'(u_hat)/beta - beta v, ||v||^2
-                hipLaunchKernelGGL(k_lsqr_fold, dim3(1), dim3(256), 0, c.stream, parts_v, grid, slot_v);
+                for (int k = M - 1; k >= 0; k--) {                       // v <- A'(u_hat)/beta - beta v, ||v||^2 (member 0 last: it reports)
+                    JH_TRY(use(k));
+                    JH_TRY(launch_vhat(dtype, t[k].v, t[k].atu, 1.0 / beta, -beta, parts_v(k), grid));
+                }
+                hipLaunchKernelGGL(k_lsqr_fold, dim3(1), dim3(256), 0, c.stream, parts_v(0), grid, slot_v);
                 JH_CHECK_HIP(hipGetLastError());
                 JH_CHECK_HIP(hipMemcpyAsync(c.red_host + 4, slot_v, sizeof(double), hipMemcpyDeviceToHost, c.stream));
                 JH_CHECK_HIP(hipStreamSynchronize(c.stream));
@@ -236,8 +286,11 @@ static int lsqr_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, d
             // ---- update x and w
             const double t1 = phi / rho, t2 = -theta / rho;
             ddnorm += (wnorm / rho) * (wnorm / rho);
-            JH_TRY(launch_xw(dtype, t.v, x, t.w, cv, t1, t2, parts_w, grid));     // v normalised; x += t1 w; w = v + t2 w; ||w||^2
-            hipLaunchKernelGGL(k_lsqr_fold, dim3(1), dim3(256), 0, c.stream, parts_w, grid, slot_w);
+            for (int k = M - 1; k >= 0; k--) {                           // v normalised; x += t1 w; w = v + t2 w; ||w||^2
+                JH_TRY(use(k));
+                JH_TRY(launch_xw(dtype, t[k].v, xs[k], t[k].w, cv, t1, t2, parts_w(k), grid));
+            }
+            hipLaunchKernelGGL(k_lsqr_fold, dim3(1), dim3(256), 0, c.stream, parts_w(0), grid, slot_w);
             JH_CHECK_HIP(hipGetLastError());
             JH_CHECK_HIP(hipMemcpyAsync(c.red_host + 5, slot_w, sizeof(double), hipMemcpyDeviceToHost, c.stream));   // read after the next sync
             wnorm_pending = true;
@@ -281,14 +334,17 @@ static int lsqr_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, d
     res->acond = acond;
     res->arnorm = arnorm;
     res->xnorm = xnorm;
-    JH_CHECK_HIP(hipStreamSynchronize(c.stream));                        // the temporaries die here
+    for (int k = 0; k < M; k++) {                                        // the temporaries die here
+        jh_context *ck = jh_ctx_by_id(ops[k]->ctx);
+        if (ck) { JH_TRY(use(k)); JH_CHECK_HIP(hipStreamSynchronize(ck->stream)); }
+    }
     return JH_OK;
 }
 
 extern "C" int jh_lsqr_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, double conlim,
                              int maxiter, int force_maxiter, jh_lsqr_result *res, double *history)
 {
-    return lsqr_impl(op, u, x, use_x0, damp, atol, btol, conlim, maxiter, force_maxiter, res, history, false);
+    return lsqr_impl(1, &op, &u, &x, use_x0, damp, atol, btol, conlim, maxiter, force_maxiter, res, history, Exch::none);
 }
 
 extern "C" int jh_lsqr_solve_partitioned(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol,
@@ -299,10 +355,29 @@ extern "C" int jh_lsqr_solve_partitioned(const jh_blockop *op, jh_bvec *u, jh_bv
     (void)jh_comm_info(&nranks, &rank);
     (void)jh_comm_exists(&has_comm);
     if (has_comm == 2 && (nranks > 1 || jh_ctx().force_dist))
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_lsqr_solve_partitioned: this context is a member of a single-process team (jh_comm_init_all); the loop over "
-                       "the members belongs to the host there (jh_blockop_bidiag_step_range per member + grouped all-reduces)");
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_lsqr_solve_partitioned: this context is a member of a single-process team (jh_comm_init_all): "
+                       "jh_lsqr_solve_team takes all the members' shards in one call");
     // one rank: nothing to exchange (jh_comm_init_rank is then optional, so a one-GPU run of partitioned host code works);
     // the knob force_dist runs the exchange all the same (validation of the pipelined path with a one-rank communicator)
-    return lsqr_impl(op, u, x, use_x0, damp, atol, btol, conlim, maxiter, force_maxiter, res, history,
-                     nranks > 1 || (has_comm && jh_ctx().force_dist));
+    return lsqr_impl(1, &op, &u, &x, use_x0, damp, atol, btol, conlim, maxiter, force_maxiter, res, history,
+                     (nranks > 1 || (has_comm && jh_ctx().force_dist)) ? Exch::ranks : Exch::none);
+}
+
+// ONE process, a team of n member contexts (jh_comm_init_all): member k holds ops[k] (its block rows), us[k] (its rows of the
+// right-hand side; overwritten) and xs[k] (its replica of the solution).  The same loop as jh_lsqr_solve_partitioned, the
+// members' kernels enqueued one after the other, their ranged all-reduces grouped, scalars added on the host.
+extern "C" int jh_lsqr_solve_team(int n, const jh_blockop *const *ops, jh_bvec *const *us, jh_bvec *const *xs, int use_x0, double damp, double atol,
+                                  double btol, double conlim, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history)
+{
+    JH_REQUIRE(n >= 1 && n <= JH_MAX_CTX && ops && us && xs, "jh_lsqr_solve_team: need 1..%d members", JH_MAX_CTX);
+    for (int k = 0; k < n; k++) {
+        JH_REQUIRE(ops[k] && us[k] && xs[k], "jh_lsqr_solve_team: null handle of member %d", k);
+        JH_TRY(jh_enter(ops[k], us[k], xs[k]));
+        int nranks = 1, rank = 0, has_comm = 0;
+        (void)jh_comm_info(&nranks, &rank);
+        (void)jh_comm_exists(&has_comm);
+        JH_REQUIRE(has_comm == 2 && nranks == n && rank == k, "jh_lsqr_solve_team: the handles of member %d must live in member %d's context of a team of %d "
+                   "(jh_comm_init_all); found %s, rank %d of %d", k, k, n, has_comm == 2 ? "a team" : "no team", rank, nranks);
+    }
+    return lsqr_impl(n, ops, us, xs, use_x0, damp, atol, btol, conlim, maxiter, force_maxiter, res, history, Exch::team);
 }

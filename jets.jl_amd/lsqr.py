@@ -248,7 +248,11 @@ def lsqr(A, b, x0=None, damp: float = 0.0, atol: float = 1e-6, btol: float = 1e-
     from .rowpart import RowPartitionedOp, TeamOp
 
     if isinstance(A, TeamOp):                            # one process, several contexts: b and the result are TeamVecs
-        return lsqr_core(_TeamEngine(A), b, x0, damp, atol, btol, conlim, maxiter, overwrite_b, force_maxiter)
+        eng = _TeamEngine(A)
+        native = _native_team_solve(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b, force_maxiter)
+        if native is not None:
+            return native
+        return lsqr_core(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b, force_maxiter)
     if isinstance(A, RowPartitionedOp):
         eng = _ShardEngine(A)
         dom, rng = _j.domain(A.local_op), _j.range_(A.local_op)
@@ -287,6 +291,33 @@ def _native_solve(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b, fo
                     float(conlim), int(maxiter), 1 if force_maxiter else 0, C.byref(res), hist))
     except JetsHipError as e:
         if e.status != 4:                                       # JH_ERR_UNSUPPORTED is raised before anything is touched: generic path
+            raise
+        return None
+    history = [(k + 1, hist[2 * k], hist[2 * k + 1]) for k in builtins.range(res.itn)]
+    return LsqrResult(x, res.istop, res.itn, res.r1norm, res.r2norm, res.anorm, res.acond, res.arnorm, res.xnorm, history)
+
+
+def _native_team_solve(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b, force_maxiter):
+    """jh_lsqr_solve_team: the whole loop over a single-process team behind ONE call (what the Julia binding uses).  None when a
+    member has no native tall operator or JETS_LSQR_NATIVE=0: lsqr_core then drives the team from here."""
+    from ._ffi import LsqrResultC
+    from .rowpart import TeamVec
+
+    T = eng.T
+    if os.environ.get("JETS_LSQR_NATIVE", "1") == "0" or not eng.fused_step or any(n is None for n in T._natives):
+        return None
+    M = eng.team.world
+    x = eng.zeros_dom() if x0 is None else eng.copy(eng.zeros_dom(), x0)
+    u = b if overwrite_b else eng.copy(eng.zeros_rng(), b)
+    arr = lambda hs: (C.c_void_p * M)(*[h.value if hasattr(h, "value") else h for h in hs])
+    res = LsqrResultC()
+    hist = (C.c_double * builtins.max(2 * int(maxiter), 1))()
+    try:
+        check(lib.jh_lsqr_solve_team(M, arr([n.handle for n in T._natives]), arr([u[k].handle for k in builtins.range(M)]),
+                                     arr([x[k].handle for k in builtins.range(M)]), 0 if x0 is None else 1, float(damp), float(atol), float(btol),
+                                     float(conlim), int(maxiter), 1 if force_maxiter else 0, C.byref(res), hist))
+    except JetsHipError as e:
+        if e.status != 4:
             raise
         return None
     history = [(k + 1, hist[2 * k], hist[2 * k + 1]) for k in builtins.range(res.itn)]

@@ -684,6 +684,18 @@ function bidiag_step_team!(us::Vector{<:BlockArray{T,<:HipArray{T}}}, ws::Vector
     sqrt(total)
 end
 
+# the whole LSQR solve over the team behind one call: bs[k] = member k's rows of b (overwritten), xs[k] its replica of x
+function hip_lsqr_team!(xs::Vector{<:HipArray{T}}, As::Vector{<:JopLn}, bs::Vector{<:BlockArray{T,<:HipArray{T}}}; x0::Bool=false, damp=0.0, atol=1e-6,
+                        btol=1e-6, conlim=1e8, maxiter=100) where {T}
+    hs = Ptr{Cvoid}[tall_native(A, T) for A in As]
+    any(h -> h == C_NULL, hs) && error("hip_lsqr_team!: every member needs a device-native tall block operator")
+    res = Ref{jh_lsqr_result}()
+    hist = Vector{Cdouble}(undef, 2 * max(maxiter, 1))
+    check(ccall((:jh_lsqr_solve_team, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Ref{jh_lsqr_result}, Ptr{Cdouble}),
+                length(As), hs, Ptr{Cvoid}[handle(b) for b in bs], Ptr{Cvoid}[handle(x) for x in xs], x0 ? 1 : 0, damp, atol, btol, conlim, maxiter, 0, res, hist))
+    xs, res[], reshape(hist, 2, :)[:, 1:res[].itn]
+end
+
 # measured per-operator choices (the grid walk of the tall forward): read from one operator, set on another / in another process
 function tune_get(A::JopLn, name::AbstractString)
     v = Ref{Int64}()

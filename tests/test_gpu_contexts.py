@@ -174,13 +174,36 @@ def test_a_team_of_contexts_runs_the_row_partitioned_flow(Jets, oracle, nmem):
         ref = J.lsqr(A, b, maxiter=15, atol=0.0, btol=0.0, conlim=0.0)
         hb = b.to_numpy()
         bt = rowpart.TeamVec([J.from_numpy(hb[parts[k].first * n:(parts[k].first + parts[k].count) * n], T.ranges()[k]) for k, _ in team.each()])
-        res = J.lsqr(T, bt, maxiter=15, atol=0.0, btol=0.0, conlim=0.0)
-        assert res.itn == ref.itn == 15
-        np.testing.assert_allclose([h[1] for h in res.history], [h[1] for h in ref.history], rtol=2e-4)
-        xs = [x.to_numpy() for x in res.x.members]
-        np.testing.assert_allclose(xs[0], ref.x.to_numpy(), rtol=1e-4, atol=1e-6)
-        for k in range(1, nmem):
-            assert_bits_equal(xs[k], xs[0], f"replica {k} of the LSQR solution")
+        import os
+        for native in ("1", "0"):                                # jh_lsqr_solve_team (one call), then lsqr_core driving the team from Python
+            os.environ["JETS_LSQR_NATIVE"] = native
+            try:
+                res = J.lsqr(T, bt, maxiter=15, atol=0.0, btol=0.0, conlim=0.0)
+            finally:
+                os.environ.pop("JETS_LSQR_NATIVE", None)
+            assert res.itn == ref.itn == 15
+            np.testing.assert_allclose([h[1] for h in res.history], [h[1] for h in ref.history], rtol=2e-4)
+            xs = [x.to_numpy() for x in res.x.members]
+            np.testing.assert_allclose(xs[0], ref.x.to_numpy(), rtol=1e-4, atol=1e-6)
+            for k in range(1, nmem):
+                assert_bits_equal(xs[k], xs[0], f"replica {k} of the LSQR solution (native {native})")
+        # early stopping and a warm start through the one-call team solver
+        x0 = rowpart.TeamVec([J.rand(spc, seed=5, stream=0) for _ in team.each()])
+        J.context_use(home)
+        x0h = J.rand(spc, seed=5, stream=0)
+        ref2 = J.lsqr(A, b, x0=x0h, maxiter=60, atol=1e-5, btol=1e-5, damp=0.1)
+        res2 = J.lsqr(T, bt, x0=x0, maxiter=60, atol=1e-5, btol=1e-5, damp=0.1)
+        assert res2.istop == ref2.istop and abs(res2.itn - ref2.itn) <= 1 and res2.itn < 60
+        np.testing.assert_allclose(res2.x[0].to_numpy(), ref2.x.to_numpy(), rtol=1e-3, atol=1e-5)
+        # the members' handles in the wrong order are refused
+        from jets_jl_amd._ffi import lib, LsqrResultC
+        if nmem >= 2:
+            arr = lambda hs: (C.c_void_p * nmem)(*[h.value for h in hs])
+            order = list(range(nmem))[::-1]
+            r = LsqrResultC()
+            rc = lib.jh_lsqr_solve_team(nmem, arr([T._natives[k].handle for k in order]), arr([bt[k].handle for k in order]),
+                                        arr([res.x[k].handle for k in order]), 0, 0.0, 0.0, 0.0, 0.0, 3, 0, C.byref(r), None)
+            assert rc == 1 and b"must live in member" in lib.jh_last_error()
         # a member's collective outside a group is refused, not deadlocked
         with pytest.raises(J.JetsHipError, match="jh_comm_group_begin"):
             from jets_jl_amd._ffi import lib, check
