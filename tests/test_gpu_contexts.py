@@ -259,3 +259,54 @@ def test_a_team_of_one_goes_through_rccl(Jets, oracle):
         team.close()
         J.context_use(home)
         J.context_destroy(ctx)
+
+
+def test_two_host_threads_each_driving_its_own_context(Jets, oracle, two_contexts):
+    """One host thread per context, concurrently (the current context is per THREAD; ctypes releases the GIL around every call):
+    each builds its own operator and runs forward / adjoint / fused A'A / a broadcast / LSQR in a loop; every result must be
+    the oracle's bits -- nothing of one context (stream, scratch, partial sums, the deferred accumulators) leaks into the other."""
+    import threading
+
+    J = Jets
+    base, extra = two_contexts
+    dt, shape = np.float32, (64, 32, 16)
+    n = int(np.prod(shape))
+    errors = []
+
+    def work(ctx, nrow, seed):
+        try:
+            J.context_use(ctx)
+            spc = J.JetSpace(dt, *shape)
+            cs = [J.rand(spc, seed=seed, stream=i) for i in range(nrow)]
+            A = J.blockop([[J.JopDiagonal(c)] for c in cs])
+            ops = [[oracle.Block("diag", n, coeff=u01(oracle, dt, seed, i, n))] for i in range(nrow)]
+            for rep in range(12):
+                hm = u01(oracle, dt, seed + 1, rep, n)
+                m = J.from_numpy(hm.reshape(shape, order="F"))
+                assert J.context_of(m) == ctx
+                d = A * m
+                want_d = oracle.block_df(ops, [np.zeros(n, dt) for _ in range(nrow)], [hm])
+                assert_bits_equal(d.to_numpy(), np.concatenate(want_d), f"thread of context {ctx}: forward, repetition {rep}")
+                mt = A.H * d
+                want_m = oracle.block_df_adj(ops, [np.zeros(n, dt)], want_d)[0]
+                assert_bits_equal(mt.to_numpy().ravel(order="F"), want_m, f"thread of context {ctx}: adjoint, repetition {rep}")
+                y = (A.H @ A) * m
+                assert_bits_equal(y.to_numpy().ravel(order="F"), want_m, f"thread of context {ctx}: fused A'A, repetition {rep}")
+                z = J.zeros(spc)
+                J.broadcast_(z, "x0*x1+s0", [m, mt], [0.5])
+                assert_bits_equal(z.to_numpy().ravel(order="F"), hm * want_m + np.float32(0.5), f"thread of context {ctx}: broadcast")
+                res = J.lsqr(A, d, maxiter=8, atol=0.0, btol=0.0, conlim=0.0)
+                assert J.context_of(res.x) == ctx and res.itn == 8
+                assert rel_err(res.x.to_numpy().ravel(order="F"), hm) < 5e-2 and res.history[-1][1] < 0.1 * res.history[0][1]   # 8 iterations in
+            J.close(A)
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((ctx, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(base, 7, 40)), threading.Thread(target=work, args=(extra, 10, 50))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=240)
+    assert not any(t.is_alive() for t in ts), "a worker thread hangs"
+    assert not errors, errors
+    J.context_use(base)
