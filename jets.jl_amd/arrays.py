@@ -593,6 +593,8 @@ def similar(x: _DevVec, T=None, n: int | None = None):
     T = x.dtype if T is None else np.dtype(T)
     if isinstance(n, tuple):
         n = n[0]
+    if _device.several_contexts():                         # similar(x) lives where x lives
+        _device.context_use(_device.context_of(x))
     if isinstance(x, BlockArray):
         if n is None or n == x.length():
             return Array(JetBSpace([JetSpace(T, *s.size()) for s in x.spaces]))
