@@ -99,7 +99,7 @@ int jh_context_create(int device, int *ctx);      /* an ADDITIONAL context (own 
                                                    * that already has one; it becomes current */
 int jh_context_use(int ctx);                      /* make it the calling thread's current context (hipSetDevice included) */
 int jh_context_current(int *ctx, int *device);
-int jh_context_destroy(int ctx);                  /* its vectors / operators must have been destroyed first */
+int jh_context_destroy(int ctx);                  /* refused (JH_ERR_STATE) while vectors / operators / events created in it are alive */
 int jh_set_device(int device);                    /* = jh_context_use(the primary context of `device`) */
 int jh_device_info(char *name, int name_cap, int64_t *total_mem, int64_t *free_mem, int *cu_count);
 int jh_get_stream(void **hip_stream);    /* hipStream_t the library enqueues on                   */

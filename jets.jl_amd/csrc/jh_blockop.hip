@@ -2561,10 +2561,12 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);   // host staging vectors die at return
     if (e != hipSuccess) {
+        jh_handle_born(op->ctx);                                  // (jh_blockop_destroy counts it out again)
         jh_blockop_destroy(op);
         return jh_fail(JH_ERR_HIP, "jh_blockop_create: %s", hipGetErrorString(e));
     }
     *out = op;
+    jh_handle_born(op->ctx);
     return JH_OK;
 }
 
@@ -2583,6 +2585,7 @@ int jh_blockop_destroy(jh_blockop *op)
     if (op->dev_col_off) (void)hipFree(op->dev_col_off);
     if (op->dev_row_touched) (void)hipFree(op->dev_row_touched);
     if (op->dev_dims) (void)hipFree(op->dev_dims);
+    jh_handle_died(op->ctx);
     delete op;
     return JH_OK;
 }

@@ -239,7 +239,11 @@ int jh_context_current(int *ctx, int *device)
 
 int jh_context_destroy(int ctx)
 {
-    JH_REQUIRE(jh_ctx_by_id(ctx), "jh_context_destroy: no context %d", ctx);
+    const jh_context *c = jh_ctx_by_id(ctx);
+    JH_REQUIRE(c, "jh_context_destroy: no context %d", ctx);
+    if (c->live_handles > 0)
+        return jh_fail(JH_ERR_STATE, "jh_context_destroy: context %d still owns %lld vectors / operators / events; destroy them first", ctx,
+                       (long long)c->live_handles);
     return ctx_destroy(ctx);
 }
 
@@ -309,6 +313,7 @@ int jh_event_create(jh_event **ev)
         return jh_fail(JH_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(r));
     }
     *ev = e;
+    jh_handle_born(e->ctx);
     return JH_OK;
 }
 
@@ -333,6 +338,7 @@ int jh_event_destroy(jh_event *ev)
 {
     if (!ev) return JH_OK;
     if (ev->ev) (void)hipEventDestroy(ev->ev);
+    jh_handle_died(ev->ctx);
     delete ev;
     return JH_OK;
 }
@@ -381,6 +387,7 @@ int jh_bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec
         return jh_fail(JH_ERR_HIP, "jh_bvec_create: hipMemsetAsync: %s", hipGetErrorString(e));
     }
     *out = v;
+    jh_handle_born(v->ctx);
     return JH_OK;
 }
 
@@ -396,6 +403,7 @@ int jh_bvec_wrap(void *device_ptr, int64_t nblocks, const int64_t *block_len, in
     v->data = device_ptr;
     v->owns = false;
     *out = v;
+    jh_handle_born(v->ctx);
     return JH_OK;
 }
 
@@ -420,6 +428,7 @@ int jh_bvec_view(jh_bvec *parent, int64_t first_block, int64_t count, jh_bvec **
     v->data = parent->ptr(base);
     v->owns = false;
     *out = v;
+    jh_handle_born(v->ctx);
     return JH_OK;
 }
 
@@ -434,6 +443,7 @@ int jh_bvec_destroy(jh_bvec *v)
         }
         (void)hipFree(v->data);
     }
+    jh_handle_died(v->ctx);
     delete v;
     return JH_OK;
 }

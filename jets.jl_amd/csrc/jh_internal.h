@@ -38,6 +38,7 @@ struct jh_context {
     int id = -1;                       // index in the context table
     bool primary = false;              // created by jh_init(device): jh_init(device) again returns it
     int device = -1;
+    int64_t live_handles = 0;          // vectors (views included), operators and events created here and not yet destroyed
     int cu_count = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // the stream everything is enqueued on
@@ -80,6 +81,8 @@ struct jh_context {
 };
 jh_context &jh_ctx();                  // the calling thread's current context (a never-ready dummy before jh_init)
 jh_context *jh_ctx_by_id(int id);      // nullptr when there is no such context
+inline void jh_handle_born(int ctx) { if (jh_context *c = jh_ctx_by_id(ctx)) c->live_handles++; }
+inline void jh_handle_died(int ctx) { if (jh_context *c = jh_ctx_by_id(ctx)) c->live_handles--; }
 int jh_require_ready();                // the current context exists; re-selects its device if another library switched
 int jh_enter_ids(const int *ids, int n);
 // entry points: make the handles' context current.  Null handles are skipped (the entry point reports them itself); handles of

@@ -22,6 +22,9 @@ def two_contexts(Jets):
     extra = J.context_create(0)
     J.context_use(base)
     yield base, extra
+    import gc
+
+    gc.collect()                                                     # a context is destroyed after everything created in it
     J.context_use(base)
     J.context_destroy(extra)
 
@@ -63,8 +66,9 @@ def test_handles_carry_their_context_and_mixed_handles_are_refused(Jets, two_con
     finally:
         J.context_use(base)
         J.tune(adj_split=-1)
-    # an unknown context / a device without a context
+    # an unknown context / a device without a context / a context that still owns handles
     assert lib.jh_context_use(63) == 5 and lib.jh_set_device(7) == 5
+    assert lib.jh_context_destroy(extra) == 5 and b"still owns" in lib.jh_last_error()
     for x in (x1, y1, b):
         x.close()
 
@@ -113,17 +117,30 @@ def _team_contexts(J, nmem):
 
 @pytest.mark.parametrize("nmem", [2, 3])
 def test_a_team_of_contexts_runs_the_row_partitioned_flow(Jets, oracle, nmem):
+    import gc
+
     from jets_jl_amd import rowpart
 
     J = Jets
     J.init(0)
     home = J.context_current()[0]
-    dt, nrow, shape = np.float32, 11, (64, 64, 16)
-    n = int(np.prod(shape))
-    spc = J.JetSpace(dt, *shape)
     ctxs, extra = _team_contexts(J, nmem)
     team = rowpart.Team(ctxs)
     try:
+        _team_flow(J, oracle, rowpart, team, ctxs, nmem, home)
+    finally:
+        team.close()
+        gc.collect()                                                 # the members' vectors and operators die before their contexts
+        J.context_use(home)
+        for c in extra:
+            J.context_destroy(c)
+
+
+def _team_flow(J, oracle, rowpart, team, ctxs, nmem, home):
+    dt, nrow, shape = np.float32, 11, (64, 64, 16)
+    n = int(np.prod(shape))
+    spc = J.JetSpace(dt, *shape)
+    if True:
         parts = [rowpart.partition_rows(nrow, nmem, k) for k in range(nmem)]
         local_ops, coeffs = [], []
         for k, _ in team.each():
@@ -211,11 +228,6 @@ def test_a_team_of_contexts_runs_the_row_partitioned_flow(Jets, oracle, nmem):
         J.close(A)
         for Ak in local_ops:
             J.close(Ak)
-    finally:
-        team.close()
-        J.context_use(home)
-        for c in extra:
-            J.context_destroy(c)
 
 
 def test_a_team_of_one_goes_through_rccl(Jets, oracle):
@@ -224,15 +236,27 @@ def test_a_team_of_one_goes_through_rccl(Jets, oracle):
     step then equal the single-context ordered walk bit for bit."""
     from jets_jl_amd import rowpart
 
+    import gc
+
     J = Jets
     J.init(0)
     home = J.context_current()[0]
-    dt, nrow, shape = np.float32, 6, (64, 64, 16)
-    n = int(np.prod(shape))
-    spc = J.JetSpace(dt, *shape)
     ctx = J.context_create(0)
     team = rowpart.Team([ctx])
     try:
+        _team_of_one(J, oracle, rowpart, team, ctx)
+    finally:
+        team.close()
+        gc.collect()
+        J.context_use(home)
+        J.context_destroy(ctx)
+
+
+def _team_of_one(J, oracle, rowpart, team, ctx):
+    dt, nrow, shape = np.float32, 6, (64, 64, 16)
+    n = int(np.prod(shape))
+    spc = J.JetSpace(dt, *shape)
+    if True:
         with J.using_context(ctx):
             cs = [J.rand(spc, seed=1, stream=0, index_base=i * n) for i in range(nrow)]
             A = J.blockop([[J.JopDiagonal(c)] for c in cs])
@@ -255,10 +279,6 @@ def test_a_team_of_one_goes_through_rccl(Jets, oracle):
         assert_bits_equal(w[0].to_numpy().ravel(order="F"), oracle.block_df_adj(ops, [np.zeros(n, dt)], want_u)[0], "team of one: one-pass step, w")
         assert nrm2 > 0
         J.close(A)
-    finally:
-        team.close()
-        J.context_use(home)
-        J.context_destroy(ctx)
 
 
 def test_two_host_threads_each_driving_its_own_context(Jets, oracle, two_contexts):
