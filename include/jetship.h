@@ -351,7 +351,7 @@ int jh_tune_get(const char *name, int64_t *value);
 /* Per-operator choices made by measurement.  "fwd_walk": the grid walk of the tall forward of an operator far larger than the
  * caches (which one is fastest depends on where the slabs landed physically).  It is chosen LAZILY: while it is -1 each
  * jh_blockop_mul runs the next candidate between two events -- no extra launches, no host synchronisation, jh_blockop_mul
- * returns after enqueue -- and after 12 calls the fastest is kept ("fwd_trials" counts the timed calls so far).  A host that
+ * returns after enqueue -- and after 16 calls the fastest is kept ("fwd_trials" counts the timed calls so far).  A host that
  * wants the steady state at once (or the same choice in every process) reads it from one operator and sets it on another;
  * setting -1 measures again.  "upd_walk" is the same for jh_blockop_mul_axpby (0 / 1, chosen over its first two calls), "step_mode"
  * for jh_blockop_bidiag_step: 0 plain walk, 1 the same with XCD-contiguous tiles, 2 chained row chunks (one batch of 8 rows per

@@ -1486,9 +1486,14 @@ int launch_tall_fwd_shape(const jh_blockop *op, void *d, const void *m, int64_t 
 // -- and the column-persistent walk (rows per workgroup = all rows: a workgroup keeps its m tile and streams every block row
 // through it, no m re-reads), which is the best of the placement-independent shapes (22.0 vs 23.0 ms for the 16-row sweep,
 // profiles/sweep_r01_fwd_persistent_1024x256.txt)
-constexpr int K_FWD_CANDIDATES = 6;
+// Candidates 6 and 7 (late round 2) are ONE block row per workgroup with all rows concurrent -- workgroups that are born, move
+// one tile of one row and die: the fastest shapes at the row counts a rank owns on 2 and 4 GPUs (512 rows: 6.32 TB/s against
+// 5.98 for the best of the first six, 256 rows: 6.2 against 6.06; profiles/sweep_r02_fwd_rows.txt), equal to the others at 1024.
+constexpr int K_FWD_CANDIDATES = 8;
+static_assert(2 * K_FWD_CANDIDATES <= jh_blockop::LazyTune::SLOTS, "two passes per candidate must fit the trial slots");
 const TallShape k_fwd_candidates[K_FWD_CANDIDATES] = {TallShape{1024, 8, 16, 0}, TallShape{512, 1, 2, 1}, TallShape{256, 4, 4, 0},
-                                                      TallShape{256, 4, 16, 1}, TallShape{512, 4, 8, 1}, TallShape{1024, 8, 1 << 20, 0}};
+                                                      TallShape{256, 4, 16, 1}, TallShape{512, 4, 8, 1}, TallShape{1024, 8, 1 << 20, 0},
+                                                      TallShape{512, 8, 1, 1},  TallShape{256, 1, 1, 1}};
 
 // For operators far larger than the caches the row-concurrent walk is 5-7 % faster than the sequential sweep in some
 // processes and 10-15 % slower in others (profiles/repeat_r01.txt: same binary, same box; it depends on where the slabs landed

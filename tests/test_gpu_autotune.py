@@ -20,18 +20,18 @@ def test_lazy_forward_autotune_converges_without_changing_bits(Jets, oracle):
     hm0, hm9 = u01(oracle, dt, 2, 0, 4096), oracle.rng_u01(dt, 2, 0, 12345, 4096)
     assert J.op_tune_get(A, "fwd_walk") is None or J.op_tune_get(A, "fwd_walk") == -1
     walks = set()
-    for call in range(14):
+    for call in range(18):
         J.fill_(d, 0)
         J.mul_(d, A, m)
         walks.add((J.tune_get("last_fwd_walk"), J.tune_get("last_fwd_rows_per_wg")))
-        flat = d.to_numpy() if call in (0, 5, 11, 13) else None          # slices of two rows, bit for bit, under whichever candidate ran
+        flat = d.to_numpy() if call in (0, 5, 11, 13, 15, 17) else None          # slices of two rows, bit for bit, under whichever candidate ran
         if flat is not None:
             assert_bits_equal(flat[:4096], ha0 * hm0, f"call {call}: row 0")
             assert_bits_equal(flat[9 * n + 12345:9 * n + 12345 + 4096], ha9 * hm9, f"call {call}: row 9")
     assert len(walks) >= 3, "the first calls must have tried several candidate shapes"
-    assert J.op_tune_get(A, "fwd_trials") == 12
+    assert J.op_tune_get(A, "fwd_trials") == 16
     pick = J.op_tune_get(A, "fwd_walk")
-    assert 0 <= pick < 6, "after 12 timed calls (+ their completion) the choice is made"
+    assert 0 <= pick < 8, "after 16 timed calls (+ their completion) the choice is made"
     # export / import: a second operator starts in the steady state, and -1 measures again
     B = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
     J.mul_(d, B, m)                                             # builds the handle (and runs trial 0)

@@ -39,7 +39,7 @@ for dt, shape, s in (("float32", (256, 256, 256), 4), ("float64", (256, 256, 128
     N = A.H @ A
     nat = _blk._tall_native(A)
     blk = n * s
-    for _ in range(14):                                                  # let the forward walk settle
+    for _ in range(18):                                                  # let the forward walk settle
         J.mul_(d, A, m)
         J.synchronize()
     t_f = timed(lambda: J.mul_(d, A, m))

@@ -56,7 +56,7 @@ def pair():
     T.mul_adj_(mt, d)
 
 
-for _ in range(args.warmup + 12):                        # + the forward's lazy walk trials
+for _ in range(args.warmup + 16):                        # + the forward's lazy walk trials
     pair()
 team.synchronize()
 t0 = time.perf_counter()
