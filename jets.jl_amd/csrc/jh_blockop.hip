@@ -1227,7 +1227,7 @@ template <typename S, int E, int NS>
 __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                         const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
                                         S *__restrict__ m, const S *__restrict__ d, unsigned ntiles,
-                                        int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride)
+                                        int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride, int nt_out)
 {
     typedef typename vec_of<S, NS>::type V;
     int64_t j, tile;                                                       // block column, tile
@@ -1271,7 +1271,10 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
                     touched = true;
                 }
         }
-        if (touched) st<false>(reinterpret_cast<V *>(m + col_off[j] * E + s), acc);
+        if (touched) {
+            if (nt_out) st<true>(reinterpret_cast<V *>(m + col_off[j] * E + s), acc);   // a large result written once (a wide operator's adjoint)
+            else st<false>(reinterpret_cast<V *>(m + col_off[j] * E + s), acc);         // a slab of the split walk / a small domain vector: read again soon
+        }
     }
 }
 
@@ -1866,7 +1869,7 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
     if (vec)
         hipLaunchKernelGGL((k_block_adj_general_vec<S, E, NS>), dim3(grid, (unsigned)parts), dim3(256), 0, c.stream,
                            op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d, ntiles,
-                           per, (S *)slabs, out_scalars);
+                           per, (S *)slabs, out_scalars, (parts == 1 && c.nt && out_scalars * (int64_t)sizeof(S) >= ((int64_t)64 << 20)) ? 1 : 0);
     else
         hipLaunchKernelGGL((k_block_adj_general<S, E>), dim3(grid, (unsigned)parts), dim3(256), 0, c.stream,
                            op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d, ntiles,

@@ -459,3 +459,29 @@ def test_adjoint_in_several_row_launches_gives_the_bits_of_one(Jets, oracle, row
         assert_bits_equal(y.to_numpy().ravel(order="F"), ref_m[0], f"fused A'A, {rows} rows per launch")
     finally:
         Jets.tune(adj_rows_per_launch=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+def test_wide_operator_with_a_large_result_streams_it_out(Jets, oracle, dt):
+    """1 x 20 diagonal blocks of 4 MiB (8 MiB complex): the adjoint's result (80 / 160 MiB, written once) leaves through
+    nontemporal stores in the general kernel; bits of m_j = conj(a_j) .* d (src/Jets.jl:1051) and of the forward into a dirty d."""
+    J = Jets
+    K, n = 20, 1 << 20
+    spc = J.JetSpace(dt, n)
+    coeff = [J.rand(spc, seed=31, stream=j) for j in range(K)]
+    W = J.blockop([[J.JopDiagonal(c) for c in coeff]])
+    hd = u01(oracle, dt, 32, 0, n)
+    d = J.from_numpy(hd)
+    mt = J.rand(J.domain(W), seed=33, stream=0)                      # dirty
+    J.mul_(mt, W.H, d)
+    got = mt.to_numpy()
+    ops = [[oracle.Block("diag", n, coeff=u01(oracle, dt, 31, j, n)) for j in range(K)]]
+    want_m = oracle.block_df_adj(ops, [np.empty(n, dt) for _ in range(K)], [hd])
+    for j in (0, 7, 19):
+        assert_bits_equal(got[j * n:(j + 1) * n], want_m[j], f"wide adjoint, block column {j}")
+    d2 = J.from_numpy(hd)                                            # the forward adds to d as found (1024)
+    J.mul_(d2, W, mt)
+    want = oracle.block_df(ops, [hd.copy()], want_m)[0]
+    assert_bits_equal(d2.to_numpy(), want, "wide forward into d as found, columns in order")
+    J.close(W)
