@@ -285,8 +285,12 @@ int main(void)
     CK(jh_bvec_destroy(d));
     CK(jh_bvec_destroy(m));
     CK(jh_bvec_destroy(mt));
-    CK(jh_bvec_destroy(y));
     CK(jh_shutdown());
+    /* a handle that outlives jh_shutdown: its calls fail with a status, its destruction still releases the memory */
+    REQUIRE(jh_fill(y, 1.0, 0.0) == JH_ERR_STATE, "a vector of a destroyed context is refused, not dereferenced");
+    REQUIRE(strlen(jh_last_error()) > 0, "error message is set");
+    CK(jh_bvec_destroy(y));
+    REQUIRE(jh_synchronize() == JH_ERR_STATE, "handle-less calls after jh_shutdown report the missing context");
     free(hd); free(hmt); free(hy); free(oa); free(om); free(od); free(omt);
     printf("forward, adjoint, fused A'A: bit-exact vs oracle; norm/dot within 1e-5; dot-product test %.6e ~ %.6e\n", lhs, rhs);
     printf("C HOST OK\n");
