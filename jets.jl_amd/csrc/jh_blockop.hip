@@ -2575,6 +2575,21 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
     }
     *out = op;
     jh_handle_born(op->ctx);
+    // the tall twin of a wide elementwise operator (jh_internal.h): block i = the adjoint of block (0, i).  For a real element type
+    // the adjoint of a diagonal / scalar / identity block is the block itself, so the twin stays all-DIAG where the wide one is
+    if (nrow == 1 && ncol >= 2 && op->elementwise && !op->nonlinear) {
+        std::vector<jh_block_desc> tb(op->blocks);
+        bool uniform = true;
+        for (auto &b : tb) {
+            if (b.kind == JH_OP_SQUARE) uniform = false;
+            if (b.nr != tb[0].nr || b.nc != tb[0].nc || b.nr != b.nc) uniform = false;
+            if (jh_dtype_complex(dtype)) b.adjoint = b.adjoint ? 0 : 1;
+        }
+        if (uniform && tb[0].nr > 0 && ((size_t)tb[0].nr * jh_dtype_size(dtype)) % 16 == 0) {
+            jh_blockop *tw = nullptr;
+            if (jh_blockop_create(ncol, 1, tb.data(), col_len, row_len, dtype, &tw) == JH_OK) op->twin = tw;   // (a failure only costs the fast path)
+        }
+    }
     return JH_OK;
 }
 
@@ -2593,6 +2608,7 @@ int jh_blockop_destroy(jh_blockop *op)
     if (op->dev_col_off) (void)hipFree(op->dev_col_off);
     if (op->dev_row_touched) (void)hipFree(op->dev_row_touched);
     if (op->dev_dims) (void)hipFree(op->dev_dims);
+    if (op->twin) (void)jh_blockop_destroy(op->twin);
     jh_handle_died(op->ctx);
     delete op;
     return JH_OK;
@@ -2716,6 +2732,8 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
     if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, false, op->dev_row_off);
     if (op->small_loop && jh_ctx().small_loop) return loop_small(op, m->data, d->data, 1, 0);
     if (!op->elementwise) return run_loop_graphed(op, 1, m->data, d->data, [&] { return loop_adj(op, m->data, d->data); });
+    // a wide operator's adjoint is its tall twin's forward (same bits: one rounded product per element, zero blocks untouched)
+    if (op->twin && (tall_fast_ok(op->twin, m->data, d->data) || tall_mixed_ok(op->twin, m->data, d->data))) return jh_blockop_mul(op->twin, m, d);
     switch (op->dtype) {
     case JH_F32: return general_adj<float, 1>(op, m->data, d->data);
     case JH_F64: return general_adj<double, 1>(op, m->data, d->data);

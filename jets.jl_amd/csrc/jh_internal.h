@@ -187,6 +187,10 @@ struct jh_blockop {
     mutable int64_t step_span = 0;           // the call shape (scalars per call) the trials are being run on
 
     int64_t diag_stride_elems = 0;
+    // a WIDE operator (1 x K) of elementwise children: its adjoint m_j = A_1j' d (1051: direct write, zero blocks skipped) IS the
+    // forward of the tall K x 1 operator of the blocks A_1j' -- `twin` is that operator (same coefficient arrays), so the wide
+    // adjoint runs on the tall forward kernels with their measured grid walk instead of the general kernel
+    jh_blockop *twin = nullptr;
 };
 
 bool jh_blockop_tall_fast(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr);   // tall, all DIAG, equal 16-byte aligned blocks
