@@ -1448,7 +1448,8 @@ int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n
     c.last_adj_launches = (op->nrow + rows_per_launch - 1) / rows_per_launch;
     // many rows of small blocks: split-row walk (pick_adj_parts) -- one launch over (tiles, parts), then the fold
     const int64_t gx0 = (s_end - s_begin + (int64_t)sh.unroll * BLK * NS - 1) / ((int64_t)sh.unroll * BLK * NS);
-    int64_t parts = direct ? 1 : pick_adj_parts(gx0, op->nrow);
+    const int from_found = (MODE == 0) ? c.adj_from_found : 0;              // continue from what `out` holds (a wide operator's forward)
+    int64_t parts = (direct || from_found) ? 1 : pick_adj_parts(gx0, op->nrow);
     int64_t rows_per_part = 0;
     const int64_t part_stride = s_end - s_begin;
     void *slabs = nullptr;
@@ -1468,7 +1469,7 @@ int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n
             hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, NT, MODE, BLK>), dim3((unsigned)gx, (unsigned)parts), \
                                dim3(BLK), 0,                                                                           \
                                c.stream, op->dev_blocks, op->nrow, a_base, a_stride, (S *)out, (const S *)in, n_scalars,   \
-                               direct, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0, rows_per_part, (S *)slabs, part_stride);    \
+                               direct, s_begin, s_end, r0, r1, (r0 > 0 || from_found) ? 1 : 0, rows_per_part, (S *)slabs, part_stride); \
             JH_CHECK_HIP(hipGetLastError());                                                                           \
         }                                                                                                              \
         if (parts > 1) return launch_fold_parts<S, NS>(slabs, part_stride, parts, out, s_begin, s_end);                \
@@ -1698,7 +1699,8 @@ int launch_tall_adj_mixed_u(const jh_blockop *op, void *out, const void *in, int
 {
     jh_context &c = jh_ctx();
     const int64_t gx = (s_end - s_begin + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);
-    int64_t parts = pick_adj_parts(gx, op->nrow), rows_per_part = 0;                  // many rows of small blocks: split-row walk
+    const int from_found = (MODE == 0) ? c.adj_from_found : 0;                        // continue from what `out` holds (a wide operator's forward)
+    int64_t parts = from_found ? 1 : pick_adj_parts(gx, op->nrow), rows_per_part = 0;   // many rows of small blocks: split-row walk
     const int64_t part_stride = s_end - s_begin;
     void *slabs = nullptr;
     if (parts > 1) {
@@ -1710,7 +1712,7 @@ int launch_tall_adj_mixed_u(const jh_blockop *op, void *out, const void *in, int
     c.last_adj_launches = 1;
     hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, true, MODE, BLK, true>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, c.stream,
                        op->dev_blocks, op->nrow, (const S *)nullptr, (int64_t)0, (S *)out, (const S *)in, n_scalars, 0, s_begin, s_end,
-                       (int64_t)0, op->nrow, 0, rows_per_part, (S *)slabs, part_stride);
+                       (int64_t)0, op->nrow, from_found, rows_per_part, (S *)slabs, part_stride);
     JH_CHECK_HIP(hipGetLastError());
     if (parts > 1) return launch_fold_parts<S, NS>(slabs, part_stride, parts, out, s_begin, s_end);
     return JH_OK;
@@ -2693,6 +2695,17 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false, op->dev_row_off);
     if (op->small_loop && jh_ctx().small_loop) return loop_small(op, d->data, m->data, 0, 0);
     if (!op->elementwise) return run_loop_graphed(op, 0, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data); });
+    // a wide operator's forward d = d_found + sum_j A_1j m_j (1024: no zeroing) is its tall twin's ordered adjoint sum started from
+    // what d holds -- the same additions in the same order.  Large blocks only: the ordered walk needs >= one workgroup per CU
+    // (many small blocks take the general kernel's split walk instead)
+    if (op->twin && jh_ctx().adj_split <= 0 && (size_t)op->row_len[0] * jh_dtype_size(op->dtype) >= ((size_t)16 << 20) &&
+        (tall_fast_ok(op->twin, m->data, d->data) || tall_mixed_ok(op->twin, m->data, d->data))) {
+        jh_context &c = jh_ctx();
+        c.adj_from_found = 1;
+        const int st = jh_blockop_mul_adj(op->twin, d, m);
+        c.adj_from_found = 0;
+        return st;
+    }
     switch (op->dtype) {
     case JH_F32: return general_fwd<float, 1>(op, d->data, m->data);
     case JH_F64: return general_fwd<double, 1>(op, d->data, m->data);

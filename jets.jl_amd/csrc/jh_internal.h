@@ -78,6 +78,8 @@ struct jh_context {
     int64_t last_adj_launches = 1;     // kernel launches of the most recent tall adjoint / fused normal call (read-only knob)
     int64_t last_fwd_walk = 0;         // grid walk used by the most recent tall forward launch (read-only knob)
     int64_t last_step_chain = 0;       // row chunks of the most recent one-pass step (0: the plain walk) (read-only knob)
+    int adj_from_found = 0;            // internal, set around ONE call: the tall adjoint continues from what its output holds (the
+                                       // forward of a wide operator through its tall twin: `_d .+=` into d as found, src/Jets.jl:1024); never split
 };
 jh_context &jh_ctx();                  // the calling thread's current context (a never-ready dummy before jh_init)
 jh_context *jh_ctx_by_id(int id);      // nullptr when there is no such context

@@ -485,3 +485,43 @@ def test_wide_operator_with_a_large_result_streams_it_out(Jets, oracle, dt):
     want = oracle.block_df(ops, [hd.copy()], want_m)[0]
     assert_bits_equal(d2.to_numpy(), want, "wide forward into d as found, columns in order")
     J.close(W)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+@pytest.mark.parametrize("mixed", [False, True])
+def test_wide_operator_of_large_blocks_runs_on_its_tall_twin(Jets, oracle, dt, mixed):
+    """1 x 6 elementwise children of 16 MiB: the adjoint is the tall twin's forward, the forward the twin's ordered adjoint sum
+    started from d AS FOUND (src/Jets.jl:1024) -- bits of the oracle's loops, with a zero block and a scalar block in the mixed case."""
+    J = Jets
+    K = 6
+    n = (1 << 22) // (np.dtype(dt).itemsize // 4)
+    spc = J.JetSpace(dt, n)
+    dev, ora = [], []
+    for j in range(K):
+        if mixed and j == 2:
+            dev.append(J.JopZeroBlock(spc, spc)); ora.append(oracle.Block("zero", n))
+        elif mixed and j == 4:
+            a = 0.75 - (0.5j if np.dtype(dt).kind == "c" else 0)
+            dev.append(J.JopLn(dom=spc, rng=spc, df=J.constdiag_df, df_adj=J.constdiag_df_adj, s={"a": a}))
+            ora.append(oracle.Block("scale", n, scale=a))
+        else:
+            op = J.JopDiagonal(J.rand(spc, seed=41, stream=j))
+            adj = mixed and j == 1
+            dev.append(op.H if adj else op)
+            ora.append(oracle.Block("diag", n, coeff=u01(oracle, dt, 41, j, n), adjoint=adj))
+    W = J.blockop([dev])
+    hm = [u01(oracle, dt, 42, j, n) for j in range(K)]
+    hd = u01(oracle, dt, 43, 0, n)
+    m = J.from_numpy(np.concatenate(hm), J.domain(W))
+    d = J.from_numpy(hd)                                             # dirty: the forward adds to it
+    J.mul_(d, W, m)
+    want_d = oracle.block_df([ora], [hd.copy()], hm)[0]
+    assert_bits_equal(d.to_numpy(), want_d, "wide forward of large blocks into d as found")
+    assert J.tune_get("last_adj_parts") == 1
+    mt = J.rand(J.domain(W), seed=44, stream=0)                      # dirty: a zero block's column stays as found (1047)
+    found = mt.to_numpy().copy()
+    J.mul_(mt, W.H, d)
+    want_m = oracle.block_df_adj([ora], [found[j * n:(j + 1) * n].copy() for j in range(K)], [want_d])
+    assert_bits_equal(mt.to_numpy(), np.concatenate(want_m), "wide adjoint of large blocks")
+    J.close(W)
