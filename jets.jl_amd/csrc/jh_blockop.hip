@@ -2698,7 +2698,8 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     // a wide operator's forward d = d_found + sum_j A_1j m_j (1024: no zeroing) is its tall twin's ordered adjoint sum started from
     // what d holds -- the same additions in the same order.  Large blocks only: the ordered walk needs >= one workgroup per CU
     // (many small blocks take the general kernel's split walk instead)
-    if (op->twin && jh_ctx().adj_split <= 0 && (size_t)op->row_len[0] * jh_dtype_size(op->dtype) >= ((size_t)16 << 20) &&
+    if (op->twin && jh_ctx().wide_twin && jh_ctx().adj_split <= 0 &&
+        (jh_ctx().wide_twin == 2 || (size_t)op->row_len[0] * jh_dtype_size(op->dtype) >= ((size_t)16 << 20)) &&
         (tall_fast_ok(op->twin, m->data, d->data) || tall_mixed_ok(op->twin, m->data, d->data))) {
         jh_context &c = jh_ctx();
         c.adj_from_found = 1;
@@ -2746,7 +2747,8 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
     if (op->small_loop && jh_ctx().small_loop) return loop_small(op, m->data, d->data, 1, 0);
     if (!op->elementwise) return run_loop_graphed(op, 1, m->data, d->data, [&] { return loop_adj(op, m->data, d->data); });
     // a wide operator's adjoint is its tall twin's forward (same bits: one rounded product per element, zero blocks untouched)
-    if (op->twin && (tall_fast_ok(op->twin, m->data, d->data) || tall_mixed_ok(op->twin, m->data, d->data))) return jh_blockop_mul(op->twin, m, d);
+    if (op->twin && jh_ctx().wide_twin && (tall_fast_ok(op->twin, m->data, d->data) || tall_mixed_ok(op->twin, m->data, d->data)))
+        return jh_blockop_mul(op->twin, m, d);
     switch (op->dtype) {
     case JH_F32: return general_adj<float, 1>(op, m->data, d->data);
     case JH_F64: return general_adj<double, 1>(op, m->data, d->data);

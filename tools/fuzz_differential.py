@@ -64,6 +64,8 @@ def wide_err(a, b):
 
 t0 = time.time()
 done = fused = split = 0
+if os.environ.get("FUZZ_WIDE_TWIN"):                        # e.g. 2: wide operators' forward through the tall twin at every block size
+    J.tune(wide_twin=int(os.environ["FUZZ_WIDE_TWIN"]))
 for case in range(seed0, seed0 + ncases):
     rng = np.random.default_rng(777_000 + case)
     dt, nrow, ncol, len_r, len_c, kinds = draw(rng)
