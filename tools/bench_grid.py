@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""M x K grids of large diagonal blocks on the general kernels: forward d_i = d_i + sum_j a_ij .* m_j, adjoint m_j = sum_i conj(a_ij) .* d_i.
+Algorithmic (unique) bytes: M K n coefficients + the two vectors (+ d as found in the forward).   python tools/bench_grid.py M K EDGE"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import jets_jl_amd as J
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+edge = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+J.init(0)
+n = edge ** 3
+spc = J.JetSpace("float32", edge, edge, edge)
+coeff = J.rand(J.JetBSpace([spc] * (M * K)), seed=1, stream=0)
+A = J.blockop([[J.JopDiagonal(coeff.arrays[i * K + j]) for j in range(K)] for i in range(M)])
+m = J.rand(J.domain(A), seed=2, stream=0)
+d = J.zeros(J.range(A))
+mt = J.zeros(J.domain(A))
+
+
+def timed(fn, reps=6, warm=2):
+    for _ in range(warm):
+        fn()
+    best = 1e9
+    for _ in range(reps):
+        e0 = J.Event().record()
+        fn()
+        e1 = J.Event().record()
+        best = min(best, e0.elapsed_ms(e1))
+    return best
+
+
+b = n * 4
+for xcd in (1, 0, 2):
+    J.tune(general_xcd=xcd)
+    tf = timed(lambda: J.mul_(d, A, m))
+    ta = timed(lambda: J.mul_(mt, A.H, d))
+    print(f"{M} x {K} of {edge}^3 general_xcd={xcd}: forward {tf:7.3f} ms {(M * K + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {(M * K + M + K) * b / ta / 1e6:7.1f} GB/s", flush=True)
