@@ -1189,10 +1189,25 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
         V acc = (V)(S)0;
         bool touched = split;
         if (ncol > 1 && !split) acc = ld<false>(reinterpret_cast<const V *>(d + row_off[i] * E + s));
+        // the block table and the column offsets are read ONE GROUP AHEAD (scalar loads): a block's vector loads need them, and
+        // waiting for them block by block serialises two latencies per block (the mixed one-pass step lost 12 % to that)
+        jh_dev_block nb[GENERAL_Q];
+        int64_t noff[GENERAL_Q];
+#pragma unroll
+        for (int q = 0; q < GENERAL_Q; q++)
+            if (j_lo + q < j_hi) { nb[q] = blocks[i + (j_lo + q) * nrow]; noff[q] = col_off[j_lo + q]; }
         for (int64_t j0 = j_lo; j0 < j_hi; j0 += GENERAL_Q) {              // (1020), GENERAL_Q columns' loads in flight
             jh_dev_block b[GENERAL_Q];
+            int64_t off[GENERAL_Q];
             V x[GENERAL_Q], c[GENERAL_Q];
             bool on[GENERAL_Q];
+#pragma unroll
+            for (int q = 0; q < GENERAL_Q; q++) {
+                b[q] = nb[q];
+                off[q] = noff[q];
+                const int64_t jn = j0 + GENERAL_Q + q;
+                if (jn < j_hi) { nb[q] = blocks[i + jn * nrow]; noff[q] = col_off[jn]; }
+            }
 #pragma unroll
             for (int q = 0; q < GENERAL_Q; q++) {
                 const int64_t j = j0 + q;
@@ -1200,10 +1215,9 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
                 x[q] = (V)(S)0;
                 c[q] = (V)(S)0;
                 if (on[q]) {
-                    b[q] = blocks[i + j * nrow];
                     if (b[q].kind == JH_OP_ZERO) on[q] = (fmode != 0);     // (1022) skipped; f! keeps it as +0 -- and never loads for it
                     else {
-                        x[q] = ld<false>(reinterpret_cast<const V *>(m + col_off[j] * E + s));
+                        x[q] = ld<false>(reinterpret_cast<const V *>(m + off[q] * E + s));
                         if (block_reads_coeff(b[q], fmode != 0)) c[q] = ld<true>(reinterpret_cast<const V *>((const S *)b[q].coeff + s));   // streamed once
                     }
                 }
@@ -1244,10 +1258,23 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
     for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < ns; s += (int64_t)ntiles * 256 * NS) {
         V acc = (V)(S)0;
         bool touched = (nrow > 1);
+        jh_dev_block nb[GENERAL_Q];                                        // block table and row offsets one group ahead (see the forward)
+        int64_t noff[GENERAL_Q];
+#pragma unroll
+        for (int q = 0; q < GENERAL_Q; q++)
+            if (i_lo + q < i_hi) { nb[q] = blocks[(i_lo + q) + j * nrow]; noff[q] = row_off[i_lo + q]; }
         for (int64_t i0 = i_lo; i0 < i_hi; i0 += GENERAL_Q) {              // (1045), GENERAL_Q rows' loads in flight
             jh_dev_block b[GENERAL_Q];
+            int64_t off[GENERAL_Q];
             V x[GENERAL_Q], c[GENERAL_Q];
             bool on[GENERAL_Q];
+#pragma unroll
+            for (int q = 0; q < GENERAL_Q; q++) {
+                b[q] = nb[q];
+                off[q] = noff[q];
+                const int64_t in = i0 + GENERAL_Q + q;
+                if (in < i_hi) { nb[q] = blocks[in + j * nrow]; noff[q] = row_off[in]; }
+            }
 #pragma unroll
             for (int q = 0; q < GENERAL_Q; q++) {
                 const int64_t i = i0 + q;
@@ -1255,10 +1282,9 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
                 x[q] = (V)(S)0;
                 c[q] = (V)(S)0;
                 if (on[q]) {
-                    b[q] = blocks[i + j * nrow];
                     if (b[q].kind == JH_OP_ZERO) on[q] = false;            // (1047)
                     else {
-                        x[q] = ld<false>(reinterpret_cast<const V *>(d + row_off[i] * E + s));
+                        x[q] = ld<false>(reinterpret_cast<const V *>(d + off[q] * E + s));
                         if (block_reads_coeff(b[q], false)) c[q] = ld<true>(reinterpret_cast<const V *>((const S *)b[q].coeff + s));   // streamed once
                     }
                 }
