@@ -123,8 +123,11 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__res
             sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
             mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
         }
+        jh_dev_block nxt;                                                                  // the row table one row ahead (scalar loads)
+        if (i0 < i1) nxt = blocks[i0];
         for (int64_t i = i0; i < i1; i++) {
-            const jh_dev_block blk = blocks[i];
+            const jh_dev_block blk = nxt;
+            if (i + 1 < i1) nxt = blocks[i + 1];
             if (blk.kind == JH_OP_ZERO) continue;                                          // (1022)
             const bool rc = block_reads_coeff(blk, false);
             S *di = d + i * n_scalars;
@@ -209,12 +212,21 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
 
     int64_t i = row0;
     if constexpr (MIXED) {                 // rows of any elementwise kind (see k_tall_diag_fwd); zero blocks are skipped (1047)
+        jh_dev_block blk[DEPTH], nxt[DEPTH];                               // the row table one batch ahead (scalar loads)
+        if (i + DEPTH <= row1) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; j++) nxt[j] = blocks[i + j];
+        }
         for (; i + DEPTH <= row1; i += DEPTH) {
-            jh_dev_block blk[DEPTH];
             V av[DEPTH][U], dv[DEPTH][U];
+            const int64_t ahead = (i + 2 * DEPTH <= row1) ? i + DEPTH : i;
 #pragma unroll
             for (int j = 0; j < DEPTH; j++) {
-                blk[j] = blocks[i + j];
+                blk[j] = nxt[j];
+                nxt[j] = blocks[ahead + j];
+            }
+#pragma unroll
+            for (int j = 0; j < DEPTH; j++) {
                 const bool on = blk[j].kind != JH_OP_ZERO, rc = block_reads_coeff(blk[j], false);
 #pragma unroll
                 for (int k = 0; k < U; k++) {
@@ -333,13 +345,19 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block
     }
     const bool use_old = (beta != (S)0);
     double nrm = 0.0;
+    jh_dev_block nxt;                                                       // MIXED: the row table one row ahead
+    if (MIXED && i0 < i1) nxt = blocks[i0];
     for (int64_t i = i0; i < i1; i++) {
-        const S *a = (MIXED || !a_base) ? (const S *)blocks[i].coeff : a_base + i * a_stride;
-        S *di = d + i * n_scalars;
-        V av[U], dv[U];
         jh_dev_block blk;
         bool rc = true;
-        if constexpr (MIXED) { blk = blocks[i]; rc = block_reads_coeff(blk, false); }   // any elementwise row kind (see k_tall_diag_fwd)
+        if constexpr (MIXED) {                                              // any elementwise row kind (see k_tall_diag_fwd)
+            blk = nxt;
+            if (i + 1 < i1) nxt = blocks[i + 1];
+            rc = block_reads_coeff(blk, false);
+        }
+        const S *a = MIXED ? (const S *)blk.coeff : (!a_base ? (const S *)blocks[i].coeff : a_base + i * a_stride);
+        S *di = d + i * n_scalars;
+        V av[U], dv[U];
 #pragma unroll
         for (int k = 0; k < U; k++) {
             av[k] = rc ? ld<true>(reinterpret_cast<const V *>(a + sk[k])) : (V)(S)0;
