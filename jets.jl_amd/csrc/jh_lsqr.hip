@@ -273,10 +273,15 @@ static int lsqr_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *
             }
             // ---- eliminate the damping parameter, then the plane rotation
             const double rhobar1 = std::sqrt(rhobar * rhobar + damp * damp);
+            const double rho = std::sqrt(rhobar1 * rhobar1 + beta * beta);
+            if (!(rhobar1 > 0 && std::isfinite(rho))) {                  // only reachable with force_maxiter, far past convergence: the recurrences
+                if (!istop) istop = 6;                                   // have underflowed; x is left at its last finite update
+                itn--;
+                break;
+            }
             const double cs1 = rhobar / rhobar1, sn1 = damp / rhobar1;
             const double psi = sn1 * phibar;
             phibar = cs1 * phibar;
-            const double rho = std::sqrt(rhobar1 * rhobar1 + beta * beta);
             const double cs = rhobar1 / rho, sn = beta / rho;
             const double theta = sn * alpha;
             rhobar = -cs * alpha;

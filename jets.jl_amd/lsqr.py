@@ -380,11 +380,15 @@ def lsqr_core(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b=False, 
                     eng.lincomb(v, [1.0 / alpha], [v])
         # --- eliminate the damping parameter
         rhobar1 = math.sqrt(rhobar ** 2 + damp ** 2)
+        rho = math.sqrt(rhobar1 ** 2 + beta ** 2)
+        if not (rhobar1 > 0 and math.isfinite(rho)):     # only reachable with force_maxiter, far past convergence: the recurrences have
+            istop = istop or 6                           # underflowed; x stays at its last finite update
+            itn -= 1
+            break
         cs1, sn1 = rhobar / rhobar1, damp / rhobar1
         psi = sn1 * phibar
         phibar = cs1 * phibar
         # --- plane rotation to eliminate the subdiagonal of the bidiagonal matrix
-        rho = math.sqrt(rhobar1 ** 2 + beta ** 2)
         cs, sn = rhobar1 / rho, beta / rho
         theta = sn * alpha
         rhobar = -cs * alpha

@@ -498,3 +498,21 @@ def test_bidiag_step_in_several_row_launches(Jets, oracle):
     assert_bits_equal(outs[1][0], outs[0][0], "u")
     assert_bits_equal(outs[1][1], outs[0][1], "w")
     assert outs[1][2] == pytest.approx(outs[0][2], rel=1e-12)
+
+
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_forced_iterations_far_past_convergence_stay_finite(Jets, monkeypatch, native):
+    """force_maxiter (throughput runs) keeps iterating after every stopping rule has fired; once the recurrences underflow the loop
+    must end with x at its last finite update -- not divide by a rhobar that has become 0 (C++: NaN everywhere; Python: ZeroDivisionError)."""
+    J = Jets
+    spc = J.JetSpace(np.float32, 64, 64, 32)
+    coeff = J.rand(J.JetBSpace([spc] * 12), seed=1, stream=0)
+    A = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
+    x_true = J.rand(spc, seed=4, stream=0)
+    b = A * x_true
+    monkeypatch.setenv("JETS_LSQR_NATIVE", native)
+    res = J.lsqr(A, b, atol=0.0, btol=0.0, conlim=0.0, maxiter=4000, force_maxiter=True)
+    x = res.x.to_numpy()
+    assert np.isfinite(x).all() and res.itn < 4000 and res.istop != 0
+    assert all(np.isfinite(h[1]) and np.isfinite(h[2]) for h in res.history)
+    assert float(np.linalg.norm((x - x_true.to_numpy()).ravel()) / np.linalg.norm(x_true.to_numpy().ravel())) < 1e-5
