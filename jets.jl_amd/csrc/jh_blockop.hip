@@ -1326,6 +1326,71 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
     }
 }
 
+// ---- M x K grids whose blocks are ALL plain diagonals (>= 2 x 2, one block length, everything 16-byte aligned) --------------
+// The general kernels above decide per block what to do (kind switch, zero-block skip); those branches make the compiler wait for
+// ALL outstanding loads at every join, so more than one block's loads in flight per lane buys nothing there (GENERAL_Q).  A grid
+// of diagonals needs no decision: this kernel issues the loads of Q blocks of a line back to back -- coefficient pointers one
+// group ahead, like the general kernels -- and combines them in the reference's order, product rounded then added
+// (forward: d_i = d_i as found + a_i1 .* m_1 + a_i2 .* m_2 + ..., 1020-1024; adjoint: m_j = 0 + conj(a_1j) .* d_1 + ..., 1042-1049).
+// Same (line, tile) decode as the general kernels: the workgroups of one tile of every line run together, so the shared input
+// tile comes from HBM once.  TRANSPOSED = false: line = block row; true: line = block column.
+template <typename S, int E, int NS, int Q, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void k_grid_diag(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol, int64_t n_scalars,
+                                                   const S *__restrict__ in, S *__restrict__ out, unsigned ntiles)
+{
+    typedef typename vec_of<S, NS>::type V;
+    int64_t line, tile;
+    general_line_tile((unsigned)(TRANSPOSED ? ncol : nrow), ntiles, line, tile);
+    ntiles &= 0x7fffffffu;
+    if (tile >= ntiles) return;
+    const int64_t nsum = TRANSPOSED ? nrow : ncol;                          // blocks walked per line
+    const int64_t step = TRANSPOSED ? 1 : nrow, first = TRANSPOSED ? line * nrow : line;   // block (q) of the line = blocks[first + q * step]
+    S *o = out + line * n_scalars;
+    for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < n_scalars; s += (int64_t)ntiles * 256 * NS) {
+        V acc = TRANSPOSED ? (V)(S)0 : ld<false>(reinterpret_cast<const V *>(o + s));      // `_m .= 0` (1042) / d as found (1024)
+        const S *na[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) na[q] = (const S *)blocks[first + (q < nsum ? q : 0) * step].coeff;
+        int64_t q0 = 0;
+        for (; q0 + Q <= nsum; q0 += Q) {
+            const S *a[Q];
+            V x[Q], c[Q];
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                a[q] = na[q];
+                const int64_t qn = q0 + Q + q;
+                na[q] = (const S *)blocks[first + (qn < nsum ? qn : 0) * step].coeff;
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                c[q] = ld<true>(reinterpret_cast<const V *>(a[q] + s));                       // streamed once
+                x[q] = ld<false>(reinterpret_cast<const V *>(in + (q0 + q) * n_scalars + s));  // shared by every line: through the caches
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) acc = acc + vmul<S, E, NS, V>(c[q], x[q], TRANSPOSED);
+        }
+        for (int64_t q = q0; q < nsum; q++) {
+            const V c = ld<true>(reinterpret_cast<const V *>((const S *)blocks[first + q * step].coeff + s));
+            const V x = ld<false>(reinterpret_cast<const V *>(in + q * n_scalars + s));
+            acc = acc + vmul<S, E, NS, V>(c, x, TRANSPOSED);
+        }
+        st<true>(reinterpret_cast<V *>(o + s), acc);
+    }
+}
+
+// is `op` such a grid?  (every block an un-adjointed diagonal -- for a real element type the adjoint flag is immaterial and
+// all_diag already says so --, >= 2 x 2, aligned)
+bool grid_diag_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
+{
+    if (!(op->all_diag && op->nrow >= 2 && op->ncol >= 2)) return false;
+    const int64_t n = op->row_len[0];
+    if (n == 0 || (n * (int64_t)jh_dtype_size(op->dtype)) % 16 != 0) return false;
+    if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & 15u) return false;
+    for (const auto &b : op->blocks)
+        if (((uintptr_t)b.coeff) & 15u) return false;
+    return true;
+}
+
 // second stage of the general kernels' split walk: out[line] = (add_found ? out as found : 0) + slab 0 + slab 1 + ... for every
 // line (block row of the range / block column of the domain) that the operator touches; 64 scalar lanes x 4 part lanes per
 // workgroup, fp64 accumulation, fixed order => deterministic (tolerance parity with the single ordered sum)
@@ -1877,6 +1942,12 @@ int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
         JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)out_scalars * sizeof(S), &slabs));
     }
     c.last_adj_parts = parts;
+    if (vec && parts == 1 && !fmode && c.grid_diag && grid_diag_ok(op, d, m)) {     // a grid of plain diagonals: the branch-free kernel
+        hipLaunchKernelGGL((k_grid_diag<S, E, NS, 4, false>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol,
+                           op->row_len[0] * E, (const S *)m, (S *)d, ntiles);
+        JH_CHECK_HIP(hipGetLastError());
+        return JH_OK;
+    }
     if (vec)
         hipLaunchKernelGGL((k_block_fwd_general_vec<S, E, NS>), dim3(grid, (unsigned)parts), dim3(256), 0, c.stream,
                            op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode, ntiles,
@@ -1916,6 +1987,12 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
         JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)out_scalars * sizeof(S), &slabs));
     }
     c.last_adj_parts = parts;
+    if (vec && parts == 1 && c.grid_diag && grid_diag_ok(op, d, m)) {
+        hipLaunchKernelGGL((k_grid_diag<S, E, NS, 4, true>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol,
+                           op->row_len[0] * E, (const S *)d, (S *)m, ntiles);
+        JH_CHECK_HIP(hipGetLastError());
+        return JH_OK;
+    }
     if (vec)
         hipLaunchKernelGGL((k_block_adj_general_vec<S, E, NS>), dim3(grid, (unsigned)parts), dim3(256), 0, c.stream,
                            op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d, ntiles,

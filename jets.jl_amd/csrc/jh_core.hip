@@ -635,6 +635,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "force_dist")) { c.force_dist = value ? 1 : 0; }
     else if (!strcmp(name, "step_chain")) { JH_REQUIRE(value >= -1 && value <= 1, "step_chain must be -1 (auto), 0 or 1"); c.step_chain = value; }
     else if (!strcmp(name, "general_xcd")) { JH_REQUIRE(value >= 0 && value <= 2, "general_xcd must be 0 (never), 1 (automatic) or 2 (always)"); c.general_xcd = value; }
+    else if (!strcmp(name, "grid_diag")) { c.grid_diag = value ? 1 : 0; }
     else if (!strcmp(name, "wide_twin")) { JH_REQUIRE(value >= 0 && value <= 2, "wide_twin must be 0 (never), 1 (automatic) or 2 (always)"); c.wide_twin = value; }
     else if (!strcmp(name, "red_wgs")) { JH_REQUIRE(value >= 1 && value <= 1 << 20, "red_wgs out of range"); c.red_wgs = value; }
     else return jh_fail(JH_ERR_INVALID, "jh_tune_set: unknown knob '%s'", name);
@@ -667,6 +668,7 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "graph_replays")) *value = c.graph_replays;
     else if (!strcmp(name, "last_fwd_rows_per_wg")) *value = c.last_fwd_rows_per_wg;
     else if (!strcmp(name, "last_adj_launches")) *value = c.last_adj_launches;
+    else if (!strcmp(name, "grid_diag")) *value = c.grid_diag;
     else if (!strcmp(name, "wide_twin")) *value = c.wide_twin;
     else if (!strcmp(name, "red_wgs")) *value = c.red_wgs;
     else if (!strcmp(name, "last_fwd_walk")) *value = c.last_fwd_walk;

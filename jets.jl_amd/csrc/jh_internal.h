@@ -78,6 +78,7 @@ struct jh_context {
     int64_t last_adj_launches = 1;     // kernel launches of the most recent tall adjoint / fused normal call (read-only knob)
     int64_t last_fwd_walk = 0;         // grid walk used by the most recent tall forward launch (read-only knob)
     int64_t last_step_chain = 0;       // row chunks of the most recent one-pass step (0: the plain walk) (read-only knob)
+    int64_t grid_diag = 1;             // knob: M x K grids of plain diagonals on the branch-free kernel (0: the general kernels)
     int64_t wide_twin = 1;             // knob: wide elementwise operators on their tall twin: 0 never (general kernels), 1 adjoint always + forward from 16 MiB blocks, 2 both always (tests)
     int adj_from_found = 0;            // internal, set around ONE call: the tall adjoint continues from what its output holds (the
                                        // forward of a wide operator through its tall twin: `_d .+=` into d as found, src/Jets.jl:1024); never split

@@ -525,3 +525,38 @@ def test_wide_operator_of_large_blocks_runs_on_its_tall_twin(Jets, oracle, dt, m
     want_m = oracle.block_df_adj([ora], [found[j * n:(j + 1) * n].copy() for j in range(K)], [want_d])
     assert_bits_equal(mt.to_numpy(), np.concatenate(want_m), "wide adjoint of large blocks")
     J.close(W)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 2), (3, 5), (7, 4), (5, 9)])
+def test_grid_of_plain_diagonals_on_the_branch_free_kernel(Jets, oracle, dt, shape):
+    """M x K grids whose blocks are all un-adjointed diagonals run on k_grid_diag (four blocks' loads in flight per lane, no kind
+    switch): the bits of the oracle's loops -- forward into d AS FOUND (1024), adjoint from zero (1042) -- and of the general kernels."""
+    J = Jets
+    M, K = shape
+    n = 1024 + 64 * M                                                # 16-byte multiples for every eltype; several tiles
+    spc = J.JetSpace(dt, n)
+    coeff = [[J.rand(spc, seed=61, stream=i * K + j) for j in range(K)] for i in range(M)]
+    A = J.blockop([[J.JopDiagonal(c) for c in row] for row in coeff])
+    ops = [[oracle.Block("diag", n, coeff=u01(oracle, dt, 61, i * K + j, n)) for j in range(K)] for i in range(M)]
+    hm = [u01(oracle, dt, 62, j, n) for j in range(K)]
+    hd = [u01(oracle, dt, 63, i, n) for i in range(M)]
+    got = {}
+    for gd in (1, 0):
+        J.tune(grid_diag=gd)
+        try:
+            m = J.from_numpy(np.concatenate(hm), J.domain(A))
+            d = J.from_numpy(np.concatenate(hd), J.range(A))         # dirty
+            J.mul_(d, A, m)
+            mt = J.rand(J.domain(A), seed=64, stream=0)              # dirty
+            J.mul_(mt, A.H, d)
+            got[gd] = (d.to_numpy(), mt.to_numpy())
+        finally:
+            J.tune(grid_diag=1)
+    want_d = oracle.block_df(ops, [b.copy() for b in hd], hm)
+    want_m = oracle.block_df_adj(ops, [np.zeros(n, dt) for _ in range(K)], want_d)
+    for gd in (1, 0):
+        assert_bits_equal(got[gd][0], np.concatenate(want_d), f"grid forward, grid_diag={gd}")
+        assert_bits_equal(got[gd][1], np.concatenate(want_m), f"grid adjoint, grid_diag={gd}")
+    J.close(A)

@@ -33,8 +33,8 @@ def timed(fn, reps=6, warm=2):
 
 
 b = n * 4
-for xcd in (1, 0, 2):
-    J.tune(general_xcd=xcd)
+for gd, xcd in ((1, 1), (0, 1), (1, 1), (0, 1), (0, 0)):      # grid_diag: the branch-free kernel for grids of plain diagonals (0: the general kernels)
+    J.tune(general_xcd=xcd, grid_diag=gd)
     tf = timed(lambda: J.mul_(d, A, m))
     ta = timed(lambda: J.mul_(mt, A.H, d))
-    print(f"{M} x {K} of {edge}^3 general_xcd={xcd}: forward {tf:7.3f} ms {(M * K + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {(M * K + M + K) * b / ta / 1e6:7.1f} GB/s", flush=True)
+    print(f"{M} x {K} of {edge}^3 grid_diag={gd} general_xcd={xcd}: forward {tf:7.3f} ms {(M * K + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {(M * K + M + K) * b / ta / 1e6:7.1f} GB/s", flush=True)
