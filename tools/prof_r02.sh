@@ -20,7 +20,7 @@ CMD3="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --lsqr 10"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p2_lsqr_kt -- $CMD3 > gpurun_out/p2_lsqr_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/p2_lsqr_fetch -- $CMD3 > gpurun_out/p2_lsqr_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/p2_lsqr_write -- $CMD3 > gpurun_out/p2_lsqr_write.log 2>&1
-python3 tools/prof_summary.py --round r02 --tag _lsqr --kt gpurun_out/p2_lsqr_kt --fetch gpurun_out/p2_lsqr_fetch --write gpurun_out/p2_lsqr_write --merge --cmd "$CMD3" > gpurun_out/p2_lsqr_summary.txt 2>&1
+python3 tools/prof_summary.py --round r02 --tag _lsqr --kt gpurun_out/p2_lsqr_kt --fetch gpurun_out/p2_lsqr_fetch --write gpurun_out/p2_lsqr_write --adj-launches 2 --merge --cmd "$CMD3" > gpurun_out/p2_lsqr_summary.txt 2>&1
 mkdir -p gpurun_out/profiles_r02 && cp profiles/rocprof_r02_* profiles/traffic_latest.json gpurun_out/profiles_r02/
 find gpurun_out/p2_kt gpurun_out/p2_pin_kt gpurun_out/p2_fetch gpurun_out/p2_write gpurun_out/p2_lsqr_kt gpurun_out/p2_lsqr_fetch gpurun_out/p2_lsqr_write -type f -size +1M -delete
 head -12 gpurun_out/p2_default_summary.txt; head -14 gpurun_out/p2_pmc_summary.txt; head -16 gpurun_out/p2_lsqr_summary.txt
