@@ -69,3 +69,25 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "jets_oracle" not in src and "libjets_oracle" not in src and "from oracle" not in src, f"{f} references the oracle"
+
+
+def test_every_entry_point_is_mapped_to_the_reference_in_integration_md():
+    """INTEGRATION.md section 2 maps the ABI onto the reference: no entry point of include/jetship.h may be missing from it
+    (grouped spellings like `jh_event_create/record/elapsed_ms/destroy` count)."""
+    import re
+
+    header = open(os.path.join(ROOT, "include", "jetship.h")).read()
+    names = sorted(set(re.findall(r"^(?:int|const char \*)\s*(jh_\w+)\(", header, re.M)))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    groups = re.findall(r"`(jh_\w+(?:/\w+)+)`", doc)                 # `jh_a_b/c/d` -> jh_a_b, jh_a_c, jh_a_d
+    spelled = set()
+    for g in groups:
+        head, *rest = g.split("/")
+        spelled.add(head)
+        stem = head.rsplit("_", 1)[0]
+        for r in rest:
+            spelled.add(r if r.startswith("jh_") else f"{stem}_{r}")
+            if "_" in stem:                                           # `jh_comm_unique_id/init_rank` style: suffix replaces the last TWO words
+                spelled.add(f"{stem.rsplit('_', 1)[0]}_{r}")
+    missing = [n for n in names if n not in doc and n not in spelled]
+    assert len(names) >= 80 and not missing, missing
