@@ -451,8 +451,13 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
                                                           const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, int direct,
                                                           S alpha, S beta, double *__restrict__ partials, int64_t s_begin, int64_t s_end,
                                                           int64_t row0, int64_t row1, int accumulate, int64_t rows_per_part,
-                                                          S *__restrict__ part_out, int64_t part_stride, int remap)
+                                                          S *__restrict__ part_out, int64_t part_stride, int remap,
+                                                          const double *__restrict__ coef_dev, const int *__restrict__ done_dev)
 {
+    // coef_dev / done_dev (the graph-captured LSQR loop of small operators, jh_lsqr.hip): (alpha, beta) come from device memory --
+    // the previous iteration's scalar kernel wrote them -- and a finished solve turns the launch into a no-op
+    if (done_dev && *done_dev) return;
+    if (coef_dev) { alpha = (S)coef_dev[0]; beta = (S)coef_dev[1]; }
     // rows [row0, row1); accumulate != 0 continues w's ordered sum from what it holds (several launches, the bits of one)
     // remap != 0 (gridDim.x % 8 == 0): workgroups are dealt round-robin over the 8 XCDs, so id % 8 names the XCD; XCD x then owns
     // one CONTIGUOUS eighth of the tiles instead of every eighth tile.  +4 % on this kernel at 128-256 rows of 64 MiB blocks when
@@ -2225,6 +2230,9 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     const bool chain_ok = cb != 0 && c.step_chain != 0 && (c.step_chain == 1 || knobs_free);
     const bool remap_ok = parts == 1 && gx % 8 == 0 && gx >= 64 && rows_per_launch == op->nrow;
     int mode = 0, slot = -1;
+    if (c.step_coef_dev) {                                                // the graph-captured loop: one plain launch, nothing measured
+        if (parts > 1 || rows_per_launch != op->nrow) return jh_fail(JH_ERR_UNSUPPORTED, "one-pass step with device-resident coefficients: the split walk is not supported");
+    } else
     if (c.step_chain == 1 && chain_ok) mode = 2;
     else if (op->step_mode >= 0) mode = op->step_mode;
     else if ((remap_ok || chain_ok) && c.autotune && !stream_is_capturing(c.stream) && (op->step_span == 0 || op->step_span == span) &&
@@ -2289,10 +2297,12 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
                                c.stream,                                                                                 \
                                op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars,      \
                                direct, (S)alpha, (S)beta, c.part_dev, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0,              \
-                               rows_per_part, (S *)slabs, part_stride, remap);                                           \
+                               rows_per_part, (S *)slabs, part_stride, remap, c.step_coef_dev, c.step_done_dev);        \
             JH_CHECK_HIP(hipGetLastError());                                                                             \
             if (parts > 1) JH_TRY((launch_fold_parts<S, NS>(slabs, part_stride, parts, w, s_begin, s_end)));              \
             double part = 0.0;                                                                                           \
+            c.last_step_parts = gx * parts;                                                                              \
+            if (c.step_coef_dev && c.step_skip_fold) return trial_done(JH_OK);   /* the caller folds part_dev itself */    \
             const int st_ = finish_normsq(gx * parts, normsq ? &part : nullptr, defer, several ? 9 : -1);                \
             if (st_ != JH_OK) return trial_done(st_);                                                                    \
             total += part;                                                                                               \
@@ -2487,7 +2497,7 @@ int run_loop_graphed(const jh_blockop *op, int mode, const void *out, const void
         return body();
     }
     const uint64_t gen0 = c.buf_gen;
-    if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    if (hipStreamBeginCapture(c.stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
         (void)hipGetLastError();
         return body();
     }

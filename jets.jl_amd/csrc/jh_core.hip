@@ -88,7 +88,8 @@ static int ctx_create(int device, bool primary, int *id_out)
     c->stream = c->own_stream;
     e = hipMalloc((void **)&c->red_dev, sizeof(double) * 4 * JH_RED_SLOTS);
     if (e != hipSuccess) return fail(e, "hipMalloc");
-    e = hipMemset(c->red_dev, 0, sizeof(double) * 4 * JH_RED_SLOTS);
+    e = hipMemsetAsync(c->red_dev, 0, sizeof(double) * 4 * JH_RED_SLOTS, c->own_stream);   // (not the legacy stream: another thread may be capturing)
+    if (e == hipSuccess) e = hipStreamSynchronize(c->own_stream);
     if (e != hipSuccess) return fail(e, "hipMemset");
     e = hipHostMalloc((void **)&c->red_host, sizeof(double) * 8, hipHostMallocDefault);
     if (e != hipSuccess) return fail(e, "hipHostMalloc");
@@ -635,6 +636,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "force_dist")) { c.force_dist = value ? 1 : 0; }
     else if (!strcmp(name, "step_chain")) { JH_REQUIRE(value >= -1 && value <= 1, "step_chain must be -1 (auto), 0 or 1"); c.step_chain = value; }
     else if (!strcmp(name, "general_xcd")) { JH_REQUIRE(value >= 0 && value <= 2, "general_xcd must be 0 (never), 1 (automatic) or 2 (always)"); c.general_xcd = value; }
+    else if (!strcmp(name, "lsqr_graph")) { c.lsqr_graph = value ? 1 : 0; }
     else if (!strcmp(name, "grid_diag")) { c.grid_diag = value ? 1 : 0; }
     else if (!strcmp(name, "wide_twin")) { JH_REQUIRE(value >= 0 && value <= 2, "wide_twin must be 0 (never), 1 (automatic) or 2 (always)"); c.wide_twin = value; }
     else if (!strcmp(name, "red_wgs")) { JH_REQUIRE(value >= 1 && value <= 1 << 20, "red_wgs out of range"); c.red_wgs = value; }
@@ -668,6 +670,8 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "graph_replays")) *value = c.graph_replays;
     else if (!strcmp(name, "last_fwd_rows_per_wg")) *value = c.last_fwd_rows_per_wg;
     else if (!strcmp(name, "last_adj_launches")) *value = c.last_adj_launches;
+    else if (!strcmp(name, "lsqr_graph")) *value = c.lsqr_graph;
+    else if (!strcmp(name, "last_lsqr_graph")) *value = c.last_lsqr_graph;
     else if (!strcmp(name, "grid_diag")) *value = c.grid_diag;
     else if (!strcmp(name, "wide_twin")) *value = c.wide_twin;
     else if (!strcmp(name, "red_wgs")) *value = c.red_wgs;

@@ -80,6 +80,12 @@ struct jh_context {
     int64_t last_step_chain = 0;       // row chunks of the most recent one-pass step (0: the plain walk) (read-only knob)
     int64_t grid_diag = 1;             // knob: M x K grids of plain diagonals on the branch-free kernel (0: the general kernels)
     int64_t wide_twin = 1;             // knob: wide elementwise operators on their tall twin: 0 never (general kernels), 1 adjoint always + forward from 16 MiB blocks, 2 both always (tests)
+    const double *step_coef_dev = nullptr;   // internal, set around the calls of the graph-captured LSQR loop: the one-pass step reads (alpha, beta) from
+    const int *step_done_dev = nullptr;      // here instead of its arguments and returns at once when *step_done_dev != 0 (jh_lsqr.hip: lsqr_graph_impl)
+    int step_skip_fold = 0;                  // internal: ... and leaves the fold of its per-workgroup partial sums (part_dev[0 .. last_step_parts)) to the caller
+    int64_t last_step_parts = 0;             // per-workgroup partial sums the most recent one-pass step wrote
+    int64_t lsqr_graph = 1;            // knob: small operators' LSQR loop with device-resident recurrences, replayed as a hipGraph (0: the host loop)
+    int64_t last_lsqr_graph = 0;       // read-only: graph replays of the most recent jh_lsqr_solve (0: the host loop ran)
     int adj_from_found = 0;            // internal, set around ONE call: the tall adjoint continues from what its output holds (the
                                        // forward of a wide operator through its tall twin: `_d .+=` into d as found, src/Jets.jl:1024); never split
 };

@@ -118,6 +118,207 @@ int launch_xw(int dtype, jh_bvec *v, jh_bvec *x, jh_bvec *w, double cv, double t
 
 }  // namespace
 
+// ---- small operators: the recurrences live on the DEVICE and one iteration is a hipGraph -------------------------------------
+// The loop below (lsqr_impl) synchronises the host twice per iteration to turn two sums into the next coefficients.  For an
+// operator whose pass takes a few hundred microseconds that costs as much as the kernels (64 x 64^3: 84 us per iteration, 35 of
+// them on the device).  Here the scalars of Paige & Saunders' recurrences are a struct in device memory, two one-thread kernels
+// update it from the sums exactly as the host code does (same operations, same order, fp64), the step / v / x-w kernels read
+// their coefficients from it, and a finished solve turns every kernel into a no-op -- so an iteration has fixed launch parameters,
+// is captured ONCE as a hipGraph and replayed; the host looks at the `done` flag every few iterations.  Same kernels, same
+// arithmetic: the iterates are those of lsqr_impl bit for bit.
+struct LsqrDev {
+    double alpha, beta, rhobar, phibar, anorm, ddnorm, res2, xxnorm, z, cs2, sn2, bnorm, wnorm, damp, atol, btol, ctol;
+    double r1norm, r2norm, acond, arnorm, xnorm;
+    double coef_step[2];                         // (1, -alpha / beta): the next one-pass step
+    double coef_vhat[2];                         // (1 / beta, -beta)
+    double coef_xw[3];                           // (cv, t1, t2)
+    int itn, istop, done, pending, skipv, maxiter, force, pad;
+};
+
+// after the step: beta from ||u||^2, ||w|| of the previous iteration, the coefficients of the v update
+__device__ inline void lsqr_s1(LsqrDev *st, double normsq, const double *__restrict__ slot_w)
+{
+    st->itn++;
+    st->beta = sqrt(normsq);
+    if (st->itn >= 2) st->wnorm = sqrt(*slot_w);
+    st->skipv = 1;
+    if (st->beta > 0) {
+        st->anorm = sqrt(st->anorm * st->anorm + st->alpha * st->alpha + st->beta * st->beta + st->damp * st->damp);
+        st->coef_vhat[0] = 1.0 / st->beta;
+        st->coef_vhat[1] = -st->beta;
+        st->skipv = 0;
+    }
+}
+
+// after the v update: alpha, the rotations, the coefficients of the x / w update, the stopping rules (lsqr_impl, line by line)
+__device__ inline void lsqr_s2(LsqrDev *st, double sum_v, double *__restrict__ history)
+{
+    double alpha = st->alpha, beta = st->beta, rhobar = st->rhobar, phibar = st->phibar;
+    double cv = 1.0;
+    if (!st->skipv) {
+        alpha = sqrt(sum_v);
+        if (alpha > 0) cv = 1.0 / alpha;
+    }
+    const double damp = st->damp;
+    const double rhobar1 = sqrt(rhobar * rhobar + damp * damp);
+    const double rho = sqrt(rhobar1 * rhobar1 + beta * beta);
+    if (!(rhobar1 > 0 && isfinite(rho))) {       // far past convergence under force_maxiter: the recurrences have underflowed
+        if (!st->istop) st->istop = 6;
+        st->itn--;
+        st->alpha = alpha;
+        st->done = 1;
+        return;
+    }
+    const double cs1 = rhobar / rhobar1, sn1 = damp / rhobar1;
+    const double psi = sn1 * phibar;
+    phibar = cs1 * phibar;
+    const double cs = rhobar1 / rho, sn = beta / rho;
+    const double theta = sn * alpha;
+    rhobar = -cs * alpha;
+    const double phi = cs * phibar;
+    phibar = sn * phibar;
+    const double tau = sn * phi;
+    const double t1 = phi / rho, t2 = -theta / rho;
+    st->ddnorm += (st->wnorm / rho) * (st->wnorm / rho);
+    st->coef_xw[0] = cv;
+    st->coef_xw[1] = t1;
+    st->coef_xw[2] = t2;
+    const double delta = st->sn2 * rho, gambar = -st->cs2 * rho, rhs = phi - delta * st->z, zbar = rhs / gambar;
+    const double xnorm = sqrt(st->xxnorm + zbar * zbar);
+    const double gamma = sqrt(gambar * gambar + theta * theta);
+    st->cs2 = gambar / gamma;
+    st->sn2 = theta / gamma;
+    st->z = rhs / gamma;
+    st->xxnorm += st->z * st->z;
+    const double anorm = st->anorm;
+    const double acond = anorm * sqrt(st->ddnorm);
+    const double res1 = phibar * phibar;
+    st->res2 += psi * psi;
+    const double rnorm = sqrt(res1 + st->res2);
+    const double arnorm = alpha * fabs(tau);
+    const double r1sq = rnorm * rnorm - damp * damp * st->xxnorm;
+    const double r1norm = sqrt(fabs(r1sq)) * (r1sq >= 0 ? 1.0 : -1.0);
+    const int itn = st->itn;
+    if (history) { history[2 * (itn - 1)] = r1norm; history[2 * (itn - 1) + 1] = arnorm; }
+    const double eps = 2.220446049250313e-16, bnorm = st->bnorm;
+    const double test1 = bnorm > 0 ? rnorm / bnorm : 0.0;
+    const double test2 = rnorm > 0 ? arnorm / (anorm * rnorm + eps) : 0.0;
+    const double test3 = 1.0 / (acond + eps);
+    const double t1_ = bnorm > 0 ? test1 / (1 + anorm * xnorm / bnorm) : 0.0;
+    const double rtol = bnorm > 0 ? st->btol + st->atol * anorm * xnorm / bnorm : 0.0;
+    int istop = st->istop;
+    if (itn >= st->maxiter) istop = 7;
+    if (1 + test3 <= 1) istop = 6;
+    if (1 + test2 <= 1) istop = 5;
+    if (1 + t1_ <= 1) istop = 4;
+    if (test3 <= st->ctol) istop = 3;
+    if (test2 <= st->atol) istop = 2;
+    if (test1 <= rtol) istop = 1;
+    st->istop = istop;
+    st->alpha = alpha;
+    st->rhobar = rhobar;
+    st->phibar = phibar;
+    st->r1norm = r1norm;
+    st->r2norm = rnorm;
+    st->acond = acond;
+    st->arnorm = arnorm;
+    st->xnorm = xnorm;
+    st->coef_step[0] = 1.0;
+    st->coef_step[1] = -alpha / beta;
+    if (istop && !(st->force && itn < st->maxiter && alpha > 0 && beta > 0)) st->pending = 1;   // x and w of THIS iteration are still updated
+}
+
+__global__ void k_lsqr_s1(LsqrDev *st, const double *__restrict__ normsq, const double *__restrict__ slot_w)
+{
+    if (!st->done) lsqr_s1(st, *normsq, slot_w);
+}
+__global__ void k_lsqr_s2(LsqrDev *st, const double *__restrict__ slot_v, double *__restrict__ history)
+{
+    if (!st->done) lsqr_s2(st, *slot_v, history);
+}
+__global__ void k_lsqr_s3(LsqrDev *st)
+{
+    if (st->pending) st->done = 1;
+}
+
+// the same three steps FUSED into the single-workgroup folds that precede them (k_sum_partials / k_lsqr_fold: the same strided sums
+// and the same tree, so the same bits): an iteration is then six graph nodes instead of ten, and the chain of dependent small
+// kernels is what a small operator's iteration costs
+template <int BLK> __device__ inline double wg_sum_value(double v)
+{
+    __shared__ double sm[BLK / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = sm[0];
+#pragma unroll
+    for (int w = 1; w < BLK / 64; w++) r += sm[w];
+    return r;                                    // (valid in every lane)
+}
+__global__ __launch_bounds__(256) void k_lsqr_fold_s1(const double *__restrict__ partials, int64_t nparts, LsqrDev *st, const double *__restrict__ slot_w)
+{
+    if (st->done) return;
+    double v = 0.0;
+    for (int64_t i = threadIdx.x; i < nparts; i += 256) v += partials[i];
+    const double r = wg_sum_value<256>(v);
+    if (threadIdx.x == 0) lsqr_s1(st, 0.0 + r, slot_w);      // (k_sum_partials adds its sum to a zeroed accumulator)
+}
+__global__ __launch_bounds__(256) void k_lsqr_fold_s2(const double *__restrict__ partials, int nparts, LsqrDev *st, double *__restrict__ history)
+{
+    if (st->done) return;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) v += partials[i];
+    const double r = wg_sum_value<256>(v);
+    if (threadIdx.x == 0) lsqr_s2(st, r, history);
+}
+__global__ __launch_bounds__(256) void k_lsqr_fold_s3(const double *__restrict__ partials, int nparts, double *__restrict__ slot_w, LsqrDev *st)
+{
+    if (st->done) return;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) v += partials[i];
+    const double r = wg_sum_value<256>(v);
+    if (threadIdx.x == 0) {
+        *slot_w = r;
+        if (st->pending) st->done = 1;
+    }
+}
+
+template <typename S>
+__global__ __launch_bounds__(256) void k_lsqr_vhat_dev(S *v, const S *__restrict__ atu, int64_t n, const LsqrDev *__restrict__ st, double *__restrict__ partials)
+{
+    if (st->done || st->skipv) return;
+    const S c0 = (S)st->coef_vhat[0], c1 = (S)st->coef_vhat[1];
+    double nrm = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const S a = c0 * atu[i], b = c1 * v[i];
+        const S r = a + b;
+        v[i] = r;
+        nrm += (double)r * (double)r;
+    }
+    wg_sum_to<256>(nrm, partials + blockIdx.x);
+}
+
+template <typename S>
+__global__ __launch_bounds__(256) void k_lsqr_xw_dev(S *v, S *x, S *w, int64_t n, const LsqrDev *__restrict__ st, double *__restrict__ partials)
+{
+    if (st->done) return;
+    const S cv = (S)st->coef_xw[0], t1 = (S)st->coef_xw[1], t2 = (S)st->coef_xw[2];
+    double nrm = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const S vn = cv * v[i];
+        const S wo = w[i];
+        const S xa = (S)1 * x[i], xb = t1 * wo;
+        const S wa = (S)1 * vn, wb = t2 * wo;
+        const S wn = wa + wb;
+        v[i] = vn;
+        x[i] = xa + xb;
+        w[i] = wn;
+        nrm += (double)wn * (double)wn;
+    }
+    wg_sum_to<256>(nrm, partials + blockIdx.x);
+}
+
 // WHO sums across shards of the operator:
 //   none   one context holds all rows (jh_lsqr_solve);
 //   ranks  op/u are THIS rank's block rows of a row-partitioned operator and the exchange runs over the communicator of
@@ -346,9 +547,195 @@ static int lsqr_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *
     return JH_OK;
 }
 
+// The graph-replayed loop for ONE small operator in one context (see LsqrDev above).  *took = false: not eligible, nothing was
+// touched, the caller runs lsqr_impl.
+static int lsqr_graph_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, double conlim,
+                           int maxiter, int force_maxiter, jh_lsqr_result *res, double *history, bool *took)
+{
+    *took = false;
+    JH_TRY(jh_enter(op, u, x));
+    jh_context &c = jh_ctx();
+    c.last_lsqr_graph = 0;
+    if (!c.lsqr_graph || !op || !u || !x || !res || maxiter < 1) return JH_OK;
+    if (!jh_blockop_tall_fast(op, u->data, x->data)) return JH_OK;
+    // one plain launch per step: no split walk (pick_adj_parts), no row-chunked launches; and only where launches and host
+    // round trips matter: a pass over the operator and u below 1 GiB
+    if (!(c.adj_split <= 0 && (op->nrow < 256 || c.adj_split == 0) && c.adj_rows_per_launch == 0)) return JH_OK;
+    const int dtype = x->dtype;
+    const int64_t n = x->length;
+    if (3.0 * (double)op->nrow * (double)n * (double)jh_dtype_size(dtype) >= (double)(1ull << 30)) return JH_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c.stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return JH_OK;
+    *took = true;
+
+    Tmp t;
+    const int64_t len1[1] = {n};
+    JH_TRY(jh_bvec_create(1, len1, dtype, &t.v));
+    JH_TRY(jh_bvec_create(1, len1, dtype, &t.w));
+    JH_TRY(jh_bvec_create(1, len1, dtype, &t.atu));
+    const int64_t ns_dom = n * (jh_dtype_complex(dtype) ? 2 : 1);
+    int grid = (int)((ns_dom + 255) / 256 < 4096 ? (ns_dom + 255) / 256 : 4096);
+    if (grid < 1) grid = 1;
+    JH_CHECK_HIP(hipMalloc((void **)&t.parts, sizeof(double) * (2 * (size_t)grid + 2)));
+    double *parts_v = t.parts, *parts_w = t.parts + grid, *slot_v = t.parts + 2 * grid, *slot_w = slot_v + 1;
+    *res = jh_lsqr_result{};
+
+    // ---- the start-up of lsqr_impl, one shard, no exchange
+    if (!use_x0) JH_TRY(jh_fill(x, 0.0, 0.0));
+    double nrm = 0.0;
+    JH_TRY(jh_norm(u, 2.0, &nrm));
+    const double bnorm = std::sqrt(nrm * nrm);
+    double beta = bnorm;
+    if (use_x0) {
+        double local = 0.0;
+        JH_TRY(jh_blockop_mul_axpby(op, u, x, -1.0, 1.0, &local));
+        beta = std::sqrt(local);
+    }
+    double alpha = 0.0;
+    if (beta > 0) {
+        JH_TRY(jh_blockop_mul_adj(op, t.atu, u));
+        JH_TRY(lincomb1(t.v, 1.0 / beta, t.atu));
+        JH_TRY(jh_norm(t.v, 2.0, &alpha));
+    } else {
+        JH_TRY(jh_copy(t.v, x));
+    }
+    if (alpha > 0) JH_TRY(lincomb1(t.v, 1.0 / alpha, t.v));
+    JH_TRY(jh_copy(t.w, t.v));
+    double wnorm = 0.0;
+    JH_TRY(jh_norm(t.w, 2.0, &wnorm));
+    const double arnorm0 = alpha * beta;
+    res->r1norm = res->r2norm = beta;
+    res->arnorm = arnorm0;
+    if (arnorm0 == 0) return JH_OK;                                       // (istop = itn = 0, like lsqr_impl)
+
+    // ---- device state
+    struct Dev {
+        LsqrDev *st = nullptr;
+        double *hist = nullptr;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        ~Dev()
+        {
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (st) (void)hipFree(st);
+            if (hist) (void)hipFree(hist);
+        }
+    } d;
+    JH_CHECK_HIP(hipMalloc((void **)&d.st, sizeof(LsqrDev)));
+    JH_CHECK_HIP(hipMalloc((void **)&d.hist, sizeof(double) * 2 * (size_t)maxiter));
+    LsqrDev h{};
+    h.alpha = alpha;
+    h.beta = beta;
+    h.rhobar = alpha;
+    h.phibar = beta;
+    h.cs2 = -1.0;
+    h.bnorm = bnorm;
+    h.wnorm = wnorm;
+    h.damp = damp;
+    h.atol = atol;
+    h.btol = btol;
+    h.ctol = conlim > 0 ? 1.0 / conlim : 0.0;
+    h.r1norm = h.r2norm = beta;
+    h.arnorm = arnorm0;
+    h.coef_step[0] = 1.0;
+    h.coef_step[1] = -alpha / beta;
+    h.maxiter = maxiter;
+    h.force = force_maxiter ? 1 : 0;
+    JH_CHECK_HIP(hipMemcpyAsync(d.st, &h, sizeof(h), hipMemcpyHostToDevice, c.stream));
+    JH_CHECK_HIP(hipStreamSynchronize(c.stream));                        // `h` is a stack object
+
+    const bool f64 = (dtype == JH_F64 || dtype == JH_C64);
+    // one iteration, enqueued on the context's stream: eagerly the first time (workspaces get their size), captured the second
+    auto iteration = [&]() -> int {
+        JH_TRY(jh_normsq_reset());
+        c.step_coef_dev = d.st->coef_step;
+        c.step_done_dev = &d.st->done;
+        const int st_ = jh_blockop_bidiag_step_range(op, u, t.v, t.atu, 1.0, 0.0, 0, n, nullptr);     // (alpha, beta) come from the device
+        c.step_coef_dev = nullptr;
+        c.step_done_dev = nullptr;
+        JH_TRY(st_);
+        hipLaunchKernelGGL(k_lsqr_s1, dim3(1), dim3(1), 0, c.stream, d.st, (const double *)(c.red_dev + JH_NORMSQ_SLOT), (const double *)slot_w);
+        if (f64) hipLaunchKernelGGL((k_lsqr_vhat_dev<double>), dim3(grid), dim3(256), 0, c.stream, (double *)t.v->data, (const double *)t.atu->data, ns_dom, (const LsqrDev *)d.st, parts_v);
+        else hipLaunchKernelGGL((k_lsqr_vhat_dev<float>), dim3(grid), dim3(256), 0, c.stream, (float *)t.v->data, (const float *)t.atu->data, ns_dom, (const LsqrDev *)d.st, parts_v);
+        hipLaunchKernelGGL(k_lsqr_fold, dim3(1), dim3(256), 0, c.stream, (const double *)parts_v, grid, slot_v);
+        hipLaunchKernelGGL(k_lsqr_s2, dim3(1), dim3(1), 0, c.stream, d.st, (const double *)slot_v, d.hist);
+        if (f64) hipLaunchKernelGGL((k_lsqr_xw_dev<double>), dim3(grid), dim3(256), 0, c.stream, (double *)t.v->data, (double *)x->data, (double *)t.w->data, ns_dom, (const LsqrDev *)d.st, parts_w);
+        else hipLaunchKernelGGL((k_lsqr_xw_dev<float>), dim3(grid), dim3(256), 0, c.stream, (float *)t.v->data, (float *)x->data, (float *)t.w->data, ns_dom, (const LsqrDev *)d.st, parts_w);
+        hipLaunchKernelGGL(k_lsqr_fold, dim3(1), dim3(256), 0, c.stream, (const double *)parts_w, grid, slot_w);
+        hipLaunchKernelGGL(k_lsqr_s3, dim3(1), dim3(1), 0, c.stream, d.st);
+        JH_CHECK_HIP(hipGetLastError());
+        return JH_OK;
+    };
+    // the same iteration with the scalar steps fused into the folds (six nodes): possible when the step's partial sums fit ONE
+    // fold launch (k_sum_partials' single-level form, <= 8192 workgroups) -- known after the eager iteration
+    auto iteration_fused = [&]() -> int {
+        c.step_coef_dev = d.st->coef_step;
+        c.step_done_dev = &d.st->done;
+        c.step_skip_fold = 1;
+        const int st_ = jh_blockop_bidiag_step_range(op, u, t.v, t.atu, 1.0, 0.0, 0, n, nullptr);
+        c.step_coef_dev = nullptr;
+        c.step_done_dev = nullptr;
+        c.step_skip_fold = 0;
+        JH_TRY(st_);
+        hipLaunchKernelGGL(k_lsqr_fold_s1, dim3(1), dim3(256), 0, c.stream, (const double *)c.part_dev, c.last_step_parts, d.st, (const double *)slot_w);
+        if (f64) hipLaunchKernelGGL((k_lsqr_vhat_dev<double>), dim3(grid), dim3(256), 0, c.stream, (double *)t.v->data, (const double *)t.atu->data, ns_dom, (const LsqrDev *)d.st, parts_v);
+        else hipLaunchKernelGGL((k_lsqr_vhat_dev<float>), dim3(grid), dim3(256), 0, c.stream, (float *)t.v->data, (const float *)t.atu->data, ns_dom, (const LsqrDev *)d.st, parts_v);
+        hipLaunchKernelGGL(k_lsqr_fold_s2, dim3(1), dim3(256), 0, c.stream, (const double *)parts_v, grid, d.st, d.hist);
+        if (f64) hipLaunchKernelGGL((k_lsqr_xw_dev<double>), dim3(grid), dim3(256), 0, c.stream, (double *)t.v->data, (double *)x->data, (double *)t.w->data, ns_dom, (const LsqrDev *)d.st, parts_w);
+        else hipLaunchKernelGGL((k_lsqr_xw_dev<float>), dim3(grid), dim3(256), 0, c.stream, (float *)t.v->data, (float *)x->data, (float *)t.w->data, ns_dom, (const LsqrDev *)d.st, parts_w);
+        hipLaunchKernelGGL(k_lsqr_fold_s3, dim3(1), dim3(256), 0, c.stream, (const double *)parts_w, grid, slot_w, d.st);
+        JH_CHECK_HIP(hipGetLastError());
+        return JH_OK;
+    };
+    struct Flags { int itn, istop, done, pending; } fl{};
+    auto read_flags = [&]() -> int {
+        JH_CHECK_HIP(hipMemcpyAsync(&fl, &d.st->itn, sizeof(fl), hipMemcpyDeviceToHost, c.stream));
+        JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+        return JH_OK;
+    };
+    JH_TRY(iteration());                                                  // iteration 1, eager
+    JH_TRY(read_flags());
+    int64_t replays = 0;
+    if (!fl.done) {
+        const bool fused = c.last_step_parts > 0 && c.last_step_parts <= 8192;
+        JH_CHECK_HIP(hipStreamBeginCapture(c.stream, hipStreamCaptureModeRelaxed));   // other host threads (other contexts) keep working meanwhile
+        const int st_ = fused ? iteration_fused() : iteration();
+        hipError_t e = hipStreamEndCapture(c.stream, &d.graph);
+        if (st_ != JH_OK) return st_;
+        JH_CHECK_HIP(e);
+        JH_CHECK_HIP(hipGraphInstantiate(&d.exec, d.graph, nullptr, nullptr, 0));
+        const int batch = maxiter < 8 ? maxiter : 8;                      // replays between two looks at the flags; finished solves replay as no-ops
+        while (!fl.done) {
+            for (int k = 0; k < batch; k++) JH_CHECK_HIP(hipGraphLaunch(d.exec, c.stream));
+            replays += batch;
+            JH_TRY(read_flags());
+        }
+    }
+    c.last_lsqr_graph = replays;
+    JH_CHECK_HIP(hipMemcpyAsync(&h, d.st, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+    JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+    if (history && h.itn > 0) {                                           // (on the context's stream: a legacy-stream copy would disturb another thread's capture)
+        JH_CHECK_HIP(hipMemcpyAsync(history, d.hist, sizeof(double) * 2 * (size_t)h.itn, hipMemcpyDeviceToHost, c.stream));
+        JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+    }
+    res->istop = h.istop;
+    res->itn = h.itn;
+    res->r1norm = h.r1norm;
+    res->r2norm = h.r2norm;
+    res->anorm = h.anorm;
+    res->acond = h.acond;
+    res->arnorm = h.arnorm;
+    res->xnorm = h.xnorm;
+    return JH_OK;
+}
+
 extern "C" int jh_lsqr_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, double conlim,
                              int maxiter, int force_maxiter, jh_lsqr_result *res, double *history)
 {
+    bool took = false;
+    JH_TRY(lsqr_graph_impl(op, u, x, use_x0, damp, atol, btol, conlim, maxiter, force_maxiter, res, history, &took));   // small operators
+    if (took) return JH_OK;
     return lsqr_impl(1, &op, &u, &x, use_x0, damp, atol, btol, conlim, maxiter, force_maxiter, res, history, Exch::none);
 }
 

@@ -516,3 +516,36 @@ def test_forced_iterations_far_past_convergence_stay_finite(Jets, monkeypatch, n
     assert np.isfinite(x).all() and res.itn < 4000 and res.istop != 0
     assert all(np.isfinite(h[1]) and np.isfinite(h[2]) for h in res.history)
     assert float(np.linalg.norm((x - x_true.to_numpy()).ravel()) / np.linalg.norm(x_true.to_numpy().ravel())) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64])
+def test_graph_replayed_loop_of_small_operators_has_the_bits_of_the_host_loop(Jets, oracle, dt):
+    """Small operators: the recurrences live on the device and one iteration is replayed as a hipGraph (jh_lsqr.hip: lsqr_graph_impl)
+    -- same kernels, same fp64 operations in the same order as the host loop, so x, the iteration count, the stopping rule and the
+    whole history must be IDENTICAL, with early stopping, damping, a warm start, forced iterations and a single iteration."""
+    J = Jets
+    nrow, shape = 9, (32, 16, 8)
+    A, _, _, _ = make_tall_diag(J, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    hb = (u01(oracle, dt, 71, 0, nrow * n) - dt(0.5)).astype(dt)
+    b = J.from_numpy(hb, J.range(A))
+    x0 = J.rand(J.domain(A), seed=72, stream=0)
+    cases = (dict(maxiter=25, atol=0.0, btol=0.0, conlim=0.0), dict(maxiter=60, atol=1e-4, btol=1e-4), dict(maxiter=30, atol=0.0, btol=0.0, damp=0.25),
+             dict(maxiter=17, atol=0.0, btol=0.0, x0=x0), dict(maxiter=1, atol=0.0, btol=0.0), dict(maxiter=9, atol=1e-2, btol=1e-2, force_maxiter=True),
+             dict(maxiter=2500, atol=0.0, btol=0.0, conlim=0.0, force_maxiter=True))
+    for kw in cases:
+        out = {}
+        for graph in (1, 0):
+            J.tune(lsqr_graph=graph)
+            try:
+                r = J.lsqr(A, b, **kw)
+                out[graph] = (r, J.tune_get("last_lsqr_graph"))
+            finally:
+                J.tune(lsqr_graph=1)
+        (rg, replays), (rh, zero) = out[1], out[0]
+        assert zero == 0 and (replays > 0 or kw["maxiter"] == 1), "the graph path ran (and only when asked)"
+        assert (rg.itn, rg.istop) == (rh.itn, rh.istop), kw
+        assert_bits_equal(rg.x.to_numpy(), rh.x.to_numpy(), f"x, {kw}")
+        assert rg.history == rh.history, kw
+        for f in ("r1norm", "r2norm", "anorm", "acond", "arnorm", "xnorm"):
+            assert getattr(rg, f) == getattr(rh, f), (f, kw)
