@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Fused JetSum of K tall diagonal operators (jh_blocksum_mul / _mul_adj): d = sum_k +-(A_k m) reads K coefficient slabs and writes d once
+(unfused: 5 range-sized streams per term).   python tools/bench_jetsum.py [K] [NROW] [EDGE]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import jets_jl_amd as J
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+nrow = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+edge = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+J.init(0)
+n = edge ** 3
+spc = J.JetSpace("float32", edge, edge, edge)
+ops = []
+for k in range(K):
+    coeff = J.rand(J.JetBSpace([spc] * nrow), seed=10 + k, stream=0)
+    ops.append(J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays]))
+S = ops[0]
+for k in range(1, K):
+    S = S + ops[k] if k % 2 else S - ops[k]
+m = J.rand(spc, seed=2, stream=0)
+d = J.zeros(J.range(ops[0]))
+mt = J.zeros(spc)
+
+
+def timed(fn, reps=7, warm=3):
+    for _ in range(warm):
+        fn()
+    best = 1e9
+    for _ in range(reps):
+        e0 = J.Event().record()
+        fn()
+        e1 = J.Event().record()
+        best = min(best, e0.elapsed_ms(e1))
+    return best
+
+
+b = n * 4
+tf = timed(lambda: J.mul_(d, S, m))
+ta = timed(lambda: J.mul_(mt, S.H, d))
+print(f"JetSum of {K} tall {nrow} x {edge}^3 operators: forward {tf:7.3f} ms {((K + 1) * nrow + 1) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {((K + 1) * nrow + 1) * b / ta / 1e6:7.1f} GB/s")
