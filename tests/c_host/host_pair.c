@@ -168,6 +168,24 @@ int main(void)
         for (int64_t k = 0; k < n; k++) { num += (double)(hx[k] - hxt[k]) * (hx[k] - hxt[k]); den += (double)hxt[k] * hxt[k]; }
         REQUIRE(sqrt(num / den) < 1e-3, "LSQR recovers x_true");
         printf("jh_lsqr_solve: %d iterations, istop %d, ||x - x_true|| / ||x_true|| = %.2e\n", lr.itn, lr.istop, sqrt(num / den));
+        /* the same solve without a history buffer, and through the host loop (knob lsqr_graph = 0): the same iteration count and x */
+        jh_lsqr_result lr2, lr3;
+        CK(jh_blockop_mul(A, bb, xt));
+        CK(jh_lsqr_solve(A, bb, xs, 0, 0.0, 1e-7, 1e-7, 0.0, 40, 0, &lr2, NULL));
+        float *hx2 = malloc((size_t)n * sizeof(float));
+        REQUIRE(hx2, "host allocation");
+        CK(jh_download(xs, 0, n, hx2));
+        REQUIRE(lr2.itn == lr.itn && lr2.istop == lr.istop && memcmp(hx2, hx, (size_t)n * sizeof(float)) == 0, "LSQR without a history buffer: same solve");
+        int64_t replays = -1;
+        CK(jh_tune_get("last_lsqr_graph", &replays));
+        REQUIRE(replays > 0, "a small operator's LSQR loop is replayed as a hipGraph");
+        CK(jh_tune_set("lsqr_graph", 0));
+        CK(jh_blockop_mul(A, bb, xt));
+        CK(jh_lsqr_solve(A, bb, xs, 0, 0.0, 1e-7, 1e-7, 0.0, 40, 0, &lr3, NULL));
+        CK(jh_tune_set("lsqr_graph", 1));
+        CK(jh_download(xs, 0, n, hx2));
+        REQUIRE(lr3.itn == lr.itn && memcmp(hx2, hx, (size_t)n * sizeof(float)) == 0, "graph-replayed loop == host loop, bit for bit");
+        free(hx2);
         free(hx); free(hxt);
         CK(jh_bvec_destroy(xt));
         CK(jh_bvec_destroy(bb));
