@@ -14,7 +14,12 @@ J.init(0)
 n = edge ** 3
 spc = J.JetSpace("float32", edge, edge, edge)
 coeff = J.rand(J.JetBSpace([spc] * (M * K)), seed=1, stream=0)
-A = J.blockop([[J.JopDiagonal(coeff.arrays[i * K + j]) for j in range(K)] for i in range(M)])
+colmajor = os.environ.get("GRID_COLMAJOR", "0") == "1"           # where block (i, j)'s coefficients sit in the slab: row by row, or column by column
+pad = int(os.environ.get("GRID_PAD_BLOCKS", "0"))                 # GRID_PAD_BLOCKS=1: one unused block after every row / column of blocks (breaks the power-of-two strides)
+if pad:
+    coeff = J.rand(J.JetBSpace([spc] * (M * K + (K if colmajor else M) * pad)), seed=1, stream=0)
+idx = (lambda i, j: j * (M + pad) + i) if colmajor else (lambda i, j: i * (K + pad) + j)
+A = J.blockop([[J.JopDiagonal(coeff.arrays[idx(i, j)]) for j in range(K)] for i in range(M)])
 m = J.rand(J.domain(A), seed=2, stream=0)
 d = J.zeros(J.range(A))
 mt = J.zeros(J.domain(A))
@@ -33,8 +38,8 @@ def timed(fn, reps=6, warm=2):
 
 
 b = n * 4
-for gd, xcd in ((1, 1), (0, 1), (1, 1), (0, 1), (0, 0)):      # grid_diag: the branch-free kernel for grids of plain diagonals (0: the general kernels)
+for gd, xcd in ((1, 1), (0, 1), (1, 1), (0, 1)):      # grid_diag: the branch-free kernel for grids of plain diagonals (0: the general kernels)
     J.tune(general_xcd=xcd, grid_diag=gd)
     tf = timed(lambda: J.mul_(d, A, m))
     ta = timed(lambda: J.mul_(mt, A.H, d))
-    print(f"{M} x {K} of {edge}^3 grid_diag={gd} general_xcd={xcd}: forward {tf:7.3f} ms {(M * K + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {(M * K + M + K) * b / ta / 1e6:7.1f} GB/s", flush=True)
+    print(f"{M} x {K} of {edge}^3 {'col-major' if colmajor else 'row-major'} slab pad {pad} grid_diag={gd} general_xcd={xcd}: forward {tf:7.3f} ms {(M * K + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {(M * K + M + K) * b / ta / 1e6:7.1f} GB/s", flush=True)
