@@ -1339,7 +1339,7 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
 // (forward: d_i = d_i as found + a_i1 .* m_1 + a_i2 .* m_2 + ..., 1020-1024; adjoint: m_j = 0 + conj(a_1j) .* d_1 + ..., 1042-1049).
 // Same (line, tile) decode as the general kernels: the workgroups of one tile of every line run together, so the shared input
 // tile comes from HBM once.  TRANSPOSED = false: line = block row; true: line = block column.
-template <typename S, int E, int NS, int Q, bool TRANSPOSED>
+template <typename S, int E, int NS, int Q, bool TRANSPOSED, int U = 1>
 __global__ __launch_bounds__(256) void k_grid_diag(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol, int64_t n_scalars,
                                                    const S *__restrict__ in, S *__restrict__ out, unsigned ntiles)
 {
@@ -1351,15 +1351,23 @@ __global__ __launch_bounds__(256) void k_grid_diag(const jh_dev_block *__restric
     const int64_t nsum = TRANSPOSED ? nrow : ncol;                          // blocks walked per line
     const int64_t step = TRANSPOSED ? 1 : nrow, first = TRANSPOSED ? line * nrow : line;   // block (q) of the line = blocks[first + q * step]
     S *o = out + line * n_scalars;
-    for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < n_scalars; s += (int64_t)ntiles * 256 * NS) {
-        V acc = TRANSPOSED ? (V)(S)0 : ld<false>(reinterpret_cast<const V *>(o + s));      // `_m .= 0` (1042) / d as found (1024)
+    for (int64_t s0 = (tile * 256 * U + threadIdx.x) * NS; s0 < n_scalars; s0 += (int64_t)ntiles * 256 * U * NS) {
+        int64_t s[U];
+        bool ok[U];
+        V acc[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {                                       // U packs per lane, 256 lanes apart (clamped: branch-free loads)
+            ok[u] = s0 + (int64_t)u * 256 * NS < n_scalars;
+            s[u] = ok[u] ? s0 + (int64_t)u * 256 * NS : s0;
+            acc[u] = TRANSPOSED ? (V)(S)0 : ld<false>(reinterpret_cast<const V *>(o + s[u]));   // `_m .= 0` (1042) / d as found (1024)
+        }
         const S *na[Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) na[q] = (const S *)blocks[first + (q < nsum ? q : 0) * step].coeff;
         int64_t q0 = 0;
         for (; q0 + Q <= nsum; q0 += Q) {
             const S *a[Q];
-            V x[Q], c[Q];
+            V x[Q][U], c[Q][U];
 #pragma unroll
             for (int q = 0; q < Q; q++) {
                 a[q] = na[q];
@@ -1367,19 +1375,29 @@ __global__ __launch_bounds__(256) void k_grid_diag(const jh_dev_block *__restric
                 na[q] = (const S *)blocks[first + (qn < nsum ? qn : 0) * step].coeff;
             }
 #pragma unroll
-            for (int q = 0; q < Q; q++) {
-                c[q] = ld<true>(reinterpret_cast<const V *>(a[q] + s));                       // streamed once
-                x[q] = ld<false>(reinterpret_cast<const V *>(in + (q0 + q) * n_scalars + s));  // shared by every line: through the caches
-            }
+            for (int q = 0; q < Q; q++)
 #pragma unroll
-            for (int q = 0; q < Q; q++) acc = acc + vmul<S, E, NS, V>(c[q], x[q], TRANSPOSED);
+                for (int u = 0; u < U; u++) {
+                    c[q][u] = ld<true>(reinterpret_cast<const V *>(a[q] + s[u]));                       // streamed once
+                    x[q][u] = ld<false>(reinterpret_cast<const V *>(in + (q0 + q) * n_scalars + s[u]));  // shared by every line: through the caches
+                }
+#pragma unroll
+            for (int q = 0; q < Q; q++)
+#pragma unroll
+                for (int u = 0; u < U; u++) acc[u] = acc[u] + vmul<S, E, NS, V>(c[q][u], x[q][u], TRANSPOSED);
         }
         for (int64_t q = q0; q < nsum; q++) {
-            const V c = ld<true>(reinterpret_cast<const V *>((const S *)blocks[first + q * step].coeff + s));
-            const V x = ld<false>(reinterpret_cast<const V *>(in + q * n_scalars + s));
-            acc = acc + vmul<S, E, NS, V>(c, x, TRANSPOSED);
+            const S *aq = (const S *)blocks[first + q * step].coeff;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const V c = ld<true>(reinterpret_cast<const V *>(aq + s[u]));
+                const V x = ld<false>(reinterpret_cast<const V *>(in + q * n_scalars + s[u]));
+                acc[u] = acc[u] + vmul<S, E, NS, V>(c, x, TRANSPOSED);
+            }
         }
-        st<true>(reinterpret_cast<V *>(o + s), acc);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (ok[u]) st<true>(reinterpret_cast<V *>(o + s[u]), acc[u]);
     }
 }
 
@@ -1935,6 +1953,8 @@ int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
     constexpr int NS = 16 / sizeof(S);
     int64_t want = vec ? (maxn * E / NS + 255) / 256 : (maxn + 255) / 256;     // vec: one pack per thread (see jh_vecops.hip: grid_full)
     if (!vec && want > 4096) want = 4096;
+    const bool gdiag = vec && !fmode && c.grid_diag && grid_diag_ok(op, d, m);  // a grid of plain diagonals: the branch-free kernel,
+    const int gu = gdiag ? (c.grid_diag >= 4 ? 4 : (c.grid_diag >= 2 ? 2 : 1)) : 1;   // gu packs per lane
     general_grid(want, op->nrow, ntiles, grid, general_use_xcd(op->col_off[(size_t)op->ncol] * (int64_t)(sizeof(S) * E)));
     // split walk over the block columns (general_parts)
     const int64_t out_scalars = op->row_off[(size_t)op->nrow] * E;
@@ -1947,9 +1967,12 @@ int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
         JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)out_scalars * sizeof(S), &slabs));
     }
     c.last_adj_parts = parts;
-    if (vec && parts == 1 && !fmode && c.grid_diag && grid_diag_ok(op, d, m)) {     // a grid of plain diagonals: the branch-free kernel
-        hipLaunchKernelGGL((k_grid_diag<S, E, NS, 4, false>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol,
-                           op->row_len[0] * E, (const S *)m, (S *)d, ntiles);
+    if (gdiag && parts == 1) {
+        if (gu > 1) general_grid((want + gu - 1) / gu, op->nrow, ntiles, grid, general_use_xcd(op->col_off[(size_t)op->ncol] * (int64_t)(sizeof(S) * E)));
+#define JH_GRID(UU) hipLaunchKernelGGL((k_grid_diag<S, E, NS, 4, false, UU>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, \
+                                       op->row_len[0] * E, (const S *)m, (S *)d, ntiles)
+        if (gu == 4) JH_GRID(4); else if (gu == 2) JH_GRID(2); else JH_GRID(1);
+#undef JH_GRID
         JH_CHECK_HIP(hipGetLastError());
         return JH_OK;
     }
@@ -1993,8 +2016,12 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
     }
     c.last_adj_parts = parts;
     if (vec && parts == 1 && c.grid_diag && grid_diag_ok(op, d, m)) {
-        hipLaunchKernelGGL((k_grid_diag<S, E, NS, 4, true>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol,
-                           op->row_len[0] * E, (const S *)d, (S *)m, ntiles);
+        const int gu = c.grid_diag >= 4 ? 4 : (c.grid_diag >= 2 ? 2 : 1);
+        if (gu > 1) general_grid((want + gu - 1) / gu, op->ncol, ntiles, grid, general_use_xcd(op->row_off[(size_t)op->nrow] * (int64_t)(sizeof(S) * E)));
+#define JH_GRID(UU) hipLaunchKernelGGL((k_grid_diag<S, E, NS, 4, true, UU>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, \
+                                       op->row_len[0] * E, (const S *)d, (S *)m, ntiles)
+        if (gu == 4) JH_GRID(4); else if (gu == 2) JH_GRID(2); else JH_GRID(1);
+#undef JH_GRID
         JH_CHECK_HIP(hipGetLastError());
         return JH_OK;
     }

@@ -637,7 +637,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "step_chain")) { JH_REQUIRE(value >= -1 && value <= 1, "step_chain must be -1 (auto), 0 or 1"); c.step_chain = value; }
     else if (!strcmp(name, "general_xcd")) { JH_REQUIRE(value >= 0 && value <= 2, "general_xcd must be 0 (never), 1 (automatic) or 2 (always)"); c.general_xcd = value; }
     else if (!strcmp(name, "lsqr_graph")) { c.lsqr_graph = value ? 1 : 0; }
-    else if (!strcmp(name, "grid_diag")) { c.grid_diag = value ? 1 : 0; }
+    else if (!strcmp(name, "grid_diag")) { JH_REQUIRE(value >= 0 && value <= 4, "grid_diag must be 0 (general kernels), 1, 2 or 4 (packs per lane)"); c.grid_diag = value; }
     else if (!strcmp(name, "wide_twin")) { JH_REQUIRE(value >= 0 && value <= 2, "wide_twin must be 0 (never), 1 (automatic) or 2 (always)"); c.wide_twin = value; }
     else if (!strcmp(name, "red_wgs")) { JH_REQUIRE(value >= 1 && value <= 1 << 20, "red_wgs out of range"); c.red_wgs = value; }
     else return jh_fail(JH_ERR_INVALID, "jh_tune_set: unknown knob '%s'", name);

@@ -543,7 +543,7 @@ def test_grid_of_plain_diagonals_on_the_branch_free_kernel(Jets, oracle, dt, sha
     hm = [u01(oracle, dt, 62, j, n) for j in range(K)]
     hd = [u01(oracle, dt, 63, i, n) for i in range(M)]
     got = {}
-    for gd in (1, 0):
+    for gd in (1, 2, 4, 0):                                          # 1 / 2 / 4 packs per lane on the branch-free kernel, 0 = the general kernels
         J.tune(grid_diag=gd)
         try:
             m = J.from_numpy(np.concatenate(hm), J.domain(A))
@@ -556,7 +556,7 @@ def test_grid_of_plain_diagonals_on_the_branch_free_kernel(Jets, oracle, dt, sha
             J.tune(grid_diag=1)
     want_d = oracle.block_df(ops, [b.copy() for b in hd], hm)
     want_m = oracle.block_df_adj(ops, [np.zeros(n, dt) for _ in range(K)], want_d)
-    for gd in (1, 0):
+    for gd in (1, 2, 4, 0):
         assert_bits_equal(got[gd][0], np.concatenate(want_d), f"grid forward, grid_diag={gd}")
         assert_bits_equal(got[gd][1], np.concatenate(want_m), f"grid adjoint, grid_diag={gd}")
     J.close(A)

@@ -38,7 +38,7 @@ def timed(fn, reps=6, warm=2):
 
 
 b = n * 4
-for gd, xcd in ((1, 1), (0, 1), (1, 1), (0, 1)):      # grid_diag: the branch-free kernel for grids of plain diagonals (0: the general kernels)
+for gd, xcd in ((1, 1), (2, 1), (4, 1), (0, 1), (1, 1), (2, 1), (4, 1), (0, 1)):      # grid_diag: the branch-free kernel for grids of plain diagonals (0: the general kernels)
     J.tune(general_xcd=xcd, grid_diag=gd)
     tf = timed(lambda: J.mul_(d, A, m))
     ta = timed(lambda: J.mul_(mt, A.H, d))
