@@ -12,7 +12,20 @@ HBM before the timed region.  One step = one forward mul!(d, A, m) + one adjoint
 With N GPUs the SAME operator is row-partitioned (1024/N block rows per rank, "strong" scaling);
 the adjoint ends with one RCCL all-reduce of the 64 MiB domain vector.
 
-Extras (not the metric): --fused-normal (the fused A'A kernel), --lsqr K (K LSQR iterations on b = A x_true).
+Launch modes for N > 1 (--mode, default auto).  Whatever started us -- a bare `python bench.py --gpus N` or N copies under
+torch.distributed.run -- the process that was started NEVER touches the GPU: it is a supervisor that starts the real workers as
+child processes, watches their heartbeats and relays the outcome.
+  ranks : one worker process per GPU over torch.distributed / RCCL (the deployment model; what the driver's launch line means).
+  team  : ONE worker process drives all N GPUs through the C ABI's single-process team (jh_comm_init_all = ncclCommInitAll,
+          one context per device, grouped ranged all-reduces) -- needs no N GPU-holding processes and no IPC handles.
+  auto  : ranks first; if a rank dies or stalls BEFORE the first collective has completed (process cap, RCCL bootstrap), the
+          supervisor stops exactly the PIDs it started and runs a FRESH team-mode child instead, and the line says so
+          ("launch_mode", "launch_fallback").  A failure after the first collective is a real failure: non-zero exit, no line.
+Workers write heartbeats (phase names) to a file; no heartbeat for BENCH_WATCHDOG_S (120) seconds -- BENCH_WATCHDOG_IMPORT_S
+(300) while python / torch are still being paged in -- stops the job with "rank r stalled in phase p".
+
+Extras (not the metric): --fused-normal (the fused A'A kernel), --lsqr K (K LSQR iterations on b = A x_true), --check (team
+mode: replicas bit-identical, adjoint against the fp64 sum of the members' partial sums; --dump FILE saves member 0's result).
 BENCH_FORCE_DIST=1 under torch.distributed.run with one process exercises the RCCL path on a one-GPU box.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
@@ -30,6 +43,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # the all-cores CPU baseline must not spin on barriers in a CPU-capped container
+os.environ.setdefault("OMP_PROC_BIND", "close")       # ... and its threads stay where they first touched their pages
+os.environ.setdefault("OMP_PLACES", "cores")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 
@@ -47,7 +62,24 @@ def parse_args():
     ap.add_argument("--tune", type=str, default="", help="k=v,k=v kernel knobs (fwd_group, fwd_unroll, fwd_wg, adj_unroll, adj_depth, adj_wg, nt; 0 = automatic)")
     ap.add_argument("--fused-normal", action="store_true", help="also time the fused A'A kernel (extra field, not the metric)")
     ap.add_argument("--lsqr", type=int, default=0, help="also run this many LSQR iterations on b = A x_true (extra field, not the metric)")
+    ap.add_argument("--mode", choices=("auto", "ranks", "team"), default=os.environ.get("BENCH_MODE", "auto"),
+                    help="N > 1: one worker process per GPU (ranks), ONE worker driving all GPUs (team), or ranks with a team fallback (auto)")
+    ap.add_argument("--check", action="store_true", help="team mode: verify replicas and the adjoint after the timed region (extra field)")
+    ap.add_argument("--dump", type=str, default="", help="team mode: save member 0's adjoint result to this .npy file")
     return ap.parse_args()
+
+
+# ---- heartbeats: a worker appends "<unix time> <phase>" lines to its file; the supervisor reads the last one -------------
+_HB_PATH = os.environ.get("BENCH_HEARTBEAT")
+
+
+def beat(phase: str) -> None:
+    if _HB_PATH:
+        try:
+            with open(_HB_PATH, "a") as f:
+                f.write(f"{time.time():.3f} {phase}\n")
+        except OSError:
+            pass
 
 
 def cpu_baseline(edge: int, nblocks_full: int, sample_blocks: int, pairs: int) -> dict:
@@ -87,14 +119,17 @@ def cpu_baseline(edge: int, nblocks_full: int, sample_blocks: int, pairs: int) -
             raise RuntimeError("OpenMP run slower than the single-thread run; skipped")
         assert mt2.tobytes() == mt.tobytes(), "all-cores adjoint differs from the single-thread loop"
         tt = []
-        for _ in range(pairs):
+        for _ in range(max(pairs, 7)):
             t0 = time.perf_counter()
             jo.tall_diag_pair_omp_f32(a2, m, d2, mt2)
             tt.append(time.perf_counter() - t0)
         tt.sort()
         mo = tt[len(tt) // 2]
-        allcores = {"value": (1.0 / mo) * sample_blocks / nblocks_full, "unit": "pairs/s", "cores": nt, "kind": "port, OpenMP over element chunks (NUMA first-touch), rows in order inside a chunk",
-                    "sample": f"same sample, median {mo:.4f} s/pair, {bytes_pair / mo / 1e9:.1f} GB/s algorithmic"}
+        scale = sample_blocks / nblocks_full
+        allcores = {"value": (1.0 / mo) * scale, "unit": "pairs/s", "cores": nt, "kind": "port, OpenMP over element chunks (NUMA first-touch), rows in order inside a chunk",
+                    "spread": {"runs": len(tt), "min": scale / tt[-1], "median": scale / mo, "max": scale / tt[0]},
+                    "threads": f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')} (pinned)",
+                    "sample": f"same sample, median of {len(tt)} = {mo:.4f} s/pair, {bytes_pair / mo / 1e9:.1f} GB/s algorithmic"}
     except Exception as e:
         allcores = {"value": None, "sample": f"failed: {e!r}"}
     return {
@@ -110,65 +145,303 @@ def cpu_baseline(edge: int, nblocks_full: int, sample_blocks: int, pairs: int) -
     }
 
 
-def spawn_ranks(n: int) -> int:
-    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- one child process per GPU, the same
-    environment torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) --
-    BEFORE this process has made any GPU call (it never does: no torch import, no HIP), and relay the outcome: rank 0's ONE
-    JSON line goes to our stdout as is, the exit code is non-zero if any rank failed.  No process that has touched the GPU
-    is ever re-executed."""
-    import signal
-    import socket
-    import subprocess
+# ---- the supervisor: GPU-free, starts the workers, watches their heartbeats, falls back to team mode ----------------------
+FIRST_COLLECTIVE = "first-collective-done"
+IMPORT_PHASES = ("spawned", "python-started")
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), GROUP_RANK="0", BENCH_SELF_SPAWNED="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")               # dmabuf IPC: RCCL's intra-node transport needs it on this pool
-        env.setdefault("OMP_NUM_THREADS", "1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
 
-    def stop_all(*_):
-        for p in procs:
-            if p.poll() is None:
-                p.terminate()                                           # exact PIDs we started, nothing by pattern
-
-    signal.signal(signal.SIGTERM, lambda *a: (stop_all(), sys.exit(143)))
-    rc = 0
+def _last_beat(path):
+    """(unix time, phase) of the last complete heartbeat line, or None."""
     try:
-        live = set(range(n))
-        while live:
-            for r in sorted(live):
-                code = procs[r].poll()
-                if code is None:
-                    continue
-                live.discard(r)
-                if code != 0 and rc == 0:
-                    rc = code if code > 0 else 1
-                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
-                    stop_all()
-            time.sleep(0.05)
-    except KeyboardInterrupt:
-        stop_all()
-        rc = 130
-    finally:
-        deadline = time.time() + 15
-        for p in procs:
+        with open(path) as f:
+            lines = [ln for ln in f.read().split("\n") if ln.strip()]
+        t, _, phase = lines[-1].partition(" ")
+        return float(t), phase
+    except (OSError, IndexError, ValueError):
+        return None
+
+
+def _phases(path):
+    try:
+        with open(path) as f:
+            return [ln.partition(" ")[2] for ln in f.read().split("\n") if ln.strip()]
+    except OSError:
+        return []
+
+
+class Supervisor:
+    """One per started process.  `my_ranks` are the workers this process starts (all N for a bare launch, its own rank under
+    torch.distributed.run); the LEADER (the process that owns rank 0) reads every rank's heartbeat file, decides, and -- in auto
+    mode -- starts the team-mode child.  Supervisors of one job share `hbdir` (same node) and talk through marker files."""
+
+    def __init__(self, args, world, my_ranks, hbdir, leader, base_env, launched_by):
+        self.args, self.world, self.my_ranks, self.hbdir, self.leader = args, world, list(my_ranks), hbdir, leader
+        self.base_env, self.launched_by = base_env, launched_by
+        self.limit = float(os.environ.get("BENCH_WATCHDOG_S", "120"))
+        self.limit_import = float(os.environ.get("BENCH_WATCHDOG_IMPORT_S", "300"))
+        self.procs = {}
+        os.makedirs(hbdir, exist_ok=True)
+
+    # -- files
+    def hb(self, r):
+        return os.path.join(self.hbdir, f"rank{r}.hb")
+
+    def marker(self, name):
+        return os.path.join(self.hbdir, name)
+
+    def write_marker(self, name, text=""):
+        tmp = self.marker(name) + ".tmp%d" % os.getpid()
+        with open(tmp, "w") as f:
+            f.write(text)
+        os.replace(tmp, self.marker(name))
+
+    def read_marker(self, name):
+        try:
+            with open(self.marker(name)) as f:
+                return f.read()
+        except OSError:
+            return None
+
+    # -- children: exactly the PIDs started here, never anything by pattern
+    def start_worker(self, r, env_extra):
+        env = dict(self.base_env)
+        env.update(env_extra)
+        env["BENCH_WORKER"] = "1"
+        env["BENCH_HEARTBEAT"] = self.hb(r)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL's intra-node transport needs it on this pool
+        env.setdefault("OMP_NUM_THREADS", "1")
+        with open(self.hb(r), "a") as f:
+            f.write(f"{time.time():.3f} spawned\n")
+        self.procs[r] = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env)
+
+    def stop_children(self, grace=10.0):
+        for p in self.procs.values():
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + grace
+        for p in self.procs.values():
             try:
                 p.wait(timeout=max(0.1, deadline - time.time()))
             except subprocess.TimeoutExpired:
                 p.kill()
+                try:
+                    p.wait(timeout=5)
+                except subprocess.TimeoutExpired:
+                    pass
+
+    def say(self, msg):
+        print(f"bench.py[supervisor{' 0' if self.leader else ''}]: {msg}", file=sys.stderr, flush=True)
+
+    # -- the ranks phase.  Returns (rc, reason, reached_first_collective)
+    def run_ranks(self, rank_env):
+        for r in self.my_ranks:
+            self.start_worker(r, dict(rank_env(r), BENCH_LAUNCH_NOTE=json.dumps({"launched_by": self.launched_by, "mode_requested": self.args.mode})))
+        live = set(self.my_ranks)
+        failure = None
+        while live and failure is None:
+            for r in sorted(live):
+                code = self.procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0:
+                    lb = _last_beat(self.hb(r))
+                    failure = f"rank {r} exited with {code} in phase '{lb[1] if lb else '?'}'"
+                    with open(self.hb(r), "a") as f:
+                        f.write(f"{time.time():.3f} DIED rc={code}\n")
+            now = time.time()
+            if failure is None and self.leader:
+                for r in range(self.world):                            # the leader sees every rank's file (one node)
+                    lb = _last_beat(self.hb(r))
+                    if lb is None:
+                        continue
+                    if lb[1].startswith("DIED"):
+                        failure = f"rank {r} died ({lb[1]}; last phase '{([p for p in _phases(self.hb(r)) if not p.startswith('DIED')] or ['?'])[-1]}')"
+                    elif lb[1] != "worker-done" and now - lb[0] > (self.limit_import if lb[1] in IMPORT_PHASES else self.limit):
+                        failure = f"rank {r} stalled: no heartbeat for {now - lb[0]:.0f} s in phase '{lb[1]}'"
+                    if failure is not None:
+                        break
+                if failure is not None:                                # where every rank was: a stuck collective shows as everybody waiting for one
+                    rows = [(q, _last_beat(self.hb(q))) for q in range(self.world)]
+                    failure += "; all ranks: " + ", ".join(f"{q}:'{b[1]}' {now - b[0]:.0f}s ago" if b else f"{q}:no heartbeat" for q, b in rows)
+            if failure is None and not self.leader and self.read_marker("abort") is not None:
+                failure = "the leader aborted the ranks phase: " + (self.read_marker("abort") or "")
+            if failure is None:
+                time.sleep(0.05)
+        if failure is None:
+            return 0, None, True
+        reached = any(FIRST_COLLECTIVE in _phases(self.hb(r)) for r in range(self.world))
+        if self.leader:
+            self.write_marker("abort", failure)
+        self.stop_children()
+        self.write_marker(f"gone{min(self.my_ranks)}", "")
+        return 1, failure, reached
+
+    def run_team_child(self, note):
+        env = {k: v for k, v in self.base_env.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                                   "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+        env["BENCH_TEAM_CHILD"] = "1"
+        env["BENCH_LAUNCH_NOTE"] = json.dumps(note)
+        self.procs = {}
+        self.start_worker(0, env)
+        p = self.procs[0]
+        while True:
+            code = p.poll()
+            if code is not None:
+                return code, (None if code == 0 else f"the team-mode child exited with {code} in phase '{(_last_beat(self.hb(0)) or (0, '?'))[1]}'")
+            lb = _last_beat(self.hb(0))
+            now = time.time()
+            if lb and now - lb[0] > (self.limit_import if lb[1] in IMPORT_PHASES else self.limit):
+                self.stop_children()
+                return 1, f"the team-mode child stalled: no heartbeat for {now - lb[0]:.0f} s in phase '{lb[1]}'"
+            time.sleep(0.05)
+
+    def run(self, rank_env):
+        import signal
+
+        signal.signal(signal.SIGTERM, lambda *a: (self.stop_children(2.0), sys.exit(143)))
+        mode = self.args.mode
+        try:
+            if not self.leader:
+                return self.follow(rank_env, mode)
+            note = {"launched_by": self.launched_by, "mode_requested": mode}
+            if mode in ("auto", "ranks"):
+                rc, reason, reached = self.run_ranks(rank_env)
+                if rc == 0:
+                    self.write_marker("done", "0")
+                    return 0
+                self.say(reason)
+                if mode == "ranks" or reached:
+                    self.say("no fallback: " + ("--mode ranks" if mode == "ranks" else "the first collective had completed, so this is not a launch problem"))
+                    self.write_marker("done", "1")
+                    return 1
+                deadline = time.time() + 30                              # the other supervisors stop their workers first
+                firsts = {0} if len(self.my_ranks) == self.world else set(range(self.world))
+                while time.time() < deadline and not all(os.path.exists(self.marker(f"gone{r}")) for r in firsts):
+                    time.sleep(0.1)
+                self.say("falling back to ONE fresh process driving all GPUs (team mode)")
+                for r in range(self.world):
+                    try:
+                        os.replace(self.hb(r), self.hb(r) + ".ranks")    # kept for the diagnostics, out of the watchdog's way
+                    except OSError:
+                        pass
+                note["fallback"] = {"from": "ranks", "reason": reason}
+            rc, reason = self.run_team_child(note)
+            if rc != 0:
+                self.say(reason)
+            self.write_marker("done", str(rc))
+            return rc
+        except KeyboardInterrupt:
+            self.stop_children(2.0)
+            return 130
+
+    def follow(self, rank_env, mode):
+        """A non-leader under torch.distributed.run: run its own rank, and if the leader aborts the ranks phase (or the mode is
+        team from the start) wait for the leader's outcome."""
+        if mode in ("auto", "ranks"):
+            rc, reason, _ = self.run_ranks(rank_env)
+            if rc == 0:
+                return 0
+            self.say(reason)
+            if mode == "ranks":
+                return 1
+        deadline = time.time() + float(os.environ.get("BENCH_FOLLOW_S", "1500"))
+        while time.time() < deadline:
+            done = self.read_marker("done")
+            if done is not None:
+                return 0 if done.strip() == "0" else 1
+            time.sleep(0.2)
+        self.say("the leader never reported an outcome")
+        return 1
+
+
+def supervise(args) -> int:
+    global subprocess
+    import socket
+    import subprocess
+    import tempfile
+
+    n = args.gpus
+    if "RANK" in os.environ:                                           # one of N copies under torch.distributed.run
+        world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ["RANK"])
+        if world != n:
+            raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {n}")
+        hbdir = os.path.join(tempfile.gettempdir(), f"bench_hb_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+        sup = Supervisor(args, world, [rank], hbdir, rank == 0, dict(os.environ), "torch.distributed.run")
+        rc = sup.run(lambda r: {})
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        hbdir = tempfile.mkdtemp(prefix="bench_hb_")
+        sup = Supervisor(args, n, range(n), hbdir, True, dict(os.environ), "bare python (self-spawned)")
+        rc = sup.run(lambda r: dict(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                                    MASTER_PORT=str(port), GROUP_RANK="0", BENCH_SELF_SPAWNED="1"))
+    if sup.leader and rc == 0 and os.environ.get("BENCH_KEEP_HB") != "1":
+        import shutil
+
+        time.sleep(0.5 if "RANK" in os.environ else 0)                  # the followers read "done" first
+        shutil.rmtree(hbdir, ignore_errors=True)
     return rc
 
 
 def main():
     args = parse_args()
-    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        raise SystemExit(spawn_ranks(args.gpus))                      # the parent never touches the GPU
+    if args.gpus > 1 and os.environ.get("BENCH_WORKER") != "1":
+        raise SystemExit(supervise(args))                             # the started process never touches the GPU
+    beat("python-started")
+    if os.environ.get("BENCH_TEST_FAKE_WORKER") == "1" and os.environ.get("BENCH_WORKER") == "1":
+        return fake_worker(args)
+    if os.environ.get("BENCH_TEAM_CHILD") == "1" or (args.mode == "team" and "RANK" not in os.environ):
+        return worker_team(args)
+    return worker_ranks(args)
+
+
+def fake_worker(args):
+    """Test scaffolding for the SUPERVISOR only (tests/test_bench_supervisor.py, CPU): a worker that goes through the phases,
+    fails or stalls where the test says, and prints a line that cannot be mistaken for a measurement.  No GPU, no torch."""
+    team = os.environ.get("BENCH_TEAM_CHILD") == "1"
+    rank = 0 if team else int(os.environ.get("RANK", "0"))
+    who = "team" if team else str(rank)
+    if os.environ.get("BENCH_TEST_FAIL_BEFORE_COLLECTIVE") == who:
+        raise SystemExit(f"worker {who}: BENCH_TEST_FAIL_BEFORE_COLLECTIVE")
+    if os.environ.get("BENCH_TEST_STALL_BEFORE_COLLECTIVE") == who:
+        beat("process-group-init")
+        time.sleep(3600)
+    time.sleep(0.3)
+    if not team:                                                       # a collective completes only when EVERY rank has entered it
+        beat("at-first-collective")
+        world, hbdir = int(os.environ.get("WORLD_SIZE", "1")), os.path.dirname(_HB_PATH)
+        while not all("at-first-collective" in _phases(os.path.join(hbdir, f"rank{q}.hb")) for q in range(world)):
+            time.sleep(0.05)
+    beat(FIRST_COLLECTIVE)
+    if os.environ.get("BENCH_TEST_FAIL_AFTER_COLLECTIVE") == who:
+        raise SystemExit(f"worker {who}: BENCH_TEST_FAIL_AFTER_COLLECTIVE")
+    time.sleep(0.3)
+    if rank == 0:
+        out = {"metric": "FAKE (supervisor test, nothing was measured)", "value": None, "n_gpus": args.gpus}
+        out.update(launch_note("team" if team else "ranks"))
+        print(json.dumps(out), flush=True)
+    beat("worker-done")
+
+
+def launch_note(default_mode: str) -> dict:
+    """What the supervisor tells its worker about how the job was launched (goes into the JSON line)."""
+    try:
+        note = json.loads(os.environ.get("BENCH_LAUNCH_NOTE", "") or "{}")
+    except ValueError:
+        note = {}
+    out = {"launch_mode": default_mode}
+    if note.get("launched_by"):
+        out["launched_by"] = note["launched_by"]
+    if note.get("fallback"):
+        out["launch_fallback"] = note["fallback"]
+    return out
+
+
+def worker_ranks(args):
+    """One process per GPU (torch.distributed, backend nccl = RCCL): this rank's rows of the operator."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -177,6 +450,11 @@ def main():
 
     import torch
 
+    beat("torch-imported")
+    if os.environ.get("BENCH_TEST_FAIL_BEFORE_COLLECTIVE") == str(rank):   # tests: a rank that dies before the first collective
+        raise SystemExit(f"rank {rank}: BENCH_TEST_FAIL_BEFORE_COLLECTIVE")
+    if os.environ.get("BENCH_TEST_STALL_BEFORE_COLLECTIVE") == str(rank):  # tests: a rank stuck in "RCCL bootstrap"
+        time.sleep(3600)
     force_dist = os.environ.get("BENCH_FORCE_DIST", "0") == "1"      # run the RCCL path even with one rank (validation)
     ndev = torch.cuda.device_count()                                  # (does not initialise the GPU)
     if ndev < 1:
@@ -194,14 +472,22 @@ def main():
         import torch.distributed as dist  # noqa: F811
 
         torch.cuda.set_device(device)
+        beat("process-group-init")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend=backend)
+        probe = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(probe)                                         # RCCL's channels are up on every rank once this returns
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        assert int(probe.item()) == world
+        beat(FIRST_COLLECTIVE)
 
     import jets_jl_amd as J
 
     J.init(device)
+    beat("library-init")
     if args.tune:
         J.tune(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
 
@@ -220,6 +506,7 @@ def main():
     mt = J.zeros(J.domain(A))
     shard = J.rowpart.for_device(part, A) if dist is not None else None
     J.synchronize()
+    beat("data-resident")
 
     def forward():
         J.mul_(d, A, m)
@@ -243,6 +530,8 @@ def main():
     for _ in range(args.warmup):
         forward()
         adjoint()
+    J.synchronize()
+    beat("warmup-done")
 
     ev = [[J.Event() for _ in range(3)] for _ in range(args.steps)]
 
@@ -261,8 +550,11 @@ def main():
         ev[k][1].record()
         adjoint()
         ev[k][2].record()
+        if k % 5 == 4:
+            beat(f"step {k + 1}")                                      # (an append to a local file: microseconds, host side only)
     fence()
     elapsed = time.perf_counter() - t0
+    beat("timed-region-done")
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -365,11 +657,9 @@ def main():
         target, lsqr_driver = (shard if shard is not None else A), ("python driver over torch.distributed" if shard is not None else "jh_lsqr_solve")
         abi_mode = os.environ.get("BENCH_LSQR_ABI", "1")               # "force": also with ONE rank (validation / timing on a one-GPU box)
         if dist is not None and dist.get_backend() == "nccl" and (abi_mode == "force" or (world > 1 and abi_mode == "1")):
-            import ctypes as _C
-
             from jets_jl_amd._ffi import lib as _lib
 
-            ok = torch.tensor([1 if _lib.jh_comm_unique_id(_C.create_string_buffer(128)) == 0 else 0], device="cuda")   # loads librccl: no collective yet
+            ok = torch.tensor([1 if _lib.jh_comm_available() == 0 else 0], device="cuda")   # loads librccl, nothing else
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:
                 def exchange_id(raw):
@@ -382,6 +672,7 @@ def main():
                     J.tune(force_dist=1)                             # run the exchange with the one-rank communicator
                 target, lsqr_driver = J.rowpart.for_device(part, A, comm=abi), "jh_lsqr_solve_partitioned (C ABI communicator, pipelined exchange)"
         fence()
+        beat("lsqr")
         t_l = time.perf_counter()
         res = J.lsqr(target, d, atol=0.0, btol=0.0, conlim=0.0, maxiter=args.lsqr, overwrite_b=True, force_maxiter=True)
         fence()
@@ -442,6 +733,8 @@ def main():
             "kernels": kernels,
         }
         out.update(extra)
+        if world > 1:
+            out.update(launch_note("ranks: one process per GPU, torch.distributed over " + ("RCCL" if backend == "nccl" else backend)))
         if multi is not None:
             out["multi_gpu"] = multi
         if world == 1 and not args.no_cpu_baseline:
@@ -454,6 +747,219 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    beat("worker-done")
+
+
+def worker_team(args):
+    """ONE process drives all N GPUs: one context per device, jh_comm_init_all (ncclCommInitAll), every member's kernels enqueued
+    by this host thread, the ranged all-reduces of a range as one group (rowpart.Team / TeamOp).  Same workload, same timed
+    region, same JSON line as the one-process-per-GPU form.  With ONE visible device the members are N streams of that device
+    (the grouped sum is then a device kernel): the whole flow minus RCCL -- a functional check, not a scaling measurement."""
+    import numpy as np
+
+    import jets_jl_amd as J
+    from jets_jl_amd import rowpart
+    from jets_jl_amd._ffi import check, lib
+
+    beat("library-imported")
+    N, edge, nblocks = args.gpus, args.edge, args.nblocks
+    n = edge ** 3
+    ndev = J.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no MI355X visible -- there is no CPU path to fall back to")
+    if ndev >= N:
+        ctxs = []
+        for dev in range(N):
+            J.init(dev)
+            ctxs.append(J.context_current()[0])
+        one_device = False
+        placement = f"{N} device(s), one context each, " + ("RCCL over xGMI (ncclCommInitAll)" if N > 1 else "RCCL team of one (ncclCommInitAll)")
+    elif ndev == 1:
+        J.init(0)
+        ctxs = [J.context_current()[0]] + [J.context_create(0) for _ in range(N - 1)]
+        one_device = True
+        placement = f"{N} contexts (streams) of ONE device, device-side sum instead of RCCL: functional check of the flow, NOT a scaling measurement"
+    else:
+        raise SystemExit(f"bench.py: --gpus {N} in team mode needs {N} visible devices (or exactly one, for the functional check); {ndev} are visible")
+    if args.tune:
+        for c in ctxs:
+            with J.using_context(c):
+                J.tune(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
+    beat("contexts-created")
+    team = rowpart.Team(ctxs)
+    beat("team-formed")
+
+    blk = J.JetSpace("float32", edge, edge, edge)
+    parts = [rowpart.partition_rows(nblocks, N, k) for k in range(N)]
+    ops, coeffs, m_list, d_list = [], [], [], []
+    for k, _ in team.each():
+        Rk = J.JetBSpace([blk] * parts[k].count)
+        coeff = J.rand(Rk, seed=1, stream=0, index_base=parts[k].first * n)
+        coeffs.append(coeff)
+        ops.append(J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays]))
+        m_list.append(J.rand(blk, seed=2, stream=0))
+        d_list.append(J.rand(Rk, seed=3, stream=0, index_base=parts[k].first * n))
+    T = team.operator(ops)
+    m, d = rowpart.TeamVec(m_list), rowpart.TeamVec(d_list)
+    mt = team.zeros(T.domain())
+    team.synchronize()
+    beat("data-resident")
+
+    def forward():
+        T.mul_(d, m)
+
+    def adjoint():
+        T.mul_adj_(mt, d)
+
+    def group_sum(vec):                                                  # the whole domain vector in one piece, on the library streams
+        with team.group():
+            for k in range(N):
+                check(lib.jh_comm_allreduce_sum(vec[k].handle))
+
+    forward()
+    adjoint()
+    team.synchronize()
+    beat(FIRST_COLLECTIVE)
+    setup_forwards = 1
+    while any(J.op_tune_get(A, "fwd_walk") == -1 and 0 < J.op_tune_get(A, "fwd_trials") for A in ops) and setup_forwards < 24:
+        forward()
+        team.synchronize()
+        setup_forwards += 1
+    for _ in range(args.warmup):
+        forward()
+        adjoint()
+    team.synchronize()
+    beat("warmup-done")
+
+    def events():
+        out = []
+        for _ in team.each():
+            out.append(J.Event())
+        return out
+
+    def record(evs):
+        for e in evs:
+            e.record()                                                   # (an event records on ITS context's stream)
+
+    ev = [[events() for _ in range(3)] for _ in range(args.steps)]
+    team.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        record(ev[k][0])
+        forward()
+        record(ev[k][1])
+        adjoint()
+        record(ev[k][2])
+        if k % 5 == 4:
+            beat(f"step {k + 1}")
+    team.synchronize()
+    elapsed = time.perf_counter() - t0
+    beat("timed-region-done")
+
+    s = 4
+    per = []
+    reps = max(3, min(args.steps, 10))
+    tmp = team.zeros(T.domain())
+    for k, _ in team.each():                                             # outside the timed region: the local adjoint kernel alone, member by member
+        J.mul_(tmp[k], ops[k].H, d[k])
+        e0 = J.Event().record()
+        for _ in range(reps):
+            J.mul_(tmp[k], ops[k].H, d[k])
+        e1 = J.Event().record()
+        per.append({"rank": k, "rows": parts[k].count,
+                    "fwd_ms": sum(ev[i][0][k].elapsed_ms(ev[i][1][k]) for i in range(args.steps)) / args.steps,
+                    "adj_ms": sum(ev[i][1][k].elapsed_ms(ev[i][2][k]) for i in range(args.steps)) / args.steps,
+                    "adj_kernel_ms": e0.elapsed_ms(e1) / reps})
+        per[-1]["exposed_exchange_ms"] = per[-1]["adj_ms"] - per[-1]["adj_kernel_ms"]
+    team.synchronize()
+    scratch = team.zeros(T.domain())
+    group_sum(scratch)
+    team.synchronize()
+    e0 = events()
+    record(e0)
+    for _ in range(reps):
+        group_sum(scratch)
+    e1 = events()
+    record(e1)
+    ar_ms = max(e0[k].elapsed_ms(e1[k]) for k in range(N)) / reps
+    ar_bytes = n * s
+    multi = {"backend": "device-side sum kernel (one device)" if one_device else "rccl (ncclCommInitAll, single process)",
+             "rccl_nranks": None if one_device else N, "placement": placement, "per_rank": per,
+             "allreduce": {"bytes": ar_bytes, "chunks_in_adjoint": T.nchunks, "ms_standalone": ar_ms,
+                           "busbw_GBps": (2.0 * (N - 1) / N) * ar_bytes / ar_ms / 1e6 if N > 1 and ar_ms > 0 and not one_device else None,
+                           "exposed_ms_max": max(r["exposed_exchange_ms"] for r in per)}}
+
+    extra = {}
+    if args.check or args.dump:
+        # adjoint = sum over ALL rows (src/Jets.jl:1045-1053 summed over the members): every replica the same bits, and within
+        # 1e-5 (rel l2) of the fp64 sum of the members' ordered partial sums (tmp holds them: the local kernels above)
+        forward()
+        adjoint()
+        team.synchronize()
+        got = [mt[k].to_numpy().ravel(order="F") for k in range(N)]
+        truth = np.zeros(n, dtype=np.float64)
+        for k in range(N):
+            truth += tmp[k].to_numpy().ravel(order="F").astype(np.float64)
+        rel = float(np.linalg.norm(got[0].astype(np.float64) - truth) / np.linalg.norm(truth))
+        extra["check"] = {"replicas_bit_identical": all(g.tobytes() == got[0].tobytes() for g in got[1:]), "adjoint_rel_l2_vs_fp64_sum_of_partials": rel,
+                          "tolerance": 1e-5, "ok": bool(rel <= 1e-5 and all(g.tobytes() == got[0].tobytes() for g in got[1:]))}
+        if args.dump:
+            np.save(args.dump, got[0])
+
+    if args.lsqr:
+        x_true = rowpart.TeamVec([J.rand(blk, seed=4, stream=0) for _ in team.each()])
+        T.mul_(d, x_true)                                                # b = A x_true, member by member, in the range vectors' storage
+        team.synchronize()
+        beat("lsqr")
+        t_l = time.perf_counter()
+        res = J.lsqr(T, d, atol=0.0, btol=0.0, conlim=0.0, maxiter=args.lsqr, overwrite_b=True, force_maxiter=True)
+        team.synchronize()
+        t_l = time.perf_counter() - t_l
+        err = (res.x[0] - x_true[0]).materialize()
+        it_bytes = (3 * nblocks * n + 12 * n * N) * s
+        extra["lsqr"] = {"iterations": res.itn, "ms_per_iteration": 1e3 * t_l / max(res.itn, 1), "algorithmic_bytes_per_iteration": it_bytes,
+                         "GBps": it_bytes * res.itn / t_l / 1e9, "rel_err_vs_x_true": float(J.norm(err)) / float(J.norm(x_true[0])),
+                         "istop": res.istop, "driver": "jh_lsqr_solve_team (one call, all members)"}
+
+    pairs_per_s = args.steps / elapsed
+    pair_bytes_global = (4 * nblocks * n + 2 * n) * s
+    fwd_ms = max(r["fwd_ms"] for r in per)
+    adj_ms = max(r["adj_ms"] for r in per)
+    nloc = parts[0].count
+    fwd_bytes = adj_bytes = (2 * nloc * n + n) * s
+    kernels = {"forward": {"kernel": "k_tall_diag_fwd", "ms": fwd_ms, "bytes": fwd_bytes, "GBps": fwd_bytes / fwd_ms / 1e6, "launches_per_call": 1},
+               "adjoint": {"kernel": "k_tall_diag_adj+allreduce", "ms": adj_ms, "bytes": adj_bytes, "GBps": adj_bytes / adj_ms / 1e6, "launches_per_call": T.nchunks}}
+    dom = max(kernels.values(), key=lambda kv: kv["ms"])
+    pair0 = sorted(ev[i][0][0].elapsed_ms(ev[i][2][0]) for i in range(args.steps))
+    out = {
+        "metric": "fwd+adj mul! pairs/sec, 1024-block tall JopBlock (256^3 Float32 diagonal blocks)",
+        "value": pairs_per_s, "unit": "pairs/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step_device": {"median": pair0[len(pair0) // 2], "min": pair0[0], "max": pair0[-1]},
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic U[0,1) Float32 from the counter-based generator (seeds a=1, m=2, d=3), generated on device",
+        "config": {"workload": f"{nblocks}x1 tall JopBlock of diagonal JopLn, {edge}^3 Float32 blocks, fwd+adj mul! pair",
+                   "nblocks": nblocks, "block": [edge, edge, edge], "rows_per_gpu": nloc,
+                   "parallelism": f"row-partition x{N}, single-process team: {placement}; all-reduce({n * s / 2**20:.0f} MiB, pipelined in {T.nchunks} ranges) in adjoint",
+                   "fwd_walk_choice": {"candidates": [J.op_tune_get(A, "fwd_walk") for A in ops], "setup_forward_calls": setup_forwards}},
+        "achieved_GBps_pair": pair_bytes_global * pairs_per_s / 1e9,
+        "roofline_frac_pair": pair_bytes_global * pairs_per_s / 1e9 / (HBM_PEAK_GBS * (1 if one_device else N)),
+        "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
+                     "traffic": None, "bytes_per_launch": dom["bytes"] / dom["launches_per_call"], "ms_per_launch": dom["ms"] / dom["launches_per_call"],
+                     "launches_per_call": dom["launches_per_call"], "note": "slowest member; per-member times in multi_gpu.per_rank"},
+        "kernels": kernels,
+    }
+    if one_device and N > 1:
+        out["valid_scaling_point"] = False                                # N members time-slicing one GPU
+    out.update(extra)
+    out.update(launch_note("team: one process, one context per GPU (jh_comm_init_all)"))
+    out["launch_mode"] = "team: one process, one context per GPU (jh_comm_init_all)"
+    out["multi_gpu"] = multi
+    print(json.dumps(out), flush=True)
+    beat("line-printed")
+    for v in (tmp, scratch):
+        v.close()
+    team.close()
+    beat("worker-done")
 
 
 if __name__ == "__main__":

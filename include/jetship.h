@@ -311,6 +311,7 @@ int jh_lsqr_solve_team(int n, const jh_blockop *const *ops, jh_bvec *const *us, 
  * after the local jh_blockop_mul_adj; range-side dot/norm -> scalar all-reduce of the local partials.  The host
  * language distributes the 128-byte id of rank 0.  Collectives are enqueued on the library stream.
  * A communicator belongs to a CONTEXT (the current one at jh_comm_init_rank; collectives on a vector use its context's). */
+int jh_comm_available(void);                                    /* JH_OK when an RCCL can be loaded; no side effects (no bootstrap root, no communicator) */
 int jh_comm_unique_id(void *out128);
 int jh_comm_init_rank(const void *id128, int nranks, int rank);
 int jh_comm_destroy(void);                                      /* the current context's communicator (a team: all members') */

@@ -219,7 +219,9 @@ int loaded(const jh_bcast *bc, const jh_bcast::on_device **out)
     const int d = jh_ctx().device;
     JH_REQUIRE(d >= 0 && d < jh_bcast::MAX_DEV, "jh_bcast: device %d beyond the %d this build keeps modules for", d, jh_bcast::MAX_DEV);
     jh_bcast::on_device &f = bc->dev[d];
-    if (!f.fn_batched) {
+    // double-checked: fn_batched is published LAST (release) and read with acquire, so a host thread that sees it also sees the
+    // module and the other two functions another thread loaded
+    if (!__atomic_load_n(&f.fn_batched, __ATOMIC_ACQUIRE)) {
         std::lock_guard<std::mutex> lock(g_load_mutex);
         if (!f.fn_batched) {
             hipModule_t mod = nullptr;
@@ -235,7 +237,7 @@ int loaded(const jh_bcast *bc, const jh_bcast::on_device **out)
             f.module = mod;
             f.fn_vec = fv;
             f.fn_scalar = fs;
-            f.fn_batched = fb;
+            __atomic_store_n(&f.fn_batched, fb, __ATOMIC_RELEASE);
         }
     }
     *out = &f;

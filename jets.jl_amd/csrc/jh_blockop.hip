@@ -2760,10 +2760,7 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
 int jh_blockop_destroy(jh_blockop *op)
 {
     if (!op) return JH_OK;
-    if (jh_context *c = jh_ctx_by_id(op->ctx)) {
-        (void)jh_enter(op);
-        (void)hipStreamSynchronize(c->stream);
-    }
+    jh_quiesce_scope quiet(op->ctx);                                     // (not jh_enter: a finaliser must not change the thread's current context)
     drop_loop_graphs(op);
     lazy_release(op->fwd_tune);
     lazy_release(op->step_tune);

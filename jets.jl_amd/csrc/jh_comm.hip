@@ -63,7 +63,7 @@ comm_state none_cs;
 comm_state &cs()
 {
     const int id = jh_ctx().id;
-    return (id >= 0 && id < JH_MAX_CTX) ? g_cs[id] : none_cs;
+    return id >= 0 ? g_cs[jh_ctx_slot(id)] : none_cs;
 }
 
 int load_rccl()
@@ -98,13 +98,30 @@ int load_rccl()
     } while (0)
 
 // the side objects every communicator carries; the CURRENT context is the owner
+void free_side_objects(comm_state &s)
+{
+    if (s.scalar_dev) (void)hipFree(s.scalar_dev);
+    if (s.cstream) (void)hipStreamDestroy(s.cstream);
+    if (s.ev_main) (void)hipEventDestroy(s.ev_main);
+    if (s.ev_comm) (void)hipEventDestroy(s.ev_comm);
+    if (s.scalar_host) (void)hipHostFree(s.scalar_host);
+    s.scalar_dev = nullptr;
+    s.cstream = nullptr;
+    s.ev_main = s.ev_comm = nullptr;
+    s.scalar_host = nullptr;
+}
+
 int make_side_objects(comm_state &s)
 {
-    JH_CHECK_HIP(hipMalloc((void **)&s.scalar_dev, sizeof(double) * 64));
-    JH_CHECK_HIP(hipStreamCreateWithFlags(&s.cstream, hipStreamNonBlocking));
-    JH_CHECK_HIP(hipEventCreateWithFlags(&s.ev_main, hipEventDisableTiming));
-    JH_CHECK_HIP(hipEventCreateWithFlags(&s.ev_comm, hipEventDisableTiming));
-    JH_CHECK_HIP(hipHostMalloc((void **)&s.scalar_host, sizeof(double) * 8, hipHostMallocDefault));
+    hipError_t e = hipMalloc((void **)&s.scalar_dev, sizeof(double) * 64);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.cstream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_main, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_comm, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s.scalar_host, sizeof(double) * 8, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        free_side_objects(s);                            // nothing of a half-built set stays behind
+        return jh_fail(e == hipErrorOutOfMemory ? JH_ERR_NOMEM : JH_ERR_HIP, "jh_comm: side objects of the communicator: %s", hipGetErrorString(e));
+    }
     return JH_OK;
 }
 
@@ -115,11 +132,7 @@ int drop_state(comm_state &s)
     if (jh_ctx().ready) (void)hipStreamSynchronize(jh_ctx().stream);
     if (s.cstream) (void)hipStreamSynchronize(s.cstream);
     if (s.comm) r = g_api.CommDestroy(s.comm);
-    if (s.scalar_dev) (void)hipFree(s.scalar_dev);
-    if (s.cstream) (void)hipStreamDestroy(s.cstream);
-    if (s.ev_main) (void)hipEventDestroy(s.ev_main);
-    if (s.ev_comm) (void)hipEventDestroy(s.ev_comm);
-    if (s.scalar_host) (void)hipHostFree(s.scalar_host);
+    free_side_objects(s);
     s = comm_state();
     if (r != ncclSuccess) return jh_fail(JH_ERR_COMM, "ncclCommDestroy: %s", g_api.GetErrorString(r));
     return JH_OK;
@@ -135,6 +148,12 @@ __global__ __launch_bounds__(256) void k_team_sum(team_ptrs t, int n, size_t nsc
         for (int k = 1; k < n; k++) acc = acc + ((const S *)t.p[k])[i];
         for (int k = 0; k < n; k++) ((S *)t.p[k])[i] = acc;
     }
+}
+
+__global__ void k_pack_normsq_err(const double *normsq, const unsigned *err_word, double *out)
+{
+    out[0] = *normsq;
+    out[1] = *err_word ? 1.0 : 0.0;
 }
 
 // a collective of one member: inside an open group it is recorded (one-device team) or enqueued (RCCL); outside a group a team
@@ -170,7 +189,7 @@ int run_local_group(team_t &t)
         bool seen[TEAM_LOCAL_MAX] = {};
         for (int k = 0; k < t.n; k++) {
             const team_t::rec &rc = t.recs[r0 + k];
-            const int rank = g_cs[rc.ctx].rank;
+            const int rank = g_cs[jh_ctx_slot(rc.ctx)].rank;
             JH_REQUIRE(rank >= 0 && rank < t.n && !seen[rank], "jh_comm_group_end: a member issued collective %d twice", r0 / t.n);
             JH_REQUIRE(rc.nscal == t.recs[r0].nscal && rc.f32 == t.recs[r0].f32, "jh_comm_group_end: the members' calls of collective %d differ in size or type", r0 / t.n);
             seen[rank] = true;
@@ -181,7 +200,7 @@ int run_local_group(team_t &t)
         if (nscal == 0) continue;
         // member 0's stream does the sum after every member's stream has produced its buffer; the others wait for it
         for (int k = 1; k < t.n; k++) {
-            comm_state &s = g_cs[t.ctx[k]];
+            comm_state &s = g_cs[jh_ctx_slot(t.ctx[k])];
             JH_CHECK_HIP(hipEventRecord(s.ev_main, streams[k]));
             JH_CHECK_HIP(hipStreamWaitEvent(streams[0], s.ev_main, 0));
         }
@@ -190,7 +209,7 @@ int run_local_group(team_t &t)
         if (t.recs[r0].f32) hipLaunchKernelGGL((k_team_sum<float>), dim3((unsigned)grid), dim3(256), 0, streams[0], tp, t.n, nscal);
         else hipLaunchKernelGGL((k_team_sum<double>), dim3((unsigned)grid), dim3(256), 0, streams[0], tp, t.n, nscal);
         JH_CHECK_HIP(hipGetLastError());
-        comm_state &s0 = g_cs[t.ctx[0]];
+        comm_state &s0 = g_cs[jh_ctx_slot(t.ctx[0])];
         JH_CHECK_HIP(hipEventRecord(s0.ev_comm, streams[0]));
         for (int k = 1; k < t.n; k++) JH_CHECK_HIP(hipStreamWaitEvent(streams[k], s0.ev_comm, 0));
     }
@@ -200,6 +219,10 @@ int run_local_group(team_t &t)
 }  // namespace
 
 extern "C" {
+
+// Side-effect-free probe: can this process reach an RCCL at all?  (ncclGetUniqueId, by contrast, starts a bootstrap root -- a
+// listening socket and a thread -- per call.)
+int jh_comm_available(void) { return load_rccl(); }
 
 int jh_comm_unique_id(void *out128)
 {
@@ -223,7 +246,11 @@ int jh_comm_init_rank(const void *id128, int nranks, int rank)
     ncclUniqueId id;
     memcpy(&id, id128, NCCL_UNIQUE_ID_BYTES);
     JH_CHECK_NCCL(g_api.CommInitRank(&s.comm, nranks, id, rank));
-    JH_TRY(make_side_objects(s));
+    if (const int st = make_side_objects(s); st != JH_OK) {
+        (void)g_api.CommDestroy(s.comm);
+        s = comm_state();
+        return st;
+    }
     s.nranks = nranks;
     s.rank = rank;
     s.alive = true;
@@ -240,7 +267,7 @@ int jh_comm_init_all(int n, const int *contexts)
     for (int k = 0; k < n; k++) {
         jh_context *c = jh_ctx_by_id(contexts[k]);
         JH_REQUIRE(c && c->ready, "jh_comm_init_all: no context %d", contexts[k]);
-        JH_REQUIRE(!g_cs[contexts[k]].alive, "jh_comm_init_all: context %d already has a communicator", contexts[k]);
+        JH_REQUIRE(!g_cs[jh_ctx_slot(contexts[k])].alive, "jh_comm_init_all: context %d already has a communicator", contexts[k]);
         devs[k] = c->device;
         for (int j = 0; j < k; j++) {
             JH_REQUIRE(contexts[j] != contexts[k], "jh_comm_init_all: context %d listed twice", contexts[k]);
@@ -262,16 +289,33 @@ int jh_comm_init_all(int n, const int *contexts)
     team_t *t = new team_t();
     t->n = n;
     t->local = local;
-    for (int k = 0; k < n; k++) {
+    int st = JH_OK, built = 0;
+    for (int k = 0; k < n && st == JH_OK; k++) {
         t->ctx[k] = contexts[k];
-        JH_TRY(jh_context_use(contexts[k]));
-        comm_state &s = g_cs[contexts[k]];
+        st = jh_context_use(contexts[k]);
+        if (st != JH_OK) break;
+        comm_state &s = g_cs[jh_ctx_slot(contexts[k])];
+        st = make_side_objects(s);
+        if (st != JH_OK) break;
         s.comm = comms[k];
-        JH_TRY(make_side_objects(s));
         s.nranks = n;
         s.rank = k;
         s.team = t;
         s.alive = true;
+        built = k + 1;
+    }
+    if (st != JH_OK) {
+        // roll back: the members already set up (their communicator included), the communicators nobody owns yet, the team object;
+        // the message of the failing call is kept
+        char msg[512];
+        snprintf(msg, sizeof(msg), "%s", jh_last_error());
+        for (int k = 0; k < built; k++)
+            if (jh_context_use(contexts[k]) == JH_OK) (void)drop_state(g_cs[jh_ctx_slot(contexts[k])]);
+        for (int k = built; k < n; k++)
+            if (comms[k]) (void)g_api.CommDestroy(comms[k]);
+        delete t;
+        if (before >= 0) (void)jh_context_use(before);
+        return jh_fail(st, "jh_comm_init_all: %s (nothing of the team is left behind)", msg);
     }
     if (before >= 0) JH_TRY(jh_context_use(before));
     return JH_OK;
@@ -318,9 +362,9 @@ int jh_comm_destroy(void)
     const int before = jh_ctx().id;
     int st = JH_OK;
     for (int k = 0; k < t->n; k++) {
-        if (!jh_ctx_by_id(t->ctx[k]) || !g_cs[t->ctx[k]].alive) continue;
+        if (!jh_ctx_by_id(t->ctx[k]) || !g_cs[jh_ctx_slot(t->ctx[k])].alive) continue;
         (void)jh_context_use(t->ctx[k]);
-        const int r = drop_state(g_cs[t->ctx[k]]);
+        const int r = drop_state(g_cs[jh_ctx_slot(t->ctx[k])]);
         if (st == JH_OK) st = r;
     }
     delete t;
@@ -402,10 +446,21 @@ int jh_comm_allreduce_normsq(double *out)
     double *slot = jh_ctx().red_dev + JH_NORMSQ_SLOT;
     JH_CHECK_HIP(hipEventRecord(s.ev_main, jh_ctx().stream));
     JH_CHECK_HIP(hipStreamWaitEvent(s.cstream, s.ev_main, 0));
-    JH_CHECK_NCCL(g_api.AllReduce(slot, s.scalar_dev, 1, ncclFloat64, ncclSum, s.comm, s.cstream));      // the local accumulator stays local
-    JH_CHECK_HIP(hipMemcpyAsync(s.scalar_host, s.scalar_dev, sizeof(double), hipMemcpyDeviceToHost, s.cstream));
+    // ONE collective of two doubles: [0] the sum over ranks of ||u||^2 (the local accumulator stays local), [1] the number of ranks
+    // whose chained step raised its sticky "a hand-off poll expired" word -- so EVERY rank fails together, in the call that
+    // consumes w, when one rank's step went on with an invalid partial sum
+    hipLaunchKernelGGL(k_pack_normsq_err, dim3(1), dim3(1), 0, s.cstream, (const double *)slot, (const unsigned *)(jh_ctx().red_dev + JH_CHAIN_ERR_SLOT),
+                       s.scalar_dev);
+    JH_CHECK_HIP(hipGetLastError());
+    JH_CHECK_NCCL(g_api.AllReduce(s.scalar_dev, s.scalar_dev, 2, ncclFloat64, ncclSum, s.comm, s.cstream));
+    JH_CHECK_HIP(hipMemcpyAsync(s.scalar_host, s.scalar_dev, 2 * sizeof(double), hipMemcpyDeviceToHost, s.cstream));
     JH_CHECK_HIP(hipStreamSynchronize(s.cstream));
     *out = s.scalar_host[0];
+    if (s.scalar_host[1] != 0.0) {
+        unsigned one = 1;
+        memcpy(jh_ctx().red_host + 3, &one, sizeof(one));                                               // jh_chain_err_check clears the device word and reports
+        return jh_chain_err_check();
+    }
     return JH_OK;
 }
 

@@ -17,10 +17,33 @@ int jh_fail(int status, const char *fmt, ...)
 #include <mutex>
 static std::mutex g_ctx_mutex;                           // creation / destruction only; a handle is used by one host thread at a time
 static jh_context *g_ctxs[JH_MAX_CTX] = {};
+static int g_slot_gen[JH_MAX_CTX] = {};                  // bumped when a slot's context dies: ids are never reused
 static int g_first_ctx = -1;                             // a thread that never chose uses the first context created
 static thread_local int t_cur_ctx = -1;
 
-jh_context *jh_ctx_by_id(int id) { return (id >= 0 && id < JH_MAX_CTX) ? g_ctxs[id] : nullptr; }
+jh_context *jh_ctx_by_id(int id)
+{
+    if (id < 0) return nullptr;
+    jh_context *c = g_ctxs[jh_ctx_slot(id)];
+    return (c && c->id == id) ? c : nullptr;
+}
+
+jh_quiesce_scope::jh_quiesce_scope(int ctx)
+{
+    jh_context *c = jh_ctx_by_id(ctx);
+    if (!c || !c->ready) return;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != c->device) {
+        (void)hipSetDevice(c->device);
+        switched = prev >= 0;
+    }
+    (void)hipStreamSynchronize(c->stream);                   // stream-ordered work may still reference what is about to be freed
+}
+
+jh_quiesce_scope::~jh_quiesce_scope()
+{
+    if (switched) (void)hipSetDevice(prev);
+}
 
 jh_context &jh_ctx()
 {
@@ -63,11 +86,11 @@ static int ctx_create(int device, bool primary, int *id_out)
     std::lock_guard<std::mutex> lock(g_ctx_mutex);
     if (primary)
         for (int k = 0; k < JH_MAX_CTX; k++)
-            if (g_ctxs[k] && g_ctxs[k]->primary && g_ctxs[k]->device == device) { *id_out = k; return JH_OK; }   // idempotent
-    int id = -1;
+            if (g_ctxs[k] && g_ctxs[k]->primary && g_ctxs[k]->device == device) { *id_out = g_ctxs[k]->id; return JH_OK; }   // idempotent
+    int slot = -1;
     for (int k = 0; k < JH_MAX_CTX; k++)
-        if (!g_ctxs[k]) { id = k; break; }
-    if (id < 0) return jh_fail(JH_ERR_STATE, "jh_context_create: all %d context slots are in use", JH_MAX_CTX);
+        if (!g_ctxs[k]) { slot = k; break; }
+    if (slot < 0) return jh_fail(JH_ERR_STATE, "jh_context_create: all %d context slots are in use", JH_MAX_CTX);
     JH_CHECK_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     JH_CHECK_HIP(hipGetDeviceProperties(&prop, device));
@@ -94,11 +117,12 @@ static int ctx_create(int device, bool primary, int *id_out)
     e = hipHostMalloc((void **)&c->red_host, sizeof(double) * 8, hipHostMallocDefault);
     if (e != hipSuccess) return fail(e, "hipHostMalloc");
     memset(c->red_host, 0, sizeof(double) * 8);
+    const int id = slot + JH_MAX_CTX * g_slot_gen[slot];
     c->device = device;
     c->primary = primary;
     c->id = id;
     c->ready = true;
-    g_ctxs[id] = c;
+    g_ctxs[slot] = c;
     if (g_first_ctx < 0) g_first_ctx = id;
     *id_out = id;
     return JH_OK;
@@ -120,12 +144,13 @@ static int ctx_destroy(int id)
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     {
         std::lock_guard<std::mutex> lock(g_ctx_mutex);
-        g_ctxs[id] = nullptr;
+        g_ctxs[jh_ctx_slot(id)] = nullptr;
+        g_slot_gen[jh_ctx_slot(id)] = (g_slot_gen[jh_ctx_slot(id)] + 1) & 0xFFFFFF;   // a handle of the dead context no longer resolves
         delete c;
         if (g_first_ctx == id) {
             g_first_ctx = -1;
             for (int k = 0; k < JH_MAX_CTX; k++)
-                if (g_ctxs[k]) { g_first_ctx = k; break; }
+                if (g_ctxs[k]) { g_first_ctx = g_ctxs[k]->id; break; }
         }
     }
     t_cur_ctx = (before == id) ? -1 : before;
@@ -244,21 +269,21 @@ int jh_context_destroy(int ctx)
     JH_REQUIRE(c, "jh_context_destroy: no context %d", ctx);
     if (c->live_handles > 0)
         return jh_fail(JH_ERR_STATE, "jh_context_destroy: context %d still owns %lld vectors / operators / events; destroy them first", ctx,
-                       (long long)c->live_handles);
+                       (long long)c->live_handles.load());
     return ctx_destroy(ctx);
 }
 
 int jh_set_device(int device)
 {
     for (int k = 0; k < JH_MAX_CTX; k++)
-        if (g_ctxs[k] && g_ctxs[k]->primary && g_ctxs[k]->device == device) return ctx_use(k);
+        if (g_ctxs[k] && g_ctxs[k]->primary && g_ctxs[k]->device == device) return ctx_use(g_ctxs[k]->id);
     return jh_fail(JH_ERR_STATE, "jh_set_device: device %d has no context; call jh_init(%d) first", device, device);
 }
 
 int jh_shutdown(void)
 {
     for (int k = 0; k < JH_MAX_CTX; k++)
-        if (g_ctxs[k]) (void)ctx_destroy(k);
+        if (g_ctxs[k]) (void)ctx_destroy(g_ctxs[k]->id);
     jh_bcast_clear_cache();
     t_cur_ctx = -1;
     return JH_OK;
@@ -437,11 +462,7 @@ int jh_bvec_destroy(jh_bvec *v)
 {
     if (!v) return JH_OK;
     if (v->owns && v->data) {
-        // stream-ordered work may still reference the slab
-        if (jh_context *c = jh_ctx_by_id(v->ctx)) {
-            (void)jh_enter(v);
-            (void)hipStreamSynchronize(c->stream);
-        }
+        jh_quiesce_scope quiet(v->ctx);                          // (not jh_enter: a finaliser must not change the thread's current context)
         (void)hipFree(v->data);
     }
     jh_handle_died(v->ctx);

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <vector>
 #include "../../include/jetship.h"
 
@@ -32,13 +33,16 @@ int jh_fail(int status, const char *fmt, ...);
 // A host thread has a CURRENT context (jh_context_use; the first one created until then); every handle remembers the context it
 // was created in and every entry point that takes handles switches to theirs (jh_enter) -- so one process can drive several
 // GPUs through this ABI, the way SURVEY section 8e sketches it.
-constexpr int JH_MAX_CTX = 64;
+constexpr int JH_MAX_CTX = 64;          // table slots (a power of two)
+// A context id is slot + JH_MAX_CTX * generation: a slot is reused after jh_context_destroy / jh_shutdown, its generation is not, so
+// a handle that outlives its context never matches the unrelated context that later lands in the same slot.
+inline int jh_ctx_slot(int id) { return id & (JH_MAX_CTX - 1); }
 struct jh_context {
     bool ready = false;
-    int id = -1;                       // index in the context table
+    int id = -1;                       // slot + JH_MAX_CTX * generation
     bool primary = false;              // created by jh_init(device): jh_init(device) again returns it
     int device = -1;
-    int64_t live_handles = 0;          // vectors (views included), operators and events created here and not yet destroyed
+    std::atomic<int64_t> live_handles{0};   // vectors (views included), operators and events created here and not yet destroyed
     int cu_count = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // the stream everything is enqueued on
@@ -90,7 +94,18 @@ struct jh_context {
                                        // forward of a wide operator through its tall twin: `_d .+=` into d as found, src/Jets.jl:1024); never split
 };
 jh_context &jh_ctx();                  // the calling thread's current context (a never-ready dummy before jh_init)
-jh_context *jh_ctx_by_id(int id);      // nullptr when there is no such context
+jh_context *jh_ctx_by_id(int id);      // nullptr when there is no such context (also: the slot now holds a later generation)
+// Destructors (jh_bvec_destroy, jh_blockop_destroy) run at moments a garbage collector chooses: they wait for the handle's
+// context and free on its device WITHOUT making it the calling thread's current context (the device is restored when the scope
+// ends, the thread's current context is never touched).
+struct jh_quiesce_scope {
+    int prev = -1;
+    bool switched = false;
+    explicit jh_quiesce_scope(int ctx);
+    ~jh_quiesce_scope();
+    jh_quiesce_scope(const jh_quiesce_scope &) = delete;
+    jh_quiesce_scope &operator=(const jh_quiesce_scope &) = delete;
+};
 inline void jh_handle_born(int ctx) { if (jh_context *c = jh_ctx_by_id(ctx)) c->live_handles++; }
 inline void jh_handle_died(int ctx) { if (jh_context *c = jh_ctx_by_id(ctx)) c->live_handles--; }
 int jh_require_ready();                // the current context exists; re-selects its device if another library switched

@@ -538,6 +538,7 @@ function hip_lsqr!(x::HipArray{T}, A::JopLn, b::BlockArray{T,<:HipArray{T}}; x0:
 end
 
 # one process per GPU: rank 0 makes the id, the host (MPI.jl, sockets, a file) ships it, every rank joins
+comm_available() = ccall((:jh_comm_available, LIB), Cint, ()) == 0      # an RCCL can be loaded (no side effects)
 comm_unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:jh_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id)); id)
 comm_init(id::Vector{UInt8}, nranks::Integer, rank::Integer) = check(ccall((:jh_comm_init_rank, LIB), Cint, (Ptr{UInt8}, Cint, Cint), id, nranks, rank))
 comm_destroy() = check(ccall((:jh_comm_destroy, LIB), Cint, ()))

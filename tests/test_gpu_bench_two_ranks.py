@@ -69,6 +69,23 @@ def test_bench_fails_loudly_when_a_rank_dies():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["BENCH_BACKEND"] = "no-such-backend"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--nblocks", "4", "--edge", "32",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+                          "--no-cpu-baseline", "--mode", "ranks"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert out.returncode != 0
     assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "exited with" in out.stderr and "process-group-init" in out.stderr         # which rank, in which phase
+
+
+def test_bench_auto_mode_falls_back_to_a_fresh_team_child_when_the_ranks_cannot_start():
+    """The default launch mode: the ranks die before their first collective (here: a backend that does not exist, standing in for
+    a process cap or a failed RCCL bootstrap) -> the GPU-free supervisor starts ONE fresh process that drives both members as a
+    single-process team, and the line says what happened."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_BACKEND"] = "no-such-backend"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nblocks", "9", "--edge", "64",
+                          "--no-cpu-baseline", "--check"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["launch_mode"].startswith("team") and j["launch_fallback"]["from"] == "ranks" and "exited with" in j["launch_fallback"]["reason"]
+    assert j["n_gpus"] == 2 and [r["rows"] for r in j["multi_gpu"]["per_rank"]] == [5, 4] and j["check"]["ok"]

@@ -330,3 +330,53 @@ def test_two_host_threads_each_driving_its_own_context(Jets, oracle, two_context
     assert not any(t.is_alive() for t in ts), "a worker thread hangs"
     assert not errors, errors
     J.context_use(base)
+
+
+def test_a_finaliser_never_changes_the_current_context(Jets, two_contexts):
+    """jh_bvec_destroy / jh_blockop_destroy run whenever the garbage collector says so: collecting an array or an operator of
+    context B inside `using_context(A)` must leave A current (round-2 advisor finding: the destructors went through jh_enter)."""
+    import gc
+
+    J = Jets
+    base, extra = two_contexts
+    spc = J.JetSpace(np.float32, 8192)
+    with J.using_context(extra):
+        x1 = J.rand(spc, seed=5, stream=0)
+        g1 = J.rand(spc, seed=6, stream=0)
+        A1 = J.blockop([[J.JopDiagonal(g1)], [J.JopDiagonal(g1)]])
+        d1 = A1 * x1                                                   # builds the device operator
+        del d1
+    with J.using_context(base):
+        assert J.context_current()[0] == base
+        del x1
+        gc.collect()
+        assert J.context_current()[0] == base, "collecting a vector of another context switched the current context"
+        y = J.zeros(spc)                                               # a factory call right after: allocates where the caller is
+        assert J.context_of(y) == base
+        J.close(A1)
+        del A1, g1
+        gc.collect()
+        assert J.context_current()[0] == base, "collecting an operator of another context switched the current context"
+        assert J.context_of(J.rand(spc, seed=1, stream=0)) == base
+
+
+def test_a_handle_that_outlives_its_context_never_resolves_to_a_later_one(Jets):
+    """Context ids carry a generation (slot + 64 * generation): after jh_context_destroy the slot is reused, the id is not."""
+    from jets_jl_amd._ffi import lib
+
+    J = Jets
+    base = J.context_current()[0]
+    a = J.context_create(0)
+    J.context_use(base)
+    J.context_destroy(a)
+    b = J.context_create(0)                                            # lands in the slot `a` had
+    J.context_use(base)
+    try:
+        assert b != a and (b & 63) == (a & 63)
+        assert lib.jh_context_use(a) != 0 and b"does not exist" in lib.jh_last_error()
+        assert lib.jh_context_destroy(a) != 0                          # "no context": the newer one is not touched
+        J.context_use(b)
+        assert J.context_current()[0] == b
+    finally:
+        J.context_use(base)
+        J.context_destroy(b)
