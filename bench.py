@@ -296,6 +296,46 @@ class Supervisor:
                 return 1, f"the team-mode child stalled: no heartbeat for {now - lb[0]:.0f} s in phase '{lb[1]}'"
             time.sleep(0.05)
 
+    def visible_devices(self):
+        """How many devices a worker would see -- asked of a short-lived CHILD process (jh_device_count through ctypes, no torch),
+        so this process stays GPU-free.  Only the leader asks: N supervisors probing at once would be N processes on the card."""
+        forced = os.environ.get("BENCH_TEST_NDEV")
+        if forced is not None:
+            return int(forced)
+        code = ("import ctypes, sys\nlib = ctypes.CDLL(sys.argv[1])\nn = ctypes.c_int(0)\nrc = lib.jh_device_count(ctypes.byref(n))\n"
+                "print(n.value if rc == 0 else 0)\n")
+        libpath = os.environ.get("JETSHIP_LIB", os.path.join(ROOT, "jets.jl_amd", "libjetship.so"))
+        try:
+            out = subprocess.run([sys.executable, "-c", code, libpath], capture_output=True, text=True, timeout=180, env=self.base_env)
+            return int(out.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            self.say(f"could not count the visible devices ({e!r}); assuming one per rank")
+            return self.world
+
+    def plan(self, note):
+        """ranks / team / refuse, decided BEFORE any worker exists: starting N GPU-holding processes where they cannot work is not
+        always recoverable (a box that caps the processes on its cards kills the whole job, supervisor included)."""
+        mode, backend = self.args.mode, os.environ.get("BENCH_BACKEND", "nccl")
+        if mode == "team":
+            return "team"
+        ndev = self.visible_devices()
+        note["visible_devices"] = ndev
+        if ndev <= 0:
+            self.say("no MI355X visible -- there is no CPU path to fall back to")
+            return "refuse"
+        if backend != "nccl" or ndev >= self.world:                    # (gloo: validation runs with several ranks on one device)
+            return "ranks"
+        why = f"{ndev} device(s) visible for {self.world} ranks: RCCL wants one device per rank, so no rank process was started"
+        if mode == "ranks":
+            self.say(why + " (--mode ranks: not falling back; --mode team or auto runs the single-process team)")
+            return "refuse"
+        if ndev != 1:
+            self.say(why + "; a single-process team needs one device per member too (or exactly one device for the functional check)")
+            return "refuse"
+        self.say(why + "; running ONE process with one context per member instead (team mode)")
+        note["fallback"] = {"from": "ranks", "reason": why}
+        return "team"
+
     def run(self, rank_env):
         import signal
 
@@ -305,7 +345,12 @@ class Supervisor:
             if not self.leader:
                 return self.follow(rank_env, mode)
             note = {"launched_by": self.launched_by, "mode_requested": mode}
-            if mode in ("auto", "ranks"):
+            plan = self.plan(note)
+            self.write_marker("plan", plan)
+            if plan == "refuse":
+                self.write_marker("done", "1")
+                return 1
+            if plan == "ranks":
                 rc, reason, reached = self.run_ranks(rank_env)
                 if rc == 0:
                     self.write_marker("done", "0")
@@ -338,7 +383,14 @@ class Supervisor:
     def follow(self, rank_env, mode):
         """A non-leader under torch.distributed.run: run its own rank, and if the leader aborts the ranks phase (or the mode is
         team from the start) wait for the leader's outcome."""
-        if mode in ("auto", "ranks"):
+        deadline = time.time() + 240
+        while self.read_marker("plan") is None and time.time() < deadline:
+            time.sleep(0.05)
+        plan = self.read_marker("plan")
+        if plan is None:
+            self.say("the leader never published a plan")
+            return 1
+        if plan == "ranks":
             rc, reason, _ = self.run_ranks(rank_env)
             if rc == 0:
                 return 0
@@ -381,7 +433,7 @@ def supervise(args) -> int:
     if sup.leader and rc == 0 and os.environ.get("BENCH_KEEP_HB") != "1":
         import shutil
 
-        time.sleep(0.5 if "RANK" in os.environ else 0)                  # the followers read "done" first
+        time.sleep(2.0 if "RANK" in os.environ else 0)                  # the followers read "done" first
         shutil.rmtree(hbdir, ignore_errors=True)
     return rc
 

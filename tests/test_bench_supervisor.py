@@ -15,7 +15,8 @@ BENCH = os.path.join(ROOT, "bench.py")
 def run(extra_env, *argv, launcher=None, timeout=120):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
            and not k.startswith("BENCH_")}
-    env.update(BENCH_TEST_FAKE_WORKER="1", **extra_env)
+    env.update(BENCH_TEST_FAKE_WORKER="1", BENCH_TEST_NDEV="8")
+    env.update(extra_env)
     cmd = (launcher or [sys.executable]) + [BENCH] + list(argv)
     t0 = time.time()
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
@@ -91,3 +92,24 @@ def test_under_torch_distributed_run_a_dead_rank_still_ends_in_one_team_line():
     out, lines, _ = run({"BENCH_TEST_FAIL_BEFORE_COLLECTIVE": "1"}, "--gpus", "2", launcher=_torchrun(2), timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     assert len(lines) == 1 and lines[0]["launch_mode"] == "team" and "rank 1" in lines[0]["launch_fallback"]["reason"]
+
+
+def test_one_visible_device_never_starts_n_rank_processes():
+    """A one-GPU box: N RCCL ranks cannot work there, and starting them is not always recoverable (a process cap on the card kills
+    the whole job) -- the plan is made before any worker exists: auto goes straight to the team, ranks refuses with the reason."""
+    out, lines, _ = run({"BENCH_TEST_NDEV": "1", "BENCH_TEST_FAIL_BEFORE_COLLECTIVE": "0"}, "--gpus", "8")   # rank 0 would die if started
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["launch_mode"] == "team" and "1 device(s) visible for 8 ranks" in lines[0]["launch_fallback"]["reason"]
+    assert "exited with" not in out.stderr                           # no rank process ever existed
+    out, lines, _ = run({"BENCH_TEST_NDEV": "1"}, "--gpus", "8", "--mode", "ranks")
+    assert out.returncode != 0 and not lines and "no rank process was started" in out.stderr
+    out, lines, _ = run({"BENCH_TEST_NDEV": "4"}, "--gpus", "8")
+    assert out.returncode != 0 and not lines and "4 device(s) visible for 8 ranks" in out.stderr
+    out, lines, _ = run({"BENCH_TEST_NDEV": "1", "BENCH_BACKEND": "gloo"}, "--gpus", "2")   # validation over gloo: ranks share the device
+    assert out.returncode == 0 and lines[0]["launch_mode"] == "ranks"
+
+
+def test_under_torch_distributed_run_only_the_leader_plans():
+    out, lines, _ = run({"BENCH_TEST_NDEV": "1"}, "--gpus", "2", launcher=_torchrun(2), timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert len(lines) == 1 and lines[0]["launch_mode"] == "team" and lines[0]["launched_by"] == "torch.distributed.run"
