@@ -1401,6 +1401,80 @@ __global__ __launch_bounds__(256) void k_grid_diag(const jh_dev_block *__restric
     }
 }
 
+// ---- the same grids, REGISTER-TILED (round 3) -----------------------------------------------------------------------------
+// k_grid_diag gives every (line, tile) its own workgroup, so a workgroup issues TWO loads per product -- its coefficient pack
+// (from HBM) and the input pack every other line reads too (from L2) -- and runs at 59-65 % of the HBM roofline on big grids
+// although its HBM traffic is exactly the unique bytes.  Here a workgroup owns R LINES x one element tile: R accumulators stay
+// in registers, and for every summed block index q the input pack is loaded ONCE and used for the R lines, the R coefficient
+// packs next to it -- (R + 1) loads for R products, QQ such steps' loads issued back to back before any arithmetic
+// ((R + 1) * QQ = 18-20 outstanding 16-byte loads per lane, the depth the tall adjoint streams at).  Every accumulator still adds
+// its products in the reference's order, q = 0, 1, 2, ..., each product rounded before its add (forward 1020-1024: d_i as found
+// + a_i1 .* m_1 + a_i2 .* m_2 + ...; adjoint 1042-1049: 0 + conj(a_1j) .* d_1 + ...) => the bits of k_grid_diag and of the oracle.
+// Line GROUPS take the place of lines in the XCD-aware decode: the groups that read one input tile are dispatched together on one
+// XCD, so that tile still comes from HBM once.  Lines beyond the last group are clamped to the last line (branch-free loads of
+// valid memory) and not stored.
+template <typename S, int E, int NS, int R, int QQ, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void k_grid_tile(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol, int64_t n_scalars,
+                                                   const S *__restrict__ in, S *__restrict__ out, unsigned ntiles, unsigned ngroups)
+{
+    typedef typename vec_of<S, NS>::type V;
+    int64_t grp, tile;
+    general_line_tile(ngroups, ntiles, grp, tile);
+    ntiles &= 0x7fffffffu;
+    if (tile >= ntiles) return;
+    const int64_t nlines = TRANSPOSED ? ncol : nrow, nsum = TRANSPOSED ? nrow : ncol;
+    const int64_t qstep = TRANSPOSED ? 1 : nrow, lstep = TRANSPOSED ? nrow : 1;   // block (line l, q) = blocks[l * lstep + q * qstep]
+    int64_t line[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) line[r] = grp * R + r < nlines ? grp * R + r : nlines - 1;
+    for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < n_scalars; s += (int64_t)ntiles * 256 * NS) {
+        V acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            acc[r] = TRANSPOSED ? (V)(S)0 : ld<true>(reinterpret_cast<const V *>(out + line[r] * n_scalars + s));   // `_m .= 0` (1042) / d as found (1024)
+        const S *na[QQ][R];                                                   // coefficient pointers, one group of QQ steps ahead
+#pragma unroll
+        for (int q = 0; q < QQ; q++)
+#pragma unroll
+            for (int r = 0; r < R; r++) na[q][r] = (const S *)blocks[line[r] * lstep + (q < nsum ? q : 0) * qstep].coeff;
+        int64_t q0 = 0;
+        for (; q0 + QQ <= nsum; q0 += QQ) {
+            const S *a[QQ][R];
+#pragma unroll
+            for (int q = 0; q < QQ; q++) {
+                const int64_t qn = q0 + QQ + q;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    a[q][r] = na[q][r];
+                    na[q][r] = (const S *)blocks[line[r] * lstep + (qn < nsum ? qn : 0) * qstep].coeff;
+                }
+            }
+            V x[QQ], c[QQ][R];
+#pragma unroll
+            for (int q = 0; q < QQ; q++) {
+                x[q] = ld<false>(reinterpret_cast<const V *>(in + (q0 + q) * n_scalars + s));             // shared by every line group: through the caches
+#pragma unroll
+                for (int r = 0; r < R; r++) c[q][r] = ld<true>(reinterpret_cast<const V *>(a[q][r] + s));   // streamed once
+            }
+#pragma unroll
+            for (int q = 0; q < QQ; q++)
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r] = acc[r] + vmul<S, E, NS, V>(c[q][r], x[q], TRANSPOSED);
+        }
+        for (int64_t q = q0; q < nsum; q++) {
+            const V x = ld<false>(reinterpret_cast<const V *>(in + q * n_scalars + s));
+            V c[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) c[r] = ld<true>(reinterpret_cast<const V *>((const S *)blocks[line[r] * lstep + q * qstep].coeff + s));
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = acc[r] + vmul<S, E, NS, V>(c[r], x, TRANSPOSED);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (grp * R + r < nlines) st<true>(reinterpret_cast<V *>(out + line[r] * n_scalars + s), acc[r]);
+    }
+}
+
 // is `op` such a grid?  (every block an un-adjointed diagonal -- for a real element type the adjoint flag is immaterial and
 // all_diag already says so --, >= 2 x 2, aligned)
 bool grid_diag_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
@@ -1940,6 +2014,26 @@ int launch_fold_general(const void *slabs, int64_t slab_stride, int64_t parts, v
     return JH_OK;
 }
 
+// launch of the register-tiled grid kernel: R lines per workgroup (8 while the lines allow it), one pack per lane
+template <typename S, int E, int NS, bool TRANSPOSED>
+int launch_grid_tile(const jh_blockop *op, const S *in, S *out, int64_t in_bytes)
+{
+    jh_context &c = jh_ctx();
+    const int64_t nlines = TRANSPOSED ? op->ncol : op->nrow, n_scalars = op->row_len[0] * E;
+    const int R = c.grid_tile > 1 ? (int)c.grid_tile : (nlines >= 8 ? 8 : (nlines >= 4 ? 4 : 2));
+    const int64_t ngroups = (nlines + R - 1) / R;
+    unsigned ntiles, grid;
+    general_grid((n_scalars / NS + 255) / 256, ngroups, ntiles, grid, general_use_xcd(in_bytes));
+#define JH_TILE(RR, QQ) hipLaunchKernelGGL((k_grid_tile<S, E, NS, RR, QQ, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, \
+                                           op->ncol, n_scalars, in, out, ntiles, (unsigned)ngroups)
+    if (R == 8) JH_TILE(8, 2);
+    else if (R == 4) JH_TILE(4, 4);
+    else JH_TILE(2, 8);
+#undef JH_TILE
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
 template <typename S, int E>
 int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
 {
@@ -1967,6 +2061,8 @@ int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
         JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)out_scalars * sizeof(S), &slabs));
     }
     c.last_adj_parts = parts;
+    if (gdiag && parts == 1 && c.grid_tile)
+        return launch_grid_tile<S, E, NS, false>(op, (const S *)m, (S *)d, op->col_off[(size_t)op->ncol] * (int64_t)(sizeof(S) * E));
     if (gdiag && parts == 1) {
         if (gu > 1) general_grid((want + gu - 1) / gu, op->nrow, ntiles, grid, general_use_xcd(op->col_off[(size_t)op->ncol] * (int64_t)(sizeof(S) * E)));
 #define JH_GRID(UU) hipLaunchKernelGGL((k_grid_diag<S, E, NS, 4, false, UU>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, \
@@ -2015,6 +2111,8 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
         JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)out_scalars * sizeof(S), &slabs));
     }
     c.last_adj_parts = parts;
+    if (vec && parts == 1 && c.grid_diag && c.grid_tile && grid_diag_ok(op, d, m))
+        return launch_grid_tile<S, E, NS, true>(op, (const S *)d, (S *)m, op->row_off[(size_t)op->nrow] * (int64_t)(sizeof(S) * E));
     if (vec && parts == 1 && c.grid_diag && grid_diag_ok(op, d, m)) {
         const int gu = c.grid_diag >= 4 ? 4 : (c.grid_diag >= 2 ? 2 : 1);
         if (gu > 1) general_grid((want + gu - 1) / gu, op->ncol, ntiles, grid, general_use_xcd(op->row_off[(size_t)op->nrow] * (int64_t)(sizeof(S) * E)));
@@ -2268,6 +2366,10 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
         mode = lazy_next(op->step_tune, 3, 2, 1, 0.01f, &op->step_mode, &slot);
     }
     if (mode == 2 && !chain_ok) mode = 0;                                 // a trial of a mode this call cannot take runs (and times) the plain walk
+    // an expired hand-off poll (never observed; the kernel goes on with an invalid partial sum and raises the sticky error word) must
+    // fail the call that CONSUMES w: that is whichever call reads ||u||^2 back -- this one, jh_normsq_read, jh_comm_allreduce_normsq.
+    // A call that asks for no norm at all has no such reader, so it never takes the chained walk.
+    if (mode == 2 && !normsq && !defer) mode = 0;
     if (mode == 1 && !remap_ok) mode = 0;
     const int remap = mode == 1 ? 1 : 0;
     const bool timing = slot >= 0 && lazy_begin(op->step_tune, slot, c.stream);

@@ -529,10 +529,11 @@ def test_wide_operator_of_large_blocks_runs_on_its_tall_twin(Jets, oracle, dt, m
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 2), (3, 5), (7, 4), (5, 9)])
+@pytest.mark.parametrize("shape", [(2, 2), (3, 5), (7, 4), (5, 9), (19, 3), (9, 17)])
 def test_grid_of_plain_diagonals_on_the_branch_free_kernel(Jets, oracle, dt, shape):
-    """M x K grids whose blocks are all un-adjointed diagonals run on k_grid_diag (four blocks' loads in flight per lane, no kind
-    switch): the bits of the oracle's loops -- forward into d AS FOUND (1024), adjoint from zero (1042) -- and of the general kernels."""
+    """M x K grids whose blocks are all un-adjointed diagonals run register-tiled on k_grid_tile (a workgroup owns 2 / 4 / 8 lines x
+    one element tile; round 3) or on k_grid_diag (one line per workgroup, four blocks' loads in flight per lane; knob grid_tile = 0):
+    the bits of the oracle's loops -- forward into d AS FOUND (1024), adjoint from zero (1042) -- and of the general kernels."""
     J = Jets
     M, K = shape
     n = 1024 + 64 * M                                                # 16-byte multiples for every eltype; several tiles
@@ -543,8 +544,9 @@ def test_grid_of_plain_diagonals_on_the_branch_free_kernel(Jets, oracle, dt, sha
     hm = [u01(oracle, dt, 62, j, n) for j in range(K)]
     hd = [u01(oracle, dt, 63, i, n) for i in range(M)]
     got = {}
-    for gd in (1, 2, 4, 0):                                          # 1 / 2 / 4 packs per lane on the branch-free kernel, 0 = the general kernels
-        J.tune(grid_diag=gd)
+    routes = [(1, 1), (1, 2), (1, 4), (1, 8), (1, 0), (2, 0), (4, 0), (0, 0)]   # (grid_diag, grid_tile): tiled with automatic / forced R (lines
+    for gd in routes:                                                # beyond the last group are clamped), k_grid_diag with 1 / 2 / 4 packs per lane, general kernels
+        J.tune(grid_diag=gd[0], grid_tile=gd[1])
         try:
             m = J.from_numpy(np.concatenate(hm), J.domain(A))
             d = J.from_numpy(np.concatenate(hd), J.range(A))         # dirty
@@ -553,10 +555,10 @@ def test_grid_of_plain_diagonals_on_the_branch_free_kernel(Jets, oracle, dt, sha
             J.mul_(mt, A.H, d)
             got[gd] = (d.to_numpy(), mt.to_numpy())
         finally:
-            J.tune(grid_diag=1)
+            J.tune(grid_diag=1, grid_tile=1)
     want_d = oracle.block_df(ops, [b.copy() for b in hd], hm)
     want_m = oracle.block_df_adj(ops, [np.zeros(n, dt) for _ in range(K)], want_d)
-    for gd in (1, 2, 4, 0):
+    for gd in routes:
         assert_bits_equal(got[gd][0], np.concatenate(want_d), f"grid forward, grid_diag={gd}")
         assert_bits_equal(got[gd][1], np.concatenate(want_m), f"grid adjoint, grid_diag={gd}")
     J.close(A)

@@ -201,3 +201,90 @@ def test_step_mode_is_measured_per_operator_and_every_mode_has_the_same_bits(Jet
     res = J.lsqr(A, A * x_true, atol=0.0, btol=0.0, conlim=0.0, maxiter=30)
     err = (res.x - x_true).materialize()
     assert float(J.norm(err)) / float(J.norm(x_true)) < 1e-4
+
+
+def test_chained_ranged_step_beside_a_busy_second_stream(Jets):
+    """The pipelined distributed iteration runs the ranged chained step while RCCL's reduce kernels of the previous range occupy
+    part of the same device.  Stand-in: a second context (own stream) of this device streams 768 MiB triads without pause while
+    the chained step runs in four ranges; u, w keep the bits of the plain walk and no hand-off poll expires (jh_normsq_read
+    turns the sticky error word into a failed call).  tools/soak_step_chain.py --ranged --beside is the long form."""
+    from jets_jl_amd import jetblock as _blk
+    from jets_jl_amd._ffi import check, lib
+
+    J = Jets
+    home = J.context_current()[0]
+    nrow, edge = 48, 128                                               # 8 MiB rows: chained only because the knob says so
+    n = edge ** 3
+    spc = J.JetSpace(np.float32, edge, edge, edge)
+    coeff = J.rand(J.JetBSpace([spc] * nrow), seed=61, stream=0)
+    A = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
+    nat = _blk._tall_native(A)
+    u1, u2 = J.rand(J.range(A), seed=3, stream=0), J.rand(J.range(A), seed=3, stream=0)
+    v = J.rand(spc, seed=2, stream=0)
+    w1, w2 = J.zeros(spc), J.zeros(spc)
+    o1, o2 = C.c_double(0), C.c_double(0)
+    other = J.context_create(0)
+    try:
+        big = J.JetSpace(np.float32, 64 * 1024 * 1024)
+        with J.using_context(other):
+            nx, ny, nz = J.rand(big, seed=7, stream=0), J.rand(big, seed=8, stream=0), J.zeros(big)
+            marks = [J.Event() for _ in range(4)]
+        J.context_use(home)
+        handoffs = 0
+        for k in range(120):
+            alpha, beta = (1.0, -0.5) if k % 3 else (0.75, 0.25)
+            e = marks[k % 4]
+            if k >= 4:
+                e.elapsed_ms(e)                                        # never more than four batches of noise ahead
+            for _ in range(4):
+                J.lincomb_(nz, [0.5, 0.25], [nx, ny])                  # the other context's stream
+            e.record()
+            J.context_use(home)
+            J.tune(step_chain=0)
+            check(lib.jh_blockop_bidiag_step(nat.handle, u1.handle, v.handle, w1.handle, alpha, beta, C.byref(o1)))
+            J.tune(step_chain=1)
+            check(lib.jh_normsq_reset())
+            q = n // 4
+            for r in range(4):
+                check(lib.jh_blockop_bidiag_step_range(nat.handle, u2.handle, v.handle, w2.handle, alpha, beta, r * q, q, None))
+                assert J.tune_get("last_step_chain") == nrow // 8
+            check(lib.jh_normsq_read(C.byref(o2)))                     # an expired poll would fail here
+            handoffs += 4 * (nrow // 8) * (q // 4096)
+            assert abs(o1.value - o2.value) <= 1e-12 * o1.value
+            if k % 40 == 39:
+                assert_bits_equal(w2.to_numpy(), w1.to_numpy(), f"step {k}: w beside the busy stream")
+                assert_bits_equal(u2.to_numpy(), u1.to_numpy(), f"step {k}: u beside the busy stream")
+        assert handoffs >= 300_000
+        with J.using_context(other):
+            J.synchronize()
+            del nx, ny, nz, marks
+    finally:
+        J.tune(step_chain=-1)
+        import gc
+
+        gc.collect()
+        J.context_use(home)
+        J.context_destroy(other)
+
+
+def test_a_step_that_asks_for_no_norm_never_chains(Jets):
+    """An expired hand-off poll is reported by the call that reads ||u||^2 back; a whole-vector step with normsq = NULL has no
+    such reader, so it keeps the plain walk even when the knob forces chaining."""
+    from jets_jl_amd import jetblock as _blk
+    from jets_jl_amd._ffi import check, lib
+
+    J = Jets
+    spc = J.JetSpace(np.float32, 4096)
+    coeff = J.rand(J.JetBSpace([spc] * 32), seed=5, stream=0)
+    A = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
+    nat = _blk._tall_native(A)
+    u, v, w = J.rand(J.range(A), seed=3, stream=0), J.rand(spc, seed=2, stream=0), J.zeros(spc)
+    out = C.c_double(0)
+    try:
+        J.tune(step_chain=1)
+        check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, 1.0, -0.5, C.byref(out)))
+        assert J.tune_get("last_step_chain") == 4
+        check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, 1.0, -0.5, None))
+        assert J.tune_get("last_step_chain") == 0
+    finally:
+        J.tune(step_chain=-1)

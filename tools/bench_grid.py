@@ -38,8 +38,12 @@ def timed(fn, reps=6, warm=2):
 
 
 b = n * 4
-for gd, xcd in ((1, 1), (2, 1), (4, 1), (0, 1), (1, 1), (2, 1), (4, 1), (0, 1)):      # grid_diag: the branch-free kernel for grids of plain diagonals (0: the general kernels)
-    J.tune(general_xcd=xcd, grid_diag=gd)
+routes = [(1, 1), (1, 8), (1, 4), (1, 2), (1, 0), (0, 0)]               # (grid_diag, grid_tile): tiled automatic / R = 8, 4, 2; k_grid_diag; the general kernels
+if os.environ.get("GRID_ROUTES"):
+    routes = [tuple(int(v) for v in r.split(":")) for r in os.environ["GRID_ROUTES"].split(",")]
+for gd, gt in routes * 2:
+    xcd = 1
+    J.tune(general_xcd=xcd, grid_diag=gd, grid_tile=gt)
     tf = timed(lambda: J.mul_(d, A, m))
     ta = timed(lambda: J.mul_(mt, A.H, d))
-    print(f"{M} x {K} of {edge}^3 {'col-major' if colmajor else 'row-major'} slab pad {pad} grid_diag={gd} general_xcd={xcd}: forward {tf:7.3f} ms {(M * K + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {(M * K + M + K) * b / ta / 1e6:7.1f} GB/s", flush=True)
+    print(f"{M} x {K} of {edge}^3 {'col-major' if colmajor else 'row-major'} slab pad {pad} grid_diag={gd} grid_tile={gt}: forward {tf:7.3f} ms {(M * K + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {(M * K + M + K) * b / ta / 1e6:7.1f} GB/s", flush=True)

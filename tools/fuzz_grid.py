@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Fuzz of the late round-2 routes for M x K operators of plain diagonals: k_grid_diag with 1 / 2 / 4 packs per lane (knob grid_diag), wide
+"""Fuzz of the routes for M x K operators of plain diagonals: the register-tiled k_grid_tile with 2 / 4 / 8 lines per workgroup (knob
+grid_tile; round 3), k_grid_diag with 1 / 2 / 4 packs per lane (knob grid_diag), wide
 operators through their tall twin in both directions (knob wide_twin = 2) -- random shapes, block lengths (16-byte multiples), four
 eltypes, dirty outputs; forward and adjoint bit-exact vs the CPU oracle's loops.      python tools/fuzz_grid.py NCASES [SEED0]"""
 import os
@@ -36,17 +37,17 @@ for case in range(seed0, seed0 + ncases):
     want_d = oracle.block_df(ops, [b.copy() for b in hd], hm)
     want_m = oracle.block_df_adj(ops, [b.copy() for b in hmt], want_d)
     stats["grid" if (M > 1 and K > 1) else ("wide" if M == 1 else "tall")] += 1
-    for gd, wt in ((1, 1), (2, 2), (4, 2), (0, 0)):
-        J.tune(grid_diag=gd, wide_twin=wt, adj_split=0)
+    for gd, wt, gt in ((1, 1, 1), (1, 1, (2, 4, 8)[case % 3]), (1, 1, 0), (2, 2, 0), (4, 2, 0), (0, 0, 0)):   # gt: k_grid_tile with automatic / forced lines per workgroup
+        J.tune(grid_diag=gd, wide_twin=wt, grid_tile=gt, adj_split=0)
         m = J.from_numpy(np.concatenate(hm), J.domain(A))
         d = J.from_numpy(np.concatenate(hd), J.range(A))
         J.mul_(d, A, m)
         mt = J.from_numpy(np.concatenate(hmt), J.domain(A))
         J.mul_(mt, A.H, d)
-        tag = f"case {case}: {np.dtype(dt).name} {M}x{K} n={n} grid_diag={gd} wide_twin={wt}"
+        tag = f"case {case}: {np.dtype(dt).name} {M}x{K} n={n} grid_diag={gd} wide_twin={wt} grid_tile={gt}"
         assert_bits_equal(d.to_numpy(), np.concatenate(want_d), tag + " forward")
         assert_bits_equal(mt.to_numpy().ravel(order="F") if K == 1 else mt.to_numpy(), np.concatenate(want_m), tag + " adjoint")
-    J.tune(grid_diag=1, wide_twin=1, adj_split=-1)
+    J.tune(grid_diag=1, wide_twin=1, grid_tile=1, adj_split=-1)
     J.close(A)
     if (case - seed0 + 1) % 200 == 0:
         print(f"{case - seed0 + 1} cases, {time.time() - t0:.0f} s, {stats}", flush=True)
