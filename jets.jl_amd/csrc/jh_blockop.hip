@@ -1406,14 +1406,13 @@ __global__ __launch_bounds__(256) void k_grid_diag(const jh_dev_block *__restric
 // (from HBM) and the input pack every other line reads too (from L2) -- and runs at 59-65 % of the HBM roofline on big grids
 // although its HBM traffic is exactly the unique bytes.  Here a workgroup owns R LINES x one element tile: R accumulators stay
 // in registers, and for every summed block index q the input pack is loaded ONCE and used for the R lines, the R coefficient
-// packs next to it -- (R + 1) loads for R products, QQ such steps' loads issued back to back before any arithmetic
-// ((R + 1) * QQ = 18-20 outstanding 16-byte loads per lane, the depth the tall adjoint streams at).  Every accumulator still adds
+// packs next to it -- (R + 1) loads for R products, QQ such steps' loads issued back to back before any arithmetic, U packs per lane.  Every accumulator still adds
 // its products in the reference's order, q = 0, 1, 2, ..., each product rounded before its add (forward 1020-1024: d_i as found
 // + a_i1 .* m_1 + a_i2 .* m_2 + ...; adjoint 1042-1049: 0 + conj(a_1j) .* d_1 + ...) => the bits of k_grid_diag and of the oracle.
 // Line GROUPS take the place of lines in the XCD-aware decode: the groups that read one input tile are dispatched together on one
 // XCD, so that tile still comes from HBM once.  Lines beyond the last group are clamped to the last line (branch-free loads of
 // valid memory) and not stored.
-template <typename S, int E, int NS, int R, int QQ, bool TRANSPOSED>
+template <typename S, int E, int NS, int R, int QQ, int U, bool TRANSPOSED>
 __global__ __launch_bounds__(256) void k_grid_tile(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol, int64_t n_scalars,
                                                    const S *__restrict__ in, S *__restrict__ out, unsigned ntiles, unsigned ngroups)
 {
@@ -1427,11 +1426,20 @@ __global__ __launch_bounds__(256) void k_grid_tile(const jh_dev_block *__restric
     int64_t line[R];
 #pragma unroll
     for (int r = 0; r < R; r++) line[r] = grp * R + r < nlines ? grp * R + r : nlines - 1;
-    for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < n_scalars; s += (int64_t)ntiles * 256 * NS) {
-        V acc[R];
+    for (int64_t s0 = (tile * 256 * U + threadIdx.x) * NS; s0 < n_scalars; s0 += (int64_t)ntiles * 256 * U * NS) {
+        int64_t s[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {                                       // U packs per lane, 256 lanes apart (clamped: branch-free loads)
+            ok[u] = s0 + (int64_t)u * 256 * NS < n_scalars;
+            s[u] = ok[u] ? s0 + (int64_t)u * 256 * NS : s0;
+        }
+        V acc[R][U];
 #pragma unroll
         for (int r = 0; r < R; r++)
-            acc[r] = TRANSPOSED ? (V)(S)0 : ld<true>(reinterpret_cast<const V *>(out + line[r] * n_scalars + s));   // `_m .= 0` (1042) / d as found (1024)
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                acc[r][u] = TRANSPOSED ? (V)(S)0 : ld<true>(reinterpret_cast<const V *>(out + line[r] * n_scalars + s[u]));   // `_m .= 0` (1042) / d as found (1024)
         const S *na[QQ][R];                                                   // coefficient pointers, one group of QQ steps ahead
 #pragma unroll
         for (int q = 0; q < QQ; q++)
@@ -1449,29 +1457,41 @@ __global__ __launch_bounds__(256) void k_grid_tile(const jh_dev_block *__restric
                     na[q][r] = (const S *)blocks[line[r] * lstep + (qn < nsum ? qn : 0) * qstep].coeff;
                 }
             }
-            V x[QQ], c[QQ][R];
-#pragma unroll
-            for (int q = 0; q < QQ; q++) {
-                x[q] = ld<false>(reinterpret_cast<const V *>(in + (q0 + q) * n_scalars + s));             // shared by every line group: through the caches
-#pragma unroll
-                for (int r = 0; r < R; r++) c[q][r] = ld<true>(reinterpret_cast<const V *>(a[q][r] + s));   // streamed once
-            }
+            V x[QQ][U], c[QQ][R][U];
 #pragma unroll
             for (int q = 0; q < QQ; q++)
 #pragma unroll
-                for (int r = 0; r < R; r++) acc[r] = acc[r] + vmul<S, E, NS, V>(c[q][r], x[q], TRANSPOSED);
+                for (int u = 0; u < U; u++) {
+                    x[q][u] = ld<false>(reinterpret_cast<const V *>(in + (q0 + q) * n_scalars + s[u]));          // shared by every line group: through the caches
+#pragma unroll
+                    for (int r = 0; r < R; r++) c[q][r][u] = ld<true>(reinterpret_cast<const V *>(a[q][r] + s[u]));   // streamed once
+                }
+#pragma unroll
+            for (int q = 0; q < QQ; q++)
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int u = 0; u < U; u++) acc[r][u] = acc[r][u] + vmul<S, E, NS, V>(c[q][r][u], x[q][u], TRANSPOSED);
         }
         for (int64_t q = q0; q < nsum; q++) {
-            const V x = ld<false>(reinterpret_cast<const V *>(in + q * n_scalars + s));
-            V c[R];
+            const S *aq[R];
 #pragma unroll
-            for (int r = 0; r < R; r++) c[r] = ld<true>(reinterpret_cast<const V *>((const S *)blocks[line[r] * lstep + q * qstep].coeff + s));
+            for (int r = 0; r < R; r++) aq[r] = (const S *)blocks[line[r] * lstep + q * qstep].coeff;
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = acc[r] + vmul<S, E, NS, V>(c[r], x, TRANSPOSED);
+            for (int u = 0; u < U; u++) {
+                const V x = ld<false>(reinterpret_cast<const V *>(in + q * n_scalars + s[u]));
+                V c[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) c[r] = ld<true>(reinterpret_cast<const V *>(aq[r] + s[u]));
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r][u] = acc[r][u] + vmul<S, E, NS, V>(c[r], x, TRANSPOSED);
+            }
         }
 #pragma unroll
         for (int r = 0; r < R; r++)
-            if (grp * R + r < nlines) st<true>(reinterpret_cast<V *>(out + line[r] * n_scalars + s), acc[r]);
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (ok[u] && grp * R + r < nlines) st<true>(reinterpret_cast<V *>(out + line[r] * n_scalars + s[u]), acc[r][u]);
     }
 }
 
@@ -2014,21 +2034,24 @@ int launch_fold_general(const void *slabs, int64_t slab_stride, int64_t parts, v
     return JH_OK;
 }
 
-// launch of the register-tiled grid kernel: R lines per workgroup (8 while the lines allow it), one pack per lane
+// launch of the register-tiled grid kernel.  Shapes from tools/micro/grid_tile.hip (profiles/exp_r03_grid_tile.txt; same-box sweeps):
+// blocks of >= 16 MiB: 2 lines x 1 pack per lane, two steps' loads in flight -- small, short-lived workgroups win there (4 or 8 lines per
+// workgroup are 1-5 % slower, more packs per lane too); smaller blocks: 4 lines x 2 packs (32 x 32 of 128^3: 6.2 against 5.4 TB/s).
 template <typename S, int E, int NS, bool TRANSPOSED>
 int launch_grid_tile(const jh_blockop *op, const S *in, S *out, int64_t in_bytes)
 {
     jh_context &c = jh_ctx();
     const int64_t nlines = TRANSPOSED ? op->ncol : op->nrow, n_scalars = op->row_len[0] * E;
-    const int R = c.grid_tile > 1 ? (int)c.grid_tile : (nlines >= 8 ? 8 : (nlines >= 4 ? 4 : 2));
+    int R = c.grid_tile > 1 ? (int)c.grid_tile : ((n_scalars * (int64_t)sizeof(S) >= ((int64_t)16 << 20) || nlines < 4) ? 2 : 4);
+    const int U = R == 4 ? 2 : 1;
     const int64_t ngroups = (nlines + R - 1) / R;
     unsigned ntiles, grid;
-    general_grid((n_scalars / NS + 255) / 256, ngroups, ntiles, grid, general_use_xcd(in_bytes));
-#define JH_TILE(RR, QQ) hipLaunchKernelGGL((k_grid_tile<S, E, NS, RR, QQ, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, \
-                                           op->ncol, n_scalars, in, out, ntiles, (unsigned)ngroups)
-    if (R == 8) JH_TILE(8, 2);
-    else if (R == 4) JH_TILE(4, 4);
-    else JH_TILE(2, 8);
+    general_grid((n_scalars / NS + 256 * U - 1) / (256 * U), ngroups, ntiles, grid, general_use_xcd(in_bytes));
+#define JH_TILE(RR, QQ, UU) hipLaunchKernelGGL((k_grid_tile<S, E, NS, RR, QQ, UU, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, \
+                                               op->nrow, op->ncol, n_scalars, in, out, ntiles, (unsigned)ngroups)
+    if (R == 8) JH_TILE(8, 2, 1);
+    else if (R == 4) JH_TILE(4, 2, 2);
+    else JH_TILE(2, 2, 1);
 #undef JH_TILE
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;

@@ -257,7 +257,7 @@ def test_chained_ranged_step_beside_a_busy_second_stream(Jets):
         assert handoffs >= 300_000
         with J.using_context(other):
             J.synchronize()
-            del nx, ny, nz, marks
+            del nx, ny, nz, marks, e
     finally:
         J.tune(step_chain=-1)
         import gc

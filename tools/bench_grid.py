@@ -38,7 +38,7 @@ def timed(fn, reps=6, warm=2):
 
 
 b = n * 4
-routes = [(1, 1), (1, 8), (1, 4), (1, 2), (1, 0), (0, 0)]               # (grid_diag, grid_tile): tiled automatic / R = 8, 4, 2; k_grid_diag; the general kernels
+routes = [(1, 1), (1, 2), (1, 4), (1, 8), (1, 0), (0, 0)]               # (grid_diag, grid_tile): tiled automatic / 2 x 1 / 4 x 2 / 8 x 1 (lines x packs per lane); k_grid_diag; the general kernels
 if os.environ.get("GRID_ROUTES"):
     routes = [tuple(int(v) for v in r.split(":")) for r in os.environ["GRID_ROUTES"].split(",")]
 for gd, gt in routes * 2:
