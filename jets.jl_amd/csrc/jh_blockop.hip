@@ -854,7 +854,9 @@ __global__ void k_sum_partials(const double *__restrict__ partials, int64_t n, i
 // coefficient slab is read once, d is written (forward) or read (adjoint) once -- the unfused chain moves 5 range-sized
 // streams per term.  Rounding sequence == the unfused chain: product, scale (exact when 1), signed add, terms in order;
 // in the adjoint each term's rows are summed in order into its own accumulator before the terms are combined.
-constexpr int JH_SUM_MAX = 4;
+// Up to four terms run on the KM = 4 instantiations (two packs per lane); five to eight on KM = 8 (one pack per lane, to stay within
+// the registers of four waves per SIMD) -- round 3: eight terms used to be two launches, the second re-reading and re-writing d.
+constexpr int JH_SUM_MAX = 8;
 struct SumArgs {
     const jh_dev_block *blocks[JH_SUM_MAX];
     const void *a_base[JH_SUM_MAX];
@@ -863,7 +865,7 @@ struct SumArgs {
     int k;
 };
 
-template <typename S, int E, int NS, int U, int BLK>
+template <typename S, int E, int NS, int U, int BLK, int KM, int D>
 __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow, int rows_per_wg, const S *__restrict__ m,
                                                       S *__restrict__ d, int64_t n_scalars, unsigned ntiles, int accumulate)
 {
@@ -882,31 +884,43 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow
         sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
         mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
     }
-    for (int64_t i = i0; i < i1; i++) {
-        V av[JH_SUM_MAX][U];
+    // D rows' loads in flight.  The row loop is kept rolled: left to itself the compiler unrolls the eight-stream shape to 241 VGPRs
+    // (one wave per SIMD: 1.6 TB/s)
+#pragma unroll 1
+    for (int64_t i = i0; i < i1; i += D) {
+        V av[D][KM][U], dv[D][U];
 #pragma unroll
-        for (int t = 0; t < JH_SUM_MAX; t++)
-            if (t < args.k) {
-                const S *a = args.a_base[t] ? (const S *)args.a_base[t] + i * args.a_stride[t] : (const S *)args.blocks[t][i].coeff;
+        for (int j = 0; j < D; j++) {
+            const int64_t ij = i + j < i1 ? i + j : i1 - 1;                    // clamped: branch-free loads of valid memory
 #pragma unroll
-                for (int k = 0; k < U; k++) av[t][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
-            }
-#pragma unroll
-        for (int k = 0; k < U; k++) {
-            V acc = accumulate ? ld<true>(reinterpret_cast<const V *>(d + i * n_scalars + sk[k])) : (V)(S)0;   // d .= 0  (639-640)
-#pragma unroll
-            for (int t = 0; t < JH_SUM_MAX; t++)
+            for (int t = 0; t < KM; t++)
                 if (t < args.k) {
-                    V prod = vmul<S, E, NS, V>(av[t][k], mv[k], false);          // mul!(_d, A_t, m)
-                    V term = (V)(S)(args.sign[t] * args.scale[t]) * prod;        // (s_t * .) then the sign: -(s*x) == (-s)*x exactly
-                    acc = acc + term;                                            // broadcast!(sgn, d, d, _d)
+                    const S *a = args.a_base[t] ? (const S *)args.a_base[t] + ij * args.a_stride[t] : (const S *)args.blocks[t][ij].coeff;
+#pragma unroll
+                    for (int k = 0; k < U; k++) av[j][t][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
                 }
-            if (ok[k]) st<true>(reinterpret_cast<V *>(d + i * n_scalars + sk[k]), acc);
+#pragma unroll
+            for (int k = 0; k < U; k++)
+                dv[j][k] = accumulate ? ld<true>(reinterpret_cast<const V *>(d + ij * n_scalars + sk[k])) : (V)(S)0;   // d .= 0  (639-640)
         }
+#pragma unroll
+        for (int j = 0; j < D; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                V acc = dv[j][k];
+#pragma unroll
+                for (int t = 0; t < KM; t++)
+                    if (t < args.k) {
+                        V prod = vmul<S, E, NS, V>(av[j][t][k], mv[k], false);       // mul!(_d, A_t, m)
+                        V term = (V)(S)(args.sign[t] * args.scale[t]) * prod;        // (s_t * .) then the sign: -(s*x) == (-s)*x exactly
+                        acc = acc + term;                                            // broadcast!(sgn, d, d, _d)
+                    }
+                if (ok[k] && i + j < i1) st<true>(reinterpret_cast<V *>(d + (i + j) * n_scalars + sk[k]), acc);
+            }
     }
 }
 
-template <typename S, int E, int NS, int U, int DEPTH, int BLK>
+template <typename S, int E, int NS, int U, int DEPTH, int BLK, int KM>
 __global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow, S *__restrict__ out, const S *__restrict__ in,
                                                       int64_t n_scalars, int accumulate)
 {
@@ -914,24 +928,24 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow
     const int64_t s0 = ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
     bool ok[U];
     int64_t sk[U];
-    V acc[JH_SUM_MAX][U];
+    V acc[KM][U];
 #pragma unroll
     for (int k = 0; k < U; k++) {
         ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
         sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
 #pragma unroll
-        for (int t = 0; t < JH_SUM_MAX; t++) acc[t][k] = (V)(S)0;
+        for (int t = 0; t < KM; t++) acc[t][k] = (V)(S)0;
     }
     const bool direct = (nrow == 1);                                            // mul!(_m, op', _d) writes directly (1051)
     for (int64_t i = 0; i < nrow; i += DEPTH) {
-        V dv[DEPTH][U], av[DEPTH][JH_SUM_MAX][U];
+        V dv[DEPTH][U], av[DEPTH][KM][U];
 #pragma unroll
         for (int j = 0; j < DEPTH; j++)
             if (i + j < nrow) {
 #pragma unroll
                 for (int k = 0; k < U; k++) dv[j][k] = ld<true>(reinterpret_cast<const V *>(in + (i + j) * n_scalars + sk[k]));
 #pragma unroll
-                for (int t = 0; t < JH_SUM_MAX; t++)
+                for (int t = 0; t < KM; t++)
                     if (t < args.k) {
                         const S *a = args.a_base[t] ? (const S *)args.a_base[t] + (i + j) * args.a_stride[t]
                                                     : (const S *)args.blocks[t][i + j].coeff;
@@ -943,7 +957,7 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow
         for (int j = 0; j < DEPTH; j++)
             if (i + j < nrow) {
 #pragma unroll
-                for (int t = 0; t < JH_SUM_MAX; t++)
+                for (int t = 0; t < KM; t++)
                     if (t < args.k) {
 #pragma unroll
                         for (int k = 0; k < U; k++) {
@@ -957,7 +971,7 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow
     for (int k = 0; k < U; k++) {
         V r = accumulate ? ld<false>(reinterpret_cast<const V *>(out + sk[k])) : (V)(S)0;   // m .= 0  (648-649), or the sum so far
 #pragma unroll
-        for (int t = 0; t < JH_SUM_MAX; t++)
+        for (int t = 0; t < KM; t++)
             if (t < args.k) r = r + (V)(S)args.sign[t] * acc[t][k];              // broadcast!(sgn, m, m, _m)
         if (ok[k]) st<false>(reinterpret_cast<V *>(out + sk[k]), r);
     }
@@ -3136,16 +3150,24 @@ template <typename S, int E, int NS>
 static int sum_fwd_launch(const SumArgs &a, const jh_blockop *op0, void *d, const void *m, int64_t n_scalars, int accumulate)
 {
     jh_context &c = jh_ctx();
-    constexpr int BLK = 256, U = 2;
-    int G = 4;
+    constexpr int BLK = 256;
+    // rows per workgroup, from same-box sweeps (profiles/bench_jetsum_r03.txt): workgroups that move ONE batch and exit stream best --
+    // eight coefficient streams: one row of two packs per lane (5.9 TB/s; two rows of one pack 5.3-5.5, four rows 5.0-5.2);
+    // up to four streams: two rows
+    constexpr int U = 2;
+    int G = c.fwd_group > 0 ? (int)c.fwd_group : (a.k > 4 ? 1 : 2);                       // rows per workgroup (knob fwd_group: sweeps)
     if (G > op0->nrow) G = (int)op0->nrow;
     const int64_t nvec = n_scalars / NS;
     const int64_t gx = (nvec + (int64_t)BLK * U - 1) / ((int64_t)BLK * U);
     int64_t gy = (op0->nrow + G - 1) / G;
     while (gx * gy * BLK >= ((int64_t)1 << 32) && G < op0->nrow) { G *= 2; gy = (op0->nrow + G - 1) / G; }
     JH_REQUIRE(gx * gy * BLK < ((int64_t)1 << 32), "fused sum forward: grid too large");
-    hipLaunchKernelGGL((k_tall_sum_fwd<S, E, NS, U, BLK>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G,
-                       (const S *)m, (S *)d, n_scalars, (unsigned)gx, accumulate);
+    if (a.k > 4)
+        hipLaunchKernelGGL((k_tall_sum_fwd<S, E, NS, 2, BLK, 8, 1>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G,
+                           (const S *)m, (S *)d, n_scalars, (unsigned)gx, accumulate);
+    else
+        hipLaunchKernelGGL((k_tall_sum_fwd<S, E, NS, 2, BLK, 4, 1>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G,
+                           (const S *)m, (S *)d, n_scalars, (unsigned)gx, accumulate);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -3172,11 +3194,16 @@ static int sum_adj_launch(const SumArgs &a, const jh_blockop *op0, void *m, cons
 {
     jh_context &c = jh_ctx();
     c.last_adj_parts = 1;
-    constexpr int BLK = 256, U = 2, DEPTH = 2;
+    constexpr int BLK = 256, DEPTH = 2;
+    const int U = a.k > 4 ? 1 : 2;
     const int64_t nvec = n_scalars / NS;
     const int64_t gx = (nvec + (int64_t)BLK * U - 1) / ((int64_t)BLK * U);
-    hipLaunchKernelGGL((k_tall_sum_adj<S, E, NS, U, DEPTH, BLK>), dim3((unsigned)gx), dim3(BLK), 0, c.stream, a, op0->nrow, (S *)m,
-                       (const S *)d, n_scalars, accumulate);
+    if (a.k > 4)
+        hipLaunchKernelGGL((k_tall_sum_adj<S, E, NS, 1, DEPTH, BLK, 8>), dim3((unsigned)gx), dim3(BLK), 0, c.stream, a, op0->nrow, (S *)m,
+                           (const S *)d, n_scalars, accumulate);
+    else
+        hipLaunchKernelGGL((k_tall_sum_adj<S, E, NS, 2, DEPTH, BLK, 4>), dim3((unsigned)gx), dim3(BLK), 0, c.stream, a, op0->nrow, (S *)m,
+                           (const S *)d, n_scalars, accumulate);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -3199,8 +3226,9 @@ int jh_blocksum_mul(int nterms, const jh_blockop *const *ops, const double *scal
                    "jh_blocksum_mul: term %d has a different shape or element type", t);
     }
     const int64_t n = ops[0]->row_len[0];
-    for (int t0 = 0; t0 < nterms; t0 += JH_SUM_MAX) {
-        const int k = nterms - t0 < JH_SUM_MAX ? nterms - t0 : JH_SUM_MAX;
+    const int group = jh_ctx().sum_group == 4 ? 4 : JH_SUM_MAX;         // knob sum_group = 4: round 2's four terms per launch (A/B)
+    for (int t0 = 0; t0 < nterms; t0 += group) {
+        const int k = nterms - t0 < group ? nterms - t0 : group;
         SumArgs a;
         JH_TRY(sum_prepare(k, ops + t0, scale + t0, sign + t0, d, m, a, "jh_blocksum_mul"));
         const int acc = t0 > 0 ? 1 : 0;
@@ -3231,13 +3259,14 @@ int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *
                    "jh_blocksum_mul_adj: term %d has a different shape or element type", t);
     }
     const int64_t n = ops[0]->row_len[0];
+    const int group = jh_ctx().sum_group == 4 ? 4 : JH_SUM_MAX;
     void *tmp = nullptr;
     switch (ops[0]->dtype) {
 #define JH_SUM_ADJ(S, E, NS, NSCAL)                                                                         \
     JH_TRY((split_adjoint_tmp<S, NS>(ops[0], NSCAL, &tmp)));                                              \
     if (tmp) return sum_adj_split<S, E, NS>(nterms, ops, scale, sign, m->data, d->data, NSCAL, tmp);      \
-    for (int t0 = 0; t0 < nterms; t0 += JH_SUM_MAX) {                                                       \
-        const int k = nterms - t0 < JH_SUM_MAX ? nterms - t0 : JH_SUM_MAX;                                  \
+    for (int t0 = 0; t0 < nterms; t0 += group) {                                                            \
+        const int k = nterms - t0 < group ? nterms - t0 : group;                                            \
         SumArgs a;                                                                                          \
         JH_TRY(sum_prepare(k, ops + t0, scale + t0, sign + t0, d, m, a, "jh_blocksum_mul_adj"));          \
         JH_TRY((sum_adj_launch<S, E, NS>(a, ops[0], m->data, d->data, NSCAL, t0 > 0 ? 1 : 0)));             \

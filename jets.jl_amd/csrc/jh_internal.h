@@ -84,6 +84,7 @@ struct jh_context {
     int64_t last_step_chain = 0;       // row chunks of the most recent one-pass step (0: the plain walk) (read-only knob)
     int64_t grid_diag = 1;             // knob: M x K grids of plain diagonals on the branch-free kernel (0: the general kernels)
     int64_t grid_tile = 1;             // knob: ... register-tiled (k_grid_tile: R lines x one tile per workgroup): 1 automatic R, 2 / 4 / 8 that R, 0: k_grid_diag
+    int64_t sum_group = 8;             // knob: terms of a fused JetSum per launch (8; 4 = round 2's grouping, for A/B)
     int64_t wide_twin = 1;             // knob: wide elementwise operators on their tall twin: 0 never (general kernels), 1 adjoint always + forward from 16 MiB blocks, 2 both always (tests)
     const double *step_coef_dev = nullptr;   // internal, set around the calls of the graph-captured LSQR loop: the one-pass step reads (alpha, beta) from
     const int *step_done_dev = nullptr;      // here instead of its arguments and returns at once when *step_done_dev != 0 (jh_lsqr.hip: lsqr_graph_impl)

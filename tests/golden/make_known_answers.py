@@ -449,6 +449,41 @@ def main():
         tmp = block_df(ar, ops, [[ar.zero() for _ in range(n)] for _ in range(nrow)], m)
         store(case, "normal_0", ar, block_df_adj(ar, ops, [[ar.zero() for _ in range(n)]], tmp)[0])
 
+    # ---- 8. (round 3) LONG JetSums: 6, 8 and 11 terms.  The fused kernels take up to eight terms per launch and continue the
+    #         left-to-right sum from what the output holds afterwards; the reference adds term by term into d .= 0 (639-646) and
+    #         m .= 0 (648-655) whatever the count.  Signs as the nested differences of tests/known_answers.py: SUM_EXPRESSIONS
+    #         flatten them (667-676).  Drawn AFTER every earlier case, so none of the older arrays changes. ----------------------
+    for case, dtype, signs in (("sum6_f32", "f32", "+--+-+"), ("sum8_f32", "f32", "+--++-+-"), ("sum8_f64", "f64", "+--++-+-"),
+                               ("sum11_f32", "f32", "+-+---+-+-+")):
+        ar = Arith(dtype)
+        n, nrow, nt = 16, 3, len(signs)
+        terms = [[[Child("diag", n, coeff=[rng.elem(ar) for _ in range(n)])] for _ in range(nrow)] for _ in range(nt)]
+        m = [[rng.elem(ar) for _ in range(n)]]
+        m[0][0] = F(1, Fraction(0))                                                                 # -0: `0 + (-0) = +0`, then `(+0) - (-0) = +0` ...
+        din = [[rng.elem(ar) for _ in range(n)] for _ in range(nrow)]
+        CASES[f"{case}/shape"] = np.array([nrow, 1, nt], dtype=np.int64)
+        CASES[f"{case}/dtype"] = np.array([["f32", "f64", "c32", "c64"].index(dtype)], dtype=np.int64)
+        CASES[f"{case}/signs"] = np.array([1 if c == "+" else -1 for c in signs], dtype=np.int64)
+        store(case, "m_0", ar, m[0])
+        for i in range(nrow):
+            store(case, f"d_in_{i}", ar, din[i])
+        for t in range(nt):
+            for i in range(nrow):
+                store(case, f"coeff_{t}_{i}", ar, terms[t][i][0].coeff)
+        dsum = [[ar.zero() for _ in range(n)] for _ in range(nrow)]                                 # d .= 0   (640)
+        for t in range(nt):
+            tmp = block_df(ar, terms[t], [[ar.zero()] * n for _ in range(nrow)], m)                 # mul!(_d, op, m)
+            f = ar.add if signs[t] == "+" else ar.sub
+            dsum = [[f(x, y) for x, y in zip(dsum[i], tmp[i])] for i in range(nrow)]                # broadcast!(sgn, d, d, _d)
+        for i in range(nrow):
+            store(case, f"fwd_{i}", ar, dsum[i])
+        msum = [ar.zero() for _ in range(n)]                                                        # m .= 0   (649)
+        for t in range(nt):
+            tmp = block_df_adj(ar, terms[t], [[ar.zero()] * n], din)[0]
+            f = ar.add if signs[t] == "+" else ar.sub
+            msum = [f(x, y) for x, y in zip(msum, tmp)]
+        store(case, "adj_0", ar, msum)
+
     np.savez_compressed(os.path.join(HERE, "known_answers.npz"), **CASES)
     print(f"wrote {len(CASES)} arrays in {len({k.split('/')[0] for k in CASES})} cases to tests/golden/known_answers.npz")
 

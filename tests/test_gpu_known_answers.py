@@ -97,12 +97,14 @@ def test_one_pass_step_reproduces_the_known_adjoint(Jets, z, name):
 @pytest.mark.parametrize("name", ka.SUM_CASES)
 def test_jetsum_sign_rules_and_rounding_sequence(Jets, z, name):
     """A1 - (A2 - A3): the signs flatten to (+, -, +) (src/Jets.jl:667-676) and the fused sum kernels keep the unfused chain's
-    rounding sequence, incl. `0 + (-0) = +0` after `d .= 0` (640)."""
+    rounding sequence, incl. `0 + (-0) = +0` after `d .= 0` (640).  Round 3: sums of 6 and 8 terms (ONE launch of the eight-term
+    kernels) and of 11 (eight + three: the second launch continues the left-to-right sum), spelled as nested differences."""
     J = Jets
     c = ka.Case(z, name)
     nrow = c.nrow
-    ops = [J.blockop([[J.JopDiagonal(J.from_numpy(c.get(f"coeff_{t}_{i}")))] for i in range(nrow)]) for t in range(3)]
-    S = ops[0] - (ops[1] - ops[2])
+    nt = len(ka.sum_signs(c))
+    ops = [J.blockop([[J.JopDiagonal(J.from_numpy(c.get(f"coeff_{t}_{i}")))] for i in range(nrow)]) for t in range(nt)]
+    S = ka.SUM_EXPRESSIONS[name](ops)
     m = J.from_numpy(c.get("m_0"))
     d = S * m
     n = c.get("m_0").size

@@ -40,25 +40,47 @@ def test_oracle_reproduces_the_independent_known_answers(oracle, z, name):
 
 @pytest.mark.parametrize("name", ka.SUM_CASES)
 def test_oracle_chain_reproduces_the_jetsum_known_answers(oracle, z, name):
-    """JetSum_df! / df'! (src/Jets.jl:639-655) as the oracle's unfused chain: d .= 0; d = d +- mul!(tmp, A_t, m), signs (+, -, +)."""
+    """JetSum_df! / df'! (src/Jets.jl:639-655) as the oracle's unfused chain: d .= 0; d = d +- mul!(tmp, A_t, m), signs (+, -, +) for
+    the three-term cases, the stored `signs` for the long sums of round 3 (6, 8 and 11 terms)."""
     c = ka.Case(z, name)
     nrow, dt = c.nrow, c.dtype
     n = c.get("m_0").size
-    terms = [[[oracle.Block("diag", n, coeff=c.get(f"coeff_{t}_{i}").copy())] for i in range(nrow)] for t in range(3)]
-    sg = [1.0, -1.0, 1.0]
+    sg = ka.sum_signs(c)
+    nt = len(sg)
+    terms = [[[oracle.Block("diag", n, coeff=c.get(f"coeff_{t}_{i}").copy())] for i in range(nrow)] for t in range(nt)]
     m = [c.get("m_0").copy()]
     d = [np.zeros(n, dt) for _ in range(nrow)]
-    for t in range(3):
+    for t in range(nt):
         tmp = oracle.block_df(terms[t], [np.zeros(n, dt) for _ in range(nrow)], m)
         d = oracle.barr_lincomb([np.empty(n, dt) for _ in range(nrow)], [1.0, sg[t]], [d, tmp])
     for i in range(nrow):
         assert ka.bits(d[i]) == ka.bits(c.get(f"fwd_{i}")), f"{name}: sum forward block {i}"
     din = c.blocks("d_in", nrow)
     mt = [np.zeros(n, dt)]
-    for t in range(3):
+    for t in range(nt):
         tmp = oracle.block_df_adj(terms[t], [np.zeros(n, dt)], din)
         mt = oracle.barr_lincomb([np.empty(n, dt)], [1.0, sg[t]], [mt, tmp])
     assert ka.bits(mt[0]) == ka.bits(c.get("adj_0")), f"{name}: sum adjoint"
+
+
+@pytest.mark.parametrize("name", ka.SUM_CASES)
+def test_the_sum_expressions_flatten_to_the_stored_signs(z, name):
+    """The nested differences the GPU test builds (ka.SUM_EXPRESSIONS) flatten, by the reference's rule (667-676: a minus flips the
+    signs of everything inside), to the sign sequence the fixture was derived with."""
+    class Sym:
+        def __init__(self, terms):
+            self.t = terms
+
+        def __add__(self, o):
+            return Sym(self.t + o.t)
+
+        def __sub__(self, o):
+            return Sym(self.t + [(i, -sg) for i, sg in o.t])
+
+    c = ka.Case(z, name)
+    want = ka.sum_signs(c)
+    e = ka.SUM_EXPRESSIONS[name]([Sym([(i, 1.0)]) for i in range(len(want))])
+    assert [i for i, _ in e.t] == list(range(len(want))) and [sg for _, sg in e.t] == want
 
 
 def test_the_order_revealing_case_really_reveals_the_order(z):

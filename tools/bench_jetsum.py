@@ -38,6 +38,12 @@ def timed(fn, reps=7, warm=3):
 
 
 b = n * 4
-tf = timed(lambda: J.mul_(d, S, m))
-ta = timed(lambda: J.mul_(mt, S.H, d))
-print(f"JetSum of {K} tall {nrow} x {edge}^3 operators: forward {tf:7.3f} ms {((K + 1) * nrow + 1) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {((K + 1) * nrow + 1) * b / ta / 1e6:7.1f} GB/s")
+if os.environ.get("SUM_FWD_GROUP"):
+    J.tune(fwd_group=int(os.environ["SUM_FWD_GROUP"]))                # rows per workgroup of the fused forward (default 4)
+if os.environ.get("SUM_FWD_UNROLL"):
+    J.tune(fwd_unroll=int(os.environ["SUM_FWD_UNROLL"]))
+for group in (8, 4, 8, 4):                                          # terms per launch: 8 (round 3) against round 2's 4, alternating in one process
+    J.tune(sum_group=group)
+    tf = timed(lambda: J.mul_(d, S, m))
+    ta = timed(lambda: J.mul_(mt, S.H, d))
+    print(f"JetSum of {K} tall {nrow} x {edge}^3 operators, {group} terms per launch: forward {tf:7.3f} ms {((K + 1) * nrow + 1) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {((K + 1) * nrow + 1) * b / ta / 1e6:7.1f} GB/s")
