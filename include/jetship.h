@@ -305,6 +305,22 @@ int jh_lsqr_solve_partitioned(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int 
  * the host. */
 int jh_lsqr_solve_team(int n, const jh_blockop *const *ops, jh_bvec *const *us, jh_bvec *const *xs, int use_x0, double damp, double atol,
                        double btol, double conlim, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history);
+/* CGLS (conjugate gradients on the normal equations: Hestenes & Stiefel 1952; Bjorck 1996, algorithm 7.4.1) on the same problem,
+ * min ||A x - b||^2 + damp^2 ||x||^2, for a tall (>= 2 rows) all-DIAG operator -- SURVEY section 8 f-1 names it next to LSQR; like
+ * LSQR it has no counterpart inside Jets.jl (src/Jets.jl:1143-1152 points at IterativeSolvers.jl).  An iteration is TWO passes and
+ * no range-sized temporary: ||A p||^2 = <p, A'A p> through the fused normal operator (N n s bytes), then r <- r - alpha A p, ||r||^2
+ * and A'r in ONE pass of the Golub-Kahan step kernel (3 N n s) -- 4 N n s against the 7 N n s of the textbook loop over
+ * jh_blockop_mul_axpby / jh_blockop_mul_adj_axpby with its q = A p vector.  `u` holds b on entry and the residual r = b - A x on
+ * return; `x` holds x0 when use_x0 != 0.  istop: 1 ||r|| <= btol ||b||; 2 ||A'r - damp^2 x|| <= atol times its starting value;
+ * 6 breakdown (<p, (A'A + damp^2) p> not positive); 7 maxiter.  history (optional, 2*maxiter doubles): (||r||, ||A'r - damp^2 x||) per
+ * iteration.  The result record is LSQR's (r1norm = ||r||, r2norm = sqrt(||r||^2 + damp^2 ||x||^2), arnorm, xnorm; anorm = acond = 0).
+ * _partitioned / _team: the same exchange modes as the LSQR entry points (pass 1 exchanges ONE scalar; pass 2 is the pipelined step). */
+int jh_cgls_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter,
+                  int force_maxiter, jh_lsqr_result *res, double *history);
+int jh_cgls_solve_partitioned(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter,
+                              int force_maxiter, jh_lsqr_result *res, double *history);
+int jh_cgls_solve_team(int n, const jh_blockop *const *ops, jh_bvec *const *us, jh_bvec *const *xs, int use_x0, double damp, double atol,
+                       double btol, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history);
 /* ---------------------------------------------------------------- RCCL over xGMI ----------- */
 /* Row partition of a tall operator across the GPUs of a node (one process per GPU): the forward needs no exchange
  * (src/Jets.jl:1015-1031), the adjoint is a sum over rows (1045-1053) -> one in-place all-reduce of the domain vector

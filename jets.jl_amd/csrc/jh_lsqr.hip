@@ -773,3 +773,222 @@ extern "C" int jh_lsqr_solve_team(int n, const jh_blockop *const *ops, jh_bvec *
     }
     return lsqr_impl(n, ops, us, xs, use_x0, damp, atol, btol, conlim, maxiter, force_maxiter, res, history, Exch::team);
 }
+
+// ------------------------------------------------------------------ CGLS (round 3; SURVEY section 8 f-1 "LSQR/CGLS") ------------------------
+// Conjugate gradients on the normal equations (Hestenes & Stiefel 1952; Bjorck, "Numerical Methods for Least Squares Problems",
+// 1996, algorithm 7.4.1 "CGLS"), min ||A x - b||^2 + damp^2 ||x||^2, over the same shards and exchange modes as lsqr_impl.  The
+// reference ships no solver (src/Jets.jl:1143-1152 points at IterativeSolvers.jl, un-vendored), so this is the published recurrence,
+// checked against the fp64 CPU CGLS of oracle/cgls_ref.py.
+//
+//   r = b - A x0 ;  s = A'r - damp^2 x ;  p = s ;  gamma = ||s||^2
+//   repeat:  delta = ||A p||^2 + damp^2 ||p||^2 ;  alpha = gamma / delta ;  x += alpha p ;  r -= alpha A p
+//            s = A'r - damp^2 x ;  gamma' = ||s||^2 ;  p = s + (gamma'/gamma) p
+//
+// The textbook loop keeps q = A p in a range-sized vector (64 GiB at the headline size) and moves 7 N n s bytes per iteration
+// through the two fused halves (q = A p with ||q||^2: 2 N n s; r -= alpha q: 3 N n s; s = A'r: 2 N n s).  Here an iteration is TWO
+// passes and no q:   ||A p||^2 = <p, A'A p>  from the fused normal operator (jh_blockop_normal_mul: reads the coefficients only,
+// N n s bytes; the inner product is a domain-sized fp64 reduction), then ONE pass of the Golub-Kahan step kernel
+// (jh_blockop_bidiag_step with (alpha, beta) = (-alpha_k, 1)):  r <- r - alpha_k A p,  ||r||^2  and  A'r  together, 3 N n s bytes.
+// 4 N n s bytes per iteration against LSQR's 3 N n s.  Partitioned: the first pass needs a SCALAR exchange only (every shard's
+// <p, A_k'A_k p>), the second is LSQR's pipelined step (ranged all-reduces of A'r under the kernels, one host synchronisation).
+static int cgls_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *us, jh_bvec *const *xs, int use_x0, double damp, double atol,
+                     double btol, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history, const Exch ex)
+{
+    JH_REQUIRE(ops && us && xs && res && M >= 1, "jh_cgls_solve: null argument");
+    JH_REQUIRE(maxiter >= 0, "jh_cgls_solve: maxiter must be >= 0");
+    for (int k = 0; k < M; k++) JH_REQUIRE(ops[k] && us[k] && xs[k], "jh_cgls_solve: null argument (member %d)", k);
+    auto use = [&](int k) { return jh_enter(ops[k], us[k], xs[k]); };
+    JH_TRY(use(0));
+    int64_t nb = 0, n = 0;
+    int dtype = 0;
+    JH_TRY(jh_bvec_info(xs[0], &nb, &n, &dtype, nullptr));
+    for (int k = 0; k < M; k++) {
+        JH_REQUIRE(xs[k]->length == n && xs[k]->dtype == dtype, "jh_cgls_solve: member %d's x differs in length or element type", k);
+        if (!jh_blockop_tall_fast(ops[k], us[k]->data, xs[k]->data) || ops[k]->nrow < 2)   // before anything is touched
+            return jh_fail(JH_ERR_UNSUPPORTED, "jh_cgls_solve: needs a tall (>= 2 rows) all-DIAG operator with equal, 16-byte aligned blocks");
+    }
+    struct Work {                                                         // domain-sized work vectors of one member
+        jh_bvec *p = nullptr, *s = nullptr, *y = nullptr;
+        ~Work()
+        {
+            if (p) (void)jh_bvec_destroy(p);
+            if (s) (void)jh_bvec_destroy(s);
+            if (y) (void)jh_bvec_destroy(y);
+        }
+    };
+    std::vector<Work> t((size_t)M);
+    const int64_t len1[1] = {n};
+    for (int k = 0; k < M; k++) {
+        JH_TRY(use(k));
+        JH_TRY(jh_bvec_create(1, len1, dtype, &t[k].p));
+        JH_TRY(jh_bvec_create(1, len1, dtype, &t[k].s));
+        JH_TRY(jh_bvec_create(1, len1, dtype, &t[k].y));
+    }
+    *res = jh_lsqr_result{};
+    int64_t chunk = (n + 3) / 4;                                          // exchange ranges: 4, on 64 KiB boundaries (as lsqr_impl)
+    chunk = (chunk + 16383) / 16384 * 16384;
+    auto global_sum = [&](const std::vector<double> &locals, double *out) -> int {
+        double sum = 0.0;
+        for (double v : locals) sum += v;
+        *out = sum;
+        if (ex == Exch::ranks) JH_TRY(jh_comm_allreduce_scalars(out, 1, 0));
+        return JH_OK;
+    };
+    auto exchange = [&](auto &&one) -> int {
+        if (ex == Exch::none) return JH_OK;
+        if (ex == Exch::team) { JH_TRY(use(0)); JH_TRY(jh_comm_group_begin()); }
+        int st = JH_OK;
+        for (int k = 0; k < M && st == JH_OK; k++) st = one(k);
+        if (ex == Exch::team) { (void)use(0); const int st2 = jh_comm_group_end(); if (st == JH_OK) st = st2; }
+        return st;
+    };
+    auto lincomb2 = [&](jh_bvec *dst, double c0, const jh_bvec *x0, double c1, const jh_bvec *x1) {
+        const double coef[4] = {c0, 0.0, c1, 0.0};
+        const jh_bvec *v[2] = {x0, x1};
+        return jh_lincomb(dst, 2, coef, v);
+    };
+    // s = A'r (already summed over the shards, in t[k].s) - damp^2 x ;  returns ||s||^2 (member 0 speaks for all: replicas are identical)
+    auto finish_s = [&](double *gamma) -> int {
+        for (int k = 0; k < M; k++)
+            if (damp != 0.0) JH_TRY(lincomb2(t[k].s, 1.0, t[k].s, -damp * damp, xs[k]));
+        double nrm = 0.0;
+        JH_TRY(jh_norm(t[0].s, 2.0, &nrm));
+        *gamma = nrm * nrm;
+        return JH_OK;
+    };
+    std::vector<double> locals((size_t)M);
+
+    double s2 = 0.0;
+    for (int k = 0; k < M; k++) {
+        if (!use_x0) JH_TRY(jh_fill(xs[k], 0.0, 0.0));
+        double nrm = 0.0;
+        JH_TRY(jh_norm(us[k], 2.0, &nrm));                               // ||b|| (this shard's rows)
+        locals[k] = nrm * nrm;
+    }
+    JH_TRY(global_sum(locals, &s2));
+    const double bnorm = std::sqrt(s2);
+    double rr = s2;                                                       // ||r||^2
+    if (use_x0) {                                                         // r <- b - A x0
+        for (int k = 0; k < M; k++) JH_TRY(jh_blockop_mul_axpby(ops[k], us[k], xs[k], -1.0, 1.0, &locals[k]));
+        JH_TRY(global_sum(locals, &rr));
+    }
+    for (int k = 0; k < M; k++) JH_TRY(jh_blockop_mul_adj(ops[k], t[k].s, us[k]));           // s = A'r
+    JH_TRY(exchange([&](int k) { return jh_comm_allreduce_sum(t[k].s); }));
+    double gamma = 0.0;
+    JH_TRY(finish_s(&gamma));
+    for (int k = 0; k < M; k++) JH_TRY(jh_copy(t[k].p, t[k].s));
+    const double gamma0 = gamma;
+    double xnorm = 0.0;
+    if (use_x0) JH_TRY(jh_norm(xs[0], 2.0, &xnorm));
+    int itn = 0, istop = 0;
+    if (gamma > 0) {
+        while (itn < maxiter) {
+            itn++;
+            // ---- pass 1: delta = <p, A'A p> + damp^2 ||p||^2 (every shard's share of the quadratic form, then a scalar sum)
+            for (int k = 0; k < M; k++) {
+                JH_TRY(jh_blockop_normal_mul(ops[k], t[k].y, t[k].p));
+                double re = 0.0, im = 0.0;
+                JH_TRY(jh_dot(t[k].p, t[k].y, &re, &im));
+                locals[k] = re;
+            }
+            double delta = 0.0;
+            JH_TRY(global_sum(locals, &delta));
+            if (damp != 0.0) {
+                double pn = 0.0;
+                JH_TRY(jh_norm(t[0].p, 2.0, &pn));
+                delta += damp * damp * pn * pn;
+            }
+            if (!(delta > 0) || !std::isfinite(delta)) {                  // breakdown: p in the null space (or the recurrences have underflowed)
+                istop = 6;
+                itn--;
+                break;
+            }
+            const double alpha = gamma / delta;
+            for (int k = 0; k < M; k++) JH_TRY(lincomb2(xs[k], 1.0, xs[k], alpha, t[k].p));   // x += alpha p
+            // ---- pass 2: r <- r - alpha A p, ||r||^2 and A'r in ONE pass over the operator and r
+            if (ex != Exch::none) {
+                for (int k = 0; k < M; k++) { JH_TRY(use(k)); JH_TRY(jh_normsq_reset()); }
+                for (int64_t lo = 0; lo < n; lo += chunk) {
+                    const int64_t cnt = lo + chunk < n ? chunk : n - lo;
+                    for (int k = 0; k < M; k++) JH_TRY(jh_blockop_bidiag_step_range(ops[k], us[k], t[k].p, t[k].s, -alpha, 1.0, lo, cnt, nullptr));
+                    JH_TRY(exchange([&](int k) { return jh_comm_allreduce_sum_range(t[k].s, lo, cnt); }));
+                }
+                if (ex == Exch::ranks) {
+                    JH_TRY(jh_comm_allreduce_normsq(&rr));
+                } else {
+                    rr = 0.0;
+                    for (int k = M - 1; k >= 0; k--) {
+                        JH_TRY(use(k));
+                        JH_TRY(jh_comm_join());
+                        double part = 0.0;
+                        JH_TRY(jh_normsq_read(&part));
+                        rr += part;
+                    }
+                }
+            } else {
+                JH_TRY(jh_blockop_bidiag_step(ops[0], us[0], t[0].p, t[0].s, -alpha, 1.0, &rr));
+            }
+            double gamma_new = 0.0;
+            JH_TRY(finish_s(&gamma_new));
+            const double bk = gamma_new / gamma;
+            for (int k = 0; k < M; k++) JH_TRY(lincomb2(t[k].p, 1.0, t[k].s, bk, t[k].p));   // p = s + beta p
+            gamma = gamma_new;
+            const double rnorm = std::sqrt(rr), arnorm = std::sqrt(gamma);
+            if (history) { history[2 * (itn - 1)] = rnorm; history[2 * (itn - 1) + 1] = arnorm; }
+            if (itn >= maxiter) istop = 7;
+            if (arnorm <= atol * std::sqrt(gamma0)) istop = 2;            // ||A'r - damp^2 x|| small against its starting value
+            if (rnorm <= btol * bnorm) istop = 1;                         // ||r|| small against ||b||
+            if (istop && !(force_maxiter && itn < maxiter && gamma > 0)) break;
+        }
+    }
+    JH_TRY(jh_norm(xs[0], 2.0, &xnorm));
+    res->istop = istop;
+    res->itn = itn;
+    res->r1norm = std::sqrt(rr);
+    res->r2norm = std::sqrt(rr + damp * damp * xnorm * xnorm);
+    res->anorm = 0.0;                                                     // (LSQR's running estimates have no counterpart here)
+    res->acond = 0.0;
+    res->arnorm = std::sqrt(gamma);
+    res->xnorm = xnorm;
+    for (int k = 0; k < M; k++) {                                         // the temporaries die here
+        jh_context *ck = jh_ctx_by_id(ops[k]->ctx);
+        if (ck) { JH_TRY(use(k)); JH_CHECK_HIP(hipStreamSynchronize(ck->stream)); }
+    }
+    return JH_OK;
+}
+
+extern "C" int jh_cgls_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter,
+                             int force_maxiter, jh_lsqr_result *res, double *history)
+{
+    return cgls_impl(1, &op, &u, &x, use_x0, damp, atol, btol, maxiter, force_maxiter, res, history, Exch::none);
+}
+
+extern "C" int jh_cgls_solve_partitioned(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol,
+                                         int maxiter, int force_maxiter, jh_lsqr_result *res, double *history)
+{
+    JH_TRY(jh_enter(op, u, x));
+    int nranks = 1, rank = 0, has_comm = 0;
+    (void)jh_comm_info(&nranks, &rank);
+    (void)jh_comm_exists(&has_comm);
+    if (has_comm == 2 && (nranks > 1 || jh_ctx().force_dist))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_cgls_solve_partitioned: this context is a member of a single-process team (jh_comm_init_all): "
+                       "jh_cgls_solve_team takes all the members' shards in one call");
+    return cgls_impl(1, &op, &u, &x, use_x0, damp, atol, btol, maxiter, force_maxiter, res, history,
+                     (nranks > 1 || (has_comm && jh_ctx().force_dist)) ? Exch::ranks : Exch::none);
+}
+
+extern "C" int jh_cgls_solve_team(int n, const jh_blockop *const *ops, jh_bvec *const *us, jh_bvec *const *xs, int use_x0, double damp, double atol,
+                                  double btol, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history)
+{
+    JH_REQUIRE(n >= 1 && n <= JH_MAX_CTX && ops && us && xs, "jh_cgls_solve_team: need 1..%d members", JH_MAX_CTX);
+    for (int k = 0; k < n; k++) {
+        JH_REQUIRE(ops[k] && us[k] && xs[k], "jh_cgls_solve_team: null handle of member %d", k);
+        JH_TRY(jh_enter(ops[k], us[k], xs[k]));
+        int nranks = 1, rank = 0, has_comm = 0;
+        (void)jh_comm_info(&nranks, &rank);
+        (void)jh_comm_exists(&has_comm);
+        JH_REQUIRE(has_comm == 2 && nranks == n && rank == k, "jh_cgls_solve_team: the handles of member %d must live in member %d's context of a team of %d "
+                   "(jh_comm_init_all); found %s, rank %d of %d", k, k, n, has_comm == 2 ? "a team" : "no team", rank, nranks);
+    }
+    return cgls_impl(n, ops, us, xs, use_x0, damp, atol, btol, maxiter, force_maxiter, res, history, Exch::team);
+}

@@ -119,7 +119,7 @@ def test_world_size_2_forward_is_local_and_adjoint_all_reduces(tmp_path, nrow, n
 
 
 # ---------------------------------------------------------------------------------- distributed LSQR
-def _lsqr_worker(rank, world, port, nrow, n, iters, out_dir, one_pass=False):
+def _lsqr_worker(rank, world, port, nrow, n, iters, out_dir, one_pass=False, solver="lsqr"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import math
@@ -158,6 +158,10 @@ def _lsqr_worker(rank, world, port, nrow, n, iters, out_dir, one_pass=False):
             return dst
 
         def lincomb(self, dst, coefs, xs):
+            if isinstance(dst, list):                                  # a range vector: this rank's blocks (CGLS updates r that way)
+                for k in range(len(dst)):
+                    dst[k][...] = sum(c * x[k] for c, x in zip(coefs, xs))
+                return dst
             dst[...] = sum(c * x for c, x in zip(coefs, xs))
             return dst
 
@@ -191,7 +195,12 @@ def _lsqr_worker(rank, world, port, nrow, n, iters, out_dir, one_pass=False):
             comm.all_reduce_sum_(w)
             return math.sqrt(comm.all_reduce_scalars([sum(float(np.dot(t, t)) for t in u)], "sum")[0]), w
 
-    res = lsqr_core(OnePassEngine() if one_pass else NumpyShardEngine(), b_loc, None, 0.0, 0.0, 0.0, 0.0, iters)
+    if solver == "cgls":
+        from jets_jl_amd.cgls import cgls_core
+
+        res = cgls_core(NumpyShardEngine(), b_loc, None, 0.1, 0.0, 0.0, iters)                # damped: s = A'r - damp^2 x on every rank alike
+    else:
+        res = lsqr_core(OnePassEngine() if one_pass else NumpyShardEngine(), b_loc, None, 0.0, 0.0, 0.0, 0.0, iters)
     np.savez(os.path.join(out_dir, f"lsqr{rank}.npz"), x=res.x, r=np.array([h[1] for h in res.history]), itn=res.itn)
     dist.barrier()
     dist.destroy_process_group()
@@ -216,3 +225,23 @@ def test_world_size_2_lsqr_matches_single_process_fp64_lsqr(tmp_path, one_pass):
     assert np.linalg.norm(res[0]["x"] - xr) <= 1e-10 * np.linalg.norm(xr)
     ref_r = np.array([h[1] for h in info["history"]])
     assert np.allclose(res[0]["r"], ref_r, rtol=1e-9)
+
+
+def test_world_size_2_cgls_matches_single_process_fp64_cgls(tmp_path):
+    """The textbook CGLS loop (jets.jl_amd/cgls.py: cgls_core) on the row partition: forward local, ONE vector all-reduce per
+    iteration for A'r, scalar all-reduces for the range-side norms; replicas identical, iterates those of the fp64 CPU CGLS."""
+    import torch.multiprocessing as mp
+
+    from oracle import jets_oracle as jo
+    from oracle.cgls_ref import cgls_fp64
+
+    world, port, nrow, n, iters = 2, _free_port(), 5, 64, 20
+    mp.spawn(_lsqr_worker, args=(world, port, nrow, n, iters, str(tmp_path), False, "cgls"), nprocs=world, join=True)
+    res = [np.load(tmp_path / f"lsqr{r}.npz") for r in range(world)]
+    a = np.stack([jo.rng_u01(np.float64, 1, 0, i * n, n) + 0.05 for i in range(nrow)])
+    b = np.concatenate([jo.rng_u01(np.float64, 5, 0, i * n, n) - 0.5 for i in range(nrow)])
+    xr, info = cgls_fp64(lambda v: (a * v).ravel(), lambda y: (a * y.reshape(nrow, n)).sum(0), b, n, damp=0.1, atol=0.0, btol=0.0, maxiter=iters)
+    assert res[0]["x"].tobytes() == res[1]["x"].tobytes()
+    assert int(res[0]["itn"]) == info["itn"] == iters
+    assert np.linalg.norm(res[0]["x"] - xr) <= 1e-10 * np.linalg.norm(xr)
+    assert np.allclose(res[0]["r"], np.array([h[1] for h in info["history"]]), rtol=1e-9)
