@@ -571,12 +571,12 @@ def worker_ranks(args):
             J.mul_(mt, A.H, d)
 
     # operator setup, outside the warm-up count: the first forwards of a large operator each try one grid walk (lazy autotune,
-    # jh_blockop.hip: fwd_autotune_next -- no extra launches, no host sync; 16 calls until the choice is made) and the first
+    # jh_blockop.hip: lazy_next -- no extra launches, no host sync; 16 calls, 20 with a play-off between the two best, until the choice is made) and the first
     # collective builds RCCL's channels -- with --warmup 0 neither may land in the timed region
     forward()
     adjoint()
     setup_forwards = 1
-    while J.op_tune_get(A, "fwd_walk") == -1 and 0 < J.op_tune_get(A, "fwd_trials") and setup_forwards < 24:
+    while J.op_tune_get(A, "fwd_walk") == -1 and 0 < J.op_tune_get(A, "fwd_trials") and setup_forwards < 32:
         forward()
         J.synchronize()
         setup_forwards += 1
@@ -890,7 +890,7 @@ def worker_team(args):
     team.synchronize()
     beat(FIRST_COLLECTIVE)
     setup_forwards = 1
-    while any(J.op_tune_get(A, "fwd_walk") == -1 and 0 < J.op_tune_get(A, "fwd_trials") for A in ops) and setup_forwards < 24:
+    while any(J.op_tune_get(A, "fwd_walk") == -1 and 0 < J.op_tune_get(A, "fwd_trials") for A in ops) and setup_forwards < 32:
         forward()
         team.synchronize()
         setup_forwards += 1

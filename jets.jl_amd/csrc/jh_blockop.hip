@@ -1755,6 +1755,9 @@ void lazy_release(jh_blockop::LazyTune &t)
     for (auto &pair : t.ev)
         for (auto &e : pair)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (auto &e : t.rc_ev)                                                 // (the re-check's pair exists only after a choice was made)
+        if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    t.rc_in_flight = false;
 }
 
 void lazy_reset(jh_blockop::LazyTune &t)
@@ -1762,17 +1765,27 @@ void lazy_reset(jh_blockop::LazyTune &t)
     lazy_release(t);
     for (auto &st : t.state) st = 0;
     for (auto &m : t.ms) m = 0.f;
+    for (auto &m : t.best_ms) m = 0.f;
     t.launched = 0;
+    t.playoff[0] = t.playoff[1] = -1;
+    t.calls = 0;
+    t.rc_in_flight = false;
+    t.rc_slow = 0;
 }
 
 // Which candidate should THIS call run?  Trial slots are laid out pass-major after `warm` untimed-in-effect slots (their
 // timings are discarded): slot = warm + pass * ncand + candidate.  Returns the candidate and, when the call is a trial, its
 // slot (else -1).  Once every slot has a timing, *choice = the candidate with the best time over its passes -- candidate 0
 // unless another one beats it by `margin` -- and the events are released.
-int lazy_next(jh_blockop::LazyTune &t, int ncand, int npass, int warm, float margin, int *choice, int *slot)
+// playoff (round 3): two timings per candidate decide between shapes that often differ by 1-2 %, less than the timings scatter; so
+// when the runner-up is within 3 % of the winner the two run a play-off -- four more of the caller's own calls, alternating
+// winner / runner-up / winner / runner-up, each between two events like the trials -- and the best time over ALL of a
+// candidate's samples decides.
+int lazy_next(jh_blockop::LazyTune &t, int ncand, int npass, int warm, float margin, int *choice, int *slot, bool playoff = false)
 {
     *slot = -1;
-    const int total = warm + ncand * npass;
+    const int regular = warm + ncand * npass;
+    const int total = regular + (t.playoff[0] >= 0 ? 4 : 0);
     int measured = 0;
     for (int k = 0; k < t.launched; k++) {                                  // harvest what has finished (non-blocking)
         if (t.state[k] == 1 && hipEventQuery(t.ev[k][1]) == hipSuccess) {
@@ -1785,24 +1798,76 @@ int lazy_next(jh_blockop::LazyTune &t, int ncand, int npass, int warm, float mar
     (void)hipGetLastError();                                                // hipEventQuery's hipErrorNotReady is not an error
     if (measured == total) {
         float best[8] = {};
+        auto take = [&](int c, int k) { if (t.state[k] == 2 && (best[c] == 0.f || t.ms[k] < best[c])) best[c] = t.ms[k]; };
         for (int c = 0; c < ncand; c++)
-            for (int p = 0; p < npass; p++) {
-                const int k = warm + p * ncand + c;
-                if (t.state[k] == 2 && (best[c] == 0.f || t.ms[k] < best[c])) best[c] = t.ms[k];
-            }
-        int pick = 0;
+            for (int p = 0; p < npass; p++) take(c, warm + p * ncand + c);
+        if (t.playoff[0] >= 0)
+            for (int k = 0; k < 4; k++) take(t.playoff[k & 1], regular + k);
+        int pick = 0, runner = -1;
         for (int c = 1; c < ncand; c++)
             if (best[c] > 0.f && (best[pick] == 0.f || best[c] < (1.f - margin) * best[pick])) pick = c;
+        for (int c = 0; c < ncand; c++)
+            if (c != pick && best[c] > 0.f && (runner < 0 || best[c] < best[runner])) runner = c;
+        if (playoff && t.playoff[0] < 0 && runner >= 0 && best[pick] > 0.f && best[runner] <= 1.03f * best[pick] &&
+            regular + 4 <= jh_blockop::LazyTune::SLOTS) {
+            t.playoff[0] = pick;                                            // four more trials; the choice waits for them
+            t.playoff[1] = runner;
+            *slot = t.launched;
+            return pick;
+        }
+        for (int c = 0; c < ncand && c < 8; c++) t.best_ms[c] = best[c];
         *choice = pick;
         lazy_release(t);
         return pick;
     }
     if (t.launched < total) {
         *slot = t.launched;
+        if (*slot >= regular) return t.playoff[(*slot - regular) & 1];
         return *slot < warm ? 0 : (*slot - warm) % ncand;
     }
-    return 0;                                                               // every trial is in flight: the default meanwhile
+    return t.playoff[0] >= 0 ? t.playoff[0] : 0;                            // every trial is in flight: the (provisional) default meanwhile
 }
+
+// Periodic re-check of a choice already made (round 3): every 64th call of the chosen shape is timed between two events (again the
+// caller's own launch, harvested later without waiting).  Three such samples in a row that are more than 3 % slower than the best
+// time ANOTHER candidate recorded during the search rotate that candidate in; the dethroned one's record is replaced by what it
+// has just shown, so the two cannot flip back and forth on stale numbers.  Returns true when THIS call should be timed.
+bool recheck_should_time(jh_blockop::LazyTune &t, int ncand, int *choice)
+{
+    if (t.rc_in_flight && hipEventQuery(t.rc_ev[1]) == hipSuccess) {
+        float ms = 0.f;
+        t.rc_in_flight = false;
+        if (hipEventElapsedTime(&ms, t.rc_ev[0], t.rc_ev[1]) == hipSuccess && ms > 0.f && *choice >= 0 && *choice < 8) {
+            int other = -1;
+            for (int c = 0; c < ncand && c < 8; c++)
+                if (c != *choice && t.best_ms[c] > 0.f && (other < 0 || t.best_ms[c] < t.best_ms[other])) other = c;
+            if (other >= 0 && ms > 1.03f * t.best_ms[other]) {
+                if (++t.rc_slow >= 3) {
+                    t.best_ms[*choice] = ms;
+                    *choice = other;
+                    t.rc_slow = 0;
+                    t.switches++;
+                }
+            } else {
+                t.rc_slow = 0;
+                if (ms < t.best_ms[*choice] || t.best_ms[*choice] == 0.f) t.best_ms[*choice] = ms;
+            }
+        }
+    }
+    (void)hipGetLastError();
+    t.calls++;
+    // every 64th call -- and the three calls after a slow sample, so that a real slowdown is confirmed (or dismissed) at once
+    return !t.rc_in_flight && (t.calls % 64 == 0 || t.rc_slow > 0);
+}
+
+bool recheck_begin(jh_blockop::LazyTune &t, hipStream_t st)
+{
+    for (auto &e : t.rc_ev)
+        if (!e && hipEventCreate(&e) != hipSuccess) return false;
+    return hipEventRecord(t.rc_ev[0], st) == hipSuccess;
+}
+
+void recheck_end(jh_blockop::LazyTune &t, hipStream_t st, bool ok) { t.rc_in_flight = ok && hipEventRecord(t.rc_ev[1], st) == hipSuccess; }
 
 bool lazy_begin(jh_blockop::LazyTune &t, int slot, hipStream_t st)
 {
@@ -1834,10 +1899,19 @@ int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scal
         int slot = -1;
         if (op->fwd_walk < 0) {
             if (!stream_is_capturing(c.stream)) {
-                const int k = lazy_next(op->fwd_tune, K_FWD_CANDIDATES, 2, 0, 0.f, &op->fwd_walk, &slot);
+                const int k = lazy_next(op->fwd_tune, K_FWD_CANDIDATES, 2, 0, 0.f, &op->fwd_walk, &slot, true);
                 if (k >= 0 && k < K_FWD_CANDIDATES) sh = k_fwd_candidates[k];
             }
-        } else if (op->fwd_walk < K_FWD_CANDIDATES) sh = k_fwd_candidates[op->fwd_walk];
+        } else if (op->fwd_walk < K_FWD_CANDIDATES) {
+            if (!stream_is_capturing(c.stream) && recheck_should_time(op->fwd_tune, K_FWD_CANDIDATES, &op->fwd_walk)) {
+                sh = k_fwd_candidates[op->fwd_walk];
+                const bool ok = recheck_begin(op->fwd_tune, c.stream);
+                const int st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, sh);
+                recheck_end(op->fwd_tune, c.stream, ok && st == JH_OK);
+                return st;
+            }
+            sh = k_fwd_candidates[op->fwd_walk];
+        }
         if (slot >= 0) {                                                   // a timed trial: the caller's own launch between two events
             const bool ok = lazy_begin(op->fwd_tune, slot, c.stream);
             const int st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, sh);
@@ -3328,6 +3402,8 @@ int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value)
     JH_REQUIRE(op && name && value, "jh_blockop_tune_get: null argument");
     if (!strcmp(name, "fwd_walk")) *value = op->fwd_walk;                       // -1: not chosen yet
     else if (!strcmp(name, "fwd_trials")) *value = op->fwd_tune.launched;
+    else if (!strcmp(name, "fwd_switches")) *value = op->fwd_tune.switches;       // times the periodic re-check rotated another walk in
+    else if (!strcmp(name, "fwd_playoff")) *value = op->fwd_tune.playoff[0] >= 0 ? op->fwd_tune.playoff[0] * 8 + op->fwd_tune.playoff[1] : -1;
     else if (!strcmp(name, "step_trials")) *value = op->step_tune.launched;
     else if (!strcmp(name, "upd_walk")) *value = op->upd_walk;
     else if (!strcmp(name, "step_mode")) *value = op->step_mode;

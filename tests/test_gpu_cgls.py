@@ -119,13 +119,21 @@ def test_cgls_over_a_team_and_over_the_abi_communicator(Jets, oracle):
     assert dist.itn == whole.itn == iters
     np.testing.assert_allclose(dist.x.to_numpy(), xw, rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose([h[1] for h in dist.history], [h[1] for h in whole.history], rtol=1e-5)
-    # (a) a team of two contexts: rows 0..5 and 6..9
+    # (a) a team of two contexts: rows 0..5 and 6..9 (in a function of its own: every handle of the second context is gone when it returns)
     other = J.context_create(0)
     J.context_use(home)
-    team = None
     try:
-        ctxs, cuts = [home, other], [(0, 6), (6, 10)]
-        team = rowpart.Team(ctxs)
+        _team_leg(J, rowpart, [home, other], spc, n, hb, iters, xw, [h[1] for h in whole.history])
+    finally:
+        gc.collect()
+        J.context_use(home)
+        J.context_destroy(other)
+
+
+def _team_leg(J, rowpart, ctxs, spc, n, hb, iters, xw, r_hist):
+    team = rowpart.Team(ctxs)
+    try:
+        cuts = [(0, 6), (6, 10)]
         ops, bs, keep = [], [], []
         for k, _ in team.each():
             lo, hi = cuts[k]
@@ -139,14 +147,11 @@ def test_cgls_over_a_team_and_over_the_abi_communicator(Jets, oracle):
         x0, x1 = res.x[0].to_numpy(), res.x[1].to_numpy()
         assert x0.tobytes() == x1.tobytes(), "the members' replicas of x differ"
         np.testing.assert_allclose(x0, xw, rtol=2e-5, atol=1e-6)
-        np.testing.assert_allclose([h[1] for h in res.history], [h[1] for h in whole.history], rtol=1e-5)
-        del res, T, ops, bs, keep, x0, x1
+        np.testing.assert_allclose([h[1] for h in res.history], r_hist, rtol=1e-5)
+        for A in ops:
+            J.close(A)
     finally:
-        if team is not None:
-            team.close()
-        gc.collect()
-        J.context_use(home)
-        J.context_destroy(other)
+        team.close()
 
 
 def test_cgls_argument_checks(Jets, oracle):
