@@ -1070,8 +1070,11 @@ template <typename S, int E>
 __global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                     const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
                                     const S *__restrict__ m, S *__restrict__ d, int fmode, unsigned ntiles,
-                                    int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride)
+                                    int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride,
+                                    const S *__restrict__ dense_prod = nullptr, int64_t prod_stride = 0)
 {
+    // dense_prod != null (dense_mixed_fwd): block (i, j) of kind DENSE contributes the product A_ij m_j a batched GEMV launch has
+    // left, rounded like the reference's dtmp (1024), at the row's elements of slab j
     int64_t i, tile;                                                       // block row, tile
     general_line_tile((unsigned)nrow, ntiles, i, tile);
     ntiles &= 0x7fffffffu;
@@ -1096,7 +1099,9 @@ __global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int
             if (b.kind == JH_OP_ZERO && !fmode) continue;                  // (1022); JetBlock_f! has no such test
             elem<S, E> p;
             p.re = 0; p.im = 0;                                            // a zero block's `d .= 0` (942): no load -- its column may be shorter than this row
-            if (b.kind != JH_OP_ZERO) {
+            if (b.kind == JH_OP_DENSE) {
+                p = eload<S, E>(dense_prod, j * prod_stride + row_off[i] + e);   // mul!(dtmp, op, _m), computed by the column's batch
+            } else if (b.kind != JH_OP_ZERO) {
                 elem<S, E> x = eload<S, E>(m, col_off[j] + e);
                 p = apply_block<S, E>(b, x, e, false, fmode != 0);         // mul!(dtmp, op, _m)
             }
@@ -1112,8 +1117,11 @@ template <typename S, int E>
 __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                     const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
                                     S *__restrict__ m, const S *__restrict__ d, unsigned ntiles,
-                                    int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride)
+                                    int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride,
+                                    const S *__restrict__ dense_prod = nullptr, int64_t prod_stride = 0)
 {
+    // dense_prod != null (dense_mixed_adj): block (i, j) of kind DENSE contributes A_ij' d_i, left by the column's batch, rounded
+    // like the reference's mtmp (1049), at column j's elements of slab i
     int64_t j, tile;                                                       // block column, tile
     general_line_tile((unsigned)ncol, ntiles, j, tile);
     ntiles &= 0x7fffffffu;
@@ -1132,8 +1140,13 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
         for (int64_t i = i_lo; i < i_hi; i++) {                            // (1045)
             const jh_dev_block b = blocks[i + j * nrow];
             if (b.kind == JH_OP_ZERO) continue;                            // (1047)
-            elem<S, E> x = eload<S, E>(d, row_off[i] + e);
-            elem<S, E> p = apply_block<S, E>(b, x, e, true);               // mul!(mtmp, op', _d)
+            elem<S, E> p;
+            if (b.kind == JH_OP_DENSE) {
+                p = eload<S, E>(dense_prod, i * prod_stride + col_off[j] + e);   // mul!(mtmp, op', _d), computed by the column's batch
+            } else {
+                elem<S, E> x = eload<S, E>(d, row_off[i] + e);
+                p = apply_block<S, E>(b, x, e, true);                      // mul!(mtmp, op', _d)
+            }
             acc = (nrow > 1) ? eadd<S, E>(acc, p) : p;                     // (1049) / (1051)
             touched = true;
         }
@@ -2668,6 +2681,99 @@ int loop_adj(const jh_blockop *op, void *m, const void *d)           // JetBlock
     return JH_OK;
 }
 
+// ---- operators that mix BIG dense children with other kinds (round 3; the per-block loop's launch-bound corner) ------------------
+// Forward: for every block column j that holds dense children, ONE batched GEMV launch leaves A_ij m_j for all of them in slab j
+// (jh_dense.hip: k_gemv_rows_mixed, the sequential column loop: the bits of the per-child kernel), then ONE launch of the general
+// forward kernel walks every block row in the reference's order (1020-1024), `_d .+=` into d as found, taking a dense block's term
+// from its slab -- the products and the additions of the reference's loop in its order, so bit-identical to the per-block loop
+// wherever that loop's child kernel keeps one column chunk.  Adjoint: per column one launch leaves A_ij' d_i (fp64 wave reduction,
+// rounded like mtmp) in slab i, and one launch of the general adjoint kernel sums every block column in row order (1042-1049).
+// A column whose few, big children would leave the chip empty in one launch (the per-child kernel splits their columns / rows
+// instead) runs child by child into the same slabs -- those are not launch-bound.  K + 1 launches per mul! otherwise.
+template <typename S, int E>
+int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool transposed)
+{
+    jh_context &c = jh_ctx();
+    const size_t es = jh_dtype_size(op->dtype);
+    const int64_t nrange = op->row_off[(size_t)op->nrow], ndomain = op->col_off[(size_t)op->ncol];
+    const int64_t per16 = (int64_t)(16 / es) > 0 ? (int64_t)(16 / es) : 1;
+    const int64_t line_len = transposed ? ndomain : nrange;                     // a slab is laid out like the OUTPUT vector
+    const int64_t stride = (line_len + per16 - 1) / per16 * per16;              // elements; slabs stay 16-byte aligned
+    const int64_t nslabs = transposed ? op->nrow : op->ncol;
+    void *slabs = nullptr;
+    JH_TRY(jh_ensure_scratch((size_t)nslabs * (size_t)stride * es + 16, &slabs));
+    int64_t launches = 0;
+    for (int64_t j = 0; j < op->ncol; j++) {
+        int64_t ndense = 0, max_nr = 0;
+        double max_bytes = 0.0;
+        for (int64_t i = 0; i < op->nrow; i++) {
+            const jh_block_desc &b = op->blocks[(size_t)(i + j * op->nrow)];
+            if (b.kind != JH_OP_DENSE) continue;
+            ndense++;
+            if (b.nr > max_nr) max_nr = b.nr;
+            const double by = (double)b.nr * (double)b.nc * (double)es;
+            if (by > max_bytes) max_bytes = by;
+        }
+        if (!ndense || max_nr == 0 || op->col_len[(size_t)j] == 0) continue;
+        const int64_t nc = op->col_len[(size_t)j];
+        const int64_t wgs = transposed ? (nc + 3) / 4 : ((max_nr * (int64_t)es / 16 + 255) / 256);
+        const bool underfilled = !transposed && max_bytes >= (double)(1 << 20) && wgs * ndense < 2048;   // (the adjoint batch splits rows itself)
+        if (underfilled) {                                                      // few big children: the per-child kernel (column split) fills the chip
+            for (int64_t i = 0; i < op->nrow; i++) {
+                const jh_block_desc &b = op->blocks[(size_t)(i + j * op->nrow)];
+                if (b.kind != JH_OP_DENSE) continue;
+                JH_TRY(jh_launch_gemv(b.coeff, b.nr, b.nc, op->dtype, (char *)slabs + ((size_t)j * (size_t)stride + (size_t)op->row_off[(size_t)i]) * es,
+                                      (const char *)in + (size_t)op->col_off[(size_t)j] * es, 0));
+                launches++;
+            }
+            continue;
+        }
+        if (!transposed)
+            JH_TRY(jh_launch_gemv_mixed_column(op->dev_blocks + j * op->nrow, op->nrow, max_nr, ndense, max_bytes, nc, op->dtype,
+                                               (char *)slabs + (size_t)j * (size_t)stride * es, stride, (const char *)in + (size_t)op->col_off[(size_t)j] * es, 0,
+                                               op->dense_mixed_aligned, op->dev_row_off));
+        else
+            JH_TRY(jh_launch_gemv_mixed_column(op->dev_blocks + j * op->nrow, op->nrow, max_nr, ndense, max_bytes, nc, op->dtype,
+                                               (char *)slabs + (size_t)op->col_off[(size_t)j] * es, stride, in, 1, op->dense_mixed_aligned, op->dev_row_off));
+        launches++;
+    }
+    // the combine: one launch of the general kernel (scalar form: the vectors are small beside the matrices), XCD-aware decode as usual
+    const int64_t nlines = transposed ? op->ncol : op->nrow;
+    int64_t maxn = 0;
+    for (int64_t k = 0; k < nlines; k++) {
+        const int64_t len = transposed ? op->col_len[(size_t)k] : op->row_len[(size_t)k];
+        maxn = len > maxn ? len : maxn;
+    }
+    c.last_adj_parts = 1;
+    if (maxn > 0) {
+        unsigned ntiles, grid;
+        int64_t want = (maxn + 255) / 256;
+        if (want > 4096) want = 4096;
+        general_grid(want, nlines, ntiles, grid, general_use_xcd((transposed ? nrange : ndomain) * (int64_t)es));
+        if (!transposed)
+            hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3(grid, 1), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, op->dev_row_off,
+                               op->dev_col_off, (const S *)in, (S *)out, 0, ntiles, (int64_t)0, (S *)nullptr, (int64_t)0, (const S *)slabs, stride);
+        else
+            hipLaunchKernelGGL((k_block_adj_general<S, E>), dim3(grid, 1), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, op->dev_row_off,
+                               op->dev_col_off, (S *)out, (const S *)in, ntiles, (int64_t)0, (S *)nullptr, (int64_t)0, (const S *)slabs, stride);
+        JH_CHECK_HIP(hipGetLastError());
+        launches++;
+    }
+    c.last_launches = launches;
+    return JH_OK;
+}
+
+int dense_mixed(const jh_blockop *op, void *out, const void *in, bool transposed)
+{
+    switch (op->dtype) {
+    case JH_F32: return dense_mixed_apply<float, 1>(op, out, in, transposed);
+    case JH_F64: return dense_mixed_apply<double, 1>(op, out, in, transposed);
+    case JH_C32: return dense_mixed_apply<float, 2>(op, out, in, transposed);
+    case JH_C64: return dense_mixed_apply<double, 2>(op, out, in, transposed);
+    }
+    return jh_fail(JH_ERR_INVALID, "dense_mixed: unknown dtype %d", op->dtype);
+}
+
 int loop_small(const jh_blockop *op, void *out, const void *in, int transposed, int fmode)
 {
     const int64_t nlines = transposed ? op->ncol : op->nrow;
@@ -2900,6 +3006,24 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
             if (b.kind == JH_OP_DENSE && (double)b.nr * (double)b.nc * es > (double)(256 << 10)) op->small_loop = false;   // beyond 256 KiB per child the per-child kernels win (profiles/bench_graphs_r02.txt)
     }
 
+    // ... and when a matrix is bigger than that: one batched launch per block column + one combine launch (dense_mixed_apply), as long
+    // as no dense child is adjointed (those keep the per-block loop)
+    if (!op->elementwise && !op->dense_batch && !op->dense_batch_ragged && !op->dense_batch_grid && !op->dense_batch_wide && !op->small_loop &&
+        nrow <= 65535 && ncol <= 65535) {
+        op->dense_mixed = true;
+        op->dense_mixed_aligned = true;
+        const size_t es = jh_dtype_size(dtype);
+        for (int64_t j = 0; j < ncol && op->dense_mixed; j++)
+            for (int64_t i = 0; i < nrow; i++) {
+                const jh_block_desc &b = op->blocks[(size_t)(i + j * nrow)];
+                if (b.kind != JH_OP_DENSE) continue;
+                if (b.adjoint || b.nr != op->row_len[(size_t)i] || b.nc != op->col_len[(size_t)j]) { op->dense_mixed = false; break; }
+                if ((((uintptr_t)b.coeff) & 15u) || ((size_t)b.nr * es) % 16 || ((size_t)op->row_off[(size_t)i] * es) % 16) op->dense_mixed_aligned = false;
+            }
+        for (int64_t j = 0; j < ncol; j++)
+            if (((size_t)op->col_off[(size_t)j] * es) % 16) op->dense_mixed_aligned = false;            // (the adjoint's slab offsets)
+    }
+
     // strided-diagonal detection: coeff[i] = coeff[0] + i*stride  (e.g. one slab holding all diagonals)
     if (op->tall && op->all_diag && nrow >= 1) {
         op->diag_strided = true;
@@ -3066,6 +3190,7 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     if (op->dense_batch_grid) return dense_grid_fwd(op, d->data, m->data);
     if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false, op->dev_row_off);
     if (op->small_loop && jh_ctx().small_loop) return loop_small(op, d->data, m->data, 0, 0);
+    if (op->dense_mixed && jh_ctx().dense_mixed) return dense_mixed(op, d->data, m->data, false);
     if (!op->elementwise) return run_loop_graphed(op, 0, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data); });
     // a wide operator's forward d = d_found + sum_j A_1j m_j (1024: no zeroing) is its tall twin's ordered adjoint sum started from
     // what d holds -- the same additions in the same order.  Large blocks only: the ordered walk needs >= one workgroup per CU
@@ -3117,6 +3242,7 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
     if (op->dense_batch_grid) return dense_grid_adj(op, m->data, d->data);
     if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, false, op->dev_row_off);
     if (op->small_loop && jh_ctx().small_loop) return loop_small(op, m->data, d->data, 1, 0);
+    if (op->dense_mixed && jh_ctx().dense_mixed) return dense_mixed(op, m->data, d->data, true);
     if (!op->elementwise) return run_loop_graphed(op, 1, m->data, d->data, [&] { return loop_adj(op, m->data, d->data); });
     // a wide operator's adjoint is its tall twin's forward (same bits: one rounded product per element, zero blocks untouched)
     if (op->twin && jh_ctx().wide_twin && (tall_fast_ok(op->twin, m->data, d->data) || tall_mixed_ok(op->twin, m->data, d->data)))

@@ -650,6 +650,173 @@ int gemv(const void *A, int64_t nr, int64_t nc, void *y, const void *x, int adjo
     return JH_OK;
 }
 
+
+// ---- one block COLUMN of an operator that mixes dense children with other kinds (round 3) ---------------------------------------
+// Operators with DENSE children that fit none of the uniform batches above -- dense next to diagonal / identity / zero blocks,
+// children of different shapes -- and are too big for the one-launch loop used to run the reference's loop literally: one child
+// launch + one accumulate launch per non-zero block (jh_blockop.hip: loop_fwd / loop_adj).  Here the dense children of ONE block
+// column go in one launch (blockIdx.z = block row; a child that is not an un-adjointed dense matrix returns at once): column j's
+// children share nc = the column's length and the input m_j (forward) / write the same range of the domain (adjoint), and differ
+// in their row counts, which come from the row-offset table like the ragged batch's.  Every child's product is left, rounded to the
+// element type like the reference's dtmp / mtmp, in a slab (forward: slab j at the child's rows of the range; adjoint: slab i at
+// column j's elements of the domain), and ONE launch of the general kernels then walks every output line in the reference's order,
+// taking a dense block's term from its slab (jh_blockop.hip: dense_mixed_fwd / _adj): K + 1 launches instead of up to 2 M K.
+template <typename S, int E, int NS>
+__global__ __launch_bounds__(256) void k_gemv_rows_mixed(const jh_dev_block *__restrict__ blocks, int64_t nc, const S *__restrict__ x,
+                                                         S *__restrict__ out, const int64_t *__restrict__ row_off)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t z = blockIdx.z;
+    const jh_dev_block b = blocks[z];
+    if (b.kind != JH_OP_DENSE) return;
+    const int64_t ns = (row_off[z + 1] - row_off[z]) * E;
+    const int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * NS;
+    if (s >= ns) return;
+    V acc = (V)(S)0;
+    const S *col = (const S *)b.coeff + s;
+#pragma unroll 4
+    for (int64_t c = 0; c < nc; c++, col += ns) {                               // columns in order, product rounded then added: the sequential loop's bits
+        V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col));
+        if constexpr (E == 1) {
+            acc = acc + a * (V)x[c];
+        } else {
+            const S xr = x[2 * c], xi = x[2 * c + 1];
+            V p;
+#pragma unroll
+            for (int e = 0; e < NS; e += 2) {
+                p[e] = a[e] * xr - a[e + 1] * xi;
+                p[e + 1] = a[e] * xi + a[e + 1] * xr;
+            }
+            acc = acc + p;
+        }
+    }
+    *reinterpret_cast<V *>(out + row_off[z] * E + s) = acc;
+}
+
+// adjoint: child (z, this column)' d_z, one wave per (matrix column, row chunk), fp64 wave reduction; with ONE row chunk the column
+// sum is rounded and stored at once (direct != null: slab z), else the partial sums go to `partial` for k_store_cols_mixed
+template <typename S, int E, int NS>
+__global__ __launch_bounds__(256) void k_gemv_cols_mixed(const jh_dev_block *__restrict__ blocks, int64_t nc, const S *__restrict__ d,
+                                                         const int64_t *__restrict__ row_off, int64_t rows_per_chunk, double *__restrict__ partial,
+                                                         S *__restrict__ direct, int64_t slab_stride)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= nc) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t z = blockIdx.z;
+    const jh_dev_block b = blocks[z];
+    if (b.kind != JH_OP_DENSE) return;
+    const int64_t ns = (row_off[z + 1] - row_off[z]) * E;
+    const int64_t s0 = (int64_t)blockIdx.y * rows_per_chunk * E;
+    const int64_t s1 = s0 + rows_per_chunk * E < ns ? s0 + rows_per_chunk * E : ns;
+    const S *col = (const S *)b.coeff + c * ns;
+    const S *x = d + row_off[z] * E;
+    double sr = 0.0, si = 0.0;
+    for (int64_t s = s0 + (int64_t)lane * NS; s < s1; s += 64 * NS) {
+        V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col + s));
+        V xv = *reinterpret_cast<const V *>(x + s);
+        if constexpr (E == 1) {
+#pragma unroll
+            for (int e = 0; e < NS; e++) {
+                if constexpr (NS == 1) sr += (double)a * (double)xv;
+                else sr += (double)a[e] * (double)xv[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NS; e += 2) {
+                const double ar = a[e], ai = -(double)a[e + 1], xr = xv[e], xi = xv[e + 1];
+                sr += ar * xr - ai * xi;
+                si += ar * xi + ai * xr;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sr += __shfl_down(sr, off, 64);
+        if (E == 2) si += __shfl_down(si, off, 64);
+    }
+    if (lane == 0) {
+        if (direct) {
+            S *o = direct + (z * slab_stride + c) * E;
+            o[0] = (S)sr;
+            if (E == 2) o[1] = (S)si;
+        } else {
+            double *p = partial + ((z * gridDim.y + blockIdx.y) * nc + c) * 2;
+            p[0] = sr;
+            p[1] = si;
+        }
+    }
+}
+
+template <typename S, int E>
+__global__ void k_store_cols_mixed(const jh_dev_block *__restrict__ blocks, const double *__restrict__ partial, int64_t nc, int nchunks,
+                                   S *__restrict__ slabs, int64_t slab_stride)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x, z = blockIdx.y;
+    if (c >= nc || blocks[z].kind != JH_OP_DENSE) return;
+    double sr = 0.0, si = 0.0;
+    const double *p = partial + (z * nchunks * nc + c) * 2;
+    for (int k = 0; k < nchunks; k++) { sr += p[(int64_t)k * nc * 2]; si += p[(int64_t)k * nc * 2 + 1]; }
+    S *o = slabs + (z * slab_stride + c) * E;
+    o[0] = (S)sr;
+    if (E == 2) o[1] = (S)si;
+}
+
+// forward: out (slab j, laid out like the range vector) ; adjoint: out = slab 0 at this column's first element, slab z at + z * slab_stride
+template <typename S, int E>
+int gemv_mixed_column(const jh_dev_block *col_blocks, int64_t nrow, int64_t max_nr, int64_t ndense, double max_child_bytes, int64_t nc, void *out,
+                      int64_t slab_stride, const void *x, int adjoint, bool aligned, const int64_t *dev_row_off)
+{
+    jh_context &c = jh_ctx();
+    hipStream_t st = c.stream;
+    constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
+    const bool vec_ok = aligned && ((((uintptr_t)x) | ((uintptr_t)out)) & 15u) == 0;
+    if (!adjoint) {
+        const int NS = vec_ok ? NSV : E;
+        const int64_t row_wgs = (max_nr * E / NS + 255) / 256;
+        if (vec_ok)
+            hipLaunchKernelGGL((k_gemv_rows_mixed<S, E, NSV>), dim3((unsigned)row_wgs, 1, (unsigned)nrow), dim3(256), 0, st, col_blocks, nc, (const S *)x,
+                               (S *)out, dev_row_off);
+        else
+            hipLaunchKernelGGL((k_gemv_rows_mixed<S, E, E>), dim3((unsigned)row_wgs, 1, (unsigned)nrow), dim3(256), 0, st, col_blocks, nc, (const S *)x,
+                               (S *)out, dev_row_off);
+        JH_CHECK_HIP(hipGetLastError());
+        return JH_OK;
+    }
+    const int64_t col_wgs = (nc + 3) / 4;
+    int64_t nchunks = 1;                                                       // split the rows only while big children leave the chip empty
+    if (max_child_bytes >= (double)(1 << 20) && col_wgs * ndense < 2048) {
+        nchunks = (2048 + col_wgs * ndense - 1) / (col_wgs * ndense);
+        const int64_t maxc = (max_nr + 4095) / 4096;
+        if (nchunks > maxc) nchunks = maxc;
+        if (nchunks < 1) nchunks = 1;
+    }
+    int64_t rpc = (max_nr + nchunks - 1) / nchunks;
+    rpc = (rpc + 3) / 4 * 4;
+    if (rpc < 4) rpc = 4;
+    nchunks = max_nr ? (max_nr + rpc - 1) / rpc : 1;
+    double *partial = nullptr;
+    if (nchunks > 1) {
+        JH_TRY(jh_ensure_partials(2 * nrow * nchunks * nc));
+        partial = c.part_dev;
+    }
+    S *direct = nchunks > 1 ? nullptr : (S *)out;
+    if (vec_ok)
+        hipLaunchKernelGGL((k_gemv_cols_mixed<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)nrow), dim3(256), 0, st, col_blocks, nc,
+                           (const S *)x, dev_row_off, rpc, partial, direct, slab_stride);
+    else
+        hipLaunchKernelGGL((k_gemv_cols_mixed<S, E, E>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)nrow), dim3(256), 0, st, col_blocks, nc,
+                           (const S *)x, dev_row_off, rpc, partial, direct, slab_stride);
+    JH_CHECK_HIP(hipGetLastError());
+    if (nchunks > 1) {
+        hipLaunchKernelGGL((k_store_cols_mixed<S, E>), dim3((unsigned)((nc + 255) / 256), (unsigned)nrow), dim3(256), 0, st, col_blocks, partial, nc,
+                           (int)nchunks, (S *)out, slab_stride);
+        JH_CHECK_HIP(hipGetLastError());
+    }
+    return JH_OK;
+}
+
 }  // namespace
 
 int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, const void *x, int adjoint)
@@ -681,6 +848,19 @@ int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64
     case JH_C64: return gemv_batched<double, 2>(dev_blocks, nchild, nr, nc, y, x, adjoint, aligned, dev_row_off);
     }
     return jh_fail(JH_ERR_INVALID, "gemv_batched: unknown dtype %d", dtype);
+}
+
+// the dense children of ONE block column of a mixed operator (see k_gemv_rows_mixed); x: forward m_j, adjoint the whole range vector d
+int jh_launch_gemv_mixed_column(const jh_dev_block *col_blocks, int64_t nrow, int64_t max_nr, int64_t ndense, double max_child_bytes, int64_t nc,
+                                int dtype, void *out, int64_t slab_stride, const void *x, int adjoint, bool aligned, const int64_t *dev_row_off)
+{
+    switch (dtype) {
+    case JH_F32: return gemv_mixed_column<float, 1>(col_blocks, nrow, max_nr, ndense, max_child_bytes, nc, out, slab_stride, x, adjoint, aligned, dev_row_off);
+    case JH_F64: return gemv_mixed_column<double, 1>(col_blocks, nrow, max_nr, ndense, max_child_bytes, nc, out, slab_stride, x, adjoint, aligned, dev_row_off);
+    case JH_C32: return gemv_mixed_column<float, 2>(col_blocks, nrow, max_nr, ndense, max_child_bytes, nc, out, slab_stride, x, adjoint, aligned, dev_row_off);
+    case JH_C64: return gemv_mixed_column<double, 2>(col_blocks, nrow, max_nr, ndense, max_child_bytes, nc, out, slab_stride, x, adjoint, aligned, dev_row_off);
+    }
+    return jh_fail(JH_ERR_INVALID, "gemv_mixed_column: unknown dtype %d", dtype);
 }
 
 extern "C" int jh_gemv(const void *A_device, int64_t nr, int64_t nc, int dtype, jh_bvec *y, const jh_bvec *x, int adjoint)

@@ -196,3 +196,88 @@ def test_batched_ragged_tall_dense_children(Jets, oracle, dt, rows, nc):
     wide = np.clongdouble if np.iscomplexobj(mats[0]) else np.longdouble
     truth = sum(np.conj(mats[z].astype(wide)).T @ hd[off[z]:off[z + 1]].astype(wide) for z in range(len(rows)))
     assert _err(mt.to_numpy().ravel(order="F"), truth) < _tol(dt)
+
+
+# ---- round 3: BIG dense children in mixed company -- one batched launch per block column + one combine launch -----------------
+def _mixed_operator(Jets, oracle, dt, layout, row_len, col_len, seed=970):
+    """layout[i][j] in {"dense", "diag", "id", "zero"}; dense children are row_len[i] x col_len[j], the others square."""
+    dev_rows, ora_rows = [], []
+    for i, row in enumerate(layout):
+        drow, orow = [], []
+        for j, kind in enumerate(row):
+            nr, nc = row_len[i], col_len[j]
+            if kind == "dense":
+                hA = np.asfortranarray(u01(oracle, dt, seed, i * 16 + j, nr * nc).reshape((nr, nc), order="F"))
+                drow.append(Jets.JopDense(Jets.from_numpy(hA)))
+                orow.append(oracle.Block("dense", nr, nc, coeff=hA))
+            elif kind == "diag":
+                assert nr == nc
+                g = u01(oracle, dt, seed + 1, i * 16 + j, nr)
+                drow.append(Jets.JopDiagonal(Jets.from_numpy(g)))
+                orow.append(oracle.Block("diag", nr, coeff=g))
+            elif kind == "id":
+                assert nr == nc
+                drow.append(Jets.JopIdentity(Jets.JetSpace(dt, nr)))
+                orow.append(oracle.Block("identity", nr))
+            else:
+                drow.append(Jets.JopZeroBlock(Jets.JetSpace(dt, nc), Jets.JetSpace(dt, nr)))
+                orow.append(oracle.Block("zero", nr, nc))
+        dev_rows.append(drow)
+        ora_rows.append(orow)
+    return Jets.blockop(dev_rows), ora_rows
+
+
+MIXED_SHAPES = {
+    # (layout, row lengths, column lengths): every dense child is beyond 256 KiB for every element type (>= 192 x 384 x 4 B)
+    "grid3x4": ([["dense", "zero", "diag", "dense"], ["zero", "zero", "zero", "zero"], ["id", "dense", "dense", "zero"]],
+                [512, 256, 512], [512, 384, 512, 192]),
+    "tall": ([["dense"], ["diag"], ["dense"], ["zero"], ["id"]], [384, 640, 200, 640, 640], [640]),
+    "wide": ([["dense", "diag", "zero", "dense", "id"]], [448], [320, 448, 448, 1024, 448]),
+    "ragged_dense_only": ([["dense", "dense"], ["dense", "dense"], ["dense", "dense"]], [300, 524, 256], [512, 260]),
+    "odd_lengths": ([["dense", "id"], ["diag", "dense"]], [333, 387], [333, 387]),            # nothing 16-byte aligned: the scalar kernels
+}
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", sorted(MIXED_SHAPES))
+def test_big_dense_children_in_mixed_company(Jets, oracle, dt, shape):
+    """Dense children too big for the one-launch loop (> 256 KiB) next to diagonal / identity / zero blocks, or of differing shapes:
+    per block column ONE batched GEMV launch leaves the children's products in a slab, ONE launch of the general kernel combines
+    every output line in the reference's order (src/Jets.jl:1020-1024, 1042-1049).  Forward: the bits of the oracle's loops, into a
+    dirty d (`_d .+=`, a row of zero blocks left as found); adjoint: a dirty m zeroed (or, with one block row, written directly,
+    a zero block's column left as found), the dense terms from an fp64 wave reduction -> tolerance; never more than K + 1 launches."""
+    J = Jets
+    layout, row_len, col_len = MIXED_SHAPES[shape]
+    A, ops = _mixed_operator(J, oracle, dt, layout, row_len, col_len)
+    M, K = len(row_len), len(col_len)
+    hm = [u01(oracle, dt, SEED_M, j, col_len[j]) for j in range(K)]
+    hd = [u01(oracle, dt, SEED_D, i, row_len[i]) for i in range(M)]
+    hmt = [u01(oracle, dt, SEED_D + 1, j, col_len[j]) for j in range(K)]
+    want_d = oracle.block_df(ops, [b.copy() for b in hd], hm)
+    want_m = oracle.block_df_adj(ops, [b.copy() for b in hmt], want_d)
+    got = {}
+    for knob in (1, 0):                                                # the new path, then the per-block loop it replaces
+        J.tune(dense_mixed=knob)
+        try:
+            m = J.from_numpy(np.concatenate(hm), J.domain(A)) if K > 1 else J.from_numpy(hm[0])
+            d = J.from_numpy(np.concatenate(hd), J.range(A))            # dirty
+            J.mul_(d, A, m)
+            if knob:
+                assert 1 <= J.tune_get("last_launches") <= K + 1, "forward: at most one launch per block column + the combine"
+            mt = J.from_numpy(np.concatenate(hmt), J.domain(A)) if K > 1 else J.from_numpy(hmt[0])   # dirty
+            J.mul_(mt, A.H, d)
+            if knob:
+                assert 1 <= J.tune_get("last_launches") <= K + 1, "adjoint: at most one launch per block column + the combine"
+            got[knob] = (d.to_numpy(), mt.to_numpy().ravel(order="F"))
+        finally:
+            J.tune(dense_mixed=1)
+    assert_bits_equal(got[1][0], np.concatenate(want_d), f"{shape}: forward vs the oracle's loop")
+    assert_bits_equal(got[1][0], got[0][0], f"{shape}: forward vs the per-block loop")
+    assert _err(got[1][1], np.concatenate(want_m)) < _tol(dt), f"{shape}: adjoint"
+    assert _err(got[0][1], np.concatenate(want_m)) < _tol(dt)
+    # what the reference leaves untouched stays untouched: a block row of zero blocks (forward), a zero block's column of a one-row operator
+    if shape == "grid3x4":
+        assert_bits_equal(got[1][0][512:768], hd[1], "the row of zero blocks keeps d as found")
+    if shape == "wide":
+        assert_bits_equal(got[1][1][768:1216], hmt[2], "the zero block's column keeps m as found (1047 / 1051)")
+    J.close(A)
