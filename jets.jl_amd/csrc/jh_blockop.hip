@@ -2682,14 +2682,14 @@ int loop_adj(const jh_blockop *op, void *m, const void *d)           // JetBlock
 }
 
 // ---- operators that mix BIG dense children with other kinds (round 3; the per-block loop's launch-bound corner) ------------------
-// Forward: for every block column j that holds dense children, ONE batched GEMV launch leaves A_ij m_j for all of them in slab j
-// (jh_dense.hip: k_gemv_rows_mixed, the sequential column loop: the bits of the per-child kernel), then ONE launch of the general
-// forward kernel walks every block row in the reference's order (1020-1024), `_d .+=` into d as found, taking a dense block's term
-// from its slab -- the products and the additions of the reference's loop in its order, so bit-identical to the per-block loop
-// wherever that loop's child kernel keeps one column chunk.  Adjoint: per column one launch leaves A_ij' d_i (fp64 wave reduction,
-// rounded like mtmp) in slab i, and one launch of the general adjoint kernel sums every block column in row order (1042-1049).
-// A column whose few, big children would leave the chip empty in one launch (the per-child kernel splits their columns / rows
-// instead) runs child by child into the same slabs -- those are not launch-bound.  K + 1 launches per mul! otherwise.
+// Forward: ONE batched GEMV launch leaves A_ij m_j of every dense child in slab j (jh_dense.hip: k_gemv_rows_mixed, the sequential
+// column loop: the bits of the per-child kernel), then ONE launch of the general forward kernel walks every block row in the
+// reference's order (1020-1024), `_d .+=` into d as found, taking a dense block's term from its slab -- the products and the
+// additions of the reference's loop in its order, so bit-identical to the per-block loop wherever that loop's child kernel keeps one
+// column chunk.  Adjoint: one launch leaves A_ij' d_i (fp64 wave reduction, rounded like mtmp) in slab i, one launch of the general
+// adjoint kernel sums every block column in row order (1042-1049).  Two launches per mul!.  Exception: when the dense children are few
+// AND big (the batched launch would leave the chip empty; the per-child kernel splits a big child's columns / rows over the grid
+// instead) they run child by child into the same slabs -- those operators are not launch-bound.
 template <typename S, int E>
 int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool transposed)
 {
@@ -2702,40 +2702,37 @@ int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool tran
     const int64_t nslabs = transposed ? op->nrow : op->ncol;
     void *slabs = nullptr;
     JH_TRY(jh_ensure_scratch((size_t)nslabs * (size_t)stride * es + 16, &slabs));
-    int64_t launches = 0;
-    for (int64_t j = 0; j < op->ncol; j++) {
-        int64_t ndense = 0, max_nr = 0;
-        double max_bytes = 0.0;
-        for (int64_t i = 0; i < op->nrow; i++) {
-            const jh_block_desc &b = op->blocks[(size_t)(i + j * op->nrow)];
-            if (b.kind != JH_OP_DENSE) continue;
-            ndense++;
-            if (b.nr > max_nr) max_nr = b.nr;
-            const double by = (double)b.nr * (double)b.nc * (double)es;
-            if (by > max_bytes) max_bytes = by;
+    int64_t launches = 0, ndense = 0, max_nr = 0, max_nc = 0, wgs = 0;
+    double max_bytes = 0.0;
+    for (const auto &b : op->blocks) {
+        if (b.kind != JH_OP_DENSE) continue;
+        ndense++;
+        if (b.nr > max_nr) max_nr = b.nr;
+        if (b.nc > max_nc) max_nc = b.nc;
+        const double by = (double)b.nr * (double)b.nc * (double)es;
+        if (by > max_bytes) max_bytes = by;
+        wgs += transposed ? (b.nc + 3) / 4 : (b.nr * (int64_t)es / 16 + 255) / 256;
+    }
+    if (ndense && max_nr > 0 && max_nc > 0) {
+        if (max_bytes >= (double)(8 << 20) && wgs < 2048) {                     // few BIG children: child by child (column / row split inside); measured
+                                                                                // crossover 4-16 MiB per child (profiles/bench_dense_mixed_r03.txt)
+            for (int64_t j = 0; j < op->ncol; j++)
+                for (int64_t i = 0; i < op->nrow; i++) {
+                    const jh_block_desc &b = op->blocks[(size_t)(i + j * op->nrow)];
+                    if (b.kind != JH_OP_DENSE) continue;
+                    if (!transposed)
+                        JH_TRY(jh_launch_gemv(b.coeff, b.nr, b.nc, op->dtype, (char *)slabs + ((size_t)j * (size_t)stride + (size_t)op->row_off[(size_t)i]) * es,
+                                              (const char *)in + (size_t)op->col_off[(size_t)j] * es, 0));
+                    else
+                        JH_TRY(jh_launch_gemv(b.coeff, b.nr, b.nc, op->dtype, (char *)slabs + ((size_t)i * (size_t)stride + (size_t)op->col_off[(size_t)j]) * es,
+                                              (const char *)in + (size_t)op->row_off[(size_t)i] * es, 1));
+                    launches++;
+                }
+        } else {
+            JH_TRY(jh_launch_gemv_mixed_all(op->dev_blocks, op->nrow, op->ncol, max_nr, max_nc, op->dtype, slabs, stride, in, transposed ? 1 : 0,
+                                            op->dense_mixed_aligned, op->dev_row_off, op->dev_col_off));
+            launches++;
         }
-        if (!ndense || max_nr == 0 || op->col_len[(size_t)j] == 0) continue;
-        const int64_t nc = op->col_len[(size_t)j];
-        const int64_t wgs = transposed ? (nc + 3) / 4 : ((max_nr * (int64_t)es / 16 + 255) / 256);
-        const bool underfilled = !transposed && max_bytes >= (double)(1 << 20) && wgs * ndense < 2048;   // (the adjoint batch splits rows itself)
-        if (underfilled) {                                                      // few big children: the per-child kernel (column split) fills the chip
-            for (int64_t i = 0; i < op->nrow; i++) {
-                const jh_block_desc &b = op->blocks[(size_t)(i + j * op->nrow)];
-                if (b.kind != JH_OP_DENSE) continue;
-                JH_TRY(jh_launch_gemv(b.coeff, b.nr, b.nc, op->dtype, (char *)slabs + ((size_t)j * (size_t)stride + (size_t)op->row_off[(size_t)i]) * es,
-                                      (const char *)in + (size_t)op->col_off[(size_t)j] * es, 0));
-                launches++;
-            }
-            continue;
-        }
-        if (!transposed)
-            JH_TRY(jh_launch_gemv_mixed_column(op->dev_blocks + j * op->nrow, op->nrow, max_nr, ndense, max_bytes, nc, op->dtype,
-                                               (char *)slabs + (size_t)j * (size_t)stride * es, stride, (const char *)in + (size_t)op->col_off[(size_t)j] * es, 0,
-                                               op->dense_mixed_aligned, op->dev_row_off));
-        else
-            JH_TRY(jh_launch_gemv_mixed_column(op->dev_blocks + j * op->nrow, op->nrow, max_nr, ndense, max_bytes, nc, op->dtype,
-                                               (char *)slabs + (size_t)op->col_off[(size_t)j] * es, stride, in, 1, op->dense_mixed_aligned, op->dev_row_off));
-        launches++;
     }
     // the combine: one launch of the general kernel (scalar form: the vectors are small beside the matrices), XCD-aware decode as usual
     const int64_t nlines = transposed ? op->ncol : op->nrow;
@@ -2997,31 +2994,36 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
         }
     }
 
-    // anything else with DENSE blocks -- adjointed children, dense next to elementwise kinds (the reference's 3 x 4 test
-    // operator) -- whose matrices are all small: the whole block loop in one launch instead of two launches per block
+    // anything else with DENSE blocks -- adjointed children, dense next to elementwise kinds (the reference's 3 x 4 test operator),
+    // children of differing shapes.  Two routes besides the reference's per-block loop:
+    //   small_loop   the whole block loop in ONE launch, a thread forming a dense child's dot product itself (bit-exact both ways; any
+    //                adjoint flags): for SMALL operators -- every matrix <= 256 KiB (beyond that the per-child kernels win,
+    //                profiles/bench_graphs_r02.txt) and at most 512 sequential products per output element (a 64 x 2 grid of 256^2
+    //                children ran its adjoint in 1.0 ms there: 16 384 dependent loads per thread; profiles/bench_dense_mixed_r03.txt)
+    //   dense_mixed  one batched launch for all dense children + one combine launch (dense_mixed_apply): everything else, as long as no
+    //                dense child is adjointed
     if (!op->elementwise && !op->dense_batch && !op->dense_batch_ragged && !op->dense_batch_grid && !op->dense_batch_wide && nrow <= 65535 && ncol <= 65535) {
-        op->small_loop = true;
-        const double es = (double)jh_dtype_size(dtype);
-        for (const auto &b : op->blocks)
-            if (b.kind == JH_OP_DENSE && (double)b.nr * (double)b.nc * es > (double)(256 << 10)) op->small_loop = false;   // beyond 256 KiB per child the per-child kernels win (profiles/bench_graphs_r02.txt)
-    }
-
-    // ... and when a matrix is bigger than that: one batched launch per block column + one combine launch (dense_mixed_apply), as long
-    // as no dense child is adjointed (those keep the per-block loop)
-    if (!op->elementwise && !op->dense_batch && !op->dense_batch_ragged && !op->dense_batch_grid && !op->dense_batch_wide && !op->small_loop &&
-        nrow <= 65535 && ncol <= 65535) {
-        op->dense_mixed = true;
-        op->dense_mixed_aligned = true;
         const size_t es = jh_dtype_size(dtype);
-        for (int64_t j = 0; j < ncol && op->dense_mixed; j++)
+        bool small = true, eligible = true, aligned = true;
+        std::vector<int64_t> fwd_work((size_t)nrow, 0), adj_work((size_t)ncol, 0);
+        for (int64_t j = 0; j < ncol; j++)
             for (int64_t i = 0; i < nrow; i++) {
                 const jh_block_desc &b = op->blocks[(size_t)(i + j * nrow)];
                 if (b.kind != JH_OP_DENSE) continue;
-                if (b.adjoint || b.nr != op->row_len[(size_t)i] || b.nc != op->col_len[(size_t)j]) { op->dense_mixed = false; break; }
-                if ((((uintptr_t)b.coeff) & 15u) || ((size_t)b.nr * es) % 16 || ((size_t)op->row_off[(size_t)i] * es) % 16) op->dense_mixed_aligned = false;
+                if ((double)b.nr * (double)b.nc * (double)es > (double)(256 << 10)) small = false;
+                if (b.adjoint || b.nr != op->row_len[(size_t)i] || b.nc != op->col_len[(size_t)j]) eligible = false;
+                if ((((uintptr_t)b.coeff) & 15u) || ((size_t)b.nr * es) % 16 || ((size_t)op->row_off[(size_t)i] * es) % 16) aligned = false;
+                fwd_work[(size_t)i] += b.adjoint ? b.nr : b.nc;
+                adj_work[(size_t)j] += b.adjoint ? b.nc : b.nr;
             }
         for (int64_t j = 0; j < ncol; j++)
-            if (((size_t)op->col_off[(size_t)j] * es) % 16) op->dense_mixed_aligned = false;            // (the adjoint's slab offsets)
+            if (((size_t)op->col_off[(size_t)j] * es) % 16) aligned = false;                         // (the adjoint's slab offsets)
+        int64_t line_work = 0;
+        for (int64_t v : fwd_work) line_work = v > line_work ? v : line_work;
+        for (int64_t v : adj_work) line_work = v > line_work ? v : line_work;
+        op->small_loop = small && (line_work <= 512 || !eligible);
+        op->dense_mixed = eligible && !op->small_loop;
+        op->dense_mixed_aligned = aligned;
     }
 
     // strided-diagonal detection: coeff[i] = coeff[0] + i*stride  (e.g. one slab holding all diagonals)

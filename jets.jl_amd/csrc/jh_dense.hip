@@ -651,31 +651,55 @@ int gemv(const void *A, int64_t nr, int64_t nc, void *y, const void *x, int adjo
 }
 
 
-// ---- one block COLUMN of an operator that mixes dense children with other kinds (round 3) ---------------------------------------
+// ---- ALL dense children of an operator that mixes them with other kinds (round 3) ------------------------------------------------
 // Operators with DENSE children that fit none of the uniform batches above -- dense next to diagonal / identity / zero blocks,
 // children of different shapes -- and are too big for the one-launch loop used to run the reference's loop literally: one child
-// launch + one accumulate launch per non-zero block (jh_blockop.hip: loop_fwd / loop_adj).  Here the dense children of ONE block
-// column go in one launch (blockIdx.z = block row; a child that is not an un-adjointed dense matrix returns at once): column j's
-// children share nc = the column's length and the input m_j (forward) / write the same range of the domain (adjoint), and differ
-// in their row counts, which come from the row-offset table like the ragged batch's.  Every child's product is left, rounded to the
-// element type like the reference's dtmp / mtmp, in a slab (forward: slab j at the child's rows of the range; adjoint: slab i at
-// column j's elements of the domain), and ONE launch of the general kernels then walks every output line in the reference's order,
-// taking a dense block's term from its slab (jh_blockop.hip: dense_mixed_fwd / _adj): K + 1 launches instead of up to 2 M K.
+// launch + one accumulate launch per non-zero block (jh_blockop.hip: loop_fwd / loop_adj).  Here ONE launch runs every dense child
+// (blockIdx.y = block column j, blockIdx.z = block row i; a block that is not an un-adjointed dense matrix returns at once): child
+// (i, j) is row_len[i] x col_len[j], reads m_j (forward) / d_i (adjoint), and leaves its product, rounded to the element type like
+// the reference's dtmp / mtmp, in a slab (forward: slab j at row i's elements of the range; adjoint: slab i at column j's elements
+// of the domain).  ONE launch of the general kernels then walks every output line in the reference's order, taking a dense block's
+// term from its slab (jh_blockop.hip: dense_mixed_apply): two launches per mul! instead of up to 2 M K.
 template <typename S, int E, int NS>
-__global__ __launch_bounds__(256) void k_gemv_rows_mixed(const jh_dev_block *__restrict__ blocks, int64_t nc, const S *__restrict__ x,
-                                                         S *__restrict__ out, const int64_t *__restrict__ row_off)
+__global__ __launch_bounds__(256) void k_gemv_rows_mixed(const jh_dev_block *__restrict__ blocks, int64_t nrow, const S *__restrict__ m,
+                                                         S *__restrict__ slabs, int64_t slab_stride, const int64_t *__restrict__ row_off,
+                                                         const int64_t *__restrict__ col_off)
 {
     typedef typename vec_of<S, NS>::type V;
-    const int64_t z = blockIdx.z;
-    const jh_dev_block b = blocks[z];
+    const int64_t i = blockIdx.z, j = blockIdx.y;
+    const jh_dev_block b = blocks[i + j * nrow];
     if (b.kind != JH_OP_DENSE) return;
-    const int64_t ns = (row_off[z + 1] - row_off[z]) * E;
+    const int64_t ns = (row_off[i + 1] - row_off[i]) * E, nc = col_off[j + 1] - col_off[j];
     const int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * NS;
     if (s >= ns) return;
+    const S *x = m + col_off[j] * E;
     V acc = (V)(S)0;
     const S *col = (const S *)b.coeff + s;
-#pragma unroll 4
-    for (int64_t c = 0; c < nc; c++, col += ns) {                               // columns in order, product rounded then added: the sequential loop's bits
+    // columns in order, product rounded then added -- the sequential loop's bits; sixteen columns' loads in flight (the adds are
+    // serial by definition, the loads need not be: a 384-row child has 96 active lanes, latency is all there is to hide)
+    int64_t c = 0;
+    for (; c + 16 <= nc; c += 16) {
+        V a[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) a[k] = __builtin_nontemporal_load(reinterpret_cast<const V *>(col + (int64_t)k * ns));
+        col += 16 * ns;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if constexpr (E == 1) {
+                acc = acc + a[k] * (V)x[c + k];
+            } else {
+                const S xr = x[2 * (c + k)], xi = x[2 * (c + k) + 1];
+                V p;
+#pragma unroll
+                for (int e = 0; e < NS; e += 2) {
+                    p[e] = a[k][e] * xr - a[k][e + 1] * xi;
+                    p[e + 1] = a[k][e] * xi + a[k][e + 1] * xr;
+                }
+                acc = acc + p;
+            }
+        }
+    }
+    for (; c < nc; c++, col += ns) {
         V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col));
         if constexpr (E == 1) {
             acc = acc + a * (V)x[c];
@@ -690,30 +714,28 @@ __global__ __launch_bounds__(256) void k_gemv_rows_mixed(const jh_dev_block *__r
             acc = acc + p;
         }
     }
-    *reinterpret_cast<V *>(out + row_off[z] * E + s) = acc;
+    *reinterpret_cast<V *>(slabs + (j * slab_stride + row_off[i]) * E + s) = acc;
 }
 
-// adjoint: child (z, this column)' d_z, one wave per (matrix column, row chunk), fp64 wave reduction; with ONE row chunk the column
-// sum is rounded and stored at once (direct != null: slab z), else the partial sums go to `partial` for k_store_cols_mixed
+// adjoint: child (i, j)' d_i, one wave per matrix column, fp64 wave reduction, rounded and stored in slab i at column j's elements
 template <typename S, int E, int NS>
-__global__ __launch_bounds__(256) void k_gemv_cols_mixed(const jh_dev_block *__restrict__ blocks, int64_t nc, const S *__restrict__ d,
-                                                         const int64_t *__restrict__ row_off, int64_t rows_per_chunk, double *__restrict__ partial,
-                                                         S *__restrict__ direct, int64_t slab_stride)
+__global__ __launch_bounds__(256) void k_gemv_cols_mixed(const jh_dev_block *__restrict__ blocks, int64_t nrow, const S *__restrict__ d,
+                                                         S *__restrict__ slabs, int64_t slab_stride, const int64_t *__restrict__ row_off,
+                                                         const int64_t *__restrict__ col_off)
 {
     typedef typename vec_of<S, NS>::type V;
+    const int64_t i = blockIdx.z, j = blockIdx.y;
+    const jh_dev_block b = blocks[i + j * nrow];
+    if (b.kind != JH_OP_DENSE) return;
+    const int64_t nc = col_off[j + 1] - col_off[j];
     const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= nc) return;
     const int lane = threadIdx.x & 63;
-    const int64_t z = blockIdx.z;
-    const jh_dev_block b = blocks[z];
-    if (b.kind != JH_OP_DENSE) return;
-    const int64_t ns = (row_off[z + 1] - row_off[z]) * E;
-    const int64_t s0 = (int64_t)blockIdx.y * rows_per_chunk * E;
-    const int64_t s1 = s0 + rows_per_chunk * E < ns ? s0 + rows_per_chunk * E : ns;
+    const int64_t ns = (row_off[i + 1] - row_off[i]) * E;
     const S *col = (const S *)b.coeff + c * ns;
-    const S *x = d + row_off[z] * E;
+    const S *x = d + row_off[i] * E;
     double sr = 0.0, si = 0.0;
-    for (int64_t s = s0 + (int64_t)lane * NS; s < s1; s += 64 * NS) {
+    for (int64_t s = (int64_t)lane * NS; s < ns; s += 64 * NS) {
         V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col + s));
         V xv = *reinterpret_cast<const V *>(x + s);
         if constexpr (E == 1) {
@@ -737,83 +759,38 @@ __global__ __launch_bounds__(256) void k_gemv_cols_mixed(const jh_dev_block *__r
         if (E == 2) si += __shfl_down(si, off, 64);
     }
     if (lane == 0) {
-        if (direct) {
-            S *o = direct + (z * slab_stride + c) * E;
-            o[0] = (S)sr;
-            if (E == 2) o[1] = (S)si;
-        } else {
-            double *p = partial + ((z * gridDim.y + blockIdx.y) * nc + c) * 2;
-            p[0] = sr;
-            p[1] = si;
-        }
+        S *o = slabs + (i * slab_stride + col_off[j] + c) * E;
+        o[0] = (S)sr;
+        if (E == 2) o[1] = (S)si;
     }
 }
 
 template <typename S, int E>
-__global__ void k_store_cols_mixed(const jh_dev_block *__restrict__ blocks, const double *__restrict__ partial, int64_t nc, int nchunks,
-                                   S *__restrict__ slabs, int64_t slab_stride)
+int gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64_t max_nr, int64_t max_nc, void *slabs, int64_t slab_stride,
+                   const void *x, int adjoint, bool aligned, const int64_t *dev_row_off, const int64_t *dev_col_off)
 {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x, z = blockIdx.y;
-    if (c >= nc || blocks[z].kind != JH_OP_DENSE) return;
-    double sr = 0.0, si = 0.0;
-    const double *p = partial + (z * nchunks * nc + c) * 2;
-    for (int k = 0; k < nchunks; k++) { sr += p[(int64_t)k * nc * 2]; si += p[(int64_t)k * nc * 2 + 1]; }
-    S *o = slabs + (z * slab_stride + c) * E;
-    o[0] = (S)sr;
-    if (E == 2) o[1] = (S)si;
-}
-
-// forward: out (slab j, laid out like the range vector) ; adjoint: out = slab 0 at this column's first element, slab z at + z * slab_stride
-template <typename S, int E>
-int gemv_mixed_column(const jh_dev_block *col_blocks, int64_t nrow, int64_t max_nr, int64_t ndense, double max_child_bytes, int64_t nc, void *out,
-                      int64_t slab_stride, const void *x, int adjoint, bool aligned, const int64_t *dev_row_off)
-{
-    jh_context &c = jh_ctx();
-    hipStream_t st = c.stream;
+    hipStream_t st = jh_ctx().stream;
     constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
-    const bool vec_ok = aligned && ((((uintptr_t)x) | ((uintptr_t)out)) & 15u) == 0;
+    const bool vec_ok = aligned && ((((uintptr_t)x) | ((uintptr_t)slabs)) & 15u) == 0;
     if (!adjoint) {
         const int NS = vec_ok ? NSV : E;
         const int64_t row_wgs = (max_nr * E / NS + 255) / 256;
         if (vec_ok)
-            hipLaunchKernelGGL((k_gemv_rows_mixed<S, E, NSV>), dim3((unsigned)row_wgs, 1, (unsigned)nrow), dim3(256), 0, st, col_blocks, nc, (const S *)x,
-                               (S *)out, dev_row_off);
+            hipLaunchKernelGGL((k_gemv_rows_mixed<S, E, NSV>), dim3((unsigned)row_wgs, (unsigned)ncol, (unsigned)nrow), dim3(256), 0, st, blocks, nrow,
+                               (const S *)x, (S *)slabs, slab_stride, dev_row_off, dev_col_off);
         else
-            hipLaunchKernelGGL((k_gemv_rows_mixed<S, E, E>), dim3((unsigned)row_wgs, 1, (unsigned)nrow), dim3(256), 0, st, col_blocks, nc, (const S *)x,
-                               (S *)out, dev_row_off);
-        JH_CHECK_HIP(hipGetLastError());
-        return JH_OK;
+            hipLaunchKernelGGL((k_gemv_rows_mixed<S, E, E>), dim3((unsigned)row_wgs, (unsigned)ncol, (unsigned)nrow), dim3(256), 0, st, blocks, nrow,
+                               (const S *)x, (S *)slabs, slab_stride, dev_row_off, dev_col_off);
+    } else {
+        const int64_t col_wgs = (max_nc + 3) / 4;
+        if (vec_ok)
+            hipLaunchKernelGGL((k_gemv_cols_mixed<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)ncol, (unsigned)nrow), dim3(256), 0, st, blocks, nrow,
+                               (const S *)x, (S *)slabs, slab_stride, dev_row_off, dev_col_off);
+        else
+            hipLaunchKernelGGL((k_gemv_cols_mixed<S, E, E>), dim3((unsigned)col_wgs, (unsigned)ncol, (unsigned)nrow), dim3(256), 0, st, blocks, nrow,
+                               (const S *)x, (S *)slabs, slab_stride, dev_row_off, dev_col_off);
     }
-    const int64_t col_wgs = (nc + 3) / 4;
-    int64_t nchunks = 1;                                                       // split the rows only while big children leave the chip empty
-    if (max_child_bytes >= (double)(1 << 20) && col_wgs * ndense < 2048) {
-        nchunks = (2048 + col_wgs * ndense - 1) / (col_wgs * ndense);
-        const int64_t maxc = (max_nr + 4095) / 4096;
-        if (nchunks > maxc) nchunks = maxc;
-        if (nchunks < 1) nchunks = 1;
-    }
-    int64_t rpc = (max_nr + nchunks - 1) / nchunks;
-    rpc = (rpc + 3) / 4 * 4;
-    if (rpc < 4) rpc = 4;
-    nchunks = max_nr ? (max_nr + rpc - 1) / rpc : 1;
-    double *partial = nullptr;
-    if (nchunks > 1) {
-        JH_TRY(jh_ensure_partials(2 * nrow * nchunks * nc));
-        partial = c.part_dev;
-    }
-    S *direct = nchunks > 1 ? nullptr : (S *)out;
-    if (vec_ok)
-        hipLaunchKernelGGL((k_gemv_cols_mixed<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)nrow), dim3(256), 0, st, col_blocks, nc,
-                           (const S *)x, dev_row_off, rpc, partial, direct, slab_stride);
-    else
-        hipLaunchKernelGGL((k_gemv_cols_mixed<S, E, E>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)nrow), dim3(256), 0, st, col_blocks, nc,
-                           (const S *)x, dev_row_off, rpc, partial, direct, slab_stride);
     JH_CHECK_HIP(hipGetLastError());
-    if (nchunks > 1) {
-        hipLaunchKernelGGL((k_store_cols_mixed<S, E>), dim3((unsigned)((nc + 255) / 256), (unsigned)nrow), dim3(256), 0, st, col_blocks, partial, nc,
-                           (int)nchunks, (S *)out, slab_stride);
-        JH_CHECK_HIP(hipGetLastError());
-    }
     return JH_OK;
 }
 
@@ -850,17 +827,17 @@ int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64
     return jh_fail(JH_ERR_INVALID, "gemv_batched: unknown dtype %d", dtype);
 }
 
-// the dense children of ONE block column of a mixed operator (see k_gemv_rows_mixed); x: forward m_j, adjoint the whole range vector d
-int jh_launch_gemv_mixed_column(const jh_dev_block *col_blocks, int64_t nrow, int64_t max_nr, int64_t ndense, double max_child_bytes, int64_t nc,
-                                int dtype, void *out, int64_t slab_stride, const void *x, int adjoint, bool aligned, const int64_t *dev_row_off)
+// every dense child of a mixed operator in one launch (see k_gemv_rows_mixed); x: forward the domain vector, adjoint the range vector
+int jh_launch_gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64_t max_nr, int64_t max_nc, int dtype, void *slabs,
+                             int64_t slab_stride, const void *x, int adjoint, bool aligned, const int64_t *dev_row_off, const int64_t *dev_col_off)
 {
     switch (dtype) {
-    case JH_F32: return gemv_mixed_column<float, 1>(col_blocks, nrow, max_nr, ndense, max_child_bytes, nc, out, slab_stride, x, adjoint, aligned, dev_row_off);
-    case JH_F64: return gemv_mixed_column<double, 1>(col_blocks, nrow, max_nr, ndense, max_child_bytes, nc, out, slab_stride, x, adjoint, aligned, dev_row_off);
-    case JH_C32: return gemv_mixed_column<float, 2>(col_blocks, nrow, max_nr, ndense, max_child_bytes, nc, out, slab_stride, x, adjoint, aligned, dev_row_off);
-    case JH_C64: return gemv_mixed_column<double, 2>(col_blocks, nrow, max_nr, ndense, max_child_bytes, nc, out, slab_stride, x, adjoint, aligned, dev_row_off);
+    case JH_F32: return gemv_mixed_all<float, 1>(blocks, nrow, ncol, max_nr, max_nc, slabs, slab_stride, x, adjoint, aligned, dev_row_off, dev_col_off);
+    case JH_F64: return gemv_mixed_all<double, 1>(blocks, nrow, ncol, max_nr, max_nc, slabs, slab_stride, x, adjoint, aligned, dev_row_off, dev_col_off);
+    case JH_C32: return gemv_mixed_all<float, 2>(blocks, nrow, ncol, max_nr, max_nc, slabs, slab_stride, x, adjoint, aligned, dev_row_off, dev_col_off);
+    case JH_C64: return gemv_mixed_all<double, 2>(blocks, nrow, ncol, max_nr, max_nc, slabs, slab_stride, x, adjoint, aligned, dev_row_off, dev_col_off);
     }
-    return jh_fail(JH_ERR_INVALID, "gemv_mixed_column: unknown dtype %d", dtype);
+    return jh_fail(JH_ERR_INVALID, "gemv_mixed_all: unknown dtype %d", dtype);
 }
 
 extern "C" int jh_gemv(const void *A_device, int64_t nr, int64_t nc, int dtype, jh_bvec *y, const jh_bvec *x, int adjoint)

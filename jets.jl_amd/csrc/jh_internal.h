@@ -85,7 +85,7 @@ struct jh_context {
     int64_t grid_diag = 1;             // knob: M x K grids of plain diagonals on the branch-free kernel (0: the general kernels)
     int64_t grid_tile = 1;             // knob: ... register-tiled (k_grid_tile: R lines x one tile per workgroup): 1 automatic R, 2 / 4 / 8 that R, 0: k_grid_diag
     int64_t sum_group = 8;             // knob: terms of a fused JetSum per launch (8; 4 = round 2's grouping, for A/B)
-    int64_t dense_mixed = 1;           // knob: operators mixing big dense children with other kinds: per-column batches + one combine launch (0: the per-block loop)
+    int64_t dense_mixed = 1;           // knob: operators mixing big dense children with other kinds: one batched launch + one combine launch (0: the per-block loop)
     int64_t last_launches = 0;         // read-only: kernel launches of the most recent dense_mixed forward / adjoint
     int64_t wide_twin = 1;             // knob: wide elementwise operators on their tall twin: 0 never (general kernels), 1 adjoint always + forward from 16 MiB blocks, 2 both always (tests)
     const double *step_coef_dev = nullptr;   // internal, set around the calls of the graph-captured LSQR loop: the one-pass step reads (alpha, beta) from
@@ -190,7 +190,7 @@ struct jh_blockop {
     bool dense_aligned = false;              // ... and every matrix pointer on a 16-byte boundary
     bool launch_bound = true;                // the per-block loop of an operator with DENSE blocks is replayed as a hipGraph (it pays for small children)
     bool dense_mixed = false;                // DENSE blocks (none adjointed) next to other kinds or of differing shapes, too big for the one-launch loop: one
-                                             // batched launch per block column + one launch of the general kernels (dense_mixed_fwd / _adj)
+                                             // batched launch for all dense children + one launch of the general kernels (dense_mixed_apply)
     bool dense_mixed_aligned = false;        // ... every dense matrix, row length and row offset on 16 bytes
     bool small_loop = false;                 // DENSE blocks (adjointed or not) mixed with elementwise kinds, every matrix small: the whole loop in ONE launch (k_block_loop_small)
     int64_t *dev_dims = nullptr;             // nrow*ncol x {nr, nc} of the described operators (small_loop only)
@@ -250,9 +250,9 @@ int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const doub
 int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, const void *x, int adjoint);
 int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, int dtype, void *y, const void *x,
                            int adjoint, bool aligned, bool wide, const int64_t *dev_row_off = nullptr);   // jh_dense.hip: every child of a tall (or wide) operator of uniform dense blocks at once
-int jh_launch_gemv_mixed_column(const jh_dev_block *col_blocks, int64_t nrow, int64_t max_nr, int64_t ndense, double max_child_bytes, int64_t nc,
-                                int dtype, void *out, int64_t slab_stride, const void *x, int adjoint, bool aligned,
-                                const int64_t *dev_row_off);       // jh_dense.hip: the dense children of one block column of a mixed operator
+int jh_launch_gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64_t max_nr, int64_t max_nc, int dtype, void *slabs,
+                             int64_t slab_stride, const void *x, int adjoint, bool aligned, const int64_t *dev_row_off,
+                             const int64_t *dev_col_off);           // jh_dense.hip: every dense child of a mixed operator in one launch
 int jh_ensure_scratch(size_t bytes, void **out);
 extern "C" int jh_comm_exists(int *yes);  // jh_comm.hip (internal): the current context's communicator: 0 none, 1 of jh_comm_init_rank, 2 member of a single-process team
 extern "C" int jh_comm_destroy(void);   // jh_comm.hip; jh_shutdown tears the communicator down first   // growable device scratch (block-loop temporaries)
