@@ -2682,12 +2682,14 @@ int loop_adj(const jh_blockop *op, void *m, const void *d)           // JetBlock
 }
 
 // ---- operators that mix BIG dense children with other kinds (round 3; the per-block loop's launch-bound corner) ------------------
-// Forward: ONE batched GEMV launch leaves A_ij m_j of every dense child in slab j (jh_dense.hip: k_gemv_rows_mixed, the sequential
-// column loop: the bits of the per-child kernel), then ONE launch of the general forward kernel walks every block row in the
-// reference's order (1020-1024), `_d .+=` into d as found, taking a dense block's term from its slab -- the products and the
-// additions of the reference's loop in its order, so bit-identical to the per-block loop wherever that loop's child kernel keeps one
-// column chunk.  Adjoint: one launch leaves A_ij' d_i (fp64 wave reduction, rounded like mtmp) in slab i, one launch of the general
-// adjoint kernel sums every block column in row order (1042-1049).  Two launches per mul!.  Exception: when the dense children are few
+// Forward: ONE batched GEMV launch leaves A_ij m_j of every un-adjointed dense child in slab j (jh_dense.hip: k_gemv_rows_mixed, the
+// sequential column loop: the bits of the per-child kernel) -- and one more, of the wave-reduction kernel, B' m_j of the ADJOINTED
+// ones (block = B'), when there are any -- then ONE launch of the general forward kernel walks every block row in the reference's
+// order (1020-1024), `_d .+=` into d as found, taking a dense block's term from its slab: the products and the additions of the
+// reference's loop in its order, so bit-identical to the per-block loop wherever that loop's child kernel keeps one column chunk.
+// Adjoint: the same with the two kernels' roles swapped (an un-adjointed child needs B' d_i: fp64 wave reduction, rounded like mtmp; an
+// adjointed one B d_i: sequential), slab i, and the general adjoint kernel summing every block column in row order (1042-1049).
+// Two launches per mul!, three when adjointed and un-adjointed dense children meet.  Exception: when the dense children are few
 // AND big (the batched launch would leave the chip empty; the per-child kernel splits a big child's columns / rows over the grid
 // instead) they run child by child into the same slabs -- those operators are not launch-bound.
 template <typename S, int E>
@@ -2702,36 +2704,39 @@ int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool tran
     const int64_t nslabs = transposed ? op->nrow : op->ncol;
     void *slabs = nullptr;
     JH_TRY(jh_ensure_scratch((size_t)nslabs * (size_t)stride * es + 16, &slabs));
-    int64_t launches = 0, ndense = 0, max_nr = 0, max_nc = 0, wgs = 0;
+    // which kernel a dense child needs in this direction: block = B (un-adjointed) or B' (adjointed), the operator's adjoint flips it;
+    // B x is the sequential rows kernel, B' x the wave-reduction cols kernel
+    int64_t launches = 0, ndense = 0, rows_max_out = 0, cols_max_out = 0, wgs = 0;
     double max_bytes = 0.0;
-    for (const auto &b : op->blocks) {
-        if (b.kind != JH_OP_DENSE) continue;
-        ndense++;
-        if (b.nr > max_nr) max_nr = b.nr;
-        if (b.nc > max_nc) max_nc = b.nc;
-        const double by = (double)b.nr * (double)b.nc * (double)es;
-        if (by > max_bytes) max_bytes = by;
-        wgs += transposed ? (b.nc + 3) / 4 : (b.nr * (int64_t)es / 16 + 255) / 256;
-    }
-    if (ndense && max_nr > 0 && max_nc > 0) {
+    for (int64_t j = 0; j < op->ncol; j++)
+        for (int64_t i = 0; i < op->nrow; i++) {
+            const jh_block_desc &b = op->blocks[(size_t)(i + j * op->nrow)];
+            if (b.kind != JH_OP_DENSE) continue;
+            ndense++;
+            const int64_t out_len = transposed ? op->col_len[(size_t)j] : op->row_len[(size_t)i];
+            const bool rows_pass = (b.adjoint != 0) == transposed;
+            if (rows_pass) { if (out_len > rows_max_out) rows_max_out = out_len; wgs += (out_len * (int64_t)es / 16 + 255) / 256; }
+            else { if (out_len > cols_max_out) cols_max_out = out_len; wgs += (out_len + 3) / 4; }
+            const double by = (double)b.nr * (double)b.nc * (double)es;
+            if (by > max_bytes) max_bytes = by;
+        }
+    if (ndense && (rows_max_out > 0 || cols_max_out > 0)) {
         if (max_bytes >= (double)(8 << 20) && wgs < 2048) {                     // few BIG children: child by child (column / row split inside); measured
                                                                                 // crossover 4-16 MiB per child (profiles/bench_dense_mixed_r03.txt)
             for (int64_t j = 0; j < op->ncol; j++)
                 for (int64_t i = 0; i < op->nrow; i++) {
                     const jh_block_desc &b = op->blocks[(size_t)(i + j * op->nrow)];
                     if (b.kind != JH_OP_DENSE) continue;
-                    if (!transposed)
-                        JH_TRY(jh_launch_gemv(b.coeff, b.nr, b.nc, op->dtype, (char *)slabs + ((size_t)j * (size_t)stride + (size_t)op->row_off[(size_t)i]) * es,
-                                              (const char *)in + (size_t)op->col_off[(size_t)j] * es, 0));
-                    else
-                        JH_TRY(jh_launch_gemv(b.coeff, b.nr, b.nc, op->dtype, (char *)slabs + ((size_t)i * (size_t)stride + (size_t)op->col_off[(size_t)j]) * es,
-                                              (const char *)in + (size_t)op->row_off[(size_t)i] * es, 1));
+                    const bool adj = (b.adjoint != 0) != transposed;             // (op')' = op
+                    char *o = (char *)slabs + (transposed ? ((size_t)i * (size_t)stride + (size_t)op->col_off[(size_t)j]) : ((size_t)j * (size_t)stride + (size_t)op->row_off[(size_t)i])) * es;
+                    const char *x = (const char *)in + (size_t)(transposed ? op->row_off[(size_t)i] : op->col_off[(size_t)j]) * es;
+                    JH_TRY(jh_launch_gemv(b.coeff, b.nr, b.nc, op->dtype, o, x, adj ? 1 : 0));
                     launches++;
                 }
         } else {
-            JH_TRY(jh_launch_gemv_mixed_all(op->dev_blocks, op->nrow, op->ncol, max_nr, max_nc, op->dtype, slabs, stride, in, transposed ? 1 : 0,
+            JH_TRY(jh_launch_gemv_mixed_all(op->dev_blocks, op->nrow, op->ncol, rows_max_out, cols_max_out, op->dtype, slabs, stride, in, transposed ? 1 : 0,
                                             op->dense_mixed_aligned, op->dev_row_off, op->dev_col_off));
-            launches++;
+            launches += (rows_max_out > 0) + (cols_max_out > 0);
         }
     }
     // the combine: one launch of the general kernel (scalar form: the vectors are small beside the matrices), XCD-aware decode as usual
@@ -3000,8 +3005,8 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
     //                adjoint flags): for SMALL operators -- every matrix <= 256 KiB (beyond that the per-child kernels win,
     //                profiles/bench_graphs_r02.txt) and at most 512 sequential products per output element (a 64 x 2 grid of 256^2
     //                children ran its adjoint in 1.0 ms there: 16 384 dependent loads per thread; profiles/bench_dense_mixed_r03.txt)
-    //   dense_mixed  one batched launch for all dense children + one combine launch (dense_mixed_apply): everything else, as long as no
-    //                dense child is adjointed
+    //   dense_mixed  one (two, with adjointed AND un-adjointed children) batched launch for all dense children + one combine launch
+    //                (dense_mixed_apply): everything else
     if (!op->elementwise && !op->dense_batch && !op->dense_batch_ragged && !op->dense_batch_grid && !op->dense_batch_wide && nrow <= 65535 && ncol <= 65535) {
         const size_t es = jh_dtype_size(dtype);
         bool small = true, eligible = true, aligned = true;
@@ -3011,17 +3016,20 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
                 const jh_block_desc &b = op->blocks[(size_t)(i + j * nrow)];
                 if (b.kind != JH_OP_DENSE) continue;
                 if ((double)b.nr * (double)b.nc * (double)es > (double)(256 << 10)) small = false;
-                if (b.adjoint || b.nr != op->row_len[(size_t)i] || b.nc != op->col_len[(size_t)j]) eligible = false;
-                if ((((uintptr_t)b.coeff) & 15u) || ((size_t)b.nr * es) % 16 || ((size_t)op->row_off[(size_t)i] * es) % 16) aligned = false;
+                if (b.adjoint ? (b.nc != op->row_len[(size_t)i] || b.nr != op->col_len[(size_t)j])                   // block = B': B is col_len x row_len
+                              : (b.nr != op->row_len[(size_t)i] || b.nc != op->col_len[(size_t)j])) eligible = false;
+                if ((((uintptr_t)b.coeff) & 15u) || ((size_t)b.nr * es) % 16) aligned = false;
                 fwd_work[(size_t)i] += b.adjoint ? b.nr : b.nc;
                 adj_work[(size_t)j] += b.adjoint ? b.nc : b.nr;
             }
         for (int64_t j = 0; j < ncol; j++)
-            if (((size_t)op->col_off[(size_t)j] * es) % 16) aligned = false;                         // (the adjoint's slab offsets)
+            if (((size_t)op->col_off[(size_t)j] * es) % 16) aligned = false;                         // (inputs and slab offsets of both directions)
+        for (int64_t i = 0; i < nrow; i++)
+            if (((size_t)op->row_off[(size_t)i] * es) % 16) aligned = false;
         int64_t line_work = 0;
         for (int64_t v : fwd_work) line_work = v > line_work ? v : line_work;
         for (int64_t v : adj_work) line_work = v > line_work ? v : line_work;
-        op->small_loop = small && (line_work <= 512 || !eligible);
+        op->small_loop = small && (line_work <= 512 || !eligible);           // (the one-launch loop is bit-exact in the adjoint too: kept for small operators)
         op->dense_mixed = eligible && !op->small_loop;
         op->dense_mixed_aligned = aligned;
     }

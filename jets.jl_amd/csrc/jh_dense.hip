@@ -660,23 +660,29 @@ int gemv(const void *A, int64_t nr, int64_t nc, void *y, const void *x, int adjo
 // the reference's dtmp / mtmp, in a slab (forward: slab j at row i's elements of the range; adjoint: slab i at column j's elements
 // of the domain).  ONE launch of the general kernels then walks every output line in the reference's order, taking a dense block's
 // term from its slab (jh_blockop.hip: dense_mixed_apply): two launches per mul! instead of up to 2 M K.
+// y = B x for the children this pass owns (B column-major, its own leading dimension).  `transposed` = the pass belongs to the
+// operator's ADJOINT: then it takes the ADJOINTED children -- block (i, j) = B', whose adjoint is B: B is col_len[j] x row_len[i],
+// reads d_i, writes slab i at column j's elements -- while in the forward it takes the un-adjointed ones (B = row_len[i] x col_len[j],
+// reads m_j, writes slab j at row i's elements).  Columns in order, product rounded then added: the sequential loop's bits.
 template <typename S, int E, int NS>
-__global__ __launch_bounds__(256) void k_gemv_rows_mixed(const jh_dev_block *__restrict__ blocks, int64_t nrow, const S *__restrict__ m,
+__global__ __launch_bounds__(256) void k_gemv_rows_mixed(const jh_dev_block *__restrict__ blocks, int64_t nrow, const S *__restrict__ in,
                                                          S *__restrict__ slabs, int64_t slab_stride, const int64_t *__restrict__ row_off,
-                                                         const int64_t *__restrict__ col_off)
+                                                         const int64_t *__restrict__ col_off, int transposed)
 {
     typedef typename vec_of<S, NS>::type V;
     const int64_t i = blockIdx.z, j = blockIdx.y;
     const jh_dev_block b = blocks[i + j * nrow];
-    if (b.kind != JH_OP_DENSE) return;
-    const int64_t ns = (row_off[i + 1] - row_off[i]) * E, nc = col_off[j + 1] - col_off[j];
+    if (b.kind != JH_OP_DENSE || (b.adjoint != 0) != (transposed != 0)) return;
+    const int64_t rl = row_off[i + 1] - row_off[i], cl = col_off[j + 1] - col_off[j];
+    const int64_t ns = (transposed ? cl : rl) * E, nc = transposed ? rl : cl;     // B's rows (as scalars) and columns
     const int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * NS;
     if (s >= ns) return;
-    const S *x = m + col_off[j] * E;
+    const S *x = in + (transposed ? row_off[i] : col_off[j]) * E;
+    S *out = slabs + (transposed ? i * slab_stride + col_off[j] : j * slab_stride + row_off[i]) * E;
     V acc = (V)(S)0;
     const S *col = (const S *)b.coeff + s;
-    // columns in order, product rounded then added -- the sequential loop's bits; sixteen columns' loads in flight (the adds are
-    // serial by definition, the loads need not be: a 384-row child has 96 active lanes, latency is all there is to hide)
+    // sixteen columns' loads in flight (the adds are serial by definition, the loads need not be: a 384-row child has 96 active
+    // lanes, latency is all there is to hide)
     int64_t c = 0;
     for (; c + 16 <= nc; c += 16) {
         V a[16];
@@ -714,26 +720,28 @@ __global__ __launch_bounds__(256) void k_gemv_rows_mixed(const jh_dev_block *__r
             acc = acc + p;
         }
     }
-    *reinterpret_cast<V *>(slabs + (j * slab_stride + row_off[i]) * E + s) = acc;
+    *reinterpret_cast<V *>(out + s) = acc;
 }
 
-// adjoint: child (i, j)' d_i, one wave per matrix column, fp64 wave reduction, rounded and stored in slab i at column j's elements
+// y = B' x for the children this pass owns: one wave per column of B, fp64 wave reduction, rounded and stored.  In the operator's
+// adjoint (transposed) these are the UN-adjointed children (B = row_len[i] x col_len[j], reads d_i, slab i at column j's elements); in
+// the forward the ADJOINTED ones (block = B', B = col_len[j] x row_len[i], reads m_j, slab j at row i's elements).
 template <typename S, int E, int NS>
-__global__ __launch_bounds__(256) void k_gemv_cols_mixed(const jh_dev_block *__restrict__ blocks, int64_t nrow, const S *__restrict__ d,
+__global__ __launch_bounds__(256) void k_gemv_cols_mixed(const jh_dev_block *__restrict__ blocks, int64_t nrow, const S *__restrict__ in,
                                                          S *__restrict__ slabs, int64_t slab_stride, const int64_t *__restrict__ row_off,
-                                                         const int64_t *__restrict__ col_off)
+                                                         const int64_t *__restrict__ col_off, int transposed)
 {
     typedef typename vec_of<S, NS>::type V;
     const int64_t i = blockIdx.z, j = blockIdx.y;
     const jh_dev_block b = blocks[i + j * nrow];
-    if (b.kind != JH_OP_DENSE) return;
-    const int64_t nc = col_off[j + 1] - col_off[j];
+    if (b.kind != JH_OP_DENSE || (b.adjoint != 0) == (transposed != 0)) return;
+    const int64_t rl = row_off[i + 1] - row_off[i], cl = col_off[j + 1] - col_off[j];
+    const int64_t ns = (transposed ? rl : cl) * E, nc = transposed ? cl : rl;     // B's rows (as scalars) and columns
     const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= nc) return;
     const int lane = threadIdx.x & 63;
-    const int64_t ns = (row_off[i + 1] - row_off[i]) * E;
     const S *col = (const S *)b.coeff + c * ns;
-    const S *x = d + row_off[i] * E;
+    const S *x = in + (transposed ? row_off[i] : col_off[j]) * E;
     double sr = 0.0, si = 0.0;
     for (int64_t s = (int64_t)lane * NS; s < ns; s += 64 * NS) {
         V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col + s));
@@ -759,38 +767,42 @@ __global__ __launch_bounds__(256) void k_gemv_cols_mixed(const jh_dev_block *__r
         if (E == 2) si += __shfl_down(si, off, 64);
     }
     if (lane == 0) {
-        S *o = slabs + (i * slab_stride + col_off[j] + c) * E;
+        S *o = slabs + ((transposed ? i * slab_stride + col_off[j] : j * slab_stride + row_off[i]) + c) * E;
         o[0] = (S)sr;
         if (E == 2) o[1] = (S)si;
     }
 }
 
+// rows_pass / cols_pass: which of the two kernels have children to process in this direction (jh_blockop.hip knows); max_out / max_in:
+// the largest output / input length over those children (grid sizing)
 template <typename S, int E>
-int gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64_t max_nr, int64_t max_nc, void *slabs, int64_t slab_stride,
-                   const void *x, int adjoint, bool aligned, const int64_t *dev_row_off, const int64_t *dev_col_off)
+int gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64_t rows_max_out, int64_t cols_max_out, void *slabs, int64_t slab_stride,
+                   const void *x, int transposed, bool aligned, const int64_t *dev_row_off, const int64_t *dev_col_off)
 {
     hipStream_t st = jh_ctx().stream;
     constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
     const bool vec_ok = aligned && ((((uintptr_t)x) | ((uintptr_t)slabs)) & 15u) == 0;
-    if (!adjoint) {
+    if (rows_max_out > 0) {
         const int NS = vec_ok ? NSV : E;
-        const int64_t row_wgs = (max_nr * E / NS + 255) / 256;
+        const int64_t row_wgs = (rows_max_out * E / NS + 255) / 256;
         if (vec_ok)
             hipLaunchKernelGGL((k_gemv_rows_mixed<S, E, NSV>), dim3((unsigned)row_wgs, (unsigned)ncol, (unsigned)nrow), dim3(256), 0, st, blocks, nrow,
-                               (const S *)x, (S *)slabs, slab_stride, dev_row_off, dev_col_off);
+                               (const S *)x, (S *)slabs, slab_stride, dev_row_off, dev_col_off, transposed);
         else
             hipLaunchKernelGGL((k_gemv_rows_mixed<S, E, E>), dim3((unsigned)row_wgs, (unsigned)ncol, (unsigned)nrow), dim3(256), 0, st, blocks, nrow,
-                               (const S *)x, (S *)slabs, slab_stride, dev_row_off, dev_col_off);
-    } else {
-        const int64_t col_wgs = (max_nc + 3) / 4;
+                               (const S *)x, (S *)slabs, slab_stride, dev_row_off, dev_col_off, transposed);
+        JH_CHECK_HIP(hipGetLastError());
+    }
+    if (cols_max_out > 0) {
+        const int64_t col_wgs = (cols_max_out + 3) / 4;
         if (vec_ok)
             hipLaunchKernelGGL((k_gemv_cols_mixed<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)ncol, (unsigned)nrow), dim3(256), 0, st, blocks, nrow,
-                               (const S *)x, (S *)slabs, slab_stride, dev_row_off, dev_col_off);
+                               (const S *)x, (S *)slabs, slab_stride, dev_row_off, dev_col_off, transposed);
         else
             hipLaunchKernelGGL((k_gemv_cols_mixed<S, E, E>), dim3((unsigned)col_wgs, (unsigned)ncol, (unsigned)nrow), dim3(256), 0, st, blocks, nrow,
-                               (const S *)x, (S *)slabs, slab_stride, dev_row_off, dev_col_off);
+                               (const S *)x, (S *)slabs, slab_stride, dev_row_off, dev_col_off, transposed);
+        JH_CHECK_HIP(hipGetLastError());
     }
-    JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
 
@@ -827,15 +839,17 @@ int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64
     return jh_fail(JH_ERR_INVALID, "gemv_batched: unknown dtype %d", dtype);
 }
 
-// every dense child of a mixed operator in one launch (see k_gemv_rows_mixed); x: forward the domain vector, adjoint the range vector
-int jh_launch_gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64_t max_nr, int64_t max_nc, int dtype, void *slabs,
-                             int64_t slab_stride, const void *x, int adjoint, bool aligned, const int64_t *dev_row_off, const int64_t *dev_col_off)
+// every dense child of a mixed operator: one launch of the sequential (rows) kernel for the children whose product in this direction is
+// B x, one of the wave-reduction (cols) kernel for those where it is B' x (see k_gemv_rows_mixed); x: forward the domain vector, adjoint the
+// range vector; rows_max_out / cols_max_out = 0: that pass has no children
+int jh_launch_gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64_t rows_max_out, int64_t cols_max_out, int dtype, void *slabs,
+                             int64_t slab_stride, const void *x, int transposed, bool aligned, const int64_t *dev_row_off, const int64_t *dev_col_off)
 {
     switch (dtype) {
-    case JH_F32: return gemv_mixed_all<float, 1>(blocks, nrow, ncol, max_nr, max_nc, slabs, slab_stride, x, adjoint, aligned, dev_row_off, dev_col_off);
-    case JH_F64: return gemv_mixed_all<double, 1>(blocks, nrow, ncol, max_nr, max_nc, slabs, slab_stride, x, adjoint, aligned, dev_row_off, dev_col_off);
-    case JH_C32: return gemv_mixed_all<float, 2>(blocks, nrow, ncol, max_nr, max_nc, slabs, slab_stride, x, adjoint, aligned, dev_row_off, dev_col_off);
-    case JH_C64: return gemv_mixed_all<double, 2>(blocks, nrow, ncol, max_nr, max_nc, slabs, slab_stride, x, adjoint, aligned, dev_row_off, dev_col_off);
+    case JH_F32: return gemv_mixed_all<float, 1>(blocks, nrow, ncol, rows_max_out, cols_max_out, slabs, slab_stride, x, transposed, aligned, dev_row_off, dev_col_off);
+    case JH_F64: return gemv_mixed_all<double, 1>(blocks, nrow, ncol, rows_max_out, cols_max_out, slabs, slab_stride, x, transposed, aligned, dev_row_off, dev_col_off);
+    case JH_C32: return gemv_mixed_all<float, 2>(blocks, nrow, ncol, rows_max_out, cols_max_out, slabs, slab_stride, x, transposed, aligned, dev_row_off, dev_col_off);
+    case JH_C64: return gemv_mixed_all<double, 2>(blocks, nrow, ncol, rows_max_out, cols_max_out, slabs, slab_stride, x, transposed, aligned, dev_row_off, dev_col_off);
     }
     return jh_fail(JH_ERR_INVALID, "gemv_mixed_all: unknown dtype %d", dtype);
 }

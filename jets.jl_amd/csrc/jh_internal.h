@@ -250,9 +250,9 @@ int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const doub
 int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, const void *x, int adjoint);
 int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, int dtype, void *y, const void *x,
                            int adjoint, bool aligned, bool wide, const int64_t *dev_row_off = nullptr);   // jh_dense.hip: every child of a tall (or wide) operator of uniform dense blocks at once
-int jh_launch_gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64_t max_nr, int64_t max_nc, int dtype, void *slabs,
-                             int64_t slab_stride, const void *x, int adjoint, bool aligned, const int64_t *dev_row_off,
-                             const int64_t *dev_col_off);           // jh_dense.hip: every dense child of a mixed operator in one launch
+int jh_launch_gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64_t rows_max_out, int64_t cols_max_out, int dtype, void *slabs,
+                             int64_t slab_stride, const void *x, int transposed, bool aligned, const int64_t *dev_row_off,
+                             const int64_t *dev_col_off);           // jh_dense.hip: every dense child of a mixed operator in one or two launches
 int jh_ensure_scratch(size_t bytes, void **out);
 extern "C" int jh_comm_exists(int *yes);  // jh_comm.hip (internal): the current context's communicator: 0 none, 1 of jh_comm_init_rank, 2 member of a single-process team
 extern "C" int jh_comm_destroy(void);   // jh_comm.hip; jh_shutdown tears the communicator down first   // growable device scratch (block-loop temporaries)

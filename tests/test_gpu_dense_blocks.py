@@ -200,7 +200,8 @@ def test_batched_ragged_tall_dense_children(Jets, oracle, dt, rows, nc):
 
 # ---- round 3: BIG dense children in mixed company -- one batched launch per block column + one combine launch -----------------
 def _mixed_operator(Jets, oracle, dt, layout, row_len, col_len, seed=970):
-    """layout[i][j] in {"dense", "diag", "id", "zero"}; dense children are row_len[i] x col_len[j], the others square."""
+    """layout[i][j] in {"dense", "dense_adj", "diag", "id", "zero"}; dense children are row_len[i] x col_len[j] (an adjointed one is
+    the adjoint of a stored col_len[j] x row_len[i] matrix), the others square."""
     dev_rows, ora_rows = [], []
     for i, row in enumerate(layout):
         drow, orow = [], []
@@ -210,6 +211,10 @@ def _mixed_operator(Jets, oracle, dt, layout, row_len, col_len, seed=970):
                 hA = np.asfortranarray(u01(oracle, dt, seed, i * 16 + j, nr * nc).reshape((nr, nc), order="F"))
                 drow.append(Jets.JopDense(Jets.from_numpy(hA)))
                 orow.append(oracle.Block("dense", nr, nc, coeff=hA))
+            elif kind == "dense_adj":                                   # the block is B' with B stored col_len x row_len
+                hB = np.asfortranarray(u01(oracle, dt, seed, i * 16 + j, nr * nc).reshape((nc, nr), order="F"))
+                drow.append(Jets.JopDense(Jets.from_numpy(hB)).H)
+                orow.append(oracle.Block("dense", nc, nr, coeff=hB, adjoint=True))
             elif kind == "diag":
                 assert nr == nc
                 g = u01(oracle, dt, seed + 1, i * 16 + j, nr)
@@ -240,11 +245,13 @@ def _mixed_shapes(dt):
         "wide": ([["dense", "diag", "zero", "dense", "id"]], [n1], [n2, n1, n1, n1, n1]),
         "ragged_dense_only": ([["dense", "dense"], ["dense", "dense"], ["dense", "dense"]], [n2, n1, n3], [n1, n2]),
         "odd_lengths": ([["id", "dense"], ["dense", "diag"]], [n1 - 3, n1 + 5], [n1 - 3, n1 + 5]),   # nothing 16-byte aligned: the scalar kernels
+        "with_adjointed": ([["dense", "dense_adj", "diag"], ["dense_adj", "zero", "dense"], ["id", "dense", "dense_adj"]],
+                           [n1, n2, n1], [n1, n2, n1]),                                          # both batched kernels in both directions: three launches
         "few_big": ([["dense", "diag"], ["id", "dense"]], [6 * n1, 6 * n1], [6 * n1, 6 * n1]),   # 17-19 MiB children, two of them: child by child
     }
 
 
-MIXED_SHAPES = ["grid3x4", "tall", "wide", "ragged_dense_only", "odd_lengths", "few_big"]
+MIXED_SHAPES = ["grid3x4", "tall", "wide", "ragged_dense_only", "odd_lengths", "with_adjointed", "few_big"]
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -272,19 +279,23 @@ def test_big_dense_children_in_mixed_company(Jets, oracle, dt, shape):
             d = J.from_numpy(np.concatenate(hd), J.range(A))            # dirty
             J.mul_(d, A, m)
             if knob and shape != "few_big":
-                assert 1 <= J.tune_get("last_launches") <= 2, "forward: one batched launch + the combine"
+                assert 1 <= J.tune_get("last_launches") <= (3 if shape == "with_adjointed" else 2), "forward: one batched launch (two with adjointed children) + the combine"
             mt = J.from_numpy(np.concatenate(hmt), J.domain(A)) if K > 1 else J.from_numpy(hmt[0])   # dirty
             J.mul_(mt, A.H, d)
             if knob and shape != "few_big":
-                assert 1 <= J.tune_get("last_launches") <= 2, "adjoint: one batched launch + the combine"
+                assert 1 <= J.tune_get("last_launches") <= (3 if shape == "with_adjointed" else 2), "adjoint: one batched launch (two with adjointed children) + the combine"
             got[knob] = (d.to_numpy(), mt.to_numpy().ravel(order="F"))
         finally:
             J.tune(dense_mixed=1)
     if shape == "few_big":                                             # the per-child kernel splits a big child's columns: tolerance, and the loop's bits
         assert _err(got[1][0], np.concatenate(want_d)) < _tol(dt)
+        assert_bits_equal(got[1][0], got[0][0], f"{shape}: forward vs the per-block loop")
+    elif shape == "with_adjointed":                                    # an adjointed child's forward is B' m: an fp64 wave reduction here and in the loop
+        assert _err(got[1][0], np.concatenate(want_d)) < _tol(dt)
+        assert _err(got[0][0], np.concatenate(want_d)) < _tol(dt)
     else:
         assert_bits_equal(got[1][0], np.concatenate(want_d), f"{shape}: forward vs the oracle's loop")
-    assert_bits_equal(got[1][0], got[0][0], f"{shape}: forward vs the per-block loop")
+        assert_bits_equal(got[1][0], got[0][0], f"{shape}: forward vs the per-block loop")
     assert _err(got[1][1], np.concatenate(want_m)) < _tol(dt), f"{shape}: adjoint"
     assert _err(got[0][1], np.concatenate(want_m)) < _tol(dt)
     # what the reference leaves untouched stays untouched: a block row of zero blocks (forward), a zero block's column of a one-row operator

@@ -95,14 +95,14 @@ for case in range(seed0, seed0 + ncases):
         big = max(row_len) * max(col_len) * np.dtype(dt).itemsize >= (1 << 20)     # a child of 1 MiB or more may have its columns split
         # adjointed dense children / dense next to other kinds, every matrix <= 256 KiB: the one-launch block loop
         # (k_block_loop_small), whose in-thread sequential dots are the oracle's -- forward AND adjoint bit for bit
-        # ... as long as an output element needs at most 512 sequential products (round 3; with more, and no adjointed dense child, the
-        # batched launch + combine launch of dense_mixed_apply takes over: forward still bit-exact, adjoint an fp64 wave reduction)
+        # ... as long as an output element needs at most 512 sequential products (round 3; with more, the batched launches + combine launch
+        # of dense_mixed_apply take over: forward still bit-exact without adjointed children, every B' x an fp64 wave reduction)
         dense_at = [[o.kind == "dense" for o in r_] for r_ in ora]
         line_work = max([sum(col_len[j] for j in range(ncol) if dense_at[i][j]) for i in range(nrow)] +
                         [sum(row_len[i] for i in range(nrow) if dense_at[i][j]) for j in range(ncol)])
         one_launch = (has_adj or flavour >= 0.9) and not uniform and max(row_len) * max(col_len) * np.dtype(dt).itemsize <= (256 << 10) \
             and any(o.kind == "dense" for r_ in ora for o in r_) and not all(o.kind == "dense" and not o.adjoint for r_ in ora for o in r_) \
-            and (has_adj or line_work <= 512)
+            and line_work <= 512
         if one_launch:
             stats["one_launch"] = stats.get("one_launch", 0) + 1
             assert_bits_equal(d.to_numpy(), np.concatenate(ref), "forward (one-launch loop), " + tag)
