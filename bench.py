@@ -22,7 +22,8 @@ child processes, watches their heartbeats and relays the outcome.
           supervisor stops exactly the PIDs it started and runs a FRESH team-mode child instead, and the line says so
           ("launch_mode", "launch_fallback").  A failure after the first collective is a real failure: non-zero exit, no line.
 Workers write heartbeats (phase names) to a file; no heartbeat for BENCH_WATCHDOG_S (120) seconds -- BENCH_WATCHDOG_IMPORT_S
-(300) while python / torch are still being paged in -- stops the job with "rank r stalled in phase p".
+(300) while python / torch are still being paged in and until the first collective has completed (first contact with RCCL) --
+stops the job with "rank r stalled in phase p".
 
 Extras (not the metric): --fused-normal (the fused A'A kernel), --lsqr K (K LSQR iterations on b = A x_true), --check (team
 mode: replicas bit-identical, adjoint against the fp64 sum of the members' partial sums; --dump FILE saves member 0's result).
@@ -148,7 +149,12 @@ def cpu_baseline(edge: int, nblocks_full: int, sample_blocks: int, pairs: int) -
 
 # ---- the supervisor: GPU-free, starts the workers, watches their heartbeats, falls back to team mode ----------------------
 FIRST_COLLECTIVE = "first-collective-done"
-IMPORT_PHASES = ("spawned", "python-started")
+# phases in which a healthy worker may legitimately be silent for minutes: python / torch being paged in on a fresh box, and the FIRST
+# contact with RCCL (topology detection, kernel loading, channel set-up: seconds on most boxes, minutes on some -- one box of this pool
+# took 6 minutes over a one-rank RCCL test that takes 11 s elsewhere)
+SLOW_PHASES = ("spawned", "python-started", "torch-imported", "process-group-init", "library-imported", "contexts-created", "team-formed",
+               "data-resident")
+IMPORT_PHASES = SLOW_PHASES
 
 
 def _last_beat(path):

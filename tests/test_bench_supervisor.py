@@ -41,7 +41,7 @@ def test_a_rank_that_dies_before_the_first_collective_triggers_the_team_fallback
 
 
 def test_a_stalled_rank_is_named_with_its_phase_and_the_team_takes_over():
-    out, lines, took = run({"BENCH_TEST_STALL_BEFORE_COLLECTIVE": "2", "BENCH_WATCHDOG_S": "2"}, "--gpus", "3")
+    out, lines, took = run({"BENCH_TEST_STALL_BEFORE_COLLECTIVE": "2", "BENCH_WATCHDOG_S": "2", "BENCH_WATCHDOG_IMPORT_S": "2"}, "--gpus", "3")
     assert out.returncode == 0, out.stderr[-2000:]
     assert len(lines) == 1 and lines[0]["launch_mode"] == "team"
     why = lines[0]["launch_fallback"]["reason"]                        # names a stalled rank AND shows where every rank was
@@ -68,7 +68,7 @@ def test_mode_team_starts_one_child_only():
 
 
 def test_a_stalled_team_child_is_stopped_with_a_precise_error():
-    out, lines, took = run({"BENCH_TEST_STALL_BEFORE_COLLECTIVE": "team", "BENCH_WATCHDOG_S": "2"}, "--gpus", "2", "--mode", "team")
+    out, lines, took = run({"BENCH_TEST_STALL_BEFORE_COLLECTIVE": "team", "BENCH_WATCHDOG_S": "2", "BENCH_WATCHDOG_IMPORT_S": "2"}, "--gpus", "2", "--mode", "team")
     assert out.returncode != 0 and not lines and took < 60
     assert "team-mode child stalled" in out.stderr and "process-group-init" in out.stderr
 
