@@ -255,3 +255,121 @@ def test_julia_binding_covers_the_reference_api_it_claims():
         for name in [t.strip() for t in imp.replace("\n", " ").split(",") if t.strip()]:
             assert re.search(r"(?m)^(?:abstract type |struct |mutable struct |function |macro )?" + re.escape(name) + r"\b", src) or \
                 re.search(r"\b" + re.escape(name) + r"\(", src), f"`{name}` imported from Jets but not defined in the reference"
+
+
+# ---- round 3: block / bracket structure of the Julia source ------------------------------------------------------------------------
+# Still no Julia toolchain, so the binding cannot be PARSED by Julia either.  What a Python lexer can check: strings, characters and
+# comments skipped, every `function / if / for / while / let / begin / try / struct / module / quote / do` has its `end`, brackets
+# balance, `end` inside `[...]` is indexing, `for` / `if` directly inside a bracket are generators.  Calibrated (by hand, in the build
+# container) on the reference's own `src/Jets.jl` and `test/runtests.jl` -- known-good Julia of the same style --, where it reports
+# nothing.  It proves much less than a parse; it catches the unbalanced `end` or parenthesis that an unexecuted 750-line file collects.
+OPENERS = {"function", "macro", "if", "for", "while", "let", "begin", "try", "struct", "module", "baremodule", "quote", "do"}
+
+
+def julia_structure_errors(text):
+    """Block / bracket balance of Julia source: strings, chars, comments skipped; `end` inside [...] is indexing; `for` / `if`
+    directly inside a bracket are generators / filters.  Returns a list of (line, message)."""
+    errs, stack = [], []          # stack of (kind, line): kind in '(', '[', '{', or a block keyword
+    i, n, line = 0, len(text), 1
+    prev_sig, prev_word = "", ""     # previous significant token / previous word (adjoint vs char literal; `abstract type`)
+    while i < n:
+        c = text[i]
+        if c == "\n":
+            line += 1; i += 1; continue
+        if c in " \t\r":
+            i += 1; continue
+        if c == "#":
+            if text.startswith("#=", i):
+                depth, i = 1, i + 2
+                while i < n and depth:
+                    if text.startswith("#=", i): depth += 1; i += 2
+                    elif text.startswith("=#", i): depth -= 1; i += 2
+                    else:
+                        if text[i] == "\n": line += 1
+                        i += 1
+            else:
+                while i < n and text[i] != "\n": i += 1
+            continue
+        if c == '"':
+            triple = text.startswith('"""', i)
+            q = '"""' if triple else '"'
+            i += len(q)
+            while i < n and not text.startswith(q, i):
+                if text[i] == "\\": i += 1
+                elif text[i] == "$" and i + 1 < n and text[i + 1] == "(":     # interpolation: skip the balanced group
+                    d, i = 0, i + 1
+                    while i < n:
+                        if text[i] == "(": d += 1
+                        elif text[i] == ")":
+                            d -= 1
+                            if d == 0: break
+                        elif text[i] == "\n": line += 1
+                        i += 1
+                if i < n and text[i] == "\n": line += 1
+                i += 1
+            i += len(q); prev_sig = "str"; continue
+        if c == "'":
+            # a character literal ('x', '\n') -- or the adjoint operator after an identifier / closing bracket
+            if prev_sig in ("id", ")", "]", "}", "'"):
+                i += 1; prev_sig = "'"; continue
+            m = re.match(r"'(\\.|[^'\\])'", text[i:])
+            i += m.end() if m else 1; prev_sig = "chr"; continue
+        if c in "([{":
+            stack.append((c, line)); i += 1; prev_sig = c; continue
+        if c in ")]}":
+            want = {")": "(", "]": "[", "}": "{"}[c]
+            if not stack or stack[-1][0] != want:
+                errs.append((line, f"'{c}' closes {stack[-1] if stack else 'nothing'}"))
+                if stack and stack[-1][0] in "([{": stack.pop()
+            else:
+                stack.pop()
+            i += 1; prev_sig = c; continue
+        m = re.match(r"[A-Za-z_ -￿][A-Za-z_0-9! -￿]*", text[i:])
+        if m:
+            w = m.group(0)
+            is_symbol = i > 0 and text[i - 1] == ":" and (i < 2 or not (text[i - 2].isalnum() or text[i - 2] in "_)]}"))
+            is_field = i > 0 and text[i - 1] == "."
+            i += m.end()
+            if is_symbol or is_field:
+                prev_sig = "id"; continue
+            enclosing = next((k for k, _ in reversed(stack) if k != "("), None)    # nearest non-paren context
+            if w == "end":
+                if enclosing == "[":
+                    prev_sig = "id"; continue                                        # a[end]
+                # close the innermost block (parens opened inside the block must be closed already)
+                if stack and stack[-1][0] not in "([{":
+                    stack.pop()
+                else:
+                    errs.append((line, f"'end' with {stack[-1] if stack else 'nothing'} open"))
+                prev_sig = "end"; continue
+            opener = w in OPENERS or (w == "type" and prev_word in ("abstract", "primitive"))
+            if opener:
+                if w in ("for", "if") and stack and stack[-1][0] in "([{":
+                    pass                                                             # generator / comprehension filter
+                else:
+                    stack.append((w, line))
+            prev_word = w
+            prev_sig = "id"; continue
+        i += 1
+        prev_sig = c
+    for k, ln in stack:
+        errs.append((ln, f"'{k}' opened here is never closed"))
+    return errs
+
+
+
+
+def test_julia_binding_block_structure_balances():
+    errs = julia_structure_errors(open(JULIA).read())
+    assert not errs, errs[:10]
+
+
+def test_the_structure_checker_sees_what_it_should():
+    text = open(JULIA).read()
+    at = text.index("\nend\n", len(text) // 2)
+    assert julia_structure_errors(text[:at] + text[at + 4:]), "a removed `end` must be reported"
+    at = text.index("ccall((", len(text) // 3)
+    assert julia_structure_errors(text[:at + 5] + text[at + 6:]), "a removed parenthesis must be reported"
+    assert julia_structure_errors(text + "\nfunction f(x)\n  x[end] + 1\n"), "an unclosed function must be reported (x[end] is indexing)"
+    ok = "f(x) = [i for i in x if i > 0]\ng = sum(i for i in 1:3)\nh = x -> begin\n x' \nend\nstruct A; a::Int; end\nq = c == 'e' ? :end : :function\n"
+    assert not julia_structure_errors(ok)
