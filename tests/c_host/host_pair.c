@@ -185,6 +185,21 @@ int main(void)
         CK(jh_tune_set("lsqr_graph", 1));
         CK(jh_download(xs, 0, n, hx2));
         REQUIRE(lr3.itn == lr.itn && memcmp(hx2, hx, (size_t)n * sizeof(float)) == 0, "graph-replayed loop == host loop, bit for bit");
+        /* round 3: CGLS on the same system (two passes per iteration, no range-sized temporary); bb comes back holding r = b - A x */
+        jh_lsqr_result cr;
+        double chist[2 * 60];
+        CK(jh_blockop_mul(A, bb, xt));
+        CK(jh_cgls_solve(A, bb, xs, 0, 0.0, 1e-7, 1e-6, 60, 0, &cr, chist));
+        REQUIRE(cr.itn >= 1 && cr.itn <= 60 && (cr.istop == 1 || cr.istop == 2), "CGLS stops by a rule");
+        CK(jh_download(xs, 0, n, hx2));
+        num = 0;
+        for (int64_t k = 0; k < n; k++) num += (double)(hx2[k] - hxt[k]) * (hx2[k] - hxt[k]);
+        REQUIRE(sqrt(num / den) < 1e-3, "CGLS recovers x_true");
+        double rnorm = 0.0;
+        CK(jh_norm(bb, 2.0, &rnorm));
+        REQUIRE(fabs(rnorm - cr.r1norm) <= 1e-5 * (rnorm + cr.r1norm) + 1e-12, "on return u holds the residual the record reports");
+        printf("jh_cgls_solve: %d iterations, istop %d, ||x - x_true|| / ||x_true|| = %.2e\n", cr.itn, cr.istop, sqrt(num / den));
+        REQUIRE(jh_comm_available() == JH_OK, "an RCCL can be loaded (probe without side effects)");
         free(hx2);
         free(hx); free(hxt);
         CK(jh_bvec_destroy(xt));
