@@ -89,3 +89,29 @@ def test_bench_auto_mode_falls_back_to_a_fresh_team_child_when_the_ranks_cannot_
     j = json.loads(lines[0])
     assert j["launch_mode"].startswith("team") and j["launch_fallback"]["from"] == "ranks" and "exited with" in j["launch_fallback"]["reason"]
     assert j["n_gpus"] == 2 and [r["rows"] for r in j["multi_gpu"]["per_rank"]] == [5, 4] and j["check"]["ok"]
+
+
+def test_the_driver_launch_line_on_a_one_gpu_box_ends_in_a_team_line():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with the default backend (RCCL) where ONE device is
+    visible: the two started processes are supervisors; the leader counts the devices through a short-lived child, sees that two RCCL
+    ranks cannot share the device, starts NO rank process and runs one team-mode worker (two contexts of the device) instead; the
+    follower waits for the leader's outcome; torch.distributed.run sees two clean exits and stdout carries exactly one line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("BENCH_BACKEND",)}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nblocks", "10",
+           "--edge", "64", "--no-cpu-baseline", "--check"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    if j["launch_mode"].startswith("ranks"):                             # >= 2 devices visible: the ranks ran over RCCL -- fine too
+        assert j["multi_gpu"]["rccl_nranks"] == 2
+        return
+    assert j["launch_mode"].startswith("team") and j["launched_by"] == "torch.distributed.run"
+    assert "1 device(s) visible for 2 ranks" in j["launch_fallback"]["reason"] and j["valid_scaling_point"] is False
+    assert j["check"]["ok"] and [r["rows"] for r in j["multi_gpu"]["per_rank"]] == [5, 5]
