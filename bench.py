@@ -38,6 +38,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -415,9 +416,7 @@ class Supervisor:
 
 
 def supervise(args) -> int:
-    global subprocess
     import socket
-    import subprocess
     import tempfile
 
     n = args.gpus
