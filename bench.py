@@ -44,6 +44,29 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+def cpu_share() -> int:
+    """CPUs this process may really use: the affinity mask, capped by the cgroup's CPU quota (a GPU box of this pool shows 256 CPUs
+    and grants 16: 128 OpenMP threads fighting over a 16-CPU quota made the all-cores baseline swing between 0.17 and 1.96 pairs/s)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+_USER_SET_OMP_THREADS = "OMP_NUM_THREADS" in os.environ
+os.environ.setdefault("OMP_NUM_THREADS", str(cpu_share()))   # the all-cores CPU baseline uses the CPUs this process is granted, no more
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # the all-cores CPU baseline must not spin on barriers in a CPU-capped container
 os.environ.setdefault("OMP_PROC_BIND", "close")       # ... and its threads stay where they first touched their pages
 os.environ.setdefault("OMP_PLACES", "cores")
@@ -143,7 +166,7 @@ def cpu_baseline(edge: int, nblocks_full: int, sample_blocks: int, pairs: int) -
         "sample": f"{sample_blocks} of {nblocks_full} block rows ({edge}^3 Float32 each), median of {pairs} pairs = {med:.3f} s/pair, "
                   f"{bytes_pair / med / 1e9:.1f} GB/s algorithmic; value = sample pairs/s x {sample_blocks}/{nblocks_full} (bandwidth-bound, linear in rows)",
         "build": "gcc -O2 -ftree-vectorize -ffp-contract=off (oracle/Makefile; BASELINE.md section 3)",
-        "host_cores_available": os.cpu_count(),
+        "host_cores_available": os.cpu_count(), "host_cores_granted": cpu_share(),
         "all_cores_variant": allcores,
     }
 
@@ -217,7 +240,8 @@ class Supervisor:
         env["BENCH_WORKER"] = "1"
         env["BENCH_HEARTBEAT"] = self.hb(r)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL's intra-node transport needs it on this pool
-        env.setdefault("OMP_NUM_THREADS", "1")
+        if not _USER_SET_OMP_THREADS:
+            env["OMP_NUM_THREADS"] = "1"                                 # N workers share the host: no CPU work is timed at N > 1
         with open(self.hb(r), "a") as f:
             f.write(f"{time.time():.3f} spawned\n")
         self.procs[r] = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env)
