@@ -66,7 +66,8 @@ def cpu_share() -> int:
 
 
 _USER_SET_OMP_THREADS = "OMP_NUM_THREADS" in os.environ
-os.environ.setdefault("OMP_NUM_THREADS", str(cpu_share()))   # the all-cores CPU baseline uses the CPUs this process is granted, no more
+CPU_SHARE = cpu_share()                                # (once, at import: OpenMP's pinning narrows the main thread's affinity mask later)
+os.environ.setdefault("OMP_NUM_THREADS", str(CPU_SHARE))   # the all-cores CPU baseline uses the CPUs this process is granted, no more
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # the all-cores CPU baseline must not spin on barriers in a CPU-capped container
 os.environ.setdefault("OMP_PROC_BIND", "close")       # ... and its threads stay where they first touched their pages
 os.environ.setdefault("OMP_PLACES", "cores")
@@ -166,7 +167,7 @@ def cpu_baseline(edge: int, nblocks_full: int, sample_blocks: int, pairs: int) -
         "sample": f"{sample_blocks} of {nblocks_full} block rows ({edge}^3 Float32 each), median of {pairs} pairs = {med:.3f} s/pair, "
                   f"{bytes_pair / med / 1e9:.1f} GB/s algorithmic; value = sample pairs/s x {sample_blocks}/{nblocks_full} (bandwidth-bound, linear in rows)",
         "build": "gcc -O2 -ftree-vectorize -ffp-contract=off (oracle/Makefile; BASELINE.md section 3)",
-        "host_cores_available": os.cpu_count(), "host_cores_granted": cpu_share(),
+        "host_cores_available": os.cpu_count(), "host_cores_granted": CPU_SHARE,
         "all_cores_variant": allcores,
     }
 
