@@ -365,7 +365,8 @@ int jh_comm_allreduce_normsq(double *out);
  * host loop; same iterates), "grid_diag" (M x K grids of plain diagonals on the branch-free kernel k_grid_diag: 1 yes -- 2 / 4: that many packs per lane, measured no
  * better --, 0 the general kernels), "grid_tile" (those grids register-tiled, k_grid_tile -- a workgroup owns R lines x one element
  * tile, the shared input pack loaded once per R products: 1 automatic R, 2 / 4 / 8 that R, 0: k_grid_diag; same bits),
- * "sum_group" (terms of a fused JetSum per launch: 8, or 4 = round 2's grouping; same bits),
+ * "sum_group" (terms of a fused JetSum per launch: 8, or 4 = round 2's grouping; same bits), "general_tile" (grids of equal elementwise
+ * blocks of ANY kinds register-tiled, k_general_tile: 1 yes, 0 the one-line-per-workgroup general kernels; same bits),
  * "wide_twin" (1 x K elementwise operators on the tall kernels through their tall twin: 1 automatic -- the adjoint always, the forward
  * from 16 MiB blocks --, 0 never: the general kernels, 2 both always);
  * jh_tune_get also reads the counters "last_fwd_walk" (grid walk of the latest tall forward: 0 sequential, 1 all rows),

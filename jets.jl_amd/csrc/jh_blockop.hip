@@ -1522,6 +1522,83 @@ __global__ __launch_bounds__(256) void k_grid_tile(const jh_dev_block *__restric
     }
 }
 
+// ---- general M x K grids of EQUAL blocks of any elementwise kinds, register-tiled (round 3) ---------------------------------------
+// The same idea as k_grid_tile for grids that are not all plain diagonals (zero blocks, identity / scalar blocks, adjointed
+// diagonals, SQUARE Jacobians): a workgroup owns TWO lines x one element tile; per summed block index the input pack is loaded once
+// for both lines, the coefficient packs of the blocks that have one next to it, two steps' loads issued back to back.  The LOAD
+// section is branch-free -- a block without a coefficient array (or a zero block, which contributes nothing: 1022 / 1047) loads the
+// input pack's address again, an L1 hit -- so that the compiler does not drain the outstanding loads at every kind switch, which
+// is what holds k_block_*_general_vec to one block in flight (GENERAL_Q); the kind switches come afterwards, wave-uniform.
+// Each accumulator adds its non-zero blocks' terms in the reference's order, product rounded before the add: the bits of the general
+// kernels.  A block row of zero blocks only is left as found (forward, 1022); the adjoint of a grid (nrow > 1) always writes (1042).
+template <typename S, int E, int NS, int QQ, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol, int64_t n_scalars,
+                                                      const S *__restrict__ in, S *__restrict__ out, unsigned ntiles, unsigned ngroups)
+{
+    typedef typename vec_of<S, NS>::type V;
+    constexpr int R = 2;
+    int64_t grp, tile;
+    general_line_tile(ngroups, ntiles, grp, tile);
+    ntiles &= 0x7fffffffu;
+    if (tile >= ntiles) return;
+    const int64_t nlines = TRANSPOSED ? ncol : nrow, nsum = TRANSPOSED ? nrow : ncol;
+    const int64_t qstep = TRANSPOSED ? 1 : nrow, lstep = TRANSPOSED ? nrow : 1;   // block (line l, q) = blocks[l * lstep + q * qstep]
+    int64_t line[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) line[r] = grp * R + r < nlines ? grp * R + r : nlines - 1;
+    for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < n_scalars; s += (int64_t)ntiles * 256 * NS) {
+        V acc[R];
+        bool touched[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            acc[r] = TRANSPOSED ? (V)(S)0 : ld<true>(reinterpret_cast<const V *>(out + line[r] * n_scalars + s));   // `_m .= 0` (1042) / d as found (1024)
+            touched[r] = TRANSPOSED;
+        }
+        jh_dev_block nb[QQ][R];                                               // block table entries one group of steps ahead
+#pragma unroll
+        for (int q = 0; q < QQ; q++)
+#pragma unroll
+            for (int r = 0; r < R; r++) nb[q][r] = blocks[line[r] * lstep + (q < nsum ? q : 0) * qstep];
+        for (int64_t q0 = 0; q0 < nsum; q0 += QQ) {
+            jh_dev_block b[QQ][R];
+#pragma unroll
+            for (int q = 0; q < QQ; q++) {
+                const int64_t qn = q0 + QQ + q;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    b[q][r] = nb[q][r];
+                    nb[q][r] = blocks[line[r] * lstep + (qn < nsum ? qn : 0) * qstep];
+                }
+            }
+            V x[QQ], c[QQ][R];
+#pragma unroll
+            for (int q = 0; q < QQ; q++) {
+                const S *xp = in + (q0 + q < nsum ? q0 + q : 0) * n_scalars + s;                          // (a step beyond the end re-reads block 0: unused)
+                x[q] = ld<false>(reinterpret_cast<const V *>(xp));                                        // shared by every line group: through the caches
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const bool has = block_reads_coeff(b[q][r], false);
+                    const S *cp = has ? (const S *)b[q][r].coeff + s : xp;                                // no coefficient array: the input pack again (L1)
+                    c[q][r] = has ? ld<true>(reinterpret_cast<const V *>(cp)) : ld<false>(reinterpret_cast<const V *>(cp));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QQ; q++)
+                if (q0 + q < nsum) {
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        if (b[q][r].kind != JH_OP_ZERO) {                                                 // (1022) / (1047): skipped
+                            acc[r] = acc[r] + apply_block_loaded<S, E, NS, V>(b[q][r], x[q], c[q][r], TRANSPOSED, false);
+                            touched[r] = true;
+                        }
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (touched[r] && grp * R + r < nlines) st<true>(reinterpret_cast<V *>(out + line[r] * n_scalars + s), acc[r]);
+    }
+}
+
 // is `op` such a grid?  (every block an un-adjointed diagonal -- for a real element type the adjoint flag is immaterial and
 // all_diag already says so --, >= 2 x 2, aligned)
 bool grid_diag_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
@@ -2158,6 +2235,30 @@ int launch_grid_tile(const jh_blockop *op, const S *in, S *out, int64_t in_bytes
     return JH_OK;
 }
 
+// the register-tiled general kernel applies to grids (>= 2 x 2) of EQUAL, 16-byte aligned elementwise blocks
+bool general_tile_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
+{
+    if (!(op->elementwise && op->uniform_rows && op->nrow >= 2 && op->ncol >= 2)) return false;
+    const int64_t n = op->row_len[0];
+    if (n == 0) return false;
+    for (int64_t v : op->col_len) if (v != n) return false;
+    return general_vec_ok(op, rng_ptr, dom_ptr);
+}
+
+template <typename S, int E, int NS, bool TRANSPOSED>
+int launch_general_tile(const jh_blockop *op, const S *in, S *out, int64_t in_bytes)
+{
+    jh_context &c = jh_ctx();
+    const int64_t nlines = TRANSPOSED ? op->ncol : op->nrow, n_scalars = op->row_len[0] * E;
+    const int64_t ngroups = (nlines + 1) / 2;
+    unsigned ntiles, grid;
+    general_grid((n_scalars / NS + 255) / 256, ngroups, ntiles, grid, general_use_xcd(in_bytes));
+    hipLaunchKernelGGL((k_general_tile<S, E, NS, 2, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
+                       ntiles, (unsigned)ngroups);
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
+}
+
 template <typename S, int E>
 int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
 {
@@ -2187,6 +2288,8 @@ int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
     c.last_adj_parts = parts;
     if (gdiag && parts == 1 && c.grid_tile)
         return launch_grid_tile<S, E, NS, false>(op, (const S *)m, (S *)d, op->col_off[(size_t)op->ncol] * (int64_t)(sizeof(S) * E));
+    if (vec && !fmode && parts == 1 && c.general_tile && general_tile_ok(op, d, m))
+        return launch_general_tile<S, E, NS, false>(op, (const S *)m, (S *)d, op->col_off[(size_t)op->ncol] * (int64_t)(sizeof(S) * E));
     if (gdiag && parts == 1) {
         if (gu > 1) general_grid((want + gu - 1) / gu, op->nrow, ntiles, grid, general_use_xcd(op->col_off[(size_t)op->ncol] * (int64_t)(sizeof(S) * E)));
 #define JH_GRID(UU) hipLaunchKernelGGL((k_grid_diag<S, E, NS, 4, false, UU>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, \
@@ -2237,6 +2340,8 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
     c.last_adj_parts = parts;
     if (vec && parts == 1 && c.grid_diag && c.grid_tile && grid_diag_ok(op, d, m))
         return launch_grid_tile<S, E, NS, true>(op, (const S *)d, (S *)m, op->row_off[(size_t)op->nrow] * (int64_t)(sizeof(S) * E));
+    if (vec && parts == 1 && c.general_tile && general_tile_ok(op, d, m))
+        return launch_general_tile<S, E, NS, true>(op, (const S *)d, (S *)m, op->row_off[(size_t)op->nrow] * (int64_t)(sizeof(S) * E));
     if (vec && parts == 1 && c.grid_diag && grid_diag_ok(op, d, m)) {
         const int gu = c.grid_diag >= 4 ? 4 : (c.grid_diag >= 2 ? 2 : 1);
         if (gu > 1) general_grid((want + gu - 1) / gu, op->ncol, ntiles, grid, general_use_xcd(op->row_off[(size_t)op->nrow] * (int64_t)(sizeof(S) * E)));

@@ -660,6 +660,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "lsqr_graph")) { c.lsqr_graph = value ? 1 : 0; }
     else if (!strcmp(name, "grid_tile")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "grid_tile must be 0 (k_grid_diag), 1 (automatic) or 2 / 4 / 8 lines per workgroup"); c.grid_tile = value; }
     else if (!strcmp(name, "dense_mixed")) { JH_REQUIRE(value == 0 || value == 1, "dense_mixed must be 0 or 1"); c.dense_mixed = value; }
+    else if (!strcmp(name, "general_tile")) { JH_REQUIRE(value == 0 || value == 1, "general_tile must be 0 or 1"); c.general_tile = value; }
     else if (!strcmp(name, "sum_group")) { JH_REQUIRE(value == 4 || value == 8, "sum_group must be 4 or 8 terms per launch"); c.sum_group = value; }
     else if (!strcmp(name, "grid_diag")) { JH_REQUIRE(value >= 0 && value <= 4, "grid_diag must be 0 (general kernels), 1, 2 or 4 (packs per lane)"); c.grid_diag = value; }
     else if (!strcmp(name, "wide_twin")) { JH_REQUIRE(value >= 0 && value <= 2, "wide_twin must be 0 (never), 1 (automatic) or 2 (always)"); c.wide_twin = value; }
@@ -699,6 +700,7 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "grid_diag")) *value = c.grid_diag;
     else if (!strcmp(name, "grid_tile")) *value = c.grid_tile;
     else if (!strcmp(name, "sum_group")) *value = c.sum_group;
+    else if (!strcmp(name, "general_tile")) *value = c.general_tile;
     else if (!strcmp(name, "dense_mixed")) *value = c.dense_mixed;
     else if (!strcmp(name, "last_launches")) *value = c.last_launches;
     else if (!strcmp(name, "wide_twin")) *value = c.wide_twin;

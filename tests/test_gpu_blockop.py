@@ -148,9 +148,18 @@ def _mixed_ops(Jets, oracle, dt, kinds, lens_r, lens_c, seed=21):
     return Jets.blockop(dev_rows), ora_rows
 
 
+@pytest.fixture(params=[1, 0], ids=["tiled", "one-line"])
+def general_tile(request, Jets):
+    """Grids of EQUAL elementwise blocks run register-tiled (k_general_tile, round 3) or, with the knob off, on the one-line-per-
+    workgroup general kernels: the same bits either way."""
+    Jets.tune(general_tile=request.param)
+    yield request.param
+    Jets.tune(general_tile=1)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("n", [10, 64, 4100])      # 10: scalar kernel (odd 16-byte alignment); 64, 4100: 16-byte vector kernel
-def test_mixed_3x4_with_zero_blocks_bit_exact(Jets, oracle, dt, n):
+def test_mixed_3x4_with_zero_blocks_bit_exact(Jets, oracle, dt, n, general_tile):
     """test/runtests.jl:622-695 shape (3x4, zero blocks at (2,2),(3,4)) with native kinds."""
     kinds = [["diag", "identity", "diag", "scale"],
              ["diag_adj", "zero", "diag", "diag"],
@@ -561,4 +570,38 @@ def test_grid_of_plain_diagonals_on_the_branch_free_kernel(Jets, oracle, dt, sha
     for gd in routes:
         assert_bits_equal(got[gd][0], np.concatenate(want_d), f"grid forward, grid_diag={gd}")
         assert_bits_equal(got[gd][1], np.concatenate(want_m), f"grid adjoint, grid_diag={gd}")
+    J.close(A)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 2), (5, 3), (4, 7), (9, 9)])
+def test_grids_of_equal_blocks_of_every_kind_tiled_and_not(Jets, oracle, dt, shape, general_tile):
+    """M x K grids of equal blocks drawn from every elementwise kind -- incl. a block row and a block column of zero blocks only -- on
+    k_general_tile (two lines x one tile per workgroup, branch-free loads; an odd line count clamps the last group) and on the
+    one-line kernels: forward into a DIRTY d (`_d .+=`, 1024; the row of zero blocks stays as found, 1022), adjoint into a dirty m
+    (zeroed, 1042): the oracle's bits."""
+    J = Jets
+    M, K = shape
+    n = 2048 + 64                                                     # several tiles, 16-byte multiples for every eltype
+    rng = np.random.default_rng(1000 * M + K)
+    names = ["diag", "diag", "diag_adj", "identity", "scale", "zero"]
+    kinds = [[names[rng.integers(len(names))] for _ in range(K)] for _ in range(M)]
+    kinds[M - 1] = ["zero"] * K                                        # a block row of zero blocks only
+    for i in range(M):
+        kinds[i][K - 1] = "zero" if i else "diag"                      # a block column with ONE non-zero block
+    A, ops = _mixed_ops(J, oracle, dt, kinds, [n] * M, [n] * K)
+    hm = [u01(oracle, dt, SEED_M, j, n) for j in range(K)]
+    hd = [u01(oracle, dt, SEED_D, i, n) for i in range(M)]
+    hmt = [u01(oracle, dt, SEED_D + 7, j, n) for j in range(K)]
+    m = J.from_numpy(np.concatenate(hm), J.domain(A))
+    d = J.from_numpy(np.concatenate(hd), J.range(A))
+    J.mul_(d, A, m)
+    want_d = oracle.block_df(ops, [b.copy() for b in hd], hm)
+    assert_bits_equal(d.to_numpy(), np.concatenate(want_d), f"{M}x{K} forward, general_tile={general_tile}")
+    assert_bits_equal(d.to_numpy()[(M - 1) * n:], hd[M - 1], "the row of zero blocks keeps d as found")
+    mt = J.from_numpy(np.concatenate(hmt), J.domain(A))
+    J.mul_(mt, A.H, d)
+    want_m = oracle.block_df_adj(ops, [b.copy() for b in hmt], want_d)
+    assert_bits_equal(mt.to_numpy(), np.concatenate(want_m), f"{M}x{K} adjoint, general_tile={general_tile}")
     J.close(A)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""M x K grids of large blocks of MIXED kinds (diagonal, zero, identity, scalar) on the general kernels, unique (algorithmic) bytes: every diagonal once,
+every domain block once, every range block read (as found) and written once.   python tools/bench_grid_mixed.py M K EDGE"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import jets_jl_amd as J
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+edge = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+J.init(0)
+n = edge ** 3
+spc = J.JetSpace("float32", edge, edge, edge)
+rng = np.random.default_rng(7)
+kinds = rng.choice(["d", "d", "d", "z", "i", "s"], size=(M, K))
+ndiag = int((kinds == "d").sum())
+coeff = J.rand(J.JetBSpace([spc] * max(ndiag, 1)), seed=1, stream=0)
+rows, k = [], 0
+for i in range(M):
+    row = []
+    for j in range(K):
+        kd = kinds[i, j]
+        if kd == "d":
+            row.append(J.JopDiagonal(coeff.arrays[k])); k += 1
+        elif kd == "z":
+            row.append(J.JopZeroBlock(spc, spc))
+        elif kd == "i":
+            row.append(J.JopIdentity(spc))
+        else:
+            row.append(J.JopLn(dom=spc, rng=spc, df=J.constdiag_df, df_adj=J.constdiag_df_adj, s={"a": 0.5 + i}))
+    rows.append(row)
+A = J.blockop(rows)
+m = J.rand(J.domain(A), seed=2, stream=0)
+d = J.zeros(J.range(A))
+mt = J.zeros(J.domain(A))
+
+
+def timed(fn, reps=6, warm=2):
+    for _ in range(warm):
+        fn()
+    best = 1e9
+    for _ in range(reps):
+        e0 = J.Event().record()
+        fn()
+        e1 = J.Event().record()
+        best = min(best, e0.elapsed_ms(e1))
+    return best
+
+
+b = n * 4
+knob = os.environ.get("GENERAL_TILE")
+for gt in ([int(v) for v in knob.split(",")] if knob else [1, 0, 1, 0]):
+    J.tune(general_tile=gt)
+    tf = timed(lambda: J.mul_(d, A, m))
+    ta = timed(lambda: J.mul_(mt, A.H, d))
+    print(f"{M} x {K} mixed grid of {edge}^3 ({ndiag} diagonals of {M * K} blocks) general_tile={gt}: forward {tf:7.3f} ms {(ndiag + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | "
+          f"adjoint {ta:7.3f} ms {(ndiag + M + K) * b / ta / 1e6:7.1f} GB/s", flush=True)
