@@ -879,7 +879,6 @@ static int cgls_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *
     for (int k = 0; k < M; k++) JH_TRY(jh_copy(t[k].p, t[k].s));
     const double gamma0 = gamma;
     double xnorm = 0.0;
-    if (use_x0) JH_TRY(jh_norm(xs[0], 2.0, &xnorm));
     int itn = 0, istop = 0;
     if (gamma > 0) {
         while (itn < maxiter) {
