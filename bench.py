@@ -88,6 +88,7 @@ def parse_args():
     ap.add_argument("--tune", type=str, default="", help="k=v,k=v kernel knobs (fwd_group, fwd_unroll, fwd_wg, adj_unroll, adj_depth, adj_wg, nt; 0 = automatic)")
     ap.add_argument("--fused-normal", action="store_true", help="also time the fused A'A kernel (extra field, not the metric)")
     ap.add_argument("--lsqr", type=int, default=0, help="also run this many LSQR iterations on b = A x_true (extra field, not the metric)")
+    ap.add_argument("--cgnr", type=int, default=0, help="N = 1: also run this many iterations of CG on the normal equations through the fused A'A (extra field)")
     ap.add_argument("--cgls", type=int, default=0, help="N = 1: also run this many CGLS iterations on b = A x_true (extra field, not the metric)")
     ap.add_argument("--mode", choices=("auto", "ranks", "team"), default=os.environ.get("BENCH_MODE", "auto"),
                     help="N > 1: one worker process per GPU (ranks), ONE worker driving all GPUs (team), or ranks with a team fallback (auto)")
@@ -791,6 +792,22 @@ def worker_ranks(args):
                          "GBps": it_bytes * res.itn / t_c / 1e9, "rel_err_vs_x_true": float(J.norm(err)) / float(J.norm(x_true)), "istop": res.istop,
                          "driver": "jh_cgls_solve", "schedule": "two passes per iteration, no range-sized temporary: ||A p||^2 = <p, A'A p> (jh_blockop_normal_mul, N n s bytes), "
                                                                 "then r <- r - alpha A p, ||r||^2 and A'r in one pass of the step kernel (3 N n s)"}
+
+    if args.cgnr and world == 1:
+        x_true = J.rand(J.domain(A), seed=4, stream=0)
+        J.mul_(d, A, x_true)
+        fence()
+        beat("cgnr")
+        t_c = time.perf_counter()
+        res = J.cgnr(A, d, atol=0.0, btol=0.0, maxiter=args.cgnr, force_maxiter=True)
+        fence()
+        t_c = time.perf_counter() - t_c
+        err = (res.x - x_true).materialize()
+        it_bytes = (nblocks * n + 12 * n) * s                       # the coefficients once ; ~12 domain-sized streams
+        extra["cgnr"] = {"iterations": res.itn, "ms_per_iteration": 1e3 * t_c / max(res.itn, 1), "ms_total_incl_the_adjoint_pass_for_A'b": 1e3 * t_c,
+                         "algorithmic_bytes_per_iteration": it_bytes, "GBps": it_bytes * res.itn / t_c / 1e9,
+                         "rel_err_vs_x_true": float(J.norm(err)) / float(J.norm(x_true)), "istop": res.istop, "driver": "jh_cgnr_solve",
+                         "schedule": "CG on (A'A) x = A'b: one adjoint pass for A'b, then ONE fused A'A pass per iteration (jh_blockop_normal_mul: N n s bytes); b only read"}
 
     if rank == 0:
         pairs_per_s = args.steps / elapsed

@@ -321,6 +321,20 @@ int jh_cgls_solve_partitioned(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int 
                               int force_maxiter, jh_lsqr_result *res, double *history);
 int jh_cgls_solve_team(int n, const jh_blockop *const *ops, jh_bvec *const *us, jh_bvec *const *xs, int use_x0, double damp, double atol,
                        double btol, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history);
+/* Conjugate gradients on the normal equations (A'A + damp^2 I) x = A'b THROUGH THE FUSED NORMAL OPERATOR (jh_blockop_normal_mul = the
+ * reference's JetComposite (A', A), src/Jets.jl:530-534, in one kernel) -- the solver BASELINE.json's "A' o A normal-equations matvec"
+ * config is the matvec of.  After one adjoint pass for A'b an iteration reads the coefficients once (N n s bytes: a third of the LSQR
+ * iteration, a quarter of the CGLS one) and works on domain-sized vectors; `b` is read once and NOT written; ||r|| follows the exact CG
+ * recurrence ||r_k||^2 = ||r_{k-1}||^2 - alpha_k gamma_{k-1}.  Same iterates as CGLS / LSQR in exact arithmetic; in floating point its
+ * residual A'r is updated by recurrence in the domain, so the attainable accuracy goes with cond(A)^2 (CGLS / LSQR: cond(A)) -- meant
+ * for well-conditioned operators and for throughput.  istop / history / result record as jh_cgls_solve (r2norm = the recurrence's
+ * sqrt(||r||^2 + damp^2 ||x||^2)).  _partitioned / _team: one all-reduce of the domain vector A_k'A_k p per iteration. */
+int jh_cgnr_solve(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter,
+                  int force_maxiter, jh_lsqr_result *res, double *history);
+int jh_cgnr_solve_partitioned(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter,
+                              int force_maxiter, jh_lsqr_result *res, double *history);
+int jh_cgnr_solve_team(int n, const jh_blockop *const *ops, jh_bvec *const *bs, jh_bvec *const *xs, int use_x0, double damp, double atol,
+                       double btol, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history);
 /* ---------------------------------------------------------------- RCCL over xGMI ----------- */
 /* Row partition of a tall operator across the GPUs of a node (one process per GPU): the forward needs no exchange
  * (src/Jets.jl:1015-1031), the adjoint is a sum over rows (1045-1053) -> one in-place all-reduce of the domain vector

@@ -24,5 +24,5 @@ from .jetblock import *  # noqa: F401,F403
 from .broadcast import *  # noqa: F401,F403
 from .symmetric import SymmetricArray, symspace  # noqa: F401
 from .lsqr import lsqr, LsqrResult  # noqa: F401
-from .cgls import cgls  # noqa: F401
+from .cgls import cgls, cgnr  # noqa: F401
 from . import rowpart  # noqa: F401

@@ -136,6 +136,9 @@ SYMBOLS = {
     "jh_cgls_solve": (_int, [_vp, _vp, _vp, _int, C.c_double, C.c_double, C.c_double, _int, _int, C.POINTER(LsqrResultC), _dblp]),
     "jh_cgls_solve_partitioned": (_int, [_vp, _vp, _vp, _int, C.c_double, C.c_double, C.c_double, _int, _int, C.POINTER(LsqrResultC), _dblp]),
     "jh_cgls_solve_team": (_int, [_int, _vpp, _vpp, _vpp, _int, C.c_double, C.c_double, C.c_double, _int, _int, C.POINTER(LsqrResultC), _dblp]),
+    "jh_cgnr_solve": (_int, [_vp, _vp, _vp, _int, C.c_double, C.c_double, C.c_double, _int, _int, C.POINTER(LsqrResultC), _dblp]),
+    "jh_cgnr_solve_partitioned": (_int, [_vp, _vp, _vp, _int, C.c_double, C.c_double, C.c_double, _int, _int, C.POINTER(LsqrResultC), _dblp]),
+    "jh_cgnr_solve_team": (_int, [_int, _vpp, _vpp, _vpp, _int, C.c_double, C.c_double, C.c_double, _int, _int, C.POINTER(LsqrResultC), _dblp]),
     "jh_comm_available": (_int, []),
     "jh_comm_unique_id": (_int, [_vp]),
     "jh_comm_init_rank": (_int, [_vp, _int, _int]),

@@ -991,3 +991,194 @@ extern "C" int jh_cgls_solve_team(int n, const jh_blockop *const *ops, jh_bvec *
     }
     return cgls_impl(n, ops, us, xs, use_x0, damp, atol, btol, maxiter, force_maxiter, res, history, Exch::team);
 }
+
+// ------------------------------------------------------------------ CG on the normal equations through the fused A'A (round 3) -------------
+// BASELINE.json configs[2] is "JetComposite A' o A normal-equations matvec ... (chain fusion + reductions)": this is the solver that
+// matvec is for.  Conjugate gradients applied to (A'A + damp^2 I) x = A'b with the fused normal operator (jh_blockop_normal_mul reads
+// the coefficients ONCE and never forms a range-sized intermediate): after ONE adjoint pass for A'b an iteration moves N n s bytes --
+// a third of LSQR's one-pass iteration, a quarter of CGLS's -- plus domain-sized vectors; the range vector b is read once and never
+// written.  In exact arithmetic the iterates are CGLS's / LSQR's; in floating point the residual s = A'r lives in the DOMAIN and is
+// updated by recurrence (s -= alpha (A'A + damp^2) p) instead of being recomputed from r, the textbook weakness of "CGNR done
+// naively" (Bjorck 1996, section 7.4): the attainable accuracy degrades with cond(A)^2 where CGLS / LSQR keep cond(A).  For the
+// well-conditioned operators of the benchmark (every column sums N squared coefficients) it reaches the same x; ||r|| is tracked by
+// its own recurrence ||r_k||^2 = ||r_{k-1}||^2 - alpha_k gamma_{k-1} (exact for CG), so no pass over the range is needed for it.
+// Partitioned: every shard's A_k'A_k p, ONE all-reduce of that domain vector per iteration, the scalars from the replicated vectors.
+static int cgnr_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *bs, jh_bvec *const *xs, int use_x0, double damp, double atol,
+                     double btol, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history, const Exch ex)
+{
+    JH_REQUIRE(ops && bs && xs && res && M >= 1, "jh_cgnr_solve: null argument");
+    JH_REQUIRE(maxiter >= 0, "jh_cgnr_solve: maxiter must be >= 0");
+    for (int k = 0; k < M; k++) JH_REQUIRE(ops[k] && bs[k] && xs[k], "jh_cgnr_solve: null argument (member %d)", k);
+    auto use = [&](int k) { return jh_enter(ops[k], bs[k], xs[k]); };
+    JH_TRY(use(0));
+    int64_t nb = 0, n = 0;
+    int dtype = 0;
+    JH_TRY(jh_bvec_info(xs[0], &nb, &n, &dtype, nullptr));
+    for (int k = 0; k < M; k++) {
+        JH_REQUIRE(xs[k]->length == n && xs[k]->dtype == dtype, "jh_cgnr_solve: member %d's x differs in length or element type", k);
+        if (!jh_blockop_tall_fast(ops[k], bs[k]->data, xs[k]->data) || ops[k]->nrow < 2)
+            return jh_fail(JH_ERR_UNSUPPORTED, "jh_cgnr_solve: needs a tall (>= 2 rows) operator of elementwise rows with equal, 16-byte aligned blocks");
+    }
+    struct Work {
+        jh_bvec *p = nullptr, *s = nullptr, *y = nullptr;
+        ~Work()
+        {
+            if (p) (void)jh_bvec_destroy(p);
+            if (s) (void)jh_bvec_destroy(s);
+            if (y) (void)jh_bvec_destroy(y);
+        }
+    };
+    std::vector<Work> t((size_t)M);
+    const int64_t len1[1] = {n};
+    for (int k = 0; k < M; k++) {
+        JH_TRY(use(k));
+        JH_TRY(jh_bvec_create(1, len1, dtype, &t[k].p));
+        JH_TRY(jh_bvec_create(1, len1, dtype, &t[k].s));
+        JH_TRY(jh_bvec_create(1, len1, dtype, &t[k].y));
+    }
+    *res = jh_lsqr_result{};
+    auto global_sum = [&](const std::vector<double> &locals, double *out) -> int {
+        double sum = 0.0;
+        for (double v : locals) sum += v;
+        *out = sum;
+        if (ex == Exch::ranks) JH_TRY(jh_comm_allreduce_scalars(out, 1, 0));
+        return JH_OK;
+    };
+    auto allreduce = [&](auto &&vec_of) -> int {                         // every member's domain vector summed over the shards
+        if (ex == Exch::none) return JH_OK;
+        if (ex == Exch::team) { JH_TRY(use(0)); JH_TRY(jh_comm_group_begin()); }
+        int st = JH_OK;
+        for (int k = 0; k < M && st == JH_OK; k++) st = jh_comm_allreduce_sum(vec_of(k));
+        if (ex == Exch::team) { (void)use(0); const int st2 = jh_comm_group_end(); if (st == JH_OK) st = st2; }
+        return st;
+    };
+    auto lincomb2 = [&](jh_bvec *dst, double c0, const jh_bvec *x0, double c1, const jh_bvec *x1) {
+        const double coef[4] = {c0, 0.0, c1, 0.0};
+        const jh_bvec *v[2] = {x0, x1};
+        return jh_lincomb(dst, 2, coef, v);
+    };
+    std::vector<double> locals((size_t)M);
+
+    // ||b||, s = A'b
+    double s2 = 0.0;
+    for (int k = 0; k < M; k++) {
+        if (!use_x0) JH_TRY(jh_fill(xs[k], 0.0, 0.0));
+        double nrm = 0.0;
+        JH_TRY(jh_norm(bs[k], 2.0, &nrm));
+        locals[k] = nrm * nrm;
+    }
+    JH_TRY(global_sum(locals, &s2));
+    const double bnorm = std::sqrt(s2);
+    for (int k = 0; k < M; k++) JH_TRY(jh_blockop_mul_adj(ops[k], t[k].s, bs[k]));
+    JH_TRY(allreduce([&](int k) { return t[k].s; }));
+    double rr = s2;                                                       // ||b - A x||^2, by recurrence
+    if (use_x0) {                                                         // s = A'b - (A'A + damp^2) x0 ;  ||r0||^2 = ||b||^2 - 2 Re<x0, A'b> + <x0, A'A x0>
+        for (int k = 0; k < M; k++) JH_TRY(jh_blockop_normal_mul(ops[k], t[k].y, xs[k]));
+        JH_TRY(allreduce([&](int k) { return t[k].y; }));
+        double xb = 0.0, xax = 0.0, im = 0.0;
+        JH_TRY(jh_dot(xs[0], t[0].s, &xb, &im));
+        JH_TRY(jh_dot(xs[0], t[0].y, &xax, &im));
+        rr = s2 - 2.0 * xb + xax;
+        if (damp != 0.0) {                                                // the functional CG decreases is ||r||^2 + damp^2 ||x||^2
+            double x0n = 0.0;
+            JH_TRY(jh_norm(xs[0], 2.0, &x0n));
+            rr += damp * damp * x0n * x0n;
+        }
+        for (int k = 0; k < M; k++) {
+            JH_TRY(lincomb2(t[k].s, 1.0, t[k].s, -1.0, t[k].y));
+            if (damp != 0.0) JH_TRY(lincomb2(t[k].s, 1.0, t[k].s, -damp * damp, xs[k]));
+        }
+    }
+    double nrm = 0.0;
+    JH_TRY(jh_norm(t[0].s, 2.0, &nrm));
+    double gamma = nrm * nrm;
+    const double gamma0 = gamma;
+    for (int k = 0; k < M; k++) JH_TRY(jh_copy(t[k].p, t[k].s));
+    int itn = 0, istop = 0;
+    if (gamma > 0) {
+        while (itn < maxiter) {
+            itn++;
+            for (int k = 0; k < M; k++) JH_TRY(jh_blockop_normal_mul(ops[k], t[k].y, t[k].p));   // the ONE pass over the operator
+            JH_TRY(allreduce([&](int k) { return t[k].y; }));
+            if (damp != 0.0)
+                for (int k = 0; k < M; k++) JH_TRY(lincomb2(t[k].y, 1.0, t[k].y, damp * damp, t[k].p));
+            double delta = 0.0, im = 0.0;
+            JH_TRY(jh_dot(t[0].p, t[0].y, &delta, &im));                  // replicas are identical: member 0 speaks for all
+            if (!(delta > 0) || !std::isfinite(delta)) {
+                istop = 6;
+                itn--;
+                break;
+            }
+            const double alpha = gamma / delta;
+            for (int k = 0; k < M; k++) {
+                JH_TRY(lincomb2(xs[k], 1.0, xs[k], alpha, t[k].p));      // x += alpha p
+                JH_TRY(lincomb2(t[k].s, 1.0, t[k].s, -alpha, t[k].y));   // s -= alpha (A'A + damp^2) p
+            }
+            rr -= alpha * gamma;                                          // ||r||^2 (+ damp^2 ||x||^2 when damped: the functional's value)
+            if (rr < 0) rr = 0;
+            JH_TRY(jh_norm(t[0].s, 2.0, &nrm));
+            const double gamma_new = nrm * nrm;
+            const double bk = gamma_new / gamma;
+            for (int k = 0; k < M; k++) JH_TRY(lincomb2(t[k].p, 1.0, t[k].s, bk, t[k].p));
+            gamma = gamma_new;
+            const double rnorm = std::sqrt(rr), arnorm = std::sqrt(gamma);
+            if (history) { history[2 * (itn - 1)] = rnorm; history[2 * (itn - 1) + 1] = arnorm; }
+            if (itn >= maxiter) istop = 7;
+            if (arnorm <= atol * std::sqrt(gamma0)) istop = 2;
+            if (rnorm <= btol * bnorm) istop = 1;
+            if (istop && !(force_maxiter && itn < maxiter && gamma > 0)) break;
+        }
+    }
+    double xnorm = 0.0;
+    JH_TRY(jh_norm(xs[0], 2.0, &xnorm));
+    res->istop = istop;
+    res->itn = itn;
+    res->r2norm = std::sqrt(rr);                                          // sqrt(||r||^2 + damp^2 ||x||^2): what the recurrence tracks
+    const double r1sq = rr - damp * damp * xnorm * xnorm;
+    res->r1norm = std::sqrt(r1sq > 0 ? r1sq : 0.0);
+    res->anorm = 0.0;
+    res->acond = 0.0;
+    res->arnorm = std::sqrt(gamma);
+    res->xnorm = xnorm;
+    for (int k = 0; k < M; k++) {
+        jh_context *ck = jh_ctx_by_id(ops[k]->ctx);
+        if (ck) { JH_TRY(use(k)); JH_CHECK_HIP(hipStreamSynchronize(ck->stream)); }
+    }
+    return JH_OK;
+}
+
+extern "C" int jh_cgnr_solve(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter,
+                             int force_maxiter, jh_lsqr_result *res, double *history)
+{
+    return cgnr_impl(1, &op, &b, &x, use_x0, damp, atol, btol, maxiter, force_maxiter, res, history, Exch::none);
+}
+
+extern "C" int jh_cgnr_solve_partitioned(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0, double damp, double atol, double btol,
+                                         int maxiter, int force_maxiter, jh_lsqr_result *res, double *history)
+{
+    JH_TRY(jh_enter(op, b, x));
+    int nranks = 1, rank = 0, has_comm = 0;
+    (void)jh_comm_info(&nranks, &rank);
+    (void)jh_comm_exists(&has_comm);
+    if (has_comm == 2 && (nranks > 1 || jh_ctx().force_dist))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_cgnr_solve_partitioned: this context is a member of a single-process team (jh_comm_init_all): "
+                       "jh_cgnr_solve_team takes all the members' shards in one call");
+    return cgnr_impl(1, &op, &b, &x, use_x0, damp, atol, btol, maxiter, force_maxiter, res, history,
+                     (nranks > 1 || (has_comm && jh_ctx().force_dist)) ? Exch::ranks : Exch::none);
+}
+
+extern "C" int jh_cgnr_solve_team(int n, const jh_blockop *const *ops, jh_bvec *const *bs, jh_bvec *const *xs, int use_x0, double damp, double atol,
+                                  double btol, int maxiter, int force_maxiter, jh_lsqr_result *res, double *history)
+{
+    JH_REQUIRE(n >= 1 && n <= JH_MAX_CTX && ops && bs && xs, "jh_cgnr_solve_team: need 1..%d members", JH_MAX_CTX);
+    for (int k = 0; k < n; k++) {
+        JH_REQUIRE(ops[k] && bs[k] && xs[k], "jh_cgnr_solve_team: null handle of member %d", k);
+        JH_TRY(jh_enter(ops[k], bs[k], xs[k]));
+        int nranks = 1, rank = 0, has_comm = 0;
+        (void)jh_comm_info(&nranks, &rank);
+        (void)jh_comm_exists(&has_comm);
+        JH_REQUIRE(has_comm == 2 && nranks == n && rank == k, "jh_cgnr_solve_team: the handles of member %d must live in member %d's context of a team of %d "
+                   "(jh_comm_init_all); found %s, rank %d of %d", k, k, n, has_comm == 2 ? "a team" : "no team", rank, nranks);
+    }
+    return cgnr_impl(n, ops, bs, xs, use_x0, damp, atol, btol, maxiter, force_maxiter, res, history, Exch::team);
+}

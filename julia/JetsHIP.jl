@@ -553,6 +553,31 @@ function hip_cgls!(x::HipArray{T}, A::JopLn, b::BlockArray{T,<:HipArray{T}}; x0:
     end
     x, res[], reshape(hist, 2, :)[:, 1:res[].itn]
 end
+# CG on the normal equations through the fused A'A (one pass over the coefficients per iteration; b is only read)
+function hip_cgnr!(x::HipArray{T}, A::JopLn, b::BlockArray{T,<:HipArray{T}}; x0::Bool=false, damp=0.0, atol=1e-6, btol=1e-6, maxiter=100, partitioned::Bool=false) where {T}
+    h = tall_native(A, T)
+    h == C_NULL && error("hip_cgnr!: needs a tall block operator of device-native children")
+    res = Ref{jh_lsqr_result}()
+    hist = Vector{Cdouble}(undef, 2 * max(maxiter, 1))
+    if partitioned
+        check(ccall((:jh_cgnr_solve_partitioned, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble, Cint, Cint, Ref{jh_lsqr_result}, Ptr{Cdouble}),
+                    h, handle(b), handle(x), x0, damp, atol, btol, maxiter, 0, res, hist))
+    else
+        check(ccall((:jh_cgnr_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble, Cint, Cint, Ref{jh_lsqr_result}, Ptr{Cdouble}),
+                    h, handle(b), handle(x), x0, damp, atol, btol, maxiter, 0, res, hist))
+    end
+    x, res[], reshape(hist, 2, :)[:, 1:res[].itn]
+end
+function hip_cgnr_team!(xs::Vector{<:HipArray{T}}, As::Vector{<:JopLn}, bs::Vector{<:BlockArray{T,<:HipArray{T}}}; x0::Bool=false, damp=0.0, atol=1e-6,
+                        btol=1e-6, maxiter=100) where {T}
+    hs = Ptr{Cvoid}[tall_native(A, T) for A in As]
+    any(h -> h == C_NULL, hs) && error("hip_cgnr_team!: every member needs a device-native tall block operator")
+    res = Ref{jh_lsqr_result}()
+    hist = Vector{Cdouble}(undef, 2 * max(maxiter, 1))
+    check(ccall((:jh_cgnr_solve_team, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Cint, Cdouble, Cdouble, Cdouble, Cint, Cint, Ref{jh_lsqr_result}, Ptr{Cdouble}),
+                length(As), hs, Ptr{Cvoid}[handle(b) for b in bs], Ptr{Cvoid}[handle(x) for x in xs], x0 ? 1 : 0, damp, atol, btol, maxiter, 0, res, hist))
+    xs, res[], reshape(hist, 2, :)[:, 1:res[].itn]
+end
 function hip_cgls_team!(xs::Vector{<:HipArray{T}}, As::Vector{<:JopLn}, bs::Vector{<:BlockArray{T,<:HipArray{T}}}; x0::Bool=false, damp=0.0, atol=1e-6,
                         btol=1e-6, maxiter=100) where {T}
     hs = Ptr{Cvoid}[tall_native(A, T) for A in As]

@@ -107,17 +107,21 @@ def test_cgls_over_a_team_and_over_the_abi_communicator(Jets, oracle):
     hb = u01(oracle, dt, 82, 0, nrow * n) - dt(0.5)
     whole = J.cgls(A, J.from_numpy(hb, J.range(A)), atol=0.0, btol=0.0, maxiter=iters)
     xw = whole.x.to_numpy()
+    whole_n = J.cgnr(A, J.from_numpy(hb, J.range(A)), atol=0.0, btol=0.0, maxiter=iters)       # CG through the fused A'A: the same iterates
+    np.testing.assert_allclose(whole_n.x.to_numpy(), xw, rtol=2e-4, atol=1e-5)
     # (b) one-rank communicator, exchange forced
     comm = rowpart.AbiComm(nranks=1, rank=0)
     try:
         shard = rowpart.for_device(rowpart.partition_rows(nrow, 1, 0), A, comm=comm)
         J.tune(force_dist=1)
         dist = J.cgls(shard, J.from_numpy(hb, J.range(A)), atol=0.0, btol=0.0, maxiter=iters)
+        dist_n = J.cgnr(shard, J.from_numpy(hb, J.range(A)), atol=0.0, btol=0.0, maxiter=iters)   # jh_cgnr_solve_partitioned: one vector all-reduce per iteration
     finally:
         J.tune(force_dist=0)
         comm.close()
-    assert dist.itn == whole.itn == iters
+    assert dist.itn == whole.itn == iters == dist_n.itn
     np.testing.assert_allclose(dist.x.to_numpy(), xw, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(dist_n.x.to_numpy(), whole_n.x.to_numpy(), rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose([h[1] for h in dist.history], [h[1] for h in whole.history], rtol=1e-5)
     # (a) a team of two contexts: rows 0..5 and 6..9 (in a function of its own: every handle of the second context is gone when it returns)
     other = J.context_create(0)
@@ -148,6 +152,13 @@ def _team_leg(J, rowpart, ctxs, spc, n, hb, iters, xw, r_hist):
         assert x0.tobytes() == x1.tobytes(), "the members' replicas of x differ"
         np.testing.assert_allclose(x0, xw, rtol=2e-5, atol=1e-6)
         np.testing.assert_allclose([h[1] for h in res.history], r_hist, rtol=1e-5)
+        bs2 = []
+        for k, _ in team.each():                                           # every member's rows of b in ITS context
+            lo, hi = cuts[k]
+            bs2.append(J.from_numpy(hb[lo * n:hi * n], J.range(ops[k])))
+        resn = J.cgnr(T, rowpart.TeamVec(bs2), atol=0.0, btol=0.0, maxiter=iters)                   # jh_cgnr_solve_team
+        assert resn.x[0].to_numpy().tobytes() == resn.x[1].to_numpy().tobytes()
+        np.testing.assert_allclose(resn.x[0].to_numpy(), xw, rtol=2e-4, atol=1e-5)
         for A in ops:
             J.close(A)
     finally:
@@ -170,3 +181,44 @@ def test_cgls_argument_checks(Jets, oracle):
     out = LsqrResultC()
     assert lib.jh_cgls_solve(nat.handle, b.handle, x.handle, 0, 0.0, 0.0, 0.0, 3, 0, C.byref(out), None) == 4      # JH_ERR_UNSUPPORTED, nothing touched
     assert lib.jh_cgls_solve(None, b.handle, x.handle, 0, 0.0, 0.0, 0.0, 3, 0, C.byref(out), None) != 0
+
+
+@pytest.mark.parametrize("dt,xtol", [(np.float32, 2e-4), (np.float64, 1e-9), (np.complex64, 2e-4), (np.complex128, 1e-9)])
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_cgnr_through_the_fused_normal_operator_matches_textbook_cgls(Jets, oracle, dt, xtol, native, monkeypatch):
+    """CG on (A'A) x = A'b with the normal operator as ONE fused pass (jh_cgnr_solve; native = 0: A then A' through the engines) has, in
+    exact arithmetic, the iterates of CGLS: checked against the TEXTBOOK fp64 CGLS (explicit q = A p and r) -- iterate, the ||r||
+    recurrence and ||A'r|| per iteration.  b is only read."""
+    monkeypatch.setenv("JETS_CGLS_NATIVE", native)
+    nrow, shape, iters = 6, (16, 16, 16), 12
+    A, _, _, diags = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    matvec, rmatvec = _host_ops(diags, dt64)
+    hb = (u01(oracle, dt, 51, 0, nrow * n) - dt(0.5)).astype(dt)
+    b = Jets.from_numpy(hb, Jets.range(A))
+    res = Jets.cgnr(A, b, atol=0.0, btol=0.0, maxiter=iters)
+    xr, info = cgls_fp64(matvec, rmatvec, hb.astype(dt64), n, atol=0.0, btol=0.0, maxiter=iters)
+    assert res.itn == iters == info["itn"] and res.istop == 7
+    x = res.x.to_numpy().ravel(order="F").astype(dt64)
+    assert np.linalg.norm(x - xr) / np.linalg.norm(xr) < xtol
+    for (i1, r1, ar1), (i2, r2, ar2) in zip(res.history, info["history"]):
+        assert i1 == i2 and r1 == pytest.approx(r2, rel=max(10 * xtol, 1e-8)) and ar1 == pytest.approx(ar2, rel=max(100 * xtol, 1e-6))
+    assert np.array_equal(b.to_numpy(), hb), "b is read, never written"
+    assert res.r1norm == pytest.approx(info["r1norm"], rel=max(10 * xtol, 1e-8))
+
+
+def test_cgnr_damping_and_warm_start(Jets, oracle):
+    dt, nrow, shape, iters, damp = np.float64, 5, (24, 24, 3), 9, 0.35
+    A, _, _, diags = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    matvec, rmatvec = _host_ops(diags, np.float64)
+    hb = u01(oracle, dt, 52, 0, nrow * n) - 0.5
+    hx0 = u01(oracle, dt, 53, 0, n) - 0.5
+    res = Jets.cgnr(A, Jets.from_numpy(hb, Jets.range(A)), x0=Jets.from_numpy(hx0.reshape(shape, order="F")), damp=damp, atol=0.0, btol=0.0, maxiter=iters)
+    xr, info = cgls_fp64(matvec, rmatvec, hb, n, x0=hx0, damp=damp, atol=0.0, btol=0.0, maxiter=iters)
+    x = res.x.to_numpy().ravel(order="F")
+    assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
+    r = hb - matvec(x)
+    assert res.r1norm == pytest.approx(np.linalg.norm(r), rel=1e-7)                 # ||r|| from the recurrence, never from a pass over the range
+    assert res.r2norm == pytest.approx(np.sqrt(np.linalg.norm(r) ** 2 + damp ** 2 * np.linalg.norm(x) ** 2), rel=1e-7)

@@ -195,7 +195,11 @@ def _lsqr_worker(rank, world, port, nrow, n, iters, out_dir, one_pass=False, sol
             comm.all_reduce_sum_(w)
             return math.sqrt(comm.all_reduce_scalars([sum(float(np.dot(t, t)) for t in u)], "sum")[0]), w
 
-    if solver == "cgls":
+    if solver == "cgnr":
+        from jets_jl_amd.cgls import cgnr_core
+
+        res = cgnr_core(NumpyShardEngine(), b_loc, None, 0.1, 0.0, 0.0, iters)                # CG on the normal equations: A then A' per iteration here
+    elif solver == "cgls":
         from jets_jl_amd.cgls import cgls_core
 
         res = cgls_core(NumpyShardEngine(), b_loc, None, 0.1, 0.0, 0.0, iters)                # damped: s = A'r - damp^2 x on every rank alike
@@ -227,8 +231,10 @@ def test_world_size_2_lsqr_matches_single_process_fp64_lsqr(tmp_path, one_pass):
     assert np.allclose(res[0]["r"], ref_r, rtol=1e-9)
 
 
-def test_world_size_2_cgls_matches_single_process_fp64_cgls(tmp_path):
-    """The textbook CGLS loop (jets.jl_amd/cgls.py: cgls_core) on the row partition: forward local, ONE vector all-reduce per
+@pytest.mark.parametrize("solver", ["cgls", "cgnr"])
+def test_world_size_2_cgls_matches_single_process_fp64_cgls(tmp_path, solver):
+    """The textbook CGLS loop (jets.jl_amd/cgls.py: cgls_core) -- and CG on the normal equations (cgnr_core), which has the same iterates
+    in exact arithmetic -- on the row partition: forward local, ONE vector all-reduce per
     iteration for A'r, scalar all-reduces for the range-side norms; replicas identical, iterates those of the fp64 CPU CGLS."""
     import torch.multiprocessing as mp
 
@@ -236,7 +242,7 @@ def test_world_size_2_cgls_matches_single_process_fp64_cgls(tmp_path):
     from oracle.cgls_ref import cgls_fp64
 
     world, port, nrow, n, iters = 2, _free_port(), 5, 64, 20
-    mp.spawn(_lsqr_worker, args=(world, port, nrow, n, iters, str(tmp_path), False, "cgls"), nprocs=world, join=True)
+    mp.spawn(_lsqr_worker, args=(world, port, nrow, n, iters, str(tmp_path), False, solver), nprocs=world, join=True)
     res = [np.load(tmp_path / f"lsqr{r}.npz") for r in range(world)]
     a = np.stack([jo.rng_u01(np.float64, 1, 0, i * n, n) + 0.05 for i in range(nrow)])
     b = np.concatenate([jo.rng_u01(np.float64, 5, 0, i * n, n) - 0.5 for i in range(nrow)])
@@ -244,4 +250,5 @@ def test_world_size_2_cgls_matches_single_process_fp64_cgls(tmp_path):
     assert res[0]["x"].tobytes() == res[1]["x"].tobytes()
     assert int(res[0]["itn"]) == info["itn"] == iters
     assert np.linalg.norm(res[0]["x"] - xr) <= 1e-10 * np.linalg.norm(xr)
-    assert np.allclose(res[0]["r"], np.array([h[1] for h in info["history"]]), rtol=1e-9)
+    if solver == "cgls":                                                                # (cgnr reports sqrt(||r||^2 + damp^2 ||x||^2) from its recurrence)
+        assert np.allclose(res[0]["r"], np.array([h[1] for h in info["history"]]), rtol=1e-9)
