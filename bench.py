@@ -236,9 +236,8 @@ class Supervisor:
             return None
 
     # -- children: exactly the PIDs started here, never anything by pattern
-    def start_worker(self, r, env_extra):
-        env = dict(self.base_env)
-        env.update(env_extra)
+    def start_worker(self, r, env_extra, whole_env=False):
+        env = dict(env_extra) if whole_env else dict(self.base_env, **env_extra)
         env["BENCH_WORKER"] = "1"
         env["BENCH_HEARTBEAT"] = self.hb(r)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL's intra-node transport needs it on this pool
@@ -317,7 +316,7 @@ class Supervisor:
         env["BENCH_TEAM_CHILD"] = "1"
         env["BENCH_LAUNCH_NOTE"] = json.dumps(note)
         self.procs = {}
-        self.start_worker(0, env)
+        self.start_worker(0, env, whole_env=True)                          # (none of the launcher's rank variables reaches the team worker)
         p = self.procs[0]
         while True:
             code = p.poll()
