@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(256) void k_grid_tile(const jh_dev_block *__restric
 // is what holds k_block_*_general_vec to one block in flight (GENERAL_Q); the kind switches come afterwards, wave-uniform.
 // Each accumulator adds its non-zero blocks' terms in the reference's order, product rounded before the add: the bits of the general
 // kernels.  A block row of zero blocks only is left as found (forward, 1022); the adjoint of a grid (nrow > 1) always writes (1042).
-template <typename S, int E, int NS, int QQ, bool TRANSPOSED>
+template <typename S, int E, int NS, int QQ, int U, bool TRANSPOSED>
 __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol, int64_t n_scalars,
                                                       const S *__restrict__ in, S *__restrict__ out, unsigned ntiles, unsigned ngroups)
 {
@@ -1546,12 +1546,21 @@ __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__rest
     int64_t line[R];
 #pragma unroll
     for (int r = 0; r < R; r++) line[r] = grp * R + r < nlines ? grp * R + r : nlines - 1;
-    for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < n_scalars; s += (int64_t)ntiles * 256 * NS) {
-        V acc[R];
+    for (int64_t s0 = (tile * 256 * U + threadIdx.x) * NS; s0 < n_scalars; s0 += (int64_t)ntiles * 256 * U * NS) {
+        int64_t s[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {                                       // U packs per lane, 256 lanes apart (clamped: branch-free loads)
+            ok[u] = s0 + (int64_t)u * 256 * NS < n_scalars;
+            s[u] = ok[u] ? s0 + (int64_t)u * 256 * NS : s0;
+        }
+        V acc[R][U];
         bool touched[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            acc[r] = TRANSPOSED ? (V)(S)0 : ld<true>(reinterpret_cast<const V *>(out + line[r] * n_scalars + s));   // `_m .= 0` (1042) / d as found (1024)
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                acc[r][u] = TRANSPOSED ? (V)(S)0 : ld<true>(reinterpret_cast<const V *>(out + line[r] * n_scalars + s[u]));   // `_m .= 0` (1042) / d as found (1024)
             touched[r] = TRANSPOSED;
         }
         jh_dev_block nb[QQ][R];                                               // block table entries one group of steps ahead
@@ -1570,16 +1579,19 @@ __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__rest
                     nb[q][r] = blocks[line[r] * lstep + (qn < nsum ? qn : 0) * qstep];
                 }
             }
-            V x[QQ], c[QQ][R];
+            V x[QQ][U], c[QQ][R][U];
 #pragma unroll
             for (int q = 0; q < QQ; q++) {
-                const S *xp = in + (q0 + q < nsum ? q0 + q : 0) * n_scalars + s;                          // (a step beyond the end re-reads block 0: unused)
-                x[q] = ld<false>(reinterpret_cast<const V *>(xp));                                        // shared by every line group: through the caches
+                const S *xb = in + (q0 + q < nsum ? q0 + q : 0) * n_scalars;                              // (a step beyond the end re-reads block 0: unused)
+#pragma unroll
+                for (int u = 0; u < U; u++) x[q][u] = ld<false>(reinterpret_cast<const V *>(xb + s[u]));  // shared by every line group: through the caches
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const bool has = block_reads_coeff(b[q][r], false);
-                    const S *cp = has ? (const S *)b[q][r].coeff + s : xp;                                // no coefficient array: the input pack again (L1)
-                    c[q][r] = has ? ld<true>(reinterpret_cast<const V *>(cp)) : ld<false>(reinterpret_cast<const V *>(cp));
+                    const S *cb = has ? (const S *)b[q][r].coeff : xb;                                    // no coefficient array: the input pack again (L1)
+#pragma unroll
+                    for (int u = 0; u < U; u++)
+                        c[q][r][u] = has ? ld<true>(reinterpret_cast<const V *>(cb + s[u])) : ld<false>(reinterpret_cast<const V *>(cb + s[u]));
                 }
             }
 #pragma unroll
@@ -1588,14 +1600,18 @@ __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__rest
 #pragma unroll
                     for (int r = 0; r < R; r++)
                         if (b[q][r].kind != JH_OP_ZERO) {                                                 // (1022) / (1047): skipped
-                            acc[r] = acc[r] + apply_block_loaded<S, E, NS, V>(b[q][r], x[q], c[q][r], TRANSPOSED, false);
+#pragma unroll
+                            for (int u = 0; u < U; u++)
+                                acc[r][u] = acc[r][u] + apply_block_loaded<S, E, NS, V>(b[q][r], x[q][u], c[q][r][u], TRANSPOSED, false);
                             touched[r] = true;
                         }
                 }
         }
 #pragma unroll
         for (int r = 0; r < R; r++)
-            if (touched[r] && grp * R + r < nlines) st<true>(reinterpret_cast<V *>(out + line[r] * n_scalars + s), acc[r]);
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (touched[r] && ok[u] && grp * R + r < nlines) st<true>(reinterpret_cast<V *>(out + line[r] * n_scalars + s[u]), acc[r][u]);
     }
 }
 
@@ -2251,10 +2267,15 @@ int launch_general_tile(const jh_blockop *op, const S *in, S *out, int64_t in_by
     jh_context &c = jh_ctx();
     const int64_t nlines = TRANSPOSED ? op->ncol : op->nrow, n_scalars = op->row_len[0] * E;
     const int64_t ngroups = (nlines + 1) / 2;
+    const int U = (c.fwd_unroll == 2) ? 2 : 1;                           // two packs per lane did not pay here (knob fwd_unroll = 2: measurements)
     unsigned ntiles, grid;
-    general_grid((n_scalars / NS + 255) / 256, ngroups, ntiles, grid, general_use_xcd(in_bytes));
-    hipLaunchKernelGGL((k_general_tile<S, E, NS, 2, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
-                       ntiles, (unsigned)ngroups);
+    general_grid((n_scalars / NS + 256 * U - 1) / (256 * U), ngroups, ntiles, grid, general_use_xcd(in_bytes));
+    if (U == 2)
+        hipLaunchKernelGGL((k_general_tile<S, E, NS, 2, 2, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
+                           ntiles, (unsigned)ngroups);
+    else
+        hipLaunchKernelGGL((k_general_tile<S, E, NS, 2, 1, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
+                           ntiles, (unsigned)ngroups);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }

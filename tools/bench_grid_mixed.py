@@ -52,6 +52,8 @@ def timed(fn, reps=6, warm=2):
 
 
 b = n * 4
+if os.environ.get("GENERAL_TILE_U"):
+    J.tune(fwd_unroll=int(os.environ["GENERAL_TILE_U"]))
 knob = os.environ.get("GENERAL_TILE")
 for gt in ([int(v) for v in knob.split(",")] if knob else [1, 0, 1, 0]):
     J.tune(general_tile=gt)
