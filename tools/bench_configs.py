@@ -8,7 +8,8 @@ config 2  64x1 tall diagonal, 128^3 Float32                     : fwd+adj pairs/
 config 3  A'oA on a 256x1 tall diagonal (128^3 and 256^3)       : fused launch vs the unfused chain
 config 4  1024x1 tall diagonal, 256^3 Float32                   : the whole operator on one GPU, and the per-rank shards
                                                                   (512 / 256 / 128 rows) a 2 / 4 / 8 GPU row partition runs locally
-config 5  100 LSQR iterations on config 4, b = A x_true         : ms/iteration, relative error of x
+config 5  100 LSQR iterations on config 4, b = A x_true         : ms/iteration, relative error of x; the same solve by CGLS
+                                                                  (two passes) and by CG through the fused A'A (one pass of a)
 Algorithmic bytes as in SURVEY.md 8d: pair = 4*N*n*s + 2*n*s; fused A'A = N*n*s + 2*n*s.
 """
 import gc
@@ -133,3 +134,16 @@ J.lincomb_(err, [1.0, -1.0], [res.x, x_true])
 rel = J.norm(err) / J.norm(x_true)
 print(f"{'config 5: 100 LSQR iterations on config 4':58s} {1e3 * wall / max(res.itn, 1):9.2f} ms/iteration ({res.itn} iterations, "
       f"{wall:6.2f} s wall)   ||x - x_true|| / ||x_true|| = {rel:.2e}", flush=True)
+
+for name, solve in (("CGLS", lambda rhs: J.cgls(A, rhs, maxiter=100, atol=0.0, btol=0.0, overwrite_b=True, force_maxiter=True)),
+                    ("CGNR (fused A'A)", lambda rhs: J.cgnr(A, rhs, maxiter=100, atol=0.0, btol=0.0, force_maxiter=True))):
+    J.mul_(b, A, x_true)                                       # LSQR / CGLS used b's storage
+    J.synchronize()
+    t0 = time.perf_counter()
+    res = solve(b)
+    J.synchronize()
+    wall = time.perf_counter() - t0
+    J.lincomb_(err, [1.0, -1.0], [res.x, x_true])
+    rel = J.norm(err) / J.norm(x_true)
+    print(f"{'config 5: 100 %s iterations on config 4' % name:58s} {1e3 * wall / max(res.itn, 1):9.2f} ms/iteration ({res.itn} iterations, "
+          f"{wall:6.2f} s wall)   ||x - x_true|| / ||x_true|| = {rel:.2e}", flush=True)
