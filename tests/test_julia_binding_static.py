@@ -373,3 +373,136 @@ def test_the_structure_checker_sees_what_it_should():
     assert julia_structure_errors(text + "\nfunction f(x)\n  x[end] + 1\n"), "an unclosed function must be reported (x[end] is indexing)"
     ok = "f(x) = [i for i in x if i > 0]\ng = sum(i for i in 1:3)\nh = x -> begin\n x' \nend\nstruct A; a::Int; end\nq = c == 'e' ? :end : :function\n"
     assert not julia_structure_errors(ok)
+
+
+# ---- round 3: every CALLED name resolves ---------------------------------------------------------------------------------------------
+# A typo in a function name is the commonest fault of a file no Julia has loaded (it would only surface as an UndefVarError at the first
+# call).  Every name in call position must be defined in the binding, imported from Jets by name, exported by Jets, a type parameter /
+# callable argument of the enclosing method, or one of the Base / LinearAlgebra functions listed here (each one checked by hand against
+# the Julia 1.x manual; adding a name to this list is a deliberate act).
+BASE_CALLABLES = {
+    "Cint", "Float64", "Int", "Ref", "DimensionMismatch", "IndexLinear", "any", "axes", "ccall", "cld", "delete!", "divrem", "eachindex", "eltype",
+    "error", "fill", "finalizer", "findfirst", "float", "foreach", "get", "get!", "hasproperty", "imag", "invoke", "isempty", "join", "length", "map",
+    "max", "min", "ndims", "new", "one", "parse", "pop!", "prod", "push!", "range", "real", "similar", "size", "sizeof", "sqrt", "sum", "throw",
+    "typeof", "unsafe_string", "unsafe_wrap", "vec", "zeros",
+}
+JETS_EXPORTS = {"Jet", "JetAbstractSpace", "JetBSpace", "JetSpace", "JetSSpace", "Jop", "JopAdjoint", "JopLn", "JopNl", "JopZeroBlock", "domain",
+                "getblock", "getblock!", "dot_product_test", "indices", "jacobian", "jacobian!", "jet", "linearity_test", "linearization_test", "nblocks",
+                "perfstat", "point", "setblock!", "shape", "space", "state", "state!", "symspace"}      # src/Jets.jl:1288-1291
+LOCAL_CALLABLES = {"T", "f"}      # a type parameter used as a constructor; function-valued arguments (checked below to BE arguments)
+
+
+def julia_called_names(code):
+    return set(re.findall(r"(?<![\w.!:@′])([A-Za-z_][\w!′]*)\(", code))
+
+
+def julia_defined_names(code):
+    defs = set(re.findall(r"(?m)^\s*(?:@inline\s+)?function\s+(?:\w+\.)?([A-Za-z_][\w!′]*)", code))
+    defs |= set(re.findall(r"(?m)^\s*(?:@inline\s+)?([A-Za-z_][\w!′]*)\(.*\)(?:\s*where\s*\{[^}]*\}|\s*where\s+\w+)?\s*=(?!=)", code))   # f(x, k=1) = ...
+    defs |= set(re.findall(r"(?m)^\s*(?:mutable\s+)?struct\s+([A-Za-z_]\w*)", code))
+    defs |= set(re.findall(r"(?m)^\s*const\s+([A-Za-z_]\w*)", code))
+    return defs
+
+
+def test_every_called_name_in_the_julia_binding_resolves():
+    code = _julia_code_tokens()
+    imp = re.search(r"import Jets:(.*?)\n\n", open(JULIA).read(), flags=re.S).group(1)
+    imported = {t.strip() for t in imp.replace("\n", " ").split(",") if t.strip()}
+    known = julia_defined_names(code) | imported | JETS_EXPORTS | BASE_CALLABLES | LOCAL_CALLABLES
+    unknown = sorted(julia_called_names(code) - known)
+    assert not unknown, f"julia/JetsHIP.jl calls names nothing defines: {unknown}"
+    for name in LOCAL_CALLABLES - {"T"}:                       # the function-valued locals really are arguments / locals somewhere
+        assert re.search(r"[(,;]\s*%s\s*(?:::[\w{},.<: ]+)?\s*[,;)=]" % re.escape(name), code) or re.search(r"(?m)^\s*%s\s*=" % re.escape(name), code), name
+    # qualified names: Module.name with Module one of the four the file uses
+    for mod, name in set(re.findall(r"\b(Base|Broadcast|Jets|LinearAlgebra)\.([A-Za-z_][\w!′]*)", code)):
+        if mod == "Jets":
+            assert name in imported | JETS_EXPORTS, f"Jets.{name} is neither imported by name nor exported by Jets"
+    # the lint sees a typo
+    assert julia_called_names("x = chek(ccall(1))") - known == {"chek"}
+
+
+# ---- round 3: calls of the binding's own functions pass an argument count some method accepts -----------------------------------------
+def _split_args(inner):
+    """(positional, keyword) argument texts of a Julia argument list (definition or call): `;` starts the keywords, `k = v` at the top
+    level of a CALL is a keyword too (the caller decides by `is_def`)."""
+    depth, semi = 0, None
+    for k, ch in enumerate(inner):
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        elif ch == ";" and depth == 0:
+            semi = k
+            break
+    pos = _split_top(inner if semi is None else inner[:semi])
+    kw = [] if semi is None else _split_top(inner[semi + 1:])
+    return pos, kw
+
+
+def _has_top_assign(arg):
+    depth = 0
+    for k, ch in enumerate(arg):
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        elif ch == "=" and depth == 0 and arg[k + 1:k + 2] != "=" and arg[k - 1:k] not in ("=", "!", "<", ">"):
+            return True
+    return False
+
+
+def julia_method_arities(code):
+    """{name: [(min positional, max positional or None for varargs)]} for every method the file defines (both definition forms)."""
+    table = {}
+    pats = (r"(?m)^\s*(?:@inline\s+)?function\s+((?:\w+\.)?[A-Za-z_][\w!′]*)\(", r"(?m)^\s*(?:@inline\s+)?((?:\w+\.)?[A-Za-z_][\w!′]*)\(")
+    for which, pat in enumerate(pats):
+        for mt in re.finditer(pat, code):
+            end = _balanced(code, mt.end() - 1)
+            if which == 1 and not re.match(r"(?:\s*where\s*\{[^}]*\}|\s*where\s+\w+)?\s*=(?!=)", code[end:]):
+                continue                                    # a call statement, not a short-form definition
+            pos, _ = _split_args(code[mt.end():end - 1])
+            lo = sum(1 for a in pos if not _has_top_assign(a) and not a.rstrip().endswith("..."))
+            hi = None if any(a.rstrip().endswith("...") for a in pos) else len(pos)
+            table.setdefault(mt.group(1).split(".")[-1], []).append((lo, hi))
+            if "." in mt.group(1):
+                table.setdefault("<extends>", []).append(mt.group(1).split(".")[-1])     # a generic of Base / Jets / LinearAlgebra: other methods exist
+    for mt in re.finditer(r"(?m)^\s*(?:mutable\s+)?struct\s+([A-Za-z_]\w*)[^\n]*\n(.*?)^end", code, flags=re.S):   # default constructors
+        fields = [ln for ln in mt.group(2).split("\n") if re.match(r"\s*[a-z_]\w*\s*(::|$)", ln) and ln.strip()]
+        table.setdefault(mt.group(1), []).append((len(fields), len(fields)))
+    return table
+
+
+def julia_arity_errors(code, foreign=()):
+    """Calls whose positional-argument count no method DEFINED IN THE FILE accepts; names that extend a generic function of another
+    module (qualified definitions, or `foreign`: the names imported from Jets) are skipped -- their other methods are not visible here."""
+    table, errs = julia_method_arities(code), []
+    for mt in re.finditer(r"(?<![\w.!:@′])([A-Za-z_][\w!′]*)\(", code):
+        name = mt.group(1)
+        if name not in table or name in table.get("<extends>", ()) or name in foreign:
+            continue
+        end = _balanced(code, mt.end() - 1)
+        line_start = code.rfind("\n", 0, mt.start()) + 1
+        before = code[line_start:mt.start()]
+        if re.match(r"\s*(?:@inline\s+)?(?:function\s+)?(?:\w+\.)?$", before) and (
+                "function" in before or re.match(r"(?:\s*where\s*\{[^}]*\}|\s*where\s+\w+)?\s*=(?!=)", code[end:])):
+            continue                                        # the definition itself
+        pos, _ = _split_args(code[mt.end():end - 1])
+        if any(a.rstrip().endswith("...") for a in pos):
+            continue                                        # a splat: count unknown
+        npos = sum(1 for a in pos if not _has_top_assign(a))
+        if re.match(r"[ \t]*do\b", code[end:]):
+            npos += 1                                       # f(args) do ... end passes the block as the first argument
+        if not any(lo <= npos and (hi is None or npos <= hi) for lo, hi in table[name]):
+            errs.append((code[:mt.start()].count("\n") + 1, name, npos, table[name]))
+    return errs
+
+
+def test_calls_of_the_bindings_own_functions_match_a_method_by_argument_count():
+    code = _julia_code_tokens()
+    imp = re.search(r"import Jets:(.*?)\n\n", open(JULIA).read(), flags=re.S).group(1)
+    imported = {t.strip() for t in imp.replace("\n", " ").split(",") if t.strip()}
+    errs = julia_arity_errors(code, foreign=imported | BASE_CALLABLES)
+    assert not errs, errs[:10]
+    # the lint sees a dropped argument
+    probe = "g(a, b; k=1) = a + b\nh(x) = g(x)\n"
+    assert julia_arity_errors(probe) and not julia_arity_errors("g(a, b=2; k=1) = a + b\nh(x) = g(x, k=3)\n")
