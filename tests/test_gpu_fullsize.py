@@ -196,3 +196,17 @@ def test_config5_100_lsqr_iterations_on_1024x256cubed(Jets, oracle):
                       atol=0.0, btol=0.0, conlim=0.0, maxiter=30)
     got = res.x._download(0, W).astype(np.float64)
     assert np.linalg.norm(got - xr) / np.linalg.norm(xr) <= 1e-4
+    # round 3: the same solve by CGLS (two passes per iteration) and by CG through the fused A'A (one pass of the coefficients),
+    # on the operator already resident; both must reach x_true, and their recorded ||r|| must be the residual's real norm
+    for name, solve, tol in (("cgls", lambda rhs: Jets.cgls(A, rhs, atol=0.0, btol=0.0, maxiter=30, overwrite_b=True), 1e-4),
+                             ("cgnr", lambda rhs: Jets.cgnr(A, rhs, atol=0.0, btol=0.0, maxiter=30), 1e-4)):
+        Jets.mul_(b, A, x_true)                                   # LSQR / CGLS consumed b's storage
+        bnorm = float(Jets.norm(b))
+        out = solve(b)
+        err = (out.x - x_true).materialize()
+        rel = float(Jets.norm(err)) / float(Jets.norm(x_true))
+        assert rel <= tol, (name, rel)
+        assert 1 <= out.itn <= 30 and out.istop in (1, 2, 6, 7), (name, out.itn, out.istop)
+        assert out.history[0][1] < 0.5 * bnorm and out.history[min(5, out.itn - 1)][1] < 1e-2 * bnorm, (name, out.history[:6])
+        got = out.x._download(0, W).astype(np.float64)
+        assert np.linalg.norm(got - xr) / np.linalg.norm(xr) <= 1e-4, name
