@@ -178,8 +178,11 @@ int jh_bcast_check(const char *expr, int dtype, int nvec, int nscal);
 int jh_bcast_compile(const char *expr, int dtype, int nvec, int nscal, jh_bcast **out);
 /* Mixed element types (src/Jets.jl:899-904 pairs the blocks of every BlockArray operand whatever its eltype): bit k of real_mask
  * says vector operand k of a COMPLEX program is REAL of the matching precision (Float32 in a ComplexF32 program, ...) -- a real
- * mask or weight on a complex vector.  Real (x) complex arithmetic is Julia's: a*(x + iy) = (a*x) + i(a*y), a + z adds to the
- * real part.  real_mask == 0 is jh_bcast_compile. */
+ * mask or weight on a complex vector; bit nvec + k says SCALAR k is a real number (its imaginary slot is ignored).  Real (x) complex
+ * arithmetic is Julia's: a*(x + iy) = (a*x) + i(a*y), a + z adds to the real part -- so a real scalar never meets the 0 * Inf = NaN
+ * of the four-multiplication formula.  real_mask == 0 is jh_bcast_compile.
+ * The same convention without a mask wherever the ABI takes a scalar as (re, im) outside a compiled program (jh_lincomb's
+ * coefficients, the scalar of a JH_OP_SCALE block): an imaginary part that is exactly zero means a REAL scalar. */
 int jh_bcast_compile_mixed(const char *expr, int dtype, int nvec, int real_mask, int nscal, jh_bcast **out);
 int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, const double *scal_re_im);
 /* `count` broadcasts in one call (a tall nonlinear operator evaluates one per child: F(m) and point! are `count` launches

@@ -27,14 +27,16 @@ _programs = {}
 _scalar_ids = itertools.count()
 
 
-def _real_mask(dtype, vecs) -> int:
+def _real_mask(dtype, vecs, scalars=()) -> int:
     """Bit k set: operand k is REAL of the matching precision in a complex broadcast (a real mask on a complex vector,
-    src/Jets.jl:899-904).  Any other eltype mix is refused by the library."""
+    src/Jets.jl:899-904); bit len(vecs) + k: scalar k is a real number (Julia's `a::Real * z` works part by part: no 0 * Inf from
+    an imaginary part the scalar does not have).  Any other eltype mix is refused by the library."""
     dt = np.dtype(dtype)
     if dt.kind != "c":
         return 0
     real = np.dtype(np.float32 if dt == np.complex64 else np.float64)
-    return sum(1 << k for k, v in enumerate(vecs) if np.dtype(v.dtype) == real)
+    mask = sum(1 << k for k, v in enumerate(vecs) if np.dtype(v.dtype) == real)
+    return mask | sum(1 << (len(vecs) + k) for k, a in enumerate(scalars) if not isinstance(a, (complex, np.complexfloating)))
 
 
 def _program(expr: str, dtype, nvec: int, nscal: int, real_mask: int = 0):
@@ -59,7 +61,7 @@ def pack_many(jobs):
     dsts = (C.c_void_p * max(len(jobs), 1))()
     xs, sc, keep = [], [], []
     for k, (dst, expr, vecs, scalars) in enumerate(jobs):
-        progs[k] = _program(expr, dst.dtype, len(vecs), len(scalars), _real_mask(dst.dtype, vecs))
+        progs[k] = _program(expr, dst.dtype, len(vecs), len(scalars), _real_mask(dst.dtype, vecs, scalars))
         dsts[k] = dst.handle
         keep.append(dst)
         for v in vecs:
@@ -90,7 +92,7 @@ def broadcast_(dst: _DevVec, expr: str, vecs=(), scalars=()):
     """dst .= expr over x0..x{k-1} = elements of `vecs`, s0.. = `scalars` (converted to dst's eltype).  dst may alias
     any operand.  Every operation is rounded as written (-ffp-contract=off)."""
     vecs, scalars = list(vecs), list(scalars)
-    h = _program(expr, dst.dtype, len(vecs), len(scalars), _real_mask(dst.dtype, vecs))
+    h = _program(expr, dst.dtype, len(vecs), len(scalars), _real_mask(dst.dtype, vecs, scalars))
     hs = (C.c_void_p * max(len(vecs), 1))(*[v.handle for v in vecs])
     sc = (C.c_double * max(2 * len(scalars), 1))()
     for i, a in enumerate(scalars):

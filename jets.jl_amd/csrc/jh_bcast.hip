@@ -20,7 +20,7 @@
 struct jh_bcast {
     int dtype = JH_F32;
     int nvec = 0, nscal = 0;
-    int real_mask = 0;                  // bit k: vector operand k is REAL in a complex program (a real mask on a complex vector)
+    int real_mask = 0;                  // bit k: vector operand k is REAL in a complex program (a real mask on a complex vector); bit nvec + k: scalar k is
     // a program is device-agnostic (one code object for gfx950); its module is loaded per DEVICE on first use there
     struct on_device {
         hipModule_t module = nullptr;
@@ -114,7 +114,10 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
     std::string scal;
     for (int k = 0; k < nscal; k++) {
         const std::string i = std::to_string(k);
-        scal += cplx ? "    const T s" + i + "(sr" + i + ", si" + i + ");\n" : "    const T s" + i + " = sr" + i + "; (void)si" + i + ";\n";
+        // a REAL scalar of a complex program (bit nvec + k of real_mask): Julia's `a::Real * z` works part by part (the prelude's
+        // mixed operators) -- no 0 * Inf from an imaginary part the scalar does not have
+        if (cplx && !is_real(nvec + k)) scal += "    const T s" + i + "(sr" + i + ", si" + i + ");\n";
+        else scal += "    const R s" + i + " = sr" + i + "; (void)si" + i + ";\n";
     }
     // ---- 16 bytes per lane
     s += "extern \"C\" __global__ __launch_bounds__(256) void jh_bcast_vec(" + params + ")\n{\n" + scal;
@@ -307,7 +310,8 @@ int jh_bcast_compile_mixed(const char *expr, int dtype, int nvec, int real_mask,
     JH_TRY(jh_require_ready());
     JH_REQUIRE(out, "jh_bcast_compile_mixed: null argument");
     JH_TRY(check_request(expr, dtype, nvec, nscal));
-    JH_REQUIRE(real_mask >= 0 && real_mask < (1 << (nvec > 0 ? nvec : 1)) + (nvec == 0 ? 0 : 0), "jh_bcast_compile_mixed: real_mask has bits beyond the %d operands", nvec);
+    JH_REQUIRE(nvec + nscal < 31, "jh_bcast_compile_mixed: at most 30 operands and scalars");
+    JH_REQUIRE(real_mask >= 0 && real_mask < (1 << (nvec + nscal > 0 ? nvec + nscal : 1)), "jh_bcast_compile_mixed: real_mask has bits beyond the %d operands and %d scalars", nvec, nscal);
     JH_REQUIRE(real_mask == 0 || jh_dtype_complex(dtype), "jh_bcast_compile_mixed: real operands only make a difference in a complex program");
     if (real_mask == 0) return jh_bcast_compile(expr, dtype, nvec, nscal, out);
     const std::string key = std::to_string(dtype) + "/" + std::to_string(nvec) + "/" + std::to_string(nscal) + "/r" + std::to_string(real_mask) + "/" + expr;

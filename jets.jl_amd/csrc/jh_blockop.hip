@@ -74,7 +74,7 @@ __device__ inline V apply_block_loaded(const jh_dev_block &b, V x, V c, bool tra
         if (fmode && !b.adjoint) return vmul<S, E, NS, V>(x, x, false);
         return vmul<S, E, NS, V>(c + c, x, cj);
     case JH_OP_SCALE: {
-        if constexpr (E == 1) {
+        if (E == 1 || b.sim == 0.0) {                   // a real scalar multiplies part by part (Julia's a::Real * z)
             return (V)(S)b.sre * x;
         } else {
             V a;
@@ -1030,6 +1030,11 @@ __device__ inline elem<S, E> apply_block(const jh_dev_block &b, elem<S, E> x, in
         elem<S, E> a;
         a.re = (S)b.sre;
         a.im = (E == 2) ? (cj ? -(S)b.sim : (S)b.sim) : (S)0;
+        if (E == 2 && b.sim == 0.0) {                  // a real scalar multiplies part by part (Julia's a::Real * z)
+            x.re = a.re * x.re;
+            x.im = a.re * x.im;
+            return x;
+        }
         return emul<S, E>(a, x);                       // d .= a*m / m .= conj(a)*d   (1159-1160)
     }
     case JH_OP_DIAG: {

@@ -185,6 +185,8 @@ struct LincombArgs {
 
 // dst = c0*x0 + c1*x1 + ... left to right, every product and sum rounded in S (no contraction:
 // the translation unit is built with -ffp-contract=off).  E = scalars per element (1 real, 2 complex).
+// A coefficient whose imaginary part is exactly zero is a REAL scalar: Julia multiplies `a::Real * z::Complex` part by part, so
+// 1.0 * (x + Inf i) keeps x where the four-multiplication formula would make it NaN (0 * Inf), and -0.0 parts keep their sign.
 template <typename S, int E>
 __device__ inline void lincomb_elem(const LincombArgs &a, int64_t scalar_index, S *out)
 {
@@ -198,8 +200,8 @@ __device__ inline void lincomb_elem(const LincombArgs &a, int64_t scalar_index, 
             tr = (S)a.cre[j] * xj[0];
         } else {
             S cr = (S)a.cre[j], ci = (S)a.cim[j], xr = xj[0], xi = xj[1];
-            tr = cr * xr - ci * xi;     // Julia Base complex.jl `*`
-            ti = cr * xi + ci * xr;
+            if (a.cim[j] == 0.0) { tr = cr * xr; ti = cr * xi; }           // a REAL coefficient: Julia's `a::Real * z`, part by part
+            else { tr = cr * xr - ci * xi; ti = cr * xi + ci * xr; }       // Julia Base complex.jl `*`
         }
         if (j == 0) { accr = tr; acci = ti; }
         else { accr = accr + tr; acci = acci + ti; }
@@ -231,8 +233,8 @@ __global__ void k_lincomb(S *dst, int64_t n_scalars, LincombArgs a)   // dst may
                         tr = (S)a.cre[j] * xin[j].v[e];
                     } else {
                         S cr = (S)a.cre[j], ci = (S)a.cim[j], xr = xin[j].v[e], xi = xin[j].v[e + 1];
-                        tr = cr * xr - ci * xi;
-                        ti = cr * xi + ci * xr;
+                        if (a.cim[j] == 0.0) { tr = cr * xr; ti = cr * xi; }
+                        else { tr = cr * xr - ci * xi; ti = cr * xi + ci * xr; }
                     }
                     if (j == 0) { accr = tr; acci = ti; }
                     else { accr = accr + tr; acci = acci + ti; }
@@ -299,11 +301,13 @@ template <int OP> __device__ inline void red_init(double &a0, double &a1)
     else if (OP == RED_EXTREMA) { a0 = INFINITY; a1 = -INFINITY; }
     else { a0 = 0; a1 = 0; }
 }
+// max / min as Julia defines them on floats (the reference folds with `max` / `min`, src/Jets.jl:835-838, and the stdlib's block
+// norms and extrema do the same): a NaN is the answer, and stays the answer -- `b > NaN` and `b < NaN` are false for every b
 template <int OP> __device__ inline void red_combine(double &a0, double &a1, double b0, double b1)
 {
-    if (OP == RED_MAXABS) { a0 = b0 > a0 ? b0 : a0; }
-    else if (OP == RED_MINABS) { a0 = b0 < a0 ? b0 : a0; }
-    else if (OP == RED_EXTREMA) { a0 = b0 < a0 ? b0 : a0; a1 = b1 > a1 ? b1 : a1; }
+    if (OP == RED_MAXABS) { a0 = (b0 > a0 || b0 != b0) ? b0 : a0; }
+    else if (OP == RED_MINABS) { a0 = (b0 < a0 || b0 != b0) ? b0 : a0; }
+    else if (OP == RED_EXTREMA) { a0 = (b0 < a0 || b0 != b0) ? b0 : a0; a1 = (b1 > a1 || b1 != b1) ? b1 : a1; }
     else { a0 += b0; a1 += b1; }
 }
 template <typename S, int E, int OP>
@@ -320,14 +324,14 @@ __device__ inline void red_elem(const S *xe, const S *ye, double p, double &a0, 
     } else if (OP == RED_SUMSQ) {
         a0 += xr * xr + xi * xi;
     } else if (OP == RED_EXTREMA) {
-        a0 = xr < a0 ? xr : a0;
-        a1 = xr > a1 ? xr : a1;
+        a0 = (xr < a0 || xr != xr) ? xr : a0;
+        a1 = (xr > a1 || xr != xr) ? xr : a1;
     } else {
         const double ab = (E == 2) ? hypot(xr, xi) : fabs(xr);
         if (OP == RED_SUMABS) a0 += ab;
         else if (OP == RED_COUNTNZ) a0 += (ab != 0.0) ? 1.0 : 0.0;
-        else if (OP == RED_MAXABS) a0 = ab > a0 ? ab : a0;
-        else if (OP == RED_MINABS) a0 = ab < a0 ? ab : a0;
+        else if (OP == RED_MAXABS) a0 = (ab > a0 || ab != ab) ? ab : a0;
+        else if (OP == RED_MINABS) a0 = (ab < a0 || ab != ab) ? ab : a0;
         else if (OP == RED_SUMPOW) {
             const int ip = (int)p;                     // small integer p: repeated multiplication instead of pow()
             if ((double)ip == p && ip >= 1 && ip <= 8) { double t = ab; for (int q = 1; q < ip; q++) t *= ab; a0 += t; }
@@ -713,6 +717,21 @@ int jh_extrema(const jh_bvec *x, double *mn, double *mx)
     JH_REQUIRE(x->length > 0, "jh_extrema: empty vector");
     double r0 = 0, r1 = 0;
     JH_TRY((reduce_dispatch<RED_EXTREMA>(x->dtype, x->data, nullptr, x->length, 0.0, &r0, &r1)));
+    if (r0 != r0 || r1 != r1) {
+        // a NaN somewhere.  The reference folds the BLOCKS' extrema with `_mn < mn && (mn = _mn)` (src/Jets.jl:870-878), and the
+        // stdlib's extrema of a block holding a NaN is (NaN, NaN) (Julia >= 1.8): a NaN in the first block is the answer; a later
+        // block holding one compares false both ways and drops out, finite values and all.  One reduction per block, in order.
+        bool first = true;
+        for (int64_t i = 0; i < x->nblocks; i++) {
+            if (x->len(i) == 0) continue;
+            double b0 = 0, b1 = 0;
+            JH_TRY((reduce_dispatch<RED_EXTREMA>(x->dtype, x->ptr(x->off[i]), nullptr, x->len(i), 0.0, &b0, &b1)));
+            if (b0 != b0 || b1 != b1) b0 = b1 = NAN;
+            if (first) { r0 = b0; r1 = b1; first = false; continue; }
+            if (b0 < r0) r0 = b0;
+            if (b1 > r1) r1 = b1;
+        }
+    }
     *mn = r0;
     *mx = r1;
     return JH_OK;

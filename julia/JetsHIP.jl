@@ -316,9 +316,11 @@ function _emit(bc::Broadcast.Broadcasted, vecs, scals)
     op in ("+", "-", "*", "/") ? (length(args) == 1 ? "($op$(args[1]))" : "(" * join(args, " $op ") * ")") : "$op(" * join(args, ", ") * ")"
 end
 const _bcast_programs = Dict{Tuple{String,DataType,Int,Int,Int},Ptr{Cvoid}}()
-# bit k-1 set: vector leaf k is REAL of the matching precision in a complex broadcast (a real mask on a complex vector)
-_real_mask(::Type{T}, vecs) where {T<:Real} = 0
-_real_mask(::Type{Complex{R}}, vecs) where {R} = sum(Int[1 << (k - 1) for k = 1:length(vecs) if eltype(vecs[k]) === R])
+# bit k-1 set: vector leaf k is REAL of the matching precision in a complex broadcast (a real mask on a complex vector);
+# bit length(vecs)+k-1: scalar k is a Real (a::Real * z works part by part: no 0 * Inf from an imaginary part it does not have)
+_real_mask(::Type{T}, vecs, scals) where {T<:Real} = 0
+_real_mask(::Type{Complex{R}}, vecs, scals) where {R} =
+    sum(Int[1 << (k - 1) for k = 1:length(vecs) if eltype(vecs[k]) === R]) + sum(Int[1 << (length(vecs) + k - 1) for k = 1:length(scals) if scals[k] isa Real])
 function _bcast!(dest::DevVec{T}, bc::Broadcast.Broadcasted) where {T}
     vecs, scals = Any[], Number[]
     expr = _emit(bc, vecs, scals)
@@ -328,7 +330,7 @@ function _bcast!(dest::DevVec{T}, bc::Broadcast.Broadcasted) where {T}
         check(ccall((:jh_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), handle(dest), hs[1]))
         return dest
     end
-    mask = _real_mask(T, vecs)
+    mask = _real_mask(T, vecs, scals)
     prog = get!(_bcast_programs, (expr, T, length(vecs), length(scals), mask)) do
         h = Ref{Ptr{Cvoid}}()
         if mask == 0

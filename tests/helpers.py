@@ -56,3 +56,20 @@ def rel_err(a, b) -> float:
     a, b = np.asarray(a, dtype=np.complex128), np.asarray(b, dtype=np.complex128)
     den = np.linalg.norm(b.ravel())
     return float(np.linalg.norm((a - b).ravel()) / (den if den else 1.0))
+
+
+def assert_same_values(a, b, what=""):
+    """Bit for bit, except that a NaN matches any NaN: x86 and CDNA pick different payloads / signs for the NaN an invalid operation
+    produces, and which operand's payload survives -- no Julia program can observe that through `==` or `isnan`."""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.dtype == b.dtype and a.shape == b.shape, f"{what}: {a.dtype}{a.shape} vs {b.dtype}{b.shape}"
+    if a.dtype.kind == "c":
+        rt = np.float32 if a.dtype == np.complex64 else np.float64
+        a, b = a.view(rt), b.view(rt)
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb), f"{what}: NaN in different places ({int(na.sum())} vs {int(nb.sum())}; first at {np.flatnonzero(na != nb)[:5]})"
+    it = np.uint32 if a.dtype == np.float32 else np.uint64
+    ia, ib = a.view(it)[~na.ravel().reshape(a.shape)] if a.ndim else a.view(it), b.view(it)[~nb.ravel().reshape(b.shape)] if b.ndim else b.view(it)
+    if not np.array_equal(ia, ib):
+        bad = np.flatnonzero(ia != ib)
+        raise AssertionError(f"{what}: {bad.size} non-NaN elements differ bitwise; first at {bad[:5]}")

@@ -605,3 +605,56 @@ def test_grids_of_equal_blocks_of_every_kind_tiled_and_not(Jets, oracle, dt, sha
     want_m = oracle.block_df_adj(ops, [b.copy() for b in hmt], want_d)
     assert_bits_equal(mt.to_numpy(), np.concatenate(want_m), f"{M}x{K} adjoint, general_tile={general_tile}")
     J.close(A)
+
+
+# ---- IEEE special values through the hot loops (round 3) -----------------------------------------------------------------------------
+def test_special_values_go_through_every_kernel_family_like_on_the_cpu(Jets, oracle):
+    """Signed zeros, infinities, NaN, denormals and the largest finite values in the coefficients AND the vectors, four element
+    types: tall forward / ordered adjoint / fused A'A, rows of every elementwise kind, the one-pass step, a grid with a zero block,
+    a + - + sum, dense children, jh_lincomb and the compiled broadcast give the oracle's value element by element (0 * Inf = NaN
+    where the reference multiplies, an untouched 0 where it skips a zero block; complex products by the four-multiplication
+    formula; REAL scalars on complex data part by part, as Julia's a::Real * z).  Bit for bit except for the payload of a NaN.
+    The checks live in tools/check_specials.py (also a stand-alone program)."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("check_specials", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_specials.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    results = mod.run_checks(Jets, oracle)
+    assert len(results) >= 80
+    bad = [r for r in results if r[2] is not True]
+    assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("dt", [np.complex64, np.complex128])
+def test_a_real_scalar_multiplies_complex_data_part_by_part(Jets, oracle, dt):
+    """Julia: `a::Real * z` = Complex(a*re, a*im) -- 1.0 * (x + Inf i) keeps x, and (-0.0) parts keep their sign, where the
+    four-multiplication formula with an imaginary part of 0 would give NaN / +0.0.  The ABI takes scalars as (re, im): an imaginary
+    part that is exactly zero means a real scalar (include/jetship.h)."""
+    from .helpers import assert_same_values
+
+    z = np.array([complex(-0.0, 3.0), complex(2.0, -0.0), complex(-0.0, -0.0), complex(1.0, np.inf), complex(-np.inf, 2.0), complex(5.0, -7.0)] * 3, dtype=dt)
+    x = Jets.from_numpy(z)
+    out = Jets.zeros(Jets.space(x))
+    for a in (1.0, 0.75, -2.0):
+        expect = np.empty_like(z)
+        rt = z.real.dtype.type
+        with np.errstate(all="ignore"):
+            expect.real, expect.imag = rt(a) * z.real, rt(a) * z.imag
+        Jets.lincomb_(out, [a], [x])
+        assert_same_values(out.to_numpy(), expect, f"jh_lincomb, a = {a}")
+        Jets.broadcast_(out, "s0*x0", [x], [a])
+        assert_same_values(out.to_numpy(), expect, f"compiled broadcast, a = {a}")
+        spc = Jets.space(x)
+        S = Jets.blockop([[Jets.JopLn(dom=spc, rng=spc, df=Jets.constdiag_df, df_adj=Jets.constdiag_df_adj, s={"a": a})], [Jets.JopIdentity(spc)]])
+        got = (S * x).to_numpy()
+        assert_same_values(got[:z.size], expect, f"scalar block, a = {a}")
+        assert_same_values(oracle.block_df([[oracle.Block("scale", z.size, scale=a)], [oracle.Block("identity", z.size)]],
+                                           [np.zeros(z.size, dtype=dt) for _ in range(2)], [z])[0], expect, f"oracle scalar block, a = {a}")
+    c = complex(0.75, 0.5)                                         # a COMPLEX scalar keeps the four-multiplication formula
+    with np.errstate(all="ignore"):
+        expect = np.array([complex(c.real * v.real - c.imag * v.imag, c.real * v.imag + c.imag * v.real) for v in z.astype(np.complex128)], dtype=np.complex128)
+    Jets.lincomb_(out, [c], [x])
+    got = out.to_numpy()
+    assert np.array_equal(np.isnan(got.view(got.real.dtype)), np.isnan(expect.astype(dt).view(got.real.dtype)))

@@ -283,3 +283,31 @@ def test_pinned_host_buffers_round_trip(Jets, oracle):
         Jets.host_unregister(host)                                                    # not registered any more
     cube = Jets.pinned_empty((8, 4, 2), np.float64)
     assert cube.flags.f_contiguous and cube.shape == (8, 4, 2)
+
+
+# ---- IEEE special values in the reductions (round 3) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_nan_in_norm_inf_and_extrema_follows_the_references_folds(Jets, oracle, dt):
+    """`max` / `min` answer NaN when they meet one (src/Jets.jl:835-838); extrema folds the blocks' extrema with `<` / `>` (:870-878):
+    a NaN in the first block is the answer, a later block holding one drops out whole.  Big blocks too (several workgroups)."""
+    R = Jets.JetBSpace([Jets.JetSpace(dt, 3), Jets.JetSpace(dt, 70001), Jets.JetSpace(dt, 2, 5)])
+    x = Jets.rand(R, seed=5, stream=2)
+    x.assign(2.0 * x - 1.0 * Jets.ones(R))
+    clean = dev_blocks_to_numpy(x)
+    assert (float(Jets.extrema(x)[0]), float(Jets.extrema(x)[1])) == oracle.barr_extrema(clean)
+    Jets.setblock_(x, 1, np.where(np.arange(70001) == 65000, np.nan, clean[1]).astype(dt))   # a NaN deep inside the second block (0-based index)
+    blocks = dev_blocks_to_numpy(x)
+    assert math.isnan(float(Jets.norm(x, math.inf))) and math.isnan(oracle.barr_norm(blocks, math.inf))
+    assert math.isnan(float(Jets.norm(x, -math.inf))) and math.isnan(oracle.barr_norm(blocks, -math.inf))
+    assert math.isnan(float(Jets.norm(x))) and math.isnan(float(Jets.norm(x, 1)))
+    mn, mx = Jets.extrema(x)
+    assert (float(mn), float(mx)) == oracle.barr_extrema(blocks)
+    flat02 = np.concatenate([clean[0].ravel(), clean[2].ravel()])
+    assert (float(mn), float(mx)) == (flat02.min(), flat02.max())                # the block with the NaN is not seen at all
+    Jets.setblock_(x, 0, np.array([0.25, np.nan, -0.5], dtype=dt))                # ... and a NaN in the FIRST block is the answer
+    mn, mx = Jets.extrema(x)
+    omn, omx = oracle.barr_extrema(dev_blocks_to_numpy(x))
+    assert math.isnan(float(mn)) and math.isnan(float(mx)) and math.isnan(omn) and math.isnan(omx)
+    y = Jets.from_numpy(np.array([1, 2, np.inf, -3], dtype=dt))                  # infinities are ordinary values
+    assert float(Jets.norm(y, math.inf)) == math.inf and float(Jets.norm(y)) == math.inf
+    assert tuple(float(v) for v in Jets.extrema(y)) == (-3.0, math.inf)

@@ -368,3 +368,18 @@ def test_multiple_linearizations_literal_values():
         out = jo.block_df([[jo.Block("square", 2, coeff=np.array(mo))]], [np.zeros(2)], [dm])[0]
         assert out.tolist() == want
     assert jo.block_f([[jo.Block("square", 2, coeff=np.zeros(2))]], [np.zeros(2)], [np.array([3.0, 4.0])])[0].tolist() == [9.0, 16.0]
+
+
+# ---- NaN in the ordered reductions: the reference folds with Julia's `max` / `min` (src/Jets.jl:835-838), which answer NaN when either
+# argument is one; its extrema folds the blocks' (stdlib, NaN-propagating) extrema with `<` / `>` (:870-878), so a NaN in the first
+# block is the answer and a later block that holds one drops out of the comparison altogether
+@pytest.mark.parametrize("dt", REAL)
+def test_nan_in_norm_inf_and_extrema_follows_julias_max_min(dt):
+    nan = np.array(np.nan, dtype=dt)
+    x = [np.array([1, -5, 2], dtype=dt), np.array([3, nan, -9], dtype=dt), np.array([4, 0.5], dtype=dt)]
+    assert math.isnan(jo.barr_norm(x, math.inf)) and math.isnan(jo.barr_norm(x, -math.inf))
+    assert jo.barr_extrema(x) == (-5.0, 4.0)                          # the middle block compares false both ways: its -9 and 3 are not seen
+    y = [x[1], x[0], x[2]]
+    mn, mx = jo.barr_extrema(y)
+    assert math.isnan(mn) and math.isnan(mx)                          # NaN in the first block sticks
+    assert jo.barr_norm([np.array([-0.0], dtype=dt)], -math.inf) == 0.0 and not np.signbit(jo.barr_norm([np.array([-0.0], dtype=dt)], -math.inf))
