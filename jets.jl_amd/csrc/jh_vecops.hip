@@ -311,10 +311,11 @@ template <int OP> __device__ inline void red_combine(double &a0, double &a1, dou
     else { a0 += b0; a1 += b1; }
 }
 template <typename S, int E, int OP>
-__device__ inline void red_elem(const S *xe, const S *ye, double p, double &a0, double &a1)
+__device__ inline void red_elem(const S *xe, const S *ye, double p, double scale, double &a0, double &a1)
 {
-    const double xr = (double)xe[0];
-    const double xi = (E == 2) ? (double)xe[1] : 0.0;
+    // scale: 1.0, or the power of two jh_norm rescales by when the plain sum of squares / powers left the double range (exact)
+    const double xr = (OP == RED_SUMSQ || OP == RED_SUMPOW) ? (double)xe[0] * scale : (double)xe[0];
+    const double xi = (E == 2) ? ((OP == RED_SUMSQ || OP == RED_SUMPOW) ? (double)xe[1] * scale : (double)xe[1]) : 0.0;
     if (OP == RED_DOT) {
         const double yr = (double)ye[0];
         const double yi = (E == 2) ? (double)ye[1] : 0.0;
@@ -363,7 +364,7 @@ __device__ inline void block_reduce_store(double a0, double a1, double *partials
 }
 
 template <typename S, int E, int NS, int OP>
-__global__ void k_reduce(const S *__restrict__ x, const S *__restrict__ y, int64_t n_scalars, double p, double *__restrict__ partials)
+__global__ void k_reduce(const S *__restrict__ x, const S *__restrict__ y, int64_t n_scalars, double p, double scale, double *__restrict__ partials)
 {
     double a0, a1;
     red_init<OP>(a0, a1);
@@ -382,17 +383,17 @@ __global__ void k_reduce(const S *__restrict__ x, const S *__restrict__ y, int64
 #pragma unroll
         for (int u = 0; u < UN; u++)
 #pragma unroll
-            for (int e = 0; e < NS; e += E) red_elem<S, E, OP>(&xv[u].v[e], &yv[u].v[e], p, a0, a1);
+            for (int e = 0; e < NS; e += E) red_elem<S, E, OP>(&xv[u].v[e], &yv[u].v[e], p, scale, a0, a1);
     }
     for (; v < nvec; v += stride) {
         Pack<S, NS> xv = reinterpret_cast<const Pack<S, NS> *>(x)[v], yv;
         if (OP == RED_DOT) yv = reinterpret_cast<const Pack<S, NS> *>(y)[v];
 #pragma unroll
-        for (int e = 0; e < NS; e += E) red_elem<S, E, OP>(&xv.v[e], &yv.v[e], p, a0, a1);
+        for (int e = 0; e < NS; e += E) red_elem<S, E, OP>(&xv.v[e], &yv.v[e], p, scale, a0, a1);
     }
     const int64_t tail0 = nvec * NS;
     const int64_t ntail_elems = (n_scalars - tail0) / E;
-    if (tid < ntail_elems) red_elem<S, E, OP>(x + tail0 + tid * E, OP == RED_DOT ? y + tail0 + tid * E : x, p, a0, a1);
+    if (tid < ntail_elems) red_elem<S, E, OP>(x + tail0 + tid * E, OP == RED_DOT ? y + tail0 + tid * E : x, p, scale, a0, a1);
     block_reduce_store<OP>(a0, a1, partials);
 }
 
@@ -420,7 +421,7 @@ __global__ void k_reduce_final(const double *__restrict__ partials, int nparts, 
 }
 
 template <typename S, int E, int OP>
-int reduce_launch(const void *x, const void *y, int64_t n_elems, double p, double *r0, double *r1)
+int reduce_launch(const void *x, const void *y, int64_t n_elems, double p, double *r0, double *r1, double scale)
 {
     jh_context &c = jh_ctx();
     const int64_t n_scalars = n_elems * E;
@@ -437,11 +438,11 @@ int reduce_launch(const void *x, const void *y, int64_t n_elems, double p, doubl
     if (aligned) {
         grid = clamp_grid(n_scalars / NSV + 1);
         hipLaunchKernelGGL((k_reduce<S, E, NSV, OP>), dim3(grid), dim3(WG), 0, c.stream, (const S *)x, (const S *)y,
-                           n_scalars, p, partials);
+                           n_scalars, p, scale, partials);
     } else {
         grid = clamp_grid(n_elems + 1);
         hipLaunchKernelGGL((k_reduce<S, E, E, OP>), dim3(grid), dim3(WG), 0, c.stream, (const S *)x, (const S *)y, n_scalars,
-                           p, partials);
+                           p, scale, partials);
     }
     JH_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL((k_reduce_final<OP>), dim3(1), dim3(WG), 0, c.stream, partials, grid, c.red_dev);
@@ -454,13 +455,13 @@ int reduce_launch(const void *x, const void *y, int64_t n_elems, double p, doubl
 }
 
 template <int OP>
-int reduce_dispatch(int dtype, const void *x, const void *y, int64_t n, double p, double *r0, double *r1)
+int reduce_dispatch(int dtype, const void *x, const void *y, int64_t n, double p, double *r0, double *r1, double scale = 1.0)
 {
     switch (dtype) {
-    case JH_F32: return reduce_launch<float, 1, OP>(x, y, n, p, r0, r1);
-    case JH_F64: return reduce_launch<double, 1, OP>(x, y, n, p, r0, r1);
-    case JH_C32: return reduce_launch<float, 2, OP>(x, y, n, p, r0, r1);
-    case JH_C64: return reduce_launch<double, 2, OP>(x, y, n, p, r0, r1);
+    case JH_F32: return reduce_launch<float, 1, OP>(x, y, n, p, r0, r1, scale);
+    case JH_F64: return reduce_launch<double, 1, OP>(x, y, n, p, r0, r1, scale);
+    case JH_C32: return reduce_launch<float, 2, OP>(x, y, n, p, r0, r1, scale);
+    case JH_C64: return reduce_launch<double, 2, OP>(x, y, n, p, r0, r1, scale);
     }
     return jh_fail(JH_ERR_INVALID, "unknown dtype %d", dtype);
 }
@@ -699,12 +700,26 @@ int jh_norm(const jh_bvec *x, double p, double *out)
     } else if (p == 0.0) {          // :841-842
         JH_TRY((reduce_dispatch<RED_COUNTNZ>(x->dtype, x->data, nullptr, x->length, p, &r0, &r1)));
         *out = r0;
-    } else if (p == 2.0) {          // :843-846 with p = 2: (sum_i norm(x_i)^2)^(1/2)
-        JH_TRY((reduce_dispatch<RED_SUMSQ>(x->dtype, x->data, nullptr, x->length, p, &r0, &r1)));
-        *out = sqrt(r0);
-    } else {                        // :843-846
-        JH_TRY((reduce_dispatch<RED_SUMPOW>(x->dtype, x->data, nullptr, x->length, p, &r0, &r1)));
-        *out = pow(r0, 1.0 / p);
+    } else {                        // :843-846; p = 2: (sum_i norm(x_i)^2)^(1/2)
+        const bool two = (p == 2.0);
+        if (two) JH_TRY((reduce_dispatch<RED_SUMSQ>(x->dtype, x->data, nullptr, x->length, p, &r0, &r1)));
+        else JH_TRY((reduce_dispatch<RED_SUMPOW>(x->dtype, x->data, nullptr, x->length, p, &r0, &r1)));
+        *out = two ? sqrt(r0) : pow(r0, 1.0 / p);
+        // The stdlib's block norms rescale (BLAS nrm2 / generic_normp), so they neither overflow on 1e200 nor lose 1e-200.  The
+        // plain sum above does when the powers leave the double range (only Float64 data can do that for p = 2): seen as an
+        // infinite or vanishing sum, in which case the pass is repeated on x / 2^k with 2^k ~ max|x| (a power of two: exact).
+        if (p > 0 && (std::isinf(r0) || r0 < 1e-290)) {
+            double big = 0, unused = 0;
+            JH_TRY((reduce_dispatch<RED_MAXABS>(x->dtype, x->data, nullptr, x->length, p, &big, &unused)));
+            if (big > 0 && std::isfinite(big)) {
+                int ex = 0;
+                (void)frexp(big, &ex);
+                const double down = ldexp(1.0, -ex), up = ldexp(1.0, ex);
+                if (two) JH_TRY((reduce_dispatch<RED_SUMSQ>(x->dtype, x->data, nullptr, x->length, p, &r0, &r1, down)));
+                else JH_TRY((reduce_dispatch<RED_SUMPOW>(x->dtype, x->data, nullptr, x->length, p, &r0, &r1, down)));
+                *out = (two ? sqrt(r0) : pow(r0, 1.0 / p)) * up;
+            }
+        }
     }
     return JH_OK;
 }

@@ -311,3 +311,23 @@ def test_nan_in_norm_inf_and_extrema_follows_the_references_folds(Jets, oracle, 
     y = Jets.from_numpy(np.array([1, 2, np.inf, -3], dtype=dt))                  # infinities are ordinary values
     assert float(Jets.norm(y, math.inf)) == math.inf and float(Jets.norm(y)) == math.inf
     assert tuple(float(v) for v in Jets.extrema(y)) == (-3.0, math.inf)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_norm_of_huge_and_tiny_values_neither_overflows_nor_vanishes(Jets, oracle, dt):
+    """The stdlib's block norms rescale (BLAS nrm2, generic_normp): norm([1e200, 1e200]) is 1.41e200 and norm([1e-200]) is 1e-200.  The
+    device sums squares in fp64: Float32 data cannot leave that range, Float64 data can -- then the pass is repeated on x / 2^k."""
+    rt = np.float32 if dt in (np.float32, np.complex64) else np.float64
+    big, tiny = (rt(1e30), rt(1e-30)) if rt == np.float32 else (rt(1e200), rt(1e-200))
+    for v in (big, tiny):
+        h = (np.arange(1, 5001) % 7 + 1).astype(rt) * v
+        h = h.astype(dt) if np.dtype(dt).kind != "c" else (h + 1j * h[::-1]).astype(dt)
+        x = Jets.from_numpy(h)
+        truth = float(v) * float(np.linalg.norm((h / v).astype(np.complex128)))
+        assert float(Jets.norm(x)) == pytest.approx(truth, rel=1e-6 if rt == np.float32 else 1e-14)
+        # the reference itself leaves the range one level up: it squares the BLOCK norms in real(T) (`norm(_x,p)^_p`, src/Jets.jl:843-846),
+        # so it answers Inf / 0 here -- a deviation kept on purpose (DESIGN.md section 5): the device answer is the true norm
+        assert oracle.barr_norm([h], 2.0) == (math.inf if v == big else 0.0)
+        t3 = float(v) * float(np.sum(np.abs((h / v).astype(np.complex128)) ** 3) ** (1 / 3))
+        assert float(Jets.norm(x, 3)) == pytest.approx(t3, rel=1e-6 if rt == np.float32 else 1e-13)
+    assert float(Jets.norm(Jets.zeros(Jets.JetSpace(dt, 100)))) == 0.0
