@@ -243,6 +243,10 @@ int jh_blockop_mul_adj_range(const jh_blockop *op, jh_bvec *m, const jh_bvec *d,
  * once and the range-side intermediate is never materialised.  Same rounding sequence as the
  * unfused pair, so the result is bit-identical to jh_blockop_mul followed by jh_blockop_mul_adj. */
 int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m);
+/* The same fused A'A restricted to the elements [first_elem, first_elem+count) of the domain (16-byte aligned bounds): for a host
+ * that pipelines the exchange of y range by range against the kernels -- CG on the normal equations over a row partition
+ * (jh_cgnr_solve_partitioned / _team do exactly that).  Identical to jh_blockop_normal_mul on those elements. */
+int jh_blockop_normal_mul_range(const jh_blockop *op, jh_bvec *y, const jh_bvec *m, int64_t first_elem, int64_t count);
 /* JetSum of tall operators, src/Jets.jl:628-655, fused: d = sum_k sign_k*(scale_k*(A_k m)) and its adjoint
  * m = sum_k sign_k*(A_k'(scale_k d)) for tall all-DIAG operators of identical shape, ANY number of them (four per launch, later
  * launches continuing the left-to-right sum: same sequence; (K + 2*ceil(K/4) - 1) range-sized streams where the unfused chain
@@ -331,7 +335,8 @@ int jh_cgls_solve_team(int n, const jh_blockop *const *ops, jh_bvec *const *us, 
  * recurrence ||r_k||^2 = ||r_{k-1}||^2 - alpha_k gamma_{k-1}.  Same iterates as CGLS / LSQR in exact arithmetic; in floating point its
  * residual A'r is updated by recurrence in the domain, so the attainable accuracy goes with cond(A)^2 (CGLS / LSQR: cond(A)) -- meant
  * for well-conditioned operators and for throughput.  istop / history / result record as jh_cgls_solve (r2norm = the recurrence's
- * sqrt(||r||^2 + damp^2 ||x||^2)).  _partitioned / _team: one all-reduce of the domain vector A_k'A_k p per iteration. */
+ * sqrt(||r||^2 + damp^2 ||x||^2)).  _partitioned / _team: the domain vector A_k'A_k p is the only thing
+ * exchanged, in 4 element ranges (jh_blockop_normal_mul_range), each all-reduced under the next range's kernel. */
 int jh_cgnr_solve(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter,
                   int force_maxiter, jh_lsqr_result *res, double *history);
 int jh_cgnr_solve_partitioned(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter,

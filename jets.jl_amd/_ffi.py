@@ -121,6 +121,7 @@ SYMBOLS = {
     "jh_blockop_f": (_int, [_vp, _vp, _vp]),
     "jh_blockop_point": (_int, [_vp, _vp]),
     "jh_blockop_mul_adj_range": (_int, [_vp, _vp, _vp, _i64, _i64]),
+    "jh_blockop_normal_mul_range": (_int, [_vp, _vp, _vp, _i64, _i64]),
     "jh_blockop_normal_mul": (_int, [_vp, _vp, _vp]),
     "jh_blocksum_mul": (_int, [_int, _vpp, _dblp, _dblp, _vp, _vp]),
     "jh_blocksum_mul_adj": (_int, [_int, _vpp, _dblp, _dblp, _vp, _vp]),

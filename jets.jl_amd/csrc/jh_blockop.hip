@@ -3460,6 +3460,45 @@ int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m)
     return jh_fail(JH_ERR_INVALID, "jh_blockop_normal_mul: unknown dtype %d", op->dtype);
 }
 
+// The fused A'A over the elements [first_elem, first_elem + count) of the domain: for a host that pipelines the exchange of y range by
+// range against the kernels (CG on the normal equations over a row partition).  Elementwise rows: y's range depends on m's range only.
+int jh_blockop_normal_mul_range(const jh_blockop *op, jh_bvec *y, const jh_bvec *m, int64_t first_elem, int64_t count)
+{
+    JH_TRY(jh_enter(op, y, m));
+    JH_REQUIRE(op && y && m, "jh_blockop_normal_mul_range: null argument");
+    JH_REQUIRE(y->dtype == op->dtype && m->dtype == op->dtype, "jh_blockop_normal_mul_range: dtype mismatch");
+    JH_REQUIRE(y->length == op->col_off[(size_t)op->ncol] && m->length == y->length,
+               "jh_blockop_normal_mul_range: domain vectors have %lld / %lld elements, operator domain has %lld", (long long)y->length,
+               (long long)m->length, (long long)op->col_off[(size_t)op->ncol]);
+    JH_REQUIRE(y->data != m->data, "jh_blockop_normal_mul_range: y must not alias m");
+    JH_REQUIRE(first_elem >= 0 && count >= 0 && first_elem + count <= y->length,
+               "jh_blockop_normal_mul_range: elements [%lld, %lld) outside the domain vector (%lld elements)", (long long)first_elem,
+               (long long)(first_elem + count), (long long)y->length);
+    const int64_t es = (int64_t)jh_dtype_size(op->dtype);
+    JH_REQUIRE((first_elem * es) % 16 == 0 && (count * es) % 16 == 0, "jh_blockop_normal_mul_range: chunk boundaries must be 16-byte aligned");
+    const int64_t n = op->row_len[0], lo = first_elem, hi = first_elem + count;
+    if (tall_mixed_ok(op, y->data, m->data)) {
+        if (op->nonlinear && !op->pointed)
+            return jh_fail(JH_ERR_STATE, "jh_blockop_normal_mul_range: operator has nonlinear blocks and no linearisation point (jh_blockop_point)");
+        switch (op->dtype) {
+        case JH_F32: return launch_tall_adj_mixed<float, 1, 4, 1>(op, y->data, m->data, n, lo, hi);
+        case JH_F64: return launch_tall_adj_mixed<double, 1, 2, 1>(op, y->data, m->data, n, lo, hi);
+        case JH_C32: return launch_tall_adj_mixed<float, 2, 4, 1>(op, y->data, m->data, 2 * n, 2 * lo, 2 * hi);
+        case JH_C64: return launch_tall_adj_mixed<double, 2, 2, 1>(op, y->data, m->data, 2 * n, 2 * lo, 2 * hi);
+        }
+    }
+    if (!tall_fast_ok(op, y->data, m->data) || op->nrow < 2)
+        return jh_fail(JH_ERR_UNSUPPORTED,
+                       "jh_blockop_normal_mul_range: fused A'A needs a tall (>= 2 rows) operator of elementwise rows with equal, 16-byte aligned blocks");
+    switch (op->dtype) {
+    case JH_F32: return launch_tall_adj<float, 1, 4, 1>(op, y->data, m->data, n, lo, hi);
+    case JH_F64: return launch_tall_adj<double, 1, 2, 1>(op, y->data, m->data, n, lo, hi);
+    case JH_C32: return launch_tall_adj<float, 2, 4, 1>(op, y->data, m->data, 2 * n, 2 * lo, 2 * hi);
+    case JH_C64: return launch_tall_adj<double, 2, 2, 1>(op, y->data, m->data, 2 * n, 2 * lo, 2 * hi);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blockop_normal_mul_range: unknown dtype %d", op->dtype);
+}
+
 }  // extern "C" (templated launch helpers of the fused sum follow)
 
 static int sum_prepare(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, const jh_bvec *rng,

@@ -247,6 +247,37 @@ def test_ranged_adjoint_equals_whole_adjoint(Jets, oracle, dt):
         check(lib.jh_blockop_mul_adj_range(nat.handle, parts.handle, d.handle, n - 4, 8))   # past the end
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.complex128])
+@pytest.mark.parametrize("mixed", [False, True])
+def test_ranged_normal_operator_equals_the_whole_one(Jets, oracle, dt, mixed):
+    """jh_blockop_normal_mul_range over consecutive element ranges == jh_blockop_normal_mul (== the unfused chain), bit for bit; all-diagonal
+    rows and rows of several kinds."""
+    from jets_jl_amd._ffi import lib, check
+
+    nrow, shape = 5, (64, 64, 20)
+    A, diags, ops, _ = make_tall_diag(Jets, oracle, dt, nrow, shape)
+    if mixed:
+        spc = Jets.JetSpace(dt, *shape)
+        A = Jets.blockop([[Jets.JopDiagonal(diags[0])], [Jets.JopIdentity(spc)], [Jets.JopZeroBlock(spc, spc)], [Jets.JopDiagonal(diags[1]).H], [Jets.JopDiagonal(diags[2])]])
+    nat = _native(Jets, A)
+    m = Jets.rand(Jets.domain(A), seed=83, stream=0)
+    whole = Jets.mul_(Jets.zeros(Jets.domain(A)), A.H @ A, m)
+    chain = Jets.mul_(Jets.zeros(Jets.domain(A)), A.H, Jets.mul_(Jets.zeros(Jets.range(A)), A, m))
+    assert_bits_equal(whole.to_numpy(), chain.to_numpy(), "fused A'A vs the chain")
+    parts = Jets.rand(Jets.domain(A), seed=84, stream=0)            # dirty: every element must be overwritten
+    n = parts.length()
+    for lo, cnt in ((0, 16384), (16384, 32768), (49152, 4), (49156, n - 49156)):
+        check(lib.jh_blockop_normal_mul_range(nat.handle, parts.handle, m.handle, lo, cnt))
+    assert_bits_equal(parts.to_numpy(), whole.to_numpy(), "ranged A'A")
+    if np.dtype(dt).itemsize < 16:
+        with pytest.raises(Jets.JetsHipError):
+            check(lib.jh_blockop_normal_mul_range(nat.handle, parts.handle, m.handle, 1, 4))
+    with pytest.raises(Jets.JetsHipError):
+        check(lib.jh_blockop_normal_mul_range(nat.handle, parts.handle, m.handle, n - 4, 8))
+    with pytest.raises(Jets.JetsHipError):
+        check(lib.jh_blockop_normal_mul_range(nat.handle, m.handle, m.handle, 0, 16))          # y aliases m
+
+
 # ---------------------------------------------------------------------------------- one-pass Golub-Kahan step
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("nrow,shape,beta", [(4, (8, 8, 4), -1.375), (3, (100, 100, 27), 0.5), (2, (128, 128, 33), -2.0), (1, (64,), 0.25),
