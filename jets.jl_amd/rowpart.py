@@ -152,11 +152,25 @@ class RowPartitionedOp:
 
     def __init__(self, part: RowPartition, local_op, comm: Comm, local_mul: Callable, local_mul_adj: Callable,
                  local_dot: Callable, local_norm: Callable, pipelined_adj: Callable | None = None,
-                 pipelined_step: Callable | None = None):
+                 pipelined_step: Callable | None = None, pipelined_normal: Callable | None = None):
         self.part, self.local_op, self.comm = part, local_op, comm
         self._mul, self._mul_adj, self._dot, self._norm = local_mul, local_mul_adj, local_dot, local_norm
         self._pipelined_adj = pipelined_adj   # optional: local adjoint and all-reduce pipelined chunk by chunk
         self._pipelined_step = pipelined_step  # optional: one-pass Golub-Kahan step, its w all-reduced chunk by chunk
+        self._pipelined_normal = pipelined_normal  # optional: the fused A'A, its result all-reduced chunk by chunk
+
+    def normal_mul_(self, y, m, tmp_local=None, force_collective: bool = False):
+        """y = (A'A) m = sum over ALL rows A_i'(A_i m)  (JetComposite_df! over (A', A), src/Jets.jl:530-534, on a row partition): every
+        rank's fused A_k'A_k m -- its coefficients read once, no range-side intermediate -- in element ranges
+        (jh_blockop_normal_mul_range), the all-reduce of a finished range under the next range's kernel.  Operators without the
+        fused kernel run forward then adjoint through `tmp_local` (a range vector of this rank's rows)."""
+        if self._pipelined_normal is not None and (self.comm.world > 1 or force_collective):
+            if self._pipelined_normal(y, self.local_op, m):
+                return y
+        if tmp_local is None:
+            raise ValueError("normal_mul_: this operator has no fused A'A; pass tmp_local (a range vector of this rank's rows)")
+        self.mul_(tmp_local, m)
+        return self.mul_adj_(y, tmp_local, force_collective=force_collective)
 
     def bidiag_step_(self, u_local, v, w, alpha: float, beta: float, force_collective: bool = False):
         """u_local <- alpha*(A_local v) + beta*u_local ; w <- sum over ALL ranks of A_local' u_local, the all-reduce of a
@@ -283,6 +297,24 @@ def for_device(part: RowPartition, local_op, comm=None) -> RowPartitionedOp:
         join(works)
         return True
 
+    def pipelined_normal(y, A, m) -> bool:
+        """The fused A'A in `nchunks` element ranges (jh_blockop_normal_mul_range), exchanged like the adjoint's."""
+        nat = native_of(A)
+        if nat is None:
+            return False
+        t = tensor_of(y)
+        works = []
+        try:
+            for lo, cnt in chunk_bounds(y.length()):
+                check(lib.jh_blockop_normal_mul_range(nat.handle, y.handle, m.handle, lo, cnt))
+                exchange(t, lo, cnt, works)
+        except JetsHipError as e:
+            if e.status == 4 and not works:
+                return False
+            raise
+        join(works)
+        return True
+
     def pipelined_step(u, v, w, alpha, beta):
         """jh_blockop_bidiag_step in `nchunks` element ranges, enqueued back to back: every range adds its share of ||u||^2
         to a device-side accumulator (jh_normsq_reset / normsq == NULL / jh_normsq_read), so the host synchronises ONCE per
@@ -308,7 +340,7 @@ def for_device(part: RowPartition, local_op, comm=None) -> RowPartitionedOp:
         return out.value
 
     return RowPartitionedOp(part, local_op, comm, lambda d, A, m: mul_(d, A, m), lambda m, A, d: mul_(m, adjoint(A), d), dot, norm,
-                            pipelined_adj=pipelined_adj, pipelined_step=pipelined_step)
+                            pipelined_adj=pipelined_adj, pipelined_step=pipelined_step, pipelined_normal=pipelined_normal)
 
 
 def _chunk_bounds(n: int, nchunks: int):
@@ -357,6 +389,23 @@ def _for_device_abi(part: RowPartition, local_op, comm: AbiComm) -> RowPartition
         check(lib.jh_comm_join())
         return True
 
+    def pipelined_normal(y, A, m) -> bool:
+        nat = native_of(A)
+        if nat is None:
+            return False
+        done = 0
+        try:
+            for lo, cnt in _chunk_bounds(y.length(), nchunks):
+                check(lib.jh_blockop_normal_mul_range(nat.handle, y.handle, m.handle, lo, cnt))
+                check(lib.jh_comm_allreduce_sum_range(y.handle, lo, cnt))
+                done += 1
+        except JetsHipError as e:
+            if e.status == 4 and done == 0:
+                return False
+            raise
+        check(lib.jh_comm_join())
+        return True
+
     def pipelined_step(u, v, w, alpha, beta):
         nat = native_of(local_op)
         if nat is None:
@@ -377,7 +426,7 @@ def _for_device_abi(part: RowPartition, local_op, comm: AbiComm) -> RowPartition
         return (out.value, True)
 
     return RowPartitionedOp(part, local_op, comm, lambda d, A, m: mul_(d, A, m), lambda m, A, d: mul_(m, adjoint(A), d), dot, norm,
-                            pipelined_adj=pipelined_adj, pipelined_step=pipelined_step)
+                            pipelined_adj=pipelined_adj, pipelined_step=pipelined_step, pipelined_normal=pipelined_normal)
 
 
 # ------------------------------------------------------------------ ONE process, several contexts -------------------------
@@ -547,6 +596,21 @@ class TeamOp:
             for k in builtins.range(self.team.world):
                 check(lib.jh_comm_allreduce_sum(m[k].handle))
         return m
+
+    def normal_mul_(self, y: TeamVec, m: TeamVec, tmp: TeamVec | None = None) -> TeamVec:
+        """y = (A'A) m on every member's replica: the members' fused A_k'A_k m range by range, each range summed over the team under
+        the next range's kernels; forward then adjoint through `tmp` (a range-side TeamVec) for operators without the fused kernel."""
+        from ._ffi import lib, check, JetsHipError
+
+        try:
+            if self._ranged(y, lambda k, lo, cnt: check(lib.jh_blockop_normal_mul_range(self._natives[k].handle, y[k].handle, m[k].handle, lo, cnt))):
+                return y
+        except JetsHipError as e:
+            if e.status != 4:
+                raise
+        if tmp is None:
+            raise ValueError("normal_mul_: this operator has no fused A'A; pass tmp (a range-side TeamVec)")
+        return self.mul_adj_(y, self.mul_(tmp, m))
 
     def bidiag_step_(self, u: TeamVec, v: TeamVec, w: TeamVec, alpha: float, beta: float):
         """One Golub-Kahan step on every member (jh_blockop_bidiag_step_range per range) with the ranged exchange of w;

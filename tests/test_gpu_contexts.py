@@ -167,6 +167,13 @@ def _team_flow(J, oracle, rowpart, team, ctxs, nmem, home):
         assert rel_err(got[0], want_m) < 1e-6
         for k in range(1, nmem):
             assert_bits_equal(got[k], got[0], f"replica {k} of the summed adjoint")
+        # the fused normal operator over the team (ranged A_k'A_k m + grouped ranged all-reduces): A'(A m), replicas identical
+        yn = team.zeros(T.domain())
+        T.normal_mul_(yn, m)
+        gy = [x.to_numpy().ravel(order="F") for x in yn.members]
+        assert rel_err(gy[0], want_m) < 1e-6
+        for k in range(nmem):
+            assert_bits_equal(gy[k], got[0], f"replica {k} of (A'A) m against the team's adjoint of the forward")
         # one-pass step through the team vs the oracle's unfused sequence
         hu = [u01(oracle, dt, 3, i, n) for i in range(nrow)]
         u = rowpart.TeamVec([J.from_numpy(np.concatenate(hu[parts[k].first:parts[k].first + parts[k].count]), T.ranges()[k]) for k, _ in team.each()])

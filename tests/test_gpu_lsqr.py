@@ -161,6 +161,11 @@ def test_rccl_path_with_one_rank(Jets, oracle):
         assert_bits_equal(mt.to_numpy().ravel(order="F"), ref[0], "adjoint through the RCCL path")
         assert shard.dot_range(d, d) == pytest.approx(float(np.dot(hd.astype(np.float64), hd.astype(np.float64))), rel=1e-6)
         assert shard.norm_range(d, 2) == pytest.approx(float(np.linalg.norm(hd.astype(np.float64))), rel=1e-6)
+        v = Jets.rand(Jets.domain(A), seed=70, stream=0)
+        yn = Jets.rand(Jets.domain(A), seed=69, stream=0)
+        shard.normal_mul_(yn, v, force_collective=True)              # the fused A'A in ranges, each all-reduced by torch.distributed
+        Jets.synchronize()
+        assert_bits_equal(yn.to_numpy(), Jets.mul_(Jets.zeros(Jets.domain(A)), A.H @ A, v).to_numpy(), "fused A'A through the RCCL path")
     finally:
         dist.destroy_process_group()
 
@@ -197,6 +202,9 @@ def test_c_abi_rccl_entry_points_with_one_rank(Jets, oracle):
         ref2 = oracle.block_df_adj(ops2, [np.zeros(n2, dtype=dt)], [hd2[i * n2:(i + 1) * n2].copy() for i in range(5)])
         assert_bits_equal(mt2.to_numpy().ravel(order="F"), ref2[0], "pipelined adjoint through the ABI's exchange stream")
         v = Jets.rand(Jets.domain(B), seed=76, stream=0)
+        yn = Jets.rand(Jets.domain(B), seed=79, stream=0)            # dirty
+        shard2.normal_mul_(yn, v, force_collective=True)              # jh_blockop_normal_mul_range + jh_comm_allreduce_sum_range x 3, jh_comm_join
+        assert_bits_equal(yn.to_numpy(), Jets.mul_(Jets.zeros(Jets.domain(B)), B.H @ B, v).to_numpy(), "pipelined fused A'A through the ABI's exchange stream")
         u1, u2 = Jets.rand(Jets.range(B), seed=77, stream=0), Jets.rand(Jets.range(B), seed=77, stream=0)
         w1, w2 = Jets.zeros(Jets.domain(B)), Jets.zeros(Jets.domain(B))
         nrm2 = shard2.bidiag_step_(u1, v, w1, 0.75, -0.5, force_collective=True)       # ranged steps + ranged all-reduces + jh_comm_allreduce_normsq

@@ -75,8 +75,10 @@ def _worker(rank, world, port, nrow, n, out_dir):
     shard.mul_adj_(mt, d_loc)                                                      # local ordered sum + all-reduce
     dotv = shard.dot_range(d_loc, fwd)
     nrm2, nrminf, nrm1 = shard.norm_range(d_loc, 2), shard.norm_range(d_loc, float("inf")), shard.norm_range(d_loc, 1)
+    yn = np.full(n, 7.0, dtype=dt)                                                 # (A'A) m over the partition: forward into a temporary, summed adjoint
+    shard.normal_mul_(yn, m, tmp_local=[np.zeros(n, dtype=dt) for _ in range(part.count)])
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), fwd=np.concatenate(fwd), mt=mt, local=local_only, dot=dotv,
-             nrm=np.array([nrm2, nrminf, nrm1]), first=part.first, count=part.count)
+             nrm=np.array([nrm2, nrminf, nrm1]), first=part.first, count=part.count, yn=yn)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -106,6 +108,9 @@ def test_world_size_2_forward_is_local_and_adjoint_all_reduces(tmp_path, nrow, n
     # adjoint: replicas identical after the all-reduce, equal to the sum of the two ordered local sums,
     # and within the stated multi-GPU tolerance (rel l2 <= 1e-5) of the sequential reference
     assert res[0]["mt"].tobytes() == res[1]["mt"].tobytes()
+    ref_yn = jo.block_df_adj(ops, [np.zeros(n, dtype=dt)], jo.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [m]))[0]
+    assert res[0]["yn"].tobytes() == res[1]["yn"].tobytes()
+    assert np.linalg.norm(res[0]["yn"].astype(np.float64) - ref_yn) / np.linalg.norm(ref_yn) <= 1e-5
     assert np.array_equal(res[0]["mt"], res[0]["local"] + res[1]["local"])
     rel = np.linalg.norm(res[0]["mt"].astype(np.float64) - ref_adj) / np.linalg.norm(ref_adj)
     assert rel <= 1e-5
