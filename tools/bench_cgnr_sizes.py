@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""CG on the normal equations through the fused A'A at several operator sizes: ms per iteration against the time of the fused A'A
+alone (what an iteration must spend) -- the rest is the domain-side vector work and the host's scalar round trips.
+
+    python tools/bench_cgnr_sizes.py > profiles/bench_cgnr_sizes_r03.txt
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import jets_jl_amd as J
+
+J.init(0)
+print("# rows x block (Float32)   fused A'A alone   CGNR per iteration   LSQR per iteration   CGLS per iteration", flush=True)
+for nrow, edge in ((64, 64), (256, 64), (64, 128), (256, 128), (1024, 128), (256, 256), (1024, 256)):
+    blk = J.JetSpace(np.float32, edge, edge, edge)
+    coeff = J.rand(J.JetBSpace([blk] * nrow), seed=1, stream=0)
+    A = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
+    x_true = J.rand(J.domain(A), seed=4, stream=0)
+    b = J.mul(A, x_true)
+    y = J.zeros(J.domain(A))
+    N = A.H @ A
+    for _ in range(3):
+        J.mul_(y, N, x_true)
+    J.synchronize()
+    e0 = J.Event().record()
+    reps = 20
+    for _ in range(reps):
+        J.mul_(y, N, x_true)
+    e1 = J.Event().record()
+    t_n = e0.elapsed_ms(e1) / reps
+    out = []
+    iters = 12
+    for solve in (lambda: J.cgnr(A, b, maxiter=iters, atol=0.0, btol=0.0, force_maxiter=True),
+                  lambda: J.lsqr(A, b, maxiter=iters, atol=0.0, btol=0.0, conlim=0.0, force_maxiter=True, overwrite_b=True),
+                  lambda: J.cgls(A, b, maxiter=iters, atol=0.0, btol=0.0, force_maxiter=True, overwrite_b=True)):
+        for rep in range(2):                                   # the second run is timed (the first carries the lazy per-operator measurements)
+            J.mul_(b, A, x_true)                               # LSQR / CGLS use b's storage (no range-sized allocation inside the timed solve)
+            J.synchronize()
+            t0 = time.perf_counter()
+            r = solve()
+            J.synchronize()
+            dt = time.perf_counter() - t0
+        out.append(1e3 * dt / max(r.itn, 1))
+    print(f"{nrow:5d} x {edge}^3   {t_n:9.3f} ms   {out[0]:9.3f} ms ({out[0] / t_n:4.2f}x)   {out[1]:9.3f} ms   {out[2]:9.3f} ms", flush=True)
+    J.close(A)
+    del A, coeff, N, b, y, x_true
+    import gc
+    gc.collect()
