@@ -75,6 +75,7 @@ SYMBOLS = {
     "jh_comm_group_begin": (_int, []),
     "jh_comm_group_end": (_int, []),
     "jh_device_info": (_int, [C.c_char_p, _int, _i64p, _i64p, _intp]),
+    "jh_trim": (_int, []),
     "jh_get_stream": (_int, [_vpp]),
     "jh_set_stream": (_int, [_vp]),
     "jh_synchronize": (_int, []),

@@ -14,6 +14,7 @@ int jh_fail(int status, const char *fmt, ...)
 }
 
 // ---- the context table ----------------------------------------------------------------------------------------------------
+#include <map>
 #include <mutex>
 static std::mutex g_ctx_mutex;                           // creation / destruction only; a handle is used by one host thread at a time
 static jh_context *g_ctxs[JH_MAX_CTX] = {};
@@ -26,6 +27,92 @@ jh_context *jh_ctx_by_id(int id)
     if (id < 0) return nullptr;
     jh_context *c = g_ctxs[jh_ctx_slot(id)];
     return (c && c->id == id) ? c : nullptr;
+}
+
+// ---- slab cache ---------------------------------------------------------------------------------------------------------------------
+// hipMalloc of a range-sized slab is not cheap on this machine: 64 GiB takes 2-6 SECONDS whenever the runtime has to go to the driver
+// for it, which it does unpredictably (profiles/exp_r03_alloc_cost.txt; 8 GiB: 0.2 ms).  A caller in the reference's style allocates
+// such temporaries all the time (`A*m` returns a fresh vector, `zeros(range(A))` per stage, a solver's copy of b), so the slabs of
+// destroyed vectors are kept -- per device, exact size, oldest out first when the cap is reached -- and handed to the next
+// jh_bvec_create of that size.  jh_trim() / knob "slab_cache" = 0 / an allocation that does not fit release them.
+namespace {
+struct cached_slab { void *p; size_t bytes; };
+std::mutex g_slab_mutex;
+std::map<int, std::vector<cached_slab>> g_slabs;            // device -> slabs, oldest first
+std::atomic<int> g_slab_cache_on{1};
+constexpr size_t SLAB_CACHE_MIN = (size_t)1 << 30;           // smaller allocations are cheap: not worth holding memory for
+
+size_t slab_cap_bytes()                                       // at most half the device's memory sits in the cache
+{
+    static size_t cap = 0;
+    if (!cap) {
+        size_t fr = 0, tot = 0;
+        cap = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) ? tot / 2 : (size_t)128 << 30;
+    }
+    return cap;
+}
+}  // namespace
+
+size_t jh_slab_cached_bytes(int device)
+{
+    std::lock_guard<std::mutex> lock(g_slab_mutex);
+    size_t sum = 0;
+    for (const cached_slab &c : g_slabs[device]) sum += c.bytes;
+    return sum;
+}
+
+void jh_slab_trim(int device)
+{
+    std::vector<cached_slab> out;
+    {
+        std::lock_guard<std::mutex> lock(g_slab_mutex);
+        out.swap(g_slabs[device]);
+    }
+    for (const cached_slab &c : out) (void)hipFree(c.p);
+}
+
+hipError_t jh_slab_alloc(int device, size_t bytes, void **out)
+{
+    if (bytes >= SLAB_CACHE_MIN) {
+        std::lock_guard<std::mutex> lock(g_slab_mutex);
+        std::vector<cached_slab> &v = g_slabs[device];
+        for (size_t k = v.size(); k-- > 0;)                  // the most recently freed slab of that size first
+            if (v[k].bytes == bytes) {
+                *out = v[k].p;
+                v.erase(v.begin() + (long)k);
+                return hipSuccess;
+            }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory && jh_slab_cached_bytes(device) > 0) {
+        (void)hipGetLastError();
+        jh_slab_trim(device);                                // what the cache holds is free memory: give it back and ask again
+        e = hipMalloc(out, bytes);
+    }
+    return e;
+}
+
+void jh_slab_free(int device, void *p, size_t bytes)
+{
+    if (!p) return;
+    if (g_slab_cache_on.load() && bytes >= SLAB_CACHE_MIN && bytes <= slab_cap_bytes()) {
+        std::vector<cached_slab> evict;
+        {
+            std::lock_guard<std::mutex> lock(g_slab_mutex);
+            std::vector<cached_slab> &v = g_slabs[device];
+            size_t held = bytes;
+            for (const cached_slab &c : v) held += c.bytes;
+            while (held > slab_cap_bytes() && !v.empty()) {
+                held -= v.front().bytes;
+                evict.push_back(v.front());
+                v.erase(v.begin());
+            }
+            v.push_back(cached_slab{p, bytes});
+        }
+        for (const cached_slab &c : evict) (void)hipFree(c.p);
+        return;
+    }
+    (void)hipFree(p);
 }
 
 jh_quiesce_scope::jh_quiesce_scope(int ctx)
@@ -142,6 +229,12 @@ static int ctx_destroy(int id)
     if (c->chain_sync) (void)hipFree(c->chain_sync);
     if (c->red_host) (void)hipHostFree(c->red_host);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    {
+        bool last_on_device = true;
+        for (int k = 0; k < JH_MAX_CTX; k++)
+            if (g_ctxs[k] && g_ctxs[k] != c && g_ctxs[k]->device == c->device) last_on_device = false;
+        if (last_on_device) jh_slab_trim(c->device);
+    }
     {
         std::lock_guard<std::mutex> lock(g_ctx_mutex);
         g_ctxs[jh_ctx_slot(id)] = nullptr;
@@ -289,6 +382,13 @@ int jh_shutdown(void)
     return JH_OK;
 }
 
+int jh_trim(void)
+{
+    JH_TRY(jh_require_ready());
+    jh_slab_trim(jh_ctx().device);
+    return JH_OK;
+}
+
 int jh_device_info(char *name, int name_cap, int64_t *total_mem, int64_t *free_mem, int *cu_count)
 {
     JH_TRY(jh_require_ready());
@@ -299,7 +399,7 @@ int jh_device_info(char *name, int name_cap, int64_t *total_mem, int64_t *free_m
     size_t fr = 0, tot = 0;
     JH_CHECK_HIP(hipMemGetInfo(&fr, &tot));
     if (total_mem) *total_mem = (int64_t)tot;
-    if (free_mem) *free_mem = (int64_t)fr;
+    if (free_mem) *free_mem = (int64_t)(fr + jh_slab_cached_bytes(c.device));   // what the slab cache holds is available to the next allocation
     if (cu_count) *cu_count = prop.multiProcessorCount;
     return JH_OK;
 }
@@ -400,7 +500,7 @@ int jh_bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec
     if (s != JH_OK) { delete v; return s; }
     size_t bytes = (size_t)v->length * jh_dtype_size(dtype);
     if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(&v->data, bytes);
+    hipError_t e = jh_slab_alloc(jh_ctx().device, bytes, &v->data);   // a cached slab of a destroyed vector of this size, or hipMalloc
     if (e != hipSuccess) {
         delete v;
         return jh_fail(JH_ERR_NOMEM, "jh_bvec_create: hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
@@ -408,7 +508,7 @@ int jh_bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec
     v->owns = true;
     e = hipMemsetAsync(v->data, 0, bytes, jh_ctx().stream);     // zeros(R), src/Jets.jl:922-924
     if (e != hipSuccess) {
-        (void)hipFree(v->data);
+        jh_slab_free(jh_ctx().device, v->data, bytes);
         delete v;
         return jh_fail(JH_ERR_HIP, "jh_bvec_create: hipMemsetAsync: %s", hipGetErrorString(e));
     }
@@ -463,7 +563,11 @@ int jh_bvec_destroy(jh_bvec *v)
     if (!v) return JH_OK;
     if (v->owns && v->data) {
         jh_quiesce_scope quiet(v->ctx);                          // (not jh_enter: a finaliser must not change the thread's current context)
-        (void)hipFree(v->data);
+        jh_context *c = jh_ctx_by_id(v->ctx);
+        size_t bytes = (size_t)v->length * jh_dtype_size(v->dtype);
+        if (bytes == 0) bytes = 16;
+        if (c) jh_slab_free(c->device, v->data, bytes);          // big slabs wait in the cache for the next vector of their size
+        else (void)hipFree(v->data);
     }
     jh_handle_died(v->ctx);
     delete v;
@@ -648,6 +752,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "adj_wg")) { JH_REQUIRE(one_of({0, 256, 512, 1024}), "adj_wg must be 0 (auto), 256, 512 or 1024"); c.adj_wg = value; }
     else if (!strcmp(name, "fwd_order")) { JH_REQUIRE(value >= -1 && value <= 65536, "fwd_order must be -1 (auto), 0 (sequential), 1 (all rows) or k > 1 (k row groups per band)"); c.fwd_order = value; }
     else if (!strcmp(name, "nt")) { c.nt = value ? 1 : 0; }
+    else if (!strcmp(name, "slab_cache")) { g_slab_cache_on.store(value ? 1 : 0); if (!value) jh_slab_trim(c.device); }
     else if (!strcmp(name, "bcast_item_fast")) { JH_REQUIRE(value >= -1 && value <= 1, "bcast_item_fast must be -1 (auto), 0 or 1"); c.bcast_item_fast = value; }
     else if (!strcmp(name, "adj_split")) { JH_REQUIRE(value >= -1 && value <= 65535, "adj_split must be -1 (auto), 0 (never: ordered walk) or the number of row parts"); c.adj_split = value; }
     else if (!strcmp(name, "adj_rows_per_launch")) { JH_REQUIRE(value >= 0, "adj_rows_per_launch must be >= 0"); c.adj_rows_per_launch = value; }
@@ -681,6 +786,8 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "adj_wg")) *value = c.adj_wg;
     else if (!strcmp(name, "fwd_order")) *value = c.fwd_order;
     else if (!strcmp(name, "nt")) *value = c.nt;
+    else if (!strcmp(name, "slab_cache")) *value = g_slab_cache_on.load();
+    else if (!strcmp(name, "slab_cached_mib")) *value = (int64_t)(jh_slab_cached_bytes(c.device) >> 20);
     else if (!strcmp(name, "bcast_item_fast")) *value = c.bcast_item_fast;
     else if (!strcmp(name, "adj_split")) *value = c.adj_split;
     else if (!strcmp(name, "last_adj_parts")) *value = c.last_adj_parts;

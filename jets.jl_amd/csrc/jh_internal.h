@@ -37,6 +37,12 @@ constexpr int JH_MAX_CTX = 64;          // table slots (a power of two)
 // A context id is slot + JH_MAX_CTX * generation: a slot is reused after jh_context_destroy / jh_shutdown, its generation is not, so
 // a handle that outlives its context never matches the unrelated context that later lands in the same slot.
 inline int jh_ctx_slot(int id) { return id & (JH_MAX_CTX - 1); }
+// slab cache (jh_core.hip): big device allocations of destroyed vectors, kept per device for the next vector of that size
+hipError_t jh_slab_alloc(int device, size_t bytes, void **out);
+void jh_slab_free(int device, void *p, size_t bytes);
+void jh_slab_trim(int device);
+size_t jh_slab_cached_bytes(int device);
+
 struct jh_context {
     bool ready = false;
     int id = -1;                       // slot + JH_MAX_CTX * generation

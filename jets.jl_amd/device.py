@@ -15,7 +15,7 @@ import os
 
 from ._ffi import lib, check
 
-__all__ = ["init", "is_initialized", "shutdown", "synchronize", "device_count", "device_info", "stream_handle",
+__all__ = ["init", "is_initialized", "shutdown", "synchronize", "device_count", "device_info", "trim", "stream_handle",
            "set_stream", "Event", "tune", "tune_get", "local_device_from_env", "context_create", "context_use",
            "context_current", "context_destroy", "using_context", "context_of"]
 
@@ -122,6 +122,13 @@ def device_info() -> dict:
     tot, fr, cu = C.c_int64(0), C.c_int64(0), C.c_int(0)
     check(lib.jh_device_info(name, 256, C.byref(tot), C.byref(fr), C.byref(cu)))
     return {"name": name.value.decode(), "total_mem": tot.value, "free_mem": fr.value, "cu_count": cu.value}
+
+
+def trim() -> None:
+    """Give the device memory the slab cache holds (destroyed vectors of 1 GiB or more, kept for the next vector of their size) back
+    to the driver -- before another library of the process needs it.  include/jetship.h: jh_trim."""
+    init()
+    check(lib.jh_trim())
 
 
 def stream_handle() -> int:

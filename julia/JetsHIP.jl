@@ -36,6 +36,7 @@ check(status::Cint) = status == 0 ? nothing : error("libjetship: " * unsafe_stri
 
 const _inited = Ref(false)
 init(device::Integer=0) = (check(ccall((:jh_init, LIB), Cint, (Cint,), device)); _inited[] = true; nothing)
+trim() = check(ccall((:jh_trim, LIB), Cint, ()))          # hand the slab cache's device memory back to the driver (before another library needs it)
 _ensure_init() = _inited[] || init(parse(Int, get(ENV, "JETSHIP_DEVICE", "0")))      # the first allocation picks the device
 synchronize() = check(ccall((:jh_synchronize, LIB), Cint, ()))
 tune!(name::AbstractString, value::Integer) = check(ccall((:jh_tune_set, LIB), Cint, (Cstring, Int64), name, value))   # e.g. tune!("adj_split", 0)

@@ -1,0 +1,85 @@
+"""GPU: the slab cache (include/jetship.h, jh_trim): device memory of destroyed vectors of 1 GiB or more is kept for the next vector of
+exactly that size -- hipMalloc of a range-sized slab costs seconds on this machine (profiles/exp_r03_alloc_cost.txt), and the
+reference's style allocates such temporaries per call (src/Jets.jl:399, 526-533)."""
+from __future__ import annotations
+
+import gc
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GIB = 1 << 30
+
+
+def _cached_mib(J):
+    return J.tune_get("slab_cached_mib")
+
+
+def test_a_destroyed_big_vector_is_reused_by_the_next_of_its_size_and_comes_back_zeroed(Jets):
+    J = Jets
+    J.trim()
+    spc = J.JetSpace(np.float32, GIB // 2)                        # 2 GiB
+    x = J.ones(spc)
+    ptr = x.ptr
+    x.close()
+    del x
+    gc.collect()
+    assert _cached_mib(J) == 2048
+    free_with_cache = J.device_info()["free_mem"]
+    y = J.zeros(J.JetSpace(np.float32, GIB // 2 - 4))             # another size: not served from the cache
+    assert y.ptr != ptr and _cached_mib(J) == 2048
+    z = J.zeros(spc)                                              # the same size: the cached slab, zero-filled again
+    assert z.ptr == ptr and _cached_mib(J) == 0
+    assert float(J.norm(z)) == 0.0
+    z.close(); y.close()
+    del y, z
+    gc.collect()
+    assert _cached_mib(J) == 2048 + 2047                          # both went into the cache (2 GiB - 16 B is still above the 1 GiB floor)
+    J.trim()
+    assert _cached_mib(J) == 0
+    assert abs(J.device_info()["free_mem"] - free_with_cache) < 64 << 20     # cached memory was counted as free all along
+
+
+def test_small_vectors_and_a_switched_off_cache_go_straight_back_to_the_driver(Jets):
+    J = Jets
+    J.trim()
+    small = J.zeros(J.JetSpace(np.float32, 1 << 20))
+    small.close()
+    assert _cached_mib(J) == 0
+    try:
+        J.tune(slab_cache=0)
+        big = J.zeros(J.JetSpace(np.float32, GIB // 2))
+        big.close()
+        del big
+        gc.collect()
+        assert _cached_mib(J) == 0
+    finally:
+        J.tune(slab_cache=1)
+    assert J.tune_get("slab_cache") == 1
+
+
+def test_an_allocation_that_needs_the_cached_memory_gets_it(Jets):
+    """Two 100 GiB slabs destroyed (the cache's cap is half the device, so the older one is evicted), then a request the rest of the device
+    cannot satisfy: the cache is emptied and the request retried."""
+    J = Jets
+    info = J.device_info()
+    if info["free_mem"] < 270 * GIB:
+        pytest.skip(f"needs an empty 288 GiB device, {info['free_mem'] / GIB:.0f} GiB free")
+    J.trim()
+    n100 = 25 * GIB                                               # Float32 elements of a 100 GiB slab
+    a, b = J.Array(J.JetSpace(np.float32, n100)), J.Array(J.JetSpace(np.float32, n100 + 4))
+    a.close(); b.close()
+    del a, b
+    gc.collect()
+    held = _cached_mib(J)
+    assert held in (100 * 1024, 100 * 1024 + 1)                   # the younger slab; the older one went back to the driver when the cap was reached
+    c = J.Array(J.JetSpace(np.float32, 55 * GIB))                 # 220 GiB: more than what is free beside the cache
+    assert _cached_mib(J) == 0 and held > 0
+    J.fill_(c, 1.0)
+    assert float(J.norm(c, np.inf)) == 1.0
+    c.close()
+    del c
+    gc.collect()
+    J.trim()
