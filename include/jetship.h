@@ -104,9 +104,9 @@ int jh_set_device(int device);                    /* = jh_context_use(the primar
 int jh_device_info(char *name, int name_cap, int64_t *total_mem, int64_t *free_mem, int *cu_count);
 /* Slab cache.  The reference's style allocates range-sized temporaries all the time (`A*m` returns a fresh vector, `zeros(range(A))`
  * per composite stage, src/Jets.jl:399, 526-533), and hipMalloc of a 64 GiB slab costs 2-6 seconds on this machine whenever the
- * runtime goes to the driver for it (profiles/exp_r03_alloc_cost.txt).  So the device memory of a destroyed vector of 1 GiB or more
- * is kept (per device, at most half the device's memory, oldest out first) and handed to the next jh_bvec_create of exactly that
- * size; an allocation that does not fit otherwise empties the cache and tries again.  jh_device_info counts cached memory as free.
+ * runtime goes to the driver for it (profiles/exp_r03_alloc_cost.txt).  So the device memory of a destroyed vector of 16 MiB or more
+ * is kept (per device, never the last 32 GiB of it, oldest out first) and handed to the next jh_bvec_create of exactly that
+ * size; when the driver refuses an allocation of the library, cached slabs go back to it, oldest first, until the request fits.  jh_device_info counts cached memory as free.
  * jh_trim() returns it to the driver (before another library of the process needs the memory); jh_tune_set("slab_cache", 0) turns
  * the cache off (and empties it); jh_tune_get("slab_cached_mib") reads what it holds. */
 int jh_trim(void);

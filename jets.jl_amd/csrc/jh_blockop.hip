@@ -2637,7 +2637,7 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
             if (c.chain_sync) { JH_CHECK_HIP(hipStreamSynchronize(c.stream)); JH_CHECK_HIP(hipFree(c.chain_sync)); c.chain_sync = nullptr; c.chain_sync_cap = 0; }
             int64_t cap = 4096;
             while (cap < 2 + ntiles) cap *= 2;
-            JH_CHECK_HIP(hipMalloc((void **)&c.chain_sync, sizeof(unsigned) * (size_t)cap));
+            JH_CHECK_HIP(jh_device_malloc(c.device, (void **)&c.chain_sync, sizeof(unsigned) * (size_t)cap));
             c.chain_sync_cap = cap;
             c.buf_gen++;
         }
@@ -3189,7 +3189,7 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
         host[k].adjoint = op->blocks[k].adjoint;
     }
     hipStream_t st = jh_ctx().stream;
-    hipError_t e = hipMalloc((void **)&op->dev_blocks, host.size() * sizeof(jh_dev_block));
+    hipError_t e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_blocks, host.size() * sizeof(jh_dev_block));
     if (e == hipSuccess) e = hipMalloc((void **)&op->dev_row_off, sizeof(int64_t) * ((size_t)nrow + 1));
     if (e == hipSuccess) e = hipMalloc((void **)&op->dev_col_off, sizeof(int64_t) * ((size_t)ncol + 1));
     if (e == hipSuccess) e = hipMemcpyAsync(op->dev_blocks, host.data(), host.size() * sizeof(jh_dev_block), hipMemcpyHostToDevice, st);

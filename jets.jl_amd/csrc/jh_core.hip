@@ -40,16 +40,30 @@ struct cached_slab { void *p; size_t bytes; };
 std::mutex g_slab_mutex;
 std::map<int, std::vector<cached_slab>> g_slabs;            // device -> slabs, oldest first
 std::atomic<int> g_slab_cache_on{1};
-constexpr size_t SLAB_CACHE_MIN = (size_t)1 << 30;           // smaller allocations are cheap: not worth holding memory for
+constexpr size_t SLAB_CACHE_MIN = (size_t)16 << 20;          // from 16 MiB on: a thousand 64 MiB blocks re-allocated after a free cost 3.6 ms EACH (profiles/exp_r03_alloc_cost.txt)
 
-size_t slab_cap_bytes()                                       // at most half the device's memory sits in the cache
+size_t slab_cap_bytes()                                       // the cache never holds the last 32 GiB of the device
 {
     static size_t cap = 0;
     if (!cap) {
         size_t fr = 0, tot = 0;
-        cap = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) ? tot / 2 : (size_t)128 << 30;
+        cap = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > ((size_t)64 << 30)) ? tot - ((size_t)32 << 30) : (size_t)32 << 30;
     }
     return cap;
+}
+
+bool slab_evict_oldest(int device)                             // false when the cache is empty
+{
+    cached_slab victim{nullptr, 0};
+    {
+        std::lock_guard<std::mutex> lock(g_slab_mutex);
+        std::vector<cached_slab> &v = g_slabs[device];
+        if (v.empty()) return false;
+        victim = v.front();
+        v.erase(v.begin());
+    }
+    (void)hipFree(victim.p);
+    return true;
 }
 }  // namespace
 
@@ -83,10 +97,17 @@ hipError_t jh_slab_alloc(int device, size_t bytes, void **out)
                 return hipSuccess;
             }
     }
+    return jh_device_malloc(device, out, bytes);
+}
+
+// hipMalloc for everything the library allocates: what the cache holds is free memory -- when the driver says no, give slabs back,
+// oldest first, and ask again (re-used device memory is cleared by the driver at ~20 GB/s, so no more is given back than needed)
+hipError_t jh_device_malloc(int device, void **out, size_t bytes)
+{
     hipError_t e = hipMalloc(out, bytes);
-    if (e == hipErrorOutOfMemory && jh_slab_cached_bytes(device) > 0) {
+    while (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
-        jh_slab_trim(device);                                // what the cache holds is free memory: give it back and ask again
+        if (!slab_evict_oldest(device)) break;
         e = hipMalloc(out, bytes);
     }
     return e;
@@ -277,7 +298,7 @@ int jh_ensure_partials(int64_t n)
         c.part_dev = nullptr;
         c.part_cap = 0;
     }
-    JH_CHECK_HIP(hipMalloc((void **)&c.part_dev, sizeof(double) * (size_t)cap));
+    JH_CHECK_HIP(jh_device_malloc(c.device, (void **)&c.part_dev, sizeof(double) * (size_t)cap));
     c.part_cap = cap;
     c.buf_gen++;
     return JH_OK;
@@ -295,7 +316,7 @@ int jh_ensure_scratch(size_t bytes, void **out)
             c.scratch_dev = nullptr;
             c.scratch_cap = 0;
         }
-        JH_CHECK_HIP(hipMalloc(&c.scratch_dev, cap));
+        JH_CHECK_HIP(jh_device_malloc(c.device, &c.scratch_dev, cap));
         c.scratch_cap = cap;
         c.buf_gen++;
     }

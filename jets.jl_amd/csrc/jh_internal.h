@@ -39,6 +39,7 @@ constexpr int JH_MAX_CTX = 64;          // table slots (a power of two)
 inline int jh_ctx_slot(int id) { return id & (JH_MAX_CTX - 1); }
 // slab cache (jh_core.hip): big device allocations of destroyed vectors, kept per device for the next vector of that size
 hipError_t jh_slab_alloc(int device, size_t bytes, void **out);
+hipError_t jh_device_malloc(int device, void **out, size_t bytes);     // hipMalloc that takes memory back from the cache when the driver says no
 void jh_slab_free(int device, void *p, size_t bytes);
 void jh_slab_trim(int device);
 size_t jh_slab_cached_bytes(int device);

@@ -356,7 +356,7 @@ static int lsqr_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *
         JH_TRY(jh_bvec_create(1, len1, dtype, &t[k].v));
         JH_TRY(jh_bvec_create(1, len1, dtype, &t[k].w));
         JH_TRY(jh_bvec_create(1, len1, dtype, &t[k].atu));
-        JH_CHECK_HIP(hipMalloc((void **)&t[k].parts, sizeof(double) * (2 * (size_t)grid + 2)));
+        JH_CHECK_HIP(jh_device_malloc(jh_ctx().device, (void **)&t[k].parts, sizeof(double) * (2 * (size_t)grid + 2)));
     }
     auto parts_v = [&](int k) { return t[k].parts; };
     auto parts_w = [&](int k) { return t[k].parts + grid; };
@@ -576,7 +576,7 @@ static int lsqr_graph_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use
     const int64_t ns_dom = n * (jh_dtype_complex(dtype) ? 2 : 1);
     int grid = (int)((ns_dom + 255) / 256 < 4096 ? (ns_dom + 255) / 256 : 4096);
     if (grid < 1) grid = 1;
-    JH_CHECK_HIP(hipMalloc((void **)&t.parts, sizeof(double) * (2 * (size_t)grid + 2)));
+    JH_CHECK_HIP(jh_device_malloc(jh_ctx().device, (void **)&t.parts, sizeof(double) * (2 * (size_t)grid + 2)));
     double *parts_v = t.parts, *parts_w = t.parts + grid, *slot_v = t.parts + 2 * grid, *slot_w = slot_v + 1;
     *res = jh_lsqr_result{};
 

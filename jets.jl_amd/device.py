@@ -125,7 +125,7 @@ def device_info() -> dict:
 
 
 def trim() -> None:
-    """Give the device memory the slab cache holds (destroyed vectors of 1 GiB or more, kept for the next vector of their size) back
+    """Give the device memory the slab cache holds (destroyed vectors of 16 MiB or more, kept for the next vector of their size) back
     to the driver -- before another library of the process needs it.  include/jetship.h: jh_trim."""
     init()
     check(lib.jh_trim())

@@ -623,9 +623,11 @@ def JetVec_df_adj(m, d, *, op, **kw):  # :1136
 # ------------------------------------------------------------------------------ utilities ----------
 def dot_product_test(op: JopLn, m, d, mmask=None, dmask=None):
     """lhs, rhs = dot_product_test(A, m, d; mmask, dmask)  (src/Jets.jl:1211-1226)."""
-    mmask = ones(domain(op)) if mmask is None else mmask  # :1212
-    dmask = ones(range_(op)) if dmask is None else dmask  # :1213
     def masked(mask, x):  # mask .* x ; a REAL mask on a complex vector is a mixed-eltype broadcast (real (x) complex, Julia's rule)
+        if mask is None:
+            # the default mask is ones(space) (:1212-1213) and 1 .* x has x's bits: neither the ones nor the product is materialised --
+            # at the headline size each would be another 64 GiB next to A, d and A*m
+            return x
         if np.dtype(mask.dtype) != np.dtype(x.dtype):
             from .broadcast import broadcast_
 
@@ -634,10 +636,13 @@ def dot_product_test(op: JopLn, m, d, mmask=None, dmask=None):
 
     mm = masked(mmask, m)  # mmask .* m
     dd = masked(dmask, d)  # dmask .* d
-    ds = mul(op, mm)  # :1215
     ms = mul(adjoint(op), dd)  # :1216
     lhs = dot(mm, ms)  # :1218
+    ds = mul(op, mm)  # :1215
     rhs = dot(ds, dd)  # :1219
+    for tmp, src in ((ds, None), (dd, d), (mm, m), (ms, None)):          # range-sized temporaries go back (to the slab cache) now, not at the next GC
+        if tmp is not src and hasattr(tmp, "close"):
+            tmp.close()
     if np.iscomplexobj(lhs) and np.iscomplexobj(rhs):  # :1221-1225
         return lhs, rhs
     return np.real(lhs), np.real(rhs)
