@@ -122,6 +122,10 @@ int jh_event_destroy(jh_event *ev);
 /* ---------------------------------------------------------------- block vectors ------------- */
 /* zeros(R::JetBSpace) / Array(R) storage, src/Jets.jl:922-924; JetBSpace ctor 739-750. Zero-filled. */
 int jh_bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec **out);
+/* Array(R) = Array{T,N}(undef, size(R)), src/Jets.jl:105: the same vector WITHOUT the zero fill (12 ms per 64 GiB) -- its contents are
+ * whatever the memory held.  For outputs a call overwrites entirely: `A*m` of a tall operator without zero blocks (src/Jets.jl:399 passes
+ * zeros(range(A)) because a general df! may accumulate, 1024; a one-column operator without zero blocks overwrites every row, 1026). */
+int jh_bvec_create_uninit(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec **out);
 /* reshape(x::AbstractArray, R::JetBSpace), src/Jets.jl:1112: block view over caller-owned device memory */
 int jh_bvec_wrap(void *device_ptr, int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec **out);
 /* view of blocks [first, first+count) of parent sharing memory (getblock(x,i) by reference, 914) */

@@ -84,6 +84,7 @@ SYMBOLS = {
     "jh_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "jh_event_destroy": (_int, [_vp]),
     "jh_bvec_create": (_int, [_i64, _i64p, _int, _vpp]),
+    "jh_bvec_create_uninit": (_int, [_i64, _i64p, _int, _vpp]),
     "jh_bvec_wrap": (_int, [_vp, _i64, _i64p, _int, _vpp]),
     "jh_bvec_view": (_int, [_vp, _i64, _i64, _vpp]),
     "jh_bvec_destroy": (_int, [_vp]),

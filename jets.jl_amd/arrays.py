@@ -298,26 +298,29 @@ class BlockArray(_DevVec):
 
 
 # ------------------------------------------------------------------------------ factories ----------
-def _new_handle(block_lens: Sequence[int], T) -> C.c_void_p:
+def _new_handle(block_lens: Sequence[int], T, undef: bool = False) -> C.c_void_p:
     _device.init()
     h = C.c_void_p()
-    check(lib.jh_bvec_create(len(block_lens), _i64arr(block_lens), dtype_code(T), C.byref(h)))
+    create = lib.jh_bvec_create_uninit if undef else lib.jh_bvec_create
+    check(create(len(block_lens), _i64arr(block_lens), dtype_code(T), C.byref(h)))
     return h
 
 
-def Array(R: JetAbstractSpace):
-    """Array(R) / zeros(R): device storage for the space (src/Jets.jl:105-108, 922-924).  Device
-    allocations are always zero-filled."""
+def Array(R: JetAbstractSpace, undef: bool = False):
+    """Array(R) / zeros(R): device storage for the space (src/Jets.jl:105-108, 922-924).  Zero-filled unless `undef=True`
+    (Julia's Array{T}(undef, ...): for an output the next call overwrites entirely; the fill of 64 GiB is 12 ms)."""
     if isinstance(R, JetSSpace):  # src/Jets.jl:514-516
         from .symmetric import zeros_sym
 
         return zeros_sym(R)
     if isinstance(R, JetBSpace):
-        return BlockArray(_new_handle(R.block_lengths(), R.eltype()), R.spaces, R.eltype())
-    return DeviceArray(_new_handle([R.length()], R.eltype()), R.size(), R.eltype())
+        return BlockArray(_new_handle(R.block_lengths(), R.eltype(), undef), R.spaces, R.eltype())
+    return DeviceArray(_new_handle([R.length()], R.eltype(), undef), R.size(), R.eltype())
 
 
-zeros = Array
+
+def zeros(R: JetAbstractSpace):
+    return Array(R)
 
 
 def ones(R: JetAbstractSpace):

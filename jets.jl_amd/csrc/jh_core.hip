@@ -511,7 +511,13 @@ static int build_layout(jh_bvec *v, int64_t nblocks, const int64_t *block_len, i
     return JH_OK;
 }
 
-int jh_bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec **out)
+static int bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec **out, bool zero_fill);
+
+int jh_bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec **out) { return bvec_create(nblocks, block_len, dtype, out, true); }
+
+int jh_bvec_create_uninit(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec **out) { return bvec_create(nblocks, block_len, dtype, out, false); }
+
+static int bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec **out, bool zero_fill)
 {
     JH_TRY(jh_require_ready());
     JH_REQUIRE(out, "jh_bvec_create: null output");
@@ -527,7 +533,7 @@ int jh_bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_bvec
         return jh_fail(JH_ERR_NOMEM, "jh_bvec_create: hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
     }
     v->owns = true;
-    e = hipMemsetAsync(v->data, 0, bytes, jh_ctx().stream);     // zeros(R), src/Jets.jl:922-924
+    if (zero_fill) e = hipMemsetAsync(v->data, 0, bytes, jh_ctx().stream);     // zeros(R), src/Jets.jl:922-924
     if (e != hipSuccess) {
         jh_slab_free(jh_ctx().device, v->data, bytes);
         delete v;

@@ -515,6 +515,21 @@ def nblocks_op(A, i=None):  # :1074-1077
     return r if i == 1 else dm
 
 
+def overwrites_its_whole_range(A) -> bool:
+    """True when mul!(d, A, m) is known to write every element of d whatever d held: a one-column LINEAR block operator (not adjointed)
+    whose children are all device-native and none a zero block -- each row is one overwrite (src/Jets.jl:1026)."""
+    if not isinstance(A, JopLn) or not isblockop(A):
+        return False
+    ops = A.jet.s["ops"]
+    if ops.shape[1] != 1:
+        return False
+    for i in builtins.range(ops.shape[0]):
+        desc = _native_desc(ops[i, 0])
+        if desc is None or desc[0] not in ("identity", "diag", "scale", "dense") or isinstance(ops[i, 0], JopNl):
+            return False
+    return True
+
+
 def isblockop(A) -> bool:  # :1097-1098
     return isinstance(A, Jop) and jet(A).f is JetBlock_f
 

@@ -406,9 +406,13 @@ def mul_(d, A: Jop, m):
 
 
 def mul(A: Jop, m):
-    """A*m = mul!(zeros(range(A)), A, m) (src/Jets.jl:399)."""
+    """A*m = mul!(zeros(range(A)), A, m) (src/Jets.jl:399).  The zeros are there because a df! may accumulate into its output (the block
+    loop with several columns does, 1024; a zero block leaves its row as found, 1022); a one-column block operator of device-native
+    children without zero blocks overwrites every row (1026), so its output is allocated without the fill (12 ms per 64 GiB)."""
     _enter_context_of(m)
-    return mul_(zeros(range_(A)), A, m)
+    from .jetblock import overwrites_its_whole_range
+
+    return mul_(_arr.Array(range_(A), undef=True) if overwrites_its_whole_range(A) else zeros(range_(A)), A, m)
 
 
 # ------------------------------------------------------------------------------ composition --------

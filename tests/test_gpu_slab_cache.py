@@ -89,3 +89,45 @@ def test_an_allocation_that_needs_the_cached_memory_gets_it(Jets):
     del c
     gc.collect()
     J.trim()
+
+
+def test_a_times_m_skips_the_zero_fill_only_where_every_row_is_overwritten(Jets, oracle):
+    """`A*m` = mul!(zeros(range(A)), A, m) (src/Jets.jl:399).  A one-column operator of native children without zero blocks overwrites every
+    row (1026), so its output comes from jh_bvec_create_uninit -- here out of a cached slab full of garbage; an operator with a zero block
+    (its row stays as found, 1022) or with several columns (accumulates, 1024) still gets zeros."""
+    from jets_jl_amd.jetblock import overwrites_its_whole_range
+    from .helpers import assert_bits_equal
+
+    J = Jets
+    J.trim()
+    dt, n, nrow = np.float32, 6 << 20, 3                                      # rows of 24 MiB: the 72 MiB range vector is cached when destroyed
+    spc = J.JetSpace(dt, n)
+    coeffs = [J.rand(spc, seed=1, stream=i) for i in range(nrow)]
+    hc = [oracle.rng_u01(dt, 1, i, 0, n) for i in range(nrow)]
+    hm = oracle.rng_u01(dt, 2, 0, 0, n)
+    m = J.rand(spc, seed=2, stream=0)
+    A = J.blockop([[J.JopDiagonal(c)] for c in coeffs])
+    Z = J.blockop([[J.JopDiagonal(coeffs[0])], [J.JopZeroBlock(spc, spc)], [J.JopDiagonal(coeffs[2])]])
+    G = J.blockop([[J.JopDiagonal(coeffs[0]), J.JopDiagonal(coeffs[1])], [J.JopDiagonal(coeffs[2]), J.JopZeroBlock(spc, spc)], [J.JopIdentity(spc), J.JopIdentity(spc)]])
+    assert overwrites_its_whole_range(A) and not overwrites_its_whole_range(Z) and not overwrites_its_whole_range(G) and not overwrites_its_whole_range(A.H)
+    for _ in range(2):
+        junk = J.fill_(J.zeros(J.range(A)), float("nan"))                      # a range-sized slab of NaNs goes into the cache ...
+        ptr = junk.ptr
+        junk.close()
+        d = A * m                                                              # ... and comes back as the output of A*m, not zeroed
+        assert d.ptr == ptr
+        ref = oracle.block_df([[oracle.Block("diag", n, coeff=c)] for c in hc], [np.zeros(n, dtype=dt) for _ in range(nrow)], [hm])
+        assert_bits_equal(d.to_numpy(), np.concatenate(ref), "A*m into an uninitialised slab")
+        d.close()
+        junk = J.fill_(J.zeros(J.range(Z)), float("nan"))
+        junk.close()
+        dz = Z * m                                                             # the zero block's row must read 0, not the slab's NaNs
+        zops = [[oracle.Block("diag", n, coeff=hc[0])], [oracle.Block("zero", n, n)], [oracle.Block("diag", n, coeff=hc[2])]]
+        assert_bits_equal(dz.to_numpy(), np.concatenate(oracle.block_df(zops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [hm])), "zero row of Z*m")
+        dz.close()
+    x2 = J.rand(J.domain(G), seed=3, stream=0)
+    junk = J.fill_(J.zeros(J.range(G)), float("nan"))
+    junk.close()
+    dg = (G * x2).to_numpy()
+    assert np.isfinite(dg).all()
+    J.trim()
