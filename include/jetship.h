@@ -105,8 +105,9 @@ int jh_device_info(char *name, int name_cap, int64_t *total_mem, int64_t *free_m
 /* Slab cache.  The reference's style allocates range-sized temporaries all the time (`A*m` returns a fresh vector, `zeros(range(A))`
  * per composite stage, src/Jets.jl:399, 526-533), and hipMalloc of a 64 GiB slab costs 2-6 seconds on this machine whenever the
  * runtime goes to the driver for it (profiles/exp_r03_alloc_cost.txt).  So the device memory of a destroyed vector of 16 MiB or more
- * is kept (per device, never the last 32 GiB of it, oldest out first) and handed to the next jh_bvec_create of exactly that
- * size; when the driver refuses an allocation of the library, cached slabs go back to it, oldest first, until the request fits.  jh_device_info counts cached memory as free.
+ * is kept (per device, never the last 32 GiB of it) and handed to the next jh_bvec_create of exactly that
+ * size; when the cap is passed or the driver refuses an allocation of the library, slabs go back to it, chosen to cover the shortfall
+ * with about the fewest bytes (re-used device memory is cleared by the driver at about 20 GB/s: that is where the seconds go).  jh_device_info counts cached memory as free.
  * jh_trim() returns it to the driver (before another library of the process needs the memory); jh_tune_set("slab_cache", 0) turns
  * the cache off (and empties it); jh_tune_get("slab_cached_mib") reads what it holds. */
 int jh_trim(void);

@@ -33,7 +33,7 @@ jh_context *jh_ctx_by_id(int id)
 // hipMalloc of a range-sized slab is not cheap on this machine: 64 GiB takes 2-6 SECONDS whenever the runtime has to go to the driver
 // for it, which it does unpredictably (profiles/exp_r03_alloc_cost.txt; 8 GiB: 0.2 ms).  A caller in the reference's style allocates
 // such temporaries all the time (`A*m` returns a fresh vector, `zeros(range(A))` per stage, a solver's copy of b), so the slabs of
-// destroyed vectors are kept -- per device, exact size, oldest out first when the cap is reached -- and handed to the next
+// destroyed vectors are kept -- per device, exact size, as few bytes as possible given back when the cap is reached -- and handed to the next
 // jh_bvec_create of that size.  jh_trim() / knob "slab_cache" = 0 / an allocation that does not fit release them.
 namespace {
 struct cached_slab { void *p; size_t bytes; };
@@ -52,15 +52,29 @@ size_t slab_cap_bytes()                                       // the cache never
     return cap;
 }
 
-bool slab_evict_oldest(int device)                             // false when the cache is empty
+// pick (under the lock) the slab to give back when `need` more bytes are wanted: the largest one that does not overshoot the need, else
+// (every slab is bigger) the smallest -- called until the need is covered, this gives back close to the fewest bytes, and re-used
+// device memory is cleared by the driver at ~20 GB/s: the bytes given back are what a later allocation pays for
+bool slab_pick_victim(std::vector<cached_slab> &v, size_t need, cached_slab *victim)
+{
+    if (v.empty()) return false;
+    size_t under = v.size(), smallest = 0;
+    for (size_t k = 0; k < v.size(); k++) {
+        if (v[k].bytes <= need && (under == v.size() || v[k].bytes > v[under].bytes)) under = k;
+        if (v[k].bytes < v[smallest].bytes) smallest = k;
+    }
+    const size_t k = under < v.size() ? under : smallest;
+    *victim = v[k];
+    v.erase(v.begin() + (long)k);
+    return true;
+}
+
+bool slab_evict_for(int device, size_t need)                   // false when the cache is empty
 {
     cached_slab victim{nullptr, 0};
     {
         std::lock_guard<std::mutex> lock(g_slab_mutex);
-        std::vector<cached_slab> &v = g_slabs[device];
-        if (v.empty()) return false;
-        victim = v.front();
-        v.erase(v.begin());
+        if (!slab_pick_victim(g_slabs[device], need, &victim)) return false;
     }
     (void)hipFree(victim.p);
     return true;
@@ -100,14 +114,16 @@ hipError_t jh_slab_alloc(int device, size_t bytes, void **out)
     return jh_device_malloc(device, out, bytes);
 }
 
-// hipMalloc for everything the library allocates: what the cache holds is free memory -- when the driver says no, give slabs back,
-// oldest first, and ask again (re-used device memory is cleared by the driver at ~20 GB/s, so no more is given back than needed)
+// hipMalloc for everything the library allocates: what the cache holds is free memory -- when the driver says no, give back the slab
+// that covers the shortfall with the fewest bytes and ask again
 hipError_t jh_device_malloc(int device, void **out, size_t bytes)
 {
     hipError_t e = hipMalloc(out, bytes);
     while (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
-        if (!slab_evict_oldest(device)) break;
+        size_t fr = 0, tot = 0;
+        const size_t need = (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < bytes) ? bytes - fr : bytes;
+        if (!slab_evict_for(device, need)) break;
         e = hipMalloc(out, bytes);
     }
     return e;
@@ -123,10 +139,10 @@ void jh_slab_free(int device, void *p, size_t bytes)
             std::vector<cached_slab> &v = g_slabs[device];
             size_t held = bytes;
             for (const cached_slab &c : v) held += c.bytes;
-            while (held > slab_cap_bytes() && !v.empty()) {
-                held -= v.front().bytes;
-                evict.push_back(v.front());
-                v.erase(v.begin());
+            cached_slab victim{nullptr, 0};
+            while (held > slab_cap_bytes() && slab_pick_victim(v, held - slab_cap_bytes(), &victim)) {
+                held -= victim.bytes;
+                evict.push_back(victim);
             }
             v.push_back(cached_slab{p, bytes});
         }

@@ -61,8 +61,8 @@ def test_small_vectors_and_a_switched_off_cache_go_straight_back_to_the_driver(J
 
 
 def test_an_allocation_that_needs_the_cached_memory_gets_it(Jets):
-    """Two 100 GiB slabs wait in the cache, then a request the rest of the device cannot satisfy: slabs go back to the driver, oldest first,
-    until the request fits."""
+    """Two 100 GiB slabs wait in the cache, then a request the rest of the device cannot satisfy: slabs go back to the driver -- the one
+    that covers the shortfall with the fewest bytes first -- until the request fits."""
     J = Jets
     info = J.device_info()
     if info["free_mem"] < 270 * GIB:
@@ -80,7 +80,7 @@ def test_an_allocation_that_needs_the_cached_memory_gets_it(Jets):
     small.close()
     del small
     gc.collect()
-    assert _cached_mib(J) in (180 * 1024, 180 * 1024 + 1)         # 280 GiB would pass the cap: the oldest slab went back to the driver
+    assert _cached_mib(J) in (180 * 1024, 180 * 1024 + 1)         # 280 GiB would pass the cap: one 100 GiB slab went back to the driver
     c = J.Array(J.JetSpace(np.float32, 55 * GIB))                 # 220 GiB: more than what is free beside the cache -- both remaining slabs go
     assert _cached_mib(J) == 0
     J.fill_(c, 1.0)
