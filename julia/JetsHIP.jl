@@ -487,6 +487,19 @@ end
 
 # (A' ∘ A) * m fused (src/Jets.jl:530-534 over (A', A)): coefficients read once, no range-side temporary, the bits of the
 # unfused chain.  Any other composite runs the reference's chain on device arrays.
+# dot_product_test on device vectors (src/Jets.jl:1211-1226): the reference builds ones(domain(op)) / ones(range(op)) as default masks and
+# the masked copies `mmask .* m`, `dmask .* d` -- at the headline size each of those is another 64 GiB next to A, d and A*m, more than the
+# device holds.  `1 .* x` has x's bits, so without masks neither the ones nor the products are materialised; same values, same order.
+function Jets.dot_product_test(op::JopLn, m::DevVec{T}, d::DevVec{T}; mmask=[], dmask=[]) where {T}
+    mm = length(mmask) == 0 ? m : mmask .* m
+    dd = length(dmask) == 0 ? d : dmask .* d
+    ms = op' * dd
+    lhs = dot(mm, ms)
+    ds = op * mm
+    rhs = dot(ds, dd)
+    (eltype(lhs) <: Complex && eltype(rhs) <: Complex) ? (lhs, rhs) : (real(lhs), real(rhs))
+end
+
 function Jets.JetComposite_df!(d::HipArray{T}, m::HipArray{T}; ops, kwargs...) where {T}
     if length(ops) == 2 && ops[1] isa JopAdjoint && ops[1].op === ops[2]
         h = tall_native(ops[2], T)
