@@ -516,8 +516,12 @@ def nblocks_op(A, i=None):  # :1074-1077
 
 
 def overwrites_its_whole_range(A) -> bool:
-    """True when mul!(d, A, m) is known to write every element of d whatever d held: a one-column LINEAR block operator (not adjointed)
-    whose children are all device-native and none a zero block -- each row is one overwrite (src/Jets.jl:1026)."""
+    """True when mul!(d, A, m) is known to write every element of d whatever d held: a sum or a composite (they set their output themselves),
+    or a one-column LINEAR block operator (not adjointed) whose children are all device-native and none a zero block -- each row is one
+    overwrite (src/Jets.jl:1026)."""
+    inner = A.op if isinstance(A, JopAdjoint) else A
+    if isinstance(inner, (JopLn, JopNl)) and inner.jet.f in (_j.JetSum_f, _j.JetComposite_f):
+        return True                    # a sum starts with `d .= 0` (src/Jets.jl:631, 640, 649), a composite ends with `d .= chain` (526, 532, 538)
     if not isinstance(A, JopLn) or not isblockop(A):
         return False
     ops = A.jet.s["ops"]

@@ -417,29 +417,55 @@ def mul(A: Jop, m):
 
 # ------------------------------------------------------------------------------ composition --------
 class _Workspace:
-    """Zero-filled temporaries of a combinator, kept between calls.  The reference allocates `zeros(range(op))`
-    for every stage on every call (src/Jets.jl:525, 531, 537, 632, 641, 650) -- at 64 GiB per range vector that is
-    the dominant cost of a chain; here a stage's temporary is allocated once and re-zeroed (the zero fill is kept:
-    block operators skip zero blocks and accumulate into their output, src/Jets.jl:1022-1024)."""
+    """Temporaries of a combinator.  The reference allocates `zeros(range(op))` for every stage on every call
+    (src/Jets.jl:525, 531, 537, 632, 641, 650).  Here: a temporary of 16 MiB or more is taken for ONE call and given back when the
+    call returns -- the library's slab cache (include/jetship.h, jh_trim) makes that a pointer hand-over, and no combinator object
+    sits on 64 GiB between calls; smaller ones are kept and re-zeroed (an allocation per call would cost more than the kernels).
+    The zero fill is skipped where the stage overwrites its whole output (jetblock.overwrites_its_whole_range): block operators
+    skip zero blocks and accumulate into their output otherwise (src/Jets.jl:1022-1024)."""
+
+    KEEP_BELOW = 16 << 20
 
     def __init__(self):
         self._pool = {}
+        self._call = []
 
     def __deepcopy__(self, memo):  # copy(jet) gets its own, empty pool
         return _Workspace()
 
-    def zeros(self, slot, R):
+    def zeros(self, slot, R, for_op=None):
+        from .jetblock import overwrites_its_whole_range
+
+        undef = for_op is not None and overwrites_its_whole_range(for_op)
+        if R.length() * np.dtype(R.eltype()).itemsize >= self.KEEP_BELOW:
+            x = _arr.Array(R, undef=undef)
+            self._call.append(x)
+            return x
         hit = self._pool.get(slot)
         if hit is None or hit[0] != R:
             hit = (R, zeros(R))
             self._pool[slot] = hit
             return hit[1]
-        return fill_(hit[1], 0)
+        return hit[1] if undef else fill_(hit[1], 0)
+
+    def release(self):
+        """End of a call: the big temporaries go back (to the slab cache)."""
+        for x in self._call:
+            x.close()
+        self._call = []
 
     def close(self):
+        self.release()
         for _, x in self._pool.values():
             x.close()
         self._pool = {}
+
+
+def _zeroed_output(out, op):
+    """The output of a combinator's last stage: zeroed like the reference's zeros() unless the stage overwrites all of it."""
+    from .jetblock import overwrites_its_whole_range
+
+    return out if overwrites_its_whole_range(op) else fill_(out, 0)
 
 
 def JetComposite(ops: Sequence[Jop]) -> Jet:  # :522
@@ -453,10 +479,13 @@ def _chain(out, x, stages, ws):
     (src/Jets.jl:525/531/537); the last writes `out` itself after zeroing it, which is the reference's
     `d .= chain(m)` (526/532/538) without the extra copy."""
     ws = ws if ws is not None else _Workspace()
-    for k, (op, R) in enumerate(stages[:-1]):
-        x = mul_(ws.zeros(k, R), op, x)
-    op, _ = stages[-1]
-    return mul_(fill_(out, 0), op, x)
+    try:
+        for k, (op, R) in enumerate(stages[:-1]):
+            x = mul_(ws.zeros(k, R, op), op, x)
+        op, _ = stages[-1]
+        return mul_(_zeroed_output(out, op), op, x)
+    finally:
+        ws.release()
 
 
 def JetComposite_f(d, m, *, ops, _ws=None, **kw):  # :524-528  right-to-left chain
@@ -514,9 +543,13 @@ def _accumulate(sgn: str, acc, term):
 
 def JetSum_f(d, m, *, ops, sgns, _ws=None, **kw):  # :630-637
     fill_(d, 0)
-    _d = (_ws or _Workspace()).zeros("rng", range_(ops[0]))   # one temporary, zeroed once per call like the reference (:632)
-    for op, sg in zip(ops, sgns):
-        _accumulate(sg, d, mul_(_d, op, m))
+    ws = _ws or _Workspace()
+    try:
+        _d = ws.zeros("rng", range_(ops[0]))   # one temporary, zeroed once per call like the reference (:632)
+        for op, sg in zip(ops, sgns):
+            _accumulate(sg, d, mul_(_d, op, m))
+    finally:
+        ws.release()
     return d
 
 
@@ -526,9 +559,13 @@ def JetSum_df(d, m, *, ops, sgns, _ws=None, **kw):  # :639-646
     if _blk.try_fused_sum(d, m, ops, sgns, False) is not None:
         return d
     fill_(d, 0)
-    _d = (_ws or _Workspace()).zeros("rng", range_(ops[0]))
-    for op, sg in zip(ops, sgns):
-        _accumulate(sg, d, mul_(_d, JopLn(op), m))
+    ws = _ws or _Workspace()
+    try:
+        _d = ws.zeros("rng", range_(ops[0]))
+        for op, sg in zip(ops, sgns):
+            _accumulate(sg, d, mul_(_d, JopLn(op), m))
+    finally:
+        ws.release()
     return d
 
 
@@ -538,9 +575,13 @@ def JetSum_df_adj(m, d, *, ops, sgns, _ws=None, **kw):  # :648-655
     if _blk.try_fused_sum(m, d, ops, sgns, True) is not None:
         return m
     fill_(m, 0)
-    _m = (_ws or _Workspace()).zeros("dom", domain(ops[0]))
-    for op, sg in zip(ops, sgns):
-        _accumulate(sg, m, mul_(_m, adjoint(JopLn(op)), d))
+    ws = _ws or _Workspace()
+    try:
+        _m = ws.zeros("dom", domain(ops[0]))
+        for op, sg in zip(ops, sgns):
+            _accumulate(sg, m, mul_(_m, adjoint(JopLn(op)), d))
+    finally:
+        ws.release()
     return m
 
 
@@ -658,29 +699,33 @@ def linearization_test(F: JopNl, mo, mu=(1.0, 0.5, 0.25, 0.125, 0.0625, 0.03125)
     device (F!, point!, J, fused broadcasts, norms)."""
     from .arrays import rand, lincomb_, norm
 
-    mmask = ones(domain(F)) if mmask is None else mmask  # :1238
-    dmask = ones(range_(F)) if dmask is None else dmask  # :1239
+    from .broadcast import broadcast_
+
+    # the default masks are ones(space) (:1238-1239) and 1 .* x has x's bits: they are not materialised (a range-sized one is 64 GiB at the
+    # headline size); likewise d_lin and the per-mu F*(...) live in ONE range vector -- the loop below holds Fo, Jo*dm and that one
     if dm is None:  # :1242-1243   dm = mmask .* (-1 .+ 2 .* rand(domain(F)))
         r = rand(domain(F)) if seed is None else rand(domain(F), seed=int(seed), stream=0)
         lincomb_(r, [2.0], [r])
         r2 = ones(domain(F))
         lincomb_(r, [1.0, -1.0], [r, r2])
-        dm = hadamard_(r, mmask, r)
-    else:
+        dm = r if mmask is None else hadamard_(r, mmask, r)
+    elif mmask is not None:
         dm = hadamard_(dm, mmask, dm)  # :1245   dm .*= mmask
     Fo = mul(F, mo)  # :1248
     Jo = jacobian_(F, mo)  # :1249
     Jodm = mul(Jo, dm)  # :1250
     mus = sorted((float(x) for x in mu), reverse=True)  # :1252
     phi = []
-    d_lin, m_mu = _arr.similar(Fo), _arr.similar(mo)
+    d_non, m_mu = _arr.similar(Fo), _arr.similar(mo)
     for x in mus:
-        lincomb_(d_lin, [1.0, x], [Fo, Jodm])  # :1258   d_lin = Fo .+ mu .* Jo dm
         lincomb_(m_mu, [1.0, x], [mo, dm])
-        d_non = mul(F, m_mu)  # :1259   (re-points nothing: F's jet keeps mo until the next point!)
-        lincomb_(d_non, [1.0, -1.0], [d_non, d_lin])
-        hadamard_(d_non, dmask, d_non)
+        mul_(fill_(d_non, 0), F, m_mu)  # :1259   F*(mo .+ mu .* dm) = mul!(zeros(range(F)), F, .) (re-points nothing: F's jet keeps mo until the next point!)
+        broadcast_(d_non, "x0 - (x1 + s0*x2)", [d_non, Fo, Jodm], [x])  # :1258, 1260   d_non .- (Fo .+ mu .* Jo dm), every operation rounded as written
+        if dmask is not None:
+            hadamard_(d_non, dmask, d_non)
         phi.append(float(norm(d_non)))  # :1260
+    for tmp in (Fo, Jodm, d_non, m_mu):
+        tmp.close()
     mu_obs = [phi[i - 1] / phi[i] for i in builtins.range(1, len(mus))]  # :1262
     mu_exp = [(mus[i - 1] / mus[i]) ** 2 for i in builtins.range(1, len(mus))]  # :1263
     return np.array(mu_obs), np.array(mu_exp)
