@@ -302,7 +302,14 @@ def _new_handle(block_lens: Sequence[int], T, undef: bool = False) -> C.c_void_p
     _device.init()
     h = C.c_void_p()
     create = lib.jh_bvec_create_uninit if undef else lib.jh_bvec_create
-    check(create(len(block_lens), _i64arr(block_lens), dtype_code(T), C.byref(h)))
+    lens = _i64arr(block_lens)
+    st = create(len(block_lens), lens, dtype_code(T), C.byref(h))
+    if st == 3:                                  # JH_ERR_NOMEM: vectors caught in reference cycles still hold device memory -- collect them and ask again
+        import gc
+
+        gc.collect()
+        st = create(len(block_lens), lens, dtype_code(T), C.byref(h))
+    check(st)
     return h
 
 

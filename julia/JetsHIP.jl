@@ -65,7 +65,12 @@ end
 function _create(lens::Vector{Int64}, ::Type{T}) where {T}
     _ensure_init()
     h = Ref{Ptr{Cvoid}}()
-    check(ccall((:jh_bvec_create, LIB), Cint, (Int64, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}), length(lens), lens, dtype_code(T), h))
+    st = ccall((:jh_bvec_create, LIB), Cint, (Int64, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}), length(lens), lens, dtype_code(T), h)
+    if st == 3                                                     # JH_ERR_NOMEM: Julia's GC does not see device memory -- unreachable vectors may
+        GC.gc()                                                    # still hold theirs.  Their finalizers hand it to the library's slab cache; ask again.
+        st = ccall((:jh_bvec_create, LIB), Cint, (Int64, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}), length(lens), lens, dtype_code(T), h)
+    end
+    check(st)
     Slab(h[], length(lens))
 end
 
