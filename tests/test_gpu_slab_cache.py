@@ -131,3 +131,48 @@ def test_a_times_m_skips_the_zero_fill_only_where_every_row_is_overwritten(Jets,
     dg = (G * x2).to_numpy()
     assert np.isfinite(dg).all()
     J.trim()
+
+
+def test_churn_of_cached_slabs_never_hands_out_memory_that_is_still_in_use(Jets):
+    """Random create / combine / destroy of vectors of a few sizes (all above the cache's floor), destroying operands right after the
+    kernels that read them were enqueued: every survivor must hold what a host model says.  A slab handed out while a kernel still
+    reads or writes it would show up as a wrong value (the destroy waits for the vector's stream before the slab goes to the cache)."""
+    J = Jets
+    J.trim()
+    rng = np.random.default_rng(11)
+    sizes = [(4 << 20) + 8 * k for k in range(3)]                   # Float32 elements: 16 MiB + a little, three distinct sizes
+    live = []                                                        # (device vector, host value of every element)
+    hits = 0
+    for it in range(400):
+        action = rng.integers(0, 4)
+        if action <= 1 or len(live) < 3:
+            n = sizes[rng.integers(0, len(sizes))]
+            before = J.tune_get("slab_cached_mib")
+            x = J.zeros(J.JetSpace(np.float32, n))
+            hits += J.tune_get("slab_cached_mib") < before
+            val = float(rng.integers(1, 9))
+            J.fill_(x, val)
+            live.append((x, val))
+        elif action == 2:
+            i, j = rng.integers(0, len(live), 2)
+            (a, va), (b, vb) = live[i], live[j]
+            if a.length() == b.length() and i != j:
+                out = J.zeros(J.space(a))
+                J.lincomb_(out, [2.0, -1.0], [a, b])                 # enqueued ...
+                live.append((out, 2.0 * va - vb))
+                k = max(i, j)
+                live[k][0].close()                                   # ... and one operand destroyed at once: its slab goes to the cache
+                live.pop(k)
+        else:
+            k = rng.integers(0, len(live))
+            live[k][0].close()
+            live.pop(k)
+        if len(live) > 12:
+            live[0][0].close()
+            live.pop(0)
+    assert hits > 50                                                  # the cache was really in play
+    for x, val in live:
+        mn, mx = J.extrema(x)
+        assert float(mn) == float(mx) == val
+        x.close()
+    J.trim()
