@@ -92,6 +92,25 @@ int main(void)
     CK(jh_download(d, 0, (int64_t)NROW * n, hd));
     CK(jh_download(mt, 0, n, hmt));
     CK(jh_download(y, 0, n, hy));
+    {   /* the fused A'A range by range (what a host pipelining the exchange of y enqueues) into storage that was never zeroed */
+        jh_bvec *y2 = NULL;
+        const int64_t len1[1] = {n};
+        CK(jh_bvec_create_uninit(1, len1, JH_F32, &y2));
+        const int64_t cut = n >= 8 ? (n / 2) / 4 * 4 : n;
+        CK(jh_blockop_normal_mul_range(A, y2, m, 0, cut));
+        CK(jh_blockop_normal_mul_range(A, y2, m, cut, n - cut));
+        float *hy2 = malloc((size_t)n * sizeof(float));
+        REQUIRE(hy2, "host allocation");
+        CK(jh_download(y2, 0, n, hy2));
+        REQUIRE(memcmp(hy2, hy, (size_t)n * sizeof(float)) == 0, "ranged fused A'A == the whole one, bit for bit");
+        REQUIRE(jh_blockop_normal_mul_range(A, y2, m, n - 4, 8) == JH_ERR_INVALID, "a range past the end is refused");
+        free(hy2);
+        CK(jh_bvec_destroy(y2));
+        CK(jh_trim());                                   /* whatever the slab cache kept goes back to the driver */
+        int64_t cached = -1;
+        CK(jh_tune_get("slab_cached_mib", &cached));
+        REQUIRE(cached == 0, "jh_trim empties the slab cache");
+    }
 
     /* ---- the oracle on the same seeded inputs */
     float *oa = malloc((size_t)NROW * n * sizeof(float)), *om = malloc((size_t)n * sizeof(float));
