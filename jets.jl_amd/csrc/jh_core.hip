@@ -44,11 +44,10 @@ constexpr size_t SLAB_CACHE_MIN = (size_t)16 << 20;          // from 16 MiB on: 
 
 size_t slab_cap_bytes()                                       // the cache never holds the last 32 GiB of the device
 {
-    static size_t cap = 0;
-    if (!cap) {
+    static const size_t cap = [] {                            // (initialised once, thread-safely)
         size_t fr = 0, tot = 0;
-        cap = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > ((size_t)64 << 30)) ? tot - ((size_t)32 << 30) : (size_t)32 << 30;
-    }
+        return (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > ((size_t)64 << 30)) ? tot - ((size_t)32 << 30) : (size_t)32 << 30;
+    }();
     return cap;
 }
 
