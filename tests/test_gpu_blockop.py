@@ -625,6 +625,10 @@ def test_special_values_go_through_every_kernel_family_like_on_the_cpu(Jets, ora
     assert len(results) >= 80
     bad = [r for r in results if r[2] is not True]
     assert not bad, bad[:8]
+    # the same through the big-block routes (blocks of 16 / 32 MiB: register-tiled grids, chained one-pass step, nontemporal tall walks)
+    results = mod.run_checks(Jets, oracle, seed=6, n=4 << 20, dtypes=(np.float32, np.complex64))
+    bad = [r for r in results if r[2] is not True]
+    assert len(results) >= 40 and not bad, bad[:8]
 
 
 @pytest.mark.parametrize("dt", [np.complex64, np.complex128])

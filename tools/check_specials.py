@@ -2,7 +2,7 @@
 """IEEE special values (signed zeros, infinities, NaN, denormals, the largest finite values) through every kernel family, against the
 CPU oracle, element by element -- bit for bit except for the payload of a NaN.  Prints one line per check; exit status 1 on a mismatch.
 
-    python tools/check_specials.py            (one MI355X)
+    python tools/check_specials.py [elements per block]            (one MI355X; default 4120, 6291456 for the big-block routes)
 """
 import ctypes as C
 import os
@@ -46,7 +46,22 @@ def same(a, b):
 
 
 
-def run_checks(J, jo, seed=5):
+def close_or_better(a, b, rtol):
+    """For the one kernel family whose sum is NOT in the reference's order (the dense adjoint: fp64 lanes + wave reduction, tolerance parity):
+    a NaN of the device must be a NaN of the oracle (accumulating in fp64 only removes overflow-made Inf - Inf), finite pairs agree to rtol."""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    if a.dtype.kind == "c":
+        rt = np.float32 if a.dtype == np.complex64 else np.float64
+        a, b = a.view(rt), b.view(rt)
+    if (np.isnan(a) & ~np.isnan(b)).any():
+        return f"{int((np.isnan(a) & ~np.isnan(b)).sum())} NaNs the oracle does not have"
+    both = np.isfinite(a) & np.isfinite(b)
+    err = np.abs(a[both].astype(np.float64) - b[both].astype(np.float64))
+    scale = np.abs(b[both].astype(np.float64)) + np.finfo(a.dtype).tiny
+    return True if (err <= rtol * scale + 1e-30).all() else f"finite values differ by up to {float((err / scale).max()):.1e}"
+
+
+def run_checks(J, jo, seed=5, n=4096 + 24, dtypes=(np.float32, np.float64, np.complex64, np.complex128)):
     """[(dtype name, what, True | mismatch text)] for every check; J = the product package, jo = the oracle module."""
     from jets_jl_amd._ffi import lib, check
 
@@ -57,8 +72,8 @@ def run_checks(J, jo, seed=5):
         results.append((np.dtype(dt).name, what, r))
 
     with np.errstate(all="ignore"):
-        for dt in (np.float32, np.float64, np.complex64, np.complex128):
-            n, nrow = 4096 + 24, 6
+        for dt in dtypes:
+            nrow = 6
             z = lambda k=1: [np.zeros(n, dtype=dt) for _ in range(k)]
             coeffs = [specials(rng, dt, n) for _ in range(nrow)]
             hm, hd = specials(rng, dt, n), [specials(rng, dt, n) for _ in range(nrow)]
@@ -121,7 +136,8 @@ def run_checks(J, jo, seed=5):
                 dops = [[jo.Block("dense", nd, nd, coeff=np.asfortranarray(Md))], [jo.Block("dense", nd, nd, coeff=np.asfortranarray(Md))]]
                 report(dt, "dense forward", same((D * J.from_numpy(hv)).to_numpy(), np.concatenate(jo.block_df(dops, [np.zeros(nd, dtype=dt) for _ in range(2)], [hv]))))
                 h2 = [specials(rng, dt, nd, 0.1) for _ in range(2)]
-                report(dt, "dense adjoint", same((D.H * J.from_numpy(np.concatenate(h2), J.range(D))).to_numpy(), jo.block_df_adj(dops, [np.zeros(nd, dtype=dt)], h2)[0]))
+                report(dt, "dense adjoint", close_or_better((D.H * J.from_numpy(np.concatenate(h2), J.range(D))).to_numpy(), jo.block_df_adj(dops, [np.zeros(nd, dtype=dt)], h2)[0],
+                                                            1e-4 if dt in (np.float32, np.complex64) else 1e-11))
             # broadcast: a*x + b*y over block arrays
             R = J.range(A)
             X, Y = J.from_numpy(np.concatenate(hd), R), J.from_numpy(np.concatenate(ref_d), R)
@@ -145,7 +161,7 @@ if __name__ == "__main__":
     from oracle import jets_oracle as jo
 
     J.init(0)
-    out = run_checks(J, jo)
+    out = run_checks(J, jo, n=int(sys.argv[1]) if len(sys.argv) > 1 else 4096 + 24)   # e.g. 6291456: blocks of 24-48 MiB take the big-block routes
     for name, what, r in out:
         print(f"{name:10s} {what:38s} {'ok' if r is True else 'MISMATCH: ' + str(r)}", flush=True)
     sys.exit(1 if any(r is not True for _, _, r in out) else 0)
