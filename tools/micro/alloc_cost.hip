@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -37,13 +38,31 @@ static void cycle(const char *tag, size_t bytes, int reps, int sleep_ms, bool to
     }
 }
 
-int main()
+int main(int argc, char **argv)
 {
     (void)hipSetDevice(0);
     (void)hipFree(nullptr);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     printf("# free %.1f GiB of %.1f GiB\n", free_b / 1073741824.0, total_b / 1073741824.0);
+    if (argc > 1) {
+        // `alloc_cost <GiB per piece>`: the FIRST allocations of a fresh process as pieces -- do 64 GiB in small requests dodge the seconds?
+        const size_t piece = (size_t)atoi(argv[1]) << 30;
+        const int count = (int)(((size_t)128 << 30) / piece);
+        std::vector<void *> ps((size_t)count, nullptr);
+        double total = 0;
+        for (int k = 0; k < count; k++) {
+            double t0 = now();
+            hipError_t e = hipMalloc(&ps[(size_t)k], piece);
+            double dt = now() - t0;
+            total += dt;
+            if (e != hipSuccess) { printf("hipMalloc failed: %s\n", hipGetErrorString(e)); return 1; }
+            if (dt > 5.0 || k < 4) printf("  piece %3d of %zu GiB: hipMalloc %9.2f ms\n", k, piece >> 30, dt);
+        }
+        printf("## %d pieces of %zu GiB (128 GiB) as the first allocations of the process: %.1f ms in all\n", count, piece >> 30, total);
+        for (void *p : ps) (void)hipFree(p);
+        return 0;
+    }
     cycle("A", (size_t)64 << 30, 5, 0, true);
     cycle("B", (size_t)64 << 30, 4, 0, false);
     cycle("C", (size_t)64 << 30, 4, 3000, true);
