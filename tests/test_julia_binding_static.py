@@ -506,3 +506,63 @@ def test_calls_of_the_bindings_own_functions_match_a_method_by_argument_count():
     # the lint sees a dropped argument
     probe = "g(a, b; k=1) = a + b\nh(x) = g(x)\n"
     assert julia_arity_errors(probe) and not julia_arity_errors("g(a, b=2; k=1) = a + b\nh(x) = g(x, k=3)\n")
+
+
+# ---- round 3: keyword arguments passed to the binding's own functions exist ----------------------------------------------------------
+def _kw_names(parts):
+    """Names of the keyword entries of an argument list (after `;`, or `name = value` entries of a call)."""
+    names, slurp = set(), False
+    for a in parts:
+        a = a.strip()
+        if a.endswith("..."):
+            slurp = True
+            continue
+        m = re.match(r"([A-Za-z_][\w!′]*)\s*(?:::[^=]+)?(?:=(?!=)|$)", a)
+        if m:
+            names.add(m.group(1))
+    return names, slurp
+
+
+def julia_keyword_errors(code, foreign=()):
+    defs = {}                                                   # name -> [(keyword names, accepts any)]
+    pats = (r"(?m)^\s*(?:@inline\s+)?function\s+((?:\w+\.)?[A-Za-z_][\w!′]*)\(", r"(?m)^\s*(?:@inline\s+)?((?:\w+\.)?[A-Za-z_][\w!′]*)\(")
+    extends = set()
+    for which, pat in enumerate(pats):
+        for mt in re.finditer(pat, code):
+            end = _balanced(code, mt.end() - 1)
+            if which == 1 and not re.match(r"(?:\s*where\s*\{[^}]*\}|\s*where\s+\w+)?\s*=(?!=)", code[end:]):
+                continue
+            _, kw = _split_args(code[mt.end():end - 1])
+            names, slurp = _kw_names(kw)
+            defs.setdefault(mt.group(1).split(".")[-1], []).append((names, slurp))
+            if "." in mt.group(1):
+                extends.add(mt.group(1).split(".")[-1])
+    errs = []
+    for mt in re.finditer(r"(?<![\w.!:@′])([A-Za-z_][\w!′]*)\(", code):
+        name = mt.group(1)
+        if name not in defs or name in extends or name in foreign:
+            continue
+        end = _balanced(code, mt.end() - 1)
+        line_start = code.rfind("\n", 0, mt.start()) + 1
+        before = code[line_start:mt.start()]
+        if re.match(r"\s*(?:@inline\s+)?(?:function\s+)?(?:\w+\.)?$", before) and (
+                "function" in before or re.match(r"(?:\s*where\s*\{[^}]*\}|\s*where\s+\w+)?\s*=(?!=)", code[end:])):
+            continue
+        pos, kw = _split_args(code[mt.end():end - 1])
+        passed, slurp = _kw_names(kw)
+        passed |= {re.match(r"\s*([A-Za-z_][\w!′]*)", a).group(1) for a in pos if _has_top_assign(a) and re.match(r"\s*[A-Za-z_][\w!′]*\s*=(?!=)", a)}
+        if slurp or not passed:
+            continue
+        if not any(acc or passed <= names for names, acc in defs[name]):
+            errs.append((code[:mt.start()].count("\n") + 1, name, sorted(passed), [sorted(n) for n, _ in defs[name]]))
+    return errs
+
+
+def test_keyword_arguments_passed_to_the_bindings_own_functions_exist():
+    code = _julia_code_tokens()
+    imp = re.search(r"import Jets:(.*?)\n\n", open(JULIA).read(), flags=re.S).group(1)
+    imported = {t.strip() for t in imp.replace("\n", " ").split(",") if t.strip()}
+    errs = julia_keyword_errors(code, foreign=imported | BASE_CALLABLES)
+    assert not errs, errs[:10]
+    assert julia_keyword_errors("g(a; tol=1, maxiter=2) = a\nh(x) = g(x; tolerance=3)\n")
+    assert not julia_keyword_errors("g(a; tol=1, kw...) = a\nh(x) = g(x; anything=3)\nk(x) = g(x, tol=2)\n")
