@@ -118,8 +118,11 @@ __global__ void k_uniform(S *__restrict__ p, int64_t n, uint64_t key, int64_t la
     Pack<S, NS> *pv = reinterpret_cast<Pack<S, NS> *>(p);
     for (int64_t v = tid; v < nvec; v += stride) {
         Pack<S, NS> o;
+        // the counter of element i is key + (i + 1) * GOLDEN (mod 2^64): one 64-bit multiply per pack, then additions of constants --
+        // the kernel is bound by its integer multiplies (two more per element inside mix64), not by the store
+        const uint64_t z0 = key + (uint64_t)(lane_base + v * NS + 1) * GOLDEN;
 #pragma unroll
-        for (int c = 0; c < NS; c++) o.v[c] = u01_from<S>(mix64(key + (uint64_t)(lane_base + v * NS + c + 1) * GOLDEN));
+        for (int c = 0; c < NS; c++) o.v[c] = u01_from<S>(mix64(z0 + (uint64_t)c * GOLDEN));
         stnt(pv + v, o);
     }
     const int64_t tail0 = nvec * NS;
