@@ -335,7 +335,7 @@ def ones(R: JetAbstractSpace):
         from .symmetric import ones_sym
 
         return ones_sym(R)
-    return fill_(Array(R), 1.0)
+    return fill_(Array(R, undef=True), 1.0)           # (every element is written: no zero fill first)
 
 
 def rand(R: JetAbstractSpace, seed: int | None = None, stream: int | None = None, index_base: int = 0):
@@ -345,7 +345,7 @@ def rand(R: JetAbstractSpace, seed: int | None = None, stream: int | None = None
         from .symmetric import rand_sym
 
         return rand_sym(R, seed=seed, stream=stream, index_base=index_base)
-    x = Array(R)
+    x = Array(R, undef=True)                               # the generator writes every element
     if seed is None:
         seed, stream = _DEFAULT_SEED, next(_rand_counter)
     check(lib.jh_fill_uniform(x.handle, int(seed), int(stream or 0), int(index_base)))
@@ -358,7 +358,7 @@ def randn(R: JetAbstractSpace, seed: int | None = None, stream: int | None = Non
         from .symmetric import randn_sym
 
         return randn_sym(R, seed=seed, stream=stream, index_base=index_base)
-    x = Array(R)
+    x = Array(R, undef=True)
     if seed is None:
         seed, stream = _DEFAULT_SEED, next(_rand_counter)
     check(lib.jh_fill_normal(x.handle, int(seed), int(stream or 0), int(index_base)))
@@ -383,7 +383,7 @@ def from_numpy(a: np.ndarray, R: JetAbstractSpace | None = None):
     a = np.asarray(a)
     if R is None:
         R = JetSpace(a.dtype, *a.shape)
-    x = Array(R)
+    x = Array(R, undef=a.size == R.length())               # no zero fill when the upload covers the whole vector
     x._upload(a.ravel(order="F") if not isinstance(R, JetBSpace) else a.ravel())
     return x
 
@@ -617,7 +617,7 @@ def similar(x: _DevVec, T=None, n: int | None = None):
 def convert_array(x: _DevVec) -> DeviceArray:
     """convert(Array, x::BlockArray) (src/Jets.jl:862-868) as a flat device array: the slab is
     already in that layout, so this is one device-to-device copy."""
-    out = Array(JetSpace(x.dtype, x.length()))
+    out = Array(JetSpace(x.dtype, x.length()), undef=True)
     check(lib.jh_copy(out.handle, x.handle))
     return out
 
