@@ -62,13 +62,18 @@ mutable struct Slab
     end
 end
 
-function _create(lens::Vector{Int64}, ::Type{T}) where {T}
+# zero-filled (zeros(R)) or not (Array(R) = Array{T,N}(undef, ...), src/Jets.jl:105; the zero fill of 64 GiB is 11 ms) -- ccall wants literal names
+_bvec_create(lens::Vector{Int64}, ::Type{T}, h, undef::Bool) where {T} = undef ?
+    ccall((:jh_bvec_create_uninit, LIB), Cint, (Int64, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}), length(lens), lens, dtype_code(T), h) :
+    ccall((:jh_bvec_create, LIB), Cint, (Int64, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}), length(lens), lens, dtype_code(T), h)
+
+function _create(lens::Vector{Int64}, ::Type{T}, undef::Bool=false) where {T}
     _ensure_init()
     h = Ref{Ptr{Cvoid}}()
-    st = ccall((:jh_bvec_create, LIB), Cint, (Int64, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}), length(lens), lens, dtype_code(T), h)
+    st = _bvec_create(lens, T, h, undef)
     if st == 3                                                     # JH_ERR_NOMEM: Julia's GC does not see device memory -- unreachable vectors may
         GC.gc()                                                    # still hold theirs.  Their finalizers hand it to the library's slab cache; ask again.
-        st = ccall((:jh_bvec_create, LIB), Cint, (Int64, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}), length(lens), lens, dtype_code(T), h)
+        st = _bvec_create(lens, T, h, undef)
     end
     check(st)
     Slab(h[], length(lens))
@@ -135,24 +140,24 @@ _fill_uniform!(s::Slab, seed, stream) = check(ccall((:jh_fill_uniform, LIB), Cin
 _fill_normal!(s::Slab, seed, stream) = check(ccall((:jh_fill_normal, LIB), Cint, (Ptr{Cvoid}, UInt64, UInt64, Int64), s.handle, seed, stream, 0))
 _fill!(s::Slab, a) = check(ccall((:jh_fill, LIB), Cint, (Ptr{Cvoid}, Cdouble, Cdouble), s.handle, real(a), imag(a)))
 
-Base.zeros(R::HipSpace{T,N}) where {T,N} = HipArray{T,N}(_create(Int64[length(R)], T), size(R))   # device storage is created zero-filled
-Base.Array(R::HipSpace) = zeros(R)
-Base.ones(R::HipSpace{T}) where {T} = (x = zeros(R); _fill!(x.slab, one(T)); x)
-Base.rand(R::HipSpace; seed=1) = (x = zeros(R); _fill_uniform!(x.slab, seed, _next_stream()); x)
-Base.randn(R::HipSpace; seed=1) = (x = zeros(R); _fill_normal!(x.slab, seed, _next_stream()); x)
+Base.zeros(R::HipSpace{T,N}) where {T,N} = HipArray{T,N}(_create(Int64[length(R)], T), size(R))
+Base.Array(R::HipSpace{T,N}) where {T,N} = HipArray{T,N}(_create(Int64[length(R)], T, true), size(R))   # undef, like the reference's Array(R) (src/Jets.jl:105)
+Base.ones(R::HipSpace{T}) where {T} = (x = Array(R); _fill!(x.slab, one(T)); x)                         # (every element is written: no zero fill first)
+Base.rand(R::HipSpace; seed=1) = (x = Array(R); _fill_uniform!(x.slab, seed, _next_stream()); x)
+Base.randn(R::HipSpace; seed=1) = (x = Array(R); _fill_normal!(x.slab, seed, _next_stream()); x)
 
 # Array/zeros/ones/rand/randn(R::JetBSpace) (src/Jets.jl:922-924) for block spaces of device spaces: ONE slab, block i at
 # element offset R.indices[i][1]-1, handed out as the reference's BlockArray of block views
-function _blockarray(R::JetBSpace{T,<:HipSpace}) where {T}
-    o = _create(Int64[length(R.indices[i]) for i = 1:length(R.indices)], T)
+function _blockarray(R::JetBSpace{T,<:HipSpace}, undef::Bool=false) where {T}
+    o = _create(Int64[length(R.indices[i]) for i = 1:length(R.indices)], T, undef)
     arrays = [HipArray{T,ndims(R.spaces[i])}(_view(o, i), size(R.spaces[i]), o, i) for i = 1:length(R.spaces)]
     BlockArray(arrays, R.indices), o
 end
 Base.zeros(R::JetBSpace{T,S}) where {T,S<:HipSpace} = _blockarray(R)[1]
-Base.Array(R::JetBSpace{T,S}) where {T,S<:HipSpace} = _blockarray(R)[1]
-Base.ones(R::JetBSpace{T,S}) where {T,S<:HipSpace} = ((x, o) = _blockarray(R); _fill!(o, one(T)); x)
-Base.rand(R::JetBSpace{T,S}; seed=1) where {T,S<:HipSpace} = ((x, o) = _blockarray(R); _fill_uniform!(o, seed, _next_stream()); x)
-Base.randn(R::JetBSpace{T,S}; seed=1) where {T,S<:HipSpace} = ((x, o) = _blockarray(R); _fill_normal!(o, seed, _next_stream()); x)
+Base.Array(R::JetBSpace{T,S}) where {T,S<:HipSpace} = _blockarray(R, true)[1]
+Base.ones(R::JetBSpace{T,S}) where {T,S<:HipSpace} = ((x, o) = _blockarray(R, true); _fill!(o, one(T)); x)
+Base.rand(R::JetBSpace{T,S}; seed=1) where {T,S<:HipSpace} = ((x, o) = _blockarray(R, true); _fill_uniform!(o, seed, _next_stream()); x)
+Base.randn(R::JetBSpace{T,S}; seed=1) where {T,S<:HipSpace} = ((x, o) = _blockarray(R, true); _fill_normal!(o, seed, _next_stream()); x)
 
 # ---------------------------------------------------------------- HipArray: array interface
 Base.size(x::HipArray) = x.dims

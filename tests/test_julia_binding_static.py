@@ -381,7 +381,7 @@ def test_the_structure_checker_sees_what_it_should():
 # callable argument of the enclosing method, or one of the Base / LinearAlgebra functions listed here (each one checked by hand against
 # the Julia 1.x manual; adding a name to this list is a deliberate act).
 BASE_CALLABLES = {
-    "Cint", "Float64", "Int", "Ref", "DimensionMismatch", "IndexLinear", "any", "axes", "ccall", "cld", "delete!", "divrem", "eachindex", "eltype",
+    "Array", "Cint", "Float64", "Int", "Ref", "DimensionMismatch", "IndexLinear", "any", "axes", "ccall", "cld", "delete!", "divrem", "eachindex", "eltype",
     "error", "fill", "finalizer", "findfirst", "float", "foreach", "get", "get!", "hasproperty", "imag", "invoke", "isempty", "join", "length", "map",
     "max", "min", "ndims", "new", "one", "parse", "pop!", "prod", "push!", "range", "real", "similar", "size", "sizeof", "sqrt", "sum", "throw",
     "typeof", "unsafe_string", "unsafe_wrap", "vec", "zeros",
