@@ -66,7 +66,7 @@ def _native(eng, b, x0, damp, atol, btol, maxiter, overwrite_b, force_maxiter):
     if shard is not None and not (isinstance(shard.comm, AbiComm) or shard.comm.world == 1):
         return None
     x = eng.zeros_dom() if x0 is None else eng.copy(eng.zeros_dom(), x0)
-    u = b if overwrite_b else eng.copy(eng.zeros_rng(), b)
+    u = b if overwrite_b else (eng.copy_of_rng(b) if hasattr(eng, "copy_of_rng") else eng.copy(eng.zeros_rng(), b))
     res = LsqrResultC()
     hist = (C.c_double * builtins.max(2 * int(maxiter), 1))()
     try:

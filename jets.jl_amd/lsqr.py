@@ -74,6 +74,12 @@ class _Engine:
     def zeros_rng(self):
         return zeros(_j.range_(self.A))
 
+    def copy_of_rng(self, src):
+        """A private copy of a range vector (the solver's u when b must survive): storage without the zero fill, then the copy."""
+        from .arrays import Array
+
+        return copyto_(Array(_j.range_(self.A), undef=True), src)
+
     def copy(self, dst, src):
         return copyto_(dst, src)
 
@@ -281,7 +287,7 @@ def _native_solve(eng, b, x0, damp, atol, btol, conlim, maxiter, overwrite_b, fo
     if shard is not None and not (isinstance(shard.comm, AbiComm) or shard.comm.world == 1):
         return None
     x = eng.zeros_dom() if x0 is None else eng.copy(eng.zeros_dom(), x0)
-    u = b if overwrite_b else eng.copy(eng.zeros_rng(), b)
+    u = b if overwrite_b else (eng.copy_of_rng(b) if hasattr(eng, "copy_of_rng") else eng.copy(eng.zeros_rng(), b))
     res = LsqrResultC()
     hist = (C.c_double * builtins.max(2 * int(maxiter), 1))()
     try:
