@@ -90,6 +90,10 @@ def parse_args():
     ap.add_argument("--lsqr", type=int, default=0, help="also run this many LSQR iterations on b = A x_true (extra field, not the metric)")
     ap.add_argument("--cgnr", type=int, default=0, help="N = 1: also run this many iterations of CG on the normal equations through the fused A'A (extra field)")
     ap.add_argument("--cgls", type=int, default=0, help="N = 1: also run this many CGLS iterations on b = A x_true (extra field, not the metric)")
+    ap.add_argument("--placement", choices=("probe", "none"), default="probe",
+                    help="probe: the coefficient slab and the range vector come from Jets.stream_pair -- candidate allocations are measured (forward + "
+                         "adjoint of the operator itself, outside every timed region) and the best ordered pair is kept; none: plain allocation order")
+    ap.add_argument("--placement-candidates", type=int, default=3, help="allocations measured by --placement probe (2: both orders of two slabs)")
     ap.add_argument("--mode", choices=("auto", "ranks", "team"), default=os.environ.get("BENCH_MODE", "auto"),
                     help="N > 1: one worker process per GPU (ranks), ONE worker driving all GPUs (team), or ranks with a team fallback (auto)")
     ap.add_argument("--check", action="store_true", help="team mode: verify replicas and the adjoint after the timed region (extra field)")
@@ -582,10 +586,19 @@ def worker_ranks(args):
     # ---- operator + vectors, resident in HBM ------------------------------------------------------
     blk = J.JetSpace("float32", edge, edge, edge)
     Rloc = J.JetBSpace([blk] * nloc)
-    coeff = J.rand(Rloc, seed=1, stream=0, index_base=part.first * n)      # all diagonals of this rank: one slab
+    # Which allocation holds the coefficients and which the range vector is measured, not left to the order of two hipMallocs: on this chip
+    # a kernel that reads one 64 GiB slab and writes another runs up to 10 % apart between the two directions and between slabs, differently
+    # in every process (jets.jl_amd/placement.py, profiles/exp_r03_swap_roles.txt).  Same values either way (seeded by element index).
+    if args.placement == "probe":
+        coeff, d, placement = J.stream_pair(Rloc, candidates=args.placement_candidates)
+        J.rand_(coeff, seed=1, stream=0, index_base=part.first * n)        # all diagonals of this rank: one slab
+        J.rand_(d, seed=3, stream=0, index_base=part.first * n)
+    else:
+        coeff = J.rand(Rloc, seed=1, stream=0, index_base=part.first * n)
+        d = J.rand(Rloc, seed=3, stream=0, index_base=part.first * n)
+        placement = {"probed": False}
     A = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
     m = J.rand(J.domain(A), seed=2, stream=0)
-    d = J.rand(J.range(A), seed=3, stream=0, index_base=part.first * n)
     mt = J.zeros(J.domain(A))
     shard = J.rowpart.for_device(part, A) if dist is not None else None
     J.synchronize()
@@ -831,6 +844,7 @@ def worker_ranks(args):
                 "fwd_grid_walk": ("column-persistent (a workgroup streams every block row)" if J.tune_get("last_fwd_rows_per_wg") >= nloc
                                   else {0: "sequential row sweep", 1: "all rows concurrent"}.get(J.tune_get("last_fwd_walk"), "banded")),
                 "fwd_walk_choice": {"candidate": J.op_tune_get(A, "fwd_walk"), "setup_forward_calls": setup_forwards},
+                "placement": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in placement.items()},
                 "tune": {k: J.tune_get(k) for k in ("fwd_group", "fwd_unroll", "fwd_wg", "fwd_order", "adj_unroll", "adj_depth", "adj_wg", "nt", "autotune")},
             },
             "achieved_GBps_pair": pair_bytes_global * pairs_per_s / 1e9,
@@ -906,14 +920,22 @@ def worker_team(args):
 
     blk = J.JetSpace("float32", edge, edge, edge)
     parts = [rowpart.partition_rows(nblocks, N, k) for k in range(N)]
-    ops, coeffs, m_list, d_list = [], [], [], []
+    ops, coeffs, m_list, d_list, placements = [], [], [], [], []
     for k, _ in team.each():
         Rk = J.JetBSpace([blk] * parts[k].count)
-        coeff = J.rand(Rk, seed=1, stream=0, index_base=parts[k].first * n)
+        if args.placement == "probe":                                    # (as in worker_ranks: the better ordered pair of candidate allocations)
+            coeff, dk, pl = J.stream_pair(Rk, candidates=args.placement_candidates)
+            J.rand_(coeff, seed=1, stream=0, index_base=parts[k].first * n)
+            J.rand_(dk, seed=3, stream=0, index_base=parts[k].first * n)
+        else:
+            coeff = J.rand(Rk, seed=1, stream=0, index_base=parts[k].first * n)
+            dk = J.rand(Rk, seed=3, stream=0, index_base=parts[k].first * n)
+            pl = {"probed": False}
+        placements.append({kk: (round(v, 3) if isinstance(v, float) else v) for kk, v in pl.items() if kk != "pair_ms_other"})
         coeffs.append(coeff)
         ops.append(J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays]))
         m_list.append(J.rand(blk, seed=2, stream=0))
-        d_list.append(J.rand(Rk, seed=3, stream=0, index_base=parts[k].first * n))
+        d_list.append(dk)
     T = team.operator(ops)
     m, d = rowpart.TeamVec(m_list), rowpart.TeamVec(d_list)
     mt = team.zeros(T.domain())
@@ -1055,6 +1077,7 @@ def worker_team(args):
         "config": {"workload": f"{nblocks}x1 tall JopBlock of diagonal JopLn, {edge}^3 Float32 blocks, fwd+adj mul! pair",
                    "nblocks": nblocks, "block": [edge, edge, edge], "rows_per_gpu": nloc,
                    "parallelism": f"row-partition x{N}, single-process team: {placement}; all-reduce({n * s / 2**20:.0f} MiB, pipelined in {T.nchunks} ranges) in adjoint",
+                   "placement": placements,
                    "fwd_walk_choice": {"candidates": [J.op_tune_get(A, "fwd_walk") for A in ops], "setup_forward_calls": setup_forwards}},
         "achieved_GBps_pair": pair_bytes_global * pairs_per_s / 1e9,
         "roofline_frac_pair": pair_bytes_global * pairs_per_s / 1e9 / (HBM_PEAK_GBS * (1 if one_device else N)),

@@ -26,3 +26,4 @@ from .symmetric import SymmetricArray, symspace  # noqa: F401
 from .lsqr import lsqr, LsqrResult  # noqa: F401
 from .cgls import cgls, cgnr  # noqa: F401
 from . import rowpart  # noqa: F401
+from .placement import stream_pair, probe_stream_direction  # noqa: F401

@@ -22,7 +22,7 @@ from . import device as _device
 from .spaces import JetAbstractSpace, JetSpace, JetBSpace, JetSSpace, dtype_code
 
 __all__ = [
-    "DeviceArray", "BlockArray", "LinExpr", "zeros", "ones", "rand", "randn", "Array", "from_numpy", "space", "nblocks",
+    "DeviceArray", "BlockArray", "LinExpr", "zeros", "ones", "rand", "rand_", "randn", "Array", "from_numpy", "space", "nblocks",
     "indices", "getblock", "getblock_", "setblock_", "norm", "dot", "extrema", "fill_", "copyto_", "lincomb_",
     "hadamard_", "similar", "convert_array", "reshape", "vec", "length", "abs_", "pinned_empty", "host_register",
     "host_unregister", "download_into", "upload_from",
@@ -346,6 +346,14 @@ def rand(R: JetAbstractSpace, seed: int | None = None, stream: int | None = None
 
         return rand_sym(R, seed=seed, stream=stream, index_base=index_base)
     x = Array(R, undef=True)                               # the generator writes every element
+    if seed is None:
+        seed, stream = _DEFAULT_SEED, next(_rand_counter)
+    check(lib.jh_fill_uniform(x.handle, int(seed), int(stream or 0), int(index_base)))
+    return x
+
+
+def rand_(x: "_DevVec", seed: int | None = None, stream: int | None = None, index_base: int = 0):
+    """rand!(x): the same generator into existing storage (the values of rand(space(x), seed, stream, index_base))."""
     if seed is None:
         seed, stream = _DEFAULT_SEED, next(_rand_counter)
     check(lib.jh_fill_uniform(x.handle, int(seed), int(stream or 0), int(index_base)))
