@@ -25,7 +25,7 @@ module JetsHIP
 using Jets, LinearAlgebra
 import Jets: JetAbstractSpace, JetBSpace, JetSpace, BlockArray, BlockArrayStyle, Jop, JopLn, JopNl, JopAdjoint, Jet, jet, state,
              domain, getblock, getblock!, setblock!, indices, nblocks, space, point!, JopZeroBlock_df!, JetBlock_f!,
-             JetBlock_df!, JetBlock_df′!, JetComposite_df!, _constdiag_df!
+             JetBlock_df!, JetBlock_df′!, JetComposite_df!, _constdiag_df!, JetBlock
 
 export HipSpace, HipArray, JopHipDiagonal, JopHipSquare, JopHipDense, hip_lsqr!
 
@@ -773,6 +773,42 @@ function hip_lsqr_team!(xs::Vector{<:HipArray{T}}, As::Vector{<:JopLn}, bs::Vect
     check(ccall((:jh_lsqr_solve_team, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Ref{jh_lsqr_result}, Ptr{Cdouble}),
                 length(As), hs, Ptr{Cvoid}[handle(b) for b in bs], Ptr{Cvoid}[handle(x) for x in xs], x0 ? 1 : 0, damp, atol, btol, conlim, maxiter, 0, res, hist))
     xs, res[], reshape(hist, 2, :)[:, 1:res[].itn]
+end
+
+# Which of several equally sized device vectors should hold an operator's coefficients and which its range vector?  With the SAME two 64 GiB
+# slabs the tall forward runs 6 % apart between the two directions (reading one and writing the other), differently in every process, and over
+# three candidates the six ordered pairs span 41.9-46.3 ms per forward + adjoint (profiles/exp_r03_swap_roles.txt).  An application decides which
+# allocation holds which operand once, when it builds its data:
+#     coeff, d = JetsHIP.stream_pair(R)          # two UNINITIALISED block vectors of R::JetBSpace, ordered (read side, write side)
+# measured with the operator's own forward + adjoint over every ordered pair of `candidates` allocations (the Python mirror's Jets.stream_pair).
+function _pair_seconds(src::BlockArray{T,<:HipArray{T}}, dst::BlockArray{T,<:HipArray{T}}, calls::Integer) where {T}
+    A = JetBlock_hip_diagonals(src)
+    m = zeros(domain(A))
+    mt = zeros(domain(A))
+    mul!(dst, A, m)
+    mul!(mt, A', dst)
+    synchronize()
+    t0 = time_ns()
+    for _ = 1:calls
+        mul!(dst, A, m)
+        mul!(mt, A', dst)
+    end
+    synchronize()
+    t = (time_ns() - t0) / 1e9 / calls
+    close(A)
+    t
+end
+JetBlock_hip_diagonals(x::BlockArray{T,<:HipArray{T}}) where {T} = JopLn(JetBlock(reshape(Jop[JopHipDiagonal(x.arrays[i]) for i = 1:length(x.arrays)], length(x.arrays), 1)))
+function stream_pair(R::JetBSpace{T,<:HipSpace}; calls::Integer=3, candidates::Integer=2) where {T}
+    xs = [Array(R) for _ = 1:max(2, candidates)]
+    (length(R) * sizeof(T) < (4 << 30) || length(R.spaces) < 2) && return xs[1], xs[2]
+    best, bi, bj = Inf, 1, 2
+    for i = 1:length(xs), j = 1:length(xs)
+        i == j && continue
+        t = _pair_seconds(xs[i], xs[j], calls)
+        t < best && ((best, bi, bj) = (t, i, j))
+    end
+    xs[bi], xs[bj]                               # (the other candidates become garbage: their memory goes to the slab cache at the next GC)
 end
 
 # measured per-operator choices (the grid walk of the tall forward): read from one operator, set on another / in another process

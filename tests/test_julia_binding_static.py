@@ -384,7 +384,8 @@ BASE_CALLABLES = {
     "Array", "Cint", "Float64", "Int", "Ref", "DimensionMismatch", "IndexLinear", "any", "axes", "ccall", "cld", "delete!", "divrem", "eachindex", "eltype",
     "error", "fill", "finalizer", "findfirst", "float", "foreach", "get", "get!", "hasproperty", "imag", "invoke", "isempty", "join", "length", "map",
     "max", "min", "ndims", "new", "one", "parse", "pop!", "prod", "push!", "range", "real", "similar", "size", "sizeof", "sqrt", "sum", "throw",
-    "typeof", "unsafe_string", "unsafe_wrap", "vec", "zeros",
+    "typeof", "unsafe_string", "unsafe_wrap", "vec", "zeros", "time_ns", "reshape",
+    "mul!",                                  # LinearAlgebra.mul! (the binding says `using LinearAlgebra`; the reference extends it, src/Jets.jl:382-392)
 }
 JETS_EXPORTS = {"Jet", "JetAbstractSpace", "JetBSpace", "JetSpace", "JetSSpace", "Jop", "JopAdjoint", "JopLn", "JopNl", "JopZeroBlock", "domain",
                 "getblock", "getblock!", "dot_product_test", "indices", "jacobian", "jacobian!", "jet", "linearity_test", "linearization_test", "nblocks",
