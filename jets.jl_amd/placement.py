@@ -17,6 +17,7 @@ blocks are returned in allocation order, unprobed.  There is no counterpart in t
 from __future__ import annotations
 
 import builtins
+import os
 
 import numpy as np
 
@@ -31,17 +32,22 @@ PROBE_FROM_BYTES = 4 << 30
 
 def _pair_ms(src, dst, calls: int):
     """(forward ms, adjoint ms) per call of the tall diagonal operator over the blocks of `src` with `dst` as its range vector: the forward
-    reads src and writes dst (one block row per workgroup, all rows concurrent: the walk that wins wherever a row-concurrent walk wins), the
-    adjoint reads both.  Overwrites dst; src is only read."""
+    reads src and writes dst (one block row per workgroup, all rows concurrent), the adjoint reads both.  Overwrites dst; src is only read."""
     from . import jetblock as _blk
     from .jets import mul_, close, adjoint
 
     A = _blk.blockop([[_blk.JopDiagonal(c)] for c in src.arrays])
+    keep = {k: _dev.tune_get(k) for k in ("adj_wg", "adj_unroll", "adj_depth")}
     try:
+        # The probe runs OTHER kernel instantiations than the ones an operator of this size ends up on (forward: candidate 6 of the measured
+        # walks, 512 x 8 packs, where 7 = 256 x 1 usually wins; adjoint: 256 x 2 x 2 instead of the shape rule's pick): placement moves them all
+        # alike, and a profile of the application (rocprofv3 --stats averages per kernel name) is not diluted by the probe's launches.
         try:
-            _blk.op_tune_set(A, "fwd_walk", 7)
+            _blk.op_tune_set(A, "fwd_walk", int(os.environ.get("JETS_PROBE_WALK", "6")))
         except Exception:
             pass                                                   # (an operator too small for the measured walks: whatever it runs is the same both ways)
+        if os.environ.get("JETS_PROBE_ADJ", "alt") == "alt":
+            _dev.tune(adj_wg=256, adj_unroll=2, adj_depth=2)
         m, mt = _arr.Array(src.spaces[0]), _arr.Array(src.spaces[0])
         At = adjoint(A)
         mul_(dst, A, m)
@@ -58,6 +64,7 @@ def _pair_ms(src, dst, calls: int):
         _dev.synchronize()
         return e[0].elapsed_ms(e[1]) / calls, e[1].elapsed_ms(e[2]) / calls
     finally:
+        _dev.tune(**keep)
         close(A)
 
 
