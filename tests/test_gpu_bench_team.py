@@ -59,6 +59,8 @@ def test_eight_members_through_team_mode(tmp_path, nblocks, rows):
         assert mg["rccl_nranks"] == 8
     ck = j["check"]
     assert ck["ok"] and ck["replicas_bit_identical"] and ck["adjoint_rel_l2_vs_fp64_sum_of_partials"] <= 1e-5
+    # every member's slabs came from Jets.stream_pair (unprobed at this size: 1 GiB shards are below the probe's 4 GiB floor)
+    assert len(j["config"]["placement"]) == 8 and all(p == {"probed": False} for p in j["config"]["placement"])
     n = edge ** 3
     assert mt0.shape == (n,) and mt0.dtype == np.float32
     oracle_slices(nblocks, edge, mt0, [(0, 4096), (n // 2 - 1000, 3000), (n - 4096, 4096), (3 * n // 4 + 16384 - 7, 64)])   # incl. a range boundary of the pipeline
