@@ -3,8 +3,9 @@
 On MI355X the rate of a kernel that reads one huge vector and writes another depends on where the two lie physically, and NOT
 symmetrically: with the same two 64 GiB slabs the tall forward d_i = a_i .* m runs at 20.7-20.9 ms reading the first and writing
 the second, and at 23.4-23.5 ms the other way round -- which of the two directions is the fast one changes from process to
-process (profiles/exp_r03_swap_roles.txt, profiles/exp_r03_alloc_place.txt: a region of the device that takes writes fast from
-anywhere).  The adjoint reads both and does not care.  An application decides which allocation holds which operand only once, when
+process (profiles/exp_r03_swap_roles.txt; over three 64 GiB candidates typically ONE is slow to write into, 24.3-24.8 ms from either
+of the others, and fine to read from: profiles/exp_r03_step_placement.txt; on some boxes none is).  The adjoint reads both and varies by a
+few per cent.  An application decides which allocation holds which operand only once, when
 it builds its data, so that is where the choice belongs:
 
     coeff, d, info = Jets.stream_pair(R)      # two vectors of the block space R, UNINITIALISED, ordered (read side, write side)
