@@ -340,6 +340,235 @@ __global__ void k_fold_groups(const double *__restrict__ group_sums, int64_t nc,
     if (E == 2) m[c * E + 1] = (S)i;
 }
 
+// ---- the adjoint of MANY SMALL uniform children in ONE streaming kernel + a small fold (round 4) -----------------------------------
+// m = sum_z A_z' d_z over thousands of 128^2 ... 2048^2 children used to take three launches (k_gemv_cols_small / _batched, then
+// k_fold_children, then k_fold_groups): a wave lived for 4 KiB of matrix, every (child, column) sum went through six dependent
+// fp64 shuffles and left the kernel as a 16-byte partial, and the chip ran at 41 % of its HBM rate on 4096 x 256^2.  Here
+//   * a child's matrix is one flat stream of 16-byte packs (column c = packs [c P, (c+1) P), P = nr E / NS); a UNIT is one wave
+//     load (64 packs), a BATCH is B units = B KiB of one child = 64 B / L whole columns (L = P rounded up to a power of two; for
+//     P = L a batch is contiguous memory);
+//   * a WAVE owns one column batch of Gw consecutive children: per child it has B matrix loads in flight (plus the child's pack
+//     of d), forms each lane's exact fp64 products, and reduces the B x 64 lane sums through a padded LDS image read TRANSPOSED
+//     (lane r adds the B consecutive entries [r B, (r+1) B): two LDS instructions per unit instead of twelve shuffles), then a
+//     log2(L / B)-step butterfly; the child's column sum is rounded to the element type where the reference holds it in `mtmp`
+//     (1049) and added to the wave's fp64 running sum -- the children of a wave in order;
+//   * the four waves of a workgroup own four consecutive child quarters of one group: their sums are added in wave order through
+//     LDS and ONE fp64 partial per (group, column) leaves the kernel, stored [column][group] so that the fold (one wave per
+//     column, coalesced, fixed tree) reads it contiguously.
+// Deterministic (no atomics; the order is a function of the shape alone), tolerance parity like every dense adjoint (1e-6 / 1e-14).
+// DIRECT = the wide operator's m_j = A_j' d (1051): no sum over children, a wave owns (child, column batch) and stores the
+// rounded sums itself.  Workgroup ids are decoded XCD-aware: the workgroups of one group (they read the same d_z) share an XCD.
+template <typename S, int E, int NS, int B, int NPX>
+__global__ __launch_bounds__(256) void k_gemv_cols_fused(const jh_dev_block *__restrict__ blocks, int64_t nchild, int G, int P, int lsh, int64_t nc,
+                                                         int nb, const S *__restrict__ d, int64_t d_stride, double *__restrict__ partial,
+                                                         int64_t ngroups, S *__restrict__ out, int direct)
+{
+    typedef typename vec_of<S, NS>::type V;
+    constexpr int LB = B == 16 ? 4 : 3;                                        // log2 B
+    constexpr int ROW = 64 + 64 / B;                                           // doubles per unit in the padded image (one pad per B entries)
+    constexpr int PLANE = B * ROW;                                             // doubles per wave (and per real / imaginary plane)
+    __shared__ double scr[4 * E * PLANE];
+    __shared__ double comb[4][64][2];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int L = 1 << lsh, cpb = (B * 64) >> lsh;                             // columns per batch
+    int64_t cb, g = 0, zlo, zhi;
+    if (direct) {
+        const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+        cb = item % nb;
+        zlo = item / nb;
+        zhi = zlo + 1 < nchild ? zlo + 1 : nchild;                             // an item past the end walks no child
+    } else {
+        const int64_t ng8 = ngroups & ~(int64_t)7, bid = blockIdx.x;           // whole octets of groups: group g on XCD g mod 8 (ids 8 apart share an XCD);
+        if (bid < ng8 * nb) {                                                  // the last few groups (and operators of fewer than 8) in plain order, over all XCDs
+            const int64_t t = bid >> 3;
+            cb = t % nb;
+            g = (t / nb) * 8 + (bid & 7);
+        } else {
+            const int64_t r = bid - ng8 * nb;
+            cb = r % nb;
+            g = ng8 + r / nb;
+        }
+        const int Gw = (G + 3) >> 2;
+        zlo = g * G + (int64_t)wave * Gw;
+        zhi = zlo + Gw;
+        if (zhi > (g + 1) * G) zhi = (g + 1) * G;
+        if (zhi > nchild) zhi = nchild;
+    }
+    // what this lane loads in unit u: entry e = 64 u + lane of the batch = pack (e mod L) of column (e / L); the same for every child
+    uint32_t off[B];
+    uint32_t livemask = 0;
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+        const int e = u * 64 + lane, pe = e & (L - 1);
+        const int64_t c = cb * cpb + (e >> lsh);
+        const bool live = pe < P && c < nc;
+        off[u] = live ? (uint32_t)((c * P + pe) * NS) : 0u;                    // a dead lane re-reads the first pack (branch-free load section)
+        livemask |= (live ? 1u : 0u) << u;
+    }
+    uint32_t xo[NPX];
+#pragma unroll
+    for (int i = 0; i < NPX; i++) {
+        const int pe = (i * 64 + lane) & (L - 1);
+        xo[i] = pe < P ? (uint32_t)(pe * NS) : 0u;
+    }
+    double *img = scr + wave * (E * PLANE);
+    const int wr = lane + (lane >> LB);                                        // this lane's slot in a unit's row of the image
+    const int rd = lane * (B + 1);                                             // first of the B consecutive entries this lane adds
+    const int lp = lsh - LB;                                                   // log2 (lanes holding one column's run sums)
+    double accr = 0.0, acci = 0.0;
+    for (int64_t z = zlo; z < zhi; z++) {
+        const S *Az = (const S *)blocks[z].coeff;
+        const S *xz = d + z * d_stride;
+        V a[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) a[u] = __builtin_nontemporal_load(reinterpret_cast<const V *>(Az + off[u]));
+        V xv[NPX];
+#pragma unroll
+        for (int i = 0; i < NPX; i++) xv[i] = *reinterpret_cast<const V *>(xz + xo[i]);
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            const V x = xv[u % NPX];                                           // unit u holds piece u mod (L / 64) of its column
+            double pr = 0.0, pi = 0.0;
+            if constexpr (E == 1) {
+#pragma unroll
+                for (int e = 0; e < NS; e++) {
+                    if constexpr (NS == 1) pr += (double)a[u] * (double)x;
+                    else if constexpr (sizeof(S) == 4) pr = __builtin_fma((double)a[u][e], (double)x[e], pr);   // the product of two floats is exact in fp64: the same value as multiply-then-add
+                    else pr += (double)a[u][e] * (double)x[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NS; e += 2) {                               // conj(a) * x
+                    const double ar = a[u][e], ai = -(double)a[u][e + 1], xr = x[e], xi = x[e + 1];
+                    pr += ar * xr - ai * xi;
+                    pi += ar * xi + ai * xr;
+                }
+            }
+            if (!((livemask >> u) & 1u)) { pr = 0.0; pi = 0.0; }
+            img[u * ROW + wr] = pr;
+            if constexpr (E == 2) img[PLANE + u * ROW + wr] = pi;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                 // the image is this wave's own: LDS operations of one wave complete in order
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double rr = 0.0, ri = 0.0;
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            rr += img[rd + k];
+            if constexpr (E == 2) ri += img[PLANE + rd + k];
+        }
+        for (int s = 0; s < lp; s++) {                                          // the L / B lanes of one column: fixed butterfly
+            rr += __shfl_xor(rr, 1 << s, 64);
+            if constexpr (E == 2) ri += __shfl_xor(ri, 1 << s, 64);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                 // the next child's stores come after these reads
+        __builtin_amdgcn_wave_barrier();
+        if (direct) {
+            const int64_t c = cb * cpb + (lane >> lp);
+            if ((lane & ((1 << lp) - 1)) == 0 && c < nc) {
+                out[(z * nc + c) * E] = (S)rr;
+                if constexpr (E == 2) out[(z * nc + c) * E + 1] = (S)ri;
+            }
+        } else {
+            accr += (double)(S)rr;                                             // mtmp is an array of the element type (1049)
+            if constexpr (E == 2) acci += (double)(S)ri;
+        }
+    }
+    if (direct) return;
+    if ((lane & ((1 << lp) - 1)) == 0) {
+        comb[wave][lane >> lp][0] = accr;
+        comb[wave][lane >> lp][1] = acci;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < cpb) {
+        const int64_t c = cb * cpb + lane;
+        if (c < nc) {
+            double r = comb[0][lane][0], i = comb[0][lane][1];
+#pragma unroll
+            for (int w = 1; w < 4; w++) { r += comb[w][lane][0]; i += comb[w][lane][1]; }
+            double *p = partial + (c * ngroups + g) * E;
+            p[0] = r;
+            if constexpr (E == 2) p[1] = i;
+        }
+    }
+}
+
+// m[c] = sum over the groups (fixed order: 64 interleaved lane sums, then the wave's butterfly) of partial[c][g]; one wave per column
+template <typename S, int E>
+__global__ __launch_bounds__(256) void k_fold_fused(const double *__restrict__ partial, int64_t nc, int64_t ngroups, S *__restrict__ m)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= nc) return;
+    const double *p = partial + c * ngroups * E;
+    double r = 0.0, i = 0.0;
+    for (int64_t g = lane; g < ngroups; g += 64) {
+        r += p[g * E];
+        if constexpr (E == 2) i += p[g * E + 1];
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        r += __shfl_xor(r, s, 64);
+        if constexpr (E == 2) i += __shfl_xor(i, s, 64);
+    }
+    if (lane == 0) {
+        m[c * E] = (S)r;
+        if constexpr (E == 2) m[c * E + 1] = (S)i;
+    }
+}
+
+// *launched = false: not a shape for this kernel (tiny or long columns) -- the caller's older path runs.
+template <typename S, int E, int NS>
+static int launch_cols_fused(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, const S *d, int64_t d_stride, S *y, bool direct,
+                             bool *launched)
+{
+    jh_context &c = jh_ctx();
+    hipStream_t st = c.stream;
+    *launched = false;
+    constexpr int B = E == 2 ? 8 : 16;
+    if ((nr * E) % NS != 0) return JH_OK;
+    const int64_t P = nr * E / NS;
+    // columns of B .. 256 packs (Float32: 64 .. 1024 rows).  Longer columns stream as well on the wave-per-column kernels (measured,
+    // profiles/bench_dense_blocks_r04.txt: 2048^2 and 4096^2 children 5.5 against 6.6 TB/s), shorter ones are left to k_gemv_cols_small
+    if (P < B || P > 256 || nc < 1 || nchild < 1) return JH_OK;
+    if ((double)nr * (double)nc * E * sizeof(S) >= 2147483648.0) return JH_OK;   // 32-bit offsets inside a child
+    int lsh = 0;
+    while ((1 << lsh) < P) lsh++;
+    const int64_t L = (int64_t)1 << lsh, cpb = (B * 64) / L, nb = (nc + cpb - 1) / cpb;
+    if (nb > (1 << 30)) return JH_OK;
+    const int npx = L <= 64 ? 1 : (int)(L / 64);                               // packs of d_z a lane keeps per child: 1, 2 or 4
+    // children per wave: enough waves to fill the chip several times over, short-lived (workgroups that move one batch and exit
+    // stream best on this chip), but not so many groups that the fold matters
+    int64_t gw = c.dense_gw > 0 ? c.dense_gw : nchild / 1024;                  // about 256 groups (measured: profiles/bench_dense_blocks_r04.txt)
+    if (gw < 1) gw = 1;
+    if (gw * 4 > nchild) gw = (nchild + 3) / 4;
+    int64_t G = direct ? 1 : gw * 4, ngroups = direct ? 0 : (nchild + G - 1) / G;
+    int64_t wgs;
+    if (direct) wgs = (nchild * nb + 3) / 4;
+    else {
+        JH_TRY(jh_ensure_partials(nc * ngroups * E + 2));
+        wgs = ngroups * nb;
+    }
+    if (wgs > 2000000000ll) return JH_OK;
+#define JH_FUSED(NPXV)                                                                                                                              \
+    hipLaunchKernelGGL((k_gemv_cols_fused<S, E, NS, B, NPXV>), dim3((unsigned)wgs), dim3(256), 0, st, dev_blocks, nchild, (int)G, (int)P, lsh, nc, \
+                       (int)nb, d, d_stride, c.part_dev, ngroups, y, direct ? 1 : 0)
+    switch (npx) {
+    case 1: JH_FUSED(1); break;
+    case 2: JH_FUSED(2); break;
+    default: JH_FUSED(4); break;
+    }
+#undef JH_FUSED
+    JH_CHECK_HIP(hipGetLastError());
+    if (!direct) {
+        hipLaunchKernelGGL((k_fold_fused<S, E>), dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, st, c.part_dev, nc, ngroups, y);
+        JH_CHECK_HIP(hipGetLastError());
+    }
+    *launched = true;
+    return JH_OK;
+}
+
 // ---- WIDE operator (one block row of K dense children): d (+)= sum_j A_j m_j and m_j = A_j' d -----------------------------
 // forward fold, few children: the reference's order and rounding -- `_d .+= mul!(dtmp, A_j, m_j)` (1024): dtmp_j is the ordered
 // sum of its column chunks in the element type, added to d as found, j in order
@@ -458,6 +687,13 @@ int gemv_batched_wide(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr
         return JH_OK;
     }
     // m_j = A_j' d for every child
+    c.last_dense_fused = 0;
+    if (c.dense_fused) {
+        bool launched = false;
+        if (vec_ok) JH_TRY((launch_cols_fused<S, E, NSV>(dev_blocks, nchild, nr, nc, (const S *)x, 0, (S *)y, true, &launched)));
+        else JH_TRY((launch_cols_fused<S, E, E>(dev_blocks, nchild, nr, nc, (const S *)x, 0, (S *)y, true, &launched)));
+        if (launched) { c.last_dense_fused = 1; return JH_OK; }
+    }
     const int64_t col_wgs = (nc + 3) / 4;
     int64_t nchunks = 1;
     if (child_bytes >= (double)(1 << 20) && col_wgs * nchild < 2048) {
@@ -535,6 +771,13 @@ int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int
         return JH_OK;
     }
     // m = sum_z A_z' d_z  (the caller's m is overwritten: `_m .= 0` then `_m .+= mtmp`, 1042-1049)
+    c.last_dense_fused = 0;
+    if (!row_off && c.dense_fused) {                                            // many small children: one streaming kernel + a fold (round 4)
+        bool launched = false;
+        if (vec_ok) JH_TRY((launch_cols_fused<S, E, NSV>(dev_blocks, nchild, nr, nc, (const S *)x, ns, (S *)y, false, &launched)));
+        else JH_TRY((launch_cols_fused<S, E, E>(dev_blocks, nchild, nr, nc, (const S *)x, ns, (S *)y, false, &launched)));
+        if (launched) { c.last_dense_fused = 1; return JH_OK; }
+    }
     const int64_t col_wgs = (nc + 3) / 4;
     int64_t nchunks = 1;
     if (child_bytes >= (double)(1 << 20) && col_wgs * nchild < 2048) {

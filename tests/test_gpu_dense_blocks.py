@@ -305,3 +305,75 @@ def test_big_dense_children_in_mixed_company(Jets, oracle, dt, shape):
         lo = col_len[0] + col_len[1]
         assert_bits_equal(got[1][1][lo:lo + col_len[2]], hmt[2], "the zero block's column keeps m as found (1047 / 1051)")
     J.close(A)
+
+
+# ---- round 4: the fused adjoint kernel (k_gemv_cols_fused) -----------------------------------------------------------------------
+# shapes chosen for its cases: columns of P 16-byte packs with P a power of two (a batch is contiguous) and not (dead lanes), columns
+# shorter than a wave load (several columns per unit), exactly one, and 2 / 4 / 8 / 16 wave loads long (the NPX instantiations and
+# the per-unit pack of d), row counts that are not whole packs (the one-element-per-lane instantiation), column counts that leave
+# the last batch ragged, child counts that leave the last group and the last wave quarter ragged
+FUSED_SHAPES = [(37, 100, 33), (9, 256, 40), (130, 128, 128), (5, 512, 24), (3, 1024, 10), (3, 2048, 6), (2, 4096, 5), (1030, 64, 64),
+                (11, 66, 19), (6, 257, 9), (65, 96, 50), (2, 256, 256), (4, 300, 7)]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nchild,nr,nc", FUSED_SHAPES)
+def test_fused_adjoint_of_many_small_dense_children(Jets, oracle, dt, nchild, nr, nc):
+    """m = sum_z B_z' d_z (src/Jets.jl:1045-1053 with JopBaz children, test/runtests.jl:27-33, 733) on the one-kernel route: within
+    1e-6 / 1e-14 of an 80-bit host sum, the same bits on a second run (no atomics), and within tolerance of the three-launch route
+    it replaces; `last_dense_fused` says which route ran."""
+    A, ora, mats = _tall_dense(Jets, oracle, dt, nchild, nr, nc, seed=910)
+    dd = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    hd = u01(oracle, dt, SEED_D, 0, nchild * nr).reshape(nchild, nr)
+    mt = Jets.rand(Jets.domain(A), seed=6, stream=6)                              # dirty: zeroed first (1042)
+    Jets.mul_(mt, A.H, dd)
+    item = np.dtype(dt).itemsize
+    packs = nr * item / 16 if (nr * item) % 16 == 0 else nr                       # whole 16-byte packs per column, else one element per lane
+    bsz = 8 if np.iscomplexobj(mats[0]) else 16                                   # units per batch; columns of bsz .. 256 packs
+    expect_fused = bsz <= packs <= 256
+    assert Jets.tune_get("last_dense_fused") == (1 if expect_fused else 0)
+    wide = np.clongdouble if np.iscomplexobj(mats[0]) else np.longdouble
+    truth = sum(np.conj(mats[z].astype(wide)).T @ hd[z].astype(wide) for z in range(nchild))
+    assert _err(mt.to_numpy().ravel(order="F"), truth) < _tol(dt)
+    again = Jets.rand(Jets.domain(A), seed=7, stream=7)
+    Jets.mul_(again, A.H, dd)
+    assert_bits_equal(again.to_numpy(), mt.to_numpy(), "fused dense adjoint, second run")
+    for gw in (1, 3):                                                             # other groupings: other fp64 orders of the same rounded child sums
+        Jets.tune(dense_gw=gw)
+        try:
+            Jets.mul_(again, A.H, dd)
+        finally:
+            Jets.tune(dense_gw=0)
+        assert _err(again.to_numpy().ravel(order="F"), truth) < _tol(dt)
+    Jets.tune(dense_fused=0)
+    try:
+        old = Jets.zeros(Jets.domain(A))
+        Jets.mul_(old, A.H, dd)
+        assert Jets.tune_get("last_dense_fused") == 0
+    finally:
+        Jets.tune(dense_fused=1)
+    assert _err(old.to_numpy().ravel(order="F"), truth) < _tol(dt)
+    assert _err(mt.to_numpy(), old.to_numpy()) < 2 * _tol(dt)
+    m = Jets.rand(Jets.domain(A), seed=SEED_M, stream=0)
+    lhs, rhs = Jets.dot_product_test(A, m, dd)
+    assert abs(lhs - rhs) / abs(lhs + rhs) < (1e-5 if _tol(dt) > 1e-10 else 1e-12)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nchild,nr,nc", [(37, 100, 33), (9, 256, 40), (5, 512, 24), (3, 2048, 6), (70, 64, 64), (11, 66, 19)])
+def test_fused_adjoint_of_a_wide_operator_of_dense_children(Jets, oracle, dt, nchild, nr, nc):
+    """m_j = B_j' d (src/Jets.jl:1051: written directly, test/runtests.jl:752-757) on the same kernel in its DIRECT form."""
+    A, ora, mats = _wide_dense(Jets, oracle, dt, nchild, nr, nc, seed=960)
+    dd = Jets.rand(Jets.range(A), seed=SEED_D, stream=0)
+    hd = u01(oracle, dt, SEED_D, 0, nr)
+    mt = Jets.rand(Jets.domain(A), seed=6, stream=6)                              # dirty: overwritten (1051)
+    Jets.mul_(mt, A.H, dd)
+    item = np.dtype(dt).itemsize
+    packs = nr * item / 16 if (nr * item) % 16 == 0 else nr
+    bsz = 8 if np.iscomplexobj(mats[0]) else 16
+    assert Jets.tune_get("last_dense_fused") == (1 if bsz <= packs <= 256 else 0)
+    wide = np.clongdouble if np.iscomplexobj(mats[0]) else np.longdouble
+    truth = np.concatenate([np.conj(mats[z].astype(wide)).T @ hd.astype(wide) for z in range(nchild)])
+    assert _err(mt.to_numpy(), truth) < _tol(dt)
+    ref = oracle.block_df_adj(ora, [np.zeros(nc, dtype=dt) for _ in range(nchild)], [hd])
+    assert _err(mt.to_numpy(), np.concatenate(ref)) < 2 * _tol(dt)

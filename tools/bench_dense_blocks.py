@@ -12,6 +12,8 @@ import jets_jl_amd as J
 J.init(0)
 total = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024) << 20
 WIDE = len(sys.argv) > 2 and sys.argv[2] == "wide"
+GWS = [int(a[3:]) for a in sys.argv[2:] if a.startswith("gw=")]          # sweep of the fused adjoint's children-per-wave knob
+OLD = "old" in sys.argv[2:]                                              # the three-launch adjoint of rounds 1-3 beside the fused kernel
 
 
 def timed(fn, reps=5):
@@ -36,6 +38,17 @@ for k in (8192, 4096, 2048, 1024, 512, 256, 128):
     tf = timed(lambda: J.mul_(d, A, m))
     ta = timed(lambda: J.mul_(mt, A.H, d))
     nbytes = nrow * k * k * 4
+    fused = J.tune_get('last_dense_fused')
+    extra = ""
+    for gw in GWS:
+        J.tune(dense_gw=gw)
+        extra += f" gw={gw}: {timed(lambda: J.mul_(mt, A.H, d)):.3f}"
+    J.tune(dense_gw=0)
+    if OLD:
+        J.tune(dense_fused=0)
+        t_old = timed(lambda: J.mul_(mt, A.H, d))
+        J.tune(dense_fused=1)
+        extra += f" | three-launch adj {t_old:8.3f} ms {nbytes / t_old / 1e6:6.0f} GB/s"
     print(f"{nrow:6d} children of {k:5d}^2: fwd {tf:8.3f} ms {nbytes / tf / 1e6:6.0f} GB/s | adj {ta:8.3f} ms {nbytes / ta / 1e6:6.0f} GB/s   "
-          f"(graph replays so far {J.tune_get('graph_replays')})", flush=True)
+          f"(fused {fused}){extra}", flush=True)
     del A, mats, m, d, mt
