@@ -154,21 +154,25 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__res
                 st<NT>(reinterpret_cast<V *>(di + s0 + (int64_t)k * BLK * NS), vmul<S, E, NS, V>(av[k], mv[k], false));
         }
     } else {
+        // the last tile of a row: a pack past the end re-reads pack 0 and stores nothing (every mv[k] is defined on every lane:
+        // conditionally loaded ones made the compiler keep the tile in scratch, 400 bytes per lane at 8 packs x 1024 threads --
+        // tools/kernel_resources.py; tests/test_kernel_resources.py keeps every kernel of the library at 0 bytes of scratch)
         bool ok[U];
+        int64_t sk[U];
 #pragma unroll
         for (int k = 0; k < U; k++) {
             ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
-            if (ok[k]) mv[k] = ld<false>(reinterpret_cast<const V *>(m + s0 + (int64_t)k * BLK * NS));
+            sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
+            mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
         }
         for (int64_t i = i0; i < i1; i++) {
             const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
             S *di = d + i * n_scalars;
 #pragma unroll
-            for (int k = 0; k < U; k++)
-                if (ok[k]) {
-                    V av = ld<NT>(reinterpret_cast<const V *>(a + s0 + (int64_t)k * BLK * NS));
-                    st<NT>(reinterpret_cast<V *>(di + s0 + (int64_t)k * BLK * NS), vmul<S, E, NS, V>(av, mv[k], false));
-                }
+            for (int k = 0; k < U; k++) {
+                const V av = ld<NT>(reinterpret_cast<const V *>(a + sk[k]));
+                if (ok[k]) st<NT>(reinterpret_cast<V *>(di + sk[k]), vmul<S, E, NS, V>(av, mv[k], false));
+            }
         }
     }
 }
@@ -1713,6 +1717,9 @@ TallShape pick_adj_shape(int64_t nvec, int64_t nrow, int mode)
     if (c.adj_unroll) s.unroll = (int)c.adj_unroll;
     if (c.adj_depth) s.aux = (int)c.adj_depth;
     if (s.unroll == 4 && s.aux == 8) s.aux = 4;        // 4 x 8 is not instantiated (register budget)
+    // a 1024-thread workgroup has 128 VGPRs per lane: the two-stream adjoint keeps at most 8 packs per stream in flight there
+    // (2 x 8 and 4 x 4 spilled 108-176 bytes per lane to scratch; same bits with fewer rows in flight)
+    if (mode == 0 && s.wg == 1024 && s.unroll * s.aux > 8) s.aux = 8 / s.unroll;
     return s;
 }
 
@@ -1817,6 +1824,7 @@ int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n
     }
     c.last_adj_parts = parts;
 #define JH_ADJ_CASE(U, DEPTH)                                                                                          \
+    if constexpr (!(BLK == 1024 && MODE == 0 && U * DEPTH > 8))                                                        \
     if (sh.unroll == U && sh.aux == DEPTH) {                                                                           \
         int64_t gx = (s_end - s_begin + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                          \
         for (int64_t r0 = 0; r0 < op->nrow; r0 += rows_per_launch) {                                                   \
@@ -2154,7 +2162,11 @@ int launch_tall_adj_mixed(const jh_blockop *op, void *out, const void *in, int64
     if (s_end <= s_begin) return JH_OK;
     // the fused normal operator reads ONE stream: fat workgroups with more rows in flight once the blocks are big (like the
     // all-DIAG shapes of pick_adj_shape); everything else 512 x 2 x 2
-    if (MODE == 1 && n_scalars / NS >= ((int64_t)1 << 22)) return launch_tall_adj_mixed_u<S, E, NS, MODE, 1024, 4, 4>(op, out, in, n_scalars, s_begin, s_end);
+    // (ComplexF32 with its per-row kind switch: two rows in flight, four spilled 20 bytes per lane)
+    if constexpr (MODE == 1) {
+        constexpr int DEPTH = (E == 2 && sizeof(S) == 4) ? 2 : 4;
+        if (n_scalars / NS >= ((int64_t)1 << 22)) return launch_tall_adj_mixed_u<S, E, NS, MODE, 1024, 4, DEPTH>(op, out, in, n_scalars, s_begin, s_end);
+    }
     return launch_tall_adj_mixed_u<S, E, NS, MODE, 512, 2, 2>(op, out, in, n_scalars, s_begin, s_end);
 }
 
@@ -2433,8 +2445,8 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     // profiles/sweep_r01_update_1024x256.txt: 256 threads x 4 vectors x 4 rows, 5.50 TB/s (1024 x 8 x 16: 5.29)
     if (nvec >= ((int64_t)1 << 21)) { wg = 256; U = 4; G = 4; }
     else { wg = 256; U = 4; G = 8; }
-    if (c.fwd_wg == 1024 && c.fwd_unroll == 8) { wg = 1024; U = 8; }          // knob overrides (3 instantiated tilings)
-    else if (c.fwd_wg == 256 && c.fwd_unroll == 4) { wg = 256; U = 4; }
+    // knob overrides (2 instantiated tilings; round 1's 1024 x 8 -- 5.29 TB/s against 5.50 -- spilled to scratch and is gone)
+    if (c.fwd_wg == 256 && c.fwd_unroll == 4) { wg = 256; U = 4; }
     else if (c.fwd_wg == 256 && c.fwd_unroll == 1) { wg = 256; U = 1; }
     if (c.fwd_group) G = (int)c.fwd_group;
     // Grid walk: like the plain forward (autotune_fwd_walk) the row-concurrent walk wins in some processes and loses in
@@ -2473,7 +2485,6 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
         hipLaunchKernelGGL((k_tall_diag_fwd_update<S, E, NS, 4, 256, true>), dim3((unsigned)(gx * gy)), dim3(256), 0, c.stream, op->dev_blocks,
                            op->nrow, G, a_base, a_stride, (const S *)m, (S *)d, n_scalars, (unsigned)gx, (unsigned)gy, walk, (S)alpha, (S)beta,
                            c.part_dev);
-    else if (wg == 1024) JH_LAUNCH(1024, 8);
     else if (U == 4) JH_LAUNCH(256, 4);
     else JH_LAUNCH(256, 1);
 #undef JH_LAUNCH
@@ -2568,6 +2579,7 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
             if (nvec >= ((int64_t)1 << 22)) { wg = 512; U = 1; D = 4; }
         }
     }
+    if (E == 2 && sizeof(S) == 4 && wg == 1024 && U == 4 && D == 1) { U = 2; D = 2; }   // ComplexF32 at 128 VGPRs per lane: 4 x 1 spilled 20 bytes to scratch
     const int64_t gx = ((s_end - s_begin) / NS + (int64_t)wg * U - 1) / ((int64_t)wg * U);
     // many rows of small blocks: split-row walk (pick_adj_parts): u's rows are updated as before, w's sum is folded from slabs
     int64_t parts = direct ? 1 : pick_adj_parts(gx, op->nrow);
@@ -2671,6 +2683,7 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     c.last_step_chain = 0;
 #define JH_LAUNCH(BLK, UU, DD) JH_LAUNCH_M(BLK, UU, DD, false)
 #define JH_LAUNCH_M(BLK, UU, DD, MIX)                                                                                   \
+    if constexpr (!(E == 2 && sizeof(S) == 4 && BLK == 1024 && UU == 4 && DD == 1))                                      \
     if (wg == BLK && U == UU && D == DD && mixed == MIX) {                                                              \
         double total = 0.0;                                                                                              \
         const bool several = rows_per_launch < op->nrow && normsq != nullptr;   /* one read-back for all the launches */     \

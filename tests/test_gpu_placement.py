@@ -39,7 +39,7 @@ def test_the_probe_measures_every_ordered_pair_and_keeps_two_vectors(Jets, oracl
     assert info["probed"] and info["candidates"] == candidates
     assert len(info["pair_ms_other"]) == candidates * (candidates - 1) - 1
     assert info["pair_ms_kept"] == pytest.approx(info["fwd_ms_kept"] + info["adj_ms_kept"])
-    assert info["pair_ms_kept"] <= min(info["pair_ms_other"]) + 1e-9
+    assert info["pair_ms_kept"] <= min(info["pair_ms_other"]) + 0.5e-3        # (the others are reported rounded to a microsecond)
     assert x.ptr != y.ptr
     assert J.tune_get("slab_cached_mib") == (candidates - 2) * 32       # the candidates that were not kept went back (to the slab cache)
     # the two vectors are ordinary vectors: the operator built on them gives the oracle's bits

@@ -1,0 +1,46 @@
+"""CPU check of the BUILT library: no kernel of libjetship.so may spill registers to scratch memory.
+
+A streaming kernel that keeps part of its tile in scratch streams its own spills as well; round 3 shipped 32 such instantiations
+(all 1024-thread workgroups at the 128-VGPR cap, one of them a default forward-walk candidate of every large operator).  The
+code objects inside the shared library carry per-kernel metadata (`.private_segment_fixed_size`, the bytes of scratch per lane);
+tools/kernel_resources.py reads it without a GPU and without LLVM tools.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_resources  # noqa: E402
+
+LIB = os.path.join(ROOT, "jets.jl_amd", "libjetship.so")
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not os.path.exists(LIB):
+        pytest.fail("libjetship.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    return kernel_resources.kernels(LIB)
+
+
+def test_every_hot_kernel_family_is_in_the_library(kernels):
+    names = " ".join(k["name"] for k in kernels)
+    for family in ("k_tall_diag_fwd", "k_tall_diag_adj", "k_tall_diag_bidiag", "k_tall_diag_bidiag_chain", "k_tall_sum_fwd", "k_grid_tile",
+                   "k_general_tile", "k_block_fwd_general", "k_reduce", "k_lincomb", "k_uniform", "k_gemv_rows_batched", "k_gemv_cols_fused"):
+        assert family in names, f"no instantiation of {family} in {LIB}"
+    assert len(kernels) > 500
+
+
+def test_no_kernel_spills_to_scratch(kernels):
+    bad = [k for k in kernels if k["scratch"] > 0]
+    lines = [f"{k['scratch']} B/lane, {k['vgpr']} VGPRs, workgroup {k['max_wg']}: {n}" for k, n in zip(bad, kernel_resources.demangle([k["name"] for k in bad]))]
+    assert not bad, "kernels with scratch (register spills or stack arrays):\n" + "\n".join(lines)
+
+
+def test_registers_fit_the_declared_workgroup(kernels):
+    """512 VGPRs per lane and SIMD: a W-thread workgroup has W / 256 waves per SIMD, so at most 512 / (W / 256) registers per lane
+    (128 at 1024 threads).  The compiler enforces it through __launch_bounds__; a kernel AT the cap is where spills start, so the
+    count of those is reported to keep an eye on."""
+    over = [k for k in kernels if k["max_wg"] >= 256 and k["vgpr"] + k["agpr"] > 512 // (k["max_wg"] // 256)]
+    assert not over, [k["name"] for k in over]
