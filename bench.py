@@ -993,6 +993,26 @@ def worker_team(args):
     elapsed = time.perf_counter() - t0
     beat("timed-region-done")
 
+    # outside the timed region: what ONE pair costs this host thread to enqueue (no synchronisation inside the bracket).  All N
+    # members' launches come from here, so this must stay well below the pair's device time (projected 5.7 ms at 8 GPUs) --
+    # with the member loop behind one ABI call per operator application (jh_team_mul / jh_team_mul_adj), and, for comparison,
+    # spelled out call by call from Python as rounds 2-3 did
+    def enqueue_ms():
+        samples = []
+        for _ in range(7):
+            team.synchronize()
+            t_e = time.perf_counter()
+            forward()
+            adjoint()
+            samples.append(1e3 * (time.perf_counter() - t_e))
+        team.synchronize()
+        return sorted(samples)[len(samples) // 2]
+
+    host_enqueue = {"host_enqueue_ms_per_pair": enqueue_ms(), "one_abi_call_per_application": bool(T.one_call)}
+    if T.one_call:
+        T.one_call = False
+        host_enqueue["host_enqueue_ms_per_pair_call_by_call"] = enqueue_ms()
+        T.one_call = True
     s = 4
     per = []
     reps = max(3, min(args.steps, 10))
@@ -1021,7 +1041,7 @@ def worker_team(args):
     ar_ms = max(e0[k].elapsed_ms(e1[k]) for k in range(N)) / reps
     ar_bytes = n * s
     multi = {"backend": "device-side sum kernel (one device)" if one_device else "rccl (ncclCommInitAll, single process)",
-             "rccl_nranks": None if one_device else N, "placement": placement, "per_rank": per,
+             "rccl_nranks": None if one_device else N, "placement": placement, "per_rank": per, **host_enqueue,
              "allreduce": {"bytes": ar_bytes, "chunks_in_adjoint": T.nchunks, "ms_standalone": ar_ms,
                            "busbw_GBps": (2.0 * (N - 1) / N) * ar_bytes / ar_ms / 1e6 if N > 1 and ar_ms > 0 and not one_device else None,
                            "exposed_ms_max": max(r["exposed_exchange_ms"] for r in per)}}

@@ -390,6 +390,16 @@ int jh_comm_allreduce_scalars(double *values, int n, int op);   /* op: 0 sum, 1 
 int jh_comm_allreduce_sum_range(jh_bvec *v, int64_t first_elem, int64_t count);
 int jh_comm_join(void);
 int jh_comm_allreduce_normsq(double *out);
+/* A team's operator applications behind ONE call each (round 4): member k's context holds ops[k] (its block rows), its shard of the
+ * range vector and its replica of the domain vector.  jh_team_mul: d_k = A_k m_k on every member (src/Jets.jl:1015-1031: block rows
+ * are independent -- no exchange).  jh_team_mul_adj: every member's m_k = the sum over ALL members' rows of A_i' d_i (1045-1053):
+ * the members' ordered local sums in `nranges` element ranges (jh_blockop_mul_adj_range), the grouped all-reduce of a finished range
+ * running under the next range's kernels, the library streams waiting for the exchange by event.  jh_team_normal_mul: the fused
+ * A'A (530-534 over (A', A)) exchanged the same way (jh_blockop_normal_mul_range).  All three return after enqueue, without a host
+ * synchronisation.  They do what a host language would otherwise spell as about 9 ABI calls per member and pair. */
+int jh_team_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ds, const jh_bvec *const *ms);
+int jh_team_mul_adj(int n, const jh_blockop *const *ops, jh_bvec *const *ms, const jh_bvec *const *ds, int nranges);
+int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, const jh_bvec *const *ms, int nranges);
 
 /* kernel-shape tuning knobs (bench/tests only): 0 = automatic (fwd_order: -1); name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg","fwd_order","nt","autotune" (0: tall forwards keep the size-based default shape; 1: per-operator lazy measurement, see jh_blockop_tune_get),
  * "graphs" (1: operators that run the per-block loop -- those with DENSE blocks -- replay it as a hipGraph from the

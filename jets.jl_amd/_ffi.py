@@ -142,6 +142,9 @@ SYMBOLS = {
     "jh_cgnr_solve": (_int, [_vp, _vp, _vp, _int, C.c_double, C.c_double, C.c_double, _int, _int, C.POINTER(LsqrResultC), _dblp]),
     "jh_cgnr_solve_partitioned": (_int, [_vp, _vp, _vp, _int, C.c_double, C.c_double, C.c_double, _int, _int, C.POINTER(LsqrResultC), _dblp]),
     "jh_cgnr_solve_team": (_int, [_int, _vpp, _vpp, _vpp, _int, C.c_double, C.c_double, C.c_double, _int, _int, C.POINTER(LsqrResultC), _dblp]),
+    "jh_team_mul": (_int, [_int, _vpp, _vpp, _vpp]),
+    "jh_team_mul_adj": (_int, [_int, _vpp, _vpp, _vpp, _int]),
+    "jh_team_normal_mul": (_int, [_int, _vpp, _vpp, _vpp, _int]),
     "jh_comm_available": (_int, []),
     "jh_comm_unique_id": (_int, [_vp]),
     "jh_comm_init_rank": (_int, [_vp, _int, _int]),

@@ -483,3 +483,75 @@ int jh_comm_allreduce_scalars(double *values, int n, int op)
 }
 
 }  // extern "C"
+
+// ---- a TEAM's forward / adjoint / normal operator behind ONE call each (round 4) -------------------------------------------------------
+// The exchange step of the row partition (src/Jets.jl:1045-1053 summed over the members' rows) is issued range by range: every
+// member's kernel for a range, then the members' all-reduces of that range in one group, while the next range's kernels compute.
+// Driven from the host language that is 4 x (n context switches + n kernel calls + group begin + n all-reduces + group end) + n
+// joins -- about 75 ABI calls per forward + adjoint pair at 8 members, each through the binding's dispatch.  Here the member loop
+// runs in C: one call per operator application, whatever the host language costs per call.
+static int team_check(const char *who, int n, const jh_blockop *const *ops, const void *const *a, const void *const *b)
+{
+    JH_REQUIRE(n >= 1 && n <= JH_MAX_CTX && ops && a && b, "%s: need 1..%d members", who, JH_MAX_CTX);
+    for (int k = 0; k < n; k++) JH_REQUIRE(ops[k] && a[k] && b[k], "%s: null handle of member %d", who, k);
+    return JH_OK;
+}
+
+static int team_ranged(const char *who, int n, const jh_blockop *const *ops, jh_bvec *const *outs, const jh_bvec *const *ins, int nranges, bool normal)
+{
+    JH_TRY(team_check(who, n, ops, (const void *const *)outs, (const void *const *)ins));
+    JH_REQUIRE(nranges >= 1 && nranges <= 64, "%s: 1..64 exchange ranges", who);
+    for (int k = 0; k < n; k++) {                                          // every member in its own context of ONE team, before anything is enqueued
+        JH_TRY(jh_enter(ops[k], outs[k], ins[k]));
+        comm_state &s = cs();
+        JH_REQUIRE(s.alive && s.team && s.nranks == n && s.rank == k, "%s: the handles of member %d must live in member %d's context of a team of %d (jh_comm_init_all)",
+                   who, k, k, n);
+        JH_REQUIRE(outs[k]->length == outs[0]->length && outs[k]->dtype == outs[0]->dtype, "%s: member %d's domain vector differs in length or element type", who, k);
+    }
+    const int64_t len = outs[0]->length;
+    int64_t step = (len + nranges - 1) / nranges;
+    step = (step + 16383) / 16384 * 16384;                                 // range bounds on 64 KiB boundaries (as the solvers' exchange)
+    for (int64_t lo = 0; lo < len; lo += step) {
+        const int64_t cnt = lo + step < len ? step : len - lo;
+        for (int k = 0; k < n; k++)
+            JH_TRY(normal ? jh_blockop_normal_mul_range(ops[k], outs[k], ins[k], lo, cnt) : jh_blockop_mul_adj_range(ops[k], outs[k], ins[k], lo, cnt));
+        JH_TRY(jh_enter(outs[0]));
+        JH_TRY(jh_comm_group_begin());
+        int st = JH_OK;
+        for (int k = 0; k < n && st == JH_OK; k++) st = jh_comm_allreduce_sum_range(outs[k], lo, cnt);
+        (void)jh_enter(outs[0]);
+        const int st2 = jh_comm_group_end();
+        JH_TRY(st);
+        JH_TRY(st2);
+    }
+    for (int k = 0; k < n; k++) {
+        JH_TRY(jh_enter(outs[k]));
+        JH_TRY(jh_comm_join());
+    }
+    return JH_OK;
+}
+
+extern "C" {
+
+// d_k = A_k m_k on every member (1015-1031: block rows are independent, no exchange); returns after enqueue
+int jh_team_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ds, const jh_bvec *const *ms)
+{
+    JH_TRY(team_check("jh_team_mul", n, ops, (const void *const *)ds, (const void *const *)ms));
+    for (int k = 0; k < n; k++) JH_TRY(jh_blockop_mul(ops[k], ds[k], ms[k]));
+    return JH_OK;
+}
+
+// every member's m_k = sum over ALL members' rows of A_i' d_i (1045-1053): local ordered sums range by range, the grouped all-reduce of a
+// finished range under the next range's kernels, the library streams waiting for the exchange by event (no host synchronisation)
+int jh_team_mul_adj(int n, const jh_blockop *const *ops, jh_bvec *const *ms, const jh_bvec *const *ds, int nranges)
+{
+    return team_ranged("jh_team_mul_adj", n, ops, ms, ds, nranges, false);
+}
+
+// every member's y_k = (sum over all members of A_i'A_i) m: the fused normal operator (530-534 over (A', A)) exchanged the same way
+int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, const jh_bvec *const *ms, int nranges)
+{
+    return team_ranged("jh_team_normal_mul", n, ops, ys, ms, nranges, true);
+}
+
+}  // extern "C"

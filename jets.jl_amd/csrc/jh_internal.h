@@ -105,6 +105,9 @@ struct jh_context {
     int64_t last_step_parts = 0;             // per-workgroup partial sums the most recent one-pass step wrote
     int64_t lsqr_graph = 1;            // knob: small operators' LSQR loop with device-resident recurrences, replayed as a hipGraph (0: the host loop)
     int64_t last_lsqr_graph = 0;       // read-only: graph replays of the most recent jh_lsqr_solve (0: the host loop ran)
+    int64_t cgls_trace = 0;            // knob (tests): jh_cgls_solve_team stamps every member's pass 1 of its first iteration with events ...
+    int64_t last_cgls_overlaps = -1;   // read-only: ... and counts the consecutive members whose pass 1 began before the previous member's had finished (-1: not traced)
+    int red_defer = 0;                 // internal, set around ONE reduction: enqueue it and its read-back, do not wait (jh_dot_begin / jh_dot_end)
     int adj_from_found = 0;            // internal, set around ONE call: the tall adjoint continues from what its output holds (the
                                        // forward of a wide operator through its tall twin: `_d .+=` into d as found, src/Jets.jl:1024); never split
 };
@@ -250,6 +253,8 @@ bool jh_blockop_tall_fast(const jh_blockop *op, const void *rng_ptr, const void 
 void jh_bcast_clear_cache();            // jh_bcast.hip: unload every JIT-compiled broadcast program (jh_shutdown)
 int jh_chain_err_check();               // jh_blockop.hip: fails loudly if the chained step's sticky error word (copied to red_host[3]) is set
 int jh_ensure_partials(int64_t n);     // grows ctx.part_dev to >= n doubles (may synchronise + reallocate)
+extern "C" int jh_dot_begin(const jh_bvec *x, const jh_bvec *y);      // jh_vecops.hip: jh_dot in two halves (enqueue / wait + read), internal
+extern "C" int jh_dot_end(const jh_bvec *x, double *re, double *im);
 // vecops entry used by blockop for generic pieces
 int jh_launch_fill_range(void *ptr, int dtype, int64_t count, double re, double im);
 int jh_launch_copy_bytes(void *dst, const void *src, size_t bytes);

@@ -857,6 +857,8 @@ static int cgls_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *
         return JH_OK;
     };
     std::vector<double> locals((size_t)M);
+    jh_context *const trace_ctx = jh_ctx_by_id(ops[0]->ctx);              // knob cgls_trace / read-only last_cgls_overlaps live in member 0's context
+    if (trace_ctx) trace_ctx->last_cgls_overlaps = -1;
 
     double s2 = 0.0;
     for (int k = 0; k < M; k++) {
@@ -884,11 +886,38 @@ static int cgls_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *
         while (itn < maxiter) {
             itn++;
             // ---- pass 1: delta = <p, A'A p> + damp^2 ||p||^2 (every shard's share of the quadratic form, then a scalar sum)
+            // every member's pass and its inner product are ENQUEUED before the first wait: the members' GPUs run side by side (round 3
+            // waited for member k's dot before member k + 1's kernel was even launched: M passes one after the other)
+            const bool trace = itn == 1 && M > 1 && trace_ctx && trace_ctx->cgls_trace;   // tests: event timestamps of the first iteration's pass 1
+            std::vector<hipEvent_t> tev(trace ? (size_t)(2 * M) : 0, nullptr);
+            auto stamp = [&](int k, int which) -> int {
+                if (!trace) return JH_OK;
+                JH_TRY(use(k));
+                JH_CHECK_HIP(hipEventCreate(&tev[(size_t)(2 * k + which)]));
+                JH_CHECK_HIP(hipEventRecord(tev[(size_t)(2 * k + which)], jh_ctx().stream));
+                return JH_OK;
+            };
             for (int k = 0; k < M; k++) {
+                JH_TRY(stamp(k, 0));
                 JH_TRY(jh_blockop_normal_mul(ops[k], t[k].y, t[k].p));
+                JH_TRY(jh_dot_begin(t[k].p, t[k].y));
+                JH_TRY(stamp(k, 1));
+            }
+            for (int k = 0; k < M; k++) {
                 double re = 0.0, im = 0.0;
-                JH_TRY(jh_dot(t[k].p, t[k].y, &re, &im));
+                JH_TRY(jh_dot_end(t[k].p, &re, &im));
                 locals[k] = re;
+            }
+            if (trace) {                                                  // member k + 1 began before member k had finished?  (members of ONE device: one clock)
+                int64_t overlaps = 0;
+                for (int k = 0; k + 1 < M; k++) {
+                    float ms = 0.f;                                       // from k's end to (k + 1)'s begin: negative when they overlap
+                    if (hipEventElapsedTime(&ms, tev[(size_t)(2 * k + 1)], tev[(size_t)(2 * k + 2)]) == hipSuccess && ms < 0.f) overlaps++;
+                }
+                (void)hipGetLastError();
+                trace_ctx->last_cgls_overlaps = overlaps;
+                for (hipEvent_t e : tev)
+                    if (e) (void)hipEventDestroy(e);
             }
             double delta = 0.0;
             JH_TRY(global_sum(locals, &delta));

@@ -451,6 +451,7 @@ int reduce_launch(const void *x, const void *y, int64_t n_elems, double p, doubl
     hipLaunchKernelGGL((k_reduce_final<OP>), dim3(1), dim3(WG), 0, c.stream, partials, grid, c.red_dev);
     JH_CHECK_HIP(hipGetLastError());
     JH_CHECK_HIP(hipMemcpyAsync(c.red_host, c.red_dev, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    if (c.red_defer) { *r0 = *r1 = 0.0; return JH_OK; }                      // jh_dot_begin: the caller reads red_host after its own wait (jh_dot_end)
     JH_CHECK_HIP(hipStreamSynchronize(c.stream));
     *r0 = c.red_host[0];
     *r1 = c.red_host[1];
@@ -681,6 +682,33 @@ int jh_dot(const jh_bvec *x, const jh_bvec *y, double *re, double *im)
     if (x->length > 0) JH_TRY((reduce_dispatch<RED_DOT>(x->dtype, x->data, y->data, x->length, 0.0, &r0, &r1)));
     *re = r0;
     if (im) *im = r1;
+    return JH_OK;
+}
+
+// The two halves of jh_dot, for loops over the members of a team (jh_lsqr.hip: cgls_impl): jh_dot_begin enqueues the reduction and the
+// copy of its result into the context's pinned landing zone and returns; jh_dot_end waits for x's context and reads it.  Nothing else
+// that returns a scalar may run in that context in between (the landing zone is per context).
+int jh_dot_begin(const jh_bvec *x, const jh_bvec *y)
+{
+    JH_TRY(jh_enter(x, y));
+    JH_REQUIRE(x && y, "jh_dot_begin: null argument");
+    JH_REQUIRE(x->dtype == y->dtype && x->length == y->length && x->length > 0, "jh_dot_begin: vectors differ in element type or length (or are empty)");
+    jh_context &c = jh_ctx();
+    double r0 = 0, r1 = 0;
+    c.red_defer = 1;
+    const int st = reduce_dispatch<RED_DOT>(x->dtype, x->data, y->data, x->length, 0.0, &r0, &r1);
+    c.red_defer = 0;
+    return st;
+}
+
+int jh_dot_end(const jh_bvec *x, double *re, double *im)
+{
+    JH_TRY(jh_enter(x));
+    JH_REQUIRE(x && re, "jh_dot_end: null argument");
+    jh_context &c = jh_ctx();
+    JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+    *re = c.red_host[0];
+    if (im) *im = c.red_host[1];
     return JH_OK;
 }
 

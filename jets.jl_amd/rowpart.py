@@ -539,6 +539,8 @@ class TeamOp:
             raise ValueError(f"{team.world} members, {len(local_ops)} operators")
         self.team, self.local_ops = team, list(local_ops)
         self.nchunks = builtins.max(1, int(os.environ.get("JETS_AR_CHUNKS", "4")))
+        self.one_call = os.environ.get("JETS_TEAM_ONE_CALL", "1") != "0"    # the member loop in C (round 4); 0: spelled out here, call by call
+        self._op_handles = None
         self._natives = []
         for A in self.local_ops:
             nat = None
@@ -557,9 +559,34 @@ class TeamOp:
 
         return [range_(A) for A in self.local_ops]
 
+    def _handles(self, xs):
+        import ctypes as C
+
+        return (C.c_void_p * len(xs))(*[x.handle for x in xs])
+
+    def _team_call(self, fn, outs: TeamVec, ins: TeamVec, *extra) -> bool:
+        """The whole member loop behind ONE ABI call (jh_team_mul / jh_team_mul_adj / jh_team_normal_mul): False when a member has
+        no native operator or the library says 'unsupported' before anything is enqueued (the callers then take the generic path)."""
+        from ._ffi import check, JetsHipError
+
+        if any(n is None for n in self._natives):
+            return False
+        if self._op_handles is None:
+            self._op_handles = self._handles(self._natives)
+        try:
+            check(fn(self.team.world, self._op_handles, self._handles(outs.members), self._handles(ins.members), *extra))
+        except JetsHipError as e:
+            if e.status != 4:                                  # JH_ERR_UNSUPPORTED comes before anything is enqueued (every member alike)
+                raise
+            return False
+        return True
+
     def mul_(self, d: TeamVec, m: TeamVec) -> TeamVec:
+        from ._ffi import lib
         from .jets import mul_
 
+        if self.one_call and self._team_call(lib.jh_team_mul, d, m):
+            return d
         for k, _ in self.team.each():
             mul_(d[k], self.local_ops[k], m[k])
         return d
@@ -584,6 +611,8 @@ class TeamOp:
         from ._ffi import lib, check, JetsHipError
         from .jets import mul_, adjoint
 
+        if self.one_call and self._team_call(lib.jh_team_mul_adj, m, d, self.nchunks):
+            return m
         try:
             if self._ranged(m, lambda k, lo, cnt: check(lib.jh_blockop_mul_adj_range(self._natives[k].handle, m[k].handle, d[k].handle, lo, cnt))):
                 return m
@@ -602,6 +631,8 @@ class TeamOp:
         the next range's kernels; forward then adjoint through `tmp` (a range-side TeamVec) for operators without the fused kernel."""
         from ._ffi import lib, check, JetsHipError
 
+        if self.one_call and self._team_call(lib.jh_team_normal_mul, y, m, self.nchunks):
+            return y
         try:
             if self._ranged(y, lambda k, lo, cnt: check(lib.jh_blockop_normal_mul_range(self._natives[k].handle, y[k].handle, m[k].handle, lo, cnt))):
                 return y

@@ -763,6 +763,29 @@ function bidiag_step_team!(us::Vector{<:BlockArray{T,<:HipArray{T}}}, ws::Vector
     sqrt(total)
 end
 
+# the team's operator applications, the member loop behind ONE ccall each (jh_team_mul / jh_team_mul_adj / jh_team_normal_mul):
+# As[k], ds[k] = member k's block rows and its rows of the range vector, ms[k] / ys[k] = its replica of the domain vector
+function _team_natives(who::AbstractString, As::Vector{<:JopLn}, ::Type{T}) where {T}
+    hs = Ptr{Cvoid}[tall_native(A, T) for A in As]
+    any(h -> h == C_NULL, hs) && error("$who: every member needs a device-native tall block operator")
+    hs
+end
+function hip_team_mul!(ds::Vector{<:BlockArray{T,<:HipArray{T}}}, As::Vector{<:JopLn}, ms::Vector{<:HipArray{T}}) where {T}   # d_k = A_k m_k (src/Jets.jl:1015-1031), no exchange
+    hs = _team_natives("hip_team_mul!", As, T)
+    check(ccall((:jh_team_mul, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), length(As), hs, Ptr{Cvoid}[handle(d) for d in ds], Ptr{Cvoid}[handle(m) for m in ms]))
+    ds
+end
+function hip_team_mul_adj!(ms::Vector{<:HipArray{T}}, As::Vector{<:JopLn}, ds::Vector{<:BlockArray{T,<:HipArray{T}}}; chunks::Integer=4) where {T}   # every m_k = sum over ALL rows (1045-1053)
+    hs = _team_natives("hip_team_mul_adj!", As, T)
+    check(ccall((:jh_team_mul_adj, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Cint), length(As), hs, Ptr{Cvoid}[handle(m) for m in ms], Ptr{Cvoid}[handle(d) for d in ds], chunks))
+    ms
+end
+function hip_team_normal_mul!(ys::Vector{<:HipArray{T}}, As::Vector{<:JopLn}, ms::Vector{<:HipArray{T}}; chunks::Integer=4) where {T}   # every y_k = (A'A) m, fused (530-534)
+    hs = _team_natives("hip_team_normal_mul!", As, T)
+    check(ccall((:jh_team_normal_mul, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Cint), length(As), hs, Ptr{Cvoid}[handle(y) for y in ys], Ptr{Cvoid}[handle(m) for m in ms], chunks))
+    ys
+end
+
 # the whole LSQR solve over the team behind one call: bs[k] = member k's rows of b (overwritten), xs[k] its replica of x
 function hip_lsqr_team!(xs::Vector{<:HipArray{T}}, As::Vector{<:JopLn}, bs::Vector{<:BlockArray{T,<:HipArray{T}}}; x0::Bool=false, damp=0.0, atol=1e-6,
                         btol=1e-6, conlim=1e8, maxiter=100) where {T}
