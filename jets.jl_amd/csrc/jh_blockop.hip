@@ -18,6 +18,7 @@
 //    lengths; one thread per element walks a block row (forward) or block column (adjoint) in
 //    the reference's loop order with the same rounding sequence.
 #include "jh_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -498,65 +499,77 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
         // u_i <- alpha*0 + beta*u_i, and the row adds nothing to w (1047)
         // the row table is read one batch AHEAD (scalar loads): a batch's coefficient loads need its descriptors, and waiting for
         // them row by row cost 12 % at 1024 rows of 8 MiB (profiles/exp_r02_mixed_step_shapes.txt)
-        jh_dev_block blk[DEPTH], nxt[DEPTH];
-        if (i + DEPTH <= row1) {
+        // Round 4: the LOAD section of a batch is straight-line code -- a row without a coefficient array (identity, scalar, zero) loads
+        // v's pack again (an L1 hit, unused) instead of branching around the load, and "beta == 0: u is write-only" is decided once
+        // outside the row loop (two instantiations of the walk) instead of around every load of u.  With a branch per load (what the
+        // first version compiled to) the waves drained their outstanding loads at every row, and a tall operator with ONE
+        // regularisation row ran its step 13 % below the all-diagonal one (profiles/bench_mixed_rows_r02.txt; now bench_mixed_rows_r04.txt).
+        auto walk = [&](auto old_tag) {
+            constexpr bool OLD = decltype(old_tag)::value;
+            jh_dev_block blk[DEPTH], nxt[DEPTH];
+            if (i + DEPTH <= row1) {
 #pragma unroll
-            for (int j = 0; j < DEPTH; j++) nxt[j] = blocks[i + j];
-        }
-        for (; i + DEPTH <= row1; i += DEPTH) {
-            V av[DEPTH][U], uv[DEPTH][U];
-            const int64_t ahead = (i + 2 * DEPTH <= row1) ? i + DEPTH : i;
-#pragma unroll
-            for (int j = 0; j < DEPTH; j++) {
-                blk[j] = nxt[j];
-                nxt[j] = blocks[ahead + j];
+                for (int j = 0; j < DEPTH; j++) nxt[j] = blocks[i + j];
             }
+            for (; i + DEPTH <= row1; i += DEPTH) {
+                V av[DEPTH][U], uv[DEPTH][U];
+                const int64_t ahead = (i + 2 * DEPTH <= row1) ? i + DEPTH : i;
 #pragma unroll
-            for (int j = 0; j < DEPTH; j++) {
-                const bool rc = block_reads_coeff(blk[j], false);
-#pragma unroll
-                for (int k = 0; k < U; k++) {
-                    av[j][k] = rc ? ld<true>(reinterpret_cast<const V *>((const S *)blk[j].coeff + sk[k])) : (V)(S)0;
-                    uv[j][k] = use_old ? ld<true>(reinterpret_cast<const V *>(u + (i + j) * n_scalars + sk[k])) : (V)(S)0;
+                for (int j = 0; j < DEPTH; j++) {
+                    blk[j] = nxt[j];
+                    nxt[j] = blocks[ahead + j];
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < DEPTH; j++) {
-                if (blk[j].kind == JH_OP_DIAG) {                 // the common row: ONE branch per row, then the all-diagonal kernel's straight line
-                    const bool cj = blk[j].adjoint != 0;
+                for (int j = 0; j < DEPTH; j++) {
+                    const S *ap = block_reads_coeff(blk[j], false) ? (const S *)blk[j].coeff : v;   // no coefficient array: v's pack again (unused)
 #pragma unroll
                     for (int k = 0; k < U; k++) {
-                        const V t = vmul<S, E, NS, V>(av[j][k], vv[k], cj);
+                        av[j][k] = ld<true>(reinterpret_cast<const V *>(ap + sk[k]));
+                        if constexpr (OLD) uv[j][k] = ld<true>(reinterpret_cast<const V *>(u + (i + j) * n_scalars + sk[k]));
+                        else uv[j][k] = (V)(S)0;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < DEPTH; j++) {
+                    if (blk[j].kind == JH_OP_DIAG) {                 // the common row: ONE branch per row, then the all-diagonal kernel's straight line
+                        const bool cj = blk[j].adjoint != 0;
+#pragma unroll
+                        for (int k = 0; k < U; k++) {
+                            const V t = vmul<S, E, NS, V>(av[j][k], vv[k], cj);
+                            V r = (V)alpha * t;
+                            if constexpr (OLD) { V s2 = (V)beta * uv[j][k]; r = r + s2; }
+                            if (ok[k]) {
+                                st<true>(reinterpret_cast<V *>(u + (i + j) * n_scalars + sk[k]), r);
+                                nrm += vnorm2<S, NS, V>(r);
+                            }
+                            acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, !cj);
+                        }
+                        continue;
+                    }
+                    const bool on = blk[j].kind != JH_OP_ZERO;
+#pragma unroll
+                    for (int k = 0; k < U; k++) {
+                        const V t = on ? apply_block_loaded<S, E, NS, V>(blk[j], vv[k], av[j][k], false, false) : (V)(S)0;
                         V r = (V)alpha * t;
-                        if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; }
+                        if constexpr (OLD) { V s2 = (V)beta * uv[j][k]; r = r + s2; }
                         if (ok[k]) {
                             st<true>(reinterpret_cast<V *>(u + (i + j) * n_scalars + sk[k]), r);
                             nrm += vnorm2<S, NS, V>(r);
                         }
-                        acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, !cj);
+                        if (on) acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk[j], r, av[j][k], true, false);
                     }
-                    continue;
-                }
-                const bool on = blk[j].kind != JH_OP_ZERO;
-#pragma unroll
-                for (int k = 0; k < U; k++) {
-                    const V t = on ? apply_block_loaded<S, E, NS, V>(blk[j], vv[k], av[j][k], false, false) : (V)(S)0;
-                    V r = (V)alpha * t;
-                    if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; }
-                    if (ok[k]) {
-                        st<true>(reinterpret_cast<V *>(u + (i + j) * n_scalars + sk[k]), r);
-                        nrm += vnorm2<S, NS, V>(r);
-                    }
-                    if (on) acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk[j], r, av[j][k], true, false);
                 }
             }
-        }
+        };
+        if (use_old) walk(std::true_type{});
+        else walk(std::false_type{});
         for (; i < row1; i++) {
             const jh_dev_block blk = blocks[i];
-            const bool on = blk.kind != JH_OP_ZERO, rc = block_reads_coeff(blk, false);
+            const bool on = blk.kind != JH_OP_ZERO;
+            const S *ap = block_reads_coeff(blk, false) ? (const S *)blk.coeff : v;
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                const V c = rc ? ld<true>(reinterpret_cast<const V *>((const S *)blk.coeff + sk[k])) : (V)(S)0;
+                const V c = ld<true>(reinterpret_cast<const V *>(ap + sk[k]));
                 const V t = on ? apply_block_loaded<S, E, NS, V>(blk, vv[k], c, false, false) : (V)(S)0;
                 V r = (V)alpha * t;
                 if (use_old) { V s2 = (V)beta * ld<true>(reinterpret_cast<const V *>(u + i * n_scalars + sk[k])); r = r + s2; }
