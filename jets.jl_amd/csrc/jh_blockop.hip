@@ -316,6 +316,71 @@ template <int BLK> __device__ inline void wg_sum_store(double v, double *slot)
     }
 }
 
+// ---- the normal-equations pass of the device-resident CG loops (jh_lsqr.hip: cg_graph_impl; round 4) ---------------------------------
+// ONE launch per iteration where the host-driven loop makes four (p <- s + bk p ; y = A'A p ; y += damp^2 p ; <p, y>): a thread owns one
+// 16-byte pack of the domain -- it updates its pack of p (nobody else reads it in this launch: the rows below read coefficients only),
+// walks all rows in order with DEPTH rows in flight exactly as k_tall_diag_adj MODE 1 does (product, product, add, each rounded: the bits
+// of jh_blockop_normal_mul), adds the damping term with the lincomb's rounding, stores y and leaves its share of <p, y> (fp64) to the
+// workgroup's partial.  Coefficients (bk, damp^2, the flags) come from device memory, so the launch is the same every iteration.
+template <typename S, int E, int NS, int DEPTH>
+__global__ __launch_bounds__(256) void k_cg_normal(const jh_dev_block *__restrict__ blocks, int64_t nrow, const S *__restrict__ a_base, int64_t a_stride,
+                                                   S *__restrict__ p, const S *__restrict__ sres, S *__restrict__ y, int64_t n_scalars,
+                                                   const jh_cg_dev *__restrict__ stt, double *__restrict__ partials)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * NS;
+    const bool ok = s0 < n_scalars;
+    const int64_t sk = ok ? s0 : 0;
+    // the state and this lane's packs of p and s are requested together, before the first decision (a launch of this size is paced by
+    // round trips, not by bytes).  Folding the previous vector update's ||s||^2 partials and applying the second scalar update HERE, in
+    // every workgroup (one more graph node less), was tried and lost: the whole grid then waits for a fold, a barrier and an fp64 chain
+    // before its first coefficient load -- 28.7 us per iteration against 20.2 at 64 x 64^3 (profiles/bench_cgnr_sizes_r04.txt).
+    V pv = ld<false>(reinterpret_cast<const V *>(p + sk));
+    V sv = ld<false>(reinterpret_cast<const V *>(sres + sk));
+    const int done = stt->done, skip_p = stt->skip_p;
+    const double bk = stt->bk, damp2 = stt->damp2;
+    asm volatile("" : "+v"(pv), "+v"(sv));
+    if (done) return;
+    if (!skip_p) {                                                           // p = 1*s + bk*p  (jh_lincomb's sequence: bk*p rounded, then the sum)
+        const V bp = (V)(S)bk * pv;
+        pv = sv + bp;
+        if (ok) st<false>(reinterpret_cast<V *>(p + sk), pv);
+    }
+    V acc = (V)(S)0;
+    int64_t i = 0;
+    for (; i + DEPTH <= nrow; i += DEPTH) {
+        V av[DEPTH];
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            const S *a = a_base ? a_base + (i + j) * a_stride : (const S *)blocks[i + j].coeff;
+            av[j] = ld<true>(reinterpret_cast<const V *>(a + sk));
+        }
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            const V t = vmul<S, E, NS, V>(av[j], pv, false);                  // d_i = a_i .* p
+            acc = acc + vmul<S, E, NS, V>(av[j], t, true);                    // y .+= conj(a_i) .* d_i, rows in order
+        }
+    }
+    for (; i < nrow; i++) {
+        const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
+        const V av = ld<true>(reinterpret_cast<const V *>(a + sk));
+        const V t = vmul<S, E, NS, V>(av, pv, false);
+        acc = acc + vmul<S, E, NS, V>(av, t, true);
+    }
+    if (damp2 != 0.0) {                                                      // y = 1*y + damp^2*p
+        const V dp = (V)(S)damp2 * pv;
+        acc = acc + dp;
+    }
+    double part = 0.0;
+    if (ok) {
+        st<false>(reinterpret_cast<V *>(y + sk), acc);
+#pragma unroll
+        for (int e = 0; e < NS; e++) part += (double)pv[e] * (double)acc[e];   // Re <p, y>: over the scalars (a complex vector is 2n reals here)
+    }
+    wg_sum_store<256>(part, partials + blockIdx.x);
+}
+
+
 template <typename S, int NS, typename V> __device__ inline double vnorm2(V r)
 {
     double acc = 0.0;
@@ -3041,6 +3106,32 @@ int check_vectors(const jh_blockop *op, const jh_bvec *rng, const jh_bvec *dom, 
 bool jh_blockop_tall_fast(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
 {
     return tall_fast_ok(op, rng_ptr, dom_ptr) || (tall_mixed_ok(op, rng_ptr, dom_ptr) && !(op->nonlinear && !op->pointed));
+}
+
+// all-DIAG tall operators only (the caller checks: jh_lsqr.hip, cg_graph_impl); one pack per lane, 8 rows in flight
+int jh_launch_cg_normal(const jh_blockop *op, jh_bvec *p, const jh_bvec *s, jh_bvec *y, const jh_cg_dev *st, double *partials, int64_t *nparts)
+{
+    jh_context &c = jh_ctx();
+    JH_REQUIRE(op->all_diag && tall_fast_ok(op, nullptr, p->data), "cg normal pass: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
+    const int64_t n = op->row_len[0];
+    const int64_t packs = (n * (int64_t)jh_dtype_size(op->dtype)) / 16;
+    const int64_t grid = (packs + 255) / 256;
+    JH_REQUIRE(grid >= 1 && grid < ((int64_t)1 << 22), "cg normal pass: domain of %lld elements is out of range", (long long)n);
+    *nparts = grid;
+#define JH_CGN(S, E, NS)                                                                                                                        \
+    hipLaunchKernelGGL((k_cg_normal<S, E, NS, 8>), dim3((unsigned)grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow,                        \
+                       op->diag_strided ? (const S *)op->blocks[0].coeff : (const S *)nullptr, op->diag_stride_elems * E, (S *)p->data,          \
+                       (const S *)s->data, (S *)y->data, n * E, st, partials)
+    switch (op->dtype) {
+    case JH_F32: JH_CGN(float, 1, 4); break;
+    case JH_F64: JH_CGN(double, 1, 2); break;
+    case JH_C32: JH_CGN(float, 2, 4); break;
+    case JH_C64: JH_CGN(double, 2, 2); break;
+    default: return jh_fail(JH_ERR_INVALID, "cg normal pass: unknown dtype %d", op->dtype);
+    }
+#undef JH_CGN
+    JH_CHECK_HIP(hipGetLastError());
+    return JH_OK;
 }
 
 extern "C" {

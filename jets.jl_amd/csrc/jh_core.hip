@@ -814,6 +814,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "general_tile")) { JH_REQUIRE(value == 0 || value == 1, "general_tile must be 0 or 1"); c.general_tile = value; }
     else if (!strcmp(name, "dense_fused")) { JH_REQUIRE(value == 0 || value == 1, "dense_fused must be 0 or 1"); c.dense_fused = value; }
     else if (!strcmp(name, "cgls_trace")) { c.cgls_trace = value ? 1 : 0; }
+    else if (!strcmp(name, "cg_dev")) { c.cg_dev = value ? 1 : 0; }
     else if (!strcmp(name, "dense_gw")) { JH_REQUIRE(value >= 0 && value <= 4096, "dense_gw must be 0 (automatic) or 1 .. 4096 children per wave"); c.dense_gw = value; }
     else if (!strcmp(name, "sum_group")) { JH_REQUIRE(value == 4 || value == 8, "sum_group must be 4 or 8 terms per launch"); c.sum_group = value; }
     else if (!strcmp(name, "grid_diag")) { JH_REQUIRE(value >= 0 && value <= 4, "grid_diag must be 0 (general kernels), 1, 2 or 4 (packs per lane)"); c.grid_diag = value; }
@@ -860,6 +861,8 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "dense_mixed")) *value = c.dense_mixed;
     else if (!strcmp(name, "dense_fused")) *value = c.dense_fused;
     else if (!strcmp(name, "cgls_trace")) *value = c.cgls_trace;
+    else if (!strcmp(name, "cg_dev")) *value = c.cg_dev;
+    else if (!strcmp(name, "last_cg_graph")) *value = c.last_cg_graph;
     else if (!strcmp(name, "last_cgls_overlaps")) *value = c.last_cgls_overlaps;
     else if (!strcmp(name, "dense_gw")) *value = c.dense_gw;
     else if (!strcmp(name, "last_dense_fused")) *value = c.last_dense_fused;

@@ -105,6 +105,8 @@ struct jh_context {
     int64_t last_step_parts = 0;             // per-workgroup partial sums the most recent one-pass step wrote
     int64_t lsqr_graph = 1;            // knob: small operators' LSQR loop with device-resident recurrences, replayed as a hipGraph (0: the host loop)
     int64_t last_lsqr_graph = 0;       // read-only: graph replays of the most recent jh_lsqr_solve (0: the host loop ran)
+    int64_t cg_dev = 1;                // knob: small operators' CGLS / CG-on-the-normal-equations loops on the fused kernels of cg_dev_impl (graph-replayed unless lsqr_graph = 0); 0: cgls_impl / cgnr_impl
+    int64_t last_cg_graph = 0;         // read-only: graph replays of the most recent jh_cgls_solve / jh_cgnr_solve (0: a host-driven loop ran)
     int64_t cgls_trace = 0;            // knob (tests): jh_cgls_solve_team stamps every member's pass 1 of its first iteration with events ...
     int64_t last_cgls_overlaps = -1;   // read-only: ... and counts the consecutive members whose pass 1 began before the previous member's had finished (-1: not traced)
     int red_defer = 0;                 // internal, set around ONE reduction: enqueue it and its read-back, do not wait (jh_dot_begin / jh_dot_end)
@@ -250,6 +252,72 @@ struct jh_blockop {
 };
 
 bool jh_blockop_tall_fast(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr);   // tall, all DIAG, equal 16-byte aligned blocks
+// Device-resident state of CG on the normal equations / CGLS (jh_lsqr.hip, round 4): the recurrences' scalars live here, one-thread
+// epilogues of the fold kernels update them with the same fp64 operations, in the same order, as the host-driven loops (the two
+// update functions are shared `__host__ __device__` code), and every vector kernel reads its coefficients from it -- so an
+// iteration has fixed launch parameters, is captured once as a hipGraph and replayed; a finished solve turns the kernels into no-ops.
+struct jh_cg_dev {
+    double gamma, gamma0, rr, bnorm, damp2, atol, btol;
+    double alpha, bk, delta;
+    double coef_step[2];               // CGLS: (-alpha, 1) for the one-pass step r <- r - alpha A p
+    int itn, istop, done, skip_p, maxiter, force, cgls, pad;
+};
+// lane t of a 256-lane workgroup adds p[t], p[t + 256], p[t + 512], ... in THAT order (the folds of the CG kernels all use this, so
+// that every one of them forms the same bits); four loads in flight, a load past the end re-reads the last element and adds 0
+__device__ inline double jh_strided_sum256(const double *__restrict__ p, int64_t n)
+{
+    double v = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int64_t i1 = i + 256 < n ? i + 256 : n - 1, i2 = i + 512 < n ? i + 512 : n - 1, i3 = i + 768 < n ? i + 768 : n - 1;
+        const double a0 = p[i], b1 = p[i1], b2 = p[i2], b3 = p[i3];
+        v += a0;
+        v += i + 256 < n ? b1 : 0.0;
+        v += i + 512 < n ? b2 : 0.0;
+        v += i + 768 < n ? b3 : 0.0;
+    }
+    return v;
+}
+// the two scalar updates of an iteration (Hestenes & Stiefel's recurrences), shared by the host-driven loop and the device kernels
+__host__ __device__ inline void cg_s1(jh_cg_dev *st, double pap)
+{
+    st->itn++;
+    st->delta = pap;
+    if (!(pap > 0) || !((pap - pap) == 0.0)) {                            // breakdown: p in the null space, or the recurrences have left the range
+        st->istop = 6;
+        st->itn--;
+        st->done = 1;
+        return;
+    }
+    st->alpha = st->gamma / pap;
+    st->coef_step[0] = -st->alpha;
+    st->coef_step[1] = 1.0;
+}
+
+__host__ __device__ inline void cg_s2(jh_cg_dev *st, double ssum, double rsum, double *history)
+{
+    if (st->cgls) {
+        st->rr = rsum;                                                    // ||r||^2 from the step itself
+    } else {
+        st->rr -= st->alpha * st->gamma;                                  // ||r_k||^2 = ||r_{k-1}||^2 - alpha_k gamma_{k-1} (exact for CG)
+        if (st->rr < 0) st->rr = 0;
+    }
+    st->bk = ssum / st->gamma;
+    st->gamma = ssum;
+    st->skip_p = 0;
+    const double rnorm = sqrt(st->rr), arnorm = sqrt(st->gamma);
+    const int itn = st->itn;
+    if (history) { history[2 * (itn - 1)] = rnorm; history[2 * (itn - 1) + 1] = arnorm; }
+    int istop = st->istop;
+    if (itn >= st->maxiter) istop = 7;
+    if (arnorm <= st->atol * sqrt(st->gamma0)) istop = 2;
+    if (rnorm <= st->btol * st->bnorm) istop = 1;
+    st->istop = istop;
+    if (istop && !(st->force && itn < st->maxiter && st->gamma > 0)) st->done = 1;
+}
+
+// jh_blockop.hip: one launch = [p <- s + bk p unless st->skip_p] ; y = A'A p (+ damp2 p) with the bits of jh_blockop_normal_mul (+ the
+// lincomb) ; one fp64 partial of <p, y> per workgroup of 256 packs.  *nparts = the number of partials written.
+int jh_launch_cg_normal(const jh_blockop *op, jh_bvec *p, const jh_bvec *s, jh_bvec *y, const jh_cg_dev *st, double *partials, int64_t *nparts);
 void jh_bcast_clear_cache();            // jh_bcast.hip: unload every JIT-compiled broadcast program (jh_shutdown)
 int jh_chain_err_check();               // jh_blockop.hip: fails loudly if the chained step's sticky error word (copied to red_host[3]) is set
 int jh_ensure_partials(int64_t n);     // grows ctx.part_dev to >= n doubles (may synchronise + reallocate)

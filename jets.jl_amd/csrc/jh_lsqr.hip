@@ -699,16 +699,18 @@ static int lsqr_graph_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use
     int64_t replays = 0;
     if (!fl.done) {
         const bool fused = c.last_step_parts > 0 && c.last_step_parts <= 8192;
+        // round 4: EIGHT iterations per graph (finished solves replay as no-ops): one hipGraphLaunch costs the host 10-16 us
+        const int per_graph = maxiter < 8 ? maxiter : 8;
         JH_CHECK_HIP(hipStreamBeginCapture(c.stream, hipStreamCaptureModeRelaxed));   // other host threads (other contexts) keep working meanwhile
-        const int st_ = fused ? iteration_fused() : iteration();
+        int st_ = JH_OK;
+        for (int k = 0; k < per_graph && st_ == JH_OK; k++) st_ = fused ? iteration_fused() : iteration();
         hipError_t e = hipStreamEndCapture(c.stream, &d.graph);
         if (st_ != JH_OK) return st_;
         JH_CHECK_HIP(e);
         JH_CHECK_HIP(hipGraphInstantiate(&d.exec, d.graph, nullptr, nullptr, 0));
-        const int batch = maxiter < 8 ? maxiter : 8;                      // replays between two looks at the flags; finished solves replay as no-ops
-        while (!fl.done) {
-            for (int k = 0; k < batch; k++) JH_CHECK_HIP(hipGraphLaunch(d.exec, c.stream));
-            replays += batch;
+        while (!fl.done) {                                                // two graphs between two looks at the flags
+            for (int k = 0; k < 2; k++) JH_CHECK_HIP(hipGraphLaunch(d.exec, c.stream));
+            replays += 2;
             JH_TRY(read_flags());
         }
     }
@@ -985,9 +987,333 @@ static int cgls_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *
     return JH_OK;
 }
 
+// ------------------------------------------------------------------ CGLS and CG on the normal equations for SMALL operators (round 4) -----
+// The loops above (cgls_impl, cgnr_impl below) return to the host two or three times per iteration for a scalar and launch about a dozen
+// small kernels: for an operator whose fused A'A takes 11 us that is 60 us per iteration (64 x 64^3, profiles/bench_cgnr_sizes_r03.txt).
+// Here -- as lsqr_graph_impl does for LSQR -- the scalars of the recurrences are a struct in device memory (jh_cg_dev), the one-thread
+// epilogues of two fold kernels update it, every vector kernel reads its coefficients from it and becomes a no-op once the solve has
+// finished, so one iteration has fixed launch parameters, is captured ONCE as a hipGraph and replayed:
+//   CG on the normal equations, 3 nodes:  k_cg_normal  [p <- s + bk p ; y = (A'A + damp^2) p ; partial <p, y>]      (jh_blockop.hip)
+//                                         k_cg_xs      [fold of <p, y> -> alpha, breakdown ; x += alpha p ; s -= alpha y ; partial ||s||^2]
+//                                         k_cg_fold    [gamma', beta, ||r|| by recurrence, history, stopping rules]
+//   CGLS, 5 nodes:  k_cg_normal ; k_cg_fold ; the one-pass step r <- r - alpha A p, A'r, partial ||r||^2 (coefficients from the device) ;
+//                   k_cgls_xs [x += alpha p ; s -= damp^2 x ; partial ||s||^2] ; k_cg_fold
+// The two scalar updates (cg_s1, cg_s2) are `__host__ __device__` functions: with the knob lsqr_graph = 0 the SAME kernels run eagerly
+// and the host applies the same two functions between them (one read-back each) -- the host-driven form of this loop, whose iterates the
+// replayed graph reproduces bit for bit (tests/test_gpu_graphs.py).  Operators of 1 GiB and more per pass, partitioned and team solves
+// keep cgls_impl / cgnr_impl (their tuned kernels, split walks and pipelined exchange); both forms are checked against the fp64 CPU CGLS.
+// which == 1: the sum of `partials` is <p, (A'A + damp^2) p>; which == 2: the sum of `partials` is ||s||^2 and (CGLS) the sum of
+// `rparts` the step's ||r||^2 (k_sum_partials' single-level order: `0.0 + r`).  on_device: apply the scalar update here, else leave
+// the sums in out[0], out[1] for the host.
+__global__ __launch_bounds__(256) void k_cg_fold(const double *__restrict__ partials, int64_t nparts, const double *__restrict__ rparts, int64_t nrparts,
+                                                 jh_cg_dev *st, double *__restrict__ history, double *__restrict__ out, int which, int on_device)
+{
+    // every load is issued before anything depends on one (the state, the flag and the partials travel together: a dependent launch of
+    // a few hundred bytes is all latency); a finished solve changes nothing at the end instead of returning at the start
+    jh_cg_dev loc;
+    if (threadIdx.x == 0) loc = *st;
+    const int done = st->done;
+    const double v = jh_strided_sum256(partials, nparts), w = rparts ? jh_strided_sum256(rparts, nrparts) : 0.0;
+    const double r = wg_sum_value<256>(v);
+    double r2 = 0.0;
+    if (rparts) {
+        __syncthreads();                                                  // (wg_sum_value's staging array is reused)
+        r2 = 0.0 + wg_sum_value<256>(w);
+    }
+    if (threadIdx.x == 0 && !done) {
+        if (!on_device) { out[0] = r; out[1] = r2; }
+        else {
+            if (which == 1) cg_s1(&loc, r);
+            else cg_s2(&loc, r, r2, history);
+            *st = loc;
+        }
+    }
+}
+
+// fold_n != nullptr (CG on the normal equations, graph form): the fold of the <p, y> partials and the first scalar update are done HERE
+// instead of in a launch of their own -- every workgroup adds the same partials in the same order (the same bits everywhere) and forms
+// alpha = gamma / <p, y> itself (cg_s1 writes neither gamma nor damp2; what it does write -- itn, delta, alpha, the step coefficients and,
+// on a breakdown, istop and done -- no other workgroup's result depends on: on a breakdown every workgroup returns without an update,
+// whether it saw `done` or found the breakdown itself); workgroup 0 records the update.  Three graph nodes per iteration instead of
+// four: a dependent launch costs 4-5 us even when it does nothing.
+template <typename S>
+__global__ __launch_bounds__(256) void k_cg_xs(S *__restrict__ x, S *__restrict__ s, const S *__restrict__ p, const S *__restrict__ y, int64_t n,
+                                               jh_cg_dev *st, double *__restrict__ partials, const double *__restrict__ fold_n, int64_t nfold)
+{
+    // the first element's operands, the state and the partials to fold are all loaded before anything is decided (see k_cg_fold)
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    const int64_t j0 = i0 < n ? i0 : 0;
+    S x0 = x[j0], s0 = s[j0], p0 = p[j0], y0 = y ? y[j0] : (S)0;
+    const int done = st->done;
+    double alpha_d = st->alpha;
+    const double gamma = st->gamma, damp2 = st->damp2;
+    const double v = fold_n ? jh_strided_sum256(fold_n, nfold) : 0.0;
+    asm volatile("" : "+v"(x0), "+v"(s0), "+v"(p0), "+v"(y0));             // (keeps the loads above the branches below)
+    if (fold_n) {
+        const double pap = wg_sum_value<256>(v);
+        if (done) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0) cg_s1(st, pap);          // itn, delta, alpha (= gamma / pap), or the breakdown (see above)
+        if (!(pap > 0) || !((pap - pap) == 0.0)) return;                  // breakdown: nothing is updated (every workgroup decides alike)
+        alpha_d = gamma / pap;
+    } else if (done) {
+        return;
+    }
+    const S alpha = (S)alpha_d, nalpha = (S)(-alpha_d), nd2 = (S)(-damp2);
+    const bool damped = damp2 != 0.0;
+    double nrm = 0.0;
+    for (int64_t i = i0; i < n; i += stride) {
+        if (i != i0) { x0 = x[i]; s0 = s[i]; p0 = p[i]; y0 = y ? y[i] : (S)0; }
+        const S ap = alpha * p0;
+        const S xn = x0 + ap;
+        x[i] = xn;
+        S sn = s0;
+        if (y) {
+            const S ay = nalpha * y0;
+            sn = sn + ay;
+            s[i] = sn;
+        } else if (damped) {
+            const S dx = nd2 * xn;
+            sn = sn + dx;
+            s[i] = sn;
+        }
+        nrm += (double)sn * (double)sn;
+    }
+    wg_sum_to<256>(nrm, partials + blockIdx.x);
+}
+
+static int cg_dev_impl(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter, int force_maxiter,
+                       jh_lsqr_result *res, double *history, const bool cgls, bool *took)
+{
+    *took = false;
+    JH_REQUIRE(op && b && x && res, "jh_cg*_solve: null argument");
+    JH_REQUIRE(maxiter >= 0, "jh_cg*_solve: maxiter must be >= 0");
+    JH_TRY(jh_enter(op, b, x));
+    jh_context &c = jh_ctx();
+    if (c.cg_dev == 0 || maxiter < 1) return JH_OK;
+    if (!(op->tall && op->all_diag) || !jh_blockop_tall_fast(op, b->data, x->data) || op->nrow < 2) return JH_OK;
+    if (!(c.adj_split <= 0 && (op->nrow < 256 || c.adj_split == 0) && c.adj_rows_per_launch == 0)) return JH_OK;   // one plain launch per pass
+    const int dtype = x->dtype;
+    const int64_t n = x->length;
+    if (3.0 * (double)op->nrow * (double)n * (double)jh_dtype_size(dtype) >= (double)(1ull << 30)) return JH_OK;  // launch-bound sizes only
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c.stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return JH_OK;
+    *took = true;
+    c.last_cg_graph = 0;
+
+    struct Work {
+        jh_bvec *p = nullptr, *s = nullptr, *y = nullptr;
+        double *parts = nullptr, *hist = nullptr;
+        jh_cg_dev *st = nullptr;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        ~Work()
+        {
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (parts) (void)hipFree(parts);
+            if (hist) (void)hipFree(hist);
+            if (st) (void)hipFree(st);
+            if (p) (void)jh_bvec_destroy(p);
+            if (s) (void)jh_bvec_destroy(s);
+            if (y) (void)jh_bvec_destroy(y);
+        }
+    } t;
+    const int64_t len1[1] = {n};
+    JH_TRY(jh_bvec_create(1, len1, dtype, &t.p));
+    JH_TRY(jh_bvec_create(1, len1, dtype, &t.s));
+    JH_TRY(jh_bvec_create(1, len1, dtype, &t.y));
+    const bool f64 = (dtype == JH_F64 || dtype == JH_C64);
+    const int64_t ns_dom = n * (jh_dtype_complex(dtype) ? 2 : 1);
+    int grid = (int)((ns_dom + 255) / 256 < 4096 ? (ns_dom + 255) / 256 : 4096);
+    if (grid < 1) grid = 1;
+    const int64_t packs = (n * (int64_t)jh_dtype_size(dtype)) / 16, grid_n = (packs + 255) / 256;
+    JH_CHECK_HIP(jh_device_malloc(c.device, (void **)&t.parts, sizeof(double) * ((size_t)grid_n + (size_t)grid + 2)));
+    JH_CHECK_HIP(jh_device_malloc(c.device, (void **)&t.hist, sizeof(double) * 2 * (size_t)maxiter));
+    JH_CHECK_HIP(jh_device_malloc(c.device, (void **)&t.st, sizeof(jh_cg_dev)));
+    double *parts_n = t.parts, *parts_s = t.parts + grid_n, *slots = parts_s + grid;
+    *res = jh_lsqr_result{};
+    auto lincomb2 = [&](jh_bvec *dst, double c0, const jh_bvec *x0, double c1, const jh_bvec *x1) {
+        const double coef[4] = {c0, 0.0, c1, 0.0};
+        const jh_bvec *v[2] = {x0, x1};
+        return jh_lincomb(dst, 2, coef, v);
+    };
+
+    // ---- the start-up of cgls_impl / cgnr_impl (one shard, no exchange)
+    if (!use_x0) JH_TRY(jh_fill(x, 0.0, 0.0));
+    double nrm = 0.0;
+    JH_TRY(jh_norm(b, 2.0, &nrm));
+    const double s2 = nrm * nrm, bnorm = std::sqrt(s2);
+    double rr = s2;
+    if (cgls) {
+        if (use_x0) JH_TRY(jh_blockop_mul_axpby(op, b, x, -1.0, 1.0, &rr));                 // r <- b - A x0 (in b's storage)
+        JH_TRY(jh_blockop_mul_adj(op, t.s, b));                                            // s = A'r
+        if (damp != 0.0) JH_TRY(lincomb2(t.s, 1.0, t.s, -damp * damp, x));
+    } else {
+        JH_TRY(jh_blockop_mul_adj(op, t.s, b));                                            // s = A'b
+        if (use_x0) {                                                     // s = A'b - (A'A + damp^2) x0 ; ||r0||^2 = ||b||^2 - 2 Re<x0, A'b> + <x0, A'A x0>
+            JH_TRY(jh_blockop_normal_mul(op, t.y, x));
+            double xb = 0.0, xax = 0.0, im = 0.0;
+            JH_TRY(jh_dot(x, t.s, &xb, &im));
+            JH_TRY(jh_dot(x, t.y, &xax, &im));
+            rr = s2 - 2.0 * xb + xax;
+            if (damp != 0.0) {
+                double x0n = 0.0;
+                JH_TRY(jh_norm(x, 2.0, &x0n));
+                rr += damp * damp * x0n * x0n;
+            }
+            JH_TRY(lincomb2(t.s, 1.0, t.s, -1.0, t.y));
+            if (damp != 0.0) JH_TRY(lincomb2(t.s, 1.0, t.s, -damp * damp, x));
+        }
+    }
+    JH_TRY(jh_norm(t.s, 2.0, &nrm));
+    const double gamma0 = nrm * nrm;
+    JH_TRY(jh_copy(t.p, t.s));
+    jh_cg_dev h{};
+    h.gamma = h.gamma0 = gamma0;
+    h.rr = rr;
+    h.bnorm = bnorm;
+    h.damp2 = damp * damp;
+    h.atol = atol;
+    h.btol = btol;
+    h.skip_p = 1;                                                         // p = s already
+    h.maxiter = maxiter;
+    h.force = force_maxiter ? 1 : 0;
+    h.cgls = cgls ? 1 : 0;
+    auto finish = [&]() -> int {
+        double xnorm = 0.0;
+        JH_TRY(jh_norm(x, 2.0, &xnorm));
+        res->istop = h.istop;
+        res->itn = h.itn;
+        if (cgls) {
+            res->r1norm = std::sqrt(h.rr);
+            res->r2norm = std::sqrt(h.rr + damp * damp * xnorm * xnorm);
+        } else {
+            res->r2norm = std::sqrt(h.rr);
+            const double r1sq = h.rr - damp * damp * xnorm * xnorm;
+            res->r1norm = std::sqrt(r1sq > 0 ? r1sq : 0.0);
+        }
+        res->anorm = 0.0;
+        res->acond = 0.0;
+        res->arnorm = std::sqrt(h.gamma);
+        res->xnorm = xnorm;
+        return JH_OK;
+    };
+    if (!(gamma0 > 0)) return finish();
+    auto push_state = [&]() -> int {
+        JH_CHECK_HIP(hipMemcpyAsync(t.st, &h, sizeof(h), hipMemcpyHostToDevice, c.stream));
+        JH_CHECK_HIP(hipStreamSynchronize(c.stream));                    // `h` is a stack object
+        return JH_OK;
+    };
+    JH_TRY(push_state());
+
+    int64_t nparts_n = 0, nparts_r = 0;
+    // the first half of an iteration: the normal-equations pass and its fold;  the second: (CGLS: the step,) the vector updates, their fold
+    bool fuse = false;                                                    // graph form of CG on the normal equations: the first fold inside k_cg_xs
+    auto half1 = [&](int on_device) -> int {
+        JH_TRY(jh_launch_cg_normal(op, t.p, t.s, t.y, t.st, parts_n, &nparts_n));
+        if (fuse) return JH_OK;
+        hipLaunchKernelGGL(k_cg_fold, dim3(1), dim3(256), 0, c.stream, (const double *)parts_n, nparts_n, (const double *)nullptr, (int64_t)0, t.st, t.hist, slots, 1,
+                           on_device);
+        JH_CHECK_HIP(hipGetLastError());
+        return JH_OK;
+    };
+    auto half2 = [&](int on_device) -> int {
+        const double *rparts = nullptr;
+        if (cgls) {
+            c.step_coef_dev = t.st->coef_step;
+            c.step_done_dev = &t.st->done;
+            c.step_skip_fold = 1;
+            const int st_ = jh_blockop_bidiag_step_range(op, b, t.p, t.s, 0.0, 1.0, 0, n, nullptr);      // (-alpha, 1) come from the device
+            c.step_coef_dev = nullptr;
+            c.step_done_dev = nullptr;
+            c.step_skip_fold = 0;
+            JH_TRY(st_);
+            nparts_r = c.last_step_parts;
+            rparts = c.part_dev;
+        }
+        const void *yv = cgls ? nullptr : t.y->data;
+        const double *fold_n = fuse ? parts_n : nullptr;
+        if (f64) hipLaunchKernelGGL((k_cg_xs<double>), dim3(grid), dim3(256), 0, c.stream, (double *)x->data, (double *)t.s->data, (const double *)t.p->data, (const double *)yv, ns_dom, t.st, parts_s, fold_n, nparts_n);
+        else hipLaunchKernelGGL((k_cg_xs<float>), dim3(grid), dim3(256), 0, c.stream, (float *)x->data, (float *)t.s->data, (const float *)t.p->data, (const float *)yv, ns_dom, t.st, parts_s, fold_n, nparts_n);
+        hipLaunchKernelGGL(k_cg_fold, dim3(1), dim3(256), 0, c.stream, (const double *)parts_s, (int64_t)grid, rparts, nparts_r, t.st, t.hist, slots, 2, on_device);
+        JH_CHECK_HIP(hipGetLastError());
+        return JH_OK;
+    };
+    double sums[2] = {0.0, 0.0};
+    auto pull_sums = [&]() -> int {
+        JH_CHECK_HIP(hipMemcpyAsync(sums, slots, sizeof(sums), hipMemcpyDeviceToHost, c.stream));
+        JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+        return JH_OK;
+    };
+    // one host-driven iteration: the same kernels, the scalar updates applied HERE between them
+    std::vector<double> hist_host(history ? 2 * (size_t)maxiter : 0);
+    auto host_iteration = [&]() -> int {
+        JH_TRY(half1(0));
+        JH_TRY(pull_sums());
+        cg_s1(&h, sums[0]);
+        JH_TRY(push_state());
+        if (h.done) return JH_OK;
+        JH_TRY(half2(0));
+        JH_TRY(pull_sums());
+        cg_s2(&h, sums[0], sums[1], history ? hist_host.data() : nullptr);
+        return push_state();
+    };
+    if (c.lsqr_graph == 0) {                                              // knob lsqr_graph = 0: host-driven, iteration by iteration
+        while (!h.done) JH_TRY(host_iteration());
+        if (history && h.itn > 0) memcpy(history, hist_host.data(), sizeof(double) * 2 * (size_t)h.itn);
+        return finish();
+    }
+    // iteration 1 eagerly, the scalar updates on the device (workspaces get their size; the step kernel's shape is settled)
+    struct Flags { int itn, istop, done; } fl{};
+    auto read_flags = [&]() -> int {
+        JH_CHECK_HIP(hipMemcpyAsync(&fl, &t.st->itn, sizeof(fl), hipMemcpyDeviceToHost, c.stream));
+        JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+        return JH_OK;
+    };
+    fuse = !cgls;                                                         // (CGLS's step needs alpha before the vector update: its first fold stays a launch)
+    JH_TRY(half1(1));
+    JH_TRY(half2(1));
+    JH_TRY(read_flags());
+    int64_t replays = 0;
+    if (!fl.done) {
+        if (cgls && !(nparts_r > 0 && nparts_r <= 8192)) return jh_fail(JH_ERR_STATE, "device-resident CGLS: the step left %lld partial sums (expected 1..8192)", (long long)nparts_r);
+        const uint64_t gen = c.buf_gen;
+        // EIGHT iterations per graph (a finished solve replays as no-ops): one hipGraphLaunch costs the host 10-16 us, about what a whole
+        // iteration of a 64 x 64^3 operator takes on the device
+        const int per_graph = maxiter < 8 ? maxiter : 8;
+        JH_CHECK_HIP(hipStreamBeginCapture(c.stream, hipStreamCaptureModeRelaxed));
+        int st_ = JH_OK;
+        for (int k = 0; k < per_graph && st_ == JH_OK; k++) {
+            st_ = half1(1);
+            if (st_ == JH_OK) st_ = half2(1);
+        }
+        hipError_t e = hipStreamEndCapture(c.stream, &t.graph);
+        if (st_ != JH_OK) return st_;
+        JH_CHECK_HIP(e);
+        JH_REQUIRE(gen == c.buf_gen, "device-resident CG: a workspace was reallocated during capture");
+        JH_CHECK_HIP(hipGraphInstantiate(&t.exec, t.graph, nullptr, nullptr, 0));
+        while (!fl.done) {                                                // two graphs between two looks at the flags
+            for (int k = 0; k < 2; k++) JH_CHECK_HIP(hipGraphLaunch(t.exec, c.stream));
+            replays += 2;
+            JH_TRY(read_flags());
+        }
+    }
+    c.last_cg_graph = replays;
+    JH_CHECK_HIP(hipMemcpyAsync(&h, t.st, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+    JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+    if (history && h.itn > 0) {
+        JH_CHECK_HIP(hipMemcpyAsync(history, t.hist, sizeof(double) * 2 * (size_t)h.itn, hipMemcpyDeviceToHost, c.stream));
+        JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+    }
+    return finish();
+}
+
 extern "C" int jh_cgls_solve(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter,
                              int force_maxiter, jh_lsqr_result *res, double *history)
 {
+    bool took = false;
+    JH_TRY(cg_dev_impl(op, u, x, use_x0, damp, atol, btol, maxiter, force_maxiter, res, history, true, &took));   // small operators: recurrences on the device
+    if (took) return JH_OK;
     return cgls_impl(1, &op, &u, &x, use_x0, damp, atol, btol, maxiter, force_maxiter, res, history, Exch::none);
 }
 
@@ -1197,6 +1523,9 @@ static int cgnr_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *
 extern "C" int jh_cgnr_solve(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter,
                              int force_maxiter, jh_lsqr_result *res, double *history)
 {
+    bool took = false;
+    JH_TRY(cg_dev_impl(op, b, x, use_x0, damp, atol, btol, maxiter, force_maxiter, res, history, false, &took));  // small operators: recurrences on the device
+    if (took) return JH_OK;
     return cgnr_impl(1, &op, &b, &x, use_x0, damp, atol, btol, maxiter, force_maxiter, res, history, Exch::none);
 }
 

@@ -79,3 +79,58 @@ def test_graph_replay_survives_scratch_growth_and_other_operators(Jets, oracle):
         Jets.fill_(d, 0)
         Jets.mul_(d, A, m)
         assert_bits_equal(d.to_numpy(), want, "after the scratch buffer moved")
+
+
+# ---- round 4: CGLS and CG on the normal equations with the recurrences on the device (jh_lsqr.hip: cg_dev_impl) --------------------------
+@pytest.mark.parametrize("solver", ["cgnr", "cgls"])
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
+def test_graph_replayed_cg_loops_of_small_operators_have_the_bits_of_the_host_driven_loop(Jets, oracle, dt, solver):
+    """Small operators (docs/src/index.md:235-246: the iterative solver over the block operator): an iteration of CGLS / of CG through
+    the fused A'A is 4-5 graph nodes whose coefficients live in device memory; with lsqr_graph = 0 the same kernels run eagerly and the
+    host applies the same two scalar updates between them.  x, the iteration count, the stopping rule and the whole history must be
+    IDENTICAL -- with early stopping, damping, a warm start, forced iterations and a single iteration; and within solver tolerance of the
+    loops large / partitioned operators take (cg_dev = 0) and of the textbook fp64 CPU CGLS."""
+    from oracle import cgls_ref
+
+    from .helpers import make_tall_diag
+
+    J = Jets
+    nrow, shape = 9, (32, 16, 8)
+    A, _, _, diags = make_tall_diag(J, oracle, dt, nrow, shape)
+    n = int(np.prod(shape))
+    hb = (u01(oracle, dt, 71, 0, nrow * n) - dt(0.5)).astype(dt)
+    x0 = J.rand(J.domain(A), seed=72, stream=0)
+    solve = getattr(J, solver)
+    cases = (dict(maxiter=25, atol=0.0, btol=0.0), dict(maxiter=60, atol=1e-4, btol=1e-4), dict(maxiter=30, atol=0.0, btol=0.0, damp=0.25),
+             dict(maxiter=17, atol=0.0, btol=0.0, x0=x0), dict(maxiter=1, atol=0.0, btol=0.0), dict(maxiter=9, atol=1e-2, btol=1e-2, force_maxiter=True),
+             dict(maxiter=11, atol=0.0, btol=0.0, damp=0.5, x0=x0))
+    for kw in cases:
+        out = {}
+        for mode in ("graph", "host", "large"):
+            J.tune(lsqr_graph=0 if mode == "host" else 1, cg_dev=0 if mode == "large" else 1)
+            try:
+                r = solve(A, J.from_numpy(hb, J.range(A)), **kw)
+                out[mode] = (r, J.tune_get("last_cg_graph"))
+            finally:
+                J.tune(lsqr_graph=1, cg_dev=1)
+        (rg, replays), (rh, zero), (rl, _) = out["graph"], out["host"], out["large"]
+        assert zero == 0 and (replays > 0 or kw["maxiter"] == 1), "the graph path ran (and only when asked)"
+        assert (rg.itn, rg.istop) == (rh.itn, rh.istop), kw
+        assert_bits_equal(rg.x.to_numpy(), rh.x.to_numpy(), f"x, {kw}")
+        assert rg.history == rh.history, kw
+        for f in ("r1norm", "r2norm", "arnorm", "xnorm"):
+            assert getattr(rg, f) == getattr(rh, f), (f, kw)
+        single = np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64))
+        tol = 2e-4 if single else 1e-9
+        if "force_maxiter" not in kw and kw["atol"] == 0.0:
+            assert rl.itn == rg.itn
+            np.testing.assert_allclose(rg.x.to_numpy(), rl.x.to_numpy(), rtol=tol, atol=tol * 1e-1)
+            # the textbook fp64 loop (with its q = A p in a range-sized vector) on the host copies of the same data
+            D = np.stack([d.astype(np.complex128 if np.iscomplexobj(d) else np.float64) for d in diags])
+            mv = lambda v: (D * v[None, :]).ravel()
+            rmv = lambda u: (np.conj(D) * u.reshape(nrow, n)).sum(axis=0)
+            ref = cgls_ref.cgls_fp64(mv, rmv, hb.astype(D.dtype), n, x0=None if "x0" not in kw else x0.to_numpy().ravel(order="F").astype(D.dtype),
+                                     damp=kw.get("damp", 0.0), atol=0.0, btol=0.0, maxiter=kw["maxiter"])
+            xr = ref[0] if isinstance(ref, tuple) else ref.x
+            np.testing.assert_allclose(rg.x.to_numpy().ravel(order="F"), np.asarray(xr).astype(dt), rtol=tol, atol=tol * 1e-1)
+    J.close(A)

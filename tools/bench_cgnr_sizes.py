@@ -31,20 +31,24 @@ for nrow, edge in ((64, 64), (256, 64), (64, 128), (256, 128), (1024, 128), (256
         J.mul_(y, N, x_true)
     e1 = J.Event().record()
     t_n = e0.elapsed_ms(e1) / reps
-    out = []
-    iters = 12
-    for solve in (lambda: J.cgnr(A, b, maxiter=iters, atol=0.0, btol=0.0, force_maxiter=True),
-                  lambda: J.lsqr(A, b, maxiter=iters, atol=0.0, btol=0.0, conlim=0.0, force_maxiter=True, overwrite_b=True),
-                  lambda: J.cgls(A, b, maxiter=iters, atol=0.0, btol=0.0, force_maxiter=True, overwrite_b=True)):
-        for rep in range(2):                                   # the second run is timed (the first carries the lazy per-operator measurements)
+    out, marg = [], []
+    small = 3.0 * nrow * edge ** 3 * 4 < (1 << 30)             # the sizes whose loops keep their recurrences on the device (graph-replayed)
+    for solve in (lambda k: J.cgnr(A, b, maxiter=k, atol=0.0, btol=0.0, force_maxiter=True),
+                  lambda k: J.lsqr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, force_maxiter=True, overwrite_b=True),
+                  lambda k: J.cgls(A, b, maxiter=k, atol=0.0, btol=0.0, force_maxiter=True, overwrite_b=True)):
+        took = {}
+        for iters in ((12, 12, 112) if small else (12, 12)):   # 12 iterations twice (the first run carries the lazy per-operator measurements), then 112
             J.mul_(b, A, x_true)                               # LSQR / CGLS use b's storage (no range-sized allocation inside the timed solve)
             J.synchronize()
             t0 = time.perf_counter()
-            r = solve()
+            r = solve(iters)
             J.synchronize()
-            dt = time.perf_counter() - t0
-        out.append(1e3 * dt / max(r.itn, 1))
-    print(f"{nrow:5d} x {edge}^3   {t_n:9.3f} ms   {out[0]:9.3f} ms ({out[0] / t_n:4.2f}x)   {out[1]:9.3f} ms   {out[2]:9.3f} ms", flush=True)
+            took[iters] = (time.perf_counter() - t0, r.itn)
+        out.append(1e3 * took[12][0] / max(took[12][1], 1))
+        # what ONE MORE iteration costs (set-up -- work vectors, ||b||, A'b, graph capture -- cancels): (t(112) - t(12)) / 100
+        marg.append(1e3 * (took[112][0] - took[12][0]) / max(took[112][1] - took[12][1], 1) if small and took[112][1] > took[12][1] else float("nan"))
+    print(f"{nrow:5d} x {edge}^3   {t_n:9.3f} ms   {out[0]:9.3f} ms ({out[0] / t_n:4.2f}x)   {out[1]:9.3f} ms   {out[2]:9.3f} ms"
+          + (f"   | per further iteration: CGNR {1e3 * marg[0]:6.1f} us  LSQR {1e3 * marg[1]:6.1f} us  CGLS {1e3 * marg[2]:6.1f} us" if small else ""), flush=True)
     J.close(A)
     del A, coeff, N, b, y, x_true
     import gc
