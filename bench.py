@@ -93,6 +93,7 @@ def parse_args():
     ap.add_argument("--placement", choices=("probe", "none"), default="probe",
                     help="probe: the coefficient slab and the range vector come from Jets.stream_pair -- candidate allocations are measured (forward + "
                          "adjoint of the operator itself, outside every timed region) and the best ordered pair is kept; none: plain allocation order")
+    ap.add_argument("--fwd-walk", type=int, default=-1, help="pin the tall forward's grid walk to candidate K (0..7) instead of measuring it lazily (profiling one instantiation)")
     ap.add_argument("--placement-candidates", type=int, default=3, help="allocations measured by --placement probe (2: both orders of two slabs)")
     ap.add_argument("--mode", choices=("auto", "ranks", "team"), default=os.environ.get("BENCH_MODE", "auto"),
                     help="N > 1: one worker process per GPU (ranks), ONE worker driving all GPUs (team), or ranks with a team fallback (auto)")
@@ -589,8 +590,10 @@ def worker_ranks(args):
     # Which allocation holds the coefficients and which the range vector is measured, not left to the order of two hipMallocs: on this chip
     # a kernel that reads one 64 GiB slab and writes another runs up to 10 % apart between the two directions and between slabs, differently
     # in every process (jets.jl_amd/placement.py, profiles/exp_r03_swap_roles.txt).  Same values either way (seeded by element index).
+    spare = []                                                             # world == 1: the candidates not kept stay for the allocation-order leg below
     if args.placement == "probe":
-        coeff, d, placement = J.stream_pair(Rloc, candidates=args.placement_candidates)
+        coeff, d, placement = J.stream_pair(Rloc, candidates=args.placement_candidates, keep_all=(world == 1))
+        spare = placement.pop("all", [])
         J.rand_(coeff, seed=1, stream=0, index_base=part.first * n)        # all diagonals of this rank: one slab
         J.rand_(d, seed=3, stream=0, index_base=part.first * n)
     else:
@@ -598,6 +601,8 @@ def worker_ranks(args):
         d = J.rand(Rloc, seed=3, stream=0, index_base=part.first * n)
         placement = {"probed": False}
     A = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
+    if args.fwd_walk >= 0:
+        J.op_tune_set(A, "fwd_walk", args.fwd_walk)
     m = J.rand(J.domain(A), seed=2, stream=0)
     mt = J.zeros(J.domain(A))
     shard = J.rowpart.for_device(part, A) if dist is not None else None
@@ -718,9 +723,13 @@ def worker_ranks(args):
             tj = json.load(open(tpath))
             if tj.get("nblocks") == nloc and tj.get("edge") == edge:
                 key = dom["kernel"].split("+")[0]
-                if key == "k_tall_diag_fwd":                            # PMC traffic is recorded per grid walk; the column-persistent
-                    persistent = J.tune_get("last_fwd_rows_per_wg") >= nloc   # walk re-reads no m, like the row-concurrent one
-                    key += "@walk%d" % (1 if persistent else J.tune_get("last_fwd_walk"))
+                if key == "k_tall_diag_fwd":                            # PMC traffic is recorded per forward-walk CANDIDATE (round 4: one
+                    cand = J.op_tune_get(A, "fwd_walk")                 # instantiation per pass, tools/prof_walk_pmc.sh); rounds 1-2 keyed the
+                    if cand >= 0 and f"{key}@walk{cand}#round" in tj and tj[f"{key}@walk{cand}#round"] >= "r04":   # grid ORDER (0 sequential / 1 concurrent)
+                        key += "@walk%d" % cand
+                    else:
+                        persistent = J.tune_get("last_fwd_rows_per_wg") >= nloc   # the column-persistent walk re-reads no m, like the row-concurrent one
+                        key += "@walk%d" % (1 if persistent else J.tune_get("last_fwd_walk"))
                 traffic = tj.get(key)
                 if traffic is None:
                     key = key.split("@")[0]                              # counters taken over the walks the lazy autotune tried
@@ -821,6 +830,50 @@ def worker_ranks(args):
                          "rel_err_vs_x_true": float(J.norm(err)) / float(J.norm(x_true)), "istop": res.istop, "driver": "jh_cgnr_solve",
                          "schedule": "CG on (A'A) x = A'b: one adjoint pass for A'b, then ONE fused A'A pass per iteration (jh_blockop_normal_mul: N n s bytes); b only read"}
 
+    # ---- world == 1, after everything that needs the data: the SAME pair in plain allocation order ---------------------------------
+    # The headline's operands sit where the probe put them; a caller who allocates coefficients and range vector one after the other
+    # and never asks (zeros(range(A)), A*m) gets the process's first two allocations in that order.  One extra run -- the first candidate
+    # as the coefficient slab, the second as the range vector, its own operator (and lazy walk measurement), warm-up, then the same
+    # number of timed steps -- outside the headline's timed region, so that both figures are on the driver's line.
+    placement_none = None
+    if world == 1 and placement.get("probed") and len(spare) >= 2:
+        fwd_walk_hl = J.op_tune_get(A, "fwd_walk")
+        if placement.get("kept") == [0, 1]:
+            placement_none = {"value": args.steps / elapsed, "unit": "pairs/s", "same_run_as_headline": True,
+                              "note": "the probe kept the allocation order: the headline IS the allocation-order figure"}
+        else:
+            J.close(A)
+            c0, d0 = spare[0], spare[1]
+            J.rand_(c0, seed=1, stream=0, index_base=part.first * n)
+            J.rand_(d0, seed=3, stream=0, index_base=part.first * n)
+            A0 = J.blockop([[J.JopDiagonal(c)] for c in c0.arrays])
+            if args.fwd_walk >= 0:
+                J.op_tune_set(A0, "fwd_walk", args.fwd_walk)
+            J.mul_(d0, A0, m)
+            J.mul_(mt, A0.H, d0)
+            k0 = 1
+            while J.op_tune_get(A0, "fwd_walk") == -1 and 0 < J.op_tune_get(A0, "fwd_trials") and k0 < 32:
+                J.mul_(d0, A0, m)
+                J.synchronize()
+                k0 += 1
+            for _ in range(args.warmup):
+                J.mul_(d0, A0, m)
+                J.mul_(mt, A0.H, d0)
+            fence()
+            t0n = time.perf_counter()
+            for _ in range(args.steps):
+                J.mul_(d0, A0, m)
+                J.mul_(mt, A0.H, d0)
+            fence()
+            t_none = time.perf_counter() - t0n
+            placement_none = {"value": args.steps / t_none, "unit": "pairs/s", "ms_per_step": 1e3 * t_none / args.steps, "steps": args.steps,
+                              "same_run_as_headline": False, "fwd_walk_candidate": J.op_tune_get(A0, "fwd_walk"),
+                              "note": "coefficients in the process's first 64 GiB allocation, range vector in its second (what --placement none "
+                                      "does from the start); timed after the headline, same process, same warm-up and step count"}
+            A, A0 = A0, None                                          # (the line below reports the headline's walk: kept above)
+        placement_none["headline_fwd_walk_candidate"] = fwd_walk_hl
+    else:
+        fwd_walk_hl = J.op_tune_get(A, "fwd_walk")
     if rank == 0:
         pairs_per_s = args.steps / elapsed
         out = {
@@ -843,7 +896,7 @@ def worker_ranks(args):
                 "parallelism": f"row-partition x{world}" + (f" + {os.environ.get('BENCH_BACKEND', 'RCCL')} all-reduce({n * s / 2**20:.0f} MiB, pipelined in 4 chunks) in adjoint" if world > 1 else ""),
                 "fwd_grid_walk": ("column-persistent (a workgroup streams every block row)" if J.tune_get("last_fwd_rows_per_wg") >= nloc
                                   else {0: "sequential row sweep", 1: "all rows concurrent"}.get(J.tune_get("last_fwd_walk"), "banded")),
-                "fwd_walk_choice": {"candidate": J.op_tune_get(A, "fwd_walk"), "setup_forward_calls": setup_forwards},
+                "fwd_walk_choice": {"candidate": fwd_walk_hl, "setup_forward_calls": setup_forwards},
                 "placement": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in placement.items()},
                 "tune": {k: J.tune_get(k) for k in ("fwd_group", "fwd_unroll", "fwd_wg", "fwd_order", "adj_unroll", "adj_depth", "adj_wg", "nt", "autotune")},
             },
@@ -862,6 +915,8 @@ def worker_ranks(args):
             "kernels": kernels,
         }
         out.update(extra)
+        if placement_none is not None:
+            out["placement_none"] = placement_none
         if world > 1:
             out.update(launch_note("ranks: one process per GPU, torch.distributed over " + ("RCCL" if backend == "nccl" else backend)))
         if multi is not None:

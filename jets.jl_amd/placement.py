@@ -79,11 +79,11 @@ def probe_stream_direction(x, y, calls: int = 3):
     return _forward_ms(x, y, calls), _forward_ms(y, x, calls)
 
 
-def stream_pair(R, calls: int = 3, candidates: int = 2):
+def stream_pair(R, calls: int = 3, candidates: int = 2, keep_all: bool = False):
     """Two uninitialised vectors of the space R, ordered (the one to read from, the one to write to), and what was measured:
     {"probed": bool, "fwd_ms_kept", "adj_ms_kept", "pair_ms_kept": float, "pair_ms_other": [...]}.  `candidates` > 2 allocates that many vectors, measures every ordered pair
     and gives the others back (a third candidate makes it likely that one of them covers the device's fast-write region; it needs the
-    memory for the moment of the probe)."""
+    memory for the moment of the probe).  info["kept"] = the indices, in allocation order, of the two vectors returned."""
     nbytes = R.length() * np.dtype(R.eltype()).itemsize
     uniform = isinstance(R, JetBSpace) and len({s.size() for s in R.spaces}) == 1 and len(R.spaces) >= 2
     if nbytes < PROBE_FROM_BYTES or not uniform:
@@ -107,9 +107,14 @@ def stream_pair(R, calls: int = 3, candidates: int = 2):
             if i != j:
                 timed[(i, j)] = _pair_ms(xs[i], xs[j], calls)
     (i, j), best = builtins.min(timed.items(), key=lambda kv: kv[1][0] + kv[1][1])     # forward + adjoint: the pair a solver iteration pays for
-    for k, v in enumerate(xs):
-        if k not in (i, j):
-            v.close()
+    if not keep_all:
+        for k, v in enumerate(xs):
+            if k not in (i, j):
+                v.close()
     others = sorted(round(f + a, 3) for k, (f, a) in timed.items() if k != (i, j))
-    return xs[i], xs[j], {"probed": True, "candidates": candidates, "fwd_ms_kept": best[0], "adj_ms_kept": best[1], "pair_ms_kept": best[0] + best[1],
-                          "pair_ms_other": others}
+    info = {"probed": True, "candidates": candidates, "fwd_ms_kept": best[0], "adj_ms_kept": best[1], "pair_ms_kept": best[0] + best[1],
+            "pair_ms_other": others, "kept": [i, j],                       # allocation order would have been [0, 1]
+            "pair_ms_allocation_order": timed[(0, 1)][0] + timed[(0, 1)][1]}
+    if keep_all:                                                           # the caller closes what it does not keep (bench.py: its allocation-order leg)
+        info["all"] = xs
+    return xs[i], xs[j], info
