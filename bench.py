@@ -220,6 +220,21 @@ class Supervisor:
         self.procs = {}
         os.makedirs(hbdir, exist_ok=True)
 
+    def limit_for(self, phase):
+        """Seconds without a heartbeat that mean 'stalled' in this phase.  A phase that is ONE long call by construction -- a whole solve
+        after beat('lsqr'), the fence behind `--steps` asynchronously enqueued pairs -- gets a limit that grows with the work asked for
+        (a generous bound per unit: a pair takes 0.05 s and a solver iteration 0.04 s at the headline size), so that a healthy long run
+        is not reported as stalled; a stuck collective still is."""
+        if phase in IMPORT_PHASES:
+            return self.limit_import
+        unit = float(os.environ.get("BENCH_WATCHDOG_UNIT_S", "2"))
+        a = self.args
+        if phase in ("lsqr", "cgls", "cgnr"):
+            return max(self.limit, unit * max(getattr(a, "lsqr", 0) or 0, getattr(a, "cgls", 0) or 0, getattr(a, "cgnr", 0) or 0, 1))
+        if phase.startswith("step ") or phase in ("warmup-done", FIRST_COLLECTIVE, "data-resident"):
+            return max(self.limit, unit * max(getattr(a, "steps", 0) or 0, 1))
+        return self.limit
+
     # -- files
     def hb(self, r):
         return os.path.join(self.hbdir, f"rank{r}.hb")
@@ -276,7 +291,14 @@ class Supervisor:
             self.start_worker(r, dict(rank_env(r), BENCH_LAUNCH_NOTE=json.dumps({"launched_by": self.launched_by, "mode_requested": self.args.mode})))
         live = set(self.my_ranks)
         failure = None
-        while live and failure is None:
+        t_own_done = time.time()
+
+        def others_running():                                              # the leader stays until EVERY rank has said 'worker-done' (or one has failed)
+            if not self.leader:
+                return False
+            return any((_last_beat(self.hb(q)) or (0, ""))[1] != "worker-done" for q in range(self.world))
+
+        while (live or others_running()) and failure is None:
             for r in sorted(live):
                 code = self.procs[r].poll()
                 if code is None:
@@ -288,14 +310,19 @@ class Supervisor:
                     with open(self.hb(r), "a") as f:
                         f.write(f"{time.time():.3f} DIED rc={code}\n")
             now = time.time()
+            if live:
+                t_own_done = now
             if failure is None and self.leader:
                 for r in range(self.world):                            # the leader sees every rank's file (one node)
                     lb = _last_beat(self.hb(r))
                     if lb is None:
+                        if not live and now - t_own_done > self.limit:     # its own ranks are through and rank r has never written a line
+                            failure = f"rank {r} never reported (no heartbeat file {self.limit:.0f} s after the leader's own ranks finished)"
+                            break
                         continue
                     if lb[1].startswith("DIED"):
                         failure = f"rank {r} died ({lb[1]}; last phase '{([p for p in _phases(self.hb(r)) if not p.startswith('DIED')] or ['?'])[-1]}')"
-                    elif lb[1] != "worker-done" and now - lb[0] > (self.limit_import if lb[1] in IMPORT_PHASES else self.limit):
+                    elif lb[1] != "worker-done" and now - lb[0] > self.limit_for(lb[1]):
                         failure = f"rank {r} stalled: no heartbeat for {now - lb[0]:.0f} s in phase '{lb[1]}'"
                     if failure is not None:
                         break
@@ -329,7 +356,7 @@ class Supervisor:
                 return code, (None if code == 0 else f"the team-mode child exited with {code} in phase '{(_last_beat(self.hb(0)) or (0, '?'))[1]}'")
             lb = _last_beat(self.hb(0))
             now = time.time()
-            if lb and now - lb[0] > (self.limit_import if lb[1] in IMPORT_PHASES else self.limit):
+            if lb and now - lb[0] > self.limit_for(lb[1]):
                 self.stop_children()
                 return 1, f"the team-mode child stalled: no heartbeat for {now - lb[0]:.0f} s in phase '{lb[1]}'"
             time.sleep(0.05)
@@ -507,6 +534,13 @@ def fake_worker(args):
     if os.environ.get("BENCH_TEST_FAIL_AFTER_COLLECTIVE") == who:
         raise SystemExit(f"worker {who}: BENCH_TEST_FAIL_AFTER_COLLECTIVE")
     time.sleep(0.3)
+    if os.environ.get("BENCH_TEST_LONG_SOLVE_S"):                      # one long call after beat('lsqr'): healthy, silent
+        beat("lsqr")
+        time.sleep(float(os.environ["BENCH_TEST_LONG_SOLVE_S"]))
+    if os.environ.get("BENCH_TEST_SLOW_RANK") == who:                  # a rank that is still working when rank 0 has finished
+        time.sleep(float(os.environ.get("BENCH_TEST_SLOW_RANK_S", "3")))
+        if os.environ.get("BENCH_TEST_SLOW_RANK_FAILS") == "1":
+            raise SystemExit(f"worker {who}: BENCH_TEST_SLOW_RANK_FAILS")
     if rank == 0:
         out = {"metric": "FAKE (supervisor test, nothing was measured)", "value": None, "n_gpus": args.gpus}
         out.update(launch_note("team" if team else "ranks"))

@@ -207,7 +207,11 @@ int jh_bcast_apply_many(int count, const jh_bcast *const *progs, jh_bvec *const 
 int jh_bcast_destroy(jh_bcast *bc);
 /* dot(x,y), src/Jets.jl:850-856 (conjugates x). fp64 accumulation, deterministic order. */
 int jh_dot(const jh_bvec *x, const jh_bvec *y, double *re, double *im);
-/* norm(x,p), src/Jets.jl:834-848: p = 2, 1, 0, +Inf, -Inf or any other real */
+/* norm(x,p), src/Jets.jl:834-848: p = 2, 1, 0, +Inf, -Inf or any other real.  fp64 accumulation over the whole vector, result in
+ * double.  Deviation from the reference, kept on purpose: the reference forms norm(block, p)^p in the ELEMENT precision (843-846), so a
+ * BlockArray whose block norms pass sqrt(floatmax) (1.8e19 in Float32) gives Inf there and block norms below sqrt(floatmin) give 0; here
+ * the powers are summed in fp64 and, when even that sum leaves the double range, once more on x / 2^k -- the answer is the true norm.
+ * (A plain array, one block, behaves like the stdlib's norm, which rescales too.)  A vector of zeros costs one pass. */
 int jh_norm(const jh_bvec *x, double p, double *out);
 /* extrema(x), src/Jets.jl:870-878 (real dtypes) */
 int jh_extrema(const jh_bvec *x, double *mn, double *mx);

@@ -3307,8 +3307,8 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
     }
     hipStream_t st = jh_ctx().stream;
     hipError_t e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_blocks, host.size() * sizeof(jh_dev_block));
-    if (e == hipSuccess) e = hipMalloc((void **)&op->dev_row_off, sizeof(int64_t) * ((size_t)nrow + 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&op->dev_col_off, sizeof(int64_t) * ((size_t)ncol + 1));
+    if (e == hipSuccess) e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_row_off, sizeof(int64_t) * ((size_t)nrow + 1));
+    if (e == hipSuccess) e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_col_off, sizeof(int64_t) * ((size_t)ncol + 1));
     if (e == hipSuccess) e = hipMemcpyAsync(op->dev_blocks, host.data(), host.size() * sizeof(jh_dev_block), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(op->dev_row_off, op->row_off.data(), sizeof(int64_t) * ((size_t)nrow + 1), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(op->dev_col_off, op->col_off.data(), sizeof(int64_t) * ((size_t)ncol + 1), hipMemcpyHostToDevice, st);
@@ -3317,13 +3317,13 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
     for (int64_t i = 0; i < nrow; i++)
         for (int64_t j = 0; j < ncol; j++)
             if (op->blocks[(size_t)(i + j * nrow)].kind != JH_OP_ZERO) { touched[(size_t)i] = 1; break; }
-    if (e == hipSuccess) e = hipMalloc((void **)&op->dev_row_touched, (size_t)nrow);
+    if (e == hipSuccess) e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_row_touched, (size_t)nrow);
     if (e == hipSuccess) e = hipMemcpyAsync(op->dev_row_touched, touched.data(), (size_t)nrow, hipMemcpyHostToDevice, st);
     std::vector<int64_t> dims;
     if (op->small_loop) {
         dims.resize(2 * host.size());
         for (size_t k = 0; k < host.size(); k++) { dims[2 * k] = op->blocks[k].nr; dims[2 * k + 1] = op->blocks[k].nc; }
-        if (e == hipSuccess) e = hipMalloc((void **)&op->dev_dims, sizeof(int64_t) * dims.size());
+        if (e == hipSuccess) e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_dims, sizeof(int64_t) * dims.size());
         if (e == hipSuccess) e = hipMemcpyAsync(op->dev_dims, dims.data(), sizeof(int64_t) * dims.size(), hipMemcpyHostToDevice, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);   // host staging vectors die at return

@@ -113,7 +113,7 @@ void free_side_objects(comm_state &s)
 
 int make_side_objects(comm_state &s)
 {
-    hipError_t e = hipMalloc((void **)&s.scalar_dev, sizeof(double) * 64);
+    hipError_t e = jh_device_malloc(jh_ctx().device, (void **)&s.scalar_dev, sizeof(double) * 64);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.cstream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_main, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_comm, hipEventDisableTiming);

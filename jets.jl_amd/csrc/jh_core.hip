@@ -88,14 +88,19 @@ size_t jh_slab_cached_bytes(int device)
     return sum;
 }
 
-void jh_slab_trim(int device)
+void jh_slab_trim(int device)                                  // device < 0: every device
 {
     std::vector<cached_slab> out;
     {
         std::lock_guard<std::mutex> lock(g_slab_mutex);
-        out.swap(g_slabs[device]);
+        if (device >= 0) out.swap(g_slabs[device]);
+        else
+            for (auto &kv : g_slabs) {
+                out.insert(out.end(), kv.second.begin(), kv.second.end());
+                kv.second.clear();
+            }
     }
-    for (const cached_slab &c : out) (void)hipFree(c.p);
+    for (const cached_slab &c : out) (void)hipFree(c.p);   // (hipFree takes a pointer of any device)
 }
 
 hipError_t jh_slab_alloc(int device, size_t bytes, void **out)
@@ -132,6 +137,13 @@ void jh_slab_free(int device, void *p, size_t bytes)
 {
     if (!p) return;
     if (g_slab_cache_on.load() && bytes >= SLAB_CACHE_MIN && bytes <= slab_cap_bytes()) {
+        // hipFree waits for the whole device; a slab that goes to the cache instead must get the same guarantee before its next owner
+        // zero-fills or writes it: the caller has waited for the owning context's stream only, and work of OTHER streams may still touch
+        // the slab -- ranged all-reduces on a communicator's exchange stream (an early error return of a solver destroys its work
+        // vectors under them), a stream the application installed with jh_set_stream and replaced since, torch / RCCL streams on a
+        // wrapped vector.  Microseconds on an idle device, against the seconds the re-used slab saves.  (The device is current: both
+        // callers come through jh_quiesce_scope / the vector's own context.)
+        (void)hipDeviceSynchronize();
         std::vector<cached_slab> evict;
         {
             std::lock_guard<std::mutex> lock(g_slab_mutex);
@@ -144,6 +156,18 @@ void jh_slab_free(int device, void *p, size_t bytes)
                 evict.push_back(victim);
             }
             v.push_back(cached_slab{p, bytes});
+            // ... and the cache never holds the device's LAST 32 GiB either: live vectors plus cached slabs must leave that much to whoever
+            // allocates without going through jh_device_malloc's evict-and-retry (RCCL, torch in the same process).  Cached memory is
+            // still allocated as far as the driver can tell, so `free` below does not count it.
+            size_t fr = 0, tot = 0;
+            const size_t floor_bytes = (size_t)32 << 30;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > ((size_t)64 << 30) && fr < floor_bytes) {
+                size_t need = floor_bytes - fr;
+                while (need > 0 && slab_pick_victim(v, need, &victim)) {
+                    evict.push_back(victim);
+                    need = victim.bytes >= need ? 0 : need - victim.bytes;
+                }
+            }
         }
         for (const cached_slab &c : evict) (void)hipFree(c.p);
         return;
@@ -232,7 +256,7 @@ static int ctx_create(int device, bool primary, int *id_out)
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(e, "hipStreamCreateWithFlags");
     c->stream = c->own_stream;
-    e = hipMalloc((void **)&c->red_dev, sizeof(double) * 4 * JH_RED_SLOTS);
+    e = jh_device_malloc(c->device, (void **)&c->red_dev, sizeof(double) * 4 * JH_RED_SLOTS);
     if (e != hipSuccess) return fail(e, "hipMalloc");
     e = hipMemsetAsync(c->red_dev, 0, sizeof(double) * 4 * JH_RED_SLOTS, c->own_stream);   // (not the legacy stream: another thread may be capturing)
     if (e == hipSuccess) e = hipStreamSynchronize(c->own_stream);
@@ -798,7 +822,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "adj_wg")) { JH_REQUIRE(one_of({0, 256, 512, 1024}), "adj_wg must be 0 (auto), 256, 512 or 1024"); c.adj_wg = value; }
     else if (!strcmp(name, "fwd_order")) { JH_REQUIRE(value >= -1 && value <= 65536, "fwd_order must be -1 (auto), 0 (sequential), 1 (all rows) or k > 1 (k row groups per band)"); c.fwd_order = value; }
     else if (!strcmp(name, "nt")) { c.nt = value ? 1 : 0; }
-    else if (!strcmp(name, "slab_cache")) { g_slab_cache_on.store(value ? 1 : 0); if (!value) jh_slab_trim(c.device); }
+    else if (!strcmp(name, "slab_cache")) { g_slab_cache_on.store(value ? 1 : 0); if (!value) jh_slab_trim(-1); }   // the switch is process-wide: so is the trim
     else if (!strcmp(name, "bcast_item_fast")) { JH_REQUIRE(value >= -1 && value <= 1, "bcast_item_fast must be -1 (auto), 0 or 1"); c.bcast_item_fast = value; }
     else if (!strcmp(name, "adj_split")) { JH_REQUIRE(value >= -1 && value <= 65535, "adj_split must be -1 (auto), 0 (never: ordered walk) or the number of row parts"); c.adj_split = value; }
     else if (!strcmp(name, "adj_rows_per_launch")) { JH_REQUIRE(value >= 0, "adj_rows_per_launch must be >= 0"); c.adj_rows_per_launch = value; }

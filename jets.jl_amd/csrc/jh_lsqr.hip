@@ -622,8 +622,8 @@ static int lsqr_graph_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use
             if (hist) (void)hipFree(hist);
         }
     } d;
-    JH_CHECK_HIP(hipMalloc((void **)&d.st, sizeof(LsqrDev)));
-    JH_CHECK_HIP(hipMalloc((void **)&d.hist, sizeof(double) * 2 * (size_t)maxiter));
+    JH_CHECK_HIP(jh_device_malloc(c.device, (void **)&d.st, sizeof(LsqrDev)));
+    JH_CHECK_HIP(jh_device_malloc(c.device, (void **)&d.hist, sizeof(double) * 2 * (size_t)maxiter));
     LsqrDev h{};
     h.alpha = alpha;
     h.beta = beta;

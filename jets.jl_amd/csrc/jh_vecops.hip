@@ -327,6 +327,7 @@ __device__ inline void red_elem(const S *xe, const S *ye, double p, double scale
         if (E == 2) a1 += xr * yi - xi * yr;
     } else if (OP == RED_SUMSQ) {
         a0 += xr * xr + xi * xi;
+        a1 += (xr != 0.0 || xi != 0.0) ? 1.0 : 0.0;          // elements that are not zero: an all-zero vector needs no rescaled second pass (jh_norm)
     } else if (OP == RED_EXTREMA) {
         a0 = (xr < a0 || xr != xr) ? xr : a0;
         a1 = (xr > a1 || xr != xr) ? xr : a1;
@@ -739,7 +740,9 @@ int jh_norm(const jh_bvec *x, double p, double *out)
         // The stdlib's block norms rescale (BLAS nrm2 / generic_normp), so they neither overflow on 1e200 nor lose 1e-200.  The
         // plain sum above does when the powers leave the double range (only Float64 data can do that for p = 2): seen as an
         // infinite or vanishing sum, in which case the pass is repeated on x / 2^k with 2^k ~ max|x| (a power of two: exact).
-        if (p > 0 && (std::isinf(r0) || r0 < 1e-290)) {
+        // (An exactly zero vector -- x0 of a solver, a fresh zeros(R) -- also has a vanishing sum: the SUMSQ pass counts the elements
+        // that are not zero beside the sum, and zero of them means the answer is 0 without a second pass and its host round trip.)
+        if (p > 0 && (std::isinf(r0) || r0 < 1e-290) && !(two && r0 == 0.0 && r1 == 0.0)) {
             double big = 0, unused = 0;
             JH_TRY((reduce_dispatch<RED_MAXABS>(x->dtype, x->data, nullptr, x->length, p, &big, &unused)));
             if (big > 0 && std::isfinite(big)) {

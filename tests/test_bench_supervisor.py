@@ -113,3 +113,25 @@ def test_under_torch_distributed_run_only_the_leader_plans():
     out, lines, _ = run({"BENCH_TEST_NDEV": "1"}, "--gpus", "2", launcher=_torchrun(2), timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     assert len(lines) == 1 and lines[0]["launch_mode"] == "team" and lines[0]["launched_by"] == "torch.distributed.run"
+
+
+def test_a_long_silent_solve_is_not_a_stall_when_the_work_asked_for_explains_it():
+    """One J.lsqr call of --lsqr K iterations is silent by construction: the limit of that phase grows with K (round-3 advisor finding:
+    a healthy 120 s solve was reported as 'stalled')."""
+    env = {"BENCH_TEST_LONG_SOLVE_S": "4", "BENCH_WATCHDOG_S": "2", "BENCH_WATCHDOG_IMPORT_S": "5", "BENCH_WATCHDOG_UNIT_S": "0.1"}
+    out, lines, _ = run(env, "--gpus", "2", "--mode", "ranks", "--lsqr", "100")          # 100 iterations x 0.1 s = 10 s allowed
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    out, lines, _ = run(env, "--gpus", "2", "--mode", "ranks", "--lsqr", "10")           # 10 x 0.1 = 1 s -> the 2 s floor: a real stall
+    assert out.returncode != 0 and not lines and "stalled: no heartbeat" in out.stderr and "'lsqr'" in out.stderr
+
+
+def test_under_torch_distributed_run_the_leader_waits_for_every_rank():
+    """The leader used to return as soon as ITS rank had exited 0 (and removed the heartbeat directory under the other ranks): a
+    follower that is still working is waited for, and one that then fails makes the job fail."""
+    port = socket.socket(); port.bind(("127.0.0.1", 0)); p = port.getsockname()[1]; port.close()
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(p)]
+    out, lines, took = run({"BENCH_TEST_SLOW_RANK": "1", "BENCH_TEST_SLOW_RANK_S": "3"}, "--gpus", "2", "--mode", "ranks", launcher=launcher, timeout=180)
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    out, lines, took = run({"BENCH_TEST_SLOW_RANK": "1", "BENCH_TEST_SLOW_RANK_S": "3", "BENCH_TEST_SLOW_RANK_FAILS": "1"}, "--gpus", "2", "--mode", "ranks",
+                           launcher=launcher, timeout=180)
+    assert out.returncode != 0, "a rank failed after rank 0 had printed its line: the job must not report success"
