@@ -105,11 +105,20 @@ int jh_device_info(char *name, int name_cap, int64_t *total_mem, int64_t *free_m
 /* Slab cache.  The reference's style allocates range-sized temporaries all the time (`A*m` returns a fresh vector, `zeros(range(A))`
  * per composite stage, src/Jets.jl:399, 526-533), and hipMalloc of a 64 GiB slab costs 2-6 seconds on this machine whenever the
  * runtime goes to the driver for it (profiles/exp_r03_alloc_cost.txt).  So the device memory of a destroyed vector of 16 MiB or more
- * is kept (per device, never the last 32 GiB of it) and handed to the next jh_bvec_create of exactly that
- * size; when the cap is passed or the driver refuses an allocation of the library, slabs go back to it, chosen to cover the shortfall
- * with about the fewest bytes (re-used device memory is cleared by the driver at about 20 GB/s: that is where the seconds go).  jh_device_info counts cached memory as free.
+ * is kept (per device; the cache holds at most all but 32 GiB of the device, and cached plus live memory always leave the device's
+ * last 8 GiB to other allocators of the process -- RCCL, torch; knob "slab_free_floor_mib") and handed to the next jh_bvec_create of
+ * exactly that size -- after a device-wide synchronisation, as hipFree would have made; when a limit is passed or the driver refuses
+ * an allocation of the library, slabs go back to it, chosen to cover the shortfall with about the fewest bytes (re-used device memory
+ * is cleared by the driver at about 20 GB/s: that is where the seconds go).  jh_device_info counts cached memory as free.
  * jh_trim() returns it to the driver (before another library of the process needs the memory); jh_tune_set("slab_cache", 0) turns
- * the cache off (and empties it); jh_tune_get("slab_cached_mib") reads what it holds. */
+ * the cache off (and empties it, on every device); jh_tune_get("slab_cached_mib") reads what it holds.
+ * WHICH cached slab (round 4): the time to write a 64 GiB slab is a property of the slab on this chip (fill 7.2 or 6.4 TB/s; the
+ * tall forward into it 20.6-21.5 or 23.8-24.8 ms; the fast-write slabs read 3 % slower).  A slab of 4 GiB or more is probed once
+ * when it enters the cache (two fills of the dead memory, the second timed), and jh_tune_set("alloc_role", r) before an allocation says
+ * what the vector is for: 1 = an operator's output (the cached slab of its size with the fastest fill), 2 = data written once and
+ * read from then on (the slowest), 0 (default) = no preference, the most recently freed.  The host bindings set it around `A*m`
+ * (src/Jets.jl:399), stage temporaries (526-533) and rand / randn (105-108).  jh_tune_get("last_alloc_choice") = 100 x probed
+ * candidates + rank by fill time of the one taken (-1: no choice was made), "slab_probed" = cached slabs with a record. */
 int jh_trim(void);
 int jh_get_stream(void **hip_stream);    /* hipStream_t the library enqueues on                   */
 int jh_set_stream(void *hip_stream);     /* NULL restores the library's own stream                */

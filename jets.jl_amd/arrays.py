@@ -298,31 +298,45 @@ class BlockArray(_DevVec):
 
 
 # ------------------------------------------------------------------------------ factories ----------
-def _new_handle(block_lens: Sequence[int], T, undef: bool = False) -> C.c_void_p:
+ROLE_OUTPUT, ROLE_DATA = 1, 2      # what a big vector is for (knob alloc_role): an operator's output / data written once and read from then on
+_ROLE_FROM_BYTES = 4 << 30
+
+
+def _new_handle(block_lens: Sequence[int], T, undef: bool = False, role: int = 0) -> C.c_void_p:
     _device.init()
     h = C.c_void_p()
     create = lib.jh_bvec_create_uninit if undef else lib.jh_bvec_create
     lens = _i64arr(block_lens)
-    st = create(len(block_lens), lens, dtype_code(T), C.byref(h))
-    if st == 3:                                  # JH_ERR_NOMEM: vectors caught in reference cycles still hold device memory -- collect them and ask again
-        import gc
-
-        gc.collect()
+    # vectors of 4 GiB and more: the library's slab cache may hold several slabs of this size, and which of them is fast to WRITE is a
+    # property of the slab it has measured (include/jetship.h, knob alloc_role) -- say what this one is for
+    hint = role != 0 and builtins.sum(block_lens) * np.dtype(T).itemsize >= _ROLE_FROM_BYTES
+    if hint:
+        check(lib.jh_tune_set(b"alloc_role", role))
+    try:
         st = create(len(block_lens), lens, dtype_code(T), C.byref(h))
+        if st == 3:                              # JH_ERR_NOMEM: vectors caught in reference cycles still hold device memory -- collect them and ask again
+            import gc
+
+            gc.collect()
+            st = create(len(block_lens), lens, dtype_code(T), C.byref(h))
+    finally:
+        if hint:
+            lib.jh_tune_set(b"alloc_role", 0)
     check(st)
     return h
 
 
-def Array(R: JetAbstractSpace, undef: bool = False):
+def Array(R: JetAbstractSpace, undef: bool = False, role: int = 0):
     """Array(R) / zeros(R): device storage for the space (src/Jets.jl:105-108, 922-924).  Zero-filled unless `undef=True`
-    (Julia's Array{T}(undef, ...): for an output the next call overwrites entirely; the fill of 64 GiB is 12 ms)."""
+    (Julia's Array{T}(undef, ...): for an output the next call overwrites entirely; the fill of 64 GiB is 12 ms).  `role`: what a
+    vector of 4 GiB or more is for (ROLE_OUTPUT / ROLE_DATA), a hint for the library's choice among cached slabs."""
     if isinstance(R, JetSSpace):  # src/Jets.jl:514-516
         from .symmetric import zeros_sym
 
         return zeros_sym(R)
     if isinstance(R, JetBSpace):
-        return BlockArray(_new_handle(R.block_lengths(), R.eltype(), undef), R.spaces, R.eltype())
-    return DeviceArray(_new_handle([R.length()], R.eltype(), undef), R.size(), R.eltype())
+        return BlockArray(_new_handle(R.block_lengths(), R.eltype(), undef, role), R.spaces, R.eltype())
+    return DeviceArray(_new_handle([R.length()], R.eltype(), undef, role), R.size(), R.eltype())
 
 
 
@@ -345,7 +359,7 @@ def rand(R: JetAbstractSpace, seed: int | None = None, stream: int | None = None
         from .symmetric import rand_sym
 
         return rand_sym(R, seed=seed, stream=stream, index_base=index_base)
-    x = Array(R, undef=True)                               # the generator writes every element
+    x = Array(R, undef=True, role=ROLE_DATA)               # the generator writes every element (once: data to read from then on)
     if seed is None:
         seed, stream = _DEFAULT_SEED, next(_rand_counter)
     check(lib.jh_fill_uniform(x.handle, int(seed), int(stream or 0), int(index_base)))

@@ -19,6 +19,9 @@
 //    the reference's loop order with the same rounding sequence.
 #include "jh_internal.h"
 #include <type_traits>
+#include <tuple>
+#include <mutex>
+#include <map>
 
 namespace {
 
@@ -1940,6 +1943,10 @@ const TallShape k_fwd_candidates[K_FWD_CANDIDATES] = {TallShape{1024, 8, 16, 0},
                                                       TallShape{256, 4, 16, 1}, TallShape{512, 4, 8, 1}, TallShape{1024, 8, 1 << 20, 0},
                                                       TallShape{512, 8, 1, 1},  TallShape{256, 1, 1, 1}};
 
+// the order in which an untuned operator tries them: the one-row-per-workgroup walks first (the winners on most boxes and pairings,
+// profiles/repeat_r03_boxes.txt), the sequential sweeps last
+const int k_fwd_trial_order[K_FWD_CANDIDATES] = {7, 6, 1, 4, 3, 2, 0, 5};
+
 // For operators far larger than the caches the row-concurrent walk is 5-7 % faster than the sequential sweep in some
 // processes and 10-15 % slower in others (profiles/repeat_r01.txt: same binary, same box; it depends on where the slabs landed
 // physically), so the shape is chosen by measurement -- LAZILY: while an operator is untuned, each real forward call runs the
@@ -1978,7 +1985,10 @@ void lazy_reset(jh_blockop::LazyTune &t)
 // when the runner-up is within 3 % of the winner the two run a play-off -- four more of the caller's own calls, alternating
 // winner / runner-up / winner / runner-up, each between two events like the trials -- and the best time over ALL of a
 // candidate's samples decides.
-int lazy_next(jh_blockop::LazyTune &t, int ncand, int npass, int warm, float margin, int *choice, int *slot, bool playoff = false)
+// `order` (optional, ncand entries): the candidate that trial j of a pass runs -- the likely winners first, so that an operator that
+// lives for a handful of calls only (a caller in the reference's style builds operators all the time) spends them on good shapes
+int lazy_next(jh_blockop::LazyTune &t, int ncand, int npass, int warm, float margin, int *choice, int *slot, bool playoff = false,
+              const int *order = nullptr)
 {
     *slot = -1;
     const int regular = warm + ncand * npass;
@@ -1996,8 +2006,8 @@ int lazy_next(jh_blockop::LazyTune &t, int ncand, int npass, int warm, float mar
     if (measured == total) {
         float best[8] = {};
         auto take = [&](int c, int k) { if (t.state[k] == 2 && (best[c] == 0.f || t.ms[k] < best[c])) best[c] = t.ms[k]; };
-        for (int c = 0; c < ncand; c++)
-            for (int p = 0; p < npass; p++) take(c, warm + p * ncand + c);
+        for (int j = 0; j < ncand; j++)
+            for (int p = 0; p < npass; p++) take(order ? order[j] : j, warm + p * ncand + j);
         if (t.playoff[0] >= 0)
             for (int k = 0; k < 4; k++) take(t.playoff[k & 1], regular + k);
         int pick = 0, runner = -1;
@@ -2020,9 +2030,10 @@ int lazy_next(jh_blockop::LazyTune &t, int ncand, int npass, int warm, float mar
     if (t.launched < total) {
         *slot = t.launched;
         if (*slot >= regular) return t.playoff[(*slot - regular) & 1];
-        return *slot < warm ? 0 : (*slot - warm) % ncand;
+        if (*slot < warm) return order ? order[0] : 0;
+        return order ? order[(*slot - warm) % ncand] : (*slot - warm) % ncand;
     }
-    return t.playoff[0] >= 0 ? t.playoff[0] : 0;                            // every trial is in flight: the (provisional) default meanwhile
+    return t.playoff[0] >= 0 ? t.playoff[0] : (order ? order[0] : 0);       // every trial is in flight: the (provisional) default meanwhile
 }
 
 // Periodic re-check of a choice already made (round 3): every 64th call of the chosen shape is timed between two events (again the
@@ -2085,6 +2096,46 @@ bool stream_is_capturing(hipStream_t st)
     return !(hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone);
 }
 
+// Round 4: what an operator of this SHAPE chose last time.  A caller in the reference's style builds operators again and again (a new
+// JopBlock per outer iteration, per shot set): each would spend its first 16-20 forwards on the candidate walks, the slow ones included --
+// the first `d = A*m` of a new operator ran the 16-row sweep (23-24 ms at the headline size) whatever the last operator had found.
+// A new operator of a shape (device, element type, rows, block length, strided or table addressing) seen before starts with that
+// choice and its records; the periodic re-check (every 64th call) still corrects it.  Knob walk_memory (0: every operator measures);
+// jh_blockop_tune_set(op, "fwd_walk", -1) makes that operator measure for itself.
+struct WalkKey {
+    int device, dtype, strided;
+    int64_t nrow, n_scalars;
+    bool operator<(const WalkKey &o) const
+    {
+        return std::tie(device, dtype, strided, nrow, n_scalars) < std::tie(o.device, o.dtype, o.strided, o.nrow, o.n_scalars);
+    }
+};
+struct WalkRecord { int walk; float best_ms[8]; };
+std::mutex g_walk_mutex;
+std::map<WalkKey, WalkRecord> g_walk_memory;
+
+WalkKey walk_key(const jh_blockop *op, int64_t n_scalars) { return WalkKey{jh_ctx().device, op->dtype, op->diag_strided ? 1 : 0, op->nrow, n_scalars}; }
+
+void walk_remember(const jh_blockop *op, int64_t n_scalars)
+{
+    if (op->fwd_walk < 0 || op->fwd_walk >= 8) return;
+    WalkRecord r{op->fwd_walk, {}};
+    for (int k = 0; k < 8; k++) r.best_ms[k] = op->fwd_tune.best_ms[k];
+    std::lock_guard<std::mutex> lock(g_walk_mutex);
+    g_walk_memory[walk_key(op, n_scalars)] = r;
+}
+
+bool walk_recall(const jh_blockop *op, int64_t n_scalars)
+{
+    std::lock_guard<std::mutex> lock(g_walk_mutex);
+    auto it = g_walk_memory.find(walk_key(op, n_scalars));
+    if (it == g_walk_memory.end()) return false;
+    op->fwd_walk = it->second.walk;
+    for (int k = 0; k < 8; k++) op->fwd_tune.best_ms[k] = it->second.best_ms[k];
+    op->walk_inherited = true;
+    return true;
+}
+
 template <typename S, int E, int NS>
 int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
 {
@@ -2094,13 +2145,16 @@ int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scal
     const double stream_bytes = 2.0 * (double)op->nrow * (double)n_scalars * sizeof(S);
     if (c.autotune && knobs_free && stream_bytes >= 8.0 * (double)(1ull << 30) && op->nrow >= 64) {
         int slot = -1;
+        if (op->fwd_walk < 0 && op->fwd_tune.launched == 0 && !op->walk_measure_again && c.walk_memory) (void)walk_recall(op, n_scalars);
         if (op->fwd_walk < 0) {
             if (!stream_is_capturing(c.stream)) {
-                const int k = lazy_next(op->fwd_tune, K_FWD_CANDIDATES, 2, 0, 0.f, &op->fwd_walk, &slot, true);
+                const int k = lazy_next(op->fwd_tune, K_FWD_CANDIDATES, 2, 0, 0.f, &op->fwd_walk, &slot, true, k_fwd_trial_order);
                 if (k >= 0 && k < K_FWD_CANDIDATES) sh = k_fwd_candidates[k];
+                if (op->fwd_walk >= 0) walk_remember(op, n_scalars);       // the choice has just been made
             }
         } else if (op->fwd_walk < K_FWD_CANDIDATES) {
             if (!stream_is_capturing(c.stream) && recheck_should_time(op->fwd_tune, K_FWD_CANDIDATES, &op->fwd_walk)) {
+                walk_remember(op, n_scalars);                              // (the re-check may have rotated another candidate in)
                 sh = k_fwd_candidates[op->fwd_walk];
                 const bool ok = recheck_begin(op->fwd_tune, c.stream);
                 const int st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, sh);
@@ -3824,6 +3878,7 @@ int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value)
 {
     JH_REQUIRE(op && name && value, "jh_blockop_tune_get: null argument");
     if (!strcmp(name, "fwd_walk")) *value = op->fwd_walk;                       // -1: not chosen yet
+    else if (!strcmp(name, "fwd_walk_inherited")) *value = op->walk_inherited ? 1 : 0;   // the choice came from an earlier operator of the same shape
     else if (!strcmp(name, "fwd_trials")) *value = op->fwd_tune.launched;
     else if (!strcmp(name, "fwd_switches")) *value = op->fwd_tune.switches;       // times the periodic re-check rotated another walk in
     else if (!strcmp(name, "fwd_playoff")) *value = op->fwd_tune.playoff[0] >= 0 ? op->fwd_tune.playoff[0] * 8 + op->fwd_tune.playoff[1] : -1;
@@ -3841,6 +3896,8 @@ int jh_blockop_tune_set(jh_blockop *op, const char *name, int64_t value)
         JH_REQUIRE(value >= -1 && value < K_FWD_CANDIDATES, "jh_blockop_tune_set: fwd_walk must be -1 (measure again) or 0..%d", K_FWD_CANDIDATES - 1);
         lazy_reset(op->fwd_tune);
         op->fwd_walk = (int)value;
+        op->walk_measure_again = value < 0;                                 // -1: THIS operator measures, whatever operators of its shape found before
+        op->walk_inherited = false;
     } else if (!strcmp(name, "upd_walk")) {
         JH_REQUIRE(value >= -1 && value <= 1, "jh_blockop_tune_set: upd_walk must be -1, 0 or 1");
         op->upd_walk = (int)value;

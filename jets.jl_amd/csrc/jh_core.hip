@@ -1,5 +1,6 @@
 // jh_core.hip -- context, device block vectors (slabs), copies, events.  gfx950 only.
 #include "jh_internal.h"
+#include <algorithm>
 #include <initializer_list>
 
 static thread_local char g_err[512] = "";
@@ -38,8 +39,54 @@ jh_context *jh_ctx_by_id(int id)
 namespace {
 struct cached_slab { void *p; size_t bytes; };
 std::mutex g_slab_mutex;
+// Round 4: WHICH cached slab an allocation gets.  On this chip the time to WRITE a 64 GiB slab is a property of the slab: the library's
+// own fill runs at 7.2 TB/s into some and 6.4 into others (consecutive processes, one box: profiles/exp_r04_write_probe.txt), and the tall
+// forward follows it (20.6-21.5 ms into a fast-write slab, 23.8-24.8 into a slow one, whichever slab holds the coefficients); the
+// fast-write slabs read about 3 % slower (norm: 10.26 against 9.97 ms).  So a slab of 4 GiB or more is PROBED once when it enters the
+// cache (two fills of the freed memory, the second one timed: 20 ms per 64 GiB, at destroy time) and an allocation that says what it
+// is for (knob alloc_role: 1 = an operator's output, 2 = data that is written once and read from then on) takes the cached slab of
+// its size with the fastest / the slowest recorded fill; without a role (0) the most recently freed one, as before.
+constexpr size_t SLAB_PROBE_MIN = (size_t)4 << 30;
+std::map<void *, double> g_slab_fill_ms_per_gib;           // probe records, by slab (erased when the slab goes back to the driver)
+std::atomic<int64_t> g_last_alloc_choice{-1};              // 100 * candidates + rank of the chosen one by fill time (0 = fastest); -1: no choice was made
+
+__global__ __launch_bounds__(256) void k_probe_fill(uint4 *__restrict__ p, int64_t nvec)
+{
+    typedef unsigned V __attribute__((ext_vector_type(4)));
+    const V z = {0u, 0u, 0u, 0u};
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256)
+        __builtin_nontemporal_store(z, reinterpret_cast<V *>(p) + v);
+}
+
+// (the device is current; the slab is dead memory that no stream touches any more: jh_slab_free has synchronised the device)
+double slab_probe_ms_per_gib(void *p, size_t bytes, hipStream_t st)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        (void)hipGetLastError();
+        return 0.0;
+    }
+    const int64_t nvec = (int64_t)(bytes / 16);
+    int64_t grid = (nvec + 255) / 256;
+    if (grid > ((int64_t)1 << 23)) grid = (int64_t)1 << 23;
+    double out = 0.0;
+    hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)grid), dim3(256), 0, st, (uint4 *)p, nvec);          // (page tables, caches)
+    if (hipEventRecord(e0, st) == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)grid), dim3(256), 0, st, (uint4 *)p, nvec);
+        float ms = 0.f;
+        if (hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f)
+            out = (double)ms / ((double)bytes / (double)((size_t)1 << 30));
+    }
+    (void)hipGetLastError();
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return out;
+}
+void slab_forget(void *p) { g_slab_fill_ms_per_gib.erase(p); }   // under the lock
 std::map<int, std::vector<cached_slab>> g_slabs;            // device -> slabs, oldest first
 std::atomic<int> g_slab_cache_on{1};
+std::atomic<int64_t> g_slab_free_floor_mib{8192};           // knob slab_free_floor_mib
 constexpr size_t SLAB_CACHE_MIN = (size_t)16 << 20;          // from 16 MiB on: a thousand 64 MiB blocks re-allocated after a free cost 3.6 ms EACH (profiles/exp_r03_alloc_cost.txt)
 
 size_t slab_cap_bytes()                                       // the cache never holds the last 32 GiB of the device
@@ -74,6 +121,7 @@ bool slab_evict_for(int device, size_t need)                   // false when the
     {
         std::lock_guard<std::mutex> lock(g_slab_mutex);
         if (!slab_pick_victim(g_slabs[device], need, &victim)) return false;
+        slab_forget(victim.p);
     }
     (void)hipFree(victim.p);
     return true;
@@ -100,20 +148,42 @@ void jh_slab_trim(int device)                                  // device < 0: ev
                 kv.second.clear();
             }
     }
+    {
+        std::lock_guard<std::mutex> lock(g_slab_mutex);
+        for (const cached_slab &c : out) slab_forget(c.p);
+    }
     for (const cached_slab &c : out) (void)hipFree(c.p);   // (hipFree takes a pointer of any device)
 }
 
-hipError_t jh_slab_alloc(int device, size_t bytes, void **out)
+hipError_t jh_slab_alloc(int device, size_t bytes, void **out, int role)
 {
     if (bytes >= SLAB_CACHE_MIN) {
         std::lock_guard<std::mutex> lock(g_slab_mutex);
         std::vector<cached_slab> &v = g_slabs[device];
-        for (size_t k = v.size(); k-- > 0;)                  // the most recently freed slab of that size first
-            if (v[k].bytes == bytes) {
-                *out = v[k].p;
-                v.erase(v.begin() + (long)k);
-                return hipSuccess;
+        size_t pick = v.size();
+        g_last_alloc_choice.store(-1);
+        if (role != 0 && bytes >= SLAB_PROBE_MIN) {          // the probed candidates of this size: fastest fill for an output, slowest for read-mostly data
+            std::vector<std::pair<double, size_t>> cand;
+            for (size_t k = 0; k < v.size(); k++)
+                if (v[k].bytes == bytes) {
+                    auto it = g_slab_fill_ms_per_gib.find(v[k].p);
+                    if (it != g_slab_fill_ms_per_gib.end() && it->second > 0.0) cand.push_back({it->second, k});
+                }
+            if (cand.size() >= 2) {
+                std::sort(cand.begin(), cand.end());
+                const size_t rank = role == 1 ? 0 : cand.size() - 1;
+                pick = cand[rank].second;
+                g_last_alloc_choice.store((int64_t)(100 * cand.size() + rank));
             }
+        }
+        if (pick == v.size())
+            for (size_t k = v.size(); k-- > 0;)              // the most recently freed slab of that size first
+                if (v[k].bytes == bytes) { pick = k; break; }
+        if (pick < v.size()) {
+            *out = v[pick].p;
+            v.erase(v.begin() + (long)pick);
+            return hipSuccess;
+        }
     }
     return jh_device_malloc(device, out, bytes);
 }
@@ -133,7 +203,7 @@ hipError_t jh_device_malloc(int device, void **out, size_t bytes)
     return e;
 }
 
-void jh_slab_free(int device, void *p, size_t bytes)
+void jh_slab_free(int device, void *p, size_t bytes, hipStream_t st)
 {
     if (!p) return;
     if (g_slab_cache_on.load() && bytes >= SLAB_CACHE_MIN && bytes <= slab_cap_bytes()) {
@@ -144,6 +214,18 @@ void jh_slab_free(int device, void *p, size_t bytes)
         // wrapped vector.  Microseconds on an idle device, against the seconds the re-used slab saves.  (The device is current: both
         // callers come through jh_quiesce_scope / the vector's own context.)
         (void)hipDeviceSynchronize();
+        if (bytes >= SLAB_PROBE_MIN && st) {                  // how fast can this slab be written?  (once per slab: see g_slab_fill_ms_per_gib)
+            bool known;
+            {
+                std::lock_guard<std::mutex> lock(g_slab_mutex);
+                known = g_slab_fill_ms_per_gib.count(p) != 0;
+            }
+            if (!known) {
+                const double rate = slab_probe_ms_per_gib(p, bytes, st);
+                std::lock_guard<std::mutex> lock(g_slab_mutex);
+                g_slab_fill_ms_per_gib[p] = rate;
+            }
+        }
         std::vector<cached_slab> evict;
         {
             std::lock_guard<std::mutex> lock(g_slab_mutex);
@@ -153,17 +235,26 @@ void jh_slab_free(int device, void *p, size_t bytes)
             cached_slab victim{nullptr, 0};
             while (held > slab_cap_bytes() && slab_pick_victim(v, held - slab_cap_bytes(), &victim)) {
                 held -= victim.bytes;
+                slab_forget(victim.p);
                 evict.push_back(victim);
             }
             v.push_back(cached_slab{p, bytes});
-            // ... and the cache never holds the device's LAST 32 GiB either: live vectors plus cached slabs must leave that much to whoever
-            // allocates without going through jh_device_malloc's evict-and-retry (RCCL, torch in the same process).  Cached memory is
-            // still allocated as far as the driver can tell, so `free` below does not count it.
+            // ... and it never holds the device's LAST 8 GiB: live vectors plus cached slabs must leave that much to whoever allocates
+            // without going through jh_device_malloc's evict-and-retry (RCCL's buffers, torch in the same process).  Cached memory is
+            // still allocated as far as the driver can tell, so `free` below does not count it.  (Not 32 GiB here: four 64 GiB vectors
+            // -- coefficients, d, a second range vector, a solver's copy of b -- are 256 of the 288 GiB, and a floor of 32 sent the
+            // fourth back to the driver after every solve: 2 s per lsqr(A, b) at the headline size, profiles/walkthrough_r04_headline.txt.)
             size_t fr = 0, tot = 0;
-            const size_t floor_bytes = (size_t)32 << 30;
-            if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > ((size_t)64 << 30) && fr < floor_bytes) {
+            const size_t floor_bytes = (size_t)g_slab_free_floor_mib.load() << 20;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+                for (const cached_slab &c : evict) fr += c.bytes;          // (what the cap has just sent back is as good as free)
+            } else {
+                tot = 0;
+            }
+            if (tot > ((size_t)64 << 30) && fr < floor_bytes) {
                 size_t need = floor_bytes - fr;
                 while (need > 0 && slab_pick_victim(v, need, &victim)) {
+                    slab_forget(victim.p);
                     evict.push_back(victim);
                     need = victim.bytes >= need ? 0 : need - victim.bytes;
                 }
@@ -172,8 +263,20 @@ void jh_slab_free(int device, void *p, size_t bytes)
         for (const cached_slab &c : evict) (void)hipFree(c.p);
         return;
     }
+    {
+        std::lock_guard<std::mutex> lock(g_slab_mutex);
+        slab_forget(p);
+    }
     (void)hipFree(p);
 }
+int64_t jh_slab_probed(int device)
+{
+    std::lock_guard<std::mutex> lock(g_slab_mutex);
+    int64_t n = 0;
+    for (const cached_slab &c : g_slabs[device]) n += g_slab_fill_ms_per_gib.count(c.p) ? 1 : 0;
+    return n;
+}
+int64_t jh_slab_last_choice() { return g_last_alloc_choice.load(); }
 
 jh_quiesce_scope::jh_quiesce_scope(int ctx)
 {
@@ -566,7 +669,7 @@ static int bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_
     if (s != JH_OK) { delete v; return s; }
     size_t bytes = (size_t)v->length * jh_dtype_size(dtype);
     if (bytes == 0) bytes = 16;
-    hipError_t e = jh_slab_alloc(jh_ctx().device, bytes, &v->data);   // a cached slab of a destroyed vector of this size, or hipMalloc
+    hipError_t e = jh_slab_alloc(jh_ctx().device, bytes, &v->data, (int)jh_ctx().alloc_role);   // a cached slab of a destroyed vector of this size, or hipMalloc
     if (e != hipSuccess) {
         delete v;
         return jh_fail(JH_ERR_NOMEM, "jh_bvec_create: hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
@@ -578,7 +681,7 @@ static int bvec_create(int64_t nblocks, const int64_t *block_len, int dtype, jh_
         else e = hipMemsetAsync(v->data, 0, bytes, jh_ctx().stream);
     }
     if (e != hipSuccess) {
-        jh_slab_free(jh_ctx().device, v->data, bytes);
+        jh_slab_free(jh_ctx().device, v->data, bytes, jh_ctx().stream);
         delete v;
         return jh_fail(JH_ERR_HIP, "jh_bvec_create: hipMemsetAsync: %s", hipGetErrorString(e));
     }
@@ -636,7 +739,7 @@ int jh_bvec_destroy(jh_bvec *v)
         jh_context *c = jh_ctx_by_id(v->ctx);
         size_t bytes = (size_t)v->length * jh_dtype_size(v->dtype);
         if (bytes == 0) bytes = 16;
-        if (c) jh_slab_free(c->device, v->data, bytes);          // big slabs wait in the cache for the next vector of their size
+        if (c) jh_slab_free(c->device, v->data, bytes, c->stream);   // big slabs wait in the cache for the next vector of their size
         else (void)hipFree(v->data);
     }
     jh_handle_died(v->ctx);
@@ -839,6 +942,9 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "dense_fused")) { JH_REQUIRE(value == 0 || value == 1, "dense_fused must be 0 or 1"); c.dense_fused = value; }
     else if (!strcmp(name, "cgls_trace")) { c.cgls_trace = value ? 1 : 0; }
     else if (!strcmp(name, "cg_dev")) { c.cg_dev = value ? 1 : 0; }
+    else if (!strcmp(name, "walk_memory")) { c.walk_memory = value ? 1 : 0; }
+    else if (!strcmp(name, "slab_free_floor_mib")) { JH_REQUIRE(value >= 0, "slab_free_floor_mib must be >= 0"); g_slab_free_floor_mib.store(value); }
+    else if (!strcmp(name, "alloc_role")) { JH_REQUIRE(value >= 0 && value <= 2, "alloc_role must be 0 (none), 1 (an operator's output) or 2 (data written once, read from then on)"); c.alloc_role = value; }
     else if (!strcmp(name, "dense_gw")) { JH_REQUIRE(value >= 0 && value <= 4096, "dense_gw must be 0 (automatic) or 1 .. 4096 children per wave"); c.dense_gw = value; }
     else if (!strcmp(name, "sum_group")) { JH_REQUIRE(value == 4 || value == 8, "sum_group must be 4 or 8 terms per launch"); c.sum_group = value; }
     else if (!strcmp(name, "grid_diag")) { JH_REQUIRE(value >= 0 && value <= 4, "grid_diag must be 0 (general kernels), 1, 2 or 4 (packs per lane)"); c.grid_diag = value; }
@@ -886,6 +992,11 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "dense_fused")) *value = c.dense_fused;
     else if (!strcmp(name, "cgls_trace")) *value = c.cgls_trace;
     else if (!strcmp(name, "cg_dev")) *value = c.cg_dev;
+    else if (!strcmp(name, "walk_memory")) *value = c.walk_memory;
+    else if (!strcmp(name, "alloc_role")) *value = c.alloc_role;
+    else if (!strcmp(name, "slab_free_floor_mib")) *value = g_slab_free_floor_mib.load();
+    else if (!strcmp(name, "slab_probed")) *value = jh_slab_probed(c.device);
+    else if (!strcmp(name, "last_alloc_choice")) *value = jh_slab_last_choice();
     else if (!strcmp(name, "last_cg_graph")) *value = c.last_cg_graph;
     else if (!strcmp(name, "last_cgls_overlaps")) *value = c.last_cgls_overlaps;
     else if (!strcmp(name, "dense_gw")) *value = c.dense_gw;

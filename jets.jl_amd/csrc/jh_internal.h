@@ -38,11 +38,13 @@ constexpr int JH_MAX_CTX = 64;          // table slots (a power of two)
 // a handle that outlives its context never matches the unrelated context that later lands in the same slot.
 inline int jh_ctx_slot(int id) { return id & (JH_MAX_CTX - 1); }
 // slab cache (jh_core.hip): big device allocations of destroyed vectors, kept per device for the next vector of that size
-hipError_t jh_slab_alloc(int device, size_t bytes, void **out);
+hipError_t jh_slab_alloc(int device, size_t bytes, void **out, int role = 0);   // role: jh_context::alloc_role
 hipError_t jh_device_malloc(int device, void **out, size_t bytes);     // hipMalloc that takes memory back from the cache when the driver says no
-void jh_slab_free(int device, void *p, size_t bytes);
+void jh_slab_free(int device, void *p, size_t bytes, hipStream_t probe_stream = nullptr);   // probe_stream: a stream of `device` for the write probe of slabs >= 4 GiB
 void jh_slab_trim(int device);
 size_t jh_slab_cached_bytes(int device);
+int64_t jh_slab_probed(int device);    // cached slabs of the device with a write-probe record
+int64_t jh_slab_last_choice();         // 100 * candidates + rank (by fill time, 0 = fastest) of the slab the last role-guided allocation took; -1: none
 
 struct jh_context {
     bool ready = false;
@@ -105,6 +107,8 @@ struct jh_context {
     int64_t last_step_parts = 0;             // per-workgroup partial sums the most recent one-pass step wrote
     int64_t lsqr_graph = 1;            // knob: small operators' LSQR loop with device-resident recurrences, replayed as a hipGraph (0: the host loop)
     int64_t last_lsqr_graph = 0;       // read-only: graph replays of the most recent jh_lsqr_solve (0: the host loop ran)
+    int64_t walk_memory = 1;           // knob: a new tall operator starts with the forward walk the last operator of its shape chose (0: every operator measures)
+    int64_t alloc_role = 0;            // knob: what the NEXT vectors of this context are for -- 0 unknown, 1 an operator's output (the cached slab that is fastest to write), 2 data written once and read from then on (the slowest to write: those read fastest); slabs >= 4 GiB only
     int64_t cg_dev = 1;                // knob: small operators' CGLS / CG-on-the-normal-equations loops on the fused kernels of cg_dev_impl (graph-replayed unless lsqr_graph = 0); 0: cgls_impl / cgnr_impl
     int64_t last_cg_graph = 0;         // read-only: graph replays of the most recent jh_cgls_solve / jh_cgnr_solve (0: a host-driven loop ran)
     int64_t cgls_trace = 0;            // knob (tests): jh_cgls_solve_team stamps every member's pass 1 of its first iteration with events ...
@@ -217,6 +221,8 @@ struct jh_blockop {
     struct LoopGraph { const void *out; const void *in; int mode; int seen; uint64_t gen; hipGraphExec_t exec; };
     mutable std::vector<LoopGraph> loop_graphs;
     mutable int fwd_walk = -1;               // autotuned tall-forward shape: -1 untried, else an index into k_fwd_candidates (jh_blockop.hip)
+    mutable bool walk_inherited = false;     // ... taken over from an earlier operator of the same shape (jh_blockop.hip: walk_recall)
+    bool walk_measure_again = false;         // jh_blockop_tune_set(op, "fwd_walk", -1): this operator measures for itself
     // lazy autotune (jh_blockop.hip: lazy_*): the first real calls each run ONE candidate between two events -- no extra
     // launches, no host synchronisation -- and finished timings are harvested with hipEventQuery on later calls
     struct LazyTune {

@@ -412,7 +412,8 @@ def mul(A: Jop, m):
     _enter_context_of(m)
     from .jetblock import overwrites_its_whole_range
 
-    return mul_(_arr.Array(range_(A), undef=True) if overwrites_its_whole_range(A) else zeros(range_(A)), A, m)
+    R = range_(A)                                      # (an operator's output: of the cached slabs of its size the one that is fastest to write)
+    return mul_(_arr.Array(R, undef=overwrites_its_whole_range(A), role=_arr.ROLE_OUTPUT), A, m)
 
 
 # ------------------------------------------------------------------------------ composition --------
@@ -438,7 +439,7 @@ class _Workspace:
 
         undef = for_op is not None and overwrites_its_whole_range(for_op)
         if R.length() * np.dtype(R.eltype()).itemsize >= self.KEEP_BELOW:
-            x = _arr.Array(R, undef=undef)
+            x = _arr.Array(R, undef=undef, role=_arr.ROLE_OUTPUT)
             self._call.append(x)
             return x
         hit = self._pool.get(slot)

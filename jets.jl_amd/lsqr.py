@@ -76,9 +76,9 @@ class _Engine:
 
     def copy_of_rng(self, src):
         """A private copy of a range vector (the solver's u when b must survive): storage without the zero fill, then the copy."""
-        from .arrays import Array
+        from .arrays import Array, ROLE_OUTPUT
 
-        return copyto_(Array(_j.range_(self.A), undef=True), src)
+        return copyto_(Array(_j.range_(self.A), undef=True, role=ROLE_OUTPUT), src)     # (rewritten in every iteration)
 
     def copy(self, dst, src):
         return copyto_(dst, src)

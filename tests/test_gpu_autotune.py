@@ -42,9 +42,21 @@ def test_lazy_forward_autotune_converges_without_changing_bits(Jets, oracle):
     assert_bits_equal(flat[:4096], ha0 * hm0, "after the re-check: row 0")
     assert J.op_tune_get(A, "fwd_switches") >= 0 and 0 <= J.op_tune_get(A, "fwd_walk") < 8
     pick = J.op_tune_get(A, "fwd_walk")
-    # export / import: a second operator starts in the steady state, and -1 measures again
+    # round 4: a NEW operator of the same shape starts with what this one found (no trials of its own; the re-check still applies) ...
     B = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
-    J.mul_(d, B, m)                                             # builds the handle (and runs trial 0)
+    J.mul_(d, B, m)
+    assert J.op_tune_get(B, "fwd_walk") == pick and J.op_tune_get(B, "fwd_walk_inherited") == 1 and J.op_tune_get(B, "fwd_trials") == 0
+    assert_bits_equal(d.to_numpy()[:4096], ha0 * hm0, "inherited walk: row 0")
+    J.close(B)
+    # ... unless the knob says every operator measures
+    J.tune(walk_memory=0)
+    try:
+        B = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
+        J.mul_(d, B, m)                                         # builds the handle (and runs trial 0)
+        assert J.op_tune_get(B, "fwd_walk") == -1 and J.op_tune_get(B, "fwd_trials") == 1 and J.op_tune_get(B, "fwd_walk_inherited") == 0
+    finally:
+        J.tune(walk_memory=1)
+    # export / import: a second operator starts in the steady state, and -1 measures again (also with the memory on)
     J.op_tune_set(B, "fwd_walk", pick)
     J.mul_(d, B, m)
     assert J.op_tune_get(B, "fwd_walk") == pick and J.op_tune_get(B, "fwd_trials") == 0

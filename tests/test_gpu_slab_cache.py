@@ -19,6 +19,7 @@ def _cached_mib(J):
 
 def test_a_destroyed_big_vector_is_reused_by_the_next_of_its_size_and_comes_back_zeroed(Jets):
     J = Jets
+    gc.collect()                                                  # (vectors of earlier tests go to the cache now, not in the middle of this one)
     J.trim()
     spc = J.JetSpace(np.float32, GIB // 2)                        # 2 GiB
     x = J.ones(spc)
@@ -176,3 +177,56 @@ def test_churn_of_cached_slabs_never_hands_out_memory_that_is_still_in_use(Jets)
         assert float(mn) == float(mx) == val
         x.close()
     J.trim()
+
+
+def test_big_slabs_are_probed_when_they_enter_the_cache_and_an_allocation_with_a_role_takes_the_right_one(Jets, oracle):
+    """Round 4: which of several cached slabs `A*m` (src/Jets.jl:399) writes into.  A slab of 4 GiB or more is probed once when it enters the
+    cache (its fill time: a property of the slab on this chip, profiles/exp_r04_write_probe.txt); an allocation that says what it is for takes
+    the fastest-to-write (an operator's output) or the slowest-to-write (data read from then on) cached slab of its size; one that does
+    not, the most recently freed.  `A*m` says 'output', rand(R) says 'data' -- and the results do not depend on where they live."""
+    from jets_jl_amd import arrays
+
+    from .helpers import assert_bits_equal
+
+    J = Jets
+    gc.collect()
+    J.trim()
+    blk = J.JetSpace(np.float32, 1 << 20)                          # 4 MiB blocks, 1024 of them: a 4 GiB range
+    nrow = 1024
+    R = J.JetBSpace([blk] * nrow)
+    xs = [J.Array(R, undef=True) for _ in range(3)]
+    ptrs = [x.ptr for x in xs]
+    for x in xs:
+        x.close()
+    del xs, x
+    gc.collect()
+    assert _cached_mib(J) == 3 * 4096 and J.tune_get("slab_probed") == 3
+    a = J.Array(R, undef=True)                                      # no role: the most recently freed slab, no choice made
+    assert a.ptr == ptrs[2] and J.tune_get("last_alloc_choice") == -1
+    a.close()
+    del a
+    gc.collect()
+    assert J.tune_get("slab_probed") == 3                           # (probed once per slab, not once per visit to the cache)
+    out = J.Array(R, undef=True, role=arrays.ROLE_OUTPUT)
+    assert J.tune_get("last_alloc_choice") == 300 and out.ptr in ptrs        # 3 probed candidates, the fastest fill
+    data = J.rand(R, seed=1, stream=0)                              # rand says 'data': of the two left, the slowest fill
+    assert J.tune_get("last_alloc_choice") == 201 and data.ptr in ptrs and data.ptr != out.ptr
+    assert J.tune_get("alloc_role") == 0, "the hint is for one allocation"
+    A = J.blockop([[J.JopDiagonal(c)] for c in data.arrays])
+    m = J.rand(J.domain(A), seed=2, stream=0)
+    out.close()
+    del out
+    gc.collect()
+    d = A * m                                                       # 'output': the fastest of the two cached again
+    assert J.tune_get("last_alloc_choice") == 200 and d.ptr in ptrs and d.ptr != data.ptr
+    n = blk.length()
+    ha = oracle.rng_u01(np.float32, 1, 0, 5 * n, n)
+    hm = oracle.rng_u01(np.float32, 2, 0, 0, n)
+    assert_bits_equal(J.getblock(d, 5).to_numpy().ravel(), ha * hm, "row 5 of A*m")
+    J.close(A)
+    for v in (d, data, m):
+        v.close()
+    del d, data, m, A
+    gc.collect()
+    J.trim()
+    assert J.tune_get("slab_probed") == 0

@@ -43,6 +43,7 @@ for turn in (1, 2):
         m = J.rand(J.domain(A), seed=2, stream=0)
     with T("d = A*m            (allocates range(A): 64 GiB at the headline size)"):
         d = A * m
+    print(f"                    (slab choice for d: {J.tune_get('last_alloc_choice')} = 100 x probed candidates + rank by fill time, -1: no choice; {J.tune_get('slab_probed')} probed slabs left in the cache)", flush=True)
     with T("d = A*m again      (allocates again)"):
         d2 = A * m
     with T("mul!(d, A, m)      (in place)"):
