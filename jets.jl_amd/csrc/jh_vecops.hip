@@ -50,7 +50,6 @@ __host__ __device__ inline uint64_t mix64(uint64_t z)
 constexpr uint64_t GOLDEN = 0x9E3779B97F4A7C15ULL;
 
 template <typename S> __device__ inline S u01_from(uint64_t h);
-template <> __device__ inline float u01_from<float>(uint64_t h) { return (float)(h >> 40) * 0x1.0p-24f; }
 template <> __device__ inline double u01_from<double>(uint64_t h) { return (double)(h >> 11) * 0x1.0p-53; }
 
 
@@ -109,6 +108,14 @@ int fill_scalars(S *p, int64_t n, double re, double im)
 }
 
 // ---------------------------------------------------------------- uniform random --------------
+// Counter-based generator: a pure function of (seed, stream, scalar lane index), so the device fill and a CPU
+// regeneration of any slice agree bit for bit.  hash(j) = mix64(key + (j + 1) * GOLDEN), key = mix64(seed * GOLDEN + stream).
+//   Float64 lane k:  the top 53 bits of hash(k).
+//   Float32 lane k (round 4):  24 bits of hash(k >> 1) -- the top 24 for an even lane, the next 24 (bits 39..16) for an odd one: ONE
+//   hash per two values.  The kernel is bound by its 64-bit integer multiplies (two per hash, four quarter-rate 32-bit multiplies each),
+//   not by its store: with a hash per value rand(R) ran at 4.8 TB/s (60 % of the roofline, profiles/bench_suite_r03.txt).
+__device__ inline float u01_pair(uint64_t h, int odd) { return (float)(odd ? ((h >> 16) & 0xFFFFFFull) : (h >> 40)) * 0x1.0p-24f; }
+
 template <typename S, int NS>
 __global__ void k_uniform(S *__restrict__ p, int64_t n, uint64_t key, int64_t lane_base)
 {
@@ -118,15 +125,31 @@ __global__ void k_uniform(S *__restrict__ p, int64_t n, uint64_t key, int64_t la
     Pack<S, NS> *pv = reinterpret_cast<Pack<S, NS> *>(p);
     for (int64_t v = tid; v < nvec; v += stride) {
         Pack<S, NS> o;
-        // the counter of element i is key + (i + 1) * GOLDEN (mod 2^64): one 64-bit multiply per pack, then additions of constants --
-        // the kernel is bound by its integer multiplies (two more per element inside mix64), not by the store
-        const uint64_t z0 = key + (uint64_t)(lane_base + v * NS + 1) * GOLDEN;
+        if constexpr (sizeof(S) == 4) {
+            // lanes k0 .. k0 + 3 (k0 = lane_base + 4 v): pairs (k0 >> 1) and the next one -- and a third when k0 is odd.  One 64-bit multiply
+            // for the first counter, additions of a constant for the others
+            const int64_t k0 = lane_base + v * NS;
+            const uint64_t z0 = key + (uint64_t)((k0 >> 1) + 1) * GOLDEN;
+            const uint64_t h0 = mix64(z0), h1 = mix64(z0 + GOLDEN);
+            if ((k0 & 1) == 0) {
+                o.v[0] = u01_pair(h0, 0); o.v[1] = u01_pair(h0, 1); o.v[2] = u01_pair(h1, 0); o.v[3] = u01_pair(h1, 1);
+            } else {
+                const uint64_t h2 = mix64(z0 + 2 * GOLDEN);
+                o.v[0] = u01_pair(h0, 1); o.v[1] = u01_pair(h1, 0); o.v[2] = u01_pair(h1, 1); o.v[3] = u01_pair(h2, 0);
+            }
+        } else {
+            const uint64_t z0 = key + (uint64_t)(lane_base + v * NS + 1) * GOLDEN;
 #pragma unroll
-        for (int c = 0; c < NS; c++) o.v[c] = u01_from<S>(mix64(z0 + (uint64_t)c * GOLDEN));
+            for (int c = 0; c < NS; c++) o.v[c] = u01_from<S>(mix64(z0 + (uint64_t)c * GOLDEN));
+        }
         stnt(pv + v, o);
     }
     const int64_t tail0 = nvec * NS;
-    if (tid < n - tail0) p[tail0 + tid] = u01_from<S>(mix64(key + (uint64_t)(lane_base + tail0 + tid + 1) * GOLDEN));
+    if (tid < n - tail0) {
+        const int64_t k = lane_base + tail0 + tid;
+        if constexpr (sizeof(S) == 4) p[tail0 + tid] = u01_pair(mix64(key + (uint64_t)((k >> 1) + 1) * GOLDEN), (int)(k & 1));
+        else p[tail0 + tid] = u01_from<S>(mix64(key + (uint64_t)(k + 1) * GOLDEN));
+    }
 }
 
 // standard normal by Box-Muller from two counter-RNG draws per scalar lane: lane k uses draws 2k and 2k+1.

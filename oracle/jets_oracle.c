@@ -86,6 +86,13 @@ static inline uint64_t jo_mix64(uint64_t z)
     return z ^ (z >> 31);
 }
 uint64_t jo_rng_key(uint64_t seed, uint64_t stream) { return jo_mix64(seed * JO_GOLDEN + stream); }
+/* Float32 lane k: 24 bits of hash(k >> 1) -- the top 24 for an even lane, bits 39..16 for an odd one (one hash per two values: the
+ * device generator is bound by its 64-bit multiplies).  Float64 lane k: the top 53 bits of hash(k). */
+static inline float jo_u01_f32(uint64_t key, int64_t lane)
+{
+    const uint64_t h = jo_mix64(key + (uint64_t)((lane >> 1) + 1) * JO_GOLDEN);
+    return (float)((lane & 1) ? ((h >> 16) & 0xFFFFFFull) : (h >> 40)) * 0x1.0p-24f;
+}
 
 /* scalar lanes: a complex vector of n elements is 2n scalar lanes (re, im interleaved) */
 void jo_rng_u01(int dtype, uint64_t seed, uint64_t stream, int64_t index0, int64_t count, void *out)
@@ -95,9 +102,12 @@ void jo_rng_u01(int dtype, uint64_t seed, uint64_t stream, int64_t index0, int64
     int lanes = (dtype == JO_C32 || dtype == JO_C64) ? 2 : 1;
     int64_t k0 = index0 * lanes, n = count * lanes;
     for (int64_t k = 0; k < n; k++) {
-        uint64_t h = jo_mix64(key + (uint64_t)(k0 + k + 1) * JO_GOLDEN);
-        if (is64) ((double *)out)[k] = (double)(h >> 11) * 0x1.0p-53;
-        else      ((float *)out)[k] = (float)(h >> 40) * 0x1.0p-24f;
+        if (is64) {
+            uint64_t h = jo_mix64(key + (uint64_t)(k0 + k + 1) * JO_GOLDEN);
+            ((double *)out)[k] = (double)(h >> 11) * 0x1.0p-53;
+        } else {
+            ((float *)out)[k] = jo_u01_f32(key, k0 + k);
+        }
     }
 }
 
@@ -209,8 +219,7 @@ int jo_fill_u01_omp_f32(int64_t nrow, int64_t n, uint64_t seed, int64_t row0, fl
             const int64_t lo = c * JO_OMP_CHUNK, hi = lo + JO_OMP_CHUNK < n ? lo + JO_OMP_CHUNK : n;
             for (int64_t i = 0; i < nrow; i++)
                 for (int64_t k = lo; k < hi; k++) {
-                    const uint64_t h = jo_mix64(key + (uint64_t)((row0 + i) * n + k + 1) * JO_GOLDEN);
-                    rows[i][k] = (float)(h >> 40) * 0x1.0p-24f;
+                    rows[i][k] = jo_u01_f32(key, (row0 + i) * n + k);
                 }
         }
     }

@@ -52,9 +52,9 @@ void jo_bspace_indices(int64_t nblocks, const int64_t *lens, int64_t *start1, in
 int jo_barr_locate(int64_t nblocks, const int64_t *start1, const int64_t *stop1, int64_t i1,
                    int64_t *iblock1, int64_t *ilocal1);
 
-/* counter-based U[0,1) generator shared with the device: element k of stream
- * (seed, stream) is mix64(key + (k+1)*GOLDEN) with key = mix64(seed*GOLDEN + stream);
- * f32 takes the top 24 bits, f64 the top 53 bits. complex: re = element 2k, im = 2k+1. */
+/* counter-based U[0,1) generator shared with the device: hash(j) = mix64(key + (j+1)*GOLDEN) with
+ * key = mix64(seed*GOLDEN + stream).  f64 lane k: the top 53 bits of hash(k).  f32 lane k (round 4): 24 bits of hash(k >> 1),
+ * the top 24 for an even lane and bits 39..16 for an odd one -- one hash per two values.  complex: re = lane 2k, im = lane 2k+1. */
 uint64_t jo_rng_key(uint64_t seed, uint64_t stream);
 void jo_rng_u01(int dtype, uint64_t seed, uint64_t stream, int64_t index0, int64_t count, void *out);
 

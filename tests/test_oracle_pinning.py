@@ -276,7 +276,9 @@ def test_rng_known_answers_from_an_independent_big_int_implementation():
     G, M = 0x9E3779B97F4A7C15, (1 << 64) - 1
     for seed, stream, base in [(1, 0, 0), (2, 0, 5), (3, 7, 2 ** 33 + 11)]:
         key = _mix64((seed * G + stream) & M)
-        want32 = [((_mix64((key + (base + k + 1) * G) & M)) >> 40) * 2.0 ** -24 for k in range(64)]
+        # Float32 lane j: 24 bits of hash(j >> 1) -- the top 24 for an even lane, bits 39..16 for an odd one (round 4: one hash per two values)
+        h32 = lambda j: _mix64((key + ((j >> 1) + 1) * G) & M)
+        want32 = [(((h32(base + k) >> 16) & 0xFFFFFF) if (base + k) & 1 else (h32(base + k) >> 40)) * 2.0 ** -24 for k in range(64)]
         want64 = [((_mix64((key + (base + k + 1) * G) & M)) >> 11) * 2.0 ** -53 for k in range(64)]
         assert np.array_equal(jo.rng_u01(np.float32, seed, stream, base, 64), np.array(want32, dtype=np.float32))
         assert np.array_equal(jo.rng_u01(np.float64, seed, stream, base, 64), np.array(want64, dtype=np.float64))
