@@ -2969,7 +2969,10 @@ int loop_adj(const jh_blockop *op, void *m, const void *d)           // JetBlock
 // AND big (the batched launch would leave the chip empty; the per-child kernel splits a big child's columns / rows over the grid
 // instead) they run child by child into the same slabs -- those operators are not launch-bound.
 template <typename S, int E>
-int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool transposed)
+// fmode (round 4): JetBlock_f! (988-1008) of such an operator -- the dense children's products are the same launches, the combine is
+// the general kernel in its f! mode (a zero block's `d .= 0` is added, not skipped; a SQUARE child squares): two launches where the
+// per-block loop made two per block
+int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool transposed, bool fmode = false)
 {
     jh_context &c = jh_ctx();
     const size_t es = jh_dtype_size(op->dtype);
@@ -3030,7 +3033,7 @@ int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool tran
         general_grid(want, nlines, ntiles, grid, general_use_xcd((transposed ? nrange : ndomain) * (int64_t)es));
         if (!transposed)
             hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3(grid, 1), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, op->dev_row_off,
-                               op->dev_col_off, (const S *)in, (S *)out, 0, ntiles, (int64_t)0, (S *)nullptr, (int64_t)0, (const S *)slabs, stride);
+                               op->dev_col_off, (const S *)in, (S *)out, fmode ? 1 : 0, ntiles, (int64_t)0, (S *)nullptr, (int64_t)0, (const S *)slabs, stride);
         else
             hipLaunchKernelGGL((k_block_adj_general<S, E>), dim3(grid, 1), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, op->dev_row_off,
                                op->dev_col_off, (S *)out, (const S *)in, ntiles, (int64_t)0, (S *)nullptr, (int64_t)0, (const S *)slabs, stride);
@@ -3041,13 +3044,13 @@ int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool tran
     return JH_OK;
 }
 
-int dense_mixed(const jh_blockop *op, void *out, const void *in, bool transposed)
+int dense_mixed(const jh_blockop *op, void *out, const void *in, bool transposed, bool fmode = false)
 {
     switch (op->dtype) {
-    case JH_F32: return dense_mixed_apply<float, 1>(op, out, in, transposed);
-    case JH_F64: return dense_mixed_apply<double, 1>(op, out, in, transposed);
-    case JH_C32: return dense_mixed_apply<float, 2>(op, out, in, transposed);
-    case JH_C64: return dense_mixed_apply<double, 2>(op, out, in, transposed);
+    case JH_F32: return dense_mixed_apply<float, 1>(op, out, in, transposed, fmode);
+    case JH_F64: return dense_mixed_apply<double, 1>(op, out, in, transposed, fmode);
+    case JH_C32: return dense_mixed_apply<float, 2>(op, out, in, transposed, fmode);
+    case JH_C64: return dense_mixed_apply<double, 2>(op, out, in, transposed, fmode);
     }
     return jh_fail(JH_ERR_INVALID, "dense_mixed: unknown dtype %d", op->dtype);
 }
@@ -3463,6 +3466,7 @@ int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     if (op->dense_batch_grid) return dense_grid_fwd(op, d->data, m->data);
     if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false, op->dev_row_off);
     if (op->small_loop && jh_ctx().small_loop) return loop_small(op, d->data, m->data, 0, 1);
+    if (op->dense_mixed && jh_ctx().dense_mixed) return dense_mixed(op, d->data, m->data, false, true);
     if (!op->elementwise) return run_loop_graphed(op, 2, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data, true); });
     switch (op->dtype) {
     case JH_F32: return general_fwd<float, 1>(op, d->data, m->data, 1);

@@ -468,3 +468,33 @@ def test_repointing_at_the_same_vector_replays_and_follows_the_contents(Jets, or
     Jets.mul_(d2, F, m)
     hm = m.to_numpy().ravel(order="F")
     assert np.allclose(d2.to_numpy(), np.concatenate([scales[i] * hm ** 3 for i in range(nrow)]), rtol=1e-14)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64])
+def test_f_mode_of_big_dense_children_in_mixed_company_takes_two_launches(Jets, oracle, dt):
+    """Round 4: JetBlock_f! (src/Jets.jl:988-1008) of an operator that mixes dense children too big for the one-launch loop with a
+    nonlinear child (JopBar's d .= m.^2, test/runtests.jl:19-24), a diagonal and a zero block: ONE batched GEMV launch for the dense
+    children + ONE launch of the general kernel in f! mode (a zero block's `d .= 0` is added, not skipped), where the per-block loop
+    made two launches per block.  The oracle's bits, and those of the loop it replaces."""
+    J = Jets
+    n1 = {4: 352, 8: 256}[np.dtype(dt).itemsize]                  # 484 KiB / 512 KiB children: beyond the one-launch loop's 256 KiB
+    len_r, len_c = [n1, n1, n1], [n1, n1, n1]
+    kinds = [["dense", "square", "zero"], ["zero", "dense", "diag"], ["square", "zero", "dense"]]
+    hmo = _split(u01(oracle, dt, 43, 0, sum(len_c)), len_c)
+    F, ops = _mixed(J, oracle, dt, len_r, len_c, kinds, seed=960, hmo=hmo)
+    mo = J.rand(J.domain(F), seed=43, stream=0)
+    hd = _split(u01(oracle, dt, 44, 0, sum(len_r)), len_r)
+    ref = oracle.block_f(ops, [x.copy() for x in hd], hmo)
+    got = {}
+    for knob in (1, 0):
+        J.tune(dense_mixed=knob)
+        try:
+            d = J.rand(J.range(F), seed=44, stream=0)              # dirty: `_d .+=` accumulates into d as found (1001)
+            J.mul_(d, F, mo)
+            if knob:
+                assert 1 <= J.tune_get("last_launches") <= 2, "one batched launch for the dense children + the combine"
+            got[knob] = d.to_numpy()
+        finally:
+            J.tune(dense_mixed=1)
+    assert_bits_equal(got[1], np.concatenate(ref), "f! with big dense children: batched route vs the oracle")
+    assert_bits_equal(got[1], got[0], "f! with big dense children: batched route vs the per-block loop")
