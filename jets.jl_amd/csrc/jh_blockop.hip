@@ -941,7 +941,8 @@ __global__ void k_sum_partials(const double *__restrict__ partials, int64_t n, i
 // in the adjoint each term's rows are summed in order into its own accumulator before the terms are combined.
 // Up to four terms run on the KM = 4 instantiations (two packs per lane); five to eight on KM = 8 (one pack per lane, to stay within
 // the registers of four waves per SIMD) -- round 3: eight terms used to be two launches, the second re-reading and re-writing d.
-constexpr int JH_SUM_MAX = 8;
+constexpr int JH_SUM_MAX = 16;           // coefficient streams per FORWARD launch (round 4); the adjoint takes JH_SUM_ADJ_MAX
+constexpr int JH_SUM_ADJ_MAX = 8;
 struct SumArgs {
     const jh_dev_block *blocks[JH_SUM_MAX];
     const void *a_base[JH_SUM_MAX];
@@ -3709,7 +3710,9 @@ static int sum_fwd_launch(const SumArgs &a, const jh_blockop *op0, void *d, cons
     // rows per workgroup, from same-box sweeps (profiles/bench_jetsum_r03.txt): workgroups that move ONE batch and exit stream best --
     // eight coefficient streams: one row of two packs per lane (5.9 TB/s; two rows of one pack 5.3-5.5, four rows 5.0-5.2);
     // up to four streams: two rows
-    constexpr int U = 2;
+    // round 4: NINE to SIXTEEN streams in one launch (one row of ONE pack per lane: 64 registers of coefficients in flight) -- an 11-term
+    // sum as 8 + 3 read and wrote the output twice (4.97 TB/s = 62 % of the roofline over its algorithmic bytes, bench_jetsum_r03.txt)
+    const int U = a.k > 8 ? 1 : 2;
     int G = c.fwd_group > 0 ? (int)c.fwd_group : (a.k > 4 ? 1 : 2);                       // rows per workgroup (knob fwd_group: sweeps)
     if (G > op0->nrow) G = (int)op0->nrow;
     const int64_t nvec = n_scalars / NS;
@@ -3717,7 +3720,10 @@ static int sum_fwd_launch(const SumArgs &a, const jh_blockop *op0, void *d, cons
     int64_t gy = (op0->nrow + G - 1) / G;
     while (gx * gy * BLK >= ((int64_t)1 << 32) && G < op0->nrow) { G *= 2; gy = (op0->nrow + G - 1) / G; }
     JH_REQUIRE(gx * gy * BLK < ((int64_t)1 << 32), "fused sum forward: grid too large");
-    if (a.k > 4)
+    if (a.k > 8)
+        hipLaunchKernelGGL((k_tall_sum_fwd<S, E, NS, 1, BLK, 16, 1>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G,
+                           (const S *)m, (S *)d, n_scalars, (unsigned)gx, accumulate);
+    else if (a.k > 4)
         hipLaunchKernelGGL((k_tall_sum_fwd<S, E, NS, 2, BLK, 8, 1>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G,
                            (const S *)m, (S *)d, n_scalars, (unsigned)gx, accumulate);
     else
@@ -3781,7 +3787,7 @@ int jh_blocksum_mul(int nterms, const jh_blockop *const *ops, const double *scal
                    "jh_blocksum_mul: term %d has a different shape or element type", t);
     }
     const int64_t n = ops[0]->row_len[0];
-    const int group = jh_ctx().sum_group == 4 ? 4 : JH_SUM_MAX;         // knob sum_group = 4: round 2's four terms per launch (A/B)
+    const int group = jh_ctx().sum_group == 4 ? 4 : (jh_ctx().sum_group == 8 ? 8 : JH_SUM_MAX);   // knob sum_group: 4 / 8 = round 2's / round 3's terms per launch (A/B), 16 (default)
     for (int t0 = 0; t0 < nterms; t0 += group) {
         const int k = nterms - t0 < group ? nterms - t0 : group;
         SumArgs a;
@@ -3814,7 +3820,7 @@ int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *
                    "jh_blocksum_mul_adj: term %d has a different shape or element type", t);
     }
     const int64_t n = ops[0]->row_len[0];
-    const int group = jh_ctx().sum_group == 4 ? 4 : JH_SUM_MAX;
+    const int group = jh_ctx().sum_group == 4 ? 4 : JH_SUM_ADJ_MAX;       // (each term keeps its own accumulator in the adjoint: eight per launch)
     void *tmp = nullptr;
     switch (ops[0]->dtype) {
 #define JH_SUM_ADJ(S, E, NS, NSCAL)                                                                         \

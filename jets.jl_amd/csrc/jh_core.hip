@@ -946,7 +946,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "slab_free_floor_mib")) { JH_REQUIRE(value >= 0, "slab_free_floor_mib must be >= 0"); g_slab_free_floor_mib.store(value); }
     else if (!strcmp(name, "alloc_role")) { JH_REQUIRE(value >= 0 && value <= 2, "alloc_role must be 0 (none), 1 (an operator's output) or 2 (data written once, read from then on)"); c.alloc_role = value; }
     else if (!strcmp(name, "dense_gw")) { JH_REQUIRE(value >= 0 && value <= 4096, "dense_gw must be 0 (automatic) or 1 .. 4096 children per wave"); c.dense_gw = value; }
-    else if (!strcmp(name, "sum_group")) { JH_REQUIRE(value == 4 || value == 8, "sum_group must be 4 or 8 terms per launch"); c.sum_group = value; }
+    else if (!strcmp(name, "sum_group")) { JH_REQUIRE(value == 4 || value == 8 || value == 16, "sum_group must be 4, 8 or 16 terms per forward launch"); c.sum_group = value; }
     else if (!strcmp(name, "grid_diag")) { JH_REQUIRE(value >= 0 && value <= 4, "grid_diag must be 0 (general kernels), 1, 2 or 4 (packs per lane)"); c.grid_diag = value; }
     else if (!strcmp(name, "wide_twin")) { JH_REQUIRE(value >= 0 && value <= 2, "wide_twin must be 0 (never), 1 (automatic) or 2 (always)"); c.wide_twin = value; }
     else if (!strcmp(name, "red_wgs")) { JH_REQUIRE(value >= 1 && value <= 1 << 20, "red_wgs out of range"); c.red_wgs = value; }

@@ -94,7 +94,7 @@ struct jh_context {
     int64_t grid_diag = 1;             // knob: M x K grids of plain diagonals on the branch-free kernel (0: the general kernels)
     int64_t grid_tile = 1;             // knob: ... register-tiled (k_grid_tile: R lines x one tile per workgroup): 1 automatic R, 2 / 4 / 8 that R, 0: k_grid_diag
     int64_t general_tile = 1;          // knob: grids of EQUAL elementwise blocks of any kinds register-tiled (k_general_tile: two lines x one tile per workgroup); 0: k_block_*_general_vec
-    int64_t sum_group = 8;             // knob: terms of a fused JetSum per launch (8; 4 = round 2's grouping, for A/B)
+    int64_t sum_group = 16;            // knob: terms of a fused JetSum per FORWARD launch (16; 8 / 4 = round 3's / round 2's grouping, for A/B); the adjoint takes 8 (4)
     int64_t dense_mixed = 1;           // knob: operators mixing big dense children with other kinds: one batched launch + one combine launch (0: the per-block loop)
     int64_t last_launches = 0;         // read-only: kernel launches of the most recent dense_mixed forward / adjoint
     int64_t dense_fused = 1;           // knob: tall / wide adjoint of many small uniform dense children on the fused kernel (k_gemv_cols_fused, round 4); 0: the three-launch path

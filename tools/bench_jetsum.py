@@ -42,7 +42,7 @@ if os.environ.get("SUM_FWD_GROUP"):
     J.tune(fwd_group=int(os.environ["SUM_FWD_GROUP"]))                # rows per workgroup of the fused forward (default 4)
 if os.environ.get("SUM_FWD_UNROLL"):
     J.tune(fwd_unroll=int(os.environ["SUM_FWD_UNROLL"]))
-for group in (8, 4, 8, 4):                                          # terms per launch: 8 (round 3) against round 2's 4, alternating in one process
+for group in (16, 8, 16, 8):                                        # forward terms per launch: 16 (round 4) against round 3's 8, alternating in one process
     J.tune(sum_group=group)
     tf = timed(lambda: J.mul_(d, S, m))
     ta = timed(lambda: J.mul_(mt, S.H, d))
