@@ -13,7 +13,7 @@ There is no CPU fallback: importing needs libjetship.so, computing needs a gfx95
 """
 from ._ffi import JetsHipError, LIB_PATH  # noqa: F401
 from . import device  # noqa: F401
-from .device import init, synchronize, shutdown, Event, tune, tune_get, device_info, device_count, stream_handle, trim  # noqa: F401
+from .device import init, synchronize, shutdown, Event, tune, tune_get, device_info, device_count, stream_handle, set_stream, trim  # noqa: F401
 from .device import context_create, context_use, context_current, context_destroy, using_context, context_of  # noqa: F401
 from .spaces import *  # noqa: F401,F403
 from .arrays import *  # noqa: F401,F403

@@ -230,3 +230,46 @@ def test_big_slabs_are_probed_when_they_enter_the_cache_and_an_allocation_with_a
     gc.collect()
     J.trim()
     assert J.tune_get("slab_probed") == 0
+
+
+def test_a_slab_is_not_handed_out_while_another_stream_still_writes_it(Jets):
+    """Round-3 advisor finding: the destroy waited for the owning context's CURRENT stream only, and then put the slab into the cache --
+    work of any other stream (a communicator's exchange stream under an early error return, a stream the application installed with
+    jh_set_stream and has replaced since, torch / RCCL streams on a wrapped vector) was no longer covered, where hipFree used to wait
+    for the whole device.  Here a second context's stream is installed in the first, a long chain of fills of a vector is enqueued on
+    it, the own stream is restored, the vector destroyed and a new one of its size created at once (zeros): it must BE zeros."""
+    J = Jets
+    gc.collect()
+    J.trim()
+    home = J.context_current()[0]
+    other = J.context_create(0)
+    try:
+        J.context_use(other)
+        foreign = J.stream_handle()                                  # the second context's stream
+        J.context_use(home)
+        spc = J.JetSpace(np.float32, 1 << 29)                        # 2 GiB: a fill takes ~0.3 ms
+        for trial in range(3):
+            x = J.Array(spc, undef=True)
+            ptr = x.ptr
+            J.set_stream(foreign)
+            for k in range(60):                                      # ~20 ms of writes into x on the foreign stream
+                J.fill_(x, float(k + 1))
+            J.set_stream(None)                                       # back on the context's own (idle) stream
+            x.close()                                                # -> the slab goes to the cache
+            del x
+            y = J.zeros(spc)                                         # the same slab, zero-filled on the own stream
+            assert y.ptr == ptr
+            J.synchronize()
+            J.context_use(other)
+            J.synchronize()
+            J.context_use(home)
+            mn, mx = J.extrema(y)
+            assert float(mn) == 0.0 and float(mx) == 0.0, f"trial {trial}: the old writer was still running when the slab was handed out (extrema {mn}, {mx})"
+            y.close()
+            del y
+    finally:
+        J.context_use(home)
+        J.set_stream(None)
+        gc.collect()
+        J.context_destroy(other)
+        J.trim()
