@@ -16,23 +16,40 @@ template <typename S, int NS> struct vec_of { typedef S type __attribute__((ext_
 template <typename S> struct vec_of<S, 1> { typedef S type; };
 
 // ---- y = A x ---------------------------------------------------------------------------------------
-// E scalars per element, NS scalars per 16-byte vector (NS == E: one element per lane, the unaligned fallback).
-template <typename S, int E, int NS>
-__global__ __launch_bounds__(256) void k_gemv_rows(const S *__restrict__ A, int64_t nr, int64_t nc, const S *__restrict__ x,
-                                                   S *__restrict__ out, int64_t cols_per_chunk)
+// acc += A[:, c0:c1] x[c0:c1] for this lane's NS scalar rows: columns in order, product rounded then added (the sequential loop's bits);
+// sixteen columns' loads in flight (the adds are serial by definition, the loads need not be).  Round 4 A/B against four in flight:
+// no difference at any size (4 x 8192^2 children 4.8, 16 x 4096^2 5.2, smaller ones 6.2-6.5 TB/s either way,
+// profiles/bench_dense_blocks_r04.txt) -- the forward of FEW HUGE children is not held back by memory-level parallelism
+template <typename S, int E, int NS, typename V>
+__device__ inline V gemv_rows_walk(const S *__restrict__ col, int64_t ns, const S *__restrict__ x, int64_t c0, int64_t c1)
 {
-    typedef typename vec_of<S, NS>::type V;
-    const int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * NS;          // first scalar row index of this lane
-    const int64_t ns = nr * E;
-    if (s >= ns) return;
-    const int64_t c0 = (int64_t)blockIdx.y * cols_per_chunk;
-    const int64_t c1 = c0 + cols_per_chunk < nc ? c0 + cols_per_chunk : nc;
     V acc = (V)(S)0;
-    const S *col = A + c0 * ns + s;
-    for (int64_t c = c0; c < c1; c++, col += ns) {
+    int64_t c = c0;
+    for (; c + 16 <= c1; c += 16) {
+        V a[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) a[k] = __builtin_nontemporal_load(reinterpret_cast<const V *>(col + (int64_t)k * ns));
+        col += 16 * ns;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if constexpr (E == 1) {
+                acc = acc + a[k] * (V)x[c + k];
+            } else {
+                const S xr = x[2 * (c + k)], xi = x[2 * (c + k) + 1];
+                V p;
+#pragma unroll
+                for (int e = 0; e < NS; e += 2) {
+                    p[e] = a[k][e] * xr - a[k][e + 1] * xi;
+                    p[e + 1] = a[k][e] * xi + a[k][e + 1] * xr;
+                }
+                acc = acc + p;
+            }
+        }
+    }
+    for (; c < c1; c++, col += ns) {
         V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col));
         if constexpr (E == 1) {
-            acc = acc + a * (V)x[c];                                           // product rounded, then added (no FMA: -ffp-contract=off)
+            acc = acc + a * (V)x[c];
         } else {
             const S xr = x[2 * c], xi = x[2 * c + 1];
             V p;
@@ -44,6 +61,22 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const S *__restrict__ A, int6
             acc = acc + p;
         }
     }
+    return acc;
+}
+
+
+// E scalars per element, NS scalars per 16-byte vector (NS == E: one element per lane, the unaligned fallback).
+template <typename S, int E, int NS>
+__global__ __launch_bounds__(256) void k_gemv_rows(const S *__restrict__ A, int64_t nr, int64_t nc, const S *__restrict__ x,
+                                                   S *__restrict__ out, int64_t cols_per_chunk)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * NS;          // first scalar row index of this lane
+    const int64_t ns = nr * E;
+    if (s >= ns) return;
+    const int64_t c0 = (int64_t)blockIdx.y * cols_per_chunk;
+    const int64_t c1 = c0 + cols_per_chunk < nc ? c0 + cols_per_chunk : nc;
+    const V acc = gemv_rows_walk<S, E, NS, V>(A + c0 * ns + s, ns, x, c0, c1);  // product rounded, then added (no FMA: -ffp-contract=off)
     *reinterpret_cast<V *>(out + (int64_t)blockIdx.y * ns + s) = acc;          // chunk 0 of a one-chunk launch is y itself
 }
 
@@ -140,24 +173,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows_batched(const jh_dev_block *_
     x += z * x_stride;                                                         // tall: every child reads m (stride 0); wide: child z reads m_z
     const int64_t c0 = (int64_t)blockIdx.y * cols_per_chunk;
     const int64_t c1 = c0 + cols_per_chunk < nc ? c0 + cols_per_chunk : nc;
-    V acc = (V)(S)0;
-    const S *col = A + c0 * ns + s;
-#pragma unroll 4
-    for (int64_t c = c0; c < c1; c++, col += ns) {                              // columns in order, product rounded then added
-        V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col));
-        if constexpr (E == 1) {
-            acc = acc + a * (V)x[c];
-        } else {
-            const S xr = x[2 * c], xi = x[2 * c + 1];
-            V p;
-#pragma unroll
-            for (int e = 0; e < NS; e += 2) {
-                p[e] = a[e] * xr - a[e + 1] * xi;
-                p[e + 1] = a[e] * xi + a[e + 1] * xr;
-            }
-            acc = acc + p;
-        }
-    }
+    const V acc = gemv_rows_walk<S, E, NS, V>(A + c0 * ns + s, ns, x, c0, c1);  // columns in order, product rounded then added
     *reinterpret_cast<V *>(out + obase + (int64_t)blockIdx.y * chunk_stride + s) = acc;
 }
 
