@@ -945,6 +945,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "walk_memory")) { c.walk_memory = value ? 1 : 0; }
     else if (!strcmp(name, "slab_free_floor_mib")) { JH_REQUIRE(value >= 0, "slab_free_floor_mib must be >= 0"); g_slab_free_floor_mib.store(value); }
     else if (!strcmp(name, "alloc_role")) { JH_REQUIRE(value >= 0 && value <= 2, "alloc_role must be 0 (none), 1 (an operator's output) or 2 (data written once, read from then on)"); c.alloc_role = value; }
+    else if (!strcmp(name, "dense_fwd_wgs")) { JH_REQUIRE(value >= 0 && value <= 65536, "dense_fwd_wgs must be 0 (automatic) .. 65536"); c.dense_fwd_wgs = value; }
     else if (!strcmp(name, "dense_gw")) { JH_REQUIRE(value >= 0 && value <= 4096, "dense_gw must be 0 (automatic) or 1 .. 4096 children per wave"); c.dense_gw = value; }
     else if (!strcmp(name, "sum_group")) { JH_REQUIRE(value == 4 || value == 8 || value == 16, "sum_group must be 4, 8 or 16 terms per forward launch"); c.sum_group = value; }
     else if (!strcmp(name, "grid_diag")) { JH_REQUIRE(value >= 0 && value <= 4, "grid_diag must be 0 (general kernels), 1, 2 or 4 (packs per lane)"); c.grid_diag = value; }
@@ -1000,6 +1001,7 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "last_cg_graph")) *value = c.last_cg_graph;
     else if (!strcmp(name, "last_cgls_overlaps")) *value = c.last_cgls_overlaps;
     else if (!strcmp(name, "dense_gw")) *value = c.dense_gw;
+    else if (!strcmp(name, "dense_fwd_wgs")) *value = c.dense_fwd_wgs;
     else if (!strcmp(name, "last_dense_fused")) *value = c.last_dense_fused;
     else if (!strcmp(name, "last_launches")) *value = c.last_launches;
     else if (!strcmp(name, "wide_twin")) *value = c.wide_twin;

@@ -663,8 +663,9 @@ int gemv_batched_wide(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr
         const int NS = vec_ok ? NSV : E;
         const int64_t row_wgs = (ns / NS + 255) / 256;
         int64_t nchunks = 1;
-        if (child_bytes >= (double)(1 << 20) && row_wgs * nchild < 2048) {
-            nchunks = (2048 + row_wgs * nchild - 1) / (row_wgs * nchild);
+        const int64_t want_wgs = c.dense_fwd_wgs > 0 ? c.dense_fwd_wgs : 512;   // (see gemv_batched)
+        if (child_bytes >= (double)(1 << 20) && row_wgs * nchild < want_wgs) {
+            nchunks = (want_wgs + row_wgs * nchild - 1) / (row_wgs * nchild);
             const int64_t maxc = (nc + 31) / 32;
             if (nchunks > maxc) nchunks = maxc;
         }
@@ -753,8 +754,12 @@ int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int
         const int NS = vec_ok ? NSV : E;
         const int64_t row_wgs = (ns / NS + 255) / 256;
         int64_t nchunks = 1;                                                   // split the columns only while the chip is not full
-        if (!row_off && child_bytes >= (double)(1 << 20) && row_wgs * nchild < 2048) {
-            nchunks = (2048 + row_wgs * nchild - 1) / (row_wgs * nchild);
+        // columns are split over grid.y only until about 512 workgroups exist: with sixteen loads in flight per lane that fills the chip,
+        // and every further chunk is another partial row to write and to fold (round 4 sweep, profiles/bench_dense_blocks_r04.txt:
+        // 4 x 8192^2 children 4.6 -> 5.8 TB/s, 16 x 4096^2 5.3 -> 6.1 against the 2048 of rounds 1-3); knob dense_fwd_wgs
+        const int64_t want_wgs = c.dense_fwd_wgs > 0 ? c.dense_fwd_wgs : 512;
+        if (!row_off && child_bytes >= (double)(1 << 20) && row_wgs * nchild < want_wgs) {
+            nchunks = (want_wgs + row_wgs * nchild - 1) / (row_wgs * nchild);
             const int64_t maxc = (nc + 31) / 32;
             if (nchunks > maxc) nchunks = maxc;
         }
@@ -856,8 +861,9 @@ int gemv(const void *A, int64_t nr, int64_t nc, void *y, const void *x, int adjo
         const int NS = vec_ok ? NSV : E;
         const int64_t row_wgs = (ns / NS + 255) / 256;
         int64_t nchunks = 1;
-        if (bytes >= (double)(1 << 20) && row_wgs < 2048) {                    // few rows: split the columns (tiny matrices stay one ordered sum)
-            nchunks = (2048 + row_wgs - 1) / row_wgs;
+        const int64_t want_wgs = c.dense_fwd_wgs > 0 ? c.dense_fwd_wgs : 512;   // (see gemv_batched)
+        if (bytes >= (double)(1 << 20) && row_wgs < want_wgs) {                // few rows: split the columns (tiny matrices stay one ordered sum)
+            nchunks = (want_wgs + row_wgs - 1) / row_wgs;
             const int64_t maxc = (nc + 31) / 32;
             if (nchunks > maxc) nchunks = maxc;
             if (nchunks > 65535) nchunks = 65535;

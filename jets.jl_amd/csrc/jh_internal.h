@@ -98,6 +98,7 @@ struct jh_context {
     int64_t dense_mixed = 1;           // knob: operators mixing big dense children with other kinds: one batched launch + one combine launch (0: the per-block loop)
     int64_t last_launches = 0;         // read-only: kernel launches of the most recent dense_mixed forward / adjoint
     int64_t dense_fused = 1;           // knob: tall / wide adjoint of many small uniform dense children on the fused kernel (k_gemv_cols_fused, round 4); 0: the three-launch path
+    int64_t dense_fwd_wgs = 0;         // knob: workgroups the batched dense forward splits its columns for (0 = 2048)
     int64_t dense_gw = 0;              // knob: children per WAVE of that kernel (0 = from the operator's shape)
     int64_t last_dense_fused = 0;      // read-only: 1 when the most recent batched dense adjoint ran on the fused kernel
     int64_t wide_twin = 1;             // knob: wide elementwise operators on their tall twin: 0 never (general kernels), 1 adjoint always + forward from 16 MiB blocks, 2 both always (tests)

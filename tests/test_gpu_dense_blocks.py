@@ -48,7 +48,7 @@ def test_batched_dense_children_forward_and_adjoint(Jets, oracle, dt, nchild, nr
     ref_d = oracle.block_df(ora, [np.full(nr, 9, dtype=dt) for _ in range(nchild)], [hm])
     item = np.dtype(dt).itemsize
     lanes = -(-(nr * item) // 16)                                                 # 16-byte packs per column
-    split = nr * nc * item >= (1 << 20) and -(-lanes // 256) * nchild < 2048       # big children that do not fill the chip: columns split
+    split = nr * nc * item >= (1 << 20) and -(-lanes // 256) * nchild < 512       # big children that do not fill the chip: columns split
     if split:
         assert _err(d.to_numpy(), np.concatenate(ref_d)) < _tol(dt)
     else:
@@ -130,7 +130,7 @@ def test_batched_dense_children_of_a_wide_operator(Jets, oracle, dt, nchild, nr,
     ref_d = oracle.block_df(ora, [hd0.copy()], mb)
     item = np.dtype(dt).itemsize
     lanes = -(-(nr * item) // 16)
-    split = nr * nc * item >= (1 << 20) and -(-lanes // 256) * nchild < 2048
+    split = nr * nc * item >= (1 << 20) and -(-lanes // 256) * nchild < 512
     if nchild <= 64 and not split:
         assert_bits_equal(d.to_numpy(), ref_d[0], "A*m == sum_j B_j m_j into d as found")
     else:

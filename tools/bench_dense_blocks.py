@@ -13,6 +13,7 @@ J.init(0)
 total = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024) << 20
 WIDE = len(sys.argv) > 2 and sys.argv[2] == "wide"
 GWS = [int(a[3:]) for a in sys.argv[2:] if a.startswith("gw=")]          # sweep of the fused adjoint's children-per-wave knob
+FWS = [int(a[4:]) for a in sys.argv[2:] if a.startswith("fws=")]        # sweep of the forward's column-split target (workgroups)
 OLD = "old" in sys.argv[2:]                                              # the three-launch adjoint of rounds 1-3 beside the fused kernel
 
 
@@ -44,6 +45,10 @@ for k in (8192, 4096, 2048, 1024, 512, 256, 128):
         J.tune(dense_gw=gw)
         extra += f" gw={gw}: {timed(lambda: J.mul_(mt, A.H, d)):.3f}"
     J.tune(dense_gw=0)
+    for w in FWS:
+        J.tune(dense_fwd_wgs=w)
+        extra += f" fws={w}: {timed(lambda: J.mul_(d, A, m)):.3f}"
+    J.tune(dense_fwd_wgs=0)
     if OLD:
         J.tune(dense_fused=0)
         t_old = timed(lambda: J.mul_(mt, A.H, d))
