@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void k_gemv_cols_fused(const jh_dev_block *__r
 
 // m[c] = sum over the groups (fixed order: 64 interleaved lane sums, then the wave's butterfly) of partial[c][g]; one wave per column
 template <typename S, int E>
-__global__ __launch_bounds__(256) void k_fold_fused(const double *__restrict__ partial, int64_t nc, int64_t ngroups, S *__restrict__ m)
+__global__ __launch_bounds__(256) void k_fold_fused(const double *__restrict__ partial, int64_t nc, int64_t ngroups, S *__restrict__ m, int add_found = 0)
 {
     const int lane = threadIdx.x & 63;
     const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -529,8 +529,66 @@ __global__ __launch_bounds__(256) void k_fold_fused(const double *__restrict__ p
         if constexpr (E == 2) i += __shfl_xor(i, s, 64);
     }
     if (lane == 0) {
+        if (add_found) {                                                       // the wide forward: `_d .+=` into d as found (1024)
+            r += (double)m[c * E];
+            if constexpr (E == 2) i += (double)m[c * E + 1];
+        }
         m[c * E] = (S)r;
         if constexpr (E == 2) m[c * E + 1] = (S)i;
+    }
+}
+
+// ---- the FORWARD of a wide operator of MANY SMALL children in one streaming kernel + the same fold (round 4) -------------------------------
+// d = d_found + sum_j A_j m_j over thousands of small children (1 x 16384 of 128^2): three launches and a child-sized slab per child before
+// (k_gemv_rows_batched into T, k_fold_wide_groups, k_fold_wide_final: 5.0-5.1 TB/s).  Here a lane owns one 16-byte pack of ROWS of one child
+// (lpc lanes per child, 64 / lpc children per wave side by side), walks that child's columns in order with sixteen loads in flight -- the
+// sequential loop's bits for every child's product, rounded to the element type like the reference's dtmp (1024) -- and adds it to its
+// fp64 running sum over the wave's Gw children; the lane groups of a wave, then the four waves of a workgroup are combined in a fixed order
+// and ONE fp64 partial per (group, scalar row) leaves the kernel, [row][group], for k_fold_fused (which adds d as found).  Tolerance parity,
+// as the fp64 group sums of the three-launch path were (wide operators of up to 64 children keep the reference's order: k_fold_wide_ordered).
+template <typename S, int E, int NS>
+__global__ __launch_bounds__(256) void k_gemv_rows_wide_fused(const jh_dev_block *__restrict__ blocks, int64_t nchild, int G, int P, int lsh, int64_t nc,
+                                                              const S *__restrict__ x, double *__restrict__ partial, int64_t ngroups)
+{
+    typedef typename vec_of<S, NS>::type V;
+    __shared__ double comb[4][64 * NS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lpc = 1 << lsh, cpw = 64 >> lsh, sub = lane & (lpc - 1), which = lane >> lsh;
+    const int64_t g = blockIdx.x;
+    const int Gw = (G + 3) >> 2;
+    const int64_t zlo = g * G + (int64_t)wave * Gw;
+    int64_t zhi = zlo + Gw;
+    if (zhi > (g + 1) * G) zhi = (g + 1) * G;
+    if (zhi > nchild) zhi = nchild;
+    const int64_t ns = (int64_t)P * NS;                                        // scalar rows of a child
+    double gacc[NS];
+#pragma unroll
+    for (int e = 0; e < NS; e++) gacc[e] = 0.0;
+    for (int64_t zb = zlo; zb < zhi; zb += cpw) {
+        const int64_t z = zb + which;
+        const bool ok = z < zhi && sub < P;
+        const int64_t zz = ok ? z : zlo;                                       // an idle lane walks the wave's first child again (its sum is dropped)
+        const S *col = (const S *)blocks[zz].coeff + (ok ? sub * NS : 0);
+        const V acc = gemv_rows_walk<S, E, NS, V>(col, ns, x + zz * nc * E, 0, nc);
+        if (ok) {
+#pragma unroll
+            for (int e = 0; e < NS; e++) gacc[e] += (double)acc[e];            // mul!(dtmp, A_j, m_j) is an array of the element type (1024)
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NS; e++)
+        for (int s = lpc; s < 64; s <<= 1) gacc[e] += __shfl_xor(gacc[e], s, 64);   // the children a wave walked side by side
+    if (which == 0 && sub < P) {
+#pragma unroll
+        for (int e = 0; e < NS; e++) comb[wave][sub * NS + e] = gacc[e];
+    }
+    __syncthreads();
+    if (wave == 0 && which == 0 && sub < P) {
+#pragma unroll
+        for (int e = 0; e < NS; e++) {
+            const int k = sub * NS + e;
+            partial[(int64_t)k * ngroups + g] = ((comb[0][k] + comb[1][k]) + comb[2][k]) + comb[3][k];
+        }
     }
 }
 
@@ -660,6 +718,26 @@ int gemv_batched_wide(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr
     const double child_bytes = (double)nr * (double)nc * sizeof(S) * E;
     JH_REQUIRE(nchild <= 32768, "batched wide dense operator: too many children");
     if (!adjoint) {                                                            // d (+)= sum_j A_j m_j
+        c.last_dense_fused = 0;
+        if (c.dense_fused && vec_ok && nchild > 64 && ns % NSV == 0 && ns / NSV <= 64 && nc >= 1 && child_bytes < (double)(1 << 20)) {
+            // many small children: one streaming kernel + the fold (see k_gemv_rows_wide_fused)
+            const int P = (int)(ns / NSV);
+            int lsh = 0;
+            while ((1 << lsh) < P) lsh++;
+            const int cpw = 64 >> lsh;
+            int64_t gw = c.dense_gw > 0 ? c.dense_gw : nchild / 4096;            // about 1024 groups
+            if (gw < cpw) gw = cpw;
+            gw = (gw + cpw - 1) / cpw * cpw;                                     // whole wave loads of children
+            const int64_t G = gw * 4, ngroups = (nchild + G - 1) / G;
+            JH_TRY(jh_ensure_partials(ns * ngroups + 2));
+            hipLaunchKernelGGL((k_gemv_rows_wide_fused<S, E, NSV>), dim3((unsigned)ngroups), dim3(256), 0, st, dev_blocks, nchild, (int)G, P, lsh, nc,
+                               (const S *)x, c.part_dev, ngroups);
+            JH_CHECK_HIP(hipGetLastError());
+            hipLaunchKernelGGL((k_fold_fused<S, 1>), dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, st, (const double *)c.part_dev, ns, ngroups, (S *)y, 1);
+            JH_CHECK_HIP(hipGetLastError());
+            c.last_dense_fused = 1;
+            return JH_OK;
+        }
         const int NS = vec_ok ? NSV : E;
         const int64_t row_wgs = (ns / NS + 255) / 256;
         int64_t nchunks = 1;

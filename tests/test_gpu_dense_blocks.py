@@ -114,7 +114,8 @@ def _wide_dense(Jets, oracle, dt, nchild, nr, nc, seed=950):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("nchild,nr,nc", [(2, 8, 8), (3, 5, 5), (5, 64, 48), (40, 12, 7), (300, 16, 128), (7, 256, 512)])
+@pytest.mark.parametrize("nchild,nr,nc", [(2, 8, 8), (3, 5, 5), (5, 64, 48), (40, 12, 7), (300, 16, 128), (7, 256, 512),
+                                          (70, 100, 33), (130, 256, 40), (1000, 20, 7), (300, 66, 19), (2100, 128, 128)])   # round 4: the fused wide forward's shapes
 def test_batched_dense_children_of_a_wide_operator(Jets, oracle, dt, nchild, nr, nc):
     """test/runtests.jl:744-758 (short-and-fat): A*m == B1 m1 + B2 m2 + ... accumulated into d AS FOUND (src/Jets.jl:1024),
     A'd == [B1'd; B2'd; ...].  Up to 64 children the forward keeps the reference's order and rounding (bit-exact while the
@@ -127,8 +128,10 @@ def test_batched_dense_children_of_a_wide_operator(Jets, oracle, dt, nchild, nr,
     d = Jets.rand(Jets.range(A), seed=5, stream=5)                                # dirty: the reference adds into it
     hd0 = u01(oracle, dt, 5, 5, nr)
     Jets.mul_(d, A, m)
-    ref_d = oracle.block_df(ora, [hd0.copy()], mb)
     item = np.dtype(dt).itemsize
+    fused_fwd = nchild > 64 and (nr * item) % 16 == 0 and nr * item // 16 <= 64 and nr * nc * item < (1 << 20)
+    assert Jets.tune_get("last_dense_fused") == (1 if fused_fwd else 0), "many small children: the one-kernel forward (round 4)"
+    ref_d = oracle.block_df(ora, [hd0.copy()], mb)
     lanes = -(-(nr * item) // 16)
     split = nr * nc * item >= (1 << 20) and -(-lanes // 256) * nchild < 512
     if nchild <= 64 and not split:
