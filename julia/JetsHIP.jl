@@ -67,14 +67,31 @@ _bvec_create(lens::Vector{Int64}, ::Type{T}, h, undef::Bool) where {T} = undef ?
     ccall((:jh_bvec_create_uninit, LIB), Cint, (Int64, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}), length(lens), lens, dtype_code(T), h) :
     ccall((:jh_bvec_create, LIB), Cint, (Int64, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}), length(lens), lens, dtype_code(T), h)
 
+# What a vector of 4 GiB or more is for (the library's knob alloc_role, include/jetship.h): 1 = an operator's output, 2 = data written once and
+# read from then on, 0 = unknown.  Of the cached slabs of its size the library hands an output the one it has measured as fastest to write (the
+# tall forward follows the slab it writes: 20.6-21.5 against 23.8-24.8 ms at the headline size), data the slowest (those read fastest).
+const _alloc_role = Ref(0)
+function with_alloc_role(f::Function, role::Integer)
+    old = _alloc_role[]
+    _alloc_role[] = role
+    try
+        return f()
+    finally
+        _alloc_role[] = old
+    end
+end
+
 function _create(lens::Vector{Int64}, ::Type{T}, undef::Bool=false) where {T}
     _ensure_init()
     h = Ref{Ptr{Cvoid}}()
+    hint = _alloc_role[] != 0 && sum(lens) * sizeof(T) >= (4 << 30)
+    hint && tune!("alloc_role", _alloc_role[])
     st = _bvec_create(lens, T, h, undef)
     if st == 3                                                     # JH_ERR_NOMEM: Julia's GC does not see device memory -- unreachable vectors may
         GC.gc()                                                    # still hold theirs.  Their finalizers hand it to the library's slab cache; ask again.
         st = _bvec_create(lens, T, h, undef)
     end
+    hint && tune!("alloc_role", 0)
     check(st)
     Slab(h[], length(lens))
 end
@@ -156,8 +173,11 @@ end
 Base.zeros(R::JetBSpace{T,S}) where {T,S<:HipSpace} = _blockarray(R)[1]
 Base.Array(R::JetBSpace{T,S}) where {T,S<:HipSpace} = _blockarray(R, true)[1]
 Base.ones(R::JetBSpace{T,S}) where {T,S<:HipSpace} = ((x, o) = _blockarray(R, true); _fill!(o, one(T)); x)
-Base.rand(R::JetBSpace{T,S}; seed=1) where {T,S<:HipSpace} = ((x, o) = _blockarray(R, true); _fill_uniform!(o, seed, _next_stream()); x)
-Base.randn(R::JetBSpace{T,S}; seed=1) where {T,S<:HipSpace} = ((x, o) = _blockarray(R, true); _fill_normal!(o, seed, _next_stream()); x)
+Base.rand(R::JetBSpace{T,S}; seed=1) where {T,S<:HipSpace} = ((x, o) = with_alloc_role(() -> _blockarray(R, true), 2); _fill_uniform!(o, seed, _next_stream()); x)
+Base.randn(R::JetBSpace{T,S}; seed=1) where {T,S<:HipSpace} = ((x, o) = with_alloc_role(() -> _blockarray(R, true), 2); _fill_normal!(o, seed, _next_stream()); x)
+# A*m = mul!(zeros(range(A)), A, m) (src/Jets.jl:399) with the output allocated as an OUTPUT (more specific than the reference's method in m only)
+Base.:*(A::Jop, m::HipArray) = mul!(with_alloc_role(() -> zeros(range(A)), 1), A, m)
+Base.:*(A::Jop, m::BlockArray{T,<:HipArray{T}}) where {T} = mul!(with_alloc_role(() -> zeros(range(A)), 1), A, m)
 
 # ---------------------------------------------------------------- HipArray: array interface
 Base.size(x::HipArray) = x.dims
