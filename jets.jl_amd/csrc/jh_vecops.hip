@@ -116,29 +116,31 @@ int fill_scalars(S *p, int64_t n, double re, double im)
 //   not by its store: with a hash per value rand(R) ran at 4.8 TB/s (60 % of the roofline, profiles/bench_suite_r03.txt).
 __device__ inline float u01_pair(uint64_t h, int odd) { return (float)(odd ? ((h >> 16) & 0xFFFFFFull) : (h >> 40)) * 0x1.0p-24f; }
 
+// zbase = key + (j0 + 1) * GOLDEN for the hash index j0 of PACK 0's first hash (the host forms it: one 64-bit multiply per launch); pack v's
+// first hash index is j0 + 2 v for both element widths (a Float32 pack spans two pairs, a Float64 pack two lanes), so its counter is
+// zbase + v * (2 GOLDEN): a workgroup-uniform product (scalar unit) plus thread-index-times-constant -- not a 64-bit multiply per pack
 template <typename S, int NS>
-__global__ void k_uniform(S *__restrict__ p, int64_t n, uint64_t key, int64_t lane_base)
+__global__ void k_uniform(S *__restrict__ p, int64_t n, uint64_t key, int64_t lane_base, uint64_t zbase, int odd)
 {
     const int64_t nvec = n / NS;
     const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * WG;
+    constexpr uint64_t G2 = 2 * GOLDEN;
     Pack<S, NS> *pv = reinterpret_cast<Pack<S, NS> *>(p);
-    for (int64_t v = tid; v < nvec; v += stride) {
+    uint64_t z0 = zbase + (uint64_t)blockIdx.x * ((uint64_t)WG * G2) + (uint64_t)(unsigned)threadIdx.x * G2;
+    const uint64_t zstep = (uint64_t)stride * G2;
+    for (int64_t v = tid; v < nvec; v += stride, z0 += zstep) {
         Pack<S, NS> o;
         if constexpr (sizeof(S) == 4) {
-            // lanes k0 .. k0 + 3 (k0 = lane_base + 4 v): pairs (k0 >> 1) and the next one -- and a third when k0 is odd.  One 64-bit multiply
-            // for the first counter, additions of a constant for the others
-            const int64_t k0 = lane_base + v * NS;
-            const uint64_t z0 = key + (uint64_t)((k0 >> 1) + 1) * GOLDEN;
+            // lanes k0 .. k0 + 3 (k0 = lane_base + 4 v): pairs (k0 >> 1) and the next one -- and a third when k0 is odd
             const uint64_t h0 = mix64(z0), h1 = mix64(z0 + GOLDEN);
-            if ((k0 & 1) == 0) {
+            if (!odd) {
                 o.v[0] = u01_pair(h0, 0); o.v[1] = u01_pair(h0, 1); o.v[2] = u01_pair(h1, 0); o.v[3] = u01_pair(h1, 1);
             } else {
                 const uint64_t h2 = mix64(z0 + 2 * GOLDEN);
                 o.v[0] = u01_pair(h0, 1); o.v[1] = u01_pair(h1, 0); o.v[2] = u01_pair(h1, 1); o.v[3] = u01_pair(h2, 0);
             }
         } else {
-            const uint64_t z0 = key + (uint64_t)(lane_base + v * NS + 1) * GOLDEN;
 #pragma unroll
             for (int c = 0; c < NS; c++) o.v[c] = u01_from<S>(mix64(z0 + (uint64_t)c * GOLDEN));
         }
@@ -603,10 +605,12 @@ int jh_fill_uniform(jh_bvec *v, uint64_t seed, uint64_t stream, int64_t index_ba
     const int lanes = jh_dtype_complex(v->dtype) ? 2 : 1;
     const int64_t n = v->length * lanes, base = index_base * lanes;
     hipStream_t st = jh_ctx().stream;
-    if (v->dtype == JH_F32 || v->dtype == JH_C32)
-        hipLaunchKernelGGL((k_uniform<float, 4>), dim3(grid_full(n / 4 + 1)), dim3(WG), 0, st, (float *)v->data, n, key, base);
+    if (v->dtype == JH_F32 || v->dtype == JH_C32)          // pack 0 starts at lane `base`: its first hash is that of pair base >> 1
+        hipLaunchKernelGGL((k_uniform<float, 4>), dim3(grid_full(n / 4 + 1)), dim3(WG), 0, st, (float *)v->data, n, key, base,
+                           key + (uint64_t)((base >> 1) + 1) * GOLDEN, (int)(base & 1));
     else
-        hipLaunchKernelGGL((k_uniform<double, 2>), dim3(grid_full(n / 2 + 1)), dim3(WG), 0, st, (double *)v->data, n, key, base);
+        hipLaunchKernelGGL((k_uniform<double, 2>), dim3(grid_full(n / 2 + 1)), dim3(WG), 0, st, (double *)v->data, n, key, base,
+                           key + (uint64_t)(base + 1) * GOLDEN, 0);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }

@@ -71,6 +71,9 @@ def test_rand_is_the_oracle_stream_bit_exact(Jets, oracle, dt):
     # a shard regenerates its slice of the global vector (index_base)
     y = Jets.rand(Jets.JetSpace(dt, 1000), seed=7, stream=11, index_base=37)
     assert_bits_equal(y.to_numpy(), u01(oracle, dt, 7, 11, 1000, index0=37), "rand slice")
+    for n, base in ((1003, 37), (1001, 38), (3, 5), (70001, 2 ** 33 + 1)):        # odd / even bases, tails that are not whole 16-byte packs, a far offset
+        z = Jets.rand(Jets.JetSpace(dt, n), seed=7, stream=11, index_base=base)
+        assert_bits_equal(z.to_numpy(), u01(oracle, dt, 7, 11, n, index0=base), f"rand slice of {n} from {base}")
     v = x.to_numpy()
     assert (v.real >= 0).all() and (v.real < 1).all()
 
