@@ -1622,12 +1622,11 @@ __global__ __launch_bounds__(256) void k_grid_tile(const jh_dev_block *__restric
 // is what holds k_block_*_general_vec to one block in flight (GENERAL_Q); the kind switches come afterwards, wave-uniform.
 // Each accumulator adds its non-zero blocks' terms in the reference's order, product rounded before the add: the bits of the general
 // kernels.  A block row of zero blocks only is left as found (forward, 1022); the adjoint of a grid (nrow > 1) always writes (1042).
-template <typename S, int E, int NS, int QQ, int U, bool TRANSPOSED>
+template <typename S, int E, int NS, int QQ, int U, bool TRANSPOSED, int R = 2>
 __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol, int64_t n_scalars,
                                                       const S *__restrict__ in, S *__restrict__ out, unsigned ntiles, unsigned ngroups)
 {
     typedef typename vec_of<S, NS>::type V;
-    constexpr int R = 2;
     int64_t grp, tile;
     general_line_tile(ngroups, ntiles, grp, tile);
     ntiles &= 0x7fffffffu;
@@ -2416,11 +2415,19 @@ int launch_general_tile(const jh_blockop *op, const S *in, S *out, int64_t in_by
 {
     jh_context &c = jh_ctx();
     const int64_t nlines = TRANSPOSED ? op->ncol : op->nrow, n_scalars = op->row_len[0] * E;
-    const int64_t ngroups = (nlines + 1) / 2;
+    // round 4: FOUR lines per workgroup, one step in flight (the input pack is loaded once for four lines), whenever there are four lines:
+    // same box against two lines x two steps, forward | adjoint: 32 x 32 of 128^3 4.88 -> 5.28 | 4.78 -> 5.36 TB/s, 16 x 16 of 256^3
+    // 5.43 -> 5.90 | 5.28 -> 5.87, 64 x 64 of 64^3 5.1 -> 5.7 | 5.1 -> 5.7, 8 x 8 and 64 x 4 +2 % (profiles/bench_grid_mixed_r04.txt).
+    // Knob general_tile: 1 this rule, 2 / 4 that many lines always, 0 the one-line kernels
+    const bool four = c.general_tile == 4 || (c.general_tile == 1 && nlines >= 4);
+    const int64_t ngroups = four ? (nlines + 3) / 4 : (nlines + 1) / 2;
     const int U = (c.fwd_unroll == 2) ? 2 : 1;                           // two packs per lane did not pay here (knob fwd_unroll = 2: measurements)
     unsigned ntiles, grid;
     general_grid((n_scalars / NS + 256 * U - 1) / (256 * U), ngroups, ntiles, grid, general_use_xcd(in_bytes));
-    if (U == 2)
+    if (four)
+        hipLaunchKernelGGL((k_general_tile<S, E, NS, 1, 1, TRANSPOSED, 4>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
+                           ntiles, (unsigned)ngroups);
+    else if (U == 2)
         hipLaunchKernelGGL((k_general_tile<S, E, NS, 2, 2, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
                            ntiles, (unsigned)ngroups);
     else

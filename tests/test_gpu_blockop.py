@@ -148,10 +148,10 @@ def _mixed_ops(Jets, oracle, dt, kinds, lens_r, lens_c, seed=21):
     return Jets.blockop(dev_rows), ora_rows
 
 
-@pytest.fixture(params=[1, 0], ids=["tiled", "one-line"])
+@pytest.fixture(params=[1, 2, 4, 0], ids=["tiled", "tiled-2-lines", "tiled-4-lines", "one-line"])
 def general_tile(request, Jets):
-    """Grids of EQUAL elementwise blocks run register-tiled (k_general_tile, round 3) or, with the knob off, on the one-line-per-
-    workgroup general kernels: the same bits either way."""
+    """Grids of EQUAL elementwise blocks run register-tiled (k_general_tile: two lines x one tile per workgroup in round 3, four from
+    four lines on since round 4) or, with the knob off, on the one-line-per-workgroup general kernels: the same bits either way."""
     Jets.tune(general_tile=request.param)
     yield request.param
     Jets.tune(general_tile=1)
