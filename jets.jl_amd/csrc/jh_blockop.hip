@@ -2688,19 +2688,13 @@ int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n
     return finish_normsq(gx, normsq);
 }
 
-template <typename S, int E, int NS>
-int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t n_scalars, double alpha, double beta, double *normsq,
-                  int64_t s_begin = 0, int64_t s_end = -1, bool defer = false)
+// The one-pass step's launch shape (workgroup x packs per thread x rows in flight) for an operator of nvec 16-byte packs per row.
+// profiles/bench_lsqr_step_r01.txt: 1024 x 256^3 wants thin threads with many rows in flight (512 x 1 x 4: 6.13 TB/s),
+// 128 x 256^3 fat ones (512 x 4 x 2: 5.46), 64 x 128^3 256 x 4 x 1 (5.9)
+struct StepShape { int wg, U, D; };
+static StepShape pick_step_shape(const jh_blockop *op, int64_t nvec, bool complex_f32)
 {
-    if (s_end < 0) s_end = n_scalars;
-    if (s_end <= s_begin) { if (normsq) *normsq = 0.0; return JH_OK; }
     jh_context &c = jh_ctx();
-    const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
-    const int64_t a_stride = op->diag_stride_elems * E;
-    const int64_t nvec = n_scalars / NS;
-    const int direct = op->nrow == 1 ? 1 : 0;
-    // profiles/bench_lsqr_step_r01.txt: 1024 x 256^3 wants thin threads with many rows in flight (512 x 1 x 4: 6.13 TB/s),
-    // 128 x 256^3 fat ones (512 x 4 x 2: 5.46), 64 x 128^3 256 x 4 x 1 (5.9)
     int wg = 256, U = 1, D = 4;
     if (nvec >= 4 * 256 * 256) { U = 4; D = 1; }
     else if (nvec >= 2 * 256 * 256) { U = 2; D = 2; }
@@ -2719,7 +2713,24 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
             if (nvec >= ((int64_t)1 << 22)) { wg = 512; U = 1; D = 4; }
         }
     }
-    if (E == 2 && sizeof(S) == 4 && wg == 1024 && U == 4 && D == 1) { U = 2; D = 2; }   // ComplexF32 at 128 VGPRs per lane: 4 x 1 spilled 20 bytes to scratch
+    if (complex_f32 && wg == 1024 && U == 4 && D == 1) { U = 2; D = 2; }   // ComplexF32 at 128 VGPRs per lane: 4 x 1 spilled 20 bytes to scratch
+    return {wg, U, D};
+}
+
+template <typename S, int E, int NS>
+int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t n_scalars, double alpha, double beta, double *normsq,
+                  int64_t s_begin = 0, int64_t s_end = -1, bool defer = false)
+{
+    if (s_end < 0) s_end = n_scalars;
+    if (s_end <= s_begin) { if (normsq) *normsq = 0.0; return JH_OK; }
+    jh_context &c = jh_ctx();
+    const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
+    const int64_t a_stride = op->diag_stride_elems * E;
+    const int64_t nvec = n_scalars / NS;
+    const int direct = op->nrow == 1 ? 1 : 0;
+    const StepShape shape = pick_step_shape(op, nvec, E == 2 && sizeof(S) == 4);
+    int wg = shape.wg, U = shape.U, D = shape.D;
+    const bool mixed = !op->all_diag;                       // rows of several elementwise kinds (tall_mixed_ok)
     const int64_t gx = ((s_end - s_begin) / NS + (int64_t)wg * U - 1) / ((int64_t)wg * U);
     // many rows of small blocks: split-row walk (pick_adj_parts): u's rows are updated as before, w's sum is folded from slabs
     int64_t parts = direct ? 1 : pick_adj_parts(gx, op->nrow);
@@ -3171,6 +3182,18 @@ int check_vectors(const jh_blockop *op, const jh_bvec *rng, const jh_bvec *dom, 
 bool jh_blockop_tall_fast(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
 {
     return tall_fast_ok(op, rng_ptr, dom_ptr) || (tall_mixed_ok(op, rng_ptr, dom_ptr) && !(op->nonlinear && !op->pointed));
+}
+
+// into how many row ranges the one-pass step over the whole domain cuts this operator (1: one plain launch -- what the graph-replayed
+// solver loops of jh_lsqr.hip need, because only the plain launch reads its coefficients from the device)
+int64_t jh_bidiag_step_parts(const jh_blockop *op)
+{
+    if (op->nrow == 1) return 1;
+    const int64_t ssize = (int64_t)jh_dtype_size(op->dtype) / (jh_dtype_complex(op->dtype) ? 2 : 1);
+    const int64_t n_scalars = op->col_len[0] * (jh_dtype_complex(op->dtype) ? 2 : 1), NS = 16 / ssize;
+    const StepShape sh = pick_step_shape(op, n_scalars / NS, op->dtype == JH_C32);
+    const int64_t gx = (n_scalars / NS + (int64_t)sh.wg * sh.U - 1) / ((int64_t)sh.wg * sh.U);
+    return pick_adj_parts(gx, op->nrow);
 }
 
 // all-DIAG tall operators only (the caller checks: jh_lsqr.hip, cg_graph_impl); one pack per lane, 8 rows in flight

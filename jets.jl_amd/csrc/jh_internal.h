@@ -324,6 +324,7 @@ __host__ __device__ inline void cg_s2(jh_cg_dev *st, double ssum, double rsum, d
 
 // jh_blockop.hip: one launch = [p <- s + bk p unless st->skip_p] ; y = A'A p (+ damp2 p) with the bits of jh_blockop_normal_mul (+ the
 // lincomb) ; one fp64 partial of <p, y> per workgroup of 256 packs.  *nparts = the number of partials written.
+int64_t jh_bidiag_step_parts(const jh_blockop *op);   // row ranges of the one-pass step over the whole domain (1: one plain launch)
 int jh_launch_cg_normal(const jh_blockop *op, jh_bvec *p, const jh_bvec *s, jh_bvec *y, const jh_cg_dev *st, double *partials, int64_t *nparts);
 void jh_bcast_clear_cache();            // jh_bcast.hip: unload every JIT-compiled broadcast program (jh_shutdown)
 int jh_chain_err_check();               // jh_blockop.hip: fails loudly if the chained step's sticky error word (copied to red_host[3]) is set

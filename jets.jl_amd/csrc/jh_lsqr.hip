@@ -132,7 +132,7 @@ struct LsqrDev {
     double coef_step[2];                         // (1, -alpha / beta): the next one-pass step
     double coef_vhat[2];                         // (1 / beta, -beta)
     double coef_xw[3];                           // (cv, t1, t2)
-    int itn, istop, done, pending, skipv, maxiter, force, pad;
+    int itn, istop, done, pending, skipv, maxiter, force, halt;   // halt = done || pending: the NEXT step is not to run (five-node iteration below)
 };
 
 // after the step: beta from ||u||^2, ||w|| of the previous iteration, the coefficients of the v update
@@ -167,6 +167,7 @@ __device__ inline void lsqr_s2(LsqrDev *st, double sum_v, double *__restrict__ h
         st->itn--;
         st->alpha = alpha;
         st->done = 1;
+        st->halt = 1;
         return;
     }
     const double cs1 = rhobar / rhobar1, sn1 = damp / rhobar1;
@@ -225,7 +226,10 @@ __device__ inline void lsqr_s2(LsqrDev *st, double sum_v, double *__restrict__ h
     st->xnorm = xnorm;
     st->coef_step[0] = 1.0;
     st->coef_step[1] = -alpha / beta;
-    if (istop && !(st->force && itn < st->maxiter && alpha > 0 && beta > 0)) st->pending = 1;   // x and w of THIS iteration are still updated
+    if (istop && !(st->force && itn < st->maxiter && alpha > 0 && beta > 0)) {
+        st->pending = 1;                         // x and w of THIS iteration are still updated
+        st->halt = 1;
+    }
 }
 
 __global__ void k_lsqr_s1(LsqrDev *st, const double *__restrict__ normsq, const double *__restrict__ slot_w)
@@ -242,7 +246,7 @@ __global__ void k_lsqr_s3(LsqrDev *st)
 }
 
 // the same three steps FUSED into the single-workgroup folds that precede them (k_sum_partials / k_lsqr_fold: the same strided sums
-// and the same tree, so the same bits): an iteration is then six graph nodes instead of ten, and the chain of dependent small
+// and the same tree, so the same bits): an iteration is then five graph nodes instead of ten, and the chain of dependent small
 // kernels is what a small operator's iteration costs
 template <int BLK> __device__ inline double wg_sum_value(double v)
 {
@@ -256,13 +260,28 @@ template <int BLK> __device__ inline double wg_sum_value(double v)
     for (int w = 1; w < BLK / 64; w++) r += sm[w];
     return r;                                    // (valid in every lane)
 }
-__global__ __launch_bounds__(256) void k_lsqr_fold_s1(const double *__restrict__ partials, int64_t nparts, LsqrDev *st, const double *__restrict__ slot_w)
+// (round 4: FIVE nodes.  The fold of ||w||^2 that closed an iteration only fed the NEXT iteration's first scalar step, and its
+// "pending -> done" can wait until then as long as the step in between does not run: the step looks at `halt`, this fold finishes
+// the solve and sums the x / w kernel's partials itself -- same strided sums, same tree, same bits as the separate fold.)
+__global__ __launch_bounds__(256) void k_lsqr_fold_s1(const double *__restrict__ partials, int64_t nparts, LsqrDev *st, const double *__restrict__ parts_w, int nparts_w,
+                                                      double *__restrict__ slot_w)
 {
     if (st->done) return;
+    if (st->pending) {
+        if (threadIdx.x == 0) st->done = 1;
+        return;
+    }
+    double w = 0.0;
+    for (int i = threadIdx.x; i < nparts_w; i += 256) w += parts_w[i];
+    const double rw = wg_sum_value<256>(w);
+    __syncthreads();                             // (wg_sum_value's scratch is used again)
     double v = 0.0;
     for (int64_t i = threadIdx.x; i < nparts; i += 256) v += partials[i];
     const double r = wg_sum_value<256>(v);
-    if (threadIdx.x == 0) lsqr_s1(st, 0.0 + r, slot_w);      // (k_sum_partials adds its sum to a zeroed accumulator)
+    if (threadIdx.x == 0) {
+        *slot_w = rw;
+        lsqr_s1(st, 0.0 + r, slot_w);            // (k_sum_partials adds its sum to a zeroed accumulator)
+    }
 }
 __global__ __launch_bounds__(256) void k_lsqr_fold_s2(const double *__restrict__ partials, int nparts, LsqrDev *st, double *__restrict__ history)
 {
@@ -271,17 +290,6 @@ __global__ __launch_bounds__(256) void k_lsqr_fold_s2(const double *__restrict__
     for (int i = threadIdx.x; i < nparts; i += 256) v += partials[i];
     const double r = wg_sum_value<256>(v);
     if (threadIdx.x == 0) lsqr_s2(st, r, history);
-}
-__global__ __launch_bounds__(256) void k_lsqr_fold_s3(const double *__restrict__ partials, int nparts, double *__restrict__ slot_w, LsqrDev *st)
-{
-    if (st->done) return;
-    double v = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 256) v += partials[i];
-    const double r = wg_sum_value<256>(v);
-    if (threadIdx.x == 0) {
-        *slot_w = r;
-        if (st->pending) st->done = 1;
-    }
 }
 
 template <typename S>
@@ -560,7 +568,7 @@ static int lsqr_graph_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use
     if (!jh_blockop_tall_fast(op, u->data, x->data)) return JH_OK;
     // one plain launch per step: no split walk (pick_adj_parts), no row-chunked launches; and only where launches and host
     // round trips matter: a pass over the operator and u below 1 GiB
-    if (!(c.adj_split <= 0 && (op->nrow < 256 || c.adj_split == 0) && c.adj_rows_per_launch == 0)) return JH_OK;
+    if (!(jh_bidiag_step_parts(op) == 1 && c.adj_rows_per_launch == 0)) return JH_OK;
     const int dtype = x->dtype;
     const int64_t n = x->length;
     if (3.0 * (double)op->nrow * (double)n * (double)jh_dtype_size(dtype) >= (double)(1ull << 30)) return JH_OK;
@@ -667,24 +675,23 @@ static int lsqr_graph_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use
         JH_CHECK_HIP(hipGetLastError());
         return JH_OK;
     };
-    // the same iteration with the scalar steps fused into the folds (six nodes): possible when the step's partial sums fit ONE
+    // the same iteration with the scalar steps fused into the folds (five nodes): possible when the step's partial sums fit ONE
     // fold launch (k_sum_partials' single-level form, <= 8192 workgroups) -- known after the eager iteration
     auto iteration_fused = [&]() -> int {
         c.step_coef_dev = d.st->coef_step;
-        c.step_done_dev = &d.st->done;
+        c.step_done_dev = &d.st->halt;
         c.step_skip_fold = 1;
         const int st_ = jh_blockop_bidiag_step_range(op, u, t.v, t.atu, 1.0, 0.0, 0, n, nullptr);
         c.step_coef_dev = nullptr;
         c.step_done_dev = nullptr;
         c.step_skip_fold = 0;
         JH_TRY(st_);
-        hipLaunchKernelGGL(k_lsqr_fold_s1, dim3(1), dim3(256), 0, c.stream, (const double *)c.part_dev, c.last_step_parts, d.st, (const double *)slot_w);
+        hipLaunchKernelGGL(k_lsqr_fold_s1, dim3(1), dim3(256), 0, c.stream, (const double *)c.part_dev, c.last_step_parts, d.st, (const double *)parts_w, grid, slot_w);
         if (f64) hipLaunchKernelGGL((k_lsqr_vhat_dev<double>), dim3(grid), dim3(256), 0, c.stream, (double *)t.v->data, (const double *)t.atu->data, ns_dom, (const LsqrDev *)d.st, parts_v);
         else hipLaunchKernelGGL((k_lsqr_vhat_dev<float>), dim3(grid), dim3(256), 0, c.stream, (float *)t.v->data, (const float *)t.atu->data, ns_dom, (const LsqrDev *)d.st, parts_v);
         hipLaunchKernelGGL(k_lsqr_fold_s2, dim3(1), dim3(256), 0, c.stream, (const double *)parts_v, grid, d.st, d.hist);
         if (f64) hipLaunchKernelGGL((k_lsqr_xw_dev<double>), dim3(grid), dim3(256), 0, c.stream, (double *)t.v->data, (double *)x->data, (double *)t.w->data, ns_dom, (const LsqrDev *)d.st, parts_w);
         else hipLaunchKernelGGL((k_lsqr_xw_dev<float>), dim3(grid), dim3(256), 0, c.stream, (float *)t.v->data, (float *)x->data, (float *)t.w->data, ns_dom, (const LsqrDev *)d.st, parts_w);
-        hipLaunchKernelGGL(k_lsqr_fold_s3, dim3(1), dim3(256), 0, c.stream, (const double *)parts_w, grid, slot_w, d.st);
         JH_CHECK_HIP(hipGetLastError());
         return JH_OK;
     };
@@ -708,7 +715,7 @@ static int lsqr_graph_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use
         if (st_ != JH_OK) return st_;
         JH_CHECK_HIP(e);
         JH_CHECK_HIP(hipGraphInstantiate(&d.exec, d.graph, nullptr, nullptr, 0));
-        while (!fl.done) {                                                // two graphs between two looks at the flags
+        while (!(fl.done || (fused && fl.pending))) {                     // two graphs between two looks at the flags (five nodes: `pending` ends the solve)
             for (int k = 0; k < 2; k++) JH_CHECK_HIP(hipGraphLaunch(d.exec, c.stream));
             replays += 2;
             JH_TRY(read_flags());
@@ -1081,6 +1088,8 @@ __global__ __launch_bounds__(256) void k_cg_xs(S *__restrict__ x, S *__restrict_
     wg_sum_to<256>(nrm, partials + blockIdx.x);
 }
 
+static inline int64_t n_packs_of(const jh_blockop *op) { return op->col_len[0] * (int64_t)jh_dtype_size(op->dtype) / 16; }
+
 static int cg_dev_impl(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter, int force_maxiter,
                        jh_lsqr_result *res, double *history, const bool cgls, bool *took)
 {
@@ -1091,7 +1100,10 @@ static int cg_dev_impl(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0,
     jh_context &c = jh_ctx();
     if (c.cg_dev == 0 || maxiter < 1) return JH_OK;
     if (!(op->tall && op->all_diag) || !jh_blockop_tall_fast(op, b->data, x->data) || op->nrow < 2) return JH_OK;
-    if (!(c.adj_split <= 0 && (op->nrow < 256 || c.adj_split == 0) && c.adj_rows_per_launch == 0)) return JH_OK;   // one plain launch per pass
+    // one plain launch per pass: CGLS' second pass is the one-pass step; the fused A'A of this loop (k_cg_normal) walks all rows in every
+    // workgroup, which fills the chip when the domain gives a workgroup per CU (many rows of tiny blocks keep the split walk of the host loop)
+    const int64_t normal_wgs = (n_packs_of(op) + 255) / 256;
+    if (c.adj_rows_per_launch != 0 || (cgls ? jh_bidiag_step_parts(op) != 1 : (c.adj_split > 0 || (op->nrow >= 256 && c.adj_split != 0 && normal_wgs < c.cu_count)))) return JH_OK;
     const int dtype = x->dtype;
     const int64_t n = x->length;
     if (3.0 * (double)op->nrow * (double)n * (double)jh_dtype_size(dtype) >= (double)(1ull << 30)) return JH_OK;  // launch-bound sizes only

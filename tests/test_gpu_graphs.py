@@ -134,3 +134,35 @@ def test_graph_replayed_cg_loops_of_small_operators_have_the_bits_of_the_host_dr
             xr = ref[0] if isinstance(ref, tuple) else ref.x
             np.testing.assert_allclose(rg.x.to_numpy().ravel(order="F"), np.asarray(xr).astype(dt), rtol=tol, atol=tol * 1e-1)
     J.close(A)
+
+
+def test_many_rows_take_the_device_loops_when_a_pass_is_one_plain_launch(Jets):
+    """256 rows and more: the split-row walk (pick_adj_parts) is what keeps the step from being one launch, not the row count.  256
+    rows of 64^3 Float32 fill the chip with the plain walk (one workgroup per CU), so all three loops replay graphs -- with the bits of
+    the host-driven loops; 256 rows of 16^3 do not (4 workgroups), so LSQR / CGLS keep the split walk and CG through the fused A'A the
+    host loop, whose A'A splits the rows."""
+    J = Jets
+    for edge, expect_graph in ((64, True), (16, False)):
+        spc = J.JetSpace(np.float32, edge, edge, edge)
+        coeff = J.rand(J.JetBSpace([spc] * 256), seed=81, stream=0)
+        A = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
+        b = J.mul(A, J.rand(spc, seed=82, stream=0))
+        for name, knob in (("lsqr", "last_lsqr_graph"), ("cgls", "last_cg_graph"), ("cgnr", "last_cg_graph")):
+            kw = dict(maxiter=21, atol=0.0, btol=0.0, force_maxiter=True)
+            if name == "lsqr":
+                kw["conlim"] = 0.0
+            out = {}
+            for graph in (1, 0):
+                J.tune(lsqr_graph=graph)
+                try:
+                    r = getattr(J, name)(A, b, **kw)
+                    out[graph] = (r, J.tune_get(knob))
+                finally:
+                    J.tune(lsqr_graph=1)
+            (rg, replays), (rh, zero) = out[1], out[0]
+            assert zero == 0 and (replays > 0) == expect_graph, (name, edge, replays)
+            assert (rg.itn, rg.istop) == (rh.itn, rh.istop) == (21, 7), (name, edge)
+            if expect_graph:
+                assert_bits_equal(rg.x.to_numpy(), rh.x.to_numpy(), f"{name} x, 256 x {edge}^3")
+                assert rg.history == rh.history, (name, edge)
+        J.close(A)
