@@ -325,62 +325,88 @@ template <int BLK> __device__ inline void wg_sum_store(double v, double *slot)
 // walks all rows in order with DEPTH rows in flight exactly as k_tall_diag_adj MODE 1 does (product, product, add, each rounded: the bits
 // of jh_blockop_normal_mul), adds the damping term with the lincomb's rounding, stores y and leaves its share of <p, y> (fp64) to the
 // workgroup's partial.  Coefficients (bk, damp^2, the flags) come from device memory, so the launch is the same every iteration.
-template <typename S, int E, int NS, int DEPTH>
-__global__ __launch_bounds__(256) void k_cg_normal(const jh_dev_block *__restrict__ blocks, int64_t nrow, const S *__restrict__ a_base, int64_t a_stride,
+template <typename S, int E, int NS, int DEPTH, int BLK = 256, int U = 1>
+__global__ __launch_bounds__(BLK) void k_cg_normal(const jh_dev_block *__restrict__ blocks, int64_t nrow, const S *__restrict__ a_base, int64_t a_stride,
                                                    S *__restrict__ p, const S *__restrict__ sres, S *__restrict__ y, int64_t n_scalars,
                                                    const jh_cg_dev *__restrict__ stt, double *__restrict__ partials)
 {
     typedef typename vec_of<S, NS>::type V;
-    const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * NS;
-    const bool ok = s0 < n_scalars;
-    const int64_t sk = ok ? s0 : 0;
+    // a thread owns U packs, BLK packs apart (the shapes of the fused normal operator, launch_tall_adj_mixed: fat workgroups once the
+    // blocks are big -- 64 x 128^3 with 256 x 1 x 8: 120 us per pass, with 512 x 2 x 2: 80)
+    int64_t sk[U];
+    bool ok[U];
+    V pv[U], sv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int64_t s0 = (((int64_t)blockIdx.x * U + u) * BLK + threadIdx.x) * NS;
+        ok[u] = s0 < n_scalars;
+        sk[u] = ok[u] ? s0 : 0;
+    }
     // the state and this lane's packs of p and s are requested together, before the first decision (a launch of this size is paced by
     // round trips, not by bytes).  Folding the previous vector update's ||s||^2 partials and applying the second scalar update HERE, in
     // every workgroup (one more graph node less), was tried and lost: the whole grid then waits for a fold, a barrier and an fp64 chain
     // before its first coefficient load -- 28.7 us per iteration against 20.2 at 64 x 64^3 (profiles/bench_cgnr_sizes_r04.txt).
-    V pv = ld<false>(reinterpret_cast<const V *>(p + sk));
-    V sv = ld<false>(reinterpret_cast<const V *>(sres + sk));
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        pv[u] = ld<false>(reinterpret_cast<const V *>(p + sk[u]));
+        sv[u] = ld<false>(reinterpret_cast<const V *>(sres + sk[u]));
+    }
     const int done = stt->done, skip_p = stt->skip_p;
     const double bk = stt->bk, damp2 = stt->damp2;
-    asm volatile("" : "+v"(pv), "+v"(sv));
+#pragma unroll
+    for (int u = 0; u < U; u++) asm volatile("" : "+v"(pv[u]), "+v"(sv[u]));
     if (done) return;
     if (!skip_p) {                                                           // p = 1*s + bk*p  (jh_lincomb's sequence: bk*p rounded, then the sum)
-        const V bp = (V)(S)bk * pv;
-        pv = sv + bp;
-        if (ok) st<false>(reinterpret_cast<V *>(p + sk), pv);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const V bp = (V)(S)bk * pv[u];
+            pv[u] = sv[u] + bp;
+            if (ok[u]) st<false>(reinterpret_cast<V *>(p + sk[u]), pv[u]);
+        }
     }
-    V acc = (V)(S)0;
+    V acc[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) acc[u] = (V)(S)0;
     int64_t i = 0;
     for (; i + DEPTH <= nrow; i += DEPTH) {
-        V av[DEPTH];
+        V av[DEPTH][U];
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) {
             const S *a = a_base ? a_base + (i + j) * a_stride : (const S *)blocks[i + j].coeff;
-            av[j] = ld<true>(reinterpret_cast<const V *>(a + sk));
+#pragma unroll
+            for (int u = 0; u < U; u++) av[j][u] = ld<true>(reinterpret_cast<const V *>(a + sk[u]));
         }
 #pragma unroll
-        for (int j = 0; j < DEPTH; j++) {
-            const V t = vmul<S, E, NS, V>(av[j], pv, false);                  // d_i = a_i .* p
-            acc = acc + vmul<S, E, NS, V>(av[j], t, true);                    // y .+= conj(a_i) .* d_i, rows in order
-        }
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const V t = vmul<S, E, NS, V>(av[j][u], pv[u], false);        // d_i = a_i .* p
+                acc[u] = acc[u] + vmul<S, E, NS, V>(av[j][u], t, true);       // y .+= conj(a_i) .* d_i, rows in order
+            }
     }
     for (; i < nrow; i++) {
         const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
-        const V av = ld<true>(reinterpret_cast<const V *>(a + sk));
-        const V t = vmul<S, E, NS, V>(av, pv, false);
-        acc = acc + vmul<S, E, NS, V>(av, t, true);
-    }
-    if (damp2 != 0.0) {                                                      // y = 1*y + damp^2*p
-        const V dp = (V)(S)damp2 * pv;
-        acc = acc + dp;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const V av = ld<true>(reinterpret_cast<const V *>(a + sk[u]));
+            const V t = vmul<S, E, NS, V>(av, pv[u], false);
+            acc[u] = acc[u] + vmul<S, E, NS, V>(av, t, true);
+        }
     }
     double part = 0.0;
-    if (ok) {
-        st<false>(reinterpret_cast<V *>(y + sk), acc);
 #pragma unroll
-        for (int e = 0; e < NS; e++) part += (double)pv[e] * (double)acc[e];   // Re <p, y>: over the scalars (a complex vector is 2n reals here)
+    for (int u = 0; u < U; u++) {
+        if (damp2 != 0.0) {                                                  // y = 1*y + damp^2*p
+            const V dp = (V)(S)damp2 * pv[u];
+            acc[u] = acc[u] + dp;
+        }
+        if (ok[u]) {
+            st<false>(reinterpret_cast<V *>(y + sk[u]), acc[u]);
+#pragma unroll
+            for (int e = 0; e < NS; e++) part += (double)pv[u][e] * (double)acc[u][e];   // Re <p, y>: over the scalars (a complex vector is 2n reals here)
+        }
     }
-    wg_sum_store<256>(part, partials + blockIdx.x);
+    wg_sum_store<BLK>(part, partials + blockIdx.x);
 }
 
 
@@ -3203,13 +3229,22 @@ int jh_launch_cg_normal(const jh_blockop *op, jh_bvec *p, const jh_bvec *s, jh_b
     JH_REQUIRE(op->all_diag && tall_fast_ok(op, nullptr, p->data), "cg normal pass: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
     const int64_t n = op->row_len[0];
     const int64_t packs = (n * (int64_t)jh_dtype_size(op->dtype)) / 16;
-    const int64_t grid = (packs + 255) / 256;
+    // launch-bound domains: thin workgroups with eight rows in flight; from 2 MiB blocks on the fused normal operator's shapes
+    const int shape = packs >= ((int64_t)1 << 22) ? 2 : (packs >= ((int64_t)1 << 17) ? 1 : 0);
+    const int64_t per_wg = shape == 2 ? 4096 : (shape == 1 ? 1024 : 256);
+    const int64_t grid = (packs + per_wg - 1) / per_wg;
     JH_REQUIRE(grid >= 1 && grid < ((int64_t)1 << 22), "cg normal pass: domain of %lld elements is out of range", (long long)n);
     *nparts = grid;
-#define JH_CGN(S, E, NS)                                                                                                                        \
-    hipLaunchKernelGGL((k_cg_normal<S, E, NS, 8>), dim3((unsigned)grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow,                        \
+#define JH_CGN_S(S, E, NS, DEPTH, BLK, U)                                                                                                       \
+    hipLaunchKernelGGL((k_cg_normal<S, E, NS, DEPTH, BLK, U>), dim3((unsigned)grid), dim3(BLK), 0, c.stream, op->dev_blocks, op->nrow,           \
                        op->diag_strided ? (const S *)op->blocks[0].coeff : (const S *)nullptr, op->diag_stride_elems * E, (S *)p->data,          \
                        (const S *)s->data, (S *)y->data, n * E, st, partials)
+#define JH_CGN(S, E, NS)                                                                                                                        \
+    do {                                                                                                                                        \
+        if (shape == 2) JH_CGN_S(S, E, NS, ((E == 2 && sizeof(S) == 4) ? 2 : 4), 1024, 4);                                                      \
+        else if (shape == 1) JH_CGN_S(S, E, NS, 2, 512, 2);                                                                                     \
+        else JH_CGN_S(S, E, NS, 8, 256, 1);                                                                                                     \
+    } while (0)
     switch (op->dtype) {
     case JH_F32: JH_CGN(float, 1, 4); break;
     case JH_F64: JH_CGN(double, 1, 2); break;
@@ -3217,6 +3252,7 @@ int jh_launch_cg_normal(const jh_blockop *op, jh_bvec *p, const jh_bvec *s, jh_b
     case JH_C64: JH_CGN(double, 2, 2); break;
     default: return jh_fail(JH_ERR_INVALID, "cg normal pass: unknown dtype %d", op->dtype);
     }
+#undef JH_CGN_S
 #undef JH_CGN
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;

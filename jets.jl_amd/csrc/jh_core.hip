@@ -941,7 +941,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "general_tile")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "general_tile must be 0 (one-line kernels), 1 (automatic), 2 or 4 lines per workgroup"); c.general_tile = value; }
     else if (!strcmp(name, "dense_fused")) { JH_REQUIRE(value == 0 || value == 1, "dense_fused must be 0 or 1"); c.dense_fused = value; }
     else if (!strcmp(name, "cgls_trace")) { c.cgls_trace = value ? 1 : 0; }
-    else if (!strcmp(name, "cg_dev")) { c.cg_dev = value ? 1 : 0; }
+    else if (!strcmp(name, "cg_dev")) { c.cg_dev = value < 0 ? 0 : (value > 2 ? 2 : value); }
     else if (!strcmp(name, "walk_memory")) { c.walk_memory = value ? 1 : 0; }
     else if (!strcmp(name, "slab_free_floor_mib")) { JH_REQUIRE(value >= 0, "slab_free_floor_mib must be >= 0"); g_slab_free_floor_mib.store(value); }
     else if (!strcmp(name, "alloc_role")) { JH_REQUIRE(value >= 0 && value <= 2, "alloc_role must be 0 (none), 1 (an operator's output) or 2 (data written once, read from then on)"); c.alloc_role = value; }

@@ -166,3 +166,34 @@ def test_many_rows_take_the_device_loops_when_a_pass_is_one_plain_launch(Jets):
                 assert_bits_equal(rg.x.to_numpy(), rh.x.to_numpy(), f"{name} x, 256 x {edge}^3")
                 assert rg.history == rh.history, (name, edge)
         J.close(A)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64, np.float64])
+@pytest.mark.parametrize("shape,nrow", [((128, 128, 32), 5), ((256, 256, 64), 3), ((256, 256, 256), 3)])
+def test_cg_normal_pass_at_its_three_launch_shapes(Jets, dt, shape, nrow):
+    """k_cg_normal launches thin workgroups for launch-bound domains and the fused normal operator's fat ones from 2 MiB / 64 MiB blocks on
+    (jh_launch_cg_normal): whichever shape, the replayed loop has the bits of the host-driven one (same kernels), both agree with the loop
+    of large operators (cg_dev = 0: separate lincombs around jh_blockop_normal_mul) to solver tolerance, and the solve converges."""
+    J = Jets
+    if np.dtype(dt).itemsize * int(np.prod(shape)) * nrow > (1 << 30):
+        pytest.skip("more than 1 GiB of coefficients for a shape check")
+    spc = J.JetSpace(dt, *shape)
+    coeff = J.rand(J.JetBSpace([spc] * nrow), seed=91, stream=0)
+    A = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
+    x_true = J.rand(spc, seed=92, stream=0)
+    b = J.mul(A, x_true)
+    out = {}
+    for mode in ("graph", "host", "large"):
+        J.tune(lsqr_graph=0 if mode == "host" else 1, cg_dev=0 if mode == "large" else 1)
+        try:
+            out[mode] = (J.cgnr(A, b, maxiter=12, atol=0.0, btol=0.0, damp=0.125), J.tune_get("last_cg_graph"))
+        finally:
+            J.tune(lsqr_graph=1, cg_dev=1)
+    (rg, replays), (rh, zero), (rl, _) = out["graph"], out["host"], out["large"]
+    assert replays > 0 and zero == 0
+    assert (rg.itn, rg.istop) == (rh.itn, rh.istop) == (rl.itn, rl.istop)
+    assert_bits_equal(rg.x.to_numpy(), rh.x.to_numpy(), f"x, {shape}")
+    assert rg.history == rh.history
+    tol = 2e-4 if np.dtype(dt).itemsize <= 8 and np.dtype(dt) != np.dtype(np.float64) else 1e-9
+    np.testing.assert_allclose(rg.x.to_numpy(), rl.x.to_numpy(), rtol=tol, atol=tol * 1e-1)
+    J.close(A)

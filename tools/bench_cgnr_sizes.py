@@ -13,6 +13,8 @@ import numpy as np
 import jets_jl_amd as J
 
 J.init(0)
+if len(sys.argv) > 1:
+    J.tune(cg_dev=int(sys.argv[1]))                               # 2: the device-resident CG loops at every size
 print("# rows x block (Float32)   fused A'A alone   CGNR per iteration   LSQR per iteration   CGLS per iteration", flush=True)
 for nrow, edge in ((64, 64), (256, 64), (64, 128), (256, 128), (1024, 128), (256, 256), (1024, 256)):
     blk = J.JetSpace(np.float32, edge, edge, edge)
@@ -37,7 +39,8 @@ for nrow, edge in ((64, 64), (256, 64), (64, 128), (256, 128), (1024, 128), (256
                   lambda k: J.lsqr(A, b, maxiter=k, atol=0.0, btol=0.0, conlim=0.0, force_maxiter=True, overwrite_b=True),
                   lambda k: J.cgls(A, b, maxiter=k, atol=0.0, btol=0.0, force_maxiter=True, overwrite_b=True)):
         took = {}
-        for iters in ((12, 12, 112) if small else (12, 12)):   # 12 iterations twice (the first run carries the lazy per-operator measurements), then 112
+        hi = 112 if small else 36
+        for iters in (12, 12, hi):   # 12 iterations twice (the first run carries the lazy per-operator measurements), then 112
             J.mul_(b, A, x_true)                               # LSQR / CGLS use b's storage (no range-sized allocation inside the timed solve)
             J.synchronize()
             t0 = time.perf_counter()
@@ -46,9 +49,9 @@ for nrow, edge in ((64, 64), (256, 64), (64, 128), (256, 128), (1024, 128), (256
             took[iters] = (time.perf_counter() - t0, r.itn)
         out.append(1e3 * took[12][0] / max(took[12][1], 1))
         # what ONE MORE iteration costs (set-up -- work vectors, ||b||, A'b, graph capture -- cancels): (t(112) - t(12)) / 100
-        marg.append(1e3 * (took[112][0] - took[12][0]) / max(took[112][1] - took[12][1], 1) if small and took[112][1] > took[12][1] else float("nan"))
+        marg.append(1e3 * (took[hi][0] - took[12][0]) / max(took[hi][1] - took[12][1], 1) if took[hi][1] > took[12][1] else float("nan"))
     print(f"{nrow:5d} x {edge}^3   {t_n:9.3f} ms   {out[0]:9.3f} ms ({out[0] / t_n:4.2f}x)   {out[1]:9.3f} ms   {out[2]:9.3f} ms"
-          + (f"   | per further iteration: CGNR {1e3 * marg[0]:6.1f} us  LSQR {1e3 * marg[1]:6.1f} us  CGLS {1e3 * marg[2]:6.1f} us" if small else ""), flush=True)
+          + f"   | per further iteration: CGNR {1e3 * marg[0]:8.1f} us  LSQR {1e3 * marg[1]:8.1f} us  CGLS {1e3 * marg[2]:8.1f} us", flush=True)
     J.close(A)
     del A, coeff, N, b, y, x_true
     import gc
