@@ -423,13 +423,26 @@ int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, 
  * host loop; same iterates), "grid_diag" (M x K grids of plain diagonals on the branch-free kernel k_grid_diag: 1 yes -- 2 / 4: that many packs per lane, measured no
  * better --, 0 the general kernels), "grid_tile" (those grids register-tiled, k_grid_tile -- a workgroup owns R lines x one element
  * tile, the shared input pack loaded once per R products: 1 automatic R, 2 / 4 / 8 that R, 0: k_grid_diag; same bits),
- * "sum_group" (terms of a fused JetSum per launch: 8, or 4 = round 2's grouping; same bits), "general_tile" (grids of equal elementwise
- * blocks of ANY kinds register-tiled, k_general_tile: 1 yes, 0 the one-line-per-workgroup general kernels; same bits),
+ * "sum_group" (terms of a fused JetSum forward per launch: 16, 8, or 4 = round 2's grouping; same bits), "general_tile" (grids of equal elementwise
+ * blocks of ANY kinds register-tiled, k_general_tile: 1 automatic -- four lines per workgroup when there are four, else two --, 2 / 4 that many
+ * lines, 0 the one-line-per-workgroup general kernels; same bits),
  * "wide_twin" (1 x K elementwise operators on the tall kernels through their tall twin: 1 automatic -- the adjoint always, the forward
  * from 16 MiB blocks --, 0 never: the general kernels, 2 both always);
+ * round 4: "cg_dev" (jh_cgls_solve / jh_cgnr_solve with the recurrences on the device, graph-replayed unless lsqr_graph = 0: 1 automatic -- CGLS
+ * below 1 GiB per pass, CG through the fused A'A up to 2 GiB of coefficients --, 2 at any size, 0 never: the host loops; within solver tolerance
+ * of each other), "dense_fused" (adjoint of many small DENSE children / forward of a 1 x K operator of them in ONE fused launch + fold: 1
+ * automatic, 0 the batched kernels of round 3; tolerance parity either way), "dense_gw" (children per group of that launch, 0 automatic),
+ * "dense_fwd_wgs" (workgroups the column-split dense forward aims for, 0 = 512), "walk_memory" (1: an operator of a (device, eltype, rows,
+ * block size) already measured in this process starts from that forward walk and confirms it; 0: every operator measures all candidates),
+ * "cgls_trace" (1: jh_cgls_solve_team records when each member's first pass began and ended; counter "last_cgls_overlaps"), "small_loop"
+ * (operators whose DENSE children are all small in one launch: 1 yes, 0 the per-block loop), "force_dist" (1: run the exchange of the partitioned
+ * solvers with a one-rank communicator too; validation), "adj_rows_per_launch" (tall adjoint / fused normal: block rows per launch, 0 all
+ * rows in one; same bits), "dense_mixed" (operators mixing big DENSE children with other kinds as one batched launch + one launch of the
+ * general kernels: 1 yes, 0 the per-block loop; counter "last_launches");
  * jh_tune_get also reads the counters "last_fwd_walk" (grid walk of the latest tall forward: 0 sequential, 1 all rows),
- * "last_fwd_rows_per_wg", "last_adj_launches", "last_adj_parts", "graph_replays" and "last_lsqr_graph" (graph replays of the latest
- * jh_lsqr_solve; 0: the host loop ran). */
+ * "last_fwd_rows_per_wg", "last_adj_launches", "last_adj_parts", "last_step_chain" (row chunks of the latest one-pass step, 0: the plain walk), "graph_replays", "last_lsqr_graph" / "last_cg_graph" (graph replays of the latest
+ * jh_lsqr_solve / jh_cgls_solve or jh_cgnr_solve; 0: the host loop ran) and "last_dense_fused" (1: the latest dense adjoint / wide forward took the
+ * fused launch). */
 int jh_tune_set(const char *name, int64_t value);
 int jh_tune_get(const char *name, int64_t *value);
 /* Per-operator choices made by measurement.  "fwd_walk": the grid walk of the tall forward of an operator far larger than the
@@ -439,7 +452,10 @@ int jh_tune_get(const char *name, int64_t *value);
  * wants the steady state at once (or the same choice in every process) reads it from one operator and sets it on another;
  * setting -1 measures again.  "upd_walk" is the same for jh_blockop_mul_axpby (0 / 1, chosen over its first two calls), "step_mode"
  * for jh_blockop_bidiag_step: 0 plain walk, 1 the same with XCD-contiguous tiles, 2 chained row chunks (one batch of 8 rows per
- * workgroup, the ordered sum handed from chunk to chunk: same bits), chosen over its first seven eligible calls. */
+ * workgroup, the ordered sum handed from chunk to chunk: same bits), chosen over its first seven eligible calls ("step_trials" counts
+ * them).  Read-only: "fwd_walk_inherited" (1: the forward walk came from an earlier operator of the same device, eltype, row count and
+ * block size -- knob "walk_memory"), "fwd_switches" (times the periodic re-check rotated another walk in), "fwd_playoff" (the two walks of
+ * the final play-off as 8 a + b, -1: none yet). */
 int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value);
 int jh_blockop_tune_set(jh_blockop *op, const char *name, int64_t value);
 

@@ -91,3 +91,17 @@ def test_every_entry_point_is_mapped_to_the_reference_in_integration_md():
                 spelled.add(f"{stem.rsplit('_', 1)[0]}_{r}")
     missing = [n for n in names if n not in doc and n not in spelled]
     assert len(names) >= 80 and not missing, missing
+
+
+def test_every_knob_the_library_accepts_is_described_in_the_header():
+    """jh_tune_set / jh_tune_get / jh_blockop_tune_* take a NAME: the names the sources compare against are the interface, so each one
+    must appear, quoted, in include/jetship.h's description of the knobs."""
+    import re
+
+    hdr = open(os.path.join(ROOT, "include", "jetship.h")).read()
+    names = set()
+    for f in ("jh_core.hip", "jh_blockop.hip"):
+        names |= set(re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', open(os.path.join(ROOT, "jets.jl_amd", "csrc", f)).read()))
+    assert len(names) > 40
+    missing = sorted(n for n in names if f'"{n}"' not in hdr)
+    assert not missing, f"knobs without a description in include/jetship.h: {missing}"
