@@ -419,7 +419,7 @@ int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, 
  * third call with the same vectors on; 0: always eager), "general_xcd" (the general M x K kernels' grid order: 1 automatic -- XCD-aware when the
  * input vector is >= 32 MiB, line by line below --, 0 never XCD-aware, 2 always), "red_wgs", "bcast_item_fast" (batched broadcasts with a shared operand: -1 automatic, 0 plain kernel, 1 items fastest), "step_chain" (the one-pass step as chained row chunks: -1 measured per operator, 0 never, 1 whenever the shape allows), "adj_split" (split-row walk of the tall adjoint / fused normal /
  * one-pass step: -1 automatic, 0 never -- always the ordered, bit-exact walk --, k > 1 that many row parts)};
- * "lsqr_graph" (jh_lsqr_solve below 1 GiB per pass: the loop with device-resident recurrences replayed as a hipGraph, 1 yes, 0 the
+ * "lsqr_graph" (jh_lsqr_solve below 1 GiB per pass -- 2 GiB when the blocks are below 16 MiB --: the loop with device-resident recurrences replayed as a hipGraph, 1 yes, 2 at any size, 0 the
  * host loop; same iterates), "grid_diag" (M x K grids of plain diagonals on the branch-free kernel k_grid_diag: 1 yes -- 2 / 4: that many packs per lane, measured no
  * better --, 0 the general kernels), "grid_tile" (those grids register-tiled, k_grid_tile -- a workgroup owns R lines x one element
  * tile, the shared input pack loaded once per R products: 1 automatic R, 2 / 4 / 8 that R, 0: k_grid_diag; same bits),
@@ -429,7 +429,7 @@ int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, 
  * "wide_twin" (1 x K elementwise operators on the tall kernels through their tall twin: 1 automatic -- the adjoint always, the forward
  * from 16 MiB blocks --, 0 never: the general kernels, 2 both always);
  * round 4: "cg_dev" (jh_cgls_solve / jh_cgnr_solve with the recurrences on the device, graph-replayed unless lsqr_graph = 0: 1 automatic -- CGLS
- * below 1 GiB per pass, CG through the fused A'A up to 2 GiB of coefficients --, 2 at any size, 0 never: the host loops; within solver tolerance
+ * like lsqr_graph, CG through the fused A'A up to 2 GiB of coefficients --, 2 at any size, 0 never: the host loops; within solver tolerance
  * of each other), "dense_fused" (adjoint of many small DENSE children / forward of a 1 x K operator of them in ONE fused launch + fold: 1
  * automatic, 0 the batched kernels of round 3; tolerance parity either way), "dense_gw" (children per group of that launch, 0 automatic),
  * "dense_fwd_wgs" (workgroups the column-split dense forward aims for, 0 = 512), "walk_memory" (1: an operator of a (device, eltype, rows,

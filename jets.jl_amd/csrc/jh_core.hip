@@ -935,7 +935,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "force_dist")) { c.force_dist = value ? 1 : 0; }
     else if (!strcmp(name, "step_chain")) { JH_REQUIRE(value >= -1 && value <= 1, "step_chain must be -1 (auto), 0 or 1"); c.step_chain = value; }
     else if (!strcmp(name, "general_xcd")) { JH_REQUIRE(value >= 0 && value <= 2, "general_xcd must be 0 (never), 1 (automatic) or 2 (always)"); c.general_xcd = value; }
-    else if (!strcmp(name, "lsqr_graph")) { c.lsqr_graph = value ? 1 : 0; }
+    else if (!strcmp(name, "lsqr_graph")) { c.lsqr_graph = value < 0 ? 0 : (value > 2 ? 2 : value); }
     else if (!strcmp(name, "grid_tile")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "grid_tile must be 0 (k_grid_diag), 1 (automatic) or 2 / 4 / 8 lines per workgroup"); c.grid_tile = value; }
     else if (!strcmp(name, "dense_mixed")) { JH_REQUIRE(value == 0 || value == 1, "dense_mixed must be 0 or 1"); c.dense_mixed = value; }
     else if (!strcmp(name, "general_tile")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "general_tile must be 0 (one-line kernels), 1 (automatic), 2 or 4 lines per workgroup"); c.general_tile = value; }

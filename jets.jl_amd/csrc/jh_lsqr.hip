@@ -571,7 +571,11 @@ static int lsqr_graph_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use
     if (!(jh_bidiag_step_parts(op) == 1 && c.adj_rows_per_launch == 0)) return JH_OK;
     const int dtype = x->dtype;
     const int64_t n = x->length;
-    if (3.0 * (double)op->nrow * (double)n * (double)jh_dtype_size(dtype) >= (double)(1ull << 30)) return JH_OK;
+    // (late round 4: up to 2 GiB per pass when the blocks are below 16 MiB -- the sizes whose step has one way to walk, so nothing is lost by not measuring
+    // it per operator: 64 x 128^3 317 -> 305 us per iteration; knob lsqr_graph = 2: any size)
+    const double pass_bytes = 3.0 * (double)op->nrow * (double)n * (double)jh_dtype_size(dtype);
+    if (c.lsqr_graph < 2 && !(pass_bytes < (double)(1ull << 30) || (pass_bytes < (double)(2ull << 30) && (double)n * (double)jh_dtype_size(dtype) < (double)(16u << 20))))
+        return JH_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(c.stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return JH_OK;
     *took = true;
@@ -1106,10 +1110,12 @@ static int cg_dev_impl(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0,
     if (c.adj_rows_per_launch != 0 || (cgls ? jh_bidiag_step_parts(op) != 1 : (c.adj_split > 0 || (op->nrow >= 256 && c.adj_split != 0 && normal_wgs < c.cu_count)))) return JH_OK;
     const int dtype = x->dtype;
     const int64_t n = x->length;
-    // only where launches and host round trips matter (knob cg_dev = 2: any size): CGLS below 1 GiB per pass over the operator and r; CG through
+    // only where launches and host round trips matter (knob cg_dev = 2: any size): CGLS below 1 GiB per pass over the operator and r (2 GiB when the
+    // blocks are below 16 MiB: the step then has one way to walk); CG through
     // the fused A'A up to 2 GiB of coefficients (64 x 128^3: 140 -> 111 us per iteration, 256 x 128^3: 368 -> 346; no difference from 4 GiB on)
     const double coeff_bytes = (double)op->nrow * (double)n * (double)jh_dtype_size(dtype);
-    if (c.cg_dev < 2 && (cgls ? 3.0 * coeff_bytes >= (double)(1ull << 30) : coeff_bytes > (double)(2ull << 30))) return JH_OK;
+    const bool cgls_small = 3.0 * coeff_bytes < (double)(1ull << 30) || (3.0 * coeff_bytes < (double)(2ull << 30) && coeff_bytes / (double)op->nrow < (double)(16u << 20));
+    if (c.cg_dev < 2 && (cgls ? !cgls_small : coeff_bytes > (double)(2ull << 30))) return JH_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(c.stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return JH_OK;
     *took = true;

@@ -15,6 +15,8 @@ import jets_jl_amd as J
 J.init(0)
 if len(sys.argv) > 1:
     J.tune(cg_dev=int(sys.argv[1]))                               # 2: the device-resident CG loops at every size
+if len(sys.argv) > 2:
+    J.tune(lsqr_graph=int(sys.argv[2]))                           # 2: LSQR's too
 print("# rows x block (Float32)   fused A'A alone   CGNR per iteration   LSQR per iteration   CGLS per iteration", flush=True)
 for nrow, edge in ((64, 64), (256, 64), (64, 128), (256, 128), (1024, 128), (256, 256), (1024, 256)):
     blk = J.JetSpace(np.float32, edge, edge, edge)
