@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define JETSHIP_ABI_VERSION 1
+#define JETSHIP_ABI_VERSION 2   /* 2 (round 4): jh_block_desc.scale_flags, jh_lincomb_typed */
 
 typedef enum {
     JH_OK = 0,
@@ -82,7 +82,20 @@ typedef struct {
     double scale_re;     /* SCALE: a                                                         */
     double scale_im;
     int64_t nr, nc;      /* range / domain length of the described (un-adjointed) operator   */
+    int32_t scale_flags; /* SCALE: JH_SCALAR_* -- the TYPE of a, which Julia dispatches on    */
+    int32_t reserved;    /* 0                                                                */
 } jh_block_desc;
+
+/* The TYPE of a scalar that arrives as (re, im) doubles (src/Jets.jl:1159 `d .= a * m`, 889-911 broadcast): Julia's arithmetic follows it.
+ *   JH_SCALAR_COMPLEX  a is a Complex: the full complex product (re*re' - im*im', re*im' + im*re') even when its imaginary part is zero.
+ *                      Without the flag an imaginary part of exactly zero stands for a Real: `a::Real * z` multiplies part by part (no
+ *                      0 * Inf = NaN, signed zeros kept); a non-zero imaginary part implies the flag.
+ *   JH_SCALAR_WIDE     a is Float64-based (Float64 / ComplexF64) and the elements are 32-bit: Julia promotes, computes in Float64 and rounds
+ *                      ONCE when the result is stored into the Float32 / ComplexF32 destination.  Without it the scalar is converted to the
+ *                      element type first (`T(a) * x`: Float32, integers, irrationals, or any scalar against 64-bit elements -- where the
+ *                      flag is ignored).  In jh_lincomb_typed a sum with a wide term is a Float64 sum from there on, as in Julia.
+ * A binding sets them from the scalar's type; 0 is what a binding that does not know passes. */
+enum { JH_SCALAR_COMPLEX = 1, JH_SCALAR_WIDE = 2 };
 
 typedef struct jh_bvec jh_bvec;
 typedef struct jh_blockop jh_blockop;
@@ -182,6 +195,9 @@ int jh_abs(jh_bvec *dst_real, const jh_bvec *x);
 /* BlockArray broadcast, src/Jets.jl:889-911.  dst = c0*x0 .+ c1*x1 .+ ... evaluated left to right in
  * eltype T (each product and each sum rounded, no FMA); coef is k (re,im) pairs; dst may alias any x. */
 int jh_lincomb(jh_bvec *dst, int k, const double *coef_re_im, const jh_bvec *const *x);
+/* the same with the coefficients' TYPES (k x JH_SCALAR_*; NULL: jh_lincomb).  A wide coefficient makes its product, and every sum after
+ * it, Float64 arithmetic rounded once on the store -- Julia's promotion in `x .= a .* u .+ b .* v` with a::Float64, u::Vector{Float32}. */
+int jh_lincomb_typed(jh_bvec *dst, int k, const double *coef_re_im, const int32_t *coef_flags, const jh_bvec *const *x);
 /* dst = x .* y -- the masks of dot_product_test, src/Jets.jl:1215-1219.  conj_x is a flag word: bit 0 conj.(x) .* y;
  * bit 1 (2 .* x) .* y, the Jacobian of d .= m.^2 about x (test/runtests.jl:20); 3 = conj.(2 .* x) .* y. */
 int jh_hadamard(jh_bvec *dst, const jh_bvec *x, const jh_bvec *y, int conj_x);

@@ -10,6 +10,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import numpy as np
+
 __all__ = ["lib", "check", "JetsHipError", "LIB_PATH", "BlockDesc", "SYMBOLS", "DTYPES", "KINDS"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -37,7 +39,21 @@ class BlockDesc(C.Structure):
         ("scale_im", C.c_double),
         ("nr", C.c_int64),
         ("nc", C.c_int64),
+        ("scale_flags", C.c_int32),
+        ("reserved", C.c_int32),
     ]
+
+
+SCALAR_COMPLEX, SCALAR_WIDE = 1, 2   # JH_SCALAR_* of include/jetship.h
+
+
+def scalar_flags(a) -> int:
+    """The TYPE of a scalar as Julia's dispatch sees it (src/Jets.jl:1159 `a * m`; include/jetship.h JH_SCALAR_*), read off the Python object:
+    a Python or numpy complex is a Complex scalar (full complex product even with a zero imaginary part); numpy's float64 / complex128 are
+    Julia's Float64 / ComplexF64 (against 32-bit elements: promoted arithmetic, one rounding on the store); plain Python numbers and 32-bit
+    numpy scalars are taken in the vectors' element type (Julia's `T(a)`, what an Int, a Float32 or an Irrational like pi gives)."""
+    f = SCALAR_COMPLEX if isinstance(a, (complex, np.complexfloating)) else 0
+    return f | (SCALAR_WIDE if isinstance(a, (np.float64, np.complex128)) else 0)
 
 
 class LsqrResultC(C.Structure):
@@ -105,6 +121,7 @@ SYMBOLS = {
     "jh_fill_normal": (_int, [_vp, C.c_uint64, C.c_uint64, _i64]),
     "jh_abs": (_int, [_vp, _vp]),
     "jh_lincomb": (_int, [_vp, _int, _dblp, _vpp]),
+    "jh_lincomb_typed": (_int, [_vp, _int, _dblp, C.POINTER(C.c_int32), _vpp]),
     "jh_hadamard": (_int, [_vp, _vp, _vp, _int]),
     "jh_bcast_check": (_int, [C.c_char_p, _int, _int, _int]),
     "jh_bcast_compile": (_int, [C.c_char_p, _int, _int, _int, _vpp]),

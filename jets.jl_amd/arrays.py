@@ -17,7 +17,7 @@ from typing import Sequence
 
 import numpy as np
 
-from ._ffi import lib, check
+from ._ffi import lib, check, scalar_flags
 from . import device as _device
 from .spaces import JetAbstractSpace, JetSpace, JetBSpace, JetSSpace, dtype_code
 
@@ -602,11 +602,13 @@ def lincomb_(dst: _DevVec, coefs: Sequence, xs: Sequence[_DevVec]):
     """dst .= c1*x1 .+ c2*x2 .+ ... in one fused pass, evaluated left to right in eltype T."""
     k = len(xs)
     cf = (C.c_double * (2 * k))()
+    fl = (C.c_int32 * k)()
     for j, c in enumerate(coefs):
+        fl[j] = scalar_flags(c)                      # the coefficient's TYPE: Julia's arithmetic follows it (include/jetship.h JH_SCALAR_*)
         cc = complex(c)
         cf[2 * j], cf[2 * j + 1] = cc.real, cc.imag
     hs = (C.c_void_p * k)(*[x.handle for x in xs])
-    check(lib.jh_lincomb(dst.handle, k, cf, hs))
+    check(lib.jh_lincomb_typed(dst.handle, k, cf, fl, hs))
     return dst
 
 

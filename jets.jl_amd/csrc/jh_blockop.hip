@@ -78,9 +78,9 @@ __device__ inline V apply_block_loaded(const jh_dev_block &b, V x, V c, bool tra
         if (fmode && !b.adjoint) return vmul<S, E, NS, V>(x, x, false);
         return vmul<S, E, NS, V>(c + c, x, cj);
     case JH_OP_SCALE: {
-        if (E == 1 || b.sim == 0.0) {                   // a real scalar multiplies part by part (Julia's a::Real * z)
+        if (E == 1 || b.sim != b.sim) {                 // a REAL scalar (sim = NaN, jh_dev_block_of) multiplies part by part (Julia's a::Real * z)
             return (V)(S)b.sre * x;
-        } else {
+        } else {                                        // a Complex one: the full product, also when its imaginary part is zero
             V a;
 #pragma unroll
             for (int e = 0; e < NS; e += 2) { a[e] = (S)b.sre; a[e + 1] = (S)b.sim; }
@@ -1142,7 +1142,7 @@ __device__ inline elem<S, E> apply_block(const jh_dev_block &b, elem<S, E> x, in
         elem<S, E> a;
         a.re = (S)b.sre;
         a.im = (E == 2) ? (cj ? -(S)b.sim : (S)b.sim) : (S)0;
-        if (E == 2 && b.sim == 0.0) {                  // a real scalar multiplies part by part (Julia's a::Real * z)
+        if (E == 2 && b.sim != b.sim) {                // a REAL scalar (sim = NaN) multiplies part by part (Julia's a::Real * z)
             x.re = a.re * x.re;
             x.im = a.re * x.im;
             return x;
@@ -2914,7 +2914,8 @@ int child_apply(int dtype, const jh_block_desc &b, void *out, const void *in, bo
     case JH_OP_SCALE: {
         const double cre = b.scale_re, cim = adj ? -b.scale_im : b.scale_im;
         const void *xs[1] = {in};
-        return jh_launch_lincomb_raw(out, dtype, n_out, 1, &cre, &cim, xs);
+        const int32_t fl = b.scale_flags;
+        return jh_launch_lincomb_raw(out, dtype, n_out, 1, &cre, &cim, xs, &fl);
     }
     case JH_OP_IDENTITY:
         if (n_out > 0) JH_CHECK_HIP(hipMemcpyAsync(out, in, (size_t)n_out * jh_dtype_size(dtype), hipMemcpyDeviceToDevice, jh_ctx().stream));
@@ -3315,8 +3316,16 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
                     status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: DIAG block (%lld,%lld) has no coefficients", (long long)i, (long long)j);
                 if (b.kind != JH_OP_DIAG) op->all_diag = false;
                 if (b.kind == JH_OP_DIAG && b.adjoint && jh_dtype_complex(dtype)) op->all_diag = false;
-                if (b.kind == JH_OP_SCALE && b.scale_im != 0.0 && !jh_dtype_complex(dtype))
+                if (b.kind == JH_OP_SCALE && (b.scale_im != 0.0 || (b.scale_flags & JH_SCALAR_COMPLEX)) && !jh_dtype_complex(dtype))
                     status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: complex scale on a real operator");
+                if (b.kind == JH_OP_SCALE && (b.scale_flags & JH_SCALAR_WIDE) && (dtype == JH_F32 || dtype == JH_C32)) {
+                    // a Float64-based scalar against 32-bit elements computes in Float64 (JH_SCALAR_WIDE): the per-block loop's scalar stage
+                    // (the typed lincomb) does that; the fused elementwise kernels keep their registers for the element type
+                    op->wide_scale = true;
+                    op->elementwise = false;
+                }
+                if (b.kind == JH_OP_SCALE && (b.scale_flags & ~(JH_SCALAR_COMPLEX | JH_SCALAR_WIDE)))
+                    status = jh_fail(JH_ERR_INVALID, "jh_blockop_create: unknown scale_flags %d on block (%lld,%lld)", b.scale_flags, (long long)i, (long long)j);
             } else if (b.kind == JH_OP_ZERO) {
                 op->all_diag = false;
             } else {
@@ -3379,7 +3388,7 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
     //                children ran its adjoint in 1.0 ms there: 16 384 dependent loads per thread; profiles/bench_dense_mixed_r03.txt)
     //   dense_mixed  one (two, with adjointed AND un-adjointed children) batched launch for all dense children + one combine launch
     //                (dense_mixed_apply): everything else
-    if (!op->elementwise && !op->dense_batch && !op->dense_batch_ragged && !op->dense_batch_grid && !op->dense_batch_wide && nrow <= 65535 && ncol <= 65535) {
+    if (!op->elementwise && !op->wide_scale && !op->dense_batch && !op->dense_batch_ragged && !op->dense_batch_grid && !op->dense_batch_wide && nrow <= 65535 && ncol <= 65535) {
         const size_t es = jh_dtype_size(dtype);
         bool small = true, eligible = true, aligned = true;
         std::vector<int64_t> fwd_work((size_t)nrow, 0), adj_work((size_t)ncol, 0);
@@ -3423,11 +3432,7 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
 
     std::vector<jh_dev_block> host((size_t)(nrow * ncol));
     for (size_t k = 0; k < host.size(); k++) {
-        host[k].coeff = op->blocks[k].coeff;
-        host[k].sre = op->blocks[k].scale_re;
-        host[k].sim = op->blocks[k].scale_im;
-        host[k].kind = op->blocks[k].kind;
-        host[k].adjoint = op->blocks[k].adjoint;
+        host[k] = jh_dev_block_of(op->blocks[k]);
     }
     hipStream_t st = jh_ctx().stream;
     hipError_t e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_blocks, host.size() * sizeof(jh_dev_block));
@@ -3512,11 +3517,7 @@ int jh_blockop_point(jh_blockop *op, const jh_bvec *mo)
             if (b.kind == JH_OP_SQUARE) b.coeff = (const char *)mo->data + (size_t)op->col_off[(size_t)j] * es;   // getblock(mo, icol) (1063)
         }
     for (size_t k = 0; k < host.size(); k++) {
-        host[k].coeff = op->blocks[k].coeff;
-        host[k].sre = op->blocks[k].scale_re;
-        host[k].sim = op->blocks[k].scale_im;
-        host[k].kind = op->blocks[k].kind;
-        host[k].adjoint = op->blocks[k].adjoint;
+        host[k] = jh_dev_block_of(op->blocks[k]);
     }
     hipStream_t st = jh_ctx().stream;
     JH_CHECK_HIP(hipMemcpyAsync(op->dev_blocks, host.data(), host.size() * sizeof(jh_dev_block), hipMemcpyHostToDevice, st));

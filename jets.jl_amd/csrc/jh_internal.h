@@ -182,10 +182,27 @@ struct jh_event {
 // one entry per block, device-resident, column-major nrow x ncol
 struct jh_dev_block {
     const void *coeff;
-    double sre, sim;
+    double sre, sim;     // SCALE: the scalar; sim is NaN for a REAL scalar (see jh_dev_block_of)
     int32_t kind;
     int32_t adjoint;
 };
+
+// the device form of a block description.  A SCALE block's scalar is Real unless it is flagged JH_SCALAR_COMPLEX or has a non-zero
+// imaginary part: Julia's `a::Real * z` multiplies part by part, a Complex `a` takes the full product even when imag(a) == 0 (with THAT
+// zero's sign).  The kernels tell the two apart by sim: NaN = "no imaginary part" (one comparison, no extra field in a 32-byte entry).
+// (Blocks whose scalar is WIDE never reach the fused kernels: jh_blockop_create routes such operators through the per-block loop,
+// whose scalar stage is the typed lincomb.)
+inline jh_dev_block jh_dev_block_of(const jh_block_desc &b)
+{
+    jh_dev_block d{};
+    d.coeff = b.coeff;
+    d.sre = b.scale_re;
+    const bool cplx = (b.scale_flags & JH_SCALAR_COMPLEX) || b.scale_im != 0.0;
+    d.sim = cplx ? b.scale_im : __builtin_nan("");
+    d.kind = b.kind;
+    d.adjoint = b.adjoint;
+    return d;
+}
 
 struct jh_blockop {
     int ctx = -1;
@@ -202,7 +219,8 @@ struct jh_blockop {
     bool tall = false;                       // ncol == 1
     bool uniform_rows = false;               // all row_len equal
     bool all_diag = false;                   // every block is an un-adjointed... DIAG (adjoint flag irrelevant up to conj)
-    bool elementwise = false;                // no DENSE block
+    bool elementwise = false;                // no DENSE block (and no wide scalar)
+    bool wide_scale = false;                 // a SCALE block with JH_SCALAR_WIDE on 32-bit elements: the per-block loop (its scalar stage computes in Float64)
     bool dense_batch = false;                // tall, >= 2 rows, every block an un-adjointed DENSE matrix of one shape: batched kernels (jh_dense.hip)
     bool dense_batch_wide = false;           // the same for ONE block row of >= 2 such children
     bool dense_batch_ragged = false;         // tall, every block an un-adjointed DENSE matrix with the same column count, row counts differ (one column chunk suffices)
@@ -337,7 +355,7 @@ int jh_launch_copy_bytes(void *dst, const void *src, size_t bytes);
 int jh_launch_hadamard_raw(void *dst, const void *x, const void *y, int dtype, int64_t count, int conj_x);
 // dst = (2 .* mo) .* x  (conj: conj.(2 .* mo) .* x): the Jacobian of d .= m.^2 about mo
 int jh_launch_square_jvp_raw(void *dst, const void *mo, const void *x, int dtype, int64_t count, int conj_mo);
-int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const double *cre, const double *cim, const void *const *x);
+int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const double *cre, const double *cim, const void *const *x, const int32_t *flags = nullptr);
 // dense child operator (jh_dense.hip): y = A x (rows) or y = A^H x / A^T x (cols); A column-major nr x nc
 int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, const void *x, int adjoint);
 int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int64_t nc, int dtype, void *y, const void *x,

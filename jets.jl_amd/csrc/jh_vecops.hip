@@ -208,37 +208,94 @@ constexpr int MAX_TERMS = 8;
 struct LincombArgs {
     const void *x[MAX_TERMS];
     double cre[MAX_TERMS], cim[MAX_TERMS];
+    unsigned char flags[MAX_TERMS];               // JH_SCALAR_* per coefficient, normalised by lincomb_args_flags
     int k;
 };
 
-// dst = c0*x0 + c1*x1 + ... left to right, every product and sum rounded in S (no contraction:
-// the translation unit is built with -ffp-contract=off).  E = scalars per element (1 real, 2 complex).
-// A coefficient whose imaginary part is exactly zero is a REAL scalar: Julia multiplies `a::Real * z::Complex` part by part, so
-// 1.0 * (x + Inf i) keeps x where the four-multiplication formula would make it NaN (0 * Inf), and -0.0 parts keep their sign.
-template <typename S, int E>
-__device__ inline void lincomb_elem(const LincombArgs &a, int64_t scalar_index, S *out)
+// the coefficients' types as the kernels read them: COMPLEX when flagged or when the imaginary part is non-zero (an untyped (re, 0) pair
+// stands for a Real), WIDE only against 32-bit elements.  Returns whether any coefficient is wide.
+static bool lincomb_args_flags(LincombArgs &a, const int32_t *flags, int dtype)
 {
-    S accr = 0, acci = 0;
-#pragma unroll
-    for (int j = 0; j < MAX_TERMS; j++) {
-        if (j >= a.k) break;
-        const S *xj = (const S *)a.x[j] + scalar_index;
-        S tr, ti = 0;
-        if (E == 1) {
-            tr = (S)a.cre[j] * xj[0];
-        } else {
-            S cr = (S)a.cre[j], ci = (S)a.cim[j], xr = xj[0], xi = xj[1];
-            if (a.cim[j] == 0.0) { tr = cr * xr; ti = cr * xi; }           // a REAL coefficient: Julia's `a::Real * z`, part by part
-            else { tr = cr * xr - ci * xi; ti = cr * xi + ci * xr; }       // Julia Base complex.jl `*`
-        }
-        if (j == 0) { accr = tr; acci = ti; }
-        else { accr = accr + tr; acci = acci + ti; }
+    bool any_wide = false;
+    for (int j = 0; j < a.k; j++) {
+        const int f = flags ? flags[j] : 0;
+        a.flags[j] = (unsigned char)((f & JH_SCALAR_COMPLEX) | (a.cim[j] != 0.0 ? JH_SCALAR_COMPLEX : 0));
+        if ((f & JH_SCALAR_WIDE) && (dtype == JH_F32 || dtype == JH_C32)) { a.flags[j] |= JH_SCALAR_WIDE; any_wide = true; }
     }
-    out[0] = accr;
-    if (E == 2) out[1] = acci;
+    return any_wide;
 }
 
-template <typename S, int E, int NS>   // NS scalars per pack, NS % E == 0
+// dst = c0*x0 + c1*x1 + ... left to right, every product and sum rounded in S (no contraction:
+// the translation unit is built with -ffp-contract=off).  E = scalars per element (1 real, 2 complex).
+// A REAL coefficient (no JH_SCALAR_COMPLEX) multiplies part by part as Julia's `a::Real * z::Complex` does, so 1.0 * (x + Inf i) keeps
+// x where the four-multiplication formula would make it NaN (0 * Inf), and -0.0 parts keep their sign.
+// WIDE (S = float, some coefficient is Float64-based): Julia's promotion -- that coefficient's product is a Float64 product, a sum with a
+// Float64 operand is a Float64 sum, and the Float32 element is ONE rounding of the final value (`x .= a .* u .+ b .* v` with a::Float64).
+// GET(j, part) is operand j's real (0) / imaginary (1) part of the element at hand.
+template <typename S, int E, bool WIDE, typename GET>
+__device__ inline void lincomb_one(const LincombArgs &a, GET get, S &outr, S &outi)
+{
+    if constexpr (!WIDE) {
+        S accr = 0, acci = 0;
+#pragma unroll
+        for (int j = 0; j < MAX_TERMS; j++) {
+            if (j < a.k) {
+                S tr, ti = 0;
+                if (E == 1) {
+                    tr = (S)a.cre[j] * get(j, 0);
+                } else {
+                    const S cr = (S)a.cre[j], ci = (S)a.cim[j], xr = get(j, 0), xi = get(j, 1);
+                    if (!(a.flags[j] & JH_SCALAR_COMPLEX)) { tr = cr * xr; ti = cr * xi; }
+                    else { tr = cr * xr - ci * xi; ti = cr * xi + ci * xr; }       // Julia Base complex.jl `*`
+                }
+                if (j == 0) { accr = tr; acci = ti; }
+                else { accr = accr + tr; acci = acci + ti; }
+            }
+        }
+        outr = accr;
+        outi = acci;
+    } else {
+        double accr = 0, acci = 0;                   // a narrow value is held exactly
+        bool acc_wide = false;
+#pragma unroll
+        for (int j = 0; j < MAX_TERMS; j++) {
+            if (j < a.k) {
+                double tr, ti = 0;
+                const bool tw = (a.flags[j] & JH_SCALAR_WIDE) != 0, tc = (a.flags[j] & JH_SCALAR_COMPLEX) != 0;
+                if (tw) {
+                    const double xr = (double)get(j, 0), xi = E == 2 ? (double)get(j, 1) : 0.0;
+                    if (E == 1) tr = a.cre[j] * xr;
+                    else if (!tc) { tr = a.cre[j] * xr; ti = a.cre[j] * xi; }
+                    else { tr = a.cre[j] * xr - a.cim[j] * xi; ti = a.cre[j] * xi + a.cim[j] * xr; }
+                } else {
+                    const S cr = (S)a.cre[j], ci = (S)a.cim[j], xr = get(j, 0), xi = E == 2 ? get(j, 1) : (S)0;
+                    S sr, si = 0;
+                    if (E == 1) sr = cr * xr;
+                    else if (!tc) { sr = cr * xr; si = cr * xi; }
+                    else { sr = cr * xr - ci * xi; si = cr * xi + ci * xr; }
+                    tr = (double)sr;
+                    ti = (double)si;
+                }
+                if (j == 0) { accr = tr; acci = ti; acc_wide = tw; }
+                else if (acc_wide || tw) { accr = accr + tr; acci = acci + ti; acc_wide = true; }
+                else { accr = (double)((S)accr + (S)tr); acci = (double)((S)acci + (S)ti); }
+            }
+        }
+        outr = (S)accr;
+        outi = (S)acci;
+    }
+}
+
+template <typename S, int E, bool WIDE>
+__device__ inline void lincomb_elem(const LincombArgs &a, int64_t scalar_index, S *out)
+{
+    S r, i;
+    lincomb_one<S, E, WIDE>(a, [&](int j, int part) { return ((const S *)a.x[j])[scalar_index + part]; }, r, i);
+    out[0] = r;
+    if (E == 2) out[1] = i;
+}
+
+template <typename S, int E, int NS, bool WIDE = false>   // NS scalars per pack, NS % E == 0
 __global__ void k_lincomb(S *dst, int64_t n_scalars, LincombArgs a)   // dst may alias an operand (x .= a*x .+ b*y): no __restrict__
 {
     const int64_t nvec = n_scalars / NS;
@@ -252,30 +309,16 @@ __global__ void k_lincomb(S *dst, int64_t n_scalars, LincombArgs a)   // dst may
         Pack<S, NS> o;
 #pragma unroll
         for (int e = 0; e < NS; e += E) {
-            S accr = 0, acci = 0;
-#pragma unroll
-            for (int j = 0; j < MAX_TERMS; j++) {
-                if (j < a.k) {
-                    S tr, ti = 0;
-                    if (E == 1) {
-                        tr = (S)a.cre[j] * xin[j].v[e];
-                    } else {
-                        S cr = (S)a.cre[j], ci = (S)a.cim[j], xr = xin[j].v[e], xi = xin[j].v[e + 1];
-                        if (a.cim[j] == 0.0) { tr = cr * xr; ti = cr * xi; }
-                        else { tr = cr * xr - ci * xi; ti = cr * xi + ci * xr; }
-                    }
-                    if (j == 0) { accr = tr; acci = ti; }
-                    else { accr = accr + tr; acci = acci + ti; }
-                }
-            }
-            o.v[e] = accr;
-            if (E == 2) o.v[e + 1] = acci;
+            S r, i;
+            lincomb_one<S, E, WIDE>(a, [&](int j, int part) { return xin[j].v[e + part]; }, r, i);
+            o.v[e] = r;
+            if (E == 2) o.v[e + 1] = i;
         }
         stnt(reinterpret_cast<Pack<S, NS> *>(dst) + v, o);
     }
     const int64_t tail0 = nvec * NS;
     const int64_t ntail_elems = (n_scalars - tail0) / E;
-    if (tid < ntail_elems) lincomb_elem<S, E>(a, tail0 + tid * E, dst + tail0 + tid * E);
+    if (tid < ntail_elems) lincomb_elem<S, E, WIDE>(a, tail0 + tid * E, dst + tail0 + tid * E);
 }
 
 // ---------------------------------------------------------------- hadamard --------------------
@@ -496,19 +539,30 @@ int reduce_dispatch(int dtype, const void *x, const void *y, int64_t n, double p
     return jh_fail(JH_ERR_INVALID, "unknown dtype %d", dtype);
 }
 
-template <typename S, int E>
-int lincomb_launch(void *dst, int64_t n_elems, const LincombArgs &a)
+template <typename S, int E, bool WIDE>
+void lincomb_launch_w(void *dst, int64_t n_elems, const LincombArgs &a)
 {
     const int64_t n_scalars = n_elems * E;
-    if (n_scalars == 0) return JH_OK;
     constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
     uintptr_t bits = (uintptr_t)dst;
     for (int j = 0; j < a.k; j++) bits |= (uintptr_t)a.x[j];
     if ((bits & 15u) == 0)
-        hipLaunchKernelGGL((k_lincomb<S, E, NSV>), dim3(grid_full(n_scalars / NSV + 1)), dim3(WG), 0, jh_ctx().stream, (S *)dst,
+        hipLaunchKernelGGL((k_lincomb<S, E, NSV, WIDE>), dim3(grid_full(n_scalars / NSV + 1)), dim3(WG), 0, jh_ctx().stream, (S *)dst,
                            n_scalars, a);
     else
-        hipLaunchKernelGGL((k_lincomb<S, E, E>), dim3(grid_full(n_elems + 1)), dim3(WG), 0, jh_ctx().stream, (S *)dst, n_scalars, a);
+        hipLaunchKernelGGL((k_lincomb<S, E, E, WIDE>), dim3(grid_full(n_elems + 1)), dim3(WG), 0, jh_ctx().stream, (S *)dst, n_scalars, a);
+}
+
+template <typename S, int E>
+int lincomb_launch(void *dst, int64_t n_elems, const LincombArgs &a, bool any_wide = false)
+{
+    if (n_elems * E == 0) return JH_OK;
+    if constexpr (sizeof(S) == 4) {
+        if (any_wide) lincomb_launch_w<S, E, true>(dst, n_elems, a);
+        else lincomb_launch_w<S, E, false>(dst, n_elems, a);
+    } else {
+        lincomb_launch_w<S, E, false>(dst, n_elems, a);
+    }
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -548,16 +602,17 @@ int jh_launch_square_jvp_raw(void *dst, const void *mo, const void *x, int dtype
     return jh_launch_hadamard_raw(dst, mo, x, dtype, count, 2 | (conj_mo ? 1 : 0));
 }
 
-// dst = c0*x0 (+ c1*x1): k in {1, 2}
-int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const double *cre, const double *cim, const void *const *x)
+// dst = c0*x0 (+ c1*x1): k in {1, 2}; flags: the coefficients' JH_SCALAR_* (nullptr: untyped)
+int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const double *cre, const double *cim, const void *const *x, const int32_t *flags)
 {
     LincombArgs a;
     a.k = k;
     for (int j = 0; j < k; j++) { a.x[j] = x[j]; a.cre[j] = cre[j]; a.cim[j] = cim[j]; }
+    const bool wide = lincomb_args_flags(a, flags, dtype);
     switch (dtype) {
-    case JH_F32: return lincomb_launch<float, 1>(dst, count, a);
+    case JH_F32: return lincomb_launch<float, 1>(dst, count, a, wide);
     case JH_F64: return lincomb_launch<double, 1>(dst, count, a);
-    case JH_C32: return lincomb_launch<float, 2>(dst, count, a);
+    case JH_C32: return lincomb_launch<float, 2>(dst, count, a, wide);
     case JH_C64: return lincomb_launch<double, 2>(dst, count, a);
     }
     return jh_fail(JH_ERR_INVALID, "lincomb: unknown dtype %d", dtype);
@@ -655,7 +710,7 @@ int jh_abs(jh_bvec *dst, const jh_bvec *x)
     return JH_OK;
 }
 
-int jh_lincomb(jh_bvec *dst, int k, const double *coef, const jh_bvec *const *x)
+int jh_lincomb_typed(jh_bvec *dst, int k, const double *coef, const int32_t *coef_flags, const jh_bvec *const *x)
 {
     JH_TRY(jh_enter(dst));
     JH_REQUIRE(dst && coef && x, "jh_lincomb: null argument");
@@ -668,20 +723,25 @@ int jh_lincomb(jh_bvec *dst, int k, const double *coef, const jh_bvec *const *x)
         JH_REQUIRE(x[j]->dtype == dst->dtype, "jh_lincomb: dtype mismatch on operand %d", j);
         JH_REQUIRE(x[j]->length == dst->length, "jh_lincomb: length mismatch on operand %d (%lld vs %lld)", j,
                    (long long)x[j]->length, (long long)dst->length);
-        JH_REQUIRE(jh_dtype_complex(dst->dtype) || coef[2 * j + 1] == 0.0,
+        JH_REQUIRE(jh_dtype_complex(dst->dtype) || (coef[2 * j + 1] == 0.0 && !(coef_flags && (coef_flags[j] & JH_SCALAR_COMPLEX))),
                    "jh_lincomb: complex coefficient %d on a real vector", j);
+        JH_REQUIRE(!coef_flags || (coef_flags[j] & ~(JH_SCALAR_COMPLEX | JH_SCALAR_WIDE)) == 0, "jh_lincomb_typed: unknown flags %d on coefficient %d",
+                   coef_flags ? coef_flags[j] : 0, j);
         a.x[j] = x[j]->data;
         a.cre[j] = coef[2 * j];
         a.cim[j] = coef[2 * j + 1];
     }
+    const bool wide = lincomb_args_flags(a, coef_flags, dst->dtype);
     switch (dst->dtype) {
-    case JH_F32: return lincomb_launch<float, 1>(dst->data, dst->length, a);
+    case JH_F32: return lincomb_launch<float, 1>(dst->data, dst->length, a, wide);
     case JH_F64: return lincomb_launch<double, 1>(dst->data, dst->length, a);
-    case JH_C32: return lincomb_launch<float, 2>(dst->data, dst->length, a);
+    case JH_C32: return lincomb_launch<float, 2>(dst->data, dst->length, a, wide);
     case JH_C64: return lincomb_launch<double, 2>(dst->data, dst->length, a);
     }
     return jh_fail(JH_ERR_INVALID, "jh_lincomb: unknown dtype %d", dst->dtype);
 }
+
+int jh_lincomb(jh_bvec *dst, int k, const double *coef, const jh_bvec *const *x) { return jh_lincomb_typed(dst, k, coef, nullptr, x); }
 
 int jh_hadamard(jh_bvec *dst, const jh_bvec *x, const jh_bvec *y, int conj_x)
 {

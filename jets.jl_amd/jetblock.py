@@ -14,7 +14,7 @@ from typing import Sequence
 
 import numpy as np
 
-from ._ffi import lib, check, BlockDesc, KINDS, JetsHipError
+from ._ffi import lib, check, BlockDesc, KINDS, JetsHipError, scalar_flags, SCALAR_WIDE
 from . import arrays as _arr
 from . import device as _dev
 from .arrays import DeviceArray, zeros, lincomb_, hadamard_, copyto_, fill_, getblock, _i64arr
@@ -168,7 +168,7 @@ def _native_desc(op: Jop):
     if j.df is diagonal_df and j.df_adj is diagonal_df_adj:
         return ("diag", adj, j.s["diagonal"], 0.0)
     if j.df is _j.constdiag_df and j.df_adj is _j.constdiag_df_adj:
-        return ("scale", adj, None, complex(j.s["a"]))
+        return ("scale", adj, None, j.s["a"])             # (as given: its TYPE says how Julia multiplies, _ffi.scalar_flags)
     if j.df is dense_df and j.df_adj is dense_df_adj:
         return ("dense", adj, j.s["A"], 0.0)
     return None
@@ -190,7 +190,7 @@ class NativeBlockOp:
                 b.kind, b.adjoint = KINDS[kind], adj
                 b.coeff = coeff.ptr if coeff is not None else None
                 sc = complex(scale)
-                b.scale_re, b.scale_im = sc.real, sc.imag
+                b.scale_re, b.scale_im, b.scale_flags = sc.real, sc.imag, scalar_flags(scale)
                 b.nr, b.nc = range_(base).length(), domain(base).length()
                 if coeff is not None:
                     self._keep.append(coeff)
@@ -599,8 +599,14 @@ def _real_scale(op):
     if isinstance(op, JopAdjoint):
         op = op.op                                    # conj(a) == a for a real a
     if isinstance(op, JopLn) and op.jet.df is _j.constdiag_df and op.jet.df_adj is _j.constdiag_df_adj:
-        a = complex(op.jet.s["a"])
-        return a.real if a.imag == 0.0 else None
+        a = op.jet.s["a"]
+        # the fused kernels multiply by T(a), part by part: right for a Real scalar of the elements' precision.  A Complex scalar (full
+        # product, even with a zero imaginary part) and a Float64 one against 32-bit elements (promoted arithmetic) take the chain.
+        fl = scalar_flags(a)
+        T = np.dtype(domain(op).eltype())
+        if T.itemsize // (2 if T.kind == "c" else 1) == 8:
+            fl &= ~SCALAR_WIDE                            # nothing is wider than 64-bit elements
+        return None if fl or complex(a).imag != 0.0 else float(complex(a).real)
     return None
 
 

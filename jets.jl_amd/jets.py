@@ -623,7 +623,7 @@ def constdiag_df(d, m, *, a, **kw):  # :1159   d .= a * m
 
 
 def constdiag_df_adj(m, d, *, a, **kw):  # :1160   m .= conj(a) * d
-    return lincomb_(m, [np.conj(a)], [d])
+    return lincomb_(m, [a.conjugate() if isinstance(a, (complex, np.complexfloating)) else a], [d])   # (conj keeps a's TYPE: np.conj would widen a Python complex)
 
 
 def scale_op(a, A: Jop) -> Jop:  # :1161-1164

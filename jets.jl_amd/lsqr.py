@@ -25,6 +25,12 @@ import os
 
 from ._ffi import lib, check, JetsHipError
 from .arrays import zeros, lincomb_, norm, copyto_, reshape
+
+
+def _plain(coefs):
+    """The solvers' recurrences run in fp64 and their coefficients are applied in the vectors' element type (what the C++ loops of
+    jh_lsqr.hip do): plain Python floats, so that a numpy float64 from a norm is not read as Julia's Float64 (promoted arithmetic)."""
+    return [float(c) for c in coefs]
 from . import jets as _j
 from . import jetblock as _blk
 
@@ -84,7 +90,7 @@ class _Engine:
         return copyto_(dst, src)
 
     def lincomb(self, dst, coefs, xs):
-        return lincomb_(dst, coefs, xs)
+        return lincomb_(dst, _plain(coefs), xs)
 
     def norm_dom(self, x) -> float:
         return float(norm(x))
@@ -106,7 +112,7 @@ class _Engine:
         if self._tmp_r is None:
             self._tmp_r = zeros(_j.range_(self.A))
         _j.mul_(self._tmp_r, self.L, v)
-        lincomb_(u, [alpha, beta], [self._tmp_r, u])
+        lincomb_(u, _plain([alpha, beta]), [self._tmp_r, u])
         return float(norm(u)) ** 2
 
     def fwd(self, u, v, alpha, beta) -> float:
@@ -149,7 +155,7 @@ class _Engine:
         if self._tmp_d is None:
             self._tmp_d = zeros(_j.domain(self.A))
         _j.mul_(self._tmp_d, _j.adjoint(self.L), u)
-        lincomb_(v, [alpha, beta], [self._tmp_d, v])
+        lincomb_(v, _plain([alpha, beta]), [self._tmp_d, v])
         return float(norm(v))
 
 
@@ -186,7 +192,7 @@ class _ShardEngine(_Engine):
         if self._tmp_d is None:
             self._tmp_d = zeros(_j.domain(self.A))
         self.shard.mul_adj_(self._tmp_d, u)              # local A'u + all-reduce
-        lincomb_(v, [alpha, beta], [self._tmp_d, v])
+        lincomb_(v, _plain([alpha, beta]), [self._tmp_d, v])
         return float(norm(v))
 
 
@@ -216,7 +222,7 @@ class _TeamEngine:
 
     def lincomb(self, dst, coefs, xs):
         for k, _ in self.team.each():
-            lincomb_(dst[k], coefs, [x[k] for x in xs])
+            lincomb_(dst[k], _plain(coefs), [x[k] for x in xs])
         return dst
 
     def norm_dom(self, x) -> float:

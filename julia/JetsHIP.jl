@@ -416,7 +416,13 @@ struct jh_block_desc          # mirrors include/jetship.h
     scale_im::Cdouble
     nr::Int64
     nc::Int64
+    scale_flags::Int32        # JH_SCALAR_*: the TYPE of a, which Julia's `a * m` dispatches on
+    reserved::Int32
 end
+jh_block_desc(kind, adjoint, coeff, re, im, nr, nc) = jh_block_desc(kind, adjoint, coeff, re, im, nr, nc, 0, 0)
+# JH_SCALAR_COMPLEX = 1: a Complex scalar takes the full complex product even when its imaginary part is zero (a Real one multiplies part
+# by part); JH_SCALAR_WIDE = 2: a Float64-based scalar against 32-bit elements is promoted arithmetic, rounded once on the store
+_scalar_flags(a::Number) = Cint((a isa Complex ? 1 : 0) | (real(typeof(a)) === Float64 ? 2 : 0))
 
 function block_desc(op::Jop)
     adj = op isa JopAdjoint
@@ -435,7 +441,7 @@ function block_desc(op::Jop)
         return jh_block_desc(5, adj, C_NULL, 0, 0, nr, nc)
     elseif j.df! === _constdiag_df!                                     # a*I, src/Jets.jl:1159-1164
         a = state(base).a
-        return jh_block_desc(2, adj, C_NULL, real(a), imag(a), nr, nc)
+        return jh_block_desc(2, adj, C_NULL, real(a), imag(a), nr, nc, _scalar_flags(a), 0)
     end
     nothing            # not device-native: the reference's per-block loop handles it (on device arrays, child by child)
 end

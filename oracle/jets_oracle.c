@@ -148,10 +148,10 @@ void jo_barr_convert(int dtype, int64_t nb, const void *const *arrays, const int
 }
 
 void jo_barr_lincomb(int dtype, int64_t nb, void *const *dst, const int64_t *lens, int k,
-                     const double *coef, const void *const *const *srcs)
+                     const double *coef, const int32_t *flags, const void *const *const *srcs)
 {
-    DISPATCH(dtype, barr_lincomb_f32(nb, dst, lens, k, coef, srcs), barr_lincomb_f64(nb, dst, lens, k, coef, srcs),
-             barr_lincomb_c32(nb, dst, lens, k, coef, srcs), barr_lincomb_c64(nb, dst, lens, k, coef, srcs));
+    DISPATCH(dtype, barr_lincomb_f32(nb, dst, lens, k, coef, flags, srcs), barr_lincomb_f64(nb, dst, lens, k, coef, flags, srcs),
+             barr_lincomb_c32(nb, dst, lens, k, coef, flags, srcs), barr_lincomb_c64(nb, dst, lens, k, coef, flags, srcs));
 }
 
 void jo_child_mul(int dtype, const jo_block *b, void *d, const void *m)

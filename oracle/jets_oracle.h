@@ -44,7 +44,13 @@ typedef struct {
     const void *coeff;  /* DIAG: diagonal (len = block len); DENSE: column-major nr x nc; SQUARE: the point mo */
     double sre, sim;    /* SCALE: the scalar a                                        */
     int64_t nr, nc;     /* range / domain length of the described (un-adjointed) op   */
+    int32_t sflags;     /* SCALE: JO_SCALAR_* -- what Julia knows from the scalar's TYPE   */
+    int32_t reserved;
 } jo_block;
+
+/* the TYPE of a scalar (src/Jets.jl:1159 `a * m`, 889-911 broadcast): Julia dispatches on it, a (re, im) pair alone cannot say */
+enum { JO_SCALAR_COMPLEX = 1,   /* a Complex scalar: the full complex product even when its imaginary part is zero */
+       JO_SCALAR_WIDE = 2 };    /* a Float64-based scalar against 32-bit elements: promoted arithmetic, one rounding on the store */
 
 /* src/Jets.jl:739-750  JetBSpace constructor: cumulative 1-based inclusive ranges */
 void jo_bspace_indices(int64_t nblocks, const int64_t *lens, int64_t *start1, int64_t *stop1);
@@ -73,7 +79,7 @@ void jo_barr_fill(int dtype, int64_t nb, void *const *arrays, const int64_t *len
 void jo_barr_convert(int dtype, int64_t nb, const void *const *arrays, const int64_t *lens, void *flat);
 /* src/Jets.jl:905-911 with bc = c1*x1 .+ c2*x2 .+ ... (left-to-right, each op rounded in T) */
 void jo_barr_lincomb(int dtype, int64_t nb, void *const *dst, const int64_t *lens, int k,
-                     const double *coef_re_im, const void *const *const *srcs);
+                     const double *coef_re_im, const int32_t *coef_flags /* k x JO_SCALAR_*, or NULL */, const void *const *const *srcs);
 
 /* child mul! for the device-native block kinds.
  * DIAG  : test/runtests.jl:3-4   d .= diagonal .* m ; m .= conj.(diagonal) .* d

@@ -21,7 +21,18 @@ KIND = {"zero": 0, "identity": 1, "scale": 2, "diag": 3, "dense": 4, "square": 5
 
 class _Block(C.Structure):
     _fields_ = [("kind", C.c_int32), ("adjoint", C.c_int32), ("coeff", C.c_void_p), ("sre", C.c_double), ("sim", C.c_double),
-                ("nr", C.c_int64), ("nc", C.c_int64)]
+                ("nr", C.c_int64), ("nc", C.c_int64), ("sflags", C.c_int32), ("reserved", C.c_int32)]
+
+
+SCALAR_COMPLEX, SCALAR_WIDE = 1, 2
+
+
+def scalar_flags(a) -> int:
+    """What Julia knows from a scalar's TYPE (jets_oracle.h JO_SCALAR_*), read off the Python object the way the host mirror does: a Python or
+    numpy complex is a Complex scalar; numpy's float64 / complex128 are Float64-based (promoted arithmetic against 32-bit elements); plain
+    Python numbers and 32-bit numpy scalars are taken in the vectors' element type (Julia's `T(a)`)."""
+    f = SCALAR_COMPLEX if isinstance(a, (complex, np.complexfloating)) else 0
+    return f | (SCALAR_WIDE if isinstance(a, (np.float64, np.complex128)) else 0)
 
 
 def build(force: bool = False) -> str:
@@ -131,12 +142,14 @@ def barr_lincomb(dst, coefs, srcs):
     dst = _check_blocks(dst)
     k = len(srcs)
     cf = (C.c_double * (2 * k))()
+    fl = (C.c_int32 * k)()
     for j, c in enumerate(coefs):
+        fl[j] = scalar_flags(c)
         c = complex(c)
         cf[2 * j], cf[2 * j + 1] = c.real, c.imag
     ptrs = [_ptrs(_check_blocks(s, dst[0].dtype)) for s in srcs]
     pp = (C.POINTER(C.c_void_p) * k)(*[C.cast(p, C.POINTER(C.c_void_p)) for p in ptrs])
-    _lib.jo_barr_lincomb(C.c_int(DT[dst[0].dtype]), C.c_int64(len(dst)), _ptrs(dst), _lens(dst), C.c_int(k), cf, pp)
+    _lib.jo_barr_lincomb(C.c_int(DT[dst[0].dtype]), C.c_int64(len(dst)), _ptrs(dst), _lens(dst), C.c_int(k), cf, fl, pp)
     return dst
 
 
@@ -148,7 +161,7 @@ class Block:
     def __init__(self, kind, nr, nc=None, coeff=None, scale=0.0, adjoint=False):
         self.kind, self.nr, self.nc = kind, int(nr), int(nr if nc is None else nc)
         self.coeff = None if coeff is None else np.asfortranarray(coeff)
-        self.scale, self.adjoint = complex(scale), bool(adjoint)
+        self.scale, self.adjoint, self.scale_flags = complex(scale), bool(adjoint), scalar_flags(scale)
 
     @property
     def rng_len(self):
@@ -168,7 +181,7 @@ def _ops_array(ops):
             b, o = arr[i + j * nrow], ops[i][j]
             b.kind, b.adjoint = KIND[o.kind], 1 if o.adjoint else 0
             b.coeff = o.coeff.ctypes.data if o.coeff is not None else None
-            b.sre, b.sim, b.nr, b.nc = o.scale.real, o.scale.imag, o.nr, o.nc
+            b.sre, b.sim, b.nr, b.nc, b.sflags = o.scale.real, o.scale.imag, o.nr, o.nc, o.scale_flags
     return arr, nrow, ncol
 
 

@@ -73,3 +73,50 @@ def assert_same_values(a, b, what=""):
     if not np.array_equal(ia, ib):
         bad = np.flatnonzero(ia != ib)
         raise AssertionError(f"{what}: {bad.size} non-NaN elements differ bitwise; first at {bad[:5]}")
+
+
+# ---- Julia's scalar arithmetic, spelled out with real numpy operations (each one IEEE-rounded, no contraction) ----------------------------------
+def julia_scalar_term(a, x):
+    """`a * x[k]` as Julia computes it for a scalar of a's TYPE (src/Jets.jl:1159 `d .= a * m`; base/complex.jl), BEFORE the store's
+    conversion: (re, im, precision) with re / im arrays in the arithmetic's precision.  A Python / numpy complex is a Complex (full product,
+    also with a zero imaginary part), a Real multiplies part by part; numpy's float64 / complex128 are Float64-based (promoted arithmetic
+    against 32-bit elements), everything else is taken in x's precision."""
+    x = np.asarray(x)
+    R = np.float32 if x.dtype in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
+    W = np.float64 if isinstance(a, (np.float64, np.complex128)) else R
+    cplx = isinstance(a, (complex, np.complexfloating))
+    ar, ai = W(complex(a).real), W(complex(a).imag)
+    xr = np.real(x).astype(W)
+    xi = np.imag(x).astype(W) if x.dtype.kind == "c" else None
+    with np.errstate(all="ignore"):
+        if xi is None:
+            assert not cplx
+            return ar * xr, None, W
+        if not cplx:
+            return ar * xr, ar * xi, W
+        return ar * xr - ai * xi, ar * xi + ai * xr, W
+
+
+def julia_lincomb(coefs, xs):
+    """`dst .= c1 .* x1 .+ c2 .* x2 .+ ...` left to right with Julia's promotion: a sum with a Float64 operand is a Float64 sum; ONE rounding
+    into the vectors' element type at the end."""
+    x0 = np.asarray(xs[0])
+    R = np.float32 if x0.dtype in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
+    acc_r = acc_i = None
+    prec = R
+    with np.errstate(all="ignore"):
+        for c, x in zip(coefs, xs):
+            tr, ti, W = julia_scalar_term(c, x)
+            if acc_r is None:
+                acc_r, acc_i, prec = tr, ti, W
+                continue
+            prec = np.float64 if np.float64 in (prec, W) else R
+            acc_r = acc_r.astype(prec) + tr.astype(prec)
+            if ti is not None:
+                acc_i = acc_i.astype(prec) + ti.astype(prec)
+    with np.errstate(all="ignore"):
+        if acc_i is None:
+            return acc_r.astype(R)
+        out = np.empty(x0.shape, dtype=x0.dtype)
+        out.real, out.imag = acc_r.astype(R), acc_i.astype(R)
+    return out

@@ -58,7 +58,8 @@ def test_oracle_reproduces_mixed_fixtures(oracle, tag, dt):
 def test_oracle_reproduces_vector_fixtures(oracle, tag, dt):
     lens = G[f"{tag}_lens"]
     u, v, w = (_split(G[f"{tag}_{k}"], lens) for k in "uvw")
-    x = oracle.barr_lincomb([np.empty_like(t) for t in u], list(G[f"{tag}_coef"]), [u, v, w])
+    coef = [c.item() for c in G[f"{tag}_coef"]]     # plain Python numbers: taken in the element type (a numpy float64 would be Julia's Float64: promoted)
+    x = oracle.barr_lincomb([np.empty_like(t) for t in u], coef, [u, v, w])
     assert_bits_equal(np.concatenate(x), G[f"{tag}_x"], f"{tag} lincomb")
     for p, want in zip(G[f"{tag}_norm_p"], G[f"{tag}_norms"]):
         assert oracle.barr_norm(u, float(p)) == want
@@ -119,7 +120,7 @@ def test_hip_reproduces_vector_fixtures(Jets, tag, dt):
     lens = [int(k) for k in G[f"{tag}_lens"]]
     R = Jets.JetBSpace([Jets.JetSpace(dt, k) for k in lens])
     u, v, w = (Jets.from_numpy(G[f"{tag}_{k}"], R) for k in "uvw")
-    c = list(G[f"{tag}_coef"])
+    c = [k.item() for k in G[f"{tag}_coef"]]        # (plain Python numbers, as in the oracle's test above)
     x = (c[0] * u + c[1] * v + c[2] * w).materialize()
     assert_bits_equal(x.to_numpy(), G[f"{tag}_x"], f"{tag} lincomb")
     tol = 1e-5 if np.dtype(dt) == np.dtype(np.float32) else 1e-12
@@ -187,7 +188,7 @@ def test_hip_reproduces_nonlinear_fixtures(Jets, tag, dt):
 @pytest.mark.parametrize("tag,dt", GK)
 def test_oracle_reproduces_golub_kahan_fixtures(oracle, tag, dt):
     a, v, u = GN[f"{tag}_a"], GN[f"{tag}_v"], GN[f"{tag}_u"]
-    alpha, beta = GN[f"{tag}_alpha_beta"]
+    alpha, beta = (float(x) for x in GN[f"{tag}_alpha_beta"])   # plain Python numbers: taken in the element type
     nrow, n = a.shape
     ops = [[oracle.Block("diag", n, coeff=np.ascontiguousarray(a[i]))] for i in range(nrow)]
     tmp = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [v])

@@ -1,0 +1,123 @@
+"""The TYPE of a scalar decides Julia's arithmetic (src/Jets.jl:1159-1160 `d .= a * m`, `m .= conj(a) * d`; 889-911 broadcast): a Real
+multiplies a complex element part by part, a Complex takes the full product even with a zero imaginary part, and a Float64 scalar against
+Float32 elements is promoted arithmetic rounded once on the store.  The oracle (CPU, here) and the HIP path (-m gpu) are both checked
+against Julia's formulas spelled out with real numpy operations (tests/helpers.py: julia_scalar_term / julia_lincomb), on data that
+holds signed zeros, infinities and values whose products round differently in the two precisions."""
+import numpy as np
+import pytest
+
+from .helpers import assert_same_values as assert_bits_equal   # bit for bit, a NaN matching any NaN (payloads differ between x86 and CDNA)
+from .helpers import julia_lincomb, julia_scalar_term
+
+SPECIALS = [0.0, -0.0, np.inf, -np.inf, 1.0, -1.0, 1e-30, 3.0e38]
+
+
+def _data(dt, n, seed):
+    rng = np.random.default_rng(seed)
+    dt = np.dtype(dt)
+    if dt.kind == "c":
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(dt)
+        k = 0
+        for re in SPECIALS:                      # every pairing of special parts
+            for im in SPECIALS:
+                x[k] = complex(re, im)
+                k += 1
+    else:
+        x = rng.standard_normal(n).astype(dt)
+        x[:len(SPECIALS)] = SPECIALS
+    return x
+
+
+def _store(tr, ti, dt):
+    R = np.float32 if np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
+    with np.errstate(all="ignore"):
+        if ti is None:
+            return tr.astype(R)
+        out = np.empty(tr.shape, dtype=dt)
+        out.real, out.imag = tr.astype(R), ti.astype(R)
+        return out
+
+
+def scalars_for(dt):
+    """scalars of every type class against elements of type dt"""
+    real = [2.5, np.float32(0.1), np.float64(0.1), np.float64(3.14), 3]
+    if np.dtype(dt).kind != "c":
+        return real
+    return real + [2 + 0j, complex(0.1, -0.0), np.complex64(0.1 + 0.3j), np.complex128(0.1 + 0.3j), np.complex128(3.14 + 0j), 0.7 - 1.3j]
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
+def test_oracle_scale_blocks_and_lincomb_follow_the_scalars_type(oracle, dt):
+    n = 200
+    x, y = _data(dt, n, 5), _data(dt, n, 6)[::-1].copy()
+    for a in scalars_for(dt):
+        want = _store(*julia_scalar_term(a, x)[:2], dt)
+        got = oracle.block_df([[oracle.Block("scale", n, scale=a)]], [np.zeros(n, dtype=dt)], [x])[0]
+        assert_bits_equal(got, want, f"a * m, a = {a!r} ({type(a).__name__}), {np.dtype(dt)}")
+        want = _store(*julia_scalar_term(a.conjugate() if isinstance(a, (complex, np.complexfloating)) else a, x)[:2], dt)
+        got = oracle.block_df_adj([[oracle.Block("scale", n, scale=a)]], [np.zeros(n, dtype=dt)], [x])[0]
+        assert_bits_equal(got, want, f"conj(a) * d, a = {a!r} ({type(a).__name__}), {np.dtype(dt)}")
+        for b in scalars_for(dt)[::2]:
+            got = oracle.barr_lincomb([np.empty(n, dtype=dt)], [a, b], [[x], [y]])[0]
+            assert_bits_equal(got, julia_lincomb([a, b], [x, y]), f"a*x + b*y, a = {a!r}, b = {b!r}, {np.dtype(dt)}")
+    # the type matters: a Complex 2 + 0im against a Real 2 on a signed zero and an infinity, Float64 0.1 against Float32(0.1)
+    if np.dtype(dt).kind == "c":
+        z = np.array([complex(-0.0, -1.0), complex(1.0, np.inf)], dtype=dt)
+        as_real = oracle.block_df([[oracle.Block("scale", 2, scale=2.0)]], [np.zeros(2, dtype=dt)], [z])[0]
+        as_cplx = oracle.block_df([[oracle.Block("scale", 2, scale=2 + 0j)]], [np.zeros(2, dtype=dt)], [z])[0]
+        assert np.signbit(as_real[0].real) and not np.signbit(as_cplx[0].real)
+        assert as_real[1].real == 2.0 and np.isnan(as_cplx[1].real)
+    if np.dtype(dt) == np.dtype(np.float32):
+        narrow = oracle.barr_lincomb([np.empty(n, dtype=dt)], [0.1], [[x]])[0]
+        wide = oracle.barr_lincomb([np.empty(n, dtype=dt)], [np.float64(0.1)], [[x]])[0]
+        assert (narrow != wide).sum() > n // 10, "Float64(0.1) * x rounded once differs from Float32(0.1) * x in many last bits"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
+def test_hip_scale_blocks_and_lincomb_follow_the_scalars_type(Jets, oracle, dt):
+    """a * A through JH_OP_SCALE blocks -- next to a diagonal in a tall operator, in a 2 x 2 grid and as the stage of `a * G` (the fused
+    kernels for scalars of the elements' precision, the per-block loop / the chain for wide and Complex-typed ones) -- and `a*u + b*v`
+    through jh_lincomb_typed, against Julia's formulas and against the oracle given the same Python objects."""
+    J = Jets
+    n = 256
+    spc = J.JetSpace(dt, n)
+    x, y, g = _data(dt, n, 5), _data(dt, n, 6)[::-1].copy(), _data(dt, n, 7)
+    dx, dy = J.from_numpy(x, spc), J.from_numpy(y, spc)
+    G = J.JopDiagonal(J.from_numpy(g, spc))
+    zero = np.zeros(n, dtype=dt)
+    for a in scalars_for(dt):
+        S = J.JopLn(dom=spc, rng=spc, df=J.constdiag_df, df_adj=J.constdiag_df_adj, s={"a": a})
+        so, go = oracle.Block("scale", n, scale=a), oracle.Block("diag", n, coeff=g)
+        what = f"a = {a!r} ({type(a).__name__}), {np.dtype(dt)}"
+        # Julia's formula for the scalar rows themselves
+        want_f = _store(*julia_scalar_term(a, x)[:2], dt)
+        # tall [a*I ; G]
+        A = J.blockop([[S], [G]])
+        d = J.mul(A, dx).to_numpy()
+        assert_bits_equal(d[:n], want_f, f"[a*I; G] forward row 1 vs Julia's formula, {what}")
+        assert_bits_equal(d, np.concatenate(oracle.block_df([[so], [go]], [zero.copy(), zero.copy()], [x])), f"[a*I; G] forward vs oracle, {what}")
+        dd = np.concatenate([x, y])
+        mt = J.mul(A.H, J.from_numpy(dd, J.range(A))).to_numpy()
+        assert_bits_equal(mt, oracle.block_df_adj([[so], [go]], [zero.copy()], [x, y])[0], f"[a*I; G]' vs oracle, {what}")
+        J.close(A)
+        # 2 x 2 grid [[a*I, G], [G, a*I]]
+        B = J.blockop([[S, G], [G, S]])
+        d2 = J.mul(B, J.from_numpy(dd, J.domain(B))).to_numpy()
+        assert_bits_equal(d2, np.concatenate(oracle.block_df([[so, go], [go, so]], [zero.copy(), zero.copy()], [x, y])), f"grid forward vs oracle, {what}")
+        m2 = J.mul(B.H, J.from_numpy(dd, J.range(B))).to_numpy()
+        assert_bits_equal(m2, np.concatenate(oracle.block_df_adj([[so, go], [go, so]], [zero.copy(), zero.copy()], [x, y])), f"grid adjoint vs oracle, {what}")
+        J.close(B)
+        # a * T for a tall all-diagonal T: the composite (fused into the forward for a Real scalar of the elements' precision)
+        T = J.blockop([[G], [G]])
+        aT = a * T
+        d3 = J.mul(aT, dx).to_numpy()
+        with np.errstate(all="ignore"):
+            inner = oracle.block_df([[go], [go]], [zero.copy(), zero.copy()], [x])
+        want3 = np.concatenate([_store(*julia_scalar_term(a, blk)[:2], dt) for blk in inner])
+        assert_bits_equal(d3, want3, f"(a * T) m vs Julia's formula, {what}")
+        J.close(T)
+        for b in scalars_for(dt)[::2]:
+            got = (a * dx + b * dy).materialize().to_numpy()
+            assert_bits_equal(got, julia_lincomb([a, b], [x, y]), f"a*x + b*y vs Julia's formula, b = {b!r}, {what}")
+            assert_bits_equal(got, oracle.barr_lincomb([np.empty(n, dtype=dt)], [a, b], [[x], [y]])[0], f"a*x + b*y vs oracle, b = {b!r}, {what}")
