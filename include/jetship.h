@@ -219,9 +219,14 @@ int jh_bcast_compile(const char *expr, int dtype, int nvec, int nscal, jh_bcast 
  * mask or weight on a complex vector; bit nvec + k says SCALAR k is a real number (its imaginary slot is ignored).  Real (x) complex
  * arithmetic is Julia's: a*(x + iy) = (a*x) + i(a*y), a + z adds to the real part -- so a real scalar never meets the 0 * Inf = NaN
  * of the four-multiplication formula.  real_mask == 0 is jh_bcast_compile.
- * The same convention without a mask wherever the ABI takes a scalar as (re, im) outside a compiled program (jh_lincomb's
- * coefficients, the scalar of a JH_OP_SCALE block): an imaginary part that is exactly zero means a REAL scalar. */
+ * Outside a compiled program the scalar's type travels as JH_SCALAR_* flags (jh_lincomb_typed, jh_block_desc.scale_flags).
+ * jh_bcast_compile_typed adds wide_mask: bit k says scalar k is Float64-based (JH_SCALAR_WIDE) in a 32-bit program -- it enters the
+ * expression as a double, every operation it meets is a double operation (Julia's promotion is the language's own), and the element
+ * type comes back with the ONE rounding of the store: `x .= a .* u .+ v` with a::Float64, u, v::Vector{Float32}.  Ignored for 64-bit
+ * programs; wide_mask == 0 is jh_bcast_compile_mixed. */
 int jh_bcast_compile_mixed(const char *expr, int dtype, int nvec, int real_mask, int nscal, jh_bcast **out);
+int jh_bcast_compile_typed(const char *expr, int dtype, int nvec, int real_mask, int nscal, int wide_mask, jh_bcast **out);
+int jh_bcast_check_typed(const char *expr, int dtype, int nvec, int real_mask, int nscal, int wide_mask);   /* compiles only, like jh_bcast_check */
 int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, const double *scal_re_im);
 /* `count` broadcasts in one call (a tall nonlinear operator evaluates one per child: F(m) and point! are `count` launches
  * enqueued back to back instead of `count` trips through the host language).  Operand k's vectors and scalars follow

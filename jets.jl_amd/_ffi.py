@@ -126,6 +126,8 @@ SYMBOLS = {
     "jh_bcast_check": (_int, [C.c_char_p, _int, _int, _int]),
     "jh_bcast_compile": (_int, [C.c_char_p, _int, _int, _int, _vpp]),
     "jh_bcast_compile_mixed": (_int, [C.c_char_p, _int, _int, _int, _int, _vpp]),
+    "jh_bcast_compile_typed": (_int, [C.c_char_p, _int, _int, _int, _int, _int, _vpp]),
+    "jh_bcast_check_typed": (_int, [C.c_char_p, _int, _int, _int, _int, _int]),
     "jh_bcast_apply": (_int, [_vp, _vp, _vpp, _dblp]),
     "jh_bcast_apply_many": (_int, [_int, _vpp, _vpp, _vpp, _dblp]),
     "jh_bcast_destroy": (_int, [_vp]),

@@ -39,12 +39,22 @@ def _real_mask(dtype, vecs, scalars=()) -> int:
     return mask | sum(1 << (len(vecs) + k) for k, a in enumerate(scalars) if not isinstance(a, (complex, np.complexfloating)))
 
 
-def _program(expr: str, dtype, nvec: int, nscal: int, real_mask: int = 0):
-    key = (expr, np.dtype(dtype).str, nvec, nscal, real_mask)
+def _wide_mask(dtype, scalars=()) -> int:
+    """Bit k set: scalar k is Float64-based (numpy float64 / complex128 -- Julia's Float64 / ComplexF64) in a 32-bit program: promoted
+    arithmetic, one rounding on the store (include/jetship.h JH_SCALAR_WIDE; _ffi.scalar_flags)."""
+    if np.dtype(dtype) not in (np.dtype(np.float32), np.dtype(np.complex64)):
+        return 0
+    return sum(1 << k for k, a in enumerate(scalars) if isinstance(a, (np.float64, np.complex128)))
+
+
+def _program(expr: str, dtype, nvec: int, nscal: int, real_mask: int = 0, wide_mask: int = 0):
+    key = (expr, np.dtype(dtype).str, nvec, nscal, real_mask, wide_mask)
     h = _programs.get(key)
     if h is None:
         h = C.c_void_p()
-        if real_mask:
+        if wide_mask:
+            check(lib.jh_bcast_compile_typed(expr.encode(), dtype_code(dtype), nvec, real_mask, nscal, wide_mask, C.byref(h)))
+        elif real_mask:
             check(lib.jh_bcast_compile_mixed(expr.encode(), dtype_code(dtype), nvec, real_mask, nscal, C.byref(h)))
         else:
             check(lib.jh_bcast_compile(expr.encode(), dtype_code(dtype), nvec, nscal, C.byref(h)))
@@ -61,7 +71,7 @@ def pack_many(jobs):
     dsts = (C.c_void_p * max(len(jobs), 1))()
     xs, sc, keep = [], [], []
     for k, (dst, expr, vecs, scalars) in enumerate(jobs):
-        progs[k] = _program(expr, dst.dtype, len(vecs), len(scalars), _real_mask(dst.dtype, vecs, scalars))
+        progs[k] = _program(expr, dst.dtype, len(vecs), len(scalars), _real_mask(dst.dtype, vecs, scalars), _wide_mask(dst.dtype, scalars))
         dsts[k] = dst.handle
         keep.append(dst)
         for v in vecs:
@@ -89,10 +99,10 @@ def broadcast_many_(jobs):
 
 
 def broadcast_(dst: _DevVec, expr: str, vecs=(), scalars=()):
-    """dst .= expr over x0..x{k-1} = elements of `vecs`, s0.. = `scalars` (converted to dst's eltype).  dst may alias
+    """dst .= expr over x0..x{k-1} = elements of `vecs`, s0.. = `scalars` (converted to dst's eltype; a numpy float64 / complex128 against 32-bit elements stays a double: Julia's promotion).  dst may alias
     any operand.  Every operation is rounded as written (-ffp-contract=off)."""
     vecs, scalars = list(vecs), list(scalars)
-    h = _program(expr, dst.dtype, len(vecs), len(scalars), _real_mask(dst.dtype, vecs, scalars))
+    h = _program(expr, dst.dtype, len(vecs), len(scalars), _real_mask(dst.dtype, vecs, scalars), _wide_mask(dst.dtype, scalars))
     hs = (C.c_void_p * max(len(vecs), 1))(*[v.handle for v in vecs])
     sc = (C.c_double * max(2 * len(scalars), 1))()
     for i, a in enumerate(scalars):

@@ -20,6 +20,7 @@
 struct jh_bcast {
     int dtype = JH_F32;
     int nvec = 0, nscal = 0;
+    int wide_mask = 0;                  // bit k: scalar k is Float64-based in a 32-bit program (JH_SCALAR_WIDE): it enters the expression as a double
     int real_mask = 0;                  // bit k: vector operand k is REAL in a complex program (a real mask on a complex vector); bit nvec + k: scalar k is
     // a program is device-agnostic (one code object for gfx950); its module is loaded per DEVICE on first use there
     struct on_device {
@@ -40,31 +41,51 @@ constexpr int JH_BCAST_MAX_VEC = 8, JH_BCAST_MAX_SCAL = 8;
 
 // complex arithmetic for the generated code: plain formulas, every product and sum rounded (like jh_vecops.hip)
 const char *k_prelude = R"SRC(
+// the precision of a mixed operation is the wider operand's (Julia's promotion == C++'s usual arithmetic conversions for float / double / ints)
+template <typename A, typename B> struct wd_ { typedef decltype(A() + B()) t; };
+template <typename B> struct is_num_ { static const bool v = false; };
+template <> struct is_num_<float> { static const bool v = true; };
+template <> struct is_num_<double> { static const bool v = true; };
+template <> struct is_num_<int> { static const bool v = true; };
+template <> struct is_num_<long> { static const bool v = true; };
+template <> struct is_num_<long long> { static const bool v = true; };
+template <bool C, typename T> struct en_ {};
+template <typename T> struct en_<true, T> { typedef T t; };
 template <typename R> struct cx {
     typedef R real_t;
     R re, im;
     __device__ cx() : re(0), im(0) {}
     __device__ cx(R r) : re(r), im(0) {}
     __device__ cx(R r, R i) : re(r), im(i) {}
+    template <typename Q> __device__ explicit cx(cx<Q> o) : re((R)o.re), im((R)o.im) {}   // the store's conversion (and a widening)
 };
-template <typename R> __device__ inline cx<R> operator+(cx<R> a, cx<R> b) { return cx<R>(a.re + b.re, a.im + b.im); }
-template <typename R> __device__ inline cx<R> operator-(cx<R> a, cx<R> b) { return cx<R>(a.re - b.re, a.im - b.im); }
+#define CXW_ typename wd_<R1, R2>::t
+template <typename R1, typename R2> __device__ inline cx<CXW_> operator+(cx<R1> a, cx<R2> b) { typedef CXW_ W; return cx<W>((W)a.re + (W)b.re, (W)a.im + (W)b.im); }
+template <typename R1, typename R2> __device__ inline cx<CXW_> operator-(cx<R1> a, cx<R2> b) { typedef CXW_ W; return cx<W>((W)a.re - (W)b.re, (W)a.im - (W)b.im); }
 template <typename R> __device__ inline cx<R> operator-(cx<R> a) { return cx<R>(-a.re, -a.im); }
-template <typename R> __device__ inline cx<R> operator*(cx<R> a, cx<R> b) { return cx<R>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
-template <typename R> __device__ inline cx<R> operator/(cx<R> a, cx<R> b)
+template <typename R1, typename R2> __device__ inline cx<CXW_> operator*(cx<R1> a, cx<R2> b)
 {
-    const R den = b.re * b.re + b.im * b.im;
-    return cx<R>((a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den);
+    typedef CXW_ W;
+    return cx<W>((W)a.re * (W)b.re - (W)a.im * (W)b.im, (W)a.re * (W)b.im + (W)a.im * (W)b.re);
 }
-// real (x) complex: the real operand is a non-deduced parameter, so literals and other real types convert to R
-template <typename R> __device__ inline cx<R> operator+(cx<R> a, typename cx<R>::real_t b) { return cx<R>(a.re + b, a.im); }
-template <typename R> __device__ inline cx<R> operator+(typename cx<R>::real_t a, cx<R> b) { return cx<R>(a + b.re, b.im); }
-template <typename R> __device__ inline cx<R> operator-(cx<R> a, typename cx<R>::real_t b) { return cx<R>(a.re - b, a.im); }
-template <typename R> __device__ inline cx<R> operator-(typename cx<R>::real_t a, cx<R> b) { return cx<R>(a - b.re, -b.im); }
-template <typename R> __device__ inline cx<R> operator*(cx<R> a, typename cx<R>::real_t b) { return cx<R>(a.re * b, a.im * b); }
-template <typename R> __device__ inline cx<R> operator*(typename cx<R>::real_t a, cx<R> b) { return cx<R>(a * b.re, a * b.im); }
-template <typename R> __device__ inline cx<R> operator/(cx<R> a, typename cx<R>::real_t b) { return cx<R>(a.re / b, a.im / b); }
-template <typename R> __device__ inline cx<R> operator/(typename cx<R>::real_t a, cx<R> b) { return cx<R>(a) / b; }
+template <typename R1, typename R2> __device__ inline cx<CXW_> operator/(cx<R1> a, cx<R2> b)
+{
+    typedef CXW_ W;
+    const W den = (W)b.re * (W)b.re + (W)b.im * (W)b.im;
+    return cx<W>(((W)a.re * (W)b.re + (W)a.im * (W)b.im) / den, ((W)a.im * (W)b.re - (W)a.re * (W)b.im) / den);
+}
+#undef CXW_
+// real (x) complex, part by part (Julia's a::Real * z): any arithmetic type; an integer takes the complex operand's precision, a double widens it
+#define CXR_ typename en_<is_num_<B>::v, cx<typename wd_<R, B>::t>>::t
+template <typename R, typename B> __device__ inline CXR_ operator+(cx<R> a, B b) { typedef typename wd_<R, B>::t W; return cx<W>((W)a.re + (W)b, (W)a.im); }
+template <typename R, typename B> __device__ inline CXR_ operator+(B a, cx<R> b) { typedef typename wd_<R, B>::t W; return cx<W>((W)a + (W)b.re, (W)b.im); }
+template <typename R, typename B> __device__ inline CXR_ operator-(cx<R> a, B b) { typedef typename wd_<R, B>::t W; return cx<W>((W)a.re - (W)b, (W)a.im); }
+template <typename R, typename B> __device__ inline CXR_ operator-(B a, cx<R> b) { typedef typename wd_<R, B>::t W; return cx<W>((W)a - (W)b.re, -(W)b.im); }
+template <typename R, typename B> __device__ inline CXR_ operator*(cx<R> a, B b) { typedef typename wd_<R, B>::t W; return cx<W>((W)a.re * (W)b, (W)a.im * (W)b); }
+template <typename R, typename B> __device__ inline CXR_ operator*(B a, cx<R> b) { typedef typename wd_<R, B>::t W; return cx<W>((W)a * (W)b.re, (W)a * (W)b.im); }
+template <typename R, typename B> __device__ inline CXR_ operator/(cx<R> a, B b) { typedef typename wd_<R, B>::t W; return cx<W>((W)a.re / (W)b, (W)a.im / (W)b); }
+template <typename R, typename B> __device__ inline CXR_ operator/(B a, cx<R> b) { typedef typename wd_<R, B>::t W; return cx<W>((W)a) / b; }
+#undef CXR_
 template <typename R> __device__ inline cx<R> conj(cx<R> a) { return cx<R>(a.re, -a.im); }
 template <typename R> __device__ inline R real(cx<R> a) { return a.re; }
 template <typename R> __device__ inline R imag(cx<R> a) { return a.im; }
@@ -83,7 +104,7 @@ __device__ inline float sign(float a) { return (a > 0.f) - (a < 0.f); }
 __device__ inline double sign(double a) { return (a > 0.0) - (a < 0.0); }
 )SRC";
 
-std::string build_source(const std::string &expr, int dtype, int nvec, int nscal, int real_mask)
+std::string build_source(const std::string &expr, int dtype, int nvec, int nscal, int real_mask, int wide_mask)
 {
     const bool is64 = (dtype == JH_F64 || dtype == JH_C64), cplx = jh_dtype_complex(dtype);
     const char *R = is64 ? "double" : "float";
@@ -109,15 +130,19 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
     }
     std::string params = "R *dst_";   // may alias an operand (x .= f.(x, y)): no __restrict__
     for (int k = 0; k < nvec; k++) params += ", const R *p" + std::to_string(k);
-    for (int k = 0; k < nscal; k++) params += ", R sr" + std::to_string(k) + ", R si" + std::to_string(k);
+    // a WIDE scalar (JH_SCALAR_WIDE: Julia's Float64 against 32-bit elements) enters as a double: every operation it meets is then a double
+    // operation by the language's own promotion, and the element type comes back with the ONE rounding of the final conversion to T
+    auto is_wide = [&](int k) { return !is64 && ((wide_mask >> k) & 1); };
+    auto sreal = [&](int k) { return std::string(is_wide(k) ? "double" : "R"); };
+    for (int k = 0; k < nscal; k++) params += ", " + sreal(k) + " sr" + std::to_string(k) + ", " + sreal(k) + " si" + std::to_string(k);
     params += ", long n_scalars";
     std::string scal;
     for (int k = 0; k < nscal; k++) {
         const std::string i = std::to_string(k);
         // a REAL scalar of a complex program (bit nvec + k of real_mask): Julia's `a::Real * z` works part by part (the prelude's
         // mixed operators) -- no 0 * Inf from an imaginary part the scalar does not have
-        if (cplx && !is_real(nvec + k)) scal += "    const T s" + i + "(sr" + i + ", si" + i + ");\n";
-        else scal += "    const R s" + i + " = sr" + i + "; (void)si" + i + ";\n";
+        if (cplx && !is_real(nvec + k)) scal += "    const cx<" + sreal(k) + "> s" + i + "(sr" + i + ", si" + i + ");\n";
+        else scal += "    const " + sreal(k) + " s" + i + " = sr" + i + "; (void)si" + i + ";\n";
     }
     // ---- 16 bytes per lane
     s += "extern \"C\" __global__ __launch_bounds__(256) void jh_bcast_vec(" + params + ")\n{\n" + scal;
@@ -137,16 +162,18 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
     // (jh_bcast_apply_many: the children of a tall nonlinear operator in ONE launch instead of one launch per child)
     // item_fast_: the ITEM is the fastest block index (workgroups that read the same pack of a shared operand -- the model
     // vector every child of a tall nonlinear operator evaluates -- are dispatched together: it comes from L2, not HBM)
-    s += "extern \"C\" __global__ __launch_bounds__(256) void jh_bcast_vec_batched(const void *const *tbl_, const R *sc_, long n_scalars, int item_fast_, int shared_mask_)\n{\n";
+    const bool any_wide = !is64 && wide_mask != 0;          // then the scalar table holds doubles for every scalar of the program
+    s += std::string("extern \"C\" __global__ __launch_bounds__(256) void jh_bcast_vec_batched(const void *const *tbl_, const ") + (any_wide ? "double" : "R") +
+         " *sc_, long n_scalars, int item_fast_, int shared_mask_)\n{\n";
     s += "    const long item_ = item_fast_ ? blockIdx.x : blockIdx.y, tile_ = item_fast_ ? blockIdx.y : blockIdx.x;\n";
     s += "    const long ntile_ = item_fast_ ? gridDim.y : gridDim.x;\n";
     s += "    const void *const *row_ = tbl_ + item_ * " + std::to_string(nvec + 1) + ";\n";
     s += "    R *dst_ = (R *)row_[0];\n";
     for (int k = 0; k < nvec; k++) s += "    const R *p" + std::to_string(k) + " = (const R *)row_[" + std::to_string(k + 1) + "];\n";
-    if (nscal > 0) s += "    const R *srow_ = sc_ + item_ * " + std::to_string(2 * nscal) + ";\n";
+    if (nscal > 0) s += std::string("    const ") + (any_wide ? "double" : "R") + " *srow_ = sc_ + item_ * " + std::to_string(2 * nscal) + ";\n";
     for (int k = 0; k < nscal; k++) {
         const std::string i = std::to_string(k);
-        s += "    const R sr" + i + " = srow_[" + std::to_string(2 * k) + "], si" + i + " = srow_[" + std::to_string(2 * k + 1) + "];\n";
+        s += "    const " + sreal(k) + " sr" + i + " = (" + sreal(k) + ")srow_[" + std::to_string(2 * k) + "], si" + i + " = (" + sreal(k) + ")srow_[" + std::to_string(2 * k + 1) + "];\n";
     }
     s += scal;
     s += "    const long nvec = n_scalars / " + std::to_string(NS) + ";\n";
@@ -184,9 +211,9 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
 std::mutex g_cache_mutex;
 std::map<std::string, jh_bcast *> g_cache;      // (dtype, nvec, nscal, expr) -> compiled program, shared by every handle
 
-int compile_code(const std::string &expr, int dtype, int nvec, int nscal, std::vector<char> &code, int real_mask = 0)
+int compile_code(const std::string &expr, int dtype, int nvec, int nscal, std::vector<char> &code, int real_mask = 0, int wide_mask = 0)
 {
-    const std::string src = build_source(expr, dtype, nvec, nscal, real_mask);
+    const std::string src = build_source(expr, dtype, nvec, nscal, real_mask, wide_mask);
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "jh_bcast.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return jh_fail(JH_ERR_HIP, "jh_bcast_compile: hiprtcCreateProgram failed");
@@ -247,15 +274,16 @@ int loaded(const jh_bcast *bc, const jh_bcast::on_device **out)
     return JH_OK;
 }
 
-int compile(const std::string &expr, int dtype, int nvec, int nscal, jh_bcast **out, int real_mask = 0)
+int compile(const std::string &expr, int dtype, int nvec, int nscal, jh_bcast **out, int real_mask = 0, int wide_mask = 0)
 {
     std::vector<char> code;
-    JH_TRY(compile_code(expr, dtype, nvec, nscal, code, real_mask));
+    JH_TRY(compile_code(expr, dtype, nvec, nscal, code, real_mask, wide_mask));
     jh_bcast *bc = new jh_bcast();
     bc->dtype = dtype;
     bc->nvec = nvec;
     bc->nscal = nscal;
     bc->real_mask = real_mask;
+    bc->wide_mask = wide_mask;
     bc->expr = expr;
     bc->code.swap(code);
     const jh_bcast::on_device *fns = nullptr;
@@ -286,6 +314,13 @@ int jh_bcast_check(const char *expr, int dtype, int nvec, int nscal)
     return compile_code(expr, dtype, nvec, nscal, code);      // hiprtc cross-compiles: no device needed
 }
 
+int jh_bcast_check_typed(const char *expr, int dtype, int nvec, int real_mask, int nscal, int wide_mask)
+{
+    JH_TRY(check_request(expr, dtype, nvec, nscal));
+    std::vector<char> code;
+    return compile_code(expr, dtype, nvec, nscal, code, real_mask, (dtype == JH_F64 || dtype == JH_C64) ? 0 : wide_mask);
+}
+
 int jh_bcast_compile(const char *expr, int dtype, int nvec, int nscal, jh_bcast **out)
 {
     JH_TRY(jh_require_ready());
@@ -305,16 +340,19 @@ int jh_bcast_compile(const char *expr, int dtype, int nvec, int nscal, jh_bcast 
     return JH_OK;
 }
 
-int jh_bcast_compile_mixed(const char *expr, int dtype, int nvec, int real_mask, int nscal, jh_bcast **out)
+int jh_bcast_compile_typed(const char *expr, int dtype, int nvec, int real_mask, int nscal, int wide_mask, jh_bcast **out)
 {
     JH_TRY(jh_require_ready());
-    JH_REQUIRE(out, "jh_bcast_compile_mixed: null argument");
+    JH_REQUIRE(out, "jh_bcast_compile_typed: null argument");
     JH_TRY(check_request(expr, dtype, nvec, nscal));
-    JH_REQUIRE(nvec + nscal < 31, "jh_bcast_compile_mixed: at most 30 operands and scalars");
-    JH_REQUIRE(real_mask >= 0 && real_mask < (1 << (nvec + nscal > 0 ? nvec + nscal : 1)), "jh_bcast_compile_mixed: real_mask has bits beyond the %d operands and %d scalars", nvec, nscal);
-    JH_REQUIRE(real_mask == 0 || jh_dtype_complex(dtype), "jh_bcast_compile_mixed: real operands only make a difference in a complex program");
-    if (real_mask == 0) return jh_bcast_compile(expr, dtype, nvec, nscal, out);
-    const std::string key = std::to_string(dtype) + "/" + std::to_string(nvec) + "/" + std::to_string(nscal) + "/r" + std::to_string(real_mask) + "/" + expr;
+    JH_REQUIRE(nvec + nscal < 31, "jh_bcast_compile_typed: at most 30 operands and scalars");
+    JH_REQUIRE(real_mask >= 0 && real_mask < (1 << (nvec + nscal > 0 ? nvec + nscal : 1)), "jh_bcast_compile_typed: real_mask has bits beyond the %d operands and %d scalars", nvec, nscal);
+    JH_REQUIRE(real_mask == 0 || jh_dtype_complex(dtype), "jh_bcast_compile_typed: real operands only make a difference in a complex program");
+    JH_REQUIRE(wide_mask >= 0 && wide_mask < (1 << (nscal > 0 ? nscal : 1)), "jh_bcast_compile_typed: wide_mask has bits beyond the %d scalars", nscal);
+    if (dtype == JH_F64 || dtype == JH_C64) wide_mask = 0;              // nothing is wider than 64-bit elements
+    if (real_mask == 0 && wide_mask == 0) return jh_bcast_compile(expr, dtype, nvec, nscal, out);
+    const std::string key = std::to_string(dtype) + "/" + std::to_string(nvec) + "/" + std::to_string(nscal) + "/r" + std::to_string(real_mask) + "/w" +
+                            std::to_string(wide_mask) + "/" + expr;
     std::lock_guard<std::mutex> lock(g_cache_mutex);
     auto it = g_cache.find(key);
     if (it != g_cache.end()) {
@@ -322,10 +360,15 @@ int jh_bcast_compile_mixed(const char *expr, int dtype, int nvec, int real_mask,
         return JH_OK;
     }
     jh_bcast *bc = nullptr;
-    JH_TRY(compile(expr, dtype, nvec, nscal, &bc, real_mask));
+    JH_TRY(compile(expr, dtype, nvec, nscal, &bc, real_mask, wide_mask));
     g_cache[key] = bc;
     *out = bc;
     return JH_OK;
+}
+
+int jh_bcast_compile_mixed(const char *expr, int dtype, int nvec, int real_mask, int nscal, jh_bcast **out)
+{
+    return jh_bcast_compile_typed(expr, dtype, nvec, real_mask, nscal, 0, out);
 }
 
 int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, const double *scal_re_im)
@@ -361,7 +404,7 @@ int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, co
     args[na++] = &dptr;
     for (int k = 0; k < bc->nvec; k++) { ptrs[k] = x[k]->data; args[na++] = &ptrs[k]; }
     for (int k = 0; k < 2 * bc->nscal; k++) {
-        if (is64) { sd[k] = scal_re_im[k]; args[na++] = &sd[k]; }
+        if (is64 || ((bc->wide_mask >> (k / 2)) & 1)) { sd[k] = scal_re_im[k]; args[na++] = &sd[k]; }   // (a wide scalar of a 32-bit program is a double parameter)
         else { sf[k] = (float)scal_re_im[k]; args[na++] = &sf[k]; }
     }
     args[na++] = &n_arg;
@@ -447,7 +490,7 @@ static int apply_many_batched(int count, const jh_bcast *const *progs, jh_bvec *
     std::vector<const void *> tbl;
     std::vector<char> sc;
     for (Group &g : groups) {
-        const bool is64 = (g.bc->dtype == JH_F64 || g.bc->dtype == JH_C64);
+        const bool is64 = (g.bc->dtype == JH_F64 || g.bc->dtype == JH_C64) || g.bc->wide_mask != 0;   // (a program with a wide scalar reads doubles)
         g.tbl_at = tbl.size();
         sc.resize((sc.size() + 15) / 16 * 16);
         g.sc_at = sc.size();
@@ -474,7 +517,7 @@ static int apply_many_batched(int count, const jh_bcast *const *progs, jh_bvec *
         const bool cplx = jh_dtype_complex(bc->dtype), is64 = (bc->dtype == JH_F64 || bc->dtype == JH_C64);
         const int NS = is64 ? 2 : 4;
         const int64_t n_scalars = g.len * (cplx ? 2 : 1);
-        const size_t row = (size_t)bc->nvec + 1, sc_row = 2 * (size_t)bc->nscal * (is64 ? 8 : 4);
+        const size_t row = (size_t)bc->nvec + 1, sc_row = 2 * (size_t)bc->nscal * ((is64 || bc->wide_mask != 0) ? 8 : 4);
         const int gcount = (int)g.items.size();
         int64_t gx = (n_scalars / NS + 255) / 256;
         if (gx > 65535) gx = 65535;                           // the kernel strides

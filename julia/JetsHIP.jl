@@ -352,6 +352,8 @@ const _bcast_programs = Dict{Tuple{String,DataType,Int,Int,Int},Ptr{Cvoid}}()
 _real_mask(::Type{T}, vecs, scals) where {T<:Real} = 0
 _real_mask(::Type{Complex{R}}, vecs, scals) where {R} =
     sum(Int[1 << (k - 1) for k = 1:length(vecs) if eltype(vecs[k]) === R]) + sum(Int[1 << (length(vecs) + k - 1) for k = 1:length(scals) if scals[k] isa Real])
+# bit k-1: scalar k is Float64-based against 32-bit elements (JH_SCALAR_WIDE): Julia promotes, computes in Float64 and rounds once on the store
+_wide_mask(::Type{T}, scals) where {T} = real(T) === Float32 ? sum(Int[1 << (k - 1) for k = 1:length(scals) if real(typeof(scals[k])) === Float64]) : 0
 function _bcast!(dest::DevVec{T}, bc::Broadcast.Broadcasted) where {T}
     vecs, scals = Any[], Number[]
     expr = _emit(bc, vecs, scals)
@@ -362,9 +364,12 @@ function _bcast!(dest::DevVec{T}, bc::Broadcast.Broadcasted) where {T}
         return dest
     end
     mask = _real_mask(T, vecs, scals)
-    prog = get!(_bcast_programs, (expr, T, length(vecs), length(scals), mask)) do
+    wide = _wide_mask(T, scals)
+    prog = get!(_bcast_programs, (expr, T, length(vecs), length(scals), mask | (wide << 32))) do
         h = Ref{Ptr{Cvoid}}()
-        if mask == 0
+        if wide != 0
+            check(ccall((:jh_bcast_compile_typed, LIB), Cint, (Cstring, Cint, Cint, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), expr, dtype_code(T), length(vecs), mask, length(scals), wide, h))
+        elseif mask == 0
             check(ccall((:jh_bcast_compile, LIB), Cint, (Cstring, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), expr, dtype_code(T), length(vecs), length(scals), h))
         else
             check(ccall((:jh_bcast_compile_mixed, LIB), Cint, (Cstring, Cint, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), expr, dtype_code(T), length(vecs), mask, length(scals), h))

@@ -121,3 +121,50 @@ def test_hip_scale_blocks_and_lincomb_follow_the_scalars_type(Jets, oracle, dt):
             got = (a * dx + b * dy).materialize().to_numpy()
             assert_bits_equal(got, julia_lincomb([a, b], [x, y]), f"a*x + b*y vs Julia's formula, b = {b!r}, {what}")
             assert_bits_equal(got, oracle.barr_lincomb([np.empty(n, dtype=dt)], [a, b], [[x], [y]])[0], f"a*x + b*y vs oracle, b = {b!r}, {what}")
+
+
+def test_typed_broadcast_programs_compile_for_every_mix():
+    """hiprtc cross-compiles without a GPU (jh_bcast_check_typed): wide and narrow, real and complex scalars next to complex and real
+    operands in one expression -- the generated code's mixed-precision operators must resolve for every combination."""
+    import ctypes as C
+    import os
+
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jets.jl_amd", "libjetship.so"))
+    lib.jh_last_error.restype = C.c_char_p
+    cases = [("s0*x0 + s1*x1", 0, 2, 0, 2, 1), ("s0*x0 + s1*x1", 0, 2, 0, 2, 3),
+             ("s0*x0 + s1*x1", 2, 2, 0, 2, 1), ("s0*x0 + s1*x1", 2, 2, 4, 2, 1), ("s0*x0 + s1*x1", 2, 2, 12, 2, 3),
+             ("(x0 / s0) - (s1 / x1) + conj(x0) * 2", 2, 2, 0, 2, 2), ("s0*x0 + x1", 2, 2, 2, 1, 1), ("s0*x0 + x1", 3, 2, 0, 1, 1),
+             ("(s0 - x0) * (s1 + x1) / s0", 0, 2, 0, 2, 2)]
+    for expr, dt, nvec, real_mask, nscal, wide_mask in cases:
+        assert lib.jh_bcast_check_typed(expr.encode(), dt, nvec, real_mask, nscal, wide_mask) == 0, (expr, dt, real_mask, wide_mask, lib.jh_last_error())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [np.float32, np.complex64, np.float64])
+def test_hip_compiled_broadcast_promotes_like_julia(Jets, dt):
+    """`x .= a .* u .+ b .* v` and friends through the hiprtc-compiled broadcast with Float64 scalars against 32-bit elements: Float64
+    arithmetic wherever such a scalar has entered, one rounding on the store -- the same bits as the typed lincomb and as Julia's formulas;
+    and an expression with a division and a difference against numpy's own promotion (strong numpy scalars, real dtypes)."""
+    J = Jets
+    n = 1000
+    spc = J.JetSpace(dt, n)
+    x, y = _data(dt, n, 11), _data(dt, n, 12)[::-1].copy()
+    dx, dy = J.from_numpy(x, spc), J.from_numpy(y, spc)
+    out = J.zeros(spc)
+    scal = scalars_for(dt)
+    for a in scal:
+        for b in scal[::2]:
+            J.broadcast_(out, "s0*x0 + s1*x1", [dx, dy], [a, b])
+            assert_bits_equal(out.to_numpy(), julia_lincomb([a, b], [x, y]), f"s0*x0 + s1*x1, a = {a!r} ({type(a).__name__}), b = {b!r}, {np.dtype(dt)}")
+    if np.dtype(dt).kind != "c":
+        xs, ys = np.abs(x[np.isfinite(x)][:512]) + dt(0.5), np.abs(y[np.isfinite(y)][:512]) + dt(0.25)
+        xs, ys = xs[:min(xs.size, ys.size)], ys[:min(xs.size, ys.size)]
+        spc2 = J.JetSpace(dt, xs.size)
+        d2 = J.zeros(spc2)
+        for a, b in ((np.float64(0.1), np.float32(0.3)), (0.1, np.float64(0.3)), (np.float64(1.7), np.float64(0.3)), (0.1, 0.3)):
+            J.broadcast_(d2, "(x0 - s0) / (x1 + s1) - s0 * x1", [J.from_numpy(xs, spc2), J.from_numpy(ys, spc2)], [a, b])
+            aa = a if isinstance(a, np.generic) else dt(a)      # a plain Python number is taken in the element type
+            bb = b if isinstance(b, np.generic) else dt(b)
+            with np.errstate(all="ignore"):
+                want = ((xs - aa) / (ys + bb) - aa * ys).astype(dt)
+            assert_bits_equal(d2.to_numpy(), want, f"(x0 - s0) / (x1 + s1) - s0 * x1, a = {a!r}, b = {b!r}, {np.dtype(dt)}")
