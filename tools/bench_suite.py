@@ -24,8 +24,9 @@ R = J.JetBSpace([blk] * nblocks)
 L = nblocks * n
 
 
-def timeit(fn, reps=5):
-    fn(); fn()
+def timeit(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
     e0 = J.Event().record()
     for _ in range(reps):
         fn()
@@ -50,7 +51,10 @@ flat_f = J.zeros(J.JetSpace(np.float32, L))
 host_blk = np.zeros((edge, edge, edge), dtype=np.float32, order="F")
 dev_blk = J.rand(blk, seed=5, stream=0)
 
-row("mul!(d, A, m)", (2 * L + n) * s, timeit(lambda: J.mul_(d, A, m)))
+# the forward chooses its grid walk over its first calls (each one a timed trial of one candidate): the first row is what
+# those calls average, the second the steady state every later call runs at
+row("mul!(d, A, m)  [first 7 calls: walk trials]", (2 * L + n) * s, timeit(lambda: J.mul_(d, A, m)))
+row("mul!(d, A, m)", (2 * L + n) * s, timeit(lambda: J.mul_(d, A, m), reps=10, warm=24))
 row("mul!(m, A', d)", (2 * L + n) * s, timeit(lambda: J.mul_(mt, A.H, d)))
 C = A.H @ A
 row("mul!(y, A' o A, m)  [fused]", (L + 2 * n) * s, timeit(lambda: J.mul_(mt, C, m)))
