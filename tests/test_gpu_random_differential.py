@@ -40,6 +40,17 @@ def _case(rng):
     return dt, nrow, ncol, len_r, len_c, kinds
 
 
+def _typed(a, which, dt):
+    """The same value as a scalar of another TYPE -- Julia's arithmetic follows it (tests/test_scalar_types.py): a plain Python number (taken in
+    the element type), numpy's 32-bit and 64-bit scalars (the latter promoted arithmetic against 32-bit elements: such an operator runs
+    the per-block loop), and for complex element types a Real scalar and a Complex one with a zero imaginary part."""
+    cplx = np.dtype(dt).kind == "c"
+    kinds = [lambda v: v, np.complex64 if cplx else np.float32, np.complex128 if cplx else np.float64, lambda v: v]
+    if cplx:
+        kinds += [lambda v: float(v.real), lambda v: np.float64(v.real), lambda v: complex(v.real, 0.0)]
+    return kinds[which % len(kinds)](a)
+
+
 def _build(Jets, oracle, dt, len_r, len_c, kinds, seed):
     dev_rows, ora_rows = [], []
     for i, row in enumerate(kinds):
@@ -53,6 +64,7 @@ def _build(Jets, oracle, dt, len_r, len_c, kinds, seed):
                 dr.append(Jets.JopIdentity(dom)); orow.append(oracle.Block("identity", nr))
             elif k == "scale":
                 a = (0.3 + 0.5 * i - 0.25 * j) - (0.125j * (j + 1) if np.dtype(dt).kind == "c" else 0)
+                a = _typed(a, i + 3 * j + seed, dt)
                 dr.append(Jets.JopLn(dom=dom, rng=dom, df=Jets.constdiag_df, df_adj=Jets.constdiag_df_adj, s={"a": a}))
                 orow.append(oracle.Block("scale", nr, scale=a))
             else:

@@ -60,8 +60,12 @@ for case in range(seed0, seed0 + ncases):
                 dev.append(J.JopIdentity(spc)); ora.append(oracle.Block("identity", n))
             elif k.startswith("scale"):
                 a = (0.375 + 0.125 * i) - (0.25j * (i + 1) if cplx else 0)
+                # scalars of every TYPE class (tests/test_scalar_types.py): numpy 64-bit ones are promoted arithmetic against 32-bit elements
+                tk = [lambda v: v, np.complex64 if cplx else np.float32, np.complex128 if cplx else np.float64] + ([lambda v: float(v.real), lambda v: complex(v.real, 0.0)] if cplx else [])
+                a = tk[(i + seed) % len(tk)](a)
                 op = J.JopLn(dom=spc, rng=spc, df=J.constdiag_df, df_adj=J.constdiag_df_adj, s={"a": a})
                 dev.append(op.H if k.endswith("adj") else op); ora.append(oracle.Block("scale", n, scale=a, adjoint=k.endswith("adj")))
+                ora[-1].scale_src = a
             else:
                 op = J.JopDiagonal(J.rand(spc, seed=seed, stream=i))
                 dev.append(op.H if k.endswith("adj") else op)
@@ -86,7 +90,8 @@ for case in range(seed0, seed0 + ncases):
     tmp = oracle.block_df(ops, [np.zeros(n, dt) for _ in range(nrow)], [hm])
     assert_bits_equal(y.to_numpy().ravel(order="F"), oracle.block_df_adj(ops, [np.zeros(n, dt)], tmp)[0], tag + " fused A'A")
     nat = _blk._tall_native(A)
-    if nat is None or n % per16 != 0:
+    wide = np.dtype(dt).itemsize // (2 if cplx else 1) == 4 and any(isinstance(getattr(b, "scale_src", None), (np.float64, np.complex128)) for b in ora)
+    if nat is None or n % per16 != 0 or wide:          # (a wide scalar: the per-block loop -- no ranged / fused entry points)
         stats["general"] += 1
         J.close(A)
         continue
