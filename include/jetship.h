@@ -314,6 +314,15 @@ int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *
 int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double alpha, double beta, double *normsq);
 int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double alpha, double beta, double in_scale,
                              double *normsq);
+/* The scalar-times-operator chain (src/Jets.jl:1159-1164) in one pass each way, for a REAL scalar of any Julia type:
+ *   jh_blockop_mul_scaled      d = a * (A m)          (`d .= a * tmp`, 1159)
+ *   jh_blockop_mul_adj_scaled  m = A' (conj(a) d)     (`tmp .= conj(a) * d`, 1160; conj(a) == a)
+ * a_flags = JH_SCALAR_WIDE for a Float64 scalar against 32-bit elements: the scalar stage is then the promoted product rounded once
+ * (Float32(a * Float64(x))), the bits of the unfused chain with jh_lincomb_typed; 0: a is taken in the element type, i.e.
+ * jh_blockop_mul_axpby(alpha = a, beta = 0) / jh_blockop_mul_adj_axpby(in_scale = a).  A Complex scalar (JH_SCALAR_COMPLEX) is
+ * JH_ERR_UNSUPPORTED: the unfused chain.  Same operators as the two calls above. */
+int jh_blockop_mul_scaled(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double a, int a_flags);
+int jh_blockop_mul_adj_scaled(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double a, int a_flags);
 /* One Golub-Kahan / LSQR step over vec(A) (src/Jets.jl:1138-1154) in ONE pass over the operator and the range vector:
  *   u <- alpha*(A v) + beta*u ;   w <- A' u (the new u) ;   *normsq = ||u||^2
  * i.e. jh_blockop_mul_axpby(op, u, v, alpha, beta, normsq) followed by jh_blockop_mul_adj(op, w, u), with u and w

@@ -148,6 +148,8 @@ SYMBOLS = {
     "jh_blocksum_mul_adj": (_int, [_int, _vpp, _dblp, _dblp, _vp, _vp]),
     "jh_blockop_mul_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
     "jh_blockop_mul_adj_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _dblp]),
+    "jh_blockop_mul_scaled": (_int, [_vp, _vp, _vp, C.c_double, _int]),
+    "jh_blockop_mul_adj_scaled": (_int, [_vp, _vp, _vp, C.c_double, _int]),
     "jh_blockop_bidiag_step": (_int, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
     "jh_blockop_bidiag_step_range": (_int, [_vp, _vp, _vp, _vp, C.c_double, C.c_double, _i64, _i64, _dblp]),
     "jh_normsq_reset": (_int, []),

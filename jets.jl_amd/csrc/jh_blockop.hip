@@ -419,12 +419,14 @@ template <typename S, int NS, typename V> __device__ inline double vnorm2(V r)
 }
 
 // forward: d_i = alpha * (a_i .* m) + beta * d_i ; sequential row sweep (tile index fastest)
-template <typename S, int E, int NS, int U, int BLK, bool MIXED = false>
+// WIDE (S = float, beta == 0): the scalar is Julia's Float64 (JH_SCALAR_WIDE) -- d_i = Float32(wscal * Float64(a_i .* m)), the promoted
+// product of `d .= a * tmp` (src/Jets.jl:1159) rounded once on the store
+template <typename S, int E, int NS, int U, int BLK, bool MIXED = false, bool WIDE = false>
 __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block *__restrict__ blocks, int64_t nrow, int rows_per_wg,
                                                               const S *__restrict__ a_base, int64_t a_stride,
                                                               const S *__restrict__ m, S *__restrict__ d, int64_t n_scalars,
                                                               unsigned ntiles, unsigned ngroups, int walk, S alpha, S beta,
-                                                              double *__restrict__ partials)
+                                                              double *__restrict__ partials, double wscal = 0.0)
 {
     typedef typename vec_of<S, NS>::type V;
     // walk 0: tile index fastest (one block row at a time); walk 1: row group fastest (all rows concurrently)
@@ -467,7 +469,13 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block
             V t;
             if constexpr (MIXED) t = (blk.kind != JH_OP_ZERO) ? apply_block_loaded<S, E, NS, V>(blk, mv[k], av[k], false, false) : (V)(S)0;   // a zero row of the zeros() temporary
             else t = vmul<S, E, NS, V>(av[k], mv[k], false);      // mul!(tmp, A_i, m)
-            V s1 = (V)alpha * t;
+            V s1;
+            if constexpr (WIDE) {
+#pragma unroll
+                for (int e = 0; e < NS; e++) s1[e] = (S)(wscal * (double)t[e]);
+            } else {
+                s1 = (V)alpha * t;
+            }
             V r = s1;
             if (use_old) { V s2 = (V)beta * dv[k]; r = s1 + s2; }   // d_i .= alpha*tmp .+ beta*d_i
             if (ok[k]) {
@@ -479,14 +487,25 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block
     wg_sum_store<BLK>(nrm, partials + blockIdx.x);
 }
 
-// adjoint: out = alpha * (sum_i conj(a_i) .* d_i, rows in order) + beta * out
-template <typename S, int E, int NS, int U, int DEPTH, int BLK>
+// adjoint: out = alpha * (sum_i conj(a_i) .* (gamma * d_i), rows in order) + beta * out
+// WIDE (S = float): gamma is Julia's Float64 -- every d_i is scaled as Float32(wscal * Float64(d_i)), the `m .= conj(a) * d` stage (1160)
+template <typename S, int E, int NS, int U, int DEPTH, int BLK, bool WIDE = false>
 __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                               const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ out,
                                                               const S *__restrict__ in, int64_t n_scalars, int direct, S alpha, S beta,
-                                                              S gamma, double *__restrict__ partials)
+                                                              S gamma, double *__restrict__ partials, double wscal = 0.0)
 {
     typedef typename vec_of<S, NS>::type V;
+    auto scaled = [&](V x) -> V {                          // gamma * d_i, rounded to the element type
+        if constexpr (WIDE) {
+            V r;
+#pragma unroll
+            for (int e = 0; e < NS; e++) r[e] = (S)(wscal * (double)x[e]);
+            return r;
+        } else {
+            return (V)gamma * x;                           // gamma = 1: exact
+        }
+    };
     const int64_t s0 = ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
     bool ok[U];
     int64_t sk[U];
@@ -512,14 +531,14 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block
 #pragma unroll
         for (int j = 0; j < DEPTH; j++)
 #pragma unroll
-            for (int k = 0; k < U; k++) acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], (V)gamma * dv[j][k], true);   // gamma = 1: exact
+            for (int k = 0; k < U; k++) acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], scaled(dv[j][k]), true);
     }
     for (; i < nrow; i++) {
         const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
 #pragma unroll
         for (int k = 0; k < U; k++) {
             V p = vmul<S, E, NS, V>(ld<true>(reinterpret_cast<const V *>(a + sk[k])),
-                                    (V)gamma * ld<true>(reinterpret_cast<const V *>(in + i * n_scalars + sk[k])), true);
+                                    scaled(ld<true>(reinterpret_cast<const V *>(in + i * n_scalars + sk[k]))), true);
             acc[k] = direct ? p : acc[k] + p;
         }
     }
@@ -2600,7 +2619,7 @@ int finish_normsq(int64_t nparts, double *normsq, bool defer = false, int privat
 }
 
 template <typename S, int E, int NS>
-int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_scalars, double alpha, double beta, double *normsq)
+int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_scalars, double alpha, double beta, double *normsq, bool wide = false)
 {
     jh_context &c = jh_ctx();
     const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
@@ -2643,17 +2662,24 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
         JH_CHECK_HIP(hipEventCreate(&e1));
         JH_CHECK_HIP(hipEventRecord(e0, c.stream));
     }
-#define JH_LAUNCH(BLK, UU)                                                                                             \
-    hipLaunchKernelGGL((k_tall_diag_fwd_update<S, E, NS, UU, BLK>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream,  \
+#define JH_LAUNCH_W(BLK, UU, MX, WD)                                                                                   \
+    hipLaunchKernelGGL((k_tall_diag_fwd_update<S, E, NS, UU, BLK, MX, WD>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, \
                        op->dev_blocks, op->nrow, G, a_base, a_stride, (const S *)m, (S *)d, n_scalars, (unsigned)gx,   \
-                       (unsigned)gy, walk, (S)alpha, (S)beta, c.part_dev)
-    if (mixed)
-        hipLaunchKernelGGL((k_tall_diag_fwd_update<S, E, NS, 4, 256, true>), dim3((unsigned)(gx * gy)), dim3(256), 0, c.stream, op->dev_blocks,
-                           op->nrow, G, a_base, a_stride, (const S *)m, (S *)d, n_scalars, (unsigned)gx, (unsigned)gy, walk, (S)alpha, (S)beta,
-                           c.part_dev);
-    else if (U == 4) JH_LAUNCH(256, 4);
-    else JH_LAUNCH(256, 1);
-#undef JH_LAUNCH
+                       (unsigned)gy, walk, (S)alpha, (S)beta, c.part_dev, alpha)
+    // (a wide scalar: Float32 elements only, beta == 0 -- checked by the caller; one instantiation per tiling)
+    if constexpr (sizeof(S) == 4) {
+        if (wide) {
+            if (mixed) JH_LAUNCH_W(256, 4, true, true);
+            else if (U == 4) JH_LAUNCH_W(256, 4, false, true);
+            else JH_LAUNCH_W(256, 1, false, true);
+        }
+    }
+    if (!(sizeof(S) == 4 && wide)) {
+        if (mixed) JH_LAUNCH_W(256, 4, true, false);
+        else if (U == 4) JH_LAUNCH_W(256, 4, false, false);
+        else JH_LAUNCH_W(256, 1, false, false);
+    }
+#undef JH_LAUNCH_W
     JH_CHECK_HIP(hipGetLastError());
     if (trial >= 0) JH_CHECK_HIP(hipEventRecord(e1, c.stream));
     const int st = finish_normsq(gx * gy, normsq);          // synchronises (normsq != NULL on a trial)
@@ -2672,7 +2698,7 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
 
 template <typename S, int E, int NS>
 int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n_scalars, double alpha, double beta, double gamma,
-                      double *normsq)
+                      double *normsq, bool wide = false)
 {
     jh_context &c = jh_ctx();
     const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
@@ -2682,7 +2708,7 @@ int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n
     {   // many rows of small blocks: the row sum through the split walk of the plain adjoint, then out = (alpha*gamma)*t + beta*out
         // with ||out||^2 in a small epilogue (tolerance parity, like every split sum)
         void *tmp = nullptr;
-        JH_TRY((split_adjoint_tmp<S, NS>(op, n_scalars, &tmp)));
+        if (!wide) JH_TRY((split_adjoint_tmp<S, NS>(op, n_scalars, &tmp)));   // (a wide in_scale is applied per d_i before the sum: the ordered walk)
         if (tmp) {
             JH_TRY((launch_tall_adj<S, E, NS, 0>(op, tmp, in, n_scalars)));
             int64_t g = (n_scalars + 255) / 256;
@@ -2701,15 +2727,25 @@ int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n
     if (nvec >= ((int64_t)1 << 22)) wg = 512;
     const int64_t gx = (nvec + (int64_t)wg * U - 1) / ((int64_t)wg * U);
     JH_TRY(jh_ensure_partials(gx));
-#define JH_LAUNCH(BLK, UU, DD)                                                                                         \
-    hipLaunchKernelGGL((k_tall_diag_adj_update<S, E, NS, UU, DD, BLK>), dim3((unsigned)gx), dim3(BLK), 0, c.stream,     \
+#define JH_LAUNCH_W(BLK, UU, DD, WD)                                                                                   \
+    hipLaunchKernelGGL((k_tall_diag_adj_update<S, E, NS, UU, DD, BLK, WD>), dim3((unsigned)gx), dim3(BLK), 0, c.stream, \
                        op->dev_blocks, op->nrow, a_base, a_stride, (S *)out, (const S *)in, n_scalars, direct, (S)alpha, \
-                       (S)beta, (S)gamma, c.part_dev)
-    if (wg == 512) JH_LAUNCH(512, 4, 4);
-    else if (U == 4) JH_LAUNCH(256, 4, 2);
-    else if (U == 2) JH_LAUNCH(256, 2, 4);
-    else JH_LAUNCH(256, 1, 4);
-#undef JH_LAUNCH
+                       (S)beta, (S)gamma, c.part_dev, gamma)
+    if constexpr (sizeof(S) == 4) {
+        if (wide) {
+            if (wg == 512) JH_LAUNCH_W(512, 4, 4, true);
+            else if (U == 4) JH_LAUNCH_W(256, 4, 2, true);
+            else if (U == 2) JH_LAUNCH_W(256, 2, 4, true);
+            else JH_LAUNCH_W(256, 1, 4, true);
+        }
+    }
+    if (!(sizeof(S) == 4 && wide)) {
+        if (wg == 512) JH_LAUNCH_W(512, 4, 4, false);
+        else if (U == 4) JH_LAUNCH_W(256, 4, 2, false);
+        else if (U == 2) JH_LAUNCH_W(256, 2, 4, false);
+        else JH_LAUNCH_W(256, 1, 4, false);
+    }
+#undef JH_LAUNCH_W
     JH_CHECK_HIP(hipGetLastError());
     return finish_normsq(gx, normsq);
 }
@@ -4041,6 +4077,47 @@ int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d,
     case JH_C64: return launch_adj_update<double, 2, 2>(op, m->data, d->data, 2 * n, alpha, beta, in_scale, normsq);
     }
     return jh_fail(JH_ERR_INVALID, "jh_blockop_mul_adj_axpby: unknown dtype %d", op->dtype);
+}
+
+// (a * A) m and (a * A)' d = A'(conj(a) d) of the scalar-times-operator chain (src/Jets.jl:1159-1164) in one pass each, for a REAL scalar of
+// any Julia type: jh_blockop_mul_axpby(alpha = a, beta = 0) / jh_blockop_mul_adj_axpby(in_scale = a) when a is taken in the element type,
+// the WIDE instantiations of the same kernels (Float64 product, one rounding) when a is Float64-based and the elements are 32-bit
+int jh_blockop_mul_scaled(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double a, int a_flags)
+{
+    JH_REQUIRE((a_flags & ~(JH_SCALAR_COMPLEX | JH_SCALAR_WIDE)) == 0, "jh_blockop_mul_scaled: unknown flags %d", a_flags);
+    if (a_flags & JH_SCALAR_COMPLEX) return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_scaled: a Complex scalar takes the unfused chain (jh_blockop_mul, jh_lincomb_typed)");
+    JH_TRY(jh_enter(op, d, m));
+    JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_scaled"));
+    if (!jh_blockop_tall_fast(op, d->data, m->data))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_scaled: needs a tall operator of elementwise rows with equal, 16-byte aligned blocks");
+    const int64_t n = op->row_len[0];
+    const bool wide = (a_flags & JH_SCALAR_WIDE) != 0;
+    switch (op->dtype) {
+    case JH_F32: return launch_fwd_update<float, 1, 4>(op, d->data, m->data, n, a, 0.0, nullptr, wide);
+    case JH_F64: return launch_fwd_update<double, 1, 2>(op, d->data, m->data, n, a, 0.0, nullptr);
+    case JH_C32: return launch_fwd_update<float, 2, 4>(op, d->data, m->data, 2 * n, a, 0.0, nullptr, wide);
+    case JH_C64: return launch_fwd_update<double, 2, 2>(op, d->data, m->data, 2 * n, a, 0.0, nullptr);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blockop_mul_scaled: unknown dtype %d", op->dtype);
+}
+
+int jh_blockop_mul_adj_scaled(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double a, int a_flags)
+{
+    JH_REQUIRE((a_flags & ~(JH_SCALAR_COMPLEX | JH_SCALAR_WIDE)) == 0, "jh_blockop_mul_adj_scaled: unknown flags %d", a_flags);
+    if (a_flags & JH_SCALAR_COMPLEX) return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_scaled: a Complex scalar takes the unfused chain (jh_lincomb_typed, jh_blockop_mul_adj)");
+    JH_TRY(jh_enter(op, m, d));
+    JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_adj_scaled"));
+    if (!tall_fast_ok(op, d->data, m->data))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_scaled: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
+    const int64_t n = op->row_len[0];
+    const bool wide = (a_flags & JH_SCALAR_WIDE) != 0;
+    switch (op->dtype) {
+    case JH_F32: return launch_adj_update<float, 1, 4>(op, m->data, d->data, n, 1.0, 0.0, a, nullptr, wide);
+    case JH_F64: return launch_adj_update<double, 1, 2>(op, m->data, d->data, n, 1.0, 0.0, a, nullptr);
+    case JH_C32: return launch_adj_update<float, 2, 4>(op, m->data, d->data, 2 * n, 1.0, 0.0, a, nullptr, wide);
+    case JH_C64: return launch_adj_update<double, 2, 2>(op, m->data, d->data, 2 * n, 1.0, 0.0, a, nullptr);
+    }
+    return jh_fail(JH_ERR_INVALID, "jh_blockop_mul_adj_scaled: unknown dtype %d", op->dtype);
 }
 
 }  // extern "C"

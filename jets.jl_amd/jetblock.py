@@ -594,19 +594,24 @@ def _tall_native(op):
     return _pointed_native(nat, j.s["ops"], j.mo)
 
 
-def _real_scale(op):
-    """The real scalar a of an `a*` operator (src/Jets.jl:1159-1162), else None."""
+def _real_scale(op, allow_wide=False):
+    """The real scalar a of an `a*` operator (src/Jets.jl:1159-1162) when the fused kernels reproduce Julia's arithmetic for it, else None.
+    They multiply by T(a), part by part: right for a Real scalar of the elements' precision.  A Complex scalar (full product, even with
+    a zero imaginary part) takes the chain; a Float64 one against 32-bit elements (promoted arithmetic) is fused only where the caller
+    can say so (allow_wide: the result is then the pair (a, JH_SCALAR_* flags) for jh_blockop_mul[_adj]_scaled)."""
     if isinstance(op, JopAdjoint):
         op = op.op                                    # conj(a) == a for a real a
     if isinstance(op, JopLn) and op.jet.df is _j.constdiag_df and op.jet.df_adj is _j.constdiag_df_adj:
         a = op.jet.s["a"]
-        # the fused kernels multiply by T(a), part by part: right for a Real scalar of the elements' precision.  A Complex scalar (full
-        # product, even with a zero imaginary part) and a Float64 one against 32-bit elements (promoted arithmetic) take the chain.
         fl = scalar_flags(a)
         T = np.dtype(domain(op).eltype())
         if T.itemsize // (2 if T.kind == "c" else 1) == 8:
             fl &= ~SCALAR_WIDE                            # nothing is wider than 64-bit elements
-        return None if fl or complex(a).imag != 0.0 else float(complex(a).real)
+        if (fl & ~SCALAR_WIDE) or complex(a).imag != 0.0:
+            return None
+        if allow_wide:
+            return float(complex(a).real), fl
+        return None if fl else float(complex(a).real)
     return None
 
 
@@ -614,9 +619,10 @@ def try_fused_chain(out, x, ops: Sequence[Jop]):
     """Two-stage chains of JetComposite_df / df' (src/Jets.jl:530-540) that one kernel computes with the unfused
     chain's exact rounding sequence; returns None when the chain does not qualify:
       (A', A)   normal operator, coefficients read once            -> jh_blockop_normal_mul
-      (a, A)    scalar * operator, forward                         -> jh_blockop_mul_axpby(alpha = a, beta = 0)
-      (A', a')  scalar * operator, adjoint: A'(conj(a) d)          -> jh_blockop_mul_adj_axpby(in_scale = a)
-    for a tall all-diagonal device-native block operator A and a real scalar a."""
+      (a, A)    scalar * operator, forward                         -> jh_blockop_mul_scaled
+      (A', a')  scalar * operator, adjoint: A'(conj(a) d)          -> jh_blockop_mul_adj_scaled
+    for a tall all-diagonal device-native block operator A and a Real scalar a (of the elements' precision or wider: the scalar's
+    type goes along, so that the fused pass has the bits of the chain)."""
     if len(ops) != 2:
         return None
     left, right = ops
@@ -626,18 +632,18 @@ def try_fused_chain(out, x, ops: Sequence[Jop]):
             if nat is not None and right.jet.s["ops"].shape[0] >= 2:
                 return nat.normal_mul(out, x)
             return None
-        a = _real_scale(left)
+        a = _real_scale(left, allow_wide=True)
         if a is not None and not isinstance(right, JopAdjoint):
             nat = _tall_native(right)
             if nat is not None:
-                check(lib.jh_blockop_mul_axpby(nat.handle, out.handle, x.handle, a, 0.0, None))
+                check(lib.jh_blockop_mul_scaled(nat.handle, out.handle, x.handle, a[0], a[1]))
                 return out
             return None
-        a = _real_scale(right)
+        a = _real_scale(right, allow_wide=True)
         if a is not None and isinstance(left, JopAdjoint):
             nat = _tall_native(left.op)
             if nat is not None:
-                check(lib.jh_blockop_mul_adj_axpby(nat.handle, out.handle, x.handle, 1.0, 0.0, a, None))
+                check(lib.jh_blockop_mul_adj_scaled(nat.handle, out.handle, x.handle, a[0], a[1]))
                 return out
     except JetsHipError as e:  # JH_ERR_UNSUPPORTED: not eligible for the fused kernel (mixed kinds, ragged blocks)
         if e.status == 4:

@@ -567,6 +567,17 @@ function mul_adj_axpby!(v::HipArray{T}, A::JopLn, u::BlockArray{T,<:HipArray{T}}
     sqrt(nrm2[])
 end
 
+# d <- a * (A m)   /   m <- A' (conj(a) d) for a Real scalar of any type: the scalar-times-operator chain (src/Jets.jl:1159-1164) in one pass each
+# way with the scalar's TYPE (a Float64 against Float32 elements: promoted product, one rounding -- the bits of `d .= a * tmp`)
+function mul_scaled!(d::BlockArray{T,<:HipArray{T}}, a::Real, A::JopLn, m::HipArray{T}) where {T}
+    check(ccall((:jh_blockop_mul_scaled, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cint), tall_native(A, T), handle(d), handle(m), a, _scalar_flags(a)))
+    d
+end
+function mul_adj_scaled!(m::HipArray{T}, a::Real, A::JopLn, d::BlockArray{T,<:HipArray{T}}) where {T}
+    check(ccall((:jh_blockop_mul_adj_scaled, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cint), tall_native(A, T), handle(m), handle(d), a, _scalar_flags(a)))
+    m
+end
+
 # one whole Golub-Kahan step in one pass: u <- alpha*(A v) + beta*u ; w <- A'u ; returns ||u||   (3/5 of the bytes of the two halves)
 function bidiag_step!(u::BlockArray{T,<:HipArray{T}}, w::HipArray{T}, A::JopLn, v::HipArray{T}, alpha::Real, beta::Real) where {T}
     nrm2 = Ref{Cdouble}()

@@ -116,6 +116,11 @@ def test_hip_scale_blocks_and_lincomb_follow_the_scalars_type(Jets, oracle, dt):
             inner = oracle.block_df([[go], [go]], [zero.copy(), zero.copy()], [x])
         want3 = np.concatenate([_store(*julia_scalar_term(a, blk)[:2], dt) for blk in inner])
         assert_bits_equal(d3, want3, f"(a * T) m vs Julia's formula, {what}")
+        # (a * T)' d = T' (conj(a) d): the scalar stage rounds into a range-sized temporary (`m .= conj(a) * d`, 1160), then the ordered row sum
+        ac = a.conjugate() if isinstance(a, (complex, np.complexfloating)) else a
+        scaled = [_store(*julia_scalar_term(ac, blk)[:2], dt) for blk in (x, y)]
+        m3 = J.mul(aT.H, J.from_numpy(dd, J.range(aT))).to_numpy()
+        assert_bits_equal(m3, oracle.block_df_adj([[go], [go]], [zero.copy()], scaled)[0], f"(a * T)' d vs Julia's formula + the oracle's row sum, {what}")
         J.close(T)
         for b in scalars_for(dt)[::2]:
             got = (a * dx + b * dy).materialize().to_numpy()
@@ -168,3 +173,32 @@ def test_hip_compiled_broadcast_promotes_like_julia(Jets, dt):
             with np.errstate(all="ignore"):
                 want = ((xs - aa) / (ys + bb) - aa * ys).astype(dt)
             assert_bits_equal(d2.to_numpy(), want, f"(x0 - s0) / (x1 + s1) - s0 * x1, a = {a!r}, b = {b!r}, {np.dtype(dt)}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+@pytest.mark.parametrize("n", [1 << 20, 1 << 22, 1 << 24])
+def test_hip_wide_scalar_times_tall_operator_fused_at_every_launch_shape(Jets, oracle, dt, n):
+    """`(a * A) m` and `(a * A)' d` for a Float64 scalar against 32-bit elements on the fused kernels' WIDE instantiations
+    (jh_blockop_mul_scaled / _adj_scaled), at block sizes that select each of their launch shapes: the bits of Julia's promoted product
+    rounded once, and NOT those of Float32(a) * x."""
+    J = Jets
+    if np.dtype(dt).itemsize * n * 3 > (1 << 29):
+        pytest.skip("more than 512 MiB of coefficients for a shape check")
+    spc = J.JetSpace(dt, n)
+    g = [oracle.rng_u01(dt, 21, i, 0, n) for i in range(3)]
+    x = oracle.rng_u01(dt, 22, 0, 0, n)
+    T = J.blockop([[J.JopDiagonal(J.from_numpy(gi, spc))] for gi in g])
+    a = np.float64(0.1)
+    aT = a * T
+    ops = [[oracle.Block("diag", n, coeff=gi)] for gi in g]
+    inner = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(3)], [x])
+    want = np.concatenate([_store(*julia_scalar_term(a, blk)[:2], dt) for blk in inner])
+    got = J.mul(aT, J.from_numpy(x, spc)).to_numpy()
+    assert_bits_equal(got, want, f"(a * T) m, n = {n}, {np.dtype(dt)}")
+    narrow = np.concatenate([_store(*julia_scalar_term(0.1, blk)[:2], dt) for blk in inner])
+    assert (got.view(np.uint32) != narrow.view(np.uint32)).mean() > 0.1, "the wide product differs from Float32(0.1) * x in many last bits"
+    scaled = [_store(*julia_scalar_term(a, blk)[:2], dt) for blk in inner]
+    m = J.mul(aT.H, J.from_numpy(np.concatenate(inner), J.range(aT))).to_numpy()
+    assert_bits_equal(m, oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], scaled)[0], f"(a * T)' d, n = {n}, {np.dtype(dt)}")
+    J.close(T)
