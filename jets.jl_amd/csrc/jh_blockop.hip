@@ -3862,7 +3862,10 @@ static int sum_adj_launch(const SumArgs &a, const jh_blockop *op0, void *m, cons
     const int U = a.k > 4 ? 1 : 2;
     const int64_t nvec = n_scalars / NS;
     const int64_t gx = (nvec + (int64_t)BLK * U - 1) / ((int64_t)BLK * U);
-    if (a.k > 4)
+    if (a.k > 8)                                                            // sixteen accumulators, one row in flight (knob sum_adj_group = 16)
+        hipLaunchKernelGGL((k_tall_sum_adj<S, E, NS, 1, 1, BLK, 16>), dim3((unsigned)gx), dim3(BLK), 0, c.stream, a, op0->nrow, (S *)m,
+                           (const S *)d, n_scalars, accumulate);
+    else if (a.k > 4)
         hipLaunchKernelGGL((k_tall_sum_adj<S, E, NS, 1, DEPTH, BLK, 8>), dim3((unsigned)gx), dim3(BLK), 0, c.stream, a, op0->nrow, (S *)m,
                            (const S *)d, n_scalars, accumulate);
     else
@@ -3923,7 +3926,7 @@ int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *
                    "jh_blocksum_mul_adj: term %d has a different shape or element type", t);
     }
     const int64_t n = ops[0]->row_len[0];
-    const int group = jh_ctx().sum_group == 4 ? 4 : JH_SUM_ADJ_MAX;       // (each term keeps its own accumulator in the adjoint: eight per launch)
+    const int group = jh_ctx().sum_group == 4 ? 4 : (jh_ctx().sum_adj_group == 16 ? JH_SUM_MAX : JH_SUM_ADJ_MAX);   // (each term keeps its own accumulator in the adjoint: eight per launch; knob sum_adj_group = 16: sixteen)
     void *tmp = nullptr;
     switch (ops[0]->dtype) {
 #define JH_SUM_ADJ(S, E, NS, NSCAL)                                                                         \

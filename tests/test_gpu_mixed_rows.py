@@ -116,7 +116,7 @@ def test_lsqr_on_data_rows_plus_regularisation_and_a_muted_row(Jets, oracle):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.complex128])
-@pytest.mark.parametrize("nterms", [2, 4, 5, 9, 13])
+@pytest.mark.parametrize("nterms", [2, 4, 5, 9, 13, 17])
 def test_long_jetsum_keeps_the_unfused_rounding_sequence(Jets, oracle, dt, nterms):
     """JetSum of MORE than four tall diagonal operators (src/Jets.jl:628-655): the fused kernels take the terms four at a time,
     later launches continuing the left-to-right sum from what the output holds -- bit-identical to the unfused chain

@@ -43,7 +43,7 @@ if os.environ.get("SUM_FWD_GROUP"):
 if os.environ.get("SUM_FWD_UNROLL"):
     J.tune(fwd_unroll=int(os.environ["SUM_FWD_UNROLL"]))
 for group in (16, 8, 16, 8):                                        # forward terms per launch: 16 (round 4) against round 3's 8, alternating in one process
-    J.tune(sum_group=group)
+    J.tune(sum_group=group, sum_adj_group=group)                    # (the adjoint: 16 or 8 accumulators per launch)
     tf = timed(lambda: J.mul_(d, S, m))
     ta = timed(lambda: J.mul_(mt, S.H, d))
     print(f"JetSum of {K} tall {nrow} x {edge}^3 operators, {group} terms per launch: forward {tf:7.3f} ms {((K + 1) * nrow + 1) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {((K + 1) * nrow + 1) * b / ta / 1e6:7.1f} GB/s")
