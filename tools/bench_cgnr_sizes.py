@@ -2,7 +2,7 @@
 """CG on the normal equations through the fused A'A at several operator sizes: ms per iteration against the time of the fused A'A
 alone (what an iteration must spend) -- the rest is the domain-side vector work and the host's scalar round trips.
 
-    python tools/bench_cgnr_sizes.py > profiles/bench_cgnr_sizes_r03.txt
+    python tools/bench_cgnr_sizes.py [CG_DEV [LSQR_GRAPH]] > profiles/bench_cgnr_sizes_r04.txt     (knobs cg_dev / lsqr_graph; 2 = the device-resident loops at every size)
 """
 import os
 import sys
