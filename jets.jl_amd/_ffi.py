@@ -44,6 +44,7 @@ class BlockDesc(C.Structure):
     ]
 
 
+ABI_VERSION = 2                      # JETSHIP_ABI_VERSION of include/jetship.h
 SCALAR_COMPLEX, SCALAR_WIDE = 1, 2   # JH_SCALAR_* of include/jetship.h
 
 
@@ -194,6 +195,8 @@ def _load():
         fn = getattr(handle, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if handle.jh_abi_version() != ABI_VERSION:          # struct layouts (jh_block_desc) are part of the version: never mix
+        raise ImportError(f"{LIB_PATH} speaks ABI version {handle.jh_abi_version()}, this binding {ABI_VERSION}: rebuild the library (make -C jets.jl_amd/csrc)")
     return handle
 
 
