@@ -38,6 +38,7 @@ int main(void)
 {
     const int64_t n = (int64_t)EDGE * EDGE * EDGE;      /* one block: EDGE^3 Float32, contiguous, column-major */
     int ndev = 0;
+    REQUIRE(jh_abi_version() == JETSHIP_ABI_VERSION, "the library and the header it was compiled against speak the same ABI version");
     CK(jh_device_count(&ndev));
     REQUIRE(ndev >= 1, "no HIP device");
     CK(jh_init(0));
