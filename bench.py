@@ -93,7 +93,7 @@ def parse_args():
     ap.add_argument("--placement", choices=("probe", "none"), default="probe",
                     help="probe: the coefficient slab and the range vector come from Jets.stream_pair -- candidate allocations are measured (forward + "
                          "adjoint of the operator itself, outside every timed region) and the best ordered pair is kept; none: plain allocation order")
-    ap.add_argument("--fwd-walk", type=int, default=-1, help="pin the tall forward's grid walk to candidate K (0..7) instead of measuring it lazily (profiling one instantiation)")
+    ap.add_argument("--fwd-walk", type=int, default=-1, help="pin the tall forward's grid walk to candidate K (0..9; 8, 9: column bands, tried by operators of fewer than 1024 rows) instead of measuring it lazily (profiling one instantiation)")
     ap.add_argument("--placement-candidates", type=int, default=3, help="allocations measured by --placement probe (2: both orders of two slabs)")
     ap.add_argument("--mode", choices=("auto", "ranks", "team"), default=os.environ.get("BENCH_MODE", "auto"),
                     help="N > 1: one worker process per GPU (ranks), ONE worker driving all GPUs (team), or ranks with a team fallback (auto)")

@@ -470,7 +470,7 @@ int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, 
  * solvers with a one-rank communicator too; validation), "adj_rows_per_launch" (tall adjoint / fused normal: block rows per launch, 0 all
  * rows in one; same bits), "dense_mixed" (operators mixing big DENSE children with other kinds as one batched launch + one launch of the
  * general kernels: 1 yes, 0 the per-block loop; counter "last_launches");
- * jh_tune_get also reads the counters "last_fwd_walk" (grid walk of the latest tall forward: 0 sequential, 1 all rows),
+ * jh_tune_get also reads the counters "last_fwd_walk" (grid walk of the latest tall forward: 0 sequential, 1 all rows, 2 column bands),
  * "last_fwd_rows_per_wg", "last_adj_launches", "last_adj_parts", "last_step_chain" (row chunks of the latest one-pass step, 0: the plain walk), "graph_replays", "last_lsqr_graph" / "last_cg_graph" (graph replays of the latest
  * jh_lsqr_solve / jh_cgls_solve or jh_cgnr_solve; 0: the host loop ran) and "last_dense_fused" (1: the latest dense adjoint / wide forward took the
  * fused launch). */
@@ -479,14 +479,14 @@ int jh_tune_get(const char *name, int64_t *value);
 /* Per-operator choices made by measurement.  "fwd_walk": the grid walk of the tall forward of an operator far larger than the
  * caches (which one is fastest depends on where the slabs landed physically).  It is chosen LAZILY: while it is -1 each
  * jh_blockop_mul runs the next candidate between two events -- no extra launches, no host synchronisation, jh_blockop_mul
- * returns after enqueue -- and after 16 calls the fastest is kept ("fwd_trials" counts the timed calls so far).  A host that
+ * returns after enqueue -- and after 16 calls (20 for operators of fewer than 1024 rows, which also try two column-band walks: candidates 8, 9) the fastest is kept ("fwd_trials" counts the timed calls so far).  A host that
  * wants the steady state at once (or the same choice in every process) reads it from one operator and sets it on another;
  * setting -1 measures again.  "upd_walk" is the same for jh_blockop_mul_axpby (0 / 1, chosen over its first two calls), "step_mode"
  * for jh_blockop_bidiag_step: 0 plain walk, 1 the same with XCD-contiguous tiles, 2 chained row chunks (one batch of 8 rows per
  * workgroup, the ordered sum handed from chunk to chunk: same bits), chosen over its first seven eligible calls ("step_trials" counts
  * them).  Read-only: "fwd_walk_inherited" (1: the forward walk came from an earlier operator of the same device, eltype, row count and
  * block size -- knob "walk_memory"), "fwd_switches" (times the periodic re-check rotated another walk in), "fwd_playoff" (the two walks of
- * the final play-off as 8 a + b, -1: none yet). */
+ * the final play-off as 16 a + b, -1: none yet). */
 int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value);
 int jh_blockop_tune_set(jh_blockop *op, const char *name, int64_t value);
 

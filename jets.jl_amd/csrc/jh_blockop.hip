@@ -104,15 +104,29 @@ template <typename S, int E, int NS, int U, bool NT, int BLK, bool MIXED = false
 __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__restrict__ blocks, int64_t nrow, int rows_per_wg,
                                                        const S *__restrict__ a_base, int64_t a_stride,
                                                        const S *__restrict__ m, S *__restrict__ d, int64_t n_scalars,
-                                                       unsigned ntiles, unsigned ngroups, unsigned band)
+                                                       unsigned ntiles, unsigned ngroups, unsigned band, unsigned ctiles)
 {
     typedef typename vec_of<S, NS>::type V;
-    const unsigned per_band = ntiles * band;                  // workgroups in a full band
-    const unsigned b = blockIdx.x / per_band;
-    const unsigned r = blockIdx.x - b * per_band;
-    const unsigned width = (b * band + band <= ngroups) ? band : ngroups - b * band;   // last band may be narrower
-    const unsigned tile = r / width;
-    const unsigned grp = b * band + r % width;
+    unsigned tile, grp;
+    if (ctiles) {
+        // COLUMN bands (late round 4): `ctiles` consecutive tiles of one row group, then the same tiles of the next group, ... then the next
+        // band of tiles.  Inside a group's share of a band the workgroups stream linearly like a copy (32-64 tiles = 128-256 KiB), the band
+        // of m is reused by every row from L2: at 128-512 rows +3 ... +10 % over the row-concurrent walk, whose consecutive workgroups are a
+        // whole block apart (tools/micro/fwd_small_rows.hip, profiles/exp_r04_fwd_small_rows.txt); at 1024 rows the row-concurrent walk wins
+        const unsigned per_c = ctiles * ngroups;              // workgroups in a full column band
+        const unsigned cb = blockIdx.x / per_c;
+        const unsigned r = blockIdx.x - cb * per_c;
+        const unsigned cw = (cb * ctiles + ctiles <= ntiles) ? ctiles : ntiles - cb * ctiles;   // last band may be narrower
+        grp = r / cw;
+        tile = cb * ctiles + r % cw;
+    } else {
+        const unsigned per_band = ntiles * band;              // workgroups in a full band
+        const unsigned b = blockIdx.x / per_band;
+        const unsigned r = blockIdx.x - b * per_band;
+        const unsigned width = (b * band + band <= ngroups) ? band : ngroups - b * band;   // last band may be narrower
+        tile = r / width;
+        grp = b * band + r % width;
+    }
     const int64_t s0 = ((int64_t)tile * U * BLK + threadIdx.x) * NS;
     const int64_t i0 = (int64_t)grp * rows_per_wg;
     const int64_t i1 = (i0 + rows_per_wg < nrow) ? i0 + rows_per_wg : nrow;
@@ -1809,7 +1823,7 @@ __global__ __launch_bounds__(256) void k_fold_general(const S *__restrict__ slab
 //   adjoint  wants FEW, FAT workgroups: 4 vectors per thread as long as >= 256 workgroups remain
 //            (1024 x 256^3: 6.6-6.7 TB/s; 64 x 128^3: 6.8-7.1 TB/s; 1024 x 64^3: 1 vector, 7.1 TB/s)
 //   fused A'A reads one stream, so it keeps twice the rows in flight.
-struct TallShape { int wg, unroll, aux, order; };   // aux = rows per workgroup (forward) / rows in flight (adjoint)
+struct TallShape { int wg, unroll, aux, order, ctiles = 0; };   // aux = rows per workgroup (forward) / rows in flight (adjoint); ctiles: forward column bands (tiles per band, 0: none)
 
 TallShape pick_fwd_shape(int64_t nvec, int64_t nrow, size_t vec_bytes)
 {
@@ -1898,7 +1912,7 @@ int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     }
     int64_t band = sh.order <= 0 ? 1 : (sh.order == 1 ? gy : sh.order);   // order: 0 sequential, 1 all rows, k>1 = k groups per band
     if (band > gy) band = gy;
-    c.last_fwd_walk = sh.order;
+    c.last_fwd_walk = sh.ctiles ? 2 : sh.order;
     c.last_fwd_rows_per_wg = G;
 #define JH_FWD_CASE(U)                                                                                               \
     case U: {                                                                                                         \
@@ -1906,7 +1920,7 @@ int launch_tall_fwd_u(const jh_blockop *op, void *d, const void *m, int64_t n_sc
         JH_REQUIRE(gx * gy * BLK < (int64_t)1 << 32, "tall forward: grid of %lld workgroups is too large", (long long)(gx * gy)); \
         hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, NT, BLK>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, \
                            op->dev_blocks, op->nrow, (int)G, a_base, a_stride, (const S *)m, (S *)d, n_scalars,      \
-                           (unsigned)gx, (unsigned)gy, (unsigned)band);                                            \
+                           (unsigned)gx, (unsigned)gy, (unsigned)band, (unsigned)sh.ctiles);                       \
     } break;
     switch (sh.unroll) {
         JH_FWD_CASE(1)
@@ -1982,15 +1996,22 @@ int launch_tall_fwd_shape(const jh_blockop *op, void *d, const void *m, int64_t 
 // Candidates 6 and 7 (late round 2) are ONE block row per workgroup with all rows concurrent -- workgroups that are born, move
 // one tile of one row and die: the fastest shapes at the row counts a rank owns on 2 and 4 GPUs (512 rows: 6.32 TB/s against
 // 5.98 for the best of the first six, 256 rows: 6.2 against 6.06; profiles/sweep_r02_fwd_rows.txt), equal to the others at 1024.
-constexpr int K_FWD_CANDIDATES = 8;
-static_assert(2 * K_FWD_CANDIDATES <= jh_blockop::LazyTune::SLOTS, "two passes per candidate must fit the trial slots");
+// Candidates 8 and 9 (late round 4): one block row per workgroup in COLUMN bands of 32 / 64 tiles (k_tall_diag_fwd's ctiles decode) -- tried by
+// operators of fewer than 1024 rows only (the row counts a rank owns on 2 / 4 / 8 GPUs): 128 rows 5.8 -> 6.4 TB/s, 256 rows 5.8 -> 6.1, 512 rows
+// 6.05 -> 6.4 where a copy between the same slabs runs at 6.5; at 1024 rows the row-concurrent walk equals the copy and the bands lose 2 %.
+constexpr int K_FWD_CANDIDATES = 10, K_FWD_CANDIDATES_TALL = 8;          // (operators of >= 1024 rows try the first eight)
+static_assert(2 * K_FWD_CANDIDATES + 4 <= jh_blockop::LazyTune::SLOTS, "two passes per candidate and the play-off must fit the trial slots");
+static_assert(K_FWD_CANDIDATES <= jh_blockop::LazyTune::MAXC, "the candidates' records");
 const TallShape k_fwd_candidates[K_FWD_CANDIDATES] = {TallShape{1024, 8, 16, 0}, TallShape{512, 1, 2, 1}, TallShape{256, 4, 4, 0},
                                                       TallShape{256, 4, 16, 1}, TallShape{512, 4, 8, 1}, TallShape{1024, 8, 1 << 20, 0},
-                                                      TallShape{512, 8, 1, 1},  TallShape{256, 1, 1, 1}};
+                                                      TallShape{512, 8, 1, 1},  TallShape{256, 1, 1, 1},
+                                                      TallShape{256, 1, 1, 1, 32}, TallShape{256, 1, 1, 1, 64}};
 
 // the order in which an untuned operator tries them: the one-row-per-workgroup walks first (the winners on most boxes and pairings,
 // profiles/repeat_r03_boxes.txt), the sequential sweeps last
-const int k_fwd_trial_order[K_FWD_CANDIDATES] = {7, 6, 1, 4, 3, 2, 0, 5};
+const int k_fwd_trial_order[K_FWD_CANDIDATES_TALL] = {7, 6, 1, 4, 3, 2, 0, 5};
+const int k_fwd_trial_order_few[K_FWD_CANDIDATES] = {8, 9, 7, 6, 1, 4, 3, 2, 0, 5};
+static inline int fwd_candidates_of(const jh_blockop *op) { return op->nrow < 1024 ? K_FWD_CANDIDATES : K_FWD_CANDIDATES_TALL; }
 
 // For operators far larger than the caches the row-concurrent walk is 5-7 % faster than the sequential sweep in some
 // processes and 10-15 % slower in others (profiles/repeat_r01.txt: same binary, same box; it depends on where the slabs landed
@@ -2049,7 +2070,7 @@ int lazy_next(jh_blockop::LazyTune &t, int ncand, int npass, int warm, float mar
     }
     (void)hipGetLastError();                                                // hipEventQuery's hipErrorNotReady is not an error
     if (measured == total) {
-        float best[8] = {};
+        float best[jh_blockop::LazyTune::MAXC] = {};
         auto take = [&](int c, int k) { if (t.state[k] == 2 && (best[c] == 0.f || t.ms[k] < best[c])) best[c] = t.ms[k]; };
         for (int j = 0; j < ncand; j++)
             for (int p = 0; p < npass; p++) take(order ? order[j] : j, warm + p * ncand + j);
@@ -2067,7 +2088,7 @@ int lazy_next(jh_blockop::LazyTune &t, int ncand, int npass, int warm, float mar
             *slot = t.launched;
             return pick;
         }
-        for (int c = 0; c < ncand && c < 8; c++) t.best_ms[c] = best[c];
+        for (int c = 0; c < ncand && c < jh_blockop::LazyTune::MAXC; c++) t.best_ms[c] = best[c];
         *choice = pick;
         lazy_release(t);
         return pick;
@@ -2090,9 +2111,9 @@ bool recheck_should_time(jh_blockop::LazyTune &t, int ncand, int *choice)
     if (t.rc_in_flight && hipEventQuery(t.rc_ev[1]) == hipSuccess) {
         float ms = 0.f;
         t.rc_in_flight = false;
-        if (hipEventElapsedTime(&ms, t.rc_ev[0], t.rc_ev[1]) == hipSuccess && ms > 0.f && *choice >= 0 && *choice < 8) {
+        if (hipEventElapsedTime(&ms, t.rc_ev[0], t.rc_ev[1]) == hipSuccess && ms > 0.f && *choice >= 0 && *choice < jh_blockop::LazyTune::MAXC) {
             int other = -1;
-            for (int c = 0; c < ncand && c < 8; c++)
+            for (int c = 0; c < ncand && c < jh_blockop::LazyTune::MAXC; c++)
                 if (c != *choice && t.best_ms[c] > 0.f && (other < 0 || t.best_ms[c] < t.best_ms[other])) other = c;
             if (other >= 0 && ms > 1.03f * t.best_ms[other]) {
                 if (++t.rc_slow >= 3) {
@@ -2155,7 +2176,7 @@ struct WalkKey {
         return std::tie(device, dtype, strided, nrow, n_scalars) < std::tie(o.device, o.dtype, o.strided, o.nrow, o.n_scalars);
     }
 };
-struct WalkRecord { int walk; float best_ms[8]; };
+struct WalkRecord { int walk; float best_ms[jh_blockop::LazyTune::MAXC]; };
 std::mutex g_walk_mutex;
 std::map<WalkKey, WalkRecord> g_walk_memory;
 
@@ -2163,9 +2184,9 @@ WalkKey walk_key(const jh_blockop *op, int64_t n_scalars) { return WalkKey{jh_ct
 
 void walk_remember(const jh_blockop *op, int64_t n_scalars)
 {
-    if (op->fwd_walk < 0 || op->fwd_walk >= 8) return;
+    if (op->fwd_walk < 0 || op->fwd_walk >= K_FWD_CANDIDATES) return;
     WalkRecord r{op->fwd_walk, {}};
-    for (int k = 0; k < 8; k++) r.best_ms[k] = op->fwd_tune.best_ms[k];
+    for (int k = 0; k < jh_blockop::LazyTune::MAXC; k++) r.best_ms[k] = op->fwd_tune.best_ms[k];
     std::lock_guard<std::mutex> lock(g_walk_mutex);
     g_walk_memory[walk_key(op, n_scalars)] = r;
 }
@@ -2176,7 +2197,7 @@ bool walk_recall(const jh_blockop *op, int64_t n_scalars)
     auto it = g_walk_memory.find(walk_key(op, n_scalars));
     if (it == g_walk_memory.end()) return false;
     op->fwd_walk = it->second.walk;
-    for (int k = 0; k < 8; k++) op->fwd_tune.best_ms[k] = it->second.best_ms[k];
+    for (int k = 0; k < jh_blockop::LazyTune::MAXC; k++) op->fwd_tune.best_ms[k] = it->second.best_ms[k];
     op->walk_inherited = true;
     return true;
 }
@@ -2193,12 +2214,13 @@ int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scal
         if (op->fwd_walk < 0 && op->fwd_tune.launched == 0 && !op->walk_measure_again && c.walk_memory) (void)walk_recall(op, n_scalars);
         if (op->fwd_walk < 0) {
             if (!stream_is_capturing(c.stream)) {
-                const int k = lazy_next(op->fwd_tune, K_FWD_CANDIDATES, 2, 0, 0.f, &op->fwd_walk, &slot, true, k_fwd_trial_order);
+                const int nc = fwd_candidates_of(op);
+                const int k = lazy_next(op->fwd_tune, nc, 2, 0, 0.f, &op->fwd_walk, &slot, true, nc == K_FWD_CANDIDATES ? k_fwd_trial_order_few : k_fwd_trial_order);
                 if (k >= 0 && k < K_FWD_CANDIDATES) sh = k_fwd_candidates[k];
                 if (op->fwd_walk >= 0) walk_remember(op, n_scalars);       // the choice has just been made
             }
         } else if (op->fwd_walk < K_FWD_CANDIDATES) {
-            if (!stream_is_capturing(c.stream) && recheck_should_time(op->fwd_tune, K_FWD_CANDIDATES, &op->fwd_walk)) {
+            if (!stream_is_capturing(c.stream) && recheck_should_time(op->fwd_tune, fwd_candidates_of(op), &op->fwd_walk)) {
                 walk_remember(op, n_scalars);                              // (the re-check may have rotated another candidate in)
                 sh = k_fwd_candidates[op->fwd_walk];
                 const bool ok = recheck_begin(op->fwd_tune, c.stream);
@@ -2303,7 +2325,7 @@ int launch_tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int64_t 
     c.last_fwd_walk = 0;
     c.last_fwd_rows_per_wg = G;
     hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, true, BLK, true>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, op->dev_blocks,
-                       op->nrow, (int)G, (const S *)nullptr, (int64_t)0, (const S *)m, (S *)d, n_scalars, (unsigned)gx, (unsigned)gy, 1u);
+                       op->nrow, (int)G, (const S *)nullptr, (int64_t)0, (const S *)m, (S *)d, n_scalars, (unsigned)gx, (unsigned)gy, 1u, 0u);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -3997,7 +4019,7 @@ int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value)
     else if (!strcmp(name, "fwd_walk_inherited")) *value = op->walk_inherited ? 1 : 0;   // the choice came from an earlier operator of the same shape
     else if (!strcmp(name, "fwd_trials")) *value = op->fwd_tune.launched;
     else if (!strcmp(name, "fwd_switches")) *value = op->fwd_tune.switches;       // times the periodic re-check rotated another walk in
-    else if (!strcmp(name, "fwd_playoff")) *value = op->fwd_tune.playoff[0] >= 0 ? op->fwd_tune.playoff[0] * 8 + op->fwd_tune.playoff[1] : -1;
+    else if (!strcmp(name, "fwd_playoff")) *value = op->fwd_tune.playoff[0] >= 0 ? op->fwd_tune.playoff[0] * 16 + op->fwd_tune.playoff[1] : -1;
     else if (!strcmp(name, "step_trials")) *value = op->step_tune.launched;
     else if (!strcmp(name, "upd_walk")) *value = op->upd_walk;
     else if (!strcmp(name, "step_mode")) *value = op->step_mode;

@@ -246,7 +246,8 @@ struct jh_blockop {
     // lazy autotune (jh_blockop.hip: lazy_*): the first real calls each run ONE candidate between two events -- no extra
     // launches, no host synchronisation -- and finished timings are harvested with hipEventQuery on later calls
     struct LazyTune {
-        static constexpr int SLOTS = 24;     // 8 candidates x 2 passes + a play-off of 4 (round 3)
+        static constexpr int SLOTS = 24;     // up to 10 candidates x 2 passes + a play-off of 4
+        static constexpr int MAXC = 12;      // candidates whose best times are kept
         hipEvent_t ev[SLOTS][2] = {};
         float ms[SLOTS] = {};
         unsigned char state[SLOTS] = {};     // 0 not launched, 1 in flight, 2 measured, 3 failed
@@ -254,7 +255,7 @@ struct jh_blockop {
         // round 3: when the runner-up is within 3 % of the winner, the two are timed twice more, alternating (the play-off slots
         // follow the regular ones), before the choice is made; the candidates' best times are kept for the periodic re-check
         int playoff[2] = {-1, -1};
-        float best_ms[8] = {};
+        float best_ms[MAXC] = {};
         // periodic re-check of the chosen candidate (every 64th call is timed; three slow samples in a row rotate the runner-up in)
         int64_t calls = 0;
         hipEvent_t rc_ev[2] = {};

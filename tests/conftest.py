@@ -10,6 +10,11 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# The HIP runtime aborts the process on a GPU fault or a hardware exception event -- also one raised by ANOTHER tenant of a shared host resetting
+# the GPUs -- and says why only at log level 1 and above (errors); glibc's fatal messages go to the terminal unless told otherwise.  Make both
+# end up in the test log (before the runtime is loaded).
+os.environ.setdefault("AMD_LOG_LEVEL", "1")
+os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -36,7 +36,7 @@ def timed(reps=6, warm=2):
 
 
 for rnd in range(2):
-    for walk in range(8):
+    for walk in range(10):
         J.op_tune_set(A, "fwd_walk", walk)
         lo, med = timed()
         print(f"{nrow} x {edge}^3 candidate {walk}: min {lo:7.3f} ms {b / lo / 1e6:7.1f} GB/s  median {med:7.3f} ms  rows/wg {J.tune_get('last_fwd_rows_per_wg')}", flush=True)
