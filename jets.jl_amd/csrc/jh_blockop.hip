@@ -1831,12 +1831,14 @@ TallShape pick_fwd_shape(int64_t nvec, int64_t nrow, size_t vec_bytes)
     (void)vec_bytes;
     TallShape s;
     if (nvec >= ((int64_t)1 << 21) && nrow >= 512) s = TallShape{1024, 8, 16, 0};
-    else if (nvec >= ((int64_t)1 << 21)) s = TallShape{256, 4, 4, 0};
+    else if (nvec >= ((int64_t)1 << 21)) s = TallShape{256, 1, 1, 1, 32};   // blocks of >= 32 MiB, fewer than 512 rows: column bands (16-32 x 256^3: 6.05-6.19 -> 6.67 TB/s with
+                                                                            // 256 x 4 x 4 rows sequential before; profiles/exp_r04_small_fwd.txt)
     else s = TallShape{256, 1, 2, 0};
     if (c.fwd_wg) s.wg = (int)c.fwd_wg;
     if (c.fwd_unroll) s.unroll = (int)c.fwd_unroll;
     if (c.fwd_group) s.aux = (int)c.fwd_group;
     if (c.fwd_order >= 0) s.order = (int)c.fwd_order;
+    if (c.fwd_ctiles >= 0) s.ctiles = (int)c.fwd_ctiles;
     return s;
 }
 
@@ -1999,7 +2001,7 @@ int launch_tall_fwd_shape(const jh_blockop *op, void *d, const void *m, int64_t 
 // Candidates 8 and 9 (late round 4): one block row per workgroup in COLUMN bands of 32 / 64 tiles (k_tall_diag_fwd's ctiles decode) -- tried by
 // operators of fewer than 1024 rows only (the row counts a rank owns on 2 / 4 / 8 GPUs): 128 rows 5.8 -> 6.4 TB/s, 256 rows 5.8 -> 6.1, 512 rows
 // 6.05 -> 6.4 where a copy between the same slabs runs at 6.5; at 1024 rows the row-concurrent walk equals the copy and the bands lose 2 %.
-constexpr int K_FWD_CANDIDATES = 10, K_FWD_CANDIDATES_TALL = 8;          // (operators of >= 1024 rows try the first eight)
+constexpr int K_FWD_CANDIDATES = 10, K_FWD_CANDIDATES_TALL = 8;          // (operators of >= 1024 rows of blocks >= 64 MiB try the first eight)
 static_assert(2 * K_FWD_CANDIDATES + 4 <= jh_blockop::LazyTune::SLOTS, "two passes per candidate and the play-off must fit the trial slots");
 static_assert(K_FWD_CANDIDATES <= jh_blockop::LazyTune::MAXC, "the candidates' records");
 const TallShape k_fwd_candidates[K_FWD_CANDIDATES] = {TallShape{1024, 8, 16, 0}, TallShape{512, 1, 2, 1}, TallShape{256, 4, 4, 0},
@@ -2011,7 +2013,13 @@ const TallShape k_fwd_candidates[K_FWD_CANDIDATES] = {TallShape{1024, 8, 16, 0},
 // profiles/repeat_r03_boxes.txt), the sequential sweeps last
 const int k_fwd_trial_order[K_FWD_CANDIDATES_TALL] = {7, 6, 1, 4, 3, 2, 0, 5};
 const int k_fwd_trial_order_few[K_FWD_CANDIDATES] = {8, 9, 7, 6, 1, 4, 3, 2, 0, 5};
-static inline int fwd_candidates_of(const jh_blockop *op) { return op->nrow < 1024 ? K_FWD_CANDIDATES : K_FWD_CANDIDATES_TALL; }
+// (the bands also for >= 1024 rows of blocks below 64 MiB: 1024 x 128^3 with a non-diagonal row runs its banded forward + adjoint pair at 6.55 TB/s
+// where the all-diagonal operator's best of eight gave 6.31)
+static inline int fwd_candidates_of(const jh_blockop *op)
+{
+    const bool small_blocks = (double)op->row_len[0] * (double)jh_dtype_size(op->dtype) < (double)(64u << 20);
+    return (op->nrow < 1024 || small_blocks) ? K_FWD_CANDIDATES : K_FWD_CANDIDATES_TALL;
+}
 
 // For operators far larger than the caches the row-concurrent walk is 5-7 % faster than the sequential sweep in some
 // processes and 10-15 % slower in others (profiles/repeat_r01.txt: same binary, same box; it depends on where the slabs landed
@@ -2217,6 +2225,9 @@ int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scal
                 const int nc = fwd_candidates_of(op);
                 const int k = lazy_next(op->fwd_tune, nc, 2, 0, 0.f, &op->fwd_walk, &slot, true, nc == K_FWD_CANDIDATES ? k_fwd_trial_order_few : k_fwd_trial_order);
                 if (k >= 0 && k < K_FWD_CANDIDATES) sh = k_fwd_candidates[k];
+                // the column-persistent walk (candidate 5) has one workgroup per 128 KiB of a ROW: with small blocks that is a handful of
+                // workgroups walking thousands of rows (4096 x 64^3: 17.8 ms where the others take 1.4-1.7) -- such a trial runs candidate 0's shape
+                if (k == 5 && n_scalars / NS < (int64_t)512 * 1024 * 8) sh = k_fwd_candidates[0];
                 if (op->fwd_walk >= 0) walk_remember(op, n_scalars);       // the choice has just been made
             }
         } else if (op->fwd_walk < K_FWD_CANDIDATES) {
@@ -2315,17 +2326,23 @@ template <typename S, int E, int NS>
 int launch_tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
 {
     jh_context &c = jh_ctx();
-    constexpr int BLK = 256, U = 4;
-    int64_t G = 4;
+    // late round 4: one pack per lane, two rows per workgroup, COLUMN bands of 32 tiles (128 KiB of each row, then the same tiles of the next
+    // row group: k_tall_diag_fwd's ctiles decode) -- against round 3's 256 x 4 packs x 4 rows in a sequential sweep: 1024 x 64^3 5.0 -> 6.1 TB/s,
+    // 4096 x 64^3 5.3 -> 6.3, 16384 x 32^3 5.5 -> 6.4, 64 x 128^3 5.6 -> 6.4, 2048 x 128^3 5.6 -> 6.35, 256 x 256^3 5.8 -> 6.4
+    // (profiles/exp_r04_mixed_fwd.txt).  Knobs fwd_group / fwd_ctiles override rows per workgroup / tiles per band (0: sequential sweep).
+    constexpr int BLK = 256, U = 1;
+    int64_t G = c.fwd_group > 0 ? c.fwd_group : 2;
     if (G > op->nrow) G = op->nrow;
     const int64_t gx = (n_scalars + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);
     int64_t gy = (op->nrow + G - 1) / G;
     while (gx * gy * BLK >= ((int64_t)1 << 32) && G < op->nrow) { G *= 2; gy = (op->nrow + G - 1) / G; }
     JH_REQUIRE(gx * gy * BLK < (int64_t)1 << 32, "tall forward: grid of %lld workgroups is too large", (long long)(gx * gy));
-    c.last_fwd_walk = 0;
+    int64_t ctiles = c.fwd_ctiles >= 0 ? c.fwd_ctiles : 32;
+    if (ctiles > gx) ctiles = gx;
+    c.last_fwd_walk = ctiles ? 2 : 0;
     c.last_fwd_rows_per_wg = G;
     hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, true, BLK, true>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, op->dev_blocks,
-                       op->nrow, (int)G, (const S *)nullptr, (int64_t)0, (const S *)m, (S *)d, n_scalars, (unsigned)gx, (unsigned)gy, 1u, 0u);
+                       op->nrow, (int)G, (const S *)nullptr, (int64_t)0, (const S *)m, (S *)d, n_scalars, (unsigned)gx, (unsigned)gy, 1u, (unsigned)ctiles);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
