@@ -443,9 +443,18 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block
                                                               double *__restrict__ partials, double wscal = 0.0)
 {
     typedef typename vec_of<S, NS>::type V;
-    // walk 0: tile index fastest (one block row at a time); walk 1: row group fastest (all rows concurrently)
-    const unsigned tile = walk ? blockIdx.x / ngroups : blockIdx.x % ntiles;
-    const unsigned grp = walk ? blockIdx.x % ngroups : blockIdx.x / ntiles;
+    // walk 0: tile index fastest (one block row at a time); walk 1: row group fastest (all rows concurrently); walk >= 2: COLUMN bands of
+    // `walk` tiles (that many consecutive tiles of one row group, then the same tiles of the next group, ... then the next band: k_tall_diag_fwd)
+    unsigned tile, grp;
+    if (walk >= 2) {
+        const unsigned ct = (unsigned)walk, per_c = ct * ngroups, cb = blockIdx.x / per_c, r = blockIdx.x - cb * per_c;
+        const unsigned cw = (cb * ct + ct <= ntiles) ? ct : ntiles - cb * ct;
+        grp = r / cw;
+        tile = cb * ct + r % cw;
+    } else {
+        tile = walk ? blockIdx.x / ngroups : blockIdx.x % ntiles;
+        grp = walk ? blockIdx.x % ngroups : blockIdx.x / ntiles;
+    }
     const int64_t s0 = ((int64_t)tile * U * BLK + threadIdx.x) * NS;
     const int64_t i0 = (int64_t)grp * rows_per_wg;
     const int64_t i1 = (i0 + rows_per_wg < nrow) ? i0 + rows_per_wg : nrow;
@@ -2664,31 +2673,32 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
     const int64_t a_stride = op->diag_stride_elems * E;
     const int64_t nvec = n_scalars / NS;
-    // three streams per row (a, d in, d out): same tilings as the plain forward, fewer instantiations
-    int wg, U, G;
-    // profiles/sweep_r01_update_1024x256.txt: 256 threads x 4 vectors x 4 rows, 5.50 TB/s (1024 x 8 x 16: 5.29)
-    if (nvec >= ((int64_t)1 << 21)) { wg = 256; U = 4; G = 4; }
-    else { wg = 256; U = 4; G = 8; }
-    // knob overrides (2 instantiated tilings; round 1's 1024 x 8 -- 5.29 TB/s against 5.50 -- spilled to scratch and is gone)
-    if (c.fwd_wg == 256 && c.fwd_unroll == 4) { wg = 256; U = 4; }
-    else if (c.fwd_wg == 256 && c.fwd_unroll == 1) { wg = 256; U = 1; }
+    // three streams per row (a, d in, d out).  Late round 4: one pack per lane, two rows per workgroup, COLUMN bands of 32 tiles (k_tall_diag_fwd's
+    // walk: 128 KiB of a row group, then the same tiles of the next, ...) -- against round 1's 256 x 4 packs x 4 rows sequential: beta = 0 (the pass of
+    // `(a * A) * m`) 6.07 / 5.65 / 5.92 / 5.88 -> 6.22 / 6.14 / 6.13 / 6.17 TB/s at 128 x 256^3 / 256 x 256^3 / 1024 x 128^3 / 1024 x 256^3,
+    // beta != 0 5.73-5.82 -> 6.02-6.27 (profiles/exp_r04_update_fwd.txt)
+    int wg = 256, U = 1, G = 2, walk = 32;
+    // knob overrides: fwd_unroll 4 / 1 (the two instantiated tilings), fwd_group rows per workgroup, fwd_order 0 / 1 the sequential / row-concurrent
+    // walk of rounds 1-3, fwd_ctiles tiles per band
+    if (c.fwd_unroll == 4) { U = 4; G = 4; }
     if (c.fwd_group) G = (int)c.fwd_group;
-    // Grid walk: like the plain forward (autotune_fwd_walk) the row-concurrent walk wins in some processes and loses in
-    // others.  This kernel updates d in place, so it cannot be re-run for timing: the first two real calls on a large
-    // operator use walk 0 and walk 1 and are timed with events (only when the caller asked for the norm, i.e. the call
-    // synchronises anyway); later calls use the faster one.
+    if (c.fwd_order == 0 || c.fwd_order == 1) walk = (int)c.fwd_order;
+    if (c.fwd_ctiles >= 2) walk = (int)c.fwd_ctiles;
+    else if (c.fwd_ctiles == 0 && walk >= 2) walk = 0;
+    // Which walk: like the plain forward the row-concurrent walk (256 x 4 packs, two rows) wins in some processes at full size (1024 x 256^3,
+    // beta = 0: 6.42 against 6.17) and loses in others.  This kernel updates d in place, so it cannot be re-run for timing: the first two real calls
+    // on a large operator use the bands and the row-concurrent walk and are timed with events (only when the caller asked for the norm, i.e. the
+    // call synchronises anyway); later calls use the faster one (upd_walk: 0 bands, 1 row-concurrent).
     const double stream_bytes = 3.0 * (double)op->nrow * (double)n_scalars * sizeof(S);
-    const bool knobs_free = !c.fwd_wg && !c.fwd_unroll && !c.fwd_group && c.fwd_order < 0;
-    const bool tunable = c.autotune && knobs_free && normsq && stream_bytes >= 8.0 * (double)(1ull << 30) && op->nrow >= 64;
-    int walk = (c.fwd_order == 1) ? 1 : 0;
+    const bool knobs_free = !c.fwd_wg && !c.fwd_unroll && !c.fwd_group && c.fwd_order < 0 && c.fwd_ctiles < 0;
+    const bool mixed = !op->all_diag;                       // rows of several elementwise kinds: the bands, always
+    const bool tunable = !mixed && c.autotune && knobs_free && normsq && stream_bytes >= 8.0 * (double)(1ull << 30) && op->nrow >= 64;
     int trial = -1;
     if (tunable) {
-        if (op->upd_walk >= 0) walk = op->upd_walk;
-        else { trial = op->upd_trials; walk = trial; }        // trial 0 -> walk 0, trial 1 -> walk 1
+        int which = op->upd_walk;
+        if (which < 0) { trial = op->upd_trials; which = trial; }        // trial 0 -> bands, trial 1 -> row-concurrent
+        if (which == 1) { U = 4; G = 2; walk = 1; }
     }
-    const bool mixed = !op->all_diag;                       // rows of several elementwise kinds: the 256 x 4 tiling, sequential sweep
-    if (mixed) { wg = 256; U = 4; walk = 0; trial = -1; }
-    if (walk == 1 && !c.fwd_group) G = 2;
     if (G > op->nrow) G = (int)op->nrow;
     const int64_t gx = (nvec + (int64_t)wg * U - 1) / ((int64_t)wg * U);
     int64_t gy = (op->nrow + G - 1) / G;
@@ -2708,13 +2718,15 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     // (a wide scalar: Float32 elements only, beta == 0 -- checked by the caller; one instantiation per tiling)
     if constexpr (sizeof(S) == 4) {
         if (wide) {
-            if (mixed) JH_LAUNCH_W(256, 4, true, true);
+            if (mixed && U == 4) JH_LAUNCH_W(256, 4, true, true);
+            else if (mixed) JH_LAUNCH_W(256, 1, true, true);
             else if (U == 4) JH_LAUNCH_W(256, 4, false, true);
             else JH_LAUNCH_W(256, 1, false, true);
         }
     }
     if (!(sizeof(S) == 4 && wide)) {
-        if (mixed) JH_LAUNCH_W(256, 4, true, false);
+        if (mixed && U == 4) JH_LAUNCH_W(256, 4, true, false);
+        else if (mixed) JH_LAUNCH_W(256, 1, true, false);
         else if (U == 4) JH_LAUNCH_W(256, 4, false, false);
         else JH_LAUNCH_W(256, 1, false, false);
     }
