@@ -1210,18 +1210,22 @@ __device__ inline elem<S, E> apply_block(const jh_dev_block &b, elem<S, E> x, in
 // XCDs, each with its own L2, so the lines of a tile get workgroup ids 8 apart: same XCD, dispatched together -- the shared
 // input comes from HBM once and from that L2 afterwards (without this an M x K operator with big blocks re-reads every
 // input block once per line: profiles/bench_blocks_nl_r01.txt).
+// Late round 4: the group of tiles that every line walks before the next group starts is 8 << k tiles (k in bits 28..30 of `ntiles`, knob
+// general_band): bands of 32 tiles stream 128 KiB of every block linearly where 8 tiles made every workgroup jump a whole block after 32 KiB
+// (the tall forward's column bands); any multiple of 8 keeps the lines of a tile on one XCD.
 __device__ inline void general_line_tile(unsigned nlines, unsigned ntiles, int64_t &line, int64_t &tile)
 {
+    const unsigned k = (ntiles >> 28) & 7u, T = 8u << k;
     if (ntiles & 0x80000000u) {                              // knob general_xcd = 0 (A/B measurements): tile fastest, line by line
-        const unsigned padded = ((ntiles & 0x7fffffffu) + 7u) / 8u * 8u;
+        const unsigned padded = ((ntiles & 0x0fffffffu) + T - 1u) / T * T;
         line = blockIdx.x / padded;
         tile = blockIdx.x - (unsigned)line * padded;
         return;
     }
-    const unsigned per = 8u * nlines;
+    const unsigned per = T * nlines;
     const unsigned grp = blockIdx.x / per, rem = blockIdx.x - grp * per;
-    line = rem >> 3;
-    tile = (int64_t)grp * 8 + (rem & 7u);
+    line = rem >> (3u + k);
+    tile = (int64_t)grp * T + (rem & (T - 1u));
 }
 
 // JetBlock_df! (1010-1032): one line per block row, threads over the row's elements.
@@ -1236,7 +1240,7 @@ __global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int
     // left, rounded like the reference's dtmp (1024), at the row's elements of slab j
     int64_t i, tile;                                                       // block row, tile
     general_line_tile((unsigned)nrow, ntiles, i, tile);
-    ntiles &= 0x7fffffffu;
+    ntiles &= 0x0fffffffu;
     if (tile >= ntiles) return;
     // q_per_part > 0: split walk (many block columns of small blocks, general_parts): workgroup row blockIdx.y sums its own
     // columns, in order, from zero into slab blockIdx.y; k_fold_general adds d as found and the slabs afterwards
@@ -1283,7 +1287,7 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
     // like the reference's mtmp (1049), at column j's elements of slab i
     int64_t j, tile;                                                       // block column, tile
     general_line_tile((unsigned)ncol, ntiles, j, tile);
-    ntiles &= 0x7fffffffu;
+    ntiles &= 0x0fffffffu;
     if (tile >= ntiles) return;
     int64_t i_lo = 0, i_hi = nrow;                                         // q_per_part > 0: split walk over the block rows
     if (q_per_part > 0) {
@@ -1388,7 +1392,7 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
     typedef typename vec_of<S, NS>::type V;
     int64_t i, tile;                                                       // block row, tile
     general_line_tile((unsigned)nrow, ntiles, i, tile);
-    ntiles &= 0x7fffffffu;
+    ntiles &= 0x0fffffffu;
     if (tile >= ntiles) return;
     const bool split = q_per_part > 0;                                     // split walk over the block columns (see the scalar kernel)
     int64_t j_lo = 0, j_hi = ncol;
@@ -1459,7 +1463,7 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
     typedef typename vec_of<S, NS>::type V;
     int64_t j, tile;                                                       // block column, tile
     general_line_tile((unsigned)ncol, ntiles, j, tile);
-    ntiles &= 0x7fffffffu;
+    ntiles &= 0x0fffffffu;
     if (tile >= ntiles) return;
     int64_t i_lo = 0, i_hi = nrow;                                         // q_per_part > 0: split walk over the block rows
     if (q_per_part > 0) {
@@ -1532,7 +1536,7 @@ __global__ __launch_bounds__(256) void k_grid_diag(const jh_dev_block *__restric
     typedef typename vec_of<S, NS>::type V;
     int64_t line, tile;
     general_line_tile((unsigned)(TRANSPOSED ? ncol : nrow), ntiles, line, tile);
-    ntiles &= 0x7fffffffu;
+    ntiles &= 0x0fffffffu;
     if (tile >= ntiles) return;
     const int64_t nsum = TRANSPOSED ? nrow : ncol;                          // blocks walked per line
     const int64_t step = TRANSPOSED ? 1 : nrow, first = TRANSPOSED ? line * nrow : line;   // block (q) of the line = blocks[first + q * step]
@@ -1605,7 +1609,7 @@ __global__ __launch_bounds__(256) void k_grid_tile(const jh_dev_block *__restric
     typedef typename vec_of<S, NS>::type V;
     int64_t grp, tile;
     general_line_tile(ngroups, ntiles, grp, tile);
-    ntiles &= 0x7fffffffu;
+    ntiles &= 0x0fffffffu;
     if (tile >= ntiles) return;
     const int64_t nlines = TRANSPOSED ? ncol : nrow, nsum = TRANSPOSED ? nrow : ncol;
     const int64_t qstep = TRANSPOSED ? 1 : nrow, lstep = TRANSPOSED ? nrow : 1;   // block (line l, q) = blocks[l * lstep + q * qstep]
@@ -1697,7 +1701,7 @@ __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__rest
     typedef typename vec_of<S, NS>::type V;
     int64_t grp, tile;
     general_line_tile(ngroups, ntiles, grp, tile);
-    ntiles &= 0x7fffffffu;
+    ntiles &= 0x0fffffffu;
     if (tile >= ntiles) return;
     const int64_t nlines = TRANSPOSED ? ncol : nrow, nsum = TRANSPOSED ? nrow : ncol;
     const int64_t qstep = TRANSPOSED ? 1 : nrow, lstep = TRANSPOSED ? nrow : 1;   // block (line l, q) = blocks[l * lstep + q * qstep]
@@ -2422,12 +2426,15 @@ static inline bool general_use_xcd(int64_t input_bytes)
 
 static inline void general_grid(int64_t want_tiles, int64_t nlines, unsigned &ntiles, unsigned &grid, bool xcd)
 {
-    int64_t cap = (((int64_t)1 << 24) / nlines) / 8 * 8 - 8;               // grid * 256 threads < 2^32
-    if (cap < 8) cap = 8;
+    const int64_t band = jh_ctx().general_band;                            // tiles per band: 8, 16, 32 or 64 (knob general_band)
+    const unsigned k = band >= 64 ? 3u : (band >= 32 ? 2u : (band >= 16 ? 1u : 0u));
+    const int64_t T = (int64_t)8 << k;
+    int64_t cap = (((int64_t)1 << 24) / nlines) / T * T - T;               // grid * 256 threads < 2^32
+    if (cap < T) cap = T;
     if (want_tiles > cap) want_tiles = cap;                                // the kernels stride over the rest
     if (want_tiles < 1) want_tiles = 1;
-    ntiles = (unsigned)want_tiles;
-    grid = (unsigned)(((want_tiles + 7) / 8) * 8 * nlines);
+    ntiles = (unsigned)want_tiles | (k << 28);
+    grid = (unsigned)(((want_tiles + T - 1) / T) * T * nlines);
     if (!xcd) ntiles |= 0x80000000u;                                       // flag for the kernels' decode: tile fastest, line by line
 }
 

@@ -41,9 +41,12 @@ b = n * 4
 routes = [(1, 1), (1, 2), (1, 4), (1, 8), (1, 0), (0, 0)]               # (grid_diag, grid_tile): tiled automatic / 2 x 1 / 4 x 2 / 8 x 1 (lines x packs per lane); k_grid_diag; the general kernels
 if os.environ.get("GRID_ROUTES"):
     routes = [tuple(int(v) for v in r.split(":")) for r in os.environ["GRID_ROUTES"].split(",")]
-for gd, gt in routes * 2:
+bands = [int(v) for v in os.environ.get("GENERAL_BAND", "").split(",") if v]      # tiles per band of the grid kernels (8 / 16 / 32 / 64), cycled
+for it, (gd, gt) in enumerate(routes * 2):
     xcd = 1
     J.tune(general_xcd=xcd, grid_diag=gd, grid_tile=gt)
+    if bands:
+        J.tune(general_band=bands[it % len(bands)])
     tf = timed(lambda: J.mul_(d, A, m))
     ta = timed(lambda: J.mul_(mt, A.H, d))
-    print(f"{M} x {K} of {edge}^3 {'col-major' if colmajor else 'row-major'} slab pad {pad} grid_diag={gd} grid_tile={gt}: forward {tf:7.3f} ms {(M * K + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {(M * K + M + K) * b / ta / 1e6:7.1f} GB/s", flush=True)
+    print(f"{M} x {K} of {edge}^3 {'col-major' if colmajor else 'row-major'} slab pad {pad} grid_diag={gd} grid_tile={gt}{' band ' + str(bands[it % len(bands)]) if bands else ''}: forward {tf:7.3f} ms {(M * K + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {(M * K + M + K) * b / ta / 1e6:7.1f} GB/s", flush=True)

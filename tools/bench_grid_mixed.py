@@ -55,9 +55,12 @@ b = n * 4
 if os.environ.get("GENERAL_TILE_U"):
     J.tune(fwd_unroll=int(os.environ["GENERAL_TILE_U"]))
 knob = os.environ.get("GENERAL_TILE")
-for gt in ([int(v) for v in knob.split(",")] if knob else [1, 0, 1, 0]):
+bands = [int(v) for v in os.environ.get("GENERAL_BAND", "").split(",") if v]      # tiles per band of the general kernels (8 / 16 / 32 / 64), cycled with the tile knob
+for it, gt in enumerate([int(v) for v in knob.split(",")] if knob else [1, 0, 1, 0]):
     J.tune(general_tile=gt)
+    if bands:
+        J.tune(general_band=bands[it % len(bands)])
     tf = timed(lambda: J.mul_(d, A, m))
     ta = timed(lambda: J.mul_(mt, A.H, d))
-    print(f"{M} x {K} mixed grid of {edge}^3 ({ndiag} diagonals of {M * K} blocks) general_tile={gt}: forward {tf:7.3f} ms {(ndiag + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | "
+    print(f"{M} x {K} mixed grid of {edge}^3 ({ndiag} diagonals of {M * K} blocks) general_tile={gt}{' band ' + str(bands[it % len(bands)]) if bands else ''}: forward {tf:7.3f} ms {(ndiag + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | "
           f"adjoint {ta:7.3f} ms {(ndiag + M + K) * b / ta / 1e6:7.1f} GB/s", flush=True)

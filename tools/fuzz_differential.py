@@ -21,6 +21,8 @@ from tests.test_gpu_random_differential import KINDS, _build, _split
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 J.init(0)
+if os.environ.get("GENERAL_BAND"):
+    J.tune(general_band=int(os.environ["GENERAL_BAND"]))               # tiles per band of the general kernels' decode (8 / 16 / 32 / 64)
 POOL = [0, 1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 64, 100, 256, 257, 1000, 1024, 4100, 16384, 70001]
 
 

@@ -17,6 +17,8 @@ from tests.helpers import DTYPES, assert_bits_equal, u01
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 J.init(0)
+if os.environ.get("GENERAL_BAND"):
+    J.tune(general_band=int(os.environ["GENERAL_BAND"]))               # tiles per band of the grid kernels' decode (8 / 16 / 32 / 64)
 t0 = time.time()
 stats = {"grid": 0, "wide": 0, "tall": 0}
 for case in range(seed0, seed0 + ncases):
