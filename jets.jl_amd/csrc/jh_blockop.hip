@@ -2886,8 +2886,10 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     const bool knobs_free = !c.adj_wg && !c.adj_unroll && !c.adj_depth;
     int cb = 0;                                                           // chained: workgroup size (0: the shape does not allow it)
     if (!direct && parts == 1 && rows_per_launch == op->nrow && nchunks >= 2)
-        for (int b : {1024, 512, 256})
+        for (int b : {1024, 512, 256}) {
+            if (c.step_chain == 1 && c.adj_wg && c.adj_wg != b) continue;  // (knobs step_chain = 1 + adj_wg: that workgroup size, for sweeps)
             if (span % ((int64_t)b * NS) == 0 && (c.step_chain == 1 || (b == 1024 && span / ((int64_t)b * NS) >= 1024 && op->nrow >= 16))) { cb = b; break; }
+        }
     const int64_t ntiles = cb ? span / ((int64_t)cb * NS) : 0;
     if (cb && !(ntiles * nchunks * cb < ((int64_t)1 << 32) && ntiles < ((int64_t)1 << 24))) cb = 0;
     const bool chain_ok = cb != 0 && c.step_chain != 0 && (c.step_chain == 1 || knobs_free);
