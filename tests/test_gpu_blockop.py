@@ -662,3 +662,55 @@ def test_a_real_scalar_multiplies_complex_data_part_by_part(Jets, oracle, dt):
     Jets.lincomb_(out, [c], [x])
     got = out.to_numpy()
     assert np.array_equal(np.isnan(got.view(got.real.dtype)), np.isnan(expect.astype(dt).view(got.real.dtype)))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("mixed", [False, True])
+def test_tall_forward_in_column_bands_of_any_width_has_the_same_bits(Jets, oracle, dt, mixed):
+    """The tall forward's column-band walk (k_tall_diag_fwd's ctiles decode, late round 4: `ctiles` consecutive tiles of one row group, then the
+    same tiles of the next group, ... then the next band) only re-orders workgroups: whatever the band width -- narrower than a row, wider than
+    it, not a divisor of the tile count -- and whatever the rows per workgroup, with a ragged last tile, strided or table-addressed
+    coefficients, all-diagonal or with rows of other kinds, d = A m and the fused update d = alpha (A m) + beta d keep their bits."""
+    import ctypes as C
+
+    from jets_jl_amd import jetblock as _blk
+    from jets_jl_amd._ffi import check, lib
+
+    J = Jets
+    nrow, n = 7, 4 * 4096 + 1028                                  # 17 tiles of 256 packs (Float32) and a ragged one
+    spc = J.JetSpace(dt, n)
+    hm = u01(oracle, dt, 2, 0, n)
+    m = J.from_numpy(hm, spc)
+    for strided in (True, False):
+        if strided:
+            coeff = J.rand(J.JetBSpace([spc] * nrow), seed=31, stream=0)
+            devs = list(coeff.arrays)
+            hc = [oracle.rng_u01(dt, 31, 0, i * n, n) for i in range(nrow)]
+        else:
+            devs = [J.rand(spc, seed=31, stream=i) for i in range(nrow)]
+            hc = [u01(oracle, dt, 31, i, n) for i in range(nrow)]
+        rows = [[J.JopDiagonal(c)] for c in devs]
+        ops = [[oracle.Block("diag", n, coeff=c)] for c in hc]
+        if mixed:
+            rows[2], ops[2] = [J.JopIdentity(spc)], [oracle.Block("identity", n)]
+            rows[5], ops[5] = [J.JopZeroBlock(spc, spc)], [oracle.Block("zero", n, n)]
+        A = J.blockop(rows)
+        hd0 = [u01(oracle, dt, 3, i, n) for i in range(nrow)]
+        want = np.concatenate(oracle.block_df(ops, [b.copy() for b in hd0], [hm]))
+        tmp = oracle.block_df(ops, [np.zeros(n, dt) for _ in range(nrow)], [hm])
+        want_upd = np.concatenate(oracle.barr_lincomb([np.empty(n, dt) for _ in range(nrow)], [0.75, -0.5], [tmp, hd0]))
+        nat = _blk._tall_native(A)
+        try:
+            for ct in (0, 1, 3, 5, 17, 32, 64, 1000):
+                for grp in (1, 2, 5):
+                    J.tune(fwd_wg=256, fwd_unroll=1, fwd_group=grp, fwd_ctiles=ct)
+                    d = J.from_numpy(np.concatenate(hd0), J.range(A))
+                    J.mul_(d, A, m)
+                    assert_bits_equal(d.to_numpy(), want, f"forward, bands of {ct} tiles, {grp} rows per workgroup, strided {strided}, mixed {mixed}, {np.dtype(dt)}")
+                    if nat is not None:
+                        d = J.from_numpy(np.concatenate(hd0), J.range(A))
+                        check(lib.jh_blockop_mul_axpby(nat.handle, d.handle, m.handle, 0.75, -0.5, None))
+                        assert_bits_equal(d.to_numpy(), want_upd, f"forward update, bands of {ct} tiles, {grp} rows per workgroup, strided {strided}, mixed {mixed}, {np.dtype(dt)}")
+        finally:
+            J.tune(fwd_wg=0, fwd_unroll=0, fwd_group=0, fwd_ctiles=-1)
+        J.close(A)
