@@ -453,7 +453,8 @@ int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, 
  * host loop; same iterates), "grid_diag" (M x K grids of plain diagonals on the branch-free kernel k_grid_diag: 1 yes -- 2 / 4: that many packs per lane, measured no
  * better --, 0 the general kernels), "grid_tile" (those grids register-tiled, k_grid_tile -- a workgroup owns R lines x one element
  * tile, the shared input pack loaded once per R products: 1 automatic R, 2 / 4 / 8 that R, 0: k_grid_diag; same bits),
- * "sum_group" (terms of a fused JetSum forward per launch: 16, 8, or 4 = round 2's grouping; same bits), "general_band" (tiles of every line the general M x K kernels walk before the next group of tiles starts: 8, or 16 / 32 / 64 -- measured neutral;
+ * "sum_group" (terms of a fused JetSum forward per launch: 16, 8, or 4 = round 2's grouping; same bits), "bcast_band" (batched broadcasts with a shared operand -- F(m) of a tall nonlinear operator -- in column bands of that many tiles: 0 = 32, 1 = items
+ * fastest without bands; same bits), "general_band" (tiles of every line the general M x K kernels walk before the next group of tiles starts: 8, or 16 / 32 / 64 -- measured neutral;
  * same bits), "fwd_ctiles" (tall forward in column bands of that many tiles of one row -- then the same tiles of the next rows, then the next band: -1 the shape's own, 0 none; same bits), "sum_adj_group" (terms of its adjoint per launch,
  * each with its own accumulator: 8, or 16; same bits), "general_tile" (grids of equal elementwise
  * blocks of ANY kinds register-tiled, k_general_tile: 1 automatic -- four lines per workgroup when there are four, else two --, 2 / 4 that many

@@ -165,8 +165,12 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
     const bool any_wide = !is64 && wide_mask != 0;          // then the scalar table holds doubles for every scalar of the program
     s += std::string("extern \"C\" __global__ __launch_bounds__(256) void jh_bcast_vec_batched(const void *const *tbl_, const ") + (any_wide ? "double" : "R") +
          " *sc_, long n_scalars, int item_fast_, int shared_mask_)\n{\n";
-    s += "    const long item_ = item_fast_ ? blockIdx.x : blockIdx.y, tile_ = item_fast_ ? blockIdx.y : blockIdx.x;\n";
-    s += "    const long ntile_ = item_fast_ ? gridDim.y : gridDim.x;\n";
+    // item_fast_ > 1: COLUMN bands of that many tiles (late round 4; the tall forward's walk): blockIdx.x = (item, tile within the band),
+    // blockIdx.y = band -- the workgroups of one item stream item_fast_ consecutive tiles, the shared operand's band is re-used by every item from L2
+    s += "    const long band_ = item_fast_ > 1 ? item_fast_ : 1;\n";
+    s += "    const long item_ = item_fast_ ? blockIdx.x / band_ : blockIdx.y;\n";
+    s += "    const long tile_ = item_fast_ ? (long)blockIdx.y * band_ + blockIdx.x % band_ : blockIdx.x;\n";
+    s += "    const long ntile_ = item_fast_ ? (long)gridDim.y * band_ : gridDim.x;\n";
     s += "    const void *const *row_ = tbl_ + item_ * " + std::to_string(nvec + 1) + ";\n";
     s += "    R *dst_ = (R *)row_[0];\n";
     for (int k = 0; k < nvec; k++) s += "    const R *p" + std::to_string(k) + " = (const R *)row_[" + std::to_string(k + 1) + "];\n";
@@ -534,6 +538,13 @@ static int apply_many_batched(int count, const jh_bcast *const *progs, jh_bvec *
             if (shared) shared_mask |= 1 << j;
         }
         if (shared_mask && knob != 0 && (knob == 1 || (size_t)g.len * jh_dtype_size(bc->dtype) >= ((size_t)32 << 20))) item_fast = 1;
+        // ... in column bands of 32 tiles (128 KiB of every item at a time; knob bcast_band: tiles per band, 1 = the item-fastest order of round 3)
+        const int64_t band = jh_ctx().bcast_band > 0 ? jh_ctx().bcast_band : 32;
+        if (item_fast && band > 1 && gx >= 2 * band) {
+            item_fast = (int)band;
+            gx = (gx + band - 1) / band;                       // bands (blockIdx.y); blockIdx.x = item * band + tile within the band
+        }
+        const int64_t xmul = item_fast > 1 ? item_fast : 1;
         if (knob == 0) shared_mask = 0;                        // A/B: the plain kernel
         for (int k0 = 0; k0 < gcount; k0 += 65535) {
             const int gy = gcount - k0 < 65535 ? gcount - k0 : 65535;
@@ -542,7 +553,7 @@ static int apply_many_batched(int count, const jh_bcast *const *progs, jh_bvec *
             long n_arg = (long)n_scalars;
             void *args[5] = {&tbl_arg, &sc_arg, &n_arg, &item_fast, &shared_mask};
             if (item_fast)
-                JH_CHECK_HIP(hipModuleLaunchKernel(fns->fn_batched, (unsigned)gy, (unsigned)gx, 1, 256, 1, 1, 0, st, args, nullptr));
+                JH_CHECK_HIP(hipModuleLaunchKernel(fns->fn_batched, (unsigned)(gy * xmul), (unsigned)gx, 1, 256, 1, 1, 0, st, args, nullptr));
             else
                 JH_CHECK_HIP(hipModuleLaunchKernel(fns->fn_batched, (unsigned)gx, (unsigned)gy, 1, 256, 1, 1, 0, st, args, nullptr));
         }

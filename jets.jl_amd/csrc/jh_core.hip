@@ -948,6 +948,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "dense_fwd_wgs")) { JH_REQUIRE(value >= 0 && value <= 65536, "dense_fwd_wgs must be 0 (automatic) .. 65536"); c.dense_fwd_wgs = value; }
     else if (!strcmp(name, "dense_gw")) { JH_REQUIRE(value >= 0 && value <= 4096, "dense_gw must be 0 (automatic) or 1 .. 4096 children per wave"); c.dense_gw = value; }
     else if (!strcmp(name, "sum_group")) { JH_REQUIRE(value == 4 || value == 8 || value == 16, "sum_group must be 4, 8 or 16 terms per forward launch"); c.sum_group = value; }
+    else if (!strcmp(name, "bcast_band")) { c.bcast_band = value < 0 ? 0 : value; }
     else if (!strcmp(name, "general_band")) { JH_REQUIRE(value == 8 || value == 16 || value == 32 || value == 64, "general_band must be 8, 16, 32 or 64 tiles"); c.general_band = value; }
     else if (!strcmp(name, "fwd_ctiles")) { c.fwd_ctiles = value < -1 ? -1 : value; }
     else if (!strcmp(name, "sum_adj_group")) { c.sum_adj_group = value == 16 ? 16 : 8; }
@@ -991,6 +992,7 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "grid_diag")) *value = c.grid_diag;
     else if (!strcmp(name, "grid_tile")) *value = c.grid_tile;
     else if (!strcmp(name, "sum_group")) *value = c.sum_group;
+    else if (!strcmp(name, "bcast_band")) *value = c.bcast_band;
     else if (!strcmp(name, "general_band")) *value = c.general_band;
     else if (!strcmp(name, "fwd_ctiles")) *value = c.fwd_ctiles;
     else if (!strcmp(name, "sum_adj_group")) *value = c.sum_adj_group;

@@ -95,6 +95,7 @@ struct jh_context {
     int64_t grid_tile = 1;             // knob: ... register-tiled (k_grid_tile: R lines x one tile per workgroup): 1 automatic R, 2 / 4 / 8 that R, 0: k_grid_diag
     int64_t general_tile = 1;          // knob: grids of EQUAL elementwise blocks of any kinds register-tiled (k_general_tile: two lines x one tile per workgroup); 0: k_block_*_general_vec
     int64_t sum_group = 16;            // knob: terms of a fused JetSum per FORWARD launch (16; 8 / 4 = round 3's / round 2's grouping, for A/B); the adjoint takes 8 (4)
+    int64_t bcast_band = 0;            // knob: batched broadcasts with a shared operand in column bands of this many tiles (0: 32; 1: items fastest, no bands)
     int64_t general_band = 8;          // knob: tiles of every line the general M x K kernels walk before the next group of tiles starts: 8, 16, 32, 64
     int64_t fwd_ctiles = -1;           // knob: tall forward in column bands of this many tiles (-1: the shape's own, 0: none)
     int64_t sum_adj_group = 16;        // knob: terms of a fused JetSum ADJOINT per launch (each keeps its own accumulator): 16 (one row in flight; +1-2 % at 11-16 terms), or 8

@@ -498,3 +498,33 @@ def test_f_mode_of_big_dense_children_in_mixed_company_takes_two_launches(Jets, 
             J.tune(dense_mixed=1)
     assert_bits_equal(got[1], np.concatenate(ref), "f! with big dense children: batched route vs the oracle")
     assert_bits_equal(got[1], got[0], "f! with big dense children: batched route vs the per-block loop")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex128])
+def test_batched_broadcast_of_a_tall_nonlinear_operator_in_column_bands(Jets, dt):
+    """F(m) of a tall operator of elementwise children is ONE batched launch whose items share the model vector; for big children the items are the
+    fastest block index, in column bands of 32 tiles since late round 4 (jh_bcast.hip: item_fast_ > 1).  Forced here on small children
+    (knob bcast_item_fast = 1) with bands narrower than, equal to and wider than the vector's tile count, a ragged last tile: the same bits as the
+    item-by-item evaluation."""
+    J = Jets
+    nrow, n = 12, 70004                                            # 69 tiles of 256 packs (Float32), the last one ragged
+    spc = J.JetSpace(dt, n)
+    F = J.blockop([[J.JopElementwise(spc, "x0*x0 + x0", "2*x0 + 1")] for _ in range(nrow)])
+    rng = np.random.default_rng(5)
+    hm = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if np.dtype(dt).kind == "c" else 0)).astype(dt)
+    m = J.from_numpy(hm, spc)
+    with np.errstate(all="ignore"):
+        want = np.concatenate([hm * hm + hm] * nrow)
+    ref = J.mul(F, m).to_numpy()
+    try:
+        J.tune(bcast_item_fast=1)
+        for band in (1, 3, 32, 34, 1000):
+            J.tune(bcast_band=band)
+            d = J.zeros(J.range(F))
+            J.mul_(d, F, m)
+            got = d.to_numpy()
+            assert got.tobytes() == ref.tobytes(), f"bands of {band} tiles against the default order, {np.dtype(dt)}"
+            np.testing.assert_allclose(got, want, rtol=1e-5 if np.dtype(dt) == np.dtype(np.float32) else 1e-12)
+    finally:
+        J.tune(bcast_item_fast=-1, bcast_band=0)
+    J.close(F)

@@ -13,6 +13,8 @@ def timed(fn, reps=3):
 EXPR = os.environ.get("EXPR", "exp(x0)")
 if os.environ.get("ITEM_FAST"):
     J.tune(bcast_item_fast=int(os.environ["ITEM_FAST"]))
+if os.environ.get("BCAST_BAND"):
+    J.tune(bcast_band=int(os.environ["BCAST_BAND"]))              # tiles per column band of the batched broadcast (1: items fastest, no bands; 0: the default, 32)
 for nrow, n in ((256, 1 << 24), (64, 1 << 22), (1024, 1 << 18), (4096, 1 << 16), (16384, 1 << 14)):
     spc = J.JetSpace(np.float32, n)
     F = J.blockop([[J.JopElementwise(spc, EXPR, EXPR)] for _ in range(nrow)])
