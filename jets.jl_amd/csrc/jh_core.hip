@@ -390,6 +390,7 @@ static int ctx_destroy(int id)
     if (c->part_dev) (void)hipFree(c->part_dev);
     if (c->scratch_dev) (void)hipFree(c->scratch_dev);
     if (c->chain_sync) (void)hipFree(c->chain_sync);
+    if (c->bcast_last.dev) (void)hipFree(c->bcast_last.dev);
     if (c->red_host) (void)hipHostFree(c->red_host);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     {
@@ -474,6 +475,8 @@ int jh_require_ready()
     if (hipGetDevice(&cur) == hipSuccess && cur != c.device) JH_CHECK_HIP(hipSetDevice(c.device));
     return JH_OK;
 }
+
+std::atomic<int64_t> jh_bvec_generation{0};   // see jh_internal.h
 
 extern "C" {
 
@@ -743,6 +746,7 @@ int jh_bvec_destroy(jh_bvec *v)
         else (void)hipFree(v->data);
     }
     jh_handle_died(v->ctx);
+    jh_bvec_generation.fetch_add(1);                             // (cached device tables naming this handle's data are stale from here on)
     delete v;
     return JH_OK;
 }

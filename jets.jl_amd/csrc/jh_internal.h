@@ -60,6 +60,17 @@ struct jh_context {
     double *red_host = nullptr;        // pinned, 8 doubles
     double *part_dev = nullptr;        // growable per-workgroup partials of the fused solver updates
     int64_t part_cap = 0;
+    // the device tables of the latest batched broadcast (jh_bcast.hip: apply_many_batched), kept while the SAME batch is issued again
+    struct bcast_group { const struct jh_bcast *bc; int64_t len, gx; int gcount, item_fast, shared_mask; size_t tbl_at, sc_at; bool wide_scal; };
+    struct bcast_batch {
+        std::vector<const void *> key;       // progs, dsts, xs -- the argument arrays, element by element
+        std::vector<double> scal;
+        int count = -1;
+        int64_t gen = -1, knob_item = 0, knob_band = 0;
+        void *dev = nullptr;
+        size_t dev_cap = 0, tbl_bytes = 0;
+        std::vector<bcast_group> groups;
+    } bcast_last;
     void *scratch_dev = nullptr;       // growable scratch: dtmp / mtmp of the per-block loop (src/Jets.jl:1013, 1037)
     size_t scratch_cap = 0;
     unsigned *chain_sync = nullptr;    // chained one-pass step (k_tall_diag_bidiag_chain): [0] ticket counter, [1] unused, [2..] per-tile hand-off flags
@@ -360,6 +371,7 @@ int jh_launch_copy_bytes(void *dst, const void *src, size_t bytes);
 int jh_launch_hadamard_raw(void *dst, const void *x, const void *y, int dtype, int64_t count, int conj_x);
 // dst = (2 .* mo) .* x  (conj: conj.(2 .* mo) .* x): the Jacobian of d .= m.^2 about mo
 int jh_launch_square_jvp_raw(void *dst, const void *mo, const void *x, int dtype, int64_t count, int conj_mo);
+extern std::atomic<int64_t> jh_bvec_generation;   // bumped whenever a vector handle is created or destroyed (a handle never changes otherwise)
 int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const double *cre, const double *cim, const void *const *x, const int32_t *flags = nullptr);
 // dense child operator (jh_dense.hip): y = A x (rows) or y = A^H x / A^T x (cols); A column-major nr x nc
 int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, const void *x, int adjoint);

@@ -386,7 +386,11 @@ def JetBlock_f(d, m, *, ops, dom, rng, _native=None, **kw):  # :988-1008
     if nat is not None and not nat.host_f:
         return nat.f(d, m)  # one fused launch, same loop order and rounding
     nrow, ncol = ops.shape
-    if ncol == 1 and all(isinstance(op, JopNl) and op.jet.f is elementwise_f for op in ops.flat):
+    memo = _native.__dict__ if _native is not None else {}
+    all_elementwise = memo.get("all_elementwise")             # (decided once per operator: a loop over 16 384 children costs a millisecond per call)
+    if all_elementwise is None:
+        all_elementwise = memo["all_elementwise"] = ncol == 1 and all(isinstance(op, JopNl) and op.jet.f is elementwise_f for op in ops.flat)
+    if all_elementwise:
         from .broadcast import pack_many, run_packed   # every child's f! (1003) in one trip through the ABI (one launch when alike)
 
         packs = _native.__dict__.setdefault("fpacks", {}) if _native is not None else {}

@@ -528,3 +528,45 @@ def test_batched_broadcast_of_a_tall_nonlinear_operator_in_column_bands(Jets, dt
     finally:
         J.tune(bcast_item_fast=-1, bcast_band=0)
     J.close(F)
+
+
+def test_repeated_batched_broadcast_reuses_its_tables_and_notices_changes(Jets):
+    """F(m) of a tall nonlinear operator into the same vectors again and again goes straight to the launches (jh_bcast.hip: the device tables of
+    the last batch are kept while the argument arrays are the same and no vector handle has died since).  The tables hold POINTERS, so new
+    contents of m are seen; another destination, a destroyed handle, another model vector all rebuild them."""
+    import gc
+
+    J = Jets
+    nrow, n = 64, 4096
+    spc = J.JetSpace(np.float32, n)
+    F = J.blockop([[J.JopElementwise(spc, "x0*x0 + x0", "2*x0 + 1")] for _ in range(nrow)])
+    rng = np.random.default_rng(9)
+
+    def check(d, m, hm, what):
+        J.mul_(d, F, m)
+        got = d.to_numpy()
+        want = np.concatenate([hm * hm + hm] * nrow)
+        assert got.tobytes() == want.tobytes(), what
+
+    hm = rng.standard_normal(n).astype(np.float32)
+    m = J.from_numpy(hm, spc)
+    d = J.zeros(J.range(F))
+    check(d, m, hm, "first call (tables built)")
+    check(d, m, hm, "second call (tables re-used)")
+    hm2 = rng.standard_normal(n).astype(np.float32)
+    m.assign(hm2)                                                  # same handle, new contents
+    check(d, m, hm2, "new contents of m through the kept tables")
+    d2 = J.zeros(J.range(F))
+    check(d2, m, hm2, "another destination")
+    check(d, m, hm2, "back to the first destination")
+    scratch = J.zeros(spc)
+    scratch.close()                                                # a handle died: the kept tables are not trusted any more
+    check(d, m, hm2, "after an unrelated vector was destroyed")
+    d.close()
+    del d
+    gc.collect()
+    d3 = J.zeros(J.range(F))                                       # may well get d's slab and d's handle address back
+    m3 = J.from_numpy(hm, spc)
+    check(d3, m3, hm, "a new destination and a new model vector")
+    check(d3, m3, hm, "and again")
+    J.close(F)
