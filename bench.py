@@ -626,8 +626,14 @@ def worker_ranks(args):
     # in every process (jets.jl_amd/placement.py, profiles/exp_r03_swap_roles.txt).  Same values either way (seeded by element index).
     spare = []                                                             # world == 1: the candidates not kept stay for the allocation-order leg below
     if args.placement == "probe":
-        coeff, d, placement = J.stream_pair(Rloc, candidates=args.placement_candidates, keep_all=(world == 1))
+        # (with a solver section on the command line nothing spare is kept: a third live 64 GiB vector beside a solver's own copy of b
+        # can exhaust the device, and the allocation-order leg is then left out -- round-4 advisor finding)
+        solver_sections = bool(args.lsqr or args.cgls or args.cgnr)
+        coeff, d, placement = J.stream_pair(Rloc, candidates=args.placement_candidates, keep_all=(world == 1 and not solver_sections))
         spare = placement.pop("all", [])
+        for k, v in enumerate(spare):                                      # the leg needs candidates 0 and 1 only
+            if k >= 2 and v is not coeff and v is not d:
+                v.close()
         J.rand_(coeff, seed=1, stream=0, index_base=part.first * n)        # all diagonals of this rank: one slab
         J.rand_(d, seed=3, stream=0, index_base=part.first * n)
     else:
@@ -870,6 +876,9 @@ def worker_ranks(args):
     # as the coefficient slab, the second as the range vector, its own operator (and lazy walk measurement), warm-up, then the same
     # number of timed steps -- outside the headline's timed region, so that both figures are on the driver's line.
     placement_none = None
+    # what the HEADLINE's forward ran, read before the leg below launches anything (the context's last_* knobs describe the latest launch)
+    fwd_grid_walk_hl = ("column-persistent (a workgroup streams every block row)" if J.tune_get("last_fwd_rows_per_wg") >= nloc
+                        else {0: "sequential row sweep", 1: "all rows concurrent"}.get(J.tune_get("last_fwd_walk"), "banded"))
     if world == 1 and placement.get("probed") and len(spare) >= 2:
         fwd_walk_hl = J.op_tune_get(A, "fwd_walk")
         if placement.get("kept") == [0, 1]:
@@ -928,8 +937,7 @@ def worker_ranks(args):
                 "workload": f"{nblocks}x1 tall JopBlock of diagonal JopLn, {edge}^3 Float32 blocks, fwd+adj mul! pair",
                 "nblocks": nblocks, "block": [edge, edge, edge], "rows_per_gpu": nloc,
                 "parallelism": f"row-partition x{world}" + (f" + {os.environ.get('BENCH_BACKEND', 'RCCL')} all-reduce({n * s / 2**20:.0f} MiB, pipelined in 4 chunks) in adjoint" if world > 1 else ""),
-                "fwd_grid_walk": ("column-persistent (a workgroup streams every block row)" if J.tune_get("last_fwd_rows_per_wg") >= nloc
-                                  else {0: "sequential row sweep", 1: "all rows concurrent"}.get(J.tune_get("last_fwd_walk"), "banded")),
+                "fwd_grid_walk": fwd_grid_walk_hl,
                 "fwd_walk_choice": {"candidate": fwd_walk_hl, "setup_forward_calls": setup_forwards},
                 "placement": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in placement.items()},
                 "tune": {k: J.tune_get(k) for k in ("fwd_group", "fwd_unroll", "fwd_wg", "fwd_order", "adj_unroll", "adj_depth", "adj_wg", "nt", "autotune")},

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define JETSHIP_ABI_VERSION 2   /* 2 (round 4): jh_block_desc.scale_flags, jh_lincomb_typed */
+#define JETSHIP_ABI_VERSION 3   /* 2 (round 4): jh_block_desc.scale_flags, jh_lincomb_typed; 3 (round 5): jh_blocksum_mul[_adj]_typed */
 
 typedef enum {
     JH_OK = 0,
@@ -302,6 +302,16 @@ int jh_blockop_normal_mul_range(const jh_blockop *op, jh_bvec *y, const jh_bvec 
  * chain (one temporary + one accumulate pass per term).  sign_k is +1 or -1, scale_k = 1 for a bare operator. */
 int jh_blocksum_mul(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, jh_bvec *d, const jh_bvec *m);
 int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, jh_bvec *m, const jh_bvec *d);
+/* The same with the scalars' TYPES (nterms x JH_SCALAR_*; NULL: the two calls above, every scale_k taken in the element type).  The
+ * reference's own example `A = 1.0*A1 - 2.0*A2 + 3.0*A3` (src/Jets.jl:686, 703) on Float32 operators has Float64 scalars: Julia's scalar
+ * stage `d .= a * tmp` (1159) / `tmp .= conj(a) * d` (1160) is then the promoted product rounded once.  JH_SCALAR_WIDE on a term makes
+ * the launch take the WIDE instantiations of the sum kernels (that stage as Float32(a * Float64(x)) per element; terms without the flag
+ * keep T(a) -- for them both formulas round the same exact product): still ONE pass, the bits of the unfused chain.  The flag is ignored
+ * for 64-bit elements.  JH_SCALAR_COMPLEX: JH_ERR_UNSUPPORTED (the unfused chain, whose scalar stage is jh_lincomb_typed). */
+int jh_blocksum_mul_typed(int nterms, const jh_blockop *const *ops, const double *scale, const int32_t *scale_flags, const double *sign,
+                          jh_bvec *d, const jh_bvec *m);
+int jh_blocksum_mul_adj_typed(int nterms, const jh_blockop *const *ops, const double *scale, const int32_t *scale_flags, const double *sign,
+                              jh_bvec *m, const jh_bvec *d);
 
 /* Fused solver updates (the two halves of an LSQR / CGLS iteration; callers: IterativeSolvers-style loops over
  * vec(A), src/Jets.jl:1138-1154).  d = alpha*(A m) + beta*d  /  m = alpha*(A' d) + beta*m  with real alpha, beta,

@@ -44,7 +44,7 @@ class BlockDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 2                      # JETSHIP_ABI_VERSION of include/jetship.h
+ABI_VERSION = 3                      # JETSHIP_ABI_VERSION of include/jetship.h
 SCALAR_COMPLEX, SCALAR_WIDE = 1, 2   # JH_SCALAR_* of include/jetship.h
 
 
@@ -147,6 +147,8 @@ SYMBOLS = {
     "jh_blockop_normal_mul": (_int, [_vp, _vp, _vp]),
     "jh_blocksum_mul": (_int, [_int, _vpp, _dblp, _dblp, _vp, _vp]),
     "jh_blocksum_mul_adj": (_int, [_int, _vpp, _dblp, _dblp, _vp, _vp]),
+    "jh_blocksum_mul_typed": (_int, [_int, _vpp, _dblp, C.POINTER(C.c_int32), _dblp, _vp, _vp]),
+    "jh_blocksum_mul_adj_typed": (_int, [_int, _vpp, _dblp, C.POINTER(C.c_int32), _dblp, _vp, _vp]),
     "jh_blockop_mul_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
     "jh_blockop_mul_adj_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _dblp]),
     "jh_blockop_mul_scaled": (_int, [_vp, _vp, _vp, C.c_double, _int]),

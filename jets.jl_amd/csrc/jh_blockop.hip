@@ -78,7 +78,7 @@ __device__ inline V apply_block_loaded(const jh_dev_block &b, V x, V c, bool tra
         if (fmode && !b.adjoint) return vmul<S, E, NS, V>(x, x, false);
         return vmul<S, E, NS, V>(c + c, x, cj);
     case JH_OP_SCALE: {
-        if (E == 1 || b.sim != b.sim) {                 // a REAL scalar (sim = NaN, jh_dev_block_of) multiplies part by part (Julia's a::Real * z)
+        if (E == 1 || b.real_scale) {                   // a REAL scalar (jh_dev_block_of) multiplies part by part (Julia's a::Real * z)
             return (V)(S)b.sre * x;
         } else {                                        // a Complex one: the full product, also when its imaginary part is zero
             V a;
@@ -1019,7 +1019,13 @@ struct SumArgs {
     int k;
 };
 
-template <typename S, int E, int NS, int U, int BLK, int KM, int D>
+// WIDE (S = float; round 5): some scale_k is Julia's Float64 (JH_SCALAR_WIDE: `1.0*A1 - 2.0*A2 + 3.0*A3` on Float32 operators, the reference's
+// own docstring example, src/Jets.jl:686) -- the scalar stage `_d .= a * tmp` (1159) is then the promoted product rounded once,
+// Float32(a * Float64(tmp)); the signed add stays a Float32 add (`broadcast!(sgn, d, d, _d)`, 644).  EVERY term of such a launch is
+// computed that way with scale_k as a double: for a scalar that is T(a) in Julia the host passes double(T(a)), and
+// Float32(double(a32) * Float64(x)) == a32 * x in Float32 arithmetic (the Float64 product of two Float32 values is exact, so both
+// round the exact product once) -- one instantiation serves sums that mix wide and narrow scalars, with the chain's bits.
+template <typename S, int E, int NS, int U, int BLK, int KM, int D, bool WIDE = false>
 __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow, int rows_per_wg, const S *__restrict__ m,
                                                       S *__restrict__ d, int64_t n_scalars, unsigned ntiles, int accumulate)
 {
@@ -1066,7 +1072,14 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow
                 for (int t = 0; t < KM; t++)
                     if (t < args.k) {
                         V prod = vmul<S, E, NS, V>(av[j][t][k], mv[k], false);       // mul!(_d, A_t, m)
-                        V term = (V)(S)(args.sign[t] * args.scale[t]) * prod;        // (s_t * .) then the sign: -(s*x) == (-s)*x exactly
+                        V term;
+                        if constexpr (WIDE) {
+                            const double sd = args.sign[t] * args.scale[t];          // -(Float32(s*x)) == Float32((-s)*x) exactly
+#pragma unroll
+                            for (int e = 0; e < NS; e++) term[e] = (S)(sd * (double)prod[e]);
+                        } else {
+                            term = (V)(S)(args.sign[t] * args.scale[t]) * prod;      // (s_t * .) then the sign: -(s*x) == (-s)*x exactly
+                        }
                         acc = acc + term;                                            // broadcast!(sgn, d, d, _d)
                     }
                 if (ok[k] && i + j < i1) st<true>(reinterpret_cast<V *>(d + (i + j) * n_scalars + sk[k]), acc);
@@ -1074,7 +1087,8 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow
     }
 }
 
-template <typename S, int E, int NS, int U, int DEPTH, int BLK, int KM>
+// WIDE: as in the forward -- the adjoint's scalar stage `tmp .= conj(a) * d` (1160) is Float32(a * Float64(d_i)) per element
+template <typename S, int E, int NS, int U, int DEPTH, int BLK, int KM, bool WIDE = false>
 __global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow, S *__restrict__ out, const S *__restrict__ in,
                                                       int64_t n_scalars, int accumulate)
 {
@@ -1115,7 +1129,14 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow
                     if (t < args.k) {
 #pragma unroll
                         for (int k = 0; k < U; k++) {
-                            V p = vmul<S, E, NS, V>(av[j][t][k], (V)(S)args.scale[t] * dv[j][k], true);   // conj(a_i) .* (s_t * d_i)
+                            V sd;
+                            if constexpr (WIDE) {
+#pragma unroll
+                                for (int e = 0; e < NS; e++) sd[e] = (S)(args.scale[t] * (double)dv[j][k][e]);
+                            } else {
+                                sd = (V)(S)args.scale[t] * dv[j][k];
+                            }
+                            V p = vmul<S, E, NS, V>(av[j][t][k], sd, true);                                // conj(a_i) .* (s_t * d_i)
                             acc[t][k] = direct ? p : acc[t][k] + p;
                         }
                     }
@@ -1184,7 +1205,7 @@ __device__ inline elem<S, E> apply_block(const jh_dev_block &b, elem<S, E> x, in
         elem<S, E> a;
         a.re = (S)b.sre;
         a.im = (E == 2) ? (cj ? -(S)b.sim : (S)b.sim) : (S)0;
-        if (E == 2 && b.sim != b.sim) {                // a REAL scalar (sim = NaN) multiplies part by part (Julia's a::Real * z)
+        if (E == 2 && b.real_scale) {                  // a REAL scalar multiplies part by part (Julia's a::Real * z)
             x.re = a.re * x.re;
             x.im = a.re * x.im;
             return x;
@@ -2028,6 +2049,17 @@ const int k_fwd_trial_order[K_FWD_CANDIDATES_TALL] = {7, 6, 1, 4, 3, 2, 0, 5};
 const int k_fwd_trial_order_few[K_FWD_CANDIDATES] = {8, 9, 7, 6, 1, 4, 3, 2, 0, 5};
 // (the bands also for >= 1024 rows of blocks below 64 MiB: 1024 x 128^3 with a non-diagonal row runs its banded forward + adjoint pair at 6.55 TB/s
 // where the all-diagonal operator's best of eight gave 6.31)
+// The shape candidate k RUNS on rows of `nvec` 16-byte packs -- in a trial, once chosen, in the periodic re-check and when an operator inherits
+// the choice (walk memory): the column-persistent walk (candidate 5) has one workgroup per 128 KiB of a ROW, so with small blocks it is a
+// handful of workgroups walking thousands of rows (4096 x 64^3: 17.8 ms where the others take 1.4-1.7) -- there candidate 5 IS candidate 0's
+// shape, everywhere, so a timing of "5" is always a timing of what a choice of 5 would run (round-4 advisor finding: the trial alone was
+// substituted, and a tie or play-off won by 5 then ran the real column-persistent walk for ~192 calls until the re-check rotated it out)
+static inline TallShape fwd_candidate_shape(int k, int64_t nvec)
+{
+    if (k == 5 && nvec < (int64_t)512 * 1024 * 8) return k_fwd_candidates[0];
+    return k_fwd_candidates[k];
+}
+
 static inline int fwd_candidates_of(const jh_blockop *op)
 {
     const bool small_blocks = (double)op->row_len[0] * (double)jh_dtype_size(op->dtype) < (double)(64u << 20);
@@ -2237,22 +2269,19 @@ int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scal
             if (!stream_is_capturing(c.stream)) {
                 const int nc = fwd_candidates_of(op);
                 const int k = lazy_next(op->fwd_tune, nc, 2, 0, 0.f, &op->fwd_walk, &slot, true, nc == K_FWD_CANDIDATES ? k_fwd_trial_order_few : k_fwd_trial_order);
-                if (k >= 0 && k < K_FWD_CANDIDATES) sh = k_fwd_candidates[k];
-                // the column-persistent walk (candidate 5) has one workgroup per 128 KiB of a ROW: with small blocks that is a handful of
-                // workgroups walking thousands of rows (4096 x 64^3: 17.8 ms where the others take 1.4-1.7) -- such a trial runs candidate 0's shape
-                if (k == 5 && n_scalars / NS < (int64_t)512 * 1024 * 8) sh = k_fwd_candidates[0];
+                if (k >= 0 && k < K_FWD_CANDIDATES) sh = fwd_candidate_shape(k, n_scalars / NS);
                 if (op->fwd_walk >= 0) walk_remember(op, n_scalars);       // the choice has just been made
             }
         } else if (op->fwd_walk < K_FWD_CANDIDATES) {
             if (!stream_is_capturing(c.stream) && recheck_should_time(op->fwd_tune, fwd_candidates_of(op), &op->fwd_walk)) {
                 walk_remember(op, n_scalars);                              // (the re-check may have rotated another candidate in)
-                sh = k_fwd_candidates[op->fwd_walk];
+                sh = fwd_candidate_shape(op->fwd_walk, n_scalars / NS);
                 const bool ok = recheck_begin(op->fwd_tune, c.stream);
                 const int st = launch_tall_fwd_shape<S, E, NS>(op, d, m, n_scalars, sh);
                 recheck_end(op->fwd_tune, c.stream, ok && st == JH_OK);
                 return st;
             }
-            sh = k_fwd_candidates[op->fwd_walk];
+            sh = fwd_candidate_shape(op->fwd_walk, n_scalars / NS);
         }
         if (slot >= 0) {                                                   // a timed trial: the caller's own launch between two events
             const bool ok = lazy_begin(op->fwd_tune, slot, c.stream);
@@ -3840,8 +3869,10 @@ int jh_blockop_normal_mul_range(const jh_blockop *op, jh_bvec *y, const jh_bvec 
 
 }  // extern "C" (templated launch helpers of the fused sum follow)
 
+// *wide (optional): set when a term's scale carries JH_SCALAR_WIDE and the elements are 32-bit -- the launch then takes the WIDE
+// instantiation and every scale that is NOT wide goes in as double(Float32(a)) (see k_tall_sum_fwd)
 static int sum_prepare(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, const jh_bvec *rng,
-                       const jh_bvec *dom, SumArgs &a, const char *who)
+                       const jh_bvec *dom, SumArgs &a, const char *who, const int32_t *flags = nullptr, bool *wide = nullptr)
 {
     JH_REQUIRE(ops && scale && sign && rng && dom, "%s: null argument", who);
     JH_REQUIRE(nterms >= 1 && nterms <= JH_SUM_MAX, "%s: %d terms in one group (1..%d)", who, nterms, JH_SUM_MAX);
@@ -3860,13 +3891,25 @@ static int sum_prepare(int nterms, const jh_blockop *const *ops, const double *s
         a.a_stride[t] = op->diag_stride_elems * (jh_dtype_complex(op->dtype) ? 2 : 1);
         a.scale[t] = scale[t];
         a.sign[t] = sign[t];
+        if (flags) {
+            JH_REQUIRE((flags[t] & ~(JH_SCALAR_COMPLEX | JH_SCALAR_WIDE)) == 0, "%s: unknown scale flags %d on term %d", who, flags[t], t);
+            if (flags[t] & JH_SCALAR_COMPLEX) return jh_fail(JH_ERR_UNSUPPORTED, "%s: a Complex scale (term %d) takes the unfused chain", who, t);
+        }
     }
+    const bool narrow = ops[0]->dtype == JH_F32 || ops[0]->dtype == JH_C32;
+    bool any_wide = false;
+    if (flags && narrow)
+        for (int t = 0; t < nterms; t++) any_wide = any_wide || (flags[t] & JH_SCALAR_WIDE);
+    if (any_wide)
+        for (int t = 0; t < nterms; t++)
+            if (!(flags[t] & JH_SCALAR_WIDE)) a.scale[t] = (double)(float)scale[t];   // T(a), exactly representable: same bits either way
+    if (wide) *wide = any_wide;
     for (int t = nterms; t < JH_SUM_MAX; t++) { a.blocks[t] = nullptr; a.a_base[t] = nullptr; a.a_stride[t] = 0; a.scale[t] = 0; a.sign[t] = 0; }
     return JH_OK;
 }
 
 template <typename S, int E, int NS>
-static int sum_fwd_launch(const SumArgs &a, const jh_blockop *op0, void *d, const void *m, int64_t n_scalars, int accumulate)
+static int sum_fwd_launch(const SumArgs &a, const jh_blockop *op0, void *d, const void *m, int64_t n_scalars, int accumulate, bool wide = false)
 {
     jh_context &c = jh_ctx();
     constexpr int BLK = 256;
@@ -3883,15 +3926,22 @@ static int sum_fwd_launch(const SumArgs &a, const jh_blockop *op0, void *d, cons
     int64_t gy = (op0->nrow + G - 1) / G;
     while (gx * gy * BLK >= ((int64_t)1 << 32) && G < op0->nrow) { G *= 2; gy = (op0->nrow + G - 1) / G; }
     JH_REQUIRE(gx * gy * BLK < ((int64_t)1 << 32), "fused sum forward: grid too large");
-    if (a.k > 8)
-        hipLaunchKernelGGL((k_tall_sum_fwd<S, E, NS, 1, BLK, 16, 1>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G,
-                           (const S *)m, (S *)d, n_scalars, (unsigned)gx, accumulate);
-    else if (a.k > 4)
-        hipLaunchKernelGGL((k_tall_sum_fwd<S, E, NS, 2, BLK, 8, 1>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G,
-                           (const S *)m, (S *)d, n_scalars, (unsigned)gx, accumulate);
-    else
-        hipLaunchKernelGGL((k_tall_sum_fwd<S, E, NS, 2, BLK, 4, 1>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G,
-                           (const S *)m, (S *)d, n_scalars, (unsigned)gx, accumulate);
+#define JH_SUM_FWD(UU, KM, WD)                                                                                                           \
+    hipLaunchKernelGGL((k_tall_sum_fwd<S, E, NS, UU, BLK, KM, 1, WD>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G, \
+                       (const S *)m, (S *)d, n_scalars, (unsigned)gx, accumulate)
+    if constexpr (sizeof(S) == 4) {
+        if (wide) {                                                         // a Float64 scale on 32-bit elements: promoted products (k_tall_sum_fwd)
+            if (a.k > 8) JH_SUM_FWD(1, 16, true);
+            else if (a.k > 4) JH_SUM_FWD(2, 8, true);
+            else JH_SUM_FWD(2, 4, true);
+            JH_CHECK_HIP(hipGetLastError());
+            return JH_OK;
+        }
+    }
+    if (a.k > 8) JH_SUM_FWD(1, 16, false);
+    else if (a.k > 4) JH_SUM_FWD(2, 8, false);
+    else JH_SUM_FWD(2, 4, false);
+#undef JH_SUM_FWD
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -3914,7 +3964,7 @@ static int sum_adj_split(int nterms, const jh_blockop *const *ops, const double 
 }
 
 template <typename S, int E, int NS>
-static int sum_adj_launch(const SumArgs &a, const jh_blockop *op0, void *m, const void *d, int64_t n_scalars, int accumulate)
+static int sum_adj_launch(const SumArgs &a, const jh_blockop *op0, void *m, const void *d, int64_t n_scalars, int accumulate, bool wide = false)
 {
     jh_context &c = jh_ctx();
     c.last_adj_parts = 1;
@@ -3922,15 +3972,22 @@ static int sum_adj_launch(const SumArgs &a, const jh_blockop *op0, void *m, cons
     const int U = a.k > 4 ? 1 : 2;
     const int64_t nvec = n_scalars / NS;
     const int64_t gx = (nvec + (int64_t)BLK * U - 1) / ((int64_t)BLK * U);
-    if (a.k > 8)                                                            // sixteen accumulators, one row in flight (knob sum_adj_group = 16)
-        hipLaunchKernelGGL((k_tall_sum_adj<S, E, NS, 1, 1, BLK, 16>), dim3((unsigned)gx), dim3(BLK), 0, c.stream, a, op0->nrow, (S *)m,
-                           (const S *)d, n_scalars, accumulate);
-    else if (a.k > 4)
-        hipLaunchKernelGGL((k_tall_sum_adj<S, E, NS, 1, DEPTH, BLK, 8>), dim3((unsigned)gx), dim3(BLK), 0, c.stream, a, op0->nrow, (S *)m,
-                           (const S *)d, n_scalars, accumulate);
-    else
-        hipLaunchKernelGGL((k_tall_sum_adj<S, E, NS, 2, DEPTH, BLK, 4>), dim3((unsigned)gx), dim3(BLK), 0, c.stream, a, op0->nrow, (S *)m,
-                           (const S *)d, n_scalars, accumulate);
+#define JH_SUM_ADJ_K(UU, DD, KM, WD)                                                                                                  \
+    hipLaunchKernelGGL((k_tall_sum_adj<S, E, NS, UU, DD, BLK, KM, WD>), dim3((unsigned)gx), dim3(BLK), 0, c.stream, a, op0->nrow, (S *)m, \
+                       (const S *)d, n_scalars, accumulate)
+    if constexpr (sizeof(S) == 4) {
+        if (wide) {
+            if (a.k > 8) JH_SUM_ADJ_K(1, 1, 16, true);
+            else if (a.k > 4) JH_SUM_ADJ_K(1, DEPTH, 8, true);
+            else JH_SUM_ADJ_K(2, DEPTH, 4, true);
+            JH_CHECK_HIP(hipGetLastError());
+            return JH_OK;
+        }
+    }
+    if (a.k > 8) JH_SUM_ADJ_K(1, 1, 16, false);                             // sixteen accumulators, one row in flight (knob sum_adj_group = 16)
+    else if (a.k > 4) JH_SUM_ADJ_K(1, DEPTH, 8, false);
+    else JH_SUM_ADJ_K(2, DEPTH, 4, false);
+#undef JH_SUM_ADJ_K
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -3941,6 +3998,16 @@ extern "C" {
 // holds -- the unfused chain's sequence ((0 +- t1) +- t2) +- ... whatever the grouping.
 int jh_blocksum_mul(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, jh_bvec *d, const jh_bvec *m)
 {
+    return jh_blocksum_mul_typed(nterms, ops, scale, nullptr, sign, d, m);
+}
+
+// scale_flags (nterms x JH_SCALAR_*, or NULL: every scale is taken in the element type): the Julia TYPE of each term's scalar.  A
+// Float64 scale against 32-bit elements (JH_SCALAR_WIDE) keeps the sum fused -- the WIDE instantiations of the sum kernels compute that
+// term's scalar stage as the promoted product rounded once, the bits of the unfused chain (jh_blockop_mul, jh_lincomb_typed, signed add);
+// a Complex scale (JH_SCALAR_COMPLEX) is JH_ERR_UNSUPPORTED: the unfused chain.
+int jh_blocksum_mul_typed(int nterms, const jh_blockop *const *ops, const double *scale, const int32_t *scale_flags, const double *sign,
+                          jh_bvec *d, const jh_bvec *m)
+{
     JH_TRY(jh_enter(d, m));
     JH_REQUIRE(ops && scale && sign && d && m, "jh_blocksum_mul: null argument");
     JH_REQUIRE(nterms >= 1 && nterms <= 4096, "jh_blocksum_mul: %d terms (1..4096 supported)", nterms);
@@ -3948,7 +4015,7 @@ int jh_blocksum_mul(int nterms, const jh_blockop *const *ops, const double *scal
         JH_REQUIRE(ops[t], "jh_blocksum_mul: null operator %d", t);
         JH_REQUIRE(ops[t]->ctx == d->ctx, "jh_blocksum_mul: operator %d lives in context %d, the vectors in %d", t, ops[t]->ctx, d->ctx);
         SumArgs probe;
-        JH_TRY(sum_prepare(1, ops + t, scale + t, sign + t, d, m, probe, "jh_blocksum_mul"));
+        JH_TRY(sum_prepare(1, ops + t, scale + t, sign + t, d, m, probe, "jh_blocksum_mul", scale_flags ? scale_flags + t : nullptr));
         JH_REQUIRE(ops[t]->nrow == ops[0]->nrow && ops[t]->row_len[0] == ops[0]->row_len[0] && ops[t]->dtype == ops[0]->dtype,
                    "jh_blocksum_mul: term %d has a different shape or element type", t);
     }
@@ -3957,13 +4024,14 @@ int jh_blocksum_mul(int nterms, const jh_blockop *const *ops, const double *scal
     for (int t0 = 0; t0 < nterms; t0 += group) {
         const int k = nterms - t0 < group ? nterms - t0 : group;
         SumArgs a;
-        JH_TRY(sum_prepare(k, ops + t0, scale + t0, sign + t0, d, m, a, "jh_blocksum_mul"));
+        bool wide = false;
+        JH_TRY(sum_prepare(k, ops + t0, scale + t0, sign + t0, d, m, a, "jh_blocksum_mul", scale_flags ? scale_flags + t0 : nullptr, &wide));
         const int acc = t0 > 0 ? 1 : 0;
         int st = JH_OK;
         switch (ops[0]->dtype) {
-        case JH_F32: st = sum_fwd_launch<float, 1, 4>(a, ops[0], d->data, m->data, n, acc); break;
+        case JH_F32: st = sum_fwd_launch<float, 1, 4>(a, ops[0], d->data, m->data, n, acc, wide); break;
         case JH_F64: st = sum_fwd_launch<double, 1, 2>(a, ops[0], d->data, m->data, n, acc); break;
-        case JH_C32: st = sum_fwd_launch<float, 2, 4>(a, ops[0], d->data, m->data, 2 * n, acc); break;
+        case JH_C32: st = sum_fwd_launch<float, 2, 4>(a, ops[0], d->data, m->data, 2 * n, acc, wide); break;
         case JH_C64: st = sum_fwd_launch<double, 2, 2>(a, ops[0], d->data, m->data, 2 * n, acc); break;
         default: return jh_fail(JH_ERR_INVALID, "jh_blocksum_mul: unknown dtype");
         }
@@ -3974,6 +4042,12 @@ int jh_blocksum_mul(int nterms, const jh_blockop *const *ops, const double *scal
 
 int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *scale, const double *sign, jh_bvec *m, const jh_bvec *d)
 {
+    return jh_blocksum_mul_adj_typed(nterms, ops, scale, nullptr, sign, m, d);
+}
+
+int jh_blocksum_mul_adj_typed(int nterms, const jh_blockop *const *ops, const double *scale, const int32_t *scale_flags, const double *sign,
+                              jh_bvec *m, const jh_bvec *d)
+{
     JH_TRY(jh_enter(m, d));
     JH_REQUIRE(ops && scale && sign && d && m, "jh_blocksum_mul_adj: null argument");
     JH_REQUIRE(nterms >= 1 && nterms <= 4096, "jh_blocksum_mul_adj: %d terms (1..4096 supported)", nterms);
@@ -3981,22 +4055,26 @@ int jh_blocksum_mul_adj(int nterms, const jh_blockop *const *ops, const double *
         JH_REQUIRE(ops[t], "jh_blocksum_mul_adj: null operator %d", t);
         JH_REQUIRE(ops[t]->ctx == d->ctx, "jh_blocksum_mul_adj: operator %d lives in context %d, the vectors in %d", t, ops[t]->ctx, d->ctx);
         SumArgs probe;
-        JH_TRY(sum_prepare(1, ops + t, scale + t, sign + t, d, m, probe, "jh_blocksum_mul_adj"));
+        JH_TRY(sum_prepare(1, ops + t, scale + t, sign + t, d, m, probe, "jh_blocksum_mul_adj", scale_flags ? scale_flags + t : nullptr));
         JH_REQUIRE(ops[t]->nrow == ops[0]->nrow && ops[t]->row_len[0] == ops[0]->row_len[0] && ops[t]->dtype == ops[0]->dtype,
                    "jh_blocksum_mul_adj: term %d has a different shape or element type", t);
     }
     const int64_t n = ops[0]->row_len[0];
     const int group = jh_ctx().sum_group == 4 ? 4 : (jh_ctx().sum_adj_group == 16 ? JH_SUM_MAX : JH_SUM_ADJ_MAX);   // (each term keeps its own accumulator in the adjoint: eight per launch; knob sum_adj_group = 16: sixteen)
     void *tmp = nullptr;
+    bool any_wide = false;
+    if (scale_flags && (ops[0]->dtype == JH_F32 || ops[0]->dtype == JH_C32))
+        for (int t = 0; t < nterms; t++) any_wide = any_wide || (scale_flags[t] & JH_SCALAR_WIDE);
     switch (ops[0]->dtype) {
 #define JH_SUM_ADJ(S, E, NS, NSCAL)                                                                         \
-    JH_TRY((split_adjoint_tmp<S, NS>(ops[0], NSCAL, &tmp)));                                              \
+    if (!any_wide) JH_TRY((split_adjoint_tmp<S, NS>(ops[0], NSCAL, &tmp)));   /* (a wide scale is applied per d_i before the sum: the ordered walk) */ \
     if (tmp) return sum_adj_split<S, E, NS>(nterms, ops, scale, sign, m->data, d->data, NSCAL, tmp);      \
     for (int t0 = 0; t0 < nterms; t0 += group) {                                                            \
         const int k = nterms - t0 < group ? nterms - t0 : group;                                            \
         SumArgs a;                                                                                          \
-        JH_TRY(sum_prepare(k, ops + t0, scale + t0, sign + t0, d, m, a, "jh_blocksum_mul_adj"));          \
-        JH_TRY((sum_adj_launch<S, E, NS>(a, ops[0], m->data, d->data, NSCAL, t0 > 0 ? 1 : 0)));             \
+        bool wide = false;                                                                                  \
+        JH_TRY(sum_prepare(k, ops + t0, scale + t0, sign + t0, d, m, a, "jh_blocksum_mul_adj", scale_flags ? scale_flags + t0 : nullptr, &wide)); \
+        JH_TRY((sum_adj_launch<S, E, NS>(a, ops[0], m->data, d->data, NSCAL, t0 > 0 ? 1 : 0, wide)));       \
     }                                                                                                       \
     return JH_OK;
     case JH_F32: JH_SUM_ADJ(float, 1, 4, n)

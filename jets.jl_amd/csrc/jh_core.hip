@@ -213,6 +213,20 @@ void jh_slab_free(int device, void *p, size_t bytes, hipStream_t st)
         // vectors under them), a stream the application installed with jh_set_stream and replaced since, torch / RCCL streams on a
         // wrapped vector.  Microseconds on an idle device, against the seconds the re-used slab saves.  (The device is current: both
         // callers come through jh_quiesce_scope / the vector's own context.)
+        // While `st` is being captured into a graph neither is possible (the synchronisation would invalidate the capture, the probe's
+        // fills would land in the graph): such a slab goes back to the driver like a small one (round-4 advisor finding).
+        if (st) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+                (void)hipGetLastError();
+                {
+                    std::lock_guard<std::mutex> lock(g_slab_mutex);
+                    slab_forget(p);
+                }
+                (void)hipFree(p);
+                return;
+            }
+        }
         (void)hipDeviceSynchronize();
         if (bytes >= SLAB_PROBE_MIN && st) {                  // how fast can this slab be written?  (once per slab: see g_slab_fill_ms_per_gib)
             bool known;
@@ -348,6 +362,7 @@ static int ctx_create(int device, bool primary, int *id_out)
         return jh_fail(JH_ERR_UNSUPPORTED, "jh_init: device %d is %s; libjetship is built for gfx950 (MI355X) only", device,
                        prop.gcnArchName);
     jh_context *c = new jh_context();
+    c->device = device;                                       // (before the first jh_device_malloc: its evict-and-retry looks in THIS device's slab cache)
     auto fail = [&](hipError_t e, const char *what) {
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
         if (c->red_dev) (void)hipFree(c->red_dev);

@@ -197,14 +197,18 @@ struct jh_event {
 // one entry per block, device-resident, column-major nrow x ncol
 struct jh_dev_block {
     const void *coeff;
-    double sre, sim;     // SCALE: the scalar; sim is NaN for a REAL scalar (see jh_dev_block_of)
-    int32_t kind;
+    double sre, sim;     // SCALE: the scalar
+    int16_t kind;
+    int16_t real_scale;  // SCALE: 1 = a REAL scalar (see jh_dev_block_of)
     int32_t adjoint;
 };
+static_assert(sizeof(jh_dev_block) == 32, "one table entry = one s_load_dwordx8");
 
 // the device form of a block description.  A SCALE block's scalar is Real unless it is flagged JH_SCALAR_COMPLEX or has a non-zero
 // imaginary part: Julia's `a::Real * z` multiplies part by part, a Complex `a` takes the full product even when imag(a) == 0 (with THAT
-// zero's sign).  The kernels tell the two apart by sim: NaN = "no imaginary part" (one comparison, no extra field in a 32-byte entry).
+// zero's sign).  The kernels tell the two apart by the flag `real_scale` (round 5; round 4 used sim = NaN as the sentinel, which made a
+// Complex scalar with a NaN imaginary part look Real and drop the NaN Julia's full product gives -- `imag != 0.0` is true for NaN, so
+// such a scalar is Complex here and keeps its NaN).
 // (Blocks whose scalar is WIDE never reach the fused kernels: jh_blockop_create routes such operators through the per-block loop,
 // whose scalar stage is the typed lincomb.)
 inline jh_dev_block jh_dev_block_of(const jh_block_desc &b)
@@ -213,8 +217,9 @@ inline jh_dev_block jh_dev_block_of(const jh_block_desc &b)
     d.coeff = b.coeff;
     d.sre = b.scale_re;
     const bool cplx = (b.scale_flags & JH_SCALAR_COMPLEX) || b.scale_im != 0.0;
-    d.sim = cplx ? b.scale_im : __builtin_nan("");
-    d.kind = b.kind;
+    d.sim = cplx ? b.scale_im : 0.0;
+    d.real_scale = cplx ? 0 : 1;
+    d.kind = (int16_t)b.kind;
     d.adjoint = b.adjoint;
     return d;
 }
@@ -371,7 +376,7 @@ int jh_launch_copy_bytes(void *dst, const void *src, size_t bytes);
 int jh_launch_hadamard_raw(void *dst, const void *x, const void *y, int dtype, int64_t count, int conj_x);
 // dst = (2 .* mo) .* x  (conj: conj.(2 .* mo) .* x): the Jacobian of d .= m.^2 about mo
 int jh_launch_square_jvp_raw(void *dst, const void *mo, const void *x, int dtype, int64_t count, int conj_mo);
-extern std::atomic<int64_t> jh_bvec_generation;   // bumped whenever a vector handle is created or destroyed (a handle never changes otherwise)
+extern std::atomic<int64_t> jh_bvec_generation;   // bumped whenever a vector handle is DESTROYED (enough: a cached table can only go stale through a handle it names dying; a handle never changes otherwise)
 int jh_launch_lincomb_raw(void *dst, int dtype, int64_t count, int k, const double *cre, const double *cim, const void *const *x, const int32_t *flags = nullptr);
 // dense child operator (jh_dense.hip): y = A x (rows) or y = A^H x / A^T x (cols); A column-major nr x nc
 int jh_launch_gemv(const void *A, int64_t nr, int64_t nc, int dtype, void *y, const void *x, int adjoint);

@@ -658,33 +658,39 @@ def try_fused_chain(out, x, ops: Sequence[Jop]):
 
 def try_fused_sum(out, x, ops: Sequence[Jop], sgns: Sequence[str], transposed: bool):
     """JetSum_df / JetSum_df' (src/Jets.jl:639-655) when every term is a tall all-diagonal device-native block operator
-    A_k or a real scalar times one (the composite (a, A_k)): one fused launch (jh_blocksum_mul / jh_blocksum_mul_adj).
-    Returns None when the sum does not qualify."""
-    if not (1 <= len(ops) <= 4096):                          # any number of terms: the library groups them by four
+    A_k or a Real scalar times one (the composite (a, A_k)): one fused launch (jh_blocksum_mul_typed / jh_blocksum_mul_adj_typed).
+    The scalars' Julia types go along (round 5): `1.0*A1 - 2.0*A2 + 3.0*A3` (src/Jets.jl:686) with numpy float64 scalars on Float32
+    operators is WIDE -- promoted products, one rounding -- and still one pass.  Returns None when the sum does not qualify."""
+    if not (1 <= len(ops) <= 4096):                          # any number of terms: the library groups them by sixteen
         return None
-    nats, scales = [], []
+    nats, scales, flags = [], [], []
     for op in ops:
         op = JopLn(op)
         if isinstance(op, JopAdjoint):
             return None
-        scale = 1.0
+        scale, fl = 1.0, 0
         if op.jet.f is _j.JetComposite_f:
             inner = op.jet.s["ops"]
-            if len(inner) != 2 or _real_scale(inner[0]) is None or isinstance(inner[0], JopAdjoint):
+            if len(inner) != 2 or isinstance(inner[0], JopAdjoint):
                 return None
-            scale, op = _real_scale(inner[0]), inner[1]
+            a = _real_scale(inner[0], allow_wide=True)
+            if a is None:
+                return None
+            (scale, fl), op = a, inner[1]
         nat = _tall_native(op) if not isinstance(op, JopAdjoint) else None
         if nat is None:
             return None
         nats.append(nat)
         scales.append(scale)
+        flags.append(fl)
     k = len(nats)
     hs = (C.c_void_p * k)(*[n.handle for n in nats])
     sc = (C.c_double * k)(*scales)
+    fg = (C.c_int32 * k)(*flags)
     sg = (C.c_double * k)(*[1.0 if s == _j.PLUS else -1.0 for s in sgns])
-    fn = lib.jh_blocksum_mul_adj if transposed else lib.jh_blocksum_mul
+    fn = lib.jh_blocksum_mul_adj_typed if transposed else lib.jh_blocksum_mul_typed
     try:
-        check(fn(k, hs, sc, sg, out.handle, x.handle))
+        check(fn(k, hs, sc, fg, sg, out.handle, x.handle))
     except JetsHipError as e:
         if e.status == 4:
             return None

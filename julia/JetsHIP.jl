@@ -25,7 +25,7 @@ module JetsHIP
 using Jets, LinearAlgebra
 import Jets: JetAbstractSpace, JetBSpace, JetSpace, BlockArray, BlockArrayStyle, Jop, JopLn, JopNl, JopAdjoint, Jet, jet, state,
              domain, getblock, getblock!, setblock!, indices, nblocks, space, point!, JopZeroBlock_df!, JetBlock_f!,
-             JetBlock_df!, JetBlock_df′!, JetComposite_df!, _constdiag_df!, JetBlock
+             JetBlock_df!, JetBlock_df′!, JetComposite_df!, JetComposite_df′!, JetSum_df!, JetSum_df′!, _constdiag_df!, _constdiag_df′!, JetBlock
 
 export HipSpace, HipArray, JopHipDiagonal, JopHipSquare, JopHipDense, hip_lsqr!
 
@@ -33,7 +33,7 @@ const LIB = get(ENV, "JETSHIP_LIB", "libjetship.so")
 
 # ---------------------------------------------------------------- errors (src/Jets.jl:131,179,1116: plain error(...))
 check(status::Cint) = status == 0 ? nothing : error("libjetship: " * unsafe_string(ccall((:jh_last_error, LIB), Cstring, ())))
-const ABI_VERSION = 2       # JETSHIP_ABI_VERSION of include/jetship.h: struct layouts (jh_block_desc) are part of it
+const ABI_VERSION = 3       # JETSHIP_ABI_VERSION of include/jetship.h: struct layouts (jh_block_desc) are part of it
 function __init__()
     v = ccall((:jh_abi_version, LIB), Cint, ())
     v == ABI_VERSION || error("libjetship speaks ABI version $v, this binding $ABI_VERSION: rebuild the library")
@@ -272,7 +272,12 @@ function Jets.setblock!(x::BlockArray{T,<:HipArray{T}}, iblock, xblock::Array{T}
 end
 Jets.getblock!(x::BlockArray{T,<:HipArray{T}}, iblock, xblock::HipArray{T}) where {T} = copyto!(xblock, x.arrays[iblock])
 Jets.setblock!(x::BlockArray{T,<:HipArray{T}}, iblock, xblock::HipArray{T}) where {T} = copyto!(x.arrays[iblock], xblock)
-Jets.setblock!(x::BlockArray{T,<:HipArray{T}}, iblock, a::Number) where {T} = fill!(x.arrays[iblock], a)          # test/runtests.jl:518-519
+function Jets.setblock!(x::BlockArray{T,<:HipArray{T}}, iblock, a::Number) where {T}                             # test/runtests.jl:518-519
+    o = whole(x)
+    o === nothing && return fill!(x.arrays[iblock], a)
+    check(ccall((:jh_setblock_fill, LIB), Cint, (Ptr{Cvoid}, Int64, Cdouble, Cdouble), o.handle, iblock - 1, real(a), imag(a)))
+    x.arrays[iblock]
+end
 
 # ---------------------------------------------------------------- fill!, norm, dot, extrema (src/Jets.jl:834-885): one pass over the slab
 Base.fill!(x::HipArray, a) = (_fill!(x.slab, a); x)
@@ -557,6 +562,93 @@ function Jets.JetComposite_df!(d::HipArray{T}, m::HipArray{T}; ops, kwargs...) w
     invoke(JetComposite_df!, Tuple{AbstractArray,Any}, d, m; ops=ops, kwargs...)
 end
 
+# ---- scalar * operator and sums of tall device operators: ONE ccall per mul! (rows a18 / a19 of the scope table) --------------------------
+# `a * A` (src/Jets.jl:1161-1164) builds its scalar stage on domain(A) for BOTH of its spaces, which composes only when A is square (the
+# one case the reference tests, test/runtests.jl:789-795).  For a tall device operator the stage lives on range(A) instead -- the
+# documented deviation of DESIGN.md section 5 -- so that `1.0*A1 - 2.0*A2 + 3.0*A3` (the reference's own example, 686) exists for the
+# seismic-shot layout at all.
+function Base.:*(a::Number, A::JopLn{<:Jet{<:HipSpace,<:JetBSpace}})
+    _a = JopLn(dom = range(A), rng = range(A), df! = _constdiag_df!, df′! = _constdiag_df′!, s=(a=a,))
+    _a ∘ A
+end
+
+# Scalars whose product with an element the fused kernels reproduce: Julia promotes (Float64 scalar, Float32 element) to Float64 and
+# rounds once on the store -- JH_SCALAR_WIDE, the WIDE instantiations --, every other type here is converted to the element type first,
+# T(a).  A Complex scalar (full complex product) and the big number types (BigFloat / BigInt promote the ELEMENT) take the unfused chain.
+const FusableReal = Union{Float16,Float32,Float64,Base.BitInteger,Bool,AbstractIrrational}
+function _fusable_scalar(op::Jop)          # the `a` of an un-adjointed `a*I` stage (1159-1162), or nothing
+    (op isa JopLn && jet(op).df! === _constdiag_df!) || return nothing
+    a = state(op).a
+    a isa FusableReal ? a : nothing
+end
+
+# (a, A): d = a * (A m) in one pass, the bits of the chain (tmp = A m; d .= a * tmp)
+function Jets.JetComposite_df!(d::BlockArray{T,<:HipArray{T}}, m::HipArray{T}; ops, kwargs...) where {T}
+    if length(ops) == 2 && handle(d) != C_NULL
+        a = _fusable_scalar(ops[1])
+        h = a === nothing ? C_NULL : tall_native(ops[2], T)
+        if h != C_NULL
+            st = ccall((:jh_blockop_mul_scaled, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cint), h, handle(d), handle(m), Float64(a), _scalar_flags(a))
+            st == 4 || (check(st); return d)                    # JH_ERR_UNSUPPORTED (rows of mixed kinds, ragged blocks): the chain below
+        end
+    end
+    invoke(JetComposite_df!, Tuple{AbstractArray,Any}, d, m; ops=ops, kwargs...)
+end
+# (a, A)' = A' o a': m = A' (conj(a) d) in one pass (conj(a) == a for a Real a)
+function Jets.JetComposite_df′!(m::HipArray{T}, d::BlockArray{T,<:HipArray{T}}; ops, kwargs...) where {T}
+    if length(ops) == 2 && handle(d) != C_NULL
+        a = _fusable_scalar(ops[1])
+        h = a === nothing ? C_NULL : tall_native(ops[2], T)
+        if h != C_NULL
+            st = ccall((:jh_blockop_mul_adj_scaled, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cint), h, handle(m), handle(d), Float64(a), _scalar_flags(a))
+            st == 4 || (check(st); return m)
+        end
+    end
+    invoke(JetComposite_df′!, Tuple{AbstractArray,Any}, m, d; ops=ops, kwargs...)
+end
+
+# JetSum_df! / JetSum_df′! (src/Jets.jl:639-655; the terms and signs arrive flattened, 657-676): when every term is a tall device-native
+# operator A_k or the composite (a_k, A_k) of a fusable Real scalar, the whole sum is ONE ccall -- (K + 1) range-sized streams where the
+# reference's loop (a zeros() temporary, one mul! and one accumulate pass per term) moves 5K + 1 -- with the chain's rounding sequence:
+# product, scalar stage (typed: JH_SCALAR_WIDE for a Float64 scalar on Float32 elements), signed add, terms in order.
+function _sum_term(op::Jop, ::Type{T}) where {T}          # (handle, scale, JH_SCALAR_* flags) or nothing
+    op isa JopAdjoint && return nothing
+    L = JopLn(op)
+    if jet(L).df! === JetComposite_df!
+        inner = state(L).ops
+        length(inner) == 2 || return nothing
+        a = _fusable_scalar(inner[1])
+        a === nothing && return nothing
+        h = tall_native(inner[2], T)
+        return h == C_NULL ? nothing : (h, Float64(a), _scalar_flags(a))
+    end
+    h = tall_native(L, T)
+    h == C_NULL ? nothing : (h, 1.0, Cint(0))
+end
+function _fused_sum(out, x, ops, sgns, ::Type{T}, transposed::Bool) where {T}      # true when the fused launch ran
+    (handle(out) == C_NULL || handle(x) == C_NULL || length(ops) > 4096) && return false
+    terms = map(op -> _sum_term(op, T), collect(ops))
+    any(isnothing, terms) && return false
+    hs = Ptr{Cvoid}[t[1] for t in terms]
+    sc = Cdouble[t[2] for t in terms]
+    fl = Int32[t[3] for t in terms]
+    sg = Cdouble[s === (-) ? -1.0 : 1.0 for s in sgns]
+    st = transposed ?
+        ccall((:jh_blocksum_mul_adj_typed, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cvoid}, Ptr{Cvoid}), length(hs), hs, sc, fl, sg, handle(out), handle(x)) :
+        ccall((:jh_blocksum_mul_typed, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cvoid}, Ptr{Cvoid}), length(hs), hs, sc, fl, sg, handle(out), handle(x))
+    st == 4 && return false                                      # JH_ERR_UNSUPPORTED: the reference's loop
+    check(st)
+    true
+end
+function Jets.JetSum_df!(d::BlockArray{T,<:HipArray{T}}, m::HipArray{T}; ops, sgns, kwargs...) where {T}
+    _fused_sum(d, m, ops, sgns, T, false) && return d
+    invoke(JetSum_df!, Tuple{Any,Any}, d, m; ops=ops, sgns=sgns, kwargs...)
+end
+function Jets.JetSum_df′!(m::HipArray{T}, d::BlockArray{T,<:HipArray{T}}; ops, sgns, kwargs...) where {T}
+    _fused_sum(m, d, ops, sgns, T, true) && return m
+    invoke(JetSum_df′!, Tuple{Any,Any}, m, d; ops=ops, sgns=sgns, kwargs...)
+end
+
 # ---------------------------------------------------------------- solver steps and the multi-GPU exchange
 # u <- alpha*(A v) + beta*u, returns ||u||   /   v <- alpha*(A' (in_scale*u)) + beta*v, returns ||v||   (LSQR / CGLS halves)
 function mul_axpby!(u::BlockArray{T,<:HipArray{T}}, A::JopLn, v::HipArray{T}, alpha::Real, beta::Real) where {T}
@@ -573,7 +665,8 @@ function mul_adj_axpby!(v::HipArray{T}, A::JopLn, u::BlockArray{T,<:HipArray{T}}
 end
 
 # d <- a * (A m)   /   m <- A' (conj(a) d) for a Real scalar of any type: the scalar-times-operator chain (src/Jets.jl:1159-1164) in one pass each
-# way with the scalar's TYPE (a Float64 against Float32 elements: promoted product, one rounding -- the bits of `d .= a * tmp`)
+# way with the scalar's TYPE (a Float64 against Float32 elements: promoted product, one rounding -- the bits of `d .= a * tmp`).  The explicit
+# spelling of what `mul!(d, a*A, m)` / `mul!(m, (a*A)', d)` reach through the JetComposite_df! / df′! methods above.
 function mul_scaled!(d::BlockArray{T,<:HipArray{T}}, a::Real, A::JopLn, m::HipArray{T}) where {T}
     check(ccall((:jh_blockop_mul_scaled, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cint), tall_native(A, T), handle(d), handle(m), a, _scalar_flags(a)))
     d
@@ -891,6 +984,98 @@ tune_set!(A::JopLn, name::AbstractString, value::Integer) = check(ccall((:jh_blo
 # range-side reductions of a row-partitioned vector: local fp64 partial, scalar all-reduce
 dot_partitioned(x::BlockArray{T,<:HipArray{T}}, y::BlockArray{T,<:HipArray{T}}) where {T<:Real} = T(allreduce_scalars!(Float64[dot(x, y)])[1])
 norm_partitioned(x::BlockArray{T,<:HipArray{T}}) where {T} = float(real(T))(sqrt(allreduce_scalars!(Float64[Float64(norm(x))^2])[1]))
+
+# ---------------------------------------------------------------- the rest of the ABI (round 5: every entry point of include/jetship.h is bound)
+device_count() = (n = Ref{Cint}(0); check(ccall((:jh_device_count, LIB), Cint, (Ref{Cint},), n)); Int(n[]))
+function device_info()
+    name = Vector{UInt8}(undef, 256)
+    tot, fr, cus = Ref{Int64}(0), Ref{Int64}(0), Ref{Cint}(0)
+    check(ccall((:jh_device_info, LIB), Cint, (Ptr{UInt8}, Cint, Ref{Int64}, Ref{Int64}, Ref{Cint}), name, length(name), tot, fr, cus))
+    (name = unsafe_string(pointer(name)), total_mem = tot[], free_mem = fr[], cu_count = Int(cus[]))
+end
+shutdown() = (check(ccall((:jh_shutdown, LIB), Cint, ())); empty!(_handles); empty!(_points); empty!(_bcast_programs); _inited[] = false; nothing)
+tune_get(name::AbstractString) = (v = Ref{Int64}(0); check(ccall((:jh_tune_get, LIB), Cint, (Cstring, Ref{Int64}), name, v)); v[])
+# the library's stream: hand it to another library (MPI, a torch-like runtime), or make the library enqueue on the application's stream
+stream() = (p = Ref{Ptr{Cvoid}}(C_NULL); check(ccall((:jh_get_stream, LIB), Cint, (Ref{Ptr{Cvoid}},), p)); p[])
+set_stream!(hip_stream::Ptr{Cvoid}) = check(ccall((:jh_set_stream, LIB), Cint, (Ptr{Cvoid},), hip_stream))       # C_NULL: the library's own again
+function comm_info()
+    n, r = Ref{Cint}(1), Ref{Cint}(0)
+    check(ccall((:jh_comm_info, LIB), Cint, (Ref{Cint}, Ref{Cint}), n, r))
+    (nranks = Int(n[]), rank = Int(r[]))
+end
+# stream-ordered timing (what tools/ and bench.py use on the Python side)
+mutable struct HipEvent
+    handle::Ptr{Cvoid}
+    function HipEvent()
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:jh_event_create, LIB), Cint, (Ref{Ptr{Cvoid}},), h))
+        e = new(h[])
+        finalizer(e -> ccall((:jh_event_destroy, LIB), Cint, (Ptr{Cvoid},), e.handle), e)
+        e
+    end
+end
+record!(e::HipEvent) = (check(ccall((:jh_event_record, LIB), Cint, (Ptr{Cvoid},), e.handle)); e)
+function elapsed_ms(start::HipEvent, stop::HipEvent)          # waits for `stop`
+    ms = Ref{Cfloat}(0)
+    check(ccall((:jh_event_elapsed_ms, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cfloat}), start.handle, stop.handle, ms))
+    Float64(ms[])
+end
+# page-lock an existing host array in place for the DMA of copyto! / getblock! / setblock! (pinned_array allocates one instead)
+pin!(a::Array) = (check(ccall((:jh_host_register, LIB), Cint, (Ptr{Cvoid}, Csize_t), a, sizeof(a))); a)
+unpin!(a::Array) = (check(ccall((:jh_host_unregister, LIB), Cint, (Ptr{Cvoid},), a)); a)
+# where block `iblock` (1-based) of a slab lives: (0-based element offset, length, device pointer) -- for interop with other HIP code
+function block_info(x::BlockArray{T,<:HipArray{T}}, iblock::Integer) where {T}
+    o = whole(x)
+    o === nothing && error("block_info: the blocks of this BlockArray do not live in one slab")
+    off, len, p = Ref{Int64}(0), Ref{Int64}(0), Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:jh_bvec_block, LIB), Cint, (Ptr{Cvoid}, Int64, Ref{Int64}, Ref{Int64}, Ref{Ptr{Cvoid}}), o.handle, iblock - 1, off, len, p))
+    (offset = off[], length = len[], ptr = p[])
+end
+# abs.(x) of a complex device vector into a real one (test/runtests.jl:546-550 `abs.(x)` on a complex BlockArray), without the JIT
+function abs!(dst::DevVec{R}, x::DevVec{Complex{R}}) where {R}
+    check(ccall((:jh_abs, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), handle(dst), handle(x)))
+    dst
+end
+# dst = c1*x1 + c2*x2 + ... left to right with every coefficient's Julia TYPE (the no-JIT spelling of `a*u .+ b*v`; k <= 8): what the
+# scalar stage of the unfused chains is made of (`d .= a * m`, src/Jets.jl:1159)
+function lincomb!(dst::DevVec{T}, coefs::Vector{<:Number}, xs::Vector{<:DevVec{T}}) where {T}
+    length(coefs) == length(xs) || throw(DimensionMismatch("lincomb!: $(length(coefs)) coefficients for $(length(xs)) vectors"))
+    c = Cdouble[]
+    foreach(a -> (push!(c, real(a)); push!(c, imag(a))), coefs)
+    check(ccall((:jh_lincomb_typed, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Int32}, Ptr{Ptr{Cvoid}}), handle(dst), length(xs), c, Int32[_scalar_flags(a) for a in coefs], Ptr{Cvoid}[handle(x) for x in xs]))
+    dst
+end
+# many equally shaped broadcasts in ONE launch (F(m) / point! of thousands of elementwise-nonlinear children): program k writes dsts[k]
+# from its nvec operands xs[k] (flattened) and nscal scalars (re, im pairs, flattened)
+function bcast_apply_many!(progs::Vector{Ptr{Cvoid}}, dsts::Vector{<:DevVec}, xs::Vector{<:DevVec}, scalars::Vector{Cdouble}=Cdouble[])
+    check(ccall((:jh_bcast_apply_many, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Cdouble}), length(progs), progs, Ptr{Cvoid}[handle(d) for d in dsts], Ptr{Cvoid}[handle(x) for x in xs], scalars))
+    dsts
+end
+# does the library accept this expression (compiles it for gfx950, needs no GPU)?  0 = yes
+bcast_check(expr::AbstractString, ::Type{T}, nvec::Integer, nscal::Integer; real_mask::Integer=0, wide_mask::Integer=0) where {T} =
+    ccall((:jh_bcast_check_typed, LIB), Cint, (Cstring, Cint, Cint, Cint, Cint, Cint), expr, dtype_code(T), nvec, real_mask, nscal, wide_mask) == 0
+# unload every compiled broadcast program of this session
+function release_broadcasts!()
+    for (_, prog) in _bcast_programs
+        ccall((:jh_bcast_destroy, LIB), Cint, (Ptr{Cvoid},), prog)
+    end
+    empty!(_bcast_programs)
+    nothing
+end
+# the fused A'A of a row-partitioned operator: every rank's A_k'A_k m in `chunks` element ranges, the all-reduce of a finished range under the
+# next range's kernel (what jh_cgnr_solve_partitioned does per iteration)
+function normal_mul_partitioned!(y::HipArray{T}, A::JopLn, m::HipArray{T}; chunks::Integer=4) where {T}
+    h = tall_native(A, T)
+    n = length(y)
+    step = cld(cld(n, max(chunks, 1)), 16384) * 16384
+    for lo = 0:step:n-1
+        cnt = min(step, n - lo)
+        check(ccall((:jh_blockop_normal_mul_range, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64), h, handle(y), handle(m), lo, cnt))
+        check(ccall((:jh_comm_allreduce_sum_range, LIB), Cint, (Ptr{Cvoid}, Int64, Int64), handle(y), lo, cnt))
+    end
+    check(ccall((:jh_comm_join, LIB), Cint, ()))
+    y
+end
 
 # close(A) releases the device operator (src/Jets.jl:1120-1124 cascade)
 function release!(ops)

@@ -202,3 +202,79 @@ def test_hip_wide_scalar_times_tall_operator_fused_at_every_launch_shape(Jets, o
     m = J.mul(aT.H, J.from_numpy(np.concatenate(inner), J.range(aT))).to_numpy()
     assert_bits_equal(m, oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], scaled)[0], f"(a * T)' d, n = {n}, {np.dtype(dt)}")
     J.close(T)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+@pytest.mark.parametrize("nterms", [3, 6, 11, 19])
+def test_hip_jetsum_with_wide_scalars_stays_fused_with_the_chains_bits(Jets, oracle, monkeypatch, dt, nterms):
+    """The reference's own docstring example `A = 1.0*A1 - 2.0*A2 + 3.0*A3` (src/Jets.jl:686, 703) on Float32 operators: numpy float64
+    scalars are Julia's Float64 -- "wide" against 32-bit elements.  Round 4 sent such sums to the unfused chain ((5K + 1) range-sized
+    streams); round 5's WIDE instantiations of the sum kernels keep them ONE pass ((K + 1) streams), every launch shape (4 / 8 / 16
+    streams per launch, 19 = 16 + 3 continuing the left-to-right sum), with the bits (a) of the unfused chain on the device and (b) of
+    Julia's formulas spelled out in numpy: product in the element type, scalar stage promoted and rounded once, signed add in the
+    element type, terms in order; adjoint: scalar stage on d, ordered row sum per term, signed add."""
+    import sys
+
+    J = Jets
+    blk = sys.modules[J.blockop.__module__]
+    n, nrow = 3 * 4096 + 64, 5
+    spc = J.JetSpace(dt, n)
+    scal = [np.float64(1.0), np.float64(2.0), np.float64(3.14), np.float64(0.1), np.float32(0.7), 3, np.float64(-1.7)]       # wide, narrow and integer scalars mixed
+    coeffs = [[oracle.rng_u01(dt, 31 + t, i, 0, n) for i in range(nrow)] for t in range(nterms)]
+    ops = [J.blockop([[J.JopDiagonal(J.from_numpy(g, spc))] for g in coeffs[t]]) for t in range(nterms)]
+    S, signs = None, []
+    for t in range(nterms):
+        a = scal[t % len(scal)]
+        term = ops[t] if t == 4 else a * ops[t]                  # one bare operator among the scaled ones
+        if S is None:
+            S = term
+            signs.append(1)
+        elif t % 3 == 1:
+            S = S - term
+            signs.append(-1)
+        else:
+            S = S + term
+            signs.append(1)
+    x = oracle.rng_u01(dt, 41, 0, 0, n)
+    x[:len(SPECIALS)] = np.asarray(SPECIALS, dtype=np.float32).astype(dt)
+    din = [oracle.rng_u01(dt, 42, i, 0, n) for i in range(nrow)]
+
+    fused_calls = []
+    real_try = blk.try_fused_sum
+
+    def counting(out, xx, o, s, transposed):
+        r = real_try(out, xx, o, s, transposed)
+        fused_calls.append(r is not None)
+        return r
+
+    monkeypatch.setattr(blk, "try_fused_sum", counting)
+    d_fused = J.mul(S, J.from_numpy(x, spc)).to_numpy()
+    m_fused = J.mul(S.H, J.from_numpy(np.concatenate(din), J.range(S))).to_numpy().ravel(order="F")
+    assert fused_calls == [True, True], "a sum with Float64 scalars on 32-bit operators must take the fused route"
+    monkeypatch.setattr(blk, "try_fused_sum", lambda *a, **k: None)
+    d_chain = J.mul(S, J.from_numpy(x, spc)).to_numpy()
+    m_chain = J.mul(S.H, J.from_numpy(np.concatenate(din), J.range(S))).to_numpy().ravel(order="F")
+    monkeypatch.undo()
+    assert_bits_equal(d_fused, d_chain, f"fused JetSum forward vs the unfused chain, {nterms} terms, {np.dtype(dt)}")
+    assert_bits_equal(m_fused, m_chain, f"fused JetSum adjoint vs the unfused chain, {nterms} terms, {np.dtype(dt)}")
+
+    # Julia's formulas, term by term
+    zero = lambda: np.zeros(n, dtype=dt)
+    want_d = [zero() for _ in range(nrow)]
+    want_m = zero()
+    with np.errstate(all="ignore"):
+        for t in range(nterms):
+            a = 1 if t == 4 else scal[t % len(scal)]
+            obl = [[oracle.Block("diag", n, coeff=g)] for g in coeffs[t]]
+            prod = oracle.block_df(obl, [zero() for _ in range(nrow)], [x])
+            for i in range(nrow):
+                term = prod[i] if t == 4 else _store(*julia_scalar_term(a, prod[i])[:2], dt)
+                want_d[i] = (want_d[i] + term) if signs[t] > 0 else (want_d[i] - term)
+            scaled = din if t == 4 else [_store(*julia_scalar_term(a, b)[:2], dt) for b in din]
+            _m = oracle.block_df_adj(obl, [zero()], scaled)[0]
+            want_m = (want_m + _m) if signs[t] > 0 else (want_m - _m)
+    assert_bits_equal(d_fused, np.concatenate(want_d), f"fused JetSum forward vs Julia's formulas, {nterms} terms, {np.dtype(dt)}")
+    assert_bits_equal(m_fused, want_m, f"fused JetSum adjoint vs Julia's formulas, {nterms} terms, {np.dtype(dt)}")
+    for A in ops:
+        J.close(A)

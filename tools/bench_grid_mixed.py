@@ -52,6 +52,9 @@ def timed(fn, reps=6, warm=2):
 
 
 b = n * 4
+# algorithmic bytes per launch, for tools/prof_any.sh (regex over the kernel's template name: TRANSPOSED = false / true)
+print(f"ALGO k_general_tile<.*false|k_block_fwd_general {(ndiag + K + 2 * M) * b}")
+print(f"ALGO k_general_tile<.*true|k_block_adj_general {(ndiag + M + K) * b}", flush=True)
 if os.environ.get("GENERAL_TILE_U"):
     J.tune(fwd_unroll=int(os.environ["GENERAL_TILE_U"]))
 knob = os.environ.get("GENERAL_TILE")

@@ -17,9 +17,14 @@ ops = []
 for k in range(K):
     coeff = J.rand(J.JetBSpace([spc] * nrow), seed=10 + k, stream=0)
     ops.append(J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays]))
-S = ops[0]
+# SUM_SCALE=wide: every term a numpy float64 scalar times its operator -- Julia's Float64 against Float32 elements, the reference's own
+# `1.0*A1 - 2.0*A2 + 3.0*A3` (src/Jets.jl:686); round 5: still ONE pass (WIDE instantiations); SUM_SCALE=narrow: Python floats, T(a)
+import numpy as np
+scale_mode = os.environ.get("SUM_SCALE", "")
+term = (lambda k: np.float64(0.5 + 0.37 * k) * ops[k]) if scale_mode == "wide" else ((lambda k: (0.5 + 0.37 * k) * ops[k]) if scale_mode == "narrow" else (lambda k: ops[k]))
+S = term(0)
 for k in range(1, K):
-    S = S + ops[k] if k % 2 else S - ops[k]
+    S = S + term(k) if k % 2 else S - term(k)
 m = J.rand(spc, seed=2, stream=0)
 d = J.zeros(J.range(ops[0]))
 mt = J.zeros(spc)
@@ -42,8 +47,10 @@ if os.environ.get("SUM_FWD_GROUP"):
     J.tune(fwd_group=int(os.environ["SUM_FWD_GROUP"]))                # rows per workgroup of the fused forward (default 4)
 if os.environ.get("SUM_FWD_UNROLL"):
     J.tune(fwd_unroll=int(os.environ["SUM_FWD_UNROLL"]))
-for group in (16, 8, 16, 8):                                        # forward terms per launch: 16 (round 4) against round 3's 8, alternating in one process
+print(f"ALGO k_tall_sum_(fwd|adj) {((K + 1) * nrow + 1) * b}", flush=True)       # per launch when the sum is ONE launch (K <= terms per launch): tools/prof_any.sh
+groups = tuple(int(v) for v in os.environ.get("SUM_GROUPS", "16,8,16,8").split(","))
+for group in groups:                                        # forward terms per launch: 16 (round 4) against round 3's 8, alternating in one process
     J.tune(sum_group=group, sum_adj_group=group)                    # (the adjoint: 16 or 8 accumulators per launch)
     tf = timed(lambda: J.mul_(d, S, m))
     ta = timed(lambda: J.mul_(mt, S.H, d))
-    print(f"JetSum of {K} tall {nrow} x {edge}^3 operators, {group} terms per launch: forward {tf:7.3f} ms {((K + 1) * nrow + 1) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {((K + 1) * nrow + 1) * b / ta / 1e6:7.1f} GB/s")
+    print(f"JetSum of {K} tall {nrow} x {edge}^3 operators{' (' + scale_mode + ' scalars)' if scale_mode else ''}, {group} terms per launch: forward {tf:7.3f} ms {((K + 1) * nrow + 1) * b / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {((K + 1) * nrow + 1) * b / ta / 1e6:7.1f} GB/s")
