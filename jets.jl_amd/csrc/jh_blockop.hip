@@ -802,7 +802,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
                                                                 const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, S alpha,
                                                                 S beta, double *__restrict__ partials, int64_t s_begin, int64_t s_end,
                                                                 unsigned ntiles, unsigned nchunks, unsigned *__restrict__ sync,
-                                                                S *__restrict__ wpart, unsigned *__restrict__ err)
+                                                                S *__restrict__ wpart, unsigned *__restrict__ err, unsigned ctiles)
 {
     typedef typename vec_of<S, NS>::type V;
     typedef unsigned U4 __attribute__((ext_vector_type(4)));
@@ -811,7 +811,20 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
     if (threadIdx.x == 0) s_ticket = atomicAdd(&sync[0], 1u);              // logical id = order of arrival
     __syncthreads();
     const unsigned ticket = s_ticket;
-    const unsigned chunk = ticket / ntiles, tile = ticket - chunk * ntiles;
+    // ctiles == 0: tiles fastest over the whole row -- every tile of chunk 0, then every tile of chunk 1, ...
+    // ctiles  > 0 (round 5): COLUMN bands -- `ctiles` consecutive tiles of chunk 0, the same tiles of chunk 1, ... of the last chunk, then the
+    // next band (k_tall_diag_fwd's walk).  The band of v is then re-read by every chunk from L2 instead of the Infinity Cache, and (c, t) still
+    // only waits for (c - 1, t), whose ticket is smaller by the band's width: started, and depending on smaller tickets only.
+    unsigned chunk, tile;
+    if (ctiles) {
+        const unsigned per_band = ctiles * nchunks, b = ticket / per_band, r = ticket - b * per_band;
+        const unsigned cw = (b * ctiles + ctiles <= ntiles) ? ctiles : ntiles - b * ctiles;     // the last band may be narrower
+        chunk = r / cw;
+        tile = b * ctiles + r % cw;
+    } else {
+        chunk = ticket / ntiles;
+        tile = ticket - chunk * ntiles;
+    }
     const int64_t row0 = (int64_t)chunk * DEPTH, row1 = (row0 + DEPTH < nrow) ? row0 + DEPTH : nrow;
     const int64_t span = s_end - s_begin;                                   // the host guarantees span % (U * BLK * NS) == 0: full tiles only
     int64_t sk[U];
@@ -925,7 +938,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
 #pragma unroll
         for (int k = 0; k < U; k++) st<false>(reinterpret_cast<V *>(w + sk[k]), acc[k]);
     }
-    wg_sum_store<BLK>(nrm, partials + ticket);
+    wg_sum_store<BLK>(nrm, partials + (size_t)chunk * ntiles + tile);     // by (chunk, tile): the fold's order does not depend on the walk
 }
 
 // out[s] = sum over parts p = 0..nparts-1 (in that order within a part lane, part lanes in order) of parts[p][s - s_begin]:
@@ -2549,11 +2562,18 @@ int launch_general_tile(const jh_blockop *op, const S *in, S *out, int64_t in_by
     // 5.43 -> 5.90 | 5.28 -> 5.87, 64 x 64 of 64^3 5.1 -> 5.7 | 5.1 -> 5.7, 8 x 8 and 64 x 4 +2 % (profiles/bench_grid_mixed_r04.txt).
     // Knob general_tile: 1 this rule, 2 / 4 that many lines always, 0 the one-line kernels
     const bool four = c.general_tile == 4 || (c.general_tile == 1 && nlines >= 4);
-    const int64_t ngroups = four ? (nlines + 3) / 4 : (nlines + 1) / 2;
+    const int exp_r = c.general_tile == 42 ? 4 : (c.general_tile == 8 ? 8 : 0);     // round-5 experiment shapes: 42 = 4 lines x 2 steps, 8 = 8 lines x 1 step (8 x 2 needs more than 512 registers per lane)
+    const int64_t ngroups = exp_r ? (nlines + exp_r - 1) / exp_r : (four ? (nlines + 3) / 4 : (nlines + 1) / 2);
     const int U = (c.fwd_unroll == 2) ? 2 : 1;                           // two packs per lane did not pay here (knob fwd_unroll = 2: measurements)
     unsigned ntiles, grid;
     general_grid((n_scalars / NS + 256 * U - 1) / (256 * U), ngroups, ntiles, grid, general_use_xcd(in_bytes));
-    if (four)
+    if (c.general_tile == 42)
+        hipLaunchKernelGGL((k_general_tile<S, E, NS, 2, 1, TRANSPOSED, 4>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
+                           ntiles, (unsigned)ngroups);
+    else if (c.general_tile == 8)
+        hipLaunchKernelGGL((k_general_tile<S, E, NS, 1, 1, TRANSPOSED, 8>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
+                           ntiles, (unsigned)ngroups);
+    else if (four)
         hipLaunchKernelGGL((k_general_tile<S, E, NS, 1, 1, TRANSPOSED, 4>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
                            ntiles, (unsigned)ngroups);
     else if (U == 2)
@@ -2960,10 +2980,13 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
         JH_TRY(jh_ensure_partials(ntiles * nchunks));
         JH_CHECK_HIP(hipMemsetAsync(c.chain_sync, 0, sizeof(unsigned) * (size_t)(2 + ntiles), c.stream));   // ticket counter + flags
         unsigned *err = reinterpret_cast<unsigned *>(c.red_dev + JH_CHAIN_ERR_SLOT);
+        // column bands of the chained walk (knob step_band: -1 the default below, 0 none = tiles fastest over the whole row, k tiles per band)
+        int64_t cband = c.step_band >= 0 ? c.step_band : 0;
+        if (cband >= ntiles) cband = 0;
 #define JH_CHAIN(BLK, MIX)                                                                                                \
     hipLaunchKernelGGL((k_tall_diag_bidiag_chain<S, E, NS, 1, CD, BLK, MIX>), dim3((unsigned)(ntiles * nchunks)), dim3(BLK), 0, c.stream, \
                        op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars, (S)alpha, (S)beta,   \
-                       c.part_dev, s_begin, s_end, (unsigned)ntiles, (unsigned)nchunks, c.chain_sync, (S *)wpart, err)
+                       c.part_dev, s_begin, s_end, (unsigned)ntiles, (unsigned)nchunks, c.chain_sync, (S *)wpart, err, (unsigned)cband)
         if (mixed) {
             if (cb == 1024) JH_CHAIN(1024, true);
             else if (cb == 512) JH_CHAIN(512, true);

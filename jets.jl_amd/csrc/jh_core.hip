@@ -953,11 +953,12 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "small_loop")) { c.small_loop = value ? 1 : 0; }
     else if (!strcmp(name, "force_dist")) { c.force_dist = value ? 1 : 0; }
     else if (!strcmp(name, "step_chain")) { JH_REQUIRE(value >= -1 && value <= 1, "step_chain must be -1 (auto), 0 or 1"); c.step_chain = value; }
+    else if (!strcmp(name, "step_band")) { JH_REQUIRE(value >= -1 && value < ((int64_t)1 << 24), "step_band must be -1 (default), 0 (none) or a number of tiles"); c.step_band = value; }
     else if (!strcmp(name, "general_xcd")) { JH_REQUIRE(value >= 0 && value <= 2, "general_xcd must be 0 (never), 1 (automatic) or 2 (always)"); c.general_xcd = value; }
     else if (!strcmp(name, "lsqr_graph")) { c.lsqr_graph = value < 0 ? 0 : (value > 2 ? 2 : value); }
     else if (!strcmp(name, "grid_tile")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "grid_tile must be 0 (k_grid_diag), 1 (automatic) or 2 / 4 / 8 lines per workgroup"); c.grid_tile = value; }
     else if (!strcmp(name, "dense_mixed")) { JH_REQUIRE(value == 0 || value == 1, "dense_mixed must be 0 or 1"); c.dense_mixed = value; }
-    else if (!strcmp(name, "general_tile")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "general_tile must be 0 (one-line kernels), 1 (automatic), 2 or 4 lines per workgroup"); c.general_tile = value; }
+    else if (!strcmp(name, "general_tile")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 42 || value == 8, "general_tile must be 0 (one-line kernels), 1 (automatic), 2 or 4 lines per workgroup (42 / 8: 4 lines x 2 steps, 8 lines)"); c.general_tile = value; }
     else if (!strcmp(name, "dense_fused")) { JH_REQUIRE(value == 0 || value == 1, "dense_fused must be 0 or 1"); c.dense_fused = value; }
     else if (!strcmp(name, "cgls_trace")) { c.cgls_trace = value ? 1 : 0; }
     else if (!strcmp(name, "cg_dev")) { c.cg_dev = value < 0 ? 0 : (value > 2 ? 2 : value); }
@@ -1001,6 +1002,7 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "small_loop")) *value = c.small_loop;
     else if (!strcmp(name, "force_dist")) *value = c.force_dist;
     else if (!strcmp(name, "step_chain")) *value = c.step_chain;
+    else if (!strcmp(name, "step_band")) *value = c.step_band;
     else if (!strcmp(name, "last_step_chain")) *value = c.last_step_chain;
     else if (!strcmp(name, "general_xcd")) *value = c.general_xcd;
     else if (!strcmp(name, "graph_replays")) *value = c.graph_replays;

@@ -102,6 +102,7 @@ struct jh_context {
     int64_t last_adj_launches = 1;     // kernel launches of the most recent tall adjoint / fused normal call (read-only knob)
     int64_t last_fwd_walk = 0;         // grid walk used by the most recent tall forward launch (read-only knob)
     int64_t last_step_chain = 0;       // row chunks of the most recent one-pass step (0: the plain walk) (read-only knob)
+    int64_t step_band = -1;            // knob: the chained one-pass step in column bands of this many tiles (-1: the default, 0: none -- tiles fastest over the whole row)
     int64_t grid_diag = 1;             // knob: M x K grids of plain diagonals on the branch-free kernel (0: the general kernels)
     int64_t grid_tile = 1;             // knob: ... register-tiled (k_grid_tile: R lines x one tile per workgroup): 1 automatic R, 2 / 4 / 8 that R, 0: k_grid_diag
     int64_t general_tile = 1;          // knob: grids of EQUAL elementwise blocks of any kinds register-tiled (k_general_tile: two lines x one tile per workgroup); 0: k_block_*_general_vec

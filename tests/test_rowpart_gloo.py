@@ -46,10 +46,18 @@ def _free_port():
 def _worker(rank, world, port, nrow, n, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import torch
     import torch.distributed as dist
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    _exchange_body(rank, world, nrow, n, out_dir)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _exchange_body(rank, world, nrow, n, out_dir):
+    """forward / adjoint / range-side reductions / normal operator of one rank of an initialised process group"""
+    import torch
+
     from jets_jl_amd import rowpart
     from oracle import jets_oracle as jo
 
@@ -79,8 +87,6 @@ def _worker(rank, world, port, nrow, n, out_dir):
     shard.normal_mul_(yn, m, tmp_local=[np.zeros(n, dtype=dt) for _ in range(part.count)])
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), fwd=np.concatenate(fwd), mt=mt, local=local_only, dot=dotv,
              nrm=np.array([nrm2, nrminf, nrm1]), first=part.first, count=part.count, yn=yn)
-    dist.barrier()
-    dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("nrow,n", [(6, 1000), (5, 257)])
@@ -127,12 +133,20 @@ def test_world_size_2_forward_is_local_and_adjoint_all_reduces(tmp_path, nrow, n
 def _lsqr_worker(rank, world, port, nrow, n, iters, out_dir, one_pass=False, solver="lsqr"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import math
-
-    import torch
     import torch.distributed as dist
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    _solver_body(rank, world, nrow, n, iters, out_dir, one_pass, solver)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _solver_body(rank, world, nrow, n, iters, out_dir, one_pass=False, solver="lsqr", tag="lsqr"):
+    """one solve (LSQR in either schedule, CGLS, CG on the normal equations) by one rank of an initialised process group"""
+    import math
+
+    import torch
+
     from jets_jl_amd import rowpart
     from jets_jl_amd.lsqr import lsqr_core
     from oracle import jets_oracle as jo
@@ -210,9 +224,7 @@ def _lsqr_worker(rank, world, port, nrow, n, iters, out_dir, one_pass=False, sol
         res = cgls_core(NumpyShardEngine(), b_loc, None, 0.1, 0.0, 0.0, iters)                # damped: s = A'r - damp^2 x on every rank alike
     else:
         res = lsqr_core(OnePassEngine() if one_pass else NumpyShardEngine(), b_loc, None, 0.0, 0.0, 0.0, 0.0, iters)
-    np.savez(os.path.join(out_dir, f"lsqr{rank}.npz"), x=res.x, r=np.array([h[1] for h in res.history]), itn=res.itn)
-    dist.barrier()
-    dist.destroy_process_group()
+    np.savez(os.path.join(out_dir, f"{tag}{rank}.npz"), x=res.x, r=np.array([h[1] for h in res.history]), itn=res.itn)
 
 
 @pytest.mark.parametrize("one_pass", [False, True])
@@ -257,3 +269,76 @@ def test_world_size_2_cgls_matches_single_process_fp64_cgls(tmp_path, solver):
     assert np.linalg.norm(res[0]["x"] - xr) <= 1e-10 * np.linalg.norm(xr)
     if solver == "cgls":                                                                # (cgnr reports sqrt(||r||^2 + damp^2 ||x||^2) from its recurrence)
         assert np.allclose(res[0]["r"], np.array([h[1] for h in info["history"]]), rtol=1e-9)
+
+
+# ---------------------------------------------------------------------------------- world size 8, uneven partition (round 5)
+# The contract's deployment is one process per GPU at N = 1, 2, 4, 8 (src/Jets.jl:1015-1031 rows independent, 1045-1053 summed over the
+# ranks); until round 5 the ranks path had only ever run at world size 2.  ONE job of eight gloo ranks runs everything on partitions
+# that do not divide evenly (1003 rows: three ranks own 126, five own 125): the forward / adjoint exchange and the range-side
+# reductions, LSQR in both schedules, CGLS and CG on the normal equations.
+def _world8_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _exchange_body(rank, world, 1003, 40, out_dir)
+    for tag, one_pass, solver in (("lsqr2p", False, "lsqr"), ("lsqr1p", True, "lsqr"), ("cgls", False, "cgls"), ("cgnr", False, "cgnr")):
+        _solver_body(rank, world, 1003, 16, 6, out_dir, one_pass, solver, tag=tag)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_8_uneven_partition_exchange_and_solvers(tmp_path):
+    import torch.multiprocessing as mp
+
+    from oracle import jets_oracle as jo
+    from oracle.cgls_ref import cgls_fp64
+    from oracle.lsqr_ref import lsqr_fp64
+
+    world, port = 8, _free_port()
+    mp.spawn(_world8_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+
+    # ---- the exchange step
+    nrow, n, dt = 1003, 40, np.float32
+    res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    counts = [int(r["count"]) for r in res]
+    assert counts == [126, 126, 126, 125, 125, 125, 125, 125] and [int(r["first"]) for r in res] == list(np.cumsum([0] + counts[:-1]))
+    a = [jo.rng_u01(dt, 1, 0, i * n, n) for i in range(nrow)]
+    d = [jo.rng_u01(dt, 3, 0, i * n, n) for i in range(nrow)]
+    m = jo.rng_u01(dt, 2, 0, 0, n)
+    ops = [[jo.Block("diag", n, coeff=g)] for g in a]
+    ref_fwd = np.concatenate(jo.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [m]))
+    ref_adj = jo.block_df_adj(ops, [np.zeros(n, dtype=dt)], d)[0]
+    assert np.concatenate([r["fwd"] for r in res]).tobytes() == ref_fwd.tobytes()                 # forward: local rows, bit for bit
+    for r in res[1:]:                                                                             # replicas identical after every exchange
+        assert r["mt"].tobytes() == res[0]["mt"].tobytes() and r["yn"].tobytes() == res[0]["yn"].tobytes()
+        assert float(r["dot"]) == float(res[0]["dot"]) and r["nrm"].tobytes() == res[0]["nrm"].tobytes()
+    fp64_sum = np.sum([r["local"].astype(np.float64) for r in res], axis=0)                       # the ranks' ordered local sums, added exactly
+    assert np.linalg.norm(res[0]["mt"].astype(np.float64) - fp64_sum) <= 1e-6 * np.linalg.norm(fp64_sum)
+    assert np.linalg.norm(res[0]["mt"].astype(np.float64) - ref_adj) <= 1e-5 * np.linalg.norm(ref_adj)   # the stated multi-GPU tolerance
+    ref_yn = jo.block_df_adj(ops, [np.zeros(n, dtype=dt)], jo.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [m]))[0]
+    assert np.linalg.norm(res[0]["yn"].astype(np.float64) - ref_yn) <= 1e-5 * np.linalg.norm(ref_yn)
+    flat_d = np.concatenate(d).astype(np.float64)
+    assert float(res[0]["dot"]) == pytest.approx(float(np.dot(flat_d, ref_fwd.astype(np.float64))), rel=1e-5)
+    assert res[0]["nrm"][0] == pytest.approx(np.linalg.norm(flat_d), rel=1e-5)
+    assert res[0]["nrm"][1] == pytest.approx(np.abs(flat_d).max(), rel=1e-7)
+    assert res[0]["nrm"][2] == pytest.approx(np.abs(flat_d).sum(), rel=1e-5)
+
+    # ---- the solvers: replicas bit-identical, iterates those of the single-process fp64 solvers
+    # (6 iterations: with 1003 rows per unknown the columns are nearly orthogonal and equally long, LSQR reaches machine precision -- and its
+    # stopping rule -- after 9)
+    nrow, n, iters = 1003, 16, 6
+    a = np.stack([jo.rng_u01(np.float64, 1, 0, i * n, n) + 0.05 for i in range(nrow)])
+    b = np.concatenate([jo.rng_u01(np.float64, 5, 0, i * n, n) - 0.5 for i in range(nrow)])
+    A, At = (lambda v: (a * v).ravel()), (lambda y: (a * y.reshape(nrow, n)).sum(0))
+    xl, il = lsqr_fp64(A, At, b, n, atol=0.0, btol=0.0, conlim=0.0, maxiter=iters)
+    xc, ic = cgls_fp64(A, At, b, n, damp=0.1, atol=0.0, btol=0.0, maxiter=iters)
+    for tag, xr, info in (("lsqr2p", xl, il), ("lsqr1p", xl, il), ("cgls", xc, ic), ("cgnr", xc, ic)):
+        sol = [np.load(tmp_path / f"{tag}{r}.npz") for r in range(world)]
+        for r in sol[1:]:
+            assert r["x"].tobytes() == sol[0]["x"].tobytes(), f"{tag}: replicas differ"
+        assert int(sol[0]["itn"]) == info["itn"] == iters, tag
+        assert np.linalg.norm(sol[0]["x"] - xr) <= 1e-10 * np.linalg.norm(xr), tag
+        if tag != "cgnr":
+            assert np.allclose(sol[0]["r"], np.array([h[1] for h in info["history"]]), rtol=1e-9), tag
