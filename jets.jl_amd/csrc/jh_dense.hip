@@ -15,6 +15,26 @@ namespace {
 template <typename S, int NS> struct vec_of { typedef S type __attribute__((ext_vector_type(NS))); };
 template <typename S> struct vec_of<S, 1> { typedef S type; };
 
+// every operand of these kernels lives in HBM: load / store through address_space(1) pointers, so that the compiler emits global_load /
+// global_store (never flat_*: a flat access also waits on the LDS counter and costs an address-space check) -- in particular for the
+// matrix pointers READ FROM THE BLOCK TABLE, whose address space the compiler cannot know (round 5; jh_blockop.hip has done so since
+// round 1; tests/test_kernel_resources.py disassembles this code object and finds no flat access)
+template <typename V> __device__ inline V ldg_nt(const V *p)
+{
+    typedef const V __attribute__((address_space(1))) *gp;
+    return __builtin_nontemporal_load((gp)p);
+}
+template <typename V> __device__ inline V ldg(const V *p)
+{
+    typedef const V __attribute__((address_space(1))) *gp;
+    return *(gp)p;
+}
+template <typename V, typename W> __device__ inline void stg(V *p, W v)
+{
+    typedef V __attribute__((address_space(1))) *gp;
+    *(gp)p = (V)v;
+}
+
 // ---- y = A x ---------------------------------------------------------------------------------------
 // acc += A[:, c0:c1] x[c0:c1] for this lane's NS scalar rows: columns in order, product rounded then added (the sequential loop's bits);
 // sixteen columns' loads in flight (the adds are serial by definition, the loads need not be).  Round 4 A/B against four in flight:
@@ -28,7 +48,7 @@ __device__ inline V gemv_rows_walk(const S *__restrict__ col, int64_t ns, const 
     for (; c + 16 <= c1; c += 16) {
         V a[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) a[k] = __builtin_nontemporal_load(reinterpret_cast<const V *>(col + (int64_t)k * ns));
+        for (int k = 0; k < 16; k++) a[k] = ldg_nt(reinterpret_cast<const V *>(col + (int64_t)k * ns));
         col += 16 * ns;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -47,7 +67,7 @@ __device__ inline V gemv_rows_walk(const S *__restrict__ col, int64_t ns, const 
         }
     }
     for (; c < c1; c++, col += ns) {
-        V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col));
+        V a = ldg_nt(reinterpret_cast<const V *>(col));
         if constexpr (E == 1) {
             acc = acc + a * (V)x[c];
         } else {
@@ -77,7 +97,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const S *__restrict__ A, int6
     const int64_t c0 = (int64_t)blockIdx.y * cols_per_chunk;
     const int64_t c1 = c0 + cols_per_chunk < nc ? c0 + cols_per_chunk : nc;
     const V acc = gemv_rows_walk<S, E, NS, V>(A + c0 * ns + s, ns, x, c0, c1);  // product rounded, then added (no FMA: -ffp-contract=off)
-    *reinterpret_cast<V *>(out + (int64_t)blockIdx.y * ns + s) = acc;          // chunk 0 of a one-chunk launch is y itself
+    stg(reinterpret_cast<V *>(out + (int64_t)blockIdx.y * ns + s), acc);          // chunk 0 of a one-chunk launch is y itself
 }
 
 // out[k] = sum over chunks (in order) of partial[chunk][k]
@@ -106,8 +126,8 @@ __global__ __launch_bounds__(256) void k_gemv_cols(const S *__restrict__ A, int6
     const S *col = A + c * ns;
     double sr = 0.0, si = 0.0;
     for (int64_t s = s0 + (int64_t)lane * NS; s < s1; s += 64 * NS) {
-        V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col + s));
-        V xv = *reinterpret_cast<const V *>(x + s);
+        V a = ldg_nt(reinterpret_cast<const V *>(col + s));
+        V xv = ldg(reinterpret_cast<const V *>(x + s));
         if constexpr (E == 1) {
 #pragma unroll
             for (int e = 0; e < NS; e++) {
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows_batched(const jh_dev_block *_
     const int64_t c0 = (int64_t)blockIdx.y * cols_per_chunk;
     const int64_t c1 = c0 + cols_per_chunk < nc ? c0 + cols_per_chunk : nc;
     const V acc = gemv_rows_walk<S, E, NS, V>(A + c0 * ns + s, ns, x, c0, c1);  // columns in order, product rounded then added
-    *reinterpret_cast<V *>(out + obase + (int64_t)blockIdx.y * chunk_stride + s) = acc;
+    stg(reinterpret_cast<V *>(out + obase + (int64_t)blockIdx.y * chunk_stride + s), acc);
 }
 
 // y[z][k] = sum over column chunks (in order) of partial[z][chunk][k]
@@ -212,8 +232,8 @@ __global__ __launch_bounds__(256) void k_gemv_cols_batched(const jh_dev_block *_
     const S *x = d + dbase;                                                    // tall: child z reads d_z; wide: every child reads d (stride 0)
     double sr = 0.0, si = 0.0;
     for (int64_t s = s0 + (int64_t)lane * NS; s < s1; s += 64 * NS) {
-        V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col + s));
-        V xv = *reinterpret_cast<const V *>(x + s);
+        V a = ldg_nt(reinterpret_cast<const V *>(col + s));
+        V xv = ldg(reinterpret_cast<const V *>(x + s));
         if constexpr (E == 1) {
 #pragma unroll
             for (int e = 0; e < NS; e++) {
@@ -262,8 +282,8 @@ __global__ __launch_bounds__(256) void k_gemv_cols_small(const jh_dev_block *__r
         xv[ch] = (V)(S)0;
         if (live && zl0 + ch < nchild) {
             const int64_t z = z0 + zl0 + ch;
-            a[ch] = __builtin_nontemporal_load(reinterpret_cast<const V *>((const S *)blocks[z].coeff + c * ns + s));
-            xv[ch] = *reinterpret_cast<const V *>(d + z * d_stride + s);
+            a[ch] = ldg_nt(reinterpret_cast<const V *>((const S *)blocks[z].coeff + c * ns + s));
+            xv[ch] = ldg(reinterpret_cast<const V *>(d + z * d_stride + s));
         }
     }
 #pragma unroll
@@ -438,10 +458,10 @@ __global__ __launch_bounds__(256) void k_gemv_cols_fused(const jh_dev_block *__r
         const S *xz = d + z * d_stride;
         V a[B];
 #pragma unroll
-        for (int u = 0; u < B; u++) a[u] = __builtin_nontemporal_load(reinterpret_cast<const V *>(Az + off[u]));
+        for (int u = 0; u < B; u++) a[u] = ldg_nt(reinterpret_cast<const V *>(Az + off[u]));
         V xv[NPX];
 #pragma unroll
-        for (int i = 0; i < NPX; i++) xv[i] = *reinterpret_cast<const V *>(xz + xo[i]);
+        for (int i = 0; i < NPX; i++) xv[i] = ldg(reinterpret_cast<const V *>(xz + xo[i]));
 #pragma unroll
         for (int u = 0; u < B; u++) {
             const V x = xv[u % NPX];                                           // unit u holds piece u mod (L / 64) of its column
@@ -1030,7 +1050,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows_mixed(const jh_dev_block *__r
     for (; c + 16 <= nc; c += 16) {
         V a[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) a[k] = __builtin_nontemporal_load(reinterpret_cast<const V *>(col + (int64_t)k * ns));
+        for (int k = 0; k < 16; k++) a[k] = ldg_nt(reinterpret_cast<const V *>(col + (int64_t)k * ns));
         col += 16 * ns;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -1049,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows_mixed(const jh_dev_block *__r
         }
     }
     for (; c < nc; c++, col += ns) {
-        V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col));
+        V a = ldg_nt(reinterpret_cast<const V *>(col));
         if constexpr (E == 1) {
             acc = acc + a * (V)x[c];
         } else {
@@ -1063,7 +1083,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows_mixed(const jh_dev_block *__r
             acc = acc + p;
         }
     }
-    *reinterpret_cast<V *>(out + s) = acc;
+    stg(reinterpret_cast<V *>(out + s), acc);
 }
 
 // y = B' x for the children this pass owns: one wave per column of B, fp64 wave reduction, rounded and stored.  In the operator's
@@ -1087,8 +1107,8 @@ __global__ __launch_bounds__(256) void k_gemv_cols_mixed(const jh_dev_block *__r
     const S *x = in + (transposed ? row_off[i] : col_off[j]) * E;
     double sr = 0.0, si = 0.0;
     for (int64_t s = (int64_t)lane * NS; s < ns; s += 64 * NS) {
-        V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(col + s));
-        V xv = *reinterpret_cast<const V *>(x + s);
+        V a = ldg_nt(reinterpret_cast<const V *>(col + s));
+        V xv = ldg(reinterpret_cast<const V *>(x + s));
         if constexpr (E == 1) {
 #pragma unroll
             for (int e = 0; e < NS; e++) {

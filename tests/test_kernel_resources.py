@@ -44,3 +44,41 @@ def test_registers_fit_the_declared_workgroup(kernels):
     count of those is reported to keep an eye on."""
     over = [k for k in kernels if k["max_wg"] >= 256 and k["vgpr"] + k["agpr"] > 512 // (k["max_wg"] // 256)]
     assert not over, [k["name"] for k in over]
+
+
+def test_no_kernel_addresses_hbm_through_flat_instructions(tmp_path):
+    """Every operand of the library's kernels lives in HBM, so every access should be a `global_*` (or scalar) instruction: a `flat_*`
+    access goes through the address-space check, also waits on the LDS counter and cannot take the nontemporal / sc bits the streaming
+    kernels rely on.  The compiler falls back to flat when it cannot know a pointer's address space -- pointers READ FROM THE BLOCK TABLE,
+    as every dense child's matrix is: round 4's jh_dense code object held 612 flat loads / stores (17 in each of k_gemv_rows_batched,
+    k_gemv_rows_wide_fused, k_gemv_rows_mixed).  Round 5 routes them through address_space(1) helpers (jh_dense.hip: ldg / ldg_nt / stg;
+    jh_blockop.hip: ld / st).  This test disassembles every gfx950 code object of the built library."""
+    import re
+    import shutil
+    import subprocess
+
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    data = open(LIB, "rb").read()
+    total, per_kernel, nobj = 0, {}, 0
+    for name, off, size, _typ in kernel_resources._elf_sections(data):
+        if name != ".hip_fatbin":
+            continue
+        for co in kernel_resources._code_objects(data[off:off + size]):
+            nobj += 1
+            path = tmp_path / f"co{nobj}.co"
+            path.write_bytes(co)
+            text = subprocess.run([objdump, "-d", str(path)], capture_output=True, text=True, check=True).stdout
+            assert "global_load" in text or "s_load" in text, "the disassembly is empty?"
+            cur = None
+            for ln in text.splitlines():
+                mt = re.match(r"^[0-9a-f]+ <(\w+)>:", ln)
+                if mt:
+                    cur = mt.group(1)
+                elif re.search(r"\bflat_(load|store|atomic)", ln):
+                    total += 1
+                    per_kernel[cur] = per_kernel.get(cur, 0) + 1
+    assert nobj >= 5, "one code object per translation unit"
+    worst = sorted(per_kernel.items(), key=lambda kv: -kv[1])[:8]
+    assert total == 0, f"{total} flat accesses; worst kernels: {list(zip(kernel_resources.demangle([k for k, _ in worst]), [v for _, v in worst]))}"
