@@ -339,7 +339,7 @@ template <int BLK> __device__ inline void wg_sum_store(double v, double *slot)
 // walks all rows in order with DEPTH rows in flight exactly as k_tall_diag_adj MODE 1 does (product, product, add, each rounded: the bits
 // of jh_blockop_normal_mul), adds the damping term with the lincomb's rounding, stores y and leaves its share of <p, y> (fp64) to the
 // workgroup's partial.  Coefficients (bk, damp^2, the flags) come from device memory, so the launch is the same every iteration.
-template <typename S, int E, int NS, int DEPTH, int BLK = 256, int U = 1>
+template <typename S, int E, int NS, int DEPTH, int BLK = 256, int U = 1, bool NT = true>
 __global__ __launch_bounds__(BLK) void k_cg_normal(const jh_dev_block *__restrict__ blocks, int64_t nrow, const S *__restrict__ a_base, int64_t a_stride,
                                                    S *__restrict__ p, const S *__restrict__ sres, S *__restrict__ y, int64_t n_scalars,
                                                    const jh_cg_dev *__restrict__ stt, double *__restrict__ partials)
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(BLK) void k_cg_normal(const jh_dev_block *__restric
         for (int j = 0; j < DEPTH; j++) {
             const S *a = a_base ? a_base + (i + j) * a_stride : (const S *)blocks[i + j].coeff;
 #pragma unroll
-            for (int u = 0; u < U; u++) av[j][u] = ld<true>(reinterpret_cast<const V *>(a + sk[u]));
+            for (int u = 0; u < U; u++) av[j][u] = ld<NT>(reinterpret_cast<const V *>(a + sk[u]));
         }
 #pragma unroll
         for (int j = 0; j < DEPTH; j++)
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(BLK) void k_cg_normal(const jh_dev_block *__restric
         const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const V av = ld<true>(reinterpret_cast<const V *>(a + sk[u]));
+            const V av = ld<NT>(reinterpret_cast<const V *>(a + sk[u]));
             const V t = vmul<S, E, NS, V>(av, pv[u], false);
             acc[u] = acc[u] + vmul<S, E, NS, V>(av, t, true);
         }
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block
 // A thread owns U 16-byte vectors of the DOMAIN (v and the accumulator stay in registers) and walks all rows with DEPTH rows
 // in flight; every coefficient and every element of u is read once, u is written once: (3*N*n + 2*n)*s bytes where the two
 // separate halves move (5*N*n + 3*n)*s.  u and w come out bit-identical to the two-kernel sequence.
-template <typename S, int E, int NS, int U, int DEPTH, int BLK, bool MIXED = false>
+template <typename S, int E, int NS, int U, int DEPTH, int BLK, bool MIXED = false, bool NT = true>
 __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                           const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ u,
                                                           const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, int direct,
@@ -724,8 +724,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
             const S *a = a_base ? a_base + (i + j) * a_stride : (const S *)blocks[i + j].coeff;
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                av[j][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
-                uv[j][k] = use_old ? ld<true>(reinterpret_cast<const V *>(u + (i + j) * n_scalars + sk[k])) : (V)(S)0;
+                av[j][k] = ld<NT>(reinterpret_cast<const V *>(a + sk[k]));
+                uv[j][k] = use_old ? ld<NT>(reinterpret_cast<const V *>(u + (i + j) * n_scalars + sk[k])) : (V)(S)0;
             }
         }
 #pragma unroll
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
                 V r = (V)alpha * t;
                 if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; }  // u_i .= alpha*tmp .+ beta*u_i
                 if (ok[k]) {
-                    st<true>(reinterpret_cast<V *>(u + (i + j) * n_scalars + sk[k]), r);
+                    st<NT>(reinterpret_cast<V *>(u + (i + j) * n_scalars + sk[k]), r);
                     nrm += vnorm2<S, NS, V>(r);
                 }
                 acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, true);  // _m .+= conj(a_i) .* u_i   (1049)
@@ -746,12 +746,12 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
         const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
 #pragma unroll
         for (int k = 0; k < U; k++) {
-            V av = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+            V av = ld<NT>(reinterpret_cast<const V *>(a + sk[k]));
             V t = vmul<S, E, NS, V>(av, vv[k], false);
             V r = (V)alpha * t;
-            if (use_old) { V s2 = (V)beta * ld<true>(reinterpret_cast<const V *>(u + i * n_scalars + sk[k])); r = r + s2; }
+            if (use_old) { V s2 = (V)beta * ld<NT>(reinterpret_cast<const V *>(u + i * n_scalars + sk[k])); r = r + s2; }
             if (ok[k]) {
-                st<true>(reinterpret_cast<V *>(u + i * n_scalars + sk[k]), r);
+                st<NT>(reinterpret_cast<V *>(u + i * n_scalars + sk[k]), r);
                 nrm += vnorm2<S, NS, V>(r);
             }
             V p = vmul<S, E, NS, V>(av, r, true);
@@ -1038,6 +1038,10 @@ struct SumArgs {
 // computed that way with scale_k as a double: for a scalar that is T(a) in Julia the host passes double(T(a)), and
 // Float32(double(a32) * Float64(x)) == a32 * x in Float32 arithmetic (the Float64 product of two Float32 values is exact, so both
 // round the exact product once) -- one instantiation serves sums that mix wide and narrow scalars, with the chain's bits.
+// Occupancy (round 5): the WIDE instantiations, written for their arithmetic, turned out FASTER than the plain ones on the same box (16 terms:
+// adjoint 6.27 against 5.80 TB/s, forward 5.87 against 5.60) -- the compiler had given them fewer registers (150 / 121 VGPRs against 206 / 148),
+// i.e. three / four waves per SIMD instead of two / three (profiles/rocprof_r05_jetsum_summary.md: traffic = the algorithmic bytes, so the
+// shortfall was never wasted bytes).  amdgpu_waves_per_eu asks for that occupancy in every instantiation.
 template <typename S, int E, int NS, int U, int BLK, int KM, int D, bool WIDE = false>
 __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow, int rows_per_wg, const S *__restrict__ m,
                                                       S *__restrict__ d, int64_t n_scalars, unsigned ntiles, int accumulate)
@@ -2309,21 +2313,21 @@ int launch_tall_fwd(const jh_blockop *op, void *d, const void *m, int64_t n_scal
 template <typename S, int E, int NS>
 int launch_tall_fwd_shape(const jh_blockop *op, void *d, const void *m, int64_t n_scalars, const TallShape &sh)
 {
-    jh_context &c = jh_ctx();
-    if (sh.wg == 256) return c.nt ? launch_tall_fwd_u<S, E, NS, true, 256>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 256>(op, d, m, n_scalars, sh);
-    if (sh.wg == 512) return c.nt ? launch_tall_fwd_u<S, E, NS, true, 512>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 512>(op, d, m, n_scalars, sh);
-    return c.nt ? launch_tall_fwd_u<S, E, NS, true, 1024>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 1024>(op, d, m, n_scalars, sh);
+    const bool nt = jh_stream_nt(2.0 * (double)op->nrow * (double)n_scalars * sizeof(S));     // coefficients read + range vector written
+    if (sh.wg == 256) return nt ? launch_tall_fwd_u<S, E, NS, true, 256>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 256>(op, d, m, n_scalars, sh);
+    if (sh.wg == 512) return nt ? launch_tall_fwd_u<S, E, NS, true, 512>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 512>(op, d, m, n_scalars, sh);
+    return nt ? launch_tall_fwd_u<S, E, NS, true, 1024>(op, d, m, n_scalars, sh) : launch_tall_fwd_u<S, E, NS, false, 1024>(op, d, m, n_scalars, sh);
 }
 template <typename S, int E, int NS, int MODE>
 int launch_tall_adj(const jh_blockop *op, void *out, const void *in, int64_t n_scalars, int64_t s_begin = 0, int64_t s_end = -1)
 {
-    jh_context &c = jh_ctx();
     if (s_end < 0) s_end = n_scalars;
     if (s_end <= s_begin) return JH_OK;
     const TallShape sh = pick_adj_shape(n_scalars / NS, op->nrow, MODE);
-    if (sh.wg == 256) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 256>(op, out, in, n_scalars, sh, s_begin, s_end) : launch_tall_adj_u<S, E, NS, false, MODE, 256>(op, out, in, n_scalars, sh, s_begin, s_end);
-    if (sh.wg == 512) return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 512>(op, out, in, n_scalars, sh, s_begin, s_end) : launch_tall_adj_u<S, E, NS, false, MODE, 512>(op, out, in, n_scalars, sh, s_begin, s_end);
-    return c.nt ? launch_tall_adj_u<S, E, NS, true, MODE, 1024>(op, out, in, n_scalars, sh, s_begin, s_end) : launch_tall_adj_u<S, E, NS, false, MODE, 1024>(op, out, in, n_scalars, sh, s_begin, s_end);
+    const bool nt = jh_stream_nt((MODE == 0 ? 2.0 : 1.0) * (double)op->nrow * (double)n_scalars * sizeof(S));   // coefficients (+ the range vector)
+    if (sh.wg == 256) return nt ? launch_tall_adj_u<S, E, NS, true, MODE, 256>(op, out, in, n_scalars, sh, s_begin, s_end) : launch_tall_adj_u<S, E, NS, false, MODE, 256>(op, out, in, n_scalars, sh, s_begin, s_end);
+    if (sh.wg == 512) return nt ? launch_tall_adj_u<S, E, NS, true, MODE, 512>(op, out, in, n_scalars, sh, s_begin, s_end) : launch_tall_adj_u<S, E, NS, false, MODE, 512>(op, out, in, n_scalars, sh, s_begin, s_end);
+    return nt ? launch_tall_adj_u<S, E, NS, true, MODE, 1024>(op, out, in, n_scalars, sh, s_begin, s_end) : launch_tall_adj_u<S, E, NS, false, MODE, 1024>(op, out, in, n_scalars, sh, s_begin, s_end);
 }
 
 // Does the plain tall adjoint (MODE 0) take the split walk for this operator?  If so, reserve scratch for its slabs PLUS one
@@ -3007,7 +3011,9 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     }
     c.last_step_chain = 0;
 #define JH_LAUNCH(BLK, UU, DD) JH_LAUNCH_M(BLK, UU, DD, false)
-#define JH_LAUNCH_M(BLK, UU, DD, MIX)                                                                                   \
+#define JH_LAUNCH_T(BLK, UU, DD) JH_LAUNCH_N(BLK, UU, DD, false, false)
+#define JH_LAUNCH_M(BLK, UU, DD, MIX) JH_LAUNCH_N(BLK, UU, DD, MIX, true)
+#define JH_LAUNCH_N(BLK, UU, DD, MIX, NTV)                                                                              \
     if constexpr (!(E == 2 && sizeof(S) == 4 && BLK == 1024 && UU == 4 && DD == 1))                                      \
     if (wg == BLK && U == UU && D == DD && mixed == MIX) {                                                              \
         double total = 0.0;                                                                                              \
@@ -3015,7 +3021,7 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
         if (several) JH_CHECK_HIP(hipMemsetAsync(c.red_dev + 9, 0, sizeof(double), c.stream));                           \
         for (int64_t r0 = 0; r0 < op->nrow; r0 += rows_per_launch) {                                                     \
             const int64_t r1 = r0 + rows_per_launch < op->nrow ? r0 + rows_per_launch : op->nrow;                          \
-            hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK, MIX>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, \
+            hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK, MIX, NTV>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, \
                                c.stream,                                                                                 \
                                op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars,      \
                                direct, (S)alpha, (S)beta, c.part_dev, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0,              \
@@ -3037,12 +3043,18 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
         if (normsq) *normsq = total;                                                                                     \
         return trial_done(JH_OK);                                                                                        \
     }
+    // operators whose pass fits the Infinity Cache (jh_stream_nt: knob nt) run the three shapes small blocks select with TEMPORAL loads / stores
+    if (!mixed && wg == 256 && !jh_stream_nt(2.0 * (double)op->nrow * (double)n_scalars * sizeof(S))) {
+        JH_LAUNCH_T(256, 1, 4) JH_LAUNCH_T(256, 2, 2) JH_LAUNCH_T(256, 4, 1)
+    }
     JH_LAUNCH(256, 1, 4) JH_LAUNCH(256, 2, 2) JH_LAUNCH(256, 4, 1) JH_LAUNCH(256, 4, 2) JH_LAUNCH(256, 1, 8)
     JH_LAUNCH(512, 1, 4) JH_LAUNCH(512, 2, 2) JH_LAUNCH(512, 4, 1) JH_LAUNCH(512, 4, 2) JH_LAUNCH(512, 1, 8)
     JH_LAUNCH(1024, 1, 4) JH_LAUNCH(1024, 2, 2) JH_LAUNCH(1024, 4, 1)      // 1024 x 4 x 2 would need > 128 VGPRs per lane
     JH_LAUNCH_M(512, 1, 4, true) JH_LAUNCH_M(256, 2, 2, true) JH_LAUNCH_M(256, 4, 1, true) JH_LAUNCH_M(256, 1, 4, true)
 #undef JH_LAUNCH
+#undef JH_LAUNCH_T
 #undef JH_LAUNCH_M
+#undef JH_LAUNCH_N
     return jh_fail(JH_ERR_INVALID, "fused bidiagonalisation step: shape %d x %d x %d is not instantiated", wg, U, D);
 }
 
@@ -3384,15 +3396,17 @@ int jh_launch_cg_normal(const jh_blockop *op, jh_bvec *p, const jh_bvec *s, jh_b
     const int64_t grid = (packs + per_wg - 1) / per_wg;
     JH_REQUIRE(grid >= 1 && grid < ((int64_t)1 << 22), "cg normal pass: domain of %lld elements is out of range", (long long)n);
     *nparts = grid;
-#define JH_CGN_S(S, E, NS, DEPTH, BLK, U)                                                                                                       \
-    hipLaunchKernelGGL((k_cg_normal<S, E, NS, DEPTH, BLK, U>), dim3((unsigned)grid), dim3(BLK), 0, c.stream, op->dev_blocks, op->nrow,           \
+#define JH_CGN_S(S, E, NS, DEPTH, BLK, U, NTV)                                                                                                  \
+    hipLaunchKernelGGL((k_cg_normal<S, E, NS, DEPTH, BLK, U, NTV>), dim3((unsigned)grid), dim3(BLK), 0, c.stream, op->dev_blocks, op->nrow,      \
                        op->diag_strided ? (const S *)op->blocks[0].coeff : (const S *)nullptr, op->diag_stride_elems * E, (S *)p->data,          \
                        (const S *)s->data, (S *)y->data, n * E, st, partials)
+    // the coefficients of an operator that an iteration re-reads and that fit the Infinity Cache are loaded TEMPORAL (jh_stream_nt)
+    const bool nt = jh_stream_nt((double)op->nrow * (double)n * (double)jh_dtype_size(op->dtype));
 #define JH_CGN(S, E, NS)                                                                                                                        \
     do {                                                                                                                                        \
-        if (shape == 2) JH_CGN_S(S, E, NS, ((E == 2 && sizeof(S) == 4) ? 2 : 4), 1024, 4);                                                      \
-        else if (shape == 1) JH_CGN_S(S, E, NS, 2, 512, 2);                                                                                     \
-        else JH_CGN_S(S, E, NS, 8, 256, 1);                                                                                                     \
+        if (shape == 2) JH_CGN_S(S, E, NS, ((E == 2 && sizeof(S) == 4) ? 2 : 4), 1024, 4, true);                                                \
+        else if (shape == 1) { if (nt) JH_CGN_S(S, E, NS, 2, 512, 2, true); else JH_CGN_S(S, E, NS, 2, 512, 2, false); }                        \
+        else { if (nt) JH_CGN_S(S, E, NS, 8, 256, 1, true); else JH_CGN_S(S, E, NS, 8, 256, 1, false); }                                        \
     } while (0)
     switch (op->dtype) {
     case JH_F32: JH_CGN(float, 1, 4); break;

@@ -943,7 +943,8 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "adj_depth")) { JH_REQUIRE(one_of({0, 1, 2, 4, 8}), "adj_depth must be 0 (auto), 1, 2, 4 or 8"); c.adj_depth = value; }
     else if (!strcmp(name, "adj_wg")) { JH_REQUIRE(one_of({0, 256, 512, 1024}), "adj_wg must be 0 (auto), 256, 512 or 1024"); c.adj_wg = value; }
     else if (!strcmp(name, "fwd_order")) { JH_REQUIRE(value >= -1 && value <= 65536, "fwd_order must be -1 (auto), 0 (sequential), 1 (all rows) or k > 1 (k row groups per band)"); c.fwd_order = value; }
-    else if (!strcmp(name, "nt")) { c.nt = value ? 1 : 0; }
+    else if (!strcmp(name, "nt")) { JH_REQUIRE(value >= 0 && value <= 2, "nt must be 0 (temporal), 1 (nontemporal unless the working set is cache-resident) or 2 (always nontemporal)"); c.nt = value; }
+    else if (!strcmp(name, "nt_resident_mib")) { JH_REQUIRE(value >= 0, "nt_resident_mib must be >= 0"); c.nt_resident_mib = value; }
     else if (!strcmp(name, "slab_cache")) { g_slab_cache_on.store(value ? 1 : 0); if (!value) jh_slab_trim(-1); }   // the switch is process-wide: so is the trim
     else if (!strcmp(name, "bcast_item_fast")) { JH_REQUIRE(value >= -1 && value <= 1, "bcast_item_fast must be -1 (auto), 0 or 1"); c.bcast_item_fast = value; }
     else if (!strcmp(name, "adj_split")) { JH_REQUIRE(value >= -1 && value <= 65535, "adj_split must be -1 (auto), 0 (never: ordered walk) or the number of row parts"); c.adj_split = value; }
@@ -991,6 +992,7 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "adj_wg")) *value = c.adj_wg;
     else if (!strcmp(name, "fwd_order")) *value = c.fwd_order;
     else if (!strcmp(name, "nt")) *value = c.nt;
+    else if (!strcmp(name, "nt_resident_mib")) *value = c.nt_resident_mib;
     else if (!strcmp(name, "slab_cache")) *value = g_slab_cache_on.load();
     else if (!strcmp(name, "slab_cached_mib")) *value = (int64_t)(jh_slab_cached_bytes(c.device) >> 20);
     else if (!strcmp(name, "bcast_item_fast")) *value = c.bcast_item_fast;

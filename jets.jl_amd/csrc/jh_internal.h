@@ -89,7 +89,8 @@ struct jh_context {
     int64_t adj_split = -1;            // split-row walk of the adjoint-shaped kernels: -1 automatic, 0 never (ordered, bit-exact), k > 1 parts
     int64_t last_adj_parts = 1;        // row parts of the most recent tall adjoint / fused normal / one-pass step (read-only knob)
     int64_t bcast_item_fast = -1;      // batched broadcasts with a shared operand: items as the fastest block index (-1 automatic, 0 never, 1 always)
-    int64_t nt = 1;                    // nontemporal loads/stores on the streamed operands
+    int64_t nt = 1;                    // nontemporal loads/stores on the streamed operands: 0 never, 1 unless the working set stays in the Infinity Cache (jh_stream_nt), 2 always
+    int64_t nt_resident_mib = 0;       // knob: working sets up to this many MiB count as cache-resident for nt = 1 (0: none -- everything streams)
     int64_t autotune = 1;              // time both grid walks of the tall forward once per large operator
     int64_t general_xcd = 1;           // general M x K kernels: 1 = XCD-aware (line, tile) decode from 32 MiB of input on, else line by line; 0 never; 2 always
     int64_t graphs = 1;                // replay launch-bound per-block loops as hipGraphs (jh_blockop.hip: run_loop_graphed)
@@ -135,6 +136,17 @@ struct jh_context {
                                        // forward of a wide operator through its tall twin: `_d .+=` into d as found, src/Jets.jl:1024); never split
 };
 jh_context &jh_ctx();                  // the calling thread's current context (a never-ready dummy before jh_init)
+// Should a kernel that is launched again and again over the same operands (a solver's step, the fused A'A of CG) stream them NONTEMPORAL?
+// Nontemporal loads do not stay in the 256 MiB Infinity Cache: right for operands far larger than it (every byte is used once per pass),
+// wrong for an operator that fits -- its coefficients would come from HBM every iteration although the cache could hold them.
+// Knob nt: 0 never, 2 always, 1 (default): nontemporal unless the working set of one pass is at most nt_resident_mib.
+inline bool jh_stream_nt(double working_set_bytes)
+{
+    const jh_context &c = jh_ctx();
+    if (c.nt == 0) return false;
+    if (c.nt >= 2) return true;
+    return !(working_set_bytes <= (double)c.nt_resident_mib * 1048576.0);
+}
 jh_context *jh_ctx_by_id(int id);      // nullptr when there is no such context (also: the slot now holds a later generation)
 // Destructors (jh_bvec_destroy, jh_blockop_destroy) run at moments a garbage collector chooses: they wait for the handle's
 // context and free on its device WITHOUT making it the calling thread's current context (the device is restored when the scope

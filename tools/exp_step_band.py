@@ -50,10 +50,11 @@ for nblocks, edge in shapes:
         else:
             nat.tune_set("step_mode", 2); J.tune(step_band=key)
         one_pass(0.75, 0.0)
-        got = (w.to_numpy().tobytes(), out.value, J.getblock(u, nblocks - 1).to_numpy().tobytes())
+        got = (w.to_numpy().tobytes(), J.getblock(u, nblocks - 1).to_numpy().tobytes(), out.value)
         if ref is None:
             ref = got
-        assert got == ref, f"walk {key}: w / ||u||^2 / last block of u differ from the plain walk"
+        assert got[:2] == ref[:2], f"walk {key}: w / last block of u differ from the plain walk"
+        assert abs(got[2] - ref[2]) <= 1e-12 * abs(ref[2]), f"walk {key}: ||u||^2"       # (fp64 partial sums folded in the walk's own order: tolerance)
     J.tune(step_band=-1); nat.tune_set("step_mode", -1)
     print(f"{nblocks:5d} x {edge}^3 one-pass step, TB/s over 3 N n s: " + " | ".join(f"{k if k == 'plain' else 'band ' + str(k)} {b3 / res[k] / 1e9:5.2f} ({res[k]:.3f} ms)" for k in ["plain"] + bands) + "   [bits identical]", flush=True)
     del u, v, w, coeff; J.close(A)
