@@ -90,7 +90,9 @@ struct jh_context {
     int64_t last_adj_parts = 1;        // row parts of the most recent tall adjoint / fused normal / one-pass step (read-only knob)
     int64_t bcast_item_fast = -1;      // batched broadcasts with a shared operand: items as the fastest block index (-1 automatic, 0 never, 1 always)
     int64_t nt = 1;                    // nontemporal loads/stores on the streamed operands: 0 never, 1 unless the working set stays in the Infinity Cache (jh_stream_nt), 2 always
-    int64_t nt_resident_mib = 0;       // knob: working sets up to this many MiB count as cache-resident for nt = 1 (0: none -- everything streams)
+    int64_t nt_resident_mib = 256;     // knob: working sets up to this many MiB count as cache-resident for nt = 1 (0: none -- everything streams).  256 from
+                                       // profiles/exp_r05_nt_small.txt: with coefficients + range vector <= 256 MiB temporal loads win (pair +7 %, one-pass step +7 ... +19 %,
+                                       // LSQR iteration -9 %), from 512 MiB on nontemporal ones do (+10 ... +15 %)
     int64_t autotune = 1;              // time both grid walks of the tall forward once per large operator
     int64_t general_xcd = 1;           // general M x K kernels: 1 = XCD-aware (line, tile) decode from 32 MiB of input on, else line by line; 0 never; 2 always
     int64_t graphs = 1;                // replay launch-bound per-block loops as hipGraphs (jh_blockop.hip: run_loop_graphed)
