@@ -105,6 +105,8 @@ struct jh_context {
     int64_t last_adj_launches = 1;     // kernel launches of the most recent tall adjoint / fused normal call (read-only knob)
     int64_t last_fwd_walk = 0;         // grid walk used by the most recent tall forward launch (read-only knob)
     int64_t last_step_chain = 0;       // row chunks of the most recent one-pass step (0: the plain walk) (read-only knob)
+    int64_t step_pipe = 0;             // knob (experiment): the all-diagonal one-pass step software-pipelined (k_tall_diag_bidiag PIPE), shapes 512 / 256 x 1 x 4, 512 x 1 x 8
+    int64_t step_chunk = 8;            // knob (experiment): rows per chunk of the chained one-pass step: 8, or 16 (all-diagonal operators, 512 / 256 lanes)
     int64_t step_band = -1;            // knob: the chained one-pass step in column bands of this many tiles (-1: the default, 0: none -- tiles fastest over the whole row)
     int64_t grid_diag = 1;             // knob: M x K grids of plain diagonals on the branch-free kernel (0: the general kernels)
     int64_t grid_tile = 1;             // knob: ... register-tiled (k_grid_tile: R lines x one tile per workgroup): 1 automatic R, 2 / 4 / 8 that R, 0: k_grid_diag

@@ -160,7 +160,10 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block
 // A thread owns U 16-byte vectors of the DOMAIN (v and the accumulator stay in registers) and walks all rows with DEPTH rows
 // in flight; every coefficient and every element of u is read once, u is written once: (3*N*n + 2*n)*s bytes where the two
 // separate halves move (5*N*n + 3*n)*s.  u and w come out bit-identical to the two-kernel sequence.
-template <typename S, int E, int NS, int U, int DEPTH, int BLK, bool MIXED = false, bool NT = true>
+// PIPE (round 5, an experiment behind the knob step_pipe): the all-diagonal walk software-pipelined -- the loads of batch b + 1 are issued
+// BEFORE batch b is combined and stored (two register buffers), so a wave always has a batch of loads in flight instead of alternating
+// between "all loads" and "all arithmetic + stores".  Same rows, same order, same bits.
+template <typename S, int E, int NS, int U, int DEPTH, int BLK, bool MIXED = false, bool NT = true, bool PIPE = false>
 __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                           const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ u,
                                                           const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, int direct,
@@ -291,7 +294,49 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
             }
         }
     }
-    for (; !MIXED && !direct && i + DEPTH <= row1; i += DEPTH) {
+    if constexpr (!MIXED && PIPE) {
+        auto loadb = [&](V (&av)[DEPTH][U], V (&uv)[DEPTH][U], int64_t ib) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; j++) {
+                const S *a = a_base ? a_base + (ib + j) * a_stride : (const S *)blocks[ib + j].coeff;
+#pragma unroll
+                for (int k = 0; k < U; k++) {
+                    av[j][k] = ld<NT>(reinterpret_cast<const V *>(a + sk[k]));
+                    uv[j][k] = use_old ? ld<NT>(reinterpret_cast<const V *>(u + (ib + j) * n_scalars + sk[k])) : (V)(S)0;
+                }
+            }
+        };
+        auto compb = [&](V (&av)[DEPTH][U], V (&uv)[DEPTH][U], int64_t ib) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+                for (int k = 0; k < U; k++) {
+                    V t = vmul<S, E, NS, V>(av[j][k], vv[k], false);
+                    V r = (V)alpha * t;
+                    if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; }
+                    if (ok[k]) {
+                        st<NT>(reinterpret_cast<V *>(u + (ib + j) * n_scalars + sk[k]), r);
+                        nrm += vnorm2<S, NS, V>(r);
+                    }
+                    acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, true);
+                }
+        };
+        if (!direct && i + DEPTH <= row1) {
+            V avA[DEPTH][U], uvA[DEPTH][U], avB[DEPTH][U], uvB[DEPTH][U];
+            loadb(avA, uvA, i);
+            for (;;) {
+                if (i + 2 * DEPTH > row1) { compb(avA, uvA, i); i += DEPTH; break; }
+                loadb(avB, uvB, i + DEPTH);
+                compb(avA, uvA, i);
+                i += DEPTH;
+                if (i + 2 * DEPTH > row1) { compb(avB, uvB, i); i += DEPTH; break; }
+                loadb(avA, uvA, i + DEPTH);
+                compb(avB, uvB, i);
+                i += DEPTH;
+            }
+        }
+    }
+    for (; !MIXED && !PIPE && !direct && i + DEPTH <= row1; i += DEPTH) {
         V av[DEPTH][U], uv[DEPTH][U];
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) {
@@ -785,12 +830,15 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     //           (rows of any elementwise kind: the MIXED instantiation, profiles/bench_mixed_rows_r02.txt)
     // All three compute the same bits.  A mode other than 0 stays only if it wins by 1 %.  Knob step_chain: -1 measure,
     // 0 never chain, 1 chain whenever the shape allows (tests); jh_blockop_tune_get/set "step_mode" exports / imports the choice.
-    constexpr int CD = 8;                                                 // rows per chunk = rows in flight
+    // rows per chunk = rows in flight: 8; knob step_chunk = 16 (round 5, experiment: half as many hand-offs and re-reads of v; all-diagonal
+    // operators, 512 or 256 lanes per workgroup -- sixteen rows of a and u in flight are 128 registers per lane)
+    const int CD = (c.step_chunk == 16 && !mixed) ? 16 : 8;
     const int64_t span = s_end - s_begin, nchunks = (op->nrow + CD - 1) / CD;
     const bool knobs_free = !c.adj_wg && !c.adj_unroll && !c.adj_depth;
     int cb = 0;                                                           // chained: workgroup size (0: the shape does not allow it)
     if (!direct && parts == 1 && rows_per_launch == op->nrow && nchunks >= 2)
         for (int b : {1024, 512, 256}) {
+            if (CD == 16 && b == 1024) continue;
             if (c.step_chain == 1 && c.adj_wg && c.adj_wg != b) continue;  // (knobs step_chain = 1 + adj_wg: that workgroup size, for sweeps)
             if (span % ((int64_t)b * NS) == 0 && (c.step_chain == 1 || (b == 1024 && span / ((int64_t)b * NS) >= 1024 && op->nrow >= 16))) { cb = b; break; }
         }
@@ -838,20 +886,25 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
         // column bands of the chained walk (knob step_band: -1 the default below, 0 none = tiles fastest over the whole row, k tiles per band)
         int64_t cband = c.step_band >= 0 ? c.step_band : 0;
         if (cband >= ntiles) cband = 0;
-#define JH_CHAIN(BLK, MIX)                                                                                                \
-    hipLaunchKernelGGL((k_tall_diag_bidiag_chain<S, E, NS, 1, CD, BLK, MIX>), dim3((unsigned)(ntiles * nchunks)), dim3(BLK), 0, c.stream, \
+#define JH_CHAIN(BLK, MIX) JH_CHAIN_D(BLK, MIX, 8)
+#define JH_CHAIN_D(BLK, MIX, CDD)                                                                                         \
+    hipLaunchKernelGGL((k_tall_diag_bidiag_chain<S, E, NS, 1, CDD, BLK, MIX>), dim3((unsigned)(ntiles * nchunks)), dim3(BLK), 0, c.stream, \
                        op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars, (S)alpha, (S)beta,   \
                        c.part_dev, s_begin, s_end, (unsigned)ntiles, (unsigned)nchunks, c.chain_sync, (S *)wpart, err, (unsigned)cband)
         if (mixed) {
             if (cb == 1024) JH_CHAIN(1024, true);
             else if (cb == 512) JH_CHAIN(512, true);
             else JH_CHAIN(256, true);
+        } else if (CD == 16) {
+            if (cb == 512) JH_CHAIN_D(512, false, 16);
+            else JH_CHAIN_D(256, false, 16);
         } else {
             if (cb == 1024) JH_CHAIN(1024, false);
             else if (cb == 512) JH_CHAIN(512, false);
             else JH_CHAIN(256, false);
         }
 #undef JH_CHAIN
+#undef JH_CHAIN_D
         JH_CHECK_HIP(hipGetLastError());
         c.last_step_chain = nchunks;
         c.last_adj_parts = 1;
@@ -864,7 +917,9 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
 #define JH_LAUNCH(BLK, UU, DD) JH_LAUNCH_M(BLK, UU, DD, false)
 #define JH_LAUNCH_T(BLK, UU, DD) JH_LAUNCH_N(BLK, UU, DD, false, false)
 #define JH_LAUNCH_M(BLK, UU, DD, MIX) JH_LAUNCH_N(BLK, UU, DD, MIX, true)
-#define JH_LAUNCH_N(BLK, UU, DD, MIX, NTV)                                                                              \
+#define JH_LAUNCH_P(BLK, UU, DD) JH_LAUNCH_Q(BLK, UU, DD, false, true, true)
+#define JH_LAUNCH_N(BLK, UU, DD, MIX, NTV) JH_LAUNCH_Q(BLK, UU, DD, MIX, NTV, false)
+#define JH_LAUNCH_Q(BLK, UU, DD, MIX, NTV, PP)                                                                          \
     if constexpr (!(E == 2 && sizeof(S) == 4 && BLK == 1024 && UU == 4 && DD == 1))                                      \
     if (wg == BLK && U == UU && D == DD && mixed == MIX) {                                                              \
         double total = 0.0;                                                                                              \
@@ -872,7 +927,7 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
         if (several) JH_CHECK_HIP(hipMemsetAsync(c.red_dev + 9, 0, sizeof(double), c.stream));                           \
         for (int64_t r0 = 0; r0 < op->nrow; r0 += rows_per_launch) {                                                     \
             const int64_t r1 = r0 + rows_per_launch < op->nrow ? r0 + rows_per_launch : op->nrow;                          \
-            hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK, MIX, NTV>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, \
+            hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK, MIX, NTV, PP>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, \
                                c.stream,                                                                                 \
                                op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars,      \
                                direct, (S)alpha, (S)beta, c.part_dev, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0,              \
@@ -898,6 +953,9 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     if (!mixed && wg == 256 && !jh_stream_nt(2.0 * (double)op->nrow * (double)n_scalars * sizeof(S))) {
         JH_LAUNCH_T(256, 1, 4) JH_LAUNCH_T(256, 2, 2) JH_LAUNCH_T(256, 4, 1)
     }
+    if (!mixed && c.step_pipe) {                                                    // the software-pipelined walk (experiment: knob step_pipe)
+        JH_LAUNCH_P(512, 1, 4) JH_LAUNCH_P(256, 1, 4) JH_LAUNCH_P(512, 1, 8)
+    }
     JH_LAUNCH(256, 1, 4) JH_LAUNCH(256, 2, 2) JH_LAUNCH(256, 4, 1) JH_LAUNCH(256, 4, 2) JH_LAUNCH(256, 1, 8)
     JH_LAUNCH(512, 1, 4) JH_LAUNCH(512, 2, 2) JH_LAUNCH(512, 4, 1) JH_LAUNCH(512, 4, 2) JH_LAUNCH(512, 1, 8)
     JH_LAUNCH(1024, 1, 4) JH_LAUNCH(1024, 2, 2) JH_LAUNCH(1024, 4, 1)      // 1024 x 4 x 2 would need > 128 VGPRs per lane
@@ -906,6 +964,8 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
 #undef JH_LAUNCH_T
 #undef JH_LAUNCH_M
 #undef JH_LAUNCH_N
+#undef JH_LAUNCH_P
+#undef JH_LAUNCH_Q
     return jh_fail(JH_ERR_INVALID, "fused bidiagonalisation step: shape %d x %d x %d is not instantiated", wg, U, D);
 }
 
