@@ -659,7 +659,7 @@ def worker_ranks(args):
             J.mul_(mt, A.H, d)
 
     # operator setup, outside the warm-up count: the first forwards of a large operator each try one grid walk (lazy autotune,
-    # jh_blockop.hip: lazy_next -- no extra launches, no host sync; 16 calls, 20 with a play-off between the two best, until the choice is made) and the first
+    # jh_tall.hip: lazy_next -- no extra launches, no host sync; 16 calls, 20 with a play-off between the two best, until the choice is made) and the first
     # collective builds RCCL's channels -- with --warmup 0 neither may land in the timed region
     forward()
     adjoint()

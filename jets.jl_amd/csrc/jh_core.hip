@@ -954,8 +954,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "small_loop")) { c.small_loop = value ? 1 : 0; }
     else if (!strcmp(name, "force_dist")) { c.force_dist = value ? 1 : 0; }
     else if (!strcmp(name, "step_chain")) { JH_REQUIRE(value >= -1 && value <= 1, "step_chain must be -1 (auto), 0 or 1"); c.step_chain = value; }
-    else if (!strcmp(name, "step_pipe")) { c.step_pipe = value ? 1 : 0; }
-    else if (!strcmp(name, "step_chunk")) { JH_REQUIRE(value == 8 || value == 16, "step_chunk must be 8 or 16"); c.step_chunk = value; }
+    else if (!strcmp(name, "step_chunk")) { JH_REQUIRE(value == 0 || value == 8 || value == 16 || value == 32, "step_chunk must be 0 (automatic), 8, 16 or 32"); c.step_chunk = value; }
     else if (!strcmp(name, "step_band")) { JH_REQUIRE(value >= -1 && value < ((int64_t)1 << 24), "step_band must be -1 (default), 0 (none) or a number of tiles"); c.step_band = value; }
     else if (!strcmp(name, "general_xcd")) { JH_REQUIRE(value >= 0 && value <= 2, "general_xcd must be 0 (never), 1 (automatic) or 2 (always)"); c.general_xcd = value; }
     else if (!strcmp(name, "lsqr_graph")) { c.lsqr_graph = value < 0 ? 0 : (value > 2 ? 2 : value); }
@@ -1007,7 +1006,6 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "force_dist")) *value = c.force_dist;
     else if (!strcmp(name, "step_chain")) *value = c.step_chain;
     else if (!strcmp(name, "step_band")) *value = c.step_band;
-    else if (!strcmp(name, "step_pipe")) *value = c.step_pipe;
     else if (!strcmp(name, "step_chunk")) *value = c.step_chunk;
     else if (!strcmp(name, "last_step_chain")) *value = c.last_step_chain;
     else if (!strcmp(name, "general_xcd")) *value = c.general_xcd;

@@ -17,7 +17,7 @@ template <typename S> struct vec_of<S, 1> { typedef S type; };
 
 // every operand of these kernels lives in HBM: load / store through address_space(1) pointers, so that the compiler emits global_load /
 // global_store (never flat_*: a flat access also waits on the LDS counter and costs an address-space check) -- in particular for the
-// matrix pointers READ FROM THE BLOCK TABLE, whose address space the compiler cannot know (round 5; jh_blockop.hip has done so since
+// matrix pointers READ FROM THE BLOCK TABLE, whose address space the compiler cannot know (round 5; the block-operator kernels -- jh_blockop_common.h: ld / st -- have done so since
 // round 1; tests/test_kernel_resources.py disassembles this code object and finds no flat access)
 template <typename V> __device__ inline V ldg_nt(const V *p)
 {
@@ -1017,12 +1017,12 @@ int gemv(const void *A, int64_t nr, int64_t nc, void *y, const void *x, int adjo
 // ---- ALL dense children of an operator that mixes them with other kinds (round 3) ------------------------------------------------
 // Operators with DENSE children that fit none of the uniform batches above -- dense next to diagonal / identity / zero blocks,
 // children of different shapes -- and are too big for the one-launch loop used to run the reference's loop literally: one child
-// launch + one accumulate launch per non-zero block (jh_blockop.hip: loop_fwd / loop_adj).  Here ONE launch runs every dense child
+// launch + one accumulate launch per non-zero block (jh_general.hip: loop_fwd / loop_adj).  Here ONE launch runs every dense child
 // (blockIdx.y = block column j, blockIdx.z = block row i; a block that is not an un-adjointed dense matrix returns at once): child
 // (i, j) is row_len[i] x col_len[j], reads m_j (forward) / d_i (adjoint), and leaves its product, rounded to the element type like
 // the reference's dtmp / mtmp, in a slab (forward: slab j at row i's elements of the range; adjoint: slab i at column j's elements
 // of the domain).  ONE launch of the general kernels then walks every output line in the reference's order, taking a dense block's
-// term from its slab (jh_blockop.hip: dense_mixed_apply): two launches per mul! instead of up to 2 M K.
+// term from its slab (jh_general.hip: dense_mixed_apply): two launches per mul! instead of up to 2 M K.
 // y = B x for the children this pass owns (B column-major, its own leading dimension).  `transposed` = the pass belongs to the
 // operator's ADJOINT: then it takes the ADJOINTED children -- block (i, j) = B', whose adjoint is B: B is col_len[j] x row_len[i],
 // reads d_i, writes slab i at column j's elements -- while in the forward it takes the un-adjointed ones (B = row_len[i] x col_len[j],
@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(256) void k_gemv_cols_mixed(const jh_dev_block *__r
     }
 }
 
-// rows_pass / cols_pass: which of the two kernels have children to process in this direction (jh_blockop.hip knows); max_out / max_in:
+// rows_pass / cols_pass: which of the two kernels have children to process in this direction (jh_general.hip: dense_mixed_apply knows); max_out / max_in:
 // the largest output / input length over those children (grid sizing)
 template <typename S, int E>
 int gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64_t rows_max_out, int64_t cols_max_out, void *slabs, int64_t slab_stride,

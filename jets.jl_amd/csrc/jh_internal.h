@@ -77,7 +77,7 @@ struct jh_context {
     int64_t chain_sync_cap = 0;
     int64_t step_chain = -1;           // knob: one-pass step as chained row chunks: -1 automatic, 0 never, 1 always (when the shape allows)
     // tuning knobs (jh_tune_set)
-    // 0 = pick from the problem size (jh_blockop.hip: pick_fwd_shape / pick_adj_shape)
+    // 0 = pick from the problem size (jh_tall.hip: pick_fwd_shape / pick_adj_shape)
     int64_t fwd_group = 0;             // block rows streamed per workgroup (tall forward)
     int64_t fwd_unroll = 0;            // 16-byte vectors per thread per block (tall forward)
     int64_t fwd_wg = 0;                // threads per workgroup (tall forward)
@@ -105,8 +105,7 @@ struct jh_context {
     int64_t last_adj_launches = 1;     // kernel launches of the most recent tall adjoint / fused normal call (read-only knob)
     int64_t last_fwd_walk = 0;         // grid walk used by the most recent tall forward launch (read-only knob)
     int64_t last_step_chain = 0;       // row chunks of the most recent one-pass step (0: the plain walk) (read-only knob)
-    int64_t step_pipe = 0;             // knob (experiment): the all-diagonal one-pass step software-pipelined (k_tall_diag_bidiag PIPE), shapes 512 / 256 x 1 x 4, 512 x 1 x 8
-    int64_t step_chunk = 8;            // knob (experiment): rows per chunk of the chained one-pass step: 8, or 16 (all-diagonal operators, 512 / 256 lanes)
+    int64_t step_chunk = 0;            // knob: rows per chunk of the chained one-pass step: 0 automatic (32 rows x 256 lanes for all-diagonal operators, else 8), 8, 16, 32
     int64_t step_band = -1;            // knob: the chained one-pass step in column bands of this many tiles (-1: the default, 0: none -- tiles fastest over the whole row)
     int64_t grid_diag = 1;             // knob: M x K grids of plain diagonals on the branch-free kernel (0: the general kernels)
     int64_t grid_tile = 1;             // knob: ... register-tiled (k_grid_tile: R lines x one tile per workgroup): 1 automatic R, 2 / 4 / 8 that R, 0: k_grid_diag
@@ -276,10 +275,10 @@ struct jh_blockop {
     // hipGraph replay of the per-block loop (operators with DENSE blocks: 2 launches per block), keyed on the vectors' addresses
     struct LoopGraph { const void *out; const void *in; int mode; int seen; uint64_t gen; hipGraphExec_t exec; };
     mutable std::vector<LoopGraph> loop_graphs;
-    mutable int fwd_walk = -1;               // autotuned tall-forward shape: -1 untried, else an index into k_fwd_candidates (jh_blockop.hip)
-    mutable bool walk_inherited = false;     // ... taken over from an earlier operator of the same shape (jh_blockop.hip: walk_recall)
+    mutable int fwd_walk = -1;               // autotuned tall-forward shape: -1 untried, else an index into k_fwd_candidates (jh_tall.hip)
+    mutable bool walk_inherited = false;     // ... taken over from an earlier operator of the same shape (jh_tall.hip: walk_recall)
     bool walk_measure_again = false;         // jh_blockop_tune_set(op, "fwd_walk", -1): this operator measures for itself
-    // lazy autotune (jh_blockop.hip: lazy_*): the first real calls each run ONE candidate between two events -- no extra
+    // lazy autotune (jh_tall.hip: lazy_*): the first real calls each run ONE candidate between two events -- no extra
     // launches, no host synchronisation -- and finished timings are harvested with hipEventQuery on later calls
     struct LazyTune {
         static constexpr int SLOTS = 24;     // up to 10 candidates x 2 passes + a play-off of 4
@@ -378,12 +377,12 @@ __host__ __device__ inline void cg_s2(jh_cg_dev *st, double ssum, double rsum, d
     if (istop && !(st->force && itn < st->maxiter && st->gamma > 0)) st->done = 1;
 }
 
-// jh_blockop.hip: one launch = [p <- s + bk p unless st->skip_p] ; y = A'A p (+ damp2 p) with the bits of jh_blockop_normal_mul (+ the
+// jh_tall.hip: one launch = [p <- s + bk p unless st->skip_p] ; y = A'A p (+ damp2 p) with the bits of jh_blockop_normal_mul (+ the
 // lincomb) ; one fp64 partial of <p, y> per workgroup of 256 packs.  *nparts = the number of partials written.
 int64_t jh_bidiag_step_parts(const jh_blockop *op);   // row ranges of the one-pass step over the whole domain (1: one plain launch)
 int jh_launch_cg_normal(const jh_blockop *op, jh_bvec *p, const jh_bvec *s, jh_bvec *y, const jh_cg_dev *st, double *partials, int64_t *nparts);
 void jh_bcast_clear_cache();            // jh_bcast.hip: unload every JIT-compiled broadcast program (jh_shutdown)
-int jh_chain_err_check();               // jh_blockop.hip: fails loudly if the chained step's sticky error word (copied to red_host[3]) is set
+int jh_chain_err_check();               // jh_core.hip: fails loudly if the chained step's sticky error word (copied to red_host[3]) is set
 int jh_ensure_partials(int64_t n);     // grows ctx.part_dev to >= n doubles (may synchronise + reallocate)
 extern "C" int jh_dot_begin(const jh_bvec *x, const jh_bvec *y);      // jh_vecops.hip: jh_dot in two halves (enqueue / wait + read), internal
 extern "C" int jh_dot_end(const jh_bvec *x, double *re, double *im);

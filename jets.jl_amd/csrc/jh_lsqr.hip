@@ -1004,7 +1004,7 @@ static int cgls_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *
 // Here -- as lsqr_graph_impl does for LSQR -- the scalars of the recurrences are a struct in device memory (jh_cg_dev), the one-thread
 // epilogues of two fold kernels update it, every vector kernel reads its coefficients from it and becomes a no-op once the solve has
 // finished, so one iteration has fixed launch parameters, is captured ONCE as a hipGraph and replayed:
-//   CG on the normal equations, 3 nodes:  k_cg_normal  [p <- s + bk p ; y = (A'A + damp^2) p ; partial <p, y>]      (jh_blockop.hip)
+//   CG on the normal equations, 3 nodes:  k_cg_normal  [p <- s + bk p ; y = (A'A + damp^2) p ; partial <p, y>]      (jh_tall.hip)
 //                                         k_cg_xs      [fold of <p, y> -> alpha, breakdown ; x += alpha p ; s -= alpha y ; partial ||s||^2]
 //                                         k_cg_fold    [gamma', beta, ||r|| by recurrence, history, stopping rules]
 //   CGLS, 5 nodes:  k_cg_normal ; k_cg_fold ; the one-pass step r <- r - alpha A p, A'r, partial ||r||^2 (coefficients from the device) ;

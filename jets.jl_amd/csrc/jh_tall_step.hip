@@ -160,10 +160,9 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block
 // A thread owns U 16-byte vectors of the DOMAIN (v and the accumulator stay in registers) and walks all rows with DEPTH rows
 // in flight; every coefficient and every element of u is read once, u is written once: (3*N*n + 2*n)*s bytes where the two
 // separate halves move (5*N*n + 3*n)*s.  u and w come out bit-identical to the two-kernel sequence.
-// PIPE (round 5, an experiment behind the knob step_pipe): the all-diagonal walk software-pipelined -- the loads of batch b + 1 are issued
-// BEFORE batch b is combined and stored (two register buffers), so a wave always has a batch of loads in flight instead of alternating
-// between "all loads" and "all arithmetic + stores".  Same rows, same order, same bits.
-template <typename S, int E, int NS, int U, int DEPTH, int BLK, bool MIXED = false, bool NT = true, bool PIPE = false>
+// (Round 5, tried and dropped: the all-diagonal walk SOFTWARE-PIPELINED -- the loads of batch b + 1 issued before batch b is combined and
+// stored, two register buffers: 34.27 against 34.50 ms at 1024 x 256^3, 8.80 against 8.79 at 256 x 256^3, profiles/exp_r05_step_pipe.txt.)
+template <typename S, int E, int NS, int U, int DEPTH, int BLK, bool MIXED = false, bool NT = true>
 __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                           const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ u,
                                                           const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, int direct,
@@ -294,49 +293,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
             }
         }
     }
-    if constexpr (!MIXED && PIPE) {
-        auto loadb = [&](V (&av)[DEPTH][U], V (&uv)[DEPTH][U], int64_t ib) {
-#pragma unroll
-            for (int j = 0; j < DEPTH; j++) {
-                const S *a = a_base ? a_base + (ib + j) * a_stride : (const S *)blocks[ib + j].coeff;
-#pragma unroll
-                for (int k = 0; k < U; k++) {
-                    av[j][k] = ld<NT>(reinterpret_cast<const V *>(a + sk[k]));
-                    uv[j][k] = use_old ? ld<NT>(reinterpret_cast<const V *>(u + (ib + j) * n_scalars + sk[k])) : (V)(S)0;
-                }
-            }
-        };
-        auto compb = [&](V (&av)[DEPTH][U], V (&uv)[DEPTH][U], int64_t ib) {
-#pragma unroll
-            for (int j = 0; j < DEPTH; j++)
-#pragma unroll
-                for (int k = 0; k < U; k++) {
-                    V t = vmul<S, E, NS, V>(av[j][k], vv[k], false);
-                    V r = (V)alpha * t;
-                    if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; }
-                    if (ok[k]) {
-                        st<NT>(reinterpret_cast<V *>(u + (ib + j) * n_scalars + sk[k]), r);
-                        nrm += vnorm2<S, NS, V>(r);
-                    }
-                    acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, true);
-                }
-        };
-        if (!direct && i + DEPTH <= row1) {
-            V avA[DEPTH][U], uvA[DEPTH][U], avB[DEPTH][U], uvB[DEPTH][U];
-            loadb(avA, uvA, i);
-            for (;;) {
-                if (i + 2 * DEPTH > row1) { compb(avA, uvA, i); i += DEPTH; break; }
-                loadb(avB, uvB, i + DEPTH);
-                compb(avA, uvA, i);
-                i += DEPTH;
-                if (i + 2 * DEPTH > row1) { compb(avB, uvB, i); i += DEPTH; break; }
-                loadb(avA, uvA, i + DEPTH);
-                compb(avB, uvB, i);
-                i += DEPTH;
-            }
-        }
-    }
-    for (; !MIXED && !PIPE && !direct && i + DEPTH <= row1; i += DEPTH) {
+    for (; !MIXED && !direct && i + DEPTH <= row1; i += DEPTH) {
         V av[DEPTH][U], uv[DEPTH][U];
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) {
@@ -830,13 +787,25 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     //           (rows of any elementwise kind: the MIXED instantiation, profiles/bench_mixed_rows_r02.txt)
     // All three compute the same bits.  A mode other than 0 stays only if it wins by 1 %.  Knob step_chain: -1 measure,
     // 0 never chain, 1 chain whenever the shape allows (tests); jh_blockop_tune_get/set "step_mode" exports / imports the choice.
-    // rows per chunk = rows in flight: 8; knob step_chunk = 16 (round 5, experiment: half as many hand-offs and re-reads of v; all-diagonal
-    // operators, 512 or 256 lanes per workgroup -- sixteen rows of a and u in flight are 128 registers per lane)
-    const int CD = (c.step_chunk == 16 && !mixed) ? 16 : 8;
-    const int64_t span = s_end - s_begin, nchunks = (op->nrow + CD - 1) / CD;
+    // rows per chunk = rows in flight.  Round 5: THIRTY-TWO rows of one 256-lane tile per workgroup for all-diagonal operators (thirty-two rows
+    // of a and u in flight are 256 registers per lane: one wave per SIMD, 64 loads in flight per lane) -- a quarter of the hand-offs and of the
+    // re-reads of v of the 8-row chunks of rounds 2-4, and each workgroup still "born, moves one batch, dies": 1024 x 256^3 5.98 -> 6.23 TB/s
+    // (34.5 -> 33.1 ms), 256 x 256^3 5.99 -> 6.23, 128 x 256^3 6.11 -> 6.36, and rows of 8 MiB, where the 8-row chunks never paid, 5.67 -> 6.02
+    // (profiles/exp_r05_step_chunks.txt; 16-row chunks of 512 lanes: 6.19-6.29 on 64 MiB rows, 5.2 on 8 MiB rows).  Rows of several kinds keep
+    // 8 rows x 1024 lanes (their row descriptors live in SGPRs).  Knob step_chunk: 0 this rule, 8 / 16 / 32 that many rows.
+    const int64_t span = s_end - s_begin;
     const bool knobs_free = !c.adj_wg && !c.adj_unroll && !c.adj_depth;
-    int cb = 0;                                                           // chained: workgroup size (0: the shape does not allow it)
-    if (!direct && parts == 1 && rows_per_launch == op->nrow && nchunks >= 2)
+    int CD = 8, cb = 0;                                                   // rows per chunk; chained: workgroup size (0: the shape does not allow it)
+    const bool chain_base = !direct && parts == 1 && rows_per_launch == op->nrow;
+    if (chain_base && !mixed && (c.step_chunk == 0 || c.step_chunk == 32) && span % ((int64_t)256 * NS) == 0 && op->nrow > 32 &&
+        (c.step_chain == 1 || (span / ((int64_t)256 * NS) >= 2048 && op->nrow >= 64)) && !(c.step_chain == 1 && c.adj_wg && c.adj_wg != 256)) {
+        CD = 32;
+        cb = 256;
+    } else if (!mixed && c.step_chunk == 16) {
+        CD = 16;
+    }
+    const int64_t nchunks = (op->nrow + CD - 1) / CD;
+    if (!cb && chain_base && nchunks >= 2)
         for (int b : {1024, 512, 256}) {
             if (CD == 16 && b == 1024) continue;
             if (c.step_chain == 1 && c.adj_wg && c.adj_wg != b) continue;  // (knobs step_chain = 1 + adj_wg: that workgroup size, for sweeps)
@@ -895,6 +864,8 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
             if (cb == 1024) JH_CHAIN(1024, true);
             else if (cb == 512) JH_CHAIN(512, true);
             else JH_CHAIN(256, true);
+        } else if (CD == 32) {
+            JH_CHAIN_D(256, false, 32);
         } else if (CD == 16) {
             if (cb == 512) JH_CHAIN_D(512, false, 16);
             else JH_CHAIN_D(256, false, 16);
@@ -917,9 +888,7 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
 #define JH_LAUNCH(BLK, UU, DD) JH_LAUNCH_M(BLK, UU, DD, false)
 #define JH_LAUNCH_T(BLK, UU, DD) JH_LAUNCH_N(BLK, UU, DD, false, false)
 #define JH_LAUNCH_M(BLK, UU, DD, MIX) JH_LAUNCH_N(BLK, UU, DD, MIX, true)
-#define JH_LAUNCH_P(BLK, UU, DD) JH_LAUNCH_Q(BLK, UU, DD, false, true, true)
-#define JH_LAUNCH_N(BLK, UU, DD, MIX, NTV) JH_LAUNCH_Q(BLK, UU, DD, MIX, NTV, false)
-#define JH_LAUNCH_Q(BLK, UU, DD, MIX, NTV, PP)                                                                          \
+#define JH_LAUNCH_N(BLK, UU, DD, MIX, NTV)                                                                              \
     if constexpr (!(E == 2 && sizeof(S) == 4 && BLK == 1024 && UU == 4 && DD == 1))                                      \
     if (wg == BLK && U == UU && D == DD && mixed == MIX) {                                                              \
         double total = 0.0;                                                                                              \
@@ -927,7 +896,7 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
         if (several) JH_CHECK_HIP(hipMemsetAsync(c.red_dev + 9, 0, sizeof(double), c.stream));                           \
         for (int64_t r0 = 0; r0 < op->nrow; r0 += rows_per_launch) {                                                     \
             const int64_t r1 = r0 + rows_per_launch < op->nrow ? r0 + rows_per_launch : op->nrow;                          \
-            hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK, MIX, NTV, PP>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, \
+            hipLaunchKernelGGL((k_tall_diag_bidiag<S, E, NS, UU, DD, BLK, MIX, NTV>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, \
                                c.stream,                                                                                 \
                                op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars,      \
                                direct, (S)alpha, (S)beta, c.part_dev, s_begin, s_end, r0, r1, r0 > 0 ? 1 : 0,              \
@@ -953,9 +922,6 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     if (!mixed && wg == 256 && !jh_stream_nt(2.0 * (double)op->nrow * (double)n_scalars * sizeof(S))) {
         JH_LAUNCH_T(256, 1, 4) JH_LAUNCH_T(256, 2, 2) JH_LAUNCH_T(256, 4, 1)
     }
-    if (!mixed && c.step_pipe) {                                                    // the software-pipelined walk (experiment: knob step_pipe)
-        JH_LAUNCH_P(512, 1, 4) JH_LAUNCH_P(256, 1, 4) JH_LAUNCH_P(512, 1, 8)
-    }
     JH_LAUNCH(256, 1, 4) JH_LAUNCH(256, 2, 2) JH_LAUNCH(256, 4, 1) JH_LAUNCH(256, 4, 2) JH_LAUNCH(256, 1, 8)
     JH_LAUNCH(512, 1, 4) JH_LAUNCH(512, 2, 2) JH_LAUNCH(512, 4, 1) JH_LAUNCH(512, 4, 2) JH_LAUNCH(512, 1, 8)
     JH_LAUNCH(1024, 1, 4) JH_LAUNCH(1024, 2, 2) JH_LAUNCH(1024, 4, 1)      // 1024 x 4 x 2 would need > 128 VGPRs per lane
@@ -964,8 +930,6 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
 #undef JH_LAUNCH_T
 #undef JH_LAUNCH_M
 #undef JH_LAUNCH_N
-#undef JH_LAUNCH_P
-#undef JH_LAUNCH_Q
     return jh_fail(JH_ERR_INVALID, "fused bidiagonalisation step: shape %d x %d x %d is not instantiated", wg, U, D);
 }
 

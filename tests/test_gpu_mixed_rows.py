@@ -1,5 +1,5 @@
 """GPU: tall operators whose rows are NOT all plain diagonals -- zero blocks, identity / scalar rows, adjointed (conjugated)
-diagonals -- on the tall kernels' tiling with a per-row kind (jh_blockop.hip: MIXED instantiations), incl. the fused A'A, the
+diagonals -- on the tall kernels' tiling with a per-row kind (jh_tall.hip / jh_tall_step.hip: MIXED instantiations), incl. the fused A'A, the
 fused forward update, the ranged adjoint and the one-pass LSQR step.  Bit-exact against the CPU oracle's loops
 (src/Jets.jl:1010-1057: zero rows skipped 1022 / 1047), every eltype, aligned block lengths (others take the general kernels)."""
 import ctypes as C

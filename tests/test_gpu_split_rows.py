@@ -3,7 +3,7 @@
 The ordered walk (one thread per 16-byte vector of the domain, all rows in sequence: the reference's loop,
 src/Jets.jl:1045-1053, bit for bit) leaves the chip idle when a block has few elements; from 256 rows on, when it would
 launch fewer workgroups than the chip has CUs, the library cuts the rows into contiguous parts, sums each part in order
-and folds the parts in a fixed order with fp64 accumulation (jh_blockop.hip: pick_adj_parts, k_fold_parts).
+and folds the parts in a fixed order with fp64 accumulation (jh_tall.hip: pick_adj_parts, k_fold_parts).
 
 Bar (stated): the split sum is DETERMINISTIC (same bits run to run) and within rel-l2 1e-6 (Float32 / ComplexF32) or
 1e-14 (Float64 / ComplexF64) of the fp64 / exact-order-free truth -- tighter than the ordered Float32 sum itself, whose

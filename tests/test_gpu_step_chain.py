@@ -30,12 +30,22 @@ def _native(J, A):
     return _blk._tall_native(A)
 
 
+def _expected_chunks(nrow, chunk):
+    """row chunks of the chained walk of an ALL-DIAGONAL operator under the knob step_chunk (jh_tall_step.hip: launch_bidiag): 0 = automatic =
+    32 rows of a 256-lane tile per workgroup (round 5) when there are more than 32 rows, else 8-row chunks; one chunk = the plain walk (0)"""
+    cd = 32 if (chunk in (0, 32) and nrow > 32) else (16 if chunk == 16 else 8)
+    return (nrow + cd - 1) // cd if nrow > cd else 0
+
+
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("nrow,slab", [(2, True), (8, False), (9, True), (16, False), (37, True), (64, False)])
-def test_chained_step_has_the_bits_of_the_ordered_walk(Jets, oracle, dt, nrow, slab):
+@pytest.mark.parametrize("chunk", [0, 8, 16])
+@pytest.mark.parametrize("nrow,slab", [(2, True), (8, False), (9, True), (16, False), (33, False), (37, True), (64, False), (100, True)])
+def test_chained_step_has_the_bits_of_the_ordered_walk(Jets, oracle, dt, nrow, slab, chunk):
     from jets_jl_amd._ffi import lib, check
 
     J = Jets
+    if chunk and nrow < 16 and dt != np.float32:
+        pytest.skip("the forced chunk sizes differ from the automatic rule only above their own row count: one element type suffices below")
     n = 4096                                                   # 256 lanes x 16 B divide every eltype's row
     A, ops = _op(J, oracle, dt, nrow, n, slab)
     nat = _native(J, A)
@@ -50,11 +60,11 @@ def test_chained_step_has_the_bits_of_the_ordered_walk(Jets, oracle, dt, nrow, s
         want_w = oracle.block_df_adj(ops, [np.zeros(n, dt)], want_u)[0]
         nrm = float(sum(np.vdot(b.astype(np.complex128), b.astype(np.complex128)).real for b in want_u))
         try:
-            J.tune(step_chain=1)
+            J.tune(step_chain=1, step_chunk=chunk)
             u = J.from_numpy(np.concatenate(hu), J.range(A))
             w = J.rand(J.domain(A), seed=9, stream=0)           # dirty
             check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, alpha, beta, C.byref(out)))
-            assert J.tune_get("last_step_chain") == ((nrow + 7) // 8 if nrow > 8 else 0)     # one chunk = nothing to chain: the plain walk
+            assert J.tune_get("last_step_chain") == _expected_chunks(nrow, chunk)            # one chunk = nothing to chain: the plain walk
             assert_bits_equal(u.to_numpy(), np.concatenate(want_u), f"chained step: u ({alpha}, {beta})")
             assert_bits_equal(w.to_numpy().ravel(order="F"), want_w, f"chained step: w ({alpha}, {beta})")
             assert abs(out.value - nrm) <= 1e-12 * nrm
@@ -70,7 +80,7 @@ def test_chained_step_has_the_bits_of_the_ordered_walk(Jets, oracle, dt, nrow, s
             assert_bits_equal(w2.to_numpy().ravel(order="F"), want_w, "chained ranged step: w")
             assert abs(out.value - nrm) <= 1e-12 * nrm
         finally:
-            J.tune(step_chain=-1)
+            J.tune(step_chain=-1, step_chunk=0)
         # and the plain walk agrees, of course
         J.tune(step_chain=0)
         try:
@@ -203,7 +213,8 @@ def test_step_mode_is_measured_per_operator_and_every_mode_has_the_same_bits(Jet
     assert float(J.norm(err)) / float(J.norm(x_true)) < 1e-4
 
 
-def test_chained_ranged_step_beside_a_busy_second_stream(Jets):
+@pytest.mark.parametrize("chunk", [8, 0])
+def test_chained_ranged_step_beside_a_busy_second_stream(Jets, chunk):
     """The pipelined distributed iteration runs the ranged chained step while RCCL's reduce kernels of the previous range occupy
     part of the same device.  Stand-in: a second context (own stream) of this device streams 768 MiB triads without pause while
     the chained step runs in four ranges; u, w keep the bits of the plain walk and no hand-off poll expires (jh_normsq_read
@@ -214,6 +225,7 @@ def test_chained_ranged_step_beside_a_busy_second_stream(Jets):
     J = Jets
     home = J.context_current()[0]
     nrow, edge = 48, 128                                               # 8 MiB rows: chained only because the knob says so
+    chunks, lanes = (6, 1024) if chunk == 8 else (2, 256)              # 8-row chunks of 1024-lane tiles (rounds 2-4) / round 5's 32-row chunks of 256-lane tiles
     n = edge ** 3
     spc = J.JetSpace(np.float32, edge, edge, edge)
     coeff = J.rand(J.JetBSpace([spc] * nrow), seed=61, stream=0)
@@ -242,14 +254,14 @@ def test_chained_ranged_step_beside_a_busy_second_stream(Jets):
             J.context_use(home)
             J.tune(step_chain=0)
             check(lib.jh_blockop_bidiag_step(nat.handle, u1.handle, v.handle, w1.handle, alpha, beta, C.byref(o1)))
-            J.tune(step_chain=1)
+            J.tune(step_chain=1, step_chunk=chunk)
             check(lib.jh_normsq_reset())
             q = n // 4
             for r in range(4):
                 check(lib.jh_blockop_bidiag_step_range(nat.handle, u2.handle, v.handle, w2.handle, alpha, beta, r * q, q, None))
-                assert J.tune_get("last_step_chain") == nrow // 8
+                assert J.tune_get("last_step_chain") == chunks
             check(lib.jh_normsq_read(C.byref(o2)))                     # an expired poll would fail here
-            handoffs += 4 * (nrow // 8) * (q // 4096)
+            handoffs += 4 * chunks * (q // (4 * lanes))
             assert abs(o1.value - o2.value) <= 1e-12 * o1.value
             if k % 40 == 39:
                 assert_bits_equal(w2.to_numpy(), w1.to_numpy(), f"step {k}: w beside the busy stream")
@@ -259,7 +271,7 @@ def test_chained_ranged_step_beside_a_busy_second_stream(Jets):
             J.synchronize()
             del nx, ny, nz, marks, e
     finally:
-        J.tune(step_chain=-1)
+        J.tune(step_chain=-1, step_chunk=0)
         import gc
 
         gc.collect()

@@ -52,7 +52,7 @@ def test_no_kernel_addresses_hbm_through_flat_instructions(tmp_path):
     kernels rely on.  The compiler falls back to flat when it cannot know a pointer's address space -- pointers READ FROM THE BLOCK TABLE,
     as every dense child's matrix is: round 4's jh_dense code object held 612 flat loads / stores (17 in each of k_gemv_rows_batched,
     k_gemv_rows_wide_fused, k_gemv_rows_mixed).  Round 5 routes them through address_space(1) helpers (jh_dense.hip: ldg / ldg_nt / stg;
-    jh_blockop.hip: ld / st).  This test disassembles every gfx950 code object of the built library."""
+    jh_blockop_common.h: ld / st).  This test disassembles every gfx950 code object of the built library."""
     import re
     import shutil
     import subprocess

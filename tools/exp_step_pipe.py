@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
-"""Round 5, second structural attempt at the one-pass LSQR step: the plain walk SOFTWARE-PIPELINED (knob step_pipe: the next batch's loads are
-issued before the current batch is combined and stored) against the plain walk and the chained row chunks, alternating in one process;
-w and the last block of u compared bit for bit.   python tools/exp_step_pipe.py [NROW EDGE]"""
+"""Round 5, structural attempts at the one-pass LSQR step beside the plain walk and the chained row chunks (8 rows per workgroup): chunks of
+16 rows (512 or 256 lanes) and of 32 rows (256 lanes) -- half / a quarter of the hand-offs and of the re-reads of v -- alternating in one
+process; w and the last block of u compared bit for bit.  (The first version of this tool also timed a software-pipelined plain walk:
+34.27 against 34.50 ms at 1024 x 256^3, dropped -- profiles/exp_r05_step_pipe.txt.)   python tools/exp_step_pipe.py [NROW EDGE]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import jets_jl_amd as J
 from jets_jl_amd._ffi import lib, check
 from jets_jl_amd import jetblock as _blk
 J.init(0)
-shapes = [(1024, 256), (256, 256), (1024, 128), (4096, 64)]
+shapes = [(1024, 256), (256, 256), (128, 256), (1024, 128)]
 if len(sys.argv) > 2:
     shapes = [(int(sys.argv[1]), int(sys.argv[2]))]
-variants = [("plain", 0, 0, 0), ("pipelined", 0, 1, 0), ("pipelined, 8 rows", 0, 1, 8), ("chained", 2, 0, 0), ("chained, 16-row chunks", 2, 0, -16)]
+variants = [("plain", 0, 0, 0), ("chained", 2, 0, 0), ("chained, 16-row chunks", 2, 0, -16), ("chained, 16 rows x 256 lanes", 2, 0, -1016), ("chained, 32-row chunks", 2, 0, -32)]
 for nblocks, edge in shapes:
     n = edge ** 3
     blk = J.JetSpace("float32", edge, edge, edge)
@@ -24,10 +25,10 @@ for nblocks, edge in shapes:
         check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, alpha, beta, C.byref(out)))
     def select(mode, pipe, depth):
         nat.tune_set("step_mode", mode)
-        if depth == -16:                                               # chained with sixteen rows per chunk (forced: step_chain = 1 takes the first workgroup size that divides)
-            J.tune(step_pipe=0, step_chunk=16, step_chain=1, adj_depth=0, adj_unroll=0, adj_wg=0)
+        if depth < 0:                                                  # chained with 16 / 32 rows per chunk (forced: step_chain = 1 takes the first workgroup size that divides, or adj_wg)
+            J.tune(step_chunk=(-depth) % 1000, step_chain=1, adj_depth=0, adj_unroll=0, adj_wg=256 if depth <= -1000 else 0)
         else:
-            J.tune(step_pipe=pipe, step_chunk=8, step_chain=-1, adj_depth=depth, adj_unroll=1 if depth else 0, adj_wg=512 if depth else 0)
+            J.tune(step_chunk=8, step_chain=-1, adj_depth=0, adj_unroll=0, adj_wg=0)
     def timed(reps=6):
         best = 1e9
         for _ in range(reps):

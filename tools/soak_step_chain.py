@@ -93,7 +93,8 @@ for k in range(steps):
         check(lib.jh_blockop_bidiag_step(nat.handle, u2.handle, v.handle, w2.handle, alpha, beta, C.byref(o2)))
     chunks = J.tune_get("last_step_chain")
     assert chunks > 0, "the chained walk did not run"
-    handoffs += chunks * (n // 4096)
+    tile = 4096 if J.tune_get('step_chunk') in (8, 16) or nrow <= 32 else 1024     # scalars per tile: 1024 lanes x 4 (8-row chunks) / 256 lanes x 4 (round 5's 32-row chunks)
+    handoffs += chunks * (n // tile)
     assert abs(o1.value - o2.value) <= 1e-12 * o1.value, (k, o1.value, o2.value)
     if k % 100 == 99 or k == steps - 1:
         a, b = w1.to_numpy(), w2.to_numpy()
@@ -107,5 +108,5 @@ if noise is not None:
     with J.using_context(other):
         J.synchronize()
     extra = f", beside {noise['launches']} concurrent 1.5 GiB triads on a second stream of the device"
-print(f"soak ok: {steps} chained steps{' in 4 ranges' if ranged else ''} of {nrow} x {edge}^3 ({chunks} chunks x {n // 4096} tiles per step, "
+print(f"soak ok: {steps} chained steps{' in 4 ranges' if ranged else ''} of {nrow} x {edge}^3 ({chunks} chunks x {n // tile} tiles per step, "
       f"{handoffs / 1e6:.1f} M hand-offs in all){extra}, no expired poll, bits of the plain walk, {time.time() - t0:.0f} s")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The tall forward per candidate walk (jh_blockop.hip: k_fwd_candidates) at the row counts a rank owns on 1 / 2 / 4 / 8 GPUs, plus a
+"""The tall forward per candidate walk (jh_tall.hip: k_fwd_candidates) at the row counts a rank owns on 1 / 2 / 4 / 8 GPUs, plus a
 grid of knob shapes around them: which (workgroup, vectors per lane, rows per workgroup, order) is fastest at 128 / 256 / 512 rows?
 
     python tools/sweep_fwd_rows.py NROW [EDGE] [--grid]"""
