@@ -43,7 +43,7 @@ template <typename S> __device__ inline S sum_sign(const SumArgs &a, int t) { if
 // computed that way with scale_k as a double: for a scalar that is T(a) in Julia the host passes double(T(a)), and
 // Float32(double(a32) * Float64(x)) == a32 * x in Float32 arithmetic (the Float64 product of two Float32 values is exact, so both
 // round the exact product once) -- one instantiation serves sums that mix wide and narrow scalars, with the chain's bits.
-template <typename S, int E, int NS, int U, int BLK, int KM, bool STRIDED, bool WIDE = false>
+template <typename S, int E, int NS, int U, int BLK, int KM, bool STRIDED, bool WIDE = false, int D = 1>
 __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow, int rows_per_wg, const S *__restrict__ m,
                                                       S *__restrict__ d, int64_t n_scalars, unsigned ntiles, int accumulate)
 {
@@ -62,49 +62,56 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow
         sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
         mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
     }
-    // one row per iteration, its KM coefficient packs (x U) in flight.  The row loop is kept rolled: left to itself the compiler unrolls
-    // the eight-stream shape to 241 VGPRs (one wave per SIMD: 1.6 TB/s)
+    // D rows per iteration, their D x KM coefficient packs (x U) in flight (D = 1: one row).  The row loop is kept rolled: left to itself the
+    // compiler unrolls the eight-stream shape to 241 VGPRs (one wave per SIMD: 1.6 TB/s).  A row beyond the group's last re-reads that
+    // last row (branch-free loads) and is not stored.
 #pragma unroll 1
-    for (int64_t i = i0; i < i1; i++) {
-        V av[KM][U], dv[U];
-        if constexpr (STRIDED) {
-            const int64_t roff = i * args.stride;
+    for (int64_t i = i0; i < i1; i += D) {
+        V av[D][KM][U], dv[D][U];
 #pragma unroll
-            for (int t = 0; t < KM; t++) {
-                const S *a = (const S *)args.a0[t] + roff;
+        for (int j = 0; j < D; j++) {
+            const int64_t ij = i + j < i1 ? i + j : i1 - 1;
+            if constexpr (STRIDED) {
+                const int64_t roff = ij * args.stride;
 #pragma unroll
-                for (int k = 0; k < U; k++) av[t][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
-            }
-        } else {
-            const S *ap[KM];
+                for (int t = 0; t < KM; t++) {
+                    const S *a = (const S *)args.a0[t] + roff;
 #pragma unroll
-            for (int t = 0; t < KM; t++) ap[t] = (const S *)((const jh_dev_block *)args.a0[t])[i].coeff;     // KM scalar loads, one wait
-#pragma unroll
-            for (int t = 0; t < KM; t++)
-#pragma unroll
-                for (int k = 0; k < U; k++) av[t][k] = ld<true>(reinterpret_cast<const V *>(ap[t] + sk[k]));
-        }
-#pragma unroll
-        for (int k = 0; k < U; k++)
-            dv[k] = accumulate ? ld<true>(reinterpret_cast<const V *>(d + i * n_scalars + sk[k])) : (V)(S)0;   // d .= 0  (639-640)
-#pragma unroll
-        for (int k = 0; k < U; k++) {
-            V acc = dv[k];
-#pragma unroll
-            for (int t = 0; t < KM; t++) {
-                const V prod = vmul<S, E, NS, V>(av[t][k], mv[k], false);            // mul!(_d, A_t, m)
-                V term;
-                if constexpr (WIDE) {
-#pragma unroll
-                    for (int e = 0; e < NS; e++) term[e] = (S)(args.coef[t] * (double)prod[e]);
-                } else {
-                    term = sum_coef<S>(args, t) * prod;                              // (s_t * .) then the sign: -(s*x) == (-s)*x exactly
+                    for (int k = 0; k < U; k++) av[j][t][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
                 }
-                const V sum = acc + term;                                            // broadcast!(sgn, d, d, _d)
-                acc = (t < args.k) ? sum : acc;                                      // (a term beyond k: dropped, wave-uniform)
+            } else {
+                const S *ap[KM];
+#pragma unroll
+                for (int t = 0; t < KM; t++) ap[t] = (const S *)((const jh_dev_block *)args.a0[t])[ij].coeff;     // KM scalar loads, one wait
+#pragma unroll
+                for (int t = 0; t < KM; t++)
+#pragma unroll
+                    for (int k = 0; k < U; k++) av[j][t][k] = ld<true>(reinterpret_cast<const V *>(ap[t] + sk[k]));
             }
-            if (ok[k]) st<true>(reinterpret_cast<V *>(d + i * n_scalars + sk[k]), acc);
+#pragma unroll
+            for (int k = 0; k < U; k++)
+                dv[j][k] = accumulate ? ld<true>(reinterpret_cast<const V *>(d + ij * n_scalars + sk[k])) : (V)(S)0;   // d .= 0  (639-640)
         }
+#pragma unroll
+        for (int j = 0; j < D; j++)
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                V acc = dv[j][k];
+#pragma unroll
+                for (int t = 0; t < KM; t++) {
+                    const V prod = vmul<S, E, NS, V>(av[j][t][k], mv[k], false);         // mul!(_d, A_t, m)
+                    V term;
+                    if constexpr (WIDE) {
+#pragma unroll
+                        for (int e = 0; e < NS; e++) term[e] = (S)(args.coef[t] * (double)prod[e]);
+                    } else {
+                        term = sum_coef<S>(args, t) * prod;                          // (s_t * .) then the sign: -(s*x) == (-s)*x exactly
+                    }
+                    const V sum = acc + term;                                        // broadcast!(sgn, d, d, _d)
+                    acc = (t < args.k) ? sum : acc;                                  // (a term beyond k: dropped, wave-uniform)
+                }
+                if (ok[k] && i + j < i1) st<true>(reinterpret_cast<V *>(d + (i + j) * n_scalars + sk[k]), acc);
+            }
     }
 }
 
@@ -387,9 +394,11 @@ static int sum_fwd_launch(const SumArgs &a, bool strided, const jh_blockop *op0,
     int64_t gy = (op0->nrow + G - 1) / G;
     while (gx * gy * BLK >= ((int64_t)1 << 32) && G < op0->nrow) { G *= 2; gy = (op0->nrow + G - 1) / G; }
     JH_REQUIRE(gx * gy * BLK < ((int64_t)1 << 32), "fused sum forward: grid too large");
-#define JH_SUM_FWD(UU, KM, ST, WD)                                                                                                       \
-    hipLaunchKernelGGL((k_tall_sum_fwd<S, E, NS, UU, BLK, KM, ST, WD>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G, \
+#define JH_SUM_FWD_D(UU, KM, ST, WD, DD)                                                                                                 \
+    hipLaunchKernelGGL((k_tall_sum_fwd<S, E, NS, UU, BLK, KM, ST, WD, DD>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G, \
                        (const S *)m, (S *)d, n_scalars, (unsigned)gx, accumulate)
+// (D = 2 rows in flight per workgroup were measured and lose 3-6 % in the forward: profiles/exp_r05_jetsum_rows.txt)
+#define JH_SUM_FWD(UU, KM, ST, WD) JH_SUM_FWD_D(UU, KM, ST, WD, 1)
 #define JH_SUM_FWD_FEW(UU, KM, ST, WD)                                                                                                   \
     hipLaunchKernelGGL((k_tall_sum_fwd_few<S, E, NS, UU, BLK, KM, 1, ST, WD>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, a, op0->nrow, G, \
                        (const S *)m, (S *)d, n_scalars, (unsigned)gx, accumulate)
@@ -413,6 +422,7 @@ static int sum_fwd_launch(const SumArgs &a, bool strided, const jh_blockop *op0,
 #undef JH_SUM_FWD_K
 #undef JH_SUM_FWD_FEW
 #undef JH_SUM_FWD
+#undef JH_SUM_FWD_D
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -451,7 +461,7 @@ static int sum_adj_launch(const SumArgs &a, bool strided, const jh_blockop *op0,
                        (const S *)d, n_scalars, accumulate)
 #define JH_SUM_ADJ_S(ST, WD)                                                                                                          \
     do {                                                                                                                              \
-        if (a.k > 12) JH_SUM_ADJ_K(1, 1, 16, ST, WD);      /* sixteen accumulators, one row in flight (knob sum_adj_group = 16) */     \
+        if (a.k > 12) JH_SUM_ADJ_K(1, 1, 16, ST, WD);      /* sixteen accumulators, one row in flight (two: +1 ... +2 %, noise level: exp_r05_jetsum_rows.txt) */ \
         else if (a.k > 8) JH_SUM_ADJ_K(1, 1, 12, ST, WD);                                                                             \
         else if (a.k > 4) JH_SUM_ADJ_FEW(1, DEPTH, 8, ST, WD);                                                                        \
         else JH_SUM_ADJ_FEW(2, DEPTH, 4, ST, WD);                                                                                     \

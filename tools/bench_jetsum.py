@@ -49,6 +49,15 @@ if os.environ.get("SUM_FWD_UNROLL"):
     J.tune(fwd_unroll=int(os.environ["SUM_FWD_UNROLL"]))
 print(f"ALGO k_tall_sum_(fwd|adj) {((K + 1) * nrow + 1) * b}", flush=True)       # per launch when the sum is ONE launch (K <= terms per launch): tools/prof_any.sh
 groups = tuple(int(v) for v in os.environ.get("SUM_GROUPS", "16,8,16,8").split(","))
+if os.environ.get("SUM_SWEEP"):                                     # round 5: rows in flight per workgroup of the 9..16-term kernels, alternating in one process
+    for rnd in range(2):
+        for g, dd in ((1, 1), (2, 2), (1, 1)):
+            J.tune(fwd_group=g, adj_depth=dd, sum_group=16, sum_adj_group=16)
+            tf = timed(lambda: J.mul_(d, S, m))
+            ta = timed(lambda: J.mul_(mt, S.H, d))
+            print(f"JetSum of {K} tall {nrow} x {edge}^3 operators: forward {g} row(s) in flight {tf:7.3f} ms {((K + 1) * nrow + 1) * b / tf / 1e6:7.1f} GB/s | adjoint {dd} row(s) in flight {ta:7.3f} ms {((K + 1) * nrow + 1) * b / ta / 1e6:7.1f} GB/s", flush=True)
+    J.tune(fwd_group=0, adj_depth=0)
+    sys.exit(0)
 for group in groups:                                        # forward terms per launch: 16 (round 4) against round 3's 8, alternating in one process
     J.tune(sum_group=group, sum_adj_group=group)                    # (the adjoint: 16 or 8 accumulators per launch)
     tf = timed(lambda: J.mul_(d, S, m))
