@@ -960,7 +960,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "lsqr_graph")) { c.lsqr_graph = value < 0 ? 0 : (value > 2 ? 2 : value); }
     else if (!strcmp(name, "grid_tile")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "grid_tile must be 0 (k_grid_diag), 1 (automatic) or 2 / 4 / 8 lines per workgroup"); c.grid_tile = value; }
     else if (!strcmp(name, "dense_mixed")) { JH_REQUIRE(value == 0 || value == 1, "dense_mixed must be 0 or 1"); c.dense_mixed = value; }
-    else if (!strcmp(name, "general_tile")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 42 || value == 8, "general_tile must be 0 (one-line kernels), 1 (automatic), 2 or 4 lines per workgroup (42 / 8: 4 lines x 2 steps, 8 lines)"); c.general_tile = value; }
+    else if (!strcmp(name, "general_tile")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "general_tile must be 0 (one-line kernels), 1 (automatic), 2 or 4 lines per workgroup"); c.general_tile = value; }
     else if (!strcmp(name, "dense_fused")) { JH_REQUIRE(value == 0 || value == 1, "dense_fused must be 0 or 1"); c.dense_fused = value; }
     else if (!strcmp(name, "cgls_trace")) { c.cgls_trace = value ? 1 : 0; }
     else if (!strcmp(name, "cg_dev")) { c.cg_dev = value < 0 ? 0 : (value > 2 ? 2 : value); }

@@ -822,18 +822,13 @@ int launch_general_tile(const jh_blockop *op, const S *in, S *out, int64_t in_by
     // 5.43 -> 5.90 | 5.28 -> 5.87, 64 x 64 of 64^3 5.1 -> 5.7 | 5.1 -> 5.7, 8 x 8 and 64 x 4 +2 % (profiles/bench_grid_mixed_r04.txt).
     // Knob general_tile: 1 this rule, 2 / 4 that many lines always, 0 the one-line kernels
     const bool four = c.general_tile == 4 || (c.general_tile == 1 && nlines >= 4);
-    const int exp_r = c.general_tile == 42 ? 4 : (c.general_tile == 8 ? 8 : 0);     // round-5 experiment shapes: 42 = 4 lines x 2 steps, 8 = 8 lines x 1 step (8 x 2 needs more than 512 registers per lane)
-    const int64_t ngroups = exp_r ? (nlines + exp_r - 1) / exp_r : (four ? (nlines + 3) / 4 : (nlines + 1) / 2);
+    // (round 5: 4 lines x 2 steps, 8 lines, and two packs per lane on the four-line shape were measured on the PMC evidence that the kernel moves
+    // exactly its unique bytes -- all within -7 ... +2 % of this shape, 8 lines far below: profiles/exp_r05_general_tile_shapes.txt)
+    const int64_t ngroups = four ? (nlines + 3) / 4 : (nlines + 1) / 2;
     const int U = (c.fwd_unroll == 2) ? 2 : 1;                           // two packs per lane did not pay here (knob fwd_unroll = 2: measurements)
     unsigned ntiles, grid;
     general_grid((n_scalars / NS + 256 * U - 1) / (256 * U), ngroups, ntiles, grid, general_use_xcd(in_bytes));
-    if (c.general_tile == 42)
-        hipLaunchKernelGGL((k_general_tile<S, E, NS, 2, 1, TRANSPOSED, 4>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
-                           ntiles, (unsigned)ngroups);
-    else if (c.general_tile == 8)
-        hipLaunchKernelGGL((k_general_tile<S, E, NS, 1, 1, TRANSPOSED, 8>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
-                           ntiles, (unsigned)ngroups);
-    else if (four)
+    if (four)
         hipLaunchKernelGGL((k_general_tile<S, E, NS, 1, 1, TRANSPOSED, 4>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
                            ntiles, (unsigned)ngroups);
     else if (U == 2)
