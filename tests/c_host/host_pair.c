@@ -267,6 +267,89 @@ int main(void)
         CK(jh_bvec_destroy(u)); CK(jh_bvec_destroy(u2)); CK(jh_bvec_destroy(v)); CK(jh_bvec_destroy(w)); CK(jh_bvec_destroy(w2));
     }
 
+    /* ---- round 5 from plain C: `1.0*A1 - 2.0*A2 + 3.14*A3` (src/Jets.jl:686) with Float64 scalars on Float32 operators as ONE fused call each way
+     *      (jh_blocksum_mul_typed / _adj_typed with JH_SCALAR_WIDE), against the reference's loop spelled out: product in Float32, scalar stage
+     *      promoted and rounded once (1159-1160), signed add in Float32 (644, 653) */
+    {
+        jh_bvec *c2 = NULL, *c3 = NULL, *ds = NULL, *ms = NULL;
+        jh_blockop *A2 = NULL, *A3 = NULL;
+        CK(jh_bvec_create(NROW, lens, JH_F32, &c2));
+        CK(jh_bvec_create(NROW, lens, JH_F32, &c3));
+        CK(jh_bvec_create(NROW, lens, JH_F32, &ds));
+        CK(jh_bvec_create(1, lens, JH_F32, &ms));
+        CK(jh_fill_uniform(c2, 11, 0, 0));
+        CK(jh_fill_uniform(c3, 12, 0, 0));
+        jh_block_desc d2[NROW], d3[NROW];
+        memset(d2, 0, sizeof d2);
+        memset(d3, 0, sizeof d3);
+        for (int i = 0; i < NROW; i++) {
+            int64_t off = 0, len = 0;
+            void *p2 = NULL, *p3 = NULL;
+            CK(jh_bvec_block(c2, i, &off, &len, &p2));
+            CK(jh_bvec_block(c3, i, &off, &len, &p3));
+            d2[i].kind = d3[i].kind = JH_OP_DIAG;
+            d2[i].coeff = p2;
+            d3[i].coeff = p3;
+            d2[i].nr = d2[i].nc = d3[i].nr = d3[i].nc = n;
+        }
+        CK(jh_blockop_create(NROW, 1, d2, lens, lens, JH_F32, &A2));
+        CK(jh_blockop_create(NROW, 1, d3, lens, lens, JH_F32, &A3));
+        const jh_blockop *terms[3] = {A, A2, A3};
+        const double scale[3] = {1.0, 2.0, 3.14}, sign[3] = {1.0, -1.0, 1.0};
+        const int32_t flags[3] = {JH_SCALAR_WIDE, JH_SCALAR_WIDE, JH_SCALAR_WIDE};
+        CK(jh_fill(ds, 7.0, 0.0));                                                   /* dirty: the sum starts from d .= 0 (640) */
+        CK(jh_blocksum_mul_typed(3, terms, scale, flags, sign, ds, m));
+        CK(jh_fill(ms, 7.0, 0.0));
+        CK(jh_blocksum_mul_adj_typed(3, terms, scale, flags, sign, ms, ds));
+        float *hs = malloc((size_t)NROW * n * sizeof(float)), *hms = malloc((size_t)n * sizeof(float));
+        float *o2 = malloc((size_t)NROW * n * sizeof(float)), *o3 = malloc((size_t)NROW * n * sizeof(float));
+        float *ws = malloc((size_t)NROW * n * sizeof(float)), *wm = malloc((size_t)n * sizeof(float));
+        REQUIRE(hs && hms && o2 && o3 && ws && wm, "host allocation");
+        CK(jh_download(ds, 0, (int64_t)NROW * n, hs));
+        CK(jh_download(ms, 0, n, hms));
+        jo_rng_u01(JO_F32, 11, 0, 0, (int64_t)NROW * n, o2);
+        jo_rng_u01(JO_F32, 12, 0, 0, (int64_t)NROW * n, o3);
+        const float *oc[3] = {oa, o2, o3};
+        for (int64_t k = 0; k < (int64_t)NROW * n; k++) {                            /* forward, element by element */
+            float acc = 0.0f;
+            for (int t = 0; t < 3; t++) {
+                const volatile float prod = oc[t][k] * om[k % n];                    /* mul!(_d, A_t, m): a Float32 product */
+                const float term = (float)(scale[t] * (double)prod);                 /* _d .= a * tmp with a::Float64: promoted, rounded once */
+                acc = sign[t] > 0 ? acc + term : acc - term;                         /* broadcast!(sgn, d, d, _d) */
+            }
+            ws[k] = acc;
+        }
+        REQUIRE(memcmp(hs, ws, (size_t)NROW * n * sizeof(float)) == 0, "fused JetSum with Float64 scalars: forward bit-exact vs the reference's loop");
+        for (int64_t e = 0; e < n; e++) {                                            /* adjoint: per term the ordered row sum of conj(a) .* (s * d_i) */
+            float acc = 0.0f;
+            for (int t = 0; t < 3; t++) {
+                float rowsum = 0.0f;
+                for (int i = 0; i < NROW; i++) {
+                    const float sd = (float)(scale[t] * (double)ws[(size_t)i * n + e]);
+                    const volatile float p = oc[t][(size_t)i * n + e] * sd;
+                    rowsum = rowsum + p;
+                }
+                acc = sign[t] > 0 ? acc + rowsum : acc - rowsum;
+            }
+            wm[e] = acc;
+        }
+        REQUIRE(memcmp(hms, wm, (size_t)n * sizeof(float)) == 0, "fused JetSum with Float64 scalars: adjoint bit-exact vs the reference's loop");
+        /* (a * A) m in one pass with the scalar's type */
+        CK(jh_blockop_mul_scaled(A2, ds, m, 3.14, JH_SCALAR_WIDE));
+        CK(jh_download(ds, 0, (int64_t)NROW * n, hs));
+        for (int64_t k = 0; k < (int64_t)NROW * n; k++) {
+            const volatile float prod = o2[k] * om[k % n];
+            ws[k] = (float)(3.14 * (double)prod);
+        }
+        REQUIRE(memcmp(hs, ws, (size_t)NROW * n * sizeof(float)) == 0, "(3.14 * A) m in one pass: the promoted product rounded once");
+        REQUIRE(jh_blocksum_mul_typed(3, terms, scale, (const int32_t[3]){JH_SCALAR_COMPLEX, 0, 0}, sign, ds, m) == JH_ERR_UNSUPPORTED,
+                "a Complex scale is refused with JH_ERR_UNSUPPORTED (the binding runs the unfused chain)");
+        printf("typed fused sums and scaled passes from C: ok\n");
+        free(hs); free(hms); free(o2); free(o3); free(ws); free(wm);
+        CK(jh_blockop_destroy(A2)); CK(jh_blockop_destroy(A3));
+        CK(jh_bvec_destroy(c2)); CK(jh_bvec_destroy(c3)); CK(jh_bvec_destroy(ds)); CK(jh_bvec_destroy(ms));
+    }
+
     /* ---- ONE process, several contexts (include/jetship.h Conventions): a team of two contexts -- one per device
      *      when two devices are visible (RCCL), else two streams of this device (the sum is a device kernel) -- each holding
      *      half of A's rows; the grouped, ranged all-reduce makes both replicas of A'd the full sum */

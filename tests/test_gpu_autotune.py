@@ -76,3 +76,36 @@ def test_lazy_forward_autotune_converges_without_changing_bits(Jets, oracle, dt)
     assert J.op_tune_get(B, "fwd_trials") == 1
     with pytest.raises(Exception):
         J.op_tune_set(B, "fwd_walk", 99)
+
+
+def test_the_column_persistent_candidate_never_runs_on_small_blocks(Jets, oracle):
+    """Candidate 5 (a workgroup keeps its m tile and streams EVERY block row through it) has one workgroup per 128 KiB of a row: on rows of
+    1 MiB that is eight workgroups walking thousands of rows -- 17.8 ms where the other walks take 1.4-1.7 (4096 x 64^3).  Its TRIAL therefore
+    ran candidate 0's shape on small blocks, but round 4 stored a "5" that won such a trial (a tie, a play-off) and from then on launched the
+    real column-persistent walk (round-4 advisor finding).  Since round 5 the substitution is part of what candidate 5 IS on such rows -- trial,
+    chosen walk, re-check and inherited choice alike (jh_tall.hip: fwd_candidate_shape)."""
+    J = Jets
+    nrow, edge = 4096, 64                                       # 1 MiB rows, 8 GiB streamed per forward: inside the lazily measured regime
+    dt = np.float32
+    spc = J.JetSpace(dt, edge, edge, edge)
+    n = edge ** 3
+    coeff = J.rand(J.JetBSpace([spc] * nrow), seed=1, stream=0)
+    A = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])
+    m = J.rand(spc, seed=2, stream=0)
+    d = J.zeros(J.range(A))
+    want = oracle.rng_u01(dt, 1, 0, 77 * n + 4096, 4096) * oracle.rng_u01(dt, 2, 0, 4096, 4096)
+    J.op_tune_set(A, "fwd_walk", 5)                             # "the measurement chose 5"
+    for _ in range(3):
+        J.mul_(d, A, m)
+        assert J.tune_get("last_fwd_rows_per_wg") == 16, "candidate 5 on rows below 4 M packs runs candidate 0's 16-row sweep, not one workgroup per column of tiles"
+    e0 = J.Event().record()
+    J.mul_(d, A, m)
+    e1 = J.Event().record()
+    assert e0.elapsed_ms(e1) < 6.0, "the column-persistent walk itself takes ~18 ms on this shape"
+    assert_bits_equal(d._download(77 * n + 4096, 4096), want, "row 77 under the substituted shape")
+    B = J.blockop([[J.JopDiagonal(c)] for c in coeff.arrays])   # a new operator of the shape: whatever it inherits or measures, never the real candidate 5
+    for _ in range(30):
+        J.mul_(d, B, m)
+        assert J.tune_get("last_fwd_rows_per_wg") < nrow
+    J.close(A)
+    J.close(B)

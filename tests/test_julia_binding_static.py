@@ -426,6 +426,21 @@ def test_julia_binding_block_structure_balances():
     assert not errs, errs[:10]
 
 
+def test_julia_parity_script_is_structurally_balanced():
+    """julia/test/runtests.jl (round 5): the parity test a maintainer runs where Julia, Jets.jl and an MI355X exist -- the reference itself
+    as the oracle, the hot loops bit for bit.  Written, not executed; at least its blocks and brackets balance, it uses the binding's exported
+    names, and it compares every hot-path result with the reference on host copies."""
+    path = os.path.join(ROOT, "julia", "test", "runtests.jl")
+    text = open(path).read()
+    assert not julia_structure_errors(text), julia_structure_errors(text)[:10]
+    for needle in ("using Test, LinearAlgebra, Jets, JetsHIP", "HipSpace(", "JopHipDiagonal(", "@blockop", "samebits(host(d), convert(Array, dh))",
+                   "samebits(host(mt), mth)", "(A' ∘ A) * m", "1.0 * A[1] - 2.0 * A[2] + 3.14 * A[3]", "dot_product_test(A", "hip_lsqr!("):
+        assert needle in text, f"julia/test/runtests.jl lacks `{needle}`"
+    exported = re.search(r"(?m)^export (.*)$", open(JULIA).read()).group(1)
+    for name in ("HipSpace", "HipArray", "JopHipDiagonal", "JopHipSquare", "JopHipDense", "hip_lsqr!"):
+        assert name in exported, f"{name} is used unqualified by the parity script but not exported by the binding"
+
+
 def test_the_structure_checker_sees_what_it_should():
     text = open(JULIA).read()
     at = text.index("\nend\n", len(text) // 2)
