@@ -40,6 +40,11 @@ def test_lazy_forward_autotune_converges_without_changing_bits(Jets, oracle, dt)
             assert_bits_equal(flat[:4096], ha0, f"call {call}: row 0")
             assert_bits_equal(flat[9 * n + 12345:9 * n + 12345 + 4096], ha9, f"call {call}: row 9")
     assert len(walks) >= 3 and any(w[0] == 2 for w in walks), "the first calls must have tried several candidate shapes, the column bands among them"
+    for _ in range(4):                                          # the choice is made by the first call that finds every trial FINISHED (the library never waits):
+        if J.op_tune_get(A, "fwd_walk") != -1:                  # the host runs ahead of the device, so let the last play-off trial complete (round 5: this
+            break                                               # raced once in a while)
+        J.synchronize()
+        J.mul_(d, A, m)
     trials, po = J.op_tune_get(A, "fwd_trials"), J.op_tune_get(A, "fwd_playoff")
     assert (trials, po >= 0) in ((20, False), (24, True)), "20 timed calls, or 24 with a play-off between the two best"
     pick = J.op_tune_get(A, "fwd_walk")
