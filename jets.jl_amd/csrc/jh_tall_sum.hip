@@ -386,8 +386,7 @@ static int sum_fwd_launch(const SumArgs &a, bool strided, const jh_blockop *op0,
     // up to four streams: two rows
     // round 4: NINE to SIXTEEN streams in one launch (one row of ONE pack per lane: 64 registers of coefficients in flight) -- an 11-term
     // sum as 8 + 3 read and wrote the output twice (4.97 TB/s = 62 % of the roofline over its algorithmic bytes, bench_jetsum_r03.txt)
-    const bool U2 = c.fwd_unroll == 2;                                                      // experiment: two packs per lane on the 9..16-term shapes too
-    const int U = (a.k > 8 && !U2) ? 1 : 2;
+    const int U = a.k > 8 ? 1 : 2;
     int G = c.fwd_group > 0 ? (int)c.fwd_group : (a.k > 4 ? 1 : 2);                       // rows per workgroup (knob fwd_group: sweeps)
     if (G > op0->nrow) G = (int)op0->nrow;
     const int64_t nvec = n_scalars / NS;
@@ -405,8 +404,8 @@ static int sum_fwd_launch(const SumArgs &a, bool strided, const jh_blockop *op0,
                        (const S *)m, (S *)d, n_scalars, (unsigned)gx, accumulate)
 #define JH_SUM_FWD_K(ST, WD)                                                                                                             \
     do {                                                                                                                                 \
-        if (a.k > 12) { if (U2) JH_SUM_FWD(2, 16, ST, WD); else JH_SUM_FWD(1, 16, ST, WD); }                                             \
-        else if (a.k > 8) { if (U2) JH_SUM_FWD(2, 12, ST, WD); else JH_SUM_FWD(1, 12, ST, WD); }                                         \
+        if (a.k > 12) JH_SUM_FWD(1, 16, ST, WD);                                                                                         \
+        else if (a.k > 8) JH_SUM_FWD(1, 12, ST, WD);                                                                                     \
         else if (a.k > 4) JH_SUM_FWD_FEW(2, 8, ST, WD);                                                                                  \
         else JH_SUM_FWD_FEW(2, 4, ST, WD);                                                                                               \
     } while (0)
