@@ -214,9 +214,9 @@ struct jh_event {
 struct jh_dev_block {
     const void *coeff;
     double sre, sim;     // SCALE: the scalar
-    int16_t kind;
-    int16_t real_scale;  // SCALE: 1 = a REAL scalar (see jh_dev_block_of)
-    int32_t adjoint;
+    int32_t kind : 16;        // (bit-fields of ONE 32-bit word, not two int16_t: gfx950 has no sub-dword scalar load, so an int16_t member of a
+    int32_t real_scale : 16;  //  wave-uniform table entry is fetched with a VECTOR global_load_ushort + readfirstlane -- a memory round trip in front of
+    int32_t adjoint;          //  every step's coefficient loads in the general kernels)      real_scale: SCALE, 1 = a REAL scalar (see jh_dev_block_of)
 };
 static_assert(sizeof(jh_dev_block) == 32, "one table entry = one s_load_dwordx8");
 

@@ -418,23 +418,44 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
     if (full) {                                                             // the batch's loads go out BEFORE the wait for the predecessor
         // u first: its addresses are arithmetic, so these loads are in flight while the row table (separate coefficient arrays,
         // rows of several kinds) is still being fetched -- a workgroup that lives for one batch cannot hide that round trip
-        // otherwise (256 x 256^3 over separate arrays: chained step 5.7 TB/s against 6.1-6.3 over one slab)
+        // otherwise (256 x 256^3 over separate arrays: chained step 5.7 TB/s against 6.1-6.3 over one slab).
+        // The whole section is BRANCH-FREE and its addresses are opaque to the compiler (round 5, from the ISA): a `use_old ? load : 0` or
+        // `reads a coefficient ? load : 0` per row compiles to a branch per load and, at the first merge, an s_waitcnt vmcnt(0) for that
+        // load to RETURN before the other 63 are issued -- one memory round trip per workgroup with nothing else resident on the CU.
+        // beta == 0 (u may hold anything and is not used) aims the u loads at v's pack, and so does a row without a coefficient array with
+        // its coefficient load: hits in L2 (every chunk reads v) whose values nobody reads.  (Aimed at the row's u pack instead, the second
+        // streaming load of a line still in flight fetched it twice: 50 % scalar rows 5.8 -> 5.2 TB/s.)
+        const S *ub = use_old ? u + row0 * n_scalars : v, *vd = v;
+        int64_t ustep = use_old ? n_scalars : 0;
+        asm volatile("" : "+s"(ub), "+s"(ustep), "+s"(vd));
 #pragma unroll
         for (int j = 0; j < DEPTH; j++)
 #pragma unroll
-            for (int k = 0; k < U; k++) uv[j][k] = use_old ? ld<true>(reinterpret_cast<const V *>(u + (row0 + j) * n_scalars + sk[k])) : (V)(S)0;
+            for (int k = 0; k < U; k++) uv[j][k] = ld<true>(reinterpret_cast<const V *>(ub + j * ustep + sk[k]));
+        if (!MIXED && a_base) {
+            const S *ap = a_base + row0 * a_stride;
 #pragma unroll
-        for (int j = 0; j < DEPTH; j++) {
-            const S *a;
-            bool rc = true;
-            if constexpr (MIXED) {
-                blk[j] = blocks[row0 + j];
-                a = (const S *)blk[j].coeff;
-                rc = block_reads_coeff(blk[j], false);
-            } else
-                a = a_base ? a_base + (row0 + j) * a_stride : (const S *)blocks[row0 + j].coeff;
+            for (int j = 0; j < DEPTH; j++)
 #pragma unroll
-            for (int k = 0; k < U; k++) av[j][k] = rc ? ld<true>(reinterpret_cast<const V *>(a + sk[k])) : (V)(S)0;
+                for (int k = 0; k < U; k++) av[j][k] = ld<true>(reinterpret_cast<const V *>(ap + j * a_stride + sk[k]));
+        } else {
+            constexpr int G = DEPTH < 8 ? DEPTH : 8;                       // table entries are fetched G rows at a time: one scalar round trip per group
+#pragma unroll
+            for (int g = 0; g < DEPTH; g += G) {
+                const S *ap[G];
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    if constexpr (MIXED) {
+                        blk[g + j] = blocks[row0 + g + j];
+                        ap[j] = block_reads_coeff(blk[g + j], false) ? (const S *)blk[g + j].coeff : vd;
+                    } else
+                        ap[j] = (const S *)blocks[row0 + g + j].coeff;
+                }
+#pragma unroll
+                for (int j = 0; j < G; j++)
+#pragma unroll
+                    for (int k = 0; k < U; k++) av[g + j][k] = ld<true>(reinterpret_cast<const V *>(ap[j] + sk[k]));
+            }
         }
     }
     if (chunk > 0) {

@@ -16,7 +16,7 @@ J.init(0)
 n = edge ** 3
 spc = J.JetSpace("float32", edge, edge, edge)
 rng = np.random.default_rng(7)
-kinds = rng.choice(["d", "d", "d", "z", "i", "s"], size=(M, K))
+kinds = rng.choice(list(os.environ.get("GRID_KINDS", "dddzis")), size=(M, K))   # GRID_KINDS=ddz: diagonals and zero blocks only, ...
 ndiag = int((kinds == "d").sum())
 coeff = J.rand(J.JetBSpace([spc] * max(ndiag, 1)), seed=1, stream=0)
 rows, k = [], 0

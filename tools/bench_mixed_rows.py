@@ -75,7 +75,13 @@ for name, kinds, densify in cases:
     J.op_tune_set(A, "step_mode", 2)                                          # chained row chunks (rows of any elementwise kind)
     t_c = timed(step)
     chained = J.tune_get("last_step_chain") > 0
+    extra = ""
+    for ch in [int(v) for v in os.environ.get("STEP_CHUNKS", "").split(",") if v]:   # STEP_CHUNKS=8,32: the chained walk again with that many rows per chunk
+        J.tune(step_chunk=ch)
+        t_x = timed(step)
+        extra += f" | chunk {ch}: {t_x:7.3f} ms {b_step / t_x / 1e6:7.1f} GB/s ({J.tune_get('last_step_chain')} chunks)"
+        J.tune(step_chunk=0)
     print(f"{nrow} x {edge}^3  {name:28s} pair {t_f + t_a:8.3f} ms {b_pair / (t_f + t_a) / 1e6:7.1f} GB/s | A'A {t_n:7.3f} ms {b_normal / t_n / 1e6:7.1f} GB/s | "
-          f"one-pass step {t_s:7.3f} ms {b_step / t_s / 1e6:7.1f} GB/s | chained {t_c:7.3f} ms {b_step / t_c / 1e6:7.1f} GB/s{'' if chained else ' (not taken)'}",
+          f"one-pass step {t_s:7.3f} ms {b_step / t_s / 1e6:7.1f} GB/s | chained {t_c:7.3f} ms {b_step / t_c / 1e6:7.1f} GB/s{'' if chained else ' (not taken)'}{extra}",
           flush=True)
     J.close(A)
