@@ -45,6 +45,8 @@ bands = [int(v) for v in os.environ.get("GENERAL_BAND", "").split(",") if v]    
 for it, (gd, gt) in enumerate(routes * 2):
     xcd = 1
     J.tune(general_xcd=xcd, grid_diag=gd, grid_tile=gt)
+    if os.environ.get("GENERAL_TILE"):                                    # with grid_diag = 0: which general kernel takes the grid
+        J.tune(general_tile=int(os.environ["GENERAL_TILE"]))
     if bands:
         J.tune(general_band=bands[it % len(bands)])
     tf = timed(lambda: J.mul_(d, A, m))

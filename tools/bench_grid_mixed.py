@@ -59,8 +59,16 @@ if os.environ.get("GENERAL_TILE_U"):
     J.tune(fwd_unroll=int(os.environ["GENERAL_TILE_U"]))
 knob = os.environ.get("GENERAL_TILE")
 bands = [int(v) for v in os.environ.get("GENERAL_BAND", "").split(",") if v]      # tiles per band of the general kernels (8 / 16 / 32 / 64), cycled with the tile knob
+bits = {}
 for it, gt in enumerate([int(v) for v in knob.split(",")] if knob else [1, 0, 1, 0]):
     J.tune(general_tile=gt)
+    if edge <= 128:                                               # every route's bits against the first route's (forward from a dirty d, adjoint)
+        J.copyto_(d, J.rand(J.range(A), seed=9, stream=0))
+        J.mul_(d, A, m)
+        J.mul_(mt, A.H, d)
+        got = (d.to_numpy().tobytes(), mt.to_numpy().tobytes())
+        ref = bits.setdefault("ref", got)
+        print(f"general_tile={gt}: bits {'==' if got == ref else '!='} first route's", flush=True)
     if bands:
         J.tune(general_band=bands[it % len(bands)])
     tf = timed(lambda: J.mul_(d, A, m))
