@@ -570,16 +570,29 @@ __global__ __launch_bounds__(256) void k_grid_tile(const jh_dev_block *__restric
 // is what holds k_block_*_general_vec to one block in flight (GENERAL_Q); the kind switches come afterwards, wave-uniform.
 // Each accumulator adds its non-zero blocks' terms in the reference's order, product rounded before the add: the bits of the general
 // kernels.  A block row of zero blocks only is left as found (forward, 1022); the adjoint of a grid (nrow > 1) always writes (1042).
-template <typename S, int E, int NS, int QQ, int U, bool TRANSPOSED, int R = 2>
+//
+// LIST (round 5, late): the steps of a line group come from a list built at create (jh_blockop.hip: build_step_lists) -- the summed
+// block indices at which ANY line of the group has a non-zero block, ascending -- instead of 0 ... nsum - 1.  A step that is left out
+// had only zero blocks, which contribute nothing and are skipped by the reference too (1022 / 1047): same terms, same order, same bits;
+// what goes away is the step's input-pack load (HBM / L2 bytes nobody needs), its dummy loads and its branches.  Block-diagonal,
+// banded and arrow-shaped operators walk a handful of steps per line group instead of a whole block row / column.
+// Layout: one record of `step_stride` ints per line group -- [count, index 0, index 1, ..., two padding entries] -- so that the record's address does
+// not depend on a loaded value (count and the first indices arrive with one scalar load); the indices are fetched TWO steps ahead and the table
+// entries one step ahead, so no step waits for an index -> table entry -> coefficient chain of dependent round trips.
+template <typename S, int E, int NS, int QQ, int U, bool TRANSPOSED, int R = 2, bool LIST = false>
 __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol, int64_t n_scalars,
-                                                      const S *__restrict__ in, S *__restrict__ out, unsigned ntiles, unsigned ngroups)
+                                                      const S *__restrict__ in, S *__restrict__ out, unsigned ntiles, unsigned ngroups,
+                                                      const int *__restrict__ steps, int step_stride)
 {
+    static_assert(!LIST || QQ == 1, "the step list walks one step at a time");
     typedef typename vec_of<S, NS>::type V;
     int64_t grp, tile;
     general_line_tile(ngroups, ntiles, grp, tile);
     ntiles &= 0x0fffffffu;
     if (tile >= ntiles) return;
-    const int64_t nlines = TRANSPOSED ? ncol : nrow, nsum = TRANSPOSED ? nrow : ncol;
+    const int64_t nlines = TRANSPOSED ? ncol : nrow;
+    const int *sidx = LIST ? steps + grp * step_stride + 1 : nullptr;
+    const int64_t nsum = LIST ? (int64_t)sidx[-1] : (TRANSPOSED ? nrow : ncol);        // LIST: the group's own step count
     const int64_t qstep = TRANSPOSED ? 1 : nrow, lstep = TRANSPOSED ? nrow : 1;   // block (line l, q) = blocks[l * lstep + q * qstep]
     int64_t line[R];
 #pragma unroll
@@ -602,25 +615,28 @@ __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__rest
             touched[r] = TRANSPOSED;
         }
         jh_dev_block nb[QQ][R];                                               // block table entries one group of steps ahead
+        int64_t nq = LIST ? (int64_t)sidx[0] : 0, nq2 = LIST ? (int64_t)sidx[1] : 0;   // LIST: the summed block indices one and two steps ahead (two padding entries)
 #pragma unroll
         for (int q = 0; q < QQ; q++)
 #pragma unroll
-            for (int r = 0; r < R; r++) nb[q][r] = blocks[line[r] * lstep + (q < nsum ? q : 0) * qstep];
+            for (int r = 0; r < R; r++) nb[q][r] = blocks[line[r] * lstep + (LIST ? nq : (q < nsum ? q : 0)) * qstep];
         for (int64_t q0 = 0; q0 < nsum; q0 += QQ) {
             jh_dev_block b[QQ][R];
+            const int64_t qcur = nq;
+            if (LIST) { nq = nq2; nq2 = sidx[q0 + 2]; }
 #pragma unroll
             for (int q = 0; q < QQ; q++) {
                 const int64_t qn = q0 + QQ + q;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     b[q][r] = nb[q][r];
-                    nb[q][r] = blocks[line[r] * lstep + (qn < nsum ? qn : 0) * qstep];
+                    nb[q][r] = blocks[line[r] * lstep + (LIST ? nq : (qn < nsum ? qn : 0)) * qstep];
                 }
             }
             V x[QQ][U], c[QQ][R][U];
 #pragma unroll
             for (int q = 0; q < QQ; q++) {
-                const S *xb = in + (q0 + q < nsum ? q0 + q : 0) * n_scalars;                              // (a step beyond the end re-reads block 0: unused)
+                const S *xb = in + (LIST ? qcur : (q0 + q < nsum ? q0 + q : 0)) * n_scalars;               // (a step beyond the end re-reads block 0: unused)
 #pragma unroll
                 for (int u = 0; u < U; u++) x[q][u] = ld<false>(reinterpret_cast<const V *>(xb + s[u]));  // shared by every line group: through the caches
 #pragma unroll
@@ -828,15 +844,29 @@ int launch_general_tile(const jh_blockop *op, const S *in, S *out, int64_t in_by
     const int U = (c.fwd_unroll == 2) ? 2 : 1;                           // two packs per lane did not pay here (knob fwd_unroll = 2: measurements)
     unsigned ntiles, grid;
     general_grid((n_scalars / NS + 256 * U - 1) / (256 * U), ngroups, ntiles, grid, general_use_xcd(in_bytes));
-    if (four)
+    // late round 5: a SPARSE grid walks its line groups' step lists (k_general_tile LIST; built at create for four-line groups).  Knob general_list:
+    // 1 automatic, 0 never, 2 whenever the operator has lists (tests).  Automatic = the lists leave out at least an eighth of the steps AND on average
+    // at least eight steps per line group: a left-out step saves an input-pack load from L2 and ~60 instructions, the list costs one more dependent
+    // scalar round trip before a workgroup's first vector load -- 8 x 8 grids of 256^3 (at most four steps saved per group) run 0 ... 6 % slower on
+    // their lists, 16 x 16 block-bidiagonal +15 %, 32 x 32 block-diagonal of 128^3 2.9 -> 5.6 TB/s forward, 2.3 -> 5.5 adjoint, 64 x 64 of 64^3
+    // 1.7 -> 6.3 / 1.5 -> 6.1 (profiles/bench_grid_sparse_r05.txt)
+    const int dir = TRANSPOSED ? 1 : 0;
+    const int64_t full_steps = ngroups * (TRANSPOSED ? op->nrow : op->ncol);
+    const bool list = four && U == 1 && op->dev_steps[dir] && c.general_list != 0 &&
+                      (c.general_list == 2 || (op->list_steps[dir] * 8 <= full_steps * 7 && full_steps - op->list_steps[dir] >= 8 * ngroups));
+    c.last_general_list = list ? 1 : 0;
+    if (list)
+        hipLaunchKernelGGL((k_general_tile<S, E, NS, 1, 1, TRANSPOSED, 4, true>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
+                           ntiles, (unsigned)ngroups, op->dev_steps[dir], (int)op->step_stride[dir]);
+    else if (four)
         hipLaunchKernelGGL((k_general_tile<S, E, NS, 1, 1, TRANSPOSED, 4>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
-                           ntiles, (unsigned)ngroups);
+                           ntiles, (unsigned)ngroups, (const int *)nullptr, 0);
     else if (U == 2)
         hipLaunchKernelGGL((k_general_tile<S, E, NS, 2, 2, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
-                           ntiles, (unsigned)ngroups);
+                           ntiles, (unsigned)ngroups, (const int *)nullptr, 0);
     else
         hipLaunchKernelGGL((k_general_tile<S, E, NS, 2, 1, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
-                           ntiles, (unsigned)ngroups);
+                           ntiles, (unsigned)ngroups, (const int *)nullptr, 0);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }

@@ -1,0 +1,93 @@
+"""Sparse M x K grids on the step-list walk of the register-tiled general kernel (k_general_tile LIST, late round 5): per group of four
+lines the kernel visits only the summed block indices at which some line of the group has a non-zero block.  The reference skips zero
+blocks itself (src/Jets.jl:1022 forward, 1047 adjoint), so leaving their steps out changes no term and no order: the oracle's bits."""
+import numpy as np
+import pytest
+
+from .helpers import assert_bits_equal, u01
+from .test_gpu_blockop import _mixed_ops
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [np.float32, np.float64, np.complex64, np.complex128]
+
+
+def _pattern(name, M, K, rng):
+    names = ["diag", "diag_adj", "identity", "scale"]
+    pick = lambda: names[rng.integers(len(names))]
+    kinds = [["zero"] * K for _ in range(M)]
+    for i in range(M):
+        for j in range(K):
+            if name == "blockdiag":
+                on = i == j
+            elif name == "bidiag":
+                on = i == j or i == j + 1
+            elif name == "arrow":
+                on = i == j or i == 0 or j == 0
+            elif name == "band":
+                on = abs(i - j) <= 2
+            elif name == "rand":
+                on = rng.random() < 0.15
+            elif name == "holes":                      # whole groups of four lines without a block, in both directions
+                on = (i // 4) % 2 == 0 and (j // 4) % 2 == 1 and rng.random() < 0.5
+            else:
+                raise AssertionError(name)
+            if on:
+                kinds[i][j] = pick()
+    return kinds
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(4, 4), (9, 7), (16, 16), (6, 33), (37, 5)])
+@pytest.mark.parametrize("name", ["blockdiag", "bidiag", "arrow", "band", "rand", "holes"])
+def test_sparse_grids_walk_their_step_lists_with_the_oracles_bits(Jets, oracle, dt, shape, name):
+    J = Jets
+    M, K = shape
+    n = 1024 + 64                                                      # a full tile and a ragged one, 16-byte multiples for every eltype
+    rng = np.random.default_rng(1000 * M + K + 7 * sum(map(ord, name)))
+    kinds = _pattern(name, M, K, rng)
+    A, ops = _mixed_ops(J, oracle, dt, kinds, [n] * M, [n] * K)
+    hm = [u01(oracle, dt, 31, j, n) for j in range(K)]
+    hd = [u01(oracle, dt, 32, i, n) for i in range(M)]
+    hmt = [u01(oracle, dt, 33, j, n) for j in range(K)]
+    want_d = oracle.block_df(ops, [b.copy() for b in hd], hm)          # forward into a DIRTY d (`_d .+=`, 1024; rows of zero blocks stay as found, 1022)
+    want_m = oracle.block_df_adj(ops, [b.copy() for b in hmt], want_d)  # adjoint into a dirty m (zeroed, 1042)
+    used = {}
+    try:
+        for route in (2, 1, 0):                                        # the lists always / by the automatic rule / never
+            J.tune(general_list=route)
+            m = J.from_numpy(np.concatenate(hm), J.domain(A))
+            d = J.from_numpy(np.concatenate(hd), J.range(A))
+            J.mul_(d, A, m)
+            fwd_list = J.tune_get("last_general_list")
+            assert_bits_equal(d.to_numpy(), np.concatenate(want_d), f"{M}x{K} {name} forward, general_list={route}")
+            mt = J.from_numpy(np.concatenate(hmt), J.domain(A))
+            J.mul_(mt, A.H, d)
+            adj_list = J.tune_get("last_general_list")
+            assert_bits_equal(mt.to_numpy(), np.concatenate(want_m), f"{M}x{K} {name} adjoint, general_list={route}")
+            used[route] = (fwd_list, adj_list)
+    finally:
+        J.tune(general_list=1)
+    assert used[0] == (0, 0)
+    assert used[2] == (1 if M >= 4 else 0, 1 if K >= 4 else 0), used    # lists exist for every direction with at least four lines
+    J.close(A)
+
+
+def test_the_automatic_rule_takes_the_lists_only_where_they_drop_steps(Jets):
+    """A block-diagonal 16 x 16 grid walks 4 of 16 steps per line group (lists); a full grid with a single zero block keeps the plain walk."""
+    J = Jets
+    n = 4096
+    spc = J.JetSpace(np.float32, n)
+
+    def grid(pred):
+        return J.blockop([[J.JopDiagonal(J.rand(spc, seed=3, stream=16 * i + j)) if pred(i, j) else J.JopZeroBlock(spc, spc) for j in range(16)] for i in range(16)])
+
+    m = J.rand(J.JetBSpace([spc] * 16), seed=4, stream=0)
+    for pred, want in ((lambda i, j: i == j, 1), (lambda i, j: (i, j) != (3, 5), 0)):
+        A = grid(pred)
+        d = J.zeros(J.range(A))
+        J.mul_(d, A, m)
+        assert J.tune_get("last_general_list") == want
+        J.mul_(J.zeros(J.domain(A)), A.H, d)
+        assert J.tune_get("last_general_list") == want
+        J.close(A)
