@@ -468,7 +468,10 @@ int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, 
  * same bits), "fwd_ctiles" (tall forward in column bands of that many tiles of one row -- then the same tiles of the next rows, then the next band: -1 the shape's own, 0 none; same bits), "sum_adj_group" (terms of its adjoint per launch,
  * each with its own accumulator: 8, or 16; same bits), "general_tile" (grids of equal elementwise
  * blocks of ANY kinds register-tiled, k_general_tile: 1 automatic -- four lines per workgroup when there are four, else two --, 2 / 4 that many
- * lines, 0 the one-line-per-workgroup general kernels; same bits),
+ * lines, 0 the one-line-per-workgroup general kernels; same bits), "general_list" (late round 5: SPARSE grids of equal elementwise blocks walk lists of
+ * their non-zero steps built at create instead of whole block rows / columns -- the zero blocks the reference skips, src/Jets.jl:1022 / 1047, then cost
+ * nothing: 1 automatic -- only when the lists leave out an eighth of the steps; four-line lists, per-line lists or the plain walk by measurement, see
+ * "gen_walk_fwd" below --, 0 never, 2 / 3 always the four-line / per-line lists; same bits; counter "last_general_list": 0 plain, 1 four-line, 2 per-line),
  * "wide_twin" (1 x K elementwise operators on the tall kernels through their tall twin: 1 automatic -- the adjoint always, the forward
  * from 16 MiB blocks --, 0 never: the general kernels, 2 both always);
  * round 4: "cg_dev" (jh_cgls_solve / jh_cgnr_solve with the recurrences on the device, graph-replayed unless lsqr_graph = 0: 1 automatic -- CGLS
@@ -496,7 +499,9 @@ int jh_tune_get(const char *name, int64_t *value);
  * setting -1 measures again.  "upd_walk" is the same for jh_blockop_mul_axpby (0 / 1, chosen over its first two calls), "step_mode"
  * for jh_blockop_bidiag_step: 0 plain walk, 1 the same with XCD-contiguous tiles, 2 chained row chunks (one batch of 8 rows per
  * workgroup, the ordered sum handed from chunk to chunk: same bits), chosen over its first seven eligible calls ("step_trials" counts
- * them).  Read-only: "fwd_walk_inherited" (1: the forward walk came from an earlier operator of the same device, eltype, row count and
+ * them), "gen_walk_fwd" / "gen_walk_adj" for jh_blockop_mul / _mul_adj of a sparse M x K grid that moves >= 64 MiB per call: 0 the four-line
+ * step lists, 1 the per-line lists, 2 the plain walk, chosen over the first seven calls of each direction ("gen_trials" counts them; same bits).
+ * Read-only: "fwd_walk_inherited" (1: the forward walk came from an earlier operator of the same device, eltype, row count and
  * block size -- knob "walk_memory"), "fwd_switches" (times the periodic re-check rotated another walk in), "fwd_playoff" (the two walks of
  * the final play-off as 16 a + b, -1: none yet). */
 int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value);

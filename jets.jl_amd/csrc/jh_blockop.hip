@@ -282,42 +282,44 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
             if (op->blocks[(size_t)(i + j * nrow)].kind != JH_OP_ZERO) { touched[(size_t)i] = 1; break; }
     if (e == hipSuccess) e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_row_touched, (size_t)nrow);
     if (e == hipSuccess) e = hipMemcpyAsync(op->dev_row_touched, touched.data(), (size_t)nrow, hipMemcpyHostToDevice, st);
-    // step lists for sparse grids (jh_general.hip: k_general_tile LIST): grids of EQUAL elementwise blocks, directions with >= 4 lines
-    std::vector<int> steps[2];
+    // step lists for sparse grids (jh_general.hip: k_general_tile LIST): grids of EQUAL elementwise blocks; four-line groups (directions with >= 4 lines)
+    // and single lines
+    std::vector<int> steps[2][2];
     if (op->elementwise && op->uniform_rows && nrow >= 2 && ncol >= 2 && nrow < ((int64_t)1 << 30) && ncol < ((int64_t)1 << 30)) {
         bool equal = true;
         for (int64_t v : op->col_len) if (v != op->row_len[0]) equal = false;
-        for (int dir = 0; dir < 2 && equal; dir++) {
-            const int64_t nlines = dir ? ncol : nrow, nsum = dir ? nrow : ncol;
-            if (nlines < 4) continue;
-            const int64_t ngroups = (nlines + 3) / 4;
-            std::vector<std::vector<int>> per((size_t)ngroups);
-            size_t longest = 0;
-            int64_t total = 0;
-            for (int64_t g = 0; g < ngroups; g++) {
-                for (int64_t q = 0; q < nsum; q++) {
-                    bool any = false;
-                    for (int64_t l = 4 * g; l < 4 * g + 4 && l < nlines && !any; l++)
-                        any = op->blocks[(size_t)(dir ? q + l * nrow : l + q * nrow)].kind != JH_OP_ZERO;
-                    if (any) per[(size_t)g].push_back((int)q);
+        for (int dir = 0; dir < 2 && equal; dir++)
+            for (int set = 0; set < 2; set++) {
+                const int64_t nlines = dir ? ncol : nrow, nsum = dir ? nrow : ncol, R = set ? 1 : 4;
+                if (nlines < R) continue;
+                const int64_t ngroups = (nlines + R - 1) / R;
+                std::vector<std::vector<int>> per((size_t)ngroups);
+                size_t longest = 0;
+                int64_t total = 0;
+                for (int64_t g = 0; g < ngroups; g++) {
+                    for (int64_t q = 0; q < nsum; q++) {
+                        bool any = false;
+                        for (int64_t l = R * g; l < R * g + R && l < nlines && !any; l++)
+                            any = op->blocks[(size_t)(dir ? q + l * nrow : l + q * nrow)].kind != JH_OP_ZERO;
+                        if (any) per[(size_t)g].push_back((int)q);
+                    }
+                    longest = per[(size_t)g].size() > longest ? per[(size_t)g].size() : longest;
+                    total += (int64_t)per[(size_t)g].size();
                 }
-                longest = per[(size_t)g].size() > longest ? per[(size_t)g].size() : longest;
-                total += (int64_t)per[(size_t)g].size();
+                const size_t stride = (longest + 1 + JH_STEP_PAD + 3) / 4 * 4;   // count + indices + look-ahead entries, records on 16-byte boundaries
+                if ((double)stride * (double)ngroups > 1.0e9) continue;        // (a table of this size is not a grid of big blocks)
+                std::vector<int> &L = steps[dir][set];
+                L.assign(stride * (size_t)ngroups, 0);
+                for (int64_t g = 0; g < ngroups; g++) {
+                    int *rec = L.data() + (size_t)g * stride;
+                    rec[0] = (int)per[(size_t)g].size();
+                    for (size_t k = 0; k < per[(size_t)g].size(); k++) rec[1 + k] = per[(size_t)g][k];
+                }
+                op->list_steps[dir][set] = total;
+                op->step_stride[dir][set] = (int64_t)stride;
+                if (e == hipSuccess) e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_steps[dir][set], L.size() * sizeof(int));
+                if (e == hipSuccess) e = hipMemcpyAsync(op->dev_steps[dir][set], L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice, st);
             }
-            const size_t stride = (longest + 3 + 3) / 4 * 4;              // count + indices + two look-ahead entries, records on 16-byte boundaries
-            if ((double)stride * (double)ngroups > 1.0e9) continue;       // (a table of this size is not a grid of big blocks)
-            std::vector<int> &L = steps[dir];
-            L.assign(stride * (size_t)ngroups, 0);
-            for (int64_t g = 0; g < ngroups; g++) {
-                int *rec = L.data() + (size_t)g * stride;
-                rec[0] = (int)per[(size_t)g].size();
-                for (size_t k = 0; k < per[(size_t)g].size(); k++) rec[1 + k] = per[(size_t)g][k];
-            }
-            op->list_steps[dir] = total;
-            op->step_stride[dir] = (int64_t)stride;
-            if (e == hipSuccess) e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_steps[dir], L.size() * sizeof(int));
-            if (e == hipSuccess) e = hipMemcpyAsync(op->dev_steps[dir], L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice, st);
-        }
     }
     std::vector<int64_t> dims;
     if (op->small_loop) {
@@ -359,13 +361,16 @@ int jh_blockop_destroy(jh_blockop *op)
     drop_loop_graphs(op);
     lazy_release(op->fwd_tune);
     lazy_release(op->step_tune);
+    lazy_release(op->gen_tune[0]);
+    lazy_release(op->gen_tune[1]);
     if (op->dev_blocks) (void)hipFree(op->dev_blocks);
     if (op->dev_row_off) (void)hipFree(op->dev_row_off);
     if (op->dev_col_off) (void)hipFree(op->dev_col_off);
     if (op->dev_row_touched) (void)hipFree(op->dev_row_touched);
     if (op->dev_dims) (void)hipFree(op->dev_dims);
     for (int dir = 0; dir < 2; dir++)
-        if (op->dev_steps[dir]) (void)hipFree(op->dev_steps[dir]);
+        for (int set = 0; set < 2; set++)
+            if (op->dev_steps[dir][set]) (void)hipFree(op->dev_steps[dir][set]);
     if (op->twin) (void)jh_blockop_destroy(op->twin);
     jh_handle_died(op->ctx);
     delete op;

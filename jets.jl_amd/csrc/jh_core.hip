@@ -961,7 +961,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "grid_tile")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "grid_tile must be 0 (k_grid_diag), 1 (automatic) or 2 / 4 / 8 lines per workgroup"); c.grid_tile = value; }
     else if (!strcmp(name, "dense_mixed")) { JH_REQUIRE(value == 0 || value == 1, "dense_mixed must be 0 or 1"); c.dense_mixed = value; }
     else if (!strcmp(name, "general_tile")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "general_tile must be 0 (one-line kernels), 1 (automatic), 2 or 4 lines per workgroup"); c.general_tile = value; }
-    else if (!strcmp(name, "general_list")) { JH_REQUIRE(value >= 0 && value <= 2, "general_list must be 0 (never), 1 (automatic) or 2 (always)"); c.general_list = value; }
+    else if (!strcmp(name, "general_list")) { JH_REQUIRE(value >= 0 && value <= 3, "general_list must be 0 (never), 1 (automatic), 2 (always the four-line lists) or 3 (always the per-line lists)"); c.general_list = value; }
     else if (!strcmp(name, "dense_fused")) { JH_REQUIRE(value == 0 || value == 1, "dense_fused must be 0 or 1"); c.dense_fused = value; }
     else if (!strcmp(name, "cgls_trace")) { c.cgls_trace = value ? 1 : 0; }
     else if (!strcmp(name, "cg_dev")) { c.cg_dev = value < 0 ? 0 : (value > 2 ? 2 : value); }

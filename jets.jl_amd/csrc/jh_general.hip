@@ -584,7 +584,6 @@ __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__rest
                                                       const S *__restrict__ in, S *__restrict__ out, unsigned ntiles, unsigned ngroups,
                                                       const int *__restrict__ steps, int step_stride)
 {
-    static_assert(!LIST || QQ == 1, "the step list walks one step at a time");
     typedef typename vec_of<S, NS>::type V;
     int64_t grp, tile;
     general_line_tile(ngroups, ntiles, grp, tile);
@@ -615,28 +614,37 @@ __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__rest
             touched[r] = TRANSPOSED;
         }
         jh_dev_block nb[QQ][R];                                               // block table entries one group of steps ahead
-        int64_t nq = LIST ? (int64_t)sidx[0] : 0, nq2 = LIST ? (int64_t)sidx[1] : 0;   // LIST: the summed block indices one and two steps ahead (two padding entries)
+        int nq[QQ], nq2[QQ];                                                  // LIST: the summed block indices one and two groups of steps ahead (the record's padding
+#pragma unroll                                                                //       entries are index 0: valid memory, never combined)
+        for (int q = 0; q < QQ; q++) {
+            nq[q] = LIST ? sidx[q] : 0;
+            nq2[q] = LIST ? sidx[QQ + q] : 0;
+        }
 #pragma unroll
         for (int q = 0; q < QQ; q++)
 #pragma unroll
-            for (int r = 0; r < R; r++) nb[q][r] = blocks[line[r] * lstep + (LIST ? nq : (q < nsum ? q : 0)) * qstep];
+            for (int r = 0; r < R; r++) nb[q][r] = blocks[line[r] * lstep + (LIST ? (int64_t)nq[q] : (q < nsum ? q : 0)) * qstep];
         for (int64_t q0 = 0; q0 < nsum; q0 += QQ) {
             jh_dev_block b[QQ][R];
-            const int64_t qcur = nq;
-            if (LIST) { nq = nq2; nq2 = sidx[q0 + 2]; }
+            int qcur[QQ];
+#pragma unroll
+            for (int q = 0; q < QQ; q++) {
+                qcur[q] = nq[q];
+                if (LIST) { nq[q] = nq2[q]; nq2[q] = sidx[q0 + 2 * QQ + q]; }
+            }
 #pragma unroll
             for (int q = 0; q < QQ; q++) {
                 const int64_t qn = q0 + QQ + q;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     b[q][r] = nb[q][r];
-                    nb[q][r] = blocks[line[r] * lstep + (LIST ? nq : (qn < nsum ? qn : 0)) * qstep];
+                    nb[q][r] = blocks[line[r] * lstep + (LIST ? (int64_t)nq[q] : (qn < nsum ? qn : 0)) * qstep];
                 }
             }
             V x[QQ][U], c[QQ][R][U];
 #pragma unroll
             for (int q = 0; q < QQ; q++) {
-                const S *xb = in + (LIST ? qcur : (q0 + q < nsum ? q0 + q : 0)) * n_scalars;               // (a step beyond the end re-reads block 0: unused)
+                const S *xb = in + (LIST ? (int64_t)qcur[q] : (q0 + q < nsum ? q0 + q : 0)) * n_scalars;   // (a step beyond the end re-reads block 0: unused)
 #pragma unroll
                 for (int u = 0; u < U; u++) x[q][u] = ld<false>(reinterpret_cast<const V *>(xb + s[u]));  // shared by every line group: through the caches
 #pragma unroll
@@ -844,20 +852,40 @@ int launch_general_tile(const jh_blockop *op, const S *in, S *out, int64_t in_by
     const int U = (c.fwd_unroll == 2) ? 2 : 1;                           // two packs per lane did not pay here (knob fwd_unroll = 2: measurements)
     unsigned ntiles, grid;
     general_grid((n_scalars / NS + 256 * U - 1) / (256 * U), ngroups, ntiles, grid, general_use_xcd(in_bytes));
-    // late round 5: a SPARSE grid walks its line groups' step lists (k_general_tile LIST; built at create for four-line groups).  Knob general_list:
-    // 1 automatic, 0 never, 2 whenever the operator has lists (tests).  Automatic = the lists leave out at least an eighth of the steps AND on average
-    // at least eight steps per line group: a left-out step saves an input-pack load from L2 and ~60 instructions, the list costs one more dependent
-    // scalar round trip before a workgroup's first vector load -- 8 x 8 grids of 256^3 (at most four steps saved per group) run 0 ... 6 % slower on
-    // their lists, 16 x 16 block-bidiagonal +15 %, 32 x 32 block-diagonal of 128^3 2.9 -> 5.6 TB/s forward, 2.3 -> 5.5 adjoint, 64 x 64 of 64^3
-    // 1.7 -> 6.3 / 1.5 -> 6.1 (profiles/bench_grid_sparse_r05.txt)
+    // late round 5: a SPARSE grid walks step lists built at create (k_general_tile LIST) -- per group of four lines the summed block indices at which one
+    // of the lines has a non-zero block (the input pack still shared by four lines), or per line its own non-zero blocks (no dummy load at all, four
+    // steps' loads in flight).  Same bits as the plain walk.  32 x 32 block-diagonal of 128^3: forward 2.9 -> 5.6 TB/s, adjoint 2.3 -> 5.5; 64 x 64 of
+    // 64^3 1.7 -> 6.6 / 1.4 -> 6.1; 16 x 16 block-bidiagonal of 256^3 5.2 -> 6.1 / 4.8 -> 6.0 (profiles/bench_grid_sparse_r05.txt).
+    // Knob general_list: 0 never, 2 / 3 always the four-line / per-line lists (tests), 1 automatic: lists only when the four-line lists leave out at
+    // least an eighth of the steps (a dense mix keeps the plain walk); WHICH walk then is measured per operator and direction over its first seven
+    // calls (lazy_next, as the tall forward's grid walk: no extra launches, no host synchronisation) when the operator moves >= 64 MiB per call --
+    // four-line against per-line lists differ by -12 ... +37 % with the pattern, 8 x 8 grids of 256^3 are as fast or faster on the plain walk;
+    // smaller operators take the four-line lists when they save >= 8 steps per group on average, else the plain walk.
     const int dir = TRANSPOSED ? 1 : 0;
-    const int64_t full_steps = ngroups * (TRANSPOSED ? op->nrow : op->ncol);
-    const bool list = four && U == 1 && op->dev_steps[dir] && c.general_list != 0 &&
-                      (c.general_list == 2 || (op->list_steps[dir] * 8 <= full_steps * 7 && full_steps - op->list_steps[dir] >= 8 * ngroups));
-    c.last_general_list = list ? 1 : 0;
-    if (list)
+    const int64_t nsum_all = TRANSPOSED ? op->nrow : op->ncol, full_steps = ngroups * nsum_all;
+    const bool have4 = four && U == 1 && op->dev_steps[dir][0], have1 = U == 1 && op->dev_steps[dir][1];
+    int list = 0, slot = -1;                                              // list: 0 the plain walk, 1 the four-line lists, 2 the per-line lists
+    if (c.general_list == 2) list = have4 ? 1 : 0;
+    else if (c.general_list == 3) list = have1 ? 2 : 0;
+    else if (c.general_list == 1 && have4 && op->list_steps[dir][0] * 8 <= full_steps * 7) {
+        list = full_steps - op->list_steps[dir][0] >= 8 * ngroups ? 1 : 0;
+        if (have1 && c.autotune && (double)op->list_steps[dir][1] * (double)n_scalars * sizeof(S) >= (double)((int64_t)64 << 20) && !stream_is_capturing(c.stream)) {
+            static const int walk_list[3] = {1, 2, 0};
+            int cand = op->gen_walk[dir];
+            if (cand < 0) cand = lazy_next(op->gen_tune[dir], 3, 2, 1, 0.01f, &op->gen_walk[dir], &slot);
+            list = walk_list[cand >= 0 && cand < 3 ? cand : 0];
+        }
+    }
+    const bool timing = slot >= 0 && lazy_begin(op->gen_tune[dir], slot, c.stream);
+    c.last_general_list = list;
+    if (list == 2) {
+        // every line on its own: a step = a non-zero block (no dummy loads at all), four steps' loads in flight
+        general_grid((n_scalars / NS + 255) / 256, nlines, ntiles, grid, general_use_xcd(in_bytes));
+        hipLaunchKernelGGL((k_general_tile<S, E, NS, 4, 1, TRANSPOSED, 1, true>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
+                           ntiles, (unsigned)nlines, op->dev_steps[dir][1], (int)op->step_stride[dir][1]);
+    } else if (list == 1)
         hipLaunchKernelGGL((k_general_tile<S, E, NS, 1, 1, TRANSPOSED, 4, true>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
-                           ntiles, (unsigned)ngroups, op->dev_steps[dir], (int)op->step_stride[dir]);
+                           ntiles, (unsigned)ngroups, op->dev_steps[dir][0], (int)op->step_stride[dir][0]);
     else if (four)
         hipLaunchKernelGGL((k_general_tile<S, E, NS, 1, 1, TRANSPOSED, 4>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
                            ntiles, (unsigned)ngroups, (const int *)nullptr, 0);
@@ -867,7 +895,9 @@ int launch_general_tile(const jh_blockop *op, const S *in, S *out, int64_t in_by
     else
         hipLaunchKernelGGL((k_general_tile<S, E, NS, 2, 1, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
                            ntiles, (unsigned)ngroups, (const int *)nullptr, 0);
-    JH_CHECK_HIP(hipGetLastError());
+    const hipError_t le = hipGetLastError();
+    if (slot >= 0) lazy_end(op->gen_tune[dir], slot, c.stream, timing && le == hipSuccess);
+    JH_CHECK_HIP(le);
     return JH_OK;
 }
 

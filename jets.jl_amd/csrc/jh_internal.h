@@ -110,8 +110,8 @@ struct jh_context {
     int64_t grid_diag = 1;             // knob: M x K grids of plain diagonals on the branch-free kernel (0: the general kernels)
     int64_t grid_tile = 1;             // knob: ... register-tiled (k_grid_tile: R lines x one tile per workgroup): 1 automatic R, 2 / 4 / 8 that R, 0: k_grid_diag
     int64_t general_tile = 1;          // knob: grids of EQUAL elementwise blocks of any kinds register-tiled (k_general_tile: two lines x one tile per workgroup); 0: k_block_*_general_vec
-    int64_t general_list = 1;          // knob: sparse grids walk per-line-group lists of their non-zero steps (k_general_tile LIST): 1 when the lists drop >= 1/8 of the steps, 0 never, 2 always
-    int64_t last_general_list = 0;     // read-only: 1 when the most recent register-tiled general launch walked a step list
+    int64_t general_list = 1;          // knob: sparse grids walk lists of their non-zero steps (k_general_tile LIST): 1 automatic (jh_general.hip: launch_general_tile), 0 never, 2 always the four-line lists, 3 always the per-line lists
+    int64_t last_general_list = 0;     // read-only: the most recent register-tiled general launch walked 0 no list, 1 its four-line lists, 2 its per-line lists
     int64_t sum_group = 16;            // knob: terms of a fused JetSum per FORWARD launch (16; 8 / 4 = round 3's / round 2's grouping, for A/B); the adjoint takes 8 (4)
     int64_t bcast_band = 0;            // knob: batched broadcasts with a shared operand in column bands of this many tiles (0: 32; 1: items fastest, no bands)
     int64_t general_band = 8;          // knob: tiles of every line the general M x K kernels walk before the next group of tiles starts: 8, 16, 32, 64
@@ -221,6 +221,7 @@ struct jh_dev_block {
     int32_t adjoint;          //  every step's coefficient loads in the general kernels)      real_scale: SCALE, 1 = a REAL scalar (see jh_dev_block_of)
 };
 static_assert(sizeof(jh_dev_block) == 32, "one table entry = one s_load_dwordx8");
+constexpr int JH_STEP_PAD = 12;        // padding entries of a step-list record: three groups of up to four steps in flight (k_general_tile LIST)
 
 // the device form of a block description.  A SCALE block's scalar is Real unless it is flagged JH_SCALAR_COMPLEX or has a non-zero
 // imaginary part: Julia's `a::Real * z` multiplies part by part, a Complex `a` takes the full product even when imag(a) == 0 (with THAT
@@ -253,12 +254,13 @@ struct jh_blockop {
     int64_t *dev_row_off = nullptr;          // nrow+1
     int64_t *dev_col_off = nullptr;          // ncol+1
     unsigned char *dev_row_touched = nullptr; // nrow: 1 when the block row has a non-zero block (the linear forward writes it)
-    // step lists of the register-tiled general kernel (k_general_tile LIST), [0] forward (lines = block rows, groups of four), [1] adjoint (lines =
-    // block columns): one record of step_stride ints per group -- the count, then the ascending summed block indices at which one of the group's
-    // lines has a non-zero block, then two padding entries (the kernel looks two steps ahead)
-    int *dev_steps[2] = {nullptr, nullptr};
-    int64_t step_stride[2] = {0, 0};
-    int64_t list_steps[2] = {0, 0};          // steps of all groups together (compare with ngroups * nsum: the plain walk's steps)
+    // step lists of the register-tiled general kernel (k_general_tile LIST): [dir][set], dir 0 forward (lines = block rows), 1 adjoint (lines = block
+    // columns); set 0: groups of FOUR lines (a step = a summed block index at which one of the group's lines has a non-zero block), set 1: every line
+    // on its own (a step = a non-zero block).  One record of step_stride ints per group: the count, the ascending indices, JH_STEP_PAD padding entries
+    // (the kernel fetches indices two groups of steps ahead).
+    int *dev_steps[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int64_t step_stride[2][2] = {{0, 0}, {0, 0}};
+    int64_t list_steps[2][2] = {{0, 0}, {0, 0}};   // steps of all groups together (compare with ngroups * nsum: the plain walk's steps)
     // classification for the fast paths
     bool tall = false;                       // ncol == 1
     bool uniform_rows = false;               // all row_len equal
@@ -308,6 +310,8 @@ struct jh_blockop {
     };
     mutable LazyTune fwd_tune;               // tall forward: K_FWD_CANDIDATES shapes x 2 passes -> fwd_walk
     mutable LazyTune step_tune;              // one-pass step: plain / tile map / chained x 2 passes (+ a warm-up) -> step_mode
+    mutable LazyTune gen_tune[2];            // sparse grids on the register-tiled general kernel, per direction: four-line lists / per-line lists / plain walk -> gen_walk
+    mutable int gen_walk[2] = {-1, -1};      // -1 untried, 0 the four-line step lists, 1 the per-line lists, 2 the plain walk (jh_general.hip: launch_general_tile)
     mutable int upd_walk = -1;               // same for the fused forward update (timed on its first two real calls)
     mutable int upd_trials = 0;
     mutable float upd_ms[2] = {0.f, 0.f};

@@ -1109,6 +1109,9 @@ int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value)
     else if (!strcmp(name, "step_trials")) *value = op->step_tune.launched;
     else if (!strcmp(name, "upd_walk")) *value = op->upd_walk;
     else if (!strcmp(name, "step_mode")) *value = op->step_mode;
+    else if (!strcmp(name, "gen_walk_fwd")) *value = op->gen_walk[0];            // sparse grids: -1 not chosen, 0 four-line step lists, 1 per-line lists, 2 plain walk
+    else if (!strcmp(name, "gen_walk_adj")) *value = op->gen_walk[1];
+    else if (!strcmp(name, "gen_trials")) *value = op->gen_tune[0].launched + op->gen_tune[1].launched;
     else return jh_fail(JH_ERR_INVALID, "jh_blockop_tune_get: unknown per-operator knob '%s'", name);
     return JH_OK;
 }
@@ -1131,6 +1134,11 @@ int jh_blockop_tune_set(jh_blockop *op, const char *name, int64_t value)
         lazy_reset(op->step_tune);
         op->step_span = 0;
         op->step_mode = (int)value;
+    } else if (!strcmp(name, "gen_walk_fwd") || !strcmp(name, "gen_walk_adj")) {
+        JH_REQUIRE(value >= -1 && value <= 2, "jh_blockop_tune_set: %s must be -1 (measure), 0 (four-line step lists), 1 (per-line lists) or 2 (plain walk)", name);
+        const int dir = !strcmp(name, "gen_walk_adj") ? 1 : 0;
+        lazy_reset(op->gen_tune[dir]);
+        op->gen_walk[dir] = (int)value;
     } else return jh_fail(JH_ERR_INVALID, "jh_blockop_tune_set: unknown per-operator knob '%s'", name);
     return JH_OK;
 }

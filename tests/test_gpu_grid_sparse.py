@@ -54,7 +54,7 @@ def test_sparse_grids_walk_their_step_lists_with_the_oracles_bits(Jets, oracle, 
     want_m = oracle.block_df_adj(ops, [b.copy() for b in hmt], want_d)  # adjoint into a dirty m (zeroed, 1042)
     used = {}
     try:
-        for route in (2, 1, 0):                                        # the lists always / by the automatic rule / never
+        for route in (3, 2, 1, 0):                                     # the per-line lists / the four-line lists always / by the automatic rule / never
             J.tune(general_list=route)
             m = J.from_numpy(np.concatenate(hm), J.domain(A))
             d = J.from_numpy(np.concatenate(hd), J.range(A))
@@ -69,7 +69,8 @@ def test_sparse_grids_walk_their_step_lists_with_the_oracles_bits(Jets, oracle, 
     finally:
         J.tune(general_list=1)
     assert used[0] == (0, 0)
-    assert used[2] == (1 if M >= 4 else 0, 1 if K >= 4 else 0), used    # lists exist for every direction with at least four lines
+    assert used[2] == (1 if M >= 4 else 0, 1 if K >= 4 else 0), used    # four-line lists exist for every direction with at least four lines
+    assert used[3] == (2, 2), used
     J.close(A)
 
 
@@ -91,3 +92,45 @@ def test_the_automatic_rule_takes_the_lists_only_where_they_drop_steps(Jets):
         J.mul_(J.zeros(J.domain(A)), A.H, d)
         assert J.tune_get("last_general_list") == want
         J.close(A)
+
+
+def test_a_big_sparse_grid_measures_its_walk_over_its_first_calls_and_keeps_its_bits(Jets):
+    """16 x 16 block-bidiagonal of 4 MiB blocks (124 MiB of coefficients per call): the first seven calls per direction each run ONE candidate walk
+    (four-line lists / per-line lists / plain) between two events, then the operator keeps the fastest -- every call with the bits of the plain walk;
+    the choice can be read, forced and measured again through the per-operator knobs."""
+    J = Jets
+    n = 1 << 20
+    spc = J.JetSpace(np.float32, n)
+    A = J.blockop([[J.JopDiagonal(J.rand(spc, seed=5, stream=16 * i + j)) if i == j or i == j + 1 else J.JopZeroBlock(spc, spc) for j in range(16)] for i in range(16)])
+    m = J.rand(J.domain(A), seed=6, stream=0)
+    d0 = J.rand(J.range(A), seed=7, stream=0)
+    try:
+        J.tune(general_list=0)
+        d = J.copyto_(J.zeros(J.range(A)), d0)
+        J.mul_(d, A, m)
+        mt = J.mul_(J.zeros(J.domain(A)), A.H, d)
+        want = (d.to_numpy().tobytes(), mt.to_numpy().tobytes())
+        J.tune(general_list=1)
+        assert J.op_tune_get(A, "gen_walk_fwd") == -1 and J.op_tune_get(A, "gen_walk_adj") == -1
+        seen = set()
+        for _ in range(12):
+            J.copyto_(d, d0)
+            J.mul_(d, A, m)
+            seen.add(J.tune_get("last_general_list"))
+            J.mul_(mt, A.H, d)
+            assert (d.to_numpy().tobytes(), mt.to_numpy().tobytes()) == want
+        assert seen == {0, 1, 2}                                           # every candidate ran as a trial
+        assert J.op_tune_get(A, "gen_walk_fwd") in (0, 1, 2) and J.op_tune_get(A, "gen_walk_adj") in (0, 1, 2)
+        assert J.op_tune_get(A, "gen_trials") == 14                        # a warm-up + three candidates x two passes, per direction
+        for walk, lst in ((2, 0), (0, 1), (1, 2)):                         # forced choices
+            J.op_tune_set(A, "gen_walk_fwd", walk)
+            J.copyto_(d, d0)
+            J.mul_(d, A, m)
+            assert J.tune_get("last_general_list") == lst and d.to_numpy().tobytes() == want[0]
+        J.op_tune_set(A, "gen_walk_fwd", -1)                               # measure again
+        J.copyto_(d, d0)
+        J.mul_(d, A, m)
+        assert J.op_tune_get(A, "gen_walk_fwd") == -1 and J.op_tune_get(A, "gen_trials") == 7 + 1 and d.to_numpy().tobytes() == want[0]
+    finally:
+        J.tune(general_list=1)
+    J.close(A)

@@ -56,7 +56,7 @@ def timed(fn, reps=6, warm=2):
 
 
 knob = os.environ.get("GENERAL_LIST")
-routes = [int(v) for v in knob.split(",")] if knob else [1, 0, 1, 0]
+routes = [int(v) for v in knob.split(",")] if knob else [3, 2, 0, 1, 3, 2, 0, 1]
 for pat in patterns:
     kinds = kinds_of(pat)
     ndiag = int((kinds == "d").sum())
@@ -100,8 +100,17 @@ for pat in patterns:
             same = "==" if got == ref else "!="
         else:
             same = "??"
+        walk = ""
+        if gl == 1:                                                        # the automatic route measures over its first seven calls per direction
+            for _ in range(9):
+                J.mul_(d, A, m)
+                J.mul_(mt, A.H, d)
+            J.synchronize()
+            J.mul_(d, A, m)
+            J.mul_(mt, A.H, d)
+            walk = f" [chose fwd {J.op_tune_get(A, 'gen_walk_fwd')} adj {J.op_tune_get(A, 'gen_walk_adj')}; last launch list {J.tune_get('last_general_list')}]"
         tf = timed(lambda: J.mul_(d, A, m))
         ta = timed(lambda: J.mul_(mt, A.H, d))
         print(f"{M} x {K} {pat:8s} of {edge}^3 ({int(nz.sum())} non-zero blocks, {ndiag} diagonals) general_list={gl} bits {same}: "
-              f"forward {tf:7.3f} ms {fwd_bytes / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {adj_bytes / ta / 1e6:7.1f} GB/s", flush=True)
+              f"forward {tf:7.3f} ms {fwd_bytes / tf / 1e6:7.1f} GB/s | adjoint {ta:7.3f} ms {adj_bytes / ta / 1e6:7.1f} GB/s{walk}", flush=True)
     del A, m, d, mt, coeff
