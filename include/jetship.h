@@ -484,7 +484,14 @@ int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, 
  * (operators whose DENSE children are all small in one launch: 1 yes, 0 the per-block loop), "force_dist" (1: run the exchange of the partitioned
  * solvers with a one-rank communicator too; validation), "adj_rows_per_launch" (tall adjoint / fused normal: block rows per launch, 0 all
  * rows in one; same bits), "dense_mixed" (operators mixing big DENSE children with other kinds as one batched launch + one launch of the
- * general kernels: 1 yes, 0 the per-block loop; counter "last_launches");
+ * general kernels: 1 yes, 0 the per-block loop; counter "last_launches"); late round 5: "dense_list" (1: those batched launches walk LISTS of the dense
+ * children built at create -- no workgroup for a block pair without a dense child, few big children spread over the chip, products in one compact scratch
+ * vector, the combine launch over each line's step list: block-diagonal / block-banded operators of dense children at any block count; 0: round 3's grid
+ * over every block pair), "dense_list_split" (1: the list kernel of y = B x picks its lane layout -- column groups of one workgroup meet in LDS:
+ * deterministic, tolerance parity like any BLAS gemv --, 0: columns in order, the sequential loop's bits; counter "last_dense_rl" = row lanes per workgroup of
+ * the latest such launch, 256: columns in order), "dense_list_cpw" (columns per lane group of the list kernel of y = B' x: 0 by column length, 1 / 2 / 4; same contract),
+ * "small_loop_max_kib" (operators of SMALL dense children whose matrices together reach this many KiB take
+ * the list route instead of the one-launch loop: 512);
  * jh_tune_get also reads the counters "last_fwd_walk" (grid walk of the latest tall forward: 0 sequential, 1 all rows, 2 column bands),
  * "last_fwd_rows_per_wg", "last_adj_launches", "last_adj_parts", "last_step_chain" (row chunks of the latest one-pass step, 0: the plain walk), "graph_replays", "last_lsqr_graph" / "last_cg_graph" (graph replays of the latest
  * jh_lsqr_solve / jh_cgls_solve or jh_cgnr_solve; 0: the host loop ran) and "last_dense_fused" (1: the latest dense adjoint / wide forward took the

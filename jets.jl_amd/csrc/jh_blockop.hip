@@ -245,7 +245,11 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
         for (int64_t v : fwd_work) line_work = v > line_work ? v : line_work;
         for (int64_t v : adj_work) line_work = v > line_work ? v : line_work;
         op->small_loop = small && (line_work <= 512 || !eligible);           // (the one-launch loop is bit-exact in the adjoint too: kept for small operators)
-        op->dense_mixed = eligible && !op->small_loop;
+        // late round 5: an eligible operator is ALSO prepared for the batched route -- MANY small children (a block-diagonal operator of 256 matrices of
+        // 256 x 256) move far more bytes than one launch of the loop can stream (a thread forms a whole dot product: 0.2-0.5 TB/s); use_small_loop decides per call
+        op->dense_mixed = eligible;
+        for (const auto &b : op->blocks)
+            if (b.kind == JH_OP_DENSE) op->dense_bytes += (double)b.nr * (double)b.nc * (double)es;
         op->dense_mixed_aligned = aligned;
     }
 
@@ -264,9 +268,26 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
         }
     }
 
+    // where the products of a dense_mixed operator's dense children go: one compact scratch vector per direction, a 16-byte aligned piece per child
+    if (op->dense_mixed) {
+        const int64_t per16 = (int64_t)(16 / jh_dtype_size(dtype)) > 0 ? (int64_t)(16 / jh_dtype_size(dtype)) : 1;
+        for (int dir = 0; dir < 2; dir++) {
+            op->prod_off[dir].assign((size_t)(nrow * ncol), -1);
+            int64_t at = 0;
+            for (int64_t j = 0; j < ncol; j++)
+                for (int64_t i = 0; i < nrow; i++) {
+                    if (op->blocks[(size_t)(i + j * nrow)].kind != JH_OP_DENSE) continue;
+                    const int64_t out_len = dir ? op->col_len[(size_t)j] : op->row_len[(size_t)i];
+                    op->prod_off[dir][(size_t)(i + j * nrow)] = at;
+                    at += (out_len + per16 - 1) / per16 * per16;
+                }
+            op->prod_total[dir] = at;
+        }
+    }
     std::vector<jh_dev_block> host((size_t)(nrow * ncol));
     for (size_t k = 0; k < host.size(); k++) {
         host[k] = jh_dev_block_of(op->blocks[k]);
+        if (op->dense_mixed && op->blocks[k].kind == JH_OP_DENSE) jh_dev_block_set_prod_off(host[k], op->prod_off[0][k], op->prod_off[1][k]);
     }
     hipStream_t st = jh_ctx().stream;
     hipError_t e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_blocks, host.size() * sizeof(jh_dev_block));
@@ -284,12 +305,13 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
     if (e == hipSuccess) e = hipMemcpyAsync(op->dev_row_touched, touched.data(), (size_t)nrow, hipMemcpyHostToDevice, st);
     // step lists for sparse grids (jh_general.hip: k_general_tile LIST): grids of EQUAL elementwise blocks; four-line groups (directions with >= 4 lines)
     // and single lines
+    // (the per-line lists also serve the one-line general kernels -- the combine launch of dense_mixed_apply --, for grids of any blocks)
     std::vector<int> steps[2][2];
-    if (op->elementwise && op->uniform_rows && nrow >= 2 && ncol >= 2 && nrow < ((int64_t)1 << 30) && ncol < ((int64_t)1 << 30)) {
-        bool equal = true;
+    if (nrow >= 2 && ncol >= 2 && nrow < ((int64_t)1 << 30) && ncol < ((int64_t)1 << 30)) {
+        bool equal = op->elementwise && op->uniform_rows;                  // the four-line lists are k_general_tile's: grids of EQUAL elementwise blocks
         for (int64_t v : op->col_len) if (v != op->row_len[0]) equal = false;
-        for (int dir = 0; dir < 2 && equal; dir++)
-            for (int set = 0; set < 2; set++) {
+        for (int dir = 0; dir < 2; dir++)
+            for (int set = equal ? 0 : 1; set < 2; set++) {
                 const int64_t nlines = dir ? ncol : nrow, nsum = dir ? nrow : ncol, R = set ? 1 : 4;
                 if (nlines < R) continue;
                 const int64_t ngroups = (nlines + R - 1) / R;
@@ -320,6 +342,36 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
                 if (e == hipSuccess) e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_steps[dir][set], L.size() * sizeof(int));
                 if (e == hipSuccess) e = hipMemcpyAsync(op->dev_steps[dir][set], L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice, st);
             }
+    }
+    // the dense children of a dense_mixed operator as lists per direction and pass (jh_dense.hip: k_gemv_rows_list / k_gemv_cols_list)
+    std::vector<jh_dense_item> items[2][2];
+    if (op->dense_mixed) {
+        for (int dir = 0; dir < 2; dir++) {
+            for (int64_t j = 0; j < ncol; j++)
+                for (int64_t i = 0; i < nrow; i++) {
+                    const jh_block_desc &b = op->blocks[(size_t)(i + j * nrow)];
+                    if (b.kind != JH_OP_DENSE) continue;
+                    const int64_t out_len = dir ? op->col_len[(size_t)j] : op->row_len[(size_t)i], in_len = dir ? op->row_len[(size_t)i] : op->col_len[(size_t)j];
+                    if (out_len == 0) continue;                               // (an empty product; a child with an empty INPUT stays: its slab piece must hold zeros)
+                    const int pass = ((b.adjoint != 0) == (dir != 0)) ? 0 : 1;
+                    jh_dense_item it;
+                    it.A = b.coeff;
+                    it.nr = pass == 0 ? out_len : in_len;
+                    it.nc = pass == 0 ? in_len : out_len;
+                    it.x_off = dir ? op->row_off[(size_t)i] : op->col_off[(size_t)j];
+                    it.out_off = op->prod_off[dir][(size_t)(i + j * nrow)];
+                    items[dir][pass].push_back(it);
+                    if (out_len > op->items_max_out[dir][pass]) op->items_max_out[dir][pass] = out_len;
+                    if (in_len > op->items_max_in[dir][pass]) op->items_max_in[dir][pass] = in_len;
+                }
+            for (int pass = 0; pass < 2; pass++) {
+                op->n_items[dir][pass] = (int64_t)items[dir][pass].size();
+                if (items[dir][pass].empty()) continue;
+                const size_t bytes = items[dir][pass].size() * sizeof(jh_dense_item);
+                if (e == hipSuccess) e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_items[dir][pass], bytes);
+                if (e == hipSuccess) e = hipMemcpyAsync(op->dev_items[dir][pass], items[dir][pass].data(), bytes, hipMemcpyHostToDevice, st);
+            }
+        }
     }
     std::vector<int64_t> dims;
     if (op->small_loop) {
@@ -371,6 +423,9 @@ int jh_blockop_destroy(jh_blockop *op)
     for (int dir = 0; dir < 2; dir++)
         for (int set = 0; set < 2; set++)
             if (op->dev_steps[dir][set]) (void)hipFree(op->dev_steps[dir][set]);
+    for (int dir = 0; dir < 2; dir++)
+        for (int pass = 0; pass < 2; pass++)
+            if (op->dev_items[dir][pass]) (void)hipFree(op->dev_items[dir][pass]);
     if (op->twin) (void)jh_blockop_destroy(op->twin);
     jh_handle_died(op->ctx);
     delete op;
@@ -396,11 +451,28 @@ int jh_blockop_point(jh_blockop *op, const jh_bvec *mo)
         }
     for (size_t k = 0; k < host.size(); k++) {
         host[k] = jh_dev_block_of(op->blocks[k]);
+        if (op->dense_mixed && op->blocks[k].kind == JH_OP_DENSE) jh_dev_block_set_prod_off(host[k], op->prod_off[0][k], op->prod_off[1][k]);
     }
     hipStream_t st = jh_ctx().stream;
     JH_CHECK_HIP(hipMemcpyAsync(op->dev_blocks, host.data(), host.size() * sizeof(jh_dev_block), hipMemcpyHostToDevice, st));
     JH_CHECK_HIP(hipStreamSynchronize(st));                             // host staging vector dies at return
     return JH_OK;
+}
+
+// the one-launch loop for operators of small dense children -- unless the batched route is available too and the children together are
+// big enough to be a streaming problem (knob small_loop_max_kib: dense bytes from which the batched route takes over)
+static inline bool use_small_loop(const jh_blockop *op)
+{
+    const jh_context &c = jh_ctx();
+    if (!(op->small_loop && c.small_loop)) return false;
+    return !(op->dense_mixed && c.dense_mixed && c.dense_list && op->dense_bytes >= (double)c.small_loop_max_kib * 1024.0);
+}
+// the batched route (dense_mixed_apply); an operator that is ALSO a one-launch-loop operator takes it only in place of that loop (knob small_loop = 0 still
+// means the reference's per-block loop for those)
+static inline bool use_dense_mixed(const jh_blockop *op)
+{
+    const jh_context &c = jh_ctx();
+    return op->dense_mixed && c.dense_mixed && (!op->small_loop || (c.small_loop && !use_small_loop(op)));
 }
 
 int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
@@ -411,8 +483,8 @@ int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
     if (op->dense_batch_grid) return dense_grid_fwd(op, d->data, m->data);
     if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false, op->dev_row_off);
-    if (op->small_loop && jh_ctx().small_loop) return loop_small(op, d->data, m->data, 0, 1);
-    if (op->dense_mixed && jh_ctx().dense_mixed) return dense_mixed(op, d->data, m->data, false, true);
+    if (use_small_loop(op)) return loop_small(op, d->data, m->data, 0, 1);
+    if (use_dense_mixed(op)) return dense_mixed(op, d->data, m->data, false, true);
     if (!op->elementwise) return run_loop_graphed(op, 2, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data, true); });
     return jhb::general_fwd(op, d->data, m->data, 1);
     return jh_fail(JH_ERR_INVALID, "jh_blockop_f: unknown dtype %d", op->dtype);
@@ -434,8 +506,8 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
     if (op->dense_batch_grid) return dense_grid_fwd(op, d->data, m->data);
     if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false, op->dev_row_off);
-    if (op->small_loop && jh_ctx().small_loop) return loop_small(op, d->data, m->data, 0, 0);
-    if (op->dense_mixed && jh_ctx().dense_mixed) return dense_mixed(op, d->data, m->data, false);
+    if (use_small_loop(op)) return loop_small(op, d->data, m->data, 0, 0);
+    if (use_dense_mixed(op)) return dense_mixed(op, d->data, m->data, false);
     if (!op->elementwise) return run_loop_graphed(op, 0, d->data, m->data, [&] { return loop_fwd(op, d->data, m->data); });
     // a wide operator's forward d = d_found + sum_j A_1j m_j (1024: no zeroing) is its tall twin's ordered adjoint sum started from
     // what d holds -- the same additions in the same order.  Large blocks only: the ordered walk needs >= one workgroup per CU
@@ -469,8 +541,8 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, true);
     if (op->dense_batch_grid) return dense_grid_adj(op, m->data, d->data);
     if (op->dense_batch_ragged) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->dense_max_nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, false, op->dev_row_off);
-    if (op->small_loop && jh_ctx().small_loop) return loop_small(op, m->data, d->data, 1, 0);
-    if (op->dense_mixed && jh_ctx().dense_mixed) return dense_mixed(op, m->data, d->data, true);
+    if (use_small_loop(op)) return loop_small(op, m->data, d->data, 1, 0);
+    if (use_dense_mixed(op)) return dense_mixed(op, m->data, d->data, true);
     if (!op->elementwise) return run_loop_graphed(op, 1, m->data, d->data, [&] { return loop_adj(op, m->data, d->data); });
     // a wide operator's adjoint is its tall twin's forward (same bits: one rounded product per element, zero blocks untouched)
     if (op->twin && jh_ctx().wide_twin && (tall_fast_ok(op->twin, m->data, d->data) || tall_mixed_ok(op->twin, m->data, d->data)))

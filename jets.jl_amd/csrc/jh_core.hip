@@ -962,6 +962,10 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "dense_mixed")) { JH_REQUIRE(value == 0 || value == 1, "dense_mixed must be 0 or 1"); c.dense_mixed = value; }
     else if (!strcmp(name, "general_tile")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "general_tile must be 0 (one-line kernels), 1 (automatic), 2 or 4 lines per workgroup"); c.general_tile = value; }
     else if (!strcmp(name, "general_list")) { JH_REQUIRE(value >= 0 && value <= 3, "general_list must be 0 (never), 1 (automatic), 2 (always the four-line lists) or 3 (always the per-line lists)"); c.general_list = value; }
+    else if (!strcmp(name, "small_loop_max_kib")) { JH_REQUIRE(value >= 0, "small_loop_max_kib must be >= 0"); c.small_loop_max_kib = value; }
+    else if (!strcmp(name, "dense_list")) { JH_REQUIRE(value >= 0 && value <= 2, "dense_list must be 0 (the grid over every block pair), 1 (the children's lists) or 2 (... also for few big children)"); c.dense_list = value; }
+    else if (!strcmp(name, "dense_list_cpw")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "dense_list_cpw must be 0 (by column length), 1, 2 or 4"); c.dense_list_cpw = value; }
+    else if (!strcmp(name, "dense_list_split")) { JH_REQUIRE(value == 0 || value == 1, "dense_list_split must be 0 (columns in order) or 1 (automatic lane layout)"); c.dense_list_split = value; }
     else if (!strcmp(name, "dense_fused")) { JH_REQUIRE(value == 0 || value == 1, "dense_fused must be 0 or 1"); c.dense_fused = value; }
     else if (!strcmp(name, "cgls_trace")) { c.cgls_trace = value ? 1 : 0; }
     else if (!strcmp(name, "cg_dev")) { c.cg_dev = value < 0 ? 0 : (value > 2 ? 2 : value); }
@@ -1024,6 +1028,11 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "sum_adj_group")) *value = c.sum_adj_group;
     else if (!strcmp(name, "general_tile")) *value = c.general_tile;
     else if (!strcmp(name, "general_list")) *value = c.general_list;
+    else if (!strcmp(name, "dense_list")) *value = c.dense_list;
+    else if (!strcmp(name, "small_loop_max_kib")) *value = c.small_loop_max_kib;
+    else if (!strcmp(name, "dense_list_split")) *value = c.dense_list_split;
+    else if (!strcmp(name, "dense_list_cpw")) *value = c.dense_list_cpw;
+    else if (!strcmp(name, "last_dense_rl")) *value = c.last_dense_rl;
     else if (!strcmp(name, "last_general_list")) *value = c.last_general_list;
     else if (!strcmp(name, "dense_mixed")) *value = c.dense_mixed;
     else if (!strcmp(name, "dense_fused")) *value = c.dense_fused;

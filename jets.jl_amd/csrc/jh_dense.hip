@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows_mixed(const jh_dev_block *__r
     const int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * NS;
     if (s >= ns) return;
     const S *x = in + (transposed ? row_off[i] : col_off[j]) * E;
-    S *out = slabs + (transposed ? i * slab_stride + col_off[j] : j * slab_stride + row_off[i]) * E;
+    S *out = slabs + jh_dev_block_prod_off(b, transposed != 0) * E;
     V acc = (V)(S)0;
     const S *col = (const S *)b.coeff + s;
     // sixteen columns' loads in flight (the adds are serial by definition, the loads need not be: a 384-row child has 96 active
@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(256) void k_gemv_cols_mixed(const jh_dev_block *__r
         if (E == 2) si += __shfl_down(si, off, 64);
     }
     if (lane == 0) {
-        S *o = slabs + ((transposed ? i * slab_stride + col_off[j] : j * slab_stride + row_off[i]) + c) * E;
+        S *o = slabs + (jh_dev_block_prod_off(b, transposed != 0) + c) * E;
         o[0] = (S)sr;
         if (E == 2) o[1] = (S)si;
     }
@@ -1166,6 +1166,207 @@ int gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64
                                (const S *)x, (S *)slabs, slab_stride, dev_row_off, dev_col_off, transposed);
         JH_CHECK_HIP(hipGetLastError());
     }
+    return JH_OK;
+}
+
+
+// ---- the dense children of a SPARSE / mixed operator as a LIST (late round 5) ---------------------------------------------------------
+// k_gemv_rows_mixed / k_gemv_cols_mixed above launch a grid over EVERY (block row, block column) pair and let the pairs that hold no dense
+// child return at once: fine for a 3 x 4 operator, ruinous for a block-diagonal one -- 256 x 256 blocks with 511 dense children launched
+// 8.4 M workgroups of which 65 k had work (adjoint 1.86 ms = 0.29 TB/s), 64 children of 1024^2 ran their forward on 64 workgroups.
+// jh_blockop_create now lists the dense children of each direction and pass (jh_dense_item: matrix, shape, where its input block and
+// its slab piece start), and these two kernels walk the list:
+//  * rows (y = B x): 256 lanes = RL row lanes x CG column groups (RL = 2^rl_shift chosen at launch: the rows of the children, shrunk
+//    while the launch would leave the chip empty); a lane owns NS rows and walks every CG-th column, sixteen loads in flight; the CG partial
+//    rows meet in LDS and are added in group order.  CG = 1 (knob dense_list_split = 0, or children of >= 256 * NS rows that fill the
+//    chip anyway): columns in order, product rounded then added -- the sequential loop's bits, k_gemv_rows_mixed's; CG > 1:
+//    deterministic, tolerance parity (like the column chunks of k_gemv_rows and like any BLAS).
+//  * cols (y = B' x): a group of SUB lanes (a wave, or half / a quarter of one for short columns) owns CPW = 4 columns at once -- the input
+//    pack is loaded once for the four, four matrix loads in flight per step --, fp64 partials, xor-butterfly inside the group.
+template <typename S, int E, int NS>
+__global__ __launch_bounds__(256) void k_gemv_rows_list(const jh_dense_item *__restrict__ items, unsigned chunks, int rl_shift, const S *__restrict__ in,
+                                                        S *__restrict__ slabs)
+{
+    typedef typename vec_of<S, NS>::type V;
+    __shared__ V sm[256];
+    const unsigned item = blockIdx.x / chunks, chunk = blockIdx.x - item * chunks;
+    const jh_dense_item it = items[item];
+    const int RL = 1 << rl_shift, CG = 256 >> rl_shift;
+    const int rowlane = threadIdx.x & (RL - 1), cg = threadIdx.x >> rl_shift;
+    const int64_t ns = it.nr * E, nc = it.nc;
+    if ((int64_t)chunk * RL * NS >= ns) return;                               // (the whole workgroup: this child has fewer row chunks than the longest)
+    const int64_t s = ((int64_t)chunk * RL + rowlane) * NS;
+    const bool live = s < ns;
+    const S *x = in + it.x_off * E;
+    V acc = (V)(S)0;
+    if (live) {
+        const S *col = (const S *)it.A + s + (int64_t)cg * ns;
+        const int64_t step = (int64_t)CG * ns;
+        int64_t c = cg;
+        for (; c + 15 * (int64_t)CG < nc; c += 16 * (int64_t)CG) {
+            V a[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) a[k] = ldg_nt(reinterpret_cast<const V *>(col + (int64_t)k * step));
+            col += 16 * step;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int64_t ck = c + (int64_t)k * CG;
+                if constexpr (E == 1) {
+                    acc = acc + a[k] * (V)x[ck];
+                } else {
+                    const S xr = x[2 * ck], xi = x[2 * ck + 1];
+                    V p;
+#pragma unroll
+                    for (int e = 0; e < NS; e += 2) {
+                        p[e] = a[k][e] * xr - a[k][e + 1] * xi;
+                        p[e + 1] = a[k][e] * xi + a[k][e + 1] * xr;
+                    }
+                    acc = acc + p;
+                }
+            }
+        }
+        for (; c < nc; c += CG, col += step) {
+            V a = ldg_nt(reinterpret_cast<const V *>(col));
+            if constexpr (E == 1) {
+                acc = acc + a * (V)x[c];
+            } else {
+                const S xr = x[2 * c], xi = x[2 * c + 1];
+                V p;
+#pragma unroll
+                for (int e = 0; e < NS; e += 2) {
+                    p[e] = a[e] * xr - a[e + 1] * xi;
+                    p[e + 1] = a[e] * xi + a[e + 1] * xr;
+                }
+                acc = acc + p;
+            }
+        }
+    }
+    S *out = slabs + it.out_off * E;
+    if (CG == 1) {
+        if (live) stg(reinterpret_cast<V *>(out + s), acc);
+        return;
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (cg == 0 && live) {
+        V t = sm[rowlane];
+        for (int g = 1; g < CG; g++) t = t + sm[g * RL + rowlane];
+        stg(reinterpret_cast<V *>(out + s), t);
+    }
+}
+
+template <typename S, int E, int NS, int CPW>
+__global__ __launch_bounds__(256) void k_gemv_cols_list(const jh_dense_item *__restrict__ items, unsigned chunks, int sub_shift, const S *__restrict__ in,
+                                                        S *__restrict__ slabs)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const unsigned item = blockIdx.x / chunks, chunk = blockIdx.x - item * chunks;
+    const jh_dense_item it = items[item];
+    const int SUB = 1 << sub_shift, G = 256 >> sub_shift;
+    const int g = threadIdx.x >> sub_shift, l = threadIdx.x & (SUB - 1);
+    const int64_t ns = it.nr * E, nc = it.nc;
+    const int64_t c0 = ((int64_t)chunk * G + g) * CPW;
+    if (c0 >= nc) return;
+    const S *x = in + it.x_off * E;
+    const S *colp[CPW];
+#pragma unroll
+    for (int k = 0; k < CPW; k++) colp[k] = (const S *)it.A + (c0 + k < nc ? c0 + k : nc - 1) * ns;   // (columns past the end re-read the last one: not stored)
+    double sr[CPW], si[CPW];
+#pragma unroll
+    for (int k = 0; k < CPW; k++) { sr[k] = 0.0; si[k] = 0.0; }
+    constexpr int UNR = CPW == 1 ? 4 : (CPW == 2 ? 2 : 1);
+#pragma unroll UNR
+    for (int64_t s = (int64_t)l * NS; s < ns; s += (int64_t)SUB * NS) {
+        const V xv = ldg(reinterpret_cast<const V *>(x + s));
+        V a[CPW];
+#pragma unroll
+        for (int k = 0; k < CPW; k++) a[k] = ldg_nt(reinterpret_cast<const V *>(colp[k] + s));
+#pragma unroll
+        for (int k = 0; k < CPW; k++) {
+            if constexpr (E == 1) {
+#pragma unroll
+                for (int e = 0; e < NS; e++) {
+                    if constexpr (NS == 1) sr[k] += (double)a[k] * (double)xv;
+                    else sr[k] += (double)a[k][e] * (double)xv[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NS; e += 2) {
+                    const double ar = a[k][e], ai = -(double)a[k][e + 1], xr = xv[e], xi = xv[e + 1];
+                    sr[k] += ar * xr - ai * xi;
+                    si[k] += ar * xi + ai * xr;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CPW; k++)
+        for (int off = SUB >> 1; off > 0; off >>= 1) {
+            sr[k] += __shfl_xor(sr[k], off, 64);
+            if (E == 2) si[k] += __shfl_xor(si[k], off, 64);
+        }
+    if (l == 0) {
+        S *o = slabs + (it.out_off + c0) * E;
+#pragma unroll
+        for (int k = 0; k < CPW; k++)
+            if (c0 + k < nc) {
+                o[(int64_t)k * E] = (S)sr[k];
+                if (E == 2) o[(int64_t)k * E + 1] = (S)si[k];
+            }
+    }
+}
+
+static inline int pow2_shift_at_least(int64_t v)                             // smallest k with 2^k >= v
+{
+    int k = 0;
+    while (((int64_t)1 << k) < v) k++;
+    return k;
+}
+
+// pass 0: y = B x for every item (max_out = the longest output, B's rows); pass 1: y = B' x (max_out = the most columns, max_in = the longest column)
+template <typename S, int E>
+int gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64_t max_in, int pass, void *slabs, const void *x, bool aligned)
+{
+    if (nitems == 0 || max_out == 0) return JH_OK;
+    jh_context &c = jh_ctx();
+    hipStream_t st = c.stream;
+    constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
+    const bool vec_ok = aligned && ((((uintptr_t)x) | ((uintptr_t)slabs)) & 15u) == 0;
+    const int NS = vec_ok ? NSV : E;
+    if (pass == 0) {
+        const int64_t lanes = (max_out * E + NS - 1) / NS;                   // row lanes of the longest child
+        int sh = 8;                                                          // RL = 256: every lane a row lane, columns in order (the sequential loop's bits)
+        if (c.dense_list_split != 0) {
+            sh = pow2_shift_at_least(lanes);
+            if (sh > 8) sh = 8;
+            if (sh < 4) sh = 4;
+            // few workgroups: narrower row sets, more column groups per workgroup and more workgroups per child
+            while (sh > 4 && nitems * ((lanes + ((int64_t)1 << sh) - 1) >> sh) < 4 * (int64_t)c.cu_count) sh--;
+        }
+        const int64_t chunks = (lanes + ((int64_t)1 << sh) - 1) >> sh;
+        JH_REQUIRE(nitems * chunks < ((int64_t)1 << 31), "dense child list: %lld x %lld workgroups exceed the grid", (long long)nitems, (long long)chunks);
+        c.last_dense_rl = (int64_t)1 << sh;
+        if (vec_ok)
+            hipLaunchKernelGGL((k_gemv_rows_list<S, E, NSV>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs);
+        else
+            hipLaunchKernelGGL((k_gemv_rows_list<S, E, E>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs);
+    } else {
+        const int64_t lanes = (max_in * E + NS - 1) / NS;                    // lanes one column keeps busy
+        int sh = pow2_shift_at_least(lanes);
+        if (sh > 6) sh = 6;
+        if (sh < 4) sh = 4;
+        // columns per lane group: four share one load of the input pack -- right for short columns (a group is done after a step or two); long columns
+        // (>= 8 steps of a full wave) run one column per wave like k_gemv_cols_mixed: more waves, the same loads in flight (knob dense_list_cpw: 0 this rule)
+        int cpw = c.dense_list_cpw ? (int)c.dense_list_cpw : (lanes >= 512 ? 1 : (lanes >= 128 ? 2 : 4));   // (adjoint of 16 x 4096^2: 6.66 / 6.69 / 5.97 TB/s with 1 / 2 / 4; 256 x 512^2: 3.69 / 6.44 / 6.17; 256 x 256^2: 2.10 / 3.11 / 3.47)
+        const int64_t per_wg = (int64_t)(256 >> sh) * cpw;                   // columns per workgroup
+        const int64_t chunks = (max_out + per_wg - 1) / per_wg;
+        JH_REQUIRE(nitems * chunks < ((int64_t)1 << 31), "dense child list: %lld x %lld workgroups exceed the grid", (long long)nitems, (long long)chunks);
+#define JH_COLS(NSX, CPWX) hipLaunchKernelGGL((k_gemv_cols_list<S, E, NSX, CPWX>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs)
+        if (vec_ok) { if (cpw == 1) JH_COLS(NSV, 1); else if (cpw == 2) JH_COLS(NSV, 2); else JH_COLS(NSV, 4); }
+        else { if (cpw == 1) JH_COLS(E, 1); else if (cpw == 2) JH_COLS(E, 2); else JH_COLS(E, 4); }
+#undef JH_COLS
+    }
+    JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
 
@@ -1215,6 +1416,18 @@ int jh_launch_gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t n
     case JH_C64: return gemv_mixed_all<double, 2>(blocks, nrow, ncol, rows_max_out, cols_max_out, slabs, slab_stride, x, transposed, aligned, dev_row_off, dev_col_off);
     }
     return jh_fail(JH_ERR_INVALID, "gemv_mixed_all: unknown dtype %d", dtype);
+}
+
+// the dense children of one direction and pass of a sparse / mixed operator from their list (jh_blockop_create builds it)
+int jh_launch_gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64_t max_in, int pass, int dtype, void *slabs, const void *x, bool aligned)
+{
+    switch (dtype) {
+    case JH_F32: return gemv_list<float, 1>(items, nitems, max_out, max_in, pass, slabs, x, aligned);
+    case JH_F64: return gemv_list<double, 1>(items, nitems, max_out, max_in, pass, slabs, x, aligned);
+    case JH_C32: return gemv_list<float, 2>(items, nitems, max_out, max_in, pass, slabs, x, aligned);
+    case JH_C64: return gemv_list<double, 2>(items, nitems, max_out, max_in, pass, slabs, x, aligned);
+    }
+    return jh_fail(JH_ERR_INVALID, "gemv_list: unknown dtype %d", dtype);
 }
 
 extern "C" int jh_gemv(const void *A_device, int64_t nr, int64_t nc, int dtype, jh_bvec *y, const jh_bvec *x, int adjoint)

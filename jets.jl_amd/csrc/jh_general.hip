@@ -110,10 +110,13 @@ __global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int
                                     const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
                                     const S *__restrict__ m, S *__restrict__ d, int fmode, unsigned ntiles,
                                     int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride,
-                                    const S *__restrict__ dense_prod = nullptr, int64_t prod_stride = 0)
+                                    const S *__restrict__ dense_prod = nullptr, const int *__restrict__ steps = nullptr, int step_stride = 0)
 {
     // dense_prod != null (dense_mixed_fwd): block (i, j) of kind DENSE contributes the product A_ij m_j a batched GEMV launch has
-    // left, rounded like the reference's dtmp (1024), at the row's elements of slab j
+    // left, rounded like the reference's dtmp (1024), at the place its table entry names (jh_dev_block_prod_off: a compact scratch vector,
+    // one piece per dense child -- late round 5; rounds 3-4 kept ncol slabs of the whole range vector's length)
+    // steps != null (late round 5; never with the split walk or in f! mode): the row's non-zero blocks from its step list (jh_blockop_create) -- a
+    // block-diagonal operator of 1024 x 1024 blocks walks one table entry per row instead of 1024
     int64_t i, tile;                                                       // block row, tile
     general_line_tile((unsigned)nrow, ntiles, i, tile);
     ntiles &= 0x0fffffffu;
@@ -133,13 +136,16 @@ __global__ void k_block_fwd_general(const jh_dev_block *__restrict__ blocks, int
         bool touched = split;
         if (ncol > 1 && !split) { acc = eload<S, E>(d, row_off[i] + e); }   // `_d .+=` accumulates into d as found (1024 / 1001)
         else { acc.re = 0; acc.im = 0; }
-        for (int64_t j = j_lo; j < j_hi; j++) {                            // (1020)
+        const int *sidx = steps ? steps + i * step_stride + 1 : nullptr;
+        if (sidx) j_hi = sidx[-1];
+        for (int64_t jj = j_lo; jj < j_hi; jj++) {                         // (1020)
+            const int64_t j = sidx ? (int64_t)sidx[jj] : jj;
             const jh_dev_block b = blocks[i + j * nrow];
             if (b.kind == JH_OP_ZERO && !fmode) continue;                  // (1022); JetBlock_f! has no such test
             elem<S, E> p;
             p.re = 0; p.im = 0;                                            // a zero block's `d .= 0` (942): no load -- its column may be shorter than this row
             if (b.kind == JH_OP_DENSE) {
-                p = eload<S, E>(dense_prod, j * prod_stride + row_off[i] + e);   // mul!(dtmp, op, _m), computed by the column's batch
+                p = eload<S, E>(dense_prod, jh_dev_block_prod_off(b, false) + e);   // mul!(dtmp, op, _m), computed by the batched launch
             } else if (b.kind != JH_OP_ZERO) {
                 elem<S, E> x = eload<S, E>(m, col_off[j] + e);
                 p = apply_block<S, E>(b, x, e, false, fmode != 0);         // mul!(dtmp, op, _m)
@@ -157,10 +163,10 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
                                     const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
                                     S *__restrict__ m, const S *__restrict__ d, unsigned ntiles,
                                     int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride,
-                                    const S *__restrict__ dense_prod = nullptr, int64_t prod_stride = 0)
+                                    const S *__restrict__ dense_prod = nullptr, const int *__restrict__ steps = nullptr, int step_stride = 0)
 {
-    // dense_prod != null (dense_mixed_adj): block (i, j) of kind DENSE contributes A_ij' d_i, left by the column's batch, rounded
-    // like the reference's mtmp (1049), at column j's elements of slab i
+    // dense_prod != null (dense_mixed_adj): block (i, j) of kind DENSE contributes A_ij' d_i, left by the batched launch, rounded
+    // like the reference's mtmp (1049), at the place its table entry names; steps: the column's non-zero blocks (see the forward)
     int64_t j, tile;                                                       // block column, tile
     general_line_tile((unsigned)ncol, ntiles, j, tile);
     ntiles &= 0x0fffffffu;
@@ -176,12 +182,15 @@ __global__ void k_block_adj_general(const jh_dev_block *__restrict__ blocks, int
         elem<S, E> acc;
         acc.re = 0; acc.im = 0;                                            // `_m .= 0` when nrow > 1 (1042)
         bool touched = (nrow > 1);
-        for (int64_t i = i_lo; i < i_hi; i++) {                            // (1045)
+        const int *sidx = steps ? steps + j * step_stride + 1 : nullptr;
+        if (sidx) i_hi = sidx[-1];
+        for (int64_t ii = i_lo; ii < i_hi; ii++) {                         // (1045)
+            const int64_t i = sidx ? (int64_t)sidx[ii] : ii;
             const jh_dev_block b = blocks[i + j * nrow];
             if (b.kind == JH_OP_ZERO) continue;                            // (1047)
             elem<S, E> p;
             if (b.kind == JH_OP_DENSE) {
-                p = eload<S, E>(dense_prod, i * prod_stride + col_off[j] + e);   // mul!(mtmp, op', _d), computed by the column's batch
+                p = eload<S, E>(dense_prod, jh_dev_block_prod_off(b, true) + e);   // mul!(mtmp, op', _d), computed by the batched launch
             } else {
                 elem<S, E> x = eload<S, E>(d, row_off[i] + e);
                 p = apply_block<S, E>(b, x, e, true);                      // mul!(mtmp, op', _d)
@@ -1148,16 +1157,23 @@ int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool tran
     jh_context &c = jh_ctx();
     const size_t es = jh_dtype_size(op->dtype);
     const int64_t nrange = op->row_off[(size_t)op->nrow], ndomain = op->col_off[(size_t)op->ncol];
-    const int64_t per16 = (int64_t)(16 / es) > 0 ? (int64_t)(16 / es) : 1;
-    const int64_t line_len = transposed ? ndomain : nrange;                     // a slab is laid out like the OUTPUT vector
-    const int64_t stride = (line_len + per16 - 1) / per16 * per16;              // elements; slabs stay 16-byte aligned
-    const int64_t nslabs = transposed ? op->nrow : op->ncol;
-    void *slabs = nullptr;
-    JH_TRY(jh_ensure_scratch((size_t)nslabs * (size_t)stride * es + 16, &slabs));
+    const int dir = transposed ? 1 : 0;
+    void *slabs = nullptr;                                                      // the products of the dense children: one compact piece each (op->prod_off)
+    JH_TRY(jh_ensure_scratch((size_t)op->prod_total[dir] * es + 16, &slabs));
     // which kernel a dense child needs in this direction: block = B (un-adjointed) or B' (adjointed), the operator's adjoint flips it;
     // B x is the sequential rows kernel, B' x the wave-reduction cols kernel
     int64_t launches = 0, ndense = 0, rows_max_out = 0, cols_max_out = 0, wgs = 0;
     double max_bytes = 0.0;
+    if (c.dense_list) {
+        // late round 5: the children from their LISTS (built at create: nothing here walks the M x K block table on the host -- a block-diagonal operator of
+        // 1024 x 1024 blocks spent 1 ms per call in the scan below --, no workgroup for a block pair without a dense child, few children spread over the chip)
+        for (int pass = 0; pass < 2; pass++)
+            if (op->n_items[dir][pass] > 0) {
+                JH_TRY(jh_launch_gemv_list(op->dev_items[dir][pass], op->n_items[dir][pass], op->items_max_out[dir][pass], op->items_max_in[dir][pass], pass, op->dtype,
+                                           slabs, in, op->dense_mixed_aligned));
+                launches++;
+            }
+    } else
     for (int64_t j = 0; j < op->ncol; j++)
         for (int64_t i = 0; i < op->nrow; i++) {
             const jh_block_desc &b = op->blocks[(size_t)(i + j * op->nrow)];
@@ -1178,13 +1194,13 @@ int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool tran
                     const jh_block_desc &b = op->blocks[(size_t)(i + j * op->nrow)];
                     if (b.kind != JH_OP_DENSE) continue;
                     const bool adj = (b.adjoint != 0) != transposed;             // (op')' = op
-                    char *o = (char *)slabs + (transposed ? ((size_t)i * (size_t)stride + (size_t)op->col_off[(size_t)j]) : ((size_t)j * (size_t)stride + (size_t)op->row_off[(size_t)i])) * es;
+                    char *o = (char *)slabs + (size_t)op->prod_off[dir][(size_t)(i + j * op->nrow)] * es;
                     const char *x = (const char *)in + (size_t)(transposed ? op->row_off[(size_t)i] : op->col_off[(size_t)j]) * es;
                     JH_TRY(jh_launch_gemv(b.coeff, b.nr, b.nc, op->dtype, o, x, adj ? 1 : 0));
                     launches++;
                 }
         } else {
-            JH_TRY(jh_launch_gemv_mixed_all(op->dev_blocks, op->nrow, op->ncol, rows_max_out, cols_max_out, op->dtype, slabs, stride, in, transposed ? 1 : 0,
+            JH_TRY(jh_launch_gemv_mixed_all(op->dev_blocks, op->nrow, op->ncol, rows_max_out, cols_max_out, op->dtype, slabs, 0, in, transposed ? 1 : 0,
                                             op->dense_mixed_aligned, op->dev_row_off, op->dev_col_off));
             launches += (rows_max_out > 0) + (cols_max_out > 0);
         }
@@ -1202,12 +1218,17 @@ int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool tran
         int64_t want = (maxn + 255) / 256;
         if (want > 4096) want = 4096;
         general_grid(want, nlines, ntiles, grid, general_use_xcd((transposed ? nrange : ndomain) * (int64_t)es));
+        // the lines' non-zero blocks from their step lists when those leave out an eighth of the table entries (never in f! mode: it adds a zero block's +0)
+        const int64_t nsum_all = transposed ? op->nrow : op->ncol;
+        const bool use_list = !fmode && c.general_list != 0 && op->dev_steps[dir][1] && op->list_steps[dir][1] * 8 <= nlines * nsum_all * 7;
+        const int *lsteps = use_list ? op->dev_steps[dir][1] : nullptr;
+        const int lstride = use_list ? (int)op->step_stride[dir][1] : 0;
         if (!transposed)
             hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3(grid, 1), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, op->dev_row_off,
-                               op->dev_col_off, (const S *)in, (S *)out, fmode ? 1 : 0, ntiles, (int64_t)0, (S *)nullptr, (int64_t)0, (const S *)slabs, stride);
+                               op->dev_col_off, (const S *)in, (S *)out, fmode ? 1 : 0, ntiles, (int64_t)0, (S *)nullptr, (int64_t)0, (const S *)slabs, lsteps, lstride);
         else
             hipLaunchKernelGGL((k_block_adj_general<S, E>), dim3(grid, 1), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, op->dev_row_off,
-                               op->dev_col_off, (S *)out, (const S *)in, ntiles, (int64_t)0, (S *)nullptr, (int64_t)0, (const S *)slabs, stride);
+                               op->dev_col_off, (S *)out, (const S *)in, ntiles, (int64_t)0, (S *)nullptr, (int64_t)0, (const S *)slabs, lsteps, lstride);
         JH_CHECK_HIP(hipGetLastError());
         launches++;
     }

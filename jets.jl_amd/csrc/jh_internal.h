@@ -117,6 +117,11 @@ struct jh_context {
     int64_t general_band = 8;          // knob: tiles of every line the general M x K kernels walk before the next group of tiles starts: 8, 16, 32, 64
     int64_t fwd_ctiles = -1;           // knob: tall forward in column bands of this many tiles (-1: the shape's own, 0: none)
     int64_t sum_adj_group = 16;        // knob: terms of a fused JetSum ADJOINT per launch (each keeps its own accumulator): 16 (one row in flight; +1-2 % at 11-16 terms), or 8
+    int64_t small_loop_max_kib = 512;  // knob: operators of small dense children whose matrices together reach this many KiB take the batched route (lists) instead of the one-launch loop
+    int64_t dense_list = 1;            // knob: the dense children of dense_mixed operators from their LIST (k_gemv_*_list, late round 5); 0: the grid over every block pair (k_gemv_*_mixed)
+    int64_t dense_list_split = 1;      // knob: ... 1 the rows pass picks its lane layout (column groups per workgroup: deterministic, tolerance parity), 0 columns in order (the sequential loop's bits)
+    int64_t dense_list_cpw = 0;        // knob: columns per lane group of the list kernel of y = B' x: 0 by column length, 1 / 2 / 4
+    int64_t last_dense_rl = 0;         // read-only: row lanes per workgroup of the latest rows pass of the list kernels (256: columns in order)
     int64_t dense_mixed = 1;           // knob: operators mixing big dense children with other kinds: one batched launch + one combine launch (0: the per-block loop)
     int64_t last_launches = 0;         // read-only: kernel launches of the most recent dense_mixed forward / adjoint
     int64_t dense_fused = 1;           // knob: tall / wide adjoint of many small uniform dense children on the fused kernel (k_gemv_cols_fused, round 4); 0: the three-launch path
@@ -221,6 +226,20 @@ struct jh_dev_block {
     int32_t adjoint;          //  every step's coefficient loads in the general kernels)      real_scale: SCALE, 1 = a REAL scalar (see jh_dev_block_of)
 };
 static_assert(sizeof(jh_dev_block) == 32, "one table entry = one s_load_dwordx8");
+// A DENSE entry has no scalar: its two scalar slots hold where the child's product goes in the scratch vector of dense_mixed_apply (elements; forward in
+// `sre`, adjoint in `sim`, as the bit patterns of two int64) -- one compact piece per dense child and direction (late round 5)
+__host__ __device__ inline int64_t jh_dev_block_prod_off(const jh_dev_block &b, bool transposed)
+{
+    const double v = transposed ? b.sim : b.sre;
+    int64_t o;
+    __builtin_memcpy(&o, &v, sizeof(o));
+    return o;
+}
+inline void jh_dev_block_set_prod_off(jh_dev_block &b, int64_t fwd, int64_t adj)
+{
+    __builtin_memcpy(&b.sre, &fwd, sizeof(fwd));
+    __builtin_memcpy(&b.sim, &adj, sizeof(adj));
+}
 constexpr int JH_STEP_PAD = 12;        // padding entries of a step-list record: three groups of up to four steps in flight (k_general_tile LIST)
 
 // the device form of a block description.  A SCALE block's scalar is Real unless it is flagged JH_SCALAR_COMPLEX or has a non-zero
@@ -242,6 +261,14 @@ inline jh_dev_block jh_dev_block_of(const jh_block_desc &b)
     d.adjoint = b.adjoint;
     return d;
 }
+
+// one dense child of a sparse / mixed operator, as the list kernels of jh_dense.hip see it: B is nr x nc, column-major; the pass computes y = B x
+// (rows pass: x has nc elements, y nr) or y = B' x (cols pass: x has nr, y nc); x_off: where x starts in the operator's input vector, out_off: where
+// y goes in the slabs of dense_mixed_apply (both in elements)
+struct jh_dense_item {
+    const void *A;
+    int64_t nr, nc, x_off, out_off;
+};
 
 struct jh_blockop {
     int ctx = -1;
@@ -277,6 +304,12 @@ struct jh_blockop {
     bool dense_mixed = false;                // DENSE blocks (none adjointed) next to other kinds or of differing shapes, too big for the one-launch loop: one
                                              // batched launch for all dense children + one launch of the general kernels (dense_mixed_apply)
     bool dense_mixed_aligned = false;        // ... every dense matrix, row length and row offset on 16 bytes
+    // the dense children of a dense_mixed operator as lists, [direction: 0 forward, 1 adjoint][pass: 0 y = B x, 1 y = B' x] (jh_dense.hip: k_gemv_*_list)
+    jh_dense_item *dev_items[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int64_t n_items[2][2] = {{0, 0}, {0, 0}}, items_max_out[2][2] = {{0, 0}, {0, 0}}, items_max_in[2][2] = {{0, 0}, {0, 0}};
+    std::vector<int64_t> prod_off[2];        // per block (column-major like `blocks`; DENSE blocks of a dense_mixed operator only, else -1): where its product goes
+    int64_t prod_total[2] = {0, 0};          // elements of the product scratch vector per direction
+    double dense_bytes = 0.0;                // bytes of all DENSE children together
     bool small_loop = false;                 // DENSE blocks (adjointed or not) mixed with elementwise kinds, every matrix small: the whole loop in ONE launch (k_block_loop_small)
     int64_t *dev_dims = nullptr;             // nrow*ncol x {nr, nc} of the described operators (small_loop only)
     bool nonlinear = false;                  // has a SQUARE block (JopNl child)
@@ -413,6 +446,8 @@ int jh_launch_gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64
 int jh_launch_gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64_t rows_max_out, int64_t cols_max_out, int dtype, void *slabs,
                              int64_t slab_stride, const void *x, int transposed, bool aligned, const int64_t *dev_row_off,
                              const int64_t *dev_col_off);           // jh_dense.hip: every dense child of a mixed operator in one or two launches
+int jh_launch_gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64_t max_in, int pass, int dtype, void *slabs, const void *x,
+                        bool aligned);                                  // jh_dense.hip: the dense children of one direction and pass of a dense_mixed operator, from their list
 int jh_ensure_scratch(size_t bytes, void **out);
 extern "C" int jh_comm_exists(int *yes);  // jh_comm.hip (internal): the current context's communicator: 0 none, 1 of jh_comm_init_rank, 2 member of a single-process team
 extern "C" int jh_comm_destroy(void);   // jh_comm.hip; jh_shutdown tears the communicator down first   // growable device scratch (block-loop temporaries)

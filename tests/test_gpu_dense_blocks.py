@@ -275,24 +275,28 @@ def test_big_dense_children_in_mixed_company(Jets, oracle, dt, shape):
     want_d = oracle.block_df(ops, [b.copy() for b in hd], hm)
     want_m = oracle.block_df_adj(ops, [b.copy() for b in hmt], want_d)
     got = {}
-    for knob in (1, 0):                                                # the new path, then the per-block loop it replaces
-        J.tune(dense_mixed=knob)
+    for knob in (1, 0, 2):                                             # the batched path with columns in order, the per-block loop it replaces, the batched path
+        J.tune(dense_mixed=1 if knob else 0, dense_list_split=1 if knob == 2 else 0)   # with its own lane layout (late round 5: column groups per workgroup)
         try:
             m = J.from_numpy(np.concatenate(hm), J.domain(A)) if K > 1 else J.from_numpy(hm[0])
             d = J.from_numpy(np.concatenate(hd), J.range(A))            # dirty
             J.mul_(d, A, m)
-            if knob and shape != "few_big":
+            if knob:
                 assert 1 <= J.tune_get("last_launches") <= (3 if shape == "with_adjointed" else 2), "forward: one batched launch (two with adjointed children) + the combine"
             mt = J.from_numpy(np.concatenate(hmt), J.domain(A)) if K > 1 else J.from_numpy(hmt[0])   # dirty
             J.mul_(mt, A.H, d)
-            if knob and shape != "few_big":
+            if knob:
                 assert 1 <= J.tune_get("last_launches") <= (3 if shape == "with_adjointed" else 2), "adjoint: one batched launch (two with adjointed children) + the combine"
             got[knob] = (d.to_numpy(), mt.to_numpy().ravel(order="F"))
         finally:
-            J.tune(dense_mixed=1)
-    if shape == "few_big":                                             # the per-child kernel splits a big child's columns: tolerance, and the loop's bits
-        assert _err(got[1][0], np.concatenate(want_d)) < _tol(dt)
-        assert_bits_equal(got[1][0], got[0][0], f"{shape}: forward vs the per-block loop")
+            J.tune(dense_mixed=1, dense_list_split=1)
+    # the default lane layout of the list kernels (column groups that meet in LDS): deterministic, tolerance parity -- like the column chunks of the per-child
+    # kernel and like any BLAS (the reference's dense child is LinearAlgebra's gemv)
+    assert _err(got[2][0], np.concatenate(want_d)) < _tol(dt), f"{shape}: forward, automatic lane layout"
+    assert _err(got[2][1], np.concatenate(want_m)) < _tol(dt), f"{shape}: adjoint, automatic lane layout"
+    if shape == "few_big":                                             # the per-child kernel of the loop splits a big child's columns: tolerance; since late
+        assert _err(got[1][0], np.concatenate(want_d)) < _tol(dt)      # round 5 the batched route takes such children from its lists too (columns in order here)
+        assert _err(got[0][0], np.concatenate(want_d)) < _tol(dt)
     elif shape == "with_adjointed":                                    # an adjointed child's forward is B' m: an fp64 wave reduction here and in the loop
         assert _err(got[1][0], np.concatenate(want_d)) < _tol(dt)
         assert _err(got[0][0], np.concatenate(want_d)) < _tol(dt)

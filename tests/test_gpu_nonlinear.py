@@ -486,8 +486,8 @@ def test_f_mode_of_big_dense_children_in_mixed_company_takes_two_launches(Jets, 
     hd = _split(u01(oracle, dt, 44, 0, sum(len_r)), len_r)
     ref = oracle.block_f(ops, [x.copy() for x in hd], hmo)
     got = {}
-    for knob in (1, 0):
-        J.tune(dense_mixed=knob)
+    for knob in (1, 0, 2):                                         # batched route with columns in order / the per-block loop / batched, automatic lane layout
+        J.tune(dense_mixed=1 if knob else 0, dense_list_split=1 if knob == 2 else 0)
         try:
             d = J.rand(J.range(F), seed=44, stream=0)              # dirty: `_d .+=` accumulates into d as found (1001)
             J.mul_(d, F, mo)
@@ -495,9 +495,12 @@ def test_f_mode_of_big_dense_children_in_mixed_company_takes_two_launches(Jets, 
                 assert 1 <= J.tune_get("last_launches") <= 2, "one batched launch for the dense children + the combine"
             got[knob] = d.to_numpy()
         finally:
-            J.tune(dense_mixed=1)
+            J.tune(dense_mixed=1, dense_list_split=1)
     assert_bits_equal(got[1], np.concatenate(ref), "f! with big dense children: batched route vs the oracle")
     assert_bits_equal(got[1], got[0], "f! with big dense children: batched route vs the per-block loop")
+    # late round 5: by default the list kernel splits a child's columns over lane groups of a workgroup: deterministic, tolerance parity (as any BLAS gemv)
+    want = np.concatenate(ref)
+    assert np.linalg.norm(got[2] - want) / np.linalg.norm(want) < (1e-5 if np.dtype(dt).itemsize <= 8 and np.dtype(dt) != np.float64 else 1e-12)
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.complex128])

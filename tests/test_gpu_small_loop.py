@@ -10,6 +10,15 @@ from .helpers import DTYPES, assert_bits_equal, u01, rel_err
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _the_loop_at_any_size(Jets):
+    """Late round 5: operators whose dense children TOGETHER reach 512 KiB take the batched list route instead (knob small_loop_max_kib; tolerance parity
+    there -- tests/test_gpu_dense_lists.py); these tests are about the one-launch loop and its bits, so they pin it."""
+    Jets.tune(small_loop_max_kib=1 << 40)
+    yield
+    Jets.tune(small_loop_max_kib=512)
+
+
 def _reference_3x4(J, oracle, dt, n, seed=5):
     """[A11 J12 A13 A14; A21 Z22 J23 A24'; J31 A32 A33 Z34] with dense A (n x n), diagonal J (the Jacobian of JopBar), zero Z."""
     layout = [["dense", "diag", "dense", "dense"], ["dense", "zero", "diag", "dense_adj"], ["diag", "dense", "dense", "zero"]]

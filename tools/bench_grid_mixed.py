@@ -57,11 +57,14 @@ print(f"ALGO k_general_tile<.*false|k_block_fwd_general {(ndiag + K + 2 * M) * b
 print(f"ALGO k_general_tile<.*true|k_block_adj_general {(ndiag + M + K) * b}", flush=True)
 if os.environ.get("GENERAL_TILE_U"):
     J.tune(fwd_unroll=int(os.environ["GENERAL_TILE_U"]))
+lists = [int(v) for v in os.environ.get("GENERAL_LIST", "").split(",") if v]         # step-list route per iteration (0 plain, 2 four-line lists, 3 per-line lists), cycled
 knob = os.environ.get("GENERAL_TILE")
 bands = [int(v) for v in os.environ.get("GENERAL_BAND", "").split(",") if v]      # tiles per band of the general kernels (8 / 16 / 32 / 64), cycled with the tile knob
 bits = {}
 for it, gt in enumerate([int(v) for v in knob.split(",")] if knob else [1, 0, 1, 0]):
     J.tune(general_tile=gt)
+    if lists:
+        J.tune(general_list=lists[it % len(lists)])
     if edge <= 128:                                               # every route's bits against the first route's (forward from a dirty d, adjoint)
         J.copyto_(d, J.rand(J.range(A), seed=9, stream=0))
         J.mul_(d, A, m)
@@ -73,5 +76,5 @@ for it, gt in enumerate([int(v) for v in knob.split(",")] if knob else [1, 0, 1,
         J.tune(general_band=bands[it % len(bands)])
     tf = timed(lambda: J.mul_(d, A, m))
     ta = timed(lambda: J.mul_(mt, A.H, d))
-    print(f"{M} x {K} mixed grid of {edge}^3 ({ndiag} diagonals of {M * K} blocks) general_tile={gt}{' band ' + str(bands[it % len(bands)]) if bands else ''}: forward {tf:7.3f} ms {(ndiag + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | "
+    print(f"{M} x {K} mixed grid of {edge}^3 ({ndiag} diagonals of {M * K} blocks) general_tile={gt}{' list ' + str(lists[it % len(lists)]) if lists else ''}{' band ' + str(bands[it % len(bands)]) if bands else ''}: forward {tf:7.3f} ms {(ndiag + K + 2 * M) * b / tf / 1e6:7.1f} GB/s | "
           f"adjoint {ta:7.3f} ms {(ndiag + M + K) * b / ta / 1e6:7.1f} GB/s", flush=True)
