@@ -272,7 +272,8 @@ template <typename S, int E, int NS>
 __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                         const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
                                         const S *__restrict__ m, S *__restrict__ d, int fmode, unsigned ntiles,
-                                        int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride)
+                                        int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride,
+                                        const int *__restrict__ steps = nullptr, int step_stride = 0)
 {
     typedef typename vec_of<S, NS>::type V;
     int64_t i, tile;                                                       // block row, tile
@@ -286,6 +287,11 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
         j_hi = j_lo + q_per_part < ncol ? j_lo + q_per_part : ncol;
         d = slabs + (int64_t)blockIdx.y * slab_stride;
     }
+    // steps != null (late round 5; never with the split walk or in f! mode): walk the row's step list -- its non-zero blocks, ascending -- instead of
+    // every table entry (a ragged block-diagonal grid of 64 x 64 blocks ran at 1.4 TB/s on its 63 zero blocks per row)
+    const int *sidx = steps ? steps + i * step_stride + 1 : nullptr;
+    if (sidx) j_hi = sidx[-1];
+#define JH_COL(jj) (sidx ? (int64_t)sidx[jj] : (int64_t)(jj))
     const int64_t ns = (row_off[i + 1] - row_off[i]) * E;                 // scalars in this block row
     for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < ns; s += (int64_t)ntiles * 256 * NS) {
         V acc = (V)(S)0;
@@ -297,7 +303,7 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
         int64_t noff[GENERAL_Q];
 #pragma unroll
         for (int q = 0; q < GENERAL_Q; q++)
-            if (j_lo + q < j_hi) { nb[q] = blocks[i + (j_lo + q) * nrow]; noff[q] = col_off[j_lo + q]; }
+            if (j_lo + q < j_hi) { const int64_t jc = JH_COL(j_lo + q); nb[q] = blocks[i + jc * nrow]; noff[q] = col_off[jc]; }
         for (int64_t j0 = j_lo; j0 < j_hi; j0 += GENERAL_Q) {              // (1020), GENERAL_Q columns' loads in flight
             jh_dev_block b[GENERAL_Q];
             int64_t off[GENERAL_Q];
@@ -308,7 +314,7 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
                 b[q] = nb[q];
                 off[q] = noff[q];
                 const int64_t jn = j0 + GENERAL_Q + q;
-                if (jn < j_hi) { nb[q] = blocks[i + jn * nrow]; noff[q] = col_off[jn]; }
+                if (jn < j_hi) { const int64_t jc = JH_COL(jn); nb[q] = blocks[i + jc * nrow]; noff[q] = col_off[jc]; }
             }
 #pragma unroll
             for (int q = 0; q < GENERAL_Q; q++) {
@@ -339,11 +345,14 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
     }
 }
 
+#undef JH_COL
+
 template <typename S, int E, int NS>
 __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks, int64_t nrow, int64_t ncol,
                                         const int64_t *__restrict__ row_off, const int64_t *__restrict__ col_off,
                                         S *__restrict__ m, const S *__restrict__ d, unsigned ntiles,
-                                        int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride, int nt_out)
+                                        int64_t q_per_part, S *__restrict__ slabs, int64_t slab_stride, int nt_out,
+                                        const int *__restrict__ steps = nullptr, int step_stride = 0)
 {
     typedef typename vec_of<S, NS>::type V;
     int64_t j, tile;                                                       // block column, tile
@@ -356,6 +365,9 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
         i_hi = i_lo + q_per_part < nrow ? i_lo + q_per_part : nrow;
         m = slabs + (int64_t)blockIdx.y * slab_stride;
     }
+    const int *sidx = steps ? steps + j * step_stride + 1 : nullptr;       // the column's non-zero blocks (see the forward)
+    if (sidx) i_hi = sidx[-1];
+#define JH_ROW(ii) (sidx ? (int64_t)sidx[ii] : (int64_t)(ii))
     const int64_t ns = (col_off[j + 1] - col_off[j]) * E;
     for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < ns; s += (int64_t)ntiles * 256 * NS) {
         V acc = (V)(S)0;
@@ -364,7 +376,7 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
         int64_t noff[GENERAL_Q];
 #pragma unroll
         for (int q = 0; q < GENERAL_Q; q++)
-            if (i_lo + q < i_hi) { nb[q] = blocks[(i_lo + q) + j * nrow]; noff[q] = row_off[i_lo + q]; }
+            if (i_lo + q < i_hi) { const int64_t ir = JH_ROW(i_lo + q); nb[q] = blocks[ir + j * nrow]; noff[q] = row_off[ir]; }
         for (int64_t i0 = i_lo; i0 < i_hi; i0 += GENERAL_Q) {              // (1045), GENERAL_Q rows' loads in flight
             jh_dev_block b[GENERAL_Q];
             int64_t off[GENERAL_Q];
@@ -375,7 +387,7 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
                 b[q] = nb[q];
                 off[q] = noff[q];
                 const int64_t in = i0 + GENERAL_Q + q;
-                if (in < i_hi) { nb[q] = blocks[in + j * nrow]; noff[q] = row_off[in]; }
+                if (in < i_hi) { const int64_t ir = JH_ROW(in); nb[q] = blocks[ir + j * nrow]; noff[q] = row_off[ir]; }
             }
 #pragma unroll
             for (int q = 0; q < GENERAL_Q; q++) {
@@ -405,6 +417,8 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
         }
     }
 }
+
+#undef JH_ROW
 
 // ---- M x K grids whose blocks are ALL plain diagonals (>= 2 x 2, one block length, everything 16-byte aligned) --------------
 // The general kernels above decide per block what to do (kind switch, zero-block skip); those branches make the compiler wait for
@@ -929,6 +943,13 @@ int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
     // split walk over the block columns (general_parts)
     const int64_t out_scalars = op->row_off[(size_t)op->nrow] * E;
     int64_t parts = (op->nrow <= 65535) ? general_parts((int64_t)grid, op->ncol, out_scalars * (int64_t)sizeof(S)) : 1;
+    // late round 5: a SPARSE grid walks each row's step list (its non-zero blocks) instead of every table entry -- then there is nothing to split either
+    // (unless the lists themselves are long and the launch small: then the split walk's parallelism over the block columns is what the shape needs)
+    const bool use_list = !fmode && c.general_list != 0 && op->dev_steps[0][1] && op->list_steps[0][1] * 8 <= op->nrow * op->ncol * 7 &&
+                          !(parts > 1 && op->list_steps[0][1] >= 32 * op->nrow);
+    const int *lsteps = use_list ? op->dev_steps[0][1] : nullptr;
+    const int lstride = use_list ? (int)op->step_stride[0][1] : 0;
+    if (use_list) parts = 1;
     int64_t per = 0;
     void *slabs = nullptr;
     if (parts > 1) {
@@ -953,11 +974,11 @@ int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
     if (vec)
         hipLaunchKernelGGL((k_block_fwd_general_vec<S, E, NS>), dim3(grid, (unsigned)parts), dim3(256), 0, c.stream,
                            op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode, ntiles,
-                           per, (S *)slabs, out_scalars);
+                           per, (S *)slabs, out_scalars, lsteps, lstride);
     else
         hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3(grid, (unsigned)parts), dim3(256), 0, c.stream,
                            op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (const S *)m, (S *)d, fmode, ntiles,
-                           per, (S *)slabs, out_scalars);
+                           per, (S *)slabs, out_scalars, (const S *)nullptr, lsteps, lstride);
     JH_CHECK_HIP(hipGetLastError());
     if (parts > 1)      // JetBlock_f! touches every row (1001); the linear loop leaves a row of zero blocks as found (1022)
         return launch_fold_general<S>(slabs, out_scalars, parts, d, op->dev_row_off, E, op->nrow, maxn * E, fmode ? nullptr : op->dev_row_touched, 1);
@@ -981,6 +1002,11 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
     // split walk over the block rows (general_parts); nrow >= 4 there, so every column is zeroed first (1042): all lines touched
     const int64_t out_scalars = op->col_off[(size_t)op->ncol] * E;
     int64_t parts = (op->ncol <= 65535) ? general_parts((int64_t)grid, op->nrow, out_scalars * (int64_t)sizeof(S)) : 1;
+    const bool use_list = c.general_list != 0 && op->dev_steps[1][1] && op->list_steps[1][1] * 8 <= op->nrow * op->ncol * 7 &&
+                          !(parts > 1 && op->list_steps[1][1] >= 32 * op->ncol);                                           // (see general_fwd)
+    const int *lsteps = use_list ? op->dev_steps[1][1] : nullptr;
+    const int lstride = use_list ? (int)op->step_stride[1][1] : 0;
+    if (use_list) parts = 1;
     int64_t per = 0;
     void *slabs = nullptr;
     if (parts > 1) {
@@ -1006,11 +1032,11 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
     if (vec)
         hipLaunchKernelGGL((k_block_adj_general_vec<S, E, NS>), dim3(grid, (unsigned)parts), dim3(256), 0, c.stream,
                            op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d, ntiles,
-                           per, (S *)slabs, out_scalars, (parts == 1 && c.nt && out_scalars * (int64_t)sizeof(S) >= ((int64_t)64 << 20)) ? 1 : 0);
+                           per, (S *)slabs, out_scalars, (parts == 1 && c.nt && out_scalars * (int64_t)sizeof(S) >= ((int64_t)64 << 20)) ? 1 : 0, lsteps, lstride);
     else
         hipLaunchKernelGGL((k_block_adj_general<S, E>), dim3(grid, (unsigned)parts), dim3(256), 0, c.stream,
                            op->dev_blocks, op->nrow, op->ncol, op->dev_row_off, op->dev_col_off, (S *)m, (const S *)d, ntiles,
-                           per, (S *)slabs, out_scalars);
+                           per, (S *)slabs, out_scalars, (const S *)nullptr, lsteps, lstride);
     JH_CHECK_HIP(hipGetLastError());
     if (parts > 1) return launch_fold_general<S>(slabs, out_scalars, parts, m, op->dev_col_off, E, op->ncol, maxn * E, nullptr, 0);
     return JH_OK;

@@ -134,3 +134,41 @@ def test_a_big_sparse_grid_measures_its_walk_over_its_first_calls_and_keeps_its_
     finally:
         J.tune(general_list=1)
     J.close(A)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("aligned", [True, False], ids=["packs", "odd-lengths"])
+@pytest.mark.parametrize("M", [6, 21, 40])
+def test_ragged_sparse_grids_walk_step_lists_on_the_one_line_kernels(Jets, oracle, dt, aligned, M):
+    """Block-diagonal / block-banded grids whose blocks differ in length run on the one-line general kernels (16-byte packs, or element by element when a length
+    or offset is odd); they too walk each line's step list when the grid is sparse -- the same terms in the same order, the oracle's bits; a line without any
+    block keeps d as found (1022) / is zeroed in the adjoint (1042)."""
+    J = Jets
+    rng = np.random.default_rng(50 + M)
+    per16 = 16 // np.dtype(dt).itemsize
+    lens = [int(rng.choice([3, 8, 20, 65])) * (per16 if aligned else 1) + (0 if aligned else int(rng.integers(0, 2))) for _ in range(M)]
+    names = ["diag", "diag_adj", "identity", "scale"]
+    kinds = [["zero"] * M for _ in range(M)]
+    for i in range(M):
+        for j in range(M):
+            if lens[i] == lens[j] and (i == j or abs(i - j) == 3 or rng.random() < 0.05) and i != M - 1 and j != 1:   # row M-1 and column 1 hold no block
+                kinds[i][j] = names[rng.integers(len(names))]
+    A, ops = _mixed_ops(J, oracle, dt, kinds, lens, lens)
+    hm = [u01(oracle, dt, 61, j, lens[j]) for j in range(M)]
+    hd = [u01(oracle, dt, 62, i, lens[i]) for i in range(M)]
+    hmt = [u01(oracle, dt, 63, j, lens[j]) for j in range(M)]
+    want_d = oracle.block_df(ops, [b.copy() for b in hd], hm)
+    want_m = oracle.block_df_adj(ops, [b.copy() for b in hmt], want_d)
+    try:
+        for route in (1, 0):
+            J.tune(general_list=route, adj_split=0)
+            d = J.from_numpy(np.concatenate(hd), J.range(A))
+            J.mul_(d, A, J.from_numpy(np.concatenate(hm), J.domain(A)))
+            assert_bits_equal(d.to_numpy(), np.concatenate(want_d), f"ragged {M} x {M} forward, general_list={route}")
+            mt = J.from_numpy(np.concatenate(hmt), J.domain(A))
+            J.mul_(mt, A.H, d)
+            assert_bits_equal(mt.to_numpy(), np.concatenate(want_m), f"ragged {M} x {M} adjoint, general_list={route}")
+    finally:
+        J.tune(general_list=1, adj_split=-1)
+    assert_bits_equal(d.to_numpy()[-lens[-1]:], hd[-1], "the row without blocks keeps d as found")
+    J.close(A)

@@ -18,6 +18,7 @@ patterns = sys.argv[4:] or ["diag", "bidiag", "arrow", "band5", "rand10", "rand2
 J.init(0)
 n = edge ** 3
 spc = J.JetSpace("float32", edge, edge, edge)
+RAGGED = os.environ.get("RAGGED", "0") == "1"      # block i has n - 4096 * (i % 3) elements: such grids run on the one-line general kernels (square grids only)
 
 
 def kinds_of(pat):
@@ -60,12 +61,24 @@ routes = [int(v) for v in knob.split(",")] if knob else [3, 2, 0, 1, 3, 2, 0, 1]
 for pat in patterns:
     kinds = kinds_of(pat)
     ndiag = int((kinds == "d").sum())
+    if RAGGED:
+        assert M == K
+        lens = [n - 4096 * (i % 3) for i in range(M)]
+        spcs = [J.JetSpace("float32", v) for v in lens]
+        kinds[np.array(lens)[:, None] != np.array(lens)[None, :]] = "z"      # an elementwise block is square
+        ndiag = int((kinds == "d").sum())
     coeff = J.rand(J.JetBSpace([spc] * max(ndiag, 1)), seed=1, stream=0)
     rows, k = [], 0
     for i in range(M):
         row = []
         for j in range(K):
             kd = kinds[i, j]
+            if RAGGED:
+                if kd == "d":
+                    row.append(J.JopDiagonal(J.rand(spcs[i], seed=1, stream=k))); k += 1
+                else:
+                    row.append(J.JopZeroBlock(spcs[j], spcs[i]))
+                continue
             if kd == "d":
                 row.append(J.JopDiagonal(coeff.arrays[k])); k += 1
             elif kd == "z":
