@@ -46,6 +46,8 @@ def timed(fn, reps=20, warm=5):
 
 
 b = nd * N * N * 4 + 3 * M * N * 4
+# algorithmic bytes per launch of the children's kernels alone, for tools/prof_any.sh: the matrices, the input vector, the products
+print(f"ALGO k_gemv_rows_list|k_gemv_cols_list|k_gemv_rows_mixed|k_gemv_cols_mixed {nd * N * N * 4 + M * N * 4 + nd * N * 4}", flush=True)
 for dl in [int(v) for v in os.environ.get("DENSE_LIST", "1,0,1,0").split(",")]:
   J.tune(dense_list=dl)
   tf = timed(lambda: J.mul_(d, A, m))

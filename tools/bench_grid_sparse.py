@@ -97,7 +97,9 @@ for pat in patterns:
     b = n * 4
     fwd_bytes = (ndiag + cols_t + 2 * rows_t) * b
     adj_bytes = (ndiag + rows_t + K) * b                                   # the adjoint of a grid writes every domain block (1042)
-    print(f"ALGO {pat} fwd {fwd_bytes} adj {adj_bytes}", flush=True)
+    # algorithmic bytes per launch for tools/prof_any.sh (regex over the kernel's template name; the LIST instantiations end in `..., R, true>`)
+    print(f"ALGO k_general_tile<.*,.false,.[0-9],.(true|false)>|k_block_fwd_general {fwd_bytes}")
+    print(f"ALGO k_general_tile<.*,.true,.[0-9],.(true|false)>|k_block_adj_general {adj_bytes}", flush=True)
     bits = {}
     for gl in routes:
         try:
