@@ -360,10 +360,29 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
                     it.nc = pass == 0 ? in_len : out_len;
                     it.x_off = dir ? op->row_off[(size_t)i] : op->col_off[(size_t)j];
                     it.out_off = op->prod_off[dir][(size_t)(i + j * nrow)];
+                    it.line_off = dir ? op->col_off[(size_t)j] : op->row_off[(size_t)i];
                     items[dir][pass].push_back(it);
                     if (out_len > op->items_max_out[dir][pass]) op->items_max_out[dir][pass] = out_len;
                     if (in_len > op->items_max_in[dir][pass]) op->items_max_in[dir][pass] = in_len;
                 }
+            // direct mode: every line of this direction with exactly one non-zero block, a dense child (forward: lines without blocks allowed -- they stay as
+            // found, 1022; adjoint of a grid: none -- a column without blocks must be zeroed, 1042, which is the combine launch's work)
+            {
+                const int64_t nlines = dir ? ncol : nrow, nsum = dir ? nrow : ncol;
+                bool direct = true;
+                for (int64_t l = 0; l < nlines && direct; l++) {
+                    int nz = 0, dense = 0;
+                    for (int64_t q = 0; q < nsum; q++) {
+                        const jh_block_desc &b = op->blocks[(size_t)(dir ? q + l * nrow : l + q * nrow)];
+                        if (b.kind != JH_OP_ZERO) nz++;
+                        if (b.kind == JH_OP_DENSE) dense++;
+                    }
+                    const int64_t len = dir ? op->col_len[(size_t)l] : op->row_len[(size_t)l];
+                    if (nz > 1 || nz != dense) direct = false;
+                    if (nz == 0 && dir == 1 && nrow > 1 && len > 0) direct = false;
+                }
+                op->dense_direct[dir] = direct;
+            }
             for (int pass = 0; pass < 2; pass++) {
                 op->n_items[dir][pass] = (int64_t)items[dir][pass].size();
                 if (items[dir][pass].empty()) continue;

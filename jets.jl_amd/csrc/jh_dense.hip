@@ -1185,7 +1185,7 @@ int gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64
 //    pack is loaded once for the four, four matrix loads in flight per step --, fp64 partials, xor-butterfly inside the group.
 template <typename S, int E, int NS>
 __global__ __launch_bounds__(256) void k_gemv_rows_list(const jh_dense_item *__restrict__ items, unsigned chunks, int rl_shift, const S *__restrict__ in,
-                                                        S *__restrict__ slabs)
+                                                        S *__restrict__ slabs, S *__restrict__ direct_out, int add_found)
 {
     typedef typename vec_of<S, NS>::type V;
     __shared__ V sm[256];
@@ -1241,9 +1241,14 @@ __global__ __launch_bounds__(256) void k_gemv_rows_list(const jh_dense_item *__r
             }
         }
     }
-    S *out = slabs + it.out_off * E;
+    // direct_out (the operator's output vector): every output line has this ONE block -- the product goes where the combine launch would have put it,
+    // rounded first like dtmp, then added to d as found (1024) when the operator has more than one block column
+    S *out = direct_out ? direct_out + it.line_off * E : slabs + it.out_off * E;
     if (CG == 1) {
-        if (live) stg(reinterpret_cast<V *>(out + s), acc);
+        if (live) {
+            if (add_found) acc = ldg(reinterpret_cast<const V *>(out + s)) + acc;
+            stg(reinterpret_cast<V *>(out + s), acc);
+        }
         return;
     }
     sm[threadIdx.x] = acc;
@@ -1251,13 +1256,14 @@ __global__ __launch_bounds__(256) void k_gemv_rows_list(const jh_dense_item *__r
     if (cg == 0 && live) {
         V t = sm[rowlane];
         for (int g = 1; g < CG; g++) t = t + sm[g * RL + rowlane];
+        if (add_found) t = ldg(reinterpret_cast<const V *>(out + s)) + t;
         stg(reinterpret_cast<V *>(out + s), t);
     }
 }
 
 template <typename S, int E, int NS, int CPW>
 __global__ __launch_bounds__(256) void k_gemv_cols_list(const jh_dense_item *__restrict__ items, unsigned chunks, int sub_shift, const S *__restrict__ in,
-                                                        S *__restrict__ slabs)
+                                                        S *__restrict__ slabs, S *__restrict__ direct_out, int add_found)
 {
     typedef typename vec_of<S, NS>::type V;
     const unsigned item = blockIdx.x / chunks, chunk = blockIdx.x - item * chunks;
@@ -1306,12 +1312,14 @@ __global__ __launch_bounds__(256) void k_gemv_cols_list(const jh_dense_item *__r
             if (E == 2) si[k] += __shfl_xor(si[k], off, 64);
         }
     if (l == 0) {
-        S *o = slabs + (it.out_off + c0) * E;
+        S *o = direct_out ? direct_out + (it.line_off + c0) * E : slabs + (it.out_off + c0) * E;
 #pragma unroll
         for (int k = 0; k < CPW; k++)
             if (c0 + k < nc) {
-                o[(int64_t)k * E] = (S)sr[k];
-                if (E == 2) o[(int64_t)k * E + 1] = (S)si[k];
+                S vr = (S)sr[k], vi = (S)si[k];                                  // rounded like dtmp / mtmp, then (direct mode of a forward) added to d as found
+                if (add_found) { vr = o[(int64_t)k * E] + vr; if (E == 2) vi = o[(int64_t)k * E + 1] + vi; }
+                o[(int64_t)k * E] = vr;
+                if (E == 2) o[(int64_t)k * E + 1] = vi;
             }
     }
 }
@@ -1325,13 +1333,14 @@ static inline int pow2_shift_at_least(int64_t v)                             // 
 
 // pass 0: y = B x for every item (max_out = the longest output, B's rows); pass 1: y = B' x (max_out = the most columns, max_in = the longest column)
 template <typename S, int E>
-int gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64_t max_in, int pass, void *slabs, const void *x, bool aligned)
+int gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64_t max_in, int pass, void *slabs, const void *x, bool aligned, void *direct_out,
+              int add_found)
 {
     if (nitems == 0 || max_out == 0) return JH_OK;
     jh_context &c = jh_ctx();
     hipStream_t st = c.stream;
     constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
-    const bool vec_ok = aligned && ((((uintptr_t)x) | ((uintptr_t)slabs)) & 15u) == 0;
+    const bool vec_ok = aligned && ((((uintptr_t)x) | ((uintptr_t)slabs) | ((uintptr_t)direct_out)) & 15u) == 0;
     const int NS = vec_ok ? NSV : E;
     if (pass == 0) {
         const int64_t lanes = (max_out * E + NS - 1) / NS;                   // row lanes of the longest child
@@ -1347,9 +1356,9 @@ int gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64
         JH_REQUIRE(nitems * chunks < ((int64_t)1 << 31), "dense child list: %lld x %lld workgroups exceed the grid", (long long)nitems, (long long)chunks);
         c.last_dense_rl = (int64_t)1 << sh;
         if (vec_ok)
-            hipLaunchKernelGGL((k_gemv_rows_list<S, E, NSV>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs);
+            hipLaunchKernelGGL((k_gemv_rows_list<S, E, NSV>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs, (S *)direct_out, add_found);
         else
-            hipLaunchKernelGGL((k_gemv_rows_list<S, E, E>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs);
+            hipLaunchKernelGGL((k_gemv_rows_list<S, E, E>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs, (S *)direct_out, add_found);
     } else {
         const int64_t lanes = (max_in * E + NS - 1) / NS;                    // lanes one column keeps busy
         int sh = pow2_shift_at_least(lanes);
@@ -1361,7 +1370,7 @@ int gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64
         const int64_t per_wg = (int64_t)(256 >> sh) * cpw;                   // columns per workgroup
         const int64_t chunks = (max_out + per_wg - 1) / per_wg;
         JH_REQUIRE(nitems * chunks < ((int64_t)1 << 31), "dense child list: %lld x %lld workgroups exceed the grid", (long long)nitems, (long long)chunks);
-#define JH_COLS(NSX, CPWX) hipLaunchKernelGGL((k_gemv_cols_list<S, E, NSX, CPWX>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs)
+#define JH_COLS(NSX, CPWX) hipLaunchKernelGGL((k_gemv_cols_list<S, E, NSX, CPWX>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs, (S *)direct_out, add_found)
         if (vec_ok) { if (cpw == 1) JH_COLS(NSV, 1); else if (cpw == 2) JH_COLS(NSV, 2); else JH_COLS(NSV, 4); }
         else { if (cpw == 1) JH_COLS(E, 1); else if (cpw == 2) JH_COLS(E, 2); else JH_COLS(E, 4); }
 #undef JH_COLS
@@ -1419,13 +1428,14 @@ int jh_launch_gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t n
 }
 
 // the dense children of one direction and pass of a sparse / mixed operator from their list (jh_blockop_create builds it)
-int jh_launch_gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64_t max_in, int pass, int dtype, void *slabs, const void *x, bool aligned)
+int jh_launch_gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64_t max_in, int pass, int dtype, void *slabs, const void *x, bool aligned,
+                        void *direct_out, int add_found)
 {
     switch (dtype) {
-    case JH_F32: return gemv_list<float, 1>(items, nitems, max_out, max_in, pass, slabs, x, aligned);
-    case JH_F64: return gemv_list<double, 1>(items, nitems, max_out, max_in, pass, slabs, x, aligned);
-    case JH_C32: return gemv_list<float, 2>(items, nitems, max_out, max_in, pass, slabs, x, aligned);
-    case JH_C64: return gemv_list<double, 2>(items, nitems, max_out, max_in, pass, slabs, x, aligned);
+    case JH_F32: return gemv_list<float, 1>(items, nitems, max_out, max_in, pass, slabs, x, aligned, direct_out, add_found);
+    case JH_F64: return gemv_list<double, 1>(items, nitems, max_out, max_in, pass, slabs, x, aligned, direct_out, add_found);
+    case JH_C32: return gemv_list<float, 2>(items, nitems, max_out, max_in, pass, slabs, x, aligned, direct_out, add_found);
+    case JH_C64: return gemv_list<double, 2>(items, nitems, max_out, max_in, pass, slabs, x, aligned, direct_out, add_found);
     }
     return jh_fail(JH_ERR_INVALID, "gemv_list: unknown dtype %d", dtype);
 }

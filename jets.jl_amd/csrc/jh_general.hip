@@ -1184,6 +1184,22 @@ int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool tran
     const size_t es = jh_dtype_size(op->dtype);
     const int64_t nrange = op->row_off[(size_t)op->nrow], ndomain = op->col_off[(size_t)op->ncol];
     const int dir = transposed ? 1 : 0;
+    // late round 5, direct mode: when every output line holds ONE block, a dense child (a block-diagonal operator), the children's launch writes the output
+    // vector itself -- the product rounded like dtmp / mtmp, then (forward of an operator with several block columns) added to d as found (1024): what the
+    // combine launch would have computed, in one launch, without scratch.  Knob dense_direct (1; 0: always through the scratch vector and the combine)
+    if (c.dense_list && c.dense_direct && op->dense_direct[dir] && !fmode) {
+        int64_t launches = 0;
+        const int add_found = (!transposed && op->ncol > 1) ? 1 : 0;
+        for (int pass = 0; pass < 2; pass++)
+            if (op->n_items[dir][pass] > 0) {
+                JH_TRY(jh_launch_gemv_list(op->dev_items[dir][pass], op->n_items[dir][pass], op->items_max_out[dir][pass], op->items_max_in[dir][pass], pass, op->dtype,
+                                           nullptr, in, op->dense_mixed_aligned, out, add_found));
+                launches++;
+            }
+        c.last_adj_parts = 1;
+        c.last_launches = launches;
+        return JH_OK;
+    }
     void *slabs = nullptr;                                                      // the products of the dense children: one compact piece each (op->prod_off)
     JH_TRY(jh_ensure_scratch((size_t)op->prod_total[dir] * es + 16, &slabs));
     // which kernel a dense child needs in this direction: block = B (un-adjointed) or B' (adjointed), the operator's adjoint flips it;

@@ -120,6 +120,7 @@ struct jh_context {
     int64_t small_loop_max_kib = 512;  // knob: operators of small dense children whose matrices together reach this many KiB take the batched route (lists) instead of the one-launch loop
     int64_t dense_list = 1;            // knob: the dense children of dense_mixed operators from their LIST (k_gemv_*_list, late round 5); 0: the grid over every block pair (k_gemv_*_mixed)
     int64_t dense_list_split = 1;      // knob: ... 1 the rows pass picks its lane layout (column groups per workgroup: deterministic, tolerance parity), 0 columns in order (the sequential loop's bits)
+    int64_t dense_direct = 1;          // knob: block-diagonal operators of dense children in ONE launch (the list kernels write the output vector); 0: scratch + combine
     int64_t dense_list_cpw = 0;        // knob: columns per lane group of the list kernel of y = B' x: 0 by column length, 1 / 2 / 4
     int64_t last_dense_rl = 0;         // read-only: row lanes per workgroup of the latest rows pass of the list kernels (256: columns in order)
     int64_t dense_mixed = 1;           // knob: operators mixing big dense children with other kinds: one batched launch + one combine launch (0: the per-block loop)
@@ -268,6 +269,7 @@ inline jh_dev_block jh_dev_block_of(const jh_block_desc &b)
 struct jh_dense_item {
     const void *A;
     int64_t nr, nc, x_off, out_off;
+    int64_t line_off;                  // where the child's output LINE starts in the operator's output vector (elements): the direct mode writes there
 };
 
 struct jh_blockop {
@@ -307,6 +309,9 @@ struct jh_blockop {
     // the dense children of a dense_mixed operator as lists, [direction: 0 forward, 1 adjoint][pass: 0 y = B x, 1 y = B' x] (jh_dense.hip: k_gemv_*_list)
     jh_dense_item *dev_items[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int64_t n_items[2][2] = {{0, 0}, {0, 0}}, items_max_out[2][2] = {{0, 0}, {0, 0}}, items_max_in[2][2] = {{0, 0}, {0, 0}};
+    bool dense_direct[2] = {false, false};   // every output line of this direction holds exactly ONE non-zero block, a dense child (block-diagonal operators and
+                                             // their permutations; forward: or none; adjoint: every column has one): the list kernels write the output vector
+                                             // themselves -- one launch, no scratch, no combine (the same product, rounded, then the same addition to d as found)
     std::vector<int64_t> prod_off[2];        // per block (column-major like `blocks`; DENSE blocks of a dense_mixed operator only, else -1): where its product goes
     int64_t prod_total[2] = {0, 0};          // elements of the product scratch vector per direction
     double dense_bytes = 0.0;                // bytes of all DENSE children together
@@ -447,7 +452,7 @@ int jh_launch_gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t n
                              int64_t slab_stride, const void *x, int transposed, bool aligned, const int64_t *dev_row_off,
                              const int64_t *dev_col_off);           // jh_dense.hip: every dense child of a mixed operator in one or two launches
 int jh_launch_gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64_t max_in, int pass, int dtype, void *slabs, const void *x,
-                        bool aligned);                                  // jh_dense.hip: the dense children of one direction and pass of a dense_mixed operator, from their list
+                        bool aligned, void *direct_out = nullptr, int add_found = 0);                                  // jh_dense.hip: the dense children of one direction and pass of a dense_mixed operator, from their list
 int jh_ensure_scratch(size_t bytes, void **out);
 extern "C" int jh_comm_exists(int *yes);  // jh_comm.hip (internal): the current context's communicator: 0 none, 1 of jh_comm_init_rank, 2 member of a single-process team
 extern "C" int jh_comm_destroy(void);   // jh_comm.hip; jh_shutdown tears the communicator down first   // growable device scratch (block-loop temporaries)

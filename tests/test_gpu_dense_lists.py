@@ -81,14 +81,16 @@ def test_block_sparse_operators_of_dense_children_on_the_list_route(Jets, oracle
     want_m = np.concatenate(oracle.block_df_adj(ops, [b.copy() for b in hmt], [want_d[i * n:(i + 1) * n] for i in range(M)]))
     got = {}
     try:
-        for route in ("lists", "lists-in-order", "grid", "loop"):
+        for route in ("lists", "lists-combine", "lists-in-order", "grid", "loop"):    # lists-combine: never the one-launch direct mode of block-diagonal operators
             J.tune(small_loop_max_kib=0, dense_list=0 if route == "grid" else 1, dense_list_split=0 if route == "lists-in-order" else 1,
-                   dense_mixed=0 if route == "loop" else 1, small_loop=0 if route == "loop" else 1)
+                   dense_mixed=0 if route == "loop" else 1, small_loop=0 if route == "loop" else 1, dense_direct=0 if route == "lists-combine" else 1)
             m = J.from_numpy(np.concatenate(hm), J.domain(A))
             d = J.from_numpy(np.concatenate(hd), J.range(A))
             J.mul_(d, A, m)
             if route != "loop":
                 assert 1 <= J.tune_get("last_launches") <= 3                             # the children's pass(es) + the combine, whatever M is
+            if route == "lists" and name == "blockdiag":
+                assert J.tune_get("last_launches") == 1                                  # every line holds one dense child: the children's launch writes d itself
             mt = J.from_numpy(np.concatenate(hmt), J.domain(A))
             J.mul_(mt, A.H, J.from_numpy(want_d, J.range(A)))
             got[route] = (d.to_numpy(), mt.to_numpy())
@@ -101,9 +103,11 @@ def test_block_sparse_operators_of_dense_children_on_the_list_route(Jets, oracle
         assert_bits_equal(d.to_numpy(), got["lists"][0], "second run of the list route")
         if name != "mixed":                                                              # only un-adjointed children: columns in order = the oracle's loop
             assert_bits_equal(got["lists-in-order"][0], want_d, f"{name}: forward with columns in order vs the oracle")
+        assert_bits_equal(got["lists"][0], got["lists-combine"][0], "direct mode: the forward's bits with and without the combine launch")
+        assert_bits_equal(got["lists"][1], got["lists-combine"][1], "direct mode: the adjoint's bits with and without the combine launch")
         # rows / columns without any block stay as the reference leaves them: d as found (1022), m zeroed (1042)
     finally:
-        J.tune(small_loop_max_kib=512, dense_list=1, dense_list_split=1, dense_mixed=1, small_loop=1)
+        J.tune(small_loop_max_kib=512, dense_list=1, dense_list_split=1, dense_mixed=1, small_loop=1, dense_direct=1)
     J.close(A)
 
 
@@ -138,14 +142,14 @@ def test_ragged_children_and_lines_without_blocks(Jets, oracle):
 
 
 def test_many_small_children_leave_the_one_launch_loop(Jets):
-    """256 children of 64 x 64 on a block diagonal (4 MiB together): the batched list route by default (2 launches), the loop when pinned."""
+    """256 children of 64 x 64 on a block diagonal (4 MiB together): the batched list route by default (ONE launch: every line holds one dense child), the loop when pinned."""
     J = Jets
     n, M = 64, 256
     spc, mat = J.JetSpace(np.float32, n), J.JetSpace(np.float32, n, n)
     A = J.blockop([[J.JopDense(J.rand(mat, seed=9, stream=i)) if i == j else J.JopZeroBlock(spc, spc) for j in range(M)] for i in range(M)])
     m = J.rand(J.domain(A), seed=10, stream=0)
     d = J.mul_(J.zeros(J.range(A)), A, m)
-    assert J.tune_get("last_launches") == 2
+    assert J.tune_get("last_launches") == 1
     try:
         J.tune(small_loop_max_kib=1 << 40)
         d2 = J.mul_(J.zeros(J.range(A)), A, m)

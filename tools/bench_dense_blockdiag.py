@@ -11,6 +11,8 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 band = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 J.init(0)
+if os.environ.get("DENSE_DIRECT"):
+    J.tune(dense_direct=int(os.environ["DENSE_DIRECT"]))
 if os.environ.get("DENSE_LIST_CPW"):
     J.tune(dense_list_cpw=int(os.environ["DENSE_LIST_CPW"]))
 if os.environ.get("SMALL_LOOP_MAX_KIB"):

@@ -57,9 +57,9 @@ for case in range(seed0, seed0 + ncases):
     want_m = oracle.block_df_adj(ops, [b.copy() for b in hmt], want_d)
     wd, wm = np.concatenate(want_d), np.concatenate(want_m)
     tag = f"case {case}: {np.dtype(dt).name} {M}x{K} rows={row_len[:6]} cols={col_len[:6]} fill={fill} dense={nd} adjointed={nadj}"
-    for route in ("lists", "lists-in-order", "grid", "loop"):
+    for route in ("lists", "lists-combine", "lists-in-order", "grid", "loop"):    # lists-combine: never the one-launch direct mode of block-diagonal operators
         J.tune(small_loop_max_kib=0, dense_list=0 if route == "grid" else 1, dense_list_split=0 if route == "lists-in-order" else 1,
-               dense_mixed=0 if route == "loop" else 1, small_loop=0 if route == "loop" else 1)
+               dense_mixed=0 if route == "loop" else 1, small_loop=0 if route == "loop" else 1, dense_direct=0 if route == "lists-combine" else 1)
         d = J.from_numpy(np.concatenate(hd), J.range(A))
         J.mul_(d, A, J.from_numpy(np.concatenate(hm), J.domain(A)))
         mt = J.from_numpy(np.concatenate(hmt), J.domain(A))
@@ -69,7 +69,7 @@ for case in range(seed0, seed0 + ncases):
         if route == "lists-in-order" and nadj == 0:
             assert_bits_equal(d.to_numpy(), wd, "forward with columns in order, " + tag)
             stats["bits"] += 1
-    J.tune(small_loop_max_kib=512, dense_list=1, dense_list_split=1, dense_mixed=1, small_loop=1)
+    J.tune(small_loop_max_kib=512, dense_list=1, dense_list_split=1, dense_mixed=1, small_loop=1, dense_direct=1)
     J.close(A)
     if (case - seed0 + 1) % 100 == 0:
         print(f"{case - seed0 + 1} cases, {time.time() - t0:.0f} s, {stats}", flush=True)
