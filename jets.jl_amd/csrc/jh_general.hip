@@ -708,9 +708,7 @@ bool grid_diag_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr
     const int64_t n = op->row_len[0];
     if (n == 0 || (n * (int64_t)jh_dtype_size(op->dtype)) % 16 != 0) return false;
     if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & 15u) return false;
-    for (const auto &b : op->blocks)
-        if (((uintptr_t)b.coeff) & 15u) return false;
-    return true;
+    return op->coeff_aligned16;
 }
 
 // second stage of the general kernels' split walk: out[line] = (add_found ? out as found : 0) + slab 0 + slab 1 + ... for every
@@ -751,13 +749,8 @@ __global__ __launch_bounds__(256) void k_fold_general(const S *__restrict__ slab
 // every block boundary / coefficient pointer / vector base on a 16-byte boundary?
 bool general_vec_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
 {
-    const int64_t es = (int64_t)jh_dtype_size(op->dtype);
     if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & 15u) return false;
-    for (int64_t v : op->row_len) if ((v * es) % 16) return false;
-    for (int64_t v : op->col_len) if ((v * es) % 16) return false;
-    for (const auto &b : op->blocks)
-        if ((b.kind == JH_OP_DIAG || b.kind == JH_OP_SQUARE) && (((uintptr_t)b.coeff) & 15u)) return false;
-    return true;
+    return op->lens_aligned16 && op->coeff_aligned16;                     // (both known since jh_blockop_create / jh_blockop_point)
 }
 
 // tiles per line and the 1-D grid of the general kernels: ceil(ntiles / 8) * 8 * nlines workgroups of 256 lanes, < 2^24

@@ -319,6 +319,9 @@ struct jh_blockop {
     int64_t *dev_dims = nullptr;             // nrow*ncol x {nr, nc} of the described operators (small_loop only)
     bool nonlinear = false;                  // has a SQUARE block (JopNl child)
     bool pointed = false;                    // jh_blockop_point has been called (SQUARE blocks have their mo)
+    bool coeff_aligned16 = true;             // every coefficient array of a DIAG / SQUARE block starts on a 16-byte boundary (jh_blockop_create; again at jh_blockop_point,
+                                             // which moves the SQUARE blocks' arrays): what the per-call route tests used to find by walking all M x K descriptors
+    bool lens_aligned16 = true;              // every row and column length a multiple of 16 bytes
     bool diag_strided = false;               // coeff[i] = coeff[0] + i*stride bytes
     // hipGraph replay of the per-block loop (operators with DENSE blocks: 2 launches per block), keyed on the vectors' addresses
     struct LoopGraph { const void *out; const void *in; int mode; int seen; uint64_t gen; hipGraphExec_t exec; };

@@ -903,9 +903,7 @@ bool tall_fast_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr
     const int64_t n = op->row_len[0];
     if (n == 0 || (n * (int64_t)es) % 16 != 0) return false;
     if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & 15u) return false;
-    for (const auto &b : op->blocks)
-        if (((uintptr_t)b.coeff) & 15u) return false;
-    return true;
+    return op->coeff_aligned16;
 }
 }  // namespace jhb
 namespace {
@@ -923,9 +921,7 @@ bool tall_mixed_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_pt
     const int64_t n = op->row_len[0];
     if (n == 0 || (n * (int64_t)es) % 16 != 0) return false;
     if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & 15u) return false;
-    for (const auto &b : op->blocks)
-        if ((b.kind == JH_OP_DIAG || b.kind == JH_OP_SQUARE) && (((uintptr_t)b.coeff) & 15u)) return false;
-    return true;
+    return op->coeff_aligned16;
 }
 }  // namespace jhb
 namespace {
