@@ -489,7 +489,8 @@ int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, 
  * vector, the combine launch over each line's step list: block-diagonal / block-banded operators of dense children at any block count; 0: round 3's grid
  * over every block pair), "dense_list_split" (1: the list kernel of y = B x picks its lane layout -- column groups of one workgroup meet in LDS:
  * deterministic, tolerance parity like any BLAS gemv --, 0: columns in order, the sequential loop's bits; counter "last_dense_rl" = row lanes per workgroup of
- * the latest such launch, 256: columns in order), "dense_direct" (1: an operator whose every output line holds ONE block, a dense child -- block-diagonal --, in ONE launch: the list kernels write the
+ * the latest such launch, 256: columns in order), "dense_grid" (read by jh_blockop_create: M x K grids of uniform dense children on the list route -- 0, the default -- or as one tall batch per
+ * block column -- 1, rounds 2-4), "dense_direct" (1: an operator whose every output line holds ONE block, a dense child -- block-diagonal --, in ONE launch: the list kernels write the
  * output vector, same products and additions; 0: scratch vector + combine launch), "dense_list_cpw" (columns per lane group of the list kernel of y = B' x: 0 by column length, 1 / 2 / 4; same contract),
  * "small_loop_max_kib" (operators of SMALL dense children whose matrices together reach this many KiB take
  * the list route instead of the one-launch loop: 512);

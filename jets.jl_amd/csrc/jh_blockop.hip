@@ -195,7 +195,7 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
         if (op->dense_batch_ragged && max_bytes >= (double)(1 << 20) && ((maxnr * (int64_t)es / 16 + 255) / 256) * nrow < 2048) op->dense_batch_ragged = false;
         if (op->dense_batch_ragged) { op->dense_aligned = al; op->dense_max_nr = maxnr; }
     }
-    if (nrow >= 2 && ncol >= 2 && !op->elementwise) {                          // ... or a grid of them: one tall batch per block column
+    if (nrow >= 2 && ncol >= 2 && !op->elementwise && jh_ctx().dense_grid) {   // ... or a grid of them: one tall batch per block column
         op->dense_batch_grid = true;
         op->dense_aligned = true;
         for (size_t k = 0; k < op->blocks.size() && op->dense_batch_grid; k++) {

@@ -965,6 +965,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "small_loop_max_kib")) { JH_REQUIRE(value >= 0, "small_loop_max_kib must be >= 0"); c.small_loop_max_kib = value; }
     else if (!strcmp(name, "dense_list")) { JH_REQUIRE(value >= 0 && value <= 2, "dense_list must be 0 (the grid over every block pair), 1 (the children's lists) or 2 (... also for few big children)"); c.dense_list = value; }
     else if (!strcmp(name, "dense_list_cpw")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "dense_list_cpw must be 0 (by column length), 1, 2 or 4"); c.dense_list_cpw = value; }
+    else if (!strcmp(name, "dense_grid")) { c.dense_grid = value ? 1 : 0; }
     else if (!strcmp(name, "dense_direct")) { c.dense_direct = value ? 1 : 0; }
     else if (!strcmp(name, "dense_list_split")) { JH_REQUIRE(value == 0 || value == 1, "dense_list_split must be 0 (columns in order) or 1 (automatic lane layout)"); c.dense_list_split = value; }
     else if (!strcmp(name, "dense_fused")) { JH_REQUIRE(value == 0 || value == 1, "dense_fused must be 0 or 1"); c.dense_fused = value; }
@@ -1033,6 +1034,7 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "small_loop_max_kib")) *value = c.small_loop_max_kib;
     else if (!strcmp(name, "dense_list_split")) *value = c.dense_list_split;
     else if (!strcmp(name, "dense_direct")) *value = c.dense_direct;
+    else if (!strcmp(name, "dense_grid")) *value = c.dense_grid;
     else if (!strcmp(name, "dense_list_cpw")) *value = c.dense_list_cpw;
     else if (!strcmp(name, "last_dense_rl")) *value = c.last_dense_rl;
     else if (!strcmp(name, "last_general_list")) *value = c.last_general_list;

@@ -11,6 +11,8 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 band = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 J.init(0)
+if os.environ.get("DENSE_GRID"):
+    J.tune(dense_grid=int(os.environ["DENSE_GRID"]))
 if os.environ.get("DENSE_DIRECT"):
     J.tune(dense_direct=int(os.environ["DENSE_DIRECT"]))
 if os.environ.get("DENSE_LIST_CPW"):
@@ -24,7 +26,7 @@ rows = []
 for i in range(M):
     row = []
     for j in range(M):
-        if i == j or (band and i == j + 1):
+        if band == 2 or i == j or (band and i == j + 1):                # BAND = 2: every block dense (a full grid)
             row.append(J.JopDense(J.rand(mat, seed=7, stream=i * M + j))); nd += 1
         else:
             row.append(J.JopZeroBlock(spc, spc))
@@ -56,5 +58,5 @@ for dl in [int(v) for v in os.environ.get("DENSE_LIST", "1,0,1,0").split(",")]:
   lf = J.tune_get("last_launches")
   rl = J.tune_get("last_dense_rl")
   ta = timed(lambda: J.mul_(mt, A.H, d))
-  print(f"dense_list={dl} rl={rl} " +f"{M} x {M} block-{'bidiagonal' if band else 'diagonal'} of {N} x {N} dense Float32 children ({nd} matrices, {b / 2**20:.0f} MiB): forward {tf:7.3f} ms {b / tf / 1e6:7.1f} GB/s "
+  print(f"dense_list={dl} rl={rl} " +f"{M} x {M} {'full grid' if band == 2 else ('block-bidiagonal' if band else 'block-diagonal')} of {N} x {N} dense Float32 children ({nd} matrices, {b / 2**20:.0f} MiB): forward {tf:7.3f} ms {b / tf / 1e6:7.1f} GB/s "
       f"({lf} launches) | adjoint {ta:7.3f} ms {b / ta / 1e6:7.1f} GB/s ({J.tune_get('last_launches')} launches)", flush=True)
