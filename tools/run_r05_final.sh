@@ -1,7 +1,7 @@
 # round 5, final validation of the tree: the whole GPU suite, smoke(), the default bench, and the rocprofv3 kernel trace (+ --stats) of the DEFAULT bench
 # command (the program directly after `--`); summaries -> gpurun_out/ (copied into profiles/ by hand)
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_r05_final.txt 2>&1; echo "pytest rc $?"; tail -3 gpurun_out/pytest_gpu_r05_final.txt
+timeout -k 10 900 python -m pytest tests -m gpu -x -q --timeout 120 > gpurun_out/pytest_gpu_r05_final.txt 2>&1; echo "pytest rc $?"; tail -3 gpurun_out/pytest_gpu_r05_final.txt
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 timeout -k 10 600 python bench.py > gpurun_out/bench_r05_final.json 2> gpurun_out/bench_r05_final.err; echo "bench rc $?"
 python - <<'PY'
