@@ -350,6 +350,17 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
                 if (e == hipSuccess) e = hipMemcpyAsync(op->dev_steps[dir][set], L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice, st);
             }
     }
+    // the non-zero rows of a tall operator whose rows are not all diagonals (jh_tall.hip: launch_tall_fwd_mixed)
+    std::vector<int> rows_nz;
+    if (op->tall && op->elementwise && !op->all_diag && nrow >= 2 && nrow < ((int64_t)1 << 31)) {
+        for (int64_t i = 0; i < nrow; i++)
+            if (op->blocks[(size_t)i].kind != JH_OP_ZERO) rows_nz.push_back((int)i);
+        op->n_rows_nz = (int64_t)rows_nz.size();
+        if (!rows_nz.empty() && op->n_rows_nz < nrow) {
+            if (e == hipSuccess) e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_rows_nz, rows_nz.size() * sizeof(int));
+            if (e == hipSuccess) e = hipMemcpyAsync(op->dev_rows_nz, rows_nz.data(), rows_nz.size() * sizeof(int), hipMemcpyHostToDevice, st);
+        }
+    }
     // the dense children of a dense_mixed operator as lists per direction and pass (jh_dense.hip: k_gemv_rows_list / k_gemv_cols_list)
     std::vector<jh_dense_item> items[2][2];
     if (op->dense_mixed) {
@@ -446,6 +457,7 @@ int jh_blockop_destroy(jh_blockop *op)
     if (op->dev_col_off) (void)hipFree(op->dev_col_off);
     if (op->dev_row_touched) (void)hipFree(op->dev_row_touched);
     if (op->dev_dims) (void)hipFree(op->dev_dims);
+    if (op->dev_rows_nz) (void)hipFree(op->dev_rows_nz);
     for (int dir = 0; dir < 2; dir++)
         for (int set = 0; set < 2; set++)
             if (op->dev_steps[dir][set]) (void)hipFree(op->dev_steps[dir][set]);

@@ -320,6 +320,8 @@ struct jh_blockop {
     int64_t *dev_dims = nullptr;             // nrow*ncol x {nr, nc} of the described operators (small_loop only)
     bool nonlinear = false;                  // has a SQUARE block (JopNl child)
     bool pointed = false;                    // jh_blockop_point has been called (SQUARE blocks have their mo)
+    int *dev_rows_nz = nullptr;              // a tall operator of elementwise rows of several kinds: its non-ZERO rows, ascending (the forward of an operator with many
+    int64_t n_rows_nz = 0;                   // zero rows -- muted shots -- launches workgroups for those only)
     bool coeff_aligned16 = true;             // every coefficient array of a DIAG / SQUARE block starts on a 16-byte boundary (jh_blockop_create; again at jh_blockop_point,
                                              // which moves the SQUARE blocks' arrays): what the per-call route tests used to find by walking all M x K descriptors
     bool lens_aligned16 = true;              // every row and column length a multiple of 16 bytes

@@ -63,11 +63,16 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__res
             sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
             mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
         }
+        // late round 5: a tall operator with MANY zero rows (muted shots) walks the list of its non-zero rows (a_stride < 0: a_base is that list and nrow
+        // its length) -- a workgroup per zero row cost more than the rows that do something: 1024 x 128^3 with one row in eight 0.83 -> see DESIGN 3.6
+        const int *rows = a_stride < 0 ? reinterpret_cast<const int *>(a_base) : nullptr;
         jh_dev_block nxt;                                                                  // the row table one row ahead (scalar loads)
-        if (i0 < i1) nxt = blocks[i0];
-        for (int64_t i = i0; i < i1; i++) {
+        int64_t inext = (i0 < i1) ? (rows ? (int64_t)rows[i0] : i0) : 0;
+        if (i0 < i1) nxt = blocks[inext];
+        for (int64_t ii = i0; ii < i1; ii++) {
             const jh_dev_block blk = nxt;
-            if (i + 1 < i1) nxt = blocks[i + 1];
+            const int64_t i = inext;
+            if (ii + 1 < i1) { inext = rows ? (int64_t)rows[ii + 1] : ii + 1; nxt = blocks[inext]; }
             if (blk.kind == JH_OP_ZERO) continue;                                          // (1022)
             const bool rc = block_reads_coeff(blk, false);
             S *di = d + i * n_scalars;
@@ -936,18 +941,23 @@ int launch_tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int64_t 
     // 4096 x 64^3 5.3 -> 6.3, 16384 x 32^3 5.5 -> 6.4, 64 x 128^3 5.6 -> 6.4, 2048 x 128^3 5.6 -> 6.35, 256 x 256^3 5.8 -> 6.4
     // (profiles/exp_r04_mixed_fwd.txt).  Knobs fwd_group / fwd_ctiles override rows per workgroup / tiles per band (0: sequential sweep).
     constexpr int BLK = 256, U = 1;
+    // the rows the launch covers: all of them, or (late round 5) the operator's non-zero rows when an eighth or more are zero blocks (knob general_list = 0: all)
+    const bool listed = c.general_list != 0 && op->dev_rows_nz && op->n_rows_nz * 8 <= op->nrow * 7;
+    const int64_t nrows = listed ? op->n_rows_nz : op->nrow;
+    if (nrows == 0) return JH_OK;                                          // every row a zero block: d stays as found (1022)
     int64_t G = c.fwd_group > 0 ? c.fwd_group : 2;
-    if (G > op->nrow) G = op->nrow;
+    if (G > nrows) G = nrows;
     const int64_t gx = (n_scalars + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);
-    int64_t gy = (op->nrow + G - 1) / G;
-    while (gx * gy * BLK >= ((int64_t)1 << 32) && G < op->nrow) { G *= 2; gy = (op->nrow + G - 1) / G; }
+    int64_t gy = (nrows + G - 1) / G;
+    while (gx * gy * BLK >= ((int64_t)1 << 32) && G < nrows) { G *= 2; gy = (nrows + G - 1) / G; }
     JH_REQUIRE(gx * gy * BLK < (int64_t)1 << 32, "tall forward: grid of %lld workgroups is too large", (long long)(gx * gy));
     int64_t ctiles = c.fwd_ctiles >= 0 ? c.fwd_ctiles : 32;
     if (ctiles > gx) ctiles = gx;
     c.last_fwd_walk = ctiles ? 2 : 0;
     c.last_fwd_rows_per_wg = G;
     hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, true, BLK, true>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, op->dev_blocks,
-                       op->nrow, (int)G, (const S *)nullptr, (int64_t)0, (const S *)m, (S *)d, n_scalars, (unsigned)gx, (unsigned)gy, 1u, (unsigned)ctiles);
+                       nrows, (int)G, listed ? reinterpret_cast<const S *>(op->dev_rows_nz) : (const S *)nullptr, (int64_t)(listed ? -1 : 0), (const S *)m, (S *)d,
+                       n_scalars, (unsigned)gx, (unsigned)gy, 1u, (unsigned)ctiles);
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }

@@ -172,3 +172,33 @@ def test_ragged_sparse_grids_walk_step_lists_on_the_one_line_kernels(Jets, oracl
         J.tune(general_list=1, adj_split=-1)
     assert_bits_equal(d.to_numpy()[-lens[-1]:], hd[-1], "the row without blocks keeps d as found")
     J.close(A)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,keep", [(9, 2), (64, 8), (37, 5), (5, 7)])
+def test_a_tall_operator_with_many_zero_rows_launches_only_its_other_rows(Jets, oracle, dt, nrow, keep):
+    """Tall operators whose rows are mostly zero blocks (muted shots): the forward covers the listed non-zero rows only (row i of the launch = the list's i-th
+    row); every zero row keeps d as found (src/Jets.jl:1022), the others the oracle's bits; the adjoint and the fused A'A are unchanged."""
+    J = Jets
+    n = 2048 + 64
+    names = ["diag", "diag_adj", "identity", "scale"]
+    kinds = [[names[(i // keep) % 4] if i % keep == 0 else "zero"] for i in range(nrow)]
+    A, ops = _mixed_ops(J, oracle, dt, kinds, [n] * nrow, [n])
+    hm = [u01(oracle, dt, 71, 0, n)]
+    hd = [u01(oracle, dt, 72, i, n) for i in range(nrow)]
+    want_d = oracle.block_df(ops, [b.copy() for b in hd], hm)
+    want_m = oracle.block_df_adj(ops, [np.zeros(n, dt)], want_d)
+    try:
+        for route in (1, 0):
+            J.tune(general_list=route)
+            d = J.from_numpy(np.concatenate(hd), J.range(A))
+            J.mul_(d, A, J.from_numpy(hm[0], J.domain(A)))
+            assert_bits_equal(d.to_numpy(), np.concatenate(want_d), f"tall {nrow} rows, one in {keep} non-zero, forward, general_list={route}")
+            mt = J.mul_(J.rand(J.domain(A), seed=3, stream=3), A.H, d)
+            assert_bits_equal(mt.to_numpy().ravel(order="F"), want_m[0], f"adjoint, general_list={route}")
+    finally:
+        J.tune(general_list=1)
+    for i in range(nrow):
+        if i % keep:
+            assert_bits_equal(d.to_numpy()[i * n:(i + 1) * n], hd[i], "a zero row keeps d as found")
+    J.close(A)
