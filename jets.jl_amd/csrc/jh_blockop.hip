@@ -293,6 +293,12 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
     op->coeff_aligned16 = true;
     for (const auto &b : op->blocks)
         if ((b.kind == JH_OP_DIAG || b.kind == JH_OP_SQUARE) && (((uintptr_t)b.coeff) & 15u)) op->coeff_aligned16 = false;
+    op->coeff_scalar_aligned = true;                                       // (a device array of the element type always is; a caller's raw pointer need not be)
+    {
+        const size_t sa = jh_dtype_complex(dtype) ? jh_dtype_size(dtype) / 2 : jh_dtype_size(dtype);
+        for (const auto &b : op->blocks)
+            if ((b.kind == JH_OP_DIAG || b.kind == JH_OP_SQUARE) && (((uintptr_t)b.coeff) & (sa - 1))) op->coeff_scalar_aligned = false;
+    }
     op->lens_aligned16 = true;
     for (int64_t v : op->row_len) if (((size_t)v * jh_dtype_size(dtype)) % 16) op->lens_aligned16 = false;
     for (int64_t v : op->col_len) if (((size_t)v * jh_dtype_size(dtype)) % 16) op->lens_aligned16 = false;
@@ -540,8 +546,8 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     if (tall_fast_ok(op, d->data, m->data)) {
         return jhb::tall_fwd(op, d->data, m->data);
     }
-    if (tall_mixed_ok(op, d->data, m->data)) {                 // rows of several elementwise kinds: the tall tiling with a per-row kind
-        return jhb::tall_fwd_mixed(op, d->data, m->data);
+    if (tall_mixed_ok(op, d->data, m->data) || tall_unaligned_ok(op, d->data, m->data)) {   // rows of several elementwise kinds: the tall tiling with a per-row kind
+        return jhb::tall_fwd_mixed(op, d->data, m->data);                                   // (and rows that are not whole, aligned packs: the same instantiations)
     }
     if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false);
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
@@ -555,7 +561,7 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
     // (many small blocks take the general kernel's split walk instead)
     if (op->twin && jh_ctx().wide_twin && jh_ctx().adj_split <= 0 &&
         (jh_ctx().wide_twin == 2 || (size_t)op->row_len[0] * jh_dtype_size(op->dtype) >= ((size_t)16 << 20)) &&
-        (tall_fast_ok(op->twin, m->data, d->data) || tall_mixed_ok(op->twin, m->data, d->data))) {
+        (tall_fast_ok(op->twin, m->data, d->data) || tall_mixed_ok(op->twin, m->data, d->data) || tall_unaligned_ok(op->twin, m->data, d->data))) {
         jh_context &c = jh_ctx();
         c.adj_from_found = 1;
         const int st = jh_blockop_mul_adj(op->twin, d, m);
@@ -575,7 +581,7 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
     if (tall_fast_ok(op, d->data, m->data)) {
         return jhb::tall_adj(op, m->data, d->data, 0, false);
     }
-    if (tall_mixed_ok(op, d->data, m->data)) {
+    if (tall_mixed_ok(op, d->data, m->data) || tall_unaligned_ok(op, d->data, m->data)) {
         return jhb::tall_adj(op, m->data, d->data, 0, true);
     }
     if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, m->data, d->data, 1, op->dense_aligned, false);
@@ -586,7 +592,8 @@ int jh_blockop_mul_adj(const jh_blockop *op, jh_bvec *m, const jh_bvec *d)
     if (use_dense_mixed(op)) return dense_mixed(op, m->data, d->data, true);
     if (!op->elementwise) return run_loop_graphed(op, 1, m->data, d->data, [&] { return loop_adj(op, m->data, d->data); });
     // a wide operator's adjoint is its tall twin's forward (same bits: one rounded product per element, zero blocks untouched)
-    if (op->twin && jh_ctx().wide_twin && (tall_fast_ok(op->twin, m->data, d->data) || tall_mixed_ok(op->twin, m->data, d->data)))
+    if (op->twin && jh_ctx().wide_twin &&
+        (tall_fast_ok(op->twin, m->data, d->data) || tall_mixed_ok(op->twin, m->data, d->data) || tall_unaligned_ok(op->twin, m->data, d->data)))
         return jh_blockop_mul(op->twin, m, d);
     return jhb::general_adj(op, m->data, d->data);
     return jh_fail(JH_ERR_INVALID, "jh_blockop_mul_adj: unknown dtype %d", op->dtype);
@@ -620,7 +627,7 @@ int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m)
                "jh_blockop_normal_mul: domain vectors have %lld / %lld elements, operator domain has %lld", (long long)y->length,
                (long long)m->length, (long long)op->col_off[(size_t)op->ncol]);
     JH_REQUIRE(y->data != m->data, "jh_blockop_normal_mul: y must not alias m");
-    if (tall_mixed_ok(op, y->data, m->data)) {                  // rows of several elementwise kinds (a zero row adds nothing: 1022 + 1047)
+    if (tall_mixed_ok(op, y->data, m->data) || (!tall_fast_ok(op, y->data, m->data) && tall_unaligned_ok(op, y->data, m->data))) {   // rows of several elementwise kinds (a zero row adds nothing: 1022 + 1047)
         if (op->nonlinear && !op->pointed)
             return jh_fail(JH_ERR_STATE, "jh_blockop_normal_mul: operator has nonlinear blocks and no linearisation point (jh_blockop_point)");
         return jhb::tall_adj(op, y->data, m->data, 1, true);

@@ -29,6 +29,41 @@ template <bool NT, typename V> __device__ inline void st(V *p, V v)
     else *(gp)p = v;
 }
 
+// UNDER-ALIGNED packs (round 5, session 3).  A block vector is ONE contiguous slab (src/Jets.jl:742-748: block i starts where block i - 1 ends), so with
+// blocks of 101^3 Float32 elements -- odd grid sizes are the rule in the reference's applications -- only every fourth block starts on a 16-byte boundary
+// and a row is not a whole number of packs.  gfx950 executes global_load / global_store_dwordx4 at any dword-aligned address; what must not happen is the
+// COMPILER believing in 16 bytes, so these helpers access the pack through a type aligned like its scalar (same instruction, no alignment assumed).
+// The row's last, partial pack (n % NS != 0) is LOADED from n - NS -- inside the row, overlapping its neighbour -- and STORED scalar by scalar, only the
+// scalars that neighbour does not own (st_pack): every scalar is written once, by one lane, from loads of its own position -- safe in place too.
+template <bool NT, typename S, int NS> __device__ inline typename vec_of<S, NS>::type ldu(const S *p)
+{
+    typedef typename vec_of<S, NS>::type V;
+    typedef V __attribute__((aligned(alignof(S)))) UV;
+    typedef const UV __attribute__((address_space(1))) *gp;
+    if (NT) return __builtin_nontemporal_load((gp)p);
+    return *(gp)p;
+}
+template <bool NT, typename S, int NS> __device__ inline void stu(S *p, typename vec_of<S, NS>::type v)
+{
+    typedef typename vec_of<S, NS>::type V;
+    typedef V __attribute__((aligned(alignof(S)))) UV;
+    typedef UV __attribute__((address_space(1))) *gp;
+    if (NT) __builtin_nontemporal_store(v, (gp)p);
+    else *(gp)p = v;
+}
+// where the pack that nominally starts at scalar s of a row of n >= NS scalars is loaded from
+template <int NS> __device__ inline int64_t pack_start(int64_t s, int64_t n) { return s + NS <= n ? s : n - NS; }
+// store the pack loaded from `sc` = pack_start(s, n): all of it, or (the partial pack) the scalars from s on
+template <bool NT, typename S, int NS> __device__ inline void st_pack(S *row, int64_t s, int64_t sc, typename vec_of<S, NS>::type v)
+{
+    if (sc == s) stu<NT, S, NS>(row + s, v);
+    else {
+#pragma unroll
+        for (int e = 0; e < NS; e++)
+            if (sc + e >= s) st<NT>(row + sc + e, (S)v[e]);
+    }
+}
+
 // a (conj?) * b on a vector of NS scalars holding NS/E elements; every product/sum rounded.
 template <typename S, int E, int NS, typename V> __device__ inline V vmul(V a, V b, bool conj_a)
 {
@@ -115,6 +150,7 @@ namespace jhb {
 // ---- jh_tall.hip
 bool tall_fast_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr);     // tall, all DIAG, equal 16-byte aligned blocks
 bool tall_mixed_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr);    // tall, >= 2 equal rows of any elementwise kind
+bool tall_unaligned_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr);   // the same without the 16-byte conditions (whole-vector forward / adjoint / A'A)
 TallShape pick_adj_shape(int64_t nvec, int64_t nrow, int mode);
 int64_t pick_adj_parts(int64_t gx, int64_t nrow);
 void lazy_release(jh_blockop::LazyTune &t);

@@ -130,6 +130,7 @@ struct jh_context {
     int64_t dense_fwd_wgs = 0;         // knob: workgroups the batched dense forward splits its columns for (0 = 2048)
     int64_t dense_gw = 0;              // knob: children per WAVE of that kernel (0 = from the operator's shape)
     int64_t last_dense_fused = 0;      // read-only: 1 when the most recent batched dense adjoint ran on the fused kernel
+    int64_t tall_unaligned = 1;        // knob: tall operators whose rows are not whole, 16-byte aligned packs (odd block lengths in one slab) on the under-aligned tall kernels (jh_tall.hip: tall_unaligned_ok); 0: the general kernels as before
     int64_t wide_twin = 1;             // knob: wide elementwise operators on their tall twin: 0 never (general kernels), 1 adjoint always + forward from 16 MiB blocks, 2 both always (tests)
     const double *step_coef_dev = nullptr;   // internal, set around the calls of the graph-captured LSQR loop: the one-pass step reads (alpha, beta) from
     const int *step_done_dev = nullptr;      // here instead of its arguments and returns at once when *step_done_dev != 0 (jh_lsqr.hip: lsqr_graph_impl)
@@ -325,6 +326,7 @@ struct jh_blockop {
     bool coeff_aligned16 = true;             // every coefficient array of a DIAG / SQUARE block starts on a 16-byte boundary (jh_blockop_create; again at jh_blockop_point,
                                              // which moves the SQUARE blocks' arrays): what the per-call route tests used to find by walking all M x K descriptors
     bool lens_aligned16 = true;              // every row and column length a multiple of 16 bytes
+    bool coeff_scalar_aligned = true;        // every such array starts on a multiple of its scalar's size (what the under-aligned tall route needs, jh_tall.hip: tall_unaligned_ok)
     bool diag_strided = false;               // coeff[i] = coeff[0] + i*stride bytes
     // hipGraph replay of the per-block loop (operators with DENSE blocks: 2 launches per block), keyed on the vectors' addresses
     struct LoopGraph { const void *out; const void *in; int mode; int seen; uint64_t gen; hipGraphExec_t exec; };

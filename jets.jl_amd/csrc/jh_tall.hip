@@ -55,13 +55,15 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__res
     const bool full = ((int64_t)(tile + 1) * U * BLK * NS) <= n_scalars;
     V mv[U];
     if constexpr (MIXED) {
+        // (round 5, session 3) these instantiations also serve rows that are NOT whole, 16-byte aligned packs -- blocks of 101^3 elements in one slab
+        // (tall_unaligned_ok): every access goes through the under-aligned helpers, the row's last pack is loaded from n - NS and stored by st_pack
         bool ok[U];
         int64_t sk[U];
 #pragma unroll
         for (int k = 0; k < U; k++) {
             ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
-            sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
-            mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
+            sk[k] = ok[k] ? pack_start<NS>(s0 + (int64_t)k * BLK * NS, n_scalars) : 0;
+            mv[k] = ldu<false, S, NS>(m + sk[k]);
         }
         // late round 5: a tall operator with MANY zero rows (muted shots) walks the list of its non-zero rows (a_stride < 0: a_base is that list and nrow
         // its length) -- a workgroup per zero row cost more than the rows that do something: 1024 x 128^3 with one row in eight 0.83 -> see DESIGN 3.6
@@ -78,8 +80,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__res
             S *di = d + i * n_scalars;
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                const V c = rc ? ld<NT>(reinterpret_cast<const V *>((const S *)blk.coeff + sk[k])) : (V)(S)0;
-                if (ok[k]) st<NT>(reinterpret_cast<V *>(di + sk[k]), apply_block_loaded<S, E, NS, V>(blk, mv[k], c, false, false));   // (1026)
+                const V c = rc ? ldu<NT, S, NS>((const S *)blk.coeff + sk[k]) : (V)(S)0;
+                if (ok[k]) st_pack<NT, S, NS>(di, s0 + (int64_t)k * BLK * NS, sk[k], apply_block_loaded<S, E, NS, V>(blk, mv[k], c, false, false));   // (1026)
             }
         }
         return;
@@ -148,16 +150,22 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
     const int64_t s0 = s_begin + ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
     bool ok[U];
     V acc[U], mv[U];
+    // clamp out-of-range vectors onto a valid address so the main loop is branch-free.  MIXED (round 5, session 3): these instantiations also serve rows
+    // that are not whole, 16-byte aligned packs (see k_tall_diag_fwd): under-aligned accesses, the domain's last pack loaded from s_end - NS (st_pack)
+    int64_t sk[U];
 #pragma unroll
     for (int k = 0; k < U; k++) {
         ok[k] = (s0 + (int64_t)k * BLK * NS) < s_end;
-        acc[k] = (accumulate && ok[k]) ? ld<false>(reinterpret_cast<const V *>(out + s0 + (int64_t)k * BLK * NS)) : (V)(S)0;
-        if (MODE == 1) mv[k] = ok[k] ? ld<false>(reinterpret_cast<const V *>(in + s0 + (int64_t)k * BLK * NS)) : (V)(S)0;
+        if constexpr (MIXED) {
+            sk[k] = ok[k] ? pack_start<NS>(s0 + (int64_t)k * BLK * NS, s_end) : s_begin;
+            acc[k] = (accumulate && ok[k]) ? ldu<false, S, NS>(out + sk[k]) : (V)(S)0;
+            if (MODE == 1) mv[k] = ok[k] ? ldu<false, S, NS>(in + sk[k]) : (V)(S)0;
+        } else {
+            sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : s_begin;
+            acc[k] = (accumulate && ok[k]) ? ld<false>(reinterpret_cast<const V *>(out + s0 + (int64_t)k * BLK * NS)) : (V)(S)0;
+            if (MODE == 1) mv[k] = ok[k] ? ld<false>(reinterpret_cast<const V *>(in + s0 + (int64_t)k * BLK * NS)) : (V)(S)0;
+        }
     }
-    // clamp out-of-range vectors onto a valid address so the main loop is branch-free
-    int64_t sk[U];
-#pragma unroll
-    for (int k = 0; k < U; k++) sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : s_begin;
 
     int64_t i = row0;
     if constexpr (MIXED) {                 // rows of any elementwise kind (see k_tall_diag_fwd); zero blocks are skipped (1047)
@@ -179,8 +187,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
                 const bool on = blk[j].kind != JH_OP_ZERO, rc = block_reads_coeff(blk[j], false);
 #pragma unroll
                 for (int k = 0; k < U; k++) {
-                    av[j][k] = rc ? ld<NT>(reinterpret_cast<const V *>((const S *)blk[j].coeff + sk[k])) : (V)(S)0;
-                    dv[j][k] = (MODE == 0 && on) ? ld<NT>(reinterpret_cast<const V *>(in + (i + j) * n_scalars + sk[k])) : (V)(S)0;
+                    av[j][k] = rc ? ldu<NT, S, NS>((const S *)blk[j].coeff + sk[k]) : (V)(S)0;
+                    dv[j][k] = (MODE == 0 && on) ? ldu<NT, S, NS>(in + (i + j) * n_scalars + sk[k]) : (V)(S)0;
                 }
             }
 #pragma unroll
@@ -199,8 +207,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
             const bool rc = block_reads_coeff(blk, false);
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                const V c = rc ? ld<NT>(reinterpret_cast<const V *>((const S *)blk.coeff + sk[k])) : (V)(S)0;
-                const V t = (MODE == 0) ? ld<NT>(reinterpret_cast<const V *>(in + i * n_scalars + sk[k])) : apply_block_loaded<S, E, NS, V>(blk, mv[k], c, false, false);
+                const V c = rc ? ldu<NT, S, NS>((const S *)blk.coeff + sk[k]) : (V)(S)0;
+                const V t = (MODE == 0) ? ldu<NT, S, NS>(in + i * n_scalars + sk[k]) : apply_block_loaded<S, E, NS, V>(blk, mv[k], c, false, false);
                 acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk, t, c, true, false);
             }
         }
@@ -237,7 +245,10 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
     }
 #pragma unroll
     for (int k = 0; k < U; k++)
-        if (ok[k]) st<false>(reinterpret_cast<V *>(out + s0 + (int64_t)k * BLK * NS), acc[k]);
+        if (ok[k]) {
+            if constexpr (MIXED) st_pack<false, S, NS>(out, s0 + (int64_t)k * BLK * NS, sk[k], acc[k]);
+            else st<false>(reinterpret_cast<V *>(out + s0 + (int64_t)k * BLK * NS), acc[k]);
+        }
 }
 
 // ---- the normal-equations pass of the device-resident CG loops (jh_lsqr.hip: cg_graph_impl; round 4) ---------------------------------
@@ -343,14 +354,15 @@ __global__ __launch_bounds__(1024) void k_fold_parts(const S *__restrict__ parts
     const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t s = s_begin + ((int64_t)blockIdx.x * 64 + v) * NS;
     const bool ok = s < s_end;
+    const int64_t sc = ok ? pack_start<NS>(s, s_end) : s_begin;     // (the last, partial pack of a domain that is not whole packs: loaded from s_end - NS, st_pack)
     double acc[NS];
 #pragma unroll
     for (int e = 0; e < NS; e++) acc[e] = 0.0;
     if (ok) {
-        const S *src = parts + (s - s_begin);
+        const S *src = parts + (sc - s_begin);
 #pragma unroll 4
         for (int p = q; p < nparts; p += 16) {
-            const V x = ld<false>(reinterpret_cast<const V *>(src + (int64_t)p * part_stride));
+            const V x = ldu<false, S, NS>(src + (int64_t)p * part_stride);
 #pragma unroll
             for (int e = 0; e < NS; e++) acc[e] += (double)x[e];
         }
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(1024) void k_fold_parts(const S *__restrict__ parts
             for (int qq = 1; qq < 16; qq++) t += sm[qq][e][v];
             r[e] = (S)t;
         }
-        st<false>(reinterpret_cast<V *>(out + s), r);
+        st_pack<false, S, NS>(out, s, sc, r);
     }
 }
 
@@ -460,7 +472,7 @@ template <typename S, int NS>
 int launch_fold_parts(const void *parts, int64_t part_stride, int64_t nparts, void *out, int64_t s_begin, int64_t s_end)
 {
     jh_context &c = jh_ctx();
-    const int64_t gx = ((s_end - s_begin) / NS + 63) / 64;
+    const int64_t gx = ((s_end - s_begin + NS - 1) / NS + 63) / 64;
     hipLaunchKernelGGL((k_fold_parts<S, NS>), dim3((unsigned)gx), dim3(1024), 0, c.stream, (const S *)parts, part_stride, (int)nparts,
                        (S *)out, s_begin, s_end);
     JH_CHECK_HIP(hipGetLastError());
@@ -927,6 +939,29 @@ bool tall_mixed_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_pt
     if (n == 0 || (n * (int64_t)es) % 16 != 0) return false;
     if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & 15u) return false;
     return op->coeff_aligned16;
+}
+}  // namespace jhb
+namespace {
+
+// Rows that are NOT whole 16-byte packs, or do not start on 16-byte boundaries (round 5, session 3): a tall operator of >= 2 equal elementwise rows whose
+// block length is odd -- 101^3 Float32 elements -- has three rows in four start off a 16-byte boundary inside the range vector's slab (and, when the
+// diagonals are blocks of one slab too, inside the coefficients).  Such operators used to drop to the general kernels' 4-byte-per-lane forms (256 x 1 of
+// 524 289 Float32: forward 2.0, adjoint 3.1 TB/s); they now run the MIXED instantiations of the tall kernels, whose accesses are under-aligned packs and
+// whose last pack per row is partial (jh_blockop_common.h: ldu / st_pack) -- the same terms in the same order, so the same bits.  All-diagonal operators
+// included: the per-row kind switch costs them a scalar branch per row.  Whole-vector forward, adjoint and fused A'A only; the solver steps, fused sums
+// and ranged calls keep asking for aligned blocks and fall back to compositions of these.
+}  // namespace
+namespace jhb {
+bool tall_unaligned_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
+{
+    if (!(op->tall && op->uniform_rows && op->elementwise) || op->nrow < 2) return false;
+    if (jh_ctx().tall_unaligned == 0) return false;                       // knob: 0 sends such operators to the general kernels as before
+    const size_t es = jh_dtype_size(op->dtype);
+    const int64_t n = op->row_len[0];
+    if (n * (int64_t)es < 16) return false;                               // at least one pack per row
+    const size_t sa = jh_dtype_complex(op->dtype) ? es / 2 : es;          // the scalar's alignment
+    if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & (sa - 1)) return false;
+    return op->coeff_scalar_aligned;
 }
 }  // namespace jhb
 namespace {
