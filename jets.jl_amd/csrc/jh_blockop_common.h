@@ -140,6 +140,14 @@ template <typename S, int NS, typename V> __device__ inline double vnorm2(V r)
     for (int e = 0; e < NS; e++) acc += (double)r[e] * (double)r[e];
     return acc;
 }
+// the same over the scalars e >= e0 of the pack: a row's partial last pack (loaded from n - NS, pack_start) counts the scalars it OWNS, e0 = s - pack_start(s, n)
+template <typename S, int NS, typename V> __device__ inline double vnorm2_from(V r, int e0)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < NS; e++) acc += e >= e0 ? (double)r[e] * (double)r[e] : 0.0;
+    return acc;
+}
 
 
 }  // namespace

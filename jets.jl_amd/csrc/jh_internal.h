@@ -372,6 +372,7 @@ struct jh_blockop {
 };
 
 bool jh_blockop_tall_fast(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr);   // tall, all DIAG, equal 16-byte aligned blocks
+bool jh_blockop_tall_step_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr);   // that, or rows off the 16-byte pack grid (whole-vector fused passes only; jh_tall.hip)
 // Device-resident state of CG on the normal equations / CGLS (jh_lsqr.hip, round 4): the recurrences' scalars live here, one-thread
 // epilogues of the fold kernels update them with the same fp64 operations, in the same order, as the host-driven loops (the two
 // update functions are shared `__host__ __device__` code), and every vector kernel reads its coefficients from it -- so an

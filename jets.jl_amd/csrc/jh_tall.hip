@@ -1099,6 +1099,13 @@ bool jh_blockop_tall_fast(const jh_blockop *op, const void *rng_ptr, const void 
     return tall_fast_ok(op, rng_ptr, dom_ptr) || (tall_mixed_ok(op, rng_ptr, dom_ptr) && !(op->nonlinear && !op->pointed));
 }
 
+// what the WHOLE-VECTOR fused passes accept (forward update, one-pass step, and the host-driven solver loops built on them): the above, or rows off the
+// 16-byte pack grid on the under-aligned MIXED instantiations (tall_unaligned_ok).  Ranged calls and the graph-replayed loops keep jh_blockop_tall_fast.
+bool jh_blockop_tall_step_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
+{
+    return jh_blockop_tall_fast(op, rng_ptr, dom_ptr) || (tall_unaligned_ok(op, rng_ptr, dom_ptr) && !(op->nonlinear && !op->pointed));
+}
+
 // all-DIAG tall operators only (the caller checks: jh_lsqr.hip, cg_graph_impl); one pack per lane, 8 rows in flight
 int jh_launch_cg_normal(const jh_blockop *op, jh_bvec *p, const jh_bvec *s, jh_bvec *y, const jh_cg_dev *st, double *partials, int64_t *nparts)
 {

@@ -6,6 +6,12 @@
 
 namespace {
 
+// rows that are not whole, 16-byte aligned packs (jh_tall.hip: tall_unaligned_ok): such operators run the MIXED instantiations, whose accesses are under-aligned
+static inline bool packs_unaligned(const jh_blockop *op, size_t row_bytes, const void *a, const void *b, const void *c = nullptr)
+{
+    return row_bytes % 16 != 0 || !op->coeff_aligned16 || ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15u) != 0;
+}
+
 // forward: d_i = alpha * (a_i .* m) + beta * d_i ; sequential row sweep (tile index fastest)
 // WIDE (S = float, beta == 0): the scalar is Julia's Float64 (JH_SCALAR_WIDE) -- d_i = Float32(wscal * Float64(a_i .* m)), the promoted
 // product of `d .= a * tmp` (src/Jets.jl:1159) rounded once on the store
@@ -38,8 +44,15 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block
 #pragma unroll
     for (int k = 0; k < U; k++) {
         ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
-        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
-        mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
+        // MIXED (round 5, session 3): these instantiations also serve rows that are not whole, 16-byte aligned packs (jh_tall.hip: tall_unaligned_ok) --
+        // under-aligned accesses, the row's last pack loaded from n - NS, stored and counted from its own first scalar on (st_pack, vnorm2_from)
+        if constexpr (MIXED) {
+            sk[k] = ok[k] ? pack_start<NS>(s0 + (int64_t)k * BLK * NS, n_scalars) : 0;
+            mv[k] = ldu<false, S, NS>(m + sk[k]);
+        } else {
+            sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
+            mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
+        }
     }
     const bool use_old = (beta != (S)0);
     double nrm = 0.0;
@@ -58,8 +71,13 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block
         V av[U], dv[U];
 #pragma unroll
         for (int k = 0; k < U; k++) {
-            av[k] = rc ? ld<true>(reinterpret_cast<const V *>(a + sk[k])) : (V)(S)0;
-            dv[k] = use_old ? ld<true>(reinterpret_cast<const V *>(di + sk[k])) : (V)(S)0;   // beta == 0: d is write-only
+            if constexpr (MIXED) {
+                av[k] = rc ? ldu<true, S, NS>(a + sk[k]) : (V)(S)0;
+                dv[k] = use_old ? ldu<true, S, NS>(di + sk[k]) : (V)(S)0;
+            } else {
+                av[k] = rc ? ld<true>(reinterpret_cast<const V *>(a + sk[k])) : (V)(S)0;
+                dv[k] = use_old ? ld<true>(reinterpret_cast<const V *>(di + sk[k])) : (V)(S)0;   // beta == 0: d is write-only
+            }
         }
 #pragma unroll
         for (int k = 0; k < U; k++) {
@@ -76,8 +94,14 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block
             V r = s1;
             if (use_old) { V s2 = (V)beta * dv[k]; r = s1 + s2; }   // d_i .= alpha*tmp .+ beta*d_i
             if (ok[k]) {
-                st<true>(reinterpret_cast<V *>(di + sk[k]), r);
-                nrm += vnorm2<S, NS, V>(r);
+                if constexpr (MIXED) {
+                    const int64_t sn = s0 + (int64_t)k * BLK * NS;
+                    st_pack<true, S, NS>(di, sn, sk[k], r);
+                    nrm += vnorm2_from<S, NS, V>(r, (int)(sn - sk[k]));
+                } else {
+                    st<true>(reinterpret_cast<V *>(di + sk[k]), r);
+                    nrm += vnorm2<S, NS, V>(r);
+                }
             }
         }
     }
@@ -196,12 +220,23 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
     bool ok[U];
     int64_t sk[U];
     V acc[U], vv[U];
+    int e0[U];                                                              // MIXED: the first scalar of pack k that this lane OWNS (0 but for a row's partial last pack)
 #pragma unroll
     for (int k = 0; k < U; k++) {
         ok[k] = (s0 + (int64_t)k * BLK * NS) < s_end;
-        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : s_begin;
-        acc[k] = (accumulate && ok[k]) ? ld<false>(reinterpret_cast<const V *>(w + sk[k])) : (V)(S)0;
-        vv[k] = ld<false>(reinterpret_cast<const V *>(v + sk[k]));
+        // MIXED (round 5, session 3): these instantiations also serve rows that are not whole, 16-byte aligned packs (jh_tall.hip: tall_unaligned_ok) --
+        // under-aligned accesses, the last pack loaded from s_end - NS, stored and counted from its own first scalar on (st_pack, vnorm2_from)
+        if constexpr (MIXED) {
+            sk[k] = ok[k] ? pack_start<NS>(s0 + (int64_t)k * BLK * NS, s_end) : s_begin;
+            e0[k] = ok[k] ? (int)(s0 + (int64_t)k * BLK * NS - sk[k]) : 0;
+            acc[k] = (accumulate && ok[k]) ? ldu<false, S, NS>(w + sk[k]) : (V)(S)0;
+            vv[k] = ldu<false, S, NS>(v + sk[k]);
+        } else {
+            sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : s_begin;
+            e0[k] = 0;
+            acc[k] = (accumulate && ok[k]) ? ld<false>(reinterpret_cast<const V *>(w + sk[k])) : (V)(S)0;
+            vv[k] = ld<false>(reinterpret_cast<const V *>(v + sk[k]));
+        }
     }
     const bool use_old = (beta != (S)0);
     double nrm = 0.0;
@@ -236,8 +271,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
                     const S *ap = block_reads_coeff(blk[j], false) ? (const S *)blk[j].coeff : v;   // no coefficient array: v's pack again (unused)
 #pragma unroll
                     for (int k = 0; k < U; k++) {
-                        av[j][k] = ld<true>(reinterpret_cast<const V *>(ap + sk[k]));
-                        if constexpr (OLD) uv[j][k] = ld<true>(reinterpret_cast<const V *>(u + (i + j) * n_scalars + sk[k]));
+                        av[j][k] = ldu<true, S, NS>(ap + sk[k]);
+                        if constexpr (OLD) uv[j][k] = ldu<true, S, NS>(u + (i + j) * n_scalars + sk[k]);
                         else uv[j][k] = (V)(S)0;
                     }
                 }
@@ -251,8 +286,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
                             V r = (V)alpha * t;
                             if constexpr (OLD) { V s2 = (V)beta * uv[j][k]; r = r + s2; }
                             if (ok[k]) {
-                                st<true>(reinterpret_cast<V *>(u + (i + j) * n_scalars + sk[k]), r);
-                                nrm += vnorm2<S, NS, V>(r);
+                                st_pack<true, S, NS>(u + (i + j) * n_scalars, sk[k] + e0[k], sk[k], r);
+                                nrm += vnorm2_from<S, NS, V>(r, e0[k]);
                             }
                             acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, !cj);
                         }
@@ -265,8 +300,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
                         V r = (V)alpha * t;
                         if constexpr (OLD) { V s2 = (V)beta * uv[j][k]; r = r + s2; }
                         if (ok[k]) {
-                            st<true>(reinterpret_cast<V *>(u + (i + j) * n_scalars + sk[k]), r);
-                            nrm += vnorm2<S, NS, V>(r);
+                            st_pack<true, S, NS>(u + (i + j) * n_scalars, sk[k] + e0[k], sk[k], r);
+                            nrm += vnorm2_from<S, NS, V>(r, e0[k]);
                         }
                         if (on) acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk[j], r, av[j][k], true, false);
                     }
@@ -281,13 +316,13 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
             const S *ap = block_reads_coeff(blk, false) ? (const S *)blk.coeff : v;
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                const V c = ld<true>(reinterpret_cast<const V *>(ap + sk[k]));
+                const V c = ldu<true, S, NS>(ap + sk[k]);
                 const V t = on ? apply_block_loaded<S, E, NS, V>(blk, vv[k], c, false, false) : (V)(S)0;
                 V r = (V)alpha * t;
-                if (use_old) { V s2 = (V)beta * ld<true>(reinterpret_cast<const V *>(u + i * n_scalars + sk[k])); r = r + s2; }
+                if (use_old) { V s2 = (V)beta * ldu<true, S, NS>(u + i * n_scalars + sk[k]); r = r + s2; }
                 if (ok[k]) {
-                    st<true>(reinterpret_cast<V *>(u + i * n_scalars + sk[k]), r);
-                    nrm += vnorm2<S, NS, V>(r);
+                    st_pack<true, S, NS>(u + i * n_scalars, sk[k] + e0[k], sk[k], r);
+                    nrm += vnorm2_from<S, NS, V>(r, e0[k]);
                 }
                 if (on) acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk, r, c, true, false);
             }
@@ -336,7 +371,10 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
     }
 #pragma unroll
     for (int k = 0; k < U; k++)
-        if (ok[k]) st<false>(reinterpret_cast<V *>(w + sk[k]), acc[k]);
+        if (ok[k]) {
+            if constexpr (MIXED) st_pack<false, S, NS>(w, sk[k] + e0[k], sk[k], acc[k]);
+            else st<false>(reinterpret_cast<V *>(w + sk[k]), acc[k]);
+        }
     wg_sum_store<BLK>(nrm, partials + tile + (size_t)blockIdx.y * gridDim.x);      // by tile: the fold's order does not depend on remap
 }
 
@@ -606,7 +644,7 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     jh_context &c = jh_ctx();
     const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
     const int64_t a_stride = op->diag_stride_elems * E;
-    const int64_t nvec = n_scalars / NS;
+    const int64_t nvec = (n_scalars + NS - 1) / NS;
     // three streams per row (a, d in, d out).  Late round 4: one pack per lane, two rows per workgroup, COLUMN bands of 32 tiles (k_tall_diag_fwd's
     // walk: 128 KiB of a row group, then the same tiles of the next, ...) -- against round 1's 256 x 4 packs x 4 rows sequential: beta = 0 (the pass of
     // `(a * A) * m`) 6.07 / 5.65 / 5.92 / 5.88 -> 6.22 / 6.14 / 6.13 / 6.17 TB/s at 128 x 256^3 / 256 x 256^3 / 1024 x 128^3 / 1024 x 256^3,
@@ -625,7 +663,7 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
     // call synchronises anyway); later calls use the faster one (upd_walk: 0 bands, 1 row-concurrent).
     const double stream_bytes = 3.0 * (double)op->nrow * (double)n_scalars * sizeof(S);
     const bool knobs_free = !c.fwd_wg && !c.fwd_unroll && !c.fwd_group && c.fwd_order < 0 && c.fwd_ctiles < 0;
-    const bool mixed = !op->all_diag;                       // rows of several elementwise kinds: the bands, always
+    const bool mixed = !op->all_diag || packs_unaligned(op, (size_t)n_scalars * sizeof(S), d, m);   // rows of several elementwise kinds (or off the pack grid): the bands, always
     const bool tunable = !mixed && c.autotune && knobs_free && normsq && stream_bytes >= 8.0 * (double)(1ull << 30) && op->nrow >= 64;
     int trial = -1;
     if (tunable) {
@@ -739,7 +777,7 @@ int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n
 // profiles/bench_lsqr_step_r01.txt: 1024 x 256^3 wants thin threads with many rows in flight (512 x 1 x 4: 6.13 TB/s),
 // 128 x 256^3 fat ones (512 x 4 x 2: 5.46), 64 x 128^3 256 x 4 x 1 (5.9)
 struct StepShape { int wg, U, D; };
-static StepShape pick_step_shape(const jh_blockop *op, int64_t nvec, bool complex_f32)
+static StepShape pick_step_shape(const jh_blockop *op, int64_t nvec, bool complex_f32, bool mixed)
 {
     jh_context &c = jh_ctx();
     int wg = 256, U = 1, D = 4;
@@ -750,8 +788,7 @@ static StepShape pick_step_shape(const jh_blockop *op, int64_t nvec, bool comple
     if (c.adj_wg) wg = (int)c.adj_wg;                       // the adjoint's knobs select among the instantiated shapes
     if (c.adj_unroll) U = (int)c.adj_unroll;
     if (c.adj_depth) D = (int)c.adj_depth;
-    const bool mixed = !op->all_diag;                       // rows of several elementwise kinds (tall_mixed_ok): four instantiated shapes
-    if (mixed) {
+    if (mixed) {                                            // rows of several elementwise kinds (tall_mixed_ok) or off the pack grid: four instantiated shapes
         auto inst = [](int w_, int u_, int d_) { return (w_ == 512 && u_ == 1 && d_ == 4) || (w_ == 256 && ((u_ == 2 && d_ == 2) || (u_ == 4 && d_ == 1) || (u_ == 1 && d_ == 4))); };
         if (!inst(wg, U, D)) {                              // the all-diagonal rule without the knobs, 512 threads always as 512 x 1 x 4
             wg = 256; U = 1; D = 4;
@@ -775,10 +812,11 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     const int64_t a_stride = op->diag_stride_elems * E;
     const int64_t nvec = n_scalars / NS;
     const int direct = op->nrow == 1 ? 1 : 0;
-    const StepShape shape = pick_step_shape(op, nvec, E == 2 && sizeof(S) == 4);
+    const bool unaligned = packs_unaligned(op, (size_t)n_scalars * sizeof(S), u, v, w);   // (whole-vector calls only: jh_blockop_bidiag_step)
+    const bool mixed = !op->all_diag || unaligned;          // rows of several elementwise kinds (tall_mixed_ok), or off the pack grid
+    const StepShape shape = pick_step_shape(op, nvec, E == 2 && sizeof(S) == 4, mixed);
     int wg = shape.wg, U = shape.U, D = shape.D;
-    const bool mixed = !op->all_diag;                       // rows of several elementwise kinds (tall_mixed_ok)
-    const int64_t gx = ((s_end - s_begin) / NS + (int64_t)wg * U - 1) / ((int64_t)wg * U);
+    const int64_t gx = ((s_end - s_begin + NS - 1) / NS + (int64_t)wg * U - 1) / ((int64_t)wg * U);
     // many rows of small blocks: split-row walk (pick_adj_parts): u's rows are updated as before, w's sum is folded from slabs
     int64_t parts = direct ? 1 : pick_adj_parts(gx, op->nrow);
     int64_t rows_per_part = 0;
@@ -817,7 +855,7 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     const int64_t span = s_end - s_begin;
     const bool knobs_free = !c.adj_wg && !c.adj_unroll && !c.adj_depth;
     int CD = 8, cb = 0;                                                   // rows per chunk; chained: workgroup size (0: the shape does not allow it)
-    const bool chain_base = !direct && parts == 1 && rows_per_launch == op->nrow;
+    const bool chain_base = !direct && parts == 1 && rows_per_launch == op->nrow && !unaligned;   // (the chained kernels keep whole, aligned packs)
     if (chain_base && !mixed && (c.step_chunk == 0 || c.step_chunk == 32) && span % ((int64_t)256 * NS) == 0 && op->nrow > 32 &&
         (c.step_chain == 1 || (span / ((int64_t)256 * NS) >= 2048 && op->nrow >= 64)) && !(c.step_chain == 1 && c.adj_wg && c.adj_wg != 256)) {
         CD = 32;
@@ -964,7 +1002,8 @@ int64_t jh_bidiag_step_parts(const jh_blockop *op)
     if (op->nrow == 1) return 1;
     const int64_t ssize = (int64_t)jh_dtype_size(op->dtype) / (jh_dtype_complex(op->dtype) ? 2 : 1);
     const int64_t n_scalars = op->col_len[0] * (jh_dtype_complex(op->dtype) ? 2 : 1), NS = 16 / ssize;
-    const StepShape sh = pick_step_shape(op, n_scalars / NS, op->dtype == JH_C32);
+    const bool mixed = !op->all_diag || !op->coeff_aligned16 || (n_scalars * ssize) % 16 != 0;
+    const StepShape sh = pick_step_shape(op, n_scalars / NS, op->dtype == JH_C32, mixed);
     const int64_t gx = (n_scalars / NS + (int64_t)sh.wg * sh.U - 1) / ((int64_t)sh.wg * sh.U);
     return pick_adj_parts(gx, op->nrow);
 }
@@ -977,8 +1016,9 @@ int jh_blockop_bidiag_step(const jh_blockop *op, jh_bvec *u, const jh_bvec *v, j
     JH_TRY(check_vectors(op, u, v, "jh_blockop_bidiag_step"));
     JH_REQUIRE(w && w->dtype == op->dtype && w->length == v->length, "jh_blockop_bidiag_step: w must be a domain vector of the operator");
     JH_REQUIRE(w->data != v->data, "jh_blockop_bidiag_step: w must not alias v");
-    if (!jh_blockop_tall_fast(op, u->data, v->data) || (((uintptr_t)w->data) & 15u))
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_bidiag_step: needs a tall operator of elementwise rows with equal, 16-byte aligned blocks");
+    // (round 5, session 3: rows off the 16-byte pack grid -- odd block lengths in one slab -- run the plain walk's MIXED instantiations on under-aligned packs)
+    if (!jh_blockop_tall_step_ok(op, u->data, v->data) || (((uintptr_t)w->data) & (jh_dtype_size(op->dtype) / (jh_dtype_complex(op->dtype) ? 2 : 1) - 1)))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_bidiag_step: needs a tall operator of >= 2 equal elementwise rows");
     const int64_t n = op->row_len[0];
     switch (op->dtype) {
     case JH_F32: return launch_bidiag<float, 1, 4>(op, u->data, v->data, w->data, n, alpha, beta, normsq);
@@ -1037,8 +1077,8 @@ int jh_blockop_mul_axpby(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, dou
 {
     JH_TRY(jh_enter(op, d, m));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_axpby"));
-    if (!jh_blockop_tall_fast(op, d->data, m->data))
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_axpby: needs a tall operator of elementwise rows with equal, 16-byte aligned blocks; "
+    if (!jh_blockop_tall_step_ok(op, d->data, m->data))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_axpby: needs a tall operator of equal elementwise rows; "
                                            "use jh_blockop_mul into a temporary, jh_lincomb and jh_norm instead");
     const int64_t n = op->row_len[0];
     switch (op->dtype) {
@@ -1077,8 +1117,8 @@ int jh_blockop_mul_scaled(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, do
     if (a_flags & JH_SCALAR_COMPLEX) return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_scaled: a Complex scalar takes the unfused chain (jh_blockop_mul, jh_lincomb_typed)");
     JH_TRY(jh_enter(op, d, m));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_scaled"));
-    if (!jh_blockop_tall_fast(op, d->data, m->data))
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_scaled: needs a tall operator of elementwise rows with equal, 16-byte aligned blocks");
+    if (!jh_blockop_tall_step_ok(op, d->data, m->data))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_scaled: needs a tall operator of equal elementwise rows");
     const int64_t n = op->row_len[0];
     const bool wide = (a_flags & JH_SCALAR_WIDE) != 0;
     switch (op->dtype) {

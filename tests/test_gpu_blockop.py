@@ -440,12 +440,17 @@ def test_tall_operator_with_a_few_scalar_rows_stays_on_the_tall_kernels(Jets, or
     refB = oracle.block_df(oraB, [np.zeros(n, dt) for _ in range(3)], [hm])
     assert_bits_equal(u3.to_numpy(), np.concatenate(refB), "one-pass step on 1 diagonal + 2 identity rows: u")
     assert_bits_equal(w.to_numpy(), oracle.block_df_adj(oraB, [np.zeros(n, dt)], refB)[0], "... w")
-    # a block length that is not a multiple of 16 bytes has no tall tiling: the step says so and the caller takes another path
-    odd = Jets.JetSpace(dt, 4097 if np.dtype(dt).itemsize == 4 else 4097)
-    if (4097 * np.dtype(dt).itemsize) % 16:
-        Cop = Jets.blockop([[Jets.JopDiagonal(Jets.rand(odd, seed=7, stream=0))], [Jets.JopIdentity(odd)]])
-        natC = jetblock._native_op(Cop.jet.s["_native"], Cop.jet.s["ops"], Cop.jet.rng.eltype())
-        assert lib.jh_blockop_bidiag_step(natC.handle, Jets.zeros(Jets.range(Cop)).handle, Jets.zeros(odd).handle, Jets.zeros(odd).handle, 1.0, 0.0, C.byref(out)) == 4
+    # a block length that is not a multiple of 16 bytes: under-aligned packs since round 5 (tests/test_gpu_tall_unaligned.py); rows shorter than ONE pack
+    # have no tall tiling: the step says so and the caller takes another path
+    odd = Jets.JetSpace(dt, 4097)
+    Cop = Jets.blockop([[Jets.JopDiagonal(Jets.rand(odd, seed=7, stream=0))], [Jets.JopIdentity(odd)]])
+    natC = jetblock._native_op(Cop.jet.s["_native"], Cop.jet.s["ops"], Cop.jet.rng.eltype())
+    assert lib.jh_blockop_bidiag_step(natC.handle, Jets.zeros(Jets.range(Cop)).handle, Jets.zeros(odd).handle, Jets.zeros(odd).handle, 1.0, 0.0, C.byref(out)) == 0
+    if np.dtype(dt).itemsize < 16:
+        tiny = Jets.JetSpace(dt, 1)
+        Dop = Jets.blockop([[Jets.JopDiagonal(Jets.rand(tiny, seed=7, stream=0))], [Jets.JopIdentity(tiny)]])
+        natD = jetblock._native_op(Dop.jet.s["_native"], Dop.jet.s["ops"], Dop.jet.rng.eltype())
+        assert lib.jh_blockop_bidiag_step(natD.handle, Jets.zeros(Jets.range(Dop)).handle, Jets.zeros(tiny).handle, Jets.zeros(tiny).handle, 1.0, 0.0, C.byref(out)) == 4
 
 
 @pytest.mark.parametrize("rows", [1, 3, 5, 64])

@@ -364,10 +364,14 @@ def test_bidiag_step_argument_checks(Jets, oracle):
     B = Jets.blockop([[Jets.JopDiagonal(Jets.rand(spc))], [Jets.JopIdentity(spc)]])                              # not all-DIAG: per-row kinds
     assert lib.jh_blockop_bidiag_step(_native(Jets, B).handle, Jets.zeros(Jets.range(B)).handle, v.handle,
                                       Jets.zeros(spc).handle, 1.0, 0.0, C.byref(out)) == 0
-    odd = Jets.JetSpace(np.float32, 63)                                                                          # 252-byte rows: no 16-byte tiling
-    Cop = Jets.blockop([[Jets.JopDiagonal(Jets.rand(odd))], [Jets.JopIdentity(odd)]])
+    odd = Jets.JetSpace(np.float32, 63)                                                                          # 252-byte rows: off the 16-byte pack grid --
+    Cop = Jets.blockop([[Jets.JopDiagonal(Jets.rand(odd))], [Jets.JopIdentity(odd)]])                            # under-aligned packs since round 5 (tests/test_gpu_tall_unaligned.py)
     assert lib.jh_blockop_bidiag_step(_native(Jets, Cop).handle, Jets.zeros(Jets.range(Cop)).handle, Jets.zeros(odd).handle,
-                                      Jets.zeros(odd).handle, 1.0, 0.0, C.byref(out)) == 4                         # JH_ERR_UNSUPPORTED
+                                      Jets.zeros(odd).handle, 1.0, 0.0, C.byref(out)) == 0
+    tiny = Jets.JetSpace(np.float32, 3)                                                                          # 12-byte rows: less than one pack
+    Dop = Jets.blockop([[Jets.JopDiagonal(Jets.rand(tiny))], [Jets.JopIdentity(tiny)]])
+    assert lib.jh_blockop_bidiag_step(_native(Jets, Dop).handle, Jets.zeros(Jets.range(Dop)).handle, Jets.zeros(tiny).handle,
+                                      Jets.zeros(tiny).handle, 1.0, 0.0, C.byref(out)) == 4                        # JH_ERR_UNSUPPORTED
 
 
 def test_lsqr_one_pass_and_two_pass_iterations_agree(Jets, oracle, monkeypatch):

@@ -145,3 +145,100 @@ def test_many_small_rows_off_the_pack_grid_take_the_split_walk_and_its_fold(Jets
     finally:
         J.tune(adj_split=-1)
     J.close(A)
+
+
+# ---------------------------------------------------------------------------------- the fused solver passes on rows off the pack grid
+def _native(A):
+    from jets_jl_amd import jetblock
+
+    j = A.jet
+    return jetblock._native_op(j.s["_native"], j.s["ops"], j.rng.eltype())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,n,name,beta", [(2, 67, "diag", -1.375), (5, 1027, "diag", 0.5), (33, 4099, "diag", -2.0), (7, 35937, "diag", 0.0),
+                                              (3, 1025, "mixed", 0.25), (18, 8193, "mixed", -0.3), (9, 1030301, "diag", -1.375), (6, 6 * 1024 + 3, "mixed", 0.0)])
+def test_the_one_pass_step_and_the_forward_update_off_the_pack_grid(Jets, oracle, dt, nrow, n, name, beta):
+    """jh_blockop_mul_axpby and jh_blockop_bidiag_step (whole vector) on odd block lengths: u and w BIT-EXACT against the oracle's unfused chain,
+    ||u||^2 within 1e-6 / 1e-13 -- the partial last pack of a row counts the scalars it owns once."""
+    import ctypes as C
+
+    from jets_jl_amd._ffi import check, lib
+
+    J = Jets
+    if n * nrow * np.dtype(dt).itemsize > 2 ** 27:
+        pytest.skip("kept small")
+    A, ops = _mixed_ops(J, oracle, dt, _kinds(nrow, name), [n] * nrow, [n])
+    nat = _native(A)
+    alpha = 0.75
+    hv, hu = u01(oracle, dt, 51, 0, n), u01(oracle, dt, 52, 0, nrow * n)
+    hu_blocks = [hu[i * n:(i + 1) * n].copy() for i in range(nrow)]
+    tmp = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [hv])
+    if beta != 0.0:
+        ref_u = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [alpha, beta], [tmp, hu_blocks])
+    else:
+        ref_u = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], [alpha], [tmp])
+    ref_w = oracle.block_df_adj(ops, [np.full(n, 5, dtype=dt)], ref_u)
+    truth = float(np.sum(np.abs(np.concatenate(ref_u).astype(np.complex128)) ** 2))
+    tol = 1e-6 if np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-13
+    out = C.c_double(0)
+    # the forward update alone
+    v = J.from_numpy(hv, J.domain(A))
+    u = J.from_numpy(hu, J.range(A))
+    check(lib.jh_blockop_mul_axpby(nat.handle, u.handle, v.handle, alpha, beta, C.byref(out)))
+    assert_bits_equal(u.to_numpy(), np.concatenate(ref_u), "u <- alpha*A v + beta*u (forward update)")
+    assert out.value == pytest.approx(truth, rel=tol)
+    # the one-pass step
+    u = J.from_numpy(hu, J.range(A))
+    w = J.rand(J.domain(A), seed=53, stream=0)                                        # dirty: must be overwritten
+    check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, alpha, beta, C.byref(out)))
+    assert_bits_equal(u.to_numpy(), np.concatenate(ref_u), "u <- alpha*A v + beta*u (one-pass step)")
+    assert_bits_equal(w.to_numpy().ravel(order="F"), ref_w[0], "w <- A'u")
+    assert out.value == pytest.approx(truth, rel=tol)
+    J.close(A)
+
+
+@pytest.mark.parametrize("dt,xtol", [(np.float32, 1e-4), (np.float64, 1e-10), (np.complex64, 1e-4)])
+def test_the_solver_loops_behind_the_abi_take_operators_off_the_pack_grid(Jets, oracle, dt, xtol, monkeypatch):
+    """LSQR, CGLS and CG on the normal equations on 6 rows of 17 x 17 x 15 = 4335 elements: the native loops (one pass per iteration) accept the operator
+    -- jh_lsqr_solve itself is called, so a fall-back to the generic loop cannot hide -- and agree with the fp64 CPU solvers."""
+    import ctypes as C
+
+    from jets_jl_amd._ffi import check, lib
+    from oracle.lsqr_ref import lsqr_fp64
+
+    J = Jets
+    nrow, shape, iters = 6, (17, 17, 15), 12
+    n = int(np.prod(shape))
+    spc = J.JetSpace(dt, *shape)
+    slab = J.rand(J.JetBSpace([spc] * nrow), seed=1, stream=7)                       # the diagonals: blocks of ONE slab (off the grid like the range vector)
+    A = J.blockop([[J.JopDiagonal(slab.arrays[i])] for i in range(nrow)])
+    diags = [g.copy() for g in np.split(slab.to_numpy(), nrow)]
+    dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    a64 = [g.astype(dt64) for g in diags]
+    matvec = lambda x: np.concatenate([g * x for g in a64])
+    rmatvec = lambda y: sum(np.conj(g) * y[i * n:(i + 1) * n] for i, g in enumerate(a64))
+    hb = (u01(oracle, dt, 51, 0, nrow * n) - dt(0.5)).astype(dt)
+    b = J.from_numpy(hb, J.range(A))
+    xr, info = lsqr_fp64(matvec, rmatvec, hb.astype(dt64), n, atol=0.0, btol=0.0, conlim=0.0, maxiter=iters)
+    # the ABI's own loop, called directly: JH_OK, not JH_ERR_UNSUPPORTED
+    nat = _native(A)
+    u = J.from_numpy(hb, J.range(A))
+    x = J.zeros(J.domain(A))
+    from jets_jl_amd._ffi import LsqrResultC as _R
+    res = _R()
+    check(lib.jh_lsqr_solve(nat.handle, u.handle, x.handle, 0, 0.0, 0.0, 0.0, 0.0, iters, 0, C.byref(res), None))
+    assert res.itn == iters
+    got = x.to_numpy().ravel(order="F").astype(dt64)
+    assert np.linalg.norm(got - xr) / np.linalg.norm(xr) < xtol
+    # and through the drivers (native by default)
+    monkeypatch.setenv("JETS_LSQR_NATIVE", "1")
+    r = J.lsqr(A, b, atol=0.0, btol=0.0, conlim=0.0, maxiter=iters)
+    assert np.linalg.norm(r.x.to_numpy().ravel(order="F").astype(dt64) - xr) / np.linalg.norm(xr) < xtol
+    a = np.stack(a64)
+    x_ls = (np.conj(a) * hb.astype(dt64).reshape(nrow, n)).sum(0) / (np.abs(a) ** 2).sum(0)
+    for solver in (J.cgls, J.cgnr):
+        rc = solver(A, b, maxiter=60, atol=0.0, btol=0.0)
+        xc = rc.x.to_numpy().ravel(order="F").astype(dt64)
+        assert np.linalg.norm(xc - x_ls) / np.linalg.norm(x_ls) < max(10 * xtol, 1e-6), solver.__name__
+    J.close(A)
