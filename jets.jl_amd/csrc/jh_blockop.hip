@@ -299,6 +299,9 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
         for (const auto &b : op->blocks)
             if ((b.kind == JH_OP_DIAG || b.kind == JH_OP_SQUARE) && (((uintptr_t)b.coeff) & (sa - 1))) op->coeff_scalar_aligned = false;
     }
+    op->lens_hold_a_pack = true;                                           // every non-empty row / column at least 16 bytes long
+    for (int64_t v : op->row_len) if (v > 0 && (size_t)v * jh_dtype_size(dtype) < 16) op->lens_hold_a_pack = false;
+    for (int64_t v : op->col_len) if (v > 0 && (size_t)v * jh_dtype_size(dtype) < 16) op->lens_hold_a_pack = false;
     op->lens_aligned16 = true;
     for (int64_t v : op->row_len) if (((size_t)v * jh_dtype_size(dtype)) % 16) op->lens_aligned16 = false;
     for (int64_t v : op->col_len) if (((size_t)v * jh_dtype_size(dtype)) % 16) op->lens_aligned16 = false;

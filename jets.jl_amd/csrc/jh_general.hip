@@ -293,10 +293,13 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
     if (sidx) j_hi = sidx[-1];
 #define JH_COL(jj) (sidx ? (int64_t)sidx[jj] : (int64_t)(jj))
     const int64_t ns = (row_off[i + 1] - row_off[i]) * E;                 // scalars in this block row
+    // (round 5, session 3) lines need not be whole, 16-byte aligned packs: under-aligned accesses, a line's last pack loaded from ns - NS and stored from its
+    // own first scalar on (jh_blockop_common.h: ldu / pack_start / st_pack; general_vec_ok)
     for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < ns; s += (int64_t)ntiles * 256 * NS) {
+        const int64_t sc = pack_start<NS>(s, ns);
         V acc = (V)(S)0;
         bool touched = split;
-        if (ncol > 1 && !split) acc = ld<false>(reinterpret_cast<const V *>(d + row_off[i] * E + s));
+        if (ncol > 1 && !split) acc = ldu<false, S, NS>(d + row_off[i] * E + sc);
         // the block table and the column offsets are read ONE GROUP AHEAD (scalar loads): a block's vector loads need them, and
         // waiting for them block by block serialises two latencies per block (the mixed one-pass step lost 12 % to that)
         jh_dev_block nb[GENERAL_Q];
@@ -325,8 +328,8 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
                 if (on[q]) {
                     if (b[q].kind == JH_OP_ZERO) on[q] = (fmode != 0);     // (1022) skipped; f! keeps it as +0 -- and never loads for it
                     else {
-                        x[q] = ld<false>(reinterpret_cast<const V *>(m + off[q] * E + s));
-                        if (block_reads_coeff(b[q], fmode != 0)) c[q] = ld<true>(reinterpret_cast<const V *>((const S *)b[q].coeff + s));   // streamed once
+                        x[q] = ldu<false, S, NS>(m + off[q] * E + sc);
+                        if (block_reads_coeff(b[q], fmode != 0)) c[q] = ldu<true, S, NS>((const S *)b[q].coeff + sc);   // streamed once
                     }
                 }
             }
@@ -339,8 +342,8 @@ __global__ void k_block_fwd_general_vec(const jh_dev_block *__restrict__ blocks,
                 }
         }
         if (touched) {
-            if (split) st<false>(reinterpret_cast<V *>(d + row_off[i] * E + s), acc);            // a slab: the fold reads it back
-            else st<true>(reinterpret_cast<V *>(d + row_off[i] * E + s), acc);                   // the result row: written once
+            if (split) st_pack<false, S, NS>(d + row_off[i] * E, s, sc, acc);                    // a slab: the fold reads it back
+            else st_pack<true, S, NS>(d + row_off[i] * E, s, sc, acc);                           // the result row: written once
         }
     }
 }
@@ -370,6 +373,7 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
 #define JH_ROW(ii) (sidx ? (int64_t)sidx[ii] : (int64_t)(ii))
     const int64_t ns = (col_off[j + 1] - col_off[j]) * E;
     for (int64_t s = (tile * 256 + threadIdx.x) * NS; s < ns; s += (int64_t)ntiles * 256 * NS) {
+        const int64_t sc = pack_start<NS>(s, ns);                             // (lines off the pack grid: see the forward)
         V acc = (V)(S)0;
         bool touched = (nrow > 1);
         jh_dev_block nb[GENERAL_Q];                                        // block table and row offsets one group ahead (see the forward)
@@ -398,8 +402,8 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
                 if (on[q]) {
                     if (b[q].kind == JH_OP_ZERO) on[q] = false;            // (1047)
                     else {
-                        x[q] = ld<false>(reinterpret_cast<const V *>(d + off[q] * E + s));
-                        if (block_reads_coeff(b[q], false)) c[q] = ld<true>(reinterpret_cast<const V *>((const S *)b[q].coeff + s));   // streamed once
+                        x[q] = ldu<false, S, NS>(d + off[q] * E + sc);
+                        if (block_reads_coeff(b[q], false)) c[q] = ldu<true, S, NS>((const S *)b[q].coeff + sc);   // streamed once
                     }
                 }
             }
@@ -412,8 +416,8 @@ __global__ void k_block_adj_general_vec(const jh_dev_block *__restrict__ blocks,
                 }
         }
         if (touched) {
-            if (nt_out) st<true>(reinterpret_cast<V *>(m + col_off[j] * E + s), acc);   // a large result written once (a wide operator's adjoint)
-            else st<false>(reinterpret_cast<V *>(m + col_off[j] * E + s), acc);         // a slab of the split walk / a small domain vector: read again soon
+            if (nt_out) st_pack<true, S, NS>(m + col_off[j] * E, s, sc, acc);           // a large result written once (a wide operator's adjoint)
+            else st_pack<false, S, NS>(m + col_off[j] * E, s, sc, acc);                 // a slab of the split walk / a small domain vector: read again soon
         }
     }
 }
@@ -622,10 +626,12 @@ __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__rest
     for (int64_t s0 = (tile * 256 * U + threadIdx.x) * NS; s0 < n_scalars; s0 += (int64_t)ntiles * 256 * U * NS) {
         int64_t s[U];
         bool ok[U];
-#pragma unroll
+        int64_t sn[U];                                                      // (round 5, session 3) sn: where the pack nominally starts; s: where it is loaded from --
+#pragma unroll                                                              // blocks need not be whole, 16-byte aligned packs (ldu / pack_start / st_pack)
         for (int u = 0; u < U; u++) {                                       // U packs per lane, 256 lanes apart (clamped: branch-free loads)
             ok[u] = s0 + (int64_t)u * 256 * NS < n_scalars;
-            s[u] = ok[u] ? s0 + (int64_t)u * 256 * NS : s0;
+            sn[u] = ok[u] ? s0 + (int64_t)u * 256 * NS : s0;
+            s[u] = pack_start<NS>(sn[u], n_scalars);
         }
         V acc[R][U];
         bool touched[R];
@@ -633,7 +639,7 @@ __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__rest
         for (int r = 0; r < R; r++) {
 #pragma unroll
             for (int u = 0; u < U; u++)
-                acc[r][u] = TRANSPOSED ? (V)(S)0 : ld<true>(reinterpret_cast<const V *>(out + line[r] * n_scalars + s[u]));   // `_m .= 0` (1042) / d as found (1024)
+                acc[r][u] = TRANSPOSED ? (V)(S)0 : ldu<true, S, NS>(out + line[r] * n_scalars + s[u]);   // `_m .= 0` (1042) / d as found (1024)
             touched[r] = TRANSPOSED;
         }
         jh_dev_block nb[QQ][R];                                               // block table entries one group of steps ahead
@@ -669,14 +675,14 @@ __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__rest
             for (int q = 0; q < QQ; q++) {
                 const S *xb = in + (LIST ? (int64_t)qcur[q] : (q0 + q < nsum ? q0 + q : 0)) * n_scalars;   // (a step beyond the end re-reads block 0: unused)
 #pragma unroll
-                for (int u = 0; u < U; u++) x[q][u] = ld<false>(reinterpret_cast<const V *>(xb + s[u]));  // shared by every line group: through the caches
+                for (int u = 0; u < U; u++) x[q][u] = ldu<false, S, NS>(xb + s[u]);                     // shared by every line group: through the caches
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const bool has = block_reads_coeff(b[q][r], false);
                     const S *cb = has ? (const S *)b[q][r].coeff : xb;                                    // no coefficient array: the input pack again (L1)
 #pragma unroll
                     for (int u = 0; u < U; u++)
-                        c[q][r][u] = has ? ld<true>(reinterpret_cast<const V *>(cb + s[u])) : ld<false>(reinterpret_cast<const V *>(cb + s[u]));
+                        c[q][r][u] = has ? ldu<true, S, NS>(cb + s[u]) : ldu<false, S, NS>(cb + s[u]);
                 }
             }
 #pragma unroll
@@ -696,7 +702,7 @@ __global__ __launch_bounds__(256) void k_general_tile(const jh_dev_block *__rest
         for (int r = 0; r < R; r++)
 #pragma unroll
             for (int u = 0; u < U; u++)
-                if (touched[r] && ok[u] && grp * R + r < nlines) st<true>(reinterpret_cast<V *>(out + line[r] * n_scalars + s[u]), acc[r][u]);
+                if (touched[r] && ok[u] && grp * R + r < nlines) st_pack<true, S, NS>(out + line[r] * n_scalars, sn[u], s[u], acc[r][u]);
     }
 }
 
@@ -747,10 +753,15 @@ __global__ __launch_bounds__(256) void k_fold_general(const S *__restrict__ slab
 }
 
 // every block boundary / coefficient pointer / vector base on a 16-byte boundary?
+// Round 5, session 3: or -- blocks of odd lengths in one slab -- every non-empty line at least one pack long and everything aligned like its scalar:
+// the 16-byte-per-lane kernels then work on under-aligned packs (knob tall_unaligned = 0: the 4-byte-per-lane kernels as before)
 bool general_vec_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
 {
-    if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & 15u) return false;
-    return op->lens_aligned16 && op->coeff_aligned16;                     // (both known since jh_blockop_create / jh_blockop_point)
+    const bool aligned = !((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & 15u) && op->lens_aligned16 && op->coeff_aligned16;   // (known since jh_blockop_create / jh_blockop_point)
+    if (aligned) return true;
+    const size_t es = jh_dtype_size(op->dtype), sa = jh_dtype_complex(op->dtype) ? es / 2 : es;
+    if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & (sa - 1)) return false;
+    return jh_ctx().tall_unaligned != 0 && op->lens_hold_a_pack && op->coeff_scalar_aligned;
 }
 
 // tiles per line and the 1-D grid of the general kernels: ceil(ntiles / 8) * 8 * nlines workgroups of 256 lanes, < 2^24
@@ -867,7 +878,7 @@ int launch_general_tile(const jh_blockop *op, const S *in, S *out, int64_t in_by
     const int64_t ngroups = four ? (nlines + 3) / 4 : (nlines + 1) / 2;
     const int U = (c.fwd_unroll == 2) ? 2 : 1;                           // two packs per lane did not pay here (knob fwd_unroll = 2: measurements)
     unsigned ntiles, grid;
-    general_grid((n_scalars / NS + 256 * U - 1) / (256 * U), ngroups, ntiles, grid, general_use_xcd(in_bytes));
+    general_grid(((n_scalars + NS - 1) / NS + 256 * U - 1) / (256 * U), ngroups, ntiles, grid, general_use_xcd(in_bytes));
     // late round 5: a SPARSE grid walks step lists built at create (k_general_tile LIST) -- per group of four lines the summed block indices at which one
     // of the lines has a non-zero block (the input pack still shared by four lines), or per line its own non-zero blocks (no dummy load at all, four
     // steps' loads in flight).  Same bits as the plain walk.  32 x 32 block-diagonal of 128^3: forward 2.9 -> 5.6 TB/s, adjoint 2.3 -> 5.5; 64 x 64 of
@@ -896,7 +907,7 @@ int launch_general_tile(const jh_blockop *op, const S *in, S *out, int64_t in_by
     c.last_general_list = list;
     if (list == 2) {
         // every line on its own: a step = a non-zero block (no dummy loads at all), four steps' loads in flight
-        general_grid((n_scalars / NS + 255) / 256, nlines, ntiles, grid, general_use_xcd(in_bytes));
+        general_grid(((n_scalars + NS - 1) / NS + 255) / 256, nlines, ntiles, grid, general_use_xcd(in_bytes));
         hipLaunchKernelGGL((k_general_tile<S, E, NS, 4, 1, TRANSPOSED, 1, true>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
                            ntiles, (unsigned)nlines, op->dev_steps[dir][1], (int)op->step_stride[dir][1]);
     } else if (list == 1)
@@ -928,7 +939,7 @@ int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
     unsigned ntiles, grid;
     const bool vec = general_vec_ok(op, d, m);
     constexpr int NS = 16 / sizeof(S);
-    int64_t want = vec ? (maxn * E / NS + 255) / 256 : (maxn + 255) / 256;     // vec: one pack per thread (see jh_vecops.hip: grid_full)
+    int64_t want = vec ? ((maxn * E + NS - 1) / NS + 255) / 256 : (maxn + 255) / 256;     // vec: one pack per thread (see jh_vecops.hip: grid_full)
     if (!vec && want > 4096) want = 4096;
     const bool gdiag = vec && !fmode && c.grid_diag && grid_diag_ok(op, d, m);  // a grid of plain diagonals: the branch-free kernel,
     const int gu = gdiag ? (c.grid_diag >= 4 ? 4 : (c.grid_diag >= 2 ? 2 : 1)) : 1;   // gu packs per lane
@@ -989,7 +1000,7 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
     unsigned ntiles, grid;
     const bool vec = general_vec_ok(op, d, m);
     constexpr int NS = 16 / sizeof(S);
-    int64_t want = vec ? (maxn * E / NS + 255) / 256 : (maxn + 255) / 256;
+    int64_t want = vec ? ((maxn * E + NS - 1) / NS + 255) / 256 : (maxn + 255) / 256;
     if (!vec && want > 4096) want = 4096;
     general_grid(want, op->ncol, ntiles, grid, general_use_xcd(op->row_off[(size_t)op->nrow] * (int64_t)(sizeof(S) * E)));
     // split walk over the block rows (general_parts); nrow >= 4 there, so every column is zeroed first (1042): all lines touched

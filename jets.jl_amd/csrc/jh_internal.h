@@ -326,6 +326,7 @@ struct jh_blockop {
     bool coeff_aligned16 = true;             // every coefficient array of a DIAG / SQUARE block starts on a 16-byte boundary (jh_blockop_create; again at jh_blockop_point,
                                              // which moves the SQUARE blocks' arrays): what the per-call route tests used to find by walking all M x K descriptors
     bool lens_aligned16 = true;              // every row and column length a multiple of 16 bytes
+    bool lens_hold_a_pack = true;            // every non-empty row and column length at least 16 bytes (the general kernels' under-aligned packs, jh_general.hip: general_vec_ok)
     bool coeff_scalar_aligned = true;        // every such array starts on a multiple of its scalar's size (what the under-aligned tall route needs, jh_tall.hip: tall_unaligned_ok)
     bool diag_strided = false;               // coeff[i] = coeff[0] + i*stride bytes
     // hipGraph replay of the per-block loop (operators with DENSE blocks: 2 launches per block), keyed on the vectors' addresses

@@ -242,3 +242,69 @@ def test_the_solver_loops_behind_the_abi_take_operators_off_the_pack_grid(Jets, 
         xc = rc.x.to_numpy().ravel(order="F").astype(dt64)
         assert np.linalg.norm(xc - x_ls) / np.linalg.norm(x_ls) < max(10 * xtol, 1e-6), solver.__name__
     J.close(A)
+
+
+# ---------------------------------------------------------------------------------- M x K grids off the pack grid (the general kernels)
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 2), (3, 4), (9, 7), (16, 16), (5, 33)])
+@pytest.mark.parametrize("n", [5, 67, 1027, 2 * 1024 * 4 + 1])
+def test_grids_of_equal_odd_blocks_have_the_oracles_bits_on_every_route(Jets, oracle, dt, shape, n):
+    """Equal blocks of an odd length: the register-tiled general kernel (2 / 4 lines per workgroup, step lists) and the one-line kernels, all on
+    under-aligned packs, against the 4-byte-per-lane kernels (tall_unaligned = 0) and the oracle: forward into a dirty d (1024), adjoint (1042-1053)."""
+    J = Jets
+    if n * np.dtype(dt).itemsize < 16:
+        pytest.skip("less than one pack per block: the 4-byte-per-lane kernels")
+    M, K = shape
+    names = ["diag", "diag_adj", "identity", "scale", "zero", "diag", "zero"]
+    kinds = [[names[(3 * i + 5 * j + (i * j) // 3) % 7] for j in range(K)] for i in range(M)]
+    A, ops = _mixed_ops(J, oracle, dt, kinds, [n] * M, [n] * K)
+    hm = [u01(oracle, dt, 31, j, n) for j in range(K)]
+    hd = [u01(oracle, dt, 32, i, n) for i in range(M)]
+    hmt = [u01(oracle, dt, 33, j, n) for j in range(K)]
+    want_d = oracle.block_df(ops, [b.copy() for b in hd], hm)
+    want_m = oracle.block_df_adj(ops, [b.copy() for b in hmt], want_d)
+    try:
+        for knobs in (dict(), dict(general_tile=2), dict(general_tile=4), dict(general_tile=0), dict(general_list=2), dict(general_list=3), dict(tall_unaligned=0)):
+            J.tune(general_tile=1, general_list=1, tall_unaligned=1)
+            J.tune(**knobs)
+            d = J.from_numpy(np.concatenate(hd), J.range(A))
+            J.mul_(d, A, J.from_numpy(np.concatenate(hm), J.domain(A)))
+            assert_bits_equal(d.to_numpy(), np.concatenate(want_d), f"{M} x {K} of {n} forward, {knobs}")
+            mt = J.from_numpy(np.concatenate(hmt), J.domain(A))
+            J.mul_(mt, A.H, d)
+            assert_bits_equal(mt.to_numpy(), np.concatenate(want_m), f"{M} x {K} of {n} adjoint, {knobs}")
+    finally:
+        J.tune(general_tile=1, general_list=1, tall_unaligned=1)
+    J.close(A)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("pattern", ["blockdiag", "bidiag", "full"])
+def test_ragged_grids_of_odd_blocks(Jets, oracle, dt, pattern):
+    """Block lengths that differ from line to line and are odd: the one-line 16-byte kernels on under-aligned packs (every line has its own last, partial
+    pack), with and without the step lists."""
+    J = Jets
+    lens = [1027, 67, 4099, 5 if np.dtype(dt).itemsize >= 8 else 9, 2051, 1027, 333, 4099, 129]
+    M = len(lens)
+    names = ["diag", "diag_adj", "identity", "scale"]
+    on = {"blockdiag": lambda i, j: i == j, "bidiag": lambda i, j: i == j or i == j + 1, "full": lambda i, j: True}[pattern]
+    # elementwise blocks are square: off-diagonal blocks of a ragged grid can only be zero blocks unless the two lengths agree
+    kinds = [[(names[(i + 2 * j) % 4] if on(i, j) and lens[i] == lens[j] else "zero") for j in range(M)] for i in range(M)]
+    A, ops = _mixed_ops(J, oracle, dt, kinds, lens, lens)
+    hm = [u01(oracle, dt, 31, j, lens[j]) for j in range(M)]
+    hd = [u01(oracle, dt, 32, i, lens[i]) for i in range(M)]
+    want_d = oracle.block_df(ops, [b.copy() for b in hd], hm)
+    want_m = oracle.block_df_adj(ops, [np.zeros(lens[j], dt) for j in range(M)], want_d)
+    try:
+        for knobs in (dict(), dict(general_list=0), dict(tall_unaligned=0)):
+            J.tune(general_list=1, tall_unaligned=1)
+            J.tune(**knobs)
+            d = J.from_numpy(np.concatenate(hd), J.range(A))
+            J.mul_(d, A, J.from_numpy(np.concatenate(hm), J.domain(A)))
+            assert_bits_equal(d.to_numpy(), np.concatenate(want_d), f"ragged {pattern} forward, {knobs}")
+            mt = J.rand(J.domain(A), seed=4, stream=4)
+            J.mul_(mt, A.H, d)
+            assert_bits_equal(mt.to_numpy(), np.concatenate(want_m), f"ragged {pattern} adjoint, {knobs}")
+    finally:
+        J.tune(general_list=1, tall_unaligned=1)
+    J.close(A)
