@@ -23,8 +23,11 @@ template <typename S, int NS> __device__ inline Pack<S, NS> ldnt(const Pack<S, N
     if constexpr (NS == 1) {
         o.v[0] = __builtin_nontemporal_load(reinterpret_cast<const S *>(p));
     } else {
+        // (round 5, session 3) the pack is addressed through a type aligned like its SCALAR: the same global_load_dwordx4, which gfx950 executes at any
+        // dword-aligned address -- a view that starts off a 16-byte boundary (block 1 of a vector of 255^3-element blocks) keeps the 16-byte-per-lane kernels
         typedef S V __attribute__((ext_vector_type(NS)));
-        V v = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+        typedef V __attribute__((aligned(alignof(S)))) UV;
+        V v = __builtin_nontemporal_load(reinterpret_cast<const UV *>(p));
         __builtin_memcpy(&o, &v, sizeof(o));
     }
     return o;
@@ -35,9 +38,10 @@ template <typename S, int NS> __device__ inline void stnt(Pack<S, NS> *p, const 
         __builtin_nontemporal_store(o.v[0], reinterpret_cast<S *>(p));
     } else {
         typedef S V __attribute__((ext_vector_type(NS)));
+        typedef V __attribute__((aligned(alignof(S)))) UV;
         V v;
         __builtin_memcpy(&v, &o, sizeof(o));
-        __builtin_nontemporal_store(v, reinterpret_cast<V *>(p));
+        __builtin_nontemporal_store(v, reinterpret_cast<UV *>(p));
     }
 }
 
@@ -458,8 +462,8 @@ __global__ void k_reduce(const S *__restrict__ x, const S *__restrict__ y, int64
             for (int e = 0; e < NS; e += E) red_elem<S, E, OP>(&xv[u].v[e], &yv[u].v[e], p, scale, a0, a1);
     }
     for (; v < nvec; v += stride) {
-        Pack<S, NS> xv = reinterpret_cast<const Pack<S, NS> *>(x)[v], yv;
-        if (OP == RED_DOT) yv = reinterpret_cast<const Pack<S, NS> *>(y)[v];
+        Pack<S, NS> xv = ldnt(reinterpret_cast<const Pack<S, NS> *>(x) + v), yv;
+        if (OP == RED_DOT) yv = ldnt(reinterpret_cast<const Pack<S, NS> *>(y) + v);
 #pragma unroll
         for (int e = 0; e < NS; e += E) red_elem<S, E, OP>(&xv.v[e], &yv.v[e], p, scale, a0, a1);
     }
@@ -498,7 +502,7 @@ int reduce_launch(const void *x, const void *y, int64_t n_elems, double p, doubl
     jh_context &c = jh_ctx();
     const int64_t n_scalars = n_elems * E;
     constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
-    const bool aligned = (((uintptr_t)x | (uintptr_t)(y ? y : x)) & 15u) == 0;
+    const bool aligned = (((uintptr_t)x | (uintptr_t)(y ? y : x)) & (sizeof(S) - 1)) == 0;   // (like the scalar: ldnt addresses its pack under-aligned)
     int grid;
     const int64_t cap = c.red_wgs > 0 ? c.red_wgs : 16384;
     auto clamp_grid = [&](int64_t packs) {
@@ -546,7 +550,7 @@ void lincomb_launch_w(void *dst, int64_t n_elems, const LincombArgs &a)
     constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
     uintptr_t bits = (uintptr_t)dst;
     for (int j = 0; j < a.k; j++) bits |= (uintptr_t)a.x[j];
-    if ((bits & 15u) == 0)
+    if ((bits & (sizeof(S) - 1)) == 0)                                     // aligned like the scalar: ldnt / stnt address their packs under-aligned
         hipLaunchKernelGGL((k_lincomb<S, E, NSV, WIDE>), dim3(grid_full(n_scalars / NSV + 1)), dim3(WG), 0, jh_ctx().stream, (S *)dst,
                            n_scalars, a);
     else
@@ -574,7 +578,7 @@ int hadamard_launch(void *dst, const void *x, const void *y, int64_t n_elems, in
     if (n_scalars == 0) return JH_OK;
     constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
     uintptr_t bits = (uintptr_t)dst | (uintptr_t)x | (uintptr_t)y;
-    if ((bits & 15u) == 0)
+    if ((bits & (sizeof(S) - 1)) == 0)
         hipLaunchKernelGGL((k_hadamard<S, E, NSV>), dim3(grid_full(n_scalars / NSV + 1)), dim3(WG), 0, jh_ctx().stream, (S *)dst,
                            (const S *)x, (const S *)y, n_scalars, conj_x);
     else
