@@ -114,14 +114,19 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
     std::string s = k_prelude;
     s += std::string("typedef ") + R + " R;\n";
     s += cplx ? "typedef cx<R> T;\n" : "typedef R T;\n";
+    // (round 5, session 3) packs are ADDRESSED through a type aligned like the scalar -- the same global_load / global_store_dwordx4, which gfx950 executes at
+    // any dword-aligned address -- and a vector whose length is not a whole number of packs loads its last pack from n - NS and stores only the scalars
+    // that pack's lane owns: a BlockArray of 255^3-element blocks (odd length, views off the 16-byte grid) keeps the 16-byte-per-lane kernel
+    const std::string A = is64 ? "8" : "4";
     s += "typedef R V __attribute__((ext_vector_type(" + std::to_string(NS) + ")));\n";
-    s += "typedef const V __attribute__((address_space(1))) *gvp;\ntypedef V __attribute__((address_space(1))) *gvq;\n";
+    s += "typedef V UV_ __attribute__((aligned(" + A + ")));\n";
+    s += "typedef const UV_ __attribute__((address_space(1))) *gvp;\ntypedef UV_ __attribute__((address_space(1))) *gvq;\n";
     s += "typedef const R __attribute__((address_space(1))) *gsp;\ntypedef R __attribute__((address_space(1))) *gsq;\n";
     // a REAL operand of a complex program (src/Jets.jl:899-904 pairs blocks whatever their eltypes; Julia's real (x) complex
     // arithmetic = the prelude's mixed operators): NS/2 reals per lane where the complex operands have NS/2 elements
-    if (cplx && NS / 2 > 1) s += "typedef R RV __attribute__((ext_vector_type(" + std::to_string(NS / 2) + ")));\n#define RGET(P, e) ((R)(P)[e])\n";
-    else s += "typedef R RV;\n#define RGET(P, e) ((R)(P))\n";
-    s += "typedef const RV __attribute__((address_space(1))) *grvp;\n";
+    if (cplx && NS / 2 > 1) s += "typedef R RV __attribute__((ext_vector_type(" + std::to_string(NS / 2) + ")));\ntypedef RV URV_ __attribute__((aligned(" + A + ")));\n#define RGET(P, e) ((R)(P)[e])\n";
+    else s += "typedef R RV;\ntypedef R URV_;\n#define RGET(P, e) ((R)(P))\n";
+    s += "typedef const URV_ __attribute__((address_space(1))) *grvp;\n";
     auto is_real = [&](int k) { return cplx && ((real_mask >> k) & 1); };
     // element accessors on a pack
     if (!cplx) {
@@ -147,18 +152,23 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
     }
     // ---- 16 bytes per lane
     s += "extern \"C\" __global__ __launch_bounds__(256) void jh_bcast_vec(" + params + ")\n{\n" + scal;
-    s += "    const long nvec = n_scalars / " + std::to_string(NS) + ";\n";
+    const std::string NSs = std::to_string(NS);
+    // pack v nominally starts at scalar s_ = v * NS and is loaded from c_: s_, or n - NS for the last, partial pack (n_scalars >= NS: the host checks)
+    const std::string pack_pos = "        const long s_ = v * " + NSs + ", c_ = s_ + " + NSs + " <= n_scalars ? s_ : n_scalars - " + NSs + ";\n";
+    const std::string pack_store = "        if (c_ == s_) __builtin_nontemporal_store(r_, (gvq)(dst_ + c_));\n"
+                                   "        else {\n#pragma unroll\n            for (int e = 0; e < " + NSs + "; e++) if (c_ + e >= s_) ((gsq)dst_)[c_ + e] = r_[e];\n        }\n";
+    s += "    const long nvec = (n_scalars + " + NSs + " - 1) / " + NSs + ";\n";
     s += "    const long stride = (long)gridDim.x * 256;\n";
-    s += "    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {\n";
+    s += "    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {\n" + pack_pos;
     for (int k = 0; k < nvec; k++)
-        s += is_real(k) ? "        const RV X" + std::to_string(k) + " = __builtin_nontemporal_load((grvp)p" + std::to_string(k) + " + v);\n"
-                        : "        const V X" + std::to_string(k) + " = __builtin_nontemporal_load((gvp)p" + std::to_string(k) + " + v);\n";
+        s += is_real(k) ? "        const RV X" + std::to_string(k) + " = __builtin_nontemporal_load((grvp)(p" + std::to_string(k) + " + c_ / 2));\n"
+                        : "        const V X" + std::to_string(k) + " = __builtin_nontemporal_load((gvp)(p" + std::to_string(k) + " + c_));\n";
     s += "        V r_;\n#pragma unroll\n        for (int e = 0; e < " + std::to_string(NS / E) + "; e++) {\n";
     for (int k = 0; k < nvec; k++)
         s += is_real(k) ? "            const R x" + std::to_string(k) + " = RGET(X" + std::to_string(k) + ", e);\n"
                         : "            const T x" + std::to_string(k) + " = GET(X" + std::to_string(k) + ", e);\n";
     s += "            const T val_ = (T)(" + expr + ");\n            PUT(r_, e, val_);\n        }\n";
-    s += "        __builtin_nontemporal_store(r_, (gvq)dst_ + v);\n    }\n}\n";
+    s += pack_store + "    }\n}\n";
     // ---- 16 bytes per lane, batched: item blockIdx.y takes its destination, operands and scalars from device tables
     // (jh_bcast_apply_many: the children of a tall nonlinear operator in ONE launch instead of one launch per child)
     // item_fast_: the ITEM is the fastest block index (workgroups that read the same pack of a shared operand -- the model
@@ -181,20 +191,20 @@ std::string build_source(const std::string &expr, int dtype, int nvec, int nscal
         s += "    const " + sreal(k) + " sr" + i + " = (" + sreal(k) + ")srow_[" + std::to_string(2 * k) + "], si" + i + " = (" + sreal(k) + ")srow_[" + std::to_string(2 * k + 1) + "];\n";
     }
     s += scal;
-    s += "    const long nvec = n_scalars / " + std::to_string(NS) + ";\n";
+    s += "    const long nvec = (n_scalars + " + NSs + " - 1) / " + NSs + ";\n";
     s += "    const long stride = ntile_ * 256;\n";
-    s += "    for (long v = tile_ * 256 + threadIdx.x; v < nvec; v += stride) {\n";
+    s += "    for (long v = tile_ * 256 + threadIdx.x; v < nvec; v += stride) {\n" + pack_pos;
     // an operand every item shares is loaded through the caches (bit k of shared_mask_), the streamed ones nontemporally
     for (int k = 0; k < nvec; k++)
         s += std::string("        const ") + (is_real(k) ? "RV" : "V") + " X" + std::to_string(k) + " = ((shared_mask_ >> " + std::to_string(k) + ") & 1) ? *((" +
-             (is_real(k) ? "grvp" : "gvp") + ")p" + std::to_string(k) + " + v) : __builtin_nontemporal_load((" + (is_real(k) ? "grvp" : "gvp") + ")p" +
-             std::to_string(k) + " + v);\n";
+             (is_real(k) ? "grvp" : "gvp") + ")(p" + std::to_string(k) + (is_real(k) ? " + c_ / 2" : " + c_") + ")) : __builtin_nontemporal_load((" + (is_real(k) ? "grvp" : "gvp") + ")(p" +
+             std::to_string(k) + (is_real(k) ? " + c_ / 2" : " + c_") + "));\n";
     s += "        V r_;\n#pragma unroll\n        for (int e = 0; e < " + std::to_string(NS / E) + "; e++) {\n";
     for (int k = 0; k < nvec; k++)
         s += is_real(k) ? "            const R x" + std::to_string(k) + " = RGET(X" + std::to_string(k) + ", e);\n"
                         : "            const T x" + std::to_string(k) + " = GET(X" + std::to_string(k) + ", e);\n";
     s += "            const T val_ = (T)(" + expr + ");\n            PUT(r_, e, val_);\n        }\n";
-    s += "        __builtin_nontemporal_store(r_, (gvq)dst_ + v);\n    }\n}\n";
+    s += pack_store + "    }\n}\n";
     // ---- one element per lane
     s += "extern \"C\" __global__ __launch_bounds__(256) void jh_bcast_scalar(" + params + ")\n{\n" + scal;
     s += "    const long nel = n_scalars / " + std::to_string(E) + ";\n";
@@ -397,7 +407,7 @@ int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, co
     const bool cplx = jh_dtype_complex(bc->dtype), is64 = (bc->dtype == JH_F64 || bc->dtype == JH_C64);
     const int64_t n_scalars = dst->length * (cplx ? 2 : 1);
     const int NS = is64 ? 2 : 4;
-    const bool vec_ok = ((bits & 15u) == 0) && (n_scalars % NS == 0);
+    const bool vec_ok = ((bits & (uintptr_t)(is64 ? 7u : 3u)) == 0) && n_scalars >= NS;   // aligned like the scalar, at least one pack (the kernel's packs are under-aligned, its last one partial)
     // kernel arguments: dst, p0.., (sr, si).., n_scalars
     void *dptr = dst->data;
     const void *ptrs[JH_BCAST_MAX_VEC];
@@ -413,7 +423,7 @@ int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, co
         else { sf[k] = (float)scal_re_im[k]; args[na++] = &sf[k]; }
     }
     args[na++] = &n_arg;
-    const int64_t work = vec_ok ? n_scalars / NS : dst->length;
+    const int64_t work = vec_ok ? (n_scalars + NS - 1) / NS : dst->length;
     int64_t grid = (work + 255) / 256;
     if (grid > ((int64_t)1 << 23)) grid = (int64_t)1 << 23;              // grid x 256 threads < 2^32; the kernel strides
     const jh_bcast::on_device *fns = nullptr;
@@ -490,19 +500,20 @@ static int apply_many_batched(int count, const jh_bcast *const *progs, jh_bvec *
         if (dsts[k]->ctx != dsts[0]->ctx) return JH_OK;                      // (the item-by-item path works context by context)
         if ((bc->nvec > 0 && !xs) || (bc->nscal > 0 && !scal_re_im)) return JH_OK;
         const int NS = (bc->dtype == JH_F64 || bc->dtype == JH_C64) ? 2 : 4;
-        if ((dsts[k]->length * (jh_dtype_complex(bc->dtype) ? 2 : 1)) % NS != 0) return JH_OK;
+        if ((dsts[k]->length * (jh_dtype_complex(bc->dtype) ? 2 : 1)) < NS) return JH_OK;      // (less than one pack: item by item, the scalar kernel)
         xoff[(size_t)k] = ix;
         soff[(size_t)k] = is;
-        bits |= (uintptr_t)dsts[k]->data;
+        bits = (uintptr_t)dsts[k]->data;
         for (int j = 0; j < bc->nvec; j++) {
             const jh_bvec *x = xs[ix + j];
             if (!x || x->dtype != bc->dtype || x->length != dsts[k]->length || x->ctx != dsts[k]->ctx) return JH_OK;
             bits |= (uintptr_t)x->data;
         }
+        // aligned like the scalar (device arrays of the element type are; a raw wrapped pointer need not be): the kernel's packs are under-aligned
+        if (bits & (uintptr_t)(NS == 2 ? 7u : 3u)) return JH_OK;
         ix += bc->nvec;
         is += 2 * bc->nscal;
     }
-    if (bits & 15u) return JH_OK;
     {   // one launch has no order between items: an operand must not overlap ANOTHER item's destination (its own is fine, elementwise)
         std::vector<std::pair<uintptr_t, int>> dst_lo((size_t)count);
         auto nbytes = [&](int k) { return (size_t)dsts[k]->length * jh_dtype_size(dsts[k]->dtype); };
@@ -583,7 +594,7 @@ static int apply_many_batched(int count, const jh_bcast *const *progs, jh_bvec *
         const int NS = is64 ? 2 : 4;
         const int64_t n_scalars = g.len * (cplx ? 2 : 1);
         const int gcount = (int)g.items.size();
-        int64_t gx = (n_scalars / NS + 255) / 256;
+        int64_t gx = ((n_scalars + NS - 1) / NS + 255) / 256;
         if (gx > 65535) gx = 65535;                           // the kernel strides
         // an operand every item of the group shares (the model vector of F(m) / point!) is loaded through the caches; beyond
         // 32 MiB per vector the items also become the fastest block index, so that it is read from HBM once per XCD instead of

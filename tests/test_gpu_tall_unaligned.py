@@ -308,3 +308,46 @@ def test_ragged_grids_of_odd_blocks(Jets, oracle, dt, pattern):
     finally:
         J.tune(general_list=1, tall_unaligned=1)
     J.close(A)
+
+
+# ---------------------------------------------------------------------------------- JIT broadcast off the pack grid
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [5, 7, 1027, 4099, 2 * 1024 * 4 + 1])
+def test_broadcast_on_odd_lengths_and_views_off_the_grid_is_bit_exact(Jets, oracle, dt, n):
+    """The 16-byte-per-lane JIT kernel on under-aligned packs with a partial last pack (src/Jets.jl:889-911): whole vectors of odd length, blocks that start
+    off the 16-byte grid, in place (dst aliases an operand), and many such items in ONE launch -- numpy's bits (every operation rounded as written)."""
+    J = Jets
+    T = np.dtype(dt).type
+    count = 9
+    R = J.JetBSpace([J.JetSpace(dt, n)] * count)
+    u, v = J.rand(R, seed=1, stream=0), J.rand(R, seed=2, stream=0)
+    hu, hv = u01(oracle, dt, 1, 0, count * n), u01(oracle, dt, 2, 0, count * n)
+    a, b = T(0.37), T(-1.25)
+    x = J.zeros(R)
+    J.broadcast_(x, "s0*x0 + s1*x1*x0", [u, v], [a, b])
+    want = a * hu + (b * hv) * hu
+    assert_bits_equal(x.to_numpy(), want, "whole vector")
+    # block by block (every block but the first few starts off the grid), into a dirty destination whose neighbours must not change
+    y = J.rand(R, seed=3, stream=0)
+    hy = u01(oracle, dt, 3, 0, count * n)
+    for k in (1, 2, 3, 6):
+        J.broadcast_(y.arrays[k], "s0*x0 + s1*x1*x0", [u.arrays[k], v.arrays[k]], [a, b])
+        hy[k * n:(k + 1) * n] = want[k * n:(k + 1) * n]
+    assert_bits_equal(y.to_numpy(), hy, "single blocks: their bits, and nothing outside them")
+    # in place
+    z = J.rand(R, seed=4, stream=0)
+    hz = u01(oracle, dt, 4, 0, count * n)
+    J.broadcast_(z, "x0*x0 + x1", [z, u], [])
+    assert_bits_equal(z.to_numpy(), hz * hz + hu, "in place, whole vector")
+    J.broadcast_(z.arrays[5], "x0 + x0", [z.arrays[5]], [])
+    hz = hz * hz + hu
+    hz[5 * n:6 * n] = hz[5 * n:6 * n] + hz[5 * n:6 * n]
+    assert_bits_equal(z.to_numpy(), hz, "in place, one block off the grid")
+    # many items in one launch
+    one, many = J.zeros(R), J.zeros(R)
+    for k in range(count):
+        J.broadcast_(one.arrays[k], "s0*x0*x1 + s1", [u.arrays[k], v.arrays[k]], [0.5 + k, -0.25 * k])
+    J.broadcast_many_((many.arrays[k], "s0*x0*x1 + s1", [u.arrays[k], v.arrays[k]], [0.5 + k, -0.25 * k]) for k in range(count))
+    assert many.to_numpy().tobytes() == one.to_numpy().tobytes()
+    if n * np.dtype(dt).itemsize >= 16:
+        assert_bits_equal(one.to_numpy()[n:2 * n], T(1.5) * hu[n:2 * n] * hv[n:2 * n] + T(-0.25), "item 1 of the batch")
