@@ -230,8 +230,8 @@ int jh_bcast_check_typed(const char *expr, int dtype, int nvec, int real_mask, i
 int jh_bcast_apply(const jh_bcast *bc, jh_bvec *dst, const jh_bvec *const *x, const double *scal_re_im);
 /* `count` broadcasts in one call (a tall nonlinear operator evaluates one per child: F(m) and point! are `count` launches
  * enqueued back to back instead of `count` trips through the host language).  Operand k's vectors and scalars follow
- * each other in the flattened lists `x` (sum of nvec entries) and `scal_re_im` (2 * sum of nscal doubles).  When every pointer is
- * 16-byte aligned and no operand overlaps another item's destination (the items then have no order among them), items that
+ * each other in the flattened lists `x` (sum of nvec entries) and `scal_re_im` (2 * sum of nscal doubles).  When every item holds
+ * at least one 16-byte pack and no operand overlaps another item's destination (the items then have no order among them), items that
  * share a program and a length run as ONE launch (same bits); otherwise the items are launched in order. */
 int jh_bcast_apply_many(int count, const jh_bcast *const *progs, jh_bvec *const *dsts, const jh_bvec *const *x, const double *scal_re_im);
 int jh_bcast_destroy(jh_bcast *bc);
@@ -264,6 +264,14 @@ int jh_blockop_destroy(jh_blockop *op);
  * Tall, wide and M x K operators made of un-adjointed DENSE blocks of one shape (tall ones may differ in row counts) run
  * batched GEMV kernels: every child in one launch. */
 int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m);
+/* BLOCK LENGTHS NEED NOT BE MULTIPLES OF 16 BYTES (round 5).  A block vector is one contiguous slab (src/Jets.jl:742-748), so with blocks of 101^3 Float32
+ * elements most blocks start off a 16-byte boundary and end inside a 16-byte pack.  The fused kernels address their packs under-aligned and treat a
+ * row's last, partial pack separately: jh_blockop_mul / _mul_adj / _normal_mul / _f (tall, wide and M x K operators of elementwise blocks),
+ * jh_blockop_mul_axpby / _mul_scaled, jh_blockop_bidiag_step and the one-shard solver loops built on them (jh_lsqr_solve, jh_cgls_solve, jh_cgnr_solve),
+ * the block-vector primitives and jh_bcast_apply[_many] -- same bits as on aligned blocks' kernels (the same terms in the same order).  What still asks for
+ * 16-byte aligned blocks: the *_range calls and the partitioned / team solvers built on them, jh_blockop_mul_adj_axpby / _mul_adj_scaled, the fused sums
+ * (jh_blocksum_*) and the graph-replayed small-operator loops -- their callers fall back to compositions of the calls above (JH_ERR_UNSUPPORTED comes
+ * before anything is touched).  jh_tune_set("tall_unaligned", 0) restores the 4-byte-per-lane kernels of rounds 1-4 for such operators. */
 /* mul!(m, A', d) -> JetBlock_df'!, src/Jets.jl:1034-1057: m zeroed when nrow > 1 (1042), rows summed
  * in order i = 0..nrow-1 with the product rounded before the add (1049) => bit-exact on one GPU.
  * Exception, automatic from 256 rows on when a block is too small to fill the chip with one thread per 16 bytes of the
@@ -473,7 +481,9 @@ int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, 
  * nothing: 1 automatic -- only when the lists leave out an eighth of the steps; four-line lists, per-line lists or the plain walk by measurement, see
  * "gen_walk_fwd" below --, 0 never, 2 / 3 always the four-line / per-line lists; same bits; counter "last_general_list": 0 plain, 1 four-line, 2 per-line),
  * "wide_twin" (1 x K elementwise operators on the tall kernels through their tall twin: 1 automatic -- the adjoint always, the forward
- * from 16 MiB blocks --, 0 never: the general kernels, 2 both always);
+ * from 16 MiB blocks --, 0 never: the general kernels, 2 both always), "tall_unaligned" (round 5: operators whose blocks are not whole, 16-byte
+ * aligned packs -- odd block lengths in one slab -- on the 16-byte-per-lane kernels with under-aligned packs: 1 yes, 0 the 4-byte-per-lane kernels
+ * of rounds 1-4; same bits);
  * round 4: "cg_dev" (jh_cgls_solve / jh_cgnr_solve with the recurrences on the device, graph-replayed unless lsqr_graph = 0: 1 automatic -- CGLS
  * like lsqr_graph, CG through the fused A'A up to 2 GiB of coefficients --, 2 at any size, 0 never: the host loops; within solver tolerance
  * of each other), "dense_fused" (adjoint of many small DENSE children / forward of a 1 x K operator of them in ONE fused launch + fold: 1
