@@ -268,9 +268,9 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m);
  * elements most blocks start off a 16-byte boundary and end inside a 16-byte pack.  The fused kernels address their packs under-aligned and treat a
  * row's last, partial pack separately: jh_blockop_mul / _mul_adj / _normal_mul / _f (tall, wide and M x K operators of elementwise blocks),
  * jh_blockop_mul_axpby / _mul_scaled, jh_blockop_bidiag_step and the one-shard solver loops built on them (jh_lsqr_solve, jh_cgls_solve, jh_cgnr_solve),
- * the block-vector primitives and jh_bcast_apply[_many] -- same bits as on aligned blocks' kernels (the same terms in the same order).  What still asks for
- * 16-byte aligned blocks: the *_range calls and the partitioned / team solvers built on them, jh_blockop_mul_adj_axpby / _mul_adj_scaled, the fused sums
- * (jh_blocksum_*) and the graph-replayed small-operator loops -- their callers fall back to compositions of the calls above (JH_ERR_UNSUPPORTED comes
+ * the fused sums (jh_blocksum_*), the block-vector primitives and jh_bcast_apply[_many] -- same bits as on aligned blocks' kernels (the same terms in the
+ * same order).  What still asks for 16-byte aligned blocks: the *_range calls and the partitioned / team solvers built on them,
+ * jh_blockop_mul_adj_axpby / _mul_adj_scaled and the graph-replayed small-operator loops -- their callers fall back to compositions of the calls above (JH_ERR_UNSUPPORTED comes
  * before anything is touched).  jh_tune_set("tall_unaligned", 0) restores the 4-byte-per-lane kernels of rounds 1-4 for such operators. */
 /* mul!(m, A', d) -> JetBlock_df'!, src/Jets.jl:1034-1057: m zeroed when nrow > 1 (1042), rows summed
  * in order i = 0..nrow-1 with the product rounded before the add (1049) => bit-exact on one GPU.

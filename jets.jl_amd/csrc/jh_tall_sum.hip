@@ -25,6 +25,8 @@ constexpr int JH_SUM_ADJ_MAX = 8;
 // block TABLES (every term's row pointer is read, all scalar loads issued together) is a template parameter; terms beyond k are filled
 // with term 0's addresses on the host -- their loads are L1 hits, their arithmetic is computed and dropped by a wave-uniform select --
 // and sign * scale arrives as ONE factor per term.
+// Round 5, session 3: rows need not be whole, 16-byte aligned packs (odd block lengths in one slab, jh_tall.hip: tall_unaligned_ok) -- every access of
+// these kernels is an under-aligned pack (ldu), a row's last pack is loaded from n - NS and stored from its own first scalar on (st_pack).
 struct SumArgs {
     const void *a0[JH_SUM_MAX];          // STRIDED: row 0 of term t's coefficients; else term t's device block table (jh_dev_block *)
     int64_t stride;                      // STRIDED: scalars from one row to the next (the same for every term)
@@ -59,8 +61,8 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow
 #pragma unroll
     for (int k = 0; k < U; k++) {
         ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
-        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
-        mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
+        sk[k] = ok[k] ? pack_start<NS>(s0 + (int64_t)k * BLK * NS, n_scalars) : 0;
+        mv[k] = ldu<false, S, NS>(m + sk[k]);
     }
     // D rows per iteration, their D x KM coefficient packs (x U) in flight (D = 1: one row).  The row loop is kept rolled: left to itself the
     // compiler unrolls the eight-stream shape to 241 VGPRs (one wave per SIMD: 1.6 TB/s).  A row beyond the group's last re-reads that
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow
                 for (int t = 0; t < KM; t++) {
                     const S *a = (const S *)args.a0[t] + roff;
 #pragma unroll
-                    for (int k = 0; k < U; k++) av[j][t][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+                    for (int k = 0; k < U; k++) av[j][t][k] = ldu<true, S, NS>(a + sk[k]);
                 }
             } else {
                 const S *ap[KM];
@@ -86,11 +88,11 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow
 #pragma unroll
                 for (int t = 0; t < KM; t++)
 #pragma unroll
-                    for (int k = 0; k < U; k++) av[j][t][k] = ld<true>(reinterpret_cast<const V *>(ap[t] + sk[k]));
+                    for (int k = 0; k < U; k++) av[j][t][k] = ldu<true, S, NS>(ap[t] + sk[k]);
             }
 #pragma unroll
             for (int k = 0; k < U; k++)
-                dv[j][k] = accumulate ? ld<true>(reinterpret_cast<const V *>(d + ij * n_scalars + sk[k])) : (V)(S)0;   // d .= 0  (639-640)
+                dv[j][k] = accumulate ? ldu<true, S, NS>(d + ij * n_scalars + sk[k]) : (V)(S)0;   // d .= 0  (639-640)
         }
 #pragma unroll
         for (int j = 0; j < D; j++)
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow
                     const V sum = acc + term;                                        // broadcast!(sgn, d, d, _d)
                     acc = (t < args.k) ? sum : acc;                                  // (a term beyond k: dropped, wave-uniform)
                 }
-                if (ok[k] && i + j < i1) st<true>(reinterpret_cast<V *>(d + (i + j) * n_scalars + sk[k]), acc);
+                if (ok[k] && i + j < i1) st_pack<true, S, NS>(d + (i + j) * n_scalars, s0 + (int64_t)k * BLK * NS, sk[k], acc);
             }
     }
 }
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow
 #pragma unroll
     for (int k = 0; k < U; k++) {
         ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
-        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
+        sk[k] = ok[k] ? pack_start<NS>(s0 + (int64_t)k * BLK * NS, n_scalars) : 0;
 #pragma unroll
         for (int t = 0; t < KM; t++) acc[t][k] = (V)(S)0;
     }
@@ -146,14 +148,14 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow
 #pragma unroll
         for (int j = 0; j < D; j++) {
 #pragma unroll
-            for (int k = 0; k < U; k++) dv[j][k] = ld<true>(reinterpret_cast<const V *>(in + (i + j) * n_scalars + sk[k]));
+            for (int k = 0; k < U; k++) dv[j][k] = ldu<true, S, NS>(in + (i + j) * n_scalars + sk[k]);
             if constexpr (STRIDED) {
                 const int64_t roff = (i + j) * args.stride;
 #pragma unroll
                 for (int t = 0; t < KM; t++) {
                     const S *a = (const S *)args.a0[t] + roff;
 #pragma unroll
-                    for (int k = 0; k < U; k++) av[j][t][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+                    for (int k = 0; k < U; k++) av[j][t][k] = ldu<true, S, NS>(a + sk[k]);
                 }
             } else {
                 const S *ap[KM];
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow
 #pragma unroll
                 for (int t = 0; t < KM; t++)
 #pragma unroll
-                    for (int k = 0; k < U; k++) av[j][t][k] = ld<true>(reinterpret_cast<const V *>(ap[t] + sk[k]));
+                    for (int k = 0; k < U; k++) av[j][t][k] = ldu<true, S, NS>(ap[t] + sk[k]);
             }
         }
 #pragma unroll
@@ -186,13 +188,13 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow
     for (; i < nrow; i++) batch(i, std::integral_constant<int, 1>{});
 #pragma unroll
     for (int k = 0; k < U; k++) {
-        V r = accumulate ? ld<false>(reinterpret_cast<const V *>(out + sk[k])) : (V)(S)0;   // m .= 0  (648-649), or the sum so far
+        V r = accumulate ? ldu<false, S, NS>(out + sk[k]) : (V)(S)0;   // m .= 0  (648-649), or the sum so far
 #pragma unroll
         for (int t = 0; t < KM; t++) {
             const V sum = r + sum_sign<S>(args, t) * acc[t][k];                  // broadcast!(sgn, m, m, _m)
             r = (t < args.k) ? sum : r;
         }
-        if (ok[k]) st<false>(reinterpret_cast<V *>(out + sk[k]), r);
+        if (ok[k]) st_pack<false, S, NS>(out, s0 + (int64_t)k * BLK * NS, sk[k], r);
     }
 }
 
@@ -216,8 +218,8 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd_few(SumArgs args, int64_t 
 #pragma unroll
     for (int k = 0; k < U; k++) {
         ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
-        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
-        mv[k] = ld<false>(reinterpret_cast<const V *>(m + sk[k]));
+        sk[k] = ok[k] ? pack_start<NS>(s0 + (int64_t)k * BLK * NS, n_scalars) : 0;
+        mv[k] = ldu<false, S, NS>(m + sk[k]);
     }
     // D rows' loads in flight.  The row loop is kept rolled: left to itself the compiler unrolls the eight-stream shape to 241 VGPRs
     // (one wave per SIMD: 1.6 TB/s)
@@ -232,11 +234,11 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd_few(SumArgs args, int64_t 
                 if (t < args.k) {
                     const S *a = STRIDED ? (const S *)args.a0[t] + ij * args.stride : (const S *)((const jh_dev_block *)args.a0[t])[ij].coeff;
 #pragma unroll
-                    for (int k = 0; k < U; k++) av[j][t][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+                    for (int k = 0; k < U; k++) av[j][t][k] = ldu<true, S, NS>(a + sk[k]);
                 }
 #pragma unroll
             for (int k = 0; k < U; k++)
-                dv[j][k] = accumulate ? ld<true>(reinterpret_cast<const V *>(d + ij * n_scalars + sk[k])) : (V)(S)0;   // d .= 0  (639-640)
+                dv[j][k] = accumulate ? ldu<true, S, NS>(d + ij * n_scalars + sk[k]) : (V)(S)0;   // d .= 0  (639-640)
         }
 #pragma unroll
         for (int j = 0; j < D; j++)
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd_few(SumArgs args, int64_t 
                         }
                         acc = acc + term;                                            // broadcast!(sgn, d, d, _d)
                     }
-                if (ok[k] && i + j < i1) st<true>(reinterpret_cast<V *>(d + (i + j) * n_scalars + sk[k]), acc);
+                if (ok[k] && i + j < i1) st_pack<true, S, NS>(d + (i + j) * n_scalars, s0 + (int64_t)k * BLK * NS, sk[k], acc);
             }
     }
 }
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_adj_few(SumArgs args, int64_t 
 #pragma unroll
     for (int k = 0; k < U; k++) {
         ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
-        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
+        sk[k] = ok[k] ? pack_start<NS>(s0 + (int64_t)k * BLK * NS, n_scalars) : 0;
 #pragma unroll
         for (int t = 0; t < KM; t++) acc[t][k] = (V)(S)0;
     }
@@ -286,13 +288,13 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_adj_few(SumArgs args, int64_t 
         for (int j = 0; j < DEPTH; j++)
             if (i + j < nrow) {
 #pragma unroll
-                for (int k = 0; k < U; k++) dv[j][k] = ld<true>(reinterpret_cast<const V *>(in + (i + j) * n_scalars + sk[k]));
+                for (int k = 0; k < U; k++) dv[j][k] = ldu<true, S, NS>(in + (i + j) * n_scalars + sk[k]);
 #pragma unroll
                 for (int t = 0; t < KM; t++)
                     if (t < args.k) {
                         const S *a = STRIDED ? (const S *)args.a0[t] + (i + j) * args.stride : (const S *)((const jh_dev_block *)args.a0[t])[i + j].coeff;
 #pragma unroll
-                        for (int k = 0; k < U; k++) av[j][t][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
+                        for (int k = 0; k < U; k++) av[j][t][k] = ldu<true, S, NS>(a + sk[k]);
                     }
             }
 #pragma unroll
@@ -318,11 +320,11 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_adj_few(SumArgs args, int64_t 
     }
 #pragma unroll
     for (int k = 0; k < U; k++) {
-        V r = accumulate ? ld<false>(reinterpret_cast<const V *>(out + sk[k])) : (V)(S)0;   // m .= 0  (648-649), or the sum so far
+        V r = accumulate ? ldu<false, S, NS>(out + sk[k]) : (V)(S)0;   // m .= 0  (648-649), or the sum so far
 #pragma unroll
         for (int t = 0; t < KM; t++)
             if (t < args.k) r = r + sum_sign<S>(args, t) * acc[t][k];            // broadcast!(sgn, m, m, _m)
-        if (ok[k]) st<false>(reinterpret_cast<V *>(out + sk[k]), r);
+        if (ok[k]) st_pack<false, S, NS>(out, s0 + (int64_t)k * BLK * NS, sk[k], r);
     }
 }
 
@@ -345,8 +347,8 @@ static int sum_prepare(int nterms, const jh_blockop *const *ops, const double *s
         const jh_blockop *op = ops[t];
         JH_REQUIRE(op, "%s: null operator %d", who, t);
         JH_TRY(check_vectors(op, rng, dom, who));
-        if (!tall_fast_ok(op, rng->data, dom->data))
-            return jh_fail(JH_ERR_UNSUPPORTED, "%s: term %d is not a tall all-DIAG operator with equal, 16-byte aligned blocks", who, t);
+        if (!tall_fast_ok(op, rng->data, dom->data) && !(op->all_diag && tall_unaligned_ok(op, rng->data, dom->data)))   // (rows off the 16-byte pack grid: under-aligned packs)
+            return jh_fail(JH_ERR_UNSUPPORTED, "%s: term %d is not a tall all-DIAG operator with equal blocks", who, t);
         JH_REQUIRE(op->nrow == ops[0]->nrow && op->row_len[0] == ops[0]->row_len[0] && op->dtype == ops[0]->dtype,
                    "%s: term %d has a different shape or element type", who, t);
         JH_REQUIRE(sign[t] == 1.0 || sign[t] == -1.0, "%s: sign %d must be +1 or -1", who, t);
@@ -389,7 +391,7 @@ static int sum_fwd_launch(const SumArgs &a, bool strided, const jh_blockop *op0,
     const int U = a.k > 8 ? 1 : 2;
     int G = c.fwd_group > 0 ? (int)c.fwd_group : (a.k > 4 ? 1 : 2);                       // rows per workgroup (knob fwd_group: sweeps)
     if (G > op0->nrow) G = (int)op0->nrow;
-    const int64_t nvec = n_scalars / NS;
+    const int64_t nvec = (n_scalars + NS - 1) / NS;
     const int64_t gx = (nvec + (int64_t)BLK * U - 1) / ((int64_t)BLK * U);
     int64_t gy = (op0->nrow + G - 1) / G;
     while (gx * gy * BLK >= ((int64_t)1 << 32) && G < op0->nrow) { G *= 2; gy = (op0->nrow + G - 1) / G; }
@@ -436,7 +438,7 @@ static int sum_adj_split(int nterms, const jh_blockop *const *ops, const double 
     const int dtype = ops[0]->dtype;
     const int64_t n_elems = n_scalars / E;
     for (int t = 0; t < nterms; t++) {
-        JH_TRY(jhb::tall_adj(ops[t], tmp, d, 0, false));
+        JH_TRY(jhb::tall_adj(ops[t], tmp, d, 0, !tall_fast_ok(ops[t], d, tmp)));   // (rows off the pack grid: the MIXED instantiations)
         const double cre[2] = {t == 0 ? sign[t] * scale[t] : 1.0, sign[t] * scale[t]}, cim[2] = {0.0, 0.0};
         const void *xs[2] = {t == 0 ? tmp : m, tmp};
         JH_TRY(jh_launch_lincomb_raw(m, dtype, n_elems, t == 0 ? 1 : 2, cre, cim, xs));
@@ -451,7 +453,7 @@ static int sum_adj_launch(const SumArgs &a, bool strided, const jh_blockop *op0,
     c.last_adj_parts = 1;
     constexpr int BLK = 256, DEPTH = 2;
     const int U = a.k > 4 ? 1 : 2;
-    const int64_t nvec = n_scalars / NS;
+    const int64_t nvec = (n_scalars + NS - 1) / NS;
     const int64_t gx = (nvec + (int64_t)BLK * U - 1) / ((int64_t)BLK * U);
 #define JH_SUM_ADJ_K(UU, DD, KM, ST, WD)                                                                                              \
     hipLaunchKernelGGL((k_tall_sum_adj<S, E, NS, UU, DD, BLK, KM, ST, WD>), dim3((unsigned)gx), dim3(BLK), 0, c.stream, a, op0->nrow, (S *)m, \

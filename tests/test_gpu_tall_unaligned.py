@@ -351,3 +351,65 @@ def test_broadcast_on_odd_lengths_and_views_off_the_grid_is_bit_exact(Jets, orac
     assert many.to_numpy().tobytes() == one.to_numpy().tobytes()
     if n * np.dtype(dt).itemsize >= 16:
         assert_bits_equal(one.to_numpy()[n:2 * n], T(1.5) * hu[n:2 * n] * hv[n:2 * n] + T(-0.25), "item 1 of the batch")
+
+
+# ---------------------------------------------------------------------------------- fused JetSum off the pack grid
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64])
+@pytest.mark.parametrize("nterms", [2, 4, 7, 11, 16, 19])
+@pytest.mark.parametrize("n", [1027, 4099])
+def test_the_fused_jetsum_takes_odd_blocks_with_the_chains_bits(Jets, oracle, dt, nterms, n):
+    """JetSum of tall diagonal operators of an odd block length (src/Jets.jl:628-655): the fused kernels (four / eight / twelve / sixteen streams per
+    launch, later launches continuing the sum) on under-aligned packs -- jh_blocksum_mul_typed itself must accept the operators -- bit-identical to
+    the unfused chain d .= 0; d = d +- s_t (A_t m); same for the adjoint."""
+    import ctypes as C
+
+    from jets_jl_amd._ffi import check, lib
+
+    J = Jets
+    nrow = 5
+    spc = J.JetSpace(dt, n)
+    ops, hcoef = [], []
+    for t in range(nterms):
+        slab = J.rand(J.JetBSpace([spc] * nrow), seed=90 + t, stream=0)                 # one slab per term: rows off the grid, one stride (STRIDED addressing)
+        if t % 3 == 2:                                                                # ... and every third term from separate arrays (the block TABLES)
+            arrs = [J.rand(spc, seed=90 + t, stream=100 + i) for i in range(nrow)]
+            hcoef.append([u01(oracle, dt, 90 + t, 100 + i, n) for i in range(nrow)])
+        else:
+            arrs = slab.arrays
+            hcoef.append([g.copy() for g in np.split(slab.to_numpy(), nrow)])
+        ops.append(J.blockop([[J.JopDiagonal(a)] for a in arrs]))
+    scales = [1.0 if t % 3 else 0.5 + t for t in range(nterms)]
+    signs = [1.0 if t % 2 == 0 else -1.0 for t in range(nterms)]
+    hm = u01(oracle, dt, 2, 0, n)
+    hd = [u01(oracle, dt, 3, i, n) for i in range(nrow)]
+    want = [np.zeros(n, dt) for _ in range(nrow)]
+    want_m = [np.zeros(n, dt)]
+    for t in range(nterms):
+        ora = [[oracle.Block("diag", n, coeff=c)] for c in hcoef[t]]
+        tmp = oracle.block_df(ora, [np.zeros(n, dt) for _ in range(nrow)], [hm])
+        if scales[t] != 1.0:
+            tmp = oracle.barr_lincomb([np.empty(n, dt) for _ in range(nrow)], [scales[t]], [tmp])
+        want = oracle.barr_lincomb([np.empty(n, dt) for _ in range(nrow)], [1.0, signs[t]], [want, tmp])
+        din = hd if scales[t] == 1.0 else oracle.barr_lincomb([np.empty(n, dt) for _ in range(nrow)], [scales[t]], [hd])
+        tm = oracle.block_df_adj(ora, [np.zeros(n, dt)], din)
+        want_m = oracle.barr_lincomb([np.empty(n, dt)], [1.0, signs[t]], [want_m, tm])
+    # the ABI call itself: JH_OK, not JH_ERR_UNSUPPORTED
+    nats = [_native(A) for A in ops]
+    hs = (C.c_void_p * nterms)(*[x.handle for x in nats])
+    sc = (C.c_double * nterms)(*scales)
+    fg = (C.c_int32 * nterms)(*([0] * nterms))
+    sg = (C.c_double * nterms)(*signs)
+    m = J.from_numpy(hm, J.domain(ops[0]))
+    d = J.rand(J.range(ops[0]), seed=7, stream=7)
+    check(lib.jh_blocksum_mul_typed(nterms, hs, sc, fg, sg, d.handle, m.handle))
+    assert_bits_equal(d.to_numpy(), np.concatenate(want), f"{nterms}-term sum of {n}-element rows, forward")
+    mt = J.rand(J.domain(ops[0]), seed=8, stream=8)
+    din = J.from_numpy(np.concatenate(hd), J.range(ops[0]))                           # (kept alive across the call: a temporary would be destroyed first)
+    check(lib.jh_blocksum_mul_adj_typed(nterms, hs, sc, fg, sg, mt.handle, din.handle))
+    assert_bits_equal(mt.to_numpy().ravel(order="F"), want_m[0], f"{nterms}-term sum, adjoint")
+    # and through the operator algebra
+    S = scales[0] * ops[0] if scales[0] != 1.0 else ops[0]
+    for t in range(1, nterms):
+        term = scales[t] * ops[t] if scales[t] != 1.0 else ops[t]
+        S = S + term if signs[t] > 0 else S - term
+    assert_bits_equal((S * m).to_numpy(), np.concatenate(want), "A1 +- s2*A2 ... forward")
