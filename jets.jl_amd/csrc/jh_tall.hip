@@ -81,7 +81,9 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__res
 #pragma unroll
             for (int k = 0; k < U; k++) {
                 const V c = rc ? ldu<NT, S, NS>((const S *)blk.coeff + sk[k]) : (V)(S)0;
-                if (ok[k]) st_pack<NT, S, NS>(di, s0 + (int64_t)k * BLK * NS, sk[k], apply_block_loaded<S, E, NS, V>(blk, mv[k], c, false, false));   // (1026)
+                // (the store stays a streaming store whatever NT says: temporal stores of a range vector larger than the caches leave dirty lines whose
+                // write-back lands on the NEXT kernel -- 256 x 255^3: forward alone 5.82 -> 5.75 ms, forward + adjoint pair 11.8 -> 12.2)
+                if (ok[k]) st_pack<true, S, NS>(di, s0 + (int64_t)k * BLK * NS, sk[k], apply_block_loaded<S, E, NS, V>(blk, mv[k], c, false, false));   // (1026)
             }
         }
         return;
@@ -990,9 +992,17 @@ int launch_tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int64_t 
     if (ctiles > gx) ctiles = gx;
     c.last_fwd_walk = ctiles ? 2 : 0;
     c.last_fwd_rows_per_wg = G;
-    hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, true, BLK, true>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, op->dev_blocks,
-                       nrows, (int)G, listed ? reinterpret_cast<const S *>(op->dev_rows_nz) : (const S *)nullptr, (int64_t)(listed ? -1 : 0), (const S *)m, (S *)d,
-                       n_scalars, (unsigned)gx, (unsigned)gy, 1u, (unsigned)ctiles);
+#define JH_FWD_MIXED(NTV)                                                                                                                   \
+    hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, NTV, BLK, true>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, op->dev_blocks,        \
+                       nrows, (int)G, listed ? reinterpret_cast<const S *>(op->dev_rows_nz) : (const S *)nullptr, (int64_t)(listed ? -1 : 0), (const S *)m, (S *)d, \
+                       n_scalars, (unsigned)gx, (unsigned)gy, 1u, (unsigned)ctiles)
+    // Rows off the 16-byte grid take TEMPORAL LOADS: a 128-byte line that two neighbouring waves share is then still in L2 when the second one asks --
+    // streamed, it came from HBM twice (forward 256 x 255^3 5.82 -> 5.92 TB/s, 512 x 127^3 5.02 -> 5.11, 1024 x 101^3 5.30 -> 5.47; aligned rows: no
+    // difference either way; profiles/bench_unaligned_r05.txt).  The STORES stay streaming stores (k_tall_diag_fwd).  Knob ua_nt: -1 this rule,
+    // 0 / 1 temporal / nontemporal loads always.
+    const bool off_grid = (n_scalars * (int64_t)sizeof(S)) % 16 != 0 || !op->coeff_aligned16 || ((((uintptr_t)d) | ((uintptr_t)m)) & 15u) != 0;
+    if (c.ua_nt == 0 || (c.ua_nt < 0 && off_grid)) JH_FWD_MIXED(false); else JH_FWD_MIXED(true);
+#undef JH_FWD_MIXED
     JH_CHECK_HIP(hipGetLastError());
     return JH_OK;
 }
@@ -1013,9 +1023,15 @@ int launch_tall_adj_mixed_u(const jh_blockop *op, void *out, const void *in, int
     }
     c.last_adj_parts = parts;
     c.last_adj_launches = 1;
-    hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, true, MODE, BLK, true>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, c.stream,
-                       op->dev_blocks, op->nrow, (const S *)nullptr, (int64_t)0, (S *)out, (const S *)in, n_scalars, 0, s_begin, s_end,
-                       (int64_t)0, op->nrow, from_found, rows_per_part, (S *)slabs, part_stride);
+#define JH_ADJ_MIXED(NTV)                                                                                                                   \
+    hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, NTV, MODE, BLK, true>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, c.stream, \
+                       op->dev_blocks, op->nrow, (const S *)nullptr, (int64_t)0, (S *)out, (const S *)in, n_scalars, 0, s_begin, s_end,            \
+                       (int64_t)0, op->nrow, from_found, rows_per_part, (S *)slabs, part_stride)
+    // (rows off the 16-byte grid: temporal loads, see launch_tall_fwd_mixed -- from 32 MiB rows on: 256 x 255^3 adjoint 5.83 -> 6.17 TB/s, but 512 x 127^3
+    // 5.97 -> 5.73 and 1024 x 101^3 5.70 -> 5.67 on the same boxes)
+    const bool off_grid = (n_scalars * (int64_t)sizeof(S)) % 16 != 0 || !op->coeff_aligned16 || ((((uintptr_t)out) | ((uintptr_t)in)) & 15u) != 0;
+    if (c.ua_nt == 0 || (c.ua_nt < 0 && off_grid && n_scalars * (int64_t)sizeof(S) >= ((int64_t)32 << 20))) JH_ADJ_MIXED(false); else JH_ADJ_MIXED(true);
+#undef JH_ADJ_MIXED
     JH_CHECK_HIP(hipGetLastError());
     if (parts > 1) return launch_fold_parts<S, NS>(slabs, part_stride, parts, out, s_begin, s_end);
     return JH_OK;

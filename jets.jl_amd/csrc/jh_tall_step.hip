@@ -15,7 +15,7 @@ static inline bool packs_unaligned(const jh_blockop *op, size_t row_bytes, const
 // forward: d_i = alpha * (a_i .* m) + beta * d_i ; sequential row sweep (tile index fastest)
 // WIDE (S = float, beta == 0): the scalar is Julia's Float64 (JH_SCALAR_WIDE) -- d_i = Float32(wscal * Float64(a_i .* m)), the promoted
 // product of `d .= a * tmp` (src/Jets.jl:1159) rounded once on the store
-template <typename S, int E, int NS, int U, int BLK, bool MIXED = false, bool WIDE = false>
+template <typename S, int E, int NS, int U, int BLK, bool MIXED = false, bool WIDE = false, bool NT = true>
 __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block *__restrict__ blocks, int64_t nrow, int rows_per_wg,
                                                               const S *__restrict__ a_base, int64_t a_stride,
                                                               const S *__restrict__ m, S *__restrict__ d, int64_t n_scalars,
@@ -71,9 +71,9 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block
         V av[U], dv[U];
 #pragma unroll
         for (int k = 0; k < U; k++) {
-            if constexpr (MIXED) {
-                av[k] = rc ? ldu<true, S, NS>(a + sk[k]) : (V)(S)0;
-                dv[k] = use_old ? ldu<true, S, NS>(di + sk[k]) : (V)(S)0;
+            if constexpr (MIXED) {                                      // (NT = false: rows off the 16-byte grid, see launch_fwd_update)
+                av[k] = rc ? ldu<NT, S, NS>(a + sk[k]) : (V)(S)0;
+                dv[k] = use_old ? ldu<NT, S, NS>(di + sk[k]) : (V)(S)0;
             } else {
                 av[k] = rc ? ld<true>(reinterpret_cast<const V *>(a + sk[k])) : (V)(S)0;
                 dv[k] = use_old ? ld<true>(reinterpret_cast<const V *>(di + sk[k])) : (V)(S)0;   // beta == 0: d is write-only
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd_update(const jh_dev_block
             if (ok[k]) {
                 if constexpr (MIXED) {
                     const int64_t sn = s0 + (int64_t)k * BLK * NS;
-                    st_pack<true, S, NS>(di, sn, sk[k], r);
+                    st_pack<true, S, NS>(di, sn, sk[k], r);               // (streaming whatever NT says: jh_tall.hip, k_tall_diag_fwd)
                     nrm += vnorm2_from<S, NS, V>(r, (int)(sn - sk[k]));
                 } else {
                     st<true>(reinterpret_cast<V *>(di + sk[k]), r);
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
                     const S *ap = block_reads_coeff(blk[j], false) ? (const S *)blk[j].coeff : v;   // no coefficient array: v's pack again (unused)
 #pragma unroll
                     for (int k = 0; k < U; k++) {
-                        av[j][k] = ldu<true, S, NS>(ap + sk[k]);
-                        if constexpr (OLD) uv[j][k] = ldu<true, S, NS>(u + (i + j) * n_scalars + sk[k]);
+                        av[j][k] = ldu<NT, S, NS>(ap + sk[k]);
+                        if constexpr (OLD) uv[j][k] = ldu<NT, S, NS>(u + (i + j) * n_scalars + sk[k]);
                         else uv[j][k] = (V)(S)0;
                     }
                 }
@@ -316,10 +316,10 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag(const jh_dev_block *__
             const S *ap = block_reads_coeff(blk, false) ? (const S *)blk.coeff : v;
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                const V c = ldu<true, S, NS>(ap + sk[k]);
+                const V c = ldu<NT, S, NS>(ap + sk[k]);
                 const V t = on ? apply_block_loaded<S, E, NS, V>(blk, vv[k], c, false, false) : (V)(S)0;
                 V r = (V)alpha * t;
-                if (use_old) { V s2 = (V)beta * ldu<true, S, NS>(u + i * n_scalars + sk[k]); r = r + s2; }
+                if (use_old) { V s2 = (V)beta * ldu<NT, S, NS>(u + i * n_scalars + sk[k]); r = r + s2; }
                 if (ok[k]) {
                     st_pack<true, S, NS>(u + i * n_scalars, sk[k] + e0[k], sk[k], r);
                     nrm += vnorm2_from<S, NS, V>(r, e0[k]);
@@ -683,10 +683,16 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
         JH_CHECK_HIP(hipEventCreate(&e1));
         JH_CHECK_HIP(hipEventRecord(e0, c.stream));
     }
-#define JH_LAUNCH_W(BLK, UU, MX, WD)                                                                                   \
-    hipLaunchKernelGGL((k_tall_diag_fwd_update<S, E, NS, UU, BLK, MX, WD>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, \
+#define JH_LAUNCH_WN(BLK, UU, MX, WD, NTV)                                                                             \
+    hipLaunchKernelGGL((k_tall_diag_fwd_update<S, E, NS, UU, BLK, MX, WD, NTV>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, \
                        op->dev_blocks, op->nrow, G, a_base, a_stride, (const S *)m, (S *)d, n_scalars, (unsigned)gx,   \
                        (unsigned)gy, walk, (S)alpha, (S)beta, c.part_dev, alpha)
+#define JH_LAUNCH_W(BLK, UU, MX, WD) JH_LAUNCH_WN(BLK, UU, MX, WD, true)
+    // rows off the 16-byte grid: temporal accesses (jh_tall.hip: launch_tall_fwd_mixed), one pack per lane
+    const bool off_grid = packs_unaligned(op, (size_t)n_scalars * sizeof(S), d, m);
+    if (off_grid && !(sizeof(S) == 4 && wide) && (c.ua_nt == 0 || c.ua_nt < 0)) {
+        if (U == 4) JH_LAUNCH_WN(256, 4, true, false, false); else JH_LAUNCH_WN(256, 1, true, false, false);
+    } else
     // (a wide scalar: Float32 elements only, beta == 0 -- checked by the caller; one instantiation per tiling)
     if constexpr (sizeof(S) == 4) {
         if (wide) {
@@ -697,12 +703,14 @@ int launch_fwd_update(const jh_blockop *op, void *d, const void *m, int64_t n_sc
         }
     }
     if (!(sizeof(S) == 4 && wide)) {
-        if (mixed && U == 4) JH_LAUNCH_W(256, 4, true, false);
+        if (off_grid && (c.ua_nt == 0 || c.ua_nt < 0)) { /* launched above */ }
+        else if (mixed && U == 4) JH_LAUNCH_W(256, 4, true, false);
         else if (mixed) JH_LAUNCH_W(256, 1, true, false);
         else if (U == 4) JH_LAUNCH_W(256, 4, false, false);
         else JH_LAUNCH_W(256, 1, false, false);
     }
 #undef JH_LAUNCH_W
+#undef JH_LAUNCH_WN
     JH_CHECK_HIP(hipGetLastError());
     if (trial >= 0) JH_CHECK_HIP(hipEventRecord(e1, c.stream));
     const int st = finish_normsq(gx * gy, normsq);          // synchronises (normsq != NULL on a trial)
@@ -984,6 +992,9 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     JH_LAUNCH(256, 1, 4) JH_LAUNCH(256, 2, 2) JH_LAUNCH(256, 4, 1) JH_LAUNCH(256, 4, 2) JH_LAUNCH(256, 1, 8)
     JH_LAUNCH(512, 1, 4) JH_LAUNCH(512, 2, 2) JH_LAUNCH(512, 4, 1) JH_LAUNCH(512, 4, 2) JH_LAUNCH(512, 1, 8)
     JH_LAUNCH(1024, 1, 4) JH_LAUNCH(1024, 2, 2) JH_LAUNCH(1024, 4, 1)      // 1024 x 4 x 2 would need > 128 VGPRs per lane
+    if (unaligned && c.ua_nt <= 0) {                                       // rows off the 16-byte grid: temporal accesses (jh_tall.hip: launch_tall_fwd_mixed)
+        JH_LAUNCH_N(512, 1, 4, true, false) JH_LAUNCH_N(256, 2, 2, true, false) JH_LAUNCH_N(256, 4, 1, true, false) JH_LAUNCH_N(256, 1, 4, true, false)
+    }
     JH_LAUNCH_M(512, 1, 4, true) JH_LAUNCH_M(256, 2, 2, true) JH_LAUNCH_M(256, 4, 1, true) JH_LAUNCH_M(256, 1, 4, true)
 #undef JH_LAUNCH
 #undef JH_LAUNCH_T
