@@ -128,7 +128,10 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__res
 
 // one thread: U vectors of the domain, all rows in order.  MODE 0: adjoint (reads a_i, d_i);
 // MODE 1: fused normal equations y = sum_i conj(a_i) .* (a_i .* m) (reads a_i only).
-template <typename S, int E, int NS, int U, int DEPTH, bool NT, int MODE, int BLK, bool MIXED = false>
+// TAIL (MIXED only): the instantiation also serves rows that are not whole, 16-byte aligned packs (a partial last pack).  False for the ONE shape whose
+// registers do not hold the extra state -- 1024 lanes x 4 packs x 4 rows of the fused A'A (128 VGPRs per lane; with the tail logic it spilled 12-28 bytes) --
+// which therefore keeps aligned operators only; off the grid that size runs 4 packs x 2 rows (launch_tall_adj_mixed)
+template <typename S, int E, int NS, int U, int DEPTH, bool NT, int MODE, int BLK, bool MIXED = false, bool TAIL = MIXED>
 __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                        const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ out,
                                                        const S *__restrict__ in, int64_t n_scalars, int direct,
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
 #pragma unroll
     for (int k = 0; k < U; k++) {
         ok[k] = (s0 + (int64_t)k * BLK * NS) < s_end;
-        if constexpr (MIXED) {
+        if constexpr (TAIL) {
             sk[k] = ok[k] ? pack_start<NS>(s0 + (int64_t)k * BLK * NS, s_end) : s_begin;
             acc[k] = (accumulate && ok[k]) ? ldu<false, S, NS>(out + sk[k]) : (V)(S)0;
             if (MODE == 1) mv[k] = ok[k] ? ldu<false, S, NS>(in + sk[k]) : (V)(S)0;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
 #pragma unroll
     for (int k = 0; k < U; k++)
         if (ok[k]) {
-            if constexpr (MIXED) st_pack<false, S, NS>(out, s0 + (int64_t)k * BLK * NS, sk[k], acc[k]);
+            if constexpr (TAIL) st_pack<false, S, NS>(out, s0 + (int64_t)k * BLK * NS, sk[k], acc[k]);
             else st<false>(reinterpret_cast<V *>(out + s0 + (int64_t)k * BLK * NS), acc[k]);
         }
 }
@@ -1007,7 +1010,7 @@ int launch_tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int64_t 
     return JH_OK;
 }
 
-template <typename S, int E, int NS, int MODE, int BLK, int U, int DEPTH>
+template <typename S, int E, int NS, int MODE, int BLK, int U, int DEPTH, bool TAIL = true>
 int launch_tall_adj_mixed_u(const jh_blockop *op, void *out, const void *in, int64_t n_scalars, int64_t s_begin, int64_t s_end)
 {
     jh_context &c = jh_ctx();
@@ -1024,7 +1027,7 @@ int launch_tall_adj_mixed_u(const jh_blockop *op, void *out, const void *in, int
     c.last_adj_parts = parts;
     c.last_adj_launches = 1;
 #define JH_ADJ_MIXED(NTV)                                                                                                                   \
-    hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, NTV, MODE, BLK, true>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, c.stream, \
+    hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, NTV, MODE, BLK, true, TAIL>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, c.stream, \
                        op->dev_blocks, op->nrow, (const S *)nullptr, (int64_t)0, (S *)out, (const S *)in, n_scalars, 0, s_begin, s_end,            \
                        (int64_t)0, op->nrow, from_found, rows_per_part, (S *)slabs, part_stride)
     // (rows off the 16-byte grid: temporal loads, see launch_tall_fwd_mixed -- from 32 MiB rows on: 256 x 255^3 adjoint 5.83 -> 6.17 TB/s, but 512 x 127^3
@@ -1047,7 +1050,13 @@ int launch_tall_adj_mixed(const jh_blockop *op, void *out, const void *in, int64
     // (ComplexF32 with its per-row kind switch: two rows in flight, four spilled 20 bytes per lane)
     if constexpr (MODE == 1) {
         constexpr int DEPTH = (E == 2 && sizeof(S) == 4) ? 2 : 4;
-        if (n_scalars / NS >= ((int64_t)1 << 22)) return launch_tall_adj_mixed_u<S, E, NS, MODE, 1024, 4, DEPTH>(op, out, in, n_scalars, s_begin, s_end);
+        if (n_scalars / NS >= ((int64_t)1 << 22)) {
+            // (four rows in flight only on whole, aligned packs: k_tall_diag_adj's TAIL)
+            const bool off_grid = (n_scalars * (int64_t)sizeof(S)) % 16 != 0 || !op->coeff_aligned16 || ((((uintptr_t)out) | ((uintptr_t)in)) & 15u) != 0 ||
+                                  (s_end - s_begin) % NS != 0;
+            if (off_grid) return launch_tall_adj_mixed_u<S, E, NS, MODE, 1024, 4, 2>(op, out, in, n_scalars, s_begin, s_end);
+            return launch_tall_adj_mixed_u<S, E, NS, MODE, 1024, 4, DEPTH, DEPTH == 2>(op, out, in, n_scalars, s_begin, s_end);
+        }
     }
     return launch_tall_adj_mixed_u<S, E, NS, MODE, 512, 2, 2>(op, out, in, n_scalars, s_begin, s_end);
 }

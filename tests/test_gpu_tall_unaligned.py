@@ -413,3 +413,19 @@ def test_the_fused_jetsum_takes_odd_blocks_with_the_chains_bits(Jets, oracle, dt
         term = scales[t] * ops[t] if scales[t] != 1.0 else ops[t]
         S = S + term if signs[t] > 0 else S - term
     assert_bits_equal((S * m).to_numpy(), np.concatenate(want), "A1 +- s2*A2 ... forward")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_the_fused_normal_operator_on_big_odd_blocks(Jets, oracle, dt):
+    """Rows of >= 64 MiB select the fat shape of the fused A'A (1024 lanes x 4 packs): off the grid it runs two rows in flight with the partial-pack logic,
+    on the grid four rows without (k_tall_diag_adj's TAIL) -- the chain's bits both ways."""
+    J = Jets
+    nrow = 3
+    for n in ((1 << 24) + 1, 1 << 24) if np.dtype(dt).itemsize == 4 else ((1 << 23) + 1, 1 << 23):
+        kinds = [["diag"], ["identity"], ["diag_adj"]]
+        A, ops = _mixed_ops(J, oracle, dt, kinds, [n] * nrow, [n])
+        hm = [u01(oracle, dt, 81, 0, n)]
+        want_y = oracle.block_df_adj(ops, [np.zeros(n, dt)], oracle.block_df(ops, [np.zeros(n, dt) for _ in range(nrow)], hm))
+        y = J.mul_(J.rand(J.domain(A), seed=5, stream=5), J.compose(A.H, A), J.from_numpy(hm[0], J.domain(A)))
+        assert_bits_equal(y.to_numpy().ravel(order="F"), want_y[0], f"fused A'A, rows of {n}")
+        J.close(A)
