@@ -34,6 +34,51 @@ template <typename V, typename W> __device__ inline void stg(V *p, W v)
     typedef V __attribute__((address_space(1))) *gp;
     *(gp)p = (V)v;
 }
+// UNDER-ALIGNED packs (round 5, session 3; the block-operator kernels' ldu, jh_blockop_common.h): a pack addressed through a type aligned like its scalar -- the
+// same global_load_dwordx4, at any dword-aligned address.  The adjoint (column) kernels use them: a k x k child with k odd has every column off the 16-byte
+// grid and a partial last pack per column; that pack is loaded from the column's end minus NS and only its scalars from e0 on are summed (cols_accumulate).
+template <typename S, int NS> __device__ inline typename vec_of<S, NS>::type ldgu_nt(const S *p)
+{
+    typedef typename vec_of<S, NS>::type V;
+    if constexpr (NS == 1) {
+        return ldg_nt(p);
+    } else {
+        typedef V __attribute__((aligned(alignof(S)))) UV;
+        typedef const UV __attribute__((address_space(1))) *gp;
+        return __builtin_nontemporal_load((gp)p);
+    }
+}
+template <typename S, int NS> __device__ inline typename vec_of<S, NS>::type ldgu(const S *p)
+{
+    typedef typename vec_of<S, NS>::type V;
+    if constexpr (NS == 1) {
+        return ldg(p);
+    } else {
+        typedef V __attribute__((aligned(alignof(S)))) UV;
+        typedef const UV __attribute__((address_space(1))) *gp;
+        return *(gp)p;
+    }
+}
+// sr (+ i si) += conj(a) . x over the scalars e >= e0 of one pack (e0 = 0: the whole pack)
+template <typename S, int E, int NS, typename V> __device__ inline void cols_accumulate(const V &a, const V &xv, int e0, double &sr, double &si)
+{
+    if constexpr (E == 1) {
+        if constexpr (NS == 1) { if (e0 <= 0) sr += (double)a * (double)xv; }
+        else {
+#pragma unroll
+            for (int e = 0; e < NS; e++) sr += e >= e0 ? (double)a[e] * (double)xv[e] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < NS; e += 2) {
+            const double ar = a[e], ai = -(double)a[e + 1], xr = xv[e], xi = xv[e + 1];
+            if (e >= e0) {
+                sr += ar * xr - ai * xi;
+                si += ar * xi + ai * xr;
+            }
+        }
+    }
+}
 
 // ---- y = A x ---------------------------------------------------------------------------------------
 // acc += A[:, c0:c1] x[c0:c1] for this lane's NS scalar rows: columns in order, product rounded then added (the sequential loop's bits);
@@ -125,23 +170,12 @@ __global__ __launch_bounds__(256) void k_gemv_cols(const S *__restrict__ A, int6
     const int64_t s1 = s0 + rows_per_chunk * E < ns ? s0 + rows_per_chunk * E : ns;
     const S *col = A + c * ns;
     double sr = 0.0, si = 0.0;
+    // (columns need not be whole, 16-byte aligned packs: under-aligned loads, the chunk's last pack from s1 - NS -- the host guarantees ns >= NS)
     for (int64_t s = s0 + (int64_t)lane * NS; s < s1; s += 64 * NS) {
-        V a = ldg_nt(reinterpret_cast<const V *>(col + s));
-        V xv = ldg(reinterpret_cast<const V *>(x + s));
-        if constexpr (E == 1) {
-#pragma unroll
-            for (int e = 0; e < NS; e++) {
-                if constexpr (NS == 1) sr += (double)a * (double)xv;
-                else sr += (double)a[e] * (double)xv[e];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < NS; e += 2) {                                   // conj(a) * x
-                const double ar = a[e], ai = -(double)a[e + 1], xr = xv[e], xi = xv[e + 1];
-                sr += ar * xr - ai * xi;
-                si += ar * xi + ai * xr;
-            }
-        }
+        const int64_t sc = s + NS <= s1 ? s : s1 - NS;
+        V a = ldgu_nt<S, NS>(col + sc);
+        V xv = ldgu<S, NS>(x + sc);
+        cols_accumulate<S, E, NS, V>(a, xv, (int)(s - sc), sr, si);              // conj(a) * x
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -231,23 +265,12 @@ __global__ __launch_bounds__(256) void k_gemv_cols_batched(const jh_dev_block *_
     const S *col = (const S *)blocks[z].coeff + c * ns;
     const S *x = d + dbase;                                                    // tall: child z reads d_z; wide: every child reads d (stride 0)
     double sr = 0.0, si = 0.0;
+    // (columns need not be whole, 16-byte aligned packs: under-aligned loads, the chunk's last pack from s1 - NS -- the host guarantees ns >= NS)
     for (int64_t s = s0 + (int64_t)lane * NS; s < s1; s += 64 * NS) {
-        V a = ldg_nt(reinterpret_cast<const V *>(col + s));
-        V xv = ldg(reinterpret_cast<const V *>(x + s));
-        if constexpr (E == 1) {
-#pragma unroll
-            for (int e = 0; e < NS; e++) {
-                if constexpr (NS == 1) sr += (double)a * (double)xv;
-                else sr += (double)a[e] * (double)xv[e];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < NS; e += 2) {
-                const double ar = a[e], ai = -(double)a[e + 1], xr = xv[e], xi = xv[e + 1];
-                sr += ar * xr - ai * xi;
-                si += ar * xi + ai * xr;
-            }
-        }
+        const int64_t sc = s + NS <= s1 ? s : s1 - NS;
+        V a = ldgu_nt<S, NS>(col + sc);
+        V xv = ldgu<S, NS>(x + sc);
+        cols_accumulate<S, E, NS, V>(a, xv, (int)(s - sc), sr, si);              // conj(a) * x
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -824,7 +847,7 @@ int gemv_batched_wide(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr
     JH_TRY(jh_ensure_partials(2 * nchild * nchunks * nc));
     if (nchunks == 1 && (vec_ok ? launch_cols_small<S, E, NSV>(dev_blocks, 0, nchild, nr, nc, (const S *)x, 0, c.part_dev, st)
                                 : launch_cols_small<S, E, E>(dev_blocks, 0, nchild, nr, nc, (const S *)x, 0, c.part_dev, st))) {
-    } else if (vec_ok)
+    } else if (vec_ok || (c.tall_unaligned != 0 && ns >= NSV && ((((uintptr_t)x) | ((uintptr_t)y)) & (sizeof(S) - 1)) == 0))   // (columns off the 16-byte grid: under-aligned packs)
         hipLaunchKernelGGL((k_gemv_cols_batched<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)nchild), dim3(256), 0, st, dev_blocks,
                            (int64_t)0, nr, nc, (const S *)x, (int64_t)0, c.part_dev, rpc, (const int64_t *)nullptr);
     else
@@ -890,6 +913,9 @@ int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int
         return JH_OK;
     }
     // m = sum_z A_z' d_z  (the caller's m is overwritten: `_m .= 0` then `_m .+= mtmp`, 1042-1049)
+    // round 5, session 3: children whose columns are not whole, 16-byte aligned packs (k x k with k odd) keep the 16-byte-per-lane column kernel
+    // on under-aligned packs (k_gemv_cols_batched): 128 children of 1023^2 3.1 -> see profiles/bench_unaligned_r05.txt; knob tall_unaligned = 0: as before
+    const bool vec_cols_ua = !vec_ok && c.tall_unaligned != 0 && !row_off && ns >= NSV && ((((uintptr_t)x) | ((uintptr_t)y)) & (sizeof(S) - 1)) == 0;
     c.last_dense_fused = 0;
     if (!row_off && c.dense_fused) {                                            // many small children: one streaming kernel + a fold (round 4)
         bool launched = false;
@@ -926,7 +952,7 @@ int gemv_batched(const jh_dev_block *dev_blocks, int64_t nchild, int64_t nr, int
         const S *d0 = (const S *)x;
         if (!row_off && nchunks == 1 && (vec_ok ? launch_cols_small<S, E, NSV>(dev_blocks, z0, gz, nr, nc, d0, ns, c.part_dev, st)
                                                 : launch_cols_small<S, E, E>(dev_blocks, z0, gz, nr, nc, d0, ns, c.part_dev, st))) {
-        } else if (vec_ok)
+        } else if (vec_ok || vec_cols_ua)
             hipLaunchKernelGGL((k_gemv_cols_batched<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)nchunks, (unsigned)gz), dim3(256), 0, st, dev_blocks,
                                z0, nr, nc, d0, ns, c.part_dev, rpc, row_off);
         else
@@ -1001,7 +1027,9 @@ int gemv(const void *A, int64_t nr, int64_t nc, void *y, const void *x, int adjo
     if (rpc < 4) rpc = 4;
     nchunks = nr ? (nr + rpc - 1) / rpc : 1;
     JH_TRY(jh_ensure_partials(2 * nchunks * nc));
-    if (vec_ok)
+    // (columns off the 16-byte grid -- k x k with k odd -- keep the 16-byte-per-lane kernel on under-aligned packs: k_gemv_cols)
+    const bool vec_cols_ua = !vec_ok && c.tall_unaligned != 0 && ns >= NSV && ((((uintptr_t)A) | ((uintptr_t)x) | ((uintptr_t)y)) & (sizeof(S) - 1)) == 0;
+    if (vec_ok || vec_cols_ua)
         hipLaunchKernelGGL((k_gemv_cols<S, E, NSV>), dim3((unsigned)col_wgs, (unsigned)nchunks), dim3(256), 0, st, (const S *)A, nr, nc,
                            (const S *)x, c.part_dev, rpc);
     else
@@ -1281,28 +1309,25 @@ __global__ __launch_bounds__(256) void k_gemv_cols_list(const jh_dense_item *__r
 #pragma unroll
     for (int k = 0; k < CPW; k++) { sr[k] = 0.0; si[k] = 0.0; }
     constexpr int UNR = CPW == 1 ? 4 : (CPW == 2 ? 2 : 1);
+    // (columns need not be whole, 16-byte aligned packs: under-aligned loads, the column's last pack from ns - NS; a column shorter than one pack -- a
+    // child of a list whose other children are longer -- is summed scalar by scalar)
+    if (NS > E && ns < NS) {
+        for (int64_t s = (int64_t)l * E; s < ns; s += (int64_t)SUB * E) {
+            typedef typename vec_of<S, E>::type VE;
+            const VE xv = ldgu<S, E>(x + s);
+#pragma unroll
+            for (int k = 0; k < CPW; k++) cols_accumulate<S, E, E, VE>(ldgu_nt<S, E>(colp[k] + s), xv, 0, sr[k], si[k]);
+        }
+    } else {
 #pragma unroll UNR
-    for (int64_t s = (int64_t)l * NS; s < ns; s += (int64_t)SUB * NS) {
-        const V xv = ldg(reinterpret_cast<const V *>(x + s));
-        V a[CPW];
+        for (int64_t s = (int64_t)l * NS; s < ns; s += (int64_t)SUB * NS) {
+            const int64_t sc = s + NS <= ns ? s : ns - NS;
+            const V xv = ldgu<S, NS>(x + sc);
+            V a[CPW];
 #pragma unroll
-        for (int k = 0; k < CPW; k++) a[k] = ldg_nt(reinterpret_cast<const V *>(colp[k] + s));
+            for (int k = 0; k < CPW; k++) a[k] = ldgu_nt<S, NS>(colp[k] + sc);
 #pragma unroll
-        for (int k = 0; k < CPW; k++) {
-            if constexpr (E == 1) {
-#pragma unroll
-                for (int e = 0; e < NS; e++) {
-                    if constexpr (NS == 1) sr[k] += (double)a[k] * (double)xv;
-                    else sr[k] += (double)a[k][e] * (double)xv[e];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < NS; e += 2) {
-                    const double ar = a[k][e], ai = -(double)a[k][e + 1], xr = xv[e], xi = xv[e + 1];
-                    sr[k] += ar * xr - ai * xi;
-                    si[k] += ar * xi + ai * xr;
-                }
-            }
+            for (int k = 0; k < CPW; k++) cols_accumulate<S, E, NS, V>(a[k], xv, (int)(s - sc), sr[k], si[k]);
         }
     }
 #pragma unroll
@@ -1341,7 +1366,9 @@ int gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64
     hipStream_t st = c.stream;
     constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
     const bool vec_ok = aligned && ((((uintptr_t)x) | ((uintptr_t)slabs) | ((uintptr_t)direct_out)) & 15u) == 0;
-    const int NS = vec_ok ? NSV : E;
+    // (the column kernel also on children off the 16-byte grid: under-aligned packs, k_gemv_cols_list)
+    const bool vec_cols = vec_ok || (pass == 1 && c.tall_unaligned != 0 && (((uintptr_t)x) & (sizeof(S) - 1)) == 0);
+    const int NS = (pass == 1 ? vec_cols : vec_ok) ? NSV : E;
     if (pass == 0) {
         const int64_t lanes = (max_out * E + NS - 1) / NS;                   // row lanes of the longest child
         int sh = 8;                                                          // RL = 256: every lane a row lane, columns in order (the sequential loop's bits)
@@ -1371,7 +1398,7 @@ int gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64
         const int64_t chunks = (max_out + per_wg - 1) / per_wg;
         JH_REQUIRE(nitems * chunks < ((int64_t)1 << 31), "dense child list: %lld x %lld workgroups exceed the grid", (long long)nitems, (long long)chunks);
 #define JH_COLS(NSX, CPWX) hipLaunchKernelGGL((k_gemv_cols_list<S, E, NSX, CPWX>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs, (S *)direct_out, add_found)
-        if (vec_ok) { if (cpw == 1) JH_COLS(NSV, 1); else if (cpw == 2) JH_COLS(NSV, 2); else JH_COLS(NSV, 4); }
+        if (vec_cols) { if (cpw == 1) JH_COLS(NSV, 1); else if (cpw == 2) JH_COLS(NSV, 2); else JH_COLS(NSV, 4); }
         else { if (cpw == 1) JH_COLS(E, 1); else if (cpw == 2) JH_COLS(E, 2); else JH_COLS(E, 4); }
 #undef JH_COLS
     }
