@@ -480,3 +480,51 @@ def test_the_chained_step_with_a_ragged_last_tile(Jets, oracle, dt, nrow, n, nam
     finally:
         J.tune(step_chain=-1, adj_wg=0, step_chain_tail=1)
     J.close(A)
+
+
+# ---------------------------------------------------------------------------------- dense children of odd dimensions: the adjoint's column kernels
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("layout", ["tall", "wide", "blockdiag", "single"])
+@pytest.mark.parametrize("nch,nr,nc", [(3, 1023, 515), (2, 2047, 1021), (5, 67, 33), (4, 5, 9)])
+def test_dense_children_of_odd_dimensions_adjoint_on_under_aligned_packs(Jets, oracle, dt, layout, nch, nr, nc):
+    """k x l children with k odd: every column of the matrix starts off the 16-byte grid and ends inside a pack.  The adjoint's column kernels (single,
+    batched with row chunks, list) sum under-aligned packs, the last one of a column (of a chunk) from its own first scalar on: within the dense kernels'
+    tolerance of an extended-precision host product, identical on a second run, and equal to the 4-byte-per-lane kernels' result within the same tolerance."""
+    J = Jets
+    if layout == "single":
+        nch = 1
+    wide_t = np.clongdouble if np.dtype(dt).kind == "c" else np.longdouble
+    tol = 2e-5 if np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4 else 1e-12
+    mats = [np.asfortranarray(u01(oracle, dt, 11, z, nr * nc).reshape((nr, nc), order="F")) for z in range(nch)]
+    dev = [J.JopDense(J.from_numpy(hA)) for hA in mats]
+    if layout in ("tall", "single"):
+        A = J.blockop([[op] for op in dev])
+        hd = u01(oracle, dt, 3, 0, nch * nr).reshape(nch, nr)
+        truth = sum(np.conj(mats[z].astype(wide_t)).T @ hd[z].astype(wide_t) for z in range(nch))
+    elif layout == "wide":
+        A = J.blockop([dev])
+        hd = u01(oracle, dt, 3, 0, nr).reshape(1, nr)
+        truth = np.concatenate([np.conj(mats[z].astype(wide_t)).T @ hd[0].astype(wide_t) for z in range(nch)])
+    else:
+        A = J.blockop([[dev[i] if i == j else J.JopZeroBlock(J.JetSpace(dt, nc), J.JetSpace(dt, nr)) for j in range(nch)] for i in range(nch)])
+        hd = u01(oracle, dt, 3, 0, nch * nr).reshape(nch, nr)
+        truth = np.concatenate([np.conj(mats[z].astype(wide_t)).T @ hd[z].astype(wide_t) for z in range(nch)])
+    d = J.from_numpy(hd.ravel(), J.range(A))
+    err = lambda a, b: float(np.linalg.norm(a.astype(wide_t) - b) / np.linalg.norm(b))
+    got = {}
+    try:
+        for knob in (1, 0):
+            J.tune(tall_unaligned=knob)
+            mt = J.rand(J.domain(A), seed=6, stream=6)                                   # dirty: zeroed first (1042)
+            J.mul_(mt, A.H, d)
+            got[knob] = mt.to_numpy().ravel(order="F").copy()
+            assert err(got[knob], truth) < tol, f"{layout} adjoint, tall_unaligned={knob}"
+            again = J.zeros(J.domain(A))
+            J.mul_(again, A.H, d)
+            assert_bits_equal(again.to_numpy().ravel(order="F"), got[knob], "second run")
+    finally:
+        J.tune(tall_unaligned=1)
+    m = J.rand(J.domain(A), seed=2, stream=0)
+    lhs, rhs = J.dot_product_test(A, m, d)
+    assert abs(lhs - rhs) / abs(lhs + rhs) < (1e-5 if tol > 1e-10 else 1e-12)
+    J.close(A)
