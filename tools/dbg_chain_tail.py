@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""The chained one-pass step on rows off the 16-byte grid (17 rows of 4099 Float32 elements), nine calls alternating the workgroup sizes: prints which scalars of w
+differ from the first call's.  Found the hand-off race of the first TAIL version (lanes past the end handed on packs computed from u as already updated in place:
+1 ... 3 wrong tail scalars in one run out of three at 1024 lanes); clean since a lane hands on only the scalars it owns."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""EXPERIMENT: rows off the 16-byte grid with temporal instead of nontemporal accesses (knob ua_nt)."""
+"""EXPERIMENT: rows off the 16-byte grid with temporal instead of nontemporal loads (knob ua_nt: 1 streamed, 0 temporal): forward, adjoint and the alternating
+pair, two rounds in one process (one child adjointed, so that an ALIGNED size also runs the MIXED instantiations).    python tools/exp_ua_nt.py NROW EDGE"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
