@@ -269,8 +269,9 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m);
  * row's last, partial pack separately: jh_blockop_mul / _mul_adj / _normal_mul / _f (tall, wide and M x K operators of elementwise blocks),
  * jh_blockop_mul_axpby / _mul_scaled, jh_blockop_bidiag_step and the one-shard solver loops built on them (jh_lsqr_solve, jh_cgls_solve, jh_cgnr_solve),
  * the fused sums (jh_blocksum_*), the block-vector primitives and jh_bcast_apply[_many] -- same bits as on aligned blocks' kernels (the same terms in the
- * same order).  What still asks for 16-byte aligned blocks: the *_range calls and the partitioned / team solvers built on them,
- * jh_blockop_mul_adj_axpby / _mul_adj_scaled and the graph-replayed small-operator loops -- their callers fall back to compositions of the calls above (JH_ERR_UNSUPPORTED comes
+ * same order) -- and the *_range calls with the partitioned / team solvers built on them: the ranges are cut in the DOMAIN at 16-byte bounds as before, the
+ * last one may end with the vector (inside a pack).  What still asks for 16-byte aligned blocks: jh_blockop_mul_adj_axpby / _mul_adj_scaled and the
+ * graph-replayed small-operator loops -- their callers fall back to compositions of the calls above (JH_ERR_UNSUPPORTED comes
  * before anything is touched).  jh_tune_set("tall_unaligned", 0) restores the 4-byte-per-lane kernels of rounds 1-4 for such operators. */
 /* mul!(m, A', d) -> JetBlock_df'!, src/Jets.jl:1034-1057: m zeroed when nrow > 1 (1042), rows summed
  * in order i = 0..nrow-1 with the product rounded before the add (1049) => bit-exact on one GPU.
@@ -291,7 +292,7 @@ int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m);
  * operator that has SQUARE blocks and no point (the reference hits a DimensionMismatch on its empty m0). */
 int jh_blockop_point(jh_blockop *op, const jh_bvec *mo);
 /* The same adjoint restricted to the elements [first_elem, first_elem+count) of the domain vector (16-byte aligned
- * bounds; tall all-DIAG operators): lets a multi-GPU host pipeline the exchange chunk by chunk -- all-reduce chunk k
+ * bounds -- the last range may end with the vector instead --; tall operators of elementwise rows): lets a multi-GPU host pipeline the exchange chunk by chunk -- all-reduce chunk k
  * while the kernel computes chunk k+1.  Results are identical to jh_blockop_mul_adj on those elements. */
 int jh_blockop_mul_adj_range(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, int64_t first_elem, int64_t count);
 /* (A' o A) m -> JetComposite_df! over (A', A), src/Jets.jl:530-534, fused: A's coefficients are read

@@ -609,13 +609,16 @@ int jh_blockop_mul_adj_range(const jh_blockop *op, jh_bvec *m, const jh_bvec *d,
     JH_REQUIRE(first_elem >= 0 && count >= 0 && first_elem + count <= m->length,
                "jh_blockop_mul_adj_range: elements [%lld, %lld) outside the domain vector (%lld elements)", (long long)first_elem,
                (long long)(first_elem + count), (long long)m->length);
-    const bool mixed = tall_mixed_ok(op, d->data, m->data);
+    // (rows off the 16-byte pack grid: the MIXED instantiations, like the whole-vector call -- the LAST range may then end inside a pack)
+    const bool fast = tall_fast_ok(op, d->data, m->data);
+    const bool mixed = !fast && (tall_mixed_ok(op, d->data, m->data) || tall_unaligned_ok(op, d->data, m->data));
     if (mixed && op->nonlinear && !op->pointed)
         return jh_fail(JH_ERR_STATE, "jh_blockop_mul_adj_range: operator has nonlinear blocks and no linearisation point (jh_blockop_point)");
-    if (!mixed && !tall_fast_ok(op, d->data, m->data))
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_range: needs a tall operator of elementwise rows with equal, 16-byte aligned blocks");
+    if (!mixed && !fast)
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_range: needs a tall operator of >= 2 equal elementwise rows");
     const int64_t es = (int64_t)jh_dtype_size(op->dtype);
-    JH_REQUIRE((first_elem * es) % 16 == 0 && (count * es) % 16 == 0, "jh_blockop_mul_adj_range: chunk boundaries must be 16-byte aligned");
+    JH_REQUIRE((first_elem * es) % 16 == 0 && ((count * es) % 16 == 0 || first_elem + count == m->length),
+               "jh_blockop_mul_adj_range: chunk boundaries must be 16-byte aligned (the last chunk may end with the vector)");
     if (mixed) return jhb::tall_adj(op, m->data, d->data, 0, true, first_elem, first_elem + count);
     return jhb::tall_adj(op, m->data, d->data, 0, false, first_elem, first_elem + count);
     return jh_fail(JH_ERR_INVALID, "jh_blockop_mul_adj_range: unknown dtype %d", op->dtype);
@@ -658,9 +661,10 @@ int jh_blockop_normal_mul_range(const jh_blockop *op, jh_bvec *y, const jh_bvec 
                "jh_blockop_normal_mul_range: elements [%lld, %lld) outside the domain vector (%lld elements)", (long long)first_elem,
                (long long)(first_elem + count), (long long)y->length);
     const int64_t es = (int64_t)jh_dtype_size(op->dtype);
-    JH_REQUIRE((first_elem * es) % 16 == 0 && (count * es) % 16 == 0, "jh_blockop_normal_mul_range: chunk boundaries must be 16-byte aligned");
+    JH_REQUIRE((first_elem * es) % 16 == 0 && ((count * es) % 16 == 0 || first_elem + count == y->length),
+               "jh_blockop_normal_mul_range: chunk boundaries must be 16-byte aligned (the last chunk may end with the vector)");
     const int64_t lo = first_elem, hi = first_elem + count;
-    if (tall_mixed_ok(op, y->data, m->data)) {
+    if (tall_mixed_ok(op, y->data, m->data) || (!tall_fast_ok(op, y->data, m->data) && tall_unaligned_ok(op, y->data, m->data))) {   // (rows off the pack grid too)
         if (op->nonlinear && !op->pointed)
             return jh_fail(JH_ERR_STATE, "jh_blockop_normal_mul_range: operator has nonlinear blocks and no linearisation point (jh_blockop_point)");
         return jhb::tall_adj(op, y->data, m->data, 1, true, lo, hi);

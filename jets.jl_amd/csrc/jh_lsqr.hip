@@ -351,10 +351,10 @@ static int lsqr_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *
     JH_TRY(jh_bvec_info(xs[0], &nb, &n, &dtype, nullptr));
     for (int k = 0; k < M; k++) {
         JH_REQUIRE(xs[k]->length == n && xs[k]->dtype == dtype, "jh_lsqr_solve: member %d's x differs in length or element type", k);
-        // before anything is touched: the caller can still take another path.  One shard, no exchange: whole-vector passes only, which also take rows off
-        // the 16-byte pack grid (jh_blockop_tall_step_ok); the pipelined exchange cuts the domain into 16-byte aligned ranges
-        if (!(ex == Exch::none ? jh_blockop_tall_step_ok(ops[k], us[k]->data, xs[k]->data) : jh_blockop_tall_fast(ops[k], us[k]->data, xs[k]->data)))
-            return jh_fail(JH_ERR_UNSUPPORTED, "jh_lsqr_solve: needs a tall operator of equal elementwise rows (16-byte aligned blocks when partitioned)");
+        // before anything is touched: the caller can still take another path.  Rows off the 16-byte pack grid are fine (jh_blockop_tall_step_ok): the
+        // pipelined exchange cuts the DOMAIN at 16-byte bounds, and the last range may end with the vector
+        if (!jh_blockop_tall_step_ok(ops[k], us[k]->data, xs[k]->data))
+            return jh_fail(JH_ERR_UNSUPPORTED, "jh_lsqr_solve: needs a tall operator of >= 2 equal elementwise rows");
     }
     std::vector<Tmp> t((size_t)M);
     const int64_t len1[1] = {n};
@@ -819,9 +819,9 @@ static int cgls_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *
     JH_TRY(jh_bvec_info(xs[0], &nb, &n, &dtype, nullptr));
     for (int k = 0; k < M; k++) {
         JH_REQUIRE(xs[k]->length == n && xs[k]->dtype == dtype, "jh_cgls_solve: member %d's x differs in length or element type", k);
-        // before anything is touched (one shard, no exchange: rows off the 16-byte pack grid too, as in lsqr_impl)
-        if (!(ex == Exch::none ? jh_blockop_tall_step_ok(ops[k], us[k]->data, xs[k]->data) : jh_blockop_tall_fast(ops[k], us[k]->data, xs[k]->data)) || ops[k]->nrow < 2)
-            return jh_fail(JH_ERR_UNSUPPORTED, "jh_cgls_solve: needs a tall (>= 2 rows) operator of equal elementwise rows (16-byte aligned blocks when partitioned)");
+        // before anything is touched (rows off the 16-byte pack grid too, as in lsqr_impl)
+        if (!jh_blockop_tall_step_ok(ops[k], us[k]->data, xs[k]->data) || ops[k]->nrow < 2)
+            return jh_fail(JH_ERR_UNSUPPORTED, "jh_cgls_solve: needs a tall (>= 2 rows) operator of equal elementwise rows");
     }
     struct Work {                                                         // domain-sized work vectors of one member
         jh_bvec *p = nullptr, *s = nullptr, *y = nullptr;
@@ -1396,8 +1396,8 @@ static int cgnr_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *
     JH_TRY(jh_bvec_info(xs[0], &nb, &n, &dtype, nullptr));
     for (int k = 0; k < M; k++) {
         JH_REQUIRE(xs[k]->length == n && xs[k]->dtype == dtype, "jh_cgnr_solve: member %d's x differs in length or element type", k);
-        if (!(ex == Exch::none ? jh_blockop_tall_step_ok(ops[k], bs[k]->data, xs[k]->data) : jh_blockop_tall_fast(ops[k], bs[k]->data, xs[k]->data)) || ops[k]->nrow < 2)
-            return jh_fail(JH_ERR_UNSUPPORTED, "jh_cgnr_solve: needs a tall (>= 2 rows) operator of equal elementwise rows (16-byte aligned blocks when partitioned)");
+        if (!jh_blockop_tall_step_ok(ops[k], bs[k]->data, xs[k]->data) || ops[k]->nrow < 2)
+            return jh_fail(JH_ERR_UNSUPPORTED, "jh_cgnr_solve: needs a tall (>= 2 rows) operator of equal elementwise rows");
     }
     struct Work {
         jh_bvec *p = nullptr, *s = nullptr, *y = nullptr;

@@ -1016,7 +1016,8 @@ int launch_tall_adj_mixed_u(const jh_blockop *op, void *out, const void *in, int
     jh_context &c = jh_ctx();
     const int64_t gx = (s_end - s_begin + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);
     const int from_found = (MODE == 0) ? c.adj_from_found : 0;                        // continue from what `out` holds (a wide operator's forward)
-    int64_t parts = from_found ? 1 : pick_adj_parts(gx, op->nrow), rows_per_part = 0;   // many rows of small blocks: split-row walk
+    int64_t parts = (from_found || s_end - s_begin < NS) ? 1 : pick_adj_parts(gx, op->nrow), rows_per_part = 0;   // many rows of small blocks: split-row walk (not for a range
+                                                                                                                  // shorter than one pack: it loads from before its begin)
     const int64_t part_stride = s_end - s_begin;
     void *slabs = nullptr;
     if (parts > 1) {

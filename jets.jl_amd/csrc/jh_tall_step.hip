@@ -879,8 +879,8 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     int wg = shape.wg, U = shape.U, D = shape.D;
     const int64_t gx = ((s_end - s_begin + NS - 1) / NS + (int64_t)wg * U - 1) / ((int64_t)wg * U);
     // many rows of small blocks: split-row walk (pick_adj_parts): u's rows are updated as before, w's sum is folded from slabs
-    int64_t parts = direct ? 1 : pick_adj_parts(gx, op->nrow);
-    int64_t rows_per_part = 0;
+    int64_t parts = (direct || s_end - s_begin < NS) ? 1 : pick_adj_parts(gx, op->nrow);   // (a range shorter than one pack -- the tail of an off-grid vector -- loads from before
+    int64_t rows_per_part = 0;                                                            //  its begin: no slabs indexed from there)
     const int64_t part_stride = s_end - s_begin;
     void *slabs = nullptr;
     if (parts > 1) {
@@ -1115,10 +1115,12 @@ int jh_blockop_bidiag_step_range(const jh_blockop *op, jh_bvec *u, const jh_bvec
     JH_REQUIRE(first_elem >= 0 && count >= 0 && first_elem + count <= v->length,
                "jh_blockop_bidiag_step_range: elements [%lld, %lld) outside the domain vector (%lld elements)", (long long)first_elem,
                (long long)(first_elem + count), (long long)v->length);
-    if (!jh_blockop_tall_fast(op, u->data, v->data) || (((uintptr_t)w->data) & 15u))
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_bidiag_step_range: needs a tall operator of elementwise rows with equal, 16-byte aligned blocks");
+    // (rows off the 16-byte pack grid: the plain walk's MIXED instantiations, like the whole-vector call -- the LAST range may then end inside a pack)
+    if (!jh_blockop_tall_step_ok(op, u->data, v->data) || (((uintptr_t)w->data) & (jh_dtype_size(op->dtype) / (jh_dtype_complex(op->dtype) ? 2 : 1) - 1)))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_bidiag_step_range: needs a tall operator of >= 2 equal elementwise rows");
     const int64_t es = (int64_t)jh_dtype_size(op->dtype);
-    JH_REQUIRE((first_elem * es) % 16 == 0 && (count * es) % 16 == 0, "jh_blockop_bidiag_step_range: chunk boundaries must be 16-byte aligned");
+    JH_REQUIRE((first_elem * es) % 16 == 0 && ((count * es) % 16 == 0 || first_elem + count == v->length),
+               "jh_blockop_bidiag_step_range: chunk boundaries must be 16-byte aligned (the last chunk may end with the vector)");
     const int64_t n = op->row_len[0], lo = first_elem, hi = first_elem + count;
     switch (op->dtype) {
     case JH_F32: return launch_bidiag<float, 1, 4>(op, u->data, v->data, w->data, n, alpha, beta, normsq, lo, hi, true);

@@ -115,8 +115,9 @@ def _team_contexts(J, nmem):
     return [base] + extra, extra
 
 
+@pytest.mark.parametrize("shape", [(64, 64, 16), (65, 63, 17)], ids=["aligned", "odd-blocks"])     # 69 615 elements: rows off the 16-byte grid, the last exchange range ends inside a pack
 @pytest.mark.parametrize("nmem", [2, 3])
-def test_a_team_of_contexts_runs_the_row_partitioned_flow(Jets, oracle, nmem):
+def test_a_team_of_contexts_runs_the_row_partitioned_flow(Jets, oracle, nmem, shape):
     import gc
 
     from jets_jl_amd import rowpart
@@ -127,7 +128,7 @@ def test_a_team_of_contexts_runs_the_row_partitioned_flow(Jets, oracle, nmem):
     ctxs, extra = _team_contexts(J, nmem)
     team = rowpart.Team(ctxs)
     try:
-        _team_flow(J, oracle, rowpart, team, ctxs, nmem, home)
+        _team_flow(J, oracle, rowpart, team, ctxs, nmem, home, shape)
     finally:
         team.close()
         gc.collect()                                                 # the members' vectors and operators die before their contexts
@@ -136,8 +137,8 @@ def test_a_team_of_contexts_runs_the_row_partitioned_flow(Jets, oracle, nmem):
             J.context_destroy(c)
 
 
-def _team_flow(J, oracle, rowpart, team, ctxs, nmem, home):
-    dt, nrow, shape = np.float32, 11, (64, 64, 16)
+def _team_flow(J, oracle, rowpart, team, ctxs, nmem, home, shape=(64, 64, 16)):
+    dt, nrow = np.float32, 11
     n = int(np.prod(shape))
     spc = J.JetSpace(dt, *shape)
     if True:

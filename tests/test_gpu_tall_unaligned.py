@@ -528,3 +528,50 @@ def test_dense_children_of_odd_dimensions_adjoint_on_under_aligned_packs(Jets, o
     lhs, rhs = J.dot_product_test(A, m, d)
     assert abs(lhs - rhs) / abs(lhs + rhs) < (1e-5 if tol > 1e-10 else 1e-12)
     J.close(A)
+
+
+# ---------------------------------------------------------------------------------- the ranged calls (the multi-GPU exchange's pipelining) off the pack grid
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64])
+@pytest.mark.parametrize("name", ["diag", "mixed"])
+@pytest.mark.parametrize("n", [69615, 49153, 16385 + 2])
+def test_ranged_calls_on_rows_off_the_pack_grid_equal_the_whole_ones(Jets, oracle, dt, name, n):
+    """jh_blockop_mul_adj_range / _normal_mul_range / _bidiag_step_range over the exchange's ranges (16-byte aligned bounds in the DOMAIN; the last range ends
+    with the vector -- inside a pack, and may be a single element) == the whole-vector calls, bit for bit; what a row-partitioned solver runs per chunk."""
+    import ctypes as C
+
+    from jets_jl_amd._ffi import check, lib
+
+    J = Jets
+    nrow = 5
+    A, ops = _mixed_ops(J, oracle, dt, _kinds(nrow, name), [n] * nrow, [n])
+    nat = _native(A)
+    step = 16384
+    ranges = [(lo, min(step, n - lo)) for lo in range(0, n, step)]
+    d = J.rand(J.range(A), seed=81, stream=0)
+    m = J.rand(J.domain(A), seed=80, stream=0)
+    whole = J.mul_(J.zeros(J.domain(A)), A.H, d)
+    parts = J.rand(J.domain(A), seed=82, stream=0)                                    # dirty: every element must be overwritten
+    for lo, cnt in ranges:
+        check(lib.jh_blockop_mul_adj_range(nat.handle, parts.handle, d.handle, lo, cnt))
+    assert_bits_equal(parts.to_numpy(), whole.to_numpy(), f"ranged adjoint {ranges[-1]}")
+    yw = J.mul_(J.zeros(J.domain(A)), J.compose(A.H, A), m)
+    yp = J.rand(J.domain(A), seed=83, stream=0)
+    for lo, cnt in ranges:
+        check(lib.jh_blockop_normal_mul_range(nat.handle, yp.handle, m.handle, lo, cnt))
+    assert_bits_equal(yp.to_numpy(), yw.to_numpy(), "ranged A'A")
+    out = C.c_double(0)
+    u1, u2 = J.rand(J.range(A), seed=84, stream=0), J.rand(J.range(A), seed=84, stream=0)
+    w1, w2 = J.zeros(J.domain(A)), J.rand(J.domain(A), seed=85, stream=0)
+    check(lib.jh_blockop_bidiag_step(nat.handle, u1.handle, m.handle, w1.handle, 0.75, -1.375, C.byref(out)))
+    total_whole = out.value
+    total = 0.0
+    for lo, cnt in ranges:
+        check(lib.jh_blockop_bidiag_step_range(nat.handle, u2.handle, m.handle, w2.handle, 0.75, -1.375, lo, cnt, C.byref(out)))
+        total += out.value
+    assert_bits_equal(u2.to_numpy(), u1.to_numpy(), "u: ranges == whole")
+    assert_bits_equal(w2.to_numpy(), w1.to_numpy(), "w: ranges == whole")
+    assert total == pytest.approx(total_whole, rel=1e-12)
+    if np.dtype(dt).itemsize < 16 and (n * np.dtype(dt).itemsize) % 16:
+        with pytest.raises(J.JetsHipError):                                           # a MIDDLE range must still end on a 16-byte bound
+            check(lib.jh_blockop_mul_adj_range(nat.handle, parts.handle, d.handle, 0, 16385 if np.dtype(dt).itemsize == 4 else 16383))
+    J.close(A)
