@@ -134,8 +134,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block
 #pragma unroll
     for (int k = 0; k < U; k++) {
         ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
-        sk[k] = ok[k] ? s0 + (int64_t)k * BLK * NS : 0;
-        acc[k] = (V)(S)0;
+        sk[k] = ok[k] ? pack_start<NS>(s0 + (int64_t)k * BLK * NS, n_scalars) : 0;   // (rows need not be whole, 16-byte aligned packs: ldu / st_pack / vnorm2_from,
+        acc[k] = (V)(S)0;                                                            //  jh_blockop_common.h; round 5, last session)
     }
     int64_t i = 0;
     for (; !direct && i + DEPTH <= nrow; i += DEPTH) {
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block
             const S *a = a_base ? a_base + (i + j) * a_stride : (const S *)blocks[i + j].coeff;
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                av[j][k] = ld<true>(reinterpret_cast<const V *>(a + sk[k]));
-                dv[j][k] = ld<true>(reinterpret_cast<const V *>(in + (i + j) * n_scalars + sk[k]));
+                av[j][k] = ldu<true, S, NS>(a + sk[k]);
+                dv[j][k] = ldu<true, S, NS>(in + (i + j) * n_scalars + sk[k]);
             }
         }
 #pragma unroll
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block
         const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
 #pragma unroll
         for (int k = 0; k < U; k++) {
-            V p = vmul<S, E, NS, V>(ld<true>(reinterpret_cast<const V *>(a + sk[k])),
-                                    scaled(ld<true>(reinterpret_cast<const V *>(in + i * n_scalars + sk[k]))), true);
+            V p = vmul<S, E, NS, V>(ldu<true, S, NS>(a + sk[k]),
+                                    scaled(ldu<true, S, NS>(in + i * n_scalars + sk[k])), true);
             acc[k] = direct ? p : acc[k] + p;
         }
     }
@@ -168,10 +168,11 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj_update(const jh_dev_block
     for (int k = 0; k < U; k++) {
         V s1 = (V)alpha * acc[k];
         V r = s1;
-        if (beta != (S)0) { V s2 = (V)beta * ld<false>(reinterpret_cast<const V *>(out + sk[k])); r = s1 + s2; }
+        if (beta != (S)0) { V s2 = (V)beta * ldu<false, S, NS>(out + sk[k]); r = s1 + s2; }
         if (ok[k]) {
-            st<false>(reinterpret_cast<V *>(out + sk[k]), r);
-            nrm += vnorm2<S, NS, V>(r);
+            const int64_t sn = s0 + (int64_t)k * BLK * NS;
+            st_pack<false, S, NS>(out, sn, sk[k], r);
+            nrm += vnorm2_from<S, NS, V>(r, (int)(sn - sk[k]));
         }
     }
     wg_sum_store<BLK>(nrm, partials + blockIdx.x);
@@ -787,14 +788,14 @@ int launch_adj_update(const jh_blockop *op, void *out, const void *in, int64_t n
     jh_context &c = jh_ctx();
     const S *a_base = op->diag_strided ? (const S *)op->blocks[0].coeff : nullptr;
     const int64_t a_stride = op->diag_stride_elems * E;
-    const int64_t nvec = n_scalars / NS;
+    const int64_t nvec = (n_scalars + NS - 1) / NS;
     const int direct = op->nrow == 1 ? 1 : 0;
     {   // many rows of small blocks: the row sum through the split walk of the plain adjoint, then out = (alpha*gamma)*t + beta*out
         // with ||out||^2 in a small epilogue (tolerance parity, like every split sum)
         void *tmp = nullptr;
         if (!wide) JH_TRY(jhb::split_adjoint_tmp(op, &tmp));   // (a wide in_scale is applied per d_i before the sum: the ordered walk)
         if (tmp) {
-            JH_TRY(jhb::tall_adj(op, tmp, in, 0, false));
+            JH_TRY(jhb::tall_adj(op, tmp, in, 0, !tall_fast_ok(op, in, tmp)));   // (rows off the pack grid: the MIXED instantiations)
             int64_t g = (n_scalars + 255) / 256;
             if (g > 2048) g = 2048;
             JH_TRY(jh_ensure_partials(g));
@@ -1173,8 +1174,8 @@ int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d,
 {
     JH_TRY(jh_enter(op, m, d));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_adj_axpby"));
-    if (!tall_fast_ok(op, d->data, m->data))
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_axpby: needs a tall all-DIAG operator with equal, 16-byte aligned blocks; "
+    if (!tall_fast_ok(op, d->data, m->data) && !(op->all_diag && tall_unaligned_ok(op, d->data, m->data)))   // (rows off the 16-byte pack grid: under-aligned packs)
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_axpby: needs a tall all-DIAG operator with equal blocks; "
                                            "use jh_blockop_mul_adj into a temporary, jh_lincomb and jh_norm instead");
     const int64_t n = op->row_len[0];
     switch (op->dtype) {
@@ -1214,8 +1215,8 @@ int jh_blockop_mul_adj_scaled(const jh_blockop *op, jh_bvec *m, const jh_bvec *d
     if (a_flags & JH_SCALAR_COMPLEX) return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_scaled: a Complex scalar takes the unfused chain (jh_lincomb_typed, jh_blockop_mul_adj)");
     JH_TRY(jh_enter(op, m, d));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_adj_scaled"));
-    if (!tall_fast_ok(op, d->data, m->data))
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_scaled: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
+    if (!tall_fast_ok(op, d->data, m->data) && !(op->all_diag && tall_unaligned_ok(op, d->data, m->data)))
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_scaled: needs a tall all-DIAG operator with equal blocks");
     const int64_t n = op->row_len[0];
     const bool wide = (a_flags & JH_SCALAR_WIDE) != 0;
     switch (op->dtype) {

@@ -575,3 +575,34 @@ def test_ranged_calls_on_rows_off_the_pack_grid_equal_the_whole_ones(Jets, oracl
         with pytest.raises(J.JetsHipError):                                           # a MIDDLE range must still end on a 16-byte bound
             check(lib.jh_blockop_mul_adj_range(nat.handle, parts.handle, d.handle, 0, 16385 if np.dtype(dt).itemsize == 4 else 16383))
     J.close(A)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,n", [(2, 67), (5, 1027), (33, 4099), (7, 35937), (3, 2 * 1024 * 4 * 4 + 1)])
+def test_the_fused_adjoint_update_off_the_pack_grid(Jets, oracle, dt, nrow, n):
+    """jh_blockop_mul_adj_axpby (m <- alpha A'(gamma d) + beta m, ||m||^2) and (a * A)' d = jh_blockop_mul_adj_scaled on odd block lengths: bit-exact
+    against the unfused chain, the norm counted once per scalar."""
+    import ctypes as C
+
+    from jets_jl_amd._ffi import check, lib
+
+    J = Jets
+    A, ops = _mixed_ops(J, oracle, dt, _kinds(nrow, "diag"), [n] * nrow, [n])
+    nat = _native(A)
+    alpha, beta, gamma = 0.75, -1.375, 0.5
+    hm = u01(oracle, dt, 41, 0, n)
+    hd = [u01(oracle, dt, 42, i, n) for i in range(nrow)]
+    m = J.from_numpy(hm, J.domain(A))
+    d = J.from_numpy(np.concatenate(hd), J.range(A))
+    out = C.c_double(0)
+    check(lib.jh_blockop_mul_adj_axpby(nat.handle, m.handle, d.handle, alpha, beta, gamma, C.byref(out)))
+    din = oracle.barr_lincomb([np.empty(n, dt) for _ in range(nrow)], [gamma], [hd])
+    tmpm = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], din)
+    refm = oracle.barr_lincomb([np.empty(n, dtype=dt)], [alpha, beta], [tmpm, [hm]])
+    assert_bits_equal(m.to_numpy().ravel(order="F"), refm[0], "m <- alpha*A'(gamma d) + beta*m")
+    tol = 1e-6 if np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-13
+    assert out.value == pytest.approx(float(np.sum(np.abs(refm[0].astype(np.complex128)) ** 2)), rel=tol)
+    mt = J.rand(J.domain(A), seed=9, stream=9)
+    check(lib.jh_blockop_mul_adj_scaled(nat.handle, mt.handle, d.handle, gamma, 0))
+    assert_bits_equal(mt.to_numpy().ravel(order="F"), tmpm[0], "(a * A)' d")
+    J.close(A)
