@@ -567,7 +567,7 @@ static int lsqr_graph_impl(const jh_blockop *op, jh_bvec *u, jh_bvec *x, int use
     jh_context &c = jh_ctx();
     c.last_lsqr_graph = 0;
     if (!c.lsqr_graph || !op || !u || !x || !res || maxiter < 1) return JH_OK;
-    if (!jh_blockop_tall_fast(op, u->data, x->data)) return JH_OK;
+    if (!jh_blockop_tall_step_ok(op, u->data, x->data)) return JH_OK;       // (rows off the 16-byte pack grid too: the plain step's MIXED instantiations)
     // one plain launch per step: no split walk (pick_adj_parts), no row-chunked launches; and only where launches and host
     // round trips matter: a pass over the operator and u below 1 GiB
     if (!(jh_bidiag_step_parts(op) == 1 && c.adj_rows_per_launch == 0)) return JH_OK;
@@ -1106,7 +1106,7 @@ static int cg_dev_impl(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0,
     JH_TRY(jh_enter(op, b, x));
     jh_context &c = jh_ctx();
     if (c.cg_dev == 0 || maxiter < 1) return JH_OK;
-    if (!(op->tall && op->all_diag) || !jh_blockop_tall_fast(op, b->data, x->data) || op->nrow < 2) return JH_OK;
+    if (!(op->tall && op->all_diag) || !jh_blockop_tall_step_ok(op, b->data, x->data) || op->nrow < 2) return JH_OK;   // (rows off the 16-byte pack grid too)
     // one plain launch per pass: CGLS' second pass is the one-pass step; the fused A'A of this loop (k_cg_normal) walks all rows in every
     // workgroup, which fills the chip when the domain gives a workgroup per CU (many rows of tiny blocks keep the split walk of the host loop)
     const int64_t normal_wgs = (n_packs_of(op) + 255) / 256;

@@ -271,13 +271,15 @@ __global__ __launch_bounds__(BLK) void k_cg_normal(const jh_dev_block *__restric
     // a thread owns U packs, BLK packs apart (the shapes of the fused normal operator, launch_tall_adj_mixed: fat workgroups once the
     // blocks are big -- 64 x 128^3 with 256 x 1 x 8: 120 us per pass, with 512 x 2 x 2: 80)
     int64_t sk[U];
+    int e0[U];
     bool ok[U];
     V pv[U], sv[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int64_t s0 = (((int64_t)blockIdx.x * U + u) * BLK + threadIdx.x) * NS;
         ok[u] = s0 < n_scalars;
-        sk[u] = ok[u] ? s0 : 0;
+        sk[u] = ok[u] ? pack_start<NS>(s0, n_scalars) : 0;                       // (rows need not be whole, 16-byte aligned packs: ldu / st_pack, the partial last pack's
+        e0[u] = ok[u] ? (int)(s0 - sk[u]) : 0;                                   //  scalars before e0 belong to the neighbouring lane; round 5, last session)
     }
     // the state and this lane's packs of p and s are requested together, before the first decision (a launch of this size is paced by
     // round trips, not by bytes).  Folding the previous vector update's ||s||^2 partials and applying the second scalar update HERE, in
@@ -285,8 +287,8 @@ __global__ __launch_bounds__(BLK) void k_cg_normal(const jh_dev_block *__restric
     // before its first coefficient load -- 28.7 us per iteration against 20.2 at 64 x 64^3 (profiles/bench_cgnr_sizes_r04.txt).
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        pv[u] = ld<false>(reinterpret_cast<const V *>(p + sk[u]));
-        sv[u] = ld<false>(reinterpret_cast<const V *>(sres + sk[u]));
+        pv[u] = ldu<false, S, NS>(p + sk[u]);
+        sv[u] = ldu<false, S, NS>(sres + sk[u]);
     }
     const int done = stt->done, skip_p = stt->skip_p;
     const double bk = stt->bk, damp2 = stt->damp2;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(BLK) void k_cg_normal(const jh_dev_block *__restric
         for (int u = 0; u < U; u++) {
             const V bp = (V)(S)bk * pv[u];
             pv[u] = sv[u] + bp;
-            if (ok[u]) st<false>(reinterpret_cast<V *>(p + sk[u]), pv[u]);
+            if (ok[u]) st_pack<false, S, NS>(p, sk[u] + e0[u], sk[u], pv[u]);
         }
     }
     V acc[U];
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(BLK) void k_cg_normal(const jh_dev_block *__restric
         for (int j = 0; j < DEPTH; j++) {
             const S *a = a_base ? a_base + (i + j) * a_stride : (const S *)blocks[i + j].coeff;
 #pragma unroll
-            for (int u = 0; u < U; u++) av[j][u] = ld<NT>(reinterpret_cast<const V *>(a + sk[u]));
+            for (int u = 0; u < U; u++) av[j][u] = ldu<NT, S, NS>(a + sk[u]);
         }
 #pragma unroll
         for (int j = 0; j < DEPTH; j++)
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(BLK) void k_cg_normal(const jh_dev_block *__restric
         const S *a = a_base ? a_base + i * a_stride : (const S *)blocks[i].coeff;
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const V av = ld<NT>(reinterpret_cast<const V *>(a + sk[u]));
+            const V av = ldu<NT, S, NS>(a + sk[u]);
             const V t = vmul<S, E, NS, V>(av, pv[u], false);
             acc[u] = acc[u] + vmul<S, E, NS, V>(av, t, true);
         }
@@ -338,9 +340,9 @@ __global__ __launch_bounds__(BLK) void k_cg_normal(const jh_dev_block *__restric
             acc[u] = acc[u] + dp;
         }
         if (ok[u]) {
-            st<false>(reinterpret_cast<V *>(y + sk[u]), acc[u]);
+            st_pack<false, S, NS>(y, sk[u] + e0[u], sk[u], acc[u]);
 #pragma unroll
-            for (int e = 0; e < NS; e++) part += (double)pv[u][e] * (double)acc[u][e];   // Re <p, y>: over the scalars (a complex vector is 2n reals here)
+            for (int e = 0; e < NS; e++) part += e >= e0[u] ? (double)pv[u][e] * (double)acc[u][e] : 0.0;   // Re <p, y>: over the scalars (a complex vector is 2n reals here)
         }
     }
     wg_sum_store<BLK>(part, partials + blockIdx.x);
@@ -1136,9 +1138,9 @@ bool jh_blockop_tall_step_ok(const jh_blockop *op, const void *rng_ptr, const vo
 int jh_launch_cg_normal(const jh_blockop *op, jh_bvec *p, const jh_bvec *s, jh_bvec *y, const jh_cg_dev *st, double *partials, int64_t *nparts)
 {
     jh_context &c = jh_ctx();
-    JH_REQUIRE(op->all_diag && tall_fast_ok(op, nullptr, p->data), "cg normal pass: needs a tall all-DIAG operator with equal, 16-byte aligned blocks");
+    JH_REQUIRE(op->all_diag && (tall_fast_ok(op, nullptr, p->data) || tall_unaligned_ok(op, nullptr, p->data)), "cg normal pass: needs a tall all-DIAG operator with equal blocks");
     const int64_t n = op->row_len[0];
-    const int64_t packs = (n * (int64_t)jh_dtype_size(op->dtype)) / 16;
+    const int64_t packs = (n * (int64_t)jh_dtype_size(op->dtype) + 15) / 16;
     // launch-bound domains: thin workgroups with eight rows in flight; from 2 MiB blocks on the fused normal operator's shapes
     const int shape = packs >= ((int64_t)1 << 22) ? 2 : (packs >= ((int64_t)1 << 17) ? 1 : 0);
     const int64_t per_wg = shape == 2 ? 4096 : (shape == 1 ? 1024 : 256);

@@ -82,9 +82,10 @@ def test_graph_replay_survives_scratch_growth_and_other_operators(Jets, oracle):
 
 
 # ---- round 4: CGLS and CG on the normal equations with the recurrences on the device (jh_lsqr.hip: cg_dev_impl) --------------------------
+@pytest.mark.parametrize("shape", [(32, 16, 8), (31, 17, 7)], ids=["aligned", "odd-blocks"])    # 3689 elements: rows off the 16-byte pack grid (round 5)
 @pytest.mark.parametrize("solver", ["cgnr", "cgls"])
 @pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
-def test_graph_replayed_cg_loops_of_small_operators_have_the_bits_of_the_host_driven_loop(Jets, oracle, dt, solver):
+def test_graph_replayed_cg_loops_of_small_operators_have_the_bits_of_the_host_driven_loop(Jets, oracle, dt, solver, shape):
     """Small operators (docs/src/index.md:235-246: the iterative solver over the block operator): an iteration of CGLS / of CG through
     the fused A'A is 4-5 graph nodes whose coefficients live in device memory; with lsqr_graph = 0 the same kernels run eagerly and the
     host applies the same two scalar updates between them.  x, the iteration count, the stopping rule and the whole history must be
@@ -95,7 +96,7 @@ def test_graph_replayed_cg_loops_of_small_operators_have_the_bits_of_the_host_dr
     from .helpers import make_tall_diag
 
     J = Jets
-    nrow, shape = 9, (32, 16, 8)
+    nrow = 9
     A, _, _, diags = make_tall_diag(J, oracle, dt, nrow, shape)
     n = int(np.prod(shape))
     hb = (u01(oracle, dt, 71, 0, nrow * n) - dt(0.5)).astype(dt)

@@ -561,13 +561,14 @@ def test_forced_iterations_far_past_convergence_stay_finite(Jets, monkeypatch, n
     assert float(np.linalg.norm((x - x_true.to_numpy()).ravel()) / np.linalg.norm(x_true.to_numpy().ravel())) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(32, 16, 8), (31, 17, 7)], ids=["aligned", "odd-blocks"])    # 3689 elements: rows off the 16-byte pack grid (round 5)
 @pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64])
-def test_graph_replayed_loop_of_small_operators_has_the_bits_of_the_host_loop(Jets, oracle, dt):
+def test_graph_replayed_loop_of_small_operators_has_the_bits_of_the_host_loop(Jets, oracle, dt, shape):
     """Small operators: the recurrences live on the device and one iteration is replayed as a hipGraph (jh_lsqr.hip: lsqr_graph_impl)
     -- same kernels, same fp64 operations in the same order as the host loop, so x, the iteration count, the stopping rule and the
     whole history must be IDENTICAL, with early stopping, damping, a warm start, forced iterations and a single iteration."""
     J = Jets
-    nrow, shape = 9, (32, 16, 8)
+    nrow = 9
     A, _, _, _ = make_tall_diag(J, oracle, dt, nrow, shape)
     n = int(np.prod(shape))
     hb = (u01(oracle, dt, 71, 0, nrow * n) - dt(0.5)).astype(dt)
