@@ -210,3 +210,65 @@ def test_config5_100_lsqr_iterations_on_1024x256cubed(Jets, oracle):
         assert out.history[0][1] < 0.5 * bnorm and out.history[min(5, out.itn - 1)][1] < 1e-2 * bnorm, (name, out.history[:6])
         got = out.x._download(0, W).astype(np.float64)
         assert np.linalg.norm(got - xr) / np.linalg.norm(xr) <= 1e-4, name
+
+
+def test_headline_size_with_an_odd_edge_1024x255cubed_properties(Jets, oracle):
+    """The headline operator with an ODD edge -- 1024 x 1 of 255^3 Float32 blocks (63 GiB of coefficients + 63 GiB range vector): three rows in four start off a
+    16-byte boundary of their slab and every row ends inside a 16-byte pack (round 5, last session: under-aligned packs).  The same
+    size-independent properties as config 4: slices of the adjoint (all 1024 rows in order), of the fused A'A, of the forward and of the one-pass step against
+    the oracle on regenerated slices -- including the LAST elements of rows and of the domain, where the partial packs are -- bit for bit; fused == chained
+    on the whole vector; the dot-product test; ||u||^2 counted once per scalar."""
+    import ctypes as C
+
+    from jets_jl_amd import jetblock
+    from jets_jl_amd._ffi import check, lib
+
+    info = Jets.device_info()
+    if info["free_mem"] < 200 * 2 ** 30:
+        pytest.skip(f"needs ~195 GiB of free HBM, device reports {info['free_mem'] / 2**30:.0f} GiB")
+    nblocks, edge = 1024, 255
+    n = edge ** 3
+    assert (n * 4) % 16 != 0
+    A, coeff, m, d = _build(Jets, nblocks, edge)
+    f32 = np.float32
+    W = 4096
+    offs = (0, 12345 * 4 + 1, n // 2 + 63, n - W)                                # the last slice ends with the row: the partial pack
+    mt = Jets.mul_(Jets.zeros(Jets.domain(A)), A.H, d)
+    for off in offs:
+        ha = [oracle.rng_u01(f32, 1, 0, i * n + off, W) for i in range(nblocks)]
+        hd = [oracle.rng_u01(f32, 3, 0, i * n + off, W) for i in range(nblocks)]
+        ref = oracle.block_df_adj([[oracle.Block("diag", W, coeff=g)] for g in ha], [np.zeros(W, dtype=f32)], hd)[0]
+        assert_bits_equal(mt._download(off, W), ref, f"adjoint slice at {off}")
+    md = float(Jets.dot(m, mt))
+    y_fused = Jets.mul(A.H @ A, m)
+    for off in (0, n - W):
+        hm0 = oracle.rng_u01(f32, 2, 0, off, W)
+        ha0 = [oracle.rng_u01(f32, 1, 0, i * n + off, W) for i in range(nblocks)]
+        ref_y = oracle.normal_df([[oracle.Block("diag", W, coeff=g)] for g in ha0], [np.zeros(W, dtype=f32)], [hm0])[0]
+        assert_bits_equal(y_fused._download(off, W), ref_y, f"fused normal slice at {off}")
+    Jets.mul_(d, A, m)
+    for i in (0, 1, 2, 3, 511, 1023):                                          # rows 1 .. 3: the three misalignments
+        for off in (0, n // 3, n - W):
+            ha = oracle.rng_u01(f32, 1, 0, i * n + off, W)
+            hm = oracle.rng_u01(f32, 2, 0, off, W)
+            assert_bits_equal(d._download(i * n + off, W), ha * hm, f"forward row {i} slice at {off}")
+    y_chain = Jets.mul_(Jets.zeros(Jets.domain(A)), A.H, d)
+    diff = (y_fused - y_chain).materialize()
+    assert float(Jets.norm(diff, math.inf)) == 0.0
+    d0 = Jets.rand(Jets.range(A), seed=3, stream=0)
+    lhs = float(Jets.dot(d, d0))
+    assert abs(lhs - md) / abs(lhs + md) < 1e-5
+    del d0
+    nat = jetblock._native_op(A.jet.s["_native"], A.jet.s["ops"], A.jet.rng.eltype())
+    w, out = Jets.zeros(Jets.domain(A)), C.c_double(0)
+    check(lib.jh_blockop_bidiag_step(nat.handle, d.handle, m.handle, w.handle, 0.75, -1.375, C.byref(out)))
+    for off in (0, n // 2 + 63, n - W):
+        hm = oracle.rng_u01(f32, 2, 0, off, W)
+        ha = [oracle.rng_u01(f32, 1, 0, i * n + off, W) for i in range(nblocks)]
+        hu = [f32(0.75) * (g * hm) + f32(-1.375) * (g * hm) for g in ha]
+        for i in (0, 1, 700, 1023):
+            assert_bits_equal(d._download(i * n + off, W), hu[i], f"step: u row {i} slice at {off}")
+        ref_w = oracle.block_df_adj([[oracle.Block("diag", W, coeff=g)] for g in ha], [np.zeros(W, dtype=f32)], hu)[0]
+        assert_bits_equal(w._download(off, W), ref_w, f"step: w slice at {off}")
+    N = float(nblocks) * n
+    assert out.value == pytest.approx(N * 0.625 ** 2 / 9, rel=1e-3)
