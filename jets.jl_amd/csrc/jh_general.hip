@@ -520,19 +520,20 @@ __global__ __launch_bounds__(256) void k_grid_tile(const jh_dev_block *__restric
 #pragma unroll
     for (int r = 0; r < R; r++) line[r] = grp * R + r < nlines ? grp * R + r : nlines - 1;
     for (int64_t s0 = (tile * 256 * U + threadIdx.x) * NS; s0 < n_scalars; s0 += (int64_t)ntiles * 256 * U * NS) {
-        int64_t s[U];
-        bool ok[U];
+        int64_t s[U], sn[U];                                                 // sn: where the pack nominally starts; s: where it is loaded from (blocks need not be
+        bool ok[U];                                                         // whole, 16-byte aligned packs: ldu / pack_start / st_pack; round 5, last session)
 #pragma unroll
         for (int u = 0; u < U; u++) {                                       // U packs per lane, 256 lanes apart (clamped: branch-free loads)
             ok[u] = s0 + (int64_t)u * 256 * NS < n_scalars;
-            s[u] = ok[u] ? s0 + (int64_t)u * 256 * NS : s0;
+            sn[u] = ok[u] ? s0 + (int64_t)u * 256 * NS : s0;
+            s[u] = pack_start<NS>(sn[u], n_scalars);
         }
         V acc[R][U];
 #pragma unroll
         for (int r = 0; r < R; r++)
 #pragma unroll
             for (int u = 0; u < U; u++)
-                acc[r][u] = TRANSPOSED ? (V)(S)0 : ld<true>(reinterpret_cast<const V *>(out + line[r] * n_scalars + s[u]));   // `_m .= 0` (1042) / d as found (1024)
+                acc[r][u] = TRANSPOSED ? (V)(S)0 : ldu<true, S, NS>(out + line[r] * n_scalars + s[u]);   // `_m .= 0` (1042) / d as found (1024)
         const S *na[QQ][R];                                                   // coefficient pointers, one group of QQ steps ahead
 #pragma unroll
         for (int q = 0; q < QQ; q++)
@@ -555,9 +556,9 @@ __global__ __launch_bounds__(256) void k_grid_tile(const jh_dev_block *__restric
             for (int q = 0; q < QQ; q++)
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    x[q][u] = ld<false>(reinterpret_cast<const V *>(in + (q0 + q) * n_scalars + s[u]));          // shared by every line group: through the caches
+                    x[q][u] = ldu<false, S, NS>(in + (q0 + q) * n_scalars + s[u]);          // shared by every line group: through the caches
 #pragma unroll
-                    for (int r = 0; r < R; r++) c[q][r][u] = ld<true>(reinterpret_cast<const V *>(a[q][r] + s[u]));   // streamed once
+                    for (int r = 0; r < R; r++) c[q][r][u] = ldu<true, S, NS>(a[q][r] + s[u]);   // streamed once
                 }
 #pragma unroll
             for (int q = 0; q < QQ; q++)
@@ -572,10 +573,10 @@ __global__ __launch_bounds__(256) void k_grid_tile(const jh_dev_block *__restric
             for (int r = 0; r < R; r++) aq[r] = (const S *)blocks[line[r] * lstep + q * qstep].coeff;
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const V x = ld<false>(reinterpret_cast<const V *>(in + q * n_scalars + s[u]));
+                const V x = ldu<false, S, NS>(in + q * n_scalars + s[u]);
                 V c[R];
 #pragma unroll
-                for (int r = 0; r < R; r++) c[r] = ld<true>(reinterpret_cast<const V *>(aq[r] + s[u]));
+                for (int r = 0; r < R; r++) c[r] = ldu<true, S, NS>(aq[r] + s[u]);
 #pragma unroll
                 for (int r = 0; r < R; r++) acc[r][u] = acc[r][u] + vmul<S, E, NS, V>(c[r], x, TRANSPOSED);
             }
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(256) void k_grid_tile(const jh_dev_block *__restric
         for (int r = 0; r < R; r++)
 #pragma unroll
             for (int u = 0; u < U; u++)
-                if (ok[u] && grp * R + r < nlines) st<true>(reinterpret_cast<V *>(out + line[r] * n_scalars + s[u]), acc[r][u]);
+                if (ok[u] && grp * R + r < nlines) st_pack<true, S, NS>(out + line[r] * n_scalars, sn[u], s[u], acc[r][u]);
     }
 }
 
@@ -717,6 +718,19 @@ bool grid_diag_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr
     return op->coeff_aligned16;
 }
 
+// the register-tiled kernel of such grids also takes blocks off the 16-byte pack grid (under-aligned packs, a partial last pack per block)
+bool grid_tile_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
+{
+    if (grid_diag_ok(op, rng_ptr, dom_ptr)) return true;
+    if (!(op->all_diag && op->nrow >= 2 && op->ncol >= 2) || jh_ctx().tall_unaligned == 0) return false;
+    const size_t es = jh_dtype_size(op->dtype), sa = jh_dtype_complex(op->dtype) ? es / 2 : es;
+    const int64_t n = op->row_len[0];
+    if (n * (int64_t)es < 16 || !op->uniform_rows) return false;
+    for (int64_t v : op->col_len) if (v != n) return false;
+    if ((((uintptr_t)rng_ptr) | ((uintptr_t)dom_ptr)) & (sa - 1)) return false;
+    return op->coeff_scalar_aligned;
+}
+
 // second stage of the general kernels' split walk: out[line] = (add_found ? out as found : 0) + slab 0 + slab 1 + ... for every
 // line (block row of the range / block column of the domain) that the operator touches; 64 scalar lanes x 4 part lanes per
 // workgroup, fp64 accumulation, fixed order => deterministic (tolerance parity with the single ordered sum)
@@ -842,7 +856,7 @@ int launch_grid_tile(const jh_blockop *op, const S *in, S *out, int64_t in_bytes
     const int U = R == 4 ? 2 : 1;
     const int64_t ngroups = (nlines + R - 1) / R;
     unsigned ntiles, grid;
-    general_grid((n_scalars / NS + 256 * U - 1) / (256 * U), ngroups, ntiles, grid, general_use_xcd(in_bytes));
+    general_grid(((n_scalars + NS - 1) / NS + 256 * U - 1) / (256 * U), ngroups, ntiles, grid, general_use_xcd(in_bytes));
 #define JH_TILE(RR, QQ, UU) hipLaunchKernelGGL((k_grid_tile<S, E, NS, RR, QQ, UU, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, \
                                                op->nrow, op->ncol, n_scalars, in, out, ntiles, (unsigned)ngroups)
     if (R == 8) JH_TILE(8, 2, 1);
@@ -962,7 +976,7 @@ int general_fwd(const jh_blockop *op, void *d, const void *m, int fmode = 0)
         JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)out_scalars * sizeof(S), &slabs));
     }
     c.last_adj_parts = parts;
-    if (gdiag && parts == 1 && c.grid_tile)
+    if (vec && !fmode && parts == 1 && c.grid_diag && c.grid_tile && grid_tile_ok(op, d, m))
         return launch_grid_tile<S, E, NS, false>(op, (const S *)m, (S *)d, op->col_off[(size_t)op->ncol] * (int64_t)(sizeof(S) * E));
     if (vec && !fmode && parts == 1 && c.general_tile && general_tile_ok(op, d, m))
         return launch_general_tile<S, E, NS, false>(op, (const S *)m, (S *)d, op->col_off[(size_t)op->ncol] * (int64_t)(sizeof(S) * E));
@@ -1019,7 +1033,7 @@ int general_adj(const jh_blockop *op, void *m, const void *d)
         JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)out_scalars * sizeof(S), &slabs));
     }
     c.last_adj_parts = parts;
-    if (vec && parts == 1 && c.grid_diag && c.grid_tile && grid_diag_ok(op, d, m))
+    if (vec && parts == 1 && c.grid_diag && c.grid_tile && grid_tile_ok(op, d, m))
         return launch_grid_tile<S, E, NS, true>(op, (const S *)d, (S *)m, op->row_off[(size_t)op->nrow] * (int64_t)(sizeof(S) * E));
     if (vec && parts == 1 && c.general_tile && general_tile_ok(op, d, m))
         return launch_general_tile<S, E, NS, true>(op, (const S *)d, (S *)m, op->row_off[(size_t)op->nrow] * (int64_t)(sizeof(S) * E));

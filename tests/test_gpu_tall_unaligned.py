@@ -606,3 +606,34 @@ def test_the_fused_adjoint_update_off_the_pack_grid(Jets, oracle, dt, nrow, n):
     check(lib.jh_blockop_mul_adj_scaled(nat.handle, mt.handle, d.handle, gamma, 0))
     assert_bits_equal(mt.to_numpy().ravel(order="F"), tmpm[0], "(a * A)' d")
     J.close(A)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 2), (4, 3), (9, 16), (33, 5)])
+@pytest.mark.parametrize("n", [7, 1027, 2 * 1024 * 4 + 1])
+def test_grids_of_plain_diagonals_of_odd_blocks_on_the_all_diagonal_kernel(Jets, oracle, dt, shape, n):
+    """M x K grids whose blocks are ALL plain diagonals of an odd length: k_grid_tile (2 / 4 / 8 lines per workgroup) on under-aligned packs, against the
+    general register-tiled kernel (grid_tile = 0 ... grid_diag = 0) and the oracle: forward into a dirty d (1024), adjoint (1042-1053), bit for bit."""
+    J = Jets
+    if n * np.dtype(dt).itemsize < 16:
+        pytest.skip("less than one pack per block")
+    M, K = shape
+    A, ops = _mixed_ops(J, oracle, dt, [["diag"] * K for _ in range(M)], [n] * M, [n] * K)
+    hm = [u01(oracle, dt, 31, j, n) for j in range(K)]
+    hd = [u01(oracle, dt, 32, i, n) for i in range(M)]
+    hmt = [u01(oracle, dt, 33, j, n) for j in range(K)]
+    want_d = oracle.block_df(ops, [b.copy() for b in hd], hm)
+    want_m = oracle.block_df_adj(ops, [b.copy() for b in hmt], want_d)
+    try:
+        for knobs in (dict(), dict(grid_tile=2), dict(grid_tile=4), dict(grid_tile=8), dict(grid_tile=0), dict(grid_diag=0), dict(tall_unaligned=0)):
+            J.tune(grid_tile=1, grid_diag=1, tall_unaligned=1)
+            J.tune(**knobs)
+            d = J.from_numpy(np.concatenate(hd), J.range(A))
+            J.mul_(d, A, J.from_numpy(np.concatenate(hm), J.domain(A)))
+            assert_bits_equal(d.to_numpy(), np.concatenate(want_d), f"{M} x {K} of {n} forward, {knobs}")
+            mt = J.from_numpy(np.concatenate(hmt), J.domain(A))
+            J.mul_(mt, A.H, d)
+            assert_bits_equal(mt.to_numpy(), np.concatenate(want_m), f"{M} x {K} of {n} adjoint, {knobs}")
+    finally:
+        J.tune(grid_tile=1, grid_diag=1, tall_unaligned=1)
+    J.close(A)
