@@ -271,8 +271,7 @@ int jh_blockop_mul(const jh_blockop *op, jh_bvec *d, const jh_bvec *m);
  * the fused sums (jh_blocksum_*), the block-vector primitives and jh_bcast_apply[_many] -- same bits as on aligned blocks' kernels (the same terms in the
  * same order) -- and the *_range calls with the partitioned / team solvers built on them: the ranges are cut in the DOMAIN at 16-byte bounds as before, the
  * last one may end with the vector (inside a pack).  jh_blockop_mul_adj_axpby / _mul_adj_scaled and the graph-replayed small-operator loops likewise.
- * Not specialised for such blocks (correct, slower): the FORWARD of a list of dense children of odd dimensions runs 4 bytes per lane.  jh_tune_set("tall_unaligned", 0) restores the 4-byte-per-lane kernels
- * of rounds 1-4 for every such operator. */
+ * jh_tune_set("tall_unaligned", 0) restores the 4-byte-per-lane kernels of rounds 1-4 for every such operator. */
 /* mul!(m, A', d) -> JetBlock_df'!, src/Jets.jl:1034-1057: m zeroed when nrow > 1 (1042), rows summed
  * in order i = 0..nrow-1 with the product rounded before the add (1049) => bit-exact on one GPU.
  * Exception, automatic from 256 rows on when a block is too small to fill the chip with one thread per 16 bytes of the

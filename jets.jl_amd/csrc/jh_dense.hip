@@ -59,6 +59,24 @@ template <typename S, int NS> __device__ inline typename vec_of<S, NS>::type ldg
         return *(gp)p;
     }
 }
+// store the pack loaded from sc for the nominal start s (jh_blockop_common.h: st_pack): all of it, or the scalars from s on
+template <typename S, int NS> __device__ inline void stgu_pack(S *row, int64_t s, int64_t sc, typename vec_of<S, NS>::type v)
+{
+    typedef typename vec_of<S, NS>::type V;
+    if constexpr (NS == 1) {
+        stg(row + s, v);
+    } else {
+        if (sc == s) {
+            typedef V __attribute__((aligned(alignof(S)))) UV;
+            typedef UV __attribute__((address_space(1))) *gp;
+            *(gp)(row + s) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < NS; e++)
+                if (sc + e >= s) stg(row + sc + e, (S)v[e]);
+        }
+    }
+}
 // sr (+ i si) += conj(a) . x over the scalars e >= e0 of one pack (e0 = 0: the whole pack)
 template <typename S, int E, int NS, typename V> __device__ inline void cols_accumulate(const V &a, const V &xv, int e0, double &sr, double &si)
 {
@@ -1225,16 +1243,19 @@ __global__ __launch_bounds__(256) void k_gemv_rows_list(const jh_dense_item *__r
     if ((int64_t)chunk * RL * NS >= ns) return;                               // (the whole workgroup: this child has fewer row chunks than the longest)
     const int64_t s = ((int64_t)chunk * RL + rowlane) * NS;
     const bool live = s < ns;
+    // (round 5, last session) the child's rows need not be whole, 16-byte aligned packs: under-aligned loads, the last pack of the rows from ns - NS and
+    // stored from its own first scalar on (the host guarantees ns >= NS for every child of the list when NS > E)
+    const int64_t sc = (NS > E && live && s + NS > ns) ? ns - NS : s;
     const S *x = in + it.x_off * E;
     V acc = (V)(S)0;
     if (live) {
-        const S *col = (const S *)it.A + s + (int64_t)cg * ns;
+        const S *col = (const S *)it.A + sc + (int64_t)cg * ns;
         const int64_t step = (int64_t)CG * ns;
         int64_t c = cg;
         for (; c + 15 * (int64_t)CG < nc; c += 16 * (int64_t)CG) {
             V a[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) a[k] = ldg_nt(reinterpret_cast<const V *>(col + (int64_t)k * step));
+            for (int k = 0; k < 16; k++) a[k] = ldgu_nt<S, NS>(col + (int64_t)k * step);
             col += 16 * step;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -1254,7 +1275,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows_list(const jh_dense_item *__r
             }
         }
         for (; c < nc; c += CG, col += step) {
-            V a = ldg_nt(reinterpret_cast<const V *>(col));
+            V a = ldgu_nt<S, NS>(col);
             if constexpr (E == 1) {
                 acc = acc + a * (V)x[c];
             } else {
@@ -1274,8 +1295,8 @@ __global__ __launch_bounds__(256) void k_gemv_rows_list(const jh_dense_item *__r
     S *out = direct_out ? direct_out + it.line_off * E : slabs + it.out_off * E;
     if (CG == 1) {
         if (live) {
-            if (add_found) acc = ldg(reinterpret_cast<const V *>(out + s)) + acc;
-            stg(reinterpret_cast<V *>(out + s), acc);
+            if (add_found) acc = ldgu<S, NS>(out + sc) + acc;
+            stgu_pack<S, NS>(out, s, sc, acc);
         }
         return;
     }
@@ -1284,8 +1305,8 @@ __global__ __launch_bounds__(256) void k_gemv_rows_list(const jh_dense_item *__r
     if (cg == 0 && live) {
         V t = sm[rowlane];
         for (int g = 1; g < CG; g++) t = t + sm[g * RL + rowlane];
-        if (add_found) t = ldg(reinterpret_cast<const V *>(out + s)) + t;
-        stg(reinterpret_cast<V *>(out + s), t);
+        if (add_found) t = ldgu<S, NS>(out + sc) + t;
+        stgu_pack<S, NS>(out, s, sc, t);
     }
 }
 
@@ -1358,17 +1379,20 @@ static inline int pow2_shift_at_least(int64_t v)                             // 
 
 // pass 0: y = B x for every item (max_out = the longest output, B's rows); pass 1: y = B' x (max_out = the most columns, max_in = the longest column)
 template <typename S, int E>
-int gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64_t max_in, int pass, void *slabs, const void *x, bool aligned, void *direct_out,
+int gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64_t max_in, int pass, void *slabs, const void *x, int aligned, void *direct_out,
               int add_found)
 {
     if (nitems == 0 || max_out == 0) return JH_OK;
     jh_context &c = jh_ctx();
     hipStream_t st = c.stream;
     constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
-    const bool vec_ok = aligned && ((((uintptr_t)x) | ((uintptr_t)slabs) | ((uintptr_t)direct_out)) & 15u) == 0;
-    // (the column kernel also on children off the 16-byte grid: under-aligned packs, k_gemv_cols_list)
-    const bool vec_cols = vec_ok || (pass == 1 && c.tall_unaligned != 0 && (((uintptr_t)x) & (sizeof(S) - 1)) == 0);
-    const int NS = (pass == 1 ? vec_cols : vec_ok) ? NSV : E;
+    // aligned: 2 every matrix, dimension and vector on the 16-byte grid; 1 not, but every dimension holds a pack (children of odd dimensions: under-aligned packs); 0 neither
+    const bool vec_ok = aligned == 2 && ((((uintptr_t)x) | ((uintptr_t)slabs) | ((uintptr_t)direct_out)) & 15u) == 0;
+    const bool scalar_aligned = ((((uintptr_t)x) | ((uintptr_t)slabs) | ((uintptr_t)direct_out)) & (sizeof(S) - 1)) == 0;
+    // (the column kernel sums a column shorter than a pack scalar by scalar itself; the row kernel needs every child's rows to hold one)
+    const bool vec_cols = vec_ok || (pass == 1 && c.tall_unaligned != 0 && scalar_aligned);
+    const bool vec_rows = vec_ok || (pass == 0 && aligned >= 1 && c.tall_unaligned != 0 && scalar_aligned);
+    const int NS = (pass == 1 ? vec_cols : vec_rows) ? NSV : E;
     if (pass == 0) {
         const int64_t lanes = (max_out * E + NS - 1) / NS;                   // row lanes of the longest child
         int sh = 8;                                                          // RL = 256: every lane a row lane, columns in order (the sequential loop's bits)
@@ -1382,7 +1406,7 @@ int gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64
         const int64_t chunks = (lanes + ((int64_t)1 << sh) - 1) >> sh;
         JH_REQUIRE(nitems * chunks < ((int64_t)1 << 31), "dense child list: %lld x %lld workgroups exceed the grid", (long long)nitems, (long long)chunks);
         c.last_dense_rl = (int64_t)1 << sh;
-        if (vec_ok)
+        if (vec_rows)
             hipLaunchKernelGGL((k_gemv_rows_list<S, E, NSV>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs, (S *)direct_out, add_found);
         else
             hipLaunchKernelGGL((k_gemv_rows_list<S, E, E>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs, (S *)direct_out, add_found);
@@ -1455,7 +1479,7 @@ int jh_launch_gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t n
 }
 
 // the dense children of one direction and pass of a sparse / mixed operator from their list (jh_blockop_create builds it)
-int jh_launch_gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64_t max_in, int pass, int dtype, void *slabs, const void *x, bool aligned,
+int jh_launch_gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64_t max_in, int pass, int dtype, void *slabs, const void *x, int aligned,
                         void *direct_out, int add_found)
 {
     switch (dtype) {

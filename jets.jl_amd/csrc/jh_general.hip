@@ -1211,7 +1211,7 @@ int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool tran
         for (int pass = 0; pass < 2; pass++)
             if (op->n_items[dir][pass] > 0) {
                 JH_TRY(jh_launch_gemv_list(op->dev_items[dir][pass], op->n_items[dir][pass], op->items_max_out[dir][pass], op->items_max_in[dir][pass], pass, op->dtype,
-                                           nullptr, in, op->dense_mixed_aligned, out, add_found));
+                                           nullptr, in, op->dense_mixed_aligned ? 2 : (op->lens_hold_a_pack ? 1 : 0), out, add_found));
                 launches++;
             }
         c.last_adj_parts = 1;
@@ -1230,7 +1230,7 @@ int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool tran
         for (int pass = 0; pass < 2; pass++)
             if (op->n_items[dir][pass] > 0) {
                 JH_TRY(jh_launch_gemv_list(op->dev_items[dir][pass], op->n_items[dir][pass], op->items_max_out[dir][pass], op->items_max_in[dir][pass], pass, op->dtype,
-                                           slabs, in, op->dense_mixed_aligned));
+                                           slabs, in, op->dense_mixed_aligned ? 2 : (op->lens_hold_a_pack ? 1 : 0)));
                 launches++;
             }
     } else

@@ -464,7 +464,7 @@ int jh_launch_gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t n
                              int64_t slab_stride, const void *x, int transposed, bool aligned, const int64_t *dev_row_off,
                              const int64_t *dev_col_off);           // jh_dense.hip: every dense child of a mixed operator in one or two launches
 int jh_launch_gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64_t max_in, int pass, int dtype, void *slabs, const void *x,
-                        bool aligned, void *direct_out = nullptr, int add_found = 0);                                  // jh_dense.hip: the dense children of one direction and pass of a dense_mixed operator, from their list
+                        int aligned, void *direct_out = nullptr, int add_found = 0);                                  // jh_dense.hip: the dense children of one direction and pass of a dense_mixed operator, from their list
 int jh_ensure_scratch(size_t bytes, void **out);
 extern "C" int jh_comm_exists(int *yes);  // jh_comm.hip (internal): the current context's communicator: 0 none, 1 of jh_comm_init_rank, 2 member of a single-process team
 extern "C" int jh_comm_destroy(void);   // jh_comm.hip; jh_shutdown tears the communicator down first   // growable device scratch (block-loop temporaries)
