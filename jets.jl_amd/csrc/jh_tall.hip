@@ -1036,7 +1036,12 @@ int launch_tall_adj_mixed_u(const jh_blockop *op, void *out, const void *in, int
     // (rows off the 16-byte grid: temporal loads, see launch_tall_fwd_mixed -- from 32 MiB rows on: 256 x 255^3 adjoint 5.83 -> 6.17 TB/s, but 512 x 127^3
     // 5.97 -> 5.73 and 1024 x 101^3 5.70 -> 5.67 on the same boxes)
     const bool off_grid = (n_scalars * (int64_t)sizeof(S)) % 16 != 0 || !op->coeff_aligned16 || ((((uintptr_t)out) | ((uintptr_t)in)) & 15u) != 0;
-    if (c.ua_nt == 0 || (c.ua_nt < 0 && off_grid && n_scalars * (int64_t)sizeof(S) >= ((int64_t)32 << 20))) JH_ADJ_MIXED(false); else JH_ADJ_MIXED(true);
+    // (the shape without the partial-pack logic only ever sees aligned rows: no temporal instantiation of it)
+    if constexpr (TAIL) {
+        if (c.ua_nt == 0 || (c.ua_nt < 0 && off_grid && n_scalars * (int64_t)sizeof(S) >= ((int64_t)32 << 20))) JH_ADJ_MIXED(false); else JH_ADJ_MIXED(true);
+    } else {
+        JH_ADJ_MIXED(true);
+    }
 #undef JH_ADJ_MIXED
     JH_CHECK_HIP(hipGetLastError());
     if (parts > 1) return launch_fold_parts<S, NS>(slabs, part_stride, parts, out, s_begin, s_end);

@@ -404,9 +404,6 @@ __device__ inline void st_nt_16(void *p, unsigned __attribute__((ext_vector_type
     // for its own stores, not behind inline assembly
     asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
-// one SCALAR of a pack, write-through (the chained step's TAIL: a lane hands on only the scalars it owns)
-__device__ inline void st_sc1_scalar(float *p, float v) { asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
-__device__ inline void st_sc1_scalar(double *p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
 __device__ inline unsigned __attribute__((ext_vector_type(4))) ld_sc1_16(const void *p)
 {
     unsigned __attribute__((ext_vector_type(4))) v;
@@ -414,11 +411,7 @@ __device__ inline unsigned __attribute__((ext_vector_type(4))) ld_sc1_16(const v
     return v;
 }
 
-// TAIL (round 5, session 3; MIXED 8-row shapes only): rows that are not whole, 16-byte aligned packs.  The last tile may be ragged: a lane whose pack is
-// the row's partial last one loads it from s_end - NS and owns its scalars from e0 on; a lane past the end loads that same pack and owns nothing
-// (e0 = NS) -- it stores nothing, counts nothing and hands nothing on, but goes through the barriers like everyone else.
-// Loads are temporal there (a line two neighbouring tiles share: jh_tall.hip, launch_tall_fwd_mixed).
-template <typename S, int E, int NS, int U, int DEPTH, int BLK, bool MIXED = false, bool TAIL = false>
+template <typename S, int E, int NS, int U, int DEPTH, int BLK, bool MIXED = false>
 __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_block *__restrict__ blocks, int64_t nrow,
                                                                 const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ u,
                                                                 const S *__restrict__ v, S *__restrict__ w, int64_t n_scalars, S alpha,
@@ -448,36 +441,15 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
         tile = ticket - chunk * ntiles;
     }
     const int64_t row0 = (int64_t)chunk * DEPTH, row1 = (row0 + DEPTH < nrow) ? row0 + DEPTH : nrow;
-    const int64_t span = s_end - s_begin;                                   // !TAIL: the host guarantees span % (U * BLK * NS) == 0: full tiles only
-    constexpr bool LNT = !TAIL;                                             // the streamed loads' policy
+    const int64_t span = s_end - s_begin;                                   // the host guarantees span % (U * BLK * NS) == 0: full tiles only
     int64_t sk[U];
-    int e0[U];                                                              // TAIL: the leading scalars of pack k this lane does NOT own (0: a whole pack; NS: past the end)
     V acc[U], vv[U];
 #pragma unroll
     for (int k = 0; k < U; k++) {
         sk[k] = s_begin + (((int64_t)tile * U + k) * BLK + threadIdx.x) * NS;
-        e0[k] = 0;
-        if constexpr (TAIL) {
-            const int64_t sn = sk[k];
-            sk[k] = sn + NS <= s_end ? sn : s_end - NS;
-            e0[k] = sn < s_end ? (int)(sn - sk[k]) : NS;
-        }
         acc[k] = (V)(S)0;
-        vv[k] = ldu<false, S, NS>(v + sk[k]);
+        vv[k] = ld<false>(reinterpret_cast<const V *>(v + sk[k]));
     }
-    // one pack of u: the whole pack as a streaming store, or (TAIL) the scalars this lane owns
-    auto store_u = [&](S *row, int k, V r) {
-        if constexpr (TAIL) {
-            if (e0[k] == 0) st_nt_16(row + sk[k], __builtin_bit_cast(U4, r));
-            else {
-#pragma unroll
-                for (int e = 0; e < NS; e++)
-                    if (e >= e0[k]) st<true>(row + sk[k] + e, (S)r[e]);
-            }
-        } else {
-            st_nt_16(row + sk[k], __builtin_bit_cast(U4, r));
-        }
-    };
     const bool use_old = (beta != (S)0);
     const bool full = row0 + DEPTH <= nrow;
     V av[DEPTH][U], uv[DEPTH][U];
@@ -498,13 +470,13 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
 #pragma unroll
         for (int j = 0; j < DEPTH; j++)
 #pragma unroll
-            for (int k = 0; k < U; k++) uv[j][k] = ldu<LNT, S, NS>(ub + j * ustep + sk[k]);
+            for (int k = 0; k < U; k++) uv[j][k] = ld<true>(reinterpret_cast<const V *>(ub + j * ustep + sk[k]));
         if (!MIXED && a_base) {
             const S *ap = a_base + row0 * a_stride;
 #pragma unroll
             for (int j = 0; j < DEPTH; j++)
 #pragma unroll
-                for (int k = 0; k < U; k++) av[j][k] = ldu<LNT, S, NS>(ap + j * a_stride + sk[k]);
+                for (int k = 0; k < U; k++) av[j][k] = ld<true>(reinterpret_cast<const V *>(ap + j * a_stride + sk[k]));
         } else {
             constexpr int G = DEPTH < 8 ? DEPTH : 8;                       // table entries are fetched G rows at a time: one scalar round trip per group
 #pragma unroll
@@ -521,7 +493,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
 #pragma unroll
                 for (int j = 0; j < G; j++)
 #pragma unroll
-                    for (int k = 0; k < U; k++) av[g + j][k] = ldu<LNT, S, NS>(ap[j] + sk[k]);
+                    for (int k = 0; k < U; k++) av[g + j][k] = ld<true>(reinterpret_cast<const V *>(ap[j] + sk[k]));
             }
         }
     }
@@ -554,8 +526,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
                     V t = vmul<S, E, NS, V>(av[j][k], vv[k], cj);           // mul!(tmp, A_i, v)
                     V r = (V)alpha * t;
                     if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; } // u_i .= alpha*tmp .+ beta*u_i
-                    store_u(u + (row0 + j) * n_scalars, k, r);
-                    nrm += TAIL ? vnorm2_from<S, NS, V>(r, e0[k]) : vnorm2<S, NS, V>(r);
+                    st_nt_16(u + (row0 + j) * n_scalars + sk[k], __builtin_bit_cast(U4, r));
+                    nrm += vnorm2<S, NS, V>(r);
                     acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], r, !cj);  // _m .+= conj(a_i) .* u_i   (1049)
                 }
             } else if constexpr (MIXED) {
@@ -564,8 +536,8 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
                     V t = on ? apply_block_loaded<S, E, NS, V>(blk[j], vv[k], av[j][k], false, false) : (V)(S)0;
                     V r = (V)alpha * t;
                     if (use_old) { V s2 = (V)beta * uv[j][k]; r = r + s2; }
-                    store_u(u + (row0 + j) * n_scalars, k, r);
-                    nrm += TAIL ? vnorm2_from<S, NS, V>(r, e0[k]) : vnorm2<S, NS, V>(r);
+                    st_nt_16(u + (row0 + j) * n_scalars + sk[k], __builtin_bit_cast(U4, r));
+                    nrm += vnorm2<S, NS, V>(r);
                     if (on) acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk[j], r, av[j][k], true, false);
                 }
             }
@@ -578,14 +550,14 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
             const bool on = !MIXED || b1.kind != JH_OP_ZERO, rc = !MIXED || block_reads_coeff(b1, false);
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                V a1 = rc ? ldu<LNT, S, NS>(a + sk[k]) : (V)(S)0;
+                V a1 = rc ? ld<true>(reinterpret_cast<const V *>(a + sk[k])) : (V)(S)0;
                 V t;
                 if constexpr (MIXED) t = on ? apply_block_loaded<S, E, NS, V>(b1, vv[k], a1, false, false) : (V)(S)0;
                 else t = vmul<S, E, NS, V>(a1, vv[k], false);
                 V r = (V)alpha * t;
-                if (use_old) { V s2 = (V)beta * ldu<LNT, S, NS>(u + i * n_scalars + sk[k]); r = r + s2; }
-                store_u(u + i * n_scalars, k, r);
-                nrm += TAIL ? vnorm2_from<S, NS, V>(r, e0[k]) : vnorm2<S, NS, V>(r);
+                if (use_old) { V s2 = (V)beta * ld<true>(reinterpret_cast<const V *>(u + i * n_scalars + sk[k])); r = r + s2; }
+                st_nt_16(u + i * n_scalars + sk[k], __builtin_bit_cast(U4, r));
+                nrm += vnorm2<S, NS, V>(r);
                 if constexpr (MIXED) { if (on) acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(b1, r, a1, true, false); }
                 else acc[k] = acc[k] + vmul<S, E, NS, V>(a1, r, true);
             }
@@ -594,38 +566,13 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_bidiag_chain(const jh_dev_blo
     if (chunk + 1 < nchunks) {                                              // hand the ordered partial sum on
         S *dst = wpart + (int64_t)(chunk & 1u) * span - s_begin;
 #pragma unroll
-        for (int k = 0; k < U; k++) {
-            if constexpr (TAIL) {
-                // ONLY the scalars this lane owns: what it holds for the others came from loads of u that a neighbour may already have updated in
-                // place -- a lane past the end holds nothing but such values (1024 lanes: 1 ... 3 wrong tail scalars of w in one run out of three,
-                // when every lane of the ragged tile wrote "the same" pack)
-                if (e0[k] == 0) st_sc1_16(dst + sk[k], __builtin_bit_cast(U4, acc[k]));
-                else {
-#pragma unroll
-                    for (int e = 0; e < NS; e++)
-                        if (e >= e0[k]) st_sc1_scalar(dst + sk[k] + e, (S)acc[k][e]);
-                }
-            } else {
-                st_sc1_16(dst + sk[k], __builtin_bit_cast(U4, acc[k]));
-            }
-        }
+        for (int k = 0; k < U; k++) st_sc1_16(dst + sk[k], __builtin_bit_cast(U4, acc[k]));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(&sync[2 + tile], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
 #pragma unroll
-        for (int k = 0; k < U; k++) {
-            if constexpr (TAIL) {
-                if (e0[k] == 0) stu<false, S, NS>(w + sk[k], acc[k]);
-                else {
-#pragma unroll
-                    for (int e = 0; e < NS; e++)
-                        if (e >= e0[k]) st<false>(w + sk[k] + e, (S)acc[k][e]);
-                }
-            } else {
-                st<false>(reinterpret_cast<V *>(w + sk[k]), acc[k]);
-            }
-        }
+        for (int k = 0; k < U; k++) st<false>(reinterpret_cast<V *>(w + sk[k]), acc[k]);
     }
     wg_sum_store<BLK>(nrm, partials + (size_t)chunk * ntiles + tile);     // by (chunk, tile): the fold's order does not depend on the walk
 }
@@ -917,9 +864,9 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     const int64_t span = s_end - s_begin;
     const bool knobs_free = !c.adj_wg && !c.adj_unroll && !c.adj_depth;
     int CD = 8, cb = 0;                                                   // rows per chunk; chained: workgroup size (0: the shape does not allow it)
-    const bool chain_base = !direct && parts == 1 && rows_per_launch == op->nrow;
-    // rows off the 16-byte grid chain on the MIXED 8-row shapes' TAIL instantiations (ragged last tile, under-aligned packs); knob step_chain_tail = 0: the plain walk
-    const bool tail = unaligned && c.step_chain_tail != 0 && span >= NS;
+    // (rows off the 16-byte grid keep the plain walk: a chained walk with a ragged last tile -- lanes that own part of a pack or nothing, handing on only what they own --
+    // was built, tested and measured at -3 ... +6 % against it, profiles/exp_r05_chain_tail.txt; not kept)
+    const bool chain_base = !direct && parts == 1 && rows_per_launch == op->nrow && !unaligned;
     if (chain_base && !mixed && (c.step_chunk == 0 || c.step_chunk == 32) && span % ((int64_t)256 * NS) == 0 && op->nrow > 32 &&
         (c.step_chain == 1 || (span / ((int64_t)256 * NS) >= 2048 && op->nrow >= 64)) && !(c.step_chain == 1 && c.adj_wg && c.adj_wg != 256)) {
         CD = 32;
@@ -928,14 +875,13 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
         CD = 16;
     }
     const int64_t nchunks = (op->nrow + CD - 1) / CD;
-    if (!cb && chain_base && nchunks >= 2 && (!unaligned || tail))
+    if (!cb && chain_base && nchunks >= 2)
         for (int b : {1024, 512, 256}) {
             if (CD == 16 && b == 1024) continue;
-            if (tail && E == 2 && b == 1024) continue;                     // (the complex TAIL instantiations do not fit 128 VGPRs per lane: 512 lanes at most)
             if (c.step_chain == 1 && c.adj_wg && c.adj_wg != b) continue;  // (knobs step_chain = 1 + adj_wg: that workgroup size, for sweeps)
-            if ((tail || span % ((int64_t)b * NS) == 0) && (c.step_chain == 1 || (b == 1024 && span / ((int64_t)b * NS) >= 1024 && op->nrow >= 16))) { cb = b; break; }
+            if (span % ((int64_t)b * NS) == 0 && (c.step_chain == 1 || (b == 1024 && span / ((int64_t)b * NS) >= 1024 && op->nrow >= 16))) { cb = b; break; }
         }
-    const int64_t ntiles = cb ? ((span + NS - 1) / NS + cb - 1) / cb : 0;
+    const int64_t ntiles = cb ? span / ((int64_t)cb * NS) : 0;
     if (cb && !(ntiles * nchunks * cb < ((int64_t)1 << 32) && ntiles < ((int64_t)1 << 24))) cb = 0;
     const bool chain_ok = cb != 0 && c.step_chain != 0 && (c.step_chain == 1 || knobs_free);
     const bool remap_ok = parts == 1 && gx % 8 == 0 && gx >= 64 && rows_per_launch == op->nrow;
@@ -984,15 +930,7 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
     hipLaunchKernelGGL((k_tall_diag_bidiag_chain<S, E, NS, 1, CDD, BLK, MIX>), dim3((unsigned)(ntiles * nchunks)), dim3(BLK), 0, c.stream, \
                        op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars, (S)alpha, (S)beta,   \
                        c.part_dev, s_begin, s_end, (unsigned)ntiles, (unsigned)nchunks, c.chain_sync, (S *)wpart, err, (unsigned)cband)
-#define JH_CHAIN_TAIL(BLK)                                                                                                \
-    hipLaunchKernelGGL((k_tall_diag_bidiag_chain<S, E, NS, 1, 8, BLK, true, true>), dim3((unsigned)(ntiles * nchunks)), dim3(BLK), 0, c.stream, \
-                       op->dev_blocks, op->nrow, a_base, a_stride, (S *)u, (const S *)v, (S *)w, n_scalars, (S)alpha, (S)beta,   \
-                       c.part_dev, s_begin, s_end, (unsigned)ntiles, (unsigned)nchunks, c.chain_sync, (S *)wpart, err, (unsigned)cband)
-        if (tail) {
-            if (cb == 1024) { if constexpr (E == 1) JH_CHAIN_TAIL(1024); }
-            else if (cb == 512) JH_CHAIN_TAIL(512);
-            else JH_CHAIN_TAIL(256);
-        } else if (mixed) {
+        if (mixed) {
             if (cb == 1024) JH_CHAIN(1024, true);
             else if (cb == 512) JH_CHAIN(512, true);
             else JH_CHAIN(256, true);
@@ -1008,7 +946,6 @@ int launch_bidiag(const jh_blockop *op, void *u, const void *v, void *w, int64_t
         }
 #undef JH_CHAIN
 #undef JH_CHAIN_D
-#undef JH_CHAIN_TAIL
         JH_CHECK_HIP(hipGetLastError());
         c.last_step_chain = nchunks;
         c.last_adj_parts = 1;

@@ -431,57 +431,6 @@ def test_the_fused_normal_operator_on_big_odd_blocks(Jets, oracle, dt):
         J.close(A)
 
 
-@pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("nrow,n,name,beta", [(17, 4099, "diag", -1.375), (33, 1027, "mixed", 0.5), (40, 2 * 4096 + 1, "diag", 0.0), (9, 1030301, "diag", -0.3),
-                                              (26, 67, "mixed", -2.0), (16, 4 * 1024 * 4 + 2, "mixed", 0.0)])
-def test_the_chained_step_with_a_ragged_last_tile(Jets, oracle, dt, nrow, n, name, beta):
-    """The one-pass step as chained row chunks (k_tall_diag_bidiag_chain's TAIL instantiations, forced by step_chain = 1) on rows off the pack grid: lanes past
-    the end of the last tile own nothing, the partial last pack is stored and counted once; u, w bit-exact against the unfused chain, like the plain walk."""
-    import ctypes as C
-
-    from jets_jl_amd._ffi import check, lib
-
-    J = Jets
-    if n * nrow * np.dtype(dt).itemsize > 2 ** 27 or n * np.dtype(dt).itemsize < 16:
-        pytest.skip("kept small / less than a pack")
-    A, ops = _mixed_ops(J, oracle, dt, _kinds(nrow, name), [n] * nrow, [n])
-    nat = _native(A)
-    alpha = 0.75
-    hv, hu = u01(oracle, dt, 51, 0, n), u01(oracle, dt, 52, 0, nrow * n)
-    hu_blocks = [hu[i * n:(i + 1) * n].copy() for i in range(nrow)]
-    tmp = oracle.block_df(ops, [np.zeros(n, dtype=dt) for _ in range(nrow)], [hv])
-    coefs, terms = ([alpha, beta], [tmp, hu_blocks]) if beta != 0.0 else ([alpha], [tmp])
-    ref_u = oracle.barr_lincomb([np.empty(n, dtype=dt) for _ in range(nrow)], coefs, terms)
-    ref_w = oracle.block_df_adj(ops, [np.full(n, 5, dtype=dt)], ref_u)
-    truth = float(np.sum(np.abs(np.concatenate(ref_u).astype(np.complex128)) ** 2))
-    tol = 1e-6 if np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-13
-    out = C.c_double(0)
-    v = J.from_numpy(hv, J.domain(A))
-    off_grid = (n * np.dtype(dt).itemsize) % 16 != 0
-    try:
-        for wg in (0, 256, 512, 1024):
-            J.tune(step_chain=1, adj_wg=wg)
-            u = J.from_numpy(hu, J.range(A))
-            w = J.rand(J.domain(A), seed=53, stream=0)
-            check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, alpha, beta, C.byref(out)))
-            chained = J.tune_get("last_step_chain")
-            if off_grid and not (np.dtype(dt).kind == "c" and wg == 1024):
-                assert chained > 0, f"the chained walk was not taken (adj_wg={wg})"
-            assert_bits_equal(u.to_numpy(), np.concatenate(ref_u), f"u, chained={chained}, adj_wg={wg}")
-            assert_bits_equal(w.to_numpy().ravel(order="F"), ref_w[0], f"w, chained={chained}, adj_wg={wg}")
-            assert out.value == pytest.approx(truth, rel=tol)
-        J.tune(step_chain=1, adj_wg=0, step_chain_tail=0)                             # the knob: the plain walk for such rows
-        u = J.from_numpy(hu, J.range(A))
-        w = J.rand(J.domain(A), seed=53, stream=0)
-        check(lib.jh_blockop_bidiag_step(nat.handle, u.handle, v.handle, w.handle, alpha, beta, C.byref(out)))
-        if off_grid:
-            assert J.tune_get("last_step_chain") == 0
-        assert_bits_equal(w.to_numpy().ravel(order="F"), ref_w[0], "w, plain walk")
-    finally:
-        J.tune(step_chain=-1, adj_wg=0, step_chain_tail=1)
-    J.close(A)
-
-
 # ---------------------------------------------------------------------------------- dense children of odd dimensions: the adjoint's column kernels
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("layout", ["tall", "wide", "blockdiag", "single"])
