@@ -529,6 +529,11 @@ int jh_blockop_f(const jh_blockop *op, jh_bvec *d, const jh_bvec *m)
 {
     JH_TRY(jh_enter(op, d, m));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_f"));
+    // round 5, last session: a TALL nonlinear operator of elementwise children (SQUARE, diagonals, identity, scalar, zero rows) evaluates F(m) on the tall
+    // tiling -- the model tile in registers, one pass over the rows (256 x 256^3 SQUARE children: see profiles/bench_unaligned_r05.txt) -- instead of
+    // the general one-line kernels; every row is written (1003), the same products
+    if (jh_ctx().tall_f != 0 && (tall_mixed_ok(op, d->data, m->data) || tall_unaligned_ok(op, d->data, m->data)))
+        return jhb::tall_fwd_mixed(op, d->data, m->data, 1);
     if (op->dense_batch) return jh_launch_gemv_batched(op->dev_blocks, op->nrow, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, false);
     if (op->dense_batch_wide) return jh_launch_gemv_batched(op->dev_blocks, op->ncol, op->blocks[0].nr, op->blocks[0].nc, op->dtype, d->data, m->data, 0, op->dense_aligned, true);
     if (op->dense_batch_grid) return dense_grid_fwd(op, d->data, m->data);

@@ -170,7 +170,7 @@ bool stream_is_capturing(hipStream_t st);
 // by element type; vectors as raw device pointers.  tall_adj: mode 0 the adjoint, 1 the fused A'A; mixed: rows of several kinds (the caller has
 // checked tall_fast_ok / tall_mixed_ok); [first_elem, end_elem) of the domain, end_elem < 0: the whole vector
 int tall_fwd(const jh_blockop *op, void *d, const void *m);
-int tall_fwd_mixed(const jh_blockop *op, void *d, const void *m);
+int tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int fmode = 0);   // fmode: JetBlock_f! of a tall nonlinear operator (every row written, SQUARE children square)
 int tall_adj(const jh_blockop *op, void *out, const void *in, int mode, bool mixed, int64_t first_elem = 0, int64_t end_elem = -1);
 int fold_parts(int dtype, const void *parts, int64_t part_stride, int64_t nparts, void *out, int64_t s_begin, int64_t s_end);   // (scalars: a complex vector is 2n reals)
 int split_adjoint_tmp(const jh_blockop *op, void **tmp);

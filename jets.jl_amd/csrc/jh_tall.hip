@@ -26,8 +26,10 @@ template <typename S, int E, int NS, int U, bool NT, int BLK, bool MIXED = false
 __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__restrict__ blocks, int64_t nrow, int rows_per_wg,
                                                        const S *__restrict__ a_base, int64_t a_stride,
                                                        const S *__restrict__ m, S *__restrict__ d, int64_t n_scalars,
-                                                       unsigned ntiles, unsigned ngroups, unsigned band, unsigned ctiles)
+                                                       unsigned ntiles, unsigned ngroups, unsigned band, unsigned ctiles, int fmode = 0)
 {
+    // fmode (MIXED only; round 5, last session): JetBlock_f! of a tall NONLINEAR operator (src/Jets.jl:1003: d_i = F_i(m), every child overwrites its row -- a
+    // zero block writes zeros, nothing is skipped); a SQUARE child squares its input, linear children apply df!
     typedef typename vec_of<S, NS>::type V;
     unsigned tile, grp;
     if (ctiles) {
@@ -75,15 +77,15 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__res
             const jh_dev_block blk = nxt;
             const int64_t i = inext;
             if (ii + 1 < i1) { inext = rows ? (int64_t)rows[ii + 1] : ii + 1; nxt = blocks[inext]; }
-            if (blk.kind == JH_OP_ZERO) continue;                                          // (1022)
-            const bool rc = block_reads_coeff(blk, false);
+            if (blk.kind == JH_OP_ZERO && !fmode) continue;                                // (1022; f!: JopZeroBlock's d .= 0, 942)
+            const bool rc = block_reads_coeff(blk, fmode != 0);
             S *di = d + i * n_scalars;
 #pragma unroll
             for (int k = 0; k < U; k++) {
                 const V c = rc ? ldu<NT, S, NS>((const S *)blk.coeff + sk[k]) : (V)(S)0;
                 // (the store stays a streaming store whatever NT says: temporal stores of a range vector larger than the caches leave dirty lines whose
                 // write-back lands on the NEXT kernel -- 256 x 255^3: forward alone 5.82 -> 5.75 ms, forward + adjoint pair 11.8 -> 12.2)
-                if (ok[k]) st_pack<true, S, NS>(di, s0 + (int64_t)k * BLK * NS, sk[k], apply_block_loaded<S, E, NS, V>(blk, mv[k], c, false, false));   // (1026)
+                if (ok[k]) st_pack<true, S, NS>(di, s0 + (int64_t)k * BLK * NS, sk[k], apply_block_loaded<S, E, NS, V>(blk, mv[k], c, false, fmode != 0));   // (1026 / 1003)
             }
         }
         return;
@@ -975,7 +977,7 @@ namespace {
 
 // one shape per kernel for the mixed rows (they are the exception; the all-DIAG instantiations keep their tuned shapes)
 template <typename S, int E, int NS>
-int launch_tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int64_t n_scalars)
+int launch_tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int64_t n_scalars, int fmode = 0)
 {
     jh_context &c = jh_ctx();
     // late round 4: one pack per lane, two rows per workgroup, COLUMN bands of 32 tiles (128 KiB of each row, then the same tiles of the next
@@ -984,7 +986,7 @@ int launch_tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int64_t 
     // (profiles/exp_r04_mixed_fwd.txt).  Knobs fwd_group / fwd_ctiles override rows per workgroup / tiles per band (0: sequential sweep).
     constexpr int BLK = 256, U = 1;
     // the rows the launch covers: all of them, or (late round 5) the operator's non-zero rows when an eighth or more are zero blocks (knob general_list = 0: all)
-    const bool listed = c.general_list != 0 && op->dev_rows_nz && op->n_rows_nz * 8 <= op->nrow * 7;
+    const bool listed = !fmode && c.general_list != 0 && op->dev_rows_nz && op->n_rows_nz * 8 <= op->nrow * 7;   // (f! writes every row)
     const int64_t nrows = listed ? op->n_rows_nz : op->nrow;
     if (nrows == 0) return JH_OK;                                          // every row a zero block: d stays as found (1022)
     int64_t G = c.fwd_group > 0 ? c.fwd_group : 2;
@@ -1000,7 +1002,7 @@ int launch_tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int64_t 
 #define JH_FWD_MIXED(NTV)                                                                                                                   \
     hipLaunchKernelGGL((k_tall_diag_fwd<S, E, NS, U, NTV, BLK, true>), dim3((unsigned)(gx * gy)), dim3(BLK), 0, c.stream, op->dev_blocks,        \
                        nrows, (int)G, listed ? reinterpret_cast<const S *>(op->dev_rows_nz) : (const S *)nullptr, (int64_t)(listed ? -1 : 0), (const S *)m, (S *)d, \
-                       n_scalars, (unsigned)gx, (unsigned)gy, 1u, (unsigned)ctiles)
+                       n_scalars, (unsigned)gx, (unsigned)gy, 1u, (unsigned)ctiles, fmode)
     // Rows off the 16-byte grid take TEMPORAL LOADS: a 128-byte line that two neighbouring waves share is then still in L2 when the second one asks --
     // streamed, it came from HBM twice (forward 256 x 255^3 5.82 -> 5.92 TB/s, 512 x 127^3 5.02 -> 5.11, 1024 x 101^3 5.30 -> 5.47; aligned rows: no
     // difference either way; profiles/bench_unaligned_r05.txt).  The STORES stay streaming stores (k_tall_diag_fwd).  Knob ua_nt: -1 this rule,
@@ -1091,10 +1093,10 @@ int tall_fwd(const jh_blockop *op, void *d, const void *m)
 #undef JH_CALL
 }
 
-int tall_fwd_mixed(const jh_blockop *op, void *d, const void *m)
+int tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int fmode)
 {
     const int64_t n = op->row_len[0];
-#define JH_CALL(S, E, NS) launch_tall_fwd_mixed<S, E, NS>(op, d, m, n * E)
+#define JH_CALL(S, E, NS) launch_tall_fwd_mixed<S, E, NS>(op, d, m, n * E, fmode)
     JH_BY_DTYPE(JH_CALL);
 #undef JH_CALL
 }

@@ -586,3 +586,48 @@ def test_grids_of_plain_diagonals_of_odd_blocks_on_the_all_diagonal_kernel(Jets,
     finally:
         J.tune(grid_tile=1, grid_diag=1, tall_unaligned=1)
     J.close(A)
+
+
+# ---------------------------------------------------------------------------------- F(m) of a tall nonlinear operator on the tall tiling
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("n", [64, 4100, 1027, 2 * 1024 * 4 + 1])
+@pytest.mark.parametrize("nrow", [2, 9, 40])
+def test_f_of_a_tall_nonlinear_operator_on_the_tall_tiling(Jets, oracle, dt, n, nrow):
+    """JetBlock_f! (src/Jets.jl:988-1008) of a tall operator whose children are SQUARE (the reference's JopBar), diagonals, identity / scalar rows and zero
+    blocks: every row is WRITTEN (a zero block's zeros included -- nothing is skipped in f!, 1003), SQUARE children square the model; the tall tiling
+    (tall_f = 1, aligned and odd block lengths) and the general kernels (tall_f = 0) against the oracle's block_f, bit for bit, into a dirty d."""
+    J = Jets
+    if n * np.dtype(dt).itemsize < 16:
+        pytest.skip("less than one pack per row")
+    spc = J.JetSpace(dt, n)
+    hm = u01(oracle, dt, 11, 0, n)
+    names = ["square", "diag", "zero", "identity", "square", "scale", "diag_adj"]
+    rows, ops = [], []
+    for i in range(nrow):
+        k = names[(2 * i + i // 3) % 7] if i else "square"
+        if k == "square":
+            rows.append([J.JopSquare(spc)]); ops.append([oracle.Block("square", n, coeff=hm)])
+        elif k == "zero":
+            rows.append([J.JopZeroBlock(spc, spc)]); ops.append([oracle.Block("zero", n, n)])
+        elif k == "identity":
+            rows.append([J.JopIdentity(spc)]); ops.append([oracle.Block("identity", n)])
+        elif k == "scale":
+            a = 0.3 + i
+            rows.append([J.JopLn(dom=spc, rng=spc, df=J.constdiag_df, df_adj=J.constdiag_df_adj, s={"a": a})]); ops.append([oracle.Block("scale", n, scale=a)])
+        else:
+            g = J.rand(spc, seed=21, stream=i)
+            op = J.JopDiagonal(g)
+            rows.append([op.H if k == "diag_adj" else op]); ops.append([oracle.Block("diag", n, coeff=u01(oracle, dt, 21, i, n), adjoint=(k == "diag_adj"))])
+    F = J.blockop(rows)
+    assert isinstance(F, J.JopNl)
+    hd = [u01(oracle, dt, 32, i, n) for i in range(nrow)]
+    want = oracle.block_f(ops, [b.copy() for b in hd], [hm])
+    try:
+        for knob in (1, 0):
+            J.tune(tall_f=knob)
+            d = J.from_numpy(np.concatenate(hd), J.range(F))
+            J.mul_(d, F, J.from_numpy(hm, J.domain(F)))
+            assert_bits_equal(d.to_numpy(), np.concatenate(want), f"F(m), {nrow} rows of {n}, tall_f={knob}")
+    finally:
+        J.tune(tall_f=1)
+    J.close(F)
