@@ -1,6 +1,6 @@
 // jh_blockop.hip -- the block operator behind the C ABI: jh_blockop_create / _destroy / _point and the dispatch of JetBlock_df! /
 // JetBlock_df'! / JetBlock_f! (src/Jets.jl:988-1057) and of the fused A'oA (530-534 over (A', A)) to the kernel families:
-//   jh_tall.hip       tall fast path (ncol == 1, elementwise rows, equal 16-byte aligned blocks): the BASELINE.json workload
+//   jh_tall.hip       tall fast path (ncol == 1, equal elementwise rows; blocks off the 16-byte grid on the MIXED instantiations): the BASELINE.json workload
 //   jh_tall_step.hip  fused solver updates and the one-pass LSQR step          jh_tall_sum.hip   fused JetSum
 //   jh_general.hip    any nrow x ncol mix of kinds, grids, per-block loops     jh_dense.hip      dense children
 // (round 5: one 4 200-line translation unit until then; jh_blockop_common.h)
@@ -645,7 +645,7 @@ int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m)
     }
     if (!tall_fast_ok(op, y->data, m->data) || op->nrow < 2)
         return jh_fail(JH_ERR_UNSUPPORTED,
-                       "jh_blockop_normal_mul: fused A'A needs a tall (>= 2 rows) operator of elementwise rows with equal, 16-byte aligned blocks; "
+                       "jh_blockop_normal_mul: fused A'A needs a tall (>= 2 rows) operator of equal elementwise rows; "
                        "chain jh_blockop_mul and jh_blockop_mul_adj instead");
     return jhb::tall_adj(op, y->data, m->data, 1, false);
     return jh_fail(JH_ERR_INVALID, "jh_blockop_normal_mul: unknown dtype %d", op->dtype);
@@ -676,7 +676,7 @@ int jh_blockop_normal_mul_range(const jh_blockop *op, jh_bvec *y, const jh_bvec 
     }
     if (!tall_fast_ok(op, y->data, m->data) || op->nrow < 2)
         return jh_fail(JH_ERR_UNSUPPORTED,
-                       "jh_blockop_normal_mul_range: fused A'A needs a tall (>= 2 rows) operator of elementwise rows with equal, 16-byte aligned blocks");
+                       "jh_blockop_normal_mul_range: fused A'A needs a tall (>= 2 rows) operator of equal elementwise rows");
     return jhb::tall_adj(op, y->data, m->data, 1, false, lo, hi);
     return jh_fail(JH_ERR_INVALID, "jh_blockop_normal_mul_range: unknown dtype %d", op->dtype);
 }

@@ -957,8 +957,8 @@ namespace {
 // diagonals are blocks of one slab too, inside the coefficients).  Such operators used to drop to the general kernels' 4-byte-per-lane forms (256 x 1 of
 // 524 289 Float32: forward 2.0, adjoint 3.1 TB/s); they now run the MIXED instantiations of the tall kernels, whose accesses are under-aligned packs and
 // whose last pack per row is partial (jh_blockop_common.h: ldu / st_pack) -- the same terms in the same order, so the same bits.  All-diagonal operators
-// included: the per-row kind switch costs them a scalar branch per row.  Whole-vector forward, adjoint and fused A'A only; the solver steps, fused sums
-// and ranged calls keep asking for aligned blocks and fall back to compositions of these.
+// included: the per-row kind switch costs them a scalar branch per row.  The fused forward update, the one-pass step (plain walk), the ranged calls, the
+// fused sums and adjoint update and the solver loops (host-driven, graph-replayed, partitioned) take such operators as well (jh_blockop_tall_step_ok).
 }  // namespace
 namespace jhb {
 bool tall_unaligned_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
@@ -1134,8 +1134,8 @@ bool jh_blockop_tall_fast(const jh_blockop *op, const void *rng_ptr, const void 
     return tall_fast_ok(op, rng_ptr, dom_ptr) || (tall_mixed_ok(op, rng_ptr, dom_ptr) && !(op->nonlinear && !op->pointed));
 }
 
-// what the WHOLE-VECTOR fused passes accept (forward update, one-pass step, and the host-driven solver loops built on them): the above, or rows off the
-// 16-byte pack grid on the under-aligned MIXED instantiations (tall_unaligned_ok).  Ranged calls and the graph-replayed loops keep jh_blockop_tall_fast.
+// what the fused passes accept (forward update, one-pass step -- whole-vector or ranged --, and the solver loops built on them): the above, or rows off the
+// 16-byte pack grid on the under-aligned MIXED instantiations (tall_unaligned_ok)
 bool jh_blockop_tall_step_ok(const jh_blockop *op, const void *rng_ptr, const void *dom_ptr)
 {
     return jh_blockop_tall_fast(op, rng_ptr, dom_ptr) || (tall_unaligned_ok(op, rng_ptr, dom_ptr) && !(op->nonlinear && !op->pointed));
