@@ -338,7 +338,8 @@ int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d,
  * a_flags = JH_SCALAR_WIDE for a Float64 scalar against 32-bit elements: the scalar stage is then the promoted product rounded once
  * (Float32(a * Float64(x))), the bits of the unfused chain with jh_lincomb_typed; 0: a is taken in the element type, i.e.
  * jh_blockop_mul_axpby(alpha = a, beta = 0) / jh_blockop_mul_adj_axpby(in_scale = a).  A Complex scalar (JH_SCALAR_COMPLEX) is
- * JH_ERR_UNSUPPORTED: the unfused chain.  Same operators as the two calls above. */
+ * JH_ERR_UNSUPPORTED: the unfused chain.  Same operators as the two calls above; round 5: jh_blockop_mul_adj_scaled with a scalar of the element
+ * type also takes tall operators with rows of SEVERAL kinds (the adjoint scales d_i on the way in: one pass, the chain's bits). */
 int jh_blockop_mul_scaled(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double a, int a_flags);
 int jh_blockop_mul_adj_scaled(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double a, int a_flags);
 /* One Golub-Kahan / LSQR step over vec(A) (src/Jets.jl:1138-1154) in ONE pass over the operator and the range vector:

@@ -130,6 +130,7 @@ struct jh_context {
     int64_t dense_fwd_wgs = 0;         // knob: workgroups the batched dense forward splits its columns for (0 = 2048)
     int64_t dense_gw = 0;              // knob: children per WAVE of that kernel (0 = from the operator's shape)
     int64_t last_dense_fused = 0;      // read-only: 1 when the most recent batched dense adjoint ran on the fused kernel
+    double adj_in_scale = 1.0;         // internal: the MIXED tall adjoint multiplies every d_i by it first (jh_blockop_mul_adj_scaled on rows of several kinds); 1 outside that call
     int64_t tall_f = 1;                // knob: F(m) of a tall nonlinear operator of elementwise children on the tall tiling (jh_blockop_f): 1 yes, 0 the general kernels
     int64_t ua_nt = -1;                // knob: accesses of the tall kernels on rows off the 16-byte grid: -1 temporal there, nontemporal on aligned rows; 0 / 1 temporal / nontemporal always
     int64_t tall_unaligned = 1;        // knob: tall operators whose rows are not whole, 16-byte aligned packs (odd block lengths in one slab) on the under-aligned tall kernels (jh_tall.hip: tall_unaligned_ok); 0: the general kernels as before

@@ -138,8 +138,10 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
                                                        const S *__restrict__ a_base, int64_t a_stride, S *__restrict__ out,
                                                        const S *__restrict__ in, int64_t n_scalars, int direct,
                                                        int64_t s_begin, int64_t s_end, int64_t row0, int64_t row1, int accumulate,
-                                                       int64_t rows_per_part, S *__restrict__ part_out, int64_t part_stride)
+                                                       int64_t rows_per_part, S *__restrict__ part_out, int64_t part_stride, S in_scale = (S)1)
 {
+    // in_scale (MIXED, MODE 0): every d_i is multiplied by it, rounded, before A_i' is applied -- (a * A)' d = A'(conj(a) d) of the scalar-times-operator chain
+    // (src/Jets.jl:1160) in one pass for operators with rows of several kinds; 1 is exact (x * 1 == x bit for bit), so the plain adjoint pays one multiply
     // rows [row0, row1) of the operator; accumulate != 0 continues the ordered sum from what `out` holds (a long operator
     // can be walked in several launches with the bits of one: ((0 + p_0) + p_1) + ... is the same sequence)
     // the launch covers the scalar range [s_begin, s_end) of the domain vector (the whole vector, or one chunk
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
 #pragma unroll
                 for (int k = 0; k < U; k++) {
                     av[j][k] = rc ? ldu<NT, S, NS>((const S *)blk[j].coeff + sk[k]) : (V)(S)0;
-                    dv[j][k] = (MODE == 0 && on) ? ldu<NT, S, NS>(in + (i + j) * n_scalars + sk[k]) : (V)(S)0;
+                    dv[j][k] = (MODE == 0 && on) ? (V)in_scale * ldu<NT, S, NS>(in + (i + j) * n_scalars + sk[k]) : (V)(S)0;
                 }
             }
 #pragma unroll
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
 #pragma unroll
             for (int k = 0; k < U; k++) {
                 const V c = rc ? ldu<NT, S, NS>((const S *)blk.coeff + sk[k]) : (V)(S)0;
-                const V t = (MODE == 0) ? ldu<NT, S, NS>(in + i * n_scalars + sk[k]) : apply_block_loaded<S, E, NS, V>(blk, mv[k], c, false, false);
+                const V t = (MODE == 0) ? (V)in_scale * ldu<NT, S, NS>(in + i * n_scalars + sk[k]) : apply_block_loaded<S, E, NS, V>(blk, mv[k], c, false, false);
                 acc[k] = acc[k] + apply_block_loaded<S, E, NS, V>(blk, t, c, true, false);
             }
         }
@@ -1034,7 +1036,7 @@ int launch_tall_adj_mixed_u(const jh_blockop *op, void *out, const void *in, int
 #define JH_ADJ_MIXED(NTV)                                                                                                                   \
     hipLaunchKernelGGL((k_tall_diag_adj<S, E, NS, U, DEPTH, NTV, MODE, BLK, true, TAIL>), dim3((unsigned)gx, (unsigned)parts), dim3(BLK), 0, c.stream, \
                        op->dev_blocks, op->nrow, (const S *)nullptr, (int64_t)0, (S *)out, (const S *)in, n_scalars, 0, s_begin, s_end,            \
-                       (int64_t)0, op->nrow, from_found, rows_per_part, (S *)slabs, part_stride)
+                       (int64_t)0, op->nrow, from_found, rows_per_part, (S *)slabs, part_stride, (S)(MODE == 0 ? c.adj_in_scale : 1.0))
     // (rows off the 16-byte grid: temporal loads, see launch_tall_fwd_mixed -- from 32 MiB rows on: 256 x 255^3 adjoint 5.83 -> 6.17 TB/s, but 512 x 127^3
     // 5.97 -> 5.73 and 1024 x 101^3 5.70 -> 5.67 on the same boxes)
     const bool off_grid = (n_scalars * (int64_t)sizeof(S)) % 16 != 0 || !op->coeff_aligned16 || ((((uintptr_t)out) | ((uintptr_t)in)) & 15u) != 0;

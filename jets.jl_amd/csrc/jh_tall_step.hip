@@ -1152,8 +1152,19 @@ int jh_blockop_mul_adj_scaled(const jh_blockop *op, jh_bvec *m, const jh_bvec *d
     if (a_flags & JH_SCALAR_COMPLEX) return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_scaled: a Complex scalar takes the unfused chain (jh_lincomb_typed, jh_blockop_mul_adj)");
     JH_TRY(jh_enter(op, m, d));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_adj_scaled"));
-    if (!tall_fast_ok(op, d->data, m->data) && !(op->all_diag && tall_unaligned_ok(op, d->data, m->data)))
-        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_scaled: needs a tall all-DIAG operator with equal blocks");
+    if (!tall_fast_ok(op, d->data, m->data) && !(op->all_diag && tall_unaligned_ok(op, d->data, m->data))) {
+        // rows of several kinds (round 5, last session): the MIXED adjoint with its input scaled on the way in -- one pass instead of the chain's two
+        // (a narrow real scalar; a wide one keeps the chain)
+        if (!(a_flags & JH_SCALAR_WIDE) && !(op->nonlinear && !op->pointed) &&
+            (tall_mixed_ok(op, d->data, m->data) || tall_unaligned_ok(op, d->data, m->data))) {
+            jh_context &c = jh_ctx();
+            c.adj_in_scale = a;
+            const int st = jhb::tall_adj(op, m->data, d->data, 0, true);
+            c.adj_in_scale = 1.0;
+            return st;
+        }
+        return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_scaled: needs a tall operator of equal elementwise rows (a Float64 scalar on 32-bit elements: all diagonals)");
+    }
     const int64_t n = op->row_len[0];
     const bool wide = (a_flags & JH_SCALAR_WIDE) != 0;
     switch (op->dtype) {

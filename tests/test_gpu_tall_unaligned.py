@@ -631,3 +631,43 @@ def test_f_of_a_tall_nonlinear_operator_on_the_tall_tiling(Jets, oracle, dt, n, 
     finally:
         J.tune(tall_f=1)
     J.close(F)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,n", [(3, 1024), (18, 4100), (5, 1027), (300, 67)])
+def test_scalar_times_a_tall_operator_of_several_kinds_adjoint_in_one_pass(Jets, oracle, dt, nrow, n):
+    """(a * A)' d = A'(conj(a) d) (src/Jets.jl:1160) for a tall operator with rows of several kinds (and / or off the pack grid): the MIXED adjoint scales d_i on
+    the way in -- jh_blockop_mul_adj_scaled itself accepts the operator -- with the bits of the chain tmp .= a * d; A' tmp."""
+    import ctypes as C
+
+    from jets_jl_amd._ffi import check, lib
+
+    J = Jets
+    if n * np.dtype(dt).itemsize < 16:
+        pytest.skip("less than one pack per row")
+    A, ops = _mixed_ops(J, oracle, dt, _kinds(nrow, "mixed"), [n] * nrow, [n])
+    nat = _native(A)
+    a = 0.625
+    hd = [u01(oracle, dt, 42, i, n) for i in range(nrow)]
+    d = J.from_numpy(np.concatenate(hd), J.range(A))
+    din = oracle.barr_lincomb([np.empty(n, dt) for _ in range(nrow)], [a], [hd])
+    want = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], din)[0]
+    try:
+        J.tune(adj_split=0)                                                           # the ordered walk: the chain's bits (the split walk: tolerance, below)
+        mt = J.rand(J.domain(A), seed=9, stream=9)
+        check(lib.jh_blockop_mul_adj_scaled(nat.handle, mt.handle, d.handle, a, 0))
+        assert_bits_equal(mt.to_numpy().ravel(order="F"), want, "(a * A)' d, one pass")
+        T = np.dtype(dt).type(a) if np.dtype(dt).kind != "c" else np.zeros(1, dt).real.dtype.type(a)
+        got = ((T * A).H * d).to_numpy().ravel(order="F")
+        assert_bits_equal(got, want, "through the operator algebra")
+    finally:
+        J.tune(adj_split=-1)
+    mt2 = J.rand(J.domain(A), seed=9, stream=9)
+    check(lib.jh_blockop_mul_adj_scaled(nat.handle, mt2.handle, d.handle, a, 0))
+    tol = 1e-5 if np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4 else 1e-12
+    assert np.linalg.norm(mt2.to_numpy().ravel(order="F") - want) <= tol * np.linalg.norm(want)
+    # the plain adjoint afterwards is unscaled again
+    plain = J.mul_(J.zeros(J.domain(A)), A.H, d)
+    ref = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], hd)[0]
+    assert np.linalg.norm(plain.to_numpy().ravel(order="F") - ref) <= tol * np.linalg.norm(ref)
+    J.close(A)
