@@ -991,7 +991,10 @@ int launch_tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int64_t 
     const bool listed = !fmode && c.general_list != 0 && op->dev_rows_nz && op->n_rows_nz * 8 <= op->nrow * 7;   // (f! writes every row)
     const int64_t nrows = listed ? op->n_rows_nz : op->nrow;
     if (nrows == 0) return JH_OK;                                          // every row a zero block: d stays as found (1022)
-    int64_t G = c.fwd_group > 0 ? c.fwd_group : 2;
+    // (rows of a few KiB -- traces rather than volumes --: more rows per workgroup, so that a workgroup still moves ~16 KiB: 262144 x 513 Float32 4.3 -> see
+    // profiles/bench_unaligned_r05.txt)
+    const int64_t row_bytes = n_scalars * (int64_t)sizeof(S);
+    int64_t G = c.fwd_group > 0 ? c.fwd_group : (row_bytes <= 2560 ? 8 : (row_bytes <= 5120 ? 4 : 2));
     if (G > nrows) G = nrows;
     const int64_t gx = (n_scalars + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);
     int64_t gy = (nrows + G - 1) / G;
@@ -1070,6 +1073,11 @@ int launch_tall_adj_mixed(const jh_blockop *op, void *out, const void *in, int64
             return launch_tall_adj_mixed_u<S, E, NS, MODE, 1024, 4, DEPTH, DEPTH == 2>(op, out, in, n_scalars, s_begin, s_end);
         }
     }
+    // rows of a few KiB (traces rather than volumes: 1001 or 2049 samples): thin workgroups, one pack per lane and four rows in flight -- the 512 x 2 shape issued
+    // its (clamped) loads for 1024 packs where a row has 129: 262144 x 513 Float32 adjoint 2.1 -> see profiles/bench_unaligned_r05.txt (the split-row walk
+    // supplies the workgroups)
+    if ((s_end - s_begin + NS - 1) / NS < 2048 && !(E == 2 && sizeof(S) == 4))
+        return launch_tall_adj_mixed_u<S, E, NS, MODE, 256, 1, 4>(op, out, in, n_scalars, s_begin, s_end);
     return launch_tall_adj_mixed_u<S, E, NS, MODE, 512, 2, 2>(op, out, in, n_scalars, s_begin, s_end);
 }
 
