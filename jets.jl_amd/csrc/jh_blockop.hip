@@ -74,6 +74,20 @@ int run_loop_graphed(const jh_blockop *op, int mode, const void *out, const void
     return body();
 }
 
+// what the per-call route tests need to know about the coefficient arrays of ALL blocks, once per create / point! (a 512 x 512 block-diagonal operator
+// spent 0.2 ms per call walking its descriptors): on the 16-byte grid? aligned like their scalar at least (a device array of the element type always is;
+// a caller's raw pointer -- or a point vector wrapped at an odd address -- need not be)?
+static void scan_coeff_alignment(jh_blockop *op)
+{
+    const size_t sa = jh_dtype_complex(op->dtype) ? jh_dtype_size(op->dtype) / 2 : jh_dtype_size(op->dtype);
+    op->coeff_aligned16 = true;
+    op->coeff_scalar_aligned = true;
+    for (const auto &b : op->blocks)
+        if (b.kind == JH_OP_DIAG || b.kind == JH_OP_SQUARE) {
+            if (((uintptr_t)b.coeff) & 15u) op->coeff_aligned16 = false;
+            if (((uintptr_t)b.coeff) & (sa - 1)) op->coeff_scalar_aligned = false;
+        }
+}
 
 }  // namespace
 
@@ -290,15 +304,7 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
         if (op->dense_mixed && op->blocks[k].kind == JH_OP_DENSE) jh_dev_block_set_prod_off(host[k], op->prod_off[0][k], op->prod_off[1][k]);
     }
     // what the per-call route tests need to know about ALL blocks, once (a 512 x 512 block-diagonal operator spent 0.2 ms per call walking its descriptors)
-    op->coeff_aligned16 = true;
-    for (const auto &b : op->blocks)
-        if ((b.kind == JH_OP_DIAG || b.kind == JH_OP_SQUARE) && (((uintptr_t)b.coeff) & 15u)) op->coeff_aligned16 = false;
-    op->coeff_scalar_aligned = true;                                       // (a device array of the element type always is; a caller's raw pointer need not be)
-    {
-        const size_t sa = jh_dtype_complex(dtype) ? jh_dtype_size(dtype) / 2 : jh_dtype_size(dtype);
-        for (const auto &b : op->blocks)
-            if ((b.kind == JH_OP_DIAG || b.kind == JH_OP_SQUARE) && (((uintptr_t)b.coeff) & (sa - 1))) op->coeff_scalar_aligned = false;
-    }
+    scan_coeff_alignment(op);
     op->lens_hold_a_pack = true;                                           // every non-empty row / column at least 16 bytes long
     for (int64_t v : op->row_len) if (v > 0 && (size_t)v * jh_dtype_size(dtype) < 16) op->lens_hold_a_pack = false;
     for (int64_t v : op->col_len) if (v > 0 && (size_t)v * jh_dtype_size(dtype) < 16) op->lens_hold_a_pack = false;
@@ -500,9 +506,7 @@ int jh_blockop_point(jh_blockop *op, const jh_bvec *mo)
         host[k] = jh_dev_block_of(op->blocks[k]);
         if (op->dense_mixed && op->blocks[k].kind == JH_OP_DENSE) jh_dev_block_set_prod_off(host[k], op->prod_off[0][k], op->prod_off[1][k]);
     }
-    op->coeff_aligned16 = true;                                          // (the SQUARE blocks' arrays have moved)
-    for (const auto &b : op->blocks)
-        if ((b.kind == JH_OP_DIAG || b.kind == JH_OP_SQUARE) && (((uintptr_t)b.coeff) & 15u)) op->coeff_aligned16 = false;
+    scan_coeff_alignment(op);                                            // (the SQUARE blocks' arrays have moved)
     hipStream_t st = jh_ctx().stream;
     JH_CHECK_HIP(hipMemcpyAsync(op->dev_blocks, host.data(), host.size() * sizeof(jh_dev_block), hipMemcpyHostToDevice, st));
     JH_CHECK_HIP(hipStreamSynchronize(st));                             // host staging vector dies at return

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
     for (int k = 0; k < U; k++) {
         ok[k] = (s0 + (int64_t)k * BLK * NS) < s_end;
         if constexpr (TAIL) {
-            sk[k] = ok[k] ? pack_start<NS>(s0 + (int64_t)k * BLK * NS, s_end) : s_begin;
+            sk[k] = pack_start<NS>(ok[k] ? s0 + (int64_t)k * BLK * NS : s_begin, s_end);   // (idle lanes too: a range shorter than one pack ends with the vector, and a pack read from s_begin would run past it)
             acc[k] = (accumulate && ok[k]) ? ldu<false, S, NS>(out + sk[k]) : (V)(S)0;
             if (MODE == 1) mv[k] = ok[k] ? ldu<false, S, NS>(in + sk[k]) : (V)(S)0;
         } else {
@@ -479,6 +479,19 @@ int64_t pick_adj_parts(int64_t gx, int64_t nrow)
 }  // namespace jhb
 namespace {
 
+// The split walk's slabs live at the start of the context's scratch buffer.  A caller may have placed the OUTPUT behind slabs it reserved there
+// (split_adjoint_tmp): the walk must then neither regrow the buffer (that frees what `out` points into) nor need more slabs than were reserved
+// (they would lie over `out`).  Either would be silent corruption, so it is an error here.
+static int adj_slabs(void *out, size_t bytes, void **slabs)
+{
+    jh_context &c = jh_ctx();
+    const char *b = (const char *)c.scratch_dev, *o = (const char *)out;
+    if (b && o >= b && o < b + c.scratch_cap)
+        JH_REQUIRE(bytes <= c.scratch_cap && o >= b + bytes, "split adjoint: %zu bytes of slabs would overlap the output reserved %zu bytes into the scratch buffer",
+                   bytes, (size_t)(o - b));
+    return jh_ensure_scratch(bytes, slabs);
+}
+
 template <typename S, int NS>
 int launch_fold_parts(const void *parts, int64_t part_stride, int64_t nparts, void *out, int64_t s_begin, int64_t s_end)
 {
@@ -551,7 +564,7 @@ int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n
     if (parts > 1) {
         rows_per_part = (op->nrow + parts - 1) / parts;
         parts = (op->nrow + rows_per_part - 1) / rows_per_part;                // no empty part
-        JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)part_stride * sizeof(S), &slabs));
+        JH_TRY(adj_slabs(out, (size_t)parts * (size_t)part_stride * sizeof(S), &slabs));
         rows_per_launch = op->nrow;
         c.last_adj_launches = 1;
     }
@@ -904,7 +917,7 @@ int launch_tall_adj(const jh_blockop *op, void *out, const void *in, int64_t n_s
 // domain-sized temporary behind them and return that temporary: the kernels that have no split variant of their own
 // (fused adjoint update, JetSum adjoint) then run "split adjoint into the temporary + a small epilogue" instead of crawling.
 template <typename S, int NS>
-int split_adjoint_tmp(const jh_blockop *op, int64_t n_scalars, void **tmp)
+int split_adjoint_tmp(const jh_blockop *op, int64_t n_scalars, bool c32, void **tmp)
 {
     *tmp = nullptr;
     if (op->nrow == 1) return JH_OK;
@@ -912,6 +925,16 @@ int split_adjoint_tmp(const jh_blockop *op, int64_t n_scalars, void **tmp)
     const int64_t gx0 = (n_scalars + (int64_t)sh.unroll * sh.wg * NS - 1) / ((int64_t)sh.unroll * sh.wg * NS);
     int64_t parts = pick_adj_parts(gx0, op->nrow);
     if (parts <= 1) return JH_OK;
+    // The caller sends operators off the 16-byte grid to tall_adj(..., mixed = true), whose MODE-0 shapes (launch_tall_adj_mixed: 256 x 1 for rows
+    // below 2048 packs, else -- and always for ComplexF32 -- 512 x 2) launch fewer workgroups per part than the all-DIAG shape above and so cut the rows
+    // into MORE parts.  Reserve for whichever route asks for most (round-5 advisor finding: 1024 rows of 40001 Float32 reserved 52 slabs, the mixed
+    // launch used 64 -- slabs 52..63 lay over the temporary, or the launcher regrew the scratch and freed the memory `tmp` points into).
+    {
+        const int64_t packs = (n_scalars + NS - 1) / NS;
+        const int64_t per_wg = (packs < 2048 && !c32) ? (int64_t)256 * NS : (int64_t)1024 * NS;
+        const int64_t parts_mixed = pick_adj_parts((n_scalars + per_wg - 1) / per_wg, op->nrow);
+        if (parts_mixed > parts) parts = parts_mixed;
+    }
     const int64_t rows_per_part = (op->nrow + parts - 1) / parts;
     parts = (op->nrow + rows_per_part - 1) / rows_per_part;
     const size_t slab_bytes = ((size_t)parts * (size_t)n_scalars * sizeof(S) + 255) / 256 * 256;
@@ -1032,7 +1055,7 @@ int launch_tall_adj_mixed_u(const jh_blockop *op, void *out, const void *in, int
     if (parts > 1) {
         rows_per_part = (op->nrow + parts - 1) / parts;
         parts = (op->nrow + rows_per_part - 1) / rows_per_part;
-        JH_TRY(jh_ensure_scratch((size_t)parts * (size_t)part_stride * sizeof(S), &slabs));
+        JH_TRY(adj_slabs(out, (size_t)parts * (size_t)part_stride * sizeof(S), &slabs));
     }
     c.last_adj_parts = parts;
     c.last_adj_launches = 1;
@@ -1132,8 +1155,8 @@ int fold_parts(int dtype, const void *parts, int64_t part_stride, int64_t nparts
 int split_adjoint_tmp(const jh_blockop *op, void **tmp)
 {
     const int64_t ns = op->row_len[0] * (jh_dtype_complex(op->dtype) ? 2 : 1);
-    if (op->dtype == JH_F32 || op->dtype == JH_C32) return ::split_adjoint_tmp<float, 4>(op, ns, tmp);
-    return ::split_adjoint_tmp<double, 2>(op, ns, tmp);
+    if (op->dtype == JH_F32 || op->dtype == JH_C32) return ::split_adjoint_tmp<float, 4>(op, ns, op->dtype == JH_C32, tmp);
+    return ::split_adjoint_tmp<double, 2>(op, ns, false, tmp);
 }
 #undef JH_BY_DTYPE
 

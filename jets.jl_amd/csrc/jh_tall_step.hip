@@ -1130,6 +1130,7 @@ int jh_blockop_mul_adj_axpby(const jh_blockop *op, jh_bvec *m, const jh_bvec *d,
 int jh_blockop_mul_scaled(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, double a, int a_flags)
 {
     JH_REQUIRE((a_flags & ~(JH_SCALAR_COMPLEX | JH_SCALAR_WIDE)) == 0, "jh_blockop_mul_scaled: unknown flags %d", a_flags);
+    if (op && (op->dtype == JH_F64 || op->dtype == JH_C64)) a_flags &= ~JH_SCALAR_WIDE;   // nothing is wider than 64-bit elements (the header: "ignored there")
     if (a_flags & JH_SCALAR_COMPLEX) return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_scaled: a Complex scalar takes the unfused chain (jh_blockop_mul, jh_lincomb_typed)");
     JH_TRY(jh_enter(op, d, m));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_scaled"));
@@ -1149,6 +1150,7 @@ int jh_blockop_mul_scaled(const jh_blockop *op, jh_bvec *d, const jh_bvec *m, do
 int jh_blockop_mul_adj_scaled(const jh_blockop *op, jh_bvec *m, const jh_bvec *d, double a, int a_flags)
 {
     JH_REQUIRE((a_flags & ~(JH_SCALAR_COMPLEX | JH_SCALAR_WIDE)) == 0, "jh_blockop_mul_adj_scaled: unknown flags %d", a_flags);
+    if (op && (op->dtype == JH_F64 || op->dtype == JH_C64)) a_flags &= ~JH_SCALAR_WIDE;   // nothing is wider than 64-bit elements (the header: "ignored there")
     if (a_flags & JH_SCALAR_COMPLEX) return jh_fail(JH_ERR_UNSUPPORTED, "jh_blockop_mul_adj_scaled: a Complex scalar takes the unfused chain (jh_lincomb_typed, jh_blockop_mul_adj)");
     JH_TRY(jh_enter(op, m, d));
     JH_TRY(check_vectors(op, d, m, "jh_blockop_mul_adj_scaled"));

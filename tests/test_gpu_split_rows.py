@@ -383,3 +383,53 @@ def test_split_jetsum_adjoint(Jets, oracle, knob, dt):
     ordered = (S.H * d).to_numpy().ravel(order="F")
     err0 = float(np.linalg.norm(np.abs(ordered.astype(wide) - truth).astype(np.longdouble))) / scale
     assert err <= 4 * err0 + _tol(dt)
+
+
+# ---------------------------------------------------------------------------------- round 6: the temporary behind the slabs (round-5 advisor finding)
+@pytest.mark.parametrize("dt,nrow,n", [(np.float32, 1024, 40001), (np.float32, 300, 10001), (np.complex64, 512, 2051), (np.float64, 288, 9999),
+                                       (np.float32, 512, 8192 + 4)])
+def test_fused_adjoint_update_and_jetsum_adjoint_split_walk_off_the_pack_grid(Jets, oracle, knob, dt, nrow, n):
+    """Off-grid all-diagonal operators of >= 256 rows of mid-sized blocks: jh_blockop_mul_adj_axpby and jh_blocksum_mul_adj run "split adjoint into a
+    temporary behind the slabs + epilogue" (jh_tall.hip: split_adjoint_tmp), and the adjoint they call is the MIXED one, whose launch shape cuts the rows
+    into MORE parts than the all-diagonal shape the reservation used to be sized with (1024 rows of 40001 Float32: 52 slabs reserved, 64 used -- the last
+    slabs lay over the temporary, or the scratch was regrown under it).  Stated bar as for every split sum: deterministic, rel-l2 1e-6 / 1e-14 of the truth."""
+    from jets_jl_amd._ffi import check, lib
+
+    J = Jets
+    A, ha, _keep = _slab_operator(J, oracle, dt, nrow, n)
+    B, hb, _keep2 = _slab_operator(J, oracle, dt, nrow, n, table=True)
+    hd = u01(oracle, dt, SEED_D, 0, nrow * n).reshape(nrow, n)
+    d = J.rand(J.range(A), seed=SEED_D, stream=0)
+    wide = np.clongdouble if np.iscomplexobj(ha) else np.longdouble
+    tA = np.sum(np.conj(ha.astype(wide)) * hd.astype(wide), axis=0)
+    tB = np.sum(np.conj(hb.astype(wide)) * hd.astype(wide), axis=0)
+    knob(-1)
+    natA, natB = _native(J, A), _native(J, B)
+    # m <- alpha A'(gamma d) + beta m with ||m||^2
+    alpha, beta, gamma = 0.75, -1.5, 1.0
+    hm = u01(oracle, dt, SEED_M, 0, n)
+    m = J.from_numpy(hm, J.domain(A))
+    nrm = C.c_double(0)
+    check(lib.jh_blockop_mul_adj_axpby(natA.handle, m.handle, d.handle, alpha, beta, gamma, C.byref(nrm)))
+    assert J.tune_get("last_adj_parts") > 1, "this shape should take the split walk"
+    got = m.to_numpy().ravel(order="F")
+    truth = alpha * tA + beta * hm.astype(wide)
+    assert rel_err(got, truth) < 4 * _tol(dt)
+    m2 = J.from_numpy(hm, J.domain(A))
+    check(lib.jh_blockop_mul_adj_axpby(natA.handle, m2.handle, d.handle, alpha, beta, gamma, C.byref(nrm)))
+    assert_bits_equal(m2.to_numpy().ravel(order="F"), got, "fused adjoint update through the split walk, second run")
+    assert nrm.value == pytest.approx(float(np.sum(np.abs(got.astype(np.complex128)) ** 2)), rel=1e-5)
+    # m = A'd - 0.5 B'd
+    hs = (C.c_void_p * 2)(natA.handle, natB.handle)
+    sc = (C.c_double * 2)(1.0, 0.5)
+    fg = (C.c_int32 * 2)(0, 0)
+    sg = (C.c_double * 2)(1.0, -1.0)
+    ms = J.rand(J.domain(A), seed=7, stream=7)
+    check(lib.jh_blocksum_mul_adj_typed(2, hs, sc, fg, sg, ms.handle, d.handle))
+    gs = ms.to_numpy().ravel(order="F")
+    assert rel_err(gs, tA - 0.5 * tB) < 8 * _tol(dt)
+    ms2 = J.rand(J.domain(A), seed=8, stream=8)
+    check(lib.jh_blocksum_mul_adj_typed(2, hs, sc, fg, sg, ms2.handle, d.handle))
+    assert_bits_equal(ms2.to_numpy().ravel(order="F"), gs, "JetSum adjoint through the split walk, second run")
+    J.close(A)
+    J.close(B)
