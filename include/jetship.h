@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define JETSHIP_ABI_VERSION 3   /* 2 (round 4): jh_block_desc.scale_flags, jh_lincomb_typed; 3 (round 5): jh_blocksum_mul[_adj]_typed */
+#define JETSHIP_ABI_VERSION 4   /* 2 (round 4): jh_block_desc.scale_flags, jh_lincomb_typed; 3 (round 5): jh_blocksum_mul[_adj]_typed; 4 (round 6): jh_chain_*, jh_norm_blocks / jh_dot_blocks */
 
 typedef enum {
     JH_OK = 0,
@@ -320,6 +320,47 @@ int jh_blocksum_mul_typed(int nterms, const jh_blockop *const *ops, const double
                           jh_bvec *d, const jh_bvec *m);
 int jh_blocksum_mul_adj_typed(int nterms, const jh_blockop *const *ops, const double *scale, const int32_t *scale_flags, const double *sign,
                               jh_bvec *m, const jh_bvec *d);
+
+/* ---------------------------------------------------------------- fused chains (round 6) --- */
+/* JetComposite chains of ANY depth through a tall operator, in ONE pass (src/Jets.jl:522-550: the reference applies a composite stage by
+ * stage, right to left, each stage into a fresh zeros(range(op_i)), 524-540).  Around a tall operator A (>= 2 equal rows of any elementwise
+ * kinds) every other device-native stage of such a chain is elementwise -- a scalar times (1159-1164), a diagonal on the domain (a model
+ * mask, a preconditioner), a diagonal on the range (data weights: `W o A`, `A' o W o A`) -- so the chain is one of
+ *     JH_CHAIN_FORWARD   out_i = R(a_i .* P(x))                                W o A o M              x: domain, out: range
+ *     JH_CHAIN_ADJOINT   out   = Q(sum_i conj(a_i) .* R(x_i))                  M' o A' o W'            x: range,  out: domain
+ *     JH_CHAIN_NORMAL    out   = Q(sum_i conj(a_i) .* R(a_i .* P(x)))          M' o A' o W o A o M     x, out: domain (weighted normal equations)
+ * with stage lists P (`pre`: on the domain, applied before A, in the order given), R (`mid`: on the range, after A / before A') and
+ * Q (`post`: on the domain, after A').  Every stage rounds like its own mul! would (product formed and rounded in the element type
+ * before the next stage reads it; rows summed in order from +0, 1042/1049; a zero block of A leaves its stage's zeros, 1022): the result
+ * is bit-identical to the stage-by-stage chain, which moves a range-sized temporary in and out per stage (A' o W o A: 8 N n s bytes
+ * against 2 N n s here).  Stages:
+ *     JH_STAGE_SCALE  x .= a * x for a REAL scalar; flags JH_SCALAR_WIDE as in jh_blockop_mul_scaled (JH_SCALAR_COMPLEX: JH_ERR_UNSUPPORTED)
+ *     JH_STAGE_DIAG   x .= c .* x, with JH_STAGE_CONJ conj.(c) .* x.  coeff: DEVICE pointers -- ONE on the domain side; on the range side
+ *                     one PER BLOCK ROW of A (a weight vector in one slab: base + i*n; a block-diagonal operator's children: wherever they
+ *                     are; NULL: the row is an identity block).  row_flags (range side, optional): per row bit 0 = this row is conjugated
+ *                     (a child that is the adjoint of a diagonal), bit 1 = a zero block on the diagonal (the row becomes zeros, 1022).
+ * At most 4 stages per list and 2 distinct coefficient arrays per list (a list may name the same array twice -- W' o W reads w once).
+ * The handle borrows `op` and the coefficient arrays (both must outlive it) and copies everything else.
+ * jh_chain_apply(accumulate): 0 out = chain(x); +1 / -1 out = out +- chain(x) -- JetSum's `broadcast!(sgn, d, d, tmp)` (634/643/652) fused
+ * into the chain's last stage, so a term of a sum that is itself a chain (A'oA + ..., W1oA1 - W2oA2) never materialises; +2 / -2 the FIRST
+ * term of a sum: out = 0 +- chain(x), the reference's `d .= 0` (631/640/649) without the fill pass (0 - t, not -t: the sign of a zero).
+ * JH_ERR_UNSUPPORTED (take the stage-by-stage chain): operators that are not tall / elementwise / equal rows, one-row operators, many
+ * rows of small blocks (the adjoint-shaped chains have no split-row walk), arrays not aligned like their scalar. */
+typedef struct jh_chain jh_chain;
+typedef enum { JH_CHAIN_FORWARD = 0, JH_CHAIN_ADJOINT = 1, JH_CHAIN_NORMAL = 2 } jh_chain_type;
+typedef enum { JH_STAGE_SCALE = 1, JH_STAGE_DIAG = 2 } jh_stage_kind;
+enum { JH_STAGE_CONJ = 4 };              /* (beside JH_SCALAR_* in jh_chain_stage.flags) */
+typedef struct {
+    int32_t kind;                        /* jh_stage_kind                                                             */
+    int32_t flags;                       /* SCALE: JH_SCALAR_*; DIAG: JH_STAGE_CONJ                                   */
+    double a;                            /* SCALE: the real scalar                                                    */
+    const void *const *coeff;            /* DIAG: host array of device pointers (1 on the domain side, nrow on the range side) */
+    const uint8_t *row_flags;            /* DIAG on the range side: optional host array of nrow flag bytes (see above) */
+} jh_chain_stage;
+int jh_chain_create(const jh_blockop *op, int type, int npre, const jh_chain_stage *pre, int nmid, const jh_chain_stage *mid, int npost,
+                    const jh_chain_stage *post, jh_chain **out);
+int jh_chain_apply(const jh_chain *chain, jh_bvec *out, const jh_bvec *x, int accumulate);
+int jh_chain_destroy(jh_chain *chain);
 
 /* Fused solver updates (the two halves of an LSQR / CGLS iteration; callers: IterativeSolvers-style loops over
  * vec(A), src/Jets.jl:1138-1154).  d = alpha*(A m) + beta*d  /  m = alpha*(A' d) + beta*m  with real alpha, beta,

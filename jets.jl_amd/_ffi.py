@@ -44,7 +44,7 @@ class BlockDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 3                      # JETSHIP_ABI_VERSION of include/jetship.h
+ABI_VERSION = 4                      # JETSHIP_ABI_VERSION of include/jetship.h
 SCALAR_COMPLEX, SCALAR_WIDE = 1, 2   # JH_SCALAR_* of include/jetship.h
 
 
@@ -55,6 +55,16 @@ def scalar_flags(a) -> int:
     numpy scalars are taken in the vectors' element type (Julia's `T(a)`, what an Int, a Float32 or an Irrational like pi gives)."""
     f = SCALAR_COMPLEX if isinstance(a, (complex, np.complexfloating)) else 0
     return f | (SCALAR_WIDE if isinstance(a, (np.float64, np.complex128)) else 0)
+
+
+class ChainStage(C.Structure):
+    """jh_chain_stage (include/jetship.h)."""
+
+    _fields_ = [("kind", C.c_int32), ("flags", C.c_int32), ("a", C.c_double), ("coeff", C.POINTER(C.c_void_p)), ("row_flags", C.POINTER(C.c_uint8))]
+
+
+STAGE_SCALE, STAGE_DIAG, STAGE_CONJ = 1, 2, 4      # jh_stage_kind, JH_STAGE_CONJ
+CHAIN_FORWARD, CHAIN_ADJOINT, CHAIN_NORMAL = 0, 1, 2   # jh_chain_type
 
 
 class LsqrResultC(C.Structure):
@@ -149,6 +159,9 @@ SYMBOLS = {
     "jh_blocksum_mul_adj": (_int, [_int, _vpp, _dblp, _dblp, _vp, _vp]),
     "jh_blocksum_mul_typed": (_int, [_int, _vpp, _dblp, C.POINTER(C.c_int32), _dblp, _vp, _vp]),
     "jh_blocksum_mul_adj_typed": (_int, [_int, _vpp, _dblp, C.POINTER(C.c_int32), _dblp, _vp, _vp]),
+    "jh_chain_create": (_int, [_vp, _int, _int, C.POINTER(ChainStage), _int, C.POINTER(ChainStage), _int, C.POINTER(ChainStage), _vpp]),
+    "jh_chain_apply": (_int, [_vp, _vp, _vp, _int]),
+    "jh_chain_destroy": (_int, [_vp]),
     "jh_blockop_mul_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, _dblp]),
     "jh_blockop_mul_adj_axpby": (_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _dblp]),
     "jh_blockop_mul_scaled": (_int, [_vp, _vp, _vp, C.c_double, _int]),

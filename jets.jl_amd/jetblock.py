@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import builtins
 import ctypes as C
+import itertools
 from typing import Sequence
 
 import numpy as np
@@ -55,7 +56,7 @@ def diagonal_df_adj(m, d, *, diagonal, **kw):  # test/runtests.jl:4   m .= conj.
 def JopDiagonal(diag: DeviceArray) -> JopLn:
     """Diagonal operator over a device array (the reference's test fixture JopFoo, test/runtests.jl:3-8;
     JetPack's JopDiagonal in docs/src/index.md:205)."""
-    spc = JetSpace(diag.dtype, *diag.shape)
+    spc = _arr.space(diag) if isinstance(diag, _arr.BlockArray) else JetSpace(diag.dtype, *diag.shape)   # (weights over a block range keep its blocks)
     return JopLn(df=diagonal_df, df_adj=diagonal_df_adj, dom=spc, rng=spc, s={"diagonal": diag})
 
 
@@ -177,8 +178,12 @@ def _native_desc(op: Jop):
 class NativeBlockOp:
     """Owns a jh_blockop handle for a matrix of device-native blocks."""
 
+    _serials = itertools.count(1)
+
     def __init__(self, ops: np.ndarray, descs, dtype):
         nrow, ncol = ops.shape
+        self.serial = next(NativeBlockOp._serials)              # never reused (an address is): what caches of things built on this handle key on
+        self.has_zero = any(dsc[0] == "zero" for row in descs for dsc in row)
         arr = (BlockDesc * (nrow * ncol))()
         self._keep = []
         for jcol in builtins.range(ncol):

@@ -311,6 +311,8 @@ def close(A):  # :290, 317, 591-595, 717-721, 1120-1124
             close(op)
         if isinstance(j.s.get("_ws"), _Workspace):
             j.s["_ws"].close()
+        if hasattr(j.s.get("_chains"), "close"):
+            j.s["_chains"].close()
         return None
     if j.f is _blk.JetBlock_f:
         _blk.close_block(j)
@@ -434,10 +436,10 @@ class _Workspace:
     def __deepcopy__(self, memo):  # copy(jet) gets its own, empty pool
         return _Workspace()
 
-    def zeros(self, slot, R, for_op=None):
+    def zeros(self, slot, R, for_op=None, overwritten=False):
         from .jetblock import overwrites_its_whole_range
 
-        undef = for_op is not None and overwrites_its_whole_range(for_op)
+        undef = overwritten or (for_op is not None and overwrites_its_whole_range(for_op))
         if R.length() * np.dtype(R.eltype()).itemsize >= self.KEEP_BELOW:
             x = _arr.Array(R, undef=undef, role=_arr.ROLE_OUTPUT)
             self._call.append(x)
@@ -470,9 +472,11 @@ def _zeroed_output(out, op):
 
 
 def JetComposite(ops: Sequence[Jop]) -> Jet:  # :522
+    from .chains import ChainCache
+
     ops = tuple(ops)
     return Jet(f=JetComposite_f, df=JetComposite_df, df_adj=JetComposite_df_adj, dom=domain(ops[-1]), rng=range_(ops[0]),
-               s={"ops": ops, "_ws": _Workspace()})
+               s={"ops": ops, "_ws": _Workspace(), "_chains": ChainCache()})
 
 
 def _chain(out, x, stages, ws):
@@ -493,22 +497,30 @@ def JetComposite_f(d, m, *, ops, _ws=None, **kw):  # :524-528  right-to-left cha
     return _chain(d, m, [(op, range_(op)) for op in reversed(ops)], _ws)
 
 
-def JetComposite_df(d, m, *, ops, _ws=None, **kw):  # :530-534
+def JetComposite_df(d, m, *, ops, _ws=None, _chains=None, **kw):  # :530-534
     from . import jetblock as _blk
+    from . import chains as _chn
 
     fused = _blk.try_fused_chain(d, m, ops)
     if fused is not None:
         return fused
-    return _chain(d, m, [(JopLn(op), range_(JopLn(op))) for op in reversed(ops)], _ws)
+    stages = [(JopLn(op), range_(JopLn(op))) for op in reversed(ops)]
+    if len(ops) >= 2 and _chn.run(d, m, stages, _ws, _chains, "df") is not None:      # chains of any depth: every fusable run in one pass (chains.py)
+        return d
+    return _chain(d, m, stages, _ws)
 
 
-def JetComposite_df_adj(m, d, *, ops, _ws=None, **kw):  # :536-540
+def JetComposite_df_adj(m, d, *, ops, _ws=None, _chains=None, **kw):  # :536-540
     from . import jetblock as _blk
+    from . import chains as _chn
 
     fused = _blk.try_fused_chain(m, d, tuple(adjoint(JopLn(op)) for op in reversed(ops)))
     if fused is not None:
         return fused
-    return _chain(m, d, [(adjoint(JopLn(op)), domain(JopLn(op))) for op in ops], _ws)
+    stages = [(adjoint(JopLn(op)), domain(JopLn(op))) for op in ops]
+    if len(ops) >= 2 and _chn.run(m, d, stages, _ws, _chains, "df_adj") is not None:
+        return m
+    return _chain(m, d, stages, _ws)
 
 
 def jops_comp(op: Jop) -> tuple:  # :542-550
@@ -532,9 +544,11 @@ PLUS, MINUS = "+", "-"
 
 
 def JetSum(ops: Sequence[Jop], sgns: Sequence[str]) -> Jet:  # :628
+    from .chains import ChainCache
+
     ops = tuple(ops)
     return Jet(f=JetSum_f, df=JetSum_df, df_adj=JetSum_df_adj, dom=domain(ops[0]), rng=range_(ops[0]),
-               s={"ops": ops, "sgns": tuple(sgns), "_ws": _Workspace()})
+               s={"ops": ops, "sgns": tuple(sgns), "_ws": _Workspace(), "_chains": ChainCache()})
 
 
 def _accumulate(sgn: str, acc, term):
@@ -554,10 +568,13 @@ def JetSum_f(d, m, *, ops, sgns, _ws=None, **kw):  # :630-637
     return d
 
 
-def JetSum_df(d, m, *, ops, sgns, _ws=None, **kw):  # :639-646
+def JetSum_df(d, m, *, ops, sgns, _ws=None, _chains=None, **kw):  # :639-646
     from . import jetblock as _blk
+    from . import chains as _chn
 
     if _blk.try_fused_sum(d, m, ops, sgns, False) is not None:
+        return d
+    if _chn.try_sum(d, m, ops, sgns, False, _ws, _chains) is not None:                 # terms that are chains: each adds itself in its last stage
         return d
     fill_(d, 0)
     ws = _ws or _Workspace()
@@ -570,10 +587,13 @@ def JetSum_df(d, m, *, ops, sgns, _ws=None, **kw):  # :639-646
     return d
 
 
-def JetSum_df_adj(m, d, *, ops, sgns, _ws=None, **kw):  # :648-655
+def JetSum_df_adj(m, d, *, ops, sgns, _ws=None, _chains=None, **kw):  # :648-655
     from . import jetblock as _blk
+    from . import chains as _chn
 
     if _blk.try_fused_sum(m, d, ops, sgns, True) is not None:
+        return m
+    if _chn.try_sum(m, d, ops, sgns, True, _ws, _chains) is not None:
         return m
     fill_(m, 0)
     ws = _ws or _Workspace()

@@ -33,7 +33,7 @@ const LIB = get(ENV, "JETSHIP_LIB", "libjetship.so")
 
 # ---------------------------------------------------------------- errors (src/Jets.jl:131,179,1116: plain error(...))
 check(status::Cint) = status == 0 ? nothing : error("libjetship: " * unsafe_string(ccall((:jh_last_error, LIB), Cstring, ())))
-const ABI_VERSION = 3       # JETSHIP_ABI_VERSION of include/jetship.h: struct layouts (jh_block_desc) are part of it
+const ABI_VERSION = 4       # JETSHIP_ABI_VERSION of include/jetship.h: struct layouts (jh_block_desc) are part of it
 function __init__()
     v = ccall((:jh_abi_version, LIB), Cint, ())
     v == ABI_VERSION || error("libjetship speaks ABI version $v, this binding $ABI_VERSION: rebuild the library")

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in include/jetship.h but not exported by libjetship.so"
     assert sorted(SYMBOLS) == declared, "jets.jl_amd/_ffi.py must bind exactly the symbols the header declares"
-    assert handle.jh_abi_version() == 3
+    assert handle.jh_abi_version() == 4
 
 
 def test_header_cites_the_reference_for_every_entry_point_group():

@@ -1,0 +1,310 @@
+"""GPU parity: JetComposite chains of any depth and JetSum terms that are chains, fused around a tall block operator (round 6;
+jets.jl_amd/chains.py, jh_tall_chain.hip: jh_chain_*).
+
+The reference applies a composite stage by stage, right to left, each stage into a fresh zeros(range(op_i)) (src/Jets.jl:524-540), a sum term by
+term through one temporary (630-655), `a * A` as one more stage (1159-1164).  The fused kernels keep every stage's rounding, so the bar is
+BIT-EXACT three ways: against the same chain applied stage by stage on the device (chains.ENABLED = False: rounds 1-5's path), against the CPU
+oracle applying the stages one by one, and (tests/test_gpu_known_answers.py) against the softfloat known answers.  All four element types, block
+lengths on and off the 16-byte grid, rows of several kinds (zero blocks, identities, scalars, adjointed diagonals), Float64 scalars on 32-bit
+elements, weights in one slab and as a block-diagonal block operator."""
+import numpy as np
+import pytest
+
+from .helpers import DTYPES, assert_bits_equal, u01
+from .test_gpu_blockop import _mixed_ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _kinds(nrow, name):
+    names = ["diag", "diag_adj", "identity", "scale", "zero"]
+    if name == "diag":
+        return [["diag"] for _ in range(nrow)]
+    return [[names[(3 * i + i // 5) % 5]] for i in range(nrow)]
+
+
+class Rig:
+    """One tall operator A (nrow x 1, blocks of n elements) with two weight vectors on its range and two diagonals on its domain, on the device and
+    in the oracle.  A chain is a list of tokens in APPLICATION order: "A", "At", ("W", k, conj), ("M", k, conj), ("s", a), ("Wb", k, conj) (the k-th
+    weights as a block-diagonal block operator), ("I",) identity on the domain, ("opaque",) a user-written closure on the domain (d .= 2 .* m)."""
+
+    def __init__(self, J, oracle, dt, nrow, n, name="diag", seed=31):
+        self.J, self.o, self.dt, self.nrow, self.n = J, oracle, dt, nrow, n
+        self.A, self.ora = _mixed_ops(J, oracle, dt, _kinds(nrow, name), [n] * nrow, [n], seed=seed)
+        R, D = J.range(self.A), J.domain(self.A)
+        self.w = [J.rand(R, seed=seed + 1 + k, stream=0) for k in range(2)]
+        self.hw = [[b.copy() for b in np.split(w.to_numpy(), nrow)] for w in self.w]
+        self.c = [J.rand(D, seed=seed + 5 + k, stream=0) for k in range(2)]
+        self.hc = [c.to_numpy().ravel(order="F").copy() for c in self.c]
+        self.W = [J.JopDiagonal(w) for w in self.w]
+        self.M = [J.JopDiagonal(c) for c in self.c]
+        self.Wb = []
+        for k in range(2):
+            spc = J.JetSpace(dt, n)
+            rows = []
+            for i in range(nrow):
+                row = [J.JopZeroBlock(spc, spc) for _ in range(nrow)]
+                if i % 4 == 3:
+                    row[i] = J.JopIdentity(spc)
+                elif i % 7 == 5:
+                    pass                                                       # a zero block on the diagonal
+                else:
+                    d = J.JopDiagonal(self.w[k].arrays[i])
+                    row[i] = d.H if i % 3 == 1 else d
+                rows.append(row)
+            self.Wb.append(J.blockop(rows))
+
+        def twice(d, m, **kw):
+            return J.lincomb_(d, [2.0], [m])
+
+        self.opaque = J.JopLn(dom=D, rng=D, df=twice, df_adj=twice)
+
+    # ---- device
+    def op(self, tok):
+        J = self.J
+        if tok == "A":
+            return self.A
+        if tok == "At":
+            return self.A.H
+        kind = tok[0]
+        if kind == "W":
+            return self.W[tok[1]].H if tok[2] else self.W[tok[1]]
+        if kind == "Wb":
+            return self.Wb[tok[1]].H if tok[2] else self.Wb[tok[1]]
+        if kind == "M":
+            return self.M[tok[1]].H if tok[2] else self.M[tok[1]]
+        if kind == "I":
+            return J.JopIdentity(J.domain(self.A))
+        if kind == "opaque":
+            return self.opaque
+        if kind == "s":
+            side = tok[2]
+            spc = J.range(self.A) if side == "r" else J.domain(self.A)
+            return J.JopLn(dom=spc, rng=spc, df=J.constdiag_df, df_adj=J.constdiag_df_adj, s={"a": tok[1]})
+        raise ValueError(tok)
+
+    def compose(self, toks):
+        ops = [self.op(t) for t in toks]
+        out = ops[0]
+        for o in ops[1:]:
+            out = self.J.compose(o, out)                                        # applied later = further left
+        return out
+
+    # ---- oracle, stage by stage (every stage into zeros, src/Jets.jl:525/531/537)
+    def ora_apply(self, toks, x):
+        o, n, nrow, dt = self.o, self.n, self.nrow, self.dt
+        cur = [b.copy() for b in x]
+        for tok in toks:
+            if tok == "A":
+                cur = o.block_df(self.ora, [np.zeros(n, dt) for _ in range(nrow)], cur)
+            elif tok == "At":
+                cur = o.block_df_adj(self.ora, [np.zeros(n, dt)], cur)
+            elif tok[0] in ("W", "M"):
+                coef = self.hw[tok[1]] if tok[0] == "W" else [self.hc[tok[1]]]
+                cur = [o.child_mul(o.Block("diag", n, coeff=cf, adjoint=bool(tok[2])), np.zeros(n, dt), b) for cf, b in zip(coef, cur)]
+            elif tok[0] == "Wb":
+                nxt = []
+                for i, b in enumerate(cur):
+                    if i % 4 == 3:
+                        nxt.append(b.copy())
+                    elif i % 7 == 5:
+                        nxt.append(np.zeros(n, dt))
+                    else:
+                        nxt.append(o.child_mul(o.Block("diag", n, coeff=self.hw[tok[1]][i], adjoint=(i % 3 == 1) != bool(tok[2])), np.zeros(n, dt), b))
+                cur = nxt
+            elif tok[0] == "I":
+                cur = [b.copy() for b in cur]
+            elif tok[0] == "opaque":
+                cur = o.barr_lincomb([np.empty(n, dt) for _ in cur], [2.0], [cur])
+            elif tok[0] == "s":
+                cur = o.barr_lincomb([np.empty(n, dt) for _ in cur], [tok[1]], [cur])
+            else:
+                raise ValueError(tok)
+        return cur
+
+    def close(self):
+        self.J.close(self.A)
+
+
+def _run_both(J, C, x, out_space, chains):
+    """The composite C applied fused and stage by stage; returns (fused, unfused, number of fused runs applied)."""
+    before = chains.STATS["chain_calls"]
+    y1 = J.mul_(J.rand(out_space, seed=77, stream=1), C, x)                    # into a DIRTY output
+    ran = chains.STATS["chain_calls"] - before
+    chains.ENABLED[0] = False
+    try:
+        y0 = J.mul_(J.rand(out_space, seed=78, stream=2), C, x)
+    finally:
+        chains.ENABLED[0] = True
+    return y1, y0, ran
+
+
+CHAINS = {
+    # name: (tokens in application order, fused runs expected)
+    "W o A": (["A", ("W", 0, False)], 1),
+    "W' o A": (["A", ("W", 0, True)], 1),
+    "A' o W o A": (["A", ("W", 0, False), "At"], 1),
+    "(W o A)' o (W o A)": (["A", ("W", 0, False), ("W", 0, True), "At"], 1),
+    "A' o W1' o W0 o A": (["A", ("W", 0, False), ("W", 1, True), "At"], 1),
+    "M' o A' o W o A o M": ([("M", 0, False), "A", ("W", 0, False), "At", ("M", 0, True)], 1),
+    "a * (A' o A)": (["A", "At", ("s", 0.375, "d")], 1),
+    "A' o (a W) o A o (b M)": ([("M", 1, False), ("s", -1.25, "d"), "A", ("W", 1, False), ("s", 3.0, "r"), "At"], 1),
+    "A' o Wb o A": (["A", ("Wb", 0, False), "At"], 1),
+    "Wb' o A": (["A", ("Wb", 1, True)], 1),
+    "A o M": ([("M", 0, False), "A"], 1),
+    "A o I o M1 o M0": ([("M", 0, False), ("M", 1, True), ("I",), "A"], 1),
+    "M o A'  (range -> domain)": (["At", ("M", 0, False)], 1),
+    "M o A' o W'": ([("W", 0, True), "At", ("M", 1, False)], 1),
+    "A' o A o opaque o A' o W o A": (["A", ("W", 0, False), "At", ("opaque",), "A", "At"], 2),
+    "opaque o A' o W o A o opaque": ([("opaque",), "A", ("W", 0, False), "At", ("opaque",)], 1),
+    "five range-side stages": (["A", ("s", 2.0, "r"), ("W", 0, False), ("s", 0.5, "r"), ("W", 1, False), ("s", -1.0, "r"), "At"], 2),   # four stages ride with A, the fifth with A'
+}
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("name", list(CHAINS))
+@pytest.mark.parametrize("nrow,n,kinds", [(5, 4096 + 64, "diag"), (7, 1027, "diag"), (18, 2051, "mixed"), (3, 67, "mixed")])
+def test_chains_of_any_depth_have_the_bits_of_the_stage_by_stage_chain(Jets, oracle, dt, name, nrow, n, kinds):
+    from jets_jl_amd import chains
+
+    J = Jets
+    toks, runs = CHAINS[name]
+    rig = Rig(J, oracle, dt, nrow, n, kinds)
+    C = rig.compose(toks)
+    rng_in = toks[0] == "At" or (toks[0] != "A" and toks[0][0] in ("W", "Wb"))
+    xs = J.range(rig.A) if rng_in else J.domain(rig.A)
+    hx = [u01(oracle, dt, 91, i, n) for i in range(nrow if rng_in else 1)]
+    x = J.from_numpy(np.concatenate(hx), xs)
+    y1, y0, ran = _run_both(J, C, x, J.range(C), chains)
+    assert ran == runs, f"{name}: {ran} fused runs applied, expected {runs}"
+    assert_bits_equal(y1.to_numpy().ravel(order="F"), y0.to_numpy().ravel(order="F"), f"{name}: fused vs stage by stage on the device")
+    want = np.concatenate(rig.ora_apply(toks, hx))
+    assert_bits_equal(y1.to_numpy().ravel(order="F"), want, f"{name}: fused vs the oracle's stages")
+    # the adjoint of the whole composite: the same stages adjointed, in reverse (src/Jets.jl:536-540)
+    hz = [u01(oracle, dt, 92, i, n) for i in range(len(want) // n)]
+    z = J.from_numpy(np.concatenate(hz), J.range(C))
+    a1, a0, ran = _run_both(J, C.H, z, J.domain(C), chains)
+    assert ran == runs
+    assert_bits_equal(a1.to_numpy().ravel(order="F"), a0.to_numpy().ravel(order="F"), f"({name})': fused vs stage by stage on the device")
+    rig.close()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64])
+@pytest.mark.parametrize("n", [1024, 1027])
+def test_float64_scalars_on_32_bit_elements_inside_a_chain(Jets, oracle, dt, n):
+    """`3.14 * (A' o W o A)` and `A' o (2.5 W) o A` with numpy float64 scalars (Julia's Float64): the scalar stage is the promoted product rounded once
+    (include/jetship.h: JH_SCALAR_WIDE) -- fused, with the bits of the chain whose scalar stage is the typed lincomb."""
+    from jets_jl_amd import chains
+
+    J = Jets
+    rig = Rig(J, oracle, dt, 6, n, "mixed")
+    for toks in (["A", ("W", 0, False), "At", ("s", np.float64(3.14), "d")], ["A", ("s", np.float64(2.5), "r"), ("W", 0, True), "At"],
+                 [("s", np.float64(-0.1), "d"), "A", ("W", 1, False), ("s", np.float64(1.0 / 3.0), "r")]):
+        C = rig.compose(toks)
+        hx = [u01(oracle, dt, 91, 0, n)]
+        x = J.from_numpy(hx[0], J.domain(rig.A))
+        y1, y0, ran = _run_both(J, C, x, J.range(C), chains)
+        assert ran == 1
+        assert_bits_equal(y1.to_numpy().ravel(order="F"), y0.to_numpy().ravel(order="F"), f"{toks}: fused vs stage by stage")
+        assert_bits_equal(y1.to_numpy().ravel(order="F"), np.concatenate(rig.ora_apply(toks, hx)), f"{toks}: fused vs the oracle")
+    rig.close()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,n,kinds", [(5, 4096, "diag"), (9, 1027, "mixed")])
+def test_sums_whose_terms_are_chains(Jets, oracle, dt, nrow, n, kinds):
+    """JetSum (src/Jets.jl:628-655) with composite terms: A'oWoA + lam*I - B'oB on the domain, W0oA - 0.5*(W1oB) + B on the range and their adjoints --
+    every term that is one fusable run adds itself to the output in its own last stage; bit-identical to the reference's loop over one temporary."""
+    from jets_jl_amd import chains
+
+    J = Jets
+    ra, rb = Rig(J, oracle, dt, nrow, n, kinds, seed=31), Rig(J, oracle, dt, nrow, n, "diag", seed=57)
+    A, B = ra.A, rb.A
+    dom = J.domain(A)
+    lamI = 0.25 * J.JopIdentity(dom)
+    N1 = J.compose(J.compose(A.H, ra.W[0]), A)
+    N2 = J.compose(B.H, B)
+    S_dom = N1 + lamI - N2
+    F1 = J.compose(ra.W[0], A)
+    F2 = 0.5 * J.compose(ra.W[1], B)
+    S_rng = F1 - F2 + B
+    hx = u01(oracle, dt, 91, 0, n)
+    x = J.from_numpy(hx, dom)
+    for S, nfused in ((S_dom, 2), (S_rng, 2)):
+        before = chains.STATS["sum_terms_fused"]
+        y1 = J.mul_(J.rand(J.range(S), seed=77, stream=1), S, x)
+        assert chains.STATS["sum_terms_fused"] - before == nfused
+        chains.ENABLED[0] = False
+        try:
+            y0 = J.mul_(J.rand(J.range(S), seed=78, stream=2), S, x)
+        finally:
+            chains.ENABLED[0] = True
+        assert_bits_equal(y1.to_numpy().ravel(order="F"), y0.to_numpy().ravel(order="F"), "sum of chains: fused vs the reference's loop")
+    # oracle for the domain sum: d = ((0 + N1 x) + lam x) - N2 x
+    t1 = ra.ora_apply(["A", ("W", 0, False), "At"], [hx])
+    t2 = oracle.barr_lincomb([np.empty(n, dt)], [0.25], [[hx]])
+    t3 = rb.ora_apply(["A", "At"], [hx])
+    want = oracle.barr_lincomb([np.empty(n, dt)], [1.0, 1.0], [[np.zeros(n, dt)], t1])
+    want = oracle.barr_lincomb([np.empty(n, dt)], [1.0, 1.0], [want, t2])
+    want = oracle.barr_lincomb([np.empty(n, dt)], [1.0, -1.0], [want, t3])
+    y = J.mul_(J.rand(dom, seed=7, stream=7), S_dom, x)
+    assert_bits_equal(y.to_numpy().ravel(order="F"), want[0], "A'WA + lam I - B'B vs the oracle")
+    # adjoints of both sums
+    hz = np.concatenate([u01(oracle, dt, 92, i, n) for i in range(nrow)])
+    for S, z in ((S_dom, x), (S_rng, J.from_numpy(hz, J.range(S_rng)))):
+        a1 = J.mul_(J.rand(J.domain(S), seed=71, stream=1), S.H, z)
+        chains.ENABLED[0] = False
+        try:
+            a0 = J.mul_(J.rand(J.domain(S), seed=72, stream=2), S.H, z)
+        finally:
+            chains.ENABLED[0] = True
+        assert_bits_equal(a1.to_numpy().ravel(order="F"), a0.to_numpy().ravel(order="F"), "adjoint of a sum of chains: fused vs the reference's loop")
+    ra.close()
+    rb.close()
+
+
+def test_the_first_term_of_a_fused_sum_is_zero_plus_the_term(Jets, oracle):
+    """`d .= 0` then `d .= d - tmp` (src/Jets.jl:640, 643): 0 - (+0) = +0 and 0 + (-0) = +0, not the term's own zero."""
+    J = Jets
+    dt, n, nrow = np.float32, 1024, 3
+    rig = Rig(J, oracle, dt, nrow, n, "diag")
+    N = J.compose(J.compose(rig.A.H, rig.W[0]), rig.A)
+    S = N - N                                                                 # two fused terms: 0 + t, then - t
+    x = J.zeros(J.domain(rig.A))                                              # every product is +0
+    y = J.mul_(J.rand(J.domain(rig.A), seed=3, stream=3), S, x)
+    got = y.to_numpy().ravel(order="F")
+    assert not np.signbit(got).any() and not got.any()
+    xm = J.from_numpy(np.full(n, -0.0, dt), J.domain(rig.A))                  # products of -0: t = sum of (+0 + -0...) = +0; 0 + t = +0; 0 - t ...
+    S2 = J.compose(rig.W[0], rig.A) - J.compose(rig.W[1], rig.A)
+    from jets_jl_amd import chains
+
+    y1 = J.mul_(J.rand(J.range(S2), seed=4, stream=4), S2, xm)
+    chains.ENABLED[0] = False
+    try:
+        y0 = J.mul_(J.rand(J.range(S2), seed=5, stream=5), S2, xm)
+    finally:
+        chains.ENABLED[0] = True
+    assert_bits_equal(y1.to_numpy(), y0.to_numpy(), "signed zeros through a fused sum")
+    rig.close()
+
+
+def test_a_sum_with_a_bare_operator_that_has_zero_rows_keeps_the_references_loop(Jets, oracle):
+    """The reference reuses ONE temporary for all terms (src/Jets.jl:641): a block operator with a zero block leaves that row as the previous term left it
+    (1022).  A fused neighbour would not have written the temporary, so such sums are not fused -- the result still equals the reference's loop."""
+    from jets_jl_amd import chains
+
+    J = Jets
+    dt, n, nrow = np.float64, 1027, 6
+    rig = Rig(J, oracle, dt, nrow, n, "mixed")                                # has zero rows
+    S = J.compose(rig.W[0], rig.A) + rig.A
+    x = J.rand(J.domain(rig.A), seed=9, stream=9)
+    before = chains.STATS["sum_terms_fused"]
+    y1 = J.mul_(J.zeros(J.range(S)), S, x)
+    assert chains.STATS["sum_terms_fused"] == before
+    chains.ENABLED[0] = False
+    try:
+        y0 = J.mul_(J.zeros(J.range(S)), S, x)
+    finally:
+        chains.ENABLED[0] = True
+    assert_bits_equal(y1.to_numpy(), y0.to_numpy(), "stale-row quirk kept")
+    rig.close()
