@@ -406,6 +406,11 @@ function JopHipDiagonal(diag::HipArray{T,N}) where {T,N}
     spc = HipSpace{T,N}(size(diag))
     JopLn(;df! = JopHipDiagonal_df!, df′! = JopHipDiagonal_df′!, dom = spc, rng = spc, s = (diagonal=diag,))
 end
+# weights over a block range (`W ∘ A`, `A' ∘ W ∘ A`): the diagonal is a device BlockArray in one slab, the operator lives on its block space
+function JopHipDiagonal(diag::BlockArray{T,<:HipArray{T}}) where {T}
+    spc = space(diag)
+    JopLn(;df! = JopHipDiagonal_df!, df′! = JopHipDiagonal_df′!, dom = spc, rng = spc, s = (diagonal=diag,))
+end
 
 # the reference's nonlinear fixture JopBar (test/runtests.jl:19-24) on device vectors: kind SQUARE
 JopHipSquare_f!(d, m; kwargs...) = _hadamard!(d, m, m, 0)                              # d .= m.^2
@@ -559,7 +564,13 @@ function Jets.JetComposite_df!(d::HipArray{T}, m::HipArray{T}; ops, kwargs...) w
             return d
         end
     end
+    _fused_chain!(d, m, _stages_df(ops), T, 0) && return d              # chains of any depth: every fusable run in one pass (round 6)
     invoke(JetComposite_df!, Tuple{AbstractArray,Any}, d, m; ops=ops, kwargs...)
+end
+# the adjoint of a domain -> domain composite (M' ∘ A' ∘ W ∘ A ∘ M is its own shape adjointed)
+function Jets.JetComposite_df′!(m::HipArray{T}, d::HipArray{T}; ops, kwargs...) where {T}
+    _fused_chain!(m, d, _stages_df′(ops), T, 0) && return m
+    invoke(JetComposite_df′!, Tuple{AbstractArray,Any}, m, d; ops=ops, kwargs...)
 end
 
 # ---- scalar * operator and sums of tall device operators: ONE ccall per mul! (rows a18 / a19 of the scope table) --------------------------
@@ -592,6 +603,7 @@ function Jets.JetComposite_df!(d::BlockArray{T,<:HipArray{T}}, m::HipArray{T}; o
             st == 4 || (check(st); return d)                    # JH_ERR_UNSUPPORTED (rows of mixed kinds, ragged blocks): the chain below
         end
     end
+    handle(d) != C_NULL && _fused_chain!(d, m, _stages_df(ops), T, 0) && return d      # W ∘ A ∘ M and deeper (round 6)
     invoke(JetComposite_df!, Tuple{AbstractArray,Any}, d, m; ops=ops, kwargs...)
 end
 # (a, A)' = A' o a': m = A' (conj(a) d) in one pass (conj(a) == a for a Real a)
@@ -604,6 +616,7 @@ function Jets.JetComposite_df′!(m::HipArray{T}, d::BlockArray{T,<:HipArray{T}}
             st == 4 || (check(st); return m)
         end
     end
+    handle(d) != C_NULL && _fused_chain!(m, d, _stages_df′(ops), T, 0) && return m     # M' ∘ A' ∘ W' and deeper (round 6)
     invoke(JetComposite_df′!, Tuple{AbstractArray,Any}, m, d; ops=ops, kwargs...)
 end
 
@@ -642,11 +655,228 @@ function _fused_sum(out, x, ops, sgns, ::Type{T}, transposed::Bool) where {T}   
 end
 function Jets.JetSum_df!(d::BlockArray{T,<:HipArray{T}}, m::HipArray{T}; ops, sgns, kwargs...) where {T}
     _fused_sum(d, m, ops, sgns, T, false) && return d
+    _chain_sum!(d, m, ops, sgns, T, false) && return d                  # terms that are chains (W1 ∘ A1 - W2 ∘ A2 + ...): round 6
     invoke(JetSum_df!, Tuple{Any,Any}, d, m; ops=ops, sgns=sgns, kwargs...)
 end
 function Jets.JetSum_df′!(m::HipArray{T}, d::BlockArray{T,<:HipArray{T}}; ops, sgns, kwargs...) where {T}
     _fused_sum(m, d, ops, sgns, T, true) && return m
+    _chain_sum!(m, d, ops, sgns, T, true) && return m
     invoke(JetSum_df′!, Tuple{Any,Any}, m, d; ops=ops, sgns=sgns, kwargs...)
+end
+# sums on the domain (A' ∘ W ∘ A + λ²I - B' ∘ B, src/Jets.jl:639-655 over composite terms): domain -> domain both ways
+function Jets.JetSum_df!(d::HipArray{T}, m::HipArray{T}; ops, sgns, kwargs...) where {T}
+    _chain_sum!(d, m, ops, sgns, T, false) && return d
+    invoke(JetSum_df!, Tuple{Any,Any}, d, m; ops=ops, sgns=sgns, kwargs...)
+end
+function Jets.JetSum_df′!(m::HipArray{T}, d::HipArray{T}; ops, sgns, kwargs...) where {T}
+    _chain_sum!(m, d, ops, sgns, T, true) && return m
+    invoke(JetSum_df′!, Tuple{Any,Any}, m, d; ops=ops, sgns=sgns, kwargs...)
+end
+
+# ---------------------------------------------------------------- fused chains of ANY depth (round 6; the twin of jets.jl_amd/chains.py)
+# The reference applies a composite stage by stage, right to left, each stage into a fresh zeros(range(op_i)) (src/Jets.jl:524-540).  Around a tall
+# device operator A every other device-native stage is elementwise -- `a *` (1159-1164), a diagonal on the domain, a diagonal on the range -- so a
+# maximal run of such stages is ONE call of the chain kernels (include/jetship.h jh_chain_*):
+#     W ∘ A ∘ M            JH_CHAIN_FORWARD   d_i = R(a_i .* P(m))
+#     M' ∘ A' ∘ W'         JH_CHAIN_ADJOINT   m   = Q(Σ_i conj(a_i) .* R(d_i))
+#     M' ∘ A' ∘ W ∘ A ∘ M  JH_CHAIN_NORMAL    y   = Q(Σ_i conj(a_i) .* R(a_i .* P(m)))       (weighted / preconditioned normal equations)
+# with the bits of the stage-by-stage chain (each stage's product rounded before the next reads it).  A stage the device does not know splits the
+# chain: the runs on either side are fused, the stage runs on its own.
+struct jh_chain_stage         # mirrors include/jetship.h
+    kind::Int32               # 1 JH_STAGE_SCALE, 2 JH_STAGE_DIAG
+    flags::Int32              # SCALE: JH_SCALAR_* / DIAG: 4 = JH_STAGE_CONJ
+    a::Cdouble
+    coeff::Ptr{Ptr{Cvoid}}    # DIAG: device pointers, one per block row on the range side, one on the domain side
+    row_flags::Ptr{UInt8}
+end
+const _CHAIN_MAX_STAGES = 4
+_stages_df(ops) = Any[JopLn(ops[i]) for i = length(ops):-1:1]            # application order (530-534)
+_stages_df′(ops) = Any[JopLn(ops[i])' for i = 1:length(ops)]             # (536-540)
+
+# what a stage is: (kind = :tall / :scale / :diag / :identity / :opaque, ...)
+function _chain_stage(op::Jop, ::Type{T}) where {T}
+    adj = op isa JopAdjoint
+    base = adj ? op.op : op
+    base isa JopLn || return (kind=:opaque, op=op)
+    j = jet(base)
+    if j.df! === _constdiag_df!
+        a = state(base).a
+        a isa FusableReal || return (kind=:opaque, op=op)               # a Complex scalar takes the full product: the stage-by-stage chain
+        return (kind=:scale, op=op, a=Float64(a), flags=(sizeof(real(T)) == 8 ? Cint(0) : _scalar_flags(a)))
+    elseif j.df! === JopHipDiagonal_df!
+        return (kind=:diag, op=op, vec=state(base).diagonal, conj=adj)
+    end
+    h = tall_native(base, T)
+    (h != C_NULL && size(state(base).ops, 1) >= 2) && return (kind=:tall, op=op, h=h, adj=adj, nrow=size(state(base).ops, 1), n=length(domain(base)))
+    (kind=:opaque, op=op)
+end
+_elementwise(st) = st.kind === :scale || st.kind === :diag || st.kind === :identity
+_active(sts) = [st for st in sts if st.kind !== :identity]
+
+# cut the stages into steps: (:chain, type, tall, pre, mid, post, first, last) or (:op, index)   (chains.py: _segments)
+function _chain_segments(st::Vector)
+    steps, i, n = Any[], 1, length(st)
+    while i <= n
+        j = i
+        while j <= n && _elementwise(st[j]); j += 1; end
+        if j <= n && st[j].kind === :tall
+            t = st[j]
+            if !t.adj                                                   # E* A E* [A' E*]
+                while length(_active(st[i:j-1])) > _CHAIN_MAX_STAGES
+                    push!(steps, (:op, i)); i += 1
+                end
+                pre = _active(st[i:j-1])
+                k = j + 1
+                while k <= n && _elementwise(st[k]) && length(_active(st[j+1:k])) <= _CHAIN_MAX_STAGES; k += 1; end
+                mid = _active(st[j+1:k-1])
+                if k <= n && st[k].kind === :tall && st[k].adj && st[k].h == t.h
+                    l = k + 1
+                    while l <= n && _elementwise(st[l]) && length(_active(st[k+1:l])) <= _CHAIN_MAX_STAGES; l += 1; end
+                    push!(steps, (:chain, Cint(2), t, pre, mid, _active(st[k+1:l-1]), i, l - 1)); i = l
+                elseif !isempty(pre) || !isempty(mid)
+                    push!(steps, (:chain, Cint(0), t, pre, mid, Any[], i, k - 1)); i = k
+                else
+                    push!(steps, (:op, j)); i = j + 1
+                end
+            else                                                        # E* A' E*
+                while length(_active(st[i:j-1])) > _CHAIN_MAX_STAGES
+                    push!(steps, (:op, i)); i += 1
+                end
+                mid = _active(st[i:j-1])
+                l = j + 1
+                while l <= n && _elementwise(st[l]) && length(_active(st[j+1:l])) <= _CHAIN_MAX_STAGES; l += 1; end
+                post = _active(st[j+1:l-1])
+                if !isempty(mid) || !isempty(post)
+                    push!(steps, (:chain, Cint(1), t, Any[], mid, post, i, l - 1)); i = l
+                else
+                    push!(steps, (:op, j)); i = j + 1
+                end
+            end
+        else
+            for q = i:max(j - 1, i); push!(steps, (:op, q)); end
+            i = max(j, i + 1)
+        end
+    end
+    steps
+end
+
+# a diagonal before A / after A' lives on the domain (n elements), one after A / before A' on the range (nrow * n)
+function _chain_sides_ok(t, pre, mid, post)
+    for st in vcat(pre, post); (st.kind === :diag && length(st.vec) != t.n) && return false; end
+    for st in mid; (st.kind === :diag && length(st.vec) != t.nrow * t.n) && return false; end
+    true
+end
+
+const _chain_handles = Dict{Any,Any}()          # signature -> (jh_chain* or C_NULL when the library declined, what the handle borrows)
+_stage_sig(st) = st.kind === :scale ? (:s, st.a, st.flags) : (:d, UInt(_device_ptr(st.vec isa HipArray ? st.vec.slab : whole(st.vec))), length(st.vec), st.conj)
+
+function _chain_handle(ctype::Cint, t, pre, mid, post, ::Type{T}) where {T}
+    key = (ctype, t.h, map(_stage_sig, pre), map(_stage_sig, mid), map(_stage_sig, post))
+    hit = get(_chain_handles, key, nothing)
+    hit === nothing || return hit[1]
+    keep = Any[]
+    function pack(sts, nptr)
+        arr = jh_chain_stage[]
+        for st in sts
+            if st.kind === :scale
+                push!(arr, jh_chain_stage(1, st.flags, st.a, C_NULL, C_NULL))
+            else
+                base = _device_ptr(st.vec isa HipArray ? st.vec.slab : whole(st.vec))
+                ptrs = Ptr{Cvoid}[base + (i - 1) * t.n * sizeof(T) for i = 1:nptr]
+                push!(keep, ptrs); push!(keep, st.vec)
+                push!(arr, jh_chain_stage(2, st.conj ? 4 : 0, 0.0, pointer(ptrs), C_NULL))
+            end
+        end
+        push!(keep, arr)
+        arr
+    end
+    a_pre, a_mid, a_post = pack(pre, 1), pack(mid, t.nrow), pack(post, 1)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    st = GC.@preserve keep ccall((:jh_chain_create, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{jh_chain_stage}, Cint, Ptr{jh_chain_stage}, Cint, Ptr{jh_chain_stage}, Ref{Ptr{Cvoid}}),
+                                 t.h, ctype, length(a_pre), a_pre, length(a_mid), a_mid, length(a_post), a_post, h)
+    st == 4 || check(st)                                                # JH_ERR_UNSUPPORTED: remembered, the run is applied stage by stage
+    _chain_handles[key] = (st == 4 ? C_NULL : h[], keep)
+    _chain_handles[key][1]
+end
+function close_chains!()                                                # release every chain handle (their operators are about to be closed)
+    for (h, _) in values(_chain_handles)
+        h == C_NULL || ccall((:jh_chain_destroy, LIB), Cint, (Ptr{Cvoid},), h)
+    end
+    empty!(_chain_handles)
+end
+
+# x -> stages -> out with every fusable run in one ccall; false when nothing fuses (the caller runs the reference's chain).
+# accumulate != 0 (a term of a sum, 634/643/652): only when the WHOLE chain is one fused run.
+function _fused_chain!(out, x, stages::Vector, ::Type{T}, accumulate::Integer) where {T}
+    (handle(out) == C_NULL || handle(x) == C_NULL) && return false
+    st = Any[_chain_stage(op, T) for op in stages]
+    steps = Any[]
+    for step in _chain_segments(st)
+        if step[1] === :chain && !_chain_sides_ok(step[3], step[4], step[5], step[6])
+            for q = step[7]:step[8]; push!(steps, (:op, q)); end
+        else
+            push!(steps, step)
+        end
+    end
+    any(s -> s[1] === :chain, steps) || return false
+    (accumulate != 0 && length(steps) != 1) && return false
+    cur = x
+    for (k, step) in enumerate(steps)
+        last = k == length(steps)
+        if step[1] === :op
+            op = st[step[2]].op
+            cur = mul!(last ? fill!(out, 0) : zeros(range(op)), op, cur)
+            continue
+        end
+        _, ctype, t, pre, mid, post, first, stop = step
+        h = _chain_handle(ctype, t, pre, mid, post, T)
+        dst = last ? out : zeros(range(st[stop].op))
+        status = h == C_NULL ? Cint(4) : ccall((:jh_chain_apply, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), h, handle(dst), handle(cur), last ? accumulate : 0)
+        if status == 4                                                  # the library declined this run (many rows of small blocks, ...): its stages one by one
+            accumulate != 0 && return false
+            for q = first:stop
+                op = st[q].op
+                cur = mul!((last && q == stop) ? fill!(out, 0) : zeros(range(op)), op, cur)
+            end
+            continue
+        end
+        check(status)
+        cur = dst
+    end
+    true
+end
+
+# JetSum with terms that are chains (src/Jets.jl:639-655): a term that is ONE fusable run adds itself to the output in its own last stage
+# (jh_chain_apply(accumulate): +-2 the first term after `d .= 0`, +-1 afterwards); the other terms go through the temporary as in the reference.
+# A bare block operator with a zero block is refused: the reference's shared temporary keeps the PREVIOUS term's row there (1022).
+function _chain_term_fusable(op::Jop, ::Type{T}, transposed::Bool) where {T}
+    L = JopLn(op)
+    L isa JopAdjoint && return nothing
+    inner = jet(L).df! === JetComposite_df! ? state(L).ops : (L,)
+    stages = transposed ? _stages_df′(inner) : _stages_df(inner)
+    steps = _chain_segments(Any[_chain_stage(o, T) for o in stages])
+    (length(steps) == 1 && steps[1][1] === :chain) ? stages : nothing
+end
+function _chain_sum!(out, x, ops, sgns, ::Type{T}, transposed::Bool) where {T}
+    (handle(out) == C_NULL || handle(x) == C_NULL) && return false
+    plans = Any[_chain_term_fusable(op, T, transposed) for op in ops]
+    any(p -> p !== nothing, plans) || return false
+    for (op, p) in zip(ops, plans)                                       # an unfused term must overwrite the whole temporary: composites and sums do
+        p === nothing && !(jet(JopLn(op)).df! === JetComposite_df! || jet(JopLn(op)).df! === JetSum_df!) && return false
+    end
+    started, tmp = false, nothing
+    for (op, sg, p) in zip(ops, sgns, plans)
+        sign = sg === (-) ? -1 : 1
+        if p !== nothing && _fused_chain!(out, x, p, T, started ? sign : 2 * sign)
+            started = true
+            continue
+        end
+        started || fill!(out, 0)
+        started = true
+        tmp === nothing && (tmp = zeros(transposed ? domain(ops[1]) : range(ops[1])))
+        broadcast!(sg, out, out, mul!(tmp, transposed ? JopLn(op)' : JopLn(op), x))
+    end
+    true
 end
 
 # ---------------------------------------------------------------- solver steps and the multi-GPU exchange

@@ -271,3 +271,58 @@ def test_bench_self_spawn_propagates_a_failing_rank_without_a_gpu():
     assert out.returncode != 0
     assert "no MI355X visible" in out.stderr and "exited with" not in out.stderr
     assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+# ---------------------------------------------------------------------------------- round 6: the chain planner's segmentation (no GPU needed)
+def _fake_stages(spec):
+    """spec: a string over A (tall), a (its adjoint), B / b (another tall operator), e (an elementwise stage), i (identity), x (opaque)."""
+    from jets_jl_amd.chains import Stage
+
+    nats = {"A": object(), "B": object()}
+    out = []
+    for ch in spec:
+        if ch in "AaBb":
+            out.append(Stage("tall", None, None, nat=nats[ch.upper()], base=nats[ch.upper()], adj=ch.islower()))
+        elif ch == "e":
+            out.append(Stage("scale", None, None, a=2.0, flags=0))
+        elif ch == "i":
+            out.append(Stage("identity", None, None))
+        else:
+            out.append(Stage("opaque", None, None))
+    return out
+
+
+@pytest.mark.parametrize("spec,want", [
+    ("Aa", [("N", 0, 0, 0, 0, 1)]),                                   # A' o A
+    ("Aea", [("N", 0, 1, 0, 0, 2)]),                                  # A' o W o A
+    ("eAeeae", [("N", 1, 2, 1, 0, 5)]),                               # M' o A' o W2 o W1 o A o M
+    ("Ae", [("F", 0, 1, 0, 0, 1)]),                                   # W o A
+    ("eA", [("F", 1, 0, 0, 0, 1)]),                                   # A o M
+    ("ea", [("T", 0, 1, 0, 0, 1)]),                                   # A' o W'
+    ("aee", [("T", 0, 0, 2, 0, 2)]),                                  # M2 o M1 o A'
+    ("A", [("op", 0)]),                                               # a bare operator: nothing to fuse
+    ("a", [("op", 0)]),
+    ("ee", [("op", 0), ("op", 1)]),                                   # elementwise stages with no tall operator to lean on
+    ("AexAa", [("F", 0, 1, 0, 0, 1), ("op", 2), ("N", 0, 0, 0, 3, 4)]),   # an opaque stage splits the chain; both sides fuse
+    ("Aeb", [("F", 0, 1, 0, 0, 1), ("op", 2)]),                       # B' is not A': forward run, then B' alone
+    ("AeeeeeA"[:6] + "a", [("F", 0, 4, 0, 0, 4), ("T", 0, 1, 0, 5, 6)]),   # five range-side stages: four ride with A, the fifth with A'
+    ("eeeeeA", [("op", 0), ("F", 4, 0, 0, 1, 5)]),                    # five domain-side stages: the earliest runs alone
+    ("Aiea", [("N", 0, 1, 0, 0, 3)]),                                 # an identity stage costs nothing and is not a stage of the kernel
+    ("xAa", [("op", 0), ("N", 0, 0, 0, 1, 2)]),
+])
+def test_chain_planner_segments(spec, want):
+    from jets_jl_amd import chains
+
+    st = _fake_stages(spec)
+    got = []
+    for step in chains._segments(st):
+        if step[0] == "op":
+            got.append(("op", step[1]))
+        else:
+            _, ctype, _tall, pre, mid, post, first, last = step
+            got.append(({chains.CHAIN_FORWARD: "F", chains.CHAIN_ADJOINT: "T", chains.CHAIN_NORMAL: "N"}[ctype], len(pre), len(mid), len(post), first, last))
+    assert got == want
+    covered = []
+    for step in chains._segments(st):
+        covered += [step[1]] if step[0] == "op" else list(range(step[6], step[7] + 1))
+    assert covered == list(range(len(st))), "every stage is applied exactly once, in order"

@@ -132,7 +132,9 @@ def test_every_julia_ccall_matches_the_header():
                                  "jh_blockop_bidiag_step_range", "jh_blockop_mul_adj_range", "jh_blockop_tune_get", "jh_blockop_tune_set",
                                  # round 5: rows a18 / a19 -- fused JetSum and scalar * operator -- and the typed scalar stage
                                  "jh_blocksum_mul_typed", "jh_blocksum_mul_adj_typed", "jh_blockop_mul_scaled", "jh_blockop_mul_adj_scaled",
-                                 "jh_lincomb_typed", "jh_setblock_fill", "jh_blockop_normal_mul_range"])
+                                 "jh_lincomb_typed", "jh_setblock_fill", "jh_blockop_normal_mul_range",
+                                 # round 6: chains of any depth
+                                 "jh_chain_create", "jh_chain_apply", "jh_chain_destroy"])
 def test_hot_path_entry_points_are_bound_in_julia(sym):
     assert sym in {c[1] for c in julia_ccalls()}
 
@@ -196,12 +198,36 @@ def test_julia_binding_dispatches_sums_and_scalar_chains_to_the_fused_calls():
     assert ":jh_blocksum_mul_typed" in fs and ":jh_blocksum_mul_adj_typed" in fs
 
 
+def test_julia_binding_dispatches_chains_of_any_depth_to_the_chain_calls():
+    """Round 6: W o A, A' o W o A, M' o A' o W o A o M, a * (A' o A), sums whose terms are such chains -- the planner is called from
+    the methods mul! dispatches to, and the jh_chain_* ccalls sit inside the planner."""
+    code = _julia_code_tokens()
+
+    def body(start):
+        at = code.index(start)
+        return code[at:code.index("\nend\n", at)]
+
+    assert "_fused_chain!(d, m, _stages_df(ops), T, 0)" in body("function Jets.JetComposite_df!(d::HipArray{T}, m::HipArray{T}; ops")
+    assert "_fused_chain!(m, d, _stages_df′(ops), T, 0)" in body("function Jets.JetComposite_df′!(m::HipArray{T}, d::HipArray{T}; ops")
+    assert "_fused_chain!(d, m, _stages_df(ops), T, 0)" in body("function Jets.JetComposite_df!(d::BlockArray{T,<:HipArray{T}}, m::HipArray{T}; ops")
+    assert "_fused_chain!(m, d, _stages_df′(ops), T, 0)" in body("function Jets.JetComposite_df′!(m::HipArray{T}, d::BlockArray{T,<:HipArray{T}}; ops")
+    for sig in ("function Jets.JetSum_df!(d::BlockArray{T,<:HipArray{T}}, m::HipArray{T}; ops, sgns", "function Jets.JetSum_df!(d::HipArray{T}, m::HipArray{T}; ops, sgns"):
+        assert "_chain_sum!(d, m, ops, sgns, T, false)" in body(sig)
+    for sig in ("function Jets.JetSum_df′!(m::HipArray{T}, d::BlockArray{T,<:HipArray{T}}; ops, sgns", "function Jets.JetSum_df′!(m::HipArray{T}, d::HipArray{T}; ops, sgns"):
+        assert "_chain_sum!(m, d, ops, sgns, T, true)" in body(sig)
+    assert ":jh_chain_apply" in body("function _fused_chain!(") and "_chain_handle(ctype, t, pre, mid, post, T)" in body("function _fused_chain!(")
+    assert ":jh_chain_create" in body("function _chain_handle(")
+    assert "_fused_chain!(out, x, p, T, started ? sign : 2 * sign)" in body("function _chain_sum!(")
+    assert "function JopHipDiagonal(diag::BlockArray{T,<:HipArray{T}})" in code          # weights over a block range
+
+
 def test_julia_struct_layouts_match_the_header():
     """jh_block_desc and jh_lsqr_result are passed by pointer: field order and types must match the C structs."""
     h = _strip_comments(open(HEADER).read())
     j = open(JULIA).read()
 
     ctypes_of = {"int": "i32", "int32_t": "i32", "int64_t": "i64", "double": "f64"}
+    h = re.sub(r"typedef\s+enum\s*\{[^}]*\}\s*\w+\s*;", " ", h)        # (enum bodies are not structs)
 
     def c_fields(name):
         body = re.search(r"typedef\s+struct\s*\w*\s*\{([^}]*)\}\s*" + name + r"\s*;", h, flags=re.S).group(1)
@@ -228,7 +254,7 @@ def test_julia_struct_layouts_match_the_header():
             out.append(({"Int32": "i32"}.get(ftype) or _jl_class(ftype), fname))
         return out
 
-    for name in ("jh_block_desc", "jh_lsqr_result"):
+    for name in ("jh_block_desc", "jh_lsqr_result", "jh_chain_stage"):
         cf, jf = c_fields(name), jl_fields(name)
         assert cf == jf, f"{name}: C fields {cf} vs Julia fields {jf}"
 
@@ -464,6 +490,7 @@ BASE_CALLABLES = {
     "typeof", "unsafe_string", "unsafe_wrap", "vec", "zeros", "time_ns", "reshape",
     "collect", "empty!", "pointer",          # round 5: collect(::Tuple) -> Vector, empty!(::AbstractDict), pointer(::Array) (Base, Julia 1.x manual)
     "mul!",                                  # LinearAlgebra.mul! (the binding says `using LinearAlgebra`; the reference extends it, src/Jets.jl:382-392)
+    "UInt", "broadcast!", "enumerate", "values", "vcat", "zip",   # round 6 (the chain planner): Base, Julia 1.x manual; broadcast! as the reference's own JetSum uses it (src/Jets.jl:634)
 }
 JETS_EXPORTS = {"Jet", "JetAbstractSpace", "JetBSpace", "JetSpace", "JetSSpace", "Jop", "JopAdjoint", "JopLn", "JopNl", "JopZeroBlock", "domain",
                 "getblock", "getblock!", "dot_product_test", "indices", "jacobian", "jacobian!", "jet", "linearity_test", "linearization_test", "nblocks",
