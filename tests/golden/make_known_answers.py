@@ -16,6 +16,8 @@ the reference's source lines and nothing else:
                                 product rounded, THEN added, rows in order; nrow == 1: direct write (1051), zero block => untouched
       JetComposite   522-540    right-to-left chain through zeros() temporaries, `d .= g(m)`
       JetSum         639-655    `d .= 0`, then `broadcast!(sgn, d, d, mul!(_d, op, m))` term by term; sign flattening 667-676
+      chains         530-540    (round 6) composites of depth 3 to 7 around a tall operator -- A' o W o A, (W o A)' o (W o A), a * (A' o A),
+                                M' o A' o (b W) o A o (a M) -- and sums whose terms are such chains: every stage into its own zeros()
     children: diagonal (test/runtests.jl:3-4  d .= diagonal .* m / m .= conj.(diagonal) .* d), identity, scalar a (1159-1160),
     JopZeroBlock (941-951), complex product = Julia's Complex *: (ar*br - ai*bi, ar*bi + ai*br), every operation rounded.
 
@@ -483,6 +485,101 @@ def main():
             f = ar.add if signs[t] == "+" else ar.sub
             msum = [f(x, y) for x, y in zip(msum, tmp)]
         store(case, "adj_0", ar, msum)
+
+    # ---- 9. (round 6) CHAINS of depth 3 to 7 through a tall operator with rows of every kind, and sums whose terms are chains.
+    #         JetComposite_df! (530-534): `dg = mapreduce(i -> (_m -> mul!(zeros(range(JopLn(ops[i]))), JopLn(ops[i]), _m)), o, 1:n); d .= dg(m)` --
+    #         every stage into its own zeros(), right to left; JetComposite_df'! (536-540) the adjoints in the opposite order.  Stages besides the
+    #         block operator: a diagonal over the block range (`W`: d .= diagonal .* m on the whole range vector, test/runtests.jl:3-4), a diagonal on
+    #         the domain (`M`), a REAL scalar (`d .= a * m`, 1159: a::Real * z multiplies part by part).  n = 18 elements per block: rows of Float32
+    #         are 72 bytes -- off the 16-byte grid.  Drawn AFTER every earlier case, so none of the older arrays changes. ----------------------------
+    def rscale(ar, a, x):                                                       # d .= a * m for a Real a (Julia: Complex(a * re, a * im))
+        return [(fmul(a, v[0], ar.fmt), fmul(a, v[1], ar.fmt)) if ar.cplx else fmul(a, v, ar.fmt) for v in x]
+
+    def diag_stage(ar, coeff, x, conj):                                         # d .= diagonal .* m  /  m .= conj.(diagonal) .* d
+        return [ar.mul(ar.conj(c) if conj else c, v) for c, v in zip(coeff, x)]
+
+    def flat(blocks):
+        return [v for b in blocks for v in b]
+
+    def unflat(vec, nrow, n):
+        return [vec[i * n:(i + 1) * n] for i in range(nrow)]
+
+    def run_chain(ar, ops, nrow, n, stages, x):
+        """x (a flat list: the domain vector or the whole range vector) through `stages` in application order; each stage writes a fresh vector."""
+        cur = list(x)
+        for st in stages:
+            if st[0] == "A":                                                    # mul!(zeros(range(A)), A, cur)   (531)
+                cur = flat(block_df(ar, ops, [[ar.zero() for _ in range(n)] for _ in range(nrow)], [cur]))
+            elif st[0] == "At":                                                 # mul!(zeros(domain(A)), A', cur)   (537)
+                cur = block_df_adj(ar, ops, [[ar.zero() for _ in range(n)]], unflat(cur, nrow, n))[0]
+            elif st[0] == "D":
+                cur = diag_stage(ar, st[1], cur, st[2])
+            elif st[0] == "s":
+                cur = rscale(ar, st[1], cur)
+            else:
+                raise AssertionError(st)
+        return cur
+
+    for dtype in ("f32", "f64", "c32", "c64"):
+        ar = Arith(dtype)
+        n = 18
+        def dg(adj=False):
+            return Child("diag", n, coeff=[rng.elem(ar) for _ in range(n)], adjoint=adj)
+        rscal = (rng.real(ar.fmt), F(0, Fraction(0))) if ar.cplx else rng.real(ar.fmt)
+        col = [dg(), Child("zero", n), Child("identity", n), Child("scale", n, scale=rscal), dg(adj=True), dg(), dg()]
+        ops = [[c] for c in col]
+        nrow = len(ops)
+        case = f"chain_{dtype}"
+        describe(case, ops, dtype, [n] * nrow, [n])
+        store_ops(case, ar, ops)
+        w = [[rng.elem(ar) for _ in range(nrow * n)] for _ in range(2)]          # two weight vectors over the whole range
+        cdom = [rng.elem(ar) for _ in range(n)]                                 # a diagonal on the domain
+        s0, s1 = from_int(3), F(1, Fraction(5, 8))                              # real scalars, exact in every element type
+        m = [rng.elem(ar) for _ in range(n)]
+        m[2] = (F(1, Fraction(0)), F(1, Fraction(0))) if ar.cplx else F(1, Fraction(0))       # a negative zero through every stage
+        din = [rng.elem(ar) for _ in range(nrow * n)]
+        store(case, "w_0", ar, w[0])
+        store(case, "w_1", ar, w[1])
+        store(case, "c_0", ar, cdom)
+        CASES[f"{case}/scalars"] = np.array([3.0, -0.625], dtype=np.float64)
+        store(case, "m_0", ar, m)
+        store(case, "d_in", ar, din)
+        A, At = ("A",), ("At",)
+        W0, W0c, W1 = ("D", w[0], False), ("D", w[0], True), ("D", w[1], False)
+        M, Mc = ("D", cdom, False), ("D", cdom, True)
+        S0, S1 = ("s", s0), ("s", s1)
+        chains = {
+            "AtWA": [A, W0, At],                                                # A' o W o A                        (depth 3)
+            "WAtWA": [A, W0, W0c, At],                                          # (W o A)' o (W o A)                (depth 4)
+            "aAtA": [A, At, S0],                                                # a * (A' o A)                      (depth 3)
+            "MtAtsWAsM": [M, S0, A, W1, S1, At, Mc],                            # M' o A' o (b W1) o A o (a M)      (depth 7)
+        }
+        for name, stages in chains.items():
+            store(case, f"y_{name}", ar, run_chain(ar, ops, nrow, n, stages, m))
+        store(case, "f_sWcA", ar, run_chain(ar, ops, nrow, n, [A, W0c, S1], m))                  # (b W0') o A: domain -> range
+        store(case, "a_sWcA", ar, run_chain(ar, ops, nrow, n, [S1, W0, At], din))                # its adjoint: A' o W0 o b  (conj(b) == b)
+        # JetSum over chains (639-646): d .= 0; d .= d + (A'WA) m; d .= d + (a I) m; d .= d - (A'A) m
+        t1 = run_chain(ar, ops, nrow, n, [A, W0, At], m)
+        t2 = rscale(ar, s1, list(m))                                            # (b * I) m: the composite (b, I) -- I into zeros(), then the scalar stage
+        t3 = run_chain(ar, ops, nrow, n, [A, At], m)
+        acc = [ar.zero() for _ in range(n)]
+        acc = [ar.add(x, y) for x, y in zip(acc, t1)]
+        acc = [ar.add(x, y) for x, y in zip(acc, t2)]
+        acc = [ar.sub(x, y) for x, y in zip(acc, t3)]
+        store(case, "y_sum", ar, acc)
+        # ... and a sum on the range: W0 o A - (b W1) o A  (domain -> range), with its adjoint applied to d_in
+        f1 = run_chain(ar, ops, nrow, n, [A, W0], m)
+        f2 = run_chain(ar, ops, nrow, n, [A, W1, S1], m)
+        accr = [ar.zero() for _ in range(nrow * n)]
+        accr = [ar.add(x, y) for x, y in zip(accr, f1)]
+        accr = [ar.sub(x, y) for x, y in zip(accr, f2)]
+        store(case, "f_sum", ar, accr)
+        g1 = run_chain(ar, ops, nrow, n, [W0c, At], din)
+        g2 = run_chain(ar, ops, nrow, n, [S1, ("D", w[1], True), At], din)
+        accd = [ar.zero() for _ in range(n)]
+        accd = [ar.add(x, y) for x, y in zip(accd, g1)]
+        accd = [ar.sub(x, y) for x, y in zip(accd, g2)]
+        store(case, "a_sum", ar, accd)
 
     np.savez_compressed(os.path.join(HERE, "known_answers.npz"), **CASES)
     print(f"wrote {len(CASES)} arrays in {len({k.split('/')[0] for k in CASES})} cases to tests/golden/known_answers.npz")

@@ -113,3 +113,39 @@ def test_jetsum_sign_rules_and_rounding_sequence(Jets, z, name):
     din = _rng(J, ops[0], c.blocks("d_in", nrow))
     mt = S.H * din
     assert ka.bits(mt.to_numpy().ravel(order="F")) == ka.bits(c.get("adj_0")), f"{name}: sum adjoint"
+
+
+@pytest.mark.parametrize("name", ka.CHAIN_CASES)
+def test_fused_chains_reproduce_the_independent_known_answers(Jets, z, name):
+    """Round 6: composites of depth 3 to 7 around a tall operator (A' o W o A, (W o A)' o (W o A), a * (A' o A), M' o A' o (b W) o A o (a M), (b W') o A and
+    its adjoint) and sums whose terms are such chains, through the FUSED chain kernels (jh_chain_*; the test asserts the fused path ran) -- bit for bit the
+    arrays derived in softfloat from src/Jets.jl:530-540, 639-655, 1159-1160."""
+    from jets_jl_amd import chains
+
+    J = Jets
+    c = ka.Case(z, name)
+    A = ka.device_ops(J, c)
+    R, D = J.range(A), J.domain(A)
+    w = [J.JopDiagonal(J.from_numpy(c.get(f"w_{k}"), R)) for k in range(2)]
+    cdom = J.JopDiagonal(J.from_numpy(c.get("c_0"), D))
+    m, din = J.from_numpy(c.get("m_0"), D), J.from_numpy(c.get("d_in"), R)
+    for key, stages in ka.CHAINS.items():
+        C = ka.device_chain(J, c, A, w, cdom, stages)
+        x = din if key.startswith("a_") else m
+        before = chains.STATS["chain_calls"]
+        y = J.mul_(J.rand(J.range(C), seed=5, stream=5), C, x)                  # into a dirty output
+        assert chains.STATS["chain_calls"] == before + 1, f"{name}: {key} did not take the fused path"
+        got = y.to_numpy() if hasattr(y, "arrays") else y.to_numpy().ravel(order="F")
+        assert ka.bits(got) == ka.bits(c.get(key)), f"{name}: {key}"
+    for key, (terms, xin) in ka.CHAIN_SUMS.items():
+        x = din if xin == "d_in" else m
+        S = None
+        for sign, stages in terms:
+            T = ka.device_chain(J, c, A, w, cdom, stages)
+            S = T if S is None else (S + T if sign > 0 else S - T)
+        before = chains.STATS["sum_terms_fused"]
+        y = J.mul_(J.rand(J.range(S), seed=6, stream=6), S, x)
+        assert chains.STATS["sum_terms_fused"] > before, f"{name}: {key} did not fuse any term"
+        got = y.to_numpy() if hasattr(y, "arrays") else y.to_numpy().ravel(order="F")
+        assert ka.bits(got) == ka.bits(c.get(key)), f"{name}: {key}"
+    J.close(A)

@@ -63,6 +63,28 @@ def test_oracle_chain_reproduces_the_jetsum_known_answers(oracle, z, name):
     assert ka.bits(mt[0]) == ka.bits(c.get("adj_0")), f"{name}: sum adjoint"
 
 
+@pytest.mark.parametrize("name", ka.CHAIN_CASES)
+def test_oracle_stages_reproduce_the_chain_known_answers(oracle, z, name):
+    """Round 6: composites of depth 3 to 7 around a tall operator with rows of every kind (JetComposite_df! / df'!, src/Jets.jl:530-540: every stage
+    into its own zeros()) and sums whose terms are chains (639-655), derived in softfloat from the reference's lines -- the oracle applying the stages
+    one by one must reproduce every array bit for bit (tests/test_gpu_known_answers.py holds the FUSED device path to the same arrays)."""
+    c = ka.Case(z, name)
+    ops = ka.oracle_ops(oracle, c)
+    n, dt = c.col_len[0], c.dtype
+    for key, stages in ka.CHAINS.items():
+        x = c.get("d_in") if key.startswith("a_") else c.get("m_0")
+        assert ka.bits(ka.oracle_chain(oracle, c, ops, stages, x)) == ka.bits(c.get(key)), f"{name}: {key}"
+    for key, (terms, xin) in ka.CHAIN_SUMS.items():
+        x = c.get(xin)
+        acc = None
+        for sign, stages in terms:
+            t = ka.oracle_chain(oracle, c, ops, stages, x)
+            if acc is None:
+                acc = np.zeros(t.size, dt)                                       # d .= 0   (640 / 649)
+            acc = oracle.barr_lincomb([np.empty(t.size, dt)], [1.0, sign], [[acc], [t]])[0]
+        assert ka.bits(acc) == ka.bits(c.get(key)), f"{name}: {key}"
+
+
 @pytest.mark.parametrize("name", ka.SUM_CASES)
 def test_the_sum_expressions_flatten_to_the_stored_signs(z, name):
     """The nested differences the GPU test builds (ka.SUM_EXPRESSIONS) flatten, by the reference's rule (667-676: a minus flips the
