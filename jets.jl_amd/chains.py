@@ -30,7 +30,7 @@ from .jets import JopLn, JopNl, JopAdjoint, Jop, domain, range_, mul_, adjoint
 MAX_STAGES = 4          # per side (jh_tall_chain.hip: JH_CHAIN_MAX_STAGES)
 _UNSUPPORTED = 4        # JH_ERR_UNSUPPORTED
 ENABLED = [True]        # tests / A-B timings: [False] sends every composite and sum down the stage-by-stage path of rounds 1-5
-STATS = {"chain_calls": 0, "sum_terms_fused": 0}   # how often a fused run was applied (tests assert that the fused path is the one that ran)
+STATS = {"chain_calls": 0, "sum_terms_fused": 0, "bcast_calls": 0}   # how often a fused run was applied (tests assert that the fused path is the one that ran)
 
 
 # ------------------------------------------------------------------------------ classification -----
@@ -120,9 +120,18 @@ def classify(op: Jop, R) -> Stage:
 
     adj = isinstance(op, JopAdjoint)
     base = op.op if adj else op
+    if isinstance(base, JopNl) and not adj:                      # a nonlinear stage of JetComposite_f! (src/Jets.jl:524-528): its f!
+        jn = base.jet
+        if jn.f is _b.square_f:
+            return Stage("square_f", op, R)                      # d .= m.^2   (test/runtests.jl:19; benchmark/benchmarks.jl:55)
+        if jn.f is _b.elementwise_f:
+            return Stage("expr_f", op, R, vec=jn.s["f_expr"], keep=jn.s["params"])
+        return Stage("opaque", op, R)
     if not isinstance(base, JopLn):
         return Stage("opaque", op, R)
     j = base.jet
+    if j.df is _b.square_df and j.df_adj is _b.square_df_adj and j.mo is not None and j.mo.length() == domain(base).length():
+        return Stage("square_df", op, R, vec=j.mo, conj=adj)      # dd .= 2 .* mo .* dm  /  conj.(2 .* mo) .* dd   (test/runtests.jl:20)
     if j.df is _b.identity_df:
         return Stage("identity", op, R)
     if j.df is _j.constdiag_df and j.df_adj is _j.constdiag_df_adj:
@@ -326,11 +335,81 @@ def plan(stages: Sequence, cache: ChainCache | None, tag):
             steps.append(("chain", ctype, tall, pre, mid, post, st[first:last + 1]))
         else:   # a diagonal of the wrong length for its side: not the planner's business -- the stages run one by one and raise what they raise
             steps += [("op", s) for s in st[first:last + 1]]
+    steps = _merge_bcast(steps)
     if cache is not None:
         if len(cache.plans) >= 8:
             cache.plans.clear()
         cache.plans[key] = steps
     return steps
+
+
+# ---- runs of elementwise stages with NO tall operator to lean on: one JIT-compiled broadcast (broadcast.py; src/Jets.jl:889-911) -------------
+# The reference's own composition benchmark is such a chain: G = F o A o F o A with F: d .= m.^2 and A a diagonal on one plain space
+# (benchmark/benchmarks.jl:33-38, 55-60, 73-80) -- four passes through three temporaries there, ONE pass here:
+# d .= (a .* ((a .* m) .* (a .* m))) .* (a .* ((a .* m) .* (a .* m))), every operation rounded as the stages round it.
+_BCAST_KINDS = ("scale", "diag", "identity", "square_f", "square_df", "expr_f")
+_BCAST_MAX_CODE = 1500
+
+
+def _stage_len(s: Stage) -> int:
+    return s.R.length() if s.R is not None else -1
+
+
+def _merge_bcast(steps):
+    out, run = [], []
+
+    def flush():
+        active = [q for q in run if q.kind != "identity"]
+        if len(active) >= 2:
+            out.append(("bcast", list(run)))
+        else:
+            out.extend(("op", q) for q in run)
+        run.clear()
+
+    for step in steps:
+        if step[0] == "op" and step[1].kind in _BCAST_KINDS and (not run or _stage_len(step[1]) == _stage_len(run[0])):
+            run.append(step[1])
+            continue
+        flush()
+        if step[0] == "op" and step[1].kind in _BCAST_KINDS:
+            run.append(step[1])
+        else:
+            out.append(step)
+    flush()
+    return out
+
+
+def _bcast_expr(run, x):
+    """The run as ONE lazy elementwise expression over x (broadcast.BExpr): each stage wraps the previous one's expression."""
+    import re
+
+    from .broadcast import BExpr, bc, lazy
+
+    e = lazy(x)
+    for s in run:
+        if s.kind == "identity":
+            continue
+        if s.kind == "scale":
+            a = s.op.op.jet.s["a"] if isinstance(s.op, JopAdjoint) else s.op.jet.s["a"]
+            e = BExpr.of(a) * e                                # (the scalar as given: its TYPE decides the arithmetic, broadcast._wide_mask / _real_mask)
+        elif s.kind == "diag":
+            c = lazy(s.vec)
+            e = (bc.conj(c) if s.conj else c) * e
+        elif s.kind == "square_f":
+            e = e * e
+        elif s.kind == "square_df":
+            c = lazy(s.vec)
+            c2 = c + c
+            e = (bc.conj(c2) if s.conj else c2) * e
+        else:                                                     # expr_f: the child's own expression over x0 and its parameters s0..
+            fmt = s.vec.replace("{", "{{").replace("}", "}}")
+            fmt = re.sub(r"\bx0\b", "{0}", fmt)
+            for k in builtins.range(len(s.keep)):
+                fmt = re.sub(r"\bs%d\b" % k, "{%d}" % (k + 1), fmt)
+            e = BExpr._join("(" + fmt + ")", e, *s.keep)
+        if len(e.code) > _BCAST_MAX_CODE:
+            return None
+    return e
 
 
 def _chain_handle(cache: ChainCache | None, ctype, tall, pre, mid, post):
@@ -350,7 +429,7 @@ def _chain_handle(cache: ChainCache | None, ctype, tall, pre, mid, post):
 
 
 def has_chain(steps) -> bool:
-    return any(s[0] == "chain" for s in steps)
+    return any(s[0] in ("chain", "bcast") for s in steps)
 
 
 def run(out, x, stages: Sequence, ws, cache: ChainCache | None, tag, accumulate: int = 0):
@@ -361,7 +440,7 @@ def run(out, x, stages: Sequence, ws, cache: ChainCache | None, tag, accumulate:
     steps = plan(stages, cache, tag)
     if not has_chain(steps):
         return None
-    if accumulate and len(steps) != 1:
+    if accumulate and (len(steps) != 1 or steps[0][0] != "chain"):
         return None
     ws = ws if ws is not None else _j._Workspace()
     try:
@@ -372,6 +451,21 @@ def run(out, x, stages: Sequence, ws, cache: ChainCache | None, tag, accumulate:
                 s = step[1]
                 dst = _j._zeroed_output(out, s.op) if last else ws.zeros(("chain", k), s.R, s.op)
                 cur = mul_(dst, s.op, cur)
+                continue
+            if step[0] == "bcast":
+                members = step[1]
+                e = _bcast_expr(members, cur)
+                if e is not None:
+                    from .broadcast import assign_
+
+                    dst = out if last else ws.zeros(("chain", k), members[-1].R, overwritten=True)
+                    cur = assign_(dst, e)
+                    STATS["bcast_calls"] += 1
+                    continue
+                for q, s in enumerate(members):                   # (an expression too long to be worth one kernel: its stages one by one)
+                    fin = last and q == len(members) - 1
+                    d2 = _j._zeroed_output(out, s.op) if fin else ws.zeros(("chain", k, q), s.R, s.op)
+                    cur = mul_(d2, s.op, cur)
                 continue
             _, ctype, tall, pre, mid, post, members = step
             h = _chain_handle(cache, ctype, tall, pre, mid, post)

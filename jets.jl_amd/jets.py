@@ -493,8 +493,13 @@ def _chain(out, x, stages, ws):
         ws.release()
 
 
-def JetComposite_f(d, m, *, ops, _ws=None, **kw):  # :524-528  right-to-left chain
-    return _chain(d, m, [(op, range_(op)) for op in reversed(ops)], _ws)
+def JetComposite_f(d, m, *, ops, _ws=None, _chains=None, **kw):  # :524-528  right-to-left chain
+    from . import chains as _chn
+
+    stages = [(op, range_(op)) for op in reversed(ops)]
+    if len(ops) >= 2 and _chn.run(d, m, stages, _ws, _chains, "f") is not None:      # runs of elementwise stages (F o A o F o A): one fused pass (chains.py)
+        return d
+    return _chain(d, m, stages, _ws)
 
 
 def JetComposite_df(d, m, *, ops, _ws=None, _chains=None, **kw):  # :530-534

@@ -308,3 +308,84 @@ def test_a_sum_with_a_bare_operator_that_has_zero_rows_keeps_the_references_loop
         chains.ENABLED[0] = True
     assert_bits_equal(y1.to_numpy(), y0.to_numpy(), "stale-row quirk kept")
     rig.close()
+
+
+# ---------------------------------------------------------------------------------- chains of elementwise stages with no tall operator: one JIT broadcast
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("n", [100, 4099, 1 << 16])
+def test_the_references_composition_benchmark_is_one_pass(Jets, oracle, dt, n):
+    """G = F o A o F o A with F: d .= m.^2 (JopBar) and A a diagonal (JopFoo) on one plain space -- benchmark/benchmarks.jl:33-38, 55-60, 73-80 (there
+    Float64, n = 100).  mul!(d, G, m) is four stages through three temporaries in the reference (src/Jets.jl:524-528); here ONE JIT-compiled elementwise
+    pass.  J = jacobian!(G, m): mul!(d, J, dm) and mul!(m, J', d) likewise (530-540 with the children's points set by point!, 578-589).  Bit-identical
+    to the stage-by-stage chain on the device, and to numpy applying the stages one by one."""
+    from jets_jl_amd import chains
+
+    J = Jets
+    spc = J.JetSpace(dt, n)
+    a = J.rand(spc, seed=11, stream=0)
+    ha = a.to_numpy().ravel(order="F").copy()
+    A, F = J.JopDiagonal(a), J.JopSquare(spc)
+    G = J.compose(J.compose(J.compose(F, A), F), A)
+    hm = u01(oracle, dt, 12, 0, n)
+    m = J.from_numpy(hm, spc)
+
+    def both(op, x):
+        before = chains.STATS["bcast_calls"]
+        y1 = J.mul_(J.rand(spc, seed=5, stream=5), op, x)
+        ran = chains.STATS["bcast_calls"] - before
+        chains.ENABLED[0] = False
+        try:
+            y0 = J.mul_(J.rand(spc, seed=6, stream=6), op, x)
+        finally:
+            chains.ENABLED[0] = True
+        return y1.to_numpy().ravel(order="F"), y0.to_numpy().ravel(order="F"), ran
+
+    y1, y0, ran = both(G, m)
+    assert ran == 1
+    assert_bits_equal(y1, y0, "G(m): one pass vs four stages")
+
+    def cmul(x, y):                                                           # Julia's complex product, every operation rounded in the element type
+        if np.dtype(dt).kind != "c":
+            return x * y
+        rt = np.float32 if dt == np.complex64 else np.float64
+        xr, xi, yr, yi = x.real.astype(rt), x.imag.astype(rt), y.real.astype(rt), y.imag.astype(rt)
+        out = np.empty(x.shape, dt)
+        out.real = xr * yr - xi * yi
+        out.imag = xr * yi + xi * yr
+        return out
+
+    t1 = cmul(ha, hm)
+    t2 = cmul(t1, t1)
+    t3 = cmul(ha, t2)
+    assert_bits_equal(y1, cmul(t3, t3), "G(m) vs numpy, stage by stage")
+    Jg = J.jacobian_(G, m)
+    hdm = u01(oracle, dt, 13, 0, n)
+    dm = J.from_numpy(hdm, spc)
+    j1, j0, ran = both(Jg, dm)
+    assert ran == 1
+    assert_bits_equal(j1, j0, "J dm: one pass vs four stages")
+    a1, a0, ran = both(Jg.H, dm)
+    assert ran == 1
+    assert_bits_equal(a1, a0, "J' d: one pass vs four stages")
+
+
+def test_an_elementwise_nonlinear_childs_expression_is_spliced_into_the_chain(Jets, oracle):
+    """JopElementwise children carry their f as a C expression: in a chain of elementwise stages the expression is spliced in, with its parameters."""
+    from jets_jl_amd import chains
+
+    J = Jets
+    dt, n = np.float32, 5000
+    spc = J.JetSpace(dt, n)
+    a = J.rand(spc, seed=21, stream=0)
+    E = J.JopElementwise(spc, "s0*x0*x0 + s1", "2*s0*x0", [0.5, -0.25])
+    G = J.compose(J.compose(E, J.JopDiagonal(a)), E)
+    m = J.rand(spc, seed=22, stream=0)
+    before = chains.STATS["bcast_calls"]
+    y1 = J.mul_(J.zeros(spc), G, m)
+    assert chains.STATS["bcast_calls"] == before + 1
+    chains.ENABLED[0] = False
+    try:
+        y0 = J.mul_(J.zeros(spc), G, m)
+    finally:
+        chains.ENABLED[0] = True
+    assert_bits_equal(y1.to_numpy(), y0.to_numpy(), "E o A o E")

@@ -50,9 +50,9 @@ print(f"# {nrow} x 1 of {edge}^3 {np.dtype(dt).name}: {nrow * n * s / 2**30:.1f}
 
 def line(tag, op, out, x, nbytes):
     chains.ENABLED[0] = True
-    before = chains.STATS["chain_calls"] + chains.STATS["sum_terms_fused"]
+    before = chains.STATS["chain_calls"] + chains.STATS["sum_terms_fused"] + chains.STATS["bcast_calls"]
     ms_f = timed(lambda: J.mul_(out, op, x), reps)
-    ran = chains.STATS["chain_calls"] + chains.STATS["sum_terms_fused"] - before
+    ran = chains.STATS["chain_calls"] + chains.STATS["sum_terms_fused"] + chains.STATS["bcast_calls"] - before
     chains.ENABLED[0] = False
     try:
         ms_u = timed(lambda: J.mul_(out, op, x), max(2, reps // 3))
@@ -78,3 +78,15 @@ ms = timed(lambda: J.mul_(y, A.H, d), reps)
 print(f"{'A^T d   (jh_blockop_mul_adj)':34s}       {ms:9.3f} ms  {(2 * Nn + n * s) / ms / 1e9:5.2f} TB/s", flush=True)
 ms = timed(lambda: J.mul_(d, A, m), reps)
 print(f"{'A m     (jh_blockop_mul)':34s}       {ms:9.3f} ms  {(2 * Nn + n * s) / ms / 1e9:5.2f} TB/s", flush=True)
+
+# the reference's composition benchmark (benchmark/benchmarks.jl:73-80: G = F o A o F o A, F: d .= m.^2, A a diagonal) on ONE block-sized plain space:
+# algorithmic bytes 3 n s (m, a read; d written); stage by stage: four passes through three temporaries
+F = J.JopSquare(blk)
+A1 = J.JopDiagonal(c)
+G = J.compose(J.compose(J.compose(F, A1), F), A1)
+g = J.zeros(blk)
+reps = max(20, int(2.0e10 / (n * s)))
+line("G = F o A o F o A (one block)", G, g, m, 3 * n * s)
+Jg = J.jacobian_(G, m)
+line("jacobian(G) * dm", Jg, g, m, 5 * n * s)
+line("jacobian(G)' * d", Jg.H, g, m, 5 * n * s)
