@@ -25,7 +25,7 @@ module JetsHIP
 using Jets, LinearAlgebra
 import Jets: JetAbstractSpace, JetBSpace, JetSpace, BlockArray, BlockArrayStyle, Jop, JopLn, JopNl, JopAdjoint, Jet, jet, state,
              domain, getblock, getblock!, setblock!, indices, nblocks, space, point!, JopZeroBlock_df!, JetBlock_f!,
-             JetBlock_df!, JetBlock_df′!, JetComposite_df!, JetComposite_df′!, JetSum_df!, JetSum_df′!, _constdiag_df!, _constdiag_df′!, JetBlock
+             JetBlock_df!, JetBlock_df′!, JetComposite_f!, JetComposite_df!, JetComposite_df′!, JetSum_df!, JetSum_df′!, _constdiag_df!, _constdiag_df′!, JetBlock
 
 export HipSpace, HipArray, JopHipDiagonal, JopHipSquare, JopHipDense, hip_lsqr!
 
@@ -567,6 +567,11 @@ function Jets.JetComposite_df!(d::HipArray{T}, m::HipArray{T}; ops, kwargs...) w
     _fused_chain!(d, m, _stages_df(ops), T, 0) && return d              # chains of any depth: every fusable run in one pass (round 6)
     invoke(JetComposite_df!, Tuple{AbstractArray,Any}, d, m; ops=ops, kwargs...)
 end
+# JetComposite_f! (524-528) on one device space: runs of elementwise stages (F ∘ A ∘ F ∘ A, benchmark/benchmarks.jl:73) in one JIT-compiled pass
+function Jets.JetComposite_f!(d::HipArray{T}, m::HipArray{T}; ops, kwargs...) where {T}
+    _fused_chain!(d, m, Any[ops[i] for i = length(ops):-1:1], T, 0) && return d
+    invoke(JetComposite_f!, Tuple{AbstractArray,Any}, d, m; ops=ops, kwargs...)
+end
 # the adjoint of a domain -> domain composite (M' ∘ A' ∘ W ∘ A ∘ M is its own shape adjointed)
 function Jets.JetComposite_df′!(m::HipArray{T}, d::HipArray{T}; ops, kwargs...) where {T}
     _fused_chain!(m, d, _stages_df′(ops), T, 0) && return m
@@ -697,8 +702,14 @@ _stages_df′(ops) = Any[JopLn(ops[i])' for i = 1:length(ops)]             # (53
 function _chain_stage(op::Jop, ::Type{T}) where {T}
     adj = op isa JopAdjoint
     base = adj ? op.op : op
+    if base isa JopNl                                                   # a nonlinear stage of JetComposite_f! (524-528): its f!
+        return (!adj && jet(base).f! === JopHipSquare_f!) ? (kind=:square_f, op=op) : (kind=:opaque, op=op)
+    end
     base isa JopLn || return (kind=:opaque, op=op)
     j = jet(base)
+    if j.df! === JopHipSquare_df! && length(j.mₒ) == length(domain(base))   # the Jacobian of d .= m.^2 about mₒ: δd .= 2 .* mₒ .* δm
+        return (kind=:square_df, op=op, vec=j.mₒ, conj=adj)
+    end
     if j.df! === _constdiag_df!
         a = state(base).a
         a isa FusableReal || return (kind=:opaque, op=op)               # a Complex scalar takes the full product: the stage-by-stage chain
@@ -760,6 +771,50 @@ function _chain_segments(st::Vector)
     steps
 end
 
+# Runs of elementwise stages with NO tall operator to lean on -- the reference's own composition benchmark G = F ∘ A ∘ F ∘ A with F: d .= m.^2 and A a
+# diagonal (benchmark/benchmarks.jl:33-38, 55-60, 73-80), its Jacobian and its adjoint -- become ONE lazy Broadcasted tree, which _bcast! prints as a C
+# expression and runs as one JIT-compiled pass (src/Jets.jl:889-911): four passes through three temporaries in the reference.
+_bcast_kind(st) = st.kind === :scale || st.kind === :diag || st.kind === :identity || st.kind === :square_f || st.kind === :square_df
+function _merge_bcast(steps::Vector, st::Vector)
+    out, run = Any[], Int[]
+    function flush()
+        if length([q for q in run if st[q].kind !== :identity]) >= 2
+            push!(out, (:bcast, run[1], run[end]))
+        else
+            for q in run; push!(out, (:op, q)); end
+        end
+        empty!(run)
+    end
+    for step in steps
+        if step[1] === :op && _bcast_kind(st[step[2]]) && (isempty(run) || length(range(st[step[2]].op)) == length(range(st[run[1]].op)))
+            push!(run, step[2])
+        else
+            flush()
+            (step[1] === :op && _bcast_kind(st[step[2]])) ? push!(run, step[2]) : push!(out, step)
+        end
+    end
+    flush()
+    out
+end
+function _bcast_tree(st::Vector, first::Int, stop::Int, x)
+    e = x
+    for q = first:stop
+        s = st[q]
+        if s.kind === :scale
+            base = s.op isa JopAdjoint ? s.op.op : s.op
+            e = Broadcast.broadcasted(*, state(base).a, e)                 # the scalar as given: its TYPE decides the arithmetic (_wide_mask / _real_mask)
+        elseif s.kind === :diag
+            e = Broadcast.broadcasted(*, s.conj ? Broadcast.broadcasted(conj, s.vec) : s.vec, e)
+        elseif s.kind === :square_f
+            e = Broadcast.broadcasted(*, e, e)
+        elseif s.kind === :square_df
+            c2 = Broadcast.broadcasted(+, s.vec, s.vec)
+            e = Broadcast.broadcasted(*, s.conj ? Broadcast.broadcasted(conj, c2) : c2, e)
+        end
+    end
+    e
+end
+
 # a diagonal before A / after A' lives on the domain (n elements), one after A / before A' on the range (nrow * n)
 function _chain_sides_ok(t, pre, mid, post)
     for st in vcat(pre, post); (st.kind === :diag && length(st.vec) != t.n) && return false; end
@@ -818,14 +873,20 @@ function _fused_chain!(out, x, stages::Vector, ::Type{T}, accumulate::Integer) w
             push!(steps, step)
         end
     end
-    any(s -> s[1] === :chain, steps) || return false
-    (accumulate != 0 && length(steps) != 1) && return false
+    steps = _merge_bcast(steps, st)
+    any(s -> s[1] === :chain || s[1] === :bcast, steps) || return false
+    (accumulate != 0 && (length(steps) != 1 || steps[1][1] !== :chain)) && return false
     cur = x
     for (k, step) in enumerate(steps)
         last = k == length(steps)
         if step[1] === :op
             op = st[step[2]].op
             cur = mul!(last ? fill!(out, 0) : zeros(range(op)), op, cur)
+            continue
+        end
+        if step[1] === :bcast
+            dst = last ? out : zeros(range(st[step[3]].op))
+            cur = _bcast!(dst, _bcast_tree(st, step[2], step[3], cur))
             continue
         end
         _, ctype, t, pre, mid, post, first, stop = step

@@ -219,6 +219,9 @@ def test_julia_binding_dispatches_chains_of_any_depth_to_the_chain_calls():
     assert ":jh_chain_create" in body("function _chain_handle(")
     assert "_fused_chain!(out, x, p, T, started ? sign : 2 * sign)" in body("function _chain_sum!(")
     assert "function JopHipDiagonal(diag::BlockArray{T,<:HipArray{T}})" in code          # weights over a block range
+    # runs of elementwise stages with no tall operator (benchmark/benchmarks.jl:73: G = F o A o F o A): one Broadcasted tree through _bcast!
+    assert "_fused_chain!(d, m, Any[ops[i] for i = length(ops):-1:1], T, 0)" in body("function Jets.JetComposite_f!(d::HipArray{T}, m::HipArray{T}; ops")
+    assert "_bcast!(dst, _bcast_tree(st, step[2], step[3], cur))" in body("function _fused_chain!(")
 
 
 def test_julia_struct_layouts_match_the_header():

@@ -115,6 +115,28 @@ for edge, reps in ((128, 20), (256, 10)):
     del A, coeff, N, d, y, m
     gc.collect()
 
+# ---------------------------------------------------------------- config 3, weighted (round 6): A' o W o A on 256 x 256^3
+# the normal equations of a WEIGHTED least-squares problem (data weights W on the block range): a chain of depth 3 through the tall operator -- ONE pass
+# of the chain kernels (jh_chain_*: 2 N n s + 2 n s bytes) against the reference's stage-by-stage chain through two range-sized temporaries
+from jets_jl_amd import chains as _chains
+
+A, coeff = tall(256, 256)
+n = 256 ** 3
+w = J.rand(J.range(A), seed=5, stream=0)
+N = J.compose(J.compose(A.H, J.JopDiagonal(w)), A)
+m = J.rand(J.domain(A), seed=2, stream=0)
+y = J.zeros(J.domain(A))
+ms_f = timed(lambda: J.mul_(y, N, m), 10)
+_chains.ENABLED[0] = False
+ms_u = timed(lambda: J.mul_(y, N, m), 4)
+_chains.ENABLED[0] = True
+bf = (2 * 256 * n + 2 * n) * 4
+print(f"{'config 3w: A^T o W o A on 256x1 diagonal, 256^3 Float32':58s} fused {ms_f:8.3f} ms ({bf / ms_f / 1e6:7.1f} GB/s, "
+      f"{100 * bf / (ms_f * 1e-3) / PEAK:4.1f} %)   stage by stage {ms_u:8.3f} ms   speed-up {ms_u / ms_f:4.2f}x", flush=True)
+J.close(A)
+del A, coeff, N, w, y, m
+gc.collect()
+
 # ---------------------------------------------------------------- config 4
 for nrow, note in ((128, "rank-local shard at 8 GPUs"), (256, "rank-local shard at 4 GPUs"), (512, "rank-local shard at 2 GPUs"),
                    (1024, "whole operator on 1 GPU")):
