@@ -45,6 +45,12 @@
 extern "C" {
 #endif
 
+/* libjetship.so is built with -fvisibility=hidden: exactly the entry points declared in this header are exported (round 6; tests/test_abi_symbols.py
+ * compares the library's dynamic symbol table with this file). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define JETSHIP_ABI_VERSION 4   /* 2 (round 4): jh_block_desc.scale_flags, jh_lincomb_typed; 3 (round 5): jh_blocksum_mul[_adj]_typed; 4 (round 6): jh_chain_*, jh_norm_blocks / jh_dot_blocks */
 
 typedef enum {
@@ -570,6 +576,10 @@ int jh_tune_get(const char *name, int64_t *value);
  * the final play-off as 16 a + b, -1: none yet). */
 int jh_blockop_tune_get(const jh_blockop *op, const char *name, int64_t *value);
 int jh_blockop_tune_set(jh_blockop *op, const char *name, int64_t value);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

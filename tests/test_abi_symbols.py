@@ -37,6 +37,19 @@ def test_library_exports_every_declared_symbol():
     assert handle.jh_abi_version() == 4
 
 
+def test_library_exports_exactly_the_declared_symbols():
+    """Round 6: the library is built with -fvisibility=hidden and a linker version script (csrc/jetship.map) -- its dynamic symbol
+    table holds the header's entry points and NOTHING else: no cross-translation-unit helper (round 5 leaked jh_comm_exists, jh_dot_begin, jh_dot_end),
+    no C++ template instantiation, no kernel host stub."""
+    import subprocess
+
+    import jets_jl_amd as J
+
+    out = subprocess.run(["nm", "-D", "--defined-only", J.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert exported == declared_symbols(), (sorted(set(exported) - set(declared_symbols())), sorted(set(declared_symbols()) - set(exported)))
+
+
 def test_header_cites_the_reference_for_every_entry_point_group():
     text = open(HEADER).read()
     assert text.count("src/Jets.jl:") >= 25
