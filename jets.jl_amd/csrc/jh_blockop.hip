@@ -507,6 +507,7 @@ int jh_blockop_point(jh_blockop *op, const jh_bvec *mo)
         if (op->dense_mixed && op->blocks[k].kind == JH_OP_DENSE) jh_dev_block_set_prod_off(host[k], op->prod_off[0][k], op->prod_off[1][k]);
     }
     scan_coeff_alignment(op);                                            // (the SQUARE blocks' arrays have moved)
+    op->table_gen++;
     hipStream_t st = jh_ctx().stream;
     JH_CHECK_HIP(hipMemcpyAsync(op->dev_blocks, host.data(), host.size() * sizeof(jh_dev_block), hipMemcpyHostToDevice, st));
     JH_CHECK_HIP(hipStreamSynchronize(st));                             // host staging vector dies at return

@@ -324,6 +324,7 @@ struct jh_blockop {
     int64_t *dev_dims = nullptr;             // nrow*ncol x {nr, nc} of the described operators (small_loop only)
     bool nonlinear = false;                  // has a SQUARE block (JopNl child)
     bool pointed = false;                    // jh_blockop_point has been called (SQUARE blocks have their mo)
+    int64_t table_gen = 0;                   // bumped whenever the device block table is rewritten (jh_blockop_point): what is derived from it (a fused chain's row table) is rebuilt
     int *dev_rows_nz = nullptr;              // a tall operator of elementwise rows of several kinds: its non-ZERO rows, ascending (the forward of an operator with many
     int64_t n_rows_nz = 0;                   // zero rows -- muted shots -- launches workgroups for those only)
     bool coeff_aligned16 = true;             // every coefficient array of a DIAG / SQUARE block starts on a 16-byte boundary (jh_blockop_create; again at jh_blockop_point,

@@ -39,11 +39,28 @@ struct ChainProg {
     double a[JH_CHAIN_MAX_STAGES];       // SCALE on 64-bit elements; WIDE: Julia's Float64 scalar against 32-bit elements
 };
 
+// THE ROW TABLE.  One record of (1 + NW) 64-bit words per block row, built when the chain is created: word 0 describes A's block of the row, words
+// 1 .. NW the row's blocks of the range-side coefficient streams.  A word is a device pointer (48 bits) with its flags above it -- one s_load_dwordx2 per
+// row and stream, where the operator's own table entry is 8 dwords: with four rows in flight and the next four being fetched the whole entries did not fit
+// the SGPR file, and without fetching ahead the adjoint-shaped walk waited for a scalar round trip per batch (4096 x 64^3, one workgroup per CU: 3.4 TB/s).
+//   word 0:   bits 48-50 the block's kind (jh_opkind), bit 51 its adjoint flag, bit 52 "a SCALE block's scalar is Real"; a SCALE row's scalar itself is read
+//             from the operator's table where it is used
+//   word 1+:  bit 48 the row's own conj flag (a child that is the adjoint of a diagonal), bit 49 a zero block; a null pointer is an identity row
+constexpr uint64_t CR_PTR = (((uint64_t)1) << 48) - 1;
+constexpr uint64_t CW_SPECIAL = ((uint64_t)1) << 49;   // a weight word's zero-block flag
+__device__ inline int cr_kind(uint64_t e) { return (int)((e >> 48) & 7u); }
+__device__ inline bool cr_adj(uint64_t e) { return ((e >> 51) & 1u) != 0; }
+__device__ inline bool cr_real(uint64_t e) { return ((e >> 52) & 1u) != 0; }
+__device__ inline bool cr_reads(uint64_t e) { const int k = cr_kind(e); return k == JH_OP_DIAG || k == JH_OP_SQUARE; }
+__device__ inline bool cw_conj(uint64_t e) { return ((e >> 48) & 1u) != 0; }
+__device__ inline bool cw_zero(uint64_t e) { return ((e >> 49) & 1u) != 0; }
+template <typename S> __device__ inline const S *cr_ptr(uint64_t e) { return reinterpret_cast<const S *>(e & CR_PTR); }
+
 struct ChainArgs {
     ChainProg pre, mid, post;
     const void *pre_c[JH_CHAIN_MAX_STREAMS];       // domain-sized coefficient arrays of P
     const void *post_c[JH_CHAIN_MAX_STREAMS];      // ... of Q
-    const uint64_t *wtab[JH_CHAIN_MAX_STREAMS];    // R: per block row, the row's coefficient pointer | bit 0: the row's own conj flag | bit 1: a zero block
+    const uint64_t *rows;                          // the row table: nrow records of (1 + NW) words
 };
 
 // x .= a * x for a REAL scalar: part by part (Julia's a::Real * z, src/Jets.jl:1159); WIDE: the promoted product rounded once
@@ -62,15 +79,16 @@ template <typename S, int NS, typename V> __device__ inline V stage_scale(const 
     }
 }
 
-// a stage list on the DOMAIN side: the coefficient packs are loaded here (once per thread or per workgroup tile, outside the row loop)
+// a stage list on the DOMAIN side: the coefficient packs are loaded here (once per thread or per workgroup tile, outside the row loop: kept rolled)
 template <typename S, int E, int NS, typename V>
 __device__ inline V dom_prog(const ChainProg &p, const void *const *coef, V x, int64_t sk)
 {
-#pragma unroll
+#pragma unroll 1
     for (int s = 0; s < JH_CHAIN_MAX_STAGES; s++) {
         const uint32_t kind = p.st[s] & 15u;
+        if (kind == CK_NONE) break;
         if (kind == CK_SCALE || kind == CK_SCALE_WIDE) x = stage_scale<S, NS, V>(p, s, kind == CK_SCALE_WIDE, x);
-        else if (kind != CK_NONE) {
+        else {
             const V c = ldu<false, S, NS>((const S *)coef[p.st[s] >> 4] + sk);
             x = vmul<S, E, NS, V>(c, x, kind == CK_DIAG_CONJ);
         }
@@ -78,26 +96,45 @@ __device__ inline V dom_prog(const ChainProg &p, const void *const *coef, V x, i
     return x;
 }
 
-// the RANGE-side stage list of one block row, weight packs already loaded (wv[w]; we[w]: the rows' table entries)
+// one RANGE-side stage on a row's pack, weight packs already loaded (wv[w]; e[1 + w]: the row's table words)
 template <typename S, int E, int NS, int NW, typename V>
-__device__ inline V mid_prog(const ChainProg &p, V t, const V *wv, const uint64_t *we)
+__device__ inline V mid_stage(const ChainProg &p, int s, uint32_t kind, V t, const V *wv, const uint64_t *e)
 {
-#pragma unroll
-    for (int s = 0; s < JH_CHAIN_MAX_STAGES; s++) {
-        const uint32_t kind = p.st[s] & 15u;
-        if (kind == CK_SCALE || kind == CK_SCALE_WIDE) t = stage_scale<S, NS, V>(p, s, kind == CK_SCALE_WIDE, t);
-        else if (kind != CK_NONE) {
-            if constexpr (NW > 0) {
-                const bool second = NW > 1 && (p.st[s] >> 4) != 0;
-                const uint64_t e = second ? we[NW - 1] : we[0];
-                const V c = second ? wv[NW - 1] : wv[0];
-                if (e & 2u) t = (V)(S)0;                                        // a zero block on W's diagonal: the stage's zeros() stay (1022)
-                else if (e & ~(uint64_t)3) t = vmul<S, E, NS, V>(c, t, (kind == CK_DIAG_CONJ) != ((e & 1u) != 0));
-                // (a null pointer: an identity row -- d .= m, bit for bit)
-            }
+    if (kind <= CK_SCALE_WIDE) return stage_scale<S, NS, V>(p, s, kind == CK_SCALE_WIDE, t);
+    if constexpr (NW > 0) {
+        const bool second = NW > 1 && (p.st[s] >> 4) != 0;
+        const uint64_t w = second ? e[NW] : e[1];
+        const V c = second ? wv[NW - 1] : wv[0];
+        if (__builtin_expect((w & (CW_SPECIAL | CR_PTR)) > CR_PTR || (w & CR_PTR) == 0, 0)) {      // an identity row (null pointer) or a zero block: rare
+            if (cw_zero(w)) return (V)(S)0;                                     // a zero block on W's diagonal: the stage's zeros() stay (1022)
+            if ((w & CR_PTR) == 0) return t;                                     // an identity row -- d .= m, bit for bit
         }
+        if constexpr (E == 1) return c * t;                                     // (real elements: conj is the identity)
+        else return vmul<S, E, NS, V>(c, t, (kind == CK_DIAG_CONJ) != cw_conj(w));
     }
     return t;
+}
+
+// the RANGE-side stage list of one block row.  UNROLLED on purpose: rolled (`#pragma unroll 1`: a stage = a scalar load and a branch) the family is 1 MB
+// smaller and no instantiation spills an SGPR -- and it is SLOWER: Float32 A' o W o A 5.14 -> 5.35 ms (-4 %), ComplexF32 5.45 -> 8.37 ms (-35 %: the
+// packs no longer stay in registers across the loop), same box, alternating (profiles/ab_r06_chain_rolled.txt).  Nested, so that a list of k stages costs
+// k + 1 scalar compares, not four: with one wave per SIMD (rows of a few hundred KiB: one workgroup per CU) nothing hides the arithmetic phase of a batch,
+// and a taken scalar branch is ~20 cycles -- the first version spent 20+ of them per row and pack (4096 x 64^3 A' o W o A: 3.4 TB/s).
+template <typename S, int E, int NS, int NW, typename V>
+__device__ inline V mid_prog(const ChainProg &p, V t, const V *wv, const uint64_t *e)
+{
+    const uint32_t k0 = p.st[0] & 15u;
+    if (k0 == CK_NONE) return t;
+    t = mid_stage<S, E, NS, NW, V>(p, 0, k0, t, wv, e);
+    const uint32_t k1 = p.st[1] & 15u;
+    if (k1 == CK_NONE) return t;
+    t = mid_stage<S, E, NS, NW, V>(p, 1, k1, t, wv, e);
+    const uint32_t k2 = p.st[2] & 15u;
+    if (k2 == CK_NONE) return t;
+    t = mid_stage<S, E, NS, NW, V>(p, 2, k2, t, wv, e);
+    const uint32_t k3 = p.st[3] & 15u;
+    if (k3 == CK_NONE) return t;
+    return mid_stage<S, E, NS, NW, V>(p, 3, k3, t, wv, e);
 }
 
 template <typename S, int NS, typename V> __device__ inline V chain_accumulate(int accumulate, V found, V r)
@@ -109,42 +146,25 @@ template <typename S, int NS, typename V> __device__ inline V chain_accumulate(i
     return accumulate > 0 ? base + r : base - r;
 }
 
-// A row of A as the kernels hold it: 4 dwords of its 32-byte table entry (the coefficient pointer, the kind word, the adjoint flag); a SCALE
-// row's scalar is fetched where it is used.  (jh_dev_block is 8 dwords: with four rows in flight and the weights' entries beside them the
-// whole entries did not fit the SGPR file.)
-struct ChainRow {
-    const void *coeff;
-    uint32_t kw;                         // jh_dev_block's bit-field word: kind (low 16 bits, signed), real_scale (high 16)
-    int32_t adjoint;
-};
-__device__ inline ChainRow chain_row(const jh_dev_block *blocks, int64_t i)
-{
-    const uint64_t *p = reinterpret_cast<const uint64_t *>(blocks + i);
-    ChainRow r;
-    r.coeff = reinterpret_cast<const void *>(p[0]);
-    const uint64_t w = p[3];
-    r.kw = (uint32_t)w;
-    r.adjoint = (int32_t)(w >> 32);
-    return r;
-}
-__device__ inline int chain_row_kind(const ChainRow &r) { return (int)(int16_t)(r.kw & 0xffffu); }
-__device__ inline bool chain_row_reads(const ChainRow &r) { const int k = chain_row_kind(r); return k == JH_OP_DIAG || k == JH_OP_SQUARE; }
-
-// child mul! of row i on a pack (jh_blockop_common.h: apply_block_loaded, on the 4-dword row)
+// child mul! of row i on a pack (jh_blockop_common.h: apply_block_loaded, on the row's table word)
 template <typename S, int E, int NS, typename V>
-__device__ inline V chain_apply_row(const ChainRow &r, const jh_dev_block *blocks, int64_t i, V x, V c, bool transposed)
+__device__ inline V chain_apply_row(uint64_t e, const jh_dev_block *blocks, int64_t i, V x, V c, bool transposed)
 {
-    const bool cj = (r.adjoint != 0) != transposed;
-    switch (chain_row_kind(r)) {
+    const bool cj = cr_adj(e) != transposed;
+    if (__builtin_expect(cr_kind(e) == JH_OP_DIAG, 1)) {                          // (the common row first: one compare)
+        if constexpr (E == 1) return c * x;
+        else return vmul<S, E, NS, V>(c, x, cj);
+    }
+    switch (cr_kind(e)) {
     case JH_OP_IDENTITY: return x;
     case JH_OP_SQUARE: return vmul<S, E, NS, V>(c + c, x, cj);
     case JH_OP_SCALE: {
         const double sre = blocks[i].sre;
-        if (E == 1 || (r.kw >> 16) != 0) return (V)(S)sre * x;
+        if (E == 1 || cr_real(e)) return (V)(S)sre * x;
         const double sim = blocks[i].sim;
         V a;
 #pragma unroll
-        for (int e = 0; e < NS; e += 2) { a[e] = (S)sre; a[e + 1] = (S)sim; }
+        for (int q = 0; q < NS; q += 2) { a[q] = (S)sre; a[q + 1] = (S)sim; }
         return vmul<S, E, NS, V>(a, x, cj);
     }
     case JH_OP_DIAG: return vmul<S, E, NS, V>(c, x, cj);
@@ -161,7 +181,7 @@ __global__ __launch_bounds__(BLK) void k_chain_fwd(const jh_dev_block *__restric
                                                    unsigned ngroups, unsigned ctiles, int accumulate)
 {
     typedef typename vec_of<S, NS>::type V;
-    constexpr int NWA = NW > 0 ? NW : 1;
+    constexpr int NWA = NW > 0 ? NW : 1, RW = 1 + NW;
     unsigned tile, grp;
     if (ctiles) {
         const unsigned per_c = ctiles * ngroups;
@@ -181,45 +201,40 @@ __global__ __launch_bounds__(BLK) void k_chain_fwd(const jh_dev_block *__restric
     const int64_t sk = pack_start<NS>(ok ? s0 : 0, n_scalars);
     const V pm = dom_prog<S, E, NS, V>(ca.pre, ca.pre_c, ldu<false, S, NS>(m + sk), sk);
     const bool rmw = accumulate == 1 || accumulate == -1;
-    ChainRow nxt{};
-    uint64_t wnxt[NWA] = {};
-    if (i0 < i1) {
-        nxt = chain_row(blocks, i0);
+    uint64_t nxt[RW];
 #pragma unroll
-        for (int w = 0; w < NW; w++) wnxt[w] = ca.wtab[w][i0];
-    }
+    for (int w = 0; w < RW; w++) nxt[w] = i0 < i1 ? ca.rows[i0 * RW + w] : 0;
     for (int64_t i = i0; i < i1; i++) {
-        const ChainRow row = nxt;
-        uint64_t we[NWA];
+        uint64_t e[RW];
 #pragma unroll
-        for (int w = 0; w < NWA; w++) we[w] = wnxt[w];
+        for (int w = 0; w < RW; w++) e[w] = nxt[w];
         if (i + 1 < i1) {
-            nxt = chain_row(blocks, i + 1);
 #pragma unroll
-            for (int w = 0; w < NW; w++) wnxt[w] = ca.wtab[w][i + 1];
+            for (int w = 0; w < RW; w++) nxt[w] = ca.rows[(i + 1) * RW + w];
         }
         S *di = d + i * n_scalars;
-        const V c = chain_row_reads(row) ? ldu<NT, S, NS>((const S *)row.coeff + sk) : (V)(S)0;
+        const V c = cr_reads(e[0]) ? ldu<NT, S, NS>(cr_ptr<S>(e[0]) + sk) : (V)(S)0;
         V wv[NWA];
 #pragma unroll
-        for (int w = 0; w < NWA; w++) wv[w] = (NW > 0 && (we[w] & ~(uint64_t)3)) ? ldu<NT, S, NS>((const S *)(we[w] & ~(uint64_t)3) + sk) : (V)(S)0;
+        for (int w = 0; w < NWA; w++) wv[w] = (NW > 0 && (e[NW > 0 ? 1 + w : 0] & CR_PTR)) ? ldu<NT, S, NS>(cr_ptr<S>(e[NW > 0 ? 1 + w : 0]) + sk) : (V)(S)0;
         const V found = rmw ? ldu<NT, S, NS>(di + sk) : (V)(S)0;
         // a zero block of A: the stage's zeros() stay (1022), the later stages see them
-        V t = chain_row_kind(row) == JH_OP_ZERO ? (V)(S)0 : chain_apply_row<S, E, NS, V>(row, blocks, i, pm, c, false);
-        t = mid_prog<S, E, NS, NW, V>(ca.mid, t, wv, we);
+        V t = cr_kind(e[0]) == JH_OP_ZERO ? (V)(S)0 : chain_apply_row<S, E, NS, V>(e[0], blocks, i, pm, c, false);
+        t = mid_prog<S, E, NS, NW, V>(ca.mid, t, wv, e);
         if (ok) st_pack<true, S, NS>(di, s0, sk, chain_accumulate<S, NS, V>(accumulate, found, t));
     }
 }
 
 // ------------------------------------------------------------------ ADJOINT / NORMAL -----------------------------------------------------
 // MODE 0:  out = Q( sum_i conj(a_i) .* R(d_i) )          MODE 1:  out = Q( sum_i conj(a_i) .* R(a_i .* P(in)) )
-// The ordered walk of k_tall_diag_adj (jh_tall.hip): a thread owns U packs of the domain and walks all rows in order, DEPTH rows' loads in flight.
+// The ordered walk of k_tall_diag_adj (jh_tall.hip): a thread owns U packs of the domain and walks all rows in order, DEPTH rows' loads in flight, the
+// next DEPTH rows' table records already requested.
 template <typename S, int E, int NS, int U, int DEPTH, bool NT, int MODE, int BLK, int NW>
 __global__ __launch_bounds__(BLK) void k_chain_adj(const jh_dev_block *__restrict__ blocks, int64_t nrow, const ChainArgs ca, S *__restrict__ out,
                                                    const S *__restrict__ in, int64_t n_scalars, int accumulate)
 {
     typedef typename vec_of<S, NS>::type V;
-    constexpr int NWA = NW > 0 ? NW : 1;
+    constexpr int NWA = NW > 0 ? NW : 1, RW = 1 + NW;
     const int64_t s0 = ((int64_t)blockIdx.x * U * BLK + threadIdx.x) * NS;
     bool ok[U];
     int64_t sk[U];
@@ -231,43 +246,61 @@ __global__ __launch_bounds__(BLK) void k_chain_adj(const jh_dev_block *__restric
         acc[k] = (V)(S)0;                                                               // m .= 0 (1042)
         if (MODE == 1) mv[k] = dom_prog<S, E, NS, V>(ca.pre, ca.pre_c, ldu<false, S, NS>(in + sk[k]), sk[k]);
     }
-    auto batch = [&](int64_t i, auto depth_tag) {
+    // one batch of D rows whose table records are in `e`: all loads, then the arithmetic, rows in order
+    auto batch = [&](int64_t i, const uint64_t (*e)[RW], auto depth_tag) {
         constexpr int D = decltype(depth_tag)::value;
-        ChainRow row[D];
-        uint64_t we[D][NWA];
-#pragma unroll
-        for (int j = 0; j < D; j++) {
-            row[j] = chain_row(blocks, i + j);
-#pragma unroll
-            for (int w = 0; w < NWA; w++) we[j][w] = NW > 0 ? ca.wtab[w][i + j] : 0;
-        }
         V av[D][U], dv[D][U], wv[D][U][NWA];
 #pragma unroll
         for (int j = 0; j < D; j++) {
-            const bool on = chain_row_kind(row[j]) != JH_OP_ZERO, rc = chain_row_reads(row[j]);
+            const bool on = cr_kind(e[j][0]) != JH_OP_ZERO, rc = cr_reads(e[j][0]);
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                av[j][k] = rc ? ldu<NT, S, NS>((const S *)row[j].coeff + sk[k]) : (V)(S)0;
+                av[j][k] = rc ? ldu<NT, S, NS>(cr_ptr<S>(e[j][0]) + sk[k]) : (V)(S)0;
                 dv[j][k] = (MODE == 0 && on) ? ldu<NT, S, NS>(in + (i + j) * n_scalars + sk[k]) : (V)(S)0;
 #pragma unroll
-                for (int w = 0; w < NWA; w++)
-                    wv[j][k][w] = (NW > 0 && on && (we[j][w] & ~(uint64_t)3)) ? ldu<NT, S, NS>((const S *)(we[j][w] & ~(uint64_t)3) + sk[k]) : (V)(S)0;
+                for (int w = 0; w < NWA; w++) {
+                    const uint64_t we = e[j][NW > 0 ? 1 + w : 0];
+                    wv[j][k][w] = (NW > 0 && on && (we & CR_PTR)) ? ldu<NT, S, NS>(cr_ptr<S>(we) + sk[k]) : (V)(S)0;
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < D; j++)
-            if (chain_row_kind(row[j]) != JH_OP_ZERO) {                                 // a zero block is skipped (1047)
+            if (cr_kind(e[j][0]) != JH_OP_ZERO) {                                       // a zero block is skipped (1047)
 #pragma unroll
                 for (int k = 0; k < U; k++) {
-                    V t = (MODE == 0) ? dv[j][k] : chain_apply_row<S, E, NS, V>(row[j], blocks, i + j, mv[k], av[j][k], false);
-                    t = mid_prog<S, E, NS, NW, V>(ca.mid, t, wv[j][k], we[j]);
-                    acc[k] = acc[k] + chain_apply_row<S, E, NS, V>(row[j], blocks, i + j, t, av[j][k], true);   // _m .+= mul!(mtmp, op', _d) (1049)
+                    V t = (MODE == 0) ? dv[j][k] : chain_apply_row<S, E, NS, V>(e[j][0], blocks, i + j, mv[k], av[j][k], false);
+                    t = mid_prog<S, E, NS, NW, V>(ca.mid, t, wv[j][k], e[j]);
+                    acc[k] = acc[k] + chain_apply_row<S, E, NS, V>(e[j][0], blocks, i + j, t, av[j][k], true);   // _m .+= mul!(mtmp, op', _d) (1049)
                 }
             }
     };
     int64_t i = 0;
-    for (; i + DEPTH <= nrow; i += DEPTH) batch(i, std::integral_constant<int, DEPTH>{});
-    for (; i < nrow; i++) batch(i, std::integral_constant<int, 1>{});
+    uint64_t nxt[DEPTH][RW];
+    if (DEPTH <= nrow) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int w = 0; w < RW; w++) nxt[j][w] = ca.rows[(int64_t)j * RW + w];
+    }
+    for (; i + DEPTH <= nrow; i += DEPTH) {
+        uint64_t e[DEPTH][RW];
+        const int64_t ahead = (i + 2 * DEPTH <= nrow) ? i + DEPTH : i;                  // (the last full batch re-reads its own records)
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+            for (int w = 0; w < RW; w++) {
+                e[j][w] = nxt[j][w];
+                nxt[j][w] = ca.rows[(ahead + j) * RW + w];
+            }
+        batch(i, e, std::integral_constant<int, DEPTH>{});
+    }
+    for (; i < nrow; i++) {
+        uint64_t e[1][RW];
+#pragma unroll
+        for (int w = 0; w < RW; w++) e[0][w] = ca.rows[i * RW + w];
+        batch(i, e, std::integral_constant<int, 1>{});
+    }
     const bool rmw = accumulate == 1 || accumulate == -1;
 #pragma unroll
     for (int k = 0; k < U; k++) {
@@ -286,7 +319,9 @@ struct jh_chain {
     int type = 0;
     ChainArgs args{};
     int nw = 0;                              // range-side coefficient streams
-    uint64_t *dev_tab = nullptr;             // nw * nrow table entries
+    uint64_t *dev_tab = nullptr;             // the row table: nrow records of (1 + nw) words
+    std::vector<uint64_t> host_tab;          // its host copy (word 0 of every record is rebuilt when the operator is pointed again: jh_blockop_point moves
+    int64_t op_gen = -1;                     //  the SQUARE rows' arrays) and the operator's table generation it was built for
     bool coeff16 = true;                     // every coefficient array of the stages on the 16-byte grid
     double stream_bytes = 0;                 // N n s (1 + nw): what one pass streams besides the vectors
 };
@@ -333,11 +368,15 @@ int launch_chain_adj(const jh_chain *ch, void *out, const void *in, int64_t n_sc
     const bool off_grid = row_bytes % 16 != 0 || !op->coeff_aligned16 || !ch->coeff16 || ((((uintptr_t)out) | ((uintptr_t)in)) & 15u) != 0;
     const double streamed = ch->stream_bytes + (MODE == 0 ? (double)op->nrow * (double)row_bytes : 0.0);
     const bool nt = jh_stream_nt(streamed) && !(c.ua_nt == 0 || (c.ua_nt < 0 && off_grid && row_bytes >= ((int64_t)32 << 20)));
-    // shapes (lanes x packs per lane x rows in flight): thin workgroups for rows of a few KiB, 512 x 2 x 2 in between, fat ones once a row holds >= 4 M packs
-    // (the all-diagonal adjoint's rule, jh_tall.hip: pick_adj_shape); the streams in flight per row are 1 + NW (+ 1 for the ADJOINT's input)
-    int shape = packs < 2048 ? 0 : (packs >= ((int64_t)1 << 22) ? 2 : 1);
+    // shapes (lanes x packs per lane x rows in flight): thin workgroups (256 x 1 x 4) for rows of a few KiB, 512 x 2 x 2 in between, fat ones (512 x 4 x 2) once
+    // a row holds >= 256 K packs (4 MiB of Float32: the all-diagonal adjoint's rule, jh_tall.hip: pick_adj_shape); the streams in flight per row are
+    // 1 + NW (+ 1 for the ADJOINT's input)
+    // (same box, A' o W o A: 1024 x 128^3 thin 6.10 / 512 x 2 x 2 5.65 / fat 6.37 TB/s; 256 x 256^3 within 1 % of each other; profiles/ab_r06_chain_shapes.txt)
+    static const int64_t per_wg_of[3] = {256, 1024, 2048};
+    int shape = packs < 2048 ? 0 : (packs >= ((int64_t)1 << 18) ? 2 : 1);
+    while (shape > 0 && (packs + per_wg_of[shape] - 1) / per_wg_of[shape] < c.cu_count) shape--;   // a workgroup per CU at least, if the rows are long enough for it
     if (c.adj_wg == 256) shape = 0; else if (c.adj_wg == 512 && c.adj_unroll == 4) shape = 2; else if (c.adj_wg == 512) shape = 1;
-    const int64_t per_wg = shape == 0 ? 256 : (shape == 1 ? 1024 : 2048);
+    const int64_t per_wg = per_wg_of[shape];
     const int64_t gx = (packs + per_wg - 1) / per_wg;
     // many rows of small blocks want the split-row walk (jh_tall.hip: pick_adj_parts): not built for chains -- the caller takes the stage-by-stage chain
     if (jhb::pick_adj_parts(gx, op->nrow) > 1)
@@ -354,7 +393,15 @@ int launch_chain_adj(const jh_chain *ch, void *out, const void *in, int64_t n_sc
     default: JH_CHAIN_ADJ(BLKV, UV, DV, NTV, 2); break;                                                                                    \
     }
 #define JH_CHAIN_ADJ_SHAPE(NTV)                                                                                                              \
-    if (shape == 0) { JH_CHAIN_ADJ_NW(256, 1, 4, NTV) }                                                                                    \
+    if (shape == 0) {                                                                                                                      \
+        /* rows of a few hundred KiB at most: one workgroup per CU or fewer, the walk is paced by round trips -- eight rows in flight where the row \
+           records still fit the SGPR file (4096 x 64^3 A' o W o A: see profiles/bench_chains_r06_sizes.txt) */                                   \
+        switch (ch->nw) {                                                                                                                  \
+        case 0: JH_CHAIN_ADJ(256, 1, 8, NTV, 0); break;                                                                                    \
+        case 1: JH_CHAIN_ADJ(256, 1, 8, NTV, 1); break;                                                                                    \
+        default: JH_CHAIN_ADJ(256, 1, 4, NTV, 2); break;                                                                                   \
+        }                                                                                                                                  \
+    }                                                                                                                                      \
     else if (shape == 1) { JH_CHAIN_ADJ_NW(512, 2, 2, NTV) }                                                                               \
     else { JH_CHAIN_ADJ_NW(512, 4, 2, NTV) }
     if (nt) { JH_CHAIN_ADJ_SHAPE(true) } else { JH_CHAIN_ADJ_SHAPE(false) }
@@ -405,6 +452,25 @@ int build_prog(const char *side, int n, const jh_chain_stage *st, int dtype, int
     return JH_OK;
 }
 
+// word 0 of every record from the operator's blocks as they are NOW, then the table to the device (at create, and again when jh_blockop_point has
+// moved the SQUARE rows' arrays since)
+int chain_sync_rows(jh_chain *ch)
+{
+    const jh_blockop *op = ch->op;
+    const size_t rw = (size_t)(1 + ch->nw);
+    for (int64_t i = 0; i < op->nrow; i++) {
+        const jh_block_desc &b = op->blocks[(size_t)i];
+        const jh_dev_block db = jh_dev_block_of(b);
+        const uint64_t p = (uint64_t)(uintptr_t)b.coeff;
+        JH_REQUIRE((p >> 48) == 0, "fused chain: a coefficient address does not fit 48 bits");
+        ch->host_tab[(size_t)i * rw] = p | ((uint64_t)(b.kind & 7) << 48) | ((uint64_t)(b.adjoint ? 1 : 0) << 51) | ((uint64_t)(db.real_scale ? 1 : 0) << 52);
+    }
+    JH_CHECK_HIP(hipMemcpyAsync(ch->dev_tab, ch->host_tab.data(), ch->host_tab.size() * sizeof(uint64_t), hipMemcpyHostToDevice, jh_ctx().stream));
+    JH_CHECK_HIP(hipStreamSynchronize(jh_ctx().stream));
+    ch->op_gen = op->table_gen;
+    return JH_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -438,27 +504,27 @@ int jh_chain_create(const jh_blockop *op, int type, int npre, const jh_chain_sta
     for (size_t q = 0; q < s_pre.size(); q++) { ch->args.pre_c[q] = s_pre[q]->coeff[0]; note(s_pre[q]->coeff[0]); }
     for (size_t q = 0; q < s_post.size(); q++) { ch->args.post_c[q] = s_post[q]->coeff[0]; note(s_post[q]->coeff[0]); }
     ch->nw = (int)s_mid.size();
-    if (ch->nw) {
-        std::vector<uint64_t> host((size_t)ch->nw * (size_t)op->nrow);
-        for (int w = 0; w < ch->nw; w++)
-            for (int64_t i = 0; i < op->nrow; i++) {
-                const void *p = s_mid[(size_t)w]->coeff[i];
-                const unsigned fl = s_mid[(size_t)w]->row_flags ? (s_mid[(size_t)w]->row_flags[i] & 3u) : 0u;
-                note(p);
-                host[(size_t)w * (size_t)op->nrow + (size_t)i] = (uint64_t)(uintptr_t)p | fl;
-            }
-        if (!scalar_aligned) { delete ch; return jh_fail(JH_ERR_UNSUPPORTED, "jh_chain_create: a coefficient array is not aligned like its scalar"); }
-        hipError_t e = jh_device_malloc(jh_ctx().device, (void **)&ch->dev_tab, host.size() * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMemcpyAsync(ch->dev_tab, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice, jh_ctx().stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(jh_ctx().stream);
-        if (e != hipSuccess) {
-            if (ch->dev_tab) (void)hipFree(ch->dev_tab);
-            delete ch;
-            return jh_fail(e == hipErrorOutOfMemory ? JH_ERR_NOMEM : JH_ERR_HIP, "jh_chain_create: %s", hipGetErrorString(e));
+    const size_t rw = (size_t)(1 + ch->nw);
+    ch->host_tab.assign(rw * (size_t)op->nrow, 0);
+    for (int w = 0; w < ch->nw; w++)
+        for (int64_t i = 0; i < op->nrow; i++) {
+            const void *p = s_mid[(size_t)w]->coeff[i];
+            const uint64_t fl = s_mid[(size_t)w]->row_flags ? (s_mid[(size_t)w]->row_flags[i] & 3u) : 0u;
+            note(p);
+            if (((uint64_t)(uintptr_t)p) >> 48) scalar_aligned = false;           // (a device address above 2^48 does not exist on this platform)
+            ch->host_tab[(size_t)i * rw + 1 + (size_t)w] = (uint64_t)(uintptr_t)p | (fl << 48);
         }
-        for (int w = 0; w < ch->nw; w++) ch->args.wtab[w] = ch->dev_tab + (size_t)w * (size_t)op->nrow;
+    if (!scalar_aligned) { delete ch; return jh_fail(JH_ERR_UNSUPPORTED, "jh_chain_create: a coefficient array is not aligned like its scalar"); }
+    hipError_t e = jh_device_malloc(jh_ctx().device, (void **)&ch->dev_tab, ch->host_tab.size() * sizeof(uint64_t));
+    if (e != hipSuccess) {
+        delete ch;
+        return jh_fail(e == hipErrorOutOfMemory ? JH_ERR_NOMEM : JH_ERR_HIP, "jh_chain_create: %s", hipGetErrorString(e));
     }
-    if (!scalar_aligned) { if (ch->dev_tab) (void)hipFree(ch->dev_tab); delete ch; return jh_fail(JH_ERR_UNSUPPORTED, "jh_chain_create: a coefficient array is not aligned like its scalar"); }
+    ch->args.rows = ch->dev_tab;
+    {
+        const int st2 = chain_sync_rows(ch);
+        if (st2 != JH_OK) { (void)hipFree(ch->dev_tab); delete ch; return st2; }
+    }
     ch->stream_bytes = (double)op->nrow * (double)op->row_len[0] * (double)es * (double)(1 + ch->nw);
     jh_handle_born(ch->ctx);
     *out = ch;
@@ -493,6 +559,7 @@ int jh_chain_apply(const jh_chain *ch, jh_bvec *out, const jh_bvec *x, int accum
     const void *dom = ch->type == JH_CHAIN_FORWARD ? x->data : out->data;
     if (!jhb::tall_unaligned_ok(op, rng, dom) || (ch->type == JH_CHAIN_NORMAL && !jhb::tall_unaligned_ok(op, nullptr, x->data)))
         return jh_fail(JH_ERR_UNSUPPORTED, "jh_chain_apply: a vector or coefficient array is not aligned like its scalar");
+    if (ch->op_gen != op->table_gen) JH_TRY(chain_sync_rows(const_cast<jh_chain *>(ch)));   // (the operator was pointed again: its SQUARE rows' arrays moved)
     const int64_t n = op->row_len[0];
 #define JH_CHAIN_CALL(S, E, NS)                                                                                                             \
     (ch->type == JH_CHAIN_FORWARD ? launch_chain_fwd<S, E, NS>(ch, out->data, x->data, n * E, accumulate)                                   \

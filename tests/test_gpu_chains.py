@@ -389,3 +389,31 @@ def test_an_elementwise_nonlinear_childs_expression_is_spliced_into_the_chain(Je
     finally:
         chains.ENABLED[0] = True
     assert_bits_equal(y1.to_numpy(), y0.to_numpy(), "E o A o E")
+
+
+def test_a_chain_through_the_jacobian_of_a_nonlinear_operator_follows_point(Jets, oracle):
+    """J(m0)' o W o J(m0) for a tall nonlinear operator of SQUARE children (test/runtests.jl:19-24): jh_blockop_point moves the rows' coefficient arrays, and the
+    chain's row table (built from the operator's blocks when the chain was created) must follow -- fused == stage by stage at the first point and again
+    after the operator has been pointed somewhere else."""
+    from jets_jl_amd import chains
+
+    J = Jets
+    dt, n, nrow = np.float64, 1027, 5
+    spc = J.JetSpace(dt, n)
+    F = J.blockop([[J.JopSquare(spc)] if i % 2 == 0 else [J.JopDiagonal(J.rand(spc, seed=40 + i, stream=0))] for i in range(nrow)])
+    w = J.rand(J.range(F), seed=50, stream=0)
+    W = J.JopDiagonal(w)
+    x = J.rand(spc, seed=51, stream=0)
+    for seed in (60, 61, 62):
+        mo = J.rand(spc, seed=seed, stream=0)
+        Jm = J.jacobian_(F, mo)
+        N = J.compose(J.compose(Jm.H, W), Jm)
+        before = chains.STATS["chain_calls"]
+        y1 = J.mul_(J.zeros(spc), N, x)
+        assert chains.STATS["chain_calls"] == before + 1
+        chains.ENABLED[0] = False
+        try:
+            y0 = J.mul_(J.zeros(spc), N, x)
+        finally:
+            chains.ENABLED[0] = True
+        assert_bits_equal(y1.to_numpy(), y0.to_numpy(), f"J' W J at point {seed}")

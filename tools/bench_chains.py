@@ -18,6 +18,9 @@ nrow = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 edge = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dt = {"f32": np.float32, "f64": np.float64, "c32": np.complex64, "c64": np.complex128}[sys.argv[3] if len(sys.argv) > 3 else "f32"]
 J.init(0)
+for kv in os.environ.get("JETS_TUNE", "").split(","):          # e.g. JETS_TUNE=adj_wg=512,adj_unroll=2 (A/B of launch shapes)
+    if "=" in kv:
+        J.tune(**{kv.split("=")[0]: int(kv.split("=")[1])})
 
 
 def timed(fn, reps):
