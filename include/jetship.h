@@ -251,6 +251,13 @@ int jh_dot(const jh_bvec *x, const jh_bvec *y, double *re, double *im);
 int jh_norm(const jh_bvec *x, double p, double *out);
 /* extrema(x), src/Jets.jl:870-878 (real dtypes) */
 int jh_extrema(const jh_bvec *x, double *mn, double *mx);
+/* The block-wise norms and inner products themselves, ALL blocks in one pass (round 6): out[i] = norm(x_i, p) / dot(x_i, y_i) for i = 0 .. nblocks - 1 --
+ * what src/Jets.jl:836-846 / 850-856 compute block by block before they combine them, and what per-shot residual norms `[norm(getblock(r, i)) for i in
+ * 1:nblocks(r)]` ask for (through jh_norm on a view: one launch and one host round trip per block -- 34 ms for 1024 blocks of 64 MiB where one pass takes
+ * 10).  Same accumulation (fp64 lanes, fixed order: deterministic) and the same p rules as jh_norm; conj on jh_dot_blocks' first argument, im may be NULL.
+ * Synchronise; out / re / im are HOST arrays of nblocks doubles. */
+int jh_norm_blocks(const jh_bvec *x, double p, double *out);
+int jh_dot_blocks(const jh_bvec *x, const jh_bvec *y, double *re, double *im);
 
 /* child mul! of a dense operator (test/runtests.jl:27-33 JopBaz): y = A x (adjoint = 0) or y = A' x (adjoint = 1)
  * for a column-major nr x nc matrix in device memory.  Forward: columns accumulated in order, product rounded

@@ -145,6 +145,8 @@ SYMBOLS = {
     "jh_dot": (_int, [_vp, _vp, _dblp, _dblp]),
     "jh_norm": (_int, [_vp, C.c_double, _dblp]),
     "jh_extrema": (_int, [_vp, _dblp, _dblp]),
+    "jh_norm_blocks": (_int, [_vp, C.c_double, _dblp]),
+    "jh_dot_blocks": (_int, [_vp, _vp, _dblp, _dblp]),
     "jh_gemv": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _int]),
     "jh_blockop_create": (_int, [_i64, _i64, C.POINTER(BlockDesc), _i64p, _i64p, _int, _vpp]),
     "jh_blockop_destroy": (_int, [_vp]),

@@ -23,7 +23,7 @@ from .spaces import JetAbstractSpace, JetSpace, JetBSpace, JetSSpace, dtype_code
 
 __all__ = [
     "DeviceArray", "BlockArray", "LinExpr", "zeros", "ones", "rand", "rand_", "randn", "Array", "from_numpy", "space", "nblocks",
-    "indices", "getblock", "getblock_", "setblock_", "norm", "dot", "extrema", "fill_", "copyto_", "lincomb_",
+    "indices", "getblock", "getblock_", "setblock_", "norm", "dot", "extrema", "fill_", "copyto_", "lincomb_", "norm_blocks", "dot_blocks",
     "hadamard_", "similar", "convert_array", "reshape", "vec", "length", "abs_", "pinned_empty", "host_register",
     "host_unregister", "download_into", "upload_from",
 ]
@@ -576,6 +576,26 @@ def dot(x: _DevVec, y: _DevVec):
     if x.dtype.kind == "c":
         return x.dtype.type(complex(re.value, im.value))
     return x.dtype.type(re.value)
+
+
+def norm_blocks(x: _DevVec, p: float = 2) -> np.ndarray:
+    """[norm(getblock(x, i), p) for i in 1:nblocks(x)] in ONE pass over the slab (jh_norm_blocks; src/Jets.jl:836-846 forms these block norms before it
+    combines them): per-shot residual norms of a block range without a launch and a host round trip per block.  Real(eltype) precision like `norm`."""
+    nb = nblocks(x)
+    out = (C.c_double * nb)()
+    check(lib.jh_norm_blocks(x.handle, float(p), out))
+    real_t = np.float32 if x.dtype in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
+    return np.array(out[:], dtype=np.float64).astype(real_t)
+
+
+def dot_blocks(x: _DevVec, y: _DevVec) -> np.ndarray:
+    """[dot(getblock(x, i), getblock(y, i)) for i in 1:nblocks(x)] in one pass (jh_dot_blocks; 850-856 adds exactly these); conjugates x."""
+    nb = nblocks(x)
+    re, im = (C.c_double * nb)(), (C.c_double * nb)()
+    check(lib.jh_dot_blocks(x.handle, y.handle, re, im))
+    if x.dtype.kind == "c":
+        return (np.array(re[:]) + 1j * np.array(im[:])).astype(x.dtype)
+    return np.array(re[:]).astype(x.dtype)
 
 
 def extrema(x: _DevVec):

@@ -496,6 +496,102 @@ __global__ void k_reduce_final(const double *__restrict__ partials, int nparts, 
     if (threadIdx.x == 0) { out[0] = s0[0]; out[1] = s1[0]; }
 }
 
+// ---- per-BLOCK reductions in one launch (round 6): norm(x_i, p) / dot(x_i, y_i) for every block i of a block vector -- what the reference computes block by
+// block anyway (src/Jets.jl:836-846, 850-856) and what per-shot residual norms ask for.  One reduction per block through the whole-vector entry points costs a
+// launch + a host round trip each (33 us per 64 MiB block = 2 TB/s: 34 ms for 1024 blocks); here workgroup (b, c) reduces chunk c of block b -- `cpb` chunks per
+// block, each a contiguous run of whole packs, the block's odd tail scalars with chunk 0 --, a second launch folds every block's chunk partials in chunk order
+// (deterministic), one copy brings the nblocks results back.  Blocks may start off the 16-byte grid (odd lengths in one slab): under-aligned packs (ldnt).
+template <typename S, int E, int NS, int OP>
+__global__ void k_reduce_blocks(const S *__restrict__ x, const S *__restrict__ y, const int64_t *__restrict__ off, int cpb, double p, double *__restrict__ partials)
+{
+    const int64_t b = blockIdx.x / (unsigned)cpb;
+    const int c = (int)(blockIdx.x - b * (unsigned)cpb);
+    const int64_t e0 = off[b], e1 = off[b + 1];
+    const S *xb = x + e0 * E, *yb = (OP == RED_DOT) ? y + e0 * E : x;
+    const int64_t n_scalars = (e1 - e0) * E, nvec = n_scalars / NS;
+    const int64_t v0 = nvec / cpb * c + (c < nvec % cpb ? c : nvec % cpb), v1 = v0 + nvec / cpb + (c < nvec % cpb ? 1 : 0);
+    double a0, a1;
+    red_init<OP>(a0, a1);
+    constexpr int UN = 4;
+    int64_t v = v0 + threadIdx.x;
+    for (; v + (UN - 1) * WG < v1; v += UN * WG) {
+        Pack<S, NS> xv[UN], yv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            xv[u] = ldnt(reinterpret_cast<const Pack<S, NS> *>(xb) + v + u * WG);
+            if (OP == RED_DOT) yv[u] = ldnt(reinterpret_cast<const Pack<S, NS> *>(yb) + v + u * WG);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+#pragma unroll
+            for (int e = 0; e < NS; e += E) red_elem<S, E, OP>(&xv[u].v[e], &yv[u].v[e], p, 1.0, a0, a1);
+    }
+    for (; v < v1; v += WG) {
+        Pack<S, NS> xv = ldnt(reinterpret_cast<const Pack<S, NS> *>(xb) + v), yv;
+        if (OP == RED_DOT) yv = ldnt(reinterpret_cast<const Pack<S, NS> *>(yb) + v);
+#pragma unroll
+        for (int e = 0; e < NS; e += E) red_elem<S, E, OP>(&xv.v[e], &yv.v[e], p, 1.0, a0, a1);
+    }
+    const int64_t tail0 = nvec * NS, ntail_elems = (n_scalars - tail0) / E;
+    if (c == 0 && (int64_t)threadIdx.x < ntail_elems)
+        red_elem<S, E, OP>(xb + tail0 + threadIdx.x * E, yb + tail0 + threadIdx.x * E, p, 1.0, a0, a1);
+    block_reduce_store<OP>(a0, a1, partials);
+}
+
+template <int OP>
+__global__ void k_reduce_blocks_final(const double *__restrict__ partials, int cpb, int64_t nblocks, double *__restrict__ out)
+{
+    const int64_t b = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (b >= nblocks) return;
+    double a0, a1;
+    red_init<OP>(a0, a1);
+    for (int c = 0; c < cpb; c++) red_combine<OP>(a0, a1, partials[2 * (b * cpb + c)], partials[2 * (b * cpb + c) + 1]);
+    out[2 * b] = a0;
+    out[2 * b + 1] = a1;
+}
+
+template <typename S, int E, int OP>
+int reduce_blocks_launch(const jh_bvec *x, const jh_bvec *y, double p, double *host_out /* 2 * nblocks */)
+{
+    jh_context &c = jh_ctx();
+    constexpr int NSV = (16 / sizeof(S)) >= E ? (16 / sizeof(S)) : E;
+    const int64_t nb = x->nblocks;
+    int64_t longest = 0;
+    for (int64_t i = 0; i < nb; i++) longest = x->len(i) > longest ? x->len(i) : longest;
+    // chunks per block: about 16 K workgroups over the whole vector (a chunk is at least 4 packs per lane), 64 at most
+    int64_t cpb = (16384 + nb - 1) / nb;
+    const int64_t by_size = (longest * E / NSV + (int64_t)WG * 4 - 1) / ((int64_t)WG * 4);
+    if (cpb > by_size) cpb = by_size;
+    if (cpb > 64) cpb = 64;
+    if (cpb < 1) cpb = 1;
+    JH_REQUIRE(nb * cpb < ((int64_t)1 << 31), "per-block reduction: %lld blocks are too many for one launch", (long long)nb);
+    JH_TRY(jh_ensure_partials(2 * nb * cpb + 2 * nb));
+    void *offs = nullptr;
+    JH_TRY(jh_ensure_scratch((size_t)(nb + 1) * sizeof(int64_t), &offs));
+    JH_CHECK_HIP(hipMemcpyAsync(offs, x->off.data(), (size_t)(nb + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c.stream));
+    double *partials = c.part_dev, *results = c.part_dev + 2 * nb * cpb;
+    hipLaunchKernelGGL((k_reduce_blocks<S, E, NSV, OP>), dim3((unsigned)(nb * cpb)), dim3(WG), 0, c.stream, (const S *)x->data,
+                       (const S *)(y ? y->data : x->data), (const int64_t *)offs, (int)cpb, p, partials);
+    JH_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL((k_reduce_blocks_final<OP>), dim3((unsigned)((nb + WG - 1) / WG)), dim3(WG), 0, c.stream, partials, (int)cpb, nb, results);
+    JH_CHECK_HIP(hipGetLastError());
+    JH_CHECK_HIP(hipMemcpyAsync(host_out, results, (size_t)(2 * nb) * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+    return JH_OK;
+}
+
+template <int OP>
+int reduce_blocks_dispatch(const jh_bvec *x, const jh_bvec *y, double p, double *host_out)
+{
+    switch (x->dtype) {
+    case JH_F32: return reduce_blocks_launch<float, 1, OP>(x, y, p, host_out);
+    case JH_F64: return reduce_blocks_launch<double, 1, OP>(x, y, p, host_out);
+    case JH_C32: return reduce_blocks_launch<float, 2, OP>(x, y, p, host_out);
+    case JH_C64: return reduce_blocks_launch<double, 2, OP>(x, y, p, host_out);
+    }
+    return jh_fail(JH_ERR_INVALID, "unknown dtype %d", x->dtype);
+}
+
 template <typename S, int E, int OP>
 int reduce_launch(const void *x, const void *y, int64_t n_elems, double p, double *r0, double *r1, double scale)
 {
@@ -845,6 +941,62 @@ int jh_norm(const jh_bvec *x, double p, double *out)
                 *out = (two ? sqrt(r0) : pow(r0, 1.0 / p)) * up;
             }
         }
+    }
+    return JH_OK;
+}
+
+// norm(x_i, p) of EVERY block in one pass (src/Jets.jl:836-846 computes them block by block before combining): out[i], i = 0 .. nblocks - 1
+int jh_norm_blocks(const jh_bvec *x, double p, double *out)
+{
+    JH_TRY(jh_enter(x));
+    JH_REQUIRE(x && out, "jh_norm_blocks: null argument");
+    JH_REQUIRE(!std::isnan(p), "jh_norm_blocks: p is NaN");
+    const int64_t nb = x->nblocks;
+    if (nb == 0) return JH_OK;
+    if (x->length == 0) { for (int64_t i = 0; i < nb; i++) out[i] = 0.0; return JH_OK; }
+    JH_REQUIRE((((uintptr_t)x->data) & ((jh_dtype_complex(x->dtype) ? jh_dtype_size(x->dtype) / 2 : jh_dtype_size(x->dtype)) - 1)) == 0,
+               "jh_norm_blocks: the vector is not aligned like its scalar");
+    std::vector<double> r((size_t)(2 * nb));
+    const bool two = (p == 2.0);
+    if (p == INFINITY) JH_TRY((reduce_blocks_dispatch<RED_MAXABS>(x, nullptr, p, r.data())));
+    else if (p == -INFINITY) JH_TRY((reduce_blocks_dispatch<RED_MINABS>(x, nullptr, p, r.data())));
+    else if (p == 1.0) JH_TRY((reduce_blocks_dispatch<RED_SUMABS>(x, nullptr, p, r.data())));
+    else if (p == 0.0) JH_TRY((reduce_blocks_dispatch<RED_COUNTNZ>(x, nullptr, p, r.data())));
+    else if (two) JH_TRY((reduce_blocks_dispatch<RED_SUMSQ>(x, nullptr, p, r.data())));
+    else JH_TRY((reduce_blocks_dispatch<RED_SUMPOW>(x, nullptr, p, r.data())));
+    for (int64_t i = 0; i < nb; i++) {
+        const double r0 = r[(size_t)(2 * i)], r1 = r[(size_t)(2 * i + 1)];
+        if (x->len(i) == 0) { out[i] = 0.0; continue; }                       // (norm of an empty block: 0, also for p = -Inf where the fold starts at Inf)
+        if (p == INFINITY || p == -INFINITY || p == 1.0 || p == 0.0) { out[i] = r0; continue; }
+        out[i] = two ? sqrt(r0) : pow(r0, 1.0 / p);
+        // (a block whose powers left the double range: the whole-vector entry point's rescaled second pass, on that block alone -- jh_norm)
+        if (p > 0 && (std::isinf(r0) || r0 < 1e-290) && !(two && r0 == 0.0 && r1 == 0.0)) {
+            jh_bvec v;
+            v.ctx = x->ctx; v.dtype = x->dtype; v.nblocks = 1; v.length = x->len(i); v.off = {0, x->len(i)}; v.data = x->ptr(x->off[(size_t)i]); v.uniform = true;
+            JH_TRY(jh_norm(&v, p, &out[i]));
+        }
+    }
+    return JH_OK;
+}
+
+// dot(x_i, y_i) of every block pair in one pass (850-856: `a += dot(x_i, y_i)` block by block); conj on the first argument; im may be NULL
+int jh_dot_blocks(const jh_bvec *x, const jh_bvec *y, double *re, double *im)
+{
+    JH_TRY(jh_enter(x, y));
+    JH_REQUIRE(x && y && re, "jh_dot_blocks: null argument");
+    JH_REQUIRE(x->dtype == y->dtype, "jh_dot_blocks: dtype mismatch (%d vs %d)", x->dtype, y->dtype);
+    JH_REQUIRE(x->nblocks == y->nblocks && x->off == y->off, "jh_dot_blocks: the vectors' blocks differ");
+    const int64_t nb = x->nblocks;
+    if (nb == 0) return JH_OK;
+    std::vector<double> r((size_t)(2 * nb), 0.0);
+    if (x->length > 0) {
+        const size_t sa = jh_dtype_complex(x->dtype) ? jh_dtype_size(x->dtype) / 2 : jh_dtype_size(x->dtype);
+        JH_REQUIRE(((((uintptr_t)x->data) | ((uintptr_t)y->data)) & (sa - 1)) == 0, "jh_dot_blocks: a vector is not aligned like its scalar");
+        JH_TRY((reduce_blocks_dispatch<RED_DOT>(x, y, 0.0, r.data())));
+    }
+    for (int64_t i = 0; i < nb; i++) {
+        re[i] = r[(size_t)(2 * i)];
+        if (im) im[i] = r[(size_t)(2 * i + 1)];
     }
     return JH_OK;
 }

@@ -27,7 +27,7 @@ import Jets: JetAbstractSpace, JetBSpace, JetSpace, BlockArray, BlockArrayStyle,
              domain, getblock, getblock!, setblock!, indices, nblocks, space, point!, JopZeroBlock_df!, JetBlock_f!,
              JetBlock_df!, JetBlock_df′!, JetComposite_f!, JetComposite_df!, JetComposite_df′!, JetSum_df!, JetSum_df′!, _constdiag_df!, _constdiag_df′!, JetBlock
 
-export HipSpace, HipArray, JopHipDiagonal, JopHipSquare, JopHipDense, hip_lsqr!
+export HipSpace, HipArray, JopHipDiagonal, JopHipSquare, JopHipDense, hip_lsqr!, blocknorms, blockdots
 
 const LIB = get(ENV, "JETSHIP_LIB", "libjetship.so")
 
@@ -304,6 +304,23 @@ LinearAlgebra.dot(x::HipArray{T}, y::HipArray{T}) where {T} = _dot(handle(x), ha
 function LinearAlgebra.dot(x::BlockArray{T,<:HipArray{T}}, y::BlockArray{T,<:HipArray{T}}) where {T}
     hx, hy = handle(x), handle(y)
     (hx == C_NULL || hy == C_NULL) ? invoke(dot, Tuple{BlockArray{T},BlockArray{T}}, x, y) : _dot(hx, hy, T)
+end
+
+# the block-wise norms / inner products themselves, ALL blocks in one pass over the slab (round 6): what src/Jets.jl:836-846 / 850-856 compute block by
+# block before they combine them -- `blocknorms(r)` instead of `[norm(getblock(r, i)) for i in 1:nblocks(r)]` (a launch and a host round trip per block)
+function blocknorms(x::BlockArray{T,<:HipArray{T}}, p::Real=2) where {T}
+    h = handle(x)
+    h == C_NULL && return [norm(x.arrays[i], p) for i = 1:length(x.arrays)]
+    out = Vector{Cdouble}(undef, length(x.arrays))
+    check(ccall((:jh_norm_blocks, LIB), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}), h, p, out))
+    float(real(T))[v for v in out]
+end
+function blockdots(x::BlockArray{T,<:HipArray{T}}, y::BlockArray{T,<:HipArray{T}}) where {T}
+    hx, hy = handle(x), handle(y)
+    (hx == C_NULL || hy == C_NULL) && return [dot(x.arrays[i], y.arrays[i]) for i = 1:length(x.arrays)]
+    re, im = Vector{Cdouble}(undef, length(x.arrays)), Vector{Cdouble}(undef, length(x.arrays))
+    check(ccall((:jh_dot_blocks, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), hx, hy, re, im))
+    T <: Complex ? T[T(re[i], im[i]) for i = 1:length(re)] : T[T(re[i]) for i = 1:length(re)]
 end
 function _extrema(h::Ptr{Cvoid}, ::Type{T}) where {T}
     mn, mx = Ref{Cdouble}(), Ref{Cdouble}()

@@ -334,3 +334,50 @@ def test_norm_of_huge_and_tiny_values_neither_overflows_nor_vanishes(Jets, oracl
         t3 = float(v) * float(np.sum(np.abs((h / v).astype(np.complex128)) ** 3) ** (1 / 3))
         assert float(Jets.norm(x, 3)) == pytest.approx(t3, rel=1e-6 if rt == np.float32 else 1e-13)
     assert float(Jets.norm(Jets.zeros(Jets.JetSpace(dt, 100)))) == 0.0
+
+
+# ---------------------------------------------------------------------------------- round 6: per-block reductions in one pass
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("lens", [[1000] * 7, [4099, 5, 1 << 16, 33, 1027], [3], [257] * 300, [1 << 20, 1 << 20 | 1, 7]])
+def test_norm_blocks_and_dot_blocks_equal_the_block_by_block_reductions(Jets, oracle, dt, lens):
+    """jh_norm_blocks / jh_dot_blocks (round 6): norm(x_i, p) and dot(x_i, y_i) of EVERY block in one pass over the slab -- the quantities src/Jets.jl:836-846 and
+    850-856 form block by block.  Against the fp64 truth per block (stated tolerance of the reductions: 1e-5 for 32-bit, 1e-12 for 64-bit elements -- fp64
+    lanes, fixed order), against the oracle's own block norms where its Float32 accumulation is accurate enough to compare (blocks of <= 4100 elements; it
+    sums a Float32 block in Float32 like the reference's generic norm: 2e-4 off at 2^20 elements), and against the library's whole-vector entry points on views."""
+    J = Jets
+    R = J.JetBSpace([J.JetSpace(dt, n) for n in lens])
+    x, y = J.rand(R, seed=31, stream=1), J.rand(R, seed=32, stream=2)
+    hx, hy = x.to_numpy(), y.to_numpy()
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    tol = 1e-5 if np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-12
+    wide = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    for p in (2, 1, 0, np.inf, -np.inf, 3, 2.5):
+        got = J.norm_blocks(x, p)
+        assert got.shape == (len(lens),)
+        for i in range(len(lens)):
+            ab = np.abs(hx[offs[i]:offs[i + 1]].astype(wide))
+            want = float(ab.max() if p == np.inf else ab.min() if p == -np.inf else np.count_nonzero(ab) if p == 0 else ab.sum() if p == 1 else (ab ** p).sum() ** (1.0 / p))
+            assert abs(float(got[i]) - want) <= tol * max(abs(want), 1e-30), f"p={p} block {i}: {got[i]} vs {want}"
+            if lens[i] <= 4100 and p in (2, 1, 0, np.inf, -np.inf):               # the oracle's block norm (jo.barr_norm: the reference's formula on one block)
+                ora = oracle.barr_norm([hx[offs[i]:offs[i + 1]].copy()], p)
+                assert abs(float(got[i]) - ora) <= 1e-4 * max(abs(ora), 1e-30), f"p={p} block {i} vs the oracle"
+            if len(lens) <= 8:                                                   # the whole-vector entry point on the block's view (another grouping of the same fp64 sums)
+                ref = float(J.norm(J.getblock(x, i), p))
+                assert abs(float(got[i]) - ref) <= tol * max(abs(ref), 1e-30), f"p={p} block {i} vs jh_norm on the view"
+    gd = J.dot_blocks(x, y)
+    for i in range(len(lens)):
+        want = np.vdot(hx[offs[i]:offs[i + 1]].astype(np.complex128), hy[offs[i]:offs[i + 1]].astype(np.complex128))
+        assert abs(complex(gd[i]) - complex(want)) <= tol * max(abs(complex(want)), 1e-30), f"dot block {i}"
+    # the blocks' norms combine to the vector's (836-846): p = 2
+    assert abs(float(np.sqrt(np.sum(J.norm_blocks(x, 2).astype(np.float64) ** 2))) - float(J.norm(x, 2))) <= 1e-5 * float(J.norm(x, 2))
+
+
+def test_norm_blocks_rescales_a_block_whose_squares_leave_the_double_range(Jets):
+    J = Jets
+    R = J.JetBSpace([J.JetSpace(np.float64, 100)] * 3)
+    h = np.ones(300)
+    h[100:200] = 1e200
+    h[200:] = 1e-200
+    x = J.from_numpy(h, R)
+    got = J.norm_blocks(x, 2)
+    assert np.allclose(got, [10.0, 1e201, 1e-199], rtol=1e-12)
