@@ -36,6 +36,8 @@ enum { CK_NONE = 0, CK_SCALE = 1, CK_SCALE_WIDE = 2, CK_DIAG = 3, CK_DIAG_CONJ =
 struct ChainProg {
     uint32_t st[JH_CHAIN_MAX_STAGES];
     float a32[JH_CHAIN_MAX_STAGES];      // SCALE on 32-bit elements: T(a)
+    uint32_t pad_[JH_CHAIN_MAX_STAGES];  // (keeps a32[3] and a[0] apart: adjacent, the vectoriser fused their loads into one <4 x float> that it then staged
+                                         //  through a 20-byte stack copy of the argument -- a scratch frame nobody reads, but a scratch frame)
     double a[JH_CHAIN_MAX_STAGES];       // SCALE on 64-bit elements; WIDE: Julia's Float64 scalar against 32-bit elements
 };
 
@@ -79,19 +81,23 @@ template <typename S, int NS, typename V> __device__ inline V stage_scale(const 
     }
 }
 
-// a stage list on the DOMAIN side: the coefficient packs are loaded here (once per thread or per workgroup tile, outside the row loop: kept rolled)
+// a stage list on the DOMAIN side: the coefficient packs are loaded here (once per thread or per workgroup tile, outside the row loop).  Unrolled with
+// constant stage indices: indexed by a loop variable, the by-value argument struct was copied to scratch in some Float64 shapes (36 bytes per lane).
 template <typename S, int E, int NS, typename V>
-__device__ inline V dom_prog(const ChainProg &p, const void *const *coef, V x, int64_t sk)
+__device__ inline V dom_stage(const ChainProg &p, int s, uint32_t kind, const void *c0, const void *c1, V x, int64_t sk)
 {
-#pragma unroll 1
+    if (kind <= CK_SCALE_WIDE) return stage_scale<S, NS, V>(p, s, kind == CK_SCALE_WIDE, x);
+    const V c = ldu<false, S, NS>((const S *)((p.st[s] >> 4) ? c1 : c0) + sk);   // (a select of two pointers, not a computed index into the argument struct)
+    return vmul<S, E, NS, V>(c, x, kind == CK_DIAG_CONJ);
+}
+// (the two coefficient pointers by value: handing the kernel argument's array on by address kept a copy of the struct on the stack)
+template <typename S, int E, int NS, typename V>
+__device__ inline V dom_prog(const ChainProg &p, const void *c0, const void *c1, V x, int64_t sk)
+{
+#pragma unroll
     for (int s = 0; s < JH_CHAIN_MAX_STAGES; s++) {
         const uint32_t kind = p.st[s] & 15u;
-        if (kind == CK_NONE) break;
-        if (kind == CK_SCALE || kind == CK_SCALE_WIDE) x = stage_scale<S, NS, V>(p, s, kind == CK_SCALE_WIDE, x);
-        else {
-            const V c = ldu<false, S, NS>((const S *)coef[p.st[s] >> 4] + sk);
-            x = vmul<S, E, NS, V>(c, x, kind == CK_DIAG_CONJ);
-        }
+        if (kind != CK_NONE) x = dom_stage<S, E, NS, V>(p, s, kind, c0, c1, x, sk);
     }
     return x;
 }
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(BLK) void k_chain_fwd(const jh_dev_block *__restric
     const int64_t i1 = (i0 + rows_per_wg < nrow) ? i0 + rows_per_wg : nrow;
     const bool ok = s0 < n_scalars;
     const int64_t sk = pack_start<NS>(ok ? s0 : 0, n_scalars);
-    const V pm = dom_prog<S, E, NS, V>(ca.pre, ca.pre_c, ldu<false, S, NS>(m + sk), sk);
+    const V pm = dom_prog<S, E, NS, V>(ca.pre, ca.pre_c[0], ca.pre_c[1], ldu<false, S, NS>(m + sk), sk);
     const bool rmw = accumulate == 1 || accumulate == -1;
     uint64_t nxt[RW];
 #pragma unroll
@@ -244,11 +250,18 @@ __global__ __launch_bounds__(BLK) void k_chain_adj(const jh_dev_block *__restric
         ok[k] = (s0 + (int64_t)k * BLK * NS) < n_scalars;
         sk[k] = pack_start<NS>(ok[k] ? s0 + (int64_t)k * BLK * NS : 0, n_scalars);
         acc[k] = (V)(S)0;                                                               // m .= 0 (1042)
-        if (MODE == 1) mv[k] = dom_prog<S, E, NS, V>(ca.pre, ca.pre_c, ldu<false, S, NS>(in + sk[k]), sk[k]);
+        if (MODE == 1) mv[k] = ldu<false, S, NS>(in + sk[k]);
+    }
+    // (behind ONE wave-uniform test of the list's first stage, and after the loads: spelled inside the loop above, the stage list left 28 instantiations
+    // with a 68-byte scratch frame that no instruction touches -- tools/kernel_resources.py)
+    if (MODE == 1 && (ca.pre.st[0] & 15u) != CK_NONE) {
+#pragma unroll
+        for (int k = 0; k < U; k++) mv[k] = dom_prog<S, E, NS, V>(ca.pre, ca.pre_c[0], ca.pre_c[1], mv[k], sk[k]);
     }
     // one batch of D rows whose table records are in `e`: all loads, then the arithmetic, rows in order
-    auto batch = [&](int64_t i, const uint64_t (*e)[RW], auto depth_tag) {
+    auto batch = [&](int64_t i, const auto &rec, auto depth_tag) {
         constexpr int D = decltype(depth_tag)::value;
+        const auto &e = rec.w;
         V av[D][U], dv[D][U], wv[D][U][NWA];
 #pragma unroll
         for (int j = 0; j < D; j++) {
@@ -276,36 +289,38 @@ __global__ __launch_bounds__(BLK) void k_chain_adj(const jh_dev_block *__restric
             }
     };
     int64_t i = 0;
-    uint64_t nxt[DEPTH][RW];
+    struct RecD { uint64_t w[DEPTH][RW]; };                                            // (records travel as values: handed to the lambda by pointer, some
+    struct Rec1 { uint64_t w[1][RW]; };                                                //  Float64 shapes kept them in 36 bytes of scratch per lane)
+    RecD nxt;
     if (DEPTH <= nrow) {
 #pragma unroll
         for (int j = 0; j < DEPTH; j++)
 #pragma unroll
-            for (int w = 0; w < RW; w++) nxt[j][w] = ca.rows[(int64_t)j * RW + w];
+            for (int w = 0; w < RW; w++) nxt.w[j][w] = ca.rows[(int64_t)j * RW + w];
     }
     for (; i + DEPTH <= nrow; i += DEPTH) {
-        uint64_t e[DEPTH][RW];
+        RecD e;
         const int64_t ahead = (i + 2 * DEPTH <= nrow) ? i + DEPTH : i;                  // (the last full batch re-reads its own records)
 #pragma unroll
         for (int j = 0; j < DEPTH; j++)
 #pragma unroll
             for (int w = 0; w < RW; w++) {
-                e[j][w] = nxt[j][w];
-                nxt[j][w] = ca.rows[(ahead + j) * RW + w];
+                e.w[j][w] = nxt.w[j][w];
+                nxt.w[j][w] = ca.rows[(ahead + j) * RW + w];
             }
         batch(i, e, std::integral_constant<int, DEPTH>{});
     }
     for (; i < nrow; i++) {
-        uint64_t e[1][RW];
+        Rec1 e;
 #pragma unroll
-        for (int w = 0; w < RW; w++) e[0][w] = ca.rows[i * RW + w];
+        for (int w = 0; w < RW; w++) e.w[0][w] = ca.rows[i * RW + w];
         batch(i, e, std::integral_constant<int, 1>{});
     }
     const bool rmw = accumulate == 1 || accumulate == -1;
 #pragma unroll
     for (int k = 0; k < U; k++) {
         const V found = rmw ? ldu<false, S, NS>(out + sk[k]) : (V)(S)0;
-        const V r = dom_prog<S, E, NS, V>(ca.post, ca.post_c, acc[k], sk[k]);
+        const V r = dom_prog<S, E, NS, V>(ca.post, ca.post_c[0], ca.post_c[1], acc[k], sk[k]);
         if (ok[k]) st_pack<false, S, NS>(out, s0 + (int64_t)k * BLK * NS, sk[k], chain_accumulate<S, NS, V>(accumulate, found, r));
     }
 }
@@ -393,15 +408,9 @@ int launch_chain_adj(const jh_chain *ch, void *out, const void *in, int64_t n_sc
     default: JH_CHAIN_ADJ(BLKV, UV, DV, NTV, 2); break;                                                                                    \
     }
 #define JH_CHAIN_ADJ_SHAPE(NTV)                                                                                                              \
-    if (shape == 0) {                                                                                                                      \
-        /* rows of a few hundred KiB at most: one workgroup per CU or fewer, the walk is paced by round trips -- eight rows in flight where the row \
-           records still fit the SGPR file (4096 x 64^3 A' o W o A: see profiles/bench_chains_r06_sizes.txt) */                                   \
-        switch (ch->nw) {                                                                                                                  \
-        case 0: JH_CHAIN_ADJ(256, 1, 8, NTV, 0); break;                                                                                    \
-        case 1: JH_CHAIN_ADJ(256, 1, 8, NTV, 1); break;                                                                                    \
-        default: JH_CHAIN_ADJ(256, 1, 4, NTV, 2); break;                                                                                   \
-        }                                                                                                                                  \
-    }                                                                                                                                      \
+    /* (rows of a few hundred KiB at most, one workgroup per CU or fewer: eight rows in flight instead of four bought nothing -- 4096 x 64^3 3.79 -> 3.73   \
+       TB/s -- and their sixteen row records pushed the SGPR spills past what fits the lanes of the spill registers) */                             \
+    if (shape == 0) { JH_CHAIN_ADJ_NW(256, 1, 4, NTV) }                                                                                    \
     else if (shape == 1) { JH_CHAIN_ADJ_NW(512, 2, 2, NTV) }                                                                               \
     else { JH_CHAIN_ADJ_NW(512, 4, 2, NTV) }
     if (nt) { JH_CHAIN_ADJ_SHAPE(true) } else { JH_CHAIN_ADJ_SHAPE(false) }

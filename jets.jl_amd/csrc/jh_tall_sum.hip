@@ -64,11 +64,16 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow
         sk[k] = ok[k] ? pack_start<NS>(s0 + (int64_t)k * BLK * NS, n_scalars) : 0;
         mv[k] = ldu<false, S, NS>(m + sk[k]);
     }
+    // The term count as a VECTOR register the compiler cannot see through (round 6): `t < args.k` on the scalar unit made it hoist sixteen wave-uniform
+    // 64-bit select masks out of the row loop -- 32 SGPRs held for the whole kernel beside sixteen base addresses and sixteen coefficients: the 16-term
+    // forward spilled 60-146 SGPRs into VGPR lanes (tools/kernel_resources.py).  A per-lane compare is one VALU instruction per select and holds nothing.
+    int kv = args.k;
     // D rows per iteration, their D x KM coefficient packs (x U) in flight (D = 1: one row).  The row loop is kept rolled: left to itself the
     // compiler unrolls the eight-stream shape to 241 VGPRs (one wave per SIMD: 1.6 TB/s).  A row beyond the group's last re-reads that
     // last row (branch-free loads) and is not stored.
 #pragma unroll 1
     for (int64_t i = i0; i < i1; i += D) {
+        asm volatile("" : "+v"(kv));                                             // (inside the loop: a loop-invariant compare is hoisted, masks and all)
         V av[D][KM][U], dv[D][U];
 #pragma unroll
         for (int j = 0; j < D; j++) {
@@ -107,10 +112,12 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_fwd(SumArgs args, int64_t nrow
 #pragma unroll
                         for (int e = 0; e < NS; e++) term[e] = (S)(args.coef[t] * (double)prod[e]);
                     } else {
-                        term = sum_coef<S>(args, t) * prod;                          // (s_t * .) then the sign: -(s*x) == (-s)*x exactly
+                        const S cf = sum_coef<S>(args, t);                           // (s_t * .) then the sign: -(s*x) == (-s)*x exactly.  Scalar by scalar: a packed
+#pragma unroll                                                                               //  multiply wants the factor as a (c, c) PAIR of SGPRs -- sixteen pairs held across the row loop
+                        for (int e = 0; e < NS; e++) term[e] = cf * prod[e];             //  were what still spilled after the masks had gone (round 6)
                     }
                     const V sum = acc + term;                                        // broadcast!(sgn, d, d, _d)
-                    acc = (t < args.k) ? sum : acc;                                  // (a term beyond k: dropped, wave-uniform)
+                    acc = (t < kv) ? sum : acc;                                      // (a term beyond k: dropped)
                 }
                 if (ok[k] && i + j < i1) st_pack<true, S, NS>(d + (i + j) * n_scalars, s0 + (int64_t)k * BLK * NS, sk[k], acc);
             }
@@ -186,13 +193,15 @@ __global__ __launch_bounds__(BLK) void k_tall_sum_adj(SumArgs args, int64_t nrow
     int64_t i = 0;
     for (; i + DEPTH <= nrow; i += DEPTH) batch(i, std::integral_constant<int, DEPTH>{});
     for (; i < nrow; i++) batch(i, std::integral_constant<int, 1>{});
+    int kv = args.k;                                                     // (a vector register: see k_tall_sum_fwd)
+    asm volatile("" : "+v"(kv));
 #pragma unroll
     for (int k = 0; k < U; k++) {
         V r = accumulate ? ldu<false, S, NS>(out + sk[k]) : (V)(S)0;   // m .= 0  (648-649), or the sum so far
 #pragma unroll
         for (int t = 0; t < KM; t++) {
             const V sum = r + sum_sign<S>(args, t) * acc[t][k];                  // broadcast!(sgn, m, m, _m)
-            r = (t < args.k) ? sum : r;
+            r = (t < kv) ? sum : r;
         }
         if (ok[k]) st_pack<false, S, NS>(out, s0 + (int64_t)k * BLK * NS, sk[k], r);
     }
