@@ -47,7 +47,7 @@ def main():
     fe = counters(base + "_fetch", ["FETCH_SIZE"])["FETCH_SIZE"]
     wr = counters(base + "_write", ["WRITE_SIZE"])["WRITE_SIZE"]
     l2 = counters(base + "_l2", ["TCC_HIT_sum", "TCC_MISS_sum"])
-    print(f"# rocprofv3 of `{a.cmd}` (round 5, one MI355X)")
+    print(f"# rocprofv3 of `{a.cmd}` (one MI355X)")
     print()
     print("Passes: `rocprofv3 --kernel-trace --stats` | `--pmc FETCH_SIZE` | `--pmc WRITE_SIZE` | `--pmc TCC_HIT_sum TCC_MISS_sum`, each its own run of the same program")
     print(f"(counter passes restricted to kernels matching `{a.regex}`). Traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch.")
