@@ -540,7 +540,8 @@ int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, 
  * aligned packs -- odd block lengths in one slab -- on the 16-byte-per-lane kernels with under-aligned packs: 1 yes, 0 the 4-byte-per-lane kernels
  * of rounds 1-4; same bits), "ua_nt" (loads of the tall kernels on such rows: -1 temporal -- a 128-byte line two neighbouring waves share is then read
  * from HBM once -- in the forward, the forward update and the step, in the adjoint from 32 MiB rows on, nontemporal on aligned rows; 0 / 1 temporal /
- * nontemporal always; same bits), "tall_f" (F(m) of a tall nonlinear operator of elementwise children -- jh_blockop_f -- on the tall tiling: 1 yes, 0 the
+ * nontemporal always; same bits), "fwd_anchor" (round 6: the tall forward of such rows on lanes anchored to each row's own 16-byte grid -- aligned stores, and
+ * aligned loads of diagonals laid out like the range vector: -1 rows of 64 KiB or more, 0 never, 1 always; same bits), "tall_f" (F(m) of a tall nonlinear operator of elementwise children -- jh_blockop_f -- on the tall tiling: 1 yes, 0 the
  * general kernels; same bits);
  * round 4: "cg_dev" (jh_cgls_solve / jh_cgnr_solve with the recurrences on the device, graph-replayed unless lsqr_graph = 0: 1 automatic -- CGLS
  * like lsqr_graph, CG through the fused A'A up to 2 GiB of coefficients --, 2 at any size, 0 never: the host loops; within solver tolerance

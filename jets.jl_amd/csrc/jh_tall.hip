@@ -128,6 +128,61 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_fwd(const jh_dev_block *__res
     }
 }
 
+// ---- the forward of rows OFF the 16-byte grid, lanes anchored on each row's OWN grid (round 6) -------------------------------------------------------
+// k_tall_diag_fwd<MIXED> cuts every row into packs by ELEMENT index: pack p = elements [p NS, p NS + NS) of the row.  With an odd block length row i
+// starts (i n s) mod 16 bytes into a pack of the slab, so three rows in four are read and written through accesses that straddle two 16-byte slots -- a
+// wave's request touches nine 128-byte lines instead of eight, the ninth being the next wave's first (256 x 255^3: forward 0.65-0.68 of the roofline,
+// traffic x1.027; a misaligned STORE stream alone costs 5 %: profiles/exp_r05_misalign.txt).  Here a lane owns an ALIGNED pack of the range slab: the
+// elements [p NS - ph, p NS - ph + NS) of row i, ph = the row's phase in its 16-byte slot.  Rows i, i + NS, i + 2 NS, ... share their phase, so a
+// workgroup takes its rows from ONE phase class (row = class + NS * k) and loads its pack of the model -- under-aligned, from L2 -- once for all of them.
+// A diagonal that lives in a slab laid out like the range vector (one allocation for all diagonals) has the same phase: its loads are aligned too; any other
+// coefficient array is read under-aligned as before.  A row's first and last slot are partial: those two lanes go element by element.  Same products, one
+// rounding each: the bits of k_tall_diag_fwd.
+template <typename S, int E, int NS, bool NT, int BLK>
+__global__ __launch_bounds__(BLK) void k_tall_fwd_anchored(const jh_dev_block *__restrict__ blocks, int64_t nrow, int rows_per_wg, const S *__restrict__ m,
+                                                           S *__restrict__ d, int64_t n_scalars, unsigned ntiles, unsigned ngroups, unsigned ctiles,
+                                                           int base_phase, int fmode)
+{
+    typedef typename vec_of<S, NS>::type V;
+    // column bands as in k_tall_diag_fwd: `ctiles` consecutive tiles of one row group, then the same tiles of the next group
+    const unsigned per_c = ctiles * ngroups;
+    const unsigned cb = blockIdx.x / per_c;
+    const unsigned r = blockIdx.x - cb * per_c;
+    const unsigned cw = (cb * ctiles + ctiles <= ntiles) ? ctiles : ntiles - cb * ctiles;
+    const unsigned grp = r / cw, tile = cb * ctiles + r % cw;
+    // group -> (phase class q, chunk of rows_per_wg rows of that class): rows q + NS * (chunk * rows_per_wg + j)
+    const unsigned q = grp % NS, chunk = grp / NS;
+    const int ph = (int)(((int64_t)base_phase + (int64_t)q * n_scalars) % NS);       // scalars of the row's first slot that belong to the row BEFORE it
+    const int64_t p = (int64_t)tile * BLK + threadIdx.x;                               // the lane's slot of the row
+    const int64_t e_lo = p * NS - ph;                                                  // first element of the slot (negative in the row's first slot)
+    const bool any = e_lo < n_scalars && e_lo + NS > 0;
+    const bool whole = e_lo >= 0 && e_lo + NS <= n_scalars;
+    const int64_t ec = e_lo < 0 ? 0 : (e_lo + NS <= n_scalars ? e_lo : n_scalars - NS);   // a pack inside the row to load from (partial slots: clamped)
+    const V mv = ldu<false, S, NS>(m + ec);
+    for (int j = 0; j < rows_per_wg; j++) {
+        const int64_t i = (int64_t)q + (int64_t)NS * ((int64_t)chunk * rows_per_wg + j);
+        if (i >= nrow) break;
+        const jh_dev_block blk = blocks[i];
+        if (blk.kind == JH_OP_ZERO && !fmode) continue;                                // (1022; f!: JopZeroBlock's d .= 0, 942)
+        const bool rc = block_reads_coeff(blk, fmode != 0);
+        S *di = d + i * n_scalars;
+        const V c = rc ? ldu<NT, S, NS>((const S *)blk.coeff + ec) : (V)(S)0;
+        if (!any) continue;
+        const V o = apply_block_loaded<S, E, NS, V>(blk, mv, c, false, fmode != 0);    // (1026 / 1003)
+        if (whole) {
+            stu<true, S, NS>(di + e_lo, o);                                            // (an aligned address by construction)
+        } else {
+            // the row's first / last slot: the pack was loaded from `ec`; store the scalars of [e_lo, e_lo + NS) that lie in the row.  Complex elements
+            // never straddle a slot boundary's ownership here: the scalars are written one by one, each from its own position of the pack
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                const int64_t e = ec + k;
+                if (e >= e_lo && e < e_lo + NS && e >= 0 && e < n_scalars) st<true>(di + e, (S)o[k]);
+            }
+        }
+    }
+}
+
 // one thread: U vectors of the domain, all rows in order.  MODE 0: adjoint (reads a_i, d_i);
 // MODE 1: fused normal equations y = sum_i conj(a_i) .* (a_i .* m) (reads a_i only).
 // TAIL (MIXED only): the instantiation also serves rows that are not whole, 16-byte aligned packs (a partial last pack).  False for the ONE shape whose
@@ -1025,6 +1080,36 @@ int launch_tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int64_t 
     JH_REQUIRE(gx * gy * BLK < (int64_t)1 << 32, "tall forward: grid of %lld workgroups is too large", (long long)(gx * gy));
     int64_t ctiles = c.fwd_ctiles >= 0 ? c.fwd_ctiles : 32;
     if (ctiles > gx) ctiles = gx;
+    // Round 6: rows that are not whole packs (an odd block length) on lanes anchored to each row's own 16-byte grid (k_tall_fwd_anchored): from rows of
+    // 64 KiB on (below, a row's two partial slots are too large a share), not for the listed walk of mostly-zero operators.  Knob fwd_anchor: -1 this rule, 0 never, 1 always.
+    if (!listed && n_scalars % NS != 0 && n_scalars >= 2 * NS && (((uintptr_t)m) & 15u) == 0 &&
+        (c.fwd_anchor > 0 || (c.fwd_anchor < 0 && row_bytes >= (64 << 10)))) {
+        const int64_t Ga = c.fwd_group > 0 ? c.fwd_group : 1;                            // (rows of one class are NS rows apart: one row per workgroup streams best -- profiles/exp_r06_fwd_anchor.txt)
+        const int64_t slots = (n_scalars + 2 * NS - 2) / NS;                             // a row spans at most this many 16-byte slots
+        const int64_t ax = (slots + BLK - 1) / BLK;
+        const int64_t ay = NS * ((((op->nrow + NS - 1) / NS) + Ga - 1) / Ga);            // groups: NS phase classes x chunks of Ga rows of a class
+        int64_t act = c.fwd_ctiles >= 0 ? c.fwd_ctiles : (row_bytes >= ((int64_t)32 << 20) ? 32 : 128);
+        if (act > ax) act = ax;
+        if (act < 1) act = 1;
+        if (ax * ay * BLK < ((int64_t)1 << 32)) {
+            const int base_phase = (int)((((uintptr_t)d) / sizeof(S)) % NS);
+            c.last_fwd_walk = 3;
+            c.last_fwd_rows_per_wg = Ga;
+            // diagonals in ONE slab laid out like the range vector share its phase row by row: their loads are aligned as well and stream (nontemporal);
+            // separately allocated diagonals are read under-aligned -- temporal, so that a line two waves share is still in L2 (launch_tall_fwd_mixed)
+            const bool coef_like_d = op->all_diag && op->diag_strided && op->diag_stride_elems * E == n_scalars &&
+                                     (int)((((uintptr_t)op->blocks[0].coeff) / sizeof(S)) % NS) == base_phase;
+            const bool nt_loads = c.ua_nt == 1 || (c.ua_nt < 0 && coef_like_d && jh_stream_nt(2.0 * (double)op->nrow * (double)row_bytes));
+            if (!nt_loads)
+                hipLaunchKernelGGL((k_tall_fwd_anchored<S, E, NS, false, BLK>), dim3((unsigned)(ax * ay)), dim3(BLK), 0, c.stream, op->dev_blocks, op->nrow, (int)Ga,
+                                   (const S *)m, (S *)d, n_scalars, (unsigned)ax, (unsigned)ay, (unsigned)act, base_phase, fmode);
+            else
+                hipLaunchKernelGGL((k_tall_fwd_anchored<S, E, NS, true, BLK>), dim3((unsigned)(ax * ay)), dim3(BLK), 0, c.stream, op->dev_blocks, op->nrow, (int)Ga,
+                                   (const S *)m, (S *)d, n_scalars, (unsigned)ax, (unsigned)ay, (unsigned)act, base_phase, fmode);
+            JH_CHECK_HIP(hipGetLastError());
+            return JH_OK;
+        }
+    }
     c.last_fwd_walk = ctiles ? 2 : 0;
     c.last_fwd_rows_per_wg = G;
 #define JH_FWD_MIXED(NTV)                                                                                                                   \

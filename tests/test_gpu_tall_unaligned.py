@@ -671,3 +671,76 @@ def test_scalar_times_a_tall_operator_of_several_kinds_adjoint_in_one_pass(Jets,
     ref = oracle.block_df_adj(ops, [np.zeros(n, dtype=dt)], hd)[0]
     assert np.linalg.norm(plain.to_numpy().ravel(order="F") - ref) <= tol * np.linalg.norm(ref)
     J.close(A)
+
+
+# ---------------------------------------------------------------------------------- round 6: the forward on lanes anchored to each row's own 16-byte grid
+@pytest.fixture()
+def anchored(Jets):
+    Jets.tune(fwd_anchor=1)                       # every eligible operator (the default rule starts at rows of 64 KiB)
+    yield
+    Jets.tune(fwd_anchor=-1)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("n", [9, 67, 1025, 1026, 1027, 4099, 2 * 1024 * 4 + 1, 6 * 1024 + 3, 65537])
+@pytest.mark.parametrize("nrow,name", [(2, "diag"), (7, "diag"), (33, "diag"), (3, "mixed"), (18, "onezero")])
+def test_the_anchored_forward_has_the_oracles_bits(Jets, oracle, anchored, dt, n, nrow, name):
+    """k_tall_fwd_anchored (round 6): a lane owns an ALIGNED 16-byte slot of the range slab -- elements [p NS - ph, p NS - ph + NS) of its row, ph the row's
+    phase -- instead of the element-indexed pack p; a row's first and last slot are partial and go element by element.  The same products: the oracle's bits
+    (src/Jets.jl:1015-1031) for all-diagonal rows and rows of several kinds (zero rows stay as found, 1022), the operator's range in the MIDDLE of a longer
+    slab (a view at an odd offset: every phase class occurs), the blocks in front and behind untouched; diagonals in one slab (same phase as the range) and
+    in separate arrays; and F(m) of the nonlinear mode (every row written)."""
+    import ctypes as C
+
+    from jets_jl_amd._ffi import check, lib
+    from jets_jl_amd.arrays import BlockArray
+
+    J = Jets
+    if n * np.dtype(dt).itemsize < 32:
+        pytest.skip("fewer than two packs per row: the element-indexed kernel")
+    if (n * np.dtype(dt).itemsize) % 16 == 0:
+        pytest.skip("rows of whole packs (every ComplexF64 row is): nothing to anchor")
+    # "onezero": rows of several kinds with ONE zero block (an operator with an eighth or more zero rows walks the list of its non-zero rows instead)
+    kinds = [[["diag", "diag_adj", "identity", "scale"][i % 4] if i != 5 else "zero"] for i in range(nrow)] if name == "onezero" else _kinds(nrow, name)
+    A, ops = _mixed_ops(J, oracle, dt, kinds, [n] * nrow, [n])
+    spc = J.JetSpace(dt, n)
+    hm = [u01(oracle, dt, 81, 0, n)]
+    for lead in (1, 2):                                                          # blocks in front of the operator's rows: shifts every row's phase
+        big = J.rand(J.JetBSpace([spc] * (nrow + lead + 1)), seed=9, stream=lead)
+        before = big.to_numpy().copy()
+        hd = [before[(lead + i) * n:(lead + i + 1) * n].copy() for i in range(nrow)]
+        want = oracle.block_df(ops, [b.copy() for b in hd], hm)                  # into the DIRTY rows: zero rows stay as found
+        h = C.c_void_p()
+        check(lib.jh_bvec_view(big.handle, lead, nrow, C.byref(h)))
+        view = BlockArray(h, [spc] * nrow, np.dtype(dt), owner=big)
+        J.mul_(view, A, J.from_numpy(hm[0], J.domain(A)))
+        assert J.tune_get("last_fwd_walk") == 3, "the anchored kernel should have run"
+        got = big.to_numpy()
+        assert_bits_equal(got[:lead * n], before[:lead * n], "the blocks in front of the rows")
+        assert_bits_equal(got[(lead + nrow) * n:], before[(lead + nrow) * n:], "the block behind the rows")
+        assert_bits_equal(got[lead * n:(lead + nrow) * n], np.concatenate(want), f"{name} {nrow} x {n} anchored forward, {lead} blocks in front")
+    J.close(A)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64, np.float64])
+def test_the_anchored_forward_with_diagonals_in_one_slab_and_in_f_mode(Jets, oracle, anchored, dt):
+    J = Jets
+    n, nrow = 4099, 11
+    spc = J.JetSpace(dt, n)
+    slab = J.rand(J.JetBSpace([spc] * nrow), seed=21, stream=4)                  # the diagonals share the range vector's layout: aligned loads
+    A = J.blockop([[J.JopDiagonal(slab.arrays[i])] for i in range(nrow)])
+    hs = slab.to_numpy()
+    ops = [[oracle.Block("diag", n, coeff=hs[i * n:(i + 1) * n].copy())] for i in range(nrow)]
+    hm = [u01(oracle, dt, 91, 0, n)]
+    want = oracle.block_df(ops, [np.zeros(n, dt) for _ in range(nrow)], hm)
+    d = J.mul_(J.rand(J.range(A), seed=5, stream=5), A, J.from_numpy(hm[0], J.domain(A)))
+    assert J.tune_get("last_fwd_walk") == 3
+    assert_bits_equal(d.to_numpy(), np.concatenate(want), "diagonals in one slab")
+    # F(m) of a tall nonlinear operator (SQUARE children between diagonal ones): every row written (src/Jets.jl:1003)
+    F = J.blockop([[J.JopSquare(spc)] if i % 3 == 0 else [J.JopDiagonal(slab.arrays[i])] for i in range(nrow)])
+    fo = [[oracle.Block("square", n)] if i % 3 == 0 else [oracle.Block("diag", n, coeff=hs[i * n:(i + 1) * n].copy())] for i in range(nrow)]
+    wantf = oracle.block_f(fo, [np.zeros(n, dt) for _ in range(nrow)], hm)
+    df = J.mul_(J.rand(J.range(F), seed=6, stream=6), F, J.from_numpy(hm[0], J.domain(F)))
+    assert_bits_equal(df.to_numpy(), np.concatenate(wantf), "F(m) on anchored lanes")
+    J.close(A)
+    J.close(F)

@@ -25,6 +25,9 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 J.init(0)
 J.tune(adj_split=0)
+for kv in os.environ.get("JETS_TUNE", "").split(","):          # e.g. JETS_TUNE=fwd_anchor=1: every off-grid forward on the anchored kernel (round 6)
+    if "=" in kv:
+        J.tune(**{kv.split("=")[0]: int(kv.split("=")[1])})
 KINDS = ["diag", "zero", "identity", "scale", "diag_adj", "scale_adj"]
 out = C.c_double(0)
 OFFGRID = os.environ.get("FUZZ_OFFGRID", "0") == "1"           # most cases off the 16-byte pack grid (round 5, last session)
