@@ -411,14 +411,18 @@ __global__ __launch_bounds__(BLK) void k_cg_normal(const jh_dev_block *__restric
 // out[s] = sum over parts p = 0..nparts-1 (in that order within a part lane, part lanes in order) of parts[p][s - s_begin]:
 // the second stage of the split-row walk.  64 vector lanes x 16 part lanes per workgroup; fp64 accumulation (exact
 // conversions of S, so the fold adds no rounding of its own until the final cast); fixed order => deterministic.
-template <typename S, int NS>
+// PL part lanes x (1024 / PL) vector lanes per workgroup: 16 x 64 for long domains; 64 x 16 (round 6) when the domain is short and the parts are many -- 262144 rows
+// of 513 elements fold 2048 slabs of 129 packs: with sixteen part lanes that was three workgroups whose threads each walked 128 slabs one after the other
+// (20.6 us under rocprofv3, a fifth of the fused A'A it finishes); sixty-four part lanes walk 32 (see profiles/rocprof_r06_thin_summary.md).
+template <typename S, int NS, int PL = 16>
 __global__ __launch_bounds__(1024) void k_fold_parts(const S *__restrict__ parts, int64_t part_stride, int nparts, S *__restrict__ out,
                                                      int64_t s_begin, int64_t s_end)
 {
     typedef typename vec_of<S, NS>::type V;
-    __shared__ double sm[16][NS][64];
-    const int v = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int64_t s = s_begin + ((int64_t)blockIdx.x * 64 + v) * NS;
+    constexpr int VL = 1024 / PL;
+    __shared__ double sm[PL][NS][VL];
+    const int v = threadIdx.x % VL, q = threadIdx.x / VL;
+    const int64_t s = s_begin + ((int64_t)blockIdx.x * VL + v) * NS;
     const bool ok = s < s_end;
     const int64_t sc = ok ? pack_start<NS>(s, s_end) : s_begin;     // (the last, partial pack of a domain that is not whole packs: loaded from s_end - NS, st_pack)
     double acc[NS];
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(1024) void k_fold_parts(const S *__restrict__ parts
     if (ok) {
         const S *src = parts + (sc - s_begin);
 #pragma unroll 4
-        for (int p = q; p < nparts; p += 16) {
+        for (int p = q; p < nparts; p += PL) {
             const V x = ldu<false, S, NS>(src + (int64_t)p * part_stride);
 #pragma unroll
             for (int e = 0; e < NS; e++) acc[e] += (double)x[e];
@@ -441,8 +445,8 @@ __global__ __launch_bounds__(1024) void k_fold_parts(const S *__restrict__ parts
 #pragma unroll
         for (int e = 0; e < NS; e++) {
             double t = acc[e];
-#pragma unroll
-            for (int qq = 1; qq < 16; qq++) t += sm[qq][e][v];
+#pragma unroll 8
+            for (int qq = 1; qq < PL; qq++) t += sm[qq][e][v];
             r[e] = (S)t;
         }
         st_pack<false, S, NS>(out, s, sc, r);
@@ -551,7 +555,14 @@ template <typename S, int NS>
 int launch_fold_parts(const void *parts, int64_t part_stride, int64_t nparts, void *out, int64_t s_begin, int64_t s_end)
 {
     jh_context &c = jh_ctx();
-    const int64_t gx = ((s_end - s_begin + NS - 1) / NS + 63) / 64;
+    const int64_t packs = (s_end - s_begin + NS - 1) / NS;
+    if (packs <= 64 * 8 && nparts >= 256) {                              // a short domain under many slabs: more part lanes, fewer slabs per thread
+        hipLaunchKernelGGL((k_fold_parts<S, NS, 64>), dim3((unsigned)((packs + 15) / 16)), dim3(1024), 0, c.stream, (const S *)parts, part_stride, (int)nparts,
+                           (S *)out, s_begin, s_end);
+        JH_CHECK_HIP(hipGetLastError());
+        return JH_OK;
+    }
+    const int64_t gx = (packs + 63) / 64;
     hipLaunchKernelGGL((k_fold_parts<S, NS>), dim3((unsigned)gx), dim3(1024), 0, c.stream, (const S *)parts, part_stride, (int)nparts,
                        (S *)out, s_begin, s_end);
     JH_CHECK_HIP(hipGetLastError());
@@ -1184,6 +1195,9 @@ int launch_tall_adj_mixed(const jh_blockop *op, void *out, const void *in, int64
     // rows of a few KiB (traces rather than volumes: 1001 or 2049 samples): thin workgroups, one pack per lane and four rows in flight -- the 512 x 2 shape issued
     // its (clamped) loads for 1024 packs where a row has 129: 262144 x 513 Float32 adjoint 2.1 -> see profiles/bench_unaligned_r05.txt (the split-row walk
     // supplies the workgroups)
+    // (round 6, tried and dropped: the thin shape whenever 512 x 2 launches fewer than two workgroups per CU -- 256 rows of 2 MiB with an identity row in four: the
+    // ordered walk on 512 thin workgroups ran the fused A'A at 4.15 TB/s where the split walk over sixteen row parts, which 512 x 2 falls into there, runs 4.6;
+    // profiles/rocprof_r06_thin_summary.md)
     if ((s_end - s_begin + NS - 1) / NS < 2048 && !(E == 2 && sizeof(S) == 4))
         return launch_tall_adj_mixed_u<S, E, NS, MODE, 256, 1, 4>(op, out, in, n_scalars, s_begin, s_end);
     return launch_tall_adj_mixed_u<S, E, NS, MODE, 512, 2, 2>(op, out, in, n_scalars, s_begin, s_end);
