@@ -1401,7 +1401,12 @@ int gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64
             if (sh > 8) sh = 8;
             if (sh < 4) sh = 4;
             // few workgroups: narrower row sets, more column groups per workgroup and more workgroups per child
-            while (sh > 4 && nitems * ((lanes + ((int64_t)1 << sh) - 1) >> sh) < 4 * (int64_t)c.cu_count) sh--;
+            // (children whose columns do not start on 16-byte boundaries -- odd row counts --: a run of 2^sh packs per column and wave set touches one 128-byte line more
+            // than it fills, and with streaming loads that line comes from HBM again for the neighbouring run: 16 row lanes = 256-byte runs fetched x1.49 of their
+            // bytes under rocprofv3 (8 x 4095^2: forward 4.0 TB/s against 5.7 for 4096^2; profiles/rocprof_r06_dense_odd_summary.md) -- such lists keep at least
+            // `dense_list_rl_min` = 2^6 row lanes: 1 KiB runs, nine lines for eight)
+            const int sh_min = (aligned != 2 && vec_rows) ? (int)(c.dense_list_rl_min > 0 ? c.dense_list_rl_min : 6) : 4;
+            while (sh > sh_min && nitems * ((lanes + ((int64_t)1 << sh) - 1) >> sh) < 4 * (int64_t)c.cu_count) sh--;
         }
         const int64_t chunks = (lanes + ((int64_t)1 << sh) - 1) >> sh;
         JH_REQUIRE(nitems * chunks < ((int64_t)1 << 31), "dense child list: %lld x %lld workgroups exceed the grid", (long long)nitems, (long long)chunks);

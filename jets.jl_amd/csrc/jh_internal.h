@@ -122,6 +122,7 @@ struct jh_context {
     int64_t dense_list_split = 1;      // knob: ... 1 the rows pass picks its lane layout (column groups per workgroup: deterministic, tolerance parity), 0 columns in order (the sequential loop's bits)
     int64_t dense_grid = 0;            // knob, read by jh_blockop_create: M x K grids of uniform dense children on the list route (0; late round 5: 8 x 8 of 1024^2 1.8 -> 5.5 TB/s forward, 32 x 32 of 256^2 0.43 -> 4.6) or as one tall batch per block column (1: rounds 2-4)
     int64_t dense_direct = 1;          // knob: block-diagonal operators of dense children in ONE launch (the list kernels write the output vector); 0: scratch + combine
+    int64_t dense_list_rl_min = 0;     // knob: lists of dense children whose columns start off the 16-byte grid keep at least 2^this row lanes per workgroup in the rows pass (0: 6 = 1 KiB runs per column; 4 = round 5's rule)
     int64_t dense_list_cpw = 0;        // knob: columns per lane group of the list kernel of y = B' x: 0 by column length, 1 / 2 / 4
     int64_t last_dense_rl = 0;         // read-only: row lanes per workgroup of the latest rows pass of the list kernels (256: columns in order)
     int64_t dense_mixed = 1;           // knob: operators mixing big dense children with other kinds: one batched launch + one combine launch (0: the per-block loop)
