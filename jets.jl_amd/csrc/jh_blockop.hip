@@ -378,6 +378,8 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
     }
     // the dense children of a dense_mixed operator as lists per direction and pass (jh_dense.hip: k_gemv_rows_list / k_gemv_cols_list)
     std::vector<jh_dense_item> items[2][2];
+    std::vector<int> comb_ptr[2];
+    std::vector<int64_t> comb_off[2];
     if (op->dense_mixed) {
         for (int dir = 0; dir < 2; dir++) {
             for (int64_t j = 0; j < ncol; j++)
@@ -415,6 +417,29 @@ int jh_blockop_create(int64_t nrow, int64_t ncol, const jh_block_desc *blocks, c
                     if (nz == 0 && dir == 1 && nrow > 1 && len > 0) direct = false;
                 }
                 op->dense_direct[dir] = direct;
+            }
+            // the combine's lists (round 6): only when every non-zero block is a dense child
+            {
+                const int64_t nlines = dir ? ncol : nrow, nsum = dir ? nrow : ncol;
+                bool only_dense = nlines < ((int64_t)1 << 30);
+                for (const auto &b : op->blocks)
+                    if (b.kind != JH_OP_DENSE && b.kind != JH_OP_ZERO) only_dense = false;
+                if (only_dense) {
+                    comb_ptr[dir].assign((size_t)nlines + 1, 0);
+                    for (int64_t l = 0; l < nlines; l++) {
+                        for (int64_t q = 0; q < nsum; q++) {
+                            const size_t k = (size_t)(dir ? q + l * nrow : l + q * nrow);
+                            if (op->blocks[k].kind == JH_OP_DENSE) comb_off[dir].push_back(op->prod_off[dir][k]);
+                        }
+                        comb_ptr[dir][(size_t)l + 1] = (int)comb_off[dir].size();
+                    }
+                    if (!comb_off[dir].empty()) {
+                        if (e == hipSuccess) e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_comb_ptr[dir], comb_ptr[dir].size() * sizeof(int));
+                        if (e == hipSuccess) e = jh_device_malloc(jh_ctx().device, (void **)&op->dev_comb_off[dir], comb_off[dir].size() * sizeof(int64_t));
+                        if (e == hipSuccess) e = hipMemcpyAsync(op->dev_comb_ptr[dir], comb_ptr[dir].data(), comb_ptr[dir].size() * sizeof(int), hipMemcpyHostToDevice, st);
+                        if (e == hipSuccess) e = hipMemcpyAsync(op->dev_comb_off[dir], comb_off[dir].data(), comb_off[dir].size() * sizeof(int64_t), hipMemcpyHostToDevice, st);
+                    }
+                }
             }
             for (int pass = 0; pass < 2; pass++) {
                 op->n_items[dir][pass] = (int64_t)items[dir][pass].size();
@@ -479,6 +504,10 @@ int jh_blockop_destroy(jh_blockop *op)
     for (int dir = 0; dir < 2; dir++)
         for (int pass = 0; pass < 2; pass++)
             if (op->dev_items[dir][pass]) (void)hipFree(op->dev_items[dir][pass]);
+    for (int dir = 0; dir < 2; dir++) {
+        if (op->dev_comb_ptr[dir]) (void)hipFree(op->dev_comb_ptr[dir]);
+        if (op->dev_comb_off[dir]) (void)hipFree(op->dev_comb_off[dir]);
+    }
     if (op->twin) (void)jh_blockop_destroy(op->twin);
     jh_handle_died(op->ctx);
     delete op;

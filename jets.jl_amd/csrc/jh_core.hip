@@ -964,6 +964,8 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "general_list")) { JH_REQUIRE(value >= 0 && value <= 3, "general_list must be 0 (never), 1 (automatic), 2 (always the four-line lists) or 3 (always the per-line lists)"); c.general_list = value; }
     else if (!strcmp(name, "small_loop_max_kib")) { JH_REQUIRE(value >= 0, "small_loop_max_kib must be >= 0"); c.small_loop_max_kib = value; }
     else if (!strcmp(name, "dense_list")) { JH_REQUIRE(value >= 0 && value <= 2, "dense_list must be 0 (the grid over every block pair), 1 (the children's lists) or 2 (... also for few big children)"); c.dense_list = value; }
+    else if (!strcmp(name, "dense_list_shared")) { JH_REQUIRE(value == 0 || value == 1, "dense_list_shared must be 0 or 1"); c.dense_list_shared = value; }
+    else if (!strcmp(name, "dense_combine")) { JH_REQUIRE(value == 0 || value == 1, "dense_combine must be 0 or 1"); c.dense_combine = value; }
     else if (!strcmp(name, "dense_list_rl_min")) { JH_REQUIRE(value == 0 || (value >= 4 && value <= 8), "dense_list_rl_min must be 0 (default) or a shift 4 .. 8"); c.dense_list_rl_min = value; }
     else if (!strcmp(name, "dense_list_cpw")) { JH_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "dense_list_cpw must be 0 (by column length), 1, 2 or 4"); c.dense_list_cpw = value; }
     else if (!strcmp(name, "dense_grid")) { c.dense_grid = value ? 1 : 0; }
@@ -1040,6 +1042,8 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "dense_list_split")) *value = c.dense_list_split;
     else if (!strcmp(name, "dense_direct")) *value = c.dense_direct;
     else if (!strcmp(name, "dense_grid")) *value = c.dense_grid;
+    else if (!strcmp(name, "dense_list_shared")) *value = c.dense_list_shared;
+    else if (!strcmp(name, "dense_combine")) *value = c.dense_combine;
     else if (!strcmp(name, "dense_list_rl_min")) *value = c.dense_list_rl_min;
     else if (!strcmp(name, "dense_list_cpw")) *value = c.dense_list_cpw;
     else if (!strcmp(name, "last_dense_rl")) *value = c.last_dense_rl;

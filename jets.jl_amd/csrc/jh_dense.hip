@@ -1229,13 +1229,21 @@ int gemv_mixed_all(const jh_dev_block *blocks, int64_t nrow, int64_t ncol, int64
 //    deterministic, tolerance parity (like the column chunks of k_gemv_rows and like any BLAS).
 //  * cols (y = B' x): a group of SUB lanes (a wave, or half / a quarter of one for short columns) owns CPW = 4 columns at once -- the input
 //    pack is loaded once for the four, four matrix loads in flight per step --, fp64 partials, xor-butterfly inside the group.
-template <typename S, int E, int NS>
+// SHARED (round 6; children whose columns start off the 16-byte grid): neighbouring row chunks of a child share a 128-byte line at BOTH ends of every column run.
+// The workgroups are then numbered so that consecutive chunks land on the same XCD (hardware hands consecutive workgroup ids to the eight XCDs in turn), and
+// the matrix loads are temporal: the shared line is an L2 hit for the second chunk instead of a second trip to HBM.
+template <typename S, int E, int NS, bool SHARED = false>
 __global__ __launch_bounds__(256) void k_gemv_rows_list(const jh_dense_item *__restrict__ items, unsigned chunks, int rl_shift, const S *__restrict__ in,
                                                         S *__restrict__ slabs, S *__restrict__ direct_out, int add_found)
 {
     typedef typename vec_of<S, NS>::type V;
     __shared__ V sm[256];
-    const unsigned item = blockIdx.x / chunks, chunk = blockIdx.x - item * chunks;
+    unsigned bid = blockIdx.x;
+    if constexpr (SHARED) {
+        const unsigned per = gridDim.x / 8u;                                      // logical ids [x * per, x * per + per) run on XCD x; the remainder keeps its ids
+        if (bid < per * 8u) bid = (bid & 7u) * per + (bid >> 3);
+    }
+    const unsigned item = bid / chunks, chunk = bid - item * chunks;
     const jh_dense_item it = items[item];
     const int RL = 1 << rl_shift, CG = 256 >> rl_shift;
     const int rowlane = threadIdx.x & (RL - 1), cg = threadIdx.x >> rl_shift;
@@ -1255,7 +1263,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows_list(const jh_dense_item *__r
         for (; c + 15 * (int64_t)CG < nc; c += 16 * (int64_t)CG) {
             V a[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) a[k] = ldgu_nt<S, NS>(col + (int64_t)k * step);
+            for (int k = 0; k < 16; k++) a[k] = SHARED ? ldgu<S, NS>(col + (int64_t)k * step) : ldgu_nt<S, NS>(col + (int64_t)k * step);
             col += 16 * step;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -1275,7 +1283,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows_list(const jh_dense_item *__r
             }
         }
         for (; c < nc; c += CG, col += step) {
-            V a = ldgu_nt<S, NS>(col);
+            V a = SHARED ? ldgu<S, NS>(col) : ldgu_nt<S, NS>(col);
             if constexpr (E == 1) {
                 acc = acc + a * (V)x[c];
             } else {
@@ -1403,15 +1411,18 @@ int gemv_list(const jh_dense_item *items, int64_t nitems, int64_t max_out, int64
             // few workgroups: narrower row sets, more column groups per workgroup and more workgroups per child
             // (children whose columns do not start on 16-byte boundaries -- odd row counts --: a run of 2^sh packs per column and wave set touches one 128-byte line more
             // than it fills, and with streaming loads that line comes from HBM again for the neighbouring run: 16 row lanes = 256-byte runs fetched x1.49 of their
-            // bytes under rocprofv3 (8 x 4095^2: forward 4.0 TB/s against 5.7 for 4096^2; profiles/rocprof_r06_dense_odd_summary.md) -- such lists keep at least
-            // `dense_list_rl_min` = 2^6 row lanes: 1 KiB runs, nine lines for eight)
-            const int sh_min = (aligned != 2 && vec_rows) ? (int)(c.dense_list_rl_min > 0 ? c.dense_list_rl_min : 6) : 4;
+            // bytes under rocprofv3 (8 x 4095^2: forward 4.0 TB/s against 5.7 for 4096^2; profiles/rocprof_r06_dense_odd_summary.md).  Such lists run the SHARED
+            // instantiation -- neighbouring chunks on one XCD, temporal loads: the shared line is an L2 hit -- and keep at least 2^5 row lanes (knob
+            // dense_list_rl_min; without SHARED 2^6 was the best: 4.9 / 5.0 TB/s where SHARED reaches 5.7 / 5.9 on 8 x 4095^2 / 64 x 1023^2)
+            const int sh_min = (aligned != 2 && vec_rows) ? (int)(c.dense_list_rl_min > 0 ? c.dense_list_rl_min : (c.dense_list_shared ? 5 : 6)) : 4;
             while (sh > sh_min && nitems * ((lanes + ((int64_t)1 << sh) - 1) >> sh) < 4 * (int64_t)c.cu_count) sh--;
         }
         const int64_t chunks = (lanes + ((int64_t)1 << sh) - 1) >> sh;
         JH_REQUIRE(nitems * chunks < ((int64_t)1 << 31), "dense child list: %lld x %lld workgroups exceed the grid", (long long)nitems, (long long)chunks);
         c.last_dense_rl = (int64_t)1 << sh;
-        if (vec_rows)
+        if (vec_rows && aligned != 2 && chunks > 1 && c.dense_list_shared)
+            hipLaunchKernelGGL((k_gemv_rows_list<S, E, NSV, true>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs, (S *)direct_out, add_found);
+        else if (vec_rows)
             hipLaunchKernelGGL((k_gemv_rows_list<S, E, NSV>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs, (S *)direct_out, add_found);
         else
             hipLaunchKernelGGL((k_gemv_rows_list<S, E, E>), dim3((unsigned)(nitems * chunks)), dim3(256), 0, st, items, (unsigned)chunks, sh, (const S *)x, (S *)slabs, (S *)direct_out, add_found);

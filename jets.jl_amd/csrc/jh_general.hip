@@ -1192,6 +1192,43 @@ namespace {
 // Two launches per mul!, three when adjointed and un-adjointed dense children meet.  Exception: when the dense children are few
 // AND big (the batched launch would leave the chip empty; the per-child kernel splits a big child's columns / rows over the grid
 // instead) they run child by child into the same slabs -- those operators are not launch-bound.
+// The combine launch of an operator whose non-zero blocks are ALL dense children (round 6): output element e of line l is the ordered sum of the products the
+// children's launches left in the scratch vector -- `_d .+= mul!(dtmp, op, _m)` (1024) from d as found, `_m .+= mul!(mtmp, op', _d)` (1049) from the zero of
+// 1042, or a single overwrite (1026 / 1051) -- read from a per-line list of product places built at create.  The general kernel does the same sum walking the
+// block table entry by entry, each step waiting for the one before: 17-32 us for the 8 K ... 16 K output elements of a 32 x 32 / 64 x 64 grid of dense
+// children, 40 % of the whole forward (profiles/rocprof_r06_dense_odd_summary.md).  Here eight products are requested at once; the adds stay in order: same bits.
+// mode: 0 from what the output holds, 1 from +0, 2 the line's single product overwrites.
+template <typename S, int E>
+__global__ __launch_bounds__(256) void k_combine_dense(const int *__restrict__ line_ptr, const int64_t *__restrict__ prod_at, const int64_t *__restrict__ line_off,
+                                                       const S *__restrict__ prod, S *__restrict__ out, unsigned ntiles, int mode, int zero_empty)
+{
+    const unsigned l = blockIdx.x / ntiles, tile = blockIdx.x - l * ntiles;
+    const int64_t o0 = line_off[l], n = line_off[l + 1] - o0;
+    const int p0 = line_ptr[l], p1 = line_ptr[l + 1];
+    for (int64_t e = (int64_t)tile * 256 + threadIdx.x; e < n; e += (int64_t)ntiles * 256) {
+        if (p0 == p1) {                                                    // a line without blocks: the forward leaves it as found (1022), the adjoint has zeroed it (1042)
+            if (zero_empty) { elem<S, E> z; z.re = 0; z.im = 0; estore<S, E>(out, o0 + e, z); }
+            continue;
+        }
+        elem<S, E> acc;
+        if (mode == 0) acc = eload<S, E>(out, o0 + e);
+        else { acc.re = 0; acc.im = 0; }
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {
+            elem<S, E> v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = eload<S, E>(prod, prod_at[p + k] + e);
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc = (mode == 2) ? v[k] : eadd<S, E>(acc, v[k]);
+        }
+        for (; p < p1; p++) {
+            const elem<S, E> v = eload<S, E>(prod, prod_at[p] + e);
+            acc = (mode == 2) ? v : eadd<S, E>(acc, v);
+        }
+        estore<S, E>(out, o0 + e, acc);
+    }
+}
+
 template <typename S, int E>
 // fmode (round 4): JetBlock_f! (988-1008) of such an operator -- the dense children's products are the same launches, the combine is
 // the general kernel in its f! mode (a zero block's `d .= 0` is added, not skipped; a SQUARE child squares): two launches where the
@@ -1283,7 +1320,16 @@ int dense_mixed_apply(const jh_blockop *op, void *out, const void *in, bool tran
         const bool use_list = !fmode && c.general_list != 0 && op->dev_steps[dir][1] && op->list_steps[dir][1] * 8 <= nlines * nsum_all * 7;
         const int *lsteps = use_list ? op->dev_steps[dir][1] : nullptr;
         const int lstride = use_list ? (int)op->step_stride[dir][1] : 0;
-        if (!transposed)
+        if (!fmode && c.dense_combine && op->dev_comb_ptr[dir]) {             // every non-zero block a dense child: the products' ordered sum from its lists
+            const int64_t nsum = transposed ? op->nrow : op->ncol;
+            // forward: several block columns accumulate into d as found (1024), one column overwrites (1026); adjoint: several rows sum from the zero of 1042,
+            // one row writes directly (1051) and leaves a column without a block untouched (1047)
+            const int mode = nsum > 1 ? (transposed ? 1 : 0) : 2;
+            int64_t ct = (maxn + 255) / 256;
+            if (ct > 64) ct = 64;
+            hipLaunchKernelGGL((k_combine_dense<S, E>), dim3((unsigned)(nlines * ct)), dim3(256), 0, c.stream, op->dev_comb_ptr[dir], op->dev_comb_off[dir],
+                               transposed ? op->dev_col_off : op->dev_row_off, (const S *)slabs, (S *)out, (unsigned)ct, mode, (transposed && nsum > 1) ? 1 : 0);
+        } else if (!transposed)
             hipLaunchKernelGGL((k_block_fwd_general<S, E>), dim3(grid, 1), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, op->dev_row_off,
                                op->dev_col_off, (const S *)in, (S *)out, fmode ? 1 : 0, ntiles, (int64_t)0, (S *)nullptr, (int64_t)0, (const S *)slabs, lsteps, lstride);
         else

@@ -122,6 +122,8 @@ struct jh_context {
     int64_t dense_list_split = 1;      // knob: ... 1 the rows pass picks its lane layout (column groups per workgroup: deterministic, tolerance parity), 0 columns in order (the sequential loop's bits)
     int64_t dense_grid = 0;            // knob, read by jh_blockop_create: M x K grids of uniform dense children on the list route (0; late round 5: 8 x 8 of 1024^2 1.8 -> 5.5 TB/s forward, 32 x 32 of 256^2 0.43 -> 4.6) or as one tall batch per block column (1: rounds 2-4)
     int64_t dense_direct = 1;          // knob: block-diagonal operators of dense children in ONE launch (the list kernels write the output vector); 0: scratch + combine
+    int64_t dense_list_shared = 1;     // knob: the rows pass over children with columns off the 16-byte grid numbers its workgroups XCD by XCD and loads temporal (k_gemv_rows_list<SHARED>); 0: round 5's streaming loads
+    int64_t dense_combine = 1;         // knob: operators whose non-zero blocks are all dense children combine the products from per-line lists (k_combine_dense, round 6); 0: the general kernel's table walk
     int64_t dense_list_rl_min = 0;     // knob: lists of dense children whose columns start off the 16-byte grid keep at least 2^this row lanes per workgroup in the rows pass (0: 6 = 1 KiB runs per column; 4 = round 5's rule)
     int64_t dense_list_cpw = 0;        // knob: columns per lane group of the list kernel of y = B' x: 0 by column length, 1 / 2 / 4
     int64_t last_dense_rl = 0;         // read-only: row lanes per workgroup of the latest rows pass of the list kernels (256: columns in order)
@@ -315,6 +317,10 @@ struct jh_blockop {
     bool dense_mixed_aligned = false;        // ... every dense matrix, row length and row offset on 16 bytes
     // the dense children of a dense_mixed operator as lists, [direction: 0 forward, 1 adjoint][pass: 0 y = B x, 1 y = B' x] (jh_dense.hip: k_gemv_*_list)
     jh_dense_item *dev_items[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    // round 6: operators whose non-zero blocks are ALL dense (full grids, banded grids of dense children): the combine launch reads, per output line, the list of its
+    // blocks' product places in summing order -- [dir] CSR: comb_ptr (nlines + 1 ints) and comb_off (where each product starts in the scratch vector, elements)
+    int *dev_comb_ptr[2] = {nullptr, nullptr};
+    int64_t *dev_comb_off[2] = {nullptr, nullptr};
     int64_t n_items[2][2] = {{0, 0}, {0, 0}}, items_max_out[2][2] = {{0, 0}, {0, 0}}, items_max_in[2][2] = {{0, 0}, {0, 0}};
     bool dense_direct[2] = {false, false};   // every output line of this direction holds exactly ONE non-zero block, a dense child (block-diagonal operators and
                                              // their permutations; forward: or none; adjoint: every column has one): the list kernels write the output vector
