@@ -357,8 +357,11 @@ int jh_blocksum_mul_adj_typed(int nterms, const jh_blockop *const *ops, const do
  * jh_chain_apply(accumulate): 0 out = chain(x); +1 / -1 out = out +- chain(x) -- JetSum's `broadcast!(sgn, d, d, tmp)` (634/643/652) fused
  * into the chain's last stage, so a term of a sum that is itself a chain (A'oA + ..., W1oA1 - W2oA2) never materialises; +2 / -2 the FIRST
  * term of a sum: out = 0 +- chain(x), the reference's `d .= 0` (631/640/649) without the fill pass (0 - t, not -t: the sign of a zero).
- * JH_ERR_UNSUPPORTED (take the stage-by-stage chain): operators that are not tall / elementwise / equal rows, one-row operators, many
- * rows of small blocks (the adjoint-shaped chains have no split-row walk), arrays not aligned like their scalar. */
+ * Many rows of small blocks (hundreds of rows whose ordered walk would leave the chip idle): the ADJOINT / NORMAL chains sum their rows in parts
+ * like jh_blockop_mul_adj (deterministic, tolerance parity; the stages after A' and the accumulation run on the folded sum;
+ * jh_tune_set("adj_split", 0) keeps the ordered, bit-exact walk; counter "last_adj_parts").
+ * JH_ERR_UNSUPPORTED (take the stage-by-stage chain): operators that are not tall / elementwise / equal rows, one-row operators, arrays not
+ * aligned like their scalar. */
 typedef struct jh_chain jh_chain;
 typedef enum { JH_CHAIN_FORWARD = 0, JH_CHAIN_ADJOINT = 1, JH_CHAIN_NORMAL = 2 } jh_chain_type;
 typedef enum { JH_STAGE_SCALE = 1, JH_STAGE_DIAG = 2 } jh_stage_kind;
@@ -542,7 +545,10 @@ int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, 
  * from HBM once -- in the forward, the forward update and the step, in the adjoint from 32 MiB rows on, nontemporal on aligned rows; 0 / 1 temporal /
  * nontemporal always; same bits), "fwd_anchor" (round 6: the tall forward of such rows on lanes anchored to each row's own 16-byte grid -- aligned stores, and
  * aligned loads of diagonals laid out like the range vector: -1 rows of 64 KiB or more, 0 never, 1 always; same bits), "tall_f" (F(m) of a tall nonlinear operator of elementwise children -- jh_blockop_f -- on the tall tiling: 1 yes, 0 the
- * general kernels; same bits);
+ * general kernels; same bits), "dense_list_shared" (round 6: the rows pass of y = B x for DENSE children whose columns are off the 16-byte grid numbers its
+ * chunks XCD by XCD and loads temporally, so the 128-byte line two neighbouring rows share is fetched from HBM once: 1 yes, 0 round 5's pass; same bits),
+ * "dense_list_rl_min" (log2 of the fewest row lanes per workgroup of that pass, 0: automatic), "dense_combine" (round 6: operators whose non-zero blocks are
+ * all DENSE children sum the products of a block line from CSR lists in one launch: 1 yes, 0 the general step lists; same bits);
  * round 4: "cg_dev" (jh_cgls_solve / jh_cgnr_solve with the recurrences on the device, graph-replayed unless lsqr_graph = 0: 1 automatic -- CGLS
  * like lsqr_graph, CG through the fused A'A up to 2 GiB of coefficients --, 2 at any size, 0 never: the host loops; within solver tolerance
  * of each other), "dense_fused" (adjoint of many small DENSE children / forward of a 1 x K operator of them in ONE fused launch + fold: 1

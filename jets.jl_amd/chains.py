@@ -483,7 +483,7 @@ def run(out, x, stages: Sequence, ws, cache: ChainCache | None, tag, accumulate:
                         return None
             elif accumulate:
                 return None
-            if not done:                                      # the library declined this run (split-row shapes, ...): its stages one by one
+            if not done:                                      # the library declined this run: its stages one by one
                 for q, s in enumerate(members):
                     fin = last and q == len(members) - 1
                     d2 = _j._zeroed_output(out, s.op) if fin else ws.zeros(("chain", k, q), s.R, s.op)

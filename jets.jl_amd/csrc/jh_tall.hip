@@ -551,6 +551,12 @@ static int adj_slabs(void *out, size_t bytes, void **slabs)
     return jh_ensure_scratch(bytes, slabs);
 }
 
+}  // namespace
+namespace jhb {
+int split_slabs(void *out, size_t bytes, void **slabs) { return adj_slabs(out, bytes, slabs); }
+}  // namespace jhb
+namespace {
+
 template <typename S, int NS>
 int launch_fold_parts(const void *parts, int64_t part_stride, int64_t nparts, void *out, int64_t s_begin, int64_t s_end)
 {

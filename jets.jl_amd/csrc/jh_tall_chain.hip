@@ -237,7 +237,7 @@ __global__ __launch_bounds__(BLK) void k_chain_fwd(const jh_dev_block *__restric
 // next DEPTH rows' table records already requested.
 template <typename S, int E, int NS, int U, int DEPTH, bool NT, int MODE, int BLK, int NW>
 __global__ __launch_bounds__(BLK) void k_chain_adj(const jh_dev_block *__restrict__ blocks, int64_t nrow, const ChainArgs ca, S *__restrict__ out,
-                                                   const S *__restrict__ in, int64_t n_scalars, int accumulate)
+                                                   const S *__restrict__ in, int64_t n_scalars, int accumulate, int64_t rows_per_part, S *__restrict__ part_out)
 {
     typedef typename vec_of<S, NS>::type V;
     constexpr int NWA = NW > 0 ? NW : 1, RW = 1 + NW;
@@ -288,15 +288,21 @@ __global__ __launch_bounds__(BLK) void k_chain_adj(const jh_dev_block *__restric
                 }
             }
     };
+    // split-row walk (many rows of small blocks, jh_tall.hip: pick_adj_parts): workgroup row blockIdx.y sums rows [y, y + 1) * rows_per_part in order into slab y
+    // of part_out (n_scalars apart); the fold and the list after A' follow in launches of their own
     int64_t i = 0;
+    if (part_out) {
+        i = (int64_t)blockIdx.y * rows_per_part;
+        nrow = nrow < i + rows_per_part ? nrow : i + rows_per_part;
+    }
     struct RecD { uint64_t w[DEPTH][RW]; };                                            // (records travel as values: handed to the lambda by pointer, some
     struct Rec1 { uint64_t w[1][RW]; };                                                //  Float64 shapes kept them in 36 bytes of scratch per lane)
     RecD nxt;
-    if (DEPTH <= nrow) {
+    if (i + DEPTH <= nrow) {
 #pragma unroll
         for (int j = 0; j < DEPTH; j++)
 #pragma unroll
-            for (int w = 0; w < RW; w++) nxt.w[j][w] = ca.rows[(int64_t)j * RW + w];
+            for (int w = 0; w < RW; w++) nxt.w[j][w] = ca.rows[(i + j) * RW + w];
     }
     for (; i + DEPTH <= nrow; i += DEPTH) {
         RecD e;
@@ -316,6 +322,13 @@ __global__ __launch_bounds__(BLK) void k_chain_adj(const jh_dev_block *__restric
         for (int w = 0; w < RW; w++) e.w[0][w] = ca.rows[i * RW + w];
         batch(i, e, std::integral_constant<int, 1>{});
     }
+    if (part_out) {
+        S *slab = part_out + (int64_t)blockIdx.y * n_scalars;
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            if (ok[k]) st_pack<false, S, NS>(slab, s0 + (int64_t)k * BLK * NS, sk[k], acc[k]);
+        return;
+    }
     const bool rmw = accumulate == 1 || accumulate == -1;
 #pragma unroll
     for (int k = 0; k < U; k++) {
@@ -323,6 +336,20 @@ __global__ __launch_bounds__(BLK) void k_chain_adj(const jh_dev_block *__restric
         const V r = dom_prog<S, E, NS, V>(ca.post, ca.post_c[0], ca.post_c[1], acc[k], sk[k]);
         if (ok[k]) st_pack<false, S, NS>(out, s0 + (int64_t)k * BLK * NS, sk[k], chain_accumulate<S, NS, V>(accumulate, found, r));
     }
+}
+
+// The split walk's last step when the chain goes on after A' (or accumulates into what `out` holds): out = accumulate(out, Q(folded)).
+template <typename S, int E, int NS>
+__global__ __launch_bounds__(256) void k_chain_finish(const ChainArgs ca, S *__restrict__ out, const S *__restrict__ folded, int64_t n_scalars, int accumulate)
+{
+    typedef typename vec_of<S, NS>::type V;
+    const int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * NS;
+    if (s >= n_scalars) return;
+    const int64_t sc = pack_start<NS>(s, n_scalars);
+    const bool rmw = accumulate == 1 || accumulate == -1;
+    const V found = rmw ? ldu<false, S, NS>(out + sc) : (V)(S)0;
+    const V r = dom_prog<S, E, NS, V>(ca.post, ca.post_c[0], ca.post_c[1], ldu<false, S, NS>(folded + sc), sc);
+    st_pack<false, S, NS>(out, s, sc, chain_accumulate<S, NS, V>(accumulate, found, r));
 }
 
 }  // namespace
@@ -393,14 +420,27 @@ int launch_chain_adj(const jh_chain *ch, void *out, const void *in, int64_t n_sc
     if (c.adj_wg == 256) shape = 0; else if (c.adj_wg == 512 && c.adj_unroll == 4) shape = 2; else if (c.adj_wg == 512) shape = 1;
     const int64_t per_wg = per_wg_of[shape];
     const int64_t gx = (packs + per_wg - 1) / per_wg;
-    // many rows of small blocks want the split-row walk (jh_tall.hip: pick_adj_parts): not built for chains -- the caller takes the stage-by-stage chain
-    if (jhb::pick_adj_parts(gx, op->nrow) > 1)
-        return jh_fail(JH_ERR_UNSUPPORTED, "fused chain: %lld rows of %lld-byte blocks want the split-row walk; apply the chain stage by stage",
-                       (long long)op->nrow, (long long)row_bytes);
-    c.last_adj_parts = 1;
+    // many rows of small blocks: the split-row walk (jh_tall.hip: pick_adj_parts; adj_split = 0 keeps the ordered, bit-exact walk) -- parts of the row sum into
+    // slabs of the scratch buffer, the fold of k_fold_parts, then the stages after A' and the accumulation on the folded vector (k_chain_finish; folded
+    // straight into `out` when there is neither).  Tolerance parity, like every split walk.
+    int64_t parts = n_scalars < NS ? 1 : jhb::pick_adj_parts(gx, op->nrow), rows_per_part = 0;
+    // (one workgroup per CU, up to two: the chain's three or four streams per row leave the ordered walk latency-bound there -- 4096 x 64^3, 256 workgroups:
+    // A' o W o A 4.37 TB/s in one part, 7.04 in two, 6.3 in four or more; profiles/bench_chains_r06_split.txt)
+    if (parts == 1 && c.adj_split < 0 && n_scalars >= NS && op->nrow >= 256 && gx < 2 * (int64_t)c.cu_count) parts = 2;
+    const bool finish = accumulate != 0 || (ch->args.post.st[0] & 15u) != CK_NONE;
+    S *slabs = nullptr, *folded = (S *)out;
+    if (parts > 1) {
+        rows_per_part = (op->nrow + parts - 1) / parts;
+        parts = (op->nrow + rows_per_part - 1) / rows_per_part;
+        void *sp = nullptr;
+        JH_TRY(jhb::split_slabs(out, (size_t)(parts + (finish ? 1 : 0)) * (size_t)n_scalars * sizeof(S), &sp));
+        slabs = (S *)sp;
+        if (finish) folded = slabs + parts * n_scalars;
+    }
+    c.last_adj_parts = parts;
 #define JH_CHAIN_ADJ(BLKV, UV, DV, NTV, NWV)                                                                                                 \
-    hipLaunchKernelGGL((k_chain_adj<S, E, NS, UV, DV, NTV, MODE, BLKV, NWV>), dim3((unsigned)gx), dim3(BLKV), 0, c.stream, op->dev_blocks, op->nrow, \
-                       ch->args, (S *)out, (const S *)in, n_scalars, accumulate)
+    hipLaunchKernelGGL((k_chain_adj<S, E, NS, UV, DV, NTV, MODE, BLKV, NWV>), dim3((unsigned)gx, (unsigned)parts), dim3(BLKV), 0, c.stream, op->dev_blocks, \
+                       op->nrow, ch->args, (S *)out, (const S *)in, n_scalars, accumulate, rows_per_part, slabs)
 #define JH_CHAIN_ADJ_NW(BLKV, UV, DV, NTV)                                                                                                    \
     switch (ch->nw) {                                                                                                                      \
     case 0: JH_CHAIN_ADJ(BLKV, UV, DV, NTV, 0); break;                                                                                     \
@@ -418,6 +458,14 @@ int launch_chain_adj(const jh_chain *ch, void *out, const void *in, int64_t n_sc
 #undef JH_CHAIN_ADJ_NW
 #undef JH_CHAIN_ADJ
     JH_CHECK_HIP(hipGetLastError());
+    if (parts > 1) {
+        JH_TRY(jhb::fold_parts(sizeof(S) == 4 ? JH_F32 : JH_F64, slabs, n_scalars, parts, folded, 0, n_scalars));
+        if (finish) {
+            hipLaunchKernelGGL((k_chain_finish<S, E, NS>), dim3((unsigned)((packs + 255) / 256)), dim3(256), 0, c.stream, ch->args, (S *)out, (const S *)folded,
+                               n_scalars, accumulate);
+            JH_CHECK_HIP(hipGetLastError());
+        }
+    }
     return JH_OK;
 }
 

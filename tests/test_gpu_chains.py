@@ -28,7 +28,7 @@ class Rig:
     in the oracle.  A chain is a list of tokens in APPLICATION order: "A", "At", ("W", k, conj), ("M", k, conj), ("s", a), ("Wb", k, conj) (the k-th
     weights as a block-diagonal block operator), ("I",) identity on the domain, ("opaque",) a user-written closure on the domain (d .= 2 .* m)."""
 
-    def __init__(self, J, oracle, dt, nrow, n, name="diag", seed=31):
+    def __init__(self, J, oracle, dt, nrow, n, name="diag", seed=31, with_wb=True):
         self.J, self.o, self.dt, self.nrow, self.n = J, oracle, dt, nrow, n
         self.A, self.ora = _mixed_ops(J, oracle, dt, _kinds(nrow, name), [n] * nrow, [n], seed=seed)
         R, D = J.range(self.A), J.domain(self.A)
@@ -39,7 +39,7 @@ class Rig:
         self.W = [J.JopDiagonal(w) for w in self.w]
         self.M = [J.JopDiagonal(c) for c in self.c]
         self.Wb = []
-        for k in range(2):
+        for k in range(2 if with_wb else 0):
             spc = J.JetSpace(dt, n)
             rows = []
             for i in range(nrow):
@@ -417,3 +417,87 @@ def test_a_chain_through_the_jacobian_of_a_nonlinear_operator_follows_point(Jets
         finally:
             chains.ENABLED[0] = True
         assert_bits_equal(y1.to_numpy(), y0.to_numpy(), f"J' W J at point {seed}")
+
+
+SPLIT_CHAINS = ["A' o W o A", "(W o A)' o (W o A)", "M' o A' o W o A o M", "a * (A' o A)", "A' o (a W) o A o (b M)", "M o A'  (range -> domain)", "M o A' o W'"]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("name", SPLIT_CHAINS)
+@pytest.mark.parametrize("nrow,n,kinds", [(512, 1027, "diag"), (700, 260, "mixed")])
+def test_chains_over_many_small_rows_take_the_split_walk(Jets, oracle, dt, name, nrow, n, kinds):
+    """Hundreds of rows of a few KiB: the ordered walk of A' would run on a handful of workgroups, so the library cuts the row sum into parts (adj_split,
+    DESIGN.md section 3: tolerance parity, deterministic) -- the fused chain too, its stages after A' and its accumulation applied to the folded sum.  With
+    adj_split = 0 (the ordered, bit-exact walk) the fused chain has the bits of the stage-by-stage chain and of the oracle as everywhere else."""
+    from jets_jl_amd import chains
+
+    J = Jets
+    toks, runs = CHAINS[name]
+    rig = Rig(J, oracle, dt, nrow, n, kinds, with_wb=False)
+    C = rig.compose(toks)
+    rng_in = toks[0] == "At" or (toks[0] != "A" and toks[0][0] == "W")
+    xs = J.range(rig.A) if rng_in else J.domain(rig.A)
+    hx = [u01(oracle, dt, 91, i, n) for i in range(nrow if rng_in else 1)]
+    x = J.from_numpy(np.concatenate(hx), xs)
+    want = np.concatenate(rig.ora_apply(toks, hx))
+    tol = (2e-5 if np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4 else 1e-13) * np.sqrt(nrow)
+    y1, y0, ran = _run_both(J, C, x, J.range(C), chains)
+    assert ran == runs
+    scale = np.abs(want).max()
+    assert np.abs(y1.to_numpy().ravel(order="F") - want).max() <= tol * scale, f"{name}: split fused chain vs the oracle"
+    assert np.abs(y0.to_numpy().ravel(order="F") - want).max() <= tol * scale
+    y2 = J.mul_(J.rand(J.range(C), seed=79, stream=3), C, x)
+    assert J.tune_get("last_adj_parts") > 1, "the shape was chosen to take the split walk"
+    assert_bits_equal(y2.to_numpy().ravel(order="F"), y1.to_numpy().ravel(order="F"), "the split walk is deterministic")
+    J.tune(adj_split=0)
+    try:
+        y1, y0, ran = _run_both(J, C, x, J.range(C), chains)
+        assert ran == runs and J.tune_get("last_adj_parts") == 1
+        assert_bits_equal(y1.to_numpy().ravel(order="F"), y0.to_numpy().ravel(order="F"), f"{name}: ordered fused vs stage by stage")
+        assert_bits_equal(y1.to_numpy().ravel(order="F"), want, f"{name}: ordered fused vs the oracle")
+    finally:
+        J.tune(adj_split=-1)
+    rig.close()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex128])
+def test_a_sum_of_chains_over_many_small_rows(Jets, oracle, dt):
+    """A'oWoA + lam*I - (M' o B' o B o M) with 600 rows of 515 elements: the second and third terms ADD themselves to what the output holds after the fold
+    (k_chain_finish); against the reference's loop on the device (tolerance: both split their row sums) and bit-exact with adj_split = 0."""
+    from jets_jl_amd import chains
+
+    J = Jets
+    nrow, n = 600, 515
+    ra, rb = Rig(J, oracle, dt, nrow, n, "mixed", seed=31, with_wb=False), Rig(J, oracle, dt, nrow, n, "diag", seed=57, with_wb=False)
+    A, B = ra.A, rb.A
+    dom = J.domain(A)
+    N1 = J.compose(J.compose(A.H, ra.W[0]), A)
+    N2 = J.compose(ra.M[0].H, J.compose(J.compose(B.H, B), ra.M[0]))
+    S = N1 + 0.25 * J.JopIdentity(dom) - N2
+    hx = u01(oracle, dt, 91, 0, n)
+    x = J.from_numpy(hx, dom)
+
+    def both():
+        before = chains.STATS["sum_terms_fused"]
+        y1 = J.mul_(J.rand(dom, seed=77, stream=1), S, x)
+        fused = chains.STATS["sum_terms_fused"] - before
+        chains.ENABLED[0] = False
+        try:
+            y0 = J.mul_(J.rand(dom, seed=78, stream=2), S, x)
+        finally:
+            chains.ENABLED[0] = True
+        return y1.to_numpy().ravel(order="F"), y0.to_numpy().ravel(order="F"), fused
+
+    y1, y0, fused = both()
+    assert fused == 2                                   # (lam * I goes through the temporary: no tall operator in it)
+    tol = (2e-5 if dt == np.float32 else 1e-13) * np.sqrt(nrow) * np.abs(y0).max()
+    assert np.abs(y1 - y0).max() <= tol
+    J.tune(adj_split=0)
+    try:
+        y1, y0, fused = both()
+        assert fused == 2
+        assert_bits_equal(y1, y0, "ordered walk: sum of chains fused vs the reference's loop")
+    finally:
+        J.tune(adj_split=-1)
+    ra.close()
+    rb.close()
