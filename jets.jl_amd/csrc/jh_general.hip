@@ -890,7 +890,7 @@ int launch_general_tile(const jh_blockop *op, const S *in, S *out, int64_t in_by
     // (round 5: 4 lines x 2 steps, 8 lines, and two packs per lane on the four-line shape were measured on the PMC evidence that the kernel moves
     // exactly its unique bytes -- all within -7 ... +2 % of this shape, 8 lines far below: profiles/exp_r05_general_tile_shapes.txt)
     const int64_t ngroups = four ? (nlines + 3) / 4 : (nlines + 1) / 2;
-    const int U = (c.fwd_unroll == 2) ? 2 : 1;                           // two packs per lane did not pay here (knob fwd_unroll = 2: measurements)
+    constexpr int U = 1;                                                 // (two packs per lane did not pay here: measured in rounds 4-5, its instantiations dropped in round 6)
     unsigned ntiles, grid;
     general_grid(((n_scalars + NS - 1) / NS + 256 * U - 1) / (256 * U), ngroups, ntiles, grid, general_use_xcd(in_bytes));
     // late round 5: a SPARSE grid walks step lists built at create (k_general_tile LIST) -- per group of four lines the summed block indices at which one
@@ -929,9 +929,6 @@ int launch_general_tile(const jh_blockop *op, const S *in, S *out, int64_t in_by
                            ntiles, (unsigned)ngroups, op->dev_steps[dir][0], (int)op->step_stride[dir][0]);
     else if (four)
         hipLaunchKernelGGL((k_general_tile<S, E, NS, 1, 1, TRANSPOSED, 4>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
-                           ntiles, (unsigned)ngroups, (const int *)nullptr, 0);
-    else if (U == 2)
-        hipLaunchKernelGGL((k_general_tile<S, E, NS, 2, 2, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,
                            ntiles, (unsigned)ngroups, (const int *)nullptr, 0);
     else
         hipLaunchKernelGGL((k_general_tile<S, E, NS, 2, 1, TRANSPOSED>), dim3(grid), dim3(256), 0, c.stream, op->dev_blocks, op->nrow, op->ncol, n_scalars, in, out,

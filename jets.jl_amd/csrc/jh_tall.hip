@@ -484,6 +484,16 @@ TallShape pick_fwd_shape(int64_t nvec, int64_t nrow, size_t vec_bytes)
 
 }  // namespace
 namespace jhb {
+// the shapes of the all-diagonal ordered walk that exist: what the size rule of pick_adj_shape selects without knobs
+//   adjoint  (mode 0): 256 x {1x4, 2x4, 4x2, 4x4}, 512 x 4x4 (>= 4 M packs, >= 512 rows), 1024 x 4x2 (>= 4 M packs, fewer rows)
+//   fused A'A (mode 1): 256 x {1x8, 2x8, 4x4}, 1024 x 4x4 (>= 4 M packs)
+constexpr bool adj_shape_built(int mode, int wg, int u, int d)
+{
+    if (mode == 0)
+        return (wg == 256 && ((u == 1 && d == 4) || (u == 2 && d == 4) || (u == 4 && (d == 2 || d == 4)))) || (wg == 512 && u == 4 && d == 4) ||
+               (wg == 1024 && u == 4 && d == 2);
+    return (wg == 256 && ((u == 1 && d == 8) || (u == 2 && d == 8) || (u == 4 && d == 4))) || (wg == 1024 && u == 4 && d == 4);
+}
 TallShape pick_adj_shape(int64_t nvec, int64_t nrow, int mode)
 {
     jh_context &c = jh_ctx();
@@ -506,6 +516,20 @@ TallShape pick_adj_shape(int64_t nvec, int64_t nrow, int mode)
     // a 1024-thread workgroup has 128 VGPRs per lane: the two-stream adjoint keeps at most 8 packs per stream in flight there
     // (2 x 8 and 4 x 4 spilled 108-176 bytes per lane to scratch; same bits with fewer rows in flight)
     if (mode == 0 && s.wg == 1024 && s.unroll * s.aux > 8) s.aux = 8 / s.unroll;
+    // Round 6: only the (workgroup, packs, rows) shapes the SIZE RULE above can select are compiled (adj_shape_built: ten per element type, load policy aside,
+    // where rounds 1-5 compiled the knobs' whole 3 x 6 matrix -- 192 instantiations no default route reached).  A knob triple that names another shape runs
+    // the built shape of its workgroup size with the nearest packs x rows, else the rule's own shape (same bits: the rows are summed in order whatever the shape).
+    if (!adj_shape_built(mode, s.wg, s.unroll, s.aux)) {
+        static const int pairs[6][2] = {{1, 4}, {1, 8}, {2, 4}, {2, 8}, {4, 2}, {4, 4}};
+        int best = -1, best_d = 1 << 30;
+        for (int k = 0; k < 6; k++)
+            if (adj_shape_built(mode, s.wg, pairs[k][0], pairs[k][1])) {
+                const int d = 16 * (pairs[k][0] > s.unroll ? pairs[k][0] - s.unroll : s.unroll - pairs[k][0]) + (pairs[k][1] > s.aux ? pairs[k][1] - s.aux : s.aux - pairs[k][1]);
+                if (d < best_d) { best_d = d; best = k; }
+            }
+        if (best >= 0) { s.unroll = pairs[best][0]; s.aux = pairs[best][1]; }
+        else { s.wg = (mode == 1 && s.wg == 512) ? 1024 : 256; s.unroll = 4; s.aux = 4; }       // (the fused A'A has no 512-lane shape)
+    }
     return s;
 }
 }  // namespace jhb
@@ -642,7 +666,7 @@ int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n
     }
     c.last_adj_parts = parts;
 #define JH_ADJ_CASE(U, DEPTH)                                                                                          \
-    if constexpr (!(BLK == 1024 && MODE == 0 && U * DEPTH > 8))                                                        \
+    if constexpr (jhb::adj_shape_built(MODE, BLK, U, DEPTH))                                                           \
     if (sh.unroll == U && sh.aux == DEPTH) {                                                                           \
         int64_t gx = (s_end - s_begin + (int64_t)U * BLK * NS - 1) / ((int64_t)U * BLK * NS);                          \
         for (int64_t r0 = 0; r0 < op->nrow; r0 += rows_per_launch) {                                                   \
@@ -656,6 +680,7 @@ int launch_tall_adj_u(const jh_blockop *op, void *out, const void *in, int64_t n
         if (parts > 1) return launch_fold_parts<S, NS>(slabs, part_stride, parts, out, s_begin, s_end);                \
         return JH_OK;                                                                                                  \
     }
+    // (round 6: of this list only the combinations with a workgroup size that the size rule can select -- adj_shape_built)
     // Round 5: the six (packs per lane, rows in flight) shapes the size rule of pick_adj_shape can select.  Five more used to be compiled
     // for the knobs alone -- (1,1) (1,2) (2,1) (2,2) (4,1): 240 of this kernel's 524 instantiations, the bulk of the library's build
     // time -- and lost every sweep of rounds 1-2 (profiles/sweep_r02_adj_rows.txt); pick_adj_shape now maps a knob pair to the nearest
