@@ -520,7 +520,8 @@ int jh_team_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ds, const j
 int jh_team_mul_adj(int n, const jh_blockop *const *ops, jh_bvec *const *ms, const jh_bvec *const *ds, int nranges);
 int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, const jh_bvec *const *ms, int nranges);
 
-/* kernel-shape tuning knobs (bench/tests only): 0 = automatic (fwd_order: -1); name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg","fwd_order","nt" (nontemporal loads / stores on the streamed operands: 0 never, 1 unless one pass's working set is at most "nt_resident_mib" MiB -- an operator that stays in the 256 MiB Infinity Cache between a solver's iterations is loaded temporal --, 2 always),"nt_resident_mib","autotune" (0: tall forwards keep the size-based default shape; 1: per-operator lazy measurement, see jh_blockop_tune_get),
+/* kernel-shape tuning knobs (bench/tests only): 0 = automatic (fwd_order: -1); name in {"fwd_group","fwd_unroll","fwd_wg","adj_unroll","adj_depth","adj_wg" (round 6: a
+ * triple that names a shape the size rule never selects runs the nearest compiled one; same bits),"fwd_order","nt" (nontemporal loads / stores on the streamed operands: 0 never, 1 unless one pass's working set is at most "nt_resident_mib" MiB -- an operator that stays in the 256 MiB Infinity Cache between a solver's iterations is loaded temporal --, 2 always),"nt_resident_mib","autotune" (0: tall forwards keep the size-based default shape; 1: per-operator lazy measurement, see jh_blockop_tune_get),
  * "graphs" (1: operators that run the per-block loop -- those with DENSE blocks -- replay it as a hipGraph from the
  * third call with the same vectors on; 0: always eager), "general_xcd" (the general M x K kernels' grid order: 1 automatic -- XCD-aware when the
  * input vector is >= 32 MiB, line by line below --, 0 never XCD-aware, 2 always), "red_wgs", "bcast_item_fast" (batched broadcasts with a shared operand: -1 automatic, 0 plain kernel, 1 items fastest), "step_chain" (the one-pass step as chained row chunks: -1 measured per operator, 0 never, 1 whenever the shape allows), "step_chunk" (rows per chunk of the chained step: 0 automatic -- 32 rows of a 256-lane tile for all-diagonal operators, 8 rows of a 1024-lane tile otherwise --, 8, 16, 32; same bits), "step_band" (the chained step in column bands of this many tiles: -1 the default, 0 none -- tiles fastest over the whole row; same bits), "adj_split" (split-row walk of the tall adjoint / fused normal /
