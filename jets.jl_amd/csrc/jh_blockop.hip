@@ -677,10 +677,11 @@ int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m)
             return jh_fail(JH_ERR_STATE, "jh_blockop_normal_mul: operator has nonlinear blocks and no linearisation point (jh_blockop_point)");
         return jhb::tall_adj(op, y->data, m->data, 1, true);
     }
+    if (jhb::grid_normal_ok(op, y->data, m->data)) return jhb::grid_normal(op, y->data, m->data);   // N x (2 .. 4) grids of equal diagonals (round 6)
     if (!tall_fast_ok(op, y->data, m->data) || op->nrow < 2)
         return jh_fail(JH_ERR_UNSUPPORTED,
-                       "jh_blockop_normal_mul: fused A'A needs a tall (>= 2 rows) operator of equal elementwise rows; "
-                       "chain jh_blockop_mul and jh_blockop_mul_adj instead");
+                       "jh_blockop_normal_mul: fused A'A needs a tall (>= 2 rows) operator of equal elementwise rows or an N x (2 .. 4) grid of equal "
+                       "diagonals; chain jh_blockop_mul and jh_blockop_mul_adj instead");
     return jhb::tall_adj(op, y->data, m->data, 1, false);
     return jh_fail(JH_ERR_INVALID, "jh_blockop_normal_mul: unknown dtype %d", op->dtype);
 }

@@ -137,6 +137,7 @@ struct jh_context {
     int64_t tall_f = 1;                // knob: F(m) of a tall nonlinear operator of elementwise children on the tall tiling (jh_blockop_f): 1 yes, 0 the general kernels
     int64_t ua_nt = -1;                // knob: accesses of the tall kernels on rows off the 16-byte grid: -1 temporal there, nontemporal on aligned rows; 0 / 1 temporal / nontemporal always
     int64_t tall_unaligned = 1;        // knob: tall operators whose rows are not whole, 16-byte aligned packs (odd block lengths in one slab) on the under-aligned tall kernels (jh_tall.hip: tall_unaligned_ok); 0: the general kernels as before
+    int64_t grid_normal = 1;           // knob: (A', A) on an N x (2 .. 4) grid of equal diagonals in one pass (jh_grid_normal.hip); 0: JH_ERR_UNSUPPORTED as in rounds 1-5 (the caller chains the two stages)
     int64_t fwd_anchor = -1;           // knob: the tall forward of rows that are not whole packs on lanes anchored to each row's own 16-byte grid (k_tall_fwd_anchored): -1 from 64 KiB rows on, 0 never, 1 always
     int64_t wide_twin = 1;             // knob: wide elementwise operators on their tall twin: 0 never (general kernels), 1 adjoint always + forward from 16 MiB blocks, 2 both always (tests)
     const double *step_coef_dev = nullptr;   // internal, set around the calls of the graph-captured LSQR loop: the one-pass step reads (alpha, beta) from

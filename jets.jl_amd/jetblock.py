@@ -627,7 +627,7 @@ def _real_scale(op, allow_wide=False):
 def try_fused_chain(out, x, ops: Sequence[Jop]):
     """Two-stage chains of JetComposite_df / df' (src/Jets.jl:530-540) that one kernel computes with the unfused
     chain's exact rounding sequence; returns None when the chain does not qualify:
-      (A', A)   normal operator, coefficients read once            -> jh_blockop_normal_mul
+      (A', A)   normal operator, coefficients read once            -> jh_blockop_normal_mul (tall operators; N x (2 .. 4) grids of diagonals)
       (a, A)    scalar * operator, forward                         -> jh_blockop_mul_scaled
       (A', a')  scalar * operator, adjoint: A'(conj(a) d)          -> jh_blockop_mul_adj_scaled
     for a tall all-diagonal device-native block operator A and a Real scalar a (of the elements' precision or wider: the scalar's
@@ -640,6 +640,14 @@ def try_fused_chain(out, x, ops: Sequence[Jop]):
             nat = _tall_native(right)
             if nat is not None and right.jet.s["ops"].shape[0] >= 2:
                 return nat.normal_mul(out, x)
+            if nat is None and isinstance(right, JopLn) and isblockop(right) and 2 <= right.jet.s["ops"].shape[1] <= 4 and right.jet.s["ops"].shape[0] >= 2:
+                # round 6: an N x K grid of equal diagonals, K = 2 .. 4 (multi-parameter operators): one pass over the coefficients
+                # (jh_grid_normal.hip); the library declines anything else (JH_ERR_UNSUPPORTED -> the reference's chain)
+                j = right.jet
+                nat = _native_op(j.s.get("_native"), j.s["ops"], j.rng.eltype())
+                nat = None if nat is None else _pointed_native(nat, j.s["ops"], j.mo)
+                if nat is not None:
+                    return nat.normal_mul(out, x)
             return None
         a = _real_scale(left, allow_wide=True)
         if a is not None and not isinstance(right, JopAdjoint):

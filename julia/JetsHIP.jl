@@ -584,6 +584,18 @@ function Jets.JetComposite_df!(d::HipArray{T}, m::HipArray{T}; ops, kwargs...) w
     _fused_chain!(d, m, _stages_df(ops), T, 0) && return d              # chains of any depth: every fusable run in one pass (round 6)
     invoke(JetComposite_df!, Tuple{AbstractArray,Any}, d, m; ops=ops, kwargs...)
 end
+# (A' ∘ A) on an N × K GRID of equal diagonals, K = 2 … 4 (a multi-parameter operator: domain and output are block vectors): one pass over the
+# coefficients, the two-stage chain's bits (jh_grid_normal.hip); anything else: the reference's chain
+function Jets.JetComposite_df!(d::BlockArray{T,<:HipArray{T}}, m::BlockArray{T,<:HipArray{T}}; ops, kwargs...) where {T}
+    if length(ops) == 2 && ops[1] isa JopAdjoint && ops[1].op === ops[2] && ops[2] isa JopLn && jet(ops[2]).df! === JetBlock_df! && 2 <= size(state(ops[2]).ops, 2) <= 4
+        h, hd, hm = native_handle(state(ops[2]).ops, T), handle(d), handle(m)
+        if h != C_NULL && hd != C_NULL && hm != C_NULL
+            st = ccall((:jh_blockop_normal_mul, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, hd, hm)
+            st == 4 || (check(st); return d)                    # JH_ERR_UNSUPPORTED (blocks of several kinds, K > 4): the chain below
+        end
+    end
+    invoke(JetComposite_df!, Tuple{AbstractArray,Any}, d, m; ops=ops, kwargs...)
+end
 # JetComposite_f! (524-528) on one device space: runs of elementwise stages (F ∘ A ∘ F ∘ A, benchmark/benchmarks.jl:73) in one JIT-compiled pass
 function Jets.JetComposite_f!(d::HipArray{T}, m::HipArray{T}; ops, kwargs...) where {T}
     _fused_chain!(d, m, Any[ops[i] for i = length(ops):-1:1], T, 0) && return d

@@ -1,0 +1,109 @@
+"""GPU parity: the fused normal operator (A' o A) of an N x K GRID of equal diagonals, K = 2 .. 4 (round 6; jh_grid_normal.hip behind
+jh_blockop_normal_mul).
+
+The reference applies the composite (A', A) stage by stage (src/Jets.jl:530-534): JetBlock_df! into zeros(range(A)) (1010-1032), then
+JetBlock_df'! (1034-1057).  The fused pass keeps m_1 .. m_K and y_1 .. y_K in registers, reads every coefficient once and rounds every
+product and sum where the two stages round them, so it is BIT-EXACT against the two stages applied on the device and against the CPU
+oracle's two loops; with many rows of small blocks it sums in parts like every row-summing kernel (tolerance; adj_split = 0: ordered, bit-exact)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from .helpers import DTYPES, assert_bits_equal, u01
+from .test_gpu_blockop import _mixed_ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _native(J, A):
+    from jets_jl_amd import jetblock as _blk
+
+    return _blk._native_op(A.jet.s["_native"], A.jet.s["ops"], A.jet.rng.eltype())
+
+
+def _grid(J, oracle, dt, nrow, ncol, n, adjointed=False):
+    kinds = [[("diag_adj" if (adjointed and (i + j) % 3 == 0) else "diag") for j in range(ncol)] for i in range(nrow)]
+    return _mixed_ops(J, oracle, dt, kinds, [n] * nrow, [n] * ncol, seed=41)
+
+
+def _two_stage(J, A, m):
+    t = J.mul_(J.zeros(J.range(A)), A, m)                                       # zeros(range(A)) (531): the grid forward adds to d as found (1024)
+    return J.mul_(J.rand(J.domain(A), seed=6, stream=9), A.H, t)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("ncol", [2, 3, 4])
+@pytest.mark.parametrize("nrow,n", [(2, 1024), (5, 1027), (9, 4096 + 64), (7, 67), (3, 6)])
+def test_fused_normal_of_a_grid_of_diagonals_has_the_bits_of_the_two_stages(Jets, oracle, dt, ncol, nrow, n):
+    J = Jets
+    if n * np.dtype(dt).itemsize < 16:
+        pytest.skip("blocks shorter than one pack take the chain")
+    A, ora = _grid(J, oracle, dt, nrow, ncol, n)
+    hm = [u01(oracle, dt, 91, j, n) for j in range(ncol)]
+    m = J.from_numpy(np.concatenate(hm), J.domain(A))
+    nat = _native(J, A)
+    y = J.rand(J.domain(A), seed=7, stream=3)                                   # a DIRTY output
+    from jets_jl_amd._ffi import check, lib
+
+    check(lib.jh_blockop_normal_mul(nat.handle, y.handle, m.handle))            # the library takes the grid (no JH_ERR_UNSUPPORTED)
+    y2 = J.mul_(J.rand(J.domain(A), seed=8, stream=3), J.compose(A.H, A), m)    # the same through the composite
+    want_dev = _two_stage(J, A, m)
+    t = oracle.block_df(ora, [np.zeros(n, dt) for _ in range(nrow)], hm)
+    want = np.concatenate(oracle.block_df_adj(ora, [np.zeros(n, dt) for _ in range(ncol)], t))
+    assert_bits_equal(y.to_numpy().ravel(order="F"), want, "fused A'A of a grid vs the oracle's two loops")
+    assert_bits_equal(y2.to_numpy().ravel(order="F"), want, "the composite (A', A) takes the fused pass")
+    assert_bits_equal(want_dev.to_numpy().ravel(order="F"), want, "the two stages on the device")
+    J.tune(grid_normal=0)
+    try:
+        y3 = J.mul_(J.rand(J.domain(A), seed=9, stream=3), J.compose(A.H, A), m)   # knob off: JH_ERR_UNSUPPORTED -> the reference's chain
+        assert_bits_equal(y3.to_numpy().ravel(order="F"), want, "knob off: the chain")
+    finally:
+        J.tune(grid_normal=1)
+    J.close(A)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.complex64, np.complex128])
+def test_grids_the_fused_pass_declines_run_the_chain(Jets, oracle, dt):
+    """Five block columns, or blocks that are not all plain diagonals (an adjointed diagonal of a complex type): jh_blockop_normal_mul says
+    JH_ERR_UNSUPPORTED and the composite applies its two stages."""
+    J = Jets
+    n = 515
+    for ncol, adj in ((5, False), (3, True)):
+        if adj and np.dtype(dt).kind != "c":
+            continue
+        A, ora = _grid(J, oracle, dt, 4, ncol, n, adjointed=adj)
+        hm = [u01(oracle, dt, 91, j, n) for j in range(ncol)]
+        m = J.from_numpy(np.concatenate(hm), J.domain(A))
+        y = J.mul_(J.rand(J.domain(A), seed=8, stream=3), J.compose(A.H, A), m)
+        t = oracle.block_df(ora, [np.zeros(n, dt) for _ in range(4)], hm)
+        want = np.concatenate(oracle.block_df_adj(ora, [np.zeros(n, dt) for _ in range(ncol)], t))
+        assert_bits_equal(y.to_numpy().ravel(order="F"), want, f"{ncol} columns, adjointed={adj}")
+        J.close(A)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64])
+@pytest.mark.parametrize("ncol", [2, 4])
+def test_many_small_rows_take_the_split_walk(Jets, oracle, dt, ncol):
+    J = Jets
+    nrow, n = 600, 515
+    A, ora = _grid(J, oracle, dt, nrow, ncol, n)
+    hm = [u01(oracle, dt, 91, j, n) for j in range(ncol)]
+    m = J.from_numpy(np.concatenate(hm), J.domain(A))
+    N = J.compose(A.H, A)
+    t = oracle.block_df(ora, [np.zeros(n, dt) for _ in range(nrow)], hm)
+    want = np.concatenate(oracle.block_df_adj(ora, [np.zeros(n, dt) for _ in range(ncol)], t))
+    y = J.mul_(J.rand(J.domain(A), seed=8, stream=3), N, m)
+    assert J.tune_get("last_adj_parts") > 1
+    tol = (2e-5 if np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4 else 1e-13) * np.sqrt(nrow) * np.abs(want).max()
+    assert np.abs(y.to_numpy().ravel(order="F") - want).max() <= tol
+    y2 = J.mul_(J.rand(J.domain(A), seed=9, stream=3), N, m)
+    assert_bits_equal(y2.to_numpy().ravel(order="F"), y.to_numpy().ravel(order="F"), "the split walk is deterministic")
+    J.tune(adj_split=0)
+    try:
+        y3 = J.mul_(J.rand(J.domain(A), seed=10, stream=3), N, m)
+        assert J.tune_get("last_adj_parts") == 1
+        assert_bits_equal(y3.to_numpy().ravel(order="F"), want, "ordered walk: the oracle's bits")
+    finally:
+        J.tune(adj_split=-1)
+    J.close(A)
