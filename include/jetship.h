@@ -471,7 +471,8 @@ int jh_cgls_solve_team(int n, const jh_blockop *const *ops, jh_bvec *const *us, 
  * residual A'r is updated by recurrence in the domain, so the attainable accuracy goes with cond(A)^2 (CGLS / LSQR: cond(A)) -- meant
  * for well-conditioned operators and for throughput.  istop / history / result record as jh_cgls_solve (r2norm = the recurrence's
  * sqrt(||r||^2 + damp^2 ||x||^2)).  _partitioned / _team: the domain vector A_k'A_k p is the only thing
- * exchanged, in 4 element ranges (jh_blockop_normal_mul_range), each all-reduced under the next range's kernel. */
+ * exchanged, in 4 element ranges (jh_blockop_normal_mul_range), each all-reduced under the next range's kernel.
+ * Round 6: jh_cgnr_solve also takes an N x (2 .. 4) grid of equal diagonals (the fused A'A of jh_blockop_normal_mul for such grids). */
 int jh_cgnr_solve(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter,
                   int force_maxiter, jh_lsqr_result *res, double *history);
 int jh_cgnr_solve_partitioned(const jh_blockop *op, jh_bvec *b, jh_bvec *x, int use_x0, double damp, double atol, double btol, int maxiter,

@@ -182,9 +182,14 @@ def _native_cgnr(eng, b, x0, damp, atol, btol, maxiter, force_maxiter):
     from ._ffi import LsqrResultC
     from .rowpart import AbiComm
 
-    if os.environ.get("JETS_CGLS_NATIVE", "1") == "0" or eng.native is None:
-        return None
     shard = getattr(eng, "shard", None)
+    nat = eng.native
+    if nat is None and shard is None and hasattr(eng, "A"):
+        from . import jetblock as _blk
+
+        nat = _blk._grid_native(eng.A)                 # round 6: N x (2 .. 4) grids of diagonals have a fused A'A too (jh_grid_normal.hip)
+    if os.environ.get("JETS_CGLS_NATIVE", "1") == "0" or nat is None:
+        return None
     if shard is not None and not (isinstance(shard.comm, AbiComm) or shard.comm.world == 1):
         return None
     x = eng.zeros_dom() if x0 is None else eng.copy(eng.zeros_dom(), x0)
@@ -192,7 +197,7 @@ def _native_cgnr(eng, b, x0, damp, atol, btol, maxiter, force_maxiter):
     hist = (C.c_double * builtins.max(2 * int(maxiter), 1))()
     try:
         solve = lib.jh_cgnr_solve_partitioned if shard is not None else lib.jh_cgnr_solve
-        check(solve(eng.native.handle, b.handle, x.handle, 0 if x0 is None else 1, float(damp), float(atol), float(btol), int(maxiter),
+        check(solve(nat.handle, b.handle, x.handle, 0 if x0 is None else 1, float(damp), float(atol), float(btol), int(maxiter),
                     1 if force_maxiter else 0, C.byref(res), hist))
     except JetsHipError as e:
         if e.status != 4:

@@ -161,6 +161,7 @@ jh_context &jh_ctx();                  // the calling thread's current context (
 // Nontemporal loads do not stay in the 256 MiB Infinity Cache: right for operands far larger than it (every byte is used once per pass),
 // wrong for an operator that fits -- its coefficients would come from HBM every iteration although the cache could hold them.
 // Knob nt: 0 never, 2 always, 1 (default): nontemporal unless the working set of one pass is at most nt_resident_mib.
+namespace jhb { bool grid_normal_ok(const jh_blockop *op, const void *y, const void *m); }   // jh_grid_normal.hip
 inline bool jh_stream_nt(double working_set_bytes)
 {
     const jh_context &c = jh_ctx();

@@ -1396,8 +1396,11 @@ static int cgnr_impl(const int M, const jh_blockop *const *ops, jh_bvec *const *
     JH_TRY(jh_bvec_info(xs[0], &nb, &n, &dtype, nullptr));
     for (int k = 0; k < M; k++) {
         JH_REQUIRE(xs[k]->length == n && xs[k]->dtype == dtype, "jh_cgnr_solve: member %d's x differs in length or element type", k);
-        if (!jh_blockop_tall_step_ok(ops[k], bs[k]->data, xs[k]->data) || ops[k]->nrow < 2)
-            return jh_fail(JH_ERR_UNSUPPORTED, "jh_cgnr_solve: needs a tall (>= 2 rows) operator of equal elementwise rows");
+        // (round 6: one shard may also be an N x (2 .. 4) grid of equal diagonals -- its fused A'A is jh_grid_normal.hip; the loop below only ever calls
+        // jh_blockop_mul_adj and jh_blockop_normal_mul on whole vectors there)
+        const bool grid = M == 1 && ex == Exch::none && jhb::grid_normal_ok(ops[k], xs[k]->data, xs[k]->data);
+        if (!grid && (!jh_blockop_tall_step_ok(ops[k], bs[k]->data, xs[k]->data) || ops[k]->nrow < 2))
+            return jh_fail(JH_ERR_UNSUPPORTED, "jh_cgnr_solve: needs a tall (>= 2 rows) operator of equal elementwise rows (or, unpartitioned, an N x (2 .. 4) grid of equal diagonals)");
     }
     struct Work {
         jh_bvec *p = nullptr, *s = nullptr, *y = nullptr;

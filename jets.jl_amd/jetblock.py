@@ -603,6 +603,18 @@ def _tall_native(op):
     return _pointed_native(nat, j.s["ops"], j.mo)
 
 
+def _grid_native(op):
+    """The NativeBlockOp of a device-native N x K block operator with N >= 2 and K = 2 .. 4 (the shapes whose fused A'A the library has,
+    jh_grid_normal.hip), else None."""
+    if not (isinstance(op, JopLn) and isblockop(op)):
+        return None
+    j = op.jet
+    if not (2 <= j.s["ops"].shape[1] <= 4 and j.s["ops"].shape[0] >= 2):
+        return None
+    nat = _native_op(j.s.get("_native"), j.s["ops"], j.rng.eltype())
+    return None if nat is None else _pointed_native(nat, j.s["ops"], j.mo)
+
+
 def _real_scale(op, allow_wide=False):
     """The real scalar a of an `a*` operator (src/Jets.jl:1159-1162) when the fused kernels reproduce Julia's arithmetic for it, else None.
     They multiply by T(a), part by part: right for a Real scalar of the elements' precision.  A Complex scalar (full product, even with
@@ -640,12 +652,10 @@ def try_fused_chain(out, x, ops: Sequence[Jop]):
             nat = _tall_native(right)
             if nat is not None and right.jet.s["ops"].shape[0] >= 2:
                 return nat.normal_mul(out, x)
-            if nat is None and isinstance(right, JopLn) and isblockop(right) and 2 <= right.jet.s["ops"].shape[1] <= 4 and right.jet.s["ops"].shape[0] >= 2:
+            if nat is None:
                 # round 6: an N x K grid of equal diagonals, K = 2 .. 4 (multi-parameter operators): one pass over the coefficients
                 # (jh_grid_normal.hip); the library declines anything else (JH_ERR_UNSUPPORTED -> the reference's chain)
-                j = right.jet
-                nat = _native_op(j.s.get("_native"), j.s["ops"], j.rng.eltype())
-                nat = None if nat is None else _pointed_native(nat, j.s["ops"], j.mo)
+                nat = _grid_native(right)
                 if nat is not None:
                     return nat.normal_mul(out, x)
             return None

@@ -24,7 +24,7 @@ import math
 import os
 
 from ._ffi import lib, check, JetsHipError
-from .arrays import zeros, lincomb_, norm, copyto_, reshape
+from .arrays import zeros, lincomb_, norm, copyto_, reshape, fill_
 
 
 def _plain(coefs):
@@ -111,6 +111,11 @@ class _Engine:
                 self.native = None
         if self._tmp_r is None:
             self._tmp_r = zeros(_j.range_(self.A))
+            self._fwd_overwrites = _blk.overwrites_its_whole_range(self.L)
+        elif not self._fwd_overwrites:
+            # a block operator with several columns ADDS to d as found (src/Jets.jl:1024: `_d .+= mul!(dtmp, ...)`), one with zero blocks leaves
+            # their rows (1022): the reference's own `A*m` hands mul! fresh zeros (src/Jets.jl:395), and so must a reused temporary
+            fill_(self._tmp_r, 0)
         _j.mul_(self._tmp_r, self.L, v)
         lincomb_(u, _plain([alpha, beta]), [self._tmp_r, u])
         return float(norm(u)) ** 2
@@ -154,6 +159,8 @@ class _Engine:
                 self.native = None
         if self._tmp_d is None:
             self._tmp_d = zeros(_j.domain(self.A))
+        elif not (_blk.isblockop(self.L) and self.L.jet.s["ops"].shape[0] > 1) and not _blk.overwrites_its_whole_range(_j.adjoint(self.L)):
+            fill_(self._tmp_d, 0)              # (a one-row block operator's adjoint skips zero blocks, 1047; with several rows it starts from `_m .= 0`, 1042)
         _j.mul_(self._tmp_d, _j.adjoint(self.L), u)
         lincomb_(v, _plain([alpha, beta]), [self._tmp_d, v])
         return float(norm(v))

@@ -107,3 +107,60 @@ def test_many_small_rows_take_the_split_walk(Jets, oracle, dt, ncol):
     finally:
         J.tune(adj_split=-1)
     J.close(A)
+
+
+@pytest.mark.parametrize("dt,xtol", [(np.float32, 2e-4), (np.float64, 1e-11), (np.complex64, 2e-4)])
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_cgnr_on_a_grid_runs_through_the_fused_normal_operator(Jets, oracle, dt, xtol, native, monkeypatch):
+    """CG on the normal equations of a 6 x 3 grid of diagonals (jh_cgnr_solve takes such grids since round 6: one pass over the coefficients per
+    iteration; native = 0: A then A' through the engines) against the textbook fp64 CGLS on the same numbers."""
+    from .test_gpu_cgls import cgls_fp64
+
+    monkeypatch.setenv("JETS_CGLS_NATIVE", native)
+    J = Jets
+    nrow, ncol, n, iters = 6, 3, 1500, 10
+    A, ora = _grid(J, oracle, dt, nrow, ncol, n)
+    dt64 = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    coef = [[ora[i][j].coeff.astype(dt64) for j in range(ncol)] for i in range(nrow)]
+
+    def matvec(x):
+        xs = np.split(x, ncol)
+        return np.concatenate([sum(coef[i][j] * xs[j] for j in range(ncol)) for i in range(nrow)])
+
+    def rmatvec(d):
+        ds = np.split(d, nrow)
+        return np.concatenate([sum(np.conj(coef[i][j]) * ds[i] for i in range(nrow)) for j in range(ncol)])
+
+    hb = (u01(oracle, dt, 51, 0, nrow * n) - dt(0.5)).astype(dt)
+    b = J.from_numpy(hb, J.range(A))
+    res = J.cgnr(A, b, atol=0.0, btol=0.0, maxiter=iters)
+    xr, info = cgls_fp64(matvec, rmatvec, hb.astype(dt64), ncol * n, atol=0.0, btol=0.0, maxiter=iters)
+    assert res.itn == iters == info["itn"] and res.istop == 7
+    x = res.x.to_numpy().ravel(order="F").astype(dt64)
+    assert np.linalg.norm(x - xr) / np.linalg.norm(xr) < xtol
+    for (i1, r1, ar1), (i2, r2, ar2) in zip(res.history, info["history"]):
+        assert i1 == i2 and r1 == pytest.approx(r2, rel=max(10 * xtol, 1e-8))
+    assert np.array_equal(b.to_numpy(), hb), "b is read, never written"
+    J.close(A)
+
+
+def test_lsqr_and_cgls_on_a_grid_reuse_their_temporaries_correctly(Jets, oracle):
+    """A block operator with several columns ADDS to the output as found (src/Jets.jl:1024); the solvers' generic engine reuses one range-sized
+    temporary across iterations and must hand mul! zeros each time, as the reference's own `A*m` does (395).  LSQR and CGLS on a 5 x 2 grid against
+    the textbook fp64 CGLS (the same Krylov iterates in exact arithmetic)."""
+    from .test_gpu_cgls import cgls_fp64
+
+    J = Jets
+    dt, nrow, ncol, n, iters = np.float64, 5, 2, 700, 8
+    A, ora = _grid(J, oracle, dt, nrow, ncol, n)
+    coef = [[ora[i][j].coeff for j in range(ncol)] for i in range(nrow)]
+    matvec = lambda x: np.concatenate([sum(coef[i][j] * np.split(x, ncol)[j] for j in range(ncol)) for i in range(nrow)])
+    rmatvec = lambda d: np.concatenate([sum(coef[i][j] * np.split(d, nrow)[i] for i in range(nrow)) for j in range(ncol)])
+    hb = u01(oracle, dt, 51, 0, nrow * n) - 0.5
+    xr, _ = cgls_fp64(matvec, rmatvec, hb, ncol * n, atol=0.0, btol=0.0, maxiter=iters)
+    for solve in (J.lsqr, J.cgls):
+        kw = dict(conlim=0.0) if solve is J.lsqr else {}
+        res = solve(A, J.from_numpy(hb, J.range(A)), atol=0.0, btol=0.0, maxiter=iters, **kw)
+        x = res.x.to_numpy().ravel(order="F")
+        assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr), solve.__name__
+    J.close(A)

@@ -45,6 +45,16 @@ def case(N, K, edge, dt="float32"):
     fused_b = (N * K + 2 * K) * n * s
     print(f"{N:5d} x {K} of {edge}^3 {dt}: fused {tf:8.3f} ms {fused_b / tf / 1e9:6.3f} TB/s ({100 * fused_b / tf / 8e9:5.1f} % of 8 TB/s, {parts} part{'s' if parts > 1 else ''}) | "
           f"two stages {tu:8.3f} ms | {tu / tf:5.2f}x", flush=True)
+    if os.environ.get("CGNR", "0") == "1":                                 # CG on the normal equations: jh_cgnr_solve through the fused pass | A then A' through the engines
+        b = J.rand(J.range(A), seed=5, stream=0)
+        for native in ("1", "0"):
+            os.environ["JETS_CGLS_NATIVE"] = native
+            J.cgnr(A, b, atol=0.0, btol=0.0, maxiter=2)
+            e0 = J.Event().record(); J.cgnr(A, b, atol=0.0, btol=0.0, maxiter=12, force_maxiter=True); e1 = J.Event().record()
+            e2 = J.Event().record(); J.cgnr(A, b, atol=0.0, btol=0.0, maxiter=2, force_maxiter=True); e3 = J.Event().record()
+            J.synchronize()
+            print(f"        CGNR {'jh_cgnr_solve (fused A^T A)' if native == '1' else 'engines (A, then A^T)      '}: {(e0.elapsed_ms(e1) - e2.elapsed_ms(e3)) / 10:8.3f} ms per iteration", flush=True)
+        os.environ["JETS_CGLS_NATIVE"] = "1"
     J.close(A)
 
 
