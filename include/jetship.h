@@ -355,6 +355,9 @@ int jh_blocksum_mul_adj_typed(int nterms, const jh_blockop *const *ops, const do
  *                     one PER BLOCK ROW of A (a weight vector in one slab: base + i*n; a block-diagonal operator's children: wherever they
  *                     are; NULL: the row is an identity block).  row_flags (range side, optional): per row bit 0 = this row is conjugated
  *                     (a child that is the adjoint of a diagonal), bit 1 = a zero block on the diagonal (the row becomes zeros, 1022).
+ *                     JH_STAGE_ROWSUM (with row_flags): the stage is a block-diagonal BLOCK OPERATOR -- several block columns, so the reference
+ *                     ACCUMULATES each row, `_d .+= mul!(dtmp, op, _m)` into zeros (1024; adjoint 1042 / 1049): the row is 0 + c .* x (a product of -0
+ *                     becomes +0), where a plain diagonal operator stores c .* x itself.
  * At most 4 stages per list and 2 distinct coefficient arrays per list (a list may name the same array twice -- W' o W reads w once).
  * The handle borrows `op` and the coefficient arrays (both must outlive it) and copies everything else.
  * jh_chain_apply(accumulate): 0 out = chain(x); +1 / -1 out = out +- chain(x) -- JetSum's `broadcast!(sgn, d, d, tmp)` (634/643/652) fused
@@ -368,10 +371,10 @@ int jh_blocksum_mul_adj_typed(int nterms, const jh_blockop *const *ops, const do
 typedef struct jh_chain jh_chain;
 typedef enum { JH_CHAIN_FORWARD = 0, JH_CHAIN_ADJOINT = 1, JH_CHAIN_NORMAL = 2 } jh_chain_type;
 typedef enum { JH_STAGE_SCALE = 1, JH_STAGE_DIAG = 2 } jh_stage_kind;
-enum { JH_STAGE_CONJ = 4 };              /* (beside JH_SCALAR_* in jh_chain_stage.flags) */
+enum { JH_STAGE_CONJ = 4, JH_STAGE_ROWSUM = 8 };   /* (beside JH_SCALAR_* in jh_chain_stage.flags) */
 typedef struct {
     int32_t kind;                        /* jh_stage_kind                                                             */
-    int32_t flags;                       /* SCALE: JH_SCALAR_*; DIAG: JH_STAGE_CONJ                                   */
+    int32_t flags;                       /* SCALE: JH_SCALAR_*; DIAG: JH_STAGE_CONJ, JH_STAGE_ROWSUM                  */
     double a;                            /* SCALE: the real scalar                                                    */
     const void *const *coeff;            /* DIAG: host array of device pointers (1 on the domain side, nrow on the range side) */
     const uint8_t *row_flags;            /* DIAG on the range side: optional host array of nrow flag bytes (see above) */

@@ -63,7 +63,7 @@ class ChainStage(C.Structure):
     _fields_ = [("kind", C.c_int32), ("flags", C.c_int32), ("a", C.c_double), ("coeff", C.POINTER(C.c_void_p)), ("row_flags", C.POINTER(C.c_uint8))]
 
 
-STAGE_SCALE, STAGE_DIAG, STAGE_CONJ = 1, 2, 4      # jh_stage_kind, JH_STAGE_CONJ
+STAGE_SCALE, STAGE_DIAG, STAGE_CONJ, STAGE_ROWSUM = 1, 2, 4, 8      # jh_stage_kind, JH_STAGE_CONJ, JH_STAGE_ROWSUM
 CHAIN_FORWARD, CHAIN_ADJOINT, CHAIN_NORMAL = 0, 1, 2   # jh_chain_type
 
 

@@ -21,7 +21,7 @@ from typing import Sequence
 
 import numpy as np
 
-from ._ffi import (lib, check, JetsHipError, scalar_flags, SCALAR_WIDE, SCALAR_COMPLEX, ChainStage, STAGE_SCALE, STAGE_DIAG, STAGE_CONJ,
+from ._ffi import (lib, check, JetsHipError, scalar_flags, SCALAR_WIDE, SCALAR_COMPLEX, ChainStage, STAGE_SCALE, STAGE_DIAG, STAGE_CONJ, STAGE_ROWSUM,
                    CHAIN_FORWARD, CHAIN_ADJOINT, CHAIN_NORMAL)
 from . import arrays as _arr
 from . import jets as _j
@@ -192,6 +192,7 @@ class ChainHandle:
                     fl = (C.c_uint8 * nrow)(*st.row_flags)
                     g.coeff = C.cast(ptrs, C.POINTER(C.c_void_p))
                     g.row_flags = C.cast(fl, C.POINTER(C.c_uint8))
+                    g.flags |= STAGE_ROWSUM                  # a block operator of several columns accumulates its rows into zeros (src/Jets.jl:1024, 1049): 0 + c .* x
                     self._keep += [ptrs, fl, st.keep]
             return arr
 

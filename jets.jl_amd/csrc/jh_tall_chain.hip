@@ -30,6 +30,7 @@ constexpr int JH_CHAIN_MAX_STREAMS = 2;  // DIAG stages per side that read a coe
 
 // stage kinds as the kernels see them (0: no stage -- the lists are padded with it)
 enum { CK_NONE = 0, CK_SCALE = 1, CK_SCALE_WIDE = 2, CK_DIAG = 3, CK_DIAG_CONJ = 4 };
+enum : uint32_t { CK_ROWSUM = 1u << 8 };        // (stage word: kind | stream << 4 | CK_ROWSUM)
 
 // One side's stage list, packed for the scalar unit: a stage is ONE 32-bit word (kind | stream << 4) and its scalar one float (32-bit elements) or
 // double -- the range-side list lives in SGPRs for the whole row loop, beside the rows' table entries and the streams' base addresses.
@@ -87,7 +88,7 @@ template <typename S, int E, int NS, typename V>
 __device__ inline V dom_stage(const ChainProg &p, int s, uint32_t kind, const void *c0, const void *c1, V x, int64_t sk)
 {
     if (kind <= CK_SCALE_WIDE) return stage_scale<S, NS, V>(p, s, kind == CK_SCALE_WIDE, x);
-    const V c = ldu<false, S, NS>((const S *)((p.st[s] >> 4) ? c1 : c0) + sk);   // (a select of two pointers, not a computed index into the argument struct)
+    const V c = ldu<false, S, NS>((const S *)(((p.st[s] >> 4) & 15u) ? c1 : c0) + sk);   // (a select of two pointers, not a computed index into the argument struct)
     return vmul<S, E, NS, V>(c, x, kind == CK_DIAG_CONJ);
 }
 // (the two coefficient pointers by value: handing the kernel argument's array on by address kept a copy of the struct on the stack)
@@ -108,15 +109,21 @@ __device__ inline V mid_stage(const ChainProg &p, int s, uint32_t kind, V t, con
 {
     if (kind <= CK_SCALE_WIDE) return stage_scale<S, NS, V>(p, s, kind == CK_SCALE_WIDE, t);
     if constexpr (NW > 0) {
-        const bool second = NW > 1 && (p.st[s] >> 4) != 0;
+        const bool second = NW > 1 && ((p.st[s] >> 4) & 15u) != 0;
         const uint64_t w = second ? e[NW] : e[1];
         const V c = second ? wv[NW - 1] : wv[0];
+        // the children of a block-diagonal BLOCK OPERATOR (several block columns) are accumulated: `_d .+= mul!(dtmp, op, _m)` into zeros (1024), `_m .= 0` then
+        // `_m .+= ...` (1042 / 1049) -- a product of -0 leaves +0.  Found by tools/fuzz_chains.py: a zero row of A under a negative scalar, then such a stage.
+        const V zero_plus = (V)(S)0;
+        const bool rowsum = (p.st[s] & CK_ROWSUM) != 0;
         if (__builtin_expect((w & (CW_SPECIAL | CR_PTR)) > CR_PTR || (w & CR_PTR) == 0, 0)) {      // an identity row (null pointer) or a zero block: rare
-            if (cw_zero(w)) return (V)(S)0;                                     // a zero block on W's diagonal: the stage's zeros() stay (1022)
-            if ((w & CR_PTR) == 0) return t;                                     // an identity row -- d .= m, bit for bit
+            if (cw_zero(w)) return zero_plus;                                   // a zero block on W's diagonal: the stage's zeros() stay (1022)
+            if ((w & CR_PTR) == 0) return rowsum ? zero_plus + t : t;           // an identity row -- d .= m, bit for bit
         }
-        if constexpr (E == 1) return c * t;                                     // (real elements: conj is the identity)
-        else return vmul<S, E, NS, V>(c, t, (kind == CK_DIAG_CONJ) != cw_conj(w));
+        V r;
+        if constexpr (E == 1) r = c * t;                                        // (real elements: conj is the identity)
+        else r = vmul<S, E, NS, V>(c, t, (kind == CK_DIAG_CONJ) != cw_conj(w));
+        return rowsum ? zero_plus + r : r;
     }
     return t;
 }
@@ -486,7 +493,8 @@ int build_prog(const char *side, int n, const jh_chain_stage *st, int dtype, int
             p.a[s] = g.a;
             p.a32[s] = (float)g.a;
         } else if (g.kind == JH_STAGE_DIAG) {
-            JH_REQUIRE((g.flags & ~JH_STAGE_CONJ) == 0, "jh_chain_create: unknown flags %d on a DIAG stage", g.flags);
+            JH_REQUIRE((g.flags & ~(JH_STAGE_CONJ | JH_STAGE_ROWSUM)) == 0, "jh_chain_create: unknown flags %d on a DIAG stage", g.flags);
+            JH_REQUIRE(!(g.flags & JH_STAGE_ROWSUM) || g.row_flags, "jh_chain_create: JH_STAGE_ROWSUM is for the children of a block-diagonal block operator (range side, row_flags given)");
             JH_REQUIRE(g.coeff, "jh_chain_create: a DIAG stage without coefficient pointers");
             int found = -1;
             for (size_t q = 0; q < streams.size() && found < 0; q++) {
@@ -501,7 +509,7 @@ int build_prog(const char *side, int n, const jh_chain_stage *st, int dtype, int
                 found = (int)streams.size();
                 streams.push_back(&g);
             }
-            p.st[s] = (uint32_t)((g.flags & JH_STAGE_CONJ) ? CK_DIAG_CONJ : CK_DIAG) | ((uint32_t)found << 4);
+            p.st[s] = (uint32_t)((g.flags & JH_STAGE_CONJ) ? CK_DIAG_CONJ : CK_DIAG) | ((uint32_t)found << 4) | ((g.flags & JH_STAGE_ROWSUM) ? CK_ROWSUM : 0u);
         } else {
             return jh_fail(JH_ERR_INVALID, "jh_chain_create: unknown stage kind %d", g.kind);
         }

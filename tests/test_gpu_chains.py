@@ -104,13 +104,13 @@ class Rig:
                 cur = [o.child_mul(o.Block("diag", n, coeff=cf, adjoint=bool(tok[2])), np.zeros(n, dt), b) for cf, b in zip(coef, cur)]
             elif tok[0] == "Wb":
                 nxt = []
-                for i, b in enumerate(cur):
-                    if i % 4 == 3:
-                        nxt.append(b.copy())
+                for i, b in enumerate(cur):                                    # a block operator of several columns ACCUMULATES its rows into zeros
+                    if i % 4 == 3:                                             # (src/Jets.jl:1024 `_d .+= mul!(dtmp, ...)`, 1042 / 1049): 0 + product
+                        nxt.append(np.zeros(n, dt) + b)
                     elif i % 7 == 5:
                         nxt.append(np.zeros(n, dt))
                     else:
-                        nxt.append(o.child_mul(o.Block("diag", n, coeff=self.hw[tok[1]][i], adjoint=(i % 3 == 1) != bool(tok[2])), np.zeros(n, dt), b))
+                        nxt.append(np.zeros(n, dt) + o.child_mul(o.Block("diag", n, coeff=self.hw[tok[1]][i], adjoint=(i % 3 == 1) != bool(tok[2])), np.zeros(n, dt), b))
                 cur = nxt
             elif tok[0] == "I":
                 cur = [b.copy() for b in cur]
@@ -501,3 +501,28 @@ def test_a_sum_of_chains_over_many_small_rows(Jets, oracle, dt):
         J.tune(adj_split=-1)
     ra.close()
     rb.close()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_a_block_diagonal_block_operator_stage_accumulates_into_zeros(Jets, oracle, dt):
+    """The sign of a zero (found by tools/fuzz_chains.py).  A block-diagonal BLOCK OPERATOR has several block columns, so the reference accumulates each
+    of its rows into zeros -- `_d .+= mul!(dtmp, op, _m)` (src/Jets.jl:1024), adjoint `_m .= 0; _m .+= ...` (1042 / 1049) -- and a product of -0 becomes
+    +0; a plain diagonal operator (`W`) stores its product and keeps -0.  A zero row of A under a negative scalar makes the -0 (JH_STAGE_ROWSUM)."""
+    from jets_jl_amd import chains
+
+    J = Jets
+    nrow, n = 8, 70
+    rig = Rig(J, oracle, dt, nrow, n, "mixed")                                   # rows of A: diag, diag', identity, scale, ZERO, ...
+    for toks in (["A", ("s", -1.25, "r"), ("Wb", 0, False), ("s", 0.375, "r")], ["A", ("s", -1.25, "r"), ("Wb", 1, True)], ["A", ("s", -1.25, "r"), ("W", 0, False)]):
+        C = rig.compose(toks)
+        hx = [u01(oracle, dt, 91, 0, n)]
+        x = J.from_numpy(hx[0], J.domain(rig.A))
+        y1, y0, ran = _run_both(J, C, x, J.range(C), chains)
+        assert ran == 1
+        want = np.concatenate(rig.ora_apply(toks, hx))
+        assert_bits_equal(y1.to_numpy().ravel(order="F"), y0.to_numpy().ravel(order="F"), f"{toks}: fused vs stage by stage (signs of zeros included)")
+        assert_bits_equal(y1.to_numpy().ravel(order="F"), want, f"{toks}: fused vs the oracle")
+    plain = np.concatenate(rig.ora_apply(["A", ("s", -1.25, "r"), ("W", 0, False)], hx))
+    parts = plain.view(np.float32 if np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4 else np.float64)
+    assert (np.signbit(parts) & (parts == 0)).any(), "the case must contain a -0 under the plain diagonal"
+    rig.close()
