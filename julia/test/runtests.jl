@@ -146,6 +146,48 @@ end
     @test samebits(host((3.14 * A[2]) * m), T.(3.14 .* convert(Array, Ah[2] * mh)))
 end
 
+@testset "composite chains of any depth: one pass per fusable run, the chain's bits ($T)" for T in (Float32, ComplexF64)
+    # round 6 (jh_chain_*): the host twin applies the same composites stage by stage with the reference's own code (src/Jets.jl:524-540)
+    R = HipSpace(T, 10, 9, 7)
+    nrow = 6
+    g = [rand(R) for i = 1:nrow]
+    A = @blockop [JopHipDiagonal(g[i]) for i = 1:nrow, j = 1:1]
+    Ah = @blockop [JopFoo(host(g[i])) for i = 1:nrow, j = 1:1]
+    w = rand(range(A))                                                            # data weights on the block range: one slab
+    wh = Jets.BlockArray([host(getblock(w, i)) for i = 1:nrow], indices(range(Ah)))
+    W = JopHipDiagonal(w)                                                         # a diagonal operator on the BLOCK space (julia/JetsHIP.jl: JopHipDiagonal(::BlockArray))
+    Wh = JopLn(;df! = JopFoo_df!, df′! = JopFoo_df′!, dom = range(Ah), rng = range(Ah), s = (diagonal=wh,))
+    c = rand(domain(A))
+    M, Mh = JopHipDiagonal(c), JopFoo(host(c))
+    m = rand(domain(A))
+    mh = host(m)
+    d = rand(range(A))
+    dh = Jets.BlockArray([host(getblock(d, i)) for i = 1:nrow], indices(range(Ah)))
+    @test samebits(host((A' ∘ W ∘ A) * m), (Ah' ∘ Wh ∘ Ah) * mh)                  # weighted normal equations: JH_CHAIN_NORMAL
+    @test samebits(host((W ∘ A) * m), convert(Array, (Wh ∘ Ah) * mh))             # JH_CHAIN_FORWARD
+    @test samebits(host((W ∘ A)' * d), (Wh ∘ Ah)' * dh)                           # JH_CHAIN_ADJOINT
+    @test samebits(host((M' ∘ A' ∘ W ∘ A ∘ M) * m), (Mh' ∘ Ah' ∘ Wh ∘ Ah ∘ Mh) * mh)
+    S = (A' ∘ W ∘ A) - (M' ∘ A' ∘ A ∘ M)                                          # a sum whose terms are chains: each adds itself in its last stage
+    Sh = (Ah' ∘ Wh ∘ Ah) - (Mh' ∘ Ah' ∘ Ah ∘ Mh)
+    @test samebits(host(S * m), Sh * mh)
+    @test samebits(host(S' * m), Sh' * mh)
+    JetsHIP.close_chains!()
+end
+
+@testset "fused A'A of an N x K grid of diagonals; per-block norms and dots" begin
+    T, N, K = Float32, 5, 3
+    R = HipSpace(T, 33)
+    g = [rand(R) for i = 1:N, j = 1:K]
+    A = @blockop [JopHipDiagonal(g[i, j]) for i = 1:N, j = 1:K]
+    Ah = @blockop [JopFoo(host(g[i, j])) for i = 1:N, j = 1:K]
+    m = rand(domain(A))
+    mh = Jets.BlockArray([host(getblock(m, j)) for j = 1:K], indices(domain(Ah)))
+    @test samebits(host((A' ∘ A) * m), convert(Array, (Ah' ∘ Ah) * mh))           # jh_blockop_normal_mul on a grid (jh_grid_normal.hip): the two stages' bits
+    x, y = rand(range(A)), rand(range(A))
+    @test blocknorms(x, 2) ≈ [norm(host(getblock(x, i))) for i = 1:N] rtol = 1e-5  # one pass (jh_norm_blocks) instead of one reduction per block
+    @test blockdots(x, y) ≈ [dot(host(getblock(x, i)), host(getblock(y, i))) for i = 1:N] rtol = 1e-5
+end
+
 @testset "nonlinear and dense children" begin
     R = HipSpace(Float64, 50)
     F = @blockop [JopHipSquare(R) for i = 1:3, j = 1:1]
