@@ -182,8 +182,10 @@ class ChainHandle:
                     want = nblk * n
                     if st.vec.length() != want:
                         raise JetsHipError(_UNSUPPORTED, f"a diagonal of {st.vec.length()} elements on a side of {want}")
-                    ptrs = (C.c_void_p * n)(*[st.vec.ptr + i * nblk * es for i in builtins.range(n)])
-                    g.coeff = C.cast(ptrs, C.POINTER(C.c_void_p))
+                    # (one pointer per block row of a slab: numpy, not a Python loop -- a composite built anew for every application pays this per call,
+                    # 0.6 us per row as a list comprehension: 21 ms at 32768 rows where the pass itself takes 0.7)
+                    ptrs = np.uint64(st.vec.ptr) + np.arange(n, dtype=np.uint64) * np.uint64(nblk * es)
+                    g.coeff = ptrs.ctypes.data_as(C.POINTER(C.c_void_p))
                     self._keep.append(ptrs)
                 else:                                        # 'rows': the diagonal of a block-diagonal block operator (range side only)
                     if not range_side or len(st.ptrs) != nrow:
