@@ -508,6 +508,7 @@ int jh_blockop_destroy(jh_blockop *op)
         if (op->dev_comb_ptr[dir]) (void)hipFree(op->dev_comb_ptr[dir]);
         if (op->dev_comb_off[dir]) (void)hipFree(op->dev_comb_off[dir]);
     }
+    if (op->bare_chain) (void)jh_chain_destroy(op->bare_chain);
     if (op->twin) (void)jh_blockop_destroy(op->twin);
     jh_handle_died(op->ctx);
     delete op;

@@ -1177,6 +1177,9 @@ int launch_tall_adj_mixed_u(const jh_blockop *op, void *out, const void *in, int
     const int from_found = (MODE == 0) ? c.adj_from_found : 0;                        // continue from what `out` holds (a wide operator's forward)
     int64_t parts = (from_found || s_end - s_begin < NS) ? 1 : pick_adj_parts(gx, op->nrow), rows_per_part = 0;   // many rows of small blocks: split-row walk (not for a range
                                                                                                                   // shorter than one pack: it loads from before its begin)
+    if (MODE == 0 && BLK == 256 && c.adj_thin_mixed && parts == 1 && c.adj_split < 0 && !from_found && s_end - s_begin >= NS && op->nrow >= 256 &&
+        gx >= c.cu_count && gx < 2 * (int64_t)c.cu_count)
+        parts = 2;                                                                                                // (the thin shape at one workgroup per CU: latency-bound in one part)
     const int64_t part_stride = s_end - s_begin;
     void *slabs = nullptr;
     if (parts > 1) {
@@ -1229,7 +1232,12 @@ int launch_tall_adj_mixed(const jh_blockop *op, void *out, const void *in, int64
     // (round 6, tried and dropped: the thin shape whenever 512 x 2 launches fewer than two workgroups per CU -- 256 rows of 2 MiB with an identity row in four: the
     // ordered walk on 512 thin workgroups ran the fused A'A at 4.15 TB/s where the split walk over sixteen row parts, which 512 x 2 falls into there, runs 4.6;
     // profiles/rocprof_r06_thin_summary.md)
-    if ((s_end - s_begin + NS - 1) / NS < 2048 && !(E == 2 && sizeof(S) == 4))
+    // (round 6, kept for the ADJOINT only: rows of 1-8 MiB, where 512 x 2 launches fewer workgroups than the chip has CUs and falls into the split walk although
+    // thin workgroups fill it in one ordered part -- 256 x 2 MiB with an identity row: adjoint 5.42 (16 parts) -> 6.6 TB/s, what the chain kernel of the same
+    // shape showed, tools/exp_chain_vs_mixed.py; two parts when that leaves under two workgroups per CU, as for the chains)
+    const int64_t packs_here = (s_end - s_begin + NS - 1) / NS;
+    const bool thin_fills = MODE == 0 && jh_ctx().adj_thin_mixed && packs_here / 2048 < jh_ctx().cu_count && packs_here / 256 >= jh_ctx().cu_count;
+    if ((packs_here < 2048 || thin_fills) && !(E == 2 && sizeof(S) == 4))
         return launch_tall_adj_mixed_u<S, E, NS, MODE, 256, 1, 4>(op, out, in, n_scalars, s_begin, s_end);
     return launch_tall_adj_mixed_u<S, E, NS, MODE, 512, 2, 2>(op, out, in, n_scalars, s_begin, s_end);
 }
@@ -1267,6 +1275,11 @@ int tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int fmode)
 int tall_adj(const jh_blockop *op, void *out, const void *in, int mode, bool mixed, int64_t first_elem, int64_t end_elem)
 {
     const int64_t n = op->row_len[0];
+    if (mode == 0 && mixed && first_elem == 0 && (end_elem < 0 || end_elem == n)) {        // rows of up to 2 MiB: the chain kernel's packed row records (jh_tall_chain.hip)
+        bool took = false;
+        JH_TRY(bare_chain_adjoint(op, out, in, &took));
+        if (took) return JH_OK;
+    }
 #define JH_CALL(S, E, NS)                                                                                                                    \
     (mode == 0 ? (mixed ? launch_tall_adj_mixed<S, E, NS, 0>(op, out, in, n * E, first_elem * E, end_elem < 0 ? -1 : end_elem * E)           \
                         : launch_tall_adj<S, E, NS, 0>(op, out, in, n * E, first_elem * E, end_elem < 0 ? -1 : end_elem * E))                 \

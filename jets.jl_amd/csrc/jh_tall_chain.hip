@@ -641,3 +641,46 @@ int jh_chain_apply(const jh_chain *ch, jh_bvec *out, const jh_bvec *x, int accum
 }
 
 }  // extern "C"
+
+// ---- the chain kernel as the library's own adjoint of operators with rows of several kinds (round 6) ----------------------------------------------
+// With EMPTY stage lists the ADJOINT chain is m = sum_i conj(a_i) .* d_i -- jh_blockop_mul_adj -- over packed 8-byte row records requested a batch ahead,
+// where k_tall_diag_adj<MIXED> reads a 48-byte block descriptor per row behind a kind switch.  On rows of up to ~2 MiB (one workgroup per CU or the split
+// walk) that is the difference: same box, one identity row among the diagonals, TB/s library | chain kernel: 256 x 2 MiB 5.4-5.8 | 6.2-6.85,
+// 4096 x 1 MiB 5.35-5.64 | 6.8-7.0, 2048 x 512 KiB 5.3-6.1 | 6.1-6.6, 262144 x 513 elements (off the grid) 4.4 | 5.5; from 4 MiB rows on they are
+// level and the fat shapes of k_tall_diag_adj win (tools/exp_chain_vs_mixed.py, profiles/exp_r06_chain_vs_mixed.txt).  Same bits (rows in order from +0);
+// where the rows are summed in parts the part count may differ from k_tall_diag_adj's (tolerance parity either way).
+namespace jhb {
+int bare_chain_adjoint(const jh_blockop *op, void *out, const void *in, bool *took)
+{
+    *took = false;
+    jh_context &c = jh_ctx();
+    const int64_t E = jh_dtype_complex(op->dtype) ? 2 : 1;
+    const int64_t row_bytes = op->row_len[0] * (int64_t)jh_dtype_size(op->dtype);
+    if (!c.adj_bare_chain || op->nrow < 2 || row_bytes < 16 || row_bytes > ((int64_t)2 << 20)) return JH_OK;
+    if (c.adj_from_found || c.adj_in_scale != 1.0 || c.adj_rows_per_launch != 0) return JH_OK;
+    const char *sb = (const char *)c.scratch_dev;
+    if (sb && (const char *)out >= sb && (const char *)out < sb + c.scratch_cap) return JH_OK;   // an output reserved behind split_adjoint_tmp's slabs: that route's part count
+    if (!op->bare_chain || op->bare_chain->op_gen != op->table_gen) {
+        if (stream_is_capturing(c.stream)) return JH_OK;                                          // (building or refreshing the row table copies to the device)
+        if (!op->bare_chain) {
+            jh_chain *ch = nullptr;
+            const int st = jh_chain_create(op, JH_CHAIN_ADJOINT, 0, nullptr, 0, nullptr, 0, nullptr, &ch);
+            if (st == JH_ERR_UNSUPPORTED) return JH_OK;
+            JH_TRY(st);
+            op->bare_chain = ch;
+        } else {
+            JH_TRY(chain_sync_rows(op->bare_chain));
+        }
+    }
+    *took = true;
+    const jh_chain *ch = op->bare_chain;
+    const int64_t n = op->row_len[0];
+    switch (op->dtype) {
+    case JH_F32: return launch_chain_adj<float, 1, 4, 0>(ch, out, in, n * E, 0);
+    case JH_F64: return launch_chain_adj<double, 1, 2, 0>(ch, out, in, n * E, 0);
+    case JH_C32: return launch_chain_adj<float, 2, 4, 0>(ch, out, in, n * E, 0);
+    case JH_C64: return launch_chain_adj<double, 2, 2, 0>(ch, out, in, n * E, 0);
+    }
+    return jh_fail(JH_ERR_INVALID, "bare_chain_adjoint: unknown dtype %d", op->dtype);
+}
+}  // namespace jhb
