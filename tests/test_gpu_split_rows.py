@@ -433,3 +433,29 @@ def test_fused_adjoint_update_and_jetsum_adjoint_split_walk_off_the_pack_grid(Je
     assert_bits_equal(ms2.to_numpy().ravel(order="F"), gs, "JetSum adjoint through the split walk, second run")
     J.close(A)
     J.close(B)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,n", [(3, 70), (9, 1027), (33, 4096), (17, 20001)])
+def test_mixed_adjoint_on_the_chain_kernel_and_on_the_tall_kernel_agree_bit_for_bit(Jets, oracle, dt, nrow, n):
+    """Round 6: the adjoint of a tall operator with rows of several kinds (or rows off the 16-byte grid) of up to 2 MiB runs the chain kernel with empty
+    stage lists (jh_tall_chain.hip: bare_chain_adjoint; knob adj_bare_chain); with the knob off it is k_tall_diag_adj<MIXED> as in rounds 2-5.  Both sum
+    the rows in order from +0: the same bits, and the oracle's (src/Jets.jl:1042-1049).  A dirty output, zero / identity / scalar / adjointed rows."""
+    from .test_gpu_blockop import _mixed_ops
+
+    J = Jets
+    names = ["diag", "diag_adj", "identity", "scale", "zero"]
+    kinds = [[names[(3 * i + i // 5) % 5]] for i in range(nrow)]
+    A, ora = _mixed_ops(J, oracle, dt, kinds, [n] * nrow, [n], seed=33)
+    hd = [u01(oracle, dt, 92, i, n) for i in range(nrow)]
+    d = J.from_numpy(np.concatenate(hd), J.range(A))
+    want = oracle.block_df_adj(ora, [np.full(n, 7, dt)], hd)[0]
+    got = {}
+    for knob in (1, 0):
+        J.tune(adj_bare_chain=knob)
+        try:
+            got[knob] = J.mul_(J.rand(J.domain(A), seed=5, stream=knob), A.H, d).to_numpy().ravel(order="F")
+        finally:
+            J.tune(adj_bare_chain=1)
+        assert_bits_equal(got[knob], want, f"adj_bare_chain={knob}: adjoint vs the oracle")
+    J.close(A)
