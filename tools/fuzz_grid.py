@@ -2,7 +2,7 @@
 """Fuzz of the routes for M x K operators of plain diagonals: the register-tiled k_grid_tile with 2 / 4 / 8 lines per workgroup (knob
 grid_tile; round 3), k_grid_diag with 1 / 2 / 4 packs per lane (knob grid_diag), wide
 operators through their tall twin in both directions (knob wide_twin = 2) -- random shapes, block lengths (16-byte multiples), four
-eltypes, dirty outputs; forward and adjoint bit-exact vs the CPU oracle's loops.      python tools/fuzz_grid.py NCASES [SEED0]"""
+eltypes, dirty outputs; forward and adjoint (and, round 6, the fused A'A of N x (2 .. 4) grids) bit-exact vs the CPU oracle's loops.      python tools/fuzz_grid.py NCASES [SEED0]"""
 import os
 import sys
 import time
@@ -49,6 +49,14 @@ for case in range(seed0, seed0 + ncases):
         tag = f"case {case}: {np.dtype(dt).name} {M}x{K} n={n} grid_diag={gd} wide_twin={wt} grid_tile={gt}"
         assert_bits_equal(d.to_numpy(), np.concatenate(want_d), tag + " forward")
         assert_bits_equal(mt.to_numpy().ravel(order="F") if K == 1 else mt.to_numpy(), np.concatenate(want_m), tag + " adjoint")
+    if M >= 2 and 2 <= K <= 4:                                        # round 6: the fused A'A of N x (2 .. 4) grids (jh_grid_normal.hip): the two stages' bits
+        J.tune(grid_diag=1, wide_twin=1, grid_tile=1, adj_split=0)
+        t = oracle.block_df(ops, [np.zeros(n, dt) for _ in range(M)], hm)
+        want_y = oracle.block_df_adj(ops, [np.zeros(n, dt) for _ in range(K)], t)
+        m = J.from_numpy(np.concatenate(hm), J.domain(A))
+        y = J.mul_(J.from_numpy(np.concatenate(hmt), J.domain(A)), J.compose(A.H, A), m)      # (a dirty output)
+        assert_bits_equal(y.to_numpy(), np.concatenate(want_y), f"case {case}: {np.dtype(dt).name} {M}x{K} n={n} fused A'A")
+        stats["normal"] = stats.get("normal", 0) + 1
     J.tune(grid_diag=1, wide_twin=1, grid_tile=1, adj_split=-1)
     J.close(A)
     if (case - seed0 + 1) % 200 == 0:
