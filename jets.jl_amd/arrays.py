@@ -585,7 +585,7 @@ def norm_blocks(x: _DevVec, p: float = 2) -> np.ndarray:
     out = (C.c_double * nb)()
     check(lib.jh_norm_blocks(x.handle, float(p), out))
     real_t = np.float32 if x.dtype in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
-    return np.array(out[:], dtype=np.float64).astype(real_t)
+    return np.ctypeslib.as_array(out).astype(real_t)                          # (no Python list of nblocks floats on the way: 50 ns per block)
 
 
 def dot_blocks(x: _DevVec, y: _DevVec) -> np.ndarray:
@@ -594,8 +594,8 @@ def dot_blocks(x: _DevVec, y: _DevVec) -> np.ndarray:
     re, im = (C.c_double * nb)(), (C.c_double * nb)()
     check(lib.jh_dot_blocks(x.handle, y.handle, re, im))
     if x.dtype.kind == "c":
-        return (np.array(re[:]) + 1j * np.array(im[:])).astype(x.dtype)
-    return np.array(re[:]).astype(x.dtype)
+        return (np.ctypeslib.as_array(re) + 1j * np.ctypeslib.as_array(im)).astype(x.dtype)
+    return np.ctypeslib.as_array(re).astype(x.dtype)
 
 
 def extrema(x: _DevVec):

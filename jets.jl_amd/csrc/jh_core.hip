@@ -986,6 +986,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "sum_adj_group")) { c.sum_adj_group = value == 16 ? 16 : 8; }
     else if (!strcmp(name, "grid_diag")) { JH_REQUIRE(value >= 0 && value <= 4, "grid_diag must be 0 (general kernels), 1, 2 or 4 (packs per lane)"); c.grid_diag = value; }
     else if (!strcmp(name, "tall_f")) { JH_REQUIRE(value >= 0 && value <= 1, "tall_f must be 0 or 1"); c.tall_f = value; }
+    else if (!strcmp(name, "red_blocks_wave")) { c.red_blocks_wave = value ? 1 : 0; }
     else if (!strcmp(name, "adj_bare_chain")) { c.adj_bare_chain = value ? 1 : 0; }
     else if (!strcmp(name, "adj_thin_mixed")) { c.adj_thin_mixed = value ? 1 : 0; }
     else if (!strcmp(name, "grid_normal")) { c.grid_normal = value ? 1 : 0; }
@@ -1067,6 +1068,7 @@ int jh_tune_get(const char *name, int64_t *value)
     else if (!strcmp(name, "last_dense_fused")) *value = c.last_dense_fused;
     else if (!strcmp(name, "last_launches")) *value = c.last_launches;
     else if (!strcmp(name, "tall_unaligned")) *value = c.tall_unaligned;
+    else if (!strcmp(name, "red_blocks_wave")) *value = c.red_blocks_wave;
     else if (!strcmp(name, "adj_bare_chain")) *value = c.adj_bare_chain;
     else if (!strcmp(name, "adj_thin_mixed")) *value = c.adj_thin_mixed;
     else if (!strcmp(name, "grid_normal")) *value = c.grid_normal;

@@ -137,6 +137,7 @@ struct jh_context {
     int64_t tall_f = 1;                // knob: F(m) of a tall nonlinear operator of elementwise children on the tall tiling (jh_blockop_f): 1 yes, 0 the general kernels
     int64_t ua_nt = -1;                // knob: accesses of the tall kernels on rows off the 16-byte grid: -1 temporal there, nontemporal on aligned rows; 0 / 1 temporal / nontemporal always
     int64_t tall_unaligned = 1;        // knob: tall operators whose rows are not whole, 16-byte aligned packs (odd block lengths in one slab) on the under-aligned tall kernels (jh_tall.hip: tall_unaligned_ok); 0: the general kernels as before
+    int64_t red_blocks_wave = 1;       // knob: per-block reductions of many short blocks with a wave per block (k_reduce_blocks_wave); 0: a workgroup per block
     int64_t adj_bare_chain = 1;        // knob: jh_blockop_mul_adj of tall operators with rows of several kinds / off the 16-byte grid on the chain kernel (rows up to 2 MiB); 0: k_tall_diag_adj<MIXED>
     int64_t adj_thin_mixed = 1;        // knob: the MIXED tall adjoint on thin workgroups when the fat shape would not fill the chip (rows of 1-8 MiB); 0: round 5's rule
     int64_t grid_normal = 1;           // knob: (A', A) on an N x (2 .. 4) grid of equal diagonals in one pass (jh_grid_normal.hip); 0: JH_ERR_UNSUPPORTED as in rounds 1-5 (the caller chains the two stages)

@@ -538,6 +538,38 @@ __global__ void k_reduce_blocks(const S *__restrict__ x, const S *__restrict__ y
     block_reduce_store<OP>(a0, a1, partials);
 }
 
+// Many SHORT blocks (traces rather than volumes: per-trace norms): a workgroup per block is a launch slot, a tree and a barrier for a few hundred bytes --
+// 262144 blocks of 2 KiB took 6.5 ms where the whole-vector norm takes 0.12.  Here a WAVE owns a block (four blocks per workgroup): lanes stride over its
+// packs, the odd tail scalars ride with the first lanes, a shuffle tree, lane 0 writes the block's result -- no partials, no second launch, no barrier.
+template <typename S, int E, int NS, int OP>
+__global__ __launch_bounds__(WG) void k_reduce_blocks_wave(const S *__restrict__ x, const S *__restrict__ y, const int64_t *__restrict__ off, int64_t nblocks, double p,
+                                                           double *__restrict__ out)
+{
+    const int64_t b = (int64_t)blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+    if (b >= nblocks) return;                                                 // (whole waves leave: no barrier below)
+    const int lane = threadIdx.x & 63;
+    const int64_t e0 = off[b], e1 = off[b + 1];
+    const S *xb = x + e0 * E, *yb = (OP == RED_DOT) ? y + e0 * E : x;
+    const int64_t n_scalars = (e1 - e0) * E, nvec = n_scalars / NS;
+    double a0, a1;
+    red_init<OP>(a0, a1);
+    for (int64_t v = lane; v < nvec; v += 64) {
+        Pack<S, NS> xv = ldnt(reinterpret_cast<const Pack<S, NS> *>(xb) + v), yv;
+        if (OP == RED_DOT) yv = ldnt(reinterpret_cast<const Pack<S, NS> *>(yb) + v);
+#pragma unroll
+        for (int e = 0; e < NS; e += E) red_elem<S, E, OP>(&xv.v[e], &yv.v[e], p, 1.0, a0, a1);
+    }
+    const int64_t tail0 = nvec * NS, ntail_elems = (n_scalars - tail0) / E;
+    if (lane < ntail_elems) red_elem<S, E, OP>(xb + tail0 + lane * E, yb + tail0 + lane * E, p, 1.0, a0, a1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double b0 = __shfl_down(a0, o, 64);
+        double b1 = __shfl_down(a1, o, 64);
+        red_combine<OP>(a0, a1, b0, b1);
+    }
+    if (lane == 0) { out[2 * b] = a0; out[2 * b + 1] = a1; }
+}
+
 template <int OP>
 __global__ void k_reduce_blocks_final(const double *__restrict__ partials, int cpb, int64_t nblocks, double *__restrict__ out)
 {
@@ -570,6 +602,15 @@ int reduce_blocks_launch(const jh_bvec *x, const jh_bvec *y, double p, double *h
     JH_TRY(jh_ensure_scratch((size_t)(nb + 1) * sizeof(int64_t), &offs));
     JH_CHECK_HIP(hipMemcpyAsync(offs, x->off.data(), (size_t)(nb + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c.stream));
     double *partials = c.part_dev, *results = c.part_dev + 2 * nb * cpb;
+    // many short blocks (at most 16 packs per lane of a wave: 16 KiB) and enough of them to fill the chip with waves: a wave per block, one launch
+    if (cpb == 1 && longest * E / NSV <= 64 * 16 && nb >= 4 * (int64_t)c.cu_count && c.red_blocks_wave) {
+        hipLaunchKernelGGL((k_reduce_blocks_wave<S, E, NSV, OP>), dim3((unsigned)((nb + WG / 64 - 1) / (WG / 64))), dim3(WG), 0, c.stream, (const S *)x->data,
+                           (const S *)(y ? y->data : x->data), (const int64_t *)offs, nb, p, results);
+        JH_CHECK_HIP(hipGetLastError());
+        JH_CHECK_HIP(hipMemcpyAsync(host_out, results, (size_t)(2 * nb) * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        JH_CHECK_HIP(hipStreamSynchronize(c.stream));
+        return JH_OK;
+    }
     hipLaunchKernelGGL((k_reduce_blocks<S, E, NSV, OP>), dim3((unsigned)(nb * cpb)), dim3(WG), 0, c.stream, (const S *)x->data,
                        (const S *)(y ? y->data : x->data), (const int64_t *)offs, (int)cpb, p, partials);
     JH_CHECK_HIP(hipGetLastError());

@@ -381,3 +381,38 @@ def test_norm_blocks_rescales_a_block_whose_squares_leave_the_double_range(Jets)
     x = J.from_numpy(h, R)
     got = J.norm_blocks(x, 2)
     assert np.allclose(got, [10.0, 1e201, 1e-199], rtol=1e-12)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_per_block_reductions_of_many_short_blocks(Jets, oracle, dt):
+    """Thousands of short ragged blocks (traces rather than volumes; some empty): a wave per block in one launch (k_reduce_blocks_wave) -- against the fp64 truth
+    per block and against the workgroup-per-block kernels (knob red_blocks_wave = 0) within the reductions' tolerance."""
+    J = Jets
+    rng = np.random.default_rng(5)
+    lens = [int(v) for v in rng.integers(0, 700, size=1500)]
+    lens[7] = 0
+    lens[8] = 4096 // (np.dtype(dt).itemsize // 4)                                 # (the longest block the wave kernel takes: 16 KiB)
+    R = J.JetBSpace([J.JetSpace(dt, n) for n in lens])
+    x, y = J.rand(R, seed=31, stream=1), J.rand(R, seed=32, stream=2)
+    hx, hy = x.to_numpy(), y.to_numpy()
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    tol = 1e-5 if np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-12
+    wide = np.complex128 if np.dtype(dt).kind == "c" else np.float64
+    ax = np.abs(hx.astype(wide))
+    for p in (2, 1, 0, np.inf, -np.inf, 3):
+        got = J.norm_blocks(x, p).astype(np.float64)
+        J.tune(red_blocks_wave=0)
+        try:
+            other = J.norm_blocks(x, p).astype(np.float64)
+        finally:
+            J.tune(red_blocks_wave=1)
+        want = np.zeros(len(lens))
+        for i in range(len(lens)):
+            ab = ax[offs[i]:offs[i + 1]]
+            if ab.size:
+                want[i] = ab.max() if p == np.inf else ab.min() if p == -np.inf else np.count_nonzero(ab) if p == 0 else ab.sum() if p == 1 else (ab ** p).sum() ** (1.0 / p)
+        assert np.all(np.abs(got - want) <= tol * np.maximum(np.abs(want), 1e-30)), f"p={p}: wave per block vs the truth"
+        assert np.all(np.abs(got - other) <= tol * np.maximum(np.abs(want), 1e-30)), f"p={p}: wave per block vs workgroup per block"
+    gd = J.dot_blocks(x, y)
+    want = np.array([np.vdot(hx[offs[i]:offs[i + 1]].astype(np.complex128), hy[offs[i]:offs[i + 1]].astype(np.complex128)) for i in range(len(lens))])
+    assert np.all(np.abs(gd.astype(np.complex128) - want) <= tol * np.maximum(np.abs(want), 1e-30))
