@@ -218,16 +218,22 @@ class DeviceArray(_DevVec):
 class BlockArray(_DevVec):
     """Jets.BlockArray (src/Jets.jl:809-812) backed by one HIP slab."""
 
-    def __init__(self, handle, spaces: Sequence[JetAbstractSpace], dtype, owner=None):
+    def __init__(self, handle, spaces: Sequence[JetAbstractSpace], dtype, owner=None, indices=None):
         self._h = handle
-        self.spaces = list(spaces)
         self._dtype = np.dtype(dtype)
-        self.indices = []
-        stop = 0
-        for s in self.spaces:
-            self.indices.append(builtins.range(stop, stop + s.length()))
-            stop += s.length()
-        self._length = stop
+        if indices is not None:
+            # the block ranges of the JetBSpace this vector lives in, shared (never mutated): a vector of 16 384 blocks no longer walks them again --
+            # 18 ms per zeros(range(A)) of a composite's stage, every call, where the stage's kernels take 2.5 (tools/micro/prof_comp.py)
+            self.spaces, self.indices = spaces, indices
+            self._length = indices[-1].stop if indices else 0
+        else:
+            self.spaces = list(spaces)
+            self.indices = []
+            stop = 0
+            for s in self.spaces:
+                self.indices.append(builtins.range(stop, stop + s.length()))
+                stop += s.length()
+            self._length = stop
         self._owner = owner
         self._views = None
 
@@ -302,11 +308,11 @@ ROLE_OUTPUT, ROLE_DATA = 1, 2      # what a big vector is for (knob alloc_role):
 _ROLE_FROM_BYTES = 4 << 30
 
 
-def _new_handle(block_lens: Sequence[int], T, undef: bool = False, role: int = 0) -> C.c_void_p:
+def _new_handle(block_lens: Sequence[int], T, undef: bool = False, role: int = 0, lens_c=None) -> C.c_void_p:
     _device.init()
     h = C.c_void_p()
     create = lib.jh_bvec_create_uninit if undef else lib.jh_bvec_create
-    lens = _i64arr(block_lens)
+    lens = lens_c if lens_c is not None else _i64arr(block_lens)
     # vectors of 4 GiB and more: the library's slab cache may hold several slabs of this size, and which of them is fast to WRITE is a
     # property of the slab it has measured (include/jetship.h, knob alloc_role) -- say what this one is for
     hint = role != 0 and builtins.sum(block_lens) * np.dtype(T).itemsize >= _ROLE_FROM_BYTES
@@ -335,7 +341,7 @@ def Array(R: JetAbstractSpace, undef: bool = False, role: int = 0):
 
         return zeros_sym(R)
     if isinstance(R, JetBSpace):
-        return BlockArray(_new_handle(R.block_lengths(), R.eltype(), undef, role), R.spaces, R.eltype())
+        return BlockArray(_new_handle(R.block_lengths(), R.eltype(), undef, role, lens_c=R.block_lengths_c()), R.spaces, R.eltype(), indices=R.indices)
     return DeviceArray(_new_handle([R.length()], R.eltype(), undef, role), R.size(), R.eltype())
 
 
@@ -677,7 +683,7 @@ def reshape(x, R):
             raise ValueError("dimension mismatch, unable to reshape array into block space")
         h = C.c_void_p()
         check(lib.jh_bvec_wrap(C.c_void_p(x.ptr), R.nblocks(), _i64arr(R.block_lengths()), dtype_code(x.dtype), C.byref(h)))
-        return BlockArray(h, R.spaces, x.dtype, owner=x)  # :1112 views of x
+        return BlockArray(h, R.spaces, x.dtype, owner=x, indices=R.indices)  # :1112 views of x
     if isinstance(x, BlockArray):
         if x.length() != R.length():
             raise ValueError("dimension mismatch in reshape")

@@ -147,7 +147,20 @@ class JetBSpace(JetAbstractSpace):
         return len(self.spaces)
 
     def block_lengths(self) -> list[int]:
-        return [len(r) for r in self.indices]
+        lens = getattr(self, "_lens", None)
+        if lens is None:
+            lens = self._lens = [len(r) for r in self.indices]      # (a space is immutable: computed once -- every zeros(R) asks)
+        return lens
+
+    def block_lengths_c(self):
+        """The same as a ctypes int64 array (what jh_bvec_create takes), built once."""
+        arr = getattr(self, "_lens_c", None)
+        if arr is None:
+            import ctypes as _C
+
+            lens = self.block_lengths()
+            arr = self._lens_c = (_C.c_int64 * len(lens))(*lens)
+        return arr
 
     def __eq__(self, other):  # :753
         return isinstance(other, JetBSpace) and self.spaces == other.spaces and self.indices == other.indices
