@@ -223,7 +223,7 @@ class BlockArray(_DevVec):
         self._dtype = np.dtype(dtype)
         if indices is not None:
             # the block ranges of the JetBSpace this vector lives in, shared (never mutated): a vector of 16 384 blocks no longer walks them again --
-            # 18 ms per zeros(range(A)) of a composite's stage, every call, where the stage's kernels take 2.5 (tools/micro/prof_comp.py)
+            # 18 ms per zeros(range(A)) of a composite's stage, every call, where the stage's kernels take 2.5 (tools/prof_host.py)
             self.spaces, self.indices = spaces, indices
             self._length = indices[-1].stop if indices else 0
         else:

@@ -537,7 +537,7 @@ def overwrites_its_whole_range(A) -> bool:
     if ops.shape[1] != 1:
         return False
     # (the answer is a property of the children's KINDS, fixed when the operator is built: remembered in its state -- `A * m` asks on every call, and
-    # walking 65 536 children cost 17 ms per call where the forward takes 0.09; tools/micro/prof_host.py)
+    # walking 65 536 children cost 17 ms per call where the forward takes 0.09; tools/prof_host.py)
     memo = A.jet.s.get("_overwrites")
     if memo is not None:
         return memo
