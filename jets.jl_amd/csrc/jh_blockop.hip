@@ -508,7 +508,8 @@ int jh_blockop_destroy(jh_blockop *op)
         if (op->dev_comb_ptr[dir]) (void)hipFree(op->dev_comb_ptr[dir]);
         if (op->dev_comb_off[dir]) (void)hipFree(op->dev_comb_off[dir]);
     }
-    if (op->bare_chain) (void)jh_chain_destroy(op->bare_chain);
+    for (int k = 0; k < 2; k++)
+        if (op->bare_chain[k]) (void)jh_chain_destroy(op->bare_chain[k]);
     if (op->twin) (void)jh_blockop_destroy(op->twin);
     jh_handle_died(op->ctx);
     delete op;

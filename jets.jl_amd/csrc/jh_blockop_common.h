@@ -162,7 +162,7 @@ bool tall_unaligned_ok(const jh_blockop *op, const void *rng_ptr, const void *do
 TallShape pick_adj_shape(int64_t nvec, int64_t nrow, int mode);
 int64_t pick_adj_parts(int64_t gx, int64_t nrow);
 // ---- jh_tall_chain.hip
-int bare_chain_adjoint(const jh_blockop *op, void *out, const void *in, bool *took);   // the ADJOINT chain kernel with empty stage lists as jh_blockop_mul_adj of mixed / off-grid rows up to 2 MiB
+int bare_chain(const jh_blockop *op, void *out, const void *in, int mode, bool *took);   // the ADJOINT (mode 0) / NORMAL (1) chain kernel with empty stage lists as jh_blockop_mul_adj / _normal_mul of mixed / off-grid rows up to 4 MiB
 // ---- jh_grid_normal.hip
 bool grid_normal_ok(const jh_blockop *op, const void *y, const void *m);   // an N x (2 .. 4) grid of equal plain diagonals
 int grid_normal(const jh_blockop *op, void *y, const void *m);             // y = A'(A m) in one pass, the two-stage chain's bits

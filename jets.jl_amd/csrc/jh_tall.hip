@@ -246,6 +246,29 @@ __global__ __launch_bounds__(BLK) void k_tall_diag_adj(const jh_dev_block *__res
                 blk[j] = nxt[j];
                 nxt[j] = blocks[ahead + j];
             }
+            // Round 6: a batch of PLAIN diagonals (what almost every batch of such an operator is -- [A; lambda I] has one special row) takes the all-diagonal
+            // kernel's tight loop; the per-row kind switch below is what held these instantiations 20-30 % under the all-diagonal ones on rows of a few MiB
+            // (one workgroup per CU: nothing hides the issue slots) -- fused A'A, one identity row: 256 x 2 MiB 4.9 -> 6.7 TB/s (profiles/exp_r06_chain_vs_mixed.txt)
+            bool plain = true;
+#pragma unroll
+            for (int j = 0; j < DEPTH; j++) plain = plain && blk[j].kind == JH_OP_DIAG && !blk[j].adjoint;
+            if (plain) {
+#pragma unroll
+                for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+                    for (int k = 0; k < U; k++) {
+                        av[j][k] = ldu<NT, S, NS>((const S *)blk[j].coeff + sk[k]);
+                        if (MODE == 0) dv[j][k] = (V)in_scale * ldu<NT, S, NS>(in + (i + j) * n_scalars + sk[k]);
+                    }
+#pragma unroll
+                for (int j = 0; j < DEPTH; j++)
+#pragma unroll
+                    for (int k = 0; k < U; k++) {
+                        const V t = (MODE == 0) ? dv[j][k] : vmul<S, E, NS, V>(av[j][k], mv[k], false);
+                        acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], t, true);
+                    }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < DEPTH; j++) {
                 const bool on = blk[j].kind != JH_OP_ZERO, rc = block_reads_coeff(blk[j], false);
@@ -1275,9 +1298,9 @@ int tall_fwd_mixed(const jh_blockop *op, void *d, const void *m, int fmode)
 int tall_adj(const jh_blockop *op, void *out, const void *in, int mode, bool mixed, int64_t first_elem, int64_t end_elem)
 {
     const int64_t n = op->row_len[0];
-    if (mode == 0 && mixed && first_elem == 0 && (end_elem < 0 || end_elem == n)) {        // rows of up to 2 MiB: the chain kernel's packed row records (jh_tall_chain.hip)
+    if (mixed && first_elem == 0 && (end_elem < 0 || end_elem == n)) {                     // rows of up to 4 MiB: the chain kernels' packed row records (jh_tall_chain.hip)
         bool took = false;
-        JH_TRY(bare_chain_adjoint(op, out, in, &took));
+        JH_TRY(bare_chain(op, out, in, mode, &took));
         if (took) return JH_OK;
     }
 #define JH_CALL(S, E, NS)                                                                                                                    \

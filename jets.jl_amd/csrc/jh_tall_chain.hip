@@ -175,36 +175,39 @@ int jh_chain_apply(const jh_chain *ch, jh_bvec *out, const jh_bvec *x, int accum
 
 }  // extern "C"
 
-// ---- the chain kernel as the library's own adjoint of operators with rows of several kinds (round 6) ----------------------------------------------
-// With EMPTY stage lists the ADJOINT chain is m = sum_i conj(a_i) .* d_i -- jh_blockop_mul_adj -- over packed 8-byte row records requested a batch ahead,
+// ---- the chain kernels as the library's own adjoint / fused A'A of operators with rows of several kinds (round 6) -----------------------------------
+// With EMPTY stage lists the ADJOINT chain is m = sum_i conj(a_i) .* d_i -- jh_blockop_mul_adj --, the NORMAL chain jh_blockop_normal_mul, over packed 8-byte row records requested a batch ahead,
 // where k_tall_diag_adj<MIXED> reads a 48-byte block descriptor per row behind a kind switch.  On rows of up to ~2 MiB (one workgroup per CU or the split
 // walk) that is the difference: same box, one identity row among the diagonals, TB/s library | chain kernel: 256 x 2 MiB 5.4-5.8 | 6.2-6.85,
 // 4096 x 1 MiB 5.35-5.64 | 6.8-7.0, 2048 x 512 KiB 5.3-6.1 | 6.1-6.6, 262144 x 513 elements (off the grid) 4.4 | 5.5; from 4 MiB rows on they are
-// level and the fat shapes of k_tall_diag_adj win (tools/exp_chain_vs_mixed.py, profiles/exp_r06_chain_vs_mixed.txt).  Same bits (rows in order from +0);
+// level and the fat shapes of k_tall_diag_adj win (tools/exp_chain_vs_mixed.py, profiles/exp_r06_chain_vs_mixed.txt).  Later in the round both kernels learnt to run a
+// batch of PLAIN diagonals through the all-diagonal kernel's tight loop (the per-row kind switch was the cost): the adjoints drew level, and the fused A'A of the chain
+// kernel pulled ahead -- one identity row: 256 x 2 MiB 5.2 | 6.6-6.7, 1024 x 1 MiB 5.8 | 6.7-7.0, 1024 x 4 MiB 6.2 | 6.95 -- so rows of up to 4 MiB take it for both.  Same bits (rows in order from +0);
 // where the rows are summed in parts the part count may differ from k_tall_diag_adj's (tolerance parity either way).
 namespace jhb {
-int bare_chain_adjoint(const jh_blockop *op, void *out, const void *in, bool *took)
+int bare_chain(const jh_blockop *op, void *out, const void *in, int mode, bool *took)
 {
     *took = false;
     jh_context &c = jh_ctx();
     const int64_t row_bytes = op->row_len[0] * (int64_t)jh_dtype_size(op->dtype);
-    if (!c.adj_bare_chain || op->nrow < 2 || row_bytes < 16 || row_bytes > ((int64_t)2 << 20)) return JH_OK;
-    if (c.adj_from_found || c.adj_in_scale != 1.0 || c.adj_rows_per_launch != 0) return JH_OK;
+    if (!c.adj_bare_chain || op->nrow < 2 || row_bytes < 16 || row_bytes > ((int64_t)4 << 20)) return JH_OK;
+    if (c.adj_rows_per_launch != 0 || (mode == 0 && (c.adj_from_found || c.adj_in_scale != 1.0))) return JH_OK;
     const char *sb = (const char *)c.scratch_dev;
     if (sb && (const char *)out >= sb && (const char *)out < sb + c.scratch_cap) return JH_OK;   // an output reserved behind split_adjoint_tmp's slabs: that route's part count
-    if (!op->bare_chain || op->bare_chain->op_gen != op->table_gen) {
+    jh_chain *&slot = op->bare_chain[mode ? 1 : 0];
+    if (!slot || slot->op_gen != op->table_gen) {
         if (stream_is_capturing(c.stream)) return JH_OK;                                          // (building or refreshing the row table copies to the device)
-        if (!op->bare_chain) {
+        if (!slot) {
             jh_chain *ch = nullptr;
-            const int st = jh_chain_create(op, JH_CHAIN_ADJOINT, 0, nullptr, 0, nullptr, 0, nullptr, &ch);
+            const int st = jh_chain_create(op, mode ? JH_CHAIN_NORMAL : JH_CHAIN_ADJOINT, 0, nullptr, 0, nullptr, 0, nullptr, &ch);
             if (st == JH_ERR_UNSUPPORTED) return JH_OK;
             JH_TRY(st);
-            op->bare_chain = ch;
+            slot = ch;
         } else {
-            JH_TRY(chain_sync_rows(op->bare_chain));
+            JH_TRY(chain_sync_rows(slot));
         }
     }
     *took = true;
-    return chain_launch_adjoint(op->bare_chain, out, in, 0);
+    return mode ? chain_launch_normal(slot, out, in, 0) : chain_launch_adjoint(slot, out, in, 0);
 }
 }  // namespace jhb

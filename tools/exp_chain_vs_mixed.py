@@ -41,6 +41,15 @@ def case(nrow, n, special):
     p1 = J.tune_get("last_adj_parts")
     c_n, c_a = timed(lambda: hn.apply(y, m)), timed(lambda: ha.apply(y, d))
     p2 = J.tune_get("last_adj_parts")
+    t_f = timed(lambda: J.mul_(d, A, m))
+    out = __import__("ctypes").c_double(0)
+    from jets_jl_amd import jetblock as _blk
+    from jets_jl_amd._ffi import lib
+    nat = _blk._native_op(A.jet.s["_native"], A.jet.s["ops"], A.jet.rng.eltype())
+    w = J.zeros(spc)
+    st = lib.jh_blockop_bidiag_step(nat.handle, d.handle, m.handle, w.handle, 1.0, -0.5, __import__("ctypes").byref(out))
+    t_s = timed(lambda: lib.jh_blockop_bidiag_step(nat.handle, d.handle, m.handle, w.handle, 1.0, -0.5, __import__("ctypes").byref(out))) if st == 0 else float("nan")
+    print(f"{'':30s} forward {2 * Nn / t_f / 1e9:5.2f} TB/s   one-pass step {3 * Nn / t_s / 1e9:5.2f} TB/s", flush=True)
     print(f"{nrow:6d} x {n:9d}, {special} identity rows: A'A library {Nn / t_n / 1e9:5.2f} TB/s | chain kernel {Nn / c_n / 1e9:5.2f}     "
           f"adjoint library {2 * Nn / t_a / 1e9:5.2f} ({p1} parts) | chain kernel {2 * Nn / c_a / 1e9:5.2f} ({p2} parts)", flush=True)
     hn.close(); ha.close(); J.close(A)
