@@ -271,14 +271,18 @@ __global__ __launch_bounds__(BLK) void k_chain_adj(const jh_dev_block *__restric
         constexpr int D = decltype(depth_tag)::value;
         const auto &e = rec.w;
         V av[D][U], dv[D][U], wv[D][U][NWA];
-        if constexpr (NW == 0) {
-            // a batch of PLAIN diagonals (kind DIAG, not adjointed: almost every batch of any operator) with no range-side list takes the all-diagonal kernel's
-            // tight loop -- the per-row kind switch of chain_apply_row was what held the bare NORMAL chain at 5.0 TB/s on rows of a few MiB where the strided
-            // all-diagonal kernel runs 6.8 (one workgroup per CU: nothing hides the issue slots): 256 x 2 MiB 4.98 -> 6.7-6.8, 1024 x 1 MiB 4.8 -> 7.0,
-            // 4096 x 1 MiB 5.3 -> 7.3 (profiles/exp_r06_chain_vs_mixed.txt).  Same arithmetic, same order: the same bits.
-            bool plain = (ca.mid.st[0] & 15u) == CK_NONE;
+        {
+            // a batch of PLAIN diagonals (kind DIAG, not adjointed: almost every batch of any operator) takes the all-diagonal kernel's tight loop -- the per-row
+            // kind switch of chain_apply_row was what held the bare NORMAL chain at 5.0 TB/s on rows of a few MiB where the strided all-diagonal kernel runs 6.8
+            // (one workgroup per CU: nothing hides the issue slots): 256 x 2 MiB 4.98 -> 6.7-6.8, 1024 x 1 MiB 4.8 -> 7.0, 4096 x 1 MiB 5.3 -> 7.3
+            // (profiles/exp_r06_chain_vs_mixed.txt).  With range-side weights: plain weight rows too (a pointer, no flag).  Same arithmetic, same order: the same bits.
+            bool plain = true;
 #pragma unroll
-            for (int j = 0; j < D; j++) plain = plain && ((e[j][0] >> 48) & 0xFu) == (uint64_t)JH_OP_DIAG;
+            for (int j = 0; j < D; j++) {
+                plain = plain && ((e[j][0] >> 48) & 0xFu) == (uint64_t)JH_OP_DIAG;
+#pragma unroll
+                for (int w = 0; w < NW; w++) plain = plain && (e[j][1 + w] & CR_PTR) != 0 && (e[j][1 + w] >> 48) == 0;
+            }
             if (plain) {
 #pragma unroll
                 for (int j = 0; j < D; j++)
@@ -286,12 +290,15 @@ __global__ __launch_bounds__(BLK) void k_chain_adj(const jh_dev_block *__restric
                     for (int k = 0; k < U; k++) {
                         av[j][k] = ldu<NT, S, NS>(cr_ptr<S>(e[j][0]) + sk[k]);
                         if (MODE == 0) dv[j][k] = ldu<NT, S, NS>(in + (i + j) * n_scalars + sk[k]);
+#pragma unroll
+                        for (int w = 0; w < NW; w++) wv[j][k][w] = ldu<NT, S, NS>(cr_ptr<S>(e[j][1 + w]) + sk[k]);
                     }
 #pragma unroll
                 for (int j = 0; j < D; j++)
 #pragma unroll
                     for (int k = 0; k < U; k++) {
-                        const V t = (MODE == 0) ? dv[j][k] : vmul<S, E, NS, V>(av[j][k], mv[k], false);
+                        V t = (MODE == 0) ? dv[j][k] : vmul<S, E, NS, V>(av[j][k], mv[k], false);
+                        if (NW > 0 || (ca.mid.st[0] & 15u) != CK_NONE) t = mid_prog<S, E, NS, NW, V>(ca.mid, t, wv[j][k], e[j]);
                         acc[k] = acc[k] + vmul<S, E, NS, V>(av[j][k], t, true);
                     }
                 return;

@@ -50,7 +50,7 @@ def test_sgpr_spill_census(kernels):
         fam = n.replace("void (anonymous namespace)::", "").replace("void ", "").split("<")[0].split("(")[0]
         worst[fam] = max(worst[fam], k["sgpr_spills"])
     spilling = {f: w for f, w in worst.items() if w}
-    ceiling = {"k_chain_adj": 120, "k_chain_fwd": 24, "k_tall_sum_fwd": 100, "k_tall_sum_adj": 90, "k_tall_sum_fwd_few": 60, "k_tall_sum_adj_few": 24,
+    ceiling = {"k_chain_adj": 150, "k_chain_fwd": 24, "k_tall_sum_fwd": 100, "k_tall_sum_adj": 90, "k_tall_sum_fwd_few": 60, "k_tall_sum_adj_few": 24,
                "k_general_tile": 64, "k_grid_tile": 16, "k_tall_diag_bidiag": 110, "k_tall_diag_adj": 8, "k_tall_diag_bidiag_chain": 36, "k_tall_diag_fwd_update": 32, "k_lincomb": 104}
     unknown = sorted(set(spilling) - set(ceiling))
     assert not unknown, f"kernel families that spill SGPRs and are not in the census: {[(f, spilling[f]) for f in unknown]}"
