@@ -540,24 +540,46 @@ def try_sum(out, x, ops: Sequence[Jop], sgns: Sequence[str], transposed: bool, w
         if fused and steps[0][1] == CHAIN_NORMAL and not (steps[0][3] or steps[0][4] or steps[0][5]):
             fused = False      # a bare (A', A) term: the tuned fused A'A (jh_blockop_normal_mul) into the domain-sized temporary + one accumulate pass beats the
                                # general chain kernel on many rows of small blocks (4096 x 64^3: 0.62 against 1.47 ms) and equals it elsewhere
-        if not fused and not _overwrites(op, transposed):
+        mode = "chain" if fused else "generic"
+        if not fused and len(steps) == 1 and steps[0][0] == "chain" and t == 0 and sgns[0] == _j.PLUS:
+            mode = "normal_first"                             # `A'A + ...`: the fused A'A writes the output itself -- its rows are summed from +0, so it IS 0 + t (640 / 649)
+        elif not fused:
+            sts = [classify(o, R) for o, R in stages]
+            scales = [st for st in sts if st.kind == "scale"]
+            if all(st.kind in ("scale", "identity") for st in sts) and len(scales) <= 1 and all(st.flags == 0 for st in scales) and t > 0:
+                mode = ("scale", scales[0].a if scales else 1.0)   # `... + lambda * I`: d = d +- T(lambda x) in ONE pass (no temporary, no second accumulate pass)
+        if mode == "generic" and not _overwrites(op, transposed):
             return None
-        plans.append((stages, fused))
-    if not any(f for _, f in plans):
+        plans.append((stages, mode, steps))
+    if not any(m == "chain" or m == "normal_first" for _, m, _ in plans):
         return None
     ws = ws if ws is not None else _j._Workspace()
     try:
         started = False
         tmp = None
         for t, (op, sg) in enumerate(zip(ops, sgns)):
-            stages, fused = plans[t]
+            stages, mode, steps = plans[t]
             sign = 1 if sg == _j.PLUS else -1
-            if fused:
+            if mode == "chain":
                 r = run(out, x, stages, None, cache, ("sum", transposed, t), accumulate=(sign if started else 2 * sign))
                 if r is not None:
                     started = True
                     STATS["sum_terms_fused"] += 1
                     continue
+            elif mode == "normal_first":
+                try:
+                    steps[0][2].nat.normal_mul(out, x)
+                    started = True
+                    STATS["sum_terms_fused"] += 1
+                    continue
+                except JetsHipError as e:
+                    if e.status != _UNSUPPORTED:
+                        raise
+            elif isinstance(mode, tuple) and started:
+                # tmp .= a * x rounded in the element type, then d .= d +- tmp (634 / 643 / 652): k_lincomb rounds every product and adds left to right; 1 * d is d
+                _arr.lincomb_(out, [1.0, sign * mode[1]], [out, x])
+                STATS["sum_terms_fused"] += 1
+                continue
             if not started:
                 _arr.fill_(out, 0)                            # d .= 0 (640 / 649)
                 started = True

@@ -230,7 +230,7 @@ def test_sums_whose_terms_are_chains(Jets, oracle, dt, nrow, n, kinds):
     S_rng = F1 - F2 + B
     hx = u01(oracle, dt, 91, 0, n)
     x = J.from_numpy(hx, dom)
-    for S, nfused in ((S_dom, 1), (S_rng, 2)):          # (the bare B'B term takes the tuned fused A'A + one accumulate pass)
+    for S, nfused in ((S_dom, 2), (S_rng, 2)):          # (A'WA and, in one lincomb pass, lam * I; the bare B'B term takes the tuned fused A'A + one accumulate pass)
         before = chains.STATS["sum_terms_fused"]
         y1 = J.mul_(J.rand(J.range(S), seed=77, stream=1), S, x)
         assert chains.STATS["sum_terms_fused"] - before == nfused
@@ -489,13 +489,13 @@ def test_a_sum_of_chains_over_many_small_rows(Jets, oracle, dt):
         return y1.to_numpy().ravel(order="F"), y0.to_numpy().ravel(order="F"), fused
 
     y1, y0, fused = both()
-    assert fused == 2                                   # (lam * I goes through the temporary: no tall operator in it)
+    assert fused == 3                                   # (lam * I adds itself in one lincomb pass)
     tol = (2e-5 if dt == np.float32 else 1e-13) * np.sqrt(nrow) * np.abs(y0).max()
     assert np.abs(y1 - y0).max() <= tol
     J.tune(adj_split=0)
     try:
         y1, y0, fused = both()
-        assert fused == 2
+        assert fused == 3
         assert_bits_equal(y1, y0, "ordered walk: sum of chains fused vs the reference's loop")
     finally:
         J.tune(adj_split=-1)
@@ -525,4 +525,43 @@ def test_a_block_diagonal_block_operator_stage_accumulates_into_zeros(Jets, orac
     plain = np.concatenate(rig.ora_apply(["A", ("s", -1.25, "r"), ("W", 0, False)], hx))
     parts = plain.view(np.float32 if np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4 else np.float64)
     assert (np.signbit(parts) & (parts == 0)).any(), "the case must contain a -0 under the plain diagonal"
+    rig.close()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nrow,n,kinds", [(6, 1024, "diag"), (9, 1027, "mixed")])
+def test_the_regularised_normal_operator_is_two_passes(Jets, oracle, dt, nrow, n, kinds):
+    """A'A + lam*I - mu*I (src/Jets.jl:639-655 over (A', A) and scalar terms): the first term IS `0 + A'A x` (the fused pass sums its rows from +0, 640), every
+    `a * I` adds itself as d .= d +- T(a x) in one pass (product rounded, then the add: 634) -- no fill, no temporary; the bits of the reference's loop."""
+    from jets_jl_amd import chains
+
+    J = Jets
+    rig = Rig(J, oracle, dt, nrow, n, kinds, with_wb=False)
+    A, dom = rig.A, J.domain(rig.A)
+    S = J.compose(A.H, A) + 0.25 * J.JopIdentity(dom) - 1.5 * J.JopIdentity(dom) + J.JopIdentity(dom)
+    hx = u01(oracle, dt, 91, 0, n) - dt(0.5)                                       # (both signs: -0 products do not occur, cancellations do)
+    x = J.from_numpy(hx.astype(dt), dom)
+    before = chains.STATS["sum_terms_fused"]
+    y1 = J.mul_(J.rand(dom, seed=77, stream=1), S, x)
+    assert chains.STATS["sum_terms_fused"] - before == 4
+    chains.ENABLED[0] = False
+    try:
+        y0 = J.mul_(J.rand(dom, seed=78, stream=2), S, x)
+    finally:
+        chains.ENABLED[0] = True
+    assert_bits_equal(y1.to_numpy().ravel(order="F"), y0.to_numpy().ravel(order="F"), "A'A + lam I - mu I + I: fused vs the reference's loop")
+    hxl = [hx.astype(dt)]
+    t1 = rig.ora_apply(["A", "At"], hxl)
+    want = oracle.barr_lincomb([np.empty(n, dt)], [1.0, 1.0], [[np.zeros(n, dt)], t1])
+    for a, sg in ((0.25, 1.0), (1.5, -1.0), (1.0, 1.0)):
+        tmp = oracle.barr_lincomb([np.empty(n, dt)], [a], [hxl])
+        want = oracle.barr_lincomb([np.empty(n, dt)], [1.0, sg], [want, tmp])
+    assert_bits_equal(y1.to_numpy().ravel(order="F"), want[0], "vs the oracle's loop")
+    a1 = J.mul_(J.rand(dom, seed=71, stream=1), S.H, x)                            # the adjoint of the sum: the same terms adjointed
+    chains.ENABLED[0] = False
+    try:
+        a0 = J.mul_(J.rand(dom, seed=72, stream=2), S.H, x)
+    finally:
+        chains.ENABLED[0] = True
+    assert_bits_equal(a1.to_numpy().ravel(order="F"), a0.to_numpy().ravel(order="F"), "adjoint of the sum")
     rig.close()
