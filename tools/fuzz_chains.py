@@ -124,6 +124,10 @@ for case in range(seed0, seed0 + ncases):
         shape = int(rng.integers(3))
         terms = []
         for _ in range(int(rng.integers(2, 5))):
+            if shape == 2 and rng.random() < 0.3:                   # a regularisation term: a * I, I, or the bare A'A (`A'A + lam I`: fused since late round 6)
+                pick = rng.integers(3)
+                terms.append(rig.compose([("s", float(rng.choice([0.25, -1.5, 3.0])), "d"), ("I",)] if pick == 0 else ([("I",)] if pick == 1 else ["A", "At"])))
+                continue
             while True:
                 t, s = random_chain(rng, wb, allow_opaque=False)
                 kind = (s, "r" if (t.count("A") > t.count("At")) else "d")
