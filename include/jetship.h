@@ -310,7 +310,7 @@ int jh_blockop_mul_adj_range(const jh_blockop *op, jh_bvec *m, const jh_bvec *d,
 /* (A' o A) m -> JetComposite_df! over (A', A), src/Jets.jl:530-534, fused: A's coefficients are read
  * once and the range-side intermediate is never materialised.  Same rounding sequence as the
  * unfused pair, so the result is bit-identical to jh_blockop_mul followed by jh_blockop_mul_adj.
- * Operators: tall (N x 1, N >= 2) of equal elementwise rows, and -- round 6 -- N x K GRIDS of equal plain diagonals with K = 2 .. 4
+ * Operators: tall (N x 1, N >= 2) of equal elementwise rows, and -- round 6 -- N x K GRIDS of equal elementwise blocks (diagonals, zero / identity / scalar blocks) with K = 2 .. 4
  * (a multi-parameter operator: N shots x K model parameters; N K n s + 2 K n s bytes where the pair moves 2 N K n s + 2 N n s; knob
  * "grid_normal").  JH_ERR_UNSUPPORTED otherwise: chain the two calls.  Many rows of small blocks: the split-row walk, as jh_blockop_mul_adj. */
 int jh_blockop_normal_mul(const jh_blockop *op, jh_bvec *y, const jh_bvec *m);
@@ -555,7 +555,7 @@ int jh_team_normal_mul(int n, const jh_blockop *const *ops, jh_bvec *const *ys, 
  * aligned loads of diagonals laid out like the range vector: -1 rows of 64 KiB or more, 0 never, 1 always; same bits), "tall_f" (F(m) of a tall nonlinear operator of elementwise children -- jh_blockop_f -- on the tall tiling: 1 yes, 0 the
  * general kernels; same bits), "dense_list_shared" (round 6: the rows pass of y = B x for DENSE children whose columns are off the 16-byte grid numbers its
  * chunks XCD by XCD and loads temporally, so the 128-byte line two neighbouring rows share is fetched from HBM once: 1 yes, 0 round 5's pass; same bits),
- * "dense_list_rl_min" (log2 of the fewest row lanes per workgroup of that pass, 0: automatic), "red_blocks_wave" (round 6: jh_norm_blocks / jh_dot_blocks of many blocks of at most 16 KiB with a wave per block in one launch: 1 yes, 0 a workgroup per block + the fold; within the reductions' tolerance of each other), "adj_bare_chain" (round 6: jh_blockop_mul_adj and jh_blockop_normal_mul of a tall operator with rows of several kinds, or rows off the 16-byte grid, of up to 4 MiB on the chain kernels with empty stage lists -- packed row records --: 1 yes, 0 the MIXED tall kernel; same bits unless the split walk's part count changes), "adj_thin_mixed" (round 6: the adjoint of a tall operator with rows of several kinds on thin workgroups when fat ones would leave CUs idle -- rows of 1-8 MiB --: 1 yes, 0 round 5's shapes; same bits unless the split walk's part count changes), "grid_normal" (round 6: jh_blockop_normal_mul on N x (2 .. 4) grids of equal diagonals in one pass: 1 yes, 0 JH_ERR_UNSUPPORTED as before; same bits), "dense_combine" (round 6: operators whose non-zero blocks are
+ * "dense_list_rl_min" (log2 of the fewest row lanes per workgroup of that pass, 0: automatic), "red_blocks_wave" (round 6: jh_norm_blocks / jh_dot_blocks of many blocks of at most 16 KiB with a wave per block in one launch: 1 yes, 0 a workgroup per block + the fold; within the reductions' tolerance of each other), "adj_bare_chain" (round 6: jh_blockop_mul_adj and jh_blockop_normal_mul of a tall operator with rows of several kinds, or rows off the 16-byte grid, of up to 4 MiB on the chain kernels with empty stage lists -- packed row records --: 1 yes, 0 the MIXED tall kernel; same bits unless the split walk's part count changes), "adj_thin_mixed" (round 6: the adjoint of a tall operator with rows of several kinds on thin workgroups when fat ones would leave CUs idle -- rows of 1-8 MiB --: 1 yes, 0 round 5's shapes; same bits unless the split walk's part count changes), "grid_normal" (round 6: jh_blockop_normal_mul on N x (2 .. 4) grids of equal elementwise blocks -- diagonals, zero / identity / scalar blocks -- in one pass: 1 yes, 2 grids of plain diagonals only, 0 JH_ERR_UNSUPPORTED as before; same bits), "dense_combine" (round 6: operators whose non-zero blocks are
  * all DENSE children sum the products of a block line from CSR lists in one launch: 1 yes, 0 the general step lists; same bits);
  * round 4: "cg_dev" (jh_cgls_solve / jh_cgnr_solve with the recurrences on the device, graph-replayed unless lsqr_graph = 0: 1 automatic -- CGLS
  * like lsqr_graph, CG through the fused A'A up to 2 GiB of coefficients --, 2 at any size, 0 never: the host loops; within solver tolerance

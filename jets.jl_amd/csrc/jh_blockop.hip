@@ -508,6 +508,7 @@ int jh_blockop_destroy(jh_blockop *op)
         if (op->dev_comb_ptr[dir]) (void)hipFree(op->dev_comb_ptr[dir]);
         if (op->dev_comb_off[dir]) (void)hipFree(op->dev_comb_off[dir]);
     }
+    if (op->grid_words) (void)hipFree(op->grid_words);
     for (int k = 0; k < 2; k++)
         if (op->bare_chain[k]) (void)jh_chain_destroy(op->bare_chain[k]);
     if (op->twin) (void)jh_blockop_destroy(op->twin);

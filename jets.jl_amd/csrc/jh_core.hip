@@ -989,7 +989,7 @@ int jh_tune_set(const char *name, int64_t value)
     else if (!strcmp(name, "red_blocks_wave")) { c.red_blocks_wave = value ? 1 : 0; }
     else if (!strcmp(name, "adj_bare_chain")) { c.adj_bare_chain = value ? 1 : 0; }
     else if (!strcmp(name, "adj_thin_mixed")) { c.adj_thin_mixed = value ? 1 : 0; }
-    else if (!strcmp(name, "grid_normal")) { c.grid_normal = value ? 1 : 0; }
+    else if (!strcmp(name, "grid_normal")) { JH_REQUIRE(value >= 0 && value <= 2, "grid_normal must be 0, 1 or 2"); c.grid_normal = value; }
     else if (!strcmp(name, "fwd_anchor")) { JH_REQUIRE(value >= -1 && value <= 1, "fwd_anchor must be -1 (rows of >= 64 KiB that are not whole packs), 0 (never) or 1 (always)"); c.fwd_anchor = value; }
     else if (!strcmp(name, "ua_nt")) { JH_REQUIRE(value >= -1 && value <= 1, "ua_nt must be -1 (temporal accesses on rows off the 16-byte grid), 0 (temporal always) or 1 (nontemporal always)"); c.ua_nt = value; }
     else if (!strcmp(name, "tall_unaligned")) { JH_REQUIRE(value >= 0 && value <= 1, "tall_unaligned must be 0 (general kernels) or 1 (under-aligned tall kernels)"); c.tall_unaligned = value; }

@@ -140,7 +140,7 @@ struct jh_context {
     int64_t red_blocks_wave = 1;       // knob: per-block reductions of many short blocks with a wave per block (k_reduce_blocks_wave); 0: a workgroup per block
     int64_t adj_bare_chain = 1;        // knob: jh_blockop_mul_adj / _normal_mul of tall operators with rows of several kinds / off the 16-byte grid on the chain kernels (rows up to 4 MiB); 0: k_tall_diag_adj<MIXED>
     int64_t adj_thin_mixed = 1;        // knob: the MIXED tall adjoint on thin workgroups when the fat shape would not fill the chip (rows of 1-8 MiB); 0: round 5's rule
-    int64_t grid_normal = 1;           // knob: (A', A) on an N x (2 .. 4) grid of equal diagonals in one pass (jh_grid_normal.hip); 0: JH_ERR_UNSUPPORTED as in rounds 1-5 (the caller chains the two stages)
+    int64_t grid_normal = 1;           // knob: (A', A) on an N x (2 .. 4) grid of equal elementwise blocks in one pass (jh_grid_normal.hip); 2: grids of plain diagonals only; 0: JH_ERR_UNSUPPORTED as in rounds 1-5 (the caller chains the two stages)
     int64_t fwd_anchor = -1;           // knob: the tall forward of rows that are not whole packs on lanes anchored to each row's own 16-byte grid (k_tall_fwd_anchored): -1 from 64 KiB rows on, 0 never, 1 always
     int64_t wide_twin = 1;             // knob: wide elementwise operators on their tall twin: 0 never (general kernels), 1 adjoint always + forward from 16 MiB blocks, 2 both always (tests)
     const double *step_coef_dev = nullptr;   // internal, set around the calls of the graph-captured LSQR loop: the one-pass step reads (alpha, beta) from
@@ -375,6 +375,7 @@ struct jh_blockop {
     mutable LazyTune fwd_tune;               // tall forward: K_FWD_CANDIDATES shapes x 2 passes -> fwd_walk
     mutable LazyTune step_tune;              // one-pass step: plain / tile map / chained x 2 passes (+ a warm-up) -> step_mode
     mutable LazyTune gen_tune[2];            // sparse grids on the register-tiled general kernel, per direction: four-line lists / per-line lists / plain walk -> gen_walk
+    mutable void *grid_words = nullptr;      // the packed block table of a mixed N x (2 .. 4) grid (jh_grid_normal.hip), built on first use
     mutable struct jh_chain *bare_chain[2] = {nullptr, nullptr};   // the library's own ADJOINT / NORMAL chains with empty stage lists (jh_tall_chain.hip: bare_chain), built on first use
     mutable int gen_walk[2] = {-1, -1};      // -1 untried, 0 the four-line step lists, 1 the per-line lists, 2 the plain walk (jh_general.hip: launch_general_tile)
     mutable int upd_walk = -1;               // same for the fused forward update (timed on its first two real calls)

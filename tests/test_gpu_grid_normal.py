@@ -164,3 +164,42 @@ def test_lsqr_and_cgls_on_a_grid_reuse_their_temporaries_correctly(Jets, oracle)
         x = res.x.to_numpy().ravel(order="F")
         assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr), solve.__name__
     J.close(A)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("ncol", [2, 3, 4])
+@pytest.mark.parametrize("nrow,n", [(3, 1024), (7, 1027), (11, 67), (600, 515)])
+def test_fused_normal_of_a_grid_with_blocks_of_several_kinds(Jets, oracle, dt, ncol, nrow, n):
+    """The regularised multi-parameter operator -- data rows of diagonals over rows of zero / identity / scalar / adjointed blocks: a packed table of one word
+    per block, batches of plain rows on the tight loop (jh_grid_normal.hip: k_grid_normal_mixed).  The two stages' bits (zero blocks skipped: 1022 / 1047)."""
+    J = Jets
+    names = ["diag", "zero", "identity", "scale", "diag_adj", "diag"]
+    kinds = [[("diag" if i < max(1, nrow - ncol - 2) and (i % 5 != 3) else names[(2 * i + 3 * j) % 6]) for j in range(ncol)] for i in range(nrow)]
+    kinds[nrow - 1] = ["zero"] * ncol                                            # a whole row of zero blocks
+    A, ora = _mixed_ops(J, oracle, dt, kinds, [n] * nrow, [n] * ncol, seed=43)
+    hm = [u01(oracle, dt, 91, j, n) - dt(0.5) for j in range(ncol)]
+    m = J.from_numpy(np.concatenate(hm).astype(dt), J.domain(A))
+    hm = [h.astype(dt) for h in hm]
+    nat = _native(J, A)
+    from jets_jl_amd._ffi import check, lib
+
+    J.tune(adj_split=0)
+    try:
+        y = J.rand(J.domain(A), seed=7, stream=3)
+        check(lib.jh_blockop_normal_mul(nat.handle, y.handle, m.handle))        # the library takes the mixed grid
+        t = oracle.block_df(ora, [np.zeros(n, dt) for _ in range(nrow)], hm)
+        want = np.concatenate(oracle.block_df_adj(ora, [np.zeros(n, dt) for _ in range(ncol)], t))
+        assert_bits_equal(y.to_numpy().ravel(order="F"), want, "fused A'A of a mixed grid vs the oracle's two loops")
+        y2 = J.mul_(J.rand(J.domain(A), seed=8, stream=3), J.compose(A.H, A), m)
+        assert_bits_equal(y2.to_numpy().ravel(order="F"), want, "through the composite")
+        J.tune(grid_normal=2)                                                   # plain diagonals only: the composite chains its two stages
+        y3 = J.mul_(J.rand(J.domain(A), seed=9, stream=3), J.compose(A.H, A), m)
+        assert_bits_equal(y3.to_numpy().ravel(order="F"), want, "knob 2: the chain")
+    finally:
+        J.tune(grid_normal=1, adj_split=-1)
+    if nrow >= 256:                                                             # the split walk: tolerance, deterministic
+        y4 = J.mul_(J.rand(J.domain(A), seed=10, stream=3), J.compose(A.H, A), m)
+        assert J.tune_get("last_adj_parts") > 1
+        tol = (2e-5 if np.dtype(dt).itemsize // (2 if np.dtype(dt).kind == "c" else 1) == 4 else 1e-13) * np.sqrt(nrow) * np.abs(want).max()
+        assert np.abs(y4.to_numpy().ravel(order="F") - want).max() <= tol
+    J.close(A)

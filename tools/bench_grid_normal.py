@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The fused normal operator of an N x K grid of equal diagonals, K = 2 .. 4 (round 6; jh_grid_normal.hip) against the two stages the reference applies
-(JetBlock_df! into zeros(range(A)), then JetBlock_df'!; knob grid_normal = 0).
+(JetBlock_df! into zeros(range(A)), then JetBlock_df'!; knob grid_normal = 0).  REG=1: K regularisation rows (lam * I on the diagonal, zero blocks
+elsewhere) under the data rows -- a grid with blocks of several kinds.
 
     python tools/bench_grid_normal.py [N K EDGE [dtype]]...        default: a sweep
 
@@ -32,18 +33,22 @@ def case(N, K, edge, dt="float32"):
     spc = J.JetSpace(dt, edge, edge, edge)
     n, s = edge ** 3, np.dtype(dt).itemsize
     coeff = J.rand(J.JetBSpace([spc] * (N * K)), seed=1, stream=0)
-    A = J.blockop([[J.JopDiagonal(coeff.arrays[i * K + j]) for j in range(K)] for i in range(N)])
+    rows = [[J.JopDiagonal(coeff.arrays[i * K + j]) for j in range(K)] for i in range(N)]
+    if os.environ.get("REG", "0") == "1":                                   # the regularised operator: K more rows, lam * I on the diagonal, zero blocks elsewhere
+        lam = lambda: J.JopLn(dom=spc, rng=spc, df=J.constdiag_df, df_adj=J.constdiag_df_adj, s={"a": 0.5})
+        rows += [[lam() if j == k else J.JopZeroBlock(spc, spc) for j in range(K)] for k in range(K)]
+    A = J.blockop(rows)
     m = J.rand(J.domain(A), seed=2, stream=0)
     y = J.zeros(J.domain(A))
     NA = J.compose(A.H, A)
-    J.tune(grid_normal=1)
+    J.tune(grid_normal=int(os.environ.get("GRID_NORMAL", "1")))
     tf = timed(lambda: J.mul_(y, NA, m))
     parts = J.tune_get("last_adj_parts")
     J.tune(grid_normal=0)
     tu = timed(lambda: J.mul_(y, NA, m))
     J.tune(grid_normal=1)
     fused_b = (N * K + 2 * K) * n * s
-    print(f"{N:5d} x {K} of {edge}^3 {dt}: fused {tf:8.3f} ms {fused_b / tf / 1e9:6.3f} TB/s ({100 * fused_b / tf / 8e9:5.1f} % of 8 TB/s, {parts} part{'s' if parts > 1 else ''}) | "
+    print(f"{N:5d}{' + ' + str(K) + ' regularisation rows' if os.environ.get('REG', '0') == '1' else ''} x {K} of {edge}^3 {dt}: fused {tf:8.3f} ms {fused_b / tf / 1e9:6.3f} TB/s ({100 * fused_b / tf / 8e9:5.1f} % of 8 TB/s, {parts} part{'s' if parts > 1 else ''}) | "
           f"two stages {tu:8.3f} ms | {tu / tf:5.2f}x", flush=True)
     if os.environ.get("CGNR", "0") == "1":                                 # CG on the normal equations: jh_cgnr_solve through the fused pass | A then A' through the engines
         b = J.rand(J.range(A), seed=5, stream=0)
