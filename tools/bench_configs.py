@@ -169,3 +169,31 @@ for name, solve in (("CGLS", lambda rhs: J.cgls(A, rhs, maxiter=100, atol=0.0, b
     rel = J.norm(err) / J.norm(x_true)
     print(f"{'config 5: 100 %s iterations on config 4' % name:58s} {1e3 * wall / max(res.itn, 1):9.2f} ms/iteration ({res.itn} iterations, "
           f"{wall:6.2f} s wall)   ||x - x_true|| / ||x_true|| = {rel:.2e}", flush=True)
+
+# (after the headline-size sections: the 128 GiB operator of configs 4 / 5 should meet the slab cache as configs 1-3 leave it)
+J.close(A)
+del A, coeff, b, x_true, err, res
+gc.collect()
+# config 3g (round 6): the multi-parameter twin -- A'A of a 64 x 4 grid of diagonals, plain and with 4 regularisation rows (lam * I on the diagonal, zero blocks elsewhere)
+for reg in (0, 1):
+    spc = J.JetSpace(np.float32, 256, 256, 256)
+    n, NN, KK = 256 ** 3, 64, 4
+    coeff = J.rand(J.JetBSpace([spc] * (NN * KK)), seed=1, stream=0)
+    rows = [[J.JopDiagonal(coeff.arrays[i * KK + j]) for j in range(KK)] for i in range(NN)]
+    if reg:
+        rows += [[(J.JopLn(dom=spc, rng=spc, df=J.constdiag_df, df_adj=J.constdiag_df_adj, s={"a": 0.5}) if j == k else J.JopZeroBlock(spc, spc)) for j in range(KK)]
+                 for k in range(KK)]
+    A = J.blockop(rows)
+    N = J.compose(A.H, A)
+    m, y = J.rand(J.domain(A), seed=2, stream=0), J.zeros(J.domain(A))
+    ms_f = timed(lambda: J.mul_(y, N, m), 10)
+    J.tune(grid_normal=0)
+    ms_u = timed(lambda: J.mul_(y, N, m), 4)
+    J.tune(grid_normal=1)
+    bf = (NN * KK + 2 * KK) * n * 4
+    tag = f"config 3g: A^T o A on a 64{' + 4 reg.' if reg else ''} x 4 grid, 256^3 Float32"
+    print(f"{tag:58s} fused {ms_f:8.3f} ms ({bf / ms_f / 1e6:7.1f} GB/s, {100 * bf / (ms_f * 1e-3) / PEAK:4.1f} %)   two stages {ms_u:8.3f} ms   speed-up {ms_u / ms_f:4.2f}x", flush=True)
+    J.close(A)
+    del A, coeff, N, y, m, rows
+    gc.collect()
+
