@@ -277,6 +277,8 @@ bool grid_normal_ok(const jh_blockop *op, const void *y, const void *m)
 int grid_normal(const jh_blockop *op, void *y, const void *m)
 {
     if (!op->all_diag && !op->grid_words) {                   // the packed table of a mixed grid, row-major (N x K words), built on first use
+        if (stream_is_capturing(jh_ctx().stream))             // (an allocation and a synchronous copy: not inside a stream capture -- the caller chains the two stages)
+            return jh_fail(JH_ERR_UNSUPPORTED, "grid normal: the block table of this operator is built on the first call, which must not be inside a stream capture");
         const size_t nw = (size_t)op->nrow * (size_t)op->ncol;
         std::vector<uint64_t> h(nw);
         for (int64_t i = 0; i < op->nrow; i++)
